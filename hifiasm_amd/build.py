@@ -1,0 +1,84 @@
+"""In-tree build of every native artefact (no JIT cache: the .so files travel with
+the gpurun snapshot).
+
+  hifiasm_amd/libhao.so        product: HIP kernels (gfx950) + C-ABI (include/hao.h)
+  hifiasm_amd/libhaosynth.so   bench/test tooling: synthetic read generator
+  oracle/liboracle.so          TEST ORACLE: plain-C restatement of the reference path
+  oracle/_ref/ref_harness      TEST ORACLE: the unmodified reference, only when
+                               /root/reference is present (this container)
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "hifiasm_amd")
+CSRC = os.path.join(PKG, "csrc")
+ORACLE = os.path.join(ROOT, "oracle")
+REF = "/root/reference"
+
+HIP_SOURCES = ["hao_capi.hip"]          # single translation unit that #includes the kernel files
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               "-Wno-unused-result", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _run(cmd, cwd=None):
+    print("[build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=cwd)
+
+
+def build_synth(force=False):
+    out = os.path.join(PKG, "libhaosynth.so")
+    src = os.path.join(CSRC, "hao_synth.c")
+    if force or _newer(out, [src]):
+        _run(["gcc", "-O2", "-fPIC", "-shared", "-o", out, src])
+    return out
+
+
+def build_hip(force=False):
+    out = os.path.join(PKG, "libhao.so")
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "hao.h")]
+    if force or _newer(out, deps):
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        _run([hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in HIP_SOURCES] + ["-o", out])
+    return out
+
+
+def build_oracle(force=False):
+    out = os.path.join(ORACLE, "liboracle.so")
+    deps = [os.path.join(ORACLE, "hao_oracle.c"), os.path.join(ORACLE, "hao_oracle.h")]
+    if force or _newer(out, deps):
+        _run(["make", "-C", ORACLE, "liboracle.so"] + (["-B"] if force else []))
+    return out
+
+
+def build_ref(force=False):
+    """The real reference as a checker/baseline binary; only where its sources exist."""
+    if not os.path.isdir(REF):
+        return None
+    out = os.path.join(ORACLE, "_ref", "ref_harness")
+    deps = [os.path.join(ORACLE, "ref_harness.cpp"), os.path.join(ORACLE, "ref_htab_dump.cpp")]
+    if force or _newer(out, deps):
+        _run(["make", "-C", ORACLE, "-j8", "ref"])
+    return out
+
+
+def build_all(force=False):
+    build_synth(force)
+    build_hip(force)
+    build_oracle(force)
+    build_ref(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,140 @@
+/* Seeded synthetic genome / read generator (bench + test tooling, not on the hot path).
+ *
+ * genome = i.i.d. uniform ACGT (optionally with planted repeat
+ * families + a tandem satellite array: the "repeat-rich" variant of BASELINE.md 2b);
+ * reads: uniform start, strand Bernoulli(1/2), errors split 40/30/30
+ * substitution/deletion/insertion.  Every read has its own counter-based RNG
+ * stream (seed, read index), so any rank can generate any shard of the same set
+ * and the bytes are identical on every machine.
+ *
+ * Base codes 0..3 = A,C,G,T (the reference's seq_nt4_table order, htab.cpp:17-34).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline uint64_t splitmix64(uint64_t *s)
+{
+	uint64_t z = (*s += 0x9E3779B97F4A7C15ULL);
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	return z ^ (z >> 31);
+}
+
+static inline uint64_t rnd_below(uint64_t *s, uint64_t n) /* n > 0; tiny modulo bias is irrelevant here */
+{
+	return splitmix64(s) % n;
+}
+
+/* out[size] <- codes 0..3 */
+void hao_synth_genome(uint8_t *out, uint64_t size, uint64_t seed, int repeat_rich)
+{
+	uint64_t s = seed * 0xD1342543DE82EF95ULL + 1, i;
+	for (i = 0; i + 32 <= size; i += 32) {
+		uint64_t r = splitmix64(&s); int j;
+		for (j = 0; j < 32; ++j) out[i + j] = (r >> (2 * j)) & 3;
+	}
+	for (; i < size; ++i) out[i] = splitmix64(&s) & 3;
+	if (repeat_rich) {
+		uint64_t n_units = size / 2000000 ? size / 2000000 : 1, u;
+		uint8_t elem[4000], unit[171];
+		for (u = 0; u < n_units; ++u) {
+			int fam, c, j;
+			for (fam = 0; fam < 10; ++fam) {
+				for (j = 0; j < 4000; ++j) elem[j] = splitmix64(&s) & 3;
+				for (c = 0; c < 25; ++c) {
+					uint64_t p = size > 4000 ? rnd_below(&s, size - 4000) : 0;
+					for (j = 0; j < 4000 && p + j < size; ++j) {
+						uint8_t b = elem[j];
+						if (rnd_below(&s, 1000) < 15) b = (b + 1 + rnd_below(&s, 3)) & 3; /* 1.5 % divergence */
+						out[p + j] = b;
+					}
+				}
+			}
+			for (j = 0; j < 171; ++j) unit[j] = splitmix64(&s) & 3;
+			{
+				uint64_t alen = 300 * 171, p = size > alen ? rnd_below(&s, size - alen) : 0, q;
+				for (q = 0; q < alen && p + q < size; ++q) out[p + q] = unit[q % 171];
+			}
+		}
+	}
+}
+
+/* Generate read `rid` into buf (capacity cap codes); returns its length.
+ * err_ppm = error rate in parts per million; len_jit = +- uniform jitter on read_len;
+ * n_ppm = rate of N bases (code 4). */
+static uint32_t synth_one(const uint8_t *g, uint64_t G, uint64_t rid, uint32_t read_len, uint32_t len_jit, uint32_t err_ppm, uint32_t n_ppm, uint64_t seed, uint8_t *buf, uint32_t cap)
+{
+	uint64_t s = (seed + 0x51ED270B7ULL) * 0x9E3779B97F4A7C15ULL + rid * 0xD6E8FEB86659FD93ULL;
+	uint32_t L = read_len, i, n = 0;
+	uint64_t start; int rev;
+	splitmix64(&s);
+	if (len_jit) L = read_len - len_jit + (uint32_t)rnd_below(&s, 2 * (uint64_t)len_jit + 1);
+	if (L > G) L = (uint32_t)G;
+	start = rnd_below(&s, G - L + 1);
+	rev = splitmix64(&s) & 1;
+	for (i = 0; i < L && n < cap; ++i) {
+		uint8_t b = rev ? 3 - g[start + L - 1 - i] : g[start + i];
+		uint64_t r = splitmix64(&s);
+		uint32_t e = (uint32_t)(r % 1000000u);
+		if (e < err_ppm) {
+			uint32_t t = (uint32_t)((r >> 32) % 10);
+			if (t < 4) buf[n++] = (b + 1 + (uint32_t)((r >> 40) % 3)) & 3;      /* substitution */
+			else if (t < 7) { /* deletion */ }
+			else { buf[n++] = b; if (n < cap) buf[n++] = (r >> 44) & 3; }          /* insertion after */
+		} else buf[n++] = b;
+		if (n_ppm && n > 0 && (uint32_t)((r >> 20) % 1000000u) < n_ppm) buf[n - 1] = 4;
+	}
+	return n;
+}
+
+/* pass 1: lengths of reads [rid0, rid0+n). */
+void hao_synth_read_lengths(const uint8_t *g, uint64_t G, uint64_t rid0, uint64_t n, uint32_t read_len, uint32_t len_jit, uint32_t err_ppm, uint32_t n_ppm, uint64_t seed, uint32_t *len_out)
+{
+	uint32_t cap = 2 * (read_len + len_jit) + 16; uint64_t i;
+	uint8_t *buf = (uint8_t*)malloc(cap);
+	for (i = 0; i < n; ++i) len_out[i] = synth_one(g, G, rid0 + i, read_len, len_jit, err_ppm, n_ppm, seed, buf, cap);
+	free(buf);
+}
+
+/* pass 2: fill. Any of the outputs may be NULL.
+ *   codes   : concatenated codes (0..4), offsets code_off[i] (n+1 entries, caller computed from lengths)
+ *   packed  : reference read-store layout, len/4+1 bytes per read, 4 bases/byte MSB first, N -> A
+ *             (ha_compress_base, Process_Read.cpp:792-850); byte offsets pk_off[i] */
+void hao_synth_reads(const uint8_t *g, uint64_t G, uint64_t rid0, uint64_t n, uint32_t read_len, uint32_t len_jit, uint32_t err_ppm, uint32_t n_ppm, uint64_t seed,
+					 uint8_t *codes, const uint64_t *code_off, uint8_t *packed, const uint64_t *pk_off)
+{
+	uint32_t cap = 2 * (read_len + len_jit) + 16; uint64_t i;
+	uint8_t *buf = (uint8_t*)malloc(cap);
+	for (i = 0; i < n; ++i) {
+		uint32_t L = synth_one(g, G, rid0 + i, read_len, len_jit, err_ppm, n_ppm, seed, buf, cap), j;
+		if (codes) memcpy(codes + code_off[i], buf, L);
+		if (packed) {
+			uint8_t *d = packed + pk_off[i];
+			memset(d, 0, L / 4 + 1);
+			for (j = 0; j < L; ++j) d[j >> 2] |= (uint8_t)((buf[j] & 3 & -(buf[j] < 4)) << (6 - 2 * (j & 3)));
+		}
+	}
+	free(buf);
+}
+
+/* codes -> FASTA text (ACGTN). returns bytes written. out must hold sum(len)+n*(name+3). */
+uint64_t hao_synth_fasta(const uint8_t *codes, const uint64_t *code_off, uint64_t rid0, uint64_t n, char *out, int fastq, int qual)
+{
+	static const char tab[] = "ACGTN"; uint64_t i, o = 0, j;
+	for (i = 0; i < n; ++i) {
+		char name[32]; int nl = 0; uint64_t v = rid0 + i, L = code_off[i + 1] - code_off[i]; char tmp[24]; int tl = 0;
+		do { tmp[tl++] = '0' + v % 10; v /= 10; } while (v);
+		name[nl++] = fastq ? '@' : '>'; name[nl++] = 'r';
+		while (tl) name[nl++] = tmp[--tl];
+		name[nl++] = '\n';
+		memcpy(out + o, name, nl); o += nl;
+		for (j = 0; j < L; ++j) out[o + j] = tab[codes[code_off[i] + j]];
+		o += L; out[o++] = '\n';
+		if (fastq) {
+			out[o++] = '+'; out[o++] = '\n';
+			memset(out + o, 33 + qual, L); o += L; out[o++] = '\n';
+		}
+	}
+	return o;
+}

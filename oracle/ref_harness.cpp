@@ -1,0 +1,222 @@
+// TEST INFRASTRUCTURE (oracle/_ref): driver that links the UNMODIFIED reference
+// objects (chhylp123/hifiasm 0.25.0-r726, compiled from /root/reference where
+// they lie) and (a) dumps every intermediate of the overlap hot path so the C
+// restatement in oracle/hao_oracle.c and the HIP path can be pinned against
+// the real thing, (b) times the reference CPU path for bench.py's
+// cpu_baseline {"kind":"reference"}.
+//
+// Call sequence = what ha_assemble does up to the first all-reads pass
+// (Assembly.cpp:2083-2084 ha_ft_gen + ha_opt_update_cov; Assembly.cpp:1007-1008
+// ha_pt_gen; ecovlp.cpp:3234-3274 worker_hap_ec up to and including h_ec_lchain).
+//
+// usage: ref_harness [--ont] [-t N] [-k K] [-w W] [--dump PREFIX] [--time] [--nodump-hits] reads.fa
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "CommandLines.h"
+#include "Process_Read.h"
+#include "Hash_Table.h"
+#include "htab.h"
+#include "kthread.h"
+
+#define HA_KMER_GOOD_RATIO 0.333   // ecovlp.cpp / anchor.cpp:11
+#define COV_W 3072                 // ecovlp.cpp:16
+
+// ad-hoc prototypes exactly as the reference declares them (ecovlp.cpp:110; anchor.cpp:987)
+void h_ec_lchain(ha_abuf_t *ab, uint32_t rid, char* rs, uint64_t rl, uint64_t mz_w, uint64_t mz_k, All_reads *rref, overlap_region_alloc *overlap_list, Candidates_list *cl, double bw_thres,
+				 int max_n_chain, int apend_be, kvec_t_u8_warp* k_flag, kvec_t_u64_warp* dbg_ct, st_mt_t *sp, uint32_t *high_occ, uint32_t *low_occ, uint32_t is_accurate, uint32_t gen_off, int64_t mcopy_num, double mcopy_rate, uint32_t chain_cutoff, uint32_t mcopy_khit_cut, uint64_t ocv_w);
+void minimizers_qgen0(ha_abuf_t *ab, char* rs, int64_t rl, uint64_t mz_w, uint64_t mz_k, Candidates_list *cl, kvec_t_u8_warp* k_flag,
+				 void *ha_flt_tab, ha_pt_t *ha_idx, All_reads* rdb, kvec_t_u64_warp* dbg_ct, st_mt_t *sp, uint32_t *high_occ, uint32_t *low_occ);
+
+extern "C" uint64_t refdump_ft(void *flt_tab, uint64_t **keys_out, int32_t **vals_out);
+extern "C" uint64_t refdump_pt(ha_pt_t *pt, uint64_t **keys_out, uint64_t **off_out, uint64_t **pos_out, uint64_t *n_pos_out);
+extern "C" void refdump_ft_hist(const hifiasm_opt_t *o, All_reads *rs, int64_t cnt[4096], int *peak_hom, int *peak_het, uint64_t *n_distinct);
+extern "C" void refdump_pt_hist(const hifiasm_opt_t *o, const void *flt_tab, All_reads *rs, int64_t cnt[4096], uint64_t *n_distinct);
+
+static void wr(const std::string &prefix, const char *name, const void *p, size_t nbytes)
+{
+	std::string fn = prefix + "." + name;
+	FILE *fp = fopen(fn.c_str(), "wb");
+	if (!fp) { fprintf(stderr, "cannot write %s\n", fn.c_str()); exit(1); }
+	if (nbytes) fwrite(p, 1, nbytes, fp);
+	fclose(fp);
+}
+
+typedef struct {
+	UC_Read ur; ha_abuf_t *ab; overlap_region_alloc ol; Candidates_list cl; st_mt_t sp;
+	uint64_t n_ovlp, n_hits;
+} tbuf_t;
+
+typedef struct { tbuf_t *b; double bw; uint32_t high_occ, low_occ; } pass_t;
+
+static void worker_pass(void *data, long i, int tid)
+{
+	pass_t *p = (pass_t*)data; tbuf_t *b = &p->b[tid];
+	uint32_t high_occ = p->high_occ, low_occ = p->low_occ;
+	recover_UC_Read(&b->ur, &R_INF, i);
+	h_ec_lchain(b->ab, i, b->ur.seq, b->ur.length, asm_opt.mz_win, asm_opt.k_mer_length, &R_INF, &b->ol, &b->cl, p->bw, asm_opt.max_n_chain, 1, NULL, NULL, &b->sp, &high_occ, &low_occ, 1, 1, 3, 0.7, 2, 32, COV_W);
+	b->n_ovlp += b->ol.length; b->n_hits += b->cl.length;
+}
+
+static tbuf_t *tbuf_init(int n)
+{
+	tbuf_t *b = (tbuf_t*)calloc(n, sizeof(tbuf_t));
+	for (int i = 0; i < n; ++i) {
+		init_UC_Read(&b[i].ur); b[i].ab = ha_abuf_init();
+		init_overlap_region_alloc(&b[i].ol); init_Candidates_list(&b[i].cl);
+	}
+	return b;
+}
+
+int main(int argc, char *argv[])
+{
+	int n_thread = 1, is_ont = 0, do_time = 0, dump_hits = 1, k = -1, w = -1; const char *fa = 0; std::string prefix;
+	for (int i = 1; i < argc; ++i) {
+		if (!strcmp(argv[i], "--ont")) is_ont = 1;
+		else if (!strcmp(argv[i], "-t")) n_thread = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-k")) k = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-w")) w = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "--dump")) prefix = argv[++i];
+		else if (!strcmp(argv[i], "--time")) do_time = 1;
+		else if (!strcmp(argv[i], "--nodump-hits")) dump_hits = 0;
+		else fa = argv[i];
+	}
+	if (!fa) { fprintf(stderr, "usage: ref_harness [--ont] [-t N] [-k K] [-w W] [--dump PREFIX] [--time] reads.fa\n"); return 1; }
+	// the reference's own option parser, with -f0 (exact counting; SURVEY 7 "Bloom")
+	std::vector<std::string> av; char tb[32], kb[32], wb[32];
+	av.push_back("hifiasm"); av.push_back("-o"); av.push_back(prefix.empty()? std::string("/tmp/ref_harness_out") : prefix);
+	snprintf(tb, 32, "%d", n_thread); av.push_back("-t"); av.push_back(tb); av.push_back("-f0");
+	if (k > 0) { snprintf(kb, 32, "%d", k); av.push_back("-k"); av.push_back(kb); }
+	if (w > 0) { snprintf(wb, 32, "%d", w); av.push_back("-w"); av.push_back(wb); }
+	if (is_ont) av.push_back("--ont");
+	av.push_back(fa);
+	std::vector<char*> avp; for (size_t i = 0; i < av.size(); ++i) avp.push_back((char*)av[i].c_str());
+	yak_reset_realtime();
+	init_opt(&asm_opt);
+	if (!CommandLine_process((int)avp.size(), &avp[0], &asm_opt)) return 1;
+
+	int hom_cov_ft = -1, hom_cov = -1, het_cov = -1;
+	double t0 = yak_realtime();
+	ha_flt_tab = ha_ft_gen(&asm_opt, &R_INF, &hom_cov_ft, 0, 0);
+	ha_opt_update_cov(&asm_opt, hom_cov_ft);
+	double t_ft = yak_realtime() - t0; t0 = yak_realtime();
+	ha_idx = ha_pt_gen(&asm_opt, ha_flt_tab, 0, 0, &R_INF, &hom_cov, &het_cov);
+	asm_opt.hom_cov = hom_cov; asm_opt.het_cov = het_cov;
+	double t_pt = yak_realtime() - t0;
+
+	uint64_t n_reads = R_INF.total_reads;
+	uint32_t high_occ = asm_opt.hom_cov * (2.0 - HA_KMER_GOOD_RATIO);   // ecovlp.cpp:3237
+	uint32_t low_occ = asm_opt.hom_cov * HA_KMER_GOOD_RATIO;            // ecovlp.cpp:3238
+	double bw = is_ont ? 0.05 : 0.02;                                     // ecovlp.cpp:3274
+
+	if (do_time) {
+		tbuf_t *b = tbuf_init(n_thread); pass_t p; p.b = b; p.bw = bw; p.high_occ = high_occ; p.low_occ = low_occ;
+		t0 = yak_realtime();
+		kt_for(n_thread, worker_pass, &p, n_reads);
+		double t_pass = yak_realtime() - t0; uint64_t n_ovlp = 0, n_hits = 0;
+		for (int i = 0; i < n_thread; ++i) n_ovlp += b[i].n_ovlp, n_hits += b[i].n_hits;
+		printf("{\"n_reads\": %lu, \"threads\": %d, \"t_ft_gen\": %.4f, \"t_pt_gen\": %.4f, \"t_pass\": %.4f, \"overlaps\": %lu, \"chained_hits\": %lu, \"overlaps_per_sec\": %.1f, \"hom_cov\": %d, \"het_cov\": %d, \"max_n_chain\": %d}\n",
+			   (unsigned long)n_reads, n_thread, t_ft, t_pt, t_pass, (unsigned long)n_ovlp, (unsigned long)n_hits, n_ovlp / (t_pt + t_pass), hom_cov, het_cov, asm_opt.max_n_chain);
+		fflush(stdout);
+	}
+	if (prefix.empty()) return 0;
+
+	// ---------------- dumps ----------------
+	{ // read lengths
+		wr(prefix, "rlen.u64", R_INF.read_length, sizeof(uint64_t) * n_reads);
+	}
+	int64_t ft_hist[4096], pt_hist[4096]; int ft_peak_hom, ft_peak_het; uint64_t ft_distinct, pt_distinct;
+	refdump_ft_hist(&asm_opt, &R_INF, ft_hist, &ft_peak_hom, &ft_peak_het, &ft_distinct);
+	refdump_pt_hist(&asm_opt, ha_flt_tab, &R_INF, pt_hist, &pt_distinct);
+	wr(prefix, "ft_hist.i64", ft_hist, sizeof(ft_hist));
+	wr(prefix, "pt_hist.i64", pt_hist, sizeof(pt_hist));
+	uint64_t n_ft, n_ptk, n_ptp;
+	{
+		uint64_t *keys; int32_t *vals;
+		n_ft = refdump_ft(ha_flt_tab, &keys, &vals);
+		wr(prefix, "ft_keys.u64", keys, sizeof(uint64_t) * n_ft);
+		wr(prefix, "ft_vals.i32", vals, sizeof(int32_t) * n_ft);
+		free(keys); free(vals);
+	}
+	{
+		uint64_t *keys, *off, *pos;
+		n_ptk = refdump_pt(ha_idx, &keys, &off, &pos, &n_ptp);
+		wr(prefix, "pt_keys.u64", keys, sizeof(uint64_t) * n_ptk);
+		wr(prefix, "pt_off.u64", off, sizeof(uint64_t) * (n_ptk + 1));
+		wr(prefix, "pt_pos.u64", pos, sizeof(uint64_t) * n_ptp);
+		free(keys); free(off); free(pos);
+	}
+	// per-read minimizers, index-time call (htab.cpp:691): rid = read id, hf = ha_flt_tab
+	{
+		UC_Read ur; init_UC_Read(&ur); ha_mz1_v mz = {0,0,0}; st_mt_t mt = {0,0,0};
+		std::vector<uint64_t> off(n_reads + 1, 0), rec;
+		for (uint64_t i = 0; i < n_reads; ++i) {
+			recover_UC_Read(&ur, &R_INF, i); mz.n = 0;
+			mz1_ha_sketch(ur.seq, ur.length, asm_opt.mz_win, asm_opt.k_mer_length, i, !(asm_opt.flag & HA_F_NO_HPC), &mz, ha_flt_tab, asm_opt.mz_sample_dist, 0, 0, NULL, -1, asm_opt.dp_min_len, asm_opt.dp_e, &mt, asm_opt.mz_rewin, 0, NULL);
+			for (uint32_t j = 0; j < mz.n; ++j) { uint64_t q[2]; memcpy(q, &mz.a[j], 16); rec.push_back(q[0]); rec.push_back(q[1]); }
+			off[i + 1] = rec.size() / 2;
+		}
+		wr(prefix, "mz_off.u64", &off[0], sizeof(uint64_t) * off.size());
+		wr(prefix, "mz.u64", rec.data(), sizeof(uint64_t) * rec.size());
+		// same with hf = NULL and sample_dist = 0 (pure window minimizers, no count order / thinning)
+		rec.clear();
+		for (uint64_t i = 0; i < n_reads; ++i) {
+			recover_UC_Read(&ur, &R_INF, i); mz.n = 0;
+			mz1_ha_sketch(ur.seq, ur.length, asm_opt.mz_win, asm_opt.k_mer_length, i, !(asm_opt.flag & HA_F_NO_HPC), &mz, NULL, 0, 0, 0, NULL, -1, asm_opt.dp_min_len, asm_opt.dp_e, &mt, asm_opt.mz_rewin, 0, NULL);
+			for (uint32_t j = 0; j < mz.n; ++j) { uint64_t q[2]; memcpy(q, &mz.a[j], 16); rec.push_back(q[0]); rec.push_back(q[1]); }
+			off[i + 1] = rec.size() / 2;
+		}
+		wr(prefix, "mz0_off.u64", &off[0], sizeof(uint64_t) * off.size());
+		wr(prefix, "mz0.u64", rec.data(), sizeof(uint64_t) * rec.size());
+		free(mz.a); free(mt.a); destory_UC_Read(&ur);
+	}
+	uint64_t tot_ol = 0, tot_cl = 0, tot_kh = 0;
+	{ // per-read seed hits before chaining, and (ol, cl) after h_ec_lchain
+		tbuf_t *b = tbuf_init(1);
+		std::vector<uint64_t> kh_off(n_reads + 1, 0), ol_off(n_reads + 1, 0), cl_off(n_reads + 1, 0), fc_off(1, 0), fc;
+		std::vector<uint32_t> kh, ol, cl;
+		for (uint64_t i = 0; i < n_reads; ++i) {
+			uint32_t ho = high_occ, lo = low_occ;
+			recover_UC_Read(&b->ur, &R_INF, i);
+			if (dump_hits) {
+				minimizers_qgen0(b->ab, b->ur.seq, b->ur.length, asm_opt.mz_win, asm_opt.k_mer_length, &b->cl, NULL, ha_flt_tab, ha_idx, &R_INF, NULL, &b->sp, &ho, &lo);
+				for (uint64_t j = 0; j < (uint64_t)b->cl.length; ++j) { uint32_t q[4]; memcpy(q, &b->cl.list[j], 16); kh.insert(kh.end(), q, q + 4); }
+			}
+			kh_off[i + 1] = kh.size() / 4;
+			ho = high_occ; lo = low_occ;
+			h_ec_lchain(b->ab, i, b->ur.seq, b->ur.length, asm_opt.mz_win, asm_opt.k_mer_length, &R_INF, &b->ol, &b->cl, bw, asm_opt.max_n_chain, 1, NULL, NULL, &b->sp, &ho, &lo, 1, 1, 3, 0.7, 2, 32, COV_W);
+			for (uint64_t j = 0; j < b->ol.length; ++j) {
+				overlap_region *r = &b->ol.list[j];
+				uint32_t q[12] = { r->x_id, r->x_pos_s, r->x_pos_e, r->x_pos_strand, r->y_id, r->y_pos_s, r->y_pos_e, r->y_pos_strand,
+								   (uint32_t)r->shared_seed, r->align_length, r->non_homopolymer_errors, r->f_cigar.length };
+				ol.insert(ol.end(), q, q + 12);
+				for (uint32_t c = 0; c < r->f_cigar.length; ++c) fc.push_back(r->f_cigar.buffer[c]);
+				fc_off.push_back(fc.size());
+			}
+			ol_off[i + 1] = ol.size() / 12;
+			if (dump_hits)
+				for (uint64_t j = 0; j < (uint64_t)b->cl.length; ++j) { uint32_t q[4]; memcpy(q, &b->cl.list[j], 16); cl.insert(cl.end(), q, q + 4); }
+			cl_off[i + 1] = cl.size() / 4;
+			tot_cl += b->cl.length;
+		}
+		tot_ol = ol.size() / 12; tot_kh = kh.size() / 4;
+		wr(prefix, "kh_off.u64", &kh_off[0], 8 * kh_off.size()); wr(prefix, "kh.u32", kh.data(), 4 * kh.size());
+		wr(prefix, "ol_off.u64", &ol_off[0], 8 * ol_off.size()); wr(prefix, "ol.u32", ol.data(), 4 * ol.size());
+		wr(prefix, "fc_off.u64", &fc_off[0], 8 * fc_off.size()); wr(prefix, "fc.u64", fc.data(), 8 * fc.size());
+		wr(prefix, "cl_off.u64", &cl_off[0], 8 * cl_off.size()); wr(prefix, "cl.u32", cl.data(), 4 * cl.size());
+	}
+	int64_t meta[24]; memset(meta, 0, sizeof(meta));
+	meta[0] = n_reads; meta[1] = asm_opt.k_mer_length; meta[2] = asm_opt.mz_win; meta[3] = hom_cov_ft;
+	meta[4] = ft_peak_hom; meta[5] = ft_peak_het; meta[6] = asm_opt.max_n_chain; meta[7] = hom_cov; meta[8] = het_cov;
+	meta[9] = high_occ; meta[10] = low_occ; meta[11] = n_ft; meta[12] = n_ptk; meta[13] = n_ptp; meta[14] = tot_ol;
+	meta[15] = tot_cl; meta[16] = tot_kh; meta[17] = ft_distinct; meta[18] = pt_distinct; meta[19] = is_ont;
+	meta[20] = asm_opt.mz_sample_dist; meta[21] = asm_opt.mz_rewin; meta[22] = asm_opt.max_kmer_cnt;
+	meta[23] = (int64_t)(asm_opt.high_factor * 1000);
+	wr(prefix, "meta.i64", meta, sizeof(meta));
+	fprintf(stderr, "[ref_harness] reads=%lu ft=%lu pt_keys=%lu pt_pos=%lu overlaps=%lu chained_hits=%lu seed_hits=%lu hom_cov=%d het_cov=%d max_n_chain=%d\n",
+			(unsigned long)n_reads, (unsigned long)n_ft, (unsigned long)n_ptk, (unsigned long)n_ptp, (unsigned long)tot_ol, (unsigned long)tot_cl, (unsigned long)tot_kh, hom_cov, het_cov, asm_opt.max_n_chain);
+	return 0;
+}
