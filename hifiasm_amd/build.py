@@ -75,7 +75,8 @@ def build_ref(force=False):
 
 def build_all(force=False):
     build_synth(force)
-    build_hip(force)
+    if os.path.exists(os.path.join(CSRC, HIP_SOURCES[0])):
+        build_hip(force)
     build_oracle(force)
     build_ref(force)
 

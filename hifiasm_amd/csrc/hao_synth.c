@@ -36,15 +36,19 @@ void hao_synth_genome(uint8_t *out, uint64_t size, uint64_t seed, int repeat_ric
 	}
 	for (; i < size; ++i) out[i] = splitmix64(&s) & 3;
 	if (repeat_rich) {
-		uint64_t n_units = size / 2000000 ? size / 2000000 : 1, u;
+		/* level 1: per 2 Mb, 10 families x 25 copies x 4 kb + a 300 x 171 bp tandem array;
+		 * level 2 (miniature, for small fixtures): per 100 kb, 3 families x 8 copies x 1.5 kb + 40 x 171 bp */
+		const uint64_t unit_sz = repeat_rich == 1 ? 2000000 : 100000;
+		const int n_fam = repeat_rich == 1 ? 10 : 3, n_cp = repeat_rich == 1 ? 25 : 8, e_len = repeat_rich == 1 ? 4000 : 1500, n_tan = repeat_rich == 1 ? 300 : 40;
+		uint64_t n_units = size / unit_sz ? size / unit_sz : 1, u;
 		uint8_t elem[4000], unit[171];
 		for (u = 0; u < n_units; ++u) {
 			int fam, c, j;
-			for (fam = 0; fam < 10; ++fam) {
-				for (j = 0; j < 4000; ++j) elem[j] = splitmix64(&s) & 3;
-				for (c = 0; c < 25; ++c) {
-					uint64_t p = size > 4000 ? rnd_below(&s, size - 4000) : 0;
-					for (j = 0; j < 4000 && p + j < size; ++j) {
+			for (fam = 0; fam < n_fam; ++fam) {
+				for (j = 0; j < e_len; ++j) elem[j] = splitmix64(&s) & 3;
+				for (c = 0; c < n_cp; ++c) {
+					uint64_t p = size > (uint64_t)e_len ? rnd_below(&s, size - e_len) : 0;
+					for (j = 0; j < e_len && p + j < size; ++j) {
 						uint8_t b = elem[j];
 						if (rnd_below(&s, 1000) < 15) b = (b + 1 + rnd_below(&s, 3)) & 3; /* 1.5 % divergence */
 						out[p + j] = b;
@@ -53,7 +57,7 @@ void hao_synth_genome(uint8_t *out, uint64_t size, uint64_t seed, int repeat_ric
 			}
 			for (j = 0; j < 171; ++j) unit[j] = splitmix64(&s) & 3;
 			{
-				uint64_t alen = 300 * 171, p = size > alen ? rnd_below(&s, size - alen) : 0, q;
+				uint64_t alen = (uint64_t)n_tan * 171, p = size > alen ? rnd_below(&s, size - alen) : 0, q;
 				for (q = 0; q < alen && p + q < size; ++q) out[p + q] = unit[q % 171];
 			}
 		}

@@ -42,7 +42,7 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
 
 
-def make_genome(size: int, seed: int = 11, repeat_rich: bool = False) -> np.ndarray:
+def make_genome(size: int, seed: int = 11, repeat_rich: int = 0) -> np.ndarray:
     g = np.empty(size, dtype=np.uint8)
     _lib().hao_synth_genome(_p(g, C.c_uint8), size, seed, int(repeat_rich))
     return g
@@ -94,7 +94,7 @@ def make_reads(genome: np.ndarray, n_reads: int, read_len: int, err: float, seed
     return ReadSet(rid0, lens, packed, pk_off, codes, code_off if want_codes else None)
 
 
-def dataset(genome_size: int, coverage: float, read_len: int, err: float, seed: int = 11, repeat_rich: bool = False,
+def dataset(genome_size: int, coverage: float, read_len: int, err: float, seed: int = 11, repeat_rich: int = 0,
             len_jit: int = 0, n_rate: float = 0.0, want_codes: bool = True) -> ReadSet:
     g = make_genome(genome_size, seed=seed, repeat_rich=repeat_rich)
     n_reads = max(1, int(round(genome_size * coverage / read_len)))

@@ -1,0 +1,163 @@
+"""ctypes binding of oracle/liboracle.so - TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
+module; the product package (hifiasm_amd/) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+
+class Opt(C.Structure):
+    _fields_ = [("k", C.c_int), ("w", C.c_int), ("hpc", C.c_int), ("sample_dist", C.c_int), ("rewin", C.c_int),
+                ("min_hist_cnt", C.c_int), ("max_kmer_cnt", C.c_int), ("high_factor", C.c_double),
+                ("max_n_chain", C.c_int), ("is_ont", C.c_int)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ROOT, "oracle", "liboracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run __graft_entry__.build()")
+        L = C.CDLL(path)
+        vp, u8p, u64p, i64p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_int64)
+        L.hao_or_opt_default.argtypes = [C.POINTER(Opt)]
+        L.hao_or_hash64.argtypes = [C.c_uint64]; L.hao_or_hash64.restype = C.c_uint64
+        L.hao_or_create.argtypes = [u8p, u64p, C.c_uint64, C.POINTER(Opt)]; L.hao_or_create.restype = vp
+        L.hao_or_destroy.argtypes = [vp]
+        L.hao_or_ft_gen.argtypes = [vp]; L.hao_or_ft_gen.restype = C.c_int
+        L.hao_or_pt_gen.argtypes = [vp]; L.hao_or_pt_gen.restype = C.c_int
+        L.hao_or_ft_hist.argtypes = [vp]; L.hao_or_ft_hist.restype = i64p
+        L.hao_or_pt_hist.argtypes = [vp]; L.hao_or_pt_hist.restype = i64p
+        L.hao_or_ft_table.argtypes = [vp, C.POINTER(u64p), C.POINTER(C.POINTER(C.c_int32))]; L.hao_or_ft_table.restype = C.c_uint64
+        L.hao_or_pt_table.argtypes = [vp, C.POINTER(u64p), C.POINTER(u64p), C.POINTER(u64p), u64p]; L.hao_or_pt_table.restype = C.c_uint64
+        L.hao_or_stats.argtypes = [vp, i64p]
+        L.hao_or_ft_cnt.argtypes = [vp, C.c_uint64]; L.hao_or_ft_cnt.restype = C.c_int32
+        L.hao_or_kmer_hashes.argtypes = [u8p, C.c_int64, C.c_int, C.c_int, u64p]; L.hao_or_kmer_hashes.restype = C.c_int64
+        L.hao_or_sketch.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(vp)]; L.hao_or_sketch.restype = C.c_int64
+        L.hao_or_sketch_seq.argtypes = [vp, u8p, C.c_int64, C.c_uint32, C.c_int, C.c_int, C.POINTER(vp)]; L.hao_or_sketch_seq.restype = C.c_int64
+        L.hao_or_seed_hits.argtypes = [vp, C.c_uint64, C.POINTER(vp)]; L.hao_or_seed_hits.restype = C.c_int64
+        L.hao_or_lchain.argtypes = [vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i64p]
+        L.hao_or_lchain.restype = C.c_int64
+        L.hao_or_analyze_count.argtypes = [C.c_int, C.c_int, i64p, C.POINTER(C.c_int)]; L.hao_or_analyze_count.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def _arr(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    nbytes = n * np.dtype(dtype).itemsize
+    buf = (C.c_uint8 * nbytes).from_address(ptr if isinstance(ptr, int) else C.cast(ptr, C.c_void_p).value)
+    return np.frombuffer(buf, dtype=dtype).copy()
+
+
+class Oracle:
+    """CPU restatement of the reference path over one read set (codes 0..3, >=4 = N)."""
+
+    def __init__(self, codes: np.ndarray, off: np.ndarray, **kw):
+        self.L = lib()
+        self.opt = Opt()
+        self.L.hao_or_opt_default(C.byref(self.opt))
+        for k, v in kw.items():
+            setattr(self.opt, k, v)
+        self.codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        self.off = np.ascontiguousarray(off, dtype=np.uint64)
+        self.n_reads = self.off.size - 1
+        self.h = self.L.hao_or_create(self.codes.ctypes.data_as(C.POINTER(C.c_uint8)), self.off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                      self.n_reads, C.byref(self.opt))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.hao_or_destroy(self.h)
+            self.h = None
+
+    def ft_gen(self):
+        return self.L.hao_or_ft_gen(self.h)
+
+    def pt_gen(self):
+        return self.L.hao_or_pt_gen(self.h)
+
+    def stats(self):
+        out = (C.c_int64 * 8)()
+        self.L.hao_or_stats(self.h, out)
+        names = ["ft_peak_hom", "ft_peak_het", "ft_cutoff", "max_n_chain", "hom_cov", "het_cov", "high_occ", "low_occ"]
+        return dict(zip(names, [int(x) for x in out]))
+
+    def ft_hist(self):
+        return _arr(self.L.hao_or_ft_hist(self.h), 4096, np.int64)
+
+    def pt_hist(self):
+        return _arr(self.L.hao_or_pt_hist(self.h), 4096, np.int64)
+
+    def ft_table(self):
+        k, v = C.POINTER(C.c_uint64)(), C.POINTER(C.c_int32)()
+        n = self.L.hao_or_ft_table(self.h, C.byref(k), C.byref(v))
+        return _arr(k, n, np.uint64), _arr(v, n, np.int32)
+
+    def pt_table(self):
+        k, o, p = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)()
+        npos = C.c_uint64()
+        n = self.L.hao_or_pt_table(self.h, C.byref(k), C.byref(o), C.byref(p), C.byref(npos))
+        return _arr(k, n, np.uint64), _arr(o, n + 1, np.uint64), _arr(p, npos.value, np.uint64)
+
+    def kmer_hashes(self, rid):
+        s = self.codes[int(self.off[rid]):int(self.off[rid + 1])]
+        out = np.empty(max(1, s.size), dtype=np.uint64)
+        n = self.L.hao_or_kmer_hashes(s.ctypes.data_as(C.POINTER(C.c_uint8)), s.size, self.opt.k, self.opt.hpc,
+                                      out.ctypes.data_as(C.POINTER(C.c_uint64)))
+        return out[:n]
+
+    def sketch(self, rid, use_ft=True, sample_dist=None):
+        """-> uint64 [n,2] (x, info)"""
+        p = C.c_void_p()
+        sd = self.opt.sample_dist if sample_dist is None else sample_dist
+        n = self.L.hao_or_sketch(self.h, rid, int(use_ft), sd, C.byref(p))
+        return _arr(p.value, 2 * n, np.uint64).reshape(-1, 2)
+
+    def sketch_seq(self, codes, rid=0, use_ft=True, sample_dist=None):
+        p = C.c_void_p()
+        sd = self.opt.sample_dist if sample_dist is None else sample_dist
+        s = np.ascontiguousarray(codes, dtype=np.uint8)
+        n = self.L.hao_or_sketch_seq(self.h, s.ctypes.data_as(C.POINTER(C.c_uint8)), s.size, rid, int(use_ft), sd, C.byref(p))
+        return _arr(p.value, 2 * n, np.uint64).reshape(-1, 2)
+
+    def seed_hits(self, rid):
+        """-> uint32 [n,4] (readID|strand<<31, offset, self_offset, cnt)"""
+        p = C.c_void_p()
+        n = self.L.hao_or_seed_hits(self.h, rid, C.byref(p))
+        return _arr(p.value, 4 * n, np.uint32).reshape(-1, 4)
+
+    def lchain(self, rid):
+        """-> (ol uint32 [n,12], fc uint64, fc_off uint64 [n+1], cl uint32 [m,4])"""
+        ol, fc, fco, cl = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        cln = C.c_int64()
+        n = self.L.hao_or_lchain(self.h, rid, C.byref(ol), C.byref(fc), C.byref(fco), C.byref(cl), C.byref(cln))
+        fo = _arr(fco.value, n + 1, np.uint64)
+        return (_arr(ol.value, 12 * n, np.uint32).reshape(-1, 12), _arr(fc.value, int(fo[-1]) if n >= 0 and fo.size else 0, np.uint64), fo,
+                _arr(cl.value, 4 * cln.value, np.uint32).reshape(-1, 4))
+
+
+def load_ref_dump(prefix: str):
+    """Read a ref_harness --dump PREFIX directory into a dict of numpy arrays."""
+    ext = {"u64": np.uint64, "i64": np.int64, "u32": np.uint32, "i32": np.int32}
+    d = {}
+    base = os.path.basename(prefix)
+    for fn in os.listdir(os.path.dirname(prefix)):
+        if not fn.startswith(base + "."):
+            continue
+        _, name, e = fn.rsplit(".", 2)
+        d[name] = np.fromfile(os.path.join(os.path.dirname(prefix), fn), dtype=ext[e])
+    m = d["meta"]
+    names = ["n_reads", "k", "w", "hom_cov_ft", "ft_peak_hom", "ft_peak_het", "max_n_chain", "hom_cov", "het_cov", "high_occ", "low_occ",
+             "n_ft", "n_ptk", "n_ptp", "tot_ol", "tot_cl", "tot_kh", "ft_distinct", "pt_distinct", "is_ont", "sample_dist", "rewin",
+             "max_kmer_cnt", "high_factor_x1000"]
+    d["meta"] = dict(zip(names, [int(x) for x in m]))
+    return d

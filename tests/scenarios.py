@@ -1,0 +1,17 @@
+"""Small seeded read sets shared by the golden-fixture generator and the tests.
+
+Each scenario is (synth.dataset kwargs, oracle option overrides).  They are chosen to
+walk every branch of the reference hot path: plain HiFi, repeat-rich (non-empty
+high-count table, second-level minimizer thinning, real chain DP, multi-copy chains,
+max_n_chain pruning), ONT-like error, N bases, too-low coverage (peak_hom = -1: every
+k-mer lands in the filter table) and an even k (strand-symmetric k-mer skip) with a
+narrower window.
+"""
+SCENARIOS = {
+    "hifi":  (dict(genome_size=40_000, coverage=18, read_len=4000, err=0.002, seed=3, len_jit=1000), {}),
+    "rr":    (dict(genome_size=100_000, coverage=12, read_len=4000, err=0.001, seed=5, repeat_rich=2, len_jit=1000), {}),
+    "ont":   (dict(genome_size=50_000, coverage=20, read_len=6000, err=0.01, seed=6, len_jit=2000), dict(is_ont=1)),
+    "nn":    (dict(genome_size=40_000, coverage=18, read_len=4000, err=0.002, seed=7, len_jit=1000, n_rate=0.0008), {}),
+    "low":   (dict(genome_size=40_000, coverage=3, read_len=4000, err=0.002, seed=8), {}),
+    "k40":   (dict(genome_size=40_000, coverage=18, read_len=4000, err=0.002, seed=10), dict(k=40, w=30)),
+}
