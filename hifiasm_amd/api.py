@@ -1,0 +1,222 @@
+"""Host-side mirror of the reference seam over the C ABI of libhao.so (include/hao.h).
+
+The reference's interface for this path is three functions:
+``ha_ft_gen`` (htab.cpp:1136), ``ha_pt_gen`` (htab.cpp:1232) and ``h_ec_lchain``
+(anchor.cpp:2302) plus the accessors ``ha_ft_cnt`` / ``ha_pt_get`` and the finer
+``mz1_ha_sketch``.  :class:`Engine` exposes them with the same names, argument
+meaning and (absence of) error returns: failures raise :class:`HaoError`, mirroring
+the reference's ``exit(1)``.  This module is plumbing only (ctypes + numpy); all
+compute happens in the HIP kernels.  There is no CPU fallback: constructing an
+Engine without a HIP device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class HaoError(RuntimeError):
+    pass
+
+
+class Opt(C.Structure):
+    _fields_ = [("k", C.c_int32), ("w", C.c_int32), ("hpc", C.c_int32), ("sample_dist", C.c_int32), ("rewin", C.c_int32),
+                ("min_hist_cnt", C.c_int32), ("max_kmer_cnt", C.c_int32), ("max_n_chain", C.c_int32),
+                ("high_factor", C.c_double), ("is_ont", C.c_int32), ("reserved", C.c_int32)]
+
+
+ABI_SYMBOLS = [
+    "hao_opt_default", "hao_create", "hao_destroy", "hao_last_error", "hao_set_reads", "hao_ft_gen", "hao_pt_gen",
+    "hao_ft_cnt", "hao_pt_get", "hao_ft_table", "hao_pt_table", "hao_hist", "hao_stats", "hao_sketch_batch",
+    "hao_fetch_sketch", "hao_overlap_batch", "hao_fetch_seed_hits", "hao_fetch_overlaps", "hao_batch_totals",
+    "hao_stage_times",
+]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libhao.so")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise HaoError(f"{p} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(p)
+        vp, u8p, u32p, u64p, i64p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_int64)
+        L.hao_opt_default.argtypes = [C.POINTER(Opt)]
+        L.hao_create.argtypes = [C.c_int, C.POINTER(Opt), C.POINTER(vp)]
+        L.hao_destroy.argtypes = [vp]
+        L.hao_last_error.argtypes = [vp]; L.hao_last_error.restype = C.c_char_p
+        L.hao_set_reads.argtypes = [vp, u8p, u64p, u32p, C.c_uint64, u64p, u32p]
+        L.hao_ft_gen.argtypes = [vp, C.POINTER(C.c_int32)]
+        L.hao_pt_gen.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.hao_ft_cnt.argtypes = [vp, C.c_uint64]; L.hao_ft_cnt.restype = C.c_int32
+        L.hao_pt_get.argtypes = [vp, C.c_uint64, C.POINTER(u64p), C.POINTER(C.c_int32)]
+        L.hao_ft_table.argtypes = [vp, u64p, C.POINTER(u64p), C.POINTER(C.POINTER(C.c_int32))]
+        L.hao_pt_table.argtypes = [vp, u64p, C.POINTER(u64p), C.POINTER(u64p), C.POINTER(u64p), u64p]
+        L.hao_hist.argtypes = [vp, C.c_int, i64p]
+        L.hao_stats.argtypes = [vp, i64p]
+        L.hao_sketch_batch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
+        L.hao_fetch_sketch.argtypes = [vp, C.c_uint64, C.POINTER(vp), u64p]
+        L.hao_overlap_batch.argtypes = [vp, C.c_uint64, C.c_uint64]
+        L.hao_fetch_seed_hits.argtypes = [vp, C.c_uint64, C.POINTER(vp), u64p]
+        L.hao_fetch_overlaps.argtypes = [vp, C.c_uint64, C.POINTER(vp), u64p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), u64p]
+        L.hao_batch_totals.argtypes = [vp, u64p]
+        L.hao_stage_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _arr(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    nbytes = int(n) * np.dtype(dtype).itemsize
+    addr = ptr if isinstance(ptr, int) else C.cast(ptr, C.c_void_p).value
+    return np.frombuffer((C.c_uint8 * nbytes).from_address(addr), dtype=dtype).copy()
+
+
+class Engine:
+    """One engine per GPU (one process per GPU).  Options mirror hifiasm_opt_t."""
+
+    def __init__(self, device: int = 0, **opts):
+        self.L = lib()
+        self.opt = Opt()
+        self.L.hao_opt_default(C.byref(self.opt))
+        for k, v in opts.items():
+            if not hasattr(self.opt, k):
+                raise HaoError(f"unknown option {k}")
+            setattr(self.opt, k, v)
+        h = C.c_void_p()
+        rc = self.L.hao_create(device, C.byref(self.opt), C.byref(h))
+        if rc != 0:
+            raise HaoError(f"hao_create failed ({rc}): no usable HIP device - this engine has no CPU fallback")
+        self.h = h
+        self.n_reads = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.hao_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise HaoError(f"{what} failed ({rc}): {self.L.hao_last_error(self.h).decode()}")
+
+    # ---- read store (All_reads, Process_Read.h:115-146) ----
+    def set_reads(self, packed, pk_off, lengths, n_mask=None, code_off=None):
+        """packed/pk_off/lengths as produced by ha_compress_base; n_mask (per-base 0/1, with code_off) lists N sites."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        pk_off = np.ascontiguousarray(pk_off, dtype=np.uint64)
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+        n = lengths.size
+        ns_off = ns = None
+        if n_mask is not None:
+            pos = np.flatnonzero(n_mask).astype(np.uint64)
+            co = np.ascontiguousarray(code_off, dtype=np.uint64)
+            rid = np.searchsorted(co, pos, side="right") - 1
+            ns = (pos - co[rid]).astype(np.uint32)
+            ns_off = np.zeros(n + 1, dtype=np.uint64)
+            np.cumsum(np.bincount(rid, minlength=n), out=ns_off[1:], dtype=np.uint64)
+        u8p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+        self._ck(self.L.hao_set_reads(self.h, packed.ctypes.data_as(u8p), pk_off.ctypes.data_as(u64p), lengths.ctypes.data_as(u32p), n,
+                                      ns_off.ctypes.data_as(u64p) if ns_off is not None else None,
+                                      ns.ctypes.data_as(u32p) if ns is not None else None), "hao_set_reads")
+        self.n_reads = n
+
+    def set_readset(self, rs):
+        self.set_reads(rs.packed, rs.pk_off, rs.lengths, rs.n_mask(), rs.code_off)
+
+    # ---- ha_ft_gen / ha_pt_gen ----
+    def ha_ft_gen(self):
+        hom = C.c_int32()
+        self._ck(self.L.hao_ft_gen(self.h, C.byref(hom)), "hao_ft_gen")
+        return hom.value
+
+    def ha_pt_gen(self):
+        hom, het = C.c_int32(), C.c_int32()
+        self._ck(self.L.hao_pt_gen(self.h, C.byref(hom), C.byref(het)), "hao_pt_gen")
+        return hom.value, het.value
+
+    def ha_ft_cnt(self, y):
+        return self.L.hao_ft_cnt(self.h, y)
+
+    def ha_pt_get(self, y):
+        p, n = C.POINTER(C.c_uint64)(), C.c_int32()
+        self._ck(self.L.hao_pt_get(self.h, y, C.byref(p), C.byref(n)), "hao_pt_get")
+        return _arr(p, n.value, np.uint64)
+
+    def ft_table(self):
+        n, k, v = C.c_uint64(), C.POINTER(C.c_uint64)(), C.POINTER(C.c_int32)()
+        self._ck(self.L.hao_ft_table(self.h, C.byref(n), C.byref(k), C.byref(v)), "hao_ft_table")
+        return _arr(k, n.value, np.uint64), _arr(v, n.value, np.int32)
+
+    def pt_table(self):
+        nk, npos = C.c_uint64(), C.c_uint64()
+        k, o, p = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)()
+        self._ck(self.L.hao_pt_table(self.h, C.byref(nk), C.byref(k), C.byref(o), C.byref(p), C.byref(npos)), "hao_pt_table")
+        return _arr(k, nk.value, np.uint64), _arr(o, nk.value + 1, np.uint64), _arr(p, npos.value, np.uint64)
+
+    def hist(self, which):
+        out = (C.c_int64 * 4096)()
+        self._ck(self.L.hao_hist(self.h, which, out), "hao_hist")
+        return np.array(out, dtype=np.int64)
+
+    def stats(self):
+        out = (C.c_int64 * 8)()
+        self._ck(self.L.hao_stats(self.h, out), "hao_stats")
+        names = ["ft_peak_hom", "ft_peak_het", "ft_cutoff", "max_n_chain", "hom_cov", "het_cov", "high_occ", "low_occ"]
+        return dict(zip(names, [int(x) for x in out]))
+
+    # ---- mz1_ha_sketch ----
+    def sketch_batch(self, lo, hi, use_ft=True, sample_dist=None):
+        sd = self.opt.sample_dist if sample_dist is None else sample_dist
+        self._ck(self.L.hao_sketch_batch(self.h, lo, hi, int(use_ft), sd), "hao_sketch_batch")
+
+    def fetch_sketch(self, rid):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._ck(self.L.hao_fetch_sketch(self.h, rid, C.byref(p), C.byref(n)), "hao_fetch_sketch")
+        return _arr(p.value, 2 * n.value, np.uint64).reshape(-1, 2)
+
+    # ---- h_ec_lchain ----
+    def overlap_batch(self, lo, hi):
+        self._ck(self.L.hao_overlap_batch(self.h, lo, hi), "hao_overlap_batch")
+
+    def fetch_seed_hits(self, rid):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._ck(self.L.hao_fetch_seed_hits(self.h, rid, C.byref(p), C.byref(n)), "hao_fetch_seed_hits")
+        return _arr(p.value, 4 * n.value, np.uint32).reshape(-1, 4)
+
+    def h_ec_lchain(self, rid):
+        """-> (ol uint32 [n,12], fc uint64, fc_off uint64 [n+1], cl uint32 [m,4]) for a read of the last batch."""
+        ol, fc, fo, cl = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n, m = C.c_uint64(), C.c_uint64()
+        self._ck(self.L.hao_fetch_overlaps(self.h, rid, C.byref(ol), C.byref(n), C.byref(fc), C.byref(fo), C.byref(cl), C.byref(m)),
+                 "hao_fetch_overlaps")
+        foff = _arr(fo.value, n.value + 1, np.uint64)
+        nfc = int(foff[-1] - foff[0]) if foff.size else 0
+        return (_arr(ol.value, 12 * n.value, np.uint32).reshape(-1, 12), _arr(fc.value, nfc, np.uint64), foff - (foff[0] if foff.size else 0),
+                _arr(cl.value, 4 * m.value, np.uint32).reshape(-1, 4))
+
+    def batch_totals(self):
+        out = (C.c_uint64 * 8)()
+        self._ck(self.L.hao_batch_totals(self.h, out), "hao_batch_totals")
+        return dict(overlaps=int(out[0]), chained_hits=int(out[1]), seed_hits=int(out[2]), groups=int(out[3]), minimizers=int(out[4]))
+
+    def stage_times(self):
+        names = (C.c_char_p * 64)()
+        ms = (C.c_float * 64)()
+        n = self.L.hao_stage_times(self.h, names, ms, 64)
+        return [(names[i].decode(), float(ms[i])) for i in range(n)]

@@ -1,0 +1,123 @@
+// libhao.so: C ABI (include/hao.h) + host orchestration of the HIP kernels.
+// Single translation unit; the kernel files are headers.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include "hao_ctx.hpp"
+#include "hao_sketch.cuh"
+#include "hao_host.hpp"
+#include "hao_index.cuh"
+#include "hao_query.cuh"
+#include "hao_chain.cuh"
+#include "hao_pipeline.hpp"
+
+extern "C" {
+
+void hao_opt_default(hao_opt_t *o)
+{
+	memset(o, 0, sizeof(*o));
+	o->k = 51; o->w = 51; o->hpc = 1; o->sample_dist = 500; o->rewin = 1000; o->min_hist_cnt = 5;
+	o->max_kmer_cnt = 2000; o->max_n_chain = 100; o->high_factor = 5.0; o->is_ont = 0;
+}
+
+int hao_create(int device, const hao_opt_t *opt, hao_ctx **out)
+{
+	*out = nullptr;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device >= n) return HAO_ENODEV;   // no CPU fallback, by design
+	if (hipSetDevice(device) != hipSuccess) return HAO_ENODEV;
+	if (!opt || opt->k <= 0 || opt->k > 63 || opt->w <= 0 || opt->w >= 256) return HAO_EINVAL;
+	hao_ctx *c = new hao_ctx();
+	c->device = device; c->opt = *opt; c->max_n_chain = opt->max_n_chain;
+	if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return HAO_ENODEV; }
+	memset(c->ft_hist, 0, sizeof(c->ft_hist)); memset(c->pt_hist, 0, sizeof(c->pt_hist));
+	*out = c;
+	return HAO_OK;
+}
+
+void hao_destroy(hao_ctx *c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	hao_batch_free(c);
+	// DevBuf members are released explicitly (no destructors: the struct is POD-ish on purpose)
+	hao_release_all(c);
+	(void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+const char *hao_last_error(const hao_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
+
+int hao_set_reads(hao_ctx *c, const uint8_t *packed, const uint64_t *pk_off, const uint32_t *len, uint64_t n_reads,
+				  const uint64_t *nsite_off, const uint32_t *nsite)
+{
+	if (!c || !packed || !pk_off || !len) return HAO_EINVAL;
+	if (n_reads >= (1ULL << 28)) { hao_set_err(c, "more than 2^28 reads (htab.cpp:765)"); return HAO_EUNSUPP; }
+	HIP_TRY(hipSetDevice(c->device));
+	c->n_reads = n_reads; c->n_pk_bytes = pk_off[n_reads];
+	c->h_len.assign(len, len + n_reads);
+	c->n_bases = 0;
+	for (uint64_t i = 0; i < n_reads; ++i) {
+		if (len[i] >= (1u << 27)) { hao_set_err(c, "read longer than 2^27 (htab.h:13-18)"); return HAO_EUNSUPP; }
+		c->n_bases += len[i];
+	}
+	HIP_TRY(c->d_packed.reserve(c->n_pk_bytes + 16)); HIP_TRY(c->d_pk_off.reserve(n_reads + 1)); HIP_TRY(c->d_len.reserve(n_reads + 1));
+	HIP_TRY(hipMemcpyAsync(c->d_packed.p, packed, c->n_pk_bytes, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipMemsetAsync(c->d_packed.p + c->n_pk_bytes, 0, 16, c->stream));
+	HIP_TRY(hipMemcpyAsync(c->d_pk_off.p, pk_off, (n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipMemcpyAsync(c->d_len.p, len, n_reads * 4, hipMemcpyHostToDevice, c->stream));
+	c->has_n = nsite_off && nsite && nsite_off[n_reads] > 0;
+	c->h_nsite_off.clear();
+	if (c->has_n) {
+		c->h_nsite_off.assign(nsite_off, nsite_off + n_reads + 1);
+		HIP_TRY(c->d_nsite_off.reserve(n_reads + 1)); HIP_TRY(c->d_nsite.reserve(nsite_off[n_reads] + 1));
+		HIP_TRY(hipMemcpyAsync(c->d_nsite_off.p, nsite_off, (n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipMemcpyAsync(c->d_nsite.p, nsite, nsite_off[n_reads] * 4, hipMemcpyHostToDevice, c->stream));
+	}
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	c->has_ft = false; c->has_pt = false; c->h_ix_valid = false; c->sk_n = 0;
+	return HAO_OK;
+}
+
+int hao_sketch_batch(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi, int use_ft, int sample_dist)
+{
+	if (!c || rid_lo > rid_hi || rid_hi > c->n_reads) return HAO_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	c->timer.begin(c->stream);
+	int rc = hao_sketch_run(c, rid_lo, rid_hi, use_ft && c->has_ft, sample_dist, 1);
+	if (rc != HAO_OK) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	c->timer.collect(c->stage_ms);
+	c->h_mz_off.resize(c->sk_n + 1);
+	HIP_TRY(hipMemcpy(c->h_mz_off.data(), c->d_mz_off.p, (c->sk_n + 1) * 8, hipMemcpyDeviceToHost));
+	return HAO_OK;
+}
+
+int hao_fetch_sketch(hao_ctx *c, uint64_t rid, const hao_mz_t **mz, uint64_t *n)
+{
+	if (!c || rid < c->sk_lo || rid >= c->sk_lo + c->sk_n || c->h_mz_off.size() != c->sk_n + 1) return HAO_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	uint64_t s = c->h_mz_off[rid - c->sk_lo], e = c->h_mz_off[rid - c->sk_lo + 1], m = e - s;
+	c->h_mz_fetch.resize(m + 1);
+	std::vector<uint64_t> x(m + 1), info(m + 1);
+	if (m) {
+		HIP_TRY(hipMemcpy(x.data(), c->d_mz_x.p + s, m * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(info.data(), c->d_mz_info.p + s, m * 8, hipMemcpyDeviceToHost));
+	}
+	for (uint64_t i = 0; i < m; ++i) { c->h_mz_fetch[i].x = x[i]; c->h_mz_fetch[i].info = info[i]; }
+	*mz = c->h_mz_fetch.data(); *n = m;
+	return HAO_OK;
+}
+
+int hao_stage_times(hao_ctx *c, const char **names, float *ms, int cap)
+{
+	if (!c) return 0;
+	int n = 0;
+	for (auto &p : c->stage_ms) { if (n >= cap) break; names[n] = p.first.c_str(); ms[n] = p.second; ++n; }
+	return n;
+}
+
+} // extern "C"
+
+#include "hao_capi_rest.hpp"

@@ -1,0 +1,90 @@
+// Engine context: device buffers, stream, stage timers (host side of libhao.so).
+#pragma once
+#include <rocprim/rocprim.hpp>
+#include <map>
+#include "hao_common.cuh"
+
+struct hao_ctx;
+static void hao_set_err(hao_ctx *c, const std::string &m);
+
+// grow-only device buffer
+template<typename T> struct DevBuf {
+	T *p = nullptr; size_t cap = 0;
+	hipError_t reserve(size_t n) {
+		if (n <= cap) return hipSuccess;
+		if (p) (void)hipFree(p);
+		p = nullptr; cap = 0;
+		size_t want = n + n / 8 + 64;
+		hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+		if (e == hipSuccess) cap = want;
+		return e;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct StageTimer {
+	std::vector<std::string> names; std::vector<hipEvent_t> ev; hipStream_t st = nullptr;
+	void begin(hipStream_t s) { st = s; names.clear(); mark("__begin"); }
+	void mark(const char *name) {
+		size_t i = names.size();
+		if (i >= ev.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev.push_back(e); }
+		names.push_back(name); (void)hipEventRecord(ev[i], st);
+	}
+	// after stream sync: ms between consecutive marks, labelled by the later mark
+	void collect(std::vector<std::pair<std::string, float> > &out) {
+		out.clear();
+		for (size_t i = 1; i < names.size(); ++i) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[i - 1], ev[i]); out.push_back(std::make_pair(names[i], ms)); }
+	}
+	~StageTimer() { for (auto e : ev) (void)hipEventDestroy(e); }
+};
+
+struct hao_ctx {
+	int device = 0; hao_opt_t opt; std::string err; hipStream_t stream = nullptr;
+	// ---- read store (HBM) ----
+	uint64_t n_reads = 0, n_bases = 0, n_pk_bytes = 0; bool has_n = false;
+	DevBuf<uint8_t> d_packed; DevBuf<uint64_t> d_pk_off; DevBuf<uint32_t> d_len; DevBuf<uint64_t> d_nsite_off; DevBuf<uint32_t> d_nsite;
+	std::vector<uint32_t> h_len; std::vector<uint64_t> h_nsite_off;
+	// ---- filter table ----
+	bool has_ft = false; int ft_peak_hom = -1, ft_peak_het = -1, ft_cutoff = 0; int64_t ft_hist[HAO_N_COUNTS];
+	std::vector<uint64_t> h_ft_keys; std::vector<int32_t> h_ft_vals;
+	DevBuf<uint64_t> d_ft_keys; DevBuf<int32_t> d_ft_vals; DevBuf<uint32_t> d_ft_bucket;
+	int max_n_chain = 100, hom_cov = -1, het_cov = -1;
+	// ---- sketch workspace / results ----
+	uint64_t sk_lo = 0, sk_n = 0, sk_total = 0; bool sk_is_index = false;
+	DevBuf<uint64_t> d_tile_off; DevBuf<uint32_t> d_tile_ord, d_n_runs, d_tot_l; DevBuf<uint64_t> d_chunk_off, d_chunk_cnt64;
+	DevBuf<uint8_t> d_scalar_flag; DevBuf<uint32_t> d_scalar_list;
+	DevBuf<uint64_t> d_pool_x, d_pool_info; DevBuf<uint32_t> d_pool_ord; DevBuf<unsigned long long> d_cursor; DevBuf<int> d_err;
+	DevBuf<uint64_t> d_chunk_base, d_chunk_dst; DevBuf<uint32_t> d_chunk_cnt;
+	DevBuf<uint64_t> d_g_x, d_g_info; DevBuf<uint32_t> d_g_ord; DevBuf<uint64_t> d_g_off; DevBuf<uint32_t> d_new_n; DevBuf<uint64_t> d_new_n64;
+	DevBuf<uint64_t> d_mz_x, d_mz_info, d_mz_off;          // final per-read minimizers of the last sketch_batch
+	DevBuf<unsigned char> d_tmp; DevBuf<unsigned char> d_ring; DevBuf<uint32_t> d_ringord, d_cnt_ws;
+	std::vector<uint64_t> h_mz_off; std::vector<hao_mz_t> h_mz_fetch;
+	// ---- index (pt) ----
+	bool has_pt = false; int64_t pt_hist[HAO_N_COUNTS];
+	uint64_t ix_n_mz = 0, ix_n_keys = 0, ix_n_pos = 0;
+	DevBuf<uint64_t> d_ix_mz_x, d_ix_mz_info, d_ix_mz_off;  // all reads' minimizers in read order (query side reuses them)
+	DevBuf<uint64_t> d_ix_sx, d_ix_sinfo;                    // sorted by hash (stable)
+	DevBuf<uint64_t> d_ix_keys, d_ix_start; DevBuf<uint32_t> d_ix_cnt; DevBuf<uint32_t> d_ix_bucket;
+	std::vector<uint64_t> h_ix_keys, h_ix_off, h_ix_pos; bool h_ix_valid = false;
+	// ---- query batch ----
+	struct Batch;
+	Batch *batch = nullptr;
+	StageTimer timer; std::vector<std::pair<std::string, float> > stage_ms;
+};
+
+static void hao_set_err(hao_ctx *c, const std::string &m) { if (c) c->err = m; }
+
+#define HAO_CHECK_LAUNCH() HIP_TRY(hipGetLastError())
+
+// scratch for rocprim calls
+static inline hipError_t hao_tmp(hao_ctx *c, size_t bytes) { return c->d_tmp.reserve(bytes + 256); }
+
+template<typename In, typename Out>
+static int hao_excl_scan_u64(hao_ctx *c, In in, Out out, size_t n)
+{
+	size_t tb = 0;
+	HIP_TRY(rocprim::exclusive_scan(nullptr, tb, in, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), c->stream));
+	HIP_TRY(hao_tmp(c, tb));
+	HIP_TRY(rocprim::exclusive_scan(c->d_tmp.p, tb, in, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), c->stream));
+	return HAO_OK;
+}

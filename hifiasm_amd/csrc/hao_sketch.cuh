@@ -1,0 +1,573 @@
+// K1+K3: HPC k-mer hashing and (count,hash) window minimizers for gfx950.
+//
+// Replaces the per-base state machine of mz1_ha_sketch (sketch.cpp:454-579) by a
+// data-parallel closed form (validated there against the
+// reference):
+//
+//   * one "iteration" of the reference = one homopolymer run (its last base); runs
+//     get ordinals t = 1..T.  Ordinal t >= k carries a k-mer made of runs t-k+1..t.
+//   * position j is emitted iff its key (count,hash) equals the minimum key of at
+//     least one window of w consecutive ordinals [t-w+1, t], w+k-1 <= t <= T (all ties
+//     emitted), plus the first-window quirk (sketch.cpp:523-534,543-547) and the
+//     end-of-read flush for reads with fewer than w+k-1 ordinals (sketch.cpp:571-573).
+//     Equivalently  key(j) == max_{t in [j, j+w-1] valid} min_{i in [t-w+1, t]} key(i):
+//     a sliding minimum followed by a sliding maximum - both done by log-step doubling
+//     over LDS, no per-lane divergence.
+//   * non-candidate slots (span >= 256, sketch.cpp:505; filtered k-mers, :510) still
+//     occupy a window position with the maximal key.
+//
+// Work decomposition: (read, chunk of HAO_SK_CHUNK window ordinals).  Every chunk is
+// self-contained: it re-derives its runs from the packed bases using a per-read
+// run-count index at 1024-base granularity (hpc_index_kernel), so long reads split
+// over many workgroups and the grid is >> 256 workgroups for any realistic batch.
+//
+// Reads the fast path does not cover (N bases, even k: strand-symmetric k-mers,
+// sketch.cpp:502) go through sketch_scalar_kernel: the exact state machine, one lane
+// per read.  There is no host fallback.
+#pragma once
+#include "hao_common.cuh"
+
+#define HAO_SK_CHUNK 1024      // window ordinals marked per workgroup
+#define HAO_SK_TILE 1024       // bases per run-count index tile (= 64 lanes x 16 bases)
+#define HAO_SK_THREADS 256
+
+struct hao_ft_dev {            // high-count filter table, device view (sorted keys + 64K-bucket top-bits index)
+	const uint64_t *keys; const int32_t *vals; const uint32_t *bucket; uint64_t n;
+};
+
+// ha_ft_cnt (htab.cpp:1064-1070)
+__device__ __forceinline__ int32_t hao_ft_lookup(const hao_ft_dev &ft, uint64_t y)
+{
+	uint32_t b = (uint32_t)(y >> 48), lo = ft.bucket[b], hi = ft.bucket[b + 1];
+	while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (ft.keys[m] < y) lo = m + 1; else hi = m; }
+	return (lo < ft.bucket[b + 1] && ft.keys[lo] == y) ? ft.vals[lo] : 0;
+}
+
+// 16 bases (one big-endian 32-bit word of the packed read) -> bit (30-2j) set iff base j is
+// the last base of a homopolymer run.  g0 = index of base 0 of the word.
+__device__ __forceinline__ uint32_t hao_run_ends16(const uint8_t *rd, uint32_t len, uint32_t g0, uint32_t *word_out)
+{
+	if (g0 >= len) { *word_out = 0; return 0; }
+	uint32_t nb = (len >> 2) + 1, b = g0 >> 2;             // bytes available: len/4+1 (Process_Read.cpp:443)
+	uint32_t W = (uint32_t)rd[b] << 24;
+	if (b + 1 < nb) W |= (uint32_t)rd[b + 1] << 16;
+	if (b + 2 < nb) W |= (uint32_t)rd[b + 2] << 8;
+	if (b + 3 < nb) W |= (uint32_t)rd[b + 3];
+	uint32_t nxt = (b + 4 < nb) ? (uint32_t)(rd[b + 4] >> 6) : 0;      // base g0+16
+	uint32_t Y = W ^ ((W << 2) | nxt);
+	uint32_t ne = (Y | (Y >> 1)) & 0x55555555u;            // base j != base j+1
+	uint32_t rem = len - g0;                                // >= 1 bases of this word are inside the read
+	uint32_t q = rem > 16 ? 16 : rem - 1;                   // comparisons j vs j+1 valid for j < q
+	uint32_t m = q == 0 ? 0 : (q >= 16 ? 0x55555555u : ((0xFFFFFFFFu << (32 - 2 * q)) & 0x55555555u));
+	ne &= m;
+	if (rem <= 16) ne |= 1u << (30 - 2 * (rem - 1));       // the last base of the read always ends a run
+	*word_out = W;
+	return ne;
+}
+
+__device__ __forceinline__ uint32_t hao_wave_excl_scan(uint32_t v, uint32_t *total)
+{
+	uint32_t x = v; int lane = hao_lane();
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d); if (lane >= d) x += y; }
+	*total = __shfl(x, 63);
+	return x - v;
+}
+
+// ---------------------------------------------------------------------------------------
+// K_A: per-read run-count index. One wave per read; tile_ord[tile_off[r] + i] = number of
+// runs that end before base 1024*i; last entry = T (total runs). flags[r] bit0 = needs the
+// scalar path.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hpc_index_kernel(const uint8_t *packed, const uint64_t *pk_off, const uint32_t *len,
+		const uint64_t *tile_off, uint32_t *tile_ord, uint32_t *n_runs, uint64_t rid_lo, uint64_t n_sel, int hpc)
+{
+	uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= n_sel) return;
+	uint64_t rid = rid_lo + r; const uint8_t *rd = packed + pk_off[rid]; uint32_t L = len[rid];
+	uint32_t *to = tile_ord + tile_off[r]; uint32_t run = 0, nt = (L + HAO_SK_TILE - 1) / HAO_SK_TILE;
+	for (uint32_t ti = 0; ti < nt; ++ti) {
+		uint32_t W, g0 = ti * HAO_SK_TILE + hao_lane() * 16, c;
+		if (hpc) c = __popc(hao_run_ends16(rd, L, g0, &W));
+		else c = g0 >= L ? 0 : (L - g0 > 16 ? 16 : L - g0);
+		uint32_t tot; hao_wave_excl_scan(c, &tot);
+		if (hao_lane() == 0) to[ti] = run;
+		run += tot;
+	}
+	if (hao_lane() == 0) { to[nt] = run; n_runs[r] = run; }
+}
+
+struct hao_sk_args {
+	const uint8_t *packed; const uint64_t *pk_off; const uint32_t *len;
+	const uint64_t *tile_off; const uint32_t *tile_ord; const uint32_t *n_runs;
+	const uint64_t *chunk_off;     // [n_sel+1] exclusive scan of chunks per read
+	const uint8_t *scalar_flag;    // [n_sel] 1 = handled by sketch_scalar_kernel
+	uint64_t rid_lo, n_sel; int k, w, hpc;
+	hao_ft_dev ft;
+	// output pool (append order arbitrary) + per-chunk record
+	uint64_t *pool_x, *pool_info; uint32_t *pool_ord; unsigned long long *pool_cursor; uint64_t pool_cap;
+	uint64_t *chunk_base; uint32_t *chunk_cnt; int *err;
+};
+
+struct hao_key { uint64_t x; uint32_t c; };
+template<bool HAS_FT> __device__ __forceinline__ bool hao_key_lt(const hao_key &a, const hao_key &b)
+{ if (HAS_FT) return a.c < b.c || (a.c == b.c && a.x < b.x); return a.x < b.x; }
+template<bool HAS_FT> __device__ __forceinline__ bool hao_key_eq(const hao_key &a, const hao_key &b)
+{ if (HAS_FT) return a.c == b.c && a.x == b.x; return a.x == b.x; }
+
+#define HAO_SK_GMAX 6   // entries per lane: (CHUNK + 2*(w-1)) / 256 rounded up, w <= 255
+
+// ---------------------------------------------------------------------------------------
+// K_B: one workgroup per (read, chunk).
+// LDS layout (dynamic): end1[NE] u32 | rcode[NE] u8 | planes[2][NW] u64 | kx[NKP] u64 | kc[NKP] u32 |
+//                       bx[2][NKP] u64 | bc[2][NKP] u32 | misc
+// ---------------------------------------------------------------------------------------
+template<bool HAS_FT>
+__global__ __launch_bounds__(HAO_SK_THREADS) void sketch_chunk_kernel(hao_sk_args a)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	const int k = a.k, w = a.w, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int NE = HAO_SK_CHUNK + 2 * (w - 1) + k + 1;
+	const int NW = (NE + 63) / 64 + 1;
+	const int NKP = ((HAO_SK_CHUNK + 2 * (w - 1) + HAO_SK_THREADS - 1) / HAO_SK_THREADS) * HAO_SK_THREADS;
+	uint64_t *pl0 = (uint64_t*)smem, *pl1 = pl0 + NW, *kx = pl1 + NW, *bx0 = kx + NKP, *bx1 = bx0 + NKP;
+	uint32_t *end1 = (uint32_t*)(bx1 + NKP), *kc = end1 + NE, *bc0 = kc + NKP, *bc1 = bc0 + NKP;
+	uint8_t *rcode = (uint8_t*)(bc1 + NKP);
+	__shared__ uint32_t s_cnt[4]; __shared__ unsigned long long s_base; __shared__ int s_patch_prev; __shared__ int s_patch_on;
+
+	// which (read, chunk)?
+	uint64_t ch = blockIdx.x, lo = 0, hi = a.n_sel;
+	while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (a.chunk_off[m + 1] <= ch) lo = m + 1; else hi = m; }
+	const uint64_t r = lo;
+	if (a.scalar_flag[r]) return;                                   // record is written by the scalar kernel
+	const uint32_t ci = (uint32_t)(ch - a.chunk_off[r]);
+	const uint64_t rid = a.rid_lo + r; const uint8_t *rd = a.packed + a.pk_off[rid]; const uint32_t L = a.len[rid];
+	const int T = (int)a.n_runs[r];
+	const uint32_t *tord = a.tile_ord + a.tile_off[r]; const uint32_t ntile = (L + HAO_SK_TILE - 1) / HAO_SK_TILE;
+	const int j0 = k + (int)ci * HAO_SK_CHUNK, j1 = min(j0 + HAO_SK_CHUNK, T + 1);      // marks decided for ordinals [j0, j1)
+	if (j0 > T) { if (tid == 0) { a.chunk_base[ch] = 0; a.chunk_cnt[ch] = 0; } return; } // read with < k runs (its single chunk)
+	const int kk0 = max(k, j0 - w + 1), kk1 = min(T, j1 - 1 + w - 1);                  // keys needed for ordinals [kk0, kk1]
+	const int rbase = kk0 - k;                                                         // end1[e] <-> ordinal rbase + e
+	const int nE = kk1 - rbase + 1, nK = kk1 - kk0 + 1;
+	const uint64_t mask = (1ULL << k) - 1;
+
+	// ---- S2: run ends of the needed ordinal range -> rcode/end1 ----
+	if (tid == 0 && rbase == 0) end1[0] = 0;                        // ordinal 0 "ends" before base 0
+	{
+		const uint32_t first = rbase > 0 ? (uint32_t)rbase : 1u;   // first ordinal to materialise
+		uint32_t tlo = 0, thi = ntile;                              // last tile with tord[ti] < first
+		while (thi - tlo > 1) { uint32_t m = (tlo + thi) >> 1; if (tord[m] < first) tlo = m; else thi = m; }
+		for (uint32_t ti = tlo + wv; ti < ntile && tord[ti] < (uint32_t)kk1; ti += 4) {
+			uint32_t W, g0 = ti * HAO_SK_TILE + lane * 16, tot;
+			uint32_t eb = a.hpc ? hao_run_ends16(rd, L, g0, &W) : 0;
+			if (!a.hpc) { hao_run_ends16(rd, L, g0, &W); uint32_t rem = g0 >= L ? 0 : (L - g0 > 16 ? 16 : L - g0); eb = rem == 0 ? 0 : (rem >= 16 ? 0x55555555u : ((0xFFFFFFFFu << (32 - 2 * rem)) & 0x55555555u)); }
+			uint32_t o = tord[ti] + hao_wave_excl_scan(__popc(eb), &tot) + 1;
+			while (eb) {
+				int hb = 31 - __clz(eb); int j = (30 - hb) >> 1; eb &= ~(1u << hb);
+				if (o >= first && o <= (uint32_t)kk1) { int e = (int)o - rbase; rcode[e] = (W >> (30 - 2 * j)) & 3; end1[e] = g0 + j + 1; }
+				++o;
+			}
+		}
+	}
+	__syncthreads();
+	// ---- S2b: bit planes of the run codes (bit e of plane <-> run rbase+e) ----
+	for (int e0 = wv * 64; e0 < nE + 64; e0 += 256) {
+		int e = e0 + lane; uint32_t c = (e >= 1 && e < nE) ? rcode[e] : 0;
+		unsigned long long b0 = __ballot(c & 1), b1 = __ballot(c >> 1);
+		if (lane == 0 && (e0 >> 6) < NW) { pl0[e0 >> 6] = b0; pl1[e0 >> 6] = b1; }
+	}
+	__syncthreads();
+	// ---- S3: keys of ordinals kk0..kk1 ----
+	hao_key key[HAO_SK_GMAX];
+	const int G = NKP / HAO_SK_THREADS;
+#pragma unroll
+	for (int g = 0; g < HAO_SK_GMAX; ++g) {
+		key[g].x = UINT64_MAX; key[g].c = HAO_CNT_DUMMY;
+		int q = tid + g * HAO_SK_THREADS;                           // q <-> ordinal kk0 + q
+		if (g < G && q < nK) {
+			int e = q + k, s = e - k + 1;                            // runs s..e of the local arrays
+			int wi = s >> 6, sh = s & 63;
+			uint64_t W0 = pl0[wi] >> sh, W1 = pl1[wi] >> sh;
+			if (sh) { W0 |= pl0[wi + 1] << (64 - sh); W1 |= pl1[wi + 1] << (64 - sh); }
+			W0 &= mask; W1 &= mask;
+			uint64_t f1 = __brevll(W1) >> (64 - k), r1 = ~W1 & mask;  // high bit-planes of forward / reverse-complement k-mer
+			uint32_t span = end1[e] - end1[e - k];
+			if (span < 256) {
+				uint64_t y = f1 < r1 ? hao_hash64(__brevll(W0) >> (64 - k)) + hao_hash64(f1)
+									 : hao_hash64(~W0 & mask) + hao_hash64(r1);
+				if (HAS_FT) { int32_t cnt = hao_ft_lookup(a.ft, y); if (cnt < (1 << 28)) { key[g].x = y; key[g].c = (uint32_t)cnt; } }
+				else { key[g].x = y; key[g].c = 0; }
+			}
+		}
+		if (g < G) { kx[q] = key[g].x; if (HAS_FT) kc[q] = key[g].c; }
+	}
+	// ---- S4: sliding minimum over [t-w+1, t] by doubling; ping-pong bx0/bx1 ----
+	hao_key v[HAO_SK_GMAX];
+#pragma unroll
+	for (int g = 0; g < HAO_SK_GMAX; ++g) v[g] = key[g];
+	int cur = 0, cover = 1;
+	auto publish = [&](int which) {
+		uint64_t *bx = which ? bx1 : bx0; uint32_t *bc = which ? bc1 : bc0;
+#pragma unroll
+		for (int g = 0; g < HAO_SK_GMAX; ++g) if (g < G) { int q = tid + g * HAO_SK_THREADS; bx[q] = v[g].x; if (HAS_FT) bc[q] = v[g].c; }
+		__syncthreads();
+	};
+	auto fetch = [&](int which, int q, hao_key dflt) -> hao_key {
+		const uint64_t *bx = which ? bx1 : bx0; const uint32_t *bc = which ? bc1 : bc0;
+		if (q < 0 || q >= NKP) return dflt;
+		hao_key o; o.x = bx[q]; o.c = HAS_FT ? bc[q] : 0; return o;
+	};
+	const hao_key kmax = { UINT64_MAX, HAO_CNT_DUMMY }, kmin = { 0, 0 };
+	while (cover * 2 <= w) {
+		publish(cur);
+#pragma unroll
+		for (int g = 0; g < HAO_SK_GMAX; ++g) if (g < G) { hao_key o = fetch(cur, tid + g * HAO_SK_THREADS - cover, kmax); if (hao_key_lt<HAS_FT>(o, v[g])) v[g] = o; }
+		cover *= 2; cur ^= 1;
+	}
+	if (cover < w) {
+		publish(cur);
+#pragma unroll
+		for (int g = 0; g < HAO_SK_GMAX; ++g) if (g < G) { hao_key o = fetch(cur, tid + g * HAO_SK_THREADS - (w - cover), kmax); if (hao_key_lt<HAS_FT>(o, v[g])) v[g] = o; }
+		cur ^= 1;
+	}
+	// v = m(t) for t = kk0 + q.  Windows are valid only for w+k-1 <= t <= T: others count as -inf in the max pass.
+	const int tm0 = max(j0, w + k - 1);
+#pragma unroll
+	for (int g = 0; g < HAO_SK_GMAX; ++g) if (g < G) { int t = kk0 + tid + g * HAO_SK_THREADS; if (t < tm0 || t > kk1) v[g] = kmin; }
+	// ---- sliding maximum over [j, j+w-1] ----
+	cover = 1;
+	while (cover * 2 <= w) {
+		publish(cur);
+#pragma unroll
+		for (int g = 0; g < HAO_SK_GMAX; ++g) if (g < G) { hao_key o = fetch(cur, tid + g * HAO_SK_THREADS + cover, kmin); if (hao_key_lt<HAS_FT>(v[g], o)) v[g] = o; }
+		cover *= 2; cur ^= 1;
+	}
+	if (cover < w) {
+		publish(cur);
+#pragma unroll
+		for (int g = 0; g < HAO_SK_GMAX; ++g) if (g < G) { hao_key o = fetch(cur, tid + g * HAO_SK_THREADS + (w - cover), kmin); if (hao_key_lt<HAS_FT>(v[g], o)) v[g] = o; }
+		cur ^= 1;
+	}
+	// ---- marks ----
+	bool mk[HAO_SK_GMAX];
+#pragma unroll
+	for (int g = 0; g < HAO_SK_GMAX; ++g) {
+		int t = kk0 + tid + g * HAO_SK_THREADS;
+		mk[g] = g < G && t >= j0 && t < j1 && key[g].x != UINT64_MAX && hao_key_eq<HAS_FT>(key[g], v[g]);
+	}
+	// first-window quirk (chunk 0 only) and short reads: decided by one lane over <= w keys in LDS (kx/kc are intact)
+	if (tid == 0) { s_patch_on = 0; s_patch_prev = -1; }
+	__syncthreads();
+	if (ci == 0 && tid == 0) {
+		auto kq = [&](int t) -> hao_key { hao_key o; o.x = kx[t - kk0]; o.c = HAS_FT ? kc[t - kk0] : 0; return o; };
+		if (T >= w + k - 1) {
+			const int t0 = w + k - 1; int prev = -1; hao_key pk = kmax;
+			for (int t = k; t < t0; ++t) { hao_key o = kq(t); if (!hao_key_lt<HAS_FT>(pk, o)) { pk = o; prev = t; } }   // newest minimum of [k, t0-1]
+			if (prev >= 0 && pk.x != UINT64_MAX) { hao_key o = kq(t0); if (!hao_key_lt<HAS_FT>(pk, o)) { s_patch_on = 1; s_patch_prev = prev; } }
+		} else {                                                    // fewer than w+k-1 runs: only the end-of-read flush fires
+			int prev = -1; hao_key pk = kmax;
+			for (int t = max(k, T - w + 1); t <= T; ++t) { hao_key o = kq(t); if (!hao_key_lt<HAS_FT>(pk, o)) { pk = o; prev = t; } }
+			s_patch_on = 2; s_patch_prev = (prev >= 0 && pk.x != UINT64_MAX) ? prev : -1;
+		}
+	}
+	__syncthreads();
+	if (s_patch_on == 1) {          // key(t0) <= key(prev): prev itself is never emitted, its older ties in [k, t0-1] are
+		const int prev = s_patch_prev; hao_key pk; pk.x = kx[prev - kk0]; pk.c = HAS_FT ? kc[prev - kk0] : 0;
+#pragma unroll
+		for (int g = 0; g < HAO_SK_GMAX; ++g) {
+			int t = kk0 + tid + g * HAO_SK_THREADS;
+			if (g < G && t >= k && t < w + k - 1) { if (t == prev) mk[g] = false; else if (hao_key_eq<HAS_FT>(key[g], pk)) mk[g] = true; }
+		}
+	} else if (s_patch_on == 2) {
+#pragma unroll
+		for (int g = 0; g < HAO_SK_GMAX; ++g) { int t = kk0 + tid + g * HAO_SK_THREADS; mk[g] = g < G && t == s_patch_prev; }
+	}
+	// ---- S5: ordered compaction + append ----
+	// entry q = tid + 256 g: order by q. rank = (#marked with smaller q).  Count per (g, wave) via ballots.
+	uint32_t myrank[HAO_SK_GMAX]; __shared__ uint32_t s_gw[HAO_SK_GMAX][4];
+#pragma unroll
+	for (int g = 0; g < HAO_SK_GMAX; ++g) {
+		unsigned long long bal = __ballot(mk[g]);
+		myrank[g] = __popcll(bal & ((1ULL << lane) - 1));
+		if (lane == 0) s_gw[g][wv] = __popcll(bal);
+	}
+	__syncthreads();
+	if (tid == 0) {
+		uint32_t run = 0;
+		for (int g = 0; g < HAO_SK_GMAX; ++g) for (int x = 0; x < 4; ++x) { uint32_t c = s_gw[g][x]; s_gw[g][x] = run; run += c; }
+		s_cnt[0] = run;
+		unsigned long long base = run ? atomicAdd(a.pool_cursor, (unsigned long long)run) : 0ULL;
+		if (base + run > a.pool_cap) { *a.err = 1; s_cnt[0] = 0; run = 0; }
+		s_base = base; a.chunk_base[ch] = base; a.chunk_cnt[ch] = run;
+	}
+	__syncthreads();
+	if (s_cnt[0] == 0) return;
+#pragma unroll
+	for (int g = 0; g < HAO_SK_GMAX; ++g) {
+		if (!mk[g]) continue;
+		int q = tid + g * HAO_SK_THREADS, e = q + k, s = e - k + 1, wi = s >> 6, sh = s & 63;
+		uint64_t W1 = pl1[wi] >> sh; if (sh) W1 |= pl1[wi + 1] << (64 - sh); W1 &= mask;
+		uint32_t rev = (__brevll(W1) >> (64 - k)) < (~W1 & mask) ? 0 : 1;
+		uint32_t span = end1[e] - end1[e - k];
+		uint64_t o = s_base + s_gw[g][wv] + myrank[g];
+		a.pool_x[o] = key[g].x;
+		a.pool_info[o] = hao_info_pack(HAS_FT ? key[g].c : 0, end1[e] - 1, rev, span);     // rid field carries the count until the end (sketch.cpp:515)
+		a.pool_ord[o] = (uint32_t)(kk0 + q);
+	}
+}
+
+static inline size_t hao_sk_smem_bytes(int w, int k)
+{
+	size_t NE = HAO_SK_CHUNK + 2 * (w - 1) + k + 1, NW = (NE + 63) / 64 + 1;
+	size_t NKP = ((HAO_SK_CHUNK + 2 * (w - 1) + HAO_SK_THREADS - 1) / HAO_SK_THREADS) * HAO_SK_THREADS;
+	return 2 * NW * 8 + 3 * NKP * 8 + NE * 4 + 3 * NKP * 4 + NE + 64;
+}
+
+// ---------------------------------------------------------------------------------------
+// K_C: gather chunk outputs (pool, arbitrary order) into per-read lists in position order.
+// One wave per chunk. dst offset = chunk_dst[ch] (exclusive scan of chunk_cnt).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sketch_gather_kernel(const uint64_t *pool_x, const uint64_t *pool_info, const uint32_t *pool_ord,
+		const uint64_t *chunk_base, const uint32_t *chunk_cnt, const uint64_t *chunk_dst, uint64_t n_chunks,
+		uint64_t *out_x, uint64_t *out_info, uint32_t *out_ord)
+{
+	uint64_t ch = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (ch >= n_chunks) return;
+	uint64_t b = chunk_base[ch], d = chunk_dst[ch]; uint32_t n = chunk_cnt[ch];
+	for (uint32_t i = hao_lane(); i < n; i += 64) { out_x[d + i] = pool_x[b + i]; out_info[d + i] = pool_info[b + i]; out_ord[d + i] = pool_ord[b + i]; }
+}
+
+// per-read list bounds from the chunk scan: mz_off[r] = chunk_dst[chunk_off[r]]
+__global__ void sketch_read_off_kernel(const uint64_t *chunk_off, const uint64_t *chunk_dst, uint64_t n_sel, uint64_t n_chunks, uint64_t total, uint64_t *mz_off)
+{
+	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r > n_sel) return;
+	uint64_t c = chunk_off[r];
+	mz_off[r] = c < n_chunks ? chunk_dst[c] : total;
+}
+
+// ---------------------------------------------------------------------------------------
+// High-count thinning (mz1_select_mz_h, sketch.cpp:247-330; mz1_hf_select :194-216).
+// Sequential per read on a few hundred entries; one lane per read, in place on the gathered
+// list.  info.rid carries the filter-table count (0 = not a high-count k-mer).  new_n[r] <- kept.
+// ---------------------------------------------------------------------------------------
+struct hao_sel_view { uint64_t *x, *info; uint32_t *ord; int n; };
+#define SV_CNT(v, i) hao_info_rid((v).info[i])
+#define SV_HIGH(v, i) ((i) >= 0 && SV_CNT(v, i) > 0)
+#define SV_MARK 0x80000000u
+
+__device__ __forceinline__ int hao_sel_cmp(const hao_sel_view &v, int ai, int bi)     // mz1_mzcmp_l (sketch.cpp:217-225)
+{
+	if (ai >= 0 && bi >= 0) {
+		uint32_t ca = SV_CNT(v, ai), cb = SV_CNT(v, bi);
+		if (ca > 0 && cb > 0) { if (ca != cb) return ca < cb ? -1 : 1; return (v.x[ai] > v.x[bi]) - (v.x[ai] < v.x[bi]); }
+		return (int)(ca == 0) - (int)(cb == 0);
+	}
+	return (int)(ai < 0) - (int)(bi < 0);
+}
+__device__ __forceinline__ uint32_t hao_sel_ord(const hao_sel_view &v, int i) { return v.ord[i] & ~SV_MARK; }
+__device__ __forceinline__ void hao_sel_zero(hao_sel_view &v, int i) { v.info[i] &= ~0xfffffffULL; }
+
+__device__ void hao_sel_rescan(hao_sel_view &v, int si, int i, int *mi)
+{
+	int m; *mi = -1;
+	for (m = si; m <= i; ++m) if (hao_sel_cmp(v, *mi, m) >= 0) *mi = m;
+	if (SV_HIGH(v, *mi)) for (m = si; m <= i; ++m) if (SV_HIGH(v, m) && hao_sel_cmp(v, *mi, m) == 0) v.ord[m] |= SV_MARK;
+}
+
+struct hao_hent { uint64_t x; uint32_t c; int idx; };
+__device__ __forceinline__ bool hao_hent_lt(const hao_hent &a, const hao_hent &b) { return a.c < b.c || (a.c == b.c && a.x < b.x); }
+__device__ void hao_heap_down(int i, int n, hao_hent *l)                              // ksort.h:43-52 semantics (max-heap on (count,hash))
+{
+	int k = i; hao_hent tmp = l[i];
+	while ((k = (k << 1) + 1) < n) {
+		if (k != n - 1 && hao_hent_lt(l[k], l[k + 1])) ++k;
+		if (hao_hent_lt(l[k], tmp)) break;
+		l[i] = l[k]; i = k;
+	}
+	l[i] = tmp;
+}
+
+__device__ void hao_sel_heap(hao_sel_view &v, int si, int ei, int n, int len, int sample_dist)   // mz1_hf_select
+{
+	if (ei - si <= 1) return;
+	int ps = si < 0 ? 0 : (int)hao_info_pos(v.info[si]), pe = ei == n ? len : (int)hao_info_pos(v.info[ei]);
+	int q = (int)((double)(pe - ps) / sample_dist + .499), j, kk;
+	if (q > 16) q = 16;
+	hao_hent b[16];
+	for (j = si + 1, kk = 0; j < ei && kk < q; ++j, ++kk) { b[kk].x = v.x[j]; b[kk].c = SV_CNT(v, j); b[kk].idx = j; }
+	for (int i = (kk >> 1) - 1; i >= 0; --i) hao_heap_down(i, kk, b);
+	for (; j < ei; ++j) { hao_hent e; e.x = v.x[j]; e.c = SV_CNT(v, j); e.idx = j; if (hao_hent_lt(e, b[0])) { b[0] = e; hao_heap_down(0, kk, b); } }
+	for (j = 0; j < kk; ++j) if ((int)b[j].c < pe - ps) hao_sel_zero(v, b[j].idx);
+}
+
+__device__ int hao_select_high(hao_sel_view v, int len, int sample_dist, int w /*rewin*/, int k, int tot_l)
+{
+	int n = v.n, i, m, mi = -1, si, last0, any = 0, ws = w + k - 1;
+	if (n == 0) return 0;
+	for (i = 0, last0 = -1; i <= n; ++i) {
+		if (i == n || SV_CNT(v, i) == 0) {
+			if (i - last0 > 1) {
+				int ps = last0 < 0 ? 0 : (int)hao_info_pos(v.info[last0]), pe = i == n ? len : (int)hao_info_pos(v.info[i]);
+				if ((int)((double)(pe - ps) / sample_dist + .499) > 0) { any = 1; break; }
+			}
+			last0 = i;
+		}
+	}
+	if (!any) return n;
+	for (i = 0; i < n; ++i) {
+		int oi = (int)hao_sel_ord(v, i);
+		if (oi >= ws || (i + 1 < n && oi < ws && (int)hao_sel_ord(v, i + 1) > ws) || (i + 1 == n && tot_l >= ws && oi < ws)) {
+			for (m = 0; m <= i; ++m) if (SV_HIGH(v, m) && hao_sel_cmp(v, mi, m) >= 0) mi = m;
+			if (mi >= 0 && SV_HIGH(v, mi)) for (m = 0; m <= i; ++m) if (SV_HIGH(v, m) && hao_sel_cmp(v, mi, m) == 0) v.ord[m] |= SV_MARK;
+			break;
+		}
+	}
+	if (i < n) {
+		for (si = 0, ++i; i < n; ++i) {
+			for (; si < i; ++si) if ((int)hao_sel_ord(v, si) + w > (int)hao_sel_ord(v, i)) break;
+			if (hao_sel_cmp(v, i, mi) <= 0) { if (SV_HIGH(v, mi)) v.ord[mi] |= SV_MARK; mi = i; }
+			else if (si > mi) { if (SV_HIGH(v, mi)) v.ord[mi] |= SV_MARK; hao_sel_rescan(v, si, i, &mi); }
+		}
+		if (SV_HIGH(v, mi)) v.ord[mi] |= SV_MARK;
+		for (i = n - 1; si < n && (int)hao_sel_ord(v, si) + w <= tot_l + 1; ++si)
+			if (si > mi) { if (SV_HIGH(v, mi)) v.ord[mi] |= SV_MARK; hao_sel_rescan(v, si, i, &mi); }
+		for (i = 0, last0 = -1; i <= n; ++i) {
+			if (i == n || SV_CNT(v, i) == 0) {
+				if (i - last0 > 1) {
+					int ps = last0 < 0 ? 0 : (int)hao_info_pos(v.info[last0]), pe = i == n ? len : (int)hao_info_pos(v.info[i]);
+					if ((int)((double)(pe - ps) / sample_dist + .499) > 0) {
+						int nm = 0;
+						for (m = last0 + 1; m < i; ++m) if (v.ord[m] & SV_MARK) { hao_sel_zero(v, m); ++nm; }
+						if (nm == 0) hao_sel_heap(v, last0, i, n, len, sample_dist);
+					}
+				}
+				last0 = i;
+			}
+		}
+	}
+	for (i = 0, m = 0; i < n; ++i) if (SV_CNT(v, i) == 0) { v.x[m] = v.x[i]; v.info[m] = v.info[i]; v.ord[m] = v.ord[i]; ++m; }
+	return m;
+}
+
+// one lane per read; tot_l = number of valid k-mer iterations = runs (N-free reads) or the value the scalar kernel recorded
+__global__ void sketch_select_kernel(uint64_t *x, uint64_t *info, uint32_t *ord, const uint64_t *mz_off, const uint32_t *len, const uint32_t *tot_l,
+		uint64_t rid_lo, uint64_t n_sel, int sample_dist, int rewin, int k, uint32_t *new_n)
+{
+	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_sel) return;
+	hao_sel_view v; v.x = x + mz_off[r]; v.info = info + mz_off[r]; v.ord = ord + mz_off[r]; v.n = (int)(mz_off[r + 1] - mz_off[r]);
+	bool any = false;
+	for (int i = 0; i < v.n; ++i) if (SV_CNT(v, i) > 0) { any = true; break; }
+	new_n[r] = any ? (uint32_t)hao_select_high(v, (int)len[rid_lo + r], sample_dist, rewin, k, (int)tot_l[r]) : (uint32_t)v.n;
+}
+
+// final: compact the per-read lists (after thinning) and stamp the read id into info.rid (sketch.cpp:577-578)
+__global__ __launch_bounds__(256) void sketch_finish_kernel(const uint64_t *x, const uint64_t *info, const uint64_t *src_off, const uint64_t *dst_off,
+		uint64_t rid_lo, uint64_t n_sel, int stamp_rid, uint64_t *ox, uint64_t *oinfo)
+{
+	uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= n_sel) return;
+	uint64_t s = src_off[r], d = dst_off[r], n = dst_off[r + 1] - d;
+	for (uint64_t i = hao_lane(); i < n; i += 64) {
+		ox[d + i] = x[s + i];
+		oinfo[d + i] = (info[s + i] & ~0xfffffffULL) | (stamp_rid ? ((rid_lo + r) & 0xfffffffULL) : 0ULL);
+	}
+}
+
+// ---------------------------------------------------------------------------------------
+// Exact scalar state machine (sketch.cpp:454-573 restated), one lane per flagged read:
+// N bases, even k (strand-symmetric k-mer skip), anything the chunk kernel does not cover.
+// Emits into the same pool / chunk record as the chunk kernel (one record per read).
+// ---------------------------------------------------------------------------------------
+struct hao_cand { uint64_t x; uint32_t c, pos; uint8_t rev, span; };
+__device__ __forceinline__ int hao_cand_cmp(const hao_cand &a, const hao_cand &b)
+{ if (a.c != b.c) return a.c < b.c ? -1 : 1; return (a.x > b.x) - (a.x < b.x); }
+
+struct hao_scalar_args {
+	const uint8_t *packed; const uint64_t *pk_off; const uint32_t *len; const uint64_t *nsite_off; const uint32_t *nsite;
+	const uint64_t *chunk_off; const uint8_t *scalar_flag; const uint32_t *scalar_list; uint32_t n_scalar;
+	uint64_t rid_lo; int k, w, hpc, use_ft; hao_ft_dev ft;
+	hao_cand *ring_ws; uint32_t *ringord_ws;      // n_scalar * 256 entries of workspace
+	uint64_t *pool_x, *pool_info; uint32_t *pool_ord; unsigned long long *pool_cursor; uint64_t pool_cap;
+	uint64_t *chunk_base; uint32_t *chunk_cnt; uint32_t *tot_l; int *err;
+	int pass;   // 0 = count only, 1 = emit
+	uint32_t *cnt_ws;
+};
+
+__global__ void sketch_scalar_kernel(hao_scalar_args a)
+{
+	uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;
+	if (si >= a.n_scalar) return;
+	const uint32_t r = a.scalar_list[si]; const uint64_t rid = a.rid_lo + r;
+	const uint8_t *rd = a.packed + a.pk_off[rid]; const int len = (int)a.len[rid], w = a.w, k = a.k;
+	const uint32_t *ns = a.nsite ? a.nsite + a.nsite_off[rid] : nullptr; const uint32_t nn = a.nsite ? (uint32_t)(a.nsite_off[rid + 1] - a.nsite_off[rid]) : 0; uint32_t np = 0;
+	hao_cand *ring = a.ring_ws + (size_t)si * 256; uint32_t *rord = a.ringord_ws + (size_t)si * 256;
+	const hao_cand dummy = { UINT64_MAX, HAO_CNT_DUMMY, 0, 0, 0 };
+	uint64_t mask = (1ULL << k) - 1, pl[4] = {0, 0, 0, 0}; const int sh = k - 1;
+	hao_cand mn = dummy; uint32_t mn_ord = (uint32_t)-1;
+	int qrun[64], qf = 0, qc = 0, span = 0, l = 0, tl = 0, bp = 0, mbp = 0, j;
+	uint64_t out = 0, base = 0; bool emit = a.pass == 1;
+	if (emit) { base = a.chunk_base[a.chunk_off[r]]; if (a.chunk_cnt[a.chunk_off[r]] == 0) return; }
+	for (j = 0; j < w; ++j) { ring[j].x = UINT64_MAX; ring[j].c = HAO_CNT_DUMMY; ring[j].pos = (1u << 27) - 1; ring[j].rev = 1; ring[j].span = 255; }
+#define SC_PUSH(e, o) do { if (emit) { a.pool_x[base + out] = (e).x; a.pool_info[base + out] = hao_info_pack((e).c, (e).pos, (e).rev, (e).span); a.pool_ord[base + out] = (o); } ++out; } while (0)
+	for (int i = 0; i < len; ++i) {
+		while (np < nn && ns[np] < (uint32_t)i) ++np;
+		int b = (np < nn && ns[np] == (uint32_t)i) ? 4 : (int)hao_base_at(rd, i);
+		hao_cand info = dummy; bool skip = false;
+		if (b < 4) {
+			if (a.hpc) {
+				int run = 1; uint32_t npp = np;
+				while (i + run < len) {
+					while (npp < nn && ns[npp] < (uint32_t)(i + run)) ++npp;
+					if (npp < nn && ns[npp] == (uint32_t)(i + run)) break;
+					if ((int)hao_base_at(rd, i + run) != b) break;
+					++run;
+				}
+				i += run - 1;
+				qrun[(qc++ + qf) & 63] = run; span += run;
+				if (qc > k) { span -= qrun[qf]; qf = (qf + 1) & 63; --qc; }
+			} else span = l + 1 < k ? l + 1 : k;
+			pl[0] = (pl[0] << 1 | (uint64_t)(b & 1)) & mask; pl[1] = (pl[1] << 1 | (uint64_t)(b >> 1)) & mask;
+			pl[2] = pl[2] >> 1 | (uint64_t)(1 - (b & 1)) << sh; pl[3] = pl[3] >> 1 | (uint64_t)(1 - (b >> 1)) << sh;
+			if (pl[1] == pl[3]) skip = true;
+			else {
+				int z = pl[1] < pl[3] ? 0 : 1;
+				++l; ++tl;
+				if (l >= k && span < 256) {
+					uint64_t y = hao_hash64(pl[z << 1]) + hao_hash64(pl[z << 1 | 1]);
+					int32_t cnt = a.use_ft ? hao_ft_lookup(a.ft, y) : 0;
+					if (cnt < (1 << 28)) { info.x = y; info.c = (uint32_t)cnt; info.pos = (uint32_t)i; info.rev = (uint8_t)z; info.span = (uint8_t)span; }
+				}
+			}
+		} else { l = 0; qc = qf = 0; span = 0; }
+		if (skip) continue;
+		ring[bp] = info; rord[bp] = (uint32_t)l;
+		if (l == w + k - 1 && mn.x != UINT64_MAX) {
+			for (j = bp + 1; j < w; ++j) if (hao_cand_cmp(mn, ring[j]) == 0 && ring[j].pos != mn.pos) SC_PUSH(ring[j], rord[j]);
+			for (j = 0; j < bp; ++j) if (hao_cand_cmp(mn, ring[j]) == 0 && ring[j].pos != mn.pos) SC_PUSH(ring[j], rord[j]);
+		}
+		if (hao_cand_cmp(mn, info) >= 0) {
+			if (l >= w + k && mn.x != UINT64_MAX) SC_PUSH(mn, mn_ord);
+			mn = info; mbp = bp; mn_ord = rord[bp];
+		} else if (bp == mbp) {
+			if (l >= w + k - 1 && mn.x != UINT64_MAX) SC_PUSH(mn, mn_ord);
+			mn = dummy;
+			for (j = bp + 1; j < w; ++j) if (hao_cand_cmp(mn, ring[j]) >= 0) { mn = ring[j]; mbp = j; mn_ord = rord[j]; }
+			for (j = 0; j <= bp; ++j) if (hao_cand_cmp(mn, ring[j]) >= 0) { mn = ring[j]; mbp = j; mn_ord = rord[j]; }
+			if (l >= w + k - 1 && mn.x != UINT64_MAX) {
+				for (j = bp + 1; j < w; ++j) if (hao_cand_cmp(mn, ring[j]) == 0 && mn.pos != ring[j].pos) SC_PUSH(ring[j], rord[j]);
+				for (j = 0; j <= bp; ++j) if (hao_cand_cmp(mn, ring[j]) == 0 && mn.pos != ring[j].pos) SC_PUSH(ring[j], rord[j]);
+			}
+		}
+		if (++bp == w) bp = 0;
+	}
+	if (mn.x != UINT64_MAX) SC_PUSH(mn, mn_ord);
+#undef SC_PUSH
+	if (!emit) {
+		a.cnt_ws[si] = (uint32_t)out; a.tot_l[r] = (uint32_t)tl;
+		unsigned long long bs = out ? atomicAdd(a.pool_cursor, (unsigned long long)out) : 0ULL;
+		if (bs + out > a.pool_cap) { *a.err = 1; out = 0; }
+		a.chunk_base[a.chunk_off[r]] = bs; a.chunk_cnt[a.chunk_off[r]] = (uint32_t)out;
+	}
+}

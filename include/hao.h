@@ -1,0 +1,121 @@
+/* hao.h - C ABI of the MI355X-native all-vs-all overlap engine ("hao" = hifiasm-amd
+ * overlap).  Plain pointers and sizes only; every entry point names the reference
+ * interface (chhylp123/hifiasm 0.25.0-r726, file:line) it stands in for.
+ *
+ * The reference has no plugin/FFI layer: its seam is three externally linked C++
+ * functions reached from per-read worker threads,
+ *     ha_ft_gen   (htab.h:79,  htab.cpp:1136)   k-mer count -> high-count filter table
+ *     ha_pt_gen   (htab.h:86,  htab.cpp:1232)   minimizer count + position index
+ *     h_ec_lchain (anchor.cpp:2302, declared ad hoc at ecovlp.cpp:110)
+ *                                               per-read seeds -> chains -> overlap list
+ * plus the accessors ha_ft_cnt (htab.h:80), ha_pt_get / ha_pt_cnt (htab.h:88-90) and the
+ * finer per-read seam mz1_ha_sketch (htab.h:122).  A GPU wants batches, so this ABI is
+ * "precompute, then serve": hao_overlap_batch() runs the whole path for a range of
+ * query reads on the device and hao_fetch_*() serve the per-read results that a
+ * drop-in h_ec_lchain shim copies into the caller's overlap_region_alloc /
+ * Candidates_list (INTEGRATION.md shows that shim).
+ *
+ * All functions return 0 on success, a negative HAO_E* code otherwise (the reference
+ * itself exits on error; a shim maps non-zero to exit(1)).  There is NO CPU fallback:
+ * without a HIP device hao_create fails.
+ */
+#ifndef HAO_H
+#define HAO_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HAO_OK          0
+#define HAO_ENODEV     -1   /* no HIP device / HIP runtime error */
+#define HAO_EINVAL     -2   /* bad argument or call order */
+#define HAO_ENOMEM     -3
+#define HAO_EUNSUPP    -4   /* input outside what the device path implements (fails loudly, never falls back) */
+
+typedef struct hao_ctx hao_ctx;
+
+/* Mirrors the fields of hifiasm_opt_t (CommandLines.h:35-173) the hot path reads. */
+typedef struct {
+	int32_t k;             /* k_mer_length   (CommandLines.cpp:259) default 51 */
+	int32_t w;             /* mz_win         (CommandLines.cpp:263) default 51 */
+	int32_t hpc;           /* !(flag & HA_F_NO_HPC), default 1 */
+	int32_t sample_dist;   /* mz_sample_dist (CommandLines.cpp:268) default 500 */
+	int32_t rewin;         /* mz_rewin       (CommandLines.cpp:266) default 1000 */
+	int32_t min_hist_cnt;  /* min_hist_kmer_cnt, default 5 */
+	int32_t max_kmer_cnt;  /* (CommandLines.cpp:270) default 2000 */
+	int32_t max_n_chain;   /* (CommandLines.cpp:276) default 100; raised like ha_opt_update_cov */
+	double  high_factor;   /* (CommandLines.cpp:271) default 5.0 */
+	int32_t is_ont;        /* --ont: bw_thres 0.05 instead of 0.02 (ecovlp.cpp:3274) */
+	int32_t reserved;
+} hao_opt_t;
+
+/* ha_mz1_t (htab.h:13-18): info = rid:28 | pos:27 | rev:1 | span:8 (LSB first).
+ * ha_idxpos_t (htab.h:20-22) has the same bit layout without x. */
+typedef struct { uint64_t x, info; } hao_mz_t;
+/* k_mer_hit (Hash_Table.h:116-120): w0 = readID:31 | strand:1 */
+typedef struct { uint32_t w0, offset, self_offset, cnt; } hao_hit_t;
+/* the scalar fields of overlap_region (Hash_Table.h:78-106) that h_ec_lchain defines */
+typedef struct {
+	uint32_t x_id, x_pos_s, x_pos_e, x_pos_strand;
+	uint32_t y_id, y_pos_s, y_pos_e, y_pos_strand;
+	int32_t  shared_seed;
+	uint32_t align_length;            /* zero on return (anchor.cpp:2098) */
+	uint32_t non_homopolymer_errors;  /* index of the chain's first hit in the read's hit list */
+	uint32_t fc_len;                  /* Fake_Cigar.length */
+} hao_ovlp_t;
+
+void hao_opt_default(hao_opt_t *o);                       /* init_opt, CommandLines.cpp:243-380 */
+int  hao_create(int device, const hao_opt_t *opt, hao_ctx **out);
+void hao_destroy(hao_ctx *c);
+const char *hao_last_error(const hao_ctx *c);
+
+/* Read store hand-over.  Layout = the reference's All_reads (Process_Read.h:115-146):
+ * packed = concatenation of read_sperate[i] (len/4+1 bytes per read, 4 bases/byte, first base
+ * in bits 7..6; ha_compress_base, Process_Read.cpp:792-850), pk_off[n+1] byte offsets,
+ * len[n] = read_length[], nsite_off[n+1]/nsite[] = flattened N_site lists (may be NULL).
+ * Host pointers; copied to HBM once. */
+int hao_set_reads(hao_ctx *c, const uint8_t *packed, const uint64_t *pk_off, const uint32_t *len, uint64_t n_reads,
+				  const uint64_t *nsite_off, const uint32_t *nsite);
+
+/* ha_ft_gen (htab.cpp:1136-1169) at -f0 + ha_opt_update_cov (CommandLines.cpp:411-418). */
+int hao_ft_gen(hao_ctx *c, int32_t *hom_cov);
+/* ha_pt_gen (htab.cpp:1232-1287) + the asm_opt.hom_cov/het_cov update of Assembly.cpp:1007-1008.
+ * The index and the per-read minimizers stay resident in HBM. */
+int hao_pt_gen(hao_ctx *c, int32_t *hom_cov, int32_t *het_cov);
+
+/* host-side views (what non-default CPU consumers of ha_flt_tab / ha_idx need) */
+int32_t hao_ft_cnt(hao_ctx *c, uint64_t y);                                   /* ha_ft_cnt htab.cpp:1064 */
+int hao_pt_get(hao_ctx *c, uint64_t hash, const uint64_t **pos, int32_t *n);  /* ha_pt_get htab.cpp:518  */
+int hao_ft_table(hao_ctx *c, uint64_t *n, const uint64_t **keys, const int32_t **vals);
+int hao_pt_table(hao_ctx *c, uint64_t *n_keys, const uint64_t **keys, const uint64_t **off, const uint64_t **pos, uint64_t *n_pos);
+int hao_hist(hao_ctx *c, int which /*0 = all k-mers (ft), 1 = minimizers (pt)*/, int64_t cnt[4096]);
+/* out[0..7] = ft peak_hom, ft peak_het, ft cutoff, max_n_chain, hom_cov, het_cov, high_occ, low_occ */
+int hao_stats(hao_ctx *c, int64_t out[8]);
+
+/* mz1_ha_sketch (sketch.cpp:454-579) for reads [rid_lo, rid_hi): results stay on the device;
+ * use_ft = 0 passes hf = NULL; sample_dist <= w disables the high-count thinning (sketch.cpp:575).
+ * hao_fetch_sketch copies one read's list (rid field = read id, as at index time htab.cpp:691). */
+int hao_sketch_batch(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi, int use_ft, int sample_dist);
+int hao_fetch_sketch(hao_ctx *c, uint64_t rid, const hao_mz_t **mz, uint64_t *n);
+
+/* h_ec_lchain (anchor.cpp:2302-2315) with the ecovlp.cpp:3274 arguments, for query reads
+ * [rid_lo, rid_hi).  Results stay in HBM (hao_batch_dev) and are served per read. */
+int hao_overlap_batch(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi);
+/* seed hits before chaining (cl->list after minimizers_qgen0, anchor.cpp:987-1081) */
+int hao_fetch_seed_hits(hao_ctx *c, uint64_t rid, const hao_hit_t **hits, uint64_t *n);
+/* ol->list[0..n_ol), their fake cigars (fc_off[n_ol+1] into fc) and cl->list[0..n_cl) */
+int hao_fetch_overlaps(hao_ctx *c, uint64_t rid, const hao_ovlp_t **ol, uint64_t *n_ol, const uint64_t **fc, const uint64_t **fc_off,
+					   const hao_hit_t **cl, uint64_t *n_cl);
+/* totals of the last batch: out[0] = overlaps (sum ol->length), out[1] = chained hits, out[2] = seed hits,
+ * out[3] = chain groups, out[4] = minimizers of the query reads */
+int hao_batch_totals(hao_ctx *c, uint64_t out[8]);
+
+/* per-stage device time of the last call in milliseconds (HIP events on the engine's stream);
+ * names[i] points to static strings. Returns the number of stages. */
+int hao_stage_times(hao_ctx *c, const char **names, float *ms, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
