@@ -15,6 +15,88 @@ static void hao_release_all(hao_ctx *c)
 	c->d_ix_keys.release(); c->d_ix_start.release(); c->d_ix_cnt.release(); c->d_ix_bucket.release();
 }
 
+#define HAO_HAVE_FT
+#define HAO_HAVE_PT
+extern "C" {
+
+int hao_ft_gen(hao_ctx *c, int32_t *hom_cov)
+{
+	if (!c) return HAO_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	c->timer.begin(c->stream);
+	int rc = hao_ft_run(c);
+	if (rc != HAO_OK) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	c->timer.collect(c->stage_ms);
+	if (hom_cov) *hom_cov = c->ft_peak_hom;
+	return HAO_OK;
+}
+
+int32_t hao_ft_cnt(hao_ctx *c, uint64_t y)
+{
+	if (!c || !c->has_ft) return 0;
+	int64_t i = hao_bsearch(c->h_ft_keys.data(), c->h_ft_keys.size(), y);
+	return i < 0 ? 0 : c->h_ft_vals[i];
+}
+
+int hao_ft_table(hao_ctx *c, uint64_t *n, const uint64_t **keys, const int32_t **vals)
+{
+	if (!c || !c->has_ft) return HAO_EINVAL;
+	*n = c->h_ft_keys.size(); *keys = c->h_ft_keys.data(); *vals = c->h_ft_vals.data();
+	return HAO_OK;
+}
+
+int hao_hist(hao_ctx *c, int which, int64_t cnt[4096])
+{
+	if (!c) return HAO_EINVAL;
+	memcpy(cnt, which == 0 ? c->ft_hist : c->pt_hist, sizeof(int64_t) * HAO_N_COUNTS);
+	return HAO_OK;
+}
+
+int hao_stats(hao_ctx *c, int64_t out[8])
+{
+	if (!c) return HAO_EINVAL;
+	uint32_t h, l; hao_occ_thresholds(c->hom_cov, &h, &l);
+	out[0] = c->ft_peak_hom; out[1] = c->ft_peak_het; out[2] = c->ft_cutoff; out[3] = c->max_n_chain;
+	out[4] = c->hom_cov; out[5] = c->het_cov; out[6] = h; out[7] = l;
+	return HAO_OK;
+}
+
+int hao_pt_gen(hao_ctx *c, int32_t *hom_cov, int32_t *het_cov)
+{
+	if (!c) return HAO_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	c->timer.begin(c->stream);
+	int rc = hao_pt_run(c);
+	if (rc != HAO_OK) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	c->timer.collect(c->stage_ms);
+	if (hom_cov) *hom_cov = c->hom_cov;
+	if (het_cov) *het_cov = c->het_cov;
+	return HAO_OK;
+}
+
+int hao_pt_get(hao_ctx *c, uint64_t hash, const uint64_t **pos, int32_t *n)
+{
+	if (!c || !c->has_pt) return HAO_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	if (int rc = hao_pt_download(c)) return rc;
+	int64_t i = hao_bsearch(c->h_ix_keys.data(), c->h_ix_keys.size(), hash);
+	if (i < 0) { *pos = nullptr; *n = 0; return HAO_OK; }
+	*pos = c->h_ix_pos.data() + c->h_ix_off[i]; *n = (int32_t)(c->h_ix_off[i + 1] - c->h_ix_off[i]);
+	return HAO_OK;
+}
+
+int hao_pt_table(hao_ctx *c, uint64_t *n_keys, const uint64_t **keys, const uint64_t **off, const uint64_t **pos, uint64_t *n_pos)
+{
+	if (!c || !c->has_pt) return HAO_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	if (int rc = hao_pt_download(c)) return rc;
+	*n_keys = c->h_ix_keys.size(); *keys = c->h_ix_keys.data(); *off = c->h_ix_off.data(); *pos = c->h_ix_pos.data(); *n_pos = c->h_ix_pos.size();
+	return HAO_OK;
+}
+}
+
 extern "C" {
 #ifndef HAO_HAVE_FT
 int hao_ft_gen(hao_ctx *c, int32_t *hom_cov) { hao_set_err(c, "not implemented"); return HAO_EINVAL; }

@@ -1,0 +1,270 @@
+// Host orchestration: ha_ft_gen / ha_pt_gen equivalents (part of libhao.so).
+#pragma once
+#include "hao_pipeline.hpp"
+#include "hao_index.cuh"
+#include "hao_host.hpp"
+
+// run-count index for reads [lo, hi); scalar flag = read has N (or force_scalar_all)
+static int hao_prepare_runs(hao_ctx *c, uint64_t lo, uint64_t hi, bool force_scalar_all, std::vector<uint32_t> &slist)
+{
+	const uint64_t n_sel = hi - lo;
+	std::vector<uint64_t> tile_off(n_sel + 1); std::vector<uint8_t> flag(n_sel);
+	slist.clear();
+	for (uint64_t r = 0; r < n_sel; ++r) {
+		tile_off[r] = r == 0 ? 0 : tile_off[r - 1] + (c->h_len[lo + r - 1] + HAO_SK_TILE - 1) / HAO_SK_TILE + 1;
+		bool hasn = c->has_n && c->h_nsite_off[lo + r + 1] > c->h_nsite_off[lo + r];
+		flag[r] = (hasn || force_scalar_all) ? 1 : 0;
+		if (flag[r]) slist.push_back((uint32_t)r);
+	}
+	tile_off[n_sel] = tile_off[n_sel - 1] + (c->h_len[hi - 1] + HAO_SK_TILE - 1) / HAO_SK_TILE + 1;
+	HIP_TRY(c->d_tile_off.reserve(n_sel + 1)); HIP_TRY(c->d_tile_ord.reserve(tile_off[n_sel] + 1)); HIP_TRY(c->d_n_runs.reserve(n_sel + 1));
+	HIP_TRY(c->d_scalar_flag.reserve(n_sel + 1)); HIP_TRY(c->d_scalar_list.reserve(slist.size() + 1));
+	HIP_TRY(hipMemcpyAsync(c->d_tile_off.p, tile_off.data(), (n_sel + 1) * 8, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipMemcpyAsync(c->d_scalar_flag.p, flag.data(), n_sel, hipMemcpyHostToDevice, c->stream));
+	if (!slist.empty()) HIP_TRY(hipMemcpyAsync(c->d_scalar_list.p, slist.data(), slist.size() * 4, hipMemcpyHostToDevice, c->stream));
+	hipLaunchKernelGGL(hpc_index_kernel, dim3((unsigned)((n_sel + 3) / 4)), dim3(256), 0, c->stream, c->d_packed.p, c->d_pk_off.p, c->d_len.p,
+					   c->d_tile_off.p, c->d_tile_ord.p, c->d_n_runs.p, lo, n_sel, c->opt.hpc);
+	HAO_CHECK_LAUNCH();
+	HIP_TRY(hipStreamSynchronize(c->stream));   // host vectors go out of scope
+	return HAO_OK;
+}
+
+// sort keys, run-length encode, histogram.  in: d_keys[n] (destroyed). out: unique keys / counts in c->d_u_keys / d_u_cnt, n_unique.
+struct hao_rle_out { uint64_t n_unique; };
+static int hao_sort_rle_hist(hao_ctx *c, uint64_t *d_keys, uint64_t *d_keys_alt, uint64_t n, DevBuf<uint64_t> &ukeys, DevBuf<uint32_t> &ucnt, uint64_t *n_unique, int64_t hist[HAO_N_COUNTS], uint64_t **sorted_out)
+{
+	*n_unique = 0; memset(hist, 0, sizeof(int64_t) * HAO_N_COUNTS); *sorted_out = d_keys;
+	if (n == 0) return HAO_OK;
+	size_t tb = 0;
+	rocprim::double_buffer<uint64_t> db(d_keys, d_keys_alt);
+	HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, db, n, 0, 64, c->stream));
+	HIP_TRY(hao_tmp(c, tb));
+	HIP_TRY(rocprim::radix_sort_keys(c->d_tmp.p, tb, db, n, 0, 64, c->stream));
+	uint64_t *sorted = db.current(); *sorted_out = sorted;
+	HIP_TRY(ukeys.reserve(n + 1)); HIP_TRY(ucnt.reserve(n + 1)); HIP_TRY(c->d_cursor.reserve(2));
+	tb = 0;
+	HIP_TRY(rocprim::run_length_encode(nullptr, tb, sorted, n, ukeys.p, ucnt.p, (uint64_t*)c->d_cursor.p, c->stream));
+	HIP_TRY(hao_tmp(c, tb));
+	HIP_TRY(rocprim::run_length_encode(c->d_tmp.p, tb, sorted, n, ukeys.p, ucnt.p, (uint64_t*)c->d_cursor.p, c->stream));
+	HIP_TRY(hipMemcpyAsync(n_unique, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	DevBuf<unsigned long long> dh; HIP_TRY(dh.reserve(HAO_N_COUNTS));
+	HIP_TRY(hipMemsetAsync(dh.p, 0, HAO_N_COUNTS * 8, c->stream));
+	unsigned nb = (unsigned)std::min<uint64_t>((*n_unique + 255) / 256, 2048);
+	if (nb) hipLaunchKernelGGL(hao_count_hist_kernel, dim3(nb), dim3(256), 0, c->stream, ucnt.p, *n_unique, dh.p);
+	HAO_CHECK_LAUNCH();
+	HIP_TRY(hipMemcpyAsync(hist, dh.p, HAO_N_COUNTS * 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	dh.release();
+	return HAO_OK;
+}
+
+// keep runs with lo <= min(cnt,4095) <= hi -> (keys, start, cnt) ; start may be null
+static int hao_keep_runs(hao_ctx *c, const uint64_t *ukeys, const uint32_t *ucnt, uint64_t n_unique, int lo, int hi,
+						 DevBuf<uint64_t> &keys, DevBuf<uint64_t> *start, DevBuf<uint32_t> &cnt, uint64_t *n_kept, uint64_t *n_pos)
+{
+	*n_kept = 0; if (n_pos) *n_pos = 0;
+	if (n_unique == 0) return HAO_OK;
+	DevBuf<uint64_t> flag, kpos, ustart;
+	HIP_TRY(flag.reserve(n_unique + 1)); HIP_TRY(kpos.reserve(n_unique + 1)); HIP_TRY(ustart.reserve(n_unique + 1));
+	hipLaunchKernelGGL(hao_range_flag_kernel, dim3((unsigned)((n_unique + 256) / 256)), dim3(256), 0, c->stream, ucnt, n_unique, lo, hi, flag.p);
+	HAO_CHECK_LAUNCH();
+	if (int rc = hao_excl_scan_u64(c, flag.p, kpos.p, n_unique + 1)) return rc;
+	{ auto it = rocprim::make_transform_iterator(ucnt, U32ToU64()); if (int rc = hao_excl_scan_u64(c, it, ustart.p, n_unique)) return rc; }
+	HIP_TRY(hipMemcpyAsync(n_kept, kpos.p + n_unique, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(keys.reserve(*n_kept + 1)); HIP_TRY(cnt.reserve(*n_kept + 1)); if (start) HIP_TRY(start->reserve(*n_kept + 1));
+	hipLaunchKernelGGL(hao_keep_scatter_kernel, dim3((unsigned)((n_unique + 255) / 256)), dim3(256), 0, c->stream, ukeys, ucnt, ustart.p, flag.p, kpos.p, n_unique,
+					   keys.p, start ? start->p : nullptr, cnt.p);
+	HAO_CHECK_LAUNCH();
+	if (n_pos && *n_kept) {   // sum of kept counts
+		size_t tb = 0; auto it = rocprim::make_transform_iterator(cnt.p, U32ToU64());
+		HIP_TRY(rocprim::reduce(nullptr, tb, it, (uint64_t*)c->d_cursor.p, (uint64_t)0, *n_kept, rocprim::plus<uint64_t>(), c->stream));
+		HIP_TRY(hao_tmp(c, tb));
+		HIP_TRY(rocprim::reduce(c->d_tmp.p, tb, it, (uint64_t*)c->d_cursor.p, (uint64_t)0, *n_kept, rocprim::plus<uint64_t>(), c->stream));
+		HIP_TRY(hipMemcpyAsync(n_pos, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+	}
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	flag.release(); kpos.release(); ustart.release();
+	return HAO_OK;
+}
+
+static int hao_build_bucket(hao_ctx *c, const uint64_t *keys, uint64_t n, int bits, DevBuf<uint32_t> &bucket)
+{
+	uint32_t nb = 1u << bits;
+	HIP_TRY(bucket.reserve(nb + 2));
+	hipLaunchKernelGGL(hao_bucket_kernel, dim3((nb + 256) / 256), dim3(256), 0, c->stream, keys, n, 64 - bits, nb, bucket.p);
+	HAO_CHECK_LAUNCH();
+	return HAO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// ha_ft_gen at -f0 (htab.cpp:1136-1169): all HPC k-mers -> exact counts -> histogram -> peaks ->
+// keep count >= cutoff -> filter table. + ha_opt_update_cov (CommandLines.cpp:411-418).
+// ---------------------------------------------------------------------------------------
+static int hao_ft_run(hao_ctx *c)
+{
+	const uint64_t n = c->n_reads; const int k = c->opt.k;
+	c->has_ft = false; c->h_ft_keys.clear(); c->h_ft_vals.clear();
+	if (n == 0) { hao_set_err(c, "no reads"); return HAO_EINVAL; }
+	if (c->n_bases >= (1ULL << 32) * 16) { hao_set_err(c, "read set too large for one device pass"); return HAO_EUNSUPP; }
+	std::vector<uint32_t> slist;
+	if (int rc = hao_prepare_runs(c, 0, n, false, slist)) return rc;
+	DevBuf<uint64_t> slots, chunks, kmer_off, kh_chunk_off;
+	HIP_TRY(slots.reserve(n + 2)); HIP_TRY(chunks.reserve(n + 2)); HIP_TRY(kmer_off.reserve(n + 2)); HIP_TRY(kh_chunk_off.reserve(n + 2));
+	hipLaunchKernelGGL(hao_kmer_slots_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, c->d_n_runs.p, c->d_scalar_flag.p, c->d_len.p, (uint64_t)0, n, k, slots.p, chunks.p);
+	HAO_CHECK_LAUNCH();
+	if (int rc = hao_excl_scan_u64(c, slots.p, kmer_off.p, n + 1)) return rc;
+	if (int rc = hao_excl_scan_u64(c, chunks.p, kh_chunk_off.p, n + 1)) return rc;
+	uint64_t n_slots = 0, n_chunks = 0;
+	HIP_TRY(hipMemcpyAsync(&n_slots, kmer_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipMemcpyAsync(&n_chunks, kh_chunk_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	c->timer.mark("ft_index");
+	DevBuf<uint64_t> kh, kh2; HIP_TRY(kh.reserve(n_slots + 1)); HIP_TRY(kh2.reserve(n_slots + 1));
+	uint64_t n_real = n_slots;
+	if (!slist.empty()) {    // slots of N reads are upper bounds: sentinel-fill, count the real ones
+		HIP_TRY(hipMemsetAsync(kh.p, 0xff, n_slots * 8, c->stream));
+		HIP_TRY(c->d_cursor.reserve(2)); HIP_TRY(hipMemsetAsync(c->d_cursor.p, 0, 8, c->stream));
+		hipLaunchKernelGGL(kmer_hash_scalar_kernel, dim3((unsigned)((slist.size() + 63) / 64)), dim3(64), 0, c->stream, c->d_packed.p, c->d_pk_off.p, c->d_len.p,
+						   c->d_nsite_off.p, c->d_nsite.p, c->d_scalar_list.p, (uint32_t)slist.size(), kmer_off.p, (uint64_t)0, k, c->opt.hpc, kh.p, c->d_cursor.p);
+		HAO_CHECK_LAUNCH();
+		uint64_t scalar_real = 0, scalar_slots = 0;
+		HIP_TRY(hipMemcpyAsync(&scalar_real, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		for (uint32_t r : slist) scalar_slots += c->h_len[r];
+		n_real = n_slots - scalar_slots + scalar_real;
+	}
+	if (n_chunks) {
+		hao_kh_args a;
+		a.packed = c->d_packed.p; a.pk_off = c->d_pk_off.p; a.len = c->d_len.p; a.tile_off = c->d_tile_off.p; a.tile_ord = c->d_tile_ord.p; a.n_runs = c->d_n_runs.p;
+		a.chunk_off = kh_chunk_off.p; a.scalar_flag = c->d_scalar_flag.p; a.kmer_off = kmer_off.p; a.rid_lo = 0; a.n_sel = n; a.k = k; a.hpc = c->opt.hpc; a.out = kh.p;
+		hipLaunchKernelGGL(kmer_hash_chunk_kernel, dim3((unsigned)n_chunks), dim3(256), hao_kh_smem_bytes(k), c->stream, a);
+		HAO_CHECK_LAUNCH();
+	}
+	c->timer.mark("ft_hash");
+	DevBuf<uint64_t> ukeys; DevBuf<uint32_t> ucnt; uint64_t n_unique = 0, *sorted = nullptr;
+	// sentinels (0xff..ff) sort to the end: only the first n_real entries are real k-mers
+	if (int rc = hao_sort_rle_hist(c, kh.p, kh2.p, n_slots, ukeys, ucnt, &n_unique, c->ft_hist, &sorted)) return rc;
+	if (n_real < n_slots && n_unique) { --n_unique; c->ft_hist[std::min<uint64_t>(n_slots - n_real, HAO_MAX_COUNT)] -= 1; }   // drop the sentinel run
+	c->timer.mark("ft_count");
+	kh.release(); kh2.release();
+	c->ft_peak_hom = hao_find_peaks(c->ft_hist, HAO_N_COUNTS, c->opt.min_hist_cnt, &c->ft_peak_het);
+	int cutoff = (int)(c->ft_peak_hom * c->opt.high_factor);                 // htab.cpp:1160
+	if (cutoff > HAO_MAX_COUNT - 1) cutoff = HAO_MAX_COUNT - 1;
+	c->ft_cutoff = cutoff;
+	DevBuf<uint32_t> kcnt; uint64_t n_kept = 0;
+	if (int rc = hao_keep_runs(c, ukeys.p, ucnt.p, n_unique, cutoff, HAO_MAX_COUNT, c->d_ft_keys, nullptr, kcnt, &n_kept, nullptr)) return rc;
+	ukeys.release(); ucnt.release();
+	// map values (gen_hh, htab.cpp:1038-1062) as ha_ft_cnt returns them (htab.cpp:1064-1070)
+	int max_cnt = c->opt.max_kmer_cnt;
+	if (max_cnt > HAO_MAX_COUNT - 1) max_cnt = HAO_MAX_COUNT - 1;
+	if (max_cnt > INT16_MAX - 1) max_cnt = INT16_MAX - 1;
+	c->h_ft_keys.resize(n_kept); c->h_ft_vals.resize(n_kept);
+	std::vector<uint32_t> hc(n_kept);
+	if (n_kept) {
+		HIP_TRY(hipMemcpy(c->h_ft_keys.data(), c->d_ft_keys.p, n_kept * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(hc.data(), kcnt.p, n_kept * 4, hipMemcpyDeviceToHost));
+	}
+	for (uint64_t i = 0; i < n_kept; ++i) c->h_ft_vals[i] = (int)hc[i] > max_cnt ? INT32_MAX : (int32_t)hc[i];
+	HIP_TRY(c->d_ft_vals.reserve(n_kept + 1)); HIP_TRY(c->d_ft_keys.reserve(n_kept + 1));
+	if (n_kept) HIP_TRY(hipMemcpyAsync(c->d_ft_vals.p, c->h_ft_vals.data(), n_kept * 4, hipMemcpyHostToDevice, c->stream));
+	if (int rc = hao_build_bucket(c, c->d_ft_keys.p, n_kept, 16, c->d_ft_bucket)) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	kcnt.release(); slots.release(); chunks.release(); kmer_off.release(); kh_chunk_off.release();
+	c->has_ft = true;
+	{	// ha_opt_update_cov
+		int mx = (int)(c->ft_peak_hom * c->opt.high_factor + .499);
+		c->hom_cov = c->ft_peak_hom;
+		if (c->max_n_chain < mx) c->max_n_chain = mx;
+	}
+	c->timer.mark("ft_table");
+	return HAO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// ha_pt_gen (htab.cpp:1232-1287): sketch all reads (once - the reference does it twice, pass A to
+// count and pass B to insert), stable sort by hash, run-length -> histogram -> peaks -> keep keys
+// occurring 2..4094 times (2..cutoff without a filter table).
+// ---------------------------------------------------------------------------------------
+static int hao_pt_run(hao_ctx *c)
+{
+	const uint64_t n = c->n_reads;
+	c->has_pt = false; c->h_ix_valid = false;
+	if (n == 0) { hao_set_err(c, "no reads"); return HAO_EINVAL; }
+	if (int rc = hao_sketch_run(c, 0, n, c->has_ft, c->opt.sample_dist, 1)) return rc;
+	// keep the read-ordered minimizers for the query side
+	std::swap(c->d_ix_mz_x, c->d_mz_x); std::swap(c->d_ix_mz_info, c->d_mz_info); std::swap(c->d_ix_mz_off, c->d_mz_off);
+	c->ix_n_mz = c->sk_total; c->sk_n = 0;
+	const uint64_t m = c->ix_n_mz;
+	if (m >= (1ULL << 32)) { hao_set_err(c, "more than 2^32 minimizers on one device"); return HAO_EUNSUPP; }
+	HIP_TRY(c->d_ix_sx.reserve(m + 1)); HIP_TRY(c->d_ix_sinfo.reserve(m + 1));
+	if (m) {
+		size_t tb = 0;
+		HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, c->d_ix_mz_x.p, c->d_ix_sx.p, c->d_ix_mz_info.p, c->d_ix_sinfo.p, m, 0, 64, c->stream));
+		HIP_TRY(hao_tmp(c, tb));
+		HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, c->d_ix_mz_x.p, c->d_ix_sx.p, c->d_ix_mz_info.p, c->d_ix_sinfo.p, m, 0, 64, c->stream));
+	}
+	c->timer.mark("pt_sort");
+	DevBuf<uint64_t> ukeys; DevBuf<uint32_t> ucnt; uint64_t n_unique = 0;
+	memset(c->pt_hist, 0, sizeof(c->pt_hist));
+	if (m) {
+		HIP_TRY(ukeys.reserve(m + 1)); HIP_TRY(ucnt.reserve(m + 1)); HIP_TRY(c->d_cursor.reserve(2));
+		size_t tb = 0;
+		HIP_TRY(rocprim::run_length_encode(nullptr, tb, c->d_ix_sx.p, m, ukeys.p, ucnt.p, (uint64_t*)c->d_cursor.p, c->stream));
+		HIP_TRY(hao_tmp(c, tb));
+		HIP_TRY(rocprim::run_length_encode(c->d_tmp.p, tb, c->d_ix_sx.p, m, ukeys.p, ucnt.p, (uint64_t*)c->d_cursor.p, c->stream));
+		HIP_TRY(hipMemcpyAsync(&n_unique, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		DevBuf<unsigned long long> dh; HIP_TRY(dh.reserve(HAO_N_COUNTS)); HIP_TRY(hipMemsetAsync(dh.p, 0, HAO_N_COUNTS * 8, c->stream));
+		unsigned nb = (unsigned)std::min<uint64_t>((n_unique + 255) / 256, 2048);
+		if (nb) hipLaunchKernelGGL(hao_count_hist_kernel, dim3(nb), dim3(256), 0, c->stream, ucnt.p, n_unique, dh.p);
+		HAO_CHECK_LAUNCH();
+		HIP_TRY(hipMemcpyAsync(c->pt_hist, dh.p, HAO_N_COUNTS * 8, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		dh.release();
+	}
+	c->timer.mark("pt_count");
+	int het = -1;
+	c->hom_cov = hao_find_peaks(c->pt_hist, HAO_N_COUNTS, c->opt.min_hist_cnt, &het); c->het_cov = het;
+	int hi;
+	if (c->has_ft) hi = HAO_MAX_COUNT - 1;                                   // htab.cpp:1266-1269
+	else { hi = (int)(c->hom_cov * c->opt.high_factor); if (hi > HAO_MAX_COUNT - 1) hi = HAO_MAX_COUNT - 1; }   // :1258-1262
+	if (int rc = hao_keep_runs(c, ukeys.p, ucnt.p, n_unique, 2, hi, c->d_ix_keys, &c->d_ix_start, c->d_ix_cnt, &c->ix_n_keys, &c->ix_n_pos)) return rc;
+	ukeys.release(); ucnt.release();
+	int bits = 16; while ((1ULL << bits) < c->ix_n_keys / 2 && bits < 26) ++bits;
+	if (int rc = hao_build_bucket(c, c->d_ix_keys.p, c->ix_n_keys, bits, c->d_ix_bucket)) return rc;
+	c->ix_bucket_bits = bits;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (!c->has_ft) { int mx = (int)(c->hom_cov * c->opt.high_factor + .499); if (c->max_n_chain < mx) c->max_n_chain = mx; }   // Assembly.cpp:1011-1012
+	c->has_pt = true;
+	c->timer.mark("pt_table");
+	return HAO_OK;
+}
+
+static hao_pt_dev hao_pt_view(hao_ctx *c)
+{
+	hao_pt_dev p; p.keys = c->d_ix_keys.p; p.start = c->d_ix_start.p; p.cnt = c->d_ix_cnt.p; p.bucket = c->d_ix_bucket.p; p.sinfo = c->d_ix_sinfo.p;
+	p.n_keys = c->ix_n_keys; p.bshift = 64 - c->ix_bucket_bits;
+	return p;
+}
+
+// host-readable copy of the index in the canonical (keys, CSR offsets, positions) form
+static int hao_pt_download(hao_ctx *c)
+{
+	if (c->h_ix_valid) return HAO_OK;
+	const uint64_t nk = c->ix_n_keys;
+	std::vector<uint64_t> start(nk); std::vector<uint32_t> cnt(nk); std::vector<uint64_t> sinfo(c->ix_n_mz);
+	c->h_ix_keys.resize(nk); c->h_ix_off.resize(nk + 1); c->h_ix_pos.resize(c->ix_n_pos);
+	if (nk) {
+		HIP_TRY(hipMemcpy(c->h_ix_keys.data(), c->d_ix_keys.p, nk * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(start.data(), c->d_ix_start.p, nk * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(cnt.data(), c->d_ix_cnt.p, nk * 4, hipMemcpyDeviceToHost));
+	}
+	if (c->ix_n_mz) HIP_TRY(hipMemcpy(sinfo.data(), c->d_ix_sinfo.p, c->ix_n_mz * 8, hipMemcpyDeviceToHost));
+	uint64_t o = 0;
+	for (uint64_t i = 0; i < nk; ++i) { c->h_ix_off[i] = o; memcpy(c->h_ix_pos.data() + o, sinfo.data() + start[i], (size_t)cnt[i] * 8); o += cnt[i]; }
+	c->h_ix_off[nk] = o;
+	c->h_ix_valid = true;
+	return HAO_OK;
+}

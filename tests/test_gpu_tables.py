@@ -1,0 +1,62 @@
+"""GPU parity: k-mer counts / histogram / peaks / filter table (ha_ft_gen), count-aware sketch with
+high-count thinning, minimizer histogram + position index (ha_pt_gen) - all vs the oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from helpers import scenario_reads, scenario_oracle
+from scenarios import SCENARIOS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=list(SCENARIOS))
+def pair(request):
+    from hifiasm_amd.api import Engine
+    name = request.param
+    rs, okw = scenario_reads(name)
+    e = Engine(0, **okw)
+    e.set_readset(rs)
+    hom_ft = e.ha_ft_gen()
+    hom, het = e.ha_pt_gen()
+    yield name, e, scenario_oracle(name), rs, (hom_ft, hom, het)
+    e.close()
+
+
+def test_ft(pair):
+    name, e, o, rs, (hom_ft, hom, het) = pair
+    assert (e.hist(0) == o.ft_hist()).all()
+    k, v = e.ft_table()
+    ok, ov = o.ft_table()
+    assert k.shape == ok.shape and (k == ok).all() and (v == ov).all()
+    st, so = e.stats(), o.stats()
+    assert st == so, (st, so)
+    assert hom_ft == so["ft_peak_hom"]
+    for y in list(ok[:5]) + [12345, 2**63 + 11]:
+        assert e.ha_ft_cnt(int(y)) == o.L.hao_or_ft_cnt(o.h, int(y))
+
+
+def test_pt(pair):
+    name, e, o, rs, (hom_ft, hom, het) = pair
+    assert (e.hist(1) == o.pt_hist()).all()
+    k, off, pos = e.pt_table()
+    ok, ooff, opos = o.pt_table()
+    assert k.shape == ok.shape and (k == ok).all()
+    assert (off == ooff).all() and (pos == opos).all()
+    so = o.stats()
+    assert (hom, het) == (so["hom_cov"], so["het_cov"])
+    if ok.size:
+        got = e.ha_pt_get(int(ok[ok.size // 2]))
+        i = ok.size // 2
+        assert (got == opos[int(ooff[i]):int(ooff[i + 1])]).all()
+    assert e.ha_pt_get(7).size == 0
+
+
+def test_sketch_with_filter(pair):
+    name, e, o, rs, _ = pair
+    e.sketch_batch(0, rs.n)          # hf = ha_flt_tab, sample_dist = 500: count order + thinning
+    bad = 0
+    for r in range(rs.n):
+        a, b = e.fetch_sketch(r), o.sketch(r)
+        if a.shape != b.shape or (a != b).any():
+            bad += 1
+    assert bad == 0, f"{bad}/{rs.n} reads differ"
