@@ -1,0 +1,200 @@
+// Host orchestration of one query batch: h_ec_lchain for reads [lo, hi) (part of libhao.so).
+#pragma once
+#include "hao_tables.hpp"
+#include "hao_query.cuh"
+#include "hao_chain.cuh"
+
+struct hao_ctx::Batch {
+	uint64_t lo = 0, n = 0, mz0 = 0, n_mz = 0, n_anchor = 0, n_groups = 0, n_chains = 0, n_cl = 0, n_fc_raw = 0, n_ol = 0, n_fc = 0;
+	bool valid = false, host_valid = false;
+	DevBuf<uint64_t> s_start, a_off, seg, keys, keys2, g_cnt, g_off, g_start, ch_base, cl_base, fc_base, fcs, fc_raw, ol_fc_off, cc_off, cc, fc_final, fin_off, fcf_off, fc_out, fc_out_off;
+	DevBuf<uint64_t> nch64;
+	DevBuf<uint32_t> s_n, g_read, wgt, nch, nout, perm, n_final, fclen;
+	DevBuf<hao_hit_t> hits, ohits, cl;
+	DevBuf<int32_t> f, ii, p; DevBuf<int64_t> t;
+	DevBuf<hao_chain_rec> rec; DevBuf<hao_ovlp_t> ol, ol_out;
+	// host copies for fetch
+	std::vector<uint64_t> h_seg, h_fin_off, h_cl_off, h_fc_out_off; std::vector<hao_hit_t> h_hits, h_cl; std::vector<hao_ovlp_t> h_ol; std::vector<uint64_t> h_fc;
+	std::vector<uint64_t> fetch_fc_off;
+	void release() {
+		s_start.release(); a_off.release(); seg.release(); keys.release(); keys2.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
+		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fin_off.release(); fcf_off.release(); fc_out.release(); fc_out_off.release();
+		nch64.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
+		hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); ol_out.release();
+	}
+};
+
+__global__ void hao_fclen_kernel(const hao_chain_rec *rec, const uint32_t *nch, uint64_t n_groups, uint64_t *out)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;     // chain slot g*3+c
+	if (i > n_groups * HAO_MCOPY_MAX) return;
+	if (i == n_groups * HAO_MCOPY_MAX) { out[i] = 0; return; }
+	uint64_t g = i / HAO_MCOPY_MAX; uint32_t c = (uint32_t)(i % HAO_MCOPY_MAX);
+	out[i] = c < nch[g] ? rec[i].fc_len : 0;
+}
+
+static int hao_scan_u32(hao_ctx *c, const uint32_t *in, uint64_t *out, uint64_t n_plus1)
+{
+	auto it = rocprim::make_transform_iterator(in, U32ToU64());
+	return hao_excl_scan_u64(c, it, out, n_plus1);
+}
+
+static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi)
+{
+	if (!c->has_pt) { hao_set_err(c, "hao_pt_gen must run before hao_overlap_batch"); return HAO_EINVAL; }
+	if (!c->batch) c->batch = new hao_ctx::Batch();
+	hao_ctx::Batch &B = *c->batch;
+	B.valid = false; B.host_valid = false; B.lo = lo; B.n = hi - lo;
+	const uint64_t n = B.n;
+	if (n == 0) { B.n_anchor = B.n_groups = B.n_chains = B.n_cl = B.n_ol = B.n_fc = B.n_mz = 0; B.valid = true; return HAO_OK; }
+	// minimizer range of the batch (host knows the per-read offsets? keep a host copy once)
+	if (c->h_ix_mz_off.size() != c->n_reads + 1) {
+		c->h_ix_mz_off.resize(c->n_reads + 1);
+		HIP_TRY(hipMemcpy(c->h_ix_mz_off.data(), c->d_ix_mz_off.p, (c->n_reads + 1) * 8, hipMemcpyDeviceToHost));
+	}
+	B.mz0 = c->h_ix_mz_off[lo]; B.n_mz = c->h_ix_mz_off[hi] - B.mz0;
+	const uint64_t nm = B.n_mz;
+	uint32_t high_occ, low_occ; hao_occ_thresholds(c->hom_cov, &high_occ, &low_occ);
+	std::vector<uint32_t> wt; hao_seed_weight_table(high_occ, low_occ, wt);
+	HIP_TRY(B.wgt.reserve(4096)); HIP_TRY(hipMemcpyAsync(B.wgt.p, wt.data(), 4096 * 4, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(B.s_start.reserve(nm + 1)); HIP_TRY(B.s_n.reserve(nm + 1)); HIP_TRY(B.a_off.reserve(nm + 2)); HIP_TRY(B.seg.reserve(n + 2));
+	HIP_TRY(c->d_err.reserve(2)); HIP_TRY(hipMemsetAsync(c->d_err.p, 0, 4, c->stream));
+	hao_pt_dev pt = hao_pt_view(c);
+	// Q1 lookup + scan
+	hipLaunchKernelGGL(seed_count_kernel, dim3((unsigned)((nm + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_x.p, B.mz0, nm, pt, B.s_start.p, B.s_n.p);
+	HAO_CHECK_LAUNCH();
+	if (int rc = hao_scan_u32(c, B.s_n.p, B.a_off.p, nm + 1)) return rc;
+	hipLaunchKernelGGL(seed_segments_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_off.p, lo, n, B.mz0, B.a_off.p, B.seg.p);
+	HAO_CHECK_LAUNCH();
+	HIP_TRY(hipMemcpyAsync(&B.n_anchor, B.a_off.p + nm, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	c->timer.mark("q_lookup");
+	const uint64_t A = B.n_anchor;
+	if (A >= (1ULL << 32)) { hao_set_err(c, "batch produces >= 2^32 anchors: use a smaller read range"); return HAO_EUNSUPP; }
+	HIP_TRY(B.keys.reserve(A + 1)); HIP_TRY(B.keys2.reserve(A + 1)); HIP_TRY(B.hits.reserve(A + 1));
+	// Q2 expand
+	hipLaunchKernelGGL(seed_expand_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, c->d_ix_mz_off.p, c->d_ix_mz_info.p, lo, B.mz0, B.s_start.p, B.s_n.p, B.a_off.p,
+					   c->d_ix_sinfo.p, B.keys.p, c->d_err.p);
+	HAO_CHECK_LAUNCH();
+	c->timer.mark("q_expand");
+	// Q3 per-read sort of the keys
+	uint64_t *sorted = B.keys.p;
+	if (A) {
+		int tid_bits = 1; while ((1ULL << tid_bits) < c->n_reads) ++tid_bits;
+		size_t tb = 0;
+		HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, tb, B.keys.p, B.keys2.p, (unsigned)A, (unsigned)n, B.seg.p, B.seg.p + 1, 0, HAO_KEY_TID_SHIFT + tid_bits, c->stream));
+		HIP_TRY(hao_tmp(c, tb));
+		HIP_TRY(rocprim::segmented_radix_sort_keys(c->d_tmp.p, tb, B.keys.p, B.keys2.p, (unsigned)A, (unsigned)n, B.seg.p, B.seg.p + 1, 0, HAO_KEY_TID_SHIFT + tid_bits, c->stream));
+		sorted = B.keys2.p;
+	}
+	c->timer.mark("q_sort");
+	// Q4 hits
+	hipLaunchKernelGGL(hits_build_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, sorted, B.seg.p, c->d_ix_mz_off.p, c->d_ix_mz_info.p, lo, B.mz0, B.s_start.p, B.s_n.p,
+					   c->d_ix_sinfo.p, c->d_len.p, B.wgt.p, B.hits.p);
+	HAO_CHECK_LAUNCH();
+	c->timer.mark("q_hits");
+	// Q5 groups
+	HIP_TRY(B.g_cnt.reserve(n + 2)); HIP_TRY(B.g_off.reserve(n + 2));
+	hipLaunchKernelGGL(groups_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, B.hits.p, B.seg.p, n, (const uint64_t*)nullptr, B.g_cnt.p, (uint64_t*)nullptr, (uint32_t*)nullptr, 0);
+	HAO_CHECK_LAUNCH();
+	if (int rc = hao_excl_scan_u64(c, B.g_cnt.p, B.g_off.p, n + 1)) return rc;
+	HIP_TRY(hipMemcpyAsync(&B.n_groups, B.g_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
+	int err = 0; HIP_TRY(hipMemcpyAsync(&err, c->d_err.p, 4, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (err) { hao_set_err(c, "a read has more than 65536 minimizers"); return HAO_EUNSUPP; }
+	const uint64_t G = B.n_groups;
+	HIP_TRY(B.g_start.reserve(G + 1)); HIP_TRY(B.g_read.reserve(G + 1));
+	hipLaunchKernelGGL(groups_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, B.hits.p, B.seg.p, n, B.g_off.p, B.g_cnt.p, B.g_start.p, B.g_read.p, 1);
+	HAO_CHECK_LAUNCH();
+	c->timer.mark("q_groups");
+	// Q6 chain
+	HIP_TRY(B.f.reserve(A + 1)); HIP_TRY(B.ii.reserve(A + 1)); HIP_TRY(B.p.reserve(A + 1)); HIP_TRY(B.t.reserve(A + 1)); HIP_TRY(B.ohits.reserve(A + 1));
+	HIP_TRY(B.fcs.reserve(A + 6 * G + 1)); HIP_TRY(B.rec.reserve(G * HAO_MCOPY_MAX + 1)); HIP_TRY(B.nch.reserve(G + 2)); HIP_TRY(B.nout.reserve(G + 2));
+	hao_chain_par par = hao_chain_params(c->opt.k, c->opt.is_ont, c->max_n_chain);
+	if (G) {
+		hao_chain_args ca;
+		ca.hits = B.hits.p; ca.g_start = B.g_start.p; ca.g_read = B.g_read.p; ca.g_off = B.g_off.p; ca.seg = B.seg.p; ca.n_groups = G; ca.rid_lo = lo; ca.len = c->d_len.p; ca.par = par;
+		ca.f = B.f.p; ca.ii = B.ii.p; ca.p = B.p.p; ca.t = B.t.p; ca.ohits = B.ohits.p; ca.fcs = B.fcs.p; ca.rec = B.rec.p; ca.nch = B.nch.p; ca.nout = B.nout.p;
+		hipLaunchKernelGGL(chain_group_kernel, dim3((unsigned)((G + 63) / 64)), dim3(64), 0, c->stream, ca);
+		HAO_CHECK_LAUNCH();
+	}
+	HIP_TRY(hipMemsetAsync(B.nch.p + G, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(B.nout.p + G, 0, 4, c->stream));
+	c->timer.mark("q_chain");
+	// Q7 assembly
+	HIP_TRY(B.ch_base.reserve(G + 2)); HIP_TRY(B.cl_base.reserve(G + 2)); HIP_TRY(B.fc_base.reserve(G * HAO_MCOPY_MAX + 2)); HIP_TRY(B.nch64.reserve(G * HAO_MCOPY_MAX + 2));
+	if (int rc = hao_scan_u32(c, B.nch.p, B.ch_base.p, G + 1)) return rc;
+	if (int rc = hao_scan_u32(c, B.nout.p, B.cl_base.p, G + 1)) return rc;
+	hipLaunchKernelGGL(hao_fclen_kernel, dim3((unsigned)((G * HAO_MCOPY_MAX + 256) / 256)), dim3(256), 0, c->stream, B.rec.p, B.nch.p, G, B.nch64.p);
+	HAO_CHECK_LAUNCH();
+	if (int rc = hao_excl_scan_u64(c, B.nch64.p, B.fc_base.p, G * HAO_MCOPY_MAX + 1)) return rc;
+	HIP_TRY(hipMemcpyAsync(&B.n_chains, B.ch_base.p + G, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipMemcpyAsync(&B.n_cl, B.cl_base.p + G, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipMemcpyAsync(&B.n_fc_raw, B.fc_base.p + G * HAO_MCOPY_MAX, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	const uint64_t NC = B.n_chains;
+	HIP_TRY(B.ol.reserve(NC + 1)); HIP_TRY(B.ol_fc_off.reserve(NC + 1)); HIP_TRY(B.cl.reserve(B.n_cl + 1)); HIP_TRY(B.fc_raw.reserve(B.n_fc_raw + 1)); HIP_TRY(B.perm.reserve(NC + 1));
+	if (G) {
+		hao_asm_args aa;
+		aa.g_start = B.g_start.p; aa.g_read = B.g_read.p; aa.g_off = B.g_off.p; aa.n_groups = G; aa.rid_lo = lo; aa.ohits = B.ohits.p; aa.fcs = B.fcs.p; aa.rec = B.rec.p; aa.nch = B.nch.p;
+		aa.ch_base = B.ch_base.p; aa.cl_base = B.cl_base.p; aa.fc_base = B.fc_base.p; aa.ol = B.ol.p; aa.ol_fc_off = B.ol_fc_off.p; aa.cl = B.cl.p; aa.fc = B.fc_raw.p;
+		hipLaunchKernelGGL(chain_assemble_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream, aa);
+		HAO_CHECK_LAUNCH();
+	}
+	c->timer.mark("q_assemble");
+	// Q8 selection
+	{
+		std::vector<uint64_t> cco(n + 1); uint64_t o = 0;
+		for (uint64_t r = 0; r < n; ++r) { cco[r] = o; o += c->h_len[lo + r] / par.ocv_w + 2; }
+		cco[n] = o;
+		HIP_TRY(B.cc_off.reserve(n + 1)); HIP_TRY(B.cc.reserve(o + 1)); HIP_TRY(B.n_final.reserve(n + 2)); HIP_TRY(B.fc_final.reserve(n + 2));
+		HIP_TRY(B.fin_off.reserve(n + 2)); HIP_TRY(B.fcf_off.reserve(n + 2));
+		HIP_TRY(hipMemcpyAsync(B.cc_off.p, cco.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+	}
+	hao_sel_args sa;
+	sa.ol = B.ol.p; sa.g_off = B.g_off.p; sa.ch_base = B.ch_base.p; sa.cl_base = B.cl_base.p; sa.cl = B.cl.p; sa.n_sel = n; sa.rid_lo = lo; sa.len = c->d_len.p; sa.cc_off = B.cc_off.p; sa.cc = B.cc.p;
+	sa.perm = B.perm.p; sa.n_final = B.n_final.p; sa.fc_final = B.fc_final.p; sa.max_n_chain = par.max_n_chain; sa.ocv_w = par.ocv_w; sa.chain_cutoff = par.chain_cutoff;
+	hipLaunchKernelGGL(chain_select_kernel, dim3((unsigned)((n + 64) / 64)), dim3(64), 0, c->stream, sa);
+	HAO_CHECK_LAUNCH();
+	if (int rc = hao_scan_u32(c, B.n_final.p, B.fin_off.p, n + 1)) return rc;
+	if (int rc = hao_excl_scan_u64(c, B.fc_final.p, B.fcf_off.p, n + 1)) return rc;
+	HIP_TRY(hipMemcpyAsync(&B.n_ol, B.fin_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipMemcpyAsync(&B.n_fc, B.fcf_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	c->timer.mark("q_select");
+	HIP_TRY(B.ol_out.reserve(B.n_ol + 1)); HIP_TRY(B.fc_out.reserve(B.n_fc + 1)); HIP_TRY(B.fc_out_off.reserve(B.n_ol + 2));
+	hipLaunchKernelGGL(chain_final_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, B.ol.p, B.ol_fc_off.p, B.fc_raw.p, B.perm.p, B.g_off.p, B.ch_base.p,
+					   B.fin_off.p, B.fcf_off.p, n, B.ol_out.p, B.fc_out.p, B.fc_out_off.p);
+	HAO_CHECK_LAUNCH();
+	c->timer.mark("q_final");
+	B.valid = true;
+	return HAO_OK;
+}
+
+// host copies for the fetch API (one bulk download per batch)
+static int hao_batch_download(hao_ctx *c)
+{
+	hao_ctx::Batch &B = *c->batch;
+	if (B.host_valid) return HAO_OK;
+	const uint64_t n = B.n;
+	B.h_seg.assign(n + 1, 0); B.h_fin_off.assign(n + 1, 0); B.h_cl_off.assign(n + 1, 0);
+	B.h_hits.resize(B.n_anchor); B.h_cl.resize(B.n_cl); B.h_ol.resize(B.n_ol); B.h_fc.resize(B.n_fc); B.h_fc_out_off.assign(B.n_ol + 1, 0);
+	if (n) {
+		HIP_TRY(hipMemcpy(B.h_seg.data(), B.seg.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(B.h_fin_off.data(), B.fin_off.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+		std::vector<uint64_t> goff(n + 1), clb(B.n_groups + 1);
+		HIP_TRY(hipMemcpy(goff.data(), B.g_off.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(clb.data(), B.cl_base.p, (B.n_groups + 1) * 8, hipMemcpyDeviceToHost));
+		for (uint64_t r = 0; r <= n; ++r) B.h_cl_off[r] = clb[goff[r]];
+	}
+	if (B.n_anchor) HIP_TRY(hipMemcpy(B.h_hits.data(), B.hits.p, B.n_anchor * sizeof(hao_hit_t), hipMemcpyDeviceToHost));
+	if (B.n_cl) HIP_TRY(hipMemcpy(B.h_cl.data(), B.cl.p, B.n_cl * sizeof(hao_hit_t), hipMemcpyDeviceToHost));
+	if (B.n_ol) {
+		HIP_TRY(hipMemcpy(B.h_ol.data(), B.ol_out.p, B.n_ol * sizeof(hao_ovlp_t), hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(B.h_fc_out_off.data(), B.fc_out_off.p, B.n_ol * 8, hipMemcpyDeviceToHost));
+	}
+	B.h_fc_out_off[B.n_ol] = B.n_fc;
+	if (B.n_fc) HIP_TRY(hipMemcpy(B.h_fc.data(), B.fc_out.p, B.n_fc * 8, hipMemcpyDeviceToHost));
+	B.host_valid = true;
+	return HAO_OK;
+}

@@ -11,6 +11,7 @@
 #include "hao_chain.cuh"
 #include "hao_pipeline.hpp"
 #include "hao_tables.hpp"
+#include "hao_batch.hpp"
 
 extern "C" {
 

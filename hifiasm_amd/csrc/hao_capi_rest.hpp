@@ -1,7 +1,7 @@
 // remaining C ABI entry points + resource release
 #pragma once
 
-static void hao_batch_free(hao_ctx *c) { (void)c; }
+static void hao_batch_free(hao_ctx *c) { if (c->batch) { c->batch->release(); delete c->batch; c->batch = nullptr; } }
 
 static void hao_release_all(hao_ctx *c)
 {
@@ -17,6 +17,7 @@ static void hao_release_all(hao_ctx *c)
 
 #define HAO_HAVE_FT
 #define HAO_HAVE_PT
+#define HAO_HAVE_QUERY
 extern "C" {
 
 int hao_ft_gen(hao_ctx *c, int32_t *hom_cov)
@@ -84,6 +85,49 @@ int hao_pt_get(hao_ctx *c, uint64_t hash, const uint64_t **pos, int32_t *n)
 	int64_t i = hao_bsearch(c->h_ix_keys.data(), c->h_ix_keys.size(), hash);
 	if (i < 0) { *pos = nullptr; *n = 0; return HAO_OK; }
 	*pos = c->h_ix_pos.data() + c->h_ix_off[i]; *n = (int32_t)(c->h_ix_off[i + 1] - c->h_ix_off[i]);
+	return HAO_OK;
+}
+
+int hao_overlap_batch(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi)
+{
+	if (!c || rid_lo > rid_hi || rid_hi > c->n_reads) return HAO_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	c->timer.begin(c->stream);
+	int rc = hao_overlap_run(c, rid_lo, rid_hi);
+	if (rc != HAO_OK) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	c->timer.collect(c->stage_ms);
+	return HAO_OK;
+}
+
+int hao_fetch_seed_hits(hao_ctx *c, uint64_t rid, const hao_hit_t **hits, uint64_t *n)
+{
+	if (!c || !c->batch || !c->batch->valid || rid < c->batch->lo || rid >= c->batch->lo + c->batch->n) return HAO_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	if (int rc = hao_batch_download(c)) return rc;
+	hao_ctx::Batch &B = *c->batch; uint64_t r = rid - B.lo;
+	*hits = B.h_hits.data() + B.h_seg[r]; *n = B.h_seg[r + 1] - B.h_seg[r];
+	return HAO_OK;
+}
+
+int hao_fetch_overlaps(hao_ctx *c, uint64_t rid, const hao_ovlp_t **ol, uint64_t *n_ol, const uint64_t **fc, const uint64_t **fc_off, const hao_hit_t **cl, uint64_t *n_cl)
+{
+	if (!c || !c->batch || !c->batch->valid || rid < c->batch->lo || rid >= c->batch->lo + c->batch->n) return HAO_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	if (int rc = hao_batch_download(c)) return rc;
+	hao_ctx::Batch &B = *c->batch; uint64_t r = rid - B.lo, s = B.h_fin_off[r], e = B.h_fin_off[r + 1];
+	*ol = B.h_ol.data() + s; *n_ol = e - s;
+	*fc = B.h_fc.data() + B.h_fc_out_off[s]; *fc_off = B.h_fc_out_off.data() + s;     // absolute offsets; entry i spans [fc_off[i]-fc_off[0], fc_off[i+1]-fc_off[0]) of *fc
+	*cl = B.h_cl.data() + B.h_cl_off[r]; *n_cl = B.h_cl_off[r + 1] - B.h_cl_off[r];
+	return HAO_OK;
+}
+
+int hao_batch_totals(hao_ctx *c, uint64_t out[8])
+{
+	if (!c || !c->batch || !c->batch->valid) return HAO_EINVAL;
+	hao_ctx::Batch &B = *c->batch;
+	memset(out, 0, 8 * sizeof(uint64_t));
+	out[0] = B.n_ol; out[1] = B.n_cl; out[2] = B.n_anchor; out[3] = B.n_groups; out[4] = B.n_mz; out[5] = B.n_chains;
 	return HAO_OK;
 }
 

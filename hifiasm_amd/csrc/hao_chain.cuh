@@ -1,1 +1,465 @@
+// K8/K9: per-target linear chaining and per-read chain selection for gfx950.
+//
+// K8 = lchain_qdp_mcopy_fast (Hash_Table.cpp:2097-2284) with quick_ck_lchain (:2007-2094),
+// comput_sc_ch_ec (:1515-1541), cal_bw (:1475-1488), get_chainLen (:779-809),
+// push_ovlp_chain_qgen (:1752-1780), gen_fake_cigar (:88-109).
+// K9 = lchain_qgen_mcopy_fast (anchor.cpp:1920-2100): max_n_chain pruning with
+// coverage-window rescue, klib introsort tie order (ksort.h:110-160), weak-chain filter.
+//
+// Scores mix int32 with FP64 penalties; the translation unit is compiled with
+// -ffp-contract=off and every double expression keeps the reference's operation order,
+// so results are bit-identical to the x86-64 SSE2 build of the reference.
+//
+// This first version runs one lane per (query,target) group / per read: the algorithms
+// are order-dependent sequential scans over ~200 hits.  Inputs and outputs are laid out so
+// a wave-per-group version can replace the kernels without touching the pipeline.
 #pragma once
+#include "hao_common.cuh"
+#include "hao_host.hpp"
+
+#define HAO_MCOPY_MAX 3
+
+struct hao_chain_rec {          // one kept chain of a group
+	uint32_t x_pos_s, x_pos_e, y_pos_s, y_pos_e; int32_t score; uint32_t n_hits, hit_rel, fc_rel, fc_len, strand;
+};
+
+#define HH_ID(h)     ((h).w0 & 0x7fffffffu)
+#define HH_STRAND(h) ((h).w0 >> 31)
+#define HH_SPAN(h)   ((int32_t)((h).cnt & 0xffu))
+#define HH_WGT(h)    ((int32_t)((h).cnt >> 8))
+
+struct hao_cpar { double pen_gap, pen_skip, bw; int64_t max_skip, max_iter, max_dis, xl, yl; };
+
+__device__ __forceinline__ int64_t hao_ext_len(int64_t x_beg, int64_t x_end, int64_t xl, int64_t y_beg, int64_t y_end, int64_t yl)
+{	// get_chainLen
+	if (x_beg <= y_beg) x_beg = 0; else x_beg -= y_beg;
+	int64_t xr = xl - x_end - 1, yr = yl - y_end - 1;
+	if (xr <= yr) x_end = xl - 1; else x_end += yr;
+	return x_end - x_beg + 1;
+}
+
+__device__ __forceinline__ int32_t hao_band(const hao_hit_t &ai, const hao_hit_t &aj, const hao_cpar &P)
+{	// cal_bw
+	int64_t sf_s = aj.self_offset, sf_e = (int64_t)ai.self_offset + 1, ot_s = aj.offset, ot_e = (int64_t)ai.offset + 1;
+	int64_t sf_r = P.xl - sf_e, ot_r = P.yl - ot_e;
+	if (sf_s <= ot_s) sf_s = 0; else sf_s -= ot_s;
+	if (sf_r <= ot_r) sf_e = P.xl; else sf_e += ot_r;
+	return (int32_t)((double)(sf_e - sf_s) * P.bw);
+}
+
+__device__ __forceinline__ int32_t hao_pair_score(const hao_hit_t &ai, const hao_hit_t &aj, const hao_cpar &P, int64_t *dd_out)
+{	// comput_sc_ch_ec
+	int32_t dq = (int32_t)((int64_t)ai.self_offset - (int64_t)aj.self_offset); if (dq <= 0) return INT32_MIN;
+	int32_t dr = (int32_t)((int64_t)ai.offset - (int64_t)aj.offset); if (dr <= 0) return INT32_MIN;
+	int32_t dd = dr > dq ? dr - dq : dq - dr;
+	if (dd > 16 && dd > hao_band(ai, aj, P)) return INT32_MIN;
+	int32_t dg = dr < dq ? dr : dq, span = HH_SPAN(ai), sc = span < dg ? span : dg, wgt = HH_WGT(ai);
+	sc = sc >= wgt ? sc / wgt : 1;
+	if (dd || (dg > span && dg > 0)) {
+		double lin = P.pen_gap * (double)dd, ap = (double)sc * (((double)dd / (double)dg) / P.bw);
+		if (dd < 4) lin = lin > ap ? ap : lin; else lin = lin < ap ? ap : lin;
+		lin += P.pen_skip * (double)dg;
+		sc -= (int32_t)lin;
+	}
+	if (dd_out) *dd_out = dd;
+	return sc;
+}
+
+__device__ __forceinline__ void hao_region(hao_chain_rec &o, int64_t xl, int64_t yl, int64_t sc, const hao_hit_t &beg, const hao_hit_t &end)
+{	// push_ovlp_chain_qgen
+	o.strand = HH_STRAND(beg);
+	o.x_pos_s = beg.self_offset; o.y_pos_s = beg.offset; o.x_pos_e = end.self_offset; o.y_pos_e = end.offset;
+	if (o.x_pos_s <= o.y_pos_s) { o.y_pos_s -= o.x_pos_s; o.x_pos_s = 0; } else { o.x_pos_s -= o.y_pos_s; o.y_pos_s = 0; }
+	int64_t xr = xl - o.x_pos_e - 1, yr = yl - o.y_pos_e - 1;
+	if (xr <= yr) { o.x_pos_e = (uint32_t)(xl - 1); o.y_pos_e += (uint32_t)xr; } else { o.y_pos_e = (uint32_t)(yl - 1); o.x_pos_e += (uint32_t)yr; }
+	o.score = (int32_t)sc;
+}
+
+__device__ __forceinline__ uint64_t hao_fc_entry(uint32_t site, int32_t shift)
+{ uint32_t lo = shift < 0 ? ((uint32_t)(-shift) << 1 | 1u) : (uint32_t)shift << 1; return (uint64_t)site << 32 | lo; }
+
+__device__ uint32_t hao_fake_cigar(uint64_t *fc, const hao_chain_rec &o, const hao_hit_t *hit, int64_t n_hit)
+{	// gen_fake_cigar, apend_be = 1
+	int64_t pdd = INT32_MAX; uint32_t n = 0;
+	fc[n++] = hao_fc_entry(o.x_pos_s, 0);
+	for (int64_t k = 0; k < n_hit; ++k) {
+		int64_t dq = (int64_t)hit[k].self_offset - o.x_pos_s, dr = (int64_t)hit[k].offset - o.y_pos_s, dd = dr - dq;
+		if (dd != pdd) { pdd = dd; fc[n++] = hao_fc_entry(hit[k].self_offset, (int32_t)pdd); }
+	}
+	uint64_t last = fc[n - 1]; int32_t lsh = (int32_t)((uint32_t)last >> 1); if (last & 1) lsh = -lsh;
+	if ((int64_t)(int32_t)(last >> 32) != (int64_t)o.x_pos_e) fc[n++] = hao_fc_entry(o.x_pos_e, lsh);
+	return n;
+}
+
+__device__ void hao_heapsort_i64(int64_t *a, int64_t n)
+{
+	auto down = [&](int64_t i, int64_t m) { int64_t v = a[i]; for (;;) { int64_t c = 2 * i + 1; if (c >= m) break; if (c + 1 < m && a[c + 1] > a[c]) ++c; if (a[c] <= v) break; a[i] = a[c]; i = c; } a[i] = v; };
+	for (int64_t i = n / 2 - 1; i >= 0; --i) down(i, n);
+	for (int64_t m = n - 1; m > 0; --m) { int64_t tmp = a[0]; a[0] = a[m]; a[m] = tmp; down(0, m); }
+}
+
+struct hao_chain_args {
+	const hao_hit_t *hits; const uint64_t *g_start; const uint32_t *g_read; const uint64_t *g_off; const uint64_t *seg; uint64_t n_groups;
+	uint64_t rid_lo; const uint32_t *len;
+	hao_chain_par par;
+	int32_t *f, *ii, *p; int64_t *t;             // per-hit scratch
+	hao_hit_t *ohits; uint64_t *fcs; hao_chain_rec *rec; uint32_t *nch, *nout;
+};
+
+// one lane per group
+__global__ __launch_bounds__(64) void chain_group_kernel(hao_chain_args A)
+{
+	const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= A.n_groups) return;
+	const uint32_t r = A.g_read[g]; const uint64_t gs = A.g_start[g], ge = (g + 1 < A.g_off[r + 1]) ? A.g_start[g + 1] : A.seg[r + 1];
+	const hao_hit_t *a = A.hits + gs; const int64_t a_n = (int64_t)(ge - gs);
+	const uint32_t xid = (uint32_t)(A.rid_lo + r), yid = HH_ID(a[0]);
+	A.nch[g] = 0; A.nout[g] = 0;
+	if (yid == xid || a_n <= 0) return;                      // hits to the query itself are skipped (anchor.cpp:1931)
+	hao_cpar P; P.pen_gap = A.par.pen_gap; P.pen_skip = A.par.pen_skip; P.bw = A.par.bw; P.max_skip = A.par.max_skip; P.max_iter = A.par.max_iter; P.max_dis = A.par.max_dis;
+	P.xl = A.len[xid]; P.yl = A.len[yid];
+	int32_t *f = A.f + gs, *ii = A.ii + gs, *p = A.p + gs; int64_t *t = A.t + gs;
+	hao_hit_t *des = A.ohits + gs; uint64_t *fcs = A.fcs + gs + 6 * g; hao_chain_rec *rec = A.rec + g * HAO_MCOPY_MAX;
+	int64_t plus = 0, msc = INT32_MIN, msc_i = INT32_MIN, movl = INT32_MAX, si = 0, ei = a_n;
+	// ---- quick_ck_lchain ----
+	{
+		int64_t l = 0, k, z; bool sorted = true;
+		for (k = 1; k <= a_n; ++k) {
+			t[k - 1] = 0; ii[k - 1] = 0;
+			if (k < a_n && HH_STRAND(a[k]) == HH_STRAND(a[l])) {
+				if (a[k].self_offset <= a[k - 1].self_offset || a[k].offset <= a[k - 1].offset) sorted = false;
+				continue;
+			}
+			if (sorted) {
+				int64_t plus0 = 0, msc0 = INT32_MIN, msc_i0 = INT32_MIN, ddt = 0, sc, dd = 0;
+				p[l] = -1; f[l] = HH_SPAN(a[l]);
+				if (f[l] >= msc0) { msc0 = f[l]; msc_i0 = l; }
+				if (f[l] < plus0) plus0 = f[l];
+				for (z = l + 1; z < k; ++z) {
+					int32_t s = hao_pair_score(a[z], a[z - 1], P, &dd);
+					if (s == INT32_MIN) break;
+					sc = (int64_t)s + f[z - 1];
+					if (sc < HH_SPAN(a[z])) break;
+					p[z] = (int32_t)(z - 1); f[z] = (int32_t)sc; ddt += dd;
+					if (f[z] >= msc0) { msc0 = f[z]; msc_i0 = z; }
+					if (f[z] < plus0) plus0 = f[z];
+				}
+				if (z >= k && msc_i0 == k - 1) {
+					if (k - l >= 2 && ddt > 16 && ddt > hao_band(a[k - 1], a[l], P)) msc_i0 = INT32_MIN;
+					if (msc_i0 == k - 1) {
+						if (msc0 >= msc) {
+							int64_t ov = hao_ext_len(a[msc_i0].self_offset, a[msc_i0].self_offset, P.xl, a[msc_i0].offset, a[msc_i0].offset, P.yl);
+							if (msc0 > msc || ov < movl) { msc = msc0; msc_i = msc_i0; movl = ov; }
+						}
+						if (plus0 < plus) plus = plus0;
+						if (ei > k) si = k; else ei = l;
+					}
+				}
+			}
+			l = k; sorted = true;
+		}
+	}
+	// ---- DP over what the quick check left ----
+	{
+		int64_t i, j, st, max_ii = -1;
+		for (i = st = si; i < ei; ++i) {
+			int64_t max_f = HH_SPAN(a[i]), n_skip = 0, max_j = -1, end_j, sc;
+			if (i - st > P.max_iter) st = i - P.max_iter;
+			while (HH_STRAND(a[i]) != HH_STRAND(a[st])) ++st;
+			for (j = i - 1; j >= st; --j) {
+				int32_t s = hao_pair_score(a[i], a[j], P, nullptr);
+				if (s == INT32_MIN) continue;
+				sc = (int64_t)s + f[j];
+				if (sc > max_f) { max_f = sc; max_j = j; if (n_skip > 0) --n_skip; }
+				else if (t[j] == (int32_t)i) { if (++n_skip > P.max_skip) break; }
+				if (p[j] >= 0) t[p[j]] = i;
+			}
+			end_j = j;
+			if (max_ii < 0 || (int64_t)a[i].self_offset > (int64_t)a[max_ii].self_offset + P.max_dis || HH_STRAND(a[i]) != HH_STRAND(a[max_ii])) {
+				int32_t mx = INT32_MIN; max_ii = -1;
+				for (j = i - 1; j >= st && (int64_t)a[i].self_offset <= P.max_dis + (int64_t)a[j].self_offset && HH_STRAND(a[i]) == HH_STRAND(a[j]); --j)
+					if (mx < f[j]) { mx = f[j]; max_ii = j; }
+			}
+			if (max_ii >= 0 && max_ii < end_j && HH_STRAND(a[i]) == HH_STRAND(a[max_ii])) {
+				int32_t tmp = hao_pair_score(a[i], a[max_ii], P, nullptr);
+				if (tmp != INT32_MIN && max_f < (int64_t)tmp + f[max_ii]) { max_f = (int64_t)tmp + f[max_ii]; max_j = max_ii; }
+			}
+			f[i] = (int32_t)max_f; p[i] = (int32_t)max_j;
+			if (max_ii < 0 || ((int64_t)a[i].self_offset <= P.max_dis + (int64_t)a[max_ii].self_offset && HH_STRAND(a[i]) == HH_STRAND(a[max_ii]) && f[max_ii] < f[i])) max_ii = i;
+			if (f[i] >= msc) {
+				int64_t ovl = hao_ext_len(a[i].self_offset, a[i].self_offset, P.xl, a[i].offset, a[i].offset, P.yl);
+				if (f[i] > msc || ovl < movl) { msc = f[i]; msc_i = i; movl = ovl; }
+			}
+			if (f[i] < plus) plus = f[i];
+			ii[i] = 0;
+		}
+	}
+	int64_t cL = 0, i;
+	for (i = msc_i; i >= 0; i = p[i]) { ii[i] = 1; t[cL++] = i; }
+	// ---- multi-copy chains ----
+	if (A.par.mcopy_num > 1 && cL >= A.par.mcopy_khit_cut) {
+		int64_t ch_n, min_sc;
+		msc -= plus; min_sc = (int64_t)((double)msc * A.par.mcopy_rate); ii[msc_i] = 0;
+		for (i = ch_n = 0; i < a_n; ++i) {
+			f[i] -= (int32_t)plus; if (i >= ch_n) t[i] = 0;
+			if (!ii[i] && f[i] >= min_sc) { t[ch_n] = (int64_t)((uint64_t)f[i] << 32); t[ch_n] += i << 1; ++ch_n; }
+		}
+		if (ch_n > 1) {
+			int64_t n_v = 0, n_v0, n_u = 0, k, sc, j, ni; uint32_t fcn = 0;
+			hao_heapsort_i64(t, ch_n);
+			uint32_t c_nv0[HAO_MCOPY_MAX], c_ni[HAO_MCOPY_MAX];
+			for (k = ch_n - 1; k >= 0 && n_u < A.par.mcopy_num; --k) {
+				n_v0 = n_v;
+				for (i = (int64_t)((uint32_t)t[k] >> 1); i >= 0 && (t[i] & 1) == 0; ) { ii[n_v++] = (int32_t)i; t[i] |= 1; i = p[i]; }
+				if (n_v0 == n_v) continue;
+				sc = i < 0 ? (t[k] >> 32) : ((t[k] >> 32) - f[i]);
+				if (sc >= min_sc) {
+					if (!n_u || n_v - n_v0 > 1) {
+						hao_region(rec[n_u], P.xl, P.yl, sc + plus, a[ii[n_v - 1]], a[ii[n_v0]]);
+						c_nv0[n_u] = (uint32_t)n_v0; c_ni[n_u] = (uint32_t)(n_v - n_v0); ++n_u;
+					} else n_v = n_v0;
+				} else n_v = n_v0;
+			}
+			// chain member lists live in ii[]; stage the hits through the tail of t[] is not possible (t holds marks), so
+			// write each chain to des[] from a private walk: des and a may alias only if des == a (they do not: separate buffers)
+			for (k = 0, i = 0; k < n_u; ++k) {
+				n_v0 = c_nv0[k]; ni = c_ni[k];
+				rec[k].hit_rel = (uint32_t)i; rec[k].n_hits = (uint32_t)ni;
+				for (j = 0; j < ni; ++j, ++i) des[i] = a[ii[n_v0 + (ni - j - 1)]];
+				rec[k].fc_rel = fcn; rec[k].fc_len = hao_fake_cigar(fcs + fcn, rec[k], des + i - ni, ni); fcn += rec[k].fc_len;
+			}
+			A.nch[g] = (uint32_t)n_u; A.nout[g] = (uint32_t)i;
+			return;
+		} else {
+			msc += plus; i = msc_i; cL = 0;
+			while (i >= 0) { t[cL++] = i; i = p[i]; }
+		}
+	}
+	hao_region(rec[0], P.xl, P.yl, msc, a[t[cL - 1]], a[t[0]]);
+	for (i = 0; i < cL; ++i) des[i] = a[t[cL - i - 1]];
+	rec[0].hit_rel = 0; rec[0].n_hits = (uint32_t)cL; rec[0].fc_rel = 0; rec[0].fc_len = hao_fake_cigar(fcs, rec[0], des, cL);
+	A.nch[g] = 1; A.nout[g] = (uint32_t)cL;
+}
+
+// ---------------------------------------------------------------------------------------
+// Assembly: per group, materialise overlap records (creation order), chained hits (tagged with
+// the overlap ordinal inside the read) and fake cigars.  One wave per group.
+// ---------------------------------------------------------------------------------------
+struct hao_asm_args {
+	const uint64_t *g_start; const uint32_t *g_read; const uint64_t *g_off; uint64_t n_groups; uint64_t rid_lo;
+	const hao_hit_t *ohits; const uint64_t *fcs; const hao_chain_rec *rec; const uint32_t *nch;
+	const uint64_t *ch_base, *cl_base, *fc_base;   // exclusive scans over groups (chains, hits) and over chain slots (fake-cigar entries)
+	hao_ovlp_t *ol; uint64_t *ol_fc_off; hao_hit_t *cl; uint64_t *fc;
+};
+
+__global__ __launch_bounds__(256) void chain_assemble_kernel(hao_asm_args A)
+{
+	const uint64_t g = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (g >= A.n_groups) return;
+	const uint32_t n = A.nch[g]; if (n == 0) return;
+	const uint32_t r = A.g_read[g]; const uint64_t g0 = A.g_off[r];
+	const uint64_t ord0 = A.ch_base[g] - A.ch_base[g0], cl0 = A.cl_base[g0];
+	const hao_hit_t *src = A.ohits + A.g_start[g]; const uint64_t *fsrc = A.fcs + A.g_start[g] + 6 * g;
+	for (uint32_t c = 0; c < n; ++c) {
+		const hao_chain_rec rc = A.rec[g * HAO_MCOPY_MAX + c];
+		const uint64_t oi = A.ch_base[g] + c, hd = A.cl_base[g] + rc.hit_rel, fd = A.fc_base[g * HAO_MCOPY_MAX + c];
+		const uint32_t ord = (uint32_t)(ord0 + c);
+		if (hao_lane() == 0) {
+			hao_ovlp_t o;
+			o.x_id = (uint32_t)(A.rid_lo + r); o.x_pos_s = rc.x_pos_s; o.x_pos_e = rc.x_pos_e; o.x_pos_strand = 0;
+			o.y_id = HH_ID(src[rc.hit_rel]); o.y_pos_s = rc.y_pos_s; o.y_pos_e = rc.y_pos_e; o.y_pos_strand = rc.strand;
+			o.shared_seed = rc.score; o.align_length = rc.n_hits; o.non_homopolymer_errors = (uint32_t)(hd - cl0); o.fc_len = rc.fc_len;
+			A.ol[oi] = o; A.ol_fc_off[oi] = fd;
+		}
+		for (uint32_t i = hao_lane(); i < rc.n_hits; i += 64) { hao_hit_t h = src[rc.hit_rel + i]; h.w0 = (h.w0 & 0x80000000u) | (ord & 0x7fffffffu); A.cl[hd + i] = h; }
+		for (uint32_t i = hao_lane(); i < rc.fc_len; i += 64) A.fc[fd + i] = fsrc[rc.fc_rel + i];
+	}
+}
+
+// ---------------------------------------------------------------------------------------
+// K9: per-read chain selection on an index permutation (records never move; swaps of whole
+// structs in the reference = swaps of permutation entries here).
+// ---------------------------------------------------------------------------------------
+struct hao_sel_ctx { const hao_ovlp_t *r; uint32_t *pm; };
+__device__ __forceinline__ bool hao_lt_score(const hao_sel_ctx &S, int64_t i, int64_t j) { return S.r[S.pm[i]].shared_seed > S.r[S.pm[j]].shared_seed; }   // oreg_ss_lt
+__device__ __forceinline__ bool hao_lt_xs(const hao_sel_ctx &S, int64_t i, int64_t j)
+{ const hao_ovlp_t &a = S.r[S.pm[i]], &b = S.r[S.pm[j]]; return ((uint64_t)a.x_pos_s << 32 | a.x_pos_e) < ((uint64_t)b.x_pos_s << 32 | b.x_pos_e); }               // oreg_xs_lt
+__device__ __forceinline__ void hao_sw(const hao_sel_ctx &S, int64_t i, int64_t j) { uint32_t t = S.pm[i]; S.pm[i] = S.pm[j]; S.pm[j] = t; }
+
+template<int MODE> __device__ __forceinline__ bool hao_lt(const hao_sel_ctx &S, int64_t i, int64_t j) { return MODE == 0 ? hao_lt_score(S, i, j) : hao_lt_xs(S, i, j); }
+
+template<int MODE> __device__ void hao_ins_sort(const hao_sel_ctx &S, int64_t lo, int64_t hi)
+{ for (int64_t i = lo + 1; i < hi; ++i) for (int64_t j = i; j > lo && hao_lt<MODE>(S, j, j - 1); --j) hao_sw(S, j, j - 1); }
+
+template<int MODE> __device__ void hao_comb_sort(const hao_sel_ctx &S, int64_t lo, int64_t n)
+{
+	const double shrink = 1.2473309501039786540366528676643; int64_t gap = n; bool swapped;
+	do {
+		if (gap > 2) { gap = (int64_t)((double)gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
+		swapped = false;
+		for (int64_t i = lo; i < lo + n - gap; ++i) if (hao_lt<MODE>(S, i + gap, i)) { hao_sw(S, i, i + gap); swapped = true; }
+	} while (swapped || gap > 2);
+	if (gap != 1) hao_ins_sort<MODE>(S, lo, lo + n);
+}
+
+// klib introsort (ksort.h:110-160) restated over positions; the pivot sits at position t during partitioning
+template<int MODE> __device__ void hao_intro_sort(const hao_sel_ctx &S, int64_t n)
+{
+	int64_t stack[3 * 72], top = 0, s, t, i, j, k; int d;
+	if (n < 1) return;
+	if (n == 2) { if (hao_lt<MODE>(S, 1, 0)) hao_sw(S, 0, 1); return; }
+	for (d = 2; (1ull << d) < (uint64_t)n; ++d) {}
+	s = 0; t = n - 1; d <<= 1;
+	for (;;) {
+		if (s < t) {
+			if (--d == 0) { hao_comb_sort<MODE>(S, s, t - s + 1); t = s; continue; }
+			i = s; j = t; k = i + ((j - i) >> 1) + 1;
+			if (hao_lt<MODE>(S, k, i)) { if (hao_lt<MODE>(S, k, j)) k = j; }
+			else k = hao_lt<MODE>(S, j, i) ? i : j;
+			if (k != t) hao_sw(S, k, t);
+			for (;;) {
+				do ++i; while (hao_lt<MODE>(S, i, t));
+				do --j; while (i <= j && hao_lt<MODE>(S, t, j));
+				if (j <= i) break;
+				hao_sw(S, i, j);
+			}
+			hao_sw(S, i, t);
+			if (i - s > t - i) {
+				if (i - s > 16) { stack[top++] = s; stack[top++] = i - 1; stack[top++] = d; }
+				s = t - i > 16 ? i + 1 : t;
+			} else {
+				if (t - i > 16) { stack[top++] = i + 1; stack[top++] = t; stack[top++] = d; }
+				t = i - s > 16 ? i - 1 : s;
+			}
+		} else {
+			if (top == 0) { hao_ins_sort<MODE>(S, 0, n); return; }
+			d = (int)stack[--top]; t = stack[--top]; s = stack[--top];
+		}
+	}
+}
+
+__device__ __forceinline__ int hao_ov_type(const hao_ovlp_t &r, uint32_t len)       // ha_ov_type, anchor.cpp:86-91
+{
+	if (r.x_pos_s == 0 && r.x_pos_e == len - 1) return 2;
+	if (r.x_pos_s > 0 && r.x_pos_e < len - 1) return 3;
+	return r.x_pos_s == 0 ? 0 : 1;
+}
+
+__device__ void hao_cov_add(uint64_t *cc, uint64_t cwn, uint64_t ocv_w, uint64_t rl, uint64_t rs, uint64_t re)
+{
+	uint64_t m = rs / ocv_w, cws = m * ocv_w;
+	for (; m < cwn; ++m, cws += ocv_w) {
+		uint64_t cwe = cws + ocv_w; if (cwe > rl) cwe = rl;
+		uint64_t os = rs >= cws ? rs : cws, oe = re <= cwe ? re : cwe;
+		if (oe <= os) break;
+		if ((uint32_t)cc[m] + (oe - os) < UINT32_MAX) cc[m] += oe - os;
+		else { cc[m] >>= 32; cc[m] <<= 32; cc[m] |= UINT32_MAX; }
+	}
+}
+
+struct hao_sel_args {
+	const hao_ovlp_t *ol; const uint64_t *g_off; const uint64_t *ch_base; const uint64_t *cl_base; const hao_hit_t *cl;
+	uint64_t n_sel, rid_lo; const uint32_t *len; const uint64_t *cc_off; uint64_t *cc;
+	uint32_t *perm; uint32_t *n_final; uint64_t *fc_final;      // outputs: permutation (per read slice), kept count, kept fake-cigar entries
+	uint64_t max_n_chain, ocv_w; uint32_t chain_cutoff;
+};
+
+// one lane per read
+__global__ __launch_bounds__(64) void chain_select_kernel(hao_sel_args A)
+{
+	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r > A.n_sel) return;
+	if (r == A.n_sel) { A.n_final[r] = 0; A.fc_final[r] = 0; return; }
+	const uint64_t g0 = A.g_off[r], g1 = A.g_off[r + 1], o0 = A.ch_base[g0];
+	int64_t n = (int64_t)(A.ch_base[g1] - o0);
+	const uint64_t cl0 = A.cl_base[g0], cn = A.cl_base[g1] - cl0;      // chained hits of this read
+	const hao_hit_t *cl = A.cl + cl0;
+	hao_sel_ctx S; S.r = A.ol + o0; S.pm = A.perm + o0;
+	const uint64_t rl = A.len[A.rid_lo + r], max_n_chain = A.max_n_chain, ocv_w = A.ocv_w; const uint32_t chain_cutoff = A.chain_cutoff;
+	int64_t i; int lch = 0;
+	for (i = 0; i < n; ++i) { S.pm[i] = (uint32_t)i; if (S.r[i].align_length < chain_cutoff) lch = 1; }
+#define REC(i) S.r[S.pm[i]]
+	if ((uint64_t)n > max_n_chain) {
+		int32_t w, nn[4] = {0, 0, 0, 0}, s[4] = {0, 0, 0, 0}; uint64_t cwn = 0, *cc = A.cc + A.cc_off[r], kk, mm;
+		hao_intro_sort<0>(S, n);
+		for (i = 0; i < n; ++i) { w = hao_ov_type(REC(i), (uint32_t)rl); if ((uint64_t)++nn[w] == max_n_chain) s[w] = REC(i).shared_seed; }
+		if (s[0] > 0 || s[1] > 0 || s[2] > 0 || s[3] > 0) {
+			if ((uint64_t)nn[3] >= max_n_chain && rl >= ocv_w) {
+				uint64_t cws = 0, cwe;
+				cwn = rl / ocv_w + (rl % ocv_w ? 1 : 0);
+				for (mm = 0; mm < cwn; ++mm, cws += ocv_w) {
+					cwe = cws + ocv_w; if (cwe > rl) cwe = rl;
+					cc[mm] = (cwe - cws) * (max_n_chain >> 1); if (cc[mm] > UINT32_MAX) cc[mm] = UINT32_MAX; cc[mm] <<= 32;
+				}
+			}
+			for (i = 0, kk = 0, lch = 0; i < n; ++i) {
+				const hao_ovlp_t &q = REC(i); bool keep = false;
+				w = hao_ov_type(q, (uint32_t)rl);
+				if (q.shared_seed >= s[w]) { if (cwn) hao_cov_add(cc, cwn, ocv_w, rl, q.x_pos_s, (uint64_t)q.x_pos_e + 1); keep = true; }
+				else if (w == 3 && cwn > 0) {
+					uint64_t rs = q.x_pos_s, re = (uint64_t)q.x_pos_e + 1, cw0 = 0, cw1 = 0, cws, cwe, os, oe;
+					for (mm = rs / ocv_w, cws = mm * ocv_w; mm < cwn; ++mm, cws += ocv_w) {
+						cwe = cws + ocv_w; if (cwe > rl) cwe = rl;
+						os = rs >= cws ? rs : cws; oe = re <= cwe ? re : cwe;
+						if (oe <= os) break;
+						if ((oe - os) + (uint64_t)(uint32_t)cc[mm] >= (cc[mm] >> 32)) cw1 += oe - os; else cw0 += oe - os;
+					}
+					if ((double)cw0 >= (double)(cw0 + cw1) * 0.7) { hao_cov_add(cc, cwn, ocv_w, rl, rs, re); keep = true; }
+				}
+				if (keep) {
+					if (kk != (uint64_t)i) hao_sw(S, (int64_t)kk, i);
+					if (REC(kk).align_length < chain_cutoff) lch = 1;
+					++kk;
+				}
+			}
+			n = (int64_t)kk;
+		}
+	}
+	hao_intro_sort<1>(S, n);
+	if (lch) {
+		int64_t kk, ll;
+		for (i = ll = 0; i < n; ++i) {
+			if (REC(i).align_length < chain_cutoff) {
+				uint64_t zs = REC(i).x_pos_s, ze = (uint64_t)REC(i).x_pos_e + 1, ob = (uint64_t)((double)(ze - zs) * 0.95), ocn = (uint64_t)REC(i).align_length << 4;
+				int64_t osc = (int64_t)REC(i).shared_seed * 16;
+				if (ob < 16) ob = 16;
+				for (kk = 0; kk < n && ze > REC(kk).x_pos_s; ++kk) {
+					if (REC(kk).align_length < chain_cutoff || REC(kk).align_length < ocn || (int64_t)REC(kk).shared_seed < osc) continue;
+					uint64_t rs = REC(kk).x_pos_s, re = (uint64_t)REC(kk).x_pos_e + 1, os = rs >= zs ? rs : zs, oe = re <= ze ? re : ze;
+					if (oe > os && oe - os >= ob) {
+						uint64_t mm = REC(kk).non_homopolymer_errors, pp = HH_ID(cl[mm]), kn = 0;
+						for (; mm < cn && HH_ID(cl[mm]) == pp && kn < ocn; ++mm) {
+							uint64_t me = cl[mm].self_offset, ms = me - (cl[mm].cnt & 0xffu);
+							if (ms >= os && me <= oe) ++kn;
+						}
+						if (kn >= ocn) break;
+					}
+				}
+				if (kk < n && ze > REC(kk).x_pos_s) continue;
+			}
+			if (ll != i) hao_sw(S, ll, i);
+			++ll;
+		}
+		n = ll;
+	}
+	uint64_t fct = 0;
+	for (i = 0; i < n; ++i) fct += REC(i).fc_len;
+#undef REC
+	A.n_final[r] = (uint32_t)n; A.fc_final[r] = fct;
+}
+
+// final gather: records in final order (align_length zeroed, anchor.cpp:2098) + fake cigars in that order. One wave per read.
+__global__ __launch_bounds__(256) void chain_final_kernel(const hao_ovlp_t *ol, const uint64_t *ol_fc_off, const uint64_t *fc_raw, const uint32_t *perm,
+		const uint64_t *g_off, const uint64_t *ch_base, const uint64_t *fin_off, const uint64_t *fcf_off, uint64_t n_sel,
+		hao_ovlp_t *ol_out, uint64_t *fc_out, uint64_t *fc_out_off)
+{
+	const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= n_sel) return;
+	const uint64_t o0 = ch_base[g_off[r]], d0 = fin_off[r], n = fin_off[r + 1] - d0; uint64_t fo = fcf_off[r];
+	for (uint64_t i = 0; i < n; ++i) {
+		const uint64_t src = o0 + perm[o0 + i]; hao_ovlp_t o = ol[src]; const uint64_t fs = ol_fc_off[src];
+		if (hao_lane() == 0) { o.align_length = 0; ol_out[d0 + i] = o; fc_out_off[d0 + i] = fo; }
+		for (uint32_t j = hao_lane(); j < o.fc_len; j += 64) fc_out[fo + j] = fc_raw[fs + j];
+		fo += o.fc_len;
+	}
+}

@@ -65,7 +65,7 @@ struct hao_ctx {
 	DevBuf<uint64_t> d_ix_mz_x, d_ix_mz_info, d_ix_mz_off;  // all reads' minimizers in read order (query side reuses them)
 	DevBuf<uint64_t> d_ix_sx, d_ix_sinfo;                    // sorted by hash (stable)
 	DevBuf<uint64_t> d_ix_keys, d_ix_start; DevBuf<uint32_t> d_ix_cnt; DevBuf<uint32_t> d_ix_bucket;
-	std::vector<uint64_t> h_ix_keys, h_ix_off, h_ix_pos; bool h_ix_valid = false;
+	std::vector<uint64_t> h_ix_keys, h_ix_off, h_ix_pos, h_ix_mz_off; bool h_ix_valid = false;
 	// ---- query batch ----
 	struct Batch;
 	Batch *batch = nullptr;

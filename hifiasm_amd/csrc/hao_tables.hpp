@@ -190,7 +190,7 @@ static int hao_ft_run(hao_ctx *c)
 static int hao_pt_run(hao_ctx *c)
 {
 	const uint64_t n = c->n_reads;
-	c->has_pt = false; c->h_ix_valid = false;
+	c->has_pt = false; c->h_ix_valid = false; c->h_ix_mz_off.clear();
 	if (n == 0) { hao_set_err(c, "no reads"); return HAO_EINVAL; }
 	if (int rc = hao_sketch_run(c, 0, n, c->has_ft, c->opt.sample_dist, 1)) return rc;
 	// keep the read-ordered minimizers for the query side
