@@ -124,7 +124,7 @@ def main():
     def step():
         eng.ha_pt_gen()
         st = {k: v for k, v in eng.stage_times()}
-        tot = {"overlaps": 0, "chained_hits": 0, "seed_hits": 0, "groups": 0, "minimizers": 0}
+        tot = {"overlaps": 0, "chained_hits": 0, "seed_hits": 0, "groups": 0, "minimizers": 0, "seq_groups": 0, "seq_group_hits": 0}
         for lo in range(0, n_reads, bsz):
             eng.overlap_batch(lo, min(n_reads, lo + bsz))
             t = eng.batch_totals()
@@ -184,7 +184,8 @@ def main():
             "dtype": "u64 hashing / int32 + f64 chain scores", "data": "synthetic",
             "config": {"workload": a.workload, "reads_per_gpu": n_reads, "bases_per_gpu": rs.total_bases,
                        "overlaps_per_gpu_step": tot["overlaps"], "seed_hits_per_gpu_step": tot["seed_hits"],
-                       "chained_hits_per_gpu_step": tot["chained_hits"], "k": 51, "w": 51, "hpc": 1,
+                       "chained_hits_per_gpu_step": tot["chained_hits"], "groups_per_gpu_step": tot["groups"],
+                       "groups_on_sequential_path": tot["seq_groups"], "k": 51, "w": 51, "hpc": 1,
                        "parallelism": "1 process/GPU, reads sharded by rank, no data-path collective" if world > 1 else "single GPU",
                        "ha_ft_gen_s": round(t_ft, 3), "hom_cov_ft": hom_ft},
             "roofline": roofline,

@@ -213,7 +213,8 @@ class Engine:
     def batch_totals(self):
         out = (C.c_uint64 * 8)()
         self._ck(self.L.hao_batch_totals(self.h, out), "hao_batch_totals")
-        return dict(overlaps=int(out[0]), chained_hits=int(out[1]), seed_hits=int(out[2]), groups=int(out[3]), minimizers=int(out[4]))
+        return dict(overlaps=int(out[0]), chained_hits=int(out[1]), seed_hits=int(out[2]), groups=int(out[3]), minimizers=int(out[4]), chains=int(out[5]),
+                    seq_groups=int(out[6]), seq_group_hits=int(out[7]))
 
     def stage_times(self):
         names = (C.c_char_p * 64)()

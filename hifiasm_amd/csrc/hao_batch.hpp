@@ -5,13 +5,14 @@
 #include "hao_chain.cuh"
 
 struct hao_ctx::Batch {
+	uint64_t n_generic = 0, n_generic_hits = 0; DevBuf<unsigned long long> stats;
 	uint64_t lo = 0, n = 0, mz0 = 0, n_mz = 0, n_anchor = 0, n_groups = 0, n_chains = 0, n_cl = 0, n_fc_raw = 0, n_ol = 0, n_fc = 0;
 	bool valid = false, host_valid = false;
 	DevBuf<uint64_t> s_start, a_off, seg, keys, keys2, g_cnt, g_off, g_start, ch_base, cl_base, fc_base, fcs, fc_raw, ol_fc_off, cc_off, cc, fc_final, fin_off, fcf_off, fc_out, fc_out_off;
 	DevBuf<uint64_t> nch64;
 	DevBuf<uint32_t> s_n, g_read, wgt, nch, nout, perm, n_final, fclen;
 	DevBuf<hao_hit_t> hits, ohits, cl;
-	DevBuf<int32_t> f, ii, p; DevBuf<int64_t> t;
+	DevBuf<int32_t> f, ii, p, key_sc, tm; DevBuf<uint64_t> slow_list; DevBuf<int64_t> t; DevBuf<uint64_t> key_xs; DevBuf<uint32_t> key_al;
 	DevBuf<hao_chain_rec> rec; DevBuf<hao_ovlp_t> ol, ol_out;
 	// host copies for fetch
 	std::vector<uint64_t> h_seg, h_fin_off, h_cl_off, h_fc_out_off; std::vector<hao_hit_t> h_hits, h_cl; std::vector<hao_ovlp_t> h_ol; std::vector<uint64_t> h_fc;
@@ -20,7 +21,7 @@ struct hao_ctx::Batch {
 		s_start.release(); a_off.release(); seg.release(); keys.release(); keys2.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fin_off.release(); fcf_off.release(); fc_out.release(); fc_out_off.release();
 		nch64.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
-		hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); ol_out.release();
+		tm.release(); slow_list.release(); key_sc.release(); key_xs.release(); key_al.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); ol_out.release();
 	}
 };
 
@@ -114,12 +115,17 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi)
 	if (G) {
 		hao_chain_args ca;
 		ca.hits = B.hits.p; ca.g_start = B.g_start.p; ca.g_read = B.g_read.p; ca.g_off = B.g_off.p; ca.seg = B.seg.p; ca.n_groups = G; ca.rid_lo = lo; ca.len = c->d_len.p; ca.par = par;
+		HIP_TRY(B.stats.reserve(4)); HIP_TRY(hipMemsetAsync(B.stats.p, 0, 16, c->stream)); ca.stats = B.stats.p; ca.dbg_skip_generic = getenv("HAO_DBG_SKIP_GENERIC") ? 1 : 0; ca.dbg_seq = getenv("HAO_DBG_SEQ_CHAIN") ? 1 : 0;
+		HIP_TRY(B.tm.reserve(A + 1)); HIP_TRY(B.slow_list.reserve(G + 1)); ca.tm = B.tm.p; ca.slow_list = B.slow_list.p;
 		ca.f = B.f.p; ca.ii = B.ii.p; ca.p = B.p.p; ca.t = B.t.p; ca.ohits = B.ohits.p; ca.fcs = B.fcs.p; ca.rec = B.rec.p; ca.nch = B.nch.p; ca.nout = B.nout.p;
-		hipLaunchKernelGGL(chain_group_kernel, dim3((unsigned)((G + 63) / 64)), dim3(64), 0, c->stream, ca);
+		hipLaunchKernelGGL(chain_group_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream, ca);
 		HAO_CHECK_LAUNCH();
+		c->timer.mark("q_chain");
+		{ unsigned long long st[2]; HIP_TRY(hipMemcpyAsync(st, B.stats.p, 16, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); B.n_generic = st[0]; B.n_generic_hits = st[1]; }
+		if (B.n_generic && !ca.dbg_skip_generic) { hipLaunchKernelGGL(chain_dp_kernel, dim3((unsigned)B.n_generic), dim3(64), 0, c->stream, ca, B.n_generic); HAO_CHECK_LAUNCH(); }
 	}
 	HIP_TRY(hipMemsetAsync(B.nch.p + G, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(B.nout.p + G, 0, 4, c->stream));
-	c->timer.mark("q_chain");
+	c->timer.mark("q_chain_dp");
 	// Q7 assembly
 	HIP_TRY(B.ch_base.reserve(G + 2)); HIP_TRY(B.cl_base.reserve(G + 2)); HIP_TRY(B.fc_base.reserve(G * HAO_MCOPY_MAX + 2)); HIP_TRY(B.nch64.reserve(G * HAO_MCOPY_MAX + 2));
 	if (int rc = hao_scan_u32(c, B.nch.p, B.ch_base.p, G + 1)) return rc;
@@ -151,10 +157,12 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi)
 		HIP_TRY(hipMemcpyAsync(B.cc_off.p, cco.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 	}
+	HIP_TRY(B.key_xs.reserve(NC + 1)); HIP_TRY(B.key_sc.reserve(NC + 1)); HIP_TRY(B.key_al.reserve(NC + 1));
 	hao_sel_args sa;
+	sa.key_xs = B.key_xs.p; sa.key_sc = B.key_sc.p; sa.key_al = B.key_al.p;
 	sa.ol = B.ol.p; sa.g_off = B.g_off.p; sa.ch_base = B.ch_base.p; sa.cl_base = B.cl_base.p; sa.cl = B.cl.p; sa.n_sel = n; sa.rid_lo = lo; sa.len = c->d_len.p; sa.cc_off = B.cc_off.p; sa.cc = B.cc.p;
 	sa.perm = B.perm.p; sa.n_final = B.n_final.p; sa.fc_final = B.fc_final.p; sa.max_n_chain = par.max_n_chain; sa.ocv_w = par.ocv_w; sa.chain_cutoff = par.chain_cutoff;
-	hipLaunchKernelGGL(chain_select_kernel, dim3((unsigned)((n + 64) / 64)), dim3(64), 0, c->stream, sa);
+	hipLaunchKernelGGL(chain_select_kernel, dim3((unsigned)((n + 4) / 4)), dim3(256), 0, c->stream, sa);
 	HAO_CHECK_LAUNCH();
 	if (int rc = hao_scan_u32(c, B.n_final.p, B.fin_off.p, n + 1)) return rc;
 	if (int rc = hao_excl_scan_u64(c, B.fc_final.p, B.fcf_off.p, n + 1)) return rc;

@@ -127,7 +127,7 @@ int hao_batch_totals(hao_ctx *c, uint64_t out[8])
 	if (!c || !c->batch || !c->batch->valid) return HAO_EINVAL;
 	hao_ctx::Batch &B = *c->batch;
 	memset(out, 0, 8 * sizeof(uint64_t));
-	out[0] = B.n_ol; out[1] = B.n_cl; out[2] = B.n_anchor; out[3] = B.n_groups; out[4] = B.n_mz; out[5] = B.n_chains;
+	out[0] = B.n_ol; out[1] = B.n_cl; out[2] = B.n_anchor; out[3] = B.n_groups; out[4] = B.n_mz; out[5] = B.n_chains; out[6] = B.n_generic; out[7] = B.n_generic_hits;
 	return HAO_OK;
 }
 

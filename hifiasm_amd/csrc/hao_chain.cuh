@@ -104,13 +104,69 @@ struct hao_chain_args {
 	hao_chain_par par;
 	int32_t *f, *ii, *p; int64_t *t;             // per-hit scratch
 	hao_hit_t *ohits; uint64_t *fcs; hao_chain_rec *rec; uint32_t *nch, *nout;
+	unsigned long long *stats;                   // [0] groups needing the DP kernel, [1] their hits
+	uint64_t *slow_list; int32_t *tm;            // groups deferred to chain_dp_kernel; per-hit mark scratch for oversize groups
+	int dbg_skip_generic, dbg_seq;
 };
 
-// one lane per group
-__global__ __launch_bounds__(64) void chain_group_kernel(hao_chain_args A)
+// Sequential tail shared by both paths (ONE lane): backtrack the best chain, multi-copy chains
+// (Hash_Table.cpp:2178-2270), regions, chained hits, fake cigars.  f/p may live in LDS or global memory.
+__device__ void hao_chain_tail(const hao_chain_args &A, const uint64_t g, const hao_hit_t *a, const int64_t a_n, const hao_cpar &P,
+		int32_t *f, int32_t *p, int64_t *t, int32_t *ii, int64_t msc, int64_t msc_i, int64_t plus)
 {
-	const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (g >= A.n_groups) return;
+	const uint64_t gs = A.g_start[g];
+	hao_hit_t *des = A.ohits + gs; uint64_t *fcs = A.fcs + gs + 6 * g; hao_chain_rec *rec = A.rec + g * HAO_MCOPY_MAX;
+	int64_t cL = 0, i;
+	for (i = msc_i; i >= 0; i = p[i]) { ii[i] = 1; t[cL++] = i; }
+	// ---- multi-copy chains ----
+	if (A.par.mcopy_num > 1 && cL >= A.par.mcopy_khit_cut) {
+		int64_t ch_n, min_sc;
+		msc -= plus; min_sc = (int64_t)((double)msc * A.par.mcopy_rate); ii[msc_i] = 0;
+		for (i = ch_n = 0; i < a_n; ++i) {
+			f[i] -= (int32_t)plus; if (i >= ch_n) t[i] = 0;
+			if (!ii[i] && f[i] >= min_sc) { t[ch_n] = (int64_t)((uint64_t)f[i] << 32); t[ch_n] += i << 1; ++ch_n; }
+		}
+		if (ch_n > 1) {
+			int64_t n_v = 0, n_v0, n_u = 0, k, sc, j, ni; uint32_t fcn = 0;
+			hao_heapsort_i64(t, ch_n);
+			uint32_t c_nv0[HAO_MCOPY_MAX], c_ni[HAO_MCOPY_MAX];
+			for (k = ch_n - 1; k >= 0 && n_u < A.par.mcopy_num; --k) {
+				n_v0 = n_v;
+				for (i = (int64_t)((uint32_t)t[k] >> 1); i >= 0 && (t[i] & 1) == 0; ) { ii[n_v++] = (int32_t)i; t[i] |= 1; i = p[i]; }
+				if (n_v0 == n_v) continue;
+				sc = i < 0 ? (t[k] >> 32) : ((t[k] >> 32) - f[i]);
+				if (sc >= min_sc) {
+					if (!n_u || n_v - n_v0 > 1) {
+						hao_region(rec[n_u], P.xl, P.yl, sc + plus, a[ii[n_v - 1]], a[ii[n_v0]]);
+						c_nv0[n_u] = (uint32_t)n_v0; c_ni[n_u] = (uint32_t)(n_v - n_v0); ++n_u;
+					} else n_v = n_v0;
+				} else n_v = n_v0;
+			}
+			// chain member lists live in ii[]; stage the hits through the tail of t[] is not possible (t holds marks), so
+			// write each chain to des[] from a private walk: des and a may alias only if des == a (they do not: separate buffers)
+			for (k = 0, i = 0; k < n_u; ++k) {
+				n_v0 = c_nv0[k]; ni = c_ni[k];
+				rec[k].hit_rel = (uint32_t)i; rec[k].n_hits = (uint32_t)ni;
+				for (j = 0; j < ni; ++j, ++i) des[i] = a[ii[n_v0 + (ni - j - 1)]];
+				rec[k].fc_rel = fcn; rec[k].fc_len = hao_fake_cigar(fcs + fcn, rec[k], des + i - ni, ni); fcn += rec[k].fc_len;
+			}
+			A.nch[g] = (uint32_t)n_u; A.nout[g] = (uint32_t)i;
+			return;
+		} else {
+			msc += plus; i = msc_i; cL = 0;
+			while (i >= 0) { t[cL++] = i; i = p[i]; }
+		}
+	}
+	hao_region(rec[0], P.xl, P.yl, msc, a[t[cL - 1]], a[t[0]]);
+	for (i = 0; i < cL; ++i) des[i] = a[t[cL - i - 1]];
+	rec[0].hit_rel = 0; rec[0].n_hits = (uint32_t)cL; rec[0].fc_rel = 0; rec[0].fc_len = hao_fake_cigar(fcs, rec[0], des, cL);
+	A.nch[g] = 1; A.nout[g] = (uint32_t)cL;
+}
+
+
+// Generic path, executed by ONE lane: the full sequential algorithm (quick check, DP, multi-copy).
+__device__ void hao_chain_generic(const hao_chain_args &A, const uint64_t g)
+{
 	const uint32_t r = A.g_read[g]; const uint64_t gs = A.g_start[g], ge = (g + 1 < A.g_off[r + 1]) ? A.g_start[g + 1] : A.seg[r + 1];
 	const hao_hit_t *a = A.hits + gs; const int64_t a_n = (int64_t)(ge - gs);
 	const uint32_t xid = (uint32_t)(A.rid_lo + r), yid = HH_ID(a[0]);
@@ -194,51 +250,243 @@ __global__ __launch_bounds__(64) void chain_group_kernel(hao_chain_args A)
 			ii[i] = 0;
 		}
 	}
-	int64_t cL = 0, i;
-	for (i = msc_i; i >= 0; i = p[i]) { ii[i] = 1; t[cL++] = i; }
-	// ---- multi-copy chains ----
-	if (A.par.mcopy_num > 1 && cL >= A.par.mcopy_khit_cut) {
-		int64_t ch_n, min_sc;
-		msc -= plus; min_sc = (int64_t)((double)msc * A.par.mcopy_rate); ii[msc_i] = 0;
-		for (i = ch_n = 0; i < a_n; ++i) {
-			f[i] -= (int32_t)plus; if (i >= ch_n) t[i] = 0;
-			if (!ii[i] && f[i] >= min_sc) { t[ch_n] = (int64_t)((uint64_t)f[i] << 32); t[ch_n] += i << 1; ++ch_n; }
+	hao_chain_tail(A, g, a, a_n, P, f, p, t, ii, msc, msc_i, plus);
+}
+
+__device__ __forceinline__ hao_hit_t hao_shfl_hit(const hao_hit_t &h, int src)
+{ hao_hit_t o; o.w0 = __shfl(h.w0, src); o.offset = __shfl(h.offset, src); o.self_offset = __shfl(h.self_offset, src); o.cnt = __shfl(h.cnt, src); return o; }
+__device__ __forceinline__ hao_hit_t hao_shfl_up_hit(const hao_hit_t &h)
+{ hao_hit_t o; o.w0 = __shfl_up(h.w0, 1); o.offset = __shfl_up(h.offset, 1); o.self_offset = __shfl_up(h.self_offset, 1); o.cnt = __shfl_up(h.cnt, 1); return o; }
+
+// One wave per (query,target) group.
+// Fast path (data-parallel): every strand block passes quick_ck_lchain - a segmented prefix sum of pair
+// scores with per-pair validity flags - and no second chain qualifies for multi-copy output; then the best
+// block IS the chain: hits are copied through, the fake cigar is a flagged compaction.  >99.9 % of groups on
+// repeat-free genomes.  Everything else runs hao_chain_generic on lane 0 (exact sequential algorithm).
+__global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A)
+{
+	const uint64_t g = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (g >= A.n_groups) return;
+	const int lane = hao_lane();
+	const uint32_t r = A.g_read[g]; const uint64_t gs = A.g_start[g], ge = (g + 1 < A.g_off[r + 1]) ? A.g_start[g + 1] : A.seg[r + 1];
+	const hao_hit_t *a = A.hits + gs; const int64_t a_n = (int64_t)(ge - gs);
+	const uint32_t xid = (uint32_t)(A.rid_lo + r), yid = HH_ID(a[0]);
+	if (yid == xid || a_n <= 0) { if (lane == 0) { A.nch[g] = 0; A.nout[g] = 0; } return; }
+	hao_cpar P; P.pen_gap = A.par.pen_gap; P.pen_skip = A.par.pen_skip; P.bw = A.par.bw; P.max_skip = A.par.max_skip; P.max_iter = A.par.max_iter; P.max_dis = A.par.max_dis;
+	P.xl = A.len[xid]; P.yl = A.len[yid];
+	const uint32_t strand0 = HH_STRAND(a[0]);
+	// ---- parallel quick check ----
+	int32_t carry_f = 0; hao_hit_t carry_h = a[0];
+	bool fail0 = false, fail1 = false; int32_t maxf0 = INT32_MIN, maxf1 = INT32_MIN, flast0 = 0, flast1 = 0; int64_t ddt0 = 0, ddt1 = 0, k1 = 0;
+	hao_hit_t last0 = a[0], last1 = a[0];
+	for (int64_t t0 = 0; t0 < a_n; t0 += 64) {
+		const int64_t idx = t0 + lane; const bool act = idx < a_n;
+		hao_hit_t h = act ? a[idx] : carry_h;
+		hao_hit_t ph = hao_shfl_up_hit(h); if (lane == 0) ph = carry_h;
+		const bool st = act && (idx == 0 || HH_STRAND(h) != HH_STRAND(ph));
+		const int b = act && HH_STRAND(h) != strand0;
+		int32_t s = HH_SPAN(h); bool ok = true; int64_t dd = 0;
+		if (act && !st) { s = hao_pair_score(h, ph, P, &dd); ok = s != INT32_MIN; if (!ok) { s = 0; dd = 0; } }
+		int32_t x = act ? s : 0; int fl = st;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { int32_t x2 = __shfl_up(x, d); int f2 = __shfl_up(fl, d); if (lane >= d) { if (!fl) x += x2; fl |= f2; } }
+		if (!fl) x += carry_f;
+		const int32_t f = x; int32_t fp = __shfl_up(f, 1); if (lane == 0) fp = carry_f;
+		const bool brk = act && !st && (!ok || (int64_t)s + fp < (int64_t)HH_SPAN(h));
+		if (__ballot(brk && b == 0)) fail0 = true;
+		if (__ballot(brk && b == 1)) fail1 = true;
+		if (act) { if (b == 0) { maxf0 = max(maxf0, f); ddt0 += dd; } else { maxf1 = max(maxf1, f); ddt1 += dd; } }
+		k1 += __popcll(__ballot(act && b == 0));
+		const bool isend = act && (idx == a_n - 1 || HH_STRAND(a[idx + 1]) != HH_STRAND(h));
+		unsigned long long m0 = __ballot(isend && b == 0), m1 = __ballot(isend && b == 1);
+		if (m0) { int src = __ffsll((long long)m0) - 1; flast0 = __shfl(f, src); last0 = hao_shfl_hit(h, src); }
+		if (m1) { int src = __ffsll((long long)m1) - 1; flast1 = __shfl(f, src); last1 = hao_shfl_hit(h, src); }
+		carry_f = __shfl(f, 63); carry_h = hao_shfl_hit(h, 63);
+	}
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) {
+		maxf0 = max(maxf0, __shfl_xor(maxf0, d)); maxf1 = max(maxf1, __shfl_xor(maxf1, d));
+		ddt0 += __shfl_xor(ddt0, d); ddt1 += __shfl_xor(ddt1, d);
+	}
+	const bool two = k1 < a_n;
+	const hao_hit_t first0 = a[0], first1 = two ? a[k1] : a[0];
+	bool acc0 = !fail0 && flast0 == maxf0 && !(k1 >= 2 && ddt0 > 16 && ddt0 > hao_band(last0, first0, P));
+	bool acc1 = two && !fail1 && flast1 == maxf1 && !(a_n - k1 >= 2 && ddt1 > 16 && ddt1 > hao_band(last1, first1, P));
+	bool fast = acc0 && (!two || acc1);
+	int best = 0; int64_t msc = flast0;
+	if (fast && two) {
+		int64_t ov0 = hao_ext_len(last0.self_offset, last0.self_offset, P.xl, last0.offset, last0.offset, P.yl);
+		int64_t ov1 = hao_ext_len(last1.self_offset, last1.self_offset, P.xl, last1.offset, last1.offset, P.yl);
+		if (flast1 >= flast0 && (flast1 > flast0 || ov1 < ov0)) { best = 1; msc = flast1; }
+	}
+	const int64_t bl = best ? k1 : 0, cL = best ? a_n - k1 : k1;
+	if (fast && A.par.mcopy_num > 1 && cL >= A.par.mcopy_khit_cut && two) {
+		int64_t min_sc = (int64_t)((double)msc * A.par.mcopy_rate);          // plus == 0 here: every f >= span > 0
+		if ((int64_t)(best ? maxf0 : maxf1) >= min_sc) fast = false;         // a second chain may qualify: exact sequential path
+	}
+	if (!fast) {
+		if (lane == 0) { unsigned long long si_ = atomicAdd(A.stats, 1ULL); atomicAdd(A.stats + 1, (unsigned long long)a_n); A.slow_list[si_] = g; A.nch[g] = 0; A.nout[g] = 0; }
+		return;
+	}
+	// ---- single chain = the whole best block ----
+	hao_hit_t *des = A.ohits + gs; uint64_t *fcs = A.fcs + gs + 6 * g; hao_chain_rec rc;
+	hao_region(rc, P.xl, P.yl, msc, best ? first1 : first0, best ? last1 : last0);
+	uint32_t cnt = 1; int64_t carry_dd = INT32_MAX; uint32_t last_site = 0; int64_t last_dd = 0;
+	if (lane == 0) fcs[0] = hao_fc_entry(rc.x_pos_s, 0);
+	for (int64_t t0 = 0; t0 < cL; t0 += 64) {
+		const int64_t k = t0 + lane; const bool act = k < cL;
+		hao_hit_t h = act ? a[bl + k] : a[bl];
+		if (act) des[k] = h;
+		int64_t dd = ((int64_t)h.offset - rc.y_pos_s) - ((int64_t)h.self_offset - rc.x_pos_s);
+		int64_t pd = __shfl_up(dd, 1); if (lane == 0) pd = carry_dd;
+		const bool flag = act && dd != pd;
+		unsigned long long bal = __ballot(flag);
+		if (flag) fcs[cnt + __popcll(bal & ((1ULL << lane) - 1))] = hao_fc_entry(h.self_offset, (int32_t)dd);
+		if (bal) { int src = 63 - __clzll((long long)bal); last_site = __shfl(h.self_offset, src); last_dd = __shfl(dd, src); }
+		cnt += __popcll(bal); carry_dd = __shfl(dd, 63);
+	}
+	if (last_site != rc.x_pos_e) { if (lane == 0) fcs[cnt] = hao_fc_entry(rc.x_pos_e, (int32_t)last_dd); ++cnt; }
+	if (lane == 0) {
+		rc.hit_rel = 0; rc.n_hits = (uint32_t)cL; rc.fc_rel = 0; rc.fc_len = cnt;
+		A.rec[g * HAO_MCOPY_MAX] = rc; A.nch[g] = 1; A.nout[g] = (uint32_t)cL;
+	}
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Groups the quick check does not settle: one wave per group.
+//   * quick check again, data-parallel, this time storing f/p of every block (accepted blocks keep them);
+//   * the chain DP (Hash_Table.cpp:2124-2176) stays sequential in i, but the inner predecessor loop is
+//     evaluated 64 candidates at a time: pair scores in parallel, "t[p[j]] = i" marks through LDS (a mark
+//     can only land on a smaller j, so publishing a whole tile before reading is order-safe), an exclusive
+//     prefix maximum decides which candidates improve, and the n_skip / max_skip early exit is replayed over
+//     two ballot masks by scalar code - bit-identical to the sequential scan;
+//   * backtrack / multi-copy / output: hao_chain_tail on lane 0.
+// f, p and the marks live in LDS for groups up to HAO_DP_CAP hits, else in global scratch.
+// ---------------------------------------------------------------------------------------
+#define HAO_DP_CAP 2048
+
+__global__ __launch_bounds__(64) void chain_dp_kernel(hao_chain_args A, uint64_t n_slow)
+{
+	__shared__ int32_t l_f[HAO_DP_CAP], l_p[HAO_DP_CAP], l_tm[HAO_DP_CAP];
+	if (blockIdx.x >= n_slow) return;
+	const uint64_t g = A.slow_list[blockIdx.x];
+	const int lane = hao_lane();
+	if (A.dbg_seq) { if (lane == 0) hao_chain_generic(A, g); return; }
+	const uint32_t r = A.g_read[g]; const uint64_t gs = A.g_start[g], ge = (g + 1 < A.g_off[r + 1]) ? A.g_start[g + 1] : A.seg[r + 1];
+	const hao_hit_t *a = A.hits + gs; const int64_t a_n = (int64_t)(ge - gs);
+	const uint32_t xid = (uint32_t)(A.rid_lo + r), yid = HH_ID(a[0]);
+	hao_cpar P; P.pen_gap = A.par.pen_gap; P.pen_skip = A.par.pen_skip; P.bw = A.par.bw; P.max_skip = A.par.max_skip; P.max_iter = A.par.max_iter; P.max_dis = A.par.max_dis;
+	P.xl = A.len[xid]; P.yl = A.len[yid];
+	const bool in_lds = a_n <= HAO_DP_CAP;
+	int32_t *f = in_lds ? l_f : A.f + gs, *p = in_lds ? l_p : A.p + gs, *tm = in_lds ? l_tm : A.tm + gs;
+	int32_t *ii = A.ii + gs; int64_t *t = A.t + gs;
+	const uint32_t strand0 = HH_STRAND(a[0]);
+	// ---- parallel quick check, storing f/p ----
+	int32_t carry_f = 0; hao_hit_t carry_h = a[0];
+	bool fail0 = false, fail1 = false; int32_t maxf0 = INT32_MIN, maxf1 = INT32_MIN, flast0 = 0, flast1 = 0; int64_t ddt0 = 0, ddt1 = 0, k1 = 0;
+	hao_hit_t last0 = a[0], last1 = a[0];
+	for (int64_t t0 = 0; t0 < a_n; t0 += 64) {
+		const int64_t idx = t0 + lane; const bool act = idx < a_n;
+		hao_hit_t h = act ? a[idx] : carry_h;
+		hao_hit_t ph = hao_shfl_up_hit(h); if (lane == 0) ph = carry_h;
+		const bool st = act && (idx == 0 || HH_STRAND(h) != HH_STRAND(ph));
+		const int b = act && HH_STRAND(h) != strand0;
+		int32_t s = HH_SPAN(h); bool ok = true; int64_t dd = 0;
+		if (act && !st) { s = hao_pair_score(h, ph, P, &dd); ok = s != INT32_MIN; if (!ok) { s = 0; dd = 0; } }
+		int32_t x = act ? s : 0; int fl = st;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { int32_t x2 = __shfl_up(x, d); int f2 = __shfl_up(fl, d); if (lane >= d) { if (!fl) x += x2; fl |= f2; } }
+		if (!fl) x += carry_f;
+		const int32_t fv = x; int32_t fp = __shfl_up(fv, 1); if (lane == 0) fp = carry_f;
+		const bool brk = act && !st && (!ok || (int64_t)s + fp < (int64_t)HH_SPAN(h));
+		if (__ballot(brk && b == 0)) fail0 = true;
+		if (__ballot(brk && b == 1)) fail1 = true;
+		if (act) { if (b == 0) { maxf0 = max(maxf0, fv); ddt0 += dd; } else { maxf1 = max(maxf1, fv); ddt1 += dd; } f[idx] = fv; p[idx] = st ? -1 : (int32_t)(idx - 1); tm[idx] = -1; ii[idx] = 0; t[idx] = 0; }
+		k1 += __popcll(__ballot(act && b == 0));
+		const bool isend = act && (idx == a_n - 1 || HH_STRAND(a[idx + 1]) != HH_STRAND(h));
+		unsigned long long m0 = __ballot(isend && b == 0), m1 = __ballot(isend && b == 1);
+		if (m0) { int src = __ffsll((long long)m0) - 1; flast0 = __shfl(fv, src); last0 = hao_shfl_hit(h, src); }
+		if (m1) { int src = __ffsll((long long)m1) - 1; flast1 = __shfl(fv, src); last1 = hao_shfl_hit(h, src); }
+		carry_f = __shfl(fv, 63); carry_h = hao_shfl_hit(h, 63);
+	}
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) {
+		maxf0 = max(maxf0, __shfl_xor(maxf0, d)); maxf1 = max(maxf1, __shfl_xor(maxf1, d));
+		ddt0 += __shfl_xor(ddt0, d); ddt1 += __shfl_xor(ddt1, d);
+	}
+	const bool two = k1 < a_n;
+	const hao_hit_t first0 = a[0], first1 = two ? a[k1] : a[0];
+	const bool acc0 = !fail0 && flast0 == maxf0 && !(k1 >= 2 && ddt0 > 16 && ddt0 > hao_band(last0, first0, P));
+	const bool acc1 = two && !fail1 && flast1 == maxf1 && !(a_n - k1 >= 2 && ddt1 > 16 && ddt1 > hao_band(last1, first1, P));
+	int64_t plus = 0, msc = INT32_MIN, msc_i = INT32_MIN, movl = INT32_MAX, si = 0, ei = a_n;
+	if (acc0) {     // quick_ck_lchain bookkeeping for an accepted block (Hash_Table.cpp:2075-2088)
+		msc = flast0; msc_i = k1 - 1; movl = hao_ext_len(last0.self_offset, last0.self_offset, P.xl, last0.offset, last0.offset, P.yl);
+		if (ei > k1) si = k1; else ei = 0;
+	}
+	if (acc1) {
+		if ((int64_t)flast1 >= msc) {
+			int64_t ov = hao_ext_len(last1.self_offset, last1.self_offset, P.xl, last1.offset, last1.offset, P.yl);
+			if ((int64_t)flast1 > msc || ov < movl) { msc = flast1; msc_i = a_n - 1; movl = ov; }
 		}
-		if (ch_n > 1) {
-			int64_t n_v = 0, n_v0, n_u = 0, k, sc, j, ni; uint32_t fcn = 0;
-			hao_heapsort_i64(t, ch_n);
-			uint32_t c_nv0[HAO_MCOPY_MAX], c_ni[HAO_MCOPY_MAX];
-			for (k = ch_n - 1; k >= 0 && n_u < A.par.mcopy_num; --k) {
-				n_v0 = n_v;
-				for (i = (int64_t)((uint32_t)t[k] >> 1); i >= 0 && (t[i] & 1) == 0; ) { ii[n_v++] = (int32_t)i; t[i] |= 1; i = p[i]; }
-				if (n_v0 == n_v) continue;
-				sc = i < 0 ? (t[k] >> 32) : ((t[k] >> 32) - f[i]);
-				if (sc >= min_sc) {
-					if (!n_u || n_v - n_v0 > 1) {
-						hao_region(rec[n_u], P.xl, P.yl, sc + plus, a[ii[n_v - 1]], a[ii[n_v0]]);
-						c_nv0[n_u] = (uint32_t)n_v0; c_ni[n_u] = (uint32_t)(n_v - n_v0); ++n_u;
-					} else n_v = n_v0;
-				} else n_v = n_v0;
+		if (ei > a_n) si = a_n; else ei = k1;
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	// ---- DP over [si, ei) ----
+	{
+		int64_t i, st, max_ii = -1;
+		for (i = st = si; i < ei; ++i) {
+			const hao_hit_t hi = a[i];
+			int64_t max_f = HH_SPAN(hi), n_skip = 0, max_j = -1, end_j;
+			if (i - st > P.max_iter) st = i - P.max_iter;
+			while (HH_STRAND(hi) != HH_STRAND(a[st])) ++st;
+			end_j = st - 1;
+			for (int64_t jb = i - 1; jb >= st; jb -= 64) {
+				const int64_t j = jb - lane; const bool actv = j >= st;
+				int32_t s = INT32_MIN; hao_hit_t hj; int32_t pj = -1; int64_t sc = INT64_MIN;
+				if (actv) { hj = a[j]; s = hao_pair_score(hi, hj, P, nullptr); }
+				const bool valid = actv && s != INT32_MIN;
+				if (valid) { sc = (int64_t)s + f[j]; pj = p[j]; if (pj >= 0) tm[pj] = (int32_t)i; }
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				const bool mark = valid && tm[j] == (int32_t)i;
+				// exclusive prefix maximum of sc over the lanes before me, seeded with max_f
+				int64_t pm = sc;
+#pragma unroll
+				for (int d = 1; d < 64; d <<= 1) { int64_t y = __shfl_up(pm, d); if (lane >= d && y > pm) pm = y; }
+				pm = __shfl_up(pm, 1); if (lane == 0) pm = INT64_MIN;
+				if (pm < max_f) pm = max_f;
+				const bool improve = valid && sc > pm;
+				unsigned long long imask = __ballot(improve), cmask = __ballot(valid && !improve && mark), ev = imask | cmask;
+				int brk_lane = -1;
+				while (ev) {
+					int l = __ffsll((long long)ev) - 1; ev &= ev - 1;
+					if (imask >> l & 1) { if (n_skip > 0) --n_skip; }
+					else if (++n_skip > P.max_skip) { brk_lane = l; break; }
+				}
+				if (brk_lane >= 0) imask &= (1ULL << brk_lane) - 1;
+				if (imask) { int src = 63 - __clzll((long long)imask); max_f = __shfl(sc, src); max_j = jb - src; }
+				if (brk_lane >= 0) { end_j = jb - brk_lane; break; }
 			}
-			// chain member lists live in ii[]; stage the hits through the tail of t[] is not possible (t holds marks), so
-			// write each chain to des[] from a private walk: des and a may alias only if des == a (they do not: separate buffers)
-			for (k = 0, i = 0; k < n_u; ++k) {
-				n_v0 = c_nv0[k]; ni = c_ni[k];
-				rec[k].hit_rel = (uint32_t)i; rec[k].n_hits = (uint32_t)ni;
-				for (j = 0; j < ni; ++j, ++i) des[i] = a[ii[n_v0 + (ni - j - 1)]];
-				rec[k].fc_rel = fcn; rec[k].fc_len = hao_fake_cigar(fcs + fcn, rec[k], des + i - ni, ni); fcn += rec[k].fc_len;
+			if (max_ii < 0 || (int64_t)hi.self_offset > (int64_t)a[max_ii].self_offset + P.max_dis || HH_STRAND(hi) != HH_STRAND(a[max_ii])) {
+				int32_t mx = INT32_MIN; max_ii = -1;     // rare: rebuild the "best recent predecessor" (uniform sequential scan)
+				for (int64_t j = i - 1; j >= st && (int64_t)hi.self_offset <= P.max_dis + (int64_t)a[j].self_offset && HH_STRAND(hi) == HH_STRAND(a[j]); --j)
+					if (mx < f[j]) { mx = f[j]; max_ii = j; }
 			}
-			A.nch[g] = (uint32_t)n_u; A.nout[g] = (uint32_t)i;
-			return;
-		} else {
-			msc += plus; i = msc_i; cL = 0;
-			while (i >= 0) { t[cL++] = i; i = p[i]; }
+			if (max_ii >= 0 && max_ii < end_j && HH_STRAND(hi) == HH_STRAND(a[max_ii])) {
+				int32_t tmp = hao_pair_score(hi, a[max_ii], P, nullptr);
+				if (tmp != INT32_MIN && max_f < (int64_t)tmp + f[max_ii]) { max_f = (int64_t)tmp + f[max_ii]; max_j = max_ii; }
+			}
+			if (lane == 0) { f[i] = (int32_t)max_f; p[i] = (int32_t)max_j; }
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			if (max_ii < 0 || ((int64_t)hi.self_offset <= P.max_dis + (int64_t)a[max_ii].self_offset && HH_STRAND(hi) == HH_STRAND(a[max_ii]) && f[max_ii] < (int32_t)max_f)) max_ii = i;
+			if ((int32_t)max_f >= msc) {
+				int64_t ovl = hao_ext_len(hi.self_offset, hi.self_offset, P.xl, hi.offset, hi.offset, P.yl);
+				if ((int32_t)max_f > msc || ovl < movl) { msc = (int32_t)max_f; msc_i = i; movl = ovl; }
+			}
+			if ((int32_t)max_f < plus) plus = (int32_t)max_f;
 		}
 	}
-	hao_region(rec[0], P.xl, P.yl, msc, a[t[cL - 1]], a[t[0]]);
-	for (i = 0; i < cL; ++i) des[i] = a[t[cL - i - 1]];
-	rec[0].hit_rel = 0; rec[0].n_hits = (uint32_t)cL; rec[0].fc_rel = 0; rec[0].fc_len = hao_fake_cigar(fcs, rec[0], des, cL);
-	A.nch[g] = 1; A.nout[g] = (uint32_t)cL;
+	if (lane == 0) hao_chain_tail(A, g, a, a_n, P, f, p, t, ii, msc, msc_i, plus);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -278,15 +526,19 @@ __global__ __launch_bounds__(256) void chain_assemble_kernel(hao_asm_args A)
 
 // ---------------------------------------------------------------------------------------
 // K9: per-read chain selection on an index permutation (records never move; swaps of whole
-// structs in the reference = swaps of permutation entries here).
+// structs in the reference = swaps of permutation entries here).  One wave per read: all
+// lanes stage the sort keys (query interval, score, hit count) into LDS, lane 0 replays the
+// order-dependent sequential algorithm (klib introsort tie order is observable) on LDS-resident
+// keys, all lanes write the permutation back.  Reads with more chains than the LDS slice holds
+// use global scratch for the keys.
 // ---------------------------------------------------------------------------------------
-struct hao_sel_ctx { const hao_ovlp_t *r; uint32_t *pm; };
-__device__ __forceinline__ bool hao_lt_score(const hao_sel_ctx &S, int64_t i, int64_t j) { return S.r[S.pm[i]].shared_seed > S.r[S.pm[j]].shared_seed; }   // oreg_ss_lt
-__device__ __forceinline__ bool hao_lt_xs(const hao_sel_ctx &S, int64_t i, int64_t j)
-{ const hao_ovlp_t &a = S.r[S.pm[i]], &b = S.r[S.pm[j]]; return ((uint64_t)a.x_pos_s << 32 | a.x_pos_e) < ((uint64_t)b.x_pos_s << 32 | b.x_pos_e); }               // oreg_xs_lt
+#define HAO_SEL_CAP 512
+struct hao_sel_ctx { const uint64_t *xs; const int32_t *sc; const uint32_t *al; uint32_t *pm; };
 __device__ __forceinline__ void hao_sw(const hao_sel_ctx &S, int64_t i, int64_t j) { uint32_t t = S.pm[i]; S.pm[i] = S.pm[j]; S.pm[j] = t; }
-
-template<int MODE> __device__ __forceinline__ bool hao_lt(const hao_sel_ctx &S, int64_t i, int64_t j) { return MODE == 0 ? hao_lt_score(S, i, j) : hao_lt_xs(S, i, j); }
+template<int MODE> __device__ __forceinline__ bool hao_lt(const hao_sel_ctx &S, int64_t i, int64_t j)
+{	// MODE 0: oreg_ss_lt (score, descending; anchor.cpp:35)   MODE 1: oreg_xs_lt ((x_pos_s, x_pos_e) ascending; anchor.cpp:32)
+	return MODE == 0 ? S.sc[S.pm[i]] > S.sc[S.pm[j]] : S.xs[S.pm[i]] < S.xs[S.pm[j]];
+}
 
 template<int MODE> __device__ void hao_ins_sort(const hao_sel_ctx &S, int64_t lo, int64_t hi)
 { for (int64_t i = lo + 1; i < hi; ++i) for (int64_t j = i; j > lo && hao_lt<MODE>(S, j, j - 1); --j) hao_sw(S, j, j - 1); }
@@ -338,11 +590,12 @@ template<int MODE> __device__ void hao_intro_sort(const hao_sel_ctx &S, int64_t 
 	}
 }
 
-__device__ __forceinline__ int hao_ov_type(const hao_ovlp_t &r, uint32_t len)       // ha_ov_type, anchor.cpp:86-91
+__device__ __forceinline__ int hao_ov_type(uint64_t xs, uint32_t len)       // ha_ov_type, anchor.cpp:86-91
 {
-	if (r.x_pos_s == 0 && r.x_pos_e == len - 1) return 2;
-	if (r.x_pos_s > 0 && r.x_pos_e < len - 1) return 3;
-	return r.x_pos_s == 0 ? 0 : 1;
+	const uint32_t x_pos_s = (uint32_t)(xs >> 32), x_pos_e = (uint32_t)xs;
+	if (x_pos_s == 0 && x_pos_e == len - 1) return 2;
+	if (x_pos_s > 0 && x_pos_e < len - 1) return 3;
+	return x_pos_s == 0 ? 0 : 1;
 }
 
 __device__ void hao_cov_add(uint64_t *cc, uint64_t cwn, uint64_t ocv_w, uint64_t rl, uint64_t rs, uint64_t re)
@@ -360,29 +613,23 @@ __device__ void hao_cov_add(uint64_t *cc, uint64_t cwn, uint64_t ocv_w, uint64_t
 struct hao_sel_args {
 	const hao_ovlp_t *ol; const uint64_t *g_off; const uint64_t *ch_base; const uint64_t *cl_base; const hao_hit_t *cl;
 	uint64_t n_sel, rid_lo; const uint32_t *len; const uint64_t *cc_off; uint64_t *cc;
-	uint32_t *perm; uint32_t *n_final; uint64_t *fc_final;      // outputs: permutation (per read slice), kept count, kept fake-cigar entries
+	uint64_t *key_xs; int32_t *key_sc; uint32_t *key_al;          // global key scratch (reads with > HAO_SEL_CAP chains)
+	uint32_t *perm; uint32_t *n_final; uint64_t *fc_final;        // outputs: permutation (per read slice), kept count, kept fake-cigar entries
 	uint64_t max_n_chain, ocv_w; uint32_t chain_cutoff;
 };
 
-// one lane per read
-__global__ __launch_bounds__(64) void chain_select_kernel(hao_sel_args A)
+// the sequential part (lane 0). returns the kept count
+__device__ int64_t hao_select_seq(const hao_sel_args &A, const hao_sel_ctx &S, int64_t n, int lch, uint64_t r, const hao_ovlp_t *rec, const hao_hit_t *cl, uint64_t cn)
 {
-	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (r > A.n_sel) return;
-	if (r == A.n_sel) { A.n_final[r] = 0; A.fc_final[r] = 0; return; }
-	const uint64_t g0 = A.g_off[r], g1 = A.g_off[r + 1], o0 = A.ch_base[g0];
-	int64_t n = (int64_t)(A.ch_base[g1] - o0);
-	const uint64_t cl0 = A.cl_base[g0], cn = A.cl_base[g1] - cl0;      // chained hits of this read
-	const hao_hit_t *cl = A.cl + cl0;
-	hao_sel_ctx S; S.r = A.ol + o0; S.pm = A.perm + o0;
 	const uint64_t rl = A.len[A.rid_lo + r], max_n_chain = A.max_n_chain, ocv_w = A.ocv_w; const uint32_t chain_cutoff = A.chain_cutoff;
-	int64_t i; int lch = 0;
-	for (i = 0; i < n; ++i) { S.pm[i] = (uint32_t)i; if (S.r[i].align_length < chain_cutoff) lch = 1; }
-#define REC(i) S.r[S.pm[i]]
+	int64_t i;
+#define XS(i) S.xs[S.pm[i]]
+#define SC(i) S.sc[S.pm[i]]
+#define AL(i) S.al[S.pm[i]]
 	if ((uint64_t)n > max_n_chain) {
 		int32_t w, nn[4] = {0, 0, 0, 0}, s[4] = {0, 0, 0, 0}; uint64_t cwn = 0, *cc = A.cc + A.cc_off[r], kk, mm;
 		hao_intro_sort<0>(S, n);
-		for (i = 0; i < n; ++i) { w = hao_ov_type(REC(i), (uint32_t)rl); if ((uint64_t)++nn[w] == max_n_chain) s[w] = REC(i).shared_seed; }
+		for (i = 0; i < n; ++i) { w = hao_ov_type(XS(i), (uint32_t)rl); if ((uint64_t)++nn[w] == max_n_chain) s[w] = SC(i); }
 		if (s[0] > 0 || s[1] > 0 || s[2] > 0 || s[3] > 0) {
 			if ((uint64_t)nn[3] >= max_n_chain && rl >= ocv_w) {
 				uint64_t cws = 0, cwe;
@@ -393,11 +640,12 @@ __global__ __launch_bounds__(64) void chain_select_kernel(hao_sel_args A)
 				}
 			}
 			for (i = 0, kk = 0, lch = 0; i < n; ++i) {
-				const hao_ovlp_t &q = REC(i); bool keep = false;
-				w = hao_ov_type(q, (uint32_t)rl);
-				if (q.shared_seed >= s[w]) { if (cwn) hao_cov_add(cc, cwn, ocv_w, rl, q.x_pos_s, (uint64_t)q.x_pos_e + 1); keep = true; }
+				const uint64_t xs = XS(i); bool keep = false;
+				const uint64_t rs = xs >> 32, re = (uint64_t)(uint32_t)xs + 1;
+				w = hao_ov_type(xs, (uint32_t)rl);
+				if (SC(i) >= s[w]) { if (cwn) hao_cov_add(cc, cwn, ocv_w, rl, rs, re); keep = true; }
 				else if (w == 3 && cwn > 0) {
-					uint64_t rs = q.x_pos_s, re = (uint64_t)q.x_pos_e + 1, cw0 = 0, cw1 = 0, cws, cwe, os, oe;
+					uint64_t cw0 = 0, cw1 = 0, cws, cwe, os, oe;
 					for (mm = rs / ocv_w, cws = mm * ocv_w; mm < cwn; ++mm, cws += ocv_w) {
 						cwe = cws + ocv_w; if (cwe > rl) cwe = rl;
 						os = rs >= cws ? rs : cws; oe = re <= cwe ? re : cwe;
@@ -408,7 +656,7 @@ __global__ __launch_bounds__(64) void chain_select_kernel(hao_sel_args A)
 				}
 				if (keep) {
 					if (kk != (uint64_t)i) hao_sw(S, (int64_t)kk, i);
-					if (REC(kk).align_length < chain_cutoff) lch = 1;
+					if (AL(kk) < chain_cutoff) lch = 1;
 					++kk;
 				}
 			}
@@ -419,15 +667,15 @@ __global__ __launch_bounds__(64) void chain_select_kernel(hao_sel_args A)
 	if (lch) {
 		int64_t kk, ll;
 		for (i = ll = 0; i < n; ++i) {
-			if (REC(i).align_length < chain_cutoff) {
-				uint64_t zs = REC(i).x_pos_s, ze = (uint64_t)REC(i).x_pos_e + 1, ob = (uint64_t)((double)(ze - zs) * 0.95), ocn = (uint64_t)REC(i).align_length << 4;
-				int64_t osc = (int64_t)REC(i).shared_seed * 16;
+			if (AL(i) < chain_cutoff) {
+				uint64_t zs = XS(i) >> 32, ze = (uint64_t)(uint32_t)XS(i) + 1, ob = (uint64_t)((double)(ze - zs) * 0.95), ocn = (uint64_t)AL(i) << 4;
+				int64_t osc = (int64_t)SC(i) * 16;
 				if (ob < 16) ob = 16;
-				for (kk = 0; kk < n && ze > REC(kk).x_pos_s; ++kk) {
-					if (REC(kk).align_length < chain_cutoff || REC(kk).align_length < ocn || (int64_t)REC(kk).shared_seed < osc) continue;
-					uint64_t rs = REC(kk).x_pos_s, re = (uint64_t)REC(kk).x_pos_e + 1, os = rs >= zs ? rs : zs, oe = re <= ze ? re : ze;
+				for (kk = 0; kk < n && ze > (XS(kk) >> 32); ++kk) {
+					if (AL(kk) < chain_cutoff || AL(kk) < ocn || (int64_t)SC(kk) < osc) continue;
+					uint64_t rs = XS(kk) >> 32, re = (uint64_t)(uint32_t)XS(kk) + 1, os = rs >= zs ? rs : zs, oe = re <= ze ? re : ze;
 					if (oe > os && oe - os >= ob) {
-						uint64_t mm = REC(kk).non_homopolymer_errors, pp = HH_ID(cl[mm]), kn = 0;
+						uint64_t mm = rec[S.pm[kk]].non_homopolymer_errors, pp = HH_ID(cl[mm]), kn = 0;
 						for (; mm < cn && HH_ID(cl[mm]) == pp && kn < ocn; ++mm) {
 							uint64_t me = cl[mm].self_offset, ms = me - (cl[mm].cnt & 0xffu);
 							if (ms >= os && me <= oe) ++kn;
@@ -435,17 +683,51 @@ __global__ __launch_bounds__(64) void chain_select_kernel(hao_sel_args A)
 						if (kn >= ocn) break;
 					}
 				}
-				if (kk < n && ze > REC(kk).x_pos_s) continue;
+				if (kk < n && ze > (XS(kk) >> 32)) continue;
 			}
 			if (ll != i) hao_sw(S, ll, i);
 			++ll;
 		}
 		n = ll;
 	}
+#undef XS
+#undef SC
+#undef AL
+	return n;
+}
+
+__global__ __launch_bounds__(256) void chain_select_kernel(hao_sel_args A)
+{
+	__shared__ uint64_t l_xs[4][HAO_SEL_CAP]; __shared__ int32_t l_sc[4][HAO_SEL_CAP]; __shared__ uint32_t l_al[4][HAO_SEL_CAP], l_pm[4][HAO_SEL_CAP];
+	const int wv = threadIdx.x >> 6, lane = hao_lane();
+	const uint64_t r = (uint64_t)blockIdx.x * 4 + wv;
+	if (r > A.n_sel) return;
+	if (r == A.n_sel) { if (lane == 0) { A.n_final[r] = 0; A.fc_final[r] = 0; } return; }
+	const uint64_t g0 = A.g_off[r], g1 = A.g_off[r + 1], o0 = A.ch_base[g0];
+	int64_t n = (int64_t)(A.ch_base[g1] - o0);
+	const uint64_t cl0 = A.cl_base[g0], cn = A.cl_base[g1] - cl0;
+	const hao_ovlp_t *rec = A.ol + o0;
+	const bool in_lds = n <= HAO_SEL_CAP;
+	uint64_t *xs = in_lds ? l_xs[wv] : A.key_xs + o0; int32_t *sc = in_lds ? l_sc[wv] : A.key_sc + o0;
+	uint32_t *al = in_lds ? l_al[wv] : A.key_al + o0, *pm = in_lds ? l_pm[wv] : A.perm + o0;
+	int lch = 0;
+	for (int64_t i = lane; i < n; i += 64) {
+		const hao_ovlp_t q = rec[i];
+		xs[i] = (uint64_t)q.x_pos_s << 32 | q.x_pos_e; sc[i] = q.shared_seed; al[i] = q.align_length; pm[i] = (uint32_t)i;
+		if (q.align_length < A.chain_cutoff) lch = 1;
+	}
+	lch = __any(lch);
+	__threadfence_block();
+	hao_sel_ctx S; S.xs = xs; S.sc = sc; S.al = al; S.pm = pm;
+	int64_t nf = 0;
+	if (lane == 0) nf = hao_select_seq(A, S, n, lch, r, rec, A.cl + cl0, cn);
+	nf = __shfl(nf, 0);
+	__threadfence_block();
 	uint64_t fct = 0;
-	for (i = 0; i < n; ++i) fct += REC(i).fc_len;
-#undef REC
-	A.n_final[r] = (uint32_t)n; A.fc_final[r] = fct;
+	for (int64_t i = lane; i < nf; i += 64) { uint32_t pi = pm[i]; if (in_lds) A.perm[o0 + i] = pi; fct += rec[pi].fc_len; }
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) fct += __shfl_xor(fct, d);
+	if (lane == 0) { A.n_final[r] = (uint32_t)nf; A.fc_final[r] = fct; }
 }
 
 // final gather: records in final order (align_length zeroed, anchor.cpp:2098) + fake cigars in that order. One wave per read.

@@ -15,3 +15,11 @@ SCENARIOS = {
     "low":   (dict(genome_size=40_000, coverage=3, read_len=4000, err=0.002, seed=8), {}),
     "k40":   (dict(genome_size=40_000, coverage=18, read_len=4000, err=0.002, seed=10), dict(k=40, w=30)),
 }
+
+# larger sets used only by the GPU parity tests (oracle vs HIP, no golden file): enough repeat content to push
+# thousands of groups through the chain DP / multi-copy / max_n_chain code, and 15 kb reads through the chunked sketch
+BIG_SCENARIOS = {
+    "rr_big":   (dict(genome_size=400_000, coverage=30, read_len=8000, err=0.001, seed=5, repeat_rich=1, len_jit=2000), {}),
+    "hifi_15k": (dict(genome_size=300_000, coverage=25, read_len=15000, err=0.001, seed=21, len_jit=3000), {}),
+    "ont_big":  (dict(genome_size=200_000, coverage=30, read_len=12000, err=0.01, seed=6, len_jit=4000), dict(is_ont=1)),
+}

@@ -4,12 +4,12 @@ import numpy as np
 import pytest
 
 from helpers import scenario_reads, scenario_oracle
-from scenarios import SCENARIOS
+from scenarios import SCENARIOS, BIG_SCENARIOS
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=list(SCENARIOS))
+@pytest.fixture(scope="module", params=list(SCENARIOS) + list(BIG_SCENARIOS))
 def pair(request):
     from hifiasm_amd.api import Engine
     name = request.param
