@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void chain_assemble_kernel(hao_asm_args A)
 // use global scratch for the keys.
 // ---------------------------------------------------------------------------------------
 #define HAO_SEL_CAP 512
-struct hao_sel_ctx { const uint64_t *xs; const int32_t *sc; const uint32_t *al; uint32_t *pm; };
+struct hao_sel_ctx { const uint64_t *xs; const int32_t *sc; const uint32_t *al; uint32_t *pm; int32_t *stack; };
 __device__ __forceinline__ void hao_sw(const hao_sel_ctx &S, int64_t i, int64_t j) { uint32_t t = S.pm[i]; S.pm[i] = S.pm[j]; S.pm[j] = t; }
 template<int MODE> __device__ __forceinline__ bool hao_lt(const hao_sel_ctx &S, int64_t i, int64_t j)
 {	// MODE 0: oreg_ss_lt (score, descending; anchor.cpp:35)   MODE 1: oreg_xs_lt ((x_pos_s, x_pos_e) ascending; anchor.cpp:32)
@@ -557,7 +557,7 @@ template<int MODE> __device__ void hao_comb_sort(const hao_sel_ctx &S, int64_t l
 // klib introsort (ksort.h:110-160) restated over positions; the pivot sits at position t during partitioning
 template<int MODE> __device__ void hao_intro_sort(const hao_sel_ctx &S, int64_t n)
 {
-	int64_t stack[3 * 72], top = 0, s, t, i, j, k; int d;
+	int32_t *stack = S.stack; int64_t top = 0, s, t, i, j, k; int d;
 	if (n < 1) return;
 	if (n == 2) { if (hao_lt<MODE>(S, 1, 0)) hao_sw(S, 0, 1); return; }
 	for (d = 2; (1ull << d) < (uint64_t)n; ++d) {}
@@ -577,10 +577,10 @@ template<int MODE> __device__ void hao_intro_sort(const hao_sel_ctx &S, int64_t 
 			}
 			hao_sw(S, i, t);
 			if (i - s > t - i) {
-				if (i - s > 16) { stack[top++] = s; stack[top++] = i - 1; stack[top++] = d; }
+				if (i - s > 16) { stack[top++] = (int32_t)s; stack[top++] = (int32_t)(i - 1); stack[top++] = d; }
 				s = t - i > 16 ? i + 1 : t;
 			} else {
-				if (t - i > 16) { stack[top++] = i + 1; stack[top++] = t; stack[top++] = d; }
+				if (t - i > 16) { stack[top++] = (int32_t)(i + 1); stack[top++] = (int32_t)t; stack[top++] = d; }
 				t = i - s > 16 ? i - 1 : s;
 			}
 		} else {
@@ -619,7 +619,7 @@ struct hao_sel_args {
 };
 
 // the sequential part (lane 0). returns the kept count
-__device__ int64_t hao_select_seq(const hao_sel_args &A, const hao_sel_ctx &S, int64_t n, int lch, uint64_t r, const hao_ovlp_t *rec, const hao_hit_t *cl, uint64_t cn)
+__device__ int64_t hao_select_seq(const hao_sel_args &A, const hao_sel_ctx &S, int64_t n, int lch, uint64_t r, int *lch_out)
 {
 	const uint64_t rl = A.len[A.rid_lo + r], max_n_chain = A.max_n_chain, ocv_w = A.ocv_w; const uint32_t chain_cutoff = A.chain_cutoff;
 	int64_t i;
@@ -664,41 +664,60 @@ __device__ int64_t hao_select_seq(const hao_sel_args &A, const hao_sel_ctx &S, i
 		}
 	}
 	hao_intro_sort<1>(S, n);
-	if (lch) {
-		int64_t kk, ll;
-		for (i = ll = 0; i < n; ++i) {
-			if (AL(i) < chain_cutoff) {
-				uint64_t zs = XS(i) >> 32, ze = (uint64_t)(uint32_t)XS(i) + 1, ob = (uint64_t)((double)(ze - zs) * 0.95), ocn = (uint64_t)AL(i) << 4;
-				int64_t osc = (int64_t)SC(i) * 16;
-				if (ob < 16) ob = 16;
-				for (kk = 0; kk < n && ze > (XS(kk) >> 32); ++kk) {
-					if (AL(kk) < chain_cutoff || AL(kk) < ocn || (int64_t)SC(kk) < osc) continue;
-					uint64_t rs = XS(kk) >> 32, re = (uint64_t)(uint32_t)XS(kk) + 1, os = rs >= zs ? rs : zs, oe = re <= ze ? re : ze;
-					if (oe > os && oe - os >= ob) {
-						uint64_t mm = rec[S.pm[kk]].non_homopolymer_errors, pp = HH_ID(cl[mm]), kn = 0;
-						for (; mm < cn && HH_ID(cl[mm]) == pp && kn < ocn; ++mm) {
-							uint64_t me = cl[mm].self_offset, ms = me - (cl[mm].cnt & 0xffu);
-							if (ms >= os && me <= oe) ++kn;
-						}
-						if (kn >= ocn) break;
-					}
-				}
-				if (kk < n && ze > (XS(kk) >> 32)) continue;
-			}
-			if (ll != i) hao_sw(S, ll, i);
-			++ll;
-		}
-		n = ll;
-	}
+	*lch_out = lch;
 #undef XS
 #undef SC
 #undef AL
 	return n;
 }
 
+
+// weak-chain filter (anchor.cpp:2061-2096), whole wave: control flow is uniform (keys in LDS), the count of a strong
+// chain's hits inside the overlap interval is a strided wave reduction (the reference stops counting at ocn; only
+// "count >= ocn" is observable), permutation swaps by lane 0.
+__device__ int64_t hao_select_weak(const hao_sel_args &A, const hao_sel_ctx &S, int64_t n, const hao_ovlp_t *rec, const hao_hit_t *cl, uint64_t cn)
+{
+	const uint32_t chain_cutoff = A.chain_cutoff; const int lane = hao_lane();
+#define XS(i) S.xs[S.pm[i]]
+#define SC(i) S.sc[S.pm[i]]
+#define AL(i) S.al[S.pm[i]]
+	int64_t i, kk, ll;
+	for (i = ll = 0; i < n; ++i) {
+		bool drop = false;
+		if (AL(i) < chain_cutoff) {
+			uint64_t zs = XS(i) >> 32, ze = (uint64_t)(uint32_t)XS(i) + 1, ob = (uint64_t)((double)(ze - zs) * 0.95), ocn = (uint64_t)AL(i) << 4;
+			int64_t osc = (int64_t)SC(i) * 16;
+			if (ob < 16) ob = 16;
+			for (kk = 0; kk < n && ze > (XS(kk) >> 32); ++kk) {
+				if (AL(kk) < chain_cutoff || AL(kk) < ocn || (int64_t)SC(kk) < osc) continue;
+				uint64_t rs = XS(kk) >> 32, re = (uint64_t)(uint32_t)XS(kk) + 1, os = rs >= zs ? rs : zs, oe = re <= ze ? re : ze;
+				if (oe > os && oe - os >= ob) {
+					const uint64_t m0 = rec[S.pm[kk]].non_homopolymer_errors, nh = AL(kk);    // the chain's hits: cl[m0 .. m0+nh) share one ordinal tag
+					uint64_t kn = 0;
+					for (uint64_t b = 0; b < nh && kn < ocn; b += 64) {
+						uint64_t mm = m0 + b + lane; bool in = false;
+						if (b + lane < nh && mm < cn) { uint64_t me = cl[mm].self_offset, ms = me - (cl[mm].cnt & 0xffu); in = ms >= os && me <= oe; }
+						kn += __popcll(__ballot(in));
+					}
+					if (kn >= ocn) break;
+				}
+			}
+			drop = kk < n && ze > (XS(kk) >> 32);
+		}
+		if (drop) continue;
+		if (ll != i && lane == 0) hao_sw(S, ll, i);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		++ll;
+	}
+#undef XS
+#undef SC
+#undef AL
+	return ll;
+}
+
 __global__ __launch_bounds__(256) void chain_select_kernel(hao_sel_args A)
 {
-	__shared__ uint64_t l_xs[4][HAO_SEL_CAP]; __shared__ int32_t l_sc[4][HAO_SEL_CAP]; __shared__ uint32_t l_al[4][HAO_SEL_CAP], l_pm[4][HAO_SEL_CAP];
+	__shared__ uint64_t l_xs[4][HAO_SEL_CAP]; __shared__ int32_t l_sc[4][HAO_SEL_CAP]; __shared__ uint32_t l_al[4][HAO_SEL_CAP], l_pm[4][HAO_SEL_CAP]; __shared__ int32_t l_stack[4][3 * 72];
 	const int wv = threadIdx.x >> 6, lane = hao_lane();
 	const uint64_t r = (uint64_t)blockIdx.x * 4 + wv;
 	if (r > A.n_sel) return;
@@ -718,10 +737,12 @@ __global__ __launch_bounds__(256) void chain_select_kernel(hao_sel_args A)
 	}
 	lch = __any(lch);
 	__threadfence_block();
-	hao_sel_ctx S; S.xs = xs; S.sc = sc; S.al = al; S.pm = pm;
-	int64_t nf = 0;
-	if (lane == 0) nf = hao_select_seq(A, S, n, lch, r, rec, A.cl + cl0, cn);
-	nf = __shfl(nf, 0);
+	hao_sel_ctx S; S.xs = xs; S.sc = sc; S.al = al; S.pm = pm; S.stack = l_stack[wv];
+	int64_t nf = 0; int lch2 = 0;
+	if (lane == 0) nf = hao_select_seq(A, S, n, lch, r, &lch2);
+	nf = __shfl(nf, 0); lch2 = __shfl(lch2, 0);
+	__threadfence_block();
+	if (lch2) nf = hao_select_weak(A, S, nf, rec, A.cl + cl0, cn);
 	__threadfence_block();
 	uint64_t fct = 0;
 	for (int64_t i = lane; i < nf; i += 64) { uint32_t pi = pm[i]; if (in_lds) A.perm[o0 + i] = pi; fct += rec[pi].fc_len; }
