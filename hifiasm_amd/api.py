@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "hao_opt_default", "hao_create", "hao_destroy", "hao_last_error", "hao_set_reads", "hao_ft_gen", "hao_pt_gen",
     "hao_ft_cnt", "hao_pt_get", "hao_ft_table", "hao_pt_table", "hao_hist", "hao_stats", "hao_sketch_batch",
     "hao_fetch_sketch", "hao_overlap_batch", "hao_fetch_seed_hits", "hao_fetch_overlaps", "hao_batch_totals",
-    "hao_stage_times",
+    "hao_stage_times", "hao_pass_default", "hao_overlap_batch_ex",
 ]
 
 

@@ -6,6 +6,8 @@ the gpurun snapshot).
   oracle/liboracle.so          TEST ORACLE: plain-C restatement of the reference path
   oracle/_ref/ref_harness      TEST ORACLE: the unmodified reference, only when
                                /root/reference is present (this container)
+  oracle/_ref/hifiasm_ref|hao  the reference executable, plain and with its seam served by
+                               libhao.so (integration/hao_hifiasm_shim.cpp)
 """
 from __future__ import annotations
 
@@ -70,6 +72,11 @@ def build_ref(force=False):
     deps = [os.path.join(ORACLE, "ref_harness.cpp"), os.path.join(ORACLE, "ref_htab_dump.cpp")]
     if force or _newer(out, deps):
         _run(["make", "-C", ORACLE, "-j8", "ref"])
+    # drop-in demonstration binaries: plain reference + reference with the seam served by libhao.so
+    out2 = os.path.join(ORACLE, "_ref", "hifiasm_hao")
+    deps2 = [os.path.join(ROOT, "integration", "hao_hifiasm_shim.cpp"), os.path.join(ROOT, "include", "hao.h"), os.path.join(PKG, "libhao.so")]
+    if force or _newer(out2, deps2):
+        _run(["make", "-C", ORACLE, "-j8", "hao-hifiasm"])
     return out
 
 

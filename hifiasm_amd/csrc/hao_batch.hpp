@@ -40,8 +40,9 @@ static int hao_scan_u32(hao_ctx *c, const uint32_t *in, uint64_t *out, uint64_t 
 	return hao_excl_scan_u64(c, it, out, n_plus1);
 }
 
-static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi)
+static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_t &ps)
 {
+	if (ps.apend_be != 1 || ps.is_accurate != 1 || ps.gen_off != 1 || ps.mcopy_num > HAO_MCOPY_MAX || ps.ocv_w == 0) { hao_set_err(c, "unsupported h_ec_lchain arguments"); return HAO_EUNSUPP; }
 	if (!c->has_pt) { hao_set_err(c, "hao_pt_gen must run before hao_overlap_batch"); return HAO_EINVAL; }
 	if (!c->batch) c->batch = new hao_ctx::Batch();
 	hao_ctx::Batch &B = *c->batch;
@@ -55,8 +56,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi)
 	}
 	B.mz0 = c->h_ix_mz_off[lo]; B.n_mz = c->h_ix_mz_off[hi] - B.mz0;
 	const uint64_t nm = B.n_mz;
-	uint32_t high_occ, low_occ; hao_occ_thresholds(c->hom_cov, &high_occ, &low_occ);
-	std::vector<uint32_t> wt; hao_seed_weight_table(high_occ, low_occ, wt);
+	std::vector<uint32_t> wt; hao_seed_weight_table(ps.high_occ, ps.low_occ, wt);
 	HIP_TRY(B.wgt.reserve(4096)); HIP_TRY(hipMemcpyAsync(B.wgt.p, wt.data(), 4096 * 4, hipMemcpyHostToDevice, c->stream));
 	HIP_TRY(B.s_start.reserve(nm + 1)); HIP_TRY(B.s_n.reserve(nm + 1)); HIP_TRY(B.a_off.reserve(nm + 2)); HIP_TRY(B.seg.reserve(n + 2));
 	HIP_TRY(c->d_err.reserve(2)); HIP_TRY(hipMemsetAsync(c->d_err.p, 0, 4, c->stream));
@@ -111,7 +111,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi)
 	// Q6 chain
 	HIP_TRY(B.f.reserve(A + 1)); HIP_TRY(B.ii.reserve(A + 1)); HIP_TRY(B.p.reserve(A + 1)); HIP_TRY(B.t.reserve(A + 1)); HIP_TRY(B.ohits.reserve(A + 1));
 	HIP_TRY(B.fcs.reserve(A + 6 * G + 1)); HIP_TRY(B.rec.reserve(G * HAO_MCOPY_MAX + 1)); HIP_TRY(B.nch.reserve(G + 2)); HIP_TRY(B.nout.reserve(G + 2));
-	hao_chain_par par = hao_chain_params(c->opt.k, c->opt.is_ont, c->max_n_chain);
+	hao_chain_par par = hao_chain_params(c->opt.k, ps);
 	if (G) {
 		hao_chain_args ca;
 		ca.hits = B.hits.p; ca.g_start = B.g_start.p; ca.g_read = B.g_read.p; ca.g_off = B.g_off.p; ca.seg = B.seg.p; ca.n_groups = G; ca.rid_lo = lo; ca.len = c->d_len.p; ca.par = par;

@@ -88,12 +88,29 @@ int hao_pt_get(hao_ctx *c, uint64_t hash, const uint64_t **pos, int32_t *n)
 	return HAO_OK;
 }
 
+int hao_pass_default(hao_ctx *c, hao_pass_t *p)
+{
+	if (!c || !p) return HAO_EINVAL;
+	memset(p, 0, sizeof(*p));
+	p->bw_thres = c->opt.is_ont ? 0.05 : 0.02; p->max_n_chain = c->max_n_chain;
+	hao_occ_thresholds(c->hom_cov, &p->high_occ, &p->low_occ);
+	p->apend_be = 1; p->is_accurate = 1; p->gen_off = 1; p->mcopy_num = 3; p->mcopy_rate = 0.7; p->chain_cutoff = 2; p->mcopy_khit_cut = 32; p->ocv_w = 3072;
+	return HAO_OK;
+}
+
 int hao_overlap_batch(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi)
 {
-	if (!c || rid_lo > rid_hi || rid_hi > c->n_reads) return HAO_EINVAL;
+	hao_pass_t ps;
+	if (int rc = hao_pass_default(c, &ps)) return rc;
+	return hao_overlap_batch_ex(c, rid_lo, rid_hi, &ps);
+}
+
+int hao_overlap_batch_ex(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi, const hao_pass_t *pass)
+{
+	if (!c || !pass || rid_lo > rid_hi || rid_hi > c->n_reads) return HAO_EINVAL;
 	HIP_TRY(hipSetDevice(c->device));
 	c->timer.begin(c->stream);
-	int rc = hao_overlap_run(c, rid_lo, rid_hi);
+	int rc = hao_overlap_run(c, rid_lo, rid_hi, *pass);
 	if (rc != HAO_OK) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	c->timer.collect(c->stage_ms);

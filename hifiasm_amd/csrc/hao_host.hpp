@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdint>
 #include <vector>
+#include "hao.h"
 
 // Peak finder of the k-mer / minimizer count histogram: ha_analyze_count (hist.cpp:74-157) for
 // the default hg_size <= 0 (no prior homozygous-peak guess).  cnt[i] = #distinct k-mers seen i times.
@@ -69,13 +70,14 @@ struct hao_chain_par {          // set_lchain_dp_op(is_accurate = 1), anchor.cpp
 	uint32_t chain_cutoff; uint64_t ocv_w; uint64_t max_n_chain;
 };
 
-static inline hao_chain_par hao_chain_params(int k, int is_ont, int max_n_chain)
+static inline hao_chain_par hao_chain_params(int k, const hao_pass_t &ps)
 {
 	hao_chain_par p;
 	double tmp = expf(-0.01 * (double)k);       // float expf of a double argument, result widened: as the reference
 	p.pen_gap = 0.5f * tmp; p.pen_skip = 0.0005f * tmp;
 	p.max_skip = 25; p.max_iter = 5000; p.max_dis = 5000;
-	p.bw = is_ont ? 0.05 : 0.02;
-	p.mcopy_num = 3; p.mcopy_rate = 0.7; p.mcopy_khit_cut = 32; p.chain_cutoff = 2; p.ocv_w = 3072; p.max_n_chain = (uint64_t)max_n_chain;
+	p.bw = ps.bw_thres;
+	p.mcopy_num = ps.mcopy_num; p.mcopy_rate = ps.mcopy_rate; p.mcopy_khit_cut = ps.mcopy_khit_cut; p.chain_cutoff = ps.chain_cutoff; p.ocv_w = ps.ocv_w;
+	p.max_n_chain = (uint64_t)ps.max_n_chain;
 	return p;
 }

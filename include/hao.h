@@ -99,9 +99,26 @@ int hao_stats(hao_ctx *c, int64_t out[8]);
 int hao_sketch_batch(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi, int use_ft, int sample_dist);
 int hao_fetch_sketch(hao_ctx *c, uint64_t rid, const hao_mz_t **mz, uint64_t *n);
 
-/* h_ec_lchain (anchor.cpp:2302-2315) with the ecovlp.cpp:3274 arguments, for query reads
- * [rid_lo, rid_hi).  Results stay in HBM (hao_batch_dev) and are served per read. */
+/* The per-pass arguments of h_ec_lchain (anchor.cpp:2302). hao_pass_default fills them as
+ * worker_hap_ec does (ecovlp.cpp:3237-3238,3274): bw_thres 0.02 (0.05 --ont), max_n_chain and
+ * high/low_occ from the current coverage peaks, mcopy 3 / 0.7 / 32, chain_cutoff 2, ocv_w 3072.
+ * The final-round caller (ecovlp.cpp:3957) differs only in bw_thres = 0.001. */
+typedef struct {
+	double   bw_thres;
+	int32_t  max_n_chain;
+	uint32_t high_occ, low_occ;
+	int32_t  apend_be, is_accurate, gen_off;   /* must be 1, 1, 1 (every hot-path call site) */
+	int32_t  mcopy_num;                        /* <= 3 */
+	double   mcopy_rate;
+	uint32_t chain_cutoff, mcopy_khit_cut;
+	uint64_t ocv_w;
+} hao_pass_t;
+int hao_pass_default(hao_ctx *c, hao_pass_t *p);
+
+/* h_ec_lchain (anchor.cpp:2302-2315) for query reads [rid_lo, rid_hi); hao_overlap_batch uses
+ * hao_pass_default. Results stay in HBM and are served per read by hao_fetch_*. */
 int hao_overlap_batch(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi);
+int hao_overlap_batch_ex(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi, const hao_pass_t *pass);
 /* seed hits before chaining (cl->list after minimizers_qgen0, anchor.cpp:987-1081) */
 int hao_fetch_seed_hits(hao_ctx *c, uint64_t rid, const hao_hit_t **hits, uint64_t *n);
 /* ol->list[0..n_ol), their fake cigars (fc_off[n_ol+1] into fc) and cl->list[0..n_cl) */

@@ -1,0 +1,56 @@
+"""CPU-side checks of the drop-in boundary (no compute calls): the C-ABI library loads, exports every
+symbol include/hao.h declares, and refuses to run without a HIP device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "hao.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hao_[a-z_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    from hifiasm_amd import api
+    L = C.CDLL(api.lib_path())
+    names = _declared()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/hao.h but not exported by libhao.so"
+    assert set(api.ABI_SYMBOLS) <= set(names)
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from hifiasm_amd.api import Engine, HaoError
+    with pytest.raises(HaoError):
+        Engine(0)
+
+
+def test_product_never_touches_oracle():
+    """nothing under hifiasm_amd/ or include/ may import, link or name the oracle"""
+    bad = []
+    for base in ("hifiasm_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".py", ".hpp", ".cuh", ".hip", ".h", ".c")) and fn != "build.py":   # build.py only COMPILES the oracle
+                    txt = open(os.path.join(dp, fn), errors="ignore").read()
+                    if re.search(r"oracle_py|liboracle|hao_oracle|hao_or_", txt):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad
+
+
+def test_opt_defaults_match_reference():
+    """init_opt defaults (CommandLines.cpp:243-380) mirrored by hao_opt_default"""
+    from hifiasm_amd import api
+    o = api.Opt()
+    api.lib().hao_opt_default(C.byref(o))
+    assert (o.k, o.w, o.hpc, o.sample_dist, o.rewin, o.min_hist_cnt, o.max_kmer_cnt, o.max_n_chain) == (51, 51, 1, 500, 1000, 5, 2000, 100)
+    assert o.high_factor == 5.0 and o.is_ont == 0
