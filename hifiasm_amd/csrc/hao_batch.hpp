@@ -79,19 +79,30 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	HAO_CHECK_LAUNCH();
 	c->timer.mark("q_expand");
 	// Q3 per-read sort of the keys
-	uint64_t *sorted = B.keys.p;
+	uint64_t *sorted = B.keys.p; int mirror = 0;
 	if (A) {
 		int tid_bits = 1; while ((1ULL << tid_bits) < c->n_reads) ++tid_bits;
-		size_t tb = 0;
-		HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, tb, B.keys.p, B.keys2.p, (unsigned)A, (unsigned)n, B.seg.p, B.seg.p + 1, 0, HAO_KEY_TID_SHIFT + tid_bits, c->stream));
-		HIP_TRY(hao_tmp(c, tb));
-		HIP_TRY(rocprim::segmented_radix_sort_keys(c->d_tmp.p, tb, B.keys.p, B.keys2.p, (unsigned)A, (unsigned)n, B.seg.p, B.seg.p + 1, 0, HAO_KEY_TID_SHIFT + tid_bits, c->stream));
-		sorted = B.keys2.p;
+		if (getenv("HAO_DBG_ROCPRIM_SORT")) {
+			size_t tb = 0;
+			HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, tb, B.keys.p, B.keys2.p, (unsigned)A, (unsigned)n, B.seg.p, B.seg.p + 1, 0, HAO_KEY_TID_SHIFT + tid_bits, c->stream));
+			HIP_TRY(hao_tmp(c, tb));
+			HIP_TRY(rocprim::segmented_radix_sort_keys(c->d_tmp.p, tb, B.keys.p, B.keys2.p, (unsigned)A, (unsigned)n, B.seg.p, B.seg.p + 1, 0, HAO_KEY_TID_SHIFT + tid_bits, c->stream));
+			sorted = B.keys2.p;
+		} else {
+			// stable LSD passes over the (tid, rev) bits only: bits [HAO_KEY_REV_BIT, HAO_KEY_TID_SHIFT + tid_bits)
+			uint64_t *src = B.keys.p, *dst = B.keys2.p;
+			for (int sh = HAO_KEY_REV_BIT; sh < HAO_KEY_TID_SHIFT + tid_bits; sh += 8) {
+				hipLaunchKernelGGL(seg_radix_pass_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, src, dst, B.seg.p, sh);
+				HAO_CHECK_LAUNCH();
+				std::swap(src, dst);
+			}
+			sorted = src; mirror = 1;
+		}
 	}
 	c->timer.mark("q_sort");
 	// Q4 hits
 	hipLaunchKernelGGL(hits_build_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, sorted, B.seg.p, c->d_ix_mz_off.p, c->d_ix_mz_info.p, lo, B.mz0, B.s_start.p, B.s_n.p,
-					   c->d_ix_sinfo.p, c->d_len.p, B.wgt.p, B.hits.p);
+					   c->d_ix_sinfo.p, c->d_len.p, B.wgt.p, B.hits.p, mirror);
 	HAO_CHECK_LAUNCH();
 	c->timer.mark("q_hits");
 	// Q5 groups

@@ -60,13 +60,74 @@ __global__ __launch_bounds__(256) void seed_expand_kernel(const uint64_t *mz_off
 	}
 }
 
+// Q3: per-read stable LSD radix pass on one 8-bit digit of the key.  The keys of a read are generated in
+// (qidx, j) order, so only the (tid, rev) bits need sorting (stable); the rare runs of equal (tid, rev=1, qidx)
+// come out with jj descending and are mirrored in hits_build_kernel.  One workgroup per read, each wave owns a
+// contiguous quarter of the segment; digit ranks inside a 64-key tile come from an 8-ballot match, per-wave
+// digit counters live in LDS (no atomics: one leader lane per distinct digit), the keys themselves stream
+// through L2 (a read's ~100 KB segment stays cache-resident between the count and the scatter sweep).
+__device__ __forceinline__ unsigned long long hao_match8(uint32_t d, bool act)
+{
+	unsigned long long m = __ballot(act);
+#pragma unroll
+	for (int b = 0; b < 8; ++b) { unsigned long long bal = __ballot((d >> b) & 1); m &= ((d >> b) & 1) ? bal : ~bal; }
+	return m;
+}
+
+__global__ __launch_bounds__(256) void seg_radix_pass_kernel(const uint64_t *in, uint64_t *out, const uint64_t *seg, int shift)
+{
+	__shared__ uint32_t cnt[4][256]; __shared__ uint32_t tot[256];
+	const uint64_t r = blockIdx.x, s = seg[r], e = seg[r + 1]; const uint32_t n = (uint32_t)(e - s);
+	const int wv = threadIdx.x >> 6, lane = hao_lane();
+	if (n == 0) return;
+	const uint32_t chunk = ((n + 3) / 4 + 63) & ~63u, c0 = min(n, wv * chunk), c1 = min(n, c0 + chunk);
+	for (int i = threadIdx.x; i < 1024; i += 256) cnt[i >> 8][i & 255] = 0;
+	__syncthreads();
+	for (uint32_t t0 = c0; t0 < c1; t0 += 64) {
+		const uint32_t i = t0 + lane; const bool act = i < c1;
+		const uint32_t d = act ? (uint32_t)(in[s + i] >> shift) & 255u : 0;
+		const unsigned long long m = hao_match8(d, act);
+		if (act && (m & ((1ULL << lane) - 1)) == 0) cnt[wv][d] += __popcll(m);      // leader of its digit in this tile
+	}
+	__syncthreads();
+	{	// exclusive offsets in (digit major, wave minor) order
+		const int d = threadIdx.x; uint32_t run = 0;
+		for (int x = 0; x < 4; ++x) { uint32_t c = cnt[x][d]; cnt[x][d] = run; run += c; }
+		tot[d] = run;
+		__syncthreads();
+		uint32_t v = tot[d], tsum; uint32_t ex = hao_wave_excl_scan(v, &tsum);
+		__shared__ uint32_t wsum[4];
+		if (lane == 63) wsum[wv] = ex + v;
+		__syncthreads();
+		uint32_t add = 0; for (int x = 0; x < wv; ++x) add += wsum[x];
+		ex += add;
+		for (int x = 0; x < 4; ++x) cnt[x][d] += ex;
+	}
+	__syncthreads();
+	for (uint32_t t0 = c0; t0 < c1; t0 += 64) {
+		const uint32_t i = t0 + lane; const bool act = i < c1;
+		const uint64_t key = act ? in[s + i] : 0; const uint32_t d = act ? (uint32_t)(key >> shift) & 255u : 0;
+		const unsigned long long m = hao_match8(d, act);
+		uint32_t base = act ? cnt[wv][d] : 0;
+		if (act) out[s + base + __popcll(m & ((1ULL << lane) - 1))] = key;
+		if (act && (m & ((1ULL << lane) - 1)) == 0) cnt[wv][d] = base + __popcll(m);
+	}
+}
+
 // Q4: sorted key -> k_mer_hit (anchor.cpp:1055-1076). One workgroup per read.
 __global__ __launch_bounds__(256) void hits_build_kernel(const uint64_t *keys, const uint64_t *seg, const uint64_t *mz_off, const uint64_t *mz_info, uint64_t rid_lo, uint64_t mz0,
-		const uint64_t *s_start, const uint32_t *s_n, const uint64_t *sinfo, const uint32_t *len, const uint32_t *wgt_tab, hao_hit_t *hits)
+		const uint64_t *s_start, const uint32_t *s_n, const uint64_t *sinfo, const uint32_t *len, const uint32_t *wgt_tab, hao_hit_t *hits, int mirror)
 {
 	const uint64_t r = blockIdx.x, rid = rid_lo + r, m0 = mz_off[rid];
+	const uint64_t run_mask = ~(uint64_t)((1u << HAO_KEY_JJ_BITS) - 1);        // (tid, rev, qidx)
 	for (uint64_t i = seg[r] + threadIdx.x; i < seg[r + 1]; i += 256) {
-		const uint64_t key = keys[i];
+		uint64_t key = keys[i];
+		if (mirror && (key >> HAO_KEY_REV_BIT & 1)) {      // opposite-strand hits of one minimizer in one target arrive in reverse list order: mirror the run
+			uint64_t a = i, b = i;
+			while (a > seg[r] && (keys[a - 1] & run_mask) == (key & run_mask)) --a;
+			while (b + 1 < seg[r + 1] && (keys[b + 1] & run_mask) == (key & run_mask)) ++b;
+			if (a != b) key = keys[a + b - i];
+		}
 		const uint32_t jj = (uint32_t)(key & ((1u << HAO_KEY_JJ_BITS) - 1)), qidx = (uint32_t)(key >> HAO_KEY_JJ_BITS & ((1u << HAO_KEY_QI_BITS) - 1));
 		const uint32_t rev = (uint32_t)(key >> HAO_KEY_REV_BIT & 1), tid = (uint32_t)(key >> HAO_KEY_TID_SHIFT);
 		const uint64_t m = m0 + qidx, li = m - mz0; const uint32_t n = s_n[li];
