@@ -10,7 +10,7 @@ struct hao_ctx::Batch {
 	bool valid = false, host_valid = false;
 	DevBuf<uint64_t> s_start, a_off, seg, keys, keys2, g_cnt, g_off, g_start, ch_base, cl_base, fc_base, fcs, fc_raw, ol_fc_off, cc_off, cc, fc_final, fin_off, fcf_off, fc_out, fc_out_off;
 	DevBuf<uint64_t> nch64;
-	DevBuf<uint32_t> s_n, g_read, wgt, nch, nout, perm, n_final, fclen;
+	DevBuf<uint32_t> q_pos, q_cnt, s_n, g_read, wgt, nch, nout, perm, n_final, fclen;
 	DevBuf<hao_hit_t> hits, ohits, cl;
 	DevBuf<int32_t> f, ii, p, key_sc, tm; DevBuf<uint64_t> slow_list; DevBuf<int64_t> t; DevBuf<uint64_t> key_xs; DevBuf<uint32_t> key_al;
 	DevBuf<hao_chain_rec> rec; DevBuf<hao_ovlp_t> ol, ol_out;
@@ -20,7 +20,7 @@ struct hao_ctx::Batch {
 	void release() {
 		s_start.release(); a_off.release(); seg.release(); keys.release(); keys2.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fin_off.release(); fcf_off.release(); fc_out.release(); fc_out_off.release();
-		nch64.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
+		nch64.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
 		tm.release(); slow_list.release(); key_sc.release(); key_xs.release(); key_al.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); ol_out.release();
 	}
 };
@@ -58,11 +58,12 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	const uint64_t nm = B.n_mz;
 	std::vector<uint32_t> wt; hao_seed_weight_table(ps.high_occ, ps.low_occ, wt);
 	HIP_TRY(B.wgt.reserve(4096)); HIP_TRY(hipMemcpyAsync(B.wgt.p, wt.data(), 4096 * 4, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(B.q_pos.reserve(nm + 1)); HIP_TRY(B.q_cnt.reserve(nm + 1));
 	HIP_TRY(B.s_start.reserve(nm + 1)); HIP_TRY(B.s_n.reserve(nm + 1)); HIP_TRY(B.a_off.reserve(nm + 2)); HIP_TRY(B.seg.reserve(n + 2));
 	HIP_TRY(c->d_err.reserve(2)); HIP_TRY(hipMemsetAsync(c->d_err.p, 0, 4, c->stream));
 	hao_pt_dev pt = hao_pt_view(c);
 	// Q1 lookup + scan
-	hipLaunchKernelGGL(seed_count_kernel, dim3((unsigned)((nm + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_x.p, B.mz0, nm, pt, B.s_start.p, B.s_n.p);
+	hipLaunchKernelGGL(seed_count_kernel, dim3((unsigned)((nm + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_x.p, c->d_ix_mz_info.p, B.mz0, nm, pt, B.wgt.p, B.s_start.p, B.s_n.p, B.q_pos.p, B.q_cnt.p);
 	HAO_CHECK_LAUNCH();
 	if (int rc = hao_scan_u32(c, B.s_n.p, B.a_off.p, nm + 1)) return rc;
 	hipLaunchKernelGGL(seed_segments_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_off.p, lo, n, B.mz0, B.a_off.p, B.seg.p);
@@ -73,47 +74,43 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	const uint64_t A = B.n_anchor;
 	if (A >= (1ULL << 32)) { hao_set_err(c, "batch produces >= 2^32 anchors: use a smaller read range"); return HAO_EUNSUPP; }
 	HIP_TRY(B.keys.reserve(A + 1)); HIP_TRY(B.keys2.reserve(A + 1)); HIP_TRY(B.hits.reserve(A + 1));
+	// key layout of this batch
+	hao_keyfmt F;
+	{
+		uint32_t max_len = 1; uint64_t max_q = 1;
+		if (c->max_len == 0) for (uint64_t i = 0; i < c->n_reads; ++i) c->max_len = std::max(c->max_len, c->h_len[i]);
+		max_len = c->max_len;
+		for (uint64_t r = lo; r < hi; ++r) max_q = std::max<uint64_t>(max_q, c->h_ix_mz_off[r + 1] - c->h_ix_mz_off[r]);
+		F.ob = 1; while ((1ULL << F.ob) < (uint64_t)max_len) ++F.ob;
+		F.qb = 1; while ((1ULL << F.qb) < max_q) ++F.qb;
+		F.tb = 1; while ((1ULL << F.tb) < c->n_reads) ++F.tb;
+		if (F.ob + F.qb + 1 + F.tb > 64) { hao_set_err(c, "anchor key does not fit 64 bits (reads x minimizers-per-read x read length too large)"); return HAO_EUNSUPP; }
+	}
 	// Q2 expand
 	hipLaunchKernelGGL(seed_expand_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, c->d_ix_mz_off.p, c->d_ix_mz_info.p, lo, B.mz0, B.s_start.p, B.s_n.p, B.a_off.p,
-					   c->d_ix_sinfo.p, B.keys.p, c->d_err.p);
+					   c->d_ix_sinfo.p, c->d_len.p, F, B.keys.p);
 	HAO_CHECK_LAUNCH();
 	c->timer.mark("q_expand");
-	// Q3 per-read sort of the keys
-	uint64_t *sorted = B.keys.p; int mirror = 0;
+	// Q3+Q4: stable LSD passes over the (rev, tid) bits only; the last pass decodes keys into k_mer_hits
+	hao_hitb_args hb;
+	hb.mz_off = c->d_ix_mz_off.p; hb.rid_lo = lo; hb.mz0 = B.mz0; hb.q_pos = B.q_pos.p; hb.q_cnt = B.q_cnt.p; hb.F = F; hb.hits = B.hits.p;
 	if (A) {
-		int tid_bits = 1; while ((1ULL << tid_bits) < c->n_reads) ++tid_bits;
-		if (getenv("HAO_DBG_ROCPRIM_SORT")) {
-			size_t tb = 0;
-			HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, tb, B.keys.p, B.keys2.p, (unsigned)A, (unsigned)n, B.seg.p, B.seg.p + 1, 0, HAO_KEY_TID_SHIFT + tid_bits, c->stream));
-			HIP_TRY(hao_tmp(c, tb));
-			HIP_TRY(rocprim::segmented_radix_sort_keys(c->d_tmp.p, tb, B.keys.p, B.keys2.p, (unsigned)A, (unsigned)n, B.seg.p, B.seg.p + 1, 0, HAO_KEY_TID_SHIFT + tid_bits, c->stream));
-			sorted = B.keys2.p;
-		} else {
-			// stable LSD passes over the (tid, rev) bits only: bits [HAO_KEY_REV_BIT, HAO_KEY_TID_SHIFT + tid_bits)
-			uint64_t *src = B.keys.p, *dst = B.keys2.p;
-			for (int sh = HAO_KEY_REV_BIT; sh < HAO_KEY_TID_SHIFT + tid_bits; sh += 8) {
-				hipLaunchKernelGGL(seg_radix_pass_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, src, dst, B.seg.p, sh);
-				HAO_CHECK_LAUNCH();
-				std::swap(src, dst);
-			}
-			sorted = src; mirror = 1;
+		uint64_t *src = B.keys.p, *dst = B.keys2.p; const int beg_bit = F.ob + F.qb, end_bit = F.ob + F.qb + 1 + F.tb;
+		for (int sh = beg_bit; sh < end_bit; sh += 8) {
+			if (sh + 8 >= end_bit) hipLaunchKernelGGL(seg_radix_pass_kernel<true>, dim3((unsigned)n), dim3(256), 0, c->stream, src, dst, B.seg.p, sh, hb);
+			else hipLaunchKernelGGL(seg_radix_pass_kernel<false>, dim3((unsigned)n), dim3(256), 0, c->stream, src, dst, B.seg.p, sh, hb);
+			HAO_CHECK_LAUNCH();
+			std::swap(src, dst);
 		}
 	}
 	c->timer.mark("q_sort");
-	// Q4 hits
-	hipLaunchKernelGGL(hits_build_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, sorted, B.seg.p, c->d_ix_mz_off.p, c->d_ix_mz_info.p, lo, B.mz0, B.s_start.p, B.s_n.p,
-					   c->d_ix_sinfo.p, c->d_len.p, B.wgt.p, B.hits.p, mirror);
-	HAO_CHECK_LAUNCH();
-	c->timer.mark("q_hits");
 	// Q5 groups
 	HIP_TRY(B.g_cnt.reserve(n + 2)); HIP_TRY(B.g_off.reserve(n + 2));
 	hipLaunchKernelGGL(groups_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, B.hits.p, B.seg.p, n, (const uint64_t*)nullptr, B.g_cnt.p, (uint64_t*)nullptr, (uint32_t*)nullptr, 0);
 	HAO_CHECK_LAUNCH();
 	if (int rc = hao_excl_scan_u64(c, B.g_cnt.p, B.g_off.p, n + 1)) return rc;
 	HIP_TRY(hipMemcpyAsync(&B.n_groups, B.g_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
-	int err = 0; HIP_TRY(hipMemcpyAsync(&err, c->d_err.p, 4, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
-	if (err) { hao_set_err(c, "a read has more than 65536 minimizers"); return HAO_EUNSUPP; }
 	const uint64_t G = B.n_groups;
 	HIP_TRY(B.g_start.reserve(G + 1)); HIP_TRY(B.g_read.reserve(G + 1));
 	hipLaunchKernelGGL(groups_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, B.hits.p, B.seg.p, n, B.g_off.p, B.g_cnt.p, B.g_start.p, B.g_read.p, 1);

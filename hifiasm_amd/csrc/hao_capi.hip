@@ -57,7 +57,7 @@ int hao_set_reads(hao_ctx *c, const uint8_t *packed, const uint64_t *pk_off, con
 	if (!c || !packed || !pk_off || !len) return HAO_EINVAL;
 	if (n_reads >= (1ULL << 28)) { hao_set_err(c, "more than 2^28 reads (htab.cpp:765)"); return HAO_EUNSUPP; }
 	HIP_TRY(hipSetDevice(c->device));
-	c->n_reads = n_reads; c->n_pk_bytes = pk_off[n_reads];
+	c->n_reads = n_reads; c->n_pk_bytes = pk_off[n_reads]; c->max_len = 0;
 	c->h_len.assign(len, len + n_reads);
 	c->n_bases = 0;
 	for (uint64_t i = 0; i < n_reads; ++i) {

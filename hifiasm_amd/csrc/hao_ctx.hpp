@@ -41,7 +41,7 @@ struct StageTimer {
 struct hao_ctx {
 	int device = 0; hao_opt_t opt; std::string err; hipStream_t stream = nullptr;
 	// ---- read store (HBM) ----
-	uint64_t n_reads = 0, n_bases = 0, n_pk_bytes = 0; bool has_n = false;
+	uint64_t n_reads = 0, n_bases = 0, n_pk_bytes = 0; bool has_n = false; uint32_t max_len = 0;
 	DevBuf<uint8_t> d_packed; DevBuf<uint64_t> d_pk_off; DevBuf<uint32_t> d_len; DevBuf<uint64_t> d_nsite_off; DevBuf<uint32_t> d_nsite;
 	std::vector<uint32_t> h_len; std::vector<uint64_t> h_nsite_off;
 	// ---- filter table ----

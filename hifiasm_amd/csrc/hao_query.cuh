@@ -3,34 +3,39 @@
 //
 // The reference materialises 24-byte anchors and radix-sorts them by
 // (target id, strand, query pos) then by target offset.  Here an anchor is an 8-byte
-// key that is also its own payload:
+// key that is also its own payload, with a per-batch bit layout (LSB first):
 //
-//     key = tid:28 | rev:1 | qidx:16 | jj:12        (bit 0 = LSB of jj)
+//     key = offset:ob | qidx:qb | rev:1 | tid:tb          ob + qb + 1 + tb <= 64
 //
-// qidx = index of the query minimizer inside its read (strictly increasing with query
-// position), jj = index inside the minimizer's hit list, reversed for opposite-strand
-// hits.  Because a key's hit list is ordered by (rid,pos) and two hits of one k-mer in
-// one target have k-mer starts ordered like their ends, sorting the keys numerically
-// yields exactly the reference order (tid, strand, self_offset, other_off); the hit is
-// rebuilt from (qidx, jj) afterwards.  Sorting moves 8 B instead of 24 B per anchor and
+// offset = k_mer_hit::offset (target coordinate, already flipped for opposite-strand
+// hits), qidx = index of the query minimizer inside its read (strictly increasing with
+// query position), ob/qb/tb = bits needed for the longest read / the most minimizers in a
+// read of the batch / the number of reads.  A key's hit list is ordered by (rid,pos), and
+// two hits of one k-mer in one target have k-mer starts ordered like their ends, so the
+// reference order (tid, strand, self_offset, other_off) is: (tid, rev), then qidx, then list
+// order for same-strand hits / reverse list order for opposite-strand hits.
+// seed_expand_kernel emits keys already in (qidx, that order); a STABLE sort on the
+// (rev, tid) bits alone finishes the job, and the last radix pass decodes each key into a
+// k_mer_hit using only the query read's own minimizer table (staged in LDS) - no gather
+// from the index after the sort.  Sorting moves 8 B instead of 24 B per anchor and touches
 // only the bits that vary.
 #pragma once
 #include "hao_common.cuh"
 #include "hao_index.cuh"
 
-#define HAO_KEY_JJ_BITS 12
-#define HAO_KEY_QI_BITS 16
-#define HAO_KEY_REV_BIT 28
-#define HAO_KEY_TID_SHIFT 29
+struct hao_keyfmt { int ob, qb, tb; };     // bit widths; rev bit at ob+qb, tid from ob+qb+1
 
-// Q1: one thread per query minimizer of the batch: index lookup (ha_pt_get, anchor.cpp:1013)
-__global__ void seed_count_kernel(const uint64_t *mz_x, uint64_t mz0, uint64_t n_mz, hao_pt_dev pt, uint64_t *s_start, uint32_t *s_n)
+// Q1: one thread per query minimizer of the batch: index lookup (ha_pt_get, anchor.cpp:1013) and the two words every
+// hit of this minimizer shares: self_offset and cnt = weight(n) << 8 | span (anchor.cpp:1065-1076)
+__global__ void seed_count_kernel(const uint64_t *mz_x, const uint64_t *mz_info, uint64_t mz0, uint64_t n_mz, hao_pt_dev pt, const uint32_t *wgt_tab,
+		uint64_t *s_start, uint32_t *s_n, uint32_t *q_pos, uint32_t *q_cnt)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i > n_mz) return;
 	if (i == n_mz) { s_n[i] = 0; return; }
 	uint64_t st = 0; uint32_t n = hao_pt_lookup(pt, mz_x[mz0 + i], &st);
-	s_start[i] = st; s_n[i] = n;
+	const uint64_t z = mz_info[mz0 + i];
+	s_start[i] = st; s_n[i] = n; q_pos[i] = hao_info_pos(z); q_cnt[i] = wgt_tab[n] << 8 | hao_info_span(z);
 }
 
 // per-read anchor segment bounds from the per-minimizer scan
@@ -43,19 +48,32 @@ __global__ void seed_segments_kernel(const uint64_t *mz_off, uint64_t rid_lo, ui
 
 // Q2: one workgroup per read, one wave per minimizer: write the anchor keys
 __global__ __launch_bounds__(256) void seed_expand_kernel(const uint64_t *mz_off, const uint64_t *mz_info, uint64_t rid_lo, uint64_t mz0,
-		const uint64_t *s_start, const uint32_t *s_n, const uint64_t *a_off, const uint64_t *sinfo, uint64_t *keys, int *err)
+		const uint64_t *s_start, const uint32_t *s_n, const uint64_t *a_off, const uint64_t *sinfo, const uint32_t *len, hao_keyfmt F, uint64_t *keys)
 {
 	const uint64_t r = blockIdx.x, rid = rid_lo + r;
 	const uint64_t m0 = mz_off[rid], m1 = mz_off[rid + 1];
-	if (m1 - m0 > (1u << HAO_KEY_QI_BITS)) { if (threadIdx.x == 0) *err = 2; return; }
 	for (uint64_t m = m0 + (threadIdx.x >> 6); m < m1; m += 4) {
 		const uint64_t li = m - mz0; const uint32_t n = s_n[li];
 		if (n == 0) continue;
-		const uint64_t st = s_start[li], ao = a_off[li], z = mz_info[m]; const uint32_t zrev = hao_info_rev(z), qidx = (uint32_t)(m - m0);
+		const uint64_t st = s_start[li], ao = a_off[li]; const uint32_t zrev = hao_info_rev(mz_info[m]), qidx = (uint32_t)(m - m0);
 		for (uint32_t j = hao_lane(); j < n; j += 64) {
-			uint64_t y = sinfo[st + j]; uint32_t rev = zrev != hao_info_rev(y);
-			uint32_t jj = rev ? n - 1 - j : j;
-			keys[ao + j] = (uint64_t)hao_info_rid(y) << HAO_KEY_TID_SHIFT | (uint64_t)rev << HAO_KEY_REV_BIT | (uint64_t)qidx << HAO_KEY_JJ_BITS | jj;
+			const uint64_t y = sinfo[st + j]; const uint32_t rev = zrev != hao_info_rev(y), tid = hao_info_rid(y);
+			uint32_t slot = j;
+			if (rev) {   // opposite-strand hits must end up ordered by DEscending target position (ascending other_off, anchor.cpp:1023):
+				// inside the (rare) run of list entries with the same target, rev hit number k takes the slot of rev hit number R-1-k
+				uint32_t ja = j, jb = j;
+				while (ja > 0 && hao_info_rid(sinfo[st + ja - 1]) == tid) --ja;
+				while (jb + 1 < n && hao_info_rid(sinfo[st + jb + 1]) == tid) ++jb;
+				if (ja != jb) {
+					uint32_t k = 0, R = 0, x;
+					for (x = ja; x <= jb; ++x) if (zrev != hao_info_rev(sinfo[st + x])) { if (x < j) ++k; ++R; }
+					uint32_t want = R - 1 - k, seen = 0;
+					for (x = ja; x <= jb; ++x) if (zrev != hao_info_rev(sinfo[st + x])) { if (seen == want) { slot = x; break; } ++seen; }
+				}
+			}
+			// k_mer_hit::offset (anchor.cpp:1021-1023,1059-1064): target coordinate in the strand of the hit
+			const uint32_t off = rev ? len[tid] - 1 - (hao_info_pos(y) + 1 - hao_info_span(y)) : hao_info_pos(y);
+			keys[ao + slot] = (uint64_t)tid << (F.ob + F.qb + 1) | (uint64_t)rev << (F.ob + F.qb) | (uint64_t)qidx << F.ob | off;
 		}
 	}
 }
@@ -74,9 +92,30 @@ __device__ __forceinline__ unsigned long long hao_match8(uint32_t d, bool act)
 	return m;
 }
 
-__global__ __launch_bounds__(256) void seg_radix_pass_kernel(const uint64_t *in, uint64_t *out, const uint64_t *seg, int shift)
+struct hao_hitb_args {      // what the final pass needs to turn a key into a k_mer_hit (anchor.cpp:1055-1076)
+	const uint64_t *mz_off; uint64_t rid_lo, mz0; const uint32_t *q_pos, *q_cnt; hao_keyfmt F; hao_hit_t *hits;
+};
+#define HAO_QTAB_CAP 4096     // query minimizers staged in LDS per read (8 B each); longer reads read the table from global memory
+
+__device__ __forceinline__ hao_hit_t hao_key_to_hit(const hao_keyfmt &F, uint64_t key, const uint32_t *qpos, const uint32_t *qcnt)
+{
+	const uint32_t off = (uint32_t)(key & ((1ULL << F.ob) - 1)), qidx = (uint32_t)(key >> F.ob & ((1ULL << F.qb) - 1));
+	const uint32_t rev = (uint32_t)(key >> (F.ob + F.qb) & 1), tid = (uint32_t)(key >> (F.ob + F.qb + 1));
+	hao_hit_t h; h.w0 = tid | rev << 31; h.offset = off; h.self_offset = qpos[qidx]; h.cnt = qcnt[qidx];
+	return h;
+}
+
+template<bool FINAL>
+__global__ __launch_bounds__(256) void seg_radix_pass_kernel(const uint64_t *in, uint64_t *out, const uint64_t *seg, int shift, hao_hitb_args H)
 {
 	__shared__ uint32_t cnt[4][256]; __shared__ uint32_t tot[256];
+	__shared__ uint32_t l_qpos[FINAL ? HAO_QTAB_CAP : 1], l_qcnt[FINAL ? HAO_QTAB_CAP : 1];
+	const uint32_t *qpos = nullptr, *qcnt = nullptr;
+	if (FINAL) {
+		const uint64_t m0 = H.mz_off[H.rid_lo + blockIdx.x] - H.mz0, nq = H.mz_off[H.rid_lo + blockIdx.x + 1] - H.mz0 - m0;
+		if (nq <= HAO_QTAB_CAP) { for (uint32_t q = threadIdx.x; q < nq; q += 256) { l_qpos[q] = H.q_pos[m0 + q]; l_qcnt[q] = H.q_cnt[m0 + q]; } qpos = l_qpos; qcnt = l_qcnt; }
+		else { qpos = H.q_pos + m0; qcnt = H.q_cnt + m0; }
+	}
 	const uint64_t r = blockIdx.x, s = seg[r], e = seg[r + 1]; const uint32_t n = (uint32_t)(e - s);
 	const int wv = threadIdx.x >> 6, lane = hao_lane();
 	if (n == 0) return;
@@ -109,35 +148,11 @@ __global__ __launch_bounds__(256) void seg_radix_pass_kernel(const uint64_t *in,
 		const uint64_t key = act ? in[s + i] : 0; const uint32_t d = act ? (uint32_t)(key >> shift) & 255u : 0;
 		const unsigned long long m = hao_match8(d, act);
 		uint32_t base = act ? cnt[wv][d] : 0;
-		if (act) out[s + base + __popcll(m & ((1ULL << lane) - 1))] = key;
-		if (act && (m & ((1ULL << lane) - 1)) == 0) cnt[wv][d] = base + __popcll(m);
-	}
-}
-
-// Q4: sorted key -> k_mer_hit (anchor.cpp:1055-1076). One workgroup per read.
-__global__ __launch_bounds__(256) void hits_build_kernel(const uint64_t *keys, const uint64_t *seg, const uint64_t *mz_off, const uint64_t *mz_info, uint64_t rid_lo, uint64_t mz0,
-		const uint64_t *s_start, const uint32_t *s_n, const uint64_t *sinfo, const uint32_t *len, const uint32_t *wgt_tab, hao_hit_t *hits, int mirror)
-{
-	const uint64_t r = blockIdx.x, rid = rid_lo + r, m0 = mz_off[rid];
-	const uint64_t run_mask = ~(uint64_t)((1u << HAO_KEY_JJ_BITS) - 1);        // (tid, rev, qidx)
-	for (uint64_t i = seg[r] + threadIdx.x; i < seg[r + 1]; i += 256) {
-		uint64_t key = keys[i];
-		if (mirror && (key >> HAO_KEY_REV_BIT & 1)) {      // opposite-strand hits of one minimizer in one target arrive in reverse list order: mirror the run
-			uint64_t a = i, b = i;
-			while (a > seg[r] && (keys[a - 1] & run_mask) == (key & run_mask)) --a;
-			while (b + 1 < seg[r + 1] && (keys[b + 1] & run_mask) == (key & run_mask)) ++b;
-			if (a != b) key = keys[a + b - i];
+		if (act) {
+			const uint64_t pos = s + base + __popcll(m & ((1ULL << lane) - 1));
+			if (FINAL) H.hits[pos] = hao_key_to_hit(H.F, key, qpos, qcnt); else out[pos] = key;
 		}
-		const uint32_t jj = (uint32_t)(key & ((1u << HAO_KEY_JJ_BITS) - 1)), qidx = (uint32_t)(key >> HAO_KEY_JJ_BITS & ((1u << HAO_KEY_QI_BITS) - 1));
-		const uint32_t rev = (uint32_t)(key >> HAO_KEY_REV_BIT & 1), tid = (uint32_t)(key >> HAO_KEY_TID_SHIFT);
-		const uint64_t m = m0 + qidx, li = m - mz0; const uint32_t n = s_n[li];
-		const uint64_t z = mz_info[m], y = sinfo[s_start[li] + (rev ? n - 1 - jj : jj)];
-		hao_hit_t h;
-		h.w0 = tid | rev << 31;
-		h.offset = rev ? len[tid] - 1 - (hao_info_pos(y) + 1 - hao_info_span(y)) : hao_info_pos(y);
-		h.self_offset = hao_info_pos(z);
-		h.cnt = wgt_tab[n] << 8 | hao_info_span(z);
-		hits[i] = h;
+		if (act && (m & ((1ULL << lane) - 1)) == 0) cnt[wv][d] = base + __popcll(m);
 	}
 }
 
