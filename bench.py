@@ -119,7 +119,9 @@ def main():
     hom_ft = eng.ha_ft_gen()
     t_ft = time.time() - t0
     n_reads = rs.n
-    bsz = a.batch_reads if a.batch_reads > 0 else n_reads
+    # hao_overlap_batch handles < 2^32 seed hits per call: ~12.4 k hits per 15 kb read at 30x -> cap the batch
+    auto_bsz = max(1, int(2.5e9 // max(1.0, 0.83 * rs.total_bases / max(1, n_reads))))
+    bsz = a.batch_reads if a.batch_reads > 0 else min(n_reads, auto_bsz)
 
     def step():
         eng.ha_pt_gen()
