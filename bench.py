@@ -8,9 +8,13 @@ The read store is resident in HBM before the timed region (hao_set_reads) and ha
 run (it is reported separately).  Default workload = BASELINE.json
 configs[1]: synthetic 5 Mb genome, 30x HiFi, 15 kb reads, 0.1 % error, one MI355X.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns an independent
-shard of reads (its own 5 Mb genome -> weak scaling, per-GPU work fixed), there is no data-path
-collective; barrier + max-over-ranks timing, value = all ranks' overlaps / max time.
+N > 1 (launched by torch.distributed.run, one rank per GPU): ONE all-vs-all problem whose genome is
+N x the single-GPU genome, so every rank owns the same number of query reads (weak scaling).  Reads are
+sharded by query read; ha_ft_gen counts k-mers by hash range (RCCL all-to-all-v + 32 KB all-reduce),
+ha_pt_gen all-gathers the 16-byte minimizer records so every rank holds the whole index, the query
+pass needs no communication (SURVEY.md 8e layout i).  Barrier + max-over-ranks timing,
+value = all ranks' overlaps / max time.  If the RCCL communicator cannot be created the ranks fall back
+to independent shards and say so in config.parallelism.
 
 Prints ONE JSON line on rank 0.
 """
@@ -44,12 +48,13 @@ ALG = {
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def make_reads(workload, seed):
+def make_reads(workload, seed, rank=0, world=1):
+    """reads [rank*n, (rank+1)*n) of the read set over a genome `world` times the workload's genome"""
     from hifiasm_amd import synth
     g, cov, L, err, rr, ont = WORKLOADS[workload]
-    genome = synth.make_genome(g, seed=seed, repeat_rich=rr)
+    genome = synth.make_genome(g * world, seed=seed, repeat_rich=rr)
     n_reads = max(1, int(round(g * cov / L)))
-    return synth.make_reads(genome, n_reads, L, err, seed=seed + 1, want_codes=False), ont
+    return synth.make_reads(genome, n_reads, L, err, seed=seed + 1, rid0=rank * n_reads, want_codes=False), ont
 
 
 def cpu_baseline(sample_reads=4000, threads=None):
@@ -112,9 +117,29 @@ def main():
     from hifiasm_amd.api import Engine
     from hifiasm_amd import build as _b  # noqa: F401  (libraries are prebuilt; build() is the driver's job)
 
-    rs, is_ont = make_reads(a.workload, seed=11 + 1000 * rank)
+    mode = "single GPU"
+    rs, is_ont = make_reads(a.workload, seed=11, rank=rank, world=world)
     eng = Engine(local_rank, is_ont=is_ont)
     eng.set_readset(rs)
+    if world > 1:
+        try:
+            # lengths of all reads (replicated, 4 B/read) and the communicator id travel over the launcher's process group
+            lens = torch.from_numpy(rs.lengths.astype("int32")).cuda()
+            all_l = [torch.empty_like(lens) for _ in range(world)]
+            dist.all_gather(all_l, lens)
+            all_len = torch.cat(all_l).cpu().numpy().astype("uint32")
+            uid = [Engine.dist_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            eng.set_shard(rank * rs.n, all_len)
+            eng.dist_init(uid[0], rank, world)
+            mode = f"reads sharded by query over {world} GPUs; RCCL: k-mer all-to-all-v by hash range, minimizer all-gather-v (replicated index), no query-time traffic"
+        except Exception as ex:  # noqa: BLE001
+            sys.stderr.write(f"[bench] rank {rank}: sharded mode unavailable ({ex!r}); running independent shards\n")
+            eng.close()
+            rs, is_ont = make_reads(a.workload, seed=11 + 1000 * rank)
+            eng = Engine(local_rank, is_ont=is_ont)
+            eng.set_readset(rs)
+            mode = f"FALLBACK: {world} independent shards (own genome per rank), no data-path collective"
     t0 = time.time()
     hom_ft = eng.ha_ft_gen()
     t_ft = time.time() - t0
@@ -188,7 +213,7 @@ def main():
                        "overlaps_per_gpu_step": tot["overlaps"], "seed_hits_per_gpu_step": tot["seed_hits"],
                        "chained_hits_per_gpu_step": tot["chained_hits"], "groups_per_gpu_step": tot["groups"],
                        "groups_on_sequential_path": tot["seq_groups"], "k": 51, "w": 51, "hpc": 1,
-                       "parallelism": "1 process/GPU, reads sharded by rank, no data-path collective" if world > 1 else "single GPU",
+                       "parallelism": mode,
                        "ha_ft_gen_s": round(t_ft, 3), "hom_cov_ft": hom_ft},
             "roofline": roofline,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},

@@ -34,7 +34,8 @@ ABI_SYMBOLS = [
     "hao_opt_default", "hao_create", "hao_destroy", "hao_last_error", "hao_set_reads", "hao_ft_gen", "hao_pt_gen",
     "hao_ft_cnt", "hao_pt_get", "hao_ft_table", "hao_pt_table", "hao_hist", "hao_stats", "hao_sketch_batch",
     "hao_fetch_sketch", "hao_overlap_batch", "hao_fetch_seed_hits", "hao_fetch_overlaps", "hao_batch_totals",
-    "hao_stage_times", "hao_pass_default", "hao_overlap_batch_ex",
+    "hao_stage_times", "hao_pass_default", "hao_overlap_batch_ex", "hao_set_shard", "hao_dist_unique_id", "hao_dist_init",
+    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback",
 ]
 
 
@@ -70,6 +71,12 @@ def lib():
         L.hao_fetch_overlaps.argtypes = [vp, C.c_uint64, C.POINTER(vp), u64p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), u64p]
         L.hao_batch_totals.argtypes = [vp, u64p]
         L.hao_stage_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+        L.hao_set_shard.argtypes = [vp, C.c_uint64, C.c_uint64, u32p]
+        L.hao_dist_unique_id.argtypes = [u8p]
+        L.hao_dist_init.argtypes = [vp, u8p, C.c_int, C.c_int]
+        L.hao_loop_create.argtypes = [C.c_int]; L.hao_loop_create.restype = vp
+        L.hao_loop_destroy.argtypes = [vp]
+        L.hao_dist_init_loopback.argtypes = [vp, vp, C.c_int]
         _LIB = L
     return _LIB
 
@@ -138,6 +145,26 @@ class Engine:
 
     def set_readset(self, rs):
         self.set_reads(rs.packed, rs.pk_off, rs.lengths, rs.n_mask(), rs.code_off)
+
+    # ---- sharded mode (one process per GPU; reads partitioned by query read) ----
+    def set_shard(self, rid_base, all_lengths):
+        al = np.ascontiguousarray(all_lengths, dtype=np.uint32)
+        self._ck(self.L.hao_set_shard(self.h, int(rid_base), al.size, al.ctypes.data_as(C.POINTER(C.c_uint32))), "hao_set_shard")
+        self.rid_base = int(rid_base)
+
+    @staticmethod
+    def dist_unique_id():
+        buf = (C.c_uint8 * 128)()
+        if lib().hao_dist_unique_id(buf) != 0:
+            raise HaoError("hao_dist_unique_id failed")
+        return bytes(buf)
+
+    def dist_init(self, uid: bytes, rank: int, world: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._ck(self.L.hao_dist_init(self.h, buf, rank, world), "hao_dist_init")
+
+    def dist_init_loopback(self, group, rank: int):
+        self._ck(self.L.hao_dist_init_loopback(self.h, group, rank), "hao_dist_init_loopback")
 
     # ---- ha_ft_gen / ha_pt_gen ----
     def ha_ft_gen(self):

@@ -52,7 +52,7 @@ def build_hip(force=False):
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "hao.h")]
     if force or _newer(out, deps):
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-        _run([hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in HIP_SOURCES] + ["-o", out])
+        _run([hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in HIP_SOURCES] + ["-o", out, "-L/opt/rocm/lib", "-lrccl", "-lpthread"])
     return out
 
 

@@ -50,11 +50,12 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	const uint64_t n = B.n;
 	if (n == 0) { B.n_anchor = B.n_groups = B.n_chains = B.n_cl = B.n_ol = B.n_fc = B.n_mz = 0; B.valid = true; return HAO_OK; }
 	// minimizer range of the batch (host knows the per-read offsets? keep a host copy once)
-	if (c->h_ix_mz_off.size() != c->n_reads + 1) {
-		c->h_ix_mz_off.resize(c->n_reads + 1);
-		HIP_TRY(hipMemcpy(c->h_ix_mz_off.data(), c->d_ix_mz_off.p, (c->n_reads + 1) * 8, hipMemcpyDeviceToHost));
+	if (c->h_ix_mz_off.size() != c->n_total + 1) {
+		c->h_ix_mz_off.resize(c->n_total + 1);
+		HIP_TRY(hipMemcpy(c->h_ix_mz_off.data(), c->d_ix_mz_off.p, (c->n_total + 1) * 8, hipMemcpyDeviceToHost));
 	}
-	B.mz0 = c->h_ix_mz_off[lo]; B.n_mz = c->h_ix_mz_off[hi] - B.mz0;
+	const uint64_t glo = c->rid_base + lo, ghi = c->rid_base + hi;      // global read ids of the batch (== local when unsharded)
+	B.mz0 = c->h_ix_mz_off[glo]; B.n_mz = c->h_ix_mz_off[ghi] - B.mz0;
 	const uint64_t nm = B.n_mz;
 	std::vector<uint32_t> wt; hao_seed_weight_table(ps.high_occ, ps.low_occ, wt);
 	HIP_TRY(B.wgt.reserve(4096)); HIP_TRY(hipMemcpyAsync(B.wgt.p, wt.data(), 4096 * 4, hipMemcpyHostToDevice, c->stream));
@@ -66,7 +67,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	hipLaunchKernelGGL(seed_count_kernel, dim3((unsigned)((nm + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_x.p, c->d_ix_mz_info.p, B.mz0, nm, pt, B.wgt.p, B.s_start.p, B.s_n.p, B.q_pos.p, B.q_cnt.p);
 	HAO_CHECK_LAUNCH();
 	if (int rc = hao_scan_u32(c, B.s_n.p, B.a_off.p, nm + 1)) return rc;
-	hipLaunchKernelGGL(seed_segments_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_off.p, lo, n, B.mz0, B.a_off.p, B.seg.p);
+	hipLaunchKernelGGL(seed_segments_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_off.p, glo, n, B.mz0, B.a_off.p, B.seg.p);
 	HAO_CHECK_LAUNCH();
 	HIP_TRY(hipMemcpyAsync(&B.n_anchor, B.a_off.p + nm, 8, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
@@ -78,22 +79,22 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	hao_keyfmt F;
 	{
 		uint32_t max_len = 1; uint64_t max_q = 1;
-		if (c->max_len == 0) for (uint64_t i = 0; i < c->n_reads; ++i) c->max_len = std::max(c->max_len, c->h_len[i]);
+		if (c->max_len == 0) for (uint64_t i = 0; i < c->n_total; ++i) c->max_len = std::max(c->max_len, c->h_len_all[i]);
 		max_len = c->max_len;
-		for (uint64_t r = lo; r < hi; ++r) max_q = std::max<uint64_t>(max_q, c->h_ix_mz_off[r + 1] - c->h_ix_mz_off[r]);
+		for (uint64_t r = glo; r < ghi; ++r) max_q = std::max<uint64_t>(max_q, c->h_ix_mz_off[r + 1] - c->h_ix_mz_off[r]);
 		F.ob = 1; while ((1ULL << F.ob) < (uint64_t)max_len) ++F.ob;
 		F.qb = 1; while ((1ULL << F.qb) < max_q) ++F.qb;
-		F.tb = 1; while ((1ULL << F.tb) < c->n_reads) ++F.tb;
+		F.tb = 1; while ((1ULL << F.tb) < c->n_total) ++F.tb;
 		if (F.ob + F.qb + 1 + F.tb > 64) { hao_set_err(c, "anchor key does not fit 64 bits (reads x minimizers-per-read x read length too large)"); return HAO_EUNSUPP; }
 	}
 	// Q2 expand
-	hipLaunchKernelGGL(seed_expand_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, c->d_ix_mz_off.p, c->d_ix_mz_info.p, lo, B.mz0, B.s_start.p, B.s_n.p, B.a_off.p,
-					   c->d_ix_sinfo.p, c->d_len.p, F, B.keys.p);
+	hipLaunchKernelGGL(seed_expand_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, c->d_ix_mz_off.p, c->d_ix_mz_info.p, glo, B.mz0, B.s_start.p, B.s_n.p, B.a_off.p,
+					   c->d_ix_sinfo.p, c->d_len_all.p, F, B.keys.p);
 	HAO_CHECK_LAUNCH();
 	c->timer.mark("q_expand");
 	// Q3+Q4: stable LSD passes over the (rev, tid) bits only; the last pass decodes keys into k_mer_hits
 	hao_hitb_args hb;
-	hb.mz_off = c->d_ix_mz_off.p; hb.rid_lo = lo; hb.mz0 = B.mz0; hb.q_pos = B.q_pos.p; hb.q_cnt = B.q_cnt.p; hb.F = F; hb.hits = B.hits.p;
+	hb.mz_off = c->d_ix_mz_off.p; hb.rid_lo = glo; hb.mz0 = B.mz0; hb.q_pos = B.q_pos.p; hb.q_cnt = B.q_cnt.p; hb.F = F; hb.hits = B.hits.p;
 	if (A) {
 		uint64_t *src = B.keys.p, *dst = B.keys2.p; const int beg_bit = F.ob + F.qb, end_bit = F.ob + F.qb + 1 + F.tb;
 		for (int sh = beg_bit; sh < end_bit; sh += 8) {
@@ -122,7 +123,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	hao_chain_par par = hao_chain_params(c->opt.k, ps);
 	if (G) {
 		hao_chain_args ca;
-		ca.hits = B.hits.p; ca.g_start = B.g_start.p; ca.g_read = B.g_read.p; ca.g_off = B.g_off.p; ca.seg = B.seg.p; ca.n_groups = G; ca.rid_lo = lo; ca.len = c->d_len.p; ca.par = par;
+		ca.hits = B.hits.p; ca.g_start = B.g_start.p; ca.g_read = B.g_read.p; ca.g_off = B.g_off.p; ca.seg = B.seg.p; ca.n_groups = G; ca.rid_lo = glo; ca.len = c->d_len_all.p; ca.par = par;
 		HIP_TRY(B.stats.reserve(4)); HIP_TRY(hipMemsetAsync(B.stats.p, 0, 16, c->stream)); ca.stats = B.stats.p; ca.dbg_skip_generic = getenv("HAO_DBG_SKIP_GENERIC") ? 1 : 0; ca.dbg_seq = getenv("HAO_DBG_SEQ_CHAIN") ? 1 : 0;
 		HIP_TRY(B.tm.reserve(A + 1)); HIP_TRY(B.slow_list.reserve(G + 1)); ca.tm = B.tm.p; ca.slow_list = B.slow_list.p;
 		ca.f = B.f.p; ca.ii = B.ii.p; ca.p = B.p.p; ca.t = B.t.p; ca.ohits = B.ohits.p; ca.fcs = B.fcs.p; ca.rec = B.rec.p; ca.nch = B.nch.p; ca.nout = B.nout.p;
@@ -149,7 +150,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	HIP_TRY(B.ol.reserve(NC + 1)); HIP_TRY(B.ol_fc_off.reserve(NC + 1)); HIP_TRY(B.cl.reserve(B.n_cl + 1)); HIP_TRY(B.fc_raw.reserve(B.n_fc_raw + 1)); HIP_TRY(B.perm.reserve(NC + 1));
 	if (G) {
 		hao_asm_args aa;
-		aa.g_start = B.g_start.p; aa.g_read = B.g_read.p; aa.g_off = B.g_off.p; aa.n_groups = G; aa.rid_lo = lo; aa.ohits = B.ohits.p; aa.fcs = B.fcs.p; aa.rec = B.rec.p; aa.nch = B.nch.p;
+		aa.g_start = B.g_start.p; aa.g_read = B.g_read.p; aa.g_off = B.g_off.p; aa.n_groups = G; aa.rid_lo = glo; aa.ohits = B.ohits.p; aa.fcs = B.fcs.p; aa.rec = B.rec.p; aa.nch = B.nch.p;
 		aa.ch_base = B.ch_base.p; aa.cl_base = B.cl_base.p; aa.fc_base = B.fc_base.p; aa.ol = B.ol.p; aa.ol_fc_off = B.ol_fc_off.p; aa.cl = B.cl.p; aa.fc = B.fc_raw.p;
 		hipLaunchKernelGGL(chain_assemble_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream, aa);
 		HAO_CHECK_LAUNCH();
@@ -158,7 +159,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	// Q8 selection
 	{
 		std::vector<uint64_t> cco(n + 1); uint64_t o = 0;
-		for (uint64_t r = 0; r < n; ++r) { cco[r] = o; o += c->h_len[lo + r] / par.ocv_w + 2; }
+		for (uint64_t r = 0; r < n; ++r) { cco[r] = o; o += c->h_len_all[glo + r] / par.ocv_w + 2; }
 		cco[n] = o;
 		HIP_TRY(B.cc_off.reserve(n + 1)); HIP_TRY(B.cc.reserve(o + 1)); HIP_TRY(B.n_final.reserve(n + 2)); HIP_TRY(B.fc_final.reserve(n + 2));
 		HIP_TRY(B.fin_off.reserve(n + 2)); HIP_TRY(B.fcf_off.reserve(n + 2));
@@ -168,7 +169,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	HIP_TRY(B.key_xs.reserve(NC + 1)); HIP_TRY(B.key_sc.reserve(NC + 1)); HIP_TRY(B.key_al.reserve(NC + 1));
 	hao_sel_args sa;
 	sa.key_xs = B.key_xs.p; sa.key_sc = B.key_sc.p; sa.key_al = B.key_al.p;
-	sa.ol = B.ol.p; sa.g_off = B.g_off.p; sa.ch_base = B.ch_base.p; sa.cl_base = B.cl_base.p; sa.cl = B.cl.p; sa.n_sel = n; sa.rid_lo = lo; sa.len = c->d_len.p; sa.cc_off = B.cc_off.p; sa.cc = B.cc.p;
+	sa.ol = B.ol.p; sa.g_off = B.g_off.p; sa.ch_base = B.ch_base.p; sa.cl_base = B.cl_base.p; sa.cl = B.cl.p; sa.n_sel = n; sa.rid_lo = glo; sa.len = c->d_len_all.p; sa.cc_off = B.cc_off.p; sa.cc = B.cc.p;
 	sa.perm = B.perm.p; sa.n_final = B.n_final.p; sa.fc_final = B.fc_final.p; sa.max_n_chain = par.max_n_chain; sa.ocv_w = par.ocv_w; sa.chain_cutoff = par.chain_cutoff;
 	hipLaunchKernelGGL(chain_select_kernel, dim3((unsigned)((n + 4) / 4)), dim3(256), 0, c->stream, sa);
 	HAO_CHECK_LAUNCH();

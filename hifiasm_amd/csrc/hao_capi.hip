@@ -9,6 +9,7 @@
 #include "hao_index.cuh"
 #include "hao_query.cuh"
 #include "hao_chain.cuh"
+#include "hao_comm.hpp"
 #include "hao_pipeline.hpp"
 #include "hao_tables.hpp"
 #include "hao_batch.hpp"
@@ -43,6 +44,7 @@ void hao_destroy(hao_ctx *c)
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
 	hao_batch_free(c);
+	if (c->comm) { if (c->comm->nccl) ncclCommDestroy(c->comm->nccl); delete c->comm; c->comm = nullptr; }
 	// DevBuf members are released explicitly (no destructors: the struct is POD-ish on purpose)
 	hao_release_all(c);
 	(void)hipStreamDestroy(c->stream);
@@ -77,8 +79,62 @@ int hao_set_reads(hao_ctx *c, const uint8_t *packed, const uint64_t *pk_off, con
 		HIP_TRY(hipMemcpyAsync(c->d_nsite_off.p, nsite_off, (n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
 		HIP_TRY(hipMemcpyAsync(c->d_nsite.p, nsite, nsite_off[n_reads] * 4, hipMemcpyHostToDevice, c->stream));
 	}
+	// unsharded default: this engine owns every read
+	c->rid_base = 0; c->n_total = n_reads; c->h_len_all = c->h_len;
+	HIP_TRY(c->d_len_all.reserve(n_reads + 1));
+	HIP_TRY(hipMemcpyAsync(c->d_len_all.p, len, n_reads * 4, hipMemcpyHostToDevice, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	c->has_ft = false; c->has_pt = false; c->h_ix_valid = false; c->sk_n = 0;
+	return HAO_OK;
+}
+
+int hao_set_shard(hao_ctx *c, uint64_t rid_base, uint64_t n_total, const uint32_t *all_len)
+{
+	if (!c || !all_len || rid_base + c->n_reads > n_total) return HAO_EINVAL;
+	if (n_total >= (1ULL << 28)) { hao_set_err(c, "more than 2^28 reads (htab.cpp:765)"); return HAO_EUNSUPP; }
+	for (uint64_t i = 0; i < c->n_reads; ++i) if (all_len[rid_base + i] != c->h_len[i]) { hao_set_err(c, "all_len disagrees with the local read lengths"); return HAO_EINVAL; }
+	HIP_TRY(hipSetDevice(c->device));
+	c->rid_base = rid_base; c->n_total = n_total; c->h_len_all.assign(all_len, all_len + n_total); c->max_len = 0;
+	HIP_TRY(c->d_len_all.reserve(n_total + 1));
+	HIP_TRY(hipMemcpy(c->d_len_all.p, all_len, n_total * 4, hipMemcpyHostToDevice));
+	c->has_ft = false; c->has_pt = false; c->h_ix_valid = false;
+	return HAO_OK;
+}
+
+int hao_dist_unique_id(uint8_t id[128])
+{
+	ncclUniqueId u; if (ncclGetUniqueId(&u) != ncclSuccess) return HAO_ENODEV;
+	static_assert(sizeof(ncclUniqueId) <= 128, "ncclUniqueId");
+	memset(id, 0, 128); memcpy(id, &u, sizeof(u));
+	return HAO_OK;
+}
+
+int hao_dist_init(hao_ctx *c, const uint8_t id[128], int rank, int world)
+{
+	if (!c || !id || rank < 0 || rank >= world) return HAO_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	if (!c->comm) c->comm = new hao_comm();
+	ncclUniqueId u; memcpy(&u, id, sizeof(u));
+	c->comm->rank = rank; c->comm->world = world; c->comm->loop = nullptr;
+	NCCL_TRY(ncclCommInitRank(&c->comm->nccl, world, u, rank));
+	return HAO_OK;
+}
+
+// loopback group: `world` engines inside one process (one host thread each) on one GPU - for single-GPU tests of the sharded path
+void *hao_loop_create(int world)
+{
+	hao_loop_group *g = new hao_loop_group();
+	g->world = world; pthread_barrier_init(&g->bar, nullptr, world); g->ptr.assign(world, nullptr); g->cnt.resize(world); g->hostv.resize(world);
+	return g;
+}
+void hao_loop_destroy(void *grp) { if (grp) { hao_loop_group *g = (hao_loop_group*)grp; pthread_barrier_destroy(&g->bar); delete g; } }
+int hao_dist_init_loopback(hao_ctx *c, void *grp, int rank)
+{
+	if (!c || !grp) return HAO_EINVAL;
+	hao_loop_group *g = (hao_loop_group*)grp;
+	if (rank < 0 || rank >= g->world) return HAO_EINVAL;
+	if (!c->comm) c->comm = new hao_comm();
+	c->comm->rank = rank; c->comm->world = g->world; c->comm->loop = g; c->comm->nccl = nullptr;
 	return HAO_OK;
 }
 

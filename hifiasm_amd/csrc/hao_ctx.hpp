@@ -44,6 +44,8 @@ struct hao_ctx {
 	uint64_t n_reads = 0, n_bases = 0, n_pk_bytes = 0; bool has_n = false; uint32_t max_len = 0;
 	DevBuf<uint8_t> d_packed; DevBuf<uint64_t> d_pk_off; DevBuf<uint32_t> d_len; DevBuf<uint64_t> d_nsite_off; DevBuf<uint32_t> d_nsite;
 	std::vector<uint32_t> h_len; std::vector<uint64_t> h_nsite_off;
+	// sharded mode: this engine holds reads [rid_base, rid_base + n_reads) of n_total; lengths of ALL reads are replicated
+	uint64_t rid_base = 0, n_total = 0; DevBuf<uint32_t> d_len_all; std::vector<uint32_t> h_len_all; struct hao_comm *comm = nullptr;
 	// ---- filter table ----
 	bool has_ft = false; int ft_peak_hom = -1, ft_peak_het = -1, ft_cutoff = 0; int64_t ft_hist[HAO_N_COUNTS];
 	std::vector<uint64_t> h_ft_keys; std::vector<int32_t> h_ft_vals;

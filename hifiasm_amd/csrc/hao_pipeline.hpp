@@ -126,7 +126,7 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 	} else {
 		HIP_TRY(hipMemcpyAsync(c->d_mz_off.p, c->d_g_off.p, (n_sel + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
 	}
-	hipLaunchKernelGGL(sketch_finish_kernel, dim3((unsigned)((n_sel + 3) / 4)), dim3(256), 0, c->stream, c->d_g_x.p, c->d_g_info.p, src_off, c->d_mz_off.p, lo, n_sel, stamp_rid,
+	hipLaunchKernelGGL(sketch_finish_kernel, dim3((unsigned)((n_sel + 3) / 4)), dim3(256), 0, c->stream, c->d_g_x.p, c->d_g_info.p, src_off, c->d_mz_off.p, lo + c->rid_base, n_sel, stamp_rid,
 					   c->d_mz_x.p, c->d_mz_info.p);
 	HAO_CHECK_LAUNCH();
 	c->sk_total = total;

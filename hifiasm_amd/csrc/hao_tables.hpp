@@ -1,8 +1,24 @@
 // Host orchestration: ha_ft_gen / ha_pt_gen equivalents (part of libhao.so).
 #pragma once
+#include "hao_comm.hpp"
 #include "hao_pipeline.hpp"
 #include "hao_index.cuh"
 #include "hao_host.hpp"
+
+// first index with keys[i] >= target[t] (sorted keys); one thread per target
+__global__ void hao_lower_bound_kernel(const uint64_t *keys, uint64_t n, const uint64_t *targets, int nt, uint64_t *out)
+{
+	int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nt) return;
+	uint64_t lo = 0, hi = n, x = targets[t];
+	while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (keys[m] < x) lo = m + 1; else hi = m; }
+	out[t] = lo;
+}
+__global__ void hao_adjdiff_kernel(const uint64_t *off, uint64_t n, uint64_t *cnt)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) cnt[i] = off[i + 1] - off[i];
+}
 
 // run-count index for reads [lo, hi); scalar flag = read has N (or force_scalar_all)
 static int hao_prepare_runs(hao_ctx *c, uint64_t lo, uint64_t hi, bool force_scalar_all, std::vector<uint32_t> &slist)
@@ -144,9 +160,41 @@ static int hao_ft_run(hao_ctx *c)
 	}
 	c->timer.mark("ft_hash");
 	DevBuf<uint64_t> ukeys; DevBuf<uint32_t> ucnt; uint64_t n_unique = 0, *sorted = nullptr;
-	// sentinels (0xff..ff) sort to the end: only the first n_real entries are real k-mers
-	if (int rc = hao_sort_rle_hist(c, kh.p, kh2.p, n_slots, ukeys, ucnt, &n_unique, c->ft_hist, &sorted)) return rc;
-	if (n_real < n_slots && n_unique) { --n_unique; c->ft_hist[std::min<uint64_t>(n_slots - n_real, HAO_MAX_COUNT)] -= 1; }   // drop the sentinel run
+	const bool sharded = c->comm && c->comm->active();
+	if (!sharded) {
+		// sentinels (0xff..ff) sort to the end: only the first n_real entries are real k-mers
+		if (int rc = hao_sort_rle_hist(c, kh.p, kh2.p, n_slots, ukeys, ucnt, &n_unique, c->ft_hist, &sorted)) return rc;
+		if (n_real < n_slots && n_unique) { --n_unique; c->ft_hist[std::min<uint64_t>(n_slots - n_real, HAO_MAX_COUNT)] -= 1; }   // drop the sentinel run
+	} else {
+		// hash-range partition: sort local hashes, cut at i * 2^64 / world, all-to-all-v, count the owned range
+		hao_comm &cm = *c->comm; const int W = cm.world;
+		uint64_t *loc = kh.p;
+		if (n_slots) {
+			size_t tb = 0; rocprim::double_buffer<uint64_t> db(kh.p, kh2.p);
+			HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, db, n_slots, 0, 64, c->stream)); HIP_TRY(hao_tmp(c, tb));
+			HIP_TRY(rocprim::radix_sort_keys(c->d_tmp.p, tb, db, n_slots, 0, 64, c->stream));
+			loc = db.current();
+		}
+		std::vector<uint64_t> tg(W), cut(W + 1, 0), scnt(W), sdisp(W), rcnt;
+		for (int d = 0; d < W; ++d) tg[d] = d == 0 ? 0 : (uint64_t)(((unsigned __int128)d << 64) / (unsigned)W);
+		DevBuf<uint64_t> dt, dc; HIP_TRY(dt.reserve(W + 1)); HIP_TRY(dc.reserve(W + 1));
+		HIP_TRY(hipMemcpyAsync(dt.p, tg.data(), 8 * W, hipMemcpyHostToDevice, c->stream));
+		hipLaunchKernelGGL(hao_lower_bound_kernel, dim3((W + 63) / 64), dim3(64), 0, c->stream, loc, n_real, dt.p, W, dc.p);
+		HAO_CHECK_LAUNCH();
+		HIP_TRY(hipMemcpyAsync(cut.data(), dc.p, 8 * W, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		cut[W] = n_real;
+		for (int d = 0; d < W; ++d) { sdisp[d] = cut[d]; scnt[d] = cut[d + 1] - cut[d]; }
+		if (int rc = hao_comm_exchange_counts(c, cm, scnt, rcnt)) return rc;
+		uint64_t n_recv = 0; for (int d = 0; d < W; ++d) n_recv += rcnt[d];
+		DevBuf<uint64_t> rv, rv2; HIP_TRY(rv.reserve(n_recv + 1)); HIP_TRY(rv2.reserve(n_recv + 1));
+		if (int rc = hao_comm_alltoallv_u64(c, cm, loc, scnt, sdisp, rv.p, rcnt)) return rc;
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		c->timer.mark("ft_exchange");
+		if (int rc = hao_sort_rle_hist(c, rv.p, rv2.p, n_recv, ukeys, ucnt, &n_unique, c->ft_hist, &sorted)) return rc;
+		if (int rc = hao_comm_allreduce_i64(c, cm, c->ft_hist, HAO_N_COUNTS)) return rc;
+		rv.release(); rv2.release(); dt.release(); dc.release();
+	}
 	c->timer.mark("ft_count");
 	kh.release(); kh2.release();
 	c->ft_peak_hom = hao_find_peaks(c->ft_hist, HAO_N_COUNTS, c->opt.min_hist_cnt, &c->ft_peak_het);
@@ -156,6 +204,17 @@ static int hao_ft_run(hao_ctx *c)
 	DevBuf<uint32_t> kcnt; uint64_t n_kept = 0;
 	if (int rc = hao_keep_runs(c, ukeys.p, ucnt.p, n_unique, cutoff, HAO_MAX_COUNT, c->d_ft_keys, nullptr, kcnt, &n_kept, nullptr)) return rc;
 	ukeys.release(); ucnt.release();
+	if (sharded) {   // every rank kept its hash range: concatenation in rank order is the globally sorted table
+		hao_comm &cm = *c->comm; std::vector<uint64_t> cnts;
+		if (int rc = hao_comm_allgather_u64(c, cm, n_kept, cnts)) return rc;
+		uint64_t tot = 0; for (uint64_t v : cnts) tot += v;
+		DevBuf<uint64_t> gk; DevBuf<uint32_t> gc; HIP_TRY(gk.reserve(tot + 1)); HIP_TRY(gc.reserve(tot + 1));
+		if (int rc = hao_comm_allgatherv(c, cm, c->d_ft_keys.p, n_kept, 8, gk.p, cnts)) return rc;
+		if (int rc = hao_comm_allgatherv(c, cm, kcnt.p, n_kept, 4, gc.p, cnts)) return rc;
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		std::swap(c->d_ft_keys, gk); std::swap(kcnt, gc); gk.release(); gc.release();
+		n_kept = tot;
+	}
 	// map values (gen_hh, htab.cpp:1038-1062) as ha_ft_cnt returns them (htab.cpp:1064-1070)
 	int max_cnt = c->opt.max_kmer_cnt;
 	if (max_cnt > HAO_MAX_COUNT - 1) max_cnt = HAO_MAX_COUNT - 1;
@@ -194,8 +253,32 @@ static int hao_pt_run(hao_ctx *c)
 	if (n == 0) { hao_set_err(c, "no reads"); return HAO_EINVAL; }
 	if (int rc = hao_sketch_run(c, 0, n, c->has_ft, c->opt.sample_dist, 1)) return rc;
 	// keep the read-ordered minimizers for the query side
-	std::swap(c->d_ix_mz_x, c->d_mz_x); std::swap(c->d_ix_mz_info, c->d_mz_info); std::swap(c->d_ix_mz_off, c->d_mz_off);
-	c->ix_n_mz = c->sk_total; c->sk_n = 0;
+	if (!(c->comm && c->comm->active())) {
+		std::swap(c->d_ix_mz_x, c->d_mz_x); std::swap(c->d_ix_mz_info, c->d_mz_info); std::swap(c->d_ix_mz_off, c->d_mz_off);
+		c->ix_n_mz = c->sk_total; c->sk_n = 0;
+	} else {
+		// sharded: all-gather-v of the 16-byte records (x, info) and of the per-read counts; shards are contiguous read ranges in
+		// rank order, so the concatenation is in global read order and every rank builds the same index
+		hao_comm &cm = *c->comm; std::vector<uint64_t> mzc, rdc;
+		if (int rc = hao_comm_allgather_u64(c, cm, c->sk_total, mzc)) return rc;
+		if (int rc = hao_comm_allgather_u64(c, cm, n, rdc)) return rc;
+		uint64_t tot = 0, nt = 0; for (uint64_t v : mzc) tot += v; for (uint64_t v : rdc) nt += v;
+		if (nt != c->n_total) { hao_set_err(c, "shards do not add up to n_total"); return HAO_EINVAL; }
+		{ uint64_t b = 0; for (int r = 0; r < cm.rank; ++r) b += rdc[r]; if (b != c->rid_base) { hao_set_err(c, "rid_base is not the sum of the lower ranks' read counts"); return HAO_EINVAL; } }
+		HIP_TRY(c->d_ix_mz_x.reserve(tot + 1)); HIP_TRY(c->d_ix_mz_info.reserve(tot + 1)); HIP_TRY(c->d_ix_mz_off.reserve(nt + 2));
+		if (int rc = hao_comm_allgatherv(c, cm, c->d_mz_x.p, c->sk_total, 8, c->d_ix_mz_x.p, mzc)) return rc;
+		if (int rc = hao_comm_allgatherv(c, cm, c->d_mz_info.p, c->sk_total, 8, c->d_ix_mz_info.p, mzc)) return rc;
+		DevBuf<uint64_t> lc, gc; HIP_TRY(lc.reserve(n + 1)); HIP_TRY(gc.reserve(nt + 2));
+		hipLaunchKernelGGL(hao_adjdiff_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_mz_off.p, n, lc.p);
+		HAO_CHECK_LAUNCH();
+		if (int rc = hao_comm_allgatherv(c, cm, lc.p, n, 8, gc.p, rdc)) return rc;
+		HIP_TRY(hipMemsetAsync(gc.p + nt, 0, 8, c->stream));
+		if (int rc = hao_excl_scan_u64(c, gc.p, c->d_ix_mz_off.p, nt + 1)) return rc;
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		lc.release(); gc.release();
+		c->ix_n_mz = tot; c->sk_n = 0;
+		c->timer.mark("pt_allgather");
+	}
 	const uint64_t m = c->ix_n_mz;
 	if (m >= (1ULL << 32)) { hao_set_err(c, "more than 2^32 minimizers on one device"); return HAO_EUNSUPP; }
 	HIP_TRY(c->d_ix_sx.reserve(m + 1)); HIP_TRY(c->d_ix_sinfo.reserve(m + 1));

@@ -78,6 +78,23 @@ const char *hao_last_error(const hao_ctx *c);
 int hao_set_reads(hao_ctx *c, const uint8_t *packed, const uint64_t *pk_off, const uint32_t *len, uint64_t n_reads,
 				  const uint64_t *nsite_off, const uint32_t *nsite);
 
+/* ---- sharded mode: one process per GPU, reads partitioned by query read ----
+ * The reference shards its tables over threads (4096 sub-tables, htab.cpp:147-151,594-606); across GPUs the engine
+ * shards READS: rank r holds reads [rid_base, rid_base+n_local) of n_total.  After hao_set_reads (local reads) call
+ * hao_set_shard with the lengths of ALL reads (read_length[], replicated: 4 B/read), and hao_dist_init with an id
+ * produced once by hao_dist_unique_id and broadcast by the launcher (ncclGetUniqueId / ncclCommInitRank).
+ * hao_ft_gen then counts k-mers by hash range (all-to-all-v of 8-byte hashes, 32 KB histogram all-reduce,
+ * all-gather-v of the small filter table); hao_pt_gen all-gathers the 16-byte minimizer records so every rank holds
+ * the whole index; hao_overlap_batch needs no communication.  Read ids in all results are GLOBAL; the batch range of
+ * hao_overlap_batch / hao_fetch_* stays LOCAL (0 .. n_local). */
+int hao_set_shard(hao_ctx *c, uint64_t rid_base, uint64_t n_total, const uint32_t *all_len);
+int hao_dist_unique_id(uint8_t id[128]);
+int hao_dist_init(hao_ctx *c, const uint8_t id[128], int rank, int world);
+/* loopback exchange backend: `world` engines in ONE process (one host thread each) on one GPU; test-only substitute for RCCL */
+void *hao_loop_create(int world);
+void hao_loop_destroy(void *grp);
+int hao_dist_init_loopback(hao_ctx *c, void *grp, int rank);
+
 /* ha_ft_gen (htab.cpp:1136-1169) at -f0 + ha_opt_update_cov (CommandLines.cpp:411-418). */
 int hao_ft_gen(hao_ctx *c, int32_t *hom_cov);
 /* ha_pt_gen (htab.cpp:1232-1287) + the asm_opt.hom_cov/het_cov update of Assembly.cpp:1007-1008.
