@@ -124,14 +124,11 @@ def main():
     if world > 1:
         try:
             # lengths of all reads (replicated, 4 B/read) and the communicator id travel over the launcher's process group
-            lens = torch.from_numpy(rs.lengths.astype("int32")).cuda()
-            all_l = [torch.empty_like(lens) for _ in range(world)]
-            dist.all_gather(all_l, lens)
-            all_len = torch.cat(all_l).cpu().numpy().astype("uint32")
-            uid = [Engine.dist_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            eng.set_shard(rank * rs.n, all_len)
-            eng.dist_init(uid[0], rank, world)
+            from hifiasm_amd import shard
+            all_len, counts = shard.gather_lengths(dist, rs.lengths, device="cuda")
+            uid = shard.share_unique_id(dist, Engine.dist_unique_id)
+            eng.set_shard(sum(counts[:rank]), all_len)
+            eng.dist_init(uid, rank, world)
             mode = f"reads sharded by query over {world} GPUs; RCCL: k-mer all-to-all-v by hash range, minimizer all-gather-v (replicated index), no query-time traffic"
         except Exception as ex:  # noqa: BLE001
             sys.stderr.write(f"[bench] rank {rank}: sharded mode unavailable ({ex!r}); running independent shards\n")

@@ -1,0 +1,51 @@
+"""N > 1 launcher-side logic on CPU: two gloo ranks shard one read set, replicate the read lengths and share
+the communicator id exactly as bench.py does before creating the engines (the engines themselves need GPUs)."""
+import os
+import socket
+
+import numpy as np
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from hifiasm_amd import shard, synth
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    genome = synth.make_genome(60_000, seed=5)
+    n_total = 37
+    lo, hi = shard.shard_range(n_total, rank, world)
+    rs = synth.make_reads(genome, hi - lo, 3000, 0.002, seed=6, rid0=lo, len_jit=500)
+    all_len, counts = shard.gather_lengths(dist, rs.lengths)
+    uid = shard.share_unique_id(dist, lambda: b"U" * 128)
+    q.put((rank, lo, hi, rs.lengths.copy(), rs.packed.copy(), all_len, counts, uid))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_gloo():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    genome = synth.make_genome(60_000, seed=5)
+    full = synth.make_reads(genome, 37, 3000, 0.002, seed=6, len_jit=500)
+    assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == 37           # contiguous ranges in rank order
+    for rank, lo, hi, lens, packed, all_len, counts, uid in res:
+        assert (lens == full.lengths[lo:hi]).all()                                   # a shard is a slice of the one read set
+        assert (packed == full.packed[int(full.pk_off[lo]):int(full.pk_off[hi])]).all()
+        assert (all_len == full.lengths).all() and counts == [res[0][2], 37 - res[0][2]]
+        assert uid == b"U" * 128
+
+
+def test_shard_ranges_cover():
+    for n in (0, 1, 7, 1000):
+        for w in (1, 2, 3, 8):
+            r = [shard.shard_range(n, i, w) for i in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
