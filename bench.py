@@ -41,8 +41,7 @@ WORKLOADS = {
 ALG = {
     "sketch_chunk_kernel": ("base", 0.25 + 16.0 / 35.0),     # 2-bit bases in + 16-B minimizer per ~35 bases out
     "chain_group_kernel": ("anchor", 16 + 12 + 16),          # k_mer_hit in + f,p scratch + chained hit out
-    "segmented_sort": ("anchor", 2 * 8),                      # 8-B key read + written once (ideal single pass)
-    "hits_build_kernel": ("anchor", 8 + 8 + 16),              # key in + index position in + k_mer_hit out
+    "seg_radix_pass_kernel": ("anchor", 8 + 8 + 16),           # per-read sort: key in, key out once, k_mer_hit out
     "seed_expand_kernel": ("anchor", 8 + 8),                  # index position in + key out
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
@@ -142,7 +141,8 @@ def main():
     t_ft = time.time() - t0
     n_reads = rs.n
     # hao_overlap_batch handles < 2^32 seed hits per call: ~12.4 k hits per 15 kb read at 30x -> cap the batch
-    auto_bsz = max(1, int(2.5e9 // max(1.0, 0.83 * rs.total_bases / max(1, n_reads))))
+    # and ~100 B of device scratch per seed hit: keep a batch near 4e8 hits (~40 GB)
+    auto_bsz = max(1, int(4e8 // max(1.0, 0.83 * rs.total_bases / max(1, n_reads))))
     bsz = a.batch_reads if a.batch_reads > 0 else min(n_reads, auto_bsz)
 
     def step():
@@ -189,8 +189,8 @@ def main():
     if rank == 0:
         stage_ms = {k: v / a.steps for k, v in stage_sum.items()}
         # roofline of the dominant kernel: live HIP-event time of its stage on the engine's stream
-        kern_stage = {"sketch_chunk_kernel": "sk_chunks", "chain_group_kernel": "q_chain", "segmented_sort": "q_sort",
-                      "hits_build_kernel": "q_hits", "seed_expand_kernel": "q_expand"}
+        kern_stage = {"sketch_chunk_kernel": "sk_chunks", "chain_group_kernel": "q_chain", "seg_radix_pass_kernel": "q_sort",
+                      "seed_expand_kernel": "q_expand"}
         dom = max(kern_stage, key=lambda k: stage_ms.get(kern_stage[k], 0.0))
         unit, bpu = ALG[dom]
         units = rs.total_bases if unit == "base" else tot["seed_hits"]

@@ -96,10 +96,15 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	hao_hitb_args hb;
 	hb.mz_off = c->d_ix_mz_off.p; hb.rid_lo = glo; hb.mz0 = B.mz0; hb.q_pos = B.q_pos.p; hb.q_cnt = B.q_cnt.p; hb.F = F; hb.hits = B.hits.p;
 	if (A) {
-		uint64_t *src = B.keys.p, *dst = B.keys2.p; const int beg_bit = F.ob + F.qb, end_bit = F.ob + F.qb + 1 + F.tb;
-		for (int sh = beg_bit; sh < end_bit; sh += 8) {
-			if (sh + 8 >= end_bit) hipLaunchKernelGGL(seg_radix_pass_kernel<true>, dim3((unsigned)n), dim3(256), 0, c->stream, src, dst, B.seg.p, sh, hb);
-			else hipLaunchKernelGGL(seg_radix_pass_kernel<false>, dim3((unsigned)n), dim3(256), 0, c->stream, src, dst, B.seg.p, sh, hb);
+		uint64_t *src = B.keys.p, *dst = B.keys2.p; const int beg_bit = F.ob + F.qb, nb = 1 + F.tb;
+		// digits of equal width: 8 bits unless that costs an extra pass (then up to 11; the per-wave digit counters are LDS-resident)
+		int n_pass = (nb + 7) / 8; if ((nb + HAO_RDX_MAXBITS - 1) / HAO_RDX_MAXBITS < n_pass) n_pass = (nb + HAO_RDX_MAXBITS - 1) / HAO_RDX_MAXBITS;
+		const int db = (nb + n_pass - 1) / n_pass;
+		const uint32_t qcap = (uint32_t)std::min<uint64_t>(1ULL << F.qb, HAO_QTAB_CAP);
+		for (int ps_ = 0, sh = beg_bit; ps_ < n_pass; ++ps_, sh += db) {
+			const int bits = std::min(db, beg_bit + nb - sh); const size_t lds = (size_t)5 * (1u << bits) * 4;
+			if (ps_ == n_pass - 1) hipLaunchKernelGGL(seg_radix_pass_kernel<true>, dim3((unsigned)n), dim3(256), lds + 8 * qcap, c->stream, src, dst, B.seg.p, sh, bits, qcap, hb);
+			else hipLaunchKernelGGL(seg_radix_pass_kernel<false>, dim3((unsigned)n), dim3(256), lds, c->stream, src, dst, B.seg.p, sh, bits, 0u, hb);
 			HAO_CHECK_LAUNCH();
 			std::swap(src, dst);
 		}

@@ -55,11 +55,15 @@ __device__ __forceinline__ int32_t hao_pair_score(const hao_hit_t &ai, const hao
 	if (dd > 16 && dd > hao_band(ai, aj, P)) return INT32_MIN;
 	int32_t dg = dr < dq ? dr : dq, span = HH_SPAN(ai), sc = span < dg ? span : dg, wgt = HH_WGT(ai);
 	sc = sc >= wgt ? sc / wgt : 1;
-	if (dd || (dg > span && dg > 0)) {
+	if (dd) {
 		double lin = P.pen_gap * (double)dd, ap = (double)sc * (((double)dd / (double)dg) / P.bw);
 		if (dd < 4) lin = lin > ap ? ap : lin; else lin = lin < ap ? ap : lin;
 		lin += P.pen_skip * (double)dg;
 		sc -= (int32_t)lin;
+	} else if (dg > span) {
+		// dd == 0: both penalty terms are exactly +0.0 (pen_gap * 0, sc * ((0 / dg) / bw)), min(0,0) = 0, so only the
+		// skip term remains - same IEEE result as the general expression without the two divisions
+		sc -= (int32_t)(0.0 + P.pen_skip * (double)dg);
 	}
 	if (dd_out) *dd_out = dd;
 	return sc;

@@ -84,18 +84,18 @@ __global__ __launch_bounds__(256) void seed_expand_kernel(const uint64_t *mz_off
 // contiguous quarter of the segment; digit ranks inside a 64-key tile come from an 8-ballot match, per-wave
 // digit counters live in LDS (no atomics: one leader lane per distinct digit), the keys themselves stream
 // through L2 (a read's ~100 KB segment stays cache-resident between the count and the scatter sweep).
-__device__ __forceinline__ unsigned long long hao_match8(uint32_t d, bool act)
+#define HAO_RDX_MAXBITS 11       // digit width is chosen per batch so that the (rev, tid) bits take as few passes as possible
+__device__ __forceinline__ unsigned long long hao_match_bits(uint32_t d, bool act, int nbits)
 {
 	unsigned long long m = __ballot(act);
-#pragma unroll
-	for (int b = 0; b < 8; ++b) { unsigned long long bal = __ballot((d >> b) & 1); m &= ((d >> b) & 1) ? bal : ~bal; }
+	for (int b = 0; b < nbits; ++b) { unsigned long long bal = __ballot((d >> b) & 1); m &= ((d >> b) & 1) ? bal : ~bal; }
 	return m;
 }
 
 struct hao_hitb_args {      // what the final pass needs to turn a key into a k_mer_hit (anchor.cpp:1055-1076)
 	const uint64_t *mz_off; uint64_t rid_lo, mz0; const uint32_t *q_pos, *q_cnt; hao_keyfmt F; hao_hit_t *hits;
 };
-#define HAO_QTAB_CAP 4096     // query minimizers staged in LDS per read (8 B each); longer reads read the table from global memory
+#define HAO_QTAB_CAP 4096     // most query minimizers staged in LDS per read (8 B each); longer reads read the table from global memory
 
 __device__ __forceinline__ hao_hit_t hao_key_to_hit(const hao_keyfmt &F, uint64_t key, const uint32_t *qpos, const uint32_t *qcnt)
 {
@@ -106,55 +106,56 @@ __device__ __forceinline__ hao_hit_t hao_key_to_hit(const hao_keyfmt &F, uint64_
 }
 
 template<bool FINAL>
-__global__ __launch_bounds__(256) void seg_radix_pass_kernel(const uint64_t *in, uint64_t *out, const uint64_t *seg, int shift, hao_hitb_args H)
+__global__ __launch_bounds__(256) void seg_radix_pass_kernel(const uint64_t *in, uint64_t *out, const uint64_t *seg, int shift, int nbits, uint32_t qcap, hao_hitb_args H)
 {
-	__shared__ uint32_t cnt[4][256]; __shared__ uint32_t tot[256];
-	__shared__ uint32_t l_qpos[FINAL ? HAO_QTAB_CAP : 1], l_qcnt[FINAL ? HAO_QTAB_CAP : 1];
+	// dynamic LDS: cnt(4, ND) | tot[ND] | (final pass) qpos[qcap] | qcnt[qcap]
+	extern __shared__ uint32_t rdx_smem[];
+	const uint32_t ND = 1u << nbits, dmask = ND - 1;
+	uint32_t *cnt_ = rdx_smem, *tot = rdx_smem + 4 * ND, *l_qpos = tot + ND, *l_qcnt = l_qpos + qcap;
+#define cnt(x, d) cnt_[(x) * ND + (d)]
 	const uint32_t *qpos = nullptr, *qcnt = nullptr;
 	if (FINAL) {
 		const uint64_t m0 = H.mz_off[H.rid_lo + blockIdx.x] - H.mz0, nq = H.mz_off[H.rid_lo + blockIdx.x + 1] - H.mz0 - m0;
-		if (nq <= HAO_QTAB_CAP) { for (uint32_t q = threadIdx.x; q < nq; q += 256) { l_qpos[q] = H.q_pos[m0 + q]; l_qcnt[q] = H.q_cnt[m0 + q]; } qpos = l_qpos; qcnt = l_qcnt; }
+		if (nq <= qcap) { for (uint32_t q = threadIdx.x; q < nq; q += 256) { l_qpos[q] = H.q_pos[m0 + q]; l_qcnt[q] = H.q_cnt[m0 + q]; } qpos = l_qpos; qcnt = l_qcnt; }
 		else { qpos = H.q_pos + m0; qcnt = H.q_cnt + m0; }
 	}
 	const uint64_t r = blockIdx.x, s = seg[r], e = seg[r + 1]; const uint32_t n = (uint32_t)(e - s);
 	const int wv = threadIdx.x >> 6, lane = hao_lane();
 	if (n == 0) return;
 	const uint32_t chunk = ((n + 3) / 4 + 63) & ~63u, c0 = min(n, wv * chunk), c1 = min(n, c0 + chunk);
-	for (int i = threadIdx.x; i < 1024; i += 256) cnt[i >> 8][i & 255] = 0;
+	for (uint32_t i = threadIdx.x; i < 4 * ND; i += 256) cnt(i >> nbits, i & dmask) = 0;
 	__syncthreads();
 	for (uint32_t t0 = c0; t0 < c1; t0 += 64) {
 		const uint32_t i = t0 + lane; const bool act = i < c1;
-		const uint32_t d = act ? (uint32_t)(in[s + i] >> shift) & 255u : 0;
-		const unsigned long long m = hao_match8(d, act);
-		if (act && (m & ((1ULL << lane) - 1)) == 0) cnt[wv][d] += __popcll(m);      // leader of its digit in this tile
+		const uint32_t d = act ? (uint32_t)(in[s + i] >> shift) & dmask : 0;
+		const unsigned long long m = hao_match_bits(d, act, nbits);
+		if (act && (m & ((1ULL << lane) - 1)) == 0) cnt(wv, d) += __popcll(m);      // leader of its digit in this tile
 	}
 	__syncthreads();
-	{	// exclusive offsets in (digit major, wave minor) order
-		const int d = threadIdx.x; uint32_t run = 0;
-		for (int x = 0; x < 4; ++x) { uint32_t c = cnt[x][d]; cnt[x][d] = run; run += c; }
-		tot[d] = run;
-		__syncthreads();
-		uint32_t v = tot[d], tsum; uint32_t ex = hao_wave_excl_scan(v, &tsum);
+	{	// exclusive offsets in (digit major, wave minor) order: thread t owns digits [t*per, (t+1)*per)
+		const uint32_t per = (ND + 255) / 256, d0 = threadIdx.x * per; uint32_t mine = 0;
+		for (uint32_t d = d0; d < d0 + per && d < ND; ++d) { uint32_t run = 0; for (int x = 0; x < 4; ++x) { uint32_t c = cnt(x, d); cnt(x, d) = run; run += c; } tot[d] = mine; mine += run; }
+		uint32_t tsum; uint32_t ex = hao_wave_excl_scan(mine, &tsum);
 		__shared__ uint32_t wsum[4];
-		if (lane == 63) wsum[wv] = ex + v;
+		if (lane == 63) wsum[wv] = ex + mine;
 		__syncthreads();
-		uint32_t add = 0; for (int x = 0; x < wv; ++x) add += wsum[x];
-		ex += add;
-		for (int x = 0; x < 4; ++x) cnt[x][d] += ex;
+		for (int x = 0; x < wv; ++x) ex += wsum[x];
+		for (uint32_t d = d0; d < d0 + per && d < ND; ++d) { const uint32_t b = ex + tot[d]; for (int x = 0; x < 4; ++x) cnt(x, d) += b; }
 	}
 	__syncthreads();
 	for (uint32_t t0 = c0; t0 < c1; t0 += 64) {
 		const uint32_t i = t0 + lane; const bool act = i < c1;
-		const uint64_t key = act ? in[s + i] : 0; const uint32_t d = act ? (uint32_t)(key >> shift) & 255u : 0;
-		const unsigned long long m = hao_match8(d, act);
-		uint32_t base = act ? cnt[wv][d] : 0;
+		const uint64_t key = act ? in[s + i] : 0; const uint32_t d = act ? (uint32_t)(key >> shift) & dmask : 0;
+		const unsigned long long m = hao_match_bits(d, act, nbits);
+		uint32_t base = act ? cnt(wv, d) : 0;
 		if (act) {
 			const uint64_t pos = s + base + __popcll(m & ((1ULL << lane) - 1));
 			if (FINAL) H.hits[pos] = hao_key_to_hit(H.F, key, qpos, qcnt); else out[pos] = key;
 		}
-		if (act && (m & ((1ULL << lane) - 1)) == 0) cnt[wv][d] = base + __popcll(m);
+		if (act && (m & ((1ULL << lane) - 1)) == 0) cnt(wv, d) = base + __popcll(m);
 	}
 }
+#undef cnt
 
 // Q5: target groups of each read (hits are sorted by target id inside a read).
 // pass 0: count groups per read; pass 1: write group starts at g_off[r] + rank.

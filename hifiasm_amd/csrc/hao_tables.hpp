@@ -45,6 +45,8 @@ static int hao_prepare_runs(hao_ctx *c, uint64_t lo, uint64_t hi, bool force_sca
 	return HAO_OK;
 }
 
+struct RunHead { const uint64_t *k; __host__ __device__ uint64_t operator()(uint64_t i) const { return (i == 0 || k[i] != k[i - 1]) ? 1 : 0; } };
+
 // sort keys, run-length encode, histogram.  in: d_keys[n] (destroyed). out: unique keys / counts in c->d_u_keys / d_u_cnt, n_unique.
 struct hao_rle_out { uint64_t n_unique; };
 static int hao_sort_rle_hist(hao_ctx *c, uint64_t *d_keys, uint64_t *d_keys_alt, uint64_t n, DevBuf<uint64_t> &ukeys, DevBuf<uint32_t> &ucnt, uint64_t *n_unique, int64_t hist[HAO_N_COUNTS], uint64_t **sorted_out)
@@ -57,7 +59,18 @@ static int hao_sort_rle_hist(hao_ctx *c, uint64_t *d_keys, uint64_t *d_keys_alt,
 	HIP_TRY(hao_tmp(c, tb));
 	HIP_TRY(rocprim::radix_sort_keys(c->d_tmp.p, tb, db, n, 0, 64, c->stream));
 	uint64_t *sorted = db.current(); *sorted_out = sorted;
-	HIP_TRY(ukeys.reserve(n + 1)); HIP_TRY(ucnt.reserve(n + 1)); HIP_TRY(c->d_cursor.reserve(2));
+	HIP_TRY(c->d_cursor.reserve(2));
+	uint64_t n_runs = 0;
+	{	// number of distinct keys = number of run heads: lets the RLE outputs be sized exactly (matters at 10^9 k-mers)
+		auto heads = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), RunHead{sorted});
+		tb = 0;
+		HIP_TRY(rocprim::reduce(nullptr, tb, heads, (uint64_t*)c->d_cursor.p, (uint64_t)0, n, rocprim::plus<uint64_t>(), c->stream));
+		HIP_TRY(hao_tmp(c, tb));
+		HIP_TRY(rocprim::reduce(c->d_tmp.p, tb, heads, (uint64_t*)c->d_cursor.p, (uint64_t)0, n, rocprim::plus<uint64_t>(), c->stream));
+		HIP_TRY(hipMemcpyAsync(&n_runs, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+	}
+	HIP_TRY(ukeys.reserve(n_runs + 1)); HIP_TRY(ucnt.reserve(n_runs + 1));
 	tb = 0;
 	HIP_TRY(rocprim::run_length_encode(nullptr, tb, sorted, n, ukeys.p, ucnt.p, (uint64_t*)c->d_cursor.p, c->stream));
 	HIP_TRY(hao_tmp(c, tb));
