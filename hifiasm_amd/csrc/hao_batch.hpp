@@ -155,7 +155,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	HIP_TRY(B.ol.reserve(NC + 1)); HIP_TRY(B.ol_fc_off.reserve(NC + 1)); HIP_TRY(B.cl.reserve(B.n_cl + 1)); HIP_TRY(B.fc_raw.reserve(B.n_fc_raw + 1)); HIP_TRY(B.perm.reserve(NC + 1));
 	if (G) {
 		hao_asm_args aa;
-		aa.g_start = B.g_start.p; aa.g_read = B.g_read.p; aa.g_off = B.g_off.p; aa.n_groups = G; aa.rid_lo = glo; aa.ohits = B.ohits.p; aa.fcs = B.fcs.p; aa.rec = B.rec.p; aa.nch = B.nch.p;
+		aa.g_start = B.g_start.p; aa.g_read = B.g_read.p; aa.g_off = B.g_off.p; aa.n_groups = G; aa.rid_lo = glo; aa.ohits = B.ohits.p; aa.hits = B.hits.p; aa.fcs = B.fcs.p; aa.rec = B.rec.p; aa.nch = B.nch.p;
 		aa.ch_base = B.ch_base.p; aa.cl_base = B.cl_base.p; aa.fc_base = B.fc_base.p; aa.ol = B.ol.p; aa.ol_fc_off = B.ol_fc_off.p; aa.cl = B.cl.p; aa.fc = B.fc_raw.p;
 		hipLaunchKernelGGL(chain_assemble_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream, aa);
 		HAO_CHECK_LAUNCH();

@@ -21,6 +21,7 @@
 
 struct hao_chain_rec {          // one kept chain of a group
 	uint32_t x_pos_s, x_pos_e, y_pos_s, y_pos_e; int32_t score; uint32_t n_hits, hit_rel, fc_rel, fc_len, strand;
+	uint32_t src_rel, in_place;     // in_place: the chain is the contiguous run hits[g_start + src_rel ..) of the sorted seed hits (fast path, nothing was copied)
 };
 
 #define HH_ID(h)     ((h).w0 & 0x7fffffffu)
@@ -150,7 +151,7 @@ __device__ void hao_chain_tail(const hao_chain_args &A, const uint64_t g, const 
 			// write each chain to des[] from a private walk: des and a may alias only if des == a (they do not: separate buffers)
 			for (k = 0, i = 0; k < n_u; ++k) {
 				n_v0 = c_nv0[k]; ni = c_ni[k];
-				rec[k].hit_rel = (uint32_t)i; rec[k].n_hits = (uint32_t)ni;
+				rec[k].hit_rel = (uint32_t)i; rec[k].n_hits = (uint32_t)ni; rec[k].src_rel = (uint32_t)i; rec[k].in_place = 0;
 				for (j = 0; j < ni; ++j, ++i) des[i] = a[ii[n_v0 + (ni - j - 1)]];
 				rec[k].fc_rel = fcn; rec[k].fc_len = hao_fake_cigar(fcs + fcn, rec[k], des + i - ni, ni); fcn += rec[k].fc_len;
 			}
@@ -163,7 +164,7 @@ __device__ void hao_chain_tail(const hao_chain_args &A, const uint64_t g, const 
 	}
 	hao_region(rec[0], P.xl, P.yl, msc, a[t[cL - 1]], a[t[0]]);
 	for (i = 0; i < cL; ++i) des[i] = a[t[cL - i - 1]];
-	rec[0].hit_rel = 0; rec[0].n_hits = (uint32_t)cL; rec[0].fc_rel = 0; rec[0].fc_len = hao_fake_cigar(fcs, rec[0], des, cL);
+	rec[0].hit_rel = 0; rec[0].n_hits = (uint32_t)cL; rec[0].src_rel = 0; rec[0].in_place = 0; rec[0].fc_rel = 0; rec[0].fc_len = hao_fake_cigar(fcs, rec[0], des, cL);
 	A.nch[g] = 1; A.nout[g] = (uint32_t)cL;
 }
 
@@ -333,14 +334,13 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A)
 		return;
 	}
 	// ---- single chain = the whole best block ----
-	hao_hit_t *des = A.ohits + gs; uint64_t *fcs = A.fcs + gs + 6 * g; hao_chain_rec rc;
+	uint64_t *fcs = A.fcs + gs + 6 * g; hao_chain_rec rc;
 	hao_region(rc, P.xl, P.yl, msc, best ? first1 : first0, best ? last1 : last0);
 	uint32_t cnt = 1; int64_t carry_dd = INT32_MAX; uint32_t last_site = 0; int64_t last_dd = 0;
 	if (lane == 0) fcs[0] = hao_fc_entry(rc.x_pos_s, 0);
 	for (int64_t t0 = 0; t0 < cL; t0 += 64) {
 		const int64_t k = t0 + lane; const bool act = k < cL;
 		hao_hit_t h = act ? a[bl + k] : a[bl];
-		if (act) des[k] = h;
 		int64_t dd = ((int64_t)h.offset - rc.y_pos_s) - ((int64_t)h.self_offset - rc.x_pos_s);
 		int64_t pd = __shfl_up(dd, 1); if (lane == 0) pd = carry_dd;
 		const bool flag = act && dd != pd;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A)
 	}
 	if (last_site != rc.x_pos_e) { if (lane == 0) fcs[cnt] = hao_fc_entry(rc.x_pos_e, (int32_t)last_dd); ++cnt; }
 	if (lane == 0) {
-		rc.hit_rel = 0; rc.n_hits = (uint32_t)cL; rc.fc_rel = 0; rc.fc_len = cnt;
+		rc.hit_rel = 0; rc.n_hits = (uint32_t)cL; rc.src_rel = (uint32_t)bl; rc.in_place = 1; rc.fc_rel = 0; rc.fc_len = cnt;
 		A.rec[g * HAO_MCOPY_MAX] = rc; A.nch[g] = 1; A.nout[g] = (uint32_t)cL;
 	}
 }
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(hao_chain_args A, uint64_t
 // ---------------------------------------------------------------------------------------
 struct hao_asm_args {
 	const uint64_t *g_start; const uint32_t *g_read; const uint64_t *g_off; uint64_t n_groups; uint64_t rid_lo;
-	const hao_hit_t *ohits; const uint64_t *fcs; const hao_chain_rec *rec; const uint32_t *nch;
+	const hao_hit_t *ohits, *hits; const uint64_t *fcs; const hao_chain_rec *rec; const uint32_t *nch;
 	const uint64_t *ch_base, *cl_base, *fc_base;   // exclusive scans over groups (chains, hits) and over chain slots (fake-cigar entries)
 	hao_ovlp_t *ol; uint64_t *ol_fc_off; hao_hit_t *cl; uint64_t *fc;
 };
@@ -511,19 +511,20 @@ __global__ __launch_bounds__(256) void chain_assemble_kernel(hao_asm_args A)
 	const uint32_t n = A.nch[g]; if (n == 0) return;
 	const uint32_t r = A.g_read[g]; const uint64_t g0 = A.g_off[r];
 	const uint64_t ord0 = A.ch_base[g] - A.ch_base[g0], cl0 = A.cl_base[g0];
-	const hao_hit_t *src = A.ohits + A.g_start[g]; const uint64_t *fsrc = A.fcs + A.g_start[g] + 6 * g;
+	const uint64_t *fsrc = A.fcs + A.g_start[g] + 6 * g;
 	for (uint32_t c = 0; c < n; ++c) {
 		const hao_chain_rec rc = A.rec[g * HAO_MCOPY_MAX + c];
 		const uint64_t oi = A.ch_base[g] + c, hd = A.cl_base[g] + rc.hit_rel, fd = A.fc_base[g * HAO_MCOPY_MAX + c];
 		const uint32_t ord = (uint32_t)(ord0 + c);
+		const hao_hit_t *src = (rc.in_place ? A.hits : A.ohits) + A.g_start[g] + rc.src_rel;
 		if (hao_lane() == 0) {
 			hao_ovlp_t o;
 			o.x_id = (uint32_t)(A.rid_lo + r); o.x_pos_s = rc.x_pos_s; o.x_pos_e = rc.x_pos_e; o.x_pos_strand = 0;
-			o.y_id = HH_ID(src[rc.hit_rel]); o.y_pos_s = rc.y_pos_s; o.y_pos_e = rc.y_pos_e; o.y_pos_strand = rc.strand;
+			o.y_id = HH_ID(src[0]); o.y_pos_s = rc.y_pos_s; o.y_pos_e = rc.y_pos_e; o.y_pos_strand = rc.strand;
 			o.shared_seed = rc.score; o.align_length = rc.n_hits; o.non_homopolymer_errors = (uint32_t)(hd - cl0); o.fc_len = rc.fc_len;
 			A.ol[oi] = o; A.ol_fc_off[oi] = fd;
 		}
-		for (uint32_t i = hao_lane(); i < rc.n_hits; i += 64) { hao_hit_t h = src[rc.hit_rel + i]; h.w0 = (h.w0 & 0x80000000u) | (ord & 0x7fffffffu); A.cl[hd + i] = h; }
+		for (uint32_t i = hao_lane(); i < rc.n_hits; i += 64) { hao_hit_t h = src[i]; h.w0 = (h.w0 & 0x80000000u) | (ord & 0x7fffffffu); A.cl[hd + i] = h; }
 		for (uint32_t i = hao_lane(); i < rc.fc_len; i += 64) A.fc[fd + i] = fsrc[rc.fc_rel + i];
 	}
 }
