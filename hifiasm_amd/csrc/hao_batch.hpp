@@ -136,7 +136,16 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		HAO_CHECK_LAUNCH();
 		c->timer.mark("q_chain");
 		{ unsigned long long st[2]; HIP_TRY(hipMemcpyAsync(st, B.stats.p, 16, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); B.n_generic = st[0]; B.n_generic_hits = st[1]; }
-		if (B.n_generic && !ca.dbg_skip_generic) { hipLaunchKernelGGL(chain_dp_kernel, dim3((unsigned)B.n_generic), dim3(64), 0, c->stream, ca, B.n_generic); HAO_CHECK_LAUNCH(); }
+		if (B.n_generic && !ca.dbg_skip_generic) {
+			// split by size: groups up to 512 hits keep hits + DP arrays in 14 KB of LDS (many waves per CU), larger ones use the 2048-hit variant
+			std::vector<uint64_t> sl(B.n_generic), small, large;        // entries: group id | size << 40
+			HIP_TRY(hipMemcpy(sl.data(), B.slow_list.p, B.n_generic * 8, hipMemcpyDeviceToHost));
+			for (uint64_t e : sl) ((e >> 40) <= 512 ? small : large).push_back(e);
+			if (!small.empty()) HIP_TRY(hipMemcpy(B.slow_list.p, small.data(), small.size() * 8, hipMemcpyHostToDevice));
+			if (!large.empty()) HIP_TRY(hipMemcpy(B.slow_list.p + small.size(), large.data(), large.size() * 8, hipMemcpyHostToDevice));
+			if (!small.empty()) { hipLaunchKernelGGL((chain_dp_kernel<512, true>), dim3((unsigned)small.size()), dim3(64), 0, c->stream, ca, B.slow_list.p, (uint64_t)small.size()); HAO_CHECK_LAUNCH(); }
+			if (!large.empty()) { hipLaunchKernelGGL((chain_dp_kernel<HAO_DP_CAP, false>), dim3((unsigned)large.size()), dim3(64), 0, c->stream, ca, B.slow_list.p + small.size(), (uint64_t)large.size()); HAO_CHECK_LAUNCH(); }
+		}
 	}
 	HIP_TRY(hipMemsetAsync(B.nch.p + G, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(B.nout.p + G, 0, 4, c->stream));
 	c->timer.mark("q_chain_dp");

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A)
 		if ((int64_t)(best ? maxf0 : maxf1) >= min_sc) fast = false;         // a second chain may qualify: exact sequential path
 	}
 	if (!fast) {
-		if (lane == 0) { unsigned long long si_ = atomicAdd(A.stats, 1ULL); atomicAdd(A.stats + 1, (unsigned long long)a_n); A.slow_list[si_] = g; A.nch[g] = 0; A.nout[g] = 0; }
+		if (lane == 0) { unsigned long long si_ = atomicAdd(A.stats, 1ULL); atomicAdd(A.stats + 1, (unsigned long long)a_n); A.slow_list[si_] = g | (uint64_t)(a_n > 0xffffff ? 0xffffff : a_n) << 40; A.nch[g] = 0; A.nout[g] = 0; }
 		return;
 	}
 	// ---- single chain = the whole best block ----
@@ -370,19 +370,22 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A)
 // ---------------------------------------------------------------------------------------
 #define HAO_DP_CAP 2048
 
-__global__ __launch_bounds__(64) void chain_dp_kernel(hao_chain_args A, uint64_t n_slow)
+template<int CAP, bool STAGE>
+__global__ __launch_bounds__(64) void chain_dp_kernel(hao_chain_args A, const uint64_t *list, uint64_t n_slow)
 {
-	__shared__ int32_t l_f[HAO_DP_CAP], l_p[HAO_DP_CAP], l_tm[HAO_DP_CAP];
+	__shared__ int32_t l_f[CAP], l_p[CAP], l_tm[CAP]; __shared__ hao_hit_t l_a[STAGE ? CAP : 1];
 	if (blockIdx.x >= n_slow) return;
-	const uint64_t g = A.slow_list[blockIdx.x];
+	const uint64_t g = list[blockIdx.x] & ((1ULL << 40) - 1);
 	const int lane = hao_lane();
 	if (A.dbg_seq) { if (lane == 0) hao_chain_generic(A, g); return; }
 	const uint32_t r = A.g_read[g]; const uint64_t gs = A.g_start[g], ge = (g + 1 < A.g_off[r + 1]) ? A.g_start[g + 1] : A.seg[r + 1];
-	const hao_hit_t *a = A.hits + gs; const int64_t a_n = (int64_t)(ge - gs);
+	const hao_hit_t *ag = A.hits + gs; const int64_t a_n = (int64_t)(ge - gs);
+	const bool in_lds = a_n <= CAP;
+	if (STAGE && in_lds) { for (int64_t i = lane; i < a_n; i += 64) l_a[i] = ag[i]; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+	const hao_hit_t *a = (STAGE && in_lds) ? l_a : ag;          // the DP re-reads predecessors many times: small groups keep their hits in LDS
 	const uint32_t xid = (uint32_t)(A.rid_lo + r), yid = HH_ID(a[0]);
 	hao_cpar P; P.pen_gap = A.par.pen_gap; P.pen_skip = A.par.pen_skip; P.bw = A.par.bw; P.max_skip = A.par.max_skip; P.max_iter = A.par.max_iter; P.max_dis = A.par.max_dis;
 	P.xl = A.len[xid]; P.yl = A.len[yid];
-	const bool in_lds = a_n <= HAO_DP_CAP;
 	int32_t *f = in_lds ? l_f : A.f + gs, *p = in_lds ? l_p : A.p + gs, *tm = in_lds ? l_tm : A.tm + gs;
 	int32_t *ii = A.ii + gs; int64_t *t = A.t + gs;
 	const uint32_t strand0 = HH_STRAND(a[0]);
@@ -460,13 +463,20 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(hao_chain_args A, uint64_t
 				pm = __shfl_up(pm, 1); if (lane == 0) pm = INT64_MIN;
 				if (pm < max_f) pm = max_f;
 				const bool improve = valid && sc > pm;
-				unsigned long long imask = __ballot(improve), cmask = __ballot(valid && !improve && mark), ev = imask | cmask;
-				int brk_lane = -1;
-				while (ev) {
-					int l = __ffsll((long long)ev) - 1; ev &= ev - 1;
-					if (imask >> l & 1) { if (n_skip > 0) --n_skip; }
-					else if (++n_skip > P.max_skip) { brk_lane = l; break; }
-				}
+				// n_skip bookkeeping of the sequential scan (improve: n = max(n-1, 0); marked non-improving: ++n, stop when n > max_skip)
+				// is a reflected walk: n_l = S_l - min(0, min_{l' <= l} S_l') with S = n_in + prefix sum of the steps
+				const bool inc = valid && !improve && mark;
+				int32_t S = improve ? -1 : (inc ? 1 : 0);
+#pragma unroll
+				for (int d = 1; d < 64; d <<= 1) { int32_t y = __shfl_up(S, d); if (lane >= d) S += y; }
+				S += (int32_t)n_skip;
+				int32_t mn = S < 0 ? S : 0;
+#pragma unroll
+				for (int d = 1; d < 64; d <<= 1) { int32_t y = __shfl_up(mn, d); if (lane >= d && y < mn) mn = y; }
+				const int32_t nl = S - mn;
+				unsigned long long imask = __ballot(improve), bmask = __ballot(inc && nl > (int32_t)P.max_skip);
+				int brk_lane = bmask ? __ffsll((long long)bmask) - 1 : -1;
+				n_skip = __shfl(nl, brk_lane >= 0 ? brk_lane : 63);
 				if (brk_lane >= 0) imask &= (1ULL << brk_lane) - 1;
 				if (imask) { int src = 63 - __clzll((long long)imask); max_f = __shfl(sc, src); max_j = jb - src; }
 				if (brk_lane >= 0) { end_j = jb - brk_lane; break; }
