@@ -185,7 +185,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	sa.key_xs = B.key_xs.p; sa.key_sc = B.key_sc.p; sa.key_al = B.key_al.p;
 	sa.ol = B.ol.p; sa.g_off = B.g_off.p; sa.ch_base = B.ch_base.p; sa.cl_base = B.cl_base.p; sa.cl = B.cl.p; sa.n_sel = n; sa.rid_lo = glo; sa.len = c->d_len_all.p; sa.cc_off = B.cc_off.p; sa.cc = B.cc.p;
 	sa.perm = B.perm.p; sa.n_final = B.n_final.p; sa.fc_final = B.fc_final.p; sa.max_n_chain = par.max_n_chain; sa.ocv_w = par.ocv_w; sa.chain_cutoff = par.chain_cutoff;
-	hipLaunchKernelGGL(chain_select_kernel, dim3((unsigned)((n + 4) / 4)), dim3(256), 0, c->stream, sa);
+	hipLaunchKernelGGL((chain_select_kernel<4, 512>), dim3((unsigned)((n + 4) / 4)), dim3(256), 0, c->stream, sa, (int64_t)0, (int64_t)INT64_MAX);
 	HAO_CHECK_LAUNCH();
 	if (int rc = hao_scan_u32(c, B.n_final.p, B.fin_off.p, n + 1)) return rc;
 	if (int rc = hao_excl_scan_u64(c, B.fc_final.p, B.fcf_off.p, n + 1)) return rc;

@@ -730,18 +730,22 @@ __device__ int64_t hao_select_weak(const hao_sel_args &A, const hao_sel_ctx &S, 
 	return ll;
 }
 
-__global__ __launch_bounds__(256) void chain_select_kernel(hao_sel_args A)
+// WPB waves per workgroup, each wave one read; CAP = chains whose keys fit the wave's LDS slice.  Two launches cover a batch:
+// <4, 512> takes the reads with up to 512 chains, <1, 4096> the rest (reads beyond 4096 chains keep their keys in global scratch).
+template<int WPB, int CAP>
+__global__ __launch_bounds__(WPB * 64) void chain_select_kernel(hao_sel_args A, int64_t n_lo, int64_t n_hi)
 {
-	__shared__ uint64_t l_xs[4][HAO_SEL_CAP]; __shared__ int32_t l_sc[4][HAO_SEL_CAP]; __shared__ uint32_t l_al[4][HAO_SEL_CAP], l_pm[4][HAO_SEL_CAP]; __shared__ int32_t l_stack[4][3 * 72];
+	__shared__ uint64_t l_xs[WPB][CAP]; __shared__ int32_t l_sc[WPB][CAP]; __shared__ uint32_t l_al[WPB][CAP], l_pm[WPB][CAP]; __shared__ int32_t l_stack[WPB][3 * 72];
 	const int wv = threadIdx.x >> 6, lane = hao_lane();
-	const uint64_t r = (uint64_t)blockIdx.x * 4 + wv;
+	const uint64_t r = (uint64_t)blockIdx.x * WPB + wv;
 	if (r > A.n_sel) return;
-	if (r == A.n_sel) { if (lane == 0) { A.n_final[r] = 0; A.fc_final[r] = 0; } return; }
+	if (r == A.n_sel) { if (lane == 0 && n_lo == 0) { A.n_final[r] = 0; A.fc_final[r] = 0; } return; }
 	const uint64_t g0 = A.g_off[r], g1 = A.g_off[r + 1], o0 = A.ch_base[g0];
 	int64_t n = (int64_t)(A.ch_base[g1] - o0);
+	if (n < n_lo || n >= n_hi) return;                          // this read belongs to the other launch
 	const uint64_t cl0 = A.cl_base[g0], cn = A.cl_base[g1] - cl0;
 	const hao_ovlp_t *rec = A.ol + o0;
-	const bool in_lds = n <= HAO_SEL_CAP;
+	const bool in_lds = n <= CAP;
 	uint64_t *xs = in_lds ? l_xs[wv] : A.key_xs + o0; int32_t *sc = in_lds ? l_sc[wv] : A.key_sc + o0;
 	uint32_t *al = in_lds ? l_al[wv] : A.key_al + o0, *pm = in_lds ? l_pm[wv] : A.perm + o0;
 	int lch = 0;
