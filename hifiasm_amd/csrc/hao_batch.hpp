@@ -12,7 +12,7 @@ struct hao_ctx::Batch {
 	DevBuf<uint64_t> nch64;
 	DevBuf<uint32_t> q_pos, q_cnt, s_n, g_read, wgt, nch, nout, perm, n_final, fclen;
 	DevBuf<hao_hit_t> hits, ohits, cl;
-	DevBuf<int32_t> f, ii, p, key_sc, tm; DevBuf<uint64_t> slow_list; DevBuf<int64_t> t; DevBuf<uint64_t> key_xs; DevBuf<uint32_t> key_al;
+	DevBuf<int32_t> f, ii, p, key_sc, tm; DevBuf<uint64_t> slow_list; DevBuf<int64_t> t; DevBuf<uint64_t> key_xs; DevBuf<uint32_t> key_al, key_tmp;
 	DevBuf<hao_chain_rec> rec; DevBuf<hao_ovlp_t> ol, ol_out;
 	// host copies for fetch
 	std::vector<uint64_t> h_seg, h_fin_off, h_cl_off, h_fc_out_off; std::vector<hao_hit_t> h_hits, h_cl; std::vector<hao_ovlp_t> h_ol; std::vector<uint64_t> h_fc;
@@ -21,7 +21,7 @@ struct hao_ctx::Batch {
 		s_start.release(); a_off.release(); seg.release(); keys.release(); keys2.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fin_off.release(); fcf_off.release(); fc_out.release(); fc_out_off.release();
 		nch64.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
-		tm.release(); slow_list.release(); key_sc.release(); key_xs.release(); key_al.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); ol_out.release();
+		tm.release(); slow_list.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); ol_out.release();
 	}
 };
 
@@ -182,10 +182,11 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	}
 	HIP_TRY(B.key_xs.reserve(NC + 1)); HIP_TRY(B.key_sc.reserve(NC + 1)); HIP_TRY(B.key_al.reserve(NC + 1));
 	hao_sel_args sa;
-	sa.key_xs = B.key_xs.p; sa.key_sc = B.key_sc.p; sa.key_al = B.key_al.p;
+	HIP_TRY(B.key_tmp.reserve(5 * NC + 8));
+	sa.key_xs = B.key_xs.p; sa.key_sc = B.key_sc.p; sa.key_al = B.key_al.p; sa.key_tmp = B.key_tmp.p;
 	sa.ol = B.ol.p; sa.g_off = B.g_off.p; sa.ch_base = B.ch_base.p; sa.cl_base = B.cl_base.p; sa.cl = B.cl.p; sa.n_sel = n; sa.rid_lo = glo; sa.len = c->d_len_all.p; sa.cc_off = B.cc_off.p; sa.cc = B.cc.p;
 	sa.perm = B.perm.p; sa.n_final = B.n_final.p; sa.fc_final = B.fc_final.p; sa.max_n_chain = par.max_n_chain; sa.ocv_w = par.ocv_w; sa.chain_cutoff = par.chain_cutoff;
-	hipLaunchKernelGGL((chain_select_kernel<4, 512>), dim3((unsigned)((n + 4) / 4)), dim3(256), 0, c->stream, sa, (int64_t)0, (int64_t)INT64_MAX);
+	hipLaunchKernelGGL((chain_select_kernel<1, 1024>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)0, (int64_t)INT64_MAX);
 	HAO_CHECK_LAUNCH();
 	if (int rc = hao_scan_u32(c, B.n_final.p, B.fin_off.p, n + 1)) return rc;
 	if (int rc = hao_excl_scan_u64(c, B.fc_final.p, B.fcf_off.p, n + 1)) return rc;

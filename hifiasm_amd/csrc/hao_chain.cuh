@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) void chain_assemble_kernel(hao_asm_args A)
 // use global scratch for the keys.
 // ---------------------------------------------------------------------------------------
 #define HAO_SEL_CAP 512
-struct hao_sel_ctx { const uint64_t *xs; const int32_t *sc; const uint32_t *al; uint32_t *pm; int32_t *stack; };
+struct hao_sel_ctx { const uint64_t *xs; const int32_t *sc; const uint32_t *al; uint32_t *pm; int32_t *stack; uint32_t *pm2, *lpos, *rasc; };
 __device__ __forceinline__ void hao_sw(const hao_sel_ctx &S, int64_t i, int64_t j) { uint32_t t = S.pm[i]; S.pm[i] = S.pm[j]; S.pm[j] = t; }
 template<int MODE> __device__ __forceinline__ bool hao_lt(const hao_sel_ctx &S, int64_t i, int64_t j)
 {	// MODE 0: oreg_ss_lt (score, descending; anchor.cpp:35)   MODE 1: oreg_xs_lt ((x_pos_s, x_pos_e) ascending; anchor.cpp:32)
@@ -605,6 +605,104 @@ template<int MODE> __device__ void hao_intro_sort(const hao_sel_ctx &S, int64_t 
 	}
 }
 
+
+// ---------------------------------------------------------------------------------------
+// The same klib introsort, executed by a whole wave with identical results.
+//  * control (range stack, depth budget, median of three) is uniform scalar work;
+//  * the Hoare partition is data-parallel: the left pointer stops at positions whose key is not
+//    below the pivot, the right pointer at positions whose key is not above it; stop number k from
+//    the left swaps with stop number k from the right while they have not crossed, so both stop
+//    lists come from two ballots per 64-position tile and all swaps of one partition happen at
+//    once; the final pivot slot is min(left stop K+1, right stop K) (K = number of swaps);
+//  * ranges of <= 16 elements are left alone by klib and finished by ONE insertion sort over the
+//    whole array; insertion sort is stable, i.e. the finish is the stable sort of the array as the
+//    partitions left it = a bitonic sort of (key, position) pairs;
+//  * the combsort fallback (depth budget exhausted) stays sequential on lane 0.
+// ---------------------------------------------------------------------------------------
+template<int MODE> __device__ __forceinline__ uint64_t hao_skey(const hao_sel_ctx &S, uint32_t idx)
+{	// order-preserving 64-bit key: MODE 0 = score descending, MODE 1 = (x_pos_s, x_pos_e) ascending
+	return MODE == 0 ? (uint64_t)((int64_t)INT32_MAX - (int64_t)S.sc[idx]) : S.xs[idx];
+}
+
+#define HAO_WFENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+
+template<int MODE> __device__ void hao_wave_intro_sort(const hao_sel_ctx &S, int64_t n)
+{
+	const int lane = hao_lane(); int32_t *stack = S.stack; int64_t top = 0, s, t, i, j, k; int d;
+	if (n < 1) return;
+	if (n == 2) { if (lane == 0 && hao_lt<MODE>(S, 1, 0)) hao_sw(S, 0, 1); HAO_WFENCE(); return; }
+	for (d = 2; (1ull << d) < (uint64_t)n; ++d) {}
+	s = 0; t = n - 1; d <<= 1;
+	for (;;) {
+		if (s < t) {
+			if (--d == 0) { if (lane == 0) hao_comb_sort<MODE>(S, s, t - s + 1); HAO_WFENCE(); t = s; continue; }
+			i = s; j = t; k = i + ((j - i) >> 1) + 1;
+			if (hao_lt<MODE>(S, k, i)) { if (hao_lt<MODE>(S, k, j)) k = j; }
+			else k = hao_lt<MODE>(S, j, i) ? i : j;
+			if (k != t) { if (lane == 0) hao_sw(S, k, t); HAO_WFENCE(); }
+			const uint64_t rp = hao_skey<MODE>(S, S.pm[t]);
+			uint32_t nL = 0, nR = 0;
+			for (int64_t p0 = s + 1; p0 <= t; p0 += 64) {
+				const int64_t p = p0 + lane; const bool act = p <= t;
+				const uint64_t key = act ? hao_skey<MODE>(S, S.pm[p]) : 0;
+				const bool Lf = act && !(key < rp), Rf = act && p < t && !(rp < key);
+				const unsigned long long bl = __ballot(Lf), br = __ballot(Rf), lt_ = (1ULL << lane) - 1;
+				if (Lf) S.lpos[nL + __popcll(bl & lt_)] = (uint32_t)p;
+				if (Rf) S.rasc[nR + __popcll(br & lt_)] = (uint32_t)p;
+				nL += __popcll(bl); nR += __popcll(br);
+			}
+			HAO_WFENCE();
+			const uint32_t m = nL < nR ? nL : nR; uint32_t K = 0;       // swaps: left stop k with right stop k while left < right
+			for (uint32_t k0 = 0; k0 < m; k0 += 64) {
+				const uint32_t kk = k0 + lane; const bool pr = kk < m && S.lpos[kk] < S.rasc[nR - 1 - kk];
+				const unsigned long long b = __ballot(pr); const int c = __popcll(b);
+				K += c; if (c < 64) break;
+			}
+			for (uint32_t k0 = 0; k0 < K; k0 += 64) { const uint32_t kk = k0 + lane; if (kk < K) hao_sw(S, S.lpos[kk], S.rasc[nR - 1 - kk]); }
+			HAO_WFENCE();
+			i = K == 0 ? S.lpos[0] : (S.lpos[K] < S.rasc[nR - K] ? S.lpos[K] : S.rasc[nR - K]);
+			if (lane == 0) hao_sw(S, i, t);
+			HAO_WFENCE();
+			if (i - s > t - i) {
+				if (i - s > 16) { if (lane == 0) { stack[top] = (int32_t)s; stack[top + 1] = (int32_t)(i - 1); stack[top + 2] = d; } top += 3; }
+				s = t - i > 16 ? i + 1 : t;
+			} else {
+				if (t - i > 16) { if (lane == 0) { stack[top] = (int32_t)(i + 1); stack[top + 1] = (int32_t)t; stack[top + 2] = d; } top += 3; }
+				t = i - s > 16 ? i - 1 : s;
+			}
+			HAO_WFENCE();
+		} else {
+			if (top == 0) break;
+			d = stack[--top]; t = stack[--top]; s = stack[--top];
+		}
+	}
+	// klib finishes with ONE insertion sort over the whole array.  Insertion sort is stable, so its result is THE stable sort
+	// of the current array (elements can travel far: klib's partition never examines a[s], which may be out of place).
+	// A stable sort is any sort of (key, current position): bitonic network over the next power of two, padding = +inf.
+	uint32_t n2 = 1; while (n2 < (uint32_t)n) n2 <<= 1;
+	uint32_t *A_ = S.pm2, *P_ = S.lpos;                      // element = (record index, position before the sort)
+	for (uint32_t p = lane; p < n2; p += 64) { A_[p] = p < (uint32_t)n ? S.pm[p] : 0xffffffffu; P_[p] = p; }
+	HAO_WFENCE();
+	for (uint32_t kk = 2; kk <= n2; kk <<= 1) {
+		for (uint32_t jj = kk >> 1; jj > 0; jj >>= 1) {
+			for (uint32_t i0 = 0; i0 < n2; i0 += 64) {
+				const uint32_t a = i0 + lane, b = a ^ jj;
+				if (a < n2 && b > a) {
+					const uint32_t ia = A_[a], ib = A_[b], pa = P_[a], pb = P_[b];
+					const bool infa = ia == 0xffffffffu, infb = ib == 0xffffffffu;
+					const uint64_t ka = infa ? 0 : hao_skey<MODE>(S, ia), kb = infb ? 0 : hao_skey<MODE>(S, ib);
+					const bool a_gt_b = infa ? (!infb || pa > pb) : (infb ? false : (ka > kb || (ka == kb && pa > pb)));
+					const bool up = (a & kk) == 0;
+					if (a_gt_b == up) { A_[a] = ib; A_[b] = ia; P_[a] = pb; P_[b] = pa; }
+				}
+			}
+			HAO_WFENCE();
+		}
+	}
+	for (int64_t p = lane; p < n; p += 64) S.pm[p] = A_[p];
+	HAO_WFENCE();
+}
+
 __device__ __forceinline__ int hao_ov_type(uint64_t xs, uint32_t len)       // ha_ov_type, anchor.cpp:86-91
 {
 	const uint32_t x_pos_s = (uint32_t)(xs >> 32), x_pos_e = (uint32_t)xs;
@@ -628,13 +726,14 @@ __device__ void hao_cov_add(uint64_t *cc, uint64_t cwn, uint64_t ocv_w, uint64_t
 struct hao_sel_args {
 	const hao_ovlp_t *ol; const uint64_t *g_off; const uint64_t *ch_base; const uint64_t *cl_base; const hao_hit_t *cl;
 	uint64_t n_sel, rid_lo; const uint32_t *len; const uint64_t *cc_off; uint64_t *cc;
-	uint64_t *key_xs; int32_t *key_sc; uint32_t *key_al;          // global key scratch (reads with > HAO_SEL_CAP chains)
+	uint64_t *key_xs; int32_t *key_sc; uint32_t *key_al, *key_tmp;   // global key scratch (reads with more chains than the LDS slice holds); key_tmp: 5 words per chain
 	uint32_t *perm; uint32_t *n_final; uint64_t *fc_final;        // outputs: permutation (per read slice), kept count, kept fake-cigar entries
 	uint64_t max_n_chain, ocv_w; uint32_t chain_cutoff;
 };
 
 // the sequential part (lane 0). returns the kept count
-__device__ int64_t hao_select_seq(const hao_sel_args &A, const hao_sel_ctx &S, int64_t n, int lch, uint64_t r, int *lch_out)
+// max_n_chain pruning (anchor.cpp:1957-2056) on the score-sorted permutation: sequential, lane 0
+__device__ int64_t hao_select_prune(const hao_sel_args &A, const hao_sel_ctx &S, int64_t n, int lch, uint64_t r, int *lch_out)
 {
 	const uint64_t rl = A.len[A.rid_lo + r], max_n_chain = A.max_n_chain, ocv_w = A.ocv_w; const uint32_t chain_cutoff = A.chain_cutoff;
 	int64_t i;
@@ -643,7 +742,6 @@ __device__ int64_t hao_select_seq(const hao_sel_args &A, const hao_sel_ctx &S, i
 #define AL(i) S.al[S.pm[i]]
 	if ((uint64_t)n > max_n_chain) {
 		int32_t w, nn[4] = {0, 0, 0, 0}, s[4] = {0, 0, 0, 0}; uint64_t cwn = 0, *cc = A.cc + A.cc_off[r], kk, mm;
-		hao_intro_sort<0>(S, n);
 		for (i = 0; i < n; ++i) { w = hao_ov_type(XS(i), (uint32_t)rl); if ((uint64_t)++nn[w] == max_n_chain) s[w] = SC(i); }
 		if (s[0] > 0 || s[1] > 0 || s[2] > 0 || s[3] > 0) {
 			if ((uint64_t)nn[3] >= max_n_chain && rl >= ocv_w) {
@@ -678,7 +776,6 @@ __device__ int64_t hao_select_seq(const hao_sel_args &A, const hao_sel_ctx &S, i
 			n = (int64_t)kk;
 		}
 	}
-	hao_intro_sort<1>(S, n);
 	*lch_out = lch;
 #undef XS
 #undef SC
@@ -735,7 +832,7 @@ __device__ int64_t hao_select_weak(const hao_sel_args &A, const hao_sel_ctx &S, 
 template<int WPB, int CAP>
 __global__ __launch_bounds__(WPB * 64) void chain_select_kernel(hao_sel_args A, int64_t n_lo, int64_t n_hi)
 {
-	__shared__ uint64_t l_xs[WPB][CAP]; __shared__ int32_t l_sc[WPB][CAP]; __shared__ uint32_t l_al[WPB][CAP], l_pm[WPB][CAP]; __shared__ int32_t l_stack[WPB][3 * 72];
+	__shared__ uint64_t l_xs[WPB][CAP]; __shared__ int32_t l_sc[WPB][CAP]; __shared__ uint32_t l_al[WPB][CAP], l_pm[WPB][CAP], l_pm2[WPB][CAP], l_lp[WPB][CAP], l_rp[WPB][CAP]; __shared__ int32_t l_stack[WPB][3 * 72];
 	const int wv = threadIdx.x >> 6, lane = hao_lane();
 	const uint64_t r = (uint64_t)blockIdx.x * WPB + wv;
 	if (r > A.n_sel) return;
@@ -757,9 +854,15 @@ __global__ __launch_bounds__(WPB * 64) void chain_select_kernel(hao_sel_args A, 
 	lch = __any(lch);
 	__threadfence_block();
 	hao_sel_ctx S; S.xs = xs; S.sc = sc; S.al = al; S.pm = pm; S.stack = l_stack[wv];
-	int64_t nf = 0; int lch2 = 0;
-	if (lane == 0) nf = hao_select_seq(A, S, n, lch, r, &lch2);
-	nf = __shfl(nf, 0); lch2 = __shfl(lch2, 0);
+	S.pm2 = in_lds ? l_pm2[wv] : A.key_tmp + 5 * o0; S.lpos = in_lds ? l_lp[wv] : A.key_tmp + 5 * o0 + 2 * n; S.rasc = in_lds ? l_rp[wv] : A.key_tmp + 5 * o0 + 4 * n;
+	int64_t nf = n; int lch2 = lch;
+	if ((uint64_t)n > A.max_n_chain) {
+		hao_wave_intro_sort<0>(S, n);
+		if (lane == 0) nf = hao_select_prune(A, S, n, lch, r, &lch2);
+		nf = __shfl(nf, 0); lch2 = __shfl(lch2, 0);
+		HAO_WFENCE();
+	}
+	hao_wave_intro_sort<1>(S, nf);
 	__threadfence_block();
 	if (lch2) nf = hao_select_weak(A, S, nf, rec, A.cl + cl0, cn);
 	__threadfence_block();
