@@ -679,8 +679,36 @@ template<int MODE> __device__ void hao_wave_intro_sort(const hao_sel_ctx &S, int
 	// klib finishes with ONE insertion sort over the whole array.  Insertion sort is stable, so its result is THE stable sort
 	// of the current array (elements can travel far: klib's partition never examines a[s], which may be out of place).
 	// A stable sort is any sort of (key, current position): bitonic network over the next power of two, padding = +inf.
-	uint32_t n2 = 1; while (n2 < (uint32_t)n) n2 <<= 1;
 	uint32_t *A_ = S.pm2, *P_ = S.lpos;                      // element = (record index, position before the sort)
+	{	// cheap attempt first: if nothing has to move further than 16 slots, final slot = position - (#larger among the 16 before)
+		// + (#smaller among the 16 after).  Accepted only when the result is a permutation that is sorted by (key, old position):
+		// that IS the stable sort.  Otherwise (an out-of-place a[s]) fall through to the general network.
+		for (int64_t p = lane; p < n; p += 64) A_[p] = 0xffffffffu;
+		HAO_WFENCE();
+		for (int64_t p = lane; p < n; p += 64) {
+			const uint32_t me = S.pm[p]; const uint64_t key = hao_skey<MODE>(S, me); int64_t dst = p;
+			for (int64_t q = p - 16 < 0 ? 0 : p - 16; q < p; ++q) if (hao_skey<MODE>(S, S.pm[q]) > key) --dst;
+			for (int64_t q = p + 1; q <= p + 16 && q < n; ++q) if (hao_skey<MODE>(S, S.pm[q]) < key) ++dst;
+			if (dst >= 0 && dst < n) { A_[dst] = me; P_[dst] = (uint32_t)p; }
+		}
+		HAO_WFENCE();
+		int bad = 0;
+		for (int64_t p = lane; p < n; p += 64) {
+			if (A_[p] == 0xffffffffu) bad = 1;
+			else if (p > 0 && A_[p - 1] != 0xffffffffu) {
+				const uint64_t ka = hao_skey<MODE>(S, A_[p - 1]), kb = hao_skey<MODE>(S, A_[p]);
+				if (ka > kb || (ka == kb && P_[p - 1] > P_[p])) bad = 1;
+			}
+		}
+		if (!__any(bad)) {
+			HAO_WFENCE();
+			for (int64_t p = lane; p < n; p += 64) S.pm[p] = A_[p];
+			HAO_WFENCE();
+			return;
+		}
+		HAO_WFENCE();
+	}
+	uint32_t n2 = 1; while (n2 < (uint32_t)n) n2 <<= 1;
 	for (uint32_t p = lane; p < n2; p += 64) { A_[p] = p < (uint32_t)n ? S.pm[p] : 0xffffffffu; P_[p] = p; }
 	HAO_WFENCE();
 	for (uint32_t kk = 2; kk <= n2; kk <<= 1) {
@@ -800,21 +828,36 @@ __device__ int64_t hao_select_weak(const hao_sel_args &A, const hao_sel_ctx &S, 
 			uint64_t zs = XS(i) >> 32, ze = (uint64_t)(uint32_t)XS(i) + 1, ob = (uint64_t)((double)(ze - zs) * 0.95), ocn = (uint64_t)AL(i) << 4;
 			int64_t osc = (int64_t)SC(i) * 16;
 			if (ob < 16) ob = 16;
-			for (kk = 0; kk < n && ze > (XS(kk) >> 32); ++kk) {
-				if (AL(kk) < chain_cutoff || AL(kk) < ocn || (int64_t)SC(kk) < osc) continue;
-				uint64_t rs = XS(kk) >> 32, re = (uint64_t)(uint32_t)XS(kk) + 1, os = rs >= zs ? rs : zs, oe = re <= ze ? re : ze;
-				if (oe > os && oe - os >= ob) {
-					const uint64_t m0 = rec[S.pm[kk]].non_homopolymer_errors, nh = AL(kk);    // the chain's hits: cl[m0 .. m0+nh) share one ordinal tag
+			// candidates are examined 64 at a time: the cheap tests (strong enough, overlaps >= ob of the weak chain) run one per lane,
+			// only the survivors - in list order - get the wave-wide hit count; the scan stops at the first chain that covers the weak one
+			bool covered = false;
+			for (kk = 0; kk < n && !covered; kk += 64) {
+				const int64_t kq = kk + lane; bool inr = false, cand = false; uint64_t os = 0, oe = 0;
+				if (kq < n) {
+					const uint64_t xq = XS(kq); inr = ze > (xq >> 32);
+					if (inr && !(AL(kq) < chain_cutoff || AL(kq) < ocn || (int64_t)SC(kq) < osc)) {
+						const uint64_t rs = xq >> 32, re = (uint64_t)(uint32_t)xq + 1; os = rs >= zs ? rs : zs; oe = re <= ze ? re : ze;
+						cand = oe > os && oe - os >= ob;
+					}
+				}
+				const unsigned long long inm = __ballot(inr); unsigned long long cm = __ballot(cand);
+				const int nin = __popcll(inm);                      // list is sorted by x_pos_s: the in-range lanes are a prefix
+				while (cm) {
+					const int l = __ffsll((long long)cm) - 1; cm &= cm - 1;
+					if (l >= nin) break;
+					const int64_t kc = kk + l; const uint64_t cos = __shfl(os, l), coe = __shfl(oe, l);
+					const uint64_t m0 = rec[S.pm[kc]].non_homopolymer_errors, nh = AL(kc);    // the chain's hits: cl[m0 .. m0+nh) share one ordinal tag
 					uint64_t kn = 0;
 					for (uint64_t b = 0; b < nh && kn < ocn; b += 64) {
 						uint64_t mm = m0 + b + lane; bool in = false;
-						if (b + lane < nh && mm < cn) { uint64_t me = cl[mm].self_offset, ms = me - (cl[mm].cnt & 0xffu); in = ms >= os && me <= oe; }
+						if (b + lane < nh && mm < cn) { uint64_t me = cl[mm].self_offset, ms = me - (cl[mm].cnt & 0xffu); in = ms >= cos && me <= coe; }
 						kn += __popcll(__ballot(in));
 					}
-					if (kn >= ocn) break;
+					if (kn >= ocn) { covered = true; break; }
 				}
+				if (nin < 64) break;
 			}
-			drop = kk < n && ze > (XS(kk) >> 32);
+			drop = covered;
 		}
 		if (drop) continue;
 		if (ll != i && lane == 0) hao_sw(S, ll, i);
