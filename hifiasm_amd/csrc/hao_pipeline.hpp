@@ -115,7 +115,7 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 	const uint64_t *src_off = c->d_g_off.p;
 	if (use_ft && sample_dist > w) {
 		HIP_TRY(c->d_new_n.reserve(n_sel + 2)); HIP_TRY(hipMemsetAsync(c->d_new_n.p + n_sel, 0, 4, c->stream));
-		hipLaunchKernelGGL(sketch_select_kernel, dim3((unsigned)((n_sel + 63) / 64)), dim3(64), 0, c->stream, c->d_g_x.p, c->d_g_info.p, c->d_g_ord.p, c->d_g_off.p,
+		hipLaunchKernelGGL(sketch_select_kernel, dim3((unsigned)((n_sel + 3) / 4)), dim3(256), 0, c->stream, c->d_g_x.p, c->d_g_info.p, c->d_g_ord.p, c->d_g_off.p,
 						   c->d_len.p, c->d_tot_l.p, lo, n_sel, sample_dist, c->opt.rewin, k, c->d_new_n.p);
 		HAO_CHECK_LAUNCH();
 		auto it = rocprim::make_transform_iterator(c->d_new_n.p, U32ToU64());
