@@ -94,7 +94,7 @@ static int hao_keep_runs(hao_ctx *c, const uint64_t *ukeys, const uint32_t *ucnt
 {
 	*n_kept = 0; if (n_pos) *n_pos = 0;
 	if (n_unique == 0) return HAO_OK;
-	DevBuf<uint64_t> flag, kpos, ustart;
+	DevBuf<uint64_t> &flag = c->w_flag, &kpos = c->w_kpos, &ustart = c->w_ustart;
 	HIP_TRY(flag.reserve(n_unique + 1)); HIP_TRY(kpos.reserve(n_unique + 1)); HIP_TRY(ustart.reserve(n_unique + 1));
 	hipLaunchKernelGGL(hao_range_flag_kernel, dim3((unsigned)((n_unique + 256) / 256)), dim3(256), 0, c->stream, ucnt, n_unique, lo, hi, flag.p);
 	HAO_CHECK_LAUNCH();
@@ -114,7 +114,6 @@ static int hao_keep_runs(hao_ctx *c, const uint64_t *ukeys, const uint32_t *ucnt
 		HIP_TRY(hipMemcpyAsync(n_pos, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
 	}
 	HIP_TRY(hipStreamSynchronize(c->stream));
-	flag.release(); kpos.release(); ustart.release();
 	return HAO_OK;
 }
 
@@ -216,7 +215,7 @@ static int hao_ft_run(hao_ctx *c)
 	c->ft_cutoff = cutoff;
 	DevBuf<uint32_t> kcnt; uint64_t n_kept = 0;
 	if (int rc = hao_keep_runs(c, ukeys.p, ucnt.p, n_unique, cutoff, HAO_MAX_COUNT, c->d_ft_keys, nullptr, kcnt, &n_kept, nullptr)) return rc;
-	ukeys.release(); ucnt.release();
+	ukeys.release(); ucnt.release(); c->w_flag.release(); c->w_kpos.release(); c->w_ustart.release();      // k-mer sized scratch: do not keep it
 	if (sharded) {   // every rank kept its hash range: concatenation in rank order is the globally sorted table
 		hao_comm &cm = *c->comm; std::vector<uint64_t> cnts;
 		if (int rc = hao_comm_allgather_u64(c, cm, n_kept, cnts)) return rc;
@@ -302,7 +301,7 @@ static int hao_pt_run(hao_ctx *c)
 		HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, c->d_ix_mz_x.p, c->d_ix_sx.p, c->d_ix_mz_info.p, c->d_ix_sinfo.p, m, 0, 64, c->stream));
 	}
 	c->timer.mark("pt_sort");
-	DevBuf<uint64_t> ukeys; DevBuf<uint32_t> ucnt; uint64_t n_unique = 0;
+	DevBuf<uint64_t> &ukeys = c->w_ukeys; DevBuf<uint32_t> &ucnt = c->w_ucnt; uint64_t n_unique = 0;
 	memset(c->pt_hist, 0, sizeof(c->pt_hist));
 	if (m) {
 		HIP_TRY(ukeys.reserve(m + 1)); HIP_TRY(ucnt.reserve(m + 1)); HIP_TRY(c->d_cursor.reserve(2));
@@ -312,13 +311,12 @@ static int hao_pt_run(hao_ctx *c)
 		HIP_TRY(rocprim::run_length_encode(c->d_tmp.p, tb, c->d_ix_sx.p, m, ukeys.p, ucnt.p, (uint64_t*)c->d_cursor.p, c->stream));
 		HIP_TRY(hipMemcpyAsync(&n_unique, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
-		DevBuf<unsigned long long> dh; HIP_TRY(dh.reserve(HAO_N_COUNTS)); HIP_TRY(hipMemsetAsync(dh.p, 0, HAO_N_COUNTS * 8, c->stream));
+		DevBuf<unsigned long long> &dh = c->w_hist; HIP_TRY(dh.reserve(HAO_N_COUNTS)); HIP_TRY(hipMemsetAsync(dh.p, 0, HAO_N_COUNTS * 8, c->stream));
 		unsigned nb = (unsigned)std::min<uint64_t>((n_unique + 255) / 256, 2048);
 		if (nb) hipLaunchKernelGGL(hao_count_hist_kernel, dim3(nb), dim3(256), 0, c->stream, ucnt.p, n_unique, dh.p);
 		HAO_CHECK_LAUNCH();
 		HIP_TRY(hipMemcpyAsync(c->pt_hist, dh.p, HAO_N_COUNTS * 8, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
-		dh.release();
 	}
 	c->timer.mark("pt_count");
 	int het = -1;
@@ -327,7 +325,6 @@ static int hao_pt_run(hao_ctx *c)
 	if (c->has_ft) hi = HAO_MAX_COUNT - 1;                                   // htab.cpp:1266-1269
 	else { hi = (int)(c->hom_cov * c->opt.high_factor); if (hi > HAO_MAX_COUNT - 1) hi = HAO_MAX_COUNT - 1; }   // :1258-1262
 	if (int rc = hao_keep_runs(c, ukeys.p, ucnt.p, n_unique, 2, hi, c->d_ix_keys, &c->d_ix_start, c->d_ix_cnt, &c->ix_n_keys, &c->ix_n_pos)) return rc;
-	ukeys.release(); ucnt.release();
 	int bits = 16; while ((1ULL << bits) < c->ix_n_keys / 2 && bits < 26) ++bits;
 	if (int rc = hao_build_bucket(c, c->d_ix_keys.p, c->ix_n_keys, bits, c->d_ix_bucket)) return rc;
 	c->ix_bucket_bits = bits;
