@@ -8,13 +8,13 @@ static void hao_release_all(hao_ctx *c);
 
 struct U32ToU64 { __host__ __device__ uint64_t operator()(uint32_t v) const { return v; } };
 
-__global__ void hao_chunk_count_kernel(const uint32_t *n_runs, const uint8_t *scalar_flag, uint64_t n_sel, int k, uint64_t *cnt)
+__global__ void hao_chunk_count_kernel(const uint32_t *n_runs, const uint8_t *scalar_flag, uint64_t n_sel, int k, int chunk, uint64_t *cnt)
 {
 	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r > n_sel) return;
 	if (r == n_sel) { cnt[r] = 0; return; }
 	uint64_t nm = n_runs[r] >= (uint32_t)k ? n_runs[r] - k + 1 : 0;
-	cnt[r] = scalar_flag[r] ? 1 : (nm == 0 ? 1 : (nm + HAO_SK_CHUNK - 1) / HAO_SK_CHUNK);
+	cnt[r] = scalar_flag[r] ? 1 : (nm == 0 ? 1 : (nm + chunk - 1) / chunk);
 }
 
 static hao_ft_dev hao_ft_view(hao_ctx *c)
@@ -28,6 +28,7 @@ static hao_ft_dev hao_ft_view(hao_ctx *c)
 static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int sample_dist, int stamp_rid)
 {
 	const uint64_t n_sel = hi - lo; const int k = c->opt.k, w = c->opt.w;
+	const bool wave_variant = w == 51 && k + 7 <= 64 && !getenv("HAO_DBG_SK_GENERIC");     // default parameters: wave-local kernel
 	c->sk_lo = lo; c->sk_n = n_sel; c->sk_total = 0;
 	HIP_TRY(c->d_mz_off.reserve(n_sel + 2));
 	if (n_sel == 0) { HIP_TRY(hipMemsetAsync(c->d_mz_off.p, 0, 8, c->stream)); return HAO_OK; }
@@ -53,7 +54,7 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 	hipLaunchKernelGGL(hpc_index_kernel, dim3((unsigned)((n_sel + 3) / 4)), dim3(256), 0, c->stream, c->d_packed.p, c->d_pk_off.p, c->d_len.p,
 					   c->d_tile_off.p, c->d_tile_ord.p, c->d_n_runs.p, lo, n_sel, c->opt.hpc);
 	HAO_CHECK_LAUNCH();
-	hipLaunchKernelGGL(hao_chunk_count_kernel, dim3((unsigned)((n_sel + 256) / 256)), dim3(256), 0, c->stream, c->d_n_runs.p, c->d_scalar_flag.p, n_sel, k, c->d_chunk_cnt64.p);
+	hipLaunchKernelGGL(hao_chunk_count_kernel, dim3((unsigned)((n_sel + 256) / 256)), dim3(256), 0, c->stream, c->d_n_runs.p, c->d_scalar_flag.p, n_sel, k, wave_variant ? hao_sk2<51>::CHUNK : HAO_SK_CHUNK, c->d_chunk_cnt64.p);
 	HAO_CHECK_LAUNCH();
 	if (int rc = hao_excl_scan_u64(c, c->d_chunk_cnt64.p, c->d_chunk_off.p, n_sel + 1)) return rc;
 	HIP_TRY(hipMemcpyAsync(c->d_tot_l.p, c->d_n_runs.p, n_sel * 4, hipMemcpyDeviceToDevice, c->stream));
@@ -85,7 +86,10 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 		a.chunk_off = c->d_chunk_off.p; a.scalar_flag = c->d_scalar_flag.p; a.rid_lo = lo; a.n_sel = n_sel; a.k = k; a.w = w; a.hpc = c->opt.hpc; a.ft = hao_ft_view(c);
 		a.pool_x = c->d_pool_x.p; a.pool_info = c->d_pool_info.p; a.pool_ord = c->d_pool_ord.p; a.pool_cursor = c->d_cursor.p; a.pool_cap = cap;
 		a.chunk_base = c->d_chunk_base.p; a.chunk_cnt = c->d_chunk_cnt.p; a.err = c->d_err.p; a.dbg_phase = getenv("HAO_DBG_SK_PHASE") ? atoi(getenv("HAO_DBG_SK_PHASE")) : 0;
-		if (use_ft && a.ft.n > 0) hipLaunchKernelGGL(sketch_chunk_kernel<true>, dim3((unsigned)n_chunks), dim3(HAO_SK_THREADS), smem, c->stream, a);
+		if (wave_variant) {
+			if (use_ft && a.ft.n > 0) hipLaunchKernelGGL((sketch_chunk_wave_kernel<true, 51>), dim3((unsigned)n_chunks), dim3(256), 0, c->stream, a);
+			else hipLaunchKernelGGL((sketch_chunk_wave_kernel<false, 51>), dim3((unsigned)n_chunks), dim3(256), 0, c->stream, a);
+		} else if (use_ft && a.ft.n > 0) hipLaunchKernelGGL(sketch_chunk_kernel<true>, dim3((unsigned)n_chunks), dim3(HAO_SK_THREADS), smem, c->stream, a);
 		else hipLaunchKernelGGL(sketch_chunk_kernel<false>, dim3((unsigned)n_chunks), dim3(HAO_SK_THREADS), smem, c->stream, a);
 		HAO_CHECK_LAUNCH();
 		int err = 0;

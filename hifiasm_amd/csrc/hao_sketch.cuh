@@ -319,6 +319,234 @@ __global__ __launch_bounds__(HAO_SK_THREADS) void sketch_chunk_kernel(hao_sk_arg
 	}
 }
 
+// ---------------------------------------------------------------------------------------
+// K_B, wave-local variant (used when w is the compile-time W and k + 7 <= 64): each wave owns 512 consecutive
+// window ordinals in a BLOCKED layout (lane L holds entries 8L..8L+7) and decides the marks of the middle
+// 512 - 2(W-1); the four waves of a workgroup share one decode of the runs (LDS) and nothing else.
+//   * hashes: the lane extracts ONE (k+7)-bit window of each bit plane and shifts it for its 8 k-mers;
+//   * sliding minimum over W ordinals = min(prefix of my 8, full predecessors lanes, suffix of one farther lane):
+//     per-lane prefix/suffix minima in registers, lane-axis doubling with ds_bpermute shuffles, no LDS traffic,
+//     no barrier; the sliding maximum is the mirror image;
+//   * marks compact through two wave scans and one atomic per workgroup.
+// ---------------------------------------------------------------------------------------
+#define HAO_SK2_WENT 512
+template<int W> struct hao_sk2 { static constexpr int MW = HAO_SK2_WENT - 2 * (W - 1); static constexpr int CHUNK = 4 * MW; };
+
+template<bool HAS_FT> __device__ __forceinline__ hao_key hao_kmin(const hao_key &a, const hao_key &b) { return hao_key_lt<HAS_FT>(b, a) ? b : a; }
+template<bool HAS_FT> __device__ __forceinline__ hao_key hao_kmax(const hao_key &a, const hao_key &b) { return hao_key_lt<HAS_FT>(a, b) ? b : a; }
+template<bool HAS_FT> __device__ __forceinline__ hao_key hao_kshfl_up(const hao_key &a, int d)
+{ hao_key o; o.x = (uint64_t)__shfl_up((unsigned long long)a.x, d); o.c = HAS_FT ? __shfl_up(a.c, d) : 0; return o; }
+template<bool HAS_FT> __device__ __forceinline__ hao_key hao_kshfl_down(const hao_key &a, int d)
+{ hao_key o; o.x = (uint64_t)__shfl_down((unsigned long long)a.x, d); o.c = HAS_FT ? __shfl_down(a.c, d) : 0; return o; }
+
+// combine over the N lanes before (DIR = 0) / after (DIR = 1) me, of the per-lane value `all`; MIN selects min or max
+template<bool HAS_FT, bool MIN, int DIR, int N> __device__ __forceinline__ hao_key hao_lane_window(const hao_key &all)
+{
+	auto comb = [](const hao_key &a, const hao_key &b) { return MIN ? hao_kmin<HAS_FT>(a, b) : hao_kmax<HAS_FT>(a, b); };
+	auto sh = [](const hao_key &a, int d) { return DIR == 0 ? hao_kshfl_up<HAS_FT>(a, d) : hao_kshfl_down<HAS_FT>(a, d); };
+	// p[j] covers the 2^j lanes next to me (excluding me)
+	hao_key p[6]; p[0] = sh(all, 1);
+#pragma unroll
+	for (int j = 1; j < 6; ++j) if ((1 << j) <= N) p[j] = comb(p[j - 1], sh(p[j - 1], 1 << (j - 1)));
+	hao_key res = p[0]; int covered = 0; bool first = true;
+#pragma unroll
+	for (int j = 5; j >= 0; --j) if ((N >> j) & 1) { hao_key piece = covered ? sh(p[j], covered) : p[j]; res = first ? piece : comb(res, piece); first = false; covered += 1 << j; }
+	return res;
+}
+
+template<bool HAS_FT, int W>
+__global__ __launch_bounds__(256) void sketch_chunk_wave_kernel(hao_sk_args a)
+{
+	constexpr int MW = hao_sk2<W>::MW, CHUNK = hao_sk2<W>::CHUNK, NE_MAX = CHUNK + 2 * (W - 1) + 64 + 2, NW_MAX = (NE_MAX + 63) / 64 + 2;
+	__shared__ uint32_t end1[NE_MAX]; __shared__ uint8_t rcode[NE_MAX]; __shared__ uint64_t pl0[NW_MAX], pl1[NW_MAX];
+	__shared__ uint64_t fx[64]; __shared__ uint32_t fc[64]; __shared__ uint32_t s_wcnt[4]; __shared__ unsigned long long s_base; __shared__ int s_patch_prev, s_patch_on;
+	const int k = a.k, w = W, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	uint64_t ch = blockIdx.x, lo = 0, hi = a.n_sel;
+	while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (a.chunk_off[m + 1] <= ch) lo = m + 1; else hi = m; }
+	const uint64_t r = lo;
+	if (a.scalar_flag[r]) return;
+	const uint32_t ci = (uint32_t)(ch - a.chunk_off[r]);
+	const uint64_t rid = a.rid_lo + r; const uint8_t *rd = a.packed + a.pk_off[rid]; const uint32_t L = a.len[rid];
+	const int T = (int)a.n_runs[r];
+	const uint32_t *tord = a.tile_ord + a.tile_off[r]; const uint32_t ntile = (L + HAO_SK_TILE - 1) / HAO_SK_TILE;
+	const int j0 = k + (int)ci * CHUNK, j1 = min(j0 + CHUNK, T + 1);
+	if (j0 > T) { if (tid == 0) { a.chunk_base[ch] = 0; a.chunk_cnt[ch] = 0; } return; }
+	const int kk0 = max(k, j0 - w + 1), kk1 = min(T, j1 - 1 + w - 1);
+	const int rbase = kk0 - k, nE = kk1 - rbase + 1;
+	const uint64_t mask = (1ULL << k) - 1;
+	// ---- run ends of the workgroup's ordinal range -> rcode / end1 (shared by the four waves) ----
+	if (tid == 0 && rbase == 0) end1[0] = 0;
+	{
+		const uint32_t first = rbase > 0 ? (uint32_t)rbase : 1u;
+		uint32_t tlo = 0, thi = ntile;
+		while (thi - tlo > 1) { uint32_t m = (tlo + thi) >> 1; if (tord[m] < first) tlo = m; else thi = m; }
+		for (uint32_t ti = tlo + wv; ti < ntile && tord[ti] < (uint32_t)kk1; ti += 4) {
+			uint32_t Wd, g0 = ti * HAO_SK_TILE + lane * 16, tot;
+			uint32_t eb = hao_run_ends16(rd, L, g0, &Wd);
+			if (!a.hpc) { uint32_t rem = g0 >= L ? 0 : (L - g0 > 16 ? 16 : L - g0); eb = rem == 0 ? 0 : (rem >= 16 ? 0x55555555u : ((0xFFFFFFFFu << (32 - 2 * rem)) & 0x55555555u)); }
+			uint32_t o = tord[ti] + hao_wave_excl_scan(__popc(eb), &tot) + 1;
+			while (eb) {
+				int hb = 31 - __clz(eb); int j = (30 - hb) >> 1; eb &= ~(1u << hb);
+				if (o >= first && o <= (uint32_t)kk1) { int e = (int)o - rbase; rcode[e] = (Wd >> (30 - 2 * j)) & 3; end1[e] = g0 + j + 1; }
+				++o;
+			}
+		}
+	}
+	__syncthreads();
+	for (int e0 = wv * 64; e0 < nE + 128; e0 += 256) {
+		int e = e0 + lane; uint32_t c = (e >= 1 && e < nE) ? rcode[e] : 0;
+		unsigned long long b0 = __ballot(c & 1), b1 = __ballot(c >> 1);
+		if (lane == 0 && (e0 >> 6) < NW_MAX) { pl0[e0 >> 6] = b0; pl1[e0 >> 6] = b1; }
+	}
+	__syncthreads();
+	// ---- this wave's 512 ordinals: marks for [jw0, jw1), keys for [kw0, kw0 + 512) ----
+	const int jw0 = j0 + wv * MW, jw1 = min(jw0 + MW, j1);
+	const int kw0 = max(k, jw0 - (w - 1));                       // entry q <-> ordinal kw0 + q
+	const hao_key kmax = { UINT64_MAX, HAO_CNT_DUMMY }, kmin = { 0, 0 };
+	hao_key key[8];
+	{
+		const int q0 = lane * 8, t0 = kw0 + q0;                    // my first ordinal
+		const int e0 = t0 - rbase, s0 = e0 - k + 1;                // local run index of its last / first run
+		uint64_t B0 = 0, B1 = 0;
+		if (jw0 < j1 && t0 <= kk1) {
+			const int wi = s0 >> 6, sh = s0 & 63;
+			B0 = pl0[wi] >> sh; B1 = pl1[wi] >> sh;
+			if (sh) { B0 |= pl0[wi + 1] << (64 - sh); B1 |= pl1[wi + 1] << (64 - sh); }
+		}
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			key[i] = kmax;
+			const int t = t0 + i;
+			if (jw0 < j1 && t <= kk1) {
+				const uint64_t W0 = (B0 >> i) & mask, W1 = (B1 >> i) & mask;
+				const uint64_t f1 = __brevll(W1) >> (64 - k), r1 = ~W1 & mask;
+				const uint32_t span = end1[e0 + i] - end1[e0 + i - k];
+				if (span < 256) {
+					const uint64_t y = f1 < r1 ? hao_hash64(__brevll(W0) >> (64 - k)) + hao_hash64(f1) : hao_hash64(~W0 & mask) + hao_hash64(r1);
+					if (HAS_FT) { int32_t cnt = hao_ft_lookup(a.ft, y); if (cnt < (1 << 28)) { key[i].x = y; key[i].c = (uint32_t)cnt; } }
+					else { key[i].x = y; key[i].c = 0; }
+				}
+			}
+		}
+	}
+	// ---- sliding minimum over the W ordinals ending at each entry ----
+	hao_key m[8];
+	{
+		hao_key pre[8], suf[8];
+		pre[0] = key[0];
+#pragma unroll
+		for (int i = 1; i < 8; ++i) pre[i] = hao_kmin<HAS_FT>(pre[i - 1], key[i]);
+		suf[7] = key[7];
+#pragma unroll
+		for (int i = 6; i >= 0; --i) suf[i] = hao_kmin<HAS_FT>(key[i], suf[i + 1]);
+		constexpr int QA = (W - 1) / 8, QB = (W - 8) / 8;            // number of full predecessor lanes for i = 0 and i = 7
+		const hao_key AA = hao_lane_window<HAS_FT, true, 0, QA>(pre[7]);
+		const hao_key AB = QB == QA ? AA : hao_lane_window<HAS_FT, true, 0, (QB > 0 ? QB : 1)>(pre[7]);
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			constexpr int dummy = 0; (void)dummy;
+			const int rem = W - 1 - i, nfull = rem / 8, part = rem % 8;       // compile-time after unrolling
+			hao_key v = pre[i];
+			if (nfull > 0) v = hao_kmin<HAS_FT>(v, nfull == QA ? AA : AB);
+			if (part > 0) v = hao_kmin<HAS_FT>(v, hao_kshfl_up<HAS_FT>(suf[8 - part], nfull + 1));
+			m[i] = v;
+		}
+	}
+	// windows are valid for ordinals t with max(jw0, w+k-1) <= t <= T (and inside the wave's 512): the rest is -inf for the maximum
+	{
+		const int tm0 = max(jw0, w + k - 1), q0 = lane * 8;
+#pragma unroll
+		for (int i = 0; i < 8; ++i) { const int t = kw0 + q0 + i; if (t < tm0 || t > kk1 || t - kw0 < W - 1) m[i] = kmin; }
+	}
+	// ---- sliding maximum over the W ordinals starting at each entry ----
+	bool mk[8];
+	{
+		hao_key pre[8], suf[8];
+		pre[0] = m[0];
+#pragma unroll
+		for (int i = 1; i < 8; ++i) pre[i] = hao_kmax<HAS_FT>(pre[i - 1], m[i]);
+		suf[7] = m[7];
+#pragma unroll
+		for (int i = 6; i >= 0; --i) suf[i] = hao_kmax<HAS_FT>(m[i], suf[i + 1]);
+		constexpr int QA = (W - 8) / 8, QB = (W - 1) / 8;            // full successor lanes for i = 0 and i = 7
+		const hao_key AA = hao_lane_window<HAS_FT, false, 1, (QA > 0 ? QA : 1)>(pre[7]);
+		const hao_key AB = QB == QA ? AA : hao_lane_window<HAS_FT, false, 1, QB>(pre[7]);
+		const int q0 = lane * 8;
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			const int rem = W - (8 - i), nfull = rem / 8, part = rem % 8;      // entries needed after my own suffix
+			hao_key v = suf[i];
+			if (nfull > 0) v = hao_kmax<HAS_FT>(v, nfull == QA ? AA : AB);
+			if (part > 0) v = hao_kmax<HAS_FT>(v, hao_kshfl_down<HAS_FT>(pre[part - 1], nfull + 1));
+			const int t = kw0 + q0 + i;
+			mk[i] = t >= jw0 && t < jw1 && key[i].x != UINT64_MAX && hao_key_eq<HAS_FT>(key[i], v);
+		}
+	}
+	// ---- first-window quirk / short reads (wave 0 of chunk 0): one lane over <= W keys staged in LDS ----
+	if (tid == 0) { s_patch_on = 0; s_patch_prev = -1; }
+	if (ci == 0 && wv == 0 && lane < 8) {
+#pragma unroll
+		for (int i = 0; i < 8; ++i) { fx[lane * 8 + i] = key[i].x; fc[lane * 8 + i] = key[i].c; }   // ordinals k .. k+63
+	}
+	__syncthreads();
+	if (ci == 0 && tid == 0) {
+		auto kq = [&](int t) -> hao_key { hao_key o; o.x = fx[t - k]; o.c = HAS_FT ? fc[t - k] : 0; return o; };
+		if (T >= w + k - 1) {
+			const int t0 = w + k - 1; int prev = -1; hao_key pk = kmax;
+			for (int t = k; t < t0; ++t) { hao_key o = kq(t); if (!hao_key_lt<HAS_FT>(pk, o)) { pk = o; prev = t; } }
+			if (prev >= 0 && pk.x != UINT64_MAX) { hao_key o = kq(t0); if (!hao_key_lt<HAS_FT>(pk, o)) { s_patch_on = 1; s_patch_prev = prev; } }
+		} else {
+			int prev = -1; hao_key pk = kmax;
+			for (int t = max(k, T - w + 1); t <= T; ++t) { hao_key o = kq(t); if (!hao_key_lt<HAS_FT>(pk, o)) { pk = o; prev = t; } }
+			s_patch_on = 2; s_patch_prev = (prev >= 0 && pk.x != UINT64_MAX) ? prev : -1;
+		}
+	}
+	__syncthreads();
+	if (s_patch_on && wv == 0) {
+		const int prev = s_patch_prev, q0 = lane * 8;
+		if (s_patch_on == 1) {
+			hao_key pk; pk.x = fx[prev - k]; pk.c = HAS_FT ? fc[prev - k] : 0;
+#pragma unroll
+			for (int i = 0; i < 8; ++i) { const int t = kw0 + q0 + i; if (t >= k && t < w + k - 1) { if (t == prev) mk[i] = false; else if (hao_key_eq<HAS_FT>(key[i], pk)) mk[i] = true; } }
+		} else {
+#pragma unroll
+			for (int i = 0; i < 8; ++i) { const int t = kw0 + q0 + i; mk[i] = t == prev; }
+		}
+	} else if (s_patch_on == 2) {
+#pragma unroll
+		for (int i = 0; i < 8; ++i) mk[i] = false;
+	}
+	// ---- ordered compaction: entries are in ordinal order inside a lane, lanes inside a wave, waves inside the workgroup ----
+	uint32_t mine = 0;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) mine += mk[i] ? 1u : 0u;
+	uint32_t wtot; const uint32_t lane_off = hao_wave_excl_scan(mine, &wtot);
+	if (lane == 0) s_wcnt[wv] = wtot;
+	__syncthreads();
+	if (tid == 0) {
+		uint32_t run = 0;
+		for (int x = 0; x < 4; ++x) { uint32_t c = s_wcnt[x]; s_wcnt[x] = run; run += c; }
+		unsigned long long base = run ? atomicAdd(a.pool_cursor, (unsigned long long)run) : 0ULL;
+		if (base + run > a.pool_cap) { *a.err = 1; run = 0; for (int x = 0; x < 4; ++x) s_wcnt[x] = 0xffffffffu; }
+		s_base = base; a.chunk_base[ch] = base; a.chunk_cnt[ch] = run;
+	}
+	__syncthreads();
+	if (s_wcnt[wv] == 0xffffffffu || mine == 0) return;
+	uint64_t o = s_base + s_wcnt[wv] + lane_off;
+	const int q0 = lane * 8, e0 = kw0 + q0 - rbase;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		if (!mk[i]) continue;
+		const int e = e0 + i, s1 = e - k + 1, wi = s1 >> 6, sh = s1 & 63;
+		uint64_t W1 = pl1[wi] >> sh; if (sh) W1 |= pl1[wi + 1] << (64 - sh); W1 &= mask;
+		const uint32_t rev = (__brevll(W1) >> (64 - k)) < (~W1 & mask) ? 0 : 1;
+		a.pool_x[o] = key[i].x;
+		a.pool_info[o] = hao_info_pack(HAS_FT ? key[i].c : 0, end1[e] - 1, rev, end1[e] - end1[e - k]);
+		a.pool_ord[o] = (uint32_t)(kw0 + q0 + i);
+		++o;
+	}
+}
+
 static inline size_t hao_sk_smem_bytes(int w, int k)
 {
 	size_t NE = HAO_SK_CHUNK + 2 * (w - 1) + k + 1, NW = (NE + 63) / 64 + 1;
