@@ -39,10 +39,13 @@ WORKLOADS = {
 }
 # algorithmic bytes per unit (stated again in DESIGN.md)
 ALG = {
-    "sketch_chunk_kernel": ("base", 0.25 + 16.0 / 35.0),     # 2-bit bases in + 16-B minimizer per ~35 bases out
-    "chain_group_kernel": ("anchor", 16 + 12 + 16),          # k_mer_hit in + f,p scratch + chained hit out
-    "seg_radix_pass_kernel": ("anchor", 8 + 8 + 16),           # per-read sort: key in, key out once, k_mer_hit out
-    "seed_expand_kernel": ("anchor", 8 + 8),                  # index position in + key out
+    "sketch_chunk_wave_kernel": ("base", 0.25 + 16.0 / 35.0),       # 2-bit bases in + one 16-B minimizer per ~35 bases out
+    "chain_group_kernel": ("anchor", 16 + 4),                        # k_mer_hit in + fake-cigar / record out (hits stay in place)
+    "seg_radix_pass_kernel<false>": ("anchor", 8 + 8),               # key in, key out
+    "seg_radix_pass_kernel<true>": ("anchor", 8 + 16),               # key in, k_mer_hit out
+    "seed_expand_kernel": ("anchor", 8 + 8),                         # index position in + key out
+    "chain_assemble_kernel": ("anchor", 16 + 16),                    # chained hit in + tagged hit out
+    "groups_kernel": ("anchor", 2 * 16),                             # two sweeps over the hits
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -189,17 +192,25 @@ def main():
     if rank == 0:
         stage_ms = {k: v / a.steps for k, v in stage_sum.items()}
         # roofline of the dominant kernel: live HIP-event time of its stage on the engine's stream
-        kern_stage = {"sketch_chunk_kernel": "sk_chunks", "chain_group_kernel": "q_chain", "seg_radix_pass_kernel": "q_sort",
-                      "seed_expand_kernel": "q_expand"}
+        kern_stage = {"sketch_chunk_wave_kernel": "sk_chunks", "chain_group_kernel": "q_chain", "seg_radix_pass_kernel<false>": "q_sort_p0",
+                      "seg_radix_pass_kernel<true>": "q_sort_final", "seed_expand_kernel": "q_expand", "chain_assemble_kernel": "q_assemble",
+                      "groups_kernel": "q_groups"}
         dom = max(kern_stage, key=lambda k: stage_ms.get(kern_stage[k], 0.0))
         unit, bpu = ALG[dom]
         units = rs.total_bases if unit == "base" else tot["seed_hits"]
-        n_launch = 1 if unit == "base" else max(1, (n_reads + bsz - 1) // bsz)
+        n_launch = 1 if unit == "base" else max(1, (n_reads + bsz - 1) // bsz) * (2 if dom == "groups_kernel" else 1)
         k_ms = stage_ms.get(kern_stage[dom], 0.0) / n_launch
         alg_bytes = bpu * units / n_launch
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
+            if pj.get("workload") == a.workload and world == 1:
+                traffic = pj["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "kernel_ms": round(k_ms, 4), "alg_bytes_per_launch": int(alg_bytes)}
         out = {
             "metric": "read-pair overlaps/sec (sum ol->length / (ha_pt_gen + all-reads h_ec_lchain pass))",

@@ -106,10 +106,10 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			if (ps_ == n_pass - 1) hipLaunchKernelGGL(seg_radix_pass_kernel<true>, dim3((unsigned)n), dim3(256), lds + 8 * qcap, c->stream, src, dst, B.seg.p, sh, bits, qcap, hb);
 			else hipLaunchKernelGGL(seg_radix_pass_kernel<false>, dim3((unsigned)n), dim3(256), lds, c->stream, src, dst, B.seg.p, sh, bits, 0u, hb);
 			HAO_CHECK_LAUNCH();
+			c->timer.mark(ps_ == n_pass - 1 ? "q_sort_final" : (ps_ == 0 ? "q_sort_p0" : "q_sort_p1"));
 			std::swap(src, dst);
 		}
 	}
-	c->timer.mark("q_sort");
 	// Q5 groups
 	HIP_TRY(B.g_cnt.reserve(n + 2)); HIP_TRY(B.g_off.reserve(n + 2));
 	hipLaunchKernelGGL(groups_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, B.hits.p, B.seg.p, n, (const uint64_t*)nullptr, B.g_cnt.p, (uint64_t*)nullptr, (uint32_t*)nullptr, 0);
