@@ -50,12 +50,12 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	const uint64_t n = B.n;
 	if (n == 0) { B.n_anchor = B.n_groups = B.n_chains = B.n_cl = B.n_ol = B.n_fc = B.n_mz = 0; B.valid = true; return HAO_OK; }
 	// minimizer range of the batch (host knows the per-read offsets? keep a host copy once)
-	if (c->h_ix_mz_off.size() != c->n_total + 1) {
-		c->h_ix_mz_off.resize(c->n_total + 1);
-		HIP_TRY(hipMemcpy(c->h_ix_mz_off.data(), c->d_ix_mz_off.p, (c->n_total + 1) * 8, hipMemcpyDeviceToHost));
+	if (c->h_ix_mz_off.size() != c->n_reads + 1) {
+		c->h_ix_mz_off.resize(c->n_reads + 1);
+		HIP_TRY(hipMemcpy(c->h_ix_mz_off.data(), c->d_ix_mz_off.p, (c->n_reads + 1) * 8, hipMemcpyDeviceToHost));
 	}
-	const uint64_t glo = c->rid_base + lo, ghi = c->rid_base + hi;      // global read ids of the batch (== local when unsharded)
-	B.mz0 = c->h_ix_mz_off[glo]; B.n_mz = c->h_ix_mz_off[ghi] - B.mz0;
+	const uint64_t glo = c->rid_base + lo;      // global read id of the first query (== lo when unsharded); minimizer arrays are indexed locally
+	B.mz0 = c->h_ix_mz_off[lo]; B.n_mz = c->h_ix_mz_off[hi] - B.mz0;
 	const uint64_t nm = B.n_mz;
 	std::vector<uint32_t> wt; hao_seed_weight_table(ps.high_occ, ps.low_occ, wt);
 	HIP_TRY(B.wgt.reserve(4096)); HIP_TRY(hipMemcpyAsync(B.wgt.p, wt.data(), 4096 * 4, hipMemcpyHostToDevice, c->stream));
@@ -67,7 +67,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	hipLaunchKernelGGL(seed_count_kernel, dim3((unsigned)((nm + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_x.p, c->d_ix_mz_info.p, B.mz0, nm, pt, B.wgt.p, B.s_start.p, B.s_n.p, B.q_pos.p, B.q_cnt.p);
 	HAO_CHECK_LAUNCH();
 	if (int rc = hao_scan_u32(c, B.s_n.p, B.a_off.p, nm + 1)) return rc;
-	hipLaunchKernelGGL(seed_segments_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_off.p, glo, n, B.mz0, B.a_off.p, B.seg.p);
+	hipLaunchKernelGGL(seed_segments_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_off.p, lo, n, B.mz0, B.a_off.p, B.seg.p);
 	HAO_CHECK_LAUNCH();
 	HIP_TRY(hipMemcpyAsync(&B.n_anchor, B.a_off.p + nm, 8, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
@@ -81,20 +81,20 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		uint32_t max_len = 1; uint64_t max_q = 1;
 		if (c->max_len == 0) for (uint64_t i = 0; i < c->n_total; ++i) c->max_len = std::max(c->max_len, c->h_len_all[i]);
 		max_len = c->max_len;
-		for (uint64_t r = glo; r < ghi; ++r) max_q = std::max<uint64_t>(max_q, c->h_ix_mz_off[r + 1] - c->h_ix_mz_off[r]);
+		for (uint64_t r = lo; r < hi; ++r) max_q = std::max<uint64_t>(max_q, c->h_ix_mz_off[r + 1] - c->h_ix_mz_off[r]);
 		F.ob = 1; while ((1ULL << F.ob) < (uint64_t)max_len) ++F.ob;
 		F.qb = 1; while ((1ULL << F.qb) < max_q) ++F.qb;
 		F.tb = 1; while ((1ULL << F.tb) < c->n_total) ++F.tb;
 		if (F.ob + F.qb + 1 + F.tb > 64) { hao_set_err(c, "anchor key does not fit 64 bits (reads x minimizers-per-read x read length too large)"); return HAO_EUNSUPP; }
 	}
 	// Q2 expand
-	hipLaunchKernelGGL(seed_expand_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, c->d_ix_mz_off.p, c->d_ix_mz_info.p, glo, B.mz0, B.s_start.p, B.s_n.p, B.a_off.p,
+	hipLaunchKernelGGL(seed_expand_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, c->d_ix_mz_off.p, c->d_ix_mz_info.p, lo, B.mz0, B.s_start.p, B.s_n.p, B.a_off.p,
 					   c->d_ix_sinfo.p, c->d_len_all.p, F, B.keys.p);
 	HAO_CHECK_LAUNCH();
 	c->timer.mark("q_expand");
 	// Q3+Q4: stable LSD passes over the (rev, tid) bits only; the last pass decodes keys into k_mer_hits
 	hao_hitb_args hb;
-	hb.mz_off = c->d_ix_mz_off.p; hb.rid_lo = glo; hb.mz0 = B.mz0; hb.q_pos = B.q_pos.p; hb.q_cnt = B.q_cnt.p; hb.F = F; hb.hits = B.hits.p;
+	hb.mz_off = c->d_ix_mz_off.p; hb.rid_lo = lo; hb.mz0 = B.mz0; hb.q_pos = B.q_pos.p; hb.q_cnt = B.q_cnt.p; hb.F = F; hb.hits = B.hits.p;
 	if (A) {
 		uint64_t *src = B.keys.p, *dst = B.keys2.p; const int beg_bit = F.ob + F.qb, nb = 1 + F.tb;
 		// digits of equal width: 8 bits unless that costs an extra pass (then up to 11; the per-wave digit counters are LDS-resident)

@@ -63,7 +63,7 @@ struct hao_ctx {
 	std::vector<uint64_t> h_mz_off; std::vector<hao_mz_t> h_mz_fetch;
 	// ---- index (pt) ----
 	bool has_pt = false; int64_t pt_hist[HAO_N_COUNTS];
-	uint64_t ix_n_mz = 0, ix_n_keys = 0, ix_n_pos = 0; int ix_bucket_bits = 16;
+	uint64_t ix_n_mz = 0, ix_n_sorted = 0, ix_n_keys = 0, ix_n_pos = 0; int ix_bucket_bits = 16;   // ix_n_mz: local read-ordered records; ix_n_sorted: records in the (replicated) index
 	DevBuf<uint64_t> d_ix_mz_x, d_ix_mz_info, d_ix_mz_off;  // all reads' minimizers in read order (query side reuses them)
 	DevBuf<uint64_t> d_ix_sx, d_ix_sinfo;                    // sorted by hash (stable)
 	DevBuf<uint64_t> d_ix_keys, d_ix_start; DevBuf<uint32_t> d_ix_cnt; DevBuf<uint32_t> d_ix_bucket;

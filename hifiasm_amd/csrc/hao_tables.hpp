@@ -14,6 +14,11 @@ __global__ void hao_lower_bound_kernel(const uint64_t *keys, uint64_t n, const u
 	while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (keys[m] < x) lo = m + 1; else hi = m; }
 	out[t] = lo;
 }
+__global__ void hao_add_const_kernel(uint64_t *v, uint64_t n, uint64_t add)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) v[i] += add;
+}
 __global__ void hao_adjdiff_kernel(const uint64_t *off, uint64_t n, uint64_t *cnt)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -264,51 +269,28 @@ static int hao_pt_run(hao_ctx *c)
 	c->has_pt = false; c->h_ix_valid = false; c->h_ix_mz_off.clear();
 	if (n == 0) { hao_set_err(c, "no reads"); return HAO_EINVAL; }
 	if (int rc = hao_sketch_run(c, 0, n, c->has_ft, c->opt.sample_dist, 1)) return rc;
-	// keep the read-ordered minimizers for the query side
-	if (!(c->comm && c->comm->active())) {
-		std::swap(c->d_ix_mz_x, c->d_mz_x); std::swap(c->d_ix_mz_info, c->d_mz_info); std::swap(c->d_ix_mz_off, c->d_mz_off);
-		c->ix_n_mz = c->sk_total; c->sk_n = 0;
-	} else {
-		// sharded: all-gather-v of the 16-byte records (x, info) and of the per-read counts; shards are contiguous read ranges in
-		// rank order, so the concatenation is in global read order and every rank builds the same index
-		hao_comm &cm = *c->comm; std::vector<uint64_t> mzc, rdc;
-		if (int rc = hao_comm_allgather_u64(c, cm, c->sk_total, mzc)) return rc;
-		if (int rc = hao_comm_allgather_u64(c, cm, n, rdc)) return rc;
-		uint64_t tot = 0, nt = 0; for (uint64_t v : mzc) tot += v; for (uint64_t v : rdc) nt += v;
-		if (nt != c->n_total) { hao_set_err(c, "shards do not add up to n_total"); return HAO_EINVAL; }
-		{ uint64_t b = 0; for (int r = 0; r < cm.rank; ++r) b += rdc[r]; if (b != c->rid_base) { hao_set_err(c, "rid_base is not the sum of the lower ranks' read counts"); return HAO_EINVAL; } }
-		HIP_TRY(c->d_ix_mz_x.reserve(tot + 1)); HIP_TRY(c->d_ix_mz_info.reserve(tot + 1)); HIP_TRY(c->d_ix_mz_off.reserve(nt + 2));
-		if (int rc = hao_comm_allgatherv(c, cm, c->d_mz_x.p, c->sk_total, 8, c->d_ix_mz_x.p, mzc)) return rc;
-		if (int rc = hao_comm_allgatherv(c, cm, c->d_mz_info.p, c->sk_total, 8, c->d_ix_mz_info.p, mzc)) return rc;
-		DevBuf<uint64_t> lc, gc; HIP_TRY(lc.reserve(n + 1)); HIP_TRY(gc.reserve(nt + 2));
-		hipLaunchKernelGGL(hao_adjdiff_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_mz_off.p, n, lc.p);
-		HAO_CHECK_LAUNCH();
-		if (int rc = hao_comm_allgatherv(c, cm, lc.p, n, 8, gc.p, rdc)) return rc;
-		HIP_TRY(hipMemsetAsync(gc.p + nt, 0, 8, c->stream));
-		if (int rc = hao_excl_scan_u64(c, gc.p, c->d_ix_mz_off.p, nt + 1)) return rc;
-		HIP_TRY(hipStreamSynchronize(c->stream));
-		lc.release(); gc.release();
-		c->ix_n_mz = tot; c->sk_n = 0;
-		c->timer.mark("pt_allgather");
-	}
-	const uint64_t m = c->ix_n_mz;
-	if (m >= (1ULL << 32)) { hao_set_err(c, "more than 2^32 minimizers on one device"); return HAO_EUNSUPP; }
-	HIP_TRY(c->d_ix_sx.reserve(m + 1)); HIP_TRY(c->d_ix_sinfo.reserve(m + 1));
-	if (m) {
-		size_t tb = 0;
-		HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, c->d_ix_mz_x.p, c->d_ix_sx.p, c->d_ix_mz_info.p, c->d_ix_sinfo.p, m, 0, 64, c->stream));
-		HIP_TRY(hao_tmp(c, tb));
-		HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, c->d_ix_mz_x.p, c->d_ix_sx.p, c->d_ix_mz_info.p, c->d_ix_sinfo.p, m, 0, 64, c->stream));
-	}
-	c->timer.mark("pt_sort");
+	// the read-ordered minimizers of the LOCAL reads stay for the query side (the reference re-sketches every query read; same result)
+	std::swap(c->d_ix_mz_x, c->d_mz_x); std::swap(c->d_ix_mz_info, c->d_mz_info); std::swap(c->d_ix_mz_off, c->d_mz_off);
+	c->ix_n_mz = c->sk_total; c->sk_n = 0;
+	const bool sharded = c->comm && c->comm->active();
 	DevBuf<uint64_t> &ukeys = c->w_ukeys; DevBuf<uint32_t> &ucnt = c->w_ucnt; uint64_t n_unique = 0;
 	memset(c->pt_hist, 0, sizeof(c->pt_hist));
-	if (m) {
-		HIP_TRY(ukeys.reserve(m + 1)); HIP_TRY(ucnt.reserve(m + 1)); HIP_TRY(c->d_cursor.reserve(2));
+	auto sort_pairs = [&](uint64_t *kin, uint64_t *kout, uint64_t *vin, uint64_t *vout, uint64_t cnt) -> int {
+		if (!cnt) return HAO_OK;
 		size_t tb = 0;
-		HIP_TRY(rocprim::run_length_encode(nullptr, tb, c->d_ix_sx.p, m, ukeys.p, ucnt.p, (uint64_t*)c->d_cursor.p, c->stream));
+		HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, kin, kout, vin, vout, cnt, 0, 64, c->stream));
 		HIP_TRY(hao_tmp(c, tb));
-		HIP_TRY(rocprim::run_length_encode(c->d_tmp.p, tb, c->d_ix_sx.p, m, ukeys.p, ucnt.p, (uint64_t*)c->d_cursor.p, c->stream));
+		HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, kin, kout, vin, vout, cnt, 0, 64, c->stream));
+		return HAO_OK;
+	};
+	auto rle_hist = [&](const uint64_t *sorted, uint64_t cnt) -> int {       // -> ukeys/ucnt/n_unique, c->pt_hist (local)
+		n_unique = 0;
+		if (!cnt) return HAO_OK;
+		HIP_TRY(ukeys.reserve(cnt + 1)); HIP_TRY(ucnt.reserve(cnt + 1)); HIP_TRY(c->d_cursor.reserve(2));
+		size_t tb = 0;
+		HIP_TRY(rocprim::run_length_encode(nullptr, tb, sorted, cnt, ukeys.p, ucnt.p, (uint64_t*)c->d_cursor.p, c->stream));
+		HIP_TRY(hao_tmp(c, tb));
+		HIP_TRY(rocprim::run_length_encode(c->d_tmp.p, tb, sorted, cnt, ukeys.p, ucnt.p, (uint64_t*)c->d_cursor.p, c->stream));
 		HIP_TRY(hipMemcpyAsync(&n_unique, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		DevBuf<unsigned long long> &dh = c->w_hist; HIP_TRY(dh.reserve(HAO_N_COUNTS)); HIP_TRY(hipMemsetAsync(dh.p, 0, HAO_N_COUNTS * 8, c->stream));
@@ -317,14 +299,85 @@ static int hao_pt_run(hao_ctx *c)
 		HAO_CHECK_LAUNCH();
 		HIP_TRY(hipMemcpyAsync(c->pt_hist, dh.p, HAO_N_COUNTS * 8, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
+		return HAO_OK;
+	};
+	auto peaks_and_range = [&](int *hi_out) {
+		int het = -1;
+		c->hom_cov = hao_find_peaks(c->pt_hist, HAO_N_COUNTS, c->opt.min_hist_cnt, &het); c->het_cov = het;
+		int hi;
+		if (c->has_ft) hi = HAO_MAX_COUNT - 1;                                   // htab.cpp:1266-1269
+		else { hi = (int)(c->hom_cov * c->opt.high_factor); if (hi > HAO_MAX_COUNT - 1) hi = HAO_MAX_COUNT - 1; }   // :1258-1262
+		*hi_out = hi;
+	};
+	if (!sharded) {
+		const uint64_t m = c->ix_n_mz;
+		if (m >= (1ULL << 32)) { hao_set_err(c, "more than 2^32 minimizers on one device"); return HAO_EUNSUPP; }
+		HIP_TRY(c->d_ix_sx.reserve(m + 1)); HIP_TRY(c->d_ix_sinfo.reserve(m + 1));
+		if (int rc = sort_pairs(c->d_ix_mz_x.p, c->d_ix_sx.p, c->d_ix_mz_info.p, c->d_ix_sinfo.p, m)) return rc;
+		c->ix_n_sorted = m;
+		c->timer.mark("pt_sort");
+		if (int rc = rle_hist(c->d_ix_sx.p, m)) return rc;
+		c->timer.mark("pt_count");
+		int hi; peaks_and_range(&hi);
+		if (int rc = hao_keep_runs(c, ukeys.p, ucnt.p, n_unique, 2, hi, c->d_ix_keys, &c->d_ix_start, c->d_ix_cnt, &c->ix_n_keys, &c->ix_n_pos)) return rc;
+	} else {
+		// Sharded build (SURVEY 2 C1 + 8e layout i): every rank owns the hash range [r, r+1) * 2^64 / world.
+		//   local stable sort by hash -> all-to-all-v of (x, info) by range -> stable sort of the received pieces (source-rank order =
+		//   global read order, so per-key lists come out in (rid,pos) order) -> count / histogram (all-reduced) / peaks / keep ->
+		//   all-gather-v of the sorted partitions and of their key tables: concatenation in rank order is the global index.
+		hao_comm &cm = *c->comm; const int W = cm.world; const uint64_t ml = c->ix_n_mz;
+		std::vector<uint64_t> rdc;
+		if (int rc = hao_comm_allgather_u64(c, cm, n, rdc)) return rc;
+		{ uint64_t nt = 0, b = 0; for (int r = 0; r < W; ++r) { if (r < cm.rank) b += rdc[r]; nt += rdc[r]; }
+		  if (nt != c->n_total || b != c->rid_base) { hao_set_err(c, "shards are not contiguous read ranges in rank order"); return HAO_EINVAL; } }
+		DevBuf<uint64_t> lsx, lsi; HIP_TRY(lsx.reserve(ml + 1)); HIP_TRY(lsi.reserve(ml + 1));
+		if (int rc = sort_pairs(c->d_ix_mz_x.p, lsx.p, c->d_ix_mz_info.p, lsi.p, ml)) return rc;
+		std::vector<uint64_t> tg(W), cut(W + 1, 0), scnt(W), sdisp(W), rcnt;
+		for (int d = 0; d < W; ++d) tg[d] = d == 0 ? 0 : (uint64_t)(((unsigned __int128)d << 64) / (unsigned)W);
+		DevBuf<uint64_t> dt, dc; HIP_TRY(dt.reserve(W + 1)); HIP_TRY(dc.reserve(W + 1));
+		HIP_TRY(hipMemcpyAsync(dt.p, tg.data(), 8 * W, hipMemcpyHostToDevice, c->stream));
+		hipLaunchKernelGGL(hao_lower_bound_kernel, dim3((W + 63) / 64), dim3(64), 0, c->stream, lsx.p, ml, dt.p, W, dc.p);
+		HAO_CHECK_LAUNCH();
+		HIP_TRY(hipMemcpyAsync(cut.data(), dc.p, 8 * W, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		cut[W] = ml;
+		for (int d = 0; d < W; ++d) { sdisp[d] = cut[d]; scnt[d] = cut[d + 1] - cut[d]; }
+		if (int rc = hao_comm_exchange_counts(c, cm, scnt, rcnt)) return rc;
+		uint64_t n_recv = 0; for (int d = 0; d < W; ++d) n_recv += rcnt[d];
+		DevBuf<uint64_t> rx, ri, px, pi; HIP_TRY(rx.reserve(n_recv + 1)); HIP_TRY(ri.reserve(n_recv + 1)); HIP_TRY(px.reserve(n_recv + 1)); HIP_TRY(pi.reserve(n_recv + 1));
+		if (int rc = hao_comm_alltoallv_u64(c, cm, lsx.p, scnt, sdisp, rx.p, rcnt)) return rc;
+		if (int rc = hao_comm_alltoallv_u64(c, cm, lsi.p, scnt, sdisp, ri.p, rcnt)) return rc;
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		c->timer.mark("pt_alltoall");
+		if (int rc = sort_pairs(rx.p, px.p, ri.p, pi.p, n_recv)) return rc;
+		c->timer.mark("pt_sort");
+		if (int rc = rle_hist(px.p, n_recv)) return rc;
+		if (int rc = hao_comm_allreduce_i64(c, cm, c->pt_hist, HAO_N_COUNTS)) return rc;
+		c->timer.mark("pt_count");
+		int hi; peaks_and_range(&hi);
+		DevBuf<uint64_t> pk, pst; DevBuf<uint32_t> pc; uint64_t nk_p = 0, np_p = 0;
+		if (int rc = hao_keep_runs(c, ukeys.p, ucnt.p, n_unique, 2, hi, pk, &pst, pc, &nk_p, &np_p)) return rc;
+		// global layout
+		std::vector<uint64_t> part, nks, nps;
+		if (int rc = hao_comm_allgather_u64(c, cm, n_recv, part)) return rc;
+		if (int rc = hao_comm_allgather_u64(c, cm, nk_p, nks)) return rc;
+		if (int rc = hao_comm_allgather_u64(c, cm, np_p, nps)) return rc;
+		uint64_t m = 0, base = 0, nk = 0, np = 0;
+		for (int r = 0; r < W; ++r) { if (r < cm.rank) base += part[r]; m += part[r]; nk += nks[r]; np += nps[r]; }
+		if (m >= (1ULL << 32)) { hao_set_err(c, "more than 2^32 minimizers in the replicated index"); return HAO_EUNSUPP; }
+		if (nk_p) { hipLaunchKernelGGL(hao_add_const_kernel, dim3((unsigned)((nk_p + 255) / 256)), dim3(256), 0, c->stream, pst.p, nk_p, base); HAO_CHECK_LAUNCH(); }
+		HIP_TRY(c->d_ix_sx.reserve(m + 1)); HIP_TRY(c->d_ix_sinfo.reserve(m + 1));
+		HIP_TRY(c->d_ix_keys.reserve(nk + 1)); HIP_TRY(c->d_ix_start.reserve(nk + 1)); HIP_TRY(c->d_ix_cnt.reserve(nk + 1));
+		if (int rc = hao_comm_allgatherv(c, cm, px.p, n_recv, 8, c->d_ix_sx.p, part)) return rc;
+		if (int rc = hao_comm_allgatherv(c, cm, pi.p, n_recv, 8, c->d_ix_sinfo.p, part)) return rc;
+		if (int rc = hao_comm_allgatherv(c, cm, pk.p, nk_p, 8, c->d_ix_keys.p, nks)) return rc;
+		if (int rc = hao_comm_allgatherv(c, cm, pst.p, nk_p, 8, c->d_ix_start.p, nks)) return rc;
+		if (int rc = hao_comm_allgatherv(c, cm, pc.p, nk_p, 4, c->d_ix_cnt.p, nks)) return rc;
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		c->ix_n_sorted = m; c->ix_n_keys = nk; c->ix_n_pos = np;
+		lsx.release(); lsi.release(); rx.release(); ri.release(); px.release(); pi.release(); pk.release(); pst.release(); pc.release(); dt.release(); dc.release();
+		c->timer.mark("pt_allgather");
 	}
-	c->timer.mark("pt_count");
-	int het = -1;
-	c->hom_cov = hao_find_peaks(c->pt_hist, HAO_N_COUNTS, c->opt.min_hist_cnt, &het); c->het_cov = het;
-	int hi;
-	if (c->has_ft) hi = HAO_MAX_COUNT - 1;                                   // htab.cpp:1266-1269
-	else { hi = (int)(c->hom_cov * c->opt.high_factor); if (hi > HAO_MAX_COUNT - 1) hi = HAO_MAX_COUNT - 1; }   // :1258-1262
-	if (int rc = hao_keep_runs(c, ukeys.p, ucnt.p, n_unique, 2, hi, c->d_ix_keys, &c->d_ix_start, c->d_ix_cnt, &c->ix_n_keys, &c->ix_n_pos)) return rc;
 	int bits = 16; while ((1ULL << bits) < c->ix_n_keys / 2 && bits < 26) ++bits;
 	if (int rc = hao_build_bucket(c, c->d_ix_keys.p, c->ix_n_keys, bits, c->d_ix_bucket)) return rc;
 	c->ix_bucket_bits = bits;
@@ -347,14 +400,14 @@ static int hao_pt_download(hao_ctx *c)
 {
 	if (c->h_ix_valid) return HAO_OK;
 	const uint64_t nk = c->ix_n_keys;
-	std::vector<uint64_t> start(nk); std::vector<uint32_t> cnt(nk); std::vector<uint64_t> sinfo(c->ix_n_mz);
+	std::vector<uint64_t> start(nk); std::vector<uint32_t> cnt(nk); std::vector<uint64_t> sinfo(c->ix_n_sorted);
 	c->h_ix_keys.resize(nk); c->h_ix_off.resize(nk + 1); c->h_ix_pos.resize(c->ix_n_pos);
 	if (nk) {
 		HIP_TRY(hipMemcpy(c->h_ix_keys.data(), c->d_ix_keys.p, nk * 8, hipMemcpyDeviceToHost));
 		HIP_TRY(hipMemcpy(start.data(), c->d_ix_start.p, nk * 8, hipMemcpyDeviceToHost));
 		HIP_TRY(hipMemcpy(cnt.data(), c->d_ix_cnt.p, nk * 4, hipMemcpyDeviceToHost));
 	}
-	if (c->ix_n_mz) HIP_TRY(hipMemcpy(sinfo.data(), c->d_ix_sinfo.p, c->ix_n_mz * 8, hipMemcpyDeviceToHost));
+	if (c->ix_n_sorted) HIP_TRY(hipMemcpy(sinfo.data(), c->d_ix_sinfo.p, c->ix_n_sorted * 8, hipMemcpyDeviceToHost));
 	uint64_t o = 0;
 	for (uint64_t i = 0; i < nk; ++i) { c->h_ix_off[i] = o; memcpy(c->h_ix_pos.data() + o, sinfo.data() + start[i], (size_t)cnt[i] * 8); o += cnt[i]; }
 	c->h_ix_off[nk] = o;
