@@ -22,4 +22,9 @@ BIG_SCENARIOS = {
     "rr_big":   (dict(genome_size=400_000, coverage=30, read_len=8000, err=0.001, seed=5, repeat_rich=1, len_jit=2000), {}),
     "hifi_15k": (dict(genome_size=300_000, coverage=25, read_len=15000, err=0.001, seed=21, len_jit=3000), {}),
     "ont_big":  (dict(genome_size=200_000, coverage=30, read_len=12000, err=0.01, seed=6, len_jit=4000), dict(is_ont=1)),
+    # stress the capacity fallbacks: > 4096 minimizers per read (query table read from global memory), > 2048-hit groups
+    # (chain DP arrays in global scratch), and - in rr_heavy, a genome that is mostly overlapping repeat copies - reads with
+    # more than 1024 chains (selection keys in global scratch, bitonic finish)
+    "long200k": (dict(genome_size=1_000_000, coverage=16, read_len=200_000, err=0.008, seed=31, len_jit=20_000), dict(is_ont=1)),
+    "rr_heavy": (dict(genome_size=300_000, coverage=20, read_len=6000, err=0.001, seed=9, repeat_rich=1, len_jit=1500), {}),
 }
