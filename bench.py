@@ -46,6 +46,7 @@ ALG = {
     "seed_expand_kernel": ("anchor", 8 + 8),                         # index position in + key out
     "chain_assemble_kernel": ("anchor", 16 + 16),                    # chained hit in + tagged hit out
     "groups_kernel": ("anchor", 2 * 16),                             # two sweeps over the hits
+    "seg_bin_sort_kernel": ("anchor", 8 + 16),                       # key in, k_mer_hit out (groups come with the bin table)
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -194,7 +195,7 @@ def main():
         # roofline of the dominant kernel: live HIP-event time of its stage on the engine's stream
         kern_stage = {"sketch_chunk_wave_kernel": "sk_chunks", "chain_group_kernel": "q_chain", "seg_radix_pass_kernel<false>": "q_sort_p0",
                       "seg_radix_pass_kernel<true>": "q_sort_final", "seed_expand_kernel": "q_expand", "chain_assemble_kernel": "q_assemble",
-                      "groups_kernel": "q_groups"}
+                      "groups_kernel": "q_groups", "seg_bin_sort_kernel": "q_sort_bins"}
         dom = max(kern_stage, key=lambda k: stage_ms.get(kern_stage[k], 0.0))
         unit, bpu = ALG[dom]
         units = rs.total_bases if unit == "base" else tot["seed_hits"]

@@ -10,7 +10,7 @@ struct hao_ctx::Batch {
 	bool valid = false, host_valid = false;
 	DevBuf<uint64_t> s_start, a_off, seg, keys, keys2, g_cnt, g_off, g_start, ch_base, cl_base, fc_base, fcs, fc_raw, ol_fc_off, cc_off, cc, fc_final, fin_off, fcf_off, fc_out, fc_out_off;
 	DevBuf<uint64_t> nch64;
-	DevBuf<uint32_t> q_pos, q_cnt, s_n, g_read, wgt, nch, nout, perm, n_final, fclen;
+	DevBuf<uint32_t> g_tmp, q_pos, q_cnt, s_n, g_read, wgt, nch, nout, perm, n_final, fclen;
 	DevBuf<hao_hit_t> hits, ohits, cl;
 	DevBuf<int32_t> f, ii, p, key_sc, tm; DevBuf<uint64_t> slow_list; DevBuf<int64_t> t; DevBuf<uint64_t> key_xs; DevBuf<uint32_t> key_al, key_tmp;
 	DevBuf<hao_chain_rec> rec; DevBuf<hao_ovlp_t> ol, ol_out;
@@ -20,7 +20,7 @@ struct hao_ctx::Batch {
 	void release() {
 		s_start.release(); a_off.release(); seg.release(); keys.release(); keys2.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fin_off.release(); fcf_off.release(); fc_out.release(); fc_out_off.release();
-		nch64.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
+		nch64.release(); g_tmp.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
 		tm.release(); slow_list.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); ol_out.release();
 	}
 };
@@ -74,7 +74,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	c->timer.mark("q_lookup");
 	const uint64_t A = B.n_anchor;
 	if (A >= (1ULL << 32)) { hao_set_err(c, "batch produces >= 2^32 anchors: use a smaller read range"); return HAO_EUNSUPP; }
-	HIP_TRY(B.keys.reserve(A + 1)); HIP_TRY(B.keys2.reserve(A + 1)); HIP_TRY(B.hits.reserve(A + 1));
+	HIP_TRY(B.keys.reserve(A + 1)); HIP_TRY(B.hits.reserve(A + 1));
 	// key layout of this batch
 	hao_keyfmt F;
 	{
@@ -95,31 +95,49 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	// Q3+Q4: stable LSD passes over the (rev, tid) bits only; the last pass decodes keys into k_mer_hits
 	hao_hitb_args hb;
 	hb.mz_off = c->d_ix_mz_off.p; hb.rid_lo = lo; hb.mz0 = B.mz0; hb.q_pos = B.q_pos.p; hb.q_cnt = B.q_cnt.p; hb.F = F; hb.hits = B.hits.p;
-	if (A) {
-		uint64_t *src = B.keys.p, *dst = B.keys2.p; const int beg_bit = F.ob + F.qb, nb = 1 + F.tb;
-		// digits of equal width: 8 bits unless that costs an extra pass (then up to 11; the per-wave digit counters are LDS-resident)
-		int n_pass = (nb + 7) / 8; if ((nb + HAO_RDX_MAXBITS - 1) / HAO_RDX_MAXBITS < n_pass) n_pass = (nb + HAO_RDX_MAXBITS - 1) / HAO_RDX_MAXBITS;
-		const int db = (nb + n_pass - 1) / n_pass;
-		const uint32_t qcap = (uint32_t)std::min<uint64_t>(1ULL << F.qb, HAO_QTAB_CAP);
-		for (int ps_ = 0, sh = beg_bit; ps_ < n_pass; ++ps_, sh += db) {
-			const int bits = std::min(db, beg_bit + nb - sh); const size_t lds = (size_t)5 * (1u << bits) * 4;
-			if (ps_ == n_pass - 1) hipLaunchKernelGGL(seg_radix_pass_kernel<true>, dim3((unsigned)n), dim3(256), lds + 8 * qcap, c->stream, src, dst, B.seg.p, sh, bits, qcap, hb);
-			else hipLaunchKernelGGL(seg_radix_pass_kernel<false>, dim3((unsigned)n), dim3(256), lds, c->stream, src, dst, B.seg.p, sh, bits, 0u, hb);
-			HAO_CHECK_LAUNCH();
-			c->timer.mark(ps_ == n_pass - 1 ? "q_sort_final" : (ps_ == 0 ? "q_sort_p0" : "q_sort_p1"));
-			std::swap(src, dst);
-		}
-	}
-	// Q5 groups
+	const bool use_radix = getenv("HAO_DBG_RADIX") != nullptr;      // digit-wise LSD passes + a group pass over the hits (kept for A/B measurements)
+	const uint32_t qcap = (uint32_t)std::min<uint64_t>(1ULL << F.qb, HAO_QTAB_CAP);
 	HIP_TRY(B.g_cnt.reserve(n + 2)); HIP_TRY(B.g_off.reserve(n + 2));
-	hipLaunchKernelGGL(groups_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, B.hits.p, B.seg.p, n, (const uint64_t*)nullptr, B.g_cnt.p, (uint64_t*)nullptr, (uint32_t*)nullptr, 0);
-	HAO_CHECK_LAUNCH();
+	if (use_radix) {
+		HIP_TRY(B.keys2.reserve(A + 1));
+		if (A) {
+			uint64_t *src = B.keys.p, *dst = B.keys2.p; const int beg_bit = F.ob + F.qb, nb = 1 + F.tb;
+			// digits of equal width: 8 bits unless that costs an extra pass (then up to 11; the per-wave digit counters are LDS-resident)
+			int n_pass = (nb + 7) / 8; if ((nb + HAO_RDX_MAXBITS - 1) / HAO_RDX_MAXBITS < n_pass) n_pass = (nb + HAO_RDX_MAXBITS - 1) / HAO_RDX_MAXBITS;
+			const int db = (nb + n_pass - 1) / n_pass;
+			for (int ps_ = 0, sh = beg_bit; ps_ < n_pass; ++ps_, sh += db) {
+				const int bits = std::min(db, beg_bit + nb - sh); const size_t lds = (size_t)5 * (1u << bits) * 4;
+				if (ps_ == n_pass - 1) hipLaunchKernelGGL(seg_radix_pass_kernel<true>, dim3((unsigned)n), dim3(256), lds + 8 * qcap, c->stream, src, dst, B.seg.p, sh, bits, qcap, hb);
+				else hipLaunchKernelGGL(seg_radix_pass_kernel<false>, dim3((unsigned)n), dim3(256), lds, c->stream, src, dst, B.seg.p, sh, bits, 0u, hb);
+				HAO_CHECK_LAUNCH();
+				c->timer.mark(ps_ == n_pass - 1 ? "q_sort_final" : (ps_ == 0 ? "q_sort_p0" : "q_sort_p1"));
+				std::swap(src, dst);
+			}
+		}
+		hipLaunchKernelGGL(groups_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, B.hits.p, B.seg.p, n, (const uint64_t*)nullptr, B.g_cnt.p, (uint64_t*)nullptr, (uint32_t*)nullptr, 0);
+		HAO_CHECK_LAUNCH();
+	} else {
+		// Q3-Q5 in one sweep: distinct (tid, rev) bins per read -> ranked stable scatter + group lists
+		HIP_TRY(B.g_tmp.reserve(A + 1));
+		int CL = HAO_BIN_CAPLOG; if (const char *e_ = getenv("HAO_BIN_CAPLOG")) CL = atoi(e_);
+		const size_t lds = (size_t)36 * (1u << CL) + 8 * qcap;
+		if (lds > 64 * 1024) {     // beyond the default dynamic LDS limit: opt in (the CU has 160 KB)
+			const void *fn = CL == 9 ? (const void*)seg_bin_sort_kernel<9> : CL == 11 ? (const void*)seg_bin_sort_kernel<11> : (const void*)seg_bin_sort_kernel<10>;
+			HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		}
+		if (CL == 9) hipLaunchKernelGGL((seg_bin_sort_kernel<9>), dim3((unsigned)n), dim3(256), lds, c->stream, B.keys.p, B.seg.p, n, qcap, hb, B.g_tmp.p, B.g_cnt.p);
+		else if (CL == 11) hipLaunchKernelGGL((seg_bin_sort_kernel<11>), dim3((unsigned)n), dim3(256), lds, c->stream, B.keys.p, B.seg.p, n, qcap, hb, B.g_tmp.p, B.g_cnt.p);
+		else hipLaunchKernelGGL((seg_bin_sort_kernel<10>), dim3((unsigned)n), dim3(256), lds, c->stream, B.keys.p, B.seg.p, n, qcap, hb, B.g_tmp.p, B.g_cnt.p);
+		HAO_CHECK_LAUNCH();
+		c->timer.mark("q_sort_bins");
+	}
 	if (int rc = hao_excl_scan_u64(c, B.g_cnt.p, B.g_off.p, n + 1)) return rc;
 	HIP_TRY(hipMemcpyAsync(&B.n_groups, B.g_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	const uint64_t G = B.n_groups;
 	HIP_TRY(B.g_start.reserve(G + 1)); HIP_TRY(B.g_read.reserve(G + 1));
-	hipLaunchKernelGGL(groups_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, B.hits.p, B.seg.p, n, B.g_off.p, B.g_cnt.p, B.g_start.p, B.g_read.p, 1);
+	if (use_radix) hipLaunchKernelGGL(groups_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, B.hits.p, B.seg.p, n, B.g_off.p, B.g_cnt.p, B.g_start.p, B.g_read.p, 1);
+	else hipLaunchKernelGGL(groups_compact_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, B.g_tmp.p, B.seg.p, B.g_off.p, n, B.g_start.p, B.g_read.p);
 	HAO_CHECK_LAUNCH();
 	c->timer.mark("q_groups");
 	// Q6 chain
@@ -129,7 +147,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	if (G) {
 		hao_chain_args ca;
 		ca.hits = B.hits.p; ca.g_start = B.g_start.p; ca.g_read = B.g_read.p; ca.g_off = B.g_off.p; ca.seg = B.seg.p; ca.n_groups = G; ca.rid_lo = glo; ca.len = c->d_len_all.p; ca.par = par;
-		HIP_TRY(B.stats.reserve(4)); HIP_TRY(hipMemsetAsync(B.stats.p, 0, 16, c->stream)); ca.stats = B.stats.p; ca.dbg_skip_generic = getenv("HAO_DBG_SKIP_GENERIC") ? 1 : 0; ca.dbg_seq = getenv("HAO_DBG_SEQ_CHAIN") ? 1 : 0;
+		HIP_TRY(B.stats.reserve(4)); HIP_TRY(hipMemsetAsync(B.stats.p, 0, 16, c->stream)); ca.stats = B.stats.p; ca.dbg_skip_generic = getenv("HAO_DBG_SKIP_GENERIC") ? 1 : 0; ca.dbg_seq = getenv("HAO_DBG_SEQ_CHAIN") ? 1 : (getenv("HAO_DBG_DP_NOTAIL") ? 2 : 0);
 		HIP_TRY(B.tm.reserve(A + 1)); HIP_TRY(B.slow_list.reserve(G + 1)); ca.tm = B.tm.p; ca.slow_list = B.slow_list.p;
 		ca.f = B.f.p; ca.ii = B.ii.p; ca.p = B.p.p; ca.t = B.t.p; ca.ohits = B.ohits.p; ca.fcs = B.fcs.p; ca.rec = B.rec.p; ca.nch = B.nch.p; ca.nout = B.nout.p;
 		hipLaunchKernelGGL(chain_group_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream, ca);
@@ -141,6 +159,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			std::vector<uint64_t> sl(B.n_generic), small, large;        // entries: group id | size << 40
 			HIP_TRY(hipMemcpy(sl.data(), B.slow_list.p, B.n_generic * 8, hipMemcpyDeviceToHost));
 			for (uint64_t e : sl) ((e >> 40) <= 512 ? small : large).push_back(e);
+			if (getenv("HAO_DBG_DP_STATS")) { uint64_t mx = 0, h[8] = {0}; for (uint64_t e : sl) { uint64_t z = e >> 40; mx = std::max(mx, z); int b = 0; while (b < 7 && (64ULL << b) < z) ++b; ++h[b]; } fprintf(stderr, "[dp] groups %zu max %llu hist(<=64,128,..,4096,more):", sl.size(), (unsigned long long)mx); for (int b = 0; b < 8; ++b) fprintf(stderr, " %llu", (unsigned long long)h[b]); fprintf(stderr, "\n"); }
 			if (!small.empty()) HIP_TRY(hipMemcpy(B.slow_list.p, small.data(), small.size() * 8, hipMemcpyHostToDevice));
 			if (!large.empty()) HIP_TRY(hipMemcpy(B.slow_list.p + small.size(), large.data(), large.size() * 8, hipMemcpyHostToDevice));
 			if (!small.empty()) { hipLaunchKernelGGL((chain_dp_kernel<512, true>), dim3((unsigned)small.size()), dim3(64), 0, c->stream, ca, B.slow_list.p, (uint64_t)small.size()); HAO_CHECK_LAUNCH(); }

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(hao_chain_args A, const ui
 	if (blockIdx.x >= n_slow) return;
 	const uint64_t g = list[blockIdx.x] & ((1ULL << 40) - 1);
 	const int lane = hao_lane();
-	if (A.dbg_seq) { if (lane == 0) hao_chain_generic(A, g); return; }
+	if (A.dbg_seq == 1) { if (lane == 0) hao_chain_generic(A, g); return; }
 	const uint32_t r = A.g_read[g]; const uint64_t gs = A.g_start[g], ge = (g + 1 < A.g_off[r + 1]) ? A.g_start[g + 1] : A.seg[r + 1];
 	const hao_hit_t *ag = A.hits + gs; const int64_t a_n = (int64_t)(ge - gs);
 	const bool in_lds = a_n <= CAP;
@@ -500,6 +500,7 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(hao_chain_args A, const ui
 			if ((int32_t)max_f < plus) plus = (int32_t)max_f;
 		}
 	}
+	if (A.dbg_seq == 2) return;
 	if (lane == 0) hao_chain_tail(A, g, a, a_n, P, f, p, t, ii, msc, msc_i, plus);
 }
 

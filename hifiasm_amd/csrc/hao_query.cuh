@@ -157,6 +157,150 @@ __global__ __launch_bounds__(256) void seg_radix_pass_kernel(const uint64_t *in,
 }
 #undef cnt
 
+// Q3': per-read ordering in ONE sweep over the keys.  A read meets few distinct (tid, rev) values (the reads that
+// overlap it: ~2 x coverage) although their ids need 15-29 bits, so instead of radix digits the workgroup first builds
+// the set of distinct (tid, rev) bins of the read in an LDS hash table (counting per wave while inserting), sorts the
+// distinct bins, and then places every key with one stable ranked scatter - decoding it into a k_mer_hit on the way -
+// exactly like the last pass of the digit version, with the bin's rank as the "digit".  The bin table also IS the list
+// of target groups of the read (consecutive bins with the same tid), so Q5 needs no pass over the hits.
+// Reads with more distinct bins than the table holds are handled in several rounds over increasing (tid, rev) ranges
+// (range halved until it fits); every round re-reads the read's keys (L2-resident).
+// HBM traffic: keys once in (8 B), hits once out (16 B) per anchor.
+#define HAO_BIN_EMPTY 0xffffffffu
+#define HAO_BIN_CAPLOG 10        // 1024 table slots, up to 512 distinct (tid, rev) bins per round
+template<int CAPLOG>
+__global__ __launch_bounds__(256) void seg_bin_sort_kernel(const uint64_t *in, const uint64_t *seg, uint64_t n_sel, uint32_t qcap, hao_hitb_args H, uint32_t *g_tmp, uint64_t *g_cnt)
+{
+	constexpr uint32_t CAP = 1u << CAPLOG, MAXD = CAP >= 1024 ? CAP / 2 : CAP / 4;      // at most MAXD + 256 bins are ever inserted, so probing terminates; CAP >= 512
+	extern __shared__ uint32_t bs_smem[];
+	uint32_t *hk = bs_smem;                      // [CAP]    bin key (tid << 1 | rev) per slot
+	uint32_t *cw = hk + CAP;                     // [4][CAP] per-wave counts, then running output offsets
+	uint32_t *rk = cw + 4 * CAP;                 // [CAP]    rank of the slot's bin among the bins of the round
+	uint64_t *sk = (uint64_t*)(rk + CAP);        // [CAP]    (bin key << 32 | slot), sorted
+	uint32_t *tot = (uint32_t*)(sk + CAP);       // [CAP]    per-rank totals -> first output position of the bin
+	uint32_t *l_qpos = tot + CAP, *l_qcnt = l_qpos + qcap;
+	__shared__ uint32_t s_nd, s_ovf, s_c; __shared__ uint64_t s_ws[4], s_all;
+	const uint64_t r = blockIdx.x, s = seg[r], e = seg[r + 1]; const uint32_t n = (uint32_t)(e - s);
+	const int wv = threadIdx.x >> 6, lane = hao_lane(); const uint32_t tid = threadIdx.x;
+	if (r == 0 && tid == 0) g_cnt[n_sel] = 0;
+	if (n == 0) { if (tid == 0) g_cnt[r] = 0; return; }
+	const uint32_t *qpos, *qcnt;
+	{
+		const uint64_t m0 = H.mz_off[H.rid_lo + r] - H.mz0, nq = H.mz_off[H.rid_lo + r + 1] - H.mz0 - m0;
+		if (nq <= qcap) { for (uint32_t q = tid; q < nq; q += 256) { l_qpos[q] = H.q_pos[m0 + q]; l_qcnt[q] = H.q_cnt[m0 + q]; } qpos = l_qpos; qcnt = l_qcnt; }
+		else { qpos = H.q_pos + m0; qcnt = H.q_cnt + m0; }
+	}
+	const int kshift = H.F.ob + H.F.qb;
+	const uint32_t chunk = ((n + 3) / 4 + 255) & ~255u, c0 = min(n, wv * chunk), c1 = min(n, c0 + chunk);
+	const uint32_t k_end = 2u << H.F.tb;
+	uint32_t lo = 0, placed = 0, ngr = 0, last_tid = 0xffffffffu;
+	volatile uint32_t *v_ovf = &s_ovf;
+	while (lo < k_end) {
+		uint32_t hi = k_end;
+		for (;;) {      // count the bins of [lo, hi); shrink the range until they fit the table
+			for (uint32_t i = tid; i < CAP; i += 256) { hk[i] = HAO_BIN_EMPTY; cw[i] = 0; cw[CAP + i] = 0; cw[2 * CAP + i] = 0; cw[3 * CAP + i] = 0; }
+			if (tid == 0) { s_nd = 0; s_ovf = 0; s_c = 0; }
+			__syncthreads();
+			for (uint32_t t0 = c0; t0 < c1; t0 += 256) {      // four independent key loads in flight per lane
+				uint64_t kv[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) { const uint32_t i = t0 + u * 64 + lane; kv[u] = i < c1 ? in[s + i] : 0; }
+				if (*v_ovf) break;
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const uint32_t i = t0 + u * 64 + lane, kk = (uint32_t)(kv[u] >> kshift);
+					if (i < c1 && kk >= lo && kk < hi) {
+						uint32_t slot = (kk * 2654435761u) >> (32 - CAPLOG);
+						for (;;) {
+							const uint32_t old = atomicCAS(&hk[slot], HAO_BIN_EMPTY, kk);
+							if (old == HAO_BIN_EMPTY) { if (atomicAdd(&s_nd, 1u) >= MAXD) *v_ovf = 1; break; }
+							if (old == kk) break;
+							slot = (slot + 1) & (CAP - 1);
+						}
+						atomicAdd(&cw[wv * CAP + slot], 1u);
+					}
+				}
+			}
+			__syncthreads();
+			const bool ovf = *v_ovf != 0;
+			__syncthreads();
+			if (!ovf) break;
+			hi = lo + (hi - lo) / 2;      // hi - lo >= 2 here: one bin always fits
+		}
+		const uint32_t D = s_nd;
+		if (D) {
+			uint32_t P = 2; while (P < D) P <<= 1;
+			for (uint32_t i = tid; i < CAP; i += 256) if (hk[i] != HAO_BIN_EMPTY) sk[atomicAdd(&s_c, 1u)] = (uint64_t)hk[i] << 32 | i;
+			for (uint32_t i = D + tid; i < P; i += 256) sk[i] = ~0ULL;
+			__syncthreads();
+			for (uint32_t k = 2; k <= P; k <<= 1)
+				for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+					for (uint32_t i = tid; i < P; i += 256) {
+						const uint32_t x = i ^ j;
+						if (x > i) { const uint64_t a = sk[i], b = sk[x]; if ((a > b) == ((i & k) == 0)) { sk[i] = b; sk[x] = a; } }
+					}
+					__syncthreads();
+				}
+			for (uint32_t d = tid; d < D; d += 256) { const uint32_t slot = (uint32_t)sk[d]; rk[slot] = d; tot[d] = cw[slot] + cw[CAP + slot] + cw[2 * CAP + slot] + cw[3 * CAP + slot]; }
+			__syncthreads();
+			// exclusive scan over the sorted bins of (hits, group starts), packed as starts << 32 | hits; thread t owns bins [t*per, (t+1)*per)
+			const uint32_t per = P >= 256 ? P / 256 : 1, d0 = tid * per; uint64_t mine = 0;
+			for (uint32_t d = d0; d < d0 + per && d < D; ++d) {
+				const uint32_t t_k = (uint32_t)(sk[d] >> 33), t_p = d ? (uint32_t)(sk[d - 1] >> 33) : last_tid;
+				mine += (uint64_t)(t_k != t_p) << 32 | tot[d];
+			}
+			uint64_t inc = mine;
+#pragma unroll
+			for (int dl = 1; dl < 64; dl <<= 1) { const uint64_t y = __shfl_up(inc, dl); if (lane >= dl) inc += y; }
+			if (lane == 63) s_ws[wv] = inc;
+			__syncthreads();
+			uint64_t ex = inc - mine; for (int x = 0; x < wv; ++x) ex += s_ws[x];
+			if (tid == 255) s_all = ex + mine;
+			for (uint32_t d = d0; d < d0 + per && d < D; ++d) {
+				const uint32_t slot = (uint32_t)sk[d], t_k = (uint32_t)(sk[d] >> 33), t_p = d ? (uint32_t)(sk[d - 1] >> 33) : last_tid;
+				uint32_t run = placed + (uint32_t)ex;
+				if (t_k != t_p) { g_tmp[s + ngr + (uint32_t)(ex >> 32)] = run; ex += 1ULL << 32; }
+				ex += tot[d];
+				for (int x = 0; x < 4; ++x) { const uint32_t cc = cw[x * CAP + slot]; cw[x * CAP + slot] = run; run += cc; }
+			}
+			__syncthreads();
+			int nbits = 0; while ((1u << nbits) < D) ++nbits;
+			for (uint32_t t0 = c0; t0 < c1; t0 += 256) {
+				uint64_t kv[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) { const uint32_t i = t0 + u * 64 + lane; kv[u] = i < c1 ? in[s + i] : 0; }
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const uint32_t i = t0 + u * 64 + lane; const uint64_t key = kv[u]; const uint32_t kk = (uint32_t)(key >> kshift);
+					const bool inr = i < c1 && kk >= lo && kk < hi;
+					uint32_t slot = (kk * 2654435761u) >> (32 - CAPLOG);
+					if (inr) while (hk[slot] != kk) slot = (slot + 1) & (CAP - 1);
+					const uint32_t d = inr ? rk[slot] : 0;
+					const unsigned long long m = hao_match_bits(d, inr, nbits);
+					const uint32_t base = inr ? cw[wv * CAP + slot] : 0;
+					if (inr) H.hits[s + base + __popcll(m & ((1ULL << lane) - 1))] = hao_key_to_hit(H.F, key, qpos, qcnt);
+					if (inr && (m & ((1ULL << lane) - 1)) == 0) cw[wv * CAP + slot] = base + __popcll(m);
+				}
+			}
+			last_tid = (uint32_t)(sk[D - 1] >> 33);
+			const uint64_t all = s_all;
+			placed += (uint32_t)all; ngr += (uint32_t)(all >> 32);
+			__syncthreads();
+		}
+		lo = hi;
+	}
+	if (tid == 0) g_cnt[r] = ngr;
+}
+
+// group table from the per-read lists seg_bin_sort_kernel left at g_tmp[seg[r] ..): one wave per read
+__global__ __launch_bounds__(256) void groups_compact_kernel(const uint32_t *g_tmp, const uint64_t *seg, const uint64_t *g_off, uint64_t n_sel, uint64_t *g_start, uint32_t *g_read)
+{
+	const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= n_sel) return;
+	const uint64_t s = seg[r], g0 = g_off[r], ng = g_off[r + 1] - g0;
+	for (uint64_t k = hao_lane(); k < ng; k += 64) { g_start[g0 + k] = s + g_tmp[s + k]; g_read[g0 + k] = (uint32_t)r; }
+}
+
 // Q5: target groups of each read (hits are sorted by target id inside a read).
 // pass 0: count groups per read; pass 1: write group starts at g_off[r] + rank.
 __global__ __launch_bounds__(256) void groups_kernel(const hao_hit_t *hits, const uint64_t *seg, uint64_t n_sel, const uint64_t *g_off, uint64_t *g_cnt, uint64_t *g_start, uint32_t *g_read, int pass)
