@@ -41,11 +41,8 @@ WORKLOADS = {
 ALG = {
     "sketch_chunk_wave_kernel": ("base", 0.25 + 16.0 / 35.0),       # 2-bit bases in + one 16-B minimizer per ~35 bases out
     "chain_group_kernel": ("anchor", 16 + 4),                        # k_mer_hit in + fake-cigar / record out (hits stay in place)
-    "seg_radix_pass_kernel<false>": ("anchor", 8 + 8),               # key in, key out
-    "seg_radix_pass_kernel<true>": ("anchor", 8 + 16),               # key in, k_mer_hit out
     "seed_expand_kernel": ("anchor", 8 + 8),                         # index position in + key out
     "chain_assemble_kernel": ("anchor", 16 + 16),                    # chained hit in + tagged hit out
-    "groups_kernel": ("anchor", 2 * 16),                             # two sweeps over the hits
     "seg_bin_sort_kernel": ("anchor", 8 + 16),                       # key in, k_mer_hit out (groups come with the bin table)
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
@@ -193,13 +190,12 @@ def main():
     if rank == 0:
         stage_ms = {k: v / a.steps for k, v in stage_sum.items()}
         # roofline of the dominant kernel: live HIP-event time of its stage on the engine's stream
-        kern_stage = {"sketch_chunk_wave_kernel": "sk_chunks", "chain_group_kernel": "q_chain", "seg_radix_pass_kernel<false>": "q_sort_p0",
-                      "seg_radix_pass_kernel<true>": "q_sort_final", "seed_expand_kernel": "q_expand", "chain_assemble_kernel": "q_assemble",
-                      "groups_kernel": "q_groups", "seg_bin_sort_kernel": "q_sort_bins"}
+        kern_stage = {"sketch_chunk_wave_kernel": "sk_chunks", "chain_group_kernel": "q_chain", "seed_expand_kernel": "q_expand",
+                      "chain_assemble_kernel": "q_assemble", "seg_bin_sort_kernel": "q_sort_bins"}
         dom = max(kern_stage, key=lambda k: stage_ms.get(kern_stage[k], 0.0))
         unit, bpu = ALG[dom]
         units = rs.total_bases if unit == "base" else tot["seed_hits"]
-        n_launch = 1 if unit == "base" else max(1, (n_reads + bsz - 1) // bsz) * (2 if dom == "groups_kernel" else 1)
+        n_launch = 1 if unit == "base" else max(1, (n_reads + bsz - 1) // bsz)
         k_ms = stage_ms.get(kern_stage[dom], 0.0) / n_launch
         alg_bytes = bpu * units / n_launch
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0

@@ -8,20 +8,22 @@ struct hao_ctx::Batch {
 	uint64_t n_generic = 0, n_generic_hits = 0; DevBuf<unsigned long long> stats;
 	uint64_t lo = 0, n = 0, mz0 = 0, n_mz = 0, n_anchor = 0, n_groups = 0, n_chains = 0, n_cl = 0, n_fc_raw = 0, n_ol = 0, n_fc = 0;
 	bool valid = false, host_valid = false;
-	DevBuf<uint64_t> s_start, a_off, seg, keys, keys2, g_cnt, g_off, g_start, ch_base, cl_base, fc_base, fcs, fc_raw, ol_fc_off, cc_off, cc, fc_final, fin_off, fcf_off, fc_out, fc_out_off;
+	DevBuf<uint64_t> s_start, a_off, seg, keys, g_cnt, g_off, g_start, ch_base, cl_base, fc_base, fcs, fc_raw, ol_fc_off, cc_off, cc, fc_final, fin_off, fcf_off, fc_out, fc_out_off;
 	DevBuf<uint64_t> nch64;
-	DevBuf<uint32_t> g_tmp, q_pos, q_cnt, s_n, g_read, wgt, nch, nout, perm, n_final, fclen;
+	DevBuf<uint64_t> g_tmp, cls_cc, cls_co; DevBuf<hao_gent> glist; DevBuf<uint32_t> slow; hipStream_t side[HAO_NCLS]; hipEvent_t ev_qc[HAO_NCLS], ev_dp[HAO_NCLS]; bool side_ready = false;
+	DevBuf<uint32_t> q_pos, q_cnt, s_n, g_read, wgt, nch, nout, perm, n_final, fclen;
 	DevBuf<hao_hit_t> hits, ohits, cl;
-	DevBuf<int32_t> f, ii, p, key_sc, tm; DevBuf<uint64_t> slow_list; DevBuf<int64_t> t; DevBuf<uint64_t> key_xs; DevBuf<uint32_t> key_al, key_tmp;
+	DevBuf<int32_t> f, ii, p, key_sc, tm; DevBuf<int64_t> t; DevBuf<uint64_t> key_xs; DevBuf<uint32_t> key_al, key_tmp;
 	DevBuf<hao_chain_rec> rec; DevBuf<hao_ovlp_t> ol, ol_out;
 	// host copies for fetch
 	std::vector<uint64_t> h_seg, h_fin_off, h_cl_off, h_fc_out_off; std::vector<hao_hit_t> h_hits, h_cl; std::vector<hao_ovlp_t> h_ol; std::vector<uint64_t> h_fc;
 	std::vector<uint64_t> fetch_fc_off;
 	void release() {
-		s_start.release(); a_off.release(); seg.release(); keys.release(); keys2.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
+		if (side_ready) { for (int x = 0; x < HAO_NCLS; ++x) { (void)hipStreamDestroy(side[x]); (void)hipEventDestroy(ev_qc[x]); (void)hipEventDestroy(ev_dp[x]); } side_ready = false; }
+		s_start.release(); a_off.release(); seg.release(); keys.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fin_off.release(); fcf_off.release(); fc_out.release(); fc_out_off.release();
-		nch64.release(); g_tmp.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
-		tm.release(); slow_list.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); ol_out.release();
+		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); slow.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
+		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); ol_out.release();
 	}
 };
 
@@ -95,30 +97,12 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	// Q3+Q4: stable LSD passes over the (rev, tid) bits only; the last pass decodes keys into k_mer_hits
 	hao_hitb_args hb;
 	hb.mz_off = c->d_ix_mz_off.p; hb.rid_lo = lo; hb.mz0 = B.mz0; hb.q_pos = B.q_pos.p; hb.q_cnt = B.q_cnt.p; hb.F = F; hb.hits = B.hits.p;
-	const bool use_radix = getenv("HAO_DBG_RADIX") != nullptr;      // digit-wise LSD passes + a group pass over the hits (kept for A/B measurements)
+	// Q3-Q5 in one sweep: distinct (tid, rev) bins per read -> ranked stable scatter + group lists
 	const uint32_t qcap = (uint32_t)std::min<uint64_t>(1ULL << F.qb, HAO_QTAB_CAP);
-	HIP_TRY(B.g_cnt.reserve(n + 2)); HIP_TRY(B.g_off.reserve(n + 2));
-	if (use_radix) {
-		HIP_TRY(B.keys2.reserve(A + 1));
-		if (A) {
-			uint64_t *src = B.keys.p, *dst = B.keys2.p; const int beg_bit = F.ob + F.qb, nb = 1 + F.tb;
-			// digits of equal width: 8 bits unless that costs an extra pass (then up to 11; the per-wave digit counters are LDS-resident)
-			int n_pass = (nb + 7) / 8; if ((nb + HAO_RDX_MAXBITS - 1) / HAO_RDX_MAXBITS < n_pass) n_pass = (nb + HAO_RDX_MAXBITS - 1) / HAO_RDX_MAXBITS;
-			const int db = (nb + n_pass - 1) / n_pass;
-			for (int ps_ = 0, sh = beg_bit; ps_ < n_pass; ++ps_, sh += db) {
-				const int bits = std::min(db, beg_bit + nb - sh); const size_t lds = (size_t)5 * (1u << bits) * 4;
-				if (ps_ == n_pass - 1) hipLaunchKernelGGL(seg_radix_pass_kernel<true>, dim3((unsigned)n), dim3(256), lds + 8 * qcap, c->stream, src, dst, B.seg.p, sh, bits, qcap, hb);
-				else hipLaunchKernelGGL(seg_radix_pass_kernel<false>, dim3((unsigned)n), dim3(256), lds, c->stream, src, dst, B.seg.p, sh, bits, 0u, hb);
-				HAO_CHECK_LAUNCH();
-				c->timer.mark(ps_ == n_pass - 1 ? "q_sort_final" : (ps_ == 0 ? "q_sort_p0" : "q_sort_p1"));
-				std::swap(src, dst);
-			}
-		}
-		hipLaunchKernelGGL(groups_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, B.hits.p, B.seg.p, n, (const uint64_t*)nullptr, B.g_cnt.p, (uint64_t*)nullptr, (uint32_t*)nullptr, 0);
-		HAO_CHECK_LAUNCH();
-	} else {
-		// Q3-Q5 in one sweep: distinct (tid, rev) bins per read -> ranked stable scatter + group lists
-		HIP_TRY(B.g_tmp.reserve(A + 1));
+	HIP_TRY(B.g_cnt.reserve(n + 2)); HIP_TRY(B.g_off.reserve(n + 2)); HIP_TRY(B.g_tmp.reserve(A + 1));
+	HIP_TRY(B.stats.reserve(3 * HAO_NCLS + 4)); HIP_TRY(hipMemsetAsync(B.stats.p, 0, (3 * HAO_NCLS + 4) * 8, c->stream));
+	unsigned long long *d_slow_cnt = B.stats.p, *d_cls_cnt = B.stats.p + HAO_NCLS + 4;   // [0..NCLS] slow groups per class + their hits
+	{
 		int CL = HAO_BIN_CAPLOG; if (const char *e_ = getenv("HAO_BIN_CAPLOG")) CL = atoi(e_);
 		const size_t lds = (size_t)36 * (1u << CL) + 8 * qcap;
 		if (lds > 64 * 1024) {     // beyond the default dynamic LDS limit: opt in (the CU has 160 KB)
@@ -129,42 +113,64 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		else if (CL == 11) hipLaunchKernelGGL((seg_bin_sort_kernel<11>), dim3((unsigned)n), dim3(256), lds, c->stream, B.keys.p, B.seg.p, n, qcap, hb, B.g_tmp.p, B.g_cnt.p);
 		else hipLaunchKernelGGL((seg_bin_sort_kernel<10>), dim3((unsigned)n), dim3(256), lds, c->stream, B.keys.p, B.seg.p, n, qcap, hb, B.g_tmp.p, B.g_cnt.p);
 		HAO_CHECK_LAUNCH();
-		c->timer.mark("q_sort_bins");
 	}
-	if (int rc = hao_excl_scan_u64(c, B.g_cnt.p, B.g_off.p, n + 1)) return rc;
-	HIP_TRY(hipMemcpyAsync(&B.n_groups, B.g_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
+	c->timer.mark("q_sort_bins");
+	HIP_TRY(B.cls_cc.reserve(HAO_NCLS * (n + 1) + 1)); HIP_TRY(B.cls_co.reserve(HAO_NCLS * (n + 1) + 1));
+	hipLaunchKernelGGL(groups_classify_kernel, dim3((unsigned)((n + 4) / 4)), dim3(256), 0, c->stream, B.g_tmp.p, B.seg.p, B.g_cnt.p, n, B.cls_cc.p);
+	HAO_CHECK_LAUNCH();
+	if (int rc = hao_excl_scan_u64(c, B.cls_cc.p, B.cls_co.p, HAO_NCLS * (n + 1))) return rc;
+	hipLaunchKernelGGL(groups_layout_kernel, dim3(1), dim3(64), 0, c->stream, B.cls_co.p, n, d_cls_cnt);
+	HAO_CHECK_LAUNCH();
+	unsigned long long lay[HAO_NCLS + 1];
+	HIP_TRY(hipMemcpyAsync(lay, d_cls_cnt, (HAO_NCLS + 1) * 8, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
-	const uint64_t G = B.n_groups;
-	HIP_TRY(B.g_start.reserve(G + 1)); HIP_TRY(B.g_read.reserve(G + 1));
-	if (use_radix) hipLaunchKernelGGL(groups_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, B.hits.p, B.seg.p, n, B.g_off.p, B.g_cnt.p, B.g_start.p, B.g_read.p, 1);
-	else hipLaunchKernelGGL(groups_compact_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, B.g_tmp.p, B.seg.p, B.g_off.p, n, B.g_start.p, B.g_read.p);
+	const uint64_t G = B.n_groups = lay[HAO_NCLS];
+	hao_cls_layout L; unsigned long long cls_cnt[HAO_NCLS];
+	for (int x = 0; x <= HAO_NCLS; ++x) L.base[x] = lay[x];
+	for (int x = 0; x < HAO_NCLS; ++x) cls_cnt[x] = L.base[x + 1] - L.base[x];
+	HIP_TRY(B.g_start.reserve(G + 1)); HIP_TRY(B.g_read.reserve(G + 1)); HIP_TRY(B.glist.reserve(G + 1)); HIP_TRY(B.slow.reserve(G + 1));
+	hipLaunchKernelGGL(groups_compact_kernel, dim3((unsigned)((n + 4) / 4)), dim3(256), 0, c->stream, B.g_tmp.p, B.seg.p, B.cls_co.p, n, glo, c->d_len_all.p, B.g_off.p, B.g_start.p, B.g_read.p, B.glist.p);
 	HAO_CHECK_LAUNCH();
 	c->timer.mark("q_groups");
-	// Q6 chain
-	HIP_TRY(B.f.reserve(A + 1)); HIP_TRY(B.ii.reserve(A + 1)); HIP_TRY(B.p.reserve(A + 1)); HIP_TRY(B.t.reserve(A + 1)); HIP_TRY(B.ohits.reserve(A + 1));
+	// Q6 chain: quick check per size class, biggest first; the groups it does not settle go to the DP kernel of their class on a side
+	// stream, so the long sequential DPs of big groups run under the quick checks of the smaller classes
+	HIP_TRY(B.ohits.reserve(A + 1));
 	HIP_TRY(B.fcs.reserve(A + 6 * G + 1)); HIP_TRY(B.rec.reserve(G * HAO_MCOPY_MAX + 1)); HIP_TRY(B.nch.reserve(G + 2)); HIP_TRY(B.nout.reserve(G + 2));
 	hao_chain_par par = hao_chain_params(c->opt.k, ps);
 	if (G) {
 		hao_chain_args ca;
 		ca.hits = B.hits.p; ca.g_start = B.g_start.p; ca.g_read = B.g_read.p; ca.g_off = B.g_off.p; ca.seg = B.seg.p; ca.n_groups = G; ca.rid_lo = glo; ca.len = c->d_len_all.p; ca.par = par;
-		HIP_TRY(B.stats.reserve(4)); HIP_TRY(hipMemsetAsync(B.stats.p, 0, 16, c->stream)); ca.stats = B.stats.p; ca.dbg_skip_generic = getenv("HAO_DBG_SKIP_GENERIC") ? 1 : 0; ca.dbg_seq = getenv("HAO_DBG_SEQ_CHAIN") ? 1 : (getenv("HAO_DBG_DP_NOTAIL") ? 2 : 0);
-		HIP_TRY(B.tm.reserve(A + 1)); HIP_TRY(B.slow_list.reserve(G + 1)); ca.tm = B.tm.p; ca.slow_list = B.slow_list.p;
-		ca.f = B.f.p; ca.ii = B.ii.p; ca.p = B.p.p; ca.t = B.t.p; ca.ohits = B.ohits.p; ca.fcs = B.fcs.p; ca.rec = B.rec.p; ca.nch = B.nch.p; ca.nout = B.nout.p;
-		hipLaunchKernelGGL(chain_group_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream, ca);
-		HAO_CHECK_LAUNCH();
-		c->timer.mark("q_chain");
-		{ unsigned long long st[2]; HIP_TRY(hipMemcpyAsync(st, B.stats.p, 16, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); B.n_generic = st[0]; B.n_generic_hits = st[1]; }
-		if (B.n_generic && !ca.dbg_skip_generic) {
-			// split by size: groups up to 512 hits keep hits + DP arrays in 14 KB of LDS (many waves per CU), larger ones use the 2048-hit variant
-			std::vector<uint64_t> sl(B.n_generic), small, large;        // entries: group id | size << 40
-			HIP_TRY(hipMemcpy(sl.data(), B.slow_list.p, B.n_generic * 8, hipMemcpyDeviceToHost));
-			for (uint64_t e : sl) ((e >> 40) <= 512 ? small : large).push_back(e);
-			if (getenv("HAO_DBG_DP_STATS")) { uint64_t mx = 0, h[8] = {0}; for (uint64_t e : sl) { uint64_t z = e >> 40; mx = std::max(mx, z); int b = 0; while (b < 7 && (64ULL << b) < z) ++b; ++h[b]; } fprintf(stderr, "[dp] groups %zu max %llu hist(<=64,128,..,4096,more):", sl.size(), (unsigned long long)mx); for (int b = 0; b < 8; ++b) fprintf(stderr, " %llu", (unsigned long long)h[b]); fprintf(stderr, "\n"); }
-			if (!small.empty()) HIP_TRY(hipMemcpy(B.slow_list.p, small.data(), small.size() * 8, hipMemcpyHostToDevice));
-			if (!large.empty()) HIP_TRY(hipMemcpy(B.slow_list.p + small.size(), large.data(), large.size() * 8, hipMemcpyHostToDevice));
-			if (!small.empty()) { hipLaunchKernelGGL((chain_dp_kernel<512, true>), dim3((unsigned)small.size()), dim3(64), 0, c->stream, ca, B.slow_list.p, (uint64_t)small.size()); HAO_CHECK_LAUNCH(); }
-			if (!large.empty()) { hipLaunchKernelGGL((chain_dp_kernel<HAO_DP_CAP, false>), dim3((unsigned)large.size()), dim3(64), 0, c->stream, ca, B.slow_list.p + small.size(), (uint64_t)large.size()); HAO_CHECK_LAUNCH(); }
+		ca.stats = d_slow_cnt; ca.dbg_stats = getenv("HAO_DBG_DP_STATS") ? 1 : 0; ca.dbg_skip_generic = getenv("HAO_DBG_SKIP_GENERIC") ? 1 : 0;
+		ca.dbg_seq = getenv("HAO_DBG_SEQ_CHAIN") ? 1 : (getenv("HAO_DBG_DP_NOTAIL") ? 2 : (getenv("HAO_DBG_DP_SEQTAIL") ? 3 : (getenv("HAO_DBG_DP_NOSPEC") ? 4 : 0)));
+		// per-hit DP scratch in global memory is only touched by groups beyond the LDS variants (and the sequential debug path)
+		const bool need_scratch = cls_cnt[HAO_NCLS - 1] > 0 || ca.dbg_seq == 1;
+		if (need_scratch) { HIP_TRY(B.f.reserve(A + 1)); HIP_TRY(B.ii.reserve(A + 1)); HIP_TRY(B.p.reserve(A + 1)); HIP_TRY(B.t.reserve(A + 1)); HIP_TRY(B.tm.reserve(A + 1)); }
+		ca.tm = B.tm.p; ca.f = B.f.p; ca.ii = B.ii.p; ca.p = B.p.p; ca.t = B.t.p; ca.ohits = B.ohits.p; ca.fcs = B.fcs.p; ca.rec = B.rec.p; ca.nch = B.nch.p; ca.nout = B.nout.p;
+		if (!B.side_ready) {
+			for (int x = 0; x < HAO_NCLS; ++x) { HIP_TRY(hipStreamCreateWithFlags(&B.side[x], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&B.ev_qc[x], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&B.ev_dp[x], hipEventDisableTiming)); }
+			B.side_ready = true;
 		}
+		int wpb = 1; if (const char *e_ = getenv("HAO_CHAIN_WPB")) wpb = std::max(1, std::min(4, atoi(e_)));
+		const bool serial = getenv("HAO_DBG_DP_SERIAL") != nullptr;      // DP kernels on the main stream (no overlap), for A/B timing
+		int spec_min = 1; if (const char *e_ = getenv("HAO_SPEC_MINCLS")) spec_min = atoi(e_);      // tiles of <= 64 hits gain nothing from speculation
+		const int dbg_seq0 = ca.dbg_seq;
+		for (int x = HAO_NCLS - 1; x >= 0; --x) {
+			const uint64_t nl = cls_cnt[x]; if (!nl) continue;
+			ca.dbg_seq = (dbg_seq0 == 0 && x < spec_min) ? 4 : dbg_seq0;
+			const hao_gent *lst = B.glist.p + L.base[x]; uint32_t *slow = B.slow.p + L.base[x];
+			hipLaunchKernelGGL(chain_group_kernel, dim3((unsigned)((nl + wpb - 1) / wpb)), dim3(64 * wpb), 0, c->stream, ca, lst, nl, slow, x);
+			HAO_CHECK_LAUNCH();
+			if (ca.dbg_skip_generic) continue;
+			hipStream_t ds = serial ? c->stream : B.side[x];
+			if (!serial) { HIP_TRY(hipEventRecord(B.ev_qc[x], c->stream)); HIP_TRY(hipStreamWaitEvent(ds, B.ev_qc[x], 0)); }
+			if (x <= 1) hipLaunchKernelGGL((chain_dp_kernel<128, true>), dim3((unsigned)std::min<uint64_t>(nl, 256 * 24)), dim3(64), 0, ds, ca, lst, slow, d_slow_cnt + x);
+			else if (x <= 3) hipLaunchKernelGGL((chain_dp_kernel<512, true>), dim3((unsigned)std::min<uint64_t>(nl, 256 * 8)), dim3(64), 0, ds, ca, lst, slow, d_slow_cnt + x);
+			else hipLaunchKernelGGL((chain_dp_kernel<HAO_DP_CAP, false>), dim3((unsigned)std::min<uint64_t>(nl, 256 * 3)), dim3(64), 0, ds, ca, lst, slow, d_slow_cnt + x);
+			HAO_CHECK_LAUNCH();
+			if (!serial) HIP_TRY(hipEventRecord(B.ev_dp[x], ds));
+		}
+		c->timer.mark("q_chain");
+		if (!serial && !ca.dbg_skip_generic) for (int x = 0; x < HAO_NCLS; ++x) if (cls_cnt[x]) HIP_TRY(hipStreamWaitEvent(c->stream, B.ev_dp[x], 0));
 	}
 	HIP_TRY(hipMemsetAsync(B.nch.p + G, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(B.nout.p + G, 0, 4, c->stream));
 	c->timer.mark("q_chain_dp");
@@ -178,7 +184,13 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	HIP_TRY(hipMemcpyAsync(&B.n_chains, B.ch_base.p + G, 8, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipMemcpyAsync(&B.n_cl, B.cl_base.p + G, 8, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipMemcpyAsync(&B.n_fc_raw, B.fc_base.p + G * HAO_MCOPY_MAX, 8, hipMemcpyDeviceToHost, c->stream));
+	unsigned long long slow_st[HAO_NCLS + 4];
+	HIP_TRY(hipMemcpyAsync(slow_st, d_slow_cnt, (HAO_NCLS + 4) * 8, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	B.n_generic = 0; for (int x = 0; x < HAO_NCLS; ++x) B.n_generic += slow_st[x];
+	B.n_generic_hits = slow_st[HAO_NCLS];
+	if (getenv("HAO_DBG_DP_STATS")) { fprintf(stderr, "[dp] slow groups by class:"); for (int x = 0; x < HAO_NCLS; ++x) fprintf(stderr, " %llu/%llu", slow_st[x], cls_cnt[x]);
+		fprintf(stderr, "  hits %llu  dp range %llu  spec-committed %llu  spec-failures %llu\n", slow_st[HAO_NCLS], slow_st[HAO_NCLS + 3], slow_st[HAO_NCLS + 1], slow_st[HAO_NCLS + 2]); }
 	const uint64_t NC = B.n_chains;
 	HIP_TRY(B.ol.reserve(NC + 1)); HIP_TRY(B.ol_fc_off.reserve(NC + 1)); HIP_TRY(B.cl.reserve(B.n_cl + 1)); HIP_TRY(B.fc_raw.reserve(B.n_fc_raw + 1)); HIP_TRY(B.perm.reserve(NC + 1));
 	if (G) {

@@ -16,6 +16,7 @@
 #pragma once
 #include "hao_common.cuh"
 #include "hao_host.hpp"
+#include "hao_query.cuh"
 
 #define HAO_MCOPY_MAX 3
 
@@ -96,6 +97,34 @@ __device__ uint32_t hao_fake_cigar(uint64_t *fc, const hao_chain_rec &o, const h
 	return n;
 }
 
+// gen_fake_cigar (apend_be = 1) by one wave: the k-th hit of the chain is hit(k); entries are a flagged compaction
+// (an entry wherever the diagonal changes).  Returns the entry count (uniform).
+template<class HitAt>
+__device__ __forceinline__ uint32_t hao_fake_cigar_wave(uint64_t *fcs, uint32_t x_pos_s, uint32_t y_pos_s, uint32_t x_pos_e, int64_t cL, HitAt hit)
+{
+	const int lane = hao_lane();
+	uint32_t cnt = 1; int64_t carry_dd = INT32_MAX; uint32_t last_site = 0; int64_t last_dd = 0;
+	if (lane == 0) fcs[0] = hao_fc_entry(x_pos_s, 0);
+	for (int64_t t0 = 0; t0 < cL; t0 += 64) {
+		const int64_t k = t0 + lane; const bool act = k < cL;
+		const hao_hit_t h = hit(act ? k : (int64_t)0);
+		int64_t dd = ((int64_t)h.offset - y_pos_s) - ((int64_t)h.self_offset - x_pos_s);
+		int64_t pd = __shfl_up(dd, 1); if (lane == 0) pd = carry_dd;
+		const bool flag = act && dd != pd;
+		unsigned long long bal = __ballot(flag);
+		if (flag) fcs[cnt + __popcll(bal & ((1ULL << lane) - 1))] = hao_fc_entry(h.self_offset, (int32_t)dd);
+		if (bal) { int src = 63 - __clzll((long long)bal); last_site = __shfl(h.self_offset, src); last_dd = __shfl(dd, src); }
+		cnt += __popcll(bal); carry_dd = __shfl(dd, 63);
+	}
+	if (last_site != x_pos_e) { if (lane == 0) fcs[cnt] = hao_fc_entry(x_pos_e, (int32_t)last_dd); ++cnt; }
+	return cnt;
+}
+
+__device__ __forceinline__ int64_t hao_readlane_i64(int64_t v, int l)
+{ return (int64_t)((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), l) << 32); }
+
+#define HAO_WAVE_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+
 __device__ void hao_heapsort_i64(int64_t *a, int64_t n)
 {
 	auto down = [&](int64_t i, int64_t m) { int64_t v = a[i]; for (;;) { int64_t c = 2 * i + 1; if (c >= m) break; if (c + 1 < m && a[c + 1] > a[c]) ++c; if (a[c] <= v) break; a[i] = a[c]; i = c; } a[i] = v; };
@@ -109,9 +138,9 @@ struct hao_chain_args {
 	hao_chain_par par;
 	int32_t *f, *ii, *p; int64_t *t;             // per-hit scratch
 	hao_hit_t *ohits; uint64_t *fcs; hao_chain_rec *rec; uint32_t *nch, *nout;
-	unsigned long long *stats;                   // [0] groups needing the DP kernel, [1] their hits
-	uint64_t *slow_list; int32_t *tm;            // groups deferred to chain_dp_kernel; per-hit mark scratch for oversize groups
-	int dbg_skip_generic, dbg_seq;
+	unsigned long long *stats;                   // [0 .. HAO_NCLS) groups of each size class needing the DP kernel, [HAO_NCLS] their hits
+	int32_t *tm;                                 // per-hit mark scratch for oversize groups
+	int dbg_skip_generic, dbg_seq, dbg_stats;
 };
 
 // Sequential tail shared by both paths (ONE lane): backtrack the best chain, multi-copy chains
@@ -268,25 +297,29 @@ __device__ __forceinline__ hao_hit_t hao_shfl_up_hit(const hao_hit_t &h)
 // scores with per-pair validity flags - and no second chain qualifies for multi-copy output; then the best
 // block IS the chain: hits are copied through, the fake cigar is a flagged compaction.  >99.9 % of groups on
 // repeat-free genomes.  Everything else runs hao_chain_generic on lane 0 (exact sequential algorithm).
-__global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A)
+__global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, const hao_gent *list, uint64_t n_list, uint32_t *slow, int cls)
 {
-	const uint64_t g = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-	if (g >= A.n_groups) return;
+	const uint64_t li = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	if (li >= n_list) return;
 	const int lane = hao_lane();
-	const uint32_t r = A.g_read[g]; const uint64_t gs = A.g_start[g], ge = (g + 1 < A.g_off[r + 1]) ? A.g_start[g + 1] : A.seg[r + 1];
-	const hao_hit_t *a = A.hits + gs; const int64_t a_n = (int64_t)(ge - gs);
-	const uint32_t xid = (uint32_t)(A.rid_lo + r), yid = HH_ID(a[0]);
-	if (yid == xid || a_n <= 0) { if (lane == 0) { A.nch[g] = 0; A.nout[g] = 0; } return; }
+	const hao_gent e = list[li];                                  // wave-uniform: scalar loads
+	const uint64_t g = e.g, gs = e.start; const int64_t a_n = e.n;
+	const hao_hit_t *a = A.hits + gs;
+	const uint32_t xid = (uint32_t)(A.rid_lo + e.r), yid = e.yid;
+	if (yid == xid || a_n <= 0) { if (lane == 0) { A.nch[g] = 0; A.nout[g] = 0; } return; }     // hits to the query itself are skipped (anchor.cpp:1931)
+	hao_hit_t hn = a[lane < a_n ? lane : 0];                     // tile 0; every later tile is requested one iteration ahead
+	const hao_hit_t first0 = hao_shfl_hit(hn, 0);
 	hao_cpar P; P.pen_gap = A.par.pen_gap; P.pen_skip = A.par.pen_skip; P.bw = A.par.bw; P.max_skip = A.par.max_skip; P.max_iter = A.par.max_iter; P.max_dis = A.par.max_dis;
-	P.xl = A.len[xid]; P.yl = A.len[yid];
-	const uint32_t strand0 = HH_STRAND(a[0]);
+	P.xl = e.xl; P.yl = e.yl;
+	const uint32_t strand0 = HH_STRAND(first0);
 	// ---- parallel quick check ----
-	int32_t carry_f = 0; hao_hit_t carry_h = a[0];
+	int32_t carry_f = 0; hao_hit_t carry_h = first0;
 	bool fail0 = false, fail1 = false; int32_t maxf0 = INT32_MIN, maxf1 = INT32_MIN, flast0 = 0, flast1 = 0; int64_t ddt0 = 0, ddt1 = 0, k1 = 0;
-	hao_hit_t last0 = a[0], last1 = a[0];
+	hao_hit_t last0 = first0, last1 = first0;
 	for (int64_t t0 = 0; t0 < a_n; t0 += 64) {
 		const int64_t idx = t0 + lane; const bool act = idx < a_n;
-		hao_hit_t h = act ? a[idx] : carry_h;
+		hao_hit_t h = act ? hn : carry_h;
+		if (idx + 64 < a_n) hn = a[idx + 64];
 		hao_hit_t ph = hao_shfl_up_hit(h); if (lane == 0) ph = carry_h;
 		const bool st = act && (idx == 0 || HH_STRAND(h) != HH_STRAND(ph));
 		const int b = act && HH_STRAND(h) != strand0;
@@ -302,7 +335,9 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A)
 		if (__ballot(brk && b == 1)) fail1 = true;
 		if (act) { if (b == 0) { maxf0 = max(maxf0, f); ddt0 += dd; } else { maxf1 = max(maxf1, f); ddt1 += dd; } }
 		k1 += __popcll(__ballot(act && b == 0));
-		const bool isend = act && (idx == a_n - 1 || HH_STRAND(a[idx + 1]) != HH_STRAND(h));
+		// strand of the next hit: next lane, or lane 0 of the tile already on its way
+		uint32_t nw0 = __shfl_down(h.w0, 1); if (lane == 63) nw0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hn.w0);
+		const bool isend = act && (idx == a_n - 1 || (nw0 >> 31) != HH_STRAND(h));
 		unsigned long long m0 = __ballot(isend && b == 0), m1 = __ballot(isend && b == 1);
 		if (m0) { int src = __ffsll((long long)m0) - 1; flast0 = __shfl(f, src); last0 = hao_shfl_hit(h, src); }
 		if (m1) { int src = __ffsll((long long)m1) - 1; flast1 = __shfl(f, src); last1 = hao_shfl_hit(h, src); }
@@ -314,7 +349,7 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A)
 		ddt0 += __shfl_xor(ddt0, d); ddt1 += __shfl_xor(ddt1, d);
 	}
 	const bool two = k1 < a_n;
-	const hao_hit_t first0 = a[0], first1 = two ? a[k1] : a[0];
+	const hao_hit_t first1 = two ? a[k1] : first0;
 	bool acc0 = !fail0 && flast0 == maxf0 && !(k1 >= 2 && ddt0 > 16 && ddt0 > hao_band(last0, first0, P));
 	bool acc1 = two && !fail1 && flast1 == maxf1 && !(a_n - k1 >= 2 && ddt1 > 16 && ddt1 > hao_band(last1, first1, P));
 	bool fast = acc0 && (!two || acc1);
@@ -330,32 +365,110 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A)
 		if ((int64_t)(best ? maxf0 : maxf1) >= min_sc) fast = false;         // a second chain may qualify: exact sequential path
 	}
 	if (!fast) {
-		if (lane == 0) { unsigned long long si_ = atomicAdd(A.stats, 1ULL); atomicAdd(A.stats + 1, (unsigned long long)a_n); A.slow_list[si_] = g | (uint64_t)(a_n > 0xffffff ? 0xffffff : a_n) << 40; A.nch[g] = 0; A.nout[g] = 0; }
+		if (lane == 0) { unsigned long long si_ = atomicAdd(A.stats + cls, 1ULL); atomicAdd(A.stats + HAO_NCLS, (unsigned long long)a_n); slow[si_] = (uint32_t)li; A.nch[g] = 0; A.nout[g] = 0; }
 		return;
 	}
 	// ---- single chain = the whole best block ----
 	uint64_t *fcs = A.fcs + gs + 6 * g; hao_chain_rec rc;
 	hao_region(rc, P.xl, P.yl, msc, best ? first1 : first0, best ? last1 : last0);
-	uint32_t cnt = 1; int64_t carry_dd = INT32_MAX; uint32_t last_site = 0; int64_t last_dd = 0;
-	if (lane == 0) fcs[0] = hao_fc_entry(rc.x_pos_s, 0);
-	for (int64_t t0 = 0; t0 < cL; t0 += 64) {
-		const int64_t k = t0 + lane; const bool act = k < cL;
-		hao_hit_t h = act ? a[bl + k] : a[bl];
-		int64_t dd = ((int64_t)h.offset - rc.y_pos_s) - ((int64_t)h.self_offset - rc.x_pos_s);
-		int64_t pd = __shfl_up(dd, 1); if (lane == 0) pd = carry_dd;
-		const bool flag = act && dd != pd;
-		unsigned long long bal = __ballot(flag);
-		if (flag) fcs[cnt + __popcll(bal & ((1ULL << lane) - 1))] = hao_fc_entry(h.self_offset, (int32_t)dd);
-		if (bal) { int src = 63 - __clzll((long long)bal); last_site = __shfl(h.self_offset, src); last_dd = __shfl(dd, src); }
-		cnt += __popcll(bal); carry_dd = __shfl(dd, 63);
-	}
-	if (last_site != rc.x_pos_e) { if (lane == 0) fcs[cnt] = hao_fc_entry(rc.x_pos_e, (int32_t)last_dd); ++cnt; }
+	const uint32_t cnt = hao_fake_cigar_wave(fcs, rc.x_pos_s, rc.y_pos_s, rc.x_pos_e, cL, [&](int64_t k) { return a[bl + k]; });
 	if (lane == 0) {
 		rc.hit_rel = 0; rc.n_hits = (uint32_t)cL; rc.src_rel = (uint32_t)bl; rc.in_place = 1; rc.fc_rel = 0; rc.fc_len = cnt;
 		A.rec[g * HAO_MCOPY_MAX] = rc; A.nch[g] = 1; A.nout[g] = (uint32_t)cL;
 	}
 }
 
+
+// Wave-cooperative hao_chain_tail for chain_dp_kernel: the order-dependent walks (backtrack, chain extraction) stay on lane 0
+// over (normally LDS-resident) arrays; candidate collection, the sort of the (distinct) candidate keys, hit copies and fake
+// cigars run on all lanes.  cn[8] / l_rec[3]: LDS scratch of the wave.
+__device__ __forceinline__ void hao_chain_tail_wave(const hao_chain_args &A, const uint64_t g, const uint64_t gs, const hao_hit_t *a, const int64_t a_n, const hao_cpar &P,
+		int32_t *f, int32_t *p, int64_t *t, int32_t *ii, const int64_t t_cap, uint32_t *cn, hao_chain_rec *l_rec, int64_t msc, int64_t msc_i, int64_t plus)
+{
+	const int lane = hao_lane();
+	hao_hit_t *des = A.ohits + gs; uint64_t *fcs = A.fcs + gs + 6 * g; hao_chain_rec *rec = A.rec + g * HAO_MCOPY_MAX;
+	int64_t cL = 0;
+	if (lane == 0) for (int64_t i = msc_i; i >= 0; i = p[i]) { ii[i] = 1; t[cL++] = i; }
+	cL = __shfl(cL, 0);
+	HAO_WAVE_FENCE();
+	if (A.par.mcopy_num > 1 && cL >= A.par.mcopy_khit_cut) {      // multi-copy chains (Hash_Table.cpp:2178-2270)
+		msc -= plus; const int64_t min_sc = (int64_t)((double)msc * A.par.mcopy_rate);
+		if (lane == 0) ii[msc_i] = 0;
+		HAO_WAVE_FENCE();
+		int64_t ch_n = 0;
+		for (int64_t b = 0; b < a_n; b += 64) {     // candidates: chain ends off the best chain scoring >= min_sc, in index order
+			const int64_t i = b + lane; int32_t fv = 0; bool cand = false;
+			if (i < a_n) { fv = f[i] - (int32_t)plus; f[i] = fv; cand = !ii[i] && fv >= min_sc; }
+			const unsigned long long bal = __ballot(cand);
+			if (cand) t[ch_n + __popcll(bal & ((1ULL << lane) - 1))] = (int64_t)((uint64_t)fv << 32) + (i << 1);
+			ch_n += __popcll(bal);
+		}
+		HAO_WAVE_FENCE();
+		for (int64_t i = ch_n + lane; i < a_n; i += 64) t[i] = 0;
+		HAO_WAVE_FENCE();
+		if (ch_n > 1) {
+			// ascending sort of t[0, ch_n): keys are distinct (they carry the hit index), so any correct sort reproduces the reference's order
+			if (ch_n <= 64) {
+				const int64_t key = lane < ch_n ? t[lane] : INT64_MAX; int rank = 0;
+				for (int l = 0; l < (int)ch_n; ++l) rank += hao_readlane_i64(key, l) < key;
+				HAO_WAVE_FENCE();
+				if (lane < ch_n) t[rank] = key;
+			} else {
+				int64_t P2 = 128; while (P2 < ch_n) P2 <<= 1;
+				if (P2 <= t_cap) {
+					for (int64_t i = ch_n + lane; i < P2; i += 64) t[i] = INT64_MAX;
+					HAO_WAVE_FENCE();
+					for (int64_t k = 2; k <= P2; k <<= 1)
+						for (int64_t j = k >> 1; j > 0; j >>= 1) {
+							for (int64_t i = lane; i < P2; i += 64) {
+								const int64_t x = i ^ j;
+								if (x > i) { const int64_t u = t[i], v = t[x]; if ((u > v) == ((i & k) == 0)) { t[i] = v; t[x] = u; } }
+							}
+							HAO_WAVE_FENCE();
+						}
+					for (int64_t i = ch_n + lane; i < P2; i += 64) t[i] = 0;
+				} else if (lane == 0) hao_heapsort_i64(t, ch_n);
+			}
+			HAO_WAVE_FENCE();
+			if (lane == 0) {     // walk the candidates from the best score down; a chain stops where it meets an already used hit
+				int64_t n_v = 0, n_v0, k, sc, i; uint32_t nu = 0;
+				for (k = ch_n - 1; k >= 0 && nu < (uint32_t)A.par.mcopy_num; --k) {
+					n_v0 = n_v;
+					for (i = (int64_t)((uint32_t)t[k] >> 1); i >= 0 && (t[i] & 1) == 0; ) { ii[n_v++] = (int32_t)i; t[i] |= 1; i = p[i]; }
+					if (n_v0 == n_v) continue;
+					sc = i < 0 ? (t[k] >> 32) : ((t[k] >> 32) - f[i]);
+					if (sc >= min_sc && (!nu || n_v - n_v0 > 1)) {
+						hao_region(l_rec[nu], P.xl, P.yl, sc + plus, a[ii[n_v - 1]], a[ii[n_v0]]);
+						cn[nu] = (uint32_t)n_v0; cn[3 + nu] = (uint32_t)(n_v - n_v0); ++nu;
+					} else n_v = n_v0;
+				}
+				cn[6] = nu;
+			}
+			HAO_WAVE_FENCE();
+			const uint32_t n_u = cn[6]; uint32_t o = 0, fcn = 0;
+			for (uint32_t k = 0; k < n_u; ++k) {
+				const int64_t n_v0 = cn[k], ni = cn[3 + k]; hao_chain_rec rc = l_rec[k];
+				for (int64_t j = lane; j < ni; j += 64) des[o + j] = a[ii[n_v0 + (ni - j - 1)]];
+				rc.hit_rel = o; rc.n_hits = (uint32_t)ni; rc.src_rel = o; rc.in_place = 0; rc.fc_rel = fcn;
+				rc.fc_len = hao_fake_cigar_wave(fcs + fcn, rc.x_pos_s, rc.y_pos_s, rc.x_pos_e, ni, [&](int64_t q) { return a[ii[n_v0 + (ni - q - 1)]]; });
+				fcn += rc.fc_len; o += (uint32_t)ni;
+				if (lane == 0) rec[k] = rc;
+			}
+			if (lane == 0) { A.nch[g] = n_u; A.nout[g] = o; }
+			return;
+		}
+		msc += plus; cL = 0;
+		if (lane == 0) for (int64_t i = msc_i; i >= 0; i = p[i]) t[cL++] = i;
+		cL = __shfl(cL, 0);
+		HAO_WAVE_FENCE();
+	}
+	hao_chain_rec rc;
+	hao_region(rc, P.xl, P.yl, msc, a[t[cL - 1]], a[t[0]]);
+	for (int64_t i = lane; i < cL; i += 64) des[i] = a[t[cL - i - 1]];
+	rc.hit_rel = 0; rc.n_hits = (uint32_t)cL; rc.src_rel = 0; rc.in_place = 0; rc.fc_rel = 0;
+	rc.fc_len = hao_fake_cigar_wave(fcs, rc.x_pos_s, rc.y_pos_s, rc.x_pos_e, cL, [&](int64_t q) { return a[t[cL - q - 1]]; });
+	if (lane == 0) { rec[0] = rc; A.nch[g] = 1; A.nout[g] = (uint32_t)cL; }
+}
 
 // ---------------------------------------------------------------------------------------
 // Groups the quick check does not settle: one wave per group.
@@ -370,24 +483,20 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A)
 // ---------------------------------------------------------------------------------------
 #define HAO_DP_CAP 2048
 
-template<int CAP, bool STAGE>
-__global__ __launch_bounds__(64) void chain_dp_kernel(hao_chain_args A, const uint64_t *list, uint64_t n_slow)
+// INLDS is a template parameter (not a run-time select) so that every access to f/p/tm/ii/t and the staged hits is a DS
+// instruction instead of a flat one.
+template<int CAP, bool STAGE, bool INLDS>
+__device__ __forceinline__ void hao_dp_body(const hao_chain_args &A, const hao_gent &e, const hao_hit_t *ag,
+		int32_t *l_f, int32_t *l_p, int32_t *l_tm, int32_t *l_ii, int64_t *l_t, hao_hit_t *l_a, uint32_t *l_cn, hao_chain_rec *l_rec)
 {
-	__shared__ int32_t l_f[CAP], l_p[CAP], l_tm[CAP]; __shared__ hao_hit_t l_a[STAGE ? CAP : 1];
-	if (blockIdx.x >= n_slow) return;
-	const uint64_t g = list[blockIdx.x] & ((1ULL << 40) - 1);
 	const int lane = hao_lane();
-	if (A.dbg_seq == 1) { if (lane == 0) hao_chain_generic(A, g); return; }
-	const uint32_t r = A.g_read[g]; const uint64_t gs = A.g_start[g], ge = (g + 1 < A.g_off[r + 1]) ? A.g_start[g + 1] : A.seg[r + 1];
-	const hao_hit_t *ag = A.hits + gs; const int64_t a_n = (int64_t)(ge - gs);
-	const bool in_lds = a_n <= CAP;
-	if (STAGE && in_lds) { for (int64_t i = lane; i < a_n; i += 64) l_a[i] = ag[i]; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-	const hao_hit_t *a = (STAGE && in_lds) ? l_a : ag;          // the DP re-reads predecessors many times: small groups keep their hits in LDS
-	const uint32_t xid = (uint32_t)(A.rid_lo + r), yid = HH_ID(a[0]);
+	const uint64_t g = e.g, gs = e.start; const int64_t a_n = e.n;
+	if (STAGE && INLDS) { for (int64_t i = lane; i < a_n; i += 64) l_a[i] = ag[i]; HAO_WAVE_FENCE(); }
+	const hao_hit_t *a = (STAGE && INLDS) ? l_a : ag;          // the DP re-reads predecessors many times: small groups keep their hits in LDS
 	hao_cpar P; P.pen_gap = A.par.pen_gap; P.pen_skip = A.par.pen_skip; P.bw = A.par.bw; P.max_skip = A.par.max_skip; P.max_iter = A.par.max_iter; P.max_dis = A.par.max_dis;
-	P.xl = A.len[xid]; P.yl = A.len[yid];
-	int32_t *f = in_lds ? l_f : A.f + gs, *p = in_lds ? l_p : A.p + gs, *tm = in_lds ? l_tm : A.tm + gs;
-	int32_t *ii = A.ii + gs; int64_t *t = A.t + gs;
+	P.xl = e.xl; P.yl = e.yl;
+	int32_t *f = INLDS ? l_f : A.f + gs, *p = INLDS ? l_p : A.p + gs, *tm = INLDS ? l_tm : A.tm + gs;
+	int32_t *ii = INLDS ? l_ii : A.ii + gs; int64_t *t = INLDS ? l_t : A.t + gs;
 	const uint32_t strand0 = HH_STRAND(a[0]);
 	// ---- parallel quick check, storing f/p ----
 	int32_t carry_f = 0; hao_hit_t carry_h = a[0];
@@ -439,10 +548,85 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(hao_chain_args A, const ui
 		if (ei > a_n) si = a_n; else ei = k1;
 	}
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	uint32_t n_spec_ok_out = 0, n_spec_fail_out = 0;
 	// ---- DP over [si, ei) ----
+	// The chain DP is sequential in i (about one LDS/FP64-latency-bound round per hit).  Most hits of a group that failed the quick
+	// check still simply extend the chain through their predecessor, so the loop first SPECULATES on a tile of 64 hits: guess
+	// f[i] = f[i-1] + score(i, i-1), p[i] = i-1, then let lane k replay the complete predecessor scan of hit i+k (scores, running
+	// maximum, marks via p[], n_skip / max_skip break) against the guessed f/p of the tile.  If the scan of every hit before k
+	// reproduces its guess, the state hit k sees is exact, so the longest prefix of lanes that reproduce their guess is exact
+	// by induction and is committed at once; the first hit that does not is handled by the sequential round below.
 	{
-		int64_t i, st, max_ii = -1;
+		int64_t i, st, max_ii = -1; int spec_wait = 0, spec_fail = 0; uint32_t n_spec_ok = 0, n_spec_fail = 0;
+		const bool spec_on = A.dbg_seq != 4;
 		for (i = st = si; i < ei; ++i) {
+			if (spec_wait > 0) --spec_wait;
+			else if (spec_on) {
+				int64_t st2 = st; if (i - st2 > P.max_iter) st2 = i - P.max_iter;
+				const hao_hit_t h0 = a[i]; const uint32_t str_i = HH_STRAND(h0);
+				while (str_i != HH_STRAND(a[st2])) ++st2;
+				// the "best recent predecessor" bookkeeping (max_ii) is a no-op along a rising chain: require that state at the tile's first hit
+				if (i == st2 || max_ii == i - 1) {
+					const int64_t ti = i + lane; const bool inb = ti < ei;
+					const hao_hit_t hi = inb ? a[ti] : h0;
+					bool cand = inb && HH_STRAND(hi) == str_i && ti - st2 <= P.max_iter;
+					int32_t s1 = 0;
+					if (cand && ti > st2) {
+						const hao_hit_t hp = a[ti - 1];
+						s1 = hao_pair_score(hi, hp, P, nullptr);
+						cand = s1 != INT32_MIN && s1 > 0 && (int64_t)hi.self_offset <= P.max_dis + (int64_t)hp.self_offset;   // rising, within max_dis: max_ii follows the chain
+					}
+					const unsigned long long badm = __ballot(!cand);
+					const int nc = badm ? __ffsll((long long)badm) - 1 : 64;       // lanes [0, nc) carry a guess
+					int64_t fg = ti > st2 ? (int64_t)s1 : (int64_t)HH_SPAN(hi);
+					if (lane == 0 && i > st2) fg += f[i - 1];
+					if (lane >= nc) fg = 0;
+#pragma unroll
+					for (int d = 1; d < 64; d <<= 1) { const int64_t y = __shfl_up(fg, d); if (lane >= d) fg += y; }
+					const int32_t fg32 = (int32_t)fg; const int64_t pg = ti > st2 ? ti - 1 : -1;
+					if (lane < nc) { f[ti] = fg32; p[ti] = (int32_t)pg; }
+					HAO_WAVE_FENCE();
+					// replay of the predecessor scan of hit ti (Hash_Table.cpp:2131-2150) by lane k; marks of "t[p[j]] = i" kept as a bit per distance
+					int64_t mf = HH_SPAN(hi), mj = -1; int nsk = 0; unsigned long long marks = 0; bool done = lane >= nc;
+					for (int d = 1; d <= 64; ++d) {
+						const int64_t j = ti - d; const bool in = !done && j >= st2;
+						if (!__ballot(in)) break;
+						if (in) {
+							const hao_hit_t hj = a[j]; const int32_t sj = hao_pair_score(hi, hj, P, nullptr);
+							if (sj != INT32_MIN) {
+								const int64_t sc = (int64_t)sj + f[j]; const int32_t pj = p[j];
+								if (sc > mf) { mf = sc; mj = j; if (nsk > 0) --nsk; }
+								else if (marks >> (d - 1) & 1) { if (++nsk > (int)P.max_skip) done = true; }
+								if (pj >= 0) { const int64_t bb = ti - 1 - pj; if (bb < 64) marks |= 1ULL << bb; }
+							}
+						}
+					}
+					const bool ok = lane < nc && (done || ti - 65 < st2) && mf == (int64_t)fg32 && mj == pg;     // not ok: scan unfinished after 64 predecessors, or a different result
+					const unsigned long long nokm = __ballot(!ok);
+					const int m = nokm ? __ffsll((long long)nokm) - 1 : 64;
+					if (m > 0) {
+						// commit hits [i, i+m): running best chain end (first maximum, then smallest extension length, then first) and the minimum score
+						int32_t fmx = lane < m ? fg32 : INT32_MIN, fmn = lane < m ? fg32 : INT32_MAX;
+#pragma unroll
+						for (int d = 32; d >= 1; d >>= 1) { fmx = max(fmx, __shfl_xor(fmx, d)); fmn = min(fmn, __shfl_xor(fmn, d)); }
+						if ((int64_t)fmx >= msc) {
+							const int64_t ovl = hao_ext_len(hi.self_offset, hi.self_offset, P.xl, hi.offset, hi.offset, P.yl);
+							int64_t key = (lane < m && fg32 == fmx) ? ovl * 64 + lane : INT64_MAX;
+#pragma unroll
+							for (int d = 32; d >= 1; d >>= 1) { const int64_t y = __shfl_xor(key, d); if (y < key) key = y; }
+							if ((int64_t)fmx > msc || (key >> 6) < movl) { msc = fmx; msc_i = i + (key & 63); movl = key >> 6; }
+						}
+						if ((int64_t)fmn < plus) plus = fmn;
+						max_ii = i + m - 1; st = st2; i += m - 1;
+						if (m >= 8) spec_fail = 0;
+						if (m < 64) spec_wait = 1;          // hit i+m did not reproduce its guess: it takes the sequential round
+						n_spec_ok += m;
+						continue;
+					}
+					if (spec_fail < 5) ++spec_fail;
+					spec_wait = 1 << spec_fail; ++n_spec_fail;
+				}
+			}
 			const hao_hit_t hi = a[i];
 			int64_t max_f = HH_SPAN(hi), n_skip = 0, max_j = -1, end_j;
 			if (i - st > P.max_iter) st = i - P.max_iter;
@@ -456,29 +640,33 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(hao_chain_args A, const ui
 				if (valid) { sc = (int64_t)s + f[j]; pj = p[j]; if (pj >= 0) tm[pj] = (int32_t)i; }
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 				const bool mark = valid && tm[j] == (int32_t)i;
-				// exclusive prefix maximum of sc over the lanes before me, seeded with max_f
-				int64_t pm = sc;
-#pragma unroll
-				for (int d = 1; d < 64; d <<= 1) { int64_t y = __shfl_up(pm, d); if (lane >= d && y > pm) pm = y; }
-				pm = __shfl_up(pm, 1); if (lane == 0) pm = INT64_MIN;
-				if (pm < max_f) pm = max_f;
-				const bool improve = valid && sc > pm;
-				// n_skip bookkeeping of the sequential scan (improve: n = max(n-1, 0); marked non-improving: ++n, stop when n > max_skip)
-				// is a reflected walk: n_l = S_l - min(0, min_{l' <= l} S_l') with S = n_in + prefix sum of the steps
-				const bool inc = valid && !improve && mark;
-				int32_t S = improve ? -1 : (inc ? 1 : 0);
-#pragma unroll
-				for (int d = 1; d < 64; d <<= 1) { int32_t y = __shfl_up(S, d); if (lane >= d) S += y; }
-				S += (int32_t)n_skip;
-				int32_t mn = S < 0 ? S : 0;
-#pragma unroll
-				for (int d = 1; d < 64; d <<= 1) { int32_t y = __shfl_up(mn, d); if (lane >= d && y < mn) mn = y; }
-				const int32_t nl = S - mn;
-				unsigned long long imask = __ballot(improve), bmask = __ballot(inc && nl > (int32_t)P.max_skip);
-				int brk_lane = bmask ? __ffsll((long long)bmask) - 1 : -1;
-				n_skip = __shfl(nl, brk_lane >= 0 ? brk_lane : 63);
+				// candidates that improve on everything scanned before them = running records of sc, found from the lowest lane up
+				const unsigned long long vm = __ballot(valid);
+				unsigned long long imask = 0, rem = vm; int64_t cur = max_f;
+				while (rem) {
+					const unsigned long long gm = __ballot(valid && sc > cur) & rem;
+					if (!gm) break;
+					const int l = __ffsll((long long)gm) - 1;
+					imask |= 1ULL << l; cur = hao_readlane_i64(sc, l); rem = l == 63 ? 0 : (vm & (~0ULL << (l + 1)));
+				}
+				// n_skip bookkeeping of the sequential scan (improve: n = max(n-1, 0); marked non-improving: ++n, stop when n > max_skip), on scalar masks
+				const unsigned long long cmask = __ballot(mark) & ~imask;
+				int brk_lane = -1; int64_t nsk = n_skip;
+				if (cmask == 0 || imask == 0 || (63 - __clzll((long long)imask)) < (__ffsll((long long)cmask) - 1)) {   // all improvements precede all marks (the usual case)
+					nsk -= __popcll(imask); if (nsk < 0) nsk = 0;
+					const int64_t need = P.max_skip + 1 - nsk;
+					if ((int64_t)__popcll(cmask) >= need) brk_lane = __ffsll((long long)__ballot((cmask >> lane & 1) && (int64_t)__popcll(cmask & ((1ULL << lane) - 1)) == need - 1)) - 1;   // the need-th mark
+					else nsk += __popcll(cmask);
+				} else {
+					unsigned long long ev = imask | cmask;
+					while (ev) {
+						const int l = __ffsll((long long)ev) - 1; ev &= ev - 1;
+						if (imask >> l & 1) { if (nsk > 0) --nsk; } else if (++nsk > P.max_skip) { brk_lane = l; break; }
+					}
+				}
+				n_skip = nsk;
 				if (brk_lane >= 0) imask &= (1ULL << brk_lane) - 1;
-				if (imask) { int src = 63 - __clzll((long long)imask); max_f = __shfl(sc, src); max_j = jb - src; }
+				if (imask) { const int src = 63 - __clzll((long long)imask); max_f = hao_readlane_i64(sc, src); max_j = jb - src; }
 				if (brk_lane >= 0) { end_j = jb - brk_lane; break; }
 			}
 			if (max_ii < 0 || (int64_t)hi.self_offset > (int64_t)a[max_ii].self_offset + P.max_dis || HH_STRAND(hi) != HH_STRAND(a[max_ii])) {
@@ -499,9 +687,28 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(hao_chain_args A, const ui
 			}
 			if ((int32_t)max_f < plus) plus = (int32_t)max_f;
 		}
+		n_spec_ok_out = n_spec_ok; n_spec_fail_out = n_spec_fail;
 	}
+	if (A.dbg_stats && lane == 0) { atomicAdd(A.stats + HAO_NCLS + 1, (unsigned long long)n_spec_ok_out); atomicAdd(A.stats + HAO_NCLS + 2, (unsigned long long)n_spec_fail_out); atomicAdd(A.stats + HAO_NCLS + 3, (unsigned long long)(ei - si)); }
 	if (A.dbg_seq == 2) return;
-	if (lane == 0) hao_chain_tail(A, g, a, a_n, P, f, p, t, ii, msc, msc_i, plus);
+	if (A.dbg_seq == 3) { if (lane == 0) hao_chain_tail(A, g, a, a_n, P, f, p, t, ii, msc, msc_i, plus); return; }
+	hao_chain_tail_wave(A, g, gs, a, a_n, P, f, p, t, ii, INLDS ? (int64_t)CAP : (int64_t)0, l_cn, l_rec, msc, msc_i, plus);
+}
+
+template<int CAP, bool STAGE>
+__global__ __launch_bounds__(64) void chain_dp_kernel(hao_chain_args A, const hao_gent *list, const uint32_t *slow, const unsigned long long *slow_cnt)
+{
+	__shared__ int32_t l_f[CAP], l_p[CAP], l_tm[CAP], l_ii[CAP]; __shared__ int64_t l_t[CAP]; __shared__ hao_hit_t l_a[STAGE ? CAP : 1];
+	__shared__ uint32_t l_cn[8]; __shared__ hao_chain_rec l_rec[HAO_MCOPY_MAX];
+	const uint64_t n_slow = *slow_cnt;
+	for (uint64_t b = blockIdx.x; b < n_slow; b += gridDim.x) {      // persistent waves: the launch does not know how many groups failed the quick check
+		const hao_gent e = list[slow[b]];
+		if (A.dbg_seq == 1) { if (hao_lane() == 0) hao_chain_generic(A, e.g); continue; }
+		const hao_hit_t *ag = A.hits + e.start;
+		if ((int64_t)e.n <= CAP) hao_dp_body<CAP, STAGE, true>(A, e, ag, l_f, l_p, l_tm, l_ii, l_t, l_a, l_cn, l_rec);
+		else hao_dp_body<CAP, STAGE, false>(A, e, ag, l_f, l_p, l_tm, l_ii, l_t, l_a, l_cn, l_rec);
+		HAO_WAVE_FENCE();
+	}
 }
 
 // ---------------------------------------------------------------------------------------
@@ -871,24 +1078,16 @@ __device__ int64_t hao_select_weak(const hao_sel_args &A, const hao_sel_ctx &S, 
 	return ll;
 }
 
-// WPB waves per workgroup, each wave one read; CAP = chains whose keys fit the wave's LDS slice.  Two launches cover a batch:
-// <4, 512> takes the reads with up to 512 chains, <1, 4096> the rest (reads beyond 4096 chains keep their keys in global scratch).
-template<int WPB, int CAP>
-__global__ __launch_bounds__(WPB * 64) void chain_select_kernel(hao_sel_args A, int64_t n_lo, int64_t n_hi)
+// INLDS as a template parameter: the sort / prune / filter code then addresses its keys with DS instructions (a run-time
+// "LDS or global" pointer select would make every access a flat one).
+template<int CAP, bool INLDS>
+__device__ __forceinline__ void hao_select_body(const hao_sel_args &A, const uint64_t r, int64_t n, const uint64_t o0, const uint64_t cl0, const uint64_t cn,
+		uint64_t *l_xs, int32_t *l_sc, uint32_t *l_al, uint32_t *l_pm, uint32_t *l_pm2, uint32_t *l_lp, uint32_t *l_rp, int32_t *l_stack)
 {
-	__shared__ uint64_t l_xs[WPB][CAP]; __shared__ int32_t l_sc[WPB][CAP]; __shared__ uint32_t l_al[WPB][CAP], l_pm[WPB][CAP], l_pm2[WPB][CAP], l_lp[WPB][CAP], l_rp[WPB][CAP]; __shared__ int32_t l_stack[WPB][3 * 72];
-	const int wv = threadIdx.x >> 6, lane = hao_lane();
-	const uint64_t r = (uint64_t)blockIdx.x * WPB + wv;
-	if (r > A.n_sel) return;
-	if (r == A.n_sel) { if (lane == 0 && n_lo == 0) { A.n_final[r] = 0; A.fc_final[r] = 0; } return; }
-	const uint64_t g0 = A.g_off[r], g1 = A.g_off[r + 1], o0 = A.ch_base[g0];
-	int64_t n = (int64_t)(A.ch_base[g1] - o0);
-	if (n < n_lo || n >= n_hi) return;                          // this read belongs to the other launch
-	const uint64_t cl0 = A.cl_base[g0], cn = A.cl_base[g1] - cl0;
+	const int lane = hao_lane();
 	const hao_ovlp_t *rec = A.ol + o0;
-	const bool in_lds = n <= CAP;
-	uint64_t *xs = in_lds ? l_xs[wv] : A.key_xs + o0; int32_t *sc = in_lds ? l_sc[wv] : A.key_sc + o0;
-	uint32_t *al = in_lds ? l_al[wv] : A.key_al + o0, *pm = in_lds ? l_pm[wv] : A.perm + o0;
+	uint64_t *xs = INLDS ? l_xs : A.key_xs + o0; int32_t *sc = INLDS ? l_sc : A.key_sc + o0;
+	uint32_t *al = INLDS ? l_al : A.key_al + o0, *pm = INLDS ? l_pm : A.perm + o0;
 	int lch = 0;
 	for (int64_t i = lane; i < n; i += 64) {
 		const hao_ovlp_t q = rec[i];
@@ -897,8 +1096,8 @@ __global__ __launch_bounds__(WPB * 64) void chain_select_kernel(hao_sel_args A, 
 	}
 	lch = __any(lch);
 	__threadfence_block();
-	hao_sel_ctx S; S.xs = xs; S.sc = sc; S.al = al; S.pm = pm; S.stack = l_stack[wv];
-	S.pm2 = in_lds ? l_pm2[wv] : A.key_tmp + 5 * o0; S.lpos = in_lds ? l_lp[wv] : A.key_tmp + 5 * o0 + 2 * n; S.rasc = in_lds ? l_rp[wv] : A.key_tmp + 5 * o0 + 4 * n;
+	hao_sel_ctx S; S.xs = xs; S.sc = sc; S.al = al; S.pm = pm; S.stack = l_stack;
+	S.pm2 = INLDS ? l_pm2 : A.key_tmp + 5 * o0; S.lpos = INLDS ? l_lp : A.key_tmp + 5 * o0 + 2 * n; S.rasc = INLDS ? l_rp : A.key_tmp + 5 * o0 + 4 * n;
 	int64_t nf = n; int lch2 = lch;
 	if ((uint64_t)n > A.max_n_chain) {
 		hao_wave_intro_sort<0>(S, n);
@@ -911,10 +1110,28 @@ __global__ __launch_bounds__(WPB * 64) void chain_select_kernel(hao_sel_args A, 
 	if (lch2) nf = hao_select_weak(A, S, nf, rec, A.cl + cl0, cn);
 	__threadfence_block();
 	uint64_t fct = 0;
-	for (int64_t i = lane; i < nf; i += 64) { uint32_t pi = pm[i]; if (in_lds) A.perm[o0 + i] = pi; fct += rec[pi].fc_len; }
+	for (int64_t i = lane; i < nf; i += 64) { uint32_t pi = pm[i]; if (INLDS) A.perm[o0 + i] = pi; fct += rec[pi].fc_len; }
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1) fct += __shfl_xor(fct, d);
 	if (lane == 0) { A.n_final[r] = (uint32_t)nf; A.fc_final[r] = fct; }
+}
+
+// WPB waves per workgroup, each wave one read; CAP = chains whose keys fit the wave's LDS slice (reads with more chains keep
+// their keys in global scratch).
+template<int WPB, int CAP>
+__global__ __launch_bounds__(WPB * 64) void chain_select_kernel(hao_sel_args A, int64_t n_lo, int64_t n_hi)
+{
+	__shared__ uint64_t l_xs[WPB][CAP]; __shared__ int32_t l_sc[WPB][CAP]; __shared__ uint32_t l_al[WPB][CAP], l_pm[WPB][CAP], l_pm2[WPB][CAP], l_lp[WPB][CAP], l_rp[WPB][CAP]; __shared__ int32_t l_stack[WPB][3 * 72];
+	const int wv = threadIdx.x >> 6, lane = hao_lane();
+	const uint64_t r = (uint64_t)blockIdx.x * WPB + wv;
+	if (r > A.n_sel) return;
+	if (r == A.n_sel) { if (lane == 0 && n_lo == 0) { A.n_final[r] = 0; A.fc_final[r] = 0; } return; }
+	const uint64_t g0 = A.g_off[r], g1 = A.g_off[r + 1], o0 = A.ch_base[g0];
+	const int64_t n = (int64_t)(A.ch_base[g1] - o0);
+	if (n < n_lo || n >= n_hi) return;                          // this read belongs to another launch
+	const uint64_t cl0 = A.cl_base[g0], cn = A.cl_base[g1] - cl0;
+	if (n <= CAP) hao_select_body<CAP, true>(A, r, n, o0, cl0, cn, l_xs[wv], l_sc[wv], l_al[wv], l_pm[wv], l_pm2[wv], l_lp[wv], l_rp[wv], l_stack[wv]);
+	else hao_select_body<CAP, false>(A, r, n, o0, cl0, cn, l_xs[wv], l_sc[wv], l_al[wv], l_pm[wv], l_pm2[wv], l_lp[wv], l_rp[wv], l_stack[wv]);
 }
 
 // final gather: records in final order (align_length zeroed, anchor.cpp:2098) + fake cigars in that order. One wave per read.

@@ -78,13 +78,7 @@ __global__ __launch_bounds__(256) void seed_expand_kernel(const uint64_t *mz_off
 	}
 }
 
-// Q3: per-read stable LSD radix pass on one 8-bit digit of the key.  The keys of a read are generated in
-// (qidx, j) order, so only the (tid, rev) bits need sorting (stable); the rare runs of equal (tid, rev=1, qidx)
-// come out with jj descending and are mirrored in hits_build_kernel.  One workgroup per read, each wave owns a
-// contiguous quarter of the segment; digit ranks inside a 64-key tile come from an 8-ballot match, per-wave
-// digit counters live in LDS (no atomics: one leader lane per distinct digit), the keys themselves stream
-// through L2 (a read's ~100 KB segment stays cache-resident between the count and the scatter sweep).
-#define HAO_RDX_MAXBITS 11       // digit width is chosen per batch so that the (rev, tid) bits take as few passes as possible
+// rank support: lanes of a wave whose d agree on the low nbits bits (nbits ballots)
 __device__ __forceinline__ unsigned long long hao_match_bits(uint32_t d, bool act, int nbits)
 {
 	unsigned long long m = __ballot(act);
@@ -105,58 +99,6 @@ __device__ __forceinline__ hao_hit_t hao_key_to_hit(const hao_keyfmt &F, uint64_
 	return h;
 }
 
-template<bool FINAL>
-__global__ __launch_bounds__(256) void seg_radix_pass_kernel(const uint64_t *in, uint64_t *out, const uint64_t *seg, int shift, int nbits, uint32_t qcap, hao_hitb_args H)
-{
-	// dynamic LDS: cnt(4, ND) | tot[ND] | (final pass) qpos[qcap] | qcnt[qcap]
-	extern __shared__ uint32_t rdx_smem[];
-	const uint32_t ND = 1u << nbits, dmask = ND - 1;
-	uint32_t *cnt_ = rdx_smem, *tot = rdx_smem + 4 * ND, *l_qpos = tot + ND, *l_qcnt = l_qpos + qcap;
-#define cnt(x, d) cnt_[(x) * ND + (d)]
-	const uint32_t *qpos = nullptr, *qcnt = nullptr;
-	if (FINAL) {
-		const uint64_t m0 = H.mz_off[H.rid_lo + blockIdx.x] - H.mz0, nq = H.mz_off[H.rid_lo + blockIdx.x + 1] - H.mz0 - m0;
-		if (nq <= qcap) { for (uint32_t q = threadIdx.x; q < nq; q += 256) { l_qpos[q] = H.q_pos[m0 + q]; l_qcnt[q] = H.q_cnt[m0 + q]; } qpos = l_qpos; qcnt = l_qcnt; }
-		else { qpos = H.q_pos + m0; qcnt = H.q_cnt + m0; }
-	}
-	const uint64_t r = blockIdx.x, s = seg[r], e = seg[r + 1]; const uint32_t n = (uint32_t)(e - s);
-	const int wv = threadIdx.x >> 6, lane = hao_lane();
-	if (n == 0) return;
-	const uint32_t chunk = ((n + 3) / 4 + 63) & ~63u, c0 = min(n, wv * chunk), c1 = min(n, c0 + chunk);
-	for (uint32_t i = threadIdx.x; i < 4 * ND; i += 256) cnt(i >> nbits, i & dmask) = 0;
-	__syncthreads();
-	for (uint32_t t0 = c0; t0 < c1; t0 += 64) {
-		const uint32_t i = t0 + lane; const bool act = i < c1;
-		const uint32_t d = act ? (uint32_t)(in[s + i] >> shift) & dmask : 0;
-		const unsigned long long m = hao_match_bits(d, act, nbits);
-		if (act && (m & ((1ULL << lane) - 1)) == 0) cnt(wv, d) += __popcll(m);      // leader of its digit in this tile
-	}
-	__syncthreads();
-	{	// exclusive offsets in (digit major, wave minor) order: thread t owns digits [t*per, (t+1)*per)
-		const uint32_t per = (ND + 255) / 256, d0 = threadIdx.x * per; uint32_t mine = 0;
-		for (uint32_t d = d0; d < d0 + per && d < ND; ++d) { uint32_t run = 0; for (int x = 0; x < 4; ++x) { uint32_t c = cnt(x, d); cnt(x, d) = run; run += c; } tot[d] = mine; mine += run; }
-		uint32_t tsum; uint32_t ex = hao_wave_excl_scan(mine, &tsum);
-		__shared__ uint32_t wsum[4];
-		if (lane == 63) wsum[wv] = ex + mine;
-		__syncthreads();
-		for (int x = 0; x < wv; ++x) ex += wsum[x];
-		for (uint32_t d = d0; d < d0 + per && d < ND; ++d) { const uint32_t b = ex + tot[d]; for (int x = 0; x < 4; ++x) cnt(x, d) += b; }
-	}
-	__syncthreads();
-	for (uint32_t t0 = c0; t0 < c1; t0 += 64) {
-		const uint32_t i = t0 + lane; const bool act = i < c1;
-		const uint64_t key = act ? in[s + i] : 0; const uint32_t d = act ? (uint32_t)(key >> shift) & dmask : 0;
-		const unsigned long long m = hao_match_bits(d, act, nbits);
-		uint32_t base = act ? cnt(wv, d) : 0;
-		if (act) {
-			const uint64_t pos = s + base + __popcll(m & ((1ULL << lane) - 1));
-			if (FINAL) H.hits[pos] = hao_key_to_hit(H.F, key, qpos, qcnt); else out[pos] = key;
-		}
-		if (act && (m & ((1ULL << lane) - 1)) == 0) cnt(wv, d) = base + __popcll(m);
-	}
-}
-#undef cnt
-
 // Q3': per-read ordering in ONE sweep over the keys.  A read meets few distinct (tid, rev) values (the reads that
 // overlap it: ~2 x coverage) although their ids need 15-29 bits, so instead of radix digits the workgroup first builds
 // the set of distinct (tid, rev) bins of the read in an LDS hash table (counting per wave while inserting), sorts the
@@ -169,7 +111,7 @@ __global__ __launch_bounds__(256) void seg_radix_pass_kernel(const uint64_t *in,
 #define HAO_BIN_EMPTY 0xffffffffu
 #define HAO_BIN_CAPLOG 10        // 1024 table slots, up to 512 distinct (tid, rev) bins per round
 template<int CAPLOG>
-__global__ __launch_bounds__(256) void seg_bin_sort_kernel(const uint64_t *in, const uint64_t *seg, uint64_t n_sel, uint32_t qcap, hao_hitb_args H, uint32_t *g_tmp, uint64_t *g_cnt)
+__global__ __launch_bounds__(256) void seg_bin_sort_kernel(const uint64_t *in, const uint64_t *seg, uint64_t n_sel, uint32_t qcap, hao_hitb_args H, uint64_t *g_tmp, uint64_t *g_cnt)
 {
 	constexpr uint32_t CAP = 1u << CAPLOG, MAXD = CAP >= 1024 ? CAP / 2 : CAP / 4;      // at most MAXD + 256 bins are ever inserted, so probing terminates; CAP >= 512
 	extern __shared__ uint32_t bs_smem[];
@@ -184,12 +126,10 @@ __global__ __launch_bounds__(256) void seg_bin_sort_kernel(const uint64_t *in, c
 	const int wv = threadIdx.x >> 6, lane = hao_lane(); const uint32_t tid = threadIdx.x;
 	if (r == 0 && tid == 0) g_cnt[n_sel] = 0;
 	if (n == 0) { if (tid == 0) g_cnt[r] = 0; return; }
-	const uint32_t *qpos, *qcnt;
-	{
-		const uint64_t m0 = H.mz_off[H.rid_lo + r] - H.mz0, nq = H.mz_off[H.rid_lo + r + 1] - H.mz0 - m0;
-		if (nq <= qcap) { for (uint32_t q = tid; q < nq; q += 256) { l_qpos[q] = H.q_pos[m0 + q]; l_qcnt[q] = H.q_cnt[m0 + q]; } qpos = l_qpos; qcnt = l_qcnt; }
-		else { qpos = H.q_pos + m0; qcnt = H.q_cnt + m0; }
-	}
+	const uint64_t qm0 = H.mz_off[H.rid_lo + r] - H.mz0, nq = H.mz_off[H.rid_lo + r + 1] - H.mz0 - qm0;
+	const bool qlds = nq <= qcap;                  // the query's minimizer table: LDS copy, or global for very long reads (uniform branch, no flat accesses)
+	const uint32_t *g_qpos = H.q_pos + qm0, *g_qcnt = H.q_cnt + qm0;
+	if (qlds) for (uint32_t q = tid; q < nq; q += 256) { l_qpos[q] = g_qpos[q]; l_qcnt[q] = g_qcnt[q]; }
 	const int kshift = H.F.ob + H.F.qb;
 	const uint32_t chunk = ((n + 3) / 4 + 255) & ~255u, c0 = min(n, wv * chunk), c1 = min(n, c0 + chunk);
 	const uint32_t k_end = 2u << H.F.tb;
@@ -259,7 +199,7 @@ __global__ __launch_bounds__(256) void seg_bin_sort_kernel(const uint64_t *in, c
 			for (uint32_t d = d0; d < d0 + per && d < D; ++d) {
 				const uint32_t slot = (uint32_t)sk[d], t_k = (uint32_t)(sk[d] >> 33), t_p = d ? (uint32_t)(sk[d - 1] >> 33) : last_tid;
 				uint32_t run = placed + (uint32_t)ex;
-				if (t_k != t_p) { g_tmp[s + ngr + (uint32_t)(ex >> 32)] = run; ex += 1ULL << 32; }
+				if (t_k != t_p) { g_tmp[s + ngr + (uint32_t)(ex >> 32)] = (uint64_t)t_k << 32 | run; ex += 1ULL << 32; }
 				ex += tot[d];
 				for (int x = 0; x < 4; ++x) { const uint32_t cc = cw[x * CAP + slot]; cw[x * CAP + slot] = run; run += cc; }
 			}
@@ -278,7 +218,7 @@ __global__ __launch_bounds__(256) void seg_bin_sort_kernel(const uint64_t *in, c
 					const uint32_t d = inr ? rk[slot] : 0;
 					const unsigned long long m = hao_match_bits(d, inr, nbits);
 					const uint32_t base = inr ? cw[wv * CAP + slot] : 0;
-					if (inr) H.hits[s + base + __popcll(m & ((1ULL << lane) - 1))] = hao_key_to_hit(H.F, key, qpos, qcnt);
+					if (inr) H.hits[s + base + __popcll(m & ((1ULL << lane) - 1))] = qlds ? hao_key_to_hit(H.F, key, l_qpos, l_qcnt) : hao_key_to_hit(H.F, key, g_qpos, g_qcnt);
 					if (inr && (m & ((1ULL << lane) - 1)) == 0) cw[wv * CAP + slot] = base + __popcll(m);
 				}
 			}
@@ -292,36 +232,76 @@ __global__ __launch_bounds__(256) void seg_bin_sort_kernel(const uint64_t *in, c
 	if (tid == 0) g_cnt[r] = ngr;
 }
 
-// group table from the per-read lists seg_bin_sort_kernel left at g_tmp[seg[r] ..): one wave per read
-__global__ __launch_bounds__(256) void groups_compact_kernel(const uint32_t *g_tmp, const uint64_t *seg, const uint64_t *g_off, uint64_t n_sel, uint64_t *g_start, uint32_t *g_read)
+// ---- group table ----
+// seg_bin_sort_kernel leaves the groups of read r at g_tmp[seg[r] ..) as (tid << 32 | first hit, relative to the read).
+// Groups are then handed to the chain kernels through per-size-class work lists of self-contained 32-byte entries
+// (no dependent index loads in the consumers), the biggest classes first: a slow group of a big class is found early
+// and its sequential DP overlaps the quick checks of the smaller classes.
+#define HAO_NCLS 6
+struct hao_gent { uint32_t g, r; uint64_t start; uint32_t n, yid, xl, yl; };      // 32 bytes
+__host__ __device__ __forceinline__ int hao_size_class(uint32_t n) { return n <= 64 ? 0 : n <= 128 ? 1 : n <= 256 ? 2 : n <= 512 ? 3 : n <= 2048 ? 4 : 5; }
+
+// per-read group counts by class, laid out class-major: cc[x * (n_sel + 1) + r] (entry n_sel of every class = 0).  ONE exclusive scan of this
+// array gives every (class, read) its slot range in the concatenated class lists (deterministic, no atomics).  One wave per read.
+__global__ __launch_bounds__(256) void groups_classify_kernel(const uint64_t *g_tmp, const uint64_t *seg, const uint64_t *g_cnt, uint64_t n_sel, uint64_t *cc)
 {
 	const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-	if (r >= n_sel) return;
-	const uint64_t s = seg[r], g0 = g_off[r], ng = g_off[r + 1] - g0;
-	for (uint64_t k = hao_lane(); k < ng; k += 64) { g_start[g0 + k] = s + g_tmp[s + k]; g_read[g0 + k] = (uint32_t)r; }
+	if (r > n_sel) return;
+	if (r == n_sel) { if (hao_lane() < HAO_NCLS) cc[hao_lane() * (n_sel + 1) + n_sel] = 0; return; }
+	const uint64_t s = seg[r], ng = g_cnt[r]; const uint32_t n = (uint32_t)(seg[r + 1] - s);
+	uint32_t c[HAO_NCLS] = {0, 0, 0, 0, 0, 0};
+	for (uint64_t k = hao_lane(); k < ng; k += 64) {
+		const uint32_t st = (uint32_t)g_tmp[s + k], en = k + 1 < ng ? (uint32_t)g_tmp[s + k + 1] : n;
+		const int cl = hao_size_class(en - st);
+#pragma unroll
+		for (int x = 0; x < HAO_NCLS; ++x) c[x] += cl == x;
+	}
+#pragma unroll
+	for (int x = 0; x < HAO_NCLS; ++x) {
+		uint32_t v = c[x];
+#pragma unroll
+		for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+		if (hao_lane() == 0) cc[x * (n_sel + 1) + r] = v;
+	}
 }
 
-// Q5: target groups of each read (hits are sorted by target id inside a read).
-// pass 0: count groups per read; pass 1: write group starts at g_off[r] + rank.
-__global__ __launch_bounds__(256) void groups_kernel(const hao_hit_t *hits, const uint64_t *seg, uint64_t n_sel, const uint64_t *g_off, uint64_t *g_cnt, uint64_t *g_start, uint32_t *g_read, int pass)
+struct hao_cls_layout { uint64_t base[HAO_NCLS + 1]; };
+// class list bases (and the group total) from the scanned table: out[x] = co[x * (n_sel + 1)], out[HAO_NCLS] = total
+__global__ void groups_layout_kernel(const uint64_t *co, uint64_t n_sel, unsigned long long *out)
 {
-	const uint64_t r = blockIdx.x; const uint64_t s = seg[r], e = seg[r + 1];
-	__shared__ uint32_t s_w[4]; __shared__ uint64_t s_run;
-	if (threadIdx.x == 0) s_run = 0;
-	__syncthreads();
-	for (uint64_t b = s; b < e; b += 256) {
-		uint64_t i = b + threadIdx.x; bool st = false;
-		if (i < e) st = (i == s) || ((hits[i].w0 & 0x7fffffffu) != (hits[i - 1].w0 & 0x7fffffffu));
-		unsigned long long bal = __ballot(st);
-		if (hao_lane() == 0) s_w[threadIdx.x >> 6] = __popcll(bal);
-		__syncthreads();
-		uint32_t before = 0; for (int x = 0; x < (int)(threadIdx.x >> 6); ++x) before += s_w[x];
-		uint32_t rank = before + __popcll(bal & ((1ULL << hao_lane()) - 1));
-		if (pass == 1 && st) { uint64_t g = g_off[r] + s_run + rank; g_start[g] = i; g_read[g] = (uint32_t)r; }
-		__syncthreads();
-		if (threadIdx.x == 0) s_run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
-		__syncthreads();
-	}
-	if (pass == 0 && threadIdx.x == 0) g_cnt[r] = s_run;
-	if (pass == 0 && r == 0 && threadIdx.x == 1) g_cnt[n_sel] = 0;
+	const uint32_t x = threadIdx.x;
+	if (x < HAO_NCLS) out[x] = co[x * (n_sel + 1)];
+	else if (x == HAO_NCLS) out[x] = co[HAO_NCLS * (n_sel + 1) - 1];      // last entry is a zero slot: exclusive sum there = all groups
 }
+
+// group arrays (g_off, g_start, g_read) + the class work lists; one wave per read.  co = exclusive scan of the class-major count table.
+__global__ __launch_bounds__(256) void groups_compact_kernel(const uint64_t *g_tmp, const uint64_t *seg, const uint64_t *co, uint64_t n_sel, uint64_t rid_lo, const uint32_t *len,
+		uint64_t *g_off, uint64_t *g_start, uint32_t *g_read, hao_gent *glist)
+{
+	const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r > n_sel) return;
+	const int lane = hao_lane();
+	uint64_t pos[HAO_NCLS], g0 = 0, g1 = 0;           // next list slot of each class for this read; groups before / through this read
+#pragma unroll
+	for (int x = 0; x < HAO_NCLS; ++x) { const uint64_t b = co[x * (n_sel + 1)]; pos[x] = co[x * (n_sel + 1) + r]; g0 += pos[x] - b; if (r < n_sel) g1 += co[x * (n_sel + 1) + r + 1] - b; }
+	if (lane == 0) g_off[r] = g0;
+	if (r == n_sel) return;
+	const uint64_t s = seg[r], ng = g1 - g0; const uint32_t n = (uint32_t)(seg[r + 1] - s), xl = len[rid_lo + r];
+	for (uint64_t kb = 0; kb < ng; kb += 64) {
+		const uint64_t k = kb + lane; const bool act = k < ng;
+		hao_gent e; int cl = -1;
+		if (act) {
+			const uint64_t w = g_tmp[s + k]; const uint32_t st = (uint32_t)w, en = k + 1 < ng ? (uint32_t)g_tmp[s + k + 1] : n;
+			e.g = (uint32_t)(g0 + k); e.r = (uint32_t)r; e.start = s + st; e.n = en - st; e.yid = (uint32_t)(w >> 32); e.xl = xl; e.yl = len[e.yid];
+			g_start[g0 + k] = e.start; g_read[g0 + k] = (uint32_t)r;
+			cl = hao_size_class(e.n);
+		}
+#pragma unroll
+		for (int x = 0; x < HAO_NCLS; ++x) {
+			const unsigned long long m = __ballot(cl == x);
+			if (cl == x) glist[pos[x] + __popcll(m & ((1ULL << lane) - 1))] = e;
+			pos[x] += __popcll(m);
+		}
+	}
+}
+

@@ -1,0 +1,9 @@
+python -m pytest tests/test_gpu_overlap.py -x -q -m gpu 2>&1 | grep -E "passed|failed|Error" | tail -3
+run() { python bench.py --workload $1 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); s=d['stage_ms']; print(d['config']['workload'], round(d['value']/1e6,2), d['ms_per_step'], 'chain', s.get('q_chain'), 'dp', s.get('q_chain_dp'), 'ovl', d['config']['overlaps_per_gpu_step'])"; }
+for wl in bacterial5M_hifi30x bacterial5M_hifi30x_repeat; do
+  echo default; run $wl
+  echo WPB1; HAO_CHAIN_WPB=1 run $wl
+  echo SEQTAIL; HAO_DBG_DP_SEQTAIL=1 run $wl
+done
