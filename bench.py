@@ -44,6 +44,7 @@ ALG = {
     "seed_expand_kernel": ("anchor", 8 + 8),                         # index position in + key out
     "chain_assemble_kernel": ("anchor", 16 + 16),                    # chained hit in + tagged hit out
     "seg_bin_sort_kernel": ("anchor", 8 + 16),                       # key in, k_mer_hit out (groups come with the bin table)
+    "seed_bin_kernel": ("anchor", 8 + 16),                           # index record in, k_mer_hit out (bins, order and groups in LDS)
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -191,7 +192,7 @@ def main():
         stage_ms = {k: v / a.steps for k, v in stage_sum.items()}
         # roofline of the dominant kernel: live HIP-event time of its stage on the engine's stream
         kern_stage = {"sketch_chunk_wave_kernel": "sk_chunks", "chain_group_kernel": "q_chain", "seed_expand_kernel": "q_expand",
-                      "chain_assemble_kernel": "q_assemble", "seg_bin_sort_kernel": "q_sort_bins"}
+                      "chain_assemble_kernel": "q_assemble", "seed_bin_kernel": "q_sort_bins"}
         dom = max(kern_stage, key=lambda k: stage_ms.get(kern_stage[k], 0.0))
         unit, bpu = ALG[dom]
         units = rs.total_bases if unit == "base" else tot["seed_hits"]

@@ -8,9 +8,9 @@ struct hao_ctx::Batch {
 	uint64_t n_generic = 0, n_generic_hits = 0; DevBuf<unsigned long long> stats;
 	uint64_t lo = 0, n = 0, mz0 = 0, n_mz = 0, n_anchor = 0, n_groups = 0, n_chains = 0, n_cl = 0, n_fc_raw = 0, n_ol = 0, n_fc = 0;
 	bool valid = false, host_valid = false;
-	DevBuf<uint64_t> s_start, a_off, seg, keys, g_cnt, g_off, g_start, ch_base, cl_base, fc_base, fcs, fc_raw, ol_fc_off, cc_off, cc, fc_final, fin_off, fcf_off, fc_out, fc_out_off;
+	DevBuf<uint64_t> s_start, a_off, seg, g_cnt, g_off, g_start, ch_base, cl_base, fc_base, fcs, fc_raw, ol_fc_off, cc_off, cc, fc_final, fin_off, fcf_off, fc_out, fc_out_off;
 	DevBuf<uint64_t> nch64;
-	DevBuf<uint64_t> g_tmp, cls_cc, cls_co; DevBuf<hao_gent> glist; DevBuf<uint32_t> slow; hipStream_t side[HAO_NCLS]; hipEvent_t ev_qc[HAO_NCLS], ev_dp[HAO_NCLS]; bool side_ready = false;
+	DevBuf<uint64_t> g_tmp, cls_cc, cls_co; DevBuf<hao_gent> glist; DevBuf<uint32_t> slow, ovf_list; hipStream_t side[HAO_NCLS]; hipEvent_t ev_qc[HAO_NCLS], ev_dp[HAO_NCLS]; bool side_ready = false;
 	DevBuf<uint32_t> q_pos, q_cnt, s_n, g_read, wgt, nch, nout, perm, n_final, fclen;
 	DevBuf<hao_hit_t> hits, ohits, cl;
 	DevBuf<int32_t> f, ii, p, key_sc, tm; DevBuf<int64_t> t; DevBuf<uint64_t> key_xs; DevBuf<uint32_t> key_al, key_tmp;
@@ -20,9 +20,9 @@ struct hao_ctx::Batch {
 	std::vector<uint64_t> fetch_fc_off;
 	void release() {
 		if (side_ready) { for (int x = 0; x < HAO_NCLS; ++x) { (void)hipStreamDestroy(side[x]); (void)hipEventDestroy(ev_qc[x]); (void)hipEventDestroy(ev_dp[x]); } side_ready = false; }
-		s_start.release(); a_off.release(); seg.release(); keys.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
+		s_start.release(); a_off.release(); seg.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fin_off.release(); fcf_off.release(); fc_out.release(); fc_out_off.release();
-		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); slow.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
+		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); slow.release(); ovf_list.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
 		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); ol_out.release();
 	}
 };
@@ -76,42 +76,29 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	c->timer.mark("q_lookup");
 	const uint64_t A = B.n_anchor;
 	if (A >= (1ULL << 32)) { hao_set_err(c, "batch produces >= 2^32 anchors: use a smaller read range"); return HAO_EUNSUPP; }
-	HIP_TRY(B.keys.reserve(A + 1)); HIP_TRY(B.hits.reserve(A + 1));
-	// key layout of this batch
-	hao_keyfmt F;
-	{
-		uint32_t max_len = 1; uint64_t max_q = 1;
-		if (c->max_len == 0) for (uint64_t i = 0; i < c->n_total; ++i) c->max_len = std::max(c->max_len, c->h_len_all[i]);
-		max_len = c->max_len;
-		for (uint64_t r = lo; r < hi; ++r) max_q = std::max<uint64_t>(max_q, c->h_ix_mz_off[r + 1] - c->h_ix_mz_off[r]);
-		F.ob = 1; while ((1ULL << F.ob) < (uint64_t)max_len) ++F.ob;
-		F.qb = 1; while ((1ULL << F.qb) < max_q) ++F.qb;
-		F.tb = 1; while ((1ULL << F.tb) < c->n_total) ++F.tb;
-		if (F.ob + F.qb + 1 + F.tb > 64) { hao_set_err(c, "anchor key does not fit 64 bits (reads x minimizers-per-read x read length too large)"); return HAO_EUNSUPP; }
-	}
-	// Q2 expand
-	hipLaunchKernelGGL(seed_expand_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, c->d_ix_mz_off.p, c->d_ix_mz_info.p, lo, B.mz0, B.s_start.p, B.s_n.p, B.a_off.p,
-					   c->d_ix_sinfo.p, c->d_len_all.p, F, B.keys.p);
-	HAO_CHECK_LAUNCH();
-	c->timer.mark("q_expand");
-	// Q3+Q4: stable LSD passes over the (rev, tid) bits only; the last pass decodes keys into k_mer_hits
-	hao_hitb_args hb;
-	hb.mz_off = c->d_ix_mz_off.p; hb.rid_lo = lo; hb.mz0 = B.mz0; hb.q_pos = B.q_pos.p; hb.q_cnt = B.q_cnt.p; hb.F = F; hb.hits = B.hits.p;
-	// Q3-Q5 in one sweep: distinct (tid, rev) bins per read -> ranked stable scatter + group lists
-	const uint32_t qcap = (uint32_t)std::min<uint64_t>(1ULL << F.qb, HAO_QTAB_CAP);
+	HIP_TRY(B.hits.reserve(A + 1));
+	uint64_t max_q = 1;
+	for (uint64_t r = lo; r < hi; ++r) max_q = std::max<uint64_t>(max_q, c->h_ix_mz_off[r + 1] - c->h_ix_mz_off[r]);
+	int tb = 1; while ((1ULL << tb) < c->n_total) ++tb;
 	HIP_TRY(B.g_cnt.reserve(n + 2)); HIP_TRY(B.g_off.reserve(n + 2)); HIP_TRY(B.g_tmp.reserve(A + 1));
 	HIP_TRY(B.stats.reserve(3 * HAO_NCLS + 4)); HIP_TRY(hipMemsetAsync(B.stats.p, 0, (3 * HAO_NCLS + 4) * 8, c->stream));
 	unsigned long long *d_slow_cnt = B.stats.p, *d_cls_cnt = B.stats.p + HAO_NCLS + 4;   // [0..NCLS] slow groups per class + their hits
 	{
-		int CL = HAO_BIN_CAPLOG; if (const char *e_ = getenv("HAO_BIN_CAPLOG")) CL = atoi(e_);
-		const size_t lds = (size_t)36 * (1u << CL) + 8 * qcap;
-		if (lds > 64 * 1024) {     // beyond the default dynamic LDS limit: opt in (the CU has 160 KB)
-			const void *fn = CL == 9 ? (const void*)seg_bin_sort_kernel<9> : CL == 11 ? (const void*)seg_bin_sort_kernel<11> : (const void*)seg_bin_sort_kernel<10>;
-			HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		// Q2-Q5 in one kernel: index records -> bins -> sorted k_mer_hits + group lists (no anchor keys in memory)
+		hao_seed_args sa_;
+		sa_.mz_off = c->d_ix_mz_off.p; sa_.mz_info = c->d_ix_mz_info.p; sa_.rid_lo = lo; sa_.mz0 = B.mz0; sa_.s_start = B.s_start.p; sa_.s_n = B.s_n.p; sa_.a_off = B.a_off.p; sa_.seg = B.seg.p;
+		sa_.sinfo = c->d_ix_sinfo.p; sa_.len = c->d_len_all.p; sa_.q_pos = B.q_pos.p; sa_.q_cnt = B.q_cnt.p; sa_.hits = B.hits.p; sa_.g_tmp = B.g_tmp.p; sa_.g_cnt = B.g_cnt.p; sa_.n_sel = n; sa_.tb = tb;
+		sa_.qcap = (uint32_t)std::min<uint64_t>((max_q + 63) & ~63ULL, HAO_QTAB_CAP);
+		HIP_TRY(B.ovf_list.reserve(n + 1));
+		unsigned long long *d_ovf = B.stats.p + 3 * HAO_NCLS + 3;
+		const size_t lds1 = (size_t)36 * 512 + 12 * (size_t)sa_.qcap + 16, lds2 = (size_t)36 * 1024 + 12 * (size_t)sa_.qcap + 16;
+		if (lds2 > 64 * 1024) {     // beyond the default dynamic LDS limit: opt in (the CU has 160 KB)
+			HIP_TRY(hipFuncSetAttribute((const void*)seed_bin_kernel<9, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+			HIP_TRY(hipFuncSetAttribute((const void*)seed_bin_kernel<10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
 		}
-		if (CL == 9) hipLaunchKernelGGL((seg_bin_sort_kernel<9>), dim3((unsigned)n), dim3(256), lds, c->stream, B.keys.p, B.seg.p, n, qcap, hb, B.g_tmp.p, B.g_cnt.p);
-		else if (CL == 11) hipLaunchKernelGGL((seg_bin_sort_kernel<11>), dim3((unsigned)n), dim3(256), lds, c->stream, B.keys.p, B.seg.p, n, qcap, hb, B.g_tmp.p, B.g_cnt.p);
-		else hipLaunchKernelGGL((seg_bin_sort_kernel<10>), dim3((unsigned)n), dim3(256), lds, c->stream, B.keys.p, B.seg.p, n, qcap, hb, B.g_tmp.p, B.g_cnt.p);
+		hipLaunchKernelGGL((seed_bin_kernel<9, true>), dim3((unsigned)n), dim3(256), lds1, c->stream, sa_, B.ovf_list.p, d_ovf);
+		HAO_CHECK_LAUNCH();
+		hipLaunchKernelGGL((seed_bin_kernel<10, false>), dim3((unsigned)n), dim3(256), lds2, c->stream, sa_, B.ovf_list.p, d_ovf);
 		HAO_CHECK_LAUNCH();
 	}
 	c->timer.mark("q_sort_bins");
@@ -217,7 +204,10 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	sa.key_xs = B.key_xs.p; sa.key_sc = B.key_sc.p; sa.key_al = B.key_al.p; sa.key_tmp = B.key_tmp.p;
 	sa.ol = B.ol.p; sa.g_off = B.g_off.p; sa.ch_base = B.ch_base.p; sa.cl_base = B.cl_base.p; sa.cl = B.cl.p; sa.n_sel = n; sa.rid_lo = glo; sa.len = c->d_len_all.p; sa.cc_off = B.cc_off.p; sa.cc = B.cc.p;
 	sa.perm = B.perm.p; sa.n_final = B.n_final.p; sa.fc_final = B.fc_final.p; sa.max_n_chain = par.max_n_chain; sa.ocv_w = par.ocv_w; sa.chain_cutoff = par.chain_cutoff;
-	hipLaunchKernelGGL((chain_select_kernel<1, 1024>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)0, (int64_t)INT64_MAX);
+	// two launches split by chain count: the common reads (<= 128 chains) need 5 KB of LDS per wave and fill the CUs, the rest take the 1024-chain slice
+	hipLaunchKernelGGL((chain_select_kernel<1, 128>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)0, (int64_t)129);
+	HAO_CHECK_LAUNCH();
+	hipLaunchKernelGGL((chain_select_kernel<1, 1024>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)129, (int64_t)INT64_MAX);
 	HAO_CHECK_LAUNCH();
 	if (int rc = hao_scan_u32(c, B.n_final.p, B.fin_off.p, n + 1)) return rc;
 	if (int rc = hao_excl_scan_u64(c, B.fc_final.p, B.fcf_off.p, n + 1)) return rc;

@@ -1141,11 +1141,20 @@ __global__ __launch_bounds__(256) void chain_final_kernel(const hao_ovlp_t *ol, 
 {
 	const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (r >= n_sel) return;
-	const uint64_t o0 = ch_base[g_off[r]], d0 = fin_off[r], n = fin_off[r + 1] - d0; uint64_t fo = fcf_off[r];
-	for (uint64_t i = 0; i < n; ++i) {
-		const uint64_t src = o0 + perm[o0 + i]; hao_ovlp_t o = ol[src]; const uint64_t fs = ol_fc_off[src];
-		if (hao_lane() == 0) { o.align_length = 0; ol_out[d0 + i] = o; fc_out_off[d0 + i] = fo; }
-		for (uint32_t j = hao_lane(); j < o.fc_len; j += 64) fc_out[fo + j] = fc_raw[fs + j];
-		fo += o.fc_len;
+	const int lane = hao_lane();
+	const uint64_t o0 = ch_base[g_off[r]], d0 = fin_off[r], n = fin_off[r + 1] - d0; uint64_t run = fcf_off[r];
+	for (uint64_t base = 0; base < n; base += 64) {      // one kept chain per lane; fake-cigar destinations from a wave scan of the lengths
+		const uint64_t i = base + lane; const bool act = i < n;
+		hao_ovlp_t o; uint64_t fs = 0; uint32_t fl = 0;
+		if (act) { const uint64_t src = o0 + perm[o0 + i]; o = ol[src]; fs = ol_fc_off[src]; fl = o.fc_len; }
+		uint32_t inc = fl;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d); if (lane >= d) inc += y; }
+		if (act) {
+			const uint64_t fo = run + inc - fl;
+			o.align_length = 0; ol_out[d0 + i] = o; fc_out_off[d0 + i] = fo;
+			for (uint32_t j = 0; j < fl; ++j) fc_out[fo + j] = fc_raw[fs + j];
+		}
+		run += __shfl(inc, 63);
 	}
 }

@@ -1,29 +1,19 @@
-// K5-K7: seed lookup, anchor expansion, per-read ordering and k_mer_hit construction
+// K5-K7: seed lookup, per-read ordering of the seed hits and k_mer_hit construction
 // (minimizers_qgen0, anchor.cpp:987-1081) for gfx950.
 //
-// The reference materialises 24-byte anchors and radix-sorts them by
-// (target id, strand, query pos) then by target offset.  Here an anchor is an 8-byte
-// key that is also its own payload, with a per-batch bit layout (LSB first):
-//
-//     key = offset:ob | qidx:qb | rev:1 | tid:tb          ob + qb + 1 + tb <= 64
-//
-// offset = k_mer_hit::offset (target coordinate, already flipped for opposite-strand
-// hits), qidx = index of the query minimizer inside its read (strictly increasing with
-// query position), ob/qb/tb = bits needed for the longest read / the most minimizers in a
-// read of the batch / the number of reads.  A key's hit list is ordered by (rid,pos), and
-// two hits of one k-mer in one target have k-mer starts ordered like their ends, so the
-// reference order (tid, strand, self_offset, other_off) is: (tid, rev), then qidx, then list
-// order for same-strand hits / reverse list order for opposite-strand hits.
-// seed_expand_kernel emits keys already in (qidx, that order); a STABLE sort on the
-// (rev, tid) bits alone finishes the job, and the last radix pass decodes each key into a
-// k_mer_hit using only the query read's own minimizer table (staged in LDS) - no gather
-// from the index after the sort.  Sorting moves 8 B instead of 24 B per anchor and touches
-// only the bits that vary.
+// The reference materialises 24-byte anchors per read and radix-sorts them by (target id, strand, query pos), then by target
+// offset.  Here nothing is materialised between the position index and the sorted k_mer_hits:
+//   * an index list is ordered by (rid, pos), and two hits of one k-mer in one target have k-mer starts ordered like their
+//     ends, so the reference order (tid, strand, self_offset, other_off) is: (tid, rev), then the query minimizer's rank q,
+//     then list order for same-strand hits / reverse list order for opposite-strand hits;
+//   * walking a read's anchors in generation order (q, list order) therefore only needs a STABLE partition by (tid, rev);
+//   * a read meets few distinct (tid, rev) values (the reads that overlap it: ~2 x coverage) although read ids need 15-29 bits,
+//     so the partition is not digit-wise: one workgroup per read builds the set of distinct (tid, rev) bins in an LDS hash table
+//     (counting per wave while inserting), sorts the distinct bins, and places every hit with one ranked stable scatter.  The
+//     sorted bin table also IS the list of target groups of the read (consecutive bins with the same tid).
 #pragma once
 #include "hao_common.cuh"
 #include "hao_index.cuh"
-
-struct hao_keyfmt { int ob, qb, tb; };     // bit widths; rev bit at ob+qb, tid from ob+qb+1
 
 // Q1: one thread per query minimizer of the batch: index lookup (ha_pt_get, anchor.cpp:1013) and the two words every
 // hit of this minimizer shares: self_offset and cnt = weight(n) << 8 | span (anchor.cpp:1065-1076)
@@ -46,38 +36,6 @@ __global__ void seed_segments_kernel(const uint64_t *mz_off, uint64_t rid_lo, ui
 	seg[r] = a_off[mz_off[rid_lo + r] - mz0];
 }
 
-// Q2: one workgroup per read, one wave per minimizer: write the anchor keys
-__global__ __launch_bounds__(256) void seed_expand_kernel(const uint64_t *mz_off, const uint64_t *mz_info, uint64_t rid_lo, uint64_t mz0,
-		const uint64_t *s_start, const uint32_t *s_n, const uint64_t *a_off, const uint64_t *sinfo, const uint32_t *len, hao_keyfmt F, uint64_t *keys)
-{
-	const uint64_t r = blockIdx.x, rid = rid_lo + r;
-	const uint64_t m0 = mz_off[rid], m1 = mz_off[rid + 1];
-	for (uint64_t m = m0 + (threadIdx.x >> 6); m < m1; m += 4) {
-		const uint64_t li = m - mz0; const uint32_t n = s_n[li];
-		if (n == 0) continue;
-		const uint64_t st = s_start[li], ao = a_off[li]; const uint32_t zrev = hao_info_rev(mz_info[m]), qidx = (uint32_t)(m - m0);
-		for (uint32_t j = hao_lane(); j < n; j += 64) {
-			const uint64_t y = sinfo[st + j]; const uint32_t rev = zrev != hao_info_rev(y), tid = hao_info_rid(y);
-			uint32_t slot = j;
-			if (rev) {   // opposite-strand hits must end up ordered by DEscending target position (ascending other_off, anchor.cpp:1023):
-				// inside the (rare) run of list entries with the same target, rev hit number k takes the slot of rev hit number R-1-k
-				uint32_t ja = j, jb = j;
-				while (ja > 0 && hao_info_rid(sinfo[st + ja - 1]) == tid) --ja;
-				while (jb + 1 < n && hao_info_rid(sinfo[st + jb + 1]) == tid) ++jb;
-				if (ja != jb) {
-					uint32_t k = 0, R = 0, x;
-					for (x = ja; x <= jb; ++x) if (zrev != hao_info_rev(sinfo[st + x])) { if (x < j) ++k; ++R; }
-					uint32_t want = R - 1 - k, seen = 0;
-					for (x = ja; x <= jb; ++x) if (zrev != hao_info_rev(sinfo[st + x])) { if (seen == want) { slot = x; break; } ++seen; }
-				}
-			}
-			// k_mer_hit::offset (anchor.cpp:1021-1023,1059-1064): target coordinate in the strand of the hit
-			const uint32_t off = rev ? len[tid] - 1 - (hao_info_pos(y) + 1 - hao_info_span(y)) : hao_info_pos(y);
-			keys[ao + slot] = (uint64_t)tid << (F.ob + F.qb + 1) | (uint64_t)rev << (F.ob + F.qb) | (uint64_t)qidx << F.ob | off;
-		}
-	}
-}
-
 // rank support: lanes of a wave whose d agree on the low nbits bits (nbits ballots)
 __device__ __forceinline__ unsigned long long hao_match_bits(uint32_t d, bool act, int nbits)
 {
@@ -86,53 +44,56 @@ __device__ __forceinline__ unsigned long long hao_match_bits(uint32_t d, bool ac
 	return m;
 }
 
-struct hao_hitb_args {      // what the final pass needs to turn a key into a k_mer_hit (anchor.cpp:1055-1076)
-	const uint64_t *mz_off; uint64_t rid_lo, mz0; const uint32_t *q_pos, *q_cnt; hao_keyfmt F; hao_hit_t *hits;
-};
-#define HAO_QTAB_CAP 4096     // most query minimizers staged in LDS per read (8 B each); longer reads read the table from global memory
-
-__device__ __forceinline__ hao_hit_t hao_key_to_hit(const hao_keyfmt &F, uint64_t key, const uint32_t *qpos, const uint32_t *qcnt)
-{
-	const uint32_t off = (uint32_t)(key & ((1ULL << F.ob) - 1)), qidx = (uint32_t)(key >> F.ob & ((1ULL << F.qb) - 1));
-	const uint32_t rev = (uint32_t)(key >> (F.ob + F.qb) & 1), tid = (uint32_t)(key >> (F.ob + F.qb + 1));
-	hao_hit_t h; h.w0 = tid | rev << 31; h.offset = off; h.self_offset = qpos[qidx]; h.cnt = qcnt[qidx];
-	return h;
-}
-
-// Q3': per-read ordering in ONE sweep over the keys.  A read meets few distinct (tid, rev) values (the reads that
-// overlap it: ~2 x coverage) although their ids need 15-29 bits, so instead of radix digits the workgroup first builds
-// the set of distinct (tid, rev) bins of the read in an LDS hash table (counting per wave while inserting), sorts the
-// distinct bins, and then places every key with one stable ranked scatter - decoding it into a k_mer_hit on the way -
-// exactly like the last pass of the digit version, with the bin's rank as the "digit".  The bin table also IS the list
-// of target groups of the read (consecutive bins with the same tid), so Q5 needs no pass over the hits.
-// Reads with more distinct bins than the table holds are handled in several rounds over increasing (tid, rev) ranges
-// (range halved until it fits); every round re-reads the read's keys (L2-resident).
-// HBM traffic: keys once in (8 B), hits once out (16 B) per anchor.
+#define HAO_QTAB_CAP 4096     // most query minimizers whose offsets / list starts are staged in LDS per read; longer reads read them from global memory
 #define HAO_BIN_EMPTY 0xffffffffu
-#define HAO_BIN_CAPLOG 10        // 1024 table slots, up to 512 distinct (tid, rev) bins per round
-template<int CAPLOG>
-__global__ __launch_bounds__(256) void seg_bin_sort_kernel(const uint64_t *in, const uint64_t *seg, uint64_t n_sel, uint32_t qcap, hao_hitb_args H, uint64_t *g_tmp, uint64_t *g_cnt)
+
+// Q2-Q5 fused, one workgroup per read: pass A walks the read's anchors (minimizer q, list entry j) and counts bins, pass B walks them again
+// (the read's slices of the position lists are L2-resident by then) and writes each k_mer_hit to its final place.
+// HBM traffic per anchor: one 8-byte index record in, one 16-byte hit out.
+// Anchor x of the read (generation order = (q, list order)) is located through the read's exclusive anchor offsets, staged in LDS
+// with the list starts; a wave walks its chunk in order, so a lane only steps forward from the tile's first minimizer.
+struct hao_seed_args {
+	const uint64_t *mz_off, *mz_info; uint64_t rid_lo, mz0;
+	const uint64_t *s_start; const uint32_t *s_n; const uint64_t *a_off, *seg, *sinfo; const uint32_t *len, *q_pos, *q_cnt;
+	hao_hit_t *hits; uint64_t *g_tmp, *g_cnt; uint64_t n_sel; uint32_t qcap; int tb;
+};
+
+// Two launches cover a batch: <SMALL table, FIRST> takes every read and gives up (appends the read to ovf_list) when its bins do not fit in
+// one round - the small table keeps many workgroups per CU for the common reads; <bigger table, !FIRST> takes the listed reads, in as many
+// (tid, rev) range rounds as they need.
+template<int CAPLOG, bool FIRST>
+__global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t *ovf_list, unsigned long long *ovf_cnt)
 {
-	constexpr uint32_t CAP = 1u << CAPLOG, MAXD = CAP >= 1024 ? CAP / 2 : CAP / 4;      // at most MAXD + 256 bins are ever inserted, so probing terminates; CAP >= 512
+	constexpr uint32_t CAP = 1u << CAPLOG, MAXD = CAP - 288;      // at most MAXD + 256 bins are ever inserted (one per thread after the table fills), so probing terminates; CAP >= 512
 	extern __shared__ uint32_t bs_smem[];
 	uint32_t *hk = bs_smem;                      // [CAP]    bin key (tid << 1 | rev) per slot
 	uint32_t *cw = hk + CAP;                     // [4][CAP] per-wave counts, then running output offsets
 	uint32_t *rk = cw + 4 * CAP;                 // [CAP]    rank of the slot's bin among the bins of the round
 	uint64_t *sk = (uint64_t*)(rk + CAP);        // [CAP]    (bin key << 32 | slot), sorted
 	uint32_t *tot = (uint32_t*)(sk + CAP);       // [CAP]    per-rank totals -> first output position of the bin
-	uint32_t *l_qpos = tot + CAP, *l_qcnt = l_qpos + qcap;
+	uint64_t *l_ss = (uint64_t*)(tot + CAP);     // [qcap]   list start of minimizer q in the position index | strand of the minimizer << 63
+	uint32_t *l_ao = (uint32_t*)(l_ss + S.qcap); // [qcap+1] first anchor of minimizer q, relative to the read
 	__shared__ uint32_t s_nd, s_ovf, s_c; __shared__ uint64_t s_ws[4], s_all;
-	const uint64_t r = blockIdx.x, s = seg[r], e = seg[r + 1]; const uint32_t n = (uint32_t)(e - s);
+	uint64_t *g_tmp = S.g_tmp;
+	if (!FIRST && blockIdx.x >= *ovf_cnt) return;
+	const uint64_t r = FIRST ? blockIdx.x : ovf_list[blockIdx.x], s = S.seg[r], e = S.seg[r + 1]; const uint32_t n = (uint32_t)(e - s);
 	const int wv = threadIdx.x >> 6, lane = hao_lane(); const uint32_t tid = threadIdx.x;
-	if (r == 0 && tid == 0) g_cnt[n_sel] = 0;
-	if (n == 0) { if (tid == 0) g_cnt[r] = 0; return; }
-	const uint64_t qm0 = H.mz_off[H.rid_lo + r] - H.mz0, nq = H.mz_off[H.rid_lo + r + 1] - H.mz0 - qm0;
-	const bool qlds = nq <= qcap;                  // the query's minimizer table: LDS copy, or global for very long reads (uniform branch, no flat accesses)
-	const uint32_t *g_qpos = H.q_pos + qm0, *g_qcnt = H.q_cnt + qm0;
-	if (qlds) for (uint32_t q = tid; q < nq; q += 256) { l_qpos[q] = g_qpos[q]; l_qcnt[q] = g_qcnt[q]; }
-	const int kshift = H.F.ob + H.F.qb;
+	if (FIRST && r == 0 && tid == 0) S.g_cnt[S.n_sel] = 0;
+	if (n == 0) { if (tid == 0) S.g_cnt[r] = 0; return; }
+	const uint64_t m0 = S.mz_off[S.rid_lo + r], li0 = m0 - S.mz0; const uint32_t nq = (uint32_t)(S.mz_off[S.rid_lo + r + 1] - m0);
+	const bool qlds = nq <= S.qcap;                // very long reads keep the per-minimizer table in global memory (uniform branches, no flat accesses)
+	const uint64_t *g_ao = S.a_off + li0, *g_ss = S.s_start + li0, *g_info = S.mz_info + m0;
+	if (qlds) {
+		for (uint32_t q = tid; q < nq; q += 256) { l_ss[q] = g_ss[q] | (uint64_t)hao_info_rev(g_info[q]) << 63; l_ao[q] = (uint32_t)(g_ao[q] - s); }
+		if (tid == 0) l_ao[nq] = n;
+	}
+	__syncthreads();
+#define HAO_AO(q) (qlds ? l_ao[q] : ((q) >= nq ? n : (uint32_t)(g_ao[q] - s)))
+#define HAO_SS(q) (qlds ? l_ss[q] : (g_ss[q] | (uint64_t)hao_info_rev(g_info[q]) << 63))
 	const uint32_t chunk = ((n + 3) / 4 + 255) & ~255u, c0 = min(n, wv * chunk), c1 = min(n, c0 + chunk);
-	const uint32_t k_end = 2u << H.F.tb;
+	uint32_t q_c0 = 0;       // minimizer holding anchor c0: last q with AO(q) <= c0 (binary search, uniform in the wave)
+	if (c0 < c1) { uint32_t lo_ = 0, hi_ = nq; while (hi_ - lo_ > 1) { const uint32_t md = (lo_ + hi_) >> 1; if (HAO_AO(md) <= c0) lo_ = md; else hi_ = md; } q_c0 = lo_; }
+	const uint32_t k_end = 2u << S.tb;
 	uint32_t lo = 0, placed = 0, ngr = 0, last_tid = 0xffffffffu;
 	volatile uint32_t *v_ovf = &s_ovf;
 	while (lo < k_end) {
@@ -141,17 +102,25 @@ __global__ __launch_bounds__(256) void seg_bin_sort_kernel(const uint64_t *in, c
 			for (uint32_t i = tid; i < CAP; i += 256) { hk[i] = HAO_BIN_EMPTY; cw[i] = 0; cw[CAP + i] = 0; cw[2 * CAP + i] = 0; cw[3 * CAP + i] = 0; }
 			if (tid == 0) { s_nd = 0; s_ovf = 0; s_c = 0; }
 			__syncthreads();
-			for (uint32_t t0 = c0; t0 < c1; t0 += 256) {      // four independent key loads in flight per lane
-				uint64_t kv[4];
+			uint32_t qc = q_c0;
+			for (uint32_t t0 = c0; t0 < c1; t0 += 256) {      // four independent index reads in flight per lane
+				uint64_t yv[4]; uint32_t zr[4];
 #pragma unroll
-				for (int u = 0; u < 4; ++u) { const uint32_t i = t0 + u * 64 + lane; kv[u] = i < c1 ? in[s + i] : 0; }
+				for (int u = 0; u < 4; ++u) {
+					const uint32_t x = t0 + u * 64 + lane; const bool act = x < c1; uint32_t q = qc;
+					if (act) { while (HAO_AO(q + 1) <= x) ++q; }
+					qc = (uint32_t)__builtin_amdgcn_readlane((int)q, 63);
+					const uint64_t sv = HAO_SS(q);
+					yv[u] = act ? S.sinfo[(sv & ~(1ULL << 63)) + (x - HAO_AO(q))] : 0; zr[u] = (uint32_t)(sv >> 63);
+				}
 				if (*v_ovf) break;
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
-					const uint32_t i = t0 + u * 64 + lane, kk = (uint32_t)(kv[u] >> kshift);
-					if (i < c1 && kk >= lo && kk < hi) {
+					const uint32_t x = t0 + u * 64 + lane, kk = hao_info_rid(yv[u]) << 1 | (zr[u] ^ hao_info_rev(yv[u]));
+					if (x < c1 && kk >= lo && kk < hi && !*v_ovf) {        // a thread starts at most one insertion after the table was declared full
 						uint32_t slot = (kk * 2654435761u) >> (32 - CAPLOG);
-						for (;;) {
+						for (uint32_t pr = 0; ; ++pr) {
+							if (pr == CAP) { *v_ovf = 1; break; }
 							const uint32_t old = atomicCAS(&hk[slot], HAO_BIN_EMPTY, kk);
 							if (old == HAO_BIN_EMPTY) { if (atomicAdd(&s_nd, 1u) >= MAXD) *v_ovf = 1; break; }
 							if (old == kk) break;
@@ -165,6 +134,7 @@ __global__ __launch_bounds__(256) void seg_bin_sort_kernel(const uint64_t *in, c
 			const bool ovf = *v_ovf != 0;
 			__syncthreads();
 			if (!ovf) break;
+			if (FIRST) { if (tid == 0) ovf_list[atomicAdd(ovf_cnt, 1ULL)] = (uint32_t)r; return; }      // left to the launch with the bigger table
 			hi = lo + (hi - lo) / 2;      // hi - lo >= 2 here: one bin always fits
 		}
 		const uint32_t D = s_nd;
@@ -205,20 +175,54 @@ __global__ __launch_bounds__(256) void seg_bin_sort_kernel(const uint64_t *in, c
 			}
 			__syncthreads();
 			int nbits = 0; while ((1u << nbits) < D) ++nbits;
+			uint32_t qc = q_c0;
 			for (uint32_t t0 = c0; t0 < c1; t0 += 256) {
-				uint64_t kv[4];
-#pragma unroll
-				for (int u = 0; u < 4; ++u) { const uint32_t i = t0 + u * 64 + lane; kv[u] = i < c1 ? in[s + i] : 0; }
+				uint64_t yv[4]; uint32_t qv[4];
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
-					const uint32_t i = t0 + u * 64 + lane; const uint64_t key = kv[u]; const uint32_t kk = (uint32_t)(key >> kshift);
-					const bool inr = i < c1 && kk >= lo && kk < hi;
+					const uint32_t x = t0 + u * 64 + lane; const bool act = x < c1; uint32_t q = qc;
+					if (act) { while (HAO_AO(q + 1) <= x) ++q; }
+					qc = (uint32_t)__builtin_amdgcn_readlane((int)q, 63);
+					qv[u] = q;
+					yv[u] = act ? S.sinfo[(HAO_SS(q) & ~(1ULL << 63)) + (x - HAO_AO(q))] : 0;
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const uint32_t x = t0 + u * 64 + lane, q = qv[u]; uint64_t y = yv[u];
+					const uint64_t sv = HAO_SS(q), st = sv & ~(1ULL << 63); const uint32_t zrev = (uint32_t)(sv >> 63);
+					const uint32_t tidk = hao_info_rid(y), rev = zrev ^ hao_info_rev(y), kk = tidk << 1 | rev;
+					const bool inr = x < c1 && kk >= lo && kk < hi;
+					// list neighbours: from the adjacent lanes when they hold the same minimizer, else (tile edges) from memory
+					const uint32_t t_up = hao_info_rid(__shfl_up(y, 1)), t_dn = hao_info_rid(__shfl_down(y, 1));
+					const bool s_up = lane > 0 && __shfl_up(q, 1) == q, s_dn = lane < 63 && x + 1 < c1 && __shfl_down(q, 1) == q;
+					if (inr && rev) {
+						// opposite-strand hits of one k-mer in one target must come out by DEscending target position (ascending other_off,
+						// anchor.cpp:1023): inside the (rare) run of list entries with the same target, the anchor at rev position k takes the
+						// record of rev entry R-1-k
+						const uint32_t a0 = HAO_AO(q), nl = HAO_AO(q + 1) - a0, j = x - a0;
+						const bool pv = j > 0 && (s_up ? t_up : hao_info_rid(S.sinfo[st + j - 1])) == tidk, nx = j + 1 < nl && (s_dn ? t_dn : hao_info_rid(S.sinfo[st + j + 1])) == tidk;
+						if (pv || nx) {
+							uint32_t ja = j, jb = j;
+							while (ja > 0 && hao_info_rid(S.sinfo[st + ja - 1]) == tidk) --ja;
+							while (jb + 1 < nl && hao_info_rid(S.sinfo[st + jb + 1]) == tidk) ++jb;
+							uint32_t k = 0, R = 0, z;
+							for (z = ja; z <= jb; ++z) if (zrev != hao_info_rev(S.sinfo[st + z])) { if (z < j) ++k; ++R; }
+							const uint32_t want = R - 1 - k; uint32_t seen = 0;
+							for (z = ja; z <= jb; ++z) if (zrev != hao_info_rev(S.sinfo[st + z])) { if (seen == want) { y = S.sinfo[st + z]; break; } ++seen; }
+						}
+					}
 					uint32_t slot = (kk * 2654435761u) >> (32 - CAPLOG);
 					if (inr) while (hk[slot] != kk) slot = (slot + 1) & (CAP - 1);
 					const uint32_t d = inr ? rk[slot] : 0;
 					const unsigned long long m = hao_match_bits(d, inr, nbits);
 					const uint32_t base = inr ? cw[wv * CAP + slot] : 0;
-					if (inr) H.hits[s + base + __popcll(m & ((1ULL << lane) - 1))] = qlds ? hao_key_to_hit(H.F, key, l_qpos, l_qcnt) : hao_key_to_hit(H.F, key, g_qpos, g_qcnt);
+					if (inr) {
+						hao_hit_t h; h.w0 = tidk | rev << 31;
+						// k_mer_hit::offset (anchor.cpp:1021-1023,1059-1064): target coordinate in the strand of the hit
+						h.offset = rev ? S.len[tidk] - 1 - (hao_info_pos(y) + 1 - hao_info_span(y)) : hao_info_pos(y);
+						h.self_offset = S.q_pos[li0 + q]; h.cnt = S.q_cnt[li0 + q];
+						S.hits[s + base + __popcll(m & ((1ULL << lane) - 1))] = h;
+					}
 					if (inr && (m & ((1ULL << lane) - 1)) == 0) cw[wv * CAP + slot] = base + __popcll(m);
 				}
 			}
@@ -229,7 +233,9 @@ __global__ __launch_bounds__(256) void seg_bin_sort_kernel(const uint64_t *in, c
 		}
 		lo = hi;
 	}
-	if (tid == 0) g_cnt[r] = ngr;
+	if (tid == 0) S.g_cnt[r] = ngr;
+#undef HAO_AO
+#undef HAO_SS
 }
 
 // ---- group table ----
