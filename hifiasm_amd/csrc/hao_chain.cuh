@@ -58,10 +58,15 @@ __device__ __forceinline__ int32_t hao_pair_score(const hao_hit_t &ai, const hao
 	int32_t dg = dr < dq ? dr : dq, span = HH_SPAN(ai), sc = span < dg ? span : dg, wgt = HH_WGT(ai);
 	sc = sc >= wgt ? sc / wgt : 1;
 	if (dd) {
-		double lin = P.pen_gap * (double)dd, ap = (double)sc * (((double)dd / (double)dg) / P.bw);
-		if (dd < 4) lin = lin > ap ? ap : lin; else lin = lin < ap ? ap : lin;
-		lin += P.pen_skip * (double)dg;
-		sc -= (int32_t)lin;
+		double lin = P.pen_gap * (double)dd; const double skip = P.pen_skip * (double)dg;
+		// dd < 4: the penalty is min(lin, ap) + skip with ap >= 0, and FP addition is monotonic, so it lies in [0, lin + skip]; when that
+		// bound is below 1 the penalty truncates to 0 whatever ap is - the two FP64 divisions are skipped (the common 1-3 base indel)
+		if (!(dd < 4 && lin + skip < 1.0)) {
+			const double ap = (double)sc * (((double)dd / (double)dg) / P.bw);
+			if (dd < 4) lin = lin > ap ? ap : lin; else lin = lin < ap ? ap : lin;
+			lin += skip;
+			sc -= (int32_t)lin;
+		}
 	} else if (dg > span) {
 		// dd == 0: both penalty terms are exactly +0.0 (pen_gap * 0, sc * ((0 / dg) / bw)), min(0,0) = 0, so only the
 		// skip term remains - same IEEE result as the general expression without the two divisions
@@ -289,8 +294,8 @@ __device__ void hao_chain_generic(const hao_chain_args &A, const uint64_t g)
 
 __device__ __forceinline__ hao_hit_t hao_shfl_hit(const hao_hit_t &h, int src)
 { hao_hit_t o; o.w0 = __shfl(h.w0, src); o.offset = __shfl(h.offset, src); o.self_offset = __shfl(h.self_offset, src); o.cnt = __shfl(h.cnt, src); return o; }
-__device__ __forceinline__ hao_hit_t hao_shfl_up_hit(const hao_hit_t &h)
-{ hao_hit_t o; o.w0 = __shfl_up(h.w0, 1); o.offset = __shfl_up(h.offset, 1); o.self_offset = __shfl_up(h.self_offset, 1); o.cnt = __shfl_up(h.cnt, 1); return o; }
+__device__ __forceinline__ hao_hit_t hao_shfl_up_hit(const hao_hit_t &h)      // lane 0 keeps its own value (callers overwrite it)
+{ hao_hit_t o; o.w0 = hao_wave_shr1(h.w0, h.w0); o.offset = hao_wave_shr1(h.offset, h.offset); o.self_offset = hao_wave_shr1(h.self_offset, h.self_offset); o.cnt = hao_wave_shr1(h.cnt, h.cnt); return o; }
 
 // One wave per (query,target) group.
 // Fast path (data-parallel): every strand block passes quick_ck_lchain - a segmented prefix sum of pair
@@ -326,10 +331,9 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 		int32_t s = HH_SPAN(h); bool ok = true; int64_t dd = 0;
 		if (act && !st) { s = hao_pair_score(h, ph, P, &dd); ok = s != INT32_MIN; if (!ok) { s = 0; dd = 0; } }
 		int32_t x = act ? s : 0; int fl = st;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) { int32_t x2 = __shfl_up(x, d); int f2 = __shfl_up(fl, d); if (lane >= d) { if (!fl) x += x2; fl |= f2; } }
+		hao_seg_scan_add(x, fl);
 		if (!fl) x += carry_f;
-		const int32_t f = x; int32_t fp = __shfl_up(f, 1); if (lane == 0) fp = carry_f;
+		const int32_t f = x; const int32_t fp = hao_wave_shr1(f, carry_f);
 		const bool brk = act && !st && (!ok || (int64_t)s + fp < (int64_t)HH_SPAN(h));
 		if (__ballot(brk && b == 0)) fail0 = true;
 		if (__ballot(brk && b == 1)) fail1 = true;
@@ -511,10 +515,9 @@ __device__ __forceinline__ void hao_dp_body(const hao_chain_args &A, const hao_g
 		int32_t s = HH_SPAN(h); bool ok = true; int64_t dd = 0;
 		if (act && !st) { s = hao_pair_score(h, ph, P, &dd); ok = s != INT32_MIN; if (!ok) { s = 0; dd = 0; } }
 		int32_t x = act ? s : 0; int fl = st;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) { int32_t x2 = __shfl_up(x, d); int f2 = __shfl_up(fl, d); if (lane >= d) { if (!fl) x += x2; fl |= f2; } }
+		hao_seg_scan_add(x, fl);
 		if (!fl) x += carry_f;
-		const int32_t fv = x; int32_t fp = __shfl_up(fv, 1); if (lane == 0) fp = carry_f;
+		const int32_t fv = x; const int32_t fp = hao_wave_shr1(fv, carry_f);
 		const bool brk = act && !st && (!ok || (int64_t)s + fp < (int64_t)HH_SPAN(h));
 		if (__ballot(brk && b == 0)) fail0 = true;
 		if (__ballot(brk && b == 1)) fail1 = true;

@@ -51,4 +51,19 @@ __host__ __device__ __forceinline__ int64_t hao_bsearch(const uint64_t *a, uint6
 
 __device__ __forceinline__ int hao_lane() { return threadIdx.x & 63; }
 
+// Cross-lane moves on the DPP path (one VALU op, no LDS crossbar trip like ds_bpermute).  gfx9 controls: 0x110+n row_shr:n (inside rows of
+// 16 lanes), 0x142 row_bcast:15 (lane 15 of a row -> the next row, use row_mask 0xa), 0x143 row_bcast:31 (lane 31 -> rows 2,3, row_mask 0xc),
+// 0x138 wave_shr:1.  Lanes without a valid source keep `old`.  Call only in wave-uniform control flow.
+template<int CTRL, int ROWMASK> __device__ __forceinline__ int hao_dpp(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROWMASK, 0xf, false); }
+// value of the previous lane; lane 0 gets `fill`
+__device__ __forceinline__ int hao_wave_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t hao_wave_shr1(uint32_t v, uint32_t fill) { return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false); }
+// inclusive segmented sum over the wave: fl = 1 where a segment starts; on return fl = "a segment starts at or before this lane"
+__device__ __forceinline__ void hao_seg_scan_add(int32_t &x, int &fl)
+{
+#define HAO_SEG_STEP(CTRL, RM) { const int x2 = hao_dpp<CTRL, RM>(0, x), f2 = hao_dpp<CTRL, RM>(0, fl); if (!fl) x += x2; fl |= f2; }
+	HAO_SEG_STEP(0x111, 0xf) HAO_SEG_STEP(0x112, 0xf) HAO_SEG_STEP(0x114, 0xf) HAO_SEG_STEP(0x118, 0xf) HAO_SEG_STEP(0x142, 0xa) HAO_SEG_STEP(0x143, 0xc)
+#undef HAO_SEG_STEP
+}
+
 #define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { hao_set_err(c, std::string(#expr) + ": " + hipGetErrorString(_e)); return HAO_ENODEV; } } while (0)
