@@ -102,6 +102,12 @@ __device__ uint32_t hao_fake_cigar(uint64_t *fc, const hao_chain_rec &o, const h
 	return n;
 }
 
+// broadcast of lane src (wave-uniform src): v_readlane, no LDS crossbar
+__device__ __forceinline__ uint32_t hao_bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+__device__ __forceinline__ int32_t hao_bcast(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ int64_t hao_readlane_i64(int64_t v, int l)
+{ return (int64_t)((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), l) << 32); }
+
 // gen_fake_cigar (apend_be = 1) by one wave: the k-th hit of the chain is hit(k); entries are a flagged compaction
 // (an entry wherever the diagonal changes).  Returns the entry count (uniform).
 template<class HitAt>
@@ -114,19 +120,16 @@ __device__ __forceinline__ uint32_t hao_fake_cigar_wave(uint64_t *fcs, uint32_t 
 		const int64_t k = t0 + lane; const bool act = k < cL;
 		const hao_hit_t h = hit(act ? k : (int64_t)0);
 		int64_t dd = ((int64_t)h.offset - y_pos_s) - ((int64_t)h.self_offset - x_pos_s);
-		int64_t pd = __shfl_up(dd, 1); if (lane == 0) pd = carry_dd;
+		const int64_t pd = (int64_t)((uint64_t)hao_wave_shr1((uint32_t)dd, (uint32_t)carry_dd) | (uint64_t)hao_wave_shr1((uint32_t)((uint64_t)dd >> 32), (uint32_t)((uint64_t)carry_dd >> 32)) << 32);
 		const bool flag = act && dd != pd;
 		unsigned long long bal = __ballot(flag);
 		if (flag) fcs[cnt + __popcll(bal & ((1ULL << lane) - 1))] = hao_fc_entry(h.self_offset, (int32_t)dd);
-		if (bal) { int src = 63 - __clzll((long long)bal); last_site = __shfl(h.self_offset, src); last_dd = __shfl(dd, src); }
-		cnt += __popcll(bal); carry_dd = __shfl(dd, 63);
+		if (bal) { int src = 63 - __clzll((long long)bal); last_site = hao_bcast(h.self_offset, src); last_dd = hao_readlane_i64(dd, src); }
+		cnt += __popcll(bal); carry_dd = hao_readlane_i64(dd, 63);
 	}
 	if (last_site != x_pos_e) { if (lane == 0) fcs[cnt] = hao_fc_entry(x_pos_e, (int32_t)last_dd); ++cnt; }
 	return cnt;
 }
-
-__device__ __forceinline__ int64_t hao_readlane_i64(int64_t v, int l)
-{ return (int64_t)((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), l) << 32); }
 
 #define HAO_WAVE_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 
@@ -293,7 +296,7 @@ __device__ void hao_chain_generic(const hao_chain_args &A, const uint64_t g)
 }
 
 __device__ __forceinline__ hao_hit_t hao_shfl_hit(const hao_hit_t &h, int src)
-{ hao_hit_t o; o.w0 = __shfl(h.w0, src); o.offset = __shfl(h.offset, src); o.self_offset = __shfl(h.self_offset, src); o.cnt = __shfl(h.cnt, src); return o; }
+{ hao_hit_t o; o.w0 = hao_bcast(h.w0, src); o.offset = hao_bcast(h.offset, src); o.self_offset = hao_bcast(h.self_offset, src); o.cnt = hao_bcast(h.cnt, src); return o; }
 __device__ __forceinline__ hao_hit_t hao_shfl_up_hit(const hao_hit_t &h)      // lane 0 keeps its own value (callers overwrite it)
 { hao_hit_t o; o.w0 = hao_wave_shr1(h.w0, h.w0); o.offset = hao_wave_shr1(h.offset, h.offset); o.self_offset = hao_wave_shr1(h.self_offset, h.self_offset); o.cnt = hao_wave_shr1(h.cnt, h.cnt); return o; }
 
@@ -343,9 +346,9 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 		uint32_t nw0 = __shfl_down(h.w0, 1); if (lane == 63) nw0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hn.w0);
 		const bool isend = act && (idx == a_n - 1 || (nw0 >> 31) != HH_STRAND(h));
 		unsigned long long m0 = __ballot(isend && b == 0), m1 = __ballot(isend && b == 1);
-		if (m0) { int src = __ffsll((long long)m0) - 1; flast0 = __shfl(f, src); last0 = hao_shfl_hit(h, src); }
-		if (m1) { int src = __ffsll((long long)m1) - 1; flast1 = __shfl(f, src); last1 = hao_shfl_hit(h, src); }
-		carry_f = __shfl(f, 63); carry_h = hao_shfl_hit(h, 63);
+		if (m0) { int src = __ffsll((long long)m0) - 1; flast0 = hao_bcast(f, src); last0 = hao_shfl_hit(h, src); }
+		if (m1) { int src = __ffsll((long long)m1) - 1; flast1 = hao_bcast(f, src); last1 = hao_shfl_hit(h, src); }
+		carry_f = hao_bcast(f, 63); carry_h = hao_shfl_hit(h, 63);
 	}
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1) {
@@ -525,9 +528,9 @@ __device__ __forceinline__ void hao_dp_body(const hao_chain_args &A, const hao_g
 		k1 += __popcll(__ballot(act && b == 0));
 		const bool isend = act && (idx == a_n - 1 || HH_STRAND(a[idx + 1]) != HH_STRAND(h));
 		unsigned long long m0 = __ballot(isend && b == 0), m1 = __ballot(isend && b == 1);
-		if (m0) { int src = __ffsll((long long)m0) - 1; flast0 = __shfl(fv, src); last0 = hao_shfl_hit(h, src); }
-		if (m1) { int src = __ffsll((long long)m1) - 1; flast1 = __shfl(fv, src); last1 = hao_shfl_hit(h, src); }
-		carry_f = __shfl(fv, 63); carry_h = hao_shfl_hit(h, 63);
+		if (m0) { int src = __ffsll((long long)m0) - 1; flast0 = hao_bcast(fv, src); last0 = hao_shfl_hit(h, src); }
+		if (m1) { int src = __ffsll((long long)m1) - 1; flast1 = hao_bcast(fv, src); last1 = hao_shfl_hit(h, src); }
+		carry_f = hao_bcast(fv, 63); carry_h = hao_shfl_hit(h, 63);
 	}
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1) {
