@@ -5,7 +5,7 @@
 #include "hao_chain.cuh"
 
 struct hao_ctx::Batch {
-	uint64_t n_generic = 0, n_generic_hits = 0; DevBuf<unsigned long long> stats;
+	uint64_t n_generic = 0, n_generic_hits = 0; DevBuf<unsigned long long> stats, dbgbuf;
 	uint64_t lo = 0, n = 0, mz0 = 0, n_mz = 0, n_anchor = 0, n_groups = 0, n_chains = 0, n_cl = 0, n_fc_raw = 0, n_ol = 0, n_fc = 0;
 	bool valid = false, host_valid = false;
 	DevBuf<uint64_t> s_start, a_off, seg, g_cnt, g_off, g_start, ch_base, cl_base, fc_base, fcs, fc_raw, ol_fc_off, cc_off, cc, fc_final, fin_off, fcf_off, fc_out, fc_out_off;
@@ -89,9 +89,11 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		sa_.mz_off = c->d_ix_mz_off.p; sa_.mz_info = c->d_ix_mz_info.p; sa_.rid_lo = lo; sa_.mz0 = B.mz0; sa_.s_start = B.s_start.p; sa_.s_n = B.s_n.p; sa_.a_off = B.a_off.p; sa_.seg = B.seg.p;
 		sa_.sinfo = c->d_ix_sinfo.p; sa_.len = c->d_len_all.p; sa_.q_pos = B.q_pos.p; sa_.q_cnt = B.q_cnt.p; sa_.hits = B.hits.p; sa_.g_tmp = B.g_tmp.p; sa_.g_cnt = B.g_cnt.p; sa_.n_sel = n; sa_.tb = tb;
 		sa_.qcap = (uint32_t)std::min<uint64_t>((max_q + 63) & ~63ULL, HAO_QTAB_CAP);
+		sa_.dbg = nullptr;
+		if (getenv("HAO_DBG_SEEDPHASE")) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); sa_.dbg = B.dbgbuf.p; }
 		HIP_TRY(B.ovf_list.reserve(n + 1));
 		unsigned long long *d_ovf = B.stats.p + 3 * HAO_NCLS + 3;
-		const size_t lds1 = (size_t)36 * 512 + 12 * (size_t)sa_.qcap + 16, lds2 = (size_t)36 * 1024 + 12 * (size_t)sa_.qcap + 16;
+		const size_t lds1 = (size_t)40 * 512 + 12 * (size_t)sa_.qcap + 16, lds2 = (size_t)40 * 1024 + 12 * (size_t)sa_.qcap + 16;
 		if (lds2 > 64 * 1024) {     // beyond the default dynamic LDS limit: opt in (the CU has 160 KB)
 			HIP_TRY(hipFuncSetAttribute((const void*)seed_bin_kernel<9, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
 			HIP_TRY(hipFuncSetAttribute((const void*)seed_bin_kernel<10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
@@ -101,6 +103,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		hipLaunchKernelGGL((seed_bin_kernel<10, false>), dim3((unsigned)n), dim3(256), lds2, c->stream, sa_, B.ovf_list.p, d_ovf);
 		HAO_CHECK_LAUNCH();
 	}
+	if (getenv("HAO_DBG_SEEDPHASE")) { unsigned long long d_[4]; HIP_TRY(hipMemcpy(d_, B.dbgbuf.p, 32, hipMemcpyDeviceToHost)); if (d_[3]) fprintf(stderr, "[seed] blocks %llu  avg us: count pass %.1f  sort+scan %.1f  scatter pass %.1f\n", d_[3], d_[0] / 100.0 / d_[3], d_[1] / 100.0 / d_[3], d_[2] / 100.0 / d_[3]); }
 	c->timer.mark("q_sort_bins");
 	HIP_TRY(B.cls_cc.reserve(HAO_NCLS * (n + 1) + 1)); HIP_TRY(B.cls_co.reserve(HAO_NCLS * (n + 1) + 1));
 	hipLaunchKernelGGL(groups_classify_kernel, dim3((unsigned)((n + 4) / 4)), dim3(256), 0, c->stream, B.g_tmp.p, B.seg.p, B.g_cnt.p, n, B.cls_cc.p);

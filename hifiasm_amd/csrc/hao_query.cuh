@@ -56,6 +56,7 @@ struct hao_seed_args {
 	const uint64_t *mz_off, *mz_info; uint64_t rid_lo, mz0;
 	const uint64_t *s_start; const uint32_t *s_n; const uint64_t *a_off, *seg, *sinfo; const uint32_t *len, *q_pos, *q_cnt;
 	hao_hit_t *hits; uint64_t *g_tmp, *g_cnt; uint64_t n_sel; uint32_t qcap; int tb;
+	unsigned long long *dbg;      // optional: per-phase wall-clock ticks summed over workgroups (HAO_DBG_SEEDPHASE)
 };
 
 // Two launches cover a batch: <SMALL table, FIRST> takes every read and gives up (appends the read to ovf_list) when its bins do not fit in
@@ -71,7 +72,8 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 	uint32_t *rk = cw + 4 * CAP;                 // [CAP]    rank of the slot's bin among the bins of the round
 	uint64_t *sk = (uint64_t*)(rk + CAP);        // [CAP]    (bin key << 32 | slot), sorted
 	uint32_t *tot = (uint32_t*)(sk + CAP);       // [CAP]    per-rank totals -> first output position of the bin
-	uint64_t *l_ss = (uint64_t*)(tot + CAP);     // [qcap]   list start of minimizer q in the position index | strand of the minimizer << 63
+	uint32_t *bl = tot + CAP;                    // [CAP]    read length of the slot's target (opposite-strand offsets)
+	uint64_t *l_ss = (uint64_t*)(bl + CAP);      // [qcap]   list start of minimizer q in the position index | strand of the minimizer << 63
 	uint32_t *l_ao = (uint32_t*)(l_ss + S.qcap); // [qcap+1] first anchor of minimizer q, relative to the read
 	__shared__ uint32_t s_nd, s_ovf, s_c; __shared__ uint64_t s_ws[4], s_all;
 	uint64_t *g_tmp = S.g_tmp;
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 		if (tid == 0) l_ao[nq] = n;
 	}
 	__syncthreads();
+	unsigned long long tk0 = S.dbg ? wall_clock64() : 0, tk1 = 0, tk2 = 0;
 #define HAO_AO(q) (qlds ? l_ao[q] : ((q) >= nq ? n : (uint32_t)(g_ao[q] - s)))
 #define HAO_SS(q) (qlds ? l_ss[q] : (g_ss[q] | (uint64_t)hao_info_rev(g_info[q]) << 63))
 	const uint32_t chunk = ((n + 3) / 4 + 255) & ~255u, c0 = min(n, wv * chunk), c1 = min(n, c0 + chunk);
@@ -137,6 +140,7 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 			if (FIRST) { if (tid == 0) ovf_list[atomicAdd(ovf_cnt, 1ULL)] = (uint32_t)r; return; }      // left to the launch with the bigger table
 			hi = lo + (hi - lo) / 2;      // hi - lo >= 2 here: one bin always fits
 		}
+		if (S.dbg) tk1 = wall_clock64();
 		const uint32_t D = s_nd;
 		if (D) {
 			uint32_t P = 2; while (P < D) P <<= 1;
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 					}
 					__syncthreads();
 				}
-			for (uint32_t d = tid; d < D; d += 256) { const uint32_t slot = (uint32_t)sk[d]; rk[slot] = d; tot[d] = cw[slot] + cw[CAP + slot] + cw[2 * CAP + slot] + cw[3 * CAP + slot]; }
+			for (uint32_t d = tid; d < D; d += 256) { const uint32_t slot = (uint32_t)sk[d]; rk[slot] = d; bl[slot] = S.len[(uint32_t)(sk[d] >> 33)]; tot[d] = cw[slot] + cw[CAP + slot] + cw[2 * CAP + slot] + cw[3 * CAP + slot]; }
 			__syncthreads();
 			// exclusive scan over the sorted bins of (hits, group starts), packed as starts << 32 | hits; thread t owns bins [t*per, (t+1)*per)
 			const uint32_t per = P >= 256 ? P / 256 : 1, d0 = tid * per; uint64_t mine = 0;
@@ -175,16 +179,22 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 			}
 			__syncthreads();
 			int nbits = 0; while ((1u << nbits) < D) ++nbits;
+			if (S.dbg) tk2 = wall_clock64();
 			uint32_t qc = q_c0;
 			for (uint32_t t0 = c0; t0 < c1; t0 += 256) {
-				uint64_t yv[4]; uint32_t qv[4];
+				uint64_t yv[4], ype[4], yne[4]; uint32_t qv[4], qp[4], qn[4];      // everything a hit needs from memory is requested here, four tiles deep
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
 					const uint32_t x = t0 + u * 64 + lane; const bool act = x < c1; uint32_t q = qc;
 					if (act) { while (HAO_AO(q + 1) <= x) ++q; }
 					qc = (uint32_t)__builtin_amdgcn_readlane((int)q, 63);
 					qv[u] = q;
-					yv[u] = act ? S.sinfo[(HAO_SS(q) & ~(1ULL << 63)) + (x - HAO_AO(q))] : 0;
+					const uint32_t a0 = HAO_AO(q), j = x - a0; const uint64_t ad = (HAO_SS(q) & ~(1ULL << 63)) + j;
+					yv[u] = act ? S.sinfo[ad] : 0;
+					// list neighbours normally sit in the adjacent lanes; only the lanes at a tile / chunk edge fetch theirs
+					ype[u] = (act && lane == 0 && j > 0) ? S.sinfo[ad - 1] : ~0ULL;
+					yne[u] = (act && (lane == 63 || x + 1 == c1) && j + 1 < HAO_AO(q + 1) - a0) ? S.sinfo[ad + 1] : ~0ULL;
+					qp[u] = S.q_pos[li0 + q]; qn[u] = S.q_cnt[li0 + q];
 				}
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
@@ -193,14 +203,21 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 					const uint32_t tidk = hao_info_rid(y), rev = zrev ^ hao_info_rev(y), kk = tidk << 1 | rev;
 					const bool inr = x < c1 && kk >= lo && kk < hi;
 					// list neighbours: from the adjacent lanes when they hold the same minimizer, else (tile edges) from memory
-					const uint32_t t_up = hao_info_rid(__shfl_up(y, 1)), t_dn = hao_info_rid(__shfl_down(y, 1));
-					const bool s_up = lane > 0 && __shfl_up(q, 1) == q, s_dn = lane < 63 && x + 1 < c1 && __shfl_down(q, 1) == q;
+					// target of the previous / next entry of my list (0xffffffff: none): lane - 1 / lane + 1 hold them unless they belong to another
+					// minimizer (then I am the first / last entry of my list) or I sit at a tile / chunk edge (fetched above)
+					const uint32_t yt = hao_info_rid(y);
+					uint32_t t_up = hao_wave_shr1(yt, 0u), t_dn = (uint32_t)__shfl_down((int)yt, 1);             // cross-lane moves: all lanes, before any branch
+					const uint32_t q_up = hao_wave_shr1(q, 0xffffffffu), q_dn = (uint32_t)__shfl_down((int)q, 1);
+					if (lane == 0) t_up = ype[u] == ~0ULL ? 0xffffffffu : hao_info_rid(ype[u]);
+					else if (q_up != q) t_up = 0xffffffffu;
+					if (lane == 63 || x + 1 >= c1) t_dn = yne[u] == ~0ULL ? 0xffffffffu : hao_info_rid(yne[u]);
+					else if (q_dn != q) t_dn = 0xffffffffu;
 					if (inr && rev) {
 						// opposite-strand hits of one k-mer in one target must come out by DEscending target position (ascending other_off,
 						// anchor.cpp:1023): inside the (rare) run of list entries with the same target, the anchor at rev position k takes the
 						// record of rev entry R-1-k
 						const uint32_t a0 = HAO_AO(q), nl = HAO_AO(q + 1) - a0, j = x - a0;
-						const bool pv = j > 0 && (s_up ? t_up : hao_info_rid(S.sinfo[st + j - 1])) == tidk, nx = j + 1 < nl && (s_dn ? t_dn : hao_info_rid(S.sinfo[st + j + 1])) == tidk;
+						const bool pv = t_up == tidk, nx = t_dn == tidk;
 						if (pv || nx) {
 							uint32_t ja = j, jb = j;
 							while (ja > 0 && hao_info_rid(S.sinfo[st + ja - 1]) == tidk) --ja;
@@ -219,8 +236,8 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 					if (inr) {
 						hao_hit_t h; h.w0 = tidk | rev << 31;
 						// k_mer_hit::offset (anchor.cpp:1021-1023,1059-1064): target coordinate in the strand of the hit
-						h.offset = rev ? S.len[tidk] - 1 - (hao_info_pos(y) + 1 - hao_info_span(y)) : hao_info_pos(y);
-						h.self_offset = S.q_pos[li0 + q]; h.cnt = S.q_cnt[li0 + q];
+						h.offset = rev ? bl[slot] - 1 - (hao_info_pos(y) + 1 - hao_info_span(y)) : hao_info_pos(y);
+						h.self_offset = qp[u]; h.cnt = qn[u];
 						S.hits[s + base + __popcll(m & ((1ULL << lane) - 1))] = h;
 					}
 					if (inr && (m & ((1ULL << lane) - 1)) == 0) cw[wv * CAP + slot] = base + __popcll(m);
@@ -234,6 +251,7 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 		lo = hi;
 	}
 	if (tid == 0) S.g_cnt[r] = ngr;
+	if (S.dbg && tid == 0) { const unsigned long long tk3 = wall_clock64(); atomicAdd(S.dbg, tk1 - tk0); atomicAdd(S.dbg + 1, tk2 - tk1); atomicAdd(S.dbg + 2, tk3 - tk2); atomicAdd(S.dbg + 3, 1ULL); }
 #undef HAO_AO
 #undef HAO_SS
 }
