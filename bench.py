@@ -196,15 +196,18 @@ def main():
         dom = max(kern_stage, key=lambda k: stage_ms.get(kern_stage[k], 0.0))
         unit, bpu = ALG[dom]
         units = rs.total_bases if unit == "base" else tot["seed_hits"]
-        n_launch = 1 if unit == "base" else max(1, (n_reads + bsz - 1) // bsz)
-        k_ms = stage_ms.get(kern_stage[dom], 0.0) / n_launch
-        alg_bytes = bpu * units / n_launch
+        n_batches = 1 if unit == "base" else max(1, (n_reads + bsz - 1) // bsz)
+        # per batch: all launches of the kernel in one batch count as one "launch" (chain_group_kernel runs once per size class,
+        # seed_bin_kernel once per bin-table size); the stage time brackets exactly those launches
+        k_ms = stage_ms.get(kern_stage[dom], 0.0) / n_batches
+        alg_bytes = bpu * units / n_batches
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
             if pj.get("workload") == a.workload and world == 1:
-                traffic = pj["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+                tt = [v["hbm_bytes_per_launch"] * v["launches"] for k, v in pj["kernels"].items() if k.split("<")[0] == dom]
+                traffic = int(sum(tt) / max(1, pj.get("batches", 1))) if tt else None
         except Exception:
             pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

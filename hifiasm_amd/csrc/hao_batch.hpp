@@ -17,7 +17,7 @@ struct hao_ctx::Batch {
 	DevBuf<hao_chain_rec> rec; DevBuf<hao_ovlp_t> ol, ol_out;
 	// host copies for fetch
 	std::vector<uint64_t> h_seg, h_fin_off, h_cl_off, h_fc_out_off; std::vector<hao_hit_t> h_hits, h_cl; std::vector<hao_ovlp_t> h_ol; std::vector<uint64_t> h_fc;
-	std::vector<uint64_t> fetch_fc_off;
+	std::vector<uint64_t> fetch_fc_off, h_cco;
 	void release() {
 		if (side_ready) { for (int x = 0; x < HAO_NCLS; ++x) { (void)hipStreamDestroy(side[x]); (void)hipEventDestroy(ev_qc[x]); (void)hipEventDestroy(ev_dp[x]); } side_ready = false; }
 		s_start.release(); a_off.release(); seg.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
@@ -171,18 +171,10 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	hipLaunchKernelGGL(hao_fclen_kernel, dim3((unsigned)((G * HAO_MCOPY_MAX + 256) / 256)), dim3(256), 0, c->stream, B.rec.p, B.nch.p, G, B.nch64.p);
 	HAO_CHECK_LAUNCH();
 	if (int rc = hao_excl_scan_u64(c, B.nch64.p, B.fc_base.p, G * HAO_MCOPY_MAX + 1)) return rc;
-	HIP_TRY(hipMemcpyAsync(&B.n_chains, B.ch_base.p + G, 8, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipMemcpyAsync(&B.n_cl, B.cl_base.p + G, 8, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipMemcpyAsync(&B.n_fc_raw, B.fc_base.p + G * HAO_MCOPY_MAX, 8, hipMemcpyDeviceToHost, c->stream));
-	unsigned long long slow_st[HAO_NCLS + 4];
-	HIP_TRY(hipMemcpyAsync(slow_st, d_slow_cnt, (HAO_NCLS + 4) * 8, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));
-	B.n_generic = 0; for (int x = 0; x < HAO_NCLS; ++x) B.n_generic += slow_st[x];
-	B.n_generic_hits = slow_st[HAO_NCLS];
-	if (getenv("HAO_DBG_DP_STATS")) { fprintf(stderr, "[dp] slow groups by class:"); for (int x = 0; x < HAO_NCLS; ++x) fprintf(stderr, " %llu/%llu", slow_st[x], cls_cnt[x]);
-		fprintf(stderr, "  hits %llu  dp range %llu  spec-committed %llu  spec-failures %llu\n", slow_st[HAO_NCLS], slow_st[HAO_NCLS + 3], slow_st[HAO_NCLS + 1], slow_st[HAO_NCLS + 2]); }
-	const uint64_t NC = B.n_chains;
-	HIP_TRY(B.ol.reserve(NC + 1)); HIP_TRY(B.ol_fc_off.reserve(NC + 1)); HIP_TRY(B.cl.reserve(B.n_cl + 1)); HIP_TRY(B.fc_raw.reserve(B.n_fc_raw + 1)); HIP_TRY(B.perm.reserve(NC + 1));
+	// no host round trip here: the buffers downstream are sized by bounds known from G and A (<= 3 chains per group, chained hits <= seed
+	// hits, fake-cigar entries <= hits + 6 per group); the exact totals are read back once, after the last kernel
+	const uint64_t NCmax = G * HAO_MCOPY_MAX, FCmax = A + 6 * G;
+	HIP_TRY(B.ol.reserve(NCmax + 1)); HIP_TRY(B.ol_fc_off.reserve(NCmax + 1)); HIP_TRY(B.cl.reserve(A + 1)); HIP_TRY(B.fc_raw.reserve(FCmax + 1)); HIP_TRY(B.perm.reserve(NCmax + 1));
 	if (G) {
 		hao_asm_args aa;
 		aa.g_start = B.g_start.p; aa.g_read = B.g_read.p; aa.g_off = B.g_off.p; aa.n_groups = G; aa.rid_lo = glo; aa.ohits = B.ohits.p; aa.hits = B.hits.p; aa.fcs = B.fcs.p; aa.rec = B.rec.p; aa.nch = B.nch.p;
@@ -193,14 +185,14 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	c->timer.mark("q_assemble");
 	// Q8 selection
 	{
-		std::vector<uint64_t> cco(n + 1); uint64_t o = 0;
+		std::vector<uint64_t> &cco = B.h_cco; cco.resize(n + 1); uint64_t o = 0;      // (kept in the batch: the upload is asynchronous)
 		for (uint64_t r = 0; r < n; ++r) { cco[r] = o; o += c->h_len_all[glo + r] / par.ocv_w + 2; }
 		cco[n] = o;
 		HIP_TRY(B.cc_off.reserve(n + 1)); HIP_TRY(B.cc.reserve(o + 1)); HIP_TRY(B.n_final.reserve(n + 2)); HIP_TRY(B.fc_final.reserve(n + 2));
 		HIP_TRY(B.fin_off.reserve(n + 2)); HIP_TRY(B.fcf_off.reserve(n + 2));
 		HIP_TRY(hipMemcpyAsync(B.cc_off.p, cco.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-		HIP_TRY(hipStreamSynchronize(c->stream));
 	}
+	const uint64_t NC = NCmax;
 	HIP_TRY(B.key_xs.reserve(NC + 1)); HIP_TRY(B.key_sc.reserve(NC + 1)); HIP_TRY(B.key_al.reserve(NC + 1));
 	hao_sel_args sa;
 	HIP_TRY(B.key_tmp.reserve(5 * NC + 8));
@@ -214,15 +206,24 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	HAO_CHECK_LAUNCH();
 	if (int rc = hao_scan_u32(c, B.n_final.p, B.fin_off.p, n + 1)) return rc;
 	if (int rc = hao_excl_scan_u64(c, B.fc_final.p, B.fcf_off.p, n + 1)) return rc;
-	HIP_TRY(hipMemcpyAsync(&B.n_ol, B.fin_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipMemcpyAsync(&B.n_fc, B.fcf_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));
 	c->timer.mark("q_select");
-	HIP_TRY(B.ol_out.reserve(B.n_ol + 1)); HIP_TRY(B.fc_out.reserve(B.n_fc + 1)); HIP_TRY(B.fc_out_off.reserve(B.n_ol + 2));
+	HIP_TRY(B.ol_out.reserve(NCmax + 1)); HIP_TRY(B.fc_out.reserve(FCmax + 1)); HIP_TRY(B.fc_out_off.reserve(NCmax + 2));
 	hipLaunchKernelGGL(chain_final_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, B.ol.p, B.ol_fc_off.p, B.fc_raw.p, B.perm.p, B.g_off.p, B.ch_base.p,
 					   B.fin_off.p, B.fcf_off.p, n, B.ol_out.p, B.fc_out.p, B.fc_out_off.p);
 	HAO_CHECK_LAUNCH();
 	c->timer.mark("q_final");
+	HIP_TRY(hipMemcpyAsync(&B.n_chains, B.ch_base.p + G, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipMemcpyAsync(&B.n_cl, B.cl_base.p + G, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipMemcpyAsync(&B.n_fc_raw, B.fc_base.p + G * HAO_MCOPY_MAX, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipMemcpyAsync(&B.n_ol, B.fin_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipMemcpyAsync(&B.n_fc, B.fcf_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
+	unsigned long long slow_st[HAO_NCLS + 4];
+	HIP_TRY(hipMemcpyAsync(slow_st, d_slow_cnt, (HAO_NCLS + 4) * 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	B.n_generic = 0; for (int x = 0; x < HAO_NCLS; ++x) B.n_generic += slow_st[x];
+	B.n_generic_hits = slow_st[HAO_NCLS];
+	if (getenv("HAO_DBG_DP_STATS")) { fprintf(stderr, "[dp] slow groups by class:"); for (int x = 0; x < HAO_NCLS; ++x) fprintf(stderr, " %llu/%llu", slow_st[x], cls_cnt[x]);
+		fprintf(stderr, "  hits %llu  dp range %llu  spec-committed %llu  spec-failures %llu\n", slow_st[HAO_NCLS], slow_st[HAO_NCLS + 3], slow_st[HAO_NCLS + 1], slow_st[HAO_NCLS + 2]); }
 	B.valid = true;
 	return HAO_OK;
 }

@@ -748,7 +748,13 @@ __global__ __launch_bounds__(256) void chain_assemble_kernel(hao_asm_args A)
 			o.shared_seed = rc.score; o.align_length = rc.n_hits; o.non_homopolymer_errors = (uint32_t)(hd - cl0); o.fc_len = rc.fc_len;
 			A.ol[oi] = o; A.ol_fc_off[oi] = fd;
 		}
-		for (uint32_t i = hao_lane(); i < rc.n_hits; i += 64) { hao_hit_t h = src[i]; h.w0 = (h.w0 & 0x80000000u) | (ord & 0x7fffffffu); A.cl[hd + i] = h; }
+		for (uint32_t i = hao_lane(); i < rc.n_hits; i += 256) {       // four 16-byte loads in flight per lane
+			hao_hit_t h4[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) if (i + u * 64 < rc.n_hits) h4[u] = src[i + u * 64];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) if (i + u * 64 < rc.n_hits) { h4[u].w0 = (h4[u].w0 & 0x80000000u) | (ord & 0x7fffffffu); A.cl[hd + i + u * 64] = h4[u]; }
+		}
 		for (uint32_t i = hao_lane(); i < rc.fc_len; i += 64) A.fc[fd + i] = fsrc[rc.fc_rel + i];
 	}
 }
