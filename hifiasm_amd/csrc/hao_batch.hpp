@@ -153,7 +153,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			if (ca.dbg_skip_generic) continue;
 			hipStream_t ds = serial ? c->stream : B.side[x];
 			if (!serial) { HIP_TRY(hipEventRecord(B.ev_qc[x], c->stream)); HIP_TRY(hipStreamWaitEvent(ds, B.ev_qc[x], 0)); }
-			if (x <= 1) hipLaunchKernelGGL((chain_dp_kernel<128, true>), dim3((unsigned)std::min<uint64_t>(nl, 256 * 24)), dim3(64), 0, ds, ca, lst, slow, d_slow_cnt + x);
+			if (x <= 1) hipLaunchKernelGGL(chain_dp128_kernel, dim3((unsigned)std::min<uint64_t>(nl, 256 * 16)), dim3(64), 0, ds, ca, lst, slow, d_slow_cnt + x);
 			else if (x <= 3) hipLaunchKernelGGL((chain_dp_kernel<512, true>), dim3((unsigned)std::min<uint64_t>(nl, 256 * 8)), dim3(64), 0, ds, ca, lst, slow, d_slow_cnt + x);
 			else hipLaunchKernelGGL((chain_dp_kernel<HAO_DP_CAP, false>), dim3((unsigned)std::min<uint64_t>(nl, 256 * 3)), dim3(64), 0, ds, ca, lst, slow, d_slow_cnt + x);
 			HAO_CHECK_LAUNCH();
@@ -199,10 +199,13 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	sa.key_xs = B.key_xs.p; sa.key_sc = B.key_sc.p; sa.key_al = B.key_al.p; sa.key_tmp = B.key_tmp.p;
 	sa.ol = B.ol.p; sa.g_off = B.g_off.p; sa.ch_base = B.ch_base.p; sa.cl_base = B.cl_base.p; sa.cl = B.cl.p; sa.n_sel = n; sa.rid_lo = glo; sa.len = c->d_len_all.p; sa.cc_off = B.cc_off.p; sa.cc = B.cc.p;
 	sa.perm = B.perm.p; sa.n_final = B.n_final.p; sa.fc_final = B.fc_final.p; sa.max_n_chain = par.max_n_chain; sa.ocv_w = par.ocv_w; sa.chain_cutoff = par.chain_cutoff;
-	// two launches split by chain count: the common reads (<= 128 chains) need 5 KB of LDS per wave and fill the CUs, the rest take the 1024-chain slice
+	// three launches split by chain count: the common reads (<= 128 chains) need 5 KB of LDS per wave and fill the CUs; 512- and 1024-chain slices for
+	// repeat-rich reads (beyond 1024 chains the keys stay in global scratch)
 	hipLaunchKernelGGL((chain_select_kernel<1, 128>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)0, (int64_t)129);
 	HAO_CHECK_LAUNCH();
-	hipLaunchKernelGGL((chain_select_kernel<1, 1024>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)129, (int64_t)INT64_MAX);
+	hipLaunchKernelGGL((chain_select_kernel<1, 512>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)129, (int64_t)513);
+	HAO_CHECK_LAUNCH();
+	hipLaunchKernelGGL((chain_select_kernel<1, 1024>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)513, (int64_t)INT64_MAX);
 	HAO_CHECK_LAUNCH();
 	if (int rc = hao_scan_u32(c, B.n_final.p, B.fin_off.p, n + 1)) return rc;
 	if (int rc = hao_excl_scan_u64(c, B.fc_final.p, B.fcf_off.p, n + 1)) return rc;

@@ -702,7 +702,7 @@ __device__ __forceinline__ void hao_dp_body(const hao_chain_args &A, const hao_g
 }
 
 template<int CAP, bool STAGE>
-__global__ __launch_bounds__(64) void chain_dp_kernel(hao_chain_args A, const hao_gent *list, const uint32_t *slow, const unsigned long long *slow_cnt)
+__device__ __forceinline__ void hao_dp_kernel_body(const hao_chain_args &A, const hao_gent *list, const uint32_t *slow, const unsigned long long *slow_cnt)
 {
 	__shared__ int32_t l_f[CAP], l_p[CAP], l_tm[CAP], l_ii[CAP]; __shared__ int64_t l_t[CAP]; __shared__ hao_hit_t l_a[STAGE ? CAP : 1];
 	__shared__ uint32_t l_cn[8]; __shared__ hao_chain_rec l_rec[HAO_MCOPY_MAX];
@@ -716,6 +716,14 @@ __global__ __launch_bounds__(64) void chain_dp_kernel(hao_chain_args A, const ha
 		HAO_WAVE_FENCE();
 	}
 }
+
+template<int CAP, bool STAGE>
+__global__ __launch_bounds__(64) void chain_dp_kernel(hao_chain_args A, const hao_gent *list, const uint32_t *slow, const unsigned long long *slow_cnt)
+{ hao_dp_kernel_body<CAP, STAGE>(A, list, slow, slow_cnt); }
+// groups of up to 128 hits: 5 KB of LDS per wave, so registers bound the occupancy - trade a few spills for twice the waves per SIMD
+// (many small slow groups on repeat-rich reads; the DP is latency-bound)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void chain_dp128_kernel(hao_chain_args A, const hao_gent *list, const uint32_t *slow, const unsigned long long *slow_cnt)
+{ hao_dp_kernel_body<128, true>(A, list, slow, slow_cnt); }
 
 // ---------------------------------------------------------------------------------------
 // Assembly: per group, materialise overlap records (creation order), chained hits (tagged with

@@ -1,0 +1,27 @@
+"""Summarise the two rocprofv3 --pmc passes of tools/pmc.sh into per-kernel HBM bytes per launch.
+hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE tallies 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md, HBM section);
+WRITE_SIZE is taken as reported (uncalibrated)."""
+import csv, glob, json, re, sys
+root = sys.argv[1]; args = sys.argv[2:]
+wl = "bacterial5M_hifi30x"
+if "--workload" in args: wl = args[args.index("--workload") + 1]
+acc = {}
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(f"{root}/{ctr}/**/*counter_collection.csv", recursive=True):
+        disp = {}
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != ctr: continue
+            name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").strip()
+            name = re.sub(r"<.*", "", name) if name.startswith("rocprim") or "rocprim::" in name else name
+            key = (name, r["Dispatch_Id"])
+            disp[key] = disp.get(key, 0.0) + float(r["Counter_Value"])      # sum over XCD / channel instances of one dispatch
+        for (name, _), v in disp.items():
+            a = acc.setdefault(name, {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
+            a[ctr][0] += v; a[ctr][1] += 1
+out = {"workload": wl, "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline " + " ".join(args),
+       "note": __doc__.strip().split("\n", 1)[1].strip(), "kernels": {}}
+for name, a in acc.items():
+    n = max(a["FETCH_SIZE"][1], a["WRITE_SIZE"][1], 1)
+    fk = a["FETCH_SIZE"][0] / max(a["FETCH_SIZE"][1], 1); wk = a["WRITE_SIZE"][0] / max(a["WRITE_SIZE"][1], 1)
+    out["kernels"][name] = {"launches": n, "FETCH_SIZE_KB_per_launch": round(fk, 1), "WRITE_SIZE_KB_per_launch": round(wk, 1), "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+print(json.dumps(out, indent=1))
