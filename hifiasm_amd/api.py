@@ -27,7 +27,7 @@ class HaoError(RuntimeError):
 class Opt(C.Structure):
     _fields_ = [("k", C.c_int32), ("w", C.c_int32), ("hpc", C.c_int32), ("sample_dist", C.c_int32), ("rewin", C.c_int32),
                 ("min_hist_cnt", C.c_int32), ("max_kmer_cnt", C.c_int32), ("max_n_chain", C.c_int32),
-                ("high_factor", C.c_double), ("is_ont", C.c_int32), ("reserved", C.c_int32)]
+                ("high_factor", C.c_double), ("is_ont", C.c_int32), ("bf_shift", C.c_int32)]
 
 
 ABI_SYMBOLS = [

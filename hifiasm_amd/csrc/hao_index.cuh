@@ -164,3 +164,45 @@ __device__ __forceinline__ uint32_t hao_pt_lookup(const hao_pt_dev &pt, uint64_t
 	if (lo < e && pt.keys[lo] == x) { *start = pt.start[lo]; return pt.cnt[lo]; }
 	return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------
+// Bloom filter in front of the k-mer count table (ha_ft_gen at -f > 0): yak_bf_insert (htab.cpp:99-116) behind
+// ha_ct_insert_list (htab.cpp:181-214).  One filter of 2^(bf_shift-12) bits per sub-table (sub-table = low 12 hash bits), 512-bit
+// blocks, 4 probes inside ONE block; an occurrence reaches the count table only if all its probe bits were already set.
+// The outcome depends on the order of insertion, which the reference fixes: per sub-table, global (read, position) order.  A block
+// is touched only by the k-mers that map to it, so the exact result is a per-block sequential replay: sort the occurrences by
+// block id (stable: keeps the (read, position) order inside a block), then one lane replays each block with its 512 bits in LDS.
+// The 2^(bf_shift-3)-byte filter itself (16 GB at the default -f37) is never materialised.
+// ---------------------------------------------------------------------------------------
+// block id of a k-mer hash: sub-table << xb | (hash >> 12) & (2^xb - 1), xb = bf_shift - 21; sentinels (slots of N reads) sort last
+__global__ void hao_bf_block_kernel(const uint64_t *kh, uint64_t n, int xb, uint32_t *blk)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint64_t h = kh[i];
+	blk[i] = h == UINT64_MAX ? 1u << (12 + xb) : (uint32_t)((h & 4095) << xb | ((h >> 12) & ((1ULL << xb) - 1)));
+}
+
+// one lane per block run of the block-sorted list: flag[i] = 1 iff occurrence i found all four probe bits set
+__global__ __launch_bounds__(256) void hao_bf_replay_kernel(const uint32_t *blk, const uint64_t *kh, uint64_t n, int xb, uint8_t *flag)
+{
+	__shared__ uint32_t st[256][17];
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t b = blk[i];
+	if (b >> (12 + xb)) { flag[i] = 0; return; }             // sentinel
+	if (i > 0 && blk[i - 1] == b) return;                      // not the first occurrence of its block
+	uint32_t *w = st[threadIdx.x];
+#pragma unroll
+	for (int q = 0; q < 16; ++q) w[q] = 0;
+	const int nsh = xb + 9;
+	for (uint64_t j = i; j < n && blk[j] == b; ++j) {
+		const uint64_t x = kh[j] >> 12;
+		int h2 = (int)(x >> nsh & 511), z = (int)(x >> xb & 511), cnt = 0;
+		if ((h2 & 31) == 0) h2 = (h2 + 1) & 511;
+#pragma unroll
+		for (int q = 0; q < 4; ++q, z = (z + h2) & 511) { const uint32_t u = 1u << (z & 31); cnt += (w[z >> 5] & u) != 0; w[z >> 5] |= u; }
+		flag[j] = cnt == 4;
+	}
+}

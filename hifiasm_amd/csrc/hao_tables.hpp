@@ -19,6 +19,11 @@ __global__ void hao_add_const_kernel(uint64_t *v, uint64_t n, uint64_t add)
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) v[i] += add;
 }
+__global__ void hao_add_u32_kernel(uint32_t *v, uint64_t n, uint32_t add)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) v[i] += add;
+}
 __global__ void hao_adjdiff_kernel(const uint64_t *off, uint64_t n, uint64_t *cnt)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -54,7 +59,7 @@ struct RunHead { const uint64_t *k; __host__ __device__ uint64_t operator()(uint
 
 // sort keys, run-length encode, histogram.  in: d_keys[n] (destroyed). out: unique keys / counts in c->d_u_keys / d_u_cnt, n_unique.
 struct hao_rle_out { uint64_t n_unique; };
-static int hao_sort_rle_hist(hao_ctx *c, uint64_t *d_keys, uint64_t *d_keys_alt, uint64_t n, DevBuf<uint64_t> &ukeys, DevBuf<uint32_t> &ucnt, uint64_t *n_unique, int64_t hist[HAO_N_COUNTS], uint64_t **sorted_out)
+static int hao_sort_rle_hist(hao_ctx *c, uint64_t *d_keys, uint64_t *d_keys_alt, uint64_t n, DevBuf<uint64_t> &ukeys, DevBuf<uint32_t> &ucnt, uint64_t *n_unique, int64_t hist[HAO_N_COUNTS], uint64_t **sorted_out, uint32_t bias = 0)
 {
 	*n_unique = 0; memset(hist, 0, sizeof(int64_t) * HAO_N_COUNTS); *sorted_out = d_keys;
 	if (n == 0) return HAO_OK;
@@ -82,6 +87,7 @@ static int hao_sort_rle_hist(hao_ctx *c, uint64_t *d_keys, uint64_t *d_keys_alt,
 	HIP_TRY(rocprim::run_length_encode(c->d_tmp.p, tb, sorted, n, ukeys.p, ucnt.p, (uint64_t*)c->d_cursor.p, c->stream));
 	HIP_TRY(hipMemcpyAsync(n_unique, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (bias && *n_unique) { hipLaunchKernelGGL(hao_add_u32_kernel, dim3((unsigned)((*n_unique + 255) / 256)), dim3(256), 0, c->stream, ucnt.p, *n_unique, bias); HAO_CHECK_LAUNCH(); }   // table entries start at `bias`
 	DevBuf<unsigned long long> dh; HIP_TRY(dh.reserve(HAO_N_COUNTS));
 	HIP_TRY(hipMemsetAsync(dh.p, 0, HAO_N_COUNTS * 8, c->stream));
 	unsigned nb = (unsigned)std::min<uint64_t>((*n_unique + 255) / 256, 2048);
@@ -132,7 +138,7 @@ static int hao_build_bucket(hao_ctx *c, const uint64_t *keys, uint64_t n, int bi
 }
 
 // ---------------------------------------------------------------------------------------
-// ha_ft_gen at -f0 (htab.cpp:1136-1169): all HPC k-mers -> exact counts -> histogram -> peaks ->
+// ha_ft_gen (htab.cpp:1136-1169): all HPC k-mers -> [Bloom replay at -f > 0, hao_index.cuh] -> counts -> histogram -> peaks ->
 // keep count >= cutoff -> filter table. + ha_opt_update_cov (CommandLines.cpp:411-418).
 // ---------------------------------------------------------------------------------------
 static int hao_ft_run(hao_ctx *c)
@@ -178,10 +184,40 @@ static int hao_ft_run(hao_ctx *c)
 	c->timer.mark("ft_hash");
 	DevBuf<uint64_t> ukeys; DevBuf<uint32_t> ucnt; uint64_t n_unique = 0, *sorted = nullptr;
 	const bool sharded = c->comm && c->comm->active();
+	const bool bloom = c->opt.bf_shift > 12;                   // ha_ct_init: filters only if n_shift > pre (htab.cpp:153)
+	uint64_t n_cnt = n_slots; uint64_t *cnt_in = kh.p, *cnt_alt = kh2.p; uint32_t bias = 0;
+	if (bloom) {
+		const int xb = c->opt.bf_shift - 21;                   // log2 of the 512-bit blocks per sub-table
+		if (xb < 0 || 12 + xb > 31) { hao_set_err(c, "bf_shift must be 0 or 21..40"); return HAO_EUNSUPP; }   // yak_bf_init refuses < 9 bits per sub-table
+		if (sharded) { hao_set_err(c, "Bloom-filtered counting (bf_shift > 0) is not available in sharded mode: the exchange partitions k-mers by high hash bits, the filter blocks by low bits"); return HAO_EUNSUPP; }
+		DevBuf<uint32_t> blk, blk2; DevBuf<uint8_t> flag;
+		HIP_TRY(blk.reserve(n_slots + 1)); HIP_TRY(blk2.reserve(n_slots + 1)); HIP_TRY(flag.reserve(n_slots + 1));
+		uint64_t n_ins = 0;
+		if (n_slots) {
+			hipLaunchKernelGGL(hao_bf_block_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, c->stream, kh.p, n_slots, xb, blk.p);
+			HAO_CHECK_LAUNCH();
+			size_t tb = 0; rocprim::double_buffer<uint32_t> dk(blk.p, blk2.p); rocprim::double_buffer<uint64_t> dv(kh.p, kh2.p);
+			HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, dk, dv, n_slots, 0, 13 + xb, c->stream)); HIP_TRY(hao_tmp(c, tb));
+			HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, dk, dv, n_slots, 0, 13 + xb, c->stream));      // stable: (read, position) order inside a block
+			hipLaunchKernelGGL(hao_bf_replay_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, c->stream, dk.current(), dv.current(), n_slots, xb, flag.p);
+			HAO_CHECK_LAUNCH();
+			// occurrences that reach the count table, compacted into the other buffer
+			HIP_TRY(c->d_cursor.reserve(2));
+			tb = 0;
+			HIP_TRY(rocprim::select(nullptr, tb, dv.current(), flag.p, dv.alternate(), (uint64_t*)c->d_cursor.p, n_slots, c->stream)); HIP_TRY(hao_tmp(c, tb));
+			HIP_TRY(rocprim::select(c->d_tmp.p, tb, dv.current(), flag.p, dv.alternate(), (uint64_t*)c->d_cursor.p, n_slots, c->stream));
+			HIP_TRY(hipMemcpyAsync(&n_ins, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			cnt_in = dv.alternate(); cnt_alt = dv.current();
+		}
+		n_cnt = n_ins; bias = 1;                                  // the entry is created with count 1, then incremented (htab.cpp:201-205)
+		blk.release(); blk2.release(); flag.release();
+		c->timer.mark("ft_bloom");
+	}
 	if (!sharded) {
 		// sentinels (0xff..ff) sort to the end: only the first n_real entries are real k-mers
-		if (int rc = hao_sort_rle_hist(c, kh.p, kh2.p, n_slots, ukeys, ucnt, &n_unique, c->ft_hist, &sorted)) return rc;
-		if (n_real < n_slots && n_unique) { --n_unique; c->ft_hist[std::min<uint64_t>(n_slots - n_real, HAO_MAX_COUNT)] -= 1; }   // drop the sentinel run
+		if (int rc = hao_sort_rle_hist(c, cnt_in, cnt_alt, n_cnt, ukeys, ucnt, &n_unique, c->ft_hist, &sorted, bias)) return rc;
+		if (!bloom && n_real < n_slots && n_unique) { --n_unique; c->ft_hist[std::min<uint64_t>(n_slots - n_real, HAO_MAX_COUNT)] -= 1; }   // drop the sentinel run (the Bloom replay already dropped it)
 	} else {
 		// hash-range partition: sort local hashes, cut at i * 2^64 / world, all-to-all-v, count the owned range
 		hao_comm &cm = *c->comm; const int W = cm.world;

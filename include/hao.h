@@ -47,7 +47,8 @@ typedef struct {
 	int32_t max_n_chain;   /* (CommandLines.cpp:276) default 100; raised like ha_opt_update_cov */
 	double  high_factor;   /* (CommandLines.cpp:271) default 5.0 */
 	int32_t is_ont;        /* --ont: bw_thres 0.05 instead of 0.02 (ecovlp.cpp:3274) */
-	int32_t reserved;
+	int32_t bf_shift;      /* -f (CommandLines.cpp:269, reference default 37): log2 of the Bloom filter bits in front of the k-mer count table of
+	                        * ha_ft_gen (htab.cpp:99-116,140-160,196-206); 0 = exact counting. hao_opt_default sets 0; a shim passes asm_opt.bf_shift */
 } hao_opt_t;
 
 /* ha_mz1_t (htab.h:13-18): info = rid:28 | pos:27 | rev:1 | span:8 (LSB first).
@@ -95,7 +96,8 @@ void *hao_loop_create(int world);
 void hao_loop_destroy(void *grp);
 int hao_dist_init_loopback(hao_ctx *c, void *grp, int rank);
 
-/* ha_ft_gen (htab.cpp:1136-1169) at -f0 + ha_opt_update_cov (CommandLines.cpp:411-418). */
+/* ha_ft_gen (htab.cpp:1136-1169), exact (-f0) or through the reference's blocked Bloom filter (opt.bf_shift > 12, bit-exact incl. its false
+ * positives: see hao_tables.hpp), + ha_opt_update_cov (CommandLines.cpp:411-418). */
 int hao_ft_gen(hao_ctx *c, int32_t *hom_cov);
 /* ha_pt_gen (htab.cpp:1232-1287) + the asm_opt.hom_cov/het_cov update of Assembly.cpp:1007-1008.
  * The index and the per-read minimizers stay resident in HBM. */

@@ -6,6 +6,7 @@
  * order-independent).
  */
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
@@ -69,7 +70,7 @@ uint64_t hao_or_hash64(uint64_t key)
 void hao_or_opt_default(hao_or_opt_t *o)
 {
 	o->k = 51; o->w = 51; o->hpc = 1; o->sample_dist = 500; o->rewin = 1000; o->min_hist_cnt = 5;
-	o->max_kmer_cnt = 2000; o->high_factor = 5.0; o->max_n_chain = 100; o->is_ont = 0;
+	o->max_kmer_cnt = 2000; o->high_factor = 5.0; o->max_n_chain = 100; o->is_ont = 0; o->bf_shift = 0;
 }
 
 /* ------------------------------------------------------------------ */
@@ -202,16 +203,38 @@ int hao_or_analyze_count(int n_cnt, int start_cnt, const int64_t *cnt, int *peak
 
 int hao_or_ft_gen(hao_or_ctx *c)
 {
-	uint64_t tot = c->off[c->n_reads], n = 0, i, j, r; int max_cnt;
+	uint64_t tot = c->off[c->n_reads], n = 0, i, j, r, bias; int max_cnt;
 	uint64_t *h = (uint64_t*)xrealloc(0, (tot + 1) * 8), *tmp;
 	for (r = 0; r < c->n_reads; ++r)
 		n += hao_or_kmer_hashes(c->codes + c->off[r], (int64_t)(c->off[r + 1] - c->off[r]), c->opt.k, c->opt.hpc, h + n);
+	/* Bloom filter in front of the count table (ha_ct_init htab.cpp:140-160, yak_bf_insert :99-116, ha_ct_insert_list :181-214):
+	 * one filter of 2^(bf_shift-12) bits per sub-table (sub-table = low 12 hash bits), 512-bit blocks, 4 probes inside one block.
+	 * A k-mer occurrence reaches the count table only when all its probe bits were already set; the table entry then starts at
+	 * 1 and is incremented, so count = 1 + (occurrences that found all bits set).  k-mers arrive per sub-table in global
+	 * (read, position) order: step 1 of the counting pipeline fills the 4096 buffers read by read, step 2 drains each buffer in
+	 * order, and kt_pipeline keeps blocks ordered (htab.cpp:826-843, 860-880). */
+	bias = 0;
+	if (c->opt.bf_shift > 12) {
+		const int nsh = c->opt.bf_shift - 12, xb = nsh - 9;               /* yak_bf_init(n_shift - pre), YAK_BLK_SHIFT = 9 */
+		const uint64_t blocks = 4096ULL << xb; uint64_t m = 0;
+		uint8_t *bf = (uint8_t*)calloc(blocks, 64);
+		if (xb < 0 || !bf) { fprintf(stderr, "oracle: unsupported bf_shift %d\n", c->opt.bf_shift); abort(); }
+		for (i = 0; i < n; ++i) {
+			const uint64_t x = h[i] >> 12, y = x & ((1ULL << xb) - 1);
+			int h1 = (int)(x >> xb & 511), h2 = (int)(x >> nsh & 511), z = h1, q, cnt = 0;
+			uint8_t *p = bf + (((h[i] & 4095) << xb | y) << 6);
+			if ((h2 & 31) == 0) h2 = (h2 + 1) & 511;
+			for (q = 0; q < 4; ++q, z = (z + h2) & 511) { const uint8_t u = (uint8_t)(1 << (z & 7)); cnt += !!(p[z >> 3] & u); p[z >> 3] |= u; }
+			if (cnt == 4) h[m++] = h[i];
+		}
+		free(bf); n = m; bias = 1;
+	}
 	tmp = (uint64_t*)xrealloc(0, (n + 1) * 8);
 	if (n) sort_u64(h, n, tmp);
 	memset(c->ft_hist, 0, sizeof(c->ft_hist));
 	for (i = 0; i < n; i = j) {
 		for (j = i + 1; j < n && h[j] == h[i]; ++j) {}
-		++c->ft_hist[j - i > MAX_COUNT ? MAX_COUNT : j - i];
+		++c->ft_hist[j - i + bias > MAX_COUNT ? MAX_COUNT : j - i + bias];
 	}
 	c->ft_peak_hom = hao_or_analyze_count(N_COUNTS, c->opt.min_hist_cnt, c->ft_hist, &c->ft_peak_het);
 	c->ft_cutoff = (int)(c->ft_peak_hom * c->opt.high_factor);            /* htab.cpp:1160 */
@@ -226,14 +249,14 @@ int hao_or_ft_gen(hao_or_ctx *c)
 		for (i = 0; i < n; i = j) {
 			int64_t cnt;
 			for (j = i + 1; j < n && h[j] == h[i]; ++j) {}
-			cnt = j - i > MAX_COUNT ? MAX_COUNT : (int64_t)(j - i);
+			cnt = j - i + bias > MAX_COUNT ? MAX_COUNT : (int64_t)(j - i + bias);
 			if (cnt >= c->ft_cutoff) ++m;
 		}
 		c->ft_keys = (uint64_t*)xrealloc(0, (m + 1) * 8); c->ft_vals = (int32_t*)xrealloc(0, (m + 1) * 4);
 		for (i = 0, m = 0; i < n; i = j) {
 			int64_t cnt;
 			for (j = i + 1; j < n && h[j] == h[i]; ++j) {}
-			cnt = j - i > MAX_COUNT ? MAX_COUNT : (int64_t)(j - i);
+			cnt = j - i + bias > MAX_COUNT ? MAX_COUNT : (int64_t)(j - i + bias);
 			if (cnt >= c->ft_cutoff) {
 				c->ft_keys[m] = h[i];
 				c->ft_vals[m] = cnt > max_cnt ? INT32_MAX : (int32_t)cnt;    /* INT16_MAX in the map -> INT32_MAX from ha_ft_cnt */

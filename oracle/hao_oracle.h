@@ -42,6 +42,7 @@ typedef struct {
 	double high_factor;       /* 5.0 (CommandLines.cpp:271) */
 	int max_n_chain;          /* 100 (CommandLines.cpp:276); raised by ha_opt_update_cov */
 	int is_ont;               /* bw_thres 0.05 instead of 0.02 (ecovlp.cpp:3274) */
+	int bf_shift;             /* -f: log2 of the Bloom filter bits in front of the k-mer count table (CommandLines.cpp:269 default 37); 0 = exact counting */
 } hao_or_opt_t;
 
 typedef struct hao_or_ctx hao_or_ctx;

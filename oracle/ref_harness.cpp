@@ -73,22 +73,23 @@ static tbuf_t *tbuf_init(int n)
 
 int main(int argc, char *argv[])
 {
-	int n_thread = 1, is_ont = 0, do_time = 0, dump_hits = 1, k = -1, w = -1; const char *fa = 0; std::string prefix;
+	int n_thread = 1, is_ont = 0, do_time = 0, dump_hits = 1, k = -1, w = -1, bf_shift = 0; const char *fa = 0; std::string prefix;
 	for (int i = 1; i < argc; ++i) {
 		if (!strcmp(argv[i], "--ont")) is_ont = 1;
 		else if (!strcmp(argv[i], "-t")) n_thread = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-k")) k = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-w")) w = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-f")) bf_shift = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "--dump")) prefix = argv[++i];
 		else if (!strcmp(argv[i], "--time")) do_time = 1;
 		else if (!strcmp(argv[i], "--nodump-hits")) dump_hits = 0;
 		else fa = argv[i];
 	}
-	if (!fa) { fprintf(stderr, "usage: ref_harness [--ont] [-t N] [-k K] [-w W] [--dump PREFIX] [--time] reads.fa\n"); return 1; }
-	// the reference's own option parser, with -f0 (exact counting; SURVEY 7 "Bloom")
-	std::vector<std::string> av; char tb[32], kb[32], wb[32];
+	if (!fa) { fprintf(stderr, "usage: ref_harness [--ont] [-t N] [-k K] [-w W] [-f BLOOM_BITS] [--dump PREFIX] [--time] reads.fa\n"); return 1; }
+	// the reference's own option parser; -f0 (exact counting) unless -f is given (hifiasm's own default is -f37: 16 GB of Bloom filter)
+	std::vector<std::string> av; char tb[32], kb[32], wb[32], fb[32];
 	av.push_back("hifiasm"); av.push_back("-o"); av.push_back(prefix.empty()? std::string("/tmp/ref_harness_out") : prefix);
-	snprintf(tb, 32, "%d", n_thread); av.push_back("-t"); av.push_back(tb); av.push_back("-f0");
+	snprintf(tb, 32, "%d", n_thread); av.push_back("-t"); av.push_back(tb); snprintf(fb, 32, "-f%d", bf_shift); av.push_back(fb);
 	if (k > 0) { snprintf(kb, 32, "%d", k); av.push_back("-k"); av.push_back(kb); }
 	if (w > 0) { snprintf(wb, 32, "%d", w); av.push_back("-w"); av.push_back(wb); }
 	if (is_ont) av.push_back("--ont");

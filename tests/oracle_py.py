@@ -17,7 +17,7 @@ _LIB = None
 class Opt(C.Structure):
     _fields_ = [("k", C.c_int), ("w", C.c_int), ("hpc", C.c_int), ("sample_dist", C.c_int), ("rewin", C.c_int),
                 ("min_hist_cnt", C.c_int), ("max_kmer_cnt", C.c_int), ("high_factor", C.c_double),
-                ("max_n_chain", C.c_int), ("is_ont", C.c_int)]
+                ("max_n_chain", C.c_int), ("is_ont", C.c_int), ("bf_shift", C.c_int)]
 
 
 def lib():

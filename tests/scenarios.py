@@ -14,6 +14,11 @@ SCENARIOS = {
     "nn":    (dict(genome_size=40_000, coverage=18, read_len=4000, err=0.002, seed=7, len_jit=1000, n_rate=0.0008), {}),
     "low":   (dict(genome_size=40_000, coverage=3, read_len=4000, err=0.002, seed=8), {}),
     "k40":   (dict(genome_size=40_000, coverage=18, read_len=4000, err=0.002, seed=10), dict(k=40, w=30)),
+    # Bloom filter in front of the k-mer counts (-f; hifiasm's default is -f37): 2^24 bits = 8 blocks per sub-table here, so false
+    # positives (over-counted k-mers, singletons that enter the table) are frequent; repeat-rich so that the filter table is not empty
+    "bf24":  (dict(genome_size=100_000, coverage=12, read_len=4000, err=0.001, seed=12, repeat_rich=2, len_jit=1000), dict(bf_shift=24)),
+    # 2 blocks per sub-table: the filter saturates, most k-mers are counted one too many and the peaks move
+    "bf22":  (dict(genome_size=60_000, coverage=14, read_len=4000, err=0.002, seed=13, repeat_rich=1, len_jit=1000), dict(bf_shift=22)),
 }
 
 # larger sets used only by the GPU parity tests (oracle vs HIP, no golden file): enough repeat content to push

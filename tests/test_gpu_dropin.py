@@ -1,6 +1,6 @@
 """End-to-end drop-in check (BASELINE.json configs[0], "plumbing"): the UNMODIFIED reference executable
 vs the same objects with ha_ft_gen / ha_pt_gen / h_ec_lchain (+ accessors) served by libhao.so through
-integration/hao_hifiasm_shim.cpp.  Both run `-f0 --bin-only`; the three bins must agree:
+integration/hao_hifiasm_shim.cpp.  Both run `--bin-only` at `-f0` and with a Bloom pre-filter (`-f26`); the three bins must agree:
 *.ovlp.source.bin and *.ovlp.reverse.bin byte for byte, *.ec.bin except the reference's own uninitialised
 bytes: the pad byte at read_sperate[i][len/4] when len % 4 == 0 and the never-written
 tail of name_index[] beyond total_reads+1 entries.
@@ -46,14 +46,15 @@ def _ec_mask(buf):
 
 
 @pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(HAO)), reason="reference binaries not built")
-def test_bins_identical():
+@pytest.mark.parametrize("bf", ["-f0", "-f26"])      # exact counting / the Bloom pre-filter (2^26 bits instead of the default 2^37: same code, 8 KB instead of 16 GB)
+def test_bins_identical(bf):
     from hifiasm_amd import synth
     rs = synth.dataset(genome_size=300_000, coverage=30, read_len=12000, err=0.001, seed=42, len_jit=3000)
     d = tempfile.mkdtemp(prefix="hao_dropin_")
     fa = os.path.join(d, "reads.fa")
     synth.write_fasta(fa, rs)
     for exe, tag in ((REF, "ref"), (HAO, "hao")):
-        r = subprocess.run([exe, "-o", os.path.join(d, tag), "-t", "8", "-f0", "--bin-only", fa], capture_output=True, text=True, cwd=d)
+        r = subprocess.run([exe, "-o", os.path.join(d, tag), "-t", "8", bf, "--bin-only", fa], capture_output=True, text=True, cwd=d)
         assert r.returncode == 0, f"{tag} failed: {r.stderr[-1500:]}"
     for ext in ("ovlp.source.bin", "ovlp.reverse.bin"):
         a = open(os.path.join(d, f"ref.{ext}"), "rb").read()
