@@ -14,6 +14,15 @@ __global__ void hao_lower_bound_kernel(const uint64_t *keys, uint64_t n, const u
 	while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (keys[m] < x) lo = m + 1; else hi = m; }
 	out[t] = lo;
 }
+// same on the low 12 bits (keys sorted by sub-table)
+__global__ void hao_lower_bound_low12_kernel(const uint64_t *keys, uint64_t n, const uint64_t *targets, int nt, uint64_t *out)
+{
+	int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nt) return;
+	uint64_t lo = 0, hi = n, x = targets[t];
+	while (lo < hi) { uint64_t m = (lo + hi) >> 1; if ((keys[m] & 4095) < x) lo = m + 1; else hi = m; }
+	out[t] = lo;
+}
 __global__ void hao_add_const_kernel(uint64_t *v, uint64_t n, uint64_t add)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -55,6 +64,7 @@ static int hao_prepare_runs(hao_ctx *c, uint64_t lo, uint64_t hi, bool force_sca
 	return HAO_OK;
 }
 
+struct NotSentinel { __host__ __device__ bool operator()(const uint64_t &h) const { return h != UINT64_MAX; } };
 struct RunHead { const uint64_t *k; __host__ __device__ uint64_t operator()(uint64_t i) const { return (i == 0 || k[i] != k[i - 1]) ? 1 : 0; } };
 
 // sort keys, run-length encode, histogram.  in: d_keys[n] (destroyed). out: unique keys / counts in c->d_u_keys / d_u_cnt, n_unique.
@@ -137,6 +147,33 @@ static int hao_build_bucket(hao_ctx *c, const uint64_t *keys, uint64_t n, int bi
 	return HAO_OK;
 }
 
+// Bloom replay (hao_index.cuh): in[n] = k-mer hashes in insertion order (sentinels allowed) -> the occurrences that reach the count
+// table, compacted; *out / *out_alt = the two buffers (of in / alt) to hand to the counting step.
+static int hao_bloom_filter(hao_ctx *c, uint64_t *in, uint64_t *alt, uint64_t n, uint64_t **out, uint64_t **out_alt, uint64_t *n_out)
+{
+	const int xb = c->opt.bf_shift - 21;                   // log2 of the 512-bit blocks per sub-table
+	*out = in; *out_alt = alt; *n_out = 0;
+	if (n == 0) return HAO_OK;
+	DevBuf<uint32_t> blk, blk2; DevBuf<uint8_t> flag;
+	HIP_TRY(blk.reserve(n + 1)); HIP_TRY(blk2.reserve(n + 1)); HIP_TRY(flag.reserve(n + 1));
+	hipLaunchKernelGGL(hao_bf_block_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, in, n, xb, blk.p);
+	HAO_CHECK_LAUNCH();
+	size_t tb = 0; rocprim::double_buffer<uint32_t> dk(blk.p, blk2.p); rocprim::double_buffer<uint64_t> dv(in, alt);
+	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, dk, dv, n, 0, 13 + xb, c->stream)); HIP_TRY(hao_tmp(c, tb));
+	HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, dk, dv, n, 0, 13 + xb, c->stream));      // stable: insertion order inside a block
+	hipLaunchKernelGGL(hao_bf_replay_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dk.current(), dv.current(), n, xb, flag.p);
+	HAO_CHECK_LAUNCH();
+	HIP_TRY(c->d_cursor.reserve(2));
+	tb = 0;
+	HIP_TRY(rocprim::select(nullptr, tb, dv.current(), flag.p, dv.alternate(), (uint64_t*)c->d_cursor.p, n, c->stream)); HIP_TRY(hao_tmp(c, tb));
+	HIP_TRY(rocprim::select(c->d_tmp.p, tb, dv.current(), flag.p, dv.alternate(), (uint64_t*)c->d_cursor.p, n, c->stream));
+	HIP_TRY(hipMemcpyAsync(n_out, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	*out = dv.alternate(); *out_alt = dv.current();
+	blk.release(); blk2.release(); flag.release();
+	return HAO_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // ha_ft_gen (htab.cpp:1136-1169): all HPC k-mers -> [Bloom replay at -f > 0, hao_index.cuh] -> counts -> histogram -> peaks ->
 // keep count >= cutoff -> filter table. + ha_opt_update_cov (CommandLines.cpp:411-418).
@@ -184,34 +221,13 @@ static int hao_ft_run(hao_ctx *c)
 	c->timer.mark("ft_hash");
 	DevBuf<uint64_t> ukeys; DevBuf<uint32_t> ucnt; uint64_t n_unique = 0, *sorted = nullptr;
 	const bool sharded = c->comm && c->comm->active();
-	const bool bloom = c->opt.bf_shift > 12;                   // ha_ct_init: filters only if n_shift > pre (htab.cpp:153)
+	const bool bloom = c->opt.bf_shift >= 21;                  // ha_ct_init / yak_bf_init: a filter needs n_shift > pre and >= 2^9 bits per sub-table (htab.cpp:83,153), else exact counting
 	uint64_t n_cnt = n_slots; uint64_t *cnt_in = kh.p, *cnt_alt = kh2.p; uint32_t bias = 0;
 	if (bloom) {
 		const int xb = c->opt.bf_shift - 21;                   // log2 of the 512-bit blocks per sub-table
-		if (xb < 0 || 12 + xb > 31) { hao_set_err(c, "bf_shift must be 0 or 21..40"); return HAO_EUNSUPP; }   // yak_bf_init refuses < 9 bits per sub-table
-		if (sharded) { hao_set_err(c, "Bloom-filtered counting (bf_shift > 0) is not available in sharded mode: the exchange partitions k-mers by high hash bits, the filter blocks by low bits"); return HAO_EUNSUPP; }
-		DevBuf<uint32_t> blk, blk2; DevBuf<uint8_t> flag;
-		HIP_TRY(blk.reserve(n_slots + 1)); HIP_TRY(blk2.reserve(n_slots + 1)); HIP_TRY(flag.reserve(n_slots + 1));
-		uint64_t n_ins = 0;
-		if (n_slots) {
-			hipLaunchKernelGGL(hao_bf_block_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, c->stream, kh.p, n_slots, xb, blk.p);
-			HAO_CHECK_LAUNCH();
-			size_t tb = 0; rocprim::double_buffer<uint32_t> dk(blk.p, blk2.p); rocprim::double_buffer<uint64_t> dv(kh.p, kh2.p);
-			HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, dk, dv, n_slots, 0, 13 + xb, c->stream)); HIP_TRY(hao_tmp(c, tb));
-			HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, dk, dv, n_slots, 0, 13 + xb, c->stream));      // stable: (read, position) order inside a block
-			hipLaunchKernelGGL(hao_bf_replay_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, c->stream, dk.current(), dv.current(), n_slots, xb, flag.p);
-			HAO_CHECK_LAUNCH();
-			// occurrences that reach the count table, compacted into the other buffer
-			HIP_TRY(c->d_cursor.reserve(2));
-			tb = 0;
-			HIP_TRY(rocprim::select(nullptr, tb, dv.current(), flag.p, dv.alternate(), (uint64_t*)c->d_cursor.p, n_slots, c->stream)); HIP_TRY(hao_tmp(c, tb));
-			HIP_TRY(rocprim::select(c->d_tmp.p, tb, dv.current(), flag.p, dv.alternate(), (uint64_t*)c->d_cursor.p, n_slots, c->stream));
-			HIP_TRY(hipMemcpyAsync(&n_ins, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
-			HIP_TRY(hipStreamSynchronize(c->stream));
-			cnt_in = dv.alternate(); cnt_alt = dv.current();
-		}
-		n_cnt = n_ins; bias = 1;                                  // the entry is created with count 1, then incremented (htab.cpp:201-205)
-		blk.release(); blk2.release(); flag.release();
+		if (12 + xb > 31) { hao_set_err(c, "bf_shift > 40 is not supported"); return HAO_EUNSUPP; }
+		if (!sharded) { if (int rc = hao_bloom_filter(c, kh.p, kh2.p, n_slots, &cnt_in, &cnt_alt, &n_cnt)) return rc; }
+		bias = 1;                                                 // the entry is created with count 1, then incremented (htab.cpp:201-205)
 		c->timer.mark("ft_bloom");
 	}
 	if (!sharded) {
@@ -221,22 +237,42 @@ static int hao_ft_run(hao_ctx *c)
 	} else {
 		// hash-range partition: sort local hashes, cut at i * 2^64 / world, all-to-all-v, count the owned range
 		hao_comm &cm = *c->comm; const int W = cm.world;
-		uint64_t *loc = kh.p;
-		if (n_slots) {
-			size_t tb = 0; rocprim::double_buffer<uint64_t> db(kh.p, kh2.p);
-			HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, db, n_slots, 0, 64, c->stream)); HIP_TRY(hao_tmp(c, tb));
-			HIP_TRY(rocprim::radix_sort_keys(c->d_tmp.p, tb, db, n_slots, 0, 64, c->stream));
-			loc = db.current();
-		}
+		uint64_t *loc = kh.p; uint64_t n_loc = n_real;
 		std::vector<uint64_t> tg(W), cut(W + 1, 0), scnt(W), sdisp(W), rcnt;
-		for (int d = 0; d < W; ++d) tg[d] = d == 0 ? 0 : (uint64_t)(((unsigned __int128)d << 64) / (unsigned)W);
 		DevBuf<uint64_t> dt, dc; HIP_TRY(dt.reserve(W + 1)); HIP_TRY(dc.reserve(W + 1));
-		HIP_TRY(hipMemcpyAsync(dt.p, tg.data(), 8 * W, hipMemcpyHostToDevice, c->stream));
-		hipLaunchKernelGGL(hao_lower_bound_kernel, dim3((W + 63) / 64), dim3(64), 0, c->stream, loc, n_real, dt.p, W, dc.p);
-		HAO_CHECK_LAUNCH();
+		if (!bloom) {
+			if (n_slots) {
+				size_t tb = 0; rocprim::double_buffer<uint64_t> db(kh.p, kh2.p);
+				HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, db, n_slots, 0, 64, c->stream)); HIP_TRY(hao_tmp(c, tb));
+				HIP_TRY(rocprim::radix_sort_keys(c->d_tmp.p, tb, db, n_slots, 0, 64, c->stream));
+				loc = db.current();
+			}
+			for (int d = 0; d < W; ++d) tg[d] = d == 0 ? 0 : (uint64_t)(((unsigned __int128)d << 64) / (unsigned)W);
+			HIP_TRY(hipMemcpyAsync(dt.p, tg.data(), 8 * W, hipMemcpyHostToDevice, c->stream));
+			hipLaunchKernelGGL(hao_lower_bound_kernel, dim3((W + 63) / 64), dim3(64), 0, c->stream, loc, n_real, dt.p, W, dc.p);
+			HAO_CHECK_LAUNCH();
+		} else {
+			// the filter's blocks (and every copy of a k-mer) are determined by the LOW hash bits: partition by sub-table (low 12 bits), with a
+			// STABLE sort on those bits only, so that each piece stays in (read, position) order; pieces arrive in rank order = global read order
+			if (n_slots) {
+				HIP_TRY(c->d_cursor.reserve(2)); size_t tb = 0;
+				HIP_TRY(rocprim::select(nullptr, tb, kh.p, kh2.p, (uint64_t*)c->d_cursor.p, n_slots, NotSentinel(), c->stream)); HIP_TRY(hao_tmp(c, tb));
+				HIP_TRY(rocprim::select(c->d_tmp.p, tb, kh.p, kh2.p, (uint64_t*)c->d_cursor.p, n_slots, NotSentinel(), c->stream));
+				HIP_TRY(hipMemcpyAsync(&n_loc, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+				HIP_TRY(hipStreamSynchronize(c->stream));
+				tb = 0; rocprim::double_buffer<uint64_t> db(kh2.p, kh.p);
+				HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, db, n_loc, 0, 12, c->stream)); HIP_TRY(hao_tmp(c, tb));
+				HIP_TRY(rocprim::radix_sort_keys(c->d_tmp.p, tb, db, n_loc, 0, 12, c->stream));
+				loc = db.current();
+			}
+			for (int d = 0; d < W; ++d) tg[d] = ((uint64_t)d * 4096 + W - 1) / W;      // first sub-table of rank d
+			HIP_TRY(hipMemcpyAsync(dt.p, tg.data(), 8 * W, hipMemcpyHostToDevice, c->stream));
+			hipLaunchKernelGGL(hao_lower_bound_low12_kernel, dim3((W + 63) / 64), dim3(64), 0, c->stream, loc, n_loc, dt.p, W, dc.p);
+			HAO_CHECK_LAUNCH();
+		}
 		HIP_TRY(hipMemcpyAsync(cut.data(), dc.p, 8 * W, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
-		cut[W] = n_real;
+		cut[W] = n_loc;
 		for (int d = 0; d < W; ++d) { sdisp[d] = cut[d]; scnt[d] = cut[d + 1] - cut[d]; }
 		if (int rc = hao_comm_exchange_counts(c, cm, scnt, rcnt)) return rc;
 		uint64_t n_recv = 0; for (int d = 0; d < W; ++d) n_recv += rcnt[d];
@@ -244,7 +280,9 @@ static int hao_ft_run(hao_ctx *c)
 		if (int rc = hao_comm_alltoallv_u64(c, cm, loc, scnt, sdisp, rv.p, rcnt)) return rc;
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		c->timer.mark("ft_exchange");
-		if (int rc = hao_sort_rle_hist(c, rv.p, rv2.p, n_recv, ukeys, ucnt, &n_unique, c->ft_hist, &sorted)) return rc;
+		uint64_t *ci = rv.p, *ca = rv2.p, n_ci = n_recv;
+		if (bloom) { if (int rc = hao_bloom_filter(c, rv.p, rv2.p, n_recv, &ci, &ca, &n_ci)) return rc; }
+		if (int rc = hao_sort_rle_hist(c, ci, ca, n_ci, ukeys, ucnt, &n_unique, c->ft_hist, &sorted, bias)) return rc;
 		if (int rc = hao_comm_allreduce_i64(c, cm, c->ft_hist, HAO_N_COUNTS)) return rc;
 		rv.release(); rv2.release(); dt.release(); dc.release();
 	}
@@ -265,6 +303,16 @@ static int hao_ft_run(hao_ctx *c)
 		if (int rc = hao_comm_allgatherv(c, cm, c->d_ft_keys.p, n_kept, 8, gk.p, cnts)) return rc;
 		if (int rc = hao_comm_allgatherv(c, cm, kcnt.p, n_kept, 4, gc.p, cnts)) return rc;
 		HIP_TRY(hipStreamSynchronize(c->stream));
+		if (bloom && tot) {      // ranks own sub-tables, not hash ranges: the concatenation is not sorted by key yet
+			DevBuf<uint64_t> gk2; DevBuf<uint32_t> gc2; HIP_TRY(gk2.reserve(tot + 1)); HIP_TRY(gc2.reserve(tot + 1));
+			size_t tb = 0; rocprim::double_buffer<uint64_t> dk(gk.p, gk2.p); rocprim::double_buffer<uint32_t> dv(gc.p, gc2.p);
+			HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, dk, dv, tot, 0, 64, c->stream)); HIP_TRY(hao_tmp(c, tb));
+			HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, dk, dv, tot, 0, 64, c->stream));
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			if (dk.current() != gk.p) std::swap(gk, gk2);
+			if (dv.current() != gc.p) std::swap(gc, gc2);
+			gk2.release(); gc2.release();
+		}
 		std::swap(c->d_ft_keys, gk); std::swap(kcnt, gc); gk.release(); gc.release();
 		n_kept = tot;
 	}

@@ -214,7 +214,7 @@ int hao_or_ft_gen(hao_or_ctx *c)
 	 * (read, position) order: step 1 of the counting pipeline fills the 4096 buffers read by read, step 2 drains each buffer in
 	 * order, and kt_pipeline keeps blocks ordered (htab.cpp:826-843, 860-880). */
 	bias = 0;
-	if (c->opt.bf_shift > 12) {
+	if (c->opt.bf_shift >= 21) {                                          /* below 2^9 bits per sub-table yak_bf_init returns NULL: exact counting */
 		const int nsh = c->opt.bf_shift - 12, xb = nsh - 9;               /* yak_bf_init(n_shift - pre), YAK_BLK_SHIFT = 9 */
 		const uint64_t blocks = 4096ULL << xb; uint64_t m = 0;
 		uint8_t *bf = (uint8_t*)calloc(blocks, 64);

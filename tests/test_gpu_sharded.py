@@ -30,7 +30,7 @@ def _check_rank(e, o, lo, hi, errors):
             errors.append(f"read {r}")
 
 
-@pytest.mark.parametrize("name", ["hifi", "rr", "nn"])
+@pytest.mark.parametrize("name", ["hifi", "rr", "nn", "bf24"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_loopback_world(name, world):
     from hifiasm_amd.api import Engine, lib
