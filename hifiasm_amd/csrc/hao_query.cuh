@@ -66,6 +66,7 @@ template<int CAPLOG, bool FIRST>
 __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t *ovf_list, unsigned long long *ovf_cnt)
 {
 	constexpr uint32_t CAP = 1u << CAPLOG, MAXD = CAP - 288;      // at most MAXD + 256 bins are ever inserted (one per thread after the table fills), so probing terminates; CAP >= 512
+	constexpr int UA = 4;                        // tiles per lane in flight in the counting pass (chunks are multiples of 64 * UA anchors)
 	extern __shared__ uint32_t bs_smem[];
 	uint32_t *hk = bs_smem;                      // [CAP]    bin key (tid << 1 | rev) per slot
 	uint32_t *cw = hk + CAP;                     // [4][CAP] per-wave counts, then running output offsets
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 	unsigned long long tk0 = S.dbg ? wall_clock64() : 0, tk1 = 0, tk2 = 0;
 #define HAO_AO(q) (qlds ? l_ao[q] : ((q) >= nq ? n : (uint32_t)(g_ao[q] - s)))
 #define HAO_SS(q) (qlds ? l_ss[q] : (g_ss[q] | (uint64_t)hao_info_rev(g_info[q]) << 63))
-	const uint32_t chunk = ((n + 3) / 4 + 255) & ~255u, c0 = min(n, wv * chunk), c1 = min(n, c0 + chunk);
+	const uint32_t chunk = ((n + 3) / 4 + 64 * UA - 1) / (64 * UA) * (64 * UA), c0 = min(n, wv * chunk), c1 = min(n, c0 + chunk);
 	uint32_t q_c0 = 0;       // minimizer holding anchor c0: last q with AO(q) <= c0 (binary search, uniform in the wave)
 	if (c0 < c1) { uint32_t lo_ = 0, hi_ = nq; while (hi_ - lo_ > 1) { const uint32_t md = (lo_ + hi_) >> 1; if (HAO_AO(md) <= c0) lo_ = md; else hi_ = md; } q_c0 = lo_; }
 	const uint32_t k_end = 2u << S.tb;
@@ -106,10 +107,10 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 			if (tid == 0) { s_nd = 0; s_ovf = 0; s_c = 0; }
 			__syncthreads();
 			uint32_t qc = q_c0;
-			for (uint32_t t0 = c0; t0 < c1; t0 += 256) {      // four independent index reads in flight per lane
-				uint64_t yv[4]; uint32_t zr[4];
+			for (uint32_t t0 = c0; t0 < c1; t0 += 64 * UA) {      // UA independent index reads in flight per lane
+				uint64_t yv[UA]; uint32_t zr[UA];
 #pragma unroll
-				for (int u = 0; u < 4; ++u) {
+				for (int u = 0; u < UA; ++u) {
 					const uint32_t x = t0 + u * 64 + lane; const bool act = x < c1; uint32_t q = qc;
 					if (act) { while (HAO_AO(q + 1) <= x) ++q; }
 					qc = (uint32_t)__builtin_amdgcn_readlane((int)q, 63);
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 				}
 				if (*v_ovf) break;
 #pragma unroll
-				for (int u = 0; u < 4; ++u) {
+				for (int u = 0; u < UA; ++u) {
 					const uint32_t x = t0 + u * 64 + lane, kk = hao_info_rid(yv[u]) << 1 | (zr[u] ^ hao_info_rev(yv[u]));
 					if (x < c1 && kk >= lo && kk < hi && !*v_ovf) {        // a thread starts at most one insertion after the table was declared full
 						uint32_t slot = (kk * 2654435761u) >> (32 - CAPLOG);
