@@ -199,6 +199,8 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	sa.key_xs = B.key_xs.p; sa.key_sc = B.key_sc.p; sa.key_al = B.key_al.p; sa.key_tmp = B.key_tmp.p;
 	sa.ol = B.ol.p; sa.g_off = B.g_off.p; sa.ch_base = B.ch_base.p; sa.cl_base = B.cl_base.p; sa.cl = B.cl.p; sa.n_sel = n; sa.rid_lo = glo; sa.len = c->d_len_all.p; sa.cc_off = B.cc_off.p; sa.cc = B.cc.p;
 	sa.perm = B.perm.p; sa.n_final = B.n_final.p; sa.fc_final = B.fc_final.p; sa.max_n_chain = par.max_n_chain; sa.ocv_w = par.ocv_w; sa.chain_cutoff = par.chain_cutoff;
+	sa.dbg = nullptr;
+	if (getenv("HAO_DBG_SELPHASE")) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); sa.dbg = B.dbgbuf.p; }
 	// three launches split by chain count: the common reads (<= 128 chains) need 5 KB of LDS per wave and fill the CUs; 512- and 1024-chain slices for
 	// repeat-rich reads (beyond 1024 chains the keys stay in global scratch)
 	hipLaunchKernelGGL((chain_select_kernel<1, 128>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)0, (int64_t)129);
@@ -209,6 +211,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	HAO_CHECK_LAUNCH();
 	if (int rc = hao_scan_u32(c, B.n_final.p, B.fin_off.p, n + 1)) return rc;
 	if (int rc = hao_excl_scan_u64(c, B.fc_final.p, B.fcf_off.p, n + 1)) return rc;
+	if (sa.dbg) { unsigned long long d_[5]; HIP_TRY(hipMemcpy(d_, B.dbgbuf.p, 40, hipMemcpyDeviceToHost)); if (d_[4]) fprintf(stderr, "[select] reads %llu  avg us: score sort %.1f  prune %.1f  position sort %.1f  weak filter %.1f\n", d_[4], d_[0] / 100.0 / d_[4], d_[1] / 100.0 / d_[4], d_[2] / 100.0 / d_[4], d_[3] / 100.0 / d_[4]); }
 	c->timer.mark("q_select");
 	HIP_TRY(B.ol_out.reserve(NCmax + 1)); HIP_TRY(B.fc_out.reserve(FCmax + 1)); HIP_TRY(B.fc_out_off.reserve(NCmax + 2));
 	hipLaunchKernelGGL(chain_final_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, B.ol.p, B.ol_fc_off.p, B.fc_raw.p, B.perm.p, B.g_off.p, B.ch_base.p,

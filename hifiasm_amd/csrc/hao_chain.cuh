@@ -985,11 +985,14 @@ struct hao_sel_args {
 	uint64_t *key_xs; int32_t *key_sc; uint32_t *key_al, *key_tmp;   // global key scratch (reads with more chains than the LDS slice holds); key_tmp: 5 words per chain
 	uint32_t *perm; uint32_t *n_final; uint64_t *fc_final;        // outputs: permutation (per read slice), kept count, kept fake-cigar entries
 	uint64_t max_n_chain, ocv_w; uint32_t chain_cutoff;
+	unsigned long long *dbg;      // optional phase timers (HAO_DBG_SELPHASE): wall-clock ticks summed over reads: score sort, prune, position sort, weak filter, reads
 };
 
 // the sequential part (lane 0). returns the kept count
 // max_n_chain pruning (anchor.cpp:1957-2056) on the score-sorted permutation: sequential, lane 0
-__device__ int64_t hao_select_prune(const hao_sel_args &A, const hao_sel_ctx &S, int64_t n, int lch, uint64_t r, int *lch_out)
+#define HAO_SEL_CCAP 128       // coverage windows (read length / ocv_w) kept in LDS during the pruning scan; longer reads use the global array
+template<bool CCLDS>
+__device__ int64_t hao_select_prune(const hao_sel_args &A, const hao_sel_ctx &S, int64_t n, int lch, uint64_t r, int *lch_out, uint64_t *l_cc)
 {
 	const uint64_t rl = A.len[A.rid_lo + r], max_n_chain = A.max_n_chain, ocv_w = A.ocv_w; const uint32_t chain_cutoff = A.chain_cutoff;
 	int64_t i;
@@ -997,7 +1000,7 @@ __device__ int64_t hao_select_prune(const hao_sel_args &A, const hao_sel_ctx &S,
 #define SC(i) S.sc[S.pm[i]]
 #define AL(i) S.al[S.pm[i]]
 	if ((uint64_t)n > max_n_chain) {
-		int32_t w, nn[4] = {0, 0, 0, 0}, s[4] = {0, 0, 0, 0}; uint64_t cwn = 0, *cc = A.cc + A.cc_off[r], kk, mm;
+		int32_t w, nn[4] = {0, 0, 0, 0}, s[4] = {0, 0, 0, 0}; uint64_t cwn = 0, *cc = CCLDS ? l_cc : A.cc + A.cc_off[r], kk, mm;      // the scan is sequential (one lane): window counters in LDS, not a global round trip each
 		for (i = 0; i < n; ++i) { w = hao_ov_type(XS(i), (uint32_t)rl); if ((uint64_t)++nn[w] == max_n_chain) s[w] = SC(i); }
 		if (s[0] > 0 || s[1] > 0 || s[2] > 0 || s[3] > 0) {
 			if ((uint64_t)nn[3] >= max_n_chain && rl >= ocv_w) {
@@ -1050,6 +1053,18 @@ __device__ int64_t hao_select_weak(const hao_sel_args &A, const hao_sel_ctx &S, 
 #define SC(i) S.sc[S.pm[i]]
 #define AL(i) S.al[S.pm[i]]
 	int64_t i, kk, ll;
+	// Only chains with >= chain_cutoff hits can cover a weak one, and they are never dropped: list them once, in x_pos_s order (pm2 is free
+	// after the sort).  The reference scans the whole (partly compacted) list up to the first entry with x_pos_s >= ze; every entry before
+	// the weak chain has x_pos_s <= its own and the rest is still sorted, so that scan visits exactly the entries with x_pos_s < ze -
+	// and only "some strong chain covers it" is observable.  On repeat-rich reads most of the several hundred chains are weak ones.
+	uint32_t *sl = S.pm2; int64_t ns = 0;
+	for (kk = 0; kk < n; kk += 64) {
+		const int64_t kq = kk + lane; const bool st = kq < n && !(AL(kq) < chain_cutoff);
+		const unsigned long long m = __ballot(st);
+		if (st) sl[ns + __popcll(m & ((1ULL << lane) - 1))] = S.pm[kq];
+		ns += __popcll(m);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 	for (i = ll = 0; i < n; ++i) {
 		bool drop = false;
 		if (AL(i) < chain_cutoff) {
@@ -1057,24 +1072,25 @@ __device__ int64_t hao_select_weak(const hao_sel_args &A, const hao_sel_ctx &S, 
 			int64_t osc = (int64_t)SC(i) * 16;
 			if (ob < 16) ob = 16;
 			// candidates are examined 64 at a time: the cheap tests (strong enough, overlaps >= ob of the weak chain) run one per lane,
-			// only the survivors - in list order - get the wave-wide hit count; the scan stops at the first chain that covers the weak one
+			// only the survivors get the wave-wide hit count; the scan stops at the first chain that covers the weak one
 			bool covered = false;
-			for (kk = 0; kk < n && !covered; kk += 64) {
-				const int64_t kq = kk + lane; bool inr = false, cand = false; uint64_t os = 0, oe = 0;
-				if (kq < n) {
-					const uint64_t xq = XS(kq); inr = ze > (xq >> 32);
-					if (inr && !(AL(kq) < chain_cutoff || AL(kq) < ocn || (int64_t)SC(kq) < osc)) {
+			for (kk = 0; kk < ns && !covered; kk += 64) {
+				const int64_t kq = kk + lane; bool inr = false, cand = false; uint64_t os = 0, oe = 0; uint32_t ci = 0;
+				if (kq < ns) {
+					ci = sl[kq];
+					const uint64_t xq = S.xs[ci]; inr = ze > (xq >> 32);
+					if (inr && !(S.al[ci] < ocn || (int64_t)S.sc[ci] < osc)) {
 						const uint64_t rs = xq >> 32, re = (uint64_t)(uint32_t)xq + 1; os = rs >= zs ? rs : zs; oe = re <= ze ? re : ze;
 						cand = oe > os && oe - os >= ob;
 					}
 				}
 				const unsigned long long inm = __ballot(inr); unsigned long long cm = __ballot(cand);
-				const int nin = __popcll(inm);                      // list is sorted by x_pos_s: the in-range lanes are a prefix
+				const int nin = __popcll(inm);                      // the strong list is sorted by x_pos_s: the in-range lanes are a prefix
 				while (cm) {
 					const int l = __ffsll((long long)cm) - 1; cm &= cm - 1;
 					if (l >= nin) break;
-					const int64_t kc = kk + l; const uint64_t cos = __shfl(os, l), coe = __shfl(oe, l);
-					const uint64_t m0 = rec[S.pm[kc]].non_homopolymer_errors, nh = AL(kc);    // the chain's hits: cl[m0 .. m0+nh) share one ordinal tag
+					const uint32_t cc_ = (uint32_t)__shfl((int)ci, l); const uint64_t cos = __shfl(os, l), coe = __shfl(oe, l);
+					const uint64_t m0 = rec[cc_].non_homopolymer_errors, nh = S.al[cc_];    // the chain's hits: cl[m0 .. m0+nh) share one ordinal tag
 					uint64_t kn = 0;
 					for (uint64_t b = 0; b < nh && kn < ocn; b += 64) {
 						uint64_t mm = m0 + b + lane; bool in = false;
@@ -1102,7 +1118,7 @@ __device__ int64_t hao_select_weak(const hao_sel_args &A, const hao_sel_ctx &S, 
 // "LDS or global" pointer select would make every access a flat one).
 template<int CAP, bool INLDS>
 __device__ __forceinline__ void hao_select_body(const hao_sel_args &A, const uint64_t r, int64_t n, const uint64_t o0, const uint64_t cl0, const uint64_t cn,
-		uint64_t *l_xs, int32_t *l_sc, uint32_t *l_al, uint32_t *l_pm, uint32_t *l_pm2, uint32_t *l_lp, uint32_t *l_rp, int32_t *l_stack)
+		uint64_t *l_xs, int32_t *l_sc, uint32_t *l_al, uint32_t *l_pm, uint32_t *l_pm2, uint32_t *l_lp, uint32_t *l_rp, int32_t *l_stack, uint64_t *l_cc)
 {
 	const int lane = hao_lane();
 	const hao_ovlp_t *rec = A.ol + o0;
@@ -1119,16 +1135,21 @@ __device__ __forceinline__ void hao_select_body(const hao_sel_args &A, const uin
 	hao_sel_ctx S; S.xs = xs; S.sc = sc; S.al = al; S.pm = pm; S.stack = l_stack;
 	S.pm2 = INLDS ? l_pm2 : A.key_tmp + 5 * o0; S.lpos = INLDS ? l_lp : A.key_tmp + 5 * o0 + 2 * n; S.rasc = INLDS ? l_rp : A.key_tmp + 5 * o0 + 4 * n;
 	int64_t nf = n; int lch2 = lch;
+	unsigned long long tk0 = A.dbg ? wall_clock64() : 0, tk1 = tk0, tk2 = tk0, tk3, tk4;
 	if ((uint64_t)n > A.max_n_chain) {
 		hao_wave_intro_sort<0>(S, n);
-		if (lane == 0) nf = hao_select_prune(A, S, n, lch, r, &lch2);
+		if (A.dbg) tk1 = wall_clock64();
+		if (lane == 0) nf = (uint64_t)A.len[A.rid_lo + r] / A.ocv_w + 2 <= HAO_SEL_CCAP ? hao_select_prune<true>(A, S, n, lch, r, &lch2, l_cc) : hao_select_prune<false>(A, S, n, lch, r, &lch2, l_cc);
 		nf = __shfl(nf, 0); lch2 = __shfl(lch2, 0);
 		HAO_WFENCE();
+		if (A.dbg) tk2 = wall_clock64();
 	}
 	hao_wave_intro_sort<1>(S, nf);
 	__threadfence_block();
+	tk3 = A.dbg ? wall_clock64() : 0;
 	if (lch2) nf = hao_select_weak(A, S, nf, rec, A.cl + cl0, cn);
 	__threadfence_block();
+	if (A.dbg && lane == 0) { tk4 = wall_clock64(); atomicAdd(A.dbg, tk1 - tk0); atomicAdd(A.dbg + 1, tk2 - tk1); atomicAdd(A.dbg + 2, tk3 - tk2); atomicAdd(A.dbg + 3, tk4 - tk3); atomicAdd(A.dbg + 4, 1ULL); }
 	uint64_t fct = 0;
 	for (int64_t i = lane; i < nf; i += 64) { uint32_t pi = pm[i]; if (INLDS) A.perm[o0 + i] = pi; fct += rec[pi].fc_len; }
 #pragma unroll
@@ -1141,7 +1162,7 @@ __device__ __forceinline__ void hao_select_body(const hao_sel_args &A, const uin
 template<int WPB, int CAP>
 __global__ __launch_bounds__(WPB * 64) void chain_select_kernel(hao_sel_args A, int64_t n_lo, int64_t n_hi)
 {
-	__shared__ uint64_t l_xs[WPB][CAP]; __shared__ int32_t l_sc[WPB][CAP]; __shared__ uint32_t l_al[WPB][CAP], l_pm[WPB][CAP], l_pm2[WPB][CAP], l_lp[WPB][CAP], l_rp[WPB][CAP]; __shared__ int32_t l_stack[WPB][3 * 72];
+	__shared__ uint64_t l_xs[WPB][CAP]; __shared__ int32_t l_sc[WPB][CAP]; __shared__ uint32_t l_al[WPB][CAP], l_pm[WPB][CAP], l_pm2[WPB][CAP], l_lp[WPB][CAP], l_rp[WPB][CAP]; __shared__ int32_t l_stack[WPB][3 * 72]; __shared__ uint64_t l_cc[WPB][HAO_SEL_CCAP];
 	const int wv = threadIdx.x >> 6, lane = hao_lane();
 	const uint64_t r = (uint64_t)blockIdx.x * WPB + wv;
 	if (r > A.n_sel) return;
@@ -1150,8 +1171,8 @@ __global__ __launch_bounds__(WPB * 64) void chain_select_kernel(hao_sel_args A, 
 	const int64_t n = (int64_t)(A.ch_base[g1] - o0);
 	if (n < n_lo || n >= n_hi) return;                          // this read belongs to another launch
 	const uint64_t cl0 = A.cl_base[g0], cn = A.cl_base[g1] - cl0;
-	if (n <= CAP) hao_select_body<CAP, true>(A, r, n, o0, cl0, cn, l_xs[wv], l_sc[wv], l_al[wv], l_pm[wv], l_pm2[wv], l_lp[wv], l_rp[wv], l_stack[wv]);
-	else hao_select_body<CAP, false>(A, r, n, o0, cl0, cn, l_xs[wv], l_sc[wv], l_al[wv], l_pm[wv], l_pm2[wv], l_lp[wv], l_rp[wv], l_stack[wv]);
+	if (n <= CAP) hao_select_body<CAP, true>(A, r, n, o0, cl0, cn, l_xs[wv], l_sc[wv], l_al[wv], l_pm[wv], l_pm2[wv], l_lp[wv], l_rp[wv], l_stack[wv], l_cc[wv]);
+	else hao_select_body<CAP, false>(A, r, n, o0, cl0, cn, l_xs[wv], l_sc[wv], l_al[wv], l_pm[wv], l_pm2[wv], l_lp[wv], l_rp[wv], l_stack[wv], l_cc[wv]);
 }
 
 // final gather: records in final order (align_length zeroed, anchor.cpp:2098) + fake cigars in that order. One wave per read.
