@@ -94,6 +94,26 @@ def make_reads(genome: np.ndarray, n_reads: int, read_len: int, err: float, seed
     return ReadSet(rid0, lens, packed, pk_off, codes, code_off if want_codes else None)
 
 
+def from_codes(reads, rid0: int = 0) -> ReadSet:
+    """ReadSet from explicit base-code arrays (0..3, >= 4 = N): the reference read-store packing (4 bases per byte, first base in
+    bits 7..6, N stored as A; ha_compress_base, Process_Read.cpp:792-850).  For hand-made edge-case sets."""
+    lens = np.array([len(r) for r in reads], dtype=np.uint32)
+    code_off = np.zeros(len(reads) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=code_off[1:], dtype=np.uint64)
+    pk_off = np.zeros(len(reads) + 1, dtype=np.uint64)
+    np.cumsum(lens // 4 + 1, out=pk_off[1:], dtype=np.uint64)
+    codes = np.concatenate([np.asarray(r, dtype=np.uint8) for r in reads]) if reads else np.zeros(0, dtype=np.uint8)
+    packed = np.zeros(int(pk_off[-1]), dtype=np.uint8)
+    for i, r in enumerate(reads):
+        c = np.asarray(r, dtype=np.uint8).copy()
+        c[c > 3] = 0
+        pad = (-len(c)) % 4
+        q = np.concatenate([c, np.zeros(pad, dtype=np.uint8)]).reshape(-1, 4)
+        b = (q[:, 0] << 6 | q[:, 1] << 4 | q[:, 2] << 2 | q[:, 3]).astype(np.uint8)
+        packed[int(pk_off[i]):int(pk_off[i]) + b.size] = b
+    return ReadSet(rid0, lens, packed, pk_off, codes, code_off)
+
+
 def dataset(genome_size: int, coverage: float, read_len: int, err: float, seed: int = 11, repeat_rich: int = 0,
             len_jit: int = 0, n_rate: float = 0.0, want_codes: bool = True) -> ReadSet:
     g = make_genome(genome_size, seed=seed, repeat_rich=repeat_rich)

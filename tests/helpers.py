@@ -5,7 +5,7 @@ import zlib
 import numpy as np
 
 from hifiasm_amd import synth
-from scenarios import SCENARIOS, BIG_SCENARIOS
+from scenarios import SCENARIOS, BIG_SCENARIOS, build_reads
 import oracle_py
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -15,7 +15,7 @@ _CACHE = {}
 def scenario_reads(name):
     if name not in _CACHE:
         dkw, okw = (SCENARIOS.get(name) or BIG_SCENARIOS[name])
-        _CACHE[name] = (synth.dataset(**dkw), okw)
+        _CACHE[name] = (build_reads(dkw), okw)
     return _CACHE[name]
 
 

@@ -19,7 +19,49 @@ SCENARIOS = {
     "bf24":  (dict(genome_size=100_000, coverage=12, read_len=4000, err=0.001, seed=12, repeat_rich=2, len_jit=1000), dict(bf_shift=24)),
     # 2 blocks per sub-table: the filter saturates, most k-mers are counted one too many and the peaks move
     "bf22":  (dict(genome_size=60_000, coverage=14, read_len=4000, err=0.002, seed=13, repeat_rich=1, len_jit=1000), dict(bf_shift=22)),
+    # ragged / degenerate reads mixed into a normal set (see edge_reads below)
+    "edge":  (dict(builder="edge"), {}),
 }
+
+
+def edge_reads():
+    """150 ordinary 3 kb reads plus: reads of 1, 2, 10, k-1, k, k+1, w+k-3 .. w+k-1 and 150 bases, two exact copies of a read, a 4 kb
+    homopolymer (one HPC base), a dinucleotide repeat (every minimizer identical), an all-N read, a read with an N every 97 bases
+    (no k-mer survives), a read with a single N, and the reverse complement of a read."""
+    import numpy as np
+    from hifiasm_amd import synth
+    g = synth.make_genome(30_000, seed=77)
+    base = synth.make_reads(g, 150, 3000, 0.002, seed=78, len_jit=800)
+    reads = [base.codes[int(base.code_off[i]):int(base.code_off[i + 1])].copy() for i in range(base.n)]
+    rng = np.random.default_rng(5)
+    extra = []
+    for L in (1, 2, 10, 50, 51, 52, 100, 101, 102, 150):
+        st = int(rng.integers(0, 20000))
+        extra.append(g[st:st + L].copy())
+    extra.append(reads[3].copy())
+    extra.append(reads[3].copy())
+    extra.append(np.zeros(4000, dtype=np.uint8))
+    extra.append(np.tile(np.array([0, 1], dtype=np.uint8), 2000))
+    extra.append(np.full(300, 4, dtype=np.uint8))
+    x = reads[7].copy(); x[::97] = 4; extra.append(x)
+    x = reads[9].copy(); x[1500] = 4; extra.append(x)
+    x = reads[11][::-1].copy(); extra.append((3 - x).astype(np.uint8))
+    out = []
+    for i, r in enumerate(reads):
+        out.append(r)
+        if i % 8 == 0 and extra:
+            out.append(extra.pop(0))
+    out += extra
+    return synth.from_codes(out)
+
+
+def build_reads(dkw):
+    """the read set of a scenario: synth.dataset(**dkw), or a hand-made set"""
+    from hifiasm_amd import synth
+    if dkw.get("builder") == "edge":
+        return edge_reads()
+    return synth.dataset(**dkw)
+
 
 # larger sets used only by the GPU parity tests (oracle vs HIP, no golden file): enough repeat content to push
 # thousands of groups through the chain DP / multi-copy / max_n_chain code, and 15 kb reads through the chunked sketch
