@@ -142,9 +142,9 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		}
 		int wpb = 1; if (const char *e_ = getenv("HAO_CHAIN_WPB")) wpb = std::max(1, std::min(4, atoi(e_)));
 		const bool serial = getenv("HAO_DBG_DP_SERIAL") != nullptr;      // DP kernels on the main stream (no overlap), for A/B timing
-		int spec_min = 1; if (const char *e_ = getenv("HAO_SPEC_MINCLS")) spec_min = atoi(e_);      // tiles of <= 64 hits gain nothing from speculation
+		int spec_min = 2; if (const char *e_ = getenv("HAO_SPEC_MINCLS")) spec_min = atoi(e_);      // tiles of <= 64 hits gain nothing from speculation
 		const int dbg_seq0 = ca.dbg_seq;
-		for (int x = HAO_NCLS - 1; x >= 0; --x) {
+		for (int x = HAO_NCLS - 1; x >= 1; --x) {
 			const uint64_t nl = cls_cnt[x]; if (!nl) continue;
 			ca.dbg_seq = (dbg_seq0 == 0 && x < spec_min) ? 4 : dbg_seq0;
 			const hao_gent *lst = B.glist.p + L.base[x]; uint32_t *slow = B.slow.p + L.base[x];
@@ -153,14 +153,19 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			if (ca.dbg_skip_generic) continue;
 			hipStream_t ds = serial ? c->stream : B.side[x];
 			if (!serial) { HIP_TRY(hipEventRecord(B.ev_qc[x], c->stream)); HIP_TRY(hipStreamWaitEvent(ds, B.ev_qc[x], 0)); }
-			if (x <= 1) hipLaunchKernelGGL(chain_dp128_kernel, dim3((unsigned)std::min<uint64_t>(nl, 256 * 16)), dim3(64), 0, ds, ca, lst, slow, d_slow_cnt + x);
-			else if (x <= 3) hipLaunchKernelGGL((chain_dp_kernel<512, true>), dim3((unsigned)std::min<uint64_t>(nl, 256 * 8)), dim3(64), 0, ds, ca, lst, slow, d_slow_cnt + x);
+			if (x <= 2) hipLaunchKernelGGL(chain_dp128_kernel, dim3((unsigned)std::min<uint64_t>(nl, 256 * 16)), dim3(64), 0, ds, ca, lst, slow, d_slow_cnt + x);
+			else if (x <= 4) hipLaunchKernelGGL((chain_dp_kernel<512, true>), dim3((unsigned)std::min<uint64_t>(nl, 256 * 8)), dim3(64), 0, ds, ca, lst, slow, d_slow_cnt + x);
 			else hipLaunchKernelGGL((chain_dp_kernel<HAO_DP_CAP, false>), dim3((unsigned)std::min<uint64_t>(nl, 256 * 3)), dim3(64), 0, ds, ca, lst, slow, d_slow_cnt + x);
 			HAO_CHECK_LAUNCH();
 			if (!serial) HIP_TRY(hipEventRecord(B.ev_dp[x], ds));
 		}
+		ca.dbg_seq = dbg_seq0;
+		if (cls_cnt[0]) {      // groups of <= HAO_TINY_MAX hits: one lane per group, the complete sequential algorithm
+			hipLaunchKernelGGL(chain_tiny_kernel, dim3((unsigned)((cls_cnt[0] + 63) / 64)), dim3(64), 0, c->stream, ca, B.glist.p + L.base[0], (uint64_t)cls_cnt[0]);
+			HAO_CHECK_LAUNCH();
+		}
 		c->timer.mark("q_chain");
-		if (!serial && !ca.dbg_skip_generic) for (int x = 0; x < HAO_NCLS; ++x) if (cls_cnt[x]) HIP_TRY(hipStreamWaitEvent(c->stream, B.ev_dp[x], 0));
+		if (!serial && !ca.dbg_skip_generic) for (int x = 1; x < HAO_NCLS; ++x) if (cls_cnt[x]) HIP_TRY(hipStreamWaitEvent(c->stream, B.ev_dp[x], 0));
 	}
 	HIP_TRY(hipMemsetAsync(B.nch.p + G, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(B.nout.p + G, 0, 4, c->stream));
 	c->timer.mark("q_chain_dp");

@@ -133,7 +133,8 @@ __device__ __forceinline__ uint32_t hao_fake_cigar_wave(uint64_t *fcs, uint32_t 
 
 #define HAO_WAVE_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 
-__device__ void hao_heapsort_i64(int64_t *a, int64_t n)
+template<class I64P>
+__device__ void hao_heapsort_i64(I64P a, int64_t n)
 {
 	auto down = [&](int64_t i, int64_t m) { int64_t v = a[i]; for (;;) { int64_t c = 2 * i + 1; if (c >= m) break; if (c + 1 < m && a[c + 1] > a[c]) ++c; if (a[c] <= v) break; a[i] = a[c]; i = c; } a[i] = v; };
 	for (int64_t i = n / 2 - 1; i >= 0; --i) down(i, n);
@@ -153,8 +154,9 @@ struct hao_chain_args {
 
 // Sequential tail shared by both paths (ONE lane): backtrack the best chain, multi-copy chains
 // (Hash_Table.cpp:2178-2270), regions, chained hits, fake cigars.  f/p may live in LDS or global memory.
+template<class I32P, class I64P>
 __device__ void hao_chain_tail(const hao_chain_args &A, const uint64_t g, const hao_hit_t *a, const int64_t a_n, const hao_cpar &P,
-		int32_t *f, int32_t *p, int64_t *t, int32_t *ii, int64_t msc, int64_t msc_i, int64_t plus)
+		I32P f, I32P p, I64P t, I32P ii, int64_t msc, int64_t msc_i, int64_t plus)
 {
 	const uint64_t gs = A.g_start[g];
 	hao_hit_t *des = A.ohits + gs; uint64_t *fcs = A.fcs + gs + 6 * g; hao_chain_rec *rec = A.rec + g * HAO_MCOPY_MAX;
@@ -207,17 +209,15 @@ __device__ void hao_chain_tail(const hao_chain_args &A, const uint64_t g, const 
 
 
 // Generic path, executed by ONE lane: the full sequential algorithm (quick check, DP, multi-copy).
-__device__ void hao_chain_generic(const hao_chain_args &A, const uint64_t g)
+// core: group g = hits a[0, a_n) of query xid against target yid; f/ii/p/t = per-hit scratch of the caller
+template<class I32P, class I64P>
+__device__ void hao_chain_generic_core(const hao_chain_args &A, const uint64_t g, const uint64_t gs, const hao_hit_t *a, const int64_t a_n, const uint32_t xid, const uint32_t yid,
+		const uint32_t xl, const uint32_t yl, I32P f, I32P ii, I32P p, I64P t)
 {
-	const uint32_t r = A.g_read[g]; const uint64_t gs = A.g_start[g], ge = (g + 1 < A.g_off[r + 1]) ? A.g_start[g + 1] : A.seg[r + 1];
-	const hao_hit_t *a = A.hits + gs; const int64_t a_n = (int64_t)(ge - gs);
-	const uint32_t xid = (uint32_t)(A.rid_lo + r), yid = HH_ID(a[0]);
 	A.nch[g] = 0; A.nout[g] = 0;
 	if (yid == xid || a_n <= 0) return;                      // hits to the query itself are skipped (anchor.cpp:1931)
 	hao_cpar P; P.pen_gap = A.par.pen_gap; P.pen_skip = A.par.pen_skip; P.bw = A.par.bw; P.max_skip = A.par.max_skip; P.max_iter = A.par.max_iter; P.max_dis = A.par.max_dis;
-	P.xl = A.len[xid]; P.yl = A.len[yid];
-	int32_t *f = A.f + gs, *ii = A.ii + gs, *p = A.p + gs; int64_t *t = A.t + gs;
-	hao_hit_t *des = A.ohits + gs; uint64_t *fcs = A.fcs + gs + 6 * g; hao_chain_rec *rec = A.rec + g * HAO_MCOPY_MAX;
+	P.xl = xl; P.yl = yl;
 	int64_t plus = 0, msc = INT32_MIN, msc_i = INT32_MIN, movl = INT32_MAX, si = 0, ei = a_n;
 	// ---- quick_ck_lchain ----
 	{
@@ -293,6 +293,30 @@ __device__ void hao_chain_generic(const hao_chain_args &A, const uint64_t g)
 		}
 	}
 	hao_chain_tail(A, g, a, a_n, P, f, p, t, ii, msc, msc_i, plus);
+}
+
+// the same through the group arrays and the global per-hit scratch (debug path HAO_DBG_SEQ_CHAIN)
+__device__ void hao_chain_generic(const hao_chain_args &A, const uint64_t g)
+{
+	const uint32_t r = A.g_read[g]; const uint64_t gs = A.g_start[g], ge = (g + 1 < A.g_off[r + 1]) ? A.g_start[g + 1] : A.seg[r + 1];
+	const hao_hit_t *a = A.hits + gs; const int64_t a_n = (int64_t)(ge - gs);
+	const uint32_t xid = (uint32_t)(A.rid_lo + r), yid = a_n > 0 ? HH_ID(a[0]) : xid;
+	hao_chain_generic_core(A, g, gs, a, a_n, xid, yid, A.len[xid], a_n > 0 ? A.len[yid] : 0, A.f + gs, A.ii + gs, A.p + gs, A.t + gs);
+}
+
+// Groups of a handful of hits (spurious repeat matches: most groups of a repeat-rich read): one LANE per group runs the whole sequential
+// algorithm - quick check, DP, output - with its per-hit scratch lane-interleaved in LDS.  A wave settles 64 groups at once instead of one.
+// element i of a lane-interleaved LDS array (conflict-free: lane L owns words L, L + 64, ...)
+template<class T> struct hao_lane_arr { T *p; __device__ __forceinline__ T &operator[](int64_t i) const { return p[i * 64]; } };
+
+__global__ __launch_bounds__(64) void chain_tiny_kernel(hao_chain_args A, const hao_gent *list, uint64_t n_list)
+{
+	__shared__ int32_t l_f[HAO_TINY_MAX * 64], l_ii[HAO_TINY_MAX * 64], l_p[HAO_TINY_MAX * 64]; __shared__ int64_t l_t[HAO_TINY_MAX * 64];
+	const uint64_t li = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+	if (li >= n_list) return;
+	const hao_gent e = list[li];
+	const hao_lane_arr<int32_t> f{l_f + threadIdx.x}, ii{l_ii + threadIdx.x}, p{l_p + threadIdx.x}; const hao_lane_arr<int64_t> t{l_t + threadIdx.x};
+	hao_chain_generic_core(A, e.g, e.start, A.hits + e.start, (int64_t)e.n, (uint32_t)(A.rid_lo + e.r), e.yid, e.xl, e.yl, f, ii, p, t);
 }
 
 __device__ __forceinline__ hao_hit_t hao_shfl_hit(const hao_hit_t &h, int src)

@@ -262,9 +262,10 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 // Groups are then handed to the chain kernels through per-size-class work lists of self-contained 32-byte entries
 // (no dependent index loads in the consumers), the biggest classes first: a slow group of a big class is found early
 // and its sequential DP overlaps the quick checks of the smaller classes.
-#define HAO_NCLS 6
+#define HAO_NCLS 7
+#define HAO_TINY_MAX 8          // groups up to this many hits: class 0, one LANE per group (chain_tiny_kernel)
 struct hao_gent { uint32_t g, r; uint64_t start; uint32_t n, yid, xl, yl; };      // 32 bytes
-__host__ __device__ __forceinline__ int hao_size_class(uint32_t n) { return n <= 64 ? 0 : n <= 128 ? 1 : n <= 256 ? 2 : n <= 512 ? 3 : n <= 2048 ? 4 : 5; }
+__host__ __device__ __forceinline__ int hao_size_class(uint32_t n) { return n <= HAO_TINY_MAX ? 0 : n <= 64 ? 1 : n <= 128 ? 2 : n <= 256 ? 3 : n <= 512 ? 4 : n <= 2048 ? 5 : 6; }
 
 // per-read group counts by class, laid out class-major: cc[x * (n_sel + 1) + r] (entry n_sel of every class = 0).  ONE exclusive scan of this
 // array gives every (class, read) its slot range in the concatenated class lists (deterministic, no atomics).  One wave per read.
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) void groups_classify_kernel(const uint64_t *g_
 	if (r > n_sel) return;
 	if (r == n_sel) { if (hao_lane() < HAO_NCLS) cc[hao_lane() * (n_sel + 1) + n_sel] = 0; return; }
 	const uint64_t s = seg[r], ng = g_cnt[r]; const uint32_t n = (uint32_t)(seg[r + 1] - s);
-	uint32_t c[HAO_NCLS] = {0, 0, 0, 0, 0, 0};
+	uint32_t c[HAO_NCLS] = {0, 0, 0, 0, 0, 0, 0};
 	for (uint64_t k = hao_lane(); k < ng; k += 64) {
 		const uint32_t st = (uint32_t)g_tmp[s + k], en = k + 1 < ng ? (uint32_t)g_tmp[s + k + 1] : n;
 		const int cl = hao_size_class(en - st);
