@@ -10,9 +10,11 @@
 // -ffp-contract=off and every double expression keeps the reference's operation order,
 // so results are bit-identical to the x86-64 SSE2 build of the reference.
 //
-// This first version runs one lane per (query,target) group / per read: the algorithms
-// are order-dependent sequential scans over ~200 hits.  Inputs and outputs are laid out so
-// a wave-per-group version can replace the kernels without touching the pipeline.
+// Work decomposition (groups arrive as size-class work lists, hao_query.cuh):
+//   chain_tiny_kernel   groups of <= 8 hits, one LANE per group, the whole sequential algorithm
+//   chain_group_kernel  one wave per group: quick_ck_lchain as a segmented scan; settles > 99.9 % of the groups of a repeat-free genome
+//   chain_dp*_kernel    the groups the quick check leaves: speculative 64-hit tiles + wave-parallel sequential rounds, multi-copy tail
+//   chain_assemble_kernel, chain_select_kernel<CAP>, chain_final_kernel: records / chained hits in read order, per-read selection, output
 #pragma once
 #include "hao_common.cuh"
 #include "hao_host.hpp"
