@@ -10,7 +10,7 @@ struct hao_ctx::Batch {
 	bool valid = false, host_valid = false;
 	DevBuf<uint64_t> s_start, a_off, seg, g_cnt, g_off, g_start, ch_base, cl_base, fc_base, fcs, fc_raw, ol_fc_off, cc_off, cc, fc_final, fin_off, fcf_off, fc_out, fc_out_off;
 	DevBuf<uint64_t> nch64;
-	DevBuf<uint64_t> g_tmp, cls_cc, cls_co; DevBuf<hao_gent> glist; DevBuf<uint32_t> slow, ovf_list; hipStream_t side[HAO_NCLS]; hipEvent_t ev_qc[HAO_NCLS], ev_dp[HAO_NCLS]; bool side_ready = false;
+	DevBuf<uint64_t> g_tmp, cls_cc, cls_co; DevBuf<hao_gent> glist; DevBuf<uint8_t> g_cls; DevBuf<uint32_t> slow, ovf_list; hipStream_t side[HAO_NCLS]; hipEvent_t ev_qc[HAO_NCLS], ev_dp[HAO_NCLS]; bool side_ready = false;
 	DevBuf<uint32_t> q_pos, q_cnt, s_n, g_read, wgt, nch, nout, perm, n_final, fclen;
 	DevBuf<hao_hit_t> hits, ohits, cl;
 	DevBuf<int32_t> f, ii, p, key_sc, tm; DevBuf<int64_t> t; DevBuf<uint64_t> key_xs; DevBuf<uint32_t> key_al, key_tmp;
@@ -22,7 +22,7 @@ struct hao_ctx::Batch {
 		if (side_ready) { for (int x = 0; x < HAO_NCLS; ++x) { (void)hipStreamDestroy(side[x]); (void)hipEventDestroy(ev_qc[x]); (void)hipEventDestroy(ev_dp[x]); } side_ready = false; }
 		s_start.release(); a_off.release(); seg.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fin_off.release(); fcf_off.release(); fc_out.release(); fc_out_off.release();
-		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); slow.release(); ovf_list.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
+		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); g_cls.release(); slow.release(); ovf_list.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
 		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); ol_out.release();
 	}
 };
@@ -118,8 +118,8 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	hao_cls_layout L; unsigned long long cls_cnt[HAO_NCLS];
 	for (int x = 0; x <= HAO_NCLS; ++x) L.base[x] = lay[x];
 	for (int x = 0; x < HAO_NCLS; ++x) cls_cnt[x] = L.base[x + 1] - L.base[x];
-	HIP_TRY(B.g_start.reserve(G + 1)); HIP_TRY(B.g_read.reserve(G + 1)); HIP_TRY(B.glist.reserve(G + 1)); HIP_TRY(B.slow.reserve(G + 1));
-	hipLaunchKernelGGL(groups_compact_kernel, dim3((unsigned)((n + 4) / 4)), dim3(256), 0, c->stream, B.g_tmp.p, B.seg.p, B.cls_co.p, n, glo, c->d_len_all.p, B.g_off.p, B.g_start.p, B.g_read.p, B.glist.p);
+	HIP_TRY(B.g_start.reserve(G + 1)); HIP_TRY(B.g_read.reserve(G + 1)); HIP_TRY(B.g_cls.reserve(G + 1)); HIP_TRY(B.glist.reserve(G + 1)); HIP_TRY(B.slow.reserve(G + 1));
+	hipLaunchKernelGGL(groups_compact_kernel, dim3((unsigned)((n + 4) / 4)), dim3(256), 0, c->stream, B.g_tmp.p, B.seg.p, B.cls_co.p, n, glo, c->d_len_all.p, B.g_off.p, B.g_start.p, B.g_read.p, B.g_cls.p, B.glist.p);
 	HAO_CHECK_LAUNCH();
 	c->timer.mark("q_groups");
 	// Q6 chain: quick check per size class, biggest first; the groups it does not settle go to the DP kernel of their class on a side
@@ -182,10 +182,11 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	HIP_TRY(B.ol.reserve(NCmax + 1)); HIP_TRY(B.ol_fc_off.reserve(NCmax + 1)); HIP_TRY(B.cl.reserve(A + 1)); HIP_TRY(B.fc_raw.reserve(FCmax + 1)); HIP_TRY(B.perm.reserve(NCmax + 1));
 	if (G) {
 		hao_asm_args aa;
-		aa.g_start = B.g_start.p; aa.g_read = B.g_read.p; aa.g_off = B.g_off.p; aa.n_groups = G; aa.rid_lo = glo; aa.ohits = B.ohits.p; aa.hits = B.hits.p; aa.fcs = B.fcs.p; aa.rec = B.rec.p; aa.nch = B.nch.p;
+		aa.g_start = B.g_start.p; aa.g_read = B.g_read.p; aa.g_cls = B.g_cls.p; aa.g_off = B.g_off.p; aa.n_groups = G; aa.rid_lo = glo; aa.ohits = B.ohits.p; aa.hits = B.hits.p; aa.fcs = B.fcs.p; aa.rec = B.rec.p; aa.nch = B.nch.p;
 		aa.ch_base = B.ch_base.p; aa.cl_base = B.cl_base.p; aa.fc_base = B.fc_base.p; aa.ol = B.ol.p; aa.ol_fc_off = B.ol_fc_off.p; aa.cl = B.cl.p; aa.fc = B.fc_raw.p;
-		hipLaunchKernelGGL(chain_assemble_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream, aa);
-		HAO_CHECK_LAUNCH();
+		const uint64_t n_tiny = cls_cnt[0], n_rest = G - n_tiny;      // the work lists are laid out tiny class first
+		if (n_rest) { hipLaunchKernelGGL(chain_assemble_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream, aa); HAO_CHECK_LAUNCH(); }
+		if (n_tiny) { hipLaunchKernelGGL(chain_assemble_tiny_kernel, dim3((unsigned)((n_tiny + 63) / 64)), dim3(64), 0, c->stream, aa, B.glist.p + L.base[0], n_tiny); HAO_CHECK_LAUNCH(); }
 	}
 	c->timer.mark("q_assemble");
 	// Q8 selection

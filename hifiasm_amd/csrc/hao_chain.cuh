@@ -756,17 +756,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 // the overlap ordinal inside the read) and fake cigars.  One wave per group.
 // ---------------------------------------------------------------------------------------
 struct hao_asm_args {
-	const uint64_t *g_start; const uint32_t *g_read; const uint64_t *g_off; uint64_t n_groups; uint64_t rid_lo;
+	const uint64_t *g_start; const uint32_t *g_read; const uint8_t *g_cls; const uint64_t *g_off; uint64_t n_groups; uint64_t rid_lo;
 	const hao_hit_t *ohits, *hits; const uint64_t *fcs; const hao_chain_rec *rec; const uint32_t *nch;
 	const uint64_t *ch_base, *cl_base, *fc_base;   // exclusive scans over groups (chains, hits) and over chain slots (fake-cigar entries)
 	hao_ovlp_t *ol; uint64_t *ol_fc_off; hao_hit_t *cl; uint64_t *fc;
 };
 
+// one wave per group, in group order (chained hits of a read are written front to back); the tiny class has its own kernel
 __global__ __launch_bounds__(256) void chain_assemble_kernel(hao_asm_args A)
 {
 	const uint64_t g = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (g >= A.n_groups) return;
-	const uint32_t n = A.nch[g]; if (n == 0) return;
+	const uint32_t n = A.nch[g]; if (n == 0 || A.g_cls[g] == 0) return;
 	const uint32_t r = A.g_read[g]; const uint64_t g0 = A.g_off[r];
 	const uint64_t ord0 = A.ch_base[g] - A.ch_base[g0], cl0 = A.cl_base[g0];
 	const uint64_t *fsrc = A.fcs + A.g_start[g] + 6 * g;
@@ -790,6 +791,30 @@ __global__ __launch_bounds__(256) void chain_assemble_kernel(hao_asm_args A)
 			for (int u = 0; u < 4; ++u) if (i + u * 64 < rc.n_hits) { h4[u].w0 = (h4[u].w0 & 0x80000000u) | (ord & 0x7fffffffu); A.cl[hd + i + u * 64] = h4[u]; }
 		}
 		for (uint32_t i = hao_lane(); i < rc.fc_len; i += 64) A.fc[fd + i] = fsrc[rc.fc_rel + i];
+	}
+}
+
+// the same for the tiny class (<= HAO_TINY_MAX hits per group): one LANE per group
+__global__ __launch_bounds__(64) void chain_assemble_tiny_kernel(hao_asm_args A, const hao_gent *list, uint64_t n_list)
+{
+	const uint64_t li = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+	if (li >= n_list) return;
+	const hao_gent e = list[li]; const uint64_t g = e.g;
+	const uint32_t n = A.nch[g]; if (n == 0) return;
+	const uint64_t g0 = A.g_off[e.r], ord0 = A.ch_base[g] - A.ch_base[g0], cl0 = A.cl_base[g0];
+	const uint64_t *fsrc = A.fcs + e.start + 6 * g;
+	for (uint32_t c = 0; c < n; ++c) {
+		const hao_chain_rec rc = A.rec[g * HAO_MCOPY_MAX + c];
+		const uint64_t oi = A.ch_base[g] + c, hd = A.cl_base[g] + rc.hit_rel, fd = A.fc_base[g * HAO_MCOPY_MAX + c];
+		const uint32_t ord = (uint32_t)(ord0 + c);
+		const hao_hit_t *src = (rc.in_place ? A.hits : A.ohits) + e.start + rc.src_rel;
+		hao_ovlp_t o;
+		o.x_id = (uint32_t)(A.rid_lo + e.r); o.x_pos_s = rc.x_pos_s; o.x_pos_e = rc.x_pos_e; o.x_pos_strand = 0;
+		o.y_id = e.yid; o.y_pos_s = rc.y_pos_s; o.y_pos_e = rc.y_pos_e; o.y_pos_strand = rc.strand;
+		o.shared_seed = rc.score; o.align_length = rc.n_hits; o.non_homopolymer_errors = (uint32_t)(hd - cl0); o.fc_len = rc.fc_len;
+		A.ol[oi] = o; A.ol_fc_off[oi] = fd;
+		for (uint32_t i = 0; i < rc.n_hits; ++i) { hao_hit_t h = src[i]; h.w0 = (h.w0 & 0x80000000u) | (ord & 0x7fffffffu); A.cl[hd + i] = h; }
+		for (uint32_t i = 0; i < rc.fc_len; ++i) A.fc[fd + i] = fsrc[rc.fc_rel + i];
 	}
 }
 

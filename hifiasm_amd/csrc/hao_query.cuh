@@ -302,7 +302,7 @@ __global__ void groups_layout_kernel(const uint64_t *co, uint64_t n_sel, unsigne
 
 // group arrays (g_off, g_start, g_read) + the class work lists; one wave per read.  co = exclusive scan of the class-major count table.
 __global__ __launch_bounds__(256) void groups_compact_kernel(const uint64_t *g_tmp, const uint64_t *seg, const uint64_t *co, uint64_t n_sel, uint64_t rid_lo, const uint32_t *len,
-		uint64_t *g_off, uint64_t *g_start, uint32_t *g_read, hao_gent *glist)
+		uint64_t *g_off, uint64_t *g_start, uint32_t *g_read, uint8_t *g_cls, hao_gent *glist)
 {
 	const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (r > n_sel) return;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void groups_compact_kernel(const uint64_t *g_t
 			const uint64_t w = g_tmp[s + k]; const uint32_t st = (uint32_t)w, en = k + 1 < ng ? (uint32_t)g_tmp[s + k + 1] : n;
 			e.g = (uint32_t)(g0 + k); e.r = (uint32_t)r; e.start = s + st; e.n = en - st; e.yid = (uint32_t)(w >> 32); e.xl = xl; e.yl = len[e.yid];
 			g_start[g0 + k] = e.start; g_read[g0 + k] = (uint32_t)r;
-			cl = hao_size_class(e.n);
+			cl = hao_size_class(e.n); g_cls[g0 + k] = (uint8_t)cl;
 		}
 #pragma unroll
 		for (int x = 0; x < HAO_NCLS; ++x) {
