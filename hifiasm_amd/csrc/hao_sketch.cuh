@@ -137,6 +137,7 @@ __global__ __launch_bounds__(HAO_SK_THREADS) void sketch_chunk_kernel(hao_sk_arg
 
 	// which (read, chunk)?
 	uint64_t ch = blockIdx.x, lo = 0, hi = a.n_sel;
+	if (ch >= a.chunk_off[a.n_sel]) return;          // the grid is sized from read lengths (an upper bound of the run counts): no host round trip for the exact count
 	while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (a.chunk_off[m + 1] <= ch) lo = m + 1; else hi = m; }
 	const uint64_t r = lo;
 	if (a.scalar_flag[r]) return;                                   // record is written by the scalar kernel
@@ -362,6 +363,7 @@ __global__ __launch_bounds__(256) void sketch_chunk_wave_kernel(hao_sk_args a)
 	__shared__ uint64_t fx[64]; __shared__ uint32_t fc[64]; __shared__ uint32_t s_wcnt[4]; __shared__ unsigned long long s_base; __shared__ int s_patch_prev, s_patch_on;
 	const int k = a.k, w = W, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	uint64_t ch = blockIdx.x, lo = 0, hi = a.n_sel;
+	if (ch >= a.chunk_off[a.n_sel]) return;          // the grid is sized from read lengths (an upper bound of the run counts): no host round trip for the exact count
 	while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (a.chunk_off[m + 1] <= ch) lo = m + 1; else hi = m; }
 	const uint64_t r = lo;
 	if (a.scalar_flag[r]) return;
@@ -569,12 +571,11 @@ __global__ __launch_bounds__(256) void sketch_gather_kernel(const uint64_t *pool
 }
 
 // per-read list bounds from the chunk scan: mz_off[r] = chunk_dst[chunk_off[r]]
-__global__ void sketch_read_off_kernel(const uint64_t *chunk_off, const uint64_t *chunk_dst, uint64_t n_sel, uint64_t n_chunks, uint64_t total, uint64_t *mz_off)
+__global__ void sketch_read_off_kernel(const uint64_t *chunk_off, const uint64_t *chunk_dst, uint64_t n_sel, uint64_t *mz_off)
 {
 	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r > n_sel) return;
-	uint64_t c = chunk_off[r];
-	mz_off[r] = c < n_chunks ? chunk_dst[c] : total;
+	mz_off[r] = chunk_dst[chunk_off[r]];          // chunk_dst has one entry past the last chunk (= total)
 }
 
 // ---------------------------------------------------------------------------------------
