@@ -74,4 +74,6 @@ BIG_SCENARIOS = {
     # more than 1024 chains (selection keys in global scratch, bitonic finish)
     "long200k": (dict(genome_size=1_000_000, coverage=16, read_len=200_000, err=0.008, seed=31, len_jit=20_000), dict(is_ont=1)),
     "rr_heavy": (dict(genome_size=300_000, coverage=20, read_len=6000, err=0.001, seed=9, repeat_rich=1, len_jit=1500), {}),
+    # long reads over a repeat-rich genome: groups of several thousand hits that fail the quick check (chain DP with f/p/marks in global scratch)
+    "long_rr":  (dict(genome_size=600_000, coverage=10, read_len=100_000, err=0.004, seed=33, repeat_rich=1, len_jit=20_000), dict(is_ont=1)),
 }
