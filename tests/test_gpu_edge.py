@@ -74,3 +74,17 @@ def test_identical_reads():
     e, o = _both(rs)
     assert _compare_all(e, o, rs) > 0
     e.close()
+
+
+def test_bloom_with_n_reads_and_ragged_lengths():
+    """the Bloom replay must skip the sentinel slots of reads with N (scalar hashing path) - scenario 'edge' at -f23"""
+    from scenarios import edge_reads
+    rs = edge_reads()
+    e, o = _both(rs, bf_shift=23)
+    assert e.ha_ft_gen() == o.ft_gen()
+    import numpy as np
+    assert (np.array(e.hist(0)) == o.ft_hist()).all()
+    k, v = o.ft_table()
+    ek, ev = e.ft_table()
+    assert (ek == k).all() and (ev == v).all()
+    e.close()
