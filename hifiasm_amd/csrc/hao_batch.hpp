@@ -205,7 +205,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	sa.key_xs = B.key_xs.p; sa.key_sc = B.key_sc.p; sa.key_al = B.key_al.p; sa.key_tmp = B.key_tmp.p;
 	sa.ol = B.ol.p; sa.g_off = B.g_off.p; sa.ch_base = B.ch_base.p; sa.cl_base = B.cl_base.p; sa.cl = B.cl.p; sa.n_sel = n; sa.rid_lo = glo; sa.len = c->d_len_all.p; sa.cc_off = B.cc_off.p; sa.cc = B.cc.p;
 	sa.perm = B.perm.p; sa.n_final = B.n_final.p; sa.fc_final = B.fc_final.p; sa.max_n_chain = par.max_n_chain; sa.ocv_w = par.ocv_w; sa.chain_cutoff = par.chain_cutoff;
-	sa.dbg = nullptr;
+	sa.dbg = nullptr; sa.dbg_seq_prune = getenv("HAO_DBG_SEQ_PRUNE") ? 1 : 0;
 	if (getenv("HAO_DBG_SELPHASE")) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); sa.dbg = B.dbgbuf.p; }
 	// three launches split by chain count: the common reads (<= 128 chains) need 5 KB of LDS per wave and fill the CUs; 512- and 1024-chain slices for
 	// repeat-rich reads (beyond 1024 chains the keys stay in global scratch)

@@ -1036,6 +1036,7 @@ struct hao_sel_args {
 	uint64_t *key_xs; int32_t *key_sc; uint32_t *key_al, *key_tmp;   // global key scratch (reads with more chains than the LDS slice holds); key_tmp: 5 words per chain
 	uint32_t *perm; uint32_t *n_final; uint64_t *fc_final;        // outputs: permutation (per read slice), kept count, kept fake-cigar entries
 	uint64_t max_n_chain, ocv_w; uint32_t chain_cutoff;
+	int dbg_seq_prune;            // HAO_DBG_SEQ_PRUNE: one-lane pruning scan (A/B)
 	unsigned long long *dbg;      // optional phase timers (HAO_DBG_SELPHASE): wall-clock ticks summed over reads: score sort, prune, position sort, weak filter, reads
 };
 
@@ -1093,6 +1094,106 @@ __device__ int64_t hao_select_prune(const hao_sel_args &A, const hao_sel_ctx &S,
 	return n;
 }
 
+
+// The same pruning by the whole wave, bit-exact:
+//   * the per-type thresholds are a counting scan (ballots);
+//   * a chain at or above its threshold is kept unconditionally and adds its coverage; the additions commute (no counter can saturate:
+//     n * ocv_w < 2^32, checked by the caller), so a tile's unconditional chains add with LDS / global atomics;
+//   * a contained chain below the threshold is rescued when >= 70 % of its length lies in windows that are not full yet.  More coverage
+//     can only turn windows full, so a chain that fails the test against the coverage at the START of its tile fails it against the exact
+//     coverage too: all 64 candidates of a tile are tested in parallel against that lower bound, and only the (rare, once the windows
+//     fill up) survivors are replayed one by one, in order, with the exact coverage.
+template<bool CCLDS>
+__device__ int64_t hao_select_prune_wave(const hao_sel_args &A, const hao_sel_ctx &S, int64_t n, int lch, uint64_t r, int *lch_out, uint64_t *l_cc)
+{
+	const uint64_t rl = A.len[A.rid_lo + r], max_n_chain = A.max_n_chain, ocv_w = A.ocv_w; const uint32_t chain_cutoff = A.chain_cutoff;
+	const int lane = hao_lane(); const unsigned long long ltm = (1ULL << lane) - 1;
+	*lch_out = lch;
+	if ((uint64_t)n <= max_n_chain) return n;
+	unsigned long long *cc = (unsigned long long*)(CCLDS ? l_cc : A.cc + A.cc_off[r]);
+	// thresholds: score of the max_n_chain-th chain of each overlap type, in score order
+	int32_t s[4] = {0, 0, 0, 0}; uint64_t nn[4] = {0, 0, 0, 0};
+	for (int64_t b = 0; b < n; b += 64) {
+		const int64_t i = b + lane; const bool act = i < n;
+		const uint32_t me = act ? S.pm[i] : 0; const int w = act ? hao_ov_type(S.xs[me], (uint32_t)rl) : -1; const int32_t sc = act ? S.sc[me] : 0;
+#pragma unroll
+		for (int t = 0; t < 4; ++t) {
+			const unsigned long long m = __ballot(w == t); const uint64_t c = __popcll(m);
+			if (nn[t] < max_n_chain && nn[t] + c >= max_n_chain) {
+				const uint64_t need = max_n_chain - nn[t];       // the need-th set bit of m
+				const unsigned long long hit = __ballot(w == t && (uint64_t)__popcll(m & ltm) + 1 == need);
+				s[t] = hao_bcast(sc, __ffsll((long long)hit) - 1);
+			}
+			nn[t] += c;
+		}
+	}
+	if (!(s[0] > 0 || s[1] > 0 || s[2] > 0 || s[3] > 0)) return n;
+	uint64_t cwn = 0;
+	if (nn[3] >= max_n_chain && rl >= ocv_w) {
+		cwn = rl / ocv_w + (rl % ocv_w ? 1 : 0);
+		for (uint64_t mm = lane; mm < cwn; mm += 64) {
+			const uint64_t cws = mm * ocv_w; uint64_t cwe = cws + ocv_w; if (cwe > rl) cwe = rl;
+			uint64_t v = (cwe - cws) * (max_n_chain >> 1); if (v > UINT32_MAX) v = UINT32_MAX;
+			cc[mm] = v << 32;
+		}
+		HAO_WFENCE();
+	}
+	uint32_t *out = S.pm2; int64_t kk = 0; int lch2 = 0;
+	for (int64_t b = 0; b < n; b += 64) {
+		const int64_t i = b + lane; const bool act = i < n;
+		const uint32_t me = act ? S.pm[i] : 0; const uint64_t xs = act ? S.xs[me] : 0;
+		const uint64_t rs = xs >> 32, re = (uint64_t)(uint32_t)xs + 1;
+		const int w = act ? hao_ov_type(xs, (uint32_t)rl) : 0;
+		const bool unc = act && S.sc[me] >= s[w];
+		bool maybe = false;
+		auto rescue_test = [&]() -> bool {         // >= 70 % of the chain in windows that it does not fill (anchor.cpp:2016-2032)
+			uint64_t cw0 = 0, cw1 = 0, mm = rs / ocv_w, cws = mm * ocv_w;
+			for (; mm < cwn; ++mm, cws += ocv_w) {
+				uint64_t cwe = cws + ocv_w; if (cwe > rl) cwe = rl;
+				const uint64_t os = rs >= cws ? rs : cws, oe = re <= cwe ? re : cwe;
+				if (oe <= os) break;
+				const unsigned long long v = cc[mm];
+				if ((oe - os) + (uint64_t)(uint32_t)v >= (v >> 32)) cw1 += oe - os; else cw0 += oe - os;
+			}
+			return (double)cw0 >= (double)(cw0 + cw1) * 0.7;
+		};
+		auto cov_add = [&]() {                     // coverage of [rs, re) into its windows; counters cannot saturate here (caller's bound)
+			uint64_t mm = rs / ocv_w, cws = mm * ocv_w;
+			for (; mm < cwn; ++mm, cws += ocv_w) {
+				uint64_t cwe = cws + ocv_w; if (cwe > rl) cwe = rl;
+				const uint64_t os = rs >= cws ? rs : cws, oe = re <= cwe ? re : cwe;
+				if (oe <= os) break;
+				atomicAdd(cc + mm, (unsigned long long)(oe - os));
+			}
+		};
+		if (act && !unc && w == 3 && cwn > 0) maybe = rescue_test();       // against the coverage before this tile: a lower bound
+		const unsigned long long um = __ballot(unc); unsigned long long mm_ = __ballot(maybe), keepm = um;
+		if (cwn) {
+			int pos = 0;
+			for (;;) {
+				const unsigned long long rest = pos < 64 ? mm_ & ~((1ULL << pos) - 1) : 0ULL;
+				const int c = rest ? __ffsll((long long)rest) - 1 : 64;
+				if (unc && lane >= pos && lane < c) cov_add();
+				HAO_WFENCE();
+				if (c == 64) break;
+				bool ok = false;
+				if (lane == c) { ok = rescue_test(); if (ok) cov_add(); }      // exact coverage: everything kept before this chain has been added
+				HAO_WFENCE();
+				if (__ballot(ok)) keepm |= 1ULL << c;
+				pos = c + 1;
+			}
+		}
+		const bool keep = (keepm >> lane) & 1;
+		if (keep) out[kk + __popcll(keepm & ltm)] = me;
+		if (__ballot(keep && S.al[me] < chain_cutoff)) lch2 = 1;
+		kk += __popcll(keepm);
+	}
+	HAO_WFENCE();
+	for (int64_t i = lane; i < kk; i += 64) S.pm[i] = out[i];
+	HAO_WFENCE();
+	*lch_out = lch2;
+	return kk;
+}
 
 // weak-chain filter (anchor.cpp:2061-2096), whole wave: control flow is uniform (keys in LDS), the count of a strong
 // chain's hits inside the overlap interval is a strided wave reduction (the reference stops counting at ocn; only
@@ -1190,8 +1291,12 @@ __device__ __forceinline__ void hao_select_body(const hao_sel_args &A, const uin
 	if ((uint64_t)n > A.max_n_chain) {
 		hao_wave_intro_sort<0>(S, n);
 		if (A.dbg) tk1 = wall_clock64();
-		if (lane == 0) nf = (uint64_t)A.len[A.rid_lo + r] / A.ocv_w + 2 <= HAO_SEL_CCAP ? hao_select_prune<true>(A, S, n, lch, r, &lch2, l_cc) : hao_select_prune<false>(A, S, n, lch, r, &lch2, l_cc);
-		nf = __shfl(nf, 0); lch2 = __shfl(lch2, 0);
+		const bool cc_lds = (uint64_t)A.len[A.rid_lo + r] / A.ocv_w + 2 <= HAO_SEL_CCAP;
+		if ((uint64_t)n * A.ocv_w < UINT32_MAX && !A.dbg_seq_prune) nf = cc_lds ? hao_select_prune_wave<true>(A, S, n, lch, r, &lch2, l_cc) : hao_select_prune_wave<false>(A, S, n, lch, r, &lch2, l_cc);
+		else {      // a coverage counter could saturate: keep the order-dependent scan on one lane
+			if (lane == 0) nf = cc_lds ? hao_select_prune<true>(A, S, n, lch, r, &lch2, l_cc) : hao_select_prune<false>(A, S, n, lch, r, &lch2, l_cc);
+			nf = __shfl(nf, 0); lch2 = __shfl(lch2, 0);
+		}
 		HAO_WFENCE();
 		if (A.dbg) tk2 = wall_clock64();
 	}
