@@ -211,9 +211,17 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	// repeat-rich reads (beyond 1024 chains the keys stay in global scratch)
 	hipLaunchKernelGGL((chain_select_kernel<1, 128>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)0, (int64_t)129);
 	HAO_CHECK_LAUNCH();
-	hipLaunchKernelGGL((chain_select_kernel<1, 512>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)129, (int64_t)513);
-	HAO_CHECK_LAUNCH();
-	hipLaunchKernelGGL((chain_select_kernel<1, 1024>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)513, (int64_t)INT64_MAX);
+	if (getenv("HAO_DBG_SEL1")) {      // one wave per read for every size (A/B)
+		hipLaunchKernelGGL((chain_select_kernel<1, 512>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)129, (int64_t)513);
+		HAO_CHECK_LAUNCH();
+		hipLaunchKernelGGL((chain_select_kernel<1, 1024>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)513, (int64_t)INT64_MAX);
+	} else {                           // 129 .. 1024 chains: four waves per read share the sorts; beyond 1024 chains: keys in global scratch, one wave
+		hipLaunchKernelGGL((chain_select4_kernel<512>), dim3((unsigned)n), dim3(256), 0, c->stream, sa, (int64_t)129, (int64_t)513);
+		HAO_CHECK_LAUNCH();
+		hipLaunchKernelGGL((chain_select4_kernel<1024>), dim3((unsigned)n), dim3(256), 0, c->stream, sa, (int64_t)513, (int64_t)1025);
+		HAO_CHECK_LAUNCH();
+		hipLaunchKernelGGL((chain_select_kernel<1, 1024>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)1025, (int64_t)INT64_MAX);
+	}
 	HAO_CHECK_LAUNCH();
 	if (int rc = hao_scan_u32(c, B.n_final.p, B.fin_off.p, n + 1)) return rc;
 	if (int rc = hao_excl_scan_u64(c, B.fc_final.p, B.fcf_off.p, n + 1)) return rc;

@@ -1010,6 +1010,116 @@ template<int MODE> __device__ void hao_wave_intro_sort(const hao_sel_ctx &S, int
 	HAO_WFENCE();
 }
 
+// The same sort by a workgroup of NW waves.  Sub-ranges of the quicksort phase are independent (klib's explicit stack only fixes the order
+// in which they are visited, and the depth budget d travels with each sub-range), so the phase runs level by level: every wave partitions
+// the sub-ranges of the current level assigned to it (stop lists of sub-range [s, t] live at lpos/rasc[s ..]) and appends the children
+// that klib would still partition (> 16 elements) to the next level's list.  The stable finish is data-parallel over all threads.
+#define HAO_BSORT_MAXSEG 64       // > CAP / 18 sub-ranges can never be alive in one level (CAP <= 1024)
+template<int MODE, int NW> __device__ void hao_block_intro_sort(const hao_sel_ctx &S, int64_t n, int32_t *segs /*[2][3 * MAXSEG]*/, uint32_t *segn /*[2]*/, int *flag)
+{
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, NT = NW * 64;
+	if (n < 1) return;
+	if (n == 2) { if (tid == 0 && hao_lt<MODE>(S, 1, 0)) hao_sw(S, 0, 1); __syncthreads(); return; }
+	if (tid == 0) { int d0; for (d0 = 2; (1ull << d0) < (uint64_t)n; ++d0) {} segs[0] = 0; segs[1] = (int32_t)(n - 1); segs[2] = d0 << 1; segn[0] = 1; segn[1] = 0; }
+	__syncthreads();
+	for (int ci = 0; ; ci ^= 1) {
+		const uint32_t nseg = segn[ci];
+		if (nseg == 0) break;
+		const int32_t *cur = segs + ci * 3 * HAO_BSORT_MAXSEG; int32_t *nxt = segs + (ci ^ 1) * 3 * HAO_BSORT_MAXSEG;
+		for (uint32_t e = wv; e < nseg; e += NW) {
+			const int64_t s = cur[3 * e], t = cur[3 * e + 1]; int d = cur[3 * e + 2];
+			int64_t i, j, k;
+			if (--d == 0) { if (lane == 0) hao_comb_sort<MODE>(S, s, t - s + 1); HAO_WFENCE(); continue; }
+			i = s; j = t; k = i + ((j - i) >> 1) + 1;
+			if (hao_lt<MODE>(S, k, i)) { if (hao_lt<MODE>(S, k, j)) k = j; }
+			else k = hao_lt<MODE>(S, j, i) ? i : j;
+			if (k != t) { if (lane == 0) hao_sw(S, k, t); HAO_WFENCE(); }
+			const uint64_t rp = hao_skey<MODE>(S, S.pm[t]);
+			uint32_t *lpos = S.lpos + s, *rasc = S.rasc + s;
+			uint32_t nL = 0, nR = 0;
+			for (int64_t p0 = s + 1; p0 <= t; p0 += 64) {
+				const int64_t p = p0 + lane; const bool act = p <= t;
+				const uint64_t key = act ? hao_skey<MODE>(S, S.pm[p]) : 0;
+				const bool Lf = act && !(key < rp), Rf = act && p < t && !(rp < key);
+				const unsigned long long bl = __ballot(Lf), br = __ballot(Rf), lt_ = (1ULL << lane) - 1;
+				if (Lf) lpos[nL + __popcll(bl & lt_)] = (uint32_t)p;
+				if (Rf) rasc[nR + __popcll(br & lt_)] = (uint32_t)p;
+				nL += __popcll(bl); nR += __popcll(br);
+			}
+			HAO_WFENCE();
+			const uint32_t m = nL < nR ? nL : nR; uint32_t K = 0;
+			for (uint32_t k0 = 0; k0 < m; k0 += 64) {
+				const uint32_t kk = k0 + lane; const bool pr = kk < m && lpos[kk] < rasc[nR - 1 - kk];
+				const unsigned long long b = __ballot(pr); const int c = __popcll(b);
+				K += c; if (c < 64) break;
+			}
+			for (uint32_t k0 = 0; k0 < K; k0 += 64) { const uint32_t kk = k0 + lane; if (kk < K) hao_sw(S, lpos[kk], rasc[nR - 1 - kk]); }
+			HAO_WFENCE();
+			i = K == 0 ? lpos[0] : (lpos[K] < rasc[nR - K] ? lpos[K] : rasc[nR - K]);
+			if (lane == 0) {
+				hao_sw(S, i, t);
+				if (i - s > 16) { const uint32_t q = atomicAdd(&segn[ci ^ 1], 1u); nxt[3 * q] = (int32_t)s; nxt[3 * q + 1] = (int32_t)(i - 1); nxt[3 * q + 2] = d; }
+				if (t - i > 16) { const uint32_t q = atomicAdd(&segn[ci ^ 1], 1u); nxt[3 * q] = (int32_t)(i + 1); nxt[3 * q + 1] = (int32_t)t; nxt[3 * q + 2] = d; }
+			}
+			HAO_WFENCE();
+		}
+		__syncthreads();
+		if (tid == 0) segn[ci] = 0;
+		__syncthreads();
+	}
+	// stable finish = klib's final insertion sort (see hao_wave_intro_sort), all threads
+	uint32_t *A_ = S.pm2, *P_ = S.lpos;
+	for (int64_t p = tid; p < n; p += NT) A_[p] = 0xffffffffu;
+	if (tid == 0) *flag = 0;
+	__syncthreads();
+	for (int64_t p = tid; p < n; p += NT) {
+		const uint32_t me = S.pm[p]; const uint64_t key = hao_skey<MODE>(S, me); int64_t dst = p;
+		for (int64_t q = p - 16 < 0 ? 0 : p - 16; q < p; ++q) if (hao_skey<MODE>(S, S.pm[q]) > key) --dst;
+		for (int64_t q = p + 1; q <= p + 16 && q < n; ++q) if (hao_skey<MODE>(S, S.pm[q]) < key) ++dst;
+		if (dst >= 0 && dst < n) { A_[dst] = me; P_[dst] = (uint32_t)p; }      // (colliding writes leave a hole somewhere else: caught below)
+	}
+	__syncthreads();
+	{
+		int bad = 0;
+		for (int64_t p = tid; p < n; p += NT) {
+			if (A_[p] == 0xffffffffu) bad = 1;
+			else if (p > 0 && A_[p - 1] != 0xffffffffu) {
+				const uint64_t ka = hao_skey<MODE>(S, A_[p - 1]), kb = hao_skey<MODE>(S, A_[p]);
+				if (ka > kb || (ka == kb && P_[p - 1] > P_[p])) bad = 1;
+			}
+		}
+		if (bad) *flag = 1;
+	}
+	__syncthreads();
+	if (!*flag) {
+		for (int64_t p = tid; p < n; p += NT) S.pm[p] = A_[p];
+		__syncthreads();
+		return;
+	}
+	__syncthreads();
+	uint32_t n2 = 1; while (n2 < (uint32_t)n) n2 <<= 1;
+	for (uint32_t p = tid; p < n2; p += NT) { A_[p] = p < (uint32_t)n ? S.pm[p] : 0xffffffffu; P_[p] = p; }
+	__syncthreads();
+	for (uint32_t kk = 2; kk <= n2; kk <<= 1) {
+		for (uint32_t jj = kk >> 1; jj > 0; jj >>= 1) {
+			for (uint32_t a = tid; a < n2; a += NT) {
+				const uint32_t b = a ^ jj;
+				if (b > a) {
+					const uint32_t ia = A_[a], ib = A_[b], pa = P_[a], pb = P_[b];
+					const bool infa = ia == 0xffffffffu, infb = ib == 0xffffffffu;
+					const uint64_t ka = infa ? 0 : hao_skey<MODE>(S, ia), kb = infb ? 0 : hao_skey<MODE>(S, ib);
+					const bool a_gt_b = infa ? (!infb || pa > pb) : (infb ? false : (ka > kb || (ka == kb && pa > pb)));
+					const bool up = (a & kk) == 0;
+					if (a_gt_b == up) { A_[a] = ib; A_[b] = ia; P_[a] = pb; P_[b] = pa; }
+				}
+			}
+			__syncthreads();
+		}
+	}
+	for (int64_t p = tid; p < n; p += NT) S.pm[p] = A_[p];
+	__syncthreads();
+}
+
 __device__ __forceinline__ int hao_ov_type(uint64_t xs, uint32_t len)       // ha_ov_type, anchor.cpp:86-91
 {
 	const uint32_t x_pos_s = (uint32_t)(xs >> 32), x_pos_e = (uint32_t)xs;
@@ -1329,6 +1439,58 @@ __global__ __launch_bounds__(WPB * 64) void chain_select_kernel(hao_sel_args A, 
 	const uint64_t cl0 = A.cl_base[g0], cn = A.cl_base[g1] - cl0;
 	if (n <= CAP) hao_select_body<CAP, true>(A, r, n, o0, cl0, cn, l_xs[wv], l_sc[wv], l_al[wv], l_pm[wv], l_pm2[wv], l_lp[wv], l_rp[wv], l_stack[wv], l_cc[wv]);
 	else hao_select_body<CAP, false>(A, r, n, o0, cl0, cn, l_xs[wv], l_sc[wv], l_al[wv], l_pm[wv], l_pm2[wv], l_lp[wv], l_rp[wv], l_stack[wv], l_cc[wv]);
+}
+
+// Reads with hundreds of chains (repeat-rich): one workgroup of four waves per read.  The two sorts run on all four waves
+// (hao_block_intro_sort); pruning and the weak-chain filter are single-wave code (wave 0), the other waves wait at the barriers.
+template<int CAP>
+__global__ __launch_bounds__(256) void chain_select4_kernel(hao_sel_args A, int64_t n_lo, int64_t n_hi)
+{
+	__shared__ uint64_t l_xs[CAP]; __shared__ int32_t l_sc[CAP]; __shared__ uint32_t l_al[CAP], l_pm[CAP], l_pm2[CAP], l_lp[CAP], l_rp[CAP];
+	__shared__ int32_t l_stack[3 * 72]; __shared__ uint64_t l_cc[HAO_SEL_CCAP];
+	__shared__ int32_t l_segs[2 * 3 * HAO_BSORT_MAXSEG]; __shared__ uint32_t l_segn[2]; __shared__ int l_flag; __shared__ int64_t l_nf; __shared__ int l_lch;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const uint64_t r = blockIdx.x;
+	if (r >= A.n_sel) return;
+	const uint64_t g0 = A.g_off[r], g1 = A.g_off[r + 1], o0 = A.ch_base[g0];
+	const int64_t n = (int64_t)(A.ch_base[g1] - o0);
+	if (n < n_lo || n >= n_hi) return;                          // this read belongs to another launch (n <= CAP here)
+	const uint64_t cl0 = A.cl_base[g0], cn = A.cl_base[g1] - cl0;
+	const hao_ovlp_t *rec = A.ol + o0;
+	int lch = 0;
+	for (int64_t i = tid; i < n; i += 256) {
+		const hao_ovlp_t q = rec[i];
+		l_xs[i] = (uint64_t)q.x_pos_s << 32 | q.x_pos_e; l_sc[i] = q.shared_seed; l_al[i] = q.align_length; l_pm[i] = (uint32_t)i;
+		if (q.align_length < A.chain_cutoff) lch = 1;
+	}
+	if (tid == 0) l_lch = 0;
+	__syncthreads();
+	if (lch) l_lch = 1;
+	__syncthreads();
+	lch = l_lch;
+	hao_sel_ctx S; S.xs = l_xs; S.sc = l_sc; S.al = l_al; S.pm = l_pm; S.stack = l_stack; S.pm2 = l_pm2; S.lpos = l_lp; S.rasc = l_rp;
+	int64_t nf = n; int lch2 = lch;
+	if ((uint64_t)n > A.max_n_chain) {
+		hao_block_intro_sort<0, 4>(S, n, l_segs, l_segn, &l_flag);
+		if (wv == 0) {
+			const bool cc_lds = (uint64_t)A.len[A.rid_lo + r] / A.ocv_w + 2 <= HAO_SEL_CCAP;
+			if ((uint64_t)n * A.ocv_w < UINT32_MAX) nf = cc_lds ? hao_select_prune_wave<true>(A, S, n, lch, r, &lch2, l_cc) : hao_select_prune_wave<false>(A, S, n, lch, r, &lch2, l_cc);
+			else { if (lane == 0) nf = cc_lds ? hao_select_prune<true>(A, S, n, lch, r, &lch2, l_cc) : hao_select_prune<false>(A, S, n, lch, r, &lch2, l_cc); nf = __shfl(nf, 0); lch2 = __shfl(lch2, 0); }
+			if (lane == 0) { l_nf = nf; l_lch = lch2; }
+		}
+		__syncthreads();
+		nf = l_nf; lch2 = l_lch;
+	}
+	hao_block_intro_sort<1, 4>(S, nf, l_segs, l_segn, &l_flag);
+	__syncthreads();
+	if (wv != 0) return;
+	if (lch2) nf = hao_select_weak(A, S, nf, rec, A.cl + cl0, cn);
+	__threadfence_block();
+	uint64_t fct = 0;
+	for (int64_t i = lane; i < nf; i += 64) { const uint32_t pi = l_pm[i]; A.perm[o0 + i] = pi; fct += rec[pi].fc_len; }
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) fct += __shfl_xor(fct, d);
+	if (lane == 0) { A.n_final[r] = (uint32_t)nf; A.fc_final[r] = fct; }
 }
 
 // final gather: records in final order (align_length zeroed, anchor.cpp:2098) + fake cigars in that order. One wave per read.
