@@ -1509,10 +1509,16 @@ __global__ __launch_bounds__(256) void chain_final_kernel(const hao_ovlp_t *ol, 
 		uint32_t inc = fl;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d); if (lane >= d) inc += y; }
+		const uint64_t fo = run + inc - fl;
 		if (act) {
-			const uint64_t fo = run + inc - fl;
 			o.align_length = 0; ol_out[d0 + i] = o; fc_out_off[d0 + i] = fo;
-			for (uint32_t j = 0; j < fl; ++j) fc_out[fo + j] = fc_raw[fs + j];
+			if (fl <= 16) for (uint32_t j = 0; j < fl; ++j) fc_out[fo + j] = fc_raw[fs + j];
+		}
+		// long cigars (noisy reads: hundreds of entries per chain): the wave copies them together, one chain after the other
+		for (unsigned long long big = __ballot(act && fl > 16); big; big &= big - 1) {
+			const int l = __ffsll((long long)big) - 1;
+			const uint64_t cfs = hao_readlane_i64((int64_t)fs, l), cfo = hao_readlane_i64((int64_t)fo, l); const uint32_t cfl = hao_bcast(fl, l);
+			for (uint32_t j = lane; j < cfl; j += 64) fc_out[cfo + j] = fc_raw[cfs + j];
 		}
 		run += __shfl(inc, 63);
 	}
