@@ -58,7 +58,7 @@ __device__ __forceinline__ int32_t hao_pair_score(const hao_hit_t &ai, const hao
 	int32_t dd = dr > dq ? dr - dq : dq - dr;
 	if (dd > 16 && dd > hao_band(ai, aj, P)) return INT32_MIN;
 	int32_t dg = dr < dq ? dr : dq, span = HH_SPAN(ai), sc = span < dg ? span : dg, wgt = HH_WGT(ai);
-	sc = sc >= wgt ? sc / wgt : 1;
+	if (wgt != 1) sc = sc >= wgt ? (wgt == 2 ? sc >> 1 : sc / wgt) : 1;      // weight 1 (and 2) are the rule: the integer division (~40 instructions) only runs for rarer seeds
 	if (dd) {
 		double lin = P.pen_gap * (double)dd; const double skip = P.pen_skip * (double)dg;
 		// dd < 4: the penalty is min(lin, ap) + skip with ap >= 0, and FP addition is monotonic, so it lies in [0, lin + skip]; when that
@@ -152,6 +152,7 @@ struct hao_chain_args {
 	unsigned long long *stats;                   // [0 .. HAO_NCLS) groups of each size class needing the DP kernel, [HAO_NCLS] their hits
 	int32_t *tm;                                 // per-hit mark scratch for oversize groups
 	int dbg_skip_generic, dbg_seq, dbg_stats;
+	unsigned long long *dbg_qc;   // optional phase timers of chain_group_kernel (HAO_DBG_QCPHASE)
 };
 
 // Sequential tail shared by both paths (ONE lane): backtrack the best chain, multi-copy chains
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 	const uint64_t li = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	if (li >= n_list) return;
 	const int lane = hao_lane();
+	const unsigned long long tq0 = A.dbg_qc ? wall_clock64() : 0;
 	const hao_gent e = list[li];                                  // wave-uniform: scalar loads
 	const uint64_t g = e.g, gs = e.start; const int64_t a_n = e.n;
 	const hao_hit_t *a = A.hits + gs;
@@ -345,6 +347,7 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 	const hao_hit_t first0 = hao_shfl_hit(hn, 0);
 	hao_cpar P; P.pen_gap = A.par.pen_gap; P.pen_skip = A.par.pen_skip; P.bw = A.par.bw; P.max_skip = A.par.max_skip; P.max_iter = A.par.max_iter; P.max_dis = A.par.max_dis;
 	P.xl = e.xl; P.yl = e.yl;
+	const unsigned long long tq1 = A.dbg_qc ? wall_clock64() + (first0.w0 & 0) : 0;      // (+ 0 through the loaded hit: the stamp waits for tile 0)
 	const uint32_t strand0 = HH_STRAND(first0);
 	// ---- parallel quick check ----
 	int32_t carry_f = 0; hao_hit_t carry_h = first0;
@@ -381,6 +384,7 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 		maxf0 = max(maxf0, __shfl_xor(maxf0, d)); maxf1 = max(maxf1, __shfl_xor(maxf1, d));
 		ddt0 += __shfl_xor(ddt0, d); ddt1 += __shfl_xor(ddt1, d);
 	}
+	const unsigned long long tq2 = A.dbg_qc ? wall_clock64() + (unsigned long long)(maxf0 & 0) : 0;
 	const bool two = k1 < a_n;
 	const hao_hit_t first1 = two ? a[k1] : first0;
 	bool acc0 = !fail0 && flast0 == maxf0 && !(k1 >= 2 && ddt0 > 16 && ddt0 > hao_band(last0, first0, P));
@@ -408,6 +412,7 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 	if (lane == 0) {
 		rc.hit_rel = 0; rc.n_hits = (uint32_t)cL; rc.src_rel = (uint32_t)bl; rc.in_place = 1; rc.fc_rel = 0; rc.fc_len = cnt;
 		A.rec[g * HAO_MCOPY_MAX] = rc; A.nch[g] = 1; A.nout[g] = (uint32_t)cL;
+		if (A.dbg_qc && (li & 63) == 0) { /* sampled: one group in 64 */ const unsigned long long tq3 = wall_clock64(); atomicAdd(A.dbg_qc, tq1 - tq0); atomicAdd(A.dbg_qc + 1, tq2 - tq1); atomicAdd(A.dbg_qc + 2, tq3 - tq2); atomicAdd(A.dbg_qc + 3, 1ULL); atomicAdd(A.dbg_qc + 4, (unsigned long long)a_n); }
 	}
 }
 
