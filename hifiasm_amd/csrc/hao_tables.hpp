@@ -408,7 +408,7 @@ static int hao_pt_run(hao_ctx *c)
 		// Sharded build (SURVEY 2 C1 + 8e layout i): every rank owns the hash range [r, r+1) * 2^64 / world.
 		//   local stable sort by hash -> all-to-all-v of (x, info) by range -> stable sort of the received pieces (source-rank order =
 		//   global read order, so per-key lists come out in (rid,pos) order) -> count / histogram (all-reduced) / peaks / keep ->
-		//   all-gather-v of the sorted partitions and of their key tables: concatenation in rank order is the global index.
+		//   all-gather-v of the sorted position records (8 B each) and of the key tables: concatenation in rank order is the global index.
 		hao_comm &cm = *c->comm; const int W = cm.world; const uint64_t ml = c->ix_n_mz;
 		std::vector<uint64_t> rdc;
 		if (int rc = hao_comm_allgather_u64(c, cm, n, rdc)) return rc;
@@ -450,9 +450,8 @@ static int hao_pt_run(hao_ctx *c)
 		for (int r = 0; r < W; ++r) { if (r < cm.rank) base += part[r]; m += part[r]; nk += nks[r]; np += nps[r]; }
 		if (m >= (1ULL << 32)) { hao_set_err(c, "more than 2^32 minimizers in the replicated index"); return HAO_EUNSUPP; }
 		if (nk_p) { hipLaunchKernelGGL(hao_add_const_kernel, dim3((unsigned)((nk_p + 255) / 256)), dim3(256), 0, c->stream, pst.p, nk_p, base); HAO_CHECK_LAUNCH(); }
-		HIP_TRY(c->d_ix_sx.reserve(m + 1)); HIP_TRY(c->d_ix_sinfo.reserve(m + 1));
+		HIP_TRY(c->d_ix_sinfo.reserve(m + 1));      // (the sorted hashes themselves are not needed once the key table exists: only the 8-byte position records travel)
 		HIP_TRY(c->d_ix_keys.reserve(nk + 1)); HIP_TRY(c->d_ix_start.reserve(nk + 1)); HIP_TRY(c->d_ix_cnt.reserve(nk + 1));
-		if (int rc = hao_comm_allgatherv(c, cm, px.p, n_recv, 8, c->d_ix_sx.p, part)) return rc;
 		if (int rc = hao_comm_allgatherv(c, cm, pi.p, n_recv, 8, c->d_ix_sinfo.p, part)) return rc;
 		if (int rc = hao_comm_allgatherv(c, cm, pk.p, nk_p, 8, c->d_ix_keys.p, nks)) return rc;
 		if (int rc = hao_comm_allgatherv(c, cm, pst.p, nk_p, 8, c->d_ix_start.p, nks)) return rc;
