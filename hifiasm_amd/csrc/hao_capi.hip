@@ -44,7 +44,7 @@ void hao_destroy(hao_ctx *c)
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
 	hao_batch_free(c);
-	if (c->comm) { if (c->comm->nccl) ncclCommDestroy(c->comm->nccl); delete c->comm; c->comm = nullptr; }
+	if (c->comm) { if (c->comm->nccl) ncclCommDestroy(c->comm->nccl); c->comm->ag_tmp.release(); delete c->comm; c->comm = nullptr; }
 	// DevBuf members are released explicitly (no destructors: the struct is POD-ish on purpose)
 	hao_release_all(c);
 	(void)hipStreamDestroy(c->stream);

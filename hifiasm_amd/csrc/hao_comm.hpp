@@ -23,6 +23,7 @@ struct hao_loop_group {
 struct hao_comm {
 	int rank = 0, world = 1;
 	ncclComm_t nccl = nullptr; hao_loop_group *loop = nullptr;
+	DevBuf<char> ag_tmp;      // padded slots of the balanced all-gather-v
 	bool active() const { return world > 1 || nccl || loop; }
 };
 
@@ -45,6 +46,28 @@ static int hao_comm_allgather_u64(hao_ctx *c, hao_comm &cm, uint64_t v, std::vec
 	HIP_TRY(hipMemcpyAsync(d.p + cm.rank, &v, 8, hipMemcpyHostToDevice, c->stream));
 	NCCL_TRY(ncclAllGather(d.p + cm.rank, d.p, 1, ncclUint64, cm.nccl, c->stream));
 	HIP_TRY(hipMemcpyAsync(out.data(), d.p, 8 * cm.world, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	d.release();
+	return HAO_OK;
+}
+
+// the same for nv values per rank: out[r * nv + i] = value i of rank r (one collective instead of nv)
+static int hao_comm_allgather_u64n(hao_ctx *c, hao_comm &cm, const uint64_t *v, int nv, std::vector<uint64_t> &out)
+{
+	out.assign((size_t)cm.world * nv, 0);
+	if (cm.world == 1 && !cm.nccl && !cm.loop) { for (int i = 0; i < nv; ++i) out[i] = v[i]; return HAO_OK; }
+	if (cm.loop) {
+		hao_loop_group *g = cm.loop;
+		g->hostv[cm.rank].assign(v, v + nv);
+		pthread_barrier_wait(&g->bar);
+		for (int r = 0; r < cm.world; ++r) for (int i = 0; i < nv; ++i) out[(size_t)r * nv + i] = g->hostv[r][i];
+		pthread_barrier_wait(&g->bar);
+		return HAO_OK;
+	}
+	DevBuf<uint64_t> d; HIP_TRY(d.reserve((size_t)cm.world * nv + 1));
+	HIP_TRY(hipMemcpyAsync(d.p + (size_t)cm.rank * nv, v, 8 * (size_t)nv, hipMemcpyHostToDevice, c->stream));
+	NCCL_TRY(ncclAllGather(d.p + (size_t)cm.rank * nv, d.p, (size_t)nv, ncclUint64, cm.nccl, c->stream));
+	HIP_TRY(hipMemcpyAsync(out.data(), d.p, 8 * (size_t)cm.world * nv, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	d.release();
 	return HAO_OK;
@@ -88,6 +111,18 @@ static int hao_comm_allgatherv(hao_ctx *c, hao_comm &cm, const void *src, uint64
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		pthread_barrier_wait(&g->bar);
 		return HAO_OK;
+	}
+	{	// nearly equal parts (hash-range partitions are): ONE ring all-gather over padded slots - every link busy the whole time - then the slots are
+		// packed; only lopsided exchanges fall back to one broadcast per root
+		uint64_t maxc = 0, total = disp[cm.world]; for (int r = 0; r < cm.world; ++r) maxc = std::max(maxc, counts[r]);
+		if (maxc && maxc * (uint64_t)cm.world <= total + total / 4 + 4096) {
+			const size_t slot = (size_t)maxc * esz;
+			HIP_TRY(cm.ag_tmp.reserve(slot * cm.world + 16));
+			if (n_mine) HIP_TRY(hipMemcpyAsync(cm.ag_tmp.p + slot * cm.rank, src, n_mine * esz, hipMemcpyDeviceToDevice, c->stream));
+			NCCL_TRY(ncclAllGather(cm.ag_tmp.p + slot * cm.rank, cm.ag_tmp.p, slot, ncclChar, cm.nccl, c->stream));      // in place: send = recv + rank * count
+			for (int r = 0; r < cm.world; ++r) if (counts[r]) HIP_TRY(hipMemcpyAsync((char*)out + disp[r] * esz, cm.ag_tmp.p + slot * r, counts[r] * esz, hipMemcpyDeviceToDevice, c->stream));
+			return HAO_OK;
+		}
 	}
 	// own part must sit in the output before it is broadcast from there
 	if (n_mine) HIP_TRY(hipMemcpyAsync((char*)out + disp[cm.rank] * esz, src, n_mine * esz, hipMemcpyDeviceToDevice, c->stream));

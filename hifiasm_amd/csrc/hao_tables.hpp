@@ -442,10 +442,10 @@ static int hao_pt_run(hao_ctx *c)
 		DevBuf<uint64_t> pk, pst; DevBuf<uint32_t> pc; uint64_t nk_p = 0, np_p = 0;
 		if (int rc = hao_keep_runs(c, ukeys.p, ucnt.p, n_unique, 2, hi, pk, &pst, pc, &nk_p, &np_p)) return rc;
 		// global layout
-		std::vector<uint64_t> part, nks, nps;
-		if (int rc = hao_comm_allgather_u64(c, cm, n_recv, part)) return rc;
-		if (int rc = hao_comm_allgather_u64(c, cm, nk_p, nks)) return rc;
-		if (int rc = hao_comm_allgather_u64(c, cm, np_p, nps)) return rc;
+		std::vector<uint64_t> part(W), nks(W), nps(W), trip;
+		{ const uint64_t mine[3] = { n_recv, nk_p, np_p };
+		  if (int rc = hao_comm_allgather_u64n(c, cm, mine, 3, trip)) return rc;
+		  for (int r = 0; r < W; ++r) { part[r] = trip[3 * r]; nks[r] = trip[3 * r + 1]; nps[r] = trip[3 * r + 2]; } }
 		uint64_t m = 0, base = 0, nk = 0, np = 0;
 		for (int r = 0; r < W; ++r) { if (r < cm.rank) base += part[r]; m += part[r]; nk += nks[r]; np += nps[r]; }
 		if (m >= (1ULL << 32)) { hao_set_err(c, "more than 2^32 minimizers in the replicated index"); return HAO_EUNSUPP; }
