@@ -788,12 +788,14 @@ __global__ __launch_bounds__(256) void chain_assemble_kernel(hao_asm_args A)
 			o.shared_seed = rc.score; o.align_length = rc.n_hits; o.non_homopolymer_errors = (uint32_t)(hd - cl0); o.fc_len = rc.fc_len;
 			A.ol[oi] = o; A.ol_fc_off[oi] = fd;
 		}
-		for (uint32_t i = hao_lane(); i < rc.n_hits; i += 256) {       // four 16-byte loads in flight per lane
-			hao_hit_t h4[4];
+		typedef uint32_t hao_u32x4 __attribute__((ext_vector_type(4)));
+		const hao_u32x4 *src4 = (const hao_u32x4*)src; hao_u32x4 *dst4 = (hao_u32x4*)(A.cl + hd);
+		for (uint32_t i = hao_lane(); i < rc.n_hits; i += 256) {       // four 16-byte loads in flight per lane; streamed once in, once out: non-temporal
+			hao_u32x4 h4[4];
 #pragma unroll
-			for (int u = 0; u < 4; ++u) if (i + u * 64 < rc.n_hits) h4[u] = src[i + u * 64];
+			for (int u = 0; u < 4; ++u) if (i + u * 64 < rc.n_hits) h4[u] = __builtin_nontemporal_load(src4 + i + u * 64);
 #pragma unroll
-			for (int u = 0; u < 4; ++u) if (i + u * 64 < rc.n_hits) { h4[u].w0 = (h4[u].w0 & 0x80000000u) | (ord & 0x7fffffffu); A.cl[hd + i + u * 64] = h4[u]; }
+			for (int u = 0; u < 4; ++u) if (i + u * 64 < rc.n_hits) { h4[u].x = (h4[u].x & 0x80000000u) | (ord & 0x7fffffffu); __builtin_nontemporal_store(h4[u], dst4 + i + u * 64); }
 		}
 		for (uint32_t i = hao_lane(); i < rc.fc_len; i += 64) A.fc[fd + i] = fsrc[rc.fc_rel + i];
 	}
