@@ -337,6 +337,10 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 	const uint64_t li = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	if (li >= n_list) return;
 	const int lane = hao_lane();
+	// fake-cigar entries are collected during the scan (an entry wherever offset - self_offset changes: the region's constant only shifts the
+	// values), up to 64 per strand block in LDS, so the hits are read ONCE; longer cigars fall back to a second sweep
+	__shared__ uint64_t l_eb[4][2][64];
+	uint64_t (*eb)[64] = l_eb[threadIdx.x >> 6]; uint32_t ce0 = 0, ce1 = 0;
 	const unsigned long long tq0 = A.dbg_qc ? wall_clock64() : 0;
 	const hao_gent e = list[li];                                  // wave-uniform: scalar loads
 	const uint64_t g = e.g, gs = e.start; const int64_t a_n = e.n;
@@ -362,6 +366,11 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 		const int b = act && HH_STRAND(h) != strand0;
 		int32_t s = HH_SPAN(h); bool ok = true; int64_t dd = 0;
 		if (act && !st) { s = hao_pair_score(h, ph, P, &dd); ok = s != INT32_MIN; if (!ok) { s = 0; dd = 0; } }
+		{	const uint32_t diag = h.offset - h.self_offset, pdiag = ph.offset - ph.self_offset;
+			const bool cf = act && (st || diag != pdiag);
+			const unsigned long long c0 = __ballot(cf && b == 0), c1 = __ballot(cf && b == 1);
+			if (cf) { const uint32_t at = (b ? ce1 : ce0) + __popcll((b ? c1 : c0) & ((1ULL << lane) - 1)); if (at < 64) eb[b][at] = (uint64_t)h.self_offset << 32 | diag; }
+			ce0 += __popcll(c0); ce1 += __popcll(c1); }
 		int32_t x = act ? s : 0; int fl = st;
 		hao_seg_scan_add(x, fl);
 		if (!fl) x += carry_f;
@@ -408,7 +417,16 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 	// ---- single chain = the whole best block ----
 	uint64_t *fcs = A.fcs + gs + 6 * g; hao_chain_rec rc;
 	hao_region(rc, P.xl, P.yl, msc, best ? first1 : first0, best ? last1 : last0);
-	const uint32_t cnt = hao_fake_cigar_wave(fcs, rc.x_pos_s, rc.y_pos_s, rc.x_pos_e, cL, [&](int64_t k) { return a[bl + k]; });
+	uint32_t cnt; const uint32_t ce = best ? ce1 : ce0;
+	if (ce <= 64) {
+		HAO_WAVE_FENCE();
+		const int64_t cdiag = (int64_t)rc.y_pos_s - (int64_t)rc.x_pos_s;      // dd of a hit = (offset - self_offset) - cdiag
+		if (lane == 0) fcs[0] = hao_fc_entry(rc.x_pos_s, 0);
+		if ((uint32_t)lane < ce) { const uint64_t raw = eb[best][lane]; fcs[1 + lane] = hao_fc_entry((uint32_t)(raw >> 32), (int32_t)((int64_t)(int32_t)(uint32_t)raw - cdiag)); }
+		const uint64_t rlast = eb[best][ce - 1];
+		cnt = 1 + ce;
+		if ((uint32_t)(rlast >> 32) != rc.x_pos_e) { if (lane == 0) fcs[cnt] = hao_fc_entry(rc.x_pos_e, (int32_t)((int64_t)(int32_t)(uint32_t)rlast - cdiag)); ++cnt; }
+	} else cnt = hao_fake_cigar_wave(fcs, rc.x_pos_s, rc.y_pos_s, rc.x_pos_e, cL, [&](int64_t k) { return a[bl + k]; });
 	if (lane == 0) {
 		rc.hit_rel = 0; rc.n_hits = (uint32_t)cL; rc.src_rel = (uint32_t)bl; rc.in_place = 1; rc.fc_rel = 0; rc.fc_len = cnt;
 		A.rec[g * HAO_MCOPY_MAX] = rc; A.nch[g] = 1; A.nout[g] = (uint32_t)cL;
