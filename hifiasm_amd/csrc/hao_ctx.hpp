@@ -19,6 +19,15 @@ template<typename T> struct DevBuf {
 		if (e == hipSuccess) cap = want;
 		return e;
 	}
+	// allocate exactly n elements if smaller (twin of a ping-pong pair: avoids a late first allocation inside a timed pass)
+	hipError_t reserve_exact(size_t n) {
+		if (n <= cap) return hipSuccess;
+		if (p) (void)hipFree(p);
+		p = nullptr; cap = 0;
+		hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+		if (e == hipSuccess) cap = n;
+		return e;
+	}
 	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 

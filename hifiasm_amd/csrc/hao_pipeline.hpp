@@ -65,7 +65,10 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 	HIP_TRY(c->d_chunk_base.reserve(n_chunks + 1)); HIP_TRY(c->d_chunk_cnt.reserve(n_chunks + 1)); HIP_TRY(c->d_chunk_dst.reserve(n_chunks + 2));
 	if (!slist.empty()) { HIP_TRY(c->d_ring.reserve(slist.size() * 256 * sizeof(hao_cand))); HIP_TRY(c->d_ringord.reserve(slist.size() * 256)); HIP_TRY(c->d_cnt_ws.reserve(slist.size() + 1)); }
 	const size_t smem = hao_sk_smem_bytes(w, k);
-	uint64_t cap = nb / 6 + 65536, total = 0;
+	// pool: every candidate of every chunk (bound nb / 6, grown on overflow); gathered / final lists: an estimate well above the usual one minimizer per
+	// ~35 bases, checked on the device (the exact total is only read back at the end)
+	uint64_t cap = nb / 6 + 65536, gcap = std::min(cap, nb / 16 + 65536), total = 0;
+	if (const char *e_ = getenv("HAO_DBG_SK_GCAP")) gcap = (uint64_t)atoll(e_);          // force the overflow / retry path (tests)
 	hao_scalar_args sa;
 	for (int attempt = 0; ; ++attempt) {
 		HIP_TRY(c->d_pool_x.reserve(cap)); HIP_TRY(c->d_pool_info.reserve(cap)); HIP_TRY(c->d_pool_ord.reserve(cap));
@@ -98,20 +101,20 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 			if (int rc = hao_excl_scan_u64(c, it, c->d_chunk_dst.p, n_chunks + 1)) return rc;   // chunk_cnt[n_chunks] is 0 (memset)
 		}
 		if (!slist.empty()) { sa.pass = 1; hipLaunchKernelGGL(sketch_scalar_kernel, dim3((unsigned)((slist.size() + 63) / 64)), dim3(64), 0, c->stream, sa); HAO_CHECK_LAUNCH(); }
-		// everything downstream is sized by the pool capacity (>= the number of candidates), so the exact total is read back only once, at the end
-		HIP_TRY(c->d_g_x.reserve(cap + 1)); HIP_TRY(c->d_g_info.reserve(cap + 1)); HIP_TRY(c->d_g_ord.reserve(cap + 1)); HIP_TRY(c->d_g_off.reserve(n_sel + 2));
+		// everything downstream is sized by gcap, so the exact total is read back only once, at the end
+		HIP_TRY(c->d_g_x.reserve(gcap + 1)); HIP_TRY(c->d_g_info.reserve(gcap + 1)); HIP_TRY(c->d_g_ord.reserve(gcap + 1)); HIP_TRY(c->d_g_off.reserve(n_sel + 2));
 		hipLaunchKernelGGL(sketch_gather_kernel, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, c->stream, c->d_pool_x.p, c->d_pool_info.p, c->d_pool_ord.p,
-						   c->d_chunk_base.p, c->d_chunk_cnt.p, c->d_chunk_dst.p, n_chunks, c->d_g_x.p, c->d_g_info.p, c->d_g_ord.p);
+						   c->d_chunk_base.p, c->d_chunk_cnt.p, c->d_chunk_dst.p, n_chunks, c->d_g_x.p, c->d_g_info.p, c->d_g_ord.p, gcap, c->d_err.p);
 		HAO_CHECK_LAUNCH();
 		hipLaunchKernelGGL(sketch_read_off_kernel, dim3((unsigned)((n_sel + 256) / 256)), dim3(256), 0, c->stream, c->d_chunk_off.p, c->d_chunk_dst.p, n_sel, c->d_g_off.p);
 		HAO_CHECK_LAUNCH();
 		c->timer.mark("sk_gather");
-		HIP_TRY(c->d_mz_x.reserve(cap + 1)); HIP_TRY(c->d_mz_info.reserve(cap + 1));
+		HIP_TRY(c->d_mz_x.reserve(gcap + 1)); HIP_TRY(c->d_mz_info.reserve(gcap + 1));
 		const uint64_t *src_off = c->d_g_off.p;
 		if (use_ft && sample_dist > w) {
 			HIP_TRY(c->d_new_n.reserve(n_sel + 2)); HIP_TRY(hipMemsetAsync(c->d_new_n.p + n_sel, 0, 4, c->stream));
 			hipLaunchKernelGGL(sketch_select_kernel, dim3((unsigned)((n_sel + 3) / 4)), dim3(256), 0, c->stream, c->d_g_x.p, c->d_g_info.p, c->d_g_ord.p, c->d_g_off.p,
-							   c->d_len.p, c->d_tot_l.p, lo, n_sel, sample_dist, c->opt.rewin, k, c->d_new_n.p);
+							   c->d_len.p, c->d_tot_l.p, lo, n_sel, sample_dist, c->opt.rewin, k, c->d_new_n.p, c->d_err.p);
 			HAO_CHECK_LAUNCH();
 			auto it = rocprim::make_transform_iterator(c->d_new_n.p, U32ToU64());
 			if (int rc = hao_excl_scan_u64(c, it, c->d_mz_off.p, n_sel + 1)) return rc;
@@ -120,7 +123,7 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 			HIP_TRY(hipMemcpyAsync(c->d_mz_off.p, c->d_g_off.p, (n_sel + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
 		}
 		hipLaunchKernelGGL(sketch_finish_kernel, dim3((unsigned)((n_sel + 3) / 4)), dim3(256), 0, c->stream, c->d_g_x.p, c->d_g_info.p, src_off, c->d_mz_off.p, lo + c->rid_base, n_sel, stamp_rid,
-						   c->d_mz_x.p, c->d_mz_info.p);
+						   c->d_mz_x.p, c->d_mz_info.p, c->d_err.p);
 		HAO_CHECK_LAUNCH();
 		int err = 0;
 		HIP_TRY(hipMemcpyAsync(&err, c->d_err.p, 4, hipMemcpyDeviceToHost, c->stream));
@@ -128,7 +131,7 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		if (!err) break;
 		if (attempt >= 3) { hao_set_err(c, "minimizer pool overflow"); return HAO_ENOMEM; }
-		cap = attempt == 0 ? nb / 2 + 65536 : nb + 65536;       // (the kernels above ran on a truncated pool: everything is redone)
+		cap = attempt == 0 ? nb / 2 + 65536 : nb + 65536; gcap = cap;       // (the kernels above ran on truncated buffers: everything is redone)
 	}
 	c->sk_total = total;
 	c->timer.mark("sk_finish");

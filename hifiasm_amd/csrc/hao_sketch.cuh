@@ -562,11 +562,12 @@ static inline size_t hao_sk_smem_bytes(int w, int k)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sketch_gather_kernel(const uint64_t *pool_x, const uint64_t *pool_info, const uint32_t *pool_ord,
 		const uint64_t *chunk_base, const uint32_t *chunk_cnt, const uint64_t *chunk_dst, uint64_t n_chunks,
-		uint64_t *out_x, uint64_t *out_info, uint32_t *out_ord)
+		uint64_t *out_x, uint64_t *out_info, uint32_t *out_ord, uint64_t out_cap, int *err)
 {
 	uint64_t ch = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (ch >= n_chunks) return;
 	uint64_t b = chunk_base[ch], d = chunk_dst[ch]; uint32_t n = chunk_cnt[ch];
+	if (d + n > out_cap) { if (hao_lane() == 0 && n) *err = 1; return; }      // the gathered list is sized by an estimate: the host retries with the pool capacity
 	for (uint32_t i = hao_lane(); i < n; i += 64) { out_x[d + i] = pool_x[b + i]; out_info[d + i] = pool_info[b + i]; out_ord[d + i] = pool_ord[b + i]; }
 }
 
@@ -687,8 +688,9 @@ __device__ int hao_select_high(hao_sel_view v, int len, int sample_dist, int w /
 // order-dependent) thinning of mz1_select_mz_h on it, all lanes write the survivors back.
 #define HAO_SKSEL_CAP 1024
 __global__ __launch_bounds__(256) void sketch_select_kernel(uint64_t *x, uint64_t *info, uint32_t *ord, const uint64_t *mz_off, const uint32_t *len, const uint32_t *tot_l,
-		uint64_t rid_lo, uint64_t n_sel, int sample_dist, int rewin, int k, uint32_t *new_n)
+		uint64_t rid_lo, uint64_t n_sel, int sample_dist, int rewin, int k, uint32_t *new_n, const int *err)
 {
+	if (*err) return;          // an upstream buffer overflowed: the host redoes the pass with bigger buffers, the lists here are incomplete
 	__shared__ uint64_t l_x[4][HAO_SKSEL_CAP], l_info[4][HAO_SKSEL_CAP]; __shared__ uint32_t l_ord[4][HAO_SKSEL_CAP];
 	const int wv = threadIdx.x >> 6, lane = hao_lane();
 	const uint64_t r = (uint64_t)blockIdx.x * 4 + wv;
@@ -714,8 +716,9 @@ __global__ __launch_bounds__(256) void sketch_select_kernel(uint64_t *x, uint64_
 
 // final: compact the per-read lists (after thinning) and stamp the read id into info.rid (sketch.cpp:577-578)
 __global__ __launch_bounds__(256) void sketch_finish_kernel(const uint64_t *x, const uint64_t *info, const uint64_t *src_off, const uint64_t *dst_off,
-		uint64_t rid_lo, uint64_t n_sel, int stamp_rid, uint64_t *ox, uint64_t *oinfo)
+		uint64_t rid_lo, uint64_t n_sel, int stamp_rid, uint64_t *ox, uint64_t *oinfo, const int *err)
 {
+	if (*err) return;
 	uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (r >= n_sel) return;
 	uint64_t s = src_off[r], d = dst_off[r], n = dst_off[r + 1] - d;

@@ -355,6 +355,8 @@ static int hao_pt_run(hao_ctx *c)
 	if (int rc = hao_sketch_run(c, 0, n, c->has_ft, c->opt.sample_dist, 1)) return rc;
 	// the read-ordered minimizers of the LOCAL reads stay for the query side (the reference re-sketches every query read; same result)
 	std::swap(c->d_ix_mz_x, c->d_mz_x); std::swap(c->d_ix_mz_info, c->d_mz_info); std::swap(c->d_ix_mz_off, c->d_mz_off);
+	// the two buffer sets alternate between "index" and "next sketch": give the idle twin its size now, not in the middle of the next pass
+	HIP_TRY(c->d_mz_x.reserve_exact(c->d_ix_mz_x.cap)); HIP_TRY(c->d_mz_info.reserve_exact(c->d_ix_mz_info.cap)); HIP_TRY(c->d_mz_off.reserve_exact(c->d_ix_mz_off.cap));
 	c->ix_n_mz = c->sk_total; c->sk_n = 0;
 	const bool sharded = c->comm && c->comm->active();
 	DevBuf<uint64_t> &ukeys = c->w_ukeys; DevBuf<uint32_t> &ucnt = c->w_ucnt; uint64_t n_unique = 0;
