@@ -132,8 +132,8 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		ca.hits = B.hits.p; ca.g_start = B.g_start.p; ca.g_read = B.g_read.p; ca.g_off = B.g_off.p; ca.seg = B.seg.p; ca.n_groups = G; ca.rid_lo = glo; ca.len = c->d_len_all.p; ca.par = par;
 		ca.dbg_qc = nullptr;
 		if (getenv("HAO_DBG_QCPHASE")) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); ca.dbg_qc = B.dbgbuf.p; }
-		ca.stats = d_slow_cnt; ca.dbg_stats = getenv("HAO_DBG_DP_STATS") ? 1 : 0; ca.dbg_skip_generic = getenv("HAO_DBG_SKIP_GENERIC") ? 1 : 0;
-		ca.dbg_seq = getenv("HAO_DBG_SEQ_CHAIN") ? 1 : (getenv("HAO_DBG_DP_NOTAIL") ? 2 : (getenv("HAO_DBG_DP_SEQTAIL") ? 3 : (getenv("HAO_DBG_DP_NOSPEC") ? 4 : 0)));
+		ca.stats = d_slow_cnt; ca.dbg_stats = getenv("HAO_DBG_DP_STATS") ? 1 : 0;
+		ca.dbg_seq = getenv("HAO_DBG_SEQ_CHAIN") ? 1 : (getenv("HAO_DBG_DP_SEQTAIL") ? 3 : (getenv("HAO_DBG_DP_NOSPEC") ? 4 : 0));
 		// per-hit DP scratch in global memory is only touched by groups beyond the LDS variants (and the sequential debug path)
 		const bool need_scratch = cls_cnt[HAO_NCLS - 1] > 0 || ca.dbg_seq == 1;
 		if (need_scratch) { HIP_TRY(B.f.reserve(A + 1)); HIP_TRY(B.ii.reserve(A + 1)); HIP_TRY(B.p.reserve(A + 1)); HIP_TRY(B.t.reserve(A + 1)); HIP_TRY(B.tm.reserve(A + 1)); }
@@ -152,7 +152,6 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			const hao_gent *lst = B.glist.p + L.base[x]; uint32_t *slow = B.slow.p + L.base[x];
 			hipLaunchKernelGGL(chain_group_kernel, dim3((unsigned)((nl + wpb - 1) / wpb)), dim3(64 * wpb), 0, c->stream, ca, lst, nl, slow, x);
 			HAO_CHECK_LAUNCH();
-			if (ca.dbg_skip_generic) continue;
 			hipStream_t ds = serial ? c->stream : B.side[x];
 			if (!serial) { HIP_TRY(hipEventRecord(B.ev_qc[x], c->stream)); HIP_TRY(hipStreamWaitEvent(ds, B.ev_qc[x], 0)); }
 			if (x <= 2) hipLaunchKernelGGL(chain_dp128_kernel, dim3((unsigned)std::min<uint64_t>(nl, 256 * 16)), dim3(64), 0, ds, ca, lst, slow, d_slow_cnt + x);
@@ -168,7 +167,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		}
 		if (ca.dbg_qc) { unsigned long long d_[5]; HIP_TRY(hipMemcpy(d_, B.dbgbuf.p, 40, hipMemcpyDeviceToHost)); if (d_[3]) fprintf(stderr, "[qc] fast groups %llu (avg %.0f hits)  avg us: entry + tile 0 %.2f  scan loop %.2f  cigar + record %.2f\n", d_[3], (double)d_[4] / d_[3], d_[0] / 100.0 / d_[3], d_[1] / 100.0 / d_[3], d_[2] / 100.0 / d_[3]); }
 		c->timer.mark("q_chain");
-		if (!serial && !ca.dbg_skip_generic) for (int x = 1; x < HAO_NCLS; ++x) if (cls_cnt[x]) HIP_TRY(hipStreamWaitEvent(c->stream, B.ev_dp[x], 0));
+		if (!serial) for (int x = 1; x < HAO_NCLS; ++x) if (cls_cnt[x]) HIP_TRY(hipStreamWaitEvent(c->stream, B.ev_dp[x], 0));
 	}
 	HIP_TRY(hipMemsetAsync(B.nch.p + G, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(B.nout.p + G, 0, 4, c->stream));
 	c->timer.mark("q_chain_dp");

@@ -151,7 +151,7 @@ struct hao_chain_args {
 	hao_hit_t *ohits; uint64_t *fcs; hao_chain_rec *rec; uint32_t *nch, *nout;
 	unsigned long long *stats;                   // [0 .. HAO_NCLS) groups of each size class needing the DP kernel, [HAO_NCLS] their hits
 	int32_t *tm;                                 // per-hit mark scratch for oversize groups
-	int dbg_skip_generic, dbg_seq, dbg_stats;
+	int dbg_seq, dbg_stats;          // dbg_seq: 1 one-lane sequential chaining, 3 one-lane DP tail, 4 no speculative tiles (all give identical results)
 	unsigned long long *dbg_qc;   // optional phase timers of chain_group_kernel (HAO_DBG_QCPHASE)
 };
 
@@ -745,7 +745,6 @@ __device__ __forceinline__ void hao_dp_body(const hao_chain_args &A, const hao_g
 		n_spec_ok_out = n_spec_ok; n_spec_fail_out = n_spec_fail;
 	}
 	if (A.dbg_stats && lane == 0) { atomicAdd(A.stats + HAO_NCLS + 1, (unsigned long long)n_spec_ok_out); atomicAdd(A.stats + HAO_NCLS + 2, (unsigned long long)n_spec_fail_out); atomicAdd(A.stats + HAO_NCLS + 3, (unsigned long long)(ei - si)); }
-	if (A.dbg_seq == 2) return;
 	if (A.dbg_seq == 3) { if (lane == 0) hao_chain_tail(A, g, a, a_n, P, f, p, t, ii, msc, msc_i, plus); return; }
 	hao_chain_tail_wave(A, g, gs, a, a_n, P, f, p, t, ii, INLDS ? (int64_t)CAP : (int64_t)0, l_cn, l_rec, msc, msc_i, plus);
 }

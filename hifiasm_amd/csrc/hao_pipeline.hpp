@@ -88,7 +88,7 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 		a.packed = c->d_packed.p; a.pk_off = c->d_pk_off.p; a.len = c->d_len.p; a.tile_off = c->d_tile_off.p; a.tile_ord = c->d_tile_ord.p; a.n_runs = c->d_n_runs.p;
 		a.chunk_off = c->d_chunk_off.p; a.scalar_flag = c->d_scalar_flag.p; a.rid_lo = lo; a.n_sel = n_sel; a.k = k; a.w = w; a.hpc = c->opt.hpc; a.ft = hao_ft_view(c);
 		a.pool_x = c->d_pool_x.p; a.pool_info = c->d_pool_info.p; a.pool_ord = c->d_pool_ord.p; a.pool_cursor = c->d_cursor.p; a.pool_cap = cap;
-		a.chunk_base = c->d_chunk_base.p; a.chunk_cnt = c->d_chunk_cnt.p; a.err = c->d_err.p; a.dbg_phase = getenv("HAO_DBG_SK_PHASE") ? atoi(getenv("HAO_DBG_SK_PHASE")) : 0;
+		a.chunk_base = c->d_chunk_base.p; a.chunk_cnt = c->d_chunk_cnt.p; a.err = c->d_err.p;
 		if (wave_variant) {
 			if (use_ft && a.ft.n > 0) hipLaunchKernelGGL((sketch_chunk_wave_kernel<true, 51>), dim3((unsigned)n_chunks), dim3(256), 0, c->stream, a);
 			else hipLaunchKernelGGL((sketch_chunk_wave_kernel<false, 51>), dim3((unsigned)n_chunks), dim3(256), 0, c->stream, a);

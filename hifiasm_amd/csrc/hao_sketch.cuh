@@ -106,7 +106,7 @@ struct hao_sk_args {
 	hao_ft_dev ft;
 	// output pool (append order arbitrary) + per-chunk record
 	uint64_t *pool_x, *pool_info; uint32_t *pool_ord; unsigned long long *pool_cursor; uint64_t pool_cap;
-	uint64_t *chunk_base; uint32_t *chunk_cnt; int *err; int dbg_phase;
+	uint64_t *chunk_base; uint32_t *chunk_cnt; int *err;
 };
 
 struct hao_key { uint64_t x; uint32_t c; };
@@ -171,7 +171,6 @@ __global__ __launch_bounds__(HAO_SK_THREADS) void sketch_chunk_kernel(hao_sk_arg
 		}
 	}
 	__syncthreads();
-	if (a.dbg_phase == 2) return;
 	// ---- S2b: bit planes of the run codes (bit e of plane <-> run rbase+e) ----
 	for (int e0 = wv * 64; e0 < nE + 64; e0 += 256) {
 		int e = e0 + lane; uint32_t c = (e >= 1 && e < nE) ? rcode[e] : 0;
@@ -203,7 +202,6 @@ __global__ __launch_bounds__(HAO_SK_THREADS) void sketch_chunk_kernel(hao_sk_arg
 		}
 		if (g < G) { kx[q] = key[g].x; if (HAS_FT) kc[q] = key[g].c; }
 	}
-	if (a.dbg_phase == 3) { if (key[0].x == 12345) a.chunk_cnt[ch] = 1; return; }
 	// ---- S4: sliding minimum over [t-w+1, t] by doubling; ping-pong bx0/bx1 ----
 	hao_key v[HAO_SK_GMAX];
 #pragma unroll
@@ -251,7 +249,6 @@ __global__ __launch_bounds__(HAO_SK_THREADS) void sketch_chunk_kernel(hao_sk_arg
 		for (int g = 0; g < HAO_SK_GMAX; ++g) if (g < G) { hao_key o = fetch(cur, tid + g * HAO_SK_THREADS + (w - cover), kmin); if (hao_key_lt<HAS_FT>(v[g], o)) v[g] = o; }
 		cur ^= 1;
 	}
-	if (a.dbg_phase == 4) { if (v[0].x == 12345) a.chunk_cnt[ch] = 1; return; }
 	// ---- marks ----
 	bool mk[HAO_SK_GMAX];
 #pragma unroll

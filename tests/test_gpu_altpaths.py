@@ -1,0 +1,40 @@
+"""Every implementation variant that libhao.so can be switched to at run time (A/B switches kept for measurements, and the fallbacks behind
+them) must give the oracle's result: one-lane sequential chaining instead of the wave kernels, DP without speculative tiles, the one-lane DP
+tail, DP kernels on the main stream, one-wave selection for every size, the one-lane pruning scan, the generic (any w, k) sketch kernel,
+and the sketch retry after an under-sized minimizer list."""
+import os
+
+import pytest
+
+from helpers import scenario_reads, scenario_oracle
+
+pytestmark = pytest.mark.gpu
+
+SWITCHES = ["HAO_DBG_SEQ_CHAIN", "HAO_DBG_DP_NOSPEC", "HAO_DBG_DP_SEQTAIL", "HAO_DBG_DP_SERIAL", "HAO_DBG_SEL1", "HAO_DBG_SEQ_PRUNE",
+            "HAO_DBG_SK_GENERIC", "HAO_DBG_SK_GCAP", "HAO_SPEC_MINCLS", "HAO_CHAIN_WPB"]
+VALUES = {"HAO_DBG_SK_GCAP": "1000", "HAO_SPEC_MINCLS": "0", "HAO_CHAIN_WPB": "4"}
+
+
+@pytest.mark.parametrize("switch", SWITCHES)
+@pytest.mark.parametrize("name", ["rr", "rr_heavy"])
+def test_switch_keeps_results(name, switch):
+    from hifiasm_amd.api import Engine
+    rs, okw = scenario_reads(name)
+    o = scenario_oracle(name)
+    os.environ[switch] = VALUES.get(switch, "1")
+    try:
+        e = Engine(0, **okw)
+        e.set_readset(rs)
+        e.ha_ft_gen()
+        e.ha_pt_gen()
+        e.overlap_batch(0, rs.n)
+        bad = 0
+        for r in range(rs.n):
+            ol, fc, fo, cl = e.h_ec_lchain(r)
+            ool, ofc, ofo, ocl = o.lchain(r)
+            if not (ol.shape == ool.shape and (ol == ool).all() and (fc == ofc).all() and (fo == ofo).all() and cl.shape == ocl.shape and (cl == ocl).all()):
+                bad += 1
+        e.close()
+    finally:
+        del os.environ[switch]
+    assert bad == 0, f"{switch}: {bad}/{rs.n} reads differ"
