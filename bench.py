@@ -110,7 +110,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    force_sharded = os.environ.get("HAO_BENCH_FORCE_SHARDED") == "1" and "RANK" in os.environ      # exercise the N > 1 code path with one rank (tests)
+    if world > 1 or force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -122,7 +123,10 @@ def main():
     rs, is_ont = make_reads(a.workload, seed=11, rank=rank, world=world)
     eng = Engine(local_rank, is_ont=is_ont)
     eng.set_readset(rs)
-    if world > 1:
+    t0 = time.time()
+    hom_ft = None
+    if world > 1 or force_sharded:
+        ok, why = True, ""
         try:
             # lengths of all reads (replicated, 4 B/read) and the communicator id travel over the launcher's process group
             from hifiasm_amd import shard
@@ -130,16 +134,24 @@ def main():
             uid = shard.share_unique_id(dist, Engine.dist_unique_id)
             eng.set_shard(sum(counts[:rank]), all_len)
             eng.dist_init(uid, rank, world)
-            mode = f"reads sharded by query over {world} GPUs; RCCL: k-mer all-to-all-v by hash range, minimizer all-gather-v (replicated index), no query-time traffic"
+            hom_ft = eng.ha_ft_gen()
+            eng.ha_pt_gen()               # probe: every collective of the sharded build has run once before anything is timed
+            mode = f"reads sharded by query over {world} GPUs; RCCL: k-mer all-to-all-v by hash range, minimizer all-gather (replicated index), no query-time traffic"
         except Exception as ex:  # noqa: BLE001
-            sys.stderr.write(f"[bench] rank {rank}: sharded mode unavailable ({ex!r}); running independent shards\n")
+            ok, why = False, repr(ex)
+        # all ranks take the same path: one failure anywhere sends everybody to independent shards
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            sys.stderr.write(f"[bench] rank {rank}: sharded mode unavailable ({why or 'another rank failed'}); running independent shards\n")
             eng.close()
             rs, is_ont = make_reads(a.workload, seed=11 + 1000 * rank)
             eng = Engine(local_rank, is_ont=is_ont)
             eng.set_readset(rs)
+            hom_ft = None
             mode = f"FALLBACK: {world} independent shards (own genome per rank), no data-path collective"
-    t0 = time.time()
-    hom_ft = eng.ha_ft_gen()
+    if hom_ft is None:
+        hom_ft = eng.ha_ft_gen()
     t_ft = time.time() - t0
     n_reads = rs.n
     # hao_overlap_batch handles < 2^32 seed hits per call: ~12.4 k hits per 15 kb read at 30x -> cap the batch

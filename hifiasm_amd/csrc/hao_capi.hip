@@ -124,7 +124,7 @@ int hao_dist_init(hao_ctx *c, const uint8_t id[128], int rank, int world)
 void *hao_loop_create(int world)
 {
 	hao_loop_group *g = new hao_loop_group();
-	g->world = world; pthread_barrier_init(&g->bar, nullptr, world); g->ptr.assign(world, nullptr); g->cnt.resize(world); g->hostv.resize(world);
+	g->world = world; pthread_barrier_init(&g->bar, nullptr, world); g->ptr.assign(world, nullptr); g->ptr2.assign(world, nullptr); g->cnt.resize(world); g->hostv.resize(world);
 	return g;
 }
 void hao_loop_destroy(void *grp) { if (grp) { hao_loop_group *g = (hao_loop_group*)grp; pthread_barrier_destroy(&g->bar); delete g; } }

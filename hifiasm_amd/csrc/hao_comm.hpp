@@ -16,7 +16,7 @@
 
 struct hao_loop_group {
 	int world; pthread_barrier_t bar;
-	std::vector<const void*> ptr; std::vector<std::vector<uint64_t> > cnt;   // per rank: published buffer + per-destination counts
+	std::vector<const void*> ptr, ptr2; std::vector<std::vector<uint64_t> > cnt;   // per rank: published buffer(s) + per-destination counts
 	std::vector<std::vector<uint64_t> > hostv;
 };
 
@@ -24,6 +24,7 @@ struct hao_comm {
 	int rank = 0, world = 1;
 	ncclComm_t nccl = nullptr; hao_loop_group *loop = nullptr;
 	DevBuf<char> ag_tmp;      // padded slots of the balanced all-gather-v
+	std::vector<uint64_t> shard_sizes; uint64_t shard_sizes_for = ~0ULL;      // reads per rank, checked once per read set
 	bool active() const { return world > 1 || nccl || loop; }
 };
 
@@ -179,5 +180,55 @@ static int hao_comm_alltoallv_u64(hao_ctx *c, hao_comm &cm, const uint64_t *src,
 		if (rcnt[r]) NCCL_TRY(ncclRecv(out + rdisp[r], rcnt[r], ncclUint64, r, cm.nccl, c->stream));
 	}
 	NCCL_TRY(ncclGroupEnd());
+	return HAO_OK;
+}
+
+// all-to-all-v of TWO parallel u64 arrays with the same counts (minimizer hash + record): one grouped exchange
+static int hao_comm_alltoallv2_u64(hao_ctx *c, hao_comm &cm, const uint64_t *src1, const uint64_t *src2, const std::vector<uint64_t> &scnt, const std::vector<uint64_t> &sdisp,
+								   uint64_t *out1, uint64_t *out2, const std::vector<uint64_t> &rcnt)
+{
+	std::vector<uint64_t> rdisp(cm.world + 1, 0);
+	for (int r = 0; r < cm.world; ++r) rdisp[r + 1] = rdisp[r] + rcnt[r];
+	if (cm.world == 1 && !cm.nccl && !cm.loop) {
+		if (scnt[0]) { HIP_TRY(hipMemcpyAsync(out1, src1 + sdisp[0], scnt[0] * 8, hipMemcpyDeviceToDevice, c->stream)); HIP_TRY(hipMemcpyAsync(out2, src2 + sdisp[0], scnt[0] * 8, hipMemcpyDeviceToDevice, c->stream)); }
+		return HAO_OK;
+	}
+	if (cm.loop) {
+		hao_loop_group *g = cm.loop;
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		g->ptr[cm.rank] = src1; g->ptr2[cm.rank] = src2; g->cnt[cm.rank] = sdisp;
+		pthread_barrier_wait(&g->bar);
+		for (int r = 0; r < cm.world; ++r) if (rcnt[r]) {
+			HIP_TRY(hipMemcpyAsync(out1 + rdisp[r], (const uint64_t*)g->ptr[r] + g->cnt[r][cm.rank], rcnt[r] * 8, hipMemcpyDeviceToDevice, c->stream));
+			HIP_TRY(hipMemcpyAsync(out2 + rdisp[r], (const uint64_t*)g->ptr2[r] + g->cnt[r][cm.rank], rcnt[r] * 8, hipMemcpyDeviceToDevice, c->stream));
+		}
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		pthread_barrier_wait(&g->bar);
+		return HAO_OK;
+	}
+	NCCL_TRY(ncclGroupStart());
+	for (int r = 0; r < cm.world; ++r) {
+		if (scnt[r]) { NCCL_TRY(ncclSend(src1 + sdisp[r], scnt[r], ncclUint64, r, cm.nccl, c->stream)); NCCL_TRY(ncclSend(src2 + sdisp[r], scnt[r], ncclUint64, r, cm.nccl, c->stream)); }
+		if (rcnt[r]) { NCCL_TRY(ncclRecv(out1 + rdisp[r], rcnt[r], ncclUint64, r, cm.nccl, c->stream)); NCCL_TRY(ncclRecv(out2 + rdisp[r], rcnt[r], ncclUint64, r, cm.nccl, c->stream)); }
+	}
+	NCCL_TRY(ncclGroupEnd());
+	return HAO_OK;
+}
+
+// all-gather of one fixed-size slot per rank: buf = world slots of `slot` bytes, the caller has filled slot `rank`
+static int hao_comm_allgather_fixed(hao_ctx *c, hao_comm &cm, char *buf, size_t slot)
+{
+	if ((cm.world == 1 && !cm.nccl && !cm.loop) || slot == 0) return HAO_OK;
+	if (cm.loop) {
+		hao_loop_group *g = cm.loop;
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		g->ptr[cm.rank] = buf;
+		pthread_barrier_wait(&g->bar);
+		for (int r = 0; r < cm.world; ++r) if (r != cm.rank) HIP_TRY(hipMemcpyAsync(buf + slot * r, (const char*)g->ptr[r] + slot * r, slot, hipMemcpyDeviceToDevice, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		pthread_barrier_wait(&g->bar);
+		return HAO_OK;
+	}
+	NCCL_TRY(ncclAllGather(buf + slot * cm.rank, buf, slot, ncclChar, cm.nccl, c->stream));      // in place: send = recv + rank * count
 	return HAO_OK;
 }

@@ -412,14 +412,17 @@ static int hao_pt_run(hao_ctx *c)
 		//   global read order, so per-key lists come out in (rid,pos) order) -> count / histogram (all-reduced) / peaks / keep ->
 		//   all-gather-v of the sorted position records (8 B each) and of the key tables: concatenation in rank order is the global index.
 		hao_comm &cm = *c->comm; const int W = cm.world; const uint64_t ml = c->ix_n_mz;
-		std::vector<uint64_t> rdc;
-		if (int rc = hao_comm_allgather_u64(c, cm, n, rdc)) return rc;
-		{ uint64_t nt = 0, b = 0; for (int r = 0; r < W; ++r) { if (r < cm.rank) b += rdc[r]; nt += rdc[r]; }
-		  if (nt != c->n_total || b != c->rid_base) { hao_set_err(c, "shards are not contiguous read ranges in rank order"); return HAO_EINVAL; } }
+		if (cm.shard_sizes_for != n || (int)cm.shard_sizes.size() != W) {      // once per read set: the shards must be contiguous read ranges in rank order
+			if (int rc = hao_comm_allgather_u64(c, cm, n, cm.shard_sizes)) return rc;
+			cm.shard_sizes_for = n;
+			uint64_t nt = 0, b = 0; for (int r = 0; r < W; ++r) { if (r < cm.rank) b += cm.shard_sizes[r]; nt += cm.shard_sizes[r]; }
+			if (nt != c->n_total || b != c->rid_base) { cm.shard_sizes_for = ~0ULL; hao_set_err(c, "shards are not contiguous read ranges in rank order"); return HAO_EINVAL; }
+		}
 		DevBuf<uint64_t> lsx, lsi; HIP_TRY(lsx.reserve(ml + 1)); HIP_TRY(lsi.reserve(ml + 1));
+		// owner of a hash = ((x >> 48) * W) >> 16 (ranges of the top 16 bits); the local sort keeps each piece in (hash, read) order
 		if (int rc = sort_pairs(c->d_ix_mz_x.p, lsx.p, c->d_ix_mz_info.p, lsi.p, ml)) return rc;
 		std::vector<uint64_t> tg(W), cut(W + 1, 0), scnt(W), sdisp(W), rcnt;
-		for (int d = 0; d < W; ++d) tg[d] = d == 0 ? 0 : (uint64_t)(((unsigned __int128)d << 64) / (unsigned)W);
+		for (int d = 0; d < W; ++d) tg[d] = (((uint64_t)d * 65536 + W - 1) / W) << 48;      // first hash owned by rank d (low 48 bits zero: comparing whole keys orders by the top 16 bits)
 		DevBuf<uint64_t> dt, dc; HIP_TRY(dt.reserve(W + 1)); HIP_TRY(dc.reserve(W + 1));
 		HIP_TRY(hipMemcpyAsync(dt.p, tg.data(), 8 * W, hipMemcpyHostToDevice, c->stream));
 		hipLaunchKernelGGL(hao_lower_bound_kernel, dim3((W + 63) / 64), dim3(64), 0, c->stream, lsx.p, ml, dt.p, W, dc.p);
@@ -431,8 +434,7 @@ static int hao_pt_run(hao_ctx *c)
 		if (int rc = hao_comm_exchange_counts(c, cm, scnt, rcnt)) return rc;
 		uint64_t n_recv = 0; for (int d = 0; d < W; ++d) n_recv += rcnt[d];
 		DevBuf<uint64_t> rx, ri, px, pi; HIP_TRY(rx.reserve(n_recv + 1)); HIP_TRY(ri.reserve(n_recv + 1)); HIP_TRY(px.reserve(n_recv + 1)); HIP_TRY(pi.reserve(n_recv + 1));
-		if (int rc = hao_comm_alltoallv_u64(c, cm, lsx.p, scnt, sdisp, rx.p, rcnt)) return rc;
-		if (int rc = hao_comm_alltoallv_u64(c, cm, lsi.p, scnt, sdisp, ri.p, rcnt)) return rc;
+		if (int rc = hao_comm_alltoallv2_u64(c, cm, lsx.p, lsi.p, scnt, sdisp, rx.p, ri.p, rcnt)) return rc;
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		c->timer.mark("pt_alltoall");
 		if (int rc = sort_pairs(rx.p, px.p, ri.p, pi.p, n_recv)) return rc;
@@ -454,10 +456,30 @@ static int hao_pt_run(hao_ctx *c)
 		if (nk_p) { hipLaunchKernelGGL(hao_add_const_kernel, dim3((unsigned)((nk_p + 255) / 256)), dim3(256), 0, c->stream, pst.p, nk_p, base); HAO_CHECK_LAUNCH(); }
 		HIP_TRY(c->d_ix_sinfo.reserve(m + 1));      // (the sorted hashes themselves are not needed once the key table exists: only the 8-byte position records travel)
 		HIP_TRY(c->d_ix_keys.reserve(nk + 1)); HIP_TRY(c->d_ix_start.reserve(nk + 1)); HIP_TRY(c->d_ix_cnt.reserve(nk + 1));
-		if (int rc = hao_comm_allgatherv(c, cm, pi.p, n_recv, 8, c->d_ix_sinfo.p, part)) return rc;
-		if (int rc = hao_comm_allgatherv(c, cm, pk.p, nk_p, 8, c->d_ix_keys.p, nks)) return rc;
-		if (int rc = hao_comm_allgatherv(c, cm, pst.p, nk_p, 8, c->d_ix_start.p, nks)) return rc;
-		if (int rc = hao_comm_allgatherv(c, cm, pc.p, nk_p, 4, c->d_ix_cnt.p, nks)) return rc;
+		{	// ONE all-gather for the whole index: every rank's slot = [position records | keys | list starts | counts], padded to the largest partition
+			uint64_t maxm = 0, maxk = 0; for (int r = 0; r < W; ++r) { maxm = std::max(maxm, part[r]); maxk = std::max(maxk, nks[r]); }
+			const size_t o_key = (size_t)maxm * 8, o_st = o_key + (size_t)maxk * 8, o_cnt = o_st + (size_t)maxk * 8, slot = (o_cnt + (size_t)maxk * 4 + 15) & ~(size_t)15;
+			HIP_TRY(cm.ag_tmp.reserve(slot * W + 16));
+			char *mine = cm.ag_tmp.p + slot * cm.rank;
+			if (n_recv) HIP_TRY(hipMemcpyAsync(mine, pi.p, n_recv * 8, hipMemcpyDeviceToDevice, c->stream));
+			if (nk_p) {
+				HIP_TRY(hipMemcpyAsync(mine + o_key, pk.p, nk_p * 8, hipMemcpyDeviceToDevice, c->stream));
+				HIP_TRY(hipMemcpyAsync(mine + o_st, pst.p, nk_p * 8, hipMemcpyDeviceToDevice, c->stream));
+				HIP_TRY(hipMemcpyAsync(mine + o_cnt, pc.p, nk_p * 4, hipMemcpyDeviceToDevice, c->stream));
+			}
+			if (int rc = hao_comm_allgather_fixed(c, cm, cm.ag_tmp.p, slot)) return rc;
+			uint64_t dm = 0, dk = 0;
+			for (int r = 0; r < W; ++r) {
+				const char *sr = cm.ag_tmp.p + slot * r;
+				if (part[r]) HIP_TRY(hipMemcpyAsync(c->d_ix_sinfo.p + dm, sr, part[r] * 8, hipMemcpyDeviceToDevice, c->stream));
+				if (nks[r]) {
+					HIP_TRY(hipMemcpyAsync(c->d_ix_keys.p + dk, sr + o_key, nks[r] * 8, hipMemcpyDeviceToDevice, c->stream));
+					HIP_TRY(hipMemcpyAsync(c->d_ix_start.p + dk, sr + o_st, nks[r] * 8, hipMemcpyDeviceToDevice, c->stream));
+					HIP_TRY(hipMemcpyAsync(c->d_ix_cnt.p + dk, sr + o_cnt, nks[r] * 4, hipMemcpyDeviceToDevice, c->stream));
+				}
+				dm += part[r]; dk += nks[r];
+			}
+		}
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		c->ix_n_sorted = m; c->ix_n_keys = nk; c->ix_n_pos = np;
 		lsx.release(); lsi.release(); rx.release(); ri.release(); px.release(); pi.release(); pk.release(); pst.release(); pc.release(); dt.release(); dc.release();
