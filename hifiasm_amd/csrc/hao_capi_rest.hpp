@@ -11,7 +11,7 @@ static void hao_release_all(hao_ctx *c)
 	c->d_scalar_flag.release(); c->d_scalar_list.release(); c->d_pool_x.release(); c->d_pool_info.release(); c->d_pool_ord.release(); c->d_cursor.release(); c->d_err.release();
 	c->d_chunk_base.release(); c->d_chunk_dst.release(); c->d_chunk_cnt.release(); c->d_g_x.release(); c->d_g_info.release(); c->d_g_ord.release(); c->d_g_off.release();
 	c->d_new_n.release(); c->d_new_n64.release(); c->d_mz_x.release(); c->d_mz_info.release(); c->d_mz_off.release(); c->d_tmp.release(); c->d_ring.release(); c->d_ringord.release(); c->d_cnt_ws.release();
-	c->w_ukeys.release(); c->w_flag.release(); c->w_kpos.release(); c->w_ustart.release(); c->w_ucnt.release(); c->w_hist.release();
+	c->w_ukeys.release(); c->w_flag.release(); c->w_kpos.release(); c->w_ustart.release(); c->w_ucnt.release(); c->w_hist.release(); c->w_ok.release(); c->w_ok2.release(); c->w_oi.release(); c->w_oi2.release();
 	c->d_ix_mz_x.release(); c->d_ix_mz_info.release(); c->d_ix_mz_off.release(); c->d_ix_sx.release(); c->d_ix_sinfo.release();
 	c->d_ix_keys.release(); c->d_ix_start.release(); c->d_ix_cnt.release(); c->d_ix_bucket.release();
 }

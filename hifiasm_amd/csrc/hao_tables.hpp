@@ -23,6 +23,17 @@ __global__ void hao_lower_bound_low12_kernel(const uint64_t *keys, uint64_t n, c
 	while (lo < hi) { uint64_t m = (lo + hi) >> 1; if ((keys[m] & 4095) < x) lo = m + 1; else hi = m; }
 	out[t] = lo;
 }
+// owner bits of a minimizer hash (top 16) + identity permutation; gather through a sorted permutation
+__global__ void hao_owner_key_kernel(const uint64_t *x, uint64_t n, uint32_t *key, uint32_t *idx)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) { key[i] = (uint32_t)(x[i] >> 48); idx[i] = (uint32_t)i; }
+}
+__global__ void hao_gather2_kernel(const uint32_t *idx, const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t *oa, uint64_t *ob)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) { const uint32_t j = idx[i]; oa[i] = a[j]; ob[i] = b[j]; }
+}
 __global__ void hao_add_const_kernel(uint64_t *v, uint64_t n, uint64_t add)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -419,8 +430,20 @@ static int hao_pt_run(hao_ctx *c)
 			if (nt != c->n_total || b != c->rid_base) { cm.shard_sizes_for = ~0ULL; hao_set_err(c, "shards are not contiguous read ranges in rank order"); return HAO_EINVAL; }
 		}
 		DevBuf<uint64_t> lsx, lsi; HIP_TRY(lsx.reserve(ml + 1)); HIP_TRY(lsi.reserve(ml + 1));
-		// owner of a hash = ((x >> 48) * W) >> 16 (ranges of the top 16 bits); the local sort keeps each piece in (hash, read) order
-		if (int rc = sort_pairs(c->d_ix_mz_x.p, lsx.p, c->d_ix_mz_info.p, lsi.p, ml)) return rc;
+		// owner of a hash = ((x >> 48) * W) >> 16: ranges of the top 16 bits, so the local pass only groups by those bits - a stable 2-pass radix sort of
+		// (owner bits, index) and one gather instead of 8 passes over the 16-byte records; pieces stay in read order, the owner sorts what it receives.
+		// (begin_bit = 0 on a separate 16-bit key: rocprim 4.2's radix sort mis-sorts small inputs when begin_bit > 0.)
+		if (ml) {
+			DevBuf<uint32_t> &ok = c->w_ok, &ok2 = c->w_ok2, &oi = c->w_oi, &oi2 = c->w_oi2;      // persistent scratch: no allocation inside the pass
+			HIP_TRY(ok.reserve(ml + 1)); HIP_TRY(ok2.reserve(ml + 1)); HIP_TRY(oi.reserve(ml + 1)); HIP_TRY(oi2.reserve(ml + 1));
+			hipLaunchKernelGGL(hao_owner_key_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_x.p, ml, ok.p, oi.p);
+			HAO_CHECK_LAUNCH();
+			size_t tb = 0; rocprim::double_buffer<uint32_t> dk(ok.p, ok2.p), dv(oi.p, oi2.p);
+			HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, dk, dv, ml, 0, 16, c->stream)); HIP_TRY(hao_tmp(c, tb));
+			HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, dk, dv, ml, 0, 16, c->stream));
+			hipLaunchKernelGGL(hao_gather2_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, c->stream, dv.current(), c->d_ix_mz_x.p, c->d_ix_mz_info.p, ml, lsx.p, lsi.p);
+			HAO_CHECK_LAUNCH();
+		}
 		std::vector<uint64_t> tg(W), cut(W + 1, 0), scnt(W), sdisp(W), rcnt;
 		for (int d = 0; d < W; ++d) tg[d] = (((uint64_t)d * 65536 + W - 1) / W) << 48;      // first hash owned by rank d (low 48 bits zero: comparing whole keys orders by the top 16 bits)
 		DevBuf<uint64_t> dt, dc; HIP_TRY(dt.reserve(W + 1)); HIP_TRY(dc.reserve(W + 1));
