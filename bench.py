@@ -1,26 +1,31 @@
 #!/usr/bin/env python3
 """bench.py - read-pair overlaps/sec of the MI355X overlap engine (BASELINE.json metric).
 
-One step = ha_pt_gen (sketch all reads + index) + one all-reads h_ec_lchain pass over the
-workload, exactly the span BASELINE.md / SURVEY.md 8(d) define:
+One step = ha_pt_gen (sketch all reads + index) + one all-reads h_ec_lchain pass over the workload, exactly the span
+BASELINE.md / SURVEY.md 8(d) define:
     overlaps/sec = sum(ol->length) / (t(ha_pt_gen) + t(all-reads pass)).
-The read store is resident in HBM before the timed region (hao_set_reads) and ha_ft_gen has
-run (it is reported separately).  Default workload = BASELINE.json
-configs[1]: synthetic 5 Mb genome, 30x HiFi, 15 kb reads, 0.1 % error, one MI355X.
+The read store is resident in HBM before the timed region (hao_set_reads) and ha_ft_gen has run (reported separately, as in
+BASELINE.md 2b).  Default workload = BASELINE.json configs[2], the largest single-GPU configuration: synthetic 250 Mb genome,
+30x HiFi, 500 000 reads of 15 kb, 0.1 % error (`--workload bacterial5M_hifi30x` = configs[1]).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): ONE all-vs-all problem whose genome is
-N x the single-GPU genome, so every rank owns the same number of query reads (weak scaling).  Reads are
-sharded by query read; ha_ft_gen counts k-mers by hash range (RCCL all-to-all-v + 32 KB all-reduce),
-ha_pt_gen all-gathers the 16-byte minimizer records so every rank holds the whole index, the query
-pass needs no communication (SURVEY.md 8e layout i).  Barrier + max-over-ranks timing,
-value = all ranks' overlaps / max time.  If the RCCL communicator cannot be created the ranks fall back
-to independent shards and say so in config.parallelism.
+`value` is the HBM-resident rate (results stay on the device, as the contract asks); `value_boundary` is the rate of the same step
+when every batch's results (ol->list, fake cigars, cl->list in the packed wire format of include/hao.h) are also delivered into
+pinned host memory through the streaming path (hao_overlap_batch_async: the download of batch i runs under the compute of batch i+1).
+
+`--gpus N` with N > 1 launches N ranks itself (torch.distributed.run, one rank per GPU, RCCL) when it was not started by a launcher;
+under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.  N > 1: ONE all-vs-all problem whose genome is N x the single-GPU genome, so
+every rank owns the same number of query reads (weak scaling; `human3G_hifi40x` and `ont_human_30x` are fixed-size problems split over
+the ranks: strong scaling).  Reads are sharded by query read; ha_ft_gen counts k-mers by hash range (RCCL all-to-all-v + 32 KB
+all-reduce), ha_pt_gen builds the index hash-partitioned and all-gathers it (SURVEY.md 8e layout i: replicated index, no query-time
+traffic).  Barrier + max-over-ranks timing, value = all ranks' overlaps / max time.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import shutil
+import socket
 import subprocess
 import sys
 import tempfile
@@ -29,69 +34,95 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WORKLOADS = {
-    # name: (genome_size, coverage, read_len, err, repeat_rich, is_ont)
-    "bacterial5M_hifi30x": (5_000_000, 30, 15000, 0.001, 0, 0),
-    "bacterial5M_hifi30x_repeat": (5_000_000, 30, 15000, 0.001, 1, 0),
-    "chr2M_hifi30x": (2_000_000, 30, 15000, 0.001, 0, 0),
-    "chr1_250M_hifi30x": (250_000_000, 30, 15000, 0.001, 0, 0),
-    "ont5M_30x": (5_000_000, 30, 30000, 0.01, 0, 1),
-}
-# algorithmic bytes per unit (stated again in DESIGN.md)
+from hifiasm_amd.workloads import WORKLOADS, n_reads_of  # noqa: E402
+
+STRONG = {"human3G_hifi40x", "ont_human_30x"}      # fixed-size problems: the read set is split over the ranks
+# algorithmic bytes per unit (stated again in DESIGN.md 4)
 ALG = {
     "sketch_chunk_wave_kernel": ("base", 0.25 + 16.0 / 35.0),       # 2-bit bases in + one 16-B minimizer per ~35 bases out
     "chain_group_kernel": ("anchor", 16 + 4),                        # k_mer_hit in + fake-cigar / record out (hits stay in place)
-    "seed_expand_kernel": ("anchor", 8 + 8),                         # index position in + key out
     "chain_assemble_kernel": ("anchor", 16 + 16),                    # chained hit in + tagged hit out
-    "seg_bin_sort_kernel": ("anchor", 8 + 16),                       # key in, k_mer_hit out (groups come with the bin table)
     "seed_bin_kernel": ("anchor", 8 + 16),                           # index record in, k_mer_hit out (bins, order and groups in LDS)
 }
+KERN_STAGE = {"sketch_chunk_wave_kernel": "sk_chunks", "chain_group_kernel": "q_chain", "chain_assemble_kernel": "q_assemble",
+              "seed_bin_kernel": "q_sort_bins"}
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_GINST = 256 * 4 * 2.4      # wave-level VALU instructions per ns: 256 CUs x 4 SIMDs x 1 issue/cycle x 2.4 GHz
 
 
-def make_reads(workload, seed, rank=0, world=1):
-    """reads [rank*n, (rank+1)*n) of the read set over a genome `world` times the workload's genome"""
+def make_reads(workload, rank=0, world=1):
+    """this rank's shard of the workload's read set (weak scaling: genome x world; strong: the fixed set split by rank)"""
     from hifiasm_amd import synth
+    from hifiasm_amd.workloads import GENOME_SEED, READ_SEED
     g, cov, L, err, rr, ont = WORKLOADS[workload]
-    genome = synth.make_genome(g * world, seed=seed, repeat_rich=rr)
-    n_reads = max(1, int(round(g * cov / L)))
-    return synth.make_reads(genome, n_reads, L, err, seed=seed + 1, rid0=rank * n_reads, want_codes=False), ont
+    if workload in STRONG:
+        genome = synth.make_genome(g, seed=GENOME_SEED, repeat_rich=rr)
+        n_all = n_reads_of(workload)
+        lo, hi = n_all * rank // world, n_all * (rank + 1) // world
+    else:
+        genome = synth.make_genome(g * world, seed=GENOME_SEED, repeat_rich=rr)
+        n = n_reads_of(workload)
+        lo, hi = rank * n, (rank + 1) * n
+    return synth.make_reads(genome, hi - lo, L, err, seed=READ_SEED, rid0=lo, want_codes=False), ont
 
 
-def cpu_baseline(sample_reads=4000, threads=None):
-    """The real reference (oracle/_ref/ref_harness, unmodified hifiasm) on a bounded sample of the same
-    workload kind, all host cores; falls back to the C restatement (1 thread) when the binary is absent."""
+def cpu_baseline(workload, mode="sample", threads=None):
+    """The real reference (oracle/_ref/ref_harness = unmodified hifiasm objects) on the SAME workload: the benched read set itself
+    (mode "full") or, by default, a bounded sample of it - the same generator and parameters over the first <= 50 Mb of genome (100 000
+    reads of 15 kb: ~10-30 s of work on all host cores, enough to keep them busy).  Falls back to the C restatement (1 thread) when the
+    reference binary is absent."""
     from hifiasm_amd import synth
+    from hifiasm_amd.workloads import GENOME_SEED, READ_SEED
     cores = threads or os.cpu_count() or 1
-    g, cov, L, err = 2_000_000, 30, 15000, 0.001
-    genome = synth.make_genome(g, seed=11)
-    rs = synth.make_reads(genome, sample_reads, L, err, seed=12)
-    sample = f"{sample_reads} reads x {L} bp, {cov}x of a {g // 1_000_000} Mb i.i.d. genome, 0.1 % error, -f0"
+    g, cov, L, err, rr, ont = WORKLOADS[workload]
+    gs = g if mode == "full" else min(g, 50_000_000)
+    n = max(1, int(round(gs * cov / L)))
+    genome = synth.make_genome(gs, seed=GENOME_SEED, repeat_rich=rr)
+    sample = (f"{workload}: the benched read set itself" if gs == g else
+              f"{workload} generator over a {gs // 1_000_000} Mb genome") + f" ({n} reads x {L} bp, {cov}x, {err * 100:g} % error, -f0)"
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     if os.path.exists(harness):
-        d = tempfile.mkdtemp(prefix="hao_cpu_")
-        fa = os.path.join(d, "r.fa")
-        synth.write_fasta(fa, rs)
-        r = subprocess.run([harness, "-t", str(cores), "--time", fa], capture_output=True, text=True, cwd=d)
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 3 * gs * cov else None
+        d = tempfile.mkdtemp(prefix="hao_cpu_", dir=base)
         try:
-            j = json.loads(r.stdout.strip().splitlines()[-1])
+            fa = os.path.join(d, "r.fq" if ont else "r.fa")
+            synth.write_fasta_stream(fa, genome, n, L, err, seed=READ_SEED, fastq=bool(ont))
+            cmd = [harness, "-t", str(cores), "--time"] + (["--ont"] if ont else []) + [fa]
+            r = subprocess.run(cmd, capture_output=True, text=True, cwd=d)
+            j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
             return {"value": j["overlaps_per_sec"], "unit": "overlaps/s", "cores": cores, "kind": "reference", "sample": sample,
                     "t_ft_gen": j["t_ft_gen"], "t_pt_gen": j["t_pt_gen"], "t_pass": j["t_pass"], "overlaps": j["overlaps"]}
         except Exception as ex:  # fall through to the port
             sys.stderr.write(f"[bench] ref_harness failed ({ex}); using the C restatement\n")
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_py
-    n = min(sample_reads, 600)
-    sub_off = rs.code_off[: n + 1]
-    o = oracle_py.Oracle(rs.codes[: int(sub_off[-1])], sub_off)
+    nn = min(n, 600)
+    rs = synth.make_reads(genome, nn, L, err, seed=READ_SEED)
+    o = oracle_py.Oracle(rs.codes, rs.code_off, is_ont=int(ont))
     o.ft_gen()
     t0 = time.time()
     o.pt_gen()
     tot = 0
-    for r in range(n):
+    for r in range(nn):
         tot += o.lchain(r)[0].shape[0]
     dt = time.time() - t0
-    return {"value": tot / dt, "unit": "overlaps/s", "cores": 1, "kind": "port", "sample": f"first {n} of: " + sample}
+    return {"value": tot / dt, "unit": "overlaps/s", "cores": 1, "kind": "port", "sample": f"first {nn} reads of: " + sample}
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) under torch.distributed.run and relay rank 0's line"""
+    import torch
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        sys.stderr.write(f"[bench] --gpus {a.gpus} but only {have} GPU(s) are visible\n")
+        sys.exit(2)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -99,77 +130,77 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="bacterial5M_hifi30x", choices=list(WORKLOADS))
-    ap.add_argument("--batch-reads", type=int, default=0, help="query reads per hao_overlap_batch (0 = all)")
+    ap.add_argument("--workload", default="chr1_250M_hifi30x", choices=list(WORKLOADS))
+    ap.add_argument("--batch-reads", type=int, default=0, help="query reads per hao_overlap_batch (0 = sized for ~4e8 seed hits)")
+    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "none"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the boundary-inclusive (results delivered to host memory) measurement")
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
+    if a.no_cpu_baseline:
+        a.cpu_baseline = "none"
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and not (world == 1 and os.environ.get("HAO_BENCH_FORCE_SHARDED") == "1"):
+        sys.stderr.write(f"[bench] --gpus {a.gpus} disagrees with WORLD_SIZE={world}\n")
+        sys.exit(2)
     import torch
     dist = None
     force_sharded = os.environ.get("HAO_BENCH_FORCE_SHARDED") == "1" and "RANK" in os.environ      # exercise the N > 1 code path with one rank (tests)
     if world > 1 or force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if torch.cuda.device_count() <= local_rank:
+            sys.stderr.write(f"[bench] rank {rank}: no GPU {local_rank} ({torch.cuda.device_count()} visible)\n")
+            sys.exit(2)
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     from hifiasm_amd.api import Engine
-    from hifiasm_amd import build as _b  # noqa: F401  (libraries are prebuilt; build() is the driver's job)
 
     mode = "single GPU"
-    rs, is_ont = make_reads(a.workload, seed=11, rank=rank, world=world)
+    rs, is_ont = make_reads(a.workload, rank=rank, world=world)
     eng = Engine(local_rank, is_ont=is_ont)
     eng.set_readset(rs)
     t0 = time.time()
-    hom_ft = None
     if world > 1 or force_sharded:
-        ok, why = True, ""
-        try:
-            # lengths of all reads (replicated, 4 B/read) and the communicator id travel over the launcher's process group
-            from hifiasm_amd import shard
-            all_len, counts = shard.gather_lengths(dist, rs.lengths, device="cuda")
-            uid = shard.share_unique_id(dist, Engine.dist_unique_id)
-            eng.set_shard(sum(counts[:rank]), all_len)
-            eng.dist_init(uid, rank, world)
-            hom_ft = eng.ha_ft_gen()
-            eng.ha_pt_gen()               # probe: every collective of the sharded build has run once before anything is timed
-            mode = f"reads sharded by query over {world} GPUs; RCCL: k-mer all-to-all-v by hash range, minimizer all-gather (replicated index), no query-time traffic"
-        except Exception as ex:  # noqa: BLE001
-            ok, why = False, repr(ex)
-        # all ranks take the same path: one failure anywhere sends everybody to independent shards
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            sys.stderr.write(f"[bench] rank {rank}: sharded mode unavailable ({why or 'another rank failed'}); running independent shards\n")
-            eng.close()
-            rs, is_ont = make_reads(a.workload, seed=11 + 1000 * rank)
-            eng = Engine(local_rank, is_ont=is_ont)
-            eng.set_readset(rs)
-            hom_ft = None
-            mode = f"FALLBACK: {world} independent shards (own genome per rank), no data-path collective"
-    if hom_ft is None:
-        hom_ft = eng.ha_ft_gen()
+        # lengths of all reads (replicated, 4 B/read) and the communicator id travel over the launcher's process group.  No fallback: the engine's
+        # collectives carry every rank's status (hao_comm.hpp), so a failure raises on ALL ranks instead of leaving some of them inside a collective.
+        from hifiasm_amd import shard
+        all_len, counts = shard.gather_lengths(dist, rs.lengths, device="cuda")
+        uid = shard.share_unique_id(dist, Engine.dist_unique_id)
+        eng.set_shard(sum(counts[:rank]), all_len)
+        eng.dist_init(uid, rank, world)
+        mode = (f"reads sharded by query over {world} GPUs (RCCL over xGMI): k-mer all-to-all-v by hash range, hash-partitioned index build + "
+                f"all-gather (SURVEY 8e layout i: replicated index, no query-time traffic; layout ii - seed hits routed to the target's owner - not built)")
+    hom_ft = eng.ha_ft_gen()
     t_ft = time.time() - t0
     n_reads = rs.n
-    # hao_overlap_batch handles < 2^32 seed hits per call: ~12.4 k hits per 15 kb read at 30x -> cap the batch
-    # and ~100 B of device scratch per seed hit: keep a batch near 4e8 hits (~40 GB)
-    auto_bsz = max(1, int(4e8 // max(1.0, 0.83 * rs.total_bases / max(1, n_reads))))
+    # hao_overlap_batch handles < 2^32 seed hits per call and needs ~100 B of device scratch per seed hit: keep a batch near 4e8 hits (~40 GB)
+    auto_bsz = max(1, int(4e8 // max(1.0, 0.83 * rs.total_bases / max(1, n_reads) * WORKLOADS[a.workload][1] / 30.0)))
     bsz = a.batch_reads if a.batch_reads > 0 else min(n_reads, auto_bsz)
+    ranges = [(lo, min(n_reads, lo + bsz)) for lo in range(0, n_reads, bsz)]
 
-    def step():
+    def step(deliver=False):
         eng.ha_pt_gen()
         st = {k: v for k, v in eng.stage_times()}
-        tot = {"overlaps": 0, "chained_hits": 0, "seed_hits": 0, "groups": 0, "minimizers": 0, "seq_groups": 0, "seq_group_hits": 0}
-        for lo in range(0, n_reads, bsz):
-            eng.overlap_batch(lo, min(n_reads, lo + bsz))
+        tot = {"overlaps": 0, "chained_hits": 0, "seed_hits": 0, "groups": 0, "minimizers": 0, "seq_groups": 0, "seq_group_hits": 0, "host_bytes": 0}
+        for lo, hi in ranges:
+            if deliver:
+                eng.overlap_batch_async(lo, hi)      # compute of this batch; its download runs under the next batch
+            else:
+                eng.overlap_batch(lo, hi)
             t = eng.batch_totals()
-            for k in tot:
-                tot[k] += t[k]
+            for k in t:
+                if k in tot:
+                    tot[k] += t[k]
             for k, v in eng.stage_times():
                 st[k] = st.get(k, 0.0) + v
+        if deliver:
+            tot["host_bytes"] = eng.deliver_wait()      # every batch's results are in host memory
         return tot, st
 
     def sync():
@@ -177,72 +208,99 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(a.warmup):
-        step()
-    sync()
-    t0 = time.time()
-    stage_sum = {}
-    for _ in range(a.steps):
-        tot, st = step()
-        for k, v in st.items():
-            stage_sum[k] = stage_sum.get(k, 0.0) + v
-    sync()
-    dt = time.time() - t0
-    overlaps = tot["overlaps"]
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        oo = torch.tensor([overlaps], dtype=torch.int64, device="cuda")
-        dist.all_reduce(oo, op=dist.ReduceOp.SUM)
-        overlaps = int(oo.item())
+    def timed(deliver):
+        for _ in range(a.warmup):
+            step(deliver)
+        sync()
+        t0 = time.time()
+        ssum = {}
+        for _ in range(a.steps):
+            tot, st = step(deliver)
+            for k, v in st.items():
+                ssum[k] = ssum.get(k, 0.0) + v
+        sync()
+        dt = time.time() - t0
+        ov = tot["overlaps"]
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+            oo = torch.tensor([ov], dtype=torch.int64, device="cuda")
+            dist.all_reduce(oo, op=dist.ReduceOp.SUM)
+            ov = int(oo.item())
+        return dt, ov, tot, ssum
+
+    dt, overlaps, tot, stage_sum = timed(False)
     ms_per_step = dt / a.steps * 1e3
     value = overlaps / (dt / a.steps)
+    boundary = None
+    if not a.no_boundary and hasattr(eng, "overlap_batch_async"):
+        bdt, bov, btot, _ = timed(True)
+        boundary = {"value": bov / (bdt / a.steps), "ms_per_step": bdt / a.steps * 1e3, "host_bytes_per_gpu_step": btot["host_bytes"]}
 
-    out = None
     if rank == 0:
         stage_ms = {k: v / a.steps for k, v in stage_sum.items()}
         # roofline of the dominant kernel: live HIP-event time of its stage on the engine's stream
-        kern_stage = {"sketch_chunk_wave_kernel": "sk_chunks", "chain_group_kernel": "q_chain", "seed_expand_kernel": "q_expand",
-                      "chain_assemble_kernel": "q_assemble", "seed_bin_kernel": "q_sort_bins"}
-        dom = max(kern_stage, key=lambda k: stage_ms.get(kern_stage[k], 0.0))
+        dom = max(KERN_STAGE, key=lambda k: stage_ms.get(KERN_STAGE[k], 0.0))
         unit, bpu = ALG[dom]
         units = rs.total_bases if unit == "base" else tot["seed_hits"]
-        n_batches = 1 if unit == "base" else max(1, (n_reads + bsz - 1) // bsz)
+        n_batches = 1 if unit == "base" else len(ranges)
         # per batch: all launches of the kernel in one batch count as one "launch" (chain_group_kernel runs once per size class,
         # seed_bin_kernel once per bin-table size); the stage time brackets exactly those launches
-        k_ms = stage_ms.get(kern_stage[dom], 0.0) / n_batches
+        k_ms = stage_ms.get(KERN_STAGE[dom], 0.0) / n_batches
         alg_bytes = bpu * units / n_batches
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic = None
-        try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
-            if pj.get("workload") == a.workload and world == 1:
-                tt = [v["hbm_bytes_per_launch"] * v["launches"] for k, v in pj["kernels"].items() if k.split("<")[0] == dom]
-                traffic = int(sum(tt) / max(1, pj.get("batches", 1))) if tt else None
-        except Exception:
-            pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                     "kernel_ms": round(k_ms, 4), "alg_bytes_per_launch": int(alg_bytes)}
+        prof = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
+        if os.path.exists(prof) and world == 1:      # PMC counters need their own rocprofv3 passes (tools/pmc.sh): not measurable inside this run
+            try:
+                pj = json.load(open(prof))
+                if pj.get("workload") == a.workload:
+                    tt = [v["hbm_bytes_per_launch"] * v["launches"] for k, v in pj["kernels"].items() if k.split("<")[0] == dom]
+                    if tt:
+                        roofline["traffic"] = int(sum(tt) / max(1, pj.get("batches", 1)))
+                        roofline["traffic_source"] = "profiles/r02/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x 2 (gfx950 correction of MI355X_MICROARCH.md; calibrated for wide coalesced reads only - for this kernel's 8-byte gathers the true value lies between traffic_lo and traffic)"
+                        lo_ = [v.get("hbm_bytes_per_launch_raw", v["hbm_bytes_per_launch"]) * v["launches"] for k, v in pj["kernels"].items() if k.split("<")[0] == dom]
+                        roofline["traffic_lo"] = int(sum(lo_) / max(1, pj.get("batches", 1)))
+            except Exception:
+                pass
+        # the sketch kernel is instruction-issue bound, not HBM bound: report its VALU issue rate next to the HBM fraction (counters: profiles/r02/sketch_alu.json)
+        sk_ms = stage_ms.get("sk_chunks", 0.0)
+        sk = {"kernel": "sketch_chunk_wave_kernel", "kernel_ms": round(sk_ms, 4), "bases": rs.total_bases,
+              "gbases_per_s": round(rs.total_bases / (sk_ms * 1e-3) / 1e9, 2) if sk_ms > 0 else None,
+              "hbm_frac": round(ALG["sketch_chunk_wave_kernel"][1] * rs.total_bases / (sk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if sk_ms > 0 else None}
+        alu = os.path.join(ROOT, "profiles", "r02", "sketch_alu.json")
+        if os.path.exists(alu):
+            try:
+                aj = json.load(open(alu))
+                per_base = aj["valu_wave_insts_per_base"]
+                ach = per_base * rs.total_bases / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else 0.0
+                sk["roofline_alu"] = {"achieved_valu_issue": round(ach, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+                                      "frac": round(ach / VALU_PEAK_GINST, 4), "valu_wave_insts_per_base": per_base,
+                                      "source": "profiles/r02/sketch_alu.json (rocprofv3 --pmc SQ_INSTS_VALU ...) x this run's kernel time"}
+            except Exception:
+                pass
         out = {
             "metric": "read-pair overlaps/sec (sum ol->length / (ha_pt_gen + all-reads h_ec_lchain pass))",
             "value": round(value, 1), "unit": "overlaps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64 hashing / int32 + f64 chain scores", "data": "synthetic",
-            "config": {"workload": a.workload, "reads_per_gpu": n_reads, "bases_per_gpu": rs.total_bases,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if a.workload in STRONG else "weak",
+            "vs_baseline": None, "dtype": "u64 hashing / int32 + f64 chain scores", "data": "synthetic",
+            "value_boundary": round(boundary["value"], 1) if boundary else None,
+            "boundary": ({"ms_per_step": round(boundary["ms_per_step"], 3), "host_bytes_per_gpu_step": boundary["host_bytes_per_gpu_step"],
+                          "what": "same step with every batch's ol->list, fake cigars and packed cl->list delivered into pinned host memory (double-buffered, copy stream under the next batch's compute)"}
+                         if boundary else None),
+            "config": {"workload": a.workload, "reads_per_gpu": n_reads, "bases_per_gpu": rs.total_bases, "batches_per_pass": len(ranges),
                        "overlaps_per_gpu_step": tot["overlaps"], "seed_hits_per_gpu_step": tot["seed_hits"],
                        "chained_hits_per_gpu_step": tot["chained_hits"], "groups_per_gpu_step": tot["groups"],
                        "groups_on_sequential_path": tot["seq_groups"], "k": 51, "w": 51, "hpc": 1,
-                       "parallelism": mode,
-                       "ha_ft_gen_s": round(t_ft, 3), "hom_cov_ft": hom_ft},
+                       "parallelism": mode, "ha_ft_gen_s": round(t_ft, 3), "hom_cov_ft": hom_ft},
             "roofline": roofline,
+            "sketch": sk,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
         }
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
-        elif not a.no_cpu_baseline:
-            out["cpu_baseline"] = None
+        out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_baseline) if (a.cpu_baseline != "none" and world == 1) else None
         if a.verbose:
             sys.stderr.write(json.dumps(out["stage_ms"], indent=1) + "\n")
         print(json.dumps(out), flush=True)

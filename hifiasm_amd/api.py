@@ -27,7 +27,14 @@ class HaoError(RuntimeError):
 class Opt(C.Structure):
     _fields_ = [("k", C.c_int32), ("w", C.c_int32), ("hpc", C.c_int32), ("sample_dist", C.c_int32), ("rewin", C.c_int32),
                 ("min_hist_cnt", C.c_int32), ("max_kmer_cnt", C.c_int32), ("max_n_chain", C.c_int32),
-                ("high_factor", C.c_double), ("is_ont", C.c_int32), ("bf_shift", C.c_int32)]
+                ("high_factor", C.c_double), ("is_ont", C.c_int32), ("bf_shift", C.c_int32), ("hg_size", C.c_int64)]
+
+
+class Pass(C.Structure):
+    """hao_pass_t: the per-pass arguments of h_ec_lchain (anchor.cpp:2302)"""
+    _fields_ = [("bw_thres", C.c_double), ("max_n_chain", C.c_int32), ("high_occ", C.c_uint32), ("low_occ", C.c_uint32),
+                ("apend_be", C.c_int32), ("is_accurate", C.c_int32), ("gen_off", C.c_int32), ("mcopy_num", C.c_int32),
+                ("mcopy_rate", C.c_double), ("chain_cutoff", C.c_uint32), ("mcopy_khit_cut", C.c_uint32), ("ocv_w", C.c_uint64)]
 
 
 ABI_SYMBOLS = [
@@ -35,7 +42,7 @@ ABI_SYMBOLS = [
     "hao_ft_cnt", "hao_pt_get", "hao_ft_table", "hao_pt_table", "hao_hist", "hao_stats", "hao_sketch_batch",
     "hao_fetch_sketch", "hao_overlap_batch", "hao_fetch_seed_hits", "hao_fetch_overlaps", "hao_batch_totals",
     "hao_stage_times", "hao_pass_default", "hao_overlap_batch_ex", "hao_set_shard", "hao_dist_unique_id", "hao_dist_init",
-    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback",
+    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim",
 ]
 
 
@@ -67,10 +74,13 @@ def lib():
         L.hao_sketch_batch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
         L.hao_fetch_sketch.argtypes = [vp, C.c_uint64, C.POINTER(vp), u64p]
         L.hao_overlap_batch.argtypes = [vp, C.c_uint64, C.c_uint64]
+        L.hao_pass_default.argtypes = [vp, C.POINTER(Pass)]
+        L.hao_overlap_batch_ex.argtypes = [vp, C.c_uint64, C.c_uint64, C.POINTER(Pass)]
         L.hao_fetch_seed_hits.argtypes = [vp, C.c_uint64, C.POINTER(vp), u64p]
         L.hao_fetch_overlaps.argtypes = [vp, C.c_uint64, C.POINTER(vp), u64p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), u64p]
         L.hao_batch_totals.argtypes = [vp, u64p]
         L.hao_stage_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+        L.hao_batch_digest.argtypes = [vp, u64p, u64p]
         L.hao_set_shard.argtypes = [vp, C.c_uint64, C.c_uint64, u32p]
         L.hao_dist_unique_id.argtypes = [u8p]
         L.hao_dist_init.argtypes = [vp, u8p, C.c_int, C.c_int]
@@ -96,6 +106,7 @@ class Engine:
         self.L = lib()
         self.opt = Opt()
         self.L.hao_opt_default(C.byref(self.opt))
+        self.bw_thres = opts.pop("bw_thres", None)      # a per-pass argument of h_ec_lchain, not an option: overrides hao_pass_default's value
         for k, v in opts.items():
             if not hasattr(self.opt, k):
                 raise HaoError(f"unknown option {k}")
@@ -218,8 +229,22 @@ class Engine:
         return _arr(p.value, 2 * n.value, np.uint64).reshape(-1, 2)
 
     # ---- h_ec_lchain ----
-    def overlap_batch(self, lo, hi):
-        self._ck(self.L.hao_overlap_batch(self.h, lo, hi), "hao_overlap_batch")
+    def pass_default(self):
+        p = Pass()
+        self._ck(self.L.hao_pass_default(self.h, C.byref(p)), "hao_pass_default")
+        if self.bw_thres is not None:
+            p.bw_thres = self.bw_thres
+        return p
+
+    def overlap_batch(self, lo, hi, bw_thres=None):
+        """h_ec_lchain for reads [lo, hi) with worker_hap_ec's arguments (ecovlp.cpp:3274); bw_thres = 0.001 gives the final-round call (:3957)"""
+        if bw_thres is None and self.bw_thres is None:
+            self._ck(self.L.hao_overlap_batch(self.h, lo, hi), "hao_overlap_batch")
+            return
+        p = self.pass_default()
+        if bw_thres is not None:
+            p.bw_thres = bw_thres
+        self._ck(self.L.hao_overlap_batch_ex(self.h, lo, hi, C.byref(p)), "hao_overlap_batch_ex")
 
     def fetch_seed_hits(self, rid):
         p, n = C.c_void_p(), C.c_uint64()
@@ -242,6 +267,14 @@ class Engine:
         self._ck(self.L.hao_batch_totals(self.h, out), "hao_batch_totals")
         return dict(overlaps=int(out[0]), chained_hits=int(out[1]), seed_hits=int(out[2]), groups=int(out[3]), minimizers=int(out[4]), chains=int(out[5]),
                     seq_groups=int(out[6]), seq_group_hits=int(out[7]))
+
+    def batch_digest(self, n, with_seed_hits=True):
+        """per-read digests of the last batch (n reads): (digest of ol / fake cigars / cl, digest of the seed hits or None)"""
+        d = np.zeros(n, dtype=np.uint64)
+        k = np.zeros(n, dtype=np.uint64) if with_seed_hits else None
+        u64p = C.POINTER(C.c_uint64)
+        self._ck(self.L.hao_batch_digest(self.h, d.ctypes.data_as(u64p), k.ctypes.data_as(u64p) if k is not None else None), "hao_batch_digest")
+        return d, k
 
     def stage_times(self):
         names = (C.c_char_p * 64)()

@@ -43,7 +43,7 @@ def build_synth(force=False):
     out = os.path.join(PKG, "libhaosynth.so")
     src = os.path.join(CSRC, "hao_synth.c")
     if force or _newer(out, [src]):
-        _run(["gcc", "-O2", "-fPIC", "-shared", "-o", out, src])
+        _run(["gcc", "-O2", "-fPIC", "-shared", "-o", out, src, "-lpthread"])
     return out
 
 

@@ -90,7 +90,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		sa_.sinfo = c->d_ix_sinfo.p; sa_.len = c->d_len_all.p; sa_.q_pos = B.q_pos.p; sa_.q_cnt = B.q_cnt.p; sa_.hits = B.hits.p; sa_.g_tmp = B.g_tmp.p; sa_.g_cnt = B.g_cnt.p; sa_.n_sel = n; sa_.tb = tb;
 		sa_.qcap = (uint32_t)std::min<uint64_t>((max_q + 63) & ~63ULL, HAO_QTAB_CAP);
 		sa_.dbg = nullptr;
-		if (getenv("HAO_DBG_SEEDPHASE")) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); sa_.dbg = B.dbgbuf.p; }
+		if (c->sw.seedphase) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); sa_.dbg = B.dbgbuf.p; }
 		HIP_TRY(B.ovf_list.reserve(n + 1));
 		unsigned long long *d_ovf = B.stats.p + 3 * HAO_NCLS + 3;
 		const size_t lds1 = (size_t)40 * 512 + 12 * (size_t)sa_.qcap + 16, lds2 = (size_t)40 * 1024 + 12 * (size_t)sa_.qcap + 16;
@@ -103,7 +103,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		hipLaunchKernelGGL((seed_bin_kernel<10, false>), dim3((unsigned)n), dim3(256), lds2, c->stream, sa_, B.ovf_list.p, d_ovf);
 		HAO_CHECK_LAUNCH();
 	}
-	if (getenv("HAO_DBG_SEEDPHASE")) { unsigned long long d_[4]; HIP_TRY(hipMemcpy(d_, B.dbgbuf.p, 32, hipMemcpyDeviceToHost)); if (d_[3]) fprintf(stderr, "[seed] blocks %llu  avg us: count pass %.1f  sort+scan %.1f  scatter pass %.1f\n", d_[3], d_[0] / 100.0 / d_[3], d_[1] / 100.0 / d_[3], d_[2] / 100.0 / d_[3]); }
+	if (c->sw.seedphase) { unsigned long long d_[4]; HIP_TRY(hipMemcpy(d_, B.dbgbuf.p, 32, hipMemcpyDeviceToHost)); if (d_[3]) fprintf(stderr, "[seed] blocks %llu  avg us: count pass %.1f  sort+scan %.1f  scatter pass %.1f\n", d_[3], d_[0] / 100.0 / d_[3], d_[1] / 100.0 / d_[3], d_[2] / 100.0 / d_[3]); }
 	c->timer.mark("q_sort_bins");
 	HIP_TRY(B.cls_cc.reserve(HAO_NCLS * (n + 1) + 1)); HIP_TRY(B.cls_co.reserve(HAO_NCLS * (n + 1) + 1));
 	hipLaunchKernelGGL(groups_classify_kernel, dim3((unsigned)((n + 4) / 4)), dim3(256), 0, c->stream, B.g_tmp.p, B.seg.p, B.g_cnt.p, n, B.cls_cc.p);
@@ -131,9 +131,9 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		hao_chain_args ca;
 		ca.hits = B.hits.p; ca.g_start = B.g_start.p; ca.g_read = B.g_read.p; ca.g_off = B.g_off.p; ca.seg = B.seg.p; ca.n_groups = G; ca.rid_lo = glo; ca.len = c->d_len_all.p; ca.par = par;
 		ca.dbg_qc = nullptr;
-		if (getenv("HAO_DBG_QCPHASE")) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); ca.dbg_qc = B.dbgbuf.p; }
-		ca.stats = d_slow_cnt; ca.dbg_stats = getenv("HAO_DBG_DP_STATS") ? 1 : 0;
-		ca.dbg_seq = getenv("HAO_DBG_SEQ_CHAIN") ? 1 : (getenv("HAO_DBG_DP_SEQTAIL") ? 3 : (getenv("HAO_DBG_DP_NOSPEC") ? 4 : 0));
+		if (c->sw.qcphase) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); ca.dbg_qc = B.dbgbuf.p; }
+		ca.stats = d_slow_cnt; ca.dbg_stats = c->sw.dp_stats ? 1 : 0;
+		ca.dbg_seq = c->sw.seq_chain ? 1 : (c->sw.dp_seqtail ? 3 : (c->sw.dp_nospec ? 4 : 0));
 		// per-hit DP scratch in global memory is only touched by groups beyond the LDS variants (and the sequential debug path)
 		const bool need_scratch = cls_cnt[HAO_NCLS - 1] > 0 || ca.dbg_seq == 1;
 		if (need_scratch) { HIP_TRY(B.f.reserve(A + 1)); HIP_TRY(B.ii.reserve(A + 1)); HIP_TRY(B.p.reserve(A + 1)); HIP_TRY(B.t.reserve(A + 1)); HIP_TRY(B.tm.reserve(A + 1)); }
@@ -142,9 +142,9 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			for (int x = 0; x < HAO_NCLS; ++x) { HIP_TRY(hipStreamCreateWithFlags(&B.side[x], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&B.ev_qc[x], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&B.ev_dp[x], hipEventDisableTiming)); }
 			B.side_ready = true;
 		}
-		int wpb = 1; if (const char *e_ = getenv("HAO_CHAIN_WPB")) wpb = std::max(1, std::min(4, atoi(e_)));
-		const bool serial = getenv("HAO_DBG_DP_SERIAL") != nullptr;      // DP kernels on the main stream (no overlap), for A/B timing
-		int spec_min = 2; if (const char *e_ = getenv("HAO_SPEC_MINCLS")) spec_min = atoi(e_);      // tiles of <= 64 hits gain nothing from speculation
+		const int wpb = c->sw.chain_wpb;
+		const bool serial = c->sw.dp_serial;      // DP kernels on the main stream (no overlap), for A/B timing
+		const int spec_min = c->sw.spec_mincls;      // tiles of <= 64 hits gain nothing from speculation
 		const int dbg_seq0 = ca.dbg_seq;
 		for (int x = HAO_NCLS - 1; x >= 1; --x) {
 			const uint64_t nl = cls_cnt[x]; if (!nl) continue;
@@ -207,13 +207,13 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	sa.key_xs = B.key_xs.p; sa.key_sc = B.key_sc.p; sa.key_al = B.key_al.p; sa.key_tmp = B.key_tmp.p;
 	sa.ol = B.ol.p; sa.g_off = B.g_off.p; sa.ch_base = B.ch_base.p; sa.cl_base = B.cl_base.p; sa.cl = B.cl.p; sa.n_sel = n; sa.rid_lo = glo; sa.len = c->d_len_all.p; sa.cc_off = B.cc_off.p; sa.cc = B.cc.p;
 	sa.perm = B.perm.p; sa.n_final = B.n_final.p; sa.fc_final = B.fc_final.p; sa.max_n_chain = par.max_n_chain; sa.ocv_w = par.ocv_w; sa.chain_cutoff = par.chain_cutoff;
-	sa.dbg = nullptr; sa.dbg_seq_prune = getenv("HAO_DBG_SEQ_PRUNE") ? 1 : 0;
-	if (getenv("HAO_DBG_SELPHASE")) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); sa.dbg = B.dbgbuf.p; }
+	sa.dbg = nullptr; sa.dbg_seq_prune = c->sw.seq_prune ? 1 : 0;
+	if (c->sw.selphase) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); sa.dbg = B.dbgbuf.p; }
 	// three launches split by chain count: the common reads (<= 128 chains) need 5 KB of LDS per wave and fill the CUs; 512- and 1024-chain slices for
 	// repeat-rich reads (beyond 1024 chains the keys stay in global scratch)
 	hipLaunchKernelGGL((chain_select_kernel<1, 128>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)0, (int64_t)129);
 	HAO_CHECK_LAUNCH();
-	if (getenv("HAO_DBG_SEL1")) {      // one wave per read for every size (A/B)
+	if (c->sw.sel1) {      // one wave per read for every size (A/B)
 		hipLaunchKernelGGL((chain_select_kernel<1, 512>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)129, (int64_t)513);
 		HAO_CHECK_LAUNCH();
 		hipLaunchKernelGGL((chain_select_kernel<1, 1024>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)513, (int64_t)INT64_MAX);
@@ -244,7 +244,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	B.n_generic = 0; for (int x = 0; x < HAO_NCLS; ++x) B.n_generic += slow_st[x];
 	B.n_generic_hits = slow_st[HAO_NCLS];
-	if (getenv("HAO_DBG_DP_STATS")) { fprintf(stderr, "[dp] slow groups by class:"); for (int x = 0; x < HAO_NCLS; ++x) fprintf(stderr, " %llu/%llu", slow_st[x], cls_cnt[x]);
+	if (c->sw.dp_stats) { fprintf(stderr, "[dp] slow groups by class:"); for (int x = 0; x < HAO_NCLS; ++x) fprintf(stderr, " %llu/%llu", slow_st[x], cls_cnt[x]);
 		fprintf(stderr, "  hits %llu  dp range %llu  spec-committed %llu  spec-failures %llu\n", slow_st[HAO_NCLS], slow_st[HAO_NCLS + 3], slow_st[HAO_NCLS + 1], slow_st[HAO_NCLS + 2]); }
 	B.valid = true;
 	return HAO_OK;

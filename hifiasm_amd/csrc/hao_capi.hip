@@ -9,6 +9,7 @@
 #include "hao_index.cuh"
 #include "hao_query.cuh"
 #include "hao_chain.cuh"
+#include "hao_deliver.cuh"
 #include "hao_comm.hpp"
 #include "hao_pipeline.hpp"
 #include "hao_tables.hpp"
@@ -20,7 +21,7 @@ void hao_opt_default(hao_opt_t *o)
 {
 	memset(o, 0, sizeof(*o));
 	o->k = 51; o->w = 51; o->hpc = 1; o->sample_dist = 500; o->rewin = 1000; o->min_hist_cnt = 5;
-	o->max_kmer_cnt = 2000; o->max_n_chain = 100; o->high_factor = 5.0; o->is_ont = 0;
+	o->max_kmer_cnt = 2000; o->max_n_chain = 100; o->high_factor = 5.0; o->is_ont = 0; o->hg_size = -1;
 }
 
 int hao_create(int device, const hao_opt_t *opt, hao_ctx **out)
@@ -31,7 +32,7 @@ int hao_create(int device, const hao_opt_t *opt, hao_ctx **out)
 	if (hipSetDevice(device) != hipSuccess) return HAO_ENODEV;
 	if (!opt || opt->k <= 0 || opt->k > 63 || opt->w <= 0 || opt->w >= 256) return HAO_EINVAL;
 	hao_ctx *c = new hao_ctx();
-	c->device = device; c->opt = *opt; c->max_n_chain = opt->max_n_chain;
+	c->device = device; c->opt = *opt; c->max_n_chain = opt->max_n_chain; c->sw.load();
 	if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return HAO_ENODEV; }
 	memset(c->ft_hist, 0, sizeof(c->ft_hist)); memset(c->pt_hist, 0, sizeof(c->pt_hist));
 	*out = c;
@@ -44,7 +45,7 @@ void hao_destroy(hao_ctx *c)
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
 	hao_batch_free(c);
-	if (c->comm) { if (c->comm->nccl) ncclCommDestroy(c->comm->nccl); c->comm->ag_tmp.release(); delete c->comm; c->comm = nullptr; }
+	if (c->comm) { if (c->comm->nccl) ncclCommDestroy(c->comm->nccl); c->comm->release(); delete c->comm; c->comm = nullptr; }
 	// DevBuf members are released explicitly (no destructors: the struct is POD-ish on purpose)
 	hao_release_all(c);
 	(void)hipStreamDestroy(c->stream);
@@ -116,6 +117,12 @@ int hao_dist_init(hao_ctx *c, const uint8_t id[128], int rank, int world)
 	if (!c->comm) c->comm = new hao_comm();
 	ncclUniqueId u; memcpy(&u, id, sizeof(u));
 	c->comm->rank = rank; c->comm->world = world; c->comm->loop = nullptr;
+	{	// libhao.so is compiled against /opt/rocm's rccl.h but binds at run time to whichever librccl.so.1 the process loaded first (torch bundles
+		// its own): the calls used here (unique id, comm init, all-gather, all-reduce, broadcast, send / recv) are stable across 2.x, a different major is not
+		int rt = 0; NCCL_TRY(ncclGetVersion(&rt));
+		const int rt_major = rt >= 10000 ? rt / 10000 : rt / 1000;
+		if (rt_major != NCCL_MAJOR) { hao_set_err(c, "RCCL major version " + std::to_string(rt_major) + " at run time, " + std::to_string(NCCL_MAJOR) + " at compile time"); return HAO_EUNSUPP; }
+	}
 	NCCL_TRY(ncclCommInitRank(&c->comm->nccl, world, u, rank));
 	return HAO_OK;
 }

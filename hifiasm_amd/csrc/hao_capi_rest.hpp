@@ -149,6 +149,69 @@ int hao_batch_totals(hao_ctx *c, uint64_t out[8])
 	return HAO_OK;
 }
 
+int hao_batch_digest(hao_ctx *c, uint64_t *out, uint64_t *out_kh)
+{
+	if (!c || !out || !c->batch || !c->batch->valid) return HAO_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	hao_ctx::Batch &B = *c->batch; const uint64_t n = B.n;
+	if (n == 0) return HAO_OK;
+	DevBuf<uint64_t> d; HIP_TRY(d.reserve(2 * n + 2));
+	hao_digest_args a;
+	a.fin_off = B.fin_off.p; a.fcf_off = B.fcf_off.p; a.g_off = B.g_off.p; a.cl_base = B.cl_base.p; a.seg = B.seg.p;
+	a.ol = (const uint64_t*)B.ol_out.p; a.fc = B.fc_out.p; a.cl = (const uint64_t*)B.cl.p; a.hits = (const uint64_t*)B.hits.p;
+	a.n_sel = n; a.dig = d.p; a.dig_kh = out_kh ? d.p + n : nullptr;
+	hipLaunchKernelGGL(hao_digest_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, a);
+	HAO_CHECK_LAUNCH();
+	HIP_TRY(hipMemcpyAsync(out, d.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+	if (out_kh) HIP_TRY(hipMemcpyAsync(out_kh, d.p + n, n * 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	d.release();
+	return HAO_OK;
+}
+
+// Self-test of the two ways to group minimizer records by their 16 owner bits (hao_pt_run, sharded): out[0] = order violations of
+// rocprim::radix_sort_pairs(begin_bit = 48, end_bit = 64) on (hash, index) pairs, out[1] = violations of the path the engine uses (separate 16-bit
+// key, begin_bit = 0, then a gather).  A "violation" = a position whose owner bits decrease, or equal owner bits with a decreasing index (the
+// sort must be stable).  tests/test_gpu_rocprim.py pins out[1] == 0 and logs out[0].
+__global__ void hao_selftest_fill_kernel(uint64_t n, uint64_t *x, uint64_t *v)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) { x[i] = hao_hash64(i * 0x9E3779B97F4A7C15ULL + 12345); v[i] = i; }
+}
+int hao_selftest_rocprim(uint64_t n, uint64_t out[2])
+{
+	hao_ctx tmp_ctx; hao_ctx *c = &tmp_ctx;      // only for the error-string macros
+	if (!out || n == 0 || n >= (1ULL << 32)) return HAO_EINVAL;
+	out[0] = out[1] = 0;
+	hipStream_t st = nullptr;
+	DevBuf<uint64_t> x, v, x2, v2, gx, gv; DevBuf<uint32_t> ok, ok2, oi, oi2; DevBuf<unsigned char> tmp;
+	HIP_TRY(x.reserve(n)); HIP_TRY(v.reserve(n)); HIP_TRY(x2.reserve(n)); HIP_TRY(v2.reserve(n)); HIP_TRY(gx.reserve(n)); HIP_TRY(gv.reserve(n));
+	HIP_TRY(ok.reserve(n)); HIP_TRY(ok2.reserve(n)); HIP_TRY(oi.reserve(n)); HIP_TRY(oi2.reserve(n));
+	hipLaunchKernelGGL(hao_selftest_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, x.p, v.p);
+	HIP_TRY(hipGetLastError());
+	size_t tb = 0;
+	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, x.p, x2.p, v.p, v2.p, n, 48, 64, st)); HIP_TRY(tmp.reserve(tb + 256));
+	HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, x.p, x2.p, v.p, v2.p, n, 48, 64, st));
+	hipLaunchKernelGGL(hao_owner_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x.p, n, ok.p, oi.p);
+	HIP_TRY(hipGetLastError());
+	rocprim::double_buffer<uint32_t> dk(ok.p, ok2.p), dv(oi.p, oi2.p); tb = 0;
+	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, dk, dv, n, 0, 16, st)); HIP_TRY(tmp.reserve(tb + 256));
+	HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, dk, dv, n, 0, 16, st));
+	hipLaunchKernelGGL(hao_gather2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dv.current(), x.p, v.p, n, gx.p, gv.p);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipDeviceSynchronize());
+	std::vector<uint64_t> hx(n), hv(n);
+	for (int which = 0; which < 2; ++which) {
+		HIP_TRY(hipMemcpy(hx.data(), which ? gx.p : x2.p, n * 8, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(hv.data(), which ? gv.p : v2.p, n * 8, hipMemcpyDeviceToHost));
+		uint64_t bad = 0;
+		for (uint64_t i = 1; i < n; ++i) { const uint64_t a = hx[i - 1] >> 48, b = hx[i] >> 48; if (a > b || (a == b && hv[i - 1] >= hv[i])) ++bad; }
+		for (uint64_t i = 0; i < n; ++i) if (hv[i] >= n || hx[i] != hao_hash64(hv[i] * 0x9E3779B97F4A7C15ULL + 12345)) ++bad;      // a permutation of the input pairs
+		out[which] = bad;
+	}
+	x.release(); v.release(); x2.release(); v2.release(); gx.release(); gv.release(); ok.release(); ok2.release(); oi.release(); oi2.release(); tmp.release();
+	return HAO_OK;
+}
+
 int hao_pt_table(hao_ctx *c, uint64_t *n_keys, const uint64_t **keys, const uint64_t **off, const uint64_t **pos, uint64_t *n_pos)
 {
 	if (!c || !c->has_pt) return HAO_EINVAL;

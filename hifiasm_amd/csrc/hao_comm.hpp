@@ -24,76 +24,73 @@ struct hao_comm {
 	int rank = 0, world = 1;
 	ncclComm_t nccl = nullptr; hao_loop_group *loop = nullptr;
 	DevBuf<char> ag_tmp;      // padded slots of the balanced all-gather-v
-	std::vector<uint64_t> shard_sizes; uint64_t shard_sizes_for = ~0ULL;      // reads per rank, checked once per read set
+	DevBuf<uint64_t> sc_a, sc_b;      // scratch of the small host-value collectives (allocated once: no hipMalloc / hipFree on the timed path)
 	bool active() const { return world > 1 || nccl || loop; }
+	void release() { ag_tmp.release(); sc_a.release(); sc_b.release(); }
 };
+
+// Every small collective below also carries the status of the LOCAL phase that preceded it on each rank (local_rc): a rank whose allocation /
+// kernel / sort failed still takes part (with empty data) and every rank returns the same error afterwards, so nobody is left waiting in the next
+// collective for a peer that has already returned.
+static int hao_comm_verdict(hao_ctx *c, const hao_comm &cm, const std::vector<uint64_t> &status, int local_rc)
+{
+	if (local_rc) return local_rc;
+	for (int r = 0; r < cm.world; ++r) if (status[r]) { hao_set_err(c, "rank " + std::to_string(r) + " failed in the preceding local phase (code -" + std::to_string(status[r]) + ")"); return -(int)status[r]; }
+	return HAO_OK;
+}
 
 #define NCCL_TRY(expr) do { ncclResult_t _r = (expr); if (_r != ncclSuccess) { hao_set_err(c, std::string(#expr) + ": " + ncclGetErrorString(_r)); return HAO_ENODEV; } } while (0)
 
-// all ranks learn every rank's value (host u64)
-static int hao_comm_allgather_u64(hao_ctx *c, hao_comm &cm, uint64_t v, std::vector<uint64_t> &out)
+// all ranks learn nv values of every rank: out[r * nv + i] = value i of rank r (one collective); returns the agreed status (see above)
+static int hao_comm_allgather_u64n(hao_ctx *c, hao_comm &cm, const uint64_t *v, int nv, std::vector<uint64_t> &out, int local_rc = 0)
 {
-	out.assign(cm.world, 0);
-	if (cm.world == 1 && !cm.nccl && !cm.loop) { out[0] = v; return HAO_OK; }
+	const int W = cm.world, nw = nv + 1;
+	out.assign((size_t)W * nv, 0);
+	if (W == 1 && !cm.nccl && !cm.loop) { for (int i = 0; i < nv; ++i) out[i] = v[i]; return local_rc; }
+	std::vector<uint64_t> mine(v, v + nv), all((size_t)W * nw, 0), st(W, 0); mine.push_back((uint64_t)(-local_rc));
 	if (cm.loop) {
 		hao_loop_group *g = cm.loop;
-		g->hostv[cm.rank].assign(1, v);
+		g->hostv[cm.rank] = mine;
 		pthread_barrier_wait(&g->bar);
-		for (int r = 0; r < cm.world; ++r) out[r] = g->hostv[r][0];
+		for (int r = 0; r < W; ++r) for (int i = 0; i < nw; ++i) all[(size_t)r * nw + i] = g->hostv[r][i];
 		pthread_barrier_wait(&g->bar);
-		return HAO_OK;
+	} else {
+		HIP_TRY(cm.sc_a.reserve((size_t)W * nw + 1));
+		HIP_TRY(hipMemcpyAsync(cm.sc_a.p + (size_t)cm.rank * nw, mine.data(), 8 * (size_t)nw, hipMemcpyHostToDevice, c->stream));
+		NCCL_TRY(ncclAllGather(cm.sc_a.p + (size_t)cm.rank * nw, cm.sc_a.p, (size_t)nw, ncclUint64, cm.nccl, c->stream));
+		HIP_TRY(hipMemcpyAsync(all.data(), cm.sc_a.p, 8 * (size_t)W * nw, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
 	}
-	DevBuf<uint64_t> d; HIP_TRY(d.reserve(cm.world + 1));
-	HIP_TRY(hipMemcpyAsync(d.p + cm.rank, &v, 8, hipMemcpyHostToDevice, c->stream));
-	NCCL_TRY(ncclAllGather(d.p + cm.rank, d.p, 1, ncclUint64, cm.nccl, c->stream));
-	HIP_TRY(hipMemcpyAsync(out.data(), d.p, 8 * cm.world, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));
-	d.release();
-	return HAO_OK;
+	for (int r = 0; r < W; ++r) { for (int i = 0; i < nv; ++i) out[(size_t)r * nv + i] = all[(size_t)r * nw + i]; st[r] = all[(size_t)r * nw + nv]; }
+	return hao_comm_verdict(c, cm, st, local_rc);
 }
+static int hao_comm_allgather_u64(hao_ctx *c, hao_comm &cm, uint64_t v, std::vector<uint64_t> &out, int local_rc = 0)
+{ return hao_comm_allgather_u64n(c, cm, &v, 1, out, local_rc); }
 
-// the same for nv values per rank: out[r * nv + i] = value i of rank r (one collective instead of nv)
-static int hao_comm_allgather_u64n(hao_ctx *c, hao_comm &cm, const uint64_t *v, int nv, std::vector<uint64_t> &out)
+// element-wise sum of a host int64 vector over all ranks (the 4096-bin histogram); one more element carries the status
+static int hao_comm_allreduce_i64(hao_ctx *c, hao_comm &cm, int64_t *v, size_t n, int local_rc = 0)
 {
-	out.assign((size_t)cm.world * nv, 0);
-	if (cm.world == 1 && !cm.nccl && !cm.loop) { for (int i = 0; i < nv; ++i) out[i] = v[i]; return HAO_OK; }
+	if (cm.world == 1 && !cm.nccl && !cm.loop) return local_rc;
+	std::vector<int64_t> w(v, v + n); w.push_back(local_rc ? 1 : 0);
+	if (local_rc) std::fill(w.begin(), w.begin() + n, 0);
 	if (cm.loop) {
 		hao_loop_group *g = cm.loop;
-		g->hostv[cm.rank].assign(v, v + nv);
+		g->hostv[cm.rank].assign((uint64_t*)w.data(), (uint64_t*)w.data() + n + 1);
 		pthread_barrier_wait(&g->bar);
-		for (int r = 0; r < cm.world; ++r) for (int i = 0; i < nv; ++i) out[(size_t)r * nv + i] = g->hostv[r][i];
+		std::vector<int64_t> s(n + 1, 0);
+		for (int r = 0; r < cm.world; ++r) for (size_t i = 0; i <= n; ++i) s[i] += (int64_t)g->hostv[r][i];
 		pthread_barrier_wait(&g->bar);
-		return HAO_OK;
+		w = s;
+	} else {
+		HIP_TRY(cm.sc_b.reserve(n + 2));
+		HIP_TRY(hipMemcpyAsync(cm.sc_b.p, w.data(), 8 * (n + 1), hipMemcpyHostToDevice, c->stream));
+		NCCL_TRY(ncclAllReduce(cm.sc_b.p, cm.sc_b.p, n + 1, ncclInt64, ncclSum, cm.nccl, c->stream));
+		HIP_TRY(hipMemcpyAsync(w.data(), cm.sc_b.p, 8 * (n + 1), hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
 	}
-	DevBuf<uint64_t> d; HIP_TRY(d.reserve((size_t)cm.world * nv + 1));
-	HIP_TRY(hipMemcpyAsync(d.p + (size_t)cm.rank * nv, v, 8 * (size_t)nv, hipMemcpyHostToDevice, c->stream));
-	NCCL_TRY(ncclAllGather(d.p + (size_t)cm.rank * nv, d.p, (size_t)nv, ncclUint64, cm.nccl, c->stream));
-	HIP_TRY(hipMemcpyAsync(out.data(), d.p, 8 * (size_t)cm.world * nv, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));
-	d.release();
-	return HAO_OK;
-}
-
-// element-wise sum of a host int64 vector over all ranks (the 4096-bin histogram)
-static int hao_comm_allreduce_i64(hao_ctx *c, hao_comm &cm, int64_t *v, size_t n)
-{
-	if (cm.world == 1 && !cm.nccl && !cm.loop) return HAO_OK;
-	if (cm.loop) {
-		hao_loop_group *g = cm.loop;
-		g->hostv[cm.rank].assign((uint64_t*)v, (uint64_t*)v + n);
-		pthread_barrier_wait(&g->bar);
-		std::vector<int64_t> s(n, 0);
-		for (int r = 0; r < cm.world; ++r) for (size_t i = 0; i < n; ++i) s[i] += (int64_t)g->hostv[r][i];
-		pthread_barrier_wait(&g->bar);
-		memcpy(v, s.data(), n * 8);
-		return HAO_OK;
-	}
-	DevBuf<int64_t> d; HIP_TRY(d.reserve(n + 1));
-	HIP_TRY(hipMemcpyAsync(d.p, v, 8 * n, hipMemcpyHostToDevice, c->stream));
-	NCCL_TRY(ncclAllReduce(d.p, d.p, n, ncclInt64, ncclSum, cm.nccl, c->stream));
-	HIP_TRY(hipMemcpyAsync(v, d.p, 8 * n, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));
-	d.release();
+	memcpy(v, w.data(), n * 8);
+	if (local_rc) return local_rc;
+	if (w[n]) { hao_set_err(c, std::to_string((long long)w[n]) + " rank(s) failed in the preceding local phase"); return HAO_ENODEV; }
 	return HAO_OK;
 }
 
@@ -135,27 +132,33 @@ static int hao_comm_allgatherv(hao_ctx *c, hao_comm &cm, const void *src, uint64
 
 // all-to-all-v of u64 elements: rank sends src[sdisp[d] .. sdisp[d]+scnt[d]) to d; receives into out in source-rank order.
 // rcnt is filled with the received counts. out must hold sum(rcnt) (caller sizes it after the count exchange: see hao_comm_exchange_counts).
-static int hao_comm_exchange_counts(hao_ctx *c, hao_comm &cm, const std::vector<uint64_t> &scnt, std::vector<uint64_t> &rcnt)
+static int hao_comm_exchange_counts(hao_ctx *c, hao_comm &cm, const std::vector<uint64_t> &scnt_in, std::vector<uint64_t> &rcnt, int local_rc = 0)
 {
-	rcnt.assign(cm.world, 0);
-	if (cm.world == 1 && !cm.nccl && !cm.loop) { rcnt[0] = scnt[0]; return HAO_OK; }
+	const int W = cm.world;
+	std::vector<uint64_t> scnt(scnt_in); scnt.resize(W, 0);
+	if (local_rc) std::fill(scnt.begin(), scnt.end(), 0);          // a failed rank sends nothing, but it does send its status
+	rcnt.assign(W, 0);
+	if (W == 1 && !cm.nccl && !cm.loop) { rcnt[0] = scnt[0]; return local_rc; }
+	std::vector<uint64_t> st(W, 0);
 	if (cm.loop) {
 		hao_loop_group *g = cm.loop;
-		g->cnt[cm.rank] = scnt;
+		g->cnt[cm.rank] = scnt; g->cnt[cm.rank].push_back((uint64_t)(-local_rc));
 		pthread_barrier_wait(&g->bar);
-		for (int r = 0; r < cm.world; ++r) rcnt[r] = g->cnt[r][cm.rank];
+		for (int r = 0; r < W; ++r) { rcnt[r] = g->cnt[r][cm.rank]; st[r] = g->cnt[r][W]; }
 		pthread_barrier_wait(&g->bar);
-		return HAO_OK;
+		return hao_comm_verdict(c, cm, st, local_rc);
 	}
-	DevBuf<uint64_t> ds, dr; HIP_TRY(ds.reserve(cm.world + 1)); HIP_TRY(dr.reserve(cm.world + 1));
-	HIP_TRY(hipMemcpyAsync(ds.p, scnt.data(), 8 * cm.world, hipMemcpyHostToDevice, c->stream));
+	std::vector<uint64_t> snd(2 * W), rcv(2 * W, 0);
+	for (int r = 0; r < W; ++r) { snd[2 * r] = scnt[r]; snd[2 * r + 1] = (uint64_t)(-local_rc); }
+	HIP_TRY(cm.sc_a.reserve(2 * W + 1)); HIP_TRY(cm.sc_b.reserve(2 * W + 1));
+	HIP_TRY(hipMemcpyAsync(cm.sc_a.p, snd.data(), 16 * W, hipMemcpyHostToDevice, c->stream));
 	NCCL_TRY(ncclGroupStart());
-	for (int r = 0; r < cm.world; ++r) { NCCL_TRY(ncclSend(ds.p + r, 1, ncclUint64, r, cm.nccl, c->stream)); NCCL_TRY(ncclRecv(dr.p + r, 1, ncclUint64, r, cm.nccl, c->stream)); }
+	for (int r = 0; r < W; ++r) { NCCL_TRY(ncclSend(cm.sc_a.p + 2 * r, 2, ncclUint64, r, cm.nccl, c->stream)); NCCL_TRY(ncclRecv(cm.sc_b.p + 2 * r, 2, ncclUint64, r, cm.nccl, c->stream)); }
 	NCCL_TRY(ncclGroupEnd());
-	HIP_TRY(hipMemcpyAsync(rcnt.data(), dr.p, 8 * cm.world, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipMemcpyAsync(rcv.data(), cm.sc_b.p, 16 * W, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
-	ds.release(); dr.release();
-	return HAO_OK;
+	for (int r = 0; r < W; ++r) { rcnt[r] = rcv[2 * r]; st[r] = rcv[2 * r + 1]; }
+	return hao_comm_verdict(c, cm, st, local_rc);
 }
 
 static int hao_comm_alltoallv_u64(hao_ctx *c, hao_comm &cm, const uint64_t *src, const std::vector<uint64_t> &scnt, const std::vector<uint64_t> &sdisp,

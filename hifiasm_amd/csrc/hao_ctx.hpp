@@ -2,6 +2,8 @@
 #pragma once
 #include <rocprim/rocprim.hpp>
 #include <map>
+#include <algorithm>
+#include <cstdlib>
 #include "hao_common.cuh"
 
 struct hao_ctx;
@@ -47,8 +49,24 @@ struct StageTimer {
 	~StageTimer() { for (auto e : ev) (void)hipEventDestroy(e); }
 };
 
+// run-time switches (measurement aids): read from the environment ONCE, in hao_create
+struct hao_switches {
+	bool seedphase = false, qcphase = false, dp_stats = false, seq_chain = false, dp_seqtail = false, dp_nospec = false, dp_serial = false,
+		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false;
+	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1;
+	void load() {
+		auto on = [](const char *n) { return getenv(n) != nullptr; };
+		seedphase = on("HAO_DBG_SEEDPHASE"); qcphase = on("HAO_DBG_QCPHASE"); dp_stats = on("HAO_DBG_DP_STATS"); seq_chain = on("HAO_DBG_SEQ_CHAIN");
+		dp_seqtail = on("HAO_DBG_DP_SEQTAIL"); dp_nospec = on("HAO_DBG_DP_NOSPEC"); dp_serial = on("HAO_DBG_DP_SERIAL"); seq_prune = on("HAO_DBG_SEQ_PRUNE");
+		selphase = on("HAO_DBG_SELPHASE"); sel1 = on("HAO_DBG_SEL1"); sk_generic = on("HAO_DBG_SK_GENERIC");
+		if (const char *e = getenv("HAO_CHAIN_WPB")) chain_wpb = std::max(1, std::min(4, atoi(e)));
+		if (const char *e = getenv("HAO_SPEC_MINCLS")) spec_mincls = atoi(e);
+		if (const char *e = getenv("HAO_DBG_SK_GCAP")) sk_gcap = atoll(e);
+	}
+};
+
 struct hao_ctx {
-	int device = 0; hao_opt_t opt; std::string err; hipStream_t stream = nullptr;
+	int device = 0; hao_opt_t opt; std::string err; hipStream_t stream = nullptr; hao_switches sw;
 	// ---- read store (HBM) ----
 	uint64_t n_reads = 0, n_bases = 0, n_pk_bytes = 0; bool has_n = false; uint32_t max_len = 0;
 	DevBuf<uint8_t> d_packed; DevBuf<uint64_t> d_pk_off; DevBuf<uint32_t> d_len; DevBuf<uint64_t> d_nsite_off; DevBuf<uint32_t> d_nsite;

@@ -7,10 +7,28 @@
 #include <vector>
 #include "hao.h"
 
-// Peak finder of the k-mer / minimizer count histogram: ha_analyze_count (hist.cpp:74-157) for
-// the default hg_size <= 0 (no prior homozygous-peak guess).  cnt[i] = #distinct k-mers seen i times.
+// With a prior homozygous coverage (--hg-size): of the three candidate peaks pick the one nearest to the prior (ties go to the highest
+// bin `top`); a nearest peak that lies below the prior by more than half its own position is taken as the heterozygous peak and the
+// prior itself is returned; otherwise the next candidate to the left becomes the heterozygous peak (adj_m_peak_hom, hist.cpp:46-72).
+static int hao_adjust_to_prior(int prior, int top, int left, int right, int *peak_het)
+{
+	const int64_t cand[3] = { left, top, right };
+	int best = -1; int64_t best_d = -1;
+	for (int i = 0; i < 3; ++i) {
+		if (cand[i] <= 0) continue;
+		const int64_t d = cand[i] >= prior ? cand[i] - prior : prior - cand[i];
+		if (best_d == -1 || d < best_d || (d == best_d && i == 1)) { best_d = d; best = i; }
+	}
+	if (best < 0) return prior;
+	if (cand[best] < prior && (double)(prior - cand[best]) >= cand[best] * 0.51) { *peak_het = (int)cand[best]; return prior; }
+	for (int i = best - 1; i >= 0; --i) if (cand[i] > 0) { *peak_het = (int)cand[i]; break; }
+	return (int)cand[best];
+}
+
+// Peak finder of the k-mer / minimizer count histogram: ha_analyze_count (hist.cpp:74-157).  cnt[i] = #distinct k-mers seen i times;
+// prior_hom = total_bases / hg_size when --hg-size is given, else <= 0 (htab.cpp:1156,1254).
 // Returns peak_hom (or -1 when the histogram never rises: coverage too low), *peak_het = -1 if none.
-static int hao_find_peaks(const int64_t *cnt, int n_cnt, int start_cnt, int *peak_het)
+static int hao_find_peaks(const int64_t *cnt, int n_cnt, int start_cnt, int *peak_het, int prior_hom = -1)
 {
 	*peak_het = -1;
 	const int first = cnt[1] > 0 ? 1 : 2;
@@ -35,6 +53,7 @@ static int hao_find_peaks(const int64_t *cnt, int n_cnt, int start_cnt, int *pea
 	if (right > top) {
 		if (right_v < top_v * 0.05 || min_between(top + 1, right) > right_v * 0.95 || right > top * 2.5) right = -1;
 	}
+	if (prior_hom > 0) return hao_adjust_to_prior(prior_hom, top, left, right, peak_het);
 	if (right > 0) { *peak_het = top; return right; }      // top was the heterozygous peak
 	if (left > 0) *peak_het = left;
 	return top;

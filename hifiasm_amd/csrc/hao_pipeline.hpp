@@ -28,7 +28,7 @@ static hao_ft_dev hao_ft_view(hao_ctx *c)
 static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int sample_dist, int stamp_rid)
 {
 	const uint64_t n_sel = hi - lo; const int k = c->opt.k, w = c->opt.w;
-	const bool wave_variant = w == 51 && k + 7 <= 64 && !getenv("HAO_DBG_SK_GENERIC");     // default parameters: wave-local kernel
+	const bool wave_variant = w == 51 && k + 7 <= 64 && !c->sw.sk_generic;     // default parameters: wave-local kernel
 	c->sk_lo = lo; c->sk_n = n_sel; c->sk_total = 0;
 	HIP_TRY(c->d_mz_off.reserve(n_sel + 2));
 	if (n_sel == 0) { HIP_TRY(hipMemsetAsync(c->d_mz_off.p, 0, 8, c->stream)); return HAO_OK; }
@@ -68,7 +68,7 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 	// pool: every candidate of every chunk (bound nb / 6, grown on overflow); gathered / final lists: an estimate well above the usual one minimizer per
 	// ~35 bases, checked on the device (the exact total is only read back at the end)
 	uint64_t cap = nb / 6 + 65536, gcap = std::min(cap, nb / 16 + 65536), total = 0;
-	if (const char *e_ = getenv("HAO_DBG_SK_GCAP")) gcap = (uint64_t)atoll(e_);          // force the overflow / retry path (tests)
+	if (c->sw.sk_gcap >= 0) gcap = (uint64_t)c->sw.sk_gcap;          // force the overflow / retry path (tests)
 	hao_scalar_args sa;
 	for (int attempt = 0; ; ++attempt) {
 		HIP_TRY(c->d_pool_x.reserve(cap)); HIP_TRY(c->d_pool_info.reserve(cap)); HIP_TRY(c->d_pool_ord.reserve(cap));

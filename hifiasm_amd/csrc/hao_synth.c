@@ -12,6 +12,28 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
+#include <unistd.h>
+
+/* reads are independent RNG streams: both passes split [0, n) over host threads (HAO_SYNTH_THREADS, default = online cores, at most 64) */
+static int synth_threads(uint64_t n)
+{
+	long t = sysconf(_SC_NPROCESSORS_ONLN); const char *e = getenv("HAO_SYNTH_THREADS");
+	if (e) t = atol(e);
+	if (t > 64) t = 64;
+	if (t < 1) t = 1;
+	if ((uint64_t)t > n / 64 + 1) t = (long)(n / 64 + 1);
+	return (int)t;
+}
+typedef struct { void (*fn)(void *, uint64_t, uint64_t); void *arg; uint64_t lo, hi; } synth_job;
+static void *synth_tramp(void *p) { synth_job *j = (synth_job*)p; j->fn(j->arg, j->lo, j->hi); return 0; }
+static void synth_parallel(uint64_t n, void (*fn)(void *, uint64_t, uint64_t), void *arg)
+{
+	int t = synth_threads(n), i; pthread_t th[64]; synth_job jb[64];
+	if (t <= 1) { fn(arg, 0, n); return; }
+	for (i = 0; i < t; ++i) { jb[i].fn = fn; jb[i].arg = arg; jb[i].lo = n * i / t; jb[i].hi = n * (i + 1) / t; pthread_create(&th[i], 0, synth_tramp, &jb[i]); }
+	for (i = 0; i < t; ++i) pthread_join(th[i], 0);
+}
 
 static inline uint64_t splitmix64(uint64_t *s)
 {
@@ -93,33 +115,78 @@ static uint32_t synth_one(const uint8_t *g, uint64_t G, uint64_t rid, uint32_t r
 }
 
 /* pass 1: lengths of reads [rid0, rid0+n). */
+typedef struct {
+	const uint8_t *g; uint64_t G, rid0; uint32_t read_len, len_jit, err_ppm, n_ppm; uint64_t seed;
+	uint32_t *len_out; uint8_t *codes; const uint64_t *code_off; uint8_t *packed; const uint64_t *pk_off;
+} synth_args;
+
+static void synth_len_range(void *p, uint64_t lo, uint64_t hi)
+{
+	const synth_args *a = (const synth_args*)p; uint32_t cap = 2 * (a->read_len + a->len_jit) + 16; uint64_t i;
+	uint8_t *buf = (uint8_t*)malloc(cap);
+	for (i = lo; i < hi; ++i) a->len_out[i] = synth_one(a->g, a->G, a->rid0 + i, a->read_len, a->len_jit, a->err_ppm, a->n_ppm, a->seed, buf, cap);
+	free(buf);
+}
+
 void hao_synth_read_lengths(const uint8_t *g, uint64_t G, uint64_t rid0, uint64_t n, uint32_t read_len, uint32_t len_jit, uint32_t err_ppm, uint32_t n_ppm, uint64_t seed, uint32_t *len_out)
 {
-	uint32_t cap = 2 * (read_len + len_jit) + 16; uint64_t i;
-	uint8_t *buf = (uint8_t*)malloc(cap);
-	for (i = 0; i < n; ++i) len_out[i] = synth_one(g, G, rid0 + i, read_len, len_jit, err_ppm, n_ppm, seed, buf, cap);
-	free(buf);
+	synth_args a; memset(&a, 0, sizeof(a));
+	a.g = g; a.G = G; a.rid0 = rid0; a.read_len = read_len; a.len_jit = len_jit; a.err_ppm = err_ppm; a.n_ppm = n_ppm; a.seed = seed; a.len_out = len_out;
+	synth_parallel(n, synth_len_range, &a);
 }
 
 /* pass 2: fill. Any of the outputs may be NULL.
  *   codes   : concatenated codes (0..4), offsets code_off[i] (n+1 entries, caller computed from lengths)
  *   packed  : reference read-store layout, len/4+1 bytes per read, 4 bases/byte MSB first, N -> A
  *             (ha_compress_base, Process_Read.cpp:792-850); byte offsets pk_off[i] */
-void hao_synth_reads(const uint8_t *g, uint64_t G, uint64_t rid0, uint64_t n, uint32_t read_len, uint32_t len_jit, uint32_t err_ppm, uint32_t n_ppm, uint64_t seed,
-					 uint8_t *codes, const uint64_t *code_off, uint8_t *packed, const uint64_t *pk_off)
+static void synth_fill_range(void *p, uint64_t lo, uint64_t hi)
 {
-	uint32_t cap = 2 * (read_len + len_jit) + 16; uint64_t i;
+	const synth_args *a = (const synth_args*)p; uint32_t cap = 2 * (a->read_len + a->len_jit) + 16; uint64_t i;
 	uint8_t *buf = (uint8_t*)malloc(cap);
-	for (i = 0; i < n; ++i) {
-		uint32_t L = synth_one(g, G, rid0 + i, read_len, len_jit, err_ppm, n_ppm, seed, buf, cap), j;
-		if (codes) memcpy(codes + code_off[i], buf, L);
-		if (packed) {
-			uint8_t *d = packed + pk_off[i];
+	for (i = lo; i < hi; ++i) {
+		uint32_t L = synth_one(a->g, a->G, a->rid0 + i, a->read_len, a->len_jit, a->err_ppm, a->n_ppm, a->seed, buf, cap), j;
+		if (a->codes) memcpy(a->codes + a->code_off[i], buf, L);
+		if (a->packed) {
+			uint8_t *d = a->packed + a->pk_off[i];
 			memset(d, 0, L / 4 + 1);
 			for (j = 0; j < L; ++j) d[j >> 2] |= (uint8_t)((buf[j] & 3 & -(buf[j] < 4)) << (6 - 2 * (j & 3)));
 		}
 	}
 	free(buf);
+}
+
+void hao_synth_reads(const uint8_t *g, uint64_t G, uint64_t rid0, uint64_t n, uint32_t read_len, uint32_t len_jit, uint32_t err_ppm, uint32_t n_ppm, uint64_t seed,
+					 uint8_t *codes, const uint64_t *code_off, uint8_t *packed, const uint64_t *pk_off)
+{
+	synth_args a; memset(&a, 0, sizeof(a));
+	a.g = g; a.G = G; a.rid0 = rid0; a.read_len = read_len; a.len_jit = len_jit; a.err_ppm = err_ppm; a.n_ppm = n_ppm; a.seed = seed;
+	a.codes = codes; a.code_off = code_off; a.packed = packed; a.pk_off = pk_off;
+	synth_parallel(n, synth_fill_range, &a);
+}
+
+/* FASTA / FASTQ text of reads [rid0, rid0+n) straight to a file (no codes array: a 7.5 Gbase set does not have to sit in memory twice).
+ * Returns the number of bytes written, 0 on an I/O error. */
+#include <stdio.h>
+uint64_t hao_synth_fasta_file(const uint8_t *g, uint64_t G, uint64_t rid0, uint64_t n, uint32_t read_len, uint32_t len_jit, uint32_t err_ppm, uint32_t n_ppm, uint64_t seed,
+							  const char *path, int fastq, int qual)
+{
+	static const char tab[] = "ACGTN";
+	uint32_t cap = 2 * (read_len + len_jit) + 16; uint64_t i, tot = 0; uint32_t j;
+	uint8_t *buf = (uint8_t*)malloc(cap); char *line = (char*)malloc((size_t)cap * 2 + 64);
+	FILE *fp = fopen(path, "wb");
+	if (!fp) { free(buf); free(line); return 0; }
+	setvbuf(fp, 0, _IOFBF, 1 << 22);
+	for (i = 0; i < n; ++i) {
+		uint32_t L = synth_one(g, G, rid0 + i, read_len, len_jit, err_ppm, n_ppm, seed, buf, cap); size_t o;
+		o = (size_t)sprintf(line, "%cr%llu\n", fastq ? '@' : '>', (unsigned long long)(rid0 + i));
+		for (j = 0; j < L; ++j) line[o + j] = tab[buf[j]];
+		o += L; line[o++] = '\n';
+		if (fastq) { line[o++] = '+'; line[o++] = '\n'; memset(line + o, 33 + qual, L); o += L; line[o++] = '\n'; }
+		if (fwrite(line, 1, o, fp) != o) { tot = 0; break; }
+		tot += o;
+	}
+	fclose(fp); free(buf); free(line);
+	return tot;
 }
 
 /* codes -> FASTA text (ACGTN). returns bytes written. out must hold sum(len)+n*(name+3). */

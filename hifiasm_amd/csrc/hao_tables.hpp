@@ -75,6 +75,30 @@ static int hao_prepare_runs(hao_ctx *c, uint64_t lo, uint64_t hi, bool force_sca
 	return HAO_OK;
 }
 
+// prior homozygous coverage of the peak finder: total bases of ALL reads / --hg-size (htab.cpp:1156,1254: ct->bs / hg_size), -1 without one
+static int hao_prior_hom(const hao_ctx *c)
+{
+	if (c->opt.hg_size <= 0) return -1;
+	uint64_t bs = 0; for (uint32_t l : c->h_len_all) bs += l;
+	return (int)(bs / (uint64_t)c->opt.hg_size);
+}
+
+// Sharded mode: the shards must be contiguous read ranges in rank order (the index build relies on "source-rank order = global read order",
+// the Bloom replay on "rank order = insertion order").  One tiny all-gather at the start of EVERY sharded ha_ft_gen / ha_pt_gen: each rank sees
+// every rank's (n_reads, rid_base, n_total) and evaluates the same predicate on the same data, so all ranks pass or fail together; the collective
+// also carries local_rc, the status of whatever local work preceded it.
+static int hao_shard_layout_check(hao_ctx *c, hao_comm &cm, int local_rc)
+{
+	const uint64_t mine[3] = { c->n_reads, c->rid_base, c->n_total }; std::vector<uint64_t> all;
+	if (int rc = hao_comm_allgather_u64n(c, cm, mine, 3, all, local_rc)) return rc;
+	uint64_t b = 0; bool ok = true;
+	for (int r = 0; r < cm.world; ++r) { ok = ok && all[3 * r + 1] == b && all[3 * r + 2] == all[2]; b += all[3 * r]; }
+	if (!ok || b != all[2]) { hao_set_err(c, "shards are not contiguous read ranges in rank order"); return HAO_EINVAL; }
+	return HAO_OK;
+}
+// status agreement without payload (before a bulk exchange whose buffers were just allocated)
+static int hao_comm_agree(hao_ctx *c, hao_comm &cm, int local_rc) { std::vector<uint64_t> t; return hao_comm_allgather_u64(c, cm, 0, t, local_rc); }
+
 struct NotSentinel { __host__ __device__ bool operator()(const uint64_t &h) const { return h != UINT64_MAX; } };
 struct RunHead { const uint64_t *k; __host__ __device__ uint64_t operator()(uint64_t i) const { return (i == 0 || k[i] != k[i - 1]) ? 1 : 0; } };
 
@@ -193,124 +217,143 @@ static int hao_ft_run(hao_ctx *c)
 {
 	const uint64_t n = c->n_reads; const int k = c->opt.k;
 	c->has_ft = false; c->h_ft_keys.clear(); c->h_ft_vals.clear();
-	if (n == 0) { hao_set_err(c, "no reads"); return HAO_EINVAL; }
-	if (c->n_bases >= (1ULL << 32) * 16) { hao_set_err(c, "read set too large for one device pass"); return HAO_EUNSUPP; }
 	std::vector<uint32_t> slist;
-	if (int rc = hao_prepare_runs(c, 0, n, false, slist)) return rc;
-	DevBuf<uint64_t> slots, chunks, kmer_off, kh_chunk_off;
-	HIP_TRY(slots.reserve(n + 2)); HIP_TRY(chunks.reserve(n + 2)); HIP_TRY(kmer_off.reserve(n + 2)); HIP_TRY(kh_chunk_off.reserve(n + 2));
-	hipLaunchKernelGGL(hao_kmer_slots_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, c->d_n_runs.p, c->d_scalar_flag.p, c->d_len.p, (uint64_t)0, n, k, slots.p, chunks.p);
-	HAO_CHECK_LAUNCH();
-	if (int rc = hao_excl_scan_u64(c, slots.p, kmer_off.p, n + 1)) return rc;
-	if (int rc = hao_excl_scan_u64(c, chunks.p, kh_chunk_off.p, n + 1)) return rc;
-	uint64_t n_slots = 0, n_chunks = 0;
-	HIP_TRY(hipMemcpyAsync(&n_slots, kmer_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipMemcpyAsync(&n_chunks, kh_chunk_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));
-	c->timer.mark("ft_index");
-	DevBuf<uint64_t> kh, kh2; HIP_TRY(kh.reserve(n_slots + 1)); HIP_TRY(kh2.reserve(n_slots + 1));
-	uint64_t n_real = n_slots;
-	if (!slist.empty()) {    // slots of N reads are upper bounds: sentinel-fill, count the real ones
-		HIP_TRY(hipMemsetAsync(kh.p, 0xff, n_slots * 8, c->stream));
-		HIP_TRY(c->d_cursor.reserve(2)); HIP_TRY(hipMemsetAsync(c->d_cursor.p, 0, 8, c->stream));
-		hipLaunchKernelGGL(kmer_hash_scalar_kernel, dim3((unsigned)((slist.size() + 63) / 64)), dim3(64), 0, c->stream, c->d_packed.p, c->d_pk_off.p, c->d_len.p,
-						   c->d_nsite_off.p, c->d_nsite.p, c->d_scalar_list.p, (uint32_t)slist.size(), kmer_off.p, (uint64_t)0, k, c->opt.hpc, kh.p, c->d_cursor.p);
-		HAO_CHECK_LAUNCH();
-		uint64_t scalar_real = 0, scalar_slots = 0;
-		HIP_TRY(hipMemcpyAsync(&scalar_real, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
-		HIP_TRY(hipStreamSynchronize(c->stream));
-		for (uint32_t r : slist) scalar_slots += c->h_len[r];
-		n_real = n_slots - scalar_slots + scalar_real;
-	}
-	if (n_chunks) {
-		hao_kh_args a;
-		a.packed = c->d_packed.p; a.pk_off = c->d_pk_off.p; a.len = c->d_len.p; a.tile_off = c->d_tile_off.p; a.tile_ord = c->d_tile_ord.p; a.n_runs = c->d_n_runs.p;
-		a.chunk_off = kh_chunk_off.p; a.scalar_flag = c->d_scalar_flag.p; a.kmer_off = kmer_off.p; a.rid_lo = 0; a.n_sel = n; a.k = k; a.hpc = c->opt.hpc; a.out = kh.p;
-		hipLaunchKernelGGL(kmer_hash_chunk_kernel, dim3((unsigned)n_chunks), dim3(256), hao_kh_smem_bytes(k), c->stream, a);
-		HAO_CHECK_LAUNCH();
-	}
-	c->timer.mark("ft_hash");
+	DevBuf<uint64_t> slots, chunks, kmer_off, kh_chunk_off, kh, kh2;
+	uint64_t n_slots = 0, n_chunks = 0, n_real = 0;
 	DevBuf<uint64_t> ukeys; DevBuf<uint32_t> ucnt; uint64_t n_unique = 0, *sorted = nullptr;
 	const bool sharded = c->comm && c->comm->active();
 	const bool bloom = c->opt.bf_shift >= 21;                  // ha_ct_init / yak_bf_init: a filter needs n_shift > pre and >= 2^9 bits per sub-table (htab.cpp:83,153), else exact counting
-	uint64_t n_cnt = n_slots; uint64_t *cnt_in = kh.p, *cnt_alt = kh2.p; uint32_t bias = 0;
-	if (bloom) {
-		const int xb = c->opt.bf_shift - 21;                   // log2 of the 512-bit blocks per sub-table
-		if (12 + xb > 31) { hao_set_err(c, "bf_shift > 40 is not supported"); return HAO_EUNSUPP; }
-		if (!sharded) { if (int rc = hao_bloom_filter(c, kh.p, kh2.p, n_slots, &cnt_in, &cnt_alt, &n_cnt)) return rc; }
-		bias = 1;                                                 // the entry is created with count 1, then incremented (htab.cpp:201-205)
-		c->timer.mark("ft_bloom");
-	}
+	uint64_t n_cnt = 0; uint64_t *cnt_in = nullptr, *cnt_alt = nullptr; uint32_t bias = 0;
+	// everything up to the first exchange is local: in sharded mode its status travels with the first collective (ranks fail together)
+	auto local_hashes = [&]() -> int {
+		if (n == 0) { hao_set_err(c, "no reads"); return HAO_EINVAL; }
+		if (c->n_bases >= (1ULL << 32) * 16) { hao_set_err(c, "read set too large for one device pass"); return HAO_EUNSUPP; }
+		if (int rc = hao_prepare_runs(c, 0, n, false, slist)) return rc;
+		HIP_TRY(slots.reserve(n + 2)); HIP_TRY(chunks.reserve(n + 2)); HIP_TRY(kmer_off.reserve(n + 2)); HIP_TRY(kh_chunk_off.reserve(n + 2));
+		hipLaunchKernelGGL(hao_kmer_slots_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, c->d_n_runs.p, c->d_scalar_flag.p, c->d_len.p, (uint64_t)0, n, k, slots.p, chunks.p);
+		HAO_CHECK_LAUNCH();
+		if (int rc = hao_excl_scan_u64(c, slots.p, kmer_off.p, n + 1)) return rc;
+		if (int rc = hao_excl_scan_u64(c, chunks.p, kh_chunk_off.p, n + 1)) return rc;
+		HIP_TRY(hipMemcpyAsync(&n_slots, kmer_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipMemcpyAsync(&n_chunks, kh_chunk_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		c->timer.mark("ft_index");
+		HIP_TRY(kh.reserve(n_slots + 1)); HIP_TRY(kh2.reserve(n_slots + 1));
+		n_real = n_slots;
+		if (!slist.empty()) {    // slots of N reads are upper bounds: sentinel-fill, count the real ones
+			HIP_TRY(hipMemsetAsync(kh.p, 0xff, n_slots * 8, c->stream));
+			HIP_TRY(c->d_cursor.reserve(2)); HIP_TRY(hipMemsetAsync(c->d_cursor.p, 0, 8, c->stream));
+			hipLaunchKernelGGL(kmer_hash_scalar_kernel, dim3((unsigned)((slist.size() + 63) / 64)), dim3(64), 0, c->stream, c->d_packed.p, c->d_pk_off.p, c->d_len.p,
+							   c->d_nsite_off.p, c->d_nsite.p, c->d_scalar_list.p, (uint32_t)slist.size(), kmer_off.p, (uint64_t)0, k, c->opt.hpc, kh.p, c->d_cursor.p);
+			HAO_CHECK_LAUNCH();
+			uint64_t scalar_real = 0, scalar_slots = 0;
+			HIP_TRY(hipMemcpyAsync(&scalar_real, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			for (uint32_t r : slist) scalar_slots += c->h_len[r];
+			n_real = n_slots - scalar_slots + scalar_real;
+		}
+		if (n_chunks) {
+			hao_kh_args a;
+			a.packed = c->d_packed.p; a.pk_off = c->d_pk_off.p; a.len = c->d_len.p; a.tile_off = c->d_tile_off.p; a.tile_ord = c->d_tile_ord.p; a.n_runs = c->d_n_runs.p;
+			a.chunk_off = kh_chunk_off.p; a.scalar_flag = c->d_scalar_flag.p; a.kmer_off = kmer_off.p; a.rid_lo = 0; a.n_sel = n; a.k = k; a.hpc = c->opt.hpc; a.out = kh.p;
+			hipLaunchKernelGGL(kmer_hash_chunk_kernel, dim3((unsigned)n_chunks), dim3(256), hao_kh_smem_bytes(k), c->stream, a);
+			HAO_CHECK_LAUNCH();
+		}
+		c->timer.mark("ft_hash");
+		n_cnt = n_slots; cnt_in = kh.p; cnt_alt = kh2.p;
+		if (bloom) {
+			const int xb = c->opt.bf_shift - 21;                   // log2 of the 512-bit blocks per sub-table
+			if (12 + xb > 31) { hao_set_err(c, "bf_shift > 40 is not supported"); return HAO_EUNSUPP; }
+			if (!sharded) { if (int rc = hao_bloom_filter(c, kh.p, kh2.p, n_slots, &cnt_in, &cnt_alt, &n_cnt)) return rc; }
+			bias = 1;                                                 // the entry is created with count 1, then incremented (htab.cpp:201-205)
+			c->timer.mark("ft_bloom");
+		}
+		return HAO_OK;
+	};
+	const int hash_rc = local_hashes();
+	if (hash_rc && !sharded) return hash_rc;
 	if (!sharded) {
 		// sentinels (0xff..ff) sort to the end: only the first n_real entries are real k-mers
 		if (int rc = hao_sort_rle_hist(c, cnt_in, cnt_alt, n_cnt, ukeys, ucnt, &n_unique, c->ft_hist, &sorted, bias)) return rc;
 		if (!bloom && n_real < n_slots && n_unique) { --n_unique; c->ft_hist[std::min<uint64_t>(n_slots - n_real, HAO_MAX_COUNT)] -= 1; }   // drop the sentinel run (the Bloom replay already dropped it)
 	} else {
-		// hash-range partition: sort local hashes, cut at i * 2^64 / world, all-to-all-v, count the owned range
+		// hash-range partition: sort local hashes, cut at i * 2^64 / world, all-to-all-v, count the owned range.
+		// Local phases are lambdas whose status travels with the next collective (hao_comm.hpp): ranks fail together, nobody hangs.
 		hao_comm &cm = *c->comm; const int W = cm.world;
+		if (int rc = hao_shard_layout_check(c, cm, hash_rc)) return rc;
 		uint64_t *loc = kh.p; uint64_t n_loc = n_real;
-		std::vector<uint64_t> tg(W), cut(W + 1, 0), scnt(W), sdisp(W), rcnt;
-		DevBuf<uint64_t> dt, dc; HIP_TRY(dt.reserve(W + 1)); HIP_TRY(dc.reserve(W + 1));
-		if (!bloom) {
-			if (n_slots) {
-				size_t tb = 0; rocprim::double_buffer<uint64_t> db(kh.p, kh2.p);
-				HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, db, n_slots, 0, 64, c->stream)); HIP_TRY(hao_tmp(c, tb));
-				HIP_TRY(rocprim::radix_sort_keys(c->d_tmp.p, tb, db, n_slots, 0, 64, c->stream));
-				loc = db.current();
+		std::vector<uint64_t> tg(W), cut(W + 1, 0), scnt(W, 0), sdisp(W, 0), rcnt;
+		DevBuf<uint64_t> dt, dc, rv, rv2;
+		auto local_partition = [&]() -> int {
+			HIP_TRY(dt.reserve(W + 1)); HIP_TRY(dc.reserve(W + 1));
+			if (!bloom) {
+				if (n_slots) {
+					size_t tb = 0; rocprim::double_buffer<uint64_t> db(kh.p, kh2.p);
+					HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, db, n_slots, 0, 64, c->stream)); HIP_TRY(hao_tmp(c, tb));
+					HIP_TRY(rocprim::radix_sort_keys(c->d_tmp.p, tb, db, n_slots, 0, 64, c->stream));
+					loc = db.current();
+				}
+				for (int d = 0; d < W; ++d) tg[d] = d == 0 ? 0 : (uint64_t)(((unsigned __int128)d << 64) / (unsigned)W);
+				HIP_TRY(hipMemcpyAsync(dt.p, tg.data(), 8 * W, hipMemcpyHostToDevice, c->stream));
+				hipLaunchKernelGGL(hao_lower_bound_kernel, dim3((W + 63) / 64), dim3(64), 0, c->stream, loc, n_real, dt.p, W, dc.p);
+				HAO_CHECK_LAUNCH();
+			} else {
+				// the filter's blocks (and every copy of a k-mer) are determined by the LOW hash bits: partition by sub-table (low 12 bits), with a
+				// STABLE sort on those bits only, so that each piece stays in (read, position) order; pieces arrive in rank order = global read order
+				if (n_slots) {
+					HIP_TRY(c->d_cursor.reserve(2)); size_t tb = 0;
+					HIP_TRY(rocprim::select(nullptr, tb, kh.p, kh2.p, (uint64_t*)c->d_cursor.p, n_slots, NotSentinel(), c->stream)); HIP_TRY(hao_tmp(c, tb));
+					HIP_TRY(rocprim::select(c->d_tmp.p, tb, kh.p, kh2.p, (uint64_t*)c->d_cursor.p, n_slots, NotSentinel(), c->stream));
+					HIP_TRY(hipMemcpyAsync(&n_loc, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+					HIP_TRY(hipStreamSynchronize(c->stream));
+					tb = 0; rocprim::double_buffer<uint64_t> db(kh2.p, kh.p);
+					HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, db, n_loc, 0, 12, c->stream)); HIP_TRY(hao_tmp(c, tb));
+					HIP_TRY(rocprim::radix_sort_keys(c->d_tmp.p, tb, db, n_loc, 0, 12, c->stream));
+					loc = db.current();
+				}
+				for (int d = 0; d < W; ++d) tg[d] = ((uint64_t)d * 4096 + W - 1) / W;      // first sub-table of rank d
+				HIP_TRY(hipMemcpyAsync(dt.p, tg.data(), 8 * W, hipMemcpyHostToDevice, c->stream));
+				hipLaunchKernelGGL(hao_lower_bound_low12_kernel, dim3((W + 63) / 64), dim3(64), 0, c->stream, loc, n_loc, dt.p, W, dc.p);
+				HAO_CHECK_LAUNCH();
 			}
-			for (int d = 0; d < W; ++d) tg[d] = d == 0 ? 0 : (uint64_t)(((unsigned __int128)d << 64) / (unsigned)W);
-			HIP_TRY(hipMemcpyAsync(dt.p, tg.data(), 8 * W, hipMemcpyHostToDevice, c->stream));
-			hipLaunchKernelGGL(hao_lower_bound_kernel, dim3((W + 63) / 64), dim3(64), 0, c->stream, loc, n_real, dt.p, W, dc.p);
-			HAO_CHECK_LAUNCH();
-		} else {
-			// the filter's blocks (and every copy of a k-mer) are determined by the LOW hash bits: partition by sub-table (low 12 bits), with a
-			// STABLE sort on those bits only, so that each piece stays in (read, position) order; pieces arrive in rank order = global read order
-			if (n_slots) {
-				HIP_TRY(c->d_cursor.reserve(2)); size_t tb = 0;
-				HIP_TRY(rocprim::select(nullptr, tb, kh.p, kh2.p, (uint64_t*)c->d_cursor.p, n_slots, NotSentinel(), c->stream)); HIP_TRY(hao_tmp(c, tb));
-				HIP_TRY(rocprim::select(c->d_tmp.p, tb, kh.p, kh2.p, (uint64_t*)c->d_cursor.p, n_slots, NotSentinel(), c->stream));
-				HIP_TRY(hipMemcpyAsync(&n_loc, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
-				HIP_TRY(hipStreamSynchronize(c->stream));
-				tb = 0; rocprim::double_buffer<uint64_t> db(kh2.p, kh.p);
-				HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, db, n_loc, 0, 12, c->stream)); HIP_TRY(hao_tmp(c, tb));
-				HIP_TRY(rocprim::radix_sort_keys(c->d_tmp.p, tb, db, n_loc, 0, 12, c->stream));
-				loc = db.current();
-			}
-			for (int d = 0; d < W; ++d) tg[d] = ((uint64_t)d * 4096 + W - 1) / W;      // first sub-table of rank d
-			HIP_TRY(hipMemcpyAsync(dt.p, tg.data(), 8 * W, hipMemcpyHostToDevice, c->stream));
-			hipLaunchKernelGGL(hao_lower_bound_low12_kernel, dim3((W + 63) / 64), dim3(64), 0, c->stream, loc, n_loc, dt.p, W, dc.p);
-			HAO_CHECK_LAUNCH();
-		}
-		HIP_TRY(hipMemcpyAsync(cut.data(), dc.p, 8 * W, hipMemcpyDeviceToHost, c->stream));
-		HIP_TRY(hipStreamSynchronize(c->stream));
-		cut[W] = n_loc;
-		for (int d = 0; d < W; ++d) { sdisp[d] = cut[d]; scnt[d] = cut[d + 1] - cut[d]; }
-		if (int rc = hao_comm_exchange_counts(c, cm, scnt, rcnt)) return rc;
+			HIP_TRY(hipMemcpyAsync(cut.data(), dc.p, 8 * W, hipMemcpyDeviceToHost, c->stream));
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			cut[W] = n_loc;
+			for (int d = 0; d < W; ++d) { sdisp[d] = cut[d]; scnt[d] = cut[d + 1] - cut[d]; }
+			return HAO_OK;
+		};
+		if (int rc = hao_comm_exchange_counts(c, cm, scnt, rcnt, local_partition())) return rc;
 		uint64_t n_recv = 0; for (int d = 0; d < W; ++d) n_recv += rcnt[d];
-		DevBuf<uint64_t> rv, rv2; HIP_TRY(rv.reserve(n_recv + 1)); HIP_TRY(rv2.reserve(n_recv + 1));
+		auto local_recv_bufs = [&]() -> int { HIP_TRY(rv.reserve(n_recv + 1)); HIP_TRY(rv2.reserve(n_recv + 1)); return HAO_OK; };
+		if (int rc = hao_comm_agree(c, cm, local_recv_bufs())) return rc;
 		if (int rc = hao_comm_alltoallv_u64(c, cm, loc, scnt, sdisp, rv.p, rcnt)) return rc;
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		c->timer.mark("ft_exchange");
-		uint64_t *ci = rv.p, *ca = rv2.p, n_ci = n_recv;
-		if (bloom) { if (int rc = hao_bloom_filter(c, rv.p, rv2.p, n_recv, &ci, &ca, &n_ci)) return rc; }
-		if (int rc = hao_sort_rle_hist(c, ci, ca, n_ci, ukeys, ucnt, &n_unique, c->ft_hist, &sorted, bias)) return rc;
-		if (int rc = hao_comm_allreduce_i64(c, cm, c->ft_hist, HAO_N_COUNTS)) return rc;
+		auto local_count = [&]() -> int {
+			uint64_t *ci = rv.p, *ca = rv2.p, n_ci = n_recv;
+			if (bloom) { if (int rc = hao_bloom_filter(c, rv.p, rv2.p, n_recv, &ci, &ca, &n_ci)) return rc; }
+			return hao_sort_rle_hist(c, ci, ca, n_ci, ukeys, ucnt, &n_unique, c->ft_hist, &sorted, bias);
+		};
+		if (int rc = hao_comm_allreduce_i64(c, cm, c->ft_hist, HAO_N_COUNTS, local_count())) return rc;
 		rv.release(); rv2.release(); dt.release(); dc.release();
 	}
 	c->timer.mark("ft_count");
 	kh.release(); kh2.release();
-	c->ft_peak_hom = hao_find_peaks(c->ft_hist, HAO_N_COUNTS, c->opt.min_hist_cnt, &c->ft_peak_het);
+	c->ft_peak_hom = hao_find_peaks(c->ft_hist, HAO_N_COUNTS, c->opt.min_hist_cnt, &c->ft_peak_het, hao_prior_hom(c));
 	int cutoff = (int)(c->ft_peak_hom * c->opt.high_factor);                 // htab.cpp:1160
 	if (cutoff > HAO_MAX_COUNT - 1) cutoff = HAO_MAX_COUNT - 1;
 	c->ft_cutoff = cutoff;
 	DevBuf<uint32_t> kcnt; uint64_t n_kept = 0;
-	if (int rc = hao_keep_runs(c, ukeys.p, ucnt.p, n_unique, cutoff, HAO_MAX_COUNT, c->d_ft_keys, nullptr, kcnt, &n_kept, nullptr)) return rc;
+	const int keep_rc = hao_keep_runs(c, ukeys.p, ucnt.p, n_unique, cutoff, HAO_MAX_COUNT, c->d_ft_keys, nullptr, kcnt, &n_kept, nullptr);
+	if (keep_rc && !sharded) return keep_rc;
 	ukeys.release(); ucnt.release(); c->w_flag.release(); c->w_kpos.release(); c->w_ustart.release();      // k-mer sized scratch: do not keep it
 	if (sharded) {   // every rank kept its hash range: concatenation in rank order is the globally sorted table
 		hao_comm &cm = *c->comm; std::vector<uint64_t> cnts;
-		if (int rc = hao_comm_allgather_u64(c, cm, n_kept, cnts)) return rc;
+		if (int rc = hao_comm_allgather_u64(c, cm, n_kept, cnts, keep_rc)) return rc;
 		uint64_t tot = 0; for (uint64_t v : cnts) tot += v;
-		DevBuf<uint64_t> gk; DevBuf<uint32_t> gc; HIP_TRY(gk.reserve(tot + 1)); HIP_TRY(gc.reserve(tot + 1));
+		DevBuf<uint64_t> gk; DevBuf<uint32_t> gc;
+		auto local_bufs = [&]() -> int { HIP_TRY(gk.reserve(tot + 1)); HIP_TRY(gc.reserve(tot + 1)); return HAO_OK; };
+		if (int rc = hao_comm_agree(c, cm, local_bufs())) return rc;
 		if (int rc = hao_comm_allgatherv(c, cm, c->d_ft_keys.p, n_kept, 8, gk.p, cnts)) return rc;
 		if (int rc = hao_comm_allgatherv(c, cm, kcnt.p, n_kept, 4, gc.p, cnts)) return rc;
 		HIP_TRY(hipStreamSynchronize(c->stream));
@@ -362,14 +405,20 @@ static int hao_pt_run(hao_ctx *c)
 {
 	const uint64_t n = c->n_reads;
 	c->has_pt = false; c->h_ix_valid = false; c->h_ix_mz_off.clear();
-	if (n == 0) { hao_set_err(c, "no reads"); return HAO_EINVAL; }
-	if (int rc = hao_sketch_run(c, 0, n, c->has_ft, c->opt.sample_dist, 1)) return rc;
-	// the read-ordered minimizers of the LOCAL reads stay for the query side (the reference re-sketches every query read; same result)
-	std::swap(c->d_ix_mz_x, c->d_mz_x); std::swap(c->d_ix_mz_info, c->d_mz_info); std::swap(c->d_ix_mz_off, c->d_mz_off);
-	// the two buffer sets alternate between "index" and "next sketch": give the idle twin its size now, not in the middle of the next pass
-	HIP_TRY(c->d_mz_x.reserve_exact(c->d_ix_mz_x.cap)); HIP_TRY(c->d_mz_info.reserve_exact(c->d_ix_mz_info.cap)); HIP_TRY(c->d_mz_off.reserve_exact(c->d_ix_mz_off.cap));
-	c->ix_n_mz = c->sk_total; c->sk_n = 0;
 	const bool sharded = c->comm && c->comm->active();
+	// local: sketch every read; in sharded mode the status travels with the first collective (ranks fail together, hao_comm.hpp)
+	auto local_sketch = [&]() -> int {
+		if (n == 0) { hao_set_err(c, "no reads"); return HAO_EINVAL; }
+		if (int rc = hao_sketch_run(c, 0, n, c->has_ft, c->opt.sample_dist, 1)) return rc;
+		// the read-ordered minimizers of the LOCAL reads stay for the query side (the reference re-sketches every query read; same result)
+		std::swap(c->d_ix_mz_x, c->d_mz_x); std::swap(c->d_ix_mz_info, c->d_mz_info); std::swap(c->d_ix_mz_off, c->d_mz_off);
+		// the two buffer sets alternate between "index" and "next sketch": give the idle twin its size now, not in the middle of the next pass
+		HIP_TRY(c->d_mz_x.reserve_exact(c->d_ix_mz_x.cap)); HIP_TRY(c->d_mz_info.reserve_exact(c->d_ix_mz_info.cap)); HIP_TRY(c->d_mz_off.reserve_exact(c->d_ix_mz_off.cap));
+		c->ix_n_mz = c->sk_total; c->sk_n = 0;
+		return HAO_OK;
+	};
+	const int sk_rc = local_sketch();
+	if (sk_rc && !sharded) return sk_rc;
 	DevBuf<uint64_t> &ukeys = c->w_ukeys; DevBuf<uint32_t> &ucnt = c->w_ucnt; uint64_t n_unique = 0;
 	memset(c->pt_hist, 0, sizeof(c->pt_hist));
 	auto sort_pairs = [&](uint64_t *kin, uint64_t *kout, uint64_t *vin, uint64_t *vout, uint64_t cnt) -> int {
@@ -400,7 +449,7 @@ static int hao_pt_run(hao_ctx *c)
 	};
 	auto peaks_and_range = [&](int *hi_out) {
 		int het = -1;
-		c->hom_cov = hao_find_peaks(c->pt_hist, HAO_N_COUNTS, c->opt.min_hist_cnt, &het); c->het_cov = het;
+		c->hom_cov = hao_find_peaks(c->pt_hist, HAO_N_COUNTS, c->opt.min_hist_cnt, &het, hao_prior_hom(c)); c->het_cov = het;
 		int hi;
 		if (c->has_ft) hi = HAO_MAX_COUNT - 1;                                   // htab.cpp:1266-1269
 		else { hi = (int)(c->hom_cov * c->opt.high_factor); if (hi > HAO_MAX_COUNT - 1) hi = HAO_MAX_COUNT - 1; }   // :1258-1262
@@ -419,69 +468,74 @@ static int hao_pt_run(hao_ctx *c)
 		if (int rc = hao_keep_runs(c, ukeys.p, ucnt.p, n_unique, 2, hi, c->d_ix_keys, &c->d_ix_start, c->d_ix_cnt, &c->ix_n_keys, &c->ix_n_pos)) return rc;
 	} else {
 		// Sharded build (SURVEY 2 C1 + 8e layout i): every rank owns the hash range [r, r+1) * 2^64 / world.
-		//   local stable sort by hash -> all-to-all-v of (x, info) by range -> stable sort of the received pieces (source-rank order =
+		//   local stable grouping by owner -> all-to-all-v of (x, info) by range -> stable sort of the received pieces (source-rank order =
 		//   global read order, so per-key lists come out in (rid,pos) order) -> count / histogram (all-reduced) / peaks / keep ->
-		//   all-gather-v of the sorted position records (8 B each) and of the key tables: concatenation in rank order is the global index.
-		hao_comm &cm = *c->comm; const int W = cm.world; const uint64_t ml = c->ix_n_mz;
-		if (cm.shard_sizes_for != n || (int)cm.shard_sizes.size() != W) {      // once per read set: the shards must be contiguous read ranges in rank order
-			if (int rc = hao_comm_allgather_u64(c, cm, n, cm.shard_sizes)) return rc;
-			cm.shard_sizes_for = n;
-			uint64_t nt = 0, b = 0; for (int r = 0; r < W; ++r) { if (r < cm.rank) b += cm.shard_sizes[r]; nt += cm.shard_sizes[r]; }
-			if (nt != c->n_total || b != c->rid_base) { cm.shard_sizes_for = ~0ULL; hao_set_err(c, "shards are not contiguous read ranges in rank order"); return HAO_EINVAL; }
-		}
-		DevBuf<uint64_t> lsx, lsi; HIP_TRY(lsx.reserve(ml + 1)); HIP_TRY(lsi.reserve(ml + 1));
+		//   all-gather of the sorted position records (8 B each) and of the key tables: concatenation in rank order is the global index.
+		// Local phases are lambdas whose status travels with the next collective: ranks fail together.
+		hao_comm &cm = *c->comm; const int W = cm.world;
+		if (int rc = hao_shard_layout_check(c, cm, sk_rc)) return rc;
+		const uint64_t ml = c->ix_n_mz;
+		DevBuf<uint64_t> lsx, lsi, dt, dc, rx, ri, px, pi;
+		std::vector<uint64_t> tg(W), cut(W + 1, 0), scnt(W, 0), sdisp(W, 0), rcnt;
 		// owner of a hash = ((x >> 48) * W) >> 16: ranges of the top 16 bits, so the local pass only groups by those bits - a stable 2-pass radix sort of
 		// (owner bits, index) and one gather instead of 8 passes over the 16-byte records; pieces stay in read order, the owner sorts what it receives.
-		// (begin_bit = 0 on a separate 16-bit key: rocprim 4.2's radix sort mis-sorts small inputs when begin_bit > 0.)
-		if (ml) {
-			DevBuf<uint32_t> &ok = c->w_ok, &ok2 = c->w_ok2, &oi = c->w_oi, &oi2 = c->w_oi2;      // persistent scratch: no allocation inside the pass
-			HIP_TRY(ok.reserve(ml + 1)); HIP_TRY(ok2.reserve(ml + 1)); HIP_TRY(oi.reserve(ml + 1)); HIP_TRY(oi2.reserve(ml + 1));
-			hipLaunchKernelGGL(hao_owner_key_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_x.p, ml, ok.p, oi.p);
+		// (begin_bit = 0 on a separate 16-bit key: rocprim 4.2's radix sort mis-sorts small inputs when begin_bit > 0; tests/test_gpu_rocprim.py pins that.)
+		auto local_group = [&]() -> int {
+			HIP_TRY(lsx.reserve(ml + 1)); HIP_TRY(lsi.reserve(ml + 1));
+			if (ml) {
+				DevBuf<uint32_t> &ok = c->w_ok, &ok2 = c->w_ok2, &oi = c->w_oi, &oi2 = c->w_oi2;      // persistent scratch: no allocation inside the pass
+				HIP_TRY(ok.reserve(ml + 1)); HIP_TRY(ok2.reserve(ml + 1)); HIP_TRY(oi.reserve(ml + 1)); HIP_TRY(oi2.reserve(ml + 1));
+				hipLaunchKernelGGL(hao_owner_key_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_x.p, ml, ok.p, oi.p);
+				HAO_CHECK_LAUNCH();
+				size_t tb = 0; rocprim::double_buffer<uint32_t> dk(ok.p, ok2.p), dv(oi.p, oi2.p);
+				HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, dk, dv, ml, 0, 16, c->stream)); HIP_TRY(hao_tmp(c, tb));
+				HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, dk, dv, ml, 0, 16, c->stream));
+				hipLaunchKernelGGL(hao_gather2_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, c->stream, dv.current(), c->d_ix_mz_x.p, c->d_ix_mz_info.p, ml, lsx.p, lsi.p);
+				HAO_CHECK_LAUNCH();
+			}
+			for (int d = 0; d < W; ++d) tg[d] = (((uint64_t)d * 65536 + W - 1) / W) << 48;      // first hash owned by rank d (low 48 bits zero: comparing whole keys orders by the top 16 bits)
+			HIP_TRY(dt.reserve(W + 1)); HIP_TRY(dc.reserve(W + 1));
+			HIP_TRY(hipMemcpyAsync(dt.p, tg.data(), 8 * W, hipMemcpyHostToDevice, c->stream));
+			hipLaunchKernelGGL(hao_lower_bound_kernel, dim3((W + 63) / 64), dim3(64), 0, c->stream, lsx.p, ml, dt.p, W, dc.p);
 			HAO_CHECK_LAUNCH();
-			size_t tb = 0; rocprim::double_buffer<uint32_t> dk(ok.p, ok2.p), dv(oi.p, oi2.p);
-			HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, dk, dv, ml, 0, 16, c->stream)); HIP_TRY(hao_tmp(c, tb));
-			HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, dk, dv, ml, 0, 16, c->stream));
-			hipLaunchKernelGGL(hao_gather2_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, c->stream, dv.current(), c->d_ix_mz_x.p, c->d_ix_mz_info.p, ml, lsx.p, lsi.p);
-			HAO_CHECK_LAUNCH();
-		}
-		std::vector<uint64_t> tg(W), cut(W + 1, 0), scnt(W), sdisp(W), rcnt;
-		for (int d = 0; d < W; ++d) tg[d] = (((uint64_t)d * 65536 + W - 1) / W) << 48;      // first hash owned by rank d (low 48 bits zero: comparing whole keys orders by the top 16 bits)
-		DevBuf<uint64_t> dt, dc; HIP_TRY(dt.reserve(W + 1)); HIP_TRY(dc.reserve(W + 1));
-		HIP_TRY(hipMemcpyAsync(dt.p, tg.data(), 8 * W, hipMemcpyHostToDevice, c->stream));
-		hipLaunchKernelGGL(hao_lower_bound_kernel, dim3((W + 63) / 64), dim3(64), 0, c->stream, lsx.p, ml, dt.p, W, dc.p);
-		HAO_CHECK_LAUNCH();
-		HIP_TRY(hipMemcpyAsync(cut.data(), dc.p, 8 * W, hipMemcpyDeviceToHost, c->stream));
-		HIP_TRY(hipStreamSynchronize(c->stream));
-		cut[W] = ml;
-		for (int d = 0; d < W; ++d) { sdisp[d] = cut[d]; scnt[d] = cut[d + 1] - cut[d]; }
-		if (int rc = hao_comm_exchange_counts(c, cm, scnt, rcnt)) return rc;
+			HIP_TRY(hipMemcpyAsync(cut.data(), dc.p, 8 * W, hipMemcpyDeviceToHost, c->stream));
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			cut[W] = ml;
+			for (int d = 0; d < W; ++d) { sdisp[d] = cut[d]; scnt[d] = cut[d + 1] - cut[d]; }
+			return HAO_OK;
+		};
+		if (int rc = hao_comm_exchange_counts(c, cm, scnt, rcnt, local_group())) return rc;
 		uint64_t n_recv = 0; for (int d = 0; d < W; ++d) n_recv += rcnt[d];
-		DevBuf<uint64_t> rx, ri, px, pi; HIP_TRY(rx.reserve(n_recv + 1)); HIP_TRY(ri.reserve(n_recv + 1)); HIP_TRY(px.reserve(n_recv + 1)); HIP_TRY(pi.reserve(n_recv + 1));
+		auto local_recv_bufs = [&]() -> int { HIP_TRY(rx.reserve(n_recv + 1)); HIP_TRY(ri.reserve(n_recv + 1)); HIP_TRY(px.reserve(n_recv + 1)); HIP_TRY(pi.reserve(n_recv + 1)); return HAO_OK; };
+		if (int rc = hao_comm_agree(c, cm, local_recv_bufs())) return rc;
 		if (int rc = hao_comm_alltoallv2_u64(c, cm, lsx.p, lsi.p, scnt, sdisp, rx.p, ri.p, rcnt)) return rc;
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		c->timer.mark("pt_alltoall");
-		if (int rc = sort_pairs(rx.p, px.p, ri.p, pi.p, n_recv)) return rc;
-		c->timer.mark("pt_sort");
-		if (int rc = rle_hist(px.p, n_recv)) return rc;
-		if (int rc = hao_comm_allreduce_i64(c, cm, c->pt_hist, HAO_N_COUNTS)) return rc;
+		auto local_count = [&]() -> int {
+			if (int rc = sort_pairs(rx.p, px.p, ri.p, pi.p, n_recv)) return rc;
+			c->timer.mark("pt_sort");
+			return rle_hist(px.p, n_recv);
+		};
+		if (int rc = hao_comm_allreduce_i64(c, cm, c->pt_hist, HAO_N_COUNTS, local_count())) return rc;
 		c->timer.mark("pt_count");
 		int hi; peaks_and_range(&hi);
 		DevBuf<uint64_t> pk, pst; DevBuf<uint32_t> pc; uint64_t nk_p = 0, np_p = 0;
-		if (int rc = hao_keep_runs(c, ukeys.p, ucnt.p, n_unique, 2, hi, pk, &pst, pc, &nk_p, &np_p)) return rc;
+		const int keep_rc = hao_keep_runs(c, ukeys.p, ucnt.p, n_unique, 2, hi, pk, &pst, pc, &nk_p, &np_p);
 		// global layout
 		std::vector<uint64_t> part(W), nks(W), nps(W), trip;
 		{ const uint64_t mine[3] = { n_recv, nk_p, np_p };
-		  if (int rc = hao_comm_allgather_u64n(c, cm, mine, 3, trip)) return rc;
+		  if (int rc = hao_comm_allgather_u64n(c, cm, mine, 3, trip, keep_rc)) return rc;
 		  for (int r = 0; r < W; ++r) { part[r] = trip[3 * r]; nks[r] = trip[3 * r + 1]; nps[r] = trip[3 * r + 2]; } }
 		uint64_t m = 0, base = 0, nk = 0, np = 0;
 		for (int r = 0; r < W; ++r) { if (r < cm.rank) base += part[r]; m += part[r]; nk += nks[r]; np += nps[r]; }
-		if (m >= (1ULL << 32)) { hao_set_err(c, "more than 2^32 minimizers in the replicated index"); return HAO_EUNSUPP; }
-		if (nk_p) { hipLaunchKernelGGL(hao_add_const_kernel, dim3((unsigned)((nk_p + 255) / 256)), dim3(256), 0, c->stream, pst.p, nk_p, base); HAO_CHECK_LAUNCH(); }
-		HIP_TRY(c->d_ix_sinfo.reserve(m + 1));      // (the sorted hashes themselves are not needed once the key table exists: only the 8-byte position records travel)
-		HIP_TRY(c->d_ix_keys.reserve(nk + 1)); HIP_TRY(c->d_ix_start.reserve(nk + 1)); HIP_TRY(c->d_ix_cnt.reserve(nk + 1));
-		{	// ONE all-gather for the whole index: every rank's slot = [position records | keys | list starts | counts], padded to the largest partition
-			uint64_t maxm = 0, maxk = 0; for (int r = 0; r < W; ++r) { maxm = std::max(maxm, part[r]); maxk = std::max(maxk, nks[r]); }
-			const size_t o_key = (size_t)maxm * 8, o_st = o_key + (size_t)maxk * 8, o_cnt = o_st + (size_t)maxk * 8, slot = (o_cnt + (size_t)maxk * 4 + 15) & ~(size_t)15;
+		if (m >= (1ULL << 32)) { hao_set_err(c, "more than 2^32 minimizers in the replicated index"); return HAO_EUNSUPP; }      // same verdict on every rank
+		// ONE all-gather for the whole index: every rank's slot = [position records | keys | list starts | counts], padded to the largest partition
+		uint64_t maxm = 0, maxk = 0; for (int r = 0; r < W; ++r) { maxm = std::max(maxm, part[r]); maxk = std::max(maxk, nks[r]); }
+		const size_t o_key = (size_t)maxm * 8, o_st = o_key + (size_t)maxk * 8, o_cnt = o_st + (size_t)maxk * 8, slot = (o_cnt + (size_t)maxk * 4 + 15) & ~(size_t)15;
+		auto local_slot = [&]() -> int {
+			if (nk_p) { hipLaunchKernelGGL(hao_add_const_kernel, dim3((unsigned)((nk_p + 255) / 256)), dim3(256), 0, c->stream, pst.p, nk_p, base); HAO_CHECK_LAUNCH(); }
+			HIP_TRY(c->d_ix_sinfo.reserve(m + 1));      // (the sorted hashes themselves are not needed once the key table exists: only the 8-byte position records travel)
+			HIP_TRY(c->d_ix_keys.reserve(nk + 1)); HIP_TRY(c->d_ix_start.reserve(nk + 1)); HIP_TRY(c->d_ix_cnt.reserve(nk + 1));
 			HIP_TRY(cm.ag_tmp.reserve(slot * W + 16));
 			char *mine = cm.ag_tmp.p + slot * cm.rank;
 			if (n_recv) HIP_TRY(hipMemcpyAsync(mine, pi.p, n_recv * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -490,18 +544,20 @@ static int hao_pt_run(hao_ctx *c)
 				HIP_TRY(hipMemcpyAsync(mine + o_st, pst.p, nk_p * 8, hipMemcpyDeviceToDevice, c->stream));
 				HIP_TRY(hipMemcpyAsync(mine + o_cnt, pc.p, nk_p * 4, hipMemcpyDeviceToDevice, c->stream));
 			}
-			if (int rc = hao_comm_allgather_fixed(c, cm, cm.ag_tmp.p, slot)) return rc;
-			uint64_t dm = 0, dk = 0;
-			for (int r = 0; r < W; ++r) {
-				const char *sr = cm.ag_tmp.p + slot * r;
-				if (part[r]) HIP_TRY(hipMemcpyAsync(c->d_ix_sinfo.p + dm, sr, part[r] * 8, hipMemcpyDeviceToDevice, c->stream));
-				if (nks[r]) {
-					HIP_TRY(hipMemcpyAsync(c->d_ix_keys.p + dk, sr + o_key, nks[r] * 8, hipMemcpyDeviceToDevice, c->stream));
-					HIP_TRY(hipMemcpyAsync(c->d_ix_start.p + dk, sr + o_st, nks[r] * 8, hipMemcpyDeviceToDevice, c->stream));
-					HIP_TRY(hipMemcpyAsync(c->d_ix_cnt.p + dk, sr + o_cnt, nks[r] * 4, hipMemcpyDeviceToDevice, c->stream));
-				}
-				dm += part[r]; dk += nks[r];
+			return HAO_OK;
+		};
+		if (int rc = hao_comm_agree(c, cm, local_slot())) return rc;
+		if (int rc = hao_comm_allgather_fixed(c, cm, cm.ag_tmp.p, slot)) return rc;
+		uint64_t dm = 0, dk = 0;
+		for (int r = 0; r < W; ++r) {
+			const char *sr = cm.ag_tmp.p + slot * r;
+			if (part[r]) HIP_TRY(hipMemcpyAsync(c->d_ix_sinfo.p + dm, sr, part[r] * 8, hipMemcpyDeviceToDevice, c->stream));
+			if (nks[r]) {
+				HIP_TRY(hipMemcpyAsync(c->d_ix_keys.p + dk, sr + o_key, nks[r] * 8, hipMemcpyDeviceToDevice, c->stream));
+				HIP_TRY(hipMemcpyAsync(c->d_ix_start.p + dk, sr + o_st, nks[r] * 8, hipMemcpyDeviceToDevice, c->stream));
+				HIP_TRY(hipMemcpyAsync(c->d_ix_cnt.p + dk, sr + o_cnt, nks[r] * 4, hipMemcpyDeviceToDevice, c->stream));
 			}
+			dm += part[r]; dk += nks[r];
 		}
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		c->ix_n_sorted = m; c->ix_n_keys = nk; c->ix_n_pos = np;

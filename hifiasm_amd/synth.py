@@ -34,6 +34,9 @@ def _lib():
         L.hao_synth_reads.restype = None
         L.hao_synth_fasta.argtypes = [u8p, u64p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int, C.c_int]
         L.hao_synth_fasta.restype = C.c_uint64
+        L.hao_synth_fasta_file.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                           C.c_uint64, C.c_char_p, C.c_int, C.c_int]
+        L.hao_synth_fasta_file.restype = C.c_uint64
         _LIB = L
     return _LIB
 
@@ -129,3 +132,13 @@ def write_fasta(path: str, rs: ReadSet, fastq: bool = False, qual: int = 20) -> 
     w = _lib().hao_synth_fasta(_p(rs.codes, C.c_uint8), _p(rs.code_off, C.c_uint64), rs.rid0, n, buf, int(fastq), qual)
     with open(path, "wb") as fp:
         fp.write(buf.raw[:w])
+
+
+def write_fasta_stream(path: str, genome: np.ndarray, n_reads: int, read_len: int, err: float, seed: int = 7, rid0: int = 0,
+                       len_jit: int = 0, n_rate: float = 0.0, fastq: bool = False, qual: int = 20) -> int:
+    """FASTA/FASTQ of the reads make_reads() would return, written read by read (no codes array in memory)."""
+    w = _lib().hao_synth_fasta_file(_p(genome, C.c_uint8), genome.size, rid0, n_reads, read_len, len_jit, int(round(err * 1e6)),
+                                    int(round(n_rate * 1e6)), seed, path.encode(), int(fastq), qual)
+    if w == 0:
+        raise OSError(f"cannot write {path}")
+    return int(w)

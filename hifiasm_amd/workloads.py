@@ -1,0 +1,34 @@
+"""Named synthetic workloads (BASELINE.json configs 1-4) shared by bench.py and the full-size parity tests.
+
+Every read has its own counter-based RNG stream (csrc/hao_synth.c), so any rank can generate any contiguous shard of a
+workload's read set and the bytes are identical on every machine.
+"""
+from __future__ import annotations
+
+from . import synth
+
+WORKLOADS = {
+    # name: (genome_size, coverage, read_len, err, repeat_rich, is_ont)
+    "bacterial5M_hifi30x": (5_000_000, 30, 15000, 0.001, 0, 0),            # BASELINE.json configs[1]
+    "bacterial5M_hifi30x_repeat": (5_000_000, 30, 15000, 0.001, 1, 0),     # its repeat-rich variant
+    "chr2M_hifi30x": (2_000_000, 30, 15000, 0.001, 0, 0),                  # stand-in for configs[0] (chr11-2M.fa.gz is not in the image)
+    "chr1_250M_hifi30x": (250_000_000, 30, 15000, 0.001, 0, 0),            # configs[2]: the largest single-GPU configuration
+    "human3G_hifi40x": (3_000_000_000, 40, 15000, 0.001, 0, 0),            # configs[3]: 8 M reads of 15 kb, sharded over 8 GPUs
+    "ont5M_30x": (5_000_000, 30, 30000, 0.01, 0, 1),
+    "ont_human_30x": (3_000_000_000, 30, 30000, 0.01, 0, 1),               # configs[4]: 3 M reads of 30 kb, --ont
+}
+GENOME_SEED, READ_SEED = 11, 12
+
+
+def n_reads_of(name: str) -> int:
+    g, cov, L, _err, _rr, _ont = WORKLOADS[name]
+    return max(1, int(round(g * cov / L)))
+
+
+def workload_reads(name: str, lo: int = 0, hi: int | None = None, want_codes: bool = False, genome=None):
+    """reads [lo, hi) of the named workload's read set (default: all of it)"""
+    g, _cov, L, err, rr, _ont = WORKLOADS[name]
+    if genome is None:
+        genome = synth.make_genome(g, seed=GENOME_SEED, repeat_rich=rr)
+    hi = n_reads_of(name) if hi is None else hi
+    return synth.make_reads(genome, hi - lo, L, err, seed=READ_SEED, rid0=lo, want_codes=want_codes)

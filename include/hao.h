@@ -49,6 +49,8 @@ typedef struct {
 	int32_t is_ont;        /* --ont: bw_thres 0.05 instead of 0.02 (ecovlp.cpp:3274) */
 	int32_t bf_shift;      /* -f (CommandLines.cpp:269, reference default 37): log2 of the Bloom filter bits in front of the k-mer count table of
 	                        * ha_ft_gen (htab.cpp:99-116,140-160,196-206); 0 = exact counting. hao_opt_default sets 0; a shim passes asm_opt.bf_shift */
+	int64_t hg_size;       /* --hg-size (CommandLines.cpp:331,959; default -1): when > 0 the peak finder is given the prior
+	                        * homozygous coverage total_bases / hg_size (htab.cpp:1156,1254; adj_m_peak_hom, hist.cpp:46-72) */
 } hao_opt_t;
 
 /* ha_mz1_t (htab.h:13-18): info = rid:28 | pos:27 | rev:1 | span:8 (LSB first).
@@ -146,6 +148,21 @@ int hao_fetch_overlaps(hao_ctx *c, uint64_t rid, const hao_ovlp_t **ol, uint64_t
 /* totals of the last batch: out[0] = overlaps (sum ol->length), out[1] = chained hits, out[2] = seed hits,
  * out[3] = chain groups, out[4] = minimizers of the query reads */
 int hao_batch_totals(hao_ctx *c, uint64_t out[8]);
+
+/* Per-read digests of the last batch's results, computed on the device (one workgroup per read) and copied to out[n] / out_kh[n]
+ * (n = reads of the batch; out_kh may be NULL):
+ *   out[r]    = sum of term(1, i, w) over the 64-bit words of ol->list (6 per overlap_region: the 12 u32 fields of hao_ovlp_t)
+ *             + sum of term(2, i, w) over the read's fake cigars in ol order + sum of term(3, i, w) over cl->list (2 words per k_mer_hit)
+ *   out_kh[r] = sum of term(4, i, w) over the seed hits before chaining (hao_fetch_seed_hits)
+ *   term(s, i, w) = mix64(w + 0x9E3779B97F4A7C15 * (i + 1) + s * 0xD6E8FEB86659FD93)  mod 2^64,  mix64 = splitmix64's finaliser.
+ * An end-to-end integrity check for consumers on the far side of the PCIe boundary, and the way the full-size parity tests compare
+ * EVERY read of a 500 000-read pass with the reference (oracle/ref_harness.cpp --digest computes the same value from the reference's
+ * own overlap_region / Candidates_list after h_ec_lchain, anchor.cpp:2302). */
+int hao_batch_digest(hao_ctx *c, uint64_t *out, uint64_t *out_kh);
+
+/* Device self-test of the record grouping used by the sharded index build (pins a rocPRIM bit-range sort behaviour, see hao_capi_rest.hpp):
+ * out[0] = order violations of the begin_bit = 48 sort, out[1] = of the path the engine uses (must be 0). */
+int hao_selftest_rocprim(uint64_t n, uint64_t out[2]);
 
 /* per-stage device time of the last call in milliseconds (HIP events on the engine's stream);
  * names[i] points to static strings. Returns the number of stages. */

@@ -48,7 +48,7 @@ static void ensure_ctx(const hifiasm_opt_t *o)
 	p.k = o->k_mer_length; p.w = o->mz_win; p.hpc = !(o->flag & HA_F_NO_HPC); p.sample_dist = o->mz_sample_dist; p.rewin = o->mz_rewin;
 	p.min_hist_cnt = o->min_hist_kmer_cnt; p.max_kmer_cnt = o->max_kmer_cnt; p.max_n_chain = o->max_n_chain; p.high_factor = o->high_factor; p.is_ont = o->is_ont;
 	p.bf_shift = o->bf_shift;         // the device path replays the reference's Bloom filter exactly (-f37 default included)
-	if (o->hg_size > 0) die("--hg-size is not supported by the device path");
+	p.hg_size = o->hg_size;            // prior for the peak finder (htab.cpp:1156,1254)
 	if (hao_create(0, &p, &g_hao) != 0) { fprintf(stderr, "[hao-shim] ERROR: no HIP device (the device path has no CPU fallback)\n"); exit(1); }
 }
 

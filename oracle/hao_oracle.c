@@ -70,7 +70,7 @@ uint64_t hao_or_hash64(uint64_t key)
 void hao_or_opt_default(hao_or_opt_t *o)
 {
 	o->k = 51; o->w = 51; o->hpc = 1; o->sample_dist = 500; o->rewin = 1000; o->min_hist_cnt = 5;
-	o->max_kmer_cnt = 2000; o->high_factor = 5.0; o->max_n_chain = 100; o->is_ont = 0; o->bf_shift = 0;
+	o->max_kmer_cnt = 2000; o->high_factor = 5.0; o->max_n_chain = 100; o->is_ont = 0; o->bf_shift = 0; o->bw_thres = 0; o->hg_size = -1;
 }
 
 /* ------------------------------------------------------------------ */
@@ -161,7 +161,27 @@ int64_t hao_or_kmer_hashes(const uint8_t *s, int64_t len, int k, int hpc, uint64
 /* a6: histogram -> peaks   (hist.cpp:74-157, m_peak_hom <= 0)          */
 /* ------------------------------------------------------------------ */
 
-int hao_or_analyze_count(int n_cnt, int start_cnt, const int64_t *cnt, int *peak_het)
+/* hist.cpp:46-72: with a prior homozygous peak m (total bases / --hg-size) choose among (left, top, right) the candidate nearest
+ * to m (top wins ties); if it lies below m by >= 51 % of itself it is the heterozygous peak and m stands; else the next candidate to
+ * its left (if any) is the heterozygous peak */
+static int adj_peak_with_prior(int m, int top, int left, int right, int *peak_het)
+{
+	int64_t mm[3], d, min_d = -1; int i, min_i = -1;
+	mm[0] = left; mm[1] = top; mm[2] = right;
+	for (i = 0; i < 3; ++i) {
+		if (mm[i] <= 0) continue;
+		d = mm[i] >= m ? mm[i] - m : m - mm[i];
+		if (min_d == -1 || min_d > d || (min_d == d && i == 1)) { min_d = d; min_i = i; }
+	}
+	if (min_i < 0) return m;
+	if (mm[min_i] < m) { d = m - mm[min_i]; if (d >= mm[min_i] * 0.51) { *peak_het = (int)mm[min_i]; return m; } }
+	for (i = min_i - 1; i >= 0; --i) { if (mm[i] <= 0) continue; *peak_het = (int)mm[i]; break; }
+	return (int)mm[min_i];
+}
+
+int hao_or_analyze_count(int n_cnt, int start_cnt, const int64_t *cnt, int *peak_het) { return hao_or_analyze_count_m(n_cnt, start_cnt, -1, cnt, peak_het); }
+
+int hao_or_analyze_count_m(int n_cnt, int start_cnt, int m_peak_hom, const int64_t *cnt, int *peak_het)
 {
 	int i, start, low_i, max_i, max2_i, max3_i; int64_t max, max2, max3, mn;
 	*peak_het = -1;
@@ -190,6 +210,7 @@ int hao_or_analyze_count(int n_cnt, int start_cnt, const int64_t *cnt, int *peak
 		for (i = max_i + 1, mn = max; i < max3_i; ++i) if (cnt[i] < mn) mn = cnt[i];
 		if (max3 < max * 0.05 || mn > max3 * 0.95 || max3_i > max_i * 2.5) max3 = -1, max3_i = -1;
 	}
+	if (m_peak_hom > 0) return adj_peak_with_prior(m_peak_hom, max_i, max2_i, max3_i, peak_het);
 	if (max3_i > 0) { *peak_het = max_i; return max3_i; }
 	if (max2_i > 0) *peak_het = max2_i;
 	return max_i;
@@ -236,7 +257,7 @@ int hao_or_ft_gen(hao_or_ctx *c)
 		for (j = i + 1; j < n && h[j] == h[i]; ++j) {}
 		++c->ft_hist[j - i + bias > MAX_COUNT ? MAX_COUNT : j - i + bias];
 	}
-	c->ft_peak_hom = hao_or_analyze_count(N_COUNTS, c->opt.min_hist_cnt, c->ft_hist, &c->ft_peak_het);
+	c->ft_peak_hom = hao_or_analyze_count_m(N_COUNTS, c->opt.min_hist_cnt, c->opt.hg_size > 0 ? (int)(c->off[c->n_reads] / (uint64_t)c->opt.hg_size) : -1, c->ft_hist, &c->ft_peak_het);
 	c->ft_cutoff = (int)(c->ft_peak_hom * c->opt.high_factor);            /* htab.cpp:1160 */
 	if (c->ft_cutoff > MAX_COUNT - 1) c->ft_cutoff = MAX_COUNT - 1;
 	max_cnt = c->opt.max_kmer_cnt;                                         /* gen_hh clamps, htab.cpp:1042-1043 */
@@ -503,7 +524,7 @@ int hao_or_pt_gen(hao_or_ctx *c)
 		for (j = i + 1; j < n && a[j].x == a[i].x; ++j) {}
 		++c->pt_hist[j - i > MAX_COUNT ? MAX_COUNT : j - i];
 	}
-	c->hom_cov = hao_or_analyze_count(N_COUNTS, c->opt.min_hist_cnt, c->pt_hist, &c->het_cov);
+	c->hom_cov = hao_or_analyze_count_m(N_COUNTS, c->opt.min_hist_cnt, c->opt.hg_size > 0 ? (int)(c->off[c->n_reads] / (uint64_t)c->opt.hg_size) : -1, c->pt_hist, &c->het_cov);
 	if (c->has_ft) hi = MAX_COUNT - 1;                           /* htab.cpp:1266-1269 */
 	else { hi = (int)(c->hom_cov * c->opt.high_factor); if (hi > MAX_COUNT - 1) hi = MAX_COUNT - 1; }   /* :1258-1262 */
 	for (i = 0; i < n; i = j) {
@@ -946,7 +967,7 @@ int64_t hao_or_lchain(hao_or_ctx *c, uint64_t rid, const hao_or_ovlp_t **ol_out,
 	{	/* set_lchain_dp_op(is_accurate=1): float expf, float constants, double products */
 		double tmp = expf(-0.01 * (double)c->opt.k);
 		P.pen_gap = 0.5f * tmp; P.pen_skip = 0.0005f * tmp; P.max_skip = 25; P.max_iter = 5000; P.max_dis = 5000;
-		P.bw = c->opt.is_ont ? 0.05 : 0.02; P.xl = (int64_t)rl;
+		P.bw = c->opt.bw_thres > 0 ? c->opt.bw_thres : (c->opt.is_ont ? 0.05 : 0.02); P.xl = (int64_t)rl;
 	}
 	cn = seed_hits(c, rid, high_occ, low_occ);
 	c->ol_n = 0;

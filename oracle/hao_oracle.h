@@ -43,6 +43,8 @@ typedef struct {
 	int max_n_chain;          /* 100 (CommandLines.cpp:276); raised by ha_opt_update_cov */
 	int is_ont;               /* bw_thres 0.05 instead of 0.02 (ecovlp.cpp:3274) */
 	int bf_shift;             /* -f: log2 of the Bloom filter bits in front of the k-mer count table (CommandLines.cpp:269 default 37); 0 = exact counting */
+	double bw_thres;          /* bw_thres of h_ec_lchain; 0 = the EC-round value 0.02 / 0.05 --ont (ecovlp.cpp:3274); the final round passes 0.001 (:3957) */
+	long long hg_size;        /* --hg-size (CommandLines.cpp:331,959), -1 = unset: prior for the peak finder (htab.cpp:1156,1254) */
 } hao_or_opt_t;
 
 typedef struct hao_or_ctx hao_or_ctx;
@@ -85,8 +87,9 @@ int64_t hao_or_seed_hits(hao_or_ctx *c, uint64_t rid, const hao_or_hit_t **out);
 int64_t hao_or_lchain(hao_or_ctx *c, uint64_t rid, const hao_or_ovlp_t **ol, const uint64_t **fc, const uint64_t **fc_off,
 					  const hao_or_hit_t **cl, int64_t *cl_n);
 
-/* ha_analyze_count (hist.cpp:74-157) with m_peak_hom <= 0 (hg_size unset) */
+/* ha_analyze_count (hist.cpp:74-157) with m_peak_hom <= 0 (hg_size unset) / with the prior m_peak_hom (adj_m_peak_hom, hist.cpp:46-72) */
 int hao_or_analyze_count(int n_cnt, int start_cnt, const int64_t *cnt, int *peak_het);
+int hao_or_analyze_count_m(int n_cnt, int start_cnt, int m_peak_hom, const int64_t *cnt, int *peak_het);
 
 #ifdef __cplusplus
 }

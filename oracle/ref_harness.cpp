@@ -9,7 +9,15 @@
 // (Assembly.cpp:2083-2084 ha_ft_gen + ha_opt_update_cov; Assembly.cpp:1007-1008
 // ha_pt_gen; ecovlp.cpp:3234-3274 worker_hap_ec up to and including h_ec_lchain).
 //
-// usage: ref_harness [--ont] [-t N] [-k K] [-w W] [--dump PREFIX] [--time] [--nodump-hits] reads.fa
+// usage: ref_harness [--ont] [-t N] [-k K] [-w W] [-f BLOOM_BITS] [--no-hpc] [--hg-size N] [--bw X] [--dump PREFIX] [--time] [--nodump-hits]
+//                    [--reads-list FILE] [--no-tables] [--digest] reads.fa
+//   --reads-list FILE  per-read dumps (minimizers, seed hits, ol / fc / cl) only for the read ids listed in FILE (text, one per line);
+//                      the *_off arrays then have one entry per LISTED read (+1), in list order
+//   --no-tables        skip the ft / pt table dumps and the hf = NULL minimizer dump (large read sets)
+//   --digest           PREFIX.dig.u64 = per read [digest of (ol, fc, cl), digest of the seed hits], all reads, all threads; the digest is
+//                      hao_batch_digest's (include/hao.h): a position-salted sum of mixed 64-bit words, so the device computes the same
+//                      value with a parallel reduction
+//   --bw X             bw_thres of the pass (default 0.02 / 0.05 --ont; the final round uses 0.001, ecovlp.cpp:3957)
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -50,7 +58,46 @@ typedef struct {
 	uint64_t n_ovlp, n_hits;
 } tbuf_t;
 
-typedef struct { tbuf_t *b; double bw; uint32_t high_occ, low_occ; } pass_t;
+typedef struct { tbuf_t *b; double bw; uint32_t high_occ, low_occ; uint64_t *dig; } pass_t;
+
+// ---- per-read result digest (same definition as hao_batch_digest, include/hao.h) ----
+static inline uint64_t dg_mix(uint64_t z) { z ^= z >> 30; z *= 0xbf58476d1ce4e5b9ULL; z ^= z >> 27; z *= 0x94d049bb133111ebULL; z ^= z >> 31; return z; }
+static inline uint64_t dg_term(uint64_t stream, uint64_t i, uint64_t w) { return dg_mix(w + 0x9E3779B97F4A7C15ULL * (i + 1) + stream * 0xD6E8FEB86659FD93ULL); }
+static void ol_words(const overlap_region *r, uint64_t q[6])
+{
+	uint32_t f[12] = { r->x_id, r->x_pos_s, r->x_pos_e, r->x_pos_strand, r->y_id, r->y_pos_s, r->y_pos_e, r->y_pos_strand,
+					   (uint32_t)r->shared_seed, r->align_length, r->non_homopolymer_errors, r->f_cigar.length };
+	for (int t = 0; t < 6; ++t) q[t] = (uint64_t)f[2 * t] | (uint64_t)f[2 * t + 1] << 32;
+}
+static uint64_t digest_result(const overlap_region_alloc *ol, const Candidates_list *cl)
+{
+	uint64_t d = 0, nfc = 0;
+	for (uint64_t j = 0; j < ol->length; ++j) {
+		uint64_t q[6]; ol_words(&ol->list[j], q);
+		for (int t = 0; t < 6; ++t) d += dg_term(1, j * 6 + t, q[t]);
+		for (uint32_t c = 0; c < ol->list[j].f_cigar.length; ++c) d += dg_term(2, nfc++, ol->list[j].f_cigar.buffer[c]);
+	}
+	for (uint64_t j = 0; j < (uint64_t)cl->length; ++j) { uint64_t q[2]; memcpy(q, &cl->list[j], 16); d += dg_term(3, 2 * j, q[0]) + dg_term(3, 2 * j + 1, q[1]); }
+	return d;
+}
+static uint64_t digest_hits(const Candidates_list *cl)
+{
+	uint64_t d = 0;
+	for (uint64_t j = 0; j < (uint64_t)cl->length; ++j) { uint64_t q[2]; memcpy(q, &cl->list[j], 16); d += dg_term(4, 2 * j, q[0]) + dg_term(4, 2 * j + 1, q[1]); }
+	return d;
+}
+
+static void worker_digest(void *data, long i, int tid)
+{
+	pass_t *p = (pass_t*)data; tbuf_t *b = &p->b[tid];
+	uint32_t high_occ = p->high_occ, low_occ = p->low_occ;
+	recover_UC_Read(&b->ur, &R_INF, i);
+	minimizers_qgen0(b->ab, b->ur.seq, b->ur.length, asm_opt.mz_win, asm_opt.k_mer_length, &b->cl, NULL, ha_flt_tab, ha_idx, &R_INF, NULL, &b->sp, &high_occ, &low_occ);
+	p->dig[2 * i + 1] = digest_hits(&b->cl);
+	high_occ = p->high_occ; low_occ = p->low_occ;
+	h_ec_lchain(b->ab, i, b->ur.seq, b->ur.length, asm_opt.mz_win, asm_opt.k_mer_length, &R_INF, &b->ol, &b->cl, p->bw, asm_opt.max_n_chain, 1, NULL, NULL, &b->sp, &high_occ, &low_occ, 1, 1, 3, 0.7, 2, 32, COV_W);
+	p->dig[2 * i] = digest_result(&b->ol, &b->cl);
+}
 
 static void worker_pass(void *data, long i, int tid)
 {
@@ -73,7 +120,8 @@ static tbuf_t *tbuf_init(int n)
 
 int main(int argc, char *argv[])
 {
-	int n_thread = 1, is_ont = 0, do_time = 0, dump_hits = 1, k = -1, w = -1, bf_shift = 0; const char *fa = 0; std::string prefix;
+	int n_thread = 1, is_ont = 0, do_time = 0, dump_hits = 1, k = -1, w = -1, bf_shift = 0, no_hpc = 0, no_tables = 0, do_digest = 0; const char *fa = 0, *list_fn = 0, *hg = 0; std::string prefix;
+	double bw_arg = -1;
 	for (int i = 1; i < argc; ++i) {
 		if (!strcmp(argv[i], "--ont")) is_ont = 1;
 		else if (!strcmp(argv[i], "-t")) n_thread = atoi(argv[++i]);
@@ -83,6 +131,12 @@ int main(int argc, char *argv[])
 		else if (!strcmp(argv[i], "--dump")) prefix = argv[++i];
 		else if (!strcmp(argv[i], "--time")) do_time = 1;
 		else if (!strcmp(argv[i], "--nodump-hits")) dump_hits = 0;
+		else if (!strcmp(argv[i], "--no-hpc")) no_hpc = 1;
+		else if (!strcmp(argv[i], "--hg-size")) hg = argv[++i];
+		else if (!strcmp(argv[i], "--bw")) bw_arg = atof(argv[++i]);
+		else if (!strcmp(argv[i], "--reads-list")) list_fn = argv[++i];
+		else if (!strcmp(argv[i], "--no-tables")) no_tables = 1;
+		else if (!strcmp(argv[i], "--digest")) do_digest = 1;
 		else fa = argv[i];
 	}
 	if (!fa) { fprintf(stderr, "usage: ref_harness [--ont] [-t N] [-k K] [-w W] [-f BLOOM_BITS] [--dump PREFIX] [--time] reads.fa\n"); return 1; }
@@ -93,11 +147,13 @@ int main(int argc, char *argv[])
 	if (k > 0) { snprintf(kb, 32, "%d", k); av.push_back("-k"); av.push_back(kb); }
 	if (w > 0) { snprintf(wb, 32, "%d", w); av.push_back("-w"); av.push_back(wb); }
 	if (is_ont) av.push_back("--ont");
+	if (hg) { av.push_back("--hg-size"); av.push_back(hg); }
 	av.push_back(fa);
 	std::vector<char*> avp; for (size_t i = 0; i < av.size(); ++i) avp.push_back((char*)av[i].c_str());
 	yak_reset_realtime();
 	init_opt(&asm_opt);
 	if (!CommandLine_process((int)avp.size(), &avp[0], &asm_opt)) return 1;
+	if (no_hpc) asm_opt.flag |= HA_F_NO_HPC;      // what the reference's own --no-hpc style switches set (CommandLines.h); every hot-path call reads this flag
 
 	int hom_cov_ft = -1, hom_cov = -1, het_cov = -1;
 	double t0 = yak_realtime();
@@ -112,6 +168,7 @@ int main(int argc, char *argv[])
 	uint32_t high_occ = asm_opt.hom_cov * (2.0 - HA_KMER_GOOD_RATIO);   // ecovlp.cpp:3237
 	uint32_t low_occ = asm_opt.hom_cov * HA_KMER_GOOD_RATIO;            // ecovlp.cpp:3238
 	double bw = is_ont ? 0.05 : 0.02;                                     // ecovlp.cpp:3274
+	if (bw_arg >= 0) bw = bw_arg;
 
 	if (do_time) {
 		tbuf_t *b = tbuf_init(n_thread); pass_t p; p.b = b; p.bw = bw; p.high_occ = high_occ; p.low_occ = low_occ;
@@ -124,25 +181,40 @@ int main(int argc, char *argv[])
 		fflush(stdout);
 	}
 	if (prefix.empty()) return 0;
+	if (do_digest) {
+		std::vector<uint64_t> dig(2 * n_reads, 0);
+		tbuf_t *b = tbuf_init(n_thread); pass_t p; p.b = b; p.bw = bw; p.high_occ = high_occ; p.low_occ = low_occ; p.dig = dig.data();
+		kt_for(n_thread, worker_digest, &p, n_reads);
+		wr(prefix, "dig.u64", dig.data(), 8 * dig.size());
+	}
+	std::vector<uint64_t> sel;      // reads of the per-read dumps
+	if (list_fn) {
+		FILE *fp = fopen(list_fn, "r"); unsigned long v;
+		if (!fp) { fprintf(stderr, "cannot read %s\n", list_fn); return 1; }
+		while (fscanf(fp, "%lu", &v) == 1) if (v < n_reads) sel.push_back(v);
+		fclose(fp);
+	} else for (uint64_t i = 0; i < n_reads; ++i) sel.push_back(i);
+	const uint64_t n_sel = sel.size();
 
 	// ---------------- dumps ----------------
 	{ // read lengths
 		wr(prefix, "rlen.u64", R_INF.read_length, sizeof(uint64_t) * n_reads);
 	}
 	int64_t ft_hist[4096], pt_hist[4096]; int ft_peak_hom, ft_peak_het; uint64_t ft_distinct, pt_distinct;
-	refdump_ft_hist(&asm_opt, &R_INF, ft_hist, &ft_peak_hom, &ft_peak_het, &ft_distinct);
+	memset(ft_hist, 0, sizeof(ft_hist)); ft_peak_hom = hom_cov_ft; ft_peak_het = -1; ft_distinct = 0;
+	if (!no_tables) refdump_ft_hist(&asm_opt, &R_INF, ft_hist, &ft_peak_hom, &ft_peak_het, &ft_distinct);      // (recounts every k-mer: skipped for large sets)
 	refdump_pt_hist(&asm_opt, ha_flt_tab, &R_INF, pt_hist, &pt_distinct);
 	wr(prefix, "ft_hist.i64", ft_hist, sizeof(ft_hist));
 	wr(prefix, "pt_hist.i64", pt_hist, sizeof(pt_hist));
-	uint64_t n_ft, n_ptk, n_ptp;
-	{
+	uint64_t n_ft = 0, n_ptk = 0, n_ptp = 0;
+	if (!no_tables) {
 		uint64_t *keys; int32_t *vals;
 		n_ft = refdump_ft(ha_flt_tab, &keys, &vals);
 		wr(prefix, "ft_keys.u64", keys, sizeof(uint64_t) * n_ft);
 		wr(prefix, "ft_vals.i32", vals, sizeof(int32_t) * n_ft);
 		free(keys); free(vals);
 	}
-	{
+	if (!no_tables) {
 		uint64_t *keys, *off, *pos;
 		n_ptk = refdump_pt(ha_idx, &keys, &off, &pos, &n_ptp);
 		wr(prefix, "pt_keys.u64", keys, sizeof(uint64_t) * n_ptk);
@@ -153,22 +225,24 @@ int main(int argc, char *argv[])
 	// per-read minimizers, index-time call (htab.cpp:691): rid = read id, hf = ha_flt_tab
 	{
 		UC_Read ur; init_UC_Read(&ur); ha_mz1_v mz = {0,0,0}; st_mt_t mt = {0,0,0};
-		std::vector<uint64_t> off(n_reads + 1, 0), rec;
-		for (uint64_t i = 0; i < n_reads; ++i) {
+		std::vector<uint64_t> off(n_sel + 1, 0), rec;
+		for (uint64_t ii = 0; ii < n_sel; ++ii) {
+			const uint64_t i = sel[ii];
 			recover_UC_Read(&ur, &R_INF, i); mz.n = 0;
 			mz1_ha_sketch(ur.seq, ur.length, asm_opt.mz_win, asm_opt.k_mer_length, i, !(asm_opt.flag & HA_F_NO_HPC), &mz, ha_flt_tab, asm_opt.mz_sample_dist, 0, 0, NULL, -1, asm_opt.dp_min_len, asm_opt.dp_e, &mt, asm_opt.mz_rewin, 0, NULL);
 			for (uint32_t j = 0; j < mz.n; ++j) { uint64_t q[2]; memcpy(q, &mz.a[j], 16); rec.push_back(q[0]); rec.push_back(q[1]); }
-			off[i + 1] = rec.size() / 2;
+			off[ii + 1] = rec.size() / 2;
 		}
 		wr(prefix, "mz_off.u64", &off[0], sizeof(uint64_t) * off.size());
 		wr(prefix, "mz.u64", rec.data(), sizeof(uint64_t) * rec.size());
 		// same with hf = NULL and sample_dist = 0 (pure window minimizers, no count order / thinning)
 		rec.clear();
-		for (uint64_t i = 0; i < n_reads; ++i) {
+		for (uint64_t ii = 0; ii < n_sel && !no_tables; ++ii) {
+			const uint64_t i = sel[ii];
 			recover_UC_Read(&ur, &R_INF, i); mz.n = 0;
 			mz1_ha_sketch(ur.seq, ur.length, asm_opt.mz_win, asm_opt.k_mer_length, i, !(asm_opt.flag & HA_F_NO_HPC), &mz, NULL, 0, 0, 0, NULL, -1, asm_opt.dp_min_len, asm_opt.dp_e, &mt, asm_opt.mz_rewin, 0, NULL);
 			for (uint32_t j = 0; j < mz.n; ++j) { uint64_t q[2]; memcpy(q, &mz.a[j], 16); rec.push_back(q[0]); rec.push_back(q[1]); }
-			off[i + 1] = rec.size() / 2;
+			off[ii + 1] = rec.size() / 2;
 		}
 		wr(prefix, "mz0_off.u64", &off[0], sizeof(uint64_t) * off.size());
 		wr(prefix, "mz0.u64", rec.data(), sizeof(uint64_t) * rec.size());
@@ -177,16 +251,17 @@ int main(int argc, char *argv[])
 	uint64_t tot_ol = 0, tot_cl = 0, tot_kh = 0;
 	{ // per-read seed hits before chaining, and (ol, cl) after h_ec_lchain
 		tbuf_t *b = tbuf_init(1);
-		std::vector<uint64_t> kh_off(n_reads + 1, 0), ol_off(n_reads + 1, 0), cl_off(n_reads + 1, 0), fc_off(1, 0), fc;
+		std::vector<uint64_t> kh_off(n_sel + 1, 0), ol_off(n_sel + 1, 0), cl_off(n_sel + 1, 0), fc_off(1, 0), fc;
 		std::vector<uint32_t> kh, ol, cl;
-		for (uint64_t i = 0; i < n_reads; ++i) {
+		for (uint64_t ii = 0; ii < n_sel; ++ii) {
+			const uint64_t i = sel[ii];
 			uint32_t ho = high_occ, lo = low_occ;
 			recover_UC_Read(&b->ur, &R_INF, i);
 			if (dump_hits) {
 				minimizers_qgen0(b->ab, b->ur.seq, b->ur.length, asm_opt.mz_win, asm_opt.k_mer_length, &b->cl, NULL, ha_flt_tab, ha_idx, &R_INF, NULL, &b->sp, &ho, &lo);
 				for (uint64_t j = 0; j < (uint64_t)b->cl.length; ++j) { uint32_t q[4]; memcpy(q, &b->cl.list[j], 16); kh.insert(kh.end(), q, q + 4); }
 			}
-			kh_off[i + 1] = kh.size() / 4;
+			kh_off[ii + 1] = kh.size() / 4;
 			ho = high_occ; lo = low_occ;
 			h_ec_lchain(b->ab, i, b->ur.seq, b->ur.length, asm_opt.mz_win, asm_opt.k_mer_length, &R_INF, &b->ol, &b->cl, bw, asm_opt.max_n_chain, 1, NULL, NULL, &b->sp, &ho, &lo, 1, 1, 3, 0.7, 2, 32, COV_W);
 			for (uint64_t j = 0; j < b->ol.length; ++j) {
@@ -197,13 +272,14 @@ int main(int argc, char *argv[])
 				for (uint32_t c = 0; c < r->f_cigar.length; ++c) fc.push_back(r->f_cigar.buffer[c]);
 				fc_off.push_back(fc.size());
 			}
-			ol_off[i + 1] = ol.size() / 12;
+			ol_off[ii + 1] = ol.size() / 12;
 			if (dump_hits)
 				for (uint64_t j = 0; j < (uint64_t)b->cl.length; ++j) { uint32_t q[4]; memcpy(q, &b->cl.list[j], 16); cl.insert(cl.end(), q, q + 4); }
-			cl_off[i + 1] = cl.size() / 4;
+			cl_off[ii + 1] = cl.size() / 4;
 			tot_cl += b->cl.length;
 		}
 		tot_ol = ol.size() / 12; tot_kh = kh.size() / 4;
+		wr(prefix, "sel.u64", sel.data(), 8 * sel.size());
 		wr(prefix, "kh_off.u64", &kh_off[0], 8 * kh_off.size()); wr(prefix, "kh.u32", kh.data(), 4 * kh.size());
 		wr(prefix, "ol_off.u64", &ol_off[0], 8 * ol_off.size()); wr(prefix, "ol.u32", ol.data(), 4 * ol.size());
 		wr(prefix, "fc_off.u64", &fc_off[0], 8 * fc_off.size()); wr(prefix, "fc.u64", fc.data(), 8 * fc.size());

@@ -42,3 +42,50 @@ def scenario_oracle(name):
 
 def crc(a):
     return zlib.crc32(np.ascontiguousarray(a).tobytes())
+
+
+# ---- result digests (hao_batch_digest, include/hao.h; same definition in oracle/ref_harness.cpp) ----
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def dg_mix(z):
+    z = np.asarray(z, dtype=np.uint64).copy()
+    with np.errstate(over="ignore"):
+        z ^= z >> np.uint64(30); z *= np.uint64(0xbf58476d1ce4e5b9)
+        z ^= z >> np.uint64(27); z *= np.uint64(0x94d049bb133111eb)
+        z ^= z >> np.uint64(31)
+    return z
+
+
+def dg_stream(stream, words):
+    """sum over i of mix(w_i + GOLD * (i + 1) + stream * SALT)  (mod 2^64)"""
+    w = np.ascontiguousarray(words).view(np.uint64).ravel()
+    if w.size == 0:
+        return np.uint64(0)
+    with np.errstate(over="ignore"):
+        i = np.arange(1, w.size + 1, dtype=np.uint64)
+        t = dg_mix(w + np.uint64(0x9E3779B97F4A7C15) * i + np.uint64(stream) * np.uint64(0xD6E8FEB86659FD93))
+        return np.add.reduce(t, dtype=np.uint64)
+
+
+def digest_result(ol, fc, cl):
+    """digest of one read's (ol uint32 [n,12], fc uint64, cl uint32 [m,4])"""
+    with np.errstate(over="ignore"):
+        return np.uint64(dg_stream(1, np.ascontiguousarray(ol, dtype=np.uint32)) + dg_stream(2, np.ascontiguousarray(fc, dtype=np.uint64))
+                         + dg_stream(3, np.ascontiguousarray(cl, dtype=np.uint32)))
+
+
+def digest_hits(kh):
+    return np.uint64(dg_stream(4, np.ascontiguousarray(kh, dtype=np.uint32)))
+
+
+def fold_digests(d, block=256):
+    """per-read digests -> one value per block of reads: sum of mix(d_r + GOLD * (r + 1))"""
+    d = np.ascontiguousarray(d, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        t = dg_mix(d + np.uint64(0x9E3779B97F4A7C15) * np.arange(1, d.size + 1, dtype=np.uint64))
+    nb = (d.size + block - 1) // block
+    out = np.zeros(nb, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        np.add.at(out, np.arange(d.size) // block, t)
+    return out

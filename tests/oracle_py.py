@@ -17,7 +17,7 @@ _LIB = None
 class Opt(C.Structure):
     _fields_ = [("k", C.c_int), ("w", C.c_int), ("hpc", C.c_int), ("sample_dist", C.c_int), ("rewin", C.c_int),
                 ("min_hist_cnt", C.c_int), ("max_kmer_cnt", C.c_int), ("high_factor", C.c_double),
-                ("max_n_chain", C.c_int), ("is_ont", C.c_int), ("bf_shift", C.c_int)]
+                ("max_n_chain", C.c_int), ("is_ont", C.c_int), ("bf_shift", C.c_int), ("bw_thres", C.c_double), ("hg_size", C.c_longlong)]
 
 
 def lib():
@@ -143,6 +143,15 @@ class Oracle:
         fo = _arr(fco.value, n + 1, np.uint64)
         return (_arr(ol.value, 12 * n, np.uint32).reshape(-1, 12), _arr(fc.value, int(fo[-1]) if n >= 0 and fo.size else 0, np.uint64), fo,
                 _arr(cl.value, 4 * cln.value, np.uint32).reshape(-1, 4))
+
+
+_META_NAMES = ["n_reads", "k", "w", "hom_cov_ft", "ft_peak_hom", "ft_peak_het", "max_n_chain", "hom_cov", "het_cov", "high_occ", "low_occ",
+               "n_ft", "n_ptk", "n_ptp", "tot_ol", "tot_cl", "tot_kh", "ft_distinct", "pt_distinct", "is_ont", "sample_dist", "rewin",
+               "max_kmer_cnt", "high_factor_x1000"]
+
+
+def load_ref_meta(prefix: str):
+    return dict(zip(_META_NAMES, [int(x) for x in np.fromfile(prefix + ".meta.i64", dtype=np.int64)]))
 
 
 def load_ref_dump(prefix: str):

@@ -19,6 +19,17 @@ SCENARIOS = {
     "bf24":  (dict(genome_size=100_000, coverage=12, read_len=4000, err=0.001, seed=12, repeat_rich=2, len_jit=1000), dict(bf_shift=24)),
     # 2 blocks per sub-table: the filter saturates, most k-mers are counted one too many and the peaks move
     "bf22":  (dict(genome_size=60_000, coverage=14, read_len=4000, err=0.002, seed=13, repeat_rich=1, len_jit=1000), dict(bf_shift=22)),
+    # homopolymer compression off (HA_F_NO_HPC): k-mer spans = k, positions are plain base offsets
+    "hpc0":  (dict(genome_size=40_000, coverage=18, read_len=4000, err=0.002, seed=14, len_jit=1000), dict(hpc=0)),
+    # the reference's DEFAULT filter size -f37: 2^16 blocks per sub-table, 28-bit block ids; repeat-rich so the table is not empty
+    "f37":   (dict(genome_size=100_000, coverage=12, read_len=4000, err=0.001, seed=15, repeat_rich=2, len_jit=1000), dict(bf_shift=37)),
+    # the final-round call site (ecovlp.cpp:3957): bw_thres = 0.001 - on 1 % error reads most chain extensions exceed the band
+    "bw001": (dict(genome_size=50_000, coverage=20, read_len=6000, err=0.01, seed=16, len_jit=2000), dict(bw_thres=0.001)),
+    "bw001rr": (dict(genome_size=100_000, coverage=12, read_len=4000, err=0.001, seed=17, repeat_rich=2, len_jit=1000), dict(bw_thres=0.001)),
+    # --hg-size: prior homozygous coverage = total bases / hg_size (htab.cpp:1156,1254; adj_m_peak_hom hist.cpp:46-72).  hg = the genome
+    # size: the prior sits on the peak; hg2 = half of it: the only peak lies far below the prior and becomes the heterozygous peak
+    "hg":    (dict(genome_size=40_000, coverage=18, read_len=4000, err=0.002, seed=3, len_jit=1000), dict(hg_size=40_000)),
+    "hg2":   (dict(genome_size=40_000, coverage=18, read_len=4000, err=0.002, seed=3, len_jit=1000), dict(hg_size=20_000)),
     # ragged / degenerate reads mixed into a normal set (see edge_reads below)
     "edge":  (dict(builder="edge"), {}),
 }

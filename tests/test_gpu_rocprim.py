@@ -1,0 +1,21 @@
+"""Pins a rocPRIM behaviour the sharded index build depends on: radix_sort_pairs over a BIT RANGE with begin_bit > 0 has been seen
+to mis-sort inputs of 5 k - 200 k elements on this ROCm (both overloads), which is why hao_pt_run groups by a separate 16-bit owner key with
+begin_bit = 0.  hao_selftest_rocprim sorts the same random keys both ways on the device and reports (mismatches of the begin_bit = 48 sort,
+mismatches of the separate-key sort); the second MUST be 0 - the first is recorded so that a ROCm upgrade that fixes (or changes) the
+behaviour shows up in the test log instead of silently changing nothing or something."""
+import ctypes as C
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [5_000, 20_000, 200_000, 4_000_000])
+def test_owner_grouping_sort(n):
+    from hifiasm_amd.api import lib
+    L = lib()
+    L.hao_selftest_rocprim.argtypes = [C.c_uint64, C.POINTER(C.c_uint64)]
+    out = (C.c_uint64 * 2)()
+    assert L.hao_selftest_rocprim(n, out) == 0
+    print(f"[rocprim] n={n}: begin_bit=48 stable-sort mismatches {out[0]}, separate 16-bit key mismatches {out[1]}")
+    assert out[1] == 0

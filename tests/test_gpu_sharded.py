@@ -90,3 +90,38 @@ def test_rccl_single_rank():
     _check_rank(e, o, 0, rs.n, errors)
     e.close()
     assert not errors, errors[:5]
+
+
+def test_ranks_fail_together():
+    """one rank with a wrong shard layout (its rid_base is off): EVERY rank must return the layout error from the same collective - nobody may
+    be left waiting in the next exchange (the loopback barrier would deadlock the test if they did)"""
+    from hifiasm_amd.api import Engine, HaoError, lib
+    rs, okw = scenario_reads("hifi")
+    world = 2
+    cuts = [0, rs.n // 2, rs.n]
+    grp = lib().hao_loop_create(world)
+    res = [None] * world
+
+    def run(rank):
+        lo, hi = cuts[rank], cuts[rank + 1]
+        e = Engine(0, **okw)
+        e.set_readset(_shard(rs, lo, hi))
+        # rank 1 claims a base that overlaps rank 0's range; the local length check passes because the lengths array is handed in rotated
+        if rank == 1:
+            e.set_shard(0, np.concatenate([rs.lengths[lo:hi], rs.lengths[:lo]]))
+        else:
+            e.set_shard(lo, rs.lengths)
+        e.dist_init_loopback(grp, rank)
+        try:
+            e.ha_ft_gen()
+            res[rank] = "ok"
+        except HaoError as ex:
+            res[rank] = str(ex)
+        e.close()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=120) for t in th]
+    assert not any(t.is_alive() for t in th), "a rank is stuck in a collective"
+    lib().hao_loop_destroy(grp)
+    assert all(r is not None and "contiguous" in r for r in res), res

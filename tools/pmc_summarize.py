@@ -3,7 +3,7 @@ hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE tallies 64 B per 12
 WRITE_SIZE is taken as reported (uncalibrated)."""
 import csv, glob, json, re, sys
 root = sys.argv[1]; args = sys.argv[2:]
-wl = "bacterial5M_hifi30x"
+wl = "chr1_250M_hifi30x"
 if "--workload" in args: wl = args[args.index("--workload") + 1]
 acc = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -18,10 +18,17 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         for (name, _), v in disp.items():
             a = acc.setdefault(name, {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
             a[ctr][0] += v; a[ctr][1] += 1
-out = {"workload": wl, "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline " + " ".join(args),
+nb = 1
+try:      # batches per pass, from the bench line of one of the passes
+    for lf in glob.glob(root + ".*.log"):
+        for ln in open(lf, errors="ignore"):
+            if ln.startswith("{") and "batches_per_pass" in ln: nb = json.loads(ln)["config"]["batches_per_pass"]
+except Exception: pass
+out = {"workload": wl, "batches": nb, "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline " + " ".join(args),
        "note": __doc__.strip().split("\n", 1)[1].strip(), "kernels": {}}
 for name, a in acc.items():
     n = max(a["FETCH_SIZE"][1], a["WRITE_SIZE"][1], 1)
     fk = a["FETCH_SIZE"][0] / max(a["FETCH_SIZE"][1], 1); wk = a["WRITE_SIZE"][0] / max(a["WRITE_SIZE"][1], 1)
-    out["kernels"][name] = {"launches": n, "FETCH_SIZE_KB_per_launch": round(fk, 1), "WRITE_SIZE_KB_per_launch": round(wk, 1), "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+    out["kernels"][name] = {"launches": n, "FETCH_SIZE_KB_per_launch": round(fk, 1), "WRITE_SIZE_KB_per_launch": round(wk, 1), "hbm_bytes_per_launch": int((2 * fk + wk) * 1024),
+                            "hbm_bytes_per_launch_raw": int((fk + wk) * 1024)}
 print(json.dumps(out, indent=1))
