@@ -37,12 +37,26 @@ class Pass(C.Structure):
                 ("mcopy_rate", C.c_double), ("chain_cutoff", C.c_uint32), ("mcopy_khit_cut", C.c_uint32), ("ocv_w", C.c_uint64)]
 
 
+class ChainHdr(C.Structure):
+    _fields_ = [("n_hits", C.c_uint32), ("w0", C.c_uint32), ("offset", C.c_uint32), ("self_offset", C.c_uint32)]
+
+
+class Delivery(C.Structure):
+    """hao_delivery_t: read-only view of one batch's results in a pinned host arena"""
+    _fields_ = [("rid_lo", C.c_uint64), ("n_reads", C.c_uint64), ("n_ol", C.c_uint64), ("n_fc", C.c_uint64), ("n_chains", C.c_uint64),
+                ("n_cl", C.c_uint64), ("n_exc", C.c_uint64), ("bytes", C.c_uint64),
+                ("ol_off", C.c_void_p), ("ol", C.c_void_p), ("fc_off", C.c_void_p), ("fc", C.c_void_p), ("ch_off", C.c_void_p),
+                ("cl_off", C.c_void_p), ("chains", C.c_void_p), ("cl_words", C.c_void_p), ("cl_exc", C.c_void_p)]
+
+
+DELIVER_OL, DELIVER_CL = 1, 2
+
 ABI_SYMBOLS = [
     "hao_opt_default", "hao_create", "hao_destroy", "hao_last_error", "hao_set_reads", "hao_ft_gen", "hao_pt_gen",
     "hao_ft_cnt", "hao_pt_get", "hao_ft_table", "hao_pt_table", "hao_hist", "hao_stats", "hao_sketch_batch",
     "hao_fetch_sketch", "hao_overlap_batch", "hao_fetch_seed_hits", "hao_fetch_overlaps", "hao_batch_totals",
     "hao_stage_times", "hao_pass_default", "hao_overlap_batch_ex", "hao_set_shard", "hao_dist_unique_id", "hao_dist_init",
-    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim",
+    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits",
 ]
 
 
@@ -81,6 +95,9 @@ def lib():
         L.hao_batch_totals.argtypes = [vp, u64p]
         L.hao_stage_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
         L.hao_batch_digest.argtypes = [vp, u64p, u64p]
+        L.hao_overlap_batch_async.argtypes = [vp, C.c_uint64, C.c_uint64, C.POINTER(Pass), C.c_uint32, C.POINTER(C.c_int)]
+        L.hao_deliver_wait.argtypes = [vp, C.c_int, C.POINTER(Delivery)]
+        L.hao_unpack_hits.argtypes = [C.POINTER(Delivery), C.c_uint64, vp, C.c_uint64]; L.hao_unpack_hits.restype = C.c_uint64
         L.hao_set_shard.argtypes = [vp, C.c_uint64, C.c_uint64, u32p]
         L.hao_dist_unique_id.argtypes = [u8p]
         L.hao_dist_init.argtypes = [vp, u8p, C.c_int, C.c_int]
@@ -245,6 +262,48 @@ class Engine:
         if bw_thres is not None:
             p.bw_thres = bw_thres
         self._ck(self.L.hao_overlap_batch_ex(self.h, lo, hi, C.byref(p)), "hao_overlap_batch_ex")
+
+    # ---- streaming delivery (hao_overlap_batch_async / hao_deliver_wait / hao_unpack_hits) ----
+    def overlap_batch_async(self, lo, hi, parts=DELIVER_OL | DELIVER_CL, bw_thres=None):
+        """compute reads [lo, hi) and queue the copy of their results into a pinned host arena; returns the arena slot (0 / 1)"""
+        p = None
+        if bw_thres is not None or self.bw_thres is not None:
+            p = self.pass_default()
+            if bw_thres is not None:
+                p.bw_thres = bw_thres
+        slot = C.c_int(-1)
+        self._ck(self.L.hao_overlap_batch_async(self.h, lo, hi, C.byref(p) if p is not None else None, parts, C.byref(slot)), "hao_overlap_batch_async")
+        self._slots = getattr(self, "_slots", [])
+        self._slots.append(slot.value)
+        return slot.value
+
+    def deliver_wait(self, slot=None):
+        """slot given: the Delivery view of that slot (blocks until its copy has landed).  No slot: wait for every queued slot, return the bytes
+        that crossed PCIe for the batches waited on (what bench.py needs)."""
+        if slot is not None:
+            d = Delivery()
+            self._ck(self.L.hao_deliver_wait(self.h, slot, C.byref(d)), "hao_deliver_wait")
+            return d
+        tot = 0
+        for s_ in set(getattr(self, "_slots", [])[-2:]):
+            tot += int(self.deliver_wait(s_).bytes)
+        self._slots = []
+        return tot
+
+    def delivered_read(self, d, rid):
+        """(ol uint32 [n,12], fc uint64, fc_off uint64 [n+1], cl uint32 [m,4]) of read rid out of a Delivery view: what the h_ec_lchain shim hands to its caller"""
+        r = rid - d.rid_lo
+        oo = _arr(d.ol_off + 8 * r, 2, np.uint64)
+        s_, e_ = int(oo[0]), int(oo[1])
+        ol = _arr(d.ol + 48 * s_, 12 * (e_ - s_), np.uint32).reshape(-1, 12)
+        fo = _arr(d.fc_off + 8 * s_, e_ - s_ + 1, np.uint64)
+        fc = _arr(d.fc + 8 * int(fo[0]), int(fo[-1] - fo[0]), np.uint64) if fo.size else np.zeros(0, dtype=np.uint64)
+        co = _arr(d.cl_off + 8 * r, 2, np.uint64)
+        m = int(co[1] - co[0])
+        cl = np.zeros((m, 4), dtype=np.uint32)
+        got = self.L.hao_unpack_hits(C.byref(d), rid, cl.ctypes.data_as(C.c_void_p), m)
+        assert got == m
+        return ol, fc, fo - (fo[0] if fo.size else 0), cl
 
     def fetch_seed_hits(self, rid):
         p, n = C.c_void_p(), C.c_uint64()

@@ -8,22 +8,35 @@ struct hao_ctx::Batch {
 	uint64_t n_generic = 0, n_generic_hits = 0; DevBuf<unsigned long long> stats, dbgbuf;
 	uint64_t lo = 0, n = 0, mz0 = 0, n_mz = 0, n_anchor = 0, n_groups = 0, n_chains = 0, n_cl = 0, n_fc_raw = 0, n_ol = 0, n_fc = 0;
 	bool valid = false, host_valid = false;
-	DevBuf<uint64_t> s_start, a_off, seg, g_cnt, g_off, g_start, ch_base, cl_base, fc_base, fcs, fc_raw, ol_fc_off, cc_off, cc, fc_final, fin_off, fcf_off, fc_out, fc_out_off;
+	DevBuf<uint64_t> s_start, a_off, seg, g_cnt, g_off, g_start, ch_base, cl_base, fc_base, fcs, fc_raw, ol_fc_off, cc_off, cc, fc_final, fcf_off;
 	DevBuf<uint64_t> nch64;
 	DevBuf<uint64_t> g_tmp, cls_cc, cls_co; DevBuf<hao_gent> glist; DevBuf<uint8_t> g_cls; DevBuf<uint32_t> slow, ovf_list; hipStream_t side[HAO_NCLS]; hipEvent_t ev_qc[HAO_NCLS], ev_dp[HAO_NCLS]; bool side_ready = false;
 	DevBuf<uint32_t> q_pos, q_cnt, s_n, g_read, wgt, nch, nout, perm, n_final, fclen;
 	DevBuf<hao_hit_t> hits, ohits, cl;
 	DevBuf<int32_t> f, ii, p, key_sc, tm; DevBuf<int64_t> t; DevBuf<uint64_t> key_xs; DevBuf<uint32_t> key_al, key_tmp;
-	DevBuf<hao_chain_rec> rec; DevBuf<hao_ovlp_t> ol, ol_out;
+	DevBuf<hao_chain_rec> rec; DevBuf<hao_ovlp_t> ol; DevBuf<hao_cdesc> cd; bool cl_valid = false;
+	// Results of a batch that leave the device.  Two sets (+ two pinned host arenas): while the copy stream drains the set of batch i, batch i + 1
+	// computes into the other one (hao_overlap_batch_async).  The blocking API keeps using the current set.
+	struct OutSet {
+		DevBuf<hao_ovlp_t> ol_out; DevBuf<uint64_t> fin_off, fc_out, fc_out_off, ch_off, cl_off;      // ol->list in final order, per-read offsets, fake cigars
+		DevBuf<hao_chain_hdr_t> hdr; DevBuf<uint32_t> words; DevBuf<hao_hit_t> exc;                   // cl->list in the wire format (hao_deliver.cuh)
+		void release() { ol_out.release(); fin_off.release(); fc_out.release(); fc_out_off.release(); ch_off.release(); cl_off.release(); hdr.release(); words.release(); exc.release(); }
+	} out[2];
+	int cur = 0;
+	OutSet &O() { return out[cur]; }
+	// delivery state: pinned host arenas, copy stream, per-slot completion events
+	unsigned char *arena[2] = { nullptr, nullptr }; size_t arena_cap[2] = { 0, 0 }; hipStream_t copy_stream = nullptr; hipEvent_t ev_ready[2], ev_done[2]; bool dl_ready = false, dl_pending[2] = { false, false };
+	hao_delivery_t dl[2]; uint64_t dl_seq = 0, n_exc = 0; uint32_t dl_parts = 0;
 	// host copies for fetch
 	std::vector<uint64_t> h_seg, h_fin_off, h_cl_off, h_fc_out_off; std::vector<hao_hit_t> h_hits, h_cl; std::vector<hao_ovlp_t> h_ol; std::vector<uint64_t> h_fc;
 	std::vector<uint64_t> fetch_fc_off, h_cco;
 	void release() {
 		if (side_ready) { for (int x = 0; x < HAO_NCLS; ++x) { (void)hipStreamDestroy(side[x]); (void)hipEventDestroy(ev_qc[x]); (void)hipEventDestroy(ev_dp[x]); } side_ready = false; }
 		s_start.release(); a_off.release(); seg.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
-		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fin_off.release(); fcf_off.release(); fc_out.release(); fc_out_off.release();
+		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fcf_off.release();
 		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); g_cls.release(); slow.release(); ovf_list.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
-		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); ol_out.release();
+		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); cd.release(); out[0].release(); out[1].release();
+		if (dl_ready) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); for (int x = 0; x < 2; ++x) { (void)hipEventDestroy(ev_ready[x]); (void)hipEventDestroy(ev_done[x]); if (arena[x]) (void)hipHostFree(arena[x]); arena[x] = nullptr; arena_cap[x] = 0; } dl_ready = false; }
 	}
 };
 
@@ -42,15 +55,75 @@ static int hao_scan_u32(hao_ctx *c, const uint32_t *in, uint64_t *out, uint64_t 
 	return hao_excl_scan_u64(c, it, out, n_plus1);
 }
 
-static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_t &ps)
+// Queue the copy of the current batch's results into the slot's pinned arena (copy stream, after everything on the compute stream so far).
+static int hao_deliver_enqueue(hao_ctx *c)
+{
+	hao_ctx::Batch &B = *c->batch; const int s = B.cur; hao_ctx::Batch::OutSet &O = B.O(); const uint64_t n = B.n; const uint32_t parts = B.dl_parts;
+	auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+	const bool ol = parts & HAO_DELIVER_OL, cl = parts & HAO_DELIVER_CL;
+	size_t o_oloff = 0, o_ol = o_oloff + (ol ? al((n + 1) * 8) : 0), o_fcoff = o_ol + (ol ? al(B.n_ol * sizeof(hao_ovlp_t)) : 0), o_fc = o_fcoff + (ol ? al((B.n_ol + 1) * 8) : 0);
+	size_t o_choff = o_fc + (ol ? al(B.n_fc * 8) : 0), o_cloff = o_choff + (cl ? al((n + 1) * 8) : 0), o_hdr = o_cloff + (cl ? al((n + 1) * 8) : 0);
+	size_t o_words = o_hdr + (cl ? al(B.n_chains * sizeof(hao_chain_hdr_t)) : 0), o_exc = o_words + (cl ? al(B.n_cl * 4) : 0), total = o_exc + (cl ? al(B.n_exc * sizeof(hao_hit_t)) : 0);
+	if (total > B.arena_cap[s]) {
+		if (B.arena[s]) (void)hipHostFree(B.arena[s]);
+		B.arena[s] = nullptr; B.arena_cap[s] = 0;
+		const size_t want = total + total / 4 + (1 << 20);
+		HIP_TRY(hipHostMalloc((void**)&B.arena[s], want, hipHostMallocDefault));
+		B.arena_cap[s] = want;
+	}
+	unsigned char *a = B.arena[s];
+	HIP_TRY(hipEventRecord(B.ev_ready[s], c->stream));
+	HIP_TRY(hipStreamWaitEvent(B.copy_stream, B.ev_ready[s], 0));
+	auto cp = [&](size_t off, const void *src, size_t bytes) -> hipError_t { return bytes ? hipMemcpyAsync(a + off, src, bytes, hipMemcpyDeviceToHost, B.copy_stream) : hipSuccess; };
+	hao_delivery_t &d = B.dl[s];
+	d.rid_lo = B.lo; d.n_reads = n; d.n_ol = d.n_fc = d.n_chains = d.n_cl = d.n_exc = 0; d.bytes = 0;
+	if (ol && n) {
+		HIP_TRY(cp(o_oloff, O.fin_off.p, (n + 1) * 8)); HIP_TRY(cp(o_ol, O.ol_out.p, B.n_ol * sizeof(hao_ovlp_t)));
+		HIP_TRY(cp(o_fcoff, O.fc_out_off.p, B.n_ol * 8)); HIP_TRY(cp(o_fc, O.fc_out.p, B.n_fc * 8));
+		((uint64_t*)(a + o_fcoff))[B.n_ol] = B.n_fc;      // end of the last cigar (a host-side word next to, not inside, the region the copy writes)
+		d.n_ol = B.n_ol; d.n_fc = B.n_fc; d.ol_off = (const uint64_t*)(a + o_oloff); d.ol = (const hao_ovlp_t*)(a + o_ol); d.fc_off = (const uint64_t*)(a + o_fcoff); d.fc = (const uint64_t*)(a + o_fc);
+		d.bytes += (n + 1) * 8 + B.n_ol * (sizeof(hao_ovlp_t) + 8) + B.n_fc * 8;
+	}
+	if (cl && n) {
+		HIP_TRY(cp(o_choff, O.ch_off.p, (n + 1) * 8)); HIP_TRY(cp(o_cloff, O.cl_off.p, (n + 1) * 8)); HIP_TRY(cp(o_hdr, O.hdr.p, B.n_chains * sizeof(hao_chain_hdr_t)));
+		HIP_TRY(cp(o_words, O.words.p, B.n_cl * 4)); HIP_TRY(cp(o_exc, O.exc.p, B.n_exc * sizeof(hao_hit_t)));
+		d.n_chains = B.n_chains; d.n_cl = B.n_cl; d.n_exc = B.n_exc; d.ch_off = (const uint64_t*)(a + o_choff); d.cl_off = (const uint64_t*)(a + o_cloff);
+		d.chains = (const hao_chain_hdr_t*)(a + o_hdr); d.cl_words = (const uint32_t*)(a + o_words); d.cl_exc = (const hao_hit_t*)(a + o_exc);
+		d.bytes += 2 * (n + 1) * 8 + B.n_chains * sizeof(hao_chain_hdr_t) + B.n_cl * 4 + B.n_exc * sizeof(hao_hit_t);
+	}
+	HIP_TRY(hipEventRecord(B.ev_done[s], B.copy_stream));
+	B.dl_pending[s] = true;
+	return HAO_OK;
+}
+
+static int hao_deliver_init(hao_ctx *c, hao_ctx::Batch &B)
+{
+	if (B.dl_ready) return HAO_OK;
+	HIP_TRY(hipStreamCreateWithFlags(&B.copy_stream, hipStreamNonBlocking));
+	for (int x = 0; x < 2; ++x) { HIP_TRY(hipEventCreateWithFlags(&B.ev_ready[x], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&B.ev_done[x], hipEventDisableTiming)); }
+	B.dl_ready = true;
+	return HAO_OK;
+}
+
+// parts = 0: results stay in HBM (blocking API).  parts != 0 (hao_overlap_batch_async): the batch computes into output set `dl_seq & 1`, packs cl->list
+// into the wire format and queues the copy of everything asked for into that slot's pinned arena on the copy stream.
+static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_t &ps, uint32_t parts = 0, int *slot_out = nullptr)
 {
 	if (ps.apend_be != 1 || ps.is_accurate != 1 || ps.gen_off != 1 || ps.mcopy_num > HAO_MCOPY_MAX || ps.ocv_w == 0) { hao_set_err(c, "unsupported h_ec_lchain arguments"); return HAO_EUNSUPP; }
 	if (!c->has_pt) { hao_set_err(c, "hao_pt_gen must run before hao_overlap_batch"); return HAO_EINVAL; }
 	if (!c->batch) c->batch = new hao_ctx::Batch();
 	hao_ctx::Batch &B = *c->batch;
-	B.valid = false; B.host_valid = false; B.lo = lo; B.n = hi - lo;
+	B.valid = false; B.host_valid = false; B.cl_valid = false; B.lo = lo; B.n = hi - lo; B.dl_parts = parts; B.n_exc = 0;
 	const uint64_t n = B.n;
-	if (n == 0) { B.n_anchor = B.n_groups = B.n_chains = B.n_cl = B.n_ol = B.n_fc = B.n_mz = 0; B.valid = true; return HAO_OK; }
+	if (parts) {
+		if (int rc = hao_deliver_init(c, B)) return rc;
+		B.cur = (int)(B.dl_seq++ & 1);
+		if (slot_out) *slot_out = B.cur;
+	}
+	// the output set about to be written may still be feeding a copy (its previous async batch): wait for that copy, never for the other slot's
+	if (B.dl_ready && B.dl_pending[B.cur]) { HIP_TRY(hipEventSynchronize(B.ev_done[B.cur])); B.dl_pending[B.cur] = false; }
+	if (parts) { memset(&B.dl[B.cur], 0, sizeof(hao_delivery_t)); B.dl[B.cur].rid_lo = lo; B.dl[B.cur].n_reads = n; }
+	if (n == 0) { B.n_anchor = B.n_groups = B.n_chains = B.n_cl = B.n_ol = B.n_fc = B.n_mz = 0; B.valid = true; return HAO_OK; }      // (an empty delivery: nothing to copy, the view stays zeroed)
 	// minimizer range of the batch (host knows the per-read offsets? keep a host copy once)
 	if (c->h_ix_mz_off.size() != c->n_reads + 1) {
 		c->h_ix_mz_off.resize(c->n_reads + 1);
@@ -181,14 +254,25 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	// no host round trip here: the buffers downstream are sized by bounds known from G and A (<= 3 chains per group, chained hits <= seed
 	// hits, fake-cigar entries <= hits + 6 per group); the exact totals are read back once, after the last kernel
 	const uint64_t NCmax = G * HAO_MCOPY_MAX, FCmax = A + 6 * G;
-	HIP_TRY(B.ol.reserve(NCmax + 1)); HIP_TRY(B.ol_fc_off.reserve(NCmax + 1)); HIP_TRY(B.cl.reserve(A + 1)); HIP_TRY(B.fc_raw.reserve(FCmax + 1)); HIP_TRY(B.perm.reserve(NCmax + 1));
+	HIP_TRY(B.ol.reserve(NCmax + 1)); HIP_TRY(B.ol_fc_off.reserve(NCmax + 1)); HIP_TRY(B.cd.reserve(NCmax + 1)); HIP_TRY(B.fc_raw.reserve(FCmax + 1)); HIP_TRY(B.perm.reserve(NCmax + 1));
 	if (G) {
 		hao_asm_args aa;
 		aa.g_start = B.g_start.p; aa.g_read = B.g_read.p; aa.g_cls = B.g_cls.p; aa.g_off = B.g_off.p; aa.n_groups = G; aa.rid_lo = glo; aa.ohits = B.ohits.p; aa.hits = B.hits.p; aa.fcs = B.fcs.p; aa.rec = B.rec.p; aa.nch = B.nch.p;
-		aa.ch_base = B.ch_base.p; aa.cl_base = B.cl_base.p; aa.fc_base = B.fc_base.p; aa.ol = B.ol.p; aa.ol_fc_off = B.ol_fc_off.p; aa.cl = B.cl.p; aa.fc = B.fc_raw.p;
+		aa.ch_base = B.ch_base.p; aa.cl_base = B.cl_base.p; aa.fc_base = B.fc_base.p; aa.ol = B.ol.p; aa.ol_fc_off = B.ol_fc_off.p; aa.cd = B.cd.p; aa.fc = B.fc_raw.p;
 		const uint64_t n_tiny = cls_cnt[0], n_rest = G - n_tiny;      // the work lists are laid out tiny class first
 		if (n_rest) { hipLaunchKernelGGL(chain_assemble_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream, aa); HAO_CHECK_LAUNCH(); }
 		if (n_tiny) { hipLaunchKernelGGL(chain_assemble_tiny_kernel, dim3((unsigned)((n_tiny + 63) / 64)), dim3(64), 0, c->stream, aa, B.glist.p + L.base[0], n_tiny); HAO_CHECK_LAUNCH(); }
+	}
+	unsigned long long *d_exc_cnt = B.stats.p + 3 * HAO_NCLS + 2;      // (slot [3 NCLS + 2] of the stats block is free; [3 NCLS + 3] = seed overflow list cursor)
+	hao_pack_args pa; memset(&pa, 0, sizeof(pa));
+	if (parts & HAO_DELIVER_CL) {
+		hao_ctx::Batch::OutSet &O = B.O();
+		HIP_TRY(O.hdr.reserve(NCmax + 1)); HIP_TRY(O.words.reserve(A + 1)); HIP_TRY(O.exc.reserve(c->sw.exc_cap >= 0 ? (uint64_t)c->sw.exc_cap + 1 : std::max<uint64_t>(1 << 16, A / 64))); HIP_TRY(O.ch_off.reserve(n + 2)); HIP_TRY(O.cl_off.reserve(n + 2));
+		pa.cd = B.cd.p; pa.n_chains = NCmax; pa.hits = B.hits.p; pa.ohits = B.ohits.p; pa.hdr = O.hdr.p; pa.words = O.words.p; pa.exc = O.exc.p; pa.exc_cnt = d_exc_cnt; pa.exc_cap = c->sw.exc_cap >= 0 ? std::min<uint64_t>(O.exc.cap, (uint64_t)c->sw.exc_cap) : O.exc.cap;
+		// the number of chains is only known on the device here: launch over the bound, the kernel stops at ch_base[G]
+		if (G) { hipLaunchKernelGGL(hao_pack_chains_kernel, dim3((unsigned)((NCmax + 3) / 4)), dim3(256), 0, c->stream, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH(); }
+		hipLaunchKernelGGL(hao_read_ranges_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, B.g_off.p, B.ch_base.p, B.cl_base.p, n, O.ch_off.p, O.cl_off.p);
+		HAO_CHECK_LAUNCH();
 	}
 	c->timer.mark("q_assemble");
 	// Q8 selection
@@ -197,7 +281,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		for (uint64_t r = 0; r < n; ++r) { cco[r] = o; o += c->h_len_all[glo + r] / par.ocv_w + 2; }
 		cco[n] = o;
 		HIP_TRY(B.cc_off.reserve(n + 1)); HIP_TRY(B.cc.reserve(o + 1)); HIP_TRY(B.n_final.reserve(n + 2)); HIP_TRY(B.fc_final.reserve(n + 2));
-		HIP_TRY(B.fin_off.reserve(n + 2)); HIP_TRY(B.fcf_off.reserve(n + 2));
+		HIP_TRY(B.O().fin_off.reserve(n + 2)); HIP_TRY(B.fcf_off.reserve(n + 2));
 		HIP_TRY(hipMemcpyAsync(B.cc_off.p, cco.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
 	}
 	const uint64_t NC = NCmax;
@@ -205,7 +289,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	hao_sel_args sa;
 	HIP_TRY(B.key_tmp.reserve(5 * NC + 8));
 	sa.key_xs = B.key_xs.p; sa.key_sc = B.key_sc.p; sa.key_al = B.key_al.p; sa.key_tmp = B.key_tmp.p;
-	sa.ol = B.ol.p; sa.g_off = B.g_off.p; sa.ch_base = B.ch_base.p; sa.cl_base = B.cl_base.p; sa.cl = B.cl.p; sa.n_sel = n; sa.rid_lo = glo; sa.len = c->d_len_all.p; sa.cc_off = B.cc_off.p; sa.cc = B.cc.p;
+	sa.ol = B.ol.p; sa.g_off = B.g_off.p; sa.ch_base = B.ch_base.p; sa.cl_base = B.cl_base.p; sa.cd = B.cd.p; sa.hits = B.hits.p; sa.ohits = B.ohits.p; sa.n_sel = n; sa.rid_lo = glo; sa.len = c->d_len_all.p; sa.cc_off = B.cc_off.p; sa.cc = B.cc.p;
 	sa.perm = B.perm.p; sa.n_final = B.n_final.p; sa.fc_final = B.fc_final.p; sa.max_n_chain = par.max_n_chain; sa.ocv_w = par.ocv_w; sa.chain_cutoff = par.chain_cutoff;
 	sa.dbg = nullptr; sa.dbg_seq_prune = c->sw.seq_prune ? 1 : 0;
 	if (c->sw.selphase) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); sa.dbg = B.dbgbuf.p; }
@@ -225,28 +309,54 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		hipLaunchKernelGGL((chain_select_kernel<1, 1024>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)1025, (int64_t)INT64_MAX);
 	}
 	HAO_CHECK_LAUNCH();
-	if (int rc = hao_scan_u32(c, B.n_final.p, B.fin_off.p, n + 1)) return rc;
+	if (int rc = hao_scan_u32(c, B.n_final.p, B.O().fin_off.p, n + 1)) return rc;
 	if (int rc = hao_excl_scan_u64(c, B.fc_final.p, B.fcf_off.p, n + 1)) return rc;
 	if (sa.dbg) { unsigned long long d_[5]; HIP_TRY(hipMemcpy(d_, B.dbgbuf.p, 40, hipMemcpyDeviceToHost)); if (d_[4]) fprintf(stderr, "[select] reads %llu  avg us: score sort %.1f  prune %.1f  position sort %.1f  weak filter %.1f\n", d_[4], d_[0] / 100.0 / d_[4], d_[1] / 100.0 / d_[4], d_[2] / 100.0 / d_[4], d_[3] / 100.0 / d_[4]); }
 	c->timer.mark("q_select");
-	HIP_TRY(B.ol_out.reserve(NCmax + 1)); HIP_TRY(B.fc_out.reserve(FCmax + 1)); HIP_TRY(B.fc_out_off.reserve(NCmax + 2));
+	HIP_TRY(B.O().ol_out.reserve(NCmax + 1)); HIP_TRY(B.O().fc_out.reserve(FCmax + 1)); HIP_TRY(B.O().fc_out_off.reserve(NCmax + 2));
 	hipLaunchKernelGGL(chain_final_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, B.ol.p, B.ol_fc_off.p, B.fc_raw.p, B.perm.p, B.g_off.p, B.ch_base.p,
-					   B.fin_off.p, B.fcf_off.p, n, B.ol_out.p, B.fc_out.p, B.fc_out_off.p);
+					   B.O().fin_off.p, B.fcf_off.p, n, B.O().ol_out.p, B.O().fc_out.p, B.O().fc_out_off.p);
 	HAO_CHECK_LAUNCH();
 	c->timer.mark("q_final");
 	HIP_TRY(hipMemcpyAsync(&B.n_chains, B.ch_base.p + G, 8, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipMemcpyAsync(&B.n_cl, B.cl_base.p + G, 8, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipMemcpyAsync(&B.n_fc_raw, B.fc_base.p + G * HAO_MCOPY_MAX, 8, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipMemcpyAsync(&B.n_ol, B.fin_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipMemcpyAsync(&B.n_ol, B.O().fin_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipMemcpyAsync(&B.n_fc, B.fcf_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
-	unsigned long long slow_st[HAO_NCLS + 4];
+	unsigned long long slow_st[HAO_NCLS + 4], n_exc = 0;
 	HIP_TRY(hipMemcpyAsync(slow_st, d_slow_cnt, (HAO_NCLS + 4) * 8, hipMemcpyDeviceToHost, c->stream));
+	if (parts & HAO_DELIVER_CL) HIP_TRY(hipMemcpyAsync(&n_exc, d_exc_cnt, 8, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	if ((parts & HAO_DELIVER_CL) && n_exc > pa.exc_cap) {      // more verbatim hits than the list holds: grow it and pack again (the sources are untouched)
+		HIP_TRY(B.O().exc.reserve(n_exc + 1024)); pa.exc = B.O().exc.p; pa.exc_cap = B.O().exc.cap;
+		HIP_TRY(hipMemsetAsync(d_exc_cnt, 0, 8, c->stream));
+		hipLaunchKernelGGL(hao_pack_chains_kernel, dim3((unsigned)((NCmax + 3) / 4)), dim3(256), 0, c->stream, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH();
+		HIP_TRY(hipMemcpyAsync(&n_exc, d_exc_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+	}
+	B.n_exc = n_exc;
 	B.n_generic = 0; for (int x = 0; x < HAO_NCLS; ++x) B.n_generic += slow_st[x];
 	B.n_generic_hits = slow_st[HAO_NCLS];
 	if (c->sw.dp_stats) { fprintf(stderr, "[dp] slow groups by class:"); for (int x = 0; x < HAO_NCLS; ++x) fprintf(stderr, " %llu/%llu", slow_st[x], cls_cnt[x]);
 		fprintf(stderr, "  hits %llu  dp range %llu  spec-committed %llu  spec-failures %llu\n", slow_st[HAO_NCLS], slow_st[HAO_NCLS + 3], slow_st[HAO_NCLS + 1], slow_st[HAO_NCLS + 2]); }
 	B.valid = true;
+	if (parts) return hao_deliver_enqueue(c);
+	return HAO_OK;
+}
+
+// cl->list of the batch as tagged k_mer_hits in HBM: built on demand from the chain descriptors (the blocking fetch API and the digests read it;
+// the streaming delivery path packs straight from the descriptors and never needs it)
+static int hao_batch_materialize_cl(hao_ctx *c)
+{
+	hao_ctx::Batch &B = *c->batch;
+	if (B.cl_valid) return HAO_OK;
+	HIP_TRY(B.cl.reserve(B.n_cl + 1));
+	if (B.n_chains) {
+		hipLaunchKernelGGL(chain_materialize_kernel, dim3((unsigned)((B.n_chains + 3) / 4)), dim3(256), 0, c->stream, B.cd.p, B.n_chains, B.hits.p, B.ohits.p, B.cl.p);
+		HAO_CHECK_LAUNCH();
+		HIP_TRY(hipStreamSynchronize(c->stream));
+	}
+	B.cl_valid = true;
 	return HAO_OK;
 }
 
@@ -255,12 +365,13 @@ static int hao_batch_download(hao_ctx *c)
 {
 	hao_ctx::Batch &B = *c->batch;
 	if (B.host_valid) return HAO_OK;
+	if (int rc = hao_batch_materialize_cl(c)) return rc;
 	const uint64_t n = B.n;
 	B.h_seg.assign(n + 1, 0); B.h_fin_off.assign(n + 1, 0); B.h_cl_off.assign(n + 1, 0);
 	B.h_hits.resize(B.n_anchor); B.h_cl.resize(B.n_cl); B.h_ol.resize(B.n_ol); B.h_fc.resize(B.n_fc); B.h_fc_out_off.assign(B.n_ol + 1, 0);
 	if (n) {
 		HIP_TRY(hipMemcpy(B.h_seg.data(), B.seg.p, (n + 1) * 8, hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemcpy(B.h_fin_off.data(), B.fin_off.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(B.h_fin_off.data(), B.O().fin_off.p, (n + 1) * 8, hipMemcpyDeviceToHost));
 		std::vector<uint64_t> goff(n + 1), clb(B.n_groups + 1);
 		HIP_TRY(hipMemcpy(goff.data(), B.g_off.p, (n + 1) * 8, hipMemcpyDeviceToHost));
 		HIP_TRY(hipMemcpy(clb.data(), B.cl_base.p, (B.n_groups + 1) * 8, hipMemcpyDeviceToHost));
@@ -269,11 +380,11 @@ static int hao_batch_download(hao_ctx *c)
 	if (B.n_anchor) HIP_TRY(hipMemcpy(B.h_hits.data(), B.hits.p, B.n_anchor * sizeof(hao_hit_t), hipMemcpyDeviceToHost));
 	if (B.n_cl) HIP_TRY(hipMemcpy(B.h_cl.data(), B.cl.p, B.n_cl * sizeof(hao_hit_t), hipMemcpyDeviceToHost));
 	if (B.n_ol) {
-		HIP_TRY(hipMemcpy(B.h_ol.data(), B.ol_out.p, B.n_ol * sizeof(hao_ovlp_t), hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemcpy(B.h_fc_out_off.data(), B.fc_out_off.p, B.n_ol * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(B.h_ol.data(), B.O().ol_out.p, B.n_ol * sizeof(hao_ovlp_t), hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(B.h_fc_out_off.data(), B.O().fc_out_off.p, B.n_ol * 8, hipMemcpyDeviceToHost));
 	}
 	B.h_fc_out_off[B.n_ol] = B.n_fc;
-	if (B.n_fc) HIP_TRY(hipMemcpy(B.h_fc.data(), B.fc_out.p, B.n_fc * 8, hipMemcpyDeviceToHost));
+	if (B.n_fc) HIP_TRY(hipMemcpy(B.h_fc.data(), B.O().fc_out.p, B.n_fc * 8, hipMemcpyDeviceToHost));
 	B.host_valid = true;
 	return HAO_OK;
 }

@@ -118,6 +118,53 @@ int hao_overlap_batch_ex(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi, const hao
 	return HAO_OK;
 }
 
+int hao_overlap_batch_async(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi, const hao_pass_t *pass, uint32_t parts, int *slot)
+{
+	if (!c || rid_lo > rid_hi || rid_hi > c->n_reads || !(parts & (HAO_DELIVER_OL | HAO_DELIVER_CL))) return HAO_EINVAL;
+	hao_pass_t ps;
+	if (!pass) { if (int rc = hao_pass_default(c, &ps)) return rc; pass = &ps; }
+	HIP_TRY(hipSetDevice(c->device));
+	c->timer.begin(c->stream);
+	int rc = hao_overlap_run(c, rid_lo, rid_hi, *pass, parts, slot);
+	if (rc != HAO_OK) return rc;
+	c->timer.collect(c->stage_ms);      // (the batch's kernels are complete: hao_overlap_run ends with the read-back of its totals; only the copy is still running)
+	return HAO_OK;
+}
+
+int hao_deliver_wait(hao_ctx *c, int slot, hao_delivery_t *out)
+{
+	if (!c || !out || slot < 0 || slot > 1 || !c->batch || !c->batch->dl_ready) return HAO_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	hao_ctx::Batch &B = *c->batch;
+	if (B.dl_pending[slot]) { HIP_TRY(hipEventSynchronize(B.ev_done[slot])); B.dl_pending[slot] = false; }
+	*out = B.dl[slot];
+	return HAO_OK;
+}
+
+// pure function of a delivered view (any thread): the wire words of read rid back into k_mer_hits (hao_deliver.cuh describes the format)
+uint64_t hao_unpack_hits(const hao_delivery_t *d, uint64_t rid, hao_hit_t *out, uint64_t cap)
+{
+	if (!d || rid < d->rid_lo || rid >= d->rid_lo + d->n_reads || !d->cl_off) return 0;
+	const uint64_t r = rid - d->rid_lo, h0 = d->cl_off[r], nh = d->cl_off[r + 1] - h0;
+	if (nh > cap || !out) return nh;
+	uint64_t k = 0;
+	for (uint64_t ci = d->ch_off[r]; ci < d->ch_off[r + 1]; ++ci) {
+		const hao_chain_hdr_t &H = d->chains[ci];
+		uint32_t off = H.offset, self = H.self_offset; const uint32_t *w = d->cl_words + h0 + k;
+		for (uint32_t i = 0; i < H.n_hits; ++i) {
+			const uint32_t x = w[i]; hao_hit_t &o = out[k + i];
+			if (x >> 31) { o = d->cl_exc[x & 0x7fffffffu]; off = o.offset; self = o.self_offset; }
+			else {
+				const uint32_t ds = x & 0x1fffu; const int32_t dd = (int32_t)(x >> 13 & 0x7fu) - 64;
+				self += ds; off = (uint32_t)((int64_t)off + (int64_t)ds + dd);
+				o.w0 = H.w0; o.offset = off; o.self_offset = self; o.cnt = (x >> 28 & 7u) << 8 | (x >> 20 & 0xffu);
+			}
+		}
+		k += H.n_hits;
+	}
+	return k;
+}
+
 int hao_fetch_seed_hits(hao_ctx *c, uint64_t rid, const hao_hit_t **hits, uint64_t *n)
 {
 	if (!c || !c->batch || !c->batch->valid || rid < c->batch->lo || rid >= c->batch->lo + c->batch->n) return HAO_EINVAL;
@@ -155,10 +202,11 @@ int hao_batch_digest(hao_ctx *c, uint64_t *out, uint64_t *out_kh)
 	HIP_TRY(hipSetDevice(c->device));
 	hao_ctx::Batch &B = *c->batch; const uint64_t n = B.n;
 	if (n == 0) return HAO_OK;
+	if (int rc = hao_batch_materialize_cl(c)) return rc;
 	DevBuf<uint64_t> d; HIP_TRY(d.reserve(2 * n + 2));
 	hao_digest_args a;
-	a.fin_off = B.fin_off.p; a.fcf_off = B.fcf_off.p; a.g_off = B.g_off.p; a.cl_base = B.cl_base.p; a.seg = B.seg.p;
-	a.ol = (const uint64_t*)B.ol_out.p; a.fc = B.fc_out.p; a.cl = (const uint64_t*)B.cl.p; a.hits = (const uint64_t*)B.hits.p;
+	a.fin_off = B.O().fin_off.p; a.fcf_off = B.fcf_off.p; a.g_off = B.g_off.p; a.cl_base = B.cl_base.p; a.seg = B.seg.p;
+	a.ol = (const uint64_t*)B.O().ol_out.p; a.fc = B.O().fc_out.p; a.cl = (const uint64_t*)B.cl.p; a.hits = (const uint64_t*)B.hits.p;
 	a.n_sel = n; a.dig = d.p; a.dig_kh = out_kh ? d.p + n : nullptr;
 	hipLaunchKernelGGL(hao_digest_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, a);
 	HAO_CHECK_LAUNCH();

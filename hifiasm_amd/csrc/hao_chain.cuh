@@ -777,11 +777,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 // Assembly: per group, materialise overlap records (creation order), chained hits (tagged with
 // the overlap ordinal inside the read) and fake cigars.  One wave per group.
 // ---------------------------------------------------------------------------------------
+// Where a chain's hits live.  Chained hits are NOT copied when the records are assembled: > 99.9 % of the chains of clean data are contiguous runs of
+// the sorted seed hits (in_place), the rest were compacted by the DP kernel into ohits.  cl->list (the hits tagged with the chain's ordinal, in chain
+// order) exists only as this descriptor until somebody needs the bytes: the wire packer of the delivery path (hao_deliver.cuh) or
+// chain_materialize_kernel (blocking fetch API, digests).  The ordinal tag of lchain_qdp_mcopy_fast's output (Hash_Table.cpp:2272-2281) travels as w0.
+struct hao_cdesc {
+	uint64_t src;      // index of the first hit; bit 63 set: in ohits, else in hits
+	uint64_t dst;      // index of the chain's first hit in the batch's cl->list concatenation
+	uint32_t n, w0;    // hits; readID field of every hit of the chain = ordinal << 0 | strand << 31
+};
+#define HAO_CD_OHITS (1ULL << 63)
+__device__ __forceinline__ const hao_hit_t *hao_cd_src(const hao_cdesc &d, const hao_hit_t *hits, const hao_hit_t *ohits)
+{ return ((d.src & HAO_CD_OHITS) ? ohits : hits) + (d.src & ~HAO_CD_OHITS); }
+
 struct hao_asm_args {
 	const uint64_t *g_start; const uint32_t *g_read; const uint8_t *g_cls; const uint64_t *g_off; uint64_t n_groups; uint64_t rid_lo;
 	const hao_hit_t *ohits, *hits; const uint64_t *fcs; const hao_chain_rec *rec; const uint32_t *nch;
 	const uint64_t *ch_base, *cl_base, *fc_base;   // exclusive scans over groups (chains, hits) and over chain slots (fake-cigar entries)
-	hao_ovlp_t *ol; uint64_t *ol_fc_off; hao_hit_t *cl; uint64_t *fc;
+	hao_ovlp_t *ol; uint64_t *ol_fc_off; hao_cdesc *cd; uint64_t *fc;
 };
 
 // one wave per group, in group order (chained hits of a read are written front to back); the tiny class has its own kernel
@@ -804,17 +817,27 @@ __global__ __launch_bounds__(256) void chain_assemble_kernel(hao_asm_args A)
 			o.y_id = HH_ID(src[0]); o.y_pos_s = rc.y_pos_s; o.y_pos_e = rc.y_pos_e; o.y_pos_strand = rc.strand;
 			o.shared_seed = rc.score; o.align_length = rc.n_hits; o.non_homopolymer_errors = (uint32_t)(hd - cl0); o.fc_len = rc.fc_len;
 			A.ol[oi] = o; A.ol_fc_off[oi] = fd;
-		}
-		typedef uint32_t hao_u32x4 __attribute__((ext_vector_type(4)));
-		const hao_u32x4 *src4 = (const hao_u32x4*)src; hao_u32x4 *dst4 = (hao_u32x4*)(A.cl + hd);
-		for (uint32_t i = hao_lane(); i < rc.n_hits; i += 256) {       // four 16-byte loads in flight per lane; streamed once in, once out: non-temporal
-			hao_u32x4 h4[4];
-#pragma unroll
-			for (int u = 0; u < 4; ++u) if (i + u * 64 < rc.n_hits) h4[u] = __builtin_nontemporal_load(src4 + i + u * 64);
-#pragma unroll
-			for (int u = 0; u < 4; ++u) if (i + u * 64 < rc.n_hits) { h4[u].x = (h4[u].x & 0x80000000u) | (ord & 0x7fffffffu); __builtin_nontemporal_store(h4[u], dst4 + i + u * 64); }
+			hao_cdesc d; d.src = (A.g_start[g] + rc.src_rel) | (rc.in_place ? 0 : HAO_CD_OHITS); d.dst = hd; d.n = rc.n_hits; d.w0 = (rc.strand << 31) | (ord & 0x7fffffffu);
+			A.cd[oi] = d;
 		}
 		for (uint32_t i = hao_lane(); i < rc.fc_len; i += 64) A.fc[fd + i] = fsrc[rc.fc_rel + i];
+	}
+}
+
+// cl->list of the batch as plain tagged k_mer_hits (blocking fetch API, digests): one wave per chain, streamed once in, once out (non-temporal)
+__global__ __launch_bounds__(256) void chain_materialize_kernel(const hao_cdesc *cd, uint64_t n_chains, const hao_hit_t *hits, const hao_hit_t *ohits, hao_hit_t *cl)
+{
+	const uint64_t ci = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (ci >= n_chains) return;
+	const hao_cdesc d = cd[ci];
+	typedef uint32_t hao_u32x4 __attribute__((ext_vector_type(4)));
+	const hao_u32x4 *src4 = (const hao_u32x4*)hao_cd_src(d, hits, ohits); hao_u32x4 *dst4 = (hao_u32x4*)(cl + d.dst);
+	for (uint32_t i = hao_lane(); i < d.n; i += 256) {       // four 16-byte loads in flight per lane
+		hao_u32x4 h4[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) if (i + u * 64 < d.n) h4[u] = __builtin_nontemporal_load(src4 + i + u * 64);
+#pragma unroll
+		for (int u = 0; u < 4; ++u) if (i + u * 64 < d.n) { h4[u].x = d.w0; __builtin_nontemporal_store(h4[u], dst4 + i + u * 64); }
 	}
 }
 
@@ -837,7 +860,8 @@ __global__ __launch_bounds__(64) void chain_assemble_tiny_kernel(hao_asm_args A,
 		o.y_id = e.yid; o.y_pos_s = rc.y_pos_s; o.y_pos_e = rc.y_pos_e; o.y_pos_strand = rc.strand;
 		o.shared_seed = rc.score; o.align_length = rc.n_hits; o.non_homopolymer_errors = (uint32_t)(hd - cl0); o.fc_len = rc.fc_len;
 		A.ol[oi] = o; A.ol_fc_off[oi] = fd;
-		for (uint32_t i = 0; i < rc.n_hits; ++i) { hao_hit_t h = src[i]; h.w0 = (h.w0 & 0x80000000u) | (ord & 0x7fffffffu); A.cl[hd + i] = h; }
+		hao_cdesc d; d.src = (e.start + rc.src_rel) | (rc.in_place ? 0 : HAO_CD_OHITS); d.dst = hd; d.n = rc.n_hits; d.w0 = (rc.strand << 31) | (ord & 0x7fffffffu);
+		A.cd[oi] = d;
 		for (uint32_t i = 0; i < rc.fc_len; ++i) A.fc[fd + i] = fsrc[rc.fc_rel + i];
 	}
 }
@@ -1165,7 +1189,7 @@ __device__ void hao_cov_add(uint64_t *cc, uint64_t cwn, uint64_t ocv_w, uint64_t
 }
 
 struct hao_sel_args {
-	const hao_ovlp_t *ol; const uint64_t *g_off; const uint64_t *ch_base; const uint64_t *cl_base; const hao_hit_t *cl;
+	const hao_ovlp_t *ol; const uint64_t *g_off; const uint64_t *ch_base; const uint64_t *cl_base; const hao_cdesc *cd; const hao_hit_t *hits, *ohits;
 	uint64_t n_sel, rid_lo; const uint32_t *len; const uint64_t *cc_off; uint64_t *cc;
 	uint64_t *key_xs; int32_t *key_sc; uint32_t *key_al, *key_tmp;   // global key scratch (reads with more chains than the LDS slice holds); key_tmp: 5 words per chain
 	uint32_t *perm; uint32_t *n_final; uint64_t *fc_final;        // outputs: permutation (per read slice), kept count, kept fake-cigar entries
@@ -1332,7 +1356,7 @@ __device__ int64_t hao_select_prune_wave(const hao_sel_args &A, const hao_sel_ct
 // weak-chain filter (anchor.cpp:2061-2096), whole wave: control flow is uniform (keys in LDS), the count of a strong
 // chain's hits inside the overlap interval is a strided wave reduction (the reference stops counting at ocn; only
 // "count >= ocn" is observable), permutation swaps by lane 0.
-__device__ int64_t hao_select_weak(const hao_sel_args &A, const hao_sel_ctx &S, int64_t n, const hao_ovlp_t *rec, const hao_hit_t *cl, uint64_t cn)
+__device__ int64_t hao_select_weak(const hao_sel_args &A, const hao_sel_ctx &S, int64_t n, const hao_ovlp_t *rec, const hao_cdesc *cd)
 {
 	const uint32_t chain_cutoff = A.chain_cutoff; const int lane = hao_lane();
 #define XS(i) S.xs[S.pm[i]]
@@ -1376,11 +1400,11 @@ __device__ int64_t hao_select_weak(const hao_sel_args &A, const hao_sel_ctx &S, 
 					const int l = __ffsll((long long)cm) - 1; cm &= cm - 1;
 					if (l >= nin) break;
 					const uint32_t cc_ = (uint32_t)__shfl((int)ci, l); const uint64_t cos = __shfl(os, l), coe = __shfl(oe, l);
-					const uint64_t m0 = rec[cc_].non_homopolymer_errors, nh = S.al[cc_];    // the chain's hits: cl[m0 .. m0+nh) share one ordinal tag
+					const hao_hit_t *ch = hao_cd_src(cd[cc_], A.hits, A.ohits); const uint64_t nh = S.al[cc_];    // the chain's hits (the run of cl->list with its ordinal tag)
 					uint64_t kn = 0;
 					for (uint64_t b = 0; b < nh && kn < ocn; b += 64) {
-						uint64_t mm = m0 + b + lane; bool in = false;
-						if (b + lane < nh && mm < cn) { uint64_t me = cl[mm].self_offset, ms = me - (cl[mm].cnt & 0xffu); in = ms >= cos && me <= coe; }
+						bool in = false;
+						if (b + lane < nh) { uint64_t me = ch[b + lane].self_offset, ms = me - (ch[b + lane].cnt & 0xffu); in = ms >= cos && me <= coe; }
 						kn += __popcll(__ballot(in));
 					}
 					if (kn >= ocn) { covered = true; break; }
@@ -1437,7 +1461,7 @@ __device__ __forceinline__ void hao_select_body(const hao_sel_args &A, const uin
 	hao_wave_intro_sort<1>(S, nf);
 	__threadfence_block();
 	tk3 = A.dbg ? wall_clock64() : 0;
-	if (lch2) nf = hao_select_weak(A, S, nf, rec, A.cl + cl0, cn);
+	if (lch2) nf = hao_select_weak(A, S, nf, rec, A.cd + o0);
 	__threadfence_block();
 	if (A.dbg && lane == 0) { tk4 = wall_clock64(); atomicAdd(A.dbg, tk1 - tk0); atomicAdd(A.dbg + 1, tk2 - tk1); atomicAdd(A.dbg + 2, tk3 - tk2); atomicAdd(A.dbg + 3, tk4 - tk3); atomicAdd(A.dbg + 4, 1ULL); }
 	uint64_t fct = 0;
@@ -1508,7 +1532,7 @@ __global__ __launch_bounds__(256) void chain_select4_kernel(hao_sel_args A, int6
 	hao_block_intro_sort<1, 4>(S, nf, l_segs, l_segn, &l_flag);
 	__syncthreads();
 	if (wv != 0) return;
-	if (lch2) nf = hao_select_weak(A, S, nf, rec, A.cl + cl0, cn);
+	if (lch2) nf = hao_select_weak(A, S, nf, rec, A.cd + o0);
 	__threadfence_block();
 	uint64_t fct = 0;
 	for (int64_t i = lane; i < nf; i += 64) { const uint32_t pi = l_pm[i]; A.perm[o0 + i] = pi; fct += rec[pi].fc_len; }

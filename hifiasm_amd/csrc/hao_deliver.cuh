@@ -1,6 +1,7 @@
 // Result delivery kernels: per-read digests of a batch's results (integrity check across the boundary / full-size parity tests).
 #pragma once
 #include "hao_common.cuh"
+#include "hao_chain.cuh"
 
 // ---------------------------------------------------------------------------------------
 // hao_batch_digest (include/hao.h).  Per read r:
@@ -46,4 +47,63 @@ __global__ __launch_bounds__(256) void hao_digest_kernel(hao_digest_args A)
 		A.dig[r] = part[0][0] + part[0][1] + part[0][2] + part[0][3];
 		if (A.dig_kh) A.dig_kh[r] = part[1][0] + part[1][1] + part[1][2] + part[1][3];
 	}
+}
+
+// ---------------------------------------------------------------------------------------
+// Wire format of cl->list (include/hao.h, hao_chain_hdr_t / hao_unpack_hits).  A chain's hits are colinear and share their readID
+// word, so a 16-byte k_mer_hit travels as ONE 32-bit word relative to its predecessor in the chain:
+//     bits  0..12  self_offset - previous self_offset                       (0 .. 8191)
+//     bits 13..19  (offset - previous offset) - (self_offset delta) + 64    (diagonal shift -64 .. 63)
+//     bits 20..27  cnt & 0xff   (k-mer span)
+//     bits 28..30  cnt >> 8     (seed weight 0 .. 7)
+//     bit  31      0
+// or, when any field does not fit:  bit 31 = 1, bits 0..30 = index of the verbatim k_mer_hit in the batch's exception list.
+// The first hit of a chain is relative to the (offset, self_offset) stored in the chain header.  4 bytes per chained hit instead of 16
+// across PCIe; the consumer thread decodes straight into its Candidates_list (one pass, no intermediate copy).
+// One wave per chain; reads the hits where the chain kernels left them (chain descriptors), so cl->list is never materialised in HBM.
+// ---------------------------------------------------------------------------------------
+struct hao_pack_args {
+	const hao_cdesc *cd; uint64_t n_chains; const hao_hit_t *hits, *ohits;
+	hao_chain_hdr_t *hdr; uint32_t *words; hao_hit_t *exc; unsigned long long *exc_cnt; uint64_t exc_cap;
+};
+
+__global__ __launch_bounds__(256) void hao_pack_chains_kernel(hao_pack_args A, const uint64_t *n_chains_dev)
+{
+	const uint64_t ci = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (ci >= *n_chains_dev) return;      // launched over the host-side bound (3 chains per group)
+	const int lane = hao_lane();
+	const hao_cdesc d = A.cd[ci];
+	const hao_hit_t *src = hao_cd_src(d, A.hits, A.ohits);
+	if (lane == 0) { hao_chain_hdr_t h; h.n_hits = d.n; h.w0 = d.w0; h.offset = d.n ? src[0].offset : 0; h.self_offset = d.n ? src[0].self_offset : 0; A.hdr[ci] = h; }
+	for (uint32_t b = 0; b < d.n; b += 64) {
+		const uint32_t i = b + lane; const bool act = i < d.n;
+		hao_hit_t h, p; uint32_t w = 0; bool esc = false;
+		if (act) {
+			h = src[i]; p = i ? src[i - 1] : h;
+			const int64_t ds = (int64_t)h.self_offset - (int64_t)p.self_offset, dd = ((int64_t)h.offset - (int64_t)p.offset) - ds;
+			esc = ds < 0 || ds > 8191 || dd < -64 || dd > 63 || (h.cnt >> 8) > 7;
+			w = (uint32_t)ds | (uint32_t)(dd + 64) << 13 | (h.cnt & 0xffu) << 20 | (h.cnt >> 8) << 28;
+		}
+		const unsigned long long em = __ballot(act && esc);
+		if (em) {
+			unsigned long long base = 0;
+			if (lane == 0) base = atomicAdd(A.exc_cnt, (unsigned long long)__popcll(em));
+			base = (unsigned long long)hao_readlane_i64((int64_t)base, 0);
+			if (act && esc) {
+				const uint64_t k = base + __popcll(em & ((1ULL << lane) - 1));
+				if (k < A.exc_cap) { h.w0 = d.w0; A.exc[k] = h; }      // past the capacity only the count matters: the host grows the list and packs again
+				w = 0x80000000u | (uint32_t)(k & 0x7fffffffu);
+			}
+		}
+		if (act) A.words[d.dst + i] = w;
+	}
+}
+
+// per read: first chain / first hit of the read in the batch (ranges of the headers and of the packed words)
+__global__ void hao_read_ranges_kernel(const uint64_t *g_off, const uint64_t *ch_base, const uint64_t *cl_base, uint64_t n_sel, uint64_t *ch_off, uint64_t *cl_off)
+{
+	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r > n_sel) return;
+	const uint64_t g = g_off[r];
+	ch_off[r] = ch_base[g]; cl_off[r] = cl_base[g];
 }

@@ -149,6 +149,33 @@ int hao_fetch_overlaps(hao_ctx *c, uint64_t rid, const hao_ovlp_t **ol, uint64_t
  * out[3] = chain groups, out[4] = minimizers of the query reads */
 int hao_batch_totals(hao_ctx *c, uint64_t out[8]);
 
+/* ---- streaming result delivery: results of batch i cross PCIe while batch i + 1 computes ----
+ * h_ec_lchain hands ol->list and cl->list back to a per-read caller (anchor.cpp:2302; consumed by gen_hc_r_alin_ea, ecovlp.cpp:3288).  A batch's
+ * results are ~190 KB per 15 kb read, almost all of it cl->list, so the delivery path (a) ships cl->list in a 4-byte-per-hit wire format that the
+ * consumer thread decodes straight into its Candidates_list (hao_unpack_hits), (b) copies into one of two pinned host arenas on a copy stream, under
+ * the next batch's kernels.  hao_overlap_batch_async returns when the batch's kernels are done and its copy is queued; hao_deliver_wait blocks until
+ * the copy has landed and describes the arena.  A slot's arena (and the device buffers behind it) is reused by the second-next async batch: at most
+ * two batches are in flight, and the caller must be done with batch i before it starts batch i + 2.  The views are read-only and may be read by any
+ * number of threads; hao_unpack_hits is a pure function of the view. */
+#define HAO_DELIVER_OL 1u      /* ol->list + fake cigars */
+#define HAO_DELIVER_CL 2u      /* cl->list (wire format) */
+typedef struct { uint32_t n_hits, w0, offset, self_offset; } hao_chain_hdr_t;      /* one chain of cl->list: hit count, the readID word its hits share, first hit's coordinates */
+typedef struct {
+	uint64_t rid_lo, n_reads, n_ol, n_fc, n_chains, n_cl, n_exc, bytes;            /* bytes = what crossed PCIe for this batch */
+	const uint64_t *ol_off;          /* [n_reads + 1]: ol->list of read r = ol[ol_off[r] .. ol_off[r + 1]) */
+	const hao_ovlp_t *ol;
+	const uint64_t *fc_off;          /* [n_ol + 1]: fake cigar of overlap j = fc[fc_off[j] .. fc_off[j + 1]) */
+	const uint64_t *fc;
+	const uint64_t *ch_off, *cl_off; /* [n_reads + 1]: chains / hits of read r = chains[ch_off[r] ..), cl_words[cl_off[r] ..) */
+	const hao_chain_hdr_t *chains;
+	const uint32_t *cl_words;        /* one word per hit: self_offset delta:13 | diagonal shift + 64:7 | span:8 | weight:3 | 0, or 1 << 31 | index into cl_exc */
+	const hao_hit_t *cl_exc;         /* hits whose deltas do not fit a word, verbatim */
+} hao_delivery_t;
+int hao_overlap_batch_async(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi, const hao_pass_t *pass /* NULL: hao_pass_default */, uint32_t parts, int *slot);
+int hao_deliver_wait(hao_ctx *c, int slot, hao_delivery_t *out);
+/* cl->list of read rid (a read of the delivered batch) decoded into out[cap]; returns the number of hits (nothing is written if cap is too small) */
+uint64_t hao_unpack_hits(const hao_delivery_t *d, uint64_t rid, hao_hit_t *out, uint64_t cap);
+
 /* Per-read digests of the last batch's results, computed on the device (one workgroup per read) and copied to out[n] / out_kh[n]
  * (n = reads of the batch; out_kh may be NULL):
  *   out[r]    = sum of term(1, i, w) over the 64-bit words of ol->list (6 per overlap_region: the 12 u32 fields of hao_ovlp_t)

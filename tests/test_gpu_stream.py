@@ -1,0 +1,87 @@
+"""Streaming delivery (hao_overlap_batch_async / hao_deliver_wait / hao_unpack_hits): what lands in the pinned host arenas - ol->list, fake cigars
+and cl->list through the 4-byte wire format - must be bit-identical to the oracle, for every read, with two batches in flight, with the
+verbatim-hit list overflowing (grow-and-repack path), and interleaved with the blocking API."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import scenario_reads, scenario_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    return all(x.shape == y.shape and (x == y).all() for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("name", ["hifi", "rr", "ont", "edge", "rr_heavy", "long200k"])
+def test_delivered_results_equal_the_oracle(name):
+    from hifiasm_amd.api import Engine
+    rs, okw = scenario_reads(name)
+    o = scenario_oracle(name)
+    e = Engine(0, **okw)
+    e.set_readset(rs)
+    e.ha_ft_gen(); e.ha_pt_gen()
+    cuts = [0, rs.n // 3, rs.n // 3, rs.n // 2 + 1, rs.n]          # includes an empty batch
+    pending, bad, n_exc, n_cl = None, [], 0, 0
+
+    def check(slot, lo, hi):
+        nonlocal n_exc, n_cl
+        d = e.deliver_wait(slot)
+        assert (d.rid_lo, d.n_reads) == (lo, hi - lo)
+        n_exc += d.n_exc; n_cl += d.n_cl
+        for r in range(lo, hi):
+            if not _same(e.delivered_read(d, r), o.lchain(r)):
+                bad.append(r)
+
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        slot = e.overlap_batch_async(lo, hi)
+        if pending:                       # the previous batch is consumed while this one's copy is (possibly still) in flight
+            check(*pending)
+        pending = (slot, lo, hi)
+    check(*pending)
+    assert not bad, bad[:10]
+    assert n_cl > 0
+    # the blocking API afterwards (same engine) still serves the same bytes
+    e.overlap_batch(0, rs.n)
+    for r in range(0, rs.n, 7):
+        assert _same(e.h_ec_lchain(r), o.lchain(r)), r
+    e.close()
+    print(f"[stream] {name}: {n_cl} chained hits, {n_exc} verbatim ({100.0 * n_exc / max(1, n_cl):.3f} %)")
+
+
+def test_exception_list_overflow_repacks():
+    from hifiasm_amd.api import Engine
+    os.environ["HAO_DBG_EXC_CAP"] = "3"
+    try:
+        rs, okw = scenario_reads("ont")
+        o = scenario_oracle("ont")
+        e = Engine(0, **okw)
+        e.set_readset(rs)
+        e.ha_ft_gen(); e.ha_pt_gen()
+        d = e.deliver_wait(e.overlap_batch_async(0, rs.n))
+        assert d.n_exc > 3                         # 1 % error reads do produce shifts beyond +-64: the list had to grow
+        for r in range(rs.n):
+            assert _same(e.delivered_read(d, r), o.lchain(r)), r
+        e.close()
+    finally:
+        del os.environ["HAO_DBG_EXC_CAP"]
+
+
+def test_ol_only_delivery():
+    """the final round needs ol->list only (h_ec_lchain_fast_new reads no chained hits, ecovlp.cpp:5047): cl->list is neither packed nor copied"""
+    from hifiasm_amd.api import Engine, DELIVER_OL
+    rs, okw = scenario_reads("hifi")
+    o = scenario_oracle("hifi")
+    e = Engine(0, **okw)
+    e.set_readset(rs)
+    e.ha_ft_gen(); e.ha_pt_gen()
+    d = e.deliver_wait(e.overlap_batch_async(0, rs.n, parts=DELIVER_OL))
+    assert d.n_cl == 0 and d.n_ol > 0 and d.bytes < 200 * d.n_ol
+    from hifiasm_amd.api import _arr
+    off = _arr(d.ol_off, rs.n + 1, np.uint64)
+    for r in range(rs.n):
+        ol = _arr(d.ol + 48 * int(off[r]), 12 * int(off[r + 1] - off[r]), np.uint32).reshape(-1, 12)
+        assert (ol == o.lchain(r)[0]).all(), r
+    e.close()
