@@ -47,7 +47,7 @@ ALG = {
 KERN_STAGE = {"sketch_chunk_wave_kernel": "sk_chunks", "chain_group_kernel": "q_chain", "chain_assemble_kernel": "q_assemble",
               "seed_bin_kernel": "q_sort_bins"}
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
-VALU_PEAK_GINST = 256 * 4 * 2.4      # wave-level VALU instructions per ns: 256 CUs x 4 SIMDs x 1 issue/cycle x 2.4 GHz
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2      # G wave-level VALU instructions / s: 256 CUs x 4 SIMD-32 x 2.4 GHz, a wave64 instruction issues over 2 cycles (MI355X_MICROARCH.md)
 
 
 def make_reads(workload, rank=0, world=1):
@@ -187,10 +187,15 @@ def main():
     def step(deliver=False):
         eng.ha_pt_gen()
         st = {k: v for k, v in eng.stage_times()}
-        tot = {"overlaps": 0, "chained_hits": 0, "seed_hits": 0, "groups": 0, "minimizers": 0, "seq_groups": 0, "seq_group_hits": 0, "host_bytes": 0}
+        tot = {"overlaps": 0, "chained_hits": 0, "seed_hits": 0, "groups": 0, "minimizers": 0, "seq_groups": 0, "seq_group_hits": 0, "host_bytes": 0, "copy_ms": 0.0}
+        prev = None
         for lo, hi in ranges:
             if deliver:
-                eng.overlap_batch_async(lo, hi)      # compute of this batch; its download runs under the next batch
+                slot = eng.overlap_batch_async(lo, hi)      # compute of this batch; its copy runs under the next batch's kernels
+                if prev is not None:                        # the consumer takes the previous batch now (its copy ran under this batch's kernels)
+                    d = eng.deliver_wait(prev)
+                    tot["host_bytes"] += int(d.bytes); tot["copy_ms"] += float(d.copy_ms)
+                prev = slot
             else:
                 eng.overlap_batch(lo, hi)
             t = eng.batch_totals()
@@ -200,7 +205,8 @@ def main():
             for k, v in eng.stage_times():
                 st[k] = st.get(k, 0.0) + v
         if deliver:
-            tot["host_bytes"] = eng.deliver_wait()      # every batch's results are in host memory
+            d = eng.deliver_wait(prev)                      # every batch's results are in host memory
+            tot["host_bytes"] += int(d.bytes); tot["copy_ms"] += float(d.copy_ms)
         return tot, st
 
     def sync():
@@ -236,7 +242,8 @@ def main():
     boundary = None
     if not a.no_boundary and hasattr(eng, "overlap_batch_async"):
         bdt, bov, btot, _ = timed(True)
-        boundary = {"value": bov / (bdt / a.steps), "ms_per_step": bdt / a.steps * 1e3, "host_bytes_per_gpu_step": btot["host_bytes"]}
+        boundary = {"value": bov / (bdt / a.steps), "ms_per_step": bdt / a.steps * 1e3, "host_bytes_per_gpu_step": btot["host_bytes"],
+                    "copy_ms_per_step": btot["copy_ms"], "copy_gb_per_s": btot["host_bytes"] / max(1e-9, btot["copy_ms"] * 1e-3) / 1e9}
 
     if rank == 0:
         stage_ms = {k: v / a.steps for k, v in stage_sum.items()}
@@ -289,6 +296,7 @@ def main():
             "vs_baseline": None, "dtype": "u64 hashing / int32 + f64 chain scores", "data": "synthetic",
             "value_boundary": round(boundary["value"], 1) if boundary else None,
             "boundary": ({"ms_per_step": round(boundary["ms_per_step"], 3), "host_bytes_per_gpu_step": boundary["host_bytes_per_gpu_step"],
+                          "copy_ms_per_step": round(boundary["copy_ms_per_step"], 2), "copy_gb_per_s": round(boundary["copy_gb_per_s"], 2),
                           "what": "same step with every batch's ol->list, fake cigars and packed cl->list delivered into pinned host memory (double-buffered, copy stream under the next batch's compute)"}
                          if boundary else None),
             "config": {"workload": a.workload, "reads_per_gpu": n_reads, "bases_per_gpu": rs.total_bases, "batches_per_pass": len(ranges),

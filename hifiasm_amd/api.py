@@ -46,7 +46,7 @@ class Delivery(C.Structure):
     _fields_ = [("rid_lo", C.c_uint64), ("n_reads", C.c_uint64), ("n_ol", C.c_uint64), ("n_fc", C.c_uint64), ("n_chains", C.c_uint64),
                 ("n_cl", C.c_uint64), ("n_exc", C.c_uint64), ("bytes", C.c_uint64),
                 ("ol_off", C.c_void_p), ("ol", C.c_void_p), ("fc_off", C.c_void_p), ("fc", C.c_void_p), ("ch_off", C.c_void_p),
-                ("cl_off", C.c_void_p), ("chains", C.c_void_p), ("cl_words", C.c_void_p), ("cl_exc", C.c_void_p)]
+                ("cl_off", C.c_void_p), ("chains", C.c_void_p), ("cl_words", C.c_void_p), ("cl_exc", C.c_void_p), ("copy_ms", C.c_double)]
 
 
 DELIVER_OL, DELIVER_CL = 1, 2
@@ -265,7 +265,8 @@ class Engine:
 
     # ---- streaming delivery (hao_overlap_batch_async / hao_deliver_wait / hao_unpack_hits) ----
     def overlap_batch_async(self, lo, hi, parts=DELIVER_OL | DELIVER_CL, bw_thres=None):
-        """compute reads [lo, hi) and queue the copy of their results into a pinned host arena; returns the arena slot (0 / 1)"""
+        """compute reads [lo, hi) and queue the copy of their results into a pinned host arena; returns the arena slot (0 / 1).  At most two batches are
+        in flight: the slot is reused by the second-next async batch."""
         p = None
         if bw_thres is not None or self.bw_thres is not None:
             p = self.pass_default()
@@ -273,22 +274,13 @@ class Engine:
                 p.bw_thres = bw_thres
         slot = C.c_int(-1)
         self._ck(self.L.hao_overlap_batch_async(self.h, lo, hi, C.byref(p) if p is not None else None, parts, C.byref(slot)), "hao_overlap_batch_async")
-        self._slots = getattr(self, "_slots", [])
-        self._slots.append(slot.value)
         return slot.value
 
-    def deliver_wait(self, slot=None):
-        """slot given: the Delivery view of that slot (blocks until its copy has landed).  No slot: wait for every queued slot, return the bytes
-        that crossed PCIe for the batches waited on (what bench.py needs)."""
-        if slot is not None:
-            d = Delivery()
-            self._ck(self.L.hao_deliver_wait(self.h, slot, C.byref(d)), "hao_deliver_wait")
-            return d
-        tot = 0
-        for s_ in set(getattr(self, "_slots", [])[-2:]):
-            tot += int(self.deliver_wait(s_).bytes)
-        self._slots = []
-        return tot
+    def deliver_wait(self, slot):
+        """the Delivery view of a slot (blocks until its copy has landed)"""
+        d = Delivery()
+        self._ck(self.L.hao_deliver_wait(self.h, slot, C.byref(d)), "hao_deliver_wait")
+        return d
 
     def delivered_read(self, d, rid):
         """(ol uint32 [n,12], fc uint64, fc_off uint64 [n+1], cl uint32 [m,4]) of read rid out of a Delivery view: what the h_ec_lchain shim hands to its caller"""

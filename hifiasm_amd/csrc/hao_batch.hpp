@@ -25,7 +25,7 @@ struct hao_ctx::Batch {
 	int cur = 0;
 	OutSet &O() { return out[cur]; }
 	// delivery state: pinned host arenas, copy stream, per-slot completion events
-	unsigned char *arena[2] = { nullptr, nullptr }; size_t arena_cap[2] = { 0, 0 }; hipStream_t copy_stream = nullptr; hipEvent_t ev_ready[2], ev_done[2]; bool dl_ready = false, dl_pending[2] = { false, false };
+	unsigned char *arena[2] = { nullptr, nullptr }; size_t arena_cap[2] = { 0, 0 }; hipStream_t copy_stream = nullptr, copy_aux[8]; hipEvent_t ev_ready[2], ev_done[2], ev_aux[2][8]; int n_aux = 0; bool dl_ready = false, dl_pending[2] = { false, false };
 	hao_delivery_t dl[2]; uint64_t dl_seq = 0, n_exc = 0; uint32_t dl_parts = 0;
 	// host copies for fetch
 	std::vector<uint64_t> h_seg, h_fin_off, h_cl_off, h_fc_out_off; std::vector<hao_hit_t> h_hits, h_cl; std::vector<hao_ovlp_t> h_ol; std::vector<uint64_t> h_fc;
@@ -36,7 +36,7 @@ struct hao_ctx::Batch {
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fcf_off.release();
 		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); g_cls.release(); slow.release(); ovf_list.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
 		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); cd.release(); out[0].release(); out[1].release();
-		if (dl_ready) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); for (int x = 0; x < 2; ++x) { (void)hipEventDestroy(ev_ready[x]); (void)hipEventDestroy(ev_done[x]); if (arena[x]) (void)hipHostFree(arena[x]); arena[x] = nullptr; arena_cap[x] = 0; } dl_ready = false; }
+		if (dl_ready) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); for (int k = 0; k < n_aux; ++k) { (void)hipStreamSynchronize(copy_aux[k]); (void)hipStreamDestroy(copy_aux[k]); (void)hipEventDestroy(ev_aux[0][k]); (void)hipEventDestroy(ev_aux[1][k]); } for (int x = 0; x < 2; ++x) { (void)hipEventDestroy(ev_ready[x]); (void)hipEventDestroy(ev_done[x]); if (arena[x]) (void)hipHostFree(arena[x]); arena[x] = nullptr; arena_cap[x] = 0; } dl_ready = false; }
 	}
 };
 
@@ -86,7 +86,20 @@ static int hao_deliver_enqueue(hao_ctx *c)
 	}
 	if (cl && n) {
 		HIP_TRY(cp(o_choff, O.ch_off.p, (n + 1) * 8)); HIP_TRY(cp(o_cloff, O.cl_off.p, (n + 1) * 8)); HIP_TRY(cp(o_hdr, O.hdr.p, B.n_chains * sizeof(hao_chain_hdr_t)));
-		HIP_TRY(cp(o_words, O.words.p, B.n_cl * 4)); HIP_TRY(cp(o_exc, O.exc.p, B.n_exc * sizeof(hao_hit_t)));
+		HIP_TRY(cp(o_exc, O.exc.p, B.n_exc * sizeof(hao_hit_t)));
+		{	// the packed hits: 1 + n_aux pieces on as many streams
+			const int np = B.n_aux + 1; const uint64_t per = ((B.n_cl + np - 1) / np + 15) & ~15ULL;
+			for (int k = 0; k < np; ++k) {
+				const uint64_t lo_ = std::min<uint64_t>(B.n_cl, per * k), hi_ = std::min<uint64_t>(B.n_cl, per * (k + 1));
+				if (hi_ <= lo_) continue;
+				if (k == 0) { HIP_TRY(cp(o_words, O.words.p, (hi_ - lo_) * 4)); continue; }
+				hipStream_t st = B.copy_aux[k - 1];
+				HIP_TRY(hipStreamWaitEvent(st, B.ev_ready[s], 0));
+				HIP_TRY(hipMemcpyAsync(a + o_words + lo_ * 4, O.words.p + lo_, (hi_ - lo_) * 4, hipMemcpyDeviceToHost, st));
+				HIP_TRY(hipEventRecord(B.ev_aux[s][k - 1], st));
+				HIP_TRY(hipStreamWaitEvent(B.copy_stream, B.ev_aux[s][k - 1], 0));
+			}
+		}
 		d.n_chains = B.n_chains; d.n_cl = B.n_cl; d.n_exc = B.n_exc; d.ch_off = (const uint64_t*)(a + o_choff); d.cl_off = (const uint64_t*)(a + o_cloff);
 		d.chains = (const hao_chain_hdr_t*)(a + o_hdr); d.cl_words = (const uint32_t*)(a + o_words); d.cl_exc = (const hao_hit_t*)(a + o_exc);
 		d.bytes += 2 * (n + 1) * 8 + B.n_chains * sizeof(hao_chain_hdr_t) + B.n_cl * 4 + B.n_exc * sizeof(hao_hit_t);
@@ -100,7 +113,9 @@ static int hao_deliver_init(hao_ctx *c, hao_ctx::Batch &B)
 {
 	if (B.dl_ready) return HAO_OK;
 	HIP_TRY(hipStreamCreateWithFlags(&B.copy_stream, hipStreamNonBlocking));
-	for (int x = 0; x < 2; ++x) { HIP_TRY(hipEventCreateWithFlags(&B.ev_ready[x], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&B.ev_done[x], hipEventDisableTiming)); }
+	for (int x = 0; x < 2; ++x) { HIP_TRY(hipEventCreate(&B.ev_ready[x])); HIP_TRY(hipEventCreate(&B.ev_done[x])); }
+	B.n_aux = c->sw.copy_streams - 1;      // the bulk of a batch (the packed cl->list) is cut into pieces that travel on separate streams = separate DMA queues
+	for (int k = 0; k < B.n_aux; ++k) { HIP_TRY(hipStreamCreateWithFlags(&B.copy_aux[k], hipStreamNonBlocking)); for (int x = 0; x < 2; ++x) HIP_TRY(hipEventCreateWithFlags(&B.ev_aux[x][k], hipEventDisableTiming)); }
 	B.dl_ready = true;
 	return HAO_OK;
 }
@@ -139,7 +154,8 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	HIP_TRY(c->d_err.reserve(2)); HIP_TRY(hipMemsetAsync(c->d_err.p, 0, 4, c->stream));
 	hao_pt_dev pt = hao_pt_view(c);
 	// Q1 lookup + scan
-	hipLaunchKernelGGL(seed_count_kernel, dim3((unsigned)((nm + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_x.p, c->d_ix_mz_info.p, B.mz0, nm, pt, B.wgt.p, B.s_start.p, B.s_n.p, B.q_pos.p, B.q_cnt.p);
+	if (c->lk_valid) hipLaunchKernelGGL(seed_unpack_kernel, dim3((unsigned)((nm + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_lk.p, c->d_ix_mz_info.p, B.mz0, nm, B.wgt.p, B.s_start.p, B.s_n.p, B.q_pos.p, B.q_cnt.p);
+	else hipLaunchKernelGGL(seed_count_kernel, dim3((unsigned)((nm + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_x.p, c->d_ix_mz_info.p, B.mz0, nm, pt, B.wgt.p, B.s_start.p, B.s_n.p, B.q_pos.p, B.q_cnt.p);
 	HAO_CHECK_LAUNCH();
 	if (int rc = hao_scan_u32(c, B.s_n.p, B.a_off.p, nm + 1)) return rc;
 	hipLaunchKernelGGL(seed_segments_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_off.p, lo, n, B.mz0, B.a_off.p, B.seg.p);
@@ -259,16 +275,14 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		hao_asm_args aa;
 		aa.g_start = B.g_start.p; aa.g_read = B.g_read.p; aa.g_cls = B.g_cls.p; aa.g_off = B.g_off.p; aa.n_groups = G; aa.rid_lo = glo; aa.ohits = B.ohits.p; aa.hits = B.hits.p; aa.fcs = B.fcs.p; aa.rec = B.rec.p; aa.nch = B.nch.p;
 		aa.ch_base = B.ch_base.p; aa.cl_base = B.cl_base.p; aa.fc_base = B.fc_base.p; aa.ol = B.ol.p; aa.ol_fc_off = B.ol_fc_off.p; aa.cd = B.cd.p; aa.fc = B.fc_raw.p;
-		const uint64_t n_tiny = cls_cnt[0], n_rest = G - n_tiny;      // the work lists are laid out tiny class first
-		if (n_rest) { hipLaunchKernelGGL(chain_assemble_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream, aa); HAO_CHECK_LAUNCH(); }
-		if (n_tiny) { hipLaunchKernelGGL(chain_assemble_tiny_kernel, dim3((unsigned)((n_tiny + 63) / 64)), dim3(64), 0, c->stream, aa, B.glist.p + L.base[0], n_tiny); HAO_CHECK_LAUNCH(); }
+		hipLaunchKernelGGL(chain_assemble_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, c->stream, aa); HAO_CHECK_LAUNCH();
 	}
 	unsigned long long *d_exc_cnt = B.stats.p + 3 * HAO_NCLS + 2;      // (slot [3 NCLS + 2] of the stats block is free; [3 NCLS + 3] = seed overflow list cursor)
 	hao_pack_args pa; memset(&pa, 0, sizeof(pa));
 	if (parts & HAO_DELIVER_CL) {
 		hao_ctx::Batch::OutSet &O = B.O();
 		HIP_TRY(O.hdr.reserve(NCmax + 1)); HIP_TRY(O.words.reserve(A + 1)); HIP_TRY(O.exc.reserve(c->sw.exc_cap >= 0 ? (uint64_t)c->sw.exc_cap + 1 : std::max<uint64_t>(1 << 16, A / 64))); HIP_TRY(O.ch_off.reserve(n + 2)); HIP_TRY(O.cl_off.reserve(n + 2));
-		pa.cd = B.cd.p; pa.n_chains = NCmax; pa.hits = B.hits.p; pa.ohits = B.ohits.p; pa.hdr = O.hdr.p; pa.words = O.words.p; pa.exc = O.exc.p; pa.exc_cnt = d_exc_cnt; pa.exc_cap = c->sw.exc_cap >= 0 ? std::min<uint64_t>(O.exc.cap, (uint64_t)c->sw.exc_cap) : O.exc.cap;
+		pa.cd = B.cd.p; pa.n_chains = NCmax; pa.hits = B.hits.p; pa.ohits = B.ohits.p; pa.hdr = O.hdr.p; pa.words = O.words.p; pa.exc = O.exc.p; pa.exc_cnt = d_exc_cnt; pa.exc_every = (uint32_t)c->sw.exc_every; pa.exc_cap = c->sw.exc_cap >= 0 ? std::min<uint64_t>(O.exc.cap, (uint64_t)c->sw.exc_cap) : O.exc.cap;
 		// the number of chains is only known on the device here: launch over the bound, the kernel stops at ch_base[G]
 		if (G) { hipLaunchKernelGGL(hao_pack_chains_kernel, dim3((unsigned)((NCmax + 3) / 4)), dim3(256), 0, c->stream, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH(); }
 		hipLaunchKernelGGL(hao_read_ranges_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, B.g_off.p, B.ch_base.p, B.cl_base.p, n, O.ch_off.p, O.cl_off.p);

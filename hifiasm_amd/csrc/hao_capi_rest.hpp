@@ -12,7 +12,7 @@ static void hao_release_all(hao_ctx *c)
 	c->d_chunk_base.release(); c->d_chunk_dst.release(); c->d_chunk_cnt.release(); c->d_g_x.release(); c->d_g_info.release(); c->d_g_ord.release(); c->d_g_off.release();
 	c->d_new_n.release(); c->d_new_n64.release(); c->d_mz_x.release(); c->d_mz_info.release(); c->d_mz_off.release(); c->d_tmp.release(); c->d_ring.release(); c->d_ringord.release(); c->d_cnt_ws.release();
 	c->w_ukeys.release(); c->w_flag.release(); c->w_kpos.release(); c->w_ustart.release(); c->w_ucnt.release(); c->w_hist.release(); c->w_ok.release(); c->w_ok2.release(); c->w_oi.release(); c->w_oi2.release();
-	c->d_ix_mz_x.release(); c->d_ix_mz_info.release(); c->d_ix_mz_off.release(); c->d_ix_sx.release(); c->d_ix_sinfo.release();
+	c->d_ix_lk.release(); c->w_runid.release(); c->d_ix_mz_x.release(); c->d_ix_mz_info.release(); c->d_ix_mz_off.release(); c->d_ix_sx.release(); c->d_ix_sinfo.release();
 	c->d_ix_keys.release(); c->d_ix_start.release(); c->d_ix_cnt.release(); c->d_ix_bucket.release();
 }
 
@@ -136,7 +136,7 @@ int hao_deliver_wait(hao_ctx *c, int slot, hao_delivery_t *out)
 	if (!c || !out || slot < 0 || slot > 1 || !c->batch || !c->batch->dl_ready) return HAO_EINVAL;
 	HIP_TRY(hipSetDevice(c->device));
 	hao_ctx::Batch &B = *c->batch;
-	if (B.dl_pending[slot]) { HIP_TRY(hipEventSynchronize(B.ev_done[slot])); B.dl_pending[slot] = false; }
+	if (B.dl_pending[slot]) { HIP_TRY(hipEventSynchronize(B.ev_done[slot])); B.dl_pending[slot] = false; float ms = 0; if (hipEventElapsedTime(&ms, B.ev_ready[slot], B.ev_done[slot]) == hipSuccess) B.dl[slot].copy_ms = ms; }
 	*out = B.dl[slot];
 	return HAO_OK;
 }

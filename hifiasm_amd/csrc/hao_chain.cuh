@@ -797,30 +797,39 @@ struct hao_asm_args {
 	hao_ovlp_t *ol; uint64_t *ol_fc_off; hao_cdesc *cd; uint64_t *fc;
 };
 
-// one wave per group, in group order (chained hits of a read are written front to back); the tiny class has its own kernel
+// One LANE per group (every size class): the records, the chain descriptors and the short fake cigars of its <= 3 chains; cigars of more than 8
+// entries (noisy reads) are copied by the whole wave, one chain after the other.
 __global__ __launch_bounds__(256) void chain_assemble_kernel(hao_asm_args A)
 {
-	const uint64_t g = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-	if (g >= A.n_groups) return;
-	const uint32_t n = A.nch[g]; if (n == 0 || A.g_cls[g] == 0) return;
-	const uint32_t r = A.g_read[g]; const uint64_t g0 = A.g_off[r];
-	const uint64_t ord0 = A.ch_base[g] - A.ch_base[g0], cl0 = A.cl_base[g0];
-	const uint64_t *fsrc = A.fcs + A.g_start[g] + 6 * g;
-	for (uint32_t c = 0; c < n; ++c) {
-		const hao_chain_rec rc = A.rec[g * HAO_MCOPY_MAX + c];
-		const uint64_t oi = A.ch_base[g] + c, hd = A.cl_base[g] + rc.hit_rel, fd = A.fc_base[g * HAO_MCOPY_MAX + c];
-		const uint32_t ord = (uint32_t)(ord0 + c);
-		const hao_hit_t *src = (rc.in_place ? A.hits : A.ohits) + A.g_start[g] + rc.src_rel;
-		if (hao_lane() == 0) {
+	const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; const int lane = hao_lane();
+	const uint32_t n = g < A.n_groups ? A.nch[g] : 0;
+	uint32_t r = 0; uint64_t ord0 = 0, cl0 = 0, gs = 0, chb = 0, clb = 0; uint32_t yid = 0;
+	if (n) {
+		r = A.g_read[g]; const uint64_t g0 = A.g_off[r];
+		chb = A.ch_base[g]; clb = A.cl_base[g]; ord0 = chb - A.ch_base[g0]; cl0 = A.cl_base[g0]; gs = A.g_start[g];
+		yid = HH_ID(A.hits[gs]);                     // every seed hit of the group has the group's target id
+	}
+#pragma unroll
+	for (uint32_t c = 0; c < HAO_MCOPY_MAX; ++c) {
+		const bool has = c < n; uint32_t fl = 0; uint64_t fd = 0; const uint64_t *fs = nullptr;
+		if (has) {
+			const hao_chain_rec rc = A.rec[g * HAO_MCOPY_MAX + c];
+			const uint64_t oi = chb + c, hd = clb + rc.hit_rel; const uint32_t ord = (uint32_t)(ord0 + c);
+			fd = A.fc_base[g * HAO_MCOPY_MAX + c]; fl = rc.fc_len; fs = A.fcs + gs + 6 * g + rc.fc_rel;
 			hao_ovlp_t o;
 			o.x_id = (uint32_t)(A.rid_lo + r); o.x_pos_s = rc.x_pos_s; o.x_pos_e = rc.x_pos_e; o.x_pos_strand = 0;
-			o.y_id = HH_ID(src[0]); o.y_pos_s = rc.y_pos_s; o.y_pos_e = rc.y_pos_e; o.y_pos_strand = rc.strand;
+			o.y_id = yid; o.y_pos_s = rc.y_pos_s; o.y_pos_e = rc.y_pos_e; o.y_pos_strand = rc.strand;
 			o.shared_seed = rc.score; o.align_length = rc.n_hits; o.non_homopolymer_errors = (uint32_t)(hd - cl0); o.fc_len = rc.fc_len;
 			A.ol[oi] = o; A.ol_fc_off[oi] = fd;
-			hao_cdesc d; d.src = (A.g_start[g] + rc.src_rel) | (rc.in_place ? 0 : HAO_CD_OHITS); d.dst = hd; d.n = rc.n_hits; d.w0 = (rc.strand << 31) | (ord & 0x7fffffffu);
+			hao_cdesc d; d.src = (gs + rc.src_rel) | (rc.in_place ? 0 : HAO_CD_OHITS); d.dst = hd; d.n = rc.n_hits; d.w0 = (rc.strand << 31) | (ord & 0x7fffffffu);
 			A.cd[oi] = d;
+			if (fl <= 8) for (uint32_t i = 0; i < fl; ++i) A.fc[fd + i] = fs[i];
 		}
-		for (uint32_t i = hao_lane(); i < rc.fc_len; i += 64) A.fc[fd + i] = fsrc[rc.fc_rel + i];
+		for (unsigned long long big = __ballot(has && fl > 8); big; big &= big - 1) {
+			const int l = __ffsll((long long)big) - 1;
+			const uint64_t *cfs = (const uint64_t*)hao_readlane_i64((int64_t)fs, l); const uint64_t cfd = (uint64_t)hao_readlane_i64((int64_t)fd, l); const uint32_t cfl = hao_bcast(fl, l);
+			for (uint32_t j = lane; j < cfl; j += 64) A.fc[cfd + j] = cfs[j];
+		}
 	}
 }
 
@@ -838,31 +847,6 @@ __global__ __launch_bounds__(256) void chain_materialize_kernel(const hao_cdesc 
 		for (int u = 0; u < 4; ++u) if (i + u * 64 < d.n) h4[u] = __builtin_nontemporal_load(src4 + i + u * 64);
 #pragma unroll
 		for (int u = 0; u < 4; ++u) if (i + u * 64 < d.n) { h4[u].x = d.w0; __builtin_nontemporal_store(h4[u], dst4 + i + u * 64); }
-	}
-}
-
-// the same for the tiny class (<= HAO_TINY_MAX hits per group): one LANE per group
-__global__ __launch_bounds__(64) void chain_assemble_tiny_kernel(hao_asm_args A, const hao_gent *list, uint64_t n_list)
-{
-	const uint64_t li = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-	if (li >= n_list) return;
-	const hao_gent e = list[li]; const uint64_t g = e.g;
-	const uint32_t n = A.nch[g]; if (n == 0) return;
-	const uint64_t g0 = A.g_off[e.r], ord0 = A.ch_base[g] - A.ch_base[g0], cl0 = A.cl_base[g0];
-	const uint64_t *fsrc = A.fcs + e.start + 6 * g;
-	for (uint32_t c = 0; c < n; ++c) {
-		const hao_chain_rec rc = A.rec[g * HAO_MCOPY_MAX + c];
-		const uint64_t oi = A.ch_base[g] + c, hd = A.cl_base[g] + rc.hit_rel, fd = A.fc_base[g * HAO_MCOPY_MAX + c];
-		const uint32_t ord = (uint32_t)(ord0 + c);
-		const hao_hit_t *src = (rc.in_place ? A.hits : A.ohits) + e.start + rc.src_rel;
-		hao_ovlp_t o;
-		o.x_id = (uint32_t)(A.rid_lo + e.r); o.x_pos_s = rc.x_pos_s; o.x_pos_e = rc.x_pos_e; o.x_pos_strand = 0;
-		o.y_id = e.yid; o.y_pos_s = rc.y_pos_s; o.y_pos_e = rc.y_pos_e; o.y_pos_strand = rc.strand;
-		o.shared_seed = rc.score; o.align_length = rc.n_hits; o.non_homopolymer_errors = (uint32_t)(hd - cl0); o.fc_len = rc.fc_len;
-		A.ol[oi] = o; A.ol_fc_off[oi] = fd;
-		hao_cdesc d; d.src = (e.start + rc.src_rel) | (rc.in_place ? 0 : HAO_CD_OHITS); d.dst = hd; d.n = rc.n_hits; d.w0 = (rc.strand << 31) | (ord & 0x7fffffffu);
-		A.cd[oi] = d;
-		for (uint32_t i = 0; i < rc.fc_len; ++i) A.fc[fd + i] = fsrc[rc.fc_rel + i];
 	}
 }
 

@@ -53,7 +53,7 @@ struct StageTimer {
 struct hao_switches {
 	bool seedphase = false, qcphase = false, dp_stats = false, seq_chain = false, dp_seqtail = false, dp_nospec = false, dp_serial = false,
 		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false;
-	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1;
+	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; int exc_every = 0, copy_streams = 4;
 	void load() {
 		auto on = [](const char *n) { return getenv(n) != nullptr; };
 		seedphase = on("HAO_DBG_SEEDPHASE"); qcphase = on("HAO_DBG_QCPHASE"); dp_stats = on("HAO_DBG_DP_STATS"); seq_chain = on("HAO_DBG_SEQ_CHAIN");
@@ -62,7 +62,9 @@ struct hao_switches {
 		if (const char *e = getenv("HAO_CHAIN_WPB")) chain_wpb = std::max(1, std::min(4, atoi(e)));
 		if (const char *e = getenv("HAO_SPEC_MINCLS")) spec_mincls = atoi(e);
 		if (const char *e = getenv("HAO_DBG_SK_GCAP")) sk_gcap = atoll(e);
-		if (const char *e = getenv("HAO_DBG_EXC_CAP")) exc_cap = atoll(e);      // initial capacity of the wire format's verbatim-hit list (tests: force the grow-and-repack path)
+		if (const char *e = getenv("HAO_DBG_EXC_CAP")) exc_cap = atoll(e);
+		if (const char *e = getenv("HAO_DBG_EXC_EVERY")) exc_every = atoi(e);      // ship every n-th hit of a chain verbatim (tests: exercise the exception list)
+		if (const char *e = getenv("HAO_COPY_STREAMS")) copy_streams = std::max(1, std::min(8, atoi(e)));      // DMA queues the delivery copy is spread over      // initial capacity of the wire format's verbatim-hit list (tests: force the grow-and-repack path)
 	}
 };
 
@@ -94,6 +96,7 @@ struct hao_ctx {
 	uint64_t ix_n_mz = 0, ix_n_sorted = 0, ix_n_keys = 0, ix_n_pos = 0; int ix_bucket_bits = 16;   // ix_n_mz: local read-ordered records; ix_n_sorted: records in the (replicated) index
 	DevBuf<uint64_t> d_ix_mz_x, d_ix_mz_info, d_ix_mz_off;  // all reads' minimizers in read order (query side reuses them)
 	DevBuf<uint64_t> d_ix_sx, d_ix_sinfo;                    // sorted by hash (stable)
+	DevBuf<uint64_t> d_ix_lk; bool lk_valid = false; DevBuf<uint32_t> w_runid;   // per minimizer (read order): list start | count << 48 of its key (single-device build)
 	DevBuf<uint64_t> d_ix_keys, d_ix_start; DevBuf<uint32_t> d_ix_cnt; DevBuf<uint32_t> d_ix_bucket;
 	DevBuf<uint64_t> w_ukeys, w_flag, w_kpos, w_ustart; DevBuf<uint32_t> w_ucnt; DevBuf<unsigned long long> w_hist; DevBuf<uint32_t> w_ok, w_ok2, w_oi, w_oi2;   // persistent scratch of the index build
 	std::vector<uint64_t> h_ix_keys, h_ix_off, h_ix_pos, h_ix_mz_off; bool h_ix_valid = false;

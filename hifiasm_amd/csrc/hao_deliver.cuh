@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void hao_digest_kernel(hao_digest_args A)
 // ---------------------------------------------------------------------------------------
 struct hao_pack_args {
 	const hao_cdesc *cd; uint64_t n_chains; const hao_hit_t *hits, *ohits;
-	hao_chain_hdr_t *hdr; uint32_t *words; hao_hit_t *exc; unsigned long long *exc_cnt; uint64_t exc_cap;
+	hao_chain_hdr_t *hdr; uint32_t *words; hao_hit_t *exc; unsigned long long *exc_cnt; uint64_t exc_cap; uint32_t exc_every;
 };
 
 __global__ __launch_bounds__(256) void hao_pack_chains_kernel(hao_pack_args A, const uint64_t *n_chains_dev)
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void hao_pack_chains_kernel(hao_pack_args A, c
 		if (act) {
 			h = src[i]; p = i ? src[i - 1] : h;
 			const int64_t ds = (int64_t)h.self_offset - (int64_t)p.self_offset, dd = ((int64_t)h.offset - (int64_t)p.offset) - ds;
-			esc = ds < 0 || ds > 8191 || dd < -64 || dd > 63 || (h.cnt >> 8) > 7;
+			esc = ds < 0 || ds > 8191 || dd < -64 || dd > 63 || (h.cnt >> 8) > 7 || (A.exc_every && i % A.exc_every == A.exc_every - 1);
 			w = (uint32_t)ds | (uint32_t)(dd + 64) << 13 | (h.cnt & 0xffu) << 20 | (h.cnt >> 8) << 28;
 		}
 		const unsigned long long em = __ballot(act && esc);

@@ -151,6 +151,28 @@ __global__ void hao_bucket_kernel(const uint64_t *keys, uint64_t n, int shift, u
 	bucket[b] = (uint32_t)lo;
 }
 
+// ---- index build, single device: the lookup of every minimizer is a by-product of the sort ----
+// The query pass looks every minimizer of every read up in the index (ha_pt_get, anchor.cpp:1013) - but the index was just built from those same
+// minimizers: after the stable sort by hash, position j of run u knows its key's list (start of the run, run length).  Carrying the original
+// (read-order) index through the sort as the 4-byte value turns 215 M dependent bucket + binary searches per pass (11.5 GB of scattered line
+// fetches per batch of configs[2]) into one scatter at build time: lk[orig] = list start | count << 48 (count 0 = the key is not indexed).
+__global__ void hao_iota_kernel(uint32_t *v, uint64_t n)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) v[i] = (uint32_t)i;
+}
+// j = position in hash order: gather its 8-byte record (the index lists) and scatter its lookup result to read order
+__global__ void hao_index_finish_kernel(uint64_t m, const uint32_t *sidx, const uint32_t *runid, const uint32_t *ucnt, const uint64_t *ustart, int lo, int hi,
+		const uint64_t *info, uint64_t *sinfo, uint64_t *lk)
+{
+	const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= m) return;
+	const uint32_t o = sidx[j], u = runid[j] - 1;
+	sinfo[j] = info[o];
+	int c = ucnt[u] > HAO_MAX_COUNT ? HAO_MAX_COUNT : (int)ucnt[u];
+	lk[o] = (c >= lo && c <= hi) ? (ustart[u] | (uint64_t)c << 48) : 0;
+}
+
 // position index, device view: kept keys (sorted) -> (start,cnt) into the hash-sorted minimizer array
 struct hao_pt_dev {
 	const uint64_t *keys, *start; const uint32_t *cnt, *bucket; const uint64_t *sinfo; uint64_t n_keys; int bshift;

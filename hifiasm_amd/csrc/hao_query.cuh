@@ -28,6 +28,17 @@ __global__ void seed_count_kernel(const uint64_t *mz_x, const uint64_t *mz_info,
 	s_start[i] = st; s_n[i] = n; q_pos[i] = hao_info_pos(z); q_cnt[i] = wgt_tab[n] << 8 | hao_info_span(z);
 }
 
+// Q1 on a single device: the lookup results were computed when the index was built (hao_index_finish_kernel): unpack them for the batch's minimizers
+__global__ void seed_unpack_kernel(const uint64_t *lk, const uint64_t *mz_info, uint64_t mz0, uint64_t n_mz, const uint32_t *wgt_tab,
+		uint64_t *s_start, uint32_t *s_n, uint32_t *q_pos, uint32_t *q_cnt)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i > n_mz) return;
+	if (i == n_mz) { s_n[i] = 0; return; }
+	const uint64_t v = lk[mz0 + i], z = mz_info[mz0 + i]; const uint32_t n = (uint32_t)(v >> 48);
+	s_start[i] = v & ((1ULL << 48) - 1); s_n[i] = n; q_pos[i] = hao_info_pos(z); q_cnt[i] = wgt_tab[n] << 8 | hao_info_span(z);
+}
+
 // per-read anchor segment bounds from the per-minimizer scan
 __global__ void seed_segments_kernel(const uint64_t *mz_off, uint64_t rid_lo, uint64_t n_sel, uint64_t mz0, const uint64_t *a_off, uint64_t *seg)
 {

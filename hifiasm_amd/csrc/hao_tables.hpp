@@ -101,6 +101,7 @@ static int hao_comm_agree(hao_ctx *c, hao_comm &cm, int local_rc) { std::vector<
 
 struct NotSentinel { __host__ __device__ bool operator()(const uint64_t &h) const { return h != UINT64_MAX; } };
 struct RunHead { const uint64_t *k; __host__ __device__ uint64_t operator()(uint64_t i) const { return (i == 0 || k[i] != k[i - 1]) ? 1 : 0; } };
+struct RunHead32 { const uint64_t *k; __host__ __device__ uint32_t operator()(uint64_t i) const { return (i == 0 || k[i] != k[i - 1]) ? 1u : 0u; } };
 
 // sort keys, run-length encode, histogram.  in: d_keys[n] (destroyed). out: unique keys / counts in c->d_u_keys / d_u_cnt, n_unique.
 struct hao_rle_out { uint64_t n_unique; };
@@ -455,17 +456,37 @@ static int hao_pt_run(hao_ctx *c)
 		else { hi = (int)(c->hom_cov * c->opt.high_factor); if (hi > HAO_MAX_COUNT - 1) hi = HAO_MAX_COUNT - 1; }   // :1258-1262
 		*hi_out = hi;
 	};
+	c->lk_valid = false;
 	if (!sharded) {
+		// hash order through a (hash, read-order index) sort: 12 bytes per element and pass instead of 16, and the index is what lets every
+		// minimizer learn its own lookup result at build time (hao_index.cuh)
 		const uint64_t m = c->ix_n_mz;
 		if (m >= (1ULL << 32)) { hao_set_err(c, "more than 2^32 minimizers on one device"); return HAO_EUNSUPP; }
-		HIP_TRY(c->d_ix_sx.reserve(m + 1)); HIP_TRY(c->d_ix_sinfo.reserve(m + 1));
-		if (int rc = sort_pairs(c->d_ix_mz_x.p, c->d_ix_sx.p, c->d_ix_mz_info.p, c->d_ix_sinfo.p, m)) return rc;
+		HIP_TRY(c->d_ix_sx.reserve(m + 1)); HIP_TRY(c->d_ix_sinfo.reserve(m + 1)); HIP_TRY(c->w_oi.reserve(m + 1)); HIP_TRY(c->w_oi2.reserve(m + 1));
+		HIP_TRY(c->w_runid.reserve(m + 1)); HIP_TRY(c->d_ix_lk.reserve(m + 1));
+		if (m) {
+			hipLaunchKernelGGL(hao_iota_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, c->w_oi.p, m); HAO_CHECK_LAUNCH();
+			size_t tb = 0;
+			HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, c->d_ix_mz_x.p, c->d_ix_sx.p, c->w_oi.p, c->w_oi2.p, m, 0, 64, c->stream)); HIP_TRY(hao_tmp(c, tb));
+			HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, c->d_ix_mz_x.p, c->d_ix_sx.p, c->w_oi.p, c->w_oi2.p, m, 0, 64, c->stream));
+		}
 		c->ix_n_sorted = m;
 		c->timer.mark("pt_sort");
 		if (int rc = rle_hist(c->d_ix_sx.p, m)) return rc;
 		c->timer.mark("pt_count");
 		int hi; peaks_and_range(&hi);
 		if (int rc = hao_keep_runs(c, ukeys.p, ucnt.p, n_unique, 2, hi, c->d_ix_keys, &c->d_ix_start, c->d_ix_cnt, &c->ix_n_keys, &c->ix_n_pos)) return rc;
+		if (m) {      // run id of every sorted position (inclusive count of run heads), then one gather + scatter pass (c->w_ustart = run starts, left by hao_keep_runs)
+			auto heads = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), RunHead32{c->d_ix_sx.p});
+			size_t tb = 0;
+			HIP_TRY(rocprim::inclusive_scan(nullptr, tb, heads, c->w_runid.p, m, rocprim::plus<uint32_t>(), c->stream)); HIP_TRY(hao_tmp(c, tb));
+			HIP_TRY(rocprim::inclusive_scan(c->d_tmp.p, tb, heads, c->w_runid.p, m, rocprim::plus<uint32_t>(), c->stream));
+			hipLaunchKernelGGL(hao_index_finish_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, m, c->w_oi2.p, c->w_runid.p, ucnt.p, c->w_ustart.p, 2, hi,
+							   c->d_ix_mz_info.p, c->d_ix_sinfo.p, c->d_ix_lk.p);
+			HAO_CHECK_LAUNCH();
+		}
+		c->lk_valid = true;
+		c->timer.mark("pt_lookup");
 	} else {
 		// Sharded build (SURVEY 2 C1 + 8e layout i): every rank owns the hash range [r, r+1) * 2^64 / world.
 		//   local stable grouping by owner -> all-to-all-v of (x, info) by range -> stable sort of the received pieces (source-rank order =

@@ -170,6 +170,7 @@ typedef struct {
 	const hao_chain_hdr_t *chains;
 	const uint32_t *cl_words;        /* one word per hit: self_offset delta:13 | diagonal shift + 64:7 | span:8 | weight:3 | 0, or 1 << 31 | index into cl_exc */
 	const hao_hit_t *cl_exc;         /* hits whose deltas do not fit a word, verbatim */
+	double copy_ms;                  /* duration of this batch's device-to-host copy (filled by hao_deliver_wait) */
 } hao_delivery_t;
 int hao_overlap_batch_async(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi, const hao_pass_t *pass /* NULL: hao_pass_default */, uint32_t parts, int *slot);
 int hao_deliver_wait(hao_ctx *c, int slot, hao_delivery_t *out);
