@@ -38,7 +38,7 @@ class Pass(C.Structure):
 
 
 class ChainHdr(C.Structure):
-    _fields_ = [("n_hits", C.c_uint32), ("w0", C.c_uint32), ("offset", C.c_uint32), ("self_offset", C.c_uint32)]
+    _fields_ = [("n_hits", C.c_uint32), ("w0", C.c_uint32), ("q0", C.c_uint32), ("offset", C.c_uint32)]
 
 
 class Delivery(C.Structure):
@@ -46,17 +46,18 @@ class Delivery(C.Structure):
     _fields_ = [("rid_lo", C.c_uint64), ("n_reads", C.c_uint64), ("n_ol", C.c_uint64), ("n_fc", C.c_uint64), ("n_chains", C.c_uint64),
                 ("n_cl", C.c_uint64), ("n_exc", C.c_uint64), ("bytes", C.c_uint64),
                 ("ol_off", C.c_void_p), ("ol", C.c_void_p), ("fc_off", C.c_void_p), ("fc", C.c_void_p), ("ch_off", C.c_void_p),
-                ("cl_off", C.c_void_p), ("chains", C.c_void_p), ("cl_words", C.c_void_p), ("cl_exc", C.c_void_p), ("copy_ms", C.c_double)]
+                ("cl_off", C.c_void_p), ("qm_off", C.c_void_p), ("chains", C.c_void_p), ("cl_bytes", C.c_void_p), ("qmz", C.c_void_p),
+                ("cl_exc", C.c_void_p), ("exact", C.c_void_p), ("copy_ms", C.c_double)]
 
 
-DELIVER_OL, DELIVER_CL = 1, 2
+DELIVER_OL, DELIVER_CL, DELIVER_EXACT = 1, 2, 4
 
 ABI_SYMBOLS = [
     "hao_opt_default", "hao_create", "hao_destroy", "hao_last_error", "hao_set_reads", "hao_ft_gen", "hao_pt_gen",
     "hao_ft_cnt", "hao_pt_get", "hao_ft_table", "hao_pt_table", "hao_hist", "hao_stats", "hao_sketch_batch",
     "hao_fetch_sketch", "hao_overlap_batch", "hao_fetch_seed_hits", "hao_fetch_overlaps", "hao_batch_totals",
     "hao_stage_times", "hao_pass_default", "hao_overlap_batch_ex", "hao_set_shard", "hao_dist_unique_id", "hao_dist_init",
-    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits",
+    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits", "hao_exact_check", "hao_fetch_exact",
 ]
 
 
@@ -97,6 +98,8 @@ def lib():
         L.hao_batch_digest.argtypes = [vp, u64p, u64p]
         L.hao_overlap_batch_async.argtypes = [vp, C.c_uint64, C.c_uint64, C.POINTER(Pass), C.c_uint32, C.POINTER(C.c_int)]
         L.hao_deliver_wait.argtypes = [vp, C.c_int, C.POINTER(Delivery)]
+        L.hao_exact_check.argtypes = [vp]
+        L.hao_fetch_exact.argtypes = [vp, C.c_uint64, C.POINTER(vp), u64p]
         L.hao_unpack_hits.argtypes = [C.POINTER(Delivery), C.c_uint64, vp, C.c_uint64]; L.hao_unpack_hits.restype = C.c_uint64
         L.hao_set_shard.argtypes = [vp, C.c_uint64, C.c_uint64, u32p]
         L.hao_dist_unique_id.argtypes = [u8p]
@@ -296,6 +299,12 @@ class Engine:
         got = self.L.hao_unpack_hits(C.byref(d), rid, cl.ctypes.data_as(C.c_void_p), m)
         assert got == m
         return ol, fc, fo - (fo[0] if fo.size else 0), cl
+
+    def fetch_exact(self, rid):
+        """exact-overlap flags (uint8, aligned with h_ec_lchain(rid)[0]) of a read of the last batch"""
+        p, n = C.c_void_p(), C.c_uint64()
+        self._ck(self.L.hao_fetch_exact(self.h, rid, C.byref(p), C.byref(n)), "hao_fetch_exact")
+        return _arr(p.value, n.value, np.uint8)
 
     def fetch_seed_hits(self, rid):
         p, n = C.c_void_p(), C.c_uint64()

@@ -18,15 +18,16 @@ struct hao_ctx::Batch {
 	// Results of a batch that leave the device.  Two sets (+ two pinned host arenas): while the copy stream drains the set of batch i, batch i + 1
 	// computes into the other one (hao_overlap_batch_async).  The blocking API keeps using the current set.
 	struct OutSet {
-		DevBuf<hao_ovlp_t> ol_out; DevBuf<uint64_t> fin_off, fc_out, fc_out_off, ch_off, cl_off;      // ol->list in final order, per-read offsets, fake cigars
-		DevBuf<hao_chain_hdr_t> hdr; DevBuf<uint32_t> words; DevBuf<hao_hit_t> exc;                   // cl->list in the wire format (hao_deliver.cuh)
-		void release() { ol_out.release(); fin_off.release(); fc_out.release(); fc_out_off.release(); ch_off.release(); cl_off.release(); hdr.release(); words.release(); exc.release(); }
+		DevBuf<hao_ovlp_t> ol_out; DevBuf<uint64_t> fin_off, fc_out, fc_out_off, ch_off, cl_off, qm_off;      // ol->list in final order, per-read offsets, fake cigars
+		DevBuf<hao_chain_hdr_t> hdr; DevBuf<uint8_t> bytes; DevBuf<hao_exc_t> exc, exc2; DevBuf<hao_qmz_t> qmz;   // cl->list in the wire format (hao_deliver.cuh)
+		DevBuf<uint8_t> exact;                                                                        // exact-overlap flags of ol_out
+		void release() { ol_out.release(); fin_off.release(); fc_out.release(); fc_out_off.release(); ch_off.release(); cl_off.release(); qm_off.release(); hdr.release(); bytes.release(); exc.release(); exc2.release(); qmz.release(); exact.release(); }
 	} out[2];
 	int cur = 0;
 	OutSet &O() { return out[cur]; }
 	// delivery state: pinned host arenas, copy stream, per-slot completion events
 	unsigned char *arena[2] = { nullptr, nullptr }; size_t arena_cap[2] = { 0, 0 }; hipStream_t copy_stream = nullptr, copy_aux[8]; hipEvent_t ev_ready[2], ev_done[2], ev_aux[2][8]; int n_aux = 0; bool dl_ready = false, dl_pending[2] = { false, false };
-	hao_delivery_t dl[2]; uint64_t dl_seq = 0, n_exc = 0; uint32_t dl_parts = 0;
+	hao_delivery_t dl[2]; uint64_t dl_seq = 0, n_exc = 0; uint32_t dl_parts = 0; bool exact_valid = false; std::vector<uint8_t> h_exact;
 	// host copies for fetch
 	std::vector<uint64_t> h_seg, h_fin_off, h_cl_off, h_fc_out_off; std::vector<hao_hit_t> h_hits, h_cl; std::vector<hao_ovlp_t> h_ol; std::vector<uint64_t> h_fc;
 	std::vector<uint64_t> fetch_fc_off, h_cco;
@@ -49,10 +50,30 @@ __global__ void hao_fclen_kernel(const hao_chain_rec *rec, const uint32_t *nch, 
 	out[i] = c < nch[g] ? rec[i].fc_len : 0;
 }
 
+struct ExcLess { __host__ __device__ bool operator()(const hao_exc_t &a, const hao_exc_t &b) const { return a.index < b.index; } };
+
 static int hao_scan_u32(hao_ctx *c, const uint32_t *in, uint64_t *out, uint64_t n_plus1)
 {
 	auto it = rocprim::make_transform_iterator(in, U32ToU64());
 	return hao_excl_scan_u64(c, it, out, n_plus1);
+}
+
+// exact-overlap flags of the batch's final ol->list (device resident, current output set)
+static int hao_exact_run(hao_ctx *c)
+{
+	hao_ctx::Batch &B = *c->batch;
+	if (B.exact_valid) return HAO_OK;
+	if (c->comm && c->comm->active()) { hao_set_err(c, "hao_exact_check needs the bases of the target reads: single-device mode only"); return HAO_EUNSUPP; }
+	HIP_TRY(B.O().exact.reserve(B.n_ol + 1));
+	if (B.n_ol) {
+		hao_exact_args a;
+		a.ol = B.O().ol_out.p; a.n_ol = B.n_ol; a.rid_base = c->rid_base; a.packed = c->d_packed.p; a.pk_off = c->d_pk_off.p; a.len = c->d_len.p;
+		a.nsite_off = c->has_n ? c->d_nsite_off.p : nullptr; a.nsite = c->has_n ? c->d_nsite.p : nullptr; a.flags = B.O().exact.p;
+		hipLaunchKernelGGL(hao_exact_check_kernel, dim3((unsigned)((B.n_ol + 3) / 4)), dim3(256), 0, c->stream, a);
+		HAO_CHECK_LAUNCH();
+	}
+	B.exact_valid = true;
+	return HAO_OK;
 }
 
 // Queue the copy of the current batch's results into the slot's pinned arena (copy stream, after everything on the compute stream so far).
@@ -60,10 +81,11 @@ static int hao_deliver_enqueue(hao_ctx *c)
 {
 	hao_ctx::Batch &B = *c->batch; const int s = B.cur; hao_ctx::Batch::OutSet &O = B.O(); const uint64_t n = B.n; const uint32_t parts = B.dl_parts;
 	auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
-	const bool ol = parts & HAO_DELIVER_OL, cl = parts & HAO_DELIVER_CL;
+	const bool ol = parts & HAO_DELIVER_OL, cl = parts & HAO_DELIVER_CL, ex = parts & HAO_DELIVER_EXACT;
 	size_t o_oloff = 0, o_ol = o_oloff + (ol ? al((n + 1) * 8) : 0), o_fcoff = o_ol + (ol ? al(B.n_ol * sizeof(hao_ovlp_t)) : 0), o_fc = o_fcoff + (ol ? al((B.n_ol + 1) * 8) : 0);
-	size_t o_choff = o_fc + (ol ? al(B.n_fc * 8) : 0), o_cloff = o_choff + (cl ? al((n + 1) * 8) : 0), o_hdr = o_cloff + (cl ? al((n + 1) * 8) : 0);
-	size_t o_words = o_hdr + (cl ? al(B.n_chains * sizeof(hao_chain_hdr_t)) : 0), o_exc = o_words + (cl ? al(B.n_cl * 4) : 0), total = o_exc + (cl ? al(B.n_exc * sizeof(hao_hit_t)) : 0);
+	size_t o_choff = o_fc + (ol ? al(B.n_fc * 8) : 0), o_cloff = o_choff + (cl ? al((n + 1) * 8) : 0), o_qmoff = o_cloff + (cl ? al((n + 1) * 8) : 0), o_hdr = o_qmoff + (cl ? al((n + 1) * 8) : 0);
+	size_t o_qmz = o_hdr + (cl ? al(B.n_chains * sizeof(hao_chain_hdr_t)) : 0), o_bytes = o_qmz + (cl ? al(B.n_mz * sizeof(hao_qmz_t)) : 0), o_exc = o_bytes + (cl ? al(B.n_cl) : 0);
+	size_t o_ex = o_exc + (cl ? al(B.n_exc * sizeof(hao_exc_t)) : 0), total = o_ex + (ex ? al(B.n_ol) : 0);
 	if (total > B.arena_cap[s]) {
 		if (B.arena[s]) (void)hipHostFree(B.arena[s]);
 		B.arena[s] = nullptr; B.arena_cap[s] = 0;
@@ -85,25 +107,26 @@ static int hao_deliver_enqueue(hao_ctx *c)
 		d.bytes += (n + 1) * 8 + B.n_ol * (sizeof(hao_ovlp_t) + 8) + B.n_fc * 8;
 	}
 	if (cl && n) {
-		HIP_TRY(cp(o_choff, O.ch_off.p, (n + 1) * 8)); HIP_TRY(cp(o_cloff, O.cl_off.p, (n + 1) * 8)); HIP_TRY(cp(o_hdr, O.hdr.p, B.n_chains * sizeof(hao_chain_hdr_t)));
-		HIP_TRY(cp(o_exc, O.exc.p, B.n_exc * sizeof(hao_hit_t)));
-		{	// the packed hits: 1 + n_aux pieces on as many streams
-			const int np = B.n_aux + 1; const uint64_t per = ((B.n_cl + np - 1) / np + 15) & ~15ULL;
+		HIP_TRY(cp(o_choff, O.ch_off.p, (n + 1) * 8)); HIP_TRY(cp(o_cloff, O.cl_off.p, (n + 1) * 8)); HIP_TRY(cp(o_qmoff, O.qm_off.p, (n + 1) * 8));
+		HIP_TRY(cp(o_hdr, O.hdr.p, B.n_chains * sizeof(hao_chain_hdr_t))); HIP_TRY(cp(o_qmz, O.qmz.p, B.n_mz * sizeof(hao_qmz_t))); HIP_TRY(cp(o_exc, O.exc.p, B.n_exc * sizeof(hao_exc_t)));
+		{	// the packed hits: 1 + n_aux pieces on as many streams (separate DMA queues)
+			const int np = B.n_aux + 1; const uint64_t per = ((B.n_cl + np - 1) / np + 63) & ~63ULL;
 			for (int k = 0; k < np; ++k) {
 				const uint64_t lo_ = std::min<uint64_t>(B.n_cl, per * k), hi_ = std::min<uint64_t>(B.n_cl, per * (k + 1));
 				if (hi_ <= lo_) continue;
-				if (k == 0) { HIP_TRY(cp(o_words, O.words.p, (hi_ - lo_) * 4)); continue; }
+				if (k == 0) { HIP_TRY(cp(o_bytes, O.bytes.p, hi_ - lo_)); continue; }
 				hipStream_t st = B.copy_aux[k - 1];
 				HIP_TRY(hipStreamWaitEvent(st, B.ev_ready[s], 0));
-				HIP_TRY(hipMemcpyAsync(a + o_words + lo_ * 4, O.words.p + lo_, (hi_ - lo_) * 4, hipMemcpyDeviceToHost, st));
+				HIP_TRY(hipMemcpyAsync(a + o_bytes + lo_, O.bytes.p + lo_, hi_ - lo_, hipMemcpyDeviceToHost, st));
 				HIP_TRY(hipEventRecord(B.ev_aux[s][k - 1], st));
 				HIP_TRY(hipStreamWaitEvent(B.copy_stream, B.ev_aux[s][k - 1], 0));
 			}
 		}
-		d.n_chains = B.n_chains; d.n_cl = B.n_cl; d.n_exc = B.n_exc; d.ch_off = (const uint64_t*)(a + o_choff); d.cl_off = (const uint64_t*)(a + o_cloff);
-		d.chains = (const hao_chain_hdr_t*)(a + o_hdr); d.cl_words = (const uint32_t*)(a + o_words); d.cl_exc = (const hao_hit_t*)(a + o_exc);
-		d.bytes += 2 * (n + 1) * 8 + B.n_chains * sizeof(hao_chain_hdr_t) + B.n_cl * 4 + B.n_exc * sizeof(hao_hit_t);
+		d.n_chains = B.n_chains; d.n_cl = B.n_cl; d.n_exc = B.n_exc; d.ch_off = (const uint64_t*)(a + o_choff); d.cl_off = (const uint64_t*)(a + o_cloff); d.qm_off = (const uint64_t*)(a + o_qmoff);
+		d.chains = (const hao_chain_hdr_t*)(a + o_hdr); d.qmz = (const hao_qmz_t*)(a + o_qmz); d.cl_bytes = a + o_bytes; d.cl_exc = (const hao_exc_t*)(a + o_exc);
+		d.bytes += 3 * (n + 1) * 8 + B.n_chains * sizeof(hao_chain_hdr_t) + B.n_mz * sizeof(hao_qmz_t) + B.n_cl + B.n_exc * sizeof(hao_exc_t);
 	}
+	if (ex && n) { HIP_TRY(cp(o_ex, O.exact.p, B.n_ol)); d.exact = a + o_ex; d.n_ol = B.n_ol; d.bytes += B.n_ol; }
 	HIP_TRY(hipEventRecord(B.ev_done[s], B.copy_stream));
 	B.dl_pending[s] = true;
 	return HAO_OK;
@@ -128,7 +151,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	if (!c->has_pt) { hao_set_err(c, "hao_pt_gen must run before hao_overlap_batch"); return HAO_EINVAL; }
 	if (!c->batch) c->batch = new hao_ctx::Batch();
 	hao_ctx::Batch &B = *c->batch;
-	B.valid = false; B.host_valid = false; B.cl_valid = false; B.lo = lo; B.n = hi - lo; B.dl_parts = parts; B.n_exc = 0;
+	B.valid = false; B.host_valid = false; B.cl_valid = false; B.exact_valid = false; B.h_exact.clear(); B.lo = lo; B.n = hi - lo; B.dl_parts = parts; B.n_exc = 0;
 	const uint64_t n = B.n;
 	if (parts) {
 		if (int rc = hao_deliver_init(c, B)) return rc;
@@ -281,12 +304,16 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	hao_pack_args pa; memset(&pa, 0, sizeof(pa));
 	if (parts & HAO_DELIVER_CL) {
 		hao_ctx::Batch::OutSet &O = B.O();
-		HIP_TRY(O.hdr.reserve(NCmax + 1)); HIP_TRY(O.words.reserve(A + 1)); HIP_TRY(O.exc.reserve(c->sw.exc_cap >= 0 ? (uint64_t)c->sw.exc_cap + 1 : std::max<uint64_t>(1 << 16, A / 64))); HIP_TRY(O.ch_off.reserve(n + 2)); HIP_TRY(O.cl_off.reserve(n + 2));
-		pa.cd = B.cd.p; pa.n_chains = NCmax; pa.hits = B.hits.p; pa.ohits = B.ohits.p; pa.hdr = O.hdr.p; pa.words = O.words.p; pa.exc = O.exc.p; pa.exc_cnt = d_exc_cnt; pa.exc_every = (uint32_t)c->sw.exc_every; pa.exc_cap = c->sw.exc_cap >= 0 ? std::min<uint64_t>(O.exc.cap, (uint64_t)c->sw.exc_cap) : O.exc.cap;
+		HIP_TRY(O.hdr.reserve(NCmax + 1)); HIP_TRY(O.bytes.reserve(A + 16)); HIP_TRY(O.exc.reserve(c->sw.exc_cap >= 0 ? (uint64_t)c->sw.exc_cap + 1 : std::max<uint64_t>(1 << 14, A / 256)));
+		HIP_TRY(O.ch_off.reserve(n + 2)); HIP_TRY(O.cl_off.reserve(n + 2)); HIP_TRY(O.qm_off.reserve(n + 2)); HIP_TRY(O.qmz.reserve(nm + 1));
+		pa.cd = B.cd.p; pa.hits = B.hits.p; pa.ohits = B.ohits.p; pa.mz_off = c->d_ix_mz_off.p; pa.rid_lo = lo; pa.mz0 = B.mz0; pa.q_pos = B.q_pos.p;
+		pa.hdr = O.hdr.p; pa.bytes = O.bytes.p; pa.exc = O.exc.p; pa.exc_cnt = d_exc_cnt; pa.exc_every = (uint32_t)c->sw.exc_every;
+		pa.exc_cap = c->sw.exc_cap >= 0 ? std::min<uint64_t>(O.exc.cap, (uint64_t)c->sw.exc_cap) : O.exc.cap;
 		// the number of chains is only known on the device here: launch over the bound, the kernel stops at ch_base[G]
 		if (G) { hipLaunchKernelGGL(hao_pack_chains_kernel, dim3((unsigned)((NCmax + 3) / 4)), dim3(256), 0, c->stream, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH(); }
-		hipLaunchKernelGGL(hao_read_ranges_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, B.g_off.p, B.ch_base.p, B.cl_base.p, n, O.ch_off.p, O.cl_off.p);
+		hipLaunchKernelGGL(hao_read_ranges_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, B.g_off.p, B.ch_base.p, B.cl_base.p, c->d_ix_mz_off.p, lo, B.mz0, n, O.ch_off.p, O.cl_off.p, O.qm_off.p);
 		HAO_CHECK_LAUNCH();
+		if (nm) { hipLaunchKernelGGL(hao_qtab_kernel, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, c->stream, B.q_pos.p, B.q_cnt.p, nm, O.qmz.p); HAO_CHECK_LAUNCH(); }
 	}
 	c->timer.mark("q_assemble");
 	// Q8 selection
@@ -348,12 +375,20 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		HIP_TRY(hipMemcpyAsync(&n_exc, d_exc_cnt, 8, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 	}
+	if ((parts & HAO_DELIVER_CL) && n_exc > 1) {      // the list was appended in arrival order: sort it by hit index (the decoder looks hits up; also makes the bytes deterministic)
+		hao_ctx::Batch::OutSet &O = B.O(); size_t tb = 0;
+		HIP_TRY(O.exc2.reserve(n_exc + 1));
+		HIP_TRY(rocprim::merge_sort(nullptr, tb, O.exc.p, O.exc2.p, (size_t)n_exc, ExcLess(), c->stream)); HIP_TRY(hao_tmp(c, tb));
+		HIP_TRY(rocprim::merge_sort(c->d_tmp.p, tb, O.exc.p, O.exc2.p, (size_t)n_exc, ExcLess(), c->stream));
+		std::swap(O.exc, O.exc2);
+	}
 	B.n_exc = n_exc;
 	B.n_generic = 0; for (int x = 0; x < HAO_NCLS; ++x) B.n_generic += slow_st[x];
 	B.n_generic_hits = slow_st[HAO_NCLS];
 	if (c->sw.dp_stats) { fprintf(stderr, "[dp] slow groups by class:"); for (int x = 0; x < HAO_NCLS; ++x) fprintf(stderr, " %llu/%llu", slow_st[x], cls_cnt[x]);
 		fprintf(stderr, "  hits %llu  dp range %llu  spec-committed %llu  spec-failures %llu\n", slow_st[HAO_NCLS], slow_st[HAO_NCLS + 3], slow_st[HAO_NCLS + 1], slow_st[HAO_NCLS + 2]); }
 	B.valid = true;
+	if (parts & HAO_DELIVER_EXACT) { if (int rc = hao_exact_run(c)) return rc; }
 	if (parts) return hao_deliver_enqueue(c);
 	return HAO_OK;
 }

@@ -120,7 +120,7 @@ int hao_overlap_batch_ex(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi, const hao
 
 int hao_overlap_batch_async(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi, const hao_pass_t *pass, uint32_t parts, int *slot)
 {
-	if (!c || rid_lo > rid_hi || rid_hi > c->n_reads || !(parts & (HAO_DELIVER_OL | HAO_DELIVER_CL))) return HAO_EINVAL;
+	if (!c || rid_lo > rid_hi || rid_hi > c->n_reads || !(parts & (HAO_DELIVER_OL | HAO_DELIVER_CL | HAO_DELIVER_EXACT))) return HAO_EINVAL;
 	hao_pass_t ps;
 	if (!pass) { if (int rc = hao_pass_default(c, &ps)) return rc; pass = &ps; }
 	HIP_TRY(hipSetDevice(c->device));
@@ -141,28 +141,53 @@ int hao_deliver_wait(hao_ctx *c, int slot, hao_delivery_t *out)
 	return HAO_OK;
 }
 
-// pure function of a delivered view (any thread): the wire words of read rid back into k_mer_hits (hao_deliver.cuh describes the format)
+// pure function of a delivered view (any thread): the wire bytes of read rid back into k_mer_hits (hao_deliver.cuh describes the format)
 uint64_t hao_unpack_hits(const hao_delivery_t *d, uint64_t rid, hao_hit_t *out, uint64_t cap)
 {
 	if (!d || rid < d->rid_lo || rid >= d->rid_lo + d->n_reads || !d->cl_off) return 0;
 	const uint64_t r = rid - d->rid_lo, h0 = d->cl_off[r], nh = d->cl_off[r + 1] - h0;
 	if (nh > cap || !out) return nh;
+	const hao_qmz_t *qt = d->qmz + d->qm_off[r];
 	uint64_t k = 0;
 	for (uint64_t ci = d->ch_off[r]; ci < d->ch_off[r + 1]; ++ci) {
 		const hao_chain_hdr_t &H = d->chains[ci];
-		uint32_t off = H.offset, self = H.self_offset; const uint32_t *w = d->cl_words + h0 + k;
+		uint32_t q = H.q0, off = H.offset; const uint8_t *w = d->cl_bytes + h0 + k;
 		for (uint32_t i = 0; i < H.n_hits; ++i) {
-			const uint32_t x = w[i]; hao_hit_t &o = out[k + i];
-			if (x >> 31) { o = d->cl_exc[x & 0x7fffffffu]; off = o.offset; self = o.self_offset; }
-			else {
-				const uint32_t ds = x & 0x1fffu; const int32_t dd = (int32_t)(x >> 13 & 0x7fu) - 64;
-				self += ds; off = (uint32_t)((int64_t)off + (int64_t)ds + dd);
-				o.w0 = H.w0; o.offset = off; o.self_offset = self; o.cnt = (x >> 28 & 7u) << 8 | (x >> 20 & 0xffu);
+			hao_hit_t &o = out[k + i];
+			if (i && w[i] == 0xff) {      // verbatim: binary search of the hit's index in the sorted exception list
+				const uint64_t key = h0 + k + i; uint64_t lo = 0, hi = d->n_exc;
+				while (lo < hi) { const uint64_t m = (lo + hi) >> 1; if (d->cl_exc[m].index < key) lo = m + 1; else hi = m; }
+				o = d->cl_exc[lo].hit; q = d->cl_exc[lo].q; off = o.offset;
+				continue;
 			}
+			if (i) { const uint32_t qn = q + (w[i] >> 4) + 1; off = (uint32_t)((int64_t)off + (int64_t)(qt[qn].self_offset - qt[q].self_offset) + (int64_t)(w[i] & 15) - 8); q = qn; }
+			o.w0 = H.w0; o.offset = off; o.self_offset = qt[q].self_offset; o.cnt = qt[q].cnt;
 		}
 		k += H.n_hits;
 	}
 	return k;
+}
+
+int hao_exact_check(hao_ctx *c)
+{
+	if (!c || !c->batch || !c->batch->valid) return HAO_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	if (int rc = hao_exact_run(c)) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return HAO_OK;
+}
+
+int hao_fetch_exact(hao_ctx *c, uint64_t rid, const uint8_t **flags, uint64_t *n)
+{
+	if (!c || !flags || !n || !c->batch || !c->batch->valid || rid < c->batch->lo || rid >= c->batch->lo + c->batch->n) return HAO_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	if (int rc = hao_exact_check(c)) return rc;
+	if (int rc = hao_batch_download(c)) return rc;
+	hao_ctx::Batch &B = *c->batch;
+	if (B.h_exact.size() != B.n_ol + 1) { B.h_exact.assign(B.n_ol + 1, 0); if (B.n_ol) HIP_TRY(hipMemcpy(B.h_exact.data(), B.O().exact.p, B.n_ol, hipMemcpyDeviceToHost)); }
+	const uint64_t r = rid - B.lo, s_ = B.h_fin_off[r], e_ = B.h_fin_off[r + 1];
+	*flags = B.h_exact.data() + s_; *n = e_ - s_;
+	return HAO_OK;
 }
 
 int hao_fetch_seed_hits(hao_ctx *c, uint64_t rid, const hao_hit_t **hits, uint64_t *n)

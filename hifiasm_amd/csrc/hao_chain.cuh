@@ -785,6 +785,7 @@ struct hao_cdesc {
 	uint64_t src;      // index of the first hit; bit 63 set: in ohits, else in hits
 	uint64_t dst;      // index of the chain's first hit in the batch's cl->list concatenation
 	uint32_t n, w0;    // hits; readID field of every hit of the chain = ordinal << 0 | strand << 31
+	uint32_t r, pad;   // query read of the chain (index inside the batch)
 };
 #define HAO_CD_OHITS (1ULL << 63)
 __device__ __forceinline__ const hao_hit_t *hao_cd_src(const hao_cdesc &d, const hao_hit_t *hits, const hao_hit_t *ohits)
@@ -821,7 +822,7 @@ __global__ __launch_bounds__(256) void chain_assemble_kernel(hao_asm_args A)
 			o.y_id = yid; o.y_pos_s = rc.y_pos_s; o.y_pos_e = rc.y_pos_e; o.y_pos_strand = rc.strand;
 			o.shared_seed = rc.score; o.align_length = rc.n_hits; o.non_homopolymer_errors = (uint32_t)(hd - cl0); o.fc_len = rc.fc_len;
 			A.ol[oi] = o; A.ol_fc_off[oi] = fd;
-			hao_cdesc d; d.src = (gs + rc.src_rel) | (rc.in_place ? 0 : HAO_CD_OHITS); d.dst = hd; d.n = rc.n_hits; d.w0 = (rc.strand << 31) | (ord & 0x7fffffffu);
+			hao_cdesc d; d.src = (gs + rc.src_rel) | (rc.in_place ? 0 : HAO_CD_OHITS); d.dst = hd; d.n = rc.n_hits; d.w0 = (rc.strand << 31) | (ord & 0x7fffffffu); d.r = r; d.pad = 0;
 			A.cd[oi] = d;
 			if (fl <= 8) for (uint32_t i = 0; i < fl; ++i) A.fc[fd + i] = fs[i];
 		}

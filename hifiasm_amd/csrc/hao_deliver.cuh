@@ -50,21 +50,22 @@ __global__ __launch_bounds__(256) void hao_digest_kernel(hao_digest_args A)
 }
 
 // ---------------------------------------------------------------------------------------
-// Wire format of cl->list (include/hao.h, hao_chain_hdr_t / hao_unpack_hits).  A chain's hits are colinear and share their readID
-// word, so a 16-byte k_mer_hit travels as ONE 32-bit word relative to its predecessor in the chain:
-//     bits  0..12  self_offset - previous self_offset                       (0 .. 8191)
-//     bits 13..19  (offset - previous offset) - (self_offset delta) + 64    (diagonal shift -64 .. 63)
-//     bits 20..27  cnt & 0xff   (k-mer span)
-//     bits 28..30  cnt >> 8     (seed weight 0 .. 7)
-//     bit  31      0
-// or, when any field does not fit:  bit 31 = 1, bits 0..30 = index of the verbatim k_mer_hit in the batch's exception list.
-// The first hit of a chain is relative to the (offset, self_offset) stored in the chain header.  4 bytes per chained hit instead of 16
-// across PCIe; the consumer thread decodes straight into its Candidates_list (one pass, no intermediate copy).
-// One wave per chain; reads the hits where the chain kernels left them (chain descriptors), so cl->list is never materialised in HBM.
+// Wire format of cl->list (include/hao.h: hao_chain_hdr_t, hao_qmz_t, hao_unpack_hits).
+// A chained hit is a pair (query minimizer, position on the target): self_offset and cnt (seed weight << 8 | span) are properties of the QUERY
+// minimizer alone (anchor.cpp:1065-1076), and along a chain the target offset follows the query offset up to a small diagonal shift.  So the
+// batch ships, per read, its minimizer table (self_offset, cnt: 8 bytes per minimizer, ~430 per 15 kb read) once, and per chained hit ONE byte:
+//     high nibble = (minimizers skipped since the previous hit of the chain) = dq - 1     (0 .. 14)
+//     low nibble  = (target offset delta) - (self_offset delta) + 8                       (diagonal shift -8 .. 7)
+// 0xff = the hit is in the batch's exception list (verbatim, with its minimizer index), keyed by the hit's index in the batch and sorted.
+// The first hit of a chain comes from the chain header (minimizer index, target offset).  ~1.3 bytes per chained hit across PCIe instead
+// of 16; the consumer thread decodes straight into its Candidates_list.  One wave per chain, reading the hits where the chain kernels left
+// them (chain descriptors): cl->list is never materialised in HBM on this path.  The minimizer index of a hit is recovered by a binary
+// search of its self_offset in the read's table (a few hundred L1/L2-resident entries).
 // ---------------------------------------------------------------------------------------
 struct hao_pack_args {
-	const hao_cdesc *cd; uint64_t n_chains; const hao_hit_t *hits, *ohits;
-	hao_chain_hdr_t *hdr; uint32_t *words; hao_hit_t *exc; unsigned long long *exc_cnt; uint64_t exc_cap; uint32_t exc_every;
+	const hao_cdesc *cd; const hao_hit_t *hits, *ohits;
+	const uint64_t *mz_off; uint64_t rid_lo, mz0; const uint32_t *q_pos;      // per-read minimizer ranges (global offsets) and the batch's self_offset table
+	hao_chain_hdr_t *hdr; uint8_t *bytes; hao_exc_t *exc; unsigned long long *exc_cnt; uint64_t exc_cap; uint32_t exc_every;
 };
 
 __global__ __launch_bounds__(256) void hao_pack_chains_kernel(hao_pack_args A, const uint64_t *n_chains_dev)
@@ -74,36 +75,123 @@ __global__ __launch_bounds__(256) void hao_pack_chains_kernel(hao_pack_args A, c
 	const int lane = hao_lane();
 	const hao_cdesc d = A.cd[ci];
 	const hao_hit_t *src = hao_cd_src(d, A.hits, A.ohits);
-	if (lane == 0) { hao_chain_hdr_t h; h.n_hits = d.n; h.w0 = d.w0; h.offset = d.n ? src[0].offset : 0; h.self_offset = d.n ? src[0].self_offset : 0; A.hdr[ci] = h; }
+	const uint64_t m0 = A.mz_off[A.rid_lo + d.r]; const uint32_t nq = (uint32_t)(A.mz_off[A.rid_lo + d.r + 1] - m0);
+	const uint32_t *qp = A.q_pos + (m0 - A.mz0);
+	uint32_t q_prev = 0, off_prev = 0, self_prev = 0;      // the last hit of the previous tile (uniform)
 	for (uint32_t b = 0; b < d.n; b += 64) {
 		const uint32_t i = b + lane; const bool act = i < d.n;
-		hao_hit_t h, p; uint32_t w = 0; bool esc = false;
+		hao_hit_t h; h.w0 = 0; h.offset = 0; h.self_offset = 0; h.cnt = 0; uint32_t q = 0;
 		if (act) {
-			h = src[i]; p = i ? src[i - 1] : h;
-			const int64_t ds = (int64_t)h.self_offset - (int64_t)p.self_offset, dd = ((int64_t)h.offset - (int64_t)p.offset) - ds;
-			esc = ds < 0 || ds > 8191 || dd < -64 || dd > 63 || (h.cnt >> 8) > 7 || (A.exc_every && i % A.exc_every == A.exc_every - 1);
-			w = (uint32_t)ds | (uint32_t)(dd + 64) << 13 | (h.cnt & 0xffu) << 20 | (h.cnt >> 8) << 28;
+			h = src[i];
+			uint32_t lo = 0, hi = nq;      // the minimizer with this self_offset (positions are strictly ascending in the table)
+			while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (qp[m] < h.self_offset) lo = m + 1; else hi = m; }
+			q = lo;
 		}
-		const unsigned long long em = __ballot(act && esc);
+		uint32_t pq = hao_wave_shr1(q, q_prev), po = hao_wave_shr1(h.offset, off_prev), ps = hao_wave_shr1(h.self_offset, self_prev);
+		uint8_t code = 0; bool esc = false;
+		if (act && i > 0) {
+			const int64_t dq = (int64_t)q - (int64_t)pq, dd = ((int64_t)h.offset - (int64_t)po) - ((int64_t)h.self_offset - (int64_t)ps);
+			esc = dq < 1 || dq > 15 || dd < -8 || dd > 7 || (A.exc_every && i % A.exc_every == A.exc_every - 1);
+			code = esc ? 0xff : (uint8_t)((dq - 1) << 4 | (dd + 8));
+		}
+		if (b == 0 && lane == 0) { hao_chain_hdr_t H; H.n_hits = d.n; H.w0 = d.w0; H.q0 = q; H.offset = h.offset; A.hdr[ci] = H; }
+		const unsigned long long em = __ballot(esc);
 		if (em) {
 			unsigned long long base = 0;
 			if (lane == 0) base = atomicAdd(A.exc_cnt, (unsigned long long)__popcll(em));
 			base = (unsigned long long)hao_readlane_i64((int64_t)base, 0);
-			if (act && esc) {
+			if (esc) {
 				const uint64_t k = base + __popcll(em & ((1ULL << lane) - 1));
-				if (k < A.exc_cap) { h.w0 = d.w0; A.exc[k] = h; }      // past the capacity only the count matters: the host grows the list and packs again
-				w = 0x80000000u | (uint32_t)(k & 0x7fffffffu);
+				if (k < A.exc_cap) { hao_exc_t e; e.index = d.dst + i; e.q = q; e.pad = 0; e.hit = h; e.hit.w0 = d.w0; A.exc[k] = e; }      // past the capacity only the count matters: the host grows the list and packs again
 			}
 		}
-		if (act) A.words[d.dst + i] = w;
+		if (act) A.bytes[d.dst + i] = code;
+		q_prev = hao_bcast(q, 63); off_prev = hao_bcast(h.offset, 63); self_prev = hao_bcast(h.self_offset, 63);
 	}
 }
 
+// the batch's minimizer table for the consumer: (self_offset, cnt) per query minimizer, interleaved
+__global__ void hao_qtab_kernel(const uint32_t *q_pos, const uint32_t *q_cnt, uint64_t n_mz, hao_qmz_t *out)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n_mz) { hao_qmz_t v; v.self_offset = q_pos[i]; v.cnt = q_cnt[i]; out[i] = v; }
+}
+
 // per read: first chain / first hit of the read in the batch (ranges of the headers and of the packed words)
-__global__ void hao_read_ranges_kernel(const uint64_t *g_off, const uint64_t *ch_base, const uint64_t *cl_base, uint64_t n_sel, uint64_t *ch_off, uint64_t *cl_off)
+__global__ void hao_read_ranges_kernel(const uint64_t *g_off, const uint64_t *ch_base, const uint64_t *cl_base, const uint64_t *mz_off, uint64_t rid_lo, uint64_t mz0, uint64_t n_sel,
+		uint64_t *ch_off, uint64_t *cl_off, uint64_t *qm_off)
 {
 	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r > n_sel) return;
 	const uint64_t g = g_off[r];
-	ch_off[r] = ch_base[g]; cl_off[r] = cl_base[g];
+	ch_off[r] = ch_base[g]; cl_off[r] = cl_base[g]; qm_off[r] = mz_off[rid_lo + r] - mz0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Exact-overlap check right after chaining: exact_ec_check (ecovlp.cpp:2803-2808) as h_ec_lchain_fast_new applies it to
+// every candidate of the final round (ecovlp.cpp:5103-5131): the query interval [x_pos_s, x_pos_e] and the target interval
+// [y_pos_s, y_pos_e] (target strand coordinates; recover_UC_Read_sub_region, Process_Read.cpp:524-614) are "exact" iff they have the same
+// length and the same characters - N sites included (an N equals only an N; the store keeps N as A plus a side list).
+// One wave per overlap on the packed 2-bit reads already resident in HBM: 16 bases per lane and step, the reverse strand by reversing the
+// 2-bit groups of the mirrored window and complementing.  flags[j] = 1 / 0 for overlap j of the batch's final ol->list order.
+// ---------------------------------------------------------------------------------------
+// 16 bases [pos, pos+16) of a packed read as one word, base `pos` in bits 31..30; bytes past the store (len/4+1 bytes) read as 0
+__device__ __forceinline__ uint32_t hao_bases16(const uint8_t *rd, uint32_t nbytes, int64_t pos)
+{
+	uint64_t v = 0; const int64_t b = pos >> 2;
+#pragma unroll
+	for (int i = 0; i < 5; ++i) { const int64_t bi = b + i; v = v << 8 | ((bi >= 0 && bi < (int64_t)nbytes) ? rd[bi] : 0); }
+	return (uint32_t)(v >> (8 - 2 * (pos & 3)));
+}
+struct hao_exact_args {
+	const hao_ovlp_t *ol; uint64_t n_ol; uint64_t rid_base;      // x_id / y_id are global read ids; the packed store is indexed locally (single device: rid_base = 0)
+	const uint8_t *packed; const uint64_t *pk_off; const uint32_t *len; const uint64_t *nsite_off; const uint32_t *nsite;      // nsite_off == nullptr: no read has N
+	uint8_t *flags;
+};
+__global__ __launch_bounds__(256) void hao_exact_check_kernel(hao_exact_args A)
+{
+	const uint64_t j = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (j >= A.n_ol) return;
+	const int lane = hao_lane();
+	const hao_ovlp_t o = A.ol[j];
+	const uint64_t q = o.x_id - A.rid_base, t = o.y_id - A.rid_base;
+	const int64_t qs = o.x_pos_s, n = (int64_t)o.x_pos_e + 1 - qs, ts = o.y_pos_s, tn = (int64_t)o.y_pos_e + 1 - ts;
+	if (n != tn) { if (lane == 0) A.flags[j] = 0; return; }
+	const uint8_t *qd = A.packed + A.pk_off[q], *td = A.packed + A.pk_off[t];
+	const uint32_t ql = A.len[q], tl = A.len[t], qb = ql / 4 + 1, tb = tl / 4 + 1; const bool rev = o.y_pos_strand != 0;
+	bool diff = false;
+	for (int64_t i0 = 0; i0 < n && !diff; i0 += 64 * 16) {
+		const int64_t i = i0 + (int64_t)lane * 16; bool d = false;
+		if (i < n) {
+			const uint32_t a = hao_bases16(qd, qb, qs + i);
+			uint32_t b;
+			if (!rev) b = hao_bases16(td, tb, ts + i);
+			else {      // strand-1 base k = complement of forward base tl - 1 - k: the window [ts+i, ts+i+16) mirrors to forward [tl-16-(ts+i), tl-(ts+i))
+				uint32_t f = hao_bases16(td, tb, (int64_t)tl - 16 - (ts + i));
+				f = __brev(f); f = ((f & 0x55555555u) << 1) | ((f >> 1) & 0x55555555u);      // reverse the order of the 2-bit groups
+				b = ~f;
+			}
+			const int64_t rem = n - i; const uint32_t m = rem >= 16 ? 0xffffffffu : ~(0xffffffffu >> (2 * rem));
+			d = ((a ^ b) & m) != 0;
+		}
+		diff = __any(d);
+	}
+	int ok = diff ? 0 : 1;
+	if (ok && A.nsite_off && lane == 0) {      // N sites: the two intervals must carry N at exactly the same offsets (lists are ascending; rare, one lane)
+		const uint64_t qa = A.nsite_off[q], qe = A.nsite_off[q + 1], ta = A.nsite_off[t], te = A.nsite_off[t + 1];
+		if (qe > qa || te > ta) {
+			uint64_t nq = 0, nt = 0;
+			for (uint64_t x = qa; x < qe; ++x) { const int64_t p = A.nsite[x]; if (p >= qs && p < qs + n) ++nq; }
+			for (uint64_t y = ta; y < te; ++y) { const int64_t p = rev ? (int64_t)tl - 1 - A.nsite[y] : (int64_t)A.nsite[y]; if (p >= ts && p < ts + n) ++nt; }
+			if (nq != nt) ok = 0;
+			for (uint64_t x = qa; x < qe && ok; ++x) {
+				const int64_t p = A.nsite[x]; if (p < qs || p >= qs + n) continue;
+				bool found = false;
+				for (uint64_t y = ta; y < te && !found; ++y) { const int64_t pt = rev ? (int64_t)tl - 1 - A.nsite[y] : (int64_t)A.nsite[y]; found = pt - ts == p - qs; }
+				if (!found) ok = 0;
+			}
+		}
+	}
+	ok = __shfl(ok, 0) && !diff;
+	if (lane == 0) A.flags[j] = (uint8_t)ok;
 }

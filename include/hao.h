@@ -151,31 +151,48 @@ int hao_batch_totals(hao_ctx *c, uint64_t out[8]);
 
 /* ---- streaming result delivery: results of batch i cross PCIe while batch i + 1 computes ----
  * h_ec_lchain hands ol->list and cl->list back to a per-read caller (anchor.cpp:2302; consumed by gen_hc_r_alin_ea, ecovlp.cpp:3288).  A batch's
- * results are ~190 KB per 15 kb read, almost all of it cl->list, so the delivery path (a) ships cl->list in a 4-byte-per-hit wire format that the
- * consumer thread decodes straight into its Candidates_list (hao_unpack_hits), (b) copies into one of two pinned host arenas on a copy stream, under
- * the next batch's kernels.  hao_overlap_batch_async returns when the batch's kernels are done and its copy is queued; hao_deliver_wait blocks until
- * the copy has landed and describes the arena.  A slot's arena (and the device buffers behind it) is reused by the second-next async batch: at most
- * two batches are in flight, and the caller must be done with batch i before it starts batch i + 2.  The views are read-only and may be read by any
- * number of threads; hao_unpack_hits is a pure function of the view. */
+ * results are ~190 KB per 15 kb read, almost all of it cl->list (16 bytes per chained hit), more than PCIe can carry at the rate the device produces
+ * them.  The delivery path therefore (a) ships cl->list in a wire format of ~1.3 bytes per hit: a chained hit is (query minimizer, target offset);
+ * self_offset and cnt belong to the query minimizer (anchor.cpp:1065-1076) and travel once per read in its minimizer table, the hit itself is one
+ * byte - minimizers skipped since the previous hit of the chain (high nibble) and diagonal shift + 8 (low nibble), 0xff = look the hit up in the
+ * (sorted) exception list; the consumer thread decodes straight into its Candidates_list (hao_unpack_hits); (b) copies into one of two pinned host
+ * arenas on copy streams, under the next batch's kernels.  hao_overlap_batch_async returns when the batch's kernels are done and its copy is
+ * queued; hao_deliver_wait blocks until the copy has landed and describes the arena.  A slot's arena (and the device buffers behind it) is reused by
+ * the second-next async batch: at most two batches are in flight, and the caller must be done with batch i before it starts batch i + 2.  The views
+ * are read-only and may be read by any number of threads; hao_unpack_hits is a pure function of the view. */
 #define HAO_DELIVER_OL 1u      /* ol->list + fake cigars */
 #define HAO_DELIVER_CL 2u      /* cl->list (wire format) */
-typedef struct { uint32_t n_hits, w0, offset, self_offset; } hao_chain_hdr_t;      /* one chain of cl->list: hit count, the readID word its hits share, first hit's coordinates */
+#define HAO_DELIVER_EXACT 4u   /* one byte per overlap: the exact-overlap check of the final round (hao_exact_check) */
+typedef struct { uint32_t n_hits, w0, q0, offset; } hao_chain_hdr_t;      /* one chain of cl->list: hit count, the readID word its hits share, first hit: minimizer index in the read, target offset */
+typedef struct { uint32_t self_offset, cnt; } hao_qmz_t;                  /* one query minimizer: k_mer_hit::self_offset and ::cnt of every hit it seeds */
+typedef struct { uint64_t index; uint32_t q, pad; hao_hit_t hit; } hao_exc_t;   /* verbatim hit: its index in the batch's cl->list concatenation, its minimizer index, the hit */
 typedef struct {
 	uint64_t rid_lo, n_reads, n_ol, n_fc, n_chains, n_cl, n_exc, bytes;            /* bytes = what crossed PCIe for this batch */
 	const uint64_t *ol_off;          /* [n_reads + 1]: ol->list of read r = ol[ol_off[r] .. ol_off[r + 1]) */
 	const hao_ovlp_t *ol;
 	const uint64_t *fc_off;          /* [n_ol + 1]: fake cigar of overlap j = fc[fc_off[j] .. fc_off[j + 1]) */
 	const uint64_t *fc;
-	const uint64_t *ch_off, *cl_off; /* [n_reads + 1]: chains / hits of read r = chains[ch_off[r] ..), cl_words[cl_off[r] ..) */
+	const uint64_t *ch_off, *cl_off, *qm_off; /* [n_reads + 1]: chains / hits / minimizers of read r = chains[ch_off[r] ..), cl_bytes[cl_off[r] ..), qmz[qm_off[r] ..) */
 	const hao_chain_hdr_t *chains;
-	const uint32_t *cl_words;        /* one word per hit: self_offset delta:13 | diagonal shift + 64:7 | span:8 | weight:3 | 0, or 1 << 31 | index into cl_exc */
-	const hao_hit_t *cl_exc;         /* hits whose deltas do not fit a word, verbatim */
-	double copy_ms;                  /* duration of this batch's device-to-host copy (filled by hao_deliver_wait) */
+	const uint8_t *cl_bytes;         /* one byte per hit (see above) */
+	const hao_qmz_t *qmz;            /* minimizer tables of the batch's reads */
+	const hao_exc_t *cl_exc;         /* [n_exc] sorted by index */
+	const uint8_t *exact;            /* [n_ol] with HAO_DELIVER_EXACT, else NULL */
+	double copy_ms;                  /* from "batch computed" to "copy landed" (includes waiting behind the previous batch's copy); filled by hao_deliver_wait */
 } hao_delivery_t;
 int hao_overlap_batch_async(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi, const hao_pass_t *pass /* NULL: hao_pass_default */, uint32_t parts, int *slot);
 int hao_deliver_wait(hao_ctx *c, int slot, hao_delivery_t *out);
 /* cl->list of read rid (a read of the delivered batch) decoded into out[cap]; returns the number of hits (nothing is written if cap is too small) */
 uint64_t hao_unpack_hits(const hao_delivery_t *d, uint64_t rid, hao_hit_t *out, uint64_t cap);
+
+/* Exact-overlap check right after chaining: exact_ec_check (ecovlp.cpp:2803-2808) as the final round applies it to every
+ * candidate h_ec_lchain returns (h_ec_lchain_fast_new, ecovlp.cpp:5103-5131; also gen_hc_r_alin_ea's pre-pass :2847-2856): flag = 1 iff the query
+ * interval [x_pos_s, x_pos_e] and the target interval [y_pos_s, y_pos_e] on strand y_pos_strand (recover_UC_Read_sub_region,
+ * Process_Read.cpp:524-614) have equal length and equal characters, N sites included.  Runs on the packed reads resident in HBM, one wave per
+ * overlap, for the final ol->list of the last batch; single-device mode only (a sharded engine holds only its own reads' bases: HAO_EUNSUPP).
+ * hao_fetch_exact serves one read's flags (aligned with hao_fetch_overlaps' ol). */
+int hao_exact_check(hao_ctx *c);
+int hao_fetch_exact(hao_ctx *c, uint64_t rid, const uint8_t **flags, uint64_t *n);
 
 /* Per-read digests of the last batch's results, computed on the device (one workgroup per read) and copied to out[n] / out_kh[n]
  * (n = reads of the batch; out_kh may be NULL):

@@ -1067,3 +1067,26 @@ int64_t hao_or_lchain(hao_or_ctx *c, uint64_t rid, const hao_or_ovlp_t **ol_out,
 	*ol_out = c->ol; *fc_out = c->fc; *fc_off_out = c->fc_off; *cl_out = c->cl; *cl_n_out = m;
 	return c->ol_n;
 }
+
+
+/* ------------------------------------------------------------------ */
+/* f2: exact-overlap check after chaining (ecovlp.cpp:2803-2808 via :5103-5131) */
+/* ------------------------------------------------------------------ */
+void hao_or_exact(const hao_or_ctx *c, const hao_or_ovlp_t *ol, int64_t n, uint8_t *out)
+{
+	int64_t j, i;
+	for (j = 0; j < n; ++j) {
+		const hao_or_ovlp_t *z = &ol[j];
+		const uint8_t *q = c->codes + c->off[z->x_id], *t = c->codes + c->off[z->y_id];
+		int64_t tl = (int64_t)(c->off[z->y_id + 1] - c->off[z->y_id]);
+		int64_t qs = z->x_pos_s, qe = (int64_t)z->x_pos_e + 1, ts = z->y_pos_s, te = (int64_t)z->y_pos_e + 1;
+		uint8_t ok = qe - qs == te - ts;                       /* exact_ec_check: different lengths are never exact */
+		for (i = 0; ok && i < qe - qs; ++i) {
+			uint8_t a = q[qs + i] > 3 ? 4 : q[qs + i], b;      /* the read as characters: A C G T, anything else N */
+			if (!z->y_pos_strand) b = t[ts + i] > 3 ? 4 : t[ts + i];
+			else { uint8_t f = t[tl - 1 - (ts + i)]; b = f > 3 ? 4 : (uint8_t)(3 - f); }      /* strand 1: reverse complement, N stays N (Process_Read.cpp:564-614) */
+			if (a != b) ok = 0;
+		}
+		out[j] = ok;
+	}
+}

@@ -87,6 +87,11 @@ int64_t hao_or_seed_hits(hao_or_ctx *c, uint64_t rid, const hao_or_hit_t **out);
 int64_t hao_or_lchain(hao_or_ctx *c, uint64_t rid, const hao_or_ovlp_t **ol, const uint64_t **fc, const uint64_t **fc_off,
 					  const hao_or_hit_t **cl, int64_t *cl_n);
 
+/* exact_ec_check (ecovlp.cpp:2803-2808) as h_ec_lchain_fast_new applies it to every overlap h_ec_lchain returned (ecovlp.cpp:5103-5131): out[j] = 1 iff
+ * the query interval [x_pos_s, x_pos_e] equals, character by character (N only equals N), the target interval [y_pos_s, y_pos_e] taken on strand
+ * y_pos_strand (recover_UC_Read_sub_region, Process_Read.cpp:524-614).  ol = n overlaps as hao_or_lchain returned them; out holds n bytes. */
+void hao_or_exact(const hao_or_ctx *c, const hao_or_ovlp_t *ol, int64_t n, uint8_t *out);
+
 /* ha_analyze_count (hist.cpp:74-157) with m_peak_hom <= 0 (hg_size unset) / with the prior m_peak_hom (adj_m_peak_hom, hist.cpp:46-72) */
 int hao_or_analyze_count(int n_cnt, int start_cnt, const int64_t *cnt, int *peak_het);
 int hao_or_analyze_count_m(int n_cnt, int start_cnt, int m_peak_hom, const int64_t *cnt, int *peak_het);

@@ -252,7 +252,7 @@ int main(int argc, char *argv[])
 	{ // per-read seed hits before chaining, and (ol, cl) after h_ec_lchain
 		tbuf_t *b = tbuf_init(1);
 		std::vector<uint64_t> kh_off(n_sel + 1, 0), ol_off(n_sel + 1, 0), cl_off(n_sel + 1, 0), fc_off(1, 0), fc;
-		std::vector<uint32_t> kh, ol, cl;
+		std::vector<uint32_t> kh, ol, cl; std::vector<uint8_t> ex; UC_Read tu; init_UC_Read(&tu);
 		for (uint64_t ii = 0; ii < n_sel; ++ii) {
 			const uint64_t i = sel[ii];
 			uint32_t ho = high_occ, lo = low_occ;
@@ -269,6 +269,16 @@ int main(int argc, char *argv[])
 				uint32_t q[12] = { r->x_id, r->x_pos_s, r->x_pos_e, r->x_pos_strand, r->y_id, r->y_pos_s, r->y_pos_e, r->y_pos_strand,
 								   (uint32_t)r->shared_seed, r->align_length, r->non_homopolymer_errors, r->f_cigar.length };
 				ol.insert(ol.end(), q, q + 12);
+				{	// the final round's exact-overlap check of this candidate: exact_ec_check (ecovlp.cpp:2803-2808, a file-local inline: equal lengths + memcmp)
+					// on the strings h_ec_lchain_fast_new builds (ecovlp.cpp:5124-5131): the whole query read, the target interval on its strand
+					int64_t bq0 = r->x_pos_s, bq1 = (int64_t)r->x_pos_e + 1, bt0 = r->y_pos_s, bt1 = (int64_t)r->y_pos_e + 1; uint8_t e = 0;
+					if (bq1 - bq0 == bt1 - bt0) {
+						if (bt1 - bt0 + 8 > (int64_t)tu.size) { tu.size = bt1 - bt0 + 8; tu.seq = (char*)realloc(tu.seq, tu.size); }      // (resize_UC_Read, Correct.h:1341)
+						recover_UC_Read_sub_region(tu.seq, bt0, bt1 - bt0, r->y_pos_strand, &R_INF, r->y_id);
+						e = memcmp(b->ur.seq + bq0, tu.seq, bq1 - bq0) == 0;
+					}
+					ex.push_back(e);
+				}
 				for (uint32_t c = 0; c < r->f_cigar.length; ++c) fc.push_back(r->f_cigar.buffer[c]);
 				fc_off.push_back(fc.size());
 			}
@@ -281,7 +291,7 @@ int main(int argc, char *argv[])
 		tot_ol = ol.size() / 12; tot_kh = kh.size() / 4;
 		wr(prefix, "sel.u64", sel.data(), 8 * sel.size());
 		wr(prefix, "kh_off.u64", &kh_off[0], 8 * kh_off.size()); wr(prefix, "kh.u32", kh.data(), 4 * kh.size());
-		wr(prefix, "ol_off.u64", &ol_off[0], 8 * ol_off.size()); wr(prefix, "ol.u32", ol.data(), 4 * ol.size());
+		wr(prefix, "ol_off.u64", &ol_off[0], 8 * ol_off.size()); wr(prefix, "ol.u32", ol.data(), 4 * ol.size()); wr(prefix, "ex.u8", ex.data(), ex.size());
 		wr(prefix, "fc_off.u64", &fc_off[0], 8 * fc_off.size()); wr(prefix, "fc.u64", fc.data(), 8 * fc.size());
 		wr(prefix, "cl_off.u64", &cl_off[0], 8 * cl_off.size()); wr(prefix, "cl.u32", cl.data(), 4 * cl.size());
 	}

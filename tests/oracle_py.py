@@ -46,6 +46,7 @@ def lib():
         L.hao_or_seed_hits.argtypes = [vp, C.c_uint64, C.POINTER(vp)]; L.hao_or_seed_hits.restype = C.c_int64
         L.hao_or_lchain.argtypes = [vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i64p]
         L.hao_or_lchain.restype = C.c_int64
+        L.hao_or_exact.argtypes = [vp, vp, C.c_int64, u8p]
         L.hao_or_analyze_count.argtypes = [C.c_int, C.c_int, i64p, C.POINTER(C.c_int)]; L.hao_or_analyze_count.restype = C.c_int
         _LIB = L
     return _LIB
@@ -150,13 +151,25 @@ _META_NAMES = ["n_reads", "k", "w", "hom_cov_ft", "ft_peak_hom", "ft_peak_het", 
                "max_kmer_cnt", "high_factor_x1000"]
 
 
+def _exact(self, ol):
+    """exact-overlap flags (uint8) of overlaps ol (uint32 [n,12], as lchain() returns them)"""
+    a = np.ascontiguousarray(ol, dtype=np.uint32)
+    out = np.zeros(a.shape[0], dtype=np.uint8)
+    if a.shape[0]:
+        self.L.hao_or_exact(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0], out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
+Oracle.exact = _exact
+
+
 def load_ref_meta(prefix: str):
     return dict(zip(_META_NAMES, [int(x) for x in np.fromfile(prefix + ".meta.i64", dtype=np.int64)]))
 
 
 def load_ref_dump(prefix: str):
     """Read a ref_harness --dump PREFIX directory into a dict of numpy arrays."""
-    ext = {"u64": np.uint64, "i64": np.int64, "u32": np.uint32, "i32": np.int32}
+    ext = {"u64": np.uint64, "i64": np.int64, "u32": np.uint32, "i32": np.int32, "u8": np.uint8}
     d = {}
     base = os.path.basename(prefix)
     for fn in os.listdir(os.path.dirname(prefix)):

@@ -30,6 +30,8 @@ SCENARIOS = {
     # size: the prior sits on the peak; hg2 = half of it: the only peak lies far below the prior and becomes the heterozygous peak
     "hg":    (dict(genome_size=40_000, coverage=18, read_len=4000, err=0.002, seed=3, len_jit=1000), dict(hg_size=40_000)),
     "hg2":   (dict(genome_size=40_000, coverage=18, read_len=4000, err=0.002, seed=3, len_jit=1000), dict(hg_size=20_000)),
+    # corrected-read-like error rate (the final round runs on corrected reads): most overlaps are exact matches (exact-overlap check, f2)
+    "exact": (dict(genome_size=60_000, coverage=16, read_len=4000, err=0.0002, seed=18, len_jit=1500, n_rate=0.0001), dict(bw_thres=0.001)),
     # ragged / degenerate reads mixed into a normal set (see edge_reads below)
     "edge":  (dict(builder="edge"), {}),
 }

@@ -68,3 +68,4 @@ def test_seed_hits_and_chains(name):
         assert (fc == fc_all[int(g["fc_off"][s]):int(g["fc_off"][e])]).all()
         assert cl.shape[0] == int(g["cl_off"][r + 1] - g["cl_off"][r])
         assert crc(cl) == int(g["cl_crc"][r]), f"chained hits of read {r}"
+        assert (o.exact(ol) == g["ex"][s:e]).all(), f"exact-overlap flags of read {r}"      # exact_ec_check on the reference's own strings (ecovlp.cpp:2803, 5124-5131)
