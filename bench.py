@@ -241,8 +241,8 @@ def main():
     value = overlaps / (dt / a.steps)
     boundary = None
     if not a.no_boundary and hasattr(eng, "overlap_batch_async"):
-        bdt, bov, btot, _ = timed(True)
-        boundary = {"value": bov / (bdt / a.steps), "ms_per_step": bdt / a.steps * 1e3, "host_bytes_per_gpu_step": btot["host_bytes"],
+        bdt, bov, btot, bst = timed(True)
+        boundary = {"q_assemble_ms_per_step": bst.get("q_assemble", 0.0) / a.steps,"value": bov / (bdt / a.steps), "ms_per_step": bdt / a.steps * 1e3, "host_bytes_per_gpu_step": btot["host_bytes"],
                     "copy_ms_per_step": btot["copy_ms"], "copy_gb_per_s": btot["host_bytes"] / max(1e-9, btot["copy_ms"] * 1e-3) / 1e9}
 
     if rank == 0:
@@ -297,6 +297,7 @@ def main():
             "value_boundary": round(boundary["value"], 1) if boundary else None,
             "boundary": ({"ms_per_step": round(boundary["ms_per_step"], 3), "host_bytes_per_gpu_step": boundary["host_bytes_per_gpu_step"],
                           "copy_ms_per_step": round(boundary["copy_ms_per_step"], 2), "copy_gb_per_s": round(boundary["copy_gb_per_s"], 2),
+                          "assemble_and_pack_ms_per_step": round(boundary["q_assemble_ms_per_step"], 2),
                           "what": "same step with every batch's ol->list, fake cigars and packed cl->list delivered into pinned host memory (double-buffered, copy stream under the next batch's compute)"}
                          if boundary else None),
             "config": {"workload": a.workload, "reads_per_gpu": n_reads, "bases_per_gpu": rs.total_bases, "batches_per_pass": len(ranges),

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void hao_digest_kernel(hao_digest_args A)
 // them (chain descriptors): cl->list is never materialised in HBM on this path.  The minimizer index of a hit is recovered by a binary
 // search of its self_offset in the read's table (a few hundred L1/L2-resident entries).
 // ---------------------------------------------------------------------------------------
+#define HAO_PACK_QCAP 1024
 struct hao_pack_args {
 	const hao_cdesc *cd; const hao_hit_t *hits, *ohits;
 	const uint64_t *mz_off; uint64_t rid_lo, mz0; const uint32_t *q_pos;      // per-read minimizer ranges (global offsets) and the batch's self_offset table
@@ -77,6 +78,12 @@ __global__ __launch_bounds__(256) void hao_pack_chains_kernel(hao_pack_args A, c
 	const hao_hit_t *src = hao_cd_src(d, A.hits, A.ohits);
 	const uint64_t m0 = A.mz_off[A.rid_lo + d.r]; const uint32_t nq = (uint32_t)(A.mz_off[A.rid_lo + d.r + 1] - m0);
 	const uint32_t *qp = A.q_pos + (m0 - A.mz0);
+	// the read's self_offset table goes to LDS once per chain (a few hundred entries, L2-resident): nine dependent LDS reads per hit instead of nine
+	// dependent global loads; longer tables (reads beyond ~35 kb) are searched in place
+	__shared__ uint32_t s_tab[4][HAO_PACK_QCAP];
+	uint32_t *tab = s_tab[threadIdx.x >> 6]; const bool in_lds = nq <= HAO_PACK_QCAP;
+	if (in_lds) for (uint32_t k = lane; k < nq; k += 64) tab[k] = qp[k];
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 	uint32_t q_prev = 0, off_prev = 0, self_prev = 0;      // the last hit of the previous tile (uniform)
 	for (uint32_t b = 0; b < d.n; b += 64) {
 		const uint32_t i = b + lane; const bool act = i < d.n;
@@ -84,7 +91,8 @@ __global__ __launch_bounds__(256) void hao_pack_chains_kernel(hao_pack_args A, c
 		if (act) {
 			h = src[i];
 			uint32_t lo = 0, hi = nq;      // the minimizer with this self_offset (positions are strictly ascending in the table)
-			while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (qp[m] < h.self_offset) lo = m + 1; else hi = m; }
+			if (in_lds) { while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (tab[m] < h.self_offset) lo = m + 1; else hi = m; } }
+			else { while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (qp[m] < h.self_offset) lo = m + 1; else hi = m; } }
 			q = lo;
 		}
 		uint32_t pq = hao_wave_shr1(q, q_prev), po = hao_wave_shr1(h.offset, off_prev), ps = hao_wave_shr1(h.self_offset, self_prev);
