@@ -187,14 +187,17 @@ def main():
     def step(deliver=False):
         eng.ha_pt_gen()
         st = {k: v for k, v in eng.stage_times()}
-        tot = {"overlaps": 0, "chained_hits": 0, "seed_hits": 0, "groups": 0, "minimizers": 0, "seq_groups": 0, "seq_group_hits": 0, "host_bytes": 0, "copy_ms": 0.0}
+        tot = {"overlaps": 0, "chained_hits": 0, "seed_hits": 0, "groups": 0, "minimizers": 0, "seq_groups": 0, "seq_group_hits": 0, "host_bytes": 0, "copy_ms": 0.0, "t_async": 0.0, "t_wait": 0.0}
         prev = None
         for lo, hi in ranges:
             if deliver:
+                t_a = time.time()
                 slot = eng.overlap_batch_async(lo, hi)      # compute of this batch; its copy runs under the next batch's kernels
+                t_b = time.time()
                 if prev is not None:                        # the consumer takes the previous batch now (its copy ran under this batch's kernels)
                     d = eng.deliver_wait(prev)
                     tot["host_bytes"] += int(d.bytes); tot["copy_ms"] += float(d.copy_ms)
+                tot["t_async"] += (t_b - t_a) * 1e3; tot["t_wait"] += (time.time() - t_b) * 1e3
                 prev = slot
             else:
                 eng.overlap_batch(lo, hi)
@@ -242,8 +245,8 @@ def main():
     boundary = None
     if not a.no_boundary and hasattr(eng, "overlap_batch_async"):
         bdt, bov, btot, bst = timed(True)
-        boundary = {"q_assemble_ms_per_step": bst.get("q_assemble", 0.0) / a.steps,"value": bov / (bdt / a.steps), "ms_per_step": bdt / a.steps * 1e3, "host_bytes_per_gpu_step": btot["host_bytes"],
-                    "copy_ms_per_step": btot["copy_ms"], "copy_gb_per_s": btot["host_bytes"] / max(1e-9, btot["copy_ms"] * 1e-3) / 1e9}
+        boundary = {"q_assemble_ms_per_step": bst.get("q_assemble", 0.0) / a.steps, "stage_ms": {k: round(v / a.steps, 2) for k, v in bst.items()},"value": bov / (bdt / a.steps), "ms_per_step": bdt / a.steps * 1e3, "host_bytes_per_gpu_step": btot["host_bytes"],
+                    "copy_ms_per_step": btot["copy_ms"], "host_ms_in_async": btot["t_async"], "host_ms_in_wait": btot["t_wait"], "copy_gb_per_s": btot["host_bytes"] / max(1e-9, btot["copy_ms"] * 1e-3) / 1e9}
 
     if rank == 0:
         stage_ms = {k: v / a.steps for k, v in stage_sum.items()}
@@ -298,6 +301,8 @@ def main():
             "boundary": ({"ms_per_step": round(boundary["ms_per_step"], 3), "host_bytes_per_gpu_step": boundary["host_bytes_per_gpu_step"],
                           "copy_ms_per_step": round(boundary["copy_ms_per_step"], 2), "copy_gb_per_s": round(boundary["copy_gb_per_s"], 2),
                           "assemble_and_pack_ms_per_step": round(boundary["q_assemble_ms_per_step"], 2),
+                          "host_ms_in_async": round(boundary["host_ms_in_async"], 1), "host_ms_in_wait": round(boundary["host_ms_in_wait"], 1),
+                          "stage_ms": boundary["stage_ms"],
                           "what": "same step with every batch's ol->list, fake cigars and packed cl->list delivered into pinned host memory (double-buffered, copy stream under the next batch's compute)"}
                          if boundary else None),
             "config": {"workload": a.workload, "reads_per_gpu": n_reads, "bases_per_gpu": rs.total_bases, "batches_per_pass": len(ranges),

@@ -26,7 +26,9 @@ struct hao_ctx::Batch {
 	int cur = 0;
 	OutSet &O() { return out[cur]; }
 	// delivery state: pinned host arenas, copy stream, per-slot completion events
-	unsigned char *arena[2] = { nullptr, nullptr }; size_t arena_cap[2] = { 0, 0 }; hipStream_t copy_stream = nullptr, copy_aux[8]; hipEvent_t ev_ready[2], ev_done[2], ev_aux[2][8]; int n_aux = 0; bool dl_ready = false, dl_pending[2] = { false, false };
+	unsigned char *arena[2] = { nullptr, nullptr }, *arena_dev[2] = { nullptr, nullptr }; size_t arena_cap[2] = { 0, 0 }; hipStream_t copy_stream = nullptr, copy_aux[8]; hipEvent_t ev_ready[2], ev_done[2], ev_aux[2][8]; int n_aux = 0; bool dl_ready = false, dl_pending[2] = { false, false };
+	uint32_t wgt_hi = 0xffffffffu, wgt_lo = 0xffffffffu;
+	double t_evsync = 0, t_enq = 0, t_alloc = 0, t_s1 = 0, t_s2 = 0, t_s3 = 0, t_run = 0, t_pre = 0; uint64_t t_n = 0, t_nrun = 0;      // host-side time spent in the delivery plumbing (HAO_DBG_DLTIME)
 	hao_delivery_t dl[2]; uint64_t dl_seq = 0, n_exc = 0; uint32_t dl_parts = 0; bool exact_valid = false; std::vector<uint8_t> h_exact;
 	// host copies for fetch
 	std::vector<uint64_t> h_seg, h_fin_off, h_cl_off, h_fc_out_off; std::vector<hao_hit_t> h_hits, h_cl; std::vector<hao_ovlp_t> h_ol; std::vector<uint64_t> h_fc;
@@ -41,6 +43,14 @@ struct hao_ctx::Batch {
 	}
 };
 
+// coverage windows per read of the selection's pruning scan (anchor.cpp:1966-2055: ocv_w-sized windows over the query): len / ocv_w + 2
+__global__ void hao_cc_count_kernel(const uint32_t *len, uint64_t rid0, uint64_t n, uint64_t ocv_w, uint64_t *out)
+{
+	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r > n) return;
+	out[r] = r < n ? len[rid0 + r] / ocv_w + 2 : 0;
+}
+
 __global__ void hao_fclen_kernel(const hao_chain_rec *rec, const uint32_t *nch, uint64_t n_groups, uint64_t *out)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;     // chain slot g*3+c
@@ -50,6 +60,8 @@ __global__ void hao_fclen_kernel(const hao_chain_rec *rec, const uint32_t *nch, 
 	out[i] = c < nch[g] ? rec[i].fc_len : 0;
 }
 
+#include <chrono>
+static inline double hao_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct ExcLess { __host__ __device__ bool operator()(const hao_exc_t &a, const hao_exc_t &b) const { return a.index < b.index; } };
 
 static int hao_scan_u32(hao_ctx *c, const uint32_t *in, uint64_t *out, uint64_t n_plus1)
@@ -90,13 +102,22 @@ static int hao_deliver_enqueue(hao_ctx *c)
 		if (B.arena[s]) (void)hipHostFree(B.arena[s]);
 		B.arena[s] = nullptr; B.arena_cap[s] = 0;
 		const size_t want = total + total / 4 + (1 << 20);
+		const double t0_ = hao_now();
 		HIP_TRY(hipHostMalloc((void**)&B.arena[s], want, hipHostMallocDefault));
-		B.arena_cap[s] = want;
+		B.arena_cap[s] = want; B.t_alloc += hao_now() - t0_;
+		HIP_TRY(hipHostGetDevicePointer((void**)&B.arena_dev[s], B.arena[s], 0));
 	}
 	unsigned char *a = B.arena[s];
 	HIP_TRY(hipEventRecord(B.ev_ready[s], c->stream));
 	HIP_TRY(hipStreamWaitEvent(B.copy_stream, B.ev_ready[s], 0));
-	auto cp = [&](size_t off, const void *src, size_t bytes) -> hipError_t { return bytes ? hipMemcpyAsync(a + off, src, bytes, hipMemcpyDeviceToHost, B.copy_stream) : hipSuccess; };
+	const int ck = c->sw.copy_kernel;      // copy by kernel (16-byte granules: sections are 64-byte aligned in the arena, device buffers have slack past their last element)
+	auto cp = [&](size_t off, const void *src, size_t bytes) -> hipError_t {
+		if (!bytes) return hipSuccess;
+		if (!ck) return hipMemcpyAsync(a + off, src, bytes, hipMemcpyDeviceToHost, B.copy_stream);
+		const uint64_t n16 = (bytes + 15) / 16;
+		hipLaunchKernelGGL(hao_d2h_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)ck, (n16 + 255) / 256)), dim3(256), 0, B.copy_stream, (const hao_v4u*)src, (hao_v4u*)(B.arena_dev[s] + off), n16);
+		return hipGetLastError();
+	};
 	hao_delivery_t &d = B.dl[s];
 	d.rid_lo = B.lo; d.n_reads = n; d.n_ol = d.n_fc = d.n_chains = d.n_cl = d.n_exc = 0; d.bytes = 0;
 	if (ol && n) {
@@ -110,7 +131,7 @@ static int hao_deliver_enqueue(hao_ctx *c)
 		HIP_TRY(cp(o_choff, O.ch_off.p, (n + 1) * 8)); HIP_TRY(cp(o_cloff, O.cl_off.p, (n + 1) * 8)); HIP_TRY(cp(o_qmoff, O.qm_off.p, (n + 1) * 8));
 		HIP_TRY(cp(o_hdr, O.hdr.p, B.n_chains * sizeof(hao_chain_hdr_t))); HIP_TRY(cp(o_qmz, O.qmz.p, B.n_mz * sizeof(hao_qmz_t))); HIP_TRY(cp(o_exc, O.exc.p, B.n_exc * sizeof(hao_exc_t)));
 		{	// the packed hits: 1 + n_aux pieces on as many streams (separate DMA queues)
-			const int np = B.n_aux + 1; const uint64_t per = ((B.n_cl + np - 1) / np + 63) & ~63ULL;
+			const int np = ck ? 1 : B.n_aux + 1; const uint64_t per = ((B.n_cl + np - 1) / np + 63) & ~63ULL;
 			for (int k = 0; k < np; ++k) {
 				const uint64_t lo_ = std::min<uint64_t>(B.n_cl, per * k), hi_ = std::min<uint64_t>(B.n_cl, per * (k + 1));
 				if (hi_ <= lo_) continue;
@@ -150,7 +171,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	if (ps.apend_be != 1 || ps.is_accurate != 1 || ps.gen_off != 1 || ps.mcopy_num > HAO_MCOPY_MAX || ps.ocv_w == 0) { hao_set_err(c, "unsupported h_ec_lchain arguments"); return HAO_EUNSUPP; }
 	if (!c->has_pt) { hao_set_err(c, "hao_pt_gen must run before hao_overlap_batch"); return HAO_EINVAL; }
 	if (!c->batch) c->batch = new hao_ctx::Batch();
-	hao_ctx::Batch &B = *c->batch;
+	hao_ctx::Batch &B = *c->batch; const double t_run0 = hao_now();
 	B.valid = false; B.host_valid = false; B.cl_valid = false; B.exact_valid = false; B.h_exact.clear(); B.lo = lo; B.n = hi - lo; B.dl_parts = parts; B.n_exc = 0;
 	const uint64_t n = B.n;
 	if (parts) {
@@ -159,7 +180,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		if (slot_out) *slot_out = B.cur;
 	}
 	// the output set about to be written may still be feeding a copy (its previous async batch): wait for that copy, never for the other slot's
-	if (B.dl_ready && B.dl_pending[B.cur]) { HIP_TRY(hipEventSynchronize(B.ev_done[B.cur])); B.dl_pending[B.cur] = false; }
+	if (B.dl_ready && B.dl_pending[B.cur]) { const double t0_ = hao_now(); HIP_TRY(hipEventSynchronize(B.ev_done[B.cur])); B.dl_pending[B.cur] = false; B.t_evsync += hao_now() - t0_; }
 	if (parts) { memset(&B.dl[B.cur], 0, sizeof(hao_delivery_t)); B.dl[B.cur].rid_lo = lo; B.dl[B.cur].n_reads = n; }
 	if (n == 0) { B.n_anchor = B.n_groups = B.n_chains = B.n_cl = B.n_ol = B.n_fc = B.n_mz = 0; B.valid = true; return HAO_OK; }      // (an empty delivery: nothing to copy, the view stays zeroed)
 	// minimizer range of the batch (host knows the per-read offsets? keep a host copy once)
@@ -170,8 +191,12 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	const uint64_t glo = c->rid_base + lo;      // global read id of the first query (== lo when unsharded); minimizer arrays are indexed locally
 	B.mz0 = c->h_ix_mz_off[lo]; B.n_mz = c->h_ix_mz_off[hi] - B.mz0;
 	const uint64_t nm = B.n_mz;
-	std::vector<uint32_t> wt; hao_seed_weight_table(ps.high_occ, ps.low_occ, wt);
-	HIP_TRY(B.wgt.reserve(4096)); HIP_TRY(hipMemcpyAsync(B.wgt.p, wt.data(), 4096 * 4, hipMemcpyHostToDevice, c->stream));
+	// (no host-to-device copies inside a batch: with the delivery path's bulk copy of the previous batch in flight they would queue behind it on the DMA engines)
+	if (B.wgt_hi != ps.high_occ || B.wgt_lo != ps.low_occ || !B.wgt.p) {      // seed weights depend on the pass's occurrence thresholds only: uploaded when those change
+		std::vector<uint32_t> wt; hao_seed_weight_table(ps.high_occ, ps.low_occ, wt);
+		HIP_TRY(B.wgt.reserve(4096)); HIP_TRY(hipMemcpy(B.wgt.p, wt.data(), 4096 * 4, hipMemcpyHostToDevice));
+		B.wgt_hi = ps.high_occ; B.wgt_lo = ps.low_occ;
+	}
 	HIP_TRY(B.q_pos.reserve(nm + 1)); HIP_TRY(B.q_cnt.reserve(nm + 1));
 	HIP_TRY(B.s_start.reserve(nm + 1)); HIP_TRY(B.s_n.reserve(nm + 1)); HIP_TRY(B.a_off.reserve(nm + 2)); HIP_TRY(B.seg.reserve(n + 2));
 	HIP_TRY(c->d_err.reserve(2)); HIP_TRY(hipMemsetAsync(c->d_err.p, 0, 4, c->stream));
@@ -183,8 +208,12 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	if (int rc = hao_scan_u32(c, B.s_n.p, B.a_off.p, nm + 1)) return rc;
 	hipLaunchKernelGGL(seed_segments_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_off.p, lo, n, B.mz0, B.a_off.p, B.seg.p);
 	HAO_CHECK_LAUNCH();
-	HIP_TRY(hipMemcpyAsync(&B.n_anchor, B.a_off.p + nm, 8, hipMemcpyDeviceToHost, c->stream));
+	hipLaunchKernelGGL(hao_peek_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)(B.a_off.p + nm), 1, c->peek_d);
+	HAO_CHECK_LAUNCH();
+	const double ts0_ = hao_now();
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	B.t_s1 += hao_now() - ts0_; B.t_pre += ts0_ - t_run0;
+	B.n_anchor = c->peek_h[0];
 	c->timer.mark("q_lookup");
 	const uint64_t A = B.n_anchor;
 	if (A >= (1ULL << 32)) { hao_set_err(c, "batch produces >= 2^32 anchors: use a smaller read range"); return HAO_EUNSUPP; }
@@ -205,7 +234,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		if (c->sw.seedphase) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); sa_.dbg = B.dbgbuf.p; }
 		HIP_TRY(B.ovf_list.reserve(n + 1));
 		unsigned long long *d_ovf = B.stats.p + 3 * HAO_NCLS + 3;
-		const size_t lds1 = (size_t)40 * 512 + 20 * (size_t)sa_.qcap + 16, lds2 = (size_t)40 * 1024 + 20 * (size_t)sa_.qcap + 16;      // tables of CAP slots + per-minimizer (list start, first anchor, self_offset, cnt)
+		const size_t lds1 = (size_t)40 * 512 + 12 * (size_t)sa_.qcap + 16, lds2 = (size_t)40 * 1024 + 12 * (size_t)sa_.qcap + 16;
 		if (lds2 > 64 * 1024) {     // beyond the default dynamic LDS limit: opt in (the CU has 160 KB)
 			HIP_TRY(hipFuncSetAttribute((const void*)seed_bin_kernel<9, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
 			HIP_TRY(hipFuncSetAttribute((const void*)seed_bin_kernel<10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
@@ -224,8 +253,12 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	hipLaunchKernelGGL(groups_layout_kernel, dim3(1), dim3(64), 0, c->stream, B.cls_co.p, n, d_cls_cnt);
 	HAO_CHECK_LAUNCH();
 	unsigned long long lay[HAO_NCLS + 1];
-	HIP_TRY(hipMemcpyAsync(lay, d_cls_cnt, (HAO_NCLS + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+	hipLaunchKernelGGL(hao_peek_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)d_cls_cnt, HAO_NCLS + 1, c->peek_d);
+	HAO_CHECK_LAUNCH();
+	const double ts1_ = hao_now();
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	B.t_s2 += hao_now() - ts1_;
+	for (int x = 0; x <= HAO_NCLS; ++x) lay[x] = c->peek_h[x];
 	const uint64_t G = B.n_groups = lay[HAO_NCLS];
 	hao_cls_layout L; unsigned long long cls_cnt[HAO_NCLS];
 	for (int x = 0; x <= HAO_NCLS; ++x) L.base[x] = lay[x];
@@ -251,7 +284,8 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		if (need_scratch) { HIP_TRY(B.f.reserve(A + 1)); HIP_TRY(B.ii.reserve(A + 1)); HIP_TRY(B.p.reserve(A + 1)); HIP_TRY(B.t.reserve(A + 1)); HIP_TRY(B.tm.reserve(A + 1)); }
 		ca.tm = B.tm.p; ca.f = B.f.p; ca.ii = B.ii.p; ca.p = B.p.p; ca.t = B.t.p; ca.ohits = B.ohits.p; ca.fcs = B.fcs.p; ca.rec = B.rec.p; ca.nch = B.nch.p; ca.nout = B.nout.p;
 		if (!B.side_ready) {
-			for (int x = 0; x < HAO_NCLS; ++x) { HIP_TRY(hipStreamCreateWithFlags(&B.side[x], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&B.ev_qc[x], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&B.ev_dp[x], hipEventDisableTiming)); }
+			int plo_ = 0, phi_ = 0; (void)hipDeviceGetStreamPriorityRange(&plo_, &phi_);      // same priority class as the engine's stream (see hao_create)
+			for (int x = 0; x < HAO_NCLS; ++x) { HIP_TRY(hipStreamCreateWithPriority(&B.side[x], hipStreamNonBlocking, c->sw.stream_prio ? phi_ : plo_)); HIP_TRY(hipEventCreateWithFlags(&B.ev_qc[x], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&B.ev_dp[x], hipEventDisableTiming)); }
 			B.side_ready = true;
 		}
 		const int wpb = c->sw.chain_wpb;
@@ -318,12 +352,13 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	c->timer.mark("q_assemble");
 	// Q8 selection
 	{
-		std::vector<uint64_t> &cco = B.h_cco; cco.resize(n + 1); uint64_t o = 0;      // (kept in the batch: the upload is asynchronous)
-		for (uint64_t r = 0; r < n; ++r) { cco[r] = o; o += c->h_len_all[glo + r] / par.ocv_w + 2; }
-		cco[n] = o;
-		HIP_TRY(B.cc_off.reserve(n + 1)); HIP_TRY(B.cc.reserve(o + 1)); HIP_TRY(B.n_final.reserve(n + 2)); HIP_TRY(B.fc_final.reserve(n + 2));
-		HIP_TRY(B.O().fin_off.reserve(n + 2)); HIP_TRY(B.fcf_off.reserve(n + 2));
-		HIP_TRY(hipMemcpyAsync(B.cc_off.p, cco.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+		uint64_t o = 0;      // coverage windows of the pruning scan: len / ocv_w + 2 per read; offsets by a device scan, the total (a size) from the host's copy of the lengths
+		for (uint64_t r = 0; r < n; ++r) o += c->h_len_all[glo + r] / par.ocv_w + 2;
+		HIP_TRY(B.cc_off.reserve(n + 2)); HIP_TRY(B.cc.reserve(o + 1)); HIP_TRY(B.n_final.reserve(n + 2)); HIP_TRY(B.fc_final.reserve(n + 2));
+		HIP_TRY(B.O().fin_off.reserve(n + 2)); HIP_TRY(B.fcf_off.reserve(n + 2)); HIP_TRY(B.nch64.reserve(n + 2));
+		hipLaunchKernelGGL(hao_cc_count_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, c->d_len_all.p, glo, n, (uint64_t)par.ocv_w, B.nch64.p);
+		HAO_CHECK_LAUNCH();
+		if (int rc = hao_excl_scan_u64(c, B.nch64.p, B.cc_off.p, n + 1)) return rc;
 	}
 	const uint64_t NC = NCmax;
 	HIP_TRY(B.key_xs.reserve(NC + 1)); HIP_TRY(B.key_sc.reserve(NC + 1)); HIP_TRY(B.key_al.reserve(NC + 1));
@@ -359,21 +394,27 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 					   B.O().fin_off.p, B.fcf_off.p, n, B.O().ol_out.p, B.O().fc_out.p, B.O().fc_out_off.p);
 	HAO_CHECK_LAUNCH();
 	c->timer.mark("q_final");
-	HIP_TRY(hipMemcpyAsync(&B.n_chains, B.ch_base.p + G, 8, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipMemcpyAsync(&B.n_cl, B.cl_base.p + G, 8, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipMemcpyAsync(&B.n_fc_raw, B.fc_base.p + G * HAO_MCOPY_MAX, 8, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipMemcpyAsync(&B.n_ol, B.O().fin_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipMemcpyAsync(&B.n_fc, B.fcf_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
 	unsigned long long slow_st[HAO_NCLS + 4], n_exc = 0;
-	HIP_TRY(hipMemcpyAsync(slow_st, d_slow_cnt, (HAO_NCLS + 4) * 8, hipMemcpyDeviceToHost, c->stream));
-	if (parts & HAO_DELIVER_CL) HIP_TRY(hipMemcpyAsync(&n_exc, d_exc_cnt, 8, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));
+	{	// the totals of the batch: one wave gathers them into mapped host memory
+		auto peek = [&](const void *src, int nw, int at) { hipLaunchKernelGGL(hao_peek_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)src, nw, c->peek_d + at); };
+		peek(B.ch_base.p + G, 1, 0); peek(B.cl_base.p + G, 1, 1); peek(B.fc_base.p + G * HAO_MCOPY_MAX, 1, 2); peek(B.O().fin_off.p + n, 1, 3); peek(B.fcf_off.p + n, 1, 4);
+		peek(d_slow_cnt, HAO_NCLS + 4, 8); peek(d_exc_cnt, 1, 5);
+		HAO_CHECK_LAUNCH();
+		const double ts2_ = hao_now();
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		B.t_s3 += hao_now() - ts2_; B.t_run += hao_now() - t_run0; ++B.t_nrun;
+		if (c->sw.dltime && (B.t_nrun & 15) == 0) fprintf(stderr, "[batch] %llu runs (parts %u): total %.1f ms  before sync1 %.1f  sync1 %.1f  sync2 %.1f  sync3 %.1f\n", (unsigned long long)B.t_nrun, parts, B.t_run * 1e3, B.t_pre * 1e3, B.t_s1 * 1e3, B.t_s2 * 1e3, B.t_s3 * 1e3);
+		B.n_chains = c->peek_h[0]; B.n_cl = c->peek_h[1]; B.n_fc_raw = c->peek_h[2]; B.n_ol = c->peek_h[3]; B.n_fc = c->peek_h[4];
+		for (int x = 0; x < HAO_NCLS + 4; ++x) slow_st[x] = c->peek_h[8 + x];
+		if (parts & HAO_DELIVER_CL) n_exc = c->peek_h[5];
+	}
 	if ((parts & HAO_DELIVER_CL) && n_exc > pa.exc_cap) {      // more verbatim hits than the list holds: grow it and pack again (the sources are untouched)
 		HIP_TRY(B.O().exc.reserve(n_exc + 1024)); pa.exc = B.O().exc.p; pa.exc_cap = B.O().exc.cap;
 		HIP_TRY(hipMemsetAsync(d_exc_cnt, 0, 8, c->stream));
 		hipLaunchKernelGGL(hao_pack_chains_kernel, dim3((unsigned)((NCmax + 3) / 4)), dim3(256), 0, c->stream, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH();
-		HIP_TRY(hipMemcpyAsync(&n_exc, d_exc_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+		hipLaunchKernelGGL(hao_peek_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)d_exc_cnt, 1, c->peek_d + 5); HAO_CHECK_LAUNCH();
 		HIP_TRY(hipStreamSynchronize(c->stream));
+		n_exc = c->peek_h[5];
 	}
 	if ((parts & HAO_DELIVER_CL) && n_exc > 1) {      // the list was appended in arrival order: sort it by hit index (the decoder looks hits up; also makes the bytes deterministic)
 		hao_ctx::Batch::OutSet &O = B.O(); size_t tb = 0;
@@ -389,7 +430,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		fprintf(stderr, "  hits %llu  dp range %llu  spec-committed %llu  spec-failures %llu\n", slow_st[HAO_NCLS], slow_st[HAO_NCLS + 3], slow_st[HAO_NCLS + 1], slow_st[HAO_NCLS + 2]); }
 	B.valid = true;
 	if (parts & HAO_DELIVER_EXACT) { if (int rc = hao_exact_run(c)) return rc; }
-	if (parts) return hao_deliver_enqueue(c);
+	if (parts) { const double t0_ = hao_now(); const int rc_ = hao_deliver_enqueue(c); B.t_enq += hao_now() - t0_; ++B.t_n; if (c->sw.dltime && (B.t_n & 15) == 0) fprintf(stderr, "[deliver] %llu batches: slot wait %.1f ms, enqueue %.1f ms (arena alloc %.1f ms)\n", (unsigned long long)B.t_n, B.t_evsync * 1e3, B.t_enq * 1e3, B.t_alloc * 1e3); return rc_; }
 	return HAO_OK;
 }
 

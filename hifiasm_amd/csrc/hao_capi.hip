@@ -33,7 +33,13 @@ int hao_create(int device, const hao_opt_t *opt, hao_ctx **out)
 	if (!opt || opt->k <= 0 || opt->k > 63 || opt->w <= 0 || opt->w >= 256) return HAO_EINVAL;
 	hao_ctx *c = new hao_ctx();
 	c->device = device; c->opt = *opt; c->max_n_chain = opt->max_n_chain; c->sw.load();
-	if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return HAO_ENODEV; }
+	{	// HIP multiplexes streams onto a few hardware queues: with several copy streams in flight the engine's stream can end up behind a bulk copy in its
+		// queue (measured: every batch started ~5 ms late with four copy streams), which is why the delivery path uses ONE copy stream by default.
+		// HAO_STREAM_PRIO=1 puts the engine's streams in the highest priority class instead (own queues) - measured worse: the copy then starves.
+		int lo_ = 0, hi_ = 0; (void)hipDeviceGetStreamPriorityRange(&lo_, &hi_);
+		if (hipStreamCreateWithPriority(&c->stream, hipStreamDefault, c->sw.stream_prio ? hi_ : lo_) != hipSuccess) { delete c; return HAO_ENODEV; }
+	}
+	if (hipHostMalloc((void**)&c->peek_h, 512 * 8, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&c->peek_d, c->peek_h, 0) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return HAO_ENOMEM; }
 	memset(c->ft_hist, 0, sizeof(c->ft_hist)); memset(c->pt_hist, 0, sizeof(c->pt_hist));
 	*out = c;
 	return HAO_OK;
@@ -49,6 +55,7 @@ void hao_destroy(hao_ctx *c)
 	// DevBuf members are released explicitly (no destructors: the struct is POD-ish on purpose)
 	hao_release_all(c);
 	(void)hipStreamDestroy(c->stream);
+	if (c->peek_h) (void)hipHostFree(c->peek_h);
 	delete c;
 }
 

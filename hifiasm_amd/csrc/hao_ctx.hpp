@@ -52,24 +52,33 @@ struct StageTimer {
 // run-time switches (measurement aids): read from the environment ONCE, in hao_create
 struct hao_switches {
 	bool seedphase = false, qcphase = false, dp_stats = false, seq_chain = false, dp_seqtail = false, dp_nospec = false, dp_serial = false,
-		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false;
-	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; int exc_every = 0, copy_streams = 4;
+		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, dltime = false;
+	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; int exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0;
 	void load() {
 		auto on = [](const char *n) { return getenv(n) != nullptr; };
 		seedphase = on("HAO_DBG_SEEDPHASE"); qcphase = on("HAO_DBG_QCPHASE"); dp_stats = on("HAO_DBG_DP_STATS"); seq_chain = on("HAO_DBG_SEQ_CHAIN");
 		dp_seqtail = on("HAO_DBG_DP_SEQTAIL"); dp_nospec = on("HAO_DBG_DP_NOSPEC"); dp_serial = on("HAO_DBG_DP_SERIAL"); seq_prune = on("HAO_DBG_SEQ_PRUNE");
-		selphase = on("HAO_DBG_SELPHASE"); sel1 = on("HAO_DBG_SEL1"); sk_generic = on("HAO_DBG_SK_GENERIC");
+		selphase = on("HAO_DBG_SELPHASE"); sel1 = on("HAO_DBG_SEL1"); sk_generic = on("HAO_DBG_SK_GENERIC"); dltime = on("HAO_DBG_DLTIME");
 		if (const char *e = getenv("HAO_CHAIN_WPB")) chain_wpb = std::max(1, std::min(4, atoi(e)));
 		if (const char *e = getenv("HAO_SPEC_MINCLS")) spec_mincls = atoi(e);
 		if (const char *e = getenv("HAO_DBG_SK_GCAP")) sk_gcap = atoll(e);
 		if (const char *e = getenv("HAO_DBG_EXC_CAP")) exc_cap = atoll(e);
 		if (const char *e = getenv("HAO_DBG_EXC_EVERY")) exc_every = atoi(e);      // ship every n-th hit of a chain verbatim (tests: exercise the exception list)
+		if (const char *e = getenv("HAO_STREAM_PRIO")) stream_prio = atoi(e);      // 1: the engine's streams at the highest priority (A/B: measured worse - the low-priority copy then starves)
+		if (const char *e = getenv("HAO_COPY_KERNEL")) copy_kernel = atoi(e);      // n > 0: the delivery copy is done by a kernel of n workgroups writing into the mapped arena (no DMA engine)
 		if (const char *e = getenv("HAO_COPY_STREAMS")) copy_streams = std::max(1, std::min(8, atoi(e)));      // DMA queues the delivery copy is spread over      // initial capacity of the wire format's verbatim-hit list (tests: force the grow-and-repack path)
 	}
 };
 
+// A few words the host needs from the device in the middle of a batch (sizes for the next allocation): written by a one-wave kernel into pinned,
+// device-mapped host memory instead of a hipMemcpy.  A D2H memcpy - however small - queues on the device-to-host DMA engine, behind the bulk copy of the
+// previous batch's results that the delivery path has in flight there: the "asynchronous" delivery would serialise with the compute it should hide under.
+__global__ void hao_peek_kernel(const unsigned long long *src, int n, unsigned long long *dst)
+{ if ((int)threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x]; }
+
 struct hao_ctx {
 	int device = 0; hao_opt_t opt; std::string err; hipStream_t stream = nullptr; hao_switches sw;
+	unsigned long long *peek_h = nullptr, *peek_d = nullptr;      // 512 words of mapped pinned memory
 	// ---- read store (HBM) ----
 	uint64_t n_reads = 0, n_bases = 0, n_pk_bytes = 0; bool has_n = false; uint32_t max_len = 0;
 	DevBuf<uint8_t> d_packed; DevBuf<uint64_t> d_pk_off; DevBuf<uint32_t> d_len; DevBuf<uint64_t> d_nsite_off; DevBuf<uint32_t> d_nsite;

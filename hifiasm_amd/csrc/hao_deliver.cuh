@@ -203,3 +203,11 @@ __global__ __launch_bounds__(256) void hao_exact_check_kernel(hao_exact_args A)
 	ok = __shfl(ok, 0) && !diff;
 	if (lane == 0) A.flags[j] = (uint8_t)ok;
 }
+
+
+// device -> mapped pinned host memory by a few workgroups of plain 16-byte loads / stores (alternative to the DMA engines for the delivery copy)
+typedef uint32_t hao_v4u __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void hao_d2h_kernel(const hao_v4u *src, hao_v4u *dst, uint64_t n16)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}

@@ -87,8 +87,6 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 	uint32_t *bl = tot + CAP;                    // [CAP]    read length of the slot's target (opposite-strand offsets)
 	uint64_t *l_ss = (uint64_t*)(bl + CAP);      // [qcap]   list start of minimizer q in the position index | strand of the minimizer << 63
 	uint32_t *l_ao = (uint32_t*)(l_ss + S.qcap); // [qcap+1] first anchor of minimizer q, relative to the read
-	uint32_t *l_qp = l_ao + S.qcap + 1;          // [qcap]   self_offset of the hits of minimizer q
-	uint32_t *l_qn = l_qp + S.qcap;              // [qcap]   their cnt word
 	__shared__ uint32_t s_nd, s_ovf, s_c; __shared__ uint64_t s_ws[4], s_all;
 	uint64_t *g_tmp = S.g_tmp;
 	if (!FIRST && blockIdx.x >= *ovf_cnt) return;
@@ -100,7 +98,7 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 	const bool qlds = nq <= S.qcap;                // very long reads keep the per-minimizer table in global memory (uniform branches, no flat accesses)
 	const uint64_t *g_ao = S.a_off + li0, *g_ss = S.s_start + li0, *g_info = S.mz_info + m0;
 	if (qlds) {
-		for (uint32_t q = tid; q < nq; q += 256) { l_ss[q] = g_ss[q] | (uint64_t)hao_info_rev(g_info[q]) << 63; l_ao[q] = (uint32_t)(g_ao[q] - s); l_qp[q] = S.q_pos[li0 + q]; l_qn[q] = S.q_cnt[li0 + q]; }
+		for (uint32_t q = tid; q < nq; q += 256) { l_ss[q] = g_ss[q] | (uint64_t)hao_info_rev(g_info[q]) << 63; l_ao[q] = (uint32_t)(g_ao[q] - s); }
 		if (tid == 0) l_ao[nq] = n;
 	}
 	__syncthreads();
@@ -119,10 +117,9 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 			for (uint32_t i = tid; i < CAP; i += 256) { hk[i] = HAO_BIN_EMPTY; cw[i] = 0; cw[CAP + i] = 0; cw[2 * CAP + i] = 0; cw[3 * CAP + i] = 0; }
 			if (tid == 0) { s_nd = 0; s_ovf = 0; s_c = 0; }
 			__syncthreads();
-			// The index reads of tile group t + 1 are issued before group t is inserted: a lane keeps up to 2 UA gathers in flight all the time (the pass is
-			// bound by the latency of those gathers, not by their bytes)
 			uint32_t qc = q_c0;
-			auto issue = [&](uint32_t t0, uint64_t (&yv)[UA], uint32_t (&zr)[UA]) {
+			for (uint32_t t0 = c0; t0 < c1; t0 += 64 * UA) {      // UA independent index reads in flight per lane
+				uint64_t yv[UA]; uint32_t zr[UA];
 #pragma unroll
 				for (int u = 0; u < UA; ++u) {
 					const uint32_t x = t0 + u * 64 + lane; const bool act = x < c1; uint32_t q = qc;
@@ -131,8 +128,7 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 					const uint64_t sv = HAO_SS(q);
 					yv[u] = act ? S.sinfo[(sv & ~(1ULL << 63)) + (x - HAO_AO(q))] : 0; zr[u] = (uint32_t)(sv >> 63);
 				}
-			};
-			auto insert = [&](uint32_t t0, const uint64_t (&yv)[UA], const uint32_t (&zr)[UA]) {
+				if (*v_ovf) break;
 #pragma unroll
 				for (int u = 0; u < UA; ++u) {
 					const uint32_t x = t0 + u * 64 + lane, kk = hao_info_rid(yv[u]) << 1 | (zr[u] ^ hao_info_rev(yv[u]));
@@ -147,22 +143,6 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 						}
 						atomicAdd(&cw[wv * CAP + slot], 1u);
 					}
-				}
-			};
-			{
-				uint64_t ya[UA], yb[UA]; uint32_t za[UA], zb[UA]; uint32_t t0 = c0;
-				if (t0 < c1) issue(t0, ya, za);
-				while (t0 < c1) {
-					uint32_t t1 = t0 + 64 * UA;
-					if (t1 < c1) issue(t1, yb, zb);
-					if (*v_ovf) break;
-					insert(t0, ya, za);
-					t0 = t1; if (t0 >= c1) break;
-					t1 = t0 + 64 * UA;
-					if (t1 < c1) issue(t1, ya, za);
-					if (*v_ovf) break;
-					insert(t0, yb, zb);
-					t0 = t1;
 				}
 			}
 			__syncthreads();
@@ -212,11 +192,9 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 			__syncthreads();
 			int nbits = 0; while ((1u << nbits) < D) ++nbits;
 			if (S.dbg) tk2 = wall_clock64();
-			// software-pipelined like the counting pass: the index records (and, at tile / chunk edges, the target ids of the list neighbours) of the next
-			// four tiles are in flight while the current four are ranked and written
 			uint32_t qc = q_c0;
-			const uint32_t *sinfo32 = (const uint32_t*)S.sinfo;      // low word of a record = rid:28 | low 4 bits of pos
-			auto issueB = [&](uint32_t t0, uint64_t (&yv)[4], uint32_t (&ype)[4], uint32_t (&yne)[4], uint32_t (&qv)[4]) {
+			for (uint32_t t0 = c0; t0 < c1; t0 += 256) {
+				uint64_t yv[4], ype[4], yne[4]; uint32_t qv[4], qp[4], qn[4];      // everything a hit needs from memory is requested here, four tiles deep
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
 					const uint32_t x = t0 + u * 64 + lane; const bool act = x < c1; uint32_t q = qc;
@@ -225,12 +203,11 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 					qv[u] = q;
 					const uint32_t a0 = HAO_AO(q), j = x - a0; const uint64_t ad = (HAO_SS(q) & ~(1ULL << 63)) + j;
 					yv[u] = act ? S.sinfo[ad] : 0;
-					// list neighbours normally sit in the adjacent lanes; only the lanes at a tile / chunk edge fetch theirs (target id only; 0xffffffff: none)
-					ype[u] = (act && lane == 0 && j > 0) ? (sinfo32[2 * (ad - 1)] & 0xfffffffu) : 0xffffffffu;
-					yne[u] = (act && (lane == 63 || x + 1 == c1) && j + 1 < HAO_AO(q + 1) - a0) ? (sinfo32[2 * (ad + 1)] & 0xfffffffu) : 0xffffffffu;
+					// list neighbours normally sit in the adjacent lanes; only the lanes at a tile / chunk edge fetch theirs
+					ype[u] = (act && lane == 0 && j > 0) ? S.sinfo[ad - 1] : ~0ULL;
+					yne[u] = (act && (lane == 63 || x + 1 == c1) && j + 1 < HAO_AO(q + 1) - a0) ? S.sinfo[ad + 1] : ~0ULL;
+					qp[u] = S.q_pos[li0 + q]; qn[u] = S.q_cnt[li0 + q];
 				}
-			};
-			auto place = [&](uint32_t t0, const uint64_t (&yv)[4], const uint32_t (&ype)[4], const uint32_t (&yne)[4], const uint32_t (&qv)[4]) {
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
 					const uint32_t x = t0 + u * 64 + lane, q = qv[u]; uint64_t y = yv[u];
@@ -243,9 +220,9 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 					const uint32_t yt = hao_info_rid(y);
 					uint32_t t_up = hao_wave_shr1(yt, 0u), t_dn = (uint32_t)__shfl_down((int)yt, 1);             // cross-lane moves: all lanes, before any branch
 					const uint32_t q_up = hao_wave_shr1(q, 0xffffffffu), q_dn = (uint32_t)__shfl_down((int)q, 1);
-					if (lane == 0) t_up = ype[u];
+					if (lane == 0) t_up = ype[u] == ~0ULL ? 0xffffffffu : hao_info_rid(ype[u]);
 					else if (q_up != q) t_up = 0xffffffffu;
-					if (lane == 63 || x + 1 >= c1) t_dn = yne[u];
+					if (lane == 63 || x + 1 >= c1) t_dn = yne[u] == ~0ULL ? 0xffffffffu : hao_info_rid(yne[u]);
 					else if (q_dn != q) t_dn = 0xffffffffu;
 					if (inr && rev) {
 						// opposite-strand hits of one k-mer in one target must come out by DEscending target position (ascending other_off,
@@ -272,24 +249,10 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 						hao_hit_t h; h.w0 = tidk | rev << 31;
 						// k_mer_hit::offset (anchor.cpp:1021-1023,1059-1064): target coordinate in the strand of the hit
 						h.offset = rev ? bl[slot] - 1 - (hao_info_pos(y) + 1 - hao_info_span(y)) : hao_info_pos(y);
-						h.self_offset = qlds ? l_qp[q] : S.q_pos[li0 + q]; h.cnt = qlds ? l_qn[q] : S.q_cnt[li0 + q];
+						h.self_offset = qp[u]; h.cnt = qn[u];
 						S.hits[s + base + __popcll(m & ((1ULL << lane) - 1))] = h;
 					}
 					if (inr && (m & ((1ULL << lane) - 1)) == 0) cw[wv * CAP + slot] = base + __popcll(m);
-				}
-			};
-			{
-				uint64_t ya[4], yb[4]; uint32_t pa[4], pb[4], na[4], nb[4], qa[4], qb[4]; uint32_t t0 = c0;
-				if (t0 < c1) issueB(t0, ya, pa, na, qa);
-				while (t0 < c1) {
-					uint32_t t1 = t0 + 256;
-					if (t1 < c1) issueB(t1, yb, pb, nb, qb);
-					place(t0, ya, pa, na, qa);
-					t0 = t1; if (t0 >= c1) break;
-					t1 = t0 + 256;
-					if (t1 < c1) issueB(t1, ya, pa, na, qa);
-					place(t0, yb, pb, nb, qb);
-					t0 = t1;
 				}
 			}
 			last_tid = (uint32_t)(sk[D - 1] >> 33);

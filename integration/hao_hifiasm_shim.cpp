@@ -8,9 +8,9 @@
 // oracle/_ref/); it is not part of libhao.so.  The reference's definitions of the same symbols in
 // htab.o / anchor.o are demoted to weak with objcopy, so no reference file is edited.
 //
-// Restrictions of this shim (exit(1) with a message, like the reference does on bad input):
-// -f0 only (exact counting), no trio/hp mode, whole pass results are kept in host memory
-// (fine for the plumbing configuration; a production shim streams batches).
+// Restrictions of this shim (exit(1) with a message, like the reference does on bad input): no trio/hp mode.  -f (Bloom filter, default 37) and
+// --hg-size are forwarded.  h_ec_lchain is served from the streaming delivery path of libhao.so: the kt_for workers (kthread.cpp:31-53) consume
+// batch i from a pinned host arena while batch i + 1 computes; at most two batches are ever resident on the host.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -32,11 +32,17 @@ static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
 static uint64_t g_index_gen = 0;          // bumped by every ha_pt_gen
 static bool g_reads_uploaded = false;
 
-struct pass_cache_t {
-	uint64_t gen = 0; bool valid = false; hao_pass_t ps;
-	std::vector<uint64_t> ol_off, cl_off, fc_off_base; std::vector<hao_ovlp_t> ol; std::vector<hao_hit_t> cl; std::vector<uint64_t> fc, fc_off;
-};
-static pass_cache_t g_pass;
+// Streaming server behind h_ec_lchain.  Reads are cut into batches of g_bsz; a batch lives in one of the engine's two delivery slots.  kt_for hands
+// out mostly increasing read ids, so the first worker that needs batch k + 1 computes it (hao_overlap_batch_async: ~ms) while the other workers keep
+// decoding reads of batch k out of its arena; computing k + 1 recycles the slot of k - 1 once its readers have left.  A late request for an evicted
+// batch (work stealing) simply computes it again.  Everything below is guarded by g_mu; the arenas themselves are read outside the lock under a
+// per-slot reader count.
+struct slot_t { int64_t batch = -1; bool ready = false; int readers = 0; hao_delivery_t view; };
+static slot_t g_slot[2];
+static hao_pass_t g_ps; static bool g_ps_valid = false; static uint64_t g_ps_gen = 0;
+static int64_t g_computing = -1;                 // batch some worker is computing right now (the engine runs one batch at a time)
+static uint64_t g_bsz = 0;
+static pthread_cond_t g_cv = PTHREAD_COND_INITIALIZER;
 
 static void die(const char *msg) { fprintf(stderr, "[hao-shim] ERROR: %s%s%s\n", msg, g_hao ? ": " : "", g_hao ? hao_last_error(g_hao) : ""); exit(1); }
 #define CK(x) do { if ((x) != 0) die(#x); } while (0)
@@ -132,7 +138,7 @@ ha_pt_t *ha_pt_gen(const hifiasm_opt_t *asm_opt, const void *flt_tab, int read_f
 	if (hom_cov) *hom_cov = hc;
 	if (het_cov) *het_cov = ht;
 	uint64_t nk, np; const uint64_t *k, *o, *p; (void)k; (void)o; (void)p;
-	pthread_mutex_lock(&g_mu); ++g_index_gen; g_pass.valid = false; pthread_mutex_unlock(&g_mu);
+	pthread_mutex_lock(&g_mu); ++g_index_gen; g_ps_valid = false; pthread_mutex_unlock(&g_mu);
 	(void)nk; (void)np;
 	fprintf(stderr, "[M::%s] (device) peak_hom: %d; peak_het: %d\n", __func__, hc, ht);
 	return (ha_pt_t*)g_hao;
@@ -150,26 +156,9 @@ const ha_idxpos_t *ha_pt_get(const ha_pt_t *h, uint64_t hash, int *n)
 }
 const int ha_pt_cnt(const ha_pt_t *h, uint64_t hash) { int n; ha_pt_get(h, hash, &n); return n; }
 
-// one all-reads pass on the device, results kept on the host until the index changes
-static void run_pass(const hao_pass_t *ps, uint64_t n_reads)
-{
-	pass_cache_t &P = g_pass;
-	P.ol_off.assign(n_reads + 1, 0); P.cl_off.assign(n_reads + 1, 0); P.ol.clear(); P.cl.clear(); P.fc.clear(); P.fc_off.clear();
-	const uint64_t B = 2048;
-	for (uint64_t lo = 0; lo < n_reads; lo += B) {
-		uint64_t hi = lo + B < n_reads ? lo + B : n_reads;
-		CK(hao_overlap_batch_ex(g_hao, lo, hi, ps));
-		for (uint64_t r = lo; r < hi; ++r) {
-			const hao_ovlp_t *ol; const uint64_t *fc, *fo; const hao_hit_t *cl; uint64_t n_ol, n_cl;
-			CK(hao_fetch_overlaps(g_hao, r, &ol, &n_ol, &fc, &fo, &cl, &n_cl));
-			P.ol_off[r] = P.ol.size(); P.cl_off[r] = P.cl.size();
-			for (uint64_t i = 0; i < n_ol; ++i) { P.fc_off.push_back(P.fc.size()); P.fc.insert(P.fc.end(), fc + (fo[i] - fo[0]), fc + (fo[i] - fo[0]) + ol[i].fc_len); }
-			P.ol.insert(P.ol.end(), ol, ol + n_ol); P.cl.insert(P.cl.end(), cl, cl + n_cl);
-		}
-	}
-	P.ol_off[n_reads] = P.ol.size(); P.cl_off[n_reads] = P.cl.size(); P.fc_off.push_back(P.fc.size());
-	P.ps = *ps; P.gen = g_index_gen; P.valid = true;
-}
+static_assert(sizeof(k_mer_hit) == sizeof(hao_hit_t), "k_mer_hit layout");
+// the slot that holds batch k and is ready, or -1 (g_mu held)
+static int find_slot(int64_t k) { for (int x = 0; x < 2; ++x) if (g_slot[x].batch == k && g_slot[x].ready) return x; return -1; }
 
 void h_ec_lchain(ha_abuf_t *ab, uint32_t rid, char* rs, uint64_t rl, uint64_t mz_w, uint64_t mz_k, All_reads *rref, overlap_region_alloc *overlap_list, Candidates_list *cl, double bw_thres,
 				 int max_n_chain, int apend_be, kvec_t_u8_warp* k_flag, kvec_t_u64_warp* dbg_ct, st_mt_t *sp, uint32_t *high_occ, uint32_t *low_occ, uint32_t is_accurate, uint32_t gen_off,
@@ -180,26 +169,59 @@ void h_ec_lchain(ha_abuf_t *ab, uint32_t rid, char* rs, uint64_t rl, uint64_t mz
 	ps.bw_thres = bw_thres; ps.max_n_chain = max_n_chain; ps.high_occ = high_occ ? *high_occ : UINT32_MAX; ps.low_occ = low_occ ? *low_occ : 0;
 	ps.apend_be = apend_be; ps.is_accurate = is_accurate; ps.gen_off = gen_off; ps.mcopy_num = (int32_t)mcopy_num; ps.mcopy_rate = mcopy_rate;
 	ps.chain_cutoff = chain_cutoff; ps.mcopy_khit_cut = mcopy_khit_cut; ps.ocv_w = ocv_w;
+	const uint64_t n_reads = rref->total_reads;
 	pthread_mutex_lock(&g_mu);
-	if (!g_pass.valid || g_pass.gen != g_index_gen || memcmp(&g_pass.ps, &ps, sizeof(ps)) != 0) run_pass(&ps, rref->total_reads);
+	if (!g_bsz) { const char *e = getenv("HAO_SHIM_BATCH"); g_bsz = e ? strtoull(e, 0, 10) : 4096; if (!g_bsz) g_bsz = 4096; }
+	// a new pass (other arguments - e.g. the final round's bw_thres = 0.001, ecovlp.cpp:3957 - or a rebuilt index): drain the readers, forget the slots
+	while (!g_ps_valid || g_ps_gen != g_index_gen || memcmp(&g_ps, &ps, sizeof(ps)) != 0) {
+		if (g_computing >= 0 || g_slot[0].readers || g_slot[1].readers) { pthread_cond_wait(&g_cv, &g_mu); continue; }
+		g_ps = ps; g_ps_gen = g_index_gen; g_ps_valid = true;
+		for (int x = 0; x < 2; ++x) { g_slot[x].batch = -1; g_slot[x].ready = false; }
+	}
+	const int64_t k = (int64_t)(rid / g_bsz);
+	int sl;
+	while ((sl = find_slot(k)) < 0) {
+		if (g_computing >= 0) { pthread_cond_wait(&g_cv, &g_mu); continue; }       // somebody is computing (maybe this very batch): wait and look again
+		// compute batch k here.  The engine will reuse the slot it used two batches ago: wait until nobody reads that arena any more
+		g_computing = k;
+		// (which slot that is is the engine's business: it alternates; both must be idle only if the victim is unknown - track it by the returned slot)
+		static int next_slot = 0;
+		while (g_slot[next_slot].readers) pthread_cond_wait(&g_cv, &g_mu);
+		g_slot[next_slot].batch = -1; g_slot[next_slot].ready = false;
+		pthread_mutex_unlock(&g_mu);
+		const uint64_t lo = (uint64_t)k * g_bsz, hi = lo + g_bsz < n_reads ? lo + g_bsz : n_reads; int got = -1; hao_delivery_t view;
+		CK(hao_overlap_batch_async(g_hao, lo, hi, &ps, HAO_DELIVER_OL | HAO_DELIVER_CL, &got));
+		CK(hao_deliver_wait(g_hao, got, &view));
+		pthread_mutex_lock(&g_mu);
+		if (got != next_slot) die("delivery slot order");
+		g_slot[got].batch = k; g_slot[got].ready = true; g_slot[got].view = view; next_slot = got ^ 1;
+		g_computing = -1;
+		pthread_cond_broadcast(&g_cv);
+	}
+	++g_slot[sl].readers;
+	const hao_delivery_t d = g_slot[sl].view;
 	pthread_mutex_unlock(&g_mu);
-	const pass_cache_t &P = g_pass;
+	// ---- decode out of the arena (no lock: the reader count keeps the slot alive) ----
 	// ol->list: cleared, then one zero-initialised slot per overlap (kv_pushp_ol, Hash_Table.h:251-258); scalar fields as
 	// push_ovlp_chain_qgen sets them (Hash_Table.cpp:1752-1780); f_cigar through the slot's own buffer
+	const uint64_t r = rid - d.rid_lo;
 	clear_overlap_region_alloc(overlap_list);
-	for (uint64_t i = P.ol_off[rid]; i < P.ol_off[rid + 1]; ++i) {
-		const hao_ovlp_t &s = P.ol[i]; overlap_region *z;
+	for (uint64_t i = d.ol_off[r]; i < d.ol_off[r + 1]; ++i) {
+		const hao_ovlp_t &o = d.ol[i]; overlap_region *z;
 		kv_pushp_ol(overlap_region, (*overlap_list), &z);
-		z->x_id = s.x_id; z->x_pos_s = s.x_pos_s; z->x_pos_e = s.x_pos_e; z->x_pos_strand = s.x_pos_strand;
-		z->y_id = s.y_id; z->y_pos_s = s.y_pos_s; z->y_pos_e = s.y_pos_e; z->y_pos_strand = s.y_pos_strand;
-		z->shared_seed = s.shared_seed; z->align_length = 0; z->is_match = 0; z->non_homopolymer_errors = s.non_homopolymer_errors; z->strong = 0; z->overlapLen = 0;
-		resize_fake_cigar(&z->f_cigar, s.fc_len, NULL);
-		memcpy(z->f_cigar.buffer, &P.fc[P.fc_off[i]], sizeof(uint64_t) * s.fc_len); z->f_cigar.length = s.fc_len;
+		z->x_id = o.x_id; z->x_pos_s = o.x_pos_s; z->x_pos_e = o.x_pos_e; z->x_pos_strand = o.x_pos_strand;
+		z->y_id = o.y_id; z->y_pos_s = o.y_pos_s; z->y_pos_e = o.y_pos_e; z->y_pos_strand = o.y_pos_strand;
+		z->shared_seed = o.shared_seed; z->align_length = 0; z->is_match = 0; z->non_homopolymer_errors = o.non_homopolymer_errors; z->strong = 0; z->overlapLen = 0;
+		resize_fake_cigar(&z->f_cigar, o.fc_len, NULL);
+		memcpy(z->f_cigar.buffer, d.fc + d.fc_off[i], sizeof(uint64_t) * o.fc_len); z->f_cigar.length = o.fc_len;
 	}
-	// cl->list
-	uint64_t n_cl = P.cl_off[rid + 1] - P.cl_off[rid];
+	// cl->list: the wire bytes decode straight into the caller's list (k_mer_hit and hao_hit_t share their layout, Hash_Table.h:116-120)
+	const uint64_t n_cl = d.cl_off[r + 1] - d.cl_off[r];
 	clear_Candidates_list(cl);
 	if ((uint64_t)cl->size < n_cl + 1) { cl->size = n_cl + 1; REALLOC(cl->list, cl->size); }
-	memcpy(cl->list, &P.cl[P.cl_off[rid]], n_cl * sizeof(k_mer_hit));
+	if (hao_unpack_hits(&d, rid, (hao_hit_t*)cl->list, n_cl) != n_cl) die("hao_unpack_hits");
 	cl->length = n_cl;
+	pthread_mutex_lock(&g_mu);
+	if (--g_slot[sl].readers == 0) pthread_cond_broadcast(&g_cv);
+	pthread_mutex_unlock(&g_mu);
 }
