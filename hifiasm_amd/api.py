@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "hao_ft_cnt", "hao_pt_get", "hao_ft_table", "hao_pt_table", "hao_hist", "hao_stats", "hao_sketch_batch",
     "hao_fetch_sketch", "hao_overlap_batch", "hao_fetch_seed_hits", "hao_fetch_overlaps", "hao_batch_totals",
     "hao_stage_times", "hao_pass_default", "hao_overlap_batch_ex", "hao_set_shard", "hao_dist_unique_id", "hao_dist_init",
-    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits", "hao_exact_check", "hao_fetch_exact",
+    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits", "hao_exact_check", "hao_fetch_exact", "hao_window_ed_batch",
 ]
 
 
@@ -99,6 +99,7 @@ def lib():
         L.hao_overlap_batch_async.argtypes = [vp, C.c_uint64, C.c_uint64, C.POINTER(Pass), C.c_uint32, C.POINTER(C.c_int)]
         L.hao_deliver_wait.argtypes = [vp, C.c_int, C.POINTER(Delivery)]
         L.hao_exact_check.argtypes = [vp]
+        L.hao_window_ed_batch.argtypes = [vp, vp, C.c_uint64, vp]
         L.hao_fetch_exact.argtypes = [vp, C.c_uint64, C.POINTER(vp), u64p]
         L.hao_unpack_hits.argtypes = [C.POINTER(Delivery), C.c_uint64, vp, C.c_uint64]; L.hao_unpack_hits.restype = C.c_uint64
         L.hao_set_shard.argtypes = [vp, C.c_uint64, C.c_uint64, u32p]
@@ -299,6 +300,13 @@ class Engine:
         got = self.L.hao_unpack_hits(C.byref(d), rid, cl.ctypes.data_as(C.c_void_p), m)
         assert got == m
         return ol, fc, fo - (fo[0] if fo.size else 0), cl
+
+    def window_ed_batch(self, tasks):
+        """tasks: uint32 [n,10] (p_rid, p_pos, p_len, p_rev, t_rid, t_pos, t_len, t_rev, thre, abs_diag) -> int32 [n,2] (err, pe)"""
+        t = np.ascontiguousarray(tasks, dtype=np.uint32).reshape(-1, 10)
+        out = np.zeros((t.shape[0], 2), dtype=np.int32)
+        self._ck(self.L.hao_window_ed_batch(self.h, t.ctypes.data_as(C.c_void_p), t.shape[0], out.ctypes.data_as(C.c_void_p)), "hao_window_ed_batch")
+        return out
 
     def fetch_exact(self, rid):
         """exact-overlap flags (uint8, aligned with h_ec_lchain(rid)[0]) of a read of the last batch"""

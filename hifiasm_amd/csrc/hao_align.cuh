@@ -1,0 +1,74 @@
+// Windowed bit-vector edit distance: ed_band_cal_semi_64_w_absent_diag (Levenshtein_distance.h:3727-3776), the workhorse of the
+// window alignment that follows chaining (Correct.cpp:3897,4092,4156: one call per 775-base query window and candidate).  Myers' bit-parallel
+// recurrence (ed_core_64, :3116-3125) over a band of 2 thre + 1 diagonals held in ONE 64-bit word: semi-global (the text window must be consumed,
+// the pattern = padded target region may start / end anywhere inside the band), `abs_diag` leading diagonals missing when the pattern was clipped
+// at the start of its read.
+// The recurrence is sequential in the text position but every (window, candidate) pair is independent and a read has ~20 windows x ~60 candidates:
+// one LANE per pair, both strings taken straight from the packed 2-bit reads resident in HBM (the pattern possibly on the reverse strand).
+// Returns err (INT32_MAX = no alignment within thre, like clear_align) and pe (end on the pattern, -1 = none); ps / ts / te are constants of the
+// call (-1, 0, tn - 1).  Characters: 0..3, 4 = N (never matches: Peq[4] = 0).
+#pragma once
+#include "hao_common.cuh"
+
+struct hao_ed_reads { const uint8_t *packed; const uint64_t *pk_off; const uint32_t *len; const uint64_t *nsite_off; const uint32_t *nsite; };
+
+// base `pos` of read `rid` on strand `rev` as a code 0..3, 4 = N
+__device__ __forceinline__ uint32_t hao_ed_base(const hao_ed_reads &R, uint64_t rid, const uint8_t *rd, uint32_t L, int64_t pos, int rev)
+{
+	const int64_t f = rev ? (int64_t)L - 1 - pos : pos;
+	uint32_t b = hao_base_at(rd, (uint32_t)f);
+	if (R.nsite_off) { for (uint64_t k = R.nsite_off[rid]; k < R.nsite_off[rid + 1]; ++k) { const uint32_t p = R.nsite[k]; if ((int64_t)p == f) return 4; if ((int64_t)p > f) break; } }
+	return rev ? 3 - b : b;
+}
+
+__global__ __launch_bounds__(256) void hao_window_ed_kernel(hao_ed_reads R, const hao_ed_task_t *task, uint64_t n_task, hao_ed_result_t *out)
+{
+	const uint64_t i_ = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i_ >= n_task) return;
+	const hao_ed_task_t T = task[i_];
+	const uint8_t *pd = R.packed + R.pk_off[T.p_rid], *td = R.packed + R.pk_off[T.t_rid]; const uint32_t pL = R.len[T.p_rid], tL = R.len[T.t_rid];
+	const int32_t pn = (int32_t)T.p_len, tn = (int32_t)T.t_len, thre = (int32_t)T.thre, abs_diag = (int32_t)T.abs_diag;
+	hao_ed_result_t res; res.err = INT32_MAX; res.pe = -1;
+	auto P = [&](int32_t k) { return hao_ed_base(R, T.p_rid, pd, pL, (int64_t)T.p_pos + k, T.p_rev); };
+	auto Tx = [&](int32_t k) { return hao_ed_base(R, T.t_rid, td, tL, (int64_t)T.t_pos + k, T.t_rev); };
+	const int32_t last_high = thre << 1, tn0 = tn - 1, cut = thre + last_high;
+	int32_t err = abs_diag;
+	if (pn > tn + cut || tn > pn + cut || tn <= 0) { out[i_] = res; return; }
+	uint64_t Peq[5] = {0, 0, 0, 0, 0}, VP = 0, VN, X, D0, HN, HP, mm;
+	int32_t bd = ((thre << 1) + 1) - abs_diag; if (bd > pn) bd = pn;
+	int32_t i, i_bd = abs_diag;
+	for (i = 0, mm = 1ULL << i_bd; i < bd; ++i) { Peq[P(i)] |= mm; mm <<= 1; }
+	i_bd = (thre << 1) - abs_diag; VN = (1ULL << abs_diag) - 1;
+	Peq[4] = 0; mm = 1ULL << (thre << 1);
+#define HAO_ED_CORE(z) { X = Peq[(z)] | VN; D0 = ((VP + (X & VP)) ^ VP) | X; HN = VP & D0; HP = VN | ~(VP | D0); X = D0 >> 1; VN = X & HP; VP = HN | ~(X | HP); }
+	i = 0;
+	bool dead = false;
+	while (i < tn0) {
+		HAO_ED_CORE(Tx(i));
+		if (!(D0 & 1ULL)) { ++err; if (err > cut) { dead = true; break; } }
+		Peq[0] >>= 1; Peq[1] >>= 1; Peq[2] >>= 1; Peq[3] >>= 1;
+		++i; ++i_bd;
+		uint32_t cc = 4;
+		if (i_bd < pn) cc = P(i_bd);
+		if (cc < 4) Peq[cc] |= mm;
+	}
+	if (!dead) {
+		HAO_ED_CORE(Tx(i));
+		if (!(D0 & 1ULL)) { ++err; if (err > cut) dead = true; }
+	}
+#undef HAO_ED_CORE
+	if (!dead) {
+		int32_t site = tn - 1 - abs_diag;
+		const int32_t ai = pn - tn + abs_diag; int32_t uge = INT32_MAX;
+		for (i = 0; site < 0 && i < ai; ++i, ++site) { err += (int32_t)((VP >> i) & 1ULL); err -= (int32_t)((VN >> i) & 1ULL); }
+		if (err <= thre && err <= res.err) { res.err = err; res.pe = site; }
+		site -= i;
+		while (i < ai) {
+			err += (int32_t)((VP >> i) & 1ULL); err -= (int32_t)((VN >> i) & 1ULL); ++i;
+			if (err <= thre && err <= res.err) { res.err = err; res.pe = site + i; }
+			if (i == thre) uge = err;
+		}
+		if (uge <= thre && uge == res.err) res.pe = site + thre;
+	}
+	out[i_] = res;
+}

@@ -234,8 +234,8 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		if (c->sw.seedphase) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); sa_.dbg = B.dbgbuf.p; }
 		HIP_TRY(B.ovf_list.reserve(n + 1));
 		unsigned long long *d_ovf = B.stats.p + 3 * HAO_NCLS + 3;
-		const size_t lds1 = (size_t)40 * 512 + 12 * (size_t)sa_.qcap + 16, lds2 = (size_t)40 * 1024 + 12 * (size_t)sa_.qcap + 16;
-		if (lds2 > 64 * 1024) {     // beyond the default dynamic LDS limit: opt in (the CU has 160 KB)
+		const size_t lds1 = (size_t)40 * 512 + 12 * (size_t)sa_.qcap + 16 + (size_t)c->sw.seed_lds_pad, lds2 = (size_t)40 * 1024 + 12 * (size_t)sa_.qcap + 16;
+		if (lds2 > 64 * 1024 || lds1 > 64 * 1024) {     // beyond the default dynamic LDS limit: opt in (the CU has 160 KB)
 			HIP_TRY(hipFuncSetAttribute((const void*)seed_bin_kernel<9, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
 			HIP_TRY(hipFuncSetAttribute((const void*)seed_bin_kernel<10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
 		}

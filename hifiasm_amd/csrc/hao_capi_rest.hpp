@@ -168,6 +168,29 @@ uint64_t hao_unpack_hits(const hao_delivery_t *d, uint64_t rid, hao_hit_t *out, 
 	return k;
 }
 
+int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks, hao_ed_result_t *out)
+{
+	if (!c || (!tasks && n_tasks) || (!out && n_tasks)) return HAO_EINVAL;
+	if (c->comm && c->comm->active()) { hao_set_err(c, "hao_window_ed_batch needs the bases of both reads: single-device mode only"); return HAO_EUNSUPP; }
+	if (n_tasks == 0) return HAO_OK;
+	for (uint64_t i = 0; i < n_tasks; ++i) {      // the reference indexes its strings unchecked; a device kernel must not
+		const hao_ed_task_t &t = tasks[i];
+		if (t.p_rid >= c->n_reads || t.t_rid >= c->n_reads || (uint64_t)t.p_pos + t.p_len > c->h_len[t.p_rid] || (uint64_t)t.t_pos + t.t_len > c->h_len[t.t_rid] ||
+			2 * (uint64_t)t.thre + 1 > 63 || t.abs_diag > 2 * t.thre) { hao_set_err(c, "hao_window_ed_batch: task " + std::to_string(i) + " out of range"); return HAO_EINVAL; }
+	}
+	HIP_TRY(hipSetDevice(c->device));
+	DevBuf<hao_ed_task_t> dt; DevBuf<hao_ed_result_t> dr;
+	HIP_TRY(dt.reserve(n_tasks)); HIP_TRY(dr.reserve(n_tasks));
+	HIP_TRY(hipMemcpyAsync(dt.p, tasks, n_tasks * sizeof(hao_ed_task_t), hipMemcpyHostToDevice, c->stream));
+	hao_ed_reads R; R.packed = c->d_packed.p; R.pk_off = c->d_pk_off.p; R.len = c->d_len.p; R.nsite_off = c->has_n ? c->d_nsite_off.p : nullptr; R.nsite = c->has_n ? c->d_nsite.p : nullptr;
+	hipLaunchKernelGGL(hao_window_ed_kernel, dim3((unsigned)((n_tasks + 255) / 256)), dim3(256), 0, c->stream, R, dt.p, n_tasks, dr.p);
+	HAO_CHECK_LAUNCH();
+	HIP_TRY(hipMemcpyAsync(out, dr.p, n_tasks * sizeof(hao_ed_result_t), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	dt.release(); dr.release();
+	return HAO_OK;
+}
+
 int hao_exact_check(hao_ctx *c)
 {
 	if (!c || !c->batch || !c->batch->valid) return HAO_EINVAL;

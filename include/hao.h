@@ -194,6 +194,17 @@ uint64_t hao_unpack_hits(const hao_delivery_t *d, uint64_t rid, hao_hit_t *out, 
 int hao_exact_check(hao_ctx *c);
 int hao_fetch_exact(hao_ctx *c, uint64_t rid, const uint8_t **flags, uint64_t *n);
 
+/* Windowed bit-vector edit distance: ed_band_cal_semi_64_w_absent_diag (Levenshtein_distance.h:3727-3776) for a batch of independent
+ * (pattern, text) pairs taken from the reads resident in HBM - the call Correct.cpp:3897,4092,4156 makes per 775-base query window and candidate:
+ * pattern = the padded target region [p_pos, p_pos + p_len) of read p_rid on strand p_rev, text = the query window [t_pos, t_pos + t_len) of read
+ * t_rid on strand t_rev, thre = error threshold (2 thre + 1 <= 63), abs_diag = leading diagonals missing because the pattern was clipped at the
+ * start of its read.  out[i].err = edit distance or INT32_MAX (no alignment within thre, the reference's clear_align state), out[i].pe = end of the
+ * alignment on the pattern or -1; ps = -1, ts = 0, te = t_len - 1 are constants of the call.  One lane per pair; single-device mode (the bases of
+ * both reads must be local).  This is the data-parallel core of the window alignment; window placement and retries stay with the caller. */
+typedef struct { uint32_t p_rid, p_pos, p_len, p_rev, t_rid, t_pos, t_len, t_rev, thre, abs_diag; } hao_ed_task_t;
+typedef struct { int32_t err, pe; } hao_ed_result_t;
+int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks, hao_ed_result_t *out);
+
 /* Per-read digests of the last batch's results, computed on the device (one workgroup per read) and copied to out[n] / out_kh[n]
  * (n = reads of the batch; out_kh may be NULL):
  *   out[r]    = sum of term(1, i, w) over the 64-bit words of ol->list (6 per overlap_region: the 12 u32 fields of hao_ovlp_t)

@@ -1090,3 +1090,62 @@ void hao_or_exact(const hao_or_ctx *c, const hao_or_ovlp_t *ol, int64_t n, uint8
 		out[j] = ok;
 	}
 }
+
+
+/* ------------------------------------------------------------------ */
+/* f3: windowed bit-vector edit distance (Levenshtein_distance.h:3727-3776) */
+/* ------------------------------------------------------------------ */
+static inline uint8_t ed_chr(const hao_or_ctx *c, uint32_t rid, int64_t pos, int rev)
+{	/* character of the read on a strand, as a seq_nt4_table code: 0..3, 4 = N (Process_Read.cpp:524-614 builds the same strings) */
+	const uint8_t *r = c->codes + c->off[rid]; int64_t L = (int64_t)(c->off[rid + 1] - c->off[rid]);
+	uint8_t b = r[rev ? L - 1 - pos : pos];
+	return b > 3 ? 4 : (rev ? (uint8_t)(3 - b) : b);
+}
+
+void hao_or_window_ed(const hao_or_ctx *c, const uint32_t *task, int64_t n, int32_t *out)
+{
+	int64_t q;
+	for (q = 0; q < n; ++q) {
+		const uint32_t *t = task + 10 * q;
+		int32_t pn = (int32_t)t[2], tn = (int32_t)t[6], thre = (int32_t)t[8], abs_diag = (int32_t)t[9];
+		int32_t e_out = INT32_MAX, pe_out = -1;
+		uint64_t Peq[5] = {0, 0, 0, 0, 0}, VP = 0, VN, X, D0, HN, HP, mm;
+		int32_t bd, i, err = abs_diag, i_bd, tn0 = tn - 1, cut = thre + (thre << 1), dead = 0;
+#define PCH(k) ed_chr(c, t[0], (int64_t)t[1] + (k), (int)t[3])
+#define TCH(k) ed_chr(c, t[4], (int64_t)t[5] + (k), (int)t[7])
+#define CORE(z) do { X = Peq[(z)] | VN; D0 = ((VP + (X & VP)) ^ VP) | X; HN = VP & D0; HP = VN | ~(VP | D0); X = D0 >> 1; VN = X & HP; VP = HN | ~(X | HP); } while (0)
+		if (!(pn > tn + cut || tn > pn + cut) && tn > 0) {
+			bd = ((thre << 1) + 1) - abs_diag; if (bd > pn) bd = pn;
+			i_bd = abs_diag;
+			for (i = 0, mm = 1ULL << i_bd; i < bd; ++i) { Peq[PCH(i)] |= mm; mm <<= 1; }
+			i_bd = (thre << 1) - abs_diag; VN = (1ULL << abs_diag) - 1;
+			Peq[4] = 0; mm = 1ULL << (thre << 1);
+			for (i = 0; i < tn0 && !dead; ) {
+				uint8_t cc;
+				CORE(TCH(i));
+				if (!(D0 & 1ULL)) { ++err; if (err > cut) { dead = 1; break; } }
+				Peq[0] >>= 1; Peq[1] >>= 1; Peq[2] >>= 1; Peq[3] >>= 1;
+				++i; ++i_bd; cc = 4;
+				if (i_bd < pn) cc = PCH(i_bd);
+				if (cc < 4) Peq[cc] |= mm;
+			}
+			if (!dead) { CORE(TCH(i)); if (!(D0 & 1ULL)) { ++err; if (err > cut) dead = 1; } }
+			if (!dead) {
+				int32_t site = tn - 1 - abs_diag, ai = pn - tn + abs_diag, uge = INT32_MAX;
+				for (i = 0; site < 0 && i < ai; ++i, ++site) { err += (int32_t)((VP >> i) & 1ULL); err -= (int32_t)((VN >> i) & 1ULL); }
+				if (err <= thre && err <= e_out) { e_out = err; pe_out = site; }
+				site -= i;
+				while (i < ai) {
+					err += (int32_t)((VP >> i) & 1ULL); err -= (int32_t)((VN >> i) & 1ULL); ++i;
+					if (err <= thre && err <= e_out) { e_out = err; pe_out = site + i; }
+					if (i == thre) uge = err;
+				}
+				if (uge <= thre && uge == e_out) pe_out = site + thre;
+			}
+		}
+#undef PCH
+#undef TCH
+#undef CORE
+		out[2 * q] = e_out; out[2 * q + 1] = pe_out;
+	}
+}

@@ -92,6 +92,11 @@ int64_t hao_or_lchain(hao_or_ctx *c, uint64_t rid, const hao_or_ovlp_t **ol, con
  * y_pos_strand (recover_UC_Read_sub_region, Process_Read.cpp:524-614).  ol = n overlaps as hao_or_lchain returned them; out holds n bytes. */
 void hao_or_exact(const hao_or_ctx *c, const hao_or_ovlp_t *ol, int64_t n, uint8_t *out);
 
+/* ed_band_cal_semi_64_w_absent_diag (Levenshtein_distance.h:3727-3776; ed_core_64 :3116-3125): banded Myers bit-vector edit distance of the text
+ * (read t_rid, [t_pos, t_pos + t_len) on strand t_rev) against the pattern (read p_rid, [p_pos, p_pos + p_len) on strand p_rev), threshold thre,
+ * abs_diag leading diagonals absent.  task = 10 uint32 in that order (+ thre, abs_diag); out[0] = err (INT32_MAX: none), out[1] = pe (-1: none). */
+void hao_or_window_ed(const hao_or_ctx *c, const uint32_t *task, int64_t n, int32_t *out);
+
 /* ha_analyze_count (hist.cpp:74-157) with m_peak_hom <= 0 (hg_size unset) / with the prior m_peak_hom (adj_m_peak_hom, hist.cpp:46-72) */
 int hao_or_analyze_count(int n_cnt, int start_cnt, const int64_t *cnt, int *peak_het);
 int hao_or_analyze_count_m(int n_cnt, int start_cnt, int m_peak_hom, const int64_t *cnt, int *peak_het);

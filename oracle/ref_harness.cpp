@@ -17,6 +17,9 @@
 //   --digest           PREFIX.dig.u64 = per read [digest of (ol, fc, cl), digest of the seed hits], all reads, all threads; the digest is
 //                      hao_batch_digest's (include/hao.h): a position-salted sum of mixed 64-bit words, so the device computes the same
 //                      value with a parallel reduction
+//   --ed-tasks FILE    f3: FILE = uint32[n][10] tasks (p_rid, p_pos, p_len, p_rev, t_rid, t_pos, t_len, t_rev, thre, abs_diag); PREFIX.ed.i32 = int32[n][2]
+//                      (err, pe) of the reference's ed_band_cal_semi_64_w_absent_diag (Levenshtein_distance.h:3727) on the strings
+//                      recover_UC_Read_sub_region (Process_Read.cpp:524) builds for those intervals
 //   --bw X             bw_thres of the pass (default 0.02 / 0.05 --ont; the final round uses 0.001, ecovlp.cpp:3957)
 #include <stdio.h>
 #include <stdlib.h>
@@ -29,6 +32,7 @@
 #include "Hash_Table.h"
 #include "htab.h"
 #include "kthread.h"
+#include "Levenshtein_distance.h"
 
 #define HA_KMER_GOOD_RATIO 0.333   // ecovlp.cpp / anchor.cpp:11
 #define COV_W 3072                 // ecovlp.cpp:16
@@ -120,7 +124,7 @@ static tbuf_t *tbuf_init(int n)
 
 int main(int argc, char *argv[])
 {
-	int n_thread = 1, is_ont = 0, do_time = 0, dump_hits = 1, k = -1, w = -1, bf_shift = 0, no_hpc = 0, no_tables = 0, do_digest = 0; const char *fa = 0, *list_fn = 0, *hg = 0; std::string prefix;
+	int n_thread = 1, is_ont = 0, do_time = 0, dump_hits = 1, k = -1, w = -1, bf_shift = 0, no_hpc = 0, no_tables = 0, do_digest = 0; const char *fa = 0, *list_fn = 0, *hg = 0, *ed_fn = 0; std::string prefix;
 	double bw_arg = -1;
 	for (int i = 1; i < argc; ++i) {
 		if (!strcmp(argv[i], "--ont")) is_ont = 1;
@@ -137,6 +141,7 @@ int main(int argc, char *argv[])
 		else if (!strcmp(argv[i], "--reads-list")) list_fn = argv[++i];
 		else if (!strcmp(argv[i], "--no-tables")) no_tables = 1;
 		else if (!strcmp(argv[i], "--digest")) do_digest = 1;
+		else if (!strcmp(argv[i], "--ed-tasks")) ed_fn = argv[++i];
 		else fa = argv[i];
 	}
 	if (!fa) { fprintf(stderr, "usage: ref_harness [--ont] [-t N] [-k K] [-w W] [-f BLOOM_BITS] [--dump PREFIX] [--time] reads.fa\n"); return 1; }
@@ -186,6 +191,22 @@ int main(int argc, char *argv[])
 		tbuf_t *b = tbuf_init(n_thread); pass_t p; p.b = b; p.bw = bw; p.high_occ = high_occ; p.low_occ = low_occ; p.dig = dig.data();
 		kt_for(n_thread, worker_digest, &p, n_reads);
 		wr(prefix, "dig.u64", dig.data(), 8 * dig.size());
+	}
+	if (ed_fn) {
+		FILE *fp = fopen(ed_fn, "rb"); if (!fp) { fprintf(stderr, "cannot read %s\n", ed_fn); return 1; }
+		std::vector<uint32_t> tk; uint32_t rec[10];
+		while (fread(rec, 4, 10, fp) == 10) tk.insert(tk.end(), rec, rec + 10);
+		fclose(fp);
+		std::vector<int32_t> res; std::vector<char> ps, ts; bit_extz_t ez; memset(&ez, 0, sizeof(ez));
+		for (size_t i = 0; i + 10 <= tk.size(); i += 10) {
+			const uint32_t *t = &tk[i];
+			ps.resize(t[2] + 8); ts.resize(t[6] + 8);
+			recover_UC_Read_sub_region(ps.data(), t[1], t[2], (uint8_t)t[3], &R_INF, t[0]);
+			recover_UC_Read_sub_region(ts.data(), t[5], t[6], (uint8_t)t[7], &R_INF, t[4]);
+			ed_band_cal_semi_64_w_absent_diag(ps.data(), (int32_t)t[2], ts.data(), (int32_t)t[6], (int32_t)t[8], (int32_t)t[9], &ez);
+			res.push_back(ez.err); res.push_back(ez.pe);
+		}
+		wr(prefix, "ed.i32", res.data(), 4 * res.size());
 	}
 	std::vector<uint64_t> sel;      // reads of the per-read dumps
 	if (list_fn) {

@@ -89,3 +89,43 @@ def fold_digests(d, block=256):
     with np.errstate(over="ignore"):
         np.add.at(out, np.arange(d.size) // block, t)
     return out
+
+
+# ---- f3: window alignment tasks (hao_window_ed_batch / ed_band_cal_semi_64_w_absent_diag) ----
+def ed_tasks(name, n_reads=24, wl=775, seed=1):
+    """(pattern, text) pairs the way the window alignment forms them (Correct.cpp:3897): 775-base query windows of the overlaps h_ec_lchain found,
+    against the target region on the overlap's diagonal padded by thre on both sides, clipped at the read ends (abs_diag = bases clipped at the start);
+    plus degenerate and unrelated pairs.  uint32 [n,10]: p_rid, p_pos, p_len, p_rev, t_rid, t_pos, t_len, t_rev, thre, abs_diag."""
+    rs, okw = scenario_reads(name)
+    o = scenario_oracle(name)
+    rng = np.random.default_rng(seed)
+    out = []
+    L = rs.lengths.astype(np.int64)
+    for r in rng.choice(rs.n, size=min(n_reads, rs.n), replace=False):
+        ol = o.lchain(int(r))[0]
+        for z in ol[:: max(1, ol.shape[0] // 12)]:
+            xs, xe, yid, ys, ye, yrev = int(z[1]), int(z[2]), int(z[4]), int(z[5]), int(z[6]), int(z[7])
+            tl = int(L[yid])
+            for ws in range(xs, xe + 1, wl):
+                tn = min(wl, xe + 1 - ws)
+                thre = int(rng.choice([0, 3, 8, 15, 24, 31]))
+                p0 = ys + (ws - xs) - thre + int(rng.integers(-3, 4))
+                p1 = p0 + tn + 2 * thre
+                ad = 0
+                if p0 < 0:
+                    ad, p0 = min(-p0, 2 * thre), 0
+                p1 = min(p1, tl)
+                if p1 <= p0 or tn <= 0:
+                    continue
+                out.append((yid, p0, p1 - p0, yrev, int(r), ws, tn, 0, thre, ad))
+    # unrelated pairs, tiny strings, reverse-strand text, pattern shorter than the text
+    for _ in range(300):
+        a, b = (int(x) for x in rng.integers(0, rs.n, 2))
+        if L[a] < 2 or L[b] < 2:
+            continue
+        tn = int(rng.integers(1, min(900, int(L[b])) + 1))
+        pn = int(rng.integers(1, min(1000, int(L[a])) + 1))
+        thre = int(rng.choice([0, 1, 5, 15, 31]))
+        out.append((a, int(rng.integers(0, L[a] - pn + 1)), pn, int(rng.integers(0, 2)), b, int(rng.integers(0, L[b] - tn + 1)), tn, int(rng.integers(0, 2)),
+                    thre, int(rng.integers(0, 2 * thre + 1))))
+    return np.array(out, dtype=np.uint32)

@@ -47,6 +47,7 @@ def lib():
         L.hao_or_lchain.argtypes = [vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i64p]
         L.hao_or_lchain.restype = C.c_int64
         L.hao_or_exact.argtypes = [vp, vp, C.c_int64, u8p]
+        L.hao_or_window_ed.argtypes = [vp, vp, C.c_int64, vp]
         L.hao_or_analyze_count.argtypes = [C.c_int, C.c_int, i64p, C.POINTER(C.c_int)]; L.hao_or_analyze_count.restype = C.c_int
         _LIB = L
     return _LIB
@@ -161,6 +162,18 @@ def _exact(self, ol):
 
 
 Oracle.exact = _exact
+
+
+def _window_ed(self, tasks):
+    """tasks uint32 [n,10] -> int32 [n,2] (err, pe): ed_band_cal_semi_64_w_absent_diag"""
+    t = np.ascontiguousarray(tasks, dtype=np.uint32).reshape(-1, 10)
+    out = np.zeros((t.shape[0], 2), dtype=np.int32)
+    if t.shape[0]:
+        self.L.hao_or_window_ed(self.h, t.ctypes.data_as(C.c_void_p), t.shape[0], out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+Oracle.window_ed = _window_ed
 
 
 def load_ref_meta(prefix: str):

@@ -1,0 +1,27 @@
+"""Windowed bit-vector edit distance on the device (hao_window_ed_batch) against the oracle (pinned to the reference by
+tests/test_oracle_ed.py): window / candidate pairs formed like Correct.cpp:3897 does, both strands, clipped patterns (abs_diag), N bases,
+unrelated pairs (no alignment within the threshold), degenerate lengths."""
+import numpy as np
+import pytest
+
+from helpers import ed_tasks, scenario_reads, scenario_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["hifi", "ont", "nn", "edge", "rr", "hifi_15k"])
+def test_window_ed(name):
+    from hifiasm_amd.api import Engine, HaoError
+    rs, okw = scenario_reads(name)
+    o = scenario_oracle(name)
+    e = Engine(0, **okw)
+    e.set_readset(rs)
+    t = ed_tasks(name, n_reads=40, seed=5)
+    got = e.window_ed_batch(t)
+    want = o.window_ed(t)
+    assert (got == want).all(), np.flatnonzero((got != want).any(axis=1))[:10]
+    assert (want[:, 0] != 2**31 - 1).sum() > 300
+    bad = t[:1].copy(); bad[0, 2] = 10**8                       # pattern interval beyond the read: rejected, never read out of bounds
+    with pytest.raises(HaoError):
+        e.window_ed_batch(bad)
+    e.close()

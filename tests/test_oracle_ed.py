@@ -1,0 +1,18 @@
+"""The C restatement of the windowed bit-vector edit distance (oracle/hao_oracle.c: hao_or_window_ed) against the REAL reference's
+ed_band_cal_semi_64_w_absent_diag on the same (pattern, text) intervals (tests/golden/ed.npz, tests/golden/make_golden_ed.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, ed_tasks, scenario_oracle
+
+
+@pytest.mark.parametrize("name", ["hifi", "ont", "nn", "edge"])
+def test_window_ed_matches_the_reference(name):
+    g = np.load(os.path.join(GOLDEN, "ed.npz"))
+    t = ed_tasks(name)
+    assert t.shape == g[name + "_tasks"].shape and (t == g[name + "_tasks"]).all(), "task generator drifted: regenerate tests/golden/ed.npz"
+    res = scenario_oracle(name).window_ed(t)
+    assert (res == g[name + "_res"]).all(), np.flatnonzero((res != g[name + "_res"]).any(axis=1))[:10]
+    assert (res[:, 0] != 2**31 - 1).sum() > 500 and (res[:, 0] == 2**31 - 1).sum() > 100      # both outcomes are covered
