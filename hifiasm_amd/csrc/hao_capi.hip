@@ -15,6 +15,7 @@
 #include "hao_pipeline.hpp"
 #include "hao_tables.hpp"
 #include "hao_batch.hpp"
+#include "hao_files.hpp"
 
 extern "C" {
 

@@ -168,6 +168,13 @@ uint64_t hao_unpack_hits(const hao_delivery_t *d, uint64_t rid, hao_hit_t *out, 
 	return k;
 }
 
+int hao_index_save(hao_ctx *c, const char *prefix, int32_t number_of_round, const char *const *names)
+{
+	if (!c || !prefix) return HAO_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	return hao_index_save_impl(c, prefix, number_of_round, names);
+}
+
 int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks, hao_ed_result_t *out)
 {
 	if (!c || (!tasks && n_tasks) || (!out && n_tasks)) return HAO_EINVAL;

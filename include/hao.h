@@ -205,6 +205,14 @@ typedef struct { uint32_t p_rid, p_pos, p_len, p_rev, t_rid, t_pos, t_len, t_rev
 typedef struct { int32_t err, pe; } hao_ed_result_t;
 int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks, hao_ed_result_t *out);
 
+/* On-disk formats: the filter table, the position index and the read store in the reference's own resume format, so a GPU-built
+ * index can be handed to a stock hifiasm (load_pt_index, htab.cpp:1432-1550, called from Assembly.cpp:2078):
+ *   <prefix>.pt_flt  (write_pt_index, htab.cpp:1367-1430),  <prefix>.pt_flt.bin  (write_All_reads, Process_Read.cpp:69-125 - the layout of *.ec.bin),
+ *   <prefix>.pt_flt.paf.bin  (empty overlap lists).
+ * names[i] = read names or NULL ("r<i>"); number_of_round must equal the loader's -r (default 3: it exits otherwise, htab.cpp:1501-1505).
+ * Needs hao_ft_gen + hao_pt_gen; single-device mode. */
+int hao_index_save(hao_ctx *c, const char *prefix, int32_t number_of_round, const char *const *names);
+
 /* Per-read digests of the last batch's results, computed on the device (one workgroup per read) and copied to out[n] / out_kh[n]
  * (n = reads of the batch; out_kh may be NULL):
  *   out[r]    = sum of term(1, i, w) over the 64-bit words of ol->list (6 per overlap_region: the 12 u32 fields of hao_ovlp_t)

@@ -20,6 +20,8 @@
 //   --ed-tasks FILE    f3: FILE = uint32[n][10] tasks (p_rid, p_pos, p_len, p_rev, t_rid, t_pos, t_len, t_rev, thre, abs_diag); PREFIX.ed.i32 = int32[n][2]
 //                      (err, pe) of the reference's ed_band_cal_semi_64_w_absent_diag (Levenshtein_distance.h:3727) on the strings
 //                      recover_UC_Read_sub_region (Process_Read.cpp:524) builds for those intervals
+//   --load-index PFX   f4: skip ha_ft_gen / ha_pt_gen and the read parser: the tables and the read store come from PFX.pt_flt (+ .bin, .paf.bin) through
+//                      the reference's own load_pt_index (htab.cpp:1432); every dump then describes what a stock hifiasm sees after loading that index
 //   --bw X             bw_thres of the pass (default 0.02 / 0.05 --ont; the final round uses 0.001, ecovlp.cpp:3957)
 #include <stdio.h>
 #include <stdlib.h>
@@ -124,7 +126,8 @@ static tbuf_t *tbuf_init(int n)
 
 int main(int argc, char *argv[])
 {
-	int n_thread = 1, is_ont = 0, do_time = 0, dump_hits = 1, k = -1, w = -1, bf_shift = 0, no_hpc = 0, no_tables = 0, do_digest = 0; const char *fa = 0, *list_fn = 0, *hg = 0, *ed_fn = 0; std::string prefix;
+	int no_tables_hist = 0;
+	int n_thread = 1, is_ont = 0, do_time = 0, dump_hits = 1, k = -1, w = -1, bf_shift = 0, no_hpc = 0, no_tables = 0, do_digest = 0; const char *fa = 0, *list_fn = 0, *hg = 0, *ed_fn = 0, *load_pfx = 0; std::string prefix;
 	double bw_arg = -1;
 	for (int i = 1; i < argc; ++i) {
 		if (!strcmp(argv[i], "--ont")) is_ont = 1;
@@ -142,6 +145,7 @@ int main(int argc, char *argv[])
 		else if (!strcmp(argv[i], "--no-tables")) no_tables = 1;
 		else if (!strcmp(argv[i], "--digest")) do_digest = 1;
 		else if (!strcmp(argv[i], "--ed-tasks")) ed_fn = argv[++i];
+		else if (!strcmp(argv[i], "--load-index")) load_pfx = argv[++i];
 		else fa = argv[i];
 	}
 	if (!fa) { fprintf(stderr, "usage: ref_harness [--ont] [-t N] [-k K] [-w W] [-f BLOOM_BITS] [--dump PREFIX] [--time] reads.fa\n"); return 1; }
@@ -162,12 +166,18 @@ int main(int argc, char *argv[])
 
 	int hom_cov_ft = -1, hom_cov = -1, het_cov = -1;
 	double t0 = yak_realtime();
-	ha_flt_tab = ha_ft_gen(&asm_opt, &R_INF, &hom_cov_ft, 0, 0);
-	ha_opt_update_cov(&asm_opt, hom_cov_ft);
-	double t_ft = yak_realtime() - t0; t0 = yak_realtime();
-	ha_idx = ha_pt_gen(&asm_opt, ha_flt_tab, 0, 0, &R_INF, &hom_cov, &het_cov);
-	asm_opt.hom_cov = hom_cov; asm_opt.het_cov = het_cov;
-	double t_pt = yak_realtime() - t0;
+	double t_ft = 0, t_pt = 0;
+	if (load_pfx) {
+		if (!load_pt_index(&ha_flt_tab, &ha_idx, &R_INF, &asm_opt, (char*)load_pfx)) { fprintf(stderr, "load_pt_index(%s) failed\n", load_pfx); return 1; }
+		hom_cov = asm_opt.hom_cov; het_cov = asm_opt.het_cov; hom_cov_ft = -1; no_tables_hist = 1;
+	} else {
+		ha_flt_tab = ha_ft_gen(&asm_opt, &R_INF, &hom_cov_ft, 0, 0);
+		ha_opt_update_cov(&asm_opt, hom_cov_ft);
+		t_ft = yak_realtime() - t0; t0 = yak_realtime();
+		ha_idx = ha_pt_gen(&asm_opt, ha_flt_tab, 0, 0, &R_INF, &hom_cov, &het_cov);
+		asm_opt.hom_cov = hom_cov; asm_opt.het_cov = het_cov;
+		t_pt = yak_realtime() - t0;
+	}
 
 	uint64_t n_reads = R_INF.total_reads;
 	uint32_t high_occ = asm_opt.hom_cov * (2.0 - HA_KMER_GOOD_RATIO);   // ecovlp.cpp:3237
@@ -223,8 +233,9 @@ int main(int argc, char *argv[])
 	}
 	int64_t ft_hist[4096], pt_hist[4096]; int ft_peak_hom, ft_peak_het; uint64_t ft_distinct, pt_distinct;
 	memset(ft_hist, 0, sizeof(ft_hist)); ft_peak_hom = hom_cov_ft; ft_peak_het = -1; ft_distinct = 0;
-	if (!no_tables) refdump_ft_hist(&asm_opt, &R_INF, ft_hist, &ft_peak_hom, &ft_peak_het, &ft_distinct);      // (recounts every k-mer: skipped for large sets)
-	refdump_pt_hist(&asm_opt, ha_flt_tab, &R_INF, pt_hist, &pt_distinct);
+	if (!no_tables && !no_tables_hist) refdump_ft_hist(&asm_opt, &R_INF, ft_hist, &ft_peak_hom, &ft_peak_het, &ft_distinct);      // (recounts every k-mer: skipped for large sets)
+	memset(pt_hist, 0, sizeof(pt_hist)); pt_distinct = 0;
+	if (!no_tables_hist) refdump_pt_hist(&asm_opt, ha_flt_tab, &R_INF, pt_hist, &pt_distinct);
 	wr(prefix, "ft_hist.i64", ft_hist, sizeof(ft_hist));
 	wr(prefix, "pt_hist.i64", pt_hist, sizeof(pt_hist));
 	uint64_t n_ft = 0, n_ptk = 0, n_ptp = 0;

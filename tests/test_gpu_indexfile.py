@@ -1,0 +1,54 @@
+"""On-disk formats: the engine's tables and read store written by hao_index_save in the reference's resume format are loaded by the
+UNMODIFIED reference (load_pt_index, htab.cpp:1432, through oracle/_ref/ref_harness --load-index); everything the reference then computes from the
+loaded index - filter table, position index, minimizers, overlap lists, fake cigars, chained hits - must equal the golden dump it produced when it
+built the index itself from the FASTA."""
+import os
+import subprocess
+import tempfile
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_py
+from helpers import scenario_reads, load_golden
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+
+
+@pytest.mark.parametrize("name", ["hifi", "rr", "nn", "k40", "ont", "edge"])
+def test_reference_loads_the_gpu_built_index(name):
+    if not os.path.exists(HARNESS):
+        pytest.skip("oracle/_ref/ref_harness not built (needs /root/reference at build time)")
+    from hifiasm_amd import synth
+    from hifiasm_amd.api import Engine
+    rs, okw = scenario_reads(name)
+    g = load_golden(name)
+    e = Engine(0, **okw)
+    e.set_readset(rs)
+    e.ha_ft_gen(); e.ha_pt_gen()
+    d = tempfile.mkdtemp(prefix="hao_idx_")
+    e.index_save(os.path.join(d, "gpu"))
+    e.close()
+    for suffix in (".pt_flt", ".pt_flt.bin", ".pt_flt.paf.bin"):
+        assert os.path.getsize(os.path.join(d, "gpu" + suffix)) > 0
+    ont = bool(okw.get("is_ont"))
+    fa = os.path.join(d, "r.fq" if ont else "r.fa")
+    synth.write_fasta(fa, rs, fastq=ont)                      # (only to satisfy the option parser: the loader never opens it)
+    cmd = [HARNESS, "-t", "2", "--load-index", os.path.join(d, "gpu"), "--dump", os.path.join(d, "s")]
+    cmd += ["--ont"] if ont else []
+    for k_, flag in (("k", "-k"), ("w", "-w")):
+        if k_ in okw:
+            cmd += [flag, str(okw[k_])]
+    r = subprocess.run(cmd + [fa], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    dump = oracle_py.load_ref_dump(os.path.join(d, "s"))
+    for key in ("ft_keys", "ft_vals", "pt_keys", "pt_off", "pt_pos", "mz_off", "mz", "ol_off", "ol", "fc_off", "fc", "kh_off", "cl_off", "rlen", "ex"):
+        assert dump[key].shape == g[key].shape and (dump[key] == g[key]).all(), key
+    cl = dump["cl"].reshape(-1, 4)
+    crc = np.array([zlib.crc32(cl[int(dump["cl_off"][i]):int(dump["cl_off"][i + 1])].tobytes()) for i in range(rs.n)], dtype=np.uint64)
+    assert (crc == g["cl_crc"]).all()
+    for key in ("hom_cov", "het_cov", "max_n_chain", "high_occ", "low_occ"):
+        assert dump["meta"][key] == g["meta"][key], key
