@@ -71,17 +71,19 @@ struct hao_pack_args {
 
 __global__ __launch_bounds__(256) void hao_pack_chains_kernel(hao_pack_args A, const uint64_t *n_chains_dev)
 {
-	const uint64_t ci = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-	if (ci >= *n_chains_dev) return;      // launched over the host-side bound (3 chains per group)
+	// the number of chains is only known on the device when this is launched: waves stride over [0, *n_chains_dev)
+	const uint64_t n_chains = *n_chains_dev, n_waves = (uint64_t)gridDim.x * 4;
 	const int lane = hao_lane();
+	__shared__ uint32_t s_tab[4][HAO_PACK_QCAP];
+	uint32_t *tab = s_tab[threadIdx.x >> 6];
+	for (uint64_t ci = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); ci < n_chains; ci += n_waves) {
 	const hao_cdesc d = A.cd[ci];
 	const hao_hit_t *src = hao_cd_src(d, A.hits, A.ohits);
 	const uint64_t m0 = A.mz_off[A.rid_lo + d.r]; const uint32_t nq = (uint32_t)(A.mz_off[A.rid_lo + d.r + 1] - m0);
 	const uint32_t *qp = A.q_pos + (m0 - A.mz0);
 	// the read's self_offset table goes to LDS once per chain (a few hundred entries, L2-resident): nine dependent LDS reads per hit instead of nine
 	// dependent global loads; longer tables (reads beyond ~35 kb) are searched in place
-	__shared__ uint32_t s_tab[4][HAO_PACK_QCAP];
-	uint32_t *tab = s_tab[threadIdx.x >> 6]; const bool in_lds = nq <= HAO_PACK_QCAP;
+	const bool in_lds = nq <= HAO_PACK_QCAP;
 	if (in_lds) for (uint32_t k = lane; k < nq; k += 64) tab[k] = qp[k];
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 	uint32_t q_prev = 0, off_prev = 0, self_prev = 0;      // the last hit of the previous tile (uniform)
@@ -115,6 +117,8 @@ __global__ __launch_bounds__(256) void hao_pack_chains_kernel(hao_pack_args A, c
 		}
 		if (act) A.bytes[d.dst + i] = code;
 		q_prev = hao_bcast(q, 63); off_prev = hao_bcast(h.offset, 63); self_prev = hao_bcast(h.self_offset, 63);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // the table is reloaded for the wave's next chain
 	}
 }
 

@@ -46,15 +46,16 @@ def _ec_mask(buf):
 
 
 @pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(HAO)), reason="reference binaries not built")
-@pytest.mark.parametrize("bf", ["-f0", "-f26"])      # exact counting / the Bloom pre-filter (2^26 bits instead of the default 2^37: same code, 8 KB instead of 16 GB)
-def test_bins_identical(bf):
+@pytest.mark.parametrize("bf,shim_batch", [("-f0", "4096"), ("-f26", "257"), ("-f37", "64")])      # exact counting / a small Bloom pre-filter / the reference's DEFAULT 2^37-bit filter;
+def test_bins_identical(bf, shim_batch):                                                               # shim batches of 4096 / 257 / 64 reads: one batch ... dozens of batches streamed under 8 worker threads
     from hifiasm_amd import synth
     rs = synth.dataset(genome_size=300_000, coverage=30, read_len=12000, err=0.001, seed=42, len_jit=3000)
     d = tempfile.mkdtemp(prefix="hao_dropin_")
     fa = os.path.join(d, "reads.fa")
     synth.write_fasta(fa, rs)
     for exe, tag in ((REF, "ref"), (HAO, "hao")):
-        r = subprocess.run([exe, "-o", os.path.join(d, tag), "-t", "8", bf, "--bin-only", fa], capture_output=True, text=True, cwd=d)
+        r = subprocess.run([exe, "-o", os.path.join(d, tag), "-t", "8", bf, "--bin-only", fa], capture_output=True, text=True, cwd=d,
+                           env=dict(os.environ, HAO_SHIM_BATCH=shim_batch))
         assert r.returncode == 0, f"{tag} failed: {r.stderr[-1500:]}"
     for ext in ("ovlp.source.bin", "ovlp.reverse.bin"):
         a = open(os.path.join(d, f"ref.{ext}"), "rb").read()
