@@ -325,12 +325,16 @@ static int hao_ft_run(hao_ctx *c)
 		};
 		if (int rc = hao_comm_exchange_counts(c, cm, scnt, rcnt, local_partition())) return rc;
 		uint64_t n_recv = 0; for (int d = 0; d < W; ++d) n_recv += rcnt[d];
-		auto local_recv_bufs = [&]() -> int { HIP_TRY(rv.reserve(n_recv + 1)); HIP_TRY(rv2.reserve(n_recv + 1)); return HAO_OK; };
+		// peak memory: the hash buffers are the largest allocations of the whole engine (8 B per base each).  Only the sorted local piece and the receive
+		// buffer exist during the exchange; the second receive-side buffer (sort scratch) is allocated after the local piece is gone.
+		auto local_recv_bufs = [&]() -> int { if (loc == kh.p) kh2.release(); else kh.release(); HIP_TRY(rv.reserve(n_recv + 1)); return HAO_OK; };
 		if (int rc = hao_comm_agree(c, cm, local_recv_bufs())) return rc;
 		if (int rc = hao_comm_alltoallv_u64(c, cm, loc, scnt, sdisp, rv.p, rcnt)) return rc;
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		c->timer.mark("ft_exchange");
 		auto local_count = [&]() -> int {
+			kh.release(); kh2.release();
+			HIP_TRY(rv2.reserve(n_recv + 1));
 			uint64_t *ci = rv.p, *ca = rv2.p, n_ci = n_recv;
 			if (bloom) { if (int rc = hao_bloom_filter(c, rv.p, rv2.p, n_recv, &ci, &ca, &n_ci)) return rc; }
 			return hao_sort_rle_hist(c, ci, ca, n_ci, ukeys, ucnt, &n_unique, c->ft_hist, &sorted, bias);
