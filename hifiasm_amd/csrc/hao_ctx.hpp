@@ -53,7 +53,7 @@ struct StageTimer {
 struct hao_switches {
 	bool seedphase = false, qcphase = false, dp_stats = false, seq_chain = false, dp_seqtail = false, dp_nospec = false, dp_serial = false,
 		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, dltime = false;
-	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; int exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, seed_lds_pad = 0, arena_numa = 1;
+	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; int exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, seed_lds_pad = 0, arena_numa = 1, seed_tile = 512;
 	void load() {
 		auto on = [](const char *n) { return getenv(n) != nullptr; };
 		seedphase = on("HAO_DBG_SEEDPHASE"); qcphase = on("HAO_DBG_QCPHASE"); dp_stats = on("HAO_DBG_DP_STATS"); seq_chain = on("HAO_DBG_SEQ_CHAIN");
@@ -65,6 +65,7 @@ struct hao_switches {
 		if (const char *e = getenv("HAO_DBG_EXC_CAP")) exc_cap = atoll(e);
 		if (const char *e = getenv("HAO_DBG_EXC_EVERY")) exc_every = atoi(e);      // ship every n-th hit of a chain verbatim (tests: exercise the exception list)
 		if (const char *e = getenv("HAO_ARENA_NUMA")) arena_numa = atoi(e);      // 0: plain hipHostMalloc, 1: thread policy = the GPU's node, 2: that + hipHostMallocNumaUser
+		if (const char *e = getenv("HAO_SEED_TILE")) seed_tile = atoi(e);      // anchors per staged tile of the seed kernel: 512 (default: 6 workgroups per CU) or 1024 (longer runs per bin, 4 per CU)
 		if (const char *e = getenv("HAO_SEED_LDS_PAD")) seed_lds_pad = atoi(e);      // extra dynamic LDS bytes of the seed kernel = fewer resident workgroups per CU (A/B: cache footprint vs. latency hiding)
 		if (const char *e = getenv("HAO_STREAM_PRIO")) stream_prio = atoi(e);      // 1: the engine's streams at the highest priority (A/B: measured worse - the low-priority copy then starves)
 		if (const char *e = getenv("HAO_COPY_KERNEL")) copy_kernel = atoi(e);      // n > 0: the delivery copy is done by a kernel of n workgroups writing into the mapped arena (no DMA engine)

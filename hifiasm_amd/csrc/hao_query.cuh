@@ -73,21 +73,34 @@ struct hao_seed_args {
 // Two launches cover a batch: <SMALL table, FIRST> takes every read and gives up (appends the read to ovf_list) when its bins do not fit in
 // one round - the small table keeps many workgroups per CU for the common reads; <bigger table, !FIRST> takes the listed reads, in as many
 // (tid, rev) range rounds as they need.
-template<int CAPLOG, bool FIRST>
+//
+// Pass B writes through LDS.  A hit is 16 bytes and a read feeds ~100 bins, so storing hits where they are produced costs one 16-byte write
+// request per hit (the request slots of the L2, not its bytes, are what ran out: the same stores issued in generation order made the whole
+// kernel 1/3 faster).  The workgroup therefore walks the read in tiles of TILE (512) anchors: every wave ranks the hits of its quarter
+// tile (same ranked scatter as before, per-wave counts per bin), one scan over the bins turns the counts into tile offsets, the hits are
+// parked in LDS grouped by bin (in generation order inside a bin), and the tile is written out with consecutive lanes on consecutive
+// addresses: ~5 hits of a bin at a time (TILE = 1024 doubles that but its LDS and registers leave 4 instead of 6 workgroups per CU: slower).
+struct hao_stage_t { uint32_t offset, self_offset, cnt; };
+template<int CAPLOG, bool FIRST, uint32_t HAO_SEED_TILE>
 __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t *ovf_list, unsigned long long *ovf_cnt)
 {
 	constexpr uint32_t CAP = 1u << CAPLOG, MAXD = CAP - 288;      // at most MAXD + 256 bins are ever inserted (one per thread after the table fills), so probing terminates; CAP >= 512
 	constexpr int UA = 4;                        // tiles per lane in flight in the counting pass (chunks are multiples of 64 * UA anchors)
+	constexpr uint32_t STAGE_BYTES = HAO_SEED_TILE * (sizeof(hao_stage_t) + 2), SORT_BYTES = CAP * 12, UNION_BYTES = STAGE_BYTES > SORT_BYTES ? STAGE_BYTES : SORT_BYTES;
 	extern __shared__ uint32_t bs_smem[];
 	uint32_t *hk = bs_smem;                      // [CAP]    bin key (tid << 1 | rev) per slot
-	uint32_t *cw = hk + CAP;                     // [4][CAP] per-wave counts, then running output offsets
-	uint32_t *rk = cw + 4 * CAP;                 // [CAP]    rank of the slot's bin among the bins of the round
-	uint64_t *sk = (uint64_t*)(rk + CAP);        // [CAP]    (bin key << 32 | slot), sorted
-	uint32_t *tot = (uint32_t*)(sk + CAP);       // [CAP]    per-rank totals -> first output position of the bin
-	uint32_t *bl = tot + CAP;                    // [CAP]    read length of the slot's target (opposite-strand offsets)
-	uint64_t *l_ss = (uint64_t*)(bl + CAP);      // [qcap]   list start of minimizer q in the position index | strand of the minimizer << 63
+	uint32_t *cwd = hk + CAP;                    // [CAP]    hits of the bin (pass A), its first output position (between the passes); pass B, per tile:
+	                                             //          output position of the bin minus its offset in the staged tile
+	uint32_t *bl = cwd + CAP;                    // [CAP]    read length of the slot's target (opposite-strand offsets)
+	uint16_t *wc = (uint16_t*)(bl + CAP);        // [4][CAP] pass B, per tile: per-wave counts, then each wave's first staged entry of the bin
+	uint16_t *rk = wc + 4 * CAP;                 // [CAP]    rank of the slot's bin among the bins of the round
+	uint64_t *sk = (uint64_t*)(rk + CAP);        // [CAP]    (bin key << 32 | slot), sorted          } between the passes
+	uint32_t *tot = (uint32_t*)(sk + CAP);       // [CAP]    per-rank totals                          }
+	hao_stage_t *stage = (hao_stage_t*)sk;       // [TILE]   pass B: the tile's hits grouped by bin   } same memory
+	uint16_t *sslot = (uint16_t*)(stage + HAO_SEED_TILE);   // [TILE] slot of the staged hit          }
+	uint64_t *l_ss = (uint64_t*)((char*)sk + UNION_BYTES);  // [qcap]   list start of minimizer q in the position index | strand of the minimizer << 63
 	uint32_t *l_ao = (uint32_t*)(l_ss + S.qcap); // [qcap+1] first anchor of minimizer q, relative to the read
-	__shared__ uint32_t s_nd, s_ovf, s_c; __shared__ uint64_t s_ws[4], s_all;
+	__shared__ uint32_t s_nd, s_ovf, s_c, s_wt[4]; __shared__ uint64_t s_ws[4], s_all;
 	uint64_t *g_tmp = S.g_tmp;
 	if (!FIRST && blockIdx.x >= *ovf_cnt) return;
 	const uint64_t r = FIRST ? blockIdx.x : ovf_list[blockIdx.x], s = S.seg[r], e = S.seg[r + 1]; const uint32_t n = (uint32_t)(e - s);
@@ -114,7 +127,7 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 	while (lo < k_end) {
 		uint32_t hi = k_end;
 		for (;;) {      // count the bins of [lo, hi); shrink the range until they fit the table
-			for (uint32_t i = tid; i < CAP; i += 256) { hk[i] = HAO_BIN_EMPTY; cw[i] = 0; cw[CAP + i] = 0; cw[2 * CAP + i] = 0; cw[3 * CAP + i] = 0; }
+			for (uint32_t i = tid; i < CAP; i += 256) { hk[i] = HAO_BIN_EMPTY; cwd[i] = 0; ((uint32_t*)wc)[i] = 0; ((uint32_t*)wc)[CAP + i] = 0; }
 			if (tid == 0) { s_nd = 0; s_ovf = 0; s_c = 0; }
 			__syncthreads();
 			uint32_t qc = q_c0;
@@ -141,7 +154,7 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 							if (old == kk) break;
 							slot = (slot + 1) & (CAP - 1);
 						}
-						atomicAdd(&cw[wv * CAP + slot], 1u);
+						atomicAdd(&cwd[slot], 1u);
 					}
 				}
 			}
@@ -167,7 +180,7 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 					}
 					__syncthreads();
 				}
-			for (uint32_t d = tid; d < D; d += 256) { const uint32_t slot = (uint32_t)sk[d]; rk[slot] = d; bl[slot] = S.len[(uint32_t)(sk[d] >> 33)]; tot[d] = cw[slot] + cw[CAP + slot] + cw[2 * CAP + slot] + cw[3 * CAP + slot]; }
+			for (uint32_t d = tid; d < D; d += 256) { const uint32_t slot = (uint32_t)sk[d]; rk[slot] = (uint16_t)d; bl[slot] = S.len[(uint32_t)(sk[d] >> 33)]; tot[d] = cwd[slot]; }
 			__syncthreads();
 			// exclusive scan over the sorted bins of (hits, group starts), packed as starts << 32 | hits; thread t owns bins [t*per, (t+1)*per)
 			const uint32_t per = P >= 256 ? P / 256 : 1, d0 = tid * per; uint64_t mine = 0;
@@ -184,45 +197,68 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 			if (tid == 255) s_all = ex + mine;
 			for (uint32_t d = d0; d < d0 + per && d < D; ++d) {
 				const uint32_t slot = (uint32_t)sk[d], t_k = (uint32_t)(sk[d] >> 33), t_p = d ? (uint32_t)(sk[d - 1] >> 33) : last_tid;
-				uint32_t run = placed + (uint32_t)ex;
-				if (t_k != t_p) { g_tmp[s + ngr + (uint32_t)(ex >> 32)] = (uint64_t)t_k << 32 | run; ex += 1ULL << 32; }
+				if (t_k != t_p) { g_tmp[s + ngr + (uint32_t)(ex >> 32)] = (uint64_t)t_k << 32 | (placed + (uint32_t)ex); ex += 1ULL << 32; }
+				cwd[slot] = placed + (uint32_t)ex;
 				ex += tot[d];
-				for (int x = 0; x < 4; ++x) { const uint32_t cc = cw[x * CAP + slot]; cw[x * CAP + slot] = run; run += cc; }
 			}
+			const uint32_t last_tid_next = (uint32_t)(sk[D - 1] >> 33);      // (the staged tiles reuse sk / tot)
 			__syncthreads();
+			const uint64_t all = s_all;
 			int nbits = 0; while ((1u << nbits) < D) ++nbits;
 			if (S.dbg) tk2 = wall_clock64();
-			uint32_t qc = q_c0;
-			for (uint32_t t0 = c0; t0 < c1; t0 += 256) {
-				uint64_t yv[4], ype[4], yne[4]; uint32_t qv[4], qp[4], qn[4];      // everything a hit needs from memory is requested here, four tiles deep
+			constexpr int NU = HAO_SEED_TILE / 256;      // 64-anchor sub-tiles per wave and tile
+			uint16_t *wcw = wc + wv * CAP;
+			constexpr uint32_t SPT = CAP / 256;      // thread t owns slots [t * SPT, (t + 1) * SPT) in the per-tile scan and keeps their next output positions
+			uint32_t ob[SPT];
 #pragma unroll
-				for (int u = 0; u < 4; ++u) {
-					const uint32_t x = t0 + u * 64 + lane; const bool act = x < c1; uint32_t q = qc;
+			for (uint32_t k = 0; k < SPT; ++k) ob[k] = cwd[tid * SPT + k];
+			uint32_t qw = 0;      // minimizer holding the first anchor of this wave's quarter of the tile
+			uint64_t yv[NU], ype[NU], yne[NU]; uint32_t qv[NU];
+			// (requesting a tile's records one tile ahead costs 12 VGPRs = one wave per SIMD less, and loses: 70.7 against 65.8 ms per step)
+			auto request = [&](const uint32_t T0) {
+				const uint32_t x0 = T0 + wv * (HAO_SEED_TILE / 4);
+				if (x0 < n)      // gallop: 64 candidates per step (the offsets do not decrease)
+					for (;;) {
+						const uint32_t t = qw + 1 + lane;
+						const unsigned long long le = __ballot(t <= nq && HAO_AO(t) <= x0);
+						const int adv = le == ~0ULL ? 64 : __ffsll((long long)~le) - 1;
+						qw += adv; if (adv < 64) break;
+					}
+				uint32_t qc = qw;
+#pragma unroll
+				for (int u = 0; u < NU; ++u) {
+					const uint32_t x = x0 + u * 64 + lane; const bool act = x < n; uint32_t q = qc;
 					if (act) { while (HAO_AO(q + 1) <= x) ++q; }
 					qc = (uint32_t)__builtin_amdgcn_readlane((int)q, 63);
 					qv[u] = q;
 					const uint32_t a0 = HAO_AO(q), j = x - a0; const uint64_t ad = (HAO_SS(q) & ~(1ULL << 63)) + j;
 					yv[u] = act ? S.sinfo[ad] : 0;
-					// list neighbours normally sit in the adjacent lanes; only the lanes at a tile / chunk edge fetch theirs
+					// list neighbours normally sit in the adjacent lanes; only the lanes at a tile edge fetch theirs
 					ype[u] = (act && lane == 0 && j > 0) ? S.sinfo[ad - 1] : ~0ULL;
-					yne[u] = (act && (lane == 63 || x + 1 == c1) && j + 1 < HAO_AO(q + 1) - a0) ? S.sinfo[ad + 1] : ~0ULL;
-					qp[u] = S.q_pos[li0 + q]; qn[u] = S.q_cnt[li0 + q];
+					yne[u] = (act && (lane == 63 || x + 1 == n) && j + 1 < HAO_AO(q + 1) - a0) ? S.sinfo[ad + 1] : ~0ULL;
 				}
+			};
+			for (uint32_t T0 = 0; T0 < n; T0 += HAO_SEED_TILE) {
+				const uint32_t x0 = T0 + wv * (HAO_SEED_TILE / 4);
+				request(T0);
+				uint32_t qp[NU], qn[NU];      // the two words of the query minimizer: first needed when the hit is staged
 #pragma unroll
-				for (int u = 0; u < 4; ++u) {
-					const uint32_t x = t0 + u * 64 + lane, q = qv[u]; uint64_t y = yv[u];
+				for (int u = 0; u < NU; ++u) { const bool act = x0 + u * 64 + lane < n; qp[u] = act ? S.q_pos[li0 + qv[u]] : 0; qn[u] = act ? S.q_cnt[li0 + qv[u]] : 0; }
+				uint32_t ps[NU], po[NU];      // slot | rank inside the wave's quarter tile << 16 (or ~0: no hit); k_mer_hit::offset
+#pragma unroll
+				for (int u = 0; u < NU; ++u) {
+					const uint32_t x = x0 + u * 64 + lane, q = qv[u]; uint64_t y = yv[u];
 					const uint64_t sv = HAO_SS(q), st = sv & ~(1ULL << 63); const uint32_t zrev = (uint32_t)(sv >> 63);
 					const uint32_t tidk = hao_info_rid(y), rev = zrev ^ hao_info_rev(y), kk = tidk << 1 | rev;
-					const bool inr = x < c1 && kk >= lo && kk < hi;
-					// list neighbours: from the adjacent lanes when they hold the same minimizer, else (tile edges) from memory
+					const bool inr = x < n && kk >= lo && kk < hi;
 					// target of the previous / next entry of my list (0xffffffff: none): lane - 1 / lane + 1 hold them unless they belong to another
-					// minimizer (then I am the first / last entry of my list) or I sit at a tile / chunk edge (fetched above)
+					// minimizer (then I am the first / last entry of my list) or I sit at a tile edge (fetched above)
 					const uint32_t yt = hao_info_rid(y);
 					uint32_t t_up = hao_wave_shr1(yt, 0u), t_dn = (uint32_t)__shfl_down((int)yt, 1);             // cross-lane moves: all lanes, before any branch
 					const uint32_t q_up = hao_wave_shr1(q, 0xffffffffu), q_dn = (uint32_t)__shfl_down((int)q, 1);
 					if (lane == 0) t_up = ype[u] == ~0ULL ? 0xffffffffu : hao_info_rid(ype[u]);
 					else if (q_up != q) t_up = 0xffffffffu;
-					if (lane == 63 || x + 1 >= c1) t_dn = yne[u] == ~0ULL ? 0xffffffffu : hao_info_rid(yne[u]);
+					if (lane == 63 || x + 1 >= n) t_dn = yne[u] == ~0ULL ? 0xffffffffu : hao_info_rid(yne[u]);
 					else if (q_dn != q) t_dn = 0xffffffffu;
 					if (inr && rev) {
 						// opposite-strand hits of one k-mer in one target must come out by DEscending target position (ascending other_off,
@@ -244,19 +280,53 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 					if (inr) while (hk[slot] != kk) slot = (slot + 1) & (CAP - 1);
 					const uint32_t d = inr ? rk[slot] : 0;
 					const unsigned long long m = hao_match_bits(d, inr, nbits);
-					const uint32_t base = inr ? cw[wv * CAP + slot] : 0;
-					if (inr) {
-						hao_hit_t h; h.w0 = tidk | rev << 31;
-						// k_mer_hit::offset (anchor.cpp:1021-1023,1059-1064): target coordinate in the strand of the hit
-						h.offset = rev ? bl[slot] - 1 - (hao_info_pos(y) + 1 - hao_info_span(y)) : hao_info_pos(y);
-						h.self_offset = qp[u]; h.cnt = qn[u];
-						S.hits[s + base + __popcll(m & ((1ULL << lane) - 1))] = h;
-					}
-					if (inr && (m & ((1ULL << lane) - 1)) == 0) cw[wv * CAP + slot] = base + __popcll(m);
+					const uint32_t before = __popcll(m & ((1ULL << lane) - 1)), base = inr ? wcw[slot] : 0;
+					ps[u] = inr ? (slot | (base + before) << 16) : 0xffffffffu;
+					// k_mer_hit::offset (anchor.cpp:1021-1023,1059-1064): target coordinate in the strand of the hit
+					po[u] = inr ? (rev ? bl[slot] - 1 - (hao_info_pos(y) + 1 - hao_info_span(y)) : hao_info_pos(y)) : 0;
+					if (inr && before == 0) wcw[slot] = (uint16_t)(base + __popcll(m));
 				}
+				__syncthreads();
+				// tile offsets of the bins (slot order: any order keeps a bin's hits together)
+				uint32_t c_[SPT][4], mine_t = 0;
+#pragma unroll
+				for (uint32_t k = 0; k < SPT; ++k) {
+#pragma unroll
+					for (int w = 0; w < 4; ++w) { c_[k][w] = wc[w * CAP + tid * SPT + k]; mine_t += c_[k][w]; }
+				}
+				uint32_t inc_t = mine_t;
+#pragma unroll
+				for (int dl = 1; dl < 64; dl <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)inc_t, dl); if (lane >= dl) inc_t += y; }
+				if (lane == 63) s_wt[wv] = inc_t;
+				__syncthreads();
+				uint32_t ex_t = inc_t - mine_t; for (int x = 0; x < wv; ++x) ex_t += s_wt[x];
+				const uint32_t tile_n = s_wt[0] + s_wt[1] + s_wt[2] + s_wt[3];
+#pragma unroll
+				for (uint32_t k = 0; k < SPT; ++k) {
+					const uint32_t sl = tid * SPT + k, tt = c_[k][0] + c_[k][1] + c_[k][2] + c_[k][3];
+					if (tt) {
+						cwd[sl] = ob[k] - ex_t; ob[k] += tt;
+						wc[sl] = (uint16_t)ex_t; wc[CAP + sl] = (uint16_t)(ex_t + c_[k][0]); wc[2 * CAP + sl] = (uint16_t)(ex_t + c_[k][0] + c_[k][1]); wc[3 * CAP + sl] = (uint16_t)(ex_t + c_[k][0] + c_[k][1] + c_[k][2]);
+						ex_t += tt;
+					}
+				}
+				__syncthreads();
+#pragma unroll
+				for (int u = 0; u < NU; ++u)
+					if (ps[u] != 0xffffffffu) {
+						const uint32_t slot = ps[u] & 0xffffu, at = wcw[slot] + (ps[u] >> 16);
+						hao_stage_t z; z.offset = po[u]; z.self_offset = qp[u]; z.cnt = qn[u];
+						stage[at] = z; sslot[at] = (uint16_t)slot;
+					}
+				__syncthreads();
+				for (uint32_t at = tid; at < tile_n; at += 256) {
+					const uint32_t slot = sslot[at], kk = hk[slot]; const hao_stage_t z = stage[at];
+					hao_hit_t h; h.w0 = kk >> 1 | kk << 31; h.offset = z.offset; h.self_offset = z.self_offset; h.cnt = z.cnt;
+					S.hits[s + (uint32_t)(cwd[slot] + at)] = h;      // (32-bit sum: cwd may have wrapped below zero)
+				}
+				for (uint32_t i = lane; i < CAP / 2; i += 64) ((uint32_t*)wcw)[i] = 0;      // own row only: nobody else reads it before the next tile's barrier
 			}
-			last_tid = (uint32_t)(sk[D - 1] >> 33);
-			const uint64_t all = s_all;
+			last_tid = last_tid_next;
 			placed += (uint32_t)all; ngr += (uint32_t)(all >> 32);
 			__syncthreads();
 		}

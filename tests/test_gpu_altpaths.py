@@ -1,7 +1,7 @@
 """Every implementation variant that libhao.so can be switched to at run time (A/B switches kept for measurements, and the fallbacks behind
 them) must give the oracle's result: one-lane sequential chaining instead of the wave kernels, DP without speculative tiles, the one-lane DP
 tail, DP kernels on the main stream, one-wave selection for every size, the one-lane pruning scan, the generic (any w, k) sketch kernel,
-and the sketch retry after an under-sized minimizer list."""
+the sketch retry after an under-sized minimizer list, and the seed kernel's larger staged tile."""
 import os
 
 import pytest
@@ -11,8 +11,8 @@ from helpers import scenario_reads, scenario_oracle
 pytestmark = pytest.mark.gpu
 
 SWITCHES = ["HAO_DBG_SEQ_CHAIN", "HAO_DBG_DP_NOSPEC", "HAO_DBG_DP_SEQTAIL", "HAO_DBG_DP_SERIAL", "HAO_DBG_SEL1", "HAO_DBG_SEQ_PRUNE",
-            "HAO_DBG_SK_GENERIC", "HAO_DBG_SK_GCAP", "HAO_SPEC_MINCLS", "HAO_CHAIN_WPB"]
-VALUES = {"HAO_DBG_SK_GCAP": "1000", "HAO_SPEC_MINCLS": "0", "HAO_CHAIN_WPB": "4"}
+            "HAO_DBG_SK_GENERIC", "HAO_DBG_SK_GCAP", "HAO_SPEC_MINCLS", "HAO_CHAIN_WPB", "HAO_SEED_TILE"]
+VALUES = {"HAO_DBG_SK_GCAP": "1000", "HAO_SPEC_MINCLS": "0", "HAO_CHAIN_WPB": "4", "HAO_SEED_TILE": "1024"}
 
 
 @pytest.mark.parametrize("switch", SWITCHES)
