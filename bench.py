@@ -187,7 +187,7 @@ def main():
     def step(deliver=False):
         eng.ha_pt_gen()
         st = {k: v for k, v in eng.stage_times()}
-        tot = {"overlaps": 0, "chained_hits": 0, "seed_hits": 0, "groups": 0, "minimizers": 0, "seq_groups": 0, "seq_group_hits": 0, "host_bytes": 0, "copy_ms": 0.0, "t_async": 0.0, "t_wait": 0.0}
+        tot = {"overlaps": 0, "chained_hits": 0, "seed_hits": 0, "groups": 0, "minimizers": 0, "seq_groups": 0, "seq_group_hits": 0, "host_bytes": 0, "copy_ms": 0.0, "t_async": 0.0, "t_wait": 0.0, "code_bytes": 0, "delivered_hits": 0}
         prev = None
         for lo, hi in ranges:
             if deliver:
@@ -196,7 +196,7 @@ def main():
                 t_b = time.time()
                 if prev is not None:                        # the consumer takes the previous batch now (its copy ran under this batch's kernels)
                     d = eng.deliver_wait(prev)
-                    tot["host_bytes"] += int(d.bytes); tot["copy_ms"] += float(d.copy_ms)
+                    tot["host_bytes"] += int(d.bytes); tot["copy_ms"] += float(d.copy_ms); tot["code_bytes"] += int(d.n_codes); tot["delivered_hits"] += int(d.n_cl)
                 tot["t_async"] += (t_b - t_a) * 1e3; tot["t_wait"] += (time.time() - t_b) * 1e3
                 prev = slot
             else:
@@ -209,7 +209,7 @@ def main():
                 st[k] = st.get(k, 0.0) + v
         if deliver:
             d = eng.deliver_wait(prev)                      # every batch's results are in host memory
-            tot["host_bytes"] += int(d.bytes); tot["copy_ms"] += float(d.copy_ms)
+            tot["host_bytes"] += int(d.bytes); tot["copy_ms"] += float(d.copy_ms); tot["code_bytes"] += int(d.n_codes); tot["delivered_hits"] += int(d.n_cl)
         return tot, st
 
     def sync():
@@ -245,7 +245,7 @@ def main():
     boundary = None
     if not a.no_boundary and hasattr(eng, "overlap_batch_async"):
         bdt, bov, btot, bst = timed(True)
-        boundary = {"q_assemble_ms_per_step": bst.get("q_assemble", 0.0) / a.steps, "stage_ms": {k: round(v / a.steps, 2) for k, v in bst.items()},"value": bov / (bdt / a.steps), "ms_per_step": bdt / a.steps * 1e3, "host_bytes_per_gpu_step": btot["host_bytes"],
+        boundary = {"q_assemble_ms_per_step": bst.get("q_assemble", 0.0) / a.steps, "stage_ms": {k: round(v / a.steps, 2) for k, v in bst.items()},"value": bov / (bdt / a.steps), "ms_per_step": bdt / a.steps * 1e3, "host_bytes_per_gpu_step": btot["host_bytes"], "wire_bytes_per_chained_hit": (btot["delivered_hits"] / 8 + btot["delivered_hits"] / 16 + btot["code_bytes"]) / max(1, btot["delivered_hits"]),
                     "copy_ms_per_step": btot["copy_ms"], "host_ms_in_async": btot["t_async"], "host_ms_in_wait": btot["t_wait"], "copy_gb_per_s": btot["host_bytes"] / max(1e-9, btot["copy_ms"] * 1e-3) / 1e9}
 
     if rank == 0:
@@ -298,7 +298,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if a.workload in STRONG else "weak",
             "vs_baseline": None, "dtype": "u64 hashing / int32 + f64 chain scores", "data": "synthetic",
             "value_boundary": round(boundary["value"], 1) if boundary else None,
-            "boundary": ({"ms_per_step": round(boundary["ms_per_step"], 3), "host_bytes_per_gpu_step": boundary["host_bytes_per_gpu_step"],
+            "boundary": ({"ms_per_step": round(boundary["ms_per_step"], 3), "host_bytes_per_gpu_step": boundary["host_bytes_per_gpu_step"], "wire_bytes_per_chained_hit": round(boundary["wire_bytes_per_chained_hit"], 4),
                           "copy_ms_per_step": round(boundary["copy_ms_per_step"], 2), "copy_gb_per_s": round(boundary["copy_gb_per_s"], 2),
                           "assemble_and_pack_ms_per_step": round(boundary["q_assemble_ms_per_step"], 2),
                           "host_ms_in_async": round(boundary["host_ms_in_async"], 1), "host_ms_in_wait": round(boundary["host_ms_in_wait"], 1),

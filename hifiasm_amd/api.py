@@ -44,9 +44,9 @@ class ChainHdr(C.Structure):
 class Delivery(C.Structure):
     """hao_delivery_t: read-only view of one batch's results in a pinned host arena"""
     _fields_ = [("rid_lo", C.c_uint64), ("n_reads", C.c_uint64), ("n_ol", C.c_uint64), ("n_fc", C.c_uint64), ("n_chains", C.c_uint64),
-                ("n_cl", C.c_uint64), ("n_exc", C.c_uint64), ("bytes", C.c_uint64),
+                ("n_cl", C.c_uint64), ("n_exc", C.c_uint64), ("n_codes", C.c_uint64), ("bytes", C.c_uint64),
                 ("ol_off", C.c_void_p), ("ol", C.c_void_p), ("fc_off", C.c_void_p), ("fc", C.c_void_p), ("ch_off", C.c_void_p),
-                ("cl_off", C.c_void_p), ("qm_off", C.c_void_p), ("chains", C.c_void_p), ("cl_bytes", C.c_void_p), ("qmz", C.c_void_p),
+                ("cl_off", C.c_void_p), ("qm_off", C.c_void_p), ("chains", C.c_void_p), ("cl_bits", C.c_void_p), ("cl_rank", C.c_void_p), ("cl_codes", C.c_void_p), ("qmz", C.c_void_p),
                 ("cl_exc", C.c_void_p), ("exact", C.c_void_p), ("copy_ms", C.c_double)]
 
 

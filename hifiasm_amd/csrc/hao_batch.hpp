@@ -15,13 +15,14 @@ struct hao_ctx::Batch {
 	DevBuf<hao_hit_t> hits, ohits, cl;
 	DevBuf<int32_t> f, ii, p, key_sc, tm; DevBuf<int64_t> t; DevBuf<uint64_t> key_xs; DevBuf<uint32_t> key_al, key_tmp;
 	DevBuf<hao_chain_rec> rec; DevBuf<hao_ovlp_t> ol; DevBuf<hao_cdesc> cd; bool cl_valid = false;
+	DevBuf<uint8_t> pk_bytes; DevBuf<uint32_t> pk_cnt; uint64_t n_codes = 0;      // one code byte per chained hit (device only) before it is split into bits + code bytes
 	// Results of a batch that leave the device.  Two sets (+ two pinned host arenas): while the copy stream drains the set of batch i, batch i + 1
 	// computes into the other one (hao_overlap_batch_async).  The blocking API keeps using the current set.
 	struct OutSet {
 		DevBuf<hao_ovlp_t> ol_out; DevBuf<uint64_t> fin_off, fc_out, fc_out_off, ch_off, cl_off, qm_off;      // ol->list in final order, per-read offsets, fake cigars
-		DevBuf<hao_chain_hdr_t> hdr; DevBuf<uint8_t> bytes; DevBuf<hao_exc_t> exc, exc2; DevBuf<hao_qmz_t> qmz;   // cl->list in the wire format (hao_deliver.cuh)
+		DevBuf<hao_chain_hdr_t> hdr; DevBuf<uint64_t> bits; DevBuf<uint32_t> rank; DevBuf<uint8_t> codes; DevBuf<hao_exc_t> exc, exc2; DevBuf<hao_qmz_t> qmz;   // cl->list in the wire format (hao_deliver.cuh)
 		DevBuf<uint8_t> exact;                                                                        // exact-overlap flags of ol_out
-		void release() { ol_out.release(); fin_off.release(); fc_out.release(); fc_out_off.release(); ch_off.release(); cl_off.release(); qm_off.release(); hdr.release(); bytes.release(); exc.release(); exc2.release(); qmz.release(); exact.release(); }
+		void release() { ol_out.release(); fin_off.release(); fc_out.release(); fc_out_off.release(); ch_off.release(); cl_off.release(); qm_off.release(); hdr.release(); bits.release(); rank.release(); codes.release(); exc.release(); exc2.release(); qmz.release(); exact.release(); }
 	} out[2];
 	int cur = 0;
 	OutSet &O() { return out[cur]; }
@@ -38,7 +39,7 @@ struct hao_ctx::Batch {
 		s_start.release(); a_off.release(); seg.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fcf_off.release();
 		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); g_cls.release(); slow.release(); ovf_list.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
-		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); cd.release(); out[0].release(); out[1].release();
+		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); cd.release(); pk_bytes.release(); pk_cnt.release(); out[0].release(); out[1].release();
 		if (dl_ready) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); for (int k = 0; k < n_aux; ++k) { (void)hipStreamSynchronize(copy_aux[k]); (void)hipStreamDestroy(copy_aux[k]); (void)hipEventDestroy(ev_aux[0][k]); (void)hipEventDestroy(ev_aux[1][k]); } for (int x = 0; x < 2; ++x) { (void)hipEventDestroy(ev_ready[x]); (void)hipEventDestroy(ev_done[x]); if (arena[x]) (void)hipHostFree(arena[x]); arena[x] = nullptr; arena_cap[x] = 0; } dl_ready = false; }
 	}
 };
@@ -117,7 +118,9 @@ static int hao_deliver_enqueue(hao_ctx *c)
 	const bool ol = parts & HAO_DELIVER_OL, cl = parts & HAO_DELIVER_CL, ex = parts & HAO_DELIVER_EXACT;
 	size_t o_oloff = 0, o_ol = o_oloff + (ol ? al((n + 1) * 8) : 0), o_fcoff = o_ol + (ol ? al(B.n_ol * sizeof(hao_ovlp_t)) : 0), o_fc = o_fcoff + (ol ? al((B.n_ol + 1) * 8) : 0);
 	size_t o_choff = o_fc + (ol ? al(B.n_fc * 8) : 0), o_cloff = o_choff + (cl ? al((n + 1) * 8) : 0), o_qmoff = o_cloff + (cl ? al((n + 1) * 8) : 0), o_hdr = o_qmoff + (cl ? al((n + 1) * 8) : 0);
-	size_t o_qmz = o_hdr + (cl ? al(B.n_chains * sizeof(hao_chain_hdr_t)) : 0), o_bytes = o_qmz + (cl ? al(B.n_mz * sizeof(hao_qmz_t)) : 0), o_exc = o_bytes + (cl ? al(B.n_cl) : 0);
+	size_t o_qmz = o_hdr + (cl ? al(B.n_chains * sizeof(hao_chain_hdr_t)) : 0), o_bits = o_qmz + (cl ? al(B.n_mz * sizeof(hao_qmz_t)) : 0);
+	const uint64_t nw_ = (B.n_cl + 63) / 64;      // 64-hit words of the batch's bit stream
+	size_t o_rank = o_bits + (cl ? al(nw_ * 8) : 0), o_codes = o_rank + (cl ? al((nw_ + 1) * 4) : 0), o_exc = o_codes + (cl ? al(B.n_codes) : 0);
 	size_t o_ex = o_exc + (cl ? al(B.n_exc * sizeof(hao_exc_t)) : 0), total = o_ex + (ex ? al(B.n_ol) : 0);
 	if (total > B.arena_cap[s]) {
 		if (B.arena[s]) (void)hipHostFree(B.arena[s]);
@@ -145,7 +148,7 @@ static int hao_deliver_enqueue(hao_ctx *c)
 		return hipGetLastError();
 	};
 	hao_delivery_t &d = B.dl[s];
-	d.rid_lo = B.lo; d.n_reads = n; d.n_ol = d.n_fc = d.n_chains = d.n_cl = d.n_exc = 0; d.bytes = 0;
+	d.rid_lo = B.lo; d.n_reads = n; d.n_ol = d.n_fc = d.n_chains = d.n_cl = d.n_exc = d.n_codes = 0; d.bytes = 0;
 	if (ol && n) {
 		HIP_TRY(cp(o_oloff, O.fin_off.p, (n + 1) * 8)); HIP_TRY(cp(o_ol, O.ol_out.p, B.n_ol * sizeof(hao_ovlp_t)));
 		HIP_TRY(cp(o_fcoff, O.fc_out_off.p, B.n_ol * 8)); HIP_TRY(cp(o_fc, O.fc_out.p, B.n_fc * 8));
@@ -156,22 +159,23 @@ static int hao_deliver_enqueue(hao_ctx *c)
 	if (cl && n) {
 		HIP_TRY(cp(o_choff, O.ch_off.p, (n + 1) * 8)); HIP_TRY(cp(o_cloff, O.cl_off.p, (n + 1) * 8)); HIP_TRY(cp(o_qmoff, O.qm_off.p, (n + 1) * 8));
 		HIP_TRY(cp(o_hdr, O.hdr.p, B.n_chains * sizeof(hao_chain_hdr_t))); HIP_TRY(cp(o_qmz, O.qmz.p, B.n_mz * sizeof(hao_qmz_t))); HIP_TRY(cp(o_exc, O.exc.p, B.n_exc * sizeof(hao_exc_t)));
-		{	// the packed hits: 1 + n_aux pieces on as many streams (separate DMA queues)
-			const int np = ck ? 1 : B.n_aux + 1; const uint64_t per = ((B.n_cl + np - 1) / np + 63) & ~63ULL;
+		HIP_TRY(cp(o_bits, O.bits.p, nw_ * 8)); HIP_TRY(cp(o_rank, O.rank.p, (nw_ + 1) * 4));
+		{	// the code bytes: 1 + n_aux pieces on as many streams (separate DMA queues)
+			const int np = ck ? 1 : B.n_aux + 1; const uint64_t per = ((B.n_codes + np - 1) / np + 63) & ~63ULL;
 			for (int k = 0; k < np; ++k) {
-				const uint64_t lo_ = std::min<uint64_t>(B.n_cl, per * k), hi_ = std::min<uint64_t>(B.n_cl, per * (k + 1));
+				const uint64_t lo_ = std::min<uint64_t>(B.n_codes, per * k), hi_ = std::min<uint64_t>(B.n_codes, per * (k + 1));
 				if (hi_ <= lo_) continue;
-				if (k == 0) { HIP_TRY(cp(o_bytes, O.bytes.p, hi_ - lo_)); continue; }
+				if (k == 0) { HIP_TRY(cp(o_codes, O.codes.p, hi_ - lo_)); continue; }
 				hipStream_t st = B.copy_aux[k - 1];
 				HIP_TRY(hipStreamWaitEvent(st, B.ev_ready[s], 0));
-				HIP_TRY(hipMemcpyAsync(a + o_bytes + lo_, O.bytes.p + lo_, hi_ - lo_, hipMemcpyDeviceToHost, st));
+				HIP_TRY(hipMemcpyAsync(a + o_codes + lo_, O.codes.p + lo_, hi_ - lo_, hipMemcpyDeviceToHost, st));
 				HIP_TRY(hipEventRecord(B.ev_aux[s][k - 1], st));
 				HIP_TRY(hipStreamWaitEvent(B.copy_stream, B.ev_aux[s][k - 1], 0));
 			}
 		}
-		d.n_chains = B.n_chains; d.n_cl = B.n_cl; d.n_exc = B.n_exc; d.ch_off = (const uint64_t*)(a + o_choff); d.cl_off = (const uint64_t*)(a + o_cloff); d.qm_off = (const uint64_t*)(a + o_qmoff);
-		d.chains = (const hao_chain_hdr_t*)(a + o_hdr); d.qmz = (const hao_qmz_t*)(a + o_qmz); d.cl_bytes = a + o_bytes; d.cl_exc = (const hao_exc_t*)(a + o_exc);
-		d.bytes += 3 * (n + 1) * 8 + B.n_chains * sizeof(hao_chain_hdr_t) + B.n_mz * sizeof(hao_qmz_t) + B.n_cl + B.n_exc * sizeof(hao_exc_t);
+		d.n_chains = B.n_chains; d.n_cl = B.n_cl; d.n_exc = B.n_exc; d.n_codes = B.n_codes; d.ch_off = (const uint64_t*)(a + o_choff); d.cl_off = (const uint64_t*)(a + o_cloff); d.qm_off = (const uint64_t*)(a + o_qmoff);
+		d.chains = (const hao_chain_hdr_t*)(a + o_hdr); d.qmz = (const hao_qmz_t*)(a + o_qmz); d.cl_bits = (const uint64_t*)(a + o_bits); d.cl_rank = (const uint32_t*)(a + o_rank); d.cl_codes = a + o_codes; d.cl_exc = (const hao_exc_t*)(a + o_exc);
+		d.bytes += 3 * (n + 1) * 8 + B.n_chains * sizeof(hao_chain_hdr_t) + B.n_mz * sizeof(hao_qmz_t) + nw_ * 8 + (nw_ + 1) * 4 + B.n_codes + B.n_exc * sizeof(hao_exc_t);
 	}
 	if (ex && n) { HIP_TRY(cp(o_ex, O.exact.p, B.n_ol)); d.exact = a + o_ex; d.n_ol = B.n_ol; d.bytes += B.n_ol; }
 	HIP_TRY(hipEventRecord(B.ev_done[s], B.copy_stream));
@@ -369,15 +373,30 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	}
 	unsigned long long *d_exc_cnt = B.stats.p + 3 * HAO_NCLS + 2;      // (slot [3 NCLS + 2] of the stats block is free; [3 NCLS + 3] = seed overflow list cursor)
 	hao_pack_args pa; memset(&pa, 0, sizeof(pa));
+	const uint64_t NWmax = (A + 63) / 64 + 1;      // 64-hit words of the bit stream (bound: chained hits <= seed hits), plus one so that the scan's last entry is the total
+	unsigned long long *d_n_codes = B.stats.p + 3 * HAO_NCLS + 1;
+	// cl->list -> wire format: one code byte per chained hit (the number of chains / hits is only known on the device here: launch over the bounds,
+	// the kernels stop at ch_base[G] / cl_base[G]), then bits + rank directory + the code bytes of the flagged hits
+	auto pack = [&]() -> int {
+		if (!G) return HAO_OK;
+		hao_ctx::Batch::OutSet &O = B.O();
+		hipLaunchKernelGGL(hao_pack_chains_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH();
+		hipLaunchKernelGGL(hao_pack_bits_kernel, dim3((unsigned)((NWmax * 8 + 255) / 256)), dim3(256), 0, c->stream, B.pk_bytes.p, B.cl_base.p + G, NWmax, O.bits.p, B.pk_cnt.p); HAO_CHECK_LAUNCH();
+		size_t tb = 0;
+		HIP_TRY(rocprim::exclusive_scan(nullptr, tb, B.pk_cnt.p, O.rank.p, 0u, NWmax, rocprim::plus<uint32_t>(), c->stream)); HIP_TRY(hao_tmp(c, tb));
+		HIP_TRY(rocprim::exclusive_scan(c->d_tmp.p, tb, B.pk_cnt.p, O.rank.p, 0u, NWmax, rocprim::plus<uint32_t>(), c->stream));
+		hipLaunchKernelGGL(hao_pack_codes_kernel, dim3((unsigned)((NWmax * 8 + 255) / 256)), dim3(256), 0, c->stream, B.pk_bytes.p, B.cl_base.p + G, O.bits.p, O.rank.p, NWmax, O.codes.p, d_n_codes); HAO_CHECK_LAUNCH();
+		return HAO_OK;
+	};
 	if (parts & HAO_DELIVER_CL) {
 		hao_ctx::Batch::OutSet &O = B.O();
-		HIP_TRY(O.hdr.reserve(NCmax + 1)); HIP_TRY(O.bytes.reserve(A + 16)); HIP_TRY(O.exc.reserve(c->sw.exc_cap >= 0 ? (uint64_t)c->sw.exc_cap + 1 : std::max<uint64_t>(1 << 14, A / 256)));
+		HIP_TRY(O.hdr.reserve(NCmax + 1)); HIP_TRY(B.pk_bytes.reserve(A + 16)); HIP_TRY(O.exc.reserve(c->sw.exc_cap >= 0 ? (uint64_t)c->sw.exc_cap + 1 : std::max<uint64_t>(1 << 14, A / 256)));
+		HIP_TRY(O.bits.reserve(NWmax + 2)); HIP_TRY(O.rank.reserve(NWmax + 2)); HIP_TRY(B.pk_cnt.reserve(NWmax + 2)); HIP_TRY(O.codes.reserve(A + 16));
 		HIP_TRY(O.ch_off.reserve(n + 2)); HIP_TRY(O.cl_off.reserve(n + 2)); HIP_TRY(O.qm_off.reserve(n + 2)); HIP_TRY(O.qmz.reserve(nm + 1));
 		pa.cd = B.cd.p; pa.hits = B.hits.p; pa.ohits = B.ohits.p; pa.mz_off = c->d_ix_mz_off.p; pa.rid_lo = lo; pa.mz0 = B.mz0; pa.q_pos = B.q_pos.p;
-		pa.hdr = O.hdr.p; pa.bytes = O.bytes.p; pa.exc = O.exc.p; pa.exc_cnt = d_exc_cnt; pa.exc_every = (uint32_t)c->sw.exc_every;
+		pa.hdr = O.hdr.p; pa.bytes = B.pk_bytes.p; pa.exc = O.exc.p; pa.exc_cnt = d_exc_cnt; pa.exc_every = (uint32_t)c->sw.exc_every;
 		pa.exc_cap = c->sw.exc_cap >= 0 ? std::min<uint64_t>(O.exc.cap, (uint64_t)c->sw.exc_cap) : O.exc.cap;
-		// the number of chains is only known on the device here: launch over the bound, the kernel stops at ch_base[G]
-		if (G) { hipLaunchKernelGGL(hao_pack_chains_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH(); }
+		if (int rc = pack()) return rc;
 		hipLaunchKernelGGL(hao_read_ranges_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, B.g_off.p, B.ch_base.p, B.cl_base.p, c->d_ix_mz_off.p, lo, B.mz0, n, O.ch_off.p, O.cl_off.p, O.qm_off.p);
 		HAO_CHECK_LAUNCH();
 		if (nm) { hipLaunchKernelGGL(hao_qtab_kernel, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, c->stream, B.q_pos.p, B.q_cnt.p, nm, O.qmz.p); HAO_CHECK_LAUNCH(); }
@@ -431,7 +450,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	{	// the totals of the batch: one wave gathers them into mapped host memory
 		auto peek = [&](const void *src, int nw, int at) { hipLaunchKernelGGL(hao_peek_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)src, nw, c->peek_d + at); };
 		peek(B.ch_base.p + G, 1, 0); peek(B.cl_base.p + G, 1, 1); peek(B.fc_base.p + G * HAO_MCOPY_MAX, 1, 2); peek(B.O().fin_off.p + n, 1, 3); peek(B.fcf_off.p + n, 1, 4);
-		peek(d_slow_cnt, HAO_NCLS + 4, 8); peek(d_exc_cnt, 1, 5);
+		peek(d_slow_cnt, HAO_NCLS + 4, 8); peek(d_exc_cnt, 1, 5); peek(d_n_codes, 1, 6);
 		HAO_CHECK_LAUNCH();
 		const double ts2_ = hao_now();
 		HIP_TRY(hipStreamSynchronize(c->stream));
@@ -439,14 +458,16 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		if (c->sw.dltime && (B.t_nrun & 15) == 0) fprintf(stderr, "[batch] %llu runs (parts %u): total %.1f ms  before sync1 %.1f  sync1 %.1f  sync2 %.1f  sync3 %.1f\n", (unsigned long long)B.t_nrun, parts, B.t_run * 1e3, B.t_pre * 1e3, B.t_s1 * 1e3, B.t_s2 * 1e3, B.t_s3 * 1e3);
 		B.n_chains = c->peek_h[0]; B.n_cl = c->peek_h[1]; B.n_fc_raw = c->peek_h[2]; B.n_ol = c->peek_h[3]; B.n_fc = c->peek_h[4];
 		for (int x = 0; x < HAO_NCLS + 4; ++x) slow_st[x] = c->peek_h[8 + x];
-		if (parts & HAO_DELIVER_CL) n_exc = c->peek_h[5];
+		if (parts & HAO_DELIVER_CL) { n_exc = c->peek_h[5]; B.n_codes = G ? c->peek_h[6] : 0; }
 	}
 	if ((parts & HAO_DELIVER_CL) && n_exc > pa.exc_cap) {      // more verbatim hits than the list holds: grow it and pack again (the sources are untouched)
 		HIP_TRY(B.O().exc.reserve(n_exc + 1024)); pa.exc = B.O().exc.p; pa.exc_cap = B.O().exc.cap;
 		HIP_TRY(hipMemsetAsync(d_exc_cnt, 0, 8, c->stream));
-		hipLaunchKernelGGL(hao_pack_chains_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH();
+		if (int rc = pack()) return rc;
 		hipLaunchKernelGGL(hao_peek_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)d_exc_cnt, 1, c->peek_d + 5); HAO_CHECK_LAUNCH();
+		hipLaunchKernelGGL(hao_peek_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)d_n_codes, 1, c->peek_d + 6); HAO_CHECK_LAUNCH();
 		HIP_TRY(hipStreamSynchronize(c->stream));
+		B.n_codes = c->peek_h[6];
 		n_exc = c->peek_h[5];
 	}
 	if ((parts & HAO_DELIVER_CL) && n_exc > 1) {      // the list was appended in arrival order: sort it by hit index (the decoder looks hits up; also makes the bytes deterministic)

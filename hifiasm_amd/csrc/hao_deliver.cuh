@@ -53,16 +53,20 @@ __global__ __launch_bounds__(256) void hao_digest_kernel(hao_digest_args A)
 // Wire format of cl->list (include/hao.h: hao_chain_hdr_t, hao_qmz_t, hao_unpack_hits).
 // A chained hit is a pair (query minimizer, position on the target): self_offset and cnt (seed weight << 8 | span) are properties of the QUERY
 // minimizer alone (anchor.cpp:1065-1076), and along a chain the target offset follows the query offset up to a small diagonal shift.  So the
-// batch ships, per read, its minimizer table (self_offset, cnt: 8 bytes per minimizer, ~430 per 15 kb read) once, and per chained hit ONE byte:
+// batch ships, per read, its minimizer table (self_offset, cnt: 8 bytes per minimizer, ~430 per 15 kb read) once, and per chained hit a code:
 //     high nibble = (minimizers skipped since the previous hit of the chain) = dq - 1     (0 .. 14)
 //     low nibble  = (target offset delta) - (self_offset delta) + 8                       (diagonal shift -8 .. 7)
 // 0xff = the hit is in the batch's exception list (verbatim, with its minimizer index), keyed by the hit's index in the batch and sorted.
+// More than nine hits in ten have the code 0x08 (next minimizer, same diagonal), so the codes do not travel as a byte per hit: the batch ships
+// one BIT per hit (1 = this hit has a code byte), a rank directory (code bytes before every 64th hit) and the code bytes of the flagged hits
+// (hao_pack_bits_kernel, hao_pack_codes_kernel below): ~0.3 bytes per chained hit across PCIe instead of 16.
 // The first hit of a chain comes from the chain header (minimizer index, target offset).  ~1.3 bytes per chained hit across PCIe instead
 // of 16; the consumer thread decodes straight into its Candidates_list.  One wave per chain, reading the hits where the chain kernels left
 // them (chain descriptors): cl->list is never materialised in HBM on this path.  The minimizer index of a hit is recovered by a binary
 // search of its self_offset in the read's table (a few hundred L1/L2-resident entries).
 // ---------------------------------------------------------------------------------------
 #define HAO_PACK_QCAP 1024
+#define HAO_PACK_RUN 8
 struct hao_pack_args {
 	const hao_cdesc *cd; const hao_hit_t *hits, *ohits;
 	const uint64_t *mz_off; uint64_t rid_lo, mz0; const uint32_t *q_pos;      // per-read minimizer ranges (global offsets) and the batch's self_offset table
@@ -76,7 +80,10 @@ __global__ __launch_bounds__(256) void hao_pack_chains_kernel(hao_pack_args A, c
 	const int lane = hao_lane();
 	__shared__ uint32_t s_tab[4][HAO_PACK_QCAP];
 	uint32_t *tab = s_tab[threadIdx.x >> 6];
-	for (uint64_t ci = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); ci < n_chains; ci += n_waves) {
+	// a wave takes HAO_PACK_RUN consecutive chains at a time: they mostly belong to one read, whose table is then loaded once
+	uint64_t tab_read = ~0ULL;
+	for (uint64_t c0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * HAO_PACK_RUN; c0 < n_chains; c0 += n_waves * HAO_PACK_RUN)
+	for (uint64_t ci = c0; ci < c0 + HAO_PACK_RUN && ci < n_chains; ++ci) {
 	const hao_cdesc d = A.cd[ci];
 	const hao_hit_t *src = hao_cd_src(d, A.hits, A.ohits);
 	const uint64_t m0 = A.mz_off[A.rid_lo + d.r]; const uint32_t nq = (uint32_t)(A.mz_off[A.rid_lo + d.r + 1] - m0);
@@ -84,15 +91,20 @@ __global__ __launch_bounds__(256) void hao_pack_chains_kernel(hao_pack_args A, c
 	// the read's self_offset table goes to LDS once per chain (a few hundred entries, L2-resident): nine dependent LDS reads per hit instead of nine
 	// dependent global loads; longer tables (reads beyond ~35 kb) are searched in place
 	const bool in_lds = nq <= HAO_PACK_QCAP;
-	if (in_lds) for (uint32_t k = lane; k < nq; k += 64) tab[k] = qp[k];
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	if (in_lds && tab_read != d.r) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // (the previous chain's searches are done)
+		for (uint32_t k = lane; k < nq; k += 64) tab[k] = qp[k];
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		tab_read = d.r;
+	}
 	uint32_t q_prev = 0, off_prev = 0, self_prev = 0;      // the last hit of the previous tile (uniform)
 	for (uint32_t b = 0; b < d.n; b += 64) {
 		const uint32_t i = b + lane; const bool act = i < d.n;
 		hao_hit_t h; h.w0 = 0; h.offset = 0; h.self_offset = 0; h.cnt = 0; uint32_t q = 0;
 		if (act) {
 			h = src[i];
-			uint32_t lo = 0, hi = nq;      // the minimizer with this self_offset (positions are strictly ascending in the table)
+			uint32_t lo = 0, hi = nq;      // the minimizer with this self_offset (positions are strictly ascending in the table); a galloping search from the
+			                               // previous hit's minimizer (one or two probes per hit, but divergent) was slower: 62 against 50 ms per step
 			if (in_lds) { while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (tab[m] < h.self_offset) lo = m + 1; else hi = m; } }
 			else { while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (qp[m] < h.self_offset) lo = m + 1; else hi = m; } }
 			q = lo;
@@ -103,7 +115,7 @@ __global__ __launch_bounds__(256) void hao_pack_chains_kernel(hao_pack_args A, c
 			const int64_t dq = (int64_t)q - (int64_t)pq, dd = ((int64_t)h.offset - (int64_t)po) - ((int64_t)h.self_offset - (int64_t)ps);
 			esc = dq < 1 || dq > 15 || dd < -8 || dd > 7 || (A.exc_every && i % A.exc_every == A.exc_every - 1);
 			code = esc ? 0xff : (uint8_t)((dq - 1) << 4 | (dd + 8));
-		}
+		} else if (act) code = 0x08;      // first hit of a chain: described by its header, no code byte
 		if (b == 0 && lane == 0) { hao_chain_hdr_t H; H.n_hits = d.n; H.w0 = d.w0; H.q0 = q; H.offset = h.offset; A.hdr[ci] = H; }
 		const unsigned long long em = __ballot(esc);
 		if (em) {
@@ -118,8 +130,38 @@ __global__ __launch_bounds__(256) void hao_pack_chains_kernel(hao_pack_args A, c
 		if (act) A.bytes[d.dst + i] = code;
 		q_prev = hao_bcast(q, 63); off_prev = hao_bcast(h.offset, 63); self_prev = hao_bcast(h.self_offset, 63);
 	}
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // the table is reloaded for the wave's next chain
 	}
+}
+
+// One byte per hit -> bit stream + code bytes.  Thread t takes hits [8t, 8t + 8) (one 8-byte load); the eight threads of a 64-hit word combine their
+// flags.  The hit count of the batch is only known on the device when this is launched (n_dev), the grid covers the bound.
+__global__ __launch_bounds__(256) void hao_pack_bits_kernel(const uint8_t *bytes, const uint64_t *n_dev, uint64_t n_words_max, uint64_t *bits, uint32_t *cnt)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, w = t >> 3, n = *n_dev;
+	if (w >= n_words_max) return;      // (whole groups of eight threads leave together: n_words_max bounds w, not t)
+	uint32_t m8 = 0;
+	if (8 * t < n) {
+		uint64_t v = *(const uint64_t*)(bytes + 8 * t);
+#pragma unroll
+		for (int k = 0; k < 8; ++k) if (8 * t + k < n && (uint8_t)(v >> (8 * k)) != 0x08) m8 |= 1u << k;
+	}
+	uint64_t word = (uint64_t)m8 << ((t & 7) * 8);
+	word |= __shfl_xor(word, 1); word |= __shfl_xor(word, 2); word |= __shfl_xor(word, 4);
+	if ((t & 7) == 0) { bits[w] = word; cnt[w] = (uint32_t)__popcll(word); }
+}
+
+__global__ __launch_bounds__(256) void hao_pack_codes_kernel(const uint8_t *bytes, const uint64_t *n_dev, const uint64_t *bits, const uint32_t *rank, uint64_t n_words_max, uint8_t *codes,
+		unsigned long long *n_codes)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, n = *n_dev;
+	if (t == 0) *n_codes = rank[n_words_max - 1];      // (the last word of the bound is empty: its exclusive prefix is the total)
+	if (8 * t >= n) return;
+	const uint64_t word = bits[t >> 3]; const int sh = (int)(t & 7) * 8;
+	uint32_t m8 = (uint32_t)(word >> sh) & 0xffu;
+	if (!m8) return;
+	uint64_t at = rank[t >> 3] + (uint64_t)__popcll(word & ((1ULL << sh) - 1));
+	const uint64_t v = *(const uint64_t*)(bytes + 8 * t);
+	for (; m8; m8 &= m8 - 1) codes[at++] = (uint8_t)(v >> (8 * (__ffs((int)m8) - 1)));
 }
 
 // the batch's minimizer table for the consumer: (self_offset, cnt) per query minimizer, interleaved

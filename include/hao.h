@@ -152,9 +152,11 @@ int hao_batch_totals(hao_ctx *c, uint64_t out[8]);
 /* ---- streaming result delivery: results of batch i cross PCIe while batch i + 1 computes ----
  * h_ec_lchain hands ol->list and cl->list back to a per-read caller (anchor.cpp:2302; consumed by gen_hc_r_alin_ea, ecovlp.cpp:3288).  A batch's
  * results are ~190 KB per 15 kb read, almost all of it cl->list (16 bytes per chained hit), more than PCIe can carry at the rate the device produces
- * them.  The delivery path therefore (a) ships cl->list in a wire format of ~1.3 bytes per hit: a chained hit is (query minimizer, target offset);
- * self_offset and cnt belong to the query minimizer (anchor.cpp:1065-1076) and travel once per read in its minimizer table, the hit itself is one
- * byte - minimizers skipped since the previous hit of the chain (high nibble) and diagonal shift + 8 (low nibble), 0xff = look the hit up in the
+ * them.  The delivery path therefore (a) ships cl->list in a wire format of ~0.3 bytes per hit: a chained hit is (query minimizer, target offset);
+ * self_offset and cnt belong to the query minimizer (anchor.cpp:1065-1076) and travel once per read in its minimizer table; a hit whose
+ * chain simply moves on to the read's next minimizer on the same diagonal (> 90 % of them) is a 0 in the batch's bit stream, any other hit a 1
+ * plus one code byte - minimizers skipped since the previous hit of the chain (high nibble) and diagonal shift + 8 (low nibble), 0xff = look the
+ * hit up in the
  * (sorted) exception list; the consumer thread decodes straight into its Candidates_list (hao_unpack_hits); (b) copies into one of two pinned host
  * arenas on copy streams, under the next batch's kernels.  hao_overlap_batch_async returns when the batch's kernels are done and its copy is
  * queued; hao_deliver_wait blocks until the copy has landed and describes the arena.  A slot's arena (and the device buffers behind it) is reused by
@@ -167,14 +169,16 @@ typedef struct { uint32_t n_hits, w0, q0, offset; } hao_chain_hdr_t;      /* one
 typedef struct { uint32_t self_offset, cnt; } hao_qmz_t;                  /* one query minimizer: k_mer_hit::self_offset and ::cnt of every hit it seeds */
 typedef struct { uint64_t index; uint32_t q, pad; hao_hit_t hit; } hao_exc_t;   /* verbatim hit: its index in the batch's cl->list concatenation, its minimizer index, the hit */
 typedef struct {
-	uint64_t rid_lo, n_reads, n_ol, n_fc, n_chains, n_cl, n_exc, bytes;            /* bytes = what crossed PCIe for this batch */
+	uint64_t rid_lo, n_reads, n_ol, n_fc, n_chains, n_cl, n_exc, n_codes, bytes;   /* bytes = what crossed PCIe for this batch */
 	const uint64_t *ol_off;          /* [n_reads + 1]: ol->list of read r = ol[ol_off[r] .. ol_off[r + 1]) */
 	const hao_ovlp_t *ol;
 	const uint64_t *fc_off;          /* [n_ol + 1]: fake cigar of overlap j = fc[fc_off[j] .. fc_off[j + 1]) */
 	const uint64_t *fc;
-	const uint64_t *ch_off, *cl_off, *qm_off; /* [n_reads + 1]: chains / hits / minimizers of read r = chains[ch_off[r] ..), cl_bytes[cl_off[r] ..), qmz[qm_off[r] ..) */
+	const uint64_t *ch_off, *cl_off, *qm_off; /* [n_reads + 1]: chains / hits / minimizers of read r = chains[ch_off[r] ..), hits cl_off[r] .. of the batch, qmz[qm_off[r] ..) */
 	const hao_chain_hdr_t *chains;
-	const uint8_t *cl_bytes;         /* one byte per hit (see above) */
+	const uint64_t *cl_bits;         /* bit h (word h / 64, bit h % 64) = hit h of the batch (h = cl_off[r] + position in the read's cl->list) has a code byte */
+	const uint32_t *cl_rank;         /* [n_cl / 64 + 1]: code bytes before hit 64 w */
+	const uint8_t *cl_codes;         /* [n_codes] code bytes, in hit order */
 	const hao_qmz_t *qmz;            /* minimizer tables of the batch's reads */
 	const hao_exc_t *cl_exc;         /* [n_exc] sorted by index */
 	const uint8_t *exact;            /* [n_ol] with HAO_DELIVER_EXACT, else NULL */
