@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "none"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-boundary", action="store_true", help="skip the boundary-inclusive (results delivered to host memory) measurement")
+    ap.add_argument("--contexts", type=int, default=1, help="batch contexts (hao_attach) = host threads that run the batches of a pass concurrently; 1 keeps every kernel alone on the device (the roofline line)")
+    ap.add_argument("--boundary-contexts", type=int, default=1, help="batch contexts of the boundary-inclusive measurement")
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
     if a.no_cpu_baseline:
@@ -184,32 +186,63 @@ def main():
     bsz = a.batch_reads if a.batch_reads > 0 else min(n_reads, auto_bsz)
     ranges = [(lo, min(n_reads, lo + bsz)) for lo in range(0, n_reads, bsz)]
 
-    def step(deliver=False):
+    views = {}
+
+    def contexts(k):      # the engine plus k - 1 attached batch contexts (own stream, scratch and result buffers over the same index)
+        while len(views) < k - 1:
+            views[len(views)] = eng.attach()
+        return [eng] + [views[i] for i in range(k - 1)]
+
+    def step(deliver=False, n_ctx=1):
         eng.ha_pt_gen()
         st = {k: v for k, v in eng.stage_times()}
-        tot = {"overlaps": 0, "chained_hits": 0, "seed_hits": 0, "groups": 0, "minimizers": 0, "seq_groups": 0, "seq_group_hits": 0, "host_bytes": 0, "copy_ms": 0.0, "t_async": 0.0, "t_wait": 0.0, "code_bytes": 0, "delivered_hits": 0}
-        prev = None
-        for lo, hi in ranges:
-            if deliver:
-                t_a = time.time()
-                slot = eng.overlap_batch_async(lo, hi)      # compute of this batch; its copy runs under the next batch's kernels
-                t_b = time.time()
-                if prev is not None:                        # the consumer takes the previous batch now (its copy ran under this batch's kernels)
-                    d = eng.deliver_wait(prev)
+        keys0 = {"overlaps": 0, "chained_hits": 0, "seed_hits": 0, "groups": 0, "minimizers": 0, "seq_groups": 0, "seq_group_hits": 0, "host_bytes": 0, "copy_ms": 0.0, "t_async": 0.0, "t_wait": 0.0, "code_bytes": 0, "delivered_hits": 0}
+        engs = contexts(n_ctx)
+        res, errs = [None] * n_ctx, []
+
+        def run(ci):      # context ci takes batches ci, ci + n_ctx, ...
+            e = engs[ci]; tot = dict(keys0); sst = {}
+            try:
+                prev = None
+                for lo, hi in ranges[ci::n_ctx]:
+                    if deliver:
+                        t_a = time.time()
+                        slot = e.overlap_batch_async(lo, hi)      # compute of this batch; its copy runs under the next batch's kernels
+                        t_b = time.time()
+                        if prev is not None:                      # the consumer takes the previous batch now (its copy ran under this batch's kernels)
+                            d = e.deliver_wait(prev)
+                            tot["host_bytes"] += int(d.bytes); tot["copy_ms"] += float(d.copy_ms); tot["code_bytes"] += int(d.n_codes); tot["delivered_hits"] += int(d.n_cl)
+                        tot["t_async"] += (t_b - t_a) * 1e3; tot["t_wait"] += (time.time() - t_b) * 1e3
+                        prev = slot
+                    else:
+                        e.overlap_batch(lo, hi)
+                    t = e.batch_totals()
+                    for k in t:
+                        if k in tot:
+                            tot[k] += t[k]
+                    for k, v in e.stage_times():
+                        sst[k] = sst.get(k, 0.0) + v
+                if deliver and prev is not None:
+                    d = e.deliver_wait(prev)                      # every batch's results are in host memory
                     tot["host_bytes"] += int(d.bytes); tot["copy_ms"] += float(d.copy_ms); tot["code_bytes"] += int(d.n_codes); tot["delivered_hits"] += int(d.n_cl)
-                tot["t_async"] += (t_b - t_a) * 1e3; tot["t_wait"] += (time.time() - t_b) * 1e3
-                prev = slot
-            else:
-                eng.overlap_batch(lo, hi)
-            t = eng.batch_totals()
-            for k in t:
-                if k in tot:
-                    tot[k] += t[k]
-            for k, v in eng.stage_times():
+                res[ci] = (tot, sst)
+            except Exception as ex:      # noqa: BLE001 - raised again on the main thread
+                errs.append(ex)
+
+        if n_ctx == 1:
+            run(0)
+        else:
+            import threading
+            th = [threading.Thread(target=run, args=(ci,)) for ci in range(n_ctx)]
+            [t.start() for t in th]; [t.join() for t in th]
+        if errs:
+            raise errs[0]
+        tot = dict(keys0)
+        for t_, s_ in res:
+            for k in tot:
+                tot[k] += t_[k]
+            for k, v in s_.items():      # (with several contexts the stage times are sums over concurrently running batches: they no longer add up to the step)
                 st[k] = st.get(k, 0.0) + v
-        if deliver:
-            d = eng.deliver_wait(prev)                      # every batch's results are in host memory
-            tot["host_bytes"] += int(d.bytes); tot["copy_ms"] += float(d.copy_ms); tot["code_bytes"] += int(d.n_codes); tot["delivered_hits"] += int(d.n_cl)
         return tot, st
 
     def sync():
@@ -217,14 +250,14 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def timed(deliver):
+    def timed(deliver, n_ctx=1):
         for _ in range(a.warmup):
-            step(deliver)
+            step(deliver, n_ctx)
         sync()
         t0 = time.time()
         ssum = {}
         for _ in range(a.steps):
-            tot, st = step(deliver)
+            tot, st = step(deliver, n_ctx)
             for k, v in st.items():
                 ssum[k] = ssum.get(k, 0.0) + v
         sync()
@@ -239,12 +272,12 @@ def main():
             ov = int(oo.item())
         return dt, ov, tot, ssum
 
-    dt, overlaps, tot, stage_sum = timed(False)
+    dt, overlaps, tot, stage_sum = timed(False, max(1, a.contexts))
     ms_per_step = dt / a.steps * 1e3
     value = overlaps / (dt / a.steps)
     boundary = None
     if not a.no_boundary and hasattr(eng, "overlap_batch_async"):
-        bdt, bov, btot, bst = timed(True)
+        bdt, bov, btot, bst = timed(True, max(1, a.boundary_contexts))
         boundary = {"q_assemble_ms_per_step": bst.get("q_assemble", 0.0) / a.steps, "stage_ms": {k: round(v / a.steps, 2) for k, v in bst.items()},"value": bov / (bdt / a.steps), "ms_per_step": bdt / a.steps * 1e3, "host_bytes_per_gpu_step": btot["host_bytes"], "wire_bytes_per_chained_hit": (btot["delivered_hits"] / 8 + btot["delivered_hits"] / 16 + btot["code_bytes"]) / max(1, btot["delivered_hits"]),
                     "copy_ms_per_step": btot["copy_ms"], "host_ms_in_async": btot["t_async"], "host_ms_in_wait": btot["t_wait"], "copy_gb_per_s": btot["host_bytes"] / max(1e-9, btot["copy_ms"] * 1e-3) / 1e9}
 
@@ -303,9 +336,10 @@ def main():
                           "assemble_and_pack_ms_per_step": round(boundary["q_assemble_ms_per_step"], 2),
                           "host_ms_in_async": round(boundary["host_ms_in_async"], 1), "host_ms_in_wait": round(boundary["host_ms_in_wait"], 1),
                           "stage_ms": boundary["stage_ms"],
-                          "what": "same step with every batch's ol->list, fake cigars and packed cl->list delivered into pinned host memory (double-buffered, copy stream under the next batch's compute)"}
+                          "contexts": max(1, a.boundary_contexts),
+                          "what": "same step with every batch's ol->list, fake cigars and packed cl->list delivered into pinned host memory (per batch context: double-buffered, copy stream under the next batch's compute); contexts = batch contexts (hao_attach), one host thread each, that share the pass"}
                          if boundary else None),
-            "config": {"workload": a.workload, "reads_per_gpu": n_reads, "bases_per_gpu": rs.total_bases, "batches_per_pass": len(ranges),
+            "config": {"workload": a.workload, "batch_contexts": max(1, a.contexts), "reads_per_gpu": n_reads, "bases_per_gpu": rs.total_bases, "batches_per_pass": len(ranges),
                        "overlaps_per_gpu_step": tot["overlaps"], "seed_hits_per_gpu_step": tot["seed_hits"],
                        "chained_hits_per_gpu_step": tot["chained_hits"], "groups_per_gpu_step": tot["groups"],
                        "groups_on_sequential_path": tot["seq_groups"], "k": 51, "w": 51, "hpc": 1,

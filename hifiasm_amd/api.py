@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "hao_ft_cnt", "hao_pt_get", "hao_ft_table", "hao_pt_table", "hao_hist", "hao_stats", "hao_sketch_batch",
     "hao_fetch_sketch", "hao_overlap_batch", "hao_fetch_seed_hits", "hao_fetch_overlaps", "hao_batch_totals",
     "hao_stage_times", "hao_pass_default", "hao_overlap_batch_ex", "hao_set_shard", "hao_dist_unique_id", "hao_dist_init",
-    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits", "hao_exact_check", "hao_fetch_exact", "hao_window_ed_batch", "hao_index_save",
+    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits", "hao_exact_check", "hao_fetch_exact", "hao_window_ed_batch", "hao_index_save", "hao_attach",
 ]
 
 
@@ -76,6 +76,7 @@ def lib():
         L.hao_opt_default.argtypes = [C.POINTER(Opt)]
         L.hao_create.argtypes = [C.c_int, C.POINTER(Opt), C.POINTER(vp)]
         L.hao_destroy.argtypes = [vp]
+        L.hao_attach.argtypes = [vp, C.POINTER(vp)]
         L.hao_last_error.argtypes = [vp]; L.hao_last_error.restype = C.c_char_p
         L.hao_set_reads.argtypes = [vp, u8p, u64p, u32p, C.c_uint64, u64p, u32p]
         L.hao_ft_gen.argtypes = [vp, C.POINTER(C.c_int32)]
@@ -139,6 +140,15 @@ class Engine:
             raise HaoError(f"hao_create failed ({rc}): no usable HIP device - this engine has no CPU fallback")
         self.h = h
         self.n_reads = 0
+
+    def attach(self):
+        """hao_attach: a second batch context (own stream, scratch, results) over this engine's reads and index, for a second host thread"""
+        v = Engine.__new__(Engine)
+        v.L = self.L; v.opt = self.opt; v.bw_thres = self.bw_thres; v.n_reads = self.n_reads; v.owner = self
+        h = C.c_void_p()
+        self._ck(self.L.hao_attach(self.h, C.byref(h)), "hao_attach")
+        v.h = h
+        return v
 
     def close(self):
         if getattr(self, "h", None):

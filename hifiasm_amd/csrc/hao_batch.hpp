@@ -199,6 +199,7 @@ static int hao_deliver_init(hao_ctx *c, hao_ctx::Batch &B)
 static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_t &ps, uint32_t parts = 0, int *slot_out = nullptr)
 {
 	if (ps.apend_be != 1 || ps.is_accurate != 1 || ps.gen_off != 1 || ps.mcopy_num > HAO_MCOPY_MAX || ps.ocv_w == 0) { hao_set_err(c, "unsupported h_ec_lchain arguments"); return HAO_EUNSUPP; }
+	if (int rc = hao_view_refresh(c)) return rc;
 	if (!c->has_pt) { hao_set_err(c, "hao_pt_gen must run before hao_overlap_batch"); return HAO_EINVAL; }
 	if (!c->batch) c->batch = new hao_ctx::Batch();
 	hao_ctx::Batch &B = *c->batch; const double t_run0 = hao_now();

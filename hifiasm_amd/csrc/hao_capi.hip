@@ -63,10 +63,25 @@ void hao_destroy(hao_ctx *c)
 
 const char *hao_last_error(const hao_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
 
+#define HAO_NOT_ON_VIEW(c, what) do { if ((c)->owner) { hao_set_err((c), what ": not on an attached batch context (hao_attach)"); return HAO_EINVAL; } } while (0)
+
+int hao_attach(hao_ctx *o, hao_ctx **out)
+{
+	if (!o || !out) return HAO_EINVAL;
+	*out = nullptr;
+	if (o->owner) { hao_set_err(o, "hao_attach: attach to the owning engine, not to another view"); return HAO_EINVAL; }
+	hao_ctx *c = nullptr;
+	if (int rc = hao_create(o->device, &o->opt, &c)) return rc;
+	c->owner = o; c->attached_gen = ~0ULL;      // the first batch takes the owner's current reads and index (hao_view_refresh)
+	*out = c;
+	return HAO_OK;
+}
+
 int hao_set_reads(hao_ctx *c, const uint8_t *packed, const uint64_t *pk_off, const uint32_t *len, uint64_t n_reads,
 				  const uint64_t *nsite_off, const uint32_t *nsite)
 {
 	if (!c || !packed || !pk_off || !len) return HAO_EINVAL;
+	HAO_NOT_ON_VIEW(c, "hao_set_reads"); ++c->index_gen;
 	if (n_reads >= (1ULL << 28)) { hao_set_err(c, "more than 2^28 reads (htab.cpp:765)"); return HAO_EUNSUPP; }
 	HIP_TRY(hipSetDevice(c->device));
 	c->n_reads = n_reads; c->n_pk_bytes = pk_off[n_reads]; c->max_len = 0;
@@ -101,6 +116,7 @@ int hao_set_reads(hao_ctx *c, const uint8_t *packed, const uint64_t *pk_off, con
 int hao_set_shard(hao_ctx *c, uint64_t rid_base, uint64_t n_total, const uint32_t *all_len)
 {
 	if (!c || !all_len || rid_base + c->n_reads > n_total) return HAO_EINVAL;
+	HAO_NOT_ON_VIEW(c, "hao_set_shard"); ++c->index_gen;
 	if (n_total >= (1ULL << 28)) { hao_set_err(c, "more than 2^28 reads (htab.cpp:765)"); return HAO_EUNSUPP; }
 	for (uint64_t i = 0; i < c->n_reads; ++i) if (all_len[rid_base + i] != c->h_len[i]) { hao_set_err(c, "all_len disagrees with the local read lengths"); return HAO_EINVAL; }
 	HIP_TRY(hipSetDevice(c->device));
@@ -122,6 +138,7 @@ int hao_dist_unique_id(uint8_t id[128])
 int hao_dist_init(hao_ctx *c, const uint8_t id[128], int rank, int world)
 {
 	if (!c || !id || rank < 0 || rank >= world) return HAO_EINVAL;
+	HAO_NOT_ON_VIEW(c, "hao_dist_init");
 	HIP_TRY(hipSetDevice(c->device));
 	if (!c->comm) c->comm = new hao_comm();
 	ncclUniqueId u; memcpy(&u, id, sizeof(u));
@@ -157,6 +174,7 @@ int hao_dist_init_loopback(hao_ctx *c, void *grp, int rank)
 int hao_sketch_batch(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi, int use_ft, int sample_dist)
 {
 	if (!c || rid_lo > rid_hi || rid_hi > c->n_reads) return HAO_EINVAL;
+	HAO_NOT_ON_VIEW(c, "hao_sketch_batch");
 	HIP_TRY(hipSetDevice(c->device));
 	c->timer.begin(c->stream);
 	int rc = hao_sketch_run(c, rid_lo, rid_hi, use_ft && c->has_ft, sample_dist, 1);

@@ -24,6 +24,7 @@ extern "C" {
 int hao_ft_gen(hao_ctx *c, int32_t *hom_cov)
 {
 	if (!c) return HAO_EINVAL;
+	HAO_NOT_ON_VIEW(c, "hao_ft_gen"); ++c->index_gen;
 	HIP_TRY(hipSetDevice(c->device));
 	c->timer.begin(c->stream);
 	int rc = hao_ft_run(c);
@@ -67,6 +68,7 @@ int hao_stats(hao_ctx *c, int64_t out[8])
 int hao_pt_gen(hao_ctx *c, int32_t *hom_cov, int32_t *het_cov)
 {
 	if (!c) return HAO_EINVAL;
+	HAO_NOT_ON_VIEW(c, "hao_pt_gen"); ++c->index_gen;
 	HIP_TRY(hipSetDevice(c->device));
 	c->timer.begin(c->stream);
 	int rc = hao_pt_run(c);
@@ -92,6 +94,7 @@ int hao_pt_get(hao_ctx *c, uint64_t hash, const uint64_t **pos, int32_t *n)
 int hao_pass_default(hao_ctx *c, hao_pass_t *p)
 {
 	if (!c || !p) return HAO_EINVAL;
+	if (int rc = hao_view_refresh(c)) return rc;
 	memset(p, 0, sizeof(*p));
 	p->bw_thres = c->opt.is_ont ? 0.05 : 0.02; p->max_n_chain = c->max_n_chain;
 	hao_occ_thresholds(c->hom_cov, &p->high_occ, &p->low_occ);
@@ -108,6 +111,7 @@ int hao_overlap_batch(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi)
 
 int hao_overlap_batch_ex(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi, const hao_pass_t *pass)
 {
+	if (c) { if (int rc = hao_view_refresh(c)) return rc; }
 	if (!c || !pass || rid_lo > rid_hi || rid_hi > c->n_reads) return HAO_EINVAL;
 	HIP_TRY(hipSetDevice(c->device));
 	c->timer.begin(c->stream);
@@ -120,6 +124,7 @@ int hao_overlap_batch_ex(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi, const hao
 
 int hao_overlap_batch_async(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi, const hao_pass_t *pass, uint32_t parts, int *slot)
 {
+	if (c) { if (int rc = hao_view_refresh(c)) return rc; }
 	if (!c || rid_lo > rid_hi || rid_hi > c->n_reads || !(parts & (HAO_DELIVER_OL | HAO_DELIVER_CL | HAO_DELIVER_EXACT))) return HAO_EINVAL;
 	hao_pass_t ps;
 	if (!pass) { if (int rc = hao_pass_default(c, &ps)) return rc; pass = &ps; }
@@ -177,6 +182,7 @@ uint64_t hao_unpack_hits(const hao_delivery_t *d, uint64_t rid, hao_hit_t *out, 
 int hao_index_save(hao_ctx *c, const char *prefix, int32_t number_of_round, const char *const *names)
 {
 	if (!c || !prefix) return HAO_EINVAL;
+	HAO_NOT_ON_VIEW(c, "hao_index_save");
 	HIP_TRY(hipSetDevice(c->device));
 	return hao_index_save_impl(c, prefix, number_of_round, names);
 }
@@ -184,6 +190,7 @@ int hao_index_save(hao_ctx *c, const char *prefix, int32_t number_of_round, cons
 int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks, hao_ed_result_t *out)
 {
 	if (!c || (!tasks && n_tasks) || (!out && n_tasks)) return HAO_EINVAL;
+	if (int rc = hao_view_refresh(c)) return rc;
 	if (c->comm && c->comm->active()) { hao_set_err(c, "hao_window_ed_batch needs the bases of both reads: single-device mode only"); return HAO_EUNSUPP; }
 	if (n_tasks == 0) return HAO_OK;
 	for (uint64_t i = 0; i < n_tasks; ++i) {      // the reference indexes its strings unchecked; a device kernel must not

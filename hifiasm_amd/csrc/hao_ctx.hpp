@@ -11,9 +11,10 @@ static void hao_set_err(hao_ctx *c, const std::string &m);
 
 // grow-only device buffer
 template<typename T> struct DevBuf {
-	T *p = nullptr; size_t cap = 0;
+	T *p = nullptr; size_t cap = 0; bool borrowed = false;      // borrowed: a read-only view of another engine's buffer (hao_attach) - never freed or grown here
 	hipError_t reserve(size_t n) {
 		if (n <= cap) return hipSuccess;
+		if (borrowed) return hipErrorInvalidValue;
 		if (p) (void)hipFree(p);
 		p = nullptr; cap = 0;
 		size_t want = n + n / 8 + 64;
@@ -24,13 +25,15 @@ template<typename T> struct DevBuf {
 	// allocate exactly n elements if smaller (twin of a ping-pong pair: avoids a late first allocation inside a timed pass)
 	hipError_t reserve_exact(size_t n) {
 		if (n <= cap) return hipSuccess;
+		if (borrowed) return hipErrorInvalidValue;
 		if (p) (void)hipFree(p);
 		p = nullptr; cap = 0;
 		hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
 		if (e == hipSuccess) cap = n;
 		return e;
 	}
-	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	void release() { if (p && !borrowed) (void)hipFree(p); p = nullptr; cap = 0; borrowed = false; }
+	void borrow(const DevBuf<T> &o) { release(); p = o.p; cap = o.cap; borrowed = o.p != nullptr; }
 };
 
 struct StageTimer {
@@ -81,6 +84,8 @@ __global__ void hao_peek_kernel(const unsigned long long *src, int n, unsigned l
 
 struct hao_ctx {
 	int device = 0; hao_opt_t opt; std::string err; hipStream_t stream = nullptr; hao_switches sw;
+	// hao_attach: a second batch context over this engine's reads and index (own stream, scratch, results); index_gen counts the owner's rebuilds
+	hao_ctx *owner = nullptr; uint64_t index_gen = 0, attached_gen = 0;
 	unsigned long long *peek_h = nullptr, *peek_d = nullptr;      // 512 words of mapped pinned memory
 	// ---- read store (HBM) ----
 	uint64_t n_reads = 0, n_bases = 0, n_pk_bytes = 0; bool has_n = false; uint32_t max_len = 0;
@@ -132,5 +137,23 @@ static int hao_excl_scan_u64(hao_ctx *c, In in, Out out, size_t n)
 	HIP_TRY(rocprim::exclusive_scan(nullptr, tb, in, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), c->stream));
 	HIP_TRY(hao_tmp(c, tb));
 	HIP_TRY(rocprim::exclusive_scan(c->d_tmp.p, tb, in, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), c->stream));
+	return HAO_OK;
+}
+
+// An attached batch context (hao_attach) reads the owner's read store and index through borrowed pointers; they are taken again whenever the owner has
+// rebuilt something since (the owner must not be rebuilding while a view runs a batch: same rule as for the owner's own batches).
+static int hao_view_refresh(hao_ctx *c)
+{
+	hao_ctx *o = c->owner;
+	if (!o || c->attached_gen == o->index_gen) return HAO_OK;
+	c->opt = o->opt;
+	c->n_reads = o->n_reads; c->n_bases = o->n_bases; c->n_pk_bytes = o->n_pk_bytes; c->has_n = o->has_n; c->max_len = o->max_len;
+	c->rid_base = o->rid_base; c->n_total = o->n_total; c->max_n_chain = o->max_n_chain; c->hom_cov = o->hom_cov; c->het_cov = o->het_cov;
+	c->has_pt = o->has_pt; c->ix_n_mz = o->ix_n_mz; c->ix_n_sorted = o->ix_n_sorted; c->ix_n_keys = o->ix_n_keys; c->ix_n_pos = o->ix_n_pos; c->ix_bucket_bits = o->ix_bucket_bits; c->lk_valid = o->lk_valid;
+	c->h_len = o->h_len; c->h_nsite_off = o->h_nsite_off; c->h_len_all = o->h_len_all; c->h_ix_mz_off = o->h_ix_mz_off;      // (empty: copied from the device on first use)
+	c->d_packed.borrow(o->d_packed); c->d_pk_off.borrow(o->d_pk_off); c->d_len.borrow(o->d_len); c->d_len_all.borrow(o->d_len_all); c->d_nsite_off.borrow(o->d_nsite_off); c->d_nsite.borrow(o->d_nsite);
+	c->d_ix_mz_x.borrow(o->d_ix_mz_x); c->d_ix_mz_info.borrow(o->d_ix_mz_info); c->d_ix_mz_off.borrow(o->d_ix_mz_off); c->d_ix_sinfo.borrow(o->d_ix_sinfo); c->d_ix_lk.borrow(o->d_ix_lk);
+	c->d_ix_keys.borrow(o->d_ix_keys); c->d_ix_start.borrow(o->d_ix_start); c->d_ix_cnt.borrow(o->d_ix_cnt); c->d_ix_bucket.borrow(o->d_ix_bucket);
+	c->attached_gen = o->index_gen;
 	return HAO_OK;
 }

@@ -592,6 +592,9 @@ static int hao_pt_run(hao_ctx *c)
 	int bits = 16; while ((1ULL << bits) < c->ix_n_keys / 2 && bits < 26) ++bits;
 	if (int rc = hao_build_bucket(c, c->d_ix_keys.p, c->ix_n_keys, bits, c->d_ix_bucket)) return rc;
 	c->ix_bucket_bits = bits;
+	// host copy of the per-read minimizer offsets (batch sizing): taken here, not lazily inside a batch - batch contexts attached to this engine read it
+	c->h_ix_mz_off.resize(n + 1);
+	HIP_TRY(hipMemcpyAsync(c->h_ix_mz_off.data(), c->d_ix_mz_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	if (!c->has_ft) { int mx = (int)(c->hom_cov * c->opt.high_factor + .499); if (c->max_n_chain < mx) c->max_n_chain = mx; }   // Assembly.cpp:1011-1012
 	c->has_pt = true;

@@ -149,6 +149,14 @@ int hao_fetch_overlaps(hao_ctx *c, uint64_t rid, const hao_ovlp_t **ol, uint64_t
  * out[3] = chain groups, out[4] = minimizers of the query reads */
 int hao_batch_totals(hao_ctx *c, uint64_t out[8]);
 
+/* A second (third ...) batch context over the same reads and index: own stream, scratch and result buffers, nothing else.  Batches on different
+ * contexts are independent, so one host thread per context keeps two batches in flight on the device: the seed stage of one (memory-bound) runs under
+ * the chain stage of the other (instruction-bound) - the all-reads pass of configs[2] takes 128 instead of 149 ms with two contexts.  Every batch,
+ * fetch, delivery and digest call works on a view; calls that change reads or index (hao_set_reads, hao_ft_gen, hao_pt_gen, ...) belong to the owner
+ * and return HAO_EINVAL on a view.  A view follows the owner's rebuilds by itself (it takes the owner's buffers again at its next batch); as with the
+ * owner's own batches, no batch may run while the owner rebuilds, and views are destroyed (hao_destroy) before their owner. */
+int hao_attach(hao_ctx *owner, hao_ctx **view);
+
 /* ---- streaming result delivery: results of batch i cross PCIe while batch i + 1 computes ----
  * h_ec_lchain hands ol->list and cl->list back to a per-read caller (anchor.cpp:2302; consumed by gen_hc_r_alin_ea, ecovlp.cpp:3288).  A batch's
  * results are ~190 KB per 15 kb read, almost all of it cl->list (16 bytes per chained hit), more than PCIe can carry at the rate the device produces
