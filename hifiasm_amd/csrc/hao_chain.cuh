@@ -381,18 +381,14 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 		if (act) { if (b == 0) { maxf0 = max(maxf0, f); ddt0 += dd; } else { maxf1 = max(maxf1, f); ddt1 += dd; } }
 		k1 += __popcll(__ballot(act && b == 0));
 		// strand of the next hit: next lane, or lane 0 of the tile already on its way
-		uint32_t nw0 = __shfl_down(h.w0, 1); if (lane == 63) nw0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hn.w0);
+		const uint32_t nw0 = hao_wave_shl1(h.w0, (uint32_t)__builtin_amdgcn_readfirstlane((int)hn.w0));
 		const bool isend = act && (idx == a_n - 1 || (nw0 >> 31) != HH_STRAND(h));
 		unsigned long long m0 = __ballot(isend && b == 0), m1 = __ballot(isend && b == 1);
 		if (m0) { int src = __ffsll((long long)m0) - 1; flast0 = hao_bcast(f, src); last0 = hao_shfl_hit(h, src); }
 		if (m1) { int src = __ffsll((long long)m1) - 1; flast1 = hao_bcast(f, src); last1 = hao_shfl_hit(h, src); }
 		carry_f = hao_bcast(f, 63); carry_h = hao_shfl_hit(h, 63);
 	}
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1) {
-		maxf0 = max(maxf0, __shfl_xor(maxf0, d)); maxf1 = max(maxf1, __shfl_xor(maxf1, d));
-		ddt0 += __shfl_xor(ddt0, d); ddt1 += __shfl_xor(ddt1, d);
-	}
+	maxf0 = hao_wave_max_i32(maxf0); maxf1 = hao_wave_max_i32(maxf1); ddt0 = hao_wave_sum_i64(ddt0); ddt1 = hao_wave_sum_i64(ddt1);
 	const unsigned long long tq2 = A.dbg_qc ? wall_clock64() + (unsigned long long)(maxf0 & 0) : 0;
 	const bool two = k1 < a_n;
 	const hao_hit_t first1 = two ? a[k1] : first0;
@@ -581,11 +577,7 @@ __device__ __forceinline__ void hao_dp_body(const hao_chain_args &A, const hao_g
 		if (m1) { int src = __ffsll((long long)m1) - 1; flast1 = hao_bcast(fv, src); last1 = hao_shfl_hit(h, src); }
 		carry_f = hao_bcast(fv, 63); carry_h = hao_shfl_hit(h, 63);
 	}
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1) {
-		maxf0 = max(maxf0, __shfl_xor(maxf0, d)); maxf1 = max(maxf1, __shfl_xor(maxf1, d));
-		ddt0 += __shfl_xor(ddt0, d); ddt1 += __shfl_xor(ddt1, d);
-	}
+	maxf0 = hao_wave_max_i32(maxf0); maxf1 = hao_wave_max_i32(maxf1); ddt0 = hao_wave_sum_i64(ddt0); ddt1 = hao_wave_sum_i64(ddt1);
 	const bool two = k1 < a_n;
 	const hao_hit_t first0 = a[0], first1 = two ? a[k1] : a[0];
 	const bool acc0 = !fail0 && flast0 == maxf0 && !(k1 >= 2 && ddt0 > 16 && ddt0 > hao_band(last0, first0, P));
@@ -1539,9 +1531,7 @@ __global__ __launch_bounds__(256) void chain_final_kernel(const hao_ovlp_t *ol, 
 		const uint64_t i = base + lane; const bool act = i < n;
 		hao_ovlp_t o; uint64_t fs = 0; uint32_t fl = 0;
 		if (act) { const uint64_t src = o0 + perm[o0 + i]; o = ol[src]; fs = ol_fc_off[src]; fl = o.fc_len; }
-		uint32_t inc = fl;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d); if (lane >= d) inc += y; }
+		const uint32_t inc = hao_wave_incl_scan_u32(fl);
 		const uint64_t fo = run + inc - fl;
 		if (act) {
 			o.align_length = 0; ol_out[d0 + i] = o; fc_out_off[d0 + i] = fo;
@@ -1553,6 +1543,6 @@ __global__ __launch_bounds__(256) void chain_final_kernel(const hao_ovlp_t *ol, 
 			const uint64_t cfs = hao_readlane_i64((int64_t)fs, l), cfo = hao_readlane_i64((int64_t)fo, l); const uint32_t cfl = hao_bcast(fl, l);
 			for (uint32_t j = lane; j < cfl; j += 64) fc_out[cfo + j] = fc_raw[cfs + j];
 		}
-		run += __shfl(inc, 63);
+		run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
 	}
 }

@@ -66,4 +66,30 @@ __device__ __forceinline__ void hao_seg_scan_add(int32_t &x, int &fl)
 #undef HAO_SEG_STEP
 }
 
+// wave-wide reductions on the DPP path (the result is uniform): inclusive scan steps, total in lane 63
+__device__ __forceinline__ int32_t hao_wave_max_i32(int32_t v)
+{
+#define HAO_RED_STEP(CTRL, RM) v = max(v, hao_dpp<CTRL, RM>(INT32_MIN, v));
+	HAO_RED_STEP(0x111, 0xf) HAO_RED_STEP(0x112, 0xf) HAO_RED_STEP(0x114, 0xf) HAO_RED_STEP(0x118, 0xf) HAO_RED_STEP(0x142, 0xa) HAO_RED_STEP(0x143, 0xc)
+#undef HAO_RED_STEP
+	return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int64_t hao_wave_sum_i64(int64_t v)
+{
+#define HAO_RED_STEP(CTRL, RM) { const uint32_t lo2 = (uint32_t)hao_dpp<CTRL, RM>(0, (int)(uint32_t)v), hi2 = (uint32_t)hao_dpp<CTRL, RM>(0, (int)(uint32_t)((uint64_t)v >> 32)); v += (int64_t)((uint64_t)hi2 << 32 | lo2); }
+	HAO_RED_STEP(0x111, 0xf) HAO_RED_STEP(0x112, 0xf) HAO_RED_STEP(0x114, 0xf) HAO_RED_STEP(0x118, 0xf) HAO_RED_STEP(0x142, 0xa) HAO_RED_STEP(0x143, 0xc)
+#undef HAO_RED_STEP
+	return (int64_t)((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), 63) << 32 | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63));
+}
+// inclusive prefix sum over the wave (DPP)
+__device__ __forceinline__ uint32_t hao_wave_incl_scan_u32(uint32_t x)
+{
+#define HAO_RED_STEP(CTRL, RM) x += (uint32_t)hao_dpp<CTRL, RM>(0, (int)x);
+	HAO_RED_STEP(0x111, 0xf) HAO_RED_STEP(0x112, 0xf) HAO_RED_STEP(0x114, 0xf) HAO_RED_STEP(0x118, 0xf) HAO_RED_STEP(0x142, 0xa) HAO_RED_STEP(0x143, 0xc)
+#undef HAO_RED_STEP
+	return x;
+}
+// value of the next lane; lane 63 gets `fill` (DPP wave_shl:1)
+__device__ __forceinline__ uint32_t hao_wave_shl1(uint32_t v, uint32_t fill) { return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xf, 0xf, false); }
+
 #define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { hao_set_err(c, std::string(#expr) + ": " + hipGetErrorString(_e)); return HAO_ENODEV; } } while (0)

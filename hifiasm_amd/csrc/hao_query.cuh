@@ -254,8 +254,8 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 					// target of the previous / next entry of my list (0xffffffff: none): lane - 1 / lane + 1 hold them unless they belong to another
 					// minimizer (then I am the first / last entry of my list) or I sit at a tile edge (fetched above)
 					const uint32_t yt = hao_info_rid(y);
-					uint32_t t_up = hao_wave_shr1(yt, 0u), t_dn = (uint32_t)__shfl_down((int)yt, 1);             // cross-lane moves: all lanes, before any branch
-					const uint32_t q_up = hao_wave_shr1(q, 0xffffffffu), q_dn = (uint32_t)__shfl_down((int)q, 1);
+					uint32_t t_up = hao_wave_shr1(yt, 0u), t_dn = hao_wave_shl1(yt, 0u);             // cross-lane moves (DPP): all lanes, before any branch
+					const uint32_t q_up = hao_wave_shr1(q, 0xffffffffu), q_dn = hao_wave_shl1(q, 0xffffffffu);
 					if (lane == 0) t_up = ype[u] == ~0ULL ? 0xffffffffu : hao_info_rid(ype[u]);
 					else if (q_up != q) t_up = 0xffffffffu;
 					if (lane == 63 || x + 1 >= n) t_dn = yne[u] == ~0ULL ? 0xffffffffu : hao_info_rid(yne[u]);
@@ -294,9 +294,7 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 #pragma unroll
 					for (int w = 0; w < 4; ++w) { c_[k][w] = wc[w * CAP + tid * SPT + k]; mine_t += c_[k][w]; }
 				}
-				uint32_t inc_t = mine_t;
-#pragma unroll
-				for (int dl = 1; dl < 64; dl <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)inc_t, dl); if (lane >= dl) inc_t += y; }
+				const uint32_t inc_t = hao_wave_incl_scan_u32(mine_t);
 				if (lane == 63) s_wt[wv] = inc_t;
 				__syncthreads();
 				uint32_t ex_t = inc_t - mine_t; for (int x = 0; x < wv; ++x) ex_t += s_wt[x];
