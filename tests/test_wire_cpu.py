@@ -1,0 +1,94 @@
+"""The decoder of the delivery wire format (hao_unpack_hits, include/hao.h) is a pure host function of a delivered view: here the view is built by a
+Python encoder written from the format's description (one bit per hit, rank directory, code bytes, sorted exception list) and must decode back to
+the k_mer_hits it was made from.  No GPU involved: the device-side encoder is checked against the oracle by tests/test_gpu_stream.py."""
+import ctypes as C
+
+import numpy as np
+
+from hifiasm_amd import api
+
+
+def _encode(reads, rid_lo=7):
+    """reads: list of (qmz [(self_offset, cnt)], chains [(w0, [(q, offset), ...])]) -> (Delivery, keep-alive list, expected hits per read)"""
+    ch_off, cl_off, qm_off = [0], [0], [0]
+    hdr, qmz, codes, exc, flags, want = [], [], [], [], [], []
+    h = 0
+    for qt, chains in reads:
+        exp = []
+        for w0, hits in chains:
+            q0, o0 = hits[0]
+            hdr.append((len(hits), w0, q0, o0))
+            for i, (q, off) in enumerate(hits):
+                exp.append((w0, off, qt[q][0], qt[q][1]))
+                if i == 0:
+                    flags.append(0)
+                else:
+                    pq, po = hits[i - 1]
+                    dq, dd = q - pq, (off - po) - (qt[q][0] - qt[pq][0])
+                    if 1 <= dq <= 15 and -8 <= dd <= 7:
+                        code = (dq - 1) << 4 | (dd + 8)
+                    else:
+                        code = 0xff
+                        exc.append((h, q, (w0, off, qt[q][0], qt[q][1])))
+                    if code == 0x08:
+                        flags.append(0)
+                    else:
+                        flags.append(1); codes.append(code)
+                h += 1
+        want.append(np.array(exp, dtype=np.uint32).reshape(-1, 4))
+        qmz.extend(qt)
+        ch_off.append(len(hdr)); cl_off.append(h); qm_off.append(len(qmz))
+    nw = (h + 63) // 64
+    fl = np.zeros(nw * 64, dtype=np.uint8); fl[:h] = flags
+    bits = np.zeros(max(1, nw), dtype=np.uint64)
+    for w in range(nw):
+        bits[w] = sum(int(fl[64 * w + b]) << b for b in range(64))
+    rank = np.zeros(nw + 1, dtype=np.uint32)
+    rank[1:] = np.cumsum(fl.reshape(-1, 64).sum(axis=1)) if nw else 0
+    a_hdr = np.array(hdr, dtype=np.uint32).reshape(-1, 4)
+    a_qmz = np.array(qmz, dtype=np.uint32).reshape(-1, 2)
+    a_codes = np.array(codes + [0], dtype=np.uint8)
+    a_exc = np.zeros(max(1, len(exc)), dtype=[("index", "<u8"), ("q", "<u4"), ("pad", "<u4"), ("hit", "<u4", 4)])
+    for i, (idx, q, hit) in enumerate(exc):
+        a_exc[i] = (idx, q, 0, hit)
+    arrs = [np.array(x, dtype=np.uint64) for x in (ch_off, cl_off, qm_off)] + [a_hdr, a_qmz, bits, rank, a_codes, a_exc]
+    d = api.Delivery()
+    d.rid_lo, d.n_reads, d.n_chains, d.n_cl, d.n_exc, d.n_codes = rid_lo, len(reads), len(hdr), h, len(exc), len(codes)
+    d.ch_off, d.cl_off, d.qm_off = (a.ctypes.data for a in arrs[:3])
+    d.chains, d.qmz, d.cl_bits, d.cl_rank, d.cl_codes, d.cl_exc = (a.ctypes.data for a in arrs[3:])
+    return d, arrs, want
+
+
+def test_decoder_inverts_the_format():
+    rng = np.random.default_rng(5)
+    reads = []
+    for r in range(9):
+        nq = int(rng.integers(40, 400))
+        pos = np.cumsum(rng.integers(1, 90, nq)).astype(np.int64) + 50
+        qt = [(int(p), int(rng.integers(1, 5)) << 8 | int(rng.integers(20, 120))) for p in pos]
+        chains = []
+        for c in range(int(rng.integers(0, 7))):
+            n = int(rng.integers(1, 150)); q = int(rng.integers(0, 10)); off = int(rng.integers(1000, 50000)); hits = []
+            for i in range(n):
+                if q >= nq:
+                    break
+                hits.append((q, off))
+                step = 1 if rng.random() < 0.85 else int(rng.integers(2, 22))            # beyond 15 minimizers: an exception
+                nq_ = q + step
+                if nq_ < nq:
+                    shift = 0 if rng.random() < 0.8 else int(rng.integers(-12, 12))      # beyond -8 .. 7: an exception
+                    off = off + (qt[nq_][0] - qt[q][0]) + shift
+                q = nq_
+            if hits:
+                chains.append((int(rng.integers(0, 1 << 31)) | (int(rng.integers(0, 2)) << 31), hits))
+        reads.append((qt, chains))
+    reads.append(([(10, 300)], []))                                                   # a read without chains
+    d, keep, want = _encode(reads)
+    L = api.lib()
+    assert d.n_exc > 0 and d.n_codes > d.n_exc
+    for r, exp in enumerate(want):
+        out = np.zeros((exp.shape[0] + 1, 4), dtype=np.uint32)
+        assert L.hao_unpack_hits(C.byref(d), d.rid_lo + r, out.ctypes.data_as(C.c_void_p), 0) == exp.shape[0]      # cap too small: the count only
+        got = L.hao_unpack_hits(C.byref(d), d.rid_lo + r, out.ctypes.data_as(C.c_void_p), exp.shape[0])
+        assert got == exp.shape[0] and (out[:got] == exp).all(), f"read {r}"
+    assert L.hao_unpack_hits(C.byref(d), d.rid_lo + len(want), None, 0) == 0                                    # not a read of the batch
