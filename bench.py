@@ -131,7 +131,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="chr1_250M_hifi30x", choices=list(WORKLOADS))
-    ap.add_argument("--batch-reads", type=int, default=0, help="query reads per hao_overlap_batch (0 = sized for ~4e8 seed hits)")
+    ap.add_argument("--batch-reads", type=int, default=0, help="query reads per hao_overlap_batch (0 = sized for ~8e8 seed hits)")
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "none"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-boundary", action="store_true", help="skip the boundary-inclusive (results delivered to host memory) measurement")
@@ -181,8 +181,10 @@ def main():
     hom_ft = eng.ha_ft_gen()
     t_ft = time.time() - t0
     n_reads = rs.n
-    # hao_overlap_batch handles < 2^32 seed hits per call and needs ~100 B of device scratch per seed hit: keep a batch near 4e8 hits (~40 GB)
-    auto_bsz = max(1, int(4e8 // max(1.0, 0.83 * rs.total_bases / max(1, n_reads) * WORKLOADS[a.workload][1] / 30.0)))
+    # hao_overlap_batch handles < 2^32 seed hits per call and needs ~130 B of device scratch per seed hit: a batch of ~8e8 hits (~110 GB with the index;
+    # 62 500 reads of configs[2]).  Bigger batches amortise the tails of the per-batch kernels and of the DP side streams (configs[2]: 16 batches 226 ms,
+    # 8 batches 214 ms, 4 batches 209 ms per step at 200 GB)
+    auto_bsz = max(1, int(8e8 // max(1.0, 0.83 * rs.total_bases / max(1, n_reads) * WORKLOADS[a.workload][1] / 30.0)))
     bsz = a.batch_reads if a.batch_reads > 0 else min(n_reads, auto_bsz)
     ranges = [(lo, min(n_reads, lo + bsz)) for lo in range(0, n_reads, bsz)]
 
