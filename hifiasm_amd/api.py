@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "hao_ft_cnt", "hao_pt_get", "hao_ft_table", "hao_pt_table", "hao_hist", "hao_stats", "hao_sketch_batch",
     "hao_fetch_sketch", "hao_overlap_batch", "hao_fetch_seed_hits", "hao_fetch_overlaps", "hao_batch_totals",
     "hao_stage_times", "hao_pass_default", "hao_overlap_batch_ex", "hao_set_shard", "hao_dist_unique_id", "hao_dist_init",
-    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits", "hao_exact_check", "hao_fetch_exact", "hao_window_ed_batch", "hao_index_save", "hao_attach",
+    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits", "hao_exact_check", "hao_fetch_exact", "hao_window_ed_batch", "hao_index_save", "hao_attach", "hao_window_trace_batch",
 ]
 
 
@@ -101,6 +101,7 @@ def lib():
         L.hao_deliver_wait.argtypes = [vp, C.c_int, C.POINTER(Delivery)]
         L.hao_exact_check.argtypes = [vp]
         L.hao_window_ed_batch.argtypes = [vp, vp, C.c_uint64, vp]
+        L.hao_window_trace_batch.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint32]
         L.hao_index_save.argtypes = [vp, C.c_char_p, C.c_int32, vp]
         L.hao_fetch_exact.argtypes = [vp, C.c_uint64, C.POINTER(vp), u64p]
         L.hao_unpack_hits.argtypes = [C.POINTER(Delivery), C.c_uint64, vp, C.c_uint64]; L.hao_unpack_hits.restype = C.c_uint64
@@ -315,6 +316,14 @@ class Engine:
     def index_save(self, prefix, number_of_round=3):
         """write <prefix>.pt_flt / .pt_flt.bin / .pt_flt.paf.bin in the reference's resume format (write_pt_index, htab.cpp:1367)"""
         self._ck(self.L.hao_index_save(self.h, prefix.encode(), number_of_round, None), "hao_index_save")
+
+    def window_trace_batch(self, tasks, cap=80):
+        """tasks: uint32 [n,10] -> (int32 [n,6] (err, ps, pe, ts, te, cigar entries), uint16 [n,cap] cigars): global alignment in the band with traceback"""
+        t = np.ascontiguousarray(tasks, dtype=np.uint32).reshape(-1, 10)
+        out = np.zeros((t.shape[0], 6), dtype=np.int32); cig = np.zeros((t.shape[0], cap), dtype=np.uint16)
+        self._ck(self.L.hao_window_trace_batch(self.h, t.ctypes.data_as(C.c_void_p), t.shape[0], out.ctypes.data_as(C.c_void_p), cig.ctypes.data_as(C.c_void_p), cap),
+                 "hao_window_trace_batch")
+        return out, cig
 
     def window_ed_batch(self, tasks):
         """tasks: uint32 [n,10] (p_rid, p_pos, p_len, p_rev, t_rid, t_pos, t_len, t_rev, thre, abs_diag) -> int32 [n,2] (err, pe)"""

@@ -72,3 +72,86 @@ __global__ __launch_bounds__(256) void hao_window_ed_kernel(hao_ed_reads R, cons
 	}
 	out[i_] = res;
 }
+
+// ---------------------------------------------------------------------------------------
+// f3, second variant: global alignment inside the band with traceback - ed_band_cal_global_64_w_trace (Levenshtein_distance.h:3370-3442) on a cleared
+// bit_extz_t followed by gen_trace(ez, thre, 1) (:903-985).  Pattern and text are consumed entirely (|pn - tn| <= thre).  The forward sweep keeps the
+// five words of every text column (D0, VP, VN, HP, HN: 40 bytes per base and pair) in a scratch array laid out [column][word][pair], so that the lanes of
+// a wave - one pair each - write and read consecutive addresses; the traceback walks the columns backwards (indels preferred, :924-936) and emits
+// push_trace's entries (op << 14 | len; 0 match, 1 mismatch, 2 more pattern, 3 more text), reversed at the end like the reference does.
+// `path` holds `stride` pairs per row; pair i of the launch uses row slot i.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void hao_tr_push(uint16_t *cg, uint32_t cap, int32_t &n, int32_t op, int32_t len)
+{	// push_trace (:522-531); entries past the capacity are counted only
+	while (len >= 0x3fff) { if ((uint32_t)n < cap) cg[n] = (uint16_t)((op << 14) + 0x3fff); ++n; len -= 0x3fff; }
+	if (len) { if ((uint32_t)n < cap) cg[n] = (uint16_t)((op << 14) + len); ++n; }
+}
+
+__global__ __launch_bounds__(256) void hao_window_trace_kernel(hao_ed_reads R, const hao_ed_task_t *task, uint64_t n_task, uint64_t *path, uint64_t stride,
+		hao_trace_result_t *out, uint16_t *cig, uint32_t cap)
+{
+	const uint64_t i_ = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i_ >= n_task) return;
+	const hao_ed_task_t T = task[i_];
+	const uint8_t *pd = R.packed + R.pk_off[T.p_rid], *td = R.packed + R.pk_off[T.t_rid]; const uint32_t pL = R.len[T.p_rid], tL = R.len[T.t_rid];
+	const int32_t pn = (int32_t)T.p_len, tn = (int32_t)T.t_len, thre = (int32_t)T.thre;
+	hao_trace_result_t res; res.err = INT32_MAX; res.ps = 0; res.pe = -1; res.ts = 0; res.te = -1; res.n_cigar = 0;
+	auto P = [&](int32_t k) { return hao_ed_base(R, T.p_rid, pd, pL, (int64_t)T.p_pos + k, T.p_rev); };
+	auto Tx = [&](int32_t k) { return hao_ed_base(R, T.t_rid, td, tL, (int64_t)T.t_pos + k, T.t_rev); };
+	if (pn <= 0 || tn <= 0 || pn > tn + thre || tn > pn + thre) { out[i_] = res; return; }
+	uint64_t *col = path + i_;      // column i, word k: col[(5 i + k) * stride]
+	const int32_t tn0 = tn - 1, cut = thre + (thre << 1);
+	uint64_t Peq[5] = {0, 0, 0, 0, 0}, VP, VN, X, D0, HN, HP, mm;
+	int32_t bd = thre + 1; if (bd > pn) bd = pn;
+	int32_t i, i_bd = thre, err = thre;
+	for (i = 0, mm = 1ULL << thre; i < bd; ++i) { Peq[P(i)] |= mm; mm <<= 1; }
+	Peq[4] = 0;
+	VN = (1ULL << thre) - 1; VP = ((1ULL << ((thre << 1) + 1)) - 1) ^ VN;
+	mm = 1ULL << (thre << 1);
+#define HAO_ED_CORE(z) { X = Peq[(z)] | VN; D0 = ((VP + (X & VP)) ^ VP) | X; HN = VP & D0; HP = VN | ~(VP | D0); X = D0 >> 1; VN = X & HP; VP = HN | ~(X | HP); }
+#define HAO_ED_KEEP() { uint64_t *w_ = col + 5 * (uint64_t)i * stride; w_[0] = D0; w_[stride] = VP; w_[2 * stride] = VN; w_[3 * stride] = HP; w_[4 * stride] = HN; }
+	bool dead = false;
+	for (i = 0; i < tn0; ) {
+		HAO_ED_CORE(Tx(i));
+		if (!(D0 & 1ULL)) { ++err; if (err > cut) { dead = true; break; } }
+		Peq[0] >>= 1; Peq[1] >>= 1; Peq[2] >>= 1; Peq[3] >>= 1;
+		HAO_ED_KEEP();
+		++i; ++i_bd;
+		if (i_bd < pn) { const uint32_t cc = P(i_bd); if (cc < 4) Peq[cc] |= mm; }
+	}
+	if (!dead) {
+		HAO_ED_CORE(Tx(i));
+		if (!(D0 & 1ULL)) { ++err; if (err > cut) dead = true; }
+	}
+	if (dead) { out[i_] = res; return; }
+	HAO_ED_KEEP();
+#undef HAO_ED_CORE
+#undef HAO_ED_KEEP
+	int32_t site = tn - 1 - thre;
+	for (; site < pn - 1; ++site) { err += (int32_t)(VP & 1ULL); VP >>= 1; err -= (int32_t)(VN & 1ULL); VN >>= 1; }
+	if (!(site == pn - 1 && err <= thre)) { out[i_] = res; return; }
+	res.err = err; res.pe = pn - 1; res.te = tn - 1;
+	// gen_trace(ez, ptrim = thre, reverse = 1) with ts = 0, te = tn - 1, ps = 0
+	uint16_t *cg = cig + i_ * cap; int32_t ncg = 0;
+	const int32_t low = thre << 1; int32_t sft = thre + pn - tn, poff = pn - 1, cur = err, d = 0, pdir = -1, pdn = 0;
+	i = tn;
+	while (i > 0 && cur > 0) {
+		const uint64_t *w_ = col + 5 * (uint64_t)(i - 1) * stride;
+		int32_t wm = sft & 63;
+		const int32_t D = cur - (int32_t)((~(w_[0] >> wm)) & 1ULL); int32_t mn = D; d = 0;
+		if (sft != low) { const int32_t H = cur + (int32_t)((w_[4 * stride] >> wm) & 1ULL) - (int32_t)((w_[3 * stride] >> wm) & 1ULL); if (H + 1 == cur && H <= mn) { mn = H; d = 3; } }
+		if (sft != 0) { wm = (sft - 1) & 63; const int32_t V = cur + (int32_t)((w_[2 * stride] >> wm) & 1ULL) - (int32_t)((w_[stride] >> wm) & 1ULL); if (V + 1 == cur && V <= mn) { mn = V; d = 2; } }
+		if (d == 0) { if (D != cur) d = 1; --i; --poff; }
+		else if (d == 2) { --sft; --poff; }
+		else { --i; ++sft; }
+		if (d == pdir) ++pdn; else { if (pdn > 0) hao_tr_push(cg, cap, ncg, pdir, pdn); pdir = d; pdn = 1; }
+		cur = mn;
+	}
+	if (i > 0) { d = 0; poff -= i; if (d == pdir) pdn += i; else { if (pdn > 0) hao_tr_push(cg, cap, ncg, pdir, pdn); pdir = d; pdn = i; } }
+	++poff;
+	if (poff > 0) { d = 2; if (d == pdir) pdn += poff; else { if (pdn > 0) hao_tr_push(cg, cap, ncg, pdir, pdn); pdir = d; pdn = poff; } }
+	if (pdn > 0) hao_tr_push(cg, cap, ncg, pdir, pdn);
+	if ((uint32_t)ncg <= cap) for (int32_t k = 0; k < ncg / 2; ++k) { const uint16_t x_ = cg[k]; cg[k] = cg[ncg - 1 - k]; cg[ncg - 1 - k] = x_; }
+	res.n_cigar = ncg;
+	out[i_] = res;
+}

@@ -211,6 +211,38 @@ int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks
 	return HAO_OK;
 }
 
+int hao_window_trace_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks, hao_trace_result_t *out, uint16_t *cigars, uint32_t cigar_cap)
+{
+	if (!c || (!tasks && n_tasks) || (!out && n_tasks) || (!cigars && n_tasks && cigar_cap)) return HAO_EINVAL;
+	if (int rc = hao_view_refresh(c)) return rc;
+	if (c->comm && c->comm->active()) { hao_set_err(c, "hao_window_trace_batch needs the bases of both reads: single-device mode only"); return HAO_EUNSUPP; }
+	if (n_tasks == 0) return HAO_OK;
+	uint64_t tn_max = 1;
+	for (uint64_t i = 0; i < n_tasks; ++i) {      // the reference indexes its strings unchecked; a device kernel must not
+		const hao_ed_task_t &t = tasks[i];
+		if (t.p_rid >= c->n_reads || t.t_rid >= c->n_reads || (uint64_t)t.p_pos + t.p_len > c->h_len[t.p_rid] || (uint64_t)t.t_pos + t.t_len > c->h_len[t.t_rid] ||
+			2 * (uint64_t)t.thre + 1 > 63) { hao_set_err(c, "hao_window_trace_batch: task " + std::to_string(i) + " out of range"); return HAO_EINVAL; }
+		if (t.t_len > tn_max) tn_max = t.t_len;
+	}
+	HIP_TRY(hipSetDevice(c->device));
+	// the forward sweep keeps 40 bytes per text base and pair: the tasks go through in slices whose columns fit ~4 GB
+	const uint64_t slice = std::max<uint64_t>(256, std::min<uint64_t>(n_tasks, (4ULL << 30) / (40 * tn_max)) & ~255ULL);
+	DevBuf<hao_ed_task_t> dt; DevBuf<hao_trace_result_t> dr; DevBuf<uint16_t> dc; DevBuf<uint64_t> path;
+	HIP_TRY(dt.reserve(slice)); HIP_TRY(dr.reserve(slice)); HIP_TRY(dc.reserve(slice * (uint64_t)cigar_cap + 1)); HIP_TRY(path.reserve(5 * tn_max * slice + 1));
+	hao_ed_reads R; R.packed = c->d_packed.p; R.pk_off = c->d_pk_off.p; R.len = c->d_len.p; R.nsite_off = c->has_n ? c->d_nsite_off.p : nullptr; R.nsite = c->has_n ? c->d_nsite.p : nullptr;
+	for (uint64_t lo = 0; lo < n_tasks; lo += slice) {
+		const uint64_t m = std::min<uint64_t>(slice, n_tasks - lo);
+		HIP_TRY(hipMemcpyAsync(dt.p, tasks + lo, m * sizeof(hao_ed_task_t), hipMemcpyHostToDevice, c->stream));
+		hipLaunchKernelGGL(hao_window_trace_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, R, dt.p, m, path.p, slice, dr.p, dc.p, cigar_cap);
+		HAO_CHECK_LAUNCH();
+		HIP_TRY(hipMemcpyAsync(out + lo, dr.p, m * sizeof(hao_trace_result_t), hipMemcpyDeviceToHost, c->stream));
+		if (cigar_cap) HIP_TRY(hipMemcpyAsync(cigars + lo * cigar_cap, dc.p, m * (uint64_t)cigar_cap * 2, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+	}
+	dt.release(); dr.release(); dc.release(); path.release();
+	return HAO_OK;
+}
+
 int hao_exact_check(hao_ctx *c)
 {
 	if (!c || !c->batch || !c->batch->valid) return HAO_EINVAL;

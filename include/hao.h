@@ -217,6 +217,15 @@ typedef struct { uint32_t p_rid, p_pos, p_len, p_rev, t_rid, t_pos, t_len, t_rev
 typedef struct { int32_t err, pe; } hao_ed_result_t;
 int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks, hao_ed_result_t *out);
 
+/* Second variant: global alignment inside the band WITH traceback - ed_band_cal_global_64_w_trace (Levenshtein_distance.h:3370-3442) on a
+ * cleared bit_extz_t followed by gen_trace(ez, thre, 1) (:903-985), the call cal_exz_global / Correct.cpp:14537 make once a window's end points are fixed.
+ * Same task records (abs_diag is ignored); both strings are consumed entirely, so |p_len - t_len| <= thre or there is no alignment.  Per task: err
+ * (INT32_MAX = none within thre; then pe = te = -1 and no cigar), ps = ts = 0, pe = p_len - 1, te = t_len - 1, and the cigar in push_trace's encoding
+ * (uint16: op << 14 | len; op 0 match, 1 mismatch, 2 more pattern, 3 more text) at cigars + i * cigar_cap; n_cigar entries exist, those past cigar_cap
+ * are not written (an alignment within thre <= 31 has at most 2 thre + 3 entries for strings shorter than 16 383). */
+typedef struct { int32_t err, ps, pe, ts, te, n_cigar; } hao_trace_result_t;
+int hao_window_trace_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks, hao_trace_result_t *out, uint16_t *cigars, uint32_t cigar_cap);
+
 /* On-disk formats: the filter table, the position index and the read store in the reference's own resume format, so a GPU-built
  * index can be handed to a stock hifiasm (load_pt_index, htab.cpp:1432-1550, called from Assembly.cpp:2078):
  *   <prefix>.pt_flt  (write_pt_index, htab.cpp:1367-1430),  <prefix>.pt_flt.bin  (write_All_reads, Process_Read.cpp:69-125 - the layout of *.ec.bin),

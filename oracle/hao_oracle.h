@@ -96,6 +96,9 @@ void hao_or_exact(const hao_or_ctx *c, const hao_or_ovlp_t *ol, int64_t n, uint8
  * (read t_rid, [t_pos, t_pos + t_len) on strand t_rev) against the pattern (read p_rid, [p_pos, p_pos + p_len) on strand p_rev), threshold thre,
  * abs_diag leading diagonals absent.  task = 10 uint32 in that order (+ thre, abs_diag); out[0] = err (INT32_MAX: none), out[1] = pe (-1: none). */
 void hao_or_window_ed(const hao_or_ctx *c, const uint32_t *task, int64_t n, int32_t *out);
+/* f3, global alignment with traceback (ed_band_cal_global_64_w_trace + gen_trace, Levenshtein_distance.h:3370,903): out[n][6] = err, ps, pe, ts, te, cigar
+ * entries; cigar q at cig + q * cap */
+void hao_or_window_trace(const hao_or_ctx *c, const uint32_t *task, int64_t n, int32_t *out, uint16_t *cig, int64_t cap);
 
 /* ha_analyze_count (hist.cpp:74-157) with m_peak_hom <= 0 (hg_size unset) / with the prior m_peak_hom (adj_m_peak_hom, hist.cpp:46-72) */
 int hao_or_analyze_count(int n_cnt, int start_cnt, const int64_t *cnt, int *peak_het);

@@ -129,3 +129,44 @@ def ed_tasks(name, n_reads=24, wl=775, seed=1):
         out.append((a, int(rng.integers(0, L[a] - pn + 1)), pn, int(rng.integers(0, 2)), b, int(rng.integers(0, L[b] - tn + 1)), tn, int(rng.integers(0, 2)),
                     thre, int(rng.integers(0, 2 * thre + 1))))
     return np.array(out, dtype=np.uint32)
+
+
+def ed_global_tasks(name, n_reads=24, wl=775, seed=2):
+    """(pattern, text) pairs for the GLOBAL window alignment with traceback (ed_band_cal_global_64_w_trace): query windows of the overlaps against the
+    target interval on the overlap's diagonal (same length up to a few bases), plus unrelated / tiny / too-different pairs.  Same record layout as
+    ed_tasks (abs_diag = 0)."""
+    rs, okw = scenario_reads(name)
+    o = scenario_oracle(name)
+    rng = np.random.default_rng(seed)
+    out = []
+    L = rs.lengths.astype(np.int64)
+    for r in rng.choice(rs.n, size=min(n_reads, rs.n), replace=False):
+        ol = o.lchain(int(r))[0]
+        for z in ol[:: max(1, ol.shape[0] // 12)]:
+            xs, xe, yid, ys, ye, yrev = int(z[1]), int(z[2]), int(z[4]), int(z[5]), int(z[6]), int(z[7])
+            tl = int(L[yid])
+            for ws in range(xs, xe + 1, wl):
+                tn = min(wl, xe + 1 - ws)
+                thre = int(rng.choice([0, 3, 8, 15, 24, 31]))
+                p0 = max(0, ys + (ws - xs) + int(rng.integers(-2, 3)))
+                p1 = min(tl, p0 + tn + int(rng.integers(-3, 4)))
+                if p1 <= p0 or tn <= 0:
+                    continue
+                out.append((yid, p0, p1 - p0, yrev, int(r), ws, tn, 0, thre, 0))
+    for _ in range(300):
+        a, b = (int(x) for x in rng.integers(0, rs.n, 2))
+        if L[a] < 2 or L[b] < 2:
+            continue
+        tn = int(rng.integers(1, min(400, int(L[b])) + 1))
+        thre = int(rng.choice([0, 1, 5, 15, 31]))
+        pn = max(1, min(int(L[a]), tn + int(rng.integers(-thre - 2, thre + 3))))
+        out.append((a, int(rng.integers(0, L[a] - pn + 1)), pn, int(rng.integers(0, 2)), b, int(rng.integers(0, L[b] - tn + 1)), tn, int(rng.integers(0, 2)), thre, 0))
+    for a in range(min(rs.n, 40)):      # a read against itself and against its neighbourhood: exact and near-exact pairs, short strings
+        if L[a] < 40:
+            continue
+        n_ = int(rng.integers(1, 40)); p_ = int(rng.integers(0, L[a] - n_ + 1)); thre = int(rng.choice([0, 2, 7]))
+        out.append((a, p_, n_, 0, a, p_, n_, 0, thre, 0))
+        out.append((a, p_, n_, 1, a, int(L[a]) - p_ - n_, n_, 1, thre, 0))
+        if p_ + n_ + 1 <= L[a]:
+            out.append((a, p_, n_ + 1, 0, a, p_, n_, 0, max(1, thre), 0))
+    return np.array(out, dtype=np.uint32)
