@@ -101,7 +101,7 @@ def lib():
         L.hao_deliver_wait.argtypes = [vp, C.c_int, C.POINTER(Delivery)]
         L.hao_exact_check.argtypes = [vp]
         L.hao_window_ed_batch.argtypes = [vp, vp, C.c_uint64, vp]
-        L.hao_window_trace_batch.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint32]
+        L.hao_window_trace_batch.argtypes = [vp, C.c_int, vp, C.c_uint64, vp, vp, C.c_uint32]
         L.hao_index_save.argtypes = [vp, C.c_char_p, C.c_int32, vp]
         L.hao_fetch_exact.argtypes = [vp, C.c_uint64, C.POINTER(vp), u64p]
         L.hao_unpack_hits.argtypes = [C.POINTER(Delivery), C.c_uint64, vp, C.c_uint64]; L.hao_unpack_hits.restype = C.c_uint64
@@ -317,11 +317,12 @@ class Engine:
         """write <prefix>.pt_flt / .pt_flt.bin / .pt_flt.paf.bin in the reference's resume format (write_pt_index, htab.cpp:1367)"""
         self._ck(self.L.hao_index_save(self.h, prefix.encode(), number_of_round, None), "hao_index_save")
 
-    def window_trace_batch(self, tasks, cap=80):
-        """tasks: uint32 [n,10] -> (int32 [n,6] (err, ps, pe, ts, te, cigar entries), uint16 [n,cap] cigars): global alignment in the band with traceback"""
+    def window_trace_batch(self, tasks, cap=80, mode=0):
+        """tasks: uint32 [n,10] -> (int32 [n,6] (err, ps, pe, ts, te, cigar entries), uint16 [n,cap] cigars): alignment in the band with traceback;
+        mode 0 global (ed_band_cal_global_64_w_trace), 3 semi-global with absent diagonals (ed_band_cal_semi_64_w_absent_diag_trace)"""
         t = np.ascontiguousarray(tasks, dtype=np.uint32).reshape(-1, 10)
         out = np.zeros((t.shape[0], 6), dtype=np.int32); cig = np.zeros((t.shape[0], cap), dtype=np.uint16)
-        self._ck(self.L.hao_window_trace_batch(self.h, t.ctypes.data_as(C.c_void_p), t.shape[0], out.ctypes.data_as(C.c_void_p), cig.ctypes.data_as(C.c_void_p), cap),
+        self._ck(self.L.hao_window_trace_batch(self.h, mode, t.ctypes.data_as(C.c_void_p), t.shape[0], out.ctypes.data_as(C.c_void_p), cig.ctypes.data_as(C.c_void_p), cap),
                  "hao_window_trace_batch")
         return out, cig
 

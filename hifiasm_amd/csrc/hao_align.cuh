@@ -87,6 +87,7 @@ __device__ __forceinline__ void hao_tr_push(uint16_t *cg, uint32_t cap, int32_t 
 	if (len) { if ((uint32_t)n < cap) cg[n] = (uint16_t)((op << 14) + len); ++n; }
 }
 
+template<int MODE>      // 0: ed_band_cal_global_64_w_trace (:3370), 3: ed_band_cal_semi_64_w_absent_diag_trace (:3778) - the numbering of Correct.cpp:14536-14545
 __global__ __launch_bounds__(256) void hao_window_trace_kernel(hao_ed_reads R, const hao_ed_task_t *task, uint64_t n_task, uint64_t *path, uint64_t stride,
 		hao_trace_result_t *out, uint16_t *cig, uint32_t cap)
 {
@@ -94,20 +95,27 @@ __global__ __launch_bounds__(256) void hao_window_trace_kernel(hao_ed_reads R, c
 	if (i_ >= n_task) return;
 	const hao_ed_task_t T = task[i_];
 	const uint8_t *pd = R.packed + R.pk_off[T.p_rid], *td = R.packed + R.pk_off[T.t_rid]; const uint32_t pL = R.len[T.p_rid], tL = R.len[T.t_rid];
-	const int32_t pn = (int32_t)T.p_len, tn = (int32_t)T.t_len, thre = (int32_t)T.thre;
-	hao_trace_result_t res; res.err = INT32_MAX; res.ps = 0; res.pe = -1; res.ts = 0; res.te = -1; res.n_cigar = 0;
+	const int32_t pn = (int32_t)T.p_len, tn = (int32_t)T.t_len, thre = (int32_t)T.thre, abs_diag = MODE == 3 ? (int32_t)T.abs_diag : 0;
+	hao_trace_result_t res; res.err = INT32_MAX; res.ps = MODE == 3 ? -1 : 0; res.pe = -1; res.ts = 0; res.te = MODE == 3 ? tn - 1 : -1; res.n_cigar = 0;
 	auto P = [&](int32_t k) { return hao_ed_base(R, T.p_rid, pd, pL, (int64_t)T.p_pos + k, T.p_rev); };
 	auto Tx = [&](int32_t k) { return hao_ed_base(R, T.t_rid, td, tL, (int64_t)T.t_pos + k, T.t_rev); };
-	if (pn <= 0 || tn <= 0 || pn > tn + thre || tn > pn + thre) { out[i_] = res; return; }
-	uint64_t *col = path + i_;      // column i, word k: col[(5 i + k) * stride]
 	const int32_t tn0 = tn - 1, cut = thre + (thre << 1);
+	if (pn <= 0 || tn <= 0 || (MODE == 0 ? (pn > tn + thre || tn > pn + thre) : (pn > tn + cut || tn > pn + cut))) { out[i_] = res; return; }
+	uint64_t *col = path + i_;      // column i, word k: col[(5 i + k) * stride]
 	uint64_t Peq[5] = {0, 0, 0, 0, 0}, VP, VN, X, D0, HN, HP, mm;
-	int32_t bd = thre + 1; if (bd > pn) bd = pn;
-	int32_t i, i_bd = thre, err = thre;
-	for (i = 0, mm = 1ULL << thre; i < bd; ++i) { Peq[P(i)] |= mm; mm <<= 1; }
-	Peq[4] = 0;
-	VN = (1ULL << thre) - 1; VP = ((1ULL << ((thre << 1) + 1)) - 1) ^ VN;
-	mm = 1ULL << (thre << 1);
+	int32_t i, i_bd, err, bd;
+	if (MODE == 0) {
+		bd = thre + 1; if (bd > pn) bd = pn;
+		for (i = 0, mm = 1ULL << thre; i < bd; ++i) { Peq[P(i)] |= mm; mm <<= 1; }
+		i_bd = thre; err = thre;
+		VN = (1ULL << thre) - 1; VP = ((1ULL << ((thre << 1) + 1)) - 1) ^ VN;
+	} else {
+		bd = ((thre << 1) + 1) - abs_diag; if (bd > pn) bd = pn;
+		for (i = 0, mm = 1ULL << abs_diag; i < bd; ++i) { Peq[P(i)] |= mm; mm <<= 1; }
+		i_bd = (thre << 1) - abs_diag; err = abs_diag;
+		VP = 0; VN = (1ULL << abs_diag) - 1;
+	}
+	Peq[4] = 0; mm = 1ULL << (thre << 1);
 #define HAO_ED_CORE(z) { X = Peq[(z)] | VN; D0 = ((VP + (X & VP)) ^ VP) | X; HN = VP & D0; HP = VN | ~(VP | D0); X = D0 >> 1; VN = X & HP; VP = HN | ~(X | HP); }
 #define HAO_ED_KEEP() { uint64_t *w_ = col + 5 * (uint64_t)i * stride; w_[0] = D0; w_[stride] = VP; w_[2 * stride] = VN; w_[3 * stride] = HP; w_[4 * stride] = HN; }
 	bool dead = false;
@@ -117,7 +125,9 @@ __global__ __launch_bounds__(256) void hao_window_trace_kernel(hao_ed_reads R, c
 		Peq[0] >>= 1; Peq[1] >>= 1; Peq[2] >>= 1; Peq[3] >>= 1;
 		HAO_ED_KEEP();
 		++i; ++i_bd;
-		if (i_bd < pn) { const uint32_t cc = P(i_bd); if (cc < 4) Peq[cc] |= mm; }
+		uint32_t cc = 4;
+		if (i_bd < pn) cc = P(i_bd);
+		if (cc < 4) Peq[cc] |= mm;
 	}
 	if (!dead) {
 		HAO_ED_CORE(Tx(i));
@@ -127,13 +137,28 @@ __global__ __launch_bounds__(256) void hao_window_trace_kernel(hao_ed_reads R, c
 	HAO_ED_KEEP();
 #undef HAO_ED_CORE
 #undef HAO_ED_KEEP
-	int32_t site = tn - 1 - thre;
-	for (; site < pn - 1; ++site) { err += (int32_t)(VP & 1ULL); VP >>= 1; err -= (int32_t)(VN & 1ULL); VN >>= 1; }
-	if (!(site == pn - 1 && err <= thre)) { out[i_] = res; return; }
-	res.err = err; res.pe = pn - 1; res.te = tn - 1;
-	// gen_trace(ez, ptrim = thre, reverse = 1) with ts = 0, te = tn - 1, ps = 0
+	int32_t ez_err = INT32_MAX, pe = -1;
+	if (MODE == 0) {
+		int32_t site = tn - 1 - thre;
+		for (; site < pn - 1; ++site) { err += (int32_t)(VP & 1ULL); VP >>= 1; err -= (int32_t)(VN & 1ULL); VN >>= 1; }
+		if (site == pn - 1 && err <= thre) { ez_err = err; pe = pn - 1; }
+	} else {
+		int32_t site = tn - 1 - abs_diag; const int32_t ai = pn - tn + abs_diag; int32_t uge = INT32_MAX;
+		for (i = 0; site < 0 && i < ai; ++i, ++site) { err += (int32_t)((VP >> i) & 1ULL); err -= (int32_t)((VN >> i) & 1ULL); }
+		if (err <= thre && err <= ez_err) { ez_err = err; pe = site; }
+		site -= i;
+		while (i < ai) {
+			err += (int32_t)((VP >> i) & 1ULL); err -= (int32_t)((VN >> i) & 1ULL); ++i;
+			if (err <= thre && err <= ez_err) { ez_err = err; pe = site + i; }
+			if (i == thre) uge = err;
+		}
+		if (uge <= thre && uge == ez_err) pe = site + thre;
+	}
+	if (ez_err > thre) { out[i_] = res; return; }
+	res.err = ez_err; res.pe = pe; res.te = tn - 1;
+	// gen_trace(ez, ptrim, reverse = 1) with ts = 0, te = tn - 1; ptrim = thre (global: ps = 0 is known) / abs_diag (semi: ps comes out of the walk)
 	uint16_t *cg = cig + i_ * cap; int32_t ncg = 0;
-	const int32_t low = thre << 1; int32_t sft = thre + pn - tn, poff = pn - 1, cur = err, d = 0, pdir = -1, pdn = 0;
+	const int32_t low = thre << 1, ptrim = MODE == 0 ? thre : abs_diag; int32_t sft = (low + 1) - (tn + low - pe - ptrim), poff = pe, cur = ez_err, d = 0, pdir = -1, pdn = 0;
 	i = tn;
 	while (i > 0 && cur > 0) {
 		const uint64_t *w_ = col + 5 * (uint64_t)(i - 1) * stride;
@@ -149,7 +174,8 @@ __global__ __launch_bounds__(256) void hao_window_trace_kernel(hao_ed_reads R, c
 	}
 	if (i > 0) { d = 0; poff -= i; if (d == pdir) pdn += i; else { if (pdn > 0) hao_tr_push(cg, cap, ncg, pdir, pdn); pdir = d; pdn = i; } }
 	++poff;
-	if (poff > 0) { d = 2; if (d == pdir) pdn += poff; else { if (pdn > 0) hao_tr_push(cg, cap, ncg, pdir, pdn); pdir = d; pdn = poff; } }
+	if (MODE == 3) res.ps = poff;
+	else if (poff > 0) { d = 2; if (d == pdir) pdn += poff; else { if (pdn > 0) hao_tr_push(cg, cap, ncg, pdir, pdn); pdir = d; pdn = poff; } }
 	if (pdn > 0) hao_tr_push(cg, cap, ncg, pdir, pdn);
 	if ((uint32_t)ncg <= cap) for (int32_t k = 0; k < ncg / 2; ++k) { const uint16_t x_ = cg[k]; cg[k] = cg[ncg - 1 - k]; cg[ncg - 1 - k] = x_; }
 	res.n_cigar = ncg;

@@ -211,9 +211,9 @@ int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks
 	return HAO_OK;
 }
 
-int hao_window_trace_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks, hao_trace_result_t *out, uint16_t *cigars, uint32_t cigar_cap)
+int hao_window_trace_batch(hao_ctx *c, int mode, const hao_ed_task_t *tasks, uint64_t n_tasks, hao_trace_result_t *out, uint16_t *cigars, uint32_t cigar_cap)
 {
-	if (!c || (!tasks && n_tasks) || (!out && n_tasks) || (!cigars && n_tasks && cigar_cap)) return HAO_EINVAL;
+	if (!c || (mode != HAO_ALIGN_GLOBAL && mode != HAO_ALIGN_SEMI) || (!tasks && n_tasks) || (!out && n_tasks) || (!cigars && n_tasks && cigar_cap)) return HAO_EINVAL;
 	if (int rc = hao_view_refresh(c)) return rc;
 	if (c->comm && c->comm->active()) { hao_set_err(c, "hao_window_trace_batch needs the bases of both reads: single-device mode only"); return HAO_EUNSUPP; }
 	if (n_tasks == 0) return HAO_OK;
@@ -222,6 +222,10 @@ int hao_window_trace_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_ta
 		const hao_ed_task_t &t = tasks[i];
 		if (t.p_rid >= c->n_reads || t.t_rid >= c->n_reads || (uint64_t)t.p_pos + t.p_len > c->h_len[t.p_rid] || (uint64_t)t.t_pos + t.t_len > c->h_len[t.t_rid] ||
 			2 * (uint64_t)t.thre + 1 > 63) { hao_set_err(c, "hao_window_trace_batch: task " + std::to_string(i) + " out of range"); return HAO_EINVAL; }
+		if (mode == HAO_ALIGN_SEMI) {
+			const int64_t ai = (int64_t)t.p_len - (int64_t)t.t_len + (int64_t)t.abs_diag;
+			if (ai < 0 || ai > 2 * (int64_t)t.thre || t.t_len <= t.abs_diag) { hao_set_err(c, "hao_window_trace_batch: task " + std::to_string(i) + ": the band does not cover the pattern"); return HAO_EINVAL; }
+		}
 		if (t.t_len > tn_max) tn_max = t.t_len;
 	}
 	HIP_TRY(hipSetDevice(c->device));
@@ -233,7 +237,8 @@ int hao_window_trace_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_ta
 	for (uint64_t lo = 0; lo < n_tasks; lo += slice) {
 		const uint64_t m = std::min<uint64_t>(slice, n_tasks - lo);
 		HIP_TRY(hipMemcpyAsync(dt.p, tasks + lo, m * sizeof(hao_ed_task_t), hipMemcpyHostToDevice, c->stream));
-		hipLaunchKernelGGL(hao_window_trace_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, R, dt.p, m, path.p, slice, dr.p, dc.p, cigar_cap);
+		if (mode == HAO_ALIGN_SEMI) hipLaunchKernelGGL(hao_window_trace_kernel<3>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, R, dt.p, m, path.p, slice, dr.p, dc.p, cigar_cap);
+		else hipLaunchKernelGGL(hao_window_trace_kernel<0>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, R, dt.p, m, path.p, slice, dr.p, dc.p, cigar_cap);
 		HAO_CHECK_LAUNCH();
 		HIP_TRY(hipMemcpyAsync(out + lo, dr.p, m * sizeof(hao_trace_result_t), hipMemcpyDeviceToHost, c->stream));
 		if (cigar_cap) HIP_TRY(hipMemcpyAsync(cigars + lo * cigar_cap, dc.p, m * (uint64_t)cigar_cap * 2, hipMemcpyDeviceToHost, c->stream));

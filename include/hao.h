@@ -224,7 +224,12 @@ int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks
  * (uint16: op << 14 | len; op 0 match, 1 mismatch, 2 more pattern, 3 more text) at cigars + i * cigar_cap; n_cigar entries exist, those past cigar_cap
  * are not written (an alignment within thre <= 31 has at most 2 thre + 3 entries for strings shorter than 16 383). */
 typedef struct { int32_t err, ps, pe, ts, te, n_cigar; } hao_trace_result_t;
-int hao_window_trace_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks, hao_trace_result_t *out, uint16_t *cigars, uint32_t cigar_cap);
+#define HAO_ALIGN_GLOBAL 0      /* ed_band_cal_global_64_w_trace */
+#define HAO_ALIGN_SEMI 3        /* ed_band_cal_semi_64_w_absent_diag_trace (Levenshtein_distance.h:3778-3848): the traced twin of hao_window_ed_batch - the text is consumed, the
+                                 * pattern starts and ends inside the band: ps comes out of the walk, ts = 0, te = t_len - 1 (also without an alignment), abs_diag is used.
+                                 * The band must cover the pattern: 0 <= p_len - t_len + abs_diag <= 2 thre and t_len > abs_diag (else HAO_EINVAL: the reference's
+                                 * traceback would index its column words out of range).  (Numbering: the modes of Correct.cpp:14536-14545.) */
+int hao_window_trace_batch(hao_ctx *c, int mode, const hao_ed_task_t *tasks, uint64_t n_tasks, hao_trace_result_t *out, uint16_t *cigars, uint32_t cigar_cap);
 
 /* On-disk formats: the filter table, the position index and the read store in the reference's own resume format, so a GPU-built
  * index can be handed to a stock hifiasm (load_pt_index, htab.cpp:1432-1550, called from Assembly.cpp:2078):

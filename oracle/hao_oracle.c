@@ -1156,7 +1156,9 @@ void hao_or_window_ed(const hao_or_ctx *c, const uint32_t *task, int64_t n, int3
  * Pattern and text are both consumed entirely (|pn - tn| <= thre); every column's D0 / VP / VN / HP / HN words are kept and the cigar is
  * read back from them (indels preferred, :924-936).  Cigar entries are push_trace's (:522-531): op << 14 | len, ops 0 match, 1 mismatch,
  * 2 more pattern, 3 more text.  out[q] = {err, ps, pe, ts, te, cigar entries}; err = INT32_MAX (pe = te = -1, no cigar) when the pair
- * has no alignment within thre.  Cigar q goes to cig + q * cap (entries beyond cap are counted, not written). */
+ * has no alignment within thre.  Cigar q goes to cig + q * cap (entries beyond cap are counted, not written).
+ * mode 3 = the semi-global variant with traceback, ed_band_cal_semi_64_w_absent_diag_trace (:3778-3848): the text is consumed, the pattern may start and end
+ * inside the band; ps comes out of the walk (gen_trace with ptrim = abs_diag), te = tn - 1 whether or not an alignment exists. */
 /* ------------------------------------------------------------------ */
 static void tr_push(uint16_t *cg, int64_t cap, int32_t *n, int32_t op, int32_t len)
 {	/* push_trace */
@@ -1164,44 +1166,68 @@ static void tr_push(uint16_t *cg, int64_t cap, int32_t *n, int32_t op, int32_t l
 	if (len) { if (*n < cap) cg[*n] = (uint16_t)((op << 14) + len); ++*n; }
 }
 
-void hao_or_window_trace(const hao_or_ctx *c, const uint32_t *task, int64_t n, int32_t *out, uint16_t *cig, int64_t cap)
-{
+void hao_or_window_trace(const hao_or_ctx *c, const uint32_t *task, int64_t n, int mode, int32_t *out, uint16_t *cig, int64_t cap)
+{	/* mode 0: ed_band_cal_global_64_w_trace (:3370); mode 3: ed_band_cal_semi_64_w_absent_diag_trace (:3778) - the numbering of Correct.cpp:14536-14545 */
 	int64_t q; uint64_t *path = 0; int64_t path_m = 0;
 	for (q = 0; q < n; ++q) {
 		const uint32_t *t = task + 10 * q; int32_t *o = out + 6 * q; uint16_t *cg = cig + q * cap;
-		const int32_t pn = (int32_t)t[2], tn = (int32_t)t[6], thre = (int32_t)t[8];
+		const int32_t pn = (int32_t)t[2], tn = (int32_t)t[6], thre = (int32_t)t[8], abs_diag = mode == 3 ? (int32_t)t[9] : 0;
 		uint64_t Peq[5] = {0, 0, 0, 0, 0}, VP, VN, X, D0, HN, HP, mm;
-		int32_t i, err, i_bd, bd, tn0 = tn - 1, cut = thre + (thre << 1), site, ez_err = INT32_MAX, pe = -1, te = -1, ncg = 0, dead = 0;
+		int32_t i, err, i_bd, bd, tn0 = tn - 1, cut = thre + (thre << 1), ez_err = INT32_MAX, pe = -1, ncg = 0, dead = 0;
 #define PCH(k) ed_chr(c, t[0], (int64_t)t[1] + (k), (int)t[3])
 #define TCH(k) ed_chr(c, t[4], (int64_t)t[5] + (k), (int)t[7])
 #define CORE(z) do { X = Peq[(z)] | VN; D0 = ((VP + (X & VP)) ^ VP) | X; HN = VP & D0; HP = VN | ~(VP | D0); X = D0 >> 1; VN = X & HP; VP = HN | ~(X | HP); } while (0)
 #define KEEP() do { uint64_t *w_ = path + 5 * (int64_t)i; w_[0] = D0; w_[1] = VP; w_[2] = VN; w_[3] = HP; w_[4] = HN; } while (0)
-		o[0] = INT32_MAX; o[1] = 0; o[2] = -1; o[3] = 0; o[4] = -1; o[5] = 0;
-		if (pn <= 0 || tn <= 0 || pn > tn + thre || tn > pn + thre) continue;
+		o[0] = INT32_MAX; o[1] = mode == 3 ? -1 : 0; o[2] = -1; o[3] = 0; o[4] = mode == 3 ? tn - 1 : -1; o[5] = 0;
+		if (pn <= 0 || tn <= 0) continue;
+		if (mode == 0) { if (pn > tn + thre || tn > pn + thre) continue; }
+		else if (pn > tn + cut || tn > pn + cut) continue;
 		if (5 * (int64_t)tn > path_m) { path_m = 5 * (int64_t)tn + 64; path = (uint64_t*)realloc(path, path_m * 8); }
-		bd = thre + 1; if (bd > pn) bd = pn;
-		for (i = 0, mm = 1ULL << thre; i < bd; ++i) { Peq[PCH(i)] |= mm; mm <<= 1; }
-		i_bd = thre; Peq[4] = 0; err = thre;
-		VN = (1ULL << thre) - 1; VP = ((1ULL << ((thre << 1) + 1)) - 1) ^ VN;
-		mm = 1ULL << (thre << 1);
+		if (mode == 0) {
+			bd = thre + 1; if (bd > pn) bd = pn;
+			for (i = 0, mm = 1ULL << thre; i < bd; ++i) { Peq[PCH(i)] |= mm; mm <<= 1; }
+			i_bd = thre; err = thre;
+			VN = (1ULL << thre) - 1; VP = ((1ULL << ((thre << 1) + 1)) - 1) ^ VN;
+		} else {
+			bd = ((thre << 1) + 1) - abs_diag; if (bd > pn) bd = pn;
+			for (i = 0, mm = 1ULL << abs_diag; i < bd; ++i) { Peq[PCH(i)] |= mm; mm <<= 1; }
+			i_bd = (thre << 1) - abs_diag; err = abs_diag;
+			VP = 0; VN = (1ULL << abs_diag) - 1;
+		}
+		Peq[4] = 0; mm = 1ULL << (thre << 1);
 		for (i = 0; i < tn0; ) {
+			uint8_t cc = 4;
 			CORE(TCH(i));
 			if (!(D0 & 1ULL)) { ++err; if (err > cut) { dead = 1; break; } }
 			Peq[0] >>= 1; Peq[1] >>= 1; Peq[2] >>= 1; Peq[3] >>= 1;
 			KEEP();      /* (the reference stores the column after the shifts; the words themselves are not touched by them) */
 			++i; ++i_bd;
-			if (i_bd < pn) { uint8_t cc = PCH(i_bd); if (cc < 4) Peq[cc] |= mm; }
+			if (i_bd < pn) cc = PCH(i_bd);
+			if (cc < 4) Peq[cc] |= mm;
 		}
 		if (dead) continue;
 		CORE(TCH(i));
 		if (!(D0 & 1ULL)) { ++err; if (err > cut) continue; }
 		KEEP();
-		site = tn - 1 - thre;
-		for (; site < pn - 1; ++site) { err += (int32_t)(VP & 1ULL); VP >>= 1; err -= (int32_t)(VN & 1ULL); VN >>= 1; }
-		if (site == pn - 1 && err <= thre) { ez_err = err; pe = pn - 1; te = tn - 1; }
+		if (mode == 0) {
+			int32_t site = tn - 1 - thre;
+			for (; site < pn - 1; ++site) { err += (int32_t)(VP & 1ULL); VP >>= 1; err -= (int32_t)(VN & 1ULL); VN >>= 1; }
+			if (site == pn - 1 && err <= thre) { ez_err = err; pe = pn - 1; }
+		} else {
+			int32_t site = tn - 1 - abs_diag, ai = pn - tn + abs_diag, uge = INT32_MAX;
+			for (i = 0; site < 0 && i < ai; ++i, ++site) { err += (int32_t)((VP >> i) & 1ULL); err -= (int32_t)((VN >> i) & 1ULL); }
+			if (err <= thre && err <= ez_err) { ez_err = err; pe = site; }
+			site -= i;
+			while (i < ai) {
+				err += (int32_t)((VP >> i) & 1ULL); err -= (int32_t)((VN >> i) & 1ULL); ++i;
+				if (err <= thre && err <= ez_err) { ez_err = err; pe = site + i; }
+				if (i == thre) uge = err;
+			}
+			if (uge <= thre && uge == ez_err) pe = site + thre;
+		}
 		if (ez_err > thre) continue;
-		{	/* gen_trace(ez, ptrim = thre, reverse = 1); ts = 0, te = tn - 1, ps = 0 */
-			const int32_t low = thre << 1; int32_t sft = thre + pn - tn, poff = pe, cur = ez_err, d = 0, pd = -1, pdn = 0, mn, D, H, V, wm, k;
+		{	/* gen_trace(ez, ptrim, reverse = 1): ptrim = thre (global: ps = 0 is known) / abs_diag (semi: ps comes out of the walk); ts = 0, te = tn - 1 */
+			const int32_t low = thre << 1, ptrim = mode == 0 ? thre : abs_diag; int32_t sft = (low + 1) - (tn + low - pe - ptrim), poff = pe, cur = ez_err, d = 0, pd = -1, pdn = 0, mn, D, H, V, wm, k, ps = 0;
 			i = tn;
 			while (i > 0 && cur > 0) {
 				const uint64_t *w_ = path + 5 * (int64_t)(i - 1); const uint64_t d0 = w_[0], vp = w_[1], vn = w_[2], hp = w_[3], hn = w_[4];
@@ -1217,11 +1243,12 @@ void hao_or_window_trace(const hao_or_ctx *c, const uint32_t *task, int64_t n, i
 			}
 			if (i > 0) { d = 0; poff -= i; if (d == pd) pdn += i; else { if (pdn > 0) tr_push(cg, cap, &ncg, pd, pdn); pd = d; pdn = i; } }
 			++poff;
-			if (poff > 0) { d = 2; if (d == pd) pdn += poff; else { if (pdn > 0) tr_push(cg, cap, &ncg, pd, pdn); pd = d; pdn = poff; } }      /* ps = 0 is available: leading pattern bases are "more pattern" */
+			if (mode == 3) ps = poff;      /* ps was unavailable (-1): the walk's start */
+			else if (poff > 0) { d = 2; if (d == pd) pdn += poff; else { if (pdn > 0) tr_push(cg, cap, &ncg, pd, pdn); pd = d; pdn = poff; } }      /* ps = 0 is known: leading pattern bases are "more pattern" */
 			if (pdn > 0) tr_push(cg, cap, &ncg, pd, pdn);
-			for (k = 0; k < (ncg < cap ? ncg : (int32_t)cap) / 2 && ncg <= cap; ++k) { uint16_t x_ = cg[k]; cg[k] = cg[ncg - 1 - k]; cg[ncg - 1 - k] = x_; }
+			if (ncg <= cap) for (k = 0; k < ncg / 2; ++k) { uint16_t x_ = cg[k]; cg[k] = cg[ncg - 1 - k]; cg[ncg - 1 - k] = x_; }
+			o[0] = ez_err; o[1] = ps; o[2] = pe; o[3] = 0; o[4] = tn - 1; o[5] = ncg;
 		}
-		o[0] = ez_err; o[1] = 0; o[2] = pe; o[3] = 0; o[4] = te; o[5] = ncg;
 #undef PCH
 #undef TCH
 #undef CORE

@@ -22,6 +22,7 @@
 //                      recover_UC_Read_sub_region (Process_Read.cpp:524) builds for those intervals
 //   --edg-tasks FILE   f3, second variant: same task records (abs_diag unused); PREFIX.edg.i32 = int32[n][6] (err, ps, pe, ts, te, cigar entries) and
 //                      PREFIX.edg_cig.u16 = the cigars, concatenated, of ed_band_cal_global_64_w_trace (Levenshtein_distance.h:3370) on a cleared bit_extz_t
+//   --eds-tasks FILE   the same for ed_band_cal_semi_64_w_absent_diag_trace (:3778; abs_diag is used): PREFIX.eds.i32, PREFIX.eds_cig.u16
 //   --load-index PFX   f4: skip ha_ft_gen / ha_pt_gen and the read parser: the tables and the read store come from PFX.pt_flt (+ .bin, .paf.bin) through
 //                      the reference's own load_pt_index (htab.cpp:1432); every dump then describes what a stock hifiasm sees after loading that index
 //   --bw X             bw_thres of the pass (default 0.02 / 0.05 --ont; the final round uses 0.001, ecovlp.cpp:3957)
@@ -129,7 +130,7 @@ static tbuf_t *tbuf_init(int n)
 int main(int argc, char *argv[])
 {
 	int no_tables_hist = 0;
-	int n_thread = 1, is_ont = 0, do_time = 0, dump_hits = 1, k = -1, w = -1, bf_shift = 0, no_hpc = 0, no_tables = 0, do_digest = 0; const char *fa = 0, *list_fn = 0, *hg = 0, *ed_fn = 0, *edg_fn = 0, *load_pfx = 0; std::string prefix;
+	int n_thread = 1, is_ont = 0, do_time = 0, dump_hits = 1, k = -1, w = -1, bf_shift = 0, no_hpc = 0, no_tables = 0, do_digest = 0; const char *fa = 0, *list_fn = 0, *hg = 0, *ed_fn = 0, *edg_fn = 0, *eds_fn = 0, *load_pfx = 0; std::string prefix;
 	double bw_arg = -1;
 	for (int i = 1; i < argc; ++i) {
 		if (!strcmp(argv[i], "--ont")) is_ont = 1;
@@ -148,6 +149,7 @@ int main(int argc, char *argv[])
 		else if (!strcmp(argv[i], "--digest")) do_digest = 1;
 		else if (!strcmp(argv[i], "--ed-tasks")) ed_fn = argv[++i];
 		else if (!strcmp(argv[i], "--edg-tasks")) edg_fn = argv[++i];
+		else if (!strcmp(argv[i], "--eds-tasks")) eds_fn = argv[++i];
 		else if (!strcmp(argv[i], "--load-index")) load_pfx = argv[++i];
 		else fa = argv[i];
 	}
@@ -221,8 +223,9 @@ int main(int argc, char *argv[])
 		}
 		wr(prefix, "ed.i32", res.data(), 4 * res.size());
 	}
-	if (edg_fn) {
-		FILE *fp = fopen(edg_fn, "rb"); if (!fp) { fprintf(stderr, "cannot read %s\n", edg_fn); return 1; }
+	for (int tm = 0; tm < 2; ++tm) {
+		const char *tfn = tm ? eds_fn : edg_fn; if (!tfn) continue;
+		FILE *fp = fopen(tfn, "rb"); if (!fp) { fprintf(stderr, "cannot read %s\n", tfn); return 1; }
 		std::vector<uint32_t> tk; uint32_t rec[10];
 		while (fread(rec, 4, 10, fp) == 10) tk.insert(tk.end(), rec, rec + 10);
 		fclose(fp);
@@ -233,15 +236,16 @@ int main(int argc, char *argv[])
 			recover_UC_Read_sub_region(ps.data(), t[1], t[2], (uint8_t)t[3], &R_INF, t[0]);
 			recover_UC_Read_sub_region(ts.data(), t[5], t[6], (uint8_t)t[7], &R_INF, t[4]);
 			clear_align(ez); ez.pe = ez.te = -1; ez.cigar.n = 0;
-			ed_band_cal_global_64_w_trace(ps.data(), (int32_t)t[2], ts.data(), (int32_t)t[6], (int32_t)t[8], &ez);
+			if (tm) ed_band_cal_semi_64_w_absent_diag_trace(ps.data(), (int32_t)t[2], ts.data(), (int32_t)t[6], (int32_t)t[8], (int32_t)t[9], &ez);
+			else ed_band_cal_global_64_w_trace(ps.data(), (int32_t)t[2], ts.data(), (int32_t)t[6], (int32_t)t[8], &ez);
 			const bool ok = is_align(ez);
-			res.push_back(ok ? ez.err : INT32_MAX); res.push_back(ok ? ez.ps : 0); res.push_back(ok ? ez.pe : -1); res.push_back(ok ? ez.ts : 0); res.push_back(ok ? ez.te : -1);
+			res.push_back(ok ? ez.err : INT32_MAX); res.push_back(ok ? ez.ps : (tm ? -1 : 0)); res.push_back(ok ? ez.pe : -1); res.push_back(ok ? ez.ts : 0); res.push_back(ok || tm ? (int32_t)t[6] - 1 : -1);
 			res.push_back(ok ? (int32_t)ez.cigar.n : 0);
 			if (ok) cg.insert(cg.end(), ez.cigar.a, ez.cigar.a + ez.cigar.n);
 		}
-		wr(prefix, "edg.i32", res.data(), 4 * res.size());
+		wr(prefix, tm ? "eds.i32" : "edg.i32", res.data(), 4 * res.size());
 		cg.push_back(0);
-		wr(prefix, "edg_cig.u16", cg.data(), 2 * (cg.size() - 1));
+		wr(prefix, tm ? "eds_cig.u16" : "edg_cig.u16", cg.data(), 2 * (cg.size() - 1));
 	}
 	std::vector<uint64_t> sel;      // reads of the per-read dumps
 	if (list_fn) {

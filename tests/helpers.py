@@ -170,3 +170,12 @@ def ed_global_tasks(name, n_reads=24, wl=775, seed=2):
         if p_ + n_ + 1 <= L[a]:
             out.append((a, p_, n_ + 1, 0, a, p_, n_, 0, max(1, thre), 0))
     return np.array(out, dtype=np.uint32)
+
+
+def ed_semi_trace_tasks(name, n_reads=24, seed=3):
+    """tasks for the semi-global alignment WITH traceback (ed_band_cal_semi_64_w_absent_diag_trace): ed_tasks' pairs whose band covers the pattern
+    (0 <= p_len - t_len + abs_diag <= 2 thre, t_len > abs_diag) - outside of that the reference's traceback indexes its column words out of range."""
+    t = ed_tasks(name, n_reads=n_reads, seed=seed).astype(np.int64)
+    ai = t[:, 2] - t[:, 6] + t[:, 9]
+    keep = (ai >= 0) & (ai <= 2 * t[:, 8]) & (t[:, 6] > t[:, 9])
+    return t[keep].astype(np.uint32)

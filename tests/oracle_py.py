@@ -48,7 +48,7 @@ def lib():
         L.hao_or_lchain.restype = C.c_int64
         L.hao_or_exact.argtypes = [vp, vp, C.c_int64, u8p]
         L.hao_or_window_ed.argtypes = [vp, vp, C.c_int64, vp]
-        L.hao_or_window_trace.argtypes = [vp, vp, C.c_int64, vp, vp, C.c_int64]
+        L.hao_or_window_trace.argtypes = [vp, vp, C.c_int64, C.c_int, vp, vp, C.c_int64]
         L.hao_or_analyze_count.argtypes = [C.c_int, C.c_int, i64p, C.POINTER(C.c_int)]; L.hao_or_analyze_count.restype = C.c_int
         _LIB = L
     return _LIB
@@ -177,12 +177,13 @@ def _window_ed(self, tasks):
 Oracle.window_ed = _window_ed
 
 
-def _window_trace(self, tasks, cap=80):
-    """tasks uint32 [n,10] -> (int32 [n,6] (err, ps, pe, ts, te, cigar entries), uint16 [n,cap] cigars): ed_band_cal_global_64_w_trace + gen_trace"""
+def _window_trace(self, tasks, cap=80, mode=0):
+    """tasks uint32 [n,10] -> (int32 [n,6] (err, ps, pe, ts, te, cigar entries), uint16 [n,cap] cigars): mode 0 ed_band_cal_global_64_w_trace,
+    mode 3 ed_band_cal_semi_64_w_absent_diag_trace, each + gen_trace"""
     t = np.ascontiguousarray(tasks, dtype=np.uint32).reshape(-1, 10)
     out = np.zeros((t.shape[0], 6), dtype=np.int32); cig = np.zeros((t.shape[0], cap), dtype=np.uint16)
     if t.shape[0]:
-        self.L.hao_or_window_trace(self.h, t.ctypes.data_as(C.c_void_p), t.shape[0], out.ctypes.data_as(C.c_void_p), cig.ctypes.data_as(C.c_void_p), cap)
+        self.L.hao_or_window_trace(self.h, t.ctypes.data_as(C.c_void_p), t.shape[0], mode, out.ctypes.data_as(C.c_void_p), cig.ctypes.data_as(C.c_void_p), cap)
     return out, cig
 
 

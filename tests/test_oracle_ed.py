@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, ed_tasks, ed_global_tasks, scenario_oracle
+from helpers import GOLDEN, ed_tasks, ed_global_tasks, ed_semi_trace_tasks, scenario_oracle
 
 
 @pytest.mark.parametrize("name", ["hifi", "ont", "nn", "edge"])
@@ -31,3 +31,17 @@ def test_window_trace_matches_the_reference(name):
     bad = [q for q in range(t.shape[0]) if not (cig[q, :want[q, 5]] == wcig[off[q]:off[q + 1]]).all()]
     assert not bad, bad[:10]
     assert (res[:, 0] != 2**31 - 1).sum() > 500 and (res[:, 0] == 2**31 - 1).sum() > 100 and want[:, 5].max() > 30
+
+
+@pytest.mark.parametrize("name", ["hifi", "ont", "nn", "edge"])
+def test_window_semi_trace_matches_the_reference(name):
+    g = np.load(os.path.join(GOLDEN, "ed.npz"))
+    t = ed_semi_trace_tasks(name)
+    assert t.shape == g[name + "_stasks"].shape and (t == g[name + "_stasks"]).all(), "task generator drifted: regenerate tests/golden/ed.npz"
+    res, cig = scenario_oracle(name).window_trace(t, mode=3)
+    want, wcig = g[name + "_sres"], g[name + "_scig"]
+    assert (res == want).all(), np.flatnonzero((res != want).any(axis=1))[:10]
+    off = np.concatenate(([0], np.cumsum(want[:, 5])))
+    bad = [q for q in range(t.shape[0]) if not (cig[q, :want[q, 5]] == wcig[off[q]:off[q + 1]]).all()]
+    assert not bad, bad[:10]
+    assert (res[:, 0] != 2**31 - 1).sum() > 300
