@@ -319,7 +319,8 @@ class Engine:
 
     def window_trace_batch(self, tasks, cap=80, mode=0):
         """tasks: uint32 [n,10] -> (int32 [n,6] (err, ps, pe, ts, te, cigar entries), uint16 [n,cap] cigars): alignment in the band with traceback;
-        mode 0 global (ed_band_cal_global_64_w_trace), 3 semi-global with absent diagonals (ed_band_cal_semi_64_w_absent_diag_trace)"""
+        mode 0 global (ed_band_cal_global_64_w_trace), 1 / 2 forward / backward extension (ed_band_cal_extension_64_{0,1}_w_trace), 3 semi-global with absent
+        diagonals (ed_band_cal_semi_64_w_absent_diag_trace)"""
         t = np.ascontiguousarray(tasks, dtype=np.uint32).reshape(-1, 10)
         out = np.zeros((t.shape[0], 6), dtype=np.int32); cig = np.zeros((t.shape[0], cap), dtype=np.uint16)
         self._ck(self.L.hao_window_trace_batch(self.h, mode, t.ctypes.data_as(C.c_void_p), t.shape[0], out.ctypes.data_as(C.c_void_p), cig.ctypes.data_as(C.c_void_p), cap),

@@ -181,3 +181,88 @@ __global__ __launch_bounds__(256) void hao_window_trace_kernel(hao_ed_reads R, c
 	res.n_cigar = ncg;
 	out[i_] = res;
 }
+
+// Modes 1 / 2: ed_band_cal_extension_64_0_w_trace (Levenshtein_distance.h:3512-3618) / ed_band_cal_extension_64_1_w_trace (:3620-3735) on a cleared
+// bit_extz_t.  Forward extension: both strings start together and the alignment ends wherever the pattern or the text runs out (the longer string is first
+// cut to the other's length + thre); the best end is tracked along the pattern's last row while the text is swept (tmp_e), then along the last column.
+// Backward extension is the same sweep over both strings read from their ends: ps / ts move instead of pe / te and the cigar is not reversed.  A sweep
+// abandoned because the running error passed 3 thre returns before gen_trace: an end found earlier keeps its err / coordinates but gets no cigar.
+template<bool BACK>
+__global__ __launch_bounds__(256) void hao_window_ext_trace_kernel(hao_ed_reads R, const hao_ed_task_t *task, uint64_t n_task, uint64_t *path, uint64_t stride,
+		hao_trace_result_t *out, uint16_t *cig, uint32_t cap)
+{
+	const uint64_t i_ = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i_ >= n_task) return;
+	const hao_ed_task_t T = task[i_];
+	const uint8_t *pd = R.packed + R.pk_off[T.p_rid], *td = R.packed + R.pk_off[T.t_rid]; const uint32_t pL = R.len[T.p_rid], tL = R.len[T.t_rid];
+	const int32_t pn0 = (int32_t)T.p_len, tn0_ = (int32_t)T.t_len, thre = (int32_t)T.thre, pidx = pn0 - 1, tidx = tn0_ - 1;
+	int32_t pn = pn0, tn = tn0_, ez_err = INT32_MAX, a_p = -1, a_t = -1, ncg = 0;      // a_p / a_t: the moving end (pe / te forward; pidx - ps / tidx - ts backward)
+	auto P = [&](int32_t k) { return hao_ed_base(R, T.p_rid, pd, pL, (int64_t)T.p_pos + (BACK ? pidx - k : k), T.p_rev); };
+	auto Tx = [&](int32_t k) { return hao_ed_base(R, T.t_rid, td, tL, (int64_t)T.t_pos + (BACK ? tidx - k : k), T.t_rev); };
+	auto put = [&]() {
+		hao_trace_result_t res; res.err = ez_err; res.n_cigar = ncg;
+		if (BACK) { res.ps = ez_err <= thre ? pidx - a_p : INT32_MAX; res.pe = pidx; res.ts = ez_err <= thre ? tidx - a_t : INT32_MAX; res.te = tidx; }
+		else { res.ps = 0; res.pe = a_p; res.ts = 0; res.te = a_t; }
+		out[i_] = res;
+	};
+	if (pn0 <= 0 || tn0_ <= 0) { put(); return; }
+	if (pn > tn + thre) pn = tn + thre; else if (tn > pn + thre) tn = pn + thre;
+	uint64_t *col = path + i_;
+	const int32_t cut = thre + (thre << 1), pe_l = pn - 1;
+	uint64_t Peq[5] = {0, 0, 0, 0, 0}, VP, VN, X, D0, HN, HP, mm;
+	int32_t i, i_bd = thre, err = thre, tmp_e = INT32_MAX, k, poff, bd = thre + 1; if (bd > pn) bd = pn;
+	for (i = 0, mm = 1ULL << thre; i < bd; ++i) { Peq[P(i)] |= mm; mm <<= 1; }
+	Peq[4] = 0;
+	VN = (1ULL << thre) - 1; VP = ((1ULL << ((thre << 1) + 1)) - 1) ^ VN;
+	mm = 1ULL << (thre << 1);
+#define HAO_ED_CORE(z) { X = Peq[(z)] | VN; D0 = ((VP + (X & VP)) ^ VP) | X; HN = VP & D0; HP = VN | ~(VP | D0); X = D0 >> 1; VN = X & HP; VP = HN | ~(X | HP); }
+#define HAO_ED_KEEP() { uint64_t *w_ = col + 5 * (uint64_t)i * stride; w_[0] = D0; w_[stride] = VP; w_[2 * stride] = VN; w_[3 * stride] = HP; w_[4 * stride] = HN; }
+	for (i = 0; i < tn - 1; ) {
+		HAO_ED_CORE(Tx(i));
+		if (!(D0 & 1ULL)) { ++err; if (err > cut) { put(); return; } }
+		poff = i - thre; k = i + thre - pe_l;
+		if (k >= 0) {
+			if (tmp_e == INT32_MAX) { tmp_e = err; for (k = 0; poff < pe_l; ++poff, ++k) { tmp_e += (int32_t)((VP >> k) & 1ULL); tmp_e -= (int32_t)((VN >> k) & 1ULL); } }
+			else { k = (thre << 1) - k; if (k >= 0) { tmp_e += (int32_t)((HP >> k) & 1ULL); tmp_e -= (int32_t)((HN >> k) & 1ULL); } }
+			if (tmp_e <= thre && tmp_e < ez_err) { ez_err = tmp_e; a_p = pe_l; a_t = i; }
+		}
+		Peq[0] >>= 1; Peq[1] >>= 1; Peq[2] >>= 1; Peq[3] >>= 1;
+		HAO_ED_KEEP();
+		++i; ++i_bd;
+		if (i_bd < pn) { const uint32_t cc = P(i_bd); if (cc < 4) Peq[cc] |= mm; }
+	}
+	HAO_ED_CORE(Tx(i));
+	if (!(D0 & 1ULL)) { ++err; if (err > cut) { put(); return; } }
+	HAO_ED_KEEP();
+#undef HAO_ED_CORE
+#undef HAO_ED_KEEP
+	int32_t site = tn - 1 - thre;
+	while (site < pn - 1) {
+		err += (int32_t)(VP & 1ULL); VP >>= 1; err -= (int32_t)(VN & 1ULL); VN >>= 1; ++site;
+		if (err <= thre && err < ez_err) { ez_err = err; a_p = site; a_t = tn - 1; }
+	}
+	if (err <= thre && err < ez_err) { ez_err = err; a_p = site; a_t = tn - 1; }
+	if (ez_err <= thre) {      // gen_trace(ez, thre, !BACK) on the columns 0 .. a_t; ps (mirrored for the backward sweep) = 0 is known
+		uint16_t *cg = cig + i_ * cap;
+		const int32_t low = thre << 1; int32_t sft = thre + a_p - a_t, cur = ez_err, d = 0, pdir = -1, pdn = 0;
+		poff = a_p; i = a_t + 1;
+		while (i > 0 && cur > 0) {
+			const uint64_t *w_ = col + 5 * (uint64_t)(i - 1) * stride;
+			int32_t wm = sft & 63;
+			const int32_t D = cur - (int32_t)((~(w_[0] >> wm)) & 1ULL); int32_t mn = D; d = 0;
+			if (sft != low) { const int32_t H = cur + (int32_t)((w_[4 * stride] >> wm) & 1ULL) - (int32_t)((w_[3 * stride] >> wm) & 1ULL); if (H + 1 == cur && H <= mn) { mn = H; d = 3; } }
+			if (sft != 0) { wm = (sft - 1) & 63; const int32_t V = cur + (int32_t)((w_[2 * stride] >> wm) & 1ULL) - (int32_t)((w_[stride] >> wm) & 1ULL); if (V + 1 == cur && V <= mn) { mn = V; d = 2; } }
+			if (d == 0) { if (D != cur) d = 1; --i; --poff; }
+			else if (d == 2) { --sft; --poff; }
+			else { --i; ++sft; }
+			if (d == pdir) ++pdn; else { if (pdn > 0) hao_tr_push(cg, cap, ncg, pdir, pdn); pdir = d; pdn = 1; }
+			cur = mn;
+		}
+		if (i > 0) { d = 0; poff -= i; if (d == pdir) pdn += i; else { if (pdn > 0) hao_tr_push(cg, cap, ncg, pdir, pdn); pdir = d; pdn = i; } }
+		++poff;
+		if (poff > 0) { d = 2; if (d == pdir) pdn += poff; else { if (pdn > 0) hao_tr_push(cg, cap, ncg, pdir, pdn); pdir = d; pdn = poff; } }
+		if (pdn > 0) hao_tr_push(cg, cap, ncg, pdir, pdn);
+		if (!BACK && (uint32_t)ncg <= cap) for (int32_t q = 0; q < ncg / 2; ++q) { const uint16_t x_ = cg[q]; cg[q] = cg[ncg - 1 - q]; cg[ncg - 1 - q] = x_; }
+	}
+	put();
+}

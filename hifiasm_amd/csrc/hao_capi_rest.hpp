@@ -213,7 +213,7 @@ int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks
 
 int hao_window_trace_batch(hao_ctx *c, int mode, const hao_ed_task_t *tasks, uint64_t n_tasks, hao_trace_result_t *out, uint16_t *cigars, uint32_t cigar_cap)
 {
-	if (!c || (mode != HAO_ALIGN_GLOBAL && mode != HAO_ALIGN_SEMI) || (!tasks && n_tasks) || (!out && n_tasks) || (!cigars && n_tasks && cigar_cap)) return HAO_EINVAL;
+	if (!c || (mode < HAO_ALIGN_GLOBAL || mode > HAO_ALIGN_SEMI) || (!tasks && n_tasks) || (!out && n_tasks) || (!cigars && n_tasks && cigar_cap)) return HAO_EINVAL;
 	if (int rc = hao_view_refresh(c)) return rc;
 	if (c->comm && c->comm->active()) { hao_set_err(c, "hao_window_trace_batch needs the bases of both reads: single-device mode only"); return HAO_EUNSUPP; }
 	if (n_tasks == 0) return HAO_OK;
@@ -237,7 +237,9 @@ int hao_window_trace_batch(hao_ctx *c, int mode, const hao_ed_task_t *tasks, uin
 	for (uint64_t lo = 0; lo < n_tasks; lo += slice) {
 		const uint64_t m = std::min<uint64_t>(slice, n_tasks - lo);
 		HIP_TRY(hipMemcpyAsync(dt.p, tasks + lo, m * sizeof(hao_ed_task_t), hipMemcpyHostToDevice, c->stream));
-		if (mode == HAO_ALIGN_SEMI) hipLaunchKernelGGL(hao_window_trace_kernel<3>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, R, dt.p, m, path.p, slice, dr.p, dc.p, cigar_cap);
+		if (mode == HAO_ALIGN_EXT_FWD) hipLaunchKernelGGL(hao_window_ext_trace_kernel<false>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, R, dt.p, m, path.p, slice, dr.p, dc.p, cigar_cap);
+		else if (mode == HAO_ALIGN_EXT_BWD) hipLaunchKernelGGL(hao_window_ext_trace_kernel<true>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, R, dt.p, m, path.p, slice, dr.p, dc.p, cigar_cap);
+		else if (mode == HAO_ALIGN_SEMI) hipLaunchKernelGGL(hao_window_trace_kernel<3>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, R, dt.p, m, path.p, slice, dr.p, dc.p, cigar_cap);
 		else hipLaunchKernelGGL(hao_window_trace_kernel<0>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, R, dt.p, m, path.p, slice, dr.p, dc.p, cigar_cap);
 		HAO_CHECK_LAUNCH();
 		HIP_TRY(hipMemcpyAsync(out + lo, dr.p, m * sizeof(hao_trace_result_t), hipMemcpyDeviceToHost, c->stream));

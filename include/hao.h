@@ -225,6 +225,11 @@ int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks
  * are not written (an alignment within thre <= 31 has at most 2 thre + 3 entries for strings shorter than 16 383). */
 typedef struct { int32_t err, ps, pe, ts, te, n_cigar; } hao_trace_result_t;
 #define HAO_ALIGN_GLOBAL 0      /* ed_band_cal_global_64_w_trace */
+#define HAO_ALIGN_EXT_FWD 1     /* ed_band_cal_extension_64_0_w_trace (:3512-3618): both strings start together, the alignment ends where the pattern or the text runs out (the
+                                 * longer one is first cut to the other's length + thre): pe / te come out of the sweep.  Without an alignment: err INT32_MAX, pe = te = -1 */
+#define HAO_ALIGN_EXT_BWD 2     /* ed_band_cal_extension_64_1_w_trace (:3620-3735): both strings END together; ps / ts come out (INT32_MAX without an alignment), pe = p_len - 1,
+                                 * te = t_len - 1.  In both extension modes an alignment whose sweep was later abandoned (running error > 3 thre) keeps err and coordinates
+                                 * but has no cigar (n_cigar = 0), as in the reference */
 #define HAO_ALIGN_SEMI 3        /* ed_band_cal_semi_64_w_absent_diag_trace (Levenshtein_distance.h:3778-3848): the traced twin of hao_window_ed_batch - the text is consumed, the
                                  * pattern starts and ends inside the band: ps comes out of the walk, ts = 0, te = t_len - 1 (also without an alignment), abs_diag is used.
                                  * The band must cover the pattern: 0 <= p_len - t_len + abs_diag <= 2 thre and t_len > abs_diag (else HAO_EINVAL: the reference's

@@ -98,7 +98,7 @@ void hao_or_exact(const hao_or_ctx *c, const hao_or_ovlp_t *ol, int64_t n, uint8
 void hao_or_window_ed(const hao_or_ctx *c, const uint32_t *task, int64_t n, int32_t *out);
 /* f3, global alignment with traceback (ed_band_cal_global_64_w_trace + gen_trace, Levenshtein_distance.h:3370,903): out[n][6] = err, ps, pe, ts, te, cigar
  * entries; cigar q at cig + q * cap */
-void hao_or_window_trace(const hao_or_ctx *c, const uint32_t *task, int64_t n, int mode /* 0 global, 3 semi-global with absent diagonals (:3778) */, int32_t *out, uint16_t *cig, int64_t cap);
+void hao_or_window_trace(const hao_or_ctx *c, const uint32_t *task, int64_t n, int mode /* 0 global, 1 / 2 forward / backward extension (:3512, :3620), 3 semi-global with absent diagonals (:3778) */, int32_t *out, uint16_t *cig, int64_t cap);
 
 /* ha_analyze_count (hist.cpp:74-157) with m_peak_hom <= 0 (hg_size unset) / with the prior m_peak_hom (adj_m_peak_hom, hist.cpp:46-72) */
 int hao_or_analyze_count(int n_cnt, int start_cnt, const int64_t *cnt, int *peak_het);

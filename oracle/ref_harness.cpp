@@ -23,6 +23,8 @@
 //   --edg-tasks FILE   f3, second variant: same task records (abs_diag unused); PREFIX.edg.i32 = int32[n][6] (err, ps, pe, ts, te, cigar entries) and
 //                      PREFIX.edg_cig.u16 = the cigars, concatenated, of ed_band_cal_global_64_w_trace (Levenshtein_distance.h:3370) on a cleared bit_extz_t
 //   --eds-tasks FILE   the same for ed_band_cal_semi_64_w_absent_diag_trace (:3778; abs_diag is used): PREFIX.eds.i32, PREFIX.eds_cig.u16
+//   --ed1-tasks / --ed2-tasks FILE   the same for ed_band_cal_extension_64_0_w_trace / _1_w_trace (:3512, :3620): PREFIX.ed1.* / PREFIX.ed2.* (the bit_extz_t fields as
+//                      the call leaves them, also without an alignment)
 //   --load-index PFX   f4: skip ha_ft_gen / ha_pt_gen and the read parser: the tables and the read store come from PFX.pt_flt (+ .bin, .paf.bin) through
 //                      the reference's own load_pt_index (htab.cpp:1432); every dump then describes what a stock hifiasm sees after loading that index
 //   --bw X             bw_thres of the pass (default 0.02 / 0.05 --ont; the final round uses 0.001, ecovlp.cpp:3957)
@@ -130,7 +132,7 @@ static tbuf_t *tbuf_init(int n)
 int main(int argc, char *argv[])
 {
 	int no_tables_hist = 0;
-	int n_thread = 1, is_ont = 0, do_time = 0, dump_hits = 1, k = -1, w = -1, bf_shift = 0, no_hpc = 0, no_tables = 0, do_digest = 0; const char *fa = 0, *list_fn = 0, *hg = 0, *ed_fn = 0, *edg_fn = 0, *eds_fn = 0, *load_pfx = 0; std::string prefix;
+	int n_thread = 1, is_ont = 0, do_time = 0, dump_hits = 1, k = -1, w = -1, bf_shift = 0, no_hpc = 0, no_tables = 0, do_digest = 0; const char *fa = 0, *list_fn = 0, *hg = 0, *ed_fn = 0, *edg_fn = 0, *eds_fn = 0, *ed1_fn = 0, *ed2_fn = 0, *load_pfx = 0; std::string prefix;
 	double bw_arg = -1;
 	for (int i = 1; i < argc; ++i) {
 		if (!strcmp(argv[i], "--ont")) is_ont = 1;
@@ -150,6 +152,8 @@ int main(int argc, char *argv[])
 		else if (!strcmp(argv[i], "--ed-tasks")) ed_fn = argv[++i];
 		else if (!strcmp(argv[i], "--edg-tasks")) edg_fn = argv[++i];
 		else if (!strcmp(argv[i], "--eds-tasks")) eds_fn = argv[++i];
+		else if (!strcmp(argv[i], "--ed1-tasks")) ed1_fn = argv[++i];
+		else if (!strcmp(argv[i], "--ed2-tasks")) ed2_fn = argv[++i];
 		else if (!strcmp(argv[i], "--load-index")) load_pfx = argv[++i];
 		else fa = argv[i];
 	}
@@ -223,8 +227,9 @@ int main(int argc, char *argv[])
 		}
 		wr(prefix, "ed.i32", res.data(), 4 * res.size());
 	}
-	for (int tm = 0; tm < 2; ++tm) {
-		const char *tfn = tm ? eds_fn : edg_fn; if (!tfn) continue;
+	for (int tm = 0; tm < 4; ++tm) {      // 0 global, 1 semi-global, 2 / 3 forward / backward extension
+		const char *tfn = tm == 0 ? edg_fn : tm == 1 ? eds_fn : tm == 2 ? ed1_fn : ed2_fn; if (!tfn) continue;
+		const char *tag = tm == 0 ? "edg" : tm == 1 ? "eds" : tm == 2 ? "ed1" : "ed2";
 		FILE *fp = fopen(tfn, "rb"); if (!fp) { fprintf(stderr, "cannot read %s\n", tfn); return 1; }
 		std::vector<uint32_t> tk; uint32_t rec[10];
 		while (fread(rec, 4, 10, fp) == 10) tk.insert(tk.end(), rec, rec + 10);
@@ -236,16 +241,19 @@ int main(int argc, char *argv[])
 			recover_UC_Read_sub_region(ps.data(), t[1], t[2], (uint8_t)t[3], &R_INF, t[0]);
 			recover_UC_Read_sub_region(ts.data(), t[5], t[6], (uint8_t)t[7], &R_INF, t[4]);
 			clear_align(ez); ez.pe = ez.te = -1; ez.cigar.n = 0;
-			if (tm) ed_band_cal_semi_64_w_absent_diag_trace(ps.data(), (int32_t)t[2], ts.data(), (int32_t)t[6], (int32_t)t[8], (int32_t)t[9], &ez);
+			if (tm == 1) ed_band_cal_semi_64_w_absent_diag_trace(ps.data(), (int32_t)t[2], ts.data(), (int32_t)t[6], (int32_t)t[8], (int32_t)t[9], &ez);
+			else if (tm == 2) ed_band_cal_extension_64_0_w_trace(ps.data(), (int32_t)t[2], ts.data(), (int32_t)t[6], (int32_t)t[8], &ez);
+			else if (tm == 3) ed_band_cal_extension_64_1_w_trace(ps.data(), (int32_t)t[2], ts.data(), (int32_t)t[6], (int32_t)t[8], &ez);
 			else ed_band_cal_global_64_w_trace(ps.data(), (int32_t)t[2], ts.data(), (int32_t)t[6], (int32_t)t[8], &ez);
 			const bool ok = is_align(ez);
-			res.push_back(ok ? ez.err : INT32_MAX); res.push_back(ok ? ez.ps : (tm ? -1 : 0)); res.push_back(ok ? ez.pe : -1); res.push_back(ok ? ez.ts : 0); res.push_back(ok || tm ? (int32_t)t[6] - 1 : -1);
+			if (tm >= 2) { res.push_back(ok ? ez.err : INT32_MAX); res.push_back(ez.ps); res.push_back(ez.pe); res.push_back(ez.ts); res.push_back(ez.te); }
+			else { res.push_back(ok ? ez.err : INT32_MAX); res.push_back(ok ? ez.ps : (tm ? -1 : 0)); res.push_back(ok ? ez.pe : -1); res.push_back(ok ? ez.ts : 0); res.push_back(ok || tm ? (int32_t)t[6] - 1 : -1); }
 			res.push_back(ok ? (int32_t)ez.cigar.n : 0);
 			if (ok) cg.insert(cg.end(), ez.cigar.a, ez.cigar.a + ez.cigar.n);
 		}
-		wr(prefix, tm ? "eds.i32" : "edg.i32", res.data(), 4 * res.size());
+		wr(prefix, (std::string(tag) + ".i32").c_str(), res.data(), 4 * res.size());
 		cg.push_back(0);
-		wr(prefix, tm ? "eds_cig.u16" : "edg_cig.u16", cg.data(), 2 * (cg.size() - 1));
+		wr(prefix, (std::string(tag) + "_cig.u16").c_str(), cg.data(), 2 * (cg.size() - 1));
 	}
 	std::vector<uint64_t> sel;      // reads of the per-read dumps
 	if (list_fn) {

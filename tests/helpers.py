@@ -179,3 +179,42 @@ def ed_semi_trace_tasks(name, n_reads=24, seed=3):
     ai = t[:, 2] - t[:, 6] + t[:, 9]
     keep = (ai >= 0) & (ai <= 2 * t[:, 8]) & (t[:, 6] > t[:, 9])
     return t[keep].astype(np.uint32)
+
+
+def ed_ext_tasks(name, n_reads=24, wl=775, seed=4):
+    """(pattern, text) pairs for the extension alignments with traceback (ed_band_cal_extension_64_{0,1}_w_trace): both strings start (forward) or end
+    (backward) together at a point of an overlap's diagonal; either may be the longer one, by a little or by a lot; plus unrelated and tiny pairs."""
+    rs, okw = scenario_reads(name)
+    o = scenario_oracle(name)
+    rng = np.random.default_rng(seed)
+    out = []
+    L = rs.lengths.astype(np.int64)
+    for r in rng.choice(rs.n, size=min(n_reads, rs.n), replace=False):
+        ol = o.lchain(int(r))[0]
+        for z in ol[:: max(1, ol.shape[0] // 12)]:
+            xs, xe, yid, ys, ye, yrev = int(z[1]), int(z[2]), int(z[4]), int(z[5]), int(z[6]), int(z[7])
+            tl = int(L[yid])
+            for ws in range(xs, xe + 1, wl):
+                tn = min(int(rng.integers(20, wl + 1)), xe + 1 - ws)
+                thre = int(rng.choice([0, 3, 8, 15, 24, 31]))
+                p0 = max(0, ys + (ws - xs) + int(rng.integers(-1, 2)))
+                pn = tn + int(rng.choice([-60, -9, -2, 0, 1, 3, 12, 80]))
+                p1 = min(tl, p0 + max(1, pn))
+                if p1 <= p0 or tn <= 0:
+                    continue
+                out.append((yid, p0, p1 - p0, yrev, int(r), ws, tn, 0, thre, 0))
+    for _ in range(300):
+        a, b = (int(x) for x in rng.integers(0, rs.n, 2))
+        if L[a] < 2 or L[b] < 2:
+            continue
+        tn = int(rng.integers(1, min(300, int(L[b])) + 1)); pn = int(rng.integers(1, min(300, int(L[a])) + 1))
+        thre = int(rng.choice([0, 1, 5, 15, 31]))
+        out.append((a, int(rng.integers(0, L[a] - pn + 1)), pn, int(rng.integers(0, 2)), b, int(rng.integers(0, L[b] - tn + 1)), tn, int(rng.integers(0, 2)), thre, 0))
+    for a in range(min(rs.n, 40)):      # exact and near-exact short pairs
+        if L[a] < 60:
+            continue
+        n_ = int(rng.integers(1, 50)); p_ = int(rng.integers(0, L[a] - n_ - 8)); thre = int(rng.choice([0, 2, 7]))
+        out.append((a, p_, n_, 0, a, p_, n_, 0, thre, 0))
+        out.append((a, p_, n_ + 5, 0, a, p_, n_, 0, thre, 0))
+        out.append((a, p_, n_, 0, a, p_, n_ + 5, 0, thre, 0))
+    return np.array(out, dtype=np.uint32)

@@ -5,7 +5,7 @@ count, end points and cigars."""
 import numpy as np
 import pytest
 
-from helpers import ed_tasks, ed_global_tasks, ed_semi_trace_tasks, scenario_reads, scenario_oracle
+from helpers import ed_tasks, ed_global_tasks, ed_semi_trace_tasks, ed_ext_tasks, scenario_reads, scenario_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -71,4 +71,22 @@ def test_window_semi_trace(name):
     badt = t[:1].copy(); badt[0, 2] = badt[0, 6] + 2 * badt[0, 8] + 5      # the band does not cover the pattern
     with pytest.raises(HaoError):
         e.window_trace_batch(badt, mode=3)
+    e.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("name", ["hifi", "ont", "nn", "edge", "rr", "hifi_15k"])
+def test_window_extension_trace(name, mode):
+    from hifiasm_amd.api import Engine
+    rs, okw = scenario_reads(name)
+    o = scenario_oracle(name)
+    e = Engine(0, **okw)
+    e.set_readset(rs)
+    t = ed_ext_tasks(name, n_reads=40, seed=15)
+    got, gcig = e.window_trace_batch(t, mode=mode)
+    want, wcig = o.window_trace(t, mode=mode)
+    assert (got == want).all(), np.flatnonzero((got != want).any(axis=1))[:10]
+    bad = [q for q in range(t.shape[0]) if not (gcig[q, :want[q, 5]] == wcig[q, :want[q, 5]]).all()]
+    assert not bad, bad[:10]
+    assert (want[:, 0] != 2**31 - 1).sum() > 200
     e.close()

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, ed_tasks, ed_global_tasks, ed_semi_trace_tasks, scenario_oracle
+from helpers import GOLDEN, ed_tasks, ed_global_tasks, ed_semi_trace_tasks, ed_ext_tasks, scenario_oracle
 
 
 @pytest.mark.parametrize("name", ["hifi", "ont", "nn", "edge"])
@@ -41,6 +41,21 @@ def test_window_semi_trace_matches_the_reference(name):
     res, cig = scenario_oracle(name).window_trace(t, mode=3)
     want, wcig = g[name + "_sres"], g[name + "_scig"]
     assert (res == want).all(), np.flatnonzero((res != want).any(axis=1))[:10]
+    off = np.concatenate(([0], np.cumsum(want[:, 5])))
+    bad = [q for q in range(t.shape[0]) if not (cig[q, :want[q, 5]] == wcig[off[q]:off[q + 1]]).all()]
+    assert not bad, bad[:10]
+    assert (res[:, 0] != 2**31 - 1).sum() > 300
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("name", ["hifi", "ont", "nn", "edge"])
+def test_window_extension_trace_matches_the_reference(name, mode):
+    g = np.load(os.path.join(GOLDEN, "ed.npz"))
+    t = ed_ext_tasks(name)
+    assert t.shape == g[name + "_xtasks"].shape and (t == g[name + "_xtasks"]).all(), "task generator drifted: regenerate tests/golden/ed.npz"
+    res, cig = scenario_oracle(name).window_trace(t, mode=mode)
+    want, wcig = g[f"{name}_x{mode}res"], g[f"{name}_x{mode}cig"]
+    assert (res == want).all(), (np.flatnonzero((res != want).any(axis=1))[:10], res[(res != want).any(axis=1)][:3], want[(res != want).any(axis=1)][:3])
     off = np.concatenate(([0], np.cumsum(want[:, 5])))
     bad = [q for q in range(t.shape[0]) if not (cig[q, :want[q, 5]] == wcig[off[q]:off[q + 1]]).all()]
     assert not bad, bad[:10]
