@@ -66,11 +66,9 @@ __device__ __forceinline__ uint32_t hao_run_ends16(const uint8_t *rd, uint32_t l
 }
 
 __device__ __forceinline__ uint32_t hao_wave_excl_scan(uint32_t v, uint32_t *total)
-{
-	uint32_t x = v; int lane = hao_lane();
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d); if (lane >= d) x += y; }
-	*total = __shfl(x, 63);
+{	// (DPP row / bank moves: no LDS crossbar trips)
+	const uint32_t x = hao_wave_incl_scan_u32(v);
+	*total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 	return x - v;
 }
 
@@ -530,19 +528,30 @@ __global__ __launch_bounds__(256) void sketch_chunk_wave_kernel(hao_sk_args a)
 		s_base = base; a.chunk_base[ch] = base; a.chunk_cnt[ch] = run;
 	}
 	__syncthreads();
-	if (s_wcnt[wv] == 0xffffffffu || mine == 0) return;
-	uint64_t o = s_base + s_wcnt[wv] + lane_off;
-	const int q0 = lane * 8, e0 = kw0 + q0 - rbase;
+	if (s_wcnt[wv] == 0xffffffffu || wtot == 0) return;
+	// A wave marks ~16 of its 512 entries.  Writing them from where they sit would run the output code eight times (once per register slot) with two or
+	// three lanes active each time; instead the marked entries are listed in LDS (entry number, key) in output order and the first lanes of the wave write
+	// one minimizer each: one pass, consecutive lanes on consecutive addresses.  (64 per round; more than 64 marks per wave means a degenerate read.)
+	__shared__ uint16_t l_q[4][64]; __shared__ uint64_t l_x[4][64]; __shared__ uint32_t l_c[4][64];
+	const uint64_t obase = s_base + s_wcnt[wv]; const int q0 = lane * 8;
+	for (uint32_t done = 0; done < wtot; done += 64) {
+		uint32_t rnk = lane_off;
 #pragma unroll
-	for (int i = 0; i < 8; ++i) {
-		if (!mk[i]) continue;
-		const int e = e0 + i, s1 = e - k + 1, wi = s1 >> 6, sh = s1 & 63;
-		uint64_t W1 = pl1[wi] >> sh; if (sh) W1 |= pl1[wi + 1] << (64 - sh); W1 &= mask;
-		const uint32_t rev = (__brevll(W1) >> (64 - k)) < (~W1 & mask) ? 0 : 1;
-		a.pool_x[o] = key[i].x;
-		a.pool_info[o] = hao_info_pack(HAS_FT ? key[i].c : 0, end1[e] - 1, rev, end1[e] - end1[e - k]);
-		a.pool_ord[o] = (uint32_t)(kw0 + q0 + i);
-		++o;
+		for (int i = 0; i < 8; ++i) {
+			if (mk[i]) { const uint32_t at = rnk - done; if (at < 64u) { l_q[wv][at] = (uint16_t)(q0 + i); l_x[wv][at] = key[i].x; if (HAS_FT) l_c[wv][at] = key[i].c; } ++rnk; }
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		const uint32_t b = done + (uint32_t)lane;
+		if (b < wtot) {
+			const int q = l_q[wv][lane], e = kw0 + q - rbase, s1 = e - k + 1, wi = s1 >> 6, sh = s1 & 63;
+			uint64_t W1 = pl1[wi] >> sh; if (sh) W1 |= pl1[wi + 1] << (64 - sh); W1 &= mask;
+			const uint32_t rev = (__brevll(W1) >> (64 - k)) < (~W1 & mask) ? 0 : 1;
+			const uint64_t o = obase + b;
+			a.pool_x[o] = l_x[wv][lane];
+			a.pool_info[o] = hao_info_pack(HAS_FT ? l_c[wv][lane] : 0, end1[e] - 1, rev, end1[e] - end1[e - k]);
+			a.pool_ord[o] = (uint32_t)(kw0 + q);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 	}
 }
 
