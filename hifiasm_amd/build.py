@@ -58,7 +58,7 @@ def build_hip(force=False):
 
 def build_oracle(force=False):
     out = os.path.join(ORACLE, "liboracle.so")
-    deps = [os.path.join(ORACLE, "hao_oracle.c"), os.path.join(ORACLE, "hao_oracle.h")]
+    deps = [os.path.join(ORACLE, "hao_oracle.c"), os.path.join(ORACLE, "hao_oracle.h"), os.path.join(ORACLE, "hao_oracle_ed.inc")]
     if force or _newer(out, deps):
         _run(["make", "-C", ORACLE, "liboracle.so"] + (["-B"] if force else []))
     return out

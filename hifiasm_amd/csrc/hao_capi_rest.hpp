@@ -196,14 +196,18 @@ int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks
 	for (uint64_t i = 0; i < n_tasks; ++i) {      // the reference indexes its strings unchecked; a device kernel must not
 		const hao_ed_task_t &t = tasks[i];
 		if (t.p_rid >= c->n_reads || t.t_rid >= c->n_reads || (uint64_t)t.p_pos + t.p_len > c->h_len[t.p_rid] || (uint64_t)t.t_pos + t.t_len > c->h_len[t.t_rid] ||
-			2 * (uint64_t)t.thre + 1 > 63 || t.abs_diag > 2 * t.thre) { hao_set_err(c, "hao_window_ed_batch: task " + std::to_string(i) + " out of range"); return HAO_EINVAL; }
+			2 * (uint64_t)t.thre + 1 > 127 || t.abs_diag > 2 * t.thre) { hao_set_err(c, "hao_window_ed_batch: task " + std::to_string(i) + " out of range"); return HAO_EINVAL; }
+		if (2 * (uint64_t)t.thre + 1 > 64 && (int64_t)t.p_len - (int64_t)t.t_len + (int64_t)t.abs_diag > 128) {      // the final scan would read VP / VN bits beyond the two words (the reference then indexes the neighbouring vectors of its bit_extz_t)
+			hao_set_err(c, "hao_window_ed_batch: task " + std::to_string(i) + ": p_len - t_len + abs_diag > 128 with a two-word band"); return HAO_EINVAL; }
 	}
 	HIP_TRY(hipSetDevice(c->device));
 	DevBuf<hao_ed_task_t> dt; DevBuf<hao_ed_result_t> dr;
 	HIP_TRY(dt.reserve(n_tasks)); HIP_TRY(dr.reserve(n_tasks));
 	HIP_TRY(hipMemcpyAsync(dt.p, tasks, n_tasks * sizeof(hao_ed_task_t), hipMemcpyHostToDevice, c->stream));
 	hao_ed_reads R; R.packed = c->d_packed.p; R.pk_off = c->d_pk_off.p; R.len = c->d_len.p; R.nsite_off = c->has_n ? c->d_nsite_off.p : nullptr; R.nsite = c->has_n ? c->d_nsite.p : nullptr;
-	hipLaunchKernelGGL(hao_window_ed_kernel, dim3((unsigned)((n_tasks + 255) / 256)), dim3(256), 0, c->stream, R, dt.p, n_tasks, dr.p);
+	bool wide = false; for (uint64_t i = 0; i < n_tasks && !wide; ++i) wide = 2 * (uint64_t)tasks[i].thre + 1 > 64;      // bands of 65 .. 127 diagonals: the two-word instantiation takes those tasks
+	hipLaunchKernelGGL(hao_window_ed_kernel<uint64_t>, dim3((unsigned)((n_tasks + 255) / 256)), dim3(256), 0, c->stream, R, dt.p, n_tasks, dr.p);
+	if (wide) { HAO_CHECK_LAUNCH(); hipLaunchKernelGGL(hao_window_ed_kernel<hao_u128>, dim3((unsigned)((n_tasks + 255) / 256)), dim3(256), 0, c->stream, R, dt.p, n_tasks, dr.p); }
 	HAO_CHECK_LAUNCH();
 	HIP_TRY(hipMemcpyAsync(out, dr.p, n_tasks * sizeof(hao_ed_result_t), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
@@ -217,11 +221,12 @@ int hao_window_trace_batch(hao_ctx *c, int mode, const hao_ed_task_t *tasks, uin
 	if (int rc = hao_view_refresh(c)) return rc;
 	if (c->comm && c->comm->active()) { hao_set_err(c, "hao_window_trace_batch needs the bases of both reads: single-device mode only"); return HAO_EUNSUPP; }
 	if (n_tasks == 0) return HAO_OK;
-	uint64_t tn_max = 1;
+	uint64_t tn_max = 1; bool wide = false;      // wide: some band needs two 64-bit words (thre 32 .. 63)
 	for (uint64_t i = 0; i < n_tasks; ++i) {      // the reference indexes its strings unchecked; a device kernel must not
 		const hao_ed_task_t &t = tasks[i];
 		if (t.p_rid >= c->n_reads || t.t_rid >= c->n_reads || (uint64_t)t.p_pos + t.p_len > c->h_len[t.p_rid] || (uint64_t)t.t_pos + t.t_len > c->h_len[t.t_rid] ||
-			2 * (uint64_t)t.thre + 1 > 63) { hao_set_err(c, "hao_window_trace_batch: task " + std::to_string(i) + " out of range"); return HAO_EINVAL; }
+			2 * (uint64_t)t.thre + 1 > 127) { hao_set_err(c, "hao_window_trace_batch: task " + std::to_string(i) + " out of range"); return HAO_EINVAL; }
+		if (2 * (uint64_t)t.thre + 1 > 64) wide = true;
 		if (mode == HAO_ALIGN_SEMI) {
 			const int64_t ai = (int64_t)t.p_len - (int64_t)t.t_len + (int64_t)t.abs_diag;
 			if (ai < 0 || ai > 2 * (int64_t)t.thre || t.t_len <= t.abs_diag) { hao_set_err(c, "hao_window_trace_batch: task " + std::to_string(i) + ": the band does not cover the pattern"); return HAO_EINVAL; }
@@ -230,17 +235,22 @@ int hao_window_trace_batch(hao_ctx *c, int mode, const hao_ed_task_t *tasks, uin
 	}
 	HIP_TRY(hipSetDevice(c->device));
 	// the forward sweep keeps 40 bytes per text base and pair: the tasks go through in slices whose columns fit ~4 GB
-	const uint64_t slice = std::max<uint64_t>(256, std::min<uint64_t>(n_tasks, (4ULL << 30) / (40 * tn_max)) & ~255ULL);
+	const uint64_t cw = wide ? 10 : 5;      // 64-bit words kept per text column
+	const uint64_t slice = std::max<uint64_t>(256, std::min<uint64_t>(n_tasks, (4ULL << 30) / (8 * cw * tn_max)) & ~255ULL);
 	DevBuf<hao_ed_task_t> dt; DevBuf<hao_trace_result_t> dr; DevBuf<uint16_t> dc; DevBuf<uint64_t> path;
-	HIP_TRY(dt.reserve(slice)); HIP_TRY(dr.reserve(slice)); HIP_TRY(dc.reserve(slice * (uint64_t)cigar_cap + 1)); HIP_TRY(path.reserve(5 * tn_max * slice + 1));
+	HIP_TRY(dt.reserve(slice)); HIP_TRY(dr.reserve(slice)); HIP_TRY(dc.reserve(slice * (uint64_t)cigar_cap + 1)); HIP_TRY(path.reserve(cw * tn_max * slice + 1));
 	hao_ed_reads R; R.packed = c->d_packed.p; R.pk_off = c->d_pk_off.p; R.len = c->d_len.p; R.nsite_off = c->has_n ? c->d_nsite_off.p : nullptr; R.nsite = c->has_n ? c->d_nsite.p : nullptr;
 	for (uint64_t lo = 0; lo < n_tasks; lo += slice) {
 		const uint64_t m = std::min<uint64_t>(slice, n_tasks - lo);
 		HIP_TRY(hipMemcpyAsync(dt.p, tasks + lo, m * sizeof(hao_ed_task_t), hipMemcpyHostToDevice, c->stream));
-		if (mode == HAO_ALIGN_EXT_FWD) hipLaunchKernelGGL(hao_window_ext_trace_kernel<false>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, R, dt.p, m, path.p, slice, dr.p, dc.p, cigar_cap);
-		else if (mode == HAO_ALIGN_EXT_BWD) hipLaunchKernelGGL(hao_window_ext_trace_kernel<true>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, R, dt.p, m, path.p, slice, dr.p, dc.p, cigar_cap);
-		else if (mode == HAO_ALIGN_SEMI) hipLaunchKernelGGL(hao_window_trace_kernel<3>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, R, dt.p, m, path.p, slice, dr.p, dc.p, cigar_cap);
-		else hipLaunchKernelGGL(hao_window_trace_kernel<0>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, R, dt.p, m, path.p, slice, dr.p, dc.p, cigar_cap);
+		const dim3 g_((unsigned)((m + 255) / 256)), b_(256);
+#define HAO_TR_LAUNCH(K) do { hipLaunchKernelGGL((K<uint64_t>), g_, b_, 0, c->stream, R, dt.p, m, path.p, slice, dr.p, dc.p, cigar_cap); \
+		if (wide) { HAO_CHECK_LAUNCH(); hipLaunchKernelGGL((K<hao_u128>), g_, b_, 0, c->stream, R, dt.p, m, path.p, slice, dr.p, dc.p, cigar_cap); } } while (0)
+		if (mode == HAO_ALIGN_EXT_FWD) HAO_TR_LAUNCH(hao_tr_ext_fwd);
+		else if (mode == HAO_ALIGN_EXT_BWD) HAO_TR_LAUNCH(hao_tr_ext_bwd);
+		else if (mode == HAO_ALIGN_SEMI) HAO_TR_LAUNCH(hao_tr_semi);
+		else HAO_TR_LAUNCH(hao_tr_global);
+#undef HAO_TR_LAUNCH
 		HAO_CHECK_LAUNCH();
 		HIP_TRY(hipMemcpyAsync(out + lo, dr.p, m * sizeof(hao_trace_result_t), hipMemcpyDeviceToHost, c->stream));
 		if (cigar_cap) HIP_TRY(hipMemcpyAsync(cigars + lo * cigar_cap, dc.p, m * (uint64_t)cigar_cap * 2, hipMemcpyDeviceToHost, c->stream));

@@ -1102,54 +1102,6 @@ static inline uint8_t ed_chr(const hao_or_ctx *c, uint32_t rid, int64_t pos, int
 	return b > 3 ? 4 : (rev ? (uint8_t)(3 - b) : b);
 }
 
-void hao_or_window_ed(const hao_or_ctx *c, const uint32_t *task, int64_t n, int32_t *out)
-{
-	int64_t q;
-	for (q = 0; q < n; ++q) {
-		const uint32_t *t = task + 10 * q;
-		int32_t pn = (int32_t)t[2], tn = (int32_t)t[6], thre = (int32_t)t[8], abs_diag = (int32_t)t[9];
-		int32_t e_out = INT32_MAX, pe_out = -1;
-		uint64_t Peq[5] = {0, 0, 0, 0, 0}, VP = 0, VN, X, D0, HN, HP, mm;
-		int32_t bd, i, err = abs_diag, i_bd, tn0 = tn - 1, cut = thre + (thre << 1), dead = 0;
-#define PCH(k) ed_chr(c, t[0], (int64_t)t[1] + (k), (int)t[3])
-#define TCH(k) ed_chr(c, t[4], (int64_t)t[5] + (k), (int)t[7])
-#define CORE(z) do { X = Peq[(z)] | VN; D0 = ((VP + (X & VP)) ^ VP) | X; HN = VP & D0; HP = VN | ~(VP | D0); X = D0 >> 1; VN = X & HP; VP = HN | ~(X | HP); } while (0)
-		if (!(pn > tn + cut || tn > pn + cut) && tn > 0) {
-			bd = ((thre << 1) + 1) - abs_diag; if (bd > pn) bd = pn;
-			i_bd = abs_diag;
-			for (i = 0, mm = 1ULL << i_bd; i < bd; ++i) { Peq[PCH(i)] |= mm; mm <<= 1; }
-			i_bd = (thre << 1) - abs_diag; VN = (1ULL << abs_diag) - 1;
-			Peq[4] = 0; mm = 1ULL << (thre << 1);
-			for (i = 0; i < tn0 && !dead; ) {
-				uint8_t cc;
-				CORE(TCH(i));
-				if (!(D0 & 1ULL)) { ++err; if (err > cut) { dead = 1; break; } }
-				Peq[0] >>= 1; Peq[1] >>= 1; Peq[2] >>= 1; Peq[3] >>= 1;
-				++i; ++i_bd; cc = 4;
-				if (i_bd < pn) cc = PCH(i_bd);
-				if (cc < 4) Peq[cc] |= mm;
-			}
-			if (!dead) { CORE(TCH(i)); if (!(D0 & 1ULL)) { ++err; if (err > cut) dead = 1; } }
-			if (!dead) {
-				int32_t site = tn - 1 - abs_diag, ai = pn - tn + abs_diag, uge = INT32_MAX;
-				for (i = 0; site < 0 && i < ai; ++i, ++site) { err += (int32_t)((VP >> i) & 1ULL); err -= (int32_t)((VN >> i) & 1ULL); }
-				if (err <= thre && err <= e_out) { e_out = err; pe_out = site; }
-				site -= i;
-				while (i < ai) {
-					err += (int32_t)((VP >> i) & 1ULL); err -= (int32_t)((VN >> i) & 1ULL); ++i;
-					if (err <= thre && err <= e_out) { e_out = err; pe_out = site + i; }
-					if (i == thre) uge = err;
-				}
-				if (uge <= thre && uge == e_out) pe_out = site + thre;
-			}
-		}
-#undef PCH
-#undef TCH
-#undef CORE
-		out[2 * q] = e_out; out[2 * q + 1] = pe_out;
-	}
-}
-
 /* ------------------------------------------------------------------ */
 /* f3, second variant: global alignment inside the band WITH traceback:
  * ed_band_cal_global_64_w_trace (Levenshtein_distance.h:3370-3442) on a cleared bit_extz_t, then gen_trace(ez, thre, 1) (:903-985).
@@ -1166,174 +1118,31 @@ static void tr_push(uint16_t *cg, int64_t cap, int32_t *n, int32_t op, int32_t l
 	if (len) { if (*n < cap) cg[*n] = (uint16_t)((op << 14) + len); ++*n; }
 }
 
-/* modes 1 / 2: ed_band_cal_extension_64_0_w_trace (Levenshtein_distance.h:3512-3618) / ed_band_cal_extension_64_1_w_trace (:3620-3735) on a cleared
- * bit_extz_t.  Forward extension: both strings start together, the alignment may end wherever the pattern or the text runs out (the longer string is
- * first cut to the other's length + thre); the best end is tracked along the pattern's last row (tmp_e) while the text is swept, then along the last
- * column.  Backward extension is the same sweep over both strings read from their ends (ps / ts move instead of pe / te, and the cigar is not
- * reversed).  A sweep abandoned because the running error passed 3 thre RETURNS before gen_trace: an end found earlier keeps its err / coordinates but
- * gets no cigar - restated as is.  *path_p / *path_m: scratch of the caller. */
-static void tr_extension(const hao_or_ctx *c, const uint32_t *t, int back, int32_t *o, uint16_t *cg, int64_t cap, uint64_t **path_p, int64_t *path_m)
+#define HAO_CAT_(a, b) a##b
+#define HAO_CAT(a, b) HAO_CAT_(a, b)
+#define WT uint64_t
+#define FN(x) HAO_CAT(ed64_, x)
+#include "hao_oracle_ed.inc"
+#undef WT
+#undef FN
+#define WT unsigned __int128
+#define FN(x) HAO_CAT(ed128_, x)
+#include "hao_oracle_ed.inc"
+#undef WT
+#undef FN
+
+/* one band width per call, chosen like cal_exz_global does (Correct.cpp:15482-15494): 2 thre + 1 diagonals in one 64-bit word, else in two */
+void hao_or_window_ed(const hao_or_ctx *c, const uint32_t *task, int64_t n, int32_t *out)
 {
-	const int32_t pn0 = (int32_t)t[2], tn0_ = (int32_t)t[6], thre = (int32_t)t[8], pidx = pn0 - 1, tidx = tn0_ - 1;
-	int32_t pn = pn0, tn = tn0_, i, err, i_bd, bd, cut = thre + (thre << 1), pe_l, tmp_e = INT32_MAX, k, poff, site, ncg = 0;
-	int32_t ez_err = INT32_MAX, a_p = -1, a_t = -1;      /* the moving end: pe / te (forward), or its mirror pidx - ps / tidx - ts (backward) */
-	uint64_t Peq[5] = {0, 0, 0, 0, 0}, VP, VN, X, D0, HN, HP, mm, *path;
-#define PCH(k_) ed_chr(c, t[0], (int64_t)t[1] + (back ? pidx - (k_) : (k_)), (int)t[3])
-#define TCH(k_) ed_chr(c, t[4], (int64_t)t[5] + (back ? tidx - (k_) : (k_)), (int)t[7])
-#define CORE(z) do { X = Peq[(z)] | VN; D0 = ((VP + (X & VP)) ^ VP) | X; HN = VP & D0; HP = VN | ~(VP | D0); X = D0 >> 1; VN = X & HP; VP = HN | ~(X | HP); } while (0)
-#define KEEP() do { uint64_t *w_ = path + 5 * (int64_t)i; w_[0] = D0; w_[1] = VP; w_[2] = VN; w_[3] = HP; w_[4] = HN; } while (0)
-#define PUT() do { if (back) { o[0] = ez_err; o[1] = ez_err <= thre ? pidx - a_p : INT32_MAX; o[2] = pidx; o[3] = ez_err <= thre ? tidx - a_t : INT32_MAX; o[4] = tidx; } \
-		else { o[0] = ez_err; o[1] = 0; o[2] = a_p; o[3] = 0; o[4] = a_t; } o[5] = ncg; } while (0)
-	PUT();
-	if (pn0 <= 0 || tn0_ <= 0) return;
-	if (pn > tn + thre) pn = tn + thre; else if (tn > pn + thre) tn = pn + thre;
-	if (5 * (int64_t)tn > *path_m) { *path_m = 5 * (int64_t)tn + 64; *path_p = (uint64_t*)realloc(*path_p, *path_m * 8); }
-	path = *path_p; pe_l = pn - 1;
-	bd = thre + 1; if (bd > pn) bd = pn;
-	for (i = 0, mm = 1ULL << thre; i < bd; ++i) { Peq[PCH(i)] |= mm; mm <<= 1; }
-	i_bd = thre; Peq[4] = 0; err = thre;
-	VN = (1ULL << thre) - 1; VP = ((1ULL << ((thre << 1) + 1)) - 1) ^ VN;
-	mm = 1ULL << (thre << 1);
-	for (i = 0; i < tn - 1; ) {
-		CORE(TCH(i));
-		if (!(D0 & 1ULL)) { ++err; if (err > cut) { PUT(); return; } }
-		poff = i - thre; k = i + thre - pe_l;
-		if (k >= 0) {
-			if (tmp_e == INT32_MAX) { tmp_e = err; for (k = 0; poff < pe_l; ++poff, ++k) { tmp_e += (int32_t)((VP >> k) & 1ULL); tmp_e -= (int32_t)((VN >> k) & 1ULL); } }
-			else { k = (thre << 1) - k; if (k >= 0) { tmp_e += (int32_t)((HP >> k) & 1ULL); tmp_e -= (int32_t)((HN >> k) & 1ULL); } }
-			if (tmp_e <= thre && tmp_e < ez_err) { ez_err = tmp_e; a_p = pe_l; a_t = i; }
-		}
-		Peq[0] >>= 1; Peq[1] >>= 1; Peq[2] >>= 1; Peq[3] >>= 1;
-		KEEP();
-		++i; ++i_bd;
-		if (i_bd < pn) { uint8_t cc = PCH(i_bd); if (cc < 4) Peq[cc] |= mm; }
-	}
-	CORE(TCH(i));
-	if (!(D0 & 1ULL)) { ++err; if (err > cut) { PUT(); return; } }
-	KEEP();
-	site = tn - 1 - thre;
-	while (site < pn - 1) {
-		err += (int32_t)(VP & 1ULL); VP >>= 1; err -= (int32_t)(VN & 1ULL); VN >>= 1; ++site;
-		if (err <= thre && err < ez_err) { ez_err = err; a_p = site; a_t = tn - 1; }
-	}
-	if (err <= thre && err < ez_err) { ez_err = err; a_p = site; a_t = tn - 1; }
-	if (ez_err <= thre) {      /* gen_trace(ez, thre, !back) on the columns 0 .. a_t; ps (mirrored for the backward sweep) = 0 is known */
-		const int32_t low = thre << 1; int32_t sft = thre + a_p - a_t, cur = ez_err, d = 0, pd = -1, pdn = 0, mn, D, H, V, wm;
-		poff = a_p; i = a_t + 1;
-		while (i > 0 && cur > 0) {
-			const uint64_t *w_ = path + 5 * (int64_t)(i - 1); const uint64_t d0 = w_[0], vp = w_[1], vn = w_[2], hp = w_[3], hn = w_[4];
-			wm = sft & 63;
-			D = cur - (int32_t)((~(d0 >> wm)) & 1ULL); d = 0; mn = D;
-			if (sft != low) { H = cur + (int32_t)((hn >> wm) & 1ULL) - (int32_t)((hp >> wm) & 1ULL); if (H + 1 == cur && H <= mn) { mn = H; d = 3; } }
-			if (sft != 0) { wm = (sft - 1) & 63; V = cur + (int32_t)((vn >> wm) & 1ULL) - (int32_t)((vp >> wm) & 1ULL); if (V + 1 == cur && V <= mn) { mn = V; d = 2; } }
-			if (d == 0) { if (D != cur) d = 1; --i; --poff; }
-			else if (d == 2) { --sft; --poff; }
-			else { --i; ++sft; }
-			if (d == pd) ++pdn; else { if (pdn > 0) tr_push(cg, cap, &ncg, pd, pdn); pd = d; pdn = 1; }
-			cur = mn;
-		}
-		if (i > 0) { d = 0; poff -= i; if (d == pd) pdn += i; else { if (pdn > 0) tr_push(cg, cap, &ncg, pd, pdn); pd = d; pdn = i; } }
-		++poff;
-		if (poff > 0) { d = 2; if (d == pd) pdn += poff; else { if (pdn > 0) tr_push(cg, cap, &ncg, pd, pdn); pd = d; pdn = poff; } }
-		if (pdn > 0) tr_push(cg, cap, &ncg, pd, pdn);
-		if (!back && ncg <= cap) for (k = 0; k < ncg / 2; ++k) { uint16_t x_ = cg[k]; cg[k] = cg[ncg - 1 - k]; cg[ncg - 1 - k] = x_; }
-	}
-	PUT();
-#undef PCH
-#undef TCH
-#undef CORE
-#undef KEEP
-#undef PUT
+	int64_t q;
+	for (q = 0; q < n; ++q) { if (2 * task[10 * q + 8] + 1 <= 64) ed64_window_ed(c, task + 10 * q, 1, out + 2 * q); else ed128_window_ed(c, task + 10 * q, 1, out + 2 * q); }
 }
 
 void hao_or_window_trace(const hao_or_ctx *c, const uint32_t *task, int64_t n, int mode, int32_t *out, uint16_t *cig, int64_t cap)
-{	/* mode 0: ed_band_cal_global_64_w_trace (:3370); mode 3: ed_band_cal_semi_64_w_absent_diag_trace (:3778) - the numbering of Correct.cpp:14536-14545 */
-	int64_t q; uint64_t *path = 0; int64_t path_m = 0;
+{
+	int64_t q;
 	for (q = 0; q < n; ++q) {
-		const uint32_t *t = task + 10 * q; int32_t *o = out + 6 * q; uint16_t *cg = cig + q * cap;
-		const int32_t pn = (int32_t)t[2], tn = (int32_t)t[6], thre = (int32_t)t[8], abs_diag = mode == 3 ? (int32_t)t[9] : 0;
-		if (mode == 1 || mode == 2) { tr_extension(c, t, mode == 2, o, cg, cap, &path, &path_m); continue; }
-		uint64_t Peq[5] = {0, 0, 0, 0, 0}, VP, VN, X, D0, HN, HP, mm;
-		int32_t i, err, i_bd, bd, tn0 = tn - 1, cut = thre + (thre << 1), ez_err = INT32_MAX, pe = -1, ncg = 0, dead = 0;
-#define PCH(k) ed_chr(c, t[0], (int64_t)t[1] + (k), (int)t[3])
-#define TCH(k) ed_chr(c, t[4], (int64_t)t[5] + (k), (int)t[7])
-#define CORE(z) do { X = Peq[(z)] | VN; D0 = ((VP + (X & VP)) ^ VP) | X; HN = VP & D0; HP = VN | ~(VP | D0); X = D0 >> 1; VN = X & HP; VP = HN | ~(X | HP); } while (0)
-#define KEEP() do { uint64_t *w_ = path + 5 * (int64_t)i; w_[0] = D0; w_[1] = VP; w_[2] = VN; w_[3] = HP; w_[4] = HN; } while (0)
-		o[0] = INT32_MAX; o[1] = mode == 3 ? -1 : 0; o[2] = -1; o[3] = 0; o[4] = mode == 3 ? tn - 1 : -1; o[5] = 0;
-		if (pn <= 0 || tn <= 0) continue;
-		if (mode == 0) { if (pn > tn + thre || tn > pn + thre) continue; }
-		else if (pn > tn + cut || tn > pn + cut) continue;
-		if (5 * (int64_t)tn > path_m) { path_m = 5 * (int64_t)tn + 64; path = (uint64_t*)realloc(path, path_m * 8); }
-		if (mode == 0) {
-			bd = thre + 1; if (bd > pn) bd = pn;
-			for (i = 0, mm = 1ULL << thre; i < bd; ++i) { Peq[PCH(i)] |= mm; mm <<= 1; }
-			i_bd = thre; err = thre;
-			VN = (1ULL << thre) - 1; VP = ((1ULL << ((thre << 1) + 1)) - 1) ^ VN;
-		} else {
-			bd = ((thre << 1) + 1) - abs_diag; if (bd > pn) bd = pn;
-			for (i = 0, mm = 1ULL << abs_diag; i < bd; ++i) { Peq[PCH(i)] |= mm; mm <<= 1; }
-			i_bd = (thre << 1) - abs_diag; err = abs_diag;
-			VP = 0; VN = (1ULL << abs_diag) - 1;
-		}
-		Peq[4] = 0; mm = 1ULL << (thre << 1);
-		for (i = 0; i < tn0; ) {
-			uint8_t cc = 4;
-			CORE(TCH(i));
-			if (!(D0 & 1ULL)) { ++err; if (err > cut) { dead = 1; break; } }
-			Peq[0] >>= 1; Peq[1] >>= 1; Peq[2] >>= 1; Peq[3] >>= 1;
-			KEEP();      /* (the reference stores the column after the shifts; the words themselves are not touched by them) */
-			++i; ++i_bd;
-			if (i_bd < pn) cc = PCH(i_bd);
-			if (cc < 4) Peq[cc] |= mm;
-		}
-		if (dead) continue;
-		CORE(TCH(i));
-		if (!(D0 & 1ULL)) { ++err; if (err > cut) continue; }
-		KEEP();
-		if (mode == 0) {
-			int32_t site = tn - 1 - thre;
-			for (; site < pn - 1; ++site) { err += (int32_t)(VP & 1ULL); VP >>= 1; err -= (int32_t)(VN & 1ULL); VN >>= 1; }
-			if (site == pn - 1 && err <= thre) { ez_err = err; pe = pn - 1; }
-		} else {
-			int32_t site = tn - 1 - abs_diag, ai = pn - tn + abs_diag, uge = INT32_MAX;
-			for (i = 0; site < 0 && i < ai; ++i, ++site) { err += (int32_t)((VP >> i) & 1ULL); err -= (int32_t)((VN >> i) & 1ULL); }
-			if (err <= thre && err <= ez_err) { ez_err = err; pe = site; }
-			site -= i;
-			while (i < ai) {
-				err += (int32_t)((VP >> i) & 1ULL); err -= (int32_t)((VN >> i) & 1ULL); ++i;
-				if (err <= thre && err <= ez_err) { ez_err = err; pe = site + i; }
-				if (i == thre) uge = err;
-			}
-			if (uge <= thre && uge == ez_err) pe = site + thre;
-		}
-		if (ez_err > thre) continue;
-		{	/* gen_trace(ez, ptrim, reverse = 1): ptrim = thre (global: ps = 0 is known) / abs_diag (semi: ps comes out of the walk); ts = 0, te = tn - 1 */
-			const int32_t low = thre << 1, ptrim = mode == 0 ? thre : abs_diag; int32_t sft = (low + 1) - (tn + low - pe - ptrim), poff = pe, cur = ez_err, d = 0, pd = -1, pdn = 0, mn, D, H, V, wm, k, ps = 0;
-			i = tn;
-			while (i > 0 && cur > 0) {
-				const uint64_t *w_ = path + 5 * (int64_t)(i - 1); const uint64_t d0 = w_[0], vp = w_[1], vn = w_[2], hp = w_[3], hn = w_[4];
-				wm = sft & 63;
-				D = cur - (int32_t)((~(d0 >> wm)) & 1ULL); d = 0; mn = D;
-				if (sft != low) { H = cur + (int32_t)((hn >> wm) & 1ULL) - (int32_t)((hp >> wm) & 1ULL); if (H + 1 == cur && H <= mn) { mn = H; d = 3; } }
-				if (sft != 0) { wm = (sft - 1) & 63; V = cur + (int32_t)((vn >> wm) & 1ULL) - (int32_t)((vp >> wm) & 1ULL); if (V + 1 == cur && V <= mn) { mn = V; d = 2; } }
-				if (d == 0) { if (D != cur) d = 1; --i; --poff; }
-				else if (d == 2) { --sft; --poff; }
-				else { --i; ++sft; }
-				if (d == pd) ++pdn; else { if (pdn > 0) tr_push(cg, cap, &ncg, pd, pdn); pd = d; pdn = 1; }
-				cur = mn;
-			}
-			if (i > 0) { d = 0; poff -= i; if (d == pd) pdn += i; else { if (pdn > 0) tr_push(cg, cap, &ncg, pd, pdn); pd = d; pdn = i; } }
-			++poff;
-			if (mode == 3) ps = poff;      /* ps was unavailable (-1): the walk's start */
-			else if (poff > 0) { d = 2; if (d == pd) pdn += poff; else { if (pdn > 0) tr_push(cg, cap, &ncg, pd, pdn); pd = d; pdn = poff; } }      /* ps = 0 is known: leading pattern bases are "more pattern" */
-			if (pdn > 0) tr_push(cg, cap, &ncg, pd, pdn);
-			if (ncg <= cap) for (k = 0; k < ncg / 2; ++k) { uint16_t x_ = cg[k]; cg[k] = cg[ncg - 1 - k]; cg[ncg - 1 - k] = x_; }
-			o[0] = ez_err; o[1] = ps; o[2] = pe; o[3] = 0; o[4] = tn - 1; o[5] = ncg;
-		}
-#undef PCH
-#undef TCH
-#undef CORE
-#undef KEEP
+		if (2 * task[10 * q + 8] + 1 <= 64) ed64_window_trace(c, task + 10 * q, 1, mode, out + 6 * q, cig + q * cap, cap);
+		else ed128_window_trace(c, task + 10 * q, 1, mode, out + 6 * q, cig + q * cap, cap);
 	}
-	free(path);
 }

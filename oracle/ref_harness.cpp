@@ -216,13 +216,14 @@ int main(int argc, char *argv[])
 		std::vector<uint32_t> tk; uint32_t rec[10];
 		while (fread(rec, 4, 10, fp) == 10) tk.insert(tk.end(), rec, rec + 10);
 		fclose(fp);
-		std::vector<int32_t> res; std::vector<char> ps, ts; bit_extz_t ez; memset(&ez, 0, sizeof(ez));
+		std::vector<int32_t> res; std::vector<char> ps, ts; bit_extz_t ez; init_bit_extz_t(&ez, 63);
 		for (size_t i = 0; i + 10 <= tk.size(); i += 10) {
 			const uint32_t *t = &tk[i];
 			ps.resize(t[2] + 8); ts.resize(t[6] + 8);
 			recover_UC_Read_sub_region(ps.data(), t[1], t[2], (uint8_t)t[3], &R_INF, t[0]);
 			recover_UC_Read_sub_region(ts.data(), t[5], t[6], (uint8_t)t[7], &R_INF, t[4]);
-			ed_band_cal_semi_64_w_absent_diag(ps.data(), (int32_t)t[2], ts.data(), (int32_t)t[6], (int32_t)t[8], (int32_t)t[9], &ez);
+			if (2 * t[8] + 1 <= 64) ed_band_cal_semi_64_w_absent_diag(ps.data(), (int32_t)t[2], ts.data(), (int32_t)t[6], (int32_t)t[8], (int32_t)t[9], &ez);
+			else ed_band_cal_semi_128_w_absent_diag(ps.data(), (int32_t)t[2], ts.data(), (int32_t)t[6], (int32_t)t[8], (int32_t)t[9], &ez);      // (bands of 65 .. 127 diagonals: HA_ED_INIT(128))
 			res.push_back(ez.err); res.push_back(ez.pe);
 		}
 		wr(prefix, "ed.i32", res.data(), 4 * res.size());
@@ -234,17 +235,25 @@ int main(int argc, char *argv[])
 		std::vector<uint32_t> tk; uint32_t rec[10];
 		while (fread(rec, 4, 10, fp) == 10) tk.insert(tk.end(), rec, rec + 10);
 		fclose(fp);
-		std::vector<int32_t> res; std::vector<uint16_t> cg; std::vector<char> ps, ts; bit_extz_t ez; memset(&ez, 0, sizeof(ez));
+		std::vector<int32_t> res; std::vector<uint16_t> cg; std::vector<char> ps, ts; bit_extz_t ez; init_bit_extz_t(&ez, 63);
 		for (size_t i = 0; i + 10 <= tk.size(); i += 10) {
 			const uint32_t *t = &tk[i];
 			ps.resize(t[2] + 8); ts.resize(t[6] + 8);
 			recover_UC_Read_sub_region(ps.data(), t[1], t[2], (uint8_t)t[3], &R_INF, t[0]);
 			recover_UC_Read_sub_region(ts.data(), t[5], t[6], (uint8_t)t[7], &R_INF, t[4]);
 			clear_align(ez); ez.pe = ez.te = -1; ez.cigar.n = 0;
-			if (tm == 1) ed_band_cal_semi_64_w_absent_diag_trace(ps.data(), (int32_t)t[2], ts.data(), (int32_t)t[6], (int32_t)t[8], (int32_t)t[9], &ez);
-			else if (tm == 2) ed_band_cal_extension_64_0_w_trace(ps.data(), (int32_t)t[2], ts.data(), (int32_t)t[6], (int32_t)t[8], &ez);
-			else if (tm == 3) ed_band_cal_extension_64_1_w_trace(ps.data(), (int32_t)t[2], ts.data(), (int32_t)t[6], (int32_t)t[8], &ez);
-			else ed_band_cal_global_64_w_trace(ps.data(), (int32_t)t[2], ts.data(), (int32_t)t[6], (int32_t)t[8], &ez);
+			const int32_t pn_ = (int32_t)t[2], tn_ = (int32_t)t[6], th_ = (int32_t)t[8];
+			if (2 * th_ + 1 <= 64) {
+				if (tm == 1) ed_band_cal_semi_64_w_absent_diag_trace(ps.data(), pn_, ts.data(), tn_, th_, (int32_t)t[9], &ez);
+				else if (tm == 2) ed_band_cal_extension_64_0_w_trace(ps.data(), pn_, ts.data(), tn_, th_, &ez);
+				else if (tm == 3) ed_band_cal_extension_64_1_w_trace(ps.data(), pn_, ts.data(), tn_, th_, &ez);
+				else ed_band_cal_global_64_w_trace(ps.data(), pn_, ts.data(), tn_, th_, &ez);
+			} else {      // two words (HA_ED_INIT(128), Levenshtein_distance.h:2129): the choice of cal_exz_global, Correct.cpp:15482-15494
+				if (tm == 1) ed_band_cal_semi_128_w_absent_diag_trace(ps.data(), pn_, ts.data(), tn_, th_, (int32_t)t[9], &ez);
+				else if (tm == 2) ed_band_cal_extension_128_0_w_trace(ps.data(), pn_, ts.data(), tn_, th_, &ez);
+				else if (tm == 3) ed_band_cal_extension_128_1_w_trace(ps.data(), pn_, ts.data(), tn_, th_, &ez);
+				else ed_band_cal_global_128_w_trace(ps.data(), pn_, ts.data(), tn_, th_, &ez);
+			}
 			const bool ok = is_align(ez);
 			if (tm >= 2) { res.push_back(ok ? ez.err : INT32_MAX); res.push_back(ez.ps); res.push_back(ez.pe); res.push_back(ez.ts); res.push_back(ez.te); }
 			else { res.push_back(ok ? ez.err : INT32_MAX); res.push_back(ok ? ez.ps : (tm ? -1 : 0)); res.push_back(ok ? ez.pe : -1); res.push_back(ok ? ez.ts : 0); res.push_back(ok || tm ? (int32_t)t[6] - 1 : -1); }

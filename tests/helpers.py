@@ -92,8 +92,9 @@ def fold_digests(d, block=256):
 
 
 # ---- f3: window alignment tasks (hao_window_ed_batch / ed_band_cal_semi_64_w_absent_diag) ----
-def ed_tasks(name, n_reads=24, wl=775, seed=1):
-    """(pattern, text) pairs the way the window alignment forms them (Correct.cpp:3897): 775-base query windows of the overlaps h_ec_lchain found,
+def ed_tasks(name, n_reads=24, wl=775, seed=1, wide=False):
+    """wide = thresholds of 32 .. 63 (bands of two 64-bit words: the reference's 128-bit functions).
+    (pattern, text) pairs the way the window alignment forms them (Correct.cpp:3897): 775-base query windows of the overlaps h_ec_lchain found,
     against the target region on the overlap's diagonal padded by thre on both sides, clipped at the read ends (abs_diag = bases clipped at the start);
     plus degenerate and unrelated pairs.  uint32 [n,10]: p_rid, p_pos, p_len, p_rev, t_rid, t_pos, t_len, t_rev, thre, abs_diag."""
     rs, okw = scenario_reads(name)
@@ -108,7 +109,7 @@ def ed_tasks(name, n_reads=24, wl=775, seed=1):
             tl = int(L[yid])
             for ws in range(xs, xe + 1, wl):
                 tn = min(wl, xe + 1 - ws)
-                thre = int(rng.choice([0, 3, 8, 15, 24, 31]))
+                thre = int(rng.choice([32, 40, 50, 63] if wide else [0, 3, 8, 15, 24, 31]))
                 p0 = ys + (ws - xs) - thre + int(rng.integers(-3, 4))
                 p1 = p0 + tn + 2 * thre
                 ad = 0
@@ -125,13 +126,17 @@ def ed_tasks(name, n_reads=24, wl=775, seed=1):
             continue
         tn = int(rng.integers(1, min(900, int(L[b])) + 1))
         pn = int(rng.integers(1, min(1000, int(L[a])) + 1))
-        thre = int(rng.choice([0, 1, 5, 15, 31]))
+        thre = int(rng.choice([32, 45, 63] if wide else [0, 1, 5, 15, 31]))
         out.append((a, int(rng.integers(0, L[a] - pn + 1)), pn, int(rng.integers(0, 2)), b, int(rng.integers(0, L[b] - tn + 1)), tn, int(rng.integers(0, 2)),
                     thre, int(rng.integers(0, 2 * thre + 1))))
-    return np.array(out, dtype=np.uint32)
+    t = np.array(out, dtype=np.uint32)
+    if wide:      # the final scan reads bit i of VP / VN for i < p_len - t_len + abs_diag: beyond 128 the reference's two-word code indexes the neighbouring
+        ai = t[:, 2].astype(np.int64) - t[:, 6] + t[:, 9]      # vectors of its bit_extz_t (a one-word band just wraps its shift count): keep what is defined
+        t = t[ai <= 128]
+    return t
 
 
-def ed_global_tasks(name, n_reads=24, wl=775, seed=2):
+def ed_global_tasks(name, n_reads=24, wl=775, seed=2, wide=False):
     """(pattern, text) pairs for the GLOBAL window alignment with traceback (ed_band_cal_global_64_w_trace): query windows of the overlaps against the
     target interval on the overlap's diagonal (same length up to a few bases), plus unrelated / tiny / too-different pairs.  Same record layout as
     ed_tasks (abs_diag = 0)."""
@@ -147,7 +152,7 @@ def ed_global_tasks(name, n_reads=24, wl=775, seed=2):
             tl = int(L[yid])
             for ws in range(xs, xe + 1, wl):
                 tn = min(wl, xe + 1 - ws)
-                thre = int(rng.choice([0, 3, 8, 15, 24, 31]))
+                thre = int(rng.choice([32, 40, 50, 63] if wide else [0, 3, 8, 15, 24, 31]))
                 p0 = max(0, ys + (ws - xs) + int(rng.integers(-2, 3)))
                 p1 = min(tl, p0 + tn + int(rng.integers(-3, 4)))
                 if p1 <= p0 or tn <= 0:
@@ -158,13 +163,13 @@ def ed_global_tasks(name, n_reads=24, wl=775, seed=2):
         if L[a] < 2 or L[b] < 2:
             continue
         tn = int(rng.integers(1, min(400, int(L[b])) + 1))
-        thre = int(rng.choice([0, 1, 5, 15, 31]))
+        thre = int(rng.choice([32, 45, 63] if wide else [0, 1, 5, 15, 31]))
         pn = max(1, min(int(L[a]), tn + int(rng.integers(-thre - 2, thre + 3))))
         out.append((a, int(rng.integers(0, L[a] - pn + 1)), pn, int(rng.integers(0, 2)), b, int(rng.integers(0, L[b] - tn + 1)), tn, int(rng.integers(0, 2)), thre, 0))
     for a in range(min(rs.n, 40)):      # a read against itself and against its neighbourhood: exact and near-exact pairs, short strings
         if L[a] < 40:
             continue
-        n_ = int(rng.integers(1, 40)); p_ = int(rng.integers(0, L[a] - n_ + 1)); thre = int(rng.choice([0, 2, 7]))
+        n_ = int(rng.integers(1, 40)); p_ = int(rng.integers(0, L[a] - n_ + 1)); thre = int(rng.choice([33, 63] if wide else [0, 2, 7]))
         out.append((a, p_, n_, 0, a, p_, n_, 0, thre, 0))
         out.append((a, p_, n_, 1, a, int(L[a]) - p_ - n_, n_, 1, thre, 0))
         if p_ + n_ + 1 <= L[a]:
@@ -172,16 +177,16 @@ def ed_global_tasks(name, n_reads=24, wl=775, seed=2):
     return np.array(out, dtype=np.uint32)
 
 
-def ed_semi_trace_tasks(name, n_reads=24, seed=3):
+def ed_semi_trace_tasks(name, n_reads=24, seed=3, wide=False):
     """tasks for the semi-global alignment WITH traceback (ed_band_cal_semi_64_w_absent_diag_trace): ed_tasks' pairs whose band covers the pattern
     (0 <= p_len - t_len + abs_diag <= 2 thre, t_len > abs_diag) - outside of that the reference's traceback indexes its column words out of range."""
-    t = ed_tasks(name, n_reads=n_reads, seed=seed).astype(np.int64)
+    t = ed_tasks(name, n_reads=n_reads, seed=seed, wide=wide).astype(np.int64)
     ai = t[:, 2] - t[:, 6] + t[:, 9]
     keep = (ai >= 0) & (ai <= 2 * t[:, 8]) & (t[:, 6] > t[:, 9])
     return t[keep].astype(np.uint32)
 
 
-def ed_ext_tasks(name, n_reads=24, wl=775, seed=4):
+def ed_ext_tasks(name, n_reads=24, wl=775, seed=4, wide=False):
     """(pattern, text) pairs for the extension alignments with traceback (ed_band_cal_extension_64_{0,1}_w_trace): both strings start (forward) or end
     (backward) together at a point of an overlap's diagonal; either may be the longer one, by a little or by a lot; plus unrelated and tiny pairs."""
     rs, okw = scenario_reads(name)
@@ -196,7 +201,7 @@ def ed_ext_tasks(name, n_reads=24, wl=775, seed=4):
             tl = int(L[yid])
             for ws in range(xs, xe + 1, wl):
                 tn = min(int(rng.integers(20, wl + 1)), xe + 1 - ws)
-                thre = int(rng.choice([0, 3, 8, 15, 24, 31]))
+                thre = int(rng.choice([32, 40, 50, 63] if wide else [0, 3, 8, 15, 24, 31]))
                 p0 = max(0, ys + (ws - xs) + int(rng.integers(-1, 2)))
                 pn = tn + int(rng.choice([-60, -9, -2, 0, 1, 3, 12, 80]))
                 p1 = min(tl, p0 + max(1, pn))
@@ -208,12 +213,12 @@ def ed_ext_tasks(name, n_reads=24, wl=775, seed=4):
         if L[a] < 2 or L[b] < 2:
             continue
         tn = int(rng.integers(1, min(300, int(L[b])) + 1)); pn = int(rng.integers(1, min(300, int(L[a])) + 1))
-        thre = int(rng.choice([0, 1, 5, 15, 31]))
+        thre = int(rng.choice([32, 45, 63] if wide else [0, 1, 5, 15, 31]))
         out.append((a, int(rng.integers(0, L[a] - pn + 1)), pn, int(rng.integers(0, 2)), b, int(rng.integers(0, L[b] - tn + 1)), tn, int(rng.integers(0, 2)), thre, 0))
     for a in range(min(rs.n, 40)):      # exact and near-exact short pairs
         if L[a] < 60:
             continue
-        n_ = int(rng.integers(1, 50)); p_ = int(rng.integers(0, L[a] - n_ - 8)); thre = int(rng.choice([0, 2, 7]))
+        n_ = int(rng.integers(1, 50)); p_ = int(rng.integers(0, L[a] - n_ - 8)); thre = int(rng.choice([33, 63] if wide else [0, 2, 7]))
         out.append((a, p_, n_, 0, a, p_, n_, 0, thre, 0))
         out.append((a, p_, n_ + 5, 0, a, p_, n_, 0, thre, 0))
         out.append((a, p_, n_, 0, a, p_, n_ + 5, 0, thre, 0))
