@@ -267,9 +267,9 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		unsigned long long *d_ovf = B.stats.p + 3 * HAO_NCLS + 3;
 		const uint32_t tile_ = c->sw.seed_tile == 512 ? 512 : 1024;
 		const size_t lds_tile = std::max<size_t>((size_t)tile_ * (sizeof(hao_stage_t) + 2), 12 * 512);      // staged tile (>= the 12 bytes per slot of the bin sort it shares memory with)
-		const size_t lds1 = (size_t)22 * 512 + lds_tile + 12 * (size_t)sa_.qcap + 16 + (size_t)c->sw.seed_lds_pad, lds2 = (size_t)22 * 1024 + std::max<size_t>(lds_tile, 12 * 1024) + 12 * (size_t)sa_.qcap + 16;
+		const size_t lds1 = (size_t)22 * 512 + lds_tile + 12 * (size_t)sa_.qcap + 16 + (size_t)c->sw.seed_lds_pad, lds2 = (size_t)22 * 2048 + std::max<size_t>(lds_tile, 12 * 2048) + 12 * (size_t)sa_.qcap + 16;      // (second launch: 2048 slots = up to 1760 bins per id-range round)
 		auto launch = [&](auto k1, auto k2) -> int {
-			if (lds2 > 64 * 1024 || lds1 > 64 * 1024) {     // beyond the default dynamic LDS limit: opt in (the CU has 160 KB)
+			{     // beyond the default dynamic LDS limit: opt in (the CU has 160 KB)
 				HIP_TRY(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
 				HIP_TRY(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
 			}
@@ -279,8 +279,8 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			HAO_CHECK_LAUNCH();
 			return HAO_OK;
 		};
-		if (tile_ == 512) { if (int rc = launch(seed_bin_kernel<9, true, 512>, seed_bin_kernel<10, false, 512>)) return rc; }
-		else if (int rc = launch(seed_bin_kernel<9, true, 1024>, seed_bin_kernel<10, false, 1024>)) return rc;
+		if (tile_ == 512) { if (int rc = launch(seed_bin_kernel<9, true, 512>, seed_bin_kernel<11, false, 512>)) return rc; }
+		else if (int rc = launch(seed_bin_kernel<9, true, 1024>, seed_bin_kernel<11, false, 1024>)) return rc;
 	}
 	if (c->sw.seedphase) { unsigned long long d_[4]; HIP_TRY(hipMemcpy(d_, B.dbgbuf.p, 32, hipMemcpyDeviceToHost)); if (d_[3]) fprintf(stderr, "[seed] blocks %llu  avg us: count pass %.1f  sort+scan %.1f  scatter pass %.1f\n", d_[3], d_[0] / 100.0 / d_[3], d_[1] / 100.0 / d_[3], d_[2] / 100.0 / d_[3]); }
 	c->timer.mark("q_sort_bins");
