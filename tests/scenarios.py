@@ -34,6 +34,15 @@ SCENARIOS = {
     "exact": (dict(genome_size=60_000, coverage=16, read_len=4000, err=0.0002, seed=18, len_jit=1500, n_rate=0.0001), dict(bw_thres=0.001)),
     # ragged / degenerate reads mixed into a normal set (see edge_reads below)
     "edge":  (dict(builder="edge"), {}),
+    # off-default (k, w) pairs and option mixes, chosen to leave the tuned paths: small k with a narrow window, the largest k (63) with a window wider than
+    # the wave kernel's chunk overlap and no HPC, ONT mode with N bases, a tiny Bloom filter on a repeat-rich set, error-free reads, and k = 57 (the widest
+    # k the one-word window kernel takes) at the default w
+    "fz0":   (dict(genome_size=30_000, coverage=14, read_len=2500, err=0.004, seed=40, len_jit=800), dict(k=21, w=11)),
+    "fz1":   (dict(genome_size=40_000, coverage=16, read_len=5000, err=0.001, seed=41, len_jit=1500, repeat_rich=1), dict(k=63, w=80, hpc=0)),
+    "fz2":   (dict(genome_size=30_000, coverage=18, read_len=3500, err=0.012, seed=42, len_jit=1200, n_rate=0.0005), dict(k=31, w=19, is_ont=1)),
+    "fz3":   (dict(genome_size=60_000, coverage=10, read_len=3000, err=0.002, seed=43, len_jit=900, repeat_rich=2), dict(bf_shift=20)),
+    "fz4":   (dict(genome_size=25_000, coverage=25, read_len=1800, err=0.0, seed=44, len_jit=600), dict(k=45, w=25)),
+    "fz5":   (dict(genome_size=35_000, coverage=15, read_len=4500, err=0.003, seed=45, len_jit=1000), dict(k=57, w=51)),
 }
 
 
