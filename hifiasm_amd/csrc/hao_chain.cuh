@@ -1480,7 +1480,6 @@ __global__ __launch_bounds__(256) void chain_select4_kernel(hao_sel_args A, int6
 	const uint64_t g0 = A.g_off[r], g1 = A.g_off[r + 1], o0 = A.ch_base[g0];
 	const int64_t n = (int64_t)(A.ch_base[g1] - o0);
 	if (n < n_lo || n >= n_hi) return;                          // this read belongs to another launch (n <= CAP here)
-	const uint64_t cl0 = A.cl_base[g0], cn = A.cl_base[g1] - cl0;
 	const hao_ovlp_t *rec = A.ol + o0;
 	int lch = 0;
 	for (int64_t i = tid; i < n; i += 256) {
