@@ -97,7 +97,7 @@ static int hao_exact_run(hao_ctx *c)
 {
 	hao_ctx::Batch &B = *c->batch;
 	if (B.exact_valid) return HAO_OK;
-	if (c->comm && c->comm->active()) { hao_set_err(c, "hao_exact_check needs the bases of the target reads: single-device mode only"); return HAO_EUNSUPP; }
+	if (hao_is_sharded(c)) { hao_set_err(c, "hao_exact_check needs the bases of the target reads: single-device mode only"); return HAO_EUNSUPP; }
 	HIP_TRY(B.O().exact.reserve(B.n_ol + 1));
 	if (B.n_ol) {
 		hao_exact_args a;

@@ -191,7 +191,7 @@ int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks
 {
 	if (!c || (!tasks && n_tasks) || (!out && n_tasks)) return HAO_EINVAL;
 	if (int rc = hao_view_refresh(c)) return rc;
-	if (c->comm && c->comm->active()) { hao_set_err(c, "hao_window_ed_batch needs the bases of both reads: single-device mode only"); return HAO_EUNSUPP; }
+	if (hao_is_sharded(c)) { hao_set_err(c, "hao_window_ed_batch needs the bases of both reads: single-device mode only"); return HAO_EUNSUPP; }
 	if (n_tasks == 0) return HAO_OK;
 	for (uint64_t i = 0; i < n_tasks; ++i) {      // the reference indexes its strings unchecked; a device kernel must not
 		const hao_ed_task_t &t = tasks[i];
@@ -219,7 +219,7 @@ int hao_window_trace_batch(hao_ctx *c, int mode, const hao_ed_task_t *tasks, uin
 {
 	if (!c || (mode < HAO_ALIGN_GLOBAL || mode > HAO_ALIGN_SEMI) || (!tasks && n_tasks) || (!out && n_tasks) || (!cigars && n_tasks && cigar_cap)) return HAO_EINVAL;
 	if (int rc = hao_view_refresh(c)) return rc;
-	if (c->comm && c->comm->active()) { hao_set_err(c, "hao_window_trace_batch needs the bases of both reads: single-device mode only"); return HAO_EUNSUPP; }
+	if (hao_is_sharded(c)) { hao_set_err(c, "hao_window_trace_batch needs the bases of both reads: single-device mode only"); return HAO_EUNSUPP; }
 	if (n_tasks == 0) return HAO_OK;
 	uint64_t tn_max = 1; bool wide = false;      // wide: some band needs two 64-bit words (thre 32 .. 63)
 	for (uint64_t i = 0; i < n_tasks; ++i) {      // the reference indexes its strings unchecked; a device kernel must not
@@ -229,7 +229,7 @@ int hao_window_trace_batch(hao_ctx *c, int mode, const hao_ed_task_t *tasks, uin
 		if (2 * (uint64_t)t.thre + 1 > 64) wide = true;
 		if (mode == HAO_ALIGN_SEMI) {
 			const int64_t ai = (int64_t)t.p_len - (int64_t)t.t_len + (int64_t)t.abs_diag;
-			if (ai < 0 || ai > 2 * (int64_t)t.thre || t.t_len <= t.abs_diag) { hao_set_err(c, "hao_window_trace_batch: task " + std::to_string(i) + ": the band does not cover the pattern"); return HAO_EINVAL; }
+			if (ai < 0 || ai > 2 * (int64_t)t.thre || t.t_len <= t.abs_diag || t.abs_diag > 2 * t.thre) { hao_set_err(c, "hao_window_trace_batch: task " + std::to_string(i) + ": the band does not cover the pattern"); return HAO_EINVAL; }
 		}
 		if (t.t_len > tn_max) tn_max = t.t_len;
 	}
@@ -385,25 +385,4 @@ int hao_pt_table(hao_ctx *c, uint64_t *n_keys, const uint64_t **keys, const uint
 	*n_keys = c->h_ix_keys.size(); *keys = c->h_ix_keys.data(); *off = c->h_ix_off.data(); *pos = c->h_ix_pos.data(); *n_pos = c->h_ix_pos.size();
 	return HAO_OK;
 }
-}
-
-extern "C" {
-#ifndef HAO_HAVE_FT
-int hao_ft_gen(hao_ctx *c, int32_t *hom_cov) { hao_set_err(c, "not implemented"); return HAO_EINVAL; }
-int32_t hao_ft_cnt(hao_ctx *c, uint64_t y) { return 0; }
-int hao_ft_table(hao_ctx *c, uint64_t *n, const uint64_t **keys, const int32_t **vals) { return HAO_EINVAL; }
-int hao_hist(hao_ctx *c, int which, int64_t cnt[4096]) { return HAO_EINVAL; }
-int hao_stats(hao_ctx *c, int64_t out[8]) { return HAO_EINVAL; }
-#endif
-#ifndef HAO_HAVE_PT
-int hao_pt_gen(hao_ctx *c, int32_t *hom_cov, int32_t *het_cov) { hao_set_err(c, "not implemented"); return HAO_EINVAL; }
-int hao_pt_get(hao_ctx *c, uint64_t hash, const uint64_t **pos, int32_t *n) { return HAO_EINVAL; }
-int hao_pt_table(hao_ctx *c, uint64_t *n_keys, const uint64_t **keys, const uint64_t **off, const uint64_t **pos, uint64_t *n_pos) { return HAO_EINVAL; }
-#endif
-#ifndef HAO_HAVE_QUERY
-int hao_overlap_batch(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi) { hao_set_err(c, "not implemented"); return HAO_EINVAL; }
-int hao_fetch_seed_hits(hao_ctx *c, uint64_t rid, const hao_hit_t **hits, uint64_t *n) { return HAO_EINVAL; }
-int hao_fetch_overlaps(hao_ctx *c, uint64_t rid, const hao_ovlp_t **ol, uint64_t *n_ol, const uint64_t **fc, const uint64_t **fc_off, const hao_hit_t **cl, uint64_t *n_cl) { return HAO_EINVAL; }
-int hao_batch_totals(hao_ctx *c, uint64_t out[8]) { return HAO_EINVAL; }
-#endif
 }

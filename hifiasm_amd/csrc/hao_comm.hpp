@@ -28,6 +28,7 @@ struct hao_comm {
 	bool active() const { return world > 1 || nccl || loop; }
 	void release() { ag_tmp.release(); sc_a.release(); sc_b.release(); }
 };
+static bool hao_comm_is_active(const hao_comm *cm) { return cm->active(); }
 
 // Every small collective below also carries the status of the LOCAL phase that preceded it on each rank (local_rc): a rank whose allocation /
 // kernel / sort failed still takes part (with empty data) and every rank returns the same error afterwards, so nobody is left waiting in the next

@@ -55,13 +55,13 @@ struct StageTimer {
 // run-time switches (measurement aids): read from the environment ONCE, in hao_create
 struct hao_switches {
 	bool seedphase = false, qcphase = false, dp_stats = false, seq_chain = false, dp_seqtail = false, dp_nospec = false, dp_serial = false,
-		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, dltime = false;
+		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, sk_v2 = false, dltime = false;
 	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; int exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, seed_lds_pad = 0, arena_numa = 1, seed_tile = 512;
 	void load() {
 		auto on = [](const char *n) { return getenv(n) != nullptr; };
 		seedphase = on("HAO_DBG_SEEDPHASE"); qcphase = on("HAO_DBG_QCPHASE"); dp_stats = on("HAO_DBG_DP_STATS"); seq_chain = on("HAO_DBG_SEQ_CHAIN");
 		dp_seqtail = on("HAO_DBG_DP_SEQTAIL"); dp_nospec = on("HAO_DBG_DP_NOSPEC"); dp_serial = on("HAO_DBG_DP_SERIAL"); seq_prune = on("HAO_DBG_SEQ_PRUNE");
-		selphase = on("HAO_DBG_SELPHASE"); sel1 = on("HAO_DBG_SEL1"); sk_generic = on("HAO_DBG_SK_GENERIC"); dltime = on("HAO_DBG_DLTIME");
+		selphase = on("HAO_DBG_SELPHASE"); sel1 = on("HAO_DBG_SEL1"); sk_generic = on("HAO_DBG_SK_GENERIC"); sk_v2 = on("HAO_DBG_SK_V2"); dltime = on("HAO_DBG_DLTIME");
 		if (const char *e = getenv("HAO_CHAIN_WPB")) chain_wpb = std::max(1, std::min(4, atoi(e)));
 		if (const char *e = getenv("HAO_SPEC_MINCLS")) spec_mincls = atoi(e);
 		if (const char *e = getenv("HAO_DBG_SK_GCAP")) sk_gcap = atoll(e);
@@ -126,6 +126,10 @@ struct hao_ctx {
 static void hao_set_err(hao_ctx *c, const std::string &m) { if (c) c->err = m; }
 
 #define HAO_CHECK_LAUNCH() HIP_TRY(hipGetLastError())
+
+// sharded mode (the engine holds a slice of the read store)?  A view (hao_attach) has no communicator of its own: its owner's decides.
+static bool hao_comm_is_active(const struct hao_comm *cm);
+static inline bool hao_is_sharded(const hao_ctx *c) { const hao_ctx *o = c->owner ? c->owner : c; return o->comm && hao_comm_is_active(o->comm); }
 
 // scratch for rocprim calls
 static inline hipError_t hao_tmp(hao_ctx *c, size_t bytes) { return c->d_tmp.reserve(bytes + 256); }

@@ -39,7 +39,7 @@ static bool hao_kh_write(FILE *fp, const std::vector<uint64_t> &keys, const void
 static int hao_index_save_impl(hao_ctx *c, const char *prefix, int32_t number_of_round, const char *const *names)
 {
 	if (!c->has_ft || !c->has_pt) { hao_set_err(c, "hao_index_save: hao_ft_gen and hao_pt_gen must have run"); return HAO_EINVAL; }
-	if (c->comm && c->comm->active()) { hao_set_err(c, "hao_index_save: single-device mode only (a sharded engine holds a slice of the read store)"); return HAO_EUNSUPP; }
+	if (hao_is_sharded(c)) { hao_set_err(c, "hao_index_save: single-device mode only (a sharded engine holds a slice of the read store)"); return HAO_EUNSUPP; }
 	if (int rc = hao_pt_download(c)) return rc;
 	const std::string base = std::string(prefix) + ".pt_flt";
 	FILE *fp = fopen(base.c_str(), "wb");

@@ -2,6 +2,7 @@
 #pragma once
 #include "hao_ctx.hpp"
 #include "hao_sketch.cuh"
+#include "hao_sketch3.cuh"
 
 static void hao_batch_free(hao_ctx *c);
 static void hao_release_all(hao_ctx *c);
@@ -28,7 +29,9 @@ static hao_ft_dev hao_ft_view(hao_ctx *c)
 static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int sample_dist, int stamp_rid)
 {
 	const uint64_t n_sel = hi - lo; const int k = c->opt.k, w = c->opt.w;
-	const bool wave_variant = w == 51 && k + 7 <= 64 && !c->sw.sk_generic;     // default parameters: wave-local kernel
+	const bool unit_variant = w == 51 && k == 51 && !c->sw.sk_generic && !c->sw.sk_v2;     // default parameters: one wave per unit of 1024 window ordinals
+	const bool wave_variant = w == 51 && k + 7 <= 64 && !c->sw.sk_generic;     // other k at the default w (or HAO_DBG_SK_V2): the round-2 kernel, one workgroup per chunk
+	const int chunk = unit_variant ? hao_sk3<51, 51>::MW : (wave_variant ? hao_sk2<51>::CHUNK : HAO_SK_CHUNK);
 	c->sk_lo = lo; c->sk_n = n_sel; c->sk_total = 0;
 	HIP_TRY(c->d_mz_off.reserve(n_sel + 2));
 	if (n_sel == 0) { HIP_TRY(hipMemsetAsync(c->d_mz_off.p, 0, 8, c->stream)); return HAO_OK; }
@@ -52,22 +55,29 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 	if (!slist.empty()) HIP_TRY(hipMemcpyAsync(c->d_scalar_list.p, slist.data(), slist.size() * 4, hipMemcpyHostToDevice, c->stream));
 	c->timer.mark("sk_h2d");
 	hipLaunchKernelGGL(hpc_index_kernel, dim3((unsigned)((n_sel + 3) / 4)), dim3(256), 0, c->stream, c->d_packed.p, c->d_pk_off.p, c->d_len.p,
-					   c->d_tile_off.p, c->d_tile_ord.p, c->d_n_runs.p, lo, n_sel, c->opt.hpc);
+					   c->d_tile_off.p, c->d_tile_ord.p, c->d_n_runs.p, lo, n_sel, c->opt.hpc, unit_variant ? c->d_scalar_flag.p : (uint8_t*)nullptr);
 	HAO_CHECK_LAUNCH();
-	hipLaunchKernelGGL(hao_chunk_count_kernel, dim3((unsigned)((n_sel + 256) / 256)), dim3(256), 0, c->stream, c->d_n_runs.p, c->d_scalar_flag.p, n_sel, k, wave_variant ? hao_sk2<51>::CHUNK : HAO_SK_CHUNK, c->d_chunk_cnt64.p);
+	hipLaunchKernelGGL(hao_chunk_count_kernel, dim3((unsigned)((n_sel + 256) / 256)), dim3(256), 0, c->stream, c->d_n_runs.p, c->d_scalar_flag.p, n_sel, k, chunk, c->d_chunk_cnt64.p);
 	HAO_CHECK_LAUNCH();
 	if (int rc = hao_excl_scan_u64(c, c->d_chunk_cnt64.p, c->d_chunk_off.p, n_sel + 1)) return rc;
 	HIP_TRY(hipMemcpyAsync(c->d_tot_l.p, c->d_n_runs.p, n_sel * 4, hipMemcpyDeviceToDevice, c->stream));
 	uint64_t n_chunks = 0;
 	HIP_TRY(hipMemcpyAsync(&n_chunks, c->d_chunk_off.p + n_sel, 8, hipMemcpyDeviceToHost, c->stream));
+	if (unit_variant) HIP_TRY(hipMemcpyAsync(flag.data(), c->d_scalar_flag.p, n_sel, hipMemcpyDeviceToHost, c->stream));      // + the reads hpc_index_kernel left to the scalar kernel
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (unit_variant) {
+		const size_t n0 = slist.size(); slist.clear();
+		for (uint64_t r = 0; r < n_sel; ++r) if (flag[r]) slist.push_back((uint32_t)r);
+		if (slist.size() != n0) { HIP_TRY(c->d_scalar_list.reserve(slist.size() + 1)); HIP_TRY(hipMemcpyAsync(c->d_scalar_list.p, slist.data(), slist.size() * 4, hipMemcpyHostToDevice, c->stream)); }
+	}
 	c->timer.mark("sk_index");
 	HIP_TRY(c->d_chunk_base.reserve(n_chunks + 1)); HIP_TRY(c->d_chunk_cnt.reserve(n_chunks + 1)); HIP_TRY(c->d_chunk_dst.reserve(n_chunks + 2));
 	if (!slist.empty()) { HIP_TRY(c->d_ring.reserve(slist.size() * 256 * sizeof(hao_cand))); HIP_TRY(c->d_ringord.reserve(slist.size() * 256)); HIP_TRY(c->d_cnt_ws.reserve(slist.size() + 1)); }
 	const size_t smem = hao_sk_smem_bytes(w, k);
 	// pool: every candidate of every chunk (bound nb / 6, grown on overflow); gathered / final lists: an estimate well above the usual one minimizer per
 	// ~35 bases, checked on the device (the exact total is only read back at the end)
-	uint64_t cap = nb / 6 + 65536, gcap = std::min(cap, nb / 16 + 65536), total = 0;
+	const uint64_t pool_static = unit_variant ? n_chunks * SK3_SLOT : 0;
+	uint64_t cap = pool_static + nb / (unit_variant ? 32 : 6) + 65536, gcap = std::min(nb / 6 + 65536, nb / 16 + 65536), total = 0;
 	if (c->sw.sk_gcap >= 0) gcap = (uint64_t)c->sw.sk_gcap;          // force the overflow / retry path (tests)
 	hao_scalar_args sa;
 	for (int attempt = 0; ; ++attempt) {
@@ -80,7 +90,7 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 			sa.rid_lo = lo; sa.k = k; sa.w = w; sa.hpc = c->opt.hpc; sa.use_ft = use_ft; sa.ft = hao_ft_view(c);
 			sa.ring_ws = (hao_cand*)c->d_ring.p; sa.ringord_ws = c->d_ringord.p;
 			sa.pool_x = c->d_pool_x.p; sa.pool_info = c->d_pool_info.p; sa.pool_ord = c->d_pool_ord.p; sa.pool_cursor = c->d_cursor.p; sa.pool_cap = cap;
-			sa.chunk_base = c->d_chunk_base.p; sa.chunk_cnt = c->d_chunk_cnt.p; sa.tot_l = c->d_tot_l.p; sa.err = c->d_err.p; sa.pass = 0; sa.cnt_ws = c->d_cnt_ws.p;
+			sa.chunk_base = c->d_chunk_base.p; sa.chunk_cnt = c->d_chunk_cnt.p; sa.tot_l = c->d_tot_l.p; sa.err = c->d_err.p; sa.pass = 0; sa.cnt_ws = c->d_cnt_ws.p; sa.pool_static = pool_static;
 			hipLaunchKernelGGL(sketch_scalar_kernel, dim3((unsigned)((slist.size() + 63) / 64)), dim3(64), 0, c->stream, sa);
 			HAO_CHECK_LAUNCH();
 		}
@@ -88,8 +98,11 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 		a.packed = c->d_packed.p; a.pk_off = c->d_pk_off.p; a.len = c->d_len.p; a.tile_off = c->d_tile_off.p; a.tile_ord = c->d_tile_ord.p; a.n_runs = c->d_n_runs.p;
 		a.chunk_off = c->d_chunk_off.p; a.scalar_flag = c->d_scalar_flag.p; a.rid_lo = lo; a.n_sel = n_sel; a.k = k; a.w = w; a.hpc = c->opt.hpc; a.ft = hao_ft_view(c);
 		a.pool_x = c->d_pool_x.p; a.pool_info = c->d_pool_info.p; a.pool_ord = c->d_pool_ord.p; a.pool_cursor = c->d_cursor.p; a.pool_cap = cap;
-		a.chunk_base = c->d_chunk_base.p; a.chunk_cnt = c->d_chunk_cnt.p; a.err = c->d_err.p;
-		if (wave_variant) {
+		a.chunk_base = c->d_chunk_base.p; a.chunk_cnt = c->d_chunk_cnt.p; a.err = c->d_err.p; a.pool_static = pool_static;
+		if (unit_variant) {
+			if (use_ft && a.ft.n > 0) hipLaunchKernelGGL((sketch_unit_kernel<true, 51, 51>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, c->stream, a);
+			else hipLaunchKernelGGL((sketch_unit_kernel<false, 51, 51>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, c->stream, a);
+		} else if (wave_variant) {
 			if (use_ft && a.ft.n > 0) hipLaunchKernelGGL((sketch_chunk_wave_kernel<true, 51>), dim3((unsigned)n_chunks), dim3(256), 0, c->stream, a);
 			else hipLaunchKernelGGL((sketch_chunk_wave_kernel<false, 51>), dim3((unsigned)n_chunks), dim3(256), 0, c->stream, a);
 		} else if (use_ft && a.ft.n > 0) hipLaunchKernelGGL(sketch_chunk_kernel<true>, dim3((unsigned)n_chunks), dim3(HAO_SK_THREADS), smem, c->stream, a);
@@ -131,7 +144,7 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		if (!err) break;
 		if (attempt >= 3) { hao_set_err(c, "minimizer pool overflow"); return HAO_ENOMEM; }
-		cap = attempt == 0 ? nb / 2 + 65536 : nb + 65536; gcap = cap;       // (the kernels above ran on truncated buffers: everything is redone)
+		cap = pool_static + (attempt == 0 ? nb / 2 + 65536 : nb + 65536); gcap = cap - pool_static;       // (the kernels above ran on truncated buffers: everything is redone)
 	}
 	c->sk_total = total;
 	c->timer.mark("sk_finish");

@@ -77,22 +77,35 @@ __device__ __forceinline__ uint32_t hao_wave_excl_scan(uint32_t v, uint32_t *tot
 // runs that end before base 1024*i; last entry = T (total runs). flags[r] bit0 = needs the
 // scalar path.
 // ---------------------------------------------------------------------------------------
+#define SK3_MIN_TILE_RUNS 544      // hao_sketch3.cuh: a unit of 1024 window ordinals must fit 3 decode steps
+#define SK3_LONGSPAN_ENDS 67       // 17 consecutive 16-base words with <= 67 run ends: some 256 bases hold <= 51 runs, a k-mer span can reach 256
 __global__ __launch_bounds__(256) void hpc_index_kernel(const uint8_t *packed, const uint64_t *pk_off, const uint32_t *len,
-		const uint64_t *tile_off, uint32_t *tile_ord, uint32_t *n_runs, uint64_t rid_lo, uint64_t n_sel, int hpc)
+		const uint64_t *tile_off, uint32_t *tile_ord, uint32_t *n_runs, uint64_t rid_lo, uint64_t n_sel, int hpc, uint8_t *slow_flag)
 {
 	uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (r >= n_sel) return;
 	uint64_t rid = rid_lo + r; const uint8_t *rd = packed + pk_off[rid]; uint32_t L = len[rid];
 	uint32_t *to = tile_ord + tile_off[r]; uint32_t run = 0, nt = (L + HAO_SK_TILE - 1) / HAO_SK_TILE;
+	uint32_t prev_cum = 0; bool slow = false;
 	for (uint32_t ti = 0; ti < nt; ++ti) {
 		uint32_t W, g0 = ti * HAO_SK_TILE + hao_lane() * 16, c;
 		if (hpc) c = __popc(hao_run_ends16(rd, L, g0, &W));
 		else c = g0 >= L ? 0 : (L - g0 > 16 ? 16 : L - g0);
-		uint32_t tot; hao_wave_excl_scan(c, &tot);
+		uint32_t tot; const uint32_t excl = hao_wave_excl_scan(c, &tot);
 		if (hao_lane() == 0) to[ti] = run;
+		if (slow_flag && hpc) {       // reads the unit kernel leaves to the scalar one: long runs (see hao_sketch3.cuh)
+			const uint32_t cum = run + excl + c;                               // run ends up to and including this word
+			if (ti * HAO_SK_TILE + HAO_SK_TILE <= L && tot < SK3_MIN_TILE_RUNS) slow = true;
+			const int ln = hao_lane();
+			const uint32_t a = (uint32_t)__shfl((int)cum, (ln + 47) & 63), b = (uint32_t)__shfl((int)prev_cum, (ln + 47) & 63);   // lane - 17 (mod 64)
+			const uint32_t before = ln >= 17 ? a : (ti > 0 ? b : 0u);
+			if (ti * 64 + (uint32_t)ln >= 16 && g0 + 16 <= L && cum - before <= SK3_LONGSPAN_ENDS) slow = true;
+			prev_cum = cum;
+		}
 		run += tot;
 	}
 	if (hao_lane() == 0) { to[nt] = run; n_runs[r] = run; }
+	if (slow_flag && __any(slow) && hao_lane() == 0) slow_flag[r] = 1;
 }
 
 struct hao_sk_args {
@@ -105,6 +118,7 @@ struct hao_sk_args {
 	// output pool (append order arbitrary) + per-chunk record
 	uint64_t *pool_x, *pool_info; uint32_t *pool_ord; unsigned long long *pool_cursor; uint64_t pool_cap;
 	uint64_t *chunk_base; uint32_t *chunk_cnt; int *err;
+	uint64_t pool_static;          // unit kernel: the first pool_static pool entries are fixed slots of SK3_SLOT entries per unit; the cursor allocates behind them
 };
 
 struct hao_key { uint64_t x; uint32_t c; };
@@ -751,7 +765,7 @@ struct hao_scalar_args {
 	uint64_t *pool_x, *pool_info; uint32_t *pool_ord; unsigned long long *pool_cursor; uint64_t pool_cap;
 	uint64_t *chunk_base; uint32_t *chunk_cnt; uint32_t *tot_l; int *err;
 	int pass;   // 0 = count only, 1 = emit
-	uint32_t *cnt_ws;
+	uint32_t *cnt_ws; uint64_t pool_static;
 };
 
 __global__ void sketch_scalar_kernel(hao_scalar_args a)
@@ -825,7 +839,7 @@ __global__ void sketch_scalar_kernel(hao_scalar_args a)
 #undef SC_PUSH
 	if (!emit) {
 		a.cnt_ws[si] = (uint32_t)out; a.tot_l[r] = (uint32_t)tl;
-		unsigned long long bs = out ? atomicAdd(a.pool_cursor, (unsigned long long)out) : 0ULL;
+		unsigned long long bs = out ? a.pool_static + atomicAdd(a.pool_cursor, (unsigned long long)out) : 0ULL;
 		if (bs + out > a.pool_cap) { *a.err = 1; out = 0; }
 		a.chunk_base[a.chunk_off[r]] = bs; a.chunk_cnt[a.chunk_off[r]] = (uint32_t)out;
 	}

@@ -69,7 +69,7 @@ static int hao_prepare_runs(hao_ctx *c, uint64_t lo, uint64_t hi, bool force_sca
 	HIP_TRY(hipMemcpyAsync(c->d_scalar_flag.p, flag.data(), n_sel, hipMemcpyHostToDevice, c->stream));
 	if (!slist.empty()) HIP_TRY(hipMemcpyAsync(c->d_scalar_list.p, slist.data(), slist.size() * 4, hipMemcpyHostToDevice, c->stream));
 	hipLaunchKernelGGL(hpc_index_kernel, dim3((unsigned)((n_sel + 3) / 4)), dim3(256), 0, c->stream, c->d_packed.p, c->d_pk_off.p, c->d_len.p,
-					   c->d_tile_off.p, c->d_tile_ord.p, c->d_n_runs.p, lo, n_sel, c->opt.hpc);
+					   c->d_tile_off.p, c->d_tile_ord.p, c->d_n_runs.p, lo, n_sel, c->opt.hpc, (uint8_t*)nullptr);
 	HAO_CHECK_LAUNCH();
 	HIP_TRY(hipStreamSynchronize(c->stream));   // host vectors go out of scope
 	return HAO_OK;

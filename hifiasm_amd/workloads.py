@@ -15,6 +15,7 @@ WORKLOADS = {
     "chr1_250M_hifi30x": (250_000_000, 30, 15000, 0.001, 0, 0),            # configs[2]: the largest single-GPU configuration
     "human3G_hifi40x": (3_000_000_000, 40, 15000, 0.001, 0, 0),            # configs[3]: 8 M reads of 15 kb, sharded over 8 GPUs
     "ont5M_30x": (5_000_000, 30, 30000, 0.01, 0, 1),
+    "ont50M_30x": (50_000_000, 30, 30000, 0.01, 0, 1),                     # 50 000 ONT reads: the full-size parity case of --ont mode
     "ont_human_30x": (3_000_000_000, 30, 30000, 0.01, 0, 1),               # configs[4]: 3 M reads of 30 kb, --ont
 }
 GENOME_SEED, READ_SEED = 11, 12

@@ -131,7 +131,7 @@ static tbuf_t *tbuf_init(int n)
 
 int main(int argc, char *argv[])
 {
-	int no_tables_hist = 0;
+	int no_tables_hist = 0, ft_tables = 0;
 	int n_thread = 1, is_ont = 0, do_time = 0, dump_hits = 1, k = -1, w = -1, bf_shift = 0, no_hpc = 0, no_tables = 0, do_digest = 0; const char *fa = 0, *list_fn = 0, *hg = 0, *ed_fn = 0, *edg_fn = 0, *eds_fn = 0, *ed1_fn = 0, *ed2_fn = 0, *load_pfx = 0; std::string prefix;
 	double bw_arg = -1;
 	for (int i = 1; i < argc; ++i) {
@@ -148,6 +148,7 @@ int main(int argc, char *argv[])
 		else if (!strcmp(argv[i], "--bw")) bw_arg = atof(argv[++i]);
 		else if (!strcmp(argv[i], "--reads-list")) list_fn = argv[++i];
 		else if (!strcmp(argv[i], "--no-tables")) no_tables = 1;
+		else if (!strcmp(argv[i], "--ft-tables")) ft_tables = 1;      // with --no-tables: still dump the all-k-mer histogram and the filter table (not the position index)
 		else if (!strcmp(argv[i], "--digest")) do_digest = 1;
 		else if (!strcmp(argv[i], "--ed-tasks")) ed_fn = argv[++i];
 		else if (!strcmp(argv[i], "--edg-tasks")) edg_fn = argv[++i];
@@ -279,13 +280,13 @@ int main(int argc, char *argv[])
 	}
 	int64_t ft_hist[4096], pt_hist[4096]; int ft_peak_hom, ft_peak_het; uint64_t ft_distinct, pt_distinct;
 	memset(ft_hist, 0, sizeof(ft_hist)); ft_peak_hom = hom_cov_ft; ft_peak_het = -1; ft_distinct = 0;
-	if (!no_tables && !no_tables_hist) refdump_ft_hist(&asm_opt, &R_INF, ft_hist, &ft_peak_hom, &ft_peak_het, &ft_distinct);      // (recounts every k-mer: skipped for large sets)
+	if ((!no_tables || ft_tables) && !no_tables_hist) refdump_ft_hist(&asm_opt, &R_INF, ft_hist, &ft_peak_hom, &ft_peak_het, &ft_distinct);      // (recounts every k-mer: skipped for large sets)
 	memset(pt_hist, 0, sizeof(pt_hist)); pt_distinct = 0;
 	if (!no_tables_hist) refdump_pt_hist(&asm_opt, ha_flt_tab, &R_INF, pt_hist, &pt_distinct);
 	wr(prefix, "ft_hist.i64", ft_hist, sizeof(ft_hist));
 	wr(prefix, "pt_hist.i64", pt_hist, sizeof(pt_hist));
 	uint64_t n_ft = 0, n_ptk = 0, n_ptp = 0;
-	if (!no_tables) {
+	if (!no_tables || ft_tables) {
 		uint64_t *keys; int32_t *vals;
 		n_ft = refdump_ft(ha_flt_tab, &keys, &vals);
 		wr(prefix, "ft_keys.u64", keys, sizeof(uint64_t) * n_ft);

@@ -2,7 +2,9 @@
 reads of 15 kb) from the REAL reference (oracle/_ref/ref_harness = unmodified hifiasm 0.25.0-r726 compiled from /root/reference).
 
 Run in the build container only (needs /root/reference, ~20 GB of RAM, ~8 GB under /tmp, 15-40 min on 8 cores):
-    python tests/golden/make_golden_big.py [workload] [n_sample]
+    python tests/golden/make_golden_big.py [workload] [n_sample] [bf_shift]
+With bf_shift > 0 (the reference's own default is -f37) the run goes through the blocked Bloom filter; the fixture is then named
+<workload>_f<bf_shift>.npz and also holds the all-k-mer histogram of ha_ft_gen and the filter table (--ft-tables).
 What is stored (small enough for git):
   * the totals of the all-reads pass (overlaps, chained hits, hom_cov / het_cov, max_n_chain, occurrence thresholds),
   * the minimizer count histogram of ha_pt_gen,
@@ -35,6 +37,7 @@ import oracle_py  # noqa: E402
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "chr1_250M_hifi30x"
     n_sample = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    bf = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     assert os.path.exists(harness)
     g, cov, L, err, rr, ont = WORKLOADS[name]
@@ -51,6 +54,8 @@ def main():
            "--no-tables", "--nodump-hits", "--digest"]
     if ont:
         cmd.append("--ont")
+    if bf:
+        cmd += ["-f", str(bf), "--ft-tables"]
     cmd.append(fa)
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -70,6 +75,9 @@ def main():
         meta_vals=np.array(list(meta.values()) + [tj["overlaps"], tj["chained_hits"]], dtype=np.int64),
         len_crc=np.array([zlib.crc32(rs.lengths.tobytes()), zlib.crc32(rs.packed[: 1 << 20].tobytes())], dtype=np.uint64),
     )
+    if bf:
+        out.update(ft_hist=ld("ft_hist.i64", np.int64), ft_keys=ld("ft_keys.u64", np.uint64), ft_vals=ld("ft_vals.i32", np.int32))
+        name = f"{name}_f{bf}"
     path = os.path.join(HERE, f"{name}.npz")
     np.savez_compressed(path, **out)
     print(name, json.dumps(tj), "->", os.path.getsize(path) // 1024, "KiB")

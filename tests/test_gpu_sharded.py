@@ -125,3 +125,57 @@ def test_ranks_fail_together():
     assert not any(t.is_alive() for t in th), "a rank is stuck in a collective"
     lib().hao_loop_destroy(grp)
     assert all(r is not None and "contiguous" in r for r in res), res
+
+
+def test_loopback_world8_configs1():
+    """BASELINE.json configs[1] (5 Mb, 10 000 reads) split over a loopback world of 8 ranks: every rank's tables equal the single-device
+    engine's, and every read's digest (ol, fake cigars, cl; seed hits) equals the digest the single-device run produced for it.  The
+    single-device run itself is pinned to the reference at this size by test_gpu_fullsize.py / the 5 Mb fixtures of test_gpu_fullgold.py."""
+    from hifiasm_amd.api import Engine, lib
+    from hifiasm_amd.workloads import workload_reads
+    from hifiasm_amd.synth import ReadSet
+    rs = workload_reads("bacterial5M_hifi30x")
+    e1 = Engine(0)
+    e1.set_readset(rs)
+    e1.ha_ft_gen(); e1.ha_pt_gen()
+    e1.overlap_batch(0, rs.n)
+    d_ref, k_ref = e1.batch_digest(rs.n)
+    tot_ref = e1.batch_totals()
+    ref = (e1.stats(), e1.hist(0), e1.hist(1), e1.ft_table(), e1.pt_table())
+    e1.close()
+    world = 8
+    cuts = [rs.n * i // world for i in range(world + 1)]
+    grp = lib().hao_loop_create(world)
+    errors, out = [], [None] * world
+
+    def run(rank):
+        try:
+            lo, hi = cuts[rank], cuts[rank + 1]
+            sh = ReadSet(lo, rs.lengths[lo:hi].copy(), rs.packed[int(rs.pk_off[lo]):int(rs.pk_off[hi])].copy(),
+                         (rs.pk_off[lo:hi + 1] - rs.pk_off[lo]).copy(), None, None)
+            e = Engine(0)
+            e.set_readset(sh)
+            e.set_shard(lo, rs.lengths)
+            e.dist_init_loopback(grp, rank)
+            e.ha_ft_gen(); e.ha_pt_gen()
+            st = (e.stats(), e.hist(0), e.hist(1), e.ft_table(), e.pt_table())
+            e.overlap_batch(0, hi - lo)
+            out[rank] = (st, e.batch_digest(hi - lo), e.batch_totals())
+            e.close()
+        except Exception as ex:  # noqa: BLE001
+            errors.append(f"rank {rank}: {ex!r}")
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    lib().hao_loop_destroy(grp)
+    assert not errors, errors[:5]
+    tot = 0
+    for rank, (st, (d, k), t) in enumerate(out):
+        lo, hi = cuts[rank], cuts[rank + 1]
+        assert st[0] == ref[0] and (st[1] == ref[1]).all() and (st[2] == ref[2]).all()
+        assert all((a == b).all() for a, b in zip(st[3], ref[3])) and all((a == b).all() for a, b in zip(st[4], ref[4]))
+        assert (d == d_ref[lo:hi]).all(), f"rank {rank}: results of reads {lo + np.flatnonzero(d != d_ref[lo:hi])[:5]} differ from the single-device run"
+        assert (k == k_ref[lo:hi]).all(), f"rank {rank}: seed hits differ"
+        tot += t["overlaps"]
+    assert tot == tot_ref["overlaps"]
