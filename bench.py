@@ -187,6 +187,8 @@ def main():
     auto_bsz = max(1, int(8e8 // max(1.0, 0.83 * rs.total_bases / max(1, n_reads) * WORKLOADS[a.workload][1] / 30.0)))
     bsz = a.batch_reads if a.batch_reads > 0 else min(n_reads, auto_bsz)
     ranges = [(lo, min(n_reads, lo + bsz)) for lo in range(0, n_reads, bsz)]
+    # with delivery a pass needs at least two batches for the copy of one to run under the compute of the next: a pass that fits one batch is cut in four
+    dranges = ranges if len(ranges) >= 2 else [(n_reads * i // 4, n_reads * (i + 1) // 4) for i in range(4) if n_reads * (i + 1) // 4 > n_reads * i // 4]
 
     views = {}
 
@@ -198,7 +200,7 @@ def main():
     def step(deliver=False, n_ctx=1):
         eng.ha_pt_gen()
         st = {k: v for k, v in eng.stage_times()}
-        keys0 = {"overlaps": 0, "chained_hits": 0, "seed_hits": 0, "groups": 0, "minimizers": 0, "seq_groups": 0, "seq_group_hits": 0, "host_bytes": 0, "copy_ms": 0.0, "t_async": 0.0, "t_wait": 0.0, "code_bytes": 0, "delivered_hits": 0}
+        keys0 = {"overlaps": 0, "chained_hits": 0, "seed_hits": 0, "groups": 0, "minimizers": 0, "seq_groups": 0, "seq_group_hits": 0, "host_bytes": 0, "copy_ms": 0.0, "t_async": 0.0, "t_wait": 0.0, "code_bytes": 0, "delivered_hits": 0, "exceptions": 0}
         engs = contexts(n_ctx)
         res, errs = [None] * n_ctx, []
 
@@ -206,14 +208,14 @@ def main():
             e = engs[ci]; tot = dict(keys0); sst = {}
             try:
                 prev = None
-                for lo, hi in ranges[ci::n_ctx]:
+                for lo, hi in (dranges if deliver else ranges)[ci::n_ctx]:
                     if deliver:
                         t_a = time.time()
                         slot = e.overlap_batch_async(lo, hi)      # compute of this batch; its copy runs under the next batch's kernels
                         t_b = time.time()
                         if prev is not None:                      # the consumer takes the previous batch now (its copy ran under this batch's kernels)
                             d = e.deliver_wait(prev)
-                            tot["host_bytes"] += int(d.bytes); tot["copy_ms"] += float(d.copy_ms); tot["code_bytes"] += int(d.n_codes); tot["delivered_hits"] += int(d.n_cl)
+                            tot["host_bytes"] += int(d.bytes); tot["copy_ms"] += float(d.copy_ms); tot["code_bytes"] += int(d.n_codes); tot["delivered_hits"] += int(d.n_cl); tot["exceptions"] += int(d.n_exc)
                         tot["t_async"] += (t_b - t_a) * 1e3; tot["t_wait"] += (time.time() - t_b) * 1e3
                         prev = slot
                     else:
@@ -226,7 +228,7 @@ def main():
                         sst[k] = sst.get(k, 0.0) + v
                 if deliver and prev is not None:
                     d = e.deliver_wait(prev)                      # every batch's results are in host memory
-                    tot["host_bytes"] += int(d.bytes); tot["copy_ms"] += float(d.copy_ms); tot["code_bytes"] += int(d.n_codes); tot["delivered_hits"] += int(d.n_cl)
+                    tot["host_bytes"] += int(d.bytes); tot["copy_ms"] += float(d.copy_ms); tot["code_bytes"] += int(d.n_codes); tot["delivered_hits"] += int(d.n_cl); tot["exceptions"] += int(d.n_exc)
                 res[ci] = (tot, sst)
             except Exception as ex:      # noqa: BLE001 - raised again on the main thread
                 errs.append(ex)
@@ -281,7 +283,7 @@ def main():
     if not a.no_boundary and hasattr(eng, "overlap_batch_async"):
         bdt, bov, btot, bst = timed(True, max(1, a.boundary_contexts))
         boundary = {"q_assemble_ms_per_step": bst.get("q_assemble", 0.0) / a.steps, "stage_ms": {k: round(v / a.steps, 2) for k, v in bst.items()},"value": bov / (bdt / a.steps), "ms_per_step": bdt / a.steps * 1e3, "host_bytes_per_gpu_step": btot["host_bytes"], "wire_bytes_per_chained_hit": (btot["delivered_hits"] / 8 + btot["delivered_hits"] / 16 + btot["code_bytes"]) / max(1, btot["delivered_hits"]),
-                    "copy_ms_per_step": btot["copy_ms"], "host_ms_in_async": btot["t_async"], "host_ms_in_wait": btot["t_wait"], "copy_gb_per_s": btot["host_bytes"] / max(1e-9, btot["copy_ms"] * 1e-3) / 1e9}
+                    "copy_ms_per_step": btot["copy_ms"], "verbatim_hits_per_step": btot["exceptions"], "host_ms_in_async": btot["t_async"], "host_ms_in_wait": btot["t_wait"], "copy_gb_per_s": btot["host_bytes"] / max(1e-9, btot["copy_ms"] * 1e-3) / 1e9}
 
     if rank == 0:
         stage_ms = {k: v / a.steps for k, v in stage_sum.items()}
@@ -334,7 +336,7 @@ def main():
             "vs_baseline": None, "dtype": "u64 hashing / int32 + f64 chain scores", "data": "synthetic",
             "value_boundary": round(boundary["value"], 1) if boundary else None,
             "boundary": ({"ms_per_step": round(boundary["ms_per_step"], 3), "host_bytes_per_gpu_step": boundary["host_bytes_per_gpu_step"], "wire_bytes_per_chained_hit": round(boundary["wire_bytes_per_chained_hit"], 4),
-                          "copy_ms_per_step": round(boundary["copy_ms_per_step"], 2), "copy_gb_per_s": round(boundary["copy_gb_per_s"], 2),
+                          "copy_ms_per_step": round(boundary["copy_ms_per_step"], 2), "verbatim_hits_per_step": boundary["verbatim_hits_per_step"], "copy_gb_per_s": round(boundary["copy_gb_per_s"], 2),
                           "assemble_and_pack_ms_per_step": round(boundary["q_assemble_ms_per_step"], 2),
                           "host_ms_in_async": round(boundary["host_ms_in_async"], 1), "host_ms_in_wait": round(boundary["host_ms_in_wait"], 1),
                           "stage_ms": boundary["stage_ms"],

@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "hao_ft_cnt", "hao_pt_get", "hao_ft_table", "hao_pt_table", "hao_hist", "hao_stats", "hao_sketch_batch",
     "hao_fetch_sketch", "hao_overlap_batch", "hao_fetch_seed_hits", "hao_fetch_overlaps", "hao_batch_totals",
     "hao_stage_times", "hao_pass_default", "hao_overlap_batch_ex", "hao_set_shard", "hao_dist_unique_id", "hao_dist_init",
-    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits", "hao_exact_check", "hao_fetch_exact", "hao_window_ed_batch", "hao_index_save", "hao_attach", "hao_window_trace_batch",
+    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits", "hao_exact_check", "hao_fetch_exact", "hao_window_ed_batch", "hao_index_save", "hao_index_load", "hao_next_slot", "hao_attach", "hao_window_trace_batch",
 ]
 
 
@@ -103,6 +103,7 @@ def lib():
         L.hao_window_ed_batch.argtypes = [vp, vp, C.c_uint64, vp]
         L.hao_window_trace_batch.argtypes = [vp, C.c_int, vp, C.c_uint64, vp, vp, C.c_uint32]
         L.hao_index_save.argtypes = [vp, C.c_char_p, C.c_int32, vp]
+        L.hao_index_load.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int32)]
         L.hao_fetch_exact.argtypes = [vp, C.c_uint64, C.POINTER(vp), u64p]
         L.hao_unpack_hits.argtypes = [C.POINTER(Delivery), C.c_uint64, vp, C.c_uint64]; L.hao_unpack_hits.restype = C.c_uint64
         L.hao_set_shard.argtypes = [vp, C.c_uint64, C.c_uint64, u32p]
@@ -316,6 +317,12 @@ class Engine:
     def index_save(self, prefix, number_of_round=3):
         """write <prefix>.pt_flt / .pt_flt.bin / .pt_flt.paf.bin in the reference's resume format (write_pt_index, htab.cpp:1367)"""
         self._ck(self.L.hao_index_save(self.h, prefix.encode(), number_of_round, None), "hao_index_save")
+
+    def index_load(self, prefix):
+        """hao_index_load: read store + filter table + position index from <prefix>.pt_flt[.bin] -> number_of_round stored in the file"""
+        r = C.c_int32(0)
+        self._ck(self.L.hao_index_load(self.h, prefix.encode(), C.byref(r)), "hao_index_load")
+        return r.value
 
     def window_trace_batch(self, tasks, cap=80, mode=0):
         """tasks: uint32 [n,10] -> (int32 [n,6] (err, ps, pe, ts, te, cigar entries), uint16 [n,cap] cigars): alignment in the band with traceback;

@@ -15,6 +15,7 @@ struct hao_ctx::Batch {
 	DevBuf<hao_hit_t> hits, ohits, cl;
 	DevBuf<int32_t> f, ii, p, key_sc, tm; DevBuf<int64_t> t; DevBuf<uint64_t> key_xs; DevBuf<uint32_t> key_al, key_tmp;
 	DevBuf<hao_chain_rec> rec; DevBuf<hao_ovlp_t> ol; DevBuf<hao_cdesc> cd; bool cl_valid = false;
+	DevBuf<uint16_t> hq; DevBuf<uint8_t> hcode;      // delivery path: query minimizer index / wire code of every seed hit (seed kernel, chain_group_kernel)
 	DevBuf<uint8_t> pk_bytes; DevBuf<uint32_t> pk_cnt; uint64_t n_codes = 0;      // one code byte per chained hit (device only) before it is split into bits + code bytes
 	// Results of a batch that leave the device.  Two sets (+ two pinned host arenas): while the copy stream drains the set of batch i, batch i + 1
 	// computes into the other one (hao_overlap_batch_async).  The blocking API keeps using the current set.
@@ -261,12 +262,13 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		sa_.mz_off = c->d_ix_mz_off.p; sa_.mz_info = c->d_ix_mz_info.p; sa_.rid_lo = lo; sa_.mz0 = B.mz0; sa_.s_start = B.s_start.p; sa_.s_n = B.s_n.p; sa_.a_off = B.a_off.p; sa_.seg = B.seg.p;
 		sa_.sinfo = c->d_ix_sinfo.p; sa_.len = c->d_len_all.p; sa_.q_pos = B.q_pos.p; sa_.q_cnt = B.q_cnt.p; sa_.hits = B.hits.p; sa_.g_tmp = B.g_tmp.p; sa_.g_cnt = B.g_cnt.p; sa_.n_sel = n; sa_.tb = tb;
 		sa_.qcap = (uint32_t)std::min<uint64_t>((max_q + 63) & ~63ULL, HAO_QTAB_CAP);
-		sa_.dbg = nullptr;
+		sa_.dbg = nullptr; sa_.hq = nullptr;
+		if ((parts & HAO_DELIVER_CL) && !c->sw.pack_search) { HIP_TRY(B.hq.reserve(A + 64)); HIP_TRY(B.hcode.reserve(A + 64)); sa_.hq = B.hq.p; }
 		if (c->sw.seedphase) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); sa_.dbg = B.dbgbuf.p; }
 		HIP_TRY(B.ovf_list.reserve(n + 1));
 		unsigned long long *d_ovf = B.stats.p + 3 * HAO_NCLS + 3;
 		const uint32_t tile_ = c->sw.seed_tile == 512 ? 512 : 1024;
-		const size_t lds_tile = std::max<size_t>((size_t)tile_ * (sizeof(hao_stage_t) + 2), 12 * 512);      // staged tile (>= the 12 bytes per slot of the bin sort it shares memory with)
+		const size_t lds_tile = std::max<size_t>((size_t)tile_ * (sizeof(hao_stage_t) + 4), 12 * 512);      // staged tile (>= the 12 bytes per slot of the bin sort it shares memory with)
 		const size_t lds1 = (size_t)22 * 512 + lds_tile + 12 * (size_t)sa_.qcap + 16 + (size_t)c->sw.seed_lds_pad, lds2 = (size_t)22 * 2048 + std::max<size_t>(lds_tile, 12 * 2048) + 12 * (size_t)sa_.qcap + 16;      // (second launch: 2048 slots = up to 1760 bins per id-range round)
 		auto launch = [&](auto k1, auto k2) -> int {
 			{     // beyond the default dynamic LDS limit: opt in (the CU has 160 KB)
@@ -313,7 +315,8 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	if (G) {
 		hao_chain_args ca;
 		ca.hits = B.hits.p; ca.g_start = B.g_start.p; ca.g_read = B.g_read.p; ca.g_off = B.g_off.p; ca.seg = B.seg.p; ca.n_groups = G; ca.rid_lo = glo; ca.len = c->d_len_all.p; ca.par = par;
-		ca.dbg_qc = nullptr;
+		ca.dbg_qc = nullptr; ca.hq = nullptr; ca.hcode = nullptr;
+		if ((parts & HAO_DELIVER_CL) && !c->sw.pack_search) { ca.hq = B.hq.p; ca.hcode = B.hcode.p; }
 		if (c->sw.qcphase) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); ca.dbg_qc = B.dbgbuf.p; }
 		ca.stats = d_slow_cnt; ca.dbg_stats = c->sw.dp_stats ? 1 : 0;
 		ca.dbg_seq = c->sw.seq_chain ? 1 : (c->sw.dp_seqtail ? 3 : (c->sw.dp_nospec ? 4 : 0));
@@ -395,6 +398,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		HIP_TRY(O.bits.reserve(NWmax + 2)); HIP_TRY(O.rank.reserve(NWmax + 2)); HIP_TRY(B.pk_cnt.reserve(NWmax + 2)); HIP_TRY(O.codes.reserve(A + 16));
 		HIP_TRY(O.ch_off.reserve(n + 2)); HIP_TRY(O.cl_off.reserve(n + 2)); HIP_TRY(O.qm_off.reserve(n + 2)); HIP_TRY(O.qmz.reserve(nm + 1));
 		pa.cd = B.cd.p; pa.hits = B.hits.p; pa.ohits = B.ohits.p; pa.mz_off = c->d_ix_mz_off.p; pa.rid_lo = lo; pa.mz0 = B.mz0; pa.q_pos = B.q_pos.p;
+		if (!c->sw.pack_search) { pa.hq = B.hq.p; pa.hcode = B.hcode.p; }
 		pa.hdr = O.hdr.p; pa.bytes = B.pk_bytes.p; pa.exc = O.exc.p; pa.exc_cnt = d_exc_cnt; pa.exc_every = (uint32_t)c->sw.exc_every;
 		pa.exc_cap = c->sw.exc_cap >= 0 ? std::min<uint64_t>(O.exc.cap, (uint64_t)c->sw.exc_cap) : O.exc.cap;
 		if (int rc = pack()) return rc;

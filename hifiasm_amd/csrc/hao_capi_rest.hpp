@@ -142,6 +142,7 @@ int hao_deliver_wait(hao_ctx *c, int slot, hao_delivery_t *out)
 	HIP_TRY(hipSetDevice(c->device));
 	hao_ctx::Batch &B = *c->batch;
 	if (B.dl_pending[slot]) { HIP_TRY(hipEventSynchronize(B.ev_done[slot])); B.dl_pending[slot] = false; float ms = 0; if (hipEventElapsedTime(&ms, B.ev_ready[slot], B.ev_done[slot]) == hipSuccess) B.dl[slot].copy_ms = ms; }
+	if (B.dl[slot].n_ol && B.dl[slot].fc_off) ((uint64_t*)B.dl[slot].fc_off)[B.dl[slot].n_ol] = B.dl[slot].n_fc;      // end of the last cigar: set once the copy has landed (HAO_COPY_KERNEL rounds its sections up to 16 bytes and would overwrite an earlier store)
 	*out = B.dl[slot];
 	return HAO_OK;
 }
@@ -185,6 +186,21 @@ int hao_index_save(hao_ctx *c, const char *prefix, int32_t number_of_round, cons
 	HAO_NOT_ON_VIEW(c, "hao_index_save");
 	HIP_TRY(hipSetDevice(c->device));
 	return hao_index_save_impl(c, prefix, number_of_round, names);
+}
+
+int hao_next_slot(hao_ctx *c, int *slot)
+{
+	if (!c || !slot) return HAO_EINVAL;
+	*slot = c->batch ? (int)(c->batch->dl_seq & 1) : 0;
+	return HAO_OK;
+}
+
+int hao_index_load(hao_ctx *c, const char *prefix, int32_t *number_of_round)
+{
+	if (!c || !prefix) return HAO_EINVAL;
+	HAO_NOT_ON_VIEW(c, "hao_index_load");
+	HIP_TRY(hipSetDevice(c->device));
+	return hao_index_load_impl(c, prefix, number_of_round);
 }
 
 int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks, hao_ed_result_t *out)

@@ -153,6 +153,8 @@ struct hao_chain_args {
 	int32_t *tm;                                 // per-hit mark scratch for oversize groups
 	int dbg_seq, dbg_stats;          // dbg_seq: 1 one-lane sequential chaining, 3 one-lane DP tail, 4 no speculative tiles (all give identical results)
 	unsigned long long *dbg_qc;   // optional phase timers of chain_group_kernel (HAO_DBG_QCPHASE)
+	const uint16_t *hq; uint8_t *hcode;      // delivery path: query minimizer index of every seed hit (seed kernel) -> wire code byte of every seed hit relative to its
+	                                         // predecessor in the sorted order (hao_deliver.cuh): the quick check has both hits in registers anyway
 };
 
 // Sequential tail shared by both paths (ONE lane): backtrack the best chain, multi-copy chains
@@ -348,6 +350,8 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 	const uint32_t xid = (uint32_t)(A.rid_lo + e.r), yid = e.yid;
 	if (yid == xid || a_n <= 0) { if (lane == 0) { A.nch[g] = 0; A.nout[g] = 0; } return; }     // hits to the query itself are skipped (anchor.cpp:1931)
 	hao_hit_t hn = a[lane < a_n ? lane : 0];                     // tile 0; every later tile is requested one iteration ahead
+	const uint16_t *hqg = A.hcode ? A.hq + gs : nullptr; uint8_t *hcg = A.hcode ? A.hcode + gs : nullptr;
+	uint32_t qn = hcg ? hqg[lane < a_n ? lane : 0] : 0u, carry_q = 0;
 	const hao_hit_t first0 = hao_shfl_hit(hn, 0);
 	hao_cpar P; P.pen_gap = A.par.pen_gap; P.pen_skip = A.par.pen_skip; P.bw = A.par.bw; P.max_skip = A.par.max_skip; P.max_iter = A.par.max_iter; P.max_dis = A.par.max_dis;
 	P.xl = e.xl; P.yl = e.yl;
@@ -360,9 +364,17 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 	for (int64_t t0 = 0; t0 < a_n; t0 += 64) {
 		const int64_t idx = t0 + lane; const bool act = idx < a_n;
 		hao_hit_t h = act ? hn : carry_h;
-		if (idx + 64 < a_n) hn = a[idx + 64];
+		const uint32_t q = qn;
+		if (idx + 64 < a_n) { hn = a[idx + 64]; if (hcg) qn = hqg[idx + 64]; }
 		hao_hit_t ph = hao_shfl_up_hit(h); if (lane == 0) ph = carry_h;
 		const bool st = act && (idx == 0 || HH_STRAND(h) != HH_STRAND(ph));
+		if (hcg) {      // wire code of this hit relative to the previous one of its strand block: minimizers skipped << 4 | diagonal shift + 8; 0xff = not expressible
+			const uint32_t pq = hao_wave_shr1(q, carry_q);
+			const int32_t dq = (int32_t)(q - pq), sh = (int32_t)((h.offset - ph.offset) - (h.self_offset - ph.self_offset));
+			const uint8_t code = st ? (uint8_t)0x08 : ((dq < 1 || dq > 15 || sh < -8 || sh > 7 || q == 65535u) ? (uint8_t)0xff : (uint8_t)((dq - 1) << 4 | (sh + 8)));
+			if (act) hcg[idx] = code;
+			carry_q = hao_bcast(q, 63);
+		}
 		const int b = act && HH_STRAND(h) != strand0;
 		int32_t s = HH_SPAN(h); bool ok = true; int64_t dd = 0;
 		if (act && !st) { s = hao_pair_score(h, ph, P, &dd); ok = s != INT32_MIN; if (!ok) { s = 0; dd = 0; } }
@@ -814,7 +826,7 @@ __global__ __launch_bounds__(256) void chain_assemble_kernel(hao_asm_args A)
 			o.y_id = yid; o.y_pos_s = rc.y_pos_s; o.y_pos_e = rc.y_pos_e; o.y_pos_strand = rc.strand;
 			o.shared_seed = rc.score; o.align_length = rc.n_hits; o.non_homopolymer_errors = (uint32_t)(hd - cl0); o.fc_len = rc.fc_len;
 			A.ol[oi] = o; A.ol_fc_off[oi] = fd;
-			hao_cdesc d; d.src = (gs + rc.src_rel) | (rc.in_place ? 0 : HAO_CD_OHITS); d.dst = hd; d.n = rc.n_hits; d.w0 = (rc.strand << 31) | (ord & 0x7fffffffu); d.r = r; d.pad = 0;
+			hao_cdesc d; d.src = (gs + rc.src_rel) | (rc.in_place ? 0 : HAO_CD_OHITS); d.dst = hd; d.n = rc.n_hits; d.w0 = (rc.strand << 31) | (ord & 0x7fffffffu); d.r = r; d.pad = (rc.in_place && A.g_cls[g] >= 1) ? 1u : 0u;      // pad bit 0: the hits' wire codes exist (chain_group_kernel saw the group)
 			A.cd[oi] = d;
 			if (fl <= 8) for (uint32_t i = 0; i < fl; ++i) A.fc[fd + i] = fs[i];
 		}

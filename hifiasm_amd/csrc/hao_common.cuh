@@ -81,6 +81,13 @@ __device__ __forceinline__ int64_t hao_wave_sum_i64(int64_t v)
 #undef HAO_RED_STEP
 	return (int64_t)((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), 63) << 32 | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63));
 }
+__device__ __forceinline__ uint32_t hao_wave_min_u32(uint32_t v)
+{
+#define HAO_RED_STEP(CTRL, RM) v = min(v, (uint32_t)hao_dpp<CTRL, RM>(-1, (int)v));
+	HAO_RED_STEP(0x111, 0xf) HAO_RED_STEP(0x112, 0xf) HAO_RED_STEP(0x114, 0xf) HAO_RED_STEP(0x118, 0xf) HAO_RED_STEP(0x142, 0xa) HAO_RED_STEP(0x143, 0xc)
+#undef HAO_RED_STEP
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 // inclusive prefix sum over the wave (DPP)
 __device__ __forceinline__ uint32_t hao_wave_incl_scan_u32(uint32_t x)
 {

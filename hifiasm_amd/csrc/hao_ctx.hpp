@@ -43,6 +43,8 @@ struct StageTimer {
 		size_t i = names.size();
 		if (i >= ev.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev.push_back(e); }
 		names.push_back(name); (void)hipEventRecord(ev[i], st);
+		static const bool dbg_sync = getenv("HAO_DBG_SYNC") != nullptr;      // localise a device fault: wait for the stage and say its name
+		if (dbg_sync) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[stage] %s: %s\n", name, hipGetErrorString(e)); fflush(stderr); }
 	}
 	// after stream sync: ms between consecutive marks, labelled by the later mark
 	void collect(std::vector<std::pair<std::string, float> > &out) {
@@ -55,13 +57,13 @@ struct StageTimer {
 // run-time switches (measurement aids): read from the environment ONCE, in hao_create
 struct hao_switches {
 	bool seedphase = false, qcphase = false, dp_stats = false, seq_chain = false, dp_seqtail = false, dp_nospec = false, dp_serial = false,
-		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, sk_v2 = false, dltime = false;
+		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, sk_v2 = false, dltime = false, sk_nofuse = false, pack_search = false;
 	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; int exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, seed_lds_pad = 0, arena_numa = 1, seed_tile = 512;
 	void load() {
 		auto on = [](const char *n) { return getenv(n) != nullptr; };
 		seedphase = on("HAO_DBG_SEEDPHASE"); qcphase = on("HAO_DBG_QCPHASE"); dp_stats = on("HAO_DBG_DP_STATS"); seq_chain = on("HAO_DBG_SEQ_CHAIN");
 		dp_seqtail = on("HAO_DBG_DP_SEQTAIL"); dp_nospec = on("HAO_DBG_DP_NOSPEC"); dp_serial = on("HAO_DBG_DP_SERIAL"); seq_prune = on("HAO_DBG_SEQ_PRUNE");
-		selphase = on("HAO_DBG_SELPHASE"); sel1 = on("HAO_DBG_SEL1"); sk_generic = on("HAO_DBG_SK_GENERIC"); sk_v2 = on("HAO_DBG_SK_V2"); dltime = on("HAO_DBG_DLTIME");
+		selphase = on("HAO_DBG_SELPHASE"); sel1 = on("HAO_DBG_SEL1"); sk_generic = on("HAO_DBG_SK_GENERIC"); sk_v2 = on("HAO_DBG_SK_V2"); sk_nofuse = on("HAO_DBG_SK_NOFUSE"); pack_search = on("HAO_DBG_PACK_SEARCH");      // the wire packer searches every hit's minimizer (round-2 path) instead of gathering the quick check's code bytes dltime = on("HAO_DBG_DLTIME");
 		if (const char *e = getenv("HAO_CHAIN_WPB")) chain_wpb = std::max(1, std::min(4, atoi(e)));
 		if (const char *e = getenv("HAO_SPEC_MINCLS")) spec_mincls = atoi(e);
 		if (const char *e = getenv("HAO_DBG_SK_GCAP")) sk_gcap = atoll(e);
@@ -101,7 +103,7 @@ struct hao_ctx {
 	// ---- sketch workspace / results ----
 	uint64_t sk_lo = 0, sk_n = 0, sk_total = 0; bool sk_is_index = false;
 	DevBuf<uint64_t> d_tile_off; DevBuf<uint32_t> d_tile_ord, d_n_runs, d_tot_l; DevBuf<uint64_t> d_chunk_off, d_chunk_cnt64;
-	DevBuf<uint8_t> d_scalar_flag; DevBuf<uint32_t> d_scalar_list;
+	DevBuf<uint8_t> d_scalar_flag; DevBuf<uint32_t> d_scalar_list, d_unit_rid;
 	DevBuf<uint64_t> d_pool_x, d_pool_info; DevBuf<uint32_t> d_pool_ord; DevBuf<unsigned long long> d_cursor; DevBuf<int> d_err;
 	DevBuf<uint64_t> d_chunk_base, d_chunk_dst; DevBuf<uint32_t> d_chunk_cnt;
 	DevBuf<uint64_t> d_g_x, d_g_info; DevBuf<uint32_t> d_g_ord; DevBuf<uint64_t> d_g_off; DevBuf<uint32_t> d_new_n; DevBuf<uint64_t> d_new_n64;

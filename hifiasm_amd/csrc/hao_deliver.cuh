@@ -71,6 +71,7 @@ struct hao_pack_args {
 	const hao_cdesc *cd; const hao_hit_t *hits, *ohits;
 	const uint64_t *mz_off; uint64_t rid_lo, mz0; const uint32_t *q_pos;      // per-read minimizer ranges (global offsets) and the batch's self_offset table
 	hao_chain_hdr_t *hdr; uint8_t *bytes; hao_exc_t *exc; unsigned long long *exc_cnt; uint64_t exc_cap; uint32_t exc_every;
+	const uint16_t *hq; const uint8_t *hcode;      // per seed hit: query minimizer index (seed kernel), wire code (chain_group_kernel); null: every chain is searched
 };
 
 __global__ __launch_bounds__(256) void hao_pack_chains_kernel(hao_pack_args A, const uint64_t *n_chains_dev)
@@ -88,8 +89,31 @@ __global__ __launch_bounds__(256) void hao_pack_chains_kernel(hao_pack_args A, c
 	const hao_hit_t *src = hao_cd_src(d, A.hits, A.ohits);
 	const uint64_t m0 = A.mz_off[A.rid_lo + d.r]; const uint32_t nq = (uint32_t)(A.mz_off[A.rid_lo + d.r + 1] - m0);
 	const uint32_t *qp = A.q_pos + (m0 - A.mz0);
-	// the read's self_offset table goes to LDS once per chain (a few hundred entries, L2-resident): nine dependent LDS reads per hit instead of nine
-	// dependent global loads; longer tables (reads beyond ~35 kb) are searched in place
+	if (A.hcode && (d.pad & 1u) && nq < 65535u) {
+		// the common chain = a contiguous run of the sorted seed hits whose codes the quick check already wrote: a 1-byte gather per hit instead of the
+		// 16-byte hit + a search of its minimizer; only the first hit (header) and the hits without a code (verbatim list) are read
+		const uint64_t si = d.src;
+		for (uint32_t b = 0; b < d.n; b += 64) {
+			const uint32_t i = b + lane; const bool act = i < d.n;
+			uint8_t code = 0x08; bool esc = false;
+			if (act && i > 0) { code = A.hcode[si + i]; esc = code == 0xff || (A.exc_every && i % A.exc_every == A.exc_every - 1); if (esc) code = 0xff; }
+			if (b == 0 && lane == 0) { hao_chain_hdr_t H; H.n_hits = d.n; H.w0 = d.w0; H.q0 = A.hq[si]; H.offset = A.hits[si].offset; A.hdr[ci] = H; }
+			const unsigned long long em = __ballot(esc);
+			if (em) {
+				unsigned long long base = 0;
+				if (lane == 0) base = atomicAdd(A.exc_cnt, (unsigned long long)__popcll(em));
+				base = (unsigned long long)hao_readlane_i64((int64_t)base, 0);
+				if (esc) {
+					const uint64_t k = base + __popcll(em & ((1ULL << lane) - 1));
+					if (k < A.exc_cap) { hao_exc_t e; e.index = d.dst + i; e.q = A.hq[si + i]; e.pad = 0; e.hit = A.hits[si + i]; e.hit.w0 = d.w0; A.exc[k] = e; }
+				}
+			}
+			if (act) A.bytes[d.dst + i] = code;
+		}
+		continue;
+	}
+	// every other chain: the read's self_offset table goes to LDS once per read (a few hundred entries, L2-resident): nine dependent LDS reads per hit
+	// instead of nine dependent global loads; longer tables (reads beyond ~35 kb) are searched in place
 	const bool in_lds = nq <= HAO_PACK_QCAP;
 	if (in_lds && tab_read != d.r) {
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // (the previous chain's searches are done)

@@ -110,3 +110,141 @@ static int hao_index_save_impl(hao_ctx *c, const char *prefix, int32_t number_of
 	if (!ok) { hao_set_err(c, "short write on " + base + ".paf.bin"); return HAO_EINVAL; }
 	return HAO_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// The reader: an index dump of a stock hifiasm (write_pt_index, htab.cpp:1367-1430: <prefix>.pt_flt + .pt_flt.bin) - or one written by
+// hao_index_save - becomes the engine's state, as load_pt_index (htab.cpp:1432-1550) makes it the reference's: read store, high-count filter
+// table, position index, coverage peaks and max_n_chain.  What the file does not hold is derived here: the query side's read-ordered minimizers
+// (the reference re-sketches every query read; the engine sketches all reads once with the loaded filter table) and every minimizer's lookup result.
+// ---------------------------------------------------------------------------------------
+static bool hao_kh_read(FILE *fp, size_t vsz, std::vector<uint64_t> &keys, std::vector<uint8_t> &vals)
+{
+	uint32_t n_buckets = 0, bits = 0, count = 0; uint8_t ff = 0; keys.clear(); vals.clear();
+	if (fread(&n_buckets, 4, 1, fp) != 1 || fread(&bits, 4, 1, fp) != 1 || fread(&count, 4, 1, fp) != 1 || fread(&ff, 1, 1, fp) != 1) return false;
+	std::vector<uint32_t> used;
+	if (ff) { used.resize(n_buckets < 32 ? 1 : n_buckets >> 5); if (fread(used.data(), 4, used.size(), fp) != used.size()) return false; }
+	if (fread(&ff, 1, 1, fp) != 1) return false;
+	if (!ff) return count == 0;
+	const size_t bsz = 8 + vsz; std::vector<uint8_t> bk((size_t)n_buckets * bsz);
+	if (n_buckets && fread(bk.data(), bsz, n_buckets, fp) != n_buckets) return false;
+	if (used.empty()) return count == 0;
+	keys.reserve(count); vals.reserve((size_t)count * vsz);
+	for (uint32_t b = 0; b < n_buckets; ++b)
+		if (used[b >> 5] >> (b & 31) & 1) { uint64_t k; memcpy(&k, &bk[(size_t)b * bsz], 8); keys.push_back(k); vals.insert(vals.end(), &bk[(size_t)b * bsz + 8], &bk[(size_t)b * bsz + 8] + vsz); }
+	return keys.size() == count;
+}
+
+// lookup result of every read-ordered minimizer in the loaded index (what hao_index_finish_kernel leaves at build time)
+__global__ void hao_lk_fill_kernel(const uint64_t *mz_x, uint64_t n_mz, hao_pt_dev pt, uint64_t *lk)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_mz) return;
+	uint64_t st = 0; const uint32_t n = hao_pt_lookup(pt, mz_x[i], &st);
+	lk[i] = n ? (st | (uint64_t)n << 48) : 0;
+}
+
+
+static int hao_index_load_impl(hao_ctx *c, const char *prefix, int32_t *number_of_round)
+{
+	if (hao_is_sharded(c)) { hao_set_err(c, "hao_index_load: single-device mode only"); return HAO_EUNSUPP; }
+	const std::string base = std::string(prefix) + ".pt_flt";
+	FILE *fp = fopen(base.c_str(), "rb");
+	if (!fp) { hao_set_err(c, "cannot read " + base); return HAO_EINVAL; }
+	auto bad = [&](const std::string &what) { if (fp) fclose(fp); hao_set_err(c, "hao_index_load: " + what); return HAO_EINVAL; };
+	char mode = 0; bool have_ft = false, have_pt = false;
+	std::vector<uint64_t> ftk; std::vector<int32_t> ftv;
+	if (fread(&mode, 1, 1, fp) != 1) return bad("empty " + base);
+	if (mode == 'f') {
+		std::vector<uint64_t> k; std::vector<uint8_t> v;
+		if (!hao_kh_read(fp, 2, k, v)) return bad("filter table of " + base);
+		std::vector<std::pair<uint64_t, int32_t> > kv(k.size());
+		for (size_t i = 0; i < k.size(); ++i) { int16_t x; memcpy(&x, &v[2 * i], 2); kv[i] = std::make_pair(k[i], x == INT16_MAX ? INT32_MAX : (int32_t)x); }      // ha_ft_cnt's view of the value (htab.cpp:1064-1070)
+		std::sort(kv.begin(), kv.end());
+		ftk.resize(kv.size()); ftv.resize(kv.size());
+		for (size_t i = 0; i < kv.size(); ++i) { ftk[i] = kv[i].first; ftv[i] = kv[i].second; }
+		have_ft = true;
+		if (fread(&mode, 1, 1, fp) != 1) mode = 0;
+	}
+	struct Ent { uint64_t hash; uint32_t sub, cnt; uint64_t off; };
+	std::vector<Ent> ents; std::vector<std::vector<uint64_t> > pos;
+	if (mode == 'h') {
+		int32_t k = 0, pre = 0; uint64_t tot = 0, tot_pos = 0;
+		if (fread(&k, 4, 1, fp) != 1 || fread(&pre, 4, 1, fp) != 1 || fread(&tot, 8, 1, fp) != 1 || fread(&tot_pos, 8, 1, fp) != 1 || pre < 0 || pre > 20) return bad("index header of " + base);
+		if (k != c->opt.k) return bad("the index was built with k = " + std::to_string(k) + ", the engine runs with k = " + std::to_string(c->opt.k));
+		pos.resize((size_t)1 << pre); ents.reserve(tot);
+		std::vector<uint64_t> kk; std::vector<uint8_t> vv;
+		for (uint32_t s = 0; s < (1u << pre); ++s) {
+			uint64_t na = 0;
+			if (!hao_kh_read(fp, 8, kk, vv) || fread(&na, 8, 1, fp) != 1) return bad("sub-table " + std::to_string(s) + " of " + base);
+			pos[s].resize(na);
+			if (na && fread(pos[s].data(), 8, na, fp) != na) return bad("positions of sub-table " + std::to_string(s));
+			for (size_t i = 0; i < kk.size(); ++i) {      // key = hash >> pre << 12 | count (htab.cpp:122-124, 303-314), value = offset of its list
+				Ent e; e.hash = ((kk[i] >> 12) << pre) | s; e.sub = s; e.cnt = (uint32_t)(kk[i] & 4095); memcpy(&e.off, &vv[8 * i], 8);
+				if (e.off + e.cnt > na) return bad("a list of sub-table " + std::to_string(s) + " leaves its position array");
+				ents.push_back(e);
+			}
+		}
+		if (ents.size() != tot) return bad("key count of " + base);
+		have_pt = true;
+	}
+	if (!have_ft || !have_pt) return bad(base + " holds no filter table / position index");
+	int32_t rounds = 0, hom = -1, het = -1, mnc = 100;
+	if (fread(&rounds, 4, 1, fp) != 1 || fread(&hom, 4, 1, fp) != 1 || fread(&het, 4, 1, fp) != 1 || fread(&mnc, 4, 1, fp) != 1) return bad("tail of " + base);
+	fclose(fp); fp = nullptr;
+	if (number_of_round) *number_of_round = rounds;
+	// ---- the read store (load_All_reads, Process_Read.cpp:127-232) ----
+	fp = fopen((base + ".bin").c_str(), "rb");
+	if (!fp) { hao_set_err(c, "cannot read " + base + ".bin"); return HAO_EINVAL; }
+	int32_t adapter = 0; uint64_t index_size = 0, name_index_size = 0, n = 0, total_bases = 0, total_name = 0;
+	if (fread(&adapter, 4, 1, fp) != 1 || fread(&index_size, 8, 1, fp) != 1 || fread(&name_index_size, 8, 1, fp) != 1 || fread(&n, 8, 1, fp) != 1 || fread(&total_bases, 8, 1, fp) != 1 ||
+		fread(&total_name, 8, 1, fp) != 1 || n >= (1ULL << 28)) return bad("header of " + base + ".bin");
+	std::vector<uint64_t> ns_off(n + 1, 0), len64(n), pk_off(n + 1, 0); std::vector<uint32_t> ns, len(n); std::vector<uint8_t> packed;
+	for (uint64_t i = 0; i < n; ++i) {
+		uint64_t cnt = 0; if (fread(&cnt, 8, 1, fp) != 1) return bad("N sites of read " + std::to_string(i));
+		for (uint64_t j = 0; j < cnt; ++j) { uint64_t p; if (fread(&p, 8, 1, fp) != 1) return bad("N sites of read " + std::to_string(i)); ns.push_back((uint32_t)p); }
+		ns_off[i + 1] = ns.size();
+	}
+	if (n && fread(len64.data(), 8, n, fp) != n) return bad("read lengths");
+	for (uint64_t i = 0; i < n; ++i) { if (len64[i] >= (1ULL << 27)) return bad("read longer than 2^27"); len[i] = (uint32_t)len64[i]; pk_off[i + 1] = pk_off[i] + len64[i] / 4 + 1; }
+	packed.resize(pk_off[n] + 1);
+	if (pk_off[n] && fread(packed.data(), 1, pk_off[n], fp) != pk_off[n]) return bad("packed reads");
+	fclose(fp); fp = nullptr;      // (names, trio flags and the second copy of the peaks are not the engine's business)
+	if (int rc = hao_set_reads(c, packed.data(), pk_off.data(), len.data(), n, ns_off.data(), ns.empty() ? nullptr : ns.data())) return rc;
+	// ---- filter table ----
+	c->h_ft_keys = ftk; c->h_ft_vals = ftv; const uint64_t nf = ftk.size();
+	HIP_TRY(c->d_ft_keys.reserve(nf + 1)); HIP_TRY(c->d_ft_vals.reserve(nf + 1));
+	if (nf) { HIP_TRY(hipMemcpyAsync(c->d_ft_keys.p, ftk.data(), nf * 8, hipMemcpyHostToDevice, c->stream)); HIP_TRY(hipMemcpyAsync(c->d_ft_vals.p, ftv.data(), nf * 4, hipMemcpyHostToDevice, c->stream)); }
+	if (int rc = hao_build_bucket(c, c->d_ft_keys.p, nf, 16, c->d_ft_bucket)) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	c->has_ft = true; c->ft_peak_hom = -1; c->ft_peak_het = -1; c->ft_cutoff = 0; memset(c->ft_hist, 0, sizeof(c->ft_hist));
+	// ---- position index: keys ascending, every key's list in file order (= (rid, pos) order) ----
+	std::sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.hash < b.hash; });
+	const uint64_t nk = ents.size(); uint64_t np = 0; for (const Ent &e : ents) np += e.cnt;
+	std::vector<uint64_t> keys(nk), start(nk), sinfo(np); std::vector<uint32_t> cnt(nk);
+	{ uint64_t o = 0; for (uint64_t i = 0; i < nk; ++i) { const Ent &e = ents[i]; keys[i] = e.hash; start[i] = o; cnt[i] = e.cnt; memcpy(sinfo.data() + o, pos[e.sub].data() + e.off, (size_t)e.cnt * 8); o += e.cnt; } }
+	HIP_TRY(c->d_ix_keys.reserve(nk + 1)); HIP_TRY(c->d_ix_start.reserve(nk + 1)); HIP_TRY(c->d_ix_cnt.reserve(nk + 1)); HIP_TRY(c->d_ix_sinfo.reserve(np + 1));
+	if (nk) { HIP_TRY(hipMemcpyAsync(c->d_ix_keys.p, keys.data(), nk * 8, hipMemcpyHostToDevice, c->stream)); HIP_TRY(hipMemcpyAsync(c->d_ix_start.p, start.data(), nk * 8, hipMemcpyHostToDevice, c->stream));
+			  HIP_TRY(hipMemcpyAsync(c->d_ix_cnt.p, cnt.data(), nk * 4, hipMemcpyHostToDevice, c->stream)); }
+	if (np) HIP_TRY(hipMemcpyAsync(c->d_ix_sinfo.p, sinfo.data(), np * 8, hipMemcpyHostToDevice, c->stream));
+	c->ix_n_keys = nk; c->ix_n_pos = np; c->ix_n_sorted = np;
+	int bits = 16; while ((1ULL << bits) < nk / 2 && bits < 26) ++bits;
+	if (int rc = hao_build_bucket(c, c->d_ix_keys.p, nk, bits, c->d_ix_bucket)) return rc;
+	c->ix_bucket_bits = bits;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	c->hom_cov = hom; c->het_cov = het; c->max_n_chain = mnc; memset(c->pt_hist, 0, sizeof(c->pt_hist));
+	// ---- query side: read-ordered minimizers (with the loaded filter table) and their lookup results ----
+	if (n == 0) { hao_set_err(c, "hao_index_load: no reads"); return HAO_EINVAL; }
+	if (int rc = hao_sketch_run(c, 0, n, 1, c->opt.sample_dist, 1)) return rc;
+	std::swap(c->d_ix_mz_x, c->d_mz_x); std::swap(c->d_ix_mz_info, c->d_mz_info); std::swap(c->d_ix_mz_off, c->d_mz_off);
+	c->ix_n_mz = c->sk_total; c->sk_n = 0;
+	const uint64_t m = c->ix_n_mz;
+	if (m >= (1ULL << 32)) { hao_set_err(c, "more than 2^32 minimizers on one device"); return HAO_EUNSUPP; }
+	HIP_TRY(c->d_ix_lk.reserve(m + 1));
+	if (m) { hipLaunchKernelGGL(hao_lk_fill_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_x.p, m, hao_pt_view(c), c->d_ix_lk.p); HAO_CHECK_LAUNCH(); }
+	c->lk_valid = true;
+	c->h_ix_mz_off.resize(n + 1);
+	HIP_TRY(hipMemcpyAsync(c->h_ix_mz_off.data(), c->d_ix_mz_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	c->has_pt = true; c->h_ix_valid = false;
+	return HAO_OK;
+}

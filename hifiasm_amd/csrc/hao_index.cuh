@@ -206,20 +206,22 @@ __global__ void hao_bf_block_kernel(const uint64_t *kh, uint64_t n, int xb, uint
 	blk[i] = h == UINT64_MAX ? 1u << (12 + xb) : (uint32_t)((h & 4095) << xb | ((h >> 12) & ((1ULL << xb) - 1)));
 }
 
-// one lane per block run of the block-sorted list: flag[i] = 1 iff occurrence i found all four probe bits set
-__global__ __launch_bounds__(256) void hao_bf_replay_kernel(const uint32_t *blk, const uint64_t *kh, uint64_t n, int xb, uint8_t *flag)
+// One lane per block RUN of the block-sorted list (runs from a run-length pass: consecutive lanes take consecutive runs, every lane replays its ~n / 2^(bf_shift-9)
+// occurrences - about 20 at the reference's default on 30x human-size input): flag[j] = 1 iff occurrence j found all four probe bits set.  (One lane per
+// OCCURRENCE with only the run heads working left three lanes of a wave busy: minutes for the 5.6 G occurrences of BASELINE configs[2].)  flag[] is
+// zeroed beforehand: the sentinel run is skipped.
+__global__ __launch_bounds__(256) void hao_bf_replay_kernel(const uint32_t *run_blk, const uint32_t *run_len, const uint64_t *run_start, uint64_t n_runs, const uint64_t *kh, int xb, uint8_t *flag)
 {
 	__shared__ uint32_t st[256][17];
-	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	const uint32_t b = blk[i];
-	if (b >> (12 + xb)) { flag[i] = 0; return; }             // sentinel
-	if (i > 0 && blk[i - 1] == b) return;                      // not the first occurrence of its block
+	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_runs) return;
+	if (run_blk[r] >> (12 + xb)) return;                       // sentinels
 	uint32_t *w = st[threadIdx.x];
 #pragma unroll
 	for (int q = 0; q < 16; ++q) w[q] = 0;
 	const int nsh = xb + 9;
-	for (uint64_t j = i; j < n && blk[j] == b; ++j) {
+	const uint64_t j0 = run_start[r], j1 = j0 + run_len[r];
+	for (uint64_t j = j0; j < j1; ++j) {
 		const uint64_t x = kh[j] >> 12;
 		int h2 = (int)(x >> nsh & 511), z = (int)(x >> xb & 511), cnt = 0;
 		if ((h2 & 31) == 0) h2 = (h2 + 1) & 511;

@@ -18,6 +18,14 @@ __global__ void hao_chunk_count_kernel(const uint32_t *n_runs, const uint8_t *sc
 	cnt[r] = scalar_flag[r] ? 1 : (nm == 0 ? 1 : (nm + chunk - 1) / chunk);
 }
 
+// read of every unit (the unit kernel's one load instead of a search in chunk_off)
+__global__ void hao_unit_rid_kernel(const uint64_t *chunk_off, uint64_t n_sel, uint32_t *unit_rid)
+{
+	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_sel) return;
+	for (uint64_t u = chunk_off[r]; u < chunk_off[r + 1]; ++u) unit_rid[u] = (uint32_t)r;
+}
+
 static hao_ft_dev hao_ft_view(hao_ctx *c)
 {
 	hao_ft_dev f; f.keys = c->d_ft_keys.p; f.vals = c->d_ft_vals.p; f.bucket = c->d_ft_bucket.p; f.n = c->h_ft_keys.size();
@@ -72,6 +80,11 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 	}
 	c->timer.mark("sk_index");
 	HIP_TRY(c->d_chunk_base.reserve(n_chunks + 1)); HIP_TRY(c->d_chunk_cnt.reserve(n_chunks + 1)); HIP_TRY(c->d_chunk_dst.reserve(n_chunks + 2));
+	if (unit_variant) {
+		HIP_TRY(c->d_unit_rid.reserve(n_chunks + 1));
+		hipLaunchKernelGGL(hao_unit_rid_kernel, dim3((unsigned)((n_sel + 255) / 256)), dim3(256), 0, c->stream, c->d_chunk_off.p, n_sel, c->d_unit_rid.p);
+		HAO_CHECK_LAUNCH();
+	}
 	if (!slist.empty()) { HIP_TRY(c->d_ring.reserve(slist.size() * 256 * sizeof(hao_cand))); HIP_TRY(c->d_ringord.reserve(slist.size() * 256)); HIP_TRY(c->d_cnt_ws.reserve(slist.size() + 1)); }
 	const size_t smem = hao_sk_smem_bytes(w, k);
 	// pool: every candidate of every chunk (bound nb / 6, grown on overflow); gathered / final lists: an estimate well above the usual one minimizer per
@@ -98,7 +111,7 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 		a.packed = c->d_packed.p; a.pk_off = c->d_pk_off.p; a.len = c->d_len.p; a.tile_off = c->d_tile_off.p; a.tile_ord = c->d_tile_ord.p; a.n_runs = c->d_n_runs.p;
 		a.chunk_off = c->d_chunk_off.p; a.scalar_flag = c->d_scalar_flag.p; a.rid_lo = lo; a.n_sel = n_sel; a.k = k; a.w = w; a.hpc = c->opt.hpc; a.ft = hao_ft_view(c);
 		a.pool_x = c->d_pool_x.p; a.pool_info = c->d_pool_info.p; a.pool_ord = c->d_pool_ord.p; a.pool_cursor = c->d_cursor.p; a.pool_cap = cap;
-		a.chunk_base = c->d_chunk_base.p; a.chunk_cnt = c->d_chunk_cnt.p; a.err = c->d_err.p; a.pool_static = pool_static;
+		a.chunk_base = c->d_chunk_base.p; a.chunk_cnt = c->d_chunk_cnt.p; a.err = c->d_err.p; a.pool_static = pool_static; a.unit_rid = c->d_unit_rid.p; a.n_units = n_chunks;
 		if (unit_variant) {
 			if (use_ft && a.ft.n > 0) hipLaunchKernelGGL((sketch_unit_kernel<true, 51, 51>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, c->stream, a);
 			else hipLaunchKernelGGL((sketch_unit_kernel<false, 51, 51>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, c->stream, a);
@@ -115,16 +128,22 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 		}
 		if (!slist.empty()) { sa.pass = 1; hipLaunchKernelGGL(sketch_scalar_kernel, dim3((unsigned)((slist.size() + 63) / 64)), dim3(64), 0, c->stream, sa); HAO_CHECK_LAUNCH(); }
 		// everything downstream is sized by gcap, so the exact total is read back only once, at the end
-		HIP_TRY(c->d_g_x.reserve(gcap + 1)); HIP_TRY(c->d_g_info.reserve(gcap + 1)); HIP_TRY(c->d_g_ord.reserve(gcap + 1)); HIP_TRY(c->d_g_off.reserve(n_sel + 2));
-		hipLaunchKernelGGL(sketch_gather_kernel, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, c->stream, c->d_pool_x.p, c->d_pool_info.p, c->d_pool_ord.p,
-						   c->d_chunk_base.p, c->d_chunk_cnt.p, c->d_chunk_dst.p, n_chunks, c->d_g_x.p, c->d_g_info.p, c->d_g_ord.p, gcap, c->d_err.p);
-		HAO_CHECK_LAUNCH();
+		const bool thin = use_ft && (a.ft.n > 0 || c->sw.sk_nofuse) && sample_dist > w;      // (an empty filter table: no minimizer has a count, mz1_select_mz_h keeps everything)
+		HIP_TRY(c->d_g_off.reserve(n_sel + 2)); HIP_TRY(c->d_mz_x.reserve(gcap + 1)); HIP_TRY(c->d_mz_info.reserve(gcap + 1));
 		hipLaunchKernelGGL(sketch_read_off_kernel, dim3((unsigned)((n_sel + 256) / 256)), dim3(256), 0, c->stream, c->d_chunk_off.p, c->d_chunk_dst.p, n_sel, c->d_g_off.p);
 		HAO_CHECK_LAUNCH();
-		c->timer.mark("sk_gather");
-		HIP_TRY(c->d_mz_x.reserve(gcap + 1)); HIP_TRY(c->d_mz_info.reserve(gcap + 1));
-		const uint64_t *src_off = c->d_g_off.p;
-		if (use_ft && sample_dist > w) {
+		if (!thin) {      // pool -> final lists in one pass
+			HIP_TRY(hipMemcpyAsync(c->d_mz_off.p, c->d_g_off.p, (n_sel + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+			hipLaunchKernelGGL(sketch_gather_finish_kernel, dim3((unsigned)((n_sel + 3) / 4)), dim3(256), 0, c->stream, c->d_pool_x.p, c->d_pool_info.p, c->d_chunk_base.p, c->d_chunk_cnt.p,
+							   c->d_chunk_dst.p, c->d_chunk_off.p, lo + c->rid_base, n_sel, stamp_rid, c->d_mz_x.p, c->d_mz_info.p, gcap, c->d_err.p);
+			HAO_CHECK_LAUNCH();
+			c->timer.mark("sk_gather");
+		} else {
+			HIP_TRY(c->d_g_x.reserve(gcap + 1)); HIP_TRY(c->d_g_info.reserve(gcap + 1)); HIP_TRY(c->d_g_ord.reserve(gcap + 1));
+			hipLaunchKernelGGL(sketch_gather_kernel, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, c->stream, c->d_pool_x.p, c->d_pool_info.p, c->d_pool_ord.p,
+							   c->d_chunk_base.p, c->d_chunk_cnt.p, c->d_chunk_dst.p, n_chunks, c->d_g_x.p, c->d_g_info.p, c->d_g_ord.p, gcap, c->d_err.p);
+			HAO_CHECK_LAUNCH();
+			c->timer.mark("sk_gather");
 			HIP_TRY(c->d_new_n.reserve(n_sel + 2)); HIP_TRY(hipMemsetAsync(c->d_new_n.p + n_sel, 0, 4, c->stream));
 			hipLaunchKernelGGL(sketch_select_kernel, dim3((unsigned)((n_sel + 3) / 4)), dim3(256), 0, c->stream, c->d_g_x.p, c->d_g_info.p, c->d_g_ord.p, c->d_g_off.p,
 							   c->d_len.p, c->d_tot_l.p, lo, n_sel, sample_dist, c->opt.rewin, k, c->d_new_n.p, c->d_err.p);
@@ -132,12 +151,10 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 			auto it = rocprim::make_transform_iterator(c->d_new_n.p, U32ToU64());
 			if (int rc = hao_excl_scan_u64(c, it, c->d_mz_off.p, n_sel + 1)) return rc;
 			c->timer.mark("sk_select");
-		} else {
-			HIP_TRY(hipMemcpyAsync(c->d_mz_off.p, c->d_g_off.p, (n_sel + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+			hipLaunchKernelGGL(sketch_finish_kernel, dim3((unsigned)((n_sel + 3) / 4)), dim3(256), 0, c->stream, c->d_g_x.p, c->d_g_info.p, c->d_g_off.p, c->d_mz_off.p, lo + c->rid_base, n_sel, stamp_rid,
+							   c->d_mz_x.p, c->d_mz_info.p, c->d_err.p);
+			HAO_CHECK_LAUNCH();
 		}
-		hipLaunchKernelGGL(sketch_finish_kernel, dim3((unsigned)((n_sel + 3) / 4)), dim3(256), 0, c->stream, c->d_g_x.p, c->d_g_info.p, src_off, c->d_mz_off.p, lo + c->rid_base, n_sel, stamp_rid,
-						   c->d_mz_x.p, c->d_mz_info.p, c->d_err.p);
-		HAO_CHECK_LAUNCH();
 		int err = 0;
 		HIP_TRY(hipMemcpyAsync(&err, c->d_err.p, 4, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipMemcpyAsync(&total, c->d_mz_off.p + n_sel, 8, hipMemcpyDeviceToHost, c->stream));

@@ -68,6 +68,7 @@ struct hao_seed_args {
 	const uint64_t *s_start; const uint32_t *s_n; const uint64_t *a_off, *seg, *sinfo; const uint32_t *len, *q_pos, *q_cnt;
 	hao_hit_t *hits; uint64_t *g_tmp, *g_cnt; uint64_t n_sel; uint32_t qcap; int tb;
 	unsigned long long *dbg;      // optional: per-phase wall-clock ticks summed over workgroups (HAO_DBG_SEEDPHASE)
+	uint16_t *hq;      // optional (delivery path): index of the query minimizer of every hit (saturating at 65535), next to hits[]: the wire packer's codes need it (hao_deliver.cuh)
 };
 
 // Two launches cover a batch: <SMALL table, FIRST> takes every read and gives up (appends the read to ovf_list) when its bins do not fit in
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 {
 	constexpr uint32_t CAP = 1u << CAPLOG, MAXD = CAP - 288;      // at most MAXD + 256 bins are ever inserted (one per thread after the table fills), so probing terminates; CAP >= 512
 	constexpr int UA = 4;                        // tiles per lane in flight in the counting pass (chunks are multiples of 64 * UA anchors)
-	constexpr uint32_t STAGE_BYTES = HAO_SEED_TILE * (sizeof(hao_stage_t) + 2), SORT_BYTES = CAP * 12, UNION_BYTES = STAGE_BYTES > SORT_BYTES ? STAGE_BYTES : SORT_BYTES;
+	constexpr uint32_t STAGE_BYTES = HAO_SEED_TILE * (sizeof(hao_stage_t) + 4), SORT_BYTES = CAP * 12, UNION_BYTES = STAGE_BYTES > SORT_BYTES ? STAGE_BYTES : SORT_BYTES;
 	extern __shared__ uint32_t bs_smem[];
 	uint32_t *hk = bs_smem;                      // [CAP]    bin key (tid << 1 | rev) per slot
 	uint32_t *cwd = hk + CAP;                    // [CAP]    hits of the bin (pass A), its first output position (between the passes); pass B, per tile:
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 	uint32_t *tot = (uint32_t*)(sk + CAP);       // [CAP]    per-rank totals                          }
 	hao_stage_t *stage = (hao_stage_t*)sk;       // [TILE]   pass B: the tile's hits grouped by bin   } same memory
 	uint16_t *sslot = (uint16_t*)(stage + HAO_SEED_TILE);   // [TILE] slot of the staged hit          }
+	uint16_t *sq = sslot + HAO_SEED_TILE;                   // [TILE] query minimizer of the staged hit }
 	uint64_t *l_ss = (uint64_t*)((char*)sk + UNION_BYTES);  // [qcap]   list start of minimizer q in the position index | strand of the minimizer << 63
 	uint32_t *l_ao = (uint32_t*)(l_ss + S.qcap); // [qcap+1] first anchor of minimizer q, relative to the read
 	__shared__ uint32_t s_nd, s_ovf, s_c, s_wt[4]; __shared__ uint64_t s_ws[4], s_all;
@@ -314,13 +316,14 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 					if (ps[u] != 0xffffffffu) {
 						const uint32_t slot = ps[u] & 0xffffu, at = wcw[slot] + (ps[u] >> 16);
 						hao_stage_t z; z.offset = po[u]; z.self_offset = qp[u]; z.cnt = qn[u];
-						stage[at] = z; sslot[at] = (uint16_t)slot;
+						stage[at] = z; sslot[at] = (uint16_t)slot; sq[at] = (uint16_t)(qv[u] < 65535u ? qv[u] : 65535u);
 					}
 				__syncthreads();
 				for (uint32_t at = tid; at < tile_n; at += 256) {
 					const uint32_t slot = sslot[at], kk = hk[slot]; const hao_stage_t z = stage[at];
 					hao_hit_t h; h.w0 = kk >> 1 | kk << 31; h.offset = z.offset; h.self_offset = z.self_offset; h.cnt = z.cnt;
 					S.hits[s + (uint32_t)(cwd[slot] + at)] = h;      // (32-bit sum: cwd may have wrapped below zero)
+					if (S.hq) S.hq[s + (uint32_t)(cwd[slot] + at)] = sq[at];
 				}
 				for (uint32_t i = lane; i < CAP / 2; i += 64) ((uint32_t*)wcw)[i] = 0;      // own row only: nobody else reads it before the next tile's barrier
 			}

@@ -118,6 +118,7 @@ struct hao_sk_args {
 	// output pool (append order arbitrary) + per-chunk record
 	uint64_t *pool_x, *pool_info; uint32_t *pool_ord; unsigned long long *pool_cursor; uint64_t pool_cap;
 	uint64_t *chunk_base; uint32_t *chunk_cnt; int *err;
+	const uint32_t *unit_rid; uint64_t n_units;      // unit kernel: read of every unit
 	uint64_t pool_static;          // unit kernel: the first pool_static pool entries are fixed slots of SK3_SLOT entries per unit; the cursor allocates behind them
 };
 
@@ -589,6 +590,21 @@ __global__ __launch_bounds__(256) void sketch_gather_kernel(const uint64_t *pool
 	uint64_t b = chunk_base[ch], d = chunk_dst[ch]; uint32_t n = chunk_cnt[ch];
 	if (d + n > out_cap) { if (hao_lane() == 0 && n) *err = 1; return; }      // the gathered list is sized by an estimate: the host retries with the pool capacity
 	for (uint32_t i = hao_lane(); i < n; i += 64) { out_x[d + i] = pool_x[b + i]; out_info[d + i] = pool_info[b + i]; out_ord[d + i] = pool_ord[b + i]; }
+}
+
+// K_C + final in one pass (no thinning to run in between): one wave per read walks its chunks' pool segments and writes the final list, the read id
+// stamped into info.rid (sketch.cpp:577-578).  dst offsets = chunk_dst (exclusive scan of chunk_cnt).
+__global__ __launch_bounds__(256) void sketch_gather_finish_kernel(const uint64_t *pool_x, const uint64_t *pool_info, const uint64_t *chunk_base, const uint32_t *chunk_cnt,
+		const uint64_t *chunk_dst, const uint64_t *chunk_off, uint64_t rid_lo, uint64_t n_sel, int stamp_rid, uint64_t *ox, uint64_t *oinfo, uint64_t out_cap, int *err)
+{
+	const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= n_sel) return;
+	const uint64_t rid = stamp_rid ? ((rid_lo + r) & 0xfffffffULL) : 0ULL;
+	for (uint64_t ch = chunk_off[r]; ch < chunk_off[r + 1]; ++ch) {
+		const uint64_t b = chunk_base[ch], d = chunk_dst[ch]; const uint32_t n = chunk_cnt[ch];
+		if (d + n > out_cap) { if (hao_lane() == 0 && n) *err = 1; return; }
+		for (uint32_t i = hao_lane(); i < n; i += 64) { ox[d + i] = pool_x[b + i]; oinfo[d + i] = (pool_info[b + i] & ~0xfffffffULL) | rid; }
+	}
 }
 
 // per-read list bounds from the chunk scan: mz_off[r] = chunk_dst[chunk_off[r]]

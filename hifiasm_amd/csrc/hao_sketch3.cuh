@@ -110,10 +110,8 @@ __global__ __launch_bounds__(256) void sketch_unit_kernel(hao_sk_args a)
 	const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	hao_sk3_lds &S = lds_all[wv];
 	const uint64_t un = (uint64_t)blockIdx.x * 4 + (uint64_t)wv;          // this wave's unit
-	if (un >= a.chunk_off[a.n_sel]) return;
-	uint64_t lo = 0, hi = a.n_sel;
-	while (lo < hi) { const uint64_t m = (lo + hi) >> 1; if (a.chunk_off[m + 1] <= un) lo = m + 1; else hi = m; }
-	const uint64_t r = lo;
+	if (un >= a.n_units) return;
+	const uint64_t r = a.unit_rid[un];                                   // (hao_unit_rid_kernel: no search in chunk_off)
 	if (a.scalar_flag[r]) return;                                        // record written by the scalar kernel
 	const int ui = (int)(un - a.chunk_off[r]);
 	const uint64_t rid = a.rid_lo + r; const uint8_t *rd = a.packed + a.pk_off[rid]; const uint32_t L = a.len[rid];
@@ -130,24 +128,52 @@ __global__ __launch_bounds__(256) void sketch_unit_kernel(hao_sk_args a)
 	{
 		const uint32_t *tord = a.tile_ord + a.tile_off[r]; const uint32_t ntile = (L + HAO_SK_TILE - 1) / HAO_SK_TILE;
 		const uint32_t first = (uint32_t)rbase + 1u;
-		uint32_t tlo = 0, thi = ntile;                                    // last tile with tord[ti] < first: it holds run `first`
-		while (thi - tlo > 1) { const uint32_t m = (tlo + thi) >> 1; if (tord[m] < first) tlo = m; else thi = m; }
-#pragma unroll 1
+		// tile that holds run `first` = the last tile with tord[ti] < first (tord[ti] = runs that end before tile ti).  Runs are spread evenly enough
+		// that a proportional guess is at most one tile off: six neighbouring entries are requested at once and the tile is picked among them
+		// (one round of scalar-load latency instead of a binary search); anything else falls back to the search.
+		uint32_t tlo, tbv[SK3_SMAX];
+		{
+			uint32_t gt = (uint32_t)(((uint64_t)first * ntile) / (uint32_t)(T + 1)); if (gt >= ntile) gt = ntile - 1;
+			const uint32_t b0 = gt > 0 ? gt - 1 : 0;                        // entries b0 .. b0+5 (tord has ntile + 1 entries; clamp to ntile)
+			uint32_t v[6];
+#pragma unroll
+			for (int j = 0; j < 6; ++j) v[j] = tord[min(b0 + (uint32_t)j, ntile)];
+			int pick = -1;
+#pragma unroll
+			for (int j = 0; j < 3; ++j) if (pick < 0 && b0 + (uint32_t)j < ntile && v[j] < first && (b0 + (uint32_t)j + 1 >= ntile || v[j + 1] >= first)) pick = j;
+			if (pick >= 0) {
+				tlo = b0 + (uint32_t)pick;
+#pragma unroll
+				for (int s2 = 0; s2 < SK3_SMAX; ++s2) tbv[s2] = pick == 0 ? v[s2] : (pick == 1 ? v[s2 + 1] : v[s2 + 2]);
+			} else {
+				uint32_t lo2 = 0, hi2 = ntile;
+				while (hi2 - lo2 > 1) { const uint32_t m = (lo2 + hi2) >> 1; if (tord[m] < first) lo2 = m; else hi2 = m; }
+				tlo = lo2;
+#pragma unroll
+				for (int s2 = 0; s2 < SK3_SMAX; ++s2) tbv[s2] = tord[min(tlo + (uint32_t)s2, ntile)];
+			}
+		}
+		bool live[SK3_SMAX]; uint32_t Wd[SK3_SMAX], nxt[SK3_SMAX];
+#pragma unroll
+		for (int s = 0; s < SK3_SMAX; ++s) {                               // the (up to three) 16-base words of this lane: all loads in flight before the first is used
+			const uint32_t ti = tlo + (uint32_t)s, g0 = ti * HAO_SK_TILE + (uint32_t)lane * 16u;
+			live[s] = ti < ntile && tbv[s] < (uint32_t)kk1; Wd[s] = 0; nxt[s] = 0;
+			if (live[s] && g0 < L) sk3_load16(rd, g0, Wd[s], nxt[s]);
+		}
+#pragma unroll
 		for (int s = 0; s < SK3_SMAX; ++s) {
-			const uint32_t ti = tlo + (uint32_t)s; uint32_t tb = 0; bool live = ti < ntile;
-			if (live) { tb = tord[ti]; live = tb < (uint32_t)kk1; }
+			const uint32_t ti = tlo + (uint32_t)s, tb = tbv[s];
 			const uint32_t g0 = ti * HAO_SK_TILE + (uint32_t)lane * 16u;
-			uint32_t Wd = 0, nxt = 0, eb = 0;
-			if (live && g0 < L) { sk3_load16(rd, g0, Wd, nxt); eb = sk3_run_ends(Wd, nxt, L - g0, a.hpc); }
+			const uint32_t eb = (live[s] && g0 < L) ? sk3_run_ends(Wd[s], nxt[s], L - g0, a.hpc) : 0u;
 			const uint32_t n = __popc(eb), incl = hao_wave_incl_scan_u32(n);
-			const uint32_t o = live ? tb + incl - n + 1u : 0xffffffffu;   // ordinal of the first run that ends in this word (dead steps sort last)
+			const uint32_t o = live[s] ? tb + incl - n + 1u : 0xffffffffu;   // ordinal of the first run that ends in this word (dead steps sort last)
 			S.tab_o[s * 64 + lane] = o; S.tab_eb[s * 64 + lane] = eb;
 			if (lane == 0) S.tab_g0[s] = ti * HAO_SK_TILE;
-			if (!live) continue;
+			if (!live[s]) continue;
 			// dense 2-bit codes of the word's runs, first run lowest: one funnel shift per base pulls the code in from the top iff the base ends a run
 			uint32_t acc = 0; const uint32_t E2 = eb << 1;
 #pragma unroll
-			for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_alignbit(Wd >> (30 - 2 * j), acc, (E2 >> (30 - 2 * j)) & 3u);
+			for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_alignbit(Wd[s] >> (30 - 2 * j), acc, (E2 >> (30 - 2 * j)) & 3u);
 			const uint32_t dense = n ? acc >> (32 - 2 * n) : 0u;
 			uint32_t c0 = sk3_even_bits(dense & 0x55555555u), c1 = sk3_even_bits((dense >> 1) & 0x55555555u);
 			int p = (int)o - (int)first;                                  // plane bit of the word's first run
@@ -185,9 +211,12 @@ __global__ __launch_bounds__(256) void sketch_unit_kernel(hao_sk_args a)
 			else { f0l = __builtin_amdgcn_alignbit(R0m, R0l, sf); f0h = __builtin_amdgcn_alignbit(R0h, R0m, sf) & MH; f1l = __builtin_amdgcn_alignbit(R1m, R1l, sf); f1h = __builtin_amdgcn_alignbit(R1h, R1m, sf) & MH; }
 			const uint32_t r0l = __builtin_amdgcn_alignbit(N0m, N0l, i), r0h = __builtin_amdgcn_alignbit(N0h, N0m, i) & MH;
 			const uint32_t r1l = __builtin_amdgcn_alignbit(N1m, N1l, i), r1h = __builtin_amdgcn_alignbit(N1h, N1m, i) & MH;
-			const uint64_t f1 = (uint64_t)f1h << 32 | f1l, r1 = (uint64_t)r1h << 32 | r1l;
-			const bool fw = f1 < r1;
-			const uint64_t x0 = fw ? ((uint64_t)f0h << 32 | f0l) : ((uint64_t)r0h << 32 | r0l), x1 = fw ? f1 : r1;
+			// canonical strand: forward iff f1 < r1 (sketch.cpp:503) = the borrow of f1 - r1 (two 32-bit subtracts; a 64-bit compare costs 14 issue cycles)
+			uint32_t x0l, x0h, x1l, x1h, tmp;
+			asm("v_sub_co_u32 %4, vcc, %5, %9\n\tv_subb_co_u32 %4, vcc, %6, %10, vcc\n\tv_cndmask_b32 %0, %11, %7, vcc\n\tv_cndmask_b32 %1, %12, %8, vcc\n\tv_cndmask_b32 %2, %9, %5, vcc\n\tv_cndmask_b32 %3, %10, %6, vcc"
+				: "=&v"(x0l), "=&v"(x0h), "=&v"(x1l), "=&v"(x1h), "=&v"(tmp)
+				: "v"(f1l), "v"(f1h), "v"(f0l), "v"(f0h), "v"(r1l), "v"(r1h), "v"(r0l), "v"(r0h) : "vcc");
+			const uint64_t x0 = (uint64_t)x0h << 32 | x0l, x1 = (uint64_t)x1h << 32 | x1l;
 			const uint64_t y = hao_hash64(x0) + hao_hash64(x1);
 			if (HAS_FT) { const int32_t cnt = hao_ft_lookup(a.ft, y); p[i] = cnt < (1 << 28) ? sk3_proxy<true>(y, (uint32_t)cnt) : 0xffffffffu; }
 			else p[i] = sk3_proxy<false>(y, 0);
@@ -265,16 +294,24 @@ __global__ __launch_bounds__(256) void sketch_unit_kernel(hao_sk_args a)
 			S.kx[lane] = x; S.kc[lane] = c;
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-		if (lane == 0) {
+		{	// newest minimum of the keys of ordinals [ta, tb] (= lanes ta-K .. tb-K): the lane whose proxy is the range's minimum - one DPP reduction - when
+			// exactly one lane has it (then its key is the unique minimum); proxy ties go through the sequential scan
+			const bool early = T >= W + K - 1;
+			const int ta = early ? K : max(K, T - W + 1), tb = early ? W + K - 2 : T;
+			const uint64_t mx = S.kx[lane]; const uint32_t mc = S.kc[lane];
+			const bool inr = K + lane >= ta && K + lane <= tb;
+			const uint32_t mp = inr && mx != UINT64_MAX ? sk3_proxy<HAS_FT>(mx, mc) : 0xffffffffu;
+			const uint32_t pmin = hao_wave_min_u32(mp);
+			const unsigned long long at = __ballot(mp == pmin && inr);
 			int prev = -1; uint64_t px = UINT64_MAX; uint32_t pc = HAO_CNT_DUMMY;
-			if (T >= W + K - 1) {
-				const int tt0 = W + K - 1;
-				for (int t = K; t < tt0; ++t) { const uint64_t ox = S.kx[t - K]; const uint32_t oc = S.kc[t - K]; if (!sk3_lt(px, pc, ox, oc)) { px = ox; pc = oc; prev = t; } }   // newest minimum of [K, tt0-1]
-				if (prev >= 0 && px != UINT64_MAX && !sk3_lt(px, pc, S.kx[tt0 - K], S.kc[tt0 - K])) patch_on = 1;
-			} else {
-				for (int t = max(K, T - W + 1); t <= T; ++t) { const uint64_t ox = S.kx[t - K]; const uint32_t oc = S.kc[t - K]; if (!sk3_lt(px, pc, ox, oc)) { px = ox; pc = oc; prev = t; } }
-				patch_on = 2; if (!(prev >= 0 && px != UINT64_MAX)) prev = -1;
+			if (pmin != 0xffffffffu && __popcll(at) == 1) {
+				const int src = __ffsll((long long)at) - 1; prev = K + src; px = S.kx[src]; pc = S.kc[src];
+			} else if (pmin != 0xffffffffu || __popcll(at) > 0) {             // proxy tie (or a real key with the proxy of a dummy): exact scan, every lane the same
+				for (int t = ta; t <= tb; ++t) { const uint64_t ox = S.kx[t - K]; const uint32_t oc = S.kc[t - K]; if (!sk3_lt(px, pc, ox, oc)) { px = ox; pc = oc; prev = t; } }
+				if (px == UINT64_MAX) prev = -1;
 			}
+			if (early) { if (prev >= 0 && !sk3_lt(px, pc, S.kx[W - 1], S.kc[W - 1])) patch_on = 1; }      // key(t0) <= key(prev), t0 = W+K-1 = entry W-1
+			else patch_on = 2;
 			patch_prev = prev; pkx = px; pkc = pc;
 		}
 		patch_on = __builtin_amdgcn_readfirstlane(patch_on); patch_prev = __builtin_amdgcn_readfirstlane(patch_prev);

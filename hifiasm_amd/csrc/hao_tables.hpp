@@ -197,8 +197,23 @@ static int hao_bloom_filter(hao_ctx *c, uint64_t *in, uint64_t *alt, uint64_t n,
 	size_t tb = 0; rocprim::double_buffer<uint32_t> dk(blk.p, blk2.p); rocprim::double_buffer<uint64_t> dv(in, alt);
 	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, dk, dv, n, 0, 13 + xb, c->stream)); HIP_TRY(hao_tmp(c, tb));
 	HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, dk, dv, n, 0, 13 + xb, c->stream));      // stable: insertion order inside a block
-	hipLaunchKernelGGL(hao_bf_replay_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dk.current(), dv.current(), n, xb, flag.p);
-	HAO_CHECK_LAUNCH();
+	{	// runs of equal block id -> (block, length, start); one lane replays one run
+		const uint64_t max_runs = std::min<uint64_t>(n, (1ULL << (12 + xb)) + 1);
+		DevBuf<uint32_t> rk, rl; DevBuf<uint64_t> rs; uint64_t n_runs = 0;
+		HIP_TRY(rk.reserve(max_runs + 1)); HIP_TRY(rl.reserve(max_runs + 1)); HIP_TRY(rs.reserve(max_runs + 2)); HIP_TRY(c->d_cursor.reserve(2));
+		HIP_TRY(hipMemsetAsync(flag.p, 0, n, c->stream));
+		tb = 0;
+		HIP_TRY(rocprim::run_length_encode(nullptr, tb, dk.current(), n, rk.p, rl.p, (uint64_t*)c->d_cursor.p, c->stream)); HIP_TRY(hao_tmp(c, tb));
+		HIP_TRY(rocprim::run_length_encode(c->d_tmp.p, tb, dk.current(), n, rk.p, rl.p, (uint64_t*)c->d_cursor.p, c->stream));
+		HIP_TRY(hipMemcpyAsync(&n_runs, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		auto it = rocprim::make_transform_iterator(rl.p, U32ToU64());
+		if (int rc = hao_excl_scan_u64(c, it, rs.p, n_runs)) return rc;
+		hipLaunchKernelGGL(hao_bf_replay_kernel, dim3((unsigned)((n_runs + 255) / 256)), dim3(256), 0, c->stream, rk.p, rl.p, rs.p, n_runs, dv.current(), xb, flag.p);
+		HAO_CHECK_LAUNCH();
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		rk.release(); rl.release(); rs.release();
+	}
 	HIP_TRY(c->d_cursor.reserve(2));
 	tb = 0;
 	HIP_TRY(rocprim::select(nullptr, tb, dv.current(), flag.p, dv.alternate(), (uint64_t*)c->d_cursor.p, n, c->stream)); HIP_TRY(hao_tmp(c, tb));

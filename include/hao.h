@@ -193,6 +193,9 @@ typedef struct {
 	double copy_ms;                  /* from "batch computed" to "copy landed" (includes waiting behind the previous batch's copy); filled by hao_deliver_wait */
 } hao_delivery_t;
 int hao_overlap_batch_async(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi, const hao_pass_t *pass /* NULL: hao_pass_default */, uint32_t parts, int *slot);
+/* The delivery slot (0 / 1) the NEXT hao_overlap_batch_async of this context will write: the caller must have stopped reading that arena before it
+ * starts the batch (the engine alternates the two slots; asking it keeps that policy out of the caller). */
+int hao_next_slot(hao_ctx *c, int *slot);
 int hao_deliver_wait(hao_ctx *c, int slot, hao_delivery_t *out);
 /* cl->list of read rid (a read of the delivered batch) decoded into out[cap]; returns the number of hits (nothing is written if cap is too small) */
 uint64_t hao_unpack_hits(const hao_delivery_t *d, uint64_t rid, hao_hit_t *out, uint64_t cap);
@@ -246,6 +249,12 @@ int hao_window_trace_batch(hao_ctx *c, int mode, const hao_ed_task_t *tasks, uin
  * names[i] = read names or NULL ("r<i>"); number_of_round must equal the loader's -r (default 3: it exits otherwise, htab.cpp:1501-1505).
  * Needs hao_ft_gen + hao_pt_gen; single-device mode. */
 int hao_index_save(hao_ctx *c, const char *prefix, int32_t number_of_round, const char *const *names);
+/* The reader of the same files = load_pt_index (htab.cpp:1432-1550) for the engine: an index written by a stock hifiasm (write_pt_index) or by
+ * hao_index_save becomes the engine's read store (replaces hao_set_reads), filter table and position index (replace hao_ft_gen / hao_pt_gen), with the
+ * file's hom_cov / het_cov / max_n_chain; *number_of_round = the value stored in the file.  The read-ordered minimizers of the query side are
+ * sketched here with the loaded filter table (the reference re-sketches every query read).  The file's k must equal the engine's; w, HPC and the
+ * other options are the caller's to match, as with the reference.  Histograms are not in the file: hao_hist returns zeros afterwards. */
+int hao_index_load(hao_ctx *c, const char *prefix, int32_t *number_of_round);
 
 /* Per-read digests of the last batch's results, computed on the device (one workgroup per read) and copied to out[n] / out_kh[n]
  * (n = reads of the batch; out_kh may be NULL):

@@ -16,6 +16,7 @@
 #include <string.h>
 #include <zlib.h>
 #include <pthread.h>
+#include <time.h>
 #include <vector>
 #include "kseq.h"
 #include "CommandLines.h"
@@ -35,7 +36,8 @@ static bool g_reads_uploaded = false;
 // Streaming server behind h_ec_lchain.  Reads are cut into batches of g_bsz; a batch lives in one of the engine's two delivery slots.  kt_for hands
 // out mostly increasing read ids, so the first worker that needs batch k + 1 computes it (hao_overlap_batch_async: ~ms) while the other workers keep
 // decoding reads of batch k out of its arena; computing k + 1 recycles the slot of k - 1 once its readers have left.  A late request for an evicted
-// batch (work stealing) simply computes it again.  Everything below is guarded by g_mu; the arenas themselves are read outside the lock under a
+// batch (work stealing) simply computes it again.  A producer thread computes batch k + 1 as soon as the first worker touches batch k (look-ahead).
+// Everything below is guarded by g_mu; the arenas themselves are read outside the lock under a
 // per-slot reader count.
 struct slot_t { int64_t batch = -1; bool ready = false; int readers = 0; hao_delivery_t view; };
 static slot_t g_slot[2];
@@ -160,6 +162,54 @@ static_assert(sizeof(k_mer_hit) == sizeof(hao_hit_t), "k_mer_hit layout");
 // the slot that holds batch k and is ready, or -1 (g_mu held)
 static int find_slot(int64_t k) { for (int x = 0; x < 2; ++x) if (g_slot[x].batch == k && g_slot[x].ready) return x; return -1; }
 
+static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static uint64_t g_n_reads = 0; static int64_t g_prefetch = -1; static bool g_producer_on = false, g_lookahead = true;
+static double g_wait_s = 0, g_compute_s = 0; static uint64_t g_n_wait = 0, g_n_batches = 0, g_n_prefetched = 0;
+
+// Compute batch k of the current pass into the engine's next delivery slot (g_mu held on entry and exit; released around the device work).  The engine
+// says which slot it will write (hao_next_slot): that arena may still be read by stragglers of the batch it holds - wait for them first.
+static void compute_batch(int64_t k)
+{
+	g_computing = k;
+	int nx = 0; CK(hao_next_slot(g_hao, &nx));
+	while (g_slot[nx].readers) pthread_cond_wait(&g_cv, &g_mu);
+	g_slot[nx].batch = -1; g_slot[nx].ready = false;
+	const hao_pass_t ps = g_ps; const uint64_t n_reads = g_n_reads;
+	pthread_mutex_unlock(&g_mu);
+	const double t0 = now_s();
+	const uint64_t lo = (uint64_t)k * g_bsz, hi = lo + g_bsz < n_reads ? lo + g_bsz : n_reads; int got = -1; hao_delivery_t view;
+	// the final round (worker_hap_dc_ec_gen_new_idx, ecovlp.cpp:3948-3972: the one call site with bw_thres = 0.001) reads ol->list only - h_ec_lchain_fast_new
+	// and push_ff_ovlp never look at cl->list - so its chained hits stay on the device: nothing but overlap records and fake cigars crosses PCIe there
+	const uint32_t parts = HAO_DELIVER_OL | (ps.bw_thres == 0.001 && !getenv("HAO_SHIM_FINAL_CL") ? 0u : (uint32_t)HAO_DELIVER_CL);
+	CK(hao_overlap_batch_async(g_hao, lo, hi, &ps, parts, &got));
+	CK(hao_deliver_wait(g_hao, got, &view));
+	pthread_mutex_lock(&g_mu);
+	if (got != nx) die("delivery slot order");
+	g_slot[got].batch = k; g_slot[got].ready = true; g_slot[got].view = view;
+	g_compute_s += now_s() - t0; ++g_n_batches;
+	g_computing = -1;
+	pthread_cond_broadcast(&g_cv);
+}
+
+static void *producer_main(void *)
+{
+	pthread_mutex_lock(&g_mu);
+	for (;;) {
+		while (g_prefetch < 0 || g_computing >= 0 || !g_ps_valid) pthread_cond_wait(&g_cv, &g_mu);
+		const int64_t k = g_prefetch; g_prefetch = -1;
+		if (find_slot(k) >= 0 || (uint64_t)k * g_bsz >= g_n_reads) continue;      // a worker got there first / past the end
+		compute_batch(k); ++g_n_prefetched;
+	}
+	return NULL;
+}
+
+__attribute__((destructor)) static void shim_report()
+{
+	if (getenv("HAO_SHIM_STATS") && g_n_batches)
+		fprintf(stderr, "[hao-shim] %llu batches of %llu reads (%llu by the look-ahead thread), %.1f ms each on the device path; workers waited for a batch %llu times, %.2f ms per batch in total\n",
+				(unsigned long long)g_n_batches, (unsigned long long)g_bsz, (unsigned long long)g_n_prefetched, 1e3 * g_compute_s / g_n_batches, (unsigned long long)g_n_wait, 1e3 * g_wait_s / g_n_batches);
+}
+
 void h_ec_lchain(ha_abuf_t *ab, uint32_t rid, char* rs, uint64_t rl, uint64_t mz_w, uint64_t mz_k, All_reads *rref, overlap_region_alloc *overlap_list, Candidates_list *cl, double bw_thres,
 				 int max_n_chain, int apend_be, kvec_t_u8_warp* k_flag, kvec_t_u64_warp* dbg_ct, st_mt_t *sp, uint32_t *high_occ, uint32_t *low_occ, uint32_t is_accurate, uint32_t gen_off,
 				 int64_t mcopy_num, double mcopy_rate, uint32_t chain_cutoff, uint32_t mcopy_khit_cut, uint64_t ocv_w)
@@ -171,31 +221,29 @@ void h_ec_lchain(ha_abuf_t *ab, uint32_t rid, char* rs, uint64_t rl, uint64_t mz
 	ps.chain_cutoff = chain_cutoff; ps.mcopy_khit_cut = mcopy_khit_cut; ps.ocv_w = ocv_w;
 	const uint64_t n_reads = rref->total_reads;
 	pthread_mutex_lock(&g_mu);
-	if (!g_bsz) { const char *e = getenv("HAO_SHIM_BATCH"); g_bsz = e ? strtoull(e, 0, 10) : 4096; if (!g_bsz) g_bsz = 4096; }
+	if (!g_bsz) { const char *e = getenv("HAO_SHIM_BATCH"); g_bsz = e ? strtoull(e, 0, 10) : 4096; if (!g_bsz) g_bsz = 4096; g_lookahead = getenv("HAO_SHIM_NO_LOOKAHEAD") == NULL; }
 	// a new pass (other arguments - e.g. the final round's bw_thres = 0.001, ecovlp.cpp:3957 - or a rebuilt index): drain the readers, forget the slots
 	while (!g_ps_valid || g_ps_gen != g_index_gen || memcmp(&g_ps, &ps, sizeof(ps)) != 0) {
 		if (g_computing >= 0 || g_slot[0].readers || g_slot[1].readers) { pthread_cond_wait(&g_cv, &g_mu); continue; }
+		g_prefetch = -1;      // (a look-ahead request of the old pass that nobody has started)
 		g_ps = ps; g_ps_gen = g_index_gen; g_ps_valid = true;
 		for (int x = 0; x < 2; ++x) { g_slot[x].batch = -1; g_slot[x].ready = false; }
 	}
 	const int64_t k = (int64_t)(rid / g_bsz);
-	int sl;
+	g_n_reads = n_reads;
+	int sl; bool waited = false; const double tw0 = now_s();
 	while ((sl = find_slot(k)) < 0) {
-		if (g_computing >= 0) { pthread_cond_wait(&g_cv, &g_mu); continue; }       // somebody is computing (maybe this very batch): wait and look again
-		// compute batch k here.  The engine will reuse the slot it used two batches ago: wait until nobody reads that arena any more
-		g_computing = k;
-		// (which slot that is is the engine's business: it alternates; both must be idle only if the victim is unknown - track it by the returned slot)
-		static int next_slot = 0;
-		while (g_slot[next_slot].readers) pthread_cond_wait(&g_cv, &g_mu);
-		g_slot[next_slot].batch = -1; g_slot[next_slot].ready = false;
-		pthread_mutex_unlock(&g_mu);
-		const uint64_t lo = (uint64_t)k * g_bsz, hi = lo + g_bsz < n_reads ? lo + g_bsz : n_reads; int got = -1; hao_delivery_t view;
-		CK(hao_overlap_batch_async(g_hao, lo, hi, &ps, HAO_DELIVER_OL | HAO_DELIVER_CL, &got));
-		CK(hao_deliver_wait(g_hao, got, &view));
-		pthread_mutex_lock(&g_mu);
-		if (got != next_slot) die("delivery slot order");
-		g_slot[got].batch = k; g_slot[got].ready = true; g_slot[got].view = view; next_slot = got ^ 1;
-		g_computing = -1;
+		waited = true;
+		if (g_computing >= 0) { pthread_cond_wait(&g_cv, &g_mu); continue; }       // somebody (a worker or the look-ahead thread) is computing - maybe this very batch: wait and look again
+		compute_batch(k);                                                           // (drops and retakes g_mu around the device work)
+	}
+	if (waited) { g_wait_s += now_s() - tw0; ++g_n_wait; }
+	// look-ahead: kt_for hands out ascending read ids, so batch k + 1 is needed as soon as the workers are through with k - the first reader of k asks
+	// the producer thread for it now, and it computes + lands in the other arena while k is being decoded (without it every worker would finish k and
+	// then all of them would sit through the whole compute + copy of k + 1)
+	if (g_lookahead && (uint64_t)(k + 1) * g_bsz < n_reads && find_slot(k + 1) < 0 && g_computing != k + 1 && g_prefetch != k + 1) {
+		g_prefetch = k + 1;
+		if (!g_producer_on) { g_producer_on = true; pthread_t th; if (pthread_create(&th, NULL, producer_main, NULL) != 0) die("pthread_create"); pthread_detach(th); }
 		pthread_cond_broadcast(&g_cv);
 	}
 	++g_slot[sl].readers;
@@ -216,10 +264,10 @@ void h_ec_lchain(ha_abuf_t *ab, uint32_t rid, char* rs, uint64_t rl, uint64_t mz
 		memcpy(z->f_cigar.buffer, d.fc + d.fc_off[i], sizeof(uint64_t) * o.fc_len); z->f_cigar.length = o.fc_len;
 	}
 	// cl->list: the wire bytes decode straight into the caller's list (k_mer_hit and hao_hit_t share their layout, Hash_Table.h:116-120)
-	const uint64_t n_cl = d.cl_off[r + 1] - d.cl_off[r];
+	const uint64_t n_cl = d.cl_off ? d.cl_off[r + 1] - d.cl_off[r] : 0;      // (no cl_off: a batch delivered without its chained hits - the final round)
 	clear_Candidates_list(cl);
 	if ((uint64_t)cl->size < n_cl + 1) { cl->size = n_cl + 1; REALLOC(cl->list, cl->size); }
-	if (hao_unpack_hits(&d, rid, (hao_hit_t*)cl->list, n_cl) != n_cl) die("hao_unpack_hits");
+	if (n_cl && hao_unpack_hits(&d, rid, (hao_hit_t*)cl->list, n_cl) != n_cl) die("hao_unpack_hits");
 	cl->length = n_cl;
 	pthread_mutex_lock(&g_mu);
 	if (--g_slot[sl].readers == 0) pthread_cond_broadcast(&g_cv);

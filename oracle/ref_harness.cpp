@@ -132,7 +132,7 @@ static tbuf_t *tbuf_init(int n)
 int main(int argc, char *argv[])
 {
 	int no_tables_hist = 0, ft_tables = 0;
-	int n_thread = 1, is_ont = 0, do_time = 0, dump_hits = 1, k = -1, w = -1, bf_shift = 0, no_hpc = 0, no_tables = 0, do_digest = 0; const char *fa = 0, *list_fn = 0, *hg = 0, *ed_fn = 0, *edg_fn = 0, *eds_fn = 0, *ed1_fn = 0, *ed2_fn = 0, *load_pfx = 0; std::string prefix;
+	int n_thread = 1, is_ont = 0, do_time = 0, dump_hits = 1, k = -1, w = -1, bf_shift = 0, no_hpc = 0, no_tables = 0, do_digest = 0; const char *fa = 0, *list_fn = 0, *hg = 0, *ed_fn = 0, *edg_fn = 0, *eds_fn = 0, *ed1_fn = 0, *ed2_fn = 0, *load_pfx = 0, *save_pfx = 0; std::string prefix;
 	double bw_arg = -1;
 	for (int i = 1; i < argc; ++i) {
 		if (!strcmp(argv[i], "--ont")) is_ont = 1;
@@ -156,6 +156,7 @@ int main(int argc, char *argv[])
 		else if (!strcmp(argv[i], "--ed1-tasks")) ed1_fn = argv[++i];
 		else if (!strcmp(argv[i], "--ed2-tasks")) ed2_fn = argv[++i];
 		else if (!strcmp(argv[i], "--load-index")) load_pfx = argv[++i];
+		else if (!strcmp(argv[i], "--save-index")) save_pfx = argv[++i];      // write_pt_index (htab.cpp:1367) after ha_pt_gen: <prefix>.pt_flt, .pt_flt.bin, .pt_flt.paf.bin
 		else fa = argv[i];
 	}
 	if (!fa) { fprintf(stderr, "usage: ref_harness [--ont] [-t N] [-k K] [-w W] [-f BLOOM_BITS] [--dump PREFIX] [--time] reads.fa\n"); return 1; }
@@ -187,6 +188,7 @@ int main(int argc, char *argv[])
 		ha_idx = ha_pt_gen(&asm_opt, ha_flt_tab, 0, 0, &R_INF, &hom_cov, &het_cov);
 		asm_opt.hom_cov = hom_cov; asm_opt.het_cov = het_cov;
 		t_pt = yak_realtime() - t0;
+		if (save_pfx && !write_pt_index(ha_flt_tab, ha_idx, &R_INF, &asm_opt, (char*)save_pfx)) { fprintf(stderr, "write_pt_index(%s) failed\n", save_pfx); return 1; }
 	}
 
 	uint64_t n_reads = R_INF.total_reads;

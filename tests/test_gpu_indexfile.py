@@ -52,3 +52,43 @@ def test_reference_loads_the_gpu_built_index(name):
     assert (crc == g["cl_crc"]).all()
     for key in ("hom_cov", "het_cov", "max_n_chain", "high_occ", "low_occ"):
         assert dump["meta"][key] == g["meta"][key], key
+
+
+@pytest.mark.parametrize("name", ["hifi", "rr", "nn", "ont", "edge"])
+def test_engine_loads_the_reference_built_index(name):
+    """the other direction: the UNMODIFIED reference builds the index from the FASTA and writes it (write_pt_index, htab.cpp:1367, through
+    ref_harness --save-index); hao_index_load makes it the engine's state - read store, filter table, position index, peaks - and everything the
+    engine then computes equals the golden dump / the oracle: tables, thresholds, minimizers, every read's overlaps, fake cigars and chained hits"""
+    if not os.path.exists(HARNESS):
+        pytest.skip("oracle/_ref/ref_harness not built (needs /root/reference at build time)")
+    from hifiasm_amd import synth
+    from hifiasm_amd.api import Engine
+    from helpers import scenario_oracle
+    rs, okw = scenario_reads(name)
+    g = load_golden(name)
+    d = tempfile.mkdtemp(prefix="hao_idx_")
+    ont = bool(okw.get("is_ont"))
+    fa = os.path.join(d, "r.fq" if ont else "r.fa")
+    synth.write_fasta(fa, rs, fastq=ont)
+    cmd = [HARNESS, "-t", "2", "--save-index", os.path.join(d, "ref")] + (["--ont"] if ont else [])
+    r = subprocess.run(cmd + [fa], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    e = Engine(0, **okw)
+    assert e.index_load(os.path.join(d, "ref")) == 3                       # the reference's default -r
+    keys, vals = e.ft_table()
+    assert keys.shape == g["ft_keys"].shape and (keys == g["ft_keys"]).all() and (vals == g["ft_vals"]).all()
+    pk, po, pp = e.pt_table()
+    assert (pk == g["pt_keys"]).all() and (po == g["pt_off"]).all() and (pp == g["pt_pos"]).all()
+    st = e.stats()
+    for key in ("hom_cov", "het_cov", "max_n_chain", "high_occ", "low_occ"):
+        assert st[key] == g["meta"][key], key
+    o = scenario_oracle(name)
+    e.overlap_batch(0, rs.n)
+    for rid in range(rs.n):
+        ol, fc, fo, cl = e.h_ec_lchain(rid)
+        ool, ofc, ofo, ocl = o.lchain(rid)
+        assert ol.shape == ool.shape and (ol == ool).all() and (fc == ofc).all() and cl.shape == ocl.shape and (cl == ocl).all(), rid
+    e.sketch_batch(0, rs.n)
+    for rid in range(0, rs.n, 7):
+        assert (e.fetch_sketch(rid) == o.sketch(rid)).all(), rid
+    e.close()

@@ -1,7 +1,7 @@
 """Summarise a rocprofv3 --pmc SQ_* pass into the sketch kernel's instruction counts (profiles/r02/sketch_alu.json).
 usage: python tools/sketch_alu.py <counter dir> <bases in the pass> [kernel name prefix]"""
 import csv, glob, json, re, sys
-root, bases = sys.argv[1], float(sys.argv[2]); pref = sys.argv[3] if len(sys.argv) > 3 else "sketch_chunk_wave_kernel"
+root, bases = sys.argv[1], float(sys.argv[2]); pref = sys.argv[3] if len(sys.argv) > 3 else "sketch_unit_kernel"
 acc, disp_seen = {}, set()
 for f in glob.glob(f"{root}/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -17,9 +17,6 @@ if "SQ_INSTS_SALU" in acc:
     out["salu_wave_insts_per_base"] = acc["SQ_INSTS_SALU"] / bases
 if "SQ_INSTS_LDS" in acc:
     out["lds_wave_insts_per_base"] = acc["SQ_INSTS_LDS"] / bases
-if "SQ_ACTIVE_INST_VALU" in acc and "SQ_BUSY_CYCLES" in acc and acc["SQ_BUSY_CYCLES"]:
-    # SQ_ACTIVE_INST_VALU: cycles (x4, per-SIMD quad) with a VALU instruction in flight, summed over SQs; SQ_BUSY_CYCLES: SQ-busy cycles summed the same way
-    out["valu_active_over_busy"] = acc["SQ_ACTIVE_INST_VALU"] / acc["SQ_BUSY_CYCLES"]
 if "SQ_WAVE_CYCLES" in acc and acc.get("SQ_WAVE_CYCLES"):
     for k in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"):
         if k in acc: out[k.lower() + "_over_wave_cycles"] = acc[k] / acc["SQ_WAVE_CYCLES"]
