@@ -8,9 +8,10 @@ The read store is resident in HBM before the timed region (hao_set_reads) and ha
 BASELINE.md 2b).  Default workload = BASELINE.json configs[2], the largest single-GPU configuration: synthetic 250 Mb genome,
 30x HiFi, 500 000 reads of 15 kb, 0.1 % error (`--workload bacterial5M_hifi30x` = configs[1]).
 
-`value` is the HBM-resident rate (results stay on the device, as the contract asks); `value_boundary` is the rate of the same step
-when every batch's results (ol->list, fake cigars, cl->list in the packed wire format of include/hao.h) are also delivered into
-pinned host memory through the streaming path (hao_overlap_batch_async: the download of batch i runs under the compute of batch i+1).
+`value` is the rate of the step with every batch's results (ol->list, fake cigars, cl->list in the packed wire format of
+include/hao.h) delivered into pinned host memory through the streaming path (hao_overlap_batch_async: the download of batch i runs
+under the compute of batch i+1) - what h_ec_lchain's callers actually get; `value_resident` is the same step with the results left in
+HBM (the per-kernel roofline figures come from that run: every kernel alone on the device).  `--no-boundary` measures only the latter.
 
 `--gpus N` with N > 1 launches N ranks itself (torch.distributed.run, one rank per GPU, RCCL) when it was not started by a launcher;
 under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.  N > 1: ONE all-vs-all problem whose genome is N x the single-GPU genome, so
@@ -39,13 +40,11 @@ from hifiasm_amd.workloads import WORKLOADS, n_reads_of  # noqa: E402
 STRONG = {"human3G_hifi40x", "ont_human_30x"}      # fixed-size problems: the read set is split over the ranks
 # algorithmic bytes per unit (stated again in DESIGN.md 4)
 ALG = {
-    "sketch_chunk_wave_kernel": ("base", 0.25 + 16.0 / 35.0),       # 2-bit bases in + one 16-B minimizer per ~35 bases out
+    "sketch_unit_kernel": ("base", 0.25 + 16.0 / 35.0),             # 2-bit bases in + one 16-B minimizer per ~35 bases out
     "chain_group_kernel": ("anchor", 16 + 4),                        # k_mer_hit in + fake-cigar / record out (hits stay in place)
-    "chain_assemble_kernel": ("anchor", 16 + 16),                    # chained hit in + tagged hit out
     "seed_bin_kernel": ("anchor", 8 + 16),                           # index record in, k_mer_hit out (bins, order and groups in LDS)
 }
-KERN_STAGE = {"sketch_chunk_wave_kernel": "sk_chunks", "chain_group_kernel": "q_chain", "chain_assemble_kernel": "q_assemble",
-              "seed_bin_kernel": "q_sort_bins"}
+KERN_STAGE = {"sketch_unit_kernel": "sk_chunks", "chain_group_kernel": "q_chain", "seed_bin_kernel": "q_sort_bins"}
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2      # G wave-level VALU instructions / s: 256 CUs x 4 SIMD-32 x 2.4 GHz, a wave64 instruction issues over 2 cycles (MI355X_MICROARCH.md)
 
@@ -90,7 +89,7 @@ def cpu_baseline(workload, mode="sample", threads=None):
             cmd = [harness, "-t", str(cores), "--time"] + (["--ont"] if ont else []) + [fa]
             r = subprocess.run(cmd, capture_output=True, text=True, cwd=d)
             j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-            return {"value": j["overlaps_per_sec"], "unit": "overlaps/s", "cores": cores, "kind": "reference", "sample": sample,
+            return {"value": j["overlaps_per_sec"], "unit": "overlaps/s", "cores": cores, "kind": "reference", "sample": sample, "sampled": gs != g,
                     "t_ft_gen": j["t_ft_gen"], "t_pt_gen": j["t_pt_gen"], "t_pass": j["t_pass"], "overlaps": j["overlaps"]}
         except Exception as ex:  # fall through to the port
             sys.stderr.write(f"[bench] ref_harness failed ({ex}); using the C restatement\n")
@@ -109,6 +108,16 @@ def cpu_baseline(workload, mode="sample", threads=None):
         tot += o.lchain(r)[0].shape[0]
     dt = time.time() - t0
     return {"value": tot / dt, "unit": "overlaps/s", "cores": 1, "kind": "port", "sample": f"first {nn} reads of: " + sample}
+
+
+def profile_file(name):
+    """newest committed profile of that name (PMC counters need their own rocprofv3 passes - tools/r03_final.sh - so they cannot be
+    collected inside this run; the line says where the figure comes from)"""
+    for r in ("r03", "r02"):
+        p = os.path.join(ROOT, "profiles", r, name)
+        if os.path.exists(p):
+            return p, f"profiles/{r}/{name}"
+    return None, None
 
 
 def self_launch(a):
@@ -300,40 +309,45 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                     "kernel_ms": round(k_ms, 4), "alg_bytes_per_launch": int(alg_bytes)}
-        prof = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
-        if os.path.exists(prof) and world == 1:      # PMC counters need their own rocprofv3 passes (tools/pmc.sh): not measurable inside this run
+        prof, prof_rel = profile_file("pmc_traffic.json")
+        if prof and world == 1:      # PMC counters need their own rocprofv3 passes (tools/pmc.sh): not measurable inside this run
             try:
                 pj = json.load(open(prof))
                 if pj.get("workload") == a.workload:
                     tt = [v["hbm_bytes_per_launch"] * v["launches"] for k, v in pj["kernels"].items() if k.split("<")[0] == dom]
                     if tt:
                         roofline["traffic"] = int(sum(tt) / max(1, pj.get("batches", 1)))
-                        roofline["traffic_source"] = "profiles/r02/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x 2 (gfx950 correction of MI355X_MICROARCH.md; calibrated for wide coalesced reads only - for this kernel's 8-byte gathers the true value lies between traffic_lo and traffic)"
+                        roofline["traffic_source"] = prof_rel + ": separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x 2 (gfx950 correction of MI355X_MICROARCH.md; calibrated for wide coalesced reads only - for this kernel's 8-byte gathers the true value lies between traffic_lo and traffic)"
                         lo_ = [v.get("hbm_bytes_per_launch_raw", v["hbm_bytes_per_launch"]) * v["launches"] for k, v in pj["kernels"].items() if k.split("<")[0] == dom]
                         roofline["traffic_lo"] = int(sum(lo_) / max(1, pj.get("batches", 1)))
             except Exception:
                 pass
-        # the sketch kernel is instruction-issue bound, not HBM bound: report its VALU issue rate next to the HBM fraction (counters: profiles/r02/sketch_alu.json)
+        # the sketch kernel is instruction-issue bound, not HBM bound: report its VALU issue rate next to the HBM fraction (counters: profiles/r0N/sketch_alu.json)
         sk_ms = stage_ms.get("sk_chunks", 0.0)
-        sk = {"kernel": "sketch_chunk_wave_kernel", "kernel_ms": round(sk_ms, 4), "bases": rs.total_bases,
+        sk = {"kernel": "sketch_unit_kernel", "kernel_ms": round(sk_ms, 4), "bases": rs.total_bases,
               "gbases_per_s": round(rs.total_bases / (sk_ms * 1e-3) / 1e9, 2) if sk_ms > 0 else None,
-              "hbm_frac": round(ALG["sketch_chunk_wave_kernel"][1] * rs.total_bases / (sk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if sk_ms > 0 else None}
-        alu = os.path.join(ROOT, "profiles", "r02", "sketch_alu.json")
-        if os.path.exists(alu):
+              "hbm_frac": round(ALG["sketch_unit_kernel"][1] * rs.total_bases / (sk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if sk_ms > 0 else None}
+        alu, alu_rel = profile_file("sketch_alu.json")
+        if alu:
             try:
                 aj = json.load(open(alu))
+                if not str(aj.get("kernel", "")).startswith("sketch_unit_kernel"):
+                    raise KeyError("counters of another kernel")
                 per_base = aj["valu_wave_insts_per_base"]
                 ach = per_base * rs.total_bases / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else 0.0
                 sk["roofline_alu"] = {"achieved_valu_issue": round(ach, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
                                       "frac": round(ach / VALU_PEAK_GINST, 4), "valu_wave_insts_per_base": per_base,
-                                      "source": "profiles/r02/sketch_alu.json (rocprofv3 --pmc SQ_INSTS_VALU ...) x this run's kernel time"}
+                                      "source": alu_rel + " (rocprofv3 --pmc SQ_INSTS_VALU ...) x this run's kernel time"}
             except Exception:
                 pass
         out = {
             "metric": "read-pair overlaps/sec (sum ol->length / (ha_pt_gen + all-reads h_ec_lchain pass))",
-            "value": round(value, 1), "unit": "overlaps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if a.workload in STRONG else "weak",
+            "value": round(boundary["value"] if boundary else value, 1), "unit": "overlaps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(boundary["ms_per_step"] if boundary else ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if a.workload in STRONG else "weak",
             "vs_baseline": None, "dtype": "u64 hashing / int32 + f64 chain scores", "data": "synthetic",
+            "value_is": ("boundary: every batch's ol->list, fake cigars and cl->list (wire format) delivered into pinned host memory inside the timed region" if boundary
+                         else "resident: results stay in HBM (--no-boundary)"),
+            "value_resident": round(value, 1), "ms_per_step_resident": round(ms_per_step, 3),
             "value_boundary": round(boundary["value"], 1) if boundary else None,
             "boundary": ({"ms_per_step": round(boundary["ms_per_step"], 3), "host_bytes_per_gpu_step": boundary["host_bytes_per_gpu_step"], "wire_bytes_per_chained_hit": round(boundary["wire_bytes_per_chained_hit"], 4),
                           "copy_ms_per_step": round(boundary["copy_ms_per_step"], 2), "verbatim_hits_per_step": boundary["verbatim_hits_per_step"], "copy_gb_per_s": round(boundary["copy_gb_per_s"], 2),
