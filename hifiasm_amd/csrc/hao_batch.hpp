@@ -40,7 +40,7 @@ struct hao_ctx::Batch {
 		s_start.release(); a_off.release(); seg.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fcf_off.release();
 		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); g_cls.release(); slow.release(); ovf_list.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
-		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); cd.release(); pk_bytes.release(); pk_cnt.release(); out[0].release(); out[1].release();
+		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); cd.release(); pk_bytes.release(); pk_cnt.release(); hq.release(); hcode.release(); out[0].release(); out[1].release();
 		if (dl_ready) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); for (int k = 0; k < n_aux; ++k) { (void)hipStreamSynchronize(copy_aux[k]); (void)hipStreamDestroy(copy_aux[k]); (void)hipEventDestroy(ev_aux[0][k]); (void)hipEventDestroy(ev_aux[1][k]); } for (int x = 0; x < 2; ++x) { (void)hipEventDestroy(ev_ready[x]); (void)hipEventDestroy(ev_done[x]); if (arena[x]) (void)hipHostFree(arena[x]); arena[x] = nullptr; arena_cap[x] = 0; } dl_ready = false; }
 	}
 };
@@ -232,10 +232,9 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	HIP_TRY(B.q_pos.reserve(nm + 1)); HIP_TRY(B.q_cnt.reserve(nm + 1));
 	HIP_TRY(B.s_start.reserve(nm + 1)); HIP_TRY(B.s_n.reserve(nm + 1)); HIP_TRY(B.a_off.reserve(nm + 2)); HIP_TRY(B.seg.reserve(n + 2));
 	HIP_TRY(c->d_err.reserve(2)); HIP_TRY(hipMemsetAsync(c->d_err.p, 0, 4, c->stream));
-	hao_pt_dev pt = hao_pt_view(c);
-	// Q1 lookup + scan
-	if (c->lk_valid) hipLaunchKernelGGL(seed_unpack_kernel, dim3((unsigned)((nm + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_lk.p, c->d_ix_mz_info.p, B.mz0, nm, B.wgt.p, B.s_start.p, B.s_n.p, B.q_pos.p, B.q_cnt.p);
-	else hipLaunchKernelGGL(seed_count_kernel, dim3((unsigned)((nm + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_x.p, c->d_ix_mz_info.p, B.mz0, nm, pt, B.wgt.p, B.s_start.p, B.s_n.p, B.q_pos.p, B.q_cnt.p);
+	// Q1: every minimizer's lookup result was computed when the index was built (hao_index_finish_kernel; in sharded mode by the owner of its hash, hao_tables.hpp)
+	if (!c->lk_valid) { hao_set_err(c, "index without per-minimizer lookup results"); return HAO_EINVAL; }
+	hipLaunchKernelGGL(seed_unpack_kernel, dim3((unsigned)((nm + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_lk.p, c->d_ix_mz_info.p, B.mz0, nm, B.wgt.p, B.s_start.p, B.s_n.p, B.q_pos.p, B.q_cnt.p);
 	HAO_CHECK_LAUNCH();
 	if (int rc = hao_scan_u32(c, B.s_n.p, B.a_off.p, nm + 1)) return rc;
 	hipLaunchKernelGGL(seed_segments_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_off.p, lo, n, B.mz0, B.a_off.p, B.seg.p);

@@ -393,6 +393,35 @@ int hao_selftest_rocprim(uint64_t n, uint64_t out[2])
 	return HAO_OK;
 }
 
+// Self-test of the paths that see more than 2^32 items (the k-mer occurrences of a 250 Mb genome at 30x are 5.6 G): n u32 keys, key[i] = i / 8, written by
+// the grid-stride launch shape the Bloom replay uses and run-length encoded by hao_rle.  out = { runs, sum of the run lengths, runs whose length is not 8 }:
+// n / 8, n and 0 for n a multiple of 8.  (A launch of more than 2^32 work-items and rocprim::run_length_encode's `unsigned int size` both silently process
+// n mod 2^32 items.)
+__global__ void hao_selftest_fill32_kernel(uint64_t n, uint32_t *k)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) k[i] = (uint32_t)(i >> 3);
+}
+struct hao_not8 { __host__ __device__ uint64_t operator()(const uint32_t &v) const { return v != 8; } };
+int hao_selftest_big(uint64_t n, uint64_t out[3])
+{
+	hao_ctx tmp_ctx; hao_ctx *c = &tmp_ctx;
+	if (!out || n == 0 || (n >> 3) >= (1ULL << 32)) return HAO_EINVAL;
+	out[0] = out[1] = out[2] = 0;
+	DevBuf<uint32_t> k, uk, uc;
+	HIP_TRY(k.reserve_exact(n)); HIP_TRY(uk.reserve_exact((n >> 3) + 2)); HIP_TRY(uc.reserve_exact((n >> 3) + 2)); HIP_TRY(c->d_cursor.reserve(2));
+	hipLaunchKernelGGL(hao_selftest_fill32_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 20)), dim3(256), 0, c->stream, n, k.p);
+	HIP_TRY(hipGetLastError());
+	if (int rc = hao_rle(c, (const uint32_t*)k.p, n, uk.p, uc.p, (uint64_t*)c->d_cursor.p)) return rc;
+	HIP_TRY(hipMemcpy(&out[0], c->d_cursor.p, 8, hipMemcpyDeviceToHost));
+	if (out[0] <= (n >> 3) + 1) {
+		out[1] = hao_dbg_reduce(c, rocprim::make_transform_iterator(uc.p, U32ToU64()), out[0], rocprim::plus<uint64_t>());
+		out[2] = hao_dbg_reduce(c, rocprim::make_transform_iterator(uc.p, hao_not8()), out[0], rocprim::plus<uint64_t>());
+	}
+	HIP_TRY(hipDeviceSynchronize());
+	k.release(); uk.release(); uc.release(); c->d_cursor.release(); c->d_tmp.release();
+	return HAO_OK;
+}
+
 int hao_pt_table(hao_ctx *c, uint64_t *n_keys, const uint64_t **keys, const uint64_t **off, const uint64_t **pos, uint64_t *n_pos)
 {
 	if (!c || !c->has_pt) return HAO_EINVAL;

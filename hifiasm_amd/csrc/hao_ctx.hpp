@@ -63,7 +63,8 @@ struct hao_switches {
 		auto on = [](const char *n) { return getenv(n) != nullptr; };
 		seedphase = on("HAO_DBG_SEEDPHASE"); qcphase = on("HAO_DBG_QCPHASE"); dp_stats = on("HAO_DBG_DP_STATS"); seq_chain = on("HAO_DBG_SEQ_CHAIN");
 		dp_seqtail = on("HAO_DBG_DP_SEQTAIL"); dp_nospec = on("HAO_DBG_DP_NOSPEC"); dp_serial = on("HAO_DBG_DP_SERIAL"); seq_prune = on("HAO_DBG_SEQ_PRUNE");
-		selphase = on("HAO_DBG_SELPHASE"); sel1 = on("HAO_DBG_SEL1"); sk_generic = on("HAO_DBG_SK_GENERIC"); sk_v2 = on("HAO_DBG_SK_V2"); sk_nofuse = on("HAO_DBG_SK_NOFUSE"); pack_search = on("HAO_DBG_PACK_SEARCH");      // the wire packer searches every hit's minimizer (round-2 path) instead of gathering the quick check's code bytes dltime = on("HAO_DBG_DLTIME");
+		selphase = on("HAO_DBG_SELPHASE"); sel1 = on("HAO_DBG_SEL1"); sk_generic = on("HAO_DBG_SK_GENERIC"); sk_v2 = on("HAO_DBG_SK_V2"); sk_nofuse = on("HAO_DBG_SK_NOFUSE"); pack_search = on("HAO_DBG_PACK_SEARCH");      // the wire packer searches every hit's minimizer (round-2 path) instead of gathering the quick check's code bytes
+		dltime = on("HAO_DBG_DLTIME");
 		if (const char *e = getenv("HAO_CHAIN_WPB")) chain_wpb = std::max(1, std::min(4, atoi(e)));
 		if (const char *e = getenv("HAO_SPEC_MINCLS")) spec_mincls = atoi(e);
 		if (const char *e = getenv("HAO_DBG_SK_GCAP")) sk_gcap = atoll(e);

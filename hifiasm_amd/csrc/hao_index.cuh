@@ -162,15 +162,23 @@ __global__ void hao_iota_kernel(uint32_t *v, uint64_t n)
 	if (i < n) v[i] = (uint32_t)i;
 }
 // j = position in hash order: gather its 8-byte record (the index lists) and scatter its lookup result to read order
+// (sharded build: the owner of a hash range runs this over what it RECEIVED - sidx = arrival index, base = first position of its partition in the
+// global index - and the lookup results travel back to the ranks the minimizers came from)
 __global__ void hao_index_finish_kernel(uint64_t m, const uint32_t *sidx, const uint32_t *runid, const uint32_t *ucnt, const uint64_t *ustart, int lo, int hi,
-		const uint64_t *info, uint64_t *sinfo, uint64_t *lk)
+		const uint64_t *info, uint64_t *sinfo, uint64_t *lk, uint64_t base)
 {
 	const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= m) return;
 	const uint32_t o = sidx[j], u = runid[j] - 1;
 	sinfo[j] = info[o];
 	int c = ucnt[u] > HAO_MAX_COUNT ? HAO_MAX_COUNT : (int)ucnt[u];
-	lk[o] = (c >= lo && c <= hi) ? (ustart[u] | (uint64_t)c << 48) : 0;
+	lk[o] = (c >= lo && c <= hi) ? ((ustart[u] + base) | (uint64_t)c << 48) : 0;
+}
+// out[idx[i]] = in[i]
+__global__ void hao_scatter_u64_kernel(const uint64_t *in, const uint32_t *idx, uint64_t n, uint64_t *out)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[idx[i]] = in[i];
 }
 
 // position index, device view: kept keys (sorted) -> (start,cnt) into the hash-sorted minimizer array
@@ -198,12 +206,14 @@ __device__ __forceinline__ uint32_t hao_pt_lookup(const hao_pt_dev &pt, uint64_t
 // The 2^(bf_shift-3)-byte filter itself (16 GB at the default -f37) is never materialised.
 // ---------------------------------------------------------------------------------------
 // block id of a k-mer hash: sub-table << xb | (hash >> 12) & (2^xb - 1), xb = bf_shift - 21; sentinels (slots of N reads) sort last
+// (grid-stride: there are more occurrences than the 2^32 work-items one launch can address - 5.6 G on BASELINE configs[2]; a launch of grid x block
+// beyond that silently runs only the remainder modulo 2^32)
 __global__ void hao_bf_block_kernel(const uint64_t *kh, uint64_t n, int xb, uint32_t *blk)
 {
-	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	const uint64_t h = kh[i];
-	blk[i] = h == UINT64_MAX ? 1u << (12 + xb) : (uint32_t)((h & 4095) << xb | ((h >> 12) & ((1ULL << xb) - 1)));
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t h = kh[i];
+		blk[i] = h == UINT64_MAX ? 1u << (12 + xb) : (uint32_t)((h & 4095) << xb | ((h >> 12) & ((1ULL << xb) - 1)));
+	}
 }
 
 // One lane per block RUN of the block-sorted list (runs from a run-length pass: consecutive lanes take consecutive runs, every lane replays its ~n / 2^(bf_shift-9)

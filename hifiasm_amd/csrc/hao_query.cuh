@@ -15,20 +15,8 @@
 #include "hao_common.cuh"
 #include "hao_index.cuh"
 
-// Q1: one thread per query minimizer of the batch: index lookup (ha_pt_get, anchor.cpp:1013) and the two words every
-// hit of this minimizer shares: self_offset and cnt = weight(n) << 8 | span (anchor.cpp:1065-1076)
-__global__ void seed_count_kernel(const uint64_t *mz_x, const uint64_t *mz_info, uint64_t mz0, uint64_t n_mz, hao_pt_dev pt, const uint32_t *wgt_tab,
-		uint64_t *s_start, uint32_t *s_n, uint32_t *q_pos, uint32_t *q_cnt)
-{
-	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i > n_mz) return;
-	if (i == n_mz) { s_n[i] = 0; return; }
-	uint64_t st = 0; uint32_t n = hao_pt_lookup(pt, mz_x[mz0 + i], &st);
-	const uint64_t z = mz_info[mz0 + i];
-	s_start[i] = st; s_n[i] = n; q_pos[i] = hao_info_pos(z); q_cnt[i] = wgt_tab[n] << 8 | hao_info_span(z);
-}
-
-// Q1 on a single device: the lookup results were computed when the index was built (hao_index_finish_kernel): unpack them for the batch's minimizers
+// Q1 (ha_pt_get, anchor.cpp:1013, and the two words every hit of a minimizer shares: self_offset and cnt = weight(n) << 8 | span, anchor.cpp:1065-1076):
+// the lookup results were computed when the index was built (hao_index_finish_kernel): unpack them for the batch's minimizers
 __global__ void seed_unpack_kernel(const uint64_t *lk, const uint64_t *mz_info, uint64_t mz0, uint64_t n_mz, const uint32_t *wgt_tab,
 		uint64_t *s_start, uint32_t *s_n, uint32_t *q_pos, uint32_t *q_cnt)
 {

@@ -1,5 +1,6 @@
 // Host orchestration: ha_ft_gen / ha_pt_gen equivalents (part of libhao.so).
 #pragma once
+#include <chrono>
 #include "hao_comm.hpp"
 #include "hao_pipeline.hpp"
 #include "hao_index.cuh"
@@ -103,6 +104,29 @@ struct NotSentinel { __host__ __device__ bool operator()(const uint64_t &h) cons
 struct RunHead { const uint64_t *k; __host__ __device__ uint64_t operator()(uint64_t i) const { return (i == 0 || k[i] != k[i - 1]) ? 1 : 0; } };
 struct RunHead32 { const uint64_t *k; __host__ __device__ uint32_t operator()(uint64_t i) const { return (i == 0 || k[i] != k[i - 1]) ? 1u : 0u; } };
 
+// Run-length encoding of a sorted array.  rocprim::run_length_encode takes its size as `unsigned int` (it would silently encode n mod 2^32 items: the k-mer
+// occurrences of BASELINE configs[2] are 5.6 G), so longer inputs go through what it is built on - reduce_by_key over a constant 1 - whose size is a size_t.
+template<typename Key>
+static int hao_rle(hao_ctx *c, const Key *sorted, uint64_t n, Key *ukeys, uint32_t *ucnt, uint64_t *d_n_runs)
+{
+	size_t tb = 0;
+	if (n <= 0xffffffffULL) {
+		HIP_TRY(rocprim::run_length_encode(nullptr, tb, sorted, (unsigned int)n, ukeys, ucnt, d_n_runs, c->stream)); HIP_TRY(hao_tmp(c, tb));
+		HIP_TRY(rocprim::run_length_encode(c->d_tmp.p, tb, sorted, (unsigned int)n, ukeys, ucnt, d_n_runs, c->stream));
+	} else {
+		auto ones = rocprim::make_constant_iterator<uint32_t>(1);
+		HIP_TRY(rocprim::reduce_by_key(nullptr, tb, sorted, ones, (size_t)n, ukeys, ucnt, d_n_runs, rocprim::plus<uint32_t>(), rocprim::equal_to<Key>(), c->stream)); HIP_TRY(hao_tmp(c, tb));
+		HIP_TRY(rocprim::reduce_by_key(c->d_tmp.p, tb, sorted, ones, (size_t)n, ukeys, ucnt, d_n_runs, rocprim::plus<uint32_t>(), rocprim::equal_to<Key>(), c->stream));
+	}
+	return HAO_OK;
+}
+// hipMemsetAsync in pieces below 2^31 bytes (the fill kernel's size arithmetic is 32-bit on some ROCm versions)
+static int hao_memset_big(hao_ctx *c, void *p, int v, uint64_t bytes)
+{
+	for (uint64_t o = 0; o < bytes; o += 1ULL << 30) HIP_TRY(hipMemsetAsync((char*)p + o, v, (size_t)std::min<uint64_t>(1ULL << 30, bytes - o), c->stream));
+	return HAO_OK;
+}
+
 // sort keys, run-length encode, histogram.  in: d_keys[n] (destroyed). out: unique keys / counts in c->d_u_keys / d_u_cnt, n_unique.
 struct hao_rle_out { uint64_t n_unique; };
 static int hao_sort_rle_hist(hao_ctx *c, uint64_t *d_keys, uint64_t *d_keys_alt, uint64_t n, DevBuf<uint64_t> &ukeys, DevBuf<uint32_t> &ucnt, uint64_t *n_unique, int64_t hist[HAO_N_COUNTS], uint64_t **sorted_out, uint32_t bias = 0)
@@ -127,10 +151,7 @@ static int hao_sort_rle_hist(hao_ctx *c, uint64_t *d_keys, uint64_t *d_keys_alt,
 		HIP_TRY(hipStreamSynchronize(c->stream));
 	}
 	HIP_TRY(ukeys.reserve(n_runs + 1)); HIP_TRY(ucnt.reserve(n_runs + 1));
-	tb = 0;
-	HIP_TRY(rocprim::run_length_encode(nullptr, tb, sorted, n, ukeys.p, ucnt.p, (uint64_t*)c->d_cursor.p, c->stream));
-	HIP_TRY(hao_tmp(c, tb));
-	HIP_TRY(rocprim::run_length_encode(c->d_tmp.p, tb, sorted, n, ukeys.p, ucnt.p, (uint64_t*)c->d_cursor.p, c->stream));
+	if (int rc = hao_rle(c, sorted, n, ukeys.p, ucnt.p, (uint64_t*)c->d_cursor.p)) return rc;
 	HIP_TRY(hipMemcpyAsync(n_unique, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	if (bias && *n_unique) { hipLaunchKernelGGL(hao_add_u32_kernel, dim3((unsigned)((*n_unique + 255) / 256)), dim3(256), 0, c->stream, ucnt.p, *n_unique, bias); HAO_CHECK_LAUNCH(); }   // table entries start at `bias`
@@ -183,6 +204,20 @@ static int hao_build_bucket(hao_ctx *c, const uint64_t *keys, uint64_t n, int bi
 	return HAO_OK;
 }
 
+// HAO_DBG_BLOOM: self-checks of the replay's intermediate arrays (sortedness, key / value pairing, run totals) with wall times, on stderr
+struct BlkInv { const uint32_t *k; __host__ __device__ uint64_t operator()(uint64_t i) const { return (i > 0 && k[i] < k[i - 1]) ? 1 : 0; } };
+struct BlkPair { const uint32_t *k; const uint64_t *v; int xb; __host__ __device__ uint64_t operator()(uint64_t i) const {
+	const uint64_t h = v[i]; const uint32_t b = h == UINT64_MAX ? 1u << (12 + xb) : (uint32_t)((h & 4095) << xb | ((h >> 12) & ((1ULL << xb) - 1))); return b != k[i] ? 1 : 0; } };
+struct MaxU32 { __host__ __device__ uint64_t operator()(const uint64_t &a, const uint64_t &b) const { return a > b ? a : b; } };
+template<typename It, typename Op> static uint64_t hao_dbg_reduce(hao_ctx *c, It it, uint64_t n, Op op)
+{
+	uint64_t r = 0; size_t tb = 0; (void)c->d_cursor.reserve(2);
+	(void)rocprim::reduce(nullptr, tb, it, (uint64_t*)c->d_cursor.p, (uint64_t)0, n, op, c->stream); (void)hao_tmp(c, tb);
+	(void)rocprim::reduce(c->d_tmp.p, tb, it, (uint64_t*)c->d_cursor.p, (uint64_t)0, n, op, c->stream);
+	(void)hipMemcpy(&r, c->d_cursor.p, 8, hipMemcpyDeviceToHost);
+	return r;
+}
+
 // Bloom replay (hao_index.cuh): in[n] = k-mer hashes in insertion order (sentinels allowed) -> the occurrences that reach the count
 // table, compacted; *out / *out_alt = the two buffers (of in / alt) to hand to the counting step.
 static int hao_bloom_filter(hao_ctx *c, uint64_t *in, uint64_t *alt, uint64_t n, uint64_t **out, uint64_t **out_alt, uint64_t *n_out)
@@ -191,27 +226,45 @@ static int hao_bloom_filter(hao_ctx *c, uint64_t *in, uint64_t *alt, uint64_t n,
 	*out = in; *out_alt = alt; *n_out = 0;
 	if (n == 0) return HAO_OK;
 	DevBuf<uint32_t> blk, blk2; DevBuf<uint8_t> flag;
+	const bool dbg = getenv("HAO_DBG_BLOOM") != nullptr;
+	auto now_ = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double t_ = now_();
+	auto lap = [&](const char *what) { if (dbg) { (void)hipStreamSynchronize(c->stream); const double t1 = now_(); fprintf(stderr, "[bloom] %-14s %8.3f s  (%s)\n", what, t1 - t_, hipGetErrorString(hipGetLastError())); fflush(stderr); t_ = now_(); } };
+	if (dbg) fprintf(stderr, "[bloom] n = %llu, xb = %d\n", (unsigned long long)n, xb);
 	HIP_TRY(blk.reserve(n + 1)); HIP_TRY(blk2.reserve(n + 1)); HIP_TRY(flag.reserve(n + 1));
-	hipLaunchKernelGGL(hao_bf_block_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, in, n, xb, blk.p);
+	hipLaunchKernelGGL(hao_bf_block_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 20)), dim3(256), 0, c->stream, in, n, xb, blk.p);
 	HAO_CHECK_LAUNCH();
+	lap("alloc+blockid");
 	size_t tb = 0; rocprim::double_buffer<uint32_t> dk(blk.p, blk2.p); rocprim::double_buffer<uint64_t> dv(in, alt);
 	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, dk, dv, n, 0, 13 + xb, c->stream)); HIP_TRY(hao_tmp(c, tb));
 	HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, dk, dv, n, 0, 13 + xb, c->stream));      // stable: insertion order inside a block
+	lap("sort_pairs");
+	if (dbg) {
+		const uint64_t inv = hao_dbg_reduce(c, rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), BlkInv{dk.current()}), n, rocprim::plus<uint64_t>());
+		const uint64_t mis = hao_dbg_reduce(c, rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), BlkPair{dk.current(), dv.current(), xb}), n, rocprim::plus<uint64_t>());
+		fprintf(stderr, "[bloom] after the sort: %llu inversions, %llu (key, value) pairs that do not belong together\n", (unsigned long long)inv, (unsigned long long)mis);
+		lap("checks");
+	}
 	{	// runs of equal block id -> (block, length, start); one lane replays one run
 		const uint64_t max_runs = std::min<uint64_t>(n, (1ULL << (12 + xb)) + 1);
 		DevBuf<uint32_t> rk, rl; DevBuf<uint64_t> rs; uint64_t n_runs = 0;
 		HIP_TRY(rk.reserve(max_runs + 1)); HIP_TRY(rl.reserve(max_runs + 1)); HIP_TRY(rs.reserve(max_runs + 2)); HIP_TRY(c->d_cursor.reserve(2));
-		HIP_TRY(hipMemsetAsync(flag.p, 0, n, c->stream));
-		tb = 0;
-		HIP_TRY(rocprim::run_length_encode(nullptr, tb, dk.current(), n, rk.p, rl.p, (uint64_t*)c->d_cursor.p, c->stream)); HIP_TRY(hao_tmp(c, tb));
-		HIP_TRY(rocprim::run_length_encode(c->d_tmp.p, tb, dk.current(), n, rk.p, rl.p, (uint64_t*)c->d_cursor.p, c->stream));
+		if (int rc = hao_memset_big(c, flag.p, 0, n)) return rc;
+		if (int rc = hao_rle(c, (const uint32_t*)dk.current(), n, rk.p, rl.p, (uint64_t*)c->d_cursor.p)) return rc;
 		HIP_TRY(hipMemcpyAsync(&n_runs, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
+		lap("rle");
 		auto it = rocprim::make_transform_iterator(rl.p, U32ToU64());
+		if (dbg) {
+			const uint64_t sum = hao_dbg_reduce(c, it, n_runs, rocprim::plus<uint64_t>()), mx = hao_dbg_reduce(c, it, n_runs, MaxU32());
+			fprintf(stderr, "[bloom] runs: %llu (bound %llu), lengths sum to %llu (n = %llu), longest %llu\n", (unsigned long long)n_runs, (unsigned long long)max_runs, (unsigned long long)sum, (unsigned long long)n, (unsigned long long)mx);
+			if (n_runs > max_runs) { hao_set_err(c, "bloom replay: more runs than blocks"); return HAO_EUNSUPP; }
+		}
 		if (int rc = hao_excl_scan_u64(c, it, rs.p, n_runs)) return rc;
 		hipLaunchKernelGGL(hao_bf_replay_kernel, dim3((unsigned)((n_runs + 255) / 256)), dim3(256), 0, c->stream, rk.p, rl.p, rs.p, n_runs, dv.current(), xb, flag.p);
 		HAO_CHECK_LAUNCH();
 		HIP_TRY(hipStreamSynchronize(c->stream));
+		lap("replay");
 		rk.release(); rl.release(); rs.release();
 	}
 	HIP_TRY(c->d_cursor.reserve(2));
@@ -221,6 +274,8 @@ static int hao_bloom_filter(hao_ctx *c, uint64_t *in, uint64_t *alt, uint64_t n,
 	HIP_TRY(hipMemcpyAsync(n_out, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	*out = dv.alternate(); *out_alt = dv.current();
+	lap("select");
+	if (dbg) fprintf(stderr, "[bloom] %llu of %llu occurrences reach the count table\n", (unsigned long long)*n_out, (unsigned long long)n);
 	blk.release(); blk2.release(); flag.release();
 	return HAO_OK;
 }
@@ -257,7 +312,7 @@ static int hao_ft_run(hao_ctx *c)
 		HIP_TRY(kh.reserve(n_slots + 1)); HIP_TRY(kh2.reserve(n_slots + 1));
 		n_real = n_slots;
 		if (!slist.empty()) {    // slots of N reads are upper bounds: sentinel-fill, count the real ones
-			HIP_TRY(hipMemsetAsync(kh.p, 0xff, n_slots * 8, c->stream));
+			if (int rc = hao_memset_big(c, kh.p, 0xff, n_slots * 8)) return rc;
 			HIP_TRY(c->d_cursor.reserve(2)); HIP_TRY(hipMemsetAsync(c->d_cursor.p, 0, 8, c->stream));
 			hipLaunchKernelGGL(kmer_hash_scalar_kernel, dim3((unsigned)((slist.size() + 63) / 64)), dim3(64), 0, c->stream, c->d_packed.p, c->d_pk_off.p, c->d_len.p,
 							   c->d_nsite_off.p, c->d_nsite.p, c->d_scalar_list.p, (uint32_t)slist.size(), kmer_off.p, (uint64_t)0, k, c->opt.hpc, kh.p, c->d_cursor.p);
@@ -441,22 +496,11 @@ static int hao_pt_run(hao_ctx *c)
 	if (sk_rc && !sharded) return sk_rc;
 	DevBuf<uint64_t> &ukeys = c->w_ukeys; DevBuf<uint32_t> &ucnt = c->w_ucnt; uint64_t n_unique = 0;
 	memset(c->pt_hist, 0, sizeof(c->pt_hist));
-	auto sort_pairs = [&](uint64_t *kin, uint64_t *kout, uint64_t *vin, uint64_t *vout, uint64_t cnt) -> int {
-		if (!cnt) return HAO_OK;
-		size_t tb = 0;
-		HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, kin, kout, vin, vout, cnt, 0, 64, c->stream));
-		HIP_TRY(hao_tmp(c, tb));
-		HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, kin, kout, vin, vout, cnt, 0, 64, c->stream));
-		return HAO_OK;
-	};
 	auto rle_hist = [&](const uint64_t *sorted, uint64_t cnt) -> int {       // -> ukeys/ucnt/n_unique, c->pt_hist (local)
 		n_unique = 0;
 		if (!cnt) return HAO_OK;
 		HIP_TRY(ukeys.reserve(cnt + 1)); HIP_TRY(ucnt.reserve(cnt + 1)); HIP_TRY(c->d_cursor.reserve(2));
-		size_t tb = 0;
-		HIP_TRY(rocprim::run_length_encode(nullptr, tb, sorted, cnt, ukeys.p, ucnt.p, (uint64_t*)c->d_cursor.p, c->stream));
-		HIP_TRY(hao_tmp(c, tb));
-		HIP_TRY(rocprim::run_length_encode(c->d_tmp.p, tb, sorted, cnt, ukeys.p, ucnt.p, (uint64_t*)c->d_cursor.p, c->stream));
+		if (int rc = hao_rle(c, sorted, cnt, ukeys.p, ucnt.p, (uint64_t*)c->d_cursor.p)) return rc;
 		HIP_TRY(hipMemcpyAsync(&n_unique, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		DevBuf<unsigned long long> &dh = c->w_hist; HIP_TRY(dh.reserve(HAO_N_COUNTS)); HIP_TRY(hipMemsetAsync(dh.p, 0, HAO_N_COUNTS * 8, c->stream));
@@ -501,7 +545,7 @@ static int hao_pt_run(hao_ctx *c)
 			HIP_TRY(rocprim::inclusive_scan(nullptr, tb, heads, c->w_runid.p, m, rocprim::plus<uint32_t>(), c->stream)); HIP_TRY(hao_tmp(c, tb));
 			HIP_TRY(rocprim::inclusive_scan(c->d_tmp.p, tb, heads, c->w_runid.p, m, rocprim::plus<uint32_t>(), c->stream));
 			hipLaunchKernelGGL(hao_index_finish_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, m, c->w_oi2.p, c->w_runid.p, ucnt.p, c->w_ustart.p, 2, hi,
-							   c->d_ix_mz_info.p, c->d_ix_sinfo.p, c->d_ix_lk.p);
+							   c->d_ix_mz_info.p, c->d_ix_sinfo.p, c->d_ix_lk.p, (uint64_t)0);
 			HAO_CHECK_LAUNCH();
 		}
 		c->lk_valid = true;
@@ -510,12 +554,14 @@ static int hao_pt_run(hao_ctx *c)
 		// Sharded build (SURVEY 2 C1 + 8e layout i): every rank owns the hash range [r, r+1) * 2^64 / world.
 		//   local stable grouping by owner -> all-to-all-v of (x, info) by range -> stable sort of the received pieces (source-rank order =
 		//   global read order, so per-key lists come out in (rid,pos) order) -> count / histogram (all-reduced) / peaks / keep ->
-		//   all-gather of the sorted position records (8 B each) and of the key tables: concatenation in rank order is the global index.
+		//   all-gather of the sorted position records (8 B each) and of the key tables: concatenation in rank order is the global index;
+		//   the owner also answers the lookup of every minimizer it received ((list start, count) of its run: 8 bytes back through the reverse all-to-all-v),
+		//   so the query pass of a sharded engine unpacks its lookups exactly like a single device does - no per-batch search of the key table.
 		// Local phases are lambdas whose status travels with the next collective: ranks fail together.
 		hao_comm &cm = *c->comm; const int W = cm.world;
 		if (int rc = hao_shard_layout_check(c, cm, sk_rc)) return rc;
 		const uint64_t ml = c->ix_n_mz;
-		DevBuf<uint64_t> lsx, lsi, dt, dc, rx, ri, px, pi;
+		DevBuf<uint64_t> lsx, lsi, dt, dc, rx, ri, px, pi, lkr, lkl; DevBuf<uint32_t> ai, ai2; const uint32_t *lperm = nullptr;
 		std::vector<uint64_t> tg(W), cut(W + 1, 0), scnt(W, 0), sdisp(W, 0), rcnt;
 		// owner of a hash = ((x >> 48) * W) >> 16: ranges of the top 16 bits, so the local pass only groups by those bits - a stable 2-pass radix sort of
 		// (owner bits, index) and one gather instead of 8 passes over the 16-byte records; pieces stay in read order, the owner sorts what it receives.
@@ -532,6 +578,7 @@ static int hao_pt_run(hao_ctx *c)
 				HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, dk, dv, ml, 0, 16, c->stream));
 				hipLaunchKernelGGL(hao_gather2_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, c->stream, dv.current(), c->d_ix_mz_x.p, c->d_ix_mz_info.p, ml, lsx.p, lsi.p);
 				HAO_CHECK_LAUNCH();
+				lperm = dv.current();      // (c->w_oi or c->w_oi2: untouched until the lookup results come back in this order)
 			}
 			for (int d = 0; d < W; ++d) tg[d] = (((uint64_t)d * 65536 + W - 1) / W) << 48;      // first hash owned by rank d (low 48 bits zero: comparing whole keys orders by the top 16 bits)
 			HIP_TRY(dt.reserve(W + 1)); HIP_TRY(dc.reserve(W + 1));
@@ -552,7 +599,15 @@ static int hao_pt_run(hao_ctx *c)
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		c->timer.mark("pt_alltoall");
 		auto local_count = [&]() -> int {
-			if (int rc = sort_pairs(rx.p, px.p, ri.p, pi.p, n_recv)) return rc;
+			if (n_recv >= (1ULL << 32)) { hao_set_err(c, "more than 2^32 minimizers in one hash partition"); return HAO_EUNSUPP; }
+			// (hash, arrival index) sort, as on a single device: the arrival index gathers the records and addresses the answers
+			HIP_TRY(ai.reserve(n_recv + 1)); HIP_TRY(ai2.reserve(n_recv + 1));
+			if (n_recv) {
+				hipLaunchKernelGGL(hao_iota_kernel, dim3((unsigned)((n_recv + 255) / 256)), dim3(256), 0, c->stream, ai.p, n_recv); HAO_CHECK_LAUNCH();
+				size_t tb = 0;
+				HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, rx.p, px.p, ai.p, ai2.p, n_recv, 0, 64, c->stream)); HIP_TRY(hao_tmp(c, tb));
+				HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, rx.p, px.p, ai.p, ai2.p, n_recv, 0, 64, c->stream));
+			}
 			c->timer.mark("pt_sort");
 			return rle_hist(px.p, n_recv);
 		};
@@ -569,6 +624,29 @@ static int hao_pt_run(hao_ctx *c)
 		uint64_t m = 0, base = 0, nk = 0, np = 0;
 		for (int r = 0; r < W; ++r) { if (r < cm.rank) base += part[r]; m += part[r]; nk += nks[r]; np += nps[r]; }
 		if (m >= (1ULL << 32)) { hao_set_err(c, "more than 2^32 minimizers in the replicated index"); return HAO_EUNSUPP; }      // same verdict on every rank
+		{	// records into hash order + the answer to every received minimizer (hao_index.cuh), then the answers go home: reverse all-to-all-v, 8 bytes per minimizer
+			auto local_lk = [&]() -> int {
+				HIP_TRY(lkr.reserve(n_recv + 1)); HIP_TRY(lkl.reserve(ml + 1)); HIP_TRY(c->w_runid.reserve(n_recv + 1)); HIP_TRY(c->d_ix_lk.reserve(ml + 1));
+				if (n_recv) {
+					auto heads = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), RunHead32{px.p});
+					size_t tb = 0;
+					HIP_TRY(rocprim::inclusive_scan(nullptr, tb, heads, c->w_runid.p, n_recv, rocprim::plus<uint32_t>(), c->stream)); HIP_TRY(hao_tmp(c, tb));
+					HIP_TRY(rocprim::inclusive_scan(c->d_tmp.p, tb, heads, c->w_runid.p, n_recv, rocprim::plus<uint32_t>(), c->stream));
+					hipLaunchKernelGGL(hao_index_finish_kernel, dim3((unsigned)((n_recv + 255) / 256)), dim3(256), 0, c->stream, n_recv, ai2.p, c->w_runid.p, ucnt.p, c->w_ustart.p, 2, hi,
+									   ri.p, pi.p, lkr.p, base);
+					HAO_CHECK_LAUNCH();
+				}
+				return HAO_OK;
+			};
+			if (int rc = hao_comm_agree(c, cm, local_lk())) return rc;
+			std::vector<uint64_t> rdisp(W, 0), back;
+			for (int d = 1; d < W; ++d) rdisp[d] = rdisp[d - 1] + rcnt[d - 1];
+			if (int rc = hao_comm_alltoallv_u64(c, cm, lkr.p, rcnt, rdisp, lkl.p, scnt)) return rc;      // what came from rank d goes back to rank d, in the order it came
+			if (ml) { hipLaunchKernelGGL(hao_scatter_u64_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, c->stream, lkl.p, lperm, ml, c->d_ix_lk.p); HAO_CHECK_LAUNCH(); }
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			c->lk_valid = true;
+			c->timer.mark("pt_lookup");
+		}
 		// ONE all-gather for the whole index: every rank's slot = [position records | keys | list starts | counts], padded to the largest partition
 		uint64_t maxm = 0, maxk = 0; for (int r = 0; r < W; ++r) { maxm = std::max(maxm, part[r]); maxk = std::max(maxk, nks[r]); }
 		const size_t o_key = (size_t)maxm * 8, o_st = o_key + (size_t)maxk * 8, o_cnt = o_st + (size_t)maxk * 8, slot = (o_cnt + (size_t)maxk * 4 + 15) & ~(size_t)15;
@@ -601,7 +679,7 @@ static int hao_pt_run(hao_ctx *c)
 		}
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		c->ix_n_sorted = m; c->ix_n_keys = nk; c->ix_n_pos = np;
-		lsx.release(); lsi.release(); rx.release(); ri.release(); px.release(); pi.release(); pk.release(); pst.release(); pc.release(); dt.release(); dc.release();
+		lsx.release(); lsi.release(); rx.release(); ri.release(); px.release(); pi.release(); lkr.release(); lkl.release(); ai.release(); ai2.release(); pk.release(); pst.release(); pc.release(); dt.release(); dc.release();
 		c->timer.mark("pt_allgather");
 	}
 	int bits = 16; while ((1ULL << bits) < c->ix_n_keys / 2 && bits < 26) ++bits;

@@ -270,6 +270,9 @@ int hao_batch_digest(hao_ctx *c, uint64_t *out, uint64_t *out_kh);
 /* Device self-test of the record grouping used by the sharded index build (pins a rocPRIM bit-range sort behaviour, see hao_capi_rest.hpp):
  * out[0] = order violations of the begin_bit = 48 sort, out[1] = of the path the engine uses (must be 0). */
 int hao_selftest_rocprim(uint64_t n, uint64_t out[2]);
+/* Self-test of the code paths that handle more than 2^32 items (grid-stride launches, run-length encoding through reduce_by_key): n u32 keys i / 8;
+ * out = { runs, sum of run lengths, runs of a length other than 8 } - n / 8, n, 0 for n a multiple of 8 (tests/test_gpu_rocprim.py). */
+int hao_selftest_big(uint64_t n, uint64_t out[3]);
 
 /* per-stage device time of the last call in milliseconds (HIP events on the engine's stream);
  * names[i] points to static strings. Returns the number of stages. */

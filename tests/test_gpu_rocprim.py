@@ -19,3 +19,15 @@ def test_owner_grouping_sort(n):
     assert L.hao_selftest_rocprim(n, out) == 0
     print(f"[rocprim] n={n}: begin_bit=48 stable-sort mismatches {out[0]}, separate 16-bit key mismatches {out[1]}")
     assert out[1] == 0
+
+
+def test_more_than_2_32_items():
+    """The k-mer occurrences of BASELINE configs[2] are 5.6 G: a kernel launch of more than 2^32 work-items and rocprim::run_length_encode (whose size
+    parameter is an `unsigned int`) both silently handle n mod 2^32 items.  The engine's launch shape and its run-length helper on 2^32 + 2^20 keys."""
+    from hifiasm_amd.api import lib
+    L = lib()
+    L.hao_selftest_big.argtypes = [C.c_uint64, C.POINTER(C.c_uint64)]
+    n = (1 << 32) + (1 << 20)
+    out = (C.c_uint64 * 3)()
+    assert L.hao_selftest_big(n, out) == 0
+    assert (out[0], out[1], out[2]) == (n >> 3, n, 0)
