@@ -16,7 +16,7 @@ struct hao_ctx::Batch {
 	DevBuf<int32_t> f, ii, p, key_sc, tm; DevBuf<int64_t> t; DevBuf<uint64_t> key_xs; DevBuf<uint32_t> key_al, key_tmp;
 	DevBuf<hao_chain_rec> rec; DevBuf<hao_ovlp_t> ol; DevBuf<hao_cdesc> cd; bool cl_valid = false;
 	DevBuf<uint16_t> hq; DevBuf<uint8_t> hcode;      // delivery path: query minimizer index / wire code of every seed hit (seed kernel, chain_group_kernel)
-	DevBuf<uint8_t> pk_bytes; DevBuf<uint32_t> pk_cnt; uint64_t n_codes = 0;      // one code byte per chained hit (device only) before it is split into bits + code bytes
+	DevBuf<uint8_t> pk_bytes; DevBuf<uint32_t> pk_cnt, pk_first; uint64_t n_codes = 0;      // one code byte per chained hit (device only) before it is split into bits + code bytes
 	// Results of a batch that leave the device.  Two sets (+ two pinned host arenas): while the copy stream drains the set of batch i, batch i + 1
 	// computes into the other one (hao_overlap_batch_async).  The blocking API keeps using the current set.
 	struct OutSet {
@@ -40,7 +40,7 @@ struct hao_ctx::Batch {
 		s_start.release(); a_off.release(); seg.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fcf_off.release();
 		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); g_cls.release(); slow.release(); ovf_list.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
-		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); cd.release(); pk_bytes.release(); pk_cnt.release(); hq.release(); hcode.release(); out[0].release(); out[1].release();
+		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); cd.release(); pk_bytes.release(); pk_cnt.release(); pk_first.release(); hq.release(); hcode.release(); out[0].release(); out[1].release();
 		if (dl_ready) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); for (int k = 0; k < n_aux; ++k) { (void)hipStreamSynchronize(copy_aux[k]); (void)hipStreamDestroy(copy_aux[k]); (void)hipEventDestroy(ev_aux[0][k]); (void)hipEventDestroy(ev_aux[1][k]); } for (int x = 0; x < 2; ++x) { (void)hipEventDestroy(ev_ready[x]); (void)hipEventDestroy(ev_done[x]); if (arena[x]) (void)hipHostFree(arena[x]); arena[x] = nullptr; arena_cap[x] = 0; } dl_ready = false; }
 	}
 };
@@ -383,8 +383,8 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	auto pack = [&]() -> int {
 		if (!G) return HAO_OK;
 		hao_ctx::Batch::OutSet &O = B.O();
-		hipLaunchKernelGGL(hao_pack_chains_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH();
-		hipLaunchKernelGGL(hao_pack_bits_kernel, dim3((unsigned)((NWmax * 8 + 255) / 256)), dim3(256), 0, c->stream, B.pk_bytes.p, B.cl_base.p + G, NWmax, O.bits.p, B.pk_cnt.p); HAO_CHECK_LAUNCH();
+		hipLaunchKernelGGL(hao_pack_hdr_kernel, dim3((unsigned)((NCmax + 255) / 256)), dim3(256), 0, c->stream, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH();
+		hipLaunchKernelGGL(hao_pack_flat_kernel, dim3((unsigned)pa.n_blk), dim3(256), 0, c->stream, pa, B.ch_base.p + G, B.cl_base.p + G); HAO_CHECK_LAUNCH();
 		size_t tb = 0;
 		HIP_TRY(rocprim::exclusive_scan(nullptr, tb, B.pk_cnt.p, O.rank.p, 0u, NWmax, rocprim::plus<uint32_t>(), c->stream)); HIP_TRY(hao_tmp(c, tb));
 		HIP_TRY(rocprim::exclusive_scan(c->d_tmp.p, tb, B.pk_cnt.p, O.rank.p, 0u, NWmax, rocprim::plus<uint32_t>(), c->stream));
@@ -400,6 +400,8 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		if (!c->sw.pack_search) { pa.hq = B.hq.p; pa.hcode = B.hcode.p; }
 		pa.hdr = O.hdr.p; pa.bytes = B.pk_bytes.p; pa.exc = O.exc.p; pa.exc_cnt = d_exc_cnt; pa.exc_every = (uint32_t)c->sw.exc_every;
 		pa.exc_cap = c->sw.exc_cap >= 0 ? std::min<uint64_t>(O.exc.cap, (uint64_t)c->sw.exc_cap) : O.exc.cap;
+		pa.n_blk = (NWmax * 64 + HAO_PACK_T - 1) / HAO_PACK_T; HIP_TRY(B.pk_first.reserve(pa.n_blk + 1)); pa.blk_first = B.pk_first.p;
+		pa.bits = O.bits.p; pa.cnt = B.pk_cnt.p; pa.n_words_max = NWmax;
 		if (int rc = pack()) return rc;
 		hipLaunchKernelGGL(hao_read_ranges_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, B.g_off.p, B.ch_base.p, B.cl_base.p, c->d_ix_mz_off.p, lo, B.mz0, n, O.ch_off.p, O.cl_off.p, O.qm_off.p);
 		HAO_CHECK_LAUNCH();

@@ -65,115 +65,145 @@ __global__ __launch_bounds__(256) void hao_digest_kernel(hao_digest_args A)
 // them (chain descriptors): cl->list is never materialised in HBM on this path.  The minimizer index of a hit is recovered by a binary
 // search of its self_offset in the read's table (a few hundred L1/L2-resident entries).
 // ---------------------------------------------------------------------------------------
-#define HAO_PACK_QCAP 1024
-#define HAO_PACK_RUN 8
+#define HAO_PACK_T 2048          // hits of cl->list per workgroup of the packer (8 per thread)
+#define HAO_PACK_CMAX (HAO_PACK_T + 1 + 256)
 struct hao_pack_args {
-	const hao_cdesc *cd; const hao_hit_t *hits, *ohits;
+	hao_cdesc *cd; const hao_hit_t *hits, *ohits;      // (the header kernel leaves two flags in the descriptors' pad word for the packer)
 	const uint64_t *mz_off; uint64_t rid_lo, mz0; const uint32_t *q_pos;      // per-read minimizer ranges (global offsets) and the batch's self_offset table
 	hao_chain_hdr_t *hdr; uint8_t *bytes; hao_exc_t *exc; unsigned long long *exc_cnt; uint64_t exc_cap; uint32_t exc_every;
-	const uint16_t *hq; const uint8_t *hcode;      // per seed hit: query minimizer index (seed kernel), wire code (chain_group_kernel); null: every chain is searched
+	const uint16_t *hq; const uint8_t *hcode;      // per seed hit: query minimizer index (seed kernel), wire code (chain_group_kernel); null: every hit's minimizer is searched
+	uint32_t *blk_first; uint64_t n_blk;           // first chain of every HAO_PACK_T-hit piece of cl->list
+	uint64_t *bits; uint32_t *cnt; uint64_t n_words_max;
 };
 
-__global__ __launch_bounds__(256) void hao_pack_chains_kernel(hao_pack_args A, const uint64_t *n_chains_dev)
+// minimizer index of a hit: the table position of its self_offset (positions are strictly ascending in a read's table)
+__device__ __forceinline__ uint32_t hao_pack_find_q(const uint32_t *qp, uint32_t nq, uint32_t self_offset)
+{ uint32_t lo = 0, hi = nq; while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (qp[m] < self_offset) lo = m + 1; else hi = m; } return lo; }
+
+// One LANE per chain: the chain header (the first hit: minimizer index, target offset) and, for every HAO_PACK_T-hit piece of cl->list whose first
+// position the chain holds, the piece's first chain.  (The chains tile cl->list without gaps, in order.)  Every chain is independent here: the dependent
+// loads of a chain (descriptor -> read's minimizer range -> first hit) overlap across 64 chains per wave instead of being paid once per chain and wave.
+__global__ __launch_bounds__(256) void hao_pack_hdr_kernel(hao_pack_args A, const uint64_t *n_chains_dev)
 {
-	// the number of chains is only known on the device when this is launched: waves stride over [0, *n_chains_dev)
-	const uint64_t n_chains = *n_chains_dev, n_waves = (uint64_t)gridDim.x * 4;
-	const int lane = hao_lane();
-	__shared__ uint32_t s_tab[4][HAO_PACK_QCAP];
-	uint32_t *tab = s_tab[threadIdx.x >> 6];
-	// a wave takes HAO_PACK_RUN consecutive chains at a time: they mostly belong to one read, whose table is then loaded once
-	uint64_t tab_read = ~0ULL;
-	for (uint64_t c0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * HAO_PACK_RUN; c0 < n_chains; c0 += n_waves * HAO_PACK_RUN)
-	for (uint64_t ci = c0; ci < c0 + HAO_PACK_RUN && ci < n_chains; ++ci) {
+	const uint64_t ci = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if (ci >= *n_chains_dev) return;
 	const hao_cdesc d = A.cd[ci];
 	const hao_hit_t *src = hao_cd_src(d, A.hits, A.ohits);
 	const uint64_t m0 = A.mz_off[A.rid_lo + d.r]; const uint32_t nq = (uint32_t)(A.mz_off[A.rid_lo + d.r + 1] - m0);
-	const uint32_t *qp = A.q_pos + (m0 - A.mz0);
-	if (A.hcode && (d.pad & 1u) && nq < 65535u) {
-		// the common chain = a contiguous run of the sorted seed hits whose codes the quick check already wrote: a 1-byte gather per hit instead of the
-		// 16-byte hit + a search of its minimizer; only the first hit (header) and the hits without a code (verbatim list) are read
-		const uint64_t si = d.src;
-		for (uint32_t b = 0; b < d.n; b += 64) {
-			const uint32_t i = b + lane; const bool act = i < d.n;
-			uint8_t code = 0x08; bool esc = false;
-			if (act && i > 0) { code = A.hcode[si + i]; esc = code == 0xff || (A.exc_every && i % A.exc_every == A.exc_every - 1); if (esc) code = 0xff; }
-			if (b == 0 && lane == 0) { hao_chain_hdr_t H; H.n_hits = d.n; H.w0 = d.w0; H.q0 = A.hq[si]; H.offset = A.hits[si].offset; A.hdr[ci] = H; }
-			const unsigned long long em = __ballot(esc);
-			if (em) {
-				unsigned long long base = 0;
-				if (lane == 0) base = atomicAdd(A.exc_cnt, (unsigned long long)__popcll(em));
-				base = (unsigned long long)hao_readlane_i64((int64_t)base, 0);
-				if (esc) {
-					const uint64_t k = base + __popcll(em & ((1ULL << lane) - 1));
-					if (k < A.exc_cap) { hao_exc_t e; e.index = d.dst + i; e.q = A.hq[si + i]; e.pad = 0; e.hit = A.hits[si + i]; e.hit.w0 = d.w0; A.exc[k] = e; }
-				}
-			}
-			if (act) A.bytes[d.dst + i] = code;
-		}
-		continue;
-	}
-	// every other chain: the read's self_offset table goes to LDS once per read (a few hundred entries, L2-resident): nine dependent LDS reads per hit
-	// instead of nine dependent global loads; longer tables (reads beyond ~35 kb) are searched in place
-	const bool in_lds = nq <= HAO_PACK_QCAP;
-	if (in_lds && tab_read != d.r) {
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // (the previous chain's searches are done)
-		for (uint32_t k = lane; k < nq; k += 64) tab[k] = qp[k];
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-		tab_read = d.r;
-	}
-	uint32_t q_prev = 0, off_prev = 0, self_prev = 0;      // the last hit of the previous tile (uniform)
-	for (uint32_t b = 0; b < d.n; b += 64) {
-		const uint32_t i = b + lane; const bool act = i < d.n;
-		hao_hit_t h; h.w0 = 0; h.offset = 0; h.self_offset = 0; h.cnt = 0; uint32_t q = 0;
-		if (act) {
-			h = src[i];
-			uint32_t lo = 0, hi = nq;      // the minimizer with this self_offset (positions are strictly ascending in the table); a galloping search from the
-			                               // previous hit's minimizer (one or two probes per hit, but divergent) was slower: 62 against 50 ms per step
-			if (in_lds) { while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (tab[m] < h.self_offset) lo = m + 1; else hi = m; } }
-			else { while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (qp[m] < h.self_offset) lo = m + 1; else hi = m; } }
-			q = lo;
-		}
-		uint32_t pq = hao_wave_shr1(q, q_prev), po = hao_wave_shr1(h.offset, off_prev), ps = hao_wave_shr1(h.self_offset, self_prev);
-		uint8_t code = 0; bool esc = false;
-		if (act && i > 0) {
-			const int64_t dq = (int64_t)q - (int64_t)pq, dd = ((int64_t)h.offset - (int64_t)po) - ((int64_t)h.self_offset - (int64_t)ps);
-			esc = dq < 1 || dq > 15 || dd < -8 || dd > 7 || (A.exc_every && i % A.exc_every == A.exc_every - 1);
-			code = esc ? 0xff : (uint8_t)((dq - 1) << 4 | (dd + 8));
-		} else if (act) code = 0x08;      // first hit of a chain: described by its header, no code byte
-		if (b == 0 && lane == 0) { hao_chain_hdr_t H; H.n_hits = d.n; H.w0 = d.w0; H.q0 = q; H.offset = h.offset; A.hdr[ci] = H; }
-		const unsigned long long em = __ballot(esc);
-		if (em) {
-			unsigned long long base = 0;
-			if (lane == 0) base = atomicAdd(A.exc_cnt, (unsigned long long)__popcll(em));
-			base = (unsigned long long)hao_readlane_i64((int64_t)base, 0);
-			if (esc) {
-				const uint64_t k = base + __popcll(em & ((1ULL << lane) - 1));
-				if (k < A.exc_cap) { hao_exc_t e; e.index = d.dst + i; e.q = q; e.pad = 0; e.hit = h; e.hit.w0 = d.w0; A.exc[k] = e; }      // past the capacity only the count matters: the host grows the list and packs again
-			}
-		}
-		if (act) A.bytes[d.dst + i] = code;
-		q_prev = hao_bcast(q, 63); off_prev = hao_bcast(h.offset, 63); self_prev = hao_bcast(h.self_offset, 63);
-	}
-	}
+	const bool in_place = !(d.src & HAO_CD_OHITS);
+	const hao_hit_t h0 = src[0];
+	hao_chain_hdr_t H; H.n_hits = d.n; H.w0 = d.w0; H.offset = h0.offset;
+	H.q0 = (A.hq && in_place && nq < 65535u) ? A.hq[d.src] : hao_pack_find_q(A.q_pos + (m0 - A.mz0), nq, h0.self_offset);
+	A.hdr[ci] = H;
+	// what the packer may use for this chain's hits - pad bit 1: their wire codes (bit 0 = the quick check wrote them; the 16-bit minimizer indices behind them
+	// must not have saturated), bit 2: their minimizer indices
+	const uint32_t fl = (A.hcode && (d.pad & 1u) && nq < 65535u) ? 2u : (A.hq && in_place && nq < 65535u) ? 4u : 0u;
+	A.cd[ci].pad = (d.pad & 1u) | fl;
+	for (uint64_t b = (d.dst + HAO_PACK_T - 1) / HAO_PACK_T; b * HAO_PACK_T < d.dst + d.n && b < A.n_blk; ++b) A.blk_first[b] = (uint32_t)ci;
 }
 
-// One byte per hit -> bit stream + code bytes.  Thread t takes hits [8t, 8t + 8) (one 8-byte load); the eight threads of a 64-hit word combine their
-// flags.  The hit count of the batch is only known on the device when this is launched (n_dev), the grid covers the bound.
-__global__ __launch_bounds__(256) void hao_pack_bits_kernel(const uint8_t *bytes, const uint64_t *n_dev, uint64_t n_words_max, uint64_t *bits, uint32_t *cnt)
+// cl->list -> one code byte per hit + the bit stream (1 = the hit has a code byte) + the per-word counts of the rank directory, in ONE pass over the
+// POSITIONS of cl->list: a workgroup takes HAO_PACK_T consecutive positions (thread t: 8 of them = one aligned 8-byte word of the code array), finds
+// their chains in an LDS copy of the piece's chain table and gathers the codes the quick check left next to the seed hits (1 byte per hit; chains whose
+// hits have no codes - tiny groups, the DP path - compute them from the hits).  Work is spread by position, not by chain: a 100 000-hit chain of a
+// tandem array and a 1-hit chain cost the same per hit, and no wave waits on one chain's dependent loads.
+__global__ __launch_bounds__(256) void hao_pack_flat_kernel(hao_pack_args A, const uint64_t *n_chains_dev, const uint64_t *n_cl_dev)
 {
-	const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, w = t >> 3, n = *n_dev;
-	if (w >= n_words_max) return;      // (whole groups of eight threads leave together: n_words_max bounds w, not t)
-	uint32_t m8 = 0;
-	if (8 * t < n) {
-		uint64_t v = *(const uint64_t*)(bytes + 8 * t);
-#pragma unroll
-		for (int k = 0; k < 8; ++k) if (8 * t + k < n && (uint8_t)(v >> (8 * k)) != 0x08) m8 |= 1u << k;
+	__shared__ int32_t c_dst[HAO_PACK_CMAX]; __shared__ uint32_t c_src[HAO_PACK_CMAX]; __shared__ uint8_t c_fl[HAO_PACK_CMAX]; __shared__ int64_t s_dst0;      // starts relative to the piece (only its first chain can start before it: s_dst0)
+	const uint64_t n_chains = *n_chains_dev, n_cl = *n_cl_dev, p_blk = (uint64_t)blockIdx.x * HAO_PACK_T; const uint32_t t = threadIdx.x;
+	const uint64_t w = (p_blk + 8 * t) >> 6;
+	if (p_blk >= n_cl) {      // past the batch's hits: the words up to the bound are zero (the rank scan runs over the bound)
+		if ((t & 7) == 0 && w < A.n_words_max) { A.bits[w] = 0; A.cnt[w] = 0; }
+		return;
 	}
-	uint64_t word = (uint64_t)m8 << ((t & 7) * 8);
-	word |= __shfl_xor(word, 1); word |= __shfl_xor(word, 2); word |= __shfl_xor(word, 4);
-	if ((t & 7) == 0) { bits[w] = word; cnt[w] = (uint32_t)__popcll(word); }
+	// the piece's chains: [first, ...) while they start before its end (source index < 2^32: a batch has fewer seed hits; flags: 1 = in ohits, 2 = codes, 4 = minimizer indices)
+	const uint64_t first = A.blk_first[blockIdx.x]; uint32_t nc = 0;
+	for (uint32_t base = 0; base + 256 <= HAO_PACK_CMAX; base += 256) {
+		const uint64_t ci = first + base + t; int more = 0;
+		if (ci < n_chains) {
+			const hao_cdesc d = A.cd[ci];
+			if (d.dst < p_blk + HAO_PACK_T) {
+				const int64_t rel = (int64_t)d.dst - (int64_t)p_blk;
+				c_dst[base + t] = rel < 0 ? 0 : (int32_t)rel; c_src[base + t] = (uint32_t)d.src; c_fl[base + t] = (uint8_t)((d.src & HAO_CD_OHITS ? 1u : 0u) | (d.pad & 6u));
+				if (base + t == 0) s_dst0 = rel;
+				more = 1;
+			}
+		}
+		const int got = __syncthreads_count(more);      // (chains are in position order: the ones inside the piece are a prefix of the round)
+		nc += (uint32_t)got;
+		if (got < 256) break;
+	}
+	__syncthreads();
+	const int32_t p0 = 8 * (int32_t)t;
+	uint32_t c; { uint32_t lo = 0, hi = nc; while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (c_dst[m] <= p0) lo = m; else hi = m; } c = lo; }
+	// phase 1 (LDS only): chain and index inside the chain of each of the 8 positions; phase 2: the 8 code bytes - unconditional loads, all in flight together
+	// (a position without a code reads byte 0 of the array and ignores it)
+	uint64_t ik[8]; uint32_t sk[8], ck[8]; uint8_t fk[8], code[8]; uint32_t todo = 0;      // todo: positions whose code must be computed from the hits
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		const int32_t pr = p0 + k;
+		while (c + 1 < nc && c_dst[c + 1] <= pr) ++c;
+		ck[k] = c; sk[k] = c_src[c]; fk[k] = c_fl[c]; ik[k] = (uint64_t)((int64_t)pr - (c == 0 ? s_dst0 : (int64_t)c_dst[c]));
+		if (p_blk + (uint64_t)pr >= n_cl) ik[k] = 0;      // filler past the last hit: reads as a chain start (code 0x08, no bit)
+	}
+	const uint8_t *hc = A.hcode ? A.hcode : A.bytes;      // (flag 2 is never set without codes)
+	uint8_t raw[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) raw[k] = hc[(ik[k] > 0 && (fk[k] & 2u)) ? (uint64_t)sk[k] + ik[k] : 0];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		code[k] = 0x08;
+		if (ik[k] > 0) { if (fk[k] & 2u) code[k] = raw[k]; else todo |= 1u << k; }
+	}
+	uint32_t escm = 0;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		const bool every = A.exc_every && ik[k] > 0 && ik[k] % A.exc_every == A.exc_every - 1;
+		if (code[k] == 0xff || every) escm |= 1u << k;
+	}
+	// (the per-position arrays are indexed by compile-time constants only: a run-time index would move them to scratch memory)
+	if (todo)      // chains without codes (tiny groups, the DP path's copies): from the hits themselves
+#pragma unroll
+		for (int k = 0; k < 8; ++k) if (todo & (1u << k)) {
+			const uint64_t si = sk[k], i = ik[k]; const uint32_t fl = fk[k];
+			const hao_hit_t *src = ((fl & 1u) ? A.ohits : A.hits) + si;
+			const hao_hit_t h = src[i], ph = src[i - 1]; uint32_t q, pq;
+			if (fl & 4u) { q = A.hq[si + i]; pq = A.hq[si + i - 1]; }
+			else {
+				const uint32_t rd = A.cd[first + ck[k]].r; const uint64_t m0 = A.mz_off[A.rid_lo + rd]; const uint32_t nq = (uint32_t)(A.mz_off[A.rid_lo + rd + 1] - m0);
+				q = hao_pack_find_q(A.q_pos + (m0 - A.mz0), nq, h.self_offset); pq = hao_pack_find_q(A.q_pos + (m0 - A.mz0), nq, ph.self_offset);
+			}
+			const int64_t dq = (int64_t)q - (int64_t)pq, dd = ((int64_t)h.offset - (int64_t)ph.offset) - ((int64_t)h.self_offset - (int64_t)ph.self_offset);
+			code[k] = (uint8_t)((dq - 1) << 4 | (dd + 8));
+			if (dq < 1 || dq > 15 || dd < -8 || dd > 7) escm |= 1u << k;
+		}
+	if (escm)      // verbatim list (rare): the hit itself, with its minimizer index
+#pragma unroll
+		for (int k = 0; k < 8; ++k) if (escm & (1u << k)) {
+			const uint64_t si = sk[k], i = ik[k]; const uint32_t fl = fk[k];
+			code[k] = 0xff;
+			const unsigned long long kx = atomicAdd(A.exc_cnt, 1ULL);
+			if (kx < A.exc_cap) {      // past the capacity only the count matters: the host grows the list and packs again
+				const hao_hit_t *src = ((fl & 1u) ? A.ohits : A.hits) + si;
+				hao_exc_t e; e.index = p_blk + (uint64_t)(p0 + k); e.pad = 0; e.hit = src[i]; e.hit.w0 = A.cd[first + ck[k]].w0;
+				if (fl & 6u) e.q = A.hq[si + i];
+				else {
+					const uint32_t rd = A.cd[first + ck[k]].r; const uint64_t m0 = A.mz_off[A.rid_lo + rd]; const uint32_t nq = (uint32_t)(A.mz_off[A.rid_lo + rd + 1] - m0);
+					e.q = hao_pack_find_q(A.q_pos + (m0 - A.mz0), nq, e.hit.self_offset);
+				}
+				A.exc[kx] = e;
+			}
+		}
+	uint64_t word = 0; uint32_t m8 = 0;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) { word |= (uint64_t)code[k] << (8 * k); if (code[k] != 0x08) m8 |= 1u << k; }
+	if (p_blk + 8 * t < n_cl) *(uint64_t*)(A.bytes + p_blk + 8 * t) = word;
+	uint64_t bw = (uint64_t)m8 << ((t & 7) * 8);
+	bw |= __shfl_xor(bw, 1); bw |= __shfl_xor(bw, 2); bw |= __shfl_xor(bw, 4);
+	if ((t & 7) == 0 && w < A.n_words_max) { A.bits[w] = bw; A.cnt[w] = (uint32_t)__popcll(bw); }
 }
 
+// code bytes of the flagged hits, at their rank: thread t takes hits [8t, 8t + 8)
 __global__ __launch_bounds__(256) void hao_pack_codes_kernel(const uint8_t *bytes, const uint64_t *n_dev, const uint64_t *bits, const uint32_t *rank, uint64_t n_words_max, uint8_t *codes,
 		unsigned long long *n_codes)
 {

@@ -65,6 +65,10 @@ def _check_thresholds(e, rs, g, cov):
     st = e.stats()
     assert (st["high_occ"], st["low_occ"], st["max_n_chain"]) == (m["high_occ"], m["low_occ"], m["max_n_chain"])
     assert (e.hist(1) == g["pt_hist"]).all()                     # minimizer count histogram of ha_pt_gen (htab.cpp:1249-1256)
+    if "ft_hist" in g:                                           # all-k-mer histogram and filter table of ha_ft_gen (5.6 G occurrences on configs[2]: beyond 2^32)
+        assert (e.hist(0) == g["ft_hist"]).all()
+        keys, vals = e.ft_table()
+        assert keys.shape == g["ft_keys"].shape and (keys == g["ft_keys"]).all() and (vals == g["ft_vals"]).all()
 
 
 def test_tables_and_thresholds(full):
