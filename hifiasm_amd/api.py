@@ -38,13 +38,13 @@ class Pass(C.Structure):
 
 
 class ChainHdr(C.Structure):
-    _fields_ = [("n_hits", C.c_uint32), ("w0", C.c_uint32), ("q0", C.c_uint32), ("offset", C.c_uint32)]
+    _fields_ = [("n_hits", C.c_uint32), ("w0", C.c_uint32), ("q0", C.c_uint32), ("offset", C.c_uint32), ("pos", C.c_uint64)]
 
 
 class Delivery(C.Structure):
     """hao_delivery_t: read-only view of one batch's results in a pinned host arena"""
     _fields_ = [("rid_lo", C.c_uint64), ("n_reads", C.c_uint64), ("n_ol", C.c_uint64), ("n_fc", C.c_uint64), ("n_chains", C.c_uint64),
-                ("n_cl", C.c_uint64), ("n_exc", C.c_uint64), ("n_codes", C.c_uint64), ("bytes", C.c_uint64),
+                ("n_cl", C.c_uint64), ("n_exc", C.c_uint64), ("n_codes", C.c_uint64), ("n_pos", C.c_uint64), ("bytes", C.c_uint64),
                 ("ol_off", C.c_void_p), ("ol", C.c_void_p), ("fc_off", C.c_void_p), ("fc", C.c_void_p), ("ch_off", C.c_void_p),
                 ("cl_off", C.c_void_p), ("qm_off", C.c_void_p), ("chains", C.c_void_p), ("cl_bits", C.c_void_p), ("cl_rank", C.c_void_p), ("cl_codes", C.c_void_p), ("qmz", C.c_void_p),
                 ("cl_exc", C.c_void_p), ("exact", C.c_void_p), ("copy_ms", C.c_double)]

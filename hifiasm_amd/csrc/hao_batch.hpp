@@ -16,7 +16,7 @@ struct hao_ctx::Batch {
 	DevBuf<int32_t> f, ii, p, key_sc, tm; DevBuf<int64_t> t; DevBuf<uint64_t> key_xs; DevBuf<uint32_t> key_al, key_tmp;
 	DevBuf<hao_chain_rec> rec; DevBuf<hao_ovlp_t> ol; DevBuf<hao_cdesc> cd; bool cl_valid = false;
 	DevBuf<uint16_t> hq; DevBuf<uint8_t> hcode;      // delivery path: query minimizer index / wire code of every seed hit (seed kernel, chain_group_kernel)
-	DevBuf<uint8_t> pk_bytes; DevBuf<uint32_t> pk_cnt, pk_first; uint64_t n_codes = 0;      // one code byte per chained hit (device only) before it is split into bits + code bytes
+	DevBuf<uint32_t> pk_cnt; uint64_t n_codes = 0;      // one code byte per chained hit (device only) before it is split into bits + code bytes
 	// Results of a batch that leave the device.  Two sets (+ two pinned host arenas): while the copy stream drains the set of batch i, batch i + 1
 	// computes into the other one (hao_overlap_batch_async).  The blocking API keeps using the current set.
 	struct OutSet {
@@ -40,7 +40,7 @@ struct hao_ctx::Batch {
 		s_start.release(); a_off.release(); seg.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fcf_off.release();
 		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); g_cls.release(); slow.release(); ovf_list.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
-		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); cd.release(); pk_bytes.release(); pk_cnt.release(); pk_first.release(); hq.release(); hcode.release(); out[0].release(); out[1].release();
+		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); cd.release(); pk_cnt.release(); hq.release(); hcode.release(); out[0].release(); out[1].release();
 		if (dl_ready) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); for (int k = 0; k < n_aux; ++k) { (void)hipStreamSynchronize(copy_aux[k]); (void)hipStreamDestroy(copy_aux[k]); (void)hipEventDestroy(ev_aux[0][k]); (void)hipEventDestroy(ev_aux[1][k]); } for (int x = 0; x < 2; ++x) { (void)hipEventDestroy(ev_ready[x]); (void)hipEventDestroy(ev_done[x]); if (arena[x]) (void)hipHostFree(arena[x]); arena[x] = nullptr; arena_cap[x] = 0; } dl_ready = false; }
 	}
 };
@@ -120,7 +120,7 @@ static int hao_deliver_enqueue(hao_ctx *c)
 	size_t o_oloff = 0, o_ol = o_oloff + (ol ? al((n + 1) * 8) : 0), o_fcoff = o_ol + (ol ? al(B.n_ol * sizeof(hao_ovlp_t)) : 0), o_fc = o_fcoff + (ol ? al((B.n_ol + 1) * 8) : 0);
 	size_t o_choff = o_fc + (ol ? al(B.n_fc * 8) : 0), o_cloff = o_choff + (cl ? al((n + 1) * 8) : 0), o_qmoff = o_cloff + (cl ? al((n + 1) * 8) : 0), o_hdr = o_qmoff + (cl ? al((n + 1) * 8) : 0);
 	size_t o_qmz = o_hdr + (cl ? al(B.n_chains * sizeof(hao_chain_hdr_t)) : 0), o_bits = o_qmz + (cl ? al(B.n_mz * sizeof(hao_qmz_t)) : 0);
-	const uint64_t nw_ = (B.n_cl + 63) / 64;      // 64-hit words of the batch's bit stream
+	const uint64_t nw_ = cl ? (B.n_anchor + 63) / 64 : 0;      // 64-position words of the batch's bit stream (positions = seed hits)
 	size_t o_rank = o_bits + (cl ? al(nw_ * 8) : 0), o_codes = o_rank + (cl ? al((nw_ + 1) * 4) : 0), o_exc = o_codes + (cl ? al(B.n_codes) : 0);
 	size_t o_ex = o_exc + (cl ? al(B.n_exc * sizeof(hao_exc_t)) : 0), total = o_ex + (ex ? al(B.n_ol) : 0);
 	if (total > B.arena_cap[s]) {
@@ -149,7 +149,7 @@ static int hao_deliver_enqueue(hao_ctx *c)
 		return hipGetLastError();
 	};
 	hao_delivery_t &d = B.dl[s];
-	d.rid_lo = B.lo; d.n_reads = n; d.n_ol = d.n_fc = d.n_chains = d.n_cl = d.n_exc = d.n_codes = 0; d.bytes = 0;
+	d.rid_lo = B.lo; d.n_reads = n; d.n_ol = d.n_fc = d.n_chains = d.n_cl = d.n_exc = d.n_codes = d.n_pos = 0; d.bytes = 0;
 	if (ol && n) {
 		HIP_TRY(cp(o_oloff, O.fin_off.p, (n + 1) * 8)); HIP_TRY(cp(o_ol, O.ol_out.p, B.n_ol * sizeof(hao_ovlp_t)));
 		HIP_TRY(cp(o_fcoff, O.fc_out_off.p, B.n_ol * 8)); HIP_TRY(cp(o_fc, O.fc_out.p, B.n_fc * 8));
@@ -174,7 +174,7 @@ static int hao_deliver_enqueue(hao_ctx *c)
 				HIP_TRY(hipStreamWaitEvent(B.copy_stream, B.ev_aux[s][k - 1], 0));
 			}
 		}
-		d.n_chains = B.n_chains; d.n_cl = B.n_cl; d.n_exc = B.n_exc; d.n_codes = B.n_codes; d.ch_off = (const uint64_t*)(a + o_choff); d.cl_off = (const uint64_t*)(a + o_cloff); d.qm_off = (const uint64_t*)(a + o_qmoff);
+		d.n_chains = B.n_chains; d.n_cl = B.n_cl; d.n_exc = B.n_exc; d.n_codes = B.n_codes; d.n_pos = B.n_anchor; d.ch_off = (const uint64_t*)(a + o_choff); d.cl_off = (const uint64_t*)(a + o_cloff); d.qm_off = (const uint64_t*)(a + o_qmoff);
 		d.chains = (const hao_chain_hdr_t*)(a + o_hdr); d.qmz = (const hao_qmz_t*)(a + o_qmz); d.cl_bits = (const uint64_t*)(a + o_bits); d.cl_rank = (const uint32_t*)(a + o_rank); d.cl_codes = a + o_codes; d.cl_exc = (const hao_exc_t*)(a + o_exc);
 		d.bytes += 3 * (n + 1) * 8 + B.n_chains * sizeof(hao_chain_hdr_t) + B.n_mz * sizeof(hao_qmz_t) + nw_ * 8 + (nw_ + 1) * 4 + B.n_codes + B.n_exc * sizeof(hao_exc_t);
 	}
@@ -262,7 +262,11 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		sa_.sinfo = c->d_ix_sinfo.p; sa_.len = c->d_len_all.p; sa_.q_pos = B.q_pos.p; sa_.q_cnt = B.q_cnt.p; sa_.hits = B.hits.p; sa_.g_tmp = B.g_tmp.p; sa_.g_cnt = B.g_cnt.p; sa_.n_sel = n; sa_.tb = tb;
 		sa_.qcap = (uint32_t)std::min<uint64_t>((max_q + 63) & ~63ULL, HAO_QTAB_CAP);
 		sa_.dbg = nullptr; sa_.hq = nullptr;
-		if ((parts & HAO_DELIVER_CL) && !c->sw.pack_search) { HIP_TRY(B.hq.reserve(A + 64)); HIP_TRY(B.hcode.reserve(A + 64)); sa_.hq = B.hq.p; }
+		if (parts & HAO_DELIVER_CL) {      // the wire format's code array (one byte per seed hit, 0x08 = nothing to say) and, for the quick check's codes, every hit's minimizer index
+			HIP_TRY(B.hcode.reserve(A + 64));
+			{ const uint64_t n16 = (A + 31) / 16; hipLaunchKernelGGL(hao_fill16_kernel, dim3((unsigned)std::min<uint64_t>((n16 + 255) / 256, 1u << 14)), dim3(256), 0, c->stream, (hao_fill_v4*)B.hcode.p, n16, 0x08080808u); HAO_CHECK_LAUNCH(); }
+			if (!c->sw.pack_search) { HIP_TRY(B.hq.reserve(A + 64)); sa_.hq = B.hq.p; }
+		}
 		if (c->sw.seedphase) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); sa_.dbg = B.dbgbuf.p; }
 		HIP_TRY(B.ovf_list.reserve(n + 1));
 		unsigned long long *d_ovf = B.stats.p + 3 * HAO_NCLS + 3;
@@ -314,7 +318,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	if (G) {
 		hao_chain_args ca;
 		ca.hits = B.hits.p; ca.g_start = B.g_start.p; ca.g_read = B.g_read.p; ca.g_off = B.g_off.p; ca.seg = B.seg.p; ca.n_groups = G; ca.rid_lo = glo; ca.len = c->d_len_all.p; ca.par = par;
-		ca.dbg_qc = nullptr; ca.hq = nullptr; ca.hcode = nullptr;
+		ca.dbg_qc = nullptr; ca.hq = nullptr; ca.hcode = nullptr; ca.exc_every = (uint32_t)c->sw.exc_every;
 		if ((parts & HAO_DELIVER_CL) && !c->sw.pack_search) { ca.hq = B.hq.p; ca.hcode = B.hcode.p; }
 		if (c->sw.qcphase) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); ca.dbg_qc = B.dbgbuf.p; }
 		ca.stats = d_slow_cnt; ca.dbg_stats = c->sw.dp_stats ? 1 : 0;
@@ -376,32 +380,33 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	}
 	unsigned long long *d_exc_cnt = B.stats.p + 3 * HAO_NCLS + 2;      // (slot [3 NCLS + 2] of the stats block is free; [3 NCLS + 3] = seed overflow list cursor)
 	hao_pack_args pa; memset(&pa, 0, sizeof(pa));
-	const uint64_t NWmax = (A + 63) / 64 + 1;      // 64-hit words of the bit stream (bound: chained hits <= seed hits), plus one so that the scan's last entry is the total
+	const uint64_t NW = (A + 63) / 64;      // 64-position words of the bit stream (positions = seed hits)
 	unsigned long long *d_n_codes = B.stats.p + 3 * HAO_NCLS + 1;
-	// cl->list -> wire format: one code byte per chained hit (the number of chains / hits is only known on the device here: launch over the bounds,
-	// the kernels stop at ch_base[G] / cl_base[G]), then bits + rank directory + the code bytes of the flagged hits
+	// cl->list -> wire format (hao_deliver.cuh): chain headers; codes of the chains the DP compacted; then ONE pass over the code array the quick check
+	// filled - bits, rank directory, code bytes of the flagged positions, verbatim list.  (The number of chains is only known on the device here: launches
+	// cover the bound, the kernels stop at ch_base[G].)
 	auto pack = [&]() -> int {
 		if (!G) return HAO_OK;
 		hao_ctx::Batch::OutSet &O = B.O();
 		hipLaunchKernelGGL(hao_pack_hdr_kernel, dim3((unsigned)((NCmax + 255) / 256)), dim3(256), 0, c->stream, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH();
-		hipLaunchKernelGGL(hao_pack_flat_kernel, dim3((unsigned)pa.n_blk), dim3(256), 0, c->stream, pa, B.ch_base.p + G, B.cl_base.p + G); HAO_CHECK_LAUNCH();
+		hipLaunchKernelGGL(hao_pack_ohits_kernel, dim3((unsigned)std::min<uint64_t>((NCmax + 3) / 4, 1u << 16)), dim3(256), 0, c->stream, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH();
+		hipLaunchKernelGGL(hao_pack_bits_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, c->stream, pa, A, NW, O.bits.p, B.pk_cnt.p); HAO_CHECK_LAUNCH();
 		size_t tb = 0;
-		HIP_TRY(rocprim::exclusive_scan(nullptr, tb, B.pk_cnt.p, O.rank.p, 0u, NWmax, rocprim::plus<uint32_t>(), c->stream)); HIP_TRY(hao_tmp(c, tb));
-		HIP_TRY(rocprim::exclusive_scan(c->d_tmp.p, tb, B.pk_cnt.p, O.rank.p, 0u, NWmax, rocprim::plus<uint32_t>(), c->stream));
-		hipLaunchKernelGGL(hao_pack_codes_kernel, dim3((unsigned)((NWmax * 8 + 255) / 256)), dim3(256), 0, c->stream, B.pk_bytes.p, B.cl_base.p + G, O.bits.p, O.rank.p, NWmax, O.codes.p, d_n_codes); HAO_CHECK_LAUNCH();
+		HIP_TRY(rocprim::exclusive_scan(nullptr, tb, B.pk_cnt.p, O.rank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), c->stream)); HIP_TRY(hao_tmp(c, tb));
+		HIP_TRY(rocprim::exclusive_scan(c->d_tmp.p, tb, B.pk_cnt.p, O.rank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), c->stream));
+		hipLaunchKernelGGL(hao_pack_codes_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, c->stream, B.hcode.p, A, O.bits.p, O.rank.p, NW, O.codes.p, d_n_codes); HAO_CHECK_LAUNCH();
 		return HAO_OK;
 	};
 	if (parts & HAO_DELIVER_CL) {
 		hao_ctx::Batch::OutSet &O = B.O();
-		HIP_TRY(O.hdr.reserve(NCmax + 1)); HIP_TRY(B.pk_bytes.reserve(A + 16)); HIP_TRY(O.exc.reserve(c->sw.exc_cap >= 0 ? (uint64_t)c->sw.exc_cap + 1 : std::max<uint64_t>(1 << 14, A / 256)));
-		HIP_TRY(O.bits.reserve(NWmax + 2)); HIP_TRY(O.rank.reserve(NWmax + 2)); HIP_TRY(B.pk_cnt.reserve(NWmax + 2)); HIP_TRY(O.codes.reserve(A + 16));
+		HIP_TRY(O.hdr.reserve(NCmax + 1)); HIP_TRY(O.exc.reserve(c->sw.exc_cap >= 0 ? (uint64_t)c->sw.exc_cap + 1 : std::max<uint64_t>(1 << 14, A / 256)));
+		HIP_TRY(O.bits.reserve(NW + 2)); HIP_TRY(O.rank.reserve(NW + 2)); HIP_TRY(B.pk_cnt.reserve(NW + 2)); HIP_TRY(O.codes.reserve(A + 16));
+		HIP_TRY(hipMemsetAsync(B.pk_cnt.p + NW, 0, 4, c->stream));      // (the scan runs over NW + 1 counts: its last output is the total)
 		HIP_TRY(O.ch_off.reserve(n + 2)); HIP_TRY(O.cl_off.reserve(n + 2)); HIP_TRY(O.qm_off.reserve(n + 2)); HIP_TRY(O.qmz.reserve(nm + 1));
-		pa.cd = B.cd.p; pa.hits = B.hits.p; pa.ohits = B.ohits.p; pa.mz_off = c->d_ix_mz_off.p; pa.rid_lo = lo; pa.mz0 = B.mz0; pa.q_pos = B.q_pos.p;
-		if (!c->sw.pack_search) { pa.hq = B.hq.p; pa.hcode = B.hcode.p; }
-		pa.hdr = O.hdr.p; pa.bytes = B.pk_bytes.p; pa.exc = O.exc.p; pa.exc_cnt = d_exc_cnt; pa.exc_every = (uint32_t)c->sw.exc_every;
+		pa.cd = B.cd.p; pa.hits = B.hits.p; pa.ohits = B.ohits.p; pa.mz_off = c->d_ix_mz_off.p; pa.seg = B.seg.p; pa.n_sel = n; pa.rid_lo = lo; pa.mz0 = B.mz0; pa.q_pos = B.q_pos.p;
+		pa.hq = c->sw.pack_search ? nullptr : B.hq.p; pa.have_codes = c->sw.pack_search ? 0 : 1;
+		pa.hdr = O.hdr.p; pa.bytes = B.hcode.p; pa.exc = O.exc.p; pa.exc_cnt = d_exc_cnt; pa.exc_every = (uint32_t)c->sw.exc_every;
 		pa.exc_cap = c->sw.exc_cap >= 0 ? std::min<uint64_t>(O.exc.cap, (uint64_t)c->sw.exc_cap) : O.exc.cap;
-		pa.n_blk = (NWmax * 64 + HAO_PACK_T - 1) / HAO_PACK_T; HIP_TRY(B.pk_first.reserve(pa.n_blk + 1)); pa.blk_first = B.pk_first.p;
-		pa.bits = O.bits.p; pa.cnt = B.pk_cnt.p; pa.n_words_max = NWmax;
 		if (int rc = pack()) return rc;
 		hipLaunchKernelGGL(hao_read_ranges_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, B.g_off.p, B.ch_base.p, B.cl_base.p, c->d_ix_mz_off.p, lo, B.mz0, n, O.ch_off.p, O.cl_off.p, O.qm_off.p);
 		HAO_CHECK_LAUNCH();

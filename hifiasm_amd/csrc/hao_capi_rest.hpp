@@ -16,9 +16,6 @@ static void hao_release_all(hao_ctx *c)
 	c->d_ix_keys.release(); c->d_ix_start.release(); c->d_ix_cnt.release(); c->d_ix_bucket.release();
 }
 
-#define HAO_HAVE_FT
-#define HAO_HAVE_PT
-#define HAO_HAVE_QUERY
 extern "C" {
 
 int hao_ft_gen(hao_ctx *c, int32_t *hom_cov)
@@ -158,17 +155,17 @@ uint64_t hao_unpack_hits(const hao_delivery_t *d, uint64_t rid, hao_hit_t *out, 
 	for (uint64_t ci = d->ch_off[r]; ci < d->ch_off[r + 1]; ++ci) {
 		const hao_chain_hdr_t &H = d->chains[ci];
 		uint32_t q = H.q0, off = H.offset;
-		const uint64_t g = h0 + k;      // index of the chain's first hit in the batch; its code bytes start at rank(g)
-		uint64_t cp = d->cl_rank[g >> 6] + (uint64_t)__builtin_popcountll(d->cl_bits[g >> 6] & ((1ULL << (g & 63)) - 1));
+		const uint64_t g = H.pos;      // position of the chain's first hit; the code bytes of its later hits start at rank(g + 1) (the byte at g itself, if any, is not the chain's)
+		uint64_t cp = H.n_hits > 1 ? d->cl_rank[(g + 1) >> 6] + (uint64_t)__builtin_popcountll(d->cl_bits[(g + 1) >> 6] & ((1ULL << ((g + 1) & 63)) - 1)) : 0;
 		for (uint32_t i = 0; i < H.n_hits; ++i) {
 			hao_hit_t &o = out[k + i];
 			if (i) {
 				const uint64_t gi = g + i; uint8_t w = 0x08;      // no code byte: the read's next minimizer, same diagonal
 				if (d->cl_bits[gi >> 6] >> (gi & 63) & 1) w = d->cl_codes[cp++];
-				if (w == 0xff) {      // verbatim: binary search of the hit's index in the sorted exception list
+				if (w == 0xff) {      // verbatim: binary search of the position in the sorted exception list
 					uint64_t lo = 0, hi = d->n_exc;
 					while (lo < hi) { const uint64_t m = (lo + hi) >> 1; if (d->cl_exc[m].index < gi) lo = m + 1; else hi = m; }
-					o = d->cl_exc[lo].hit; q = d->cl_exc[lo].q; off = o.offset;
+					o = d->cl_exc[lo].hit; o.w0 = H.w0; q = d->cl_exc[lo].q; off = o.offset;
 					continue;
 				}
 				const uint32_t qn = q + (w >> 4) + 1; off = (uint32_t)((int64_t)off + (int64_t)(qt[qn].self_offset - qt[q].self_offset) + (int64_t)(w & 15) - 8); q = qn;

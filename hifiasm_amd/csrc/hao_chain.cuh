@@ -153,6 +153,7 @@ struct hao_chain_args {
 	int32_t *tm;                                 // per-hit mark scratch for oversize groups
 	int dbg_seq, dbg_stats;          // dbg_seq: 1 one-lane sequential chaining, 3 one-lane DP tail, 4 no speculative tiles (all give identical results)
 	unsigned long long *dbg_qc;   // optional phase timers of chain_group_kernel (HAO_DBG_QCPHASE)
+	uint32_t exc_every;      // (tests) every n-th hit of a group gets the code 0xff: exercises the verbatim list
 	const uint16_t *hq; uint8_t *hcode;      // delivery path: query minimizer index of every seed hit (seed kernel) -> wire code byte of every seed hit relative to its
 	                                         // predecessor in the sorted order (hao_deliver.cuh): the quick check has both hits in registers anyway
 };
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 		if (hcg) {      // wire code of this hit relative to the previous one of its strand block: minimizers skipped << 4 | diagonal shift + 8; 0xff = not expressible
 			const uint32_t pq = hao_wave_shr1(q, carry_q);
 			const int32_t dq = (int32_t)(q - pq), sh = (int32_t)((h.offset - ph.offset) - (h.self_offset - ph.self_offset));
-			const uint8_t code = st ? (uint8_t)0x08 : ((dq < 1 || dq > 15 || sh < -8 || sh > 7 || q == 65535u) ? (uint8_t)0xff : (uint8_t)((dq - 1) << 4 | (sh + 8)));
+			const uint8_t code = st ? (uint8_t)0x08 : ((dq < 1 || dq > 15 || sh < -8 || sh > 7 || q == 65535u || (A.exc_every && idx % A.exc_every == A.exc_every - 1)) ? (uint8_t)0xff : (uint8_t)((dq - 1) << 4 | (sh + 8)));
 			if (act) hcg[idx] = code;
 			carry_q = hao_bcast(q, 63);
 		}
@@ -419,6 +420,8 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 		if ((int64_t)(best ? maxf0 : maxf1) >= min_sc) fast = false;         // a second chain may qualify: exact sequential path
 	}
 	if (!fast) {
+		// the DP decides this group's chains: the codes written above describe none of them (a void 0xff would only become a useless verbatim-list entry)
+		if (hcg) for (int64_t i = lane; i < a_n; i += 64) hcg[i] = 0x08;
 		if (lane == 0) { unsigned long long si_ = atomicAdd(A.stats + cls, 1ULL); atomicAdd(A.stats + HAO_NCLS, (unsigned long long)a_n); slow[si_] = (uint32_t)li; A.nch[g] = 0; A.nout[g] = 0; }
 		return;
 	}

@@ -53,169 +53,162 @@ __global__ __launch_bounds__(256) void hao_digest_kernel(hao_digest_args A)
 // Wire format of cl->list (include/hao.h: hao_chain_hdr_t, hao_qmz_t, hao_unpack_hits).
 // A chained hit is a pair (query minimizer, position on the target): self_offset and cnt (seed weight << 8 | span) are properties of the QUERY
 // minimizer alone (anchor.cpp:1065-1076), and along a chain the target offset follows the query offset up to a small diagonal shift.  So the
-// batch ships, per read, its minimizer table (self_offset, cnt: 8 bytes per minimizer, ~430 per 15 kb read) once, and per chained hit a code:
+// batch ships, per read, its minimizer table (self_offset, cnt: 8 bytes per minimizer, ~430 per 15 kb read) once, and per hit a code:
 //     high nibble = (minimizers skipped since the previous hit of the chain) = dq - 1     (0 .. 14)
 //     low nibble  = (target offset delta) - (self_offset delta) + 8                       (diagonal shift -8 .. 7)
-// 0xff = the hit is in the batch's exception list (verbatim, with its minimizer index), keyed by the hit's index in the batch and sorted.
+// 0xff = the hit is in the batch's exception list (verbatim, with its minimizer index), keyed by the hit's POSITION and sorted.
 // More than nine hits in ten have the code 0x08 (next minimizer, same diagonal), so the codes do not travel as a byte per hit: the batch ships
-// one BIT per hit (1 = this hit has a code byte), a rank directory (code bytes before every 64th hit) and the code bytes of the flagged hits
-// (hao_pack_bits_kernel, hao_pack_codes_kernel below): ~0.3 bytes per chained hit across PCIe instead of 16.
-// The first hit of a chain comes from the chain header (minimizer index, target offset).  ~1.3 bytes per chained hit across PCIe instead
-// of 16; the consumer thread decodes straight into its Candidates_list.  One wave per chain, reading the hits where the chain kernels left
-// them (chain descriptors): cl->list is never materialised in HBM on this path.  The minimizer index of a hit is recovered by a binary
-// search of its self_offset in the read's table (a few hundred L1/L2-resident entries).
+// one BIT per position (1 = a code byte exists), a rank directory (code bytes before every 64th position) and the code bytes of the flagged
+// positions: ~0.3 bytes per chained hit across PCIe instead of 16.
+//
+// POSITIONS are indices into the batch's sorted SEED hits, not into the concatenated cl->list: > 99.9 % of the chains are contiguous runs of the
+// seed hits (chain descriptors, hao_chain.cuh), and the quick check (chain_group_kernel) already computes every seed hit's code relative to its
+// predecessor while it has both in registers.  With positions = seed-hit indices that byte array IS the code array of the wire format: nothing is
+// gathered per chain (the per-chain gather was latency-bound: 3 ms per 745 M-hit batch), the bit stream is one coalesced pass over it, and a chain
+// header carries the position of its first hit.  The 3.5 % of seed hits that are in no chain cost a bit each.  A group that went through the
+// DP (its <= 3 chains were compacted into ohits[group start ..)) uses the same positions - the group's range is its own - and its codes are
+// written over the quick check's by hao_pack_ohits_kernel.  The code byte at a chain's FIRST position is meaningless (the header describes that
+// hit) and skipped by the decoder.  Exception entries carry the hit as the seed stage wrote it: the decoder sets its readID word from the header.
 // ---------------------------------------------------------------------------------------
-#define HAO_PACK_T 2048          // hits of cl->list per workgroup of the packer (8 per thread)
-#define HAO_PACK_CMAX (HAO_PACK_T + 1 + 256)
+#define HAO_PACK_QCAP 1024
+#define HAO_CODE_EXC_DONE 0xfe      // device only: "verbatim, and its list entry exists already" (hao_pack_ohits_kernel); leaves the device as 0xff
 struct hao_pack_args {
-	hao_cdesc *cd; const hao_hit_t *hits, *ohits;      // (the header kernel leaves two flags in the descriptors' pad word for the packer)
-	const uint64_t *mz_off; uint64_t rid_lo, mz0; const uint32_t *q_pos;      // per-read minimizer ranges (global offsets) and the batch's self_offset table
+	const hao_cdesc *cd; const hao_hit_t *hits, *ohits;
+	const uint64_t *mz_off, *seg; uint64_t rid_lo, mz0, n_sel; const uint32_t *q_pos;      // per-read minimizer ranges (global offsets), seed-hit ranges, the batch's self_offset table
 	hao_chain_hdr_t *hdr; uint8_t *bytes; hao_exc_t *exc; unsigned long long *exc_cnt; uint64_t exc_cap; uint32_t exc_every;
-	const uint16_t *hq; const uint8_t *hcode;      // per seed hit: query minimizer index (seed kernel), wire code (chain_group_kernel); null: every hit's minimizer is searched
-	uint32_t *blk_first; uint64_t n_blk;           // first chain of every HAO_PACK_T-hit piece of cl->list
-	uint64_t *bits; uint32_t *cnt; uint64_t n_words_max;
+	const uint16_t *hq; int have_codes;      // per seed hit: query minimizer index (seed kernel); have_codes: bytes[] holds the quick check's codes (else every chain is coded here)
 };
 
 // minimizer index of a hit: the table position of its self_offset (positions are strictly ascending in a read's table)
 __device__ __forceinline__ uint32_t hao_pack_find_q(const uint32_t *qp, uint32_t nq, uint32_t self_offset)
 { uint32_t lo = 0, hi = nq; while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (qp[m] < self_offset) lo = m + 1; else hi = m; } return lo; }
 
-// One LANE per chain: the chain header (the first hit: minimizer index, target offset) and, for every HAO_PACK_T-hit piece of cl->list whose first
-// position the chain holds, the piece's first chain.  (The chains tile cl->list without gaps, in order.)  Every chain is independent here: the dependent
-// loads of a chain (descriptor -> read's minimizer range -> first hit) overlap across 64 chains per wave instead of being paid once per chain and wave.
+// One LANE per chain: its header (hit count, readID word, first hit: minimizer index, target offset, position).  Chains are independent: the dependent
+// loads of one (descriptor -> read's minimizer range -> first hit) overlap across the 64 chains of a wave.
 __global__ __launch_bounds__(256) void hao_pack_hdr_kernel(hao_pack_args A, const uint64_t *n_chains_dev)
 {
 	const uint64_t ci = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 	if (ci >= *n_chains_dev) return;
 	const hao_cdesc d = A.cd[ci];
-	const hao_hit_t *src = hao_cd_src(d, A.hits, A.ohits);
-	const uint64_t m0 = A.mz_off[A.rid_lo + d.r]; const uint32_t nq = (uint32_t)(A.mz_off[A.rid_lo + d.r + 1] - m0);
-	const bool in_place = !(d.src & HAO_CD_OHITS);
-	const hao_hit_t h0 = src[0];
-	hao_chain_hdr_t H; H.n_hits = d.n; H.w0 = d.w0; H.offset = h0.offset;
-	H.q0 = (A.hq && in_place && nq < 65535u) ? A.hq[d.src] : hao_pack_find_q(A.q_pos + (m0 - A.mz0), nq, h0.self_offset);
+	const hao_hit_t h0 = hao_cd_src(d, A.hits, A.ohits)[0];
+	const uint64_t pos = d.src & ~HAO_CD_OHITS;
+	uint32_t q0 = (A.hq && !(d.src & HAO_CD_OHITS)) ? A.hq[pos] : 65535u;
+	if (q0 == 65535u) { const uint64_t m0 = A.mz_off[A.rid_lo + d.r]; q0 = hao_pack_find_q(A.q_pos + (m0 - A.mz0), (uint32_t)(A.mz_off[A.rid_lo + d.r + 1] - m0), h0.self_offset); }
+	hao_chain_hdr_t H; H.n_hits = d.n; H.w0 = d.w0; H.q0 = q0; H.offset = h0.offset; H.pos = pos;
 	A.hdr[ci] = H;
-	// what the packer may use for this chain's hits - pad bit 1: their wire codes (bit 0 = the quick check wrote them; the 16-bit minimizer indices behind them
-	// must not have saturated), bit 2: their minimizer indices
-	const uint32_t fl = (A.hcode && (d.pad & 1u) && nq < 65535u) ? 2u : (A.hq && in_place && nq < 65535u) ? 4u : 0u;
-	A.cd[ci].pad = (d.pad & 1u) | fl;
-	for (uint64_t b = (d.dst + HAO_PACK_T - 1) / HAO_PACK_T; b * HAO_PACK_T < d.dst + d.n && b < A.n_blk; ++b) A.blk_first[b] = (uint32_t)ci;
 }
 
-// cl->list -> one code byte per hit + the bit stream (1 = the hit has a code byte) + the per-word counts of the rank directory, in ONE pass over the
-// POSITIONS of cl->list: a workgroup takes HAO_PACK_T consecutive positions (thread t: 8 of them = one aligned 8-byte word of the code array), finds
-// their chains in an LDS copy of the piece's chain table and gathers the codes the quick check left next to the seed hits (1 byte per hit; chains whose
-// hits have no codes - tiny groups, the DP path - compute them from the hits).  Work is spread by position, not by chain: a 100 000-hit chain of a
-// tandem array and a 1-hit chain cost the same per hit, and no wave waits on one chain's dependent loads.
-__global__ __launch_bounds__(256) void hao_pack_flat_kernel(hao_pack_args A, const uint64_t *n_chains_dev, const uint64_t *n_cl_dev)
+// Codes of the chains whose hits are NOT the seed hits at their positions (the DP's compacted copies in ohits; with HAO_DBG_PACK_SEARCH every chain):
+// one wave per chain, the minimizer index of a hit by a binary search of its self_offset in the read's table (staged in LDS once per read), codes
+// written at the chain's positions; a hit without a code goes to the verbatim list right here (its code is marked HAO_CODE_EXC_DONE).
+__global__ __launch_bounds__(256) void hao_pack_ohits_kernel(hao_pack_args A, const uint64_t *n_chains_dev)
 {
-	__shared__ int32_t c_dst[HAO_PACK_CMAX]; __shared__ uint32_t c_src[HAO_PACK_CMAX]; __shared__ uint8_t c_fl[HAO_PACK_CMAX]; __shared__ int64_t s_dst0;      // starts relative to the piece (only its first chain can start before it: s_dst0)
-	const uint64_t n_chains = *n_chains_dev, n_cl = *n_cl_dev, p_blk = (uint64_t)blockIdx.x * HAO_PACK_T; const uint32_t t = threadIdx.x;
-	const uint64_t w = (p_blk + 8 * t) >> 6;
-	if (p_blk >= n_cl) {      // past the batch's hits: the words up to the bound are zero (the rank scan runs over the bound)
-		if ((t & 7) == 0 && w < A.n_words_max) { A.bits[w] = 0; A.cnt[w] = 0; }
-		return;
-	}
-	// the piece's chains: [first, ...) while they start before its end (source index < 2^32: a batch has fewer seed hits; flags: 1 = in ohits, 2 = codes, 4 = minimizer indices)
-	const uint64_t first = A.blk_first[blockIdx.x]; uint32_t nc = 0;
-	for (uint32_t base = 0; base + 256 <= HAO_PACK_CMAX; base += 256) {
-		const uint64_t ci = first + base + t; int more = 0;
-		if (ci < n_chains) {
-			const hao_cdesc d = A.cd[ci];
-			if (d.dst < p_blk + HAO_PACK_T) {
-				const int64_t rel = (int64_t)d.dst - (int64_t)p_blk;
-				c_dst[base + t] = rel < 0 ? 0 : (int32_t)rel; c_src[base + t] = (uint32_t)d.src; c_fl[base + t] = (uint8_t)((d.src & HAO_CD_OHITS ? 1u : 0u) | (d.pad & 6u));
-				if (base + t == 0) s_dst0 = rel;
-				more = 1;
-			}
+	const uint64_t n_chains = *n_chains_dev, n_waves = (uint64_t)gridDim.x * 4;
+	const int lane = hao_lane();
+	__shared__ uint32_t s_tab[4][HAO_PACK_QCAP];
+	uint32_t *tab = s_tab[threadIdx.x >> 6];
+	uint64_t tab_read = ~0ULL;
+	for (uint64_t ci = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); ci < n_chains; ci += n_waves) {
+		const hao_cdesc d = A.cd[ci];
+		if (A.have_codes && !(d.src & HAO_CD_OHITS)) continue;
+		const hao_hit_t *src = hao_cd_src(d, A.hits, A.ohits); const uint64_t pos = d.src & ~HAO_CD_OHITS;
+		const uint64_t m0 = A.mz_off[A.rid_lo + d.r]; const uint32_t nq = (uint32_t)(A.mz_off[A.rid_lo + d.r + 1] - m0);
+		const uint32_t *qp = A.q_pos + (m0 - A.mz0);
+		const bool in_lds = nq <= HAO_PACK_QCAP;
+		if (in_lds && tab_read != d.r) {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // (the previous chain's searches are done)
+			for (uint32_t k = lane; k < nq; k += 64) tab[k] = qp[k];
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			tab_read = d.r;
 		}
-		const int got = __syncthreads_count(more);      // (chains are in position order: the ones inside the piece are a prefix of the round)
-		nc += (uint32_t)got;
-		if (got < 256) break;
-	}
-	__syncthreads();
-	const int32_t p0 = 8 * (int32_t)t;
-	uint32_t c; { uint32_t lo = 0, hi = nc; while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (c_dst[m] <= p0) lo = m; else hi = m; } c = lo; }
-	// phase 1 (LDS only): chain and index inside the chain of each of the 8 positions; phase 2: the 8 code bytes - unconditional loads, all in flight together
-	// (a position without a code reads byte 0 of the array and ignores it)
-	uint64_t ik[8]; uint32_t sk[8], ck[8]; uint8_t fk[8], code[8]; uint32_t todo = 0;      // todo: positions whose code must be computed from the hits
-#pragma unroll
-	for (int k = 0; k < 8; ++k) {
-		const int32_t pr = p0 + k;
-		while (c + 1 < nc && c_dst[c + 1] <= pr) ++c;
-		ck[k] = c; sk[k] = c_src[c]; fk[k] = c_fl[c]; ik[k] = (uint64_t)((int64_t)pr - (c == 0 ? s_dst0 : (int64_t)c_dst[c]));
-		if (p_blk + (uint64_t)pr >= n_cl) ik[k] = 0;      // filler past the last hit: reads as a chain start (code 0x08, no bit)
-	}
-	const uint8_t *hc = A.hcode ? A.hcode : A.bytes;      // (flag 2 is never set without codes)
-	uint8_t raw[8];
-#pragma unroll
-	for (int k = 0; k < 8; ++k) raw[k] = hc[(ik[k] > 0 && (fk[k] & 2u)) ? (uint64_t)sk[k] + ik[k] : 0];
-#pragma unroll
-	for (int k = 0; k < 8; ++k) {
-		code[k] = 0x08;
-		if (ik[k] > 0) { if (fk[k] & 2u) code[k] = raw[k]; else todo |= 1u << k; }
-	}
-	uint32_t escm = 0;
-#pragma unroll
-	for (int k = 0; k < 8; ++k) {
-		const bool every = A.exc_every && ik[k] > 0 && ik[k] % A.exc_every == A.exc_every - 1;
-		if (code[k] == 0xff || every) escm |= 1u << k;
-	}
-	// (the per-position arrays are indexed by compile-time constants only: a run-time index would move them to scratch memory)
-	if (todo)      // chains without codes (tiny groups, the DP path's copies): from the hits themselves
-#pragma unroll
-		for (int k = 0; k < 8; ++k) if (todo & (1u << k)) {
-			const uint64_t si = sk[k], i = ik[k]; const uint32_t fl = fk[k];
-			const hao_hit_t *src = ((fl & 1u) ? A.ohits : A.hits) + si;
-			const hao_hit_t h = src[i], ph = src[i - 1]; uint32_t q, pq;
-			if (fl & 4u) { q = A.hq[si + i]; pq = A.hq[si + i - 1]; }
-			else {
-				const uint32_t rd = A.cd[first + ck[k]].r; const uint64_t m0 = A.mz_off[A.rid_lo + rd]; const uint32_t nq = (uint32_t)(A.mz_off[A.rid_lo + rd + 1] - m0);
-				q = hao_pack_find_q(A.q_pos + (m0 - A.mz0), nq, h.self_offset); pq = hao_pack_find_q(A.q_pos + (m0 - A.mz0), nq, ph.self_offset);
+		uint32_t q_prev = 0, off_prev = 0, self_prev = 0;      // the last hit of the previous tile (uniform)
+		for (uint32_t b = 0; b < d.n; b += 64) {
+			const uint32_t i = b + lane; const bool act = i < d.n;
+			hao_hit_t h; h.w0 = 0; h.offset = 0; h.self_offset = 0; h.cnt = 0; uint32_t q = 0;
+			if (act) { h = src[i]; q = hao_pack_find_q(in_lds ? tab : qp, nq, h.self_offset); }
+			const uint32_t pq = hao_wave_shr1(q, q_prev), po = hao_wave_shr1(h.offset, off_prev), ps = hao_wave_shr1(h.self_offset, self_prev);
+			bool esc = false;
+			if (act && i > 0) {
+				const int64_t dq = (int64_t)q - (int64_t)pq, dd = ((int64_t)h.offset - (int64_t)po) - ((int64_t)h.self_offset - (int64_t)ps);
+				esc = dq < 1 || dq > 15 || dd < -8 || dd > 7 || (A.exc_every && i % A.exc_every == A.exc_every - 1);
+				A.bytes[pos + i] = esc ? (uint8_t)HAO_CODE_EXC_DONE : (uint8_t)((dq - 1) << 4 | (dd + 8));
 			}
-			const int64_t dq = (int64_t)q - (int64_t)pq, dd = ((int64_t)h.offset - (int64_t)ph.offset) - ((int64_t)h.self_offset - (int64_t)ph.self_offset);
-			code[k] = (uint8_t)((dq - 1) << 4 | (dd + 8));
-			if (dq < 1 || dq > 15 || dd < -8 || dd > 7) escm |= 1u << k;
-		}
-	if (escm)      // verbatim list (rare): the hit itself, with its minimizer index
-#pragma unroll
-		for (int k = 0; k < 8; ++k) if (escm & (1u << k)) {
-			const uint64_t si = sk[k], i = ik[k]; const uint32_t fl = fk[k];
-			code[k] = 0xff;
-			const unsigned long long kx = atomicAdd(A.exc_cnt, 1ULL);
-			if (kx < A.exc_cap) {      // past the capacity only the count matters: the host grows the list and packs again
-				const hao_hit_t *src = ((fl & 1u) ? A.ohits : A.hits) + si;
-				hao_exc_t e; e.index = p_blk + (uint64_t)(p0 + k); e.pad = 0; e.hit = src[i]; e.hit.w0 = A.cd[first + ck[k]].w0;
-				if (fl & 6u) e.q = A.hq[si + i];
-				else {
-					const uint32_t rd = A.cd[first + ck[k]].r; const uint64_t m0 = A.mz_off[A.rid_lo + rd]; const uint32_t nq = (uint32_t)(A.mz_off[A.rid_lo + rd + 1] - m0);
-					e.q = hao_pack_find_q(A.q_pos + (m0 - A.mz0), nq, e.hit.self_offset);
+			const unsigned long long em = __ballot(esc);
+			if (em) {      // one atomic per wave and tile (a repeat-rich pass has millions of verbatim hits: one atomic each serialises on the counter)
+				unsigned long long base = 0;
+				if (lane == 0) base = atomicAdd(A.exc_cnt, (unsigned long long)__popcll(em));
+				base = (unsigned long long)hao_readlane_i64((int64_t)base, 0);
+				if (esc) {
+					const uint64_t k = base + __popcll(em & ((1ULL << lane) - 1));
+					if (k < A.exc_cap) { hao_exc_t e; e.index = pos + i; e.q = q; e.pad = 0; e.hit = h; A.exc[k] = e; }      // past the capacity only the count matters: the host grows the list and packs again
 				}
-				A.exc[kx] = e;
 			}
+			q_prev = hao_bcast(q, 63); off_prev = hao_bcast(h.offset, 63); self_prev = hao_bcast(h.self_offset, 63);
 		}
-	uint64_t word = 0; uint32_t m8 = 0;
-#pragma unroll
-	for (int k = 0; k < 8; ++k) { word |= (uint64_t)code[k] << (8 * k); if (code[k] != 0x08) m8 |= 1u << k; }
-	if (p_blk + 8 * t < n_cl) *(uint64_t*)(A.bytes + p_blk + 8 * t) = word;
-	uint64_t bw = (uint64_t)m8 << ((t & 7) * 8);
-	bw |= __shfl_xor(bw, 1); bw |= __shfl_xor(bw, 2); bw |= __shfl_xor(bw, 4);
-	if ((t & 7) == 0 && w < A.n_words_max) { A.bits[w] = bw; A.cnt[w] = (uint32_t)__popcll(bw); }
+	}
 }
 
-// code bytes of the flagged hits, at their rank: thread t takes hits [8t, 8t + 8)
-__global__ __launch_bounds__(256) void hao_pack_codes_kernel(const uint8_t *bytes, const uint64_t *n_dev, const uint64_t *bits, const uint32_t *rank, uint64_t n_words_max, uint8_t *codes,
+// One byte per position -> bit stream + per-word counts of the rank directory; a 0xff met on the way (the quick check could not express the hit) becomes
+// an entry of the verbatim list: the seed hit at the position and its minimizer index.  Thread t takes positions [8t, 8t + 8) (one 8-byte load); the
+// eight threads of a 64-position word combine their flags.
+__global__ __launch_bounds__(256) void hao_pack_bits_kernel(hao_pack_args A, uint64_t n, uint64_t n_words, uint64_t *bits, uint32_t *cnt)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, w = t >> 3;
+	uint32_t m8 = 0, e8 = 0; uint64_t v = 0;
+	if (8 * t < n) {
+		v = *(const uint64_t*)(A.bytes + 8 * t);
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const uint8_t b = (uint8_t)(v >> (8 * k));
+			if (8 * t + k < n && b != 0x08) m8 |= 1u << k;
+			if (8 * t + k < n && b == 0xff) e8 |= 1u << k;
+		}
+	}
+	if (__ballot(e8 != 0)) {      // verbatim entries: one atomic per wave reserves the wave's slots (the repeat-rich sets have millions per pass)
+		const uint32_t ne = (uint32_t)__popc(e8), inc = hao_wave_incl_scan_u32(ne), tot = hao_bcast(inc, 63);
+		unsigned long long base = 0;
+		if (hao_lane() == 63) base = atomicAdd(A.exc_cnt, (unsigned long long)tot);
+		base = (unsigned long long)hao_readlane_i64((int64_t)base, 63);
+		unsigned long long kx = base + inc - ne;
+		for (uint32_t m = e8; m; m &= m - 1, ++kx) {
+			if (kx >= A.exc_cap) continue;      // past the capacity only the count matters: the host grows the list and packs again
+			const uint64_t p = 8 * t + (uint32_t)(__ffs((int)m) - 1);
+			hao_exc_t e; e.index = p; e.pad = 0; e.hit = A.hits[p]; e.q = A.hq ? A.hq[p] : 65535u;
+			if (e.q == 65535u) {      // the 16-bit index saturated (a read of > 65 534 minimizers): the read of the position, then its table
+				uint64_t lo = 0, hi = A.n_sel; while (hi - lo > 1) { const uint64_t md = (lo + hi) >> 1; if (A.seg[md] <= p) lo = md; else hi = md; }
+				const uint64_t m0 = A.mz_off[A.rid_lo + lo];
+				e.q = hao_pack_find_q(A.q_pos + (m0 - A.mz0), (uint32_t)(A.mz_off[A.rid_lo + lo + 1] - m0), e.hit.self_offset);
+			}
+			A.exc[kx] = e;
+		}
+	}
+	uint64_t word = (uint64_t)m8 << ((t & 7) * 8);
+	word |= __shfl_xor(word, 1); word |= __shfl_xor(word, 2); word |= __shfl_xor(word, 4);
+	if ((t & 7) == 0 && w < n_words) { bits[w] = word; cnt[w] = (uint32_t)__popcll(word); }      // (no lane leaves early: the slot reservation above is wave-wide)
+}
+
+// code bytes of the flagged positions, at their rank: thread t takes positions [8t, 8t + 8)
+__global__ __launch_bounds__(256) void hao_pack_codes_kernel(const uint8_t *bytes, uint64_t n, const uint64_t *bits, const uint32_t *rank, uint64_t n_words, uint8_t *codes,
 		unsigned long long *n_codes)
 {
-	const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, n = *n_dev;
-	if (t == 0) *n_codes = rank[n_words_max - 1];      // (the last word of the bound is empty: its exclusive prefix is the total)
+	const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if (t == 0) *n_codes = rank[n_words];      // (exclusive prefix over n_words + 1 counts: the last entry is the total)
 	if (8 * t >= n) return;
 	const uint64_t word = bits[t >> 3]; const int sh = (int)(t & 7) * 8;
 	uint32_t m8 = (uint32_t)(word >> sh) & 0xffu;
 	if (!m8) return;
 	uint64_t at = rank[t >> 3] + (uint64_t)__popcll(word & ((1ULL << sh) - 1));
 	const uint64_t v = *(const uint64_t*)(bytes + 8 * t);
-	for (; m8; m8 &= m8 - 1) codes[at++] = (uint8_t)(v >> (8 * (__ffs((int)m8) - 1)));
+	for (; m8; m8 &= m8 - 1) { const uint8_t b = (uint8_t)(v >> (8 * (__ffs((int)m8) - 1))); codes[at++] = b == HAO_CODE_EXC_DONE ? (uint8_t)0xff : b; }
+}
+
+// fill by a kernel: a big hipMemsetAsync travels through the DMA queues, where the previous batch's result copy is in flight (measured: the copy of a
+// configs[2] batch then took 28 instead of 18 ms and was no longer hidden under the next batch's kernels)
+typedef uint32_t hao_fill_v4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void hao_fill16_kernel(hao_fill_v4 *p, uint64_t n16, uint32_t word)
+{
+	const hao_fill_v4 v = { word, word, word, word };
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) p[i] = v;
 }
 
 // the batch's minimizer table for the consumer: (self_offset, cnt) per query minimizer, interleaved

@@ -164,8 +164,9 @@ int hao_attach(hao_ctx *owner, hao_ctx **view);
  * self_offset and cnt belong to the query minimizer (anchor.cpp:1065-1076) and travel once per read in its minimizer table; a hit whose
  * chain simply moves on to the read's next minimizer on the same diagonal (> 90 % of them) is a 0 in the batch's bit stream, any other hit a 1
  * plus one code byte - minimizers skipped since the previous hit of the chain (high nibble) and diagonal shift + 8 (low nibble), 0xff = look the
- * hit up in the
- * (sorted) exception list; the consumer thread decodes straight into its Candidates_list (hao_unpack_hits); (b) copies into one of two pinned host
+ * hit up in the (sorted) exception list.  Bits, codes and exceptions are addressed by POSITION = index among the batch's sorted seed hits (a chain is
+ * a contiguous run of positions, its header says where it starts; the code at a chain's first position is not the chain's and is skipped; positions
+ * in no chain cost their bit); the consumer thread decodes straight into its Candidates_list (hao_unpack_hits); (b) copies into one of two pinned host
  * arenas on copy streams, under the next batch's kernels.  hao_overlap_batch_async returns when the batch's kernels are done and its copy is
  * queued; hao_deliver_wait blocks until the copy has landed and describes the arena.  A slot's arena (and the device buffers behind it) is reused by
  * the second-next async batch: at most two batches are in flight, and the caller must be done with batch i before it starts batch i + 2.  The views
@@ -173,22 +174,22 @@ int hao_attach(hao_ctx *owner, hao_ctx **view);
 #define HAO_DELIVER_OL 1u      /* ol->list + fake cigars */
 #define HAO_DELIVER_CL 2u      /* cl->list (wire format) */
 #define HAO_DELIVER_EXACT 4u   /* one byte per overlap: the exact-overlap check of the final round (hao_exact_check) */
-typedef struct { uint32_t n_hits, w0, q0, offset; } hao_chain_hdr_t;      /* one chain of cl->list: hit count, the readID word its hits share, first hit: minimizer index in the read, target offset */
+typedef struct { uint32_t n_hits, w0, q0, offset; uint64_t pos; } hao_chain_hdr_t;   /* one chain of cl->list: hit count, the readID word its hits share, first hit: minimizer index in the read, target offset, position; hit i of the chain has position pos + i */
 typedef struct { uint32_t self_offset, cnt; } hao_qmz_t;                  /* one query minimizer: k_mer_hit::self_offset and ::cnt of every hit it seeds */
-typedef struct { uint64_t index; uint32_t q, pad; hao_hit_t hit; } hao_exc_t;   /* verbatim hit: its index in the batch's cl->list concatenation, its minimizer index, the hit */
+typedef struct { uint64_t index; uint32_t q, pad; hao_hit_t hit; } hao_exc_t;   /* verbatim hit: its position, its minimizer index, the hit (its readID word is the seed stage's: the decoder writes the chain's) */
 typedef struct {
-	uint64_t rid_lo, n_reads, n_ol, n_fc, n_chains, n_cl, n_exc, n_codes, bytes;   /* bytes = what crossed PCIe for this batch */
+	uint64_t rid_lo, n_reads, n_ol, n_fc, n_chains, n_cl, n_exc, n_codes, n_pos, bytes;   /* n_pos = positions of the batch (its seed hits); bytes = what crossed PCIe for this batch */
 	const uint64_t *ol_off;          /* [n_reads + 1]: ol->list of read r = ol[ol_off[r] .. ol_off[r + 1]) */
 	const hao_ovlp_t *ol;
 	const uint64_t *fc_off;          /* [n_ol + 1]: fake cigar of overlap j = fc[fc_off[j] .. fc_off[j + 1]) */
 	const uint64_t *fc;
 	const uint64_t *ch_off, *cl_off, *qm_off; /* [n_reads + 1]: chains / hits / minimizers of read r = chains[ch_off[r] ..), hits cl_off[r] .. of the batch, qmz[qm_off[r] ..) */
 	const hao_chain_hdr_t *chains;
-	const uint64_t *cl_bits;         /* bit h (word h / 64, bit h % 64) = hit h of the batch (h = cl_off[r] + position in the read's cl->list) has a code byte */
-	const uint32_t *cl_rank;         /* [n_cl / 64 + 1]: code bytes before hit 64 w */
-	const uint8_t *cl_codes;         /* [n_codes] code bytes, in hit order */
+	const uint64_t *cl_bits;         /* bit p (word p / 64, bit p % 64) = position p has a code byte */
+	const uint32_t *cl_rank;         /* [n_pos / 64 + 1]: code bytes before position 64 w */
+	const uint8_t *cl_codes;         /* [n_codes] code bytes, in position order */
 	const hao_qmz_t *qmz;            /* minimizer tables of the batch's reads */
-	const hao_exc_t *cl_exc;         /* [n_exc] sorted by index */
+	const hao_exc_t *cl_exc;         /* [n_exc] sorted by position */
 	const uint8_t *exact;            /* [n_ol] with HAO_DELIVER_EXACT, else NULL */
 	double copy_ms;                  /* from "batch computed" to "copy landed" (includes waiting behind the previous batch's copy); filled by hao_deliver_wait */
 } hao_delivery_t;

@@ -1,5 +1,6 @@
 """The decoder of the delivery wire format (hao_unpack_hits, include/hao.h) is a pure host function of a delivered view: here the view is built by a
-Python encoder written from the format's description (one bit per hit, rank directory, code bytes, sorted exception list) and must decode back to
+Python encoder written from the format's description (one bit per position = seed hit, rank directory, code bytes, sorted exception list, chain headers
+with the position of their first hit) and must decode back to
 the k_mer_hits it was made from.  No GPU involved: the device-side encoder is checked against the oracle by tests/test_gpu_stream.py."""
 import ctypes as C
 
@@ -8,20 +9,36 @@ import numpy as np
 from hifiasm_amd import api
 
 
-def _encode(reads, rid_lo=7):
-    """reads: list of (qmz [(self_offset, cnt)], chains [(w0, [(q, offset), ...])]) -> (Delivery, keep-alive list, expected hits per read)"""
+def _encode(reads, rid_lo=7, seed=3):
+    """reads: list of (qmz [(self_offset, cnt)], chains [(w0, [(q, offset), ...])]) -> (Delivery, keep-alive list, expected hits per read).
+    Positions are indices among the batch's seed hits: every chain is a run of consecutive positions somewhere in the read's range, with positions that
+    belong to no chain (random code bytes, some of them flagged, one of them 0xff with a bogus list entry) between the chains; the byte at a chain's
+    first position is arbitrary as well."""
+    rng = np.random.default_rng(seed)
     ch_off, cl_off, qm_off = [0], [0], [0]
-    hdr, qmz, codes, exc, flags, want = [], [], [], [], [], []
+    hdr, qmz, exc, want = [], [], [], []
+    byte_at = []                                 # code byte of every position (0x08 = no code byte)
     h = 0
+
+    def filler(n):
+        for _ in range(n):
+            b = int(rng.choice([0x08, 0x08, 0x17, 0x2a, 0xff]))
+            if b == 0xff:
+                exc.append((len(byte_at), 9999, (1, 2, 3, 4)))      # an entry nobody may look up
+            byte_at.append(b)
+
     for qt, chains in reads:
         exp = []
+        filler(int(rng.integers(0, 70)))
         for w0, hits in chains:
             q0, o0 = hits[0]
-            hdr.append((len(hits), w0, q0, o0))
+            hdr.append((len(hits), w0, q0, o0, len(byte_at)))
             for i, (q, off) in enumerate(hits):
                 exp.append((w0, off, qt[q][0], qt[q][1]))
                 if i == 0:
-                    flags.append(0)
+                    byte_at.append(int(rng.choice([0x08, 0x31, 0xff])))      # not the chain's: skipped by the decoder
+                    if byte_at[-1] == 0xff:
+                        exc.append((len(byte_at) - 1, 7777, (5, 6, 7, 8)))
                 else:
                     pq, po = hits[i - 1]
                     dq, dd = q - pq, (off - po) - (qt[q][0] - qt[pq][0])
@@ -29,31 +46,35 @@ def _encode(reads, rid_lo=7):
                         code = (dq - 1) << 4 | (dd + 8)
                     else:
                         code = 0xff
-                        exc.append((h, q, (w0, off, qt[q][0], qt[q][1])))
-                    if code == 0x08:
-                        flags.append(0)
-                    else:
-                        flags.append(1); codes.append(code)
+                        exc.append((len(byte_at), q, (w0 ^ 0x5a5a, off, qt[q][0], qt[q][1])))      # the entry's readID word is the seed stage's, not the chain's
+                    byte_at.append(code)
                 h += 1
+            filler(int(rng.integers(0, 5)))
         want.append(np.array(exp, dtype=np.uint32).reshape(-1, 4))
         qmz.extend(qt)
         ch_off.append(len(hdr)); cl_off.append(h); qm_off.append(len(qmz))
-    nw = (h + 63) // 64
-    fl = np.zeros(nw * 64, dtype=np.uint8); fl[:h] = flags
+    n_pos = len(byte_at)
+    nw = (n_pos + 63) // 64
+    by = np.full(nw * 64, 0x08, dtype=np.uint8); by[:n_pos] = byte_at
+    fl = (by != 0x08).astype(np.uint8)
+    codes = by[fl == 1]
     bits = np.zeros(max(1, nw), dtype=np.uint64)
     for w in range(nw):
         bits[w] = sum(int(fl[64 * w + b]) << b for b in range(64))
     rank = np.zeros(nw + 1, dtype=np.uint32)
     rank[1:] = np.cumsum(fl.reshape(-1, 64).sum(axis=1)) if nw else 0
-    a_hdr = np.array(hdr, dtype=np.uint32).reshape(-1, 4)
+    a_hdr = np.zeros(max(1, len(hdr)), dtype=[("n_hits", "<u4"), ("w0", "<u4"), ("q0", "<u4"), ("offset", "<u4"), ("pos", "<u8")])
+    for i, t in enumerate(hdr):
+        a_hdr[i] = t
     a_qmz = np.array(qmz, dtype=np.uint32).reshape(-1, 2)
-    a_codes = np.array(codes + [0], dtype=np.uint8)
+    a_codes = np.concatenate([codes, np.zeros(1, dtype=np.uint8)])
+    exc.sort(key=lambda e: e[0])
     a_exc = np.zeros(max(1, len(exc)), dtype=[("index", "<u8"), ("q", "<u4"), ("pad", "<u4"), ("hit", "<u4", 4)])
     for i, (idx, q, hit) in enumerate(exc):
         a_exc[i] = (idx, q, 0, hit)
     arrs = [np.array(x, dtype=np.uint64) for x in (ch_off, cl_off, qm_off)] + [a_hdr, a_qmz, bits, rank, a_codes, a_exc]
     d = api.Delivery()
-    d.rid_lo, d.n_reads, d.n_chains, d.n_cl, d.n_exc, d.n_codes = rid_lo, len(reads), len(hdr), h, len(exc), len(codes)
+    d.rid_lo, d.n_reads, d.n_chains, d.n_cl, d.n_exc, d.n_codes, d.n_pos = rid_lo, len(reads), len(hdr), h, len(exc), int(codes.size), n_pos
     d.ch_off, d.cl_off, d.qm_off = (a.ctypes.data for a in arrs[:3])
     d.chains, d.qmz, d.cl_bits, d.cl_rank, d.cl_codes, d.cl_exc = (a.ctypes.data for a in arrs[3:])
     return d, arrs, want
