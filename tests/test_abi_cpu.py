@@ -54,3 +54,26 @@ def test_opt_defaults_match_reference():
     api.lib().hao_opt_default(C.byref(o))
     assert (o.k, o.w, o.hpc, o.sample_dist, o.rewin, o.min_hist_cnt, o.max_kmer_cnt, o.max_n_chain) == (51, 51, 1, 500, 1000, 5, 2000, 100)
     assert o.high_factor == 5.0 and o.is_ont == 0
+
+
+def test_replicated_index_headroom():
+    """The replicated position index holds < 2^32 minimizers (the index sort carries a 32-bit arrival index; hao_pt_gen returns HAO_EUNSUPP beyond).  What the
+    multi-GPU workloads of BASELINE.json need against that, from the minimizer densities the REFERENCE measured on the full-size fixtures (sum of count x
+    histogram of ha_pt_gen = minimizers of the pass): configs[3] (human 3 Gb, 40x HiFi) and configs[4] (human 3 Gb, 30x ONT) must stay below the limit - and the
+    margin is printed, because 80 % of a hard limit is a number a maintainer should see."""
+    import numpy as np
+    from hifiasm_amd.workloads import WORKLOADS
+    limit = 1 << 32
+    out = {}
+    for fixture, target in (("chr1_250M_hifi30x", "human3G_hifi40x"), ("ont50M_30x", "ont_human_30x")):
+        g = np.load(os.path.join(ROOT, "tests", "golden", fixture + ".npz"))
+        h = g["pt_hist"].astype(np.int64)
+        n_mz = int((h * np.arange(h.size)).sum())
+        gs, cov = WORKLOADS[fixture][0], WORKLOADS[fixture][1]
+        density = n_mz / float(gs * cov)                       # minimizers per sequenced base
+        tg, tcov = WORKLOADS[target][0], WORKLOADS[target][1]
+        need = density * tg * tcov
+        out[target] = (density, need, need / limit)
+        assert need < limit, (target, need)
+    print("[index headroom]", {k: (round(v[0], 5), f"{v[1] / 1e9:.2f} G minimizers", f"{100 * v[2]:.0f} % of 2^32") for k, v in out.items()})
+    assert 0.7 < out["human3G_hifi40x"][2] < 0.9               # DESIGN.md 8 quotes 80 %
