@@ -16,6 +16,61 @@ static void hao_release_all(hao_ctx *c)
 	c->d_ix_keys.release(); c->d_ix_start.release(); c->d_ix_cnt.release(); c->d_ix_bucket.release();
 }
 
+// ---- f3 (hao_align.cuh): host side of the window-alignment batches ----
+// tasks -> device, and their order by text window (hao_align.cuh: a wave takes 64 neighbours of that order, which mostly share one text)
+static int hao_al_upload_sorted(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n, DevBuf<hao_ed_task_t> &dt, DevBuf<uint32_t> &order)
+{
+	DevBuf<uint64_t> k1, k2; DevBuf<uint32_t> i1;
+	HIP_TRY(dt.reserve(n)); HIP_TRY(k1.reserve(n)); HIP_TRY(k2.reserve(n)); HIP_TRY(i1.reserve(n)); HIP_TRY(order.reserve(n));
+	HIP_TRY(hipMemcpyAsync(dt.p, tasks, n * sizeof(hao_ed_task_t), hipMemcpyHostToDevice, c->stream));
+	hipLaunchKernelGGL(hao_al_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dt.p, n, k1.p, i1.p); HAO_CHECK_LAUNCH();
+	size_t tb = 0;
+	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, k1.p, k2.p, i1.p, order.p, n, 0, 64, c->stream)); HIP_TRY(hao_tmp(c, tb));
+	HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, k1.p, k2.p, i1.p, order.p, n, 0, 64, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	k1.release(); k2.release(); i1.release();
+	return HAO_OK;
+}
+static hao_ed_reads hao_al_reads_of(hao_ctx *c)
+{
+	hao_ed_reads R; R.packed = c->d_packed.p; R.pk_off = c->d_pk_off.p; R.len = c->d_len.p; R.nsite_off = c->has_n ? c->d_nsite_off.p : nullptr; R.nsite = c->has_n ? c->d_nsite.p : nullptr;
+	return R;
+}
+
+template<int MODE> static int hao_al_trace_run(hao_ctx *c, const hao_ed_reads &R, const hao_ed_task_t *dt, const uint32_t *order, uint64_t n, bool wide, uint64_t tn_max,
+		hao_trace_result_t *dr, uint8_t *want, uint16_t *dc, uint32_t cap)
+{
+	// first sweep: no column storage, every task; decides which tasks end within their threshold (want[])
+	const dim3 g_((unsigned)((n + 255) / 256)), b_(256);
+	hipLaunchKernelGGL((hao_al_kernel<uint64_t, MODE, false>), g_, b_, 0, c->stream, R, dt, order, n, (uint64_t*)nullptr, (uint64_t)0, (hao_ed_result_t*)nullptr, dr, want, (uint16_t*)nullptr, 0u);
+	if (wide) { HAO_CHECK_LAUNCH(); hipLaunchKernelGGL((hao_al_kernel<hao_u128, MODE, false>), g_, b_, 0, c->stream, R, dt, order, n, (uint64_t*)nullptr, (uint64_t)0, (hao_ed_result_t*)nullptr, dr, want, (uint16_t*)nullptr, 0u); }
+	HAO_CHECK_LAUNCH();
+	// the tasks of the second sweep, still in text order
+	DevBuf<uint32_t> sel; DevBuf<uint64_t> path; uint64_t n_sel = 0;
+	HIP_TRY(sel.reserve(n + 1)); HIP_TRY(c->d_cursor.reserve(2));
+	size_t tb = 0;
+	HIP_TRY(rocprim::select(nullptr, tb, order, sel.p, (uint64_t*)c->d_cursor.p, n, hao_al_flagged{want}, c->stream)); HIP_TRY(hao_tmp(c, tb));
+	HIP_TRY(rocprim::select(c->d_tmp.p, tb, order, sel.p, (uint64_t*)c->d_cursor.p, n, hao_al_flagged{want}, c->stream));
+	HIP_TRY(hipMemcpyAsync(&n_sel, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (n_sel) {
+		// second sweep: 40 (two-word bands: 80) bytes per text column and selected pair, in slices whose columns fit ~4 GB; then the traceback
+		const uint64_t cw = wide ? 10 : 5;
+		const uint64_t slice = std::max<uint64_t>(256, std::min<uint64_t>((n_sel + 255) & ~255ULL, ((4ULL << 30) / (8 * cw * tn_max)) & ~255ULL));
+		HIP_TRY(path.reserve(cw * tn_max * slice + 1));
+		for (uint64_t lo = 0; lo < n_sel; lo += slice) {
+			const uint64_t m = std::min<uint64_t>(slice, n_sel - lo);
+			const dim3 g2((unsigned)((m + 255) / 256));
+			hipLaunchKernelGGL((hao_al_kernel<uint64_t, MODE, true>), g2, b_, 0, c->stream, R, dt, sel.p + lo, m, path.p, slice, (hao_ed_result_t*)nullptr, dr, (uint8_t*)nullptr, dc, cap);
+			if (wide) { HAO_CHECK_LAUNCH(); hipLaunchKernelGGL((hao_al_kernel<hao_u128, MODE, true>), g2, b_, 0, c->stream, R, dt, sel.p + lo, m, path.p, slice, (hao_ed_result_t*)nullptr, dr, (uint8_t*)nullptr, dc, cap); }
+			HAO_CHECK_LAUNCH();
+		}
+		HIP_TRY(hipStreamSynchronize(c->stream));
+	}
+	sel.release(); path.release();
+	return HAO_OK;
+}
+
 extern "C" {
 
 int hao_ft_gen(hao_ctx *c, int32_t *hom_cov)
@@ -206,25 +261,28 @@ int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks
 	if (int rc = hao_view_refresh(c)) return rc;
 	if (hao_is_sharded(c)) { hao_set_err(c, "hao_window_ed_batch needs the bases of both reads: single-device mode only"); return HAO_EUNSUPP; }
 	if (n_tasks == 0) return HAO_OK;
+	if (n_tasks >= (1ULL << 32)) { hao_set_err(c, "hao_window_ed_batch: more than 2^32 tasks in one call"); return HAO_EUNSUPP; }
+	bool wide = false;      // bands of 65 .. 127 diagonals: the two-word instantiation takes those tasks
 	for (uint64_t i = 0; i < n_tasks; ++i) {      // the reference indexes its strings unchecked; a device kernel must not
 		const hao_ed_task_t &t = tasks[i];
 		if (t.p_rid >= c->n_reads || t.t_rid >= c->n_reads || (uint64_t)t.p_pos + t.p_len > c->h_len[t.p_rid] || (uint64_t)t.t_pos + t.t_len > c->h_len[t.t_rid] ||
 			2 * (uint64_t)t.thre + 1 > 127 || t.abs_diag > 2 * t.thre) { hao_set_err(c, "hao_window_ed_batch: task " + std::to_string(i) + " out of range"); return HAO_EINVAL; }
 		if (2 * (uint64_t)t.thre + 1 > 64 && (int64_t)t.p_len - (int64_t)t.t_len + (int64_t)t.abs_diag > 128) {      // the final scan would read VP / VN bits beyond the two words (the reference then indexes the neighbouring vectors of its bit_extz_t)
 			hao_set_err(c, "hao_window_ed_batch: task " + std::to_string(i) + ": p_len - t_len + abs_diag > 128 with a two-word band"); return HAO_EINVAL; }
+		if (2 * (uint64_t)t.thre + 1 > 64) wide = true;
 	}
 	HIP_TRY(hipSetDevice(c->device));
-	DevBuf<hao_ed_task_t> dt; DevBuf<hao_ed_result_t> dr;
-	HIP_TRY(dt.reserve(n_tasks)); HIP_TRY(dr.reserve(n_tasks));
-	HIP_TRY(hipMemcpyAsync(dt.p, tasks, n_tasks * sizeof(hao_ed_task_t), hipMemcpyHostToDevice, c->stream));
-	hao_ed_reads R; R.packed = c->d_packed.p; R.pk_off = c->d_pk_off.p; R.len = c->d_len.p; R.nsite_off = c->has_n ? c->d_nsite_off.p : nullptr; R.nsite = c->has_n ? c->d_nsite.p : nullptr;
-	bool wide = false; for (uint64_t i = 0; i < n_tasks && !wide; ++i) wide = 2 * (uint64_t)tasks[i].thre + 1 > 64;      // bands of 65 .. 127 diagonals: the two-word instantiation takes those tasks
-	hipLaunchKernelGGL(hao_window_ed_kernel<uint64_t>, dim3((unsigned)((n_tasks + 255) / 256)), dim3(256), 0, c->stream, R, dt.p, n_tasks, dr.p);
-	if (wide) { HAO_CHECK_LAUNCH(); hipLaunchKernelGGL(hao_window_ed_kernel<hao_u128>, dim3((unsigned)((n_tasks + 255) / 256)), dim3(256), 0, c->stream, R, dt.p, n_tasks, dr.p); }
+	DevBuf<hao_ed_task_t> dt; DevBuf<uint32_t> order; DevBuf<hao_ed_result_t> dr;
+	if (int rc = hao_al_upload_sorted(c, tasks, n_tasks, dt, order)) return rc;
+	HIP_TRY(dr.reserve(n_tasks));
+	const hao_ed_reads R = hao_al_reads_of(c);
+	const dim3 g_((unsigned)((n_tasks + 255) / 256)), b_(256);
+	hipLaunchKernelGGL((hao_al_kernel<uint64_t, HAO_AL_ED, false>), g_, b_, 0, c->stream, R, dt.p, order.p, n_tasks, (uint64_t*)nullptr, (uint64_t)0, dr.p, (hao_trace_result_t*)nullptr, (uint8_t*)nullptr, (uint16_t*)nullptr, 0u);
+	if (wide) { HAO_CHECK_LAUNCH(); hipLaunchKernelGGL((hao_al_kernel<hao_u128, HAO_AL_ED, false>), g_, b_, 0, c->stream, R, dt.p, order.p, n_tasks, (uint64_t*)nullptr, (uint64_t)0, dr.p, (hao_trace_result_t*)nullptr, (uint8_t*)nullptr, (uint16_t*)nullptr, 0u); }
 	HAO_CHECK_LAUNCH();
 	HIP_TRY(hipMemcpyAsync(out, dr.p, n_tasks * sizeof(hao_ed_result_t), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
-	dt.release(); dr.release();
+	dt.release(); dr.release(); order.release();
 	return HAO_OK;
 }
 
@@ -234,6 +292,7 @@ int hao_window_trace_batch(hao_ctx *c, int mode, const hao_ed_task_t *tasks, uin
 	if (int rc = hao_view_refresh(c)) return rc;
 	if (hao_is_sharded(c)) { hao_set_err(c, "hao_window_trace_batch needs the bases of both reads: single-device mode only"); return HAO_EUNSUPP; }
 	if (n_tasks == 0) return HAO_OK;
+	if (n_tasks >= (1ULL << 32)) { hao_set_err(c, "hao_window_trace_batch: more than 2^32 tasks in one call"); return HAO_EUNSUPP; }
 	uint64_t tn_max = 1; bool wide = false;      // wide: some band needs two 64-bit words (thre 32 .. 63)
 	for (uint64_t i = 0; i < n_tasks; ++i) {      // the reference indexes its strings unchecked; a device kernel must not
 		const hao_ed_task_t &t = tasks[i];
@@ -247,29 +306,21 @@ int hao_window_trace_batch(hao_ctx *c, int mode, const hao_ed_task_t *tasks, uin
 		if (t.t_len > tn_max) tn_max = t.t_len;
 	}
 	HIP_TRY(hipSetDevice(c->device));
-	// the forward sweep keeps 40 bytes per text base and pair: the tasks go through in slices whose columns fit ~4 GB
-	const uint64_t cw = wide ? 10 : 5;      // 64-bit words kept per text column
-	const uint64_t slice = std::max<uint64_t>(256, std::min<uint64_t>(n_tasks, (4ULL << 30) / (8 * cw * tn_max)) & ~255ULL);
-	DevBuf<hao_ed_task_t> dt; DevBuf<hao_trace_result_t> dr; DevBuf<uint16_t> dc; DevBuf<uint64_t> path;
-	HIP_TRY(dt.reserve(slice)); HIP_TRY(dr.reserve(slice)); HIP_TRY(dc.reserve(slice * (uint64_t)cigar_cap + 1)); HIP_TRY(path.reserve(cw * tn_max * slice + 1));
-	hao_ed_reads R; R.packed = c->d_packed.p; R.pk_off = c->d_pk_off.p; R.len = c->d_len.p; R.nsite_off = c->has_n ? c->d_nsite_off.p : nullptr; R.nsite = c->has_n ? c->d_nsite.p : nullptr;
-	for (uint64_t lo = 0; lo < n_tasks; lo += slice) {
-		const uint64_t m = std::min<uint64_t>(slice, n_tasks - lo);
-		HIP_TRY(hipMemcpyAsync(dt.p, tasks + lo, m * sizeof(hao_ed_task_t), hipMemcpyHostToDevice, c->stream));
-		const dim3 g_((unsigned)((m + 255) / 256)), b_(256);
-#define HAO_TR_LAUNCH(K) do { hipLaunchKernelGGL((K<uint64_t>), g_, b_, 0, c->stream, R, dt.p, m, path.p, slice, dr.p, dc.p, cigar_cap); \
-		if (wide) { HAO_CHECK_LAUNCH(); hipLaunchKernelGGL((K<hao_u128>), g_, b_, 0, c->stream, R, dt.p, m, path.p, slice, dr.p, dc.p, cigar_cap); } } while (0)
-		if (mode == HAO_ALIGN_EXT_FWD) HAO_TR_LAUNCH(hao_tr_ext_fwd);
-		else if (mode == HAO_ALIGN_EXT_BWD) HAO_TR_LAUNCH(hao_tr_ext_bwd);
-		else if (mode == HAO_ALIGN_SEMI) HAO_TR_LAUNCH(hao_tr_semi);
-		else HAO_TR_LAUNCH(hao_tr_global);
-#undef HAO_TR_LAUNCH
-		HAO_CHECK_LAUNCH();
-		HIP_TRY(hipMemcpyAsync(out + lo, dr.p, m * sizeof(hao_trace_result_t), hipMemcpyDeviceToHost, c->stream));
-		if (cigar_cap) HIP_TRY(hipMemcpyAsync(cigars + lo * cigar_cap, dc.p, m * (uint64_t)cigar_cap * 2, hipMemcpyDeviceToHost, c->stream));
-		HIP_TRY(hipStreamSynchronize(c->stream));
-	}
-	dt.release(); dr.release(); dc.release(); path.release();
+	DevBuf<hao_ed_task_t> dt; DevBuf<uint32_t> order; DevBuf<hao_trace_result_t> dr; DevBuf<uint16_t> dc; DevBuf<uint8_t> want;
+	if (int rc = hao_al_upload_sorted(c, tasks, n_tasks, dt, order)) return rc;
+	HIP_TRY(dr.reserve(n_tasks)); HIP_TRY(want.reserve(n_tasks)); HIP_TRY(dc.reserve(n_tasks * (uint64_t)cigar_cap + 1));
+	HIP_TRY(hipMemsetAsync(want.p, 0, n_tasks, c->stream));
+	const hao_ed_reads R = hao_al_reads_of(c);
+	int rc;
+	if (mode == HAO_ALIGN_EXT_FWD) rc = hao_al_trace_run<HAO_AL_EXT_FWD>(c, R, dt.p, order.p, n_tasks, wide, tn_max, dr.p, want.p, dc.p, cigar_cap);
+	else if (mode == HAO_ALIGN_EXT_BWD) rc = hao_al_trace_run<HAO_AL_EXT_BWD>(c, R, dt.p, order.p, n_tasks, wide, tn_max, dr.p, want.p, dc.p, cigar_cap);
+	else if (mode == HAO_ALIGN_SEMI) rc = hao_al_trace_run<HAO_AL_SEMI>(c, R, dt.p, order.p, n_tasks, wide, tn_max, dr.p, want.p, dc.p, cigar_cap);
+	else rc = hao_al_trace_run<HAO_AL_GLOBAL>(c, R, dt.p, order.p, n_tasks, wide, tn_max, dr.p, want.p, dc.p, cigar_cap);
+	if (rc) return rc;
+	HIP_TRY(hipMemcpyAsync(out, dr.p, n_tasks * sizeof(hao_trace_result_t), hipMemcpyDeviceToHost, c->stream));
+	if (cigar_cap) HIP_TRY(hipMemcpyAsync(cigars, dc.p, n_tasks * (uint64_t)cigar_cap * 2, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	dt.release(); dr.release(); dc.release(); want.release(); order.release();
 	return HAO_OK;
 }
 

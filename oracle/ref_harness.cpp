@@ -34,6 +34,7 @@
 #include <stdint.h>
 #include <string>
 #include <vector>
+#include <thread>
 #include "CommandLines.h"
 #include "Process_Read.h"
 #include "Hash_Table.h"
@@ -230,6 +231,27 @@ int main(int argc, char *argv[])
 			res.push_back(ez.err); res.push_back(ez.pe);
 		}
 		wr(prefix, "ed.i32", res.data(), 4 * res.size());
+		if (do_time) {      // the same calls on n_thread threads (own strings and bit_extz_t each; a task = recover both strings + the function, as Correct.cpp:3897 does per candidate)
+			const size_t nt = tk.size() / 10; const int T = n_thread > 0 ? n_thread : 1;
+			const double t_ed0 = yak_realtime();
+			std::vector<std::thread> th; std::vector<int64_t> sink(T, 0);
+			for (int w_ = 0; w_ < T; ++w_) th.emplace_back([&, w_]() {
+				std::vector<char> ps_, ts_; bit_extz_t ez_; init_bit_extz_t(&ez_, 63); int64_t acc = 0;
+				for (size_t q = nt * w_ / T; q < nt * (w_ + 1) / T; ++q) {
+					const uint32_t *t = &tk[10 * q];
+					ps_.resize(t[2] + 8); ts_.resize(t[6] + 8);
+					recover_UC_Read_sub_region(ps_.data(), t[1], t[2], (uint8_t)t[3], &R_INF, t[0]);
+					recover_UC_Read_sub_region(ts_.data(), t[5], t[6], (uint8_t)t[7], &R_INF, t[4]);
+					if (2 * t[8] + 1 <= 64) ed_band_cal_semi_64_w_absent_diag(ps_.data(), (int32_t)t[2], ts_.data(), (int32_t)t[6], (int32_t)t[8], (int32_t)t[9], &ez_);
+					else ed_band_cal_semi_128_w_absent_diag(ps_.data(), (int32_t)t[2], ts_.data(), (int32_t)t[6], (int32_t)t[8], (int32_t)t[9], &ez_);
+					acc += ez_.err;
+				}
+				sink[w_] = acc;
+			});
+			for (auto &x : th) x.join();
+			const double dt_ed = yak_realtime() - t_ed0;
+			printf("{\"ed_pairs\": %zu, \"ed_threads\": %d, \"ed_seconds\": %.4f, \"ed_pairs_per_sec\": %.1f, \"ed_checksum\": %lld}\n", nt, T, dt_ed, nt / (dt_ed > 0 ? dt_ed : 1e-9), (long long)sink[0]);
+		}
 	}
 	for (int tm = 0; tm < 4; ++tm) {      // 0 global, 1 semi-global, 2 / 3 forward / backward extension
 		const char *tfn = tm == 0 ? edg_fn : tm == 1 ? eds_fn : tm == 2 ? ed1_fn : ed2_fn; if (!tfn) continue;
