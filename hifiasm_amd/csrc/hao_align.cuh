@@ -108,7 +108,7 @@ HAO_AL_FN uint32_t hao_al_pstream_next(hao_al_pstream &P)
 
 // ---- lane state ----
 template<typename WT> struct hao_al_state {
-	WT eq[5], VP, VN, HP, HN, D0;        // Myers' vectors over the band: match masks per character (eq[4] = N: never matches), vertical / horizontal deltas, diagonal zeros
+	WT eq[4], VP, VN, HP, HN, D0;        // Myers' vectors over the band: match masks per character (N matches nothing: no mask), vertical / horizontal deltas, diagonal zeros
 	WT top;                              // the band's highest diagonal: where the next pattern character enters
 	int32_t pn, tn, thre, adiag, cut;    // (clipped) lengths, threshold, missing leading diagonals, error bound of the sweep (3 thre)
 	int32_t err, i_bd;                   // running error on the band's lowest diagonal; pattern index of the character that entered last
@@ -116,6 +116,12 @@ template<typename WT> struct hao_al_state {
 	int32_t alive, dead;                 // alive: the task takes part in the sweep; dead: the sweep was abandoned (error bound passed)
 	hao_al_pstream ps;
 };
+
+// the match masks are only ever indexed by compile-time constants (a run-time index would push the whole lane state into scratch memory: measured 15 x slower)
+template<typename WT> HAO_AL_FN WT hao_al_eq_of(const hao_al_state<WT> &S, uint32_t c)
+{ return c == 0 ? S.eq[0] : c == 1 ? S.eq[1] : c == 2 ? S.eq[2] : c == 3 ? S.eq[3] : (WT)0; }
+template<typename WT> HAO_AL_FN void hao_al_eq_or(hao_al_state<WT> &S, uint32_t c, WT m)
+{ S.eq[0] |= c == 0 ? m : (WT)0; S.eq[1] |= c == 1 ? m : (WT)0; S.eq[2] |= c == 2 ? m : (WT)0; S.eq[3] |= c == 3 ? m : (WT)0; }
 
 // set-up of a task (the checks and initial vectors of the reference's functions): false = the answer is already known (no alignment)
 template<typename WT, int MODE> HAO_AL_FN bool hao_al_init(hao_al_state<WT> &S, const hao_ed_reads &R, const hao_ed_task_t &T)
@@ -129,7 +135,7 @@ template<typename WT, int MODE> HAO_AL_FN bool hao_al_init(hao_al_state<WT> &S, 
 	else if (MODE == HAO_AL_GLOBAL) { if (S.pn <= 0 || S.tn <= 0 || S.pn > S.tn + thre || S.tn > S.pn + thre) return false; }
 	else { if (S.pn <= 0 || S.tn <= 0) return false; if (S.pn > S.tn + thre) S.pn = S.tn + thre; else if (S.tn > S.pn + thre) S.tn = S.pn + thre; }
 	hao_al_pstream_init(S.ps, hao_al_walk_of(R, T.p_rid, T.p_pos, T.p_len, T.p_rev, back));
-	for (int c = 0; c < 5; ++c) S.eq[c] = 0;
+	S.eq[0] = 0; S.eq[1] = 0; S.eq[2] = 0; S.eq[3] = 0;
 	int32_t first, bd;
 	if (MODE == HAO_AL_SEMI || MODE == HAO_AL_ED) {      // the band starts abs_diag diagonals in: the pattern was clipped at the start of its read
 		first = S.adiag; bd = ((thre << 1) + 1) - S.adiag; S.i_bd = (thre << 1) - S.adiag; S.err = S.adiag;
@@ -140,8 +146,8 @@ template<typename WT, int MODE> HAO_AL_FN bool hao_al_init(hao_al_state<WT> &S, 
 	}
 	if (bd > S.pn) bd = S.pn;
 	WT mm = ((WT)1) << first;
-	for (int32_t i = 0; i < bd; ++i) { S.eq[hao_al_pstream_next(S.ps)] |= mm; mm <<= 1; }
-	S.eq[4] = 0; S.top = ((WT)1) << (thre << 1);
+	for (int32_t i = 0; i < bd; ++i) { hao_al_eq_or(S, hao_al_pstream_next(S.ps), mm); mm <<= 1; }      // (an N in the pattern sets no mask: the reference's Peq[4] is cleared after its loop)
+	S.top = ((WT)1) << (thre << 1);
 	S.HP = 0; S.HN = 0; S.D0 = 0;
 	S.alive = 1;
 	return true;
@@ -152,14 +158,15 @@ template<typename WT> HAO_AL_FN void hao_al_keep(const hao_al_state<WT> &S, uint
 {
 	constexpr int NW = sizeof(WT) / 8;
 	uint64_t *w_ = col + 5 * NW * (uint64_t)i * stride;
-	const WT v[5] = { S.D0, S.VP, S.VN, S.HP, S.HN };
-	for (int k = 0; k < 5; ++k) { w_[(uint64_t)k * NW * stride] = (uint64_t)v[k]; if (NW == 2) w_[((uint64_t)k * NW + 1) * stride] = (uint64_t)((hao_u128)v[k] >> 64); }
+#define HAO_AL_PUT(k_, v_) { w_[(uint64_t)(k_) * NW * stride] = (uint64_t)(v_); if (NW == 2) w_[((uint64_t)(k_) * NW + 1) * stride] = (uint64_t)((hao_u128)(v_) >> 64); }
+	HAO_AL_PUT(0, S.D0) HAO_AL_PUT(1, S.VP) HAO_AL_PUT(2, S.VN) HAO_AL_PUT(3, S.HP) HAO_AL_PUT(4, S.HN)
+#undef HAO_AL_PUT
 }
 
 // text column i (character tc) of the sweep.  KEEP: the column's vectors go to the scratch array.
 template<typename WT, int MODE, bool KEEP> HAO_AL_FN void hao_al_column(hao_al_state<WT> &S, uint32_t tc, int32_t i, uint64_t *col, uint64_t stride)
 {
-	WT X = S.eq[tc] | S.VN;
+	WT X = hao_al_eq_of(S, tc) | S.VN;
 	S.D0 = ((S.VP + (X & S.VP)) ^ S.VP) | X; S.HN = S.VP & S.D0; S.HP = S.VN | ~(S.VP | S.D0);
 	X = S.D0 >> 1; S.VN = X & S.HP; S.VP = S.HN | ~(X | S.HP);
 	if (!(S.D0 & (WT)1)) { ++S.err; if (S.err > S.cut) { S.dead = 1; return; } }
@@ -176,7 +183,7 @@ template<typename WT, int MODE, bool KEEP> HAO_AL_FN void hao_al_column(hao_al_s
 	if (KEEP) hao_al_keep(S, col, stride, i);
 	if (!last) {
 		++S.i_bd;
-		if (S.i_bd < S.pn) { const uint32_t pc = hao_al_pstream_next(S.ps); if (pc < 4) S.eq[pc] |= S.top; }
+		if (S.i_bd < S.pn) hao_al_eq_or(S, hao_al_pstream_next(S.ps), S.top);
 	}
 }
 

@@ -14,21 +14,19 @@ static void hao_release_all(hao_ctx *c)
 	c->w_ukeys.release(); c->w_flag.release(); c->w_kpos.release(); c->w_ustart.release(); c->w_ucnt.release(); c->w_hist.release(); c->w_ok.release(); c->w_ok2.release(); c->w_oi.release(); c->w_oi2.release();
 	c->d_ix_lk.release(); c->w_runid.release(); c->d_ix_mz_x.release(); c->d_ix_mz_info.release(); c->d_ix_mz_off.release(); c->d_ix_sx.release(); c->d_ix_sinfo.release();
 	c->d_ix_keys.release(); c->d_ix_start.release(); c->d_ix_cnt.release(); c->d_ix_bucket.release();
+	c->al_task.release(); c->al_k1.release(); c->al_k2.release(); c->al_path.release(); c->al_i1.release(); c->al_order.release(); c->al_sel.release(); c->al_res.release(); c->al_tres.release(); c->al_want.release(); c->al_cig.release();
 }
 
 // ---- f3 (hao_align.cuh): host side of the window-alignment batches ----
 // tasks -> device, and their order by text window (hao_align.cuh: a wave takes 64 neighbours of that order, which mostly share one text)
-static int hao_al_upload_sorted(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n, DevBuf<hao_ed_task_t> &dt, DevBuf<uint32_t> &order)
+static int hao_al_upload_sorted(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n)
 {
-	DevBuf<uint64_t> k1, k2; DevBuf<uint32_t> i1;
-	HIP_TRY(dt.reserve(n)); HIP_TRY(k1.reserve(n)); HIP_TRY(k2.reserve(n)); HIP_TRY(i1.reserve(n)); HIP_TRY(order.reserve(n));
-	HIP_TRY(hipMemcpyAsync(dt.p, tasks, n * sizeof(hao_ed_task_t), hipMemcpyHostToDevice, c->stream));
-	hipLaunchKernelGGL(hao_al_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dt.p, n, k1.p, i1.p); HAO_CHECK_LAUNCH();
+	HIP_TRY(c->al_task.reserve(n)); HIP_TRY(c->al_k1.reserve(n)); HIP_TRY(c->al_k2.reserve(n)); HIP_TRY(c->al_i1.reserve(n)); HIP_TRY(c->al_order.reserve(n));
+	HIP_TRY(hipMemcpyAsync(c->al_task.p, tasks, n * sizeof(hao_ed_task_t), hipMemcpyHostToDevice, c->stream));
+	hipLaunchKernelGGL(hao_al_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->al_task.p, n, c->al_k1.p, c->al_i1.p); HAO_CHECK_LAUNCH();
 	size_t tb = 0;
-	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, k1.p, k2.p, i1.p, order.p, n, 0, 64, c->stream)); HIP_TRY(hao_tmp(c, tb));
-	HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, k1.p, k2.p, i1.p, order.p, n, 0, 64, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));
-	k1.release(); k2.release(); i1.release();
+	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, c->al_k1.p, c->al_k2.p, c->al_i1.p, c->al_order.p, n, 0, 64, c->stream)); HIP_TRY(hao_tmp(c, tb));
+	HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, c->al_k1.p, c->al_k2.p, c->al_i1.p, c->al_order.p, n, 0, 64, c->stream));
 	return HAO_OK;
 }
 static hao_ed_reads hao_al_reads_of(hao_ctx *c)
@@ -46,7 +44,7 @@ template<int MODE> static int hao_al_trace_run(hao_ctx *c, const hao_ed_reads &R
 	if (wide) { HAO_CHECK_LAUNCH(); hipLaunchKernelGGL((hao_al_kernel<hao_u128, MODE, false>), g_, b_, 0, c->stream, R, dt, order, n, (uint64_t*)nullptr, (uint64_t)0, (hao_ed_result_t*)nullptr, dr, want, (uint16_t*)nullptr, 0u); }
 	HAO_CHECK_LAUNCH();
 	// the tasks of the second sweep, still in text order
-	DevBuf<uint32_t> sel; DevBuf<uint64_t> path; uint64_t n_sel = 0;
+	DevBuf<uint32_t> &sel = c->al_sel; DevBuf<uint64_t> &path = c->al_path; uint64_t n_sel = 0;
 	HIP_TRY(sel.reserve(n + 1)); HIP_TRY(c->d_cursor.reserve(2));
 	size_t tb = 0;
 	HIP_TRY(rocprim::select(nullptr, tb, order, sel.p, (uint64_t*)c->d_cursor.p, n, hao_al_flagged{want}, c->stream)); HIP_TRY(hao_tmp(c, tb));
@@ -65,9 +63,7 @@ template<int MODE> static int hao_al_trace_run(hao_ctx *c, const hao_ed_reads &R
 			if (wide) { HAO_CHECK_LAUNCH(); hipLaunchKernelGGL((hao_al_kernel<hao_u128, MODE, true>), g2, b_, 0, c->stream, R, dt, sel.p + lo, m, path.p, slice, (hao_ed_result_t*)nullptr, dr, (uint8_t*)nullptr, dc, cap); }
 			HAO_CHECK_LAUNCH();
 		}
-		HIP_TRY(hipStreamSynchronize(c->stream));
 	}
-	sel.release(); path.release();
 	return HAO_OK;
 }
 
@@ -272,9 +268,9 @@ int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks
 		if (2 * (uint64_t)t.thre + 1 > 64) wide = true;
 	}
 	HIP_TRY(hipSetDevice(c->device));
-	DevBuf<hao_ed_task_t> dt; DevBuf<uint32_t> order; DevBuf<hao_ed_result_t> dr;
-	if (int rc = hao_al_upload_sorted(c, tasks, n_tasks, dt, order)) return rc;
-	HIP_TRY(dr.reserve(n_tasks));
+	if (int rc = hao_al_upload_sorted(c, tasks, n_tasks)) return rc;
+	HIP_TRY(c->al_res.reserve(n_tasks));
+	DevBuf<hao_ed_task_t> &dt = c->al_task; DevBuf<uint32_t> &order = c->al_order; DevBuf<hao_ed_result_t> &dr = c->al_res;
 	const hao_ed_reads R = hao_al_reads_of(c);
 	const dim3 g_((unsigned)((n_tasks + 255) / 256)), b_(256);
 	hipLaunchKernelGGL((hao_al_kernel<uint64_t, HAO_AL_ED, false>), g_, b_, 0, c->stream, R, dt.p, order.p, n_tasks, (uint64_t*)nullptr, (uint64_t)0, dr.p, (hao_trace_result_t*)nullptr, (uint8_t*)nullptr, (uint16_t*)nullptr, 0u);
@@ -282,7 +278,6 @@ int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks
 	HAO_CHECK_LAUNCH();
 	HIP_TRY(hipMemcpyAsync(out, dr.p, n_tasks * sizeof(hao_ed_result_t), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
-	dt.release(); dr.release(); order.release();
 	return HAO_OK;
 }
 
@@ -306,8 +301,8 @@ int hao_window_trace_batch(hao_ctx *c, int mode, const hao_ed_task_t *tasks, uin
 		if (t.t_len > tn_max) tn_max = t.t_len;
 	}
 	HIP_TRY(hipSetDevice(c->device));
-	DevBuf<hao_ed_task_t> dt; DevBuf<uint32_t> order; DevBuf<hao_trace_result_t> dr; DevBuf<uint16_t> dc; DevBuf<uint8_t> want;
-	if (int rc = hao_al_upload_sorted(c, tasks, n_tasks, dt, order)) return rc;
+	if (int rc = hao_al_upload_sorted(c, tasks, n_tasks)) return rc;
+	DevBuf<hao_ed_task_t> &dt = c->al_task; DevBuf<uint32_t> &order = c->al_order; DevBuf<hao_trace_result_t> &dr = c->al_tres; DevBuf<uint16_t> &dc = c->al_cig; DevBuf<uint8_t> &want = c->al_want;
 	HIP_TRY(dr.reserve(n_tasks)); HIP_TRY(want.reserve(n_tasks)); HIP_TRY(dc.reserve(n_tasks * (uint64_t)cigar_cap + 1));
 	HIP_TRY(hipMemsetAsync(want.p, 0, n_tasks, c->stream));
 	const hao_ed_reads R = hao_al_reads_of(c);
@@ -320,7 +315,7 @@ int hao_window_trace_batch(hao_ctx *c, int mode, const hao_ed_task_t *tasks, uin
 	HIP_TRY(hipMemcpyAsync(out, dr.p, n_tasks * sizeof(hao_trace_result_t), hipMemcpyDeviceToHost, c->stream));
 	if (cigar_cap) HIP_TRY(hipMemcpyAsync(cigars, dc.p, n_tasks * (uint64_t)cigar_cap * 2, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
-	dt.release(); dr.release(); dc.release(); want.release(); order.release();
+	if (c->al_path.cap > (1ULL << 27)) c->al_path.release();      // (more than 1 GB of column scratch is not kept between calls)
 	return HAO_OK;
 }
 

@@ -121,6 +121,9 @@ struct hao_ctx {
 	DevBuf<uint64_t> w_ukeys, w_flag, w_kpos, w_ustart; DevBuf<uint32_t> w_ucnt; DevBuf<unsigned long long> w_hist; DevBuf<uint32_t> w_ok, w_ok2, w_oi, w_oi2;   // persistent scratch of the index build
 	std::vector<uint64_t> h_ix_keys, h_ix_off, h_ix_pos, h_ix_mz_off; bool h_ix_valid = false;
 	// ---- query batch ----
+	// f3 (hao_align.cuh): scratch of the window-alignment batches, kept between calls (a hipMalloc / hipFree pair per buffer and call cost more than the kernels)
+	DevBuf<hao_ed_task_t> al_task; DevBuf<uint64_t> al_k1, al_k2, al_path; DevBuf<uint32_t> al_i1, al_order, al_sel; DevBuf<hao_ed_result_t> al_res; DevBuf<hao_trace_result_t> al_tres;
+	DevBuf<uint8_t> al_want; DevBuf<uint16_t> al_cig;
 	struct Batch;
 	Batch *batch = nullptr;
 	StageTimer timer; std::vector<std::pair<std::string, float> > stage_ms;
