@@ -77,3 +77,38 @@ def test_replicated_index_headroom():
         assert need < limit, (target, need)
     print("[index headroom]", {k: (round(v[0], 5), f"{v[1] / 1e9:.2f} G minimizers", f"{100 * v[2]:.0f} % of 2^32") for k, v in out.items()})
     assert 0.7 < out["human3G_hifi40x"][2] < 0.9               # DESIGN.md 8 quotes 80 %
+
+
+def test_ctypes_mirrors_match_the_header(tmp_path):
+    """hifiasm_amd/api.py mirrors four structs of include/hao.h by hand: a C program prints the header's sizes and field offsets, ctypes must agree
+    (the delivery view and the chain header changed shape in round 3)."""
+    import subprocess
+    from hifiasm_amd import api
+    src = tmp_path / "sz.c"
+    src.write_text('''#include <stdio.h>
+#include <stddef.h>
+#include "hao.h"
+#define S(t) printf(#t " %zu\\n", sizeof(t))
+#define O(t, f) printf(#t "." #f " %zu\\n", offsetof(t, f))
+int main(void) {
+    S(hao_opt_t); O(hao_opt_t, high_factor); O(hao_opt_t, hg_size);
+    S(hao_pass_t); O(hao_pass_t, mcopy_rate); O(hao_pass_t, ocv_w);
+    S(hao_chain_hdr_t); O(hao_chain_hdr_t, pos);
+    S(hao_delivery_t); O(hao_delivery_t, n_pos); O(hao_delivery_t, bytes); O(hao_delivery_t, ol_off); O(hao_delivery_t, chains); O(hao_delivery_t, cl_exc); O(hao_delivery_t, copy_ms);
+    S(hao_hit_t); S(hao_ovlp_t); S(hao_exc_t); S(hao_qmz_t); S(hao_ed_task_t); S(hao_ed_result_t); S(hao_trace_result_t);
+    return 0;
+}
+''')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    got = {k: int(v) for k, v in got.items()}
+    for name, cls in (("hao_opt_t", api.Opt), ("hao_pass_t", api.Pass), ("hao_chain_hdr_t", api.ChainHdr), ("hao_delivery_t", api.Delivery)):
+        assert C.sizeof(cls) == got[name], name
+    for key, v in got.items():
+        if "." in key:
+            t, f = key.split(".")
+            cls = {"hao_opt_t": api.Opt, "hao_pass_t": api.Pass, "hao_chain_hdr_t": api.ChainHdr, "hao_delivery_t": api.Delivery}[t]
+            assert getattr(cls, f).offset == v, key
+    # record sizes the tests and the decoder assume (numpy views of the delivered arrays)
+    assert (got["hao_hit_t"], got["hao_ovlp_t"], got["hao_exc_t"], got["hao_qmz_t"], got["hao_ed_task_t"], got["hao_ed_result_t"], got["hao_trace_result_t"]) == (16, 48, 32, 8, 40, 8, 24)
