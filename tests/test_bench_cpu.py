@@ -1,0 +1,33 @@
+"""bench.py's host-side pieces that run without a GPU: the reference CPU baseline leg (oracle/_ref/ref_harness on the workload's own read generator) and
+the profile lookup.  The JSON contract itself needs a device (tests/test_gpu_rccl.py, the driver's run)."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m
+
+
+def test_cpu_baseline_leg():
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_harness")):
+        pytest.skip("the reference binary is built only where /root/reference exists")
+    b = _bench()
+    r = b.cpu_baseline("chr2M_hifi30x", "full", threads=4)
+    assert r["kind"] == "reference" and r["unit"] == "overlaps/s" and r["cores"] == 4 and r["value"] > 0 and r["overlaps"] > 10_000
+    assert r["sampled"] is False and "chr2M_hifi30x" in r["sample"]
+    r2 = b.cpu_baseline("chr1_250M_hifi30x", "sample", threads=1) if os.environ.get("HAO_TEST_SLOW") else None      # (20 s of reference time: opt-in)
+    assert r2 is None or r2["sampled"] is True
+
+
+def test_profile_lookup_prefers_the_newest_round():
+    b = _bench()
+    p, rel = b.profile_file("pmc_traffic.json")
+    assert rel == "profiles/r03/pmc_traffic.json" and os.path.exists(p)
+    assert b.profile_file("no_such_file.json") == (None, None)
+    assert set(b.KERN_STAGE) == set(b.ALG)
