@@ -23,10 +23,12 @@
 #ifdef HAO_ALIGN_HOST_MODEL
 #include <string.h>
 #define HAO_AL_FN static inline
+#define HAO_AL_MFN inline
 #define HAO_AL_MEMCPY memcpy
 #else
 #include "hao_common.cuh"
 #define HAO_AL_FN __host__ __device__ __forceinline__
+#define HAO_AL_MFN __host__ __device__ __forceinline__
 #define HAO_AL_MEMCPY __builtin_memcpy
 #endif
 
@@ -35,8 +37,47 @@ typedef unsigned __int128 hao_u128;
 #define HAO_AL_CH 1024                   // text columns staged per refill
 enum { HAO_AL_GLOBAL = 0, HAO_AL_EXT_FWD = 1, HAO_AL_EXT_BWD = 2, HAO_AL_SEMI = 3, HAO_AL_ED = 4 };      // 0 .. 3: the numbering of Correct.cpp:14536-14545; 4: semi-global without traceback
 
-// one launch serves one band word type and skips the tasks of the other (cal_exz_global picks by band width, Correct.cpp:15482-15494)
-template<typename WT> HAO_AL_FN bool hao_al_mine(uint32_t thre) { return (2 * thre + 1 <= 64) == (sizeof(WT) == 8); }
+// Bands of more than two words (thre 64 .. 127: the reference's *_infi_* functions, Levenshtein_distance.h:2134-3100, picked by cal_exz_infi, Correct.cpp:14508-14564, with
+// nword = ceil((2 thre + 1) / 64)): the same lane functions over an N-word integer.  The word count is part of the semantics - what shifts in at the top of the last word
+// reaches the band after enough columns - so N is exactly the reference's nword (3 or 4), not "wide enough".  tests/ed_model.cpp instantiates these on the CPU and
+// tests/test_ed_model_cpu.py compares them with the reference's own functions (tests/golden/ed_wide.npz); the device library does not instantiate them yet
+// (hao_window_*_batch still refuse thre > 63): they have not run on a GPU.
+template<int N> struct hao_wide {
+	uint64_t a[N];
+	HAO_AL_MFN hao_wide() {}
+	HAO_AL_MFN hao_wide(int v) { a[0] = (uint64_t)(int64_t)v; for (int k = 1; k < N; ++k) a[k] = v < 0 ? ~0ULL : 0ULL; }
+	HAO_AL_MFN explicit operator int32_t() const { return (int32_t)a[0]; }
+	HAO_AL_MFN explicit operator uint64_t() const { return a[0]; }
+	HAO_AL_MFN bool operator!() const { uint64_t o = 0; for (int k = 0; k < N; ++k) o |= a[k]; return o == 0; }
+	HAO_AL_MFN hao_wide operator~() const { hao_wide r; for (int k = 0; k < N; ++k) r.a[k] = ~a[k]; return r; }
+	HAO_AL_MFN hao_wide operator|(const hao_wide &o) const { hao_wide r; for (int k = 0; k < N; ++k) r.a[k] = a[k] | o.a[k]; return r; }
+	HAO_AL_MFN hao_wide operator&(const hao_wide &o) const { hao_wide r; for (int k = 0; k < N; ++k) r.a[k] = a[k] & o.a[k]; return r; }
+	HAO_AL_MFN hao_wide operator^(const hao_wide &o) const { hao_wide r; for (int k = 0; k < N; ++k) r.a[k] = a[k] ^ o.a[k]; return r; }
+	HAO_AL_MFN hao_wide operator+(const hao_wide &o) const { hao_wide r; uint64_t c = 0; for (int k = 0; k < N; ++k) { const uint64_t x = a[k] + c; c = x < c; r.a[k] = x + o.a[k]; c |= r.a[k] < o.a[k]; } return r; }
+	HAO_AL_MFN hao_wide operator-(int v) const { hao_wide r; uint64_t b = (uint64_t)v; for (int k = 0; k < N; ++k) { r.a[k] = a[k] - b; b = a[k] < b; } return r; }      // (v >= 0)
+	HAO_AL_MFN hao_wide operator<<(int s) const {
+		hao_wide r; const int ws = s >> 6, bs = s & 63;
+		for (int k = N - 1; k >= 0; --k) { const int j = k - ws; uint64_t v = j >= 0 ? a[j] << bs : 0; if (bs && j - 1 >= 0) v |= a[j - 1] >> (64 - bs); r.a[k] = v; }
+		return r;
+	}
+	HAO_AL_MFN hao_wide operator>>(int s) const {
+		hao_wide r; const int ws = s >> 6, bs = s & 63;
+		for (int k = 0; k < N; ++k) { const int j = k + ws; uint64_t v = j < N ? a[j] >> bs : 0; if (bs && j + 1 < N) v |= a[j + 1] << (64 - bs); r.a[k] = v; }
+		return r;
+	}
+	HAO_AL_MFN hao_wide &operator|=(const hao_wide &o) { for (int k = 0; k < N; ++k) a[k] |= o.a[k]; return *this; }
+	HAO_AL_MFN hao_wide &operator<<=(int s) { *this = *this << s; return *this; }
+	HAO_AL_MFN hao_wide &operator>>=(int s) { *this = *this >> s; return *this; }
+};
+// 64-bit word h of a band vector
+HAO_AL_FN uint64_t hao_al_word64(uint64_t v, int h) { (void)h; return v; }
+HAO_AL_FN uint64_t hao_al_word64(hao_u128 v, int h) { return (uint64_t)(v >> (64 * h)); }
+template<int N> HAO_AL_FN uint64_t hao_al_word64(const hao_wide<N> &v, int h) { return v.a[h]; }
+
+// words a band of 2 thre + 1 diagonals needs (the reference's nword); one launch serves one band word type and skips the tasks of the others
+// (cal_exz_global / cal_exz_infi pick by band width, Correct.cpp:15482-15494, 14508-14564)
+HAO_AL_FN uint32_t hao_al_nword(uint32_t thre) { return (2 * thre + 1 + 63) >> 6; }
+template<typename WT> HAO_AL_FN bool hao_al_mine(uint32_t thre) { return hao_al_nword(thre) == (uint32_t)(sizeof(WT) / 8); }
 // w_<sf>_set_bit_lsub (:1029-1033): the low l bits set.  The 128-bit macro shifts a 64-bit word by 64 when l == 64: undefined in C, 0 on x86-64 (shift count
 // modulo 64) - the reference as built starts abs_diag = 64 from VN = 0, and so does this.
 template<typename WT> HAO_AL_FN WT hao_al_lsub(int32_t l) { return (sizeof(WT) == 16 && l == 64) ? (WT)0 : (WT)((((WT)1) << l) - 1); }
@@ -158,7 +199,7 @@ template<typename WT> HAO_AL_FN void hao_al_keep(const hao_al_state<WT> &S, uint
 {
 	constexpr int NW = sizeof(WT) / 8;
 	uint64_t *w_ = col + 5 * NW * (uint64_t)i * stride;
-#define HAO_AL_PUT(k_, v_) { w_[(uint64_t)(k_) * NW * stride] = (uint64_t)(v_); if (NW == 2) w_[((uint64_t)(k_) * NW + 1) * stride] = (uint64_t)((hao_u128)(v_) >> 64); }
+#define HAO_AL_PUT(k_, v_) { for (int h_ = 0; h_ < NW; ++h_) w_[((uint64_t)(k_) * NW + h_) * stride] = hao_al_word64(v_, h_); }
 	HAO_AL_PUT(0, S.D0) HAO_AL_PUT(1, S.VP) HAO_AL_PUT(2, S.VN) HAO_AL_PUT(3, S.HP) HAO_AL_PUT(4, S.HN)
 #undef HAO_AL_PUT
 }
@@ -290,10 +331,10 @@ template<typename WT, int MODE, bool TRACE> HAO_AL_FN bool hao_al_finish(hao_al_
 
 // do two tasks align against the same text (same stretch, same strand, same band word)?
 HAO_AL_FN bool hao_al_same_text(const hao_ed_task_t &a, const hao_ed_task_t &b)
-{ return a.t_rid == b.t_rid && a.t_pos == b.t_pos && a.t_len == b.t_len && a.t_rev == b.t_rev && ((2 * a.thre + 1 <= 64) == (2 * b.thre + 1 <= 64)); }
+{ return a.t_rid == b.t_rid && a.t_pos == b.t_pos && a.t_len == b.t_len && a.t_rev == b.t_rev && hao_al_nword(a.thre) == hao_al_nword(b.thre); }
 // sort key of a task: band word, text read, text position, text strand (tasks of one text window become neighbours; the text length is compared on the spot)
 HAO_AL_FN uint64_t hao_al_sort_key(const hao_ed_task_t &t)
-{ return (uint64_t)(2 * t.thre + 1 > 64) << 63 | (uint64_t)(t.t_rid & 0xfffffffu) << 35 | (uint64_t)(t.t_pos & 0x7ffffffu) << 8 | (uint64_t)(t.t_rev & 1u) << 7; }
+{ return (uint64_t)((hao_al_nword(t.thre) - 1) & 3u) << 62 | (uint64_t)(t.t_rid & 0xfffffffu) << 34 | (uint64_t)(t.t_pos & 0x7ffffffu) << 7 | (uint64_t)(t.t_rev & 1u) << 6; }
 
 #ifndef HAO_ALIGN_HOST_MODEL
 // ---------------------------------------------------------------------------------------

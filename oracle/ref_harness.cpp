@@ -227,7 +227,8 @@ int main(int argc, char *argv[])
 			recover_UC_Read_sub_region(ps.data(), t[1], t[2], (uint8_t)t[3], &R_INF, t[0]);
 			recover_UC_Read_sub_region(ts.data(), t[5], t[6], (uint8_t)t[7], &R_INF, t[4]);
 			if (2 * t[8] + 1 <= 64) ed_band_cal_semi_64_w_absent_diag(ps.data(), (int32_t)t[2], ts.data(), (int32_t)t[6], (int32_t)t[8], (int32_t)t[9], &ez);
-			else ed_band_cal_semi_128_w_absent_diag(ps.data(), (int32_t)t[2], ts.data(), (int32_t)t[6], (int32_t)t[8], (int32_t)t[9], &ez);      // (bands of 65 .. 127 diagonals: HA_ED_INIT(128))
+			else if (2 * t[8] + 1 <= 128) ed_band_cal_semi_128_w_absent_diag(ps.data(), (int32_t)t[2], ts.data(), (int32_t)t[6], (int32_t)t[8], (int32_t)t[9], &ez);      // (bands of 65 .. 127 diagonals: HA_ED_INIT(128))
+			else { int32_t nw_ = (int32_t)((2 * t[8] + 1 + 63) >> 6); ed_band_cal_semi_infi_w_absent_diag(ps.data(), (int32_t)t[2], ts.data(), (int32_t)t[6], (int32_t)t[8], (int32_t)t[9], &nw_, &ez); }      // (wider bands: nword as cal_exz_infi computes it, Correct.cpp:14511)
 			res.push_back(ez.err); res.push_back(ez.pe);
 		}
 		wr(prefix, "ed.i32", res.data(), 4 * res.size());
@@ -273,6 +274,12 @@ int main(int argc, char *argv[])
 				else if (tm == 2) ed_band_cal_extension_64_0_w_trace(ps.data(), pn_, ts.data(), tn_, th_, &ez);
 				else if (tm == 3) ed_band_cal_extension_64_1_w_trace(ps.data(), pn_, ts.data(), tn_, th_, &ez);
 				else ed_band_cal_global_64_w_trace(ps.data(), pn_, ts.data(), tn_, th_, &ez);
+			} else if (2 * th_ + 1 > 128) {      // more than two words: the *_infi_* functions with nword = ceil((2 thre + 1) / 64), the choice of cal_exz_infi, Correct.cpp:14556-14565
+				int32_t nw_ = (2 * th_ + 1 + 63) >> 6;
+				if (tm == 1) ed_band_cal_semi_infi_w_absent_diag_trace(ps.data(), pn_, ts.data(), tn_, th_, (int32_t)t[9], &nw_, &ez);
+				else if (tm == 2) ed_band_cal_extension_infi_0_w_trace(ps.data(), pn_, ts.data(), tn_, th_, &nw_, &ez);
+				else if (tm == 3) ed_band_cal_extension_infi_1_w_trace(ps.data(), pn_, ts.data(), tn_, th_, &nw_, &ez);
+				else ed_band_cal_global_infi_w_trace(ps.data(), pn_, ts.data(), tn_, th_, &nw_, &ez);
 			} else {      // two words (HA_ED_INIT(128), Levenshtein_distance.h:2129): the choice of cal_exz_global, Correct.cpp:15482-15494
 				if (tm == 1) ed_band_cal_semi_128_w_absent_diag_trace(ps.data(), pn_, ts.data(), tn_, th_, (int32_t)t[9], &ez);
 				else if (tm == 2) ed_band_cal_extension_128_0_w_trace(ps.data(), pn_, ts.data(), tn_, th_, &ez);

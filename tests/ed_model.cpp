@@ -57,44 +57,60 @@ static void model_launch(const hao_ed_reads &R, const hao_ed_task_t *task, const
 	}
 }
 
+// the instantiations a batch needs: band class 0 = one- and two-word bands (what the device library launches), 1 = three- and four-word bands (thre 64 .. 127)
+template<int MODE, bool TRACE>
+static void model_launch_all(int band, bool two_types, const hao_ed_reads &R, const hao_ed_task_t *task, const uint32_t *order, uint64_t n_order, uint64_t *path, uint64_t stride,
+		hao_ed_result_t *out_ed, hao_trace_result_t *out_tr, uint8_t *want_trace, uint16_t *cig, uint32_t cap)
+{
+	if (band == 0) {
+		model_launch<uint64_t, MODE, TRACE>(R, task, order, n_order, path, stride, out_ed, out_tr, want_trace, cig, cap);
+		if (two_types) model_launch<hao_u128, MODE, TRACE>(R, task, order, n_order, path, stride, out_ed, out_tr, want_trace, cig, cap);
+	} else {
+		model_launch<hao_wide<3>, MODE, TRACE>(R, task, order, n_order, path, stride, out_ed, out_tr, want_trace, cig, cap);
+		model_launch<hao_wide<4>, MODE, TRACE>(R, task, order, n_order, path, stride, out_ed, out_tr, want_trace, cig, cap);
+	}
+}
+
 template<int MODE>
-static void model_trace(const hao_ed_reads &R, const hao_ed_task_t *task, const std::vector<uint32_t> &order, bool wide, uint64_t tn_max, hao_trace_result_t *out, uint16_t *cig, uint32_t cap,
+static void model_trace(int band, const hao_ed_reads &R, const hao_ed_task_t *task, const std::vector<uint32_t> &order, bool wide, uint64_t tn_max, hao_trace_result_t *out, uint16_t *cig, uint32_t cap,
 		uint64_t slice_bytes)
 {
 	const uint64_t n = order.size();
 	std::vector<uint8_t> want(n, 0);
-	model_launch<uint64_t, MODE, false>(R, task, order.data(), n, nullptr, 0, nullptr, out, want.data(), nullptr, 0);
-	if (wide) model_launch<hao_u128, MODE, false>(R, task, order.data(), n, nullptr, 0, nullptr, out, want.data(), nullptr, 0);
+	model_launch_all<MODE, false>(band, wide, R, task, order.data(), n, nullptr, 0, nullptr, out, want.data(), nullptr, 0);
 	std::vector<uint32_t> sel; for (uint32_t i : order) if (want[i]) sel.push_back(i);
 	const uint64_t n_sel = sel.size();
 	if (!n_sel) return;
-	const uint64_t cw = wide ? 10 : 5;
+	const uint64_t cw = band ? 20 : (wide ? 10 : 5);      // 64-bit words kept per text column: 5 vectors x the widest band word of the batch
 	const uint64_t slice = std::max<uint64_t>(256, std::min<uint64_t>((n_sel + 255) & ~255ULL, (slice_bytes / (8 * cw * tn_max)) & ~255ULL));
 	std::vector<uint64_t> path(cw * tn_max * slice + 1);
 	for (uint64_t lo = 0; lo < n_sel; lo += slice) {
 		const uint64_t m = std::min<uint64_t>(slice, n_sel - lo);
-		model_launch<uint64_t, MODE, true>(R, task, sel.data() + lo, m, path.data(), slice, nullptr, out, nullptr, cig, cap);
-		if (wide) model_launch<hao_u128, MODE, true>(R, task, sel.data() + lo, m, path.data(), slice, nullptr, out, nullptr, cig, cap);
+		model_launch_all<MODE, true>(band, wide, R, task, sel.data() + lo, m, path.data(), slice, nullptr, out, nullptr, cig, cap);
 	}
 }
 
 // mode 0 .. 3: hao_window_trace_batch's modes (out_tr, cig); 4: hao_window_ed_batch (out_ed).  slice_bytes: column scratch of one second-sweep slice
-// (the product uses 4 GB; tests pass something small to cross slice boundaries).
+// (the product uses 4 GB; tests pass something small to cross slice boundaries).  band: 0 = bands of one / two words (thre <= 63: what libhao.so launches),
+// 1 = three / four words (thre 64 .. 127: the reference's *_infi_* functions; model only so far).
 extern "C" int hao_model_window(int mode, const uint8_t *packed, const uint64_t *pk_off, const uint32_t *len, const uint64_t *nsite_off, const uint32_t *nsite,
-		const hao_ed_task_t *tasks, uint64_t n, hao_ed_result_t *out_ed, hao_trace_result_t *out_tr, uint16_t *cig, uint32_t cap, uint64_t slice_bytes)
+		const hao_ed_task_t *tasks, uint64_t n, hao_ed_result_t *out_ed, hao_trace_result_t *out_tr, uint16_t *cig, uint32_t cap, uint64_t slice_bytes, int band)
 {
 	hao_ed_reads R; R.packed = packed; R.pk_off = pk_off; R.len = len; R.nsite_off = nsite_off; R.nsite = nsite;
 	std::vector<uint32_t> order(n); for (uint64_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
 	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hao_al_sort_key(tasks[a]) < hao_al_sort_key(tasks[b]); });
 	bool wide = false; uint64_t tn_max = 1;
-	for (uint64_t i = 0; i < n; ++i) { if (2 * (uint64_t)tasks[i].thre + 1 > 64) wide = true; if (tasks[i].t_len > tn_max) tn_max = tasks[i].t_len; }
-	if (mode == HAO_AL_ED) {
-		model_launch<uint64_t, HAO_AL_ED, false>(R, tasks, order.data(), n, nullptr, 0, out_ed, nullptr, nullptr, nullptr, 0);
-		if (wide) model_launch<hao_u128, HAO_AL_ED, false>(R, tasks, order.data(), n, nullptr, 0, out_ed, nullptr, nullptr, nullptr, 0);
-	} else if (mode == HAO_AL_GLOBAL) model_trace<HAO_AL_GLOBAL>(R, tasks, order, wide, tn_max, out_tr, cig, cap, slice_bytes);
-	else if (mode == HAO_AL_EXT_FWD) model_trace<HAO_AL_EXT_FWD>(R, tasks, order, wide, tn_max, out_tr, cig, cap, slice_bytes);
-	else if (mode == HAO_AL_EXT_BWD) model_trace<HAO_AL_EXT_BWD>(R, tasks, order, wide, tn_max, out_tr, cig, cap, slice_bytes);
-	else if (mode == HAO_AL_SEMI) model_trace<HAO_AL_SEMI>(R, tasks, order, wide, tn_max, out_tr, cig, cap, slice_bytes);
+	for (uint64_t i = 0; i < n; ++i) {
+		const uint32_t nw = hao_al_nword(tasks[i].thre);
+		if (band == 0 ? nw > 2 : (nw < 3 || nw > 4)) return -2;      // a task of another band class
+		if (nw == 2) wide = true;
+		if (tasks[i].t_len > tn_max) tn_max = tasks[i].t_len;
+	}
+	if (mode == HAO_AL_ED) model_launch_all<HAO_AL_ED, false>(band, wide, R, tasks, order.data(), n, nullptr, 0, out_ed, nullptr, nullptr, nullptr, 0);
+	else if (mode == HAO_AL_GLOBAL) model_trace<HAO_AL_GLOBAL>(band, R, tasks, order, wide, tn_max, out_tr, cig, cap, slice_bytes);
+	else if (mode == HAO_AL_EXT_FWD) model_trace<HAO_AL_EXT_FWD>(band, R, tasks, order, wide, tn_max, out_tr, cig, cap, slice_bytes);
+	else if (mode == HAO_AL_EXT_BWD) model_trace<HAO_AL_EXT_BWD>(band, R, tasks, order, wide, tn_max, out_tr, cig, cap, slice_bytes);
+	else if (mode == HAO_AL_SEMI) model_trace<HAO_AL_SEMI>(band, R, tasks, order, wide, tn_max, out_tr, cig, cap, slice_bytes);
 	else return -1;
 	return 0;
 }

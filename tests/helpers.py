@@ -92,6 +92,10 @@ def fold_digests(d, block=256):
 
 
 # ---- f3: window alignment tasks (hao_window_ed_batch / ed_band_cal_semi_64_w_absent_diag) ----
+# thresholds by band class (wide = 0 / False: one 64-bit word, 1 / True: two words, 2: three or four words = the reference's *_infi_* functions)
+_THRE_W = ([0, 3, 8, 15, 24, 31], [32, 40, 50, 63], [64, 80, 95, 96, 110, 127])      # window / candidate pairs
+_THRE_U = ([0, 1, 5, 15, 31], [32, 45, 63], [64, 97, 127])                          # unrelated pairs
+_THRE_S = ([0, 2, 7], [33, 63], [65, 127])                                          # a read against itself
 def ed_tasks(name, n_reads=24, wl=775, seed=1, wide=False):
     """wide = thresholds of 32 .. 63 (bands of two 64-bit words: the reference's 128-bit functions).
     (pattern, text) pairs the way the window alignment forms them (Correct.cpp:3897): 775-base query windows of the overlaps h_ec_lchain found,
@@ -109,7 +113,7 @@ def ed_tasks(name, n_reads=24, wl=775, seed=1, wide=False):
             tl = int(L[yid])
             for ws in range(xs, xe + 1, wl):
                 tn = min(wl, xe + 1 - ws)
-                thre = int(rng.choice([32, 40, 50, 63] if wide else [0, 3, 8, 15, 24, 31]))
+                thre = int(rng.choice(_THRE_W[int(wide)]))
                 p0 = ys + (ws - xs) - thre + int(rng.integers(-3, 4))
                 p1 = p0 + tn + 2 * thre
                 ad = 0
@@ -126,13 +130,13 @@ def ed_tasks(name, n_reads=24, wl=775, seed=1, wide=False):
             continue
         tn = int(rng.integers(1, min(900, int(L[b])) + 1))
         pn = int(rng.integers(1, min(1000, int(L[a])) + 1))
-        thre = int(rng.choice([32, 45, 63] if wide else [0, 1, 5, 15, 31]))
+        thre = int(rng.choice(_THRE_U[int(wide)]))
         out.append((a, int(rng.integers(0, L[a] - pn + 1)), pn, int(rng.integers(0, 2)), b, int(rng.integers(0, L[b] - tn + 1)), tn, int(rng.integers(0, 2)),
                     thre, int(rng.integers(0, 2 * thre + 1))))
     t = np.array(out, dtype=np.uint32)
-    if wide:      # the final scan reads bit i of VP / VN for i < p_len - t_len + abs_diag: beyond 128 the reference's two-word code indexes the neighbouring
+    if wide:      # the final scan reads bit i of VP / VN for i < p_len - t_len + abs_diag: beyond the band's words the reference's multi-word code indexes the neighbouring
         ai = t[:, 2].astype(np.int64) - t[:, 6] + t[:, 9]      # vectors of its bit_extz_t (a one-word band just wraps its shift count): keep what is defined
-        t = t[ai <= 128]
+        t = t[ai <= 64 * ((2 * t[:, 8].astype(np.int64) + 1 + 63) // 64)]
     return t
 
 
@@ -152,7 +156,7 @@ def ed_global_tasks(name, n_reads=24, wl=775, seed=2, wide=False):
             tl = int(L[yid])
             for ws in range(xs, xe + 1, wl):
                 tn = min(wl, xe + 1 - ws)
-                thre = int(rng.choice([32, 40, 50, 63] if wide else [0, 3, 8, 15, 24, 31]))
+                thre = int(rng.choice(_THRE_W[int(wide)]))
                 p0 = max(0, ys + (ws - xs) + int(rng.integers(-2, 3)))
                 p1 = min(tl, p0 + tn + int(rng.integers(-3, 4)))
                 if p1 <= p0 or tn <= 0:
@@ -163,13 +167,13 @@ def ed_global_tasks(name, n_reads=24, wl=775, seed=2, wide=False):
         if L[a] < 2 or L[b] < 2:
             continue
         tn = int(rng.integers(1, min(400, int(L[b])) + 1))
-        thre = int(rng.choice([32, 45, 63] if wide else [0, 1, 5, 15, 31]))
+        thre = int(rng.choice(_THRE_U[int(wide)]))
         pn = max(1, min(int(L[a]), tn + int(rng.integers(-thre - 2, thre + 3))))
         out.append((a, int(rng.integers(0, L[a] - pn + 1)), pn, int(rng.integers(0, 2)), b, int(rng.integers(0, L[b] - tn + 1)), tn, int(rng.integers(0, 2)), thre, 0))
     for a in range(min(rs.n, 40)):      # a read against itself and against its neighbourhood: exact and near-exact pairs, short strings
         if L[a] < 40:
             continue
-        n_ = int(rng.integers(1, 40)); p_ = int(rng.integers(0, L[a] - n_ + 1)); thre = int(rng.choice([33, 63] if wide else [0, 2, 7]))
+        n_ = int(rng.integers(1, 40)); p_ = int(rng.integers(0, L[a] - n_ + 1)); thre = int(rng.choice(_THRE_S[int(wide)]))
         out.append((a, p_, n_, 0, a, p_, n_, 0, thre, 0))
         out.append((a, p_, n_, 1, a, int(L[a]) - p_ - n_, n_, 1, thre, 0))
         if p_ + n_ + 1 <= L[a]:
@@ -201,7 +205,7 @@ def ed_ext_tasks(name, n_reads=24, wl=775, seed=4, wide=False):
             tl = int(L[yid])
             for ws in range(xs, xe + 1, wl):
                 tn = min(int(rng.integers(20, wl + 1)), xe + 1 - ws)
-                thre = int(rng.choice([32, 40, 50, 63] if wide else [0, 3, 8, 15, 24, 31]))
+                thre = int(rng.choice(_THRE_W[int(wide)]))
                 p0 = max(0, ys + (ws - xs) + int(rng.integers(-1, 2)))
                 pn = tn + int(rng.choice([-60, -9, -2, 0, 1, 3, 12, 80]))
                 p1 = min(tl, p0 + max(1, pn))
@@ -213,12 +217,12 @@ def ed_ext_tasks(name, n_reads=24, wl=775, seed=4, wide=False):
         if L[a] < 2 or L[b] < 2:
             continue
         tn = int(rng.integers(1, min(300, int(L[b])) + 1)); pn = int(rng.integers(1, min(300, int(L[a])) + 1))
-        thre = int(rng.choice([32, 45, 63] if wide else [0, 1, 5, 15, 31]))
+        thre = int(rng.choice(_THRE_U[int(wide)]))
         out.append((a, int(rng.integers(0, L[a] - pn + 1)), pn, int(rng.integers(0, 2)), b, int(rng.integers(0, L[b] - tn + 1)), tn, int(rng.integers(0, 2)), thre, 0))
     for a in range(min(rs.n, 40)):      # exact and near-exact short pairs
         if L[a] < 60:
             continue
-        n_ = int(rng.integers(1, 50)); p_ = int(rng.integers(0, L[a] - n_ - 8)); thre = int(rng.choice([33, 63] if wide else [0, 2, 7]))
+        n_ = int(rng.integers(1, 50)); p_ = int(rng.integers(0, L[a] - n_ - 8)); thre = int(rng.choice(_THRE_S[int(wide)]))
         out.append((a, p_, n_, 0, a, p_, n_, 0, thre, 0))
         out.append((a, p_, n_ + 5, 0, a, p_, n_, 0, thre, 0))
         out.append((a, p_, n_, 0, a, p_, n_ + 5, 0, thre, 0))
