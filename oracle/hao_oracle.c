@@ -89,6 +89,7 @@ struct hao_or_ctx {
 	uint64_t pt_nk, pt_np; uint64_t *pt_keys, *pt_off, *pt_pos;
 	/* scratch */
 	hao_or_mz_t *mz; int64_t mz_m; uint64_t *mt; int64_t mt_m;
+	int pre_on; int64_t pre_n, pre_m, pre_totl; uint64_t *pre_x, *pre_ord; uint32_t *pre_cnt, *pre_pos;      /* hao_or_sketch_pre: the list mz1_select_mz_h receives */
 	hao_or_hit_t *hits; int64_t hits_m;
 	hao_or_ovlp_t *ol; int64_t ol_n, ol_m; uint64_t *fc; int64_t fc_n, fc_m; uint64_t *fc_off; int64_t fco_m;
 	hao_or_hit_t *cl; int64_t cl_m;
@@ -111,6 +112,7 @@ void hao_or_destroy(hao_or_ctx *c)
 	free(c->ft_keys); free(c->ft_vals); free(c->pt_keys); free(c->pt_off); free(c->pt_pos);
 	free(c->mz); free(c->mt); free(c->hits); free(c->ol); free(c->fc); free(c->fc_off); free(c->cl);
 	free(c->f); free(c->ii); free(c->p); free(c->t); free(c->cc);
+	free(c->pre_x); free(c->pre_ord); free(c->pre_cnt); free(c->pre_pos);
 	free(c);
 }
 
@@ -483,6 +485,12 @@ static int64_t sketch_core(hao_or_ctx *c, const uint8_t *s, int64_t len, uint32_
 		if (++bp == w) bp = 0;
 	}
 	if (min.x != UINT64_MAX) cv_push(&v, &min, min_ord);       /* :571-573 */
+	if (c->pre_on) {                                           /* (tests) the list as mz1_select_mz_h receives it */
+		if (v.n > c->pre_m) { c->pre_m = v.n + 64; c->pre_x = (uint64_t*)xrealloc(c->pre_x, c->pre_m * 8); c->pre_ord = (uint64_t*)xrealloc(c->pre_ord, c->pre_m * 8);
+			c->pre_cnt = (uint32_t*)xrealloc(c->pre_cnt, c->pre_m * 4); c->pre_pos = (uint32_t*)xrealloc(c->pre_pos, c->pre_m * 4); }
+		for (i = 0; i < v.n; ++i) { c->pre_x[i] = v.a[i].x; c->pre_cnt[i] = v.a[i].cnt; c->pre_pos[i] = v.a[i].pos; c->pre_ord[i] = (uint64_t)(uint32_t)v.mt[i]; }
+		c->pre_n = v.n; c->pre_totl = tl;
+	}
 	if (sample_dist > w) select_high(&v, (int)len, sample_dist, c->opt.rewin, k, tl);   /* :575 */
 	if (v.n > c->mz_m) { c->mz_m = v.n + 64; c->mz = (hao_or_mz_t*)xrealloc(c->mz, c->mz_m * sizeof(hao_or_mz_t)); }
 	for (i = 0; i < v.n; ++i) {                                /* rid overwritten by the caller's id, :577-578 */
@@ -502,6 +510,16 @@ int64_t hao_or_sketch_seq(hao_or_ctx *c, const uint8_t *codes, int64_t len, uint
 int64_t hao_or_sketch(hao_or_ctx *c, uint64_t rid, int use_ft, int sample_dist, const hao_or_mz_t **out)
 {
 	return hao_or_sketch_seq(c, c->codes + c->off[rid], (int64_t)(c->off[rid + 1] - c->off[rid]), (uint32_t)rid, use_ft, sample_dist, out);
+}
+
+/* test support: the sketch of read rid as usual, plus the candidate list (hash, count, position, k-mer ordinal) mz1_select_mz_h was given and tot_l */
+int64_t hao_or_sketch_pre(hao_or_ctx *c, uint64_t rid, int sample_dist, const hao_or_mz_t **out, int64_t *pre_n, const uint64_t **x, const uint32_t **cnt, const uint32_t **pos,
+		const uint64_t **ord, int64_t *tot_l)
+{
+	int64_t n;
+	c->pre_on = 1; n = hao_or_sketch(c, rid, 1, sample_dist, out); c->pre_on = 0;
+	*pre_n = c->pre_n; *x = c->pre_x; *cnt = c->pre_cnt; *pos = c->pre_pos; *ord = c->pre_ord; *tot_l = c->pre_totl;
+	return n;
 }
 
 /* ------------------------------------------------------------------ */

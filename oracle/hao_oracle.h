@@ -77,6 +77,9 @@ int64_t hao_or_kmer_hashes(const uint8_t *codes, int64_t len, int k, int hpc, ui
  * scratch buffer valid until the next call. */
 int64_t hao_or_sketch(hao_or_ctx *c, uint64_t rid, int use_ft, int sample_dist, const hao_or_mz_t **out);
 /* same on caller-provided codes (kernel-level tests) */
+/* test support: as hao_or_sketch(use_ft = 1), plus the candidate list mz1_select_mz_h (sketch.cpp:247) received: hash, filter-table count, position, k-mer ordinal; tot_l */
+int64_t hao_or_sketch_pre(hao_or_ctx *c, uint64_t rid, int sample_dist, const hao_or_mz_t **out, int64_t *pre_n, const uint64_t **x, const uint32_t **cnt, const uint32_t **pos,
+		const uint64_t **ord, int64_t *tot_l);
 int64_t hao_or_sketch_seq(hao_or_ctx *c, const uint8_t *codes, int64_t len, uint32_t rid, int use_ft, int sample_dist, const hao_or_mz_t **out);
 
 /* minimizers_qgen0 (anchor.cpp:987-1081): sorted seed hits of one read, before chaining */

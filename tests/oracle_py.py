@@ -125,6 +125,18 @@ class Oracle:
         n = self.L.hao_or_sketch(self.h, rid, int(use_ft), sd, C.byref(p))
         return _arr(p.value, 2 * n, np.uint64).reshape(-1, 2)
 
+    def sketch_pre(self, rid, sample_dist=None):
+        """the sketch of read rid (uint64 [n,2]) plus the candidate list mz1_select_mz_h received: x, cnt, pos, ord arrays and tot_l"""
+        vp = C.c_void_p
+        self.L.hao_or_sketch_pre.argtypes = [vp, C.c_uint64, C.c_int, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]
+        self.L.hao_or_sketch_pre.restype = C.c_int64
+        out, pn, x, cnt, pos, od, tl = vp(), C.c_int64(), vp(), vp(), vp(), vp(), C.c_int64()
+        sd = self.opt.sample_dist if sample_dist is None else sample_dist
+        n = self.L.hao_or_sketch_pre(self.h, rid, sd, C.byref(out), C.byref(pn), C.byref(x), C.byref(cnt), C.byref(pos), C.byref(od), C.byref(tl))
+        m = pn.value
+        return (_arr(out.value, 2 * n, np.uint64).reshape(-1, 2), _arr(x.value, m, np.uint64), _arr(cnt.value, m, np.uint32), _arr(pos.value, m, np.uint32),
+                _arr(od.value, m, np.uint64), tl.value)
+
     def sketch_seq(self, codes, rid=0, use_ft=True, sample_dist=None):
         p = C.c_void_p()
         sd = self.opt.sample_dist if sample_dist is None else sample_dist
