@@ -5,6 +5,7 @@
 #include <cstring>
 #include "hao_ctx.hpp"
 #include "hao_sketch.cuh"
+#include "hao_select2.cuh"
 #include "hao_host.hpp"
 #include "hao_index.cuh"
 #include "hao_query.cuh"
