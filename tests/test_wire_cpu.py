@@ -9,7 +9,7 @@ import numpy as np
 from hifiasm_amd import api
 
 
-def _encode(reads, rid_lo=7, seed=3):
+def _encode(reads, rid_lo=7, seed=3, fill=True):
     """reads: list of (qmz [(self_offset, cnt)], chains [(w0, [(q, offset), ...])]) -> (Delivery, keep-alive list, expected hits per read).
     Positions are indices among the batch's seed hits: every chain is a run of consecutive positions somewhere in the read's range, with positions that
     belong to no chain (random code bytes, some of them flagged, one of them 0xff with a bogus list entry) between the chains; the byte at a chain's
@@ -21,7 +21,7 @@ def _encode(reads, rid_lo=7, seed=3):
     h = 0
 
     def filler(n):
-        for _ in range(n):
+        for _ in range(n if fill else 0):
             b = int(rng.choice([0x08, 0x08, 0x17, 0x2a, 0xff]))
             if b == 0xff:
                 exc.append((len(byte_at), 9999, (1, 2, 3, 4)))      # an entry nobody may look up
@@ -113,3 +113,21 @@ def test_decoder_inverts_the_format():
         got = L.hao_unpack_hits(C.byref(d), d.rid_lo + r, out.ctypes.data_as(C.c_void_p), exp.shape[0])
         assert got == exp.shape[0] and (out[:got] == exp).all(), f"read {r}"
     assert L.hao_unpack_hits(C.byref(d), d.rid_lo + len(want), None, 0) == 0                                    # not a read of the batch
+
+
+def test_decoder_edges_of_the_position_space():
+    """a one-hit chain at the very last position of a batch whose position count is a multiple of 64 (the decoder must not look at word n_pos / 64), a two-hit chain
+    ending there, and first positions that carry a 0xff byte which is not the chain's"""
+    qt = [(100 + 37 * i, 1 << 8 | 51) for i in range(200)]
+    hit = 0
+    for last_len in (1, 2):
+        for seed in range(12):
+            first = [(q, 9000 + qt[q][0] + (3 if q == 40 else 0)) for q in range(0, 128 - 3 - last_len)]      # 128 positions in all, no filler
+            chains = [(5, first), (6 | 1 << 31, [(3, 500), (4, 537), (30, 2000)]), (7, [(q, 4000 + qt[q][0]) for q in range(10, 10 + last_len)])]
+            d, keep, want = _encode([(qt, chains)], seed=seed, fill=False)
+            assert d.n_pos == 128 and int(keep[3]["pos"][2]) + last_len == d.n_pos and d.n_exc >= 1
+            out = np.zeros((want[0].shape[0], 4), dtype=np.uint32)
+            got = api.lib().hao_unpack_hits(C.byref(d), d.rid_lo, out.ctypes.data_as(C.c_void_p), want[0].shape[0])
+            assert got == want[0].shape[0] and (out == want[0]).all()
+            hit += 1
+    assert hit == 24
