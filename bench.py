@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 from hifiasm_amd.workloads import WORKLOADS, n_reads_of  # noqa: E402
 
 STRONG = {"human3G_hifi40x", "ont_human_30x"}      # fixed-size problems: the read set is split over the ranks
+VARIANT_OF = {"chr1_250M_hifi30x": "chr1_250M_hifi30x_repeat", "bacterial5M_hifi30x": "bacterial5M_hifi30x_repeat"}      # the repeat-rich twin of a workload
 # algorithmic bytes per unit (stated again in DESIGN.md 4)
 ALG = {
     "sketch_unit_kernel": ("base", 0.25 + 16.0 / 35.0),             # 2-bit bases in + one 16-B minimizer per ~35 bases out
@@ -113,7 +114,7 @@ def cpu_baseline(workload, mode="sample", threads=None):
 def profile_file(name):
     """newest committed profile of that name (PMC counters need their own rocprofv3 passes - tools/r03_final.sh - so they cannot be
     collected inside this run; the line says where the figure comes from)"""
-    for r in ("r03", "r02"):
+    for r in ("r04", "r03", "r02"):
         p = os.path.join(ROOT, "profiles", r, name)
         if os.path.exists(p):
             return p, f"profiles/{r}/{name}"
@@ -134,46 +135,41 @@ def self_launch(a):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="chr1_250M_hifi30x", choices=list(WORKLOADS))
-    ap.add_argument("--batch-reads", type=int, default=0, help="query reads per hao_overlap_batch (0 = sized for ~8e8 seed hits)")
-    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "none"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-boundary", action="store_true", help="skip the boundary-inclusive (results delivered to host memory) measurement")
-    ap.add_argument("--contexts", type=int, default=1, help="batch contexts (hao_attach) = host threads that run the batches of a pass concurrently; 1 keeps every kernel alone on the device (the roofline line)")
-    ap.add_argument("--boundary-contexts", type=int, default=1, help="batch contexts of the boundary-inclusive measurement")
-    ap.add_argument("--verbose", action="store_true")
-    a = ap.parse_args()
-    if a.no_cpu_baseline:
-        a.cpu_baseline = "none"
+def verify_delivery(eng, workload, rs, dranges):
+    """one delivered pass, untimed: per-read digests of what landed in host memory, folded over blocks of 256 reads, against the reference's"""
+    import numpy as np
+    fx = os.path.join(ROOT, "tests", "golden", workload + ".npz")
+    res = {"reads": rs.n, "fixture": os.path.relpath(fx, ROOT) if os.path.exists(fx) else None, "equal_to_reference": None}
+    eng.ha_pt_gen()
+    dig = np.zeros(rs.n, dtype=np.uint64); n_cl = 0
+    prev = None
+    for lo, hi in list(dranges) + [(None, None)]:
+        slot = eng.overlap_batch_async(lo, hi) if lo is not None else None
+        if prev is not None:
+            d = eng.deliver_wait(prev[0])
+            dig[prev[1]:prev[2]] = eng.delivery_digest(d); n_cl += int(d.n_cl)
+        prev = (slot, lo, hi) if lo is not None else None
+    res["chained_hits_decoded"] = n_cl
+    # fold over blocks of 256 reads: sum of mix64(d_r + GOLD * (r + 1)) - the definition tests/golden/make_golden_big.py folds the reference's digests with
+    with np.errstate(over="ignore"):
+        z_ = dig + np.uint64(0x9E3779B97F4A7C15) * np.arange(1, dig.size + 1, dtype=np.uint64)
+        z_ ^= z_ >> np.uint64(30); z_ *= np.uint64(0xbf58476d1ce4e5b9); z_ ^= z_ >> np.uint64(27); z_ *= np.uint64(0x94d049bb133111eb); z_ ^= z_ >> np.uint64(31)
+        f = np.zeros((dig.size + 255) // 256, dtype=np.uint64)
+        np.add.at(f, np.arange(dig.size) // 256, z_)
+    res["fold_crc"] = int(__import__("zlib").crc32(f.tobytes()))
+    if res["fixture"]:
+        z = np.load(fx)
+        res["equal_to_reference"] = bool(z["dig_fold"].shape == f.shape and (z["dig_fold"] == f).all())
+        if not res["equal_to_reference"]:
+            sys.stderr.write(f"[bench] DELIVERED RESULTS DIFFER FROM THE REFERENCE on {workload}\n")
+    return res
 
-    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
-        self_launch(a)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and not (world == 1 and os.environ.get("HAO_BENCH_FORCE_SHARDED") == "1"):
-        sys.stderr.write(f"[bench] --gpus {a.gpus} disagrees with WORLD_SIZE={world}\n")
-        sys.exit(2)
-    import torch
-    dist = None
-    force_sharded = os.environ.get("HAO_BENCH_FORCE_SHARDED") == "1" and "RANK" in os.environ      # exercise the N > 1 code path with one rank (tests)
-    if world > 1 or force_sharded:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if torch.cuda.device_count() <= local_rank:
-            sys.stderr.write(f"[bench] rank {rank}: no GPU {local_rank} ({torch.cuda.device_count()} visible)\n")
-            sys.exit(2)
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+def run_workload(a, workload, steps, warmup, rank, local_rank, world, dist, torch, force_sharded, check_delivery=True):
+    """one workload on this rank's GPU: resident and boundary-inclusive timings, roofline of the dominant kernel; returns the line's dict on rank 0 (None elsewhere)"""
     from hifiasm_amd.api import Engine
-
     mode = "single GPU"
-    rs, is_ont = make_reads(a.workload, rank=rank, world=world)
+    rs, is_ont = make_reads(workload, rank=rank, world=world)
     eng = Engine(local_rank, is_ont=is_ont)
     eng.set_readset(rs)
     t0 = time.time()
@@ -193,7 +189,8 @@ def main():
     # hao_overlap_batch handles < 2^32 seed hits per call and needs ~130 B of device scratch per seed hit: a batch of ~8e8 hits (~110 GB with the index;
     # 62 500 reads of configs[2]).  Bigger batches amortise the tails of the per-batch kernels and of the DP side streams (configs[2]: 16 batches 226 ms,
     # 8 batches 214 ms, 4 batches 209 ms per step at 200 GB)
-    auto_bsz = max(1, int(8e8 // max(1.0, 0.83 * rs.total_bases / max(1, n_reads) * WORKLOADS[a.workload][1] / 30.0)))
+    # (a repeat-rich genome: ~1.4 x the seed hits per read, and more of them in exception lists / DP scratch)
+    auto_bsz = max(1, int(8e8 // max(1.0, (1.25 if WORKLOADS[workload][4] else 0.83) * rs.total_bases / max(1, n_reads) * WORKLOADS[workload][1] / 30.0)))
     bsz = a.batch_reads if a.batch_reads > 0 else min(n_reads, auto_bsz)
     ranges = [(lo, min(n_reads, lo + bsz)) for lo in range(0, n_reads, bsz)]
     # with delivery a pass needs at least two batches for the copy of one to run under the compute of the next: a pass that fits one batch is cut in two
@@ -265,12 +262,12 @@ def main():
             dist.barrier()
 
     def timed(deliver, n_ctx=1):
-        for _ in range(a.warmup):
+        for _ in range(warmup):
             step(deliver, n_ctx)
         sync()
         t0 = time.time()
         ssum = {}
-        for _ in range(a.steps):
+        for _ in range(steps):
             tot, st = step(deliver, n_ctx)
             for k, v in st.items():
                 ssum[k] = ssum.get(k, 0.0) + v
@@ -287,16 +284,22 @@ def main():
         return dt, ov, tot, ssum
 
     dt, overlaps, tot, stage_sum = timed(False, max(1, a.contexts))
-    ms_per_step = dt / a.steps * 1e3
-    value = overlaps / (dt / a.steps)
+    ms_per_step = dt / steps * 1e3
+    value = overlaps / (dt / steps)
     boundary = None
     if not a.no_boundary and hasattr(eng, "overlap_batch_async"):
         bdt, bov, btot, bst = timed(True, max(1, a.boundary_contexts))
-        boundary = {"q_assemble_ms_per_step": bst.get("q_assemble", 0.0) / a.steps, "stage_ms": {k: round(v / a.steps, 2) for k, v in bst.items()},"value": bov / (bdt / a.steps), "ms_per_step": bdt / a.steps * 1e3, "host_bytes_per_gpu_step": btot["host_bytes"], "wire_bytes_per_chained_hit": (btot["delivered_hits"] / 8 + btot["delivered_hits"] / 16 + btot["code_bytes"]) / max(1, btot["delivered_hits"]),
+        boundary = {"q_assemble_ms_per_step": bst.get("q_assemble", 0.0) / steps, "stage_ms": {k: round(v / steps, 2) for k, v in bst.items()},"value": bov / (bdt / steps), "ms_per_step": bdt / steps * 1e3, "host_bytes_per_gpu_step": btot["host_bytes"], "wire_bytes_per_chained_hit": (btot["delivered_hits"] / 8 + btot["delivered_hits"] / 16 + btot["code_bytes"]) / max(1, btot["delivered_hits"]),
                     "copy_ms_per_step": btot["copy_ms"], "verbatim_hits_per_step": btot["exceptions"], "host_ms_in_async": btot["t_async"], "host_ms_in_wait": btot["t_wait"], "copy_gb_per_s": btot["host_bytes"] / max(1e-9, btot["copy_ms"] * 1e-3) / 1e9}
 
+    # What `value` was quoted on must be what the reference computes: one more delivered pass (untimed), every read's digest computed on the HOST from the bytes
+    # in the pinned arena (hao_delivery_digest: ol->list, fake cigars, cl->list decoded out of the wire format) against the digests of the real reference's run on
+    # the same reads (tests/golden/<workload>.npz, made by tests/golden/make_golden_big.py from oracle/_ref/ref_harness; compared by value, nothing under oracle/ runs here)
+    if boundary is not None and world == 1 and not a.no_verify:
+        boundary["delivered_bytes_check"] = verify_delivery(eng, workload, rs, dranges)
+
     if rank == 0:
-        stage_ms = {k: v / a.steps for k, v in stage_sum.items()}
+        stage_ms = {k: v / steps for k, v in stage_sum.items()}
         # roofline of the dominant kernel: live HIP-event time of its stage on the engine's stream
         dom = max(KERN_STAGE, key=lambda k: stage_ms.get(KERN_STAGE[k], 0.0))
         unit, bpu = ALG[dom]
@@ -314,7 +317,7 @@ def main():
         if prof and world == 1:      # PMC counters need their own rocprofv3 passes (tools/pmc.sh): not measurable inside this run
             try:
                 pj = json.load(open(prof))
-                if pj.get("workload") == a.workload:
+                if pj.get("workload") == workload:
                     tt = [v["hbm_bytes_per_launch"] * v["launches"] for k, v in pj["kernels"].items() if k.split("<")[0] == dom]
                     if tt:
                         roofline["traffic"] = int(sum(tt) / max(1, pj.get("batches", 1)))
@@ -343,8 +346,8 @@ def main():
                 pass
         out = {
             "metric": "read-pair overlaps/sec (sum ol->length / (ha_pt_gen + all-reads h_ec_lchain pass))",
-            "value": round(boundary["value"] if boundary else value, 1), "unit": "overlaps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(boundary["ms_per_step"] if boundary else ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if a.workload in STRONG else "weak",
+            "value": round(boundary["value"] if boundary else value, 1), "unit": "overlaps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(boundary["ms_per_step"] if boundary else ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if workload in STRONG else "weak",
             "vs_baseline": None, "dtype": "u64 hashing / int32 + f64 chain scores", "data": "synthetic",
             "value_is": ("boundary: every batch's ol->list, fake cigars and cl->list (wire format) delivered into pinned host memory inside the timed region" if boundary
                          else "resident: results stay in HBM (--no-boundary)"),
@@ -354,11 +357,11 @@ def main():
                           "copy_ms_per_step": round(boundary["copy_ms_per_step"], 2), "verbatim_hits_per_step": boundary["verbatim_hits_per_step"], "copy_gb_per_s": round(boundary["copy_gb_per_s"], 2),
                           "assemble_and_pack_ms_per_step": round(boundary["q_assemble_ms_per_step"], 2),
                           "host_ms_in_async": round(boundary["host_ms_in_async"], 1), "host_ms_in_wait": round(boundary["host_ms_in_wait"], 1),
-                          "stage_ms": boundary["stage_ms"],
+                          "stage_ms": boundary["stage_ms"], "delivered_bytes_check": boundary.get("delivered_bytes_check"),
                           "contexts": max(1, a.boundary_contexts),
                           "what": "same step with every batch's ol->list, fake cigars and packed cl->list delivered into pinned host memory (per batch context: double-buffered, copy stream under the next batch's compute); contexts = batch contexts (hao_attach), one host thread each, that share the pass"}
                          if boundary else None),
-            "config": {"workload": a.workload, "batch_contexts": max(1, a.contexts), "reads_per_gpu": n_reads, "bases_per_gpu": rs.total_bases, "batches_per_pass": len(ranges),
+            "config": {"workload": workload, "batch_contexts": max(1, a.contexts), "reads_per_gpu": n_reads, "bases_per_gpu": rs.total_bases, "batches_per_pass": len(ranges),
                        "overlaps_per_gpu_step": tot["overlaps"], "seed_hits_per_gpu_step": tot["seed_hits"],
                        "chained_hits_per_gpu_step": tot["chained_hits"], "groups_per_gpu_step": tot["groups"],
                        "groups_on_sequential_path": tot["seq_groups"], "k": 51, "w": 51, "hpc": 1,
@@ -367,11 +370,70 @@ def main():
             "sketch": sk,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
         }
+        for v_ in views.values():
+            v_.close()
+        eng.close()
+        return out
+    for v_ in views.values():
+        v_.close()
+    eng.close()
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="chr1_250M_hifi30x", choices=list(WORKLOADS))
+    ap.add_argument("--batch-reads", type=int, default=0, help="query reads per hao_overlap_batch (0 = sized for ~8e8 seed hits)")
+    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "none"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the boundary-inclusive (results delivered to host memory) measurement")
+    ap.add_argument("--contexts", type=int, default=1, help="batch contexts (hao_attach) = host threads that run the batches of a pass concurrently; 1 keeps every kernel alone on the device (the roofline line)")
+    ap.add_argument("--boundary-contexts", type=int, default=1, help="batch contexts of the boundary-inclusive measurement")
+    ap.add_argument("--no-variants", action="store_true", help="skip the repeat-rich twin of the workload (the `variants` block of the line)")
+    ap.add_argument("--variant-steps", type=int, default=5, help="timed steps of the variant (at most --steps)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the untimed pass that digests the delivered bytes and compares them with the reference's digests")
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    if a.no_cpu_baseline:
+        a.cpu_baseline = "none"
+
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and not (world == 1 and os.environ.get("HAO_BENCH_FORCE_SHARDED") == "1"):
+        sys.stderr.write(f"[bench] --gpus {a.gpus} disagrees with WORLD_SIZE={world}\n")
+        sys.exit(2)
+    import torch
+    dist = None
+    force_sharded = os.environ.get("HAO_BENCH_FORCE_SHARDED") == "1" and "RANK" in os.environ      # exercise the N > 1 code path with one rank (tests)
+    if world > 1 or force_sharded:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if torch.cuda.device_count() <= local_rank:
+            sys.stderr.write(f"[bench] rank {rank}: no GPU {local_rank} ({torch.cuda.device_count()} visible)\n")
+            sys.exit(2)
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    from hifiasm_amd.api import Engine
+
+    out = run_workload(a, a.workload, a.steps, a.warmup, rank, local_rank, world, dist, torch, force_sharded)
+    if rank == 0:
+        # SURVEY 8d / BASELINE.md 2b: "report both variants" - the same step on the repeat-rich read set of the same size (filter table, minimizer thinning,
+        # max_n_chain pruning, the chain DP: the case that looks like a real genome), fewer steps
+        out["variants"] = None
+        var = VARIANT_OF.get(a.workload)
+        if var and world == 1 and not a.no_variants:
+            v = run_workload(a, var, max(1, min(a.steps, a.variant_steps)), min(a.warmup, 1), rank, local_rank, world, dist, torch, force_sharded)
+            out["variants"] = {"repeat_rich": {k: v[k] for k in ("value", "ms_per_step", "value_resident", "ms_per_step_resident", "steps", "warmup", "roofline", "stage_ms", "config", "boundary")}}
         out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_baseline) if (a.cpu_baseline != "none" and world == 1) else None
         if a.verbose:
             sys.stderr.write(json.dumps(out["stage_ms"], indent=1) + "\n")
         print(json.dumps(out), flush=True)
-    eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

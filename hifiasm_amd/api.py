@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "hao_ft_cnt", "hao_pt_get", "hao_ft_table", "hao_pt_table", "hao_hist", "hao_stats", "hao_sketch_batch",
     "hao_fetch_sketch", "hao_overlap_batch", "hao_fetch_seed_hits", "hao_fetch_overlaps", "hao_batch_totals",
     "hao_stage_times", "hao_pass_default", "hao_overlap_batch_ex", "hao_set_shard", "hao_dist_unique_id", "hao_dist_init",
-    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_selftest_big", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits", "hao_exact_check", "hao_fetch_exact", "hao_window_ed_batch", "hao_index_save", "hao_index_load", "hao_next_slot", "hao_attach", "hao_window_trace_batch",
+    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_selftest_big", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits", "hao_exact_check", "hao_fetch_exact", "hao_window_ed_batch", "hao_index_save", "hao_index_load", "hao_next_slot", "hao_attach", "hao_window_trace_batch", "hao_delivery_digest",
 ]
 
 
@@ -106,6 +106,7 @@ def lib():
         L.hao_index_load.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int32)]
         L.hao_fetch_exact.argtypes = [vp, C.c_uint64, C.POINTER(vp), u64p]
         L.hao_unpack_hits.argtypes = [C.POINTER(Delivery), C.c_uint64, vp, C.c_uint64]; L.hao_unpack_hits.restype = C.c_uint64
+        L.hao_delivery_digest.argtypes = [C.POINTER(Delivery), u64p, C.c_int]
         L.hao_set_shard.argtypes = [vp, C.c_uint64, C.c_uint64, u32p]
         L.hao_dist_unique_id.argtypes = [u8p]
         L.hao_dist_init.argtypes = [vp, u8p, C.c_int, C.c_int]
@@ -313,6 +314,12 @@ class Engine:
         got = self.L.hao_unpack_hits(C.byref(d), rid, cl.ctypes.data_as(C.c_void_p), m)
         assert got == m
         return ol, fc, fo - (fo[0] if fo.size else 0), cl
+
+    def delivery_digest(self, d, threads=None):
+        """hao_batch_digest's per-read value computed on the HOST from a delivered batch: ol, fake cigars, and cl->list decoded out of the wire format"""
+        out = np.zeros(int(d.n_reads), dtype=np.uint64)
+        self._ck(self.L.hao_delivery_digest(C.byref(d), out.ctypes.data_as(C.POINTER(C.c_uint64)), int(threads or min(32, os.cpu_count() or 1))), "hao_delivery_digest")
+        return out
 
     def index_save(self, prefix, number_of_round=3):
         """write <prefix>.pt_flt / .pt_flt.bin / .pt_flt.paf.bin in the reference's resume format (write_pt_index, htab.cpp:1367)"""

@@ -40,8 +40,8 @@ enum { HAO_AL_GLOBAL = 0, HAO_AL_EXT_FWD = 1, HAO_AL_EXT_BWD = 2, HAO_AL_SEMI = 
 // Bands of more than two words (thre 64 .. 127: the reference's *_infi_* functions, Levenshtein_distance.h:2134-3100, picked by cal_exz_infi, Correct.cpp:14508-14564, with
 // nword = ceil((2 thre + 1) / 64)): the same lane functions over an N-word integer.  The word count is part of the semantics - what shifts in at the top of the last word
 // reaches the band after enough columns - so N is exactly the reference's nword (3 or 4), not "wide enough".  tests/ed_model.cpp instantiates these on the CPU and
-// tests/test_ed_model_cpu.py compares them with the reference's own functions (tests/golden/ed_wide.npz); the device library does not instantiate them yet
-// (hao_window_*_batch still refuse thre > 63): they have not run on a GPU.
+// tests/test_ed_model_cpu.py compares them with the reference's own functions (tests/golden/ed_wide.npz) on the CPU, tests/test_gpu_zz_new.py on the device
+// (hao_capi_rest.hpp launches hao_al_kernel<hao_wide<3|4>, ...> for the tasks whose band needs three / four words).
 template<int N> struct hao_wide {
 	uint64_t a[N];
 	HAO_AL_MFN hao_wide() {}

@@ -35,14 +35,16 @@ static hao_ed_reads hao_al_reads_of(hao_ctx *c)
 	return R;
 }
 
-template<int MODE> static int hao_al_trace_run(hao_ctx *c, const hao_ed_reads &R, const hao_ed_task_t *dt, const uint32_t *order, uint64_t n, bool wide, uint64_t tn_max,
+template<int MODE> static int hao_al_trace_run(hao_ctx *c, const hao_ed_reads &R, const hao_ed_task_t *dt, const uint32_t *order, uint64_t n, uint32_t words /* bit (nword - 1): some task's band has nword words */, uint64_t tn_max,
 		hao_trace_result_t *dr, uint8_t *want, uint16_t *dc, uint32_t cap)
 {
 	// first sweep: no column storage, every task; decides which tasks end within their threshold (want[])
 	const dim3 g_((unsigned)((n + 255) / 256)), b_(256);
-	hipLaunchKernelGGL((hao_al_kernel<uint64_t, MODE, false>), g_, b_, 0, c->stream, R, dt, order, n, (uint64_t*)nullptr, (uint64_t)0, (hao_ed_result_t*)nullptr, dr, want, (uint16_t*)nullptr, 0u);
-	if (wide) { HAO_CHECK_LAUNCH(); hipLaunchKernelGGL((hao_al_kernel<hao_u128, MODE, false>), g_, b_, 0, c->stream, R, dt, order, n, (uint64_t*)nullptr, (uint64_t)0, (hao_ed_result_t*)nullptr, dr, want, (uint16_t*)nullptr, 0u); }
-	HAO_CHECK_LAUNCH();
+	// (one launch per band word count that occurs: a launch skips the tasks of the other widths, hao_al_mine)
+	if (words & 1u) { hipLaunchKernelGGL((hao_al_kernel<uint64_t, MODE, false>), g_, b_, 0, c->stream, R, dt, order, n, (uint64_t*)nullptr, (uint64_t)0, (hao_ed_result_t*)nullptr, dr, want, (uint16_t*)nullptr, 0u); HAO_CHECK_LAUNCH(); }
+	if (words & 2u) { hipLaunchKernelGGL((hao_al_kernel<hao_u128, MODE, false>), g_, b_, 0, c->stream, R, dt, order, n, (uint64_t*)nullptr, (uint64_t)0, (hao_ed_result_t*)nullptr, dr, want, (uint16_t*)nullptr, 0u); HAO_CHECK_LAUNCH(); }
+	if (words & 4u) { hipLaunchKernelGGL((hao_al_kernel<hao_wide<3>, MODE, false>), g_, b_, 0, c->stream, R, dt, order, n, (uint64_t*)nullptr, (uint64_t)0, (hao_ed_result_t*)nullptr, dr, want, (uint16_t*)nullptr, 0u); HAO_CHECK_LAUNCH(); }
+	if (words & 8u) { hipLaunchKernelGGL((hao_al_kernel<hao_wide<4>, MODE, false>), g_, b_, 0, c->stream, R, dt, order, n, (uint64_t*)nullptr, (uint64_t)0, (hao_ed_result_t*)nullptr, dr, want, (uint16_t*)nullptr, 0u); HAO_CHECK_LAUNCH(); }
 	// the tasks of the second sweep, still in text order
 	DevBuf<uint32_t> &sel = c->al_sel; DevBuf<uint64_t> &path = c->al_path; uint64_t n_sel = 0;
 	HIP_TRY(sel.reserve(n + 1)); HIP_TRY(c->d_cursor.reserve(2));
@@ -52,21 +54,24 @@ template<int MODE> static int hao_al_trace_run(hao_ctx *c, const hao_ed_reads &R
 	HIP_TRY(hipMemcpyAsync(&n_sel, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	if (n_sel) {
-		// second sweep: 40 (two-word bands: 80) bytes per text column and selected pair, in slices whose columns fit ~4 GB; then the traceback
-		const uint64_t cw = wide ? 10 : 5;
+		// second sweep: 40 bytes per band word, text column and selected pair, in slices whose columns fit ~4 GB; then the traceback
+		const uint64_t cw = 5 * (uint64_t)((words & 8u) ? 4 : (words & 4u) ? 3 : (words & 2u) ? 2 : 1);
 		const uint64_t slice = std::max<uint64_t>(256, std::min<uint64_t>((n_sel + 255) & ~255ULL, ((4ULL << 30) / (8 * cw * tn_max)) & ~255ULL));
 		HIP_TRY(path.reserve(cw * tn_max * slice + 1));
 		for (uint64_t lo = 0; lo < n_sel; lo += slice) {
 			const uint64_t m = std::min<uint64_t>(slice, n_sel - lo);
 			const dim3 g2((unsigned)((m + 255) / 256));
-			hipLaunchKernelGGL((hao_al_kernel<uint64_t, MODE, true>), g2, b_, 0, c->stream, R, dt, sel.p + lo, m, path.p, slice, (hao_ed_result_t*)nullptr, dr, (uint8_t*)nullptr, dc, cap);
-			if (wide) { HAO_CHECK_LAUNCH(); hipLaunchKernelGGL((hao_al_kernel<hao_u128, MODE, true>), g2, b_, 0, c->stream, R, dt, sel.p + lo, m, path.p, slice, (hao_ed_result_t*)nullptr, dr, (uint8_t*)nullptr, dc, cap); }
-			HAO_CHECK_LAUNCH();
+			if (words & 1u) { hipLaunchKernelGGL((hao_al_kernel<uint64_t, MODE, true>), g2, b_, 0, c->stream, R, dt, sel.p + lo, m, path.p, slice, (hao_ed_result_t*)nullptr, dr, (uint8_t*)nullptr, dc, cap); HAO_CHECK_LAUNCH(); }
+			if (words & 2u) { hipLaunchKernelGGL((hao_al_kernel<hao_u128, MODE, true>), g2, b_, 0, c->stream, R, dt, sel.p + lo, m, path.p, slice, (hao_ed_result_t*)nullptr, dr, (uint8_t*)nullptr, dc, cap); HAO_CHECK_LAUNCH(); }
+			if (words & 4u) { hipLaunchKernelGGL((hao_al_kernel<hao_wide<3>, MODE, true>), g2, b_, 0, c->stream, R, dt, sel.p + lo, m, path.p, slice, (hao_ed_result_t*)nullptr, dr, (uint8_t*)nullptr, dc, cap); HAO_CHECK_LAUNCH(); }
+			if (words & 8u) { hipLaunchKernelGGL((hao_al_kernel<hao_wide<4>, MODE, true>), g2, b_, 0, c->stream, R, dt, sel.p + lo, m, path.p, slice, (hao_ed_result_t*)nullptr, dr, (uint8_t*)nullptr, dc, cap); HAO_CHECK_LAUNCH(); }
 		}
 	}
 	return HAO_OK;
 }
 
+#include <atomic>
+#include <thread>
 extern "C" {
 
 int hao_ft_gen(hao_ctx *c, int32_t *hom_cov)
@@ -228,6 +233,40 @@ uint64_t hao_unpack_hits(const hao_delivery_t *d, uint64_t rid, hao_hit_t *out, 
 	return k;
 }
 
+// hao_batch_digest's value for every read of a DELIVERED batch, computed on the host from the bytes in the pinned arena: ol->list, the fake cigars and
+// cl->list decoded out of the wire format by hao_unpack_hits.  A pure function of the view; the reads are spread over n_threads host threads.
+int hao_delivery_digest(const hao_delivery_t *d, uint64_t *out, int n_threads)
+{
+	if (!d || (!out && d->n_reads)) return HAO_EINVAL;
+	if (d->n_reads && (!d->ol_off || !d->cl_off)) return HAO_EINVAL;      // needs HAO_DELIVER_OL | HAO_DELIVER_CL
+	const uint64_t n = d->n_reads;
+	if (n_threads < 1) n_threads = 1;
+	if ((uint64_t)n_threads > n) n_threads = (int)std::max<uint64_t>(1, n);
+	std::atomic<uint64_t> next(0); std::atomic<int> bad(0);
+	auto work = [&]() {
+		std::vector<hao_hit_t> buf;
+		for (;;) {
+			const uint64_t b0 = next.fetch_add(64); if (b0 >= n) break;
+			for (uint64_t r = b0; r < std::min(n, b0 + 64); ++r) {
+				const uint64_t o0 = d->ol_off[r], o1 = d->ol_off[r + 1], f0 = o1 > o0 ? d->fc_off[o0] : 0, f1 = o1 > o0 ? d->fc_off[o1] : 0, nh = d->cl_off[r + 1] - d->cl_off[r];
+				if (buf.size() < nh) buf.resize(nh + nh / 4 + 64);
+				if (hao_unpack_hits(d, d->rid_lo + r, buf.data(), nh) != nh) { bad = 1; out[r] = 0; continue; }
+				uint64_t s = 0; const uint64_t *w = (const uint64_t*)(d->ol + o0);
+				for (uint64_t i = 0; i < (o1 - o0) * 6; ++i) s += hao_dg_term(1, i, w[i]);
+				for (uint64_t i = 0; i < f1 - f0; ++i) s += hao_dg_term(2, i, d->fc[f0 + i]);
+				w = (const uint64_t*)buf.data();
+				for (uint64_t i = 0; i < nh * 2; ++i) s += hao_dg_term(3, i, w[i]);
+				out[r] = s;
+			}
+		}
+	};
+	std::vector<std::thread> th;
+	for (int t = 1; t < n_threads; ++t) th.emplace_back(work);
+	work();
+	for (auto &t : th) t.join();
+	return bad ? HAO_EINVAL : HAO_OK;
+}
+
 int hao_index_save(hao_ctx *c, const char *prefix, int32_t number_of_round, const char *const *names)
 {
 	if (!c || !prefix) return HAO_EINVAL;
@@ -258,14 +297,15 @@ int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks
 	if (hao_is_sharded(c)) { hao_set_err(c, "hao_window_ed_batch needs the bases of both reads: single-device mode only"); return HAO_EUNSUPP; }
 	if (n_tasks == 0) return HAO_OK;
 	if (n_tasks >= (1ULL << 32)) { hao_set_err(c, "hao_window_ed_batch: more than 2^32 tasks in one call"); return HAO_EUNSUPP; }
-	bool wide = false;      // bands of 65 .. 127 diagonals: the two-word instantiation takes those tasks
+	uint32_t words = 0;      // bit (nword - 1): some band needs nword 64-bit words (the reference's cal_exz_infi picks nword = ceil((2 thre + 1) / 64), Correct.cpp:14508-14565)
 	for (uint64_t i = 0; i < n_tasks; ++i) {      // the reference indexes its strings unchecked; a device kernel must not
 		const hao_ed_task_t &t = tasks[i];
 		if (t.p_rid >= c->n_reads || t.t_rid >= c->n_reads || (uint64_t)t.p_pos + t.p_len > c->h_len[t.p_rid] || (uint64_t)t.t_pos + t.t_len > c->h_len[t.t_rid] ||
-			2 * (uint64_t)t.thre + 1 > 127 || t.abs_diag > 2 * t.thre) { hao_set_err(c, "hao_window_ed_batch: task " + std::to_string(i) + " out of range"); return HAO_EINVAL; }
-		if (2 * (uint64_t)t.thre + 1 > 64 && (int64_t)t.p_len - (int64_t)t.t_len + (int64_t)t.abs_diag > 128) {      // the final scan would read VP / VN bits beyond the two words (the reference then indexes the neighbouring vectors of its bit_extz_t)
-			hao_set_err(c, "hao_window_ed_batch: task " + std::to_string(i) + ": p_len - t_len + abs_diag > 128 with a two-word band"); return HAO_EINVAL; }
-		if (2 * (uint64_t)t.thre + 1 > 64) wide = true;
+			t.thre > HAO_ED_MAX_THRE || t.abs_diag > 2 * t.thre) { hao_set_err(c, "hao_window_ed_batch: task " + std::to_string(i) + " out of range"); return HAO_EINVAL; }
+		const uint32_t nw = hao_al_nword(t.thre);
+		if (nw > 1 && (int64_t)t.p_len - (int64_t)t.t_len + (int64_t)t.abs_diag > 64 * (int64_t)nw) {      // the final scan would read VP / VN bits beyond the band's words (the reference then indexes the neighbouring vectors of its bit_extz_t)
+			hao_set_err(c, "hao_window_ed_batch: task " + std::to_string(i) + ": p_len - t_len + abs_diag beyond the band's words"); return HAO_EINVAL; }
+		words |= 1u << (nw - 1);
 	}
 	HIP_TRY(hipSetDevice(c->device));
 	if (int rc = hao_al_upload_sorted(c, tasks, n_tasks)) return rc;
@@ -273,9 +313,10 @@ int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks
 	DevBuf<hao_ed_task_t> &dt = c->al_task; DevBuf<uint32_t> &order = c->al_order; DevBuf<hao_ed_result_t> &dr = c->al_res;
 	const hao_ed_reads R = hao_al_reads_of(c);
 	const dim3 g_((unsigned)((n_tasks + 255) / 256)), b_(256);
-	hipLaunchKernelGGL((hao_al_kernel<uint64_t, HAO_AL_ED, false>), g_, b_, 0, c->stream, R, dt.p, order.p, n_tasks, (uint64_t*)nullptr, (uint64_t)0, dr.p, (hao_trace_result_t*)nullptr, (uint8_t*)nullptr, (uint16_t*)nullptr, 0u);
-	if (wide) { HAO_CHECK_LAUNCH(); hipLaunchKernelGGL((hao_al_kernel<hao_u128, HAO_AL_ED, false>), g_, b_, 0, c->stream, R, dt.p, order.p, n_tasks, (uint64_t*)nullptr, (uint64_t)0, dr.p, (hao_trace_result_t*)nullptr, (uint8_t*)nullptr, (uint16_t*)nullptr, 0u); }
-	HAO_CHECK_LAUNCH();
+	if (words & 1u) { hipLaunchKernelGGL((hao_al_kernel<uint64_t, HAO_AL_ED, false>), g_, b_, 0, c->stream, R, dt.p, order.p, n_tasks, (uint64_t*)nullptr, (uint64_t)0, dr.p, (hao_trace_result_t*)nullptr, (uint8_t*)nullptr, (uint16_t*)nullptr, 0u); HAO_CHECK_LAUNCH(); }
+	if (words & 2u) { hipLaunchKernelGGL((hao_al_kernel<hao_u128, HAO_AL_ED, false>), g_, b_, 0, c->stream, R, dt.p, order.p, n_tasks, (uint64_t*)nullptr, (uint64_t)0, dr.p, (hao_trace_result_t*)nullptr, (uint8_t*)nullptr, (uint16_t*)nullptr, 0u); HAO_CHECK_LAUNCH(); }
+	if (words & 4u) { hipLaunchKernelGGL((hao_al_kernel<hao_wide<3>, HAO_AL_ED, false>), g_, b_, 0, c->stream, R, dt.p, order.p, n_tasks, (uint64_t*)nullptr, (uint64_t)0, dr.p, (hao_trace_result_t*)nullptr, (uint8_t*)nullptr, (uint16_t*)nullptr, 0u); HAO_CHECK_LAUNCH(); }
+	if (words & 8u) { hipLaunchKernelGGL((hao_al_kernel<hao_wide<4>, HAO_AL_ED, false>), g_, b_, 0, c->stream, R, dt.p, order.p, n_tasks, (uint64_t*)nullptr, (uint64_t)0, dr.p, (hao_trace_result_t*)nullptr, (uint8_t*)nullptr, (uint16_t*)nullptr, 0u); HAO_CHECK_LAUNCH(); }
 	HIP_TRY(hipMemcpyAsync(out, dr.p, n_tasks * sizeof(hao_ed_result_t), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	return HAO_OK;
@@ -288,12 +329,12 @@ int hao_window_trace_batch(hao_ctx *c, int mode, const hao_ed_task_t *tasks, uin
 	if (hao_is_sharded(c)) { hao_set_err(c, "hao_window_trace_batch needs the bases of both reads: single-device mode only"); return HAO_EUNSUPP; }
 	if (n_tasks == 0) return HAO_OK;
 	if (n_tasks >= (1ULL << 32)) { hao_set_err(c, "hao_window_trace_batch: more than 2^32 tasks in one call"); return HAO_EUNSUPP; }
-	uint64_t tn_max = 1; bool wide = false;      // wide: some band needs two 64-bit words (thre 32 .. 63)
+	uint64_t tn_max = 1; uint32_t words = 0;      // bit (nword - 1): some band needs nword 64-bit words
 	for (uint64_t i = 0; i < n_tasks; ++i) {      // the reference indexes its strings unchecked; a device kernel must not
 		const hao_ed_task_t &t = tasks[i];
 		if (t.p_rid >= c->n_reads || t.t_rid >= c->n_reads || (uint64_t)t.p_pos + t.p_len > c->h_len[t.p_rid] || (uint64_t)t.t_pos + t.t_len > c->h_len[t.t_rid] ||
-			2 * (uint64_t)t.thre + 1 > 127) { hao_set_err(c, "hao_window_trace_batch: task " + std::to_string(i) + " out of range"); return HAO_EINVAL; }
-		if (2 * (uint64_t)t.thre + 1 > 64) wide = true;
+			t.thre > HAO_ED_MAX_THRE) { hao_set_err(c, "hao_window_trace_batch: task " + std::to_string(i) + " out of range"); return HAO_EINVAL; }
+		words |= 1u << (hao_al_nword(t.thre) - 1);
 		if (mode == HAO_ALIGN_SEMI) {
 			const int64_t ai = (int64_t)t.p_len - (int64_t)t.t_len + (int64_t)t.abs_diag;
 			if (ai < 0 || ai > 2 * (int64_t)t.thre || t.t_len <= t.abs_diag || t.abs_diag > 2 * t.thre) { hao_set_err(c, "hao_window_trace_batch: task " + std::to_string(i) + ": the band does not cover the pattern"); return HAO_EINVAL; }
@@ -305,17 +346,19 @@ int hao_window_trace_batch(hao_ctx *c, int mode, const hao_ed_task_t *tasks, uin
 	DevBuf<hao_ed_task_t> &dt = c->al_task; DevBuf<uint32_t> &order = c->al_order; DevBuf<hao_trace_result_t> &dr = c->al_tres; DevBuf<uint16_t> &dc = c->al_cig; DevBuf<uint8_t> &want = c->al_want;
 	HIP_TRY(dr.reserve(n_tasks)); HIP_TRY(want.reserve(n_tasks)); HIP_TRY(dc.reserve(n_tasks * (uint64_t)cigar_cap + 1));
 	HIP_TRY(hipMemsetAsync(want.p, 0, n_tasks, c->stream));
+	if (cigar_cap) HIP_TRY(hipMemsetAsync(dc.p, 0, n_tasks * (uint64_t)cigar_cap * 2, c->stream));      // tasks without an alignment get no cigar: their rows read as zeros, not as an earlier call's entries
 	const hao_ed_reads R = hao_al_reads_of(c);
 	int rc;
-	if (mode == HAO_ALIGN_EXT_FWD) rc = hao_al_trace_run<HAO_AL_EXT_FWD>(c, R, dt.p, order.p, n_tasks, wide, tn_max, dr.p, want.p, dc.p, cigar_cap);
-	else if (mode == HAO_ALIGN_EXT_BWD) rc = hao_al_trace_run<HAO_AL_EXT_BWD>(c, R, dt.p, order.p, n_tasks, wide, tn_max, dr.p, want.p, dc.p, cigar_cap);
-	else if (mode == HAO_ALIGN_SEMI) rc = hao_al_trace_run<HAO_AL_SEMI>(c, R, dt.p, order.p, n_tasks, wide, tn_max, dr.p, want.p, dc.p, cigar_cap);
-	else rc = hao_al_trace_run<HAO_AL_GLOBAL>(c, R, dt.p, order.p, n_tasks, wide, tn_max, dr.p, want.p, dc.p, cigar_cap);
+	if (mode == HAO_ALIGN_EXT_FWD) rc = hao_al_trace_run<HAO_AL_EXT_FWD>(c, R, dt.p, order.p, n_tasks, words, tn_max, dr.p, want.p, dc.p, cigar_cap);
+	else if (mode == HAO_ALIGN_EXT_BWD) rc = hao_al_trace_run<HAO_AL_EXT_BWD>(c, R, dt.p, order.p, n_tasks, words, tn_max, dr.p, want.p, dc.p, cigar_cap);
+	else if (mode == HAO_ALIGN_SEMI) rc = hao_al_trace_run<HAO_AL_SEMI>(c, R, dt.p, order.p, n_tasks, words, tn_max, dr.p, want.p, dc.p, cigar_cap);
+	else rc = hao_al_trace_run<HAO_AL_GLOBAL>(c, R, dt.p, order.p, n_tasks, words, tn_max, dr.p, want.p, dc.p, cigar_cap);
 	if (rc) return rc;
 	HIP_TRY(hipMemcpyAsync(out, dr.p, n_tasks * sizeof(hao_trace_result_t), hipMemcpyDeviceToHost, c->stream));
 	if (cigar_cap) HIP_TRY(hipMemcpyAsync(cigars, dc.p, n_tasks * (uint64_t)cigar_cap * 2, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	if (c->al_path.cap > (1ULL << 27)) c->al_path.release();      // (more than 1 GB of column scratch is not kept between calls)
+	if (c->al_cig.cap > (1ULL << 29)) c->al_cig.release();        // (nor more than 1 GB of cigar rows)
 	return HAO_OK;
 }
 

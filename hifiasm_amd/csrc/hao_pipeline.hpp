@@ -145,8 +145,11 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 			HAO_CHECK_LAUNCH();
 			c->timer.mark("sk_gather");
 			HIP_TRY(c->d_new_n.reserve(n_sel + 2)); HIP_TRY(hipMemsetAsync(c->d_new_n.p + n_sel, 0, 4, c->stream));
-			if (c->sw.sk_select2) {      // the wave-parallel thinning (hao_select2.cuh): checked on the CPU only so far, opt-in until it has run on a GPU
-				hipLaunchKernelGGL(sketch_select2_kernel, dim3((unsigned)n_sel), dim3(64), 0, c->stream, c->d_g_x.p, c->d_g_info.p, c->d_g_ord.p, c->d_g_off.p,
+			if (c->sw.sk_select2) {      // the wave-parallel thinning (hao_select2.cuh), one wave per read: reads of up to 512 candidates (30 KB of LDS per wave), then the longer ones
+				hipLaunchKernelGGL(sketch_select2_kernel<HAO_S2_CAP_SMALL>, dim3((unsigned)n_sel), dim3(64), 0, c->stream, c->d_g_x.p, c->d_g_info.p, c->d_g_ord.p, c->d_g_off.p,
+								   c->d_len.p, c->d_tot_l.p, lo, n_sel, sample_dist, c->opt.rewin, k, c->d_new_n.p, c->d_err.p);
+				HAO_CHECK_LAUNCH();
+				hipLaunchKernelGGL(sketch_select2_kernel<HAO_S2_CAP>, dim3((unsigned)n_sel), dim3(64), 0, c->stream, c->d_g_x.p, c->d_g_info.p, c->d_g_ord.p, c->d_g_off.p,
 								   c->d_len.p, c->d_tot_l.p, lo, n_sel, sample_dist, c->opt.rewin, k, c->d_new_n.p, c->d_err.p);
 			} else {
 				hipLaunchKernelGGL(sketch_select_kernel, dim3((unsigned)((n_sel + 3) / 4)), dim3(256), 0, c->stream, c->d_g_x.p, c->d_g_info.p, c->d_g_ord.p, c->d_g_off.p,

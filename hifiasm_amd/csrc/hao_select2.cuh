@@ -6,13 +6,12 @@
 // entry i from the first full window on (that first window is [0, i0]), plus the tail windows [s, n - 1] while ord[s] + w <= tot_l + 1.  Marked candidates
 // of a run (a stretch of high-count candidates) long enough to be sampled survive; a run without any takes its min(16, q) smallest through the reference's
 // heap; candidates that are not high-count always survive.
-// Here one WAVE owns a read (its <= 1024 candidates in LDS): keys are replaced by their rank (bitonic sort of 16-bit indices), window starts are a binary
+// Here one WAVE owns a read (its <= 1024 candidates in LDS; reads of <= 512 candidates - a 15 kb read has ~430 - run in an instantiation with half the arrays: 5 waves per CU instead of 2): keys are replaced by their rank (bitonic sort of 16-bit indices), window starts are a binary
 // search per entry, window minima a sparse-table range-min, the "maximum of the minima of my windows" a second sparse table, runs are walked by the lane
 // that owns their first entry, survivors are compacted by ballots.  Reads the closed form does not cover - more than 1024 candidates, k-mer ordinals that
 // restart (N bases), a window of more than 128 candidates - take the sequential routine.
-// OPT-IN (HAO_SK_SELECT2=1): written and checked on the CPU in round 3 - tests/sel2_model.cpp compiles the element functions below with g++ and walks the kernel's
-// phases with loops, tests/test_select_model_cpu.py compares with the oracle (and, off-line, 3 274 reads of the benched repeat-rich workload: 1 299 thinned, 17 left to
-// the sequential routine, no mismatch) - but it has not run on a GPU, so sketch_select_kernel stays the default.  First build: 257 VGPRs, 60 KB of LDS per wave.
+// tests/sel2_model.cpp compiles the element functions below with g++ and walks the kernel's phases with loops, tests/test_select_model_cpu.py compares with the
+// oracle on the CPU; tests/test_gpu_zz_new.py compares both thinning kernels (HAO_SK_SELECT1 / HAO_SK_SELECT2) with the oracle and the reference's digests on the device.
 #pragma once
 #include <stdint.h>
 #ifdef HAO_SEL2_HOST_MODEL
@@ -22,7 +21,8 @@
 #define HAO_S2_FN __host__ __device__ __forceinline__
 #endif
 
-#define HAO_S2_CAP 1024
+#define HAO_S2_CAP 1024         // most candidates of a read the closed form takes (two launches: reads of up to HAO_S2_CAP_SMALL candidates in 30 KB of LDS, the longer ones in 61 KB)
+#define HAO_S2_CAP_SMALL 512
 #define HAO_S2_LOG 7            // windows of up to 1 << HAO_S2_LOG candidates
 #define HAO_S2_ZERO 0xfffeu     // rank of every candidate that is not high-count: above every real rank
 #define HAO_S2_PAD 0xffffu      // index of a padding slot of the sort
@@ -31,7 +31,7 @@ struct hao_s2_view {
 	uint64_t *x, *info; uint32_t *ord;                 // the read's candidates, info.rid = filter-table count (0: not high-count); survivors are compacted in place
 	uint16_t *idx, *rank, *start, *wm, *mn, *mx;       // [CAP] sort permutation, rank, window start, window minimum; [(LOG + 1) * CAP] sparse tables (min of rank, max of wm)
 	uint8_t *flag;                                     // [CAP] bit 0: marked, bit 1: kept
-	int n, P;                                          // candidates; P = power of two >= n (sort width)
+	int n, P, cap;                                     // candidates; P = power of two >= n (sort width); cap = capacity of the arrays = stride of the sparse tables' levels
 	int len, sample_dist, w, k, tot_l;
 };
 HAO_S2_FN uint32_t hao_s2_cnt(const hao_s2_view &V, int i) { return (uint32_t)(V.info[i] & 0xfffffffu); }
@@ -80,15 +80,15 @@ HAO_S2_FN bool hao_s2_first_window(const hao_s2_view &V, int i)
 	return oi >= ws || (i + 1 < V.n && oi < ws && (int64_t)V.ord[i + 1] > ws) || (i + 1 == V.n && (int64_t)V.tot_l >= ws && oi < ws);
 }
 // sparse tables: level L (>= 1) of table t from level L - 1; op = min (is_max false) / max
-HAO_S2_FN void hao_s2_level(uint16_t *t, int n, int L, int i, bool is_max)
+HAO_S2_FN void hao_s2_level(uint16_t *t, int cap, int n, int L, int i, bool is_max)
 {
-	const int h = 1 << (L - 1); const uint16_t a = t[(L - 1) * HAO_S2_CAP + i], b = i + h < n ? t[(L - 1) * HAO_S2_CAP + i + h] : a;
-	t[L * HAO_S2_CAP + i] = is_max ? (a > b ? a : b) : (a < b ? a : b);
+	const int h = 1 << (L - 1); const uint16_t a = t[(L - 1) * cap + i], b = i + h < n ? t[(L - 1) * cap + i + h] : a;
+	t[L * cap + i] = is_max ? (a > b ? a : b) : (a < b ? a : b);
 }
-HAO_S2_FN uint16_t hao_s2_query(const uint16_t *t, int a, int b, bool is_max)      // over [a, b], b - a + 1 <= 1 << HAO_S2_LOG
+HAO_S2_FN uint16_t hao_s2_query(const uint16_t *t, int cap, int a, int b, bool is_max)      // over [a, b], b - a + 1 <= 1 << HAO_S2_LOG
 {
 	int j = 0; while ((2 << j) <= b - a + 1) ++j;
-	const uint16_t u = t[j * HAO_S2_CAP + a], v = t[j * HAO_S2_CAP + b - (1 << j) + 1];
+	const uint16_t u = t[j * cap + a], v = t[j * cap + b - (1 << j) + 1];
 	return is_max ? (u > v ? u : v) : (u < v ? u : v);
 }
 HAO_S2_FN int hao_s2_wstart(const hao_s2_view &V, int i, int i0) { return i == i0 ? 0 : (int)V.start[i]; }
@@ -98,7 +98,7 @@ HAO_S2_FN bool hao_s2_window_min(const hao_s2_view &V, int i, int i0)
 	if (i0 < 0 || i < i0) { V.wm[i] = 0; return true; }
 	const int a = hao_s2_wstart(V, i, i0);
 	if (i - a + 1 > (1 << HAO_S2_LOG)) { V.wm[i] = 0; return false; }
-	V.wm[i] = hao_s2_query(V.mn, a, i, false);
+	V.wm[i] = hao_s2_query(V.mn, V.cap, a, i, false);
 	return true;
 }
 // last start s of a tail window [s, n - 1] (s_last - 1: none): tail windows exist while ord[s] + w <= tot_l + 1
@@ -116,8 +116,8 @@ HAO_S2_FN void hao_s2_mark(const hao_s2_view &V, int j, int i0, int s_last, int 
 	const int lo = j > i0 ? j : i0;
 	int a = lo, b = V.n - 1, hi = lo - 1;      // last i >= lo whose window still starts at or before j
 	while (a <= b) { const int m = (a + b) >> 1; if (hao_s2_wstart(V, m, i0) <= j) { hi = m; a = m + 1; } else b = m - 1; }
-	uint16_t cand = hi >= lo ? hao_s2_query(V.mx, lo, hi, true) : 0;
-	if (tail_hi >= s_last && j >= s_last) { const uint16_t t = hao_s2_query(V.mn, j < tail_hi ? j : tail_hi, V.n - 1, false); if (t > cand) cand = t; }
+	uint16_t cand = hi >= lo ? hao_s2_query(V.mx, V.cap, lo, hi, true) : 0;
+	if (tail_hi >= s_last && j >= s_last) { const uint16_t t = hao_s2_query(V.mn, V.cap, j < tail_hi ? j : tail_hi, V.n - 1, false); if (t > cand) cand = t; }
 	if (cand == V.rank[j]) V.flag[j] = 1;
 }
 
@@ -165,26 +165,28 @@ HAO_S2_FN void hao_s2_finish_run(const hao_s2_view &V, int i, int e, int span, i
 __device__ __attribute__((noinline)) int hao_s2_sequential(uint64_t *x, uint64_t *info, uint32_t *ord, int n, int len, int sample_dist, int rewin, int k, int tot_l)
 { hao_sel_view v; v.n = n; v.x = x; v.info = info; v.ord = ord; return hao_select_high(v, len, sample_dist, rewin, k, tot_l); }
 #define HAO_S2_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+template<int CAP>      // candidates per read this instantiation stages: reads of (CAP / 2, CAP] (the smallest CAP: [0, CAP]; the largest CAP also takes the longer reads, sequentially)
 __global__ __launch_bounds__(64) void sketch_select2_kernel(uint64_t *x, uint64_t *info, uint32_t *ord, const uint64_t *mz_off, const uint32_t *len, const uint32_t *tot_l,
 		uint64_t rid_lo, uint64_t n_sel, int sample_dist, int rewin, int k, uint32_t *new_n, const int *err)
 {
 	if (*err) return;
-	__shared__ uint64_t l_x[HAO_S2_CAP], l_info[HAO_S2_CAP]; __shared__ uint32_t l_ord[HAO_S2_CAP];
-	__shared__ uint16_t l_idx[HAO_S2_CAP], l_rank[HAO_S2_CAP], l_start[HAO_S2_CAP], l_wm[HAO_S2_CAP], l_mn[(HAO_S2_LOG + 1) * HAO_S2_CAP], l_mx[(HAO_S2_LOG + 1) * HAO_S2_CAP];
-	__shared__ uint8_t l_flag[HAO_S2_CAP]; __shared__ int s_i0, s_bad, s_anyq;
+	__shared__ uint64_t l_x[CAP], l_info[CAP]; __shared__ uint32_t l_ord[CAP];
+	__shared__ uint16_t l_idx[CAP], l_rank[CAP], l_start[CAP], l_wm[CAP], l_mn[(HAO_S2_LOG + 1) * CAP], l_mx[(HAO_S2_LOG + 1) * CAP];
+	__shared__ uint8_t l_flag[CAP]; __shared__ int s_i0, s_bad, s_anyq;
 	const int lane = threadIdx.x;
 	const uint64_t r = blockIdx.x;
 	if (r >= n_sel) return;
 	const uint64_t o = mz_off[r]; const int n = (int)(mz_off[r + 1] - o);
+	if ((CAP < HAO_S2_CAP && n > CAP) || (CAP > HAO_S2_CAP_SMALL && n <= CAP / 2)) return;      // the other instantiation's read
 	int any = 0;
 	for (int i = lane; i < n; i += 64) if ((info[o + i] & 0xfffffffu) > 0) any = 1;
 	if (!__any(any)) { if (lane == 0) new_n[r] = (uint32_t)n; return; }
-	const bool in_lds = n <= HAO_S2_CAP;
+	const bool in_lds = n <= CAP;
 	if (in_lds) for (int i = lane; i < n; i += 64) { l_x[i] = x[o + i]; l_info[i] = info[o + i]; l_ord[i] = ord[o + i]; }
 	if (lane == 0) { s_i0 = n; s_bad = in_lds ? 0 : 1; s_anyq = 0; }
 	HAO_S2_SYNC();
 	hao_s2_view V; V.x = l_x; V.info = l_info; V.ord = l_ord; V.idx = l_idx; V.rank = l_rank; V.start = l_start; V.wm = l_wm; V.mn = l_mn; V.mx = l_mx; V.flag = l_flag;
-	V.n = n; V.len = (int)len[rid_lo + r]; V.sample_dist = sample_dist; V.w = rewin; V.k = k; V.tot_l = (int)tot_l[r];
+	V.n = n; V.cap = CAP; V.len = (int)len[rid_lo + r]; V.sample_dist = sample_dist; V.w = rewin; V.k = k; V.tot_l = (int)tot_l[r];
 	int P = 64; while (P < n) P <<= 1; V.P = P;
 	if (in_lds) {
 		// ordinals must ascend; the runs' quotas; the first full window
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(64) void sketch_select2_kernel(uint64_t *x, uint64_
 		// window starts, the sparse table of ranks, window minima, their sparse table
 		for (int i = lane; i < n; i += 64) { hao_s2_start(V, i); l_mn[i] = l_rank[i]; }
 		HAO_S2_SYNC();
-		for (int L = 1; L <= HAO_S2_LOG; ++L) { for (int i = lane; i < n; i += 64) hao_s2_level(l_mn, n, L, i, false); HAO_S2_SYNC(); }
+		for (int L = 1; L <= HAO_S2_LOG; ++L) { for (int i = lane; i < n; i += 64) hao_s2_level(l_mn, CAP, n, L, i, false); HAO_S2_SYNC(); }
 		int bad = 0;
 		for (int i = lane; i < n; i += 64) { if (!hao_s2_window_min(V, i, i0)) bad = 1; l_mx[i] = l_wm[i]; }
 		if (__any(bad)) {      // a window beyond the tables: sequential routine (the staged list is untouched so far)
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(64) void sketch_select2_kernel(uint64_t *x, uint64_
 			return;
 		}
 		HAO_S2_SYNC();
-		for (int L = 1; L <= HAO_S2_LOG; ++L) { for (int i = lane; i < n; i += 64) hao_s2_level(l_mx, n, L, i, true); HAO_S2_SYNC(); }
+		for (int L = 1; L <= HAO_S2_LOG; ++L) { for (int i = lane; i < n; i += 64) hao_s2_level(l_mx, CAP, n, L, i, true); HAO_S2_SYNC(); }
 		const int s_last = n - 1 > i0 ? (int)l_start[n - 1] : 0, tail_hi = hao_s2_tail_hi(V, s_last);
 		for (int j = lane; j < n; j += 64) hao_s2_mark(V, j, i0, s_last, tail_hi);
 	} else for (int j = lane; j < n; j += 64) l_flag[j] = 0;

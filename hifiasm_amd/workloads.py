@@ -13,6 +13,7 @@ WORKLOADS = {
     "bacterial5M_hifi30x_repeat": (5_000_000, 30, 15000, 0.001, 1, 0),     # its repeat-rich variant
     "chr2M_hifi30x": (2_000_000, 30, 15000, 0.001, 0, 0),                  # stand-in for configs[0] (chr11-2M.fa.gz is not in the image)
     "chr1_250M_hifi30x": (250_000_000, 30, 15000, 0.001, 0, 0),            # configs[2]: the largest single-GPU configuration
+    "chr1_250M_hifi30x_repeat": (250_000_000, 30, 15000, 0.001, 1, 0),     # configs[2] with the SURVEY 8d repeat recipe (125 units: half of the genome sits in 25-copy families)
     "human3G_hifi40x": (3_000_000_000, 40, 15000, 0.001, 0, 0),            # configs[3]: 8 M reads of 15 kb, sharded over 8 GPUs
     "ont5M_30x": (5_000_000, 30, 30000, 0.01, 0, 1),
     "ont50M_30x": (50_000_000, 30, 30000, 0.01, 0, 1),                     # 50 000 ONT reads: the full-size parity case of --ont mode

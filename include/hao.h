@@ -214,11 +214,14 @@ int hao_fetch_exact(hao_ctx *c, uint64_t rid, const uint8_t **flags, uint64_t *n
  * (pattern, text) pairs taken from the reads resident in HBM - the call Correct.cpp:3897,4092,4156 makes per 775-base query window and candidate:
  * pattern = the padded target region [p_pos, p_pos + p_len) of read p_rid on strand p_rev, text = the query window [t_pos, t_pos + t_len) of read
  * t_rid on strand t_rev, thre = error threshold, abs_diag = leading diagonals missing because the pattern was clipped at the start of its read.
- * Band width: 2 thre + 1 diagonals in one 64-bit word (thre <= 31) or in two (thre 32 .. 63: the reference's ed_band_cal_*_128_* functions, generated
- * from the same text by HA_ED_INIT(128), :1287-2129, and chosen by band width, cal_exz_global Correct.cpp:15482-15494); wider bands: HAO_EINVAL.  With
- * a two-word band p_len - t_len + abs_diag <= 128 is required (beyond it the reference's final scan indexes past its two words).  out[i].err = edit distance or INT32_MAX (no alignment within thre, the reference's clear_align state), out[i].pe = end of the
+ * Band width: 2 thre + 1 diagonals in one 64-bit word (thre <= 31), in two (thre 32 .. 63: the reference's ed_band_cal_*_128_* functions, generated
+ * from the same text by HA_ED_INIT(128), :1287-2129, and chosen by band width, cal_exz_global Correct.cpp:15482-15494), or in nword = 3 / 4 words
+ * (thre 64 .. 95 / 96 .. 127: the reference's ed_band_cal_*_infi_* functions, :2134-3100, which cal_exz_infi calls with nword = ceil((2 thre + 1) / 64),
+ * Correct.cpp:14508-14565); thre > HAO_ED_MAX_THRE: HAO_EINVAL.  With a band of two or more words p_len - t_len + abs_diag <= 64 nword is required
+ * (beyond it the reference's final scan indexes past its band words).  out[i].err = edit distance or INT32_MAX (no alignment within thre, the reference's clear_align state), out[i].pe = end of the
  * alignment on the pattern or -1; ps = -1, ts = 0, te = t_len - 1 are constants of the call.  One lane per pair; single-device mode (the bases of
  * both reads must be local).  This is the data-parallel core of the window alignment; window placement and retries stay with the caller. */
+#define HAO_ED_MAX_THRE 127     /* widest band: 255 diagonals in four 64-bit words */
 typedef struct { uint32_t p_rid, p_pos, p_len, p_rev, t_rid, t_pos, t_len, t_rev, thre, abs_diag; } hao_ed_task_t;
 typedef struct { int32_t err, pe; } hao_ed_result_t;
 int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks, hao_ed_result_t *out);
@@ -228,8 +231,8 @@ int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks
  * Same task records (abs_diag is ignored); both strings are consumed entirely, so |p_len - t_len| <= thre or there is no alignment.  Per task: err
  * (INT32_MAX = none within thre; then pe = te = -1 and no cigar), ps = ts = 0, pe = p_len - 1, te = t_len - 1, and the cigar in push_trace's encoding
  * (uint16: op << 14 | len; op 0 match, 1 mismatch, 2 more pattern, 3 more text) at cigars + i * cigar_cap; n_cigar entries exist, those past cigar_cap
- * are not written (an alignment within thre has at most 2 thre + 3 entries for strings shorter than 16 383: 129 for the widest band).  Band widths as for
- * hao_window_ed_batch (thre <= 63). */
+ * are not written (an alignment within thre has at most 2 thre + 3 entries for strings shorter than 16 383: 257 for the widest band).  Band widths as for
+ * hao_window_ed_batch (thre <= HAO_ED_MAX_THRE). */
 typedef struct { int32_t err, ps, pe, ts, te, n_cigar; } hao_trace_result_t;
 #define HAO_ALIGN_GLOBAL 0      /* ed_band_cal_global_64_w_trace */
 #define HAO_ALIGN_EXT_FWD 1     /* ed_band_cal_extension_64_0_w_trace (:3512-3618): both strings start together, the alignment ends where the pattern or the text runs out (the
@@ -267,6 +270,11 @@ int hao_index_load(hao_ctx *c, const char *prefix, int32_t *number_of_round);
  * EVERY read of a 500 000-read pass with the reference (oracle/ref_harness.cpp --digest computes the same value from the reference's
  * own overlap_region / Candidates_list after h_ec_lchain, anchor.cpp:2302). */
 int hao_batch_digest(hao_ctx *c, uint64_t *out, uint64_t *out_kh);
+/* The same out[r] for every read of a DELIVERED batch (needs HAO_DELIVER_OL | HAO_DELIVER_CL), computed on the host from what landed in the pinned arena:
+ * ol->list, the fake cigars, and cl->list decoded out of the wire format by hao_unpack_hits.  A pure function of the view (any thread, while the slot is
+ * not being rewritten); the reads are spread over n_threads host threads.  What crossed PCIe can thus be compared, read by read, with the device's own
+ * digest or with the reference's (tests/test_gpu_fullgold.py does it for all 500 000 reads of configs[2]; bench.py for the batches it delivers). */
+int hao_delivery_digest(const hao_delivery_t *d, uint64_t *out, int n_threads);
 
 /* Device self-test of the record grouping used by the sharded index build (pins a rocPRIM bit-range sort behaviour, see hao_capi_rest.hpp):
  * out[0] = order violations of the begin_bit = 48 sort, out[1] = of the path the engine uses (must be 0). */

@@ -45,6 +45,8 @@ static hao_pass_t g_ps; static bool g_ps_valid = false; static uint64_t g_ps_gen
 static int64_t g_computing = -1;                 // batch some worker is computing right now (the engine runs one batch at a time)
 static uint64_t g_bsz = 0;
 static pthread_cond_t g_cv = PTHREAD_COND_INITIALIZER;
+static uint64_t g_n_reads = 0; static int64_t g_prefetch = -1; static bool g_producer_on = false, g_lookahead = true;
+static int64_t g_hi_batch = -1;                  // highest batch a worker has asked for in the current pass: only that one triggers a look-ahead
 
 static void die(const char *msg) { fprintf(stderr, "[hao-shim] ERROR: %s%s%s\n", msg, g_hao ? ": " : "", g_hao ? hao_last_error(g_hao) : ""); exit(1); }
 #define CK(x) do { if ((x) != 0) die(#x); } while (0)
@@ -115,10 +117,24 @@ static void upload_reads(All_reads *rs)
 	g_reads_uploaded = true;
 }
 
+// Between passes the main thread rewrites the read store and rebuilds the tables on the same hao_ctx the look-ahead thread computes batches on: before any
+// such call, cancel the look-ahead request nobody has started, invalidate the pass (the producer does not start another batch) and wait until the batch in
+// flight, if any, has landed and every reader has left its slot.  (kt_for has returned by then, so no worker is inside h_ec_lchain; a look-ahead started
+// by the last reads of the pass may still be running.)
+static void quiesce_server()
+{
+	pthread_mutex_lock(&g_mu);
+	g_prefetch = -1; g_ps_valid = false;
+	while (g_computing >= 0 || g_slot[0].readers || g_slot[1].readers) pthread_cond_wait(&g_cv, &g_mu);
+	for (int x = 0; x < 2; ++x) { g_slot[x].batch = -1; g_slot[x].ready = false; }
+	pthread_mutex_unlock(&g_mu);
+}
+
 void *ha_ft_gen(const hifiasm_opt_t *asm_opt, All_reads *rs, int *hom_cov, int is_hp_mode, int read_from_store)
 {
 	if (is_hp_mode) die("hp mode is not replaced by the device path");
 	ensure_ctx(asm_opt);
+	quiesce_server();
 	if (!read_from_store) load_reads(asm_opt, rs);
 	upload_reads(rs);
 	int32_t hc = -1;
@@ -133,6 +149,7 @@ ha_pt_t *ha_pt_gen(const hifiasm_opt_t *asm_opt, const void *flt_tab, int read_f
 {
 	if (is_hp_mode) die("hp mode is not replaced by the device path");
 	ensure_ctx(asm_opt);
+	quiesce_server();
 	if (!read_from_store && rs->total_reads == 0) load_reads(asm_opt, rs);
 	if (read_from_store || !g_reads_uploaded || flt_tab == 0) upload_reads(rs);     // reads were rewritten by the previous round
 	int32_t hc = -1, ht = -1;
@@ -163,7 +180,6 @@ static_assert(sizeof(k_mer_hit) == sizeof(hao_hit_t), "k_mer_hit layout");
 static int find_slot(int64_t k) { for (int x = 0; x < 2; ++x) if (g_slot[x].batch == k && g_slot[x].ready) return x; return -1; }
 
 static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
-static uint64_t g_n_reads = 0; static int64_t g_prefetch = -1; static bool g_producer_on = false, g_lookahead = true;
 static double g_wait_s = 0, g_compute_s = 0; static uint64_t g_n_wait = 0, g_n_batches = 0, g_n_prefetched = 0;
 
 // Compute batch k of the current pass into the engine's next delivery slot (g_mu held on entry and exit; released around the device work).  The engine
@@ -226,7 +242,7 @@ void h_ec_lchain(ha_abuf_t *ab, uint32_t rid, char* rs, uint64_t rl, uint64_t mz
 	while (!g_ps_valid || g_ps_gen != g_index_gen || memcmp(&g_ps, &ps, sizeof(ps)) != 0) {
 		if (g_computing >= 0 || g_slot[0].readers || g_slot[1].readers) { pthread_cond_wait(&g_cv, &g_mu); continue; }
 		g_prefetch = -1;      // (a look-ahead request of the old pass that nobody has started)
-		g_ps = ps; g_ps_gen = g_index_gen; g_ps_valid = true;
+		g_ps = ps; g_ps_gen = g_index_gen; g_ps_valid = true; g_hi_batch = -1;
 		for (int x = 0; x < 2; ++x) { g_slot[x].batch = -1; g_slot[x].ready = false; }
 	}
 	const int64_t k = (int64_t)(rid / g_bsz);
@@ -241,7 +257,10 @@ void h_ec_lchain(ha_abuf_t *ab, uint32_t rid, char* rs, uint64_t rl, uint64_t mz
 	// look-ahead: kt_for hands out ascending read ids, so batch k + 1 is needed as soon as the workers are through with k - the first reader of k asks
 	// the producer thread for it now, and it computes + lands in the other arena while k is being decoded (without it every worker would finish k and
 	// then all of them would sit through the whole compute + copy of k + 1)
-	if (g_lookahead && (uint64_t)(k + 1) * g_bsz < n_reads && find_slot(k + 1) < 0 && g_computing != k + 1 && g_prefetch != k + 1) {
+	// Only the front of the pass looks ahead: a straggler that had to recompute an evicted batch j must not ask for j + 1 (already consumed) - that would
+	// evict a live batch and leave a stray computation running when kt_for returns.
+	const bool front = k >= g_hi_batch; if (front) g_hi_batch = k;
+	if (g_lookahead && front && (uint64_t)(k + 1) * g_bsz < n_reads && find_slot(k + 1) < 0 && g_computing != k + 1 && g_prefetch != k + 1) {
 		g_prefetch = k + 1;
 		if (!g_producer_on) { g_producer_on = true; pthread_t th; if (pthread_create(&th, NULL, producer_main, NULL) != 0) die("pthread_create"); pthread_detach(th); }
 		pthread_cond_broadcast(&g_cv);

@@ -5,27 +5,34 @@ unmodified hifiasm on the same reads, tests/golden/make_golden_big.py):
     sizes: 32 000 reads and the 62 500 reads bench.py runs with (~7.5e8 seed hits per batch, near the 2^32 / 8e8 sizing edge);
   * chr1_250M_hifi30x at -f37 (the reference's default Bloom filter, 28-bit block ids): the all-k-mer histogram, its peak and the filter table
     of ha_ft_gen's per-block replay on 5.6 G k-mer occurrences, then the same thresholds and a slice of the pass;
+  * chr1_250M_hifi30x_repeat: configs[2] with the SURVEY 8d repeat recipe (half of the genome in 25-copy families + tandem arrays): the realistic case;
   * ont50M_30x / ont5M_30x (--ont mode: 30 kb reads at 1 % error, bw 0.05: the chain DP path) and bacterial5M_hifi30x_repeat (repeat families +
     tandem arrays: filter table, minimizer thinning, max_n_chain pruning).
 
 Compared: coverage peaks / occurrence thresholds / max_n_chain, the minimizer count histogram, the totals of the pass, a digest of EVERY read's
 (ol, fake cigars, cl) and of every read's seed hits (hao_batch_digest, folded over blocks of 256 reads), and 256 sampled reads verbatim
-(minimizers, ol->list, fake cigars).  A slice cut differently must give the same per-read digests (batch-split invariance)."""
+(minimizers, ol->list, fake cigars).  A slice cut differently must give the same per-read digests (batch-split invariance).  The STREAMING pass
+(the one bench.py's `value` is quoted on) is compared through the bytes that landed in host memory: test_every_read_through_the_wire_format."""
 import zlib
 
 import numpy as np
 import pytest
 
-from helpers import load_golden, fold_digests, digest_result, digest_hits
+import os
+
+from helpers import load_golden, fold_digests, digest_result, digest_hits, GOLDEN
 
 pytestmark = pytest.mark.gpu
 #        workload, fixture suffix, engine options, batch sizes of the all-reads pass
 CASES = {
     "chr1": ("chr1_250M_hifi30x", "", {}, (32_000, 62_500)),
+    "chr1rr": ("chr1_250M_hifi30x_repeat", "", {}, (40_000,)),
     "ont50M": ("ont50M_30x", "", {"is_ont": 1}, (12_500,)),
     "ont5M": ("ont5M_30x", "", {"is_ont": 1}, (5_000,)),
     "repeat5M": ("bacterial5M_hifi30x_repeat", "", {}, (10_000, 3_333)),
 }
+# batch size of the STREAMING pass (hao_overlap_batch_async): what bench.py runs - ~8e8 seed hits per batch, a pass that fits one batch cut in two
+STREAM_BATCH = {"chr1": 62_500, "chr1rr": 40_000, "ont50M": 25_000, "ont5M": 2_500, "repeat5M": 5_000}
 _READS = {}
 
 
@@ -52,7 +59,10 @@ def _open(name, suffix, opts):
 @pytest.fixture(scope="module", params=list(CASES))
 def full(request):
     name, suffix, opts, batches = CASES[request.param]
+    if not os.path.exists(os.path.join(GOLDEN, name + suffix + ".npz")):
+        pytest.skip(f"no fixture tests/golden/{name}{suffix}.npz (tests/golden/make_golden_big.py)")
     e, rs, g, cov = _open(name, suffix, opts)
+    e.case = request.param
     yield e, rs, g, cov, batches
     e.close()
 
@@ -124,6 +134,47 @@ def test_every_read_against_the_reference(full):
     e.overlap_batch(lo, hi)
     d2, k2 = e.batch_digest(hi - lo)
     assert (d2 == ref[0][lo:hi]).all() and (k2 == ref[1][lo:hi]).all()
+
+
+def test_every_read_through_the_wire_format(full):
+    """The pass bench.py's `value` times: hao_overlap_batch_async -> hao_deliver_wait with the copy of batch i under the kernels of batch i + 1.  What
+    LANDED IN THE PINNED ARENA is digested on the host for every read (hao_delivery_digest: ol->list, fake cigars, and cl->list decoded out of the
+    position-addressed wire format by hao_unpack_hits) and compared with the reference's digests; the sampled reads are also compared verbatim."""
+    e, rs, g, _, _ = full
+    n, batch = rs.n, STREAM_BATCH[e.case]
+    sample = g["sample"].astype(np.int64)
+    dig = np.zeros(n, dtype=np.uint64)
+    tot = dict(ol=0, cl=0, exc=0, bytes=0)
+    bad = []
+
+    def consume(slot, lo, hi):
+        d = e.deliver_wait(slot)
+        assert (d.rid_lo, d.n_reads) == (lo, hi - lo)
+        dig[lo:hi] = e.delivery_digest(d)
+        tot["ol"] += int(d.n_ol); tot["cl"] += int(d.n_cl); tot["exc"] += int(d.n_exc); tot["bytes"] += int(d.bytes)
+        for i in np.flatnonzero((sample >= lo) & (sample < hi)):
+            r = int(sample[i])
+            ol, fc, fo, cl = e.delivered_read(d, r)
+            a, b = int(g["ol_off"][i]), int(g["ol_off"][i + 1])
+            gol = g["ol"][a:b]; gfc = g["fc"][int(g["fc_off"][a]):int(g["fc_off"][b])]
+            if not (ol.shape == gol.shape and (ol == gol).all() and fc.shape == gfc.shape and (fc == gfc).all()):
+                bad.append(("ol/fc", r))
+            if not (digest_result(ol, fc, cl) == dig[r] == g["dig_sample"][i, 0]):
+                bad.append(("digest", r))
+
+    pending = None
+    for lo in range(0, n, batch):
+        hi = min(n, lo + batch)
+        slot = e.overlap_batch_async(lo, hi)
+        if pending:
+            consume(*pending)
+        pending = (slot, lo, hi)
+    consume(*pending)
+    assert not bad, bad[:10]
+    assert tot["ol"] == g["meta"]["pass_overlaps"] and tot["cl"] == g["meta"]["pass_chained_hits"]
+    f = fold_digests(dig)
+    assert (f == g["dig_fold"]).all(), f"delivered results differ in read blocks {np.flatnonzero(f != g['dig_fold'])[:10]}"
+    print(f"[stream] {e.case}: {n} reads, {tot['cl']} chained hits ({tot['exc']} verbatim), {tot['bytes'] / 1e9:.2f} GB through the arena")
 
 
 def test_sampled_minimizers(full):
