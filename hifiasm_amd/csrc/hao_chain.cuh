@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 	uint64_t (*eb)[64] = l_eb[threadIdx.x >> 6]; uint32_t ce0 = 0, ce1 = 0;
 	const unsigned long long tq0 = A.dbg_qc ? wall_clock64() : 0;
 	const hao_gent e = list[li];                                  // wave-uniform: scalar loads
-	const uint64_t g = e.g, gs = e.start; const int64_t a_n = e.n;
+	const uint64_t g = e.g, gs = e.start; const int32_t a_n = (int32_t)e.n;      // (a group has < 2^31 hits: a batch has < 2^32 seed hits)
 	const hao_hit_t *a = A.hits + gs;
 	const uint32_t xid = (uint32_t)(A.rid_lo + e.r), yid = e.yid;
 	if (yid == xid || a_n <= 0) { if (lane == 0) { A.nch[g] = 0; A.nout[g] = 0; } return; }     // hits to the query itself are skipped (anchor.cpp:1931)
@@ -360,10 +360,10 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 	const uint32_t strand0 = HH_STRAND(first0);
 	// ---- parallel quick check ----
 	int32_t carry_f = 0; hao_hit_t carry_h = first0;
-	bool fail0 = false, fail1 = false; int32_t maxf0 = INT32_MIN, maxf1 = INT32_MIN, flast0 = 0, flast1 = 0; int64_t ddt0 = 0, ddt1 = 0, k1 = 0;
+	bool fail0 = false, fail1 = false; int32_t maxf0 = INT32_MIN, maxf1 = INT32_MIN, flast0 = 0, flast1 = 0, k1 = 0; int64_t ddt0 = 0, ddt1 = 0;
 	hao_hit_t last0 = first0, last1 = first0;
-	for (int64_t t0 = 0; t0 < a_n; t0 += 64) {
-		const int64_t idx = t0 + lane; const bool act = idx < a_n;
+	for (int32_t t0 = 0; t0 < a_n; t0 += 64) {
+		const int32_t idx = t0 + lane; const bool act = idx < a_n;
 		hao_hit_t h = act ? hn : carry_h;
 		const uint32_t q = qn;
 		if (idx + 64 < a_n) { hn = a[idx + 64]; if (hcg) qn = hqg[idx + 64]; }
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 		if (hcg) {      // wire code of this hit relative to the previous one of its strand block: minimizers skipped << 4 | diagonal shift + 8; 0xff = not expressible
 			const uint32_t pq = hao_wave_shr1(q, carry_q);
 			const int32_t dq = (int32_t)(q - pq), sh = (int32_t)((h.offset - ph.offset) - (h.self_offset - ph.self_offset));
-			const uint8_t code = st ? (uint8_t)0x08 : ((dq < 1 || dq > 15 || sh < -8 || sh > 7 || q == 65535u || (A.exc_every && idx % A.exc_every == A.exc_every - 1)) ? (uint8_t)0xff : (uint8_t)((dq - 1) << 4 | (sh + 8)));
+			const uint8_t code = st ? (uint8_t)0x08 : ((dq < 1 || dq > 15 || sh < -8 || sh > 7 || q == 65535u || (A.exc_every && (uint32_t)idx % A.exc_every == A.exc_every - 1)) ? (uint8_t)0xff : (uint8_t)((dq - 1) << 4 | (sh + 8)));
 			if (act) hcg[idx] = code;
 			carry_q = hao_bcast(q, 63);
 		}
@@ -414,14 +414,14 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 		int64_t ov1 = hao_ext_len(last1.self_offset, last1.self_offset, P.xl, last1.offset, last1.offset, P.yl);
 		if (flast1 >= flast0 && (flast1 > flast0 || ov1 < ov0)) { best = 1; msc = flast1; }
 	}
-	const int64_t bl = best ? k1 : 0, cL = best ? a_n - k1 : k1;
+	const int32_t bl = best ? k1 : 0, cL = best ? a_n - k1 : k1;
 	if (fast && A.par.mcopy_num > 1 && cL >= A.par.mcopy_khit_cut && two) {
 		int64_t min_sc = (int64_t)((double)msc * A.par.mcopy_rate);          // plus == 0 here: every f >= span > 0
 		if ((int64_t)(best ? maxf0 : maxf1) >= min_sc) fast = false;         // a second chain may qualify: exact sequential path
 	}
 	if (!fast) {
 		// the DP decides this group's chains: the codes written above describe none of them (a void 0xff would only become a useless verbatim-list entry)
-		if (hcg) for (int64_t i = lane; i < a_n; i += 64) hcg[i] = 0x08;
+		if (hcg) for (int32_t i = lane; i < a_n; i += 64) hcg[i] = 0x08;
 		if (lane == 0) { unsigned long long si_ = atomicAdd(A.stats + cls, 1ULL); atomicAdd(A.stats + HAO_NCLS, (unsigned long long)a_n); slow[si_] = (uint32_t)li; A.nch[g] = 0; A.nout[g] = 0; }
 		return;
 	}

@@ -58,7 +58,7 @@ struct StageTimer {
 struct hao_switches {
 	bool seedphase = false, qcphase = false, dp_stats = false, seq_chain = false, dp_seqtail = false, dp_nospec = false, dp_serial = false,
 		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, sk_v2 = false, dltime = false, sk_nofuse = false, pack_search = false, sk_select2 = false;
-	static constexpr bool SK_SELECT2_DEFAULT = false;      // which thinning kernel the sketch runs when the environment says nothing
+	static constexpr bool SK_SELECT2_DEFAULT = true;       // the thinning kernel the sketch runs when the environment says nothing: the wave kernel (round 4: green on the device against every repeat-rich scenario and the 5 Mb / 250 Mb repeat-rich fixtures)
 	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; int exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, seed_lds_pad = 0, arena_numa = 1, seed_tile = 512;
 	void load() {
 		auto on = [](const char *n) { return getenv(n) != nullptr; };
