@@ -15,7 +15,7 @@ struct hao_ctx::Batch {
 	DevBuf<hao_hit_t> hits, ohits, cl;
 	DevBuf<int32_t> f, ii, p, key_sc, tm; DevBuf<int64_t> t; DevBuf<uint64_t> key_xs; DevBuf<uint32_t> key_al, key_tmp;
 	DevBuf<hao_chain_rec> rec; DevBuf<hao_ovlp_t> ol; DevBuf<hao_cdesc> cd; bool cl_valid = false;
-	DevBuf<uint16_t> hq; DevBuf<uint8_t> hcode;      // delivery path: query minimizer index / wire code of every seed hit (seed kernel, chain_group_kernel)
+	DevBuf<uint16_t> hq, ohq; DevBuf<uint8_t> hcode;      // delivery path: query minimizer index / wire code of every seed hit (seed kernel, chain_group_kernel)
 	DevBuf<uint32_t> pk_cnt; uint64_t n_codes = 0;      // one code byte per chained hit (device only) before it is split into bits + code bytes
 	// Results of a batch that leave the device.  Two sets (+ two pinned host arenas): while the copy stream drains the set of batch i, batch i + 1
 	// computes into the other one (hao_overlap_batch_async).  The blocking API keeps using the current set.
@@ -40,7 +40,7 @@ struct hao_ctx::Batch {
 		s_start.release(); a_off.release(); seg.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fcf_off.release();
 		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); g_cls.release(); slow.release(); ovf_list.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
-		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); cd.release(); pk_cnt.release(); hq.release(); hcode.release(); out[0].release(); out[1].release();
+		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); cd.release(); pk_cnt.release(); hq.release(); ohq.release(); hcode.release(); out[0].release(); out[1].release();
 		if (dl_ready) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); for (int k = 0; k < n_aux; ++k) { (void)hipStreamSynchronize(copy_aux[k]); (void)hipStreamDestroy(copy_aux[k]); (void)hipEventDestroy(ev_aux[0][k]); (void)hipEventDestroy(ev_aux[1][k]); } for (int x = 0; x < 2; ++x) { (void)hipEventDestroy(ev_ready[x]); (void)hipEventDestroy(ev_done[x]); if (arena[x]) (void)hipHostFree(arena[x]); arena[x] = nullptr; arena_cap[x] = 0; } dl_ready = false; }
 	}
 };
@@ -253,7 +253,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	for (uint64_t r = lo; r < hi; ++r) max_q = std::max<uint64_t>(max_q, c->h_ix_mz_off[r + 1] - c->h_ix_mz_off[r]);
 	int tb = 1; while ((1ULL << tb) < c->n_total) ++tb;
 	HIP_TRY(B.g_cnt.reserve(n + 2)); HIP_TRY(B.g_off.reserve(n + 2)); HIP_TRY(B.g_tmp.reserve(A + 1));
-	HIP_TRY(B.stats.reserve(3 * HAO_NCLS + 4)); HIP_TRY(hipMemsetAsync(B.stats.p, 0, (3 * HAO_NCLS + 4) * 8, c->stream));
+	HIP_TRY(B.stats.reserve(3 * HAO_NCLS + 5)); HIP_TRY(hipMemsetAsync(B.stats.p, 0, (3 * HAO_NCLS + 5) * 8, c->stream));
 	unsigned long long *d_slow_cnt = B.stats.p, *d_cls_cnt = B.stats.p + HAO_NCLS + 4;   // [0..NCLS] slow groups per class + their hits
 	{
 		// Q2-Q5 in one kernel: index records -> bins -> sorted k_mer_hits + group lists (no anchor keys in memory)
@@ -268,24 +268,30 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			if (!c->sw.pack_search) { HIP_TRY(B.hq.reserve(A + 64)); sa_.hq = B.hq.p; }
 		}
 		if (c->sw.seedphase) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); sa_.dbg = B.dbgbuf.p; }
-		HIP_TRY(B.ovf_list.reserve(n + 1));
-		unsigned long long *d_ovf = B.stats.p + 3 * HAO_NCLS + 3;
+		HIP_TRY(B.ovf_list.reserve(2 * (n + 1)));
+		unsigned long long *d_ovf = B.stats.p + 3 * HAO_NCLS + 3, *d_ovf2 = B.stats.p + 3 * HAO_NCLS + 4;
+		uint32_t *ovf1 = B.ovf_list.p, *ovf2 = B.ovf_list.p + (n + 1);
 		const uint32_t tile_ = c->sw.seed_tile == 512 ? 512 : 1024;
 		const size_t lds_tile = std::max<size_t>((size_t)tile_ * (sizeof(hao_stage_t) + 4), 12 * 512);      // staged tile (>= the 12 bytes per slot of the bin sort it shares memory with)
-		const size_t lds1 = (size_t)22 * 512 + lds_tile + 12 * (size_t)sa_.qcap + 16 + (size_t)c->sw.seed_lds_pad, lds2 = (size_t)22 * 2048 + std::max<size_t>(lds_tile, 12 * 2048) + 12 * (size_t)sa_.qcap + 16;      // (second launch: 2048 slots = up to 1760 bins per id-range round)
-		auto launch = [&](auto k1, auto k2) -> int {
+		const size_t lds_q = 12 * (size_t)sa_.qcap + 16;
+		const size_t lds1 = (size_t)22 * 512 + lds_tile + lds_q + (size_t)c->sw.seed_lds_pad, lds2 = (size_t)22 * 1024 + std::max<size_t>(lds_tile, 12 * 1024) + lds_q,
+					 lds3 = (size_t)22 * 2048 + std::max<size_t>(lds_tile, 12 * 2048) + lds_q;      // (third launch: 2048 slots = up to 1760 bins per id-range round)
+		auto launch = [&](auto k1, auto k2, auto k3) -> int {
 			{     // beyond the default dynamic LDS limit: opt in (the CU has 160 KB)
 				HIP_TRY(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
 				HIP_TRY(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+				HIP_TRY(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
 			}
-			hipLaunchKernelGGL(k1, dim3((unsigned)n), dim3(256), lds1, c->stream, sa_, B.ovf_list.p, d_ovf);
+			hipLaunchKernelGGL(k1, dim3((unsigned)n), dim3(256), lds1, c->stream, sa_, (const uint32_t*)nullptr, (const unsigned long long*)nullptr, ovf1, d_ovf);
 			HAO_CHECK_LAUNCH();
-			hipLaunchKernelGGL(k2, dim3((unsigned)n), dim3(256), lds2, c->stream, sa_, B.ovf_list.p, d_ovf);
+			hipLaunchKernelGGL(k2, dim3((unsigned)n), dim3(256), lds2, c->stream, sa_, (const uint32_t*)ovf1, (const unsigned long long*)d_ovf, ovf2, d_ovf2);
+			HAO_CHECK_LAUNCH();
+			hipLaunchKernelGGL(k3, dim3((unsigned)n), dim3(256), lds3, c->stream, sa_, (const uint32_t*)ovf2, (const unsigned long long*)d_ovf2, (uint32_t*)nullptr, (unsigned long long*)nullptr);
 			HAO_CHECK_LAUNCH();
 			return HAO_OK;
 		};
-		if (tile_ == 512) { if (int rc = launch(seed_bin_kernel<9, true, 512>, seed_bin_kernel<11, false, 512>)) return rc; }
-		else if (int rc = launch(seed_bin_kernel<9, true, 1024>, seed_bin_kernel<11, false, 1024>)) return rc;
+		if (tile_ == 512) { if (int rc = launch(seed_bin_kernel<9, 0, 512>, seed_bin_kernel<10, 1, 512>, seed_bin_kernel<11, 2, 512>)) return rc; }
+		else if (int rc = launch(seed_bin_kernel<9, 0, 1024>, seed_bin_kernel<10, 1, 1024>, seed_bin_kernel<11, 2, 1024>)) return rc;
 	}
 	if (c->sw.seedphase) { unsigned long long d_[4]; HIP_TRY(hipMemcpy(d_, B.dbgbuf.p, 32, hipMemcpyDeviceToHost)); if (d_[3]) fprintf(stderr, "[seed] blocks %llu  avg us: count pass %.1f  sort+scan %.1f  scatter pass %.1f\n", d_[3], d_[0] / 100.0 / d_[3], d_[1] / 100.0 / d_[3], d_[2] / 100.0 / d_[3]); }
 	c->timer.mark("q_sort_bins");
@@ -318,8 +324,8 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	if (G) {
 		hao_chain_args ca;
 		ca.hits = B.hits.p; ca.g_start = B.g_start.p; ca.g_read = B.g_read.p; ca.g_off = B.g_off.p; ca.seg = B.seg.p; ca.n_groups = G; ca.rid_lo = glo; ca.len = c->d_len_all.p; ca.par = par;
-		ca.dbg_qc = nullptr; ca.hq = nullptr; ca.hcode = nullptr; ca.exc_every = (uint32_t)c->sw.exc_every;
-		if ((parts & HAO_DELIVER_CL) && !c->sw.pack_search) { ca.hq = B.hq.p; ca.hcode = B.hcode.p; }
+		ca.dbg_qc = nullptr; ca.hq = nullptr; ca.hcode = nullptr; ca.ohq = nullptr; ca.exc_every = (uint32_t)c->sw.exc_every;
+		if ((parts & HAO_DELIVER_CL) && !c->sw.pack_search) { HIP_TRY(B.ohq.reserve(A + 64)); ca.hq = B.hq.p; ca.hcode = B.hcode.p; ca.ohq = B.ohq.p; }
 		if (c->sw.qcphase) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); ca.dbg_qc = B.dbgbuf.p; }
 		ca.stats = d_slow_cnt; ca.dbg_stats = c->sw.dp_stats ? 1 : 0;
 		ca.dbg_seq = c->sw.seq_chain ? 1 : (c->sw.dp_seqtail ? 3 : (c->sw.dp_nospec ? 4 : 0));
@@ -389,7 +395,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		if (!G) return HAO_OK;
 		hao_ctx::Batch::OutSet &O = B.O();
 		hipLaunchKernelGGL(hao_pack_hdr_kernel, dim3((unsigned)((NCmax + 255) / 256)), dim3(256), 0, c->stream, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH();
-		hipLaunchKernelGGL(hao_pack_ohits_kernel, dim3((unsigned)std::min<uint64_t>((NCmax + 3) / 4, 1u << 16)), dim3(256), 0, c->stream, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH();
+		if (!pa.have_codes) { hipLaunchKernelGGL(hao_pack_ohits_kernel, dim3((unsigned)std::min<uint64_t>((NCmax + 3) / 4, 1u << 16)), dim3(256), 0, c->stream, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH(); }      // (HAO_DBG_PACK_SEARCH: every chain coded by the packer)
 		hipLaunchKernelGGL(hao_pack_bits_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, c->stream, pa, A, NW, O.bits.p, B.pk_cnt.p); HAO_CHECK_LAUNCH();
 		size_t tb = 0;
 		HIP_TRY(rocprim::exclusive_scan(nullptr, tb, B.pk_cnt.p, O.rank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), c->stream)); HIP_TRY(hao_tmp(c, tb));
@@ -404,7 +410,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		HIP_TRY(hipMemsetAsync(B.pk_cnt.p + NW, 0, 4, c->stream));      // (the scan runs over NW + 1 counts: its last output is the total)
 		HIP_TRY(O.ch_off.reserve(n + 2)); HIP_TRY(O.cl_off.reserve(n + 2)); HIP_TRY(O.qm_off.reserve(n + 2)); HIP_TRY(O.qmz.reserve(nm + 1));
 		pa.cd = B.cd.p; pa.hits = B.hits.p; pa.ohits = B.ohits.p; pa.mz_off = c->d_ix_mz_off.p; pa.seg = B.seg.p; pa.n_sel = n; pa.rid_lo = lo; pa.mz0 = B.mz0; pa.q_pos = B.q_pos.p;
-		pa.hq = c->sw.pack_search ? nullptr : B.hq.p; pa.have_codes = c->sw.pack_search ? 0 : 1;
+		pa.hq = c->sw.pack_search ? nullptr : B.hq.p; pa.ohq = c->sw.pack_search ? nullptr : B.ohq.p; pa.have_codes = c->sw.pack_search ? 0 : 1;
 		pa.hdr = O.hdr.p; pa.bytes = B.hcode.p; pa.exc = O.exc.p; pa.exc_cnt = d_exc_cnt; pa.exc_every = (uint32_t)c->sw.exc_every;
 		pa.exc_cap = c->sw.exc_cap >= 0 ? std::min<uint64_t>(O.exc.cap, (uint64_t)c->sw.exc_cap) : O.exc.cap;
 		if (int rc = pack()) return rc;

@@ -6,7 +6,7 @@ static void hao_batch_free(hao_ctx *c) { if (c->batch) { c->batch->release(); de
 static void hao_release_all(hao_ctx *c)
 {
 	c->d_packed.release(); c->d_pk_off.release(); c->d_len.release(); c->d_len_all.release(); c->d_nsite_off.release(); c->d_nsite.release();
-	c->d_ft_keys.release(); c->d_ft_vals.release(); c->d_ft_bucket.release();
+	c->d_ft_keys.release(); c->d_ft_vals.release(); c->d_ft_bucket.release(); c->d_ft_hbit.release(); c->d_ft_hslot.release();
 	c->d_tile_off.release(); c->d_tile_ord.release(); c->d_n_runs.release(); c->d_tot_l.release(); c->d_chunk_off.release(); c->d_chunk_cnt64.release();
 	c->d_scalar_flag.release(); c->d_scalar_list.release(); c->d_pool_x.release(); c->d_pool_info.release(); c->d_pool_ord.release(); c->d_cursor.release(); c->d_err.release();
 	c->d_chunk_base.release(); c->d_chunk_dst.release(); c->d_chunk_cnt.release(); c->d_g_x.release(); c->d_g_info.release(); c->d_g_ord.release(); c->d_g_off.release();

@@ -156,7 +156,43 @@ struct hao_chain_args {
 	uint32_t exc_every;      // (tests) every n-th hit of a group gets the code 0xff: exercises the verbatim list
 	const uint16_t *hq; uint8_t *hcode;      // delivery path: query minimizer index of every seed hit (seed kernel) -> wire code byte of every seed hit relative to its
 	                                         // predecessor in the sorted order (hao_deliver.cuh): the quick check has both hits in registers anyway
+	uint16_t *ohq;                           // delivery path: minimizer index of every hit the DP compacts into ohits (same index as ohits): the DP tails code those chains themselves
 };
+
+// Wire code (hao_deliver.cuh) of chain hit h with query minimizer q after hit ph with minimizer pq: minimizers skipped << 4 | diagonal shift + 8; what that byte
+// cannot say travels verbatim: esc = 0xff for a hit the packer finds in hits[] at its position, 0xfd for one it finds in ohits[] / ohq[] (HAO_CODE_EXC_OHITS)
+#define HAO_CODE_EXC_OHITS 0xfd
+__device__ __forceinline__ uint8_t hao_wire_code(uint32_t q, uint32_t pq, const hao_hit_t &h, const hao_hit_t &ph, uint32_t exc_every, uint32_t idx, uint8_t esc)
+{
+	const int32_t dq = (int32_t)(q - pq), sh = (int32_t)((h.offset - ph.offset) - (h.self_offset - ph.self_offset));
+	return (dq < 1 || dq > 15 || sh < -8 || sh > 7 || q == 65535u || (exc_every && idx % exc_every == exc_every - 1)) ? esc : (uint8_t)((dq - 1) << 4 | (sh + 8));
+}
+// the codes of one chain the DP compacted into ohits[o, o + n) of group gs (hit j of the chain = seed hit a[src(j)]), by ONE lane
+template<class SrcAt>
+__device__ __forceinline__ void hao_code_chain_lane(const hao_chain_args &A, const uint64_t gs, const hao_hit_t *a, int64_t o, int64_t n, SrcAt src)
+{
+	const uint16_t *hq = A.hq + gs; uint8_t *hc = A.hcode + gs; uint16_t *oq = A.ohq + gs;
+	uint32_t pq = 0; hao_hit_t ph; ph.w0 = ph.offset = ph.self_offset = ph.cnt = 0;
+	for (int64_t j = 0; j < n; ++j) {
+		const int64_t x = src(j); const uint32_t q = hq[x]; const hao_hit_t h = a[x];
+		oq[o + j] = (uint16_t)q;
+		hc[o + j] = j ? hao_wire_code(q, pq, h, ph, A.exc_every, (uint32_t)j, (uint8_t)HAO_CODE_EXC_OHITS) : (uint8_t)0x08;
+		pq = q; ph = h;
+	}
+}
+
+// the same by a wave: hit j against hit j - 1 through two reads of L2-resident data (a call would make the DP kernels save ~100 registers around it: inlined)
+template<class SrcAt>
+__device__ __forceinline__ void hao_code_chain_wave(const hao_chain_args &A, const uint64_t gs, const hao_hit_t *a, int64_t o, int64_t n, SrcAt src)
+{
+	for (int64_t j = hao_lane(); j < n; j += 64) {
+		const int64_t x = src(j); const uint32_t q = A.hq[gs + x];
+		A.ohq[gs + o + j] = (uint16_t)q;
+		uint8_t code = 0x08;
+		if (j) { const int64_t xp = src(j - 1); code = hao_wire_code(q, A.hq[gs + xp], a[x], a[xp], A.exc_every, (uint32_t)j, (uint8_t)HAO_CODE_EXC_OHITS); }
+		A.hcode[gs + o + j] = code;
+	}
+}
 
 // Sequential tail shared by both paths (ONE lane): backtrack the best chain, multi-copy chains
 // (Hash_Table.cpp:2178-2270), regions, chained hits, fake cigars.  f/p may live in LDS or global memory.
@@ -197,6 +233,7 @@ __device__ void hao_chain_tail(const hao_chain_args &A, const uint64_t g, const 
 			for (k = 0, i = 0; k < n_u; ++k) {
 				n_v0 = c_nv0[k]; ni = c_ni[k];
 				rec[k].hit_rel = (uint32_t)i; rec[k].n_hits = (uint32_t)ni; rec[k].src_rel = (uint32_t)i; rec[k].in_place = 0;
+				if (A.hcode) hao_code_chain_lane(A, gs, a, i, ni, [&](int64_t q_) { return (int64_t)ii[n_v0 + (ni - q_ - 1)]; });
 				for (j = 0; j < ni; ++j, ++i) des[i] = a[ii[n_v0 + (ni - j - 1)]];
 				rec[k].fc_rel = fcn; rec[k].fc_len = hao_fake_cigar(fcs + fcn, rec[k], des + i - ni, ni); fcn += rec[k].fc_len;
 			}
@@ -208,6 +245,7 @@ __device__ void hao_chain_tail(const hao_chain_args &A, const uint64_t g, const 
 		}
 	}
 	hao_region(rec[0], P.xl, P.yl, msc, a[t[cL - 1]], a[t[0]]);
+	if (A.hcode) hao_code_chain_lane(A, gs, a, 0, cL, [&](int64_t q_) { return (int64_t)t[cL - q_ - 1]; });
 	for (i = 0; i < cL; ++i) des[i] = a[t[cL - i - 1]];
 	rec[0].hit_rel = 0; rec[0].n_hits = (uint32_t)cL; rec[0].src_rel = 0; rec[0].in_place = 0; rec[0].fc_rel = 0; rec[0].fc_len = hao_fake_cigar(fcs, rec[0], des, cL);
 	A.nch[g] = 1; A.nout[g] = (uint32_t)cL;
@@ -426,6 +464,7 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 		return;
 	}
 	// ---- single chain = the whole best block ----
+	if (hcg && two) for (int32_t i = (best ? 0 : k1) + lane; i < (best ? k1 : a_n); i += 64) hcg[i] = 0x08;      // the other strand block is in no chain: a 0xff there would only become a verbatim-list entry nobody reads
 	uint64_t *fcs = A.fcs + gs + 6 * g; hao_chain_rec rc;
 	hao_region(rc, P.xl, P.yl, msc, best ? first1 : first0, best ? last1 : last0);
 	uint32_t cnt; const uint32_t ce = best ? ce1 : ce0;
@@ -516,6 +555,7 @@ __device__ __forceinline__ void hao_chain_tail_wave(const hao_chain_args &A, con
 			for (uint32_t k = 0; k < n_u; ++k) {
 				const int64_t n_v0 = cn[k], ni = cn[3 + k]; hao_chain_rec rc = l_rec[k];
 				for (int64_t j = lane; j < ni; j += 64) des[o + j] = a[ii[n_v0 + (ni - j - 1)]];
+				if (A.hcode) hao_code_chain_wave(A, gs, a, (int64_t)o, ni, [&](int64_t q_) { return (int64_t)ii[n_v0 + (ni - q_ - 1)]; });
 				rc.hit_rel = o; rc.n_hits = (uint32_t)ni; rc.src_rel = o; rc.in_place = 0; rc.fc_rel = fcn;
 				rc.fc_len = hao_fake_cigar_wave(fcs + fcn, rc.x_pos_s, rc.y_pos_s, rc.x_pos_e, ni, [&](int64_t q) { return a[ii[n_v0 + (ni - q - 1)]]; });
 				fcn += rc.fc_len; o += (uint32_t)ni;
@@ -532,6 +572,7 @@ __device__ __forceinline__ void hao_chain_tail_wave(const hao_chain_args &A, con
 	hao_chain_rec rc;
 	hao_region(rc, P.xl, P.yl, msc, a[t[cL - 1]], a[t[0]]);
 	for (int64_t i = lane; i < cL; i += 64) des[i] = a[t[cL - i - 1]];
+	if (A.hcode) hao_code_chain_wave(A, gs, a, (int64_t)0, cL, [&](int64_t q_) { return (int64_t)t[cL - q_ - 1]; });
 	rc.hit_rel = 0; rc.n_hits = (uint32_t)cL; rc.src_rel = 0; rc.in_place = 0; rc.fc_rel = 0;
 	rc.fc_len = hao_fake_cigar_wave(fcs, rc.x_pos_s, rc.y_pos_s, rc.x_pos_e, cL, [&](int64_t q) { return a[t[cL - q - 1]]; });
 	if (lane == 0) { rec[0] = rc; A.nch[g] = 1; A.nout[g] = (uint32_t)cL; }

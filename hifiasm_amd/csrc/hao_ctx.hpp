@@ -102,6 +102,7 @@ struct hao_ctx {
 	bool has_ft = false; int ft_peak_hom = -1, ft_peak_het = -1, ft_cutoff = 0; int64_t ft_hist[HAO_N_COUNTS];
 	std::vector<uint64_t> h_ft_keys; std::vector<int32_t> h_ft_vals;
 	DevBuf<uint64_t> d_ft_keys; DevBuf<int32_t> d_ft_vals; DevBuf<uint32_t> d_ft_bucket;
+	DevBuf<uint32_t> d_ft_hbit; DevBuf<unsigned long long> d_ft_hslot; int ft_hbits = 0;      // the filter table's hash view for the device lookups (hao_sketch.cuh: hao_ft_dev)
 	int max_n_chain = 100, hom_cov = -1, het_cov = -1;
 	// ---- sketch workspace / results ----
 	uint64_t sk_lo = 0, sk_n = 0, sk_total = 0; bool sk_is_index = false;

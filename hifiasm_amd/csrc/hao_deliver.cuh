@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256) void hao_digest_kernel(hao_digest_args A)
 // gathered per chain (the per-chain gather was latency-bound: 3 ms per 745 M-hit batch), the bit stream is one coalesced pass over it, and a chain
 // header carries the position of its first hit.  The 3.5 % of seed hits that are in no chain cost a bit each.  A group that went through the
 // DP (its <= 3 chains were compacted into ohits[group start ..)) uses the same positions - the group's range is its own - and its codes are
-// written over the quick check's by hao_pack_ohits_kernel.  The code byte at a chain's FIRST position is meaningless (the header describes that
+// written over the quick check's by the DP kernels' tails (hao_chain.cuh: hao_code_chain_lane and the wave tail; verbatim hits of such chains are marked 0xfd so that
+// the packer takes them from ohits / ohq).  The code byte at a chain's FIRST position is meaningless (the header describes that
 // hit) and skipped by the decoder.  Exception entries carry the hit as the seed stage wrote it: the decoder sets its readID word from the header.
 // ---------------------------------------------------------------------------------------
 #define HAO_PACK_QCAP 1024
@@ -76,7 +77,8 @@ struct hao_pack_args {
 	const hao_cdesc *cd; const hao_hit_t *hits, *ohits;
 	const uint64_t *mz_off, *seg; uint64_t rid_lo, mz0, n_sel; const uint32_t *q_pos;      // per-read minimizer ranges (global offsets), seed-hit ranges, the batch's self_offset table
 	hao_chain_hdr_t *hdr; uint8_t *bytes; hao_exc_t *exc; unsigned long long *exc_cnt; uint64_t exc_cap; uint32_t exc_every;
-	const uint16_t *hq; int have_codes;      // per seed hit: query minimizer index (seed kernel); have_codes: bytes[] holds the quick check's codes (else every chain is coded here)
+	const uint16_t *hq; int have_codes;      // per seed hit: query minimizer index (seed kernel); have_codes: bytes[] holds the codes the chain kernels wrote (else every chain is coded here)
+	const uint16_t *ohq;                     // per ohits entry: query minimizer index (the DP tails, hao_chain.cuh)
 };
 
 // minimizer index of a hit: the table position of its self_offset (positions are strictly ascending in a read's table)
@@ -92,13 +94,13 @@ __global__ __launch_bounds__(256) void hao_pack_hdr_kernel(hao_pack_args A, cons
 	const hao_cdesc d = A.cd[ci];
 	const hao_hit_t h0 = hao_cd_src(d, A.hits, A.ohits)[0];
 	const uint64_t pos = d.src & ~HAO_CD_OHITS;
-	uint32_t q0 = (A.hq && !(d.src & HAO_CD_OHITS)) ? A.hq[pos] : 65535u;
+	uint32_t q0 = A.hq ? ((d.src & HAO_CD_OHITS) ? (A.ohq ? A.ohq[pos] : 65535u) : A.hq[pos]) : 65535u;
 	if (q0 == 65535u) { const uint64_t m0 = A.mz_off[A.rid_lo + d.r]; q0 = hao_pack_find_q(A.q_pos + (m0 - A.mz0), (uint32_t)(A.mz_off[A.rid_lo + d.r + 1] - m0), h0.self_offset); }
 	hao_chain_hdr_t H; H.n_hits = d.n; H.w0 = d.w0; H.q0 = q0; H.offset = h0.offset; H.pos = pos;
 	A.hdr[ci] = H;
 }
 
-// Codes of the chains whose hits are NOT the seed hits at their positions (the DP's compacted copies in ohits; with HAO_DBG_PACK_SEARCH every chain):
+// HAO_DBG_PACK_SEARCH only (A/B: the round-2 packer, which codes every chain here; by default the chain kernels have written every code and this kernel does not run):
 // one wave per chain, the minimizer index of a hit by a binary search of its self_offset in the read's table (staged in LDS once per read), codes
 // written at the chain's positions; a hit without a code goes to the verbatim list right here (its code is marked HAO_CODE_EXC_DONE).
 __global__ __launch_bounds__(256) void hao_pack_ohits_kernel(hao_pack_args A, const uint64_t *n_chains_dev)
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256) void hao_pack_bits_kernel(hao_pack_args A, uin
 		for (int k = 0; k < 8; ++k) {
 			const uint8_t b = (uint8_t)(v >> (8 * k));
 			if (8 * t + k < n && b != 0x08) m8 |= 1u << k;
-			if (8 * t + k < n && b == 0xff) e8 |= 1u << k;
+			if (8 * t + k < n && (b == 0xff || b == HAO_CODE_EXC_OHITS)) e8 |= 1u << k;
 		}
 	}
 	if (__ballot(e8 != 0)) {      // verbatim entries: one atomic per wave reserves the wave's slots (the repeat-rich sets have millions per pass)
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(256) void hao_pack_bits_kernel(hao_pack_args A, uin
 		for (uint32_t m = e8; m; m &= m - 1, ++kx) {
 			if (kx >= A.exc_cap) continue;      // past the capacity only the count matters: the host grows the list and packs again
 			const uint64_t p = 8 * t + (uint32_t)(__ffs((int)m) - 1);
-			hao_exc_t e; e.index = p; e.pad = 0; e.hit = A.hits[p]; e.q = A.hq ? A.hq[p] : 65535u;
+			const bool oh = (uint8_t)(v >> (8 * (__ffs((int)m) - 1))) == HAO_CODE_EXC_OHITS;      // a hit of a chain the DP compacted: it (and its minimizer index) sit in ohits / ohq at the position
+			hao_exc_t e; e.index = p; e.pad = 0; e.hit = oh ? A.ohits[p] : A.hits[p]; e.q = oh ? A.ohq[p] : (A.hq ? A.hq[p] : 65535u);
 			if (e.q == 65535u) {      // the 16-bit index saturated (a read of > 65 534 minimizers): the read of the position, then its table
 				uint64_t lo = 0, hi = A.n_sel; while (hi - lo > 1) { const uint64_t md = (lo + hi) >> 1; if (A.seg[md] <= p) lo = md; else hi = md; }
 				const uint64_t m0 = A.mz_off[A.rid_lo + lo];
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void hao_pack_codes_kernel(const uint8_t *byte
 	if (!m8) return;
 	uint64_t at = rank[t >> 3] + (uint64_t)__popcll(word & ((1ULL << sh) - 1));
 	const uint64_t v = *(const uint64_t*)(bytes + 8 * t);
-	for (; m8; m8 &= m8 - 1) { const uint8_t b = (uint8_t)(v >> (8 * (__ffs((int)m8) - 1))); codes[at++] = b == HAO_CODE_EXC_DONE ? (uint8_t)0xff : b; }
+	for (; m8; m8 &= m8 - 1) { const uint8_t b = (uint8_t)(v >> (8 * (__ffs((int)m8) - 1))); codes[at++] = b >= HAO_CODE_EXC_OHITS ? (uint8_t)0xff : b; }      // (0xfd / 0xfe: device-only flavours of "verbatim")
 }
 
 // fill by a kernel: a big hipMemsetAsync travels through the DMA queues, where the previous batch's result copy is in flight (measured: the copy of a

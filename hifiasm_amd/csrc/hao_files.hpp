@@ -215,6 +215,7 @@ static int hao_index_load_impl(hao_ctx *c, const char *prefix, int32_t *number_o
 	HIP_TRY(c->d_ft_keys.reserve(nf + 1)); HIP_TRY(c->d_ft_vals.reserve(nf + 1));
 	if (nf) { HIP_TRY(hipMemcpyAsync(c->d_ft_keys.p, ftk.data(), nf * 8, hipMemcpyHostToDevice, c->stream)); HIP_TRY(hipMemcpyAsync(c->d_ft_vals.p, ftv.data(), nf * 4, hipMemcpyHostToDevice, c->stream)); }
 	if (int rc = hao_build_bucket(c, c->d_ft_keys.p, nf, 16, c->d_ft_bucket)) return rc;
+	if (int rc = hao_ft_build_hash(c, nf)) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	c->has_ft = true; c->ft_peak_hom = -1; c->ft_peak_het = -1; c->ft_cutoff = 0; memset(c->ft_hist, 0, sizeof(c->ft_hist));
 	// ---- position index: keys ascending, every key's list in file order (= (rid, pos) order) ----

@@ -29,6 +29,7 @@ __global__ void hao_unit_rid_kernel(const uint64_t *chunk_off, uint64_t n_sel, u
 static hao_ft_dev hao_ft_view(hao_ctx *c)
 {
 	hao_ft_dev f; f.keys = c->d_ft_keys.p; f.vals = c->d_ft_vals.p; f.bucket = c->d_ft_bucket.p; f.n = c->h_ft_keys.size();
+	f.hbit = c->d_ft_hbit.p; f.hslot = (const ulonglong2*)c->d_ft_hslot.p; f.hbits = c->ft_hbits;
 	return f;
 }
 
@@ -146,10 +147,10 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 			c->timer.mark("sk_gather");
 			HIP_TRY(c->d_new_n.reserve(n_sel + 2)); HIP_TRY(hipMemsetAsync(c->d_new_n.p + n_sel, 0, 4, c->stream));
 			if (c->sw.sk_select2) {      // the wave-parallel thinning (hao_select2.cuh), one wave per read: reads of up to 512 candidates (30 KB of LDS per wave), then the longer ones
-				hipLaunchKernelGGL(sketch_select2_kernel<HAO_S2_CAP_SMALL>, dim3((unsigned)n_sel), dim3(64), 0, c->stream, c->d_g_x.p, c->d_g_info.p, c->d_g_ord.p, c->d_g_off.p,
+				hipLaunchKernelGGL((sketch_select2_kernel<HAO_S2_CAP_SMALL, 64>), dim3((unsigned)n_sel), dim3(64), 0, c->stream, c->d_g_x.p, c->d_g_info.p, c->d_g_ord.p, c->d_g_off.p,
 								   c->d_len.p, c->d_tot_l.p, lo, n_sel, sample_dist, c->opt.rewin, k, c->d_new_n.p, c->d_err.p);
 				HAO_CHECK_LAUNCH();
-				hipLaunchKernelGGL(sketch_select2_kernel<HAO_S2_CAP>, dim3((unsigned)n_sel), dim3(64), 0, c->stream, c->d_g_x.p, c->d_g_info.p, c->d_g_ord.p, c->d_g_off.p,
+				hipLaunchKernelGGL((sketch_select2_kernel<HAO_S2_CAP, 256>), dim3((unsigned)n_sel), dim3(256), 0, c->stream, c->d_g_x.p, c->d_g_info.p, c->d_g_ord.p, c->d_g_off.p,
 								   c->d_len.p, c->d_tot_l.p, lo, n_sel, sample_dist, c->opt.rewin, k, c->d_new_n.p, c->d_err.p);
 			} else {
 				hipLaunchKernelGGL(sketch_select_kernel, dim3((unsigned)((n_sel + 3) / 4)), dim3(256), 0, c->stream, c->d_g_x.p, c->d_g_info.p, c->d_g_ord.p, c->d_g_off.p,

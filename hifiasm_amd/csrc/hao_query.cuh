@@ -59,9 +59,11 @@ struct hao_seed_args {
 	uint16_t *hq;      // optional (delivery path): index of the query minimizer of every hit (saturating at 65535), next to hits[]: the wire packer's codes need it (hao_deliver.cuh)
 };
 
-// Two launches cover a batch: <SMALL table, FIRST> takes every read and gives up (appends the read to ovf_list) when its bins do not fit in
-// one round - the small table keeps many workgroups per CU for the common reads; <bigger table, !FIRST> takes the listed reads, in as many
-// (tid, rev) range rounds as they need.
+// Three launches cover a batch: <512 slots, tier 0> takes every read and gives up (appends the read to ovf_list) when its bins do not fit in
+// one round - the small table keeps many workgroups per CU for the common reads; <1024 slots, tier 1> takes the listed reads and gives up the same
+// way (a read that crosses repeat families meets hundreds of targets: on the 250 Mb repeat-rich set nearly every read overflowed the small table, and the
+// 2048-slot kernel - 60 KB of LDS, 121 VGPRs: two workgroups per CU - took 23 ms per batch against 1.6 ms for the first launch); <2048 slots, tier 2>
+// takes what is left, in as many (tid, rev) range rounds as it needs.
 //
 // Pass B writes through LDS.  A hit is 16 bytes and a read feeds ~100 bins, so storing hits where they are produced costs one 16-byte write
 // request per hit (the request slots of the L2, not its bytes, are what ran out: the same stores issued in generation order made the whole
@@ -70,9 +72,12 @@ struct hao_seed_args {
 // parked in LDS grouped by bin (in generation order inside a bin), and the tile is written out with consecutive lanes on consecutive
 // addresses: ~5 hits of a bin at a time (TILE = 1024 doubles that but its LDS and registers leave 4 instead of 6 workgroups per CU: slower).
 struct hao_stage_t { uint32_t offset, self_offset, cnt; };
-template<int CAPLOG, bool FIRST, uint32_t HAO_SEED_TILE>
-__global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t *ovf_list, unsigned long long *ovf_cnt)
+// TIER 0: every read of the batch, gives up on overflow (-> ovf_list); TIER 1: the reads of in_list, gives up on overflow (-> ovf_list); TIER 2: the reads of in_list, in
+// as many (tid, rev) range rounds as their bins need
+template<int CAPLOG, int TIER, uint32_t HAO_SEED_TILE>
+__global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, const uint32_t *in_list, const unsigned long long *in_cnt, uint32_t *ovf_list, unsigned long long *ovf_cnt)
 {
+	constexpr bool FIRST = TIER == 0, GIVEUP = TIER < 2;
 	constexpr uint32_t CAP = 1u << CAPLOG, MAXD = CAP - 288;      // at most MAXD + 256 bins are ever inserted (one per thread after the table fills), so probing terminates; CAP >= 512
 	constexpr int UA = 4;                        // tiles per lane in flight in the counting pass (chunks are multiples of 64 * UA anchors)
 	constexpr uint32_t STAGE_BYTES = HAO_SEED_TILE * (sizeof(hao_stage_t) + 4), SORT_BYTES = CAP * 12, UNION_BYTES = STAGE_BYTES > SORT_BYTES ? STAGE_BYTES : SORT_BYTES;
@@ -92,8 +97,8 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 	uint32_t *l_ao = (uint32_t*)(l_ss + S.qcap); // [qcap+1] first anchor of minimizer q, relative to the read
 	__shared__ uint32_t s_nd, s_ovf, s_c, s_wt[4]; __shared__ uint64_t s_ws[4], s_all;
 	uint64_t *g_tmp = S.g_tmp;
-	if (!FIRST && blockIdx.x >= *ovf_cnt) return;
-	const uint64_t r = FIRST ? blockIdx.x : ovf_list[blockIdx.x], s = S.seg[r], e = S.seg[r + 1]; const uint32_t n = (uint32_t)(e - s);
+	if (!FIRST && blockIdx.x >= *in_cnt) return;
+	const uint64_t r = FIRST ? blockIdx.x : in_list[blockIdx.x], s = S.seg[r], e = S.seg[r + 1]; const uint32_t n = (uint32_t)(e - s);
 	const int wv = threadIdx.x >> 6, lane = hao_lane(); const uint32_t tid = threadIdx.x;
 	if (FIRST && r == 0 && tid == 0) S.g_cnt[S.n_sel] = 0;
 	if (n == 0) { if (tid == 0) S.g_cnt[r] = 0; return; }
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, uint32_t
 			const bool ovf = *v_ovf != 0;
 			__syncthreads();
 			if (!ovf) break;
-			if (FIRST) { if (tid == 0) ovf_list[atomicAdd(ovf_cnt, 1ULL)] = (uint32_t)r; return; }      // left to the launch with the bigger table
+			if (GIVEUP) { if (tid == 0) ovf_list[atomicAdd(ovf_cnt, 1ULL)] = (uint32_t)r; return; }      // left to the launch with the bigger table
 			hi = lo + (hi - lo) / 2;      // hi - lo >= 2 here: one bin always fits
 		}
 		if (S.dbg) tk1 = wall_clock64();

@@ -164,94 +164,90 @@ HAO_S2_FN void hao_s2_finish_run(const hao_s2_view &V, int i, int e, int span, i
 // the sequential routine for the reads the closed form does not cover: kept out of line so that its registers are not the kernel's
 __device__ __attribute__((noinline)) int hao_s2_sequential(uint64_t *x, uint64_t *info, uint32_t *ord, int n, int len, int sample_dist, int rewin, int k, int tot_l)
 { hao_sel_view v; v.n = n; v.x = x; v.info = info; v.ord = ord; return hao_select_high(v, len, sample_dist, rewin, k, tot_l); }
-#define HAO_S2_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
-template<int CAP>      // candidates per read this instantiation stages: reads of (CAP / 2, CAP] (the smallest CAP: [0, CAP]; the largest CAP also takes the longer reads, sequentially)
-__global__ __launch_bounds__(64) void sketch_select2_kernel(uint64_t *x, uint64_t *info, uint32_t *ord, const uint64_t *mz_off, const uint32_t *len, const uint32_t *tot_l,
+// NT threads per read: 64 (one wave, fences only) for the small instantiation; the 61 KB instantiation runs 256 threads per read - at two workgroups per CU one
+// wave per read left the GPU with 512 waves in flight (125 ms for the 250 Mb repeat-rich set, where half of the reads have more than 512 candidates)
+template<int NT> __device__ __forceinline__ void hao_s2_sync() { if (NT == 64) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } else __syncthreads(); }
+template<int NT> __device__ __forceinline__ bool hao_s2_any(bool v) { if (NT == 64) return __any(v) != 0; return __syncthreads_or(v ? 1 : 0) != 0; }
+template<int CAP, int NT>      // candidates per read this instantiation stages: reads of (CAP / 2, CAP] (the smallest CAP: [0, CAP]; the largest CAP also takes the longer reads, sequentially)
+__global__ __launch_bounds__(NT) void sketch_select2_kernel(uint64_t *x, uint64_t *info, uint32_t *ord, const uint64_t *mz_off, const uint32_t *len, const uint32_t *tot_l,
 		uint64_t rid_lo, uint64_t n_sel, int sample_dist, int rewin, int k, uint32_t *new_n, const int *err)
 {
 	if (*err) return;
 	__shared__ uint64_t l_x[CAP], l_info[CAP]; __shared__ uint32_t l_ord[CAP];
 	__shared__ uint16_t l_idx[CAP], l_rank[CAP], l_start[CAP], l_wm[CAP], l_mn[(HAO_S2_LOG + 1) * CAP], l_mx[(HAO_S2_LOG + 1) * CAP];
-	__shared__ uint8_t l_flag[CAP]; __shared__ int s_i0, s_bad, s_anyq;
-	const int lane = threadIdx.x;
+	__shared__ uint8_t l_flag[CAP]; __shared__ int s_i0, s_bad, s_anyq, s_m;
+	const int tid = threadIdx.x;
 	const uint64_t r = blockIdx.x;
 	if (r >= n_sel) return;
 	const uint64_t o = mz_off[r]; const int n = (int)(mz_off[r + 1] - o);
 	if ((CAP < HAO_S2_CAP && n > CAP) || (CAP > HAO_S2_CAP_SMALL && n <= CAP / 2)) return;      // the other instantiation's read
-	int any = 0;
-	for (int i = lane; i < n; i += 64) if ((info[o + i] & 0xfffffffu) > 0) any = 1;
-	if (!__any(any)) { if (lane == 0) new_n[r] = (uint32_t)n; return; }
+	bool any = false;
+	for (int i = tid; i < n; i += NT) if ((info[o + i] & 0xfffffffu) > 0) any = true;
+	if (!hao_s2_any<NT>(any)) { if (tid == 0) new_n[r] = (uint32_t)n; return; }
 	const bool in_lds = n <= CAP;
-	if (in_lds) for (int i = lane; i < n; i += 64) { l_x[i] = x[o + i]; l_info[i] = info[o + i]; l_ord[i] = ord[o + i]; }
-	if (lane == 0) { s_i0 = n; s_bad = in_lds ? 0 : 1; s_anyq = 0; }
-	HAO_S2_SYNC();
+	if (in_lds) for (int i = tid; i < n; i += NT) { l_x[i] = x[o + i]; l_info[i] = info[o + i]; l_ord[i] = ord[o + i]; }
+	if (tid == 0) { s_i0 = n; s_bad = in_lds ? 0 : 1; s_anyq = 0; s_m = 0; }
+	hao_s2_sync<NT>();
 	hao_s2_view V; V.x = l_x; V.info = l_info; V.ord = l_ord; V.idx = l_idx; V.rank = l_rank; V.start = l_start; V.wm = l_wm; V.mn = l_mn; V.mx = l_mx; V.flag = l_flag;
 	V.n = n; V.cap = CAP; V.len = (int)len[rid_lo + r]; V.sample_dist = sample_dist; V.w = rewin; V.k = k; V.tot_l = (int)tot_l[r];
 	int P = 64; while (P < n) P <<= 1; V.P = P;
 	if (in_lds) {
 		// ordinals must ascend; the runs' quotas; the first full window
-		for (int i = lane; i < n; i += 64) {
+		for (int i = tid; i < n; i += NT) {
 			if (i > 0 && l_ord[i] < l_ord[i - 1]) s_bad = 1;
 			if (hao_s2_cnt(V, i) > 0 && (i == 0 || hao_s2_cnt(V, i - 1) == 0)) { int e, span; if (hao_s2_run(V, i, e, span) > 0) s_anyq = 1; }
 			if (hao_s2_first_window(V, i)) atomicMin(&s_i0, i);
 		}
-		HAO_S2_SYNC();
+		hao_s2_sync<NT>();
 	}
-	if (s_bad) {      // the sequential routine of sketch_select_kernel (in place on the staged list, or on the global arrays of a very long read)
-		int m = 0;
-		if (lane == 0) m = in_lds ? hao_s2_sequential(l_x, l_info, l_ord, n, V.len, sample_dist, rewin, k, V.tot_l) : hao_s2_sequential(x + o, info + o, ord + o, n, V.len, sample_dist, rewin, k, V.tot_l);
-		m = __shfl(m, 0);
-		HAO_S2_SYNC();
-		if (in_lds) for (int i = lane; i < m; i += 64) { x[o + i] = l_x[i]; info[o + i] = l_info[i]; }
-		if (lane == 0) new_n[r] = (uint32_t)m;
-		return;
-	}
-	if (!s_anyq) { if (lane == 0) new_n[r] = (uint32_t)n; return; }      // no run is long enough to be sampled: everything stays (sketch.cpp:266)
+	// the sequential routine of sketch_select_kernel, by thread 0 (in place on the staged list, or on the global arrays of a very long read); survivors copied back by all
+	auto sequential = [&](bool staged) {
+		if (tid == 0) s_m = staged ? hao_s2_sequential(l_x, l_info, l_ord, n, V.len, sample_dist, rewin, k, V.tot_l) : hao_s2_sequential(x + o, info + o, ord + o, n, V.len, sample_dist, rewin, k, V.tot_l);
+		hao_s2_sync<NT>();
+		const int m = s_m;
+		if (staged) for (int i = tid; i < m; i += NT) { x[o + i] = l_x[i]; info[o + i] = l_info[i]; }
+		if (tid == 0) new_n[r] = (uint32_t)m;
+	};
+	if (s_bad) { sequential(in_lds); return; }
+	if (!s_anyq) { if (tid == 0) new_n[r] = (uint32_t)n; return; }      // no run is long enough to be sampled: everything stays (sketch.cpp:266)
 	const int i0 = s_i0 < n ? s_i0 : -1;
 	if (i0 >= 0) {
 		// ranks: bitonic sort of the candidate indices by key, then the first slot of every key
-		for (int i = lane; i < P; i += 64) l_idx[i] = i < n ? (uint16_t)i : (uint16_t)HAO_S2_PAD;
-		HAO_S2_SYNC();
+		for (int i = tid; i < P; i += NT) l_idx[i] = i < n ? (uint16_t)i : (uint16_t)HAO_S2_PAD;
+		hao_s2_sync<NT>();
 		for (int kk = 2; kk <= P; kk <<= 1)
-			for (int j = kk >> 1; j > 0; j >>= 1) { for (int i = lane; i < P; i += 64) hao_s2_bitonic(V, i, j, kk); HAO_S2_SYNC(); }
-		for (int p = lane; p < P; p += 64) hao_s2_rank(V, p);
-		HAO_S2_SYNC();
+			for (int j = kk >> 1; j > 0; j >>= 1) { for (int i = tid; i < P; i += NT) hao_s2_bitonic(V, i, j, kk); hao_s2_sync<NT>(); }
+		for (int p = tid; p < P; p += NT) hao_s2_rank(V, p);
+		hao_s2_sync<NT>();
 		// window starts, the sparse table of ranks, window minima, their sparse table
-		for (int i = lane; i < n; i += 64) { hao_s2_start(V, i); l_mn[i] = l_rank[i]; }
-		HAO_S2_SYNC();
-		for (int L = 1; L <= HAO_S2_LOG; ++L) { for (int i = lane; i < n; i += 64) hao_s2_level(l_mn, CAP, n, L, i, false); HAO_S2_SYNC(); }
-		int bad = 0;
-		for (int i = lane; i < n; i += 64) { if (!hao_s2_window_min(V, i, i0)) bad = 1; l_mx[i] = l_wm[i]; }
-		if (__any(bad)) {      // a window beyond the tables: sequential routine (the staged list is untouched so far)
-			int m = 0;
-			HAO_S2_SYNC();
-			if (lane == 0) m = hao_s2_sequential(l_x, l_info, l_ord, n, V.len, sample_dist, rewin, k, V.tot_l);
-			m = __shfl(m, 0);
-			HAO_S2_SYNC();
-			for (int i = lane; i < m; i += 64) { x[o + i] = l_x[i]; info[o + i] = l_info[i]; }
-			if (lane == 0) new_n[r] = (uint32_t)m;
-			return;
-		}
-		HAO_S2_SYNC();
-		for (int L = 1; L <= HAO_S2_LOG; ++L) { for (int i = lane; i < n; i += 64) hao_s2_level(l_mx, CAP, n, L, i, true); HAO_S2_SYNC(); }
+		for (int i = tid; i < n; i += NT) { hao_s2_start(V, i); l_mn[i] = l_rank[i]; }
+		hao_s2_sync<NT>();
+		for (int L = 1; L <= HAO_S2_LOG; ++L) { for (int i = tid; i < n; i += NT) hao_s2_level(l_mn, CAP, n, L, i, false); hao_s2_sync<NT>(); }
+		bool bad = false;
+		for (int i = tid; i < n; i += NT) { if (!hao_s2_window_min(V, i, i0)) bad = true; l_mx[i] = l_wm[i]; }
+		if (hao_s2_any<NT>(bad)) { hao_s2_sync<NT>(); sequential(true); return; }      // a window beyond the tables: sequential routine (the staged list is untouched so far)
+		hao_s2_sync<NT>();
+		for (int L = 1; L <= HAO_S2_LOG; ++L) { for (int i = tid; i < n; i += NT) hao_s2_level(l_mx, CAP, n, L, i, true); hao_s2_sync<NT>(); }
 		const int s_last = n - 1 > i0 ? (int)l_start[n - 1] : 0, tail_hi = hao_s2_tail_hi(V, s_last);
-		for (int j = lane; j < n; j += 64) hao_s2_mark(V, j, i0, s_last, tail_hi);
-	} else for (int j = lane; j < n; j += 64) l_flag[j] = 0;
-	HAO_S2_SYNC();
-	// runs: the lane that owns a run's first entry decides for the run; entries that are not high-count always stay
-	for (int i = lane; i < n; i += 64) {
+		for (int j = tid; j < n; j += NT) hao_s2_mark(V, j, i0, s_last, tail_hi);
+	} else for (int j = tid; j < n; j += NT) l_flag[j] = 0;
+	hao_s2_sync<NT>();
+	// runs: the thread that owns a run's first entry decides for the run; entries that are not high-count always stay
+	for (int i = tid; i < n; i += NT) {
 		if (hao_s2_cnt(V, i) == 0) l_flag[i] |= 2;
 		else if (i0 >= 0 && (i == 0 || hao_s2_cnt(V, i - 1) == 0)) { int e, span; const int q = hao_s2_run(V, i, e, span); if (q > 0) hao_s2_finish_run(V, i, e, span, q); }
 	}
-	HAO_S2_SYNC();
-	// survivors, in order
-	int m = 0;
-	for (int b = 0; b < n; b += 64) {
-		const int i = b + lane; const bool kp = i < n && (l_flag[i] & 2);
-		const unsigned long long bal = __ballot(kp);
-		if (kp) { const int d = m + __popcll(bal & ((1ULL << lane) - 1)); x[o + d] = l_x[i]; info[o + d] = l_info[i]; }
-		m += __popcll(bal);
+	hao_s2_sync<NT>();
+	// survivors, in order (the first wave)
+	if (tid < 64) {
+		int m = 0;
+		for (int b = 0; b < n; b += 64) {
+			const int i = b + tid; const bool kp = i < n && (l_flag[i] & 2);
+			const unsigned long long bal = __ballot(kp);
+			if (kp) { const int d = m + __popcll(bal & ((1ULL << tid) - 1)); x[o + d] = l_x[i]; info[o + d] = l_info[i]; }
+			m += __popcll(bal);
+		}
+		if (tid == 0) new_n[r] = (uint32_t)m;
 	}
-	if (lane == 0) new_n[r] = (uint32_t)m;
 }
 #endif

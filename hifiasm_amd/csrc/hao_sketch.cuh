@@ -31,16 +31,56 @@
 #define HAO_SK_TILE 1024       // bases per run-count index tile (= 64 lanes x 16 bases)
 #define HAO_SK_THREADS 256
 
-struct hao_ft_dev {            // high-count filter table, device view (sorted keys + 64K-bucket top-bits index)
-	const uint64_t *keys; const int32_t *vals; const uint32_t *bucket; uint64_t n;
+// High-count filter table, device view.  Every (HPC) k-mer of every read asks it for its count, and almost every answer is "not in the table", so the
+// lookup is laid out for that: (1) a bitmap over the top hbits bits of the hash (a few MB: it lives in the L2s / the Infinity Cache), a clear bit = count 0;
+// (2) a bucketed hash table addressed by the top hbits - 2 bits of the hash, ONE 16-byte load: two slots per bucket, a slot = the hash's low 51 bits << 13 | code
+// (code = count 1 .. 4095, 8191 = "above max_kmer_cnt": ha_ft_cnt's INT32_MAX), 0 = empty; (3) a bucket that would need a third slot holds the mark ~0 in
+// its first slot and sends its keys to the sorted array (binary search below a 64K-bucket index: the host view's layout, also what hao_index_save writes).
+// (Round 3 did (3) for every k-mer: ~9 dependent global loads per lookup; on a repeat-rich 250 Mb genome - 5 M table entries - the sketch took 288 ms
+// instead of the 20 ms of an empty table.)
+struct hao_ft_dev {
+	const uint64_t *keys; const int32_t *vals; const uint32_t *bucket; uint64_t n;      // sorted keys + values + 64K-bucket index on the top 16 hash bits
+	const uint32_t *hbit; const ulonglong2 *hslot; int hbits;                             // bitmap (2^hbits bits) and buckets (2^(hbits - 2)) of the hash view; hbits >= 15
 };
+#define HAO_FT_CODE_BITS 13
+#define HAO_FT_CODE_BIG 8191u
+#define HAO_FT_MARK (~0ULL)
 
-// ha_ft_cnt (htab.cpp:1064-1070)
-__device__ __forceinline__ int32_t hao_ft_lookup(const hao_ft_dev &ft, uint64_t y)
+__device__ __forceinline__ int32_t hao_ft_lookup_sorted(const hao_ft_dev &ft, uint64_t y)
 {
 	uint32_t b = (uint32_t)(y >> 48), lo = ft.bucket[b], hi = ft.bucket[b + 1];
 	while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (ft.keys[m] < y) lo = m + 1; else hi = m; }
 	return (lo < ft.bucket[b + 1] && ft.keys[lo] == y) ? ft.vals[lo] : 0;
+}
+// ha_ft_cnt (htab.cpp:1064-1070)
+__device__ __forceinline__ int32_t hao_ft_lookup(const hao_ft_dev &ft, uint64_t y)
+{
+	if (ft.n == 0) return 0;
+	const uint32_t fb = (uint32_t)(y >> (64 - ft.hbits));
+	if (!((ft.hbit[fb >> 5] >> (fb & 31)) & 1u)) return 0;
+	const ulonglong2 e = ft.hslot[fb >> 2];
+	if (e.x == HAO_FT_MARK) return hao_ft_lookup_sorted(ft, y);
+	const uint64_t want = y << HAO_FT_CODE_BITS, msk = ~(uint64_t)HAO_FT_CODE_BIG;
+	uint32_t code = 0;
+	if (e.x && (e.x & msk) == want) code = (uint32_t)e.x & HAO_FT_CODE_BIG;
+	else if (e.y && (e.y & msk) == want) code = (uint32_t)e.y & HAO_FT_CODE_BIG;
+	return code == HAO_FT_CODE_BIG ? INT32_MAX : (int32_t)code;
+}
+// build of the hash view from the sorted table (one thread per key; slots and bitmap zeroed beforehand): keys of one bucket are neighbours in the sorted
+// array, so a key sees its rank in its bucket and whether the bucket holds more than two keys by looking at most two keys back and ahead
+__global__ void hao_ft_hash_kernel(const uint64_t *keys, const int32_t *vals, uint64_t n, int hbits, uint32_t *hbit, unsigned long long *hslot)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint64_t y = keys[i]; const int sh = 64 - (hbits - 2); const uint64_t b = y >> sh;
+	const uint32_t fb = (uint32_t)(y >> (64 - hbits));
+	atomicOr(&hbit[fb >> 5], 1u << (fb & 31));
+	int back = 0, fwd = 0;
+	while (back < 2 && i >= (uint64_t)back + 1 && (keys[i - 1 - back] >> sh) == b) ++back;
+	while (fwd < 2 && i + 1 + fwd < n && (keys[i + 1 + fwd] >> sh) == b) ++fwd;
+	if (back + fwd + 1 > 2) { if (back == 0) { hslot[2 * b] = HAO_FT_MARK; hslot[2 * b + 1] = HAO_FT_MARK; } return; }
+	const int32_t v = vals[i]; const uint32_t code = v == INT32_MAX ? HAO_FT_CODE_BIG : (uint32_t)v;      // (a kept k-mer has a count of at least 1, at most 4095)
+	hslot[2 * b + back] = y << HAO_FT_CODE_BITS | code;
 }
 
 // 16 bases (one big-endian 32-bit word of the packed read) -> bit (30-2j) set iff base j is

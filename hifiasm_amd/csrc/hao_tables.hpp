@@ -204,6 +204,19 @@ static int hao_build_bucket(hao_ctx *c, const uint64_t *keys, uint64_t n, int bi
 	return HAO_OK;
 }
 
+// the filter table's hash view (hao_sketch.cuh: hao_ft_dev) from the sorted device arrays: 2^(hbits - 2) buckets of two slots for ~0.4 - 0.75 keys per bucket
+static int hao_ft_build_hash(hao_ctx *c, uint64_t n)
+{
+	int hb = 15; while (hb < 34 && (1ULL << (hb - 2)) * 3 < n * 4) ++hb;      // buckets >= 4/3 n
+	c->ft_hbits = hb;
+	const uint64_t nbk = 1ULL << (hb - 2), nw = (1ULL << hb) / 32;
+	HIP_TRY(c->d_ft_hbit.reserve(nw + 1)); HIP_TRY(c->d_ft_hslot.reserve(2 * nbk + 2));
+	HIP_TRY(hipMemsetAsync(c->d_ft_hbit.p, 0, nw * 4, c->stream));
+	for (uint64_t o = 0; o < 2 * nbk * 8; o += 1ULL << 30) HIP_TRY(hipMemsetAsync((char*)c->d_ft_hslot.p + o, 0, std::min<uint64_t>(1ULL << 30, 2 * nbk * 8 - o), c->stream));
+	if (n) { hipLaunchKernelGGL(hao_ft_hash_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_ft_keys.p, c->d_ft_vals.p, n, hb, c->d_ft_hbit.p, c->d_ft_hslot.p); HAO_CHECK_LAUNCH(); }
+	return HAO_OK;
+}
+
 // HAO_DBG_BLOOM: self-checks of the replay's intermediate arrays (sortedness, key / value pairing, run totals) with wall times, on stderr
 struct BlkInv { const uint32_t *k; __host__ __device__ uint64_t operator()(uint64_t i) const { return (i > 0 && k[i] < k[i - 1]) ? 1 : 0; } };
 struct BlkPair { const uint32_t *k; const uint64_t *v; int xb; __host__ __device__ uint64_t operator()(uint64_t i) const {
@@ -459,6 +472,7 @@ static int hao_ft_run(hao_ctx *c)
 	HIP_TRY(c->d_ft_vals.reserve(n_kept + 1)); HIP_TRY(c->d_ft_keys.reserve(n_kept + 1));
 	if (n_kept) HIP_TRY(hipMemcpyAsync(c->d_ft_vals.p, c->h_ft_vals.data(), n_kept * 4, hipMemcpyHostToDevice, c->stream));
 	if (int rc = hao_build_bucket(c, c->d_ft_keys.p, n_kept, 16, c->d_ft_bucket)) return rc;
+	if (int rc = hao_ft_build_hash(c, n_kept)) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	kcnt.release(); slots.release(); chunks.release(); kmer_off.release(); kh_chunk_off.release();
 	c->has_ft = true;
