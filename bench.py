@@ -196,6 +196,12 @@ def run_workload(a, workload, steps, warmup, rank, local_rank, world, dist, torc
     # with delivery a pass needs at least two batches for the copy of one to run under the compute of the next: a pass that fits one batch is cut in two
     # (more pieces hide more of the copy but pay the tails of the per-batch kernels once per piece: four pieces measured slower on every small workload)
     dranges = ranges if len(ranges) >= 2 else [(n_reads * i // 2, n_reads * (i + 1) // 2) for i in range(2) if n_reads * (i + 1) // 2 > n_reads * i // 2]
+    # the copy of a pass's LAST batch has no kernels to run under (~1 GB = 19 ms at 55 GB/s on configs[2]): the last range is cut into 1/2 + 1/4 + 1/4, so only a
+    # quarter batch's copy is exposed at the end of the pass (two more batches cost ~1 ms each of per-batch tails)
+    if len(dranges) >= 4 and not a.no_tail_split:
+        lo_, hi_ = dranges[-1]; m1, m2 = lo_ + (hi_ - lo_) // 2, lo_ + 3 * (hi_ - lo_) // 4
+        if lo_ < m1 < m2 < hi_:
+            dranges = dranges[:-1] + [(lo_, m1), (m1, m2), (m2, hi_)]
 
     views = {}
 
@@ -394,6 +400,7 @@ def main():
     ap.add_argument("--boundary-contexts", type=int, default=1, help="batch contexts of the boundary-inclusive measurement")
     ap.add_argument("--no-variants", action="store_true", help="skip the repeat-rich twin of the workload (the `variants` block of the line)")
     ap.add_argument("--variant-steps", type=int, default=5, help="timed steps of the variant (at most --steps)")
+    ap.add_argument("--no-tail-split", action="store_true", help="delivered pass: do not cut the last batch into 1/2 + 1/4 + 1/4 (A/B)")
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed pass that digests the delivered bytes and compares them with the reference's digests")
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()

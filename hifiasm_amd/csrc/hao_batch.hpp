@@ -451,7 +451,13 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		HAO_CHECK_LAUNCH();
 		hipLaunchKernelGGL((chain_select4_kernel<1024>), dim3((unsigned)n), dim3(256), 0, c->stream, sa, (int64_t)513, (int64_t)1025);
 		HAO_CHECK_LAUNCH();
-		hipLaunchKernelGGL((chain_select_kernel<1, 1024>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)1025, (int64_t)INT64_MAX);
+		// reads that cross repeat families: thousands of chains (250 Mb repeat-rich set: a quarter of the reads have more than 1024).  With the keys in global scratch
+		// and one wave per read those took 17 ms per batch; 64 / 128 KB of LDS per read keeps them on the four-wave path
+		hipLaunchKernelGGL((chain_select4_kernel<2048>), dim3((unsigned)n), dim3(256), 0, c->stream, sa, (int64_t)1025, (int64_t)2049);
+		HAO_CHECK_LAUNCH();
+		hipLaunchKernelGGL((chain_select4_kernel<4096>), dim3((unsigned)n), dim3(256), 0, c->stream, sa, (int64_t)2049, (int64_t)4097);
+		HAO_CHECK_LAUNCH();
+		hipLaunchKernelGGL((chain_select_kernel<1, 1024>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)4097, (int64_t)INT64_MAX);
 	}
 	HAO_CHECK_LAUNCH();
 	if (int rc = hao_scan_u32(c, B.n_final.p, B.O().fin_off.p, n + 1)) return rc;

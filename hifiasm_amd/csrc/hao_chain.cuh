@@ -373,7 +373,7 @@ __device__ __forceinline__ hao_hit_t hao_shfl_up_hit(const hao_hit_t &h)      //
 // scores with per-pair validity flags - and no second chain qualifies for multi-copy output; then the best
 // block IS the chain: hits are copied through, the fake cigar is a flagged compaction.  >99.9 % of groups on
 // repeat-free genomes.  Everything else runs hao_chain_generic on lane 0 (exact sequential algorithm).
-__global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, const hao_gent *list, uint64_t n_list, uint32_t *slow, int cls)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void chain_group_kernel(hao_chain_args A, const hao_gent *list, uint64_t n_list, uint32_t *slow, int cls)
 {
 	const uint64_t li = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	if (li >= n_list) return;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 	// ---- parallel quick check ----
 	int32_t carry_f = 0; hao_hit_t carry_h = first0;
 	bool fail0 = false, fail1 = false; int32_t maxf0 = INT32_MIN, maxf1 = INT32_MIN, flast0 = 0, flast1 = 0, k1 = 0; int64_t ddt0 = 0, ddt1 = 0;
-	hao_hit_t last0 = first0, last1 = first0;
+	uint32_t last0_so = first0.self_offset, last0_of = first0.offset, last1_so = last0_so, last1_of = last0_of;      // (self_offset, offset) of each block's last hit: all that is used of it
 	for (int32_t t0 = 0; t0 < a_n; t0 += 64) {
 		const int32_t idx = t0 + lane; const bool act = idx < a_n;
 		hao_hit_t h = act ? hn : carry_h;
@@ -435,14 +435,15 @@ __global__ __launch_bounds__(256) void chain_group_kernel(hao_chain_args A, cons
 		const uint32_t nw0 = hao_wave_shl1(h.w0, (uint32_t)__builtin_amdgcn_readfirstlane((int)hn.w0));
 		const bool isend = act && (idx == a_n - 1 || (nw0 >> 31) != HH_STRAND(h));
 		unsigned long long m0 = __ballot(isend && b == 0), m1 = __ballot(isend && b == 1);
-		if (m0) { int src = __ffsll((long long)m0) - 1; flast0 = hao_bcast(f, src); last0 = hao_shfl_hit(h, src); }
-		if (m1) { int src = __ffsll((long long)m1) - 1; flast1 = hao_bcast(f, src); last1 = hao_shfl_hit(h, src); }
+		if (m0) { int src = __ffsll((long long)m0) - 1; flast0 = hao_bcast(f, src); last0_so = hao_bcast(h.self_offset, src); last0_of = hao_bcast(h.offset, src); }
+		if (m1) { int src = __ffsll((long long)m1) - 1; flast1 = hao_bcast(f, src); last1_so = hao_bcast(h.self_offset, src); last1_of = hao_bcast(h.offset, src); }
 		carry_f = hao_bcast(f, 63); carry_h = hao_shfl_hit(h, 63);
 	}
 	maxf0 = hao_wave_max_i32(maxf0); maxf1 = hao_wave_max_i32(maxf1); ddt0 = hao_wave_sum_i64(ddt0); ddt1 = hao_wave_sum_i64(ddt1);
 	const unsigned long long tq2 = A.dbg_qc ? wall_clock64() + (unsigned long long)(maxf0 & 0) : 0;
 	const bool two = k1 < a_n;
 	const hao_hit_t first1 = two ? a[k1] : first0;
+	hao_hit_t last0, last1; last0.w0 = first0.w0; last0.cnt = 0; last0.self_offset = last0_so; last0.offset = last0_of; last1.w0 = first1.w0; last1.cnt = 0; last1.self_offset = last1_so; last1.offset = last1_of;
 	bool acc0 = !fail0 && flast0 == maxf0 && !(k1 >= 2 && ddt0 > 16 && ddt0 > hao_band(last0, first0, P));
 	bool acc1 = two && !fail1 && flast1 == maxf1 && !(a_n - k1 >= 2 && ddt1 > 16 && ddt1 > hao_band(last1, first1, P));
 	bool fast = acc0 && (!two || acc1);
