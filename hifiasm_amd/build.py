@@ -22,9 +22,10 @@ CSRC = os.path.join(PKG, "csrc")
 ORACLE = os.path.join(ROOT, "oracle")
 REF = "/root/reference"
 
-HIP_SOURCES = ["hao_capi.hip"]          # single translation unit that #includes the kernel files
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+HIP_SOURCES = ["hao_capi.hip", "hao_f3.hip"]      # two translation units that #include the kernel files (the second: f3's 36 window-alignment kernels); compiled side by side
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                "-Wno-unused-result", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+OBJ_DIR = os.path.join(PKG, "_obj")      # object files (git-ignored, not needed on the GPU box)
 
 
 def _newer(target: str, deps) -> bool:
@@ -52,7 +53,19 @@ def build_hip(force=False):
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "hao.h")]
     if force or _newer(out, deps):
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-        _run([hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in HIP_SOURCES] + ["-o", out, "-L/opt/rocm/lib", "-lrccl", "-lpthread"])
+        os.makedirs(OBJ_DIR, exist_ok=True)
+        objs, procs = [], []
+        for src in HIP_SOURCES:
+            obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+            objs.append(obj)
+            if force or _newer(obj, deps):
+                cmd = [hipcc] + HIPCC_FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+                print("[build]", " ".join(cmd), flush=True)
+                procs.append((cmd, subprocess.Popen(cmd)))
+        for cmd, pr in procs:
+            if pr.wait() != 0:
+                raise subprocess.CalledProcessError(pr.returncode, cmd)
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out, "-L/opt/rocm/lib", "-lrccl", "-lpthread"])
     return out
 
 

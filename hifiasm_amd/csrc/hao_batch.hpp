@@ -2,6 +2,7 @@
 #pragma once
 #include "hao_tables.hpp"
 #include "hao_query.cuh"
+#include "hao_query2.cuh"
 #include "hao_chain.cuh"
 
 struct hao_ctx::Batch {
@@ -16,7 +17,7 @@ struct hao_ctx::Batch {
 	DevBuf<int32_t> f, ii, p, key_sc, tm; DevBuf<int64_t> t; DevBuf<uint64_t> key_xs; DevBuf<uint32_t> key_al, key_tmp;
 	DevBuf<hao_chain_rec> rec; DevBuf<hao_ovlp_t> ol; DevBuf<hao_cdesc> cd; bool cl_valid = false;
 	DevBuf<uint16_t> hq, ohq; DevBuf<uint8_t> hcode;      // delivery path: query minimizer index / wire code of every seed hit (seed kernel, chain_group_kernel)
-	DevBuf<uint32_t> pk_cnt; uint64_t n_codes = 0;      // one code byte per chained hit (device only) before it is split into bits + code bytes
+	DevBuf<uint32_t> pk_cnt, pk_ecnt, pk_erank; uint64_t n_codes = 0;      // one code byte per chained hit (device only) before it is split into bits + code bytes
 	// Results of a batch that leave the device.  Two sets (+ two pinned host arenas): while the copy stream drains the set of batch i, batch i + 1
 	// computes into the other one (hao_overlap_batch_async).  The blocking API keeps using the current set.
 	struct OutSet {
@@ -40,7 +41,7 @@ struct hao_ctx::Batch {
 		s_start.release(); a_off.release(); seg.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fcf_off.release();
 		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); g_cls.release(); slow.release(); ovf_list.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
-		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); cd.release(); pk_cnt.release(); hq.release(); ohq.release(); hcode.release(); out[0].release(); out[1].release();
+		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); cd.release(); pk_cnt.release(); pk_ecnt.release(); pk_erank.release(); hq.release(); ohq.release(); hcode.release(); out[0].release(); out[1].release();
 		if (dl_ready) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); for (int k = 0; k < n_aux; ++k) { (void)hipStreamSynchronize(copy_aux[k]); (void)hipStreamDestroy(copy_aux[k]); (void)hipEventDestroy(ev_aux[0][k]); (void)hipEventDestroy(ev_aux[1][k]); } for (int x = 0; x < 2; ++x) { (void)hipEventDestroy(ev_ready[x]); (void)hipEventDestroy(ev_done[x]); if (arena[x]) (void)hipHostFree(arena[x]); arena[x] = nullptr; arena_cap[x] = 0; } dl_ready = false; }
 	}
 };
@@ -274,8 +275,8 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		const uint32_t tile_ = c->sw.seed_tile == 512 ? 512 : 1024;
 		const size_t lds_tile = std::max<size_t>((size_t)tile_ * (sizeof(hao_stage_t) + 4), 12 * 512);      // staged tile (>= the 12 bytes per slot of the bin sort it shares memory with)
 		const size_t lds_q = 12 * (size_t)sa_.qcap + 16;
-		const size_t lds1 = (size_t)22 * 512 + lds_tile + lds_q + (size_t)c->sw.seed_lds_pad, lds2 = (size_t)22 * 1024 + std::max<size_t>(lds_tile, 12 * 1024) + lds_q,
-					 lds3 = (size_t)22 * 2048 + std::max<size_t>(lds_tile, 12 * 2048) + lds_q;      // (third launch: 2048 slots = up to 1760 bins per id-range round)
+		size_t lds1 = (size_t)22 * 512 + lds_tile + lds_q + (size_t)c->sw.seed_lds_pad, lds2 = (size_t)22 * 1024 + std::max<size_t>(lds_tile, 12 * 1024) + lds_q,
+			   lds3 = (size_t)22 * 2048 + std::max<size_t>(lds_tile, 12 * 2048) + lds_q;      // (third launch: 2048 slots = up to 1760 bins per id-range round)
 		auto launch = [&](auto k1, auto k2, auto k3) -> int {
 			{     // beyond the default dynamic LDS limit: opt in (the CU has 160 KB)
 				HIP_TRY(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
@@ -290,8 +291,15 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			HAO_CHECK_LAUNCH();
 			return HAO_OK;
 		};
-		if (tile_ == 512) { if (int rc = launch(seed_bin_kernel<9, 0, 512>, seed_bin_kernel<10, 1, 512>, seed_bin_kernel<11, 2, 512>)) return rc; }
-		else if (int rc = launch(seed_bin_kernel<9, 0, 1024>, seed_bin_kernel<10, 1, 1024>, seed_bin_kernel<11, 2, 1024>)) return rc;
+		if (c->sw.seed_v2) {      // A/B (round 4, measured slower): the scatter pass without workgroup barriers (hao_query2.cuh)
+			const size_t q_ = lds_q + (size_t)c->sw.seed_lds_pad;
+			lds1 = hao_seed2_lds<9>::FIXED + q_; lds2 = hao_seed2_lds<10>::FIXED + lds_q; lds3 = hao_seed2_lds<11>::FIXED + lds_q;
+			if (c->sw.seed_pf) { if (int rc = launch(seed_bin2_kernel<9, 0, true>, seed_bin2_kernel<10, 1, true>, seed_bin2_kernel<11, 2, true>)) return rc; }
+			else if (int rc = launch(seed_bin2_kernel<9, 0, false>, seed_bin2_kernel<10, 1, true>, seed_bin2_kernel<11, 2, true>)) return rc;
+		}
+		else if (tile_ != 512) { if (int rc = launch(seed_bin_kernel<9, 0, 1024, false>, seed_bin_kernel<10, 1, 1024, false>, seed_bin_kernel<11, 2, 1024, false>)) return rc; }
+		else if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql) { if (int rc = launch(seed_bin_kernel<9, 0, 512, true>, seed_bin_kernel<10, 1, 512, true>, seed_bin_kernel<11, 2, 512, true>)) return rc; }      // every read's minimizer table fits the LDS
+		else if (int rc = launch(seed_bin_kernel<9, 0, 512, false>, seed_bin_kernel<10, 1, 512, false>, seed_bin_kernel<11, 2, 512, false>)) return rc;
 	}
 	if (c->sw.seedphase) { unsigned long long d_[4]; HIP_TRY(hipMemcpy(d_, B.dbgbuf.p, 32, hipMemcpyDeviceToHost)); if (d_[3]) fprintf(stderr, "[seed] blocks %llu  avg us: count pass %.1f  sort+scan %.1f  scatter pass %.1f\n", d_[3], d_[0] / 100.0 / d_[3], d_[1] / 100.0 / d_[3], d_[2] / 100.0 / d_[3]); }
 	c->timer.mark("q_sort_bins");
@@ -396,11 +404,16 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		hao_ctx::Batch::OutSet &O = B.O();
 		hipLaunchKernelGGL(hao_pack_hdr_kernel, dim3((unsigned)((NCmax + 255) / 256)), dim3(256), 0, c->stream, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH();
 		if (!pa.have_codes) { hipLaunchKernelGGL(hao_pack_ohits_kernel, dim3((unsigned)std::min<uint64_t>((NCmax + 3) / 4, 1u << 16)), dim3(256), 0, c->stream, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH(); }      // (HAO_DBG_PACK_SEARCH: every chain coded by the packer)
-		hipLaunchKernelGGL(hao_pack_bits_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, c->stream, pa, A, NW, O.bits.p, B.pk_cnt.p); HAO_CHECK_LAUNCH();
+		const bool scan_exc = pa.have_codes != 0;      // verbatim list by count + scan, in position order (the HAO_DBG_PACK_SEARCH packer appends its own entries through the counter: that list is sorted afterwards)
+		hipLaunchKernelGGL(hao_pack_bits_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, c->stream, pa, A, NW, O.bits.p, B.pk_cnt.p, scan_exc ? B.pk_ecnt.p : (uint32_t*)nullptr); HAO_CHECK_LAUNCH();
 		size_t tb = 0;
 		HIP_TRY(rocprim::exclusive_scan(nullptr, tb, B.pk_cnt.p, O.rank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), c->stream)); HIP_TRY(hao_tmp(c, tb));
 		HIP_TRY(rocprim::exclusive_scan(c->d_tmp.p, tb, B.pk_cnt.p, O.rank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), c->stream));
 		hipLaunchKernelGGL(hao_pack_codes_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, c->stream, B.hcode.p, A, O.bits.p, O.rank.p, NW, O.codes.p, d_n_codes); HAO_CHECK_LAUNCH();
+		if (scan_exc) {
+			HIP_TRY(rocprim::exclusive_scan(c->d_tmp.p, tb, B.pk_ecnt.p, B.pk_erank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), c->stream));
+			hipLaunchKernelGGL(hao_pack_exc_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, c->stream, pa, A, NW, B.pk_erank.p); HAO_CHECK_LAUNCH();
+		}
 		return HAO_OK;
 	};
 	if (parts & HAO_DELIVER_CL) {
@@ -408,6 +421,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		HIP_TRY(O.hdr.reserve(NCmax + 1)); HIP_TRY(O.exc.reserve(c->sw.exc_cap >= 0 ? (uint64_t)c->sw.exc_cap + 1 : std::max<uint64_t>(1 << 14, A / 256)));
 		HIP_TRY(O.bits.reserve(NW + 2)); HIP_TRY(O.rank.reserve(NW + 2)); HIP_TRY(B.pk_cnt.reserve(NW + 2)); HIP_TRY(O.codes.reserve(A + 16));
 		HIP_TRY(hipMemsetAsync(B.pk_cnt.p + NW, 0, 4, c->stream));      // (the scan runs over NW + 1 counts: its last output is the total)
+		HIP_TRY(B.pk_ecnt.reserve(NW + 2)); HIP_TRY(B.pk_erank.reserve(NW + 2)); HIP_TRY(hipMemsetAsync(B.pk_ecnt.p + NW, 0, 4, c->stream));
 		HIP_TRY(O.ch_off.reserve(n + 2)); HIP_TRY(O.cl_off.reserve(n + 2)); HIP_TRY(O.qm_off.reserve(n + 2)); HIP_TRY(O.qmz.reserve(nm + 1));
 		pa.cd = B.cd.p; pa.hits = B.hits.p; pa.ohits = B.ohits.p; pa.mz_off = c->d_ix_mz_off.p; pa.seg = B.seg.p; pa.n_sel = n; pa.rid_lo = lo; pa.mz0 = B.mz0; pa.q_pos = B.q_pos.p;
 		pa.hq = c->sw.pack_search ? nullptr : B.hq.p; pa.ohq = c->sw.pack_search ? nullptr : B.ohq.p; pa.have_codes = c->sw.pack_search ? 0 : 1;
@@ -493,7 +507,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		B.n_codes = c->peek_h[6];
 		n_exc = c->peek_h[5];
 	}
-	if ((parts & HAO_DELIVER_CL) && n_exc > 1) {      // the list was appended in arrival order: sort it by hit index (the decoder looks hits up; also makes the bytes deterministic)
+	if ((parts & HAO_DELIVER_CL) && n_exc > 1 && !pa.have_codes) {      // (HAO_DBG_PACK_SEARCH) the list was appended in arrival order: sort it by hit index (the decoder looks hits up; also makes the bytes deterministic)
 		hao_ctx::Batch::OutSet &O = B.O(); size_t tb = 0;
 		HIP_TRY(O.exc2.reserve(n_exc + 1));
 		HIP_TRY(rocprim::merge_sort(nullptr, tb, O.exc.p, O.exc2.p, (size_t)n_exc, ExcLess(), c->stream)); HIP_TRY(hao_tmp(c, tb));

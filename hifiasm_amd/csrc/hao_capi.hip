@@ -11,7 +11,6 @@
 #include "hao_query.cuh"
 #include "hao_chain.cuh"
 #include "hao_deliver.cuh"
-#include "hao_align.cuh"
 #include "hao_comm.hpp"
 #include "hao_pipeline.hpp"
 #include "hao_tables.hpp"

@@ -57,15 +57,20 @@ struct StageTimer {
 // run-time switches (measurement aids): read from the environment ONCE, in hao_create
 struct hao_switches {
 	bool seedphase = false, qcphase = false, dp_stats = false, seq_chain = false, dp_seqtail = false, dp_nospec = false, dp_serial = false,
-		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, sk_v2 = false, dltime = false, sk_nofuse = false, pack_search = false, sk_select2 = false;
+		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, sk_v2 = false, dltime = false, sk_nofuse = false, pack_search = false, sk_select2 = false, seed_v2 = false, seed_pf = true, seed_noql = false, sort64 = false;
 	static constexpr bool SK_SELECT2_DEFAULT = true;       // the thinning kernel the sketch runs when the environment says nothing: the wave kernel (round 4: green on the device against every repeat-rich scenario and the 5 Mb / 250 Mb repeat-rich fixtures)
-	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; int exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, seed_lds_pad = 0, arena_numa = 1, seed_tile = 512;
+	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; unsigned long long ix_pad = 0; int exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, seed_lds_pad = 0, arena_numa = 1, seed_tile = 512;
 	void load() {
 		auto on = [](const char *n) { return getenv(n) != nullptr; };
 		seedphase = on("HAO_DBG_SEEDPHASE"); qcphase = on("HAO_DBG_QCPHASE"); dp_stats = on("HAO_DBG_DP_STATS"); seq_chain = on("HAO_DBG_SEQ_CHAIN");
 		dp_seqtail = on("HAO_DBG_DP_SEQTAIL"); dp_nospec = on("HAO_DBG_DP_NOSPEC"); dp_serial = on("HAO_DBG_DP_SERIAL"); seq_prune = on("HAO_DBG_SEQ_PRUNE");
 		selphase = on("HAO_DBG_SELPHASE"); sel1 = on("HAO_DBG_SEL1"); sk_generic = on("HAO_DBG_SK_GENERIC"); sk_v2 = on("HAO_DBG_SK_V2"); sk_nofuse = on("HAO_DBG_SK_NOFUSE"); pack_search = on("HAO_DBG_PACK_SEARCH");      // the wire packer searches every hit's minimizer (round-2 path) instead of gathering the quick check's code bytes
 		dltime = on("HAO_DBG_DLTIME");
+		seed_v2 = on("HAO_SEED_V2");      // A/B: the seed kernel with a wave-private, barrier-free scatter pass (hao_query2.cuh; round 4: bit-exact, 1.5 x slower - fewer waves per CU)
+		if (const char *e = getenv("HAO_DBG_IX_PAD")) ix_pad = strtoull(e, nullptr, 10);      // tests: unused position records in front of the index (list starts beyond 2^32 on a small read set)
+		sort64 = on("HAO_PT_SORT64");      // A/B: the index sort over all 64 hash bits (8 passes) instead of 40 bits + fix-up (hao_index.cuh)
+		seed_noql = on("HAO_SEED_NOQL");  // A/B: the seed kernel's generic per-minimizer tables (LDS or global, all minimizers) even when every read of the batch fits the LDS
+		if (const char *e = getenv("HAO_SEED_PF")) seed_pf = atoi(e) != 0;      // 0: first launch of the seed kernel without the next tile's reads in flight (A/B)
 		sk_select2 = on("HAO_SK_SELECT2") || (SK_SELECT2_DEFAULT && !on("HAO_SK_SELECT1"));      // thinning of high-count minimizers: the wave kernel (hao_select2.cuh) / the one-lane replay (sketch_select_kernel)
 		if (const char *e = getenv("HAO_CHAIN_WPB")) chain_wpb = std::max(1, std::min(4, atoi(e)));
 		if (const char *e = getenv("HAO_SPEC_MINCLS")) spec_mincls = atoi(e);
@@ -84,7 +89,7 @@ struct hao_switches {
 // A few words the host needs from the device in the middle of a batch (sizes for the next allocation): written by a one-wave kernel into pinned,
 // device-mapped host memory instead of a hipMemcpy.  A D2H memcpy - however small - queues on the device-to-host DMA engine, behind the bulk copy of the
 // previous batch's results that the delivery path has in flight there: the "asynchronous" delivery would serialise with the compute it should hide under.
-__global__ void hao_peek_kernel(const unsigned long long *src, int n, unsigned long long *dst)
+static __global__ void hao_peek_kernel(const unsigned long long *src, int n, unsigned long long *dst)
 { if ((int)threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x]; }
 
 struct hao_ctx {
@@ -116,12 +121,13 @@ struct hao_ctx {
 	std::vector<uint64_t> h_mz_off; std::vector<hao_mz_t> h_mz_fetch;
 	// ---- index (pt) ----
 	bool has_pt = false; int64_t pt_hist[HAO_N_COUNTS];
-	uint64_t ix_n_mz = 0, ix_n_sorted = 0, ix_n_keys = 0, ix_n_pos = 0; int ix_bucket_bits = 16;   // ix_n_mz: local read-ordered records; ix_n_sorted: records in the (replicated) index
+	uint64_t ix_n_mz = 0, ix_n_sorted = 0, ix_n_keys = 0, ix_n_pos = 0, ix_pad = 0; int ix_bucket_bits = 16;   // ix_n_mz: local read-ordered records; ix_n_sorted: records in the (replicated) index
 	DevBuf<uint64_t> d_ix_mz_x, d_ix_mz_info, d_ix_mz_off;  // all reads' minimizers in read order (query side reuses them)
 	DevBuf<uint64_t> d_ix_sx, d_ix_sinfo;                    // sorted by hash (stable)
 	DevBuf<uint64_t> d_ix_lk; bool lk_valid = false; DevBuf<uint32_t> w_runid;   // per minimizer (read order): list start | count << 48 of its key (single-device build)
 	DevBuf<uint64_t> d_ix_keys, d_ix_start; DevBuf<uint32_t> d_ix_cnt; DevBuf<uint32_t> d_ix_bucket;
 	DevBuf<uint64_t> w_ukeys, w_flag, w_kpos, w_ustart; DevBuf<uint32_t> w_ucnt; DevBuf<unsigned long long> w_hist; DevBuf<uint32_t> w_ok, w_ok2, w_oi, w_oi2;   // persistent scratch of the index build
+	DevBuf<uint32_t> w_s40_list, w_s40_o; DevBuf<uint64_t> w_s40_x; DevBuf<unsigned long long> w_s40_cnt; uint64_t s40_runs = 0;      // fix-up of the 40-bit index sort (hao_index.cuh)
 	std::vector<uint64_t> h_ix_keys, h_ix_off, h_ix_pos, h_ix_mz_off; bool h_ix_valid = false;
 	// ---- query batch ----
 	// f3 (hao_align.cuh): scratch of the window-alignment batches, kept between calls (a hipMalloc / hipFree pair per buffer and call cost more than the kernels)
@@ -162,7 +168,7 @@ static int hao_view_refresh(hao_ctx *c)
 	c->opt = o->opt;
 	c->n_reads = o->n_reads; c->n_bases = o->n_bases; c->n_pk_bytes = o->n_pk_bytes; c->has_n = o->has_n; c->max_len = o->max_len;
 	c->rid_base = o->rid_base; c->n_total = o->n_total; c->max_n_chain = o->max_n_chain; c->hom_cov = o->hom_cov; c->het_cov = o->het_cov;
-	c->has_pt = o->has_pt; c->ix_n_mz = o->ix_n_mz; c->ix_n_sorted = o->ix_n_sorted; c->ix_n_keys = o->ix_n_keys; c->ix_n_pos = o->ix_n_pos; c->ix_bucket_bits = o->ix_bucket_bits; c->lk_valid = o->lk_valid;
+	c->has_pt = o->has_pt; c->ix_n_mz = o->ix_n_mz; c->ix_n_sorted = o->ix_n_sorted; c->ix_n_keys = o->ix_n_keys; c->ix_n_pos = o->ix_n_pos; c->ix_pad = o->ix_pad; c->ix_bucket_bits = o->ix_bucket_bits; c->lk_valid = o->lk_valid;
 	c->h_len = o->h_len; c->h_nsite_off = o->h_nsite_off; c->h_len_all = o->h_len_all; c->h_ix_mz_off = o->h_ix_mz_off;      // (empty: copied from the device on first use)
 	c->d_packed.borrow(o->d_packed); c->d_pk_off.borrow(o->d_pk_off); c->d_len.borrow(o->d_len); c->d_len_all.borrow(o->d_len_all); c->d_nsite_off.borrow(o->d_nsite_off); c->d_nsite.borrow(o->d_nsite);
 	c->d_ix_mz_x.borrow(o->d_ix_mz_x); c->d_ix_mz_info.borrow(o->d_ix_mz_info); c->d_ix_mz_off.borrow(o->d_ix_mz_off); c->d_ix_sinfo.borrow(o->d_ix_sinfo); c->d_ix_lk.borrow(o->d_ix_lk);

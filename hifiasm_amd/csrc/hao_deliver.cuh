@@ -153,7 +153,10 @@ __global__ __launch_bounds__(256) void hao_pack_ohits_kernel(hao_pack_args A, co
 // One byte per position -> bit stream + per-word counts of the rank directory; a 0xff met on the way (the quick check could not express the hit) becomes
 // an entry of the verbatim list: the seed hit at the position and its minimizer index.  Thread t takes positions [8t, 8t + 8) (one 8-byte load); the
 // eight threads of a 64-position word combine their flags.
-__global__ __launch_bounds__(256) void hao_pack_bits_kernel(hao_pack_args A, uint64_t n, uint64_t n_words, uint64_t *bits, uint32_t *cnt)
+// (ecnt != nullptr: the verbatim entries are NOT appended here - their number per word goes to ecnt[], a scan turns the counts into list positions and
+// hao_pack_exc_kernel writes the entries in position order.  A repeat-rich 250 Mb batch has 14 M verbatim hits in 1.3 M waves: one atomic per wave on the list's
+// counter - all on one address - made this kernel 11 ms instead of 0.3, and the list then needed a 24-byte-record merge sort by position, ~10 ms more.)
+__global__ __launch_bounds__(256) void hao_pack_bits_kernel(hao_pack_args A, uint64_t n, uint64_t n_words, uint64_t *bits, uint32_t *cnt, uint32_t *ecnt)
 {
 	const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, w = t >> 3;
 	uint32_t m8 = 0, e8 = 0; uint64_t v = 0;
@@ -166,7 +169,11 @@ __global__ __launch_bounds__(256) void hao_pack_bits_kernel(hao_pack_args A, uin
 			if (8 * t + k < n && (b == 0xff || b == HAO_CODE_EXC_OHITS)) e8 |= 1u << k;
 		}
 	}
-	if (__ballot(e8 != 0)) {      // verbatim entries: one atomic per wave reserves the wave's slots (the repeat-rich sets have millions per pass)
+	if (ecnt) {
+		uint32_t ne = (uint32_t)__popc(e8);
+		ne += __shfl_xor(ne, 1); ne += __shfl_xor(ne, 2); ne += __shfl_xor(ne, 4);
+		if ((t & 7) == 0 && w < n_words) ecnt[w] = ne;
+	} else if (__ballot(e8 != 0)) {      // verbatim entries: one atomic per wave reserves the wave's slots (the repeat-rich sets have millions per pass)
 		const uint32_t ne = (uint32_t)__popc(e8), inc = hao_wave_incl_scan_u32(ne), tot = hao_bcast(inc, 63);
 		unsigned long long base = 0;
 		if (hao_lane() == 63) base = atomicAdd(A.exc_cnt, (unsigned long long)tot);
@@ -188,6 +195,36 @@ __global__ __launch_bounds__(256) void hao_pack_bits_kernel(hao_pack_args A, uin
 	uint64_t word = (uint64_t)m8 << ((t & 7) * 8);
 	word |= __shfl_xor(word, 1); word |= __shfl_xor(word, 2); word |= __shfl_xor(word, 4);
 	if ((t & 7) == 0 && w < n_words) { bits[w] = word; cnt[w] = (uint32_t)__popcll(word); }      // (no lane leaves early: the slot reservation above is wave-wide)
+}
+
+// the verbatim list in position order (no atomics, nothing to sort): erank = exclusive prefix of hao_pack_bits_kernel's per-word counts (n_words + 1 entries: the
+// last one is the total).  Thread t takes positions [8t, 8t + 8); the eight threads of a word learn their place inside the word from each other.
+__global__ __launch_bounds__(256) void hao_pack_exc_kernel(hao_pack_args A, uint64_t n, uint64_t n_words, const uint32_t *erank)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, w = t >> 3;
+	if (t == 0) *A.exc_cnt = erank[n_words];
+	uint32_t e8 = 0; uint64_t v = 0;
+	if (8 * t < n) {
+		v = *(const uint64_t*)(A.bytes + 8 * t);
+#pragma unroll
+		for (int k = 0; k < 8; ++k) { const uint8_t b = (uint8_t)(v >> (8 * k)); if (8 * t + k < n && (b == 0xff || b == HAO_CODE_EXC_OHITS)) e8 |= 1u << k; }
+	}
+	uint64_t eword = (uint64_t)e8 << ((t & 7) * 8);
+	eword |= __shfl_xor(eword, 1); eword |= __shfl_xor(eword, 2); eword |= __shfl_xor(eword, 4);      // (no lane leaves before this)
+	if (!e8) return;
+	unsigned long long kx = (unsigned long long)erank[w] + (unsigned long long)__popcll(eword & ((1ULL << ((t & 7) * 8)) - 1));
+	for (uint32_t m = e8; m; m &= m - 1, ++kx) {
+		if (kx >= A.exc_cap) continue;      // past the capacity only the count matters: the host grows the list and packs again
+		const uint64_t p = 8 * t + (uint32_t)(__ffs((int)m) - 1);
+		const bool oh = (uint8_t)(v >> (8 * (__ffs((int)m) - 1))) == HAO_CODE_EXC_OHITS;      // a hit of a chain the DP compacted: it (and its minimizer index) sit in ohits / ohq at the position
+		hao_exc_t e; e.index = p; e.pad = 0; e.hit = oh ? A.ohits[p] : A.hits[p]; e.q = oh ? A.ohq[p] : (A.hq ? A.hq[p] : 65535u);
+		if (e.q == 65535u) {      // the 16-bit index saturated (a read of > 65 534 minimizers): the read of the position, then its table
+			uint64_t lo = 0, hi = A.n_sel; while (hi - lo > 1) { const uint64_t md = (lo + hi) >> 1; if (A.seg[md] <= p) lo = md; else hi = md; }
+			const uint64_t m0 = A.mz_off[A.rid_lo + lo];
+			e.q = hao_pack_find_q(A.q_pos + (m0 - A.mz0), (uint32_t)(A.mz_off[A.rid_lo + lo + 1] - m0), e.hit.self_offset);
+		}
+		A.exc[kx] = e;
+	}
 }
 
 // code bytes of the flagged positions, at their rank: thread t takes positions [8t, 8t + 8)

@@ -227,7 +227,7 @@ static int hao_index_load_impl(hao_ctx *c, const char *prefix, int32_t *number_o
 	if (nk) { HIP_TRY(hipMemcpyAsync(c->d_ix_keys.p, keys.data(), nk * 8, hipMemcpyHostToDevice, c->stream)); HIP_TRY(hipMemcpyAsync(c->d_ix_start.p, start.data(), nk * 8, hipMemcpyHostToDevice, c->stream));
 			  HIP_TRY(hipMemcpyAsync(c->d_ix_cnt.p, cnt.data(), nk * 4, hipMemcpyHostToDevice, c->stream)); }
 	if (np) HIP_TRY(hipMemcpyAsync(c->d_ix_sinfo.p, sinfo.data(), np * 8, hipMemcpyHostToDevice, c->stream));
-	c->ix_n_keys = nk; c->ix_n_pos = np; c->ix_n_sorted = np;
+	c->ix_n_keys = nk; c->ix_n_pos = np; c->ix_n_sorted = np; c->ix_pad = 0;
 	int bits = 16; while ((1ULL << bits) < nk / 2 && bits < 26) ++bits;
 	if (int rc = hao_build_bucket(c, c->d_ix_keys.p, nk, bits, c->d_ix_bucket)) return rc;
 	c->ix_bucket_bits = bits;

@@ -161,6 +161,59 @@ __global__ void hao_iota_kernel(uint32_t *v, uint64_t n)
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) v[i] = (uint32_t)i;
 }
+// ---- the index sort on 40 of the 64 hash bits ----
+// The (hash, read-order index) sort is LSD radix, 8 bits per pass: 8 passes of 24 bytes per element.  Two minimizers whose hashes agree in the top 40
+// bits but not below are rare (n^2 / 2^41 pairs of distinct keys: a few hundred on a 250 Mb genome, ~10^5 at human size), so the sort covers bits 24 .. 63
+// in 5 passes and the few 40-bit runs that hold more than one key are put right afterwards: hao_sort40_mark_kernel lists the runs that have a descent
+// (a run without one is already in full-key order, and stable), hao_sort40_fix_kernel - one wave per listed run - rewrites the run key by key in ascending
+// order, each key's elements in their current (= read) order, through a scratch piece.  Same result as the stable 64-bit sort, bit for bit.
+#define HAO_SORT40_LOWBITS 24
+__global__ void hao_sort40_mark_kernel(const uint64_t *sx, uint64_t m, uint32_t *list, unsigned long long *cnt, uint64_t cap)
+{
+	const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+	if (j >= m) return;
+	const uint64_t b = sx[j], a = sx[j - 1], top = b >> HAO_SORT40_LOWBITS;
+	if ((a >> HAO_SORT40_LOWBITS) != top || a <= b) return;
+	uint64_t i = j - 1;      // walk back to the head of the run; an earlier descent reports the run instead of this one
+	while (i > 0 && (sx[i - 1] >> HAO_SORT40_LOWBITS) == top) { if (sx[i - 1] > sx[i]) return; --i; }
+	const unsigned long long k = atomicAdd(cnt, 1ULL);
+	if (k < cap) list[k] = (uint32_t)i;
+}
+// cnt[0] = listed runs, cnt[1] = scratch cursor, cnt[2] = 1 if the scratch ran out (the host then sorts all 64 bits)
+__global__ __launch_bounds__(64) void hao_sort40_fix_kernel(uint64_t *sx, uint32_t *oi, uint64_t m, const uint32_t *list, unsigned long long *cnt, uint64_t cap, uint64_t *tx, uint32_t *to, uint64_t tcap)
+{
+	const uint64_t n_runs = cnt[0] < cap ? cnt[0] : cap;
+	if (blockIdx.x >= n_runs) return;
+	const int lane = hao_lane();
+	const uint64_t s = list[blockIdx.x], top = sx[s] >> HAO_SORT40_LOWBITS;
+	uint64_t e = s;
+	for (;;) {      // end of the run, 64 positions per step
+		const uint64_t i = e + lane; const unsigned long long bal = __ballot(i < m && (sx[i] >> HAO_SORT40_LOWBITS) == top);
+		if (bal == ~0ULL) { e += 64; continue; }
+		e += (uint64_t)(__ffsll((long long)~bal) - 1); break;
+	}
+	const uint64_t L = e - s;
+	unsigned long long base = 0;
+	if (lane == 0) base = atomicAdd(cnt + 1, (unsigned long long)L);
+	base = (unsigned long long)__shfl((long long)base, 0);
+	if (base + L > tcap) { if (lane == 0) cnt[2] = 1; return; }
+	uint64_t last = 0, out = 0; bool first = true;
+	while (out < L) {
+		uint64_t mn = ~0ULL;      // the smallest key not yet written
+		for (uint64_t i = s + lane; i < e; i += 64) { const uint64_t k = sx[i]; if ((first || k > last) && k < mn) mn = k; }
+#pragma unroll
+		for (int d = 32; d >= 1; d >>= 1) { const uint64_t o = (uint64_t)__shfl_xor((long long)mn, d); if (o < mn) mn = o; }
+		for (uint64_t i0 = s; i0 < e; i0 += 64) {      // its elements, in their current order
+			const uint64_t i = i0 + lane; const bool hit = i < e && sx[i] == mn; const unsigned long long bal = __ballot(hit);
+			if (hit) { const uint64_t pos = base + out + __popcll(bal & ((1ULL << lane) - 1)); tx[pos] = mn; to[pos] = oi[i]; }
+			out += __popcll(bal);
+		}
+		last = mn; first = false;
+	}
+	__threadfence();
+	for (uint64_t i = lane; i < L; i += 64) { sx[s + i] = tx[base + i]; oi[s + i] = to[base + i]; }
+}
+
 // j = position in hash order: gather its 8-byte record (the index lists) and scatter its lookup result to read order
 // (sharded build: the owner of a hash range runs this over what it RECEIVED - sidx = arrival index, base = first position of its partition in the
 // global index - and the lookup results travel back to the ranks the minimizers came from)

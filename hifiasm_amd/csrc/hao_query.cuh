@@ -43,8 +43,27 @@ __device__ __forceinline__ unsigned long long hao_match_bits(uint32_t d, bool ac
 	return m;
 }
 
+// Which minimizer holds each anchor of a 64-anchor window?  QL kernels stage only the read's NON-EMPTY minimizers, so their first-anchor offsets
+// ao[] increase strictly and a window of 64 anchors sees at most 64 list boundaries: lane i looks at boundary kc + 1 + i and pushes a flag to the lane of
+// its window position (ds_permute: lanes nobody writes to read 0; boundaries beyond the window are parked on lane 0, whose own anchor - the window's
+// first - is never a boundary because kc holds it), one ballot turns the flags into the window's boundary mask and a lane's minimizer is kc + the
+// boundaries at or before it.  Replaces a per-lane `while (ao[q + 1] <= x) ++q` (a divergent loop with an LDS round trip per step).
+// kc: compact index of the minimizer that holds anchor x0 (wave-uniform); on return, of the one that holds x0 + 64.  ao[nk] = the read's anchor count.
+__device__ __forceinline__ uint32_t hao_seed_locate(const uint32_t *ao, uint32_t nk, uint32_t &kc, uint32_t x0, int lane)
+{
+	const uint32_t cand = kc + 1 + lane, p = ao[cand < nk ? cand : nk] - x0;      // >= 1
+	const int got = __builtin_amdgcn_ds_permute((int)((p < 64 ? p : 0u) << 2), 1);
+	const unsigned long long M = __ballot(got != 0) & ~1ULL;
+	const uint32_t k = kc + __popcll(M & ((2ULL << lane) - 1));
+	kc += __popcll(M) + (__ballot(p == 64) != 0 ? 1u : 0u);
+	return k;
+}
+
 #define HAO_QTAB_CAP 4096     // most query minimizers whose offsets / list starts are staged in LDS per read; longer reads read them from global memory
 #define HAO_BIN_EMPTY 0xffffffffu
+// the workgroup's "table full" flag: relaxed LDS accesses (a volatile pointer to it compiled to flat loads, each followed by a wait for every outstanding index read)
+#define HAO_OVF() __hip_atomic_load(&s_ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define HAO_OVF_SET() __hip_atomic_store(&s_ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 
 // Q2-Q5 fused, one workgroup per read: pass A walks the read's anchors (minimizer q, list entry j) and counts bins, pass B walks them again
 // (the read's slices of the position lists are L2-resident by then) and writes each k_mer_hit to its final place.
@@ -74,8 +93,10 @@ struct hao_seed_args {
 struct hao_stage_t { uint32_t offset, self_offset, cnt; };
 // TIER 0: every read of the batch, gives up on overflow (-> ovf_list); TIER 1: the reads of in_list, gives up on overflow (-> ovf_list); TIER 2: the reads of in_list, in
 // as many (tid, rev) range rounds as their bins need
-template<int CAPLOG, int TIER, uint32_t HAO_SEED_TILE>
-__global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, const uint32_t *in_list, const unsigned long long *in_cnt, uint32_t *ovf_list, unsigned long long *ovf_cnt)
+// QL: every read of the batch has at most qcap minimizers (the host knows), so the per-minimizer tables always live in LDS: no uniform LDS / global
+// branch at every use, only the non-empty minimizers are staged (list start | query minimizer index << 48 | strand << 63), located by hao_seed_locate
+template<int CAPLOG, int TIER, uint32_t HAO_SEED_TILE, bool QL>
+__global__ __launch_bounds__(256, CAPLOG == 9 ? 6 : CAPLOG == 10 ? 3 : 1) void seed_bin_kernel(hao_seed_args S, const uint32_t *in_list, const unsigned long long *in_cnt, uint32_t *ovf_list, unsigned long long *ovf_cnt)
 {
 	constexpr bool FIRST = TIER == 0, GIVEUP = TIER < 2;
 	constexpr uint32_t CAP = 1u << CAPLOG, MAXD = CAP - 288;      // at most MAXD + 256 bins are ever inserted (one per thread after the table fills), so probing terminates; CAP >= 512
@@ -103,22 +124,38 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, const ui
 	if (FIRST && r == 0 && tid == 0) S.g_cnt[S.n_sel] = 0;
 	if (n == 0) { if (tid == 0) S.g_cnt[r] = 0; return; }
 	const uint64_t m0 = S.mz_off[S.rid_lo + r], li0 = m0 - S.mz0; const uint32_t nq = (uint32_t)(S.mz_off[S.rid_lo + r + 1] - m0);
-	const bool qlds = nq <= S.qcap;                // very long reads keep the per-minimizer table in global memory (uniform branches, no flat accesses)
+	const bool qlds = QL || nq <= S.qcap;          // very long reads keep the per-minimizer table in global memory (uniform branches, no flat accesses)
 	const uint64_t *g_ao = S.a_off + li0, *g_ss = S.s_start + li0, *g_info = S.mz_info + m0;
-	if (qlds) {
+	uint32_t nk = nq;                              // staged minimizers (QL: the non-empty ones)
+	if (QL) {
+		nk = 0;
+		for (uint32_t b = 0; b < nq; b += 256) {      // stable compaction of the minimizers that have anchors
+			const uint32_t q = b + tid; uint32_t a0 = 0, a1 = 0;
+			if (q < nq) { a0 = (uint32_t)(g_ao[q] - s); a1 = (uint32_t)(g_ao[q + 1] - s); }      // (a_off has an entry past the batch's last minimizer)
+			const bool ne = a1 > a0; const unsigned long long bal = __ballot(ne);
+			if (lane == 0) s_wt[wv] = (uint32_t)__popcll(bal);
+			__syncthreads();
+			uint32_t k = nk + (uint32_t)__popcll(bal & ((1ULL << lane) - 1)); for (int w = 0; w < wv; ++w) k += s_wt[w];
+			if (ne) { l_ao[k] = a0; l_ss[k] = g_ss[q] | (uint64_t)q << 48 | (uint64_t)hao_info_rev(g_info[q]) << 63; }
+			nk += s_wt[0] + s_wt[1] + s_wt[2] + s_wt[3];
+			__syncthreads();
+		}
+		if (tid == 0) l_ao[nk] = n;
+	} else if (qlds) {
 		for (uint32_t q = tid; q < nq; q += 256) { l_ss[q] = g_ss[q] | (uint64_t)hao_info_rev(g_info[q]) << 63; l_ao[q] = (uint32_t)(g_ao[q] - s); }
 		if (tid == 0) l_ao[nq] = n;
 	}
 	__syncthreads();
 	unsigned long long tk0 = S.dbg ? wall_clock64() : 0, tk1 = 0, tk2 = 0;
-#define HAO_AO(q) (qlds ? l_ao[q] : ((q) >= nq ? n : (uint32_t)(g_ao[q] - s)))
-#define HAO_SS(q) (qlds ? l_ss[q] : (g_ss[q] | (uint64_t)hao_info_rev(g_info[q]) << 63))
+#define HAO_AO(q) (QL ? l_ao[q] : (qlds ? l_ao[q] : ((q) >= nq ? n : (uint32_t)(g_ao[q] - s))))
+#define HAO_SS(q) (QL ? l_ss[q] : (qlds ? l_ss[q] : (g_ss[q] | (uint64_t)hao_info_rev(g_info[q]) << 63)))
+#define HAO_START(sv) ((sv) & (QL ? (1ULL << 48) - 1 : ~(1ULL << 63)))      /* list start of a staged minimizer word */
+#define HAO_QIDX(q, sv) (QL ? (uint32_t)((sv) >> 48) & 0xfffu : (q))      /* index of the minimizer in the read's full list */
 	const uint32_t chunk = ((n + 3) / 4 + 64 * UA - 1) / (64 * UA) * (64 * UA), c0 = min(n, wv * chunk), c1 = min(n, c0 + chunk);
 	uint32_t q_c0 = 0;       // minimizer holding anchor c0: last q with AO(q) <= c0 (binary search, uniform in the wave)
-	if (c0 < c1) { uint32_t lo_ = 0, hi_ = nq; while (hi_ - lo_ > 1) { const uint32_t md = (lo_ + hi_) >> 1; if (HAO_AO(md) <= c0) lo_ = md; else hi_ = md; } q_c0 = lo_; }
+	if (c0 < c1) { uint32_t lo_ = 0, hi_ = nk; while (hi_ - lo_ > 1) { const uint32_t md = (lo_ + hi_) >> 1; if (HAO_AO(md) <= c0) lo_ = md; else hi_ = md; } q_c0 = lo_; }
 	const uint32_t k_end = 2u << S.tb;
 	uint32_t lo = 0, placed = 0, ngr = 0, last_tid = 0xffffffffu;
-	volatile uint32_t *v_ovf = &s_ovf;
 	while (lo < k_end) {
 		uint32_t hi = k_end;
 		for (;;) {      // count the bins of [lo, hi); shrink the range until they fit the table
@@ -131,21 +168,21 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, const ui
 #pragma unroll
 				for (int u = 0; u < UA; ++u) {
 					const uint32_t x = t0 + u * 64 + lane; const bool act = x < c1; uint32_t q = qc;
-					if (act) { while (HAO_AO(q + 1) <= x) ++q; }
-					qc = (uint32_t)__builtin_amdgcn_readlane((int)q, 63);
+					if (QL) q = hao_seed_locate(l_ao, nk, qc, t0 + u * 64, lane);
+					else { if (act) { while (HAO_AO(q + 1) <= x) ++q; } qc = (uint32_t)__builtin_amdgcn_readlane((int)q, 63); }
 					const uint64_t sv = HAO_SS(q);
-					yv[u] = act ? S.sinfo[(sv & ~(1ULL << 63)) + (x - HAO_AO(q))] : 0; zr[u] = (uint32_t)(sv >> 63);
+					yv[u] = act ? S.sinfo[HAO_START(sv) + (x - HAO_AO(q))] : 0; zr[u] = (uint32_t)(sv >> 63);
 				}
-				if (*v_ovf) break;
+				if (HAO_OVF()) break;
 #pragma unroll
 				for (int u = 0; u < UA; ++u) {
 					const uint32_t x = t0 + u * 64 + lane, kk = hao_info_rid(yv[u]) << 1 | (zr[u] ^ hao_info_rev(yv[u]));
-					if (x < c1 && kk >= lo && kk < hi && !*v_ovf) {        // a thread starts at most one insertion after the table was declared full
+					if (x < c1 && kk >= lo && kk < hi && !HAO_OVF()) {        // a thread starts at most one insertion after the table was declared full
 						uint32_t slot = (kk * 2654435761u) >> (32 - CAPLOG);
 						for (uint32_t pr = 0; ; ++pr) {
-							if (pr == CAP) { *v_ovf = 1; break; }
+							if (pr == CAP) { HAO_OVF_SET(); break; }
 							const uint32_t old = atomicCAS(&hk[slot], HAO_BIN_EMPTY, kk);
-							if (old == HAO_BIN_EMPTY) { if (atomicAdd(&s_nd, 1u) >= MAXD) *v_ovf = 1; break; }
+							if (old == HAO_BIN_EMPTY) { if (atomicAdd(&s_nd, 1u) >= MAXD) HAO_OVF_SET(); break; }
 							if (old == kk) break;
 							slot = (slot + 1) & (CAP - 1);
 						}
@@ -154,7 +191,7 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, const ui
 				}
 			}
 			__syncthreads();
-			const bool ovf = *v_ovf != 0;
+			const bool ovf = HAO_OVF() != 0;
 			__syncthreads();
 			if (!ovf) break;
 			if (GIVEUP) { if (tid == 0) ovf_list[atomicAdd(ovf_cnt, 1ULL)] = (uint32_t)r; return; }      // left to the launch with the bigger table
@@ -215,7 +252,7 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, const ui
 				if (x0 < n)      // gallop: 64 candidates per step (the offsets do not decrease)
 					for (;;) {
 						const uint32_t t = qw + 1 + lane;
-						const unsigned long long le = __ballot(t <= nq && HAO_AO(t) <= x0);
+						const unsigned long long le = __ballot(t <= nk && HAO_AO(t) <= x0);
 						const int adv = le == ~0ULL ? 64 : __ffsll((long long)~le) - 1;
 						qw += adv; if (adv < 64) break;
 					}
@@ -223,10 +260,10 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, const ui
 #pragma unroll
 				for (int u = 0; u < NU; ++u) {
 					const uint32_t x = x0 + u * 64 + lane; const bool act = x < n; uint32_t q = qc;
-					if (act) { while (HAO_AO(q + 1) <= x) ++q; }
-					qc = (uint32_t)__builtin_amdgcn_readlane((int)q, 63);
+					if (QL) q = hao_seed_locate(l_ao, nk, qc, x0 + u * 64, lane);
+					else { if (act) { while (HAO_AO(q + 1) <= x) ++q; } qc = (uint32_t)__builtin_amdgcn_readlane((int)q, 63); }
 					qv[u] = q;
-					const uint32_t a0 = HAO_AO(q), j = x - a0; const uint64_t ad = (HAO_SS(q) & ~(1ULL << 63)) + j;
+					const uint32_t a0 = HAO_AO(q), j = x - a0; const uint64_t ad = HAO_START(HAO_SS(q)) + j;
 					yv[u] = act ? S.sinfo[ad] : 0;
 					// list neighbours normally sit in the adjacent lanes; only the lanes at a tile edge fetch theirs
 					ype[u] = (act && lane == 0 && j > 0) ? S.sinfo[ad - 1] : ~0ULL;
@@ -238,12 +275,12 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, const ui
 				request(T0);
 				uint32_t qp[NU], qn[NU];      // the two words of the query minimizer: first needed when the hit is staged
 #pragma unroll
-				for (int u = 0; u < NU; ++u) { const bool act = x0 + u * 64 + lane < n; qp[u] = act ? S.q_pos[li0 + qv[u]] : 0; qn[u] = act ? S.q_cnt[li0 + qv[u]] : 0; }
+				for (int u = 0; u < NU; ++u) { const bool act = x0 + u * 64 + lane < n; const uint32_t qi = HAO_QIDX(qv[u], HAO_SS(qv[u])); qp[u] = act ? S.q_pos[li0 + qi] : 0; qn[u] = act ? S.q_cnt[li0 + qi] : 0; }
 				uint32_t ps[NU], po[NU];      // slot | rank inside the wave's quarter tile << 16 (or ~0: no hit); k_mer_hit::offset
 #pragma unroll
 				for (int u = 0; u < NU; ++u) {
 					const uint32_t x = x0 + u * 64 + lane, q = qv[u]; uint64_t y = yv[u];
-					const uint64_t sv = HAO_SS(q), st = sv & ~(1ULL << 63); const uint32_t zrev = (uint32_t)(sv >> 63);
+					const uint64_t sv = HAO_SS(q), st = HAO_START(sv); const uint32_t zrev = (uint32_t)(sv >> 63);
 					const uint32_t tidk = hao_info_rid(y), rev = zrev ^ hao_info_rev(y), kk = tidk << 1 | rev;
 					const bool inr = x < n && kk >= lo && kk < hi;
 					// target of the previous / next entry of my list (0xffffffff: none): lane - 1 / lane + 1 hold them unless they belong to another
@@ -309,7 +346,8 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, const ui
 					if (ps[u] != 0xffffffffu) {
 						const uint32_t slot = ps[u] & 0xffffu, at = wcw[slot] + (ps[u] >> 16);
 						hao_stage_t z; z.offset = po[u]; z.self_offset = qp[u]; z.cnt = qn[u];
-						stage[at] = z; sslot[at] = (uint16_t)slot; sq[at] = (uint16_t)(qv[u] < 65535u ? qv[u] : 65535u);
+						const uint32_t qi = HAO_QIDX(qv[u], HAO_SS(qv[u]));
+						stage[at] = z; sslot[at] = (uint16_t)slot; sq[at] = (uint16_t)(qi < 65535u ? qi : 65535u);
 					}
 				__syncthreads();
 				for (uint32_t at = tid; at < tile_n; at += 256) {
@@ -330,6 +368,8 @@ __global__ __launch_bounds__(256) void seed_bin_kernel(hao_seed_args S, const ui
 	if (S.dbg && tid == 0) { const unsigned long long tk3 = wall_clock64(); atomicAdd(S.dbg, tk1 - tk0); atomicAdd(S.dbg + 1, tk2 - tk1); atomicAdd(S.dbg + 2, tk3 - tk2); atomicAdd(S.dbg + 3, 1ULL); }
 #undef HAO_AO
 #undef HAO_SS
+#undef HAO_START
+#undef HAO_QIDX
 }
 
 // ---- group table ----

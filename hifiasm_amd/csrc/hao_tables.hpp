@@ -485,6 +485,28 @@ static int hao_ft_run(hao_ctx *c)
 	return HAO_OK;
 }
 
+// (hash, read-order index) pairs in stable hash order: x[] -> sx[], iota -> oi2[] (oi[] is scratch).  sort40: 5 radix passes over hash bits 24 .. 63, then the
+// fix-up of the 40-bit runs that hold more than one key (hao_index.cuh); its counters (runs listed, scratch used, scratch overflow) land in c->peek_h[16 .. 18]
+// once the stream has been synchronised - the caller sorts again with sort40 = false if peek_h[16] > hao_sort40_cap(m) or peek_h[18] != 0.
+static inline uint64_t hao_sort40_cap(uint64_t m) { return std::max<uint64_t>(1 << 16, m >> 10); }      // dirty runs listed (expected: m^2 / 2^41 runs of ~2 keys)
+static int hao_index_sort(hao_ctx *c, const uint64_t *x, uint64_t *sx, uint32_t *oi, uint32_t *oi2, uint64_t m, bool sort40)
+{
+	hipLaunchKernelGGL(hao_iota_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, oi, m); HAO_CHECK_LAUNCH();
+	const int b0 = sort40 ? HAO_SORT40_LOWBITS : 0;
+	size_t tb = 0;
+	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, x, sx, oi, oi2, m, b0, 64, c->stream)); HIP_TRY(hao_tmp(c, tb));
+	HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, x, sx, oi, oi2, m, b0, 64, c->stream));
+	if (sort40) {
+		const uint64_t cap = hao_sort40_cap(m), tcap = 64 * cap;
+		HIP_TRY(c->w_s40_list.reserve(cap)); HIP_TRY(c->w_s40_x.reserve(tcap)); HIP_TRY(c->w_s40_o.reserve(tcap)); HIP_TRY(c->w_s40_cnt.reserve(4));
+		HIP_TRY(hipMemsetAsync(c->w_s40_cnt.p, 0, 32, c->stream));
+		hipLaunchKernelGGL(hao_sort40_mark_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, sx, m, c->w_s40_list.p, c->w_s40_cnt.p, cap); HAO_CHECK_LAUNCH();
+		hipLaunchKernelGGL(hao_sort40_fix_kernel, dim3((unsigned)cap), dim3(64), 0, c->stream, sx, oi2, m, c->w_s40_list.p, c->w_s40_cnt.p, cap, c->w_s40_x.p, c->w_s40_o.p, tcap); HAO_CHECK_LAUNCH();
+		hipLaunchKernelGGL(hao_peek_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)c->w_s40_cnt.p, 3, c->peek_d + 16); HAO_CHECK_LAUNCH();
+	}
+	return HAO_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // ha_pt_gen (htab.cpp:1232-1287): sketch all reads (once - the reference does it twice, pass A to
 // count and pass B to insert), stable sort by hash, run-length -> histogram -> peaks -> keep keys
@@ -539,17 +561,23 @@ static int hao_pt_run(hao_ctx *c)
 		// minimizer learn its own lookup result at build time (hao_index.cuh)
 		const uint64_t m = c->ix_n_mz;
 		if (m >= (1ULL << 32)) { hao_set_err(c, "more than 2^32 minimizers on one device"); return HAO_EUNSUPP; }
-		HIP_TRY(c->d_ix_sx.reserve(m + 1)); HIP_TRY(c->d_ix_sinfo.reserve(m + 1)); HIP_TRY(c->w_oi.reserve(m + 1)); HIP_TRY(c->w_oi2.reserve(m + 1));
+		const uint64_t pad = c->ix_pad = c->sw.ix_pad;      // (tests: the index's position records start `pad` entries into their buffer, so list starts exceed 2^32 on a small read set)
+		HIP_TRY(c->d_ix_sx.reserve(m + 1)); HIP_TRY(c->d_ix_sinfo.reserve(m + pad + 1)); HIP_TRY(c->w_oi.reserve(m + 1)); HIP_TRY(c->w_oi2.reserve(m + 1));
 		HIP_TRY(c->w_runid.reserve(m + 1)); HIP_TRY(c->d_ix_lk.reserve(m + 1));
-		if (m) {
-			hipLaunchKernelGGL(hao_iota_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, c->w_oi.p, m); HAO_CHECK_LAUNCH();
-			size_t tb = 0;
-			HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, c->d_ix_mz_x.p, c->d_ix_sx.p, c->w_oi.p, c->w_oi2.p, m, 0, 64, c->stream)); HIP_TRY(hao_tmp(c, tb));
-			HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, c->d_ix_mz_x.p, c->d_ix_sx.p, c->w_oi.p, c->w_oi2.p, m, 0, 64, c->stream));
+		// big inputs: 5 passes over hash bits 24 .. 63 + the fix-up of the 40-bit runs that hold two keys (hao_index_sort).  Small ones sort all 64 bits (rocprim's
+		// bit-range sort mis-sorts inputs of 5 k - 200 k elements on this ROCm, tests/test_gpu_rocprim.py); so does a retry when the fix-up's scratch ran out.
+		bool sort40 = m >= (1ULL << 23) && !c->sw.sort64;
+		for (;;) {
+			if (m) { if (int rc = hao_index_sort(c, c->d_ix_mz_x.p, c->d_ix_sx.p, c->w_oi.p, c->w_oi2.p, m, sort40)) return rc; }
+			c->ix_n_sorted = m;
+			c->timer.mark("pt_sort");
+			if (int rc = rle_hist(c->d_ix_sx.p, m)) return rc;      // (synchronises the stream)
+			if (m && sort40) {
+				c->s40_runs = c->peek_h[16];
+				if (c->peek_h[16] > hao_sort40_cap(m) || c->peek_h[18]) { sort40 = false; continue; }      // more two-key runs than the fix-up was sized for: all 64 bits after all
+			}
+			break;
 		}
-		c->ix_n_sorted = m;
-		c->timer.mark("pt_sort");
-		if (int rc = rle_hist(c->d_ix_sx.p, m)) return rc;
 		c->timer.mark("pt_count");
 		int hi; peaks_and_range(&hi);
 		if (int rc = hao_keep_runs(c, ukeys.p, ucnt.p, n_unique, 2, hi, c->d_ix_keys, &c->d_ix_start, c->d_ix_cnt, &c->ix_n_keys, &c->ix_n_pos)) return rc;
@@ -559,8 +587,9 @@ static int hao_pt_run(hao_ctx *c)
 			HIP_TRY(rocprim::inclusive_scan(nullptr, tb, heads, c->w_runid.p, m, rocprim::plus<uint32_t>(), c->stream)); HIP_TRY(hao_tmp(c, tb));
 			HIP_TRY(rocprim::inclusive_scan(c->d_tmp.p, tb, heads, c->w_runid.p, m, rocprim::plus<uint32_t>(), c->stream));
 			hipLaunchKernelGGL(hao_index_finish_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, m, c->w_oi2.p, c->w_runid.p, ucnt.p, c->w_ustart.p, 2, hi,
-							   c->d_ix_mz_info.p, c->d_ix_sinfo.p, c->d_ix_lk.p, (uint64_t)0);
+							   c->d_ix_mz_info.p, c->d_ix_sinfo.p + pad, c->d_ix_lk.p, pad);
 			HAO_CHECK_LAUNCH();
+			if (pad && c->ix_n_keys) { hipLaunchKernelGGL(hao_add_const_kernel, dim3((unsigned)((c->ix_n_keys + 255) / 256)), dim3(256), 0, c->stream, c->d_ix_start.p, c->ix_n_keys, pad); HAO_CHECK_LAUNCH(); }
 		}
 		c->lk_valid = true;
 		c->timer.mark("pt_lookup");
@@ -637,7 +666,9 @@ static int hao_pt_run(hao_ctx *c)
 		  for (int r = 0; r < W; ++r) { part[r] = trip[3 * r]; nks[r] = trip[3 * r + 1]; nps[r] = trip[3 * r + 2]; } }
 		uint64_t m = 0, base = 0, nk = 0, np = 0;
 		for (int r = 0; r < W; ++r) { if (r < cm.rank) base += part[r]; m += part[r]; nk += nks[r]; np += nps[r]; }
-		if (m >= (1ULL << 32)) { hao_set_err(c, "more than 2^32 minimizers in the replicated index"); return HAO_EUNSUPP; }      // same verdict on every rank
+		// (no limit on m: list starts are 48-bit everywhere - lk[], d_ix_start, the seed kernels' staged words; only a PARTITION is limited to 2^32 records, by its
+		// sort's 32-bit arrival index, and a partition of that size - ~60 bytes per record while it is built - would not fit a device's memory anyway)
+		const uint64_t pad = c->ix_pad = c->sw.ix_pad; base += pad;
 		{	// records into hash order + the answer to every received minimizer (hao_index.cuh), then the answers go home: reverse all-to-all-v, 8 bytes per minimizer
 			auto local_lk = [&]() -> int {
 				HIP_TRY(lkr.reserve(n_recv + 1)); HIP_TRY(lkl.reserve(ml + 1)); HIP_TRY(c->w_runid.reserve(n_recv + 1)); HIP_TRY(c->d_ix_lk.reserve(ml + 1));
@@ -666,7 +697,7 @@ static int hao_pt_run(hao_ctx *c)
 		const size_t o_key = (size_t)maxm * 8, o_st = o_key + (size_t)maxk * 8, o_cnt = o_st + (size_t)maxk * 8, slot = (o_cnt + (size_t)maxk * 4 + 15) & ~(size_t)15;
 		auto local_slot = [&]() -> int {
 			if (nk_p) { hipLaunchKernelGGL(hao_add_const_kernel, dim3((unsigned)((nk_p + 255) / 256)), dim3(256), 0, c->stream, pst.p, nk_p, base); HAO_CHECK_LAUNCH(); }
-			HIP_TRY(c->d_ix_sinfo.reserve(m + 1));      // (the sorted hashes themselves are not needed once the key table exists: only the 8-byte position records travel)
+			HIP_TRY(c->d_ix_sinfo.reserve(m + pad + 1));      // (the sorted hashes themselves are not needed once the key table exists: only the 8-byte position records travel)
 			HIP_TRY(c->d_ix_keys.reserve(nk + 1)); HIP_TRY(c->d_ix_start.reserve(nk + 1)); HIP_TRY(c->d_ix_cnt.reserve(nk + 1));
 			HIP_TRY(cm.ag_tmp.reserve(slot * W + 16));
 			char *mine = cm.ag_tmp.p + slot * cm.rank;
@@ -680,7 +711,7 @@ static int hao_pt_run(hao_ctx *c)
 		};
 		if (int rc = hao_comm_agree(c, cm, local_slot())) return rc;
 		if (int rc = hao_comm_allgather_fixed(c, cm, cm.ag_tmp.p, slot)) return rc;
-		uint64_t dm = 0, dk = 0;
+		uint64_t dm = pad, dk = 0;
 		for (int r = 0; r < W; ++r) {
 			const char *sr = cm.ag_tmp.p + slot * r;
 			if (part[r]) HIP_TRY(hipMemcpyAsync(c->d_ix_sinfo.p + dm, sr, part[r] * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -728,9 +759,9 @@ static int hao_pt_download(hao_ctx *c)
 		HIP_TRY(hipMemcpy(start.data(), c->d_ix_start.p, nk * 8, hipMemcpyDeviceToHost));
 		HIP_TRY(hipMemcpy(cnt.data(), c->d_ix_cnt.p, nk * 4, hipMemcpyDeviceToHost));
 	}
-	if (c->ix_n_sorted) HIP_TRY(hipMemcpy(sinfo.data(), c->d_ix_sinfo.p, c->ix_n_sorted * 8, hipMemcpyDeviceToHost));
+	if (c->ix_n_sorted) HIP_TRY(hipMemcpy(sinfo.data(), c->d_ix_sinfo.p + c->ix_pad, c->ix_n_sorted * 8, hipMemcpyDeviceToHost));
 	uint64_t o = 0;
-	for (uint64_t i = 0; i < nk; ++i) { c->h_ix_off[i] = o; memcpy(c->h_ix_pos.data() + o, sinfo.data() + start[i], (size_t)cnt[i] * 8); o += cnt[i]; }
+	for (uint64_t i = 0; i < nk; ++i) { c->h_ix_off[i] = o; memcpy(c->h_ix_pos.data() + o, sinfo.data() + (start[i] - c->ix_pad), (size_t)cnt[i] * 8); o += cnt[i]; }
 	c->h_ix_off[nk] = o;
 	c->h_ix_valid = true;
 	return HAO_OK;

@@ -283,6 +283,11 @@ int hao_selftest_rocprim(uint64_t n, uint64_t out[2]);
  * out = { runs, sum of run lengths, runs of a length other than 8 } - n / 8, n, 0 for n a multiple of 8 (tests/test_gpu_rocprim.py). */
 int hao_selftest_big(uint64_t n, uint64_t out[3]);
 
+/* Self-test of the index sort on 40 of the 64 hash bits + fix-up of the runs that hold several keys (hao_index.cuh; what hao_pt_gen runs on more than 2^23
+ * minimizers): n synthetic keys with many such runs, sorted that way and by the stable 64-bit sort; out = { positions where the two results differ (must
+ * be 0), runs the fix-up rewrote (must be > 0 for the test to mean anything), scratch elements used, scratch overflow flag }. */
+int hao_selftest_sortbits(hao_ctx *c, uint64_t n, uint64_t out[4]);
+
 /* per-stage device time of the last call in milliseconds (HIP events on the engine's stream);
  * names[i] points to static strings. Returns the number of stages. */
 int hao_stage_times(hao_ctx *c, const char **names, float *ms, int cap);

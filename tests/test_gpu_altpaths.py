@@ -38,3 +38,35 @@ def test_switch_keeps_results(name, switch):
     finally:
         del os.environ[switch]
     assert bad == 0, f"{switch}: {bad}/{rs.n} reads differ"
+
+
+@pytest.mark.parametrize("name", ["hifi", "rr"])
+def test_index_positions_beyond_2_32(name):
+    """List starts are 48-bit everywhere (lk[], the key table, the seed kernels' staged words, the host view): HAO_DBG_IX_PAD puts 2^32 + 12345 unused position
+    records in front of the index (34 GB), so every list of a small read set starts beyond 2^32 - the situation of a replicated index of more than 2^32
+    minimizers (human genome, 50x).  Same tables, same overlaps."""
+    from hifiasm_amd.api import Engine
+    rs, okw = scenario_reads(name)
+    o = scenario_oracle(name)
+    os.environ["HAO_DBG_IX_PAD"] = str((1 << 32) + 12345)
+    try:
+        e = Engine(0, **okw)
+        e.set_readset(rs)
+        e.ha_ft_gen()
+        e.ha_pt_gen()
+        k, off, pos = e.pt_table()
+        ok, ooff, opos = o.pt_table()
+        assert k.shape == ok.shape and (k == ok).all() and (off == ooff).all() and (pos == opos).all()
+        i = ok.size // 2
+        assert (e.ha_pt_get(int(ok[i])) == opos[int(ooff[i]):int(ooff[i + 1])]).all()
+        e.overlap_batch(0, rs.n)
+        bad = 0
+        for r in range(rs.n):
+            ol, fc, fo, cl = e.h_ec_lchain(r)
+            ool, ofc, ofo, ocl = o.lchain(r)
+            if not (ol.shape == ool.shape and (ol == ool).all() and (fc == ofc).all() and (fo == ofo).all() and cl.shape == ocl.shape and (cl == ocl).all()):
+                bad += 1
+        e.close()
+    finally:
+        del os.environ["HAO_DBG_IX_PAD"]
+    assert bad == 0, f"{bad}/{rs.n} reads differ"

@@ -31,3 +31,19 @@ def test_more_than_2_32_items():
     out = (C.c_uint64 * 3)()
     assert L.hao_selftest_big(n, out) == 0
     assert (out[0], out[1], out[2]) == (n >> 3, n, 0)
+
+
+@pytest.mark.parametrize("n", [9_000_000, 40_000_000])      # (hao_pt_gen takes this path from 2^23 minimizers on: below, rocprim's bit-range sort is the one pinned above)
+def test_index_sort_on_40_bits(n):
+    """hao_pt_gen sorts (hash, read-order index) pairs on hash bits 24 .. 63 and repairs the 40-bit runs that hold several keys (hao_index.cuh): on keys built
+    to have many such runs the result must equal the stable 64-bit sort, element for element (keys and carried indices)."""
+    from hifiasm_amd.api import Engine, lib
+    L = lib()
+    L.hao_selftest_sortbits.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    e = Engine(0)
+    out = (C.c_uint64 * 4)()
+    assert L.hao_selftest_sortbits(e.h, n, out) == 0
+    e.close()
+    print(f"[sort40] n={n}: differences {out[0]}, runs rewritten {out[1]}, scratch elements {out[2]}, overflow {out[3]}")
+    assert out[3] == 0 and 1000 < out[1] <= max(1 << 16, n >> 10)      # (beyond that many runs hao_pt_gen falls back to the 64-bit sort)
+    assert out[0] == 0

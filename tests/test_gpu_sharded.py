@@ -33,6 +33,18 @@ def _check_rank(e, o, lo, hi, errors):
 @pytest.mark.parametrize("name", ["hifi", "rr", "nn", "bf24"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_loopback_world(name, world):
+    _loopback_world(name, world)
+
+
+def test_replicated_index_beyond_2_32(monkeypatch):
+    """The replicated index has no 2^32-record limit (only a rank's hash partition has, through its sort's arrival index): with 2^32 + 999 unused position
+    records in front of every rank's copy of the index (HAO_DBG_IX_PAD, 34 GB per rank) all list starts - the ones a partition's owner sends back to the
+    minimizers' home ranks included - lie beyond 2^32; tables and every read's overlaps must not change."""
+    monkeypatch.setenv("HAO_DBG_IX_PAD", str((1 << 32) + 999))
+    _loopback_world("rr", 2)
+
+
+def _loopback_world(name, world):
     from hifiasm_amd.api import Engine, lib
     rs, okw = scenario_reads(name)
     o = scenario_oracle(name)
