@@ -368,23 +368,44 @@ __global__ __launch_bounds__(256) void hao_al_kernel(hao_ed_reads R, const hao_e
 	hao_al_state<WT> S; S.alive = 0; S.dead = 0;
 	if (mine) hao_al_init<WT, MODE>(S, R, T);
 	uint64_t *col = path + slot;      // (TRACE only)
-	for (unsigned long long hm = heads; hm; hm &= hm - 1) {
-		const int h0 = __ffsll((long long)hm) - 1; const unsigned long long rest = hm & (hm - 1); const int h1 = rest ? __ffsll((long long)rest) - 1 : 64;
-		const bool in_seg = mine && lane >= h0 && lane < h1;
-		// the segment's text (fields of its first lane: wave-uniform), staged HAO_AL_CH columns at a time
-		const uint32_t t_rid = (uint32_t)__builtin_amdgcn_readlane((int)T.t_rid, h0), t_pos = (uint32_t)__builtin_amdgcn_readlane((int)T.t_pos, h0),
-					   t_len = (uint32_t)__builtin_amdgcn_readlane((int)T.t_len, h0), t_rev = (uint32_t)__builtin_amdgcn_readlane((int)T.t_rev, h0);
-		const hao_al_walk tw = hao_al_walk_of(R, t_rid, t_pos, t_len, t_rev, MODE == HAO_AL_EXT_BWD);
-		for (int64_t k0 = 0; k0 < (int64_t)t_len; k0 += HAO_AL_CH) {
-			const int32_t n = (int32_t)((int64_t)t_len - k0 < HAO_AL_CH ? (int64_t)t_len - k0 : HAO_AL_CH);
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // (the previous range has been read)
-			hao_al_stage_bases(tw, k0, n, codes, lane, 64);
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-			hao_al_stage_nsites(tw, k0, n, codes, lane, 64);
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-			if (in_seg && S.alive && !S.dead)
-				for (int32_t i = (int32_t)k0; i < (int32_t)k0 + n && i < S.tn && !S.dead; ++i) hao_al_column<WT, MODE, TRACE>(S, codes[i - (int32_t)k0], i, col, stride);
+	// All segments of the tile sweep TOGETHER: the wave's HAO_AL_CH staged bytes are cut into one strip of `chs` columns per segment (one segment: all of
+	// them; 64 different texts: 16 columns each), every lane reads the column's character from its own segment's strip, and the wave refills the strips every chs
+	// columns - 16 base decodes per lane and refill whatever the number of segments, i.e. at worst (no two tasks share a text) what decoding one's own text costs.
+	// (Round 3 swept the segments one after the other with the lanes of the others idle: 6 % of the lanes busy on task lists whose pairs rarely share a text.)
+	const int nseg = __popcll(heads), my_seg = __popcll(heads & ((2ULL << lane) - 1)) - 1;
+	const int32_t chs = nseg > 0 ? (int32_t)(HAO_AL_CH / nseg) & ~3 : HAO_AL_CH;
+	int32_t tn_mx = (mine && S.alive && !S.dead) ? S.tn : 0;
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) { const int32_t o_ = __shfl_xor(tn_mx, d); tn_mx = o_ > tn_mx ? o_ : tn_mx; }
+	const uint8_t *strip = codes + (my_seg > 0 ? my_seg : 0) * chs;
+	for (int32_t k0 = 0; k0 < tn_mx; k0 += chs) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // (the previous range has been read)
+		int sg = 0;
+		for (unsigned long long hm = heads; hm; hm &= hm - 1, ++sg) {      // the segments' texts (fields of a segment's first lane: wave-uniform)
+			const int h0 = __ffsll((long long)hm) - 1;
+			const uint32_t t_rid = (uint32_t)__builtin_amdgcn_readlane((int)T.t_rid, h0), t_pos = (uint32_t)__builtin_amdgcn_readlane((int)T.t_pos, h0),
+						   t_len = (uint32_t)__builtin_amdgcn_readlane((int)T.t_len, h0), t_rev = (uint32_t)__builtin_amdgcn_readlane((int)T.t_rev, h0);
+			if ((int64_t)t_len <= (int64_t)k0) continue;
+			const hao_al_walk tw = hao_al_walk_of(R, t_rid, t_pos, t_len, t_rev, MODE == HAO_AL_EXT_BWD);
+			const int32_t n = (int32_t)((int64_t)t_len - k0 < chs ? (int64_t)t_len - k0 : chs);
+			hao_al_stage_bases(tw, k0, n, codes + sg * chs, lane, 64);
 		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		if (R.nsite_off) {      // N sites (after the bases are in place)
+			sg = 0;
+			for (unsigned long long hm = heads; hm; hm &= hm - 1, ++sg) {
+				const int h0 = __ffsll((long long)hm) - 1;
+				const uint32_t t_rid = (uint32_t)__builtin_amdgcn_readlane((int)T.t_rid, h0), t_pos = (uint32_t)__builtin_amdgcn_readlane((int)T.t_pos, h0),
+							   t_len = (uint32_t)__builtin_amdgcn_readlane((int)T.t_len, h0), t_rev = (uint32_t)__builtin_amdgcn_readlane((int)T.t_rev, h0);
+				if ((int64_t)t_len <= (int64_t)k0) continue;
+				const hao_al_walk tw = hao_al_walk_of(R, t_rid, t_pos, t_len, t_rev, MODE == HAO_AL_EXT_BWD);
+				const int32_t n = (int32_t)((int64_t)t_len - k0 < chs ? (int64_t)t_len - k0 : chs);
+				hao_al_stage_nsites(tw, k0, n, codes + sg * chs, lane, 64);
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		}
+		if (mine && S.alive && !S.dead)
+			for (int32_t i = k0; i < k0 + chs && i < S.tn && !S.dead; ++i) hao_al_column<WT, MODE, TRACE>(S, strip[i - k0], i, col, stride);
 	}
 	(void)live;
 	if (mine) {

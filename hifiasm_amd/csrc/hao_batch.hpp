@@ -3,6 +3,7 @@
 #include "hao_tables.hpp"
 #include "hao_query.cuh"
 #include "hao_query2.cuh"
+#include "hao_query3.cuh"
 #include "hao_chain.cuh"
 
 struct hao_ctx::Batch {
@@ -298,7 +299,14 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			else if (int rc = launch(seed_bin2_kernel<9, 0, false>, seed_bin2_kernel<10, 1, true>, seed_bin2_kernel<11, 2, true>)) return rc;
 		}
 		else if (tile_ != 512) { if (int rc = launch(seed_bin_kernel<9, 0, 1024, false>, seed_bin_kernel<10, 1, 1024, false>, seed_bin_kernel<11, 2, 1024, false>)) return rc; }
-		else if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql) { if (int rc = launch(seed_bin_kernel<9, 0, 512, true>, seed_bin_kernel<10, 1, 512, true>, seed_bin_kernel<11, 2, 512, true>)) return rc; }      // every read's minimizer table fits the LDS
+		else if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql) {      // every read's minimizer table fits the LDS
+			if (c->sw.seed_nodirect) { if (int rc = launch(seed_bin_kernel<9, 0, 512, true>, seed_bin_kernel<10, 1, 512, true>, seed_bin_kernel<11, 2, 512, true>)) return rc; }
+			else {      // reads whose bins overflow the 512-slot table: the launches without staged tiles (hao_query3.cuh)
+				lds2 = hao_seed3_lds<10>::FIXED + lds_q; lds3 = hao_seed3_lds<11>::FIXED + lds_q;
+				if (c->sw.seed_nu == 8) { if (int rc = launch(seed_bin_kernel<9, 0, 512, true>, seed_bin3_kernel<10, 1, 8>, seed_bin3_kernel<11, 2, 8>)) return rc; }
+				else if (int rc = launch(seed_bin_kernel<9, 0, 512, true>, seed_bin3_kernel<10, 1, 4>, seed_bin3_kernel<11, 2, 4>)) return rc;
+			}
+		}
 		else if (int rc = launch(seed_bin_kernel<9, 0, 512, false>, seed_bin_kernel<10, 1, 512, false>, seed_bin_kernel<11, 2, 512, false>)) return rc;
 	}
 	if (c->sw.seedphase) { unsigned long long d_[4]; HIP_TRY(hipMemcpy(d_, B.dbgbuf.p, 32, hipMemcpyDeviceToHost)); if (d_[3]) fprintf(stderr, "[seed] blocks %llu  avg us: count pass %.1f  sort+scan %.1f  scatter pass %.1f\n", d_[3], d_[0] / 100.0 / d_[3], d_[1] / 100.0 / d_[3], d_[2] / 100.0 / d_[3]); }

@@ -18,6 +18,8 @@ static void hao_release_all(hao_ctx *c)
 }
 
 #include <atomic>
+#include <new>
+#include <stdexcept>
 #include <thread>
 extern "C" {
 
@@ -234,7 +236,9 @@ int hao_index_load(hao_ctx *c, const char *prefix, int32_t *number_of_round)
 	if (!c || !prefix) return HAO_EINVAL;
 	HAO_NOT_ON_VIEW(c, "hao_index_load");
 	HIP_TRY(hipSetDevice(c->device));
-	return hao_index_load_impl(c, prefix, number_of_round);
+	try { return hao_index_load_impl(c, prefix, number_of_round); }      // (the loader sizes host vectors from file fields - checked against the file's length, but an exception must not cross the C boundary)
+	catch (const std::bad_alloc &) { c->has_ft = false; c->has_pt = false; c->lk_valid = false; hao_set_err(c, "hao_index_load: out of host memory"); return HAO_ENOMEM; }
+	catch (const std::exception &e) { c->has_ft = false; c->has_pt = false; c->lk_valid = false; hao_set_err(c, std::string("hao_index_load: ") + e.what()); return HAO_EINVAL; }
 }
 
 int hao_exact_check(hao_ctx *c)

@@ -117,10 +117,20 @@ static int hao_index_save_impl(hao_ctx *c, const char *prefix, int32_t number_of
 // table, position index, coverage peaks and max_n_chain.  What the file does not hold is derived here: the query side's read-ordered minimizers
 // (the reference re-sketches every query read; the engine sketches all reads once with the loaded filter table) and every minimizer's lookup result.
 // ---------------------------------------------------------------------------------------
+// bytes between the file position and the end of the file (sizes read from a file are checked against it before anything is allocated for them)
+static uint64_t hao_file_left(FILE *fp)
+{
+	const long at = ftell(fp); if (at < 0 || fseek(fp, 0, SEEK_END) != 0) return 0;
+	const long end = ftell(fp); (void)fseek(fp, at, SEEK_SET);
+	return end > at ? (uint64_t)(end - at) : 0;
+}
 static bool hao_kh_read(FILE *fp, size_t vsz, std::vector<uint64_t> &keys, std::vector<uint8_t> &vals)
 {
 	uint32_t n_buckets = 0, bits = 0, count = 0; uint8_t ff = 0; keys.clear(); vals.clear();
 	if (fread(&n_buckets, 4, 1, fp) != 1 || fread(&bits, 4, 1, fp) != 1 || fread(&count, 4, 1, fp) != 1 || fread(&ff, 1, 1, fp) != 1) return false;
+	// khashl _save (khashl.h:137-149): n_buckets = 1 << bits (0 for a table that never grew), count <= n_buckets, and the arrays that follow must be in the file
+	if (bits > 31 || (n_buckets != 0 && n_buckets != (1u << bits)) || count > n_buckets) return false;
+	if ((uint64_t)n_buckets * (8 + vsz) + (n_buckets >> 3) > hao_file_left(fp) + 16) return false;
 	std::vector<uint32_t> used;
 	if (ff) { used.resize(n_buckets < 32 ? 1 : n_buckets >> 5); if (fread(used.data(), 4, used.size(), fp) != used.size()) return false; }
 	if (fread(&ff, 1, 1, fp) != 1) return false;
@@ -147,6 +157,7 @@ __global__ void hao_lk_fill_kernel(const uint64_t *mz_x, uint64_t n_mz, hao_pt_d
 static int hao_index_load_impl(hao_ctx *c, const char *prefix, int32_t *number_of_round)
 {
 	if (hao_is_sharded(c)) { hao_set_err(c, "hao_index_load: single-device mode only"); return HAO_EUNSUPP; }
+	c->has_ft = false; c->has_pt = false; c->lk_valid = false; c->h_ix_valid = false;      // a load that fails half-way leaves "no index", not the previous one over new reads
 	const std::string base = std::string(prefix) + ".pt_flt";
 	FILE *fp = fopen(base.c_str(), "rb");
 	if (!fp) { hao_set_err(c, "cannot read " + base); return HAO_EINVAL; }
@@ -171,11 +182,13 @@ static int hao_index_load_impl(hao_ctx *c, const char *prefix, int32_t *number_o
 		int32_t k = 0, pre = 0; uint64_t tot = 0, tot_pos = 0;
 		if (fread(&k, 4, 1, fp) != 1 || fread(&pre, 4, 1, fp) != 1 || fread(&tot, 8, 1, fp) != 1 || fread(&tot_pos, 8, 1, fp) != 1 || pre < 0 || pre > 20) return bad("index header of " + base);
 		if (k != c->opt.k) return bad("the index was built with k = " + std::to_string(k) + ", the engine runs with k = " + std::to_string(c->opt.k));
+		if (tot > hao_file_left(fp) / 16 || tot_pos > hao_file_left(fp) / 8) return bad("index header of " + base + ": more keys / positions than the file holds");
 		pos.resize((size_t)1 << pre); ents.reserve(tot);
 		std::vector<uint64_t> kk; std::vector<uint8_t> vv;
 		for (uint32_t s = 0; s < (1u << pre); ++s) {
 			uint64_t na = 0;
 			if (!hao_kh_read(fp, 8, kk, vv) || fread(&na, 8, 1, fp) != 1) return bad("sub-table " + std::to_string(s) + " of " + base);
+			if (na > hao_file_left(fp) / 8) return bad("positions of sub-table " + std::to_string(s) + ": more than the file holds");
 			pos[s].resize(na);
 			if (na && fread(pos[s].data(), 8, na, fp) != na) return bad("positions of sub-table " + std::to_string(s));
 			for (size_t i = 0; i < kk.size(); ++i) {      // key = hash >> pre << 12 | count (htab.cpp:122-124, 303-314), value = offset of its list
@@ -197,15 +210,17 @@ static int hao_index_load_impl(hao_ctx *c, const char *prefix, int32_t *number_o
 	if (!fp) { hao_set_err(c, "cannot read " + base + ".bin"); return HAO_EINVAL; }
 	int32_t adapter = 0; uint64_t index_size = 0, name_index_size = 0, n = 0, total_bases = 0, total_name = 0;
 	if (fread(&adapter, 4, 1, fp) != 1 || fread(&index_size, 8, 1, fp) != 1 || fread(&name_index_size, 8, 1, fp) != 1 || fread(&n, 8, 1, fp) != 1 || fread(&total_bases, 8, 1, fp) != 1 ||
-		fread(&total_name, 8, 1, fp) != 1 || n >= (1ULL << 28)) return bad("header of " + base + ".bin");
+		fread(&total_name, 8, 1, fp) != 1 || n >= (1ULL << 28) || n > hao_file_left(fp) / 16) return bad("header of " + base + ".bin");      // (a read costs at least its N-site count and its length: 16 bytes)
 	std::vector<uint64_t> ns_off(n + 1, 0), len64(n), pk_off(n + 1, 0); std::vector<uint32_t> ns, len(n); std::vector<uint8_t> packed;
 	for (uint64_t i = 0; i < n; ++i) {
-		uint64_t cnt = 0; if (fread(&cnt, 8, 1, fp) != 1) return bad("N sites of read " + std::to_string(i));
-		for (uint64_t j = 0; j < cnt; ++j) { uint64_t p; if (fread(&p, 8, 1, fp) != 1) return bad("N sites of read " + std::to_string(i)); ns.push_back((uint32_t)p); }
+		uint64_t cnt = 0; if (fread(&cnt, 8, 1, fp) != 1 || cnt > hao_file_left(fp) / 8) return bad("N sites of read " + std::to_string(i));
+		for (uint64_t j = 0; j < cnt; ++j) { uint64_t p; if (fread(&p, 8, 1, fp) != 1 || p >= (1ULL << 27)) return bad("N sites of read " + std::to_string(i)); ns.push_back((uint32_t)p); }
 		ns_off[i + 1] = ns.size();
 	}
 	if (n && fread(len64.data(), 8, n, fp) != n) return bad("read lengths");
 	for (uint64_t i = 0; i < n; ++i) { if (len64[i] >= (1ULL << 27)) return bad("read longer than 2^27"); len[i] = (uint32_t)len64[i]; pk_off[i + 1] = pk_off[i] + len64[i] / 4 + 1; }
+	for (uint64_t i = 0; i < n; ++i) for (uint64_t j = ns_off[i]; j < ns_off[i + 1]; ++j) if (ns[j] >= len[i]) return bad("an N site of read " + std::to_string(i) + " lies beyond the read");
+	if (pk_off[n] > hao_file_left(fp)) return bad("packed reads: shorter than the lengths say");
 	packed.resize(pk_off[n] + 1);
 	if (pk_off[n] && fread(packed.data(), 1, pk_off[n], fp) != pk_off[n]) return bad("packed reads");
 	fclose(fp); fp = nullptr;      // (names, trio flags and the second copy of the peaks are not the engine's business)

@@ -96,6 +96,41 @@ def fold_digests(d, block=256):
 _THRE_W = ([0, 3, 8, 15, 24, 31], [32, 40, 50, 63], [64, 80, 95, 96, 110, 127])      # window / candidate pairs
 _THRE_U = ([0, 1, 5, 15, 31], [32, 45, 63], [64, 97, 127])                          # unrelated pairs
 _THRE_S = ([0, 2, 7], [33, 63], [65, 127])                                          # a read against itself
+def ed_tasks_grid(name, n_reads=24, wl=375, seed=1, wide=False):
+    """Window / candidate pairs on the reference's FIXED window grid (Correct.cpp:5645, 5993: windows of WINDOW = 375 query bases starting at multiples of
+    WINDOW, Hash_Table.h:9): every overlap h_ec_lchain found for a query read contributes one pair per grid window it covers, so the ~2 x coverage candidates of a
+    window share one text - the shape the window-alignment kernels are laid out for (tools/bench_ed.py --grid).  Windows an overlap covers only partly (its two
+    ends) are clipped to the overlap, as the reference does.  Same columns as ed_tasks."""
+    rs, okw = scenario_reads(name)
+    o = scenario_oracle(name)
+    rng = np.random.default_rng(seed)
+    out = []
+    L = rs.lengths.astype(np.int64)
+    for r in rng.choice(rs.n, size=min(n_reads, rs.n), replace=False):
+        ol = o.lchain(int(r))[0]
+        thre = int(rng.choice(_THRE_W[int(wide)]))      # (one threshold per read: the reference derives it from the window length)
+        for z in ol:
+            xs, xe, yid, ys, ye, yrev = int(z[1]), int(z[2]), int(z[4]), int(z[5]), int(z[6]), int(z[7])
+            tl = int(L[yid])
+            for g0 in range(xs // wl * wl, xe + 1, wl):
+                ws, we = max(g0, xs), min(g0 + wl - 1, xe)
+                tn = we + 1 - ws
+                p0 = ys + (ws - xs) - thre
+                p1 = p0 + tn + 2 * thre
+                ad = 0
+                if p0 < 0:
+                    ad, p0 = min(-p0, 2 * thre), 0
+                p1 = min(p1, tl)
+                if p1 <= p0 or tn <= 0:
+                    continue
+                out.append((yid, p0, p1 - p0, yrev, int(r), ws, tn, 0, thre, ad))
+    t = np.array(out, dtype=np.uint32)
+    if wide:
+        ai = t[:, 2].astype(np.int64) - t[:, 6] + t[:, 9]
+        t = t[ai <= 64 * ((2 * t[:, 8].astype(np.int64) + 1 + 63) // 64)]
+    return t
+
+
 def ed_tasks(name, n_reads=24, wl=775, seed=1, wide=False):
     """wide = thresholds of 32 .. 63 (bands of two 64-bit words: the reference's 128-bit functions).
     (pattern, text) pairs the way the window alignment forms them (Correct.cpp:3897): 775-base query windows of the overlaps h_ec_lchain found,

@@ -92,3 +92,44 @@ def test_engine_loads_the_reference_built_index(name):
     for rid in range(0, rs.n, 7):
         assert (e.fetch_sketch(rid) == o.sketch(rid)).all(), rid
     e.close()
+
+
+def test_damaged_index_files_are_refused():
+    """hao_index_load sizes its buffers from fields of the file: a truncated or overwritten file must come back as an error code (never an exception through the C
+    boundary or a crash), leave the engine without an index, and the same engine must still load the intact files afterwards."""
+    from hifiasm_amd.api import Engine, HaoError
+    rs, okw = scenario_reads("hifi")
+    e = Engine(0, **okw)
+    e.set_readset(rs)
+    e.ha_ft_gen(); e.ha_pt_gen()
+    d = tempfile.mkdtemp(prefix="hao_idx_")
+    good = os.path.join(d, "good")
+    e.index_save(good)
+    e.overlap_batch(0, rs.n)
+    want = [e.h_ec_lchain(r)[0].copy() for r in range(0, rs.n, 7)]
+    e.close()
+    blob = {s: open(good + s, "rb").read() for s in (".pt_flt", ".pt_flt.bin", ".pt_flt.paf.bin")}
+
+    def variant(tag, which, data):
+        p = os.path.join(d, tag)
+        for s, b in blob.items():
+            open(p + s, "wb").write(data if s == which else b)
+        return p
+
+    pt, rb = blob[".pt_flt"], blob[".pt_flt.bin"]
+    huge = (1 << 31).to_bytes(4, "little")
+    cases = [variant("cut_pt", ".pt_flt", pt[: len(pt) // 2]), variant("cut_pt2", ".pt_flt", pt[:40]), variant("cut_reads", ".pt_flt.bin", rb[: len(rb) // 3]),
+             variant("buckets", ".pt_flt", pt[:1] + huge + pt[5:]),                      # n_buckets of the filter table = 2^31
+             variant("count", ".pt_flt", pt[:9] + huge + pt[13:]),                       # more keys than buckets
+             variant("nreads", ".pt_flt.bin", rb[:20] + (1 << 27).to_bytes(8, "little") + rb[28:])]      # 2^27 reads in a file of a few hundred
+    e = Engine(0, **okw)
+    for p in cases:
+        with pytest.raises(HaoError):
+            e.index_load(p)
+        with pytest.raises(HaoError):                        # no index after a failed load
+            e.overlap_batch(0, 1)
+    e.index_load(good)
+    e.overlap_batch(0, rs.n)
+    got = [e.h_ec_lchain(r)[0] for r in range(0, rs.n, 7)]
+    e.close()
+    assert all(a.shape == b.shape and (a == b).all() for a, b in zip(got, want))

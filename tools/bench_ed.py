@@ -10,13 +10,14 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # resolved from this file: the tool may be started from any directory (rocprofv3 runs it from /tmp)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
-from helpers import ed_tasks, ed_global_tasks, ed_semi_trace_tasks, ed_ext_tasks, scenario_reads, scenario_oracle  # noqa: E402
+from helpers import ed_tasks, ed_tasks_grid, ed_global_tasks, ed_semi_trace_tasks, ed_ext_tasks, scenario_reads, scenario_oracle  # noqa: E402
 
 import argparse  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("scenario", nargs="?", default="hifi_15k"); ap.add_argument("n_reads", nargs="?", type=int, default=400)
 ap.add_argument("--wide", type=int, default=0, help="0: thre <= 31 (one-word bands), 1: 32 .. 63 (two words), 2: 64 .. 127 (three / four words)")
 ap.add_argument("--dry", action="store_true")
+ap.add_argument("--grid", action="store_true", help="distance-only mode on the reference's fixed window grid: every overlap of a read contributes a pair per 375-base window it covers (the candidates of a window share their text); without it: the test generator's windows, anchored at each overlap's start (hardly any two pairs share a text)")
 a_ = ap.parse_args()
 name, nr, wide, dry = a_.scenario, a_.n_reads, a_.wide, a_.dry
 rs, okw = scenario_reads(name)
@@ -26,14 +27,18 @@ if not dry:
     from hifiasm_amd.api import Engine
     e = Engine(0, **okw); e.set_readset(rs)
 CAP = 80 if wide == 0 else 264
-MODES = (("semi, distance only", lambda: ed_tasks(name, n_reads=nr, seed=11, wide=wide), lambda t: e.window_ed_batch(t), lambda t: o.window_ed(t)),
+MODES = (("semi, distance only", lambda: (ed_tasks_grid if a_.grid else ed_tasks)(name, n_reads=nr, seed=11, wide=wide), lambda t: e.window_ed_batch(t), lambda t: o.window_ed(t)),
          ("global + cigar", lambda: ed_global_tasks(name, n_reads=nr, seed=12, wide=wide), lambda t: e.window_trace_batch(t, cap=CAP), lambda t: o.window_trace(t, cap=CAP)),
          ("extension fwd + cigar", lambda: ed_ext_tasks(name, n_reads=nr, seed=14, wide=wide), lambda t: e.window_trace_batch(t, cap=CAP, mode=1), lambda t: o.window_trace(t, cap=CAP, mode=1)),
          ("extension bwd + cigar", lambda: ed_ext_tasks(name, n_reads=nr, seed=14, wide=wide), lambda t: e.window_trace_batch(t, cap=CAP, mode=2), lambda t: o.window_trace(t, cap=CAP, mode=2)),
          ("semi + cigar", lambda: ed_semi_trace_tasks(name, n_reads=nr, seed=13, wide=wide), lambda t: e.window_trace_batch(t, cap=CAP, mode=3), lambda t: o.window_trace(t, cap=CAP, mode=3)))
-for label, mk, gpu, cpu in MODES:
+for label, mk, gpu, cpu in (MODES[:1] if a_.grid else MODES):
     t = mk()
-    t = np.concatenate([t] * max(1, 400000 // max(1, t.shape[0])))
+    if not a_.grid:
+        t = np.concatenate([t] * max(1, 400000 // max(1, t.shape[0])))
+    if a_.grid:      # how many pairs share a text (= lanes of a wave that step together)
+        _, cnt_ = np.unique(t[:, 4:8], axis=0, return_counts=True)
+        print(f"[grid] {t.shape[0]} pairs over {cnt_.size} distinct texts: {t.shape[0] / cnt_.size:.1f} pairs per text on average", flush=True)
     bases = int(t[:, 6].sum())
     tg = None
     if not dry:

@@ -36,4 +36,8 @@ if has seedctr; then ( cd /tmp
 if has alu; then ( cd /tmp
   timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --output-format csv -d $O/alu -- python $R/bench.py --workload $WLMAIN --cpu-baseline none --no-boundary --no-variants --steps 1 --warmup 0 > $O/alu.log 2>&1
   cd $R && python tools/sketch_alu.py $O/alu 7500002354 sketch_unit_kernel > $O/sketch_alu.json; cat $O/sketch_alu.json; rm -rf $O/alu ); fi
+
+if has edgrid; then ( cd /tmp; for w in 0 1 2; do timeout 300 python $R/tools/bench_ed.py hifi_15k 400 --grid --wide $w; done > $O/bench_ed_grid.txt 2>&1; cat $O/bench_ed_grid.txt
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/edprofg -- python $R/tools/bench_ed.py hifi_15k 400 --grid --wide 0 > $O/edprofg.log 2>&1
+  f=$(find $O/edprofg -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel_stats_ed_grid.csv; head -6 $O/kernel_stats_ed_grid.csv | cut -c1-60,200-330; rm -rf $O/edprofg ); fi
 du -sh $O
