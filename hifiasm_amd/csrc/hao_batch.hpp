@@ -373,8 +373,15 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			if (!serial) HIP_TRY(hipEventRecord(B.ev_dp[x], ds));
 		}
 		ca.dbg_seq = dbg_seq0;
-		if (cls_cnt[0]) {      // groups of <= HAO_TINY_MAX hits: one lane per group, the complete sequential algorithm
-			hipLaunchKernelGGL(chain_tiny_kernel, dim3((unsigned)((cls_cnt[0] + 63) / 64)), dim3(64), 0, c->stream, ca, B.glist.p + L.base[0], (uint64_t)cls_cnt[0]);
+		if (cls_cnt[0]) {      // groups of <= HAO_TINY_MAX hits: eight per wave through the data-parallel quick check (A/B and HAO_DBG_SEQ_CHAIN: one lane per group, the complete sequential algorithm)
+			const hao_gent *lst0 = B.glist.p + L.base[0]; uint32_t *slow0 = B.slow.p + L.base[0];
+			const unsigned nb_lane = (unsigned)std::min<uint64_t>((cls_cnt[0] + 63) / 64, 256 * 64);
+			if (c->sw.tiny_lane || ca.dbg_seq == 1) hipLaunchKernelGGL(chain_tiny_kernel, dim3(nb_lane), dim3(64), 0, c->stream, ca, lst0, (uint64_t)cls_cnt[0], (const uint32_t*)nullptr, (const unsigned long long*)nullptr);
+			else {
+				hipLaunchKernelGGL(chain_pack8_kernel, dim3((unsigned)((cls_cnt[0] + 31) / 32)), dim3(256), 0, c->stream, ca, lst0, (uint64_t)cls_cnt[0], slow0);
+				HAO_CHECK_LAUNCH();
+				hipLaunchKernelGGL(chain_tiny_kernel, dim3(nb_lane), dim3(64), 0, c->stream, ca, lst0, (uint64_t)cls_cnt[0], (const uint32_t*)slow0, (const unsigned long long*)d_slow_cnt);
+			}
 			HAO_CHECK_LAUNCH();
 		}
 		if (ca.dbg_qc) { unsigned long long d_[5]; HIP_TRY(hipMemcpy(d_, B.dbgbuf.p, 40, hipMemcpyDeviceToHost)); if (d_[3]) fprintf(stderr, "[qc] fast groups %llu (avg %.0f hits)  avg us: entry + tile 0 %.2f  scan loop %.2f  cigar + record %.2f\n", d_[3], (double)d_[4] / d_[3], d_[0] / 100.0 / d_[3], d_[1] / 100.0 / d_[3], d_[2] / 100.0 / d_[3]); }

@@ -91,13 +91,15 @@ __device__ __forceinline__ void hao_region(hao_chain_rec &o, int64_t xl, int64_t
 __device__ __forceinline__ uint64_t hao_fc_entry(uint32_t site, int32_t shift)
 { uint32_t lo = shift < 0 ? ((uint32_t)(-shift) << 1 | 1u) : (uint32_t)shift << 1; return (uint64_t)site << 32 | lo; }
 
-__device__ uint32_t hao_fake_cigar(uint64_t *fc, const hao_chain_rec &o, const hao_hit_t *hit, int64_t n_hit)
+template<class HitAt>      // hit(k): hit k of the chain (the callers read the chain where it already sits - LDS or the sorted seed hits -, not the copy they have just stored)
+__device__ uint32_t hao_fake_cigar(uint64_t *fc, const hao_chain_rec &o, HitAt hit, int64_t n_hit)
 {	// gen_fake_cigar, apend_be = 1
 	int64_t pdd = INT32_MAX; uint32_t n = 0;
 	fc[n++] = hao_fc_entry(o.x_pos_s, 0);
 	for (int64_t k = 0; k < n_hit; ++k) {
-		int64_t dq = (int64_t)hit[k].self_offset - o.x_pos_s, dr = (int64_t)hit[k].offset - o.y_pos_s, dd = dr - dq;
-		if (dd != pdd) { pdd = dd; fc[n++] = hao_fc_entry(hit[k].self_offset, (int32_t)pdd); }
+		const hao_hit_t h = hit(k);
+		int64_t dq = (int64_t)h.self_offset - o.x_pos_s, dr = (int64_t)h.offset - o.y_pos_s, dd = dr - dq;
+		if (dd != pdd) { pdd = dd; fc[n++] = hao_fc_entry(h.self_offset, (int32_t)pdd); }
 	}
 	uint64_t last = fc[n - 1]; int32_t lsh = (int32_t)((uint32_t)last >> 1); if (last & 1) lsh = -lsh;
 	if ((int64_t)(int32_t)(last >> 32) != (int64_t)o.x_pos_e) fc[n++] = hao_fc_entry(o.x_pos_e, lsh);
@@ -168,8 +170,8 @@ __device__ __forceinline__ uint8_t hao_wire_code(uint32_t q, uint32_t pq, const 
 	return (dq < 1 || dq > 15 || sh < -8 || sh > 7 || q == 65535u || (exc_every && idx % exc_every == exc_every - 1)) ? esc : (uint8_t)((dq - 1) << 4 | (sh + 8));
 }
 // the codes of one chain the DP compacted into ohits[o, o + n) of group gs (hit j of the chain = seed hit a[src(j)]), by ONE lane
-template<class SrcAt>
-__device__ __forceinline__ void hao_code_chain_lane(const hao_chain_args &A, const uint64_t gs, const hao_hit_t *a, int64_t o, int64_t n, SrcAt src)
+template<class HitP, class SrcAt>
+__device__ __forceinline__ void hao_code_chain_lane(const hao_chain_args &A, const uint64_t gs, HitP a, int64_t o, int64_t n, SrcAt src)
 {
 	const uint16_t *hq = A.hq + gs; uint8_t *hc = A.hcode + gs; uint16_t *oq = A.ohq + gs;
 	uint32_t pq = 0; hao_hit_t ph; ph.w0 = ph.offset = ph.self_offset = ph.cnt = 0;
@@ -196,8 +198,8 @@ __device__ __forceinline__ void hao_code_chain_wave(const hao_chain_args &A, con
 
 // Sequential tail shared by both paths (ONE lane): backtrack the best chain, multi-copy chains
 // (Hash_Table.cpp:2178-2270), regions, chained hits, fake cigars.  f/p may live in LDS or global memory.
-template<class I32P, class I64P>
-__device__ void hao_chain_tail(const hao_chain_args &A, const uint64_t g, const hao_hit_t *a, const int64_t a_n, const hao_cpar &P,
+template<class HitP, class I32P, class I64P>      // HitP: the group's hits, a[i] (a pointer into the sorted seed hits, or the copy chain_tiny_kernel keeps in LDS)
+__device__ void hao_chain_tail(const hao_chain_args &A, const uint64_t g, HitP a, const int64_t a_n, const hao_cpar &P,
 		I32P f, I32P p, I64P t, I32P ii, int64_t msc, int64_t msc_i, int64_t plus)
 {
 	const uint64_t gs = A.g_start[g];
@@ -235,7 +237,7 @@ __device__ void hao_chain_tail(const hao_chain_args &A, const uint64_t g, const 
 				rec[k].hit_rel = (uint32_t)i; rec[k].n_hits = (uint32_t)ni; rec[k].src_rel = (uint32_t)i; rec[k].in_place = 0;
 				if (A.hcode) hao_code_chain_lane(A, gs, a, i, ni, [&](int64_t q_) { return (int64_t)ii[n_v0 + (ni - q_ - 1)]; });
 				for (j = 0; j < ni; ++j, ++i) des[i] = a[ii[n_v0 + (ni - j - 1)]];
-				rec[k].fc_rel = fcn; rec[k].fc_len = hao_fake_cigar(fcs + fcn, rec[k], des + i - ni, ni); fcn += rec[k].fc_len;
+				rec[k].fc_rel = fcn; rec[k].fc_len = hao_fake_cigar(fcs + fcn, rec[k], [&](int64_t q_) { return a[ii[n_v0 + (ni - q_ - 1)]]; }, ni); fcn += rec[k].fc_len;
 			}
 			A.nch[g] = (uint32_t)n_u; A.nout[g] = (uint32_t)i;
 			return;
@@ -247,15 +249,15 @@ __device__ void hao_chain_tail(const hao_chain_args &A, const uint64_t g, const 
 	hao_region(rec[0], P.xl, P.yl, msc, a[t[cL - 1]], a[t[0]]);
 	if (A.hcode) hao_code_chain_lane(A, gs, a, 0, cL, [&](int64_t q_) { return (int64_t)t[cL - q_ - 1]; });
 	for (i = 0; i < cL; ++i) des[i] = a[t[cL - i - 1]];
-	rec[0].hit_rel = 0; rec[0].n_hits = (uint32_t)cL; rec[0].src_rel = 0; rec[0].in_place = 0; rec[0].fc_rel = 0; rec[0].fc_len = hao_fake_cigar(fcs, rec[0], des, cL);
+	rec[0].hit_rel = 0; rec[0].n_hits = (uint32_t)cL; rec[0].src_rel = 0; rec[0].in_place = 0; rec[0].fc_rel = 0; rec[0].fc_len = hao_fake_cigar(fcs, rec[0], [&](int64_t q_) { return a[t[cL - q_ - 1]]; }, cL);
 	A.nch[g] = 1; A.nout[g] = (uint32_t)cL;
 }
 
 
 // Generic path, executed by ONE lane: the full sequential algorithm (quick check, DP, multi-copy).
 // core: group g = hits a[0, a_n) of query xid against target yid; f/ii/p/t = per-hit scratch of the caller
-template<class I32P, class I64P>
-__device__ void hao_chain_generic_core(const hao_chain_args &A, const uint64_t g, const uint64_t gs, const hao_hit_t *a, const int64_t a_n, const uint32_t xid, const uint32_t yid,
+template<class HitP, class I32P, class I64P>
+__device__ void hao_chain_generic_core(const hao_chain_args &A, const uint64_t g, const uint64_t gs, HitP a, const int64_t a_n, const uint32_t xid, const uint32_t yid,
 		const uint32_t xl, const uint32_t yl, I32P f, I32P ii, I32P p, I64P t)
 {
 	A.nch[g] = 0; A.nout[g] = 0;
@@ -353,14 +355,25 @@ __device__ void hao_chain_generic(const hao_chain_args &A, const uint64_t g)
 // element i of a lane-interleaved LDS array (conflict-free: lane L owns words L, L + 64, ...)
 template<class T> struct hao_lane_arr { T *p; __device__ __forceinline__ T &operator[](int64_t i) const { return p[i * 64]; } };
 
-__global__ __launch_bounds__(64) void chain_tiny_kernel(hao_chain_args A, const hao_gent *list, uint64_t n_list)
+// The lane's hits are read ONCE, with independent loads, into LDS: the sequential algorithm indexes them through its scratch arrays (a[t[k]], a[ii[k]]), and
+// every such access was a dependent global load of the same 16 - 128 bytes - ~10 memory round trips per group, the whole cost of the kernel on the repeat-rich
+// sets (28 M groups of one or two hits per batch: 8.1 ms).
+struct hao_lane_hits { const hao_hit_t *p; __device__ __forceinline__ hao_hit_t operator[](int64_t i) const { return p[i * 64]; } };
+// slow == nullptr: every group of the list (A/B, HAO_DBG_SEQ_CHAIN); else the groups slow[0 .. *slow_cnt) that chain_pack8_kernel's quick check did not settle
+__global__ __launch_bounds__(64) void chain_tiny_kernel(hao_chain_args A, const hao_gent *list, uint64_t n_list, const uint32_t *slow, const unsigned long long *slow_cnt)
 {
-	__shared__ int32_t l_f[HAO_TINY_MAX * 64], l_ii[HAO_TINY_MAX * 64], l_p[HAO_TINY_MAX * 64]; __shared__ int64_t l_t[HAO_TINY_MAX * 64];
-	const uint64_t li = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-	if (li >= n_list) return;
-	const hao_gent e = list[li];
-	const hao_lane_arr<int32_t> f{l_f + threadIdx.x}, ii{l_ii + threadIdx.x}, p{l_p + threadIdx.x}; const hao_lane_arr<int64_t> t{l_t + threadIdx.x};
-	hao_chain_generic_core(A, e.g, e.start, A.hits + e.start, (int64_t)e.n, (uint32_t)(A.rid_lo + e.r), e.yid, e.xl, e.yl, f, ii, p, t);
+	__shared__ int32_t l_f[HAO_TINY_MAX * 64], l_ii[HAO_TINY_MAX * 64], l_p[HAO_TINY_MAX * 64]; __shared__ int64_t l_t[HAO_TINY_MAX * 64]; __shared__ hao_hit_t l_a[HAO_TINY_MAX * 64];
+	const uint64_t n = slow ? (uint64_t)*slow_cnt : n_list;
+	for (uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 64) {
+		const hao_gent e = list[slow ? (uint64_t)slow[i] : i];
+		{
+			const hao_hit_t *src = A.hits + e.start;
+#pragma unroll
+			for (int k = 0; k < HAO_TINY_MAX; ++k) if ((uint32_t)k < e.n) l_a[k * 64 + threadIdx.x] = src[k];
+		}
+		const hao_lane_arr<int32_t> f{l_f + threadIdx.x}, ii{l_ii + threadIdx.x}, p{l_p + threadIdx.x}; const hao_lane_arr<int64_t> t{l_t + threadIdx.x};
+		hao_chain_generic_core(A, e.g, e.start, hao_lane_hits{l_a + threadIdx.x}, (int64_t)e.n, (uint32_t)(A.rid_lo + e.r), e.yid, e.xl, e.yl, f, ii, p, t);
+	}
 }
 
 __device__ __forceinline__ hao_hit_t hao_shfl_hit(const hao_hit_t &h, int src)
@@ -485,6 +498,107 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void chai
 	}
 }
 
+
+// Groups of <= 8 hits, EIGHT per wave: lanes 8 s .. 8 s + 7 hold the hits of the wave's s-th group, and chain_group_kernel's data-parallel quick check
+// (quick_ck_lchain, Hash_Table.cpp:2007-2094, as a segmented prefix sum over strand blocks with per-pair validity flags) runs on all eight groups at once:
+// the scan's segments end at group boundaries, every wave-wide vote / reduction becomes its 8-lane counterpart (a byte of a ballot, three xor-shuffles).  A group
+// the check settles gets its one chain in place (the best strand block of the sorted seed hits), its region, fake cigar and wire codes from its own lanes; the
+// group it does not settle goes to the class's slow list for chain_tiny_kernel (the exact sequential routine, one lane per group).  (chain_tiny_kernel ran that routine on
+// one lane per group for ALL of them: 64 divergent walks per wave - 8.1 ms per batch of the repeat-rich 250 Mb set, whose 28 M tiny groups per batch are mostly
+// single hits of repeat copies.)
+__global__ __launch_bounds__(256) void chain_pack8_kernel(hao_chain_args A, const hao_gent *list, uint64_t n_list, uint32_t *slow)
+{
+	const int lane = hao_lane(), wv = threadIdx.x >> 6, seg = lane >> 3, idx = lane & 7, sb = lane & ~7;
+	const uint64_t li = ((uint64_t)blockIdx.x * 4 + wv) * 8 + seg;      // index in the class list
+	const bool have = li < n_list;
+	hao_gent e; e.g = 0; e.r = 0; e.start = 0; e.n = 0; e.yid = 0; e.xl = 0; e.yl = 0;
+	if (have) e = list[li];
+	const int32_t a_n = (int32_t)e.n; const uint64_t g = e.g, gs = e.start;
+	const uint32_t xid = (uint32_t)(A.rid_lo + e.r), yid = e.yid;
+	const bool skip = !have || yid == xid || a_n <= 0;                       // hits to the query itself are skipped (anchor.cpp:1931)
+	const bool act = !skip && idx < a_n;
+	hao_hit_t h; h.w0 = 0; h.offset = 0; h.self_offset = 0; h.cnt = 0;
+	if (act) h = A.hits[gs + idx];
+	const uint32_t q = (A.hcode && act) ? A.hq[gs + idx] : 0u;
+	hao_cpar P; P.pen_gap = A.par.pen_gap; P.pen_skip = A.par.pen_skip; P.bw = A.par.bw; P.max_skip = A.par.max_skip; P.max_iter = A.par.max_iter; P.max_dis = A.par.max_dis;
+	P.xl = e.xl; P.yl = e.yl;
+	const hao_hit_t ph = hao_shfl_up_hit(h);
+	const uint32_t strand0 = (uint32_t)__shfl((int)HH_STRAND(h), sb);
+	const bool st = act && (idx == 0 || HH_STRAND(h) != HH_STRAND(ph));      // first hit of a strand block
+	const int b = act && HH_STRAND(h) != strand0;
+	int32_t s = HH_SPAN(h); bool ok = true; int64_t dd = 0;
+	if (act && !st) { s = hao_pair_score(h, ph, P, &dd); ok = s != INT32_MIN; if (!ok) { s = 0; dd = 0; } }
+	uint8_t code = 0x08;
+	if (A.hcode) {      // wire code of this hit relative to the previous one of its strand block (hao_deliver.cuh)
+		const uint32_t pq = hao_wave_shr1(q, 0u);
+		const int32_t dq = (int32_t)(q - pq), sh = (int32_t)((h.offset - ph.offset) - (h.self_offset - ph.self_offset));
+		if (!st) code = (dq < 1 || dq > 15 || sh < -8 || sh > 7 || q == 65535u || (A.exc_every && (uint32_t)idx % A.exc_every == A.exc_every - 1)) ? (uint8_t)0xff : (uint8_t)((dq - 1) << 4 | (sh + 8));
+	}
+	const uint32_t diag = h.offset - h.self_offset, pdiag = ph.offset - ph.self_offset;
+	const bool cf = act && (st || diag != pdiag);                            // a fake-cigar entry starts here
+	int32_t x = act ? s : 0; int fl = (st || idx == 0) ? 1 : 0;
+	hao_seg_scan_add(x, fl);
+	const int32_t f = x, fp = hao_wave_shr1(f, 0);
+	const bool brk = act && !st && (!ok || (int64_t)s + fp < (int64_t)HH_SPAN(h));
+	auto seg_byte = [&](unsigned long long m) { return (uint32_t)(m >> sb) & 0xffu; };      // the group's eight lanes of a wave-wide vote
+	const uint32_t in0 = seg_byte(__ballot(act && b == 0)), brk0 = seg_byte(__ballot(brk && b == 0)), brk1 = seg_byte(__ballot(brk && b == 1)),
+				   cf0 = seg_byte(__ballot(cf && b == 0)), cf1 = seg_byte(__ballot(cf && b == 1));
+	const int32_t k1 = __popc(in0);                                          // hits of the first strand block
+	const bool two = k1 < a_n;
+	int32_t maxf0 = (act && b == 0) ? f : INT32_MIN, maxf1 = (act && b == 1) ? f : INT32_MIN, ddt0 = (act && b == 0) ? (int32_t)dd : 0, ddt1 = (act && b == 1) ? (int32_t)dd : 0;      // (dd < 2^27 per pair)
+#pragma unroll
+	for (int d = 1; d < 8; d <<= 1) { maxf0 = max(maxf0, __shfl_xor(maxf0, d)); maxf1 = max(maxf1, __shfl_xor(maxf1, d)); ddt0 += __shfl_xor(ddt0, d); ddt1 += __shfl_xor(ddt1, d); }
+	const int l0 = sb + (k1 > 0 ? k1 - 1 : 0), f1 = sb + (two ? k1 : 0), l1 = sb + (a_n > 0 ? a_n - 1 : 0);      // lanes of: last hit of block 0, first / last hit of block 1
+	const int32_t flast0 = __shfl(f, l0), flast1 = __shfl(f, l1);
+	hao_hit_t first0, last0, first1, last1;
+	first0.w0 = (uint32_t)__shfl((int)h.w0, sb); first0.self_offset = (uint32_t)__shfl((int)h.self_offset, sb); first0.offset = (uint32_t)__shfl((int)h.offset, sb); first0.cnt = 0;
+	last0.w0 = first0.w0; last0.self_offset = (uint32_t)__shfl((int)h.self_offset, l0); last0.offset = (uint32_t)__shfl((int)h.offset, l0); last0.cnt = 0;
+	first1.w0 = (uint32_t)__shfl((int)h.w0, f1); first1.self_offset = (uint32_t)__shfl((int)h.self_offset, f1); first1.offset = (uint32_t)__shfl((int)h.offset, f1); first1.cnt = 0;
+	last1.w0 = first1.w0; last1.self_offset = (uint32_t)__shfl((int)h.self_offset, l1); last1.offset = (uint32_t)__shfl((int)h.offset, l1); last1.cnt = 0;
+	const bool acc0 = !brk0 && flast0 == maxf0 && !(k1 >= 2 && ddt0 > 16 && ddt0 > hao_band(last0, first0, P));
+	const bool acc1 = two && !brk1 && flast1 == maxf1 && !(a_n - k1 >= 2 && ddt1 > 16 && ddt1 > hao_band(last1, first1, P));
+	bool fast = acc0 && (!two || acc1);
+	int best = 0; int64_t msc = flast0;
+	if (fast && two) {
+		const int64_t ov0 = hao_ext_len(last0.self_offset, last0.self_offset, P.xl, last0.offset, last0.offset, P.yl);
+		const int64_t ov1 = hao_ext_len(last1.self_offset, last1.self_offset, P.xl, last1.offset, last1.offset, P.yl);
+		if (flast1 >= flast0 && (flast1 > flast0 || ov1 < ov0)) { best = 1; msc = flast1; }
+	}
+	const int32_t bl = best ? k1 : 0, cL = best ? a_n - k1 : k1;
+	if (fast && A.par.mcopy_num > 1 && cL >= A.par.mcopy_khit_cut && two) {
+		const int64_t min_sc = (int64_t)((double)msc * A.par.mcopy_rate);        // plus == 0 here: every f >= span > 0
+		if ((int64_t)(best ? maxf0 : maxf1) >= min_sc) fast = false;             // a second chain may qualify: exact sequential path
+	}
+	{	// The groups the check does not settle go to the class's slow list (one atomic per wave; A.stats[0] counts them like chain_group_kernel's classes) and
+		// are chained by chain_tiny_kernel, 64 to a wave: run here - one lane of a group's eight, in a quarter of the waves of a repeat-rich set (3.7 % of its
+		// tiny groups) - the sequential routine cost as much as everything else in this kernel.  Their codes keep the "nothing to say" prefill until then.
+		const bool sl = !skip && !fast && idx == 0; const unsigned long long sq = __ballot(sl);
+		if (sq) {
+			unsigned long long base = 0;
+			if (lane == 0) base = atomicAdd(A.stats, (unsigned long long)__popcll(sq));
+			base = (unsigned long long)hao_readlane_i64((int64_t)base, 0);
+			if (sl) { slow[base + __popcll(sq & ((1ULL << lane) - 1))] = (uint32_t)(li & 0xffffffffu); A.nch[g] = 0; A.nout[g] = 0; }
+		}
+	}
+	if (skip) { if (have && idx == 0) { A.nch[g] = 0; A.nout[g] = 0; } return; }
+	if (!fast) return;
+	// ---- single chain = the whole best strand block, in place ----
+	if (A.hcode && act && b == best) A.hcode[gs + idx] = code;
+	uint64_t *fcs = A.fcs + gs + 6 * g; hao_chain_rec rc;
+	hao_region(rc, P.xl, P.yl, msc, best ? first1 : first0, best ? last1 : last0);
+	const int64_t cdiag = (int64_t)rc.y_pos_s - (int64_t)rc.x_pos_s;            // dd of a hit = (offset - self_offset) - cdiag
+	const uint32_t cfm = best ? cf1 : cf0, ce = (uint32_t)__popc(cfm);
+	if (cf && b == best) fcs[1 + __popc(cfm & ((1u << idx) - 1u))] = hao_fc_entry(h.self_offset, (int32_t)((int64_t)(int32_t)diag - cdiag));
+	const int lc = sb + (cfm ? 31 - __clz((int)cfm) : 0);                     // lane of the block's last cigar entry
+	const uint32_t last_site = (uint32_t)__shfl((int)h.self_offset, lc), last_diag = (uint32_t)__shfl((int)diag, lc);
+	uint32_t cnt = 1 + ce;
+	if (last_site != rc.x_pos_e) { if (idx == 0) fcs[cnt] = hao_fc_entry(rc.x_pos_e, (int32_t)((int64_t)(int32_t)last_diag - cdiag)); ++cnt; }
+	if (idx == 0) {
+		fcs[0] = hao_fc_entry(rc.x_pos_s, 0);
+		rc.hit_rel = 0; rc.n_hits = (uint32_t)cL; rc.src_rel = (uint32_t)bl; rc.in_place = 1; rc.fc_rel = 0; rc.fc_len = cnt;
+		A.rec[g * HAO_MCOPY_MAX] = rc; A.nch[g] = 1; A.nout[g] = (uint32_t)cL;
+	}
+}
 
 // Wave-cooperative hao_chain_tail for chain_dp_kernel: the order-dependent walks (backtrack, chain extraction) stay on lane 0
 // over (normally LDS-resident) arrays; candidate collection, the sort of the (distinct) candidate keys, hit copies and fake

@@ -57,7 +57,7 @@ struct StageTimer {
 // run-time switches (measurement aids): read from the environment ONCE, in hao_create
 struct hao_switches {
 	bool seedphase = false, qcphase = false, dp_stats = false, seq_chain = false, dp_seqtail = false, dp_nospec = false, dp_serial = false,
-		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, sk_v2 = false, dltime = false, sk_nofuse = false, pack_search = false, sk_select2 = false, seed_v2 = false, seed_pf = true, seed_noql = false, sort64 = false, seed_nodirect = false;
+		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, sk_v2 = false, dltime = false, sk_nofuse = false, pack_search = false, sk_select2 = false, seed_v2 = false, seed_pf = true, seed_noql = false, sort64 = false, seed_nodirect = false, tiny_lane = false;
 	static constexpr bool SK_SELECT2_DEFAULT = true;       // the thinning kernel the sketch runs when the environment says nothing: the wave kernel (round 4: green on the device against every repeat-rich scenario and the 5 Mb / 250 Mb repeat-rich fixtures)
 	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; unsigned long long ix_pad = 0; int seed_nu = 4, exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, seed_lds_pad = 0, arena_numa = 1, seed_tile = 512;
 	void load() {
@@ -71,6 +71,7 @@ struct hao_switches {
 		sort64 = on("HAO_PT_SORT64");      // A/B: the index sort over all 64 hash bits (8 passes) instead of 40 bits + fix-up (hao_index.cuh)
 		seed_nodirect = on("HAO_SEED_NODIRECT");      // A/B: reads of many bins through the staged-tile kernel's 1024- / 2048-slot instances instead of hao_query3.cuh
 		if (const char *e = getenv("HAO_SEED_NU")) seed_nu = atoi(e) == 8 ? 8 : 4;      // 64-anchor windows a wave of seed_bin3_kernel keeps in flight
+		tiny_lane = on("HAO_DBG_TINY_LANE");      // A/B: groups of <= 8 hits by chain_tiny_kernel (one lane per group, sequential) instead of chain_pack8_kernel
 		seed_noql = on("HAO_SEED_NOQL");  // A/B: the seed kernel's generic per-minimizer tables (LDS or global, all minimizers) even when every read of the batch fits the LDS
 		if (const char *e = getenv("HAO_SEED_PF")) seed_pf = atoi(e) != 0;      // 0: first launch of the seed kernel without the next tile's reads in flight (A/B)
 		sk_select2 = on("HAO_SK_SELECT2") || (SK_SELECT2_DEFAULT && !on("HAO_SK_SELECT1"));      // thinning of high-count minimizers: the wave kernel (hao_select2.cuh) / the one-lane replay (sketch_select_kernel)
