@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "hao_ft_cnt", "hao_pt_get", "hao_ft_table", "hao_pt_table", "hao_hist", "hao_stats", "hao_sketch_batch",
     "hao_fetch_sketch", "hao_overlap_batch", "hao_fetch_seed_hits", "hao_fetch_overlaps", "hao_batch_totals",
     "hao_stage_times", "hao_pass_default", "hao_overlap_batch_ex", "hao_set_shard", "hao_dist_unique_id", "hao_dist_init",
-    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_selftest_big", "hao_selftest_sortbits", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits", "hao_exact_check", "hao_fetch_exact", "hao_window_ed_batch", "hao_index_save", "hao_index_load", "hao_next_slot", "hao_attach", "hao_window_trace_batch", "hao_delivery_digest",
+    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_selftest_big", "hao_selftest_sortbits", "hao_unpack_cigar", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits", "hao_exact_check", "hao_fetch_exact", "hao_window_ed_batch", "hao_index_save", "hao_index_load", "hao_next_slot", "hao_attach", "hao_window_trace_batch", "hao_delivery_digest",
 ]
 
 
@@ -106,6 +106,7 @@ def lib():
         L.hao_index_load.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int32)]
         L.hao_fetch_exact.argtypes = [vp, C.c_uint64, C.POINTER(vp), u64p]
         L.hao_unpack_hits.argtypes = [C.POINTER(Delivery), C.c_uint64, vp, C.c_uint64]; L.hao_unpack_hits.restype = C.c_uint64
+        L.hao_unpack_cigar.argtypes = [C.POINTER(Delivery), C.c_uint64, vp, C.c_uint32]; L.hao_unpack_cigar.restype = C.c_uint32
         L.hao_delivery_digest.argtypes = [C.POINTER(Delivery), u64p, C.c_int]
         L.hao_set_shard.argtypes = [vp, C.c_uint64, C.c_uint64, u32p]
         L.hao_dist_unique_id.argtypes = [u8p]
@@ -306,14 +307,18 @@ class Engine:
         oo = _arr(d.ol_off + 8 * r, 2, np.uint64)
         s_, e_ = int(oo[0]), int(oo[1])
         ol = _arr(d.ol + 48 * s_, 12 * (e_ - s_), np.uint32).reshape(-1, 12)
-        fo = _arr(d.fc_off + 8 * s_, e_ - s_ + 1, np.uint64)
-        fc = _arr(d.fc + 8 * int(fo[0]), int(fo[-1] - fo[0]), np.uint64) if fo.size else np.zeros(0, dtype=np.uint64)
+        lens = ol[:, 11].astype(np.int64)                                  # fc_len of every overlap; the cigars come through the decoder (the wire packs them)
+        fo = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        fc = np.zeros(int(fo[-1]), dtype=np.uint64)
+        for k in range(e_ - s_):
+            got = self.L.hao_unpack_cigar(C.byref(d), s_ + k, fc[int(fo[k]):].ctypes.data_as(C.c_void_p), int(lens[k]))
+            assert got == int(lens[k])
         co = _arr(d.cl_off + 8 * r, 2, np.uint64)
         m = int(co[1] - co[0])
         cl = np.zeros((m, 4), dtype=np.uint32)
         got = self.L.hao_unpack_hits(C.byref(d), rid, cl.ctypes.data_as(C.c_void_p), m)
         assert got == m
-        return ol, fc, fo - (fo[0] if fo.size else 0), cl
+        return ol, fc, fo, cl
 
     def delivery_digest(self, d, threads=None):
         """hao_batch_digest's per-read value computed on the HOST from a delivered batch: ol, fake cigars, and cl->list decoded out of the wire format"""

@@ -8,7 +8,7 @@
 
 struct hao_ctx::Batch {
 	uint64_t n_generic = 0, n_generic_hits = 0; DevBuf<unsigned long long> stats, dbgbuf;
-	uint64_t lo = 0, n = 0, mz0 = 0, n_mz = 0, n_anchor = 0, n_groups = 0, n_chains = 0, n_cl = 0, n_fc_raw = 0, n_ol = 0, n_fc = 0;
+	uint64_t lo = 0, n = 0, mz0 = 0, n_mz = 0, n_anchor = 0, n_groups = 0, n_chains = 0, n_cl = 0, n_fc_raw = 0, n_ol = 0, n_fc = 0, n_fcw = 0;
 	bool valid = false, host_valid = false;
 	DevBuf<uint64_t> s_start, a_off, seg, g_cnt, g_off, g_start, ch_base, cl_base, fc_base, fcs, fc_raw, ol_fc_off, cc_off, cc, fc_final, fcf_off;
 	DevBuf<uint64_t> nch64;
@@ -22,10 +22,11 @@ struct hao_ctx::Batch {
 	// Results of a batch that leave the device.  Two sets (+ two pinned host arenas): while the copy stream drains the set of batch i, batch i + 1
 	// computes into the other one (hao_overlap_batch_async).  The blocking API keeps using the current set.
 	struct OutSet {
-		DevBuf<hao_ovlp_t> ol_out; DevBuf<uint64_t> fin_off, fc_out, fc_out_off, ch_off, cl_off, qm_off;      // ol->list in final order, per-read offsets, fake cigars
+		DevBuf<hao_ovlp_t> ol_out; DevBuf<uint64_t> fin_off, fc_out, fc_out_off, ch_off, cl_off, qm_off, fcw_off, fcw_woff; DevBuf<uint32_t> fcw, fcw_len;      // (fcw*: the fake cigars as they travel, hao_deliver.cuh)
+		//      // ol->list in final order, per-read offsets, fake cigars
 		DevBuf<hao_chain_hdr_t> hdr; DevBuf<uint64_t> bits; DevBuf<uint32_t> rank; DevBuf<uint8_t> codes; DevBuf<hao_exc_t> exc, exc2; DevBuf<hao_qmz_t> qmz;   // cl->list in the wire format (hao_deliver.cuh)
 		DevBuf<uint8_t> exact;                                                                        // exact-overlap flags of ol_out
-		void release() { ol_out.release(); fin_off.release(); fc_out.release(); fc_out_off.release(); ch_off.release(); cl_off.release(); qm_off.release(); hdr.release(); bits.release(); rank.release(); codes.release(); exc.release(); exc2.release(); qmz.release(); exact.release(); }
+		void release() { fcw_off.release(); fcw_woff.release(); fcw.release(); fcw_len.release(); ol_out.release(); fin_off.release(); fc_out.release(); fc_out_off.release(); ch_off.release(); cl_off.release(); qm_off.release(); hdr.release(); bits.release(); rank.release(); codes.release(); exc.release(); exc2.release(); qmz.release(); exact.release(); }
 	} out[2];
 	int cur = 0;
 	OutSet &O() { return out[cur]; }
@@ -120,7 +121,7 @@ static int hao_deliver_enqueue(hao_ctx *c)
 	auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
 	const bool ol = parts & HAO_DELIVER_OL, cl = parts & HAO_DELIVER_CL, ex = parts & HAO_DELIVER_EXACT;
 	size_t o_oloff = 0, o_ol = o_oloff + (ol ? al((n + 1) * 8) : 0), o_fcoff = o_ol + (ol ? al(B.n_ol * sizeof(hao_ovlp_t)) : 0), o_fc = o_fcoff + (ol ? al((B.n_ol + 1) * 8) : 0);
-	size_t o_choff = o_fc + (ol ? al(B.n_fc * 8) : 0), o_cloff = o_choff + (cl ? al((n + 1) * 8) : 0), o_qmoff = o_cloff + (cl ? al((n + 1) * 8) : 0), o_hdr = o_qmoff + (cl ? al((n + 1) * 8) : 0);
+	size_t o_choff = o_fc + (ol ? al(B.n_fcw * 4) : 0), o_cloff = o_choff + (cl ? al((n + 1) * 8) : 0), o_qmoff = o_cloff + (cl ? al((n + 1) * 8) : 0), o_hdr = o_qmoff + (cl ? al((n + 1) * 8) : 0);
 	size_t o_qmz = o_hdr + (cl ? al(B.n_chains * sizeof(hao_chain_hdr_t)) : 0), o_bits = o_qmz + (cl ? al(B.n_mz * sizeof(hao_qmz_t)) : 0);
 	const uint64_t nw_ = cl ? (B.n_anchor + 63) / 64 : 0;      // 64-position words of the batch's bit stream (positions = seed hits)
 	size_t o_rank = o_bits + (cl ? al(nw_ * 8) : 0), o_codes = o_rank + (cl ? al((nw_ + 1) * 4) : 0), o_exc = o_codes + (cl ? al(B.n_codes) : 0);
@@ -154,10 +155,10 @@ static int hao_deliver_enqueue(hao_ctx *c)
 	d.rid_lo = B.lo; d.n_reads = n; d.n_ol = d.n_fc = d.n_chains = d.n_cl = d.n_exc = d.n_codes = d.n_pos = 0; d.bytes = 0;
 	if (ol && n) {
 		HIP_TRY(cp(o_oloff, O.fin_off.p, (n + 1) * 8)); HIP_TRY(cp(o_ol, O.ol_out.p, B.n_ol * sizeof(hao_ovlp_t)));
-		HIP_TRY(cp(o_fcoff, O.fc_out_off.p, B.n_ol * 8)); HIP_TRY(cp(o_fc, O.fc_out.p, B.n_fc * 8));
-		((uint64_t*)(a + o_fcoff))[B.n_ol] = B.n_fc;      // end of the last cigar (a host-side word next to, not inside, the region the copy writes)
-		d.n_ol = B.n_ol; d.n_fc = B.n_fc; d.ol_off = (const uint64_t*)(a + o_oloff); d.ol = (const hao_ovlp_t*)(a + o_ol); d.fc_off = (const uint64_t*)(a + o_fcoff); d.fc = (const uint64_t*)(a + o_fc);
-		d.bytes += (n + 1) * 8 + B.n_ol * (sizeof(hao_ovlp_t) + 8) + B.n_fc * 8;
+		HIP_TRY(cp(o_fcoff, O.fcw_off.p, B.n_ol * 8)); HIP_TRY(cp(o_fc, O.fcw.p, B.n_fcw * 4));
+		((uint64_t*)(a + o_fcoff))[B.n_ol] = B.n_fcw;      // end of the last cigar (a host-side word next to, not inside, the region the copy writes)
+		d.n_ol = B.n_ol; d.n_fc = B.n_fcw; d.ol_off = (const uint64_t*)(a + o_oloff); d.ol = (const hao_ovlp_t*)(a + o_ol); d.fc_off = (const uint64_t*)(a + o_fcoff); d.fc = (const uint32_t*)(a + o_fc);
+		d.bytes += (n + 1) * 8 + B.n_ol * (sizeof(hao_ovlp_t) + 8) + B.n_fcw * 4;
 	}
 	if (cl && n) {
 		HIP_TRY(cp(o_choff, O.ch_off.p, (n + 1) * 8)); HIP_TRY(cp(o_cloff, O.cl_off.p, (n + 1) * 8)); HIP_TRY(cp(o_qmoff, O.qm_off.p, (n + 1) * 8));
@@ -216,7 +217,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	// the output set about to be written may still be feeding a copy (its previous async batch): wait for that copy, never for the other slot's
 	if (B.dl_ready && B.dl_pending[B.cur]) { const double t0_ = hao_now(); HIP_TRY(hipEventSynchronize(B.ev_done[B.cur])); B.dl_pending[B.cur] = false; B.t_evsync += hao_now() - t0_; }
 	if (parts) { memset(&B.dl[B.cur], 0, sizeof(hao_delivery_t)); B.dl[B.cur].rid_lo = lo; B.dl[B.cur].n_reads = n; }
-	if (n == 0) { B.n_anchor = B.n_groups = B.n_chains = B.n_cl = B.n_ol = B.n_fc = B.n_mz = 0; B.valid = true; return HAO_OK; }      // (an empty delivery: nothing to copy, the view stays zeroed)
+	if (n == 0) { B.n_anchor = B.n_groups = B.n_chains = B.n_cl = B.n_ol = B.n_fc = B.n_fcw = B.n_mz = 0; B.valid = true; return HAO_OK; }      // (an empty delivery: nothing to copy, the view stays zeroed)
 	// minimizer range of the batch (host knows the per-read offsets? keep a host copy once)
 	if (c->h_ix_mz_off.size() != c->n_reads + 1) {
 		c->h_ix_mz_off.resize(c->n_reads + 1);
@@ -497,12 +498,22 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	hipLaunchKernelGGL(chain_final_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, B.ol.p, B.ol_fc_off.p, B.fc_raw.p, B.perm.p, B.g_off.p, B.ch_base.p,
 					   B.O().fin_off.p, B.fcf_off.p, n, B.O().ol_out.p, B.O().fc_out.p, B.O().fc_out_off.p);
 	HAO_CHECK_LAUNCH();
+	unsigned long long *d_n_fcw = B.stats.p + 3 * HAO_NCLS;      // (slot [3 NCLS] of the stats block is free)
+	if (parts & HAO_DELIVER_OL) {      // the fake cigars as they travel: 4 bytes per entry after the first (hao_deliver.cuh); the final counts are still on the device
+		hao_ctx::Batch::OutSet &O = B.O();
+		HIP_TRY(O.fcw_len.reserve(NCmax + 2)); HIP_TRY(O.fcw_woff.reserve(NCmax + 2)); HIP_TRY(O.fcw_off.reserve(NCmax + 2)); HIP_TRY(O.fcw.reserve(2 * (FCmax + 1)));
+		const dim3 g_((unsigned)((NCmax + 256) / 256));
+		hipLaunchKernelGGL(hao_fcpack_len_kernel, g_, dim3(256), 0, c->stream, O.ol_out.p, O.fc_out_off.p, O.fc_out.p, O.fin_off.p + n, NCmax, O.fcw_len.p); HAO_CHECK_LAUNCH();
+		auto it = rocprim::make_transform_iterator(O.fcw_len.p, FcLenMask());
+		if (int rc = hao_excl_scan_u64(c, it, O.fcw_woff.p, NCmax + 1)) return rc;
+		hipLaunchKernelGGL(hao_fcpack_write_kernel, g_, dim3(256), 0, c->stream, O.ol_out.p, O.fc_out_off.p, O.fc_out.p, O.fin_off.p + n, NCmax, O.fcw_len.p, O.fcw_woff.p, O.fcw.p, O.fcw_off.p, d_n_fcw); HAO_CHECK_LAUNCH();
+	}
 	c->timer.mark("q_final");
 	unsigned long long slow_st[HAO_NCLS + 4], n_exc = 0;
 	{	// the totals of the batch: one wave gathers them into mapped host memory
 		auto peek = [&](const void *src, int nw, int at) { hipLaunchKernelGGL(hao_peek_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)src, nw, c->peek_d + at); };
 		peek(B.ch_base.p + G, 1, 0); peek(B.cl_base.p + G, 1, 1); peek(B.fc_base.p + G * HAO_MCOPY_MAX, 1, 2); peek(B.O().fin_off.p + n, 1, 3); peek(B.fcf_off.p + n, 1, 4);
-		peek(d_slow_cnt, HAO_NCLS + 4, 8); peek(d_exc_cnt, 1, 5); peek(d_n_codes, 1, 6);
+		peek(d_slow_cnt, HAO_NCLS + 4, 8); peek(d_exc_cnt, 1, 5); peek(d_n_codes, 1, 6); peek(d_n_fcw, 1, 7);
 		HAO_CHECK_LAUNCH();
 		const double ts2_ = hao_now();
 		HIP_TRY(hipStreamSynchronize(c->stream));
@@ -511,6 +522,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		B.n_chains = c->peek_h[0]; B.n_cl = c->peek_h[1]; B.n_fc_raw = c->peek_h[2]; B.n_ol = c->peek_h[3]; B.n_fc = c->peek_h[4];
 		for (int x = 0; x < HAO_NCLS + 4; ++x) slow_st[x] = c->peek_h[8 + x];
 		if (parts & HAO_DELIVER_CL) { n_exc = c->peek_h[5]; B.n_codes = G ? c->peek_h[6] : 0; }
+		B.n_fcw = (parts & HAO_DELIVER_OL) ? c->peek_h[7] : 0;
 	}
 	if ((parts & HAO_DELIVER_CL) && n_exc > pa.exc_cap) {      // more verbatim hits than the list holds: grow it and pack again (the sources are untouched)
 		HIP_TRY(B.O().exc.reserve(n_exc + 1024)); pa.exc = B.O().exc.p; pa.exc_cap = B.O().exc.cap;

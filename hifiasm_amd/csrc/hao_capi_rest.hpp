@@ -182,6 +182,24 @@ uint64_t hao_unpack_hits(const hao_delivery_t *d, uint64_t rid, hao_hit_t *out, 
 	return k;
 }
 
+// the fake cigar of delivered overlap j back into 8-byte entries (hao_deliver.cuh: "fake cigars on the wire")
+uint32_t hao_unpack_cigar(const hao_delivery_t *d, uint64_t j, uint64_t *out, uint32_t cap)
+{
+	if (!d || !d->ol || !d->fc_off || j >= d->n_ol) return 0;
+	const uint32_t fl = d->ol[j].fc_len;
+	if (fl > cap || !out || fl == 0) return fl;
+	const uint64_t o = d->fc_off[j]; const uint32_t *w = d->fc + (o & ~HAO_FC_RAW);
+	if (o & HAO_FC_RAW) { for (uint32_t k = 0; k < fl; ++k) out[k] = (uint64_t)w[2 * k + 1] << 32 | w[2 * k]; return fl; }
+	uint32_t site = d->ol[j].x_pos_s; int64_t sh = 0;
+	out[0] = (uint64_t)site << 32;
+	for (uint32_t k = 1; k < fl; ++k) {
+		const uint32_t x = w[k - 1], z = x >> 20;
+		site += x & 0xfffffu; sh += (int64_t)(z >> 1) ^ -(int64_t)(z & 1);
+		out[k] = (uint64_t)site << 32 | (sh < 0 ? ((uint32_t)(-sh) << 1 | 1u) : (uint32_t)sh << 1);
+	}
+	return fl;
+}
+
 // hao_batch_digest's value for every read of a DELIVERED batch, computed on the host from the bytes in the pinned arena: ol->list, the fake cigars and
 // cl->list decoded out of the wire format by hao_unpack_hits.  A pure function of the view; the reads are spread over n_threads host threads.
 int hao_delivery_digest(const hao_delivery_t *d, uint64_t *out, int n_threads)
@@ -193,16 +211,21 @@ int hao_delivery_digest(const hao_delivery_t *d, uint64_t *out, int n_threads)
 	if ((uint64_t)n_threads > n) n_threads = (int)std::max<uint64_t>(1, n);
 	std::atomic<uint64_t> next(0); std::atomic<int> bad(0);
 	auto work = [&]() {
-		std::vector<hao_hit_t> buf;
+		std::vector<hao_hit_t> buf; std::vector<uint64_t> fcb;
 		for (;;) {
 			const uint64_t b0 = next.fetch_add(64); if (b0 >= n) break;
 			for (uint64_t r = b0; r < std::min(n, b0 + 64); ++r) {
-				const uint64_t o0 = d->ol_off[r], o1 = d->ol_off[r + 1], f0 = o1 > o0 ? d->fc_off[o0] : 0, f1 = o1 > o0 ? d->fc_off[o1] : 0, nh = d->cl_off[r + 1] - d->cl_off[r];
+				const uint64_t o0 = d->ol_off[r], o1 = d->ol_off[r + 1], nh = d->cl_off[r + 1] - d->cl_off[r];
 				if (buf.size() < nh) buf.resize(nh + nh / 4 + 64);
 				if (hao_unpack_hits(d, d->rid_lo + r, buf.data(), nh) != nh) { bad = 1; out[r] = 0; continue; }
 				uint64_t s = 0; const uint64_t *w = (const uint64_t*)(d->ol + o0);
 				for (uint64_t i = 0; i < (o1 - o0) * 6; ++i) s += hao_dg_term(1, i, w[i]);
-				for (uint64_t i = 0; i < f1 - f0; ++i) s += hao_dg_term(2, i, d->fc[f0 + i]);
+				{	uint64_t fi = 0;      // the fake cigars of the read's overlaps, entry by entry, through the decoder
+					for (uint64_t j = o0; j < o1; ++j) {
+						const uint32_t fl = d->ol[j].fc_len; if (fcb.size() < fl) fcb.resize(fl);
+						if (hao_unpack_cigar(d, j, fcb.data(), fl) != fl) bad = 1;
+						for (uint32_t k = 0; k < fl; ++k) s += hao_dg_term(2, fi++, fcb[k]);
+					} }
 				w = (const uint64_t*)buf.data();
 				for (uint64_t i = 0; i < nh * 2; ++i) s += hao_dg_term(3, i, w[i]);
 				out[r] = s;

@@ -181,8 +181,8 @@ typedef struct {
 	uint64_t rid_lo, n_reads, n_ol, n_fc, n_chains, n_cl, n_exc, n_codes, n_pos, bytes;   /* n_pos = positions of the batch (its seed hits); bytes = what crossed PCIe for this batch */
 	const uint64_t *ol_off;          /* [n_reads + 1]: ol->list of read r = ol[ol_off[r] .. ol_off[r + 1]) */
 	const hao_ovlp_t *ol;
-	const uint64_t *fc_off;          /* [n_ol + 1]: fake cigar of overlap j = fc[fc_off[j] .. fc_off[j + 1]) */
-	const uint64_t *fc;
+	const uint64_t *fc_off;          /* [n_ol + 1]: the fake cigar of overlap j starts at 32-bit word fc_off[j] & ~HAO_FC_RAW of fc[]; read it with hao_unpack_cigar */
+	const uint32_t *fc;              /* [n_fc] words: 4 bytes per cigar entry after an overlap's first (site step | zigzag(shift step) << 20); raw overlaps (bit 63 of their offset): 2 words per entry */
 	const uint64_t *ch_off, *cl_off, *qm_off; /* [n_reads + 1]: chains / hits / minimizers of read r = chains[ch_off[r] ..), hits cl_off[r] .. of the batch, qmz[qm_off[r] ..) */
 	const hao_chain_hdr_t *chains;
 	const uint64_t *cl_bits;         /* bit p (word p / 64, bit p % 64) = position p has a code byte */
@@ -193,6 +193,10 @@ typedef struct {
 	const uint8_t *exact;            /* [n_ol] with HAO_DELIVER_EXACT, else NULL */
 	double copy_ms;                  /* from "batch computed" to "copy landed" (includes waiting behind the previous batch's copy); filled by hao_deliver_wait */
 } hao_delivery_t;
+#define HAO_FC_RAW (1ULL << 63)
+/* The fake cigar (Fake_Cigar, Hash_Table.h:54-59; gen_fake_cigar, Hash_Table.cpp:88-109) of overlap j of a delivered batch as its ol[j].fc_len 8-byte entries
+ * (site << 32 | shift code), rebuilt from the packed words: a pure function of the view.  Returns the entry count (nothing is written when it exceeds cap). */
+uint32_t hao_unpack_cigar(const hao_delivery_t *d, uint64_t j, uint64_t *out, uint32_t cap);
 int hao_overlap_batch_async(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi, const hao_pass_t *pass /* NULL: hao_pass_default */, uint32_t parts, int *slot);
 /* The delivery slot (0 / 1) the NEXT hao_overlap_batch_async of this context will write: the caller must have stopped reading that arena before it
  * starts the batch (the engine alternates the two slots; asking it keeps that policy out of the caller). */

@@ -280,7 +280,8 @@ void h_ec_lchain(ha_abuf_t *ab, uint32_t rid, char* rs, uint64_t rl, uint64_t mz
 		z->y_id = o.y_id; z->y_pos_s = o.y_pos_s; z->y_pos_e = o.y_pos_e; z->y_pos_strand = o.y_pos_strand;
 		z->shared_seed = o.shared_seed; z->align_length = 0; z->is_match = 0; z->non_homopolymer_errors = o.non_homopolymer_errors; z->strong = 0; z->overlapLen = 0;
 		resize_fake_cigar(&z->f_cigar, o.fc_len, NULL);
-		memcpy(z->f_cigar.buffer, d.fc + d.fc_off[i], sizeof(uint64_t) * o.fc_len); z->f_cigar.length = o.fc_len;
+		if (hao_unpack_cigar(&d, i, (uint64_t*)z->f_cigar.buffer, o.fc_len) != o.fc_len) die("hao_unpack_cigar");      // (the wire carries 4 bytes per cigar entry)
+		z->f_cigar.length = o.fc_len;
 	}
 	// cl->list: the wire bytes decode straight into the caller's list (k_mer_hit and hao_hit_t share their layout, Hash_Table.h:116-120)
 	const uint64_t n_cl = d.cl_off ? d.cl_off[r + 1] - d.cl_off[r] : 0;      // (no cl_off: a batch delivered without its chained hits - the final round)

@@ -131,3 +131,54 @@ def test_decoder_edges_of_the_position_space():
             assert got == want[0].shape[0] and (out == want[0]).all()
             hit += 1
     assert hit == 24
+
+
+def test_cigar_decoder_inverts_the_format():
+    """Fake cigars travel as 4 bytes per entry after an overlap's first - site step in bits 0 .. 19, zigzag(shift step) in bits 20 .. 31, from (x_pos_s, 0) - or,
+    when a step does not fit, raw (two words per entry, bit 63 of the overlap's offset): an encoder written from that description, hao_unpack_cigar back."""
+    rng = np.random.default_rng(9)
+
+    def entry(site, sh):
+        return (site << 32) | (((-sh) << 1 | 1) if sh < 0 else (sh << 1))
+
+    cig, ol, words, off = [], [], [], []
+    for j in range(400):
+        xs = int(rng.integers(0, 5000)); site, sh = xs, 0; es = [entry(xs, 0)]
+        big = j % 7 == 3                                                         # a step beyond 2^20 bases or 2047 diagonals somewhere: the overlap travels raw
+        for k in range(int(rng.integers(0, 40))):
+            site += int(rng.integers(0, 3000)) + ((1 << 20) + 5 if big and k == 2 else 0)
+            sh += int(rng.integers(-40, 41)) + (3000 if big and k == 4 else 0)
+            es.append(entry(site, sh))
+        if j % 11 == 5:
+            es[0] = entry(xs + 1, 0)                                             # a first entry that is not (x_pos_s, 0): raw as well
+        row = np.zeros(12, dtype=np.uint32); row[1] = xs; row[11] = len(es)
+        ol.append(row); cig.append(es)
+        packable = es[0] == entry(xs, 0)
+        ws = []
+        ps, psh = xs, 0
+        for e in es[1:]:
+            s_, lo = e >> 32, e & 0xffffffff
+            sh_ = -(lo >> 1) if lo & 1 else lo >> 1
+            ds, dsh = s_ - ps, sh_ - psh
+            if not (0 <= ds < (1 << 20) and -2048 <= dsh <= 2047):
+                packable = False
+            ws.append((ds & 0xfffff) | ((((dsh << 1) ^ (dsh >> 63)) & 0xfff) << 20))
+            ps, psh = s_, sh_
+        if packable:
+            off.append(len(words)); words.extend(ws)
+        else:
+            off.append(len(words) | (1 << 63))
+            for e in es:
+                words.extend([e & 0xffffffff, e >> 32])
+    assert sum(1 for o in off if o >> 63) > 50 and sum(1 for o in off if not o >> 63) > 200
+    a_ol = np.array(ol, dtype=np.uint32); a_off = np.array(off + [len(words)], dtype=np.uint64); a_w = np.array(words, dtype=np.uint32)
+    d = api.Delivery()
+    d.n_ol, d.n_fc = len(ol), int(a_w.size)
+    d.ol, d.fc_off, d.fc = a_ol.ctypes.data, a_off.ctypes.data, a_w.ctypes.data
+    L = api.lib()
+    for j, es in enumerate(cig):
+        out = np.zeros(len(es) + 2, dtype=np.uint64)
+        assert L.hao_unpack_cigar(C.byref(d), j, out.ctypes.data_as(C.c_void_p), len(es)) == len(es)
+        assert [int(x) for x in out[:len(es)]] == es and out[len(es)] == 0
+        assert L.hao_unpack_cigar(C.byref(d), j, out.ctypes.data_as(C.c_void_p), len(es) - 1) == len(es)      # too small a buffer: the count, nothing written
+    assert L.hao_unpack_cigar(C.byref(d), len(cig), None, 0) == 0
