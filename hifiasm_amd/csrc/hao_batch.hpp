@@ -24,9 +24,9 @@ struct hao_ctx::Batch {
 	struct OutSet {
 		DevBuf<hao_ovlp_t> ol_out; DevBuf<uint64_t> fin_off, fc_out, fc_out_off, ch_off, cl_off, qm_off, fcw_off, fcw_woff; DevBuf<uint32_t> fcw, fcw_len;      // (fcw*: the fake cigars as they travel, hao_deliver.cuh)
 		//      // ol->list in final order, per-read offsets, fake cigars
-		DevBuf<hao_chain_hdr_t> hdr; DevBuf<uint64_t> bits; DevBuf<uint32_t> rank; DevBuf<uint8_t> codes; DevBuf<hao_exc_t> exc, exc2; DevBuf<hao_qmz_t> qmz;   // cl->list in the wire format (hao_deliver.cuh)
+		DevBuf<hao_chain_hdr_t> hdr; DevBuf<uint64_t> bits; DevBuf<uint32_t> rank, rank4; DevBuf<uint8_t> codes; DevBuf<hao_exc_t> exc, exc2; DevBuf<hao_qmz_t> qmz;   // cl->list in the wire format (hao_deliver.cuh)
 		DevBuf<uint8_t> exact;                                                                        // exact-overlap flags of ol_out
-		void release() { fcw_off.release(); fcw_woff.release(); fcw.release(); fcw_len.release(); ol_out.release(); fin_off.release(); fc_out.release(); fc_out_off.release(); ch_off.release(); cl_off.release(); qm_off.release(); hdr.release(); bits.release(); rank.release(); codes.release(); exc.release(); exc2.release(); qmz.release(); exact.release(); }
+		void release() { fcw_off.release(); fcw_woff.release(); fcw.release(); fcw_len.release(); ol_out.release(); fin_off.release(); fc_out.release(); fc_out_off.release(); ch_off.release(); cl_off.release(); qm_off.release(); hdr.release(); bits.release(); rank.release(); rank4.release(); codes.release(); exc.release(); exc2.release(); qmz.release(); exact.release(); }
 	} out[2];
 	int cur = 0;
 	OutSet &O() { return out[cur]; }
@@ -124,7 +124,8 @@ static int hao_deliver_enqueue(hao_ctx *c)
 	size_t o_choff = o_fc + (ol ? al(B.n_fcw * 4) : 0), o_cloff = o_choff + (cl ? al((n + 1) * 8) : 0), o_qmoff = o_cloff + (cl ? al((n + 1) * 8) : 0), o_hdr = o_qmoff + (cl ? al((n + 1) * 8) : 0);
 	size_t o_qmz = o_hdr + (cl ? al(B.n_chains * sizeof(hao_chain_hdr_t)) : 0), o_bits = o_qmz + (cl ? al(B.n_mz * sizeof(hao_qmz_t)) : 0);
 	const uint64_t nw_ = cl ? (B.n_anchor + 63) / 64 : 0;      // 64-position words of the batch's bit stream (positions = seed hits)
-	size_t o_rank = o_bits + (cl ? al(nw_ * 8) : 0), o_codes = o_rank + (cl ? al((nw_ + 1) * 4) : 0), o_exc = o_codes + (cl ? al(B.n_codes) : 0);
+	const uint64_t nr4_ = cl ? nw_ / 4 + 1 : 0;      // rank directory entries on the wire: one per 256 positions
+	size_t o_rank = o_bits + (cl ? al(nw_ * 8) : 0), o_codes = o_rank + (cl ? al(nr4_ * 4) : 0), o_exc = o_codes + (cl ? al(B.n_codes) : 0);
 	size_t o_ex = o_exc + (cl ? al(B.n_exc * sizeof(hao_exc_t)) : 0), total = o_ex + (ex ? al(B.n_ol) : 0);
 	if (total > B.arena_cap[s]) {
 		if (B.arena[s]) (void)hipHostFree(B.arena[s]);
@@ -163,7 +164,7 @@ static int hao_deliver_enqueue(hao_ctx *c)
 	if (cl && n) {
 		HIP_TRY(cp(o_choff, O.ch_off.p, (n + 1) * 8)); HIP_TRY(cp(o_cloff, O.cl_off.p, (n + 1) * 8)); HIP_TRY(cp(o_qmoff, O.qm_off.p, (n + 1) * 8));
 		HIP_TRY(cp(o_hdr, O.hdr.p, B.n_chains * sizeof(hao_chain_hdr_t))); HIP_TRY(cp(o_qmz, O.qmz.p, B.n_mz * sizeof(hao_qmz_t))); HIP_TRY(cp(o_exc, O.exc.p, B.n_exc * sizeof(hao_exc_t)));
-		HIP_TRY(cp(o_bits, O.bits.p, nw_ * 8)); HIP_TRY(cp(o_rank, O.rank.p, (nw_ + 1) * 4));
+		HIP_TRY(cp(o_bits, O.bits.p, nw_ * 8)); HIP_TRY(cp(o_rank, O.rank4.p, nr4_ * 4));
 		{	// the code bytes: 1 + n_aux pieces on as many streams (separate DMA queues)
 			const int np = ck ? 1 : B.n_aux + 1; const uint64_t per = ((B.n_codes + np - 1) / np + 63) & ~63ULL;
 			for (int k = 0; k < np; ++k) {
@@ -179,7 +180,7 @@ static int hao_deliver_enqueue(hao_ctx *c)
 		}
 		d.n_chains = B.n_chains; d.n_cl = B.n_cl; d.n_exc = B.n_exc; d.n_codes = B.n_codes; d.n_pos = B.n_anchor; d.ch_off = (const uint64_t*)(a + o_choff); d.cl_off = (const uint64_t*)(a + o_cloff); d.qm_off = (const uint64_t*)(a + o_qmoff);
 		d.chains = (const hao_chain_hdr_t*)(a + o_hdr); d.qmz = (const hao_qmz_t*)(a + o_qmz); d.cl_bits = (const uint64_t*)(a + o_bits); d.cl_rank = (const uint32_t*)(a + o_rank); d.cl_codes = a + o_codes; d.cl_exc = (const hao_exc_t*)(a + o_exc);
-		d.bytes += 3 * (n + 1) * 8 + B.n_chains * sizeof(hao_chain_hdr_t) + B.n_mz * sizeof(hao_qmz_t) + nw_ * 8 + (nw_ + 1) * 4 + B.n_codes + B.n_exc * sizeof(hao_exc_t);
+		d.bytes += 3 * (n + 1) * 8 + B.n_chains * sizeof(hao_chain_hdr_t) + B.n_mz * sizeof(hao_qmz_t) + nw_ * 8 + nr4_ * 4 + B.n_codes + B.n_exc * sizeof(hao_exc_t);
 	}
 	if (ex && n) { HIP_TRY(cp(o_ex, O.exact.p, B.n_ol)); d.exact = a + o_ex; d.n_ol = B.n_ol; d.bytes += B.n_ol; }
 	HIP_TRY(hipEventRecord(B.ev_done[s], B.copy_stream));
@@ -426,6 +427,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		HIP_TRY(rocprim::exclusive_scan(nullptr, tb, B.pk_cnt.p, O.rank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), c->stream)); HIP_TRY(hao_tmp(c, tb));
 		HIP_TRY(rocprim::exclusive_scan(c->d_tmp.p, tb, B.pk_cnt.p, O.rank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), c->stream));
 		hipLaunchKernelGGL(hao_pack_codes_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, c->stream, B.hcode.p, A, O.bits.p, O.rank.p, NW, O.codes.p, d_n_codes); HAO_CHECK_LAUNCH();
+		{ const uint64_t n4 = NW / 4 + 1; hipLaunchKernelGGL(hao_rank4_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, c->stream, O.rank.p, n4, O.rank4.p); HAO_CHECK_LAUNCH(); }
 		if (scan_exc) {
 			HIP_TRY(rocprim::exclusive_scan(c->d_tmp.p, tb, B.pk_ecnt.p, B.pk_erank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), c->stream));
 			hipLaunchKernelGGL(hao_pack_exc_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, c->stream, pa, A, NW, B.pk_erank.p); HAO_CHECK_LAUNCH();
@@ -435,7 +437,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	if (parts & HAO_DELIVER_CL) {
 		hao_ctx::Batch::OutSet &O = B.O();
 		HIP_TRY(O.hdr.reserve(NCmax + 1)); HIP_TRY(O.exc.reserve(c->sw.exc_cap >= 0 ? (uint64_t)c->sw.exc_cap + 1 : std::max<uint64_t>(1 << 14, A / 256)));
-		HIP_TRY(O.bits.reserve(NW + 2)); HIP_TRY(O.rank.reserve(NW + 2)); HIP_TRY(B.pk_cnt.reserve(NW + 2)); HIP_TRY(O.codes.reserve(A + 16));
+		HIP_TRY(O.bits.reserve(NW + 2)); HIP_TRY(O.rank.reserve(NW + 6)); HIP_TRY(O.rank4.reserve(NW / 4 + 2)); HIP_TRY(B.pk_cnt.reserve(NW + 2)); HIP_TRY(O.codes.reserve(A + 16));
 		HIP_TRY(hipMemsetAsync(B.pk_cnt.p + NW, 0, 4, c->stream));      // (the scan runs over NW + 1 counts: its last output is the total)
 		HIP_TRY(B.pk_ecnt.reserve(NW + 2)); HIP_TRY(B.pk_erank.reserve(NW + 2)); HIP_TRY(hipMemsetAsync(B.pk_ecnt.p + NW, 0, 4, c->stream));
 		HIP_TRY(O.ch_off.reserve(n + 2)); HIP_TRY(O.cl_off.reserve(n + 2)); HIP_TRY(O.qm_off.reserve(n + 2)); HIP_TRY(O.qmz.reserve(nm + 1));

@@ -161,7 +161,13 @@ uint64_t hao_unpack_hits(const hao_delivery_t *d, uint64_t rid, hao_hit_t *out, 
 		const hao_chain_hdr_t &H = d->chains[ci];
 		uint32_t q = H.q0, off = H.offset;
 		const uint64_t g = H.pos;      // position of the chain's first hit; the code bytes of its later hits start at rank(g + 1) (the byte at g itself, if any, is not the chain's)
-		uint64_t cp = H.n_hits > 1 ? d->cl_rank[(g + 1) >> 6] + (uint64_t)__builtin_popcountll(d->cl_bits[(g + 1) >> 6] & ((1ULL << ((g + 1) & 63)) - 1)) : 0;
+		uint64_t cp = 0;
+		if (H.n_hits > 1) {      // the directory has an entry per 256 positions: + the bits of the words between it and the position
+			const uint64_t wp = (g + 1) >> 6;
+			cp = d->cl_rank[wp >> 2];
+			for (uint64_t w = wp & ~3ULL; w < wp; ++w) cp += (uint64_t)__builtin_popcountll(d->cl_bits[w]);
+			cp += (uint64_t)__builtin_popcountll(d->cl_bits[wp] & ((1ULL << ((g + 1) & 63)) - 1));
+		}
 		for (uint32_t i = 0; i < H.n_hits; ++i) {
 			hao_hit_t &o = out[k + i];
 			if (i) {

@@ -242,6 +242,13 @@ __global__ __launch_bounds__(256) void hao_pack_codes_kernel(const uint8_t *byte
 	for (; m8; m8 &= m8 - 1) { const uint8_t b = (uint8_t)(v >> (8 * (__ffs((int)m8) - 1))); codes[at++] = b >= HAO_CODE_EXC_OHITS ? (uint8_t)0xff : b; }      // (0xfd / 0xfe: device-only flavours of "verbatim")
 }
 
+// the rank directory as it travels: one entry per 256 positions (every fourth word's; the decoder counts the bits of up to three words itself)
+__global__ void hao_rank4_kernel(const uint32_t *rank, uint64_t n4, uint32_t *out)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n4) out[i] = rank[4 * i];
+}
+
 // ---- fake cigars on the wire ----
 // A fake cigar (gen_fake_cigar, Hash_Table.cpp:88-109) is a list of 8-byte (query site << 32 | diagonal shift) entries: (x_pos_s, 0), one entry wherever the
 // chain's diagonal changes, and (x_pos_e, last shift) unless the last change sits there - ~11 entries per overlap of a HiFi pass, 2.66 GB of the 8.26 GB a

@@ -186,7 +186,7 @@ typedef struct {
 	const uint64_t *ch_off, *cl_off, *qm_off; /* [n_reads + 1]: chains / hits / minimizers of read r = chains[ch_off[r] ..), hits cl_off[r] .. of the batch, qmz[qm_off[r] ..) */
 	const hao_chain_hdr_t *chains;
 	const uint64_t *cl_bits;         /* bit p (word p / 64, bit p % 64) = position p has a code byte */
-	const uint32_t *cl_rank;         /* [n_pos / 64 + 1]: code bytes before position 64 w */
+	const uint32_t *cl_rank;         /* [n_pos / 256 + 1]: code bytes before position 256 i */
 	const uint8_t *cl_codes;         /* [n_codes] code bytes, in position order */
 	const hao_qmz_t *qmz;            /* minimizer tables of the batch's reads */
 	const hao_exc_t *cl_exc;         /* [n_exc] sorted by position */

@@ -1,5 +1,5 @@
 """The decoder of the delivery wire format (hao_unpack_hits, include/hao.h) is a pure host function of a delivered view: here the view is built by a
-Python encoder written from the format's description (one bit per position = seed hit, rank directory, code bytes, sorted exception list, chain headers
+Python encoder written from the format's description (one bit per position = seed hit, rank directory of one entry per 256 positions, code bytes, sorted exception list, chain headers
 with the position of their first hit) and must decode back to
 the k_mer_hits it was made from.  No GPU involved: the device-side encoder is checked against the oracle by tests/test_gpu_stream.py."""
 import ctypes as C
@@ -61,8 +61,9 @@ def _encode(reads, rid_lo=7, seed=3, fill=True):
     bits = np.zeros(max(1, nw), dtype=np.uint64)
     for w in range(nw):
         bits[w] = sum(int(fl[64 * w + b]) << b for b in range(64))
-    rank = np.zeros(nw + 1, dtype=np.uint32)
-    rank[1:] = np.cumsum(fl.reshape(-1, 64).sum(axis=1)) if nw else 0
+    rank64 = np.zeros(nw + 1, dtype=np.uint32)
+    rank64[1:] = np.cumsum(fl.reshape(-1, 64).sum(axis=1)) if nw else 0
+    rank = rank64[::4].copy()                                    # the directory that travels: code bytes before every 256th position
     a_hdr = np.zeros(max(1, len(hdr)), dtype=[("n_hits", "<u4"), ("w0", "<u4"), ("q0", "<u4"), ("offset", "<u4"), ("pos", "<u8")])
     for i, t in enumerate(hdr):
         a_hdr[i] = t
