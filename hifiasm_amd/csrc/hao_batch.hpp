@@ -22,11 +22,11 @@ struct hao_ctx::Batch {
 	// Results of a batch that leave the device.  Two sets (+ two pinned host arenas): while the copy stream drains the set of batch i, batch i + 1
 	// computes into the other one (hao_overlap_batch_async).  The blocking API keeps using the current set.
 	struct OutSet {
-		DevBuf<hao_ovlp_t> ol_out; DevBuf<uint64_t> fin_off, fc_out, fc_out_off, ch_off, cl_off, qm_off, fcw_off, fcw_woff; DevBuf<uint32_t> fcw, fcw_len;      // (fcw*: the fake cigars as they travel, hao_deliver.cuh)
+		DevBuf<hao_ovlp_t> ol_out; DevBuf<uint64_t> fin_off, fc_out, fc_out_off, ch_off, cl_off, qm_off, fcw_off; DevBuf<uint32_t> fcw;      // (fcw*: the fake cigars as they travel, hao_deliver.cuh)
 		//      // ol->list in final order, per-read offsets, fake cigars
 		DevBuf<hao_chain_hdr_t> hdr; DevBuf<uint64_t> bits; DevBuf<uint32_t> rank, rank4; DevBuf<uint8_t> codes; DevBuf<hao_exc_t> exc, exc2; DevBuf<hao_qmz_t> qmz;   // cl->list in the wire format (hao_deliver.cuh)
 		DevBuf<uint8_t> exact;                                                                        // exact-overlap flags of ol_out
-		void release() { fcw_off.release(); fcw_woff.release(); fcw.release(); fcw_len.release(); ol_out.release(); fin_off.release(); fc_out.release(); fc_out_off.release(); ch_off.release(); cl_off.release(); qm_off.release(); hdr.release(); bits.release(); rank.release(); rank4.release(); codes.release(); exc.release(); exc2.release(); qmz.release(); exact.release(); }
+		void release() { fcw_off.release(); fcw.release(); ol_out.release(); fin_off.release(); fc_out.release(); fc_out_off.release(); ch_off.release(); cl_off.release(); qm_off.release(); hdr.release(); bits.release(); rank.release(); rank4.release(); codes.release(); exc.release(); exc2.release(); qmz.release(); exact.release(); }
 	} out[2];
 	int cur = 0;
 	OutSet &O() { return out[cur]; }
@@ -497,19 +497,12 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	if (sa.dbg) { unsigned long long d_[5]; HIP_TRY(hipMemcpy(d_, B.dbgbuf.p, 40, hipMemcpyDeviceToHost)); if (d_[4]) fprintf(stderr, "[select] reads %llu  avg us: score sort %.1f  prune %.1f  position sort %.1f  weak filter %.1f\n", d_[4], d_[0] / 100.0 / d_[4], d_[1] / 100.0 / d_[4], d_[2] / 100.0 / d_[4], d_[3] / 100.0 / d_[4]); }
 	c->timer.mark("q_select");
 	HIP_TRY(B.O().ol_out.reserve(NCmax + 1)); HIP_TRY(B.O().fc_out.reserve(FCmax + 1)); HIP_TRY(B.O().fc_out_off.reserve(NCmax + 2));
+	unsigned long long *d_n_fcw = B.stats.p + 3 * HAO_NCLS;      // (slot [3 NCLS] of the stats block is free) words of the fake cigars that travel raw
+	const bool fcw_ = (parts & HAO_DELIVER_OL) != 0;
+	if (fcw_) { HIP_TRY(B.O().fcw_off.reserve(NCmax + 2)); HIP_TRY(B.O().fcw.reserve(3 * (FCmax + 1))); }      // main region: entries - overlaps words; raw overlaps behind it: two words per entry
 	hipLaunchKernelGGL(chain_final_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, B.ol.p, B.ol_fc_off.p, B.fc_raw.p, B.perm.p, B.g_off.p, B.ch_base.p,
-					   B.O().fin_off.p, B.fcf_off.p, n, B.O().ol_out.p, B.O().fc_out.p, B.O().fc_out_off.p);
+					   B.O().fin_off.p, B.fcf_off.p, n, B.O().ol_out.p, B.O().fc_out.p, B.O().fc_out_off.p, fcw_ ? B.O().fcw.p : (uint32_t*)nullptr, fcw_ ? B.O().fcw_off.p : (uint64_t*)nullptr, d_n_fcw, (uint32_t)c->sw.fc_raw_every);
 	HAO_CHECK_LAUNCH();
-	unsigned long long *d_n_fcw = B.stats.p + 3 * HAO_NCLS;      // (slot [3 NCLS] of the stats block is free)
-	if (parts & HAO_DELIVER_OL) {      // the fake cigars as they travel: 4 bytes per entry after the first (hao_deliver.cuh); the final counts are still on the device
-		hao_ctx::Batch::OutSet &O = B.O();
-		HIP_TRY(O.fcw_len.reserve(NCmax + 2)); HIP_TRY(O.fcw_woff.reserve(NCmax + 2)); HIP_TRY(O.fcw_off.reserve(NCmax + 2)); HIP_TRY(O.fcw.reserve(2 * (FCmax + 1)));
-		const dim3 g_((unsigned)((NCmax + 256) / 256));
-		hipLaunchKernelGGL(hao_fcpack_len_kernel, g_, dim3(256), 0, c->stream, O.ol_out.p, O.fc_out_off.p, O.fc_out.p, O.fin_off.p + n, NCmax, O.fcw_len.p); HAO_CHECK_LAUNCH();
-		auto it = rocprim::make_transform_iterator(O.fcw_len.p, FcLenMask());
-		if (int rc = hao_excl_scan_u64(c, it, O.fcw_woff.p, NCmax + 1)) return rc;
-		hipLaunchKernelGGL(hao_fcpack_write_kernel, g_, dim3(256), 0, c->stream, O.ol_out.p, O.fc_out_off.p, O.fc_out.p, O.fin_off.p + n, NCmax, O.fcw_len.p, O.fcw_woff.p, O.fcw.p, O.fcw_off.p, d_n_fcw); HAO_CHECK_LAUNCH();
-	}
 	c->timer.mark("q_final");
 	unsigned long long slow_st[HAO_NCLS + 4], n_exc = 0;
 	{	// the totals of the batch: one wave gathers them into mapped host memory
@@ -524,7 +517,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		B.n_chains = c->peek_h[0]; B.n_cl = c->peek_h[1]; B.n_fc_raw = c->peek_h[2]; B.n_ol = c->peek_h[3]; B.n_fc = c->peek_h[4];
 		for (int x = 0; x < HAO_NCLS + 4; ++x) slow_st[x] = c->peek_h[8 + x];
 		if (parts & HAO_DELIVER_CL) { n_exc = c->peek_h[5]; B.n_codes = G ? c->peek_h[6] : 0; }
-		B.n_fcw = (parts & HAO_DELIVER_OL) ? c->peek_h[7] : 0;
+		B.n_fcw = (parts & HAO_DELIVER_OL) ? (B.n_fc - B.n_ol) + c->peek_h[7] : 0;      // main region + the raw overlaps' words
 	}
 	if ((parts & HAO_DELIVER_CL) && n_exc > pa.exc_cap) {      // more verbatim hits than the list holds: grow it and pack again (the sources are untouched)
 		HIP_TRY(B.O().exc.reserve(n_exc + 1024)); pa.exc = B.O().exc.p; pa.exc_cap = B.O().exc.cap;

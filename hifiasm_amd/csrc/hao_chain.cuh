@@ -1689,29 +1689,68 @@ __global__ __launch_bounds__(256) void chain_select4_kernel(hao_sel_args A, int6
 }
 
 // final gather: records in final order (align_length zeroed, anchor.cpp:2098) + fake cigars in that order. One wave per read.
+// With fcw != nullptr (delivery) the cigars are also written as they travel (hao_deliver.cuh: 4 bytes per entry after an overlap's first): overlap J of the batch,
+// whose entries start at fc_out[fo], owns words [fo - J, fo - J + fc_len - 1) of the main region - every overlap before it saved exactly one entry - so no
+// offsets have to be computed; an overlap with a step that does not fit the packed word (rare) appends its entries raw, two words each, behind the main region
+// (n_main = all entries - all overlaps: both totals are on the device before this kernel runs) and says so in bit 63 of its offset.
+__device__ __forceinline__ bool hao_fc_step(uint64_t prev, uint64_t cur, uint32_t *word)
+{
+	const uint32_t ps = (uint32_t)(prev >> 32), cs = (uint32_t)(cur >> 32), pl = (uint32_t)prev, cl = (uint32_t)cur;
+	const int64_t psh = (pl & 1) ? -(int64_t)(pl >> 1) : (int64_t)(pl >> 1), csh = (cl & 1) ? -(int64_t)(cl >> 1) : (int64_t)(cl >> 1), dsh = csh - psh;
+	if (cs < ps || cs - ps >= (1u << 20) || dsh < -2048 || dsh > 2047) return false;
+	*word = (cs - ps) | (uint32_t)((dsh << 1) ^ (dsh >> 63)) << 20;
+	return true;
+}
 __global__ __launch_bounds__(256) void chain_final_kernel(const hao_ovlp_t *ol, const uint64_t *ol_fc_off, const uint64_t *fc_raw, const uint32_t *perm,
 		const uint64_t *g_off, const uint64_t *ch_base, const uint64_t *fin_off, const uint64_t *fcf_off, uint64_t n_sel,
-		hao_ovlp_t *ol_out, uint64_t *fc_out, uint64_t *fc_out_off)
+		hao_ovlp_t *ol_out, uint64_t *fc_out, uint64_t *fc_out_off, uint32_t *fcw, uint64_t *fcw_off, unsigned long long *fcw_raw_words, uint32_t raw_every /* tests: every n-th overlap travels raw */)
 {
 	const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (r >= n_sel) return;
 	const int lane = hao_lane();
 	const uint64_t o0 = ch_base[g_off[r]], d0 = fin_off[r], n = fin_off[r + 1] - d0; uint64_t run = fcf_off[r];
+	const uint64_t n_main = fcw ? fcf_off[n_sel] - fin_off[n_sel] : 0;
 	for (uint64_t base = 0; base < n; base += 64) {      // one kept chain per lane; fake-cigar destinations from a wave scan of the lengths
 		const uint64_t i = base + lane; const bool act = i < n;
 		hao_ovlp_t o; uint64_t fs = 0; uint32_t fl = 0;
 		if (act) { const uint64_t src = o0 + perm[o0 + i]; o = ol[src]; fs = ol_fc_off[src]; fl = o.fc_len; }
 		const uint32_t inc = hao_wave_incl_scan_u32(fl);
-		const uint64_t fo = run + inc - fl;
+		const uint64_t fo = run + inc - fl, wo = fo - (d0 + i);      // first entry in fc_out / first word on the wire
+		bool ok = !(raw_every && (d0 + i) % raw_every == raw_every - 1);      // the cigar fits the packed words so far
 		if (act) {
 			o.align_length = 0; ol_out[d0 + i] = o; fc_out_off[d0 + i] = fo;
-			if (fl <= 16) for (uint32_t j = 0; j < fl; ++j) fc_out[fo + j] = fc_raw[fs + j];
+			if (fl <= 16) {
+				uint64_t prev = 0;
+				for (uint32_t j = 0; j < fl; ++j) {
+					const uint64_t e = fc_raw[fs + j]; fc_out[fo + j] = e;
+					if (fcw) { uint32_t w = 0; if (j == 0) ok = ok && e == (uint64_t)o.x_pos_s << 32; else if (ok && hao_fc_step(prev, e, &w)) fcw[wo + j - 1] = w; else ok = false; }
+					prev = e;
+				}
+			}
 		}
 		// long cigars (noisy reads: hundreds of entries per chain): the wave copies them together, one chain after the other
 		for (unsigned long long big = __ballot(act && fl > 16); big; big &= big - 1) {
 			const int l = __ffsll((long long)big) - 1;
-			const uint64_t cfs = hao_readlane_i64((int64_t)fs, l), cfo = hao_readlane_i64((int64_t)fo, l); const uint32_t cfl = hao_bcast(fl, l);
-			for (uint32_t j = lane; j < cfl; j += 64) fc_out[cfo + j] = fc_raw[cfs + j];
+			const uint64_t cfs = hao_readlane_i64((int64_t)fs, l), cfo = hao_readlane_i64((int64_t)fo, l), cwo = hao_readlane_i64((int64_t)wo, l); const uint32_t cfl = hao_bcast(fl, l), cxs = hao_bcast(o.x_pos_s, l);
+			bool okw = true;
+			for (uint32_t j = lane; j < cfl; j += 64) {
+				const uint64_t e = fc_raw[cfs + j]; fc_out[cfo + j] = e;
+				if (fcw) { uint32_t w = 0; if (j == 0) okw = e == (uint64_t)cxs << 32; else if (hao_fc_step(fc_raw[cfs + j - 1], e, &w)) fcw[cwo + j - 1] = w; else okw = false; }
+			}
+			if (__ballot(!okw) && lane == l) ok = false;
+		}
+		if (fcw) {
+			// overlaps that do not fit: raw, behind the main region (one atomic per wave reserves their words)
+			const uint32_t need = (act && !ok) ? 2 * fl : 0, rinc = hao_wave_incl_scan_u32(need), rtot = hao_bcast(rinc, 63);
+			unsigned long long rb = 0;
+			if (rtot) { if (lane == 63) rb = atomicAdd(fcw_raw_words, (unsigned long long)rtot); rb = (unsigned long long)hao_readlane_i64((int64_t)rb, 63); }
+			if (act) {
+				if (ok) fcw_off[d0 + i] = wo;
+				else {
+					const uint64_t at = n_main + rb + rinc - need; fcw_off[d0 + i] = at | HAO_FC_RAW;
+					for (uint32_t j = 0; j < fl; ++j) { const uint64_t e = fc_raw[fs + j]; fcw[at + 2 * j] = (uint32_t)e; fcw[at + 2 * j + 1] = (uint32_t)(e >> 32); }
+				}
+			}
 		}
 		run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
 	}

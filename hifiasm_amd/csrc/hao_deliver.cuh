@@ -256,39 +256,8 @@ __global__ void hao_rank4_kernel(const uint32_t *rank, uint64_t n4, uint32_t *ou
 // none for the first one: bits 0 .. 19 = site - previous site, bits 20 .. 31 = zigzag(shift - previous shift), starting from the overlap's (x_pos_s, 0).  An
 // overlap with a step that does not fit (or whose first entry is not (x_pos_s, 0)) travels raw, two words per entry; bit 63 of its offset says so.
 // hao_unpack_cigar (include/hao.h) rebuilds the 8-byte entries.  Offsets count 32-bit words.
-#define HAO_FC_RAW (1ULL << 63)
-__device__ __forceinline__ bool hao_fc_step(uint64_t prev, uint64_t cur, uint32_t *word)
-{
-	const uint32_t ps = (uint32_t)(prev >> 32), cs = (uint32_t)(cur >> 32), pl = (uint32_t)prev, cl = (uint32_t)cur;
-	const int64_t psh = (pl & 1) ? -(int64_t)(pl >> 1) : (int64_t)(pl >> 1), csh = (cl & 1) ? -(int64_t)(cl >> 1) : (int64_t)(cl >> 1), dsh = csh - psh;
-	if (cs < ps || cs - ps >= (1u << 20) || dsh < -2048 || dsh > 2047) return false;
-	*word = (cs - ps) | (uint32_t)((dsh << 1) ^ (dsh >> 63)) << 20;
-	return true;
-}
-// words overlap j takes on the wire (top bit: raw); j >= the number of final overlaps (read on the device): 0.  One thread per overlap.
-__global__ void hao_fcpack_len_kernel(const hao_ovlp_t *ol, const uint64_t *fc_off, const uint64_t *fc, const uint64_t *n_ol_dev, uint64_t n_max, uint32_t *len)
-{
-	const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (j > n_max) return;
-	if (j >= *n_ol_dev) { len[j] = 0; return; }
-	const uint32_t fl = ol[j].fc_len; const uint64_t *e = fc + fc_off[j];
-	bool ok = fl >= 1 && e[0] == (uint64_t)ol[j].x_pos_s << 32; uint32_t w;
-	for (uint32_t k = 1; k < fl && ok; ++k) ok = hao_fc_step(e[k - 1], e[k], &w);
-	len[j] = ok ? fl - 1 : (2 * fl) | 0x80000000u;
-}
-__global__ void hao_fcpack_write_kernel(const hao_ovlp_t *ol, const uint64_t *fc_off, const uint64_t *fc, const uint64_t *n_ol_dev, uint64_t n_max, const uint32_t *len, const uint64_t *woff,
-		uint32_t *words, uint64_t *off_out, unsigned long long *n_words)
-{
-	const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, n_ol = *n_ol_dev;
-	if (j == 0) *n_words = woff[n_ol];
-	if (j >= n_ol || j > n_max) return;
-	const uint32_t fl = ol[j].fc_len; const uint64_t *e = fc + fc_off[j]; uint32_t *o = words + woff[j];
-	const bool raw = len[j] >> 31;
-	off_out[j] = woff[j] | (raw ? HAO_FC_RAW : 0);
-	if (raw) { for (uint32_t k = 0; k < fl; ++k) { o[2 * k] = (uint32_t)e[k]; o[2 * k + 1] = (uint32_t)(e[k] >> 32); } }
-	else for (uint32_t k = 1; k < fl; ++k) { uint32_t w = 0; (void)hao_fc_step(e[k - 1], e[k], &w); o[k - 1] = w; }
-}
-struct FcLenMask { __host__ __device__ uint64_t operator()(uint32_t v) const { return v & 0x7fffffffu; } };
+// (Written by chain_final_kernel, hao_chain.cuh, while it gathers the cigars into their final order: the packed position of an overlap's words follows from
+// its entry offset and its index, so the wire form costs no pass of its own.)
 
 // fill by a kernel: a big hipMemsetAsync travels through the DMA queues, where the previous batch's result copy is in flight (measured: the copy of a
 // configs[2] batch then took 28 instead of 18 ms and was no longer hidden under the next batch's kernels)

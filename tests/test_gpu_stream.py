@@ -71,6 +71,28 @@ def test_exception_list_overflow_repacks():
         del os.environ["HAO_DBG_EXC_EVERY"]
 
 
+@pytest.mark.parametrize("name", ["ont", "rr"])
+def test_cigars_that_travel_raw(name, monkeypatch):
+    """a fake cigar with a step the packed word cannot hold travels raw behind the packed ones (bit 63 of its offset): HAO_DBG_FC_RAW_EVERY sends every third
+    overlap that way - long ONT cigars (wave-cooperative copy) and short ones alike -, the decoder must give back the same entries"""
+    from hifiasm_amd.api import Engine
+    import ctypes as C
+    import numpy as np
+    monkeypatch.setenv("HAO_DBG_FC_RAW_EVERY", "3")
+    rs, okw = scenario_reads(name)
+    o = scenario_oracle(name)
+    e = Engine(0, **okw)
+    e.set_readset(rs)
+    e.ha_ft_gen(); e.ha_pt_gen()
+    d = e.deliver_wait(e.overlap_batch_async(0, rs.n))
+    off = np.ctypeslib.as_array(C.cast(d.fc_off, C.POINTER(C.c_uint64)), shape=(int(d.n_ol) + 1,))
+    raw = int((off[:-1] >> np.uint64(63)).sum())
+    assert abs(raw - int(d.n_ol) // 3) <= 1 and raw > 50
+    for r in range(rs.n):
+        assert _same(e.delivered_read(d, r), o.lchain(r)), r
+    e.close()
+
+
 def test_ol_only_delivery():
     """the final round needs ol->list only (h_ec_lchain_fast_new reads no chained hits, ecovlp.cpp:5047): cl->list is neither packed nor copied"""
     from hifiasm_amd.api import Engine, DELIVER_OL
