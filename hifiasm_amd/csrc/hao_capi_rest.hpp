@@ -12,7 +12,7 @@ static void hao_release_all(hao_ctx *c)
 	c->d_chunk_base.release(); c->d_chunk_dst.release(); c->d_chunk_cnt.release(); c->d_g_x.release(); c->d_g_info.release(); c->d_g_ord.release(); c->d_g_off.release();
 	c->d_new_n.release(); c->d_new_n64.release(); c->d_mz_x.release(); c->d_mz_info.release(); c->d_mz_off.release(); c->d_tmp.release(); c->d_ring.release(); c->d_ringord.release(); c->d_cnt_ws.release();
 	c->w_ukeys.release(); c->w_flag.release(); c->w_kpos.release(); c->w_ustart.release(); c->w_ucnt.release(); c->w_hist.release(); c->w_ok.release(); c->w_ok2.release(); c->w_oi.release(); c->w_oi2.release();
-	c->w_s40_list.release(); c->w_s40_o.release(); c->w_s40_x.release(); c->w_s40_cnt.release(); c->d_ix_lk.release(); c->w_runid.release(); c->d_ix_mz_x.release(); c->d_ix_mz_info.release(); c->d_ix_mz_off.release(); c->d_ix_sx.release(); c->d_ix_sinfo.release();
+	c->w_lkv2.release(); c->w_s40_list.release(); c->w_s40_o.release(); c->w_s40_x.release(); c->w_s40_cnt.release(); c->d_ix_lk.release(); c->w_runid.release(); c->d_ix_mz_x.release(); c->d_ix_mz_info.release(); c->d_ix_mz_off.release(); c->d_ix_sx.release(); c->d_ix_sinfo.release();
 	c->d_ix_keys.release(); c->d_ix_start.release(); c->d_ix_cnt.release(); c->d_ix_bucket.release();
 	c->al_task.release(); c->al_k1.release(); c->al_k2.release(); c->al_path.release(); c->al_i1.release(); c->al_order.release(); c->al_sel.release(); c->al_res.release(); c->al_tres.release(); c->al_want.release(); c->al_cig.release();
 }

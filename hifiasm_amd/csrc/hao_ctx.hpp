@@ -57,7 +57,7 @@ struct StageTimer {
 // run-time switches (measurement aids): read from the environment ONCE, in hao_create
 struct hao_switches {
 	bool seedphase = false, qcphase = false, dp_stats = false, seq_chain = false, dp_seqtail = false, dp_nospec = false, dp_serial = false,
-		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, sk_v2 = false, dltime = false, sk_nofuse = false, pack_search = false, sk_select2 = false, seed_v2 = false, seed_pf = true, seed_noql = false, sort64 = false, seed_nodirect = false, tiny_lane = false;
+		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, sk_v2 = false, dltime = false, sk_nofuse = false, pack_search = false, sk_select2 = false, seed_v2 = false, seed_pf = true, seed_noql = false, sort64 = false, seed_nodirect = false, tiny_lane = false, pt_direct = false;
 	static constexpr bool SK_SELECT2_DEFAULT = true;       // the thinning kernel the sketch runs when the environment says nothing: the wave kernel (round 4: green on the device against every repeat-rich scenario and the 5 Mb / 250 Mb repeat-rich fixtures)
 	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; unsigned long long ix_pad = 0; int seed_nu = 4, fc_raw_every = 0, exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, seed_lds_pad = 0, arena_numa = 1, seed_tile = 512;
 	void load() {
@@ -68,6 +68,7 @@ struct hao_switches {
 		dltime = on("HAO_DBG_DLTIME");
 		seed_v2 = on("HAO_SEED_V2");      // A/B: the seed kernel with a wave-private, barrier-free scatter pass (hao_query2.cuh; round 4: bit-exact, 1.5 x slower - fewer waves per CU)
 		if (const char *e = getenv("HAO_DBG_IX_PAD")) ix_pad = strtoull(e, nullptr, 10);      // tests: unused position records in front of the index (list starts beyond 2^32 on a small read set)
+		pt_direct = on("HAO_PT_DIRECT");      // A/B: the index's gather + scatter in one kernel (random 8-byte writes) instead of gather, one radix pass, windowed scatter
 		sort64 = on("HAO_PT_SORT64");      // A/B: the index sort over all 64 hash bits (8 passes) instead of 40 bits + fix-up (hao_index.cuh)
 		seed_nodirect = on("HAO_SEED_NODIRECT");      // A/B: reads of many bins through the staged-tile kernel's 1024- / 2048-slot instances instead of hao_query3.cuh
 		if (const char *e = getenv("HAO_SEED_NU")) seed_nu = atoi(e) == 8 ? 8 : 4;      // 64-anchor windows a wave of seed_bin3_kernel keeps in flight
@@ -131,7 +132,7 @@ struct hao_ctx {
 	DevBuf<uint64_t> d_ix_lk; bool lk_valid = false; DevBuf<uint32_t> w_runid;   // per minimizer (read order): list start | count << 48 of its key (single-device build)
 	DevBuf<uint64_t> d_ix_keys, d_ix_start; DevBuf<uint32_t> d_ix_cnt; DevBuf<uint32_t> d_ix_bucket;
 	DevBuf<uint64_t> w_ukeys, w_flag, w_kpos, w_ustart; DevBuf<uint32_t> w_ucnt; DevBuf<unsigned long long> w_hist; DevBuf<uint32_t> w_ok, w_ok2, w_oi, w_oi2;   // persistent scratch of the index build
-	DevBuf<uint32_t> w_s40_list, w_s40_o; DevBuf<uint64_t> w_s40_x; DevBuf<unsigned long long> w_s40_cnt; uint64_t s40_runs = 0;      // fix-up of the 40-bit index sort (hao_index.cuh)
+	DevBuf<uint32_t> w_s40_list, w_s40_o; DevBuf<uint64_t> w_s40_x, w_lkv2; DevBuf<unsigned long long> w_s40_cnt; uint64_t s40_runs = 0;      // fix-up of the 40-bit index sort (hao_index.cuh)
 	std::vector<uint64_t> h_ix_keys, h_ix_off, h_ix_pos, h_ix_mz_off; bool h_ix_valid = false;
 	// ---- query batch ----
 	// f3 (hao_align.cuh): scratch of the window-alignment batches, kept between calls (a hipMalloc / hipFree pair per buffer and call cost more than the kernels)

@@ -227,6 +227,19 @@ __global__ void hao_index_finish_kernel(uint64_t m, const uint32_t *sidx, const 
 	int c = ucnt[u] > HAO_MAX_COUNT ? HAO_MAX_COUNT : (int)ucnt[u];
 	lk[o] = (c >= lo && c <= hi) ? ((ustart[u] + base) | (uint64_t)c << 48) : 0;
 }
+// The two halves of hao_index_finish_kernel for big indexes: the gather with the lookup results left in hash order (val[j]), then - after ONE radix pass has
+// grouped the (read-order index, result) pairs by the top 8 bits of the index - a scatter whose writes of any moment fall into a window of 2^(bits - 8) results
+// (8 MB at 215 M minimizers) that the memory-side cache merges into full lines, instead of 8-byte writes all over a 1.7 GB array.
+__global__ void hao_index_gather_kernel(uint64_t m, const uint32_t *sidx, const uint32_t *runid, const uint32_t *ucnt, const uint64_t *ustart, int lo, int hi,
+		const uint64_t *info, uint64_t *sinfo, uint64_t *val, uint64_t base)
+{
+	const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= m) return;
+	const uint32_t o = sidx[j], u = runid[j] - 1;
+	sinfo[j] = info[o];
+	int c = ucnt[u] > HAO_MAX_COUNT ? HAO_MAX_COUNT : (int)ucnt[u];
+	val[j] = (c >= lo && c <= hi) ? ((ustart[u] + base) | (uint64_t)c << 48) : 0;
+}
 // out[idx[i]] = in[i]
 __global__ void hao_scatter_u64_kernel(const uint64_t *in, const uint32_t *idx, uint64_t n, uint64_t *out)
 {

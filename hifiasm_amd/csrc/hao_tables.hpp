@@ -586,9 +586,23 @@ static int hao_pt_run(hao_ctx *c)
 			size_t tb = 0;
 			HIP_TRY(rocprim::inclusive_scan(nullptr, tb, heads, c->w_runid.p, m, rocprim::plus<uint32_t>(), c->stream)); HIP_TRY(hao_tmp(c, tb));
 			HIP_TRY(rocprim::inclusive_scan(c->d_tmp.p, tb, heads, c->w_runid.p, m, rocprim::plus<uint32_t>(), c->stream));
-			hipLaunchKernelGGL(hao_index_finish_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, m, c->w_oi2.p, c->w_runid.p, ucnt.p, c->w_ustart.p, 2, hi,
-							   c->d_ix_mz_info.p, c->d_ix_sinfo.p + pad, c->d_ix_lk.p, pad);
-			HAO_CHECK_LAUNCH();
+			if (m >= (1ULL << 23) && !c->sw.pt_direct) {      // big index: gather, one radix pass on the top 8 bits of the read-order index, windowed scatter (hao_index.cuh)
+				int nb = 1; while ((1ULL << nb) < m) ++nb;
+				const int b0 = nb > 8 ? nb - 8 : 0;
+				HIP_TRY(c->w_lkv2.reserve(m + 1));
+				hipLaunchKernelGGL(hao_index_gather_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, m, c->w_oi2.p, c->w_runid.p, ucnt.p, c->w_ustart.p, 2, hi,
+								   c->d_ix_mz_info.p, c->d_ix_sinfo.p + pad, c->d_ix_sx.p, pad);      // (the sorted hashes are dead: their array takes the results in hash order)
+				HAO_CHECK_LAUNCH();
+				size_t tb2 = 0;
+				HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb2, c->w_oi2.p, c->w_oi.p, c->d_ix_sx.p, c->w_lkv2.p, m, b0, nb, c->stream)); HIP_TRY(hao_tmp(c, tb2));
+				HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb2, c->w_oi2.p, c->w_oi.p, c->d_ix_sx.p, c->w_lkv2.p, m, b0, nb, c->stream));
+				hipLaunchKernelGGL(hao_scatter_u64_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, c->w_lkv2.p, c->w_oi.p, m, c->d_ix_lk.p);
+				HAO_CHECK_LAUNCH();
+			} else {
+				hipLaunchKernelGGL(hao_index_finish_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, m, c->w_oi2.p, c->w_runid.p, ucnt.p, c->w_ustart.p, 2, hi,
+								   c->d_ix_mz_info.p, c->d_ix_sinfo.p + pad, c->d_ix_lk.p, pad);
+				HAO_CHECK_LAUNCH();
+			}
 			if (pad && c->ix_n_keys) { hipLaunchKernelGGL(hao_add_const_kernel, dim3((unsigned)((c->ix_n_keys + 255) / 256)), dim3(256), 0, c->stream, c->d_ix_start.p, c->ix_n_keys, pad); HAO_CHECK_LAUNCH(); }
 		}
 		c->lk_valid = true;

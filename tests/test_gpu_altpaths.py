@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 SWITCHES = ["HAO_DBG_SEQ_CHAIN", "HAO_DBG_DP_NOSPEC", "HAO_DBG_DP_SEQTAIL", "HAO_DBG_DP_SERIAL", "HAO_DBG_SEL1", "HAO_DBG_SEQ_PRUNE",
             "HAO_DBG_SK_GENERIC", "HAO_DBG_SK_GCAP", "HAO_SPEC_MINCLS", "HAO_CHAIN_WPB", "HAO_SEED_TILE", "HAO_DBG_TINY_LANE",
-            "HAO_SEED_V2", "HAO_SEED_NOQL", "HAO_SEED_NODIRECT", "HAO_SEED_NU", "HAO_PT_SORT64"]
+            "HAO_SEED_V2", "HAO_SEED_NOQL", "HAO_SEED_NODIRECT", "HAO_SEED_NU", "HAO_PT_SORT64", "HAO_PT_DIRECT"]
 VALUES = {"HAO_DBG_SK_GCAP": "1000", "HAO_SPEC_MINCLS": "0", "HAO_CHAIN_WPB": "4", "HAO_SEED_TILE": "1024", "HAO_SEED_NU": "8"}
 
 
