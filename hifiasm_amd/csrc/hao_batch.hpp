@@ -268,7 +268,8 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		sa_.dbg = nullptr; sa_.hq = nullptr;
 		if (parts & HAO_DELIVER_CL) {      // the wire format's code array (one byte per seed hit, 0x08 = nothing to say) and, for the quick check's codes, every hit's minimizer index
 			HIP_TRY(B.hcode.reserve(A + 64));
-			{ const uint64_t n16 = (A + 31) / 16; hipLaunchKernelGGL(hao_fill16_kernel, dim3((unsigned)std::min<uint64_t>((n16 + 255) / 256, 1u << 14)), dim3(256), 0, c->stream, (hao_fill_v4*)B.hcode.p, n16, 0x08080808u); HAO_CHECK_LAUNCH(); }
+			// (the quick-check kernels write every position of every group they see; only the debug paths that bypass them need the array pre-filled)
+			if (c->sw.seq_chain || c->sw.tiny_lane || c->sw.pack_search || c->sw.dp_seqtail || c->sw.dp_nospec) { const uint64_t n16 = (A + 31) / 16; hipLaunchKernelGGL(hao_fill16_kernel, dim3((unsigned)std::min<uint64_t>((n16 + 255) / 256, 1u << 14)), dim3(256), 0, c->stream, (hao_fill_v4*)B.hcode.p, n16, 0x08080808u); HAO_CHECK_LAUNCH(); }
 			if (!c->sw.pack_search) { HIP_TRY(B.hq.reserve(A + 64)); sa_.hq = B.hq.p; }
 		}
 		if (c->sw.seedphase) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); sa_.dbg = B.dbgbuf.p; }

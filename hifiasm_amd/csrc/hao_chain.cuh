@@ -400,7 +400,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void chai
 	const uint64_t g = e.g, gs = e.start; const int32_t a_n = (int32_t)e.n;      // (a group has < 2^31 hits: a batch has < 2^32 seed hits)
 	const hao_hit_t *a = A.hits + gs;
 	const uint32_t xid = (uint32_t)(A.rid_lo + e.r), yid = e.yid;
-	if (yid == xid || a_n <= 0) { if (lane == 0) { A.nch[g] = 0; A.nout[g] = 0; } return; }     // hits to the query itself are skipped (anchor.cpp:1931)
+	if (yid == xid || a_n <= 0) {      // hits to the query itself are skipped (anchor.cpp:1931); their positions of the code array say "nothing" (every position of the array is written by the kernel that sees its group: no fill pass)
+		if (A.hcode) for (int32_t i = lane; i < a_n; i += 64) A.hcode[gs + i] = 0x08;
+		if (lane == 0) { A.nch[g] = 0; A.nout[g] = 0; }
+		return;
+	}
 	hao_hit_t hn = a[lane < a_n ? lane : 0];                     // tile 0; every later tile is requested one iteration ahead
 	const uint16_t *hqg = A.hcode ? A.hq + gs : nullptr; uint8_t *hcg = A.hcode ? A.hcode + gs : nullptr;
 	uint32_t qn = hcg ? hqg[lane < a_n ? lane : 0] : 0u, carry_q = 0;
@@ -580,10 +584,10 @@ __global__ __launch_bounds__(256) void chain_pack8_kernel(hao_chain_args A, cons
 			if (sl) { slow[base + __popcll(sq & ((1ULL << lane) - 1))] = (uint32_t)(li & 0xffffffffu); A.nch[g] = 0; A.nout[g] = 0; }
 		}
 	}
+	if (A.hcode && have && idx < a_n) A.hcode[gs + idx] = (!skip && fast && b == best) ? code : (uint8_t)0x08;      // every position of the group gets its byte here (a chain's hits their code)
 	if (skip) { if (have && idx == 0) { A.nch[g] = 0; A.nout[g] = 0; } return; }
 	if (!fast) return;
 	// ---- single chain = the whole best strand block, in place ----
-	if (A.hcode && act && b == best) A.hcode[gs + idx] = code;
 	uint64_t *fcs = A.fcs + gs + 6 * g; hao_chain_rec rc;
 	hao_region(rc, P.xl, P.yl, msc, best ? first1 : first0, best ? last1 : last0);
 	const int64_t cdiag = (int64_t)rc.y_pos_s - (int64_t)rc.x_pos_s;            // dd of a hit = (offset - self_offset) - cdiag

@@ -194,9 +194,11 @@ static void compute_batch(int64_t k)
 	pthread_mutex_unlock(&g_mu);
 	const double t0 = now_s();
 	const uint64_t lo = (uint64_t)k * g_bsz, hi = lo + g_bsz < n_reads ? lo + g_bsz : n_reads; int got = -1; hao_delivery_t view;
-	// the final round (worker_hap_dc_ec_gen_new_idx, ecovlp.cpp:3948-3972: the one call site with bw_thres = 0.001) reads ol->list only - h_ec_lchain_fast_new
-	// and push_ff_ovlp never look at cl->list - so its chained hits stay on the device: nothing but overlap records and fake cigars crosses PCIe there
-	const uint32_t parts = HAO_DELIVER_OL | (ps.bw_thres == 0.001 && !getenv("HAO_SHIM_FINAL_CL") ? 0u : (uint32_t)HAO_DELIVER_CL);
+	// Every caller gets ol->list AND cl->list.  Opt-in (HAO_SHIM_FINAL_OL_ONLY=1): the final round (worker_hap_dc_ec_gen_new_idx, ecovlp.cpp:3948-3972, recognised by
+	// its bw_thres = 0.001 - the reference offers no other marker) reads ol->list only - h_ec_lchain_fast_new and push_ff_ovlp never look at cl->list - so its
+	// chained hits can stay on the device.  Not the default: a caller that passes 0.001 and does read cl->list would silently see an empty list.
+	static const bool final_ol_only = getenv("HAO_SHIM_FINAL_OL_ONLY") != nullptr;
+	const uint32_t parts = HAO_DELIVER_OL | (final_ol_only && ps.bw_thres == 0.001 ? 0u : (uint32_t)HAO_DELIVER_CL);
 	CK(hao_overlap_batch_async(g_hao, lo, hi, &ps, parts, &got));
 	CK(hao_deliver_wait(g_hao, got, &view));
 	pthread_mutex_lock(&g_mu);

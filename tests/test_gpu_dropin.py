@@ -55,7 +55,7 @@ def test_bins_identical(bf, shim_batch):                                        
     synth.write_fasta(fa, rs)
     for exe, tag in ((REF, "ref"), (HAO, "hao")):
         r = subprocess.run([exe, "-o", os.path.join(d, tag), "-t", "8", bf, "--bin-only", fa], capture_output=True, text=True, cwd=d,
-                           env=dict(os.environ, HAO_SHIM_BATCH=shim_batch))
+                           env=dict(os.environ, HAO_SHIM_BATCH=shim_batch, **({"HAO_SHIM_FINAL_OL_ONLY": "1"} if bf == "-f26" else {})))      # (-f26: the final round served without its chained hits, the shim's opt-in)
         assert r.returncode == 0, f"{tag} failed: {r.stderr[-1500:]}"
     for ext in ("ovlp.source.bin", "ovlp.reverse.bin"):
         a = open(os.path.join(d, f"ref.{ext}"), "rb").read()
