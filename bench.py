@@ -190,7 +190,9 @@ def run_workload(a, workload, steps, warmup, rank, local_rank, world, dist, torc
     # 62 500 reads of configs[2]).  Bigger batches amortise the tails of the per-batch kernels and of the DP side streams (configs[2]: 16 batches 226 ms,
     # 8 batches 214 ms, 4 batches 209 ms per step at 200 GB)
     # (a repeat-rich genome: ~1.4 x the seed hits per read, and more of them in exception lists / DP scratch)
-    auto_bsz = max(1, int(8e8 // max(1.0, (1.25 if WORKLOADS[workload][4] else 0.83) * rs.total_bases / max(1, n_reads) * WORKLOADS[workload][1] / 30.0)))
+    # (round 4: ~1.07e9 hits per batch on the repeat-free sets = 6 batches of configs[2], 180 of the device's 309 GB with both delivery sets - 174.7 instead of 179.3 ms resident,
+    # and two exposed copy tails less; the repeat-rich twin keeps 12 batches: 198 GB, nine would need 240)
+    auto_bsz = max(1, int(8e8 // max(1.0, (1.25 if WORKLOADS[workload][4] else 0.62) * rs.total_bases / max(1, n_reads) * WORKLOADS[workload][1] / 30.0)))
     bsz = a.batch_reads if a.batch_reads > 0 else min(n_reads, auto_bsz)
     ranges = [(lo, min(n_reads, lo + bsz)) for lo in range(0, n_reads, bsz)]
     # with delivery a pass needs at least two batches for the copy of one to run under the compute of the next: a pass that fits one batch is cut in two
@@ -373,6 +375,7 @@ def run_workload(a, workload, steps, warmup, rank, local_rank, world, dist, torc
                        "groups_on_sequential_path": tot["seq_groups"], "k": 51, "w": 51, "hpc": 1,
                        "parallelism": mode, "ha_ft_gen_s": round(t_ft, 3), "hom_cov_ft": hom_ft},
             "roofline": roofline,
+            "device_memory": (lambda fr_to: {"used_gb_at_end_of_run": round((fr_to[1] - fr_to[0]) / 1e9, 1), "total_gb": round(fr_to[1] / 1e9, 1)})(torch.cuda.mem_get_info(local_rank)),
             "sketch": sk,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
         }

@@ -81,10 +81,10 @@ static int hao_gpu_numa_node(int device)
 	if (fp) { if (fscanf(fp, "%d", &node) != 1) node = -1; fclose(fp); }
 	return node;
 }
-static void hao_mem_prefer_node(int node)
+static void hao_mem_prefer_node(int node, bool bind = false)
 {
 	unsigned long mask[16]; memset(mask, 0, sizeof(mask));
-	if (node >= 0 && node < 1024) { mask[node / 64] |= 1UL << (node % 64); (void)syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, 1024UL); }
+	if (node >= 0 && node < 1024) { mask[node / 64] |= 1UL << (node % 64); (void)syscall(SYS_set_mempolicy, bind ? 2 /* MPOL_BIND */ : 1 /* MPOL_PREFERRED */, mask, 1024UL); }
 	else (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, (unsigned long*)nullptr, 0UL);
 }
 static inline double hao_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -133,9 +133,21 @@ static int hao_deliver_enqueue(hao_ctx *c)
 		const size_t want = total + total / 4 + (1 << 20);
 		const double t0_ = hao_now();
 		const int node_ = c->sw.arena_numa ? hao_gpu_numa_node(c->device) : -1;
-		if (node_ >= 0) hao_mem_prefer_node(node_);
-		const hipError_t he_ = hipHostMalloc((void**)&B.arena[s], want, (c->sw.arena_numa == 2 && node_ >= 0) ? hipHostMallocNumaUser : hipHostMallocDefault);
-		if (node_ >= 0) hao_mem_prefer_node(-1);
+		// MPOL_BIND first: "preferred" silently falls over to the far socket when the GPU's node is short of FREE pages (a process that has just generated or
+		// parsed gigabytes of reads leaves it full of page cache) - the same box then delivers at 36 instead of 52 GB/s; bound, the kernel reclaims instead.
+		// If the bound allocation fails, once more with the preference only.
+		hipError_t he_ = hipErrorOutOfMemory;
+		if (node_ >= 0 && c->sw.arena_numa != 1) {
+			hao_mem_prefer_node(node_, true);
+			he_ = hipHostMalloc((void**)&B.arena[s], want, (c->sw.arena_numa == 2) ? hipHostMallocNumaUser : hipHostMallocDefault);
+			hao_mem_prefer_node(-1);
+			if (he_ != hipSuccess) { B.arena[s] = nullptr; (void)hipGetLastError(); }
+		}
+		if (he_ != hipSuccess) {
+			if (node_ >= 0) hao_mem_prefer_node(node_);
+			he_ = hipHostMalloc((void**)&B.arena[s], want, (c->sw.arena_numa == 2 && node_ >= 0) ? hipHostMallocNumaUser : hipHostMallocDefault);
+			if (node_ >= 0) hao_mem_prefer_node(-1);
+		}
 		if (c->sw.dltime) fprintf(stderr, "[deliver] arena %d: %zu MB, GPU NUMA node %d (policy mode %d)\n", s, want >> 20, node_, c->sw.arena_numa);
 		HIP_TRY(he_);
 		B.arena_cap[s] = want; B.t_alloc += hao_now() - t0_;

@@ -59,7 +59,7 @@ struct hao_switches {
 	bool seedphase = false, qcphase = false, dp_stats = false, seq_chain = false, dp_seqtail = false, dp_nospec = false, dp_serial = false,
 		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, sk_v2 = false, dltime = false, sk_nofuse = false, pack_search = false, sk_select2 = false, seed_v2 = false, seed_pf = true, seed_noql = false, sort64 = false, seed_nodirect = false, tiny_lane = false, pt_direct = false;
 	static constexpr bool SK_SELECT2_DEFAULT = true;       // the thinning kernel the sketch runs when the environment says nothing: the wave kernel (round 4: green on the device against every repeat-rich scenario and the 5 Mb / 250 Mb repeat-rich fixtures)
-	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; unsigned long long ix_pad = 0; int seed_nu = 4, fc_raw_every = 0, exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, seed_lds_pad = 0, arena_numa = 1, seed_tile = 512;
+	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; unsigned long long ix_pad = 0; int seed_nu = 4, fc_raw_every = 0, exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, seed_lds_pad = 0, arena_numa = 3, seed_tile = 512;
 	void load() {
 		auto on = [](const char *n) { return getenv(n) != nullptr; };
 		seedphase = on("HAO_DBG_SEEDPHASE"); qcphase = on("HAO_DBG_QCPHASE"); dp_stats = on("HAO_DBG_DP_STATS"); seq_chain = on("HAO_DBG_SEQ_CHAIN");
@@ -82,7 +82,7 @@ struct hao_switches {
 		if (const char *e = getenv("HAO_DBG_EXC_CAP")) exc_cap = atoll(e);
 		if (const char *e = getenv("HAO_DBG_FC_RAW_EVERY")) fc_raw_every = std::max(0, atoi(e));      // tests: every n-th overlap's fake cigar travels raw (the fallback of the packed wire form)
 		if (const char *e = getenv("HAO_DBG_EXC_EVERY")) exc_every = atoi(e);      // ship every n-th hit of a chain verbatim (tests: exercise the exception list)
-		if (const char *e = getenv("HAO_ARENA_NUMA")) arena_numa = atoi(e);      // 0: plain hipHostMalloc, 1: thread policy = the GPU's node, 2: that + hipHostMallocNumaUser
+		if (const char *e = getenv("HAO_ARENA_NUMA")) arena_numa = atoi(e);      // 0: plain hipHostMalloc, 1: thread policy "prefer the GPU's node", 3 (default): "bind to it", then 1 if that fails, 2: 3 + hipHostMallocNumaUser
 		if (const char *e = getenv("HAO_SEED_TILE")) seed_tile = atoi(e);      // anchors per staged tile of the seed kernel: 512 (default: 6 workgroups per CU) or 1024 (longer runs per bin, 4 per CU)
 		if (const char *e = getenv("HAO_SEED_LDS_PAD")) seed_lds_pad = atoi(e);      // extra dynamic LDS bytes of the seed kernel = fewer resident workgroups per CU (A/B: cache footprint vs. latency hiding)
 		if (const char *e = getenv("HAO_STREAM_PRIO")) stream_prio = atoi(e);      // 1: the engine's streams at the highest priority (A/B: measured worse - the low-priority copy then starves)
