@@ -328,10 +328,10 @@ def run_workload(a, workload, steps, warmup, rank, local_rank, world, dist, torc
                 if pj.get("workload") == workload:
                     tt = [v["hbm_bytes_per_launch"] * v["launches"] for k, v in pj["kernels"].items() if k.split("<")[0] == dom]
                     if tt:
-                        roofline["traffic"] = int(sum(tt) / max(1, pj.get("batches", 1)))
+                        roofline["traffic"] = int(sum(tt) / max(1, n_batches))      # (the profile's launches of one pass, spread over this run's launches per pass)
                         roofline["traffic_source"] = prof_rel + ": separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x 2 (gfx950 correction of MI355X_MICROARCH.md; calibrated for wide coalesced reads only - for this kernel's 8-byte gathers the true value lies between traffic_lo and traffic)"
                         lo_ = [v.get("hbm_bytes_per_launch_raw", v["hbm_bytes_per_launch"]) * v["launches"] for k, v in pj["kernels"].items() if k.split("<")[0] == dom]
-                        roofline["traffic_lo"] = int(sum(lo_) / max(1, pj.get("batches", 1)))
+                        roofline["traffic_lo"] = int(sum(lo_) / max(1, n_batches))
             except Exception:
                 pass
         # the sketch kernel is instruction-issue bound, not HBM bound: report its VALU issue rate next to the HBM fraction (counters: profiles/r0N/sketch_alu.json)
