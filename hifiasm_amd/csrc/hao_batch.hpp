@@ -439,12 +439,9 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		size_t tb = 0;
 		HIP_TRY(rocprim::exclusive_scan(nullptr, tb, B.pk_cnt.p, O.rank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), c->stream)); HIP_TRY(hao_tmp(c, tb));
 		HIP_TRY(rocprim::exclusive_scan(c->d_tmp.p, tb, B.pk_cnt.p, O.rank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), c->stream));
-		hipLaunchKernelGGL(hao_pack_codes_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, c->stream, B.hcode.p, A, O.bits.p, O.rank.p, NW, O.codes.p, d_n_codes); HAO_CHECK_LAUNCH();
+		if (scan_exc) HIP_TRY(rocprim::exclusive_scan(c->d_tmp.p, tb, B.pk_ecnt.p, B.pk_erank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), c->stream));
+		hipLaunchKernelGGL(hao_pack_codes_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, c->stream, pa, B.hcode.p, A, O.bits.p, O.rank.p, NW, O.codes.p, d_n_codes, scan_exc ? B.pk_erank.p : (const uint32_t*)nullptr); HAO_CHECK_LAUNCH();
 		{ const uint64_t n4 = NW / 4 + 1; hipLaunchKernelGGL(hao_rank4_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, c->stream, O.rank.p, n4, O.rank4.p); HAO_CHECK_LAUNCH(); }
-		if (scan_exc) {
-			HIP_TRY(rocprim::exclusive_scan(c->d_tmp.p, tb, B.pk_ecnt.p, B.pk_erank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), c->stream));
-			hipLaunchKernelGGL(hao_pack_exc_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, c->stream, pa, A, NW, B.pk_erank.p); HAO_CHECK_LAUNCH();
-		}
 		return HAO_OK;
 	};
 	if (parts & HAO_DELIVER_CL) {

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void hao_pack_ohits_kernel(hao_pack_args A, co
 // an entry of the verbatim list: the seed hit at the position and its minimizer index.  Thread t takes positions [8t, 8t + 8) (one 8-byte load); the
 // eight threads of a 64-position word combine their flags.
 // (ecnt != nullptr: the verbatim entries are NOT appended here - their number per word goes to ecnt[], a scan turns the counts into list positions and
-// hao_pack_exc_kernel writes the entries in position order.  A repeat-rich 250 Mb batch has 14 M verbatim hits in 1.3 M waves: one atomic per wave on the list's
+// hao_pack_codes_kernel writes the entries in position order, in the pass that places the code bytes.  A repeat-rich 250 Mb batch has 14 M verbatim hits in 1.3 M waves: one atomic per wave on the list's
 // counter - all on one address - made this kernel 11 ms instead of 0.3, and the list then needed a 24-byte-record merge sort by position, ~10 ms more.)
 __global__ __launch_bounds__(256) void hao_pack_bits_kernel(hao_pack_args A, uint64_t n, uint64_t n_words, uint64_t *bits, uint32_t *cnt, uint32_t *ecnt)
 {
@@ -197,22 +197,29 @@ __global__ __launch_bounds__(256) void hao_pack_bits_kernel(hao_pack_args A, uin
 	if ((t & 7) == 0 && w < n_words) { bits[w] = word; cnt[w] = (uint32_t)__popcll(word); }      // (no lane leaves early: the slot reservation above is wave-wide)
 }
 
-// the verbatim list in position order (no atomics, nothing to sort): erank = exclusive prefix of hao_pack_bits_kernel's per-word counts (n_words + 1 entries: the
-// last one is the total).  Thread t takes positions [8t, 8t + 8); the eight threads of a word learn their place inside the word from each other.
-__global__ __launch_bounds__(256) void hao_pack_exc_kernel(hao_pack_args A, uint64_t n, uint64_t n_words, const uint32_t *erank)
+// code bytes of the flagged positions, at their rank: thread t takes positions [8t, 8t + 8).  With erank != nullptr the same pass also writes the verbatim list
+// (hao_pack_exc_kernel's work: one read of the code array less per batch).
+__global__ __launch_bounds__(256) void hao_pack_codes_kernel(hao_pack_args A, const uint8_t *bytes, uint64_t n, const uint64_t *bits, const uint32_t *rank, uint64_t n_words, uint8_t *codes,
+		unsigned long long *n_codes, const uint32_t *erank)
 {
 	const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, w = t >> 3;
-	if (t == 0) *A.exc_cnt = erank[n_words];
-	uint32_t e8 = 0; uint64_t v = 0;
-	if (8 * t < n) {
-		v = *(const uint64_t*)(A.bytes + 8 * t);
-#pragma unroll
-		for (int k = 0; k < 8; ++k) { const uint8_t b = (uint8_t)(v >> (8 * k)); if (8 * t + k < n && (b == 0xff || b == HAO_CODE_EXC_OHITS)) e8 |= 1u << k; }
+	if (t == 0) { *n_codes = rank[n_words]; if (erank) *A.exc_cnt = erank[n_words]; }      // (exclusive prefixes over n_words + 1 counts: the last entries are the totals)
+	const bool in = 8 * t < n;
+	const uint64_t word = in ? bits[w] : 0; const int sh = (int)(t & 7) * 8;
+	uint32_t m8 = (uint32_t)(word >> sh) & 0xffu, e8 = 0;
+	uint64_t v = 0;
+	if (m8) v = *(const uint64_t*)(bytes + 8 * t);      // (a word's bits beyond n are zero)
+	if (m8) {
+		uint64_t at = rank[w] + (uint64_t)__popcll(word & ((1ULL << sh) - 1));
+		for (uint32_t m = m8; m; m &= m - 1) { const uint8_t b = (uint8_t)(v >> (8 * (__ffs((int)m) - 1))); codes[at++] = b >= HAO_CODE_EXC_OHITS ? (uint8_t)0xff : b; }      // (0xfd / 0xfe: device-only flavours of "verbatim")
 	}
-	uint64_t eword = (uint64_t)e8 << ((t & 7) * 8);
-	eword |= __shfl_xor(eword, 1); eword |= __shfl_xor(eword, 2); eword |= __shfl_xor(eword, 4);      // (no lane leaves before this)
+	if (!erank) return;      // (uniform)
+	// every verbatim position is a flagged position: only the set bits of m8 can be 0xff / 0xfd
+	for (uint32_t m = m8; m; m &= m - 1) { const int k = __ffs((int)m) - 1; const uint8_t b = (uint8_t)(v >> (8 * k)); if (b == 0xff || b == HAO_CODE_EXC_OHITS) e8 |= 1u << k; }
+	uint64_t eword = (uint64_t)e8 << sh;
+	eword |= __shfl_xor(eword, 1); eword |= __shfl_xor(eword, 2); eword |= __shfl_xor(eword, 4);      // (no lane has left before this)
 	if (!e8) return;
-	unsigned long long kx = (unsigned long long)erank[w] + (unsigned long long)__popcll(eword & ((1ULL << ((t & 7) * 8)) - 1));
+	unsigned long long kx = (unsigned long long)erank[w] + (unsigned long long)__popcll(eword & ((1ULL << sh) - 1));
 	for (uint32_t m = e8; m; m &= m - 1, ++kx) {
 		if (kx >= A.exc_cap) continue;      // past the capacity only the count matters: the host grows the list and packs again
 		const uint64_t p = 8 * t + (uint32_t)(__ffs((int)m) - 1);
@@ -225,21 +232,6 @@ __global__ __launch_bounds__(256) void hao_pack_exc_kernel(hao_pack_args A, uint
 		}
 		A.exc[kx] = e;
 	}
-}
-
-// code bytes of the flagged positions, at their rank: thread t takes positions [8t, 8t + 8)
-__global__ __launch_bounds__(256) void hao_pack_codes_kernel(const uint8_t *bytes, uint64_t n, const uint64_t *bits, const uint32_t *rank, uint64_t n_words, uint8_t *codes,
-		unsigned long long *n_codes)
-{
-	const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-	if (t == 0) *n_codes = rank[n_words];      // (exclusive prefix over n_words + 1 counts: the last entry is the total)
-	if (8 * t >= n) return;
-	const uint64_t word = bits[t >> 3]; const int sh = (int)(t & 7) * 8;
-	uint32_t m8 = (uint32_t)(word >> sh) & 0xffu;
-	if (!m8) return;
-	uint64_t at = rank[t >> 3] + (uint64_t)__popcll(word & ((1ULL << sh) - 1));
-	const uint64_t v = *(const uint64_t*)(bytes + 8 * t);
-	for (; m8; m8 &= m8 - 1) { const uint8_t b = (uint8_t)(v >> (8 * (__ffs((int)m8) - 1))); codes[at++] = b >= HAO_CODE_EXC_OHITS ? (uint8_t)0xff : b; }      // (0xfd / 0xfe: device-only flavours of "verbatim")
 }
 
 // the rank directory as it travels: one entry per 256 positions (every fourth word's; the decoder counts the bits of up to three words itself)
