@@ -17,10 +17,15 @@ except Exception as e:
 PY
   grep "^\[seed\]" $O/$name.err | tail -2
 }
+# (the kernels behind profiles/r04/seed_ab.txt under today's switch names: default = seed_bin_kernel<.., QL>, HAO_SEED_NOQL=1 = its generic tables (round 3's kernel),
+#  HAO_SEED_V2=1 = seed_bin2_kernel, the wave-private barrier-free scatter pass, HAO_SEED_PF=0 without its prefetch)
 run small_ql HAO_DBG_SEEDPHASE=1 -- --workload bacterial5M_hifi30x --no-boundary --steps 2 --warmup 1
 run small_noql HAO_DBG_SEEDPHASE=1 HAO_SEED_NOQL=1 -- --workload bacterial5M_hifi30x --no-boundary --steps 2 --warmup 1
+run small_v2 HAO_DBG_SEEDPHASE=1 HAO_SEED_V2=1 -- --workload bacterial5M_hifi30x --no-boundary --steps 2 --warmup 1
 run main_ql X=1 -- --steps 3
 run main_noql HAO_SEED_NOQL=1 -- --steps 3 --no-boundary
+run main_v2 HAO_SEED_V2=1 -- --steps 3 --no-boundary
+run main_v2_nopf HAO_SEED_V2=1 HAO_SEED_PF=0 -- --steps 3 --no-boundary
 run rr_ql X=1 -- --workload chr1_250M_hifi30x_repeat --steps 2 --no-boundary
 run rr_noql HAO_SEED_NOQL=1 -- --workload chr1_250M_hifi30x_repeat --steps 2 --no-boundary
 run ont_ql X=1 -- --workload ont50M_30x --steps 2 --no-boundary
