@@ -65,6 +65,48 @@ __device__ __forceinline__ uint32_t hao_seed_locate(const uint32_t *ao, uint32_t
 #define HAO_OVF() __hip_atomic_load(&s_ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define HAO_OVF_SET() __hip_atomic_store(&s_ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 
+// ---- pieces the seed kernels share (seed_bin_kernel here, seed_bin2_kernel / seed_bin3_kernel in hao_query2.cuh / hao_query3.cuh); all 256 threads call them ----
+// QL staging: the read's minimizers that have anchors, in order (stable compaction): l_ao[k] = first anchor of the k-th of them (relative to the read), l_ss[k] = its list
+// start | its index in the read's full minimizer list << 48 | its strand << 63; l_ao[nk] = n.  Returns nk.  (The caller synchronises before it reads the tables.)
+__device__ __forceinline__ uint32_t hao_seed_stage_nonempty(uint32_t *l_ao, uint64_t *l_ss, uint32_t *s_wt /* [4] */, const uint64_t *g_ao, const uint64_t *g_ss, const uint64_t *g_info,
+		uint64_t s, uint32_t nq, uint32_t n)
+{
+	const uint32_t tid = threadIdx.x; const int wv = tid >> 6, lane = tid & 63;
+	uint32_t nk = 0;
+	for (uint32_t b = 0; b < nq; b += 256) {
+		const uint32_t q = b + tid; uint32_t a0 = 0, a1 = 0;
+		if (q < nq) { a0 = (uint32_t)(g_ao[q] - s); a1 = (uint32_t)(g_ao[q + 1] - s); }      // (a_off has an entry past the batch's last minimizer)
+		const bool ne = a1 > a0; const unsigned long long bal = __ballot(ne);
+		if (lane == 0) s_wt[wv] = (uint32_t)__popcll(bal);
+		__syncthreads();
+		uint32_t k = nk + (uint32_t)__popcll(bal & ((1ULL << lane) - 1)); for (int w = 0; w < wv; ++w) k += s_wt[w];
+		if (ne) { l_ao[k] = a0; l_ss[k] = g_ss[q] | (uint64_t)q << 48 | (uint64_t)hao_info_rev(g_info[q]) << 63; }
+		nk += s_wt[0] + s_wt[1] + s_wt[2] + s_wt[3];
+		__syncthreads();
+	}
+	if (tid == 0) l_ao[nk] = n;
+	return nk;
+}
+// the D distinct bins of the table hk[CAP] as (bin key << 32 | slot), ascending, in sk[0 .. D) (bitonic sort over the next power of two P, padded with ~0); *s_c = 0 on entry.
+// Returns P; ends with a barrier.
+template<uint32_t CAP> __device__ __forceinline__ uint32_t hao_seed_sort_bins(const uint32_t *hk, uint64_t *sk, uint32_t *s_c, uint32_t D)
+{
+	const uint32_t tid = threadIdx.x;
+	uint32_t P = 2; while (P < D) P <<= 1;
+	for (uint32_t i = tid; i < CAP; i += 256) if (hk[i] != 0xffffffffu) sk[atomicAdd(s_c, 1u)] = (uint64_t)hk[i] << 32 | i;
+	for (uint32_t i = D + tid; i < P; i += 256) sk[i] = ~0ULL;
+	__syncthreads();
+	for (uint32_t k = 2; k <= P; k <<= 1)
+		for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+			for (uint32_t i = tid; i < P; i += 256) {
+				const uint32_t x = i ^ j;
+				if (x > i) { const uint64_t a = sk[i], b = sk[x]; if ((a > b) == ((i & k) == 0)) { sk[i] = b; sk[x] = a; } }
+			}
+			__syncthreads();
+		}
+	return P;
+}
+
 // Q2-Q5 fused, one workgroup per read: pass A walks the read's anchors (minimizer q, list entry j) and counts bins, pass B walks them again
 // (the read's slices of the position lists are L2-resident by then) and writes each k_mer_hit to its final place.
 // HBM traffic per anchor: one 8-byte index record in, one 16-byte hit out.
@@ -128,19 +170,7 @@ __global__ __launch_bounds__(256, CAPLOG == 9 ? 6 : CAPLOG == 10 ? 3 : 1) void s
 	const uint64_t *g_ao = S.a_off + li0, *g_ss = S.s_start + li0, *g_info = S.mz_info + m0;
 	uint32_t nk = nq;                              // staged minimizers (QL: the non-empty ones)
 	if (QL) {
-		nk = 0;
-		for (uint32_t b = 0; b < nq; b += 256) {      // stable compaction of the minimizers that have anchors
-			const uint32_t q = b + tid; uint32_t a0 = 0, a1 = 0;
-			if (q < nq) { a0 = (uint32_t)(g_ao[q] - s); a1 = (uint32_t)(g_ao[q + 1] - s); }      // (a_off has an entry past the batch's last minimizer)
-			const bool ne = a1 > a0; const unsigned long long bal = __ballot(ne);
-			if (lane == 0) s_wt[wv] = (uint32_t)__popcll(bal);
-			__syncthreads();
-			uint32_t k = nk + (uint32_t)__popcll(bal & ((1ULL << lane) - 1)); for (int w = 0; w < wv; ++w) k += s_wt[w];
-			if (ne) { l_ao[k] = a0; l_ss[k] = g_ss[q] | (uint64_t)q << 48 | (uint64_t)hao_info_rev(g_info[q]) << 63; }
-			nk += s_wt[0] + s_wt[1] + s_wt[2] + s_wt[3];
-			__syncthreads();
-		}
-		if (tid == 0) l_ao[nk] = n;
+		nk = hao_seed_stage_nonempty(l_ao, l_ss, s_wt, g_ao, g_ss, g_info, s, nq, n);      // only the minimizers that have anchors are staged
 	} else if (qlds) {
 		for (uint32_t q = tid; q < nq; q += 256) { l_ss[q] = g_ss[q] | (uint64_t)hao_info_rev(g_info[q]) << 63; l_ao[q] = (uint32_t)(g_ao[q] - s); }
 		if (tid == 0) l_ao[nq] = n;
@@ -200,18 +230,7 @@ __global__ __launch_bounds__(256, CAPLOG == 9 ? 6 : CAPLOG == 10 ? 3 : 1) void s
 		if (S.dbg) tk1 = wall_clock64();
 		const uint32_t D = s_nd;
 		if (D) {
-			uint32_t P = 2; while (P < D) P <<= 1;
-			for (uint32_t i = tid; i < CAP; i += 256) if (hk[i] != HAO_BIN_EMPTY) sk[atomicAdd(&s_c, 1u)] = (uint64_t)hk[i] << 32 | i;
-			for (uint32_t i = D + tid; i < P; i += 256) sk[i] = ~0ULL;
-			__syncthreads();
-			for (uint32_t k = 2; k <= P; k <<= 1)
-				for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-					for (uint32_t i = tid; i < P; i += 256) {
-						const uint32_t x = i ^ j;
-						if (x > i) { const uint64_t a = sk[i], b = sk[x]; if ((a > b) == ((i & k) == 0)) { sk[i] = b; sk[x] = a; } }
-					}
-					__syncthreads();
-				}
+			const uint32_t P = hao_seed_sort_bins<CAP>(hk, sk, &s_c, D);
 			for (uint32_t d = tid; d < D; d += 256) { const uint32_t slot = (uint32_t)sk[d]; rk[slot] = (uint16_t)d; bl[slot] = S.len[(uint32_t)(sk[d] >> 33)]; tot[d] = cwd[slot]; }
 			__syncthreads();
 			// exclusive scan over the sorted bins of (hits, group starts), packed as starts << 32 | hits; thread t owns bins [t*per, (t+1)*per)

@@ -119,18 +119,7 @@ __global__ __launch_bounds__(256) void seed_bin2_kernel(hao_seed_args S, const u
 		if (S.dbg) tk1 = wall_clock64();
 		const uint32_t D = s_nd;
 		if (D) {
-			uint32_t P = 2; while (P < D) P <<= 1;
-			for (uint32_t i = tid; i < CAP; i += 256) if (hk[i] != HAO_BIN_EMPTY) sk[atomicAdd(&s_c, 1u)] = (uint64_t)hk[i] << 32 | i;
-			for (uint32_t i = D + tid; i < P; i += 256) sk[i] = ~0ULL;
-			__syncthreads();
-			for (uint32_t k = 2; k <= P; k <<= 1)
-				for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-					for (uint32_t i = tid; i < P; i += 256) {
-						const uint32_t x = i ^ j;
-						if (x > i) { const uint64_t a = sk[i], b = sk[x]; if ((a > b) == ((i & k) == 0)) { sk[i] = b; sk[x] = a; } }
-					}
-					__syncthreads();
-				}
+			const uint32_t P = hao_seed_sort_bins<CAP>(hk, sk, &s_c, D);
 			for (uint32_t d = tid; d < D; d += 256) {
 				const uint32_t slot = (uint32_t)sk[d]; rk[slot] = (uint16_t)d; bl[slot] = S.len[(uint32_t)(sk[d] >> 33)];
 				tot[d] = cnt[slot] + cnt[CAP + slot] + cnt[2 * CAP + slot] + cnt[3 * CAP + slot];

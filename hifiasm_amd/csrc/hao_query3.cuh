@@ -40,19 +40,7 @@ __global__ __launch_bounds__(256) void seed_bin3_kernel(hao_seed_args S, const u
 	if (n == 0) { if (tid == 0) S.g_cnt[r] = 0; return; }
 	const uint64_t m0 = S.mz_off[S.rid_lo + r], li0 = m0 - S.mz0; const uint32_t nq = (uint32_t)(S.mz_off[S.rid_lo + r + 1] - m0);
 	const uint64_t *g_ao = S.a_off + li0, *g_ss = S.s_start + li0, *g_info = S.mz_info + m0;
-	uint32_t nk = 0;
-	for (uint32_t b = 0; b < nq; b += 256) {      // stable compaction of the minimizers that have anchors
-		const uint32_t q = b + tid; uint32_t a0 = 0, a1 = 0;
-		if (q < nq) { a0 = (uint32_t)(g_ao[q] - s); a1 = (uint32_t)(g_ao[q + 1] - s); }      // (a_off has an entry past the batch's last minimizer)
-		const bool ne = a1 > a0; const unsigned long long bal = __ballot(ne);
-		if (lane == 0) s_wt[wv] = (uint32_t)__popcll(bal);
-		__syncthreads();
-		uint32_t k = nk + (uint32_t)__popcll(bal & ((1ULL << lane) - 1)); for (int w = 0; w < wv; ++w) k += s_wt[w];
-		if (ne) { l_ao[k] = a0; l_ss[k] = g_ss[q] | (uint64_t)q << 48 | (uint64_t)hao_info_rev(g_info[q]) << 63; }
-		nk += s_wt[0] + s_wt[1] + s_wt[2] + s_wt[3];
-		__syncthreads();
-	}
-	if (tid == 0) l_ao[nk] = n;
+	const uint32_t nk = hao_seed_stage_nonempty(l_ao, l_ss, s_wt, g_ao, g_ss, g_info, s, nq, n);      // only the minimizers that have anchors are staged (hao_query.cuh)
 	__syncthreads();
 	unsigned long long tk0 = S.dbg ? wall_clock64() : 0, tk1 = 0, tk2 = 0;
 	// wave wv owns anchors [c0, c1) of the read in BOTH passes (a multiple of 64 * max(UA, NU) anchors)
@@ -106,18 +94,7 @@ __global__ __launch_bounds__(256) void seed_bin3_kernel(hao_seed_args S, const u
 		if (S.dbg) tk1 = wall_clock64();
 		const uint32_t D = s_nd;
 		if (D) {
-			uint32_t P = 2; while (P < D) P <<= 1;
-			for (uint32_t i = tid; i < CAP; i += 256) if (hk[i] != HAO_BIN_EMPTY) sk[atomicAdd(&s_c, 1u)] = (uint64_t)hk[i] << 32 | i;
-			for (uint32_t i = D + tid; i < P; i += 256) sk[i] = ~0ULL;
-			__syncthreads();
-			for (uint32_t k = 2; k <= P; k <<= 1)
-				for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-					for (uint32_t i = tid; i < P; i += 256) {
-						const uint32_t x = i ^ j;
-						if (x > i) { const uint64_t a = sk[i], b = sk[x]; if ((a > b) == ((i & k) == 0)) { sk[i] = b; sk[x] = a; } }
-					}
-					__syncthreads();
-				}
+			const uint32_t P = hao_seed_sort_bins<CAP>(hk, sk, &s_c, D);
 			for (uint32_t d = tid; d < D; d += 256) {
 				const uint32_t slot = (uint32_t)sk[d]; rk[slot] = (uint16_t)d;
 				tb[d] = cur[slot] + cur[CAP + slot] + cur[2 * CAP + slot] + cur[3 * CAP + slot];
