@@ -43,6 +43,23 @@ __device__ __forceinline__ unsigned long long hao_match_bits(uint32_t d, bool ac
 	return m;
 }
 
+// the same for a key of a fixed number of bits, fully unrolled: per bit one sign-extended bit field (0 / -1), one compare (the ballot) and one three-input bit
+// operation per half of the mask, m & ~(ballot ^ my bit) = v_bitop3 0x90 - 5 vector instructions per bit where the loop above costs 13.  The scatter passes
+// match on the SLOT of a hit's bin (slots and bins correspond one to one), so they need neither the bins' ranks nor a run-time bit count.
+template<int NB> __device__ __forceinline__ unsigned long long hao_match_key(uint32_t key, bool act)
+{
+	const unsigned long long m0 = __ballot(act);
+	uint32_t m_lo = (uint32_t)m0, m_hi = (uint32_t)(m0 >> 32);
+#pragma unroll
+	for (int b = 0; b < NB; ++b) {
+		const int32_t t = __builtin_amdgcn_sbfe((int)key, b, 1);
+		const unsigned long long bal = __ballot(t != 0);
+		m_lo = __builtin_amdgcn_bitop3_b32(m_lo, (uint32_t)bal, (uint32_t)t, 0x90);
+		m_hi = __builtin_amdgcn_bitop3_b32(m_hi, (uint32_t)(bal >> 32), (uint32_t)t, 0x90);
+	}
+	return (unsigned long long)m_hi << 32 | m_lo;
+}
+
 // Which minimizer holds each anchor of a 64-anchor window?  QL kernels stage only the read's NON-EMPTY minimizers, so their first-anchor offsets
 // ao[] increase strictly and a window of 64 anchors sees at most 64 list boundaries: lane i looks at boundary kc + 1 + i and pushes a flag to the lane of
 // its window position (ds_permute: lanes nobody writes to read 0; boundaries beyond the window are parked on lane 0, whose own anchor - the window's
@@ -150,7 +167,7 @@ __global__ __launch_bounds__(256, CAPLOG == 9 ? 6 : CAPLOG == 10 ? 3 : 1) void s
 	                                             //          output position of the bin minus its offset in the staged tile
 	uint32_t *bl = cwd + CAP;                    // [CAP]    read length of the slot's target (opposite-strand offsets)
 	uint16_t *wc = (uint16_t*)(bl + CAP);        // [4][CAP] pass B, per tile: per-wave counts, then each wave's first staged entry of the bin
-	uint16_t *rk = wc + 4 * CAP;                 // [CAP]    rank of the slot's bin among the bins of the round
+	uint16_t *rk = wc + 4 * CAP;                 // [CAP]    (unused since the scatter pass matches on slots; kept so that the host's LDS size formula stands)
 	uint64_t *sk = (uint64_t*)(rk + CAP);        // [CAP]    (bin key << 32 | slot), sorted          } between the passes
 	uint32_t *tot = (uint32_t*)(sk + CAP);       // [CAP]    per-rank totals                          }
 	hao_stage_t *stage = (hao_stage_t*)sk;       // [TILE]   pass B: the tile's hits grouped by bin   } same memory
@@ -231,7 +248,7 @@ __global__ __launch_bounds__(256, CAPLOG == 9 ? 6 : CAPLOG == 10 ? 3 : 1) void s
 		const uint32_t D = s_nd;
 		if (D) {
 			const uint32_t P = hao_seed_sort_bins<CAP>(hk, sk, &s_c, D);
-			for (uint32_t d = tid; d < D; d += 256) { const uint32_t slot = (uint32_t)sk[d]; rk[slot] = (uint16_t)d; bl[slot] = S.len[(uint32_t)(sk[d] >> 33)]; tot[d] = cwd[slot]; }
+			for (uint32_t d = tid; d < D; d += 256) { const uint32_t slot = (uint32_t)sk[d]; bl[slot] = S.len[(uint32_t)(sk[d] >> 33)]; tot[d] = cwd[slot]; }
 			__syncthreads();
 			// exclusive scan over the sorted bins of (hits, group starts), packed as starts << 32 | hits; thread t owns bins [t*per, (t+1)*per)
 			const uint32_t per = P >= 256 ? P / 256 : 1, d0 = tid * per; uint64_t mine = 0;
@@ -255,7 +272,6 @@ __global__ __launch_bounds__(256, CAPLOG == 9 ? 6 : CAPLOG == 10 ? 3 : 1) void s
 			const uint32_t last_tid_next = (uint32_t)(sk[D - 1] >> 33);      // (the staged tiles reuse sk / tot)
 			__syncthreads();
 			const uint64_t all = s_all;
-			int nbits = 0; while ((1u << nbits) < D) ++nbits;
 			if (S.dbg) tk2 = wall_clock64();
 			constexpr int NU = HAO_SEED_TILE / 256;      // 64-anchor sub-tiles per wave and tile
 			uint16_t *wcw = wc + wv * CAP;
@@ -264,7 +280,8 @@ __global__ __launch_bounds__(256, CAPLOG == 9 ? 6 : CAPLOG == 10 ? 3 : 1) void s
 #pragma unroll
 			for (uint32_t k = 0; k < SPT; ++k) ob[k] = cwd[tid * SPT + k];
 			uint32_t qw = 0;      // minimizer holding the first anchor of this wave's quarter of the tile
-			uint64_t yv[NU], ype[NU], yne[NU]; uint32_t qv[NU];
+			uint64_t yv[NU], ype[NU], yne[NU]; uint32_t qv[NU], qz[NU];      // qz: the minimizer's index in the read's full list | its strand << 31 (kept in a register:
+			                                                                // every LDS store in between would make the compiler read the staged word again)
 			// (requesting a tile's records one tile ahead costs 12 VGPRs = one wave per SIMD less, and loses: 70.7 against 65.8 ms per step)
 			auto request = [&](const uint32_t T0) {
 				const uint32_t x0 = T0 + wv * (HAO_SEED_TILE / 4);
@@ -282,7 +299,8 @@ __global__ __launch_bounds__(256, CAPLOG == 9 ? 6 : CAPLOG == 10 ? 3 : 1) void s
 					if (QL) q = hao_seed_locate(l_ao, nk, qc, x0 + u * 64, lane);
 					else { if (act) { while (HAO_AO(q + 1) <= x) ++q; } qc = (uint32_t)__builtin_amdgcn_readlane((int)q, 63); }
 					qv[u] = q;
-					const uint32_t a0 = HAO_AO(q), j = x - a0; const uint64_t ad = HAO_START(HAO_SS(q)) + j;
+					const uint64_t sv = HAO_SS(q); qz[u] = HAO_QIDX(q, sv) | (uint32_t)(sv >> 63) << 31;
+					const uint32_t a0 = HAO_AO(q), j = x - a0; const uint64_t ad = HAO_START(sv) + j;
 					yv[u] = act ? S.sinfo[ad] : 0;
 					// list neighbours normally sit in the adjacent lanes; only the lanes at a tile edge fetch theirs
 					ype[u] = (act && lane == 0 && j > 0) ? S.sinfo[ad - 1] : ~0ULL;
@@ -294,12 +312,12 @@ __global__ __launch_bounds__(256, CAPLOG == 9 ? 6 : CAPLOG == 10 ? 3 : 1) void s
 				request(T0);
 				uint32_t qp[NU], qn[NU];      // the two words of the query minimizer: first needed when the hit is staged
 #pragma unroll
-				for (int u = 0; u < NU; ++u) { const bool act = x0 + u * 64 + lane < n; const uint32_t qi = HAO_QIDX(qv[u], HAO_SS(qv[u])); qp[u] = act ? S.q_pos[li0 + qi] : 0; qn[u] = act ? S.q_cnt[li0 + qi] : 0; }
+				for (int u = 0; u < NU; ++u) { const bool act = x0 + u * 64 + lane < n; const uint32_t qi = qz[u] & 0x7fffffffu; qp[u] = act ? S.q_pos[li0 + qi] : 0; qn[u] = act ? S.q_cnt[li0 + qi] : 0; }
 				uint32_t ps[NU], po[NU];      // slot | rank inside the wave's quarter tile << 16 (or ~0: no hit); k_mer_hit::offset
 #pragma unroll
 				for (int u = 0; u < NU; ++u) {
 					const uint32_t x = x0 + u * 64 + lane, q = qv[u]; uint64_t y = yv[u];
-					const uint64_t sv = HAO_SS(q), st = HAO_START(sv); const uint32_t zrev = (uint32_t)(sv >> 63);
+					const uint32_t zrev = qz[u] >> 31;
 					const uint32_t tidk = hao_info_rid(y), rev = zrev ^ hao_info_rev(y), kk = tidk << 1 | rev;
 					const bool inr = x < n && kk >= lo && kk < hi;
 					// target of the previous / next entry of my list (0xffffffff: none): lane - 1 / lane + 1 hold them unless they belong to another
@@ -318,6 +336,7 @@ __global__ __launch_bounds__(256, CAPLOG == 9 ? 6 : CAPLOG == 10 ? 3 : 1) void s
 						const uint32_t a0 = HAO_AO(q), nl = HAO_AO(q + 1) - a0, j = x - a0;
 						const bool pv = t_up == tidk, nx = t_dn == tidk;
 						if (pv || nx) {
+							const uint64_t st = HAO_START(HAO_SS(q));
 							uint32_t ja = j, jb = j;
 							while (ja > 0 && hao_info_rid(S.sinfo[st + ja - 1]) == tidk) --ja;
 							while (jb + 1 < nl && hao_info_rid(S.sinfo[st + jb + 1]) == tidk) ++jb;
@@ -329,12 +348,12 @@ __global__ __launch_bounds__(256, CAPLOG == 9 ? 6 : CAPLOG == 10 ? 3 : 1) void s
 					}
 					uint32_t slot = (kk * 2654435761u) >> (32 - CAPLOG);
 					if (inr) while (hk[slot] != kk) slot = (slot + 1) & (CAP - 1);
-					const uint32_t d = inr ? rk[slot] : 0;
-					const unsigned long long m = hao_match_bits(d, inr, nbits);
-					const uint32_t before = __popcll(m & ((1ULL << lane) - 1)), base = inr ? wcw[slot] : 0;
+					// (slot < CAP on every lane: the LDS words of a lane without a hit are read unconditionally and never used - no divergent branch around a load)
+					const unsigned long long m = hao_match_key<CAPLOG>(slot, inr);
+					const uint32_t before = __popcll(m & ((1ULL << lane) - 1)), base = wcw[slot], tlen = bl[slot];
 					ps[u] = inr ? (slot | (base + before) << 16) : 0xffffffffu;
 					// k_mer_hit::offset (anchor.cpp:1021-1023,1059-1064): target coordinate in the strand of the hit
-					po[u] = inr ? (rev ? bl[slot] - 1 - (hao_info_pos(y) + 1 - hao_info_span(y)) : hao_info_pos(y)) : 0;
+					po[u] = rev ? tlen - 1 - (hao_info_pos(y) + 1 - hao_info_span(y)) : hao_info_pos(y);
 					if (inr && before == 0) wcw[slot] = (uint16_t)(base + __popcll(m));
 				}
 				__syncthreads();
@@ -365,7 +384,7 @@ __global__ __launch_bounds__(256, CAPLOG == 9 ? 6 : CAPLOG == 10 ? 3 : 1) void s
 					if (ps[u] != 0xffffffffu) {
 						const uint32_t slot = ps[u] & 0xffffu, at = wcw[slot] + (ps[u] >> 16);
 						hao_stage_t z; z.offset = po[u]; z.self_offset = qp[u]; z.cnt = qn[u];
-						const uint32_t qi = HAO_QIDX(qv[u], HAO_SS(qv[u]));
+						const uint32_t qi = qz[u] & 0x7fffffffu;
 						stage[at] = z; sslot[at] = (uint16_t)slot; sq[at] = (uint16_t)(qi < 65535u ? qi : 65535u);
 					}
 				__syncthreads();

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void seed_bin3_kernel(hao_seed_args S, const u
 	uint32_t *cur = hk + CAP;                    // [4][CAP] pass A: hits of the bin in each wave's quarter of the read; pass B: the wave's next output position in the bin
 	uint32_t *tb = cur + 4 * CAP;                // [CAP]    hits per RANK (sort .. scan), then read length of the SLOT's target (opposite-strand offsets)
 	uint64_t *sk = (uint64_t*)(tb + CAP);        // [CAP]    (bin key << 32 | slot), sorted
-	uint16_t *rk = (uint16_t*)(sk + CAP);        // [CAP]    rank of the slot's bin among the bins of the round
+	uint16_t *rk = (uint16_t*)(sk + CAP);        // [CAP]    (unused since pass B matches on slots; the layout - hao_seed3_lds - is kept)
 	uint64_t *l_ss = (uint64_t*)(rk + CAP);      // [qcap]   non-empty minimizers: list start | index in the read's minimizer list << 48 | strand << 63
 	uint32_t *l_ao = (uint32_t*)(l_ss + S.qcap); // [qcap+1] their first anchor, relative to the read
 	__shared__ uint32_t s_nd, s_ovf, s_c, s_wt[4]; __shared__ uint64_t s_ws[4], s_all;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void seed_bin3_kernel(hao_seed_args S, const u
 		if (D) {
 			const uint32_t P = hao_seed_sort_bins<CAP>(hk, sk, &s_c, D);
 			for (uint32_t d = tid; d < D; d += 256) {
-				const uint32_t slot = (uint32_t)sk[d]; rk[slot] = (uint16_t)d;
+				const uint32_t slot = (uint32_t)sk[d];
 				tb[d] = cur[slot] + cur[CAP + slot] + cur[2 * CAP + slot] + cur[3 * CAP + slot];
 			}
 			__syncthreads();
@@ -125,19 +125,19 @@ __global__ __launch_bounds__(256) void seed_bin3_kernel(hao_seed_args S, const u
 			__syncthreads();      // the totals by rank are dead: the same words take the target lengths by slot
 			for (uint32_t d = tid; d < D; d += 256) tb[(uint32_t)sk[d]] = S.len[(uint32_t)(sk[d] >> 33)];
 			const uint64_t all = s_all;
-			int nbits = 0; while ((1u << nbits) < D) ++nbits;
 			__syncthreads();
 			if (S.dbg) tk2 = wall_clock64();
 			// ---- pass B: wave-private, no barrier until the end of the round ----
 			uint32_t qc = q_c0;
 			for (uint32_t t0 = c0; t0 < c1; t0 += 64 * NU) {
-				uint64_t yv[NU]; uint32_t tpe[NU], tne[NU], qv[NU], qp[NU], qn[NU];
+				uint64_t yv[NU]; uint32_t tpe[NU], tne[NU], qv[NU], qz[NU], qp[NU], qn[NU];      // qz: index of the minimizer in the read's full list | its strand << 31
 #pragma unroll
 				for (int u = 0; u < NU; ++u) {      // the tile's index records (+ the list neighbours a 64-anchor window's edges need, + the two words of the query minimizer)
 					const uint32_t x = t0 + u * 64 + lane; const bool act = x < c1;
 					const uint32_t q = hao_seed_locate(l_ao, nk, qc, t0 + u * 64, lane);
 					qv[u] = q;
 					const uint64_t sv = l_ss[q]; const uint32_t a0 = l_ao[q], j = x - a0, qi = (uint32_t)(sv >> 48) & 0xfffu; const uint64_t ad = (sv & ((1ULL << 48) - 1)) + j;
+					qz[u] = qi | (uint32_t)(sv >> 63) << 31;
 					yv[u] = act ? S.sinfo[ad] : 0;
 					tpe[u] = (act && lane == 0 && j > 0) ? hao_info_rid(S.sinfo[ad - 1]) : 0xffffffffu;
 					tne[u] = (act && (lane == 63 || x + 1 == n) && j + 1 < l_ao[q + 1] - a0) ? hao_info_rid(S.sinfo[ad + 1]) : 0xffffffffu;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void seed_bin3_kernel(hao_seed_args S, const u
 #pragma unroll
 				for (int u = 0; u < NU; ++u) {
 					const uint32_t x = t0 + u * 64 + lane, q = qv[u]; uint64_t y = yv[u];
-					const uint64_t sv = l_ss[q], st = sv & ((1ULL << 48) - 1); const uint32_t zrev = (uint32_t)(sv >> 63);
+					const uint32_t zrev = qz[u] >> 31;
 					const uint32_t tidk = hao_info_rid(y), rev = zrev ^ hao_info_rev(y), kk = tidk << 1 | rev;
 					const bool inr = x < c1 && kk >= lo && kk < hi;
 					// target of the previous / next entry of my list (0xffffffff: none): lane - 1 / lane + 1 hold them unless they belong to another
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void seed_bin3_kernel(hao_seed_args S, const u
 						const uint32_t a0 = l_ao[q], nl = l_ao[q + 1] - a0, j = x - a0;
 						const bool pv = t_up == tidk, nx = t_dn == tidk;
 						if (pv || nx) {
+							const uint64_t st = l_ss[q] & ((1ULL << 48) - 1);
 							uint32_t ja = j, jb = j;
 							while (ja > 0 && hao_info_rid(S.sinfo[st + ja - 1]) == tidk) --ja;
 							while (jb + 1 < nl && hao_info_rid(S.sinfo[st + jb + 1]) == tidk) ++jb;
@@ -175,16 +176,15 @@ __global__ __launch_bounds__(256) void seed_bin3_kernel(hao_seed_args S, const u
 					}
 					uint32_t slot = (kk * 2654435761u) >> (32 - CAPLOG);
 					if (inr) while (hk[slot] != kk) slot = (slot + 1) & (CAP - 1);
-					const uint32_t d = inr ? rk[slot] : 0;
-					const unsigned long long m = hao_match_bits(d, inr, nbits);
-					const uint32_t before = __popcll(m & ((1ULL << lane) - 1)), base = inr ? cw[slot] : 0;
+					const unsigned long long m = hao_match_key<CAPLOG>(slot, inr);      // (slots and bins correspond one to one: hao_query.cuh)
+					const uint32_t before = __popcll(m & ((1ULL << lane) - 1)), base = cw[slot];
 					if (inr && before == 0) cw[slot] = base + (uint32_t)__popcll(m);
 					if (inr) {
 						// k_mer_hit::offset (anchor.cpp:1021-1023,1059-1064): target coordinate in the strand of the hit
 						hao_hit_t h; h.w0 = kk >> 1 | kk << 31; h.offset = rev ? tb[slot] - 1 - (hao_info_pos(y) + 1 - hao_info_span(y)) : hao_info_pos(y); h.self_offset = qp[u]; h.cnt = qn[u];
 						const uint64_t at = s + (uint32_t)(base + before);
 						S.hits[at] = h;
-						if (S.hq) { const uint32_t qi = (uint32_t)(sv >> 48) & 0xfffu; S.hq[at] = (uint16_t)qi; }
+						if (S.hq) S.hq[at] = (uint16_t)(qz[u] & 0xfffu);
 					}
 				}
 			}
