@@ -50,6 +50,11 @@ __host__ __device__ __forceinline__ int64_t hao_bsearch(const uint64_t *a, uint6
 }
 
 __device__ __forceinline__ int hao_lane() { return threadIdx.x & 63; }
+// The lanes of a wave run in lockstep: an LDS word that several lanes read in one statement may be rewritten by one of them in the next.  HAO_LOCKSTEP() marks
+// those places; it is nothing on the device and a rendezvous of the wave's lanes in the CPU emulation of the kernels (tests/simt, where lanes are fibers).
+#ifndef HAO_LOCKSTEP
+#define HAO_LOCKSTEP()
+#endif
 
 // Cross-lane moves on the DPP path (one VALU op, no LDS crossbar trip like ds_bpermute).  gfx9 controls: 0x110+n row_shr:n (inside rows of
 // 16 lanes), 0x142 row_bcast:15 (lane 15 of a row -> the next row, use row_mask 0xa), 0x143 row_bcast:31 (lane 31 -> rows 2,3, row_mask 0xc),

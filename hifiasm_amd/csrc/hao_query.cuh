@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256, CAPLOG == 9 ? 6 : CAPLOG == 10 ? 3 : 1) void s
 					yv[u] = act ? S.sinfo[HAO_START(sv) + (x - HAO_AO(q))] : 0; zr[u] = (uint32_t)(sv >> 63);
 				}
 				if (HAO_OVF()) break;
+				HAO_LOCKSTEP();      // the wave has read the flag as one: its lanes may set it from here on
 #pragma unroll
 				for (int u = 0; u < UA; ++u) {
 					const uint32_t x = t0 + u * 64 + lane, kk = hao_info_rid(yv[u]) << 1 | (zr[u] ^ hao_info_rev(yv[u]));
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(256, CAPLOG == 9 ? 6 : CAPLOG == 10 ? 3 : 1) void s
 					ps[u] = inr ? (slot | (base + before) << 16) : 0xffffffffu;
 					// k_mer_hit::offset (anchor.cpp:1021-1023,1059-1064): target coordinate in the strand of the hit
 					po[u] = rev ? tlen - 1 - (hao_info_pos(y) + 1 - hao_info_span(y)) : hao_info_pos(y);
+					HAO_LOCKSTEP();      // every lane of the match group has read wcw[slot]
 					if (inr && before == 0) wcw[slot] = (uint16_t)(base + __popcll(m));
 				}
 				__syncthreads();

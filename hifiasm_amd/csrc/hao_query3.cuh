@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256) void seed_bin3_kernel(hao_seed_args S, const u
 					yv[u] = act ? S.sinfo[(sv & ((1ULL << 48) - 1)) + (x - l_ao[q])] : 0; zr[u] = (uint32_t)(sv >> 63);
 				}
 				if (HAO_OVF()) break;
+				HAO_LOCKSTEP();      // the wave has read the flag as one: its lanes may set it from here on
 #pragma unroll
 				for (int u = 0; u < UA; ++u) {
 					const uint32_t x = t0 + u * 64 + lane, kk = hao_info_rid(yv[u]) << 1 | (zr[u] ^ hao_info_rev(yv[u]));
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(256) void seed_bin3_kernel(hao_seed_args S, const u
 					if (inr) while (hk[slot] != kk) slot = (slot + 1) & (CAP - 1);
 					const unsigned long long m = hao_match_key<CAPLOG>(slot, inr);      // (slots and bins correspond one to one: hao_query.cuh)
 					const uint32_t before = __popcll(m & ((1ULL << lane) - 1)), base = cw[slot];
+					HAO_LOCKSTEP();      // every lane of the match group has read cw[slot]
 					if (inr && before == 0) cw[slot] = base + (uint32_t)__popcll(m);
 					if (inr) {
 						// k_mer_hit::offset (anchor.cpp:1021-1023,1059-1064): target coordinate in the strand of the hit
