@@ -18,6 +18,11 @@
 #include <limits.h>
 #include <algorithm>
 #include <functional>
+#include <mutex>
+#include <map>
+#include <chrono>
+#include <dlfcn.h>
+#include <cxxabi.h>
 #include <string>
 #include <vector>
 
@@ -32,25 +37,71 @@
 #define __HIP_MEMORY_SCOPE_AGENT 3
 #define __hip_atomic_load(p, order, scope) (*(volatile decltype(p))(p))
 #define __hip_atomic_store(p, v, order, scope) (*(volatile decltype(p))(p) = (v))
-#define __builtin_amdgcn_fence(...) ((void)0)
 
 struct uint2 { unsigned x, y; }; struct uint4 { unsigned x, y, z, w; }; struct int2 { int x, y; }; struct int4 { int x, y, z, w; };
 struct ulonglong2 { unsigned long long x, y; }; struct ushort2 { unsigned short x, y; }; struct uchar4 { unsigned char x, y, z, w; };
 inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 inline ulonglong2 make_ulonglong2(unsigned long long x, unsigned long long y) { return ulonglong2{x, y}; }
-struct hao_simt_dim3 { unsigned x, y, z; };
-inline hao_simt_dim3 threadIdx, blockIdx, blockDim, gridDim;
+struct dim3 { unsigned x, y, z; constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+inline dim3 threadIdx, blockIdx, blockDim, gridDim;
+#define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
+inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((uint64_t)hi << 32 | lo) >> (sh & 31)); }
+
+// ---- host API: one "device" = this process's memory, every stream synchronous ----
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600 };
+typedef struct hao_simt_stream *hipStream_t; typedef struct hao_simt_event *hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+enum { hipStreamDefault = 0, hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostMallocMapped = 2, hipHostMallocNumaUser = 0x20000000 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : e == hipErrorOutOfMemory ? "out of memory" : "error"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipDeviceGetPCIBusId(char *b, int len, int) { snprintf(b, len, "0000:00:00.0"); return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = 0; return hipSuccess; }
+inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); if (!*p) return hipErrorOutOfMemory; memset(*p, getenv("HAO_SIMT_ZERO") ? 0 : 0xa5, n); return hipSuccess; }      // device memory is not zeroed
+template<class T> inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void**)p, n); }
+inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template<class T> inline hipError_t hipHostMalloc(T **p, size_t n, unsigned f = 0) { return hipHostMalloc((void**)p, n, f); }
+inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return hipSuccess; }
+template<class T> inline hipError_t hipHostGetDevicePointer(T **d, void *h, unsigned f) { return hipHostGetDevicePointer((void**)d, h, f); }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t)malloc(8); return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { return hipStreamCreate(s); }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { return hipStreamCreate(s); }
+inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
+inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
+inline hipError_t hipMemGetInfo(size_t *fr, size_t *tot) { *fr = (size_t)64 << 30; *tot = (size_t)64 << 30; return hipSuccess; }
 
 namespace hao_simt {
 enum { ST_NEW = 0, ST_RUN, ST_COLL, ST_BAR, ST_DONE };
 constexpr int MAXT = 1024, STACK = 96 * 1024;
 struct Fiber { void *sp; char *stack; int state; uint64_t val; const void *site; };
+struct Site { const char *file; int line; };
 struct Ctx {
 	Fiber f[MAXT]; int nthreads = 0, cur = 0; void *sched_sp = nullptr;
 	uint64_t snap[MAXT / 64][64]; uint64_t present[MAXT / 64];
-	std::function<void()> body; std::vector<char> dyn_lds; std::string error;
-	uint64_t n_exchange = 0, n_barrier = 0, n_switch = 0;
+	std::function<void()> body; std::vector<char> dyn_lds; std::string error, kernel;
+	uint64_t n_exchange = 0, n_barrier = 0, n_switch = 0, n_launch = 0, block_serial = 0, or_serial = ~0ULL;
 };
 inline Ctx g;
 
@@ -59,7 +110,7 @@ extern "C" void hao_simt_switch(void **save_sp, void *load_sp);
 #if defined(__x86_64__)
 __asm__(R"(
 .text
-.globl hao_simt_switch
+.weak hao_simt_switch
 .type hao_simt_switch,@function
 hao_simt_switch:
 	pushq %rbp
@@ -83,7 +134,18 @@ hao_simt_switch:
 #error "tests/simt: context switch written for x86-64 only"
 #endif
 
-inline void to_scheduler() { ++g.n_switch; hao_simt_switch(&g.f[g.cur].sp, g.sched_sp); }
+// a work-item that cannot go on (it stands at a cross-lane operation or a barrier, or has ended) hands the processor to the next lane of its wave that can run
+// (lanes run from the highest down, see run_block), or to the scheduler when there is none
+inline void to_scheduler()
+{
+	++g.n_switch;
+	const int me = g.cur, t0 = me & ~63;
+	for (int t = me - 1; t >= t0; --t) if (g.f[t].state == ST_NEW || g.f[t].state == ST_RUN) {
+		g.cur = t; threadIdx.x = (unsigned)t; if (g.f[t].state == ST_NEW) g.f[t].state = ST_RUN;
+		hao_simt_switch(&g.f[me].sp, g.f[t].sp); return;
+	}
+	hao_simt_switch(&g.f[me].sp, g.sched_sp);
+}
 [[noreturn]] inline void fiber_main() { g.body(); g.f[g.cur].state = ST_DONE; to_scheduler(); abort(); }
 inline void fiber_init(Fiber &F)
 {
@@ -97,9 +159,14 @@ inline void fiber_init(Fiber &F)
 }
 
 // every cross-lane operation: deposit an operand, get back the operands of all live lanes of my wave (and which lanes those are)
+inline const void *site_of(const char *file, int line)      // one record per source position, so that a mismatch can be reported by file and line
+{
+	static std::vector<Site*> tab; for (Site *t : tab) if (t->file == file && t->line == line) return t;
+	tab.push_back(new Site{file, line}); return tab.back();
+}
 // site: the source position of the operation (file, line) - the return address would differ between the copies an optimising compiler makes of one call
 #define HAO_SIMT_SITE_ARGS int line_ = __builtin_LINE(), const char *file_ = __builtin_FILE()
-#define HAO_SIMT_SITE ((const void*)((uintptr_t)file_ * 65536u + (uintptr_t)line_))
+#define HAO_SIMT_SITE (hao_simt::site_of(file_, line_))
 __attribute__((noinline)) inline const uint64_t *exchange(uint64_t v, uint64_t *present, const void *site)
 {
 	Fiber &me = g.f[g.cur]; me.val = v; me.site = site; me.state = ST_COLL;
@@ -112,6 +179,7 @@ inline void barrier() { g.f[g.cur].state = ST_BAR; to_scheduler(); }
 inline bool run_block()
 {
 	const int nt = g.nthreads, nw = (nt + 63) / 64;
+	++g.block_serial;
 	for (int t = 0; t < nt; ++t) fiber_init(g.f[t]);
 	auto resume = [&](int t) { g.cur = t; threadIdx.x = (unsigned)t; threadIdx.y = threadIdx.z = 0; if (g.f[t].state == ST_NEW) g.f[t].state = ST_RUN; hao_simt_switch(&g.sched_sp, g.f[t].sp); };
 	for (;;) {
@@ -120,14 +188,22 @@ inline bool run_block()
 			const int t0 = w * 64, t1 = std::min(nt, t0 + 64);
 			for (bool again = true; again; ) {
 				again = false;
-				for (int t = t0; t < t1; ++t) if (g.f[t].state == ST_NEW || g.f[t].state == ST_RUN) { resume(t); progress = true; }
+				// (highest lane first: in the common single-writer idiom - every lane reads, then `if (lane == 0)` or the first lane of a group writes - the writer runs
+				// last, as if in lockstep; the places where that is not enough carry HAO_LOCKSTEP() in the sources)
+				for (int t = t1 - 1; t >= t0; --t) if (g.f[t].state == ST_NEW || g.f[t].state == ST_RUN) { resume(t); progress = true; }
 				int nl = 0, nc = 0, nb = 0; const void *site = nullptr; bool same = true;
 				for (int t = t0; t < t1; ++t) {
 					const int s = g.f[t].state; if (s == ST_DONE) continue; ++nl;
 					if (s == ST_COLL) { if (nc++ == 0) site = g.f[t].site; else if (g.f[t].site != site) same = false; }
 					else if (s == ST_BAR) ++nb;
 				}
-				if (nc && (nb || !same)) { char b[200]; snprintf(b, sizeof b, "block %u wave %d: lanes stand at different cross-lane operations / barriers (%d at a cross-lane operation%s, %d at a barrier)", blockIdx.x, w, nc, same ? "" : " - not all the same one", nb); g.error = b; return false; }
+				if (nc && (nb || !same)) {
+					char b[300]; snprintf(b, sizeof b, "%s block %u wave %d: lanes stand at different cross-lane operations / barriers (%d at a barrier;", g.kernel.c_str(), blockIdx.x, w, nb); g.error = b;
+					std::vector<std::pair<const Site*, int>> seen;
+					for (int t = t0; t < t1; ++t) if (g.f[t].state == ST_COLL) { const Site *st = (const Site*)g.f[t].site; bool f = false; for (auto &x : seen) if (x.first == st) { ++x.second; f = true; } if (!f) seen.push_back({st, 1}); }
+					for (auto &x : seen) { const char *fn = strrchr(x.first->file, '/'); snprintf(b, sizeof b, " %d at %s:%d", x.second, fn ? fn + 1 : x.first->file, x.first->line); g.error += b; }
+					g.error += ")"; return false;
+				}
 				if (nc && nc == nl) {      // publish the operands; the wave goes on
 					uint64_t pr = 0; for (int t = t0; t < t1; ++t) if (g.f[t].state == ST_COLL) { pr |= 1ULL << (t - t0); g.snap[w][t - t0] = g.f[t].val; g.f[t].state = ST_RUN; } else g.snap[w][t - t0] = 0;
 					g.present[w] = pr; ++g.n_exchange; again = true; progress = true;
@@ -137,22 +213,38 @@ inline bool run_block()
 		}
 		if (!live) return true;
 		if (at_bar == live) { for (int t = 0; t < nt; ++t) if (g.f[t].state == ST_BAR) g.f[t].state = ST_RUN; ++g.n_barrier; progress = true; }
-		if (!progress) { char b[200]; snprintf(b, sizeof b, "block %u: no work-item can run (%d live, %d at the barrier): a cross-lane operation or barrier inside divergent control flow", blockIdx.x, live, at_bar); g.error = b; return false; }
+		if (!progress) { char b[200]; snprintf(b, sizeof b, "%s block %u: no work-item can run (%d live, %d at the barrier): a cross-lane operation or barrier inside divergent control flow", g.kernel.c_str(), blockIdx.x, live, at_bar); g.error = b; return false; }
 	}
 }
 
 // launch<<<grid, block, dyn_lds>>>: `call` invokes the kernel function with its arguments (it runs once per work-item)
-inline int launch(unsigned grid, unsigned block, size_t dyn_lds, std::function<void()> call)
+inline int launch(dim3 grid, dim3 block, size_t dyn_lds, std::function<void()> call)
 {
-	if (block > (unsigned)MAXT) { g.error = "block too large"; return 1; }
-	g.body = std::move(call); g.nthreads = (int)block; g.error.clear();
+	static std::recursive_mutex mu; std::lock_guard<std::recursive_mutex> lk(mu);      // host threads of the library launch one at a time
+	if (block.y != 1 || block.z != 1 || block.x > (unsigned)MAXT) { g.error = "block shape not modelled"; return 1; }
+	g.body = std::move(call); g.nthreads = (int)block.x; g.error.clear();
 	g.dyn_lds.assign(dyn_lds + 64, (char)0xa5);      // LDS is not zeroed on the device either
-	blockDim = {block, 1, 1}; gridDim = {grid, 1, 1};
-	for (unsigned b = 0; b < grid; ++b) { blockIdx = {b, 0, 0}; if (!run_block()) return 1; }
+	blockDim = block; gridDim = grid;
+	for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned b = 0; b < grid.x; ++b) { blockIdx = dim3(b, by, bz); if (!run_block()) return 1; }
+	++g.n_launch;
 	return 0;
 }
+inline int launch(unsigned grid, unsigned block, size_t dyn_lds, std::function<void()> call) { return launch(dim3(grid), dim3(block), dyn_lds, std::move(call)); }
 inline void *dyn_lds() { return g.dyn_lds.data(); }
+// HAO_SIMT_PROF=1: seconds and launches per kernel at exit
+struct Prof { std::map<std::string, std::pair<double, uint64_t>> t; ~Prof() { if (!getenv("HAO_SIMT_PROF")) return; for (auto &x : t) fprintf(stderr, "[simt prof] %9.3f s %8llu launches  %s\n", x.second.first, (unsigned long long)x.second.second, x.first.c_str());
+	fprintf(stderr, "[simt prof] total: %llu cross-lane operations, %llu barriers, %llu fiber switches, %llu launches\n", (unsigned long long)g.n_exchange, (unsigned long long)g.n_barrier, (unsigned long long)g.n_switch, (unsigned long long)g.n_launch); } };
+inline Prof prof;
 }      // namespace hao_simt
+// hipLaunchKernelGGL(kernel, grid, block, dynamic LDS, stream, args...): the kernel runs to completion here; an emulation error (divergent cross-lane operation,
+// barrier deadlock) is fatal - a wrong answer must not look like a kernel's
+template<class K, class... A> inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t dyn_lds, hipStream_t, A... args)
+{
+	{ Dl_info di; int st_ = 0; const char *nm = dladdr((void*)kernel, &di) && di.dli_sname ? di.dli_sname : "?"; char *dm = abi::__cxa_demangle(nm, nullptr, nullptr, &st_); std::string k = dm ? dm : nm; free(dm); hao_simt::g.kernel = k.substr(0, k.find('(')); }
+	const auto t0_ = std::chrono::steady_clock::now();
+	struct Acc { std::chrono::steady_clock::time_point t0; ~Acc() { auto &e = hao_simt::prof.t[hao_simt::g.kernel]; e.first += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); ++e.second; } } acc_{t0_};
+	if (hao_simt::launch(grid, block, dyn_lds, [&] { kernel(args...); })) { fprintf(stderr, "tests/simt: %s\n", hao_simt::g.error.c_str()); abort(); }
+}
 
 // ---- the device vocabulary the sources use ----
 template<class T> __forceinline__ T min(T a, T b) { return b < a ? b : a; }
@@ -168,6 +260,18 @@ __forceinline__ int64_t max(int a, int64_t b) { return max<int64_t>(a, b); }
 __forceinline__ uint32_t max(uint32_t a, int b) { return max<uint32_t>(a, (uint32_t)b); }
 
 __forceinline__ void __syncthreads() { hao_simt::barrier(); }
+// barrier + OR of a predicate over the workgroup: two accumulators used in turn (a work-item clears the one of the previous call after the barrier of this one:
+// everybody has read it by then)
+inline int __syncthreads_or(int pred)
+{
+	static unsigned acc[2]; static int gen[hao_simt::MAXT];
+	if (hao_simt::g.block_serial != hao_simt::g.or_serial) { hao_simt::g.or_serial = hao_simt::g.block_serial; acc[0] = acc[1] = 0; memset(gen, 0, sizeof gen); }
+	const int k = gen[threadIdx.x]++ & 1;
+	if (pred) acc[k] = 1;
+	hao_simt::barrier();
+	const int r = (int)acc[k]; acc[k ^ 1] = 0;
+	return r;
+}
 __forceinline__ void __threadfence() {}
 __forceinline__ void __threadfence_block() {}
 __forceinline__ unsigned long long wall_clock64() { return 0; }
@@ -200,7 +304,9 @@ __forceinline__ unsigned long long __ballot(int pred, HAO_SIMT_SITE_ARGS)
 	for (int i = 0; i < 64; ++i) if ((pr >> i & 1) && s[i]) m |= 1ULL << i;
 	return m;
 }
-#define HAO_LOCKSTEP() do { uint64_t pr_; (void)hao_simt::exchange(0, &pr_, (const void*)((uintptr_t)__FILE__ * 65536u + __LINE__)); } while (0)      /* hao_common.cuh: lanes of a wave run in lockstep */
+#define HAO_LOCKSTEP() do { uint64_t pr_; (void)hao_simt::exchange(0, &pr_, hao_simt::site_of(__FILE__, __LINE__)); } while (0)      /* hao_common.cuh: lanes of a wave run in lockstep */
+// the sources use release + acquire fence pairs where a wave's lanes hand data to each other through memory: the release is the rendezvous of the wave's lanes
+__forceinline__ void __builtin_amdgcn_fence(int order, const char *, HAO_SIMT_SITE_ARGS) { if (order != __ATOMIC_ACQUIRE) { uint64_t pr; (void)hao_simt::exchange(0, &pr, HAO_SIMT_SITE); } }
 __forceinline__ int __any(int pred, HAO_SIMT_SITE_ARGS) { return __ballot(pred, line_, file_) != 0; }
 __forceinline__ int __all(int pred, HAO_SIMT_SITE_ARGS) { uint64_t pr; const uint64_t *s = hao_simt::exchange(pred ? 1 : 0, &pr, HAO_SIMT_SITE); for (int i = 0; i < 64; ++i) if ((pr >> i & 1) && !s[i]) return 0; return 1; }
 template<class T> __forceinline__ T __shfl(T v, int src, int width = 64, HAO_SIMT_SITE_ARGS)

@@ -7,7 +7,7 @@ from helpers import scenario_reads, scenario_oracle
 import seed_model
 
 
-@pytest.mark.parametrize("name,step", [("hifi", 3), ("rr", 5), ("nn", 4), ("ont", 3), ("edge", 1), ("rr_heavy", 40)])
+@pytest.mark.parametrize("name,step", [("hifi", 3), ("rr", 5), ("nn", 4), ("ont", 3), ("edge", 3), ("rr_heavy", 40)])
 def test_bins_instead_of_digits(name, step):
     rs, okw = scenario_reads(name)
     o = scenario_oracle(name)

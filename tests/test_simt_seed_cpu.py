@@ -110,7 +110,7 @@ def check_reads(o, inp, blocks, seg, hits, g_tmp, g_cnt, hq):
     return n_hits
 
 
-@pytest.mark.parametrize("name,step,mode", [("hifi", 1, 0), ("rr", 1, 0), ("nn", 1, 0), ("ont", 1, 0), ("edge", 1, 0), ("k40", 2, 0), ("hpc0", 2, 0), ("fz2", 2, 0),
+@pytest.mark.parametrize("name,step,mode", [("hifi", 1, 0), ("rr", 1, 0), ("nn", 1, 0), ("ont", 1, 0), ("edge", 4, 0), ("k40", 2, 0), ("hpc0", 2, 0), ("fz2", 2, 0),
                                             ("hifi", 2, 1), ("rr", 2, 1), ("hifi", 2, 2), ("ont", 2, 2), ("rr", 3, 2), ("rr_heavy", 40, 0), ("rr_heavy", 55, 1), ("rr_heavy", 70, 2)])
 def test_seed_kernels_against_the_oracle(name, step, mode):
     rs, o, inp = seed_inputs(name)
