@@ -64,9 +64,28 @@ inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipDeviceGetPCIBusId(char *b, int len, int) { snprintf(b, len, "0000:00:00.0"); return hipSuccess; }
 inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = 0; return hipSuccess; }
-inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); if (!*p) return hipErrorOutOfMemory; memset(*p, getenv("HAO_SIMT_ZERO") ? 0 : 0xa5, n); return hipSuccess; }      // device memory is not zeroed
+// device memory is not zeroed (0xA5 here), and every allocation sits between guard zones that hipFree checks: a kernel that writes before or past its buffer ends the process
+namespace hao_simt_mem { constexpr size_t G = 256; struct Hdr { size_t n; size_t magic; }; }
+inline hipError_t hipMalloc(void **p, size_t n)
+{
+	using namespace hao_simt_mem;
+	char *b = (char*)malloc(n + 2 * G); if (!b) { *p = nullptr; return hipErrorOutOfMemory; }
+	memset(b, 0x5c, G); memset(b + G, getenv("HAO_SIMT_ZERO") ? 0 : 0xa5, n); memset(b + G + n, 0x5c, G);
+	Hdr h{n, 0x68616f73696d74ULL}; memcpy(b, &h, sizeof h);
+	*p = b + G; return hipSuccess;
+}
 template<class T> inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void**)p, n); }
-inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipFree(void *p)
+{
+	using namespace hao_simt_mem;
+	if (!p) return hipSuccess;
+	char *b = (char*)p - G; Hdr h; memcpy(&h, b, sizeof h);
+	bool ok = h.magic == 0x68616f73696d74ULL;
+	for (size_t i = sizeof h; ok && i < G; ++i) ok = b[i] == (char)0x5c;
+	for (size_t i = 0; ok && i < G; ++i) ok = b[G + h.n + i] == (char)0x5c;
+	if (!ok) { fprintf(stderr, "tests/simt: a device buffer of %zu bytes was written outside its bounds\n", h.magic == 0x68616f73696d74ULL ? h.n : (size_t)0); abort(); }
+	free(b); return hipSuccess;
+}
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template<class T> inline hipError_t hipHostMalloc(T **p, size_t n, unsigned f = 0) { return hipHostMalloc((void**)p, n, f); }
 inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
@@ -224,8 +243,12 @@ inline int launch(dim3 grid, dim3 block, size_t dyn_lds, std::function<void()> c
 	if (block.y != 1 || block.z != 1 || block.x > (unsigned)MAXT) { g.error = "block shape not modelled"; return 1; }
 	g.body = std::move(call); g.nthreads = (int)block.x; g.error.clear();
 	g.dyn_lds.assign(dyn_lds + 64, (char)0xa5);      // LDS is not zeroed on the device either
+	memset(g.dyn_lds.data() + dyn_lds, 0x5c, 64);      // ... and a kernel that writes past the dynamic LDS it asked for is caught by the guard words behind it
 	blockDim = block; gridDim = grid;
-	for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned b = 0; b < grid.x; ++b) { blockIdx = dim3(b, by, bz); if (!run_block()) return 1; }
+	for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned b = 0; b < grid.x; ++b) {
+		blockIdx = dim3(b, by, bz); if (!run_block()) return 1;
+		for (int i = 0; i < 64; ++i) if (g.dyn_lds[dyn_lds + i] != (char)0x5c) { g.error = g.kernel + ": a work-item wrote past the end of the dynamic LDS"; return 1; }
+	}
 	++g.n_launch;
 	return 0;
 }
