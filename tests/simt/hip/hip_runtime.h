@@ -22,6 +22,9 @@
 #include <map>
 #include <chrono>
 #include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include <cxxabi.h>
 #include <string>
 #include <vector>
@@ -254,6 +257,13 @@ inline int launch(dim3 grid, dim3 block, size_t dyn_lds, std::function<void()> c
 }
 inline int launch(unsigned grid, unsigned block, size_t dyn_lds, std::function<void()> call) { return launch(dim3(grid), dim3(block), dyn_lds, std::move(call)); }
 inline void *dyn_lds() { return g.dyn_lds.data(); }
+// HAO_SIMT_TRACE=1: every launch is printed, and SIGTERM / SIGSEGV print where the emulation stands (kernel, block, work-item, backtrace of its fiber)
+inline void on_signal(int sig)
+{
+	void *bt[48]; const int n = backtrace(bt, 48);
+	fprintf(stderr, "[simt] signal %d in %s, block %u, work-item %d\n", sig, g.kernel.c_str(), blockIdx.x, g.cur);
+	backtrace_symbols_fd(bt, n, 2); _exit(3);
+}
 // HAO_SIMT_PROF=1: seconds and launches per kernel at exit
 struct Prof { std::map<std::string, std::pair<double, uint64_t>> t; ~Prof() { if (!getenv("HAO_SIMT_PROF")) return; for (auto &x : t) fprintf(stderr, "[simt prof] %9.3f s %8llu launches  %s\n", x.second.first, (unsigned long long)x.second.second, x.first.c_str());
 	fprintf(stderr, "[simt prof] total: %llu cross-lane operations, %llu barriers, %llu fiber switches, %llu launches\n", (unsigned long long)g.n_exchange, (unsigned long long)g.n_barrier, (unsigned long long)g.n_switch, (unsigned long long)g.n_launch); } };
@@ -264,6 +274,7 @@ inline Prof prof;
 template<class K, class... A> inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t dyn_lds, hipStream_t, A... args)
 {
 	{ Dl_info di; int st_ = 0; const char *nm = dladdr((void*)kernel, &di) && di.dli_sname ? di.dli_sname : "?"; char *dm = abi::__cxa_demangle(nm, nullptr, nullptr, &st_); std::string k = dm ? dm : nm; free(dm); hao_simt::g.kernel = k.substr(0, k.find('(')); }
+	if (getenv("HAO_SIMT_TRACE")) { static bool inst = false; if (!inst) { inst = true; signal(SIGTERM, hao_simt::on_signal); signal(SIGSEGV, hao_simt::on_signal); } fprintf(stderr, "[simt] %s <<<%u, %u, %zu>>>\n", hao_simt::g.kernel.c_str(), grid.x, block.x, dyn_lds); }
 	const auto t0_ = std::chrono::steady_clock::now();
 	struct Acc { std::chrono::steady_clock::time_point t0; ~Acc() { auto &e = hao_simt::prof.t[hao_simt::g.kernel]; e.first += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); ++e.second; } } acc_{t0_};
 	if (hao_simt::launch(grid, block, dyn_lds, [&] { kernel(args...); })) { fprintf(stderr, "tests/simt: %s\n", hao_simt::g.error.c_str()); abort(); }
