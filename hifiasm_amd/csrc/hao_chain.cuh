@@ -1118,6 +1118,7 @@ template<int MODE> __device__ void hao_wave_intro_sort(const hao_sel_ctx &S, int
 			i = s; j = t; k = i + ((j - i) >> 1) + 1;
 			if (hao_lt<MODE>(S, k, i)) { if (hao_lt<MODE>(S, k, j)) k = j; }
 			else k = hao_lt<MODE>(S, j, i) ? i : j;
+			HAO_LOCKSTEP();      // every lane has compared the three pivot candidates
 			if (k != t) { if (lane == 0) hao_sw(S, k, t); HAO_WFENCE(); }
 			const uint64_t rp = hao_skey<MODE>(S, S.pm[t]);
 			uint32_t nL = 0, nR = 0;
@@ -1233,6 +1234,7 @@ template<int MODE, int NW> __device__ void hao_block_intro_sort(const hao_sel_ct
 			i = s; j = t; k = i + ((j - i) >> 1) + 1;
 			if (hao_lt<MODE>(S, k, i)) { if (hao_lt<MODE>(S, k, j)) k = j; }
 			else k = hao_lt<MODE>(S, j, i) ? i : j;
+			HAO_LOCKSTEP();      // every lane has compared the three pivot candidates
 			if (k != t) { if (lane == 0) hao_sw(S, k, t); HAO_WFENCE(); }
 			const uint64_t rp = hao_skey<MODE>(S, S.pm[t]);
 			uint32_t *lpos = S.lpos + s, *rasc = S.rasc + s;
@@ -1566,6 +1568,7 @@ __device__ int64_t hao_select_weak(const hao_sel_args &A, const hao_sel_ctx &S, 
 			drop = covered;
 		}
 		if (drop) continue;
+		HAO_LOCKSTEP();      // every lane is done with chain i's record
 		if (ll != i && lane == 0) hao_sw(S, ll, i);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 		++ll;

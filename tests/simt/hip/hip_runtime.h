@@ -122,7 +122,7 @@ struct Site { const char *file; int line; };
 struct Ctx {
 	Fiber f[MAXT]; int nthreads = 0, cur = 0; void *sched_sp = nullptr;
 	uint64_t snap[MAXT / 64][64]; uint64_t present[MAXT / 64];
-	std::function<void()> body; std::vector<char> dyn_lds; std::string error, kernel;
+	std::function<void()> body; std::vector<char> dyn_lds; std::string error, kernel; bool ascending = getenv("HAO_SIMT_ASCENDING") != nullptr;
 	uint64_t n_exchange = 0, n_barrier = 0, n_switch = 0, n_launch = 0, block_serial = 0, or_serial = ~0ULL;
 };
 inline Ctx g;
@@ -161,8 +161,8 @@ hao_simt_switch:
 inline void to_scheduler()
 {
 	++g.n_switch;
-	const int me = g.cur, t0 = me & ~63;
-	for (int t = me - 1; t >= t0; --t) if (g.f[t].state == ST_NEW || g.f[t].state == ST_RUN) {
+	const int me = g.cur, t0 = me & ~63, t1 = std::min(g.nthreads, t0 + 64);
+	for (int t = g.ascending ? me + 1 : me - 1; g.ascending ? t < t1 : t >= t0; t += g.ascending ? 1 : -1) if (g.f[t].state == ST_NEW || g.f[t].state == ST_RUN) {
 		g.cur = t; threadIdx.x = (unsigned)t; if (g.f[t].state == ST_NEW) g.f[t].state = ST_RUN;
 		hao_simt_switch(&g.f[me].sp, g.f[t].sp); return;
 	}
@@ -212,7 +212,8 @@ inline bool run_block()
 				again = false;
 				// (highest lane first: in the common single-writer idiom - every lane reads, then `if (lane == 0)` or the first lane of a group writes - the writer runs
 				// last, as if in lockstep; the places where that is not enough carry HAO_LOCKSTEP() in the sources)
-				for (int t = t1 - 1; t >= t0; --t) if (g.f[t].state == ST_NEW || g.f[t].state == ST_RUN) { resume(t); progress = true; }
+				if (!g.ascending) { for (int t = t1 - 1; t >= t0; --t) if (g.f[t].state == ST_NEW || g.f[t].state == ST_RUN) { resume(t); progress = true; } }
+				else for (int t = t0; t < t1; ++t) if (g.f[t].state == ST_NEW || g.f[t].state == ST_RUN) { resume(t); progress = true; }      // HAO_SIMT_ASCENDING=1: which kernels lean on the lane order?
 				int nl = 0, nc = 0, nb = 0; const void *site = nullptr; bool same = true;
 				for (int t = t0; t < t1; ++t) {
 					const int s = g.f[t].state; if (s == ST_DONE) continue; ++nl;
