@@ -122,7 +122,7 @@ struct Site { const char *file; int line; };
 struct Ctx {
 	Fiber f[MAXT]; int nthreads = 0, cur = 0; void *sched_sp = nullptr;
 	uint64_t snap[MAXT / 64][64]; uint64_t present[MAXT / 64];
-	std::function<void()> body; std::vector<char> dyn_lds; std::string error, kernel; bool ascending = getenv("HAO_SIMT_ASCENDING") != nullptr;
+	std::function<void()> body; std::vector<char> dyn_lds; std::string error, kernel; bool ascending = getenv("HAO_SIMT_ASCENDING") != nullptr, wave_reverse = getenv("HAO_SIMT_WAVES") && !strcmp(getenv("HAO_SIMT_WAVES"), "reverse"), fair = getenv("HAO_SIMT_FAIR") != nullptr;
 	uint64_t n_exchange = 0, n_barrier = 0, n_switch = 0, n_launch = 0, block_serial = 0, or_serial = ~0ULL;
 };
 inline Ctx g;
@@ -206,7 +206,8 @@ inline bool run_block()
 	auto resume = [&](int t) { g.cur = t; threadIdx.x = (unsigned)t; threadIdx.y = threadIdx.z = 0; if (g.f[t].state == ST_NEW) g.f[t].state = ST_RUN; hao_simt_switch(&g.sched_sp, g.f[t].sp); };
 	for (;;) {
 		bool progress = false; int live = 0, at_bar = 0;
-		for (int w = 0; w < nw; ++w) {
+		for (int wi = 0; wi < nw; ++wi) {
+			const int w = g.wave_reverse ? nw - 1 - wi : wi;      // HAO_SIMT_WAVES=reverse / HAO_SIMT_FAIR=1: other legal interleavings of a workgroup's waves (a missing barrier shows)
 			const int t0 = w * 64, t1 = std::min(nt, t0 + 64);
 			for (bool again = true; again; ) {
 				again = false;
@@ -229,7 +230,7 @@ inline bool run_block()
 				}
 				if (nc && nc == nl) {      // publish the operands; the wave goes on
 					uint64_t pr = 0; for (int t = t0; t < t1; ++t) if (g.f[t].state == ST_COLL) { pr |= 1ULL << (t - t0); g.snap[w][t - t0] = g.f[t].val; g.f[t].state = ST_RUN; } else g.snap[w][t - t0] = 0;
-					g.present[w] = pr; ++g.n_exchange; again = true; progress = true;
+					g.present[w] = pr; ++g.n_exchange; again = !g.fair; progress = true;
 				}
 			}
 			for (int t = t0; t < t1; ++t) { const int s = g.f[t].state; if (s != ST_DONE) { ++live; if (s == ST_BAR) ++at_bar; } }
