@@ -47,6 +47,23 @@ def test_product_never_touches_oracle():
     assert not bad, bad
 
 
+def test_product_never_touches_the_emulated_library():
+    """tests/simt (the device sources compiled for an emulated workgroup) is test infrastructure: nothing under hifiasm_amd/, include/ or integration/, nor
+    bench.py, names it; __graft_entry__.py only BUILDS it (build()), smoke() runs on libhao.so"""
+    bad = []
+    for base in ("hifiasm_amd", "include", "integration"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".py", ".hpp", ".cuh", ".hip", ".h", ".c", ".cpp")):
+                    txt = open(os.path.join(dp, fn), errors="ignore").read()
+                    if re.search(r"libhao_simt|simt_build|simt_suite|hao_simt::|tests/simt/_build", txt):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad
+    assert not re.search(r"simt", open(os.path.join(ROOT, "bench.py")).read())
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "simt" not in entry[entry.index("def smoke"):], "smoke() must run the device library"
+
+
 def test_opt_defaults_match_reference():
     """init_opt defaults (CommandLines.cpp:243-380) mirrored by hao_opt_default"""
     from hifiasm_amd import api
