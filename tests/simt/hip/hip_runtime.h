@@ -308,8 +308,7 @@ inline int __syncthreads_or(int pred)
 	const int r = (int)acc[k]; acc[k ^ 1] = 0;
 	return r;
 }
-__forceinline__ void __threadfence() {}
-__forceinline__ void __threadfence_block() {}
+// (__threadfence / __threadfence_block: with the other fences below - a rendezvous of the wave's lanes, because that is what the sources use them for)
 __forceinline__ unsigned long long wall_clock64() { return 0; }
 __forceinline__ int __popc(unsigned x) { return __builtin_popcount(x); }
 __forceinline__ int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
@@ -343,6 +342,8 @@ __forceinline__ unsigned long long __ballot(int pred, HAO_SIMT_SITE_ARGS)
 #define HAO_LOCKSTEP() do { uint64_t pr_; (void)hao_simt::exchange(0, &pr_, hao_simt::site_of(__FILE__, __LINE__)); } while (0)      /* hao_common.cuh: lanes of a wave run in lockstep */
 // the sources use release + acquire fence pairs where a wave's lanes hand data to each other through memory: the release is the rendezvous of the wave's lanes
 __forceinline__ void __builtin_amdgcn_fence(int order, const char *, HAO_SIMT_SITE_ARGS) { if (order != __ATOMIC_ACQUIRE) { uint64_t pr; (void)hao_simt::exchange(0, &pr, HAO_SIMT_SITE); } }
+__forceinline__ void __threadfence(HAO_SIMT_SITE_ARGS) { uint64_t pr; (void)hao_simt::exchange(0, &pr, HAO_SIMT_SITE); }
+__forceinline__ void __threadfence_block(HAO_SIMT_SITE_ARGS) { uint64_t pr; (void)hao_simt::exchange(0, &pr, HAO_SIMT_SITE); }
 __forceinline__ int __any(int pred, HAO_SIMT_SITE_ARGS) { return __ballot(pred, line_, file_) != 0; }
 __forceinline__ int __all(int pred, HAO_SIMT_SITE_ARGS) { uint64_t pr; const uint64_t *s = hao_simt::exchange(pred ? 1 : 0, &pr, HAO_SIMT_SITE); for (int i = 0; i < 64; ++i) if ((pr >> i & 1) && !s[i]) return 0; return 1; }
 template<class T> __forceinline__ T __shfl(T v, int src, int width = 64, HAO_SIMT_SITE_ARGS)

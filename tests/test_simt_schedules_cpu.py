@@ -19,3 +19,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def test_other_schedules(name, env):
     r = subprocess.run([sys.executable, os.path.join(HERE, "simt_pipeline.py"), name], capture_output=True, text=True, env=dict(os.environ, **env))
     assert r.returncode == 0 and r.stdout.startswith("OK"), (r.stdout[-400:], r.stderr[-1200:])
+
+
+@pytest.mark.parametrize("name", ["hifi", "bf22"])
+def test_big_index_path_on_a_small_read_set(name):
+    """ha_pt_gen's path for >= 2^23 minimizers (the index sort on 40 hash bits + the fix-up of the runs that hold several keys, hao_index_gather_kernel, one radix
+    pass, the windowed scatter of the lookup results) - on the device only the full-size fixtures reach it; HAO_DBG_SORT40_MIN lowers the threshold for the emulation"""
+    r = subprocess.run([sys.executable, os.path.join(HERE, "simt_pipeline.py"), name], capture_output=True, text=True, env=dict(os.environ, HAO_DBG_SORT40_MIN="1", HAO_SIMT_PROF="1"))
+    assert r.returncode == 0 and r.stdout.startswith("OK"), (r.stdout[-400:], r.stderr[-1200:])
+    assert "hao_index_gather_kernel" in r.stderr and "hao_sort40_mark_kernel" in r.stderr and "hao_scatter_u64_kernel" in r.stderr
