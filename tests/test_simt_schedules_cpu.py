@@ -27,4 +27,6 @@ def test_big_index_path_on_a_small_read_set(name):
     pass, the windowed scatter of the lookup results) - on the device only the full-size fixtures reach it; HAO_DBG_SORT40_MIN lowers the threshold for the emulation"""
     r = subprocess.run([sys.executable, os.path.join(HERE, "simt_pipeline.py"), name], capture_output=True, text=True, env=dict(os.environ, HAO_DBG_SORT40_MIN="1", HAO_SIMT_PROF="1"))
     assert r.returncode == 0 and r.stdout.startswith("OK"), (r.stdout[-400:], r.stderr[-1200:])
+    if os.environ.get("HAO_SIMT_PROF"):      # (tools/simt_coverage.py collects these lines)
+        sys.__stderr__.write("\n".join(l for l in r.stderr.splitlines() if l.startswith("[simt prof]")) + "\n")
     assert "hao_index_gather_kernel" in r.stderr and "hao_sort40_mark_kernel" in r.stderr and "hao_scatter_u64_kernel" in r.stderr
