@@ -32,7 +32,41 @@ def case(seed):
         o["hg_size"] = int(d["genome_size"] * float(rng.choice([0.5, 1.0, 2.0])))
     if rng.random() < 0.15:
         o["max_n_chain"] = int(rng.integers(1, 12))
+    if seed >= 1000 and rng.random() < 0.7:      # (seeds below 1000 keep the cases of the first sweeps)
+        d["degenerate"] = int(rng.integers(1, 1 << 30))
     return d, o
+
+
+def degenerate(rs, dseed, k, w):
+    """mixes hand-made trouble into a read set: reads shorter than / just around k and k + w, exact copies and reverse complements, homopolymer and short tandem
+    stretches (one or few HPC bases; every minimizer identical), N runs and all-N reads, a read spliced from two far-apart places"""
+    from hifiasm_amd import synth
+    rng = np.random.default_rng(dseed)
+    reads = [rs.codes[int(rs.code_off[i]):int(rs.code_off[i + 1])].copy() for i in range(rs.n)]
+    out = []
+    for r in reads:
+        x = rng.random()
+        if x < 0.06 and len(r) > 40:
+            a = int(rng.integers(0, len(r) - 20)); L = int(rng.integers(1, 400)); r = np.concatenate([r[:a], np.full(L, int(rng.integers(0, 4)), dtype=np.uint8), r[a:]])      # homopolymer
+        elif x < 0.12 and len(r) > 40:
+            a = int(rng.integers(0, len(r) - 20)); per = int(rng.integers(2, 8)); unit = rng.integers(0, 4, per).astype(np.uint8)
+            r = np.concatenate([r[:a], np.tile(unit, int(rng.integers(2, 200))), r[a:]])                                                                              # tandem repeat
+        elif x < 0.18 and len(r) > 40:
+            a = int(rng.integers(0, len(r) - 10)); r = r.copy(); r[a:a + int(rng.integers(1, 60))] = 4                                                                   # N run
+        elif x < 0.21 and len(r) > 200:
+            r = np.concatenate([r[:len(r) // 3], r[2 * len(r) // 3:]])                                                                                                     # spliced
+        out.append(r)
+        y = rng.random()
+        if y < 0.04:
+            out.append(r.copy())                                                                                                                                           # exact copy
+        elif y < 0.08:
+            out.append((3 - r[::-1]).astype(np.uint8) if (r < 4).all() else r[::-1].copy())                                                                              # reverse complement
+        elif y < 0.14:
+            L = int(rng.choice([1, 2, k - 1, k, k + 1, k + w - 2, k + w - 1, k + w, k + w + 1, int(rng.integers(1, 3 * (k + w)))]))
+            a = int(rng.integers(0, max(1, len(r) - L))); out.append(r[a:a + max(1, L)].copy())                                                                          # short reads
+        elif y < 0.15:
+            out.append(np.full(int(rng.integers(1, 500)), 4, dtype=np.uint8))                                                                                             # all N
+    return synth.from_codes(out)
 
 
 def run(seed):
@@ -42,7 +76,10 @@ def run(seed):
     path = simt_build.build_lib()
     api.lib_path = lambda: path; api._LIB = None
     d, okw = case(seed)
+    dg = d.pop("degenerate", 0)
     rs = synth.dataset(**d)
+    if dg:
+        rs = degenerate(rs, dg, okw.get("k", 51), okw.get("w", 51)); d["degenerate"] = dg
     o = oracle_py.Oracle(rs.codes, rs.code_off, **okw)
     e = api.Engine(0, **okw); e.set_readset(rs)
     bad = []
