@@ -9,6 +9,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = sys.argv[1:]
+if "-h" in args or "--help" in args:
+    print(__doc__); sys.exit(0)
 workers = []
 if args[:1] == ["-n"]:
     workers = ["-n", args[1]]; args = args[2:]
