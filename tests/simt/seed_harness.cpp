@@ -102,3 +102,26 @@ extern "C" int simt_vocab(int op, const uint32_t *in, uint64_t *out, const uint3
 	if (hao_simt::launch(1, 64, 0, [&] { vocab_kernel(op, in, out, ao, nk); })) return fail(err, errcap, hao_simt::g.error);
 	return 0;
 }
+
+// the emulator's own alarms, on kernels that deserve them: 0 a ballot only half of the wave reaches (the others go straight to the barrier), 1 two ballots at
+// different source positions, 2 a cross-lane operation one lane reaches while the others of its wave stand at the barrier,
+// 3 a store past the dynamic LDS the launch asked for, 4 (control) the same shapes written correctly.  Returns 1 with the message when the launch was refused.
+static void bad_kernel(int which, uint32_t *out)
+{
+	uint32_t *lds = (uint32_t*)hao_simt::dyn_lds(); const int lane = hao_lane();
+	if (which == 0) { if (lane < 32) out[threadIdx.x] = (uint32_t)__popcll(__ballot(1)); __syncthreads(); }
+	else if (which == 1) {      // (operations are told apart by source LINE)
+		unsigned long long b;
+		if (lane & 1) b = __ballot(lane > 3);
+		else b = __ballot(lane > 5);
+		out[threadIdx.x] = (uint32_t)b;
+	}
+	else if (which == 2) { if (lane == 0) out[0] = (uint32_t)__popcll(__ballot(1)); __syncthreads(); }
+	else if (which == 3) { lds[threadIdx.x] = 1; if (threadIdx.x == 7) lds[64 + 3] = 2; __syncthreads(); out[threadIdx.x] = lds[(threadIdx.x + 1) & 63]; }
+	else { const unsigned long long b = __ballot(lane < 32); lds[threadIdx.x & 63] = (uint32_t)__popcll(b); __syncthreads(); out[threadIdx.x] = lds[(threadIdx.x + 1) & 63]; }
+}
+extern "C" int simt_selfcheck(int which, uint32_t *out, char *err, int errcap)
+{
+	if (hao_simt::launch(1, 64, 256, [&] { bad_kernel(which, out); })) return fail(err, errcap, hao_simt::g.error);
+	return 0;
+}

@@ -58,6 +58,20 @@ def test_cross_lane_vocabulary():
         assert (k == np.searchsorted(ao, np.arange(int(ao[-1])), side="right") - 1).all(), trial
 
 
+def test_the_emulator_raises_its_alarms():
+    """kernels that break the rules the emulation checks must be refused with a message, not answered: a ballot only half a wave reaches, lanes of a wave at two
+    different cross-lane operations, one lane at a cross-lane operation while its wave stands at the barrier, a store past the dynamic LDS; and the same shapes written correctly pass"""
+    out = np.zeros(128, dtype=np.uint32)
+    want = {0: "different cross-lane operations / barriers", 1: "different cross-lane operations", 2: "63 at a barrier", 3: "past the end of the dynamic LDS"}
+    for which, text in want.items():
+        err = C.create_string_buffer(400)
+        rc = lib().simt_selfcheck(C.c_int(which), _p(out), err, C.c_int(400))
+        assert rc == 1 and text in err.value.decode(), (which, rc, err.value.decode())
+    err = C.create_string_buffer(400)
+    assert lib().simt_selfcheck(C.c_int(4), _p(out), err, C.c_int(400)) == 0, err.value.decode()
+    assert (out[:64] == 32).all()
+
+
 def seed_inputs(name):
     rs, _ = scenario_reads(name)
     o = scenario_oracle(name)
