@@ -81,12 +81,25 @@ static int hao_gpu_numa_node(int device)
 	if (fp) { if (fscanf(fp, "%d", &node) != 1) node = -1; fclose(fp); }
 	return node;
 }
-static void hao_mem_prefer_node(int node, bool bind = false)
-{
-	unsigned long mask[16]; memset(mask, 0, sizeof(mask));
-	if (node >= 0 && node < 1024) { mask[node / 64] |= 1UL << (node % 64); (void)syscall(SYS_set_mempolicy, bind ? 2 /* MPOL_BIND */ : 1 /* MPOL_PREFERRED */, mask, 1024UL); }
-	else (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, (unsigned long*)nullptr, 0UL);
-}
+// The calling thread's NUMA memory policy around one allocation.  The caller may be a thread of a host application (the shim inside hifiasm) that runs under a policy
+// of its own (numactl --interleave ...): the policy found is saved and put back, never reset to the default.
+struct hao_mempolicy_guard {
+	int old_mode = 0; unsigned long old_mask[16]; bool saved = false, applied = false;
+	// mode: 1 = MPOL_PREFERRED, 2 = MPOL_BIND
+	hao_mempolicy_guard(int node, int mode) {
+		memset(old_mask, 0, sizeof(old_mask));
+		if (node < 0 || node >= 1024) return;
+		saved = syscall(SYS_get_mempolicy, &old_mode, old_mask, 1024UL, nullptr, 0UL) == 0;
+		if (!saved) return;      // cannot restore what cannot be read: leave the policy alone
+		unsigned long mask[16]; memset(mask, 0, sizeof(mask)); mask[node / 64] |= 1UL << (node % 64);
+		applied = syscall(SYS_set_mempolicy, mode, mask, 1024UL) == 0;
+	}
+	~hao_mempolicy_guard() {
+		if (!applied) return;
+		bool any = false; for (int i = 0; i < 16; ++i) any |= old_mask[i] != 0;
+		(void)syscall(SYS_set_mempolicy, old_mode, any ? old_mask : (unsigned long*)nullptr, any ? 1024UL : 0UL);
+	}
+};
 static inline double hao_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct ExcLess { __host__ __device__ bool operator()(const hao_exc_t &a, const hao_exc_t &b) const { return a.index < b.index; } };
 
@@ -136,19 +149,20 @@ static int hao_deliver_enqueue(hao_ctx *c)
 		// MPOL_BIND first: "preferred" silently falls over to the far socket when the GPU's node is short of FREE pages (a process that has just generated or
 		// parsed gigabytes of reads leaves it full of page cache) - the same box then delivers at 36 instead of 52 GB/s; bound, the kernel reclaims instead.
 		// If the bound allocation fails, once more with the preference only.
-		hipError_t he_ = hipErrorOutOfMemory;
+		hipError_t he_ = hipErrorOutOfMemory; const char *how_ = "default policy";
 		if (node_ >= 0 && c->sw.arena_numa != 1) {
-			hao_mem_prefer_node(node_, true);
-			he_ = hipHostMalloc((void**)&B.arena[s], want, (c->sw.arena_numa == 2) ? hipHostMallocNumaUser : hipHostMallocDefault);
-			hao_mem_prefer_node(-1);
-			if (he_ != hipSuccess) { B.arena[s] = nullptr; (void)hipGetLastError(); }
+			hao_mempolicy_guard g_(node_, 2 /* MPOL_BIND */);
+			if (g_.applied) {
+				he_ = hipHostMalloc((void**)&B.arena[s], want, (c->sw.arena_numa == 2) ? hipHostMallocNumaUser : hipHostMallocDefault);
+				if (he_ != hipSuccess) { B.arena[s] = nullptr; (void)hipGetLastError(); } else how_ = "bound";
+			}
 		}
 		if (he_ != hipSuccess) {
-			if (node_ >= 0) hao_mem_prefer_node(node_);
-			he_ = hipHostMalloc((void**)&B.arena[s], want, (c->sw.arena_numa == 2 && node_ >= 0) ? hipHostMallocNumaUser : hipHostMallocDefault);
-			if (node_ >= 0) hao_mem_prefer_node(-1);
+			hao_mempolicy_guard g_(node_, 1 /* MPOL_PREFERRED */);
+			he_ = hipHostMalloc((void**)&B.arena[s], want, (c->sw.arena_numa == 2 && g_.applied) ? hipHostMallocNumaUser : hipHostMallocDefault);
+			if (he_ == hipSuccess && g_.applied) how_ = "preferred";
 		}
-		if (c->sw.dltime) fprintf(stderr, "[deliver] arena %d: %zu MB, GPU NUMA node %d (policy mode %d)\n", s, want >> 20, node_, c->sw.arena_numa);
+		if (c->sw.dltime) fprintf(stderr, "[deliver] arena %d: %zu MB, GPU NUMA node %d (requested mode %d, allocated %s)\n", s, want >> 20, node_, c->sw.arena_numa, he_ == hipSuccess ? how_ : "FAILED");
 		HIP_TRY(he_);
 		B.arena_cap[s] = want; B.t_alloc += hao_now() - t0_;
 		HIP_TRY(hipHostGetDevicePointer((void**)&B.arena_dev[s], B.arena[s], 0));
@@ -527,6 +541,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		B.n_chains = c->peek_h[0]; B.n_cl = c->peek_h[1]; B.n_fc_raw = c->peek_h[2]; B.n_ol = c->peek_h[3]; B.n_fc = c->peek_h[4];
 		for (int x = 0; x < HAO_NCLS + 4; ++x) slow_st[x] = c->peek_h[8 + x];
 		if (parts & HAO_DELIVER_CL) { n_exc = c->peek_h[5]; B.n_codes = G ? c->peek_h[6] : 0; }
+		if ((parts & HAO_DELIVER_OL) && (c->peek_h[7] >> 63)) { hao_set_err(c, "an overlap without fake-cigar entries: the packed cigar layout holds at least one per overlap"); return HAO_EUNSUPP; }
 		B.n_fcw = (parts & HAO_DELIVER_OL) ? (B.n_fc - B.n_ol) + c->peek_h[7] : 0;      // main region + the raw overlaps' words
 	}
 	if ((parts & HAO_DELIVER_CL) && n_exc > pa.exc_cap) {      // more verbatim hits than the list holds: grow it and pack again (the sources are untouched)

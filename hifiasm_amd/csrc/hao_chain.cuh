@@ -1726,6 +1726,9 @@ __global__ __launch_bounds__(256) void chain_final_kernel(const hao_ovlp_t *ol, 
 		bool ok = !(raw_every && (d0 + i) % raw_every == raw_every - 1);      // the cigar fits the packed words so far
 		if (act) {
 			o.align_length = 0; ol_out[d0 + i] = o; fc_out_off[d0 + i] = fo;
+			// the packed layout (wo = fo - J, n_main = entries - overlaps) needs at least one entry per overlap; gen_fake_cigar runs with apend_be = 1, so there always
+			// is one - should that ever change, the batch fails (bit 63 of the raw-word counter, read by the host) instead of shipping overlapping word ranges
+			if (fcw && fl == 0) atomicOr(fcw_raw_words, 1ULL << 63);
 			if (fl <= 16) {
 				uint64_t prev = 0;
 				for (uint32_t j = 0; j < fl; ++j) {

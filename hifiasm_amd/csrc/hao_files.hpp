@@ -8,6 +8,7 @@
 // bucket = hash * 2654435769 >> (32 - bits), then linear).  Host code only: the tables come from the engine's host views.
 #pragma once
 #include <cstdio>
+#include <sys/stat.h>
 #include <string>
 #include <vector>
 
@@ -118,11 +119,12 @@ static int hao_index_save_impl(hao_ctx *c, const char *prefix, int32_t number_of
 // (the reference re-sketches every query read; the engine sketches all reads once with the loaded filter table) and every minimizer's lookup result.
 // ---------------------------------------------------------------------------------------
 // bytes between the file position and the end of the file (sizes read from a file are checked against it before anything is allocated for them)
+// (the size comes from fstat: no seeking, so the stdio buffer survives - the loader asks once per read and once per sub-table)
 static uint64_t hao_file_left(FILE *fp)
 {
-	const long at = ftell(fp); if (at < 0 || fseek(fp, 0, SEEK_END) != 0) return 0;
-	const long end = ftell(fp); (void)fseek(fp, at, SEEK_SET);
-	return end > at ? (uint64_t)(end - at) : 0;
+	struct stat sb; const long at = ftell(fp);
+	if (at < 0 || fstat(fileno(fp), &sb) != 0 || sb.st_size <= at) return 0;
+	return (uint64_t)sb.st_size - (uint64_t)at;
 }
 static bool hao_kh_read(FILE *fp, size_t vsz, std::vector<uint64_t> &keys, std::vector<uint8_t> &vals)
 {
@@ -169,7 +171,11 @@ static int hao_index_load_impl(hao_ctx *c, const char *prefix, int32_t *number_o
 		std::vector<uint64_t> k; std::vector<uint8_t> v;
 		if (!hao_kh_read(fp, 2, k, v)) return bad("filter table of " + base);
 		std::vector<std::pair<uint64_t, int32_t> > kv(k.size());
-		for (size_t i = 0; i < k.size(); ++i) { int16_t x; memcpy(&x, &v[2 * i], 2); kv[i] = std::make_pair(k[i], x == INT16_MAX ? INT32_MAX : (int32_t)x); }      // ha_ft_cnt's view of the value (htab.cpp:1064-1070)
+		for (size_t i = 0; i < k.size(); ++i) {      // ha_ft_cnt's view of the value (htab.cpp:1064-1070); the device view's 13-bit code field holds 1 .. 4095 and "above the maximum"
+			int16_t x; memcpy(&x, &v[2 * i], 2);
+			if (x != INT16_MAX && (x < 1 || x > 4095)) return bad("filter table of " + base + ": a count outside 1 .. 4095");
+			kv[i] = std::make_pair(k[i], x == INT16_MAX ? INT32_MAX : (int32_t)x);
+		}
 		std::sort(kv.begin(), kv.end());
 		ftk.resize(kv.size()); ftv.resize(kv.size());
 		for (size_t i = 0; i < kv.size(); ++i) { ftk[i] = kv[i].first; ftv[i] = kv[i].second; }
@@ -193,7 +199,7 @@ static int hao_index_load_impl(hao_ctx *c, const char *prefix, int32_t *number_o
 			if (na && fread(pos[s].data(), 8, na, fp) != na) return bad("positions of sub-table " + std::to_string(s));
 			for (size_t i = 0; i < kk.size(); ++i) {      // key = hash >> pre << 12 | count (htab.cpp:122-124, 303-314), value = offset of its list
 				Ent e; e.hash = ((kk[i] >> 12) << pre) | s; e.sub = s; e.cnt = (uint32_t)(kk[i] & 4095); memcpy(&e.off, &vv[8 * i], 8);
-				if (e.off + e.cnt > na) return bad("a list of sub-table " + std::to_string(s) + " leaves its position array");
+				if (e.off > na || e.cnt > na - e.off) return bad("a list of sub-table " + std::to_string(s) + " leaves its position array");
 				ents.push_back(e);
 			}
 		}

@@ -207,7 +207,8 @@ static int hao_build_bucket(hao_ctx *c, const uint64_t *keys, uint64_t n, int bi
 // the filter table's hash view (hao_sketch.cuh: hao_ft_dev) from the sorted device arrays: 2^(hbits - 2) buckets of two slots for ~0.4 - 0.75 keys per bucket
 static int hao_ft_build_hash(hao_ctx *c, uint64_t n)
 {
-	int hb = 15; while (hb < 34 && (1ULL << (hb - 2)) * 3 < n * 4) ++hb;      // buckets >= 4/3 n
+	int hb = 15; while (hb < 32 && (1ULL << (hb - 2)) * 3 < n * 4) ++hb;      // buckets >= 4/3 n (hbits <= 32: the lookups index the bitmap with 32 bits; beyond 0.8 G keys the
+	                                                                             // buckets fill up and more of them fall back to the sorted array - slower, still exact)
 	c->ft_hbits = hb;
 	const uint64_t nbk = 1ULL << (hb - 2), nw = (1ULL << hb) / 32;
 	HIP_TRY(c->d_ft_hbit.reserve(nw + 1)); HIP_TRY(c->d_ft_hslot.reserve(2 * nbk + 2));

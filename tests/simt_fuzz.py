@@ -69,12 +69,14 @@ def degenerate(rs, dseed, k, w):
     return synth.from_codes(out)
 
 
-def run(seed):
-    import simt_build
+def run(seed, emulated=True):
+    """emulated: point hifiasm_amd.api at tests/simt's library (the caller restores it); False: whatever api loads - libhao.so on a GPU box (tests/test_gpu_fuzz.py)"""
     from hifiasm_amd import api, synth
     import oracle_py
-    path = simt_build.build_lib()
-    api.lib_path = lambda: path; api._LIB = None
+    if emulated:
+        import simt_build
+        path = simt_build.build_lib()
+        api.lib_path = lambda: path; api._LIB = None
     d, okw = case(seed)
     dg = d.pop("degenerate", 0)
     rs = synth.dataset(**d)
