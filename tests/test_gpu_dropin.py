@@ -67,3 +67,61 @@ def test_bins_identical(bf, shim_batch):                                        
     for i in _ec_mask(bytes(a)):
         a[i] = b[i] = 0
     assert a == b, "ec.bin differs outside the reference's uninitialised pad bytes"
+
+
+def _run_timed(exe, args, cwd, env):
+    import time
+    t0 = time.time()
+    r = subprocess.run([exe] + args, capture_output=True, text=True, cwd=cwd, env=env)
+    return r, time.time() - t0
+
+
+def _phase_times(stderr):
+    """hifiasm's own stage stamps `[M::name::<wall s>*<cpu/wall>]` -> {name: wall seconds at that stamp}"""
+    import re
+    out = {}
+    for m in re.finditer(r"\[M::(\w+)::([0-9.]+)\*([0-9.]+)", stderr):
+        out.setdefault(m.group(1), []).append(float(m.group(2)))
+    return out
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(HAO)), reason="reference binaries not built")
+def test_bins_identical_configs1_with_wall_clocks():
+    """BASELINE.json configs[1] (5 Mb genome, 30x, 15 kb HiFi reads, 10 000 reads) through the unmodified reference executable and through the same objects with the seam
+    served by libhao.so: three correction rounds + the final overlap round (Assembly.cpp:996-1010, 2055-2090 -> anchor.cpp:2302), every host core as a worker thread,
+    the shim's default batch size - thousands of h_ec_lchain calls per round stolen across the workers.  Bins byte-identical; the two wall-clocks go to the test log and
+    to gpurun_out/dropin_configs1.json (the number a hifiasm user would ask for; most of either run is the reference's own CPU alignment / correction code)."""
+    import json
+    from hifiasm_amd import synth, workloads
+    rs = workloads.workload_reads("bacterial5M_hifi30x", want_codes=True)
+    d = tempfile.mkdtemp(prefix="hao_dropin5M_")
+    fa = os.path.join(d, "reads.fa")
+    synth.write_fasta(fa, rs)
+    nt = str(min(os.cpu_count() or 8, 256))
+    env = {k: v for k, v in os.environ.items() if k not in ("HAO_SHIM_BATCH", "HAO_SHIM_FINAL_OL_ONLY")}
+    res = {}
+    for exe, tag in ((REF, "ref"), (HAO, "hao")):
+        r, wall = _run_timed(exe, ["-o", os.path.join(d, tag), "-t", nt, "-f0", "--bin-only", fa], d, env)
+        assert r.returncode == 0, f"{tag} failed: {r.stderr[-1500:]}"
+        res[tag] = {"wall_s": round(wall, 2), "stamps": {k: v[-1] for k, v in _phase_times(r.stderr).items()}}
+    for ext in ("ovlp.source.bin", "ovlp.reverse.bin"):
+        a = open(os.path.join(d, f"ref.{ext}"), "rb").read()
+        b = open(os.path.join(d, f"hao.{ext}"), "rb").read()
+        assert len(a) > 100000 and a == b, f"{ext} differs ({len(a)} vs {len(b)} bytes)"
+        res[ext] = len(a)
+    a = bytearray(open(os.path.join(d, "ref.ec.bin"), "rb").read())
+    b = bytearray(open(os.path.join(d, "hao.ec.bin"), "rb").read())
+    assert len(a) == len(b)
+    for i in _ec_mask(bytes(a)):
+        a[i] = b[i] = 0
+    assert a == b, "ec.bin differs outside the reference's uninitialised pad bytes"
+    res.update(workload="bacterial5M_hifi30x", reads=int(rs.n), threads=int(nt), args="-f0 --bin-only")
+    line = json.dumps(res)
+    print("[dropin configs1] " + line)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        open(os.path.join(ROOT, "gpurun_out", "dropin_configs1.json"), "w").write(line + "\n")
+    except OSError:
+        pass
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
