@@ -4,6 +4,7 @@
 #include "hao_query.cuh"
 #include "hao_query2.cuh"
 #include "hao_query3.cuh"
+#include "hao_query4.cuh"
 #include "hao_chain.cuh"
 
 struct hao_ctx::Batch {
@@ -283,7 +284,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	for (uint64_t r = lo; r < hi; ++r) max_q = std::max<uint64_t>(max_q, c->h_ix_mz_off[r + 1] - c->h_ix_mz_off[r]);
 	int tb = 1; while ((1ULL << tb) < c->n_total) ++tb;
 	HIP_TRY(B.g_cnt.reserve(n + 2)); HIP_TRY(B.g_off.reserve(n + 2)); HIP_TRY(B.g_tmp.reserve(A + 1));
-	HIP_TRY(B.stats.reserve(3 * HAO_NCLS + 5)); HIP_TRY(hipMemsetAsync(B.stats.p, 0, (3 * HAO_NCLS + 5) * 8, c->stream));
+	HIP_TRY(B.stats.reserve(3 * HAO_NCLS + 6)); HIP_TRY(hipMemsetAsync(B.stats.p, 0, (3 * HAO_NCLS + 6) * 8, c->stream));
 	unsigned long long *d_slow_cnt = B.stats.p, *d_cls_cnt = B.stats.p + HAO_NCLS + 4;   // [0..NCLS] slow groups per class + their hits
 	{
 		// Q2-Q5 in one kernel: index records -> bins -> sorted k_mer_hits + group lists (no anchor keys in memory)
@@ -299,9 +300,9 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			if (!c->sw.pack_search) { HIP_TRY(B.hq.reserve(A + 64)); sa_.hq = B.hq.p; }
 		}
 		if (c->sw.seedphase) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); sa_.dbg = B.dbgbuf.p; }
-		HIP_TRY(B.ovf_list.reserve(2 * (n + 1)));
-		unsigned long long *d_ovf = B.stats.p + 3 * HAO_NCLS + 3, *d_ovf2 = B.stats.p + 3 * HAO_NCLS + 4;
-		uint32_t *ovf1 = B.ovf_list.p, *ovf2 = B.ovf_list.p + (n + 1);
+		HIP_TRY(B.ovf_list.reserve(3 * (n + 1)));
+		unsigned long long *d_ovf = B.stats.p + 3 * HAO_NCLS + 3, *d_ovf2 = B.stats.p + 3 * HAO_NCLS + 4, *d_ovf0 = B.stats.p + 3 * HAO_NCLS + 5;
+		uint32_t *ovf1 = B.ovf_list.p, *ovf2 = B.ovf_list.p + (n + 1), *ovf0 = B.ovf_list.p + 2 * (n + 1);
 		const uint32_t tile_ = c->sw.seed_tile == 512 ? 512 : 1024;
 		const size_t lds_tile = std::max<size_t>((size_t)tile_ * (sizeof(hao_stage_t) + 4), 12 * 512);      // staged tile (>= the 12 bytes per slot of the bin sort it shares memory with)
 		const size_t lds_q = 12 * (size_t)sa_.qcap + 16;
@@ -328,6 +329,24 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			else if (int rc = launch(seed_bin2_kernel<9, 0, false>, seed_bin2_kernel<10, 1, true>, seed_bin2_kernel<11, 2, true>)) return rc;
 		}
 		else if (tile_ != 512) { if (int rc = launch(seed_bin_kernel<9, 0, 1024, false>, seed_bin_kernel<10, 1, 1024, false>, seed_bin_kernel<11, 2, 1024, false>)) return rc; }
+		else if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql && c->sw.seed_merge) {
+			// the merge kernel (hao_query4.cuh): one wave per read, one walk over the read's position lists; the reads with more rows than a wave holds go through the
+			// table kernels below it (512-slot launch over the overflow list, then the launches without staged tiles)
+			lds2 = hao_seed3_lds<10>::FIXED + lds_q; lds3 = hao_seed3_lds<11>::FIXED + lds_q;
+			auto k1 = seed_bin_kernel<9, 1, 512, true>; auto k2 = seed_bin3_kernel<10, 1, 4>; auto k3 = seed_bin3_kernel<11, 2, 4>;
+			HIP_TRY(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+			HIP_TRY(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+			HIP_TRY(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+			if (c->sw.seed_merge == 4) hipLaunchKernelGGL(seed_merge_kernel<4>, dim3((unsigned)((n + 3) / 4)), dim3(256), hao_seed4_lds<4>::TOTAL, c->stream, sa_, (const uint64_t*)c->d_ix_sinfo.p, (const uint32_t*)c->d_len_all.p, ovf0, d_ovf0);
+			else hipLaunchKernelGGL(seed_merge_kernel<8>, dim3((unsigned)((n + 3) / 4)), dim3(256), hao_seed4_lds<8>::TOTAL, c->stream, sa_, (const uint64_t*)c->d_ix_sinfo.p, (const uint32_t*)c->d_len_all.p, ovf0, d_ovf0);
+			HAO_CHECK_LAUNCH();
+			hipLaunchKernelGGL(k1, dim3((unsigned)n), dim3(256), lds1, c->stream, sa_, (const uint32_t*)ovf0, (const unsigned long long*)d_ovf0, ovf1, d_ovf);
+			HAO_CHECK_LAUNCH();
+			hipLaunchKernelGGL(k2, dim3((unsigned)n), dim3(256), lds2, c->stream, sa_, (const uint32_t*)ovf1, (const unsigned long long*)d_ovf, ovf2, d_ovf2);
+			HAO_CHECK_LAUNCH();
+			hipLaunchKernelGGL(k3, dim3((unsigned)n), dim3(256), lds3, c->stream, sa_, (const uint32_t*)ovf2, (const unsigned long long*)d_ovf2, (uint32_t*)nullptr, (unsigned long long*)nullptr);
+			HAO_CHECK_LAUNCH();
+		}
 		else if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql) {      // every read's minimizer table fits the LDS
 			if (c->sw.seed_nodirect) { if (int rc = launch(seed_bin_kernel<9, 0, 512, true>, seed_bin_kernel<10, 1, 512, true>, seed_bin_kernel<11, 2, 512, true>)) return rc; }
 			else {      // reads whose bins overflow the 512-slot table: the launches without staged tiles (hao_query3.cuh)

@@ -1,0 +1,167 @@
+// Seed stage by MERGE (K5-K7 in one pass; minimizers_qgen0, anchor.cpp:987-1081): one wave per read, no hash table, no counting pass, no staging.
+//
+// The reference orders a read's seed hits by (target id, strand, query position, target offset) - anchor.cpp:1011-1076 materialises them and radix-sorts.  Two facts
+// of the position index make that order computable in ONE walk:
+//   * every position list is sorted by (rid, pos) (ha_pt_gen, htab.cpp:380-460), so the lists of a read's minimizers are R sorted runs over the same key (rid);
+//   * inside a (target, strand) bin the order is (query minimizer, list order) - hao_query.cuh's header - and minimizers are already in query order.
+// So the hits of a read are the R-way MERGE of its lists by target, written target by target: a wave keeps one cursor per list (row), RPL rows per lane
+// (row = block * 64 + lane, so that row order = (block, lane) order); a step takes the smallest target T under any cursor (one wave-min), every row whose head record
+// belongs to T emits it - forward-strand hits first, then the opposite strand, each ranked by ballot + mbcnt in row order - and advances.  The output position is a
+// running counter (bins come out in ascending (target, strand) order, which IS the layout of the read's segment of hits[]), the group list (one entry per target)
+// is written as the targets go by, and every index record is read exactly once.  Stores of a step are consecutive 16-byte hits from consecutive active lanes.
+//
+// A row with SEVERAL records of one target (a k-mer twice in a target: rare) is found after the fact - the next minimum equals T again - and the step is redone by
+// the general routine (per-row runs read from the lists, prefix sums over rows, opposite-strand records of a run in reverse list order: anchor.cpp:1023).
+//
+// Rows: the read's minimizers that have a list (compacted).  A read with more than 64 * RPL of them, or with more than 4096 minimizers, is left to the table
+// kernels (hao_query.cuh, hao_query3.cuh) through the overflow list.
+//
+// HBM traffic per anchor: 8 bytes in (once), 16 bytes out; LDS: 12 bytes per row (the two query words of the row's hits, its list length, its minimizer); no barriers.
+// The rows' registers are named variables (ROW(i) below), not arrays: the compiler turned arrays under this control flow into register tuples it copied whole.
+#pragma once
+#include "hao_query.cuh"
+
+#define HAO_MRG_SENT (~0ULL)                 // an exhausted row: rid = 2^28 - 1 (no read has it: n_total < 2^28), so it never wins the minimum before the end
+#define HAO_MRG_END 0xfffffffu
+#define HAO_MRG_MAXRPL 8
+
+template<int RPL> struct hao_seed4_lds {      // dynamic LDS per wave: q words uint2[64 * RPL], list length u16[64 * RPL], minimizer index u16[64 * RPL]
+	static_assert(RPL >= 1 && RPL <= HAO_MRG_MAXRPL, "rows per lane");
+	static constexpr uint32_t ROWS = 64u * RPL, PER_WAVE = ROWS * 12, TOTAL = 4 * PER_WAVE;
+};
+
+__device__ __forceinline__ uint32_t hao_mbcnt(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+// one hit (anchor.cpp:1021-1023, 1059-1076): y = the index record with the HIT's strand in bit 55; offset = target coordinate in the strand of the hit
+__device__ __forceinline__ hao_hit_t hao_mrg_hit(uint64_t y, uint32_t T, uint32_t rv, uint32_t tlen, uint2 qw)
+{
+	hao_hit_t h; h.w0 = T | rv << 31;
+	h.offset = rv ? tlen - 1 - (hao_info_pos(y) + 1 - hao_info_span(y)) : hao_info_pos(y);
+	h.self_offset = qw.x; h.cnt = qw.y;
+	return h;
+}
+
+// every row i < RPL: ROWS_DO(X) expands X(0) ... X(7) under `if constexpr`
+#define HAO_MRG_ROWS_DO(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+
+template<int RPL>
+__global__ __launch_bounds__(256) void seed_merge_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, const uint32_t *__restrict__ len, uint32_t *ovf_list, unsigned long long *ovf_cnt)
+{
+	constexpr uint32_t ROWS = hao_seed4_lds<RPL>::ROWS;
+	extern __shared__ uint32_t mg_smem[];
+	const int wv = threadIdx.x >> 6, lane = hao_lane();
+	uint2 *l_q = (uint2*)((char*)mg_smem + wv * hao_seed4_lds<RPL>::PER_WAVE);      // [ROWS] self_offset, cnt of the row's hits (anchor.cpp:1065-1076)
+	uint16_t *l_cnt = (uint16_t*)(l_q + ROWS);                                        // [ROWS] length of the row's list (< 4096: the index caps a list at 4095 records)
+	uint16_t *l_qi = l_cnt + ROWS;                                                     // [ROWS] the row's minimizer: index in the read's full minimizer list
+	const uint64_t r = (uint64_t)blockIdx.x * 4 + wv;
+	if (r == 0 && lane == 0) S.g_cnt[S.n_sel] = 0;
+	if (r >= S.n_sel) return;                                                           // (no workgroup barriers anywhere: waves are independent)
+	const uint64_t s = S.seg[r]; const uint32_t n = (uint32_t)(S.seg[r + 1] - s);
+	if (n == 0) { if (lane == 0) S.g_cnt[r] = 0; return; }
+	const uint64_t m0 = S.mz_off[S.rid_lo + r], li0 = m0 - S.mz0; const uint32_t nq = (uint32_t)(S.mz_off[S.rid_lo + r + 1] - m0);
+	// rows = the minimizers with a list, in order (stable compaction by ballot)
+	uint32_t nk = 0;
+	if (nq <= HAO_QTAB_CAP)
+		for (uint32_t b = 0; b < nq && nk <= ROWS; b += 64) {
+			const uint32_t q = b + lane; const bool ne = q < nq && S.s_n[li0 + q] != 0;
+			const unsigned long long bal = __ballot(ne); const uint32_t k = nk + hao_mbcnt(bal);
+			if (ne && k < ROWS) l_qi[k] = (uint16_t)q;
+			nk += (uint32_t)__popcll(bal);
+		}
+	if (nq > HAO_QTAB_CAP || nk > ROWS) { if (lane == 0) ovf_list[atomicAdd(ovf_cnt, 1ULL)] = (uint32_t)r; return; }      // left to the table kernels
+	HAO_LOCKSTEP();      // the rows' minimizers are in LDS: every lane reads the ones of its rows
+	// per row: head record (with the HIT's strand in bit 55), the record behind it (as the index holds it: the strand is folded in when it becomes the head - a row's
+	// load is then waited for a step after it was issued, not at once), both HAO_MRG_SENT-like (rid = HAO_MRG_END) beyond the list; index of the next record to load;
+	// records left to load | strand of the minimizer << 31
+#define HAO_MRG_DECL(i) uint64_t e0_##i = HAO_MRG_SENT, e1_##i = HAO_MRG_SENT, nx_##i = 0; uint32_t rz_##i = 0;
+	HAO_MRG_ROWS_DO(HAO_MRG_DECL)
+#define HAO_MRG_INIT(i) if constexpr (i < RPL) { \
+		const uint32_t row = i * 64 + lane; \
+		if (row < nk) { \
+			const uint32_t q = l_qi[row], c = S.s_n[li0 + q], z = hao_info_rev(S.mz_info[m0 + q]); \
+			const uint64_t st = S.s_start[li0 + q], zx = (uint64_t)z << 55; \
+			l_q[row] = make_uint2(S.q_pos[li0 + q], S.q_cnt[li0 + q]); l_cnt[row] = (uint16_t)c; \
+			e0_##i = sinfo[st] ^ zx; \
+			if (c > 1) e1_##i = sinfo[st + 1]; \
+			nx_##i = st + (c > 1 ? 2 : 1); rz_##i = (c > 2 ? c - 2 : 0) | z << 31; \
+		} }
+	HAO_MRG_ROWS_DO(HAO_MRG_INIT)
+	hao_hit_t *hits = S.hits + s; uint64_t *g_tmp = S.g_tmp + s; uint16_t *hq = S.hq ? S.hq + s : nullptr;
+	uint32_t run = 0, ngr = 0;
+#define HAO_MRG_MIN(i) if constexpr (i < RPL) mn = min(mn, (uint32_t)e0_##i & 0xfffffffu);
+#define HAO_MRG_NEXT(out) { uint32_t mn = HAO_MRG_END; HAO_MRG_ROWS_DO(HAO_MRG_MIN) out = hao_wave_min_u32(mn); }
+	uint32_t T; HAO_MRG_NEXT(T)
+	while (T != HAO_MRG_END) {
+		const uint32_t tlen = len[T];
+		uint32_t c0 = 0;
+#define HAO_MRG_MASK(i) unsigned long long h_##i = 0, v_##i = 0; if constexpr (i < RPL) { \
+			h_##i = __ballot(((uint32_t)e0_##i & 0xfffffffu) == T); v_##i = __ballot(((uint32_t)(e0_##i >> 32) & 0x800000u) != 0) & h_##i; \
+			c0 += (uint32_t)__popcll(h_##i & ~v_##i); }
+		HAO_MRG_ROWS_DO(HAO_MRG_MASK)      // h: rows whose head is a record of T; v: those of them on the opposite strand
+		const uint32_t base0 = run;
+		if (lane == 0) g_tmp[ngr] = (uint64_t)T << 32 | base0;
+		++ngr;
+		uint32_t p0 = base0, p1 = base0 + c0;
+#define HAO_MRG_EMIT(i) if constexpr (i < RPL) { if (h_##i) {      /* (wave-uniform) */ \
+			const uint64_t y = e0_##i; const unsigned long long f_ = h_##i & ~v_##i; \
+			const uint32_t rv = (uint32_t)(y >> 55) & 1, a_ = hao_mbcnt(f_), t_ = hao_mbcnt(h_##i); \
+			const uint32_t at = rv ? p1 + (t_ - a_) : p0 + a_; \
+			p0 += (uint32_t)__popcll(f_); p1 += (uint32_t)__popcll(v_##i); \
+			if (((uint32_t)y & 0xfffffffu) == T) { \
+				const uint32_t row = i * 64 + lane; \
+				hits[at] = hao_mrg_hit(y, T, rv, tlen, l_q[row]); \
+				if (hq) hq[at] = l_qi[row]; \
+				e0_##i = e1_##i ^ (uint64_t)(rz_##i >> 31) << 55;      /* advance the row */ \
+				if (rz_##i & 0x7fffffffu) { e1_##i = sinfo[nx_##i]; ++nx_##i; --rz_##i; } \
+				else e1_##i = HAO_MRG_SENT; \
+			} } }
+		HAO_MRG_ROWS_DO(HAO_MRG_EMIT)
+		run = p1;
+		uint32_t Tn; HAO_MRG_NEXT(Tn)
+		if (Tn == T) {
+			// ---- some row holds several records of T: redo the target in full (the rows that took part above stand one record behind their head) ----
+			// pass 1: forward-strand records of T over all rows (where the opposite strand starts)
+			uint32_t f_mine = 0;
+#define HAO_MRG_RUN(i, ...) { const uint32_t row = i * 64 + lane, c = l_cnt[row], left = rz_##i & 0x7fffffffu, z = rz_##i >> 31; \
+				const uint64_t *lst = sinfo + (nx_##i - (c - left));      /* the row's list */ \
+				const uint32_t held = (((uint32_t)e0_##i & 0xfffffffu) != HAO_MRG_END) + (((uint32_t)e1_##i & 0xfffffffu) != HAO_MRG_END), j0 = c - left - held - 1; uint32_t j1, nf = 0, nr = 0; \
+				for (j1 = j0; j1 < c && hao_info_rid(lst[j1]) == T; ++j1) { if (z ^ hao_info_rev(lst[j1])) ++nr; else ++nf; } \
+				__VA_ARGS__ }
+#define HAO_MRG_CNT(i) if constexpr (i < RPL) { if (h_##i >> lane & 1) HAO_MRG_RUN(i, f_mine += nf; (void)nr; (void)lst;) }
+			HAO_MRG_ROWS_DO(HAO_MRG_CNT)
+			uint32_t f_tot = hao_wave_incl_scan_u32(f_mine); f_tot = (uint32_t)__builtin_amdgcn_readlane((int)f_tot, 63);
+			p0 = base0; p1 = base0 + f_tot;
+#define HAO_MRG_REDO(i) if constexpr (i < RPL) { if (h_##i) { \
+				const bool mine = h_##i >> lane & 1; uint32_t nf_ = 0, nr_ = 0; \
+				if (mine) HAO_MRG_RUN(i, nf_ = nf; nr_ = nr; (void)lst;) \
+				const uint32_t inf = hao_wave_incl_scan_u32(nf_), inr = hao_wave_incl_scan_u32(nr_); \
+				const uint32_t tf = (uint32_t)__builtin_amdgcn_readlane((int)inf, 63), tr = (uint32_t)__builtin_amdgcn_readlane((int)inr, 63); \
+				if (mine) HAO_MRG_RUN(i, \
+					const uint2 qw = l_q[row]; const uint16_t qi = l_qi[row]; \
+					uint32_t af = p0 + inf - nf, ar = p1 + inr;      /* forward records in list order; opposite-strand records of the run in REVERSE list order (anchor.cpp:1023) */ \
+					for (uint32_t j = j0; j < j1; ++j) { \
+						const uint64_t y = lst[j] ^ (uint64_t)z << 55; const uint32_t rv = (uint32_t)(y >> 55) & 1, at = rv ? --ar : af++; \
+						hits[at] = hao_mrg_hit(y, T, rv, tlen, qw); \
+						if (hq) hq[at] = qi; \
+					} \
+					const uint64_t zx = (uint64_t)z << 55;      /* the row continues behind the run */ \
+					e0_##i = j1 < c ? lst[j1] ^ zx : HAO_MRG_SENT; e1_##i = j1 + 1 < c ? lst[j1 + 1] : HAO_MRG_SENT; \
+					const uint32_t loaded = min(c, j1 + 2); \
+					nx_##i = (uint64_t)(lst - sinfo) + loaded; rz_##i = (c - loaded) | z << 31;) \
+				p0 += tf; p1 += tr; } }
+			HAO_MRG_ROWS_DO(HAO_MRG_REDO)
+			run = p1;
+			HAO_MRG_NEXT(Tn)
+		}
+		T = Tn;
+	}
+	if (lane == 0) S.g_cnt[r] = ngr;
+#undef HAO_MRG_DECL
+#undef HAO_MRG_INIT
+#undef HAO_MRG_MIN
+#undef HAO_MRG_NEXT
+#undef HAO_MRG_MASK
+#undef HAO_MRG_EMIT
+#undef HAO_MRG_RUN
+#undef HAO_MRG_CNT
+#undef HAO_MRG_REDO
+}

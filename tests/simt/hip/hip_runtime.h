@@ -399,6 +399,9 @@ __forceinline__ int __builtin_amdgcn_ds_bpermute(int addr, int v, HAO_SIMT_SITE_
 	uint64_t pr; const uint64_t *s = hao_simt::exchange((uint32_t)v, &pr, HAO_SIMT_SITE); const int k = (addr >> 2) & 63;
 	return (pr >> k & 1) ? (int)(uint32_t)s[k] : 0;
 }
+// v_mbcnt_lo / v_mbcnt_hi: base + the mask's bits below this lane (lo: lanes 0-31 of the mask, hi: lanes 32-63)
+__forceinline__ unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned base) { const int me = hao_simt::lane_id(); return base + (unsigned)__builtin_popcount(me >= 32 ? mask : mask & ((1u << me) - 1)); }
+__forceinline__ unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned base) { const int me = hao_simt::lane_id(); return base + (me <= 32 ? 0u : (unsigned)__builtin_popcount(mask & ((1u << (me - 32)) - 1))); }
 __forceinline__ int __builtin_amdgcn_sbfe(int v, unsigned off, unsigned width) { const unsigned sh = 32 - width; return (int)((unsigned)v >> off << sh) >> sh; }
 __forceinline__ unsigned __builtin_amdgcn_ubfe(unsigned v, unsigned off, unsigned width) { return width >= 32 ? v >> off : (v >> off) & ((1u << width) - 1); }
 // v_bitop3_b32: bit i of the result = bit (a_i << 2 | b_i << 1 | c_i) of the truth table

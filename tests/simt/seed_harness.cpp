@@ -3,6 +3,7 @@
 // seed_segments_kernel, then the three tiers: 512 slots for every read, 1024 and 2048 slots for the reads that overflowed).  Called by tests/test_simt_seed_cpu.py
 // only, which compares the hits and the group lists with the oracle's restatement of minimizers_qgen0.
 #include "hao_query3.cuh"
+#include "hao_query4.cuh"
 #include <execinfo.h>
 #include <signal.h>
 static void simt_segv(int) { void *bt[40]; int n = backtrace(bt, 40); fprintf(stderr, "SIGSEGV in work-item %d of block %u\n", hao_simt::g.cur, blockIdx.x); backtrace_symbols_fd(bt, n, 2); _exit(3); }
@@ -16,6 +17,8 @@ int fail(char *err, int cap, const std::string &m) { snprintf(err, cap, "%s", m.
 
 // mode 0: what the library launches by default (QL instances; overflowing reads through seed_bin3_kernel); 1: HAO_SEED_NODIRECT (all tiers seed_bin_kernel, QL);
 // 2: HAO_SEED_NOQL (per-minimizer tables possibly in global memory: qcap_force > 0 caps the LDS table to force that path)
+// 3 / 4: the merge kernel (hao_query4.cuh, 8 / 2 rows per lane) takes every chosen read first; the reads it leaves (more rows than it holds) go through the table kernels as in mode 0
+// (stats[6] = reads left by the merge kernel)
 // blocks: the reads to run in the first launch (others keep empty output); returns 0 or 1 with a message
 extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t *mz_info, const uint64_t *lk, const uint32_t *wgt, const uint64_t *sinfo, const uint32_t *len, uint64_t n_total,
 		int mode, uint32_t qcap_force, const uint32_t *blocks, uint32_t n_blocks, int want_hq,
@@ -44,10 +47,29 @@ extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t 
 	unsigned long long ovf_cnt[2] = {0, 0}; uint32_t *ovf1 = S.ovf.data(), *ovf2 = S.ovf.data() + (n + 1);
 	const size_t lds_tile = std::max<size_t>((size_t)512 * (sizeof(hao_stage_t) + 4), 12 * 512), lds_q = 12 * (size_t)sa.qcap + 16;
 	size_t lds1 = (size_t)22 * 512 + lds_tile + lds_q, lds2 = (size_t)22 * 1024 + std::max<size_t>(lds_tile, 12 * 1024) + lds_q, lds3 = (size_t)22 * 2048 + std::max<size_t>(lds_tile, 12 * 2048) + lds_q;
-	if (mode == 0) { lds2 = hao_seed3_lds<10>::FIXED + lds_q; lds3 = hao_seed3_lds<11>::FIXED + lds_q; }
+	if (mode == 0 || mode >= 3) { lds2 = hao_seed3_lds<10>::FIXED + lds_q; lds3 = hao_seed3_lds<11>::FIXED + lds_q; }
 	const uint32_t *nil32 = nullptr; const unsigned long long *nil64 = nullptr;
+	std::vector<uint32_t> ovf0(n + 4, 0); unsigned long long ovf0_cnt = 0;
+	if (mode >= 3) {      // the merge kernel: a wave per read (four reads per block); only the chosen reads' blocks run, and of those only the chosen waves' output is kept clean below
+		std::vector<char> chosen(n + 4, 0); for (uint32_t b = 0; b < n_blocks; ++b) chosen[blocks[b]] = 1;
+		const size_t ldsm = mode == 3 ? hao_seed4_lds<8>::TOTAL : hao_seed4_lds<2>::TOTAL;
+		for (uint64_t g = 0; g < (n + 3) / 4; ++g) {
+			if (!(chosen[4 * g] | chosen[4 * g + 1] | chosen[4 * g + 2] | chosen[4 * g + 3])) continue;
+			std::function<void()> call;
+			if (mode == 3) call = [&] { seed_merge_kernel<8>(sa, sinfo, len, ovf0.data(), &ovf0_cnt); };
+			else call = [&] { seed_merge_kernel<2>(sa, sinfo, len, ovf0.data(), &ovf0_cnt); };
+			hao_simt::g.body = call; hao_simt::g.nthreads = 256; hao_simt::g.error.clear(); hao_simt::g.dyn_lds.assign(ldsm + 64, (char)0xa5);
+			blockDim = {256, 1, 1}; gridDim = {(unsigned)((n + 3) / 4), 1, 1}; blockIdx = {(unsigned)g, 0, 0};
+			if (!hao_simt::run_block()) return fail(err, errcap, hao_simt::g.error);
+		}
+		stats[6] = ovf0_cnt;
+		if (ovf0_cnt) {
+			std::function<void()> call = [&] { seed_bin_kernel<9, 1, 512, true>(sa, ovf0.data(), &ovf0_cnt, ovf1, &ovf_cnt[0]); };
+			if (launch((unsigned)ovf0_cnt, 256, lds1, call)) return fail(err, errcap, hao_simt::g.error);
+		}
+	}
 	// first launch: the chosen reads only (a block per read; blockIdx.x = the read)
-	{
+	if (mode < 3) {
 		hao_simt::g.body = nullptr;
 		for (uint32_t b = 0; b < n_blocks; ++b) {
 			std::function<void()> call;
@@ -61,7 +83,7 @@ extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t 
 	stats[2] = ovf_cnt[0];
 	if (ovf_cnt[0]) {
 		std::function<void()> call;
-		if (mode == 0) call = [&] { seed_bin3_kernel<10, 1, 4>(sa, ovf1, &ovf_cnt[0], ovf2, &ovf_cnt[1]); };
+		if (mode == 0 || mode >= 3) call = [&] { seed_bin3_kernel<10, 1, 4>(sa, ovf1, &ovf_cnt[0], ovf2, &ovf_cnt[1]); };
 		else if (mode == 1) call = [&] { seed_bin_kernel<10, 1, 512, true>(sa, ovf1, &ovf_cnt[0], ovf2, &ovf_cnt[1]); };
 		else call = [&] { seed_bin_kernel<10, 1, 512, false>(sa, ovf1, &ovf_cnt[0], ovf2, &ovf_cnt[1]); };
 		if (launch((unsigned)ovf_cnt[0], 256, lds2, call)) return fail(err, errcap, hao_simt::g.error);
@@ -69,7 +91,7 @@ extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t 
 	stats[3] = ovf_cnt[1];
 	if (ovf_cnt[1]) {
 		std::function<void()> call;
-		if (mode == 0) call = [&] { seed_bin3_kernel<11, 2, 4>(sa, ovf2, &ovf_cnt[1], (uint32_t*)nullptr, (unsigned long long*)nullptr); };
+		if (mode == 0 || mode >= 3) call = [&] { seed_bin3_kernel<11, 2, 4>(sa, ovf2, &ovf_cnt[1], (uint32_t*)nullptr, (unsigned long long*)nullptr); };
 		else if (mode == 1) call = [&] { seed_bin_kernel<11, 2, 512, true>(sa, ovf2, &ovf_cnt[1], (uint32_t*)nullptr, (unsigned long long*)nullptr); };
 		else call = [&] { seed_bin_kernel<11, 2, 512, false>(sa, ovf2, &ovf_cnt[1], (uint32_t*)nullptr, (unsigned long long*)nullptr); };
 		if (launch((unsigned)ovf_cnt[1], 256, lds3, call)) return fail(err, errcap, hao_simt::g.error);

@@ -12,8 +12,16 @@ pytestmark = pytest.mark.gpu
 
 SWITCHES = ["HAO_DBG_SEQ_CHAIN", "HAO_DBG_DP_NOSPEC", "HAO_DBG_DP_SEQTAIL", "HAO_DBG_DP_SERIAL", "HAO_DBG_SEL1", "HAO_DBG_SEQ_PRUNE",
             "HAO_DBG_SK_GENERIC", "HAO_DBG_SK_GCAP", "HAO_SPEC_MINCLS", "HAO_CHAIN_WPB", "HAO_SEED_TILE", "HAO_DBG_TINY_LANE",
-            "HAO_SEED_V2", "HAO_SEED_NOQL", "HAO_SEED_NODIRECT", "HAO_SEED_NU", "HAO_PT_SORT64", "HAO_PT_DIRECT"]
-VALUES = {"HAO_DBG_SK_GCAP": "1000", "HAO_SPEC_MINCLS": "0", "HAO_CHAIN_WPB": "4", "HAO_SEED_TILE": "1024", "HAO_SEED_NU": "8"}
+            "HAO_SEED_V2", "HAO_SEED_NOQL", "HAO_SEED_MERGE=0,HAO_SEED_NODIRECT=1", "HAO_SEED_MERGE=0,HAO_SEED_NU=8", "HAO_PT_SORT64", "HAO_PT_DIRECT",
+            "HAO_SEED_MERGE=0", "HAO_SEED_MERGE=4"]      # (the table kernels for every read - rounds 1 - 4 - and the merge kernel with 4 rows per lane: most reads of these sets then overflow to the table kernels)
+VALUES = {"HAO_DBG_SK_GCAP": "1000", "HAO_SPEC_MINCLS": "0", "HAO_CHAIN_WPB": "4", "HAO_SEED_TILE": "1024"}
+
+
+def _env_of(switch):
+    """'A' -> {A: VALUES.get(A, '1')}; 'A=x,B=y' -> {A: x, B: y}"""
+    if "=" not in switch:
+        return {switch: VALUES.get(switch, "1")}
+    return dict(kv.split("=") for kv in switch.split(","))
 
 
 @pytest.mark.parametrize("switch", SWITCHES)
@@ -22,7 +30,8 @@ def test_switch_keeps_results(name, switch):
     from hifiasm_amd.api import Engine
     rs, okw = scenario_reads(name)
     o = scenario_oracle(name)
-    os.environ[switch] = VALUES.get(switch, "1")
+    env = _env_of(switch)
+    os.environ.update(env)
     try:
         e = Engine(0, **okw)
         e.set_readset(rs)
@@ -37,7 +46,8 @@ def test_switch_keeps_results(name, switch):
                 bad += 1
         e.close()
     finally:
-        del os.environ[switch]
+        for k in env:
+            del os.environ[k]
     assert bad == 0, f"{switch}: {bad}/{rs.n} reads differ"
 
 

@@ -186,3 +186,45 @@ def test_seed_kernels_with_many_bins(n_targets, nq, list_len, mode):
     first = np.flatnonzero(np.concatenate([[True], tid[1:] != tid[:-1]]))
     assert int(g_cnt[0]) == first.size and (g_tmp[s:s + first.size] == (tid[first].astype(np.uint64) << np.uint64(32) | first.astype(np.uint64))).all()
     assert int(st[2]) == (1 if bins > 224 else 0) and int(st[3]) == (1 if bins > 736 else 0), (bins, st[2:4])
+
+
+# ---- the merge kernel (hao_query4.cuh): one wave per read, the read's position lists merged by target ----
+@pytest.mark.parametrize("name,step,mode", [("hifi", 1, 3), ("rr", 1, 3), ("nn", 1, 3), ("ont", 1, 3), ("edge", 1, 3), ("k40", 1, 3), ("hpc0", 1, 3), ("fz2", 1, 3), ("rr_heavy", 25, 3),
+                                            ("hifi", 1, 4), ("rr", 1, 4), ("ont", 2, 4), ("edge", 1, 4)])
+def test_merge_kernel_against_the_oracle(name, step, mode):
+    """mode 3: 8 rows per lane (reads with up to 512 minimizers that have a list), mode 4: 2 rows per lane - most reads of these scenarios then overflow to the table kernels,
+    which checks the hand-over (overflow list -> 512-slot launch -> the launches behind it)"""
+    rs, o, inp = seed_inputs(name)
+    blocks = np.arange(0, rs.n, step)
+    out = run_seed(rs, inp, blocks, mode=mode)
+    n_hits = check_reads(o, inp, blocks, *out[:5])
+    st = out[5]
+    print(f"[simt merge] {name} mode {mode}: {blocks.size} reads, {n_hits} hits, {int(st[0])} cross-lane operations, {int(st[1])} barriers; left to the table kernels {int(st[6])}, their overflow lists {int(st[2])} / {int(st[3])}")
+    assert n_hits > 500
+
+
+@pytest.mark.parametrize("n_targets,nq,list_len,mode,run_rate", [(150, 120, 40, 3, 0.08), (600, 200, 50, 3, 0.08), (2500, 260, 60, 3, 0.08), (40, 300, 60, 3, 0.5), (12, 500, 30, 3, 0.9), (600, 200, 50, 4, 0.08)])
+def test_merge_kernel_with_runs(n_targets, nq, list_len, mode, run_rate):
+    """fabricated indexes: many targets (many steps with a single hit), and lists in which a target comes several times in a row (the redo of a target with the
+    per-row runs, forward strand in list order, opposite strand in reverse list order) - up to lists that are a handful of long runs"""
+    mz, keys, off, pos, lens = fabricated_index(n_targets, nq, list_len, seed=7 * n_targets + mode, run_rate=run_rate)
+    wgt = seed_model.weight_table(60, 8)
+    want = seed_model.seed_hits_model(mz, keys, off, pos, lens, wgt, 0)
+    n = n_targets + 1
+    cnt = (off[1:] - off[:-1]).astype(np.uint64)
+    inp = dict(mz_off=np.concatenate([np.zeros(1, dtype=np.uint64), np.full(n, nq, dtype=np.uint64)]), info=np.ascontiguousarray(mz[:, 1]),
+               lk=np.concatenate([off[:-1].astype(np.uint64) | cnt << np.uint64(48), np.zeros(1, dtype=np.uint64)]), wgt=wgt.astype(np.uint32), sinfo=pos, len=lens)
+
+    class RS:
+        pass
+    rs = RS(); rs.n = n
+    seg, hits, g_tmp, g_cnt, hq, st = run_seed(rs, inp, [0], mode=mode)
+    s, e = int(seg[0]), int(seg[1])
+    print(f"[simt merge] fabricated {n_targets} targets, {nq} minimizers, run rate {run_rate}, mode {mode}: {e - s} hits in {np.unique(want[:, 0]).size} bins; left to the table kernels {int(st[6])}")
+    assert e - s == want.shape[0] and (hits[s:e] == want).all(), np.flatnonzero((hits[s:e] != want).any(axis=1))[:5]
+    tid = want[:, 0] & 0x7fffffff
+    first = np.flatnonzero(np.concatenate([[True], tid[1:] != tid[:-1]]))
+    assert int(g_cnt[0]) == first.size and (g_tmp[s:s + first.size] == (tid[first].astype(np.uint64) << np.uint64(32) | first.astype(np.uint64))).all()
+    m0 = 0; q = hq[s:e].astype(np.int64)
+    assert (((inp["info"][m0 + q] >> np.uint64(28)) & np.uint64((1 << 27) - 1)).astype(np.uint32) == want[:, 2]).all()
+    assert int(st[6]) == (1 if (mode == 4 and nq - nq // 13 > 128) else 0)
