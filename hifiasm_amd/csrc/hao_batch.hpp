@@ -337,8 +337,13 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			HIP_TRY(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
 			HIP_TRY(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
 			HIP_TRY(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-			if (c->sw.seed_merge == 4) hipLaunchKernelGGL(seed_merge_kernel<4>, dim3((unsigned)((n + 3) / 4)), dim3(256), hao_seed4_lds<4>::TOTAL, c->stream, sa_, (const uint64_t*)c->d_ix_sinfo.p, (const uint32_t*)c->d_len_all.p, ovf0, d_ovf0);
-			else hipLaunchKernelGGL(seed_merge_kernel<8>, dim3((unsigned)((n + 3) / 4)), dim3(256), hao_seed4_lds<8>::TOTAL, c->stream, sa_, (const uint64_t*)c->d_ix_sinfo.p, (const uint32_t*)c->d_len_all.p, ovf0, d_ovf0);
+			{
+				const uint64_t *sinfo_ = c->d_ix_sinfo.p; const uint32_t *len_ = c->d_len_all.p; const dim3 g_((unsigned)((n + 3) / 4)), b_(256);
+				if (c->sw.seed_merge == 4 && c->sw.seed_mbuf == 1) hipLaunchKernelGGL((seed_merge_kernel<4, 1>), g_, b_, hao_seed4_lds<4>::TOTAL, c->stream, sa_, sinfo_, len_, ovf0, d_ovf0);
+				else if (c->sw.seed_merge == 4) hipLaunchKernelGGL((seed_merge_kernel<4, 4>), g_, b_, hao_seed4_lds<4>::TOTAL, c->stream, sa_, sinfo_, len_, ovf0, d_ovf0);
+				else if (c->sw.seed_mbuf == 1) hipLaunchKernelGGL((seed_merge_kernel<8, 1>), g_, b_, hao_seed4_lds<8>::TOTAL, c->stream, sa_, sinfo_, len_, ovf0, d_ovf0);
+				else hipLaunchKernelGGL((seed_merge_kernel<8, 4>), g_, b_, hao_seed4_lds<8>::TOTAL, c->stream, sa_, sinfo_, len_, ovf0, d_ovf0);
+			}
 			HAO_CHECK_LAUNCH();
 			hipLaunchKernelGGL(k1, dim3((unsigned)n), dim3(256), lds1, c->stream, sa_, (const uint32_t*)ovf0, (const unsigned long long*)d_ovf0, ovf1, d_ovf);
 			HAO_CHECK_LAUNCH();

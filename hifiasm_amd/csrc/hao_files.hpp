@@ -244,7 +244,7 @@ static int hao_index_load_impl(hao_ctx *c, const char *prefix, int32_t *number_o
 	const uint64_t nk = ents.size(); uint64_t np = 0; for (const Ent &e : ents) np += e.cnt;
 	std::vector<uint64_t> keys(nk), start(nk), sinfo(np); std::vector<uint32_t> cnt(nk);
 	{ uint64_t o = 0; for (uint64_t i = 0; i < nk; ++i) { const Ent &e = ents[i]; keys[i] = e.hash; start[i] = o; cnt[i] = e.cnt; memcpy(sinfo.data() + o, pos[e.sub].data() + e.off, (size_t)e.cnt * 8); o += e.cnt; } }
-	HIP_TRY(c->d_ix_keys.reserve(nk + 1)); HIP_TRY(c->d_ix_start.reserve(nk + 1)); HIP_TRY(c->d_ix_cnt.reserve(nk + 1)); HIP_TRY(c->d_ix_sinfo.reserve(np + 1));
+	HIP_TRY(c->d_ix_keys.reserve(nk + 1)); HIP_TRY(c->d_ix_start.reserve(nk + 1)); HIP_TRY(c->d_ix_cnt.reserve(nk + 1)); HIP_TRY(c->d_ix_sinfo.reserve(np + 8));
 	if (nk) { HIP_TRY(hipMemcpyAsync(c->d_ix_keys.p, keys.data(), nk * 8, hipMemcpyHostToDevice, c->stream)); HIP_TRY(hipMemcpyAsync(c->d_ix_start.p, start.data(), nk * 8, hipMemcpyHostToDevice, c->stream));
 			  HIP_TRY(hipMemcpyAsync(c->d_ix_cnt.p, cnt.data(), nk * 4, hipMemcpyHostToDevice, c->stream)); }
 	if (np) HIP_TRY(hipMemcpyAsync(c->d_ix_sinfo.p, sinfo.data(), np * 8, hipMemcpyHostToDevice, c->stream));

@@ -39,13 +39,23 @@ __device__ __forceinline__ hao_hit_t hao_mrg_hit(uint64_t y, uint32_t T, uint32_
 	h.self_offset = qw.x; h.cnt = qw.y;
 	return h;
 }
+struct hao_rec4 { uint64_t a, b, c, d; };      // four index records: one 32-byte read of a row's list
 
 // every row i < RPL: ROWS_DO(X) expands X(0) ... X(7) under `if constexpr`
 #define HAO_MRG_ROWS_DO(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+// a row's bookkeeping word: records of the list not loaded yet (bits 0-11), records in the buffer behind the head (bits 12-15), strand of the minimizer (bit 31)
+#define HAO_MRG_REM(rz) ((rz) & 0xfffu)
+#define HAO_MRG_BC(rz) ((rz) >> 12 & 0xfu)
+#define HAO_MRG_Z(rz) ((rz) >> 31)
 
-template<int RPL>
-__global__ __launch_bounds__(256) void seed_merge_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, const uint32_t *__restrict__ len, uint32_t *ovf_list, unsigned long long *ovf_cnt)
+// BUF = 1: a row reads its list one 8-byte record at a time; BUF = 4: 32 bytes at a time.  A lane's reads are its own (the lists of a read's minimizers lie anywhere
+// in the index), so every read moves a whole cache line through the memory fabric however little of it is used - and a line comes around again only after the other
+// ~500 rows of every wave of the XCD had their turn, by when the 4 MB L2 has lost it: with 8-byte reads a 128-byte line crosses the fabric up to 16 times
+// (measured: 122 ms per configs[2] pass against 59 ms for the table kernels - 6 TB/s of line traffic for 0.4 TB/s of records), with 32-byte reads 4 times.
+template<int RPL, int BUF>
+__global__ __launch_bounds__(256, BUF == 4 ? (RPL == 8 ? 3 : 5) : 4) void seed_merge_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, const uint32_t *__restrict__ len, uint32_t *ovf_list, unsigned long long *ovf_cnt)
 {
+	static_assert(BUF == 1 || BUF == 4, "records per list read");
 	constexpr uint32_t ROWS = hao_seed4_lds<RPL>::ROWS;
 	extern __shared__ uint32_t mg_smem[];
 	const int wv = threadIdx.x >> 6, lane = hao_lane();
@@ -69,20 +79,25 @@ __global__ __launch_bounds__(256) void seed_merge_kernel(hao_seed_args S, const 
 		}
 	if (nq > HAO_QTAB_CAP || nk > ROWS) { if (lane == 0) ovf_list[atomicAdd(ovf_cnt, 1ULL)] = (uint32_t)r; return; }      // left to the table kernels
 	HAO_LOCKSTEP();      // the rows' minimizers are in LDS: every lane reads the ones of its rows
-	// per row: head record (with the HIT's strand in bit 55), the record behind it (as the index holds it: the strand is folded in when it becomes the head - a row's
-	// load is then waited for a step after it was issued, not at once), both HAO_MRG_SENT-like (rid = HAO_MRG_END) beyond the list; index of the next record to load;
-	// records left to load | strand of the minimizer << 31
-#define HAO_MRG_DECL(i) uint64_t e0_##i = HAO_MRG_SENT, e1_##i = HAO_MRG_SENT, nx_##i = 0; uint32_t rz_##i = 0;
+	// per row: head record e0 (with the HIT's strand in bit 55; rid = HAO_MRG_END beyond the list), the BUF records behind it as the index holds them (b0 first; the
+	// strand is folded in when a record becomes the head - a row's read is then waited for a step after it was issued, not at once), index of the next record to
+	// load, the bookkeeping word
+#define HAO_MRG_DECL(i) uint64_t e0_##i = HAO_MRG_SENT, b0_##i = HAO_MRG_SENT, b1_##i = HAO_MRG_SENT, b2_##i = HAO_MRG_SENT, b3_##i = HAO_MRG_SENT, nx_##i = 0; uint32_t rz_##i = 0;
 	HAO_MRG_ROWS_DO(HAO_MRG_DECL)
+	// (re)fill the buffer of row i from record index nx: up to BUF of the `left` records not loaded yet.  A 32-byte read may run up to three records past the list
+	// (into the next list or the slack behind the array: every allocation of the index keeps at least eight records of it); the count says which are real
+#define HAO_MRG_FILL(i, left, z) { const uint32_t take_ = min((uint32_t)BUF, (left)); \
+			if constexpr (BUF == 4) { const hao_rec4 v_ = *(const hao_rec4*)(sinfo + nx_##i); b0_##i = v_.a; b1_##i = v_.b; b2_##i = v_.c; b3_##i = v_.d; } \
+			else b0_##i = sinfo[nx_##i]; \
+			nx_##i += take_; rz_##i = ((left) - take_) | take_ << 12 | (z) << 31; }
 #define HAO_MRG_INIT(i) if constexpr (i < RPL) { \
 		const uint32_t row = i * 64 + lane; \
 		if (row < nk) { \
 			const uint32_t q = l_qi[row], c = S.s_n[li0 + q], z = hao_info_rev(S.mz_info[m0 + q]); \
-			const uint64_t st = S.s_start[li0 + q], zx = (uint64_t)z << 55; \
+			const uint64_t st = S.s_start[li0 + q]; \
 			l_q[row] = make_uint2(S.q_pos[li0 + q], S.q_cnt[li0 + q]); l_cnt[row] = (uint16_t)c; \
-			e0_##i = sinfo[st] ^ zx; \
-			if (c > 1) e1_##i = sinfo[st + 1]; \
-			nx_##i = st + (c > 1 ? 2 : 1); rz_##i = (c > 2 ? c - 2 : 0) | z << 31; \
+			e0_##i = sinfo[st] ^ (uint64_t)z << 55; nx_##i = st + 1; rz_##i = z << 31; \
+			if (c > 1) HAO_MRG_FILL(i, c - 1, z) \
 		} }
 	HAO_MRG_ROWS_DO(HAO_MRG_INIT)
 	hao_hit_t *hits = S.hits + s; uint64_t *g_tmp = S.g_tmp + s; uint16_t *hq = S.hq ? S.hq + s : nullptr;
@@ -110,9 +125,13 @@ __global__ __launch_bounds__(256) void seed_merge_kernel(hao_seed_args S, const 
 				const uint32_t row = i * 64 + lane; \
 				hits[at] = hao_mrg_hit(y, T, rv, tlen, l_q[row]); \
 				if (hq) hq[at] = l_qi[row]; \
-				e0_##i = e1_##i ^ (uint64_t)(rz_##i >> 31) << 55;      /* advance the row */ \
-				if (rz_##i & 0x7fffffffu) { e1_##i = sinfo[nx_##i]; ++nx_##i; --rz_##i; } \
-				else e1_##i = HAO_MRG_SENT; \
+				/* advance the row: the first buffered record becomes the head, the buffer moves up, and an emptied buffer is read again */ \
+				const uint32_t bc_ = HAO_MRG_BC(rz_##i), z_ = HAO_MRG_Z(rz_##i); \
+				e0_##i = bc_ ? b0_##i ^ (uint64_t)z_ << 55 : HAO_MRG_SENT; \
+				if constexpr (BUF == 4) { b0_##i = b1_##i; b1_##i = b2_##i; b2_##i = b3_##i; } \
+				if (bc_ > 1) rz_##i -= 1u << 12; \
+				else if (HAO_MRG_REM(rz_##i)) HAO_MRG_FILL(i, HAO_MRG_REM(rz_##i), z_) \
+				else rz_##i = z_ << 31; \
 			} } }
 		HAO_MRG_ROWS_DO(HAO_MRG_EMIT)
 		run = p1;
@@ -121,9 +140,9 @@ __global__ __launch_bounds__(256) void seed_merge_kernel(hao_seed_args S, const 
 			// ---- some row holds several records of T: redo the target in full (the rows that took part above stand one record behind their head) ----
 			// pass 1: forward-strand records of T over all rows (where the opposite strand starts)
 			uint32_t f_mine = 0;
-#define HAO_MRG_RUN(i, ...) { const uint32_t row = i * 64 + lane, c = l_cnt[row], left = rz_##i & 0x7fffffffu, z = rz_##i >> 31; \
+#define HAO_MRG_RUN(i, ...) { const uint32_t row = i * 64 + lane, c = l_cnt[row], left = HAO_MRG_REM(rz_##i), z = HAO_MRG_Z(rz_##i); \
 				const uint64_t *lst = sinfo + (nx_##i - (c - left));      /* the row's list */ \
-				const uint32_t held = (((uint32_t)e0_##i & 0xfffffffu) != HAO_MRG_END) + (((uint32_t)e1_##i & 0xfffffffu) != HAO_MRG_END), j0 = c - left - held - 1; uint32_t j1, nf = 0, nr = 0; \
+				const uint32_t held = (((uint32_t)e0_##i & 0xfffffffu) != HAO_MRG_END) + HAO_MRG_BC(rz_##i), j0 = c - left - held - 1; uint32_t j1, nf = 0, nr = 0; \
 				for (j1 = j0; j1 < c && hao_info_rid(lst[j1]) == T; ++j1) { if (z ^ hao_info_rev(lst[j1])) ++nr; else ++nf; } \
 				__VA_ARGS__ }
 #define HAO_MRG_CNT(i) if constexpr (i < RPL) { if (h_##i >> lane & 1) HAO_MRG_RUN(i, f_mine += nf; (void)nr; (void)lst;) }
@@ -143,10 +162,10 @@ __global__ __launch_bounds__(256) void seed_merge_kernel(hao_seed_args S, const 
 						hits[at] = hao_mrg_hit(y, T, rv, tlen, qw); \
 						if (hq) hq[at] = qi; \
 					} \
-					const uint64_t zx = (uint64_t)z << 55;      /* the row continues behind the run */ \
-					e0_##i = j1 < c ? lst[j1] ^ zx : HAO_MRG_SENT; e1_##i = j1 + 1 < c ? lst[j1 + 1] : HAO_MRG_SENT; \
-					const uint32_t loaded = min(c, j1 + 2); \
-					nx_##i = (uint64_t)(lst - sinfo) + loaded; rz_##i = (c - loaded) | z << 31;) \
+					/* the row continues behind the run */ \
+					e0_##i = j1 < c ? lst[j1] ^ (uint64_t)z << 55 : HAO_MRG_SENT; \
+					nx_##i = (uint64_t)(lst - sinfo) + min(c, j1 + 1); rz_##i = z << 31; \
+					if (j1 + 1 < c) HAO_MRG_FILL(i, c - (j1 + 1), z)) \
 				p0 += tf; p1 += tr; } }
 			HAO_MRG_ROWS_DO(HAO_MRG_REDO)
 			run = p1;
@@ -156,6 +175,7 @@ __global__ __launch_bounds__(256) void seed_merge_kernel(hao_seed_args S, const 
 	}
 	if (lane == 0) S.g_cnt[r] = ngr;
 #undef HAO_MRG_DECL
+#undef HAO_MRG_FILL
 #undef HAO_MRG_INIT
 #undef HAO_MRG_MIN
 #undef HAO_MRG_NEXT

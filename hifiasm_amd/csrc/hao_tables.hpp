@@ -563,7 +563,7 @@ static int hao_pt_run(hao_ctx *c)
 		const uint64_t m = c->ix_n_mz;
 		if (m >= (1ULL << 32)) { hao_set_err(c, "more than 2^32 minimizers on one device"); return HAO_EUNSUPP; }
 		const uint64_t pad = c->ix_pad = c->sw.ix_pad;      // (tests: the index's position records start `pad` entries into their buffer, so list starts exceed 2^32 on a small read set)
-		HIP_TRY(c->d_ix_sx.reserve(m + 1)); HIP_TRY(c->d_ix_sinfo.reserve(m + pad + 1)); HIP_TRY(c->w_oi.reserve(m + 1)); HIP_TRY(c->w_oi2.reserve(m + 1));
+		HIP_TRY(c->d_ix_sx.reserve(m + 1)); HIP_TRY(c->d_ix_sinfo.reserve(m + pad + 8)); HIP_TRY(c->w_oi.reserve(m + 1)); HIP_TRY(c->w_oi2.reserve(m + 1));      // (sinfo + 8: the merge kernel reads 32 bytes at a time, up to three records past the last list)
 		HIP_TRY(c->w_runid.reserve(m + 1)); HIP_TRY(c->d_ix_lk.reserve(m + 1));
 		// big inputs: 5 passes over hash bits 24 .. 63 + the fix-up of the 40-bit runs that hold two keys (hao_index_sort).  Small ones sort all 64 bits (rocprim's
 		// bit-range sort mis-sorts inputs of 5 k - 200 k elements on this ROCm, tests/test_gpu_rocprim.py); so does a retry when the fix-up's scratch ran out.
@@ -712,7 +712,7 @@ static int hao_pt_run(hao_ctx *c)
 		const size_t o_key = (size_t)maxm * 8, o_st = o_key + (size_t)maxk * 8, o_cnt = o_st + (size_t)maxk * 8, slot = (o_cnt + (size_t)maxk * 4 + 15) & ~(size_t)15;
 		auto local_slot = [&]() -> int {
 			if (nk_p) { hipLaunchKernelGGL(hao_add_const_kernel, dim3((unsigned)((nk_p + 255) / 256)), dim3(256), 0, c->stream, pst.p, nk_p, base); HAO_CHECK_LAUNCH(); }
-			HIP_TRY(c->d_ix_sinfo.reserve(m + pad + 1));      // (the sorted hashes themselves are not needed once the key table exists: only the 8-byte position records travel)
+			HIP_TRY(c->d_ix_sinfo.reserve(m + pad + 8));      // (+ 8: slack for the merge kernel's 32-byte reads; the sorted hashes themselves are not needed once the key table exists: only the 8-byte position records travel)
 			HIP_TRY(c->d_ix_keys.reserve(nk + 1)); HIP_TRY(c->d_ix_start.reserve(nk + 1)); HIP_TRY(c->d_ix_cnt.reserve(nk + 1));
 			HIP_TRY(cm.ag_tmp.reserve(slot * W + 16));
 			char *mine = cm.ag_tmp.p + slot * cm.rank;

@@ -69,6 +69,17 @@ def degenerate(rs, dseed, k, w):
     return synth.from_codes(out)
 
 
+def reads_of(seed):
+    """the case's read set, its generator arguments and the engine / oracle options"""
+    from hifiasm_amd import synth
+    d, okw = case(seed)
+    dg = d.pop("degenerate", 0)
+    rs = synth.dataset(**d)
+    if dg:
+        rs = degenerate(rs, dg, okw.get("k", 51), okw.get("w", 51)); d["degenerate"] = dg
+    return rs, d, okw
+
+
 def run(seed, emulated=True):
     """emulated: point hifiasm_amd.api at tests/simt's library (the caller restores it); False: whatever api loads - libhao.so on a GPU box (tests/test_gpu_fuzz.py)"""
     from hifiasm_amd import api, synth
@@ -77,11 +88,7 @@ def run(seed, emulated=True):
         import simt_build
         path = simt_build.build_lib()
         api.lib_path = lambda: path; api._LIB = None
-    d, okw = case(seed)
-    dg = d.pop("degenerate", 0)
-    rs = synth.dataset(**d)
-    if dg:
-        rs = degenerate(rs, dg, okw.get("k", 51), okw.get("w", 51)); d["degenerate"] = dg
+    rs, d, okw = reads_of(seed)
     o = oracle_py.Oracle(rs.codes, rs.code_off, **okw)
     e = api.Engine(0, **okw); e.set_readset(rs)
     bad = []
