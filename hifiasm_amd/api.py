@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "hao_ft_cnt", "hao_pt_get", "hao_ft_table", "hao_pt_table", "hao_hist", "hao_stats", "hao_sketch_batch",
     "hao_fetch_sketch", "hao_overlap_batch", "hao_fetch_seed_hits", "hao_fetch_overlaps", "hao_batch_totals",
     "hao_stage_times", "hao_pass_default", "hao_overlap_batch_ex", "hao_set_shard", "hao_dist_unique_id", "hao_dist_init",
-    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_selftest_big", "hao_selftest_sortbits", "hao_unpack_cigar", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits", "hao_exact_check", "hao_fetch_exact", "hao_window_ed_batch", "hao_index_save", "hao_index_load", "hao_next_slot", "hao_attach", "hao_window_trace_batch", "hao_delivery_digest",
+    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_selftest_big", "hao_selftest_sortbits", "hao_unpack_cigar", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits", "hao_exact_check", "hao_fetch_exact", "hao_window_ed_batch", "hao_index_save", "hao_index_load", "hao_next_slot", "hao_attach", "hao_window_trace_batch", "hao_delivery_digest", "hao_ft_passes",
 ]
 
 
@@ -87,6 +87,7 @@ def lib():
         L.hao_pt_table.argtypes = [vp, u64p, C.POINTER(u64p), C.POINTER(u64p), C.POINTER(u64p), u64p]
         L.hao_hist.argtypes = [vp, C.c_int, i64p]
         L.hao_stats.argtypes = [vp, i64p]
+        L.hao_ft_passes.argtypes = [vp]; L.hao_ft_passes.restype = C.c_int
         L.hao_sketch_batch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
         L.hao_fetch_sketch.argtypes = [vp, C.c_uint64, C.POINTER(vp), u64p]
         L.hao_overlap_batch.argtypes = [vp, C.c_uint64, C.c_uint64]
@@ -253,6 +254,10 @@ class Engine:
         self._ck(self.L.hao_stats(self.h, out), "hao_stats")
         names = ["ft_peak_hom", "ft_peak_het", "ft_cutoff", "max_n_chain", "hom_cov", "het_cov", "high_occ", "low_occ"]
         return dict(zip(names, [int(x) for x in out]))
+
+    def ft_passes(self):
+        """hash-range passes the last ha_ft_gen counted in"""
+        return int(self.L.hao_ft_passes(self.h))
 
     # ---- mz1_ha_sketch ----
     def sketch_batch(self, lo, hi, use_ft=True, sample_dist=None):

@@ -67,6 +67,8 @@ int hao_stats(hao_ctx *c, int64_t out[8])
 	return HAO_OK;
 }
 
+int hao_ft_passes(hao_ctx *c) { return c ? c->ft_passes_used : HAO_EINVAL; }
+
 int hao_pt_gen(hao_ctx *c, int32_t *hom_cov, int32_t *het_cov)
 {
 	if (!c) return HAO_EINVAL;

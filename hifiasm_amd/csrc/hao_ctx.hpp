@@ -59,7 +59,7 @@ struct hao_switches {
 	bool seedphase = false, qcphase = false, dp_stats = false, seq_chain = false, dp_seqtail = false, dp_nospec = false, dp_serial = false,
 		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, sk_v2 = false, dltime = false, sk_nofuse = false, pack_search = false, sk_select2 = false, seed_v2 = false, seed_pf = true, seed_noql = false, sort64 = false, seed_nodirect = false, tiny_lane = false, pt_direct = false;
 	static constexpr bool SK_SELECT2_DEFAULT = true;       // the thinning kernel the sketch runs when the environment says nothing: the wave kernel (round 4: green on the device against every repeat-rich scenario and the 5 Mb / 250 Mb repeat-rich fixtures)
-	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; unsigned long long ix_pad = 0, sort40_min = 1ULL << 23; int seed_nu = 4, fc_raw_every = 0, exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, seed_lds_pad = 0, arena_numa = 3, seed_tile = 512, seed_merge = 8, seed_mbuf = 4;
+	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; unsigned long long ix_pad = 0, sort40_min = 1ULL << 23; int seed_nu = 4, fc_raw_every = 0, exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, seed_lds_pad = 0, arena_numa = 3, seed_tile = 512, seed_merge = 8, seed_mbuf = 4, ft_passes = 0; long long ft_chunk_slots = 0;
 	void load() {
 		auto on = [](const char *n) { return getenv(n) != nullptr; };
 		seedphase = on("HAO_DBG_SEEDPHASE"); qcphase = on("HAO_DBG_QCPHASE"); dp_stats = on("HAO_DBG_DP_STATS"); seq_chain = on("HAO_DBG_SEQ_CHAIN");
@@ -68,6 +68,8 @@ struct hao_switches {
 		dltime = on("HAO_DBG_DLTIME");
 		if (const char *e = getenv("HAO_SEED_MERGE")) { const int v = atoi(e); seed_merge = v == 0 ? 0 : v == 4 ? 4 : 8; }      // the seed stage by merge (hao_query4.cuh; rows per lane), 0 = A/B: the table kernels for every read (rounds 1 - 4)
 		if (const char *e = getenv("HAO_SEED_MBUF")) seed_mbuf = atoi(e) == 1 ? 1 : 4;      // records per list read of the merge kernel (8 or 32 bytes)
+		if (const char *e = getenv("HAO_FT_PASSES")) ft_passes = std::max(0, atoi(e));      // ha_ft_gen in this many hash-range passes (0: as many as the free device memory asks for)
+		if (const char *e = getenv("HAO_FT_CHUNK_SLOTS")) ft_chunk_slots = std::max(0LL, atoll(e));      // (tests) k-mer slots hashed per chunk of reads in pass mode
 		seed_v2 = on("HAO_SEED_V2");      // A/B: the seed kernel with a wave-private, barrier-free scatter pass (hao_query2.cuh; round 4: bit-exact, 1.5 x slower - fewer waves per CU)
 		if (const char *e = getenv("HAO_DBG_IX_PAD")) ix_pad = strtoull(e, nullptr, 10);      // tests: unused position records in front of the index (list starts beyond 2^32 on a small read set)
 		if (const char *e = getenv("HAO_DBG_SORT40_MIN")) sort40_min = strtoull(e, nullptr, 10);      // tests on the CPU emulation only: the big-index path (40-bit sort + fix-up, gather, windowed scatter) from this many minimizers on (on the device rocprim's bit-range sort is trusted from 2^23 elements on, tests/test_gpu_rocprim.py)
@@ -112,7 +114,7 @@ struct hao_ctx {
 	// sharded mode: this engine holds reads [rid_base, rid_base + n_reads) of n_total; lengths of ALL reads are replicated
 	uint64_t rid_base = 0, n_total = 0; DevBuf<uint32_t> d_len_all; std::vector<uint32_t> h_len_all; struct hao_comm *comm = nullptr;
 	// ---- filter table ----
-	bool has_ft = false; int ft_peak_hom = -1, ft_peak_het = -1, ft_cutoff = 0; int64_t ft_hist[HAO_N_COUNTS];
+	bool has_ft = false; int ft_peak_hom = -1, ft_peak_het = -1, ft_cutoff = 0, ft_passes_used = 1; int64_t ft_hist[HAO_N_COUNTS];
 	std::vector<uint64_t> h_ft_keys; std::vector<int32_t> h_ft_vals;
 	DevBuf<uint64_t> d_ft_keys; DevBuf<int32_t> d_ft_vals; DevBuf<uint32_t> d_ft_bucket;
 	DevBuf<uint32_t> d_ft_hbit; DevBuf<unsigned long long> d_ft_hslot; int ft_hbits = 0;      // the filter table's hash view for the device lookups (hao_sketch.cuh: hao_ft_dev)

@@ -20,6 +20,7 @@ struct hao_kh_args {
 	const uint64_t *tile_off; const uint32_t *tile_ord; const uint32_t *n_runs;
 	const uint64_t *chunk_off; const uint8_t *scalar_flag; const uint64_t *kmer_off;
 	uint64_t rid_lo, n_sel; int k, hpc; uint64_t *out;
+	uint64_t ch0;      // first workgroup of this launch in chunk_off's numbering (ha_ft_gen in passes hashes a range of reads per launch)
 };
 
 __global__ __launch_bounds__(256) void kmer_hash_chunk_kernel(hao_kh_args a)
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(256) void kmer_hash_chunk_kernel(hao_kh_args a)
 	const int k = a.k, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int NE = HAO_KH_CHUNK + k + 1, NW = (NE + 63) / 64 + 1;
 	uint64_t *pl0 = (uint64_t*)smem, *pl1 = pl0 + NW; uint8_t *rcode = (uint8_t*)(pl1 + NW);
-	uint64_t ch = blockIdx.x, lo = 0, hi = a.n_sel;
+	uint64_t ch = blockIdx.x + a.ch0, lo = 0, hi = a.n_sel;
 	while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (a.chunk_off[m + 1] <= ch) lo = m + 1; else hi = m; }
 	const uint64_t r = lo;
 	if (a.scalar_flag[r]) return;

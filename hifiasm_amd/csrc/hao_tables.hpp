@@ -298,6 +298,35 @@ static int hao_bloom_filter(hao_ctx *c, uint64_t *in, uint64_t *alt, uint64_t n,
 // ha_ft_gen (htab.cpp:1136-1169): all HPC k-mers -> [Bloom replay at -f > 0, hao_index.cuh] -> counts -> histogram -> peaks ->
 // keep count >= cutoff -> filter table. + ha_opt_update_cov (CommandLines.cpp:411-418).
 // ---------------------------------------------------------------------------------------
+// ha_ft_gen in hash-range PASSES.  One pass holds every k-mer occurrence of the local reads at once: two buffers of 8 bytes per base, the largest allocations of the
+// whole engine (configs[3]'s share of one of eight GPUs: 15 Gbases -> 2 x 120 GB).  The reference never does (htab.cpp:707-882 counts pipeline batches into 4096
+// sub-tables, :147-151).  With P passes, pass j holds only the occurrences whose hash lies in the j-th P-th of every owner's range (exact counting: ranges of the
+// hash itself, so the passes' run lists concatenate into the sorted list one pass gives; through the Bloom filter: ranges of the SUB-TABLE index - hash bits 0 - 11 -
+// because a filter's state belongs to its sub-table and the replay needs a sub-table's occurrences in insertion order): the hashes are computed read chunk by read
+// chunk into a 2 GB scratch and the pass's share is appended, in order, to the pass buffer.  Peak = 2 x 8 B x bases / P + the scratch + 12 B per distinct k-mer.
+struct FtPassPred {      // occurrences of this pass: key (the hash, or its sub-table index) inside one of the W inclusive ranges bnd[2 d] .. bnd[2 d + 1]
+	const uint64_t *bnd; int W, low12;
+	__host__ __device__ bool operator()(const uint64_t &h) const {
+		if (h == UINT64_MAX) return false;
+		const uint64_t key = low12 ? (h & 4095) : h;
+		for (int d = 0; d < W; ++d) if (key >= bnd[2 * d] && key <= bnd[2 * d + 1]) return true;
+		return false;
+	}
+};
+#define HAO_FT_CHUNK_SLOTS (1ULL << 28)      // k-mer slots hashed per chunk of reads in pass mode (2 GB of scratch, twice)
+// passes needed so that the two occurrence buffers (+ 25 % for the sort's scratch and the run lists) fit into the free device memory; HAO_FT_PASSES forces a number (tests)
+static uint64_t hao_ft_pass_count(hao_ctx *c, uint64_t n_slots)
+{
+	if (c->sw.ft_passes > 0) return (uint64_t)c->sw.ft_passes;
+	size_t fr = 0, tot = 0;
+	if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return 1; }
+	const double need = 16.0 * (double)n_slots * 1.25 + (double)(1ULL << 30), have = 0.9 * (double)fr;
+	if (need <= have) return 1;
+	const double rest = have - 2.0 * 8.0 * (double)HAO_FT_CHUNK_SLOTS - (double)(2ULL << 30);      // what the chunk scratch leaves
+	if (rest <= 0) return 64;
+	return (uint64_t)std::min<double>(64.0, std::ceil(16.0 * (double)n_slots * 1.25 / rest));
+}
+
 static int hao_ft_run(hao_ctx *c)
 {
 	const uint64_t n = c->n_reads; const int k = c->opt.k;
@@ -309,8 +338,33 @@ static int hao_ft_run(hao_ctx *c)
 	const bool sharded = c->comm && c->comm->active();
 	const bool bloom = c->opt.bf_shift >= 21;                  // ha_ct_init / yak_bf_init: a filter needs n_shift > pre and >= 2^9 bits per sub-table (htab.cpp:83,153), else exact counting
 	uint64_t n_cnt = 0; uint64_t *cnt_in = nullptr, *cnt_alt = nullptr; uint32_t bias = 0;
+	uint64_t P = 1, pass_cap = 0;      // hash-range passes (1: every occurrence at once); occurrences a pass buffer holds
+	std::vector<uint64_t> h_kmer_off, h_chunk_off;      // pass mode: the per-read slot / workgroup offsets on the host (chunk boundaries)
+	DevBuf<uint64_t> ch_tmp, ch_sel, d_bnd;             // pass mode: one chunk's hashes, the chunk's share of the pass, the pass's ranges
+	// the hash kernels over reads [a, b) into out[kmer_off[r] - base] (base = kmer_off[a]: the chunk's first slot)
+	auto hash_reads = [&](uint64_t a, uint64_t b, uint64_t slot_base, uint64_t chunk_base, uint64_t n_ch, uint64_t n_sl, uint64_t *out, uint64_t *scalar_real) -> int {
+		if (scalar_real) *scalar_real = 0;
+		const auto s0 = std::lower_bound(slist.begin(), slist.end(), (uint32_t)a), s1 = std::lower_bound(slist.begin(), slist.end(), (uint32_t)b);
+		if (s0 != s1) {    // slots of N reads are upper bounds: sentinel-fill, count the real ones
+			if (int rc = hao_memset_big(c, out, 0xff, n_sl * 8)) return rc;
+			HIP_TRY(c->d_cursor.reserve(4)); HIP_TRY(hipMemsetAsync(c->d_cursor.p + 2, 0, 8, c->stream));
+			const uint32_t ns = (uint32_t)(s1 - s0);
+			hipLaunchKernelGGL(kmer_hash_scalar_kernel, dim3((ns + 63) / 64), dim3(64), 0, c->stream, c->d_packed.p, c->d_pk_off.p, c->d_len.p,
+							   c->d_nsite_off.p, c->d_nsite.p, c->d_scalar_list.p + (s0 - slist.begin()), ns, kmer_off.p, (uint64_t)0, k, c->opt.hpc, out - slot_base, c->d_cursor.p + 2);
+			HAO_CHECK_LAUNCH();
+			if (scalar_real) { HIP_TRY(hipMemcpyAsync(scalar_real, c->d_cursor.p + 2, 8, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+		}
+		if (n_ch) {
+			hao_kh_args a_;
+			a_.packed = c->d_packed.p; a_.pk_off = c->d_pk_off.p; a_.len = c->d_len.p; a_.tile_off = c->d_tile_off.p; a_.tile_ord = c->d_tile_ord.p; a_.n_runs = c->d_n_runs.p;
+			a_.chunk_off = kh_chunk_off.p; a_.scalar_flag = c->d_scalar_flag.p; a_.kmer_off = kmer_off.p; a_.rid_lo = 0; a_.n_sel = n; a_.k = k; a_.hpc = c->opt.hpc; a_.out = out - slot_base; a_.ch0 = chunk_base;
+			hipLaunchKernelGGL(kmer_hash_chunk_kernel, dim3((unsigned)n_ch), dim3(256), hao_kh_smem_bytes(k), c->stream, a_);
+			HAO_CHECK_LAUNCH();
+		}
+		return HAO_OK;
+	};
 	// everything up to the first exchange is local: in sharded mode its status travels with the first collective (ranks fail together)
-	auto local_hashes = [&]() -> int {
+	auto local_index = [&]() -> int {
 		if (n == 0) { hao_set_err(c, "no reads"); return HAO_EINVAL; }
 		if (c->n_bases >= (1ULL << 32) * 16) { hao_set_err(c, "read set too large for one device pass"); return HAO_EUNSUPP; }
 		if (int rc = hao_prepare_runs(c, 0, n, false, slist)) return rc;
@@ -323,39 +377,84 @@ static int hao_ft_run(hao_ctx *c)
 		HIP_TRY(hipMemcpyAsync(&n_chunks, kh_chunk_off.p + n, 8, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		c->timer.mark("ft_index");
-		HIP_TRY(kh.reserve(n_slots + 1)); HIP_TRY(kh2.reserve(n_slots + 1));
-		n_real = n_slots;
-		if (!slist.empty()) {    // slots of N reads are upper bounds: sentinel-fill, count the real ones
-			if (int rc = hao_memset_big(c, kh.p, 0xff, n_slots * 8)) return rc;
-			HIP_TRY(c->d_cursor.reserve(2)); HIP_TRY(hipMemsetAsync(c->d_cursor.p, 0, 8, c->stream));
-			hipLaunchKernelGGL(kmer_hash_scalar_kernel, dim3((unsigned)((slist.size() + 63) / 64)), dim3(64), 0, c->stream, c->d_packed.p, c->d_pk_off.p, c->d_len.p,
-							   c->d_nsite_off.p, c->d_nsite.p, c->d_scalar_list.p, (uint32_t)slist.size(), kmer_off.p, (uint64_t)0, k, c->opt.hpc, kh.p, c->d_cursor.p);
-			HAO_CHECK_LAUNCH();
-			uint64_t scalar_real = 0, scalar_slots = 0;
-			HIP_TRY(hipMemcpyAsync(&scalar_real, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+		if (bloom && c->opt.bf_shift - 21 + 12 > 31) { hao_set_err(c, "bf_shift > 40 is not supported"); return HAO_EUNSUPP; }
+		return HAO_OK;
+	};
+	const int index_rc = local_index();
+	if (index_rc && !sharded) return index_rc;
+	P = index_rc ? 1 : hao_ft_pass_count(c, n_slots);
+	if (sharded) {      // every rank runs the same number of passes (the exchanges are collective): the largest any rank needs; the status of the local work travels along
+		hao_comm &cm = *c->comm;
+		if (int rc = hao_shard_layout_check(c, cm, index_rc)) return rc;
+		std::vector<uint64_t> all; if (int rc = hao_comm_allgather_u64(c, cm, P, all, 0)) return rc;
+		for (uint64_t v : all) P = std::max(P, v);
+	}
+	c->ft_passes_used = (int)P;
+	// one pass's occurrences into kh[0 .. n_slots) (P == 1: every occurrence, in its slot, sentinels where a read with N has fewer k-mers than bases)
+	auto local_hashes = [&](uint64_t pass) -> int {
+		if (P == 1) {
+			HIP_TRY(kh.reserve(n_slots + 1)); HIP_TRY(kh2.reserve(n_slots + 1));
+			n_real = n_slots;
+			uint64_t scalar_real = 0;
+			if (int rc = hash_reads(0, n, 0, 0, n_chunks, n_slots, kh.p, &scalar_real)) return rc;
+			if (!slist.empty()) { uint64_t scalar_slots = 0; for (uint32_t r : slist) scalar_slots += c->h_len[r]; n_real = n_slots - scalar_slots + scalar_real; }
+		} else {
+			if (pass == 0) {
+				h_kmer_off.resize(n + 1); h_chunk_off.resize(n + 1);
+				HIP_TRY(hipMemcpyAsync(h_kmer_off.data(), kmer_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+				HIP_TRY(hipMemcpyAsync(h_chunk_off.data(), kh_chunk_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+				HIP_TRY(hipStreamSynchronize(c->stream));
+				const uint64_t all_slots = h_kmer_off[n];
+				pass_cap = std::min<uint64_t>(all_slots, all_slots / P + all_slots / (4 * P) + (1ULL << 20));      // (hashes are uniform: a P-th + 25 %; a tiny input simply gets room for everything)
+				uint64_t biggest = 0; for (uint64_t r = 0; r < n; ++r) biggest = std::max(biggest, h_kmer_off[r + 1] - h_kmer_off[r]);
+				const uint64_t chs = std::min<uint64_t>(all_slots, std::max<uint64_t>(c->sw.ft_chunk_slots ? (uint64_t)c->sw.ft_chunk_slots : HAO_FT_CHUNK_SLOTS, biggest));
+				HIP_TRY(ch_tmp.reserve_exact(chs + 1)); HIP_TRY(ch_sel.reserve_exact(chs + 1)); HIP_TRY(kh.reserve_exact(pass_cap + 1)); HIP_TRY(kh2.reserve_exact(pass_cap + 1));
+				HIP_TRY(d_bnd.reserve(2 * 4096 + 2)); HIP_TRY(c->d_cursor.reserve(4));
+			}
+			// the pass's ranges, one per owner (a rank's share of the hash space / of the 4096 sub-tables), as the partition below cuts them
+			const int W = sharded ? c->comm->world : 1; std::vector<uint64_t> bnd(2 * (size_t)W);
+			for (int d = 0; d < W; ++d) {
+				unsigned __int128 lo, hi;      // the owner's keys [lo, hi)
+				if (!bloom) { lo = d == 0 ? 0 : (((unsigned __int128)d << 64) / (unsigned)W); hi = d + 1 == W ? ((unsigned __int128)1 << 64) : (((unsigned __int128)(d + 1) << 64) / (unsigned)W); }
+				else { lo = ((uint64_t)d * 4096 + W - 1) / W; hi = d + 1 == W ? 4096 : ((uint64_t)(d + 1) * 4096 + W - 1) / W; }
+				const unsigned __int128 span = hi - lo, a_ = lo + span * pass / P, b_ = lo + span * (pass + 1) / P;
+				if (a_ == b_) { bnd[2 * d] = 1; bnd[2 * d + 1] = 0; } else { bnd[2 * d] = (uint64_t)a_; bnd[2 * d + 1] = (uint64_t)(b_ - 1); }
+			}
+			HIP_TRY(hipMemcpyAsync(d_bnd.p, bnd.data(), bnd.size() * 8, hipMemcpyHostToDevice, c->stream));
+			const FtPassPred pred{d_bnd.p, W, bloom ? 1 : 0};
+			uint64_t cnt = 0; const uint64_t chs = ch_tmp.cap - 1;
+			for (uint64_t a = 0; a < n; ) {
+				uint64_t b = a + 1; while (b < n && h_kmer_off[b + 1] - h_kmer_off[a] <= chs) ++b;      // reads [a, b): at most chs slots (one read always fits)
+				const uint64_t sl = h_kmer_off[b] - h_kmer_off[a], nch = h_chunk_off[b] - h_chunk_off[a];
+				if (sl) {
+					if (int rc = hash_reads(a, b, h_kmer_off[a], h_chunk_off[a], nch, sl, ch_tmp.p, nullptr)) return rc;
+					size_t tb = 0; uint64_t sel = 0;
+					HIP_TRY(rocprim::select(nullptr, tb, ch_tmp.p, ch_sel.p, (uint64_t*)c->d_cursor.p, (size_t)sl, pred, c->stream)); HIP_TRY(hao_tmp(c, tb));
+					HIP_TRY(rocprim::select(c->d_tmp.p, tb, ch_tmp.p, ch_sel.p, (uint64_t*)c->d_cursor.p, (size_t)sl, pred, c->stream));
+					HIP_TRY(hipMemcpyAsync(&sel, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+					HIP_TRY(hipStreamSynchronize(c->stream));
+					if (cnt + sel > pass_cap) { hao_set_err(c, "ha_ft_gen: a hash-range pass holds more k-mer occurrences than its buffer (set HAO_FT_PASSES higher)"); return HAO_ENOMEM; }
+					if (sel) HIP_TRY(hipMemcpyAsync(kh.p + cnt, ch_sel.p, sel * 8, hipMemcpyDeviceToDevice, c->stream));
+					cnt += sel;
+				}
+				a = b;
+			}
 			HIP_TRY(hipStreamSynchronize(c->stream));
-			for (uint32_t r : slist) scalar_slots += c->h_len[r];
-			n_real = n_slots - scalar_slots + scalar_real;
-		}
-		if (n_chunks) {
-			hao_kh_args a;
-			a.packed = c->d_packed.p; a.pk_off = c->d_pk_off.p; a.len = c->d_len.p; a.tile_off = c->d_tile_off.p; a.tile_ord = c->d_tile_ord.p; a.n_runs = c->d_n_runs.p;
-			a.chunk_off = kh_chunk_off.p; a.scalar_flag = c->d_scalar_flag.p; a.kmer_off = kmer_off.p; a.rid_lo = 0; a.n_sel = n; a.k = k; a.hpc = c->opt.hpc; a.out = kh.p;
-			hipLaunchKernelGGL(kmer_hash_chunk_kernel, dim3((unsigned)n_chunks), dim3(256), hao_kh_smem_bytes(k), c->stream, a);
-			HAO_CHECK_LAUNCH();
+			n_slots = cnt; n_real = cnt;      // (no sentinels in a pass's stream)
 		}
 		c->timer.mark("ft_hash");
-		n_cnt = n_slots; cnt_in = kh.p; cnt_alt = kh2.p;
+		n_cnt = n_slots; cnt_in = kh.p; cnt_alt = kh2.p; bias = 0;
 		if (bloom) {
-			const int xb = c->opt.bf_shift - 21;                   // log2 of the 512-bit blocks per sub-table
-			if (12 + xb > 31) { hao_set_err(c, "bf_shift > 40 is not supported"); return HAO_EUNSUPP; }
 			if (!sharded) { if (int rc = hao_bloom_filter(c, kh.p, kh2.p, n_slots, &cnt_in, &cnt_alt, &n_cnt)) return rc; }
 			bias = 1;                                                 // the entry is created with count 1, then incremented (htab.cpp:201-205)
 			c->timer.mark("ft_bloom");
 		}
 		return HAO_OK;
 	};
-	const int hash_rc = local_hashes();
+	DevBuf<uint64_t> all_keys; DevBuf<uint32_t> all_cnt; uint64_t all_unique = 0; int64_t all_hist[HAO_N_COUNTS];      // pass mode: the passes' run lists, one after the other
+	memset(all_hist, 0, sizeof(all_hist));
+	for (uint64_t pass = 0; pass < P; ++pass) {
+	const int hash_rc = local_hashes(pass);
 	if (hash_rc && !sharded) return hash_rc;
 	if (!sharded) {
 		// sentinels (0xff..ff) sort to the end: only the first n_real entries are real k-mers
@@ -365,11 +464,11 @@ static int hao_ft_run(hao_ctx *c)
 		// hash-range partition: sort local hashes, cut at i * 2^64 / world, all-to-all-v, count the owned range.
 		// Local phases are lambdas whose status travels with the next collective (hao_comm.hpp): ranks fail together, nobody hangs.
 		hao_comm &cm = *c->comm; const int W = cm.world;
-		if (int rc = hao_shard_layout_check(c, cm, hash_rc)) return rc;
 		uint64_t *loc = kh.p; uint64_t n_loc = n_real;
 		std::vector<uint64_t> tg(W), cut(W + 1, 0), scnt(W, 0), sdisp(W, 0), rcnt;
 		DevBuf<uint64_t> dt, dc, rv, rv2;
 		auto local_partition = [&]() -> int {
+			if (hash_rc) return hash_rc;
 			HIP_TRY(dt.reserve(W + 1)); HIP_TRY(dc.reserve(W + 1));
 			if (!bloom) {
 				if (n_slots) {
@@ -386,7 +485,7 @@ static int hao_ft_run(hao_ctx *c)
 				// the filter's blocks (and every copy of a k-mer) are determined by the LOW hash bits: partition by sub-table (low 12 bits), with a
 				// STABLE sort on those bits only, so that each piece stays in (read, position) order; pieces arrive in rank order = global read order
 				if (n_slots) {
-					HIP_TRY(c->d_cursor.reserve(2)); size_t tb = 0;
+					HIP_TRY(c->d_cursor.reserve(4)); size_t tb = 0;
 					HIP_TRY(rocprim::select(nullptr, tb, kh.p, kh2.p, (uint64_t*)c->d_cursor.p, n_slots, NotSentinel(), c->stream)); HIP_TRY(hao_tmp(c, tb));
 					HIP_TRY(rocprim::select(c->d_tmp.p, tb, kh.p, kh2.p, (uint64_t*)c->d_cursor.p, n_slots, NotSentinel(), c->stream));
 					HIP_TRY(hipMemcpyAsync(&n_loc, c->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
@@ -409,15 +508,15 @@ static int hao_ft_run(hao_ctx *c)
 		};
 		if (int rc = hao_comm_exchange_counts(c, cm, scnt, rcnt, local_partition())) return rc;
 		uint64_t n_recv = 0; for (int d = 0; d < W; ++d) n_recv += rcnt[d];
-		// peak memory: the hash buffers are the largest allocations of the whole engine (8 B per base each).  Only the sorted local piece and the receive
-		// buffer exist during the exchange; the second receive-side buffer (sort scratch) is allocated after the local piece is gone.
-		auto local_recv_bufs = [&]() -> int { if (loc == kh.p) kh2.release(); else kh.release(); HIP_TRY(rv.reserve(n_recv + 1)); return HAO_OK; };
+		// peak memory: the hash buffers are the largest allocations of the whole engine (8 B per base each, divided by the number of passes).  Only the sorted local
+		// piece and the receive buffer exist during the exchange; the second receive-side buffer (sort scratch) is allocated after the local piece is gone.
+		auto local_recv_bufs = [&]() -> int { if (P == 1) { if (loc == kh.p) kh2.release(); else kh.release(); } HIP_TRY(rv.reserve(n_recv + 1)); return HAO_OK; };
 		if (int rc = hao_comm_agree(c, cm, local_recv_bufs())) return rc;
 		if (int rc = hao_comm_alltoallv_u64(c, cm, loc, scnt, sdisp, rv.p, rcnt)) return rc;
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		c->timer.mark("ft_exchange");
 		auto local_count = [&]() -> int {
-			kh.release(); kh2.release();
+			if (P == 1) { kh.release(); kh2.release(); }      // (pass mode keeps its two pass buffers for the next pass)
 			HIP_TRY(rv2.reserve(n_recv + 1));
 			uint64_t *ci = rv.p, *ca = rv2.p, n_ci = n_recv;
 			if (bloom) { if (int rc = hao_bloom_filter(c, rv.p, rv2.p, n_recv, &ci, &ca, &n_ci)) return rc; }
@@ -425,6 +524,33 @@ static int hao_ft_run(hao_ctx *c)
 		};
 		if (int rc = hao_comm_allreduce_i64(c, cm, c->ft_hist, HAO_N_COUNTS, local_count())) return rc;
 		rv.release(); rv2.release(); dt.release(); dc.release();
+	}
+	if (P > 1) {      // this pass's runs behind the earlier ones
+		if (all_unique + n_unique + 1 > all_keys.cap) {
+			const uint64_t want = std::max<uint64_t>((all_unique + n_unique) * (pass + 1 < P ? 2 : 1) + 64, (n_unique + 64) * (P - pass));
+			DevBuf<uint64_t> nk_; DevBuf<uint32_t> nc_; HIP_TRY(nk_.reserve_exact(want)); HIP_TRY(nc_.reserve_exact(want));
+			if (all_unique) { HIP_TRY(hipMemcpyAsync(nk_.p, all_keys.p, all_unique * 8, hipMemcpyDeviceToDevice, c->stream)); HIP_TRY(hipMemcpyAsync(nc_.p, all_cnt.p, all_unique * 4, hipMemcpyDeviceToDevice, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+			std::swap(all_keys, nk_); std::swap(all_cnt, nc_); nk_.release(); nc_.release();
+		}
+		if (n_unique) { HIP_TRY(hipMemcpyAsync(all_keys.p + all_unique, ukeys.p, n_unique * 8, hipMemcpyDeviceToDevice, c->stream)); HIP_TRY(hipMemcpyAsync(all_cnt.p + all_unique, ucnt.p, n_unique * 4, hipMemcpyDeviceToDevice, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+		all_unique += n_unique;
+		for (int i = 0; i < HAO_N_COUNTS; ++i) all_hist[i] += c->ft_hist[i];
+	}
+	}      // passes
+	if (P > 1) {
+		kh.release(); kh2.release(); ch_tmp.release(); ch_sel.release(); ukeys.release(); ucnt.release();
+		if (bloom && all_unique) {      // passes own sub-tables, not hash ranges: the concatenation is not sorted by key yet
+			DevBuf<uint64_t> k2; DevBuf<uint32_t> c2; HIP_TRY(k2.reserve_exact(all_unique + 1)); HIP_TRY(c2.reserve_exact(all_unique + 1));
+			size_t tb = 0; rocprim::double_buffer<uint64_t> dk(all_keys.p, k2.p); rocprim::double_buffer<uint32_t> dv(all_cnt.p, c2.p);
+			HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, dk, dv, all_unique, 0, 64, c->stream)); HIP_TRY(hao_tmp(c, tb));
+			HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, dk, dv, all_unique, 0, 64, c->stream));
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			if (dk.current() != all_keys.p) std::swap(all_keys, k2);
+			if (dv.current() != all_cnt.p) std::swap(all_cnt, c2);
+			k2.release(); c2.release();
+		}
+		std::swap(ukeys, all_keys); std::swap(ucnt, all_cnt); n_unique = all_unique;
+		memcpy(c->ft_hist, all_hist, sizeof(all_hist));
 	}
 	c->timer.mark("ft_count");
 	kh.release(); kh2.release();

@@ -113,6 +113,9 @@ int hao_pt_table(hao_ctx *c, uint64_t *n_keys, const uint64_t **keys, const uint
 int hao_hist(hao_ctx *c, int which /*0 = all k-mers (ft), 1 = minimizers (pt)*/, int64_t cnt[4096]);
 /* out[0..7] = ft peak_hom, ft peak_het, ft cutoff, max_n_chain, hom_cov, het_cov, high_occ, low_occ */
 int hao_stats(hao_ctx *c, int64_t out[8]);
+/* hash-range passes the last hao_ft_gen counted in (1: every k-mer occurrence of the local reads at once, 2 x 8 bytes per base; more when that does not fit the
+   free device memory, or as HAO_FT_PASSES says: htab.cpp:707-882 never holds all occurrences either); < 0: error */
+int hao_ft_passes(hao_ctx *c);
 
 /* mz1_ha_sketch (sketch.cpp:454-579) for reads [rid_lo, rid_hi): results stay on the device;
  * use_ft = 0 passes hf = NULL; sample_dist <= w disables the high-count thinning (sketch.cpp:575).

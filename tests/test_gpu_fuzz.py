@@ -1,29 +1,80 @@
 """Random small workloads and option mixes through libhao.so on the device against the oracle: the cases of tests/simt_fuzz.py (k 11 - 63, w 3 - 99, HPC on / off, ONT
 mode, Bloom filters, band widths, --hg-size, max_n_chain, N bases, planted repeats, reads of 300 - 7000 bases; seeds from 1000 on mix hand-made trouble into the
 reads: lengths around k and k + w, exact copies, reverse complements, homopolymer / tandem stretches, N runs, all-N and spliced reads).  Every read's minimizers,
-seed hits, overlap list, fake cigars and chained hits, plus the coverage peaks of both tables (anchor.cpp:2302 h_ec_lchain, Assembly.cpp:996-1010 / 2055-2090 the two
+seed hits, overlap list, fake cigars and chained hits, plus the coverage peaks of both tables (anchor.cpp:2302 h_ec_lchain; Assembly.cpp:996-1010 / 2055-2090: the two
 call sites' option sets are what `okw` varies).
 
-Both seed families of the emulator's sweeps (1 - 120, 200 - 399 without, 1000 - 1159 with degenerate reads) are here in full - in particular the ~70 cases the
-emulation never finished inside its time limit (small repeat-dense genomes whose groups of thousands of hits go through chain_dp_kernel; UNFINISHED_ON_THE_EMULATOR
-names them): on a device the whole sweep is a few minutes."""
+All 480 cases of the emulator's three sweeps (seeds 1 - 120, 200 - 399, and 1000 - 1159 with degenerate reads).  412 of them run against the oracle live.  The other 68
+are the repeat-dense ones - groups of thousands of seed hits through the chain DP - for which the ORACLE needs from seconds to twenty minutes of a CPU core (which is
+why 58 of them, UNFINISHED_ON_THE_EMULATOR, never gave an answer inside the emulator sweeps' time limits: the DP-heavy cases were the unverified ones): their
+per-read digests were computed once by the oracle (tests/golden/make_fuzz_golden.py -> tests/golden/fuzz_heavy.npz, 9.1 M overlaps) and the device's results are
+digested the same way (helpers.digest_hits / digest_result) and compared."""
+import os
+
+import numpy as np
 import pytest
 
 import simt_fuzz
+from helpers import GOLDEN, crc, digest_hits, digest_result
 
 pytestmark = pytest.mark.gpu
 
-# the cases of those sweeps for which the emulation never printed an answer inside its time limit (from the sweep logs of round 4; 1001, 1026, 1062 and 1104 also after
-# 40 minutes): the DP-heavy ones, first verified here
+# the cases of the emulator sweeps for which the emulation never printed an answer inside its time limit (round 4's sweep logs; 1001, 1026, 1062, 1104 also after 40 minutes)
 UNFINISHED_ON_THE_EMULATOR = (31, 43, 44, 46, 59, 71, 80, 98, 103, 105, 111, 120, 218, 223, 236, 240, 255, 282, 300, 325, 328, 343, 345, 355, 357, 368, 370, 378, 385, 394,
                               1001, 1004, 1013, 1017, 1026, 1032, 1034, 1037, 1055, 1062, 1069, 1071, 1085, 1086, 1088, 1091, 1092, 1095, 1104, 1108, 1109, 1112, 1117,
                               1120, 1125, 1132, 1141, 1151)
+# oracle time above two seconds here (tests/golden/make_fuzz_golden.py made their digests)
+HEAVY = (4, 11, 27, 31, 43, 44, 46, 48, 54, 59, 71, 80, 85, 98, 103, 105, 111, 120, 218, 223, 236, 240, 255, 282, 300, 312, 325, 328, 343, 345, 355, 357, 368, 370, 374, 378, 385,
+         394, 1001, 1004, 1017, 1026, 1029, 1032, 1034, 1037, 1041, 1055, 1060, 1062, 1069, 1071, 1084, 1085, 1086, 1088, 1091, 1092, 1095, 1104, 1108, 1109, 1117, 1120, 1125,
+         1132, 1141, 1151)
 SEEDS = list(range(1, 121)) + list(range(200, 400)) + list(range(1000, 1160))
-assert set(UNFINISHED_ON_THE_EMULATOR) <= set(SEEDS)
+LIGHT = [s for s in SEEDS if s not in HEAVY]
+assert set(HEAVY) <= set(SEEDS) and len(LIGHT) + len(HEAVY) == 480
 
 
-@pytest.mark.parametrize("seed", [pytest.param(s, id=f"{s}{'-new' if s in UNFINISHED_ON_THE_EMULATOR else ''}") for s in SEEDS])
+def _id(s):
+    return f"{s}{'-new' if s in UNFINISHED_ON_THE_EMULATOR else ''}"
+
+
+@pytest.mark.parametrize("seed", [pytest.param(s, id=_id(s)) for s in LIGHT])
 def test_random_workload_on_device(seed):
     d, okw, n, tot, bad = simt_fuzz.run(seed, emulated=False)
     print(f"[gpu fuzz] seed {seed}: {n} reads, {tot} overlaps, {d} {okw}")
     assert not bad, (bad, d, okw)
+
+
+_heavy = None
+
+
+def _golden():
+    global _heavy
+    if _heavy is None:
+        z = np.load(os.path.join(GOLDEN, "fuzz_heavy.npz"))
+        _heavy = {k: z[k] for k in z.files}
+    return _heavy
+
+
+@pytest.mark.parametrize("seed", [pytest.param(s, id=_id(s)) for s in HEAVY])
+def test_repeat_dense_workload_on_device(seed):
+    from hifiasm_amd import api
+    g = _golden()
+    ft, hom, het, n, tot = (int(x) for x in g[f"s{seed}_peaks"])
+    rs, d, okw = simt_fuzz.reads_of(seed)
+    assert rs.n == n
+    e = api.Engine(0, **okw); e.set_readset(rs)
+    try:
+        assert e.ha_ft_gen() == ft
+        assert e.ha_pt_gen() == (hom, het)
+        e.sketch_batch(0, rs.n)
+        sk = np.array([crc(e.fetch_sketch(r)) for r in range(rs.n)], dtype=np.uint32)
+        assert (sk == g[f"s{seed}_sketch"]).all(), f"sketch of {int((sk != g[f's{seed}_sketch']).sum())} reads"
+        e.overlap_batch(0, rs.n)
+        hd = np.zeros(rs.n, dtype=np.uint64); rd = np.zeros(rs.n, dtype=np.uint64); got = 0
+        for r in range(rs.n):
+            hd[r] = digest_hits(e.fetch_seed_hits(r))
+            ol, fc, fo, cl = e.h_ec_lchain(r); rd[r] = digest_result(ol, fc, cl); got += ol.shape[0]
+        assert (hd == g[f"s{seed}_hits"]).all(), f"seed hits of {int((hd != g[f's{seed}_hits']).sum())} reads"
+        assert got == tot and (rd == g[f"s{seed}_result"]).all(), f"overlaps of {int((rd != g[f's{seed}_result']).sum())} reads ({got} / {tot})"
+    finally:
+        e.close()
+    print(f"[gpu fuzz] seed {seed}: {n} reads, {tot} overlaps, {d} {okw}")

@@ -60,3 +60,31 @@ def test_sketch_with_filter(pair):
         if a.shape != b.shape or (a != b).any():
             bad += 1
     assert bad == 0, f"{bad}/{rs.n} reads differ"
+
+
+@pytest.mark.parametrize("name,passes,chunk", [("hifi", 3, 20000), ("nn", 2, 9000), ("rr", 5, 50000), ("bf22", 3, 20000), ("bf24", 4, 15000), ("f37", 2, 30000), ("hpc0", 7, 0), ("k40", 64, 12000), ("edge", 3, 5000)])
+def test_ft_gen_in_passes(name, passes, chunk, monkeypatch):
+    """ha_ft_gen counting in hash-range passes (what it does by itself when two 8-byte-per-base buffers do not fit the device: configs[3]'s share of one of eight
+    GPUs is 15 Gbases; htab.cpp:707-882 never holds all occurrences either): exact counting by ranges of the hash, through the Bloom filter by ranges of the
+    sub-table index, reads with N, read chunks down to one read - same histogram, peaks and filter table, and everything downstream of it"""
+    from hifiasm_amd.api import Engine
+    monkeypatch.setenv("HAO_FT_PASSES", str(passes))
+    if chunk:
+        monkeypatch.setenv("HAO_FT_CHUNK_SLOTS", str(chunk))
+    rs, okw = scenario_reads(name)
+    o = scenario_oracle(name)
+    e = Engine(0, **okw)
+    try:
+        e.set_readset(rs)
+        hom_ft = e.ha_ft_gen()
+        assert e.ft_passes() == passes
+        assert (e.hist(0) == o.ft_hist()).all()
+        k, v = e.ft_table(); ok, ov = o.ft_table()
+        assert k.shape == ok.shape and (k == ok).all() and (v == ov).all()
+        assert hom_ft == o.stats()["ft_peak_hom"]
+        hom, het = e.ha_pt_gen()
+        assert e.stats() == o.stats()
+        e.sketch_batch(0, rs.n)
+        assert all(np.array_equal(e.fetch_sketch(r), o.sketch(r)) for r in range(0, rs.n, 7))
+    finally:
+        e.close()
