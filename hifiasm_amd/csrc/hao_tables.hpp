@@ -313,18 +313,25 @@ struct FtPassPred {      // occurrences of this pass: key (the hash, or its sub-
 		return false;
 	}
 };
+#define HAO_FT_BYTES_PER_SLOT 20.0              // two 8-byte occurrence buffers + 25 % (the sort's scratch, the run lists); hifiasm_amd/memplan.py uses the same figures
+#define HAO_FT_BYTES_PER_SLOT_SHARDED 46.0
+#define HAO_FT_RUN_BYTES_PER_SLOT 3.0
 #define HAO_FT_CHUNK_SLOTS (1ULL << 28)      // k-mer slots hashed per chunk of reads in pass mode (2 GB of scratch, twice)
 // passes needed so that the two occurrence buffers (+ 25 % for the sort's scratch and the run lists) fit into the free device memory; HAO_FT_PASSES forces a number (tests)
-static uint64_t hao_ft_pass_count(hao_ctx *c, uint64_t n_slots)
+// (sharded: a pass keeps its two buffers while the receive buffer and its sort twin of about the same size exist: four buffers of a P-th, DevBuf slack included)
+static uint64_t hao_ft_pass_count(hao_ctx *c, uint64_t n_slots, bool sharded)
 {
 	if (c->sw.ft_passes > 0) return (uint64_t)c->sw.ft_passes;
 	size_t fr = 0, tot = 0;
 	if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return 1; }
-	const double need = 16.0 * (double)n_slots * 1.25 + (double)(1ULL << 30), have = 0.9 * (double)fr;
+	const double per_slot = sharded ? HAO_FT_BYTES_PER_SLOT_SHARDED : HAO_FT_BYTES_PER_SLOT;
+	const double need = per_slot * (double)n_slots + (double)(1ULL << 30), have = 0.9 * (double)fr;
 	if (need <= have) return 1;
-	const double rest = have - 2.0 * 8.0 * (double)HAO_FT_CHUNK_SLOTS - (double)(2ULL << 30);      // what the chunk scratch leaves
+	// what the chunk scratch and the run lists of ALL passes leave (12 bytes per distinct k-mer, once more while a pass's runs are appended; one distinct k-mer per ~7
+	// occurrences is allowed for: 1 / coverage + error rate x k = 0.076 at 40x and 0.1 % - an exact count of noisy reads at this scale wants the Bloom filter, as in the reference)
+	const double rest = have - 2.0 * 8.0 * (double)HAO_FT_CHUNK_SLOTS - (double)(2ULL << 30) - HAO_FT_RUN_BYTES_PER_SLOT * (double)n_slots;
 	if (rest <= 0) return 64;
-	return (uint64_t)std::min<double>(64.0, std::ceil(16.0 * (double)n_slots * 1.25 / rest));
+	return (uint64_t)std::min<double>(64.0, std::ceil(per_slot * (double)n_slots / rest));
 }
 
 static int hao_ft_run(hao_ctx *c)
@@ -382,7 +389,7 @@ static int hao_ft_run(hao_ctx *c)
 	};
 	const int index_rc = local_index();
 	if (index_rc && !sharded) return index_rc;
-	P = index_rc ? 1 : hao_ft_pass_count(c, n_slots);
+	P = index_rc ? 1 : hao_ft_pass_count(c, n_slots, sharded);
 	if (sharded) {      // every rank runs the same number of passes (the exchanges are collective): the largest any rank needs; the status of the local work travels along
 		hao_comm &cm = *c->comm;
 		if (int rc = hao_shard_layout_check(c, cm, index_rc)) return rc;

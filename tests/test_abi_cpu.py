@@ -100,6 +100,39 @@ def test_index_partition_headroom():
     print("[index headroom]", {k: (round(v[0], 5), f"{v[1] / 1e9:.2f} G minimizers", f"partition on 8 GPUs: {100 * v[2]:.0f} % of 2^32") for k, v in out.items()})
 
 
+def test_rank_memory_plan_of_the_multi_gpu_configs():
+    """Every resident buffer of one rank, phase by phase (hifiasm_amd/memplan.py: ha_ft_gen with its hash-range passes, ha_pt_gen incl. the all-gather slots that
+    become the replicated index, the all-reads pass with both delivery sets), for BASELINE.json's configs[3] (3 Gb human, 40x HiFi, 8 GPUs) and configs[4]
+    (30x ONT, 8 GPUs) against the 288 GB of an MI355X - with the minimizer densities the REFERENCE measured on the full-size fixtures.  configs[3]'s ha_ft_gen
+    is the phase that does not fit in one pass (15 Gbases per rank: four 8-byte-per-base buffers during the exchange); the plan must say so and fit with passes.
+    (tests/test_gpu_zz_rankshare.py runs that rank's share through ha_ft_gen on a device and compares the measured peak with this plan.)"""
+    import numpy as np
+    from hifiasm_amd import memplan
+    from hifiasm_amd.workloads import WORKLOADS, n_reads_of
+    src = open(os.path.join(ROOT, "hifiasm_amd", "csrc", "hao_tables.hpp")).read()
+    assert f"#define HAO_FT_BYTES_PER_SLOT {memplan.FT_PER_SLOT}" in src and f"#define HAO_FT_BYTES_PER_SLOT_SHARDED {memplan.FT_PER_SLOT_SHARDED}" in src      # the plan and the engine use the same figures
+    assert "#define HAO_FT_CHUNK_SLOTS (1ULL << 28)" in src and memplan.FT_CHUNK_SLOTS == 1 << 28 and f"#define HAO_FT_RUN_BYTES_PER_SLOT {memplan.FT_RUN_PER_SLOT}" in src
+    plans = {}
+    for fixture, target in (("chr1_250M_hifi30x", "human3G_hifi40x"), ("ont50M_30x", "ont_human_30x")):
+        g = np.load(os.path.join(ROOT, "tests", "golden", fixture + ".npz"))
+        h = g["pt_hist"].astype(np.int64)
+        gs, cov, rl, err = WORKLOADS[fixture][:4]
+        density = float((h * np.arange(h.size)).sum()) / float(gs * cov)
+        tg, tcov, trl, terr = WORKLOADS[target][:4]
+        hits_per_read = 0.92 * density * trl * tcov          # configs[2]: 11.9 k seed hits per read for 0.0287 x 15 000 x 30 = 12.9 k (list length ~ coverage)
+        # (configs[4]: noisy reads are counted through the Bloom filter, the reference's default - an exact count would keep ~0.4 distinct k-mers per base)
+        pl = memplan.rank_plan(float(tg) * tcov, n_reads_of(target), 8, density, hits_per_read, float(tg), err=terr, bloom=terr > 0.005)
+        plans[target] = pl
+        for phase in ("ft_gen", "pt_gen", "all_reads_pass"):
+            assert pl[phase] < 0.9 * memplan.HBM_BYTES, (target, phase, pl[phase] / 1e9)
+    p3 = plans["human3G_hifi40x"]
+    assert p3["passes_ft"] >= 2                                 # one pass would need 46 B x 15 Gbases = 690 GB
+    assert memplan.FT_PER_SLOT_SHARDED * 3e9 * 40 / 8 > memplan.HBM_BYTES
+    one = memplan.rank_plan(250e6 * 30, 500_000, 1, 0.02873, 11_900, 250e6)      # configs[2] on one GPU: one pass (20 B x 7.5 Gbases = 150 GB)
+    assert one["passes_ft"] == 1 and one["peak"] < 0.9 * memplan.HBM_BYTES
+    print("[rank memory plan, 8 GPUs]", {k: {q: (round(v[q] / 1e9, 1) if isinstance(v[q], float) else v[q]) for q in ("passes_ft", "ft_gen", "pt_gen", "all_reads_pass", "index", "batches_per_pass")} for k, v in plans.items()})
+
+
 def test_ctypes_mirrors_match_the_header(tmp_path):
     """hifiasm_amd/api.py mirrors four structs of include/hao.h by hand: a C program prints the header's sizes and field offsets, ctypes must agree
     (the delivery view and the chain header changed shape in round 3)."""
