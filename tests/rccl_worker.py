@@ -1,6 +1,9 @@
 """One rank of the RCCL parity run (launched by tests/test_gpu_rccl.py under torch.distributed.run, one rank per GPU): shard a scenario's reads by
 rank, build the tables through the RCCL transport (k-mer all-to-all-v, index all-to-all-v + all-gather, histogram all-reduce), run the query
-pass and compare EVERY local read with the oracle.  Exit code 0 = this rank's results are bit-exact."""
+pass and compare EVERY local read with the oracle.  Exit code 0 = this rank's results are bit-exact.
+
+`--simt` (tests/test_dist_cpu.py, no GPU): the same run with the emulated device library (tests/simt) in every process and tests/simt/rccl/rccl.h - a mailbox
+transport between processes - in RCCL's place; the launcher side uses gloo.  What executes is hao_comm.hpp's RCCL branch with two and four ranks."""
 import os
 import sys
 
@@ -19,16 +22,24 @@ def main():
     from hifiasm_amd.synth import ReadSet
     from helpers import scenario_reads, scenario_oracle
     name = sys.argv[1]
+    simt = "--simt" in sys.argv[2:]
     rank, world, lr = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
-    torch.cuda.set_device(lr)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", lr))
+    if simt:
+        import simt_build
+        from hifiasm_amd import api
+        path = simt_build.build_lib(); api.lib_path = lambda: path; api._LIB = None
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        lr = 0
+    else:
+        torch.cuda.set_device(lr)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", lr))
     rs, okw = scenario_reads(name)
     lo, hi = shard.shard_range(rs.n, rank, world)
     sub = ReadSet(lo, rs.lengths[lo:hi].copy(), rs.packed[int(rs.pk_off[lo]):int(rs.pk_off[hi])].copy(), (rs.pk_off[lo:hi + 1] - rs.pk_off[lo]).copy(),
                   rs.codes[int(rs.code_off[lo]):int(rs.code_off[hi])].copy(), (rs.code_off[lo:hi + 1] - rs.code_off[lo]).copy())
     e = Engine(lr, **okw)
     e.set_readset(sub)
-    all_len, counts = shard.gather_lengths(dist, sub.lengths, device="cuda")
+    all_len, counts = shard.gather_lengths(dist, sub.lengths, device="cpu" if simt else "cuda")
     assert (all_len == rs.lengths).all()
     e.set_shard(sum(counts[:rank]), all_len)
     e.dist_init(shard.share_unique_id(dist, Engine.dist_unique_id), rank, world)

@@ -49,3 +49,29 @@ def test_shard_ranges_cover():
         for w in (1, 2, 3, 8):
             r = [shard.shard_range(n, i, w) for i in range(w)]
             assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("name,world,env", [("hifi", 2, {}), ("nn", 3, {}), ("bf24", 2, {}), ("hifi", 4, {}), ("hifi", 2, {"HAO_FT_PASSES": "3", "HAO_FT_CHUNK_SLOTS": "25000"})])
+def test_rccl_branch_between_processes(name, world, env):
+    """hao_comm.hpp's RCCL branch with 2, 3 and 4 ranks, one PROCESS per rank under torch.distributed.run: the emulated device library (tests/simt) in every process,
+    tests/simt/rccl/rccl.h - grouped send / receive, in-place all-gather, broadcast per root, sum all-reduce over a mailbox directory - in RCCL's place, gloo on the
+    launcher side (read lengths, unique id).  Every rank compares its tables and every one of its reads with the oracle (tests/rccl_worker.py; exit code 0 = bit-exact).
+    Until a box with two GPUs runs tests/test_gpu_rccl.py this is the only place where the grouped exchange pattern runs with more than one rank."""
+    import subprocess
+    import sys
+    import simt_build
+    simt_build.build_lib()      # once, before the ranks start (they would otherwise queue on the build lock)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(root, "tests", "rccl_worker.py"), name, "--simt"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=dict(os.environ, OMP_NUM_THREADS="1", HAO_SIMT_RCCL_TIMEOUT="600", **env))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert r.stdout.count("0 differ") == world, r.stdout[-1500:]

@@ -63,7 +63,7 @@ def test_configs3_rank_share_through_ft_gen(monkeypatch):
     # exact counting: every occurrence is in exactly one run; counts saturate at 4095 only in the histogram's last bin (a random genome has no such k-mer)
     h = a["hist"].astype(np.int64)
     occ = int((h * np.arange(h.size)).sum())
-    assert h[4095] == 0 and 0.95 * rs.total_bases * 0.69 < occ < rs.total_bases      # (HPC: ~0.69 compressed bases per base, minus k - 1 per read)
+    assert h[4095] == 0 and 0.9 * rs.total_bases * 0.75 < occ < rs.total_bases      # (HPC: ~0.75 runs per base of a random genome, minus k - 1 per read)
     plan = memplan.rank_plan(float(gs) * cov / 8, n_loc, 1, 0.02873, 11_900 * cov / 30.0, float(gs))      # this device's share as a world of one
     out = {"workload": "human3G_hifi40x reads [0, 1e6)", "bases": rs.total_bases, "kmer_occurrences": occ, "distinct_kmers": int(h.sum()), "gen_s": round(t_gen, 1),
            "auto": {q: a[q] for q in ("passes", "wall_s", "peak_gb", "before_gb", "total_gb", "hom")}, "doubled": {q: d[q] for q in ("passes", "wall_s", "peak_gb")},
