@@ -43,9 +43,12 @@ VARIANT_OF = {"chr1_250M_hifi30x": "chr1_250M_hifi30x_repeat", "bacterial5M_hifi
 ALG = {
     "sketch_unit_kernel": ("base", 0.25 + 16.0 / 35.0),             # 2-bit bases in + one 16-B minimizer per ~35 bases out
     "chain_group_kernel": ("anchor", 16 + 4),                        # k_mer_hit in + fake-cigar / record out (hits stay in place)
-    "seed_bin_kernel": ("anchor", 8 + 16),                           # index record in, k_mer_hit out (bins, order and groups in LDS)
+    "seed_merge_kernel": ("anchor", 8 + 16),                         # index record in (once), k_mer_hit out (the read's position lists merged by target, hao_query4.cuh)
+    "seed_bin_kernel": ("anchor", 8 + 16),                           # (HAO_SEED_MERGE=0: the table kernels of rounds 1 - 4) index record in, k_mer_hit out
 }
-KERN_STAGE = {"sketch_unit_kernel": "sk_chunks", "chain_group_kernel": "q_chain", "seed_bin_kernel": "q_sort_bins"}
+SEED_KERNEL = "seed_bin_kernel" if os.environ.get("HAO_SEED_MERGE") == "0" else "seed_merge_kernel"
+KERN_STAGE = {"sketch_unit_kernel": "sk_chunks", "chain_group_kernel": "q_chain", SEED_KERNEL: "q_sort_bins"}
+METRIC_WORKLOAD = "human3G_hifi40x"      # BASELINE.json configs[3]: the configuration the metric is quoted on (8 GPUs)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2      # G wave-level VALU instructions / s: 256 CUs x 4 SIMD-32 x 2.4 GHz, a wave64 instruction issues over 2 cycles (MI355X_MICROARCH.md)
 
@@ -114,7 +117,7 @@ def cpu_baseline(workload, mode="sample", threads=None):
 def profile_file(name):
     """newest committed profile of that name (PMC counters need their own rocprofv3 passes - tools/r03_final.sh - so they cannot be
     collected inside this run; the line says where the figure comes from)"""
-    for r in ("r04", "r03", "r02"):
+    for r in ("r05", "r04", "r03", "r02"):
         p = os.path.join(ROOT, "profiles", r, name)
         if os.path.exists(p):
             return p, f"profiles/{r}/{name}"
@@ -321,6 +324,13 @@ def run_workload(a, workload, steps, warmup, rank, local_rank, world, dist, torc
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                     "kernel_ms": round(k_ms, 4), "alg_bytes_per_launch": int(alg_bytes)}
+        # the same figure for each of the three kernels that carry the step (the dominant one is `roofline` itself)
+        def kernel_line(kn):
+            u_, b_ = ALG[kn]; un_ = rs.total_bases if u_ == "base" else tot["seed_hits"]; nb_ = 1 if u_ == "base" else len(ranges)
+            ms_ = stage_ms.get(KERN_STAGE[kn], 0.0) / nb_
+            ach_ = b_ * un_ / nb_ / (ms_ * 1e-3) / 1e9 if ms_ > 0 else 0.0
+            return {"kernel": kn, "kernel_ms": round(ms_, 4), "launches_per_step": nb_, "alg_bytes_per_launch": int(b_ * un_ / nb_), "achieved": round(ach_, 2), "frac": round(ach_ / HBM_PEAK_GBS, 5)}
+        roofline["kernels"] = [kernel_line(kn) for kn in KERN_STAGE]
         prof, prof_rel = profile_file("pmc_traffic.json")
         if prof and world == 1:      # PMC counters need their own rocprofv3 passes (tools/pmc.sh): not measurable inside this run
             try:
@@ -394,7 +404,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="chr1_250M_hifi30x", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=list(WORKLOADS), help="default: chr1_250M_hifi30x (BASELINE configs[2], weak-scaled by --gpus); with --gpus 8: human3G_hifi40x (configs[3], the configuration the metric is quoted on, split over the ranks)")
     ap.add_argument("--batch-reads", type=int, default=0, help="query reads per hao_overlap_batch (0 = sized for ~8e8 seed hits)")
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "none"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -409,6 +419,8 @@ def main():
     a = ap.parse_args()
     if a.no_cpu_baseline:
         a.cpu_baseline = "none"
+    if a.workload is None:
+        a.workload = METRIC_WORKLOAD if a.gpus == 8 else "chr1_250M_hifi30x"
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         self_launch(a)
@@ -432,6 +444,23 @@ def main():
     from hifiasm_amd.api import Engine
 
     out = run_workload(a, a.workload, a.steps, a.warmup, rank, local_rank, world, dist, torch, force_sharded)
+    # 2 <= N < 8 ranks: the line's headline stays the weak-scaled configs[2] (comparable across N); the configuration the metric is quoted on - configs[3], the
+    # fixed 8 M-read set split over the N ranks - rides along as variants.metric_config (one untimed + one timed step, results left in HBM) when the memory plan of
+    # a rank says it fits (hifiasm_amd/memplan.py); every rank takes part
+    metric_var = None
+    if world > 1 and not a.no_variants and a.workload != METRIC_WORKLOAD:
+        from hifiasm_amd import memplan
+        g_, cov_, L_, err_ = WORKLOADS[METRIC_WORKLOAD][:4]
+        plan = memplan.rank_plan(float(g_) * cov_, n_reads_of(METRIC_WORKLOAD), world, 0.02873, 0.92 * 0.02873 * L_ * cov_, float(g_), err=err_)
+        if plan["peak"] < 0.9 * plan["hbm"]:
+            nb_ = a.no_boundary; a.no_boundary = True
+            mv = run_workload(a, METRIC_WORKLOAD, 1, 1, rank, local_rank, world, dist, torch, force_sharded)
+            a.no_boundary = nb_
+            if rank == 0:
+                metric_var = {k: mv[k] for k in ("value", "ms_per_step", "value_resident", "ms_per_step_resident", "steps", "warmup", "scaling", "roofline", "stage_ms", "config")}
+                metric_var["memory_plan_gb"] = {k: round(v / 1e9, 1) for k, v in plan.items() if isinstance(v, float)}
+        elif rank == 0:
+            metric_var = {"skipped": f"a rank's share of {METRIC_WORKLOAD} on {world} GPUs does not fit: plan peak {plan['peak'] / 1e9:.0f} GB"}
     if rank == 0:
         # SURVEY 8d / BASELINE.md 2b: "report both variants" - the same step on the repeat-rich read set of the same size (filter table, minimizer thinning,
         # max_n_chain pruning, the chain DP: the case that looks like a real genome), fewer steps
@@ -440,6 +469,14 @@ def main():
         if var and world == 1 and not a.no_variants:
             v = run_workload(a, var, max(1, min(a.steps, a.variant_steps)), min(a.warmup, 1), rank, local_rank, world, dist, torch, force_sharded)
             out["variants"] = {"repeat_rich": {k: v[k] for k in ("value", "ms_per_step", "value_resident", "ms_per_step_resident", "steps", "warmup", "roofline", "stage_ms", "config", "boundary")}}
+        if metric_var is not None:
+            out["variants"] = dict(out["variants"] or {}, metric_config=metric_var)
+        if world > 1:      # what one rank holds, phase by phase (launcher-side arithmetic from the allocation sites' sizes: hifiasm_amd/memplan.py)
+            from hifiasm_amd import memplan
+            g_, cov_, L_, err_ = WORKLOADS[a.workload][:4]
+            tb_ = float(g_) * cov_ * (1 if a.workload in STRONG else world)
+            pl_ = memplan.rank_plan(tb_, tb_ / L_, world, 0.02873, 0.92 * 0.02873 * L_ * cov_, float(g_) * (1 if a.workload in STRONG else world), err=err_, bloom=err_ > 0.005)
+            out["memory_plan_gb"] = {k: (round(v / 1e9, 1) if isinstance(v, float) else v) for k, v in pl_.items()}
         out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_baseline) if (a.cpu_baseline != "none" and world == 1) else None
         if a.verbose:
             sys.stderr.write(json.dumps(out["stage_ms"], indent=1) + "\n")

@@ -31,4 +31,13 @@ def test_profile_lookup_prefers_the_newest_round():
     newest = max(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "pmc_traffic.json")))
     assert rel == f"profiles/{newest}/pmc_traffic.json" and os.path.exists(p)
     assert b.profile_file("no_such_file.json") == (None, None)
-    assert set(b.KERN_STAGE) == set(b.ALG)
+    assert set(b.KERN_STAGE) <= set(b.ALG) and b.SEED_KERNEL in b.KERN_STAGE and len(b.KERN_STAGE) == 3
+
+
+def test_default_workload_per_gpu_count():
+    """no --workload: configs[2] (the largest single-GPU configuration) weak-scaled for 1 - 7 GPUs, configs[3] - the configuration BASELINE.json's metric is quoted on,
+    split over the ranks - for 8; with 2 - 7 GPUs configs[3] rides along as variants.metric_config (every rank runs it: the call sits outside `if rank == 0`)"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'a.workload = METRIC_WORKLOAD if a.gpus == 8 else "chr1_250M_hifi30x"' in src and 'METRIC_WORKLOAD = "human3G_hifi40x"' in src
+    i, j, k = src.index("metric_var = None"), src.index("mv = run_workload(a, METRIC_WORKLOAD"), src.index("    if rank == 0:\n        # SURVEY 8d")
+    assert i < j < k
