@@ -13,7 +13,7 @@ struct hao_ctx::Batch {
 	bool valid = false, host_valid = false;
 	DevBuf<uint64_t> s_start, a_off, seg, g_cnt, g_off, g_start, ch_base, cl_base, fc_base, fcs, fc_raw, ol_fc_off, cc_off, cc, fc_final, fcf_off;
 	DevBuf<uint64_t> nch64;
-	DevBuf<uint64_t> g_tmp, cls_cc, cls_co; DevBuf<hao_gent> glist; DevBuf<uint8_t> g_cls; DevBuf<uint32_t> slow, ovf_list; hipStream_t side[HAO_NCLS]; hipEvent_t ev_qc[HAO_NCLS], ev_dp[HAO_NCLS]; bool side_ready = false;
+	DevBuf<uint64_t> g_tmp, cls_cc, cls_co; DevBuf<hao_gent> glist; DevBuf<uint8_t> g_cls; DevBuf<uint32_t> slow, ovf_list, loc_idx, loc_idx2; DevBuf<uint64_t> loc_key, loc_key2; hipStream_t side[HAO_NCLS]; hipEvent_t ev_qc[HAO_NCLS], ev_dp[HAO_NCLS]; bool side_ready = false;
 	DevBuf<uint32_t> q_pos, q_cnt, s_n, g_read, wgt, nch, nout, perm, n_final, fclen;
 	DevBuf<hao_hit_t> hits, ohits, cl;
 	DevBuf<int32_t> f, ii, p, key_sc, tm; DevBuf<int64_t> t; DevBuf<uint64_t> key_xs; DevBuf<uint32_t> key_al, key_tmp;
@@ -43,7 +43,7 @@ struct hao_ctx::Batch {
 		if (side_ready) { for (int x = 0; x < HAO_NCLS; ++x) { (void)hipStreamDestroy(side[x]); (void)hipEventDestroy(ev_qc[x]); (void)hipEventDestroy(ev_dp[x]); } side_ready = false; }
 		s_start.release(); a_off.release(); seg.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fcf_off.release();
-		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); g_cls.release(); slow.release(); ovf_list.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
+		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); g_cls.release(); slow.release(); ovf_list.release(); loc_idx.release(); loc_idx2.release(); loc_key.release(); loc_key2.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
 		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); cd.release(); pk_cnt.release(); pk_ecnt.release(); pk_erank.release(); hq.release(); ohq.release(); hcode.release(); out[0].release(); out[1].release();
 		if (dl_ready) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); for (int k = 0; k < n_aux; ++k) { (void)hipStreamSynchronize(copy_aux[k]); (void)hipStreamDestroy(copy_aux[k]); (void)hipEventDestroy(ev_aux[0][k]); (void)hipEventDestroy(ev_aux[1][k]); } for (int x = 0; x < 2; ++x) { (void)hipEventDestroy(ev_ready[x]); (void)hipEventDestroy(ev_done[x]); if (arena[x]) (void)hipHostFree(arena[x]); arena[x] = nullptr; arena_cap[x] = 0; } dl_ready = false; }
 	}
@@ -338,11 +338,22 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			HIP_TRY(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
 			HIP_TRY(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
 			{
-				const uint64_t *sinfo_ = c->d_ix_sinfo.p; const uint32_t *len_ = c->d_len_all.p; const dim3 g_((unsigned)((n + 3) / 4)), b_(256);
-				if (c->sw.seed_merge == 4 && c->sw.seed_mbuf == 1) hipLaunchKernelGGL((seed_merge_kernel<4, 1>), g_, b_, hao_seed4_lds<4>::TOTAL, c->stream, sa_, sinfo_, len_, ovf0, d_ovf0);
-				else if (c->sw.seed_merge == 4) hipLaunchKernelGGL((seed_merge_kernel<4, 4>), g_, b_, hao_seed4_lds<4>::TOTAL, c->stream, sa_, sinfo_, len_, ovf0, d_ovf0);
-				else if (c->sw.seed_mbuf == 1) hipLaunchKernelGGL((seed_merge_kernel<8, 1>), g_, b_, hao_seed4_lds<8>::TOTAL, c->stream, sa_, sinfo_, len_, ovf0, d_ovf0);
-				else hipLaunchKernelGGL((seed_merge_kernel<8, 4>), g_, b_, hao_seed4_lds<8>::TOTAL, c->stream, sa_, sinfo_, len_, ovf0, d_ovf0);
+				const uint64_t *sinfo_ = c->d_ix_sinfo.p; const uint32_t *len_ = c->d_len_all.p; const uint32_t *order_ = nullptr;
+				unsigned nwg = (unsigned)((n + 3) / 4);
+				if (c->sw.seed_locus && n > 64) {      // launch order by locus (hao_query4.cuh): key per read, sort, an eighth of the sorted list per XCD
+					HIP_TRY(B.loc_key.reserve(n + 1)); HIP_TRY(B.loc_key2.reserve(n + 1)); HIP_TRY(B.loc_idx.reserve(n + 1)); HIP_TRY(B.loc_idx2.reserve(n + 1));
+					hipLaunchKernelGGL(seed_locus_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, sa_, sinfo_, B.loc_key.p, B.loc_idx.p);
+					HAO_CHECK_LAUNCH();
+					size_t tb = 0; rocprim::double_buffer<uint64_t> dk(B.loc_key.p, B.loc_key2.p); rocprim::double_buffer<uint32_t> dv(B.loc_idx.p, B.loc_idx2.p);
+					HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, dk, dv, (size_t)n, 0, 55, c->stream)); HIP_TRY(hao_tmp(c, tb));
+					HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, dk, dv, (size_t)n, 0, 55, c->stream));
+					order_ = dv.current(); nwg = (nwg + 7) / 8 * 8;
+				}
+				const dim3 g_(nwg), b_(256);
+				if (c->sw.seed_merge == 4 && c->sw.seed_mbuf == 1) hipLaunchKernelGGL((seed_merge_kernel<4, 1>), g_, b_, hao_seed4_lds<4>::TOTAL, c->stream, sa_, sinfo_, len_, order_, ovf0, d_ovf0);
+				else if (c->sw.seed_merge == 4) hipLaunchKernelGGL((seed_merge_kernel<4, 4>), g_, b_, hao_seed4_lds<4>::TOTAL, c->stream, sa_, sinfo_, len_, order_, ovf0, d_ovf0);
+				else if (c->sw.seed_mbuf == 1) hipLaunchKernelGGL((seed_merge_kernel<8, 1>), g_, b_, hao_seed4_lds<8>::TOTAL, c->stream, sa_, sinfo_, len_, order_, ovf0, d_ovf0);
+				else hipLaunchKernelGGL((seed_merge_kernel<8, 4>), g_, b_, hao_seed4_lds<8>::TOTAL, c->stream, sa_, sinfo_, len_, order_, ovf0, d_ovf0);
 			}
 			HAO_CHECK_LAUNCH();
 			hipLaunchKernelGGL(k1, dim3((unsigned)n), dim3(256), lds1, c->stream, sa_, (const uint32_t*)ovf0, (const unsigned long long*)d_ovf0, ovf1, d_ovf);

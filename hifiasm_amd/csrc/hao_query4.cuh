@@ -48,12 +48,32 @@ struct hao_rec4 { uint64_t a, b, c, d; };      // four index records: one 32-byt
 #define HAO_MRG_BC(rz) ((rz) >> 12 & 0xfu)
 #define HAO_MRG_Z(rz) ((rz) >> 31)
 
+// Launch order.  The reads of a batch come from all over the genome, and the ~5 of them that contain a given k-mer (a batch is a sixth of the reads at 30x) walk
+// the same position list - each from its own wave, at its own time, on any XCD: the list crosses the memory fabric once per read that uses it.  Reads of one locus
+// share most of their lists AND most of their targets, so started together on one XCD they ask for the same lines at about the same time and the XCD's L2 answers.
+// A read's locus is not known, but its smallest target is (what the merge's first step computes): reads with the same smallest target X overlap X, i.e. lie within
+// a read length of each other, and X's position in the hit orders them along X.  seed_locus_kernel writes key = (smallest target << 27 | its position) per read;
+// the host sorts the batch's reads by key and the merge kernel takes them in that order, an eighth of the sorted list per XCD (block b runs on XCD b % 8).
+__global__ __launch_bounds__(256) void seed_locus_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, uint64_t *key, uint32_t *idx)
+{
+	const int wv = threadIdx.x >> 6, lane = hao_lane();
+	const uint64_t r = (uint64_t)blockIdx.x * 4 + wv;
+	if (r >= S.n_sel) return;
+	const uint64_t m0 = S.mz_off[S.rid_lo + r], li0 = m0 - S.mz0; const uint32_t nq = (uint32_t)(S.mz_off[S.rid_lo + r + 1] - m0);
+	uint64_t best = ~0ULL;
+	for (uint32_t q = lane; q < nq; q += 64)
+		if (S.s_n[li0 + q]) { const uint64_t y = sinfo[S.s_start[li0 + q]]; best = min(best, (uint64_t)hao_info_rid(y) << 27 | hao_info_pos(y)); }
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) best = min(best, (uint64_t)__shfl_xor((unsigned long long)best, d));
+	if (lane == 0) { key[r] = best; idx[r] = (uint32_t)r; }
+}
+
 // BUF = 1: a row reads its list one 8-byte record at a time; BUF = 4: 32 bytes at a time.  A lane's reads are its own (the lists of a read's minimizers lie anywhere
 // in the index), so every read moves a whole cache line through the memory fabric however little of it is used - and a line comes around again only after the other
 // ~500 rows of every wave of the XCD had their turn, by when the 4 MB L2 has lost it: with 8-byte reads a 128-byte line crosses the fabric up to 16 times
 // (measured: 122 ms per configs[2] pass against 59 ms for the table kernels - 6 TB/s of line traffic for 0.4 TB/s of records), with 32-byte reads 4 times.
 template<int RPL, int BUF>
-__global__ __launch_bounds__(256, BUF == 4 ? (RPL == 8 ? 3 : 5) : 4) void seed_merge_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, const uint32_t *__restrict__ len, uint32_t *ovf_list, unsigned long long *ovf_cnt)
+__global__ __launch_bounds__(256, BUF == 4 ? (RPL == 8 ? 3 : 5) : 4) void seed_merge_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, const uint32_t *__restrict__ len, const uint32_t *__restrict__ order, uint32_t *ovf_list, unsigned long long *ovf_cnt)
 {
 	static_assert(BUF == 1 || BUF == 4, "records per list read");
 	constexpr uint32_t ROWS = hao_seed4_lds<RPL>::ROWS;
@@ -62,9 +82,11 @@ __global__ __launch_bounds__(256, BUF == 4 ? (RPL == 8 ? 3 : 5) : 4) void seed_m
 	uint2 *l_q = (uint2*)((char*)mg_smem + wv * hao_seed4_lds<RPL>::PER_WAVE);      // [ROWS] self_offset, cnt of the row's hits (anchor.cpp:1065-1076)
 	uint16_t *l_cnt = (uint16_t*)(l_q + ROWS);                                        // [ROWS] length of the row's list (< 4096: the index caps a list at 4095 records)
 	uint16_t *l_qi = l_cnt + ROWS;                                                     // [ROWS] the row's minimizer: index in the read's full minimizer list
-	const uint64_t r = (uint64_t)blockIdx.x * 4 + wv;
-	if (r == 0 && lane == 0) S.g_cnt[S.n_sel] = 0;
-	if (r >= S.n_sel) return;                                                           // (no workgroup barriers anywhere: waves are independent)
+	// the wave's read: in launch order, or - with a sorted order list (the grid is then a multiple of 8 blocks) - the next of its XCD's eighth of the list
+	const uint64_t slot = order ? ((uint64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * 4 + wv : (uint64_t)blockIdx.x * 4 + wv;
+	if (slot == 0 && lane == 0) S.g_cnt[S.n_sel] = 0;
+	if (slot >= S.n_sel) return;                                                        // (no workgroup barriers anywhere: waves are independent)
+	const uint64_t r = order ? order[slot] : slot;
 	const uint64_t s = S.seg[r]; const uint32_t n = (uint32_t)(S.seg[r + 1] - s);
 	if (n == 0) { if (lane == 0) S.g_cnt[r] = 0; return; }
 	const uint64_t m0 = S.mz_off[S.rid_lo + r], li0 = m0 - S.mz0; const uint32_t nq = (uint32_t)(S.mz_off[S.rid_lo + r + 1] - m0);

@@ -18,6 +18,7 @@ int fail(char *err, int cap, const std::string &m) { snprintf(err, cap, "%s", m.
 // mode 0: what the library launches by default (QL instances; overflowing reads through seed_bin3_kernel); 1: HAO_SEED_NODIRECT (all tiers seed_bin_kernel, QL);
 // 2: HAO_SEED_NOQL (per-minimizer tables possibly in global memory: qcap_force > 0 caps the LDS table to force that path)
 // 3 / 4 / 5 / 6: the merge kernel (hao_query4.cuh; 8 / 2 rows per lane reading one record at a time, 8 / 2 rows per lane reading four) takes every chosen read first; the reads it leaves (more rows than it holds) go through the table kernels as in mode 0
+// 7: 8 rows per lane, four records per read, every read of the set in LOCUS order (seed_locus_kernel + sort + the per-XCD mapping of the order list)
 // (stats[6] = reads left by the merge kernel)
 // blocks: the reads to run in the first launch (others keep empty output); returns 0 or 1 with a message
 extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t *mz_info, const uint64_t *lk, const uint32_t *wgt, const uint64_t *sinfo, const uint32_t *len, uint64_t n_total,
@@ -50,16 +51,30 @@ extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t 
 	if (mode == 0 || mode >= 3) { lds2 = hao_seed3_lds<10>::FIXED + lds_q; lds3 = hao_seed3_lds<11>::FIXED + lds_q; }
 	const uint32_t *nil32 = nullptr; const unsigned long long *nil64 = nullptr;
 	std::vector<uint32_t> ovf0(n + 4, 0); unsigned long long ovf0_cnt = 0;
-	if (mode >= 3) {      // the merge kernel: a wave per read (four reads per block); only the chosen reads' blocks run, and of those only the chosen waves' output is kept clean below
+	if (mode == 7) {      // the merge kernel in locus order: key per read, the reads sorted by key, an eighth of the sorted list per "XCD" (blocks b, b + 8, ...); every read runs
+		std::vector<uint64_t> key(n + 1, 0); std::vector<uint32_t> idx(n + 1, 0);
+		if (launch((unsigned)((n + 3) / 4), 256, 0, [&] { seed_locus_kernel(sa, sinfo, key.data(), idx.data()); })) return fail(err, errcap, hao_simt::g.error);
+		std::vector<uint32_t> ord(idx.begin(), idx.begin() + n);
+		std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+		for (uint64_t i = 0; i + 1 < n; ++i) if (key[ord[i]] > key[ord[i + 1]]) return fail(err, errcap, "locus order not sorted");
+		const unsigned nwg = (unsigned)(((n + 3) / 4 + 7) / 8 * 8);
+		if (launch(nwg, 256, hao_seed4_lds<8>::TOTAL, [&] { seed_merge_kernel<8, 4>(sa, sinfo, len, ord.data(), ovf0.data(), &ovf0_cnt); })) return fail(err, errcap, hao_simt::g.error);
+		stats[6] = ovf0_cnt; stats[7] = key[ord[0]];
+		if (ovf0_cnt) {
+			std::function<void()> call = [&] { seed_bin_kernel<9, 1, 512, true>(sa, ovf0.data(), &ovf0_cnt, ovf1, &ovf_cnt[0]); };
+			if (launch((unsigned)ovf0_cnt, 256, lds1, call)) return fail(err, errcap, hao_simt::g.error);
+		}
+	}
+	else if (mode >= 3) {      // the merge kernel: a wave per read (four reads per block); only the chosen reads' blocks run, and of those only the chosen waves' output is kept clean below
 		std::vector<char> chosen(n + 4, 0); for (uint32_t b = 0; b < n_blocks; ++b) chosen[blocks[b]] = 1;
 		const size_t ldsm = (mode == 3 || mode == 5) ? hao_seed4_lds<8>::TOTAL : hao_seed4_lds<2>::TOTAL;
 		for (uint64_t g = 0; g < (n + 3) / 4; ++g) {
 			if (!(chosen[4 * g] | chosen[4 * g + 1] | chosen[4 * g + 2] | chosen[4 * g + 3])) continue;
 			std::function<void()> call;
-			if (mode == 3) call = [&] { seed_merge_kernel<8, 1>(sa, sinfo, len, ovf0.data(), &ovf0_cnt); };
-			else if (mode == 4) call = [&] { seed_merge_kernel<2, 1>(sa, sinfo, len, ovf0.data(), &ovf0_cnt); };
-			else if (mode == 5) call = [&] { seed_merge_kernel<8, 4>(sa, sinfo, len, ovf0.data(), &ovf0_cnt); };
-			else call = [&] { seed_merge_kernel<2, 4>(sa, sinfo, len, ovf0.data(), &ovf0_cnt); };
+			if (mode == 3) call = [&] { seed_merge_kernel<8, 1>(sa, sinfo, len, nil32, ovf0.data(), &ovf0_cnt); };
+			else if (mode == 4) call = [&] { seed_merge_kernel<2, 1>(sa, sinfo, len, nil32, ovf0.data(), &ovf0_cnt); };
+			else if (mode == 5) call = [&] { seed_merge_kernel<8, 4>(sa, sinfo, len, nil32, ovf0.data(), &ovf0_cnt); };
+			else call = [&] { seed_merge_kernel<2, 4>(sa, sinfo, len, nil32, ovf0.data(), &ovf0_cnt); };
 			hao_simt::g.body = call; hao_simt::g.nthreads = 256; hao_simt::g.error.clear(); hao_simt::g.dyn_lds.assign(ldsm + 64, (char)0xa5);
 			blockDim = {256, 1, 1}; gridDim = {(unsigned)((n + 3) / 4), 1, 1}; blockIdx = {(unsigned)g, 0, 0};
 			if (!hao_simt::run_block()) return fail(err, errcap, hao_simt::g.error);

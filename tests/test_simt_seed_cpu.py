@@ -191,10 +191,12 @@ def test_seed_kernels_with_many_bins(n_targets, nq, list_len, mode):
 # ---- the merge kernel (hao_query4.cuh): one wave per read, the read's position lists merged by target ----
 @pytest.mark.parametrize("name,step,mode", [("hifi", 1, 3), ("rr", 1, 3), ("nn", 1, 3), ("ont", 1, 3), ("edge", 1, 3), ("k40", 1, 3), ("hpc0", 1, 3), ("fz2", 1, 3), ("rr_heavy", 25, 3),
                                             ("hifi", 1, 4), ("rr", 1, 4), ("ont", 2, 4), ("edge", 1, 4),
-                                            ("hifi", 1, 5), ("rr", 1, 5), ("nn", 1, 5), ("ont", 1, 5), ("edge", 1, 5), ("k40", 1, 5), ("hpc0", 1, 5), ("fz2", 1, 5), ("rr_heavy", 25, 5), ("rr", 1, 6)])
+                                            ("hifi", 1, 5), ("rr", 1, 5), ("nn", 1, 5), ("ont", 1, 5), ("edge", 1, 5), ("k40", 1, 5), ("hpc0", 1, 5), ("fz2", 1, 5), ("rr_heavy", 25, 5), ("rr", 1, 6),
+                                            ("hifi", 1, 7), ("rr", 1, 7), ("edge", 1, 7), ("ont", 1, 7)])
 def test_merge_kernel_against_the_oracle(name, step, mode):
     """mode 3: 8 rows per lane (reads with up to 512 minimizers that have a list), mode 4: 2 rows per lane - most reads of these scenarios then overflow to the table kernels,
-    which checks the hand-over (overflow list -> 512-slot launch -> the launches behind it); modes 5 / 6: the same with 32-byte list reads (four records behind every head)"""
+    which checks the hand-over (overflow list -> 512-slot launch -> the launches behind it); modes 5 / 6: the same with 32-byte list reads (four records behind every head);
+    mode 7: the library's default - every read, in locus order (smallest target, position in it), an eighth of the order per XCD"""
     rs, o, inp = seed_inputs(name)
     blocks = np.arange(0, rs.n, step)
     out = run_seed(rs, inp, blocks, mode=mode)
