@@ -76,7 +76,7 @@ template<int RPL, int BUF>
 __global__ __launch_bounds__(256, BUF == 4 ? (RPL == 8 ? 3 : 5) : 4) void seed_merge_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, const uint32_t *__restrict__ len, const uint32_t *__restrict__ order, uint32_t *ovf_list, unsigned long long *ovf_cnt)
 {
 	static_assert(BUF == 1 || BUF == 4, "records per list read");
-	constexpr uint32_t ROWS = hao_seed4_lds<RPL>::ROWS;
+	constexpr uint32_t ROWS = hao_seed4_lds<RPL>::ROWS, mrg_row0 = 0;      // (mrg_row0: first row of the wave - the row macros are shared with the four-wave kernel below)
 	extern __shared__ uint32_t mg_smem[];
 	const int wv = threadIdx.x >> 6, lane = hao_lane();
 	uint2 *l_q = (uint2*)((char*)mg_smem + wv * hao_seed4_lds<RPL>::PER_WAVE);      // [ROWS] self_offset, cnt of the row's hits (anchor.cpp:1065-1076)
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, BUF == 4 ? (RPL == 8 ? 3 : 5) : 4) void seed_m
 			// ---- some row holds several records of T: redo the target in full (the rows that took part above stand one record behind their head) ----
 			// pass 1: forward-strand records of T over all rows (where the opposite strand starts)
 			uint32_t f_mine = 0;
-#define HAO_MRG_RUN(i, ...) { const uint32_t row = i * 64 + lane, c = l_cnt[row], left = HAO_MRG_REM(rz_##i), z = HAO_MRG_Z(rz_##i); \
+#define HAO_MRG_RUN(i, ...) { const uint32_t row = mrg_row0 + i * 64 + lane, c = l_cnt[row], left = HAO_MRG_REM(rz_##i), z = HAO_MRG_Z(rz_##i); \
 				const uint64_t *lst = sinfo + (nx_##i - (c - left));      /* the row's list */ \
 				const uint32_t held = (((uint32_t)e0_##i & 0xfffffffu) != HAO_MRG_END) + HAO_MRG_BC(rz_##i), j0 = c - left - held - 1; uint32_t j1, nf = 0, nr = 0; \
 				for (j1 = j0; j1 < c && hao_info_rid(lst[j1]) == T; ++j1) { if (z ^ hao_info_rev(lst[j1])) ++nr; else ++nf; } \
@@ -196,6 +196,157 @@ __global__ __launch_bounds__(256, BUF == 4 ? (RPL == 8 ? 3 : 5) : 4) void seed_m
 		T = Tn;
 	}
 	if (lane == 0) S.g_cnt[r] = ngr;
+
+}
+
+// ---- the same merge with FOUR waves per read (one workgroup = one read) ----
+// One wave per read needs eight rows per lane: 168 registers, three waves per SIMD, and every step is one wave's ~500 dependent instructions - the kernel sits at the
+// table kernels' speed (9.7 ms per 993 M-anchor launch) with the SIMDs a third busy.  Here wave w owns rows [w * 64 RPL, (w + 1) * 64 RPL) of the read (RPL = 2: 60-odd
+// registers, eight waves per SIMD, a step is a quarter of the work per wave) and the four waves agree on the step through ONE exchange: every wave posts its own
+// smallest head target m_w with the forward / opposite-strand counts of its rows that stand on m_w, a barrier, everybody reads the four posts: T = min m_w, the waves
+// with m_w = T emit (wave order = row order: their output starts are prefix sums of the posted counts) and advance, the others sit the step out.  The posts alternate
+// between two sets of LDS words, so one barrier per step is enough (a wave can be at most one step ahead of the slowest).  A target with several records in a row is
+// redone as in the one-wave kernel, with one more exchange for the per-wave run totals.
+template<int RPL> struct hao_seed4w_lds { static constexpr uint32_t ROWS_W = 64u * RPL, ROWS = 4 * ROWS_W, TOTAL = ROWS * 12; };
+
+template<int RPL, int BUF>
+__global__ __launch_bounds__(256, RPL <= 2 ? 6 : 4) void seed_mergew_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, const uint32_t *__restrict__ len, const uint32_t *__restrict__ order, uint32_t *ovf_list, unsigned long long *ovf_cnt)
+{
+	static_assert(BUF == 1 || BUF == 4, "records per list read");
+	constexpr uint32_t ROWS_W = hao_seed4w_lds<RPL>::ROWS_W, ROWS = hao_seed4w_lds<RPL>::ROWS;
+	extern __shared__ uint32_t mg_smem[];
+	__shared__ uint4 s_x[2][4];      // [set][wave] the wave's post: smallest head target, forward hits, opposite-strand hits of its rows on it
+	__shared__ uint2 s_y[4];         // [wave] redo: forward / opposite-strand records of the target in the wave's rows
+	const int wv = threadIdx.x >> 6, lane = hao_lane();
+	uint2 *l_q = (uint2*)mg_smem;                        // [ROWS] self_offset, cnt of the row's hits
+	uint16_t *l_cnt = (uint16_t*)(l_q + ROWS);           // [ROWS] length of the row's list
+	uint16_t *l_qi = l_cnt + ROWS;                       // [ROWS] the row's minimizer
+	const uint64_t slot = order ? (uint64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (uint64_t)blockIdx.x;
+	if (slot == 0 && threadIdx.x == 0) S.g_cnt[S.n_sel] = 0;
+	if (slot >= S.n_sel) return;
+	const uint64_t r = order ? order[slot] : slot;
+	const uint64_t s = S.seg[r]; const uint32_t n = (uint32_t)(S.seg[r + 1] - s);
+	if (n == 0) { if (threadIdx.x == 0) S.g_cnt[r] = 0; return; }
+	const uint64_t m0 = S.mz_off[S.rid_lo + r], li0 = m0 - S.mz0; const uint32_t nq = (uint32_t)(S.mz_off[S.rid_lo + r + 1] - m0);
+	// rows = the minimizers with a list, in order; every wave runs the whole (short) compaction and keeps the rows of its own range
+	const uint32_t row0 = wv * ROWS_W, mrg_row0 = row0;
+	uint32_t nk = 0;
+	if (nq <= HAO_QTAB_CAP)
+		for (uint32_t b = 0; b < nq && nk <= ROWS; b += 64) {
+			const uint32_t q = b + lane; const bool ne = q < nq && S.s_n[li0 + q] != 0;
+			const unsigned long long bal = __ballot(ne); const uint32_t k = nk + hao_mbcnt(bal);
+			if (ne && k >= row0 && k < row0 + ROWS_W) l_qi[k] = (uint16_t)q;
+			nk += (uint32_t)__popcll(bal);
+		}
+	if (nq > HAO_QTAB_CAP || nk > ROWS) { if (threadIdx.x == 0) ovf_list[atomicAdd(ovf_cnt, 1ULL)] = (uint32_t)r; return; }      // (the same decision in every wave) left to the table kernels
+	HAO_LOCKSTEP();
+	HAO_MRG_ROWS_DO(HAO_MRG_DECL)
+#define HAO_MRGW_INIT(i) if constexpr (i < RPL) { \
+		const uint32_t row = row0 + i * 64 + lane; \
+		if (row < nk) { \
+			const uint32_t q = l_qi[row], c = S.s_n[li0 + q], z = hao_info_rev(S.mz_info[m0 + q]); \
+			const uint64_t st = S.s_start[li0 + q]; \
+			l_q[row] = make_uint2(S.q_pos[li0 + q], S.q_cnt[li0 + q]); l_cnt[row] = (uint16_t)c; \
+			e0_##i = sinfo[st] ^ (uint64_t)z << 55; nx_##i = st + 1; rz_##i = z << 31; \
+			if (c > 1) HAO_MRG_FILL(i, c - 1, z) \
+		} }
+	HAO_MRG_ROWS_DO(HAO_MRGW_INIT)
+	hao_hit_t *hits = S.hits + s; uint64_t *g_tmp = S.g_tmp + s; uint16_t *hq = S.hq ? S.hq + s : nullptr;
+	uint32_t run = 0, ngr = 0, par = 0, T_prev = HAO_MRG_END, run_prev = 0;
+#define HAO_MRGW_HP(i) unsigned long long hp_##i = 0;      /* rows of this wave that took part in the last step */
+	HAO_MRG_ROWS_DO(HAO_MRGW_HP)
+	for (;;) {
+		uint32_t mw; HAO_MRG_NEXT(mw)
+		uint32_t c0 = 0, c1 = 0;
+#define HAO_MRGW_MASK(i) unsigned long long h_##i = 0, v_##i = 0; if constexpr (i < RPL) { \
+			h_##i = __ballot(((uint32_t)e0_##i & 0xfffffffu) == mw); v_##i = __ballot(((uint32_t)(e0_##i >> 32) & 0x800000u) != 0) & h_##i; \
+			c0 += (uint32_t)__popcll(h_##i & ~v_##i); c1 += (uint32_t)__popcll(v_##i); }
+		HAO_MRG_ROWS_DO(HAO_MRGW_MASK)
+		if (mw == HAO_MRG_END) c0 = c1 = 0;      // (exhausted rows all "stand on" the end mark)
+		if (lane == 0) s_x[par][wv] = make_uint4(mw, c0, c1, 0);
+		__syncthreads();
+		const uint4 x0 = s_x[par][0], x1 = s_x[par][1], x2 = s_x[par][2], x3 = s_x[par][3];
+		par ^= 1;
+		const uint32_t T = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(min(x0.x, x1.x), min(x2.x, x3.x)));
+		if (T == HAO_MRG_END) break;
+		if (T == T_prev) {
+			// ---- some row holds several records of T_prev: redo that target in full (the rows that took part stand one record behind their head) ----
+			const uint32_t tlen = len[T];
+			uint32_t f_mine = 0, r_mine = 0;
+#define HAO_MRGW_CNT(i) if constexpr (i < RPL) { if (hp_##i >> lane & 1) HAO_MRG_RUN(i, f_mine += nf; r_mine += nr; (void)lst;) }
+			HAO_MRG_ROWS_DO(HAO_MRGW_CNT)
+			uint32_t f_w = hao_wave_incl_scan_u32(f_mine), r_w = hao_wave_incl_scan_u32(r_mine);
+			f_w = (uint32_t)__builtin_amdgcn_readlane((int)f_w, 63); r_w = (uint32_t)__builtin_amdgcn_readlane((int)r_w, 63);
+			if (lane == 0) s_y[wv] = make_uint2(f_w, r_w);
+			__syncthreads();
+			uint32_t p0 = run_prev, p1 = run_prev, f_all = 0, r_all = 0;
+#pragma unroll
+			for (int w = 0; w < 4; ++w) { const uint2 y = s_y[w]; if (w < wv) { p0 += y.x; p1 += y.y; } f_all += y.x; r_all += y.y; }
+			p1 += f_all;
+#define HAO_MRGW_REDO(i) if constexpr (i < RPL) { if (hp_##i) { \
+				const bool mine = hp_##i >> lane & 1; uint32_t nf_ = 0, nr_ = 0; \
+				if (mine) HAO_MRG_RUN(i, nf_ = nf; nr_ = nr; (void)lst;) \
+				const uint32_t inf = hao_wave_incl_scan_u32(nf_), inr = hao_wave_incl_scan_u32(nr_); \
+				const uint32_t tf = (uint32_t)__builtin_amdgcn_readlane((int)inf, 63), tr = (uint32_t)__builtin_amdgcn_readlane((int)inr, 63); \
+				if (mine) HAO_MRG_RUN(i, \
+					const uint2 qw = l_q[row]; const uint16_t qi = l_qi[row]; \
+					uint32_t af = p0 + inf - nf, ar = p1 + inr; \
+					for (uint32_t j = j0; j < j1; ++j) { \
+						const uint64_t y = lst[j] ^ (uint64_t)z << 55; const uint32_t rv = (uint32_t)(y >> 55) & 1, at = rv ? --ar : af++; \
+						hits[at] = hao_mrg_hit(y, T, rv, tlen, qw); \
+						if (hq) hq[at] = qi; \
+					} \
+					e0_##i = j1 < c ? lst[j1] ^ (uint64_t)z << 55 : HAO_MRG_SENT; \
+					nx_##i = (uint64_t)(lst - sinfo) + min(c, j1 + 1); rz_##i = z << 31; \
+					if (j1 + 1 < c) HAO_MRG_FILL(i, c - (j1 + 1), z)) \
+				p0 += tf; p1 += tr; } }
+			HAO_MRG_ROWS_DO(HAO_MRGW_REDO)
+			run = run_prev + f_all + r_all;
+			T_prev = HAO_MRG_END;
+#define HAO_MRGW_CLR(i) hp_##i = 0;
+			HAO_MRG_ROWS_DO(HAO_MRGW_CLR)
+			continue;      // the heads have moved: the waves post again
+		}
+		// this step's output starts: the waves that stand on T, in wave order
+		const bool my = mw == T;
+		uint32_t p0 = run, p1 = run, c0_all = 0, c1_all = 0;
+		{ const uint4 xs[4] = {x0, x1, x2, x3};
+#pragma unroll
+		  for (int w = 0; w < 4; ++w) if (xs[w].x == T) { if (w < wv) { p0 += xs[w].y; p1 += xs[w].z; } c0_all += xs[w].y; c1_all += xs[w].z; } }
+		p1 += c0_all;
+		if (threadIdx.x == 0) g_tmp[ngr] = (uint64_t)T << 32 | run;
+		++ngr; run_prev = run; run += c0_all + c1_all; T_prev = T;
+		if (my) {
+			const uint32_t tlen = len[T];
+#define HAO_MRGW_EMIT(i) if constexpr (i < RPL) { hp_##i = h_##i; if (h_##i) { \
+				const uint64_t y = e0_##i; const unsigned long long f_ = h_##i & ~v_##i; \
+				const uint32_t rv = (uint32_t)(y >> 55) & 1, a_ = hao_mbcnt(f_), t_ = hao_mbcnt(h_##i); \
+				const uint32_t at = rv ? p1 + (t_ - a_) : p0 + a_; \
+				p0 += (uint32_t)__popcll(f_); p1 += (uint32_t)__popcll(v_##i); \
+				if (((uint32_t)y & 0xfffffffu) == T) { \
+					const uint32_t row = row0 + i * 64 + lane; \
+					hits[at] = hao_mrg_hit(y, T, rv, tlen, l_q[row]); \
+					if (hq) hq[at] = l_qi[row]; \
+					const uint32_t bc_ = HAO_MRG_BC(rz_##i), z_ = HAO_MRG_Z(rz_##i); \
+					e0_##i = bc_ ? b0_##i ^ (uint64_t)z_ << 55 : HAO_MRG_SENT; \
+					if constexpr (BUF == 4) { b0_##i = b1_##i; b1_##i = b2_##i; b2_##i = b3_##i; } \
+					if (bc_ > 1) rz_##i -= 1u << 12; \
+					else if (HAO_MRG_REM(rz_##i)) HAO_MRG_FILL(i, HAO_MRG_REM(rz_##i), z_) \
+					else rz_##i = z_ << 31; \
+				} } }
+			HAO_MRG_ROWS_DO(HAO_MRGW_EMIT)
+		} else {
+			HAO_MRG_ROWS_DO(HAO_MRGW_CLR)
+		}
+	}
+	if (threadIdx.x == 0) S.g_cnt[r] = ngr;
+#undef HAO_MRGW_INIT
+#undef HAO_MRGW_HP
+#undef HAO_MRGW_MASK
+#undef HAO_MRGW_CNT
+#undef HAO_MRGW_REDO
+#undef HAO_MRGW_CLR
+#undef HAO_MRGW_EMIT
 #undef HAO_MRG_DECL
 #undef HAO_MRG_FILL
 #undef HAO_MRG_INIT
