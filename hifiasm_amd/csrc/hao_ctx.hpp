@@ -69,7 +69,7 @@ struct hao_switches {
 		if (const char *e = getenv("HAO_SEED_MERGE")) { const int v = atoi(e); seed_merge = v == 0 ? 0 : v == 4 ? 4 : 8; }      // the seed stage by merge (hao_query4.cuh; rows per lane), 0 = A/B: the table kernels for every read (rounds 1 - 4)
 		if (const char *e = getenv("HAO_SEED_MERGEW")) { const int v = atoi(e); seed_mergew = v == 0 ? 0 : v == 4 ? 4 : 2; }      // the merge with four waves per read (rows per lane: 2, default; 4), 0 = A/B: one wave per read (HAO_SEED_MERGE rows per lane)
 		if (const char *e = getenv("HAO_SEED_LOCUS")) seed_locus = atoi(e) ? 1 : 0;      // A/B: the merge kernel takes a batch's reads in locus order (1: kernel - 10 %, but the key pass + sort cost more than that: profiles/r05) or in read order (0, default)
-		if (const char *e = getenv("HAO_SEED_MBUF")) seed_mbuf = atoi(e) == 1 ? 1 : 4;      // records per list read of the merge kernel (8 or 32 bytes)
+		if (const char *e = getenv("HAO_SEED_MBUF")) { const int v = atoi(e); seed_mbuf = v == 1 ? 1 : v == 8 ? 8 : 4; }      // records per list read of the merge kernels (8, 32, or - four-wave kernel only - aligned 64 bytes)
 		if (const char *e = getenv("HAO_FT_PASSES")) ft_passes = std::max(0, atoi(e));      // ha_ft_gen in this many hash-range passes (0: as many as the free device memory asks for)
 		if (const char *e = getenv("HAO_FT_CHUNK_SLOTS")) ft_chunk_slots = std::max(0LL, atoll(e));      // (tests) k-mer slots hashed per chunk of reads in pass mode
 		seed_v2 = on("HAO_SEED_V2");      // A/B: the seed kernel with a wave-private, barrier-free scatter pass (hao_query2.cuh; round 4: bit-exact, 1.5 x slower - fewer waves per CU)

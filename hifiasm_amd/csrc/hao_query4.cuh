@@ -40,6 +40,7 @@ __device__ __forceinline__ hao_hit_t hao_mrg_hit(uint64_t y, uint32_t T, uint32_
 	return h;
 }
 struct hao_rec4 { uint64_t a, b, c, d; };      // four index records: one 32-byte read of a row's list
+struct hao_rec8 { uint64_t a, b, c, d, e, f, g, h; };      // eight: one aligned 64-byte block
 
 // every row i < RPL: ROWS_DO(X) expands X(0) ... X(7) under `if constexpr`
 #define HAO_MRG_ROWS_DO(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
@@ -104,12 +105,23 @@ __global__ __launch_bounds__(256, BUF == 4 ? (RPL == 8 ? 3 : 5) : 4) void seed_m
 	// per row: head record e0 (with the HIT's strand in bit 55; rid = HAO_MRG_END beyond the list), the BUF records behind it as the index holds them (b0 first; the
 	// strand is folded in when a record becomes the head - a row's read is then waited for a step after it was issued, not at once), index of the next record to
 	// load, the bookkeeping word
-#define HAO_MRG_DECL(i) uint64_t e0_##i = HAO_MRG_SENT, b0_##i = HAO_MRG_SENT, b1_##i = HAO_MRG_SENT, b2_##i = HAO_MRG_SENT, b3_##i = HAO_MRG_SENT, nx_##i = 0; uint32_t rz_##i = 0;
+#define HAO_MRG_DECL(i) uint64_t e0_##i = HAO_MRG_SENT, b0_##i = HAO_MRG_SENT, b1_##i = HAO_MRG_SENT, b2_##i = HAO_MRG_SENT, b3_##i = HAO_MRG_SENT, b4_##i = HAO_MRG_SENT, b5_##i = HAO_MRG_SENT, b6_##i = HAO_MRG_SENT, b7_##i = HAO_MRG_SENT, nx_##i = 0; uint32_t rz_##i = 0;
 	HAO_MRG_ROWS_DO(HAO_MRG_DECL)
 	// (re)fill the buffer of row i from record index nx: up to BUF of the `left` records not loaded yet.  A 32-byte read may run up to three records past the list
 	// (into the next list or the slack behind the array: every allocation of the index keeps at least eight records of it); the count says which are real
-#define HAO_MRG_FILL(i, left, z) { const uint32_t take_ = min((uint32_t)BUF, (left)); \
-			if constexpr (BUF == 4) { const hao_rec4 v_ = *(const hao_rec4*)(sinfo + nx_##i); b0_##i = v_.a; b1_##i = v_.b; b2_##i = v_.c; b3_##i = v_.d; } \
+#define HAO_MRG_FILL(i, left, z) { uint32_t take_ = min((uint32_t)BUF, (left)); \
+			if constexpr (BUF == 8) {      /* the ALIGNED 64-byte block that holds record nx: every sector of a list crosses the fabric once.  Only a row's first read (and the one \
+			                                  after a redo) starts inside a block: its records move down to b0 (a three-stage shift), later reads start on a block boundary */ \
+				const uint32_t off_ = (uint32_t)nx_##i & 7u; take_ = min(8u - off_, (left)); \
+				const hao_rec8 v_ = *(const hao_rec8*)(sinfo + (nx_##i - off_)); \
+				b0_##i = v_.a; b1_##i = v_.b; b2_##i = v_.c; b3_##i = v_.d; b4_##i = v_.e; b5_##i = v_.f; b6_##i = v_.g; b7_##i = v_.h; \
+				if (off_) { \
+					if (off_ & 4) { b0_##i = b4_##i; b1_##i = b5_##i; b2_##i = b6_##i; b3_##i = b7_##i; } \
+					if (off_ & 2) { b0_##i = b2_##i; b1_##i = b3_##i; b2_##i = b4_##i; b3_##i = b5_##i; b4_##i = b6_##i; b5_##i = b7_##i; } \
+					if (off_ & 1) { b0_##i = b1_##i; b1_##i = b2_##i; b2_##i = b3_##i; b3_##i = b4_##i; b4_##i = b5_##i; b5_##i = b6_##i; b6_##i = b7_##i; } \
+				} \
+			} \
+			else if constexpr (BUF == 4) { const hao_rec4 v_ = *(const hao_rec4*)(sinfo + nx_##i); b0_##i = v_.a; b1_##i = v_.b; b2_##i = v_.c; b3_##i = v_.d; } \
 			else b0_##i = sinfo[nx_##i]; \
 			nx_##i += take_; rz_##i = ((left) - take_) | take_ << 12 | (z) << 31; }
 #define HAO_MRG_INIT(i) if constexpr (i < RPL) { \
@@ -150,7 +162,8 @@ __global__ __launch_bounds__(256, BUF == 4 ? (RPL == 8 ? 3 : 5) : 4) void seed_m
 				/* advance the row: the first buffered record becomes the head, the buffer moves up, and an emptied buffer is read again */ \
 				const uint32_t bc_ = HAO_MRG_BC(rz_##i), z_ = HAO_MRG_Z(rz_##i); \
 				e0_##i = bc_ ? b0_##i ^ (uint64_t)z_ << 55 : HAO_MRG_SENT; \
-				if constexpr (BUF == 4) { b0_##i = b1_##i; b1_##i = b2_##i; b2_##i = b3_##i; } \
+				if constexpr (BUF >= 4) { b0_##i = b1_##i; b1_##i = b2_##i; b2_##i = b3_##i; } \
+				if constexpr (BUF == 8) { b3_##i = b4_##i; b4_##i = b5_##i; b5_##i = b6_##i; b6_##i = b7_##i; } \
 				if (bc_ > 1) rz_##i -= 1u << 12; \
 				else if (HAO_MRG_REM(rz_##i)) HAO_MRG_FILL(i, HAO_MRG_REM(rz_##i), z_) \
 				else rz_##i = z_ << 31; \
@@ -210,9 +223,9 @@ __global__ __launch_bounds__(256, BUF == 4 ? (RPL == 8 ? 3 : 5) : 4) void seed_m
 template<int RPL> struct hao_seed4w_lds { static constexpr uint32_t ROWS_W = 64u * RPL, ROWS = 4 * ROWS_W, TOTAL = ROWS * 12; };
 
 template<int RPL, int BUF>
-__global__ __launch_bounds__(256, RPL <= 2 ? 6 : 4) void seed_mergew_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, const uint32_t *__restrict__ len, const uint32_t *__restrict__ order, uint32_t *ovf_list, unsigned long long *ovf_cnt)
+__global__ __launch_bounds__(256, RPL <= 2 ? (BUF == 8 ? 5 : 6) : 4) void seed_mergew_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, const uint32_t *__restrict__ len, const uint32_t *__restrict__ order, uint32_t *ovf_list, unsigned long long *ovf_cnt)
 {
-	static_assert(BUF == 1 || BUF == 4, "records per list read");
+	static_assert(BUF == 1 || BUF == 4 || BUF == 8, "records per list read");
 	constexpr uint32_t ROWS_W = hao_seed4w_lds<RPL>::ROWS_W, ROWS = hao_seed4w_lds<RPL>::ROWS;
 	extern __shared__ uint32_t mg_smem[];
 	__shared__ uint4 s_x[2][4];      // [set][wave] the wave's post: smallest head target, forward hits, opposite-strand hits of its rows on it
@@ -329,7 +342,8 @@ __global__ __launch_bounds__(256, RPL <= 2 ? 6 : 4) void seed_mergew_kernel(hao_
 					if (hq) hq[at] = l_qi[row]; \
 					const uint32_t bc_ = HAO_MRG_BC(rz_##i), z_ = HAO_MRG_Z(rz_##i); \
 					e0_##i = bc_ ? b0_##i ^ (uint64_t)z_ << 55 : HAO_MRG_SENT; \
-					if constexpr (BUF == 4) { b0_##i = b1_##i; b1_##i = b2_##i; b2_##i = b3_##i; } \
+					if constexpr (BUF >= 4) { b0_##i = b1_##i; b1_##i = b2_##i; b2_##i = b3_##i; } \
+				if constexpr (BUF == 8) { b3_##i = b4_##i; b4_##i = b5_##i; b5_##i = b6_##i; b6_##i = b7_##i; } \
 					if (bc_ > 1) rz_##i -= 1u << 12; \
 					else if (HAO_MRG_REM(rz_##i)) HAO_MRG_FILL(i, HAO_MRG_REM(rz_##i), z_) \
 					else rz_##i = z_ << 31; \

@@ -65,14 +65,15 @@ extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t 
 			if (launch((unsigned)ovf0_cnt, 256, lds1, call)) return fail(err, errcap, hao_simt::g.error);
 		}
 	}
-	else if (mode == 8 || mode == 9) {      // the four-wave merge kernel: a workgroup per read (mode 8: 2 rows per lane, 32-byte reads - the library's default; 9: 1 row per lane, 8-byte reads: more reads overflow)
+	else if (mode >= 8 && mode <= 10) {      // the four-wave merge kernel: a workgroup per read (mode 8: 2 rows per lane, 32-byte reads; 9: 1 row per lane, 8-byte reads: more reads overflow; 10: 2 rows per lane, aligned 64-byte reads)
 		std::vector<char> chosen(n + 4, 0); for (uint32_t b = 0; b < n_blocks; ++b) chosen[blocks[b]] = 1;
 		for (uint64_t g = 0; g < n; ++g) {
 			if (!chosen[g]) continue;
 			std::function<void()> call;
 			if (mode == 8) call = [&] { seed_mergew_kernel<2, 4>(sa, sinfo, len, nil32, ovf0.data(), &ovf0_cnt); };
+			else if (mode == 10) call = [&] { seed_mergew_kernel<2, 8>(sa, sinfo, len, nil32, ovf0.data(), &ovf0_cnt); };
 			else call = [&] { seed_mergew_kernel<1, 1>(sa, sinfo, len, nil32, ovf0.data(), &ovf0_cnt); };
-			hao_simt::g.body = call; hao_simt::g.nthreads = 256; hao_simt::g.error.clear(); hao_simt::g.dyn_lds.assign((mode == 8 ? hao_seed4w_lds<2>::TOTAL : hao_seed4w_lds<1>::TOTAL) + 64, (char)0xa5);
+			hao_simt::g.body = call; hao_simt::g.nthreads = 256; hao_simt::g.error.clear(); hao_simt::g.dyn_lds.assign((mode != 9 ? hao_seed4w_lds<2>::TOTAL : hao_seed4w_lds<1>::TOTAL) + 64, (char)0xa5);
 			blockDim = {256, 1, 1}; gridDim = {(unsigned)n, 1, 1}; blockIdx = {(unsigned)g, 0, 0};
 			if (!hao_simt::run_block()) return fail(err, errcap, hao_simt::g.error);
 		}

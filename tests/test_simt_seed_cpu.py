@@ -98,7 +98,8 @@ def run_seed(rs, inp, blocks, mode=0, qcap_force=0, want_hq=True):
     seg = np.zeros(n + 1, dtype=np.uint64); hits = np.zeros((A + 1, 4), dtype=np.uint32); g_tmp = np.zeros(A + 1, dtype=np.uint64); g_cnt = np.zeros(n + 1, dtype=np.uint64)
     hq = np.zeros(A + 64, dtype=np.uint16); stats = np.zeros(8, dtype=np.uint64); err = C.create_string_buffer(400)
     blocks = np.ascontiguousarray(blocks, dtype=np.uint32)
-    rc = lib().simt_seed_run(C.c_uint64(n), _p(inp["mz_off"]), _p(inp["info"]), _p(inp["lk"]), _p(inp["wgt"]), _p(inp["sinfo"]), _p(inp["len"]), C.c_uint64(n),
+    sinfo = np.concatenate([np.ascontiguousarray(inp["sinfo"], dtype=np.uint64), np.full(16, 0x5a5a5a5a5a5a5a5a, dtype=np.uint64)])      # (the library keeps 8 records of slack behind the index: the merge kernels read whole 32- / 64-byte blocks)
+    rc = lib().simt_seed_run(C.c_uint64(n), _p(inp["mz_off"]), _p(inp["info"]), _p(inp["lk"]), _p(inp["wgt"]), _p(sinfo), _p(inp["len"]), C.c_uint64(n),
                              C.c_int(mode), C.c_uint32(qcap_force), _p(blocks), C.c_uint32(blocks.size), C.c_int(1 if want_hq else 0),
                              _p(seg), _p(hits), C.c_uint64(A), _p(g_tmp), _p(g_cnt), _p(hq), _p(stats), err, C.c_int(400))
     assert rc == 0, err.value.decode()
@@ -193,12 +194,13 @@ def test_seed_kernels_with_many_bins(n_targets, nq, list_len, mode):
                                             ("hifi", 1, 4), ("rr", 1, 4), ("ont", 2, 4), ("edge", 1, 4),
                                             ("hifi", 1, 5), ("rr", 1, 5), ("nn", 1, 5), ("ont", 1, 5), ("edge", 1, 5), ("k40", 1, 5), ("hpc0", 1, 5), ("fz2", 1, 5), ("rr_heavy", 25, 5), ("rr", 1, 6),
                                             ("hifi", 1, 7), ("rr", 1, 7), ("edge", 1, 7), ("ont", 1, 7),
-                                            ("hifi", 1, 8), ("rr", 1, 8), ("nn", 1, 8), ("ont", 1, 8), ("edge", 1, 8), ("k40", 1, 8), ("hpc0", 1, 8), ("fz2", 1, 8), ("rr_heavy", 25, 8), ("hifi", 1, 9), ("rr", 1, 9)])
+                                            ("hifi", 1, 8), ("rr", 1, 8), ("nn", 1, 8), ("ont", 1, 8), ("edge", 1, 8), ("k40", 1, 8), ("hpc0", 1, 8), ("fz2", 1, 8), ("rr_heavy", 25, 8), ("hifi", 1, 9), ("rr", 1, 9),
+                                            ("hifi", 1, 10), ("rr", 1, 10), ("nn", 1, 10), ("ont", 1, 10), ("edge", 1, 10), ("k40", 1, 10), ("hpc0", 1, 10), ("fz2", 1, 10), ("rr_heavy", 25, 10)])
 def test_merge_kernel_against_the_oracle(name, step, mode):
     """mode 3: 8 rows per lane (reads with up to 512 minimizers that have a list), mode 4: 2 rows per lane - most reads of these scenarios then overflow to the table kernels,
     which checks the hand-over (overflow list -> 512-slot launch -> the launches behind it); modes 5 / 6: the same with 32-byte list reads (four records behind every head);
     mode 7: every read, in locus order (smallest target, position in it), an eighth of the order per XCD; modes 8 / 9: the four-wave kernel (a workgroup per read, one
-    exchange + barrier per step), 2 rows per lane with 32-byte reads / 1 row per lane with 8-byte reads"""
+    exchange + barrier per step), 2 rows per lane with 32-byte reads / 1 row per lane with 8-byte reads; mode 10: 2 rows per lane with ALIGNED 64-byte reads (the library's default)"""
     rs, o, inp = seed_inputs(name)
     blocks = np.arange(0, rs.n, step)
     out = run_seed(rs, inp, blocks, mode=mode)
@@ -210,7 +212,8 @@ def test_merge_kernel_against_the_oracle(name, step, mode):
 
 @pytest.mark.parametrize("n_targets,nq,list_len,mode,run_rate", [(150, 120, 40, 3, 0.08), (600, 200, 50, 3, 0.08), (2500, 260, 60, 3, 0.08), (40, 300, 60, 3, 0.5), (12, 500, 30, 3, 0.9), (600, 200, 50, 4, 0.08),
                                                                  (150, 120, 40, 5, 0.08), (600, 200, 50, 5, 0.08), (2500, 260, 60, 5, 0.08), (40, 300, 60, 5, 0.5), (12, 500, 30, 5, 0.9), (600, 200, 50, 6, 0.08), (30, 200, 5, 5, 0.3),
-                                                                 (150, 120, 40, 8, 0.08), (600, 200, 50, 8, 0.08), (2500, 260, 60, 8, 0.08), (40, 300, 60, 8, 0.5), (12, 500, 30, 8, 0.9), (30, 200, 5, 8, 0.3), (600, 300, 50, 9, 0.08), (25, 540, 20, 8, 0.6)])
+                                                                 (150, 120, 40, 8, 0.08), (600, 200, 50, 8, 0.08), (2500, 260, 60, 8, 0.08), (40, 300, 60, 8, 0.5), (12, 500, 30, 8, 0.9), (30, 200, 5, 8, 0.3), (600, 300, 50, 9, 0.08), (25, 540, 20, 8, 0.6),
+                                                                 (150, 120, 40, 10, 0.08), (600, 200, 50, 10, 0.08), (2500, 260, 60, 10, 0.08), (40, 300, 60, 10, 0.5), (12, 500, 30, 10, 0.9), (30, 200, 5, 10, 0.3), (25, 540, 20, 10, 0.6), (300, 400, 9, 10, 0.2)])
 def test_merge_kernel_with_runs(n_targets, nq, list_len, mode, run_rate):
     """fabricated indexes: many targets (many steps with a single hit), and lists in which a target comes several times in a row (the redo of a target with the
     per-row runs, forward strand in list order, opposite strand in reverse list order) - up to lists that are a handful of long runs"""
@@ -234,5 +237,5 @@ def test_merge_kernel_with_runs(n_targets, nq, list_len, mode, run_rate):
     assert int(g_cnt[0]) == first.size and (g_tmp[s:s + first.size] == (tid[first].astype(np.uint64) << np.uint64(32) | first.astype(np.uint64))).all()
     m0 = 0; q = hq[s:e].astype(np.int64)
     assert (((inp["info"][m0 + q] >> np.uint64(28)) & np.uint64((1 << 27) - 1)).astype(np.uint32) == want[:, 2]).all()
-    rows = {3: 512, 4: 128, 5: 512, 6: 128, 7: 512, 8: 512, 9: 256}[mode]
+    rows = {3: 512, 4: 128, 5: 512, 6: 128, 7: 512, 8: 512, 9: 256, 10: 512}[mode]
     assert int(st[6]) == (1 if nq - len([q for q in range(nq) if q % 13 == 5]) > rows else 0)
