@@ -351,16 +351,16 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 				}
 				if (c->sw.seed_mergew) {      // four waves per read: a workgroup per read (default)
 					const dim3 gw_(order_ ? (unsigned)((n + 7) / 8 * 8) : (unsigned)n), b_(256);
-					if (c->sw.seed_mergew == 4) hipLaunchKernelGGL((seed_mergew_kernel<4, 4>), gw_, b_, hao_seed4w_lds<4>::TOTAL, c->stream, sa_, sinfo_, len_, order_, ovf0, d_ovf0);
-					else if (c->sw.seed_mbuf == 1) hipLaunchKernelGGL((seed_mergew_kernel<2, 1>), gw_, b_, hao_seed4w_lds<2>::TOTAL, c->stream, sa_, sinfo_, len_, order_, ovf0, d_ovf0);
-					else if (c->sw.seed_mbuf == 8) hipLaunchKernelGGL((seed_mergew_kernel<2, 8>), gw_, b_, hao_seed4w_lds<2>::TOTAL, c->stream, sa_, sinfo_, len_, order_, ovf0, d_ovf0);
-					else hipLaunchKernelGGL((seed_mergew_kernel<2, 4>), gw_, b_, hao_seed4w_lds<2>::TOTAL, c->stream, sa_, sinfo_, len_, order_, ovf0, d_ovf0);
+					if (c->sw.seed_mergew == 4) hipLaunchKernelGGL((seed_mergew_kernel<4, 4>), gw_, b_, hao_seed4w_lds<4>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
+					else if (c->sw.seed_mbuf == 1) hipLaunchKernelGGL((seed_mergew_kernel<2, 1>), gw_, b_, hao_seed4w_lds<2>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
+					else if (c->sw.seed_mbuf == 8) hipLaunchKernelGGL((seed_mergew_kernel<2, 8>), gw_, b_, hao_seed4w_lds<2>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
+					else hipLaunchKernelGGL((seed_mergew_kernel<2, 4>), gw_, b_, hao_seed4w_lds<2>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
 				} else {
 				const dim3 g_(nwg), b_(256);
-				if (c->sw.seed_merge == 4 && c->sw.seed_mbuf == 1) hipLaunchKernelGGL((seed_merge_kernel<4, 1>), g_, b_, hao_seed4_lds<4>::TOTAL, c->stream, sa_, sinfo_, len_, order_, ovf0, d_ovf0);
-				else if (c->sw.seed_merge == 4) hipLaunchKernelGGL((seed_merge_kernel<4, 4>), g_, b_, hao_seed4_lds<4>::TOTAL, c->stream, sa_, sinfo_, len_, order_, ovf0, d_ovf0);
-				else if (c->sw.seed_mbuf == 1) hipLaunchKernelGGL((seed_merge_kernel<8, 1>), g_, b_, hao_seed4_lds<8>::TOTAL, c->stream, sa_, sinfo_, len_, order_, ovf0, d_ovf0);
-				else hipLaunchKernelGGL((seed_merge_kernel<8, 4>), g_, b_, hao_seed4_lds<8>::TOTAL, c->stream, sa_, sinfo_, len_, order_, ovf0, d_ovf0);
+				if (c->sw.seed_merge == 4 && c->sw.seed_mbuf == 1) hipLaunchKernelGGL((seed_merge_kernel<4, 1>), g_, b_, hao_seed4_lds<4>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
+				else if (c->sw.seed_merge == 4) hipLaunchKernelGGL((seed_merge_kernel<4, 4>), g_, b_, hao_seed4_lds<4>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
+				else if (c->sw.seed_mbuf == 1) hipLaunchKernelGGL((seed_merge_kernel<8, 1>), g_, b_, hao_seed4_lds<8>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
+				else hipLaunchKernelGGL((seed_merge_kernel<8, 4>), g_, b_, hao_seed4_lds<8>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
 				}
 			}
 			HAO_CHECK_LAUNCH();

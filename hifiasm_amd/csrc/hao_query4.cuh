@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void seed_locus_kernel(hao_seed_args S, const 
 // ~500 rows of every wave of the XCD had their turn, by when the 4 MB L2 has lost it: with 8-byte reads a 128-byte line crosses the fabric up to 16 times
 // (measured: 122 ms per configs[2] pass against 59 ms for the table kernels - 6 TB/s of line traffic for 0.4 TB/s of records), with 32-byte reads 4 times.
 template<int RPL, int BUF>
-__global__ __launch_bounds__(256, BUF == 4 ? (RPL == 8 ? 3 : 5) : 4) void seed_merge_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, const uint32_t *__restrict__ len, const uint32_t *__restrict__ order, uint32_t *ovf_list, unsigned long long *ovf_cnt)
+__global__ __launch_bounds__(256, BUF == 4 ? (RPL == 8 ? 3 : 5) : 4) void seed_merge_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, const uint32_t *__restrict__ len, const uint32_t *__restrict__ order, uint32_t max_n, uint32_t *ovf_list, unsigned long long *ovf_cnt)
 {
 	static_assert(BUF == 1 || BUF == 4, "records per list read");
 	constexpr uint32_t ROWS = hao_seed4_lds<RPL>::ROWS, mrg_row0 = 0;      // (mrg_row0: first row of the wave - the row macros are shared with the four-wave kernel below)
@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256, BUF == 4 ? (RPL == 8 ? 3 : 5) : 4) void seed_m
 			if (ne && k < ROWS) l_qi[k] = (uint16_t)q;
 			nk += (uint32_t)__popcll(bal);
 		}
-	if (nq > HAO_QTAB_CAP || nk > ROWS) { if (lane == 0) ovf_list[atomicAdd(ovf_cnt, 1ULL)] = (uint32_t)r; return; }      // left to the table kernels
+	if (nq > HAO_QTAB_CAP || nk > ROWS || n > max_n) { if (lane == 0) ovf_list[atomicAdd(ovf_cnt, 1ULL)] = (uint32_t)r; return; }      // left to the table kernels (max_n: a read with that many
+	                                                                                                                                       // seed hits crosses repeat families - hundreds of targets, a step each: the tables are faster there)
 	HAO_LOCKSTEP();      // the rows' minimizers are in LDS: every lane reads the ones of its rows
 	// per row: head record e0 (with the HIT's strand in bit 55; rid = HAO_MRG_END beyond the list), the BUF records behind it as the index holds them (b0 first; the
 	// strand is folded in when a record becomes the head - a row's read is then waited for a step after it was issued, not at once), index of the next record to
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256, BUF == 4 ? (RPL == 8 ? 3 : 5) : 4) void seed_m
 template<int RPL> struct hao_seed4w_lds { static constexpr uint32_t ROWS_W = 64u * RPL, ROWS = 4 * ROWS_W, TOTAL = ROWS * 12; };
 
 template<int RPL, int BUF>
-__global__ __launch_bounds__(256, RPL <= 2 ? (BUF == 8 ? 5 : 6) : 4) void seed_mergew_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, const uint32_t *__restrict__ len, const uint32_t *__restrict__ order, uint32_t *ovf_list, unsigned long long *ovf_cnt)
+__global__ __launch_bounds__(256, RPL <= 2 ? (BUF == 8 ? 5 : 6) : 4) void seed_mergew_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, const uint32_t *__restrict__ len, const uint32_t *__restrict__ order, uint32_t max_n, uint32_t *ovf_list, unsigned long long *ovf_cnt)
 {
 	static_assert(BUF == 1 || BUF == 4 || BUF == 8, "records per list read");
 	constexpr uint32_t ROWS_W = hao_seed4w_lds<RPL>::ROWS_W, ROWS = hao_seed4w_lds<RPL>::ROWS;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256, RPL <= 2 ? (BUF == 8 ? 5 : 6) : 4) void seed_m
 			if (ne && k >= row0 && k < row0 + ROWS_W) l_qi[k] = (uint16_t)q;
 			nk += (uint32_t)__popcll(bal);
 		}
-	if (nq > HAO_QTAB_CAP || nk > ROWS) { if (threadIdx.x == 0) ovf_list[atomicAdd(ovf_cnt, 1ULL)] = (uint32_t)r; return; }      // (the same decision in every wave) left to the table kernels
+	if (nq > HAO_QTAB_CAP || nk > ROWS || n > max_n) { if (threadIdx.x == 0) ovf_list[atomicAdd(ovf_cnt, 1ULL)] = (uint32_t)r; return; }      // (the same decision in every wave) left to the table kernels
 	HAO_LOCKSTEP();
 	HAO_MRG_ROWS_DO(HAO_MRG_DECL)
 #define HAO_MRGW_INIT(i) if constexpr (i < RPL) { \

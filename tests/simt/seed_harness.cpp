@@ -51,6 +51,7 @@ extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t 
 	if (mode == 0 || mode >= 3) { lds2 = hao_seed3_lds<10>::FIXED + lds_q; lds3 = hao_seed3_lds<11>::FIXED + lds_q; }
 	const uint32_t *nil32 = nullptr; const unsigned long long *nil64 = nullptr;
 	std::vector<uint32_t> ovf0(n + 4, 0); unsigned long long ovf0_cnt = 0;
+	const uint32_t max_n = getenv("SIMT_SEED_MAXN") ? (uint32_t)atoi(getenv("SIMT_SEED_MAXN")) : 0xffffffffu;      // reads with more seed hits go to the table kernels
 	if (mode == 7) {      // the merge kernel in locus order: key per read, the reads sorted by key, an eighth of the sorted list per "XCD" (blocks b, b + 8, ...); every read runs
 		std::vector<uint64_t> key(n + 1, 0); std::vector<uint32_t> idx(n + 1, 0);
 		if (launch((unsigned)((n + 3) / 4), 256, 0, [&] { seed_locus_kernel(sa, sinfo, key.data(), idx.data()); })) return fail(err, errcap, hao_simt::g.error);
@@ -58,7 +59,7 @@ extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t 
 		std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
 		for (uint64_t i = 0; i + 1 < n; ++i) if (key[ord[i]] > key[ord[i + 1]]) return fail(err, errcap, "locus order not sorted");
 		const unsigned nwg = (unsigned)(((n + 3) / 4 + 7) / 8 * 8);
-		if (launch(nwg, 256, hao_seed4_lds<8>::TOTAL, [&] { seed_merge_kernel<8, 4>(sa, sinfo, len, ord.data(), ovf0.data(), &ovf0_cnt); })) return fail(err, errcap, hao_simt::g.error);
+		if (launch(nwg, 256, hao_seed4_lds<8>::TOTAL, [&] { seed_merge_kernel<8, 4>(sa, sinfo, len, ord.data(), max_n, ovf0.data(), &ovf0_cnt); })) return fail(err, errcap, hao_simt::g.error);
 		stats[6] = ovf0_cnt; stats[7] = key[ord[0]];
 		if (ovf0_cnt) {
 			std::function<void()> call = [&] { seed_bin_kernel<9, 1, 512, true>(sa, ovf0.data(), &ovf0_cnt, ovf1, &ovf_cnt[0]); };
@@ -70,9 +71,9 @@ extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t 
 		for (uint64_t g = 0; g < n; ++g) {
 			if (!chosen[g]) continue;
 			std::function<void()> call;
-			if (mode == 8) call = [&] { seed_mergew_kernel<2, 4>(sa, sinfo, len, nil32, ovf0.data(), &ovf0_cnt); };
-			else if (mode == 10) call = [&] { seed_mergew_kernel<2, 8>(sa, sinfo, len, nil32, ovf0.data(), &ovf0_cnt); };
-			else call = [&] { seed_mergew_kernel<1, 1>(sa, sinfo, len, nil32, ovf0.data(), &ovf0_cnt); };
+			if (mode == 8) call = [&] { seed_mergew_kernel<2, 4>(sa, sinfo, len, nil32, max_n, ovf0.data(), &ovf0_cnt); };
+			else if (mode == 10) call = [&] { seed_mergew_kernel<2, 8>(sa, sinfo, len, nil32, max_n, ovf0.data(), &ovf0_cnt); };
+			else call = [&] { seed_mergew_kernel<1, 1>(sa, sinfo, len, nil32, max_n, ovf0.data(), &ovf0_cnt); };
 			hao_simt::g.body = call; hao_simt::g.nthreads = 256; hao_simt::g.error.clear(); hao_simt::g.dyn_lds.assign((mode != 9 ? hao_seed4w_lds<2>::TOTAL : hao_seed4w_lds<1>::TOTAL) + 64, (char)0xa5);
 			blockDim = {256, 1, 1}; gridDim = {(unsigned)n, 1, 1}; blockIdx = {(unsigned)g, 0, 0};
 			if (!hao_simt::run_block()) return fail(err, errcap, hao_simt::g.error);
@@ -89,10 +90,10 @@ extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t 
 		for (uint64_t g = 0; g < (n + 3) / 4; ++g) {
 			if (!(chosen[4 * g] | chosen[4 * g + 1] | chosen[4 * g + 2] | chosen[4 * g + 3])) continue;
 			std::function<void()> call;
-			if (mode == 3) call = [&] { seed_merge_kernel<8, 1>(sa, sinfo, len, nil32, ovf0.data(), &ovf0_cnt); };
-			else if (mode == 4) call = [&] { seed_merge_kernel<2, 1>(sa, sinfo, len, nil32, ovf0.data(), &ovf0_cnt); };
-			else if (mode == 5) call = [&] { seed_merge_kernel<8, 4>(sa, sinfo, len, nil32, ovf0.data(), &ovf0_cnt); };
-			else call = [&] { seed_merge_kernel<2, 4>(sa, sinfo, len, nil32, ovf0.data(), &ovf0_cnt); };
+			if (mode == 3) call = [&] { seed_merge_kernel<8, 1>(sa, sinfo, len, nil32, max_n, ovf0.data(), &ovf0_cnt); };
+			else if (mode == 4) call = [&] { seed_merge_kernel<2, 1>(sa, sinfo, len, nil32, max_n, ovf0.data(), &ovf0_cnt); };
+			else if (mode == 5) call = [&] { seed_merge_kernel<8, 4>(sa, sinfo, len, nil32, max_n, ovf0.data(), &ovf0_cnt); };
+			else call = [&] { seed_merge_kernel<2, 4>(sa, sinfo, len, nil32, max_n, ovf0.data(), &ovf0_cnt); };
 			hao_simt::g.body = call; hao_simt::g.nthreads = 256; hao_simt::g.error.clear(); hao_simt::g.dyn_lds.assign(ldsm + 64, (char)0xa5);
 			blockDim = {256, 1, 1}; gridDim = {(unsigned)((n + 3) / 4), 1, 1}; blockIdx = {(unsigned)g, 0, 0};
 			if (!hao_simt::run_block()) return fail(err, errcap, hao_simt::g.error);
