@@ -115,7 +115,7 @@ def cpu_baseline(workload, mode="sample", threads=None):
 
 
 def profile_file(name):
-    """newest committed profile of that name (PMC counters need their own rocprofv3 passes - tools/r03_final.sh - so they cannot be
+    """newest committed profile of that name (PMC counters need their own rocprofv3 passes - tools/r05_final.sh pmc - so they cannot be
     collected inside this run; the line says where the figure comes from)"""
     for r in ("r05", "r04", "r03", "r02"):
         p = os.path.join(ROOT, "profiles", r, name)
@@ -332,7 +332,7 @@ def run_workload(a, workload, steps, warmup, rank, local_rank, world, dist, torc
             return {"kernel": kn, "kernel_ms": round(ms_, 4), "launches_per_step": nb_, "alg_bytes_per_launch": int(b_ * un_ / nb_), "achieved": round(ach_, 2), "frac": round(ach_ / HBM_PEAK_GBS, 5)}
         roofline["kernels"] = [kernel_line(kn) for kn in KERN_STAGE]
         prof, prof_rel = profile_file("pmc_traffic.json")
-        if prof and world == 1:      # PMC counters need their own rocprofv3 passes (tools/pmc.sh): not measurable inside this run
+        if prof and world == 1:      # PMC counters need their own rocprofv3 passes (tools/r05_final.sh pmc): not measurable inside this run
             try:
                 pj = json.load(open(prof))
                 if pj.get("workload") == workload:

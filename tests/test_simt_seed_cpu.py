@@ -3,6 +3,7 @@ tests/simt/hip/hip_runtime.h (one fiber per work-item; ballots, DPP moves, ds_pe
 launched like hao_batch.hpp launches them, compared with the oracle's restatement of minimizers_qgen0 (anchor.cpp:987-1081).  The same sources are what the
 `-m gpu` suite runs on the device; here they run where there is no GPU."""
 import ctypes as C
+import os
 import numpy as np
 import pytest
 
@@ -190,12 +191,17 @@ def test_seed_kernels_with_many_bins(n_targets, nq, list_len, mode):
 
 
 # ---- the merge kernel (hao_query4.cuh): one wave per read, the read's position lists merged by target ----
-@pytest.mark.parametrize("name,step,mode", [("hifi", 1, 3), ("rr", 1, 3), ("nn", 1, 3), ("ont", 1, 3), ("edge", 1, 3), ("k40", 1, 3), ("hpc0", 1, 3), ("fz2", 1, 3), ("rr_heavy", 25, 3),
+_MERGE_ALL = [("hifi", 1, 3), ("rr", 1, 3), ("nn", 1, 3), ("ont", 1, 3), ("edge", 1, 3), ("k40", 1, 3), ("hpc0", 1, 3), ("fz2", 1, 3), ("rr_heavy", 25, 3),
                                             ("hifi", 1, 4), ("rr", 1, 4), ("ont", 2, 4), ("edge", 1, 4),
                                             ("hifi", 1, 5), ("rr", 1, 5), ("nn", 1, 5), ("ont", 1, 5), ("edge", 1, 5), ("k40", 1, 5), ("hpc0", 1, 5), ("fz2", 1, 5), ("rr_heavy", 25, 5), ("rr", 1, 6),
                                             ("hifi", 1, 7), ("rr", 1, 7), ("edge", 1, 7), ("ont", 1, 7),
                                             ("hifi", 1, 8), ("rr", 1, 8), ("nn", 1, 8), ("ont", 1, 8), ("edge", 1, 8), ("k40", 1, 8), ("hpc0", 1, 8), ("fz2", 1, 8), ("rr_heavy", 25, 8), ("hifi", 1, 9), ("rr", 1, 9),
-                                            ("hifi", 1, 10), ("rr", 1, 10), ("nn", 1, 10), ("ont", 1, 10), ("edge", 1, 10), ("k40", 1, 10), ("hpc0", 1, 10), ("fz2", 1, 10), ("rr_heavy", 25, 10)])
+                                            ("hifi", 1, 10), ("rr", 1, 10), ("nn", 1, 10), ("ont", 1, 10), ("edge", 1, 10), ("k40", 1, 10), ("hpc0", 1, 10), ("fz2", 1, 10), ("rr_heavy", 25, 10)]
+# the default CPU suite runs a selection (a minute); HAO_SIMT_FULL=1 runs every combination (ten minutes)
+_MERGE_DEFAULT = {("hifi", 1, 3), ("rr", 1, 4), ("hifi", 1, 5), ("rr", 1, 5), ("edge", 1, 5), ("hifi", 1, 7), ("hifi", 1, 8), ("rr", 1, 8), ("hifi", 1, 10)}
+
+
+@pytest.mark.parametrize("name,step,mode", [c for c in _MERGE_ALL if os.environ.get("HAO_SIMT_FULL") or c in _MERGE_DEFAULT])
 def test_merge_kernel_against_the_oracle(name, step, mode):
     """mode 3: 8 rows per lane (reads with up to 512 minimizers that have a list), mode 4: 2 rows per lane - most reads of these scenarios then overflow to the table kernels,
     which checks the hand-over (overflow list -> 512-slot launch -> the launches behind it); modes 5 / 6: the same with 32-byte list reads (four records behind every head);
@@ -210,10 +216,14 @@ def test_merge_kernel_against_the_oracle(name, step, mode):
     assert n_hits > 500
 
 
-@pytest.mark.parametrize("n_targets,nq,list_len,mode,run_rate", [(150, 120, 40, 3, 0.08), (600, 200, 50, 3, 0.08), (2500, 260, 60, 3, 0.08), (40, 300, 60, 3, 0.5), (12, 500, 30, 3, 0.9), (600, 200, 50, 4, 0.08),
+_RUNS_ALL = [(150, 120, 40, 3, 0.08), (600, 200, 50, 3, 0.08), (2500, 260, 60, 3, 0.08), (40, 300, 60, 3, 0.5), (12, 500, 30, 3, 0.9), (600, 200, 50, 4, 0.08),
                                                                  (150, 120, 40, 5, 0.08), (600, 200, 50, 5, 0.08), (2500, 260, 60, 5, 0.08), (40, 300, 60, 5, 0.5), (12, 500, 30, 5, 0.9), (600, 200, 50, 6, 0.08), (30, 200, 5, 5, 0.3),
                                                                  (150, 120, 40, 8, 0.08), (600, 200, 50, 8, 0.08), (2500, 260, 60, 8, 0.08), (40, 300, 60, 8, 0.5), (12, 500, 30, 8, 0.9), (30, 200, 5, 8, 0.3), (600, 300, 50, 9, 0.08), (25, 540, 20, 8, 0.6),
-                                                                 (150, 120, 40, 10, 0.08), (600, 200, 50, 10, 0.08), (2500, 260, 60, 10, 0.08), (40, 300, 60, 10, 0.5), (12, 500, 30, 10, 0.9), (30, 200, 5, 10, 0.3), (25, 540, 20, 10, 0.6), (300, 400, 9, 10, 0.2)])
+                                                                 (150, 120, 40, 10, 0.08), (600, 200, 50, 10, 0.08), (2500, 260, 60, 10, 0.08), (40, 300, 60, 10, 0.5), (12, 500, 30, 10, 0.9), (30, 200, 5, 10, 0.3), (25, 540, 20, 10, 0.6), (300, 400, 9, 10, 0.2)]
+_RUNS_DEFAULT = {(600, 200, 50, 5, 0.08), (40, 300, 60, 5, 0.5), (12, 500, 30, 5, 0.9), (600, 200, 50, 6, 0.08), (30, 200, 5, 5, 0.3), (40, 300, 60, 8, 0.5), (600, 300, 50, 9, 0.08), (25, 540, 20, 10, 0.6), (40, 300, 60, 3, 0.5)}
+
+
+@pytest.mark.parametrize("n_targets,nq,list_len,mode,run_rate", [c for c in _RUNS_ALL if os.environ.get("HAO_SIMT_FULL") or c in _RUNS_DEFAULT])
 def test_merge_kernel_with_runs(n_targets, nq, list_len, mode, run_rate):
     """fabricated indexes: many targets (many steps with a single hit), and lists in which a target comes several times in a row (the redo of a target with the
     per-row runs, forward strand in list order, opposite strand in reverse list order) - up to lists that are a handful of long runs"""

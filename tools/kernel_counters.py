@@ -1,4 +1,4 @@
-"""Per-kernel SQ counter summary of one rocprofv3 --pmc pass (tools/r02_counters.sh) -> JSON + table.
+"""Per-kernel SQ counter summary of one rocprofv3 --pmc pass (tools/archive/r02_counters.sh) -> JSON + table.
 usage: python tools/kernel_counters.py <counter dir> [n_simd=1024]
 valu_util = SQ_INSTS_VALU x 2 cycles (a wave64 VALU instruction issues over 2 cycles on a SIMD-32) / (kernel cycles x SIMDs); kernel cycles =
 GRBM_GUI_ACTIVE summed over the 8 XCD instances / 8.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles (MI355X_MICROARCH.md)."""
