@@ -329,7 +329,9 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			else if (int rc = launch(seed_bin2_kernel<9, 0, false>, seed_bin2_kernel<10, 1, true>, seed_bin2_kernel<11, 2, true>)) return rc;
 		}
 		else if (tile_ != 512) { if (int rc = launch(seed_bin_kernel<9, 0, 1024, false>, seed_bin_kernel<10, 1, 1024, false>, seed_bin_kernel<11, 2, 1024, false>)) return rc; }
-		else if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql && c->sw.seed_merge) {
+		else if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql && c->sw.seed_merge && A <= (uint64_t)c->sw.seed_merge_avg * n) {
+			// (the batch's reads average at most seed_merge_avg seed hits: above that the reads cross repeat families - hundreds of targets, a merge step each - and the
+			// table kernels below are the faster ones: 231 against 248 ms per pass of the repeat-rich 250 Mb set, 58.9 against 54.7 ms on the repeat-free one, profiles/r05)
 			// the merge kernel (hao_query4.cuh): one wave per read, one walk over the read's position lists; the reads with more rows than a wave holds go through the
 			// table kernels below it (512-slot launch over the overflow list, then the launches without staged tiles)
 			lds2 = hao_seed3_lds<10>::FIXED + lds_q; lds3 = hao_seed3_lds<11>::FIXED + lds_q;
@@ -342,7 +344,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 				unsigned nwg = (unsigned)((n + 3) / 4);
 				if (c->sw.seed_locus && n > 64) {      // launch order by locus (hao_query4.cuh): key per read, sort, an eighth of the sorted list per XCD
 					HIP_TRY(B.loc_key.reserve(n + 1)); HIP_TRY(B.loc_key2.reserve(n + 1)); HIP_TRY(B.loc_idx.reserve(n + 1)); HIP_TRY(B.loc_idx2.reserve(n + 1));
-					hipLaunchKernelGGL(seed_locus_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, sa_, sinfo_, B.loc_key.p, B.loc_idx.p);
+					hipLaunchKernelGGL(seed_locus_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, sa_, sinfo_, (uint32_t)(c->sw.seed_locus == 1 ? 64 : 0), B.loc_key.p, B.loc_idx.p);
 					HAO_CHECK_LAUNCH();
 					size_t tb = 0; rocprim::double_buffer<uint64_t> dk(B.loc_key.p, B.loc_key2.p); rocprim::double_buffer<uint32_t> dv(B.loc_idx.p, B.loc_idx2.p);
 					HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, dk, dv, (size_t)n, 0, 55, c->stream)); HIP_TRY(hao_tmp(c, tb));

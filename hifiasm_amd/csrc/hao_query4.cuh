@@ -55,14 +55,15 @@ struct hao_rec8 { uint64_t a, b, c, d, e, f, g, h; };      // eight: one aligned
 // A read's locus is not known, but its smallest target is (what the merge's first step computes): reads with the same smallest target X overlap X, i.e. lie within
 // a read length of each other, and X's position in the hit orders them along X.  seed_locus_kernel writes key = (smallest target << 27 | its position) per read;
 // the host sorts the batch's reads by key and the merge kernel takes them in that order, an eighth of the sorted list per XCD (block b runs on XCD b % 8).
-__global__ __launch_bounds__(256) void seed_locus_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, uint64_t *key, uint32_t *idx)
+__global__ __launch_bounds__(256) void seed_locus_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, uint32_t max_q, uint64_t *key, uint32_t *idx)
 {
 	const int wv = threadIdx.x >> 6, lane = hao_lane();
 	const uint64_t r = (uint64_t)blockIdx.x * 4 + wv;
 	if (r >= S.n_sel) return;
 	const uint64_t m0 = S.mz_off[S.rid_lo + r], li0 = m0 - S.mz0; const uint32_t nq = (uint32_t)(S.mz_off[S.rid_lo + r + 1] - m0);
 	uint64_t best = ~0ULL;
-	for (uint32_t q = lane; q < nq; q += 64)
+	const uint32_t nqs = max_q && max_q < nq ? max_q : nq;      // (max_q: only the read's first minimizers - its first two kilobases - are asked: 64 of them cost one load per lane)
+	for (uint32_t q = lane; q < nqs; q += 64)
 		if (S.s_n[li0 + q]) { const uint64_t y = sinfo[S.s_start[li0 + q]]; best = min(best, (uint64_t)hao_info_rid(y) << 27 | hao_info_pos(y)); }
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1) best = min(best, (uint64_t)__shfl_xor((unsigned long long)best, d));

@@ -54,7 +54,7 @@ extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t 
 	const uint32_t max_n = getenv("SIMT_SEED_MAXN") ? (uint32_t)atoi(getenv("SIMT_SEED_MAXN")) : 0xffffffffu;      // reads with more seed hits go to the table kernels
 	if (mode == 7) {      // the merge kernel in locus order: key per read, the reads sorted by key, an eighth of the sorted list per "XCD" (blocks b, b + 8, ...); every read runs
 		std::vector<uint64_t> key(n + 1, 0); std::vector<uint32_t> idx(n + 1, 0);
-		if (launch((unsigned)((n + 3) / 4), 256, 0, [&] { seed_locus_kernel(sa, sinfo, key.data(), idx.data()); })) return fail(err, errcap, hao_simt::g.error);
+		if (launch((unsigned)((n + 3) / 4), 256, 0, [&] { seed_locus_kernel(sa, sinfo, 64u, key.data(), idx.data()); })) return fail(err, errcap, hao_simt::g.error);
 		std::vector<uint32_t> ord(idx.begin(), idx.begin() + n);
 		std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
 		for (uint64_t i = 0; i + 1 < n; ++i) if (key[ord[i]] > key[ord[i + 1]]) return fail(err, errcap, "locus order not sorted");

@@ -17,10 +17,16 @@ d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print(sys.argv[2], 'ms', d['ms_per_step'], 'M ov/s', round(d['value']/1e6,2), 'resident', d.get('ms_per_step_resident'), round(d['value_resident']/1e6,2), 'ok', ((d.get('boundary') or {}).get('delivered_bytes_check') or {}).get('equal_to_reference'))
 PY
 done; fi
-if has rrab; then for spec in rr_default: rr_all_merge:HAO_SEED_MERGE_MAXN=100000000 rr_tables:HAO_SEED_MERGE=0; do IFS=: read name envs <<< "$spec"; env ${envs:-X_=1} timeout 600 python bench.py --workload chr1_250M_hifi30x_repeat --cpu-baseline none --no-variants --no-boundary --steps 3 --warmup 1 > $O/$name.json 2> $O/$name.err; python - $O/$name.json $name <<'PY'
+if has rrab; then for spec in rr_default: rr_maxn16k:HAO_SEED_MERGE_MAXN=16000 rr_all_merge:HAO_SEED_MERGE_MAXN=100000000 rr_tables:HAO_SEED_MERGE=0; do IFS=: read name envs <<< "$spec"; env ${envs:-X_=1} timeout 600 python bench.py --workload chr1_250M_hifi30x_repeat --cpu-baseline none --no-variants --no-boundary --steps 3 --warmup 1 > $O/$name.json 2> $O/$name.err; python - $O/$name.json $name <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); s=d['stage_ms']
 print(sys.argv[2], 'resident', d['ms_per_step_resident'], 'seed', round(s['q_sort_bins'],1), 'chain', round(s['q_chain'],1), 'sel', round(s['q_select'],1), 'sketch', round(s['sk_chunks'],1))
+PY
+done; fi
+if has c2ab; then for spec in c2_merge: c2_tables:HAO_SEED_MERGE=0 c2_merge_locus:HAO_SEED_LOCUS=1; do IFS=: read name envs <<< "$spec"; env ${envs:-X_=1} timeout 600 python bench.py --workload chr1_250M_hifi30x --cpu-baseline none --no-variants --no-boundary --steps 20 --warmup 5 > $O/$name.json 2> $O/$name.err; python - $O/$name.json $name <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); s=d['stage_ms']
+print(sys.argv[2], 'resident', d['ms_per_step_resident'], 'seed', round(s['q_sort_bins'],2), 'chain', round(s['q_chain'],2), 'sketch', round(s['sk_chunks'],2), 'frac', d['roofline']['frac'])
 PY
 done; fi
 prof() { wl=$1; out=$2; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$out -- python $R/bench.py --workload $wl --cpu-baseline none --no-boundary --no-variants --steps 2 --warmup 1 > $O/prof_$out.log 2>&1; f=$(find $O/prof_$out -name "*kernel_stats.csv" | head -1); cp "$f" $O/$out.csv; head -12 $O/$out.csv | cut -c1-150; rm -rf $O/prof_$out ); }
