@@ -59,7 +59,10 @@ def _free_port():
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("name,world,env", [("hifi", 2, {}), ("nn", 3, {}), ("bf24", 2, {}), ("hifi", 4, {}), ("hifi", 2, {"HAO_FT_PASSES": "3", "HAO_FT_CHUNK_SLOTS": "25000"})])
+_RCCL_CASES = [("hifi", 2, {}), ("nn", 3, {}), ("bf24", 2, {}), ("hifi", 4, {}), ("hifi", 2, {"HAO_FT_PASSES": "3", "HAO_FT_CHUNK_SLOTS": "25000"})]
+
+
+@pytest.mark.parametrize("name,world,env", _RCCL_CASES if os.environ.get("HAO_SIMT_FULL") else [_RCCL_CASES[1], _RCCL_CASES[3], _RCCL_CASES[4]])      # (default suite: 3 ranks with N reads, 4 ranks, 2 ranks in passes; HAO_SIMT_FULL=1: all five)
 def test_rccl_branch_between_processes(name, world, env):
     """hao_comm.hpp's RCCL branch with 2, 3 and 4 ranks, one PROCESS per rank under torch.distributed.run: the emulated device library (tests/simt) in every process,
     tests/simt/rccl/rccl.h - grouped send / receive, in-place all-gather, broadcast per root, sum all-reduce over a mailbox directory - in RCCL's place, gloo on the
