@@ -459,3 +459,14 @@ int hao_pt_table(hao_ctx *c, uint64_t *n_keys, const uint64_t **keys, const uint
 	return HAO_OK;
 }
 }
+
+
+int hao_ovlp_bin_read(const char *path, uint64_t *n_reads, uint8_t **flags, uint64_t **off, hao_ma_hit_t **hits)
+{
+	if (!path || !n_reads || !flags || !off || !hits) return HAO_EINVAL;
+	try { return hao_ovlp_bin_read_impl(path, n_reads, flags, off, hits); }
+	catch (const std::bad_alloc &) { return HAO_ENOMEM; }
+	catch (const std::exception &) { return HAO_EINVAL; }
+}
+int hao_ovlp_bin_write(const char *path, uint64_t n_reads, const uint8_t *flags, const uint64_t *off, const hao_ma_hit_t *hits)
+{ return hao_ovlp_bin_write_impl(path, n_reads, flags, off, hits); }

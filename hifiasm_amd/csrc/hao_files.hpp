@@ -270,3 +270,64 @@ static int hao_index_load_impl(hao_ctx *c, const char *prefix, int32_t *number_o
 	c->has_pt = true; c->h_ix_valid = false;
 	return HAO_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------
+// *.ovlp.source.bin / *.ovlp.reverse.bin (write_ma_hit_ts / load_ma_hit_ts / write_ma / read_ma, Overlaps.cpp:23280-23469): reader and writer of the format (include/hao.h)
+// ---------------------------------------------------------------------------------------
+#define HAO_MA_DISK_BYTES 42
+static int hao_ovlp_bin_read_impl(const char *path, uint64_t *n_reads, uint8_t **flags, uint64_t **off, hao_ma_hit_t **hits)
+{
+	*n_reads = 0; *flags = nullptr; *off = nullptr; *hits = nullptr;
+	FILE *fp = fopen(path, "rb");
+	if (!fp) return HAO_EINVAL;
+	int64_t n = 0;
+	std::vector<uint8_t> fl; std::vector<uint64_t> of; std::vector<hao_ma_hit_t> hv;
+	auto bad = [&]() { fclose(fp); return HAO_EINVAL; };
+	if (fread(&n, 8, 1, fp) != 1 || n < 0 || (uint64_t)n > hao_file_left(fp) / 6) return bad();      // (a read costs at least its two flags and its length)
+	fl.resize(2 * (size_t)n); of.assign((size_t)n + 1, 0);
+	for (int64_t i = 0; i < n; ++i) {
+		uint32_t len = 0;
+		if (fread(&fl[2 * i], 1, 2, fp) != 2 || fread(&len, 4, 1, fp) != 1 || (uint64_t)len > hao_file_left(fp) / HAO_MA_DISK_BYTES) return bad();
+		of[i + 1] = of[i] + len;
+		unsigned char rec[HAO_MA_DISK_BYTES];
+		for (uint32_t k = 0; k < len; ++k) {
+			if (fread(rec, 1, HAO_MA_DISK_BYTES, fp) != HAO_MA_DISK_BYTES) return bad();
+			hao_ma_hit_t h; memset(&h, 0, sizeof h);
+			memcpy(&h.qns, rec, 8); memcpy(&h.qe, rec + 8, 4); memcpy(&h.tn, rec + 12, 4); memcpy(&h.ts, rec + 16, 4); memcpy(&h.te, rec + 20, 4);
+			h.el = rec[24]; h.no_l_indel = rec[25];
+			memcpy(&h.ml, rec + 26, 4); memcpy(&h.rev, rec + 30, 4); memcpy(&h.bl, rec + 34, 4); memcpy(&h.del, rec + 38, 4);
+			hv.push_back(h);
+		}
+	}
+	if (hao_file_left(fp) != 0) return bad();      // trailing bytes: not this format
+	fclose(fp);
+	*flags = (uint8_t*)malloc(fl.size() + 1); *off = (uint64_t*)malloc(of.size() * 8); *hits = (hao_ma_hit_t*)malloc((hv.size() + 1) * sizeof(hao_ma_hit_t));
+	if (!*flags || !*off || !*hits) { free(*flags); free(*off); free(*hits); *flags = nullptr; *off = nullptr; *hits = nullptr; return HAO_ENOMEM; }
+	if (!fl.empty()) memcpy(*flags, fl.data(), fl.size());
+	memcpy(*off, of.data(), of.size() * 8);
+	if (!hv.empty()) memcpy(*hits, hv.data(), hv.size() * sizeof(hao_ma_hit_t));
+	*n_reads = (uint64_t)n;
+	return HAO_OK;
+}
+static int hao_ovlp_bin_write_impl(const char *path, uint64_t n_reads, const uint8_t *flags, const uint64_t *off, const hao_ma_hit_t *hits)
+{
+	if (!path || !off || (n_reads && !flags)) return HAO_EINVAL;
+	for (uint64_t i = 0; i < n_reads; ++i) if (off[i + 1] < off[i] || off[i + 1] - off[i] > 0xffffffffULL) return HAO_EINVAL;
+	FILE *fp = fopen(path, "wb");
+	if (!fp) return HAO_EINVAL;
+	const int64_t n = (int64_t)n_reads; bool ok = fwrite(&n, 8, 1, fp) == 1;
+	for (uint64_t i = 0; ok && i < n_reads; ++i) {
+		const uint32_t len = (uint32_t)(off[i + 1] - off[i]);
+		ok = fwrite(flags + 2 * i, 1, 2, fp) == 2 && fwrite(&len, 4, 1, fp) == 1;
+		for (uint64_t k = off[i]; ok && k < off[i + 1]; ++k) {
+			const hao_ma_hit_t &h = hits[k]; unsigned char rec[HAO_MA_DISK_BYTES];
+			memcpy(rec, &h.qns, 8); memcpy(rec + 8, &h.qe, 4); memcpy(rec + 12, &h.tn, 4); memcpy(rec + 16, &h.ts, 4); memcpy(rec + 20, &h.te, 4);
+			rec[24] = h.el; rec[25] = h.no_l_indel;
+			memcpy(rec + 26, &h.ml, 4); memcpy(rec + 30, &h.rev, 4); memcpy(rec + 34, &h.bl, 4); memcpy(rec + 38, &h.del, 4);
+			ok = fwrite(rec, 1, HAO_MA_DISK_BYTES, fp) == HAO_MA_DISK_BYTES;
+		}
+	}
+	ok = (fclose(fp) == 0) && ok;
+	return ok ? HAO_OK : HAO_EINVAL;
+}

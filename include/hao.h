@@ -267,6 +267,17 @@ int hao_index_save(hao_ctx *c, const char *prefix, int32_t number_of_round, cons
  * other options are the caller's to match, as with the reference.  Histograms are not in the file: hao_hist returns zeros afterwards. */
 int hao_index_load(hao_ctx *c, const char *prefix, int32_t *number_of_round);
 
+/* <prefix>.ovlp.source.bin / .ovlp.reverse.bin (write_ma_hit_ts / load_ma_hit_ts, Overlaps.cpp:23328-23469): the per-read lists of ma_hit_t the reference builds from the
+ * overlap regions AFTER alignment and correction (not a product of this path: the engine serves h_ec_lchain, the reference's own code fills and writes these lists - the
+ * drop-in run's files are byte-identical, tests/test_gpu_dropin.py).  Reader and writer of the format, for tools on either side of the path: a record is the field-by-field
+ * image write_ma produces (42 bytes: qns u64, qe tn ts te u32, el no_l_indel u8, ml rev bl del as u32 each - the bit fields widened), a read contributes
+ * (is_fully_corrected u8, is_abnormal u8, length u32, its records), the file starts with the read count as int64.  Host code, no device, no context.
+ *   hao_ovlp_bin_read: *flags = 2 bytes per read, *off = n_reads + 1 record offsets, *hits = the records; all three malloc'ed (free() them); HAO_EINVAL on a damaged file
+ *   hao_ovlp_bin_write: the inverse; the output of a read is byte-identical to what was read */
+typedef struct { uint64_t qns; uint32_t qe, tn, ts, te; uint32_t ml, rev, bl, del; uint8_t el, no_l_indel, pad[6]; } hao_ma_hit_t;      /* 48 bytes in memory */
+int hao_ovlp_bin_read(const char *path, uint64_t *n_reads, uint8_t **flags, uint64_t **off, hao_ma_hit_t **hits);
+int hao_ovlp_bin_write(const char *path, uint64_t n_reads, const uint8_t *flags, const uint64_t *off, const hao_ma_hit_t *hits);
+
 /* Per-read digests of the last batch's results, computed on the device (one workgroup per read) and copied to out[n] / out_kh[n]
  * (n = reads of the batch; out_kh may be NULL):
  *   out[r]    = sum of term(1, i, w) over the 64-bit words of ol->list (6 per overlap_region: the 12 u32 fields of hao_ovlp_t)
