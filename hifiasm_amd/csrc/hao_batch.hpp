@@ -362,6 +362,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 				if (c->sw.seed_merge == 4 && c->sw.seed_mbuf == 1) hipLaunchKernelGGL((seed_merge_kernel<4, 1>), g_, b_, hao_seed4_lds<4>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
 				else if (c->sw.seed_merge == 4) hipLaunchKernelGGL((seed_merge_kernel<4, 4>), g_, b_, hao_seed4_lds<4>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
 				else if (c->sw.seed_mbuf == 1) hipLaunchKernelGGL((seed_merge_kernel<8, 1>), g_, b_, hao_seed4_lds<8>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
+				else if (c->sw.seed_malign) hipLaunchKernelGGL((seed_merge_kernel<8, 4, true>), g_, b_, hao_seed4_lds<8>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
 				else hipLaunchKernelGGL((seed_merge_kernel<8, 4>), g_, b_, hao_seed4_lds<8>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
 				}
 			}

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void seed_locus_kernel(hao_seed_args S, const 
 // in the index), so every read moves a whole cache line through the memory fabric however little of it is used - and a line comes around again only after the other
 // ~500 rows of every wave of the XCD had their turn, by when the 4 MB L2 has lost it: with 8-byte reads a 128-byte line crosses the fabric up to 16 times
 // (measured: 122 ms per configs[2] pass against 59 ms for the table kernels - 6 TB/s of line traffic for 0.4 TB/s of records), with 32-byte reads 4 times.
-template<int RPL, int BUF>
+template<int RPL, int BUF, bool AL = false>
 __global__ __launch_bounds__(256, BUF == 4 ? (RPL == 8 ? 3 : 5) : 4) void seed_merge_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, const uint32_t *__restrict__ len, const uint32_t *__restrict__ order, uint32_t max_n, uint32_t *ovf_list, unsigned long long *ovf_cnt)
 {
 	static_assert(BUF == 1 || BUF == 4, "records per list read");
@@ -121,6 +121,14 @@ __global__ __launch_bounds__(256, BUF == 4 ? (RPL == 8 ? 3 : 5) : 4) void seed_m
 					if (off_ & 4) { b0_##i = b4_##i; b1_##i = b5_##i; b2_##i = b6_##i; b3_##i = b7_##i; } \
 					if (off_ & 2) { b0_##i = b2_##i; b1_##i = b3_##i; b2_##i = b4_##i; b3_##i = b5_##i; b4_##i = b6_##i; b5_##i = b7_##i; } \
 					if (off_ & 1) { b0_##i = b1_##i; b1_##i = b2_##i; b2_##i = b3_##i; b3_##i = b4_##i; b4_##i = b5_##i; b5_##i = b6_##i; b6_##i = b7_##i; } \
+				} \
+			} \
+			else if constexpr (BUF == 4 && AL) {      /* the ALIGNED 32-byte block that holds record nx (a read never straddles a sector); as with BUF = 8 only a row's first read starts inside a block */ \
+				const uint32_t off_ = (uint32_t)nx_##i & 3u; take_ = min(4u - off_, (left)); \
+				const hao_rec4 v_ = *(const hao_rec4*)(sinfo + (nx_##i - off_)); b0_##i = v_.a; b1_##i = v_.b; b2_##i = v_.c; b3_##i = v_.d; \
+				if (off_) { \
+					if (off_ & 2) { b0_##i = b2_##i; b1_##i = b3_##i; } \
+					if (off_ & 1) { b0_##i = b1_##i; b1_##i = b2_##i; b2_##i = b3_##i; } \
 				} \
 			} \
 			else if constexpr (BUF == 4) { const hao_rec4 v_ = *(const hao_rec4*)(sinfo + nx_##i); b0_##i = v_.a; b1_##i = v_.b; b2_##i = v_.c; b3_##i = v_.d; } \
@@ -228,6 +236,7 @@ template<int RPL, int BUF>
 __global__ __launch_bounds__(256, RPL <= 2 ? (BUF == 8 ? 5 : 6) : 4) void seed_mergew_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, const uint32_t *__restrict__ len, const uint32_t *__restrict__ order, uint32_t max_n, uint32_t *ovf_list, unsigned long long *ovf_cnt)
 {
 	static_assert(BUF == 1 || BUF == 4 || BUF == 8, "records per list read");
+	constexpr bool AL = false;      // (aligned 32-byte reads exist in the one-wave kernel only; BUF = 8 reads are aligned by construction)
 	constexpr uint32_t ROWS_W = hao_seed4w_lds<RPL>::ROWS_W, ROWS = hao_seed4w_lds<RPL>::ROWS;
 	extern __shared__ uint32_t mg_smem[];
 	__shared__ uint4 s_x[2][4];      // [set][wave] the wave's post: smallest head target, forward hits, opposite-strand hits of its rows on it

@@ -18,6 +18,7 @@ int fail(char *err, int cap, const std::string &m) { snprintf(err, cap, "%s", m.
 // mode 0: what the library launches by default (QL instances; overflowing reads through seed_bin3_kernel); 1: HAO_SEED_NODIRECT (all tiers seed_bin_kernel, QL);
 // 2: HAO_SEED_NOQL (per-minimizer tables possibly in global memory: qcap_force > 0 caps the LDS table to force that path)
 // 3 / 4 / 5 / 6: the merge kernel (hao_query4.cuh; 8 / 2 rows per lane reading one record at a time, 8 / 2 rows per lane reading four) takes every chosen read first; the reads it leaves (more rows than it holds) go through the table kernels as in mode 0
+// 11: 8 rows per lane, ALIGNED 32-byte list reads
 // 7: 8 rows per lane, four records per read, every read of the set in LOCUS order (seed_locus_kernel + sort + the per-XCD mapping of the order list)
 // (stats[6] = reads left by the merge kernel)
 // blocks: the reads to run in the first launch (others keep empty output); returns 0 or 1 with a message
@@ -86,13 +87,14 @@ extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t 
 	}
 	else if (mode >= 3) {      // the merge kernel: a wave per read (four reads per block); only the chosen reads' blocks run, and of those only the chosen waves' output is kept clean below
 		std::vector<char> chosen(n + 4, 0); for (uint32_t b = 0; b < n_blocks; ++b) chosen[blocks[b]] = 1;
-		const size_t ldsm = (mode == 3 || mode == 5) ? hao_seed4_lds<8>::TOTAL : hao_seed4_lds<2>::TOTAL;
+		const size_t ldsm = (mode == 3 || mode == 5 || mode == 11) ? hao_seed4_lds<8>::TOTAL : hao_seed4_lds<2>::TOTAL;
 		for (uint64_t g = 0; g < (n + 3) / 4; ++g) {
 			if (!(chosen[4 * g] | chosen[4 * g + 1] | chosen[4 * g + 2] | chosen[4 * g + 3])) continue;
 			std::function<void()> call;
 			if (mode == 3) call = [&] { seed_merge_kernel<8, 1>(sa, sinfo, len, nil32, max_n, ovf0.data(), &ovf0_cnt); };
 			else if (mode == 4) call = [&] { seed_merge_kernel<2, 1>(sa, sinfo, len, nil32, max_n, ovf0.data(), &ovf0_cnt); };
 			else if (mode == 5) call = [&] { seed_merge_kernel<8, 4>(sa, sinfo, len, nil32, max_n, ovf0.data(), &ovf0_cnt); };
+			else if (mode == 11) call = [&] { seed_merge_kernel<8, 4, true>(sa, sinfo, len, nil32, max_n, ovf0.data(), &ovf0_cnt); };
 			else call = [&] { seed_merge_kernel<2, 4>(sa, sinfo, len, nil32, max_n, ovf0.data(), &ovf0_cnt); };
 			hao_simt::g.body = call; hao_simt::g.nthreads = 256; hao_simt::g.error.clear(); hao_simt::g.dyn_lds.assign(ldsm + 64, (char)0xa5);
 			blockDim = {256, 1, 1}; gridDim = {(unsigned)((n + 3) / 4), 1, 1}; blockIdx = {(unsigned)g, 0, 0};

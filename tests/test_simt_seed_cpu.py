@@ -196,9 +196,9 @@ _MERGE_ALL = [("hifi", 1, 3), ("rr", 1, 3), ("nn", 1, 3), ("ont", 1, 3), ("edge"
                                             ("hifi", 1, 5), ("rr", 1, 5), ("nn", 1, 5), ("ont", 1, 5), ("edge", 1, 5), ("k40", 1, 5), ("hpc0", 1, 5), ("fz2", 1, 5), ("rr_heavy", 25, 5), ("rr", 1, 6),
                                             ("hifi", 1, 7), ("rr", 1, 7), ("edge", 1, 7), ("ont", 1, 7),
                                             ("hifi", 1, 8), ("rr", 1, 8), ("nn", 1, 8), ("ont", 1, 8), ("edge", 1, 8), ("k40", 1, 8), ("hpc0", 1, 8), ("fz2", 1, 8), ("rr_heavy", 25, 8), ("hifi", 1, 9), ("rr", 1, 9),
-                                            ("hifi", 1, 10), ("rr", 1, 10), ("nn", 1, 10), ("ont", 1, 10), ("edge", 1, 10), ("k40", 1, 10), ("hpc0", 1, 10), ("fz2", 1, 10), ("rr_heavy", 25, 10)]
+                                            ("hifi", 1, 11), ("rr", 1, 11), ("edge", 1, 11), ("ont", 1, 11), ("hifi", 1, 10), ("rr", 1, 10), ("nn", 1, 10), ("ont", 1, 10), ("edge", 1, 10), ("k40", 1, 10), ("hpc0", 1, 10), ("fz2", 1, 10), ("rr_heavy", 25, 10)]
 # the default CPU suite runs a selection (a minute); HAO_SIMT_FULL=1 runs every combination (ten minutes)
-_MERGE_DEFAULT = {("rr", 1, 4), ("hifi", 1, 5), ("rr", 1, 5), ("edge", 1, 5), ("hifi", 1, 7), ("rr", 1, 8), ("hifi", 1, 10)}
+_MERGE_DEFAULT = {("rr", 1, 4), ("hifi", 1, 5), ("rr", 1, 5), ("edge", 1, 5), ("hifi", 1, 7), ("rr", 1, 8), ("hifi", 1, 10), ("rr", 1, 11)}
 
 
 @pytest.mark.parametrize("name,step,mode", [c for c in _MERGE_ALL if os.environ.get("HAO_SIMT_FULL") or c in _MERGE_DEFAULT])
@@ -220,7 +220,7 @@ _RUNS_ALL = [(150, 120, 40, 3, 0.08), (600, 200, 50, 3, 0.08), (2500, 260, 60, 3
                                                                  (150, 120, 40, 5, 0.08), (600, 200, 50, 5, 0.08), (2500, 260, 60, 5, 0.08), (40, 300, 60, 5, 0.5), (12, 500, 30, 5, 0.9), (600, 200, 50, 6, 0.08), (30, 200, 5, 5, 0.3),
                                                                  (150, 120, 40, 8, 0.08), (600, 200, 50, 8, 0.08), (2500, 260, 60, 8, 0.08), (40, 300, 60, 8, 0.5), (12, 500, 30, 8, 0.9), (30, 200, 5, 8, 0.3), (600, 300, 50, 9, 0.08), (25, 540, 20, 8, 0.6),
                                                                  (150, 120, 40, 10, 0.08), (600, 200, 50, 10, 0.08), (2500, 260, 60, 10, 0.08), (40, 300, 60, 10, 0.5), (12, 500, 30, 10, 0.9), (30, 200, 5, 10, 0.3), (25, 540, 20, 10, 0.6), (300, 400, 9, 10, 0.2)]
-_RUNS_DEFAULT = {(40, 300, 60, 5, 0.5), (12, 500, 30, 5, 0.9), (600, 200, 50, 6, 0.08), (30, 200, 5, 5, 0.3), (40, 300, 60, 8, 0.5), (25, 540, 20, 10, 0.6), (40, 300, 60, 3, 0.5)}
+_RUNS_DEFAULT = {(40, 300, 60, 5, 0.5), (12, 500, 30, 5, 0.9), (600, 200, 50, 6, 0.08), (30, 200, 5, 5, 0.3), (40, 300, 60, 8, 0.5), (25, 540, 20, 10, 0.6), (40, 300, 60, 3, 0.5), (40, 300, 60, 11, 0.5)}
 
 
 @pytest.mark.parametrize("n_targets,nq,list_len,mode,run_rate", [c for c in _RUNS_ALL if os.environ.get("HAO_SIMT_FULL") or c in _RUNS_DEFAULT])
@@ -247,5 +247,5 @@ def test_merge_kernel_with_runs(n_targets, nq, list_len, mode, run_rate):
     assert int(g_cnt[0]) == first.size and (g_tmp[s:s + first.size] == (tid[first].astype(np.uint64) << np.uint64(32) | first.astype(np.uint64))).all()
     m0 = 0; q = hq[s:e].astype(np.int64)
     assert (((inp["info"][m0 + q] >> np.uint64(28)) & np.uint64((1 << 27) - 1)).astype(np.uint32) == want[:, 2]).all()
-    rows = {3: 512, 4: 128, 5: 512, 6: 128, 7: 512, 8: 512, 9: 256, 10: 512}[mode]
+    rows = {3: 512, 4: 128, 5: 512, 6: 128, 7: 512, 8: 512, 9: 256, 10: 512, 11: 512}[mode]
     assert int(st[6]) == (1 if nq - len([q for q in range(nq) if q % 13 == 5]) > rows else 0)
