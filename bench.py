@@ -312,6 +312,9 @@ def run_workload(a, workload, steps, warmup, rank, local_rank, world, dist, torc
     if rank == 0:
         stage_ms = {k: v / steps for k, v in stage_sum.items()}
         # roofline of the dominant kernel: live HIP-event time of its stage on the engine's stream
+        # which kernels carried the seed stage: the engine gives a batch whose reads average more than HAO_SEED_MERGE_AVG (14 000) seed hits to the table kernels (hao_batch.hpp)
+        seed_kernel = SEED_KERNEL if tot["seed_hits"] <= int(os.environ.get("HAO_SEED_MERGE_AVG", "14000")) * n_reads else "seed_bin_kernel"
+        KERN_STAGE = {"sketch_unit_kernel": "sk_chunks", "chain_group_kernel": "q_chain", seed_kernel: "q_sort_bins"}
         dom = max(KERN_STAGE, key=lambda k: stage_ms.get(KERN_STAGE[k], 0.0))
         unit, bpu = ALG[dom]
         units = rs.total_bases if unit == "base" else tot["seed_hits"]

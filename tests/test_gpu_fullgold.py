@@ -190,15 +190,18 @@ def test_sampled_minimizers(full):
 
 def test_chr1_bloom_f37():
     """ha_ft_gen through the blocked Bloom filter at the reference's default -f37 on all 5.6 G k-mer occurrences of configs[2] (htab.cpp:99-116,
-    826-880): histogram, peak, filter table; then the thresholds of ha_pt_gen and the first 32 000 reads of the pass."""
+    826-880): histogram, peak, filter table; then the thresholds of ha_pt_gen and EVERY read of the all-reads pass."""
     e, rs, g, cov = _open("chr1_250M_hifi30x", "_f37", {"bf_shift": 37})
     try:
         assert (e.hist(0) == g["ft_hist"]).all()
         keys, vals = e.ft_table()
         assert keys.shape == g["ft_keys"].shape and (keys == g["ft_keys"]).all() and (vals == g["ft_vals"]).all()
         _check_thresholds(e, rs, g, cov)
-        n = 32_000                                                # 125 digest blocks of 256 reads
-        dig, dkh, _, _ = _pass(e, rs, g, 32_000, 0, n)
-        assert (fold_digests(dig) == g["dig_fold"][: n // 256]).all() and (fold_digests(dkh) == g["dig_kh_fold"][: n // 256]).all()
+        # the WHOLE pass behind the default filter (round 5; rounds 3 - 4 compared the first 32 000 reads): every read's digests, the totals, the sampled reads verbatim
+        dig, dkh, tot_ol, tot_cl = _pass(e, rs, g, 83_334)
+        assert tot_ol == g["meta"]["pass_overlaps"] and tot_cl == g["meta"]["pass_chained_hits"]
+        f, fk = fold_digests(dig), fold_digests(dkh)
+        assert (fk == g["dig_kh_fold"]).all(), f"seed hits differ in read blocks {np.flatnonzero(fk != g['dig_kh_fold'])[:10]}"
+        assert (f == g["dig_fold"]).all(), f"results differ in read blocks {np.flatnonzero(f != g['dig_fold'])[:10]}"
     finally:
         e.close()
