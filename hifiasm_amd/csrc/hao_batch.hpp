@@ -329,7 +329,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			else if (int rc = launch(seed_bin2_kernel<9, 0, false>, seed_bin2_kernel<10, 1, true>, seed_bin2_kernel<11, 2, true>)) return rc;
 		}
 		else if (tile_ != 512) { if (int rc = launch(seed_bin_kernel<9, 0, 1024, false>, seed_bin_kernel<10, 1, 1024, false>, seed_bin_kernel<11, 2, 1024, false>)) return rc; }
-		else if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql && c->sw.seed_merge && A <= (uint64_t)c->sw.seed_merge_avg * n) {
+		else if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql && c->sw.seed_merge && A <= (uint64_t)c->sw.seed_merge_avg * n && c->n_total < HAO_MRG_END) {      // (read id 2^28 - 1 is the merge's end mark: a read set that uses it - exactly 2^28 reads - takes the tables)
 			// (the batch's reads average at most seed_merge_avg seed hits: above that the reads cross repeat families - hundreds of targets, a merge step each - and the
 			// table kernels below are the faster ones: 231 against 248 ms per pass of the repeat-rich 250 Mb set, 58.9 against 54.7 ms on the repeat-free one, profiles/r05)
 			// the merge kernel (hao_query4.cuh): one wave per read, one walk over the read's position lists; the reads with more rows than a wave holds go through the
