@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "hao_ft_cnt", "hao_pt_get", "hao_ft_table", "hao_pt_table", "hao_hist", "hao_stats", "hao_sketch_batch",
     "hao_fetch_sketch", "hao_overlap_batch", "hao_fetch_seed_hits", "hao_fetch_overlaps", "hao_batch_totals",
     "hao_stage_times", "hao_pass_default", "hao_overlap_batch_ex", "hao_set_shard", "hao_dist_unique_id", "hao_dist_init",
-    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_selftest_big", "hao_selftest_sortbits", "hao_unpack_cigar", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits", "hao_exact_check", "hao_fetch_exact", "hao_window_ed_batch", "hao_index_save", "hao_index_load", "hao_next_slot", "hao_attach", "hao_window_trace_batch", "hao_delivery_digest", "hao_ft_passes", "hao_ovlp_bin_read", "hao_ovlp_bin_write",
+    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_selftest_big", "hao_selftest_sortbits", "hao_unpack_cigar", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits", "hao_exact_check", "hao_fetch_exact", "hao_window_ed_batch", "hao_index_save", "hao_index_load", "hao_next_slot", "hao_attach", "hao_window_trace_batch", "hao_delivery_digest", "hao_ft_passes", "hao_ovlp_bin_read", "hao_ovlp_bin_write", "hao_window_ed_grid", "hao_fetch_ed_grid",
 ]
 
 
@@ -357,6 +357,18 @@ class Engine:
         out = np.zeros((t.shape[0], 2), dtype=np.int32)
         self._ck(self.L.hao_window_ed_batch(self.h, t.ctypes.data_as(C.c_void_p), t.shape[0], out.ctypes.data_as(C.c_void_p)), "hao_window_ed_batch")
         return out
+
+    def window_ed_grid(self, window=375, thre=15):
+        """window / candidate pairs of the last batch on the reference's window grid, generated and aligned on the device; returns their number"""
+        n = C.c_uint64()
+        self._ck(self.L.hao_window_ed_grid(self.h, C.c_uint32(window), C.c_uint32(thre), C.byref(n)), "hao_window_ed_grid")
+        return int(n.value)
+
+    def fetch_ed_grid(self, n):
+        """(tasks uint32 [n,10], results int32 [n,2]) of the last hao_window_ed_grid"""
+        t = np.zeros((n, 10), dtype=np.uint32); r = np.zeros((n, 2), dtype=np.int32)
+        self._ck(self.L.hao_fetch_ed_grid(self.h, t.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), C.c_uint64(n)), "hao_fetch_ed_grid")
+        return t, r
 
     def fetch_exact(self, rid):
         """exact-overlap flags (uint8, aligned with h_ec_lchain(rid)[0]) of a read of the last batch"""

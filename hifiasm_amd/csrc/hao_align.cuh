@@ -346,6 +346,7 @@ __global__ void hao_al_key_kernel(const hao_ed_task_t *task, uint64_t n, uint64_
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) { key[i] = hao_al_sort_key(task[i]); idx[i] = (uint32_t)i; }
 }
+__global__ void hao_al_iota_kernel(uint32_t *idx, uint64_t n) { const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) idx[i] = (uint32_t)i; }
 struct hao_al_flagged { const uint8_t *f; __host__ __device__ bool operator()(const uint32_t &i) const { return f[i] != 0; } };
 
 template<typename WT, int MODE, bool TRACE>

@@ -5,6 +5,7 @@
 #include "hao_query2.cuh"
 #include "hao_query3.cuh"
 #include "hao_query4.cuh"
+#include "hao_grid.cuh"
 #include "hao_chain.cuh"
 
 struct hao_ctx::Batch {
@@ -126,6 +127,36 @@ static int hao_exact_run(hao_ctx *c)
 	}
 	B.exact_valid = true;
 	return HAO_OK;
+}
+
+// f3 on the device end to end (hao_grid.cuh): window / candidate pairs of the current batch's final ol->list on the grid, in text order, into c->al_task; then the distance-only
+// window alignment over them where they lie (hao_al_ed_resident, hao_f3.hip): results in c->al_res.  No host round trip but the two totals.
+int hao_al_ed_resident(hao_ctx *c, uint64_t n_tasks, uint32_t nword);      // (hao_f3.hip)
+static int hao_ed_grid_run(hao_ctx *c, uint32_t wl, uint32_t thre, uint64_t *n_tasks)
+{
+	hao_ctx::Batch &B = *c->batch; *n_tasks = 0; c->al_grid_n = 0;
+	if (hao_is_sharded(c)) { hao_set_err(c, "hao_window_ed_grid needs the bases of both reads: single-device mode only"); return HAO_EUNSUPP; }
+	if (wl == 0 || thre > HAO_ED_MAX_THRE) { hao_set_err(c, "hao_window_ed_grid: window length 0 or threshold beyond the widest band"); return HAO_EINVAL; }
+	const uint64_t n = B.n; const uint32_t nword = (2 * thre + 1 + 63) / 64;
+	if (n == 0 || B.n_ol == 0) return HAO_OK;
+	DevBuf<uint64_t> &nwin = c->al_k1, &wbase = c->al_k2;      // (the upload path's key buffers: free here)
+	HIP_TRY(nwin.reserve(n + 2)); HIP_TRY(wbase.reserve(n + 2));
+	hipLaunchKernelGGL(ed_grid_nwin_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, c->d_len.p, B.lo, n, wl, nwin.p); HAO_CHECK_LAUNCH();
+	if (int rc = hao_excl_scan_u64(c, nwin.p, wbase.p, n + 1)) return rc;
+	uint64_t W = 0; HIP_TRY(hipMemcpyAsync(&W, wbase.p + n, 8, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream));
+	DevBuf<uint64_t> &cnt = c->al_path, off; HIP_TRY(cnt.reserve(W + 2)); HIP_TRY(off.reserve(W + 2));
+	HIP_TRY(hipMemsetAsync(cnt.p + W, 0, 8, c->stream));
+	const dim3 g_((unsigned)((n + 3) / 4)), b_(256);
+	hipLaunchKernelGGL((ed_grid_kernel<false>), g_, b_, 0, c->stream, B.O().ol_out.p, B.O().fin_off.p, c->d_len.p, B.lo, n, wl, thre, nword, wbase.p, cnt.p, (hao_ed_task_t*)nullptr); HAO_CHECK_LAUNCH();
+	if (int rc = hao_excl_scan_u64(c, cnt.p, off.p, W + 1)) return rc;
+	uint64_t T = 0; HIP_TRY(hipMemcpyAsync(&T, off.p + W, 8, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream));
+	if (T >= (1ULL << 32)) { hao_set_err(c, "hao_window_ed_grid: more than 2^32 pairs in one batch"); return HAO_EUNSUPP; }
+	HIP_TRY(c->al_task.reserve(T + 1));
+	if (T) { hipLaunchKernelGGL((ed_grid_kernel<true>), g_, b_, 0, c->stream, B.O().ol_out.p, B.O().fin_off.p, c->d_len.p, B.lo, n, wl, thre, nword, wbase.p, off.p, c->al_task.p); HAO_CHECK_LAUNCH(); }
+	HIP_TRY(hipStreamSynchronize(c->stream));      // (off is a local buffer)
+	off.release();
+	*n_tasks = T; c->al_grid_n = T;
+	return T ? hao_al_ed_resident(c, T, nword) : HAO_OK;
 }
 
 // Queue the copy of the current batch's results into the slot's pinned arena (copy stream, after everything on the compute stream so far).

@@ -281,6 +281,26 @@ int hao_exact_check(hao_ctx *c)
 	return HAO_OK;
 }
 
+int hao_window_ed_grid(hao_ctx *c, uint32_t window, uint32_t thre, uint64_t *n_tasks)
+{
+	if (!c || !n_tasks || !c->batch || !c->batch->valid) return HAO_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	if (int rc = hao_ed_grid_run(c, window, thre, n_tasks)) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return HAO_OK;
+}
+
+int hao_fetch_ed_grid(hao_ctx *c, hao_ed_task_t *tasks, hao_ed_result_t *res, uint64_t cap)
+{
+	if (!c) return HAO_EINVAL;
+	HIP_TRY(hipSetDevice(c->device));
+	const uint64_t n = std::min<uint64_t>(cap, c->al_grid_n);
+	if (n && tasks) HIP_TRY(hipMemcpyAsync(tasks, c->al_task.p, n * sizeof(hao_ed_task_t), hipMemcpyDeviceToHost, c->stream));
+	if (n && res) HIP_TRY(hipMemcpyAsync(res, c->al_res.p, n * sizeof(hao_ed_result_t), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return HAO_OK;
+}
+
 int hao_fetch_exact(hao_ctx *c, uint64_t rid, const uint8_t **flags, uint64_t *n)
 {
 	if (!c || !flags || !n || !c->batch || !c->batch->valid || rid < c->batch->lo || rid >= c->batch->lo + c->batch->n) return HAO_EINVAL;

@@ -146,6 +146,7 @@ struct hao_ctx {
 	std::vector<uint64_t> h_ix_keys, h_ix_off, h_ix_pos, h_ix_mz_off; bool h_ix_valid = false;
 	// ---- query batch ----
 	// f3 (hao_align.cuh): scratch of the window-alignment batches, kept between calls (a hipMalloc / hipFree pair per buffer and call cost more than the kernels)
+	uint64_t al_grid_n = 0;      // pairs hao_window_ed_grid left in al_task / al_res
 	DevBuf<hao_ed_task_t> al_task; DevBuf<uint64_t> al_k1, al_k2, al_path; DevBuf<uint32_t> al_i1, al_order, al_sel; DevBuf<hao_ed_result_t> al_res; DevBuf<hao_trace_result_t> al_tres;
 	DevBuf<uint8_t> al_want; DevBuf<uint16_t> al_cig;
 	struct Batch;

@@ -60,6 +60,22 @@ template<int MODE> static int hao_al_trace_run(hao_ctx *c, const hao_ed_reads &R
 	return HAO_OK;
 }
 
+// the distance-only window alignment over n tasks that already lie in c->al_task in text order (hao_window_ed_grid, hao_batch.hpp): results in c->al_res
+int hao_al_ed_resident(hao_ctx *c, uint64_t n, uint32_t nword)
+{
+	HIP_TRY(c->al_order.reserve(n + 1)); HIP_TRY(c->al_res.reserve(n + 1));
+	hipLaunchKernelGGL(hao_al_iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->al_order.p, n); HAO_CHECK_LAUNCH();
+	const hao_ed_reads R = hao_al_reads_of(c);
+	const dim3 g_((unsigned)((n + 255) / 256)), b_(256);
+	hao_ed_task_t *dt = c->al_task.p; uint32_t *order = c->al_order.p; hao_ed_result_t *dr = c->al_res.p;
+	if (nword == 1) hipLaunchKernelGGL((hao_al_kernel<uint64_t, HAO_AL_ED, false>), g_, b_, 0, c->stream, R, dt, order, n, (uint64_t*)nullptr, (uint64_t)0, dr, (hao_trace_result_t*)nullptr, (uint8_t*)nullptr, (uint16_t*)nullptr, 0u);
+	else if (nword == 2) hipLaunchKernelGGL((hao_al_kernel<hao_u128, HAO_AL_ED, false>), g_, b_, 0, c->stream, R, dt, order, n, (uint64_t*)nullptr, (uint64_t)0, dr, (hao_trace_result_t*)nullptr, (uint8_t*)nullptr, (uint16_t*)nullptr, 0u);
+	else if (nword == 3) hipLaunchKernelGGL((hao_al_kernel<hao_wide<3>, HAO_AL_ED, false>), g_, b_, 0, c->stream, R, dt, order, n, (uint64_t*)nullptr, (uint64_t)0, dr, (hao_trace_result_t*)nullptr, (uint8_t*)nullptr, (uint16_t*)nullptr, 0u);
+	else hipLaunchKernelGGL((hao_al_kernel<hao_wide<4>, HAO_AL_ED, false>), g_, b_, 0, c->stream, R, dt, order, n, (uint64_t*)nullptr, (uint64_t)0, dr, (hao_trace_result_t*)nullptr, (uint8_t*)nullptr, (uint16_t*)nullptr, 0u);
+	HAO_CHECK_LAUNCH();
+	return HAO_OK;
+}
+
 extern "C" {
 
 int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks, hao_ed_result_t *out)

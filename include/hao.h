@@ -233,6 +233,16 @@ typedef struct { uint32_t p_rid, p_pos, p_len, p_rev, t_rid, t_pos, t_len, t_rev
 typedef struct { int32_t err, pe; } hao_ed_result_t;
 int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks, hao_ed_result_t *out);
 
+/* f3 without a host in the loop (round 5): the window / candidate pairs of the LAST batch (hao_overlap_batch[_ex]; results resident) are generated on the device from the
+ * batch's final ol->list on the reference's fixed window grid - windows of `window` query bases (WINDOW = 375, Hash_Table.h:9; Correct.cpp:5645, 5993) starting at
+ * multiples of `window`, one pair per overlap and grid window it covers, the window clipped to the overlap at its ends, the pattern = the target interval on the
+ * overlap's diagonal padded by thre on both sides and clipped at the read ends with abs_diag = the bases clipped at its start (the operands Correct.cpp:3897 hands to
+ * ed_band_cal_semi_64_w_absent_diag, without the fake-cigar shift) - in text order (query read, grid window, position in ol->list), and the distance-only window
+ * alignment (hao_window_ed_batch's kernels) runs over them where they lie.  Tasks and results stay in device memory; *n_tasks = their number.
+ * hao_fetch_ed_grid copies the first `cap` of them out (either pointer may be NULL).  One threshold per call (thre <= HAO_ED_MAX_THRE); single-device mode. */
+int hao_window_ed_grid(hao_ctx *c, uint32_t window, uint32_t thre, uint64_t *n_tasks);
+int hao_fetch_ed_grid(hao_ctx *c, hao_ed_task_t *tasks, hao_ed_result_t *res, uint64_t cap);
+
 /* Second variant: global alignment inside the band WITH traceback - ed_band_cal_global_64_w_trace (Levenshtein_distance.h:3370-3442) on a
  * cleared bit_extz_t followed by gen_trace(ez, thre, 1) (:903-985), the call cal_exz_global / Correct.cpp:14537 make once a window's end points are fixed.
  * Same task records (abs_diag is ignored); both strings are consumed entirely, so |p_len - t_len| <= thre or there is no alignment.  Per task: err

@@ -262,3 +262,29 @@ def ed_ext_tasks(name, n_reads=24, wl=775, seed=4, wide=False):
         out.append((a, p_, n_ + 5, 0, a, p_, n_, 0, thre, 0))
         out.append((a, p_, n_, 0, a, p_, n_ + 5, 0, thre, 0))
     return np.array(out, dtype=np.uint32)
+
+
+def ed_tasks_grid_all(lengths, ols, lo=0, wl=375, thre=15):
+    """ed_tasks_grid's pairs for EVERY read of a batch, in the order hao_window_ed_grid generates them on the device: (query read, grid window, position in ol->list);
+    lengths = the lengths of ALL reads, ols[i] = the final overlap list of read lo + i (uint32 [n, 12], hao_ovlp_t).  Pairs whose band would not cover p_len - t_len + abs_diag inside its words are left out
+    (bands of more than one word), as hao_window_ed_batch refuses them."""
+    L = np.asarray(lengths).astype(np.int64)
+    nword = (2 * thre + 1 + 63) // 64
+    out = []
+    for i, ol in enumerate(ols):
+        for w in range((int(L[lo + i]) + wl - 1) // wl):
+            g0 = w * wl
+            for z in ol:
+                xs, xe, yid, ys, yrev = int(z[1]), int(z[2]), int(z[4]), int(z[5]), int(z[7])
+                if xs // wl > w or xe // wl < w:
+                    continue
+                ws, we = max(g0, xs), min(g0 + wl - 1, xe)
+                tn = we + 1 - ws
+                p0 = ys + (ws - xs) - thre; p1 = p0 + tn + 2 * thre; ad = 0
+                if p0 < 0:
+                    ad, p0 = min(-p0, 2 * thre), 0
+                p1 = min(p1, int(L[yid]))
+                if p1 <= p0 or tn <= 0 or (nword > 1 and (p1 - p0) - tn + ad > 64 * nword):
+                    continue
+                out.append((yid, p0, p1 - p0, yrev, int(z[0]), ws, tn, 0, thre, ad))
+    return np.array(out, dtype=np.uint32).reshape(-1, 10)
