@@ -1,8 +1,7 @@
 """f3 on the device end to end (hao_window_ed_grid, hao_grid.cuh): the window / candidate pairs of a batch are generated on the device from the batch's final ol->list on the
 reference's window grid (WINDOW = 375, Hash_Table.h:9; Correct.cpp:5645, 3897) and aligned where they lie.  The device's task list must equal the list built on the host
 from the same overlaps (helpers.ed_tasks_grid_all: query read, grid window, position in ol->list) and every result the oracle's ed_band_cal_semi_64_w_absent_diag
-(pinned to the reference by tests/test_oracle_ed.py; three-word bands: the upload path's result, itself pinned to the reference's *_infi_* functions).  Thresholds of one-, two- and three-word bands; a read set with N bases; a repeat-rich one.
-(First landing: not yet run on a device when it was committed - verified on the emulated library, tests/test_simt_edgrid_cpu.py - hence xfail(strict=False).)"""
+(pinned to the reference by tests/test_oracle_ed.py; three-word bands: the upload path's result, itself pinned to the reference's *_infi_* functions).  Thresholds of one-, two- and three-word bands; a read set with N bases; a repeat-rich one."""
 import time
 
 import numpy as np
@@ -14,7 +13,6 @@ pytestmark = pytest.mark.gpu
 NOALN = 2**31 - 1
 
 
-@pytest.mark.xfail(strict=False, reason="first landing: verified on the emulated library only")
 @pytest.mark.parametrize("name,window,thre", [("hifi", 375, 15), ("hifi", 375, 40), ("nn", 375, 8), ("rr", 375, 24), ("hifi", 775, 70), ("edge", 100, 3)])
 def test_grid_pairs_generated_and_aligned_on_the_device(name, window, thre):
     from hifiasm_amd.api import Engine

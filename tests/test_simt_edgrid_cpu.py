@@ -1,3 +1,4 @@
-from simt_suite import reexport
+from simt_suite import reexport, FULL
 
-reexport(globals(), "test_gpu_zzz_edgrid")
+# (default selection: a one-word band on a batch that does not start at read 0, a read set with N bases, a three-word band; HAO_SIMT_FULL=1: all six)
+reexport(globals(), "test_gpu_zzz_edgrid", drop=lambda v: not FULL and isinstance(v, (tuple, list)) and tuple(v) in (("hifi", 375, 40), ("edge", 100, 3)))
