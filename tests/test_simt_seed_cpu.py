@@ -198,7 +198,7 @@ _MERGE_ALL = [("hifi", 1, 3), ("rr", 1, 3), ("nn", 1, 3), ("ont", 1, 3), ("edge"
                                             ("hifi", 1, 8), ("rr", 1, 8), ("nn", 1, 8), ("ont", 1, 8), ("edge", 1, 8), ("k40", 1, 8), ("hpc0", 1, 8), ("fz2", 1, 8), ("rr_heavy", 25, 8), ("hifi", 1, 9), ("rr", 1, 9),
                                             ("hifi", 1, 11), ("rr", 1, 11), ("edge", 1, 11), ("ont", 1, 11), ("hifi", 1, 10), ("rr", 1, 10), ("nn", 1, 10), ("ont", 1, 10), ("edge", 1, 10), ("k40", 1, 10), ("hpc0", 1, 10), ("fz2", 1, 10), ("rr_heavy", 25, 10)]
 # the default CPU suite runs a selection (a minute); HAO_SIMT_FULL=1 runs every combination (ten minutes)
-_MERGE_DEFAULT = {("rr", 1, 4), ("hifi", 1, 5), ("rr", 1, 5), ("edge", 1, 5), ("hifi", 1, 7), ("rr", 1, 8), ("hifi", 1, 10), ("rr", 1, 11)}
+_MERGE_DEFAULT = {("rr", 1, 4), ("hifi", 1, 5), ("rr", 1, 5), ("hifi", 1, 7), ("hifi", 1, 8), ("hifi", 1, 10), ("rr", 1, 11)}
 
 
 @pytest.mark.parametrize("name,step,mode", [c for c in _MERGE_ALL if os.environ.get("HAO_SIMT_FULL") or c in _MERGE_DEFAULT])
