@@ -14,7 +14,9 @@
 // the general routine (per-row runs read from the lists, prefix sums over rows, opposite-strand records of a run in reverse list order: anchor.cpp:1023).
 //
 // Rows: the read's minimizers that have a list (compacted).  A read with more than 64 * RPL of them, or with more than 4096 minimizers, is left to the table
-// kernels (hao_query.cuh, hao_query3.cuh) through the overflow list.
+// kernels (hao_query.cuh, hao_query3.cuh) through the overflow list; so is a read with more than max_n seed hits, and the host gives whole batches whose reads
+// average more than 14 000 hits to the table kernels (reads that cross repeat families meet hundreds of targets, a step each: the tables are faster there;
+// hao_batch.hpp).  The id 2^28 - 1 is the merge's end mark: a read set that uses it takes the tables.
 //
 // HBM traffic per anchor: 8 bytes in (once), 16 bytes out; LDS: 12 bytes per row (the two query words of the row's hits, its list length, its minimizer); no barriers.
 // The rows' registers are named variables (ROW(i) below), not arrays: the compiler turned arrays under this control flow into register tuples it copied whole.
@@ -73,7 +75,8 @@ __global__ __launch_bounds__(256) void seed_locus_kernel(hao_seed_args S, const 
 // BUF = 1: a row reads its list one 8-byte record at a time; BUF = 4: 32 bytes at a time.  A lane's reads are its own (the lists of a read's minimizers lie anywhere
 // in the index), so every read moves a whole cache line through the memory fabric however little of it is used - and a line comes around again only after the other
 // ~500 rows of every wave of the XCD had their turn, by when the 4 MB L2 has lost it: with 8-byte reads a 128-byte line crosses the fabric up to 16 times
-// (measured: 122 ms per configs[2] pass against 59 ms for the table kernels - 6 TB/s of line traffic for 0.4 TB/s of records), with 32-byte reads 4 times.
+// (measured: 122 ms per configs[2] pass against 59 ms for the table kernels), with 32-byte reads 4 times (54.7 ms: the default).  AL: the 32-byte reads on 32-byte
+// boundaries (measured slower: a row's first read then brings fewer records).  What the variants measured, side by side: profiles/r05/seed_ab.txt, DESIGN 5.
 template<int RPL, int BUF, bool AL = false>
 __global__ __launch_bounds__(256, BUF == 4 ? (RPL == 8 ? 3 : 5) : 4) void seed_merge_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, const uint32_t *__restrict__ len, const uint32_t *__restrict__ order, uint32_t max_n, uint32_t *ovf_list, unsigned long long *ovf_cnt)
 {
