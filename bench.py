@@ -334,6 +334,8 @@ def run_workload(a, workload, steps, warmup, rank, local_rank, world, dist, torc
             ach_ = b_ * un_ / nb_ / (ms_ * 1e-3) / 1e9 if ms_ > 0 else 0.0
             return {"kernel": kn, "kernel_ms": round(ms_, 4), "launches_per_step": nb_, "alg_bytes_per_launch": int(b_ * un_ / nb_), "achieved": round(ach_, 2), "frac": round(ach_ / HBM_PEAK_GBS, 5)}
         roofline["kernels"] = [kernel_line(kn) for kn in KERN_STAGE]
+        # what the device gives this byte mix (8 in + 16 out per seed hit) with no computation attached: profiles/r05/ubench_gather.txt (tools/ubench_gather.hip)
+        roofline["seed_stage_ceilings"] = {"streaming_copy_frac": 0.545, "one_coalesced_walk_of_the_lists_frac": 0.533, "lane_private_walk_frac": 0.241, "source": "profiles/r05/ubench_gather.txt"}
         prof, prof_rel = profile_file("pmc_traffic.json")
         if prof and world == 1:      # PMC counters need their own rocprofv3 passes (tools/r05_final.sh pmc): not measurable inside this run
             try:
