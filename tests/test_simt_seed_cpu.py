@@ -219,7 +219,9 @@ def test_merge_kernel_against_the_oracle(name, step, mode):
 _RUNS_ALL = [(150, 120, 40, 3, 0.08), (600, 200, 50, 3, 0.08), (2500, 260, 60, 3, 0.08), (40, 300, 60, 3, 0.5), (12, 500, 30, 3, 0.9), (600, 200, 50, 4, 0.08),
                                                                  (150, 120, 40, 5, 0.08), (600, 200, 50, 5, 0.08), (2500, 260, 60, 5, 0.08), (40, 300, 60, 5, 0.5), (12, 500, 30, 5, 0.9), (600, 200, 50, 6, 0.08), (30, 200, 5, 5, 0.3),
                                                                  (150, 120, 40, 8, 0.08), (600, 200, 50, 8, 0.08), (2500, 260, 60, 8, 0.08), (40, 300, 60, 8, 0.5), (12, 500, 30, 8, 0.9), (30, 200, 5, 8, 0.3), (600, 300, 50, 9, 0.08), (25, 540, 20, 8, 0.6),
-                                                                 (150, 120, 40, 10, 0.08), (600, 200, 50, 10, 0.08), (2500, 260, 60, 10, 0.08), (40, 300, 60, 10, 0.5), (12, 500, 30, 10, 0.9), (30, 200, 5, 10, 0.3), (25, 540, 20, 10, 0.6), (300, 400, 9, 10, 0.2)]
+                                                                 (150, 120, 40, 10, 0.08), (600, 200, 50, 10, 0.08), (2500, 260, 60, 10, 0.08), (40, 300, 60, 10, 0.5), (12, 500, 30, 10, 0.9), (30, 200, 5, 10, 0.3), (25, 540, 20, 10, 0.6), (300, 400, 9, 10, 0.2),
+             (600, 200, 50, 11, 0.08), (40, 300, 60, 11, 0.5), (12, 500, 30, 11, 0.9), (30, 200, 5, 11, 0.3),
+             (60, 555, 12, 5, 0.3), (60, 556, 12, 5, 0.3), (60, 555, 12, 8, 0.3), (60, 556, 12, 10, 0.3)]      # (555 / 556 minimizers: exactly 512 rows - the last read the kernels take - and 513, the first they leave)
 _RUNS_DEFAULT = {(40, 300, 60, 5, 0.5), (12, 500, 30, 5, 0.9), (600, 200, 50, 6, 0.08), (30, 200, 5, 5, 0.3), (40, 300, 60, 8, 0.5), (25, 540, 20, 10, 0.6), (40, 300, 60, 3, 0.5), (40, 300, 60, 11, 0.5)}
 
 
