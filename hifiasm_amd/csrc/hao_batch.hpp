@@ -313,6 +313,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	HIP_TRY(B.hits.reserve(A + 1));
 	uint64_t max_q = 1;
 	for (uint64_t r = lo; r < hi; ++r) max_q = std::max<uint64_t>(max_q, c->h_ix_mz_off[r + 1] - c->h_ix_mz_off[r]);
+	const uint64_t sum_q = c->h_ix_mz_off[hi] - c->h_ix_mz_off[lo];      // minimizers of the batch's reads
 	int tb = 1; while ((1ULL << tb) < c->n_total) ++tb;
 	HIP_TRY(B.g_cnt.reserve(n + 2)); HIP_TRY(B.g_off.reserve(n + 2)); HIP_TRY(B.g_tmp.reserve(A + 1));
 	HIP_TRY(B.stats.reserve(3 * HAO_NCLS + 6)); HIP_TRY(hipMemsetAsync(B.stats.p, 0, (3 * HAO_NCLS + 6) * 8, c->stream));
@@ -360,9 +361,10 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			else if (int rc = launch(seed_bin2_kernel<9, 0, false>, seed_bin2_kernel<10, 1, true>, seed_bin2_kernel<11, 2, true>)) return rc;
 		}
 		else if (tile_ != 512) { if (int rc = launch(seed_bin_kernel<9, 0, 1024, false>, seed_bin_kernel<10, 1, 1024, false>, seed_bin_kernel<11, 2, 1024, false>)) return rc; }
-		else if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql && c->sw.seed_merge && A <= (uint64_t)c->sw.seed_merge_avg * n && c->n_total < HAO_MRG_END) {      // (read id 2^28 - 1 is the merge's end mark: a read set that uses it - exactly 2^28 reads - takes the tables)
+		else if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql && c->sw.seed_merge && A <= (uint64_t)c->sw.seed_merge_avg * n && sum_q <= (uint64_t)c->sw.seed_merge_qavg * n && c->n_total < HAO_MRG_END) {      // (read id 2^28 - 1 is the merge's end mark: a read set that uses it - exactly 2^28 reads - takes the tables)
 			// (the batch's reads average at most seed_merge_avg seed hits: above that the reads cross repeat families - hundreds of targets, a merge step each - and the
-			// table kernels below are the faster ones: 231 against 248 ms per pass of the repeat-rich 250 Mb set, 58.9 against 54.7 ms on the repeat-free one, profiles/r05)
+			// table kernels below are the faster ones: 231 against 248 ms per pass of the repeat-rich 250 Mb set, 58.9 against 54.7 ms on the repeat-free one, profiles/r05;
+			// and at most seed_merge_qavg (520) minimizers: nearly all of them have a list at 30x, and a wave holds 512 rows - a batch of 30 kb reads (1 150 minimizers) would hand every read on)
 			// the merge kernel (hao_query4.cuh): one wave per read, one walk over the read's position lists; the reads with more rows than a wave holds go through the
 			// table kernels below it (512-slot launch over the overflow list, then the launches without staged tiles)
 			lds2 = hao_seed3_lds<10>::FIXED + lds_q; lds3 = hao_seed3_lds<11>::FIXED + lds_q;

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 SWITCHES = ["HAO_DBG_SEQ_CHAIN", "HAO_DBG_DP_NOSPEC", "HAO_DBG_DP_SEQTAIL", "HAO_DBG_DP_SERIAL", "HAO_DBG_SEL1", "HAO_DBG_SEQ_PRUNE",
             "HAO_DBG_SK_GENERIC", "HAO_DBG_SK_GCAP", "HAO_SPEC_MINCLS", "HAO_CHAIN_WPB", "HAO_SEED_TILE", "HAO_DBG_TINY_LANE",
             "HAO_SEED_V2", "HAO_SEED_NOQL", "HAO_SEED_MERGE=0,HAO_SEED_NODIRECT=1", "HAO_SEED_MERGE=0,HAO_SEED_NU=8", "HAO_PT_SORT64", "HAO_PT_DIRECT",
-            "HAO_SEED_MERGE=0", "HAO_SEED_MERGE=4", "HAO_SEED_MBUF=1", "HAO_SEED_LOCUS=1", "HAO_SEED_LOCUS=2", "HAO_SEED_MALIGN=1", "HAO_SEED_MERGE_AVG=1000000", "HAO_SEED_MERGE_AVG=1000", "HAO_SEED_MERGE_MAXN=3000", "HAO_SEED_MERGE_MAXN=1000000",
+            "HAO_SEED_MERGE=0", "HAO_SEED_MERGE=4", "HAO_SEED_MBUF=1", "HAO_SEED_LOCUS=1", "HAO_SEED_LOCUS=2", "HAO_SEED_MALIGN=1", "HAO_SEED_MERGE_AVG=1000000", "HAO_SEED_MERGE_AVG=1000", "HAO_SEED_MERGE_QAVG=50", "HAO_SEED_MERGE_MAXN=3000", "HAO_SEED_MERGE_MAXN=1000000",
             "HAO_SEED_MERGEW=2", "HAO_SEED_MERGEW=4", "HAO_SEED_MERGEW=2,HAO_SEED_MBUF=1", "HAO_SEED_MERGEW=2,HAO_SEED_MBUF=8", "HAO_SEED_MERGEW=2,HAO_SEED_LOCUS=1"]      # (the table kernels for every read - rounds 1 - 4; the one-wave merge kernel with 8 / 4 rows per lane - with 4 most reads of these sets overflow to the table kernels - and 8-byte list reads; locus order; the seed-hit limit above which a read goes to the table kernels;
 # the four-wave kernel with 2 / 4 rows per lane, 8-byte and aligned 64-byte reads)
 VALUES = {"HAO_DBG_SK_GCAP": "1000", "HAO_SPEC_MINCLS": "0", "HAO_CHAIN_WPB": "4", "HAO_SEED_TILE": "1024"}
