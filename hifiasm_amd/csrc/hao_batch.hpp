@@ -5,6 +5,7 @@
 #include "hao_query2.cuh"
 #include "hao_query3.cuh"
 #include "hao_query4.cuh"
+#include "hao_query5.cuh"
 #include "hao_grid.cuh"
 #include "hao_chain.cuh"
 
@@ -12,7 +13,7 @@ struct hao_ctx::Batch {
 	uint64_t n_generic = 0, n_generic_hits = 0; DevBuf<unsigned long long> stats, dbgbuf;
 	uint64_t lo = 0, n = 0, mz0 = 0, n_mz = 0, n_anchor = 0, n_groups = 0, n_chains = 0, n_cl = 0, n_fc_raw = 0, n_ol = 0, n_fc = 0, n_fcw = 0;
 	bool valid = false, host_valid = false;
-	DevBuf<uint64_t> s_start, a_off, seg, g_cnt, g_off, g_start, ch_base, cl_base, fc_base, fcs, fc_raw, ol_fc_off, cc_off, cc, fc_final, fcf_off;
+	DevBuf<uint64_t> s_start, s_pk, a_off, seg, g_cnt, g_off, g_start, ch_base, cl_base, fc_base, fcs, fc_raw, ol_fc_off, cc_off, cc, fc_final, fcf_off;
 	DevBuf<uint64_t> nch64;
 	DevBuf<uint64_t> g_tmp, cls_cc, cls_co; DevBuf<hao_gent> glist; DevBuf<uint8_t> g_cls; DevBuf<uint32_t> slow, ovf_list, loc_idx, loc_idx2; DevBuf<uint64_t> loc_key, loc_key2; hipStream_t side[HAO_NCLS]; hipEvent_t ev_qc[HAO_NCLS], ev_dp[HAO_NCLS]; bool side_ready = false;
 	DevBuf<uint32_t> q_pos, q_cnt, s_n, g_read, wgt, nch, nout, perm, n_final, fclen;
@@ -42,7 +43,7 @@ struct hao_ctx::Batch {
 	std::vector<uint64_t> fetch_fc_off, h_cco;
 	void release() {
 		if (side_ready) { for (int x = 0; x < HAO_NCLS; ++x) { (void)hipStreamDestroy(side[x]); (void)hipEventDestroy(ev_qc[x]); (void)hipEventDestroy(ev_dp[x]); } side_ready = false; }
-		s_start.release(); a_off.release(); seg.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
+		s_start.release(); s_pk.release(); a_off.release(); seg.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fcf_off.release();
 		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); g_cls.release(); slow.release(); ovf_list.release(); loc_idx.release(); loc_idx2.release(); loc_key.release(); loc_key2.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
 		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); cd.release(); pk_cnt.release(); pk_ecnt.release(); pk_erank.release(); hq.release(); ohq.release(); hcode.release(); out[0].release(); out[1].release();
@@ -292,11 +293,11 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		B.wgt_hi = ps.high_occ; B.wgt_lo = ps.low_occ;
 	}
 	HIP_TRY(B.q_pos.reserve(nm + 1)); HIP_TRY(B.q_cnt.reserve(nm + 1));
-	HIP_TRY(B.s_start.reserve(nm + 1)); HIP_TRY(B.s_n.reserve(nm + 1)); HIP_TRY(B.a_off.reserve(nm + 2)); HIP_TRY(B.seg.reserve(n + 2));
+	HIP_TRY(B.s_start.reserve(nm + 1)); HIP_TRY(B.s_pk.reserve(nm + 1)); HIP_TRY(B.s_n.reserve(nm + 1)); HIP_TRY(B.a_off.reserve(nm + 2)); HIP_TRY(B.seg.reserve(n + 2));
 	HIP_TRY(c->d_err.reserve(2)); HIP_TRY(hipMemsetAsync(c->d_err.p, 0, 4, c->stream));
 	// Q1: every minimizer's lookup result was computed when the index was built (hao_index_finish_kernel; in sharded mode by the owner of its hash, hao_tables.hpp)
 	if (!c->lk_valid) { hao_set_err(c, "index without per-minimizer lookup results"); return HAO_EINVAL; }
-	hipLaunchKernelGGL(seed_unpack_kernel, dim3((unsigned)((nm + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_lk.p, c->d_ix_mz_info.p, B.mz0, nm, B.wgt.p, B.s_start.p, B.s_n.p, B.q_pos.p, B.q_cnt.p);
+	hipLaunchKernelGGL(seed_unpack_kernel, dim3((unsigned)((nm + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_lk.p, c->d_ix_mz_info.p, B.mz0, nm, B.wgt.p, B.s_start.p, B.s_n.p, B.q_pos.p, B.q_cnt.p, B.s_pk.p);
 	HAO_CHECK_LAUNCH();
 	if (int rc = hao_scan_u32(c, B.s_n.p, B.a_off.p, nm + 1)) return rc;
 	hipLaunchKernelGGL(seed_segments_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, c->d_ix_mz_off.p, lo, n, B.mz0, B.a_off.p, B.seg.p);
@@ -331,7 +332,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			if (c->sw.seq_chain || c->sw.tiny_lane || c->sw.pack_search || c->sw.dp_seqtail || c->sw.dp_nospec) { const uint64_t n16 = (A + 31) / 16; hipLaunchKernelGGL(hao_fill16_kernel, dim3((unsigned)std::min<uint64_t>((n16 + 255) / 256, 1u << 14)), dim3(256), 0, c->stream, (hao_fill_v4*)B.hcode.p, n16, 0x08080808u); HAO_CHECK_LAUNCH(); }
 			if (!c->sw.pack_search) { HIP_TRY(B.hq.reserve(A + 64)); sa_.hq = B.hq.p; }
 		}
-		if (c->sw.seedphase) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); sa_.dbg = B.dbgbuf.p; }
+		if (c->sw.seedphase) { HIP_TRY(B.dbgbuf.reserve(16)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 128, c->stream)); sa_.dbg = B.dbgbuf.p; }
 		HIP_TRY(B.ovf_list.reserve(3 * (n + 1)));
 		unsigned long long *d_ovf = B.stats.p + 3 * HAO_NCLS + 3, *d_ovf2 = B.stats.p + 3 * HAO_NCLS + 4, *d_ovf0 = B.stats.p + 3 * HAO_NCLS + 5;
 		uint32_t *ovf1 = B.ovf_list.p, *ovf2 = B.ovf_list.p + (n + 1), *ovf0 = B.ovf_list.p + 2 * (n + 1);
@@ -361,6 +362,39 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			else if (int rc = launch(seed_bin2_kernel<9, 0, false>, seed_bin2_kernel<10, 1, true>, seed_bin2_kernel<11, 2, true>)) return rc;
 		}
 		else if (tile_ != 512) { if (int rc = launch(seed_bin_kernel<9, 0, 1024, false>, seed_bin_kernel<10, 1, 1024, false>, seed_bin_kernel<11, 2, 1024, false>)) return rc; }
+		else if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql && c->sw.seed_lds && A <= (uint64_t)c->sw.seed_merge_avg * n && c->n_total < HAO_MRG_END && c->ix_n_pos + c->sw.ix_pad < (1ULL << 40)) {
+			// the list-major kernel (hao_query5.cuh): one persistent workgroup per CU, a read's position lists read once with adjacent lanes on adjacent records into LDS,
+			// merged by target there.  The reads it leaves (more than 1536 minimizers, more records than the LDS holds, more than seed_merge_maxn hits) go through the
+			// table kernels below it (512-slot launch over the overflow list, then the launches without staged tiles).  Batches whose reads average more than
+			// seed_merge_avg hits - reads across repeat families: hundreds of targets, a merge step each - keep the table kernels.
+			lds2 = hao_seed3_lds<10>::FIXED + lds_q; lds3 = hao_seed3_lds<11>::FIXED + lds_q;
+			auto k1 = seed_bin_kernel<9, 1, 512, true>; auto k2 = seed_bin3_kernel<10, 1, 4>; auto k3 = seed_bin3_kernel<11, 2, 4>;
+			HIP_TRY(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+			HIP_TRY(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+			HIP_TRY(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+			{
+				const uint64_t *sinfo_ = c->d_ix_sinfo.p; const uint32_t *len_ = c->d_len_all.p; const uint64_t *spk_ = B.s_pk.p;
+				const unsigned g_ = (unsigned)std::min<uint64_t>(n, (uint64_t)c->n_cu * (c->sw.seed_lds_wg > 0 ? c->sw.seed_lds_wg : 1));
+				const bool b16_ = c->max_len_all < 65536, wide_ = max_q > 2 * HAO_L5_THREADS;      // offsets of the staged records in 16 bits; reads with more than 1024 minimizers: three per thread
+				auto go_ = [&](auto k0, size_t lds_) -> int {
+					HIP_TRY(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
+					hipLaunchKernelGGL(k0, dim3(g_), dim3(HAO_L5_THREADS), lds_, c->stream, sa_, sinfo_, len_, spk_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
+					return HAO_OK;
+				};
+				int rc_;
+				if (c->sw.seedphase && b16_ && !wide_) rc_ = go_(seed_lds_kernel<true, 2, 16, true>, hao_l5_lds<true>::TOTAL);
+				else if (b16_) rc_ = wide_ ? go_(seed_lds_kernel<true, 3, 8, false>, hao_l5_lds<true>::TOTAL) : go_(seed_lds_kernel<true, 2, 16, false>, hao_l5_lds<true>::TOTAL);
+				else rc_ = wide_ ? go_(seed_lds_kernel<false, 3, 8, false>, hao_l5_lds<false>::TOTAL) : go_(seed_lds_kernel<false, 2, 16, false>, hao_l5_lds<false>::TOTAL);
+				if (rc_) return rc_;
+			}
+			HAO_CHECK_LAUNCH();
+			hipLaunchKernelGGL(k1, dim3((unsigned)n), dim3(256), lds1, c->stream, sa_, (const uint32_t*)ovf0, (const unsigned long long*)d_ovf0, ovf1, d_ovf);
+			HAO_CHECK_LAUNCH();
+			hipLaunchKernelGGL(k2, dim3((unsigned)n), dim3(256), lds2, c->stream, sa_, (const uint32_t*)ovf1, (const unsigned long long*)d_ovf, ovf2, d_ovf2);
+			HAO_CHECK_LAUNCH();
+			hipLaunchKernelGGL(k3, dim3((unsigned)n), dim3(256), lds3, c->stream, sa_, (const uint32_t*)ovf2, (const unsigned long long*)d_ovf2, (uint32_t*)nullptr, (unsigned long long*)nullptr);
+			HAO_CHECK_LAUNCH();
+		}
 		else if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql && c->sw.seed_merge && A <= (uint64_t)c->sw.seed_merge_avg * n && sum_q <= (uint64_t)c->sw.seed_merge_qavg * n && c->n_total < HAO_MRG_END) {      // (read id 2^28 - 1 is the merge's end mark: a read set that uses it - exactly 2^28 reads - takes the tables)
 			// (the batch's reads average at most seed_merge_avg seed hits: above that the reads cross repeat families - hundreds of targets, a merge step each - and the
 			// table kernels below are the faster ones: 231 against 248 ms per pass of the repeat-rich 250 Mb set, 58.9 against 54.7 ms on the repeat-free one, profiles/r05;
@@ -417,7 +451,10 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		}
 		else if (int rc = launch(seed_bin_kernel<9, 0, 512, false>, seed_bin_kernel<10, 1, 512, false>, seed_bin_kernel<11, 2, 512, false>)) return rc;
 	}
-	if (c->sw.seedphase) { unsigned long long d_[4]; HIP_TRY(hipMemcpy(d_, B.dbgbuf.p, 32, hipMemcpyDeviceToHost)); if (d_[3]) fprintf(stderr, "[seed] blocks %llu  avg us: count pass %.1f  sort+scan %.1f  scatter pass %.1f\n", d_[3], d_[0] / 100.0 / d_[3], d_[1] / 100.0 / d_[3], d_[2] / 100.0 / d_[3]); }
+	if (c->sw.seedphase) { unsigned long long d_[16]; HIP_TRY(hipMemcpy(d_, B.dbgbuf.p, 128, hipMemcpyDeviceToHost));
+		if (d_[9]) fprintf(stderr, "[seed lds] reads %llu  avg us per read (wave 0): stage %.2f  barrier %.2f  prepare %.2f  barrier %.2f  issue loads %.2f  splitters %.2f  merge %.2f  barrier + groups %.2f  barrier %.2f\n", d_[9],
+			d_[0] / 100.0 / d_[9], d_[1] / 100.0 / d_[9], d_[2] / 100.0 / d_[9], d_[3] / 100.0 / d_[9], d_[4] / 100.0 / d_[9], d_[5] / 100.0 / d_[9], d_[6] / 100.0 / d_[9], d_[7] / 100.0 / d_[9], d_[8] / 100.0 / d_[9]);
+		else if (d_[3]) fprintf(stderr, "[seed] blocks %llu  avg us: count pass %.1f  sort+scan %.1f  scatter pass %.1f\n", d_[3], d_[0] / 100.0 / d_[3], d_[1] / 100.0 / d_[3], d_[2] / 100.0 / d_[3]); }
 	c->timer.mark("q_sort_bins");
 	HIP_TRY(B.cls_cc.reserve(HAO_NCLS * (n + 1) + 1)); HIP_TRY(B.cls_co.reserve(HAO_NCLS * (n + 1) + 1));
 	hipLaunchKernelGGL(groups_classify_kernel, dim3((unsigned)((n + 4) / 4)), dim3(256), 0, c->stream, B.g_tmp.p, B.seg.p, B.g_cnt.p, n, B.cls_cc.p);

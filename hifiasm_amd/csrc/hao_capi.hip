@@ -35,6 +35,7 @@ int hao_create(int device, const hao_opt_t *opt, hao_ctx **out)
 	if (!opt || opt->k <= 0 || opt->k > 63 || opt->w <= 0 || opt->w >= 256) return HAO_EINVAL;
 	hao_ctx *c = new hao_ctx();
 	c->device = device; c->opt = *opt; c->max_n_chain = opt->max_n_chain; c->sw.load();
+	{ int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu; }      // (persistent kernels: one workgroup per CU)
 	{	// HIP multiplexes streams onto a few hardware queues: with several copy streams in flight the engine's stream can end up behind a bulk copy in its
 		// queue (measured: every batch started ~5 ms late with four copy streams), which is why the delivery path uses ONE copy stream by default.
 		// HAO_STREAM_PRIO=1 puts the engine's streams in the highest priority class instead (own queues) - measured worse: the copy then starves.
@@ -106,6 +107,7 @@ int hao_set_reads(hao_ctx *c, const uint8_t *packed, const uint64_t *pk_off, con
 	}
 	// unsharded default: this engine owns every read
 	c->rid_base = 0; c->n_total = n_reads; c->h_len_all = c->h_len;
+	c->max_len_all = 0; for (uint64_t i = 0; i < n_reads; ++i) c->max_len_all = std::max(c->max_len_all, len[i]);
 	HIP_TRY(c->d_len_all.reserve(n_reads + 1));
 	HIP_TRY(hipMemcpyAsync(c->d_len_all.p, len, n_reads * 4, hipMemcpyHostToDevice, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
@@ -121,6 +123,7 @@ int hao_set_shard(hao_ctx *c, uint64_t rid_base, uint64_t n_total, const uint32_
 	for (uint64_t i = 0; i < c->n_reads; ++i) if (all_len[rid_base + i] != c->h_len[i]) { hao_set_err(c, "all_len disagrees with the local read lengths"); return HAO_EINVAL; }
 	HIP_TRY(hipSetDevice(c->device));
 	c->rid_base = rid_base; c->n_total = n_total; c->h_len_all.assign(all_len, all_len + n_total); c->max_len = 0;
+	c->max_len_all = 0; for (uint64_t i = 0; i < n_total; ++i) c->max_len_all = std::max(c->max_len_all, all_len[i]);
 	HIP_TRY(c->d_len_all.reserve(n_total + 1));
 	HIP_TRY(hipMemcpy(c->d_len_all.p, all_len, n_total * 4, hipMemcpyHostToDevice));
 	c->has_ft = false; c->has_pt = false; c->h_ix_valid = false;

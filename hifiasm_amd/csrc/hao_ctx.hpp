@@ -59,7 +59,7 @@ struct hao_switches {
 	bool seedphase = false, qcphase = false, dp_stats = false, seq_chain = false, dp_seqtail = false, dp_nospec = false, dp_serial = false,
 		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, sk_v2 = false, dltime = false, sk_nofuse = false, pack_search = false, sk_select2 = false, seed_v2 = false, seed_pf = true, seed_noql = false, sort64 = false, seed_nodirect = false, tiny_lane = false, pt_direct = false;
 	static constexpr bool SK_SELECT2_DEFAULT = true;       // the thinning kernel the sketch runs when the environment says nothing: the wave kernel (round 4: green on the device against every repeat-rich scenario and the 5 Mb / 250 Mb repeat-rich fixtures)
-	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; unsigned long long ix_pad = 0, sort40_min = 1ULL << 23; int seed_nu = 4, fc_raw_every = 0, exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, seed_lds_pad = 0, arena_numa = 3, seed_tile = 512, seed_merge = 8, seed_mbuf = 4, seed_locus = 0, seed_mergew = 0, seed_merge_maxn = 24000, seed_merge_avg = 14000, seed_merge_qavg = 520, seed_malign = 0, ft_passes = 0; long long ft_chunk_slots = 0;
+	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; unsigned long long ix_pad = 0, sort40_min = 1ULL << 23; int seed_nu = 4, fc_raw_every = 0, exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, seed_lds_pad = 0, arena_numa = 3, seed_tile = 512, seed_merge = 8, seed_mbuf = 4, seed_locus = 0, seed_mergew = 0, seed_merge_maxn = 24000, seed_merge_avg = 14000, seed_merge_qavg = 520, seed_malign = 0, ft_passes = 0, seed_lds = 1, seed_lds_wg = 1; long long ft_chunk_slots = 0;
 	void load() {
 		auto on = [](const char *n) { return getenv(n) != nullptr; };
 		seedphase = on("HAO_DBG_SEEDPHASE"); qcphase = on("HAO_DBG_QCPHASE"); dp_stats = on("HAO_DBG_DP_STATS"); seq_chain = on("HAO_DBG_SEQ_CHAIN");
@@ -67,6 +67,8 @@ struct hao_switches {
 		selphase = on("HAO_DBG_SELPHASE"); sel1 = on("HAO_DBG_SEL1"); sk_generic = on("HAO_DBG_SK_GENERIC"); sk_v2 = on("HAO_DBG_SK_V2"); sk_nofuse = on("HAO_DBG_SK_NOFUSE"); pack_search = on("HAO_DBG_PACK_SEARCH");      // the wire packer searches every hit's minimizer (round-2 path) instead of gathering the quick check's code bytes
 		dltime = on("HAO_DBG_DLTIME");
 		if (const char *e = getenv("HAO_SEED_MERGE")) { const int v = atoi(e); seed_merge = v == 0 ? 0 : v == 4 ? 4 : 8; }      // the seed stage by merge (hao_query4.cuh; rows per lane), 0 = A/B: the table kernels for every read (rounds 1 - 4)
+		if (const char *e = getenv("HAO_SEED_LDS")) seed_lds = atoi(e) ? 1 : 0;      // 0 = A/B: the round-5 seed stage (one-wave merge kernel / table kernels) instead of the list-major LDS kernel (hao_query5.cuh)
+		if (const char *e = getenv("HAO_SEED_LDS_WG")) seed_lds_wg = std::max(1, atoi(e));      // persistent workgroups of the list-major kernel per CU (more than one only queue: a workgroup takes the CU's whole LDS)
 		if (const char *e = getenv("HAO_SEED_MERGE_QAVG")) seed_merge_qavg = std::max(0, atoi(e));      // batches whose reads average more minimizers than this take the table kernels (a wave of the merge kernel holds 512 minimizers with a list)
 		if (const char *e = getenv("HAO_SEED_MALIGN")) seed_malign = atoi(e) ? 1 : 0;      // the one-wave merge kernel's 32-byte list reads on 32-byte boundaries
 		if (const char *e = getenv("HAO_SEED_MERGE_AVG")) seed_merge_avg = std::max(0, atoi(e));      // batches whose reads average more seed hits than this take the table kernels (measured: the repeat-rich 250 Mb set averages 16 k, the repeat-free one 12 k)
@@ -118,7 +120,7 @@ struct hao_ctx {
 	DevBuf<uint8_t> d_packed; DevBuf<uint64_t> d_pk_off; DevBuf<uint32_t> d_len; DevBuf<uint64_t> d_nsite_off; DevBuf<uint32_t> d_nsite;
 	std::vector<uint32_t> h_len; std::vector<uint64_t> h_nsite_off;
 	// sharded mode: this engine holds reads [rid_base, rid_base + n_reads) of n_total; lengths of ALL reads are replicated
-	uint64_t rid_base = 0, n_total = 0; DevBuf<uint32_t> d_len_all; std::vector<uint32_t> h_len_all; struct hao_comm *comm = nullptr;
+	uint64_t rid_base = 0, n_total = 0; uint32_t max_len_all = 0; int n_cu = 256; DevBuf<uint32_t> d_len_all; std::vector<uint32_t> h_len_all; struct hao_comm *comm = nullptr;
 	// ---- filter table ----
 	bool has_ft = false; int ft_peak_hom = -1, ft_peak_het = -1, ft_cutoff = 0, ft_passes_used = 1; int64_t ft_hist[HAO_N_COUNTS];
 	std::vector<uint64_t> h_ft_keys; std::vector<int32_t> h_ft_vals;
@@ -184,7 +186,7 @@ static int hao_view_refresh(hao_ctx *c)
 	if (!o || c->attached_gen == o->index_gen) return HAO_OK;
 	c->opt = o->opt;
 	c->n_reads = o->n_reads; c->n_bases = o->n_bases; c->n_pk_bytes = o->n_pk_bytes; c->has_n = o->has_n; c->max_len = o->max_len;
-	c->rid_base = o->rid_base; c->n_total = o->n_total; c->max_n_chain = o->max_n_chain; c->hom_cov = o->hom_cov; c->het_cov = o->het_cov;
+	c->rid_base = o->rid_base; c->n_total = o->n_total; c->max_len_all = o->max_len_all; c->n_cu = o->n_cu; c->max_n_chain = o->max_n_chain; c->hom_cov = o->hom_cov; c->het_cov = o->het_cov;
 	c->has_pt = o->has_pt; c->ix_n_mz = o->ix_n_mz; c->ix_n_sorted = o->ix_n_sorted; c->ix_n_keys = o->ix_n_keys; c->ix_n_pos = o->ix_n_pos; c->ix_pad = o->ix_pad; c->ix_bucket_bits = o->ix_bucket_bits; c->lk_valid = o->lk_valid;
 	c->h_len = o->h_len; c->h_nsite_off = o->h_nsite_off; c->h_len_all = o->h_len_all; c->h_ix_mz_off = o->h_ix_mz_off;      // (empty: copied from the device on first use)
 	c->d_packed.borrow(o->d_packed); c->d_pk_off.borrow(o->d_pk_off); c->d_len.borrow(o->d_len); c->d_len_all.borrow(o->d_len_all); c->d_nsite_off.borrow(o->d_nsite_off); c->d_nsite.borrow(o->d_nsite);

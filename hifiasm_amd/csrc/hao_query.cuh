@@ -18,13 +18,14 @@
 // Q1 (ha_pt_get, anchor.cpp:1013, and the two words every hit of a minimizer shares: self_offset and cnt = weight(n) << 8 | span, anchor.cpp:1065-1076):
 // the lookup results were computed when the index was built (hao_index_finish_kernel): unpack them for the batch's minimizers
 __global__ void seed_unpack_kernel(const uint64_t *lk, const uint64_t *mz_info, uint64_t mz0, uint64_t n_mz, const uint32_t *wgt_tab,
-		uint64_t *s_start, uint32_t *s_n, uint32_t *q_pos, uint32_t *q_cnt)
+		uint64_t *s_start, uint32_t *s_n, uint32_t *q_pos, uint32_t *q_cnt, uint64_t *s_pk = nullptr)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i > n_mz) return;
-	if (i == n_mz) { s_n[i] = 0; return; }
+	if (i == n_mz) { s_n[i] = 0; if (s_pk) s_pk[i] = 0; return; }
 	const uint64_t v = lk[mz0 + i], z = mz_info[mz0 + i]; const uint32_t n = (uint32_t)(v >> 48);
 	s_start[i] = v & ((1ULL << 48) - 1); s_n[i] = n; q_pos[i] = hao_info_pos(z); q_cnt[i] = wgt_tab[n] << 8 | hao_info_span(z);
+	if (s_pk) s_pk[i] = (v & ((1ULL << 60) - 1)) | (uint64_t)hao_info_rev(z) << 63;      // seed_lds_kernel's minimizer word: list start | list length << 48 | strand of the minimizer << 63
 }
 
 // per-read anchor segment bounds from the per-minimizer scan

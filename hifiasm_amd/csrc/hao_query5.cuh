@@ -1,0 +1,397 @@
+// Seed stage, LIST-MAJOR through LDS (K5-K7 in one pass; minimizers_qgen0, anchor.cpp:987-1081): one persistent workgroup per CU, one read at a time,
+// every position list of the read read ONCE with adjacent lanes on adjacent records, the R-way merge by target (hao_query4.cuh's formulation) run out of LDS.
+//
+// Why: the one-wave merge kernel reads its lists lane-privately (32 bytes at a time), which moves whole 128-byte lines through the fabric several times - it
+// fetched 2.5 - 5 x its records and sat at 0.33 of the HBM peak, where a coalesced walk of the same lists with the same stores runs at 0.53
+// (tools/ubench_gather.hip, profiles/r05).  The transposition between "list-major in" and "target-major out" needs the read's records on chip at once:
+// ~12 000 records of a 15 kb read at 30 x.  Here they are, 6 bytes each (key word: target | strand of the HIT << 28; offset word: 16 bits while every read is
+// shorter than 64 kb, else 32), in up to 118 KB of the CU's 160 KB.
+//
+// One workgroup of 8 waves owns the CU's LDS, so nothing else hides its memory latency: the kernel is a software pipeline over the workgroup's reads
+// (read i = blockIdx.x + i * gridDim.x).  While read e is merged,
+//   the records of read e + 1 are in flight into REGISTERS (one 8-byte record per lane and load slot; a slot = up to 16 consecutive records of one list,
+//   read by 16 adjacent lanes), issued from a slot table that the preparation of read e + 1 left in LDS;
+//   the minimizer words of read e + 2 (list start | length | strand, query position, weight) are in flight into registers;
+//   the four offsets of read e + 3 are in flight.
+// A step: write read e's records from the registers into LDS (strand folded, offset precomputed), barrier, prepare read e + 1 from its minimizer words
+// (stable compaction of the minimizers that have a list, three block scans in one, slot table), barrier, issue the three sets of loads, merge read e.
+//
+// The merge.  The hits of a read in the reference's order (target, strand, query minimizer, list order) are the merge of its lists by target (every list is
+// sorted by (rid, pos), htab.cpp:380-460).  The eight waves split the TARGET range: while the records are staged, a 256-bin histogram of their targets (bins =
+// equal slices of the read-id range) is counted in LDS; its prefix sums give seven bin boundaries with about an eighth of the read's hits between them, wave w takes
+// the targets in [s_w, s_w+1): a binary search per row in LDS finds where its range starts in every list, the sum of those positions is where its output starts.
+// (First version: splitters from 64 sampled records - eight samples per range: the slowest wave took twice the mean, profiles/r06/seed_phases.txt.)
+// Inside its range a wave runs hao_query4.cuh's step - smallest head target by one wave-min, ballots, forward hits then opposite-strand hits ranked by mbcnt,
+// one 16-byte store per hit at a running position - with heads and cursors in registers (2 per row, up to 24 rows per lane: reads with up to 1536 minimizers
+// that have a list) and everything else read from LDS: no buffers to refill, an advance is a cursor increment and a 4-byte LDS read, the end of a list is a
+// sentinel record.  A row with several records of one target (a k-mer twice in a target) shows as "the next minimum equals T again" and the target is redone
+// by the general routine (runs per row, forward records in list order, opposite-strand records in reverse list order: anchor.cpp:1023).  Group entries
+// (target, first hit) go to a per-wave LDS list and are written out behind each other after the merge.
+//
+// Reads this kernel leaves to the table kernels (overflow list, as the merge kernel did): more than 1536 minimizers, more records than the LDS holds, more load
+// slots than the slot table, more than max_n hits (reads across repeat families: hundreds of targets, a step each), more than 96 groups in one wave's range.
+// HBM traffic per seed hit: 8 bytes in (once, coalesced), 16 bytes out.
+#pragma once
+#include <type_traits>
+#include "hao_query4.cuh"
+
+#define HAO_L5_THREADS 512
+#define HAO_L5_W 8                    // waves per workgroup = target ranges per read
+#define HAO_L5_QPT_MAX 3              // minimizers per thread (template parameter QPT = 2 or 3): a read has at most 1024 / 1536; the LDS is laid out for 1536
+#define HAO_L5_R (HAO_L5_QPT_MAX * HAO_L5_THREADS)
+#define HAO_L5_CH 16                  // records per load slot
+#define HAO_L5_LPS (HAO_L5_CH / 2)     // lanes per slot: a lane reads two consecutive records with one 16-byte load (half the load instructions of 8-byte loads: the
+                                      // vector memory pipeline's address processing, not the bytes, was what the record loads of a read cost - 4 us per read)
+#define HAO_L5_SUB (HAO_L5_THREADS / HAO_L5_LPS)      // slot groups per workgroup (64)
+struct hao_rec2 { uint64_t a, b; };
+// template parameter NPF: slots per group held in registers while the previous read is merged (16: 1024 slots, four registers each; the rest of a read's slots are loaded when it is staged).
+// Registers are what bounds this kernel (one workgroup of 512 = two waves per SIMD = 256 VGPRs): the record registers (2 NPF), the merge's rows (about 5 per row:
+// 48 / 80 / 121 for 8 / 16 / 24 rows per lane) and the minimizer words (8 QPT) are all alive while a read is merged, and a single spilled register is fatal here -
+// its reload is a scratch LOAD, and the s_waitcnt vmcnt(0) in front of its use waits for every record load in flight (the first device run spent the merge waiting
+// for the prefetch it was meant to hide).  So: <QPT 2, NPF 16> for batches whose reads have at most 1024 minimizers (HiFi reads up to ~35 kb), <QPT 3, NPF 8> beyond.
+#define HAO_L5_SL 2048                // slot table
+#define HAO_L5_GW 96                  // group entries per wave
+#define HAO_L5_HB 256                 // bins of the target histogram that splits a read's target range between the waves
+// the unrolled load / staging loops: stop the scheduler from hoisting all 32 address computations (64 more live registers) in front of the first access
+#ifndef HAO_L5_SCHED_FENCE
+#define HAO_L5_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+#define HAO_L5_MASK 0xfffffffu
+#define HAO_L5_SENT 0xffffffffu
+
+template<bool B16> struct hao_l5_lds {
+	typedef typename std::conditional<B16, uint16_t, uint32_t>::type off_t;
+	static constexpr uint32_t FIXED = HAO_L5_SL * 8 + HAO_L5_W * HAO_L5_GW * 8 + HAO_L5_R * 8 /* qw */ + (HAO_L5_QPT_MAX * HAO_L5_W + 4) * 8 /* scan */ + (HAO_L5_R + 4) * 4 /* ao */ + 64 /* small words */ + 2 * HAO_L5_HB * 4 /* hist */ + HAO_L5_R * 2 /* qi */ + 64;
+	static constexpr uint32_t TOTAL = 160 * 1024;
+	static constexpr uint32_t CAP = ((TOTAL - FIXED) / (B16 ? 6 : 8) - 8) & ~7u;      // record slots (records + one sentinel per row + the guard slot 0)
+};
+
+__device__ __forceinline__ uint64_t hao_wave_incl_scan_u64(uint64_t v)
+{
+#define HAO_RED_STEP(CTRL, RM) { const uint32_t lo2 = (uint32_t)hao_dpp<CTRL, RM>(0, (int)(uint32_t)v), hi2 = (uint32_t)hao_dpp<CTRL, RM>(0, (int)(uint32_t)(v >> 32)); v += (uint64_t)hi2 << 32 | lo2; }
+	HAO_RED_STEP(0x111, 0xf) HAO_RED_STEP(0x112, 0xf) HAO_RED_STEP(0x114, 0xf) HAO_RED_STEP(0x118, 0xf) HAO_RED_STEP(0x142, 0xa) HAO_RED_STEP(0x143, 0xc)
+#undef HAO_RED_STEP
+	return v;
+}
+__device__ __forceinline__ uint64_t hao_readlane_u64(uint64_t v, int l) { return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32 | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l); }
+
+// a read's place in the pipeline: what the offsets say (alpha) and what the preparation found (gamma)
+struct hao_l5_read { uint64_t m0, s; uint32_t nq, n; uint32_t nk, nslots, nlds; bool valid, skip; };
+
+// the pointers of the workgroup's LDS block
+template<bool B16> struct hao_l5_ptr {
+	uint64_t *slots, *grp, *scan; uint2 *qw; uint32_t *recA, *ao, *sm, *hist; uint16_t *qi; typename hao_l5_lds<B16>::off_t *recB;
+	__device__ __forceinline__ hao_l5_ptr(void *base) {
+		slots = (uint64_t*)base; grp = slots + HAO_L5_SL; qw = (uint2*)(grp + HAO_L5_W * HAO_L5_GW); scan = (uint64_t*)(qw + HAO_L5_R);
+		ao = (uint32_t*)(scan + HAO_L5_QPT_MAX * HAO_L5_W + 4); sm = ao + HAO_L5_R + 4; hist = sm + 16;      /* (hist is read 16 bytes at a time: every array before it is a multiple of 16 bytes) */ recA = hist + 2 * HAO_L5_HB;
+		recB = (typename hao_l5_lds<B16>::off_t*)(recA + hao_l5_lds<B16>::CAP); qi = (uint16_t*)(recB + hao_l5_lds<B16>::CAP);
+	}
+};
+
+// slot word: list position of the slot's first record (40 bits) | records - 1 (4 bits) << 40 | strand of the minimizer << 45 | LDS position of the first record << 46
+#define HAO_L5_SLOT_G(e) ((e) & ((1ULL << 40) - 1))
+#define HAO_L5_SLOT_C(e) (((uint32_t)((e) >> 40) & 15u) + 1u)
+#define HAO_L5_SLOT_Z(e) ((uint32_t)((e) >> 45) & 1u)
+#define HAO_L5_SLOT_O(e) ((uint32_t)((e) >> 46))
+
+// an index record as the merge wants it: key = target | strand of the HIT << 28 (the rest of the word is free), off = the hit's offset on the forward
+// strand, or - opposite strand - the k-mer's start in the target, from which the emission takes tlen - 1 - start (anchor.cpp:1021-1023, 1059-1064)
+__device__ __forceinline__ void hao_l5_fold(uint64_t y, uint32_t z, uint32_t &a, uint32_t &b)
+{
+	const uint32_t rv = z ^ hao_info_rev(y);
+	a = hao_info_rid(y) | rv << 28;
+	b = rv ? hao_info_pos(y) + 1 - hao_info_span(y) : hao_info_pos(y);
+}
+
+// ---- the merge of one read out of LDS, one wave = one target range [t_lo, t_hi) ----
+template<int RPL, bool B16>
+__device__ __forceinline__ uint32_t hao_l5_merge(const hao_l5_ptr<B16> &L, const uint32_t nk, const uint32_t t_lo, const uint32_t t_hi, const int wv, const int lane,
+		hao_hit_t *__restrict__ hits, uint16_t *__restrict__ hq, const uint32_t *__restrict__ len, uint32_t &ngr_out)
+{
+	uint32_t hd[RPL], cur[RPL];
+	// where the wave's range starts in every row: lower bound of t_lo in the row's records (wave 0: the row's first record).  During the search cur[] is the
+	// lower end and hd[] the upper end of a row's interval (no arrays of their own: the registers are what this kernel is short of)
+	uint32_t before = 0;
+#pragma unroll
+	for (int i = 0; i < RPL; ++i) {
+		const uint32_t row = i * 64 + lane;
+		if (row < nk) { cur[i] = L.ao[row]; hd[i] = t_lo ? L.ao[row + 1] - 1 : cur[i]; }      // (the slot before the next row's first record is this row's sentinel)
+		else cur[i] = hd[i] = 0;                                                               // (rows beyond nk stand on the guard slot 0: a sentinel)
+		before -= cur[i];
+	}
+	if (t_lo)
+		for (;;) {
+			bool more = false;
+#pragma unroll
+			for (int i = 0; i < RPL; ++i)
+				if (cur[i] < hd[i]) {
+					const uint32_t md = (cur[i] + hd[i]) >> 1;
+					if ((L.recA[md] & HAO_L5_MASK) < t_lo) cur[i] = md + 1; else hd[i] = md;
+					more = true;
+				}
+			if (!__any(more)) break;
+		}
+#pragma unroll
+	for (int i = 0; i < RPL; ++i) { before += cur[i]; hd[i] = L.recA[cur[i]]; }
+	uint32_t run = hao_wave_incl_scan_u32(before); run = (uint32_t)__builtin_amdgcn_readlane((int)run, 63);
+	const uint32_t first = run;
+	uint32_t ngr = 0;
+	uint64_t *grp = L.grp + wv * HAO_L5_GW;
+#define HAO_L5_NEXT(out) { uint32_t mn = HAO_L5_MASK; _Pragma("unroll") for (int i = 0; i < RPL; ++i) mn = min(mn, hd[i] & HAO_L5_MASK); out = hao_wave_min_u32(mn); }
+#define HAO_L5_EMIT(slot_, at_, T_, tlen_, row_) { \
+		const uint32_t a_ = L.recA[slot_], b_ = (uint32_t)L.recB[slot_], rv_ = a_ >> 28 & 1; const uint2 qw_ = L.qw[row_]; \
+		hao_hit_t h_; h_.w0 = (T_) | rv_ << 31; h_.offset = rv_ ? (tlen_) - 1 - b_ : b_; h_.self_offset = qw_.x; h_.cnt = qw_.y; \
+		hits[at_] = h_; if (hq) hq[at_] = L.qi[row_]; }
+	uint32_t T; HAO_L5_NEXT(T)
+	while (T < t_hi) {
+		const uint32_t tlen = len[T];
+		// forward hits of T over all rows (where the opposite strand starts)
+		uint32_t c0 = 0;
+#pragma unroll
+		for (int i = 0; i < RPL; ++i) c0 += (uint32_t)__popcll(__ballot((hd[i] & 0x1fffffffu) == T));
+		const uint32_t base0 = run;
+		if (lane == 0 && ngr < HAO_L5_GW) grp[ngr] = (uint64_t)T << 32 | base0;
+		++ngr;
+		uint32_t p0 = base0, p1 = base0 + c0, part = 0;
+#pragma unroll
+		for (int i = 0; i < RPL; ++i) {
+			const bool act = (hd[i] & HAO_L5_MASK) == T;
+			const unsigned long long h = __ballot(act);
+			if (h) {      // (wave-uniform)
+				const uint32_t rv = hd[i] >> 28 & 1;
+				const unsigned long long v = __ballot(act && rv), f = h & ~v;
+				const uint32_t at = rv ? p1 + hao_mbcnt(v) : p0 + hao_mbcnt(f);
+				p0 += (uint32_t)__popcll(f); p1 += (uint32_t)__popcll(v);
+				if (act) {
+					const uint32_t row = i * 64 + lane;
+					HAO_L5_EMIT(cur[i], at, T, tlen, row)
+					++cur[i]; hd[i] = L.recA[cur[i]]; part |= 1u << i;
+				}
+			}
+		}
+		run = p1;
+		uint32_t Tn; HAO_L5_NEXT(Tn)
+		if (Tn == T) {
+			// ---- some row holds several records of T: the target again, in full (a row that took part stands one record behind its run's first) ----
+			uint32_t f_mine = 0;
+#pragma unroll
+			for (int i = 0; i < RPL; ++i)
+				if (part >> i & 1) for (uint32_t j = cur[i] - 1; (L.recA[j] & HAO_L5_MASK) == T; ++j) f_mine += !(L.recA[j] >> 28 & 1);
+			uint32_t f_tot = hao_wave_incl_scan_u32(f_mine); f_tot = (uint32_t)__builtin_amdgcn_readlane((int)f_tot, 63);
+			p0 = base0; p1 = base0 + f_tot;
+#pragma unroll
+			for (int i = 0; i < RPL; ++i) {
+				const bool mine = part >> i & 1;
+				if (__ballot(mine)) {
+					uint32_t nf = 0, nr = 0, j1 = 0;
+					if (mine) for (j1 = cur[i] - 1; (L.recA[j1] & HAO_L5_MASK) == T; ++j1) { if (L.recA[j1] >> 28 & 1) ++nr; else ++nf; }
+					const uint32_t inf = hao_wave_incl_scan_u32(nf), inr = hao_wave_incl_scan_u32(nr);
+					const uint32_t tf = (uint32_t)__builtin_amdgcn_readlane((int)inf, 63), tr = (uint32_t)__builtin_amdgcn_readlane((int)inr, 63);
+					if (mine) {
+						const uint32_t row = i * 64 + lane;
+						uint32_t af = p0 + inf - nf, ar = p1 + inr;      // forward records in list order; opposite-strand records of the run in REVERSE list order (anchor.cpp:1023)
+						for (uint32_t j = cur[i] - 1; j < j1; ++j) { const uint32_t at = (L.recA[j] >> 28 & 1) ? --ar : af++; HAO_L5_EMIT(j, at, T, tlen, row) }
+						cur[i] = j1; hd[i] = L.recA[j1];
+					}
+					p0 += tf; p1 += tr;
+				}
+			}
+			run = p1;
+			HAO_L5_NEXT(Tn)
+		}
+		T = Tn;
+	}
+#undef HAO_L5_NEXT
+#undef HAO_L5_EMIT
+	ngr_out = ngr;
+	(void)first;
+	return run;
+}
+
+template<bool B16, int QPT, int NPF, bool DBG>
+__global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, const uint32_t *__restrict__ len, const uint64_t *__restrict__ s_pk,
+		uint32_t max_n, uint32_t *ovf_list, unsigned long long *ovf_cnt)
+{
+	constexpr uint32_t CAP = hao_l5_lds<B16>::CAP;
+	extern __shared__ uint64_t l5_smem[];
+	const hao_l5_ptr<B16> L((void*)l5_smem);
+	const uint32_t tid = threadIdx.x; const int wv = tid >> 6, lane = hao_lane();
+	const uint32_t sg = tid / HAO_L5_LPS, sj = 2 * (tid % HAO_L5_LPS);      // this thread's slot group and its first record inside a slot (it takes records sj and sj + 1)
+	const uint32_t hshift = S.tb > 8 ? (uint32_t)S.tb - 8u : 0u;      // read ids have tb bits: 256 histogram bins over the id range
+	const uint64_t G = gridDim.x, b0 = blockIdx.x;
+	if (b0 == 0 && tid == 0) S.g_cnt[S.n_sel] = 0;
+	if (b0 >= S.n_sel) return;
+	if (tid < 2 * HAO_L5_HB) L.hist[tid] = 0;
+	const uint64_t nrd = (S.n_sel - b0 + G - 1) / G;      // this workgroup's reads: b0, b0 + G, ...
+	// pipeline registers
+	uint64_t av = 0;                                                        // alpha: lanes 0 - 3 of every wave hold mz_off[r], mz_off[r + 1], seg[r], seg[r + 1]
+	uint64_t raw_s[QPT]; uint32_t raw_p[QPT], raw_c[QPT];      // beta: start | n << 48 | strand << 63, query position, cnt word of the thread's minimizers
+	uint32_t t_kc[QPT], t_ao[QPT], t_p[QPT], t_c[QPT];      // gamma: row | list length << 16 (or ~0), first LDS slot, the two query words
+	hao_rec2 rec[NPF];                                               // delta: the records of this thread's slots
+	hao_l5_read rb, rd, re;
+	rb.valid = rd.valid = re.valid = false; rb.skip = rd.skip = re.skip = true; rb.m0 = rb.s = rd.m0 = rd.s = re.m0 = re.s = 0; rb.nq = rb.n = rd.nq = rd.n = re.nq = re.n = 0;
+	rb.nk = rb.nslots = rb.nlds = rd.nk = rd.nslots = rd.nlds = re.nk = re.nslots = re.nlds = 0;
+#pragma unroll
+	for (int m = 0; m < QPT; ++m) { raw_s[m] = 0; raw_p[m] = raw_c[m] = 0; t_kc[m] = HAO_L5_SENT; t_ao[m] = t_p[m] = t_c[m] = 0; }
+#pragma unroll
+	for (int i = 0; i < NPF; ++i) rec[i].a = rec[i].b = 0;
+
+	// DBG instances: wall-clock ticks (100 MHz) of wave 0 per phase, summed over the workgroups into S.dbg[0 .. 9] (HAO_DBG_SEEDPHASE)
+	unsigned long long tk_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk_last = DBG ? wall_clock64() : 0;
+#define HAO_L5_TICK(k) if constexpr (DBG) { const unsigned long long now_ = wall_clock64(); tk_acc[k] += now_ - tk_last; tk_last = now_; }
+	for (uint64_t step = 0; step < nrd + 3; ++step) {
+		// reads of this step: e = step - 3 is staged and merged, d = step - 2 prepared and its records requested, b = step - 1: its minimizer words requested, a = step: its offsets
+		re = rd; rd = rb;
+		rb.valid = step >= 1 && step - 1 < nrd; rb.skip = true;
+		if (rb.valid) {
+			const uint64_t m0 = hao_readlane_u64(av, 0), m1 = hao_readlane_u64(av, 1), s0 = hao_readlane_u64(av, 2), s1 = hao_readlane_u64(av, 3);
+			rb.m0 = m0; rb.nq = (uint32_t)(m1 - m0); rb.s = s0; rb.n = (uint32_t)(s1 - s0);
+			rb.skip = rb.n == 0 || rb.nq > (uint32_t)(QPT * HAO_L5_THREADS) || rb.n > max_n;      // (skip: nothing to load; a read that is left to the table kernels is listed when it reaches the merge step)
+		}
+		// ---- stage read e: the row table from the registers the preparation left, the records from the registers the loads filled ----
+		uint32_t *hist_e = L.hist + ((step + 1) & 1) * HAO_L5_HB;      // (this step's histogram; the other one is cleared below for the next step)
+		if (re.valid && !re.skip) {
+#pragma unroll
+			for (int m = 0; m < QPT; ++m)
+				if (t_kc[m] != HAO_L5_SENT) {
+					const uint32_t k = t_kc[m] & 0xffffu, c = t_kc[m] >> 16;
+					L.ao[k] = t_ao[m]; L.qw[k] = make_uint2(t_p[m], t_c[m]); L.qi[k] = (uint16_t)(m * HAO_L5_THREADS + tid);
+					L.recA[t_ao[m] + c] = HAO_L5_SENT;
+				}
+			if (tid == 0) { L.recA[0] = HAO_L5_SENT; L.ao[re.nk] = re.nlds + 1; }
+#pragma unroll
+			for (int i = 0; i < NPF; ++i) {
+				const uint32_t sl = i * HAO_L5_SUB + sg;
+				if (sl < re.nslots) {
+					const uint64_t e = L.slots[sl];
+					const uint32_t c = HAO_L5_SLOT_C(e), z = HAO_L5_SLOT_Z(e), o = HAO_L5_SLOT_O(e) + sj;
+					if (sj < c) { uint32_t a, b; hao_l5_fold(rec[i].a, z, a, b); L.recA[o] = a; L.recB[o] = (typename hao_l5_lds<B16>::off_t)b; atomicAdd(&hist_e[(a & HAO_L5_MASK) >> hshift], 1u); }
+					if (sj + 1 < c) { uint32_t a, b; hao_l5_fold(rec[i].b, z, a, b); L.recA[o + 1] = a; L.recB[o + 1] = (typename hao_l5_lds<B16>::off_t)b; atomicAdd(&hist_e[(a & HAO_L5_MASK) >> hshift], 1u); }
+				}
+				if ((i & 1) == 1) HAO_L5_SCHED_FENCE();
+			}
+			for (uint32_t sl = NPF * HAO_L5_SUB + sg; sl < re.nslots; sl += HAO_L5_SUB) {      // the slots beyond the registers: loaded now
+				const uint64_t e = L.slots[sl];
+				const uint32_t c = HAO_L5_SLOT_C(e), z = HAO_L5_SLOT_Z(e), o = HAO_L5_SLOT_O(e) + sj;
+				if (sj < c) { uint32_t a, b; hao_l5_fold(sinfo[HAO_L5_SLOT_G(e) + sj], z, a, b); L.recA[o] = a; L.recB[o] = (typename hao_l5_lds<B16>::off_t)b; atomicAdd(&hist_e[(a & HAO_L5_MASK) >> hshift], 1u); }
+				if (sj + 1 < c) { uint32_t a, b; hao_l5_fold(sinfo[HAO_L5_SLOT_G(e) + sj + 1], z, a, b); L.recA[o + 1] = a; L.recB[o + 1] = (typename hao_l5_lds<B16>::off_t)b; atomicAdd(&hist_e[(a & HAO_L5_MASK) >> hshift], 1u); }
+			}
+		}
+		HAO_L5_TICK(0)
+		__syncthreads();
+		HAO_L5_TICK(1)
+		// ---- prepare read d from its minimizer words: rows = the minimizers that have a list, in order; one scan for (rows, load slots, LDS slots) ----
+		{
+			uint64_t v[QPT], inc[QPT];
+			const bool go = rd.valid && !rd.skip;
+			if (tid < HAO_L5_HB) L.hist[(step & 1) * HAO_L5_HB + tid] = 0;      // next step's histogram (last read by the step before this one)
+#pragma unroll
+			for (int m = 0; m < QPT; ++m) {
+				const uint32_t q = m * HAO_L5_THREADS + tid, c = go && q < rd.nq ? (uint32_t)(raw_s[m] >> 48) & 0xfffu : 0u;
+				v[m] = c ? 1ULL | (uint64_t)((c + HAO_L5_CH - 1) / HAO_L5_CH) << 16 | (uint64_t)(c + 1) << 40 : 0ULL;
+				inc[m] = hao_wave_incl_scan_u64(v[m]);
+				if (lane == 63) L.scan[m * HAO_L5_W + wv] = inc[m];
+			}
+			__syncthreads();
+			uint64_t run = 0, basev[QPT];
+#pragma unroll
+			for (int m = 0; m < QPT; ++m)
+#pragma unroll
+				for (int w = 0; w < HAO_L5_W; ++w) { if (w == wv) basev[m] = run; run += L.scan[m * HAO_L5_W + w]; }
+			rd.nk = (uint32_t)run & 0xffffu; rd.nslots = (uint32_t)(run >> 16) & 0xffffffu; rd.nlds = (uint32_t)(run >> 40);
+			if (go && (rd.nslots > HAO_L5_SL || rd.nlds + 2 > CAP)) rd.skip = true;
+			const bool go2 = rd.valid && !rd.skip;
+#pragma unroll
+			for (int m = 0; m < QPT; ++m) {
+				t_kc[m] = HAO_L5_SENT; t_ao[m] = 0; t_p[m] = raw_p[m]; t_c[m] = raw_c[m];
+				if (go2 && v[m]) {
+					const uint64_t ex = basev[m] + inc[m] - v[m];
+					const uint32_t k = (uint32_t)ex & 0xffffu, sl0 = (uint32_t)(ex >> 16) & 0xffffffu, o0 = (uint32_t)(ex >> 40) + 1, c = (uint32_t)(raw_s[m] >> 48) & 0xfffu, z = (uint32_t)(raw_s[m] >> 63);
+					const uint64_t st = raw_s[m] & ((1ULL << 48) - 1);
+					t_kc[m] = k | c << 16; t_ao[m] = o0;
+					for (uint32_t x = 0, sl = sl0; x < c; x += HAO_L5_CH, ++sl)
+						L.slots[sl] = (st + x) | (uint64_t)(min(c - x, (uint32_t)HAO_L5_CH) - 1) << 40 | (uint64_t)z << 45 | (uint64_t)(o0 + x) << 46;
+				}
+			}
+		}
+		HAO_L5_TICK(2)
+		__syncthreads();
+		HAO_L5_TICK(3)
+		// ---- loads: the records of read d (first NPF slots per group), the minimizer words of read b, the offsets of read a ----
+		{
+			const uint32_t nsl = rd.valid && !rd.skip ? rd.nslots : 0u;
+#pragma unroll
+			for (int i = 0; i < NPF; ++i) {
+				const uint32_t sl = i * HAO_L5_SUB + sg;
+				rec[i].a = rec[i].b = 0;      // (every register is written in every step: a conditional assignment alone would keep last step's value alive across the whole loop body)
+				if (sl < nsl) {
+					const uint64_t e = L.slots[sl]; const uint32_t c = HAO_L5_SLOT_C(e);
+					if (sj + 1 < c) rec[i] = *(const hao_rec2*)(sinfo + HAO_L5_SLOT_G(e) + sj);      // (16 bytes at an 8-byte boundary)
+					else if (sj < c) rec[i].a = sinfo[HAO_L5_SLOT_G(e) + sj];                        // the odd record at the end of a list: nothing is read past it
+				}
+				if ((i & 1) == 1) HAO_L5_SCHED_FENCE();
+			}
+		}
+		{
+			const uint64_t li0 = rb.m0 - S.mz0; const uint32_t nqb = rb.valid && !rb.skip ? rb.nq : 0u;
+#pragma unroll
+			for (int m = 0; m < QPT; ++m) {
+				const uint32_t q = m * HAO_L5_THREADS + tid;
+				raw_s[m] = 0; raw_p[m] = 0; raw_c[m] = 0;
+				if (q < nqb) { raw_s[m] = s_pk[li0 + q]; raw_p[m] = S.q_pos[li0 + q]; raw_c[m] = S.q_cnt[li0 + q]; }
+			}
+		}
+		if (step < nrd) {
+			const uint64_t r = b0 + step * G;
+			if (lane < 4) av = lane < 2 ? S.mz_off[S.rid_lo + r + lane] : S.seg[r + lane - 2];
+		}
+		HAO_L5_TICK(4)
+		// ---- merge read e ----
+		if (re.valid) {
+			const uint64_t r = b0 + (step - 3) * G;
+			uint32_t ngr = 0; bool gover = false;
+			if (!re.skip) {
+				// seven splitters from the target histogram: wave w starts at the first bin whose exclusive prefix sum reaches w / 8 of the read's hits
+				uint32_t t_lo = 0, t_hi = HAO_L5_MASK;
+				{
+					const uint4 hv = *(const uint4*)(hist_e + 4 * lane);
+					const uint32_t s4 = hv.x + hv.y + hv.z + hv.w, ex0 = hao_wave_incl_scan_u32(s4) - s4, ex1 = ex0 + hv.x, ex2 = ex1 + hv.y, ex3 = ex2 + hv.z;
+					const uint32_t th_lo = (uint32_t)(((uint64_t)re.n * (uint32_t)wv) >> 3), th_hi = (uint32_t)(((uint64_t)re.n * (uint32_t)(wv + 1)) >> 3);
+					const uint32_t b_lo = (uint32_t)(__popcll(__ballot(ex0 < th_lo)) + __popcll(__ballot(ex1 < th_lo)) + __popcll(__ballot(ex2 < th_lo)) + __popcll(__ballot(ex3 < th_lo)));
+					const uint32_t b_hi = (uint32_t)(__popcll(__ballot(ex0 < th_hi)) + __popcll(__ballot(ex1 < th_hi)) + __popcll(__ballot(ex2 < th_hi)) + __popcll(__ballot(ex3 < th_hi)));
+					t_lo = b_lo << hshift;      // (wave 0: th_lo = 0, no bin below it: t_lo = 0)
+					if (wv < HAO_L5_W - 1 && b_hi < HAO_L5_HB) t_hi = b_hi << hshift;
+				}
+				hao_hit_t *hits = S.hits + re.s; uint16_t *hq = S.hq ? S.hq + re.s : nullptr;
+				HAO_L5_TICK(5)
+				if (t_lo < t_hi) {
+					if (re.nk <= 8 * 64) (void)hao_l5_merge<8, B16>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, ngr);
+					else if (QPT == 2 || re.nk <= 16 * 64) (void)hao_l5_merge<16, B16>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, ngr);
+					else if constexpr (QPT > 2) (void)hao_l5_merge<24, B16>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, ngr);
+				}
+				if (lane == 0) L.sm[wv] = ngr;
+				HAO_L5_TICK(6)
+			}
+			__syncthreads();
+			if (!re.skip) {
+				uint32_t gb = 0, tot = 0;
+#pragma unroll
+				for (int w = 0; w < HAO_L5_W; ++w) { const uint32_t g = L.sm[w]; if (w < wv) gb += g; tot += g; gover |= g > HAO_L5_GW; }
+				if (!gover) {
+					uint64_t *g_tmp = S.g_tmp + re.s; const uint64_t *grp = L.grp + wv * HAO_L5_GW;
+					for (uint32_t k = lane; k < ngr; k += 64) g_tmp[gb + k] = grp[k];
+					if (tid == 0) S.g_cnt[r] = tot;
+				}
+			}
+			if (tid == 0) {
+				if (re.n == 0) S.g_cnt[r] = 0;
+				else if (re.skip || gover) ovf_list[atomicAdd(ovf_cnt, 1ULL)] = (uint32_t)r;      // left to the table kernels
+			}
+		}
+		HAO_L5_TICK(7)
+		__syncthreads();
+		HAO_L5_TICK(8)
+	}
+	if constexpr (DBG) if (tid == 0 && S.dbg) { for (int k = 0; k < 9; ++k) atomicAdd(S.dbg + k, tk_acc[k]); atomicAdd(S.dbg + 9, (unsigned long long)nrd); }
+#undef HAO_L5_TICK
+}

@@ -9,7 +9,7 @@
 // (Assembly.cpp:2083-2084 ha_ft_gen + ha_opt_update_cov; Assembly.cpp:1007-1008
 // ha_pt_gen; ecovlp.cpp:3234-3274 worker_hap_ec up to and including h_ec_lchain).
 //
-// usage: ref_harness [--ont] [-t N] [-k K] [-w W] [-f BLOOM_BITS] [--no-hpc] [--hg-size N] [--bw X] [--dump PREFIX] [--time] [--nodump-hits]
+// usage: ref_harness [--ont] [-t N] [-k K] [-w W] [-f BLOOM_BITS] [--no-hpc] [--hg-size N] [--bw X] [-N MAX_N_CHAIN] [--rl-cut N] [--sc-cut N] [--dump PREFIX] [--time] [--nodump-hits]
 //                    [--reads-list FILE] [--no-tables] [--digest] reads.fa
 //   --reads-list FILE  per-read dumps (minimizers, seed hits, ol / fc / cl) only for the read ids listed in FILE (text, one per line);
 //                      the *_off arrays then have one entry per LISTED read (+1), in list order
@@ -27,6 +27,9 @@
 //                      the call leaves them, also without an alignment)
 //   --load-index PFX   f4: skip ha_ft_gen / ha_pt_gen and the read parser: the tables and the read store come from PFX.pt_flt (+ .bin, .paf.bin) through
 //                      the reference's own load_pt_index (htab.cpp:1432); every dump then describes what a stock hifiasm sees after loading that index
+//   -N X / --rl-cut N / --sc-cut N   handed to the reference's own option parser unchanged (CommandLines.cpp:891, :1003-1005): the floor of max_n_chain
+//                      (ha_opt_update_cov raises it to hom_cov * high_factor, :411-418) and the --ont reader's length / quality cuts (htab.cpp:763-764; the
+//                      random workloads of tests/simt_fuzz.py have reads shorter than the default 1000)
 //   --bw X             bw_thres of the pass (default 0.02 / 0.05 --ont; the final round uses 0.001, ecovlp.cpp:3957)
 #include <stdio.h>
 #include <stdlib.h>
@@ -133,7 +136,7 @@ static tbuf_t *tbuf_init(int n)
 int main(int argc, char *argv[])
 {
 	int no_tables_hist = 0, ft_tables = 0;
-	int n_thread = 1, is_ont = 0, do_time = 0, dump_hits = 1, k = -1, w = -1, bf_shift = 0, no_hpc = 0, no_tables = 0, do_digest = 0; const char *fa = 0, *list_fn = 0, *hg = 0, *ed_fn = 0, *edg_fn = 0, *eds_fn = 0, *ed1_fn = 0, *ed2_fn = 0, *load_pfx = 0, *save_pfx = 0; std::string prefix;
+	int n_thread = 1, is_ont = 0, do_time = 0, dump_hits = 1, k = -1, w = -1, bf_shift = 0, no_hpc = 0, no_tables = 0, do_digest = 0; const char *fa = 0, *list_fn = 0, *hg = 0, *opt_N = 0, *rl_cut = 0, *sc_cut = 0, *ed_fn = 0, *edg_fn = 0, *eds_fn = 0, *ed1_fn = 0, *ed2_fn = 0, *load_pfx = 0, *save_pfx = 0; std::string prefix;
 	double bw_arg = -1;
 	for (int i = 1; i < argc; ++i) {
 		if (!strcmp(argv[i], "--ont")) is_ont = 1;
@@ -147,6 +150,9 @@ int main(int argc, char *argv[])
 		else if (!strcmp(argv[i], "--no-hpc")) no_hpc = 1;
 		else if (!strcmp(argv[i], "--hg-size")) hg = argv[++i];
 		else if (!strcmp(argv[i], "--bw")) bw_arg = atof(argv[++i]);
+		else if (!strcmp(argv[i], "-N")) opt_N = argv[++i];
+		else if (!strcmp(argv[i], "--rl-cut")) rl_cut = argv[++i];
+		else if (!strcmp(argv[i], "--sc-cut")) sc_cut = argv[++i];
 		else if (!strcmp(argv[i], "--reads-list")) list_fn = argv[++i];
 		else if (!strcmp(argv[i], "--no-tables")) no_tables = 1;
 		else if (!strcmp(argv[i], "--ft-tables")) ft_tables = 1;      // with --no-tables: still dump the all-k-mer histogram and the filter table (not the position index)
@@ -169,6 +175,9 @@ int main(int argc, char *argv[])
 	if (w > 0) { snprintf(wb, 32, "%d", w); av.push_back("-w"); av.push_back(wb); }
 	if (is_ont) av.push_back("--ont");
 	if (hg) { av.push_back("--hg-size"); av.push_back(hg); }
+	if (opt_N) { av.push_back("-N"); av.push_back(opt_N); }
+	if (rl_cut) { av.push_back("--rl-cut"); av.push_back(rl_cut); }
+	if (sc_cut) { av.push_back("--sc-cut"); av.push_back(sc_cut); }
 	av.push_back(fa);
 	std::vector<char*> avp; for (size_t i = 0; i < av.size(); ++i) avp.push_back((char*)av[i].c_str());
 	yak_reset_realtime();

@@ -48,6 +48,7 @@ inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return
 inline ulonglong2 make_ulonglong2(unsigned long long x, unsigned long long y) { return ulonglong2{x, y}; }
 struct dim3 { unsigned x, y, z; constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 inline dim3 threadIdx, blockIdx, blockDim, gridDim;
+#define __builtin_amdgcn_sched_barrier(m) ((void)0)
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((uint64_t)hi << 32 | lo) >> (sh & 31)); }
@@ -65,6 +66,8 @@ inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = getenv("HAO_SIMT_CUS") ? atoi(getenv("HAO_SIMT_CUS")) : 3; return hipSuccess; }      // (three "CUs": a persistent kernel's workgroups each run several reads)
 inline hipError_t hipDeviceGetPCIBusId(char *b, int len, int) { snprintf(b, len, "0000:00:00.0"); return hipSuccess; }
 inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = 0; return hipSuccess; }
 // device memory is not zeroed (0xA5 here), and every allocation sits between guard zones that hipFree checks: a kernel that writes before or past its buffer ends the process

@@ -4,13 +4,14 @@
 // only, which compares the hits and the group lists with the oracle's restatement of minimizers_qgen0.
 #include "hao_query3.cuh"
 #include "hao_query4.cuh"
+#include "hao_query5.cuh"
 #include <execinfo.h>
 #include <signal.h>
 static void simt_segv(int) { void *bt[40]; int n = backtrace(bt, 40); fprintf(stderr, "SIGSEGV in work-item %d of block %u\n", hao_simt::g.cur, blockIdx.x); backtrace_symbols_fd(bt, n, 2); _exit(3); }
 
 namespace {
 struct Sim {
-	std::vector<uint64_t> s_start, a_off, seg, g_tmp, g_cnt; std::vector<uint32_t> s_n, q_pos, q_cnt, ovf; std::vector<hao_hit_t> hits; std::vector<uint16_t> hq;
+	std::vector<uint64_t> s_start, a_off, seg, g_tmp, g_cnt, s_pk; std::vector<uint32_t> s_n, q_pos, q_cnt, ovf; std::vector<hao_hit_t> hits; std::vector<uint16_t> hq;
 };
 int fail(char *err, int cap, const std::string &m) { snprintf(err, cap, "%s", m.c_str()); return 1; }
 }
@@ -29,9 +30,9 @@ extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t 
 	if (getenv("SIMT_DBG")) signal(SIGSEGV, simt_segv);
 	hao_simt::g.n_exchange = hao_simt::g.n_barrier = hao_simt::g.n_switch = 0;
 	Sim S; const uint64_t nm = mz_off[n];
-	S.s_start.assign(nm + 1, 0); S.s_n.assign(nm + 1, 0); S.q_pos.assign(nm + 1, 0); S.q_cnt.assign(nm + 1, 0); S.a_off.assign(nm + 2, 0); S.seg.assign(n + 2, 0);
+	S.s_start.assign(nm + 1, 0); S.s_n.assign(nm + 1, 0); S.q_pos.assign(nm + 1, 0); S.q_cnt.assign(nm + 1, 0); S.a_off.assign(nm + 2, 0); S.seg.assign(n + 2, 0); S.s_pk.assign(nm + 1, 0);
 	using hao_simt::launch;
-	if (launch((unsigned)((nm + 256) / 256), 256, 0, [&] { seed_unpack_kernel(lk, mz_info, 0, nm, wgt, S.s_start.data(), S.s_n.data(), S.q_pos.data(), S.q_cnt.data()); })) return fail(err, errcap, hao_simt::g.error);
+	if (launch((unsigned)((nm + 256) / 256), 256, 0, [&] { seed_unpack_kernel(lk, mz_info, 0, nm, wgt, S.s_start.data(), S.s_n.data(), S.q_pos.data(), S.q_cnt.data(), S.s_pk.data()); })) return fail(err, errcap, hao_simt::g.error);
 	for (uint64_t i = 0; i <= nm; ++i) S.a_off[i + 1] = S.a_off[i] + S.s_n[i];      // hao_scan_u32 (exclusive, nm + 1 entries + the total)
 	if (launch((unsigned)((n + 256) / 256), 256, 0, [&] { seed_segments_kernel(mz_off, 0, n, 0, S.a_off.data(), S.seg.data()); })) return fail(err, errcap, hao_simt::g.error);
 	const uint64_t A = S.a_off[nm];
@@ -53,7 +54,24 @@ extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t 
 	const uint32_t *nil32 = nullptr; const unsigned long long *nil64 = nullptr;
 	std::vector<uint32_t> ovf0(n + 4, 0); unsigned long long ovf0_cnt = 0;
 	const uint32_t max_n = getenv("SIMT_SEED_MAXN") ? (uint32_t)atoi(getenv("SIMT_SEED_MAXN")) : 0xffffffffu;      // reads with more seed hits go to the table kernels
-	if (mode == 7) {      // the merge kernel in locus order: key per read, the reads sorted by key, an eighth of the sorted list per "XCD" (blocks b, b + 8, ...); every read runs
+	if (mode == 12 || mode == 13) {      // the list-major kernel (hao_query5.cuh): persistent workgroups of 512 work-items, every read of the set; SIMT_SEED_GRID workgroups (default 3: every workgroup
+		// runs several reads through its pipeline); mode 12: 16-bit offsets when every read is shorter than 64 kb (what the library does), mode 13: 32-bit offsets
+		bool b16 = mode == 12; for (uint64_t r = 0; r < n_total; ++r) if (len[r] >= 65536) b16 = false;
+		const unsigned grid = (unsigned)std::min<uint64_t>(n, getenv("SIMT_SEED_GRID") ? (uint64_t)atoi(getenv("SIMT_SEED_GRID")) : 3);
+		const bool wide = max_q > 2 * HAO_L5_THREADS || getenv("SIMT_SEED_WIDE");      // (three minimizers per thread and fewer record registers: what the library launches for batches with long reads)
+		std::function<void()> call;
+		if (b16 && wide) call = [&] { seed_lds_kernel<true, 3, 8, false>(sa, sinfo, len, S.s_pk.data(), max_n, ovf0.data(), &ovf0_cnt); };
+		else if (b16) call = [&] { seed_lds_kernel<true, 2, 16, false>(sa, sinfo, len, S.s_pk.data(), max_n, ovf0.data(), &ovf0_cnt); };
+		else if (wide) call = [&] { seed_lds_kernel<false, 3, 8, false>(sa, sinfo, len, S.s_pk.data(), max_n, ovf0.data(), &ovf0_cnt); };
+		else call = [&] { seed_lds_kernel<false, 2, 16, false>(sa, sinfo, len, S.s_pk.data(), max_n, ovf0.data(), &ovf0_cnt); };
+		if (launch(grid, HAO_L5_THREADS, b16 ? hao_l5_lds<true>::TOTAL : hao_l5_lds<false>::TOTAL, call)) return fail(err, errcap, hao_simt::g.error);
+		stats[6] = ovf0_cnt;
+		if (ovf0_cnt) {
+			std::function<void()> call = [&] { seed_bin_kernel<9, 1, 512, true>(sa, ovf0.data(), &ovf0_cnt, ovf1, &ovf_cnt[0]); };
+			if (launch((unsigned)ovf0_cnt, 256, lds1, call)) return fail(err, errcap, hao_simt::g.error);
+		}
+	}
+	else if (mode == 7) {      // the merge kernel in locus order: key per read, the reads sorted by key, an eighth of the sorted list per "XCD" (blocks b, b + 8, ...); every read runs
 		std::vector<uint64_t> key(n + 1, 0); std::vector<uint32_t> idx(n + 1, 0);
 		if (launch((unsigned)((n + 3) / 4), 256, 0, [&] { seed_locus_kernel(sa, sinfo, 64u, key.data(), idx.data()); })) return fail(err, errcap, hao_simt::g.error);
 		std::vector<uint32_t> ord(idx.begin(), idx.begin() + n);
