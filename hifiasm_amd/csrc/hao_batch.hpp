@@ -332,7 +332,8 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			if (c->sw.seq_chain || c->sw.tiny_lane || c->sw.pack_search || c->sw.dp_seqtail || c->sw.dp_nospec) { const uint64_t n16 = (A + 31) / 16; hipLaunchKernelGGL(hao_fill16_kernel, dim3((unsigned)std::min<uint64_t>((n16 + 255) / 256, 1u << 14)), dim3(256), 0, c->stream, (hao_fill_v4*)B.hcode.p, n16, 0x08080808u); HAO_CHECK_LAUNCH(); }
 			if (!c->sw.pack_search) { HIP_TRY(B.hq.reserve(A + 64)); sa_.hq = B.hq.p; }
 		}
-		if (c->sw.seedphase) { HIP_TRY(B.dbgbuf.reserve(16)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 128, c->stream)); sa_.dbg = B.dbgbuf.p; }
+		if (c->sw.seedphase) { HIP_TRY(B.dbgbuf.reserve(64)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 512, c->stream)); sa_.dbg = B.dbgbuf.p;
+			if (const char *e_ = getenv("HAO_DBG_SEEDFLAGS")) { const unsigned long long f_ = strtoull(e_, nullptr, 0); HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipMemcpy(B.dbgbuf.p + 31, &f_, 8, hipMemcpyHostToDevice)); } }      // (timing experiments of the list-major seed kernel's DBG instance: results are wrong on purpose)
 		HIP_TRY(B.ovf_list.reserve(3 * (n + 1)));
 		unsigned long long *d_ovf = B.stats.p + 3 * HAO_NCLS + 3, *d_ovf2 = B.stats.p + 3 * HAO_NCLS + 4, *d_ovf0 = B.stats.p + 3 * HAO_NCLS + 5;
 		uint32_t *ovf1 = B.ovf_list.p, *ovf2 = B.ovf_list.p + (n + 1), *ovf0 = B.ovf_list.p + 2 * (n + 1);
@@ -382,7 +383,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 					return HAO_OK;
 				};
 				int rc_;
-				if (c->sw.seedphase && b16_ && !wide_) rc_ = go_(seed_lds_kernel<true, 2, 16, true>, hao_l5_lds<true>::TOTAL);
+				if (c->sw.seedphase && b16_ && !wide_) rc_ = go_(seed_lds_kernel<true, 2, 12, true>, hao_l5_lds<true>::TOTAL);
 				else if (b16_) rc_ = wide_ ? go_(seed_lds_kernel<true, 3, 8, false>, hao_l5_lds<true>::TOTAL) : go_(seed_lds_kernel<true, 2, 16, false>, hao_l5_lds<true>::TOTAL);
 				else rc_ = wide_ ? go_(seed_lds_kernel<false, 3, 8, false>, hao_l5_lds<false>::TOTAL) : go_(seed_lds_kernel<false, 2, 16, false>, hao_l5_lds<false>::TOTAL);
 				if (rc_) return rc_;
@@ -451,7 +452,9 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		}
 		else if (int rc = launch(seed_bin_kernel<9, 0, 512, false>, seed_bin_kernel<10, 1, 512, false>, seed_bin_kernel<11, 2, 512, false>)) return rc;
 	}
-	if (c->sw.seedphase) { unsigned long long d_[16]; HIP_TRY(hipMemcpy(d_, B.dbgbuf.p, 128, hipMemcpyDeviceToHost));
+	if (c->sw.seedphase) { unsigned long long d_[64]; HIP_TRY(hipMemcpy(d_, B.dbgbuf.p, 512, hipMemcpyDeviceToHost));
+		if (d_[9]) { fprintf(stderr, "[seed lds] step loop us / steps / emitting blocks per read, waves 0 - 7:"); for (int w_ = 0; w_ < 8; ++w_) fprintf(stderr, " %.2f/%.1f/%.1f", d_[32 + w_] / 100.0 / d_[9], (double)d_[40 + w_] / d_[9], (double)d_[48 + w_] / d_[9]); fprintf(stderr, "\n"); }
+		if (d_[9]) { fprintf(stderr, "[seed lds] merge us per read, waves 0 - 7:"); for (int w_ = 0; w_ < 8; ++w_) fprintf(stderr, " %.2f", d_[16 + w_] / 100.0 / d_[9]); fprintf(stderr, "\n"); }
 		if (d_[9]) fprintf(stderr, "[seed lds] reads %llu  avg us per read (wave 0): stage %.2f  barrier %.2f  prepare %.2f  barrier %.2f  issue loads %.2f  splitters %.2f  merge %.2f  barrier + groups %.2f  barrier %.2f\n", d_[9],
 			d_[0] / 100.0 / d_[9], d_[1] / 100.0 / d_[9], d_[2] / 100.0 / d_[9], d_[3] / 100.0 / d_[9], d_[4] / 100.0 / d_[9], d_[5] / 100.0 / d_[9], d_[6] / 100.0 / d_[9], d_[7] / 100.0 / d_[9], d_[8] / 100.0 / d_[9]);
 		else if (d_[3]) fprintf(stderr, "[seed] blocks %llu  avg us: count pass %.1f  sort+scan %.1f  scatter pass %.1f\n", d_[3], d_[0] / 100.0 / d_[3], d_[1] / 100.0 / d_[3], d_[2] / 100.0 / d_[3]); }

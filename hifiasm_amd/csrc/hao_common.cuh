@@ -56,6 +56,13 @@ __device__ __forceinline__ int hao_lane() { return threadIdx.x & 63; }
 #define HAO_LOCKSTEP()
 #endif
 
+// A 4-byte load through the SCALAR cache from a wave-uniform address, result in an SGPR, waited for at once.  For the rare uniform fallback of a value that normally
+// comes from LDS: written as a plain C++ load next to the LDS load the compiler may fold the two into one flat load (select of the addresses) whose s_waitcnt
+// vmcnt(0) then waits for every vector load and store the wave has in flight (hao_query5.cuh).  The CPU emulation of the kernels reads the word directly.
+#ifndef HAO_SLOAD_U32
+#define HAO_SLOAD_U32(dst, ptr) asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dst) : "s"(ptr) : "memory")
+#endif
+
 // Cross-lane moves on the DPP path (one VALU op, no LDS crossbar trip like ds_bpermute).  gfx9 controls: 0x110+n row_shr:n (inside rows of
 // 16 lanes), 0x142 row_bcast:15 (lane 15 of a row -> the next row, use row_mask 0xa), 0x143 row_bcast:31 (lane 31 -> rows 2,3, row_mask 0xc),
 // 0x138 wave_shr:1.  Lanes without a valid source keep `old`.  Call only in wave-uniform control flow.

@@ -61,7 +61,7 @@ struct hao_rec2 { uint64_t a, b; };
 
 template<bool B16> struct hao_l5_lds {
 	typedef typename std::conditional<B16, uint16_t, uint32_t>::type off_t;
-	static constexpr uint32_t FIXED = HAO_L5_SL * 8 + HAO_L5_W * HAO_L5_GW * 8 + HAO_L5_R * 8 /* qw */ + (HAO_L5_QPT_MAX * HAO_L5_W + 4) * 8 /* scan */ + (HAO_L5_R + 4) * 4 /* ao */ + 64 /* small words */ + 2 * HAO_L5_HB * 4 /* hist */ + HAO_L5_R * 2 /* qi */ + 64;
+	static constexpr uint32_t FIXED = HAO_L5_SL * 8 + HAO_L5_W * HAO_L5_GW * 8 + HAO_L5_R * 8 /* qw */ + (HAO_L5_QPT_MAX * HAO_L5_W + 4) * 8 /* scan */ + (HAO_L5_R + 4) * 4 /* ao */ + 64 /* small words */ + 5 * HAO_L5_HB * 4 /* hist x 2, bin_tid, bin_len (one word per THREAD: see the preparation) */ + HAO_L5_R * 2 /* qi */ + 64;
 	static constexpr uint32_t TOTAL = 160 * 1024;
 	static constexpr uint32_t CAP = ((TOTAL - FIXED) / (B16 ? 6 : 8) - 8) & ~7u;      // record slots (records + one sentinel per row + the guard slot 0)
 };
@@ -80,10 +80,10 @@ struct hao_l5_read { uint64_t m0, s; uint32_t nq, n; uint32_t nk, nslots, nlds; 
 
 // the pointers of the workgroup's LDS block
 template<bool B16> struct hao_l5_ptr {
-	uint64_t *slots, *grp, *scan; uint2 *qw; uint32_t *recA, *ao, *sm, *hist; uint16_t *qi; typename hao_l5_lds<B16>::off_t *recB;
+	uint64_t *slots, *grp, *scan; uint2 *qw; uint32_t *recA, *ao, *sm, *hist, *bin_tid, *bin_len; uint16_t *qi; typename hao_l5_lds<B16>::off_t *recB;
 	__device__ __forceinline__ hao_l5_ptr(void *base) {
 		slots = (uint64_t*)base; grp = slots + HAO_L5_SL; qw = (uint2*)(grp + HAO_L5_W * HAO_L5_GW); scan = (uint64_t*)(qw + HAO_L5_R);
-		ao = (uint32_t*)(scan + HAO_L5_QPT_MAX * HAO_L5_W + 4); sm = ao + HAO_L5_R + 4; hist = sm + 16;      /* (hist is read 16 bytes at a time: every array before it is a multiple of 16 bytes) */ recA = hist + 2 * HAO_L5_HB;
+		ao = (uint32_t*)(scan + HAO_L5_QPT_MAX * HAO_L5_W + 4); sm = ao + HAO_L5_R + 4; hist = sm + 16;      /* (hist is read 16 bytes at a time: every array before it is a multiple of 16 bytes) */ bin_tid = hist + 2 * HAO_L5_HB; bin_len = bin_tid + HAO_L5_HB; recA = bin_len + 2 * HAO_L5_HB;
 		recB = (typename hao_l5_lds<B16>::off_t*)(recA + hao_l5_lds<B16>::CAP); qi = (uint16_t*)(recB + hao_l5_lds<B16>::CAP);
 	}
 };
@@ -94,19 +94,23 @@ template<bool B16> struct hao_l5_ptr {
 #define HAO_L5_SLOT_Z(e) ((uint32_t)((e) >> 45) & 1u)
 #define HAO_L5_SLOT_O(e) ((uint32_t)((e) >> 46))
 
-// an index record as the merge wants it: key = target | strand of the HIT << 28 (the rest of the word is free), off = the hit's offset on the forward
-// strand, or - opposite strand - the k-mer's start in the target, from which the emission takes tlen - 1 - start (anchor.cpp:1021-1023, 1059-1064)
+// an index record as the merge wants it: key = target << 1 | strand of the HIT (29 bits; the order of the keys is the order of the output's bins), off = the hit's offset on the forward
+// strand, or - opposite strand - the k-mer's start in the target, from which the emission takes tlen - 1 - start (anchor.cpp:1021-1023, 1059-1064).  The
+// target's length: every record also leaves its target id in bin_tid[its histogram bin] (some target of the bin survives), the preparation phase reads len[] for the
+// non-empty bins (one gather of at most 256 lanes per read) and the merge takes a step's tlen from LDS when the bin's survivor is the step's target (9 in 10 steps:
+// ~60 targets in 256 bins), else by a scalar load.  (A scalar load per step cost its cache miss in front of the step's first LDS wait: 1.8 us per wave and read;
+// a gather per opposite-strand record while staging - 64 different lines per instruction - cost 4 us per read.)
 __device__ __forceinline__ void hao_l5_fold(uint64_t y, uint32_t z, uint32_t &a, uint32_t &b)
 {
 	const uint32_t rv = z ^ hao_info_rev(y);
-	a = hao_info_rid(y) | rv << 28;
+	a = hao_info_rid(y) << 1 | rv;
 	b = rv ? hao_info_pos(y) + 1 - hao_info_span(y) : hao_info_pos(y);
 }
 
 // ---- the merge of one read out of LDS, one wave = one target range [t_lo, t_hi) ----
 template<int RPL, bool B16>
 __device__ __forceinline__ uint32_t hao_l5_merge(const hao_l5_ptr<B16> &L, const uint32_t nk, const uint32_t t_lo, const uint32_t t_hi, const int wv, const int lane,
-		hao_hit_t *__restrict__ hits, uint16_t *__restrict__ hq, const uint32_t *__restrict__ len, uint32_t &ngr_out)
+		hao_hit_t *__restrict__ hits, uint16_t *__restrict__ hq, const uint32_t *__restrict__ len, const uint32_t hshift, const uint32_t dflags, unsigned long long *dbgw, uint32_t &ngr_out)
 {
 	uint32_t hd[RPL], cur[RPL];
 	// where the wave's range starts in every row: lower bound of t_lo in the row's records (wave 0: the row's first record).  During the search cur[] is the
@@ -119,92 +123,117 @@ __device__ __forceinline__ uint32_t hao_l5_merge(const hao_l5_ptr<B16> &L, const
 		else cur[i] = hd[i] = 0;                                                               // (rows beyond nk stand on the guard slot 0: a sentinel)
 		before -= cur[i];
 	}
-	if (t_lo)
+	if (t_lo)      // three pivots per step (the interval shrinks to a quarter: half the dependent LDS round trips of a binary search - the search was 2.5 us of a wave's 10.5 per read)
 		for (;;) {
 			bool more = false;
 #pragma unroll
 			for (int i = 0; i < RPL; ++i)
 				if (cur[i] < hd[i]) {
-					const uint32_t md = (cur[i] + hd[i]) >> 1;
-					if ((L.recA[md] & HAO_L5_MASK) < t_lo) cur[i] = md + 1; else hd[i] = md;
+					const uint32_t n_ = hd[i] - cur[i], p2 = cur[i] + (n_ >> 1), p1 = cur[i] + (n_ >> 2), p3 = p2 + ((hd[i] - p2) >> 1);
+					const bool l1 = (L.recA[p1] >> 1) < t_lo, l2 = (L.recA[p2] >> 1) < t_lo, l3 = (L.recA[p3] >> 1) < t_lo;
+					hd[i] = l3 ? hd[i] : l2 ? p3 : l1 ? p2 : p1;
+					cur[i] = l3 ? p3 + 1 : l2 ? p2 + 1 : l1 ? p1 + 1 : cur[i];
 					more = true;
 				}
 			if (!__any(more)) break;
 		}
+	// a row's head in registers: key word hd, offset word hb (read when the row advances: an emission then needs no LDS round trip - the first version read the
+	// offset and the row's query words inside every block of every step and waited for them there, ~130 cycles per block); QREG (up to 8 rows per lane, i.e. every
+	// read with at most 512 rows): the row's two query words in registers too
+	constexpr bool QREG = RPL <= 8, HBREG = RPL <= 16;      // (24 rows per lane: the offset word is read at the emission - no registers left for it)
+	uint32_t hb[HBREG ? RPL : 1], qx[QREG ? RPL : 1], qy[QREG ? RPL : 1];
 #pragma unroll
-	for (int i = 0; i < RPL; ++i) { before += cur[i]; hd[i] = L.recA[cur[i]]; }
+	for (int i = 0; i < RPL; ++i) {
+		before += cur[i]; hd[i] = L.recA[cur[i]]; if constexpr (HBREG) hb[i] = (uint32_t)L.recB[cur[i]];
+		if constexpr (QREG) { const uint2 q_ = L.qw[min((uint32_t)(i * 64 + lane), (uint32_t)(HAO_L5_R - 1))]; qx[i] = q_.x; qy[i] = q_.y; }
+	}
 	uint32_t run = hao_wave_incl_scan_u32(before); run = (uint32_t)__builtin_amdgcn_readlane((int)run, 63);
-	const uint32_t first = run;
 	uint32_t ngr = 0;
+	unsigned long long d_t0 = 0; uint32_t d_blocks = 0;      // (DBG instances: dbgw != nullptr)
+	if (dbgw) d_t0 = wall_clock64();
 	uint64_t *grp = L.grp + wv * HAO_L5_GW;
-#define HAO_L5_NEXT(out) { uint32_t mn = HAO_L5_MASK; _Pragma("unroll") for (int i = 0; i < RPL; ++i) mn = min(mn, hd[i] & HAO_L5_MASK); out = hao_wave_min_u32(mn); }
-#define HAO_L5_EMIT(slot_, at_, T_, tlen_, row_) { \
-		const uint32_t a_ = L.recA[slot_], b_ = (uint32_t)L.recB[slot_], rv_ = a_ >> 28 & 1; const uint2 qw_ = L.qw[row_]; \
-		hao_hit_t h_; h_.w0 = (T_) | rv_ << 31; h_.offset = rv_ ? (tlen_) - 1 - b_ : b_; h_.self_offset = qw_.x; h_.cnt = qw_.y; \
-		hits[at_] = h_; if (hq) hq[at_] = L.qi[row_]; }
-	uint32_t T; HAO_L5_NEXT(T)
-	while (T < t_hi) {
-		const uint32_t tlen = len[T];
-		// forward hits of T over all rows (where the opposite strand starts)
-		uint32_t c0 = 0;
-#pragma unroll
-		for (int i = 0; i < RPL; ++i) c0 += (uint32_t)__popcll(__ballot((hd[i] & 0x1fffffffu) == T));
-		const uint32_t base0 = run;
-		if (lane == 0 && ngr < HAO_L5_GW) grp[ngr] = (uint64_t)T << 32 | base0;
-		++ngr;
-		uint32_t p0 = base0, p1 = base0 + c0, part = 0;
+#define HAO_L5_NEXT(out) { uint32_t mn = HAO_L5_SENT; _Pragma("unroll") for (int i = 0; i < RPL; ++i) mn = min(mn, hd[i]); out = hao_wave_min_u32(mn); }
+#define HAO_L5_PUT(at_, w0_, rv_, b_, qx_, qy_, row_) { \
+		hao_hit_t h_; h_.w0 = (w0_); h_.offset = (rv_) ? tlen - 1 - (b_) : (b_); h_.self_offset = (qx_); h_.cnt = (qy_); \
+		if (!(dflags & 1)) hits[at_] = h_; if (hq) hq[at_] = L.qi[row_]; }      /* (dflags: timing experiments of the DBG instances only - 0 everywhere else) */
+	// A step = one BIN: the smallest key K = (target, strand) under any cursor; the rows whose head is K emit it in row order and advance.  (The first version stepped
+	// by target and ranked forward and opposite-strand hits in one pass: a count pass over all blocks in front of every step and two ballots, two mbcnt pairs and four
+	// selects per block - 45 instructions per emitting block where this takes 16, and at two waves per SIMD the step loop runs at the latency of its dependent
+	// instructions, ~7 cycles each: profiles/r06/seed_phases.txt.)  A row's records of one target are in POSITION order, so behind a head (T, opposite) there can be a
+	// (T, forward) record that the forward bin's step did not see, and a row can hold a key twice: both show after the step as "the next key is not above this one,
+	// same target", and the target is redone in full by the general routine (per-row runs, forward records in list order, opposite-strand records in reverse list
+	// order: anchor.cpp:1023) from where its first bin started.
+	uint32_t K; HAO_L5_NEXT(K)
+	uint32_t T_cur = HAO_L5_SENT, base_tid = run, tlen = 0;
+	while ((K >> 1) < t_hi) {
+		const uint32_t T = K >> 1, rv = K & 1;
+		if (T != T_cur) {      // (wave-uniform) a new target: its group entry and its length - from the bin table when the bin kept this target (9 in 10), else a scalar load
+			// (HAO_SLOAD_U32: inline assembly - written as two C++ loads the compiler selected between the two ADDRESSES and issued one flat load behind an
+			// s_waitcnt vmcnt(0), i.e. every step waited for every record load and hit store in flight)
+			T_cur = T; base_tid = run;
+			tlen = L.bin_len[T >> hshift];
+			if (L.bin_tid[T >> hshift] != T) HAO_SLOAD_U32(tlen, len + T);
+			if (lane == 0 && ngr < HAO_L5_GW) grp[ngr] = (uint64_t)T << 32 | run;
+			++ngr;
+		}
+		const uint32_t w0 = T | rv << 31;
 #pragma unroll
 		for (int i = 0; i < RPL; ++i) {
-			const bool act = (hd[i] & HAO_L5_MASK) == T;
+			const bool act = hd[i] == K;
 			const unsigned long long h = __ballot(act);
 			if (h) {      // (wave-uniform)
-				const uint32_t rv = hd[i] >> 28 & 1;
-				const unsigned long long v = __ballot(act && rv), f = h & ~v;
-				const uint32_t at = rv ? p1 + hao_mbcnt(v) : p0 + hao_mbcnt(f);
-				p0 += (uint32_t)__popcll(f); p1 += (uint32_t)__popcll(v);
+				const uint32_t at = run + hao_mbcnt(h);
+				run += (uint32_t)__popcll(h);
+				if (dbgw) ++d_blocks;
 				if (act) {
 					const uint32_t row = i * 64 + lane;
-					HAO_L5_EMIT(cur[i], at, T, tlen, row)
-					++cur[i]; hd[i] = L.recA[cur[i]]; part |= 1u << i;
+					if constexpr (QREG) HAO_L5_PUT(at, w0, rv, hb[i], qx[i], qy[i], row)
+					else if constexpr (HBREG) { const uint2 q_ = L.qw[row]; HAO_L5_PUT(at, w0, rv, hb[i], q_.x, q_.y, row) }
+					else { const uint2 q_ = L.qw[row]; const uint32_t b_ = (uint32_t)L.recB[cur[i]]; HAO_L5_PUT(at, w0, rv, b_, q_.x, q_.y, row) }
+					++cur[i]; hd[i] = L.recA[cur[i]]; if constexpr (HBREG) hb[i] = (uint32_t)L.recB[cur[i]];      // (first needed by the next step's minimum / emission)
 				}
 			}
 		}
-		run = p1;
-		uint32_t Tn; HAO_L5_NEXT(Tn)
-		if (Tn == T) {
-			// ---- some row holds several records of T: the target again, in full (a row that took part stands one record behind its run's first) ----
+		uint32_t Kn; HAO_L5_NEXT(Kn)
+		if ((Kn >> 1) == T && Kn <= K) {
+			// ---- a row holds a key of T twice, or a forward record of T behind an opposite-strand one: the target again, in full ----
+			// every row's run of T: from the first record of T at or before its cursor (some rows have emitted records of T, some stand on one) to the first record behind T
 			uint32_t f_mine = 0;
 #pragma unroll
-			for (int i = 0; i < RPL; ++i)
-				if (part >> i & 1) for (uint32_t j = cur[i] - 1; (L.recA[j] & HAO_L5_MASK) == T; ++j) f_mine += !(L.recA[j] >> 28 & 1);
+			for (int i = 0; i < RPL; ++i) {
+				uint32_t j0 = cur[i];
+				if ((uint32_t)(i * 64 + lane) < nk) while ((L.recA[j0 - 1] >> 1) == T) --j0;      // (the slot before a row's first record is a sentinel: the walk stops there; rows beyond nk stand on slot 0)
+				for (uint32_t j = j0; (L.recA[j] >> 1) == T; ++j) f_mine += !(L.recA[j] & 1);
+				cur[i] = j0;
+			}
 			uint32_t f_tot = hao_wave_incl_scan_u32(f_mine); f_tot = (uint32_t)__builtin_amdgcn_readlane((int)f_tot, 63);
-			p0 = base0; p1 = base0 + f_tot;
+			uint32_t p0 = base_tid, p1 = base_tid + f_tot;
 #pragma unroll
 			for (int i = 0; i < RPL; ++i) {
-				const bool mine = part >> i & 1;
+				const bool mine = (L.recA[cur[i]] >> 1) == T;
 				if (__ballot(mine)) {
-					uint32_t nf = 0, nr = 0, j1 = 0;
-					if (mine) for (j1 = cur[i] - 1; (L.recA[j1] & HAO_L5_MASK) == T; ++j1) { if (L.recA[j1] >> 28 & 1) ++nr; else ++nf; }
+					uint32_t nf = 0, nr = 0, j1 = cur[i];
+					if (mine) for (; (L.recA[j1] >> 1) == T; ++j1) { if (L.recA[j1] & 1) ++nr; else ++nf; }
 					const uint32_t inf = hao_wave_incl_scan_u32(nf), inr = hao_wave_incl_scan_u32(nr);
 					const uint32_t tf = (uint32_t)__builtin_amdgcn_readlane((int)inf, 63), tr = (uint32_t)__builtin_amdgcn_readlane((int)inr, 63);
 					if (mine) {
-						const uint32_t row = i * 64 + lane;
+						const uint32_t row = i * 64 + lane; const uint2 q_ = L.qw[row];
 						uint32_t af = p0 + inf - nf, ar = p1 + inr;      // forward records in list order; opposite-strand records of the run in REVERSE list order (anchor.cpp:1023)
-						for (uint32_t j = cur[i] - 1; j < j1; ++j) { const uint32_t at = (L.recA[j] >> 28 & 1) ? --ar : af++; HAO_L5_EMIT(j, at, T, tlen, row) }
-						cur[i] = j1; hd[i] = L.recA[j1];
+						for (uint32_t j = cur[i]; j < j1; ++j) { const uint32_t r_ = L.recA[j] & 1, at = r_ ? --ar : af++, b_ = (uint32_t)L.recB[j]; HAO_L5_PUT(at, T | r_ << 31, r_, b_, q_.x, q_.y, row) }
+						cur[i] = j1; hd[i] = L.recA[j1]; if constexpr (HBREG) hb[i] = (uint32_t)L.recB[j1];
 					}
 					p0 += tf; p1 += tr;
 				}
 			}
 			run = p1;
-			HAO_L5_NEXT(Tn)
+			HAO_L5_NEXT(Kn)
 		}
-		T = Tn;
+		K = Kn;
 	}
 #undef HAO_L5_NEXT
-#undef HAO_L5_EMIT
+#undef HAO_L5_PUT
+	if (dbgw && lane == 0) { atomicAdd(dbgw, wall_clock64() - d_t0); atomicAdd(dbgw + 8, (unsigned long long)ngr); atomicAdd(dbgw + 16, (unsigned long long)d_blocks); atomicAdd(dbgw + 24, (unsigned long long)(run)); }
 	ngr_out = ngr;
-	(void)first;
 	return run;
 }
 
@@ -222,6 +251,7 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 	if (b0 == 0 && tid == 0) S.g_cnt[S.n_sel] = 0;
 	if (b0 >= S.n_sel) return;
 	if (tid < 2 * HAO_L5_HB) L.hist[tid] = 0;
+	const uint32_t dflags = DBG && S.dbg ? (uint32_t)S.dbg[31] : 0u;      // HAO_DBG_SEEDFLAGS: 1 = the merge without its hit stores (what do the stores cost?), 2 = without the record loads' data (lists of zeros)
 	const uint64_t nrd = (S.n_sel - b0 + G - 1) / G;      // this workgroup's reads: b0, b0 + G, ...
 	// pipeline registers
 	uint64_t av = 0;                                                        // alpha: lanes 0 - 3 of every wave hold mz_off[r], mz_off[r + 1], seg[r], seg[r + 1]
@@ -263,18 +293,18 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 			for (int i = 0; i < NPF; ++i) {
 				const uint32_t sl = i * HAO_L5_SUB + sg;
 				if (sl < re.nslots) {
-					const uint64_t e = L.slots[sl];
-					const uint32_t c = HAO_L5_SLOT_C(e), z = HAO_L5_SLOT_Z(e), o = HAO_L5_SLOT_O(e) + sj;
-					if (sj < c) { uint32_t a, b; hao_l5_fold(rec[i].a, z, a, b); L.recA[o] = a; L.recB[o] = (typename hao_l5_lds<B16>::off_t)b; atomicAdd(&hist_e[(a & HAO_L5_MASK) >> hshift], 1u); }
-					if (sj + 1 < c) { uint32_t a, b; hao_l5_fold(rec[i].b, z, a, b); L.recA[o + 1] = a; L.recB[o + 1] = (typename hao_l5_lds<B16>::off_t)b; atomicAdd(&hist_e[(a & HAO_L5_MASK) >> hshift], 1u); }
+					const uint64_t e = L.slots[sl]; const uint32_t c = HAO_L5_SLOT_C(e), z = HAO_L5_SLOT_Z(e), o = HAO_L5_SLOT_O(e) + sj;
+					if (sj < c) { uint32_t a, b; hao_l5_fold(rec[i].a, z, a, b); const uint32_t t = a >> 1; L.recA[o] = a; L.recB[o] = (typename hao_l5_lds<B16>::off_t)b; atomicAdd(&hist_e[t >> hshift], 1u); L.bin_tid[t >> hshift] = t; }
+					if (sj + 1 < c) { uint32_t a, b; hao_l5_fold(rec[i].b, z, a, b); const uint32_t t = a >> 1; L.recA[o + 1] = a; L.recB[o + 1] = (typename hao_l5_lds<B16>::off_t)b; atomicAdd(&hist_e[t >> hshift], 1u); L.bin_tid[t >> hshift] = t; }
 				}
 				if ((i & 1) == 1) HAO_L5_SCHED_FENCE();
 			}
 			for (uint32_t sl = NPF * HAO_L5_SUB + sg; sl < re.nslots; sl += HAO_L5_SUB) {      // the slots beyond the registers: loaded now
 				const uint64_t e = L.slots[sl];
 				const uint32_t c = HAO_L5_SLOT_C(e), z = HAO_L5_SLOT_Z(e), o = HAO_L5_SLOT_O(e) + sj;
-				if (sj < c) { uint32_t a, b; hao_l5_fold(sinfo[HAO_L5_SLOT_G(e) + sj], z, a, b); L.recA[o] = a; L.recB[o] = (typename hao_l5_lds<B16>::off_t)b; atomicAdd(&hist_e[(a & HAO_L5_MASK) >> hshift], 1u); }
-				if (sj + 1 < c) { uint32_t a, b; hao_l5_fold(sinfo[HAO_L5_SLOT_G(e) + sj + 1], z, a, b); L.recA[o + 1] = a; L.recB[o + 1] = (typename hao_l5_lds<B16>::off_t)b; atomicAdd(&hist_e[(a & HAO_L5_MASK) >> hshift], 1u); }
+#pragma unroll
+				for (uint32_t x = 0; x < 2; ++x)
+					if (sj + x < c) { uint32_t a, b; hao_l5_fold(sinfo[HAO_L5_SLOT_G(e) + sj + x], z, a, b); const uint32_t t = a >> 1; L.recA[o + x] = a; L.recB[o + x] = (typename hao_l5_lds<B16>::off_t)b; atomicAdd(&hist_e[t >> hshift], 1u); L.bin_tid[t >> hshift] = t; }
 			}
 		}
 		HAO_L5_TICK(0)
@@ -285,6 +315,11 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 			uint64_t v[QPT], inc[QPT];
 			const bool go = rd.valid && !rd.skip;
 			if (tid < HAO_L5_HB) L.hist[(step & 1) * HAO_L5_HB + tid] = 0;      // next step's histogram (last read by the step before this one)
+			// the length of the target this step's records left in bin tid, written to LDS at the end of the preparation (the load has the scans to land).  EVERY thread
+			// loads and stores (threads 256 .. 511 a word nobody reads): under a condition, the compiler's s_waitcnt pass keeps the load's register "pending" on the path
+			// around the store and puts an s_waitcnt vmcnt(0) in front of the next write to that register - which was in the merge, with every record load in flight
+			const bool blw_ = tid < HAO_L5_HB && re.valid && !re.skip && hist_e[tid] != 0;
+			const uint32_t bl_ = len[blw_ ? L.bin_tid[tid] : 0u];
 #pragma unroll
 			for (int m = 0; m < QPT; ++m) {
 				const uint32_t q = m * HAO_L5_THREADS + tid, c = go && q < rd.nq ? (uint32_t)(raw_s[m] >> 48) & 0xfffu : 0u;
@@ -313,6 +348,7 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 						L.slots[sl] = (st + x) | (uint64_t)(min(c - x, (uint32_t)HAO_L5_CH) - 1) << 40 | (uint64_t)z << 45 | (uint64_t)(o0 + x) << 46;
 				}
 			}
+			L.bin_len[tid] = bl_;
 		}
 		HAO_L5_TICK(2)
 		__syncthreads();
@@ -326,7 +362,8 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 				rec[i].a = rec[i].b = 0;      // (every register is written in every step: a conditional assignment alone would keep last step's value alive across the whole loop body)
 				if (sl < nsl) {
 					const uint64_t e = L.slots[sl]; const uint32_t c = HAO_L5_SLOT_C(e);
-					if (sj + 1 < c) rec[i] = *(const hao_rec2*)(sinfo + HAO_L5_SLOT_G(e) + sj);      // (16 bytes at an 8-byte boundary)
+					if (DBG && (dflags & 2)) { }
+					else if (sj + 1 < c) rec[i] = *(const hao_rec2*)(sinfo + HAO_L5_SLOT_G(e) + sj);      // (16 bytes at an 8-byte boundary)
 					else if (sj < c) rec[i].a = sinfo[HAO_L5_SLOT_G(e) + sj];                        // the odd record at the end of a list: nothing is read past it
 				}
 				if ((i & 1) == 1) HAO_L5_SCHED_FENCE();
@@ -356,7 +393,10 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 				{
 					const uint4 hv = *(const uint4*)(hist_e + 4 * lane);
 					const uint32_t s4 = hv.x + hv.y + hv.z + hv.w, ex0 = hao_wave_incl_scan_u32(s4) - s4, ex1 = ex0 + hv.x, ex2 = ex1 + hv.y, ex3 = ex2 + hv.z;
-					const uint32_t th_lo = (uint32_t)(((uint64_t)re.n * (uint32_t)wv) >> 3), th_hi = (uint32_t)(((uint64_t)re.n * (uint32_t)(wv + 1)) >> 3);
+					// shares in 1/1024 of the read's hits: wave 0 needs no search for its start (about 4 % of a read's time), and the second wave of every SIMD (waves 4 - 7)
+					// loses the issue arbitration to the first (measured: 11.4 against 10.5 us per read for equal shares, profiles/r06/seed_phases.txt)
+					auto cumw = [](uint32_t w) -> uint32_t { return w == 0 ? 0u : w >= HAO_L5_W ? 1024u : w <= 4 ? 160u + (w - 1) * 126u : 538u + (w - 4) * 122u; };
+					const uint32_t th_lo = (uint32_t)(((uint64_t)re.n * cumw((uint32_t)wv)) >> 10), th_hi = (uint32_t)(((uint64_t)re.n * cumw((uint32_t)wv + 1)) >> 10);
 					const uint32_t b_lo = (uint32_t)(__popcll(__ballot(ex0 < th_lo)) + __popcll(__ballot(ex1 < th_lo)) + __popcll(__ballot(ex2 < th_lo)) + __popcll(__ballot(ex3 < th_lo)));
 					const uint32_t b_hi = (uint32_t)(__popcll(__ballot(ex0 < th_hi)) + __popcll(__ballot(ex1 < th_hi)) + __popcll(__ballot(ex2 < th_hi)) + __popcll(__ballot(ex3 < th_hi)));
 					t_lo = b_lo << hshift;      // (wave 0: th_lo = 0, no bin below it: t_lo = 0)
@@ -364,10 +404,11 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 				}
 				hao_hit_t *hits = S.hits + re.s; uint16_t *hq = S.hq ? S.hq + re.s : nullptr;
 				HAO_L5_TICK(5)
+				unsigned long long *dbgw = DBG && S.dbg ? S.dbg + 32 + wv : nullptr;      // [32 + w] ticks in wave w's step loop, [40 + w] its steps, [48 + w] its emitting blocks
 				if (t_lo < t_hi) {
-					if (re.nk <= 8 * 64) (void)hao_l5_merge<8, B16>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, ngr);
-					else if (QPT == 2 || re.nk <= 16 * 64) (void)hao_l5_merge<16, B16>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, ngr);
-					else if constexpr (QPT > 2) (void)hao_l5_merge<24, B16>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, ngr);
+					if (re.nk <= 8 * 64) (void)hao_l5_merge<8, B16>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, hshift, dflags, dbgw, ngr);
+					else if (QPT == 2 || re.nk <= 16 * 64) (void)hao_l5_merge<16, B16>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, hshift, dflags, dbgw, ngr);
+					else if constexpr (QPT > 2) (void)hao_l5_merge<24, B16>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, hshift, dflags, dbgw, ngr);
 				}
 				if (lane == 0) L.sm[wv] = ngr;
 				HAO_L5_TICK(6)
@@ -392,6 +433,9 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 		__syncthreads();
 		HAO_L5_TICK(8)
 	}
-	if constexpr (DBG) if (tid == 0 && S.dbg) { for (int k = 0; k < 9; ++k) atomicAdd(S.dbg + k, tk_acc[k]); atomicAdd(S.dbg + 9, (unsigned long long)nrd); }
+	if constexpr (DBG) if (S.dbg) {
+		if (tid == 0) { for (int k = 0; k < 9; ++k) atomicAdd(S.dbg + k, tk_acc[k]); atomicAdd(S.dbg + 9, (unsigned long long)nrd); }
+		if (lane == 0) atomicAdd(S.dbg + 16 + wv, tk_acc[6]);      // every wave's own time in the merge (search + steps)
+	}
 #undef HAO_L5_TICK
 }
