@@ -43,11 +43,10 @@ VARIANT_OF = {"chr1_250M_hifi30x": "chr1_250M_hifi30x_repeat", "bacterial5M_hifi
 ALG = {
     "sketch_unit_kernel": ("base", 0.25 + 16.0 / 35.0),             # 2-bit bases in + one 16-B minimizer per ~35 bases out
     "chain_group_kernel": ("anchor", 16 + 4),                        # k_mer_hit in + fake-cigar / record out (hits stay in place)
-    "seed_merge_kernel": ("anchor", 8 + 16),                         # index record in (once), k_mer_hit out (the read's position lists merged by target, hao_query4.cuh)
-    "seed_bin_kernel": ("anchor", 8 + 16),                           # (HAO_SEED_MERGE=0: the table kernels of rounds 1 - 4) index record in, k_mer_hit out
+    "seed_lds_kernel": ("anchor", 8 + 16),                           # index record in (once, coalesced), k_mer_hit out (the read's position lists staged in LDS and merged by target there, hao_query5.cuh)
+    "seed_merge_kernel": ("anchor", 8 + 16),                         # (HAO_SEED_LDS=0: round 5) the one-wave merge with lane-private list reads, hao_query4.cuh
+    "seed_bin_kernel": ("anchor", 8 + 16),                           # (repeat-rich batches; HAO_SEED_LDS=0 HAO_SEED_MERGE=0: the table kernels of rounds 1 - 4) index record in, k_mer_hit out
 }
-SEED_KERNEL = "seed_bin_kernel" if os.environ.get("HAO_SEED_MERGE") == "0" else "seed_merge_kernel"
-KERN_STAGE = {"sketch_unit_kernel": "sk_chunks", "chain_group_kernel": "q_chain", SEED_KERNEL: "q_sort_bins"}
 METRIC_WORKLOAD = "human3G_hifi40x"      # BASELINE.json configs[3]: the configuration the metric is quoted on (8 GPUs)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2      # G wave-level VALU instructions / s: 256 CUs x 4 SIMD-32 x 2.4 GHz, a wave64 instruction issues over 2 cycles (MI355X_MICROARCH.md)
@@ -115,9 +114,9 @@ def cpu_baseline(workload, mode="sample", threads=None):
 
 
 def profile_file(name):
-    """newest committed profile of that name (PMC counters need their own rocprofv3 passes - tools/r05_final.sh pmc - so they cannot be
+    """newest committed profile of that name (PMC counters need their own rocprofv3 passes - tools/r06_final.sh pmc - so they cannot be
     collected inside this run; the line says where the figure comes from)"""
-    for r in ("r05", "r04", "r03", "r02"):
+    for r in ("r06", "r05", "r04", "r03", "r02"):
         p = os.path.join(ROOT, "profiles", r, name)
         if os.path.exists(p):
             return p, f"profiles/{r}/{name}"
@@ -312,8 +311,12 @@ def run_workload(a, workload, steps, warmup, rank, local_rank, world, dist, torc
     if rank == 0:
         stage_ms = {k: v / steps for k, v in stage_sum.items()}
         # roofline of the dominant kernel: live HIP-event time of its stage on the engine's stream
-        # which kernels carried the seed stage: the engine gives a batch whose reads average more than HAO_SEED_MERGE_AVG (14 000) seed hits to the table kernels (hao_batch.hpp)
-        seed_kernel = SEED_KERNEL if tot["seed_hits"] <= int(os.environ.get("HAO_SEED_MERGE_AVG", "14000")) * n_reads else "seed_bin_kernel"
+        # which kernels carried the seed stage: the engine says (hao_batch_seed_path: the choice is made per batch in hao_batch.hpp - repeat-rich batches keep the table kernels)
+        try:
+            seed_path = eng.batch_seed_path()
+        except Exception:      # (the owner context ran no batch of its own: --contexts > 1)
+            seed_path = {"first_launch": "seed_bin_kernel" if os.environ.get("HAO_SEED_LDS") == "0" and os.environ.get("HAO_SEED_MERGE") == "0" else "seed_lds_kernel", "left_to_tables": None}
+        seed_kernel = seed_path["first_launch"]
         KERN_STAGE = {"sketch_unit_kernel": "sk_chunks", "chain_group_kernel": "q_chain", seed_kernel: "q_sort_bins"}
         dom = max(KERN_STAGE, key=lambda k: stage_ms.get(KERN_STAGE[k], 0.0))
         unit, bpu = ALG[dom]
@@ -335,9 +338,16 @@ def run_workload(a, workload, steps, warmup, rank, local_rank, world, dist, torc
             return {"kernel": kn, "kernel_ms": round(ms_, 4), "launches_per_step": nb_, "alg_bytes_per_launch": int(b_ * un_ / nb_), "achieved": round(ach_, 2), "frac": round(ach_ / HBM_PEAK_GBS, 5)}
         roofline["kernels"] = [kernel_line(kn) for kn in KERN_STAGE]
         # what the device gives this byte mix (8 in + 16 out per seed hit) with no computation attached: profiles/r05/ubench_gather.txt (tools/ubench_gather.hip)
-        roofline["seed_stage_ceilings"] = {"streaming_copy_frac": 0.545, "one_coalesced_walk_of_the_lists_frac": 0.533, "lane_private_walk_frac": 0.241, "source": "profiles/r05/ubench_gather.txt"}
+        roofline["seed_stage"] = {"first_launch": seed_kernel, "reads_left_to_the_table_kernels_in_the_last_batch": seed_path["left_to_tables"]}
+        # what the device gives this byte mix (8 in + 16 out per seed hit) with no computation attached: constants measured by tools/ubench_gather.hip, NOT in this run
+        ub, ub_rel = profile_file("ubench_gather.json")
+        if ub:
+            try:
+                roofline["seed_stage_ceilings"] = dict(json.load(open(ub)), source=ub_rel + " (tools/ubench_gather.hip, its own run)")
+            except Exception:
+                pass
         prof, prof_rel = profile_file("pmc_traffic.json")
-        if prof and world == 1:      # PMC counters need their own rocprofv3 passes (tools/r05_final.sh pmc): not measurable inside this run
+        if prof and world == 1:      # PMC counters need their own rocprofv3 passes (tools/r06_final.sh pmc): not measurable inside this run
             try:
                 pj = json.load(open(prof))
                 if pj.get("workload") == workload:

@@ -55,7 +55,7 @@ DELIVER_OL, DELIVER_CL, DELIVER_EXACT = 1, 2, 4
 ABI_SYMBOLS = [
     "hao_opt_default", "hao_create", "hao_destroy", "hao_last_error", "hao_set_reads", "hao_ft_gen", "hao_pt_gen",
     "hao_ft_cnt", "hao_pt_get", "hao_ft_table", "hao_pt_table", "hao_hist", "hao_stats", "hao_sketch_batch",
-    "hao_fetch_sketch", "hao_overlap_batch", "hao_fetch_seed_hits", "hao_fetch_overlaps", "hao_batch_totals",
+    "hao_fetch_sketch", "hao_overlap_batch", "hao_fetch_seed_hits", "hao_fetch_overlaps", "hao_batch_totals", "hao_batch_seed_path",
     "hao_stage_times", "hao_pass_default", "hao_overlap_batch_ex", "hao_set_shard", "hao_dist_unique_id", "hao_dist_init",
     "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_selftest_big", "hao_selftest_sortbits", "hao_unpack_cigar", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits", "hao_exact_check", "hao_fetch_exact", "hao_window_ed_batch", "hao_index_save", "hao_index_load", "hao_next_slot", "hao_attach", "hao_window_trace_batch", "hao_delivery_digest", "hao_ft_passes", "hao_ovlp_bin_read", "hao_ovlp_bin_write", "hao_window_ed_grid", "hao_fetch_ed_grid",
 ]
@@ -96,6 +96,7 @@ def lib():
         L.hao_fetch_seed_hits.argtypes = [vp, C.c_uint64, C.POINTER(vp), u64p]
         L.hao_fetch_overlaps.argtypes = [vp, C.c_uint64, C.POINTER(vp), u64p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), u64p]
         L.hao_batch_totals.argtypes = [vp, u64p]
+        L.hao_batch_seed_path.argtypes = [vp, u64p]
         L.hao_stage_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
         L.hao_batch_digest.argtypes = [vp, u64p, u64p]
         L.hao_overlap_batch_async.argtypes = [vp, C.c_uint64, C.c_uint64, C.POINTER(Pass), C.c_uint32, C.POINTER(C.c_int)]
@@ -397,6 +398,12 @@ class Engine:
         self._ck(self.L.hao_batch_totals(self.h, out), "hao_batch_totals")
         return dict(overlaps=int(out[0]), chained_hits=int(out[1]), seed_hits=int(out[2]), groups=int(out[3]), minimizers=int(out[4]), chains=int(out[5]),
                     seq_groups=int(out[6]), seq_group_hits=int(out[7]))
+
+    def batch_seed_path(self):
+        """which kernels carried the last batch's seed stage: (first launch: 2 list-major / 1 one-wave merge / 0 table kernels, reads left to the tables, 512- / 1024-slot overflows)"""
+        out = (C.c_uint64 * 4)()
+        self._ck(self.L.hao_batch_seed_path(self.h, out), "hao_batch_seed_path")
+        return dict(first_launch={0: "seed_bin_kernel", 1: "seed_merge_kernel", 2: "seed_lds_kernel"}[int(out[0])], left_to_tables=int(out[1]), overflow_512=int(out[2]), overflow_1024=int(out[3]))
 
     def batch_digest(self, n, with_seed_hits=True):
         """per-read digests of the last batch (n reads): (digest of ol / fake cigars / cl, digest of the seed hits or None)"""

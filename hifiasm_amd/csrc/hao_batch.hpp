@@ -10,7 +10,7 @@
 #include "hao_chain.cuh"
 
 struct hao_ctx::Batch {
-	uint64_t n_generic = 0, n_generic_hits = 0; DevBuf<unsigned long long> stats, dbgbuf;
+	uint64_t n_generic = 0, n_generic_hits = 0, seed_path = 0, seed_left[3] = {0, 0, 0}; DevBuf<unsigned long long> stats, dbgbuf;
 	uint64_t lo = 0, n = 0, mz0 = 0, n_mz = 0, n_anchor = 0, n_groups = 0, n_chains = 0, n_cl = 0, n_fc_raw = 0, n_ol = 0, n_fc = 0, n_fcw = 0;
 	bool valid = false, host_valid = false;
 	DevBuf<uint64_t> s_start, s_pk, a_off, seg, g_cnt, g_off, g_start, ch_base, cl_base, fc_base, fcs, fc_raw, ol_fc_off, cc_off, cc, fc_final, fcf_off;
@@ -321,7 +321,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	unsigned long long *d_slow_cnt = B.stats.p, *d_cls_cnt = B.stats.p + HAO_NCLS + 4;   // [0..NCLS] slow groups per class + their hits
 	{
 		// Q2-Q5 in one kernel: index records -> bins -> sorted k_mer_hits + group lists (no anchor keys in memory)
-		hao_seed_args sa_;
+		hao_seed_args sa_; B.seed_path = 0;
 		sa_.mz_off = c->d_ix_mz_off.p; sa_.mz_info = c->d_ix_mz_info.p; sa_.rid_lo = lo; sa_.mz0 = B.mz0; sa_.s_start = B.s_start.p; sa_.s_n = B.s_n.p; sa_.a_off = B.a_off.p; sa_.seg = B.seg.p;
 		sa_.sinfo = c->d_ix_sinfo.p; sa_.len = c->d_len_all.p; sa_.q_pos = B.q_pos.p; sa_.q_cnt = B.q_cnt.p; sa_.hits = B.hits.p; sa_.g_tmp = B.g_tmp.p; sa_.g_cnt = B.g_cnt.p; sa_.n_sel = n; sa_.tb = tb;
 		sa_.qcap = (uint32_t)std::min<uint64_t>((max_q + 63) & ~63ULL, HAO_QTAB_CAP);
@@ -332,8 +332,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			if (c->sw.seq_chain || c->sw.tiny_lane || c->sw.pack_search || c->sw.dp_seqtail || c->sw.dp_nospec) { const uint64_t n16 = (A + 31) / 16; hipLaunchKernelGGL(hao_fill16_kernel, dim3((unsigned)std::min<uint64_t>((n16 + 255) / 256, 1u << 14)), dim3(256), 0, c->stream, (hao_fill_v4*)B.hcode.p, n16, 0x08080808u); HAO_CHECK_LAUNCH(); }
 			if (!c->sw.pack_search) { HIP_TRY(B.hq.reserve(A + 64)); sa_.hq = B.hq.p; }
 		}
-		if (c->sw.seedphase) { HIP_TRY(B.dbgbuf.reserve(64)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 512, c->stream)); sa_.dbg = B.dbgbuf.p;
-			if (const char *e_ = getenv("HAO_DBG_SEEDFLAGS")) { const unsigned long long f_ = strtoull(e_, nullptr, 0); HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipMemcpy(B.dbgbuf.p + 31, &f_, 8, hipMemcpyHostToDevice)); } }      // (timing experiments of the list-major seed kernel's DBG instance: results are wrong on purpose)
+		if (c->sw.seedphase) { HIP_TRY(B.dbgbuf.reserve(64)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 512, c->stream)); sa_.dbg = B.dbgbuf.p; }
 		HIP_TRY(B.ovf_list.reserve(3 * (n + 1)));
 		unsigned long long *d_ovf = B.stats.p + 3 * HAO_NCLS + 3, *d_ovf2 = B.stats.p + 3 * HAO_NCLS + 4, *d_ovf0 = B.stats.p + 3 * HAO_NCLS + 5;
 		uint32_t *ovf1 = B.ovf_list.p, *ovf2 = B.ovf_list.p + (n + 1), *ovf0 = B.ovf_list.p + 2 * (n + 1);
@@ -364,6 +363,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		}
 		else if (tile_ != 512) { if (int rc = launch(seed_bin_kernel<9, 0, 1024, false>, seed_bin_kernel<10, 1, 1024, false>, seed_bin_kernel<11, 2, 1024, false>)) return rc; }
 		else if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql && c->sw.seed_lds && A <= (uint64_t)c->sw.seed_merge_avg * n && c->n_total < HAO_MRG_END && c->ix_n_pos + c->sw.ix_pad < (1ULL << 40)) {
+			B.seed_path = 2;
 			// the list-major kernel (hao_query5.cuh): one persistent workgroup per CU, a read's position lists read once with adjacent lanes on adjacent records into LDS,
 			// merged by target there.  The reads it leaves (more than 1536 minimizers, more records than the LDS holds, more than seed_merge_maxn hits) go through the
 			// table kernels below it (512-slot launch over the overflow list, then the launches without staged tiles).  Batches whose reads average more than
@@ -379,11 +379,11 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 				const bool b16_ = c->max_len_all < 65536, wide_ = max_q > 2 * HAO_L5_THREADS;      // offsets of the staged records in 16 bits; reads with more than 1024 minimizers: three per thread
 				auto go_ = [&](auto k0, size_t lds_) -> int {
 					HIP_TRY(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
-					hipLaunchKernelGGL(k0, dim3(g_), dim3(HAO_L5_THREADS), lds_, c->stream, sa_, sinfo_, len_, spk_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
+					hipLaunchKernelGGL(k0, dim3(g_), dim3(HAO_L5_THREADS), lds_, c->stream, sa_, sinfo_, len_, spk_, (uint32_t)c->sw.seed_merge_maxn, (uint32_t)c->sw.seed_lds_w0, ovf0, d_ovf0);
 					return HAO_OK;
 				};
 				int rc_;
-				if (c->sw.seedphase && b16_ && !wide_) rc_ = go_(seed_lds_kernel<true, 2, 12, true>, hao_l5_lds<true>::TOTAL);
+				if (c->sw.seedphase && b16_ && !wide_) rc_ = go_(seed_lds_kernel<true, 2, 14, true>, hao_l5_lds<true>::TOTAL);
 				else if (b16_) rc_ = wide_ ? go_(seed_lds_kernel<true, 3, 8, false>, hao_l5_lds<true>::TOTAL) : go_(seed_lds_kernel<true, 2, 16, false>, hao_l5_lds<true>::TOTAL);
 				else rc_ = wide_ ? go_(seed_lds_kernel<false, 3, 8, false>, hao_l5_lds<false>::TOTAL) : go_(seed_lds_kernel<false, 2, 16, false>, hao_l5_lds<false>::TOTAL);
 				if (rc_) return rc_;
@@ -397,6 +397,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			HAO_CHECK_LAUNCH();
 		}
 		else if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql && c->sw.seed_merge && A <= (uint64_t)c->sw.seed_merge_avg * n && sum_q <= (uint64_t)c->sw.seed_merge_qavg * n && c->n_total < HAO_MRG_END) {      // (read id 2^28 - 1 is the merge's end mark: a read set that uses it - exactly 2^28 reads - takes the tables)
+			B.seed_path = 1;
 			// (the batch's reads average at most seed_merge_avg seed hits: above that the reads cross repeat families - hundreds of targets, a merge step each - and the
 			// table kernels below are the faster ones: 231 against 248 ms per pass of the repeat-rich 250 Mb set, 58.9 against 54.7 ms on the repeat-free one, profiles/r05;
 			// and at most seed_merge_qavg (520) minimizers: nearly all of them have a list at 30x, and a wave holds 512 rows - a batch of 30 kb reads (1 150 minimizers) would hand every read on)
@@ -453,7 +454,6 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		else if (int rc = launch(seed_bin_kernel<9, 0, 512, false>, seed_bin_kernel<10, 1, 512, false>, seed_bin_kernel<11, 2, 512, false>)) return rc;
 	}
 	if (c->sw.seedphase) { unsigned long long d_[64]; HIP_TRY(hipMemcpy(d_, B.dbgbuf.p, 512, hipMemcpyDeviceToHost));
-		if (d_[9]) { fprintf(stderr, "[seed lds] step loop us / steps / emitting blocks per read, waves 0 - 7:"); for (int w_ = 0; w_ < 8; ++w_) fprintf(stderr, " %.2f/%.1f/%.1f", d_[32 + w_] / 100.0 / d_[9], (double)d_[40 + w_] / d_[9], (double)d_[48 + w_] / d_[9]); fprintf(stderr, "\n"); }
 		if (d_[9]) { fprintf(stderr, "[seed lds] merge us per read, waves 0 - 7:"); for (int w_ = 0; w_ < 8; ++w_) fprintf(stderr, " %.2f", d_[16 + w_] / 100.0 / d_[9]); fprintf(stderr, "\n"); }
 		if (d_[9]) fprintf(stderr, "[seed lds] reads %llu  avg us per read (wave 0): stage %.2f  barrier %.2f  prepare %.2f  barrier %.2f  issue loads %.2f  splitters %.2f  merge %.2f  barrier + groups %.2f  barrier %.2f\n", d_[9],
 			d_[0] / 100.0 / d_[9], d_[1] / 100.0 / d_[9], d_[2] / 100.0 / d_[9], d_[3] / 100.0 / d_[9], d_[4] / 100.0 / d_[9], d_[5] / 100.0 / d_[9], d_[6] / 100.0 / d_[9], d_[7] / 100.0 / d_[9], d_[8] / 100.0 / d_[9]);
@@ -651,7 +651,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	{	// the totals of the batch: one wave gathers them into mapped host memory
 		auto peek = [&](const void *src, int nw, int at) { hipLaunchKernelGGL(hao_peek_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)src, nw, c->peek_d + at); };
 		peek(B.ch_base.p + G, 1, 0); peek(B.cl_base.p + G, 1, 1); peek(B.fc_base.p + G * HAO_MCOPY_MAX, 1, 2); peek(B.O().fin_off.p + n, 1, 3); peek(B.fcf_off.p + n, 1, 4);
-		peek(d_slow_cnt, HAO_NCLS + 4, 8); peek(d_exc_cnt, 1, 5); peek(d_n_codes, 1, 6); peek(d_n_fcw, 1, 7);
+		peek(d_slow_cnt, HAO_NCLS + 4, 8); peek(d_exc_cnt, 1, 5); peek(d_n_codes, 1, 6); peek(d_n_fcw, 1, 7); peek(B.stats.p + 3 * HAO_NCLS + 3, 3, 24);
 		HAO_CHECK_LAUNCH();
 		const double ts2_ = hao_now();
 		HIP_TRY(hipStreamSynchronize(c->stream));
@@ -659,6 +659,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		if (c->sw.dltime && (B.t_nrun & 15) == 0) fprintf(stderr, "[batch] %llu runs (parts %u): total %.1f ms  before sync1 %.1f  sync1 %.1f  sync2 %.1f  sync3 %.1f\n", (unsigned long long)B.t_nrun, parts, B.t_run * 1e3, B.t_pre * 1e3, B.t_s1 * 1e3, B.t_s2 * 1e3, B.t_s3 * 1e3);
 		B.n_chains = c->peek_h[0]; B.n_cl = c->peek_h[1]; B.n_fc_raw = c->peek_h[2]; B.n_ol = c->peek_h[3]; B.n_fc = c->peek_h[4];
 		for (int x = 0; x < HAO_NCLS + 4; ++x) slow_st[x] = c->peek_h[8 + x];
+		B.seed_left[0] = c->peek_h[26]; B.seed_left[1] = c->peek_h[24]; B.seed_left[2] = c->peek_h[25];      // reads left by the first seed launch / by the 512-slot / by the 1024-slot table
 		if (parts & HAO_DELIVER_CL) { n_exc = c->peek_h[5]; B.n_codes = G ? c->peek_h[6] : 0; }
 		if ((parts & HAO_DELIVER_OL) && (c->peek_h[7] >> 63)) { hao_set_err(c, "an overlap without fake-cigar entries: the packed cigar layout holds at least one per overlap"); return HAO_EUNSUPP; }
 		B.n_fcw = (parts & HAO_DELIVER_OL) ? (B.n_fc - B.n_ol) + c->peek_h[7] : 0;      // main region + the raw overlaps' words

@@ -345,6 +345,14 @@ int hao_batch_totals(hao_ctx *c, uint64_t out[8])
 	return HAO_OK;
 }
 
+int hao_batch_seed_path(hao_ctx *c, uint64_t out[4])
+{
+	if (!c || !out || !c->batch || !c->batch->valid) return HAO_EINVAL;
+	hao_ctx::Batch &B = *c->batch;
+	out[0] = B.seed_path; out[1] = B.seed_left[0]; out[2] = B.seed_left[1]; out[3] = B.seed_left[2];
+	return HAO_OK;
+}
+
 int hao_batch_digest(hao_ctx *c, uint64_t *out, uint64_t *out_kh)
 {
 	if (!c || !out || !c->batch || !c->batch->valid) return HAO_EINVAL;

@@ -59,7 +59,7 @@ struct hao_switches {
 	bool seedphase = false, qcphase = false, dp_stats = false, seq_chain = false, dp_seqtail = false, dp_nospec = false, dp_serial = false,
 		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, sk_v2 = false, dltime = false, sk_nofuse = false, pack_search = false, sk_select2 = false, seed_v2 = false, seed_pf = true, seed_noql = false, sort64 = false, seed_nodirect = false, tiny_lane = false, pt_direct = false;
 	static constexpr bool SK_SELECT2_DEFAULT = true;       // the thinning kernel the sketch runs when the environment says nothing: the wave kernel (round 4: green on the device against every repeat-rich scenario and the 5 Mb / 250 Mb repeat-rich fixtures)
-	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; unsigned long long ix_pad = 0, sort40_min = 1ULL << 23; int seed_nu = 4, fc_raw_every = 0, exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, seed_lds_pad = 0, arena_numa = 3, seed_tile = 512, seed_merge = 8, seed_mbuf = 4, seed_locus = 0, seed_mergew = 0, seed_merge_maxn = 24000, seed_merge_avg = 14000, seed_merge_qavg = 520, seed_malign = 0, ft_passes = 0, seed_lds = 1, seed_lds_wg = 1; long long ft_chunk_slots = 0;
+	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; unsigned long long ix_pad = 0, sort40_min = 1ULL << 23; int seed_nu = 4, fc_raw_every = 0, exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, seed_lds_pad = 0, arena_numa = 3, seed_tile = 512, seed_merge = 8, seed_mbuf = 4, seed_locus = 0, seed_mergew = 0, seed_merge_maxn = 24000, seed_merge_avg = 14000, seed_merge_qavg = 520, seed_malign = 0, ft_passes = 0, seed_lds = 1, seed_lds_wg = 1, seed_lds_w0 = 176; long long ft_chunk_slots = 0;
 	void load() {
 		auto on = [](const char *n) { return getenv(n) != nullptr; };
 		seedphase = on("HAO_DBG_SEEDPHASE"); qcphase = on("HAO_DBG_QCPHASE"); dp_stats = on("HAO_DBG_DP_STATS"); seq_chain = on("HAO_DBG_SEQ_CHAIN");
@@ -68,6 +68,7 @@ struct hao_switches {
 		dltime = on("HAO_DBG_DLTIME");
 		if (const char *e = getenv("HAO_SEED_MERGE")) { const int v = atoi(e); seed_merge = v == 0 ? 0 : v == 4 ? 4 : 8; }      // the seed stage by merge (hao_query4.cuh; rows per lane), 0 = A/B: the table kernels for every read (rounds 1 - 4)
 		if (const char *e = getenv("HAO_SEED_LDS")) seed_lds = atoi(e) ? 1 : 0;      // 0 = A/B: the round-5 seed stage (one-wave merge kernel / table kernels) instead of the list-major LDS kernel (hao_query5.cuh)
+		if (const char *e = getenv("HAO_SEED_LDS_W0")) seed_lds_w0 = std::max(64, std::min(512, atoi(e)));      // wave 0's share of a read's hits in 1/1024 (it needs no search for its start)
 		if (const char *e = getenv("HAO_SEED_LDS_WG")) seed_lds_wg = std::max(1, atoi(e));      // persistent workgroups of the list-major kernel per CU (more than one only queue: a workgroup takes the CU's whole LDS)
 		if (const char *e = getenv("HAO_SEED_MERGE_QAVG")) seed_merge_qavg = std::max(0, atoi(e));      // batches whose reads average more minimizers than this take the table kernels (a wave of the merge kernel holds 512 minimizers with a list)
 		if (const char *e = getenv("HAO_SEED_MALIGN")) seed_malign = atoi(e) ? 1 : 0;      // the one-wave merge kernel's 32-byte list reads on 32-byte boundaries

@@ -110,7 +110,7 @@ __device__ __forceinline__ void hao_l5_fold(uint64_t y, uint32_t z, uint32_t &a,
 // ---- the merge of one read out of LDS, one wave = one target range [t_lo, t_hi) ----
 template<int RPL, bool B16>
 __device__ __forceinline__ uint32_t hao_l5_merge(const hao_l5_ptr<B16> &L, const uint32_t nk, const uint32_t t_lo, const uint32_t t_hi, const int wv, const int lane,
-		hao_hit_t *__restrict__ hits, uint16_t *__restrict__ hq, const uint32_t *__restrict__ len, const uint32_t hshift, const uint32_t dflags, unsigned long long *dbgw, uint32_t &ngr_out)
+		hao_hit_t *__restrict__ hits, uint16_t *__restrict__ hq, const uint32_t *__restrict__ len, const uint32_t hshift, uint32_t &ngr_out)
 {
 	uint32_t hd[RPL], cur[RPL];
 	// where the wave's range starts in every row: lower bound of t_lo in the row's records (wave 0: the row's first record).  During the search cur[] is the
@@ -149,13 +149,11 @@ __device__ __forceinline__ uint32_t hao_l5_merge(const hao_l5_ptr<B16> &L, const
 	}
 	uint32_t run = hao_wave_incl_scan_u32(before); run = (uint32_t)__builtin_amdgcn_readlane((int)run, 63);
 	uint32_t ngr = 0;
-	unsigned long long d_t0 = 0; uint32_t d_blocks = 0;      // (DBG instances: dbgw != nullptr)
-	if (dbgw) d_t0 = wall_clock64();
 	uint64_t *grp = L.grp + wv * HAO_L5_GW;
 #define HAO_L5_NEXT(out) { uint32_t mn = HAO_L5_SENT; _Pragma("unroll") for (int i = 0; i < RPL; ++i) mn = min(mn, hd[i]); out = hao_wave_min_u32(mn); }
 #define HAO_L5_PUT(at_, w0_, rv_, b_, qx_, qy_, row_) { \
 		hao_hit_t h_; h_.w0 = (w0_); h_.offset = (rv_) ? tlen - 1 - (b_) : (b_); h_.self_offset = (qx_); h_.cnt = (qy_); \
-		if (!(dflags & 1)) hits[at_] = h_; if (hq) hq[at_] = L.qi[row_]; }      /* (dflags: timing experiments of the DBG instances only - 0 everywhere else) */
+		hits[at_] = h_; if (hq) hq[at_] = L.qi[row_]; }
 	// A step = one BIN: the smallest key K = (target, strand) under any cursor; the rows whose head is K emit it in row order and advance.  (The first version stepped
 	// by target and ranked forward and opposite-strand hits in one pass: a count pass over all blocks in front of every step and two ballots, two mbcnt pairs and four
 	// selects per block - 45 instructions per emitting block where this takes 16, and at two waves per SIMD the step loop runs at the latency of its dependent
@@ -184,7 +182,6 @@ __device__ __forceinline__ uint32_t hao_l5_merge(const hao_l5_ptr<B16> &L, const
 			if (h) {      // (wave-uniform)
 				const uint32_t at = run + hao_mbcnt(h);
 				run += (uint32_t)__popcll(h);
-				if (dbgw) ++d_blocks;
 				if (act) {
 					const uint32_t row = i * 64 + lane;
 					if constexpr (QREG) HAO_L5_PUT(at, w0, rv, hb[i], qx[i], qy[i], row)
@@ -232,14 +229,13 @@ __device__ __forceinline__ uint32_t hao_l5_merge(const hao_l5_ptr<B16> &L, const
 	}
 #undef HAO_L5_NEXT
 #undef HAO_L5_PUT
-	if (dbgw && lane == 0) { atomicAdd(dbgw, wall_clock64() - d_t0); atomicAdd(dbgw + 8, (unsigned long long)ngr); atomicAdd(dbgw + 16, (unsigned long long)d_blocks); atomicAdd(dbgw + 24, (unsigned long long)(run)); }
 	ngr_out = ngr;
 	return run;
 }
 
 template<bool B16, int QPT, int NPF, bool DBG>
 __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, const uint32_t *__restrict__ len, const uint64_t *__restrict__ s_pk,
-		uint32_t max_n, uint32_t *ovf_list, unsigned long long *ovf_cnt)
+		uint32_t max_n, uint32_t w0_share, uint32_t *ovf_list, unsigned long long *ovf_cnt)
 {
 	constexpr uint32_t CAP = hao_l5_lds<B16>::CAP;
 	extern __shared__ uint64_t l5_smem[];
@@ -251,7 +247,6 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 	if (b0 == 0 && tid == 0) S.g_cnt[S.n_sel] = 0;
 	if (b0 >= S.n_sel) return;
 	if (tid < 2 * HAO_L5_HB) L.hist[tid] = 0;
-	const uint32_t dflags = DBG && S.dbg ? (uint32_t)S.dbg[31] : 0u;      // HAO_DBG_SEEDFLAGS: 1 = the merge without its hit stores (what do the stores cost?), 2 = without the record loads' data (lists of zeros)
 	const uint64_t nrd = (S.n_sel - b0 + G - 1) / G;      // this workgroup's reads: b0, b0 + G, ...
 	// pipeline registers
 	uint64_t av = 0;                                                        // alpha: lanes 0 - 3 of every wave hold mz_off[r], mz_off[r + 1], seg[r], seg[r + 1]
@@ -295,7 +290,7 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 				if (sl < re.nslots) {
 					const uint64_t e = L.slots[sl]; const uint32_t c = HAO_L5_SLOT_C(e), z = HAO_L5_SLOT_Z(e), o = HAO_L5_SLOT_O(e) + sj;
 					if (sj < c) { uint32_t a, b; hao_l5_fold(rec[i].a, z, a, b); const uint32_t t = a >> 1; L.recA[o] = a; L.recB[o] = (typename hao_l5_lds<B16>::off_t)b; atomicAdd(&hist_e[t >> hshift], 1u); L.bin_tid[t >> hshift] = t; }
-					if (sj + 1 < c) { uint32_t a, b; hao_l5_fold(rec[i].b, z, a, b); const uint32_t t = a >> 1; L.recA[o + 1] = a; L.recB[o + 1] = (typename hao_l5_lds<B16>::off_t)b; atomicAdd(&hist_e[t >> hshift], 1u); L.bin_tid[t >> hshift] = t; }
+					if (sj + 1 < c) { uint32_t a, b; hao_l5_fold(rec[i].b, z, a, b); L.recA[o + 1] = a; L.recB[o + 1] = (typename hao_l5_lds<B16>::off_t)b; }      // (the histogram is a sample: every other record)
 				}
 				if ((i & 1) == 1) HAO_L5_SCHED_FENCE();
 			}
@@ -320,6 +315,7 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 			// around the store and puts an s_waitcnt vmcnt(0) in front of the next write to that register - which was in the merge, with every record load in flight
 			const bool blw_ = tid < HAO_L5_HB && re.valid && !re.skip && hist_e[tid] != 0;
 			const uint32_t bl_ = len[blw_ ? L.bin_tid[tid] : 0u];
+			if (tid < HAO_L5_HB && !blw_) L.bin_tid[tid] = HAO_L5_SENT;      // (no sampled record in the bin: whatever an earlier read left there must not pair up with the word stored below)
 #pragma unroll
 			for (int m = 0; m < QPT; ++m) {
 				const uint32_t q = m * HAO_L5_THREADS + tid, c = go && q < rd.nq ? (uint32_t)(raw_s[m] >> 48) & 0xfffu : 0u;
@@ -362,8 +358,7 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 				rec[i].a = rec[i].b = 0;      // (every register is written in every step: a conditional assignment alone would keep last step's value alive across the whole loop body)
 				if (sl < nsl) {
 					const uint64_t e = L.slots[sl]; const uint32_t c = HAO_L5_SLOT_C(e);
-					if (DBG && (dflags & 2)) { }
-					else if (sj + 1 < c) rec[i] = *(const hao_rec2*)(sinfo + HAO_L5_SLOT_G(e) + sj);      // (16 bytes at an 8-byte boundary)
+					if (sj + 1 < c) rec[i] = *(const hao_rec2*)(sinfo + HAO_L5_SLOT_G(e) + sj);      // (16 bytes at an 8-byte boundary)
 					else if (sj < c) rec[i].a = sinfo[HAO_L5_SLOT_G(e) + sj];                        // the odd record at the end of a list: nothing is read past it
 				}
 				if ((i & 1) == 1) HAO_L5_SCHED_FENCE();
@@ -395,8 +390,11 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 					const uint32_t s4 = hv.x + hv.y + hv.z + hv.w, ex0 = hao_wave_incl_scan_u32(s4) - s4, ex1 = ex0 + hv.x, ex2 = ex1 + hv.y, ex3 = ex2 + hv.z;
 					// shares in 1/1024 of the read's hits: wave 0 needs no search for its start (about 4 % of a read's time), and the second wave of every SIMD (waves 4 - 7)
 					// loses the issue arbitration to the first (measured: 11.4 against 10.5 us per read for equal shares, profiles/r06/seed_phases.txt)
-					auto cumw = [](uint32_t w) -> uint32_t { return w == 0 ? 0u : w >= HAO_L5_W ? 1024u : w <= 4 ? 160u + (w - 1) * 126u : 538u + (w - 4) * 122u; };
-					const uint32_t th_lo = (uint32_t)(((uint64_t)re.n * cumw((uint32_t)wv)) >> 10), th_hi = (uint32_t)(((uint64_t)re.n * cumw((uint32_t)wv + 1)) >> 10);
+					// shares in 1/1024 of the (sampled) hits: wave 0 needs no search for its start and gets w0_share (default 176), the others share the rest - the second
+					// wave of every SIMD (waves 4 - 7) 4 % less than the first: it loses the issue arbitration (profiles/r06/seed_phases.txt)
+					const uint32_t tot_ = (uint32_t)__builtin_amdgcn_readlane((int)(ex0 + s4), 63), rest_ = 1024u - w0_share;
+					auto cumw = [&](uint32_t w) -> uint32_t { return w == 0 ? 0u : w >= HAO_L5_W ? 1024u : w0_share + (w <= 4 ? (w - 1) * (rest_ * 37u >> 8) : 3u * (rest_ * 37u >> 8) + (w - 4) * (rest_ * 35u >> 8)); };
+					const uint32_t th_lo = (uint32_t)(((uint64_t)tot_ * cumw((uint32_t)wv)) >> 10), th_hi = (uint32_t)(((uint64_t)tot_ * cumw((uint32_t)wv + 1)) >> 10);
 					const uint32_t b_lo = (uint32_t)(__popcll(__ballot(ex0 < th_lo)) + __popcll(__ballot(ex1 < th_lo)) + __popcll(__ballot(ex2 < th_lo)) + __popcll(__ballot(ex3 < th_lo)));
 					const uint32_t b_hi = (uint32_t)(__popcll(__ballot(ex0 < th_hi)) + __popcll(__ballot(ex1 < th_hi)) + __popcll(__ballot(ex2 < th_hi)) + __popcll(__ballot(ex3 < th_hi)));
 					t_lo = b_lo << hshift;      // (wave 0: th_lo = 0, no bin below it: t_lo = 0)
@@ -404,11 +402,10 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 				}
 				hao_hit_t *hits = S.hits + re.s; uint16_t *hq = S.hq ? S.hq + re.s : nullptr;
 				HAO_L5_TICK(5)
-				unsigned long long *dbgw = DBG && S.dbg ? S.dbg + 32 + wv : nullptr;      // [32 + w] ticks in wave w's step loop, [40 + w] its steps, [48 + w] its emitting blocks
 				if (t_lo < t_hi) {
-					if (re.nk <= 8 * 64) (void)hao_l5_merge<8, B16>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, hshift, dflags, dbgw, ngr);
-					else if (QPT == 2 || re.nk <= 16 * 64) (void)hao_l5_merge<16, B16>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, hshift, dflags, dbgw, ngr);
-					else if constexpr (QPT > 2) (void)hao_l5_merge<24, B16>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, hshift, dflags, dbgw, ngr);
+					if (re.nk <= 8 * 64) (void)hao_l5_merge<8, B16>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, hshift, ngr);
+					else if (QPT == 2 || re.nk <= 16 * 64) (void)hao_l5_merge<16, B16>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, hshift, ngr);
+					else if constexpr (QPT > 2) (void)hao_l5_merge<24, B16>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, hshift, ngr);
 				}
 				if (lane == 0) L.sm[wv] = ngr;
 				HAO_L5_TICK(6)

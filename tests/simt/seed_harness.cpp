@@ -60,10 +60,10 @@ extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t 
 		const unsigned grid = (unsigned)std::min<uint64_t>(n, getenv("SIMT_SEED_GRID") ? (uint64_t)atoi(getenv("SIMT_SEED_GRID")) : 3);
 		const bool wide = max_q > 2 * HAO_L5_THREADS || getenv("SIMT_SEED_WIDE");      // (three minimizers per thread and fewer record registers: what the library launches for batches with long reads)
 		std::function<void()> call;
-		if (b16 && wide) call = [&] { seed_lds_kernel<true, 3, 8, false>(sa, sinfo, len, S.s_pk.data(), max_n, ovf0.data(), &ovf0_cnt); };
-		else if (b16) call = [&] { seed_lds_kernel<true, 2, 16, false>(sa, sinfo, len, S.s_pk.data(), max_n, ovf0.data(), &ovf0_cnt); };
-		else if (wide) call = [&] { seed_lds_kernel<false, 3, 8, false>(sa, sinfo, len, S.s_pk.data(), max_n, ovf0.data(), &ovf0_cnt); };
-		else call = [&] { seed_lds_kernel<false, 2, 16, false>(sa, sinfo, len, S.s_pk.data(), max_n, ovf0.data(), &ovf0_cnt); };
+		if (b16 && wide) call = [&] { seed_lds_kernel<true, 3, 8, false>(sa, sinfo, len, S.s_pk.data(), max_n, 176u, ovf0.data(), &ovf0_cnt); };
+		else if (b16) call = [&] { seed_lds_kernel<true, 2, 16, false>(sa, sinfo, len, S.s_pk.data(), max_n, 176u, ovf0.data(), &ovf0_cnt); };
+		else if (wide) call = [&] { seed_lds_kernel<false, 3, 8, false>(sa, sinfo, len, S.s_pk.data(), max_n, 176u, ovf0.data(), &ovf0_cnt); };
+		else call = [&] { seed_lds_kernel<false, 2, 16, false>(sa, sinfo, len, S.s_pk.data(), max_n, 176u, ovf0.data(), &ovf0_cnt); };
 		if (launch(grid, HAO_L5_THREADS, b16 ? hao_l5_lds<true>::TOTAL : hao_l5_lds<false>::TOTAL, call)) return fail(err, errcap, hao_simt::g.error);
 		stats[6] = ovf0_cnt;
 		if (ovf0_cnt) {

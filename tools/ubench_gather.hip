@@ -59,6 +59,16 @@ __global__ __launch_bounds__(256) void copy_kernel(const uint64_t *__restrict__ 
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) { const uint64_t v = idx[i % n_idx]; out[i] = hit{(uint32_t)v, (uint32_t)(v >> 32), 1, 2}; }
 }
 
+// copy16: the yardstick without the modulo and with 16-byte accesses (round 5's copy_kernel did a 64-bit % per element and 8-byte loads and read 4.36 TB/s; the guide
+// measures 6.29 TB/s for a float4 copy): 16 bytes in (two records from a sequential array as large as the reads need), 32 bytes out per work-item
+__global__ __launch_bounds__(256) void copy16_kernel(const ulonglong2 *__restrict__ in, uint64_t n2, hit *out)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (uint64_t)gridDim.x * blockDim.x) {
+		const ulonglong2 v = in[i];
+		out[2 * i] = hit{(uint32_t)v.x, (uint32_t)(v.x >> 32), 1, 2}; out[2 * i + 1] = hit{(uint32_t)v.y, (uint32_t)(v.y >> 32), 1, 2};
+	}
+}
+
 int main(int argc, char **argv)
 {
 	const uint64_t n_rec = (uint64_t)(argc > 1 ? atof(argv[1]) : 993.0) * 1000000ULL, n_idx = (uint64_t)(argc > 2 ? atof(argv[2]) : 290.0) * 1000000ULL;
@@ -66,6 +76,7 @@ int main(int argc, char **argv)
 	uint64_t *idx, *start; hit *out;
 	CK(hipMalloc(&idx, (n_idx + 64) * 8)); CK(hipMalloc(&start, (n_lists + 512) * 8)); CK(hipMalloc(&out, (n_out + 4096) * sizeof(hit)));
 	hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, idx, n_idx + 64);
+	uint64_t *big; CK(hipMalloc(&big, (n_rec + 64) * 8)); hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, big, n_rec + 64);
 	std::vector<uint64_t> h(n_lists + 512); uint64_t x = 88172645463325252ULL;
 	for (auto &v : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = x % (n_idx - LIST_LEN - 8); }      // list starts: anywhere in the index, 8-byte aligned (as the engine's)
 	CK(hipMemcpy(start, h.data(), h.size() * 8, hipMemcpyHostToDevice));
@@ -77,6 +88,7 @@ int main(int argc, char **argv)
 			CK(hipEventRecord(e0, 0));
 			if (which == 0) hipLaunchKernelGGL(rows_kernel, dim3(g), dim3(256), 0, 0, idx, start, n_lists, out);
 			else if (which == 1) hipLaunchKernelGGL(lists_kernel, dim3(g), dim3(256), 0, 0, idx, start, n_lists, out);
+			else if (which == 3) hipLaunchKernelGGL(copy16_kernel, dim3(256 * 8), dim3(256), 0, 0, (const ulonglong2*)big, n_lists * LIST_LEN / 2, out);
 			else hipLaunchKernelGGL(copy_kernel, dim3(256 * 16), dim3(256), 0, 0, idx, n_lists * LIST_LEN, n_idx, out);
 			CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
 			float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep && ms < best) best = ms;
@@ -85,6 +97,6 @@ int main(int argc, char **argv)
 		printf("%-6s %8.3f ms  %7.1f GB/s of (8 in + 16 out) bytes  = %.3f of 8 TB/s   [%llu M records, %llu M lists of %u, index %.2f GB]\n", name, best, bytes / best / 1e6, bytes / best / 1e6 / 8000.0,
 			   (unsigned long long)(n_lists * LIST_LEN / 1000000), (unsigned long long)(n_lists / 1000000), LIST_LEN, n_idx * 8 / 1e9);
 	};
-	run("copy", 2); run("lists", 1); run("rows", 0);
+	run("copy16", 3); run("copy", 2); run("lists", 1); run("rows", 0);
 	return 0;
 }
