@@ -2,9 +2,7 @@
 #pragma once
 #include "hao_tables.hpp"
 #include "hao_query.cuh"
-#include "hao_query2.cuh"
 #include "hao_query3.cuh"
-#include "hao_query4.cuh"
 #include "hao_query5.cuh"
 #include "hao_grid.cuh"
 #include "hao_chain.cuh"
@@ -15,7 +13,7 @@ struct hao_ctx::Batch {
 	bool valid = false, host_valid = false;
 	DevBuf<uint64_t> s_start, s_pk, a_off, seg, g_cnt, g_off, g_start, ch_base, cl_base, fc_base, fcs, fc_raw, ol_fc_off, cc_off, cc, fc_final, fcf_off;
 	DevBuf<uint64_t> nch64;
-	DevBuf<uint64_t> g_tmp, cls_cc, cls_co; DevBuf<hao_gent> glist; DevBuf<uint8_t> g_cls; DevBuf<uint32_t> slow, ovf_list, loc_idx, loc_idx2; DevBuf<uint64_t> loc_key, loc_key2; hipStream_t side[HAO_NCLS]; hipEvent_t ev_qc[HAO_NCLS], ev_dp[HAO_NCLS]; bool side_ready = false;
+	DevBuf<uint64_t> g_tmp, cls_cc, cls_co; DevBuf<hao_gent> glist; DevBuf<uint8_t> g_cls; DevBuf<uint32_t> slow, ovf_list; hipStream_t side[HAO_NCLS]; hipEvent_t ev_qc[HAO_NCLS], ev_dp[HAO_NCLS]; bool side_ready = false;
 	DevBuf<uint32_t> q_pos, q_cnt, s_n, g_read, wgt, nch, nout, perm, n_final, fclen;
 	DevBuf<hao_hit_t> hits, ohits, cl;
 	DevBuf<int32_t> f, ii, p, key_sc, tm; DevBuf<int64_t> t; DevBuf<uint64_t> key_xs; DevBuf<uint32_t> key_al, key_tmp;
@@ -45,7 +43,7 @@ struct hao_ctx::Batch {
 		if (side_ready) { for (int x = 0; x < HAO_NCLS; ++x) { (void)hipStreamDestroy(side[x]); (void)hipEventDestroy(ev_qc[x]); (void)hipEventDestroy(ev_dp[x]); } side_ready = false; }
 		s_start.release(); s_pk.release(); a_off.release(); seg.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fcf_off.release();
-		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); g_cls.release(); slow.release(); ovf_list.release(); loc_idx.release(); loc_idx2.release(); loc_key.release(); loc_key2.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
+		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); g_cls.release(); slow.release(); ovf_list.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
 		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); cd.release(); pk_cnt.release(); pk_ecnt.release(); pk_erank.release(); hq.release(); ohq.release(); hcode.release(); out[0].release(); out[1].release();
 		if (dl_ready) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); for (int k = 0; k < n_aux; ++k) { (void)hipStreamSynchronize(copy_aux[k]); (void)hipStreamDestroy(copy_aux[k]); (void)hipEventDestroy(ev_aux[0][k]); (void)hipEventDestroy(ev_aux[1][k]); } for (int x = 0; x < 2; ++x) { (void)hipEventDestroy(ev_ready[x]); (void)hipEventDestroy(ev_done[x]); if (arena[x]) (void)hipHostFree(arena[x]); arena[x] = nullptr; arena_cap[x] = 0; } dl_ready = false; }
 	}
@@ -267,6 +265,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	if (!c->has_pt) { hao_set_err(c, "hao_pt_gen must run before hao_overlap_batch"); return HAO_EINVAL; }
 	if (!c->batch) c->batch = new hao_ctx::Batch();
 	hao_ctx::Batch &B = *c->batch; const double t_run0 = hao_now();
+	c->al_grid_n = 0;      // (the window-alignment grid of the previous batch's overlaps is stale)
 	B.valid = false; B.host_valid = false; B.cl_valid = false; B.exact_valid = false; B.h_exact.clear(); B.lo = lo; B.n = hi - lo; B.dl_parts = parts; B.n_exc = 0;
 	const uint64_t n = B.n;
 	if (parts) {
@@ -336,10 +335,9 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		HIP_TRY(B.ovf_list.reserve(3 * (n + 1)));
 		unsigned long long *d_ovf = B.stats.p + 3 * HAO_NCLS + 3, *d_ovf2 = B.stats.p + 3 * HAO_NCLS + 4, *d_ovf0 = B.stats.p + 3 * HAO_NCLS + 5;
 		uint32_t *ovf1 = B.ovf_list.p, *ovf2 = B.ovf_list.p + (n + 1), *ovf0 = B.ovf_list.p + 2 * (n + 1);
-		const uint32_t tile_ = c->sw.seed_tile == 512 ? 512 : 1024;
-		const size_t lds_tile = std::max<size_t>((size_t)tile_ * (sizeof(hao_stage_t) + 4), 12 * 512);      // staged tile (>= the 12 bytes per slot of the bin sort it shares memory with)
+		const size_t lds_tile = std::max<size_t>((size_t)512 * (sizeof(hao_stage_t) + 4), 12 * 512);      // staged tile (>= the 12 bytes per slot of the bin sort it shares memory with)
 		const size_t lds_q = 12 * (size_t)sa_.qcap + 16;
-		size_t lds1 = (size_t)22 * 512 + lds_tile + lds_q + (size_t)c->sw.seed_lds_pad, lds2 = (size_t)22 * 1024 + std::max<size_t>(lds_tile, 12 * 1024) + lds_q,
+		size_t lds1 = (size_t)22 * 512 + lds_tile + lds_q, lds2 = (size_t)22 * 1024 + std::max<size_t>(lds_tile, 12 * 1024) + lds_q,
 			   lds3 = (size_t)22 * 2048 + std::max<size_t>(lds_tile, 12 * 2048) + lds_q;      // (third launch: 2048 slots = up to 1760 bins per id-range round)
 		auto launch = [&](auto k1, auto k2, auto k3) -> int {
 			{     // beyond the default dynamic LDS limit: opt in (the CU has 160 KB)
@@ -355,14 +353,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			HAO_CHECK_LAUNCH();
 			return HAO_OK;
 		};
-		if (c->sw.seed_v2) {      // A/B (round 4, measured slower): the scatter pass without workgroup barriers (hao_query2.cuh)
-			const size_t q_ = lds_q + (size_t)c->sw.seed_lds_pad;
-			lds1 = hao_seed2_lds<9>::FIXED + q_; lds2 = hao_seed2_lds<10>::FIXED + lds_q; lds3 = hao_seed2_lds<11>::FIXED + lds_q;
-			if (c->sw.seed_pf) { if (int rc = launch(seed_bin2_kernel<9, 0, true>, seed_bin2_kernel<10, 1, true>, seed_bin2_kernel<11, 2, true>)) return rc; }
-			else if (int rc = launch(seed_bin2_kernel<9, 0, false>, seed_bin2_kernel<10, 1, true>, seed_bin2_kernel<11, 2, true>)) return rc;
-		}
-		else if (tile_ != 512) { if (int rc = launch(seed_bin_kernel<9, 0, 1024, false>, seed_bin_kernel<10, 1, 1024, false>, seed_bin_kernel<11, 2, 1024, false>)) return rc; }
-		else if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql && c->sw.seed_lds && A <= (uint64_t)c->sw.seed_merge_avg * n && c->n_total < HAO_MRG_END && c->ix_n_pos + c->sw.ix_pad < (1ULL << 40)) {
+		if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql && c->sw.seed_lds && A <= (uint64_t)c->sw.seed_merge_avg * n && c->n_total < HAO_L5_MASK && c->ix_n_pos + c->sw.ix_pad < (1ULL << 40)) {
 			B.seed_path = 2;
 			// the list-major kernel (hao_query5.cuh): one persistent workgroup per CU, a read's position lists read once with adjacent lanes on adjacent records into LDS,
 			// merged by target there.  The reads it leaves (more than 1536 minimizers, more records than the LDS holds, more than seed_merge_maxn hits) go through the
@@ -375,11 +366,11 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			HIP_TRY(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
 			{
 				const uint64_t *sinfo_ = c->d_ix_sinfo.p; const uint32_t *len_ = c->d_len_all.p; const uint64_t *spk_ = B.s_pk.p;
-				const unsigned g_ = (unsigned)std::min<uint64_t>(n, (uint64_t)c->n_cu * (c->sw.seed_lds_wg > 0 ? c->sw.seed_lds_wg : 1));
+				const unsigned g_ = (unsigned)std::min<uint64_t>(n, (uint64_t)c->n_cu);
 				const bool b16_ = c->max_len_all < 65536, wide_ = max_q > 2 * HAO_L5_THREADS;      // offsets of the staged records in 16 bits; reads with more than 1024 minimizers: three per thread
 				auto go_ = [&](auto k0, size_t lds_) -> int {
 					HIP_TRY(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
-					hipLaunchKernelGGL(k0, dim3(g_), dim3(HAO_L5_THREADS), lds_, c->stream, sa_, sinfo_, len_, spk_, (uint32_t)c->sw.seed_merge_maxn, (uint32_t)c->sw.seed_lds_w0, ovf0, d_ovf0);
+					hipLaunchKernelGGL(k0, dim3(g_), dim3(HAO_L5_THREADS), lds_, c->stream, sa_, sinfo_, len_, spk_, (uint32_t)c->sw.seed_merge_maxn, 176u /* wave 0's share in 1/1024: profiles/r06/seed_ab.txt */, ovf0, d_ovf0);
 					return HAO_OK;
 				};
 				int rc_;
@@ -396,60 +387,9 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			hipLaunchKernelGGL(k3, dim3((unsigned)n), dim3(256), lds3, c->stream, sa_, (const uint32_t*)ovf2, (const unsigned long long*)d_ovf2, (uint32_t*)nullptr, (unsigned long long*)nullptr);
 			HAO_CHECK_LAUNCH();
 		}
-		else if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql && c->sw.seed_merge && A <= (uint64_t)c->sw.seed_merge_avg * n && sum_q <= (uint64_t)c->sw.seed_merge_qavg * n && c->n_total < HAO_MRG_END) {      // (read id 2^28 - 1 is the merge's end mark: a read set that uses it - exactly 2^28 reads - takes the tables)
-			B.seed_path = 1;
-			// (the batch's reads average at most seed_merge_avg seed hits: above that the reads cross repeat families - hundreds of targets, a merge step each - and the
-			// table kernels below are the faster ones: 231 against 248 ms per pass of the repeat-rich 250 Mb set, 58.9 against 54.7 ms on the repeat-free one, profiles/r05;
-			// and at most seed_merge_qavg (520) minimizers: nearly all of them have a list at 30x, and a wave holds 512 rows - a batch of 30 kb reads (1 150 minimizers) would hand every read on)
-			// the merge kernel (hao_query4.cuh): one wave per read, one walk over the read's position lists; the reads with more rows than a wave holds go through the
-			// table kernels below it (512-slot launch over the overflow list, then the launches without staged tiles)
+		else if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql) {      // every read's minimizer table fits the LDS; reads whose bins overflow the 512-slot table: the launches without staged tiles (hao_query3.cuh)
 			lds2 = hao_seed3_lds<10>::FIXED + lds_q; lds3 = hao_seed3_lds<11>::FIXED + lds_q;
-			auto k1 = seed_bin_kernel<9, 1, 512, true>; auto k2 = seed_bin3_kernel<10, 1, 4>; auto k3 = seed_bin3_kernel<11, 2, 4>;
-			HIP_TRY(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-			HIP_TRY(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-			HIP_TRY(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-			{
-				const uint64_t *sinfo_ = c->d_ix_sinfo.p; const uint32_t *len_ = c->d_len_all.p; const uint32_t *order_ = nullptr;
-				unsigned nwg = (unsigned)((n + 3) / 4);
-				if (c->sw.seed_locus && n > 64) {      // launch order by locus (hao_query4.cuh): key per read, sort, an eighth of the sorted list per XCD
-					HIP_TRY(B.loc_key.reserve(n + 1)); HIP_TRY(B.loc_key2.reserve(n + 1)); HIP_TRY(B.loc_idx.reserve(n + 1)); HIP_TRY(B.loc_idx2.reserve(n + 1));
-					hipLaunchKernelGGL(seed_locus_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, sa_, sinfo_, (uint32_t)(c->sw.seed_locus == 1 ? 64 : 0), B.loc_key.p, B.loc_idx.p);
-					HAO_CHECK_LAUNCH();
-					size_t tb = 0; rocprim::double_buffer<uint64_t> dk(B.loc_key.p, B.loc_key2.p); rocprim::double_buffer<uint32_t> dv(B.loc_idx.p, B.loc_idx2.p);
-					HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, dk, dv, (size_t)n, 0, 55, c->stream)); HIP_TRY(hao_tmp(c, tb));
-					HIP_TRY(rocprim::radix_sort_pairs(c->d_tmp.p, tb, dk, dv, (size_t)n, 0, 55, c->stream));
-					order_ = dv.current(); nwg = (nwg + 7) / 8 * 8;
-				}
-				if (c->sw.seed_mergew) {      // four waves per read: a workgroup per read (default)
-					const dim3 gw_(order_ ? (unsigned)((n + 7) / 8 * 8) : (unsigned)n), b_(256);
-					if (c->sw.seed_mergew == 4) hipLaunchKernelGGL((seed_mergew_kernel<4, 4>), gw_, b_, hao_seed4w_lds<4>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
-					else if (c->sw.seed_mbuf == 1) hipLaunchKernelGGL((seed_mergew_kernel<2, 1>), gw_, b_, hao_seed4w_lds<2>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
-					else if (c->sw.seed_mbuf == 8) hipLaunchKernelGGL((seed_mergew_kernel<2, 8>), gw_, b_, hao_seed4w_lds<2>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
-					else hipLaunchKernelGGL((seed_mergew_kernel<2, 4>), gw_, b_, hao_seed4w_lds<2>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
-				} else {
-				const dim3 g_(nwg), b_(256);
-				if (c->sw.seed_merge == 4 && c->sw.seed_mbuf == 1) hipLaunchKernelGGL((seed_merge_kernel<4, 1>), g_, b_, hao_seed4_lds<4>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
-				else if (c->sw.seed_merge == 4) hipLaunchKernelGGL((seed_merge_kernel<4, 4>), g_, b_, hao_seed4_lds<4>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
-				else if (c->sw.seed_mbuf == 1) hipLaunchKernelGGL((seed_merge_kernel<8, 1>), g_, b_, hao_seed4_lds<8>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
-				else if (c->sw.seed_malign) hipLaunchKernelGGL((seed_merge_kernel<8, 4, true>), g_, b_, hao_seed4_lds<8>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
-				else hipLaunchKernelGGL((seed_merge_kernel<8, 4>), g_, b_, hao_seed4_lds<8>::TOTAL, c->stream, sa_, sinfo_, len_, order_, (uint32_t)c->sw.seed_merge_maxn, ovf0, d_ovf0);
-				}
-			}
-			HAO_CHECK_LAUNCH();
-			hipLaunchKernelGGL(k1, dim3((unsigned)n), dim3(256), lds1, c->stream, sa_, (const uint32_t*)ovf0, (const unsigned long long*)d_ovf0, ovf1, d_ovf);
-			HAO_CHECK_LAUNCH();
-			hipLaunchKernelGGL(k2, dim3((unsigned)n), dim3(256), lds2, c->stream, sa_, (const uint32_t*)ovf1, (const unsigned long long*)d_ovf, ovf2, d_ovf2);
-			HAO_CHECK_LAUNCH();
-			hipLaunchKernelGGL(k3, dim3((unsigned)n), dim3(256), lds3, c->stream, sa_, (const uint32_t*)ovf2, (const unsigned long long*)d_ovf2, (uint32_t*)nullptr, (unsigned long long*)nullptr);
-			HAO_CHECK_LAUNCH();
-		}
-		else if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql) {      // every read's minimizer table fits the LDS
-			if (c->sw.seed_nodirect) { if (int rc = launch(seed_bin_kernel<9, 0, 512, true>, seed_bin_kernel<10, 1, 512, true>, seed_bin_kernel<11, 2, 512, true>)) return rc; }
-			else {      // reads whose bins overflow the 512-slot table: the launches without staged tiles (hao_query3.cuh)
-				lds2 = hao_seed3_lds<10>::FIXED + lds_q; lds3 = hao_seed3_lds<11>::FIXED + lds_q;
-				if (c->sw.seed_nu == 8) { if (int rc = launch(seed_bin_kernel<9, 0, 512, true>, seed_bin3_kernel<10, 1, 8>, seed_bin3_kernel<11, 2, 8>)) return rc; }
-				else if (int rc = launch(seed_bin_kernel<9, 0, 512, true>, seed_bin3_kernel<10, 1, 4>, seed_bin3_kernel<11, 2, 4>)) return rc;
-			}
+			if (int rc = launch(seed_bin_kernel<9, 0, 512, true>, seed_bin3_kernel<10, 1, 4>, seed_bin3_kernel<11, 2, 4>)) return rc;
 		}
 		else if (int rc = launch(seed_bin_kernel<9, 0, 512, false>, seed_bin_kernel<10, 1, 512, false>, seed_bin_kernel<11, 2, 512, false>)) return rc;
 	}

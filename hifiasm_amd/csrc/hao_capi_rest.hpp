@@ -293,6 +293,7 @@ int hao_window_ed_grid(hao_ctx *c, uint32_t window, uint32_t thre, uint64_t *n_t
 int hao_fetch_ed_grid(hao_ctx *c, hao_ed_task_t *tasks, hao_ed_result_t *res, uint64_t cap)
 {
 	if (!c) return HAO_EINVAL;
+	if (!c->batch || !c->batch->valid || (c->al_grid_n == 0 && cap)) { hao_set_err(c, "hao_fetch_ed_grid: no pairs of hao_window_ed_grid are resident (a new batch or another window-alignment call has reused the scratch)"); return HAO_EINVAL; }
 	HIP_TRY(hipSetDevice(c->device));
 	const uint64_t n = std::min<uint64_t>(cap, c->al_grid_n);
 	if (n && tasks) HIP_TRY(hipMemcpyAsync(tasks, c->al_task.p, n * sizeof(hao_ed_task_t), hipMemcpyDeviceToHost, c->stream));

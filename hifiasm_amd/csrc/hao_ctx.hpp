@@ -57,38 +57,26 @@ struct StageTimer {
 // run-time switches (measurement aids): read from the environment ONCE, in hao_create
 struct hao_switches {
 	bool seedphase = false, qcphase = false, dp_stats = false, seq_chain = false, dp_seqtail = false, dp_nospec = false, dp_serial = false,
-		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, sk_v2 = false, dltime = false, sk_nofuse = false, pack_search = false, sk_select2 = false, seed_v2 = false, seed_pf = true, seed_noql = false, sort64 = false, seed_nodirect = false, tiny_lane = false, pt_direct = false;
+		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, sk_v2 = false, dltime = false, sk_nofuse = false, pack_search = false, sk_select2 = false, seed_noql = false, sort64 = false, tiny_lane = false, pt_direct = false;
 	static constexpr bool SK_SELECT2_DEFAULT = true;       // the thinning kernel the sketch runs when the environment says nothing: the wave kernel (round 4: green on the device against every repeat-rich scenario and the 5 Mb / 250 Mb repeat-rich fixtures)
-	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; unsigned long long ix_pad = 0, sort40_min = 1ULL << 23; int seed_nu = 4, fc_raw_every = 0, exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, seed_lds_pad = 0, arena_numa = 3, seed_tile = 512, seed_merge = 8, seed_mbuf = 4, seed_locus = 0, seed_mergew = 0, seed_merge_maxn = 24000, seed_merge_avg = 14000, seed_merge_qavg = 520, seed_malign = 0, ft_passes = 0, seed_lds = 1, seed_lds_wg = 1, seed_lds_w0 = 176; long long ft_chunk_slots = 0;
+	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; unsigned long long ix_pad = 0, sort40_min = 1ULL << 23; int fc_raw_every = 0, exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, arena_numa = 3, seed_merge_maxn = 24000, seed_merge_avg = 14000, ft_passes = 0, seed_lds = 1; long long ft_chunk_slots = 0;
 	void load() {
 		auto on = [](const char *n) { return getenv(n) != nullptr; };
 		seedphase = on("HAO_DBG_SEEDPHASE"); qcphase = on("HAO_DBG_QCPHASE"); dp_stats = on("HAO_DBG_DP_STATS"); seq_chain = on("HAO_DBG_SEQ_CHAIN");
 		dp_seqtail = on("HAO_DBG_DP_SEQTAIL"); dp_nospec = on("HAO_DBG_DP_NOSPEC"); dp_serial = on("HAO_DBG_DP_SERIAL"); seq_prune = on("HAO_DBG_SEQ_PRUNE");
 		selphase = on("HAO_DBG_SELPHASE"); sel1 = on("HAO_DBG_SEL1"); sk_generic = on("HAO_DBG_SK_GENERIC"); sk_v2 = on("HAO_DBG_SK_V2"); sk_nofuse = on("HAO_DBG_SK_NOFUSE"); pack_search = on("HAO_DBG_PACK_SEARCH");      // the wire packer searches every hit's minimizer (round-2 path) instead of gathering the quick check's code bytes
 		dltime = on("HAO_DBG_DLTIME");
-		if (const char *e = getenv("HAO_SEED_MERGE")) { const int v = atoi(e); seed_merge = v == 0 ? 0 : v == 4 ? 4 : 8; }      // the seed stage by merge (hao_query4.cuh; rows per lane), 0 = A/B: the table kernels for every read (rounds 1 - 4)
-		if (const char *e = getenv("HAO_SEED_LDS")) seed_lds = atoi(e) ? 1 : 0;      // 0 = A/B: the round-5 seed stage (one-wave merge kernel / table kernels) instead of the list-major LDS kernel (hao_query5.cuh)
-		if (const char *e = getenv("HAO_SEED_LDS_W0")) seed_lds_w0 = std::max(64, std::min(512, atoi(e)));      // wave 0's share of a read's hits in 1/1024 (it needs no search for its start)
-		if (const char *e = getenv("HAO_SEED_LDS_WG")) seed_lds_wg = std::max(1, atoi(e));      // persistent workgroups of the list-major kernel per CU (more than one only queue: a workgroup takes the CU's whole LDS)
-		if (const char *e = getenv("HAO_SEED_MERGE_QAVG")) seed_merge_qavg = std::max(0, atoi(e));      // batches whose reads average more minimizers than this take the table kernels (a wave of the merge kernel holds 512 minimizers with a list)
-		if (const char *e = getenv("HAO_SEED_MALIGN")) seed_malign = atoi(e) ? 1 : 0;      // the one-wave merge kernel's 32-byte list reads on 32-byte boundaries
-		if (const char *e = getenv("HAO_SEED_MERGE_AVG")) seed_merge_avg = std::max(0, atoi(e));      // batches whose reads average more seed hits than this take the table kernels (measured: the repeat-rich 250 Mb set averages 16 k, the repeat-free one 12 k)
-		if (const char *e = getenv("HAO_SEED_MERGE_MAXN")) seed_merge_maxn = std::max(0, atoi(e));      // reads with more seed hits than this go to the table kernels (repeat families: hundreds of targets per read)
-		if (const char *e = getenv("HAO_SEED_MERGEW")) { const int v = atoi(e); seed_mergew = v == 0 ? 0 : v == 4 ? 4 : 2; }      // A/B: the merge with four waves per read (rows per lane: 2 or 4; measured at the one-wave kernel's speed on configs[2], slower on the repeat-rich set), 0 (default) = one wave per read
-		if (const char *e = getenv("HAO_SEED_LOCUS")) { const int v = atoi(e); seed_locus = v == 2 ? 2 : v ? 1 : 0; }      // A/B: the merge kernel takes a batch's reads in locus order (1: key from the first 64 minimizers; 2: from all of them - kernel - 10 %, but the key pass + sort cost more than that: profiles/r05) or in read order (0, default)
-		if (const char *e = getenv("HAO_SEED_MBUF")) { const int v = atoi(e); seed_mbuf = v == 1 ? 1 : v == 8 ? 8 : 4; }      // records per list read of the merge kernels (8, 32, or - four-wave kernel only - aligned 64 bytes)
+		if (const char *e = getenv("HAO_SEED_LDS")) seed_lds = atoi(e) ? 1 : 0;      // 0 = the table kernels (hao_query.cuh, hao_query3.cuh) for every read instead of the list-major kernel (hao_query5.cuh): the tests run them on every scenario - they carry repeat-rich batches and the reads the list-major kernel leaves
+		if (const char *e = getenv("HAO_SEED_MERGE_AVG")) seed_merge_avg = std::max(0, atoi(e));      // batches whose reads average more seed hits than this take the table kernels (the repeat-rich 250 Mb set averages 16 k, the repeat-free one 12 k; list-major kernel on it: 341 against 226 ms, profiles/r06/seed_ab.txt)
+		if (const char *e = getenv("HAO_SEED_MERGE_MAXN")) seed_merge_maxn = std::max(0, atoi(e));      // reads with more seed hits than this are left to the table kernels by the list-major kernel (repeat families: hundreds of targets per read)
 		if (const char *e = getenv("HAO_FT_PASSES")) ft_passes = std::max(0, atoi(e));      // ha_ft_gen in this many hash-range passes (0: as many as the free device memory asks for)
 		if (const char *e = getenv("HAO_FT_CHUNK_SLOTS")) ft_chunk_slots = std::max(0LL, atoll(e));      // (tests) k-mer slots hashed per chunk of reads in pass mode
-		seed_v2 = on("HAO_SEED_V2");      // A/B: the seed kernel with a wave-private, barrier-free scatter pass (hao_query2.cuh; round 4: bit-exact, 1.5 x slower - fewer waves per CU)
 		if (const char *e = getenv("HAO_DBG_IX_PAD")) ix_pad = strtoull(e, nullptr, 10);      // tests: unused position records in front of the index (list starts beyond 2^32 on a small read set)
 		if (const char *e = getenv("HAO_DBG_SORT40_MIN")) sort40_min = strtoull(e, nullptr, 10);      // tests on the CPU emulation only: the big-index path (40-bit sort + fix-up, gather, windowed scatter) from this many minimizers on (on the device rocprim's bit-range sort is trusted from 2^23 elements on, tests/test_gpu_rocprim.py)
 		pt_direct = on("HAO_PT_DIRECT");      // A/B: the index's gather + scatter in one kernel (random 8-byte writes) instead of gather, one radix pass, windowed scatter
 		sort64 = on("HAO_PT_SORT64");      // A/B: the index sort over all 64 hash bits (8 passes) instead of 40 bits + fix-up (hao_index.cuh)
-		seed_nodirect = on("HAO_SEED_NODIRECT");      // A/B: reads of many bins through the staged-tile kernel's 1024- / 2048-slot instances instead of hao_query3.cuh
-		if (const char *e = getenv("HAO_SEED_NU")) seed_nu = atoi(e) == 8 ? 8 : 4;      // 64-anchor windows a wave of seed_bin3_kernel keeps in flight
 		tiny_lane = on("HAO_DBG_TINY_LANE");      // A/B: groups of <= 8 hits by chain_tiny_kernel (one lane per group, sequential) instead of chain_pack8_kernel
 		seed_noql = on("HAO_SEED_NOQL");  // A/B: the seed kernel's generic per-minimizer tables (LDS or global, all minimizers) even when every read of the batch fits the LDS
-		if (const char *e = getenv("HAO_SEED_PF")) seed_pf = atoi(e) != 0;      // 0: first launch of the seed kernel without the next tile's reads in flight (A/B)
 		sk_select2 = on("HAO_SK_SELECT2") || (SK_SELECT2_DEFAULT && !on("HAO_SK_SELECT1"));      // thinning of high-count minimizers: the wave kernel (hao_select2.cuh) / the one-lane replay (sketch_select_kernel)
 		if (const char *e = getenv("HAO_CHAIN_WPB")) chain_wpb = std::max(1, std::min(4, atoi(e)));
 		if (const char *e = getenv("HAO_SPEC_MINCLS")) spec_mincls = atoi(e);
@@ -97,8 +85,6 @@ struct hao_switches {
 		if (const char *e = getenv("HAO_DBG_FC_RAW_EVERY")) fc_raw_every = std::max(0, atoi(e));      // tests: every n-th overlap's fake cigar travels raw (the fallback of the packed wire form)
 		if (const char *e = getenv("HAO_DBG_EXC_EVERY")) exc_every = atoi(e);      // ship every n-th hit of a chain verbatim (tests: exercise the exception list)
 		if (const char *e = getenv("HAO_ARENA_NUMA")) arena_numa = atoi(e);      // 0: plain hipHostMalloc, 1: thread policy "prefer the GPU's node", 3 (default): "bind to it", then 1 if that fails, 2: 3 + hipHostMallocNumaUser
-		if (const char *e = getenv("HAO_SEED_TILE")) seed_tile = atoi(e);      // anchors per staged tile of the seed kernel: 512 (default: 6 workgroups per CU) or 1024 (longer runs per bin, 4 per CU)
-		if (const char *e = getenv("HAO_SEED_LDS_PAD")) seed_lds_pad = atoi(e);      // extra dynamic LDS bytes of the seed kernel = fewer resident workgroups per CU (A/B: cache footprint vs. latency hiding)
 		if (const char *e = getenv("HAO_STREAM_PRIO")) stream_prio = atoi(e);      // 1: the engine's streams at the highest priority (A/B: measured worse - the low-priority copy then starves)
 		if (const char *e = getenv("HAO_COPY_KERNEL")) copy_kernel = atoi(e);      // n > 0: the delivery copy is done by a kernel of n workgroups writing into the mapped arena (no DMA engine)
 		if (const char *e = getenv("HAO_COPY_STREAMS")) copy_streams = std::max(1, std::min(8, atoi(e)));      // DMA queues the delivery copy is spread over      // initial capacity of the wire format's verbatim-hit list (tests: force the grow-and-repack path)

@@ -83,6 +83,7 @@ int hao_window_ed_batch(hao_ctx *c, const hao_ed_task_t *tasks, uint64_t n_tasks
 	if (!c || (!tasks && n_tasks) || (!out && n_tasks)) return HAO_EINVAL;
 	if (int rc = hao_view_refresh(c)) return rc;
 	if (hao_is_sharded(c)) { hao_set_err(c, "hao_window_ed_batch needs the bases of both reads: single-device mode only"); return HAO_EUNSUPP; }
+	c->al_grid_n = 0;      // (the task / result scratch is shared with hao_window_ed_grid: what that call left is gone)
 	if (n_tasks == 0) return HAO_OK;
 	if (n_tasks >= (1ULL << 32)) { hao_set_err(c, "hao_window_ed_batch: more than 2^32 tasks in one call"); return HAO_EUNSUPP; }
 	uint32_t words = 0;      // bit (nword - 1): some band needs nword 64-bit words (the reference's cal_exz_infi picks nword = ceil((2 thre + 1) / 64), Correct.cpp:14508-14565)
@@ -115,6 +116,7 @@ int hao_window_trace_batch(hao_ctx *c, int mode, const hao_ed_task_t *tasks, uin
 	if (!c || (mode < HAO_ALIGN_GLOBAL || mode > HAO_ALIGN_SEMI) || (!tasks && n_tasks) || (!out && n_tasks) || (!cigars && n_tasks && cigar_cap)) return HAO_EINVAL;
 	if (int rc = hao_view_refresh(c)) return rc;
 	if (hao_is_sharded(c)) { hao_set_err(c, "hao_window_trace_batch needs the bases of both reads: single-device mode only"); return HAO_EUNSUPP; }
+	c->al_grid_n = 0;
 	if (n_tasks == 0) return HAO_OK;
 	if (n_tasks >= (1ULL << 32)) { hao_set_err(c, "hao_window_trace_batch: more than 2^32 tasks in one call"); return HAO_EUNSUPP; }
 	uint64_t tn_max = 1; uint32_t words = 0;      // bit (nword - 1): some band needs nword 64-bit words

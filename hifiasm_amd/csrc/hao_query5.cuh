@@ -1,7 +1,7 @@
 // Seed stage, LIST-MAJOR through LDS (K5-K7 in one pass; minimizers_qgen0, anchor.cpp:987-1081): one persistent workgroup per CU, one read at a time,
-// every position list of the read read ONCE with adjacent lanes on adjacent records, the R-way merge by target (hao_query4.cuh's formulation) run out of LDS.
+// every position list of the read read ONCE with adjacent lanes on adjacent records, the R-way merge by target run out of LDS.
 //
-// Why: the one-wave merge kernel reads its lists lane-privately (32 bytes at a time), which moves whole 128-byte lines through the fabric several times - it
+// Why: round 5's one-wave merge kernel (one wave per read, the same merge with lane-private list reads; profiles/r05) read its lists lane-privately (32 bytes at a time), which moves whole 128-byte lines through the fabric several times - it
 // fetched 2.5 - 5 x its records and sat at 0.33 of the HBM peak, where a coalesced walk of the same lists with the same stores runs at 0.53
 // (tools/ubench_gather.hip, profiles/r05).  The transposition between "list-major in" and "target-major out" needs the read's records on chip at once:
 // ~12 000 records of a 15 kb read at 30 x.  Here they are, 6 bytes each (key word: target | strand of the HIT << 28; offset word: 16 bits while every read is
@@ -21,19 +21,19 @@
 // equal slices of the read-id range) is counted in LDS; its prefix sums give seven bin boundaries with about an eighth of the read's hits between them, wave w takes
 // the targets in [s_w, s_w+1): a binary search per row in LDS finds where its range starts in every list, the sum of those positions is where its output starts.
 // (First version: splitters from 64 sampled records - eight samples per range: the slowest wave took twice the mean, profiles/r06/seed_phases.txt.)
-// Inside its range a wave runs hao_query4.cuh's step - smallest head target by one wave-min, ballots, forward hits then opposite-strand hits ranked by mbcnt,
-// one 16-byte store per hit at a running position - with heads and cursors in registers (2 per row, up to 24 rows per lane: reads with up to 1536 minimizers
+// Inside its range a wave steps bin by bin - the smallest (target, strand) key under any cursor by one wave-min, one ballot per 64 rows, the rows that stand on it
+// ranked by mbcnt, one 16-byte store per hit at a running position - with heads and cursors in registers (2 per row, up to 24 rows per lane: reads with up to 1536 minimizers
 // that have a list) and everything else read from LDS: no buffers to refill, an advance is a cursor increment and a 4-byte LDS read, the end of a list is a
 // sentinel record.  A row with several records of one target (a k-mer twice in a target) shows as "the next minimum equals T again" and the target is redone
 // by the general routine (runs per row, forward records in list order, opposite-strand records in reverse list order: anchor.cpp:1023).  Group entries
 // (target, first hit) go to a per-wave LDS list and are written out behind each other after the merge.
 //
-// Reads this kernel leaves to the table kernels (overflow list, as the merge kernel did): more than 1536 minimizers, more records than the LDS holds, more load
+// Reads this kernel leaves to the table kernels (overflow list): more than 1536 minimizers, more records than the LDS holds, more load
 // slots than the slot table, more than max_n hits (reads across repeat families: hundreds of targets, a step each), more than 96 groups in one wave's range.
 // HBM traffic per seed hit: 8 bytes in (once, coalesced), 16 bytes out.
 #pragma once
 #include <type_traits>
-#include "hao_query4.cuh"
+#include "hao_query3.cuh"
 
 #define HAO_L5_THREADS 512
 #define HAO_L5_W 8                    // waves per workgroup = target ranges per read
@@ -56,7 +56,7 @@ struct hao_rec2 { uint64_t a, b; };
 #ifndef HAO_L5_SCHED_FENCE
 #define HAO_L5_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
-#define HAO_L5_MASK 0xfffffffu
+#define HAO_L5_MASK 0xfffffffu      // the read id 2^28 - 1 is the merge's end mark: a read set that uses it (exactly 2^28 reads) takes the table kernels
 #define HAO_L5_SENT 0xffffffffu
 
 template<bool B16> struct hao_l5_lds {
@@ -66,6 +66,7 @@ template<bool B16> struct hao_l5_lds {
 	static constexpr uint32_t CAP = ((TOTAL - FIXED) / (B16 ? 6 : 8) - 8) & ~7u;      // record slots (records + one sentinel per row + the guard slot 0)
 };
 
+__device__ __forceinline__ uint32_t hao_mbcnt(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 __device__ __forceinline__ uint64_t hao_wave_incl_scan_u64(uint64_t v)
 {
 #define HAO_RED_STEP(CTRL, RM) { const uint32_t lo2 = (uint32_t)hao_dpp<CTRL, RM>(0, (int)(uint32_t)v), hi2 = (uint32_t)hao_dpp<CTRL, RM>(0, (int)(uint32_t)(v >> 32)); v += (uint64_t)hi2 << 32 | lo2; }

@@ -316,15 +316,16 @@ struct FtPassPred {      // occurrences of this pass: key (the hash, or its sub-
 #define HAO_FT_BYTES_PER_SLOT 20.0              // two 8-byte occurrence buffers + 25 % (the sort's scratch, the run lists); hifiasm_amd/memplan.py uses the same figures
 #define HAO_FT_BYTES_PER_SLOT_SHARDED 46.0
 #define HAO_FT_RUN_BYTES_PER_SLOT 3.0
+#define HAO_FT_BYTES_PER_SLOT_BLOOM 10.0        // on top, counting through the blocked Bloom filter (-f >= 21, the reference's default): hao_bloom_filter holds two 4-byte block ids and a flag per occurrence while both occurrence buffers live (+ its run table)
 #define HAO_FT_CHUNK_SLOTS (1ULL << 28)      // k-mer slots hashed per chunk of reads in pass mode (2 GB of scratch, twice)
 // passes needed so that the two occurrence buffers (+ 25 % for the sort's scratch and the run lists) fit into the free device memory; HAO_FT_PASSES forces a number (tests)
 // (sharded: a pass keeps its two buffers while the receive buffer and its sort twin of about the same size exist: four buffers of a P-th, DevBuf slack included)
-static uint64_t hao_ft_pass_count(hao_ctx *c, uint64_t n_slots, bool sharded)
+static uint64_t hao_ft_pass_count(hao_ctx *c, uint64_t n_slots, bool sharded, bool bloom)
 {
 	if (c->sw.ft_passes > 0) return (uint64_t)c->sw.ft_passes;
 	size_t fr = 0, tot = 0;
 	if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return 1; }
-	const double per_slot = sharded ? HAO_FT_BYTES_PER_SLOT_SHARDED : HAO_FT_BYTES_PER_SLOT;
+	const double per_slot = (sharded ? HAO_FT_BYTES_PER_SLOT_SHARDED : HAO_FT_BYTES_PER_SLOT) + (bloom ? HAO_FT_BYTES_PER_SLOT_BLOOM : 0.0);
 	const double need = per_slot * (double)n_slots + (double)(1ULL << 30), have = 0.9 * (double)fr;
 	if (need <= have) return 1;
 	// what the chunk scratch and the run lists of ALL passes leave (12 bytes per distinct k-mer, once more while a pass's runs are appended; one distinct k-mer per ~7
@@ -389,7 +390,7 @@ static int hao_ft_run(hao_ctx *c)
 	};
 	const int index_rc = local_index();
 	if (index_rc && !sharded) return index_rc;
-	P = index_rc ? 1 : hao_ft_pass_count(c, n_slots, sharded);
+	P = index_rc ? 1 : hao_ft_pass_count(c, n_slots, sharded, bloom);
 	if (sharded) {      // every rank runs the same number of passes (the exchanges are collective): the largest any rank needs; the status of the local work travels along
 		hao_comm &cm = *c->comm;
 		if (int rc = hao_shard_layout_check(c, cm, index_rc)) return rc;

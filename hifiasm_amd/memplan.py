@@ -4,7 +4,8 @@ BASELINE.json's configs[3] / configs[4] against the 288 GB of an MI355X with it;
 
 Per-unit figures (bytes) and where they come from:
   reads            0.25 / base + 1 / read + 4 / read (lengths of ALL reads, replicated)     hao_set_reads, hao_set_shard
-  ft, one pass     20 / k-mer slot (two 8-byte occurrence buffers + 25 %: sort scratch)     hao_tables.hpp HAO_FT_BYTES_PER_SLOT; sharded 46 (+ receive buffer and twin)
+  ft, one pass     20 / k-mer slot (two 8-byte occurrence buffers + 25 %: sort scratch)     hao_tables.hpp HAO_FT_BYTES_PER_SLOT; sharded 46 (+ receive buffer and twin);
+                   + 10 through the Bloom filter (two block ids and a flag per occurrence)   HAO_FT_BYTES_PER_SLOT_BLOOM, hao_bloom_filter
   ft, P passes     the above / P + 2 x 8 x 2^28 (the read-chunk scratch)                    hao_ft_run, local_hashes
   ft, run lists    44 / distinct k-mer of the rank's hash range (keys 8 + counts 4, once     hao_sort_rle_hist, hao_keep_runs (flag, position, start: 3 x 8)
                    more while a pass's runs are appended)
@@ -17,13 +18,13 @@ Minimizer and seed-hit densities are the REFERENCE's on the full-size fixtures (
 from __future__ import annotations
 
 HBM_BYTES = 288e9
-FT_PER_SLOT, FT_PER_SLOT_SHARDED, FT_RUN_PER_SLOT, FT_CHUNK_SLOTS = 20.0, 46.0, 3.0, 1 << 28
+FT_PER_SLOT, FT_PER_SLOT_SHARDED, FT_RUN_PER_SLOT, FT_CHUNK_SLOTS, FT_PER_SLOT_BLOOM = 20.0, 46.0, 3.0, 1 << 28, 10.0
 
 
-def ft_passes(slots: float, free_bytes: float, sharded: bool) -> int:
+def ft_passes(slots: float, free_bytes: float, sharded: bool, bloom: bool = False) -> int:
     """hao_ft_pass_count (hao_tables.hpp) for `slots` k-mer slots of local reads and `free_bytes` of free device memory"""
     import math
-    per = FT_PER_SLOT_SHARDED if sharded else FT_PER_SLOT
+    per = (FT_PER_SLOT_SHARDED if sharded else FT_PER_SLOT) + (FT_PER_SLOT_BLOOM if bloom else 0.0)
     have = 0.9 * free_bytes
     if per * slots + (1 << 30) <= have:
         return 1
@@ -41,8 +42,8 @@ def rank_plan(total_bases: float, n_reads: float, world: int, mz_per_base: float
     novel = total_bases * (1.0 - (1.0 - err) ** k)
     distinct = (1.1 * genome if bloom else genome + novel) / world
     free_ft = HBM_BYTES - reads
-    p = ft_passes(b_loc, free_ft, world > 1)
-    per = FT_PER_SLOT_SHARDED if world > 1 else FT_PER_SLOT
+    p = ft_passes(b_loc, free_ft, world > 1, bloom)
+    per = (FT_PER_SLOT_SHARDED if world > 1 else FT_PER_SLOT) + (FT_PER_SLOT_BLOOM if bloom else 0.0)
     ft_count = reads + per * b_loc / p + (2 * 8 * FT_CHUNK_SLOTS if p > 1 else 0) + 12 * distinct * (1 + (1.0 / p if p > 1 else 0))      # a pass's buffers + the run lists so far
     ft_keep = reads + 12 * distinct + 24 * distinct                                                                                        # the threshold pass over the complete run list
     ft = max(ft_count, ft_keep)

@@ -1,10 +1,14 @@
-"""TEST INFRASTRUCTURE: per-read digests of the oracle's results for the random workloads of tests/simt_fuzz.py whose oracle run is too long for the GPU suite (repeat-dense
-genomes: groups of thousands of seed hits through the chain DP - minutes on a CPU core).  `python tests/golden/make_fuzz_golden.py OUT.npz SEED` writes one seed's arrays
-(coverage peaks, per read: crc32 of the sketch, digest of the seed hits, digest of (ol, fake cigars, chained hits) - helpers.digest_hits / digest_result);
-`python tests/golden/make_fuzz_golden.py --merge DIR OUT.npz` folds the per-seed files into tests/golden/fuzz_heavy.npz.  tests/test_gpu_fuzz.py compares libhao.so's
-results with them."""
+"""TEST INFRASTRUCTURE: tests/golden/fuzz_heavy.npz - per-read digests of the REAL reference's results (oracle/_ref/ref_harness --digest: the unmodified hifiasm
+sources compiled from /root/reference) for the random workloads of tests/simt_fuzz.py whose restatement run is too long for the GPU suite (repeat-dense genomes:
+groups of thousands of seed hits through the chain DP).  Per seed: the coverage peaks, and per read the crc32 of its minimizers, the digest of its seed hits and the
+digest of (ol, fake cigars, chained hits) - the definitions of helpers.digest_hits / digest_result = hao_batch_digest (include/hao.h).  tests/test_gpu_fuzz.py
+compares libhao.so's results with them; tests/test_fuzz_ref_cpu.py recomputes a few.  (Round 5's file came from the C restatement; the reference gives the same
+arrays for all 68 seeds.)
+
+    python tests/golden/make_fuzz_golden.py [WORKERS]        (build container only; the slowest case takes five minutes of the reference)"""
 import os
 import sys
+from concurrent.futures import ProcessPoolExecutor
 
 import numpy as np
 
@@ -13,28 +17,18 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def one(seed):
-    import simt_fuzz
-    import oracle_py
-    from helpers import crc, digest_hits, digest_result
-    rs, d, okw = simt_fuzz.reads_of(seed)
-    o = oracle_py.Oracle(rs.codes, rs.code_off, **okw)
-    ft = o.ft_gen(); hom = o.pt_gen(); het = o.stats()["het_cov"]
-    sk = np.zeros(rs.n, dtype=np.uint32); hd = np.zeros(rs.n, dtype=np.uint64); rd = np.zeros(rs.n, dtype=np.uint64); tot = 0
-    for r in range(rs.n):
-        sk[r] = crc(o.sketch(r)); hd[r] = digest_hits(o.seed_hits(r))
-        ol, fc, fo, cl = o.lchain(r); rd[r] = digest_result(ol, fc, cl); tot += ol.shape[0]
-    return dict(peaks=np.array([ft, hom, het, rs.n, tot], dtype=np.int64), sketch=sk, hits=hd, result=rd)
+    import ref_fuzz
+    return seed, ref_fuzz.digests(seed, threads=2)
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "--merge":
-        out = {}
-        for f in sorted(os.listdir(sys.argv[2])):
-            if f.endswith(".npz"):
-                z = np.load(os.path.join(sys.argv[2], f))
-                for k in z.files:
-                    out[f"s{f[:-4]}_{k}"] = z[k]
-        np.savez_compressed(sys.argv[3], **out)
-        print(len(out) // 4, "seeds ->", sys.argv[3])
-    else:
-        np.savez(sys.argv[1], **one(int(sys.argv[2])))
+    import test_gpu_fuzz
+    out = {}
+    with ProcessPoolExecutor(int(sys.argv[1]) if len(sys.argv) > 1 else 6) as ex:
+        for seed, g in ex.map(one, test_gpu_fuzz.HEAVY):
+            for k, v in g.items():
+                out[f"s{seed}_{k}"] = v
+            print("seed", seed, "reads", int(g["peaks"][3]), "overlaps", int(g["peaks"][4]), flush=True)
+    path = os.path.join(ROOT, "tests", "golden", "fuzz_heavy.npz")
+    np.savez_compressed(path, **out)
+    print(len(out) // 4, "seeds ->", path)

@@ -3,7 +3,6 @@
 // seed_segments_kernel, then the three tiers: 512 slots for every read, 1024 and 2048 slots for the reads that overflowed).  Called by tests/test_simt_seed_cpu.py
 // only, which compares the hits and the group lists with the oracle's restatement of minimizers_qgen0.
 #include "hao_query3.cuh"
-#include "hao_query4.cuh"
 #include "hao_query5.cuh"
 #include <execinfo.h>
 #include <signal.h>
@@ -16,12 +15,9 @@ struct Sim {
 int fail(char *err, int cap, const std::string &m) { snprintf(err, cap, "%s", m.c_str()); return 1; }
 }
 
-// mode 0: what the library launches by default (QL instances; overflowing reads through seed_bin3_kernel); 1: HAO_SEED_NODIRECT (all tiers seed_bin_kernel, QL);
+// mode 0: the table kernels as the library launches them (QL instances; overflowing reads through seed_bin3_kernel);
 // 2: HAO_SEED_NOQL (per-minimizer tables possibly in global memory: qcap_force > 0 caps the LDS table to force that path)
-// 3 / 4 / 5 / 6: the merge kernel (hao_query4.cuh; 8 / 2 rows per lane reading one record at a time, 8 / 2 rows per lane reading four) takes every chosen read first; the reads it leaves (more rows than it holds) go through the table kernels as in mode 0
-// 11: 8 rows per lane, ALIGNED 32-byte list reads
-// 7: 8 rows per lane, four records per read, every read of the set in LOCUS order (seed_locus_kernel + sort + the per-XCD mapping of the order list)
-// (stats[6] = reads left by the merge kernel)
+// 12 / 13: the list-major kernel (hao_query5.cuh) takes every read first; the reads it leaves go through the table kernels as in mode 0 (stats[6] = reads it left)
 // blocks: the reads to run in the first launch (others keep empty output); returns 0 or 1 with a message
 extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t *mz_info, const uint64_t *lk, const uint32_t *wgt, const uint64_t *sinfo, const uint32_t *len, uint64_t n_total,
 		int mode, uint32_t qcap_force, const uint32_t *blocks, uint32_t n_blocks, int want_hq,
@@ -50,7 +46,7 @@ extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t 
 	unsigned long long ovf_cnt[2] = {0, 0}; uint32_t *ovf1 = S.ovf.data(), *ovf2 = S.ovf.data() + (n + 1);
 	const size_t lds_tile = std::max<size_t>((size_t)512 * (sizeof(hao_stage_t) + 4), 12 * 512), lds_q = 12 * (size_t)sa.qcap + 16;
 	size_t lds1 = (size_t)22 * 512 + lds_tile + lds_q, lds2 = (size_t)22 * 1024 + std::max<size_t>(lds_tile, 12 * 1024) + lds_q, lds3 = (size_t)22 * 2048 + std::max<size_t>(lds_tile, 12 * 2048) + lds_q;
-	if (mode == 0 || mode >= 3) { lds2 = hao_seed3_lds<10>::FIXED + lds_q; lds3 = hao_seed3_lds<11>::FIXED + lds_q; }
+	if (mode == 0 || mode >= 12) { lds2 = hao_seed3_lds<10>::FIXED + lds_q; lds3 = hao_seed3_lds<11>::FIXED + lds_q; }
 	const uint32_t *nil32 = nullptr; const unsigned long long *nil64 = nullptr;
 	std::vector<uint32_t> ovf0(n + 4, 0); unsigned long long ovf0_cnt = 0;
 	const uint32_t max_n = getenv("SIMT_SEED_MAXN") ? (uint32_t)atoi(getenv("SIMT_SEED_MAXN")) : 0xffffffffu;      // reads with more seed hits go to the table kernels
@@ -71,61 +67,8 @@ extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t 
 			if (launch((unsigned)ovf0_cnt, 256, lds1, call)) return fail(err, errcap, hao_simt::g.error);
 		}
 	}
-	else if (mode == 7) {      // the merge kernel in locus order: key per read, the reads sorted by key, an eighth of the sorted list per "XCD" (blocks b, b + 8, ...); every read runs
-		std::vector<uint64_t> key(n + 1, 0); std::vector<uint32_t> idx(n + 1, 0);
-		if (launch((unsigned)((n + 3) / 4), 256, 0, [&] { seed_locus_kernel(sa, sinfo, 64u, key.data(), idx.data()); })) return fail(err, errcap, hao_simt::g.error);
-		std::vector<uint32_t> ord(idx.begin(), idx.begin() + n);
-		std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
-		for (uint64_t i = 0; i + 1 < n; ++i) if (key[ord[i]] > key[ord[i + 1]]) return fail(err, errcap, "locus order not sorted");
-		const unsigned nwg = (unsigned)(((n + 3) / 4 + 7) / 8 * 8);
-		if (launch(nwg, 256, hao_seed4_lds<8>::TOTAL, [&] { seed_merge_kernel<8, 4>(sa, sinfo, len, ord.data(), max_n, ovf0.data(), &ovf0_cnt); })) return fail(err, errcap, hao_simt::g.error);
-		stats[6] = ovf0_cnt; stats[7] = key[ord[0]];
-		if (ovf0_cnt) {
-			std::function<void()> call = [&] { seed_bin_kernel<9, 1, 512, true>(sa, ovf0.data(), &ovf0_cnt, ovf1, &ovf_cnt[0]); };
-			if (launch((unsigned)ovf0_cnt, 256, lds1, call)) return fail(err, errcap, hao_simt::g.error);
-		}
-	}
-	else if (mode >= 8 && mode <= 10) {      // the four-wave merge kernel: a workgroup per read (mode 8: 2 rows per lane, 32-byte reads; 9: 1 row per lane, 8-byte reads: more reads overflow; 10: 2 rows per lane, aligned 64-byte reads)
-		std::vector<char> chosen(n + 4, 0); for (uint32_t b = 0; b < n_blocks; ++b) chosen[blocks[b]] = 1;
-		for (uint64_t g = 0; g < n; ++g) {
-			if (!chosen[g]) continue;
-			std::function<void()> call;
-			if (mode == 8) call = [&] { seed_mergew_kernel<2, 4>(sa, sinfo, len, nil32, max_n, ovf0.data(), &ovf0_cnt); };
-			else if (mode == 10) call = [&] { seed_mergew_kernel<2, 8>(sa, sinfo, len, nil32, max_n, ovf0.data(), &ovf0_cnt); };
-			else call = [&] { seed_mergew_kernel<1, 1>(sa, sinfo, len, nil32, max_n, ovf0.data(), &ovf0_cnt); };
-			hao_simt::g.body = call; hao_simt::g.nthreads = 256; hao_simt::g.error.clear(); hao_simt::g.dyn_lds.assign((mode != 9 ? hao_seed4w_lds<2>::TOTAL : hao_seed4w_lds<1>::TOTAL) + 64, (char)0xa5);
-			blockDim = {256, 1, 1}; gridDim = {(unsigned)n, 1, 1}; blockIdx = {(unsigned)g, 0, 0};
-			if (!hao_simt::run_block()) return fail(err, errcap, hao_simt::g.error);
-		}
-		stats[6] = ovf0_cnt;
-		if (ovf0_cnt) {
-			std::function<void()> call = [&] { seed_bin_kernel<9, 1, 512, true>(sa, ovf0.data(), &ovf0_cnt, ovf1, &ovf_cnt[0]); };
-			if (launch((unsigned)ovf0_cnt, 256, lds1, call)) return fail(err, errcap, hao_simt::g.error);
-		}
-	}
-	else if (mode >= 3) {      // the merge kernel: a wave per read (four reads per block); only the chosen reads' blocks run, and of those only the chosen waves' output is kept clean below
-		std::vector<char> chosen(n + 4, 0); for (uint32_t b = 0; b < n_blocks; ++b) chosen[blocks[b]] = 1;
-		const size_t ldsm = (mode == 3 || mode == 5 || mode == 11) ? hao_seed4_lds<8>::TOTAL : hao_seed4_lds<2>::TOTAL;
-		for (uint64_t g = 0; g < (n + 3) / 4; ++g) {
-			if (!(chosen[4 * g] | chosen[4 * g + 1] | chosen[4 * g + 2] | chosen[4 * g + 3])) continue;
-			std::function<void()> call;
-			if (mode == 3) call = [&] { seed_merge_kernel<8, 1>(sa, sinfo, len, nil32, max_n, ovf0.data(), &ovf0_cnt); };
-			else if (mode == 4) call = [&] { seed_merge_kernel<2, 1>(sa, sinfo, len, nil32, max_n, ovf0.data(), &ovf0_cnt); };
-			else if (mode == 5) call = [&] { seed_merge_kernel<8, 4>(sa, sinfo, len, nil32, max_n, ovf0.data(), &ovf0_cnt); };
-			else if (mode == 11) call = [&] { seed_merge_kernel<8, 4, true>(sa, sinfo, len, nil32, max_n, ovf0.data(), &ovf0_cnt); };
-			else call = [&] { seed_merge_kernel<2, 4>(sa, sinfo, len, nil32, max_n, ovf0.data(), &ovf0_cnt); };
-			hao_simt::g.body = call; hao_simt::g.nthreads = 256; hao_simt::g.error.clear(); hao_simt::g.dyn_lds.assign(ldsm + 64, (char)0xa5);
-			blockDim = {256, 1, 1}; gridDim = {(unsigned)((n + 3) / 4), 1, 1}; blockIdx = {(unsigned)g, 0, 0};
-			if (!hao_simt::run_block()) return fail(err, errcap, hao_simt::g.error);
-		}
-		stats[6] = ovf0_cnt;
-		if (ovf0_cnt) {
-			std::function<void()> call = [&] { seed_bin_kernel<9, 1, 512, true>(sa, ovf0.data(), &ovf0_cnt, ovf1, &ovf_cnt[0]); };
-			if (launch((unsigned)ovf0_cnt, 256, lds1, call)) return fail(err, errcap, hao_simt::g.error);
-		}
-	}
 	// first launch: the chosen reads only (a block per read; blockIdx.x = the read)
-	if (mode < 3) {
+	if (mode < 12) {
 		hao_simt::g.body = nullptr;
 		for (uint32_t b = 0; b < n_blocks; ++b) {
 			std::function<void()> call;
@@ -139,16 +82,14 @@ extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t 
 	stats[2] = ovf_cnt[0];
 	if (ovf_cnt[0]) {
 		std::function<void()> call;
-		if (mode == 0 || mode >= 3) call = [&] { seed_bin3_kernel<10, 1, 4>(sa, ovf1, &ovf_cnt[0], ovf2, &ovf_cnt[1]); };
-		else if (mode == 1) call = [&] { seed_bin_kernel<10, 1, 512, true>(sa, ovf1, &ovf_cnt[0], ovf2, &ovf_cnt[1]); };
+		if (mode == 0 || mode >= 12) call = [&] { seed_bin3_kernel<10, 1, 4>(sa, ovf1, &ovf_cnt[0], ovf2, &ovf_cnt[1]); };
 		else call = [&] { seed_bin_kernel<10, 1, 512, false>(sa, ovf1, &ovf_cnt[0], ovf2, &ovf_cnt[1]); };
 		if (launch((unsigned)ovf_cnt[0], 256, lds2, call)) return fail(err, errcap, hao_simt::g.error);
 	}
 	stats[3] = ovf_cnt[1];
 	if (ovf_cnt[1]) {
 		std::function<void()> call;
-		if (mode == 0 || mode >= 3) call = [&] { seed_bin3_kernel<11, 2, 4>(sa, ovf2, &ovf_cnt[1], (uint32_t*)nullptr, (unsigned long long*)nullptr); };
-		else if (mode == 1) call = [&] { seed_bin_kernel<11, 2, 512, true>(sa, ovf2, &ovf_cnt[1], (uint32_t*)nullptr, (unsigned long long*)nullptr); };
+		if (mode == 0 || mode >= 12) call = [&] { seed_bin3_kernel<11, 2, 4>(sa, ovf2, &ovf_cnt[1], (uint32_t*)nullptr, (unsigned long long*)nullptr); };
 		else call = [&] { seed_bin_kernel<11, 2, 512, false>(sa, ovf2, &ovf_cnt[1], (uint32_t*)nullptr, (unsigned long long*)nullptr); };
 		if (launch((unsigned)ovf_cnt[1], 256, lds3, call)) return fail(err, errcap, hao_simt::g.error);
 	}

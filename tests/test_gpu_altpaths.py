@@ -1,7 +1,7 @@
 """Every implementation variant that libhao.so can be switched to at run time (A/B switches kept for measurements, and the fallbacks behind
 them) must give the oracle's result: one-lane sequential chaining instead of the wave kernels, DP without speculative tiles, the one-lane DP
 tail, DP kernels on the main stream, one-wave selection for every size, the one-lane pruning scan, the generic (any w, k) sketch kernel,
-the sketch retry after an under-sized minimizer list, and the seed kernel's larger staged tile."""
+the sketch retry after an under-sized minimizer list, and the seed stage's table kernels / list-major kernel on every batch."""
 import os
 
 import pytest
@@ -11,12 +11,12 @@ from helpers import scenario_reads, scenario_oracle
 pytestmark = pytest.mark.gpu
 
 SWITCHES = ["HAO_DBG_SEQ_CHAIN", "HAO_DBG_DP_NOSPEC", "HAO_DBG_DP_SEQTAIL", "HAO_DBG_DP_SERIAL", "HAO_DBG_SEL1", "HAO_DBG_SEQ_PRUNE",
-            "HAO_DBG_SK_GENERIC", "HAO_DBG_SK_GCAP", "HAO_SPEC_MINCLS", "HAO_CHAIN_WPB", "HAO_SEED_TILE", "HAO_DBG_TINY_LANE",
-            "HAO_SEED_V2", "HAO_SEED_NOQL", "HAO_SEED_MERGE=0,HAO_SEED_NODIRECT=1", "HAO_SEED_MERGE=0,HAO_SEED_NU=8", "HAO_PT_SORT64", "HAO_PT_DIRECT",
-            "HAO_SEED_MERGE=0", "HAO_SEED_MERGE=4", "HAO_SEED_MBUF=1", "HAO_SEED_LOCUS=1", "HAO_SEED_LOCUS=2", "HAO_SEED_MALIGN=1", "HAO_SEED_MERGE_AVG=1000000", "HAO_SEED_MERGE_AVG=1000", "HAO_SEED_MERGE_QAVG=50", "HAO_SEED_MERGE_MAXN=3000", "HAO_SEED_MERGE_MAXN=1000000",
-            "HAO_SEED_MERGEW=2", "HAO_SEED_MERGEW=4", "HAO_SEED_MERGEW=2,HAO_SEED_MBUF=1", "HAO_SEED_MERGEW=2,HAO_SEED_MBUF=8", "HAO_SEED_MERGEW=2,HAO_SEED_LOCUS=1"]      # (the table kernels for every read - rounds 1 - 4; the one-wave merge kernel with 8 / 4 rows per lane - with 4 most reads of these sets overflow to the table kernels - and 8-byte list reads; locus order; the seed-hit limit above which a read goes to the table kernels;
-# the four-wave kernel with 2 / 4 rows per lane, 8-byte and aligned 64-byte reads)
-VALUES = {"HAO_DBG_SK_GCAP": "1000", "HAO_SPEC_MINCLS": "0", "HAO_CHAIN_WPB": "4", "HAO_SEED_TILE": "1024"}
+            "HAO_DBG_SK_GENERIC", "HAO_DBG_SK_GCAP", "HAO_SPEC_MINCLS", "HAO_CHAIN_WPB", "HAO_DBG_TINY_LANE",
+            "HAO_SEED_NOQL", "HAO_PT_SORT64", "HAO_PT_DIRECT",
+            "HAO_SEED_LDS=0", "HAO_SEED_MERGE_AVG=1000000", "HAO_SEED_MERGE_AVG=1000", "HAO_SEED_MERGE_MAXN=3000", "HAO_SEED_MERGE_MAXN=1000000"]
+# (the seed stage: the table kernels for every read; the list-major kernel for every batch however many hits its reads average - these sets are repeat-rich - and the
+# seed-hit limit above which it leaves a read to the table kernels)
+VALUES = {"HAO_DBG_SK_GCAP": "1000", "HAO_SPEC_MINCLS": "0", "HAO_CHAIN_WPB": "4"}
 
 
 def _env_of(switch):

@@ -37,3 +37,25 @@ def test_grid_pairs_generated_and_aligned_on_the_device(name, window, thre):
         print(f"[ed grid] {name} window {window} thre {thre}: {n} pairs, {int((want_r[:, 0] != NOALN).sum())} within the threshold, call {dt * 1e3:.2f} ms (generation + alignment, nothing crosses the host)")
     finally:
         e.close()
+
+
+def test_grid_results_are_gone_after_the_scratch_is_reused():
+    """hao_fetch_ed_grid after another window-alignment call or a new batch has taken the scratch: an error, not somebody else's tasks"""
+    from hifiasm_amd.api import Engine
+    rs, okw = scenario_reads("hifi")
+    e = Engine(0, **okw)
+    try:
+        e.set_readset(rs); e.ha_ft_gen(); e.ha_pt_gen()
+        e.overlap_batch(0, rs.n)
+        n = e.window_ed_grid(375, 15)
+        t, r = e.fetch_ed_grid(n)
+        assert n > 200 and t.shape[0] == n
+        e.window_ed_batch(t[:50])                      # the upload path reuses the task / result buffers
+        with pytest.raises(Exception):
+            e.fetch_ed_grid(n)
+        assert e.window_ed_grid(375, 15) == n
+        e.overlap_batch(3, rs.n - 3)                   # a new batch: the grid belongs to the old one's overlaps
+        with pytest.raises(Exception):
+            e.fetch_ed_grid(n)
+    finally:
+        e.close()
