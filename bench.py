@@ -35,10 +35,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from hifiasm_amd.workloads import WORKLOADS, n_reads_of  # noqa: E402
+from hifiasm_amd.workloads import WORKLOADS, LEN_JIT, n_reads_of  # noqa: E402
 
 STRONG = {"human3G_hifi40x", "ont_human_30x"}      # fixed-size problems: the read set is split over the ranks
 VARIANT_OF = {"chr1_250M_hifi30x": "chr1_250M_hifi30x_repeat", "bacterial5M_hifi30x": "bacterial5M_hifi30x_repeat"}      # the repeat-rich twin of a workload
+JITTER_OF = {"chr1_250M_hifi30x": "chr1_250M_hifi30x_jitter"}      # the same bases in reads of 8 - 25 kb (uniform): the timed numbers of the headline workload see reads that are all exactly 15 000 bases
 # algorithmic bytes per unit (stated again in DESIGN.md 4)
 ALG = {
     "sketch_unit_kernel": ("base", 0.25 + 16.0 / 35.0),             # 2-bit bases in + one 16-B minimizer per ~35 bases out
@@ -65,7 +66,7 @@ def make_reads(workload, rank=0, world=1):
         genome = synth.make_genome(g * world, seed=GENOME_SEED, repeat_rich=rr)
         n = n_reads_of(workload)
         lo, hi = rank * n, (rank + 1) * n
-    return synth.make_reads(genome, hi - lo, L, err, seed=READ_SEED, rid0=lo, want_codes=False), ont
+    return synth.make_reads(genome, hi - lo, L, err, seed=READ_SEED, rid0=lo, len_jit=LEN_JIT.get(workload, 0), want_codes=False), ont
 
 
 def cpu_baseline(workload, mode="sample", threads=None):
@@ -88,7 +89,7 @@ def cpu_baseline(workload, mode="sample", threads=None):
         d = tempfile.mkdtemp(prefix="hao_cpu_", dir=base)
         try:
             fa = os.path.join(d, "r.fq" if ont else "r.fa")
-            synth.write_fasta_stream(fa, genome, n, L, err, seed=READ_SEED, fastq=bool(ont))
+            synth.write_fasta_stream(fa, genome, n, L, err, seed=READ_SEED, len_jit=LEN_JIT.get(workload, 0), fastq=bool(ont))
             cmd = [harness, "-t", str(cores), "--time"] + (["--ont"] if ont else []) + [fa]
             r = subprocess.run(cmd, capture_output=True, text=True, cwd=d)
             j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -484,6 +485,10 @@ def main():
         if var and world == 1 and not a.no_variants:
             v = run_workload(a, var, max(1, min(a.steps, a.variant_steps)), min(a.warmup, 1), rank, local_rank, world, dist, torch, force_sharded)
             out["variants"] = {"repeat_rich": {k: v[k] for k in ("value", "ms_per_step", "value_resident", "ms_per_step_resident", "steps", "warmup", "roofline", "stage_ms", "config", "boundary")}}
+        jit = JITTER_OF.get(a.workload)
+        if jit and world == 1 and not a.no_variants:
+            v = run_workload(a, jit, max(1, min(a.steps, a.variant_steps)), min(a.warmup, 1), rank, local_rank, world, dist, torch, force_sharded)
+            out["variants"] = dict(out["variants"] or {}, length_jitter={k: v[k] for k in ("value", "ms_per_step", "value_resident", "ms_per_step_resident", "steps", "warmup", "roofline", "stage_ms", "config", "boundary")})
         if metric_var is not None:
             out["variants"] = dict(out["variants"] or {}, metric_config=metric_var)
         if world > 1:      # what one rank holds, phase by phase (launcher-side arithmetic from the allocation sites' sizes: hifiasm_amd/memplan.py)

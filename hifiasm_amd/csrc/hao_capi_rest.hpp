@@ -31,6 +31,7 @@ int hao_ft_gen(hao_ctx *c, int32_t *hom_cov)
 	c->timer.begin(c->stream);
 	int rc = hao_ft_run(c);
 	if (rc != HAO_OK) return rc;
+	c->timer.mark("ft_release");      // (hao_ft_run's buffers are gone: host_ft_release = what freeing them took)
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	c->timer.collect(c->stage_ms);
 	if (hom_cov) *hom_cov = c->ft_peak_hom;

@@ -1,5 +1,6 @@
 // Engine context: device buffers, stream, stage timers (host side of libhao.so).
 #pragma once
+#include <time.h>
 #include <rocprim/rocprim.hpp>
 #include <map>
 #include <algorithm>
@@ -37,12 +38,13 @@ template<typename T> struct DevBuf {
 };
 
 struct StageTimer {
-	std::vector<std::string> names; std::vector<hipEvent_t> ev; hipStream_t st = nullptr;
-	void begin(hipStream_t s) { st = s; names.clear(); mark("__begin"); }
+	std::vector<std::string> names; std::vector<hipEvent_t> ev; std::vector<double> host_t; hipStream_t st = nullptr;
+	static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+	void begin(hipStream_t s) { st = s; names.clear(); host_t.clear(); mark("__begin"); }
 	void mark(const char *name) {
 		size_t i = names.size();
 		if (i >= ev.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev.push_back(e); }
-		names.push_back(name); (void)hipEventRecord(ev[i], st);
+		names.push_back(name); host_t.push_back(now()); (void)hipEventRecord(ev[i], st);
 		static const bool dbg_sync = getenv("HAO_DBG_SYNC") != nullptr;      // localise a device fault: wait for the stage and say its name
 		if (dbg_sync) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[stage] %s: %s\n", name, hipGetErrorString(e)); fflush(stderr); }
 	}
@@ -50,6 +52,8 @@ struct StageTimer {
 	void collect(std::vector<std::pair<std::string, float> > &out) {
 		out.clear();
 		for (size_t i = 1; i < names.size(); ++i) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[i - 1], ev[i]); out.push_back(std::make_pair(names[i], ms)); }
+		// the HOST's wall clock between the same marks for ha_ft_gen's stages ("host_ft_..."): its wall time is allocation, scratch and per-read host loops, not kernels
+		for (size_t i = 1; i < names.size(); ++i) if (names[i].compare(0, 3, "ft_") == 0) out.push_back(std::make_pair("host_" + names[i], (float)((host_t[i] - host_t[i - 1]) * 1e3)));
 	}
 	~StageTimer() { for (auto e : ev) (void)hipEventDestroy(e); }
 };

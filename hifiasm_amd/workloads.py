@@ -14,11 +14,13 @@ WORKLOADS = {
     "chr2M_hifi30x": (2_000_000, 30, 15000, 0.001, 0, 0),                  # stand-in for configs[0] (chr11-2M.fa.gz is not in the image)
     "chr1_250M_hifi30x": (250_000_000, 30, 15000, 0.001, 0, 0),            # configs[2]: the largest single-GPU configuration
     "chr1_250M_hifi30x_repeat": (250_000_000, 30, 15000, 0.001, 1, 0),     # configs[2] with the SURVEY 8d repeat recipe (125 units: half of the genome sits in 25-copy families)
+    "chr1_250M_hifi30x_jitter": (250_000_000, 30, 16500, 0.001, 0, 0),     # configs[2] with read lengths uniform in 8 - 25 kb (LEN_JIT below): the same bases in reads that are not all alike
     "human3G_hifi40x": (3_000_000_000, 40, 15000, 0.001, 0, 0),            # configs[3]: 8 M reads of 15 kb, sharded over 8 GPUs
     "ont5M_30x": (5_000_000, 30, 30000, 0.01, 0, 1),
     "ont50M_30x": (50_000_000, 30, 30000, 0.01, 0, 1),                     # 50 000 ONT reads: the full-size parity case of --ont mode
     "ont_human_30x": (3_000_000_000, 30, 30000, 0.01, 0, 1),               # configs[4]: 3 M reads of 30 kb, --ont
 }
+LEN_JIT = {"chr1_250M_hifi30x_jitter": 8500}      # +- uniform jitter on the read length (workloads not listed: every read exactly read_len bases)
 GENOME_SEED, READ_SEED = 11, 12
 
 
@@ -33,4 +35,4 @@ def workload_reads(name: str, lo: int = 0, hi: int | None = None, want_codes: bo
     if genome is None:
         genome = synth.make_genome(g, seed=GENOME_SEED, repeat_rich=rr)
     hi = n_reads_of(name) if hi is None else hi
-    return synth.make_reads(genome, hi - lo, L, err, seed=READ_SEED, rid0=lo, want_codes=want_codes)
+    return synth.make_reads(genome, hi - lo, L, err, seed=READ_SEED, rid0=lo, len_jit=LEN_JIT.get(name, 0), want_codes=want_codes)

@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from hifiasm_amd import synth  # noqa: E402
-from hifiasm_amd.workloads import WORKLOADS, workload_reads  # noqa: E402
+from hifiasm_amd.workloads import WORKLOADS, LEN_JIT, workload_reads  # noqa: E402
 from helpers import fold_digests  # noqa: E402
 import oracle_py  # noqa: E402
 
@@ -45,7 +45,7 @@ def main():
     n_reads = max(1, int(round(g * cov / L)))
     d = tempfile.mkdtemp(prefix="hao_goldbig_", dir=os.environ.get("HAO_TMP", "/tmp"))
     fa = os.path.join(d, "r.fq" if ont else "r.fa")
-    synth.write_fasta_stream(fa, genome, n_reads, L, err, seed=12, fastq=bool(ont))
+    synth.write_fasta_stream(fa, genome, n_reads, L, err, seed=12, len_jit=LEN_JIT.get(name, 0), fastq=bool(ont))
     step = max(1, n_reads // n_sample)
     sample = np.arange(step // 2, n_reads, step, dtype=np.uint64)[:n_sample]
     with open(os.path.join(d, "list.txt"), "w") as fp:

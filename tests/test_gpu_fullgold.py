@@ -6,6 +6,8 @@ unmodified hifiasm on the same reads, tests/golden/make_golden_big.py):
   * chr1_250M_hifi30x at -f37 (the reference's default Bloom filter, 28-bit block ids): the all-k-mer histogram, its peak and the filter table
     of ha_ft_gen's per-block replay on 5.6 G k-mer occurrences, then the same thresholds and a slice of the pass;
   * chr1_250M_hifi30x_repeat: configs[2] with the SURVEY 8d repeat recipe (half of the genome in 25-copy families + tandem arrays): the realistic case;
+  * chr1_250M_hifi30x_jitter (round 6): configs[2]'s bases in reads of 8 - 25 kb (uniform): reads that are not all alike - up to 720 minimizers and 20 000 seed
+    hits per read through the list-major seed kernel, the longest ones through its hand-over to the table kernels;
   * ont50M_30x / ont5M_30x (--ont mode: 30 kb reads at 1 % error, bw 0.05: the chain DP path) and bacterial5M_hifi30x_repeat (repeat families +
     tandem arrays: filter table, minimizer thinning, max_n_chain pruning).
 
@@ -27,12 +29,13 @@ pytestmark = pytest.mark.gpu
 CASES = {
     "chr1": ("chr1_250M_hifi30x", "", {}, (32_000, 62_500)),
     "chr1rr": ("chr1_250M_hifi30x_repeat", "", {}, (40_000,)),
+    "chr1jit": ("chr1_250M_hifi30x_jitter", "", {}, (56_000,)),
     "ont50M": ("ont50M_30x", "", {"is_ont": 1}, (12_500,)),
     "ont5M": ("ont5M_30x", "", {"is_ont": 1}, (5_000,)),
     "repeat5M": ("bacterial5M_hifi30x_repeat", "", {}, (10_000, 3_333)),
 }
 # batch size of the STREAMING pass (hao_overlap_batch_async): what bench.py runs - ~8e8 seed hits per batch, a pass that fits one batch cut in two
-STREAM_BATCH = {"chr1": 62_500, "chr1rr": 40_000, "ont50M": 25_000, "ont5M": 2_500, "repeat5M": 5_000}
+STREAM_BATCH = {"chr1": 62_500, "chr1rr": 40_000, "chr1jit": 76_000, "ont50M": 25_000, "ont5M": 2_500, "repeat5M": 5_000}
 _READS = {}
 
 
