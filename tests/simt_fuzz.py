@@ -29,7 +29,7 @@ def case(seed):
     if rng.random() < 0.25:
         o["bw_thres"] = float(rng.choice([0.001, 0.02, 0.2]))
     if rng.random() < 0.2:
-        o["hg_size"] = int(d["genome_size"] * float(rng.choice([0.5, 1.0, 2.0])))
+        o["hg_size"] = max(1000, int(d["genome_size"] * float(rng.choice([0.5, 1.0, 2.0]))) // 1000 * 1000)      # (a multiple of 1000: the reference's --hg-size only parses k / m / g suffixed sizes, CommandLines.cpp:848-863 - every case must be runnable by ref_harness, tests/ref_fuzz.py)
     if rng.random() < 0.15:
         o["max_n_chain"] = int(rng.integers(1, 12))
     if seed >= 1000 and rng.random() < 0.7:      # (seeds below 1000 keep the cases of the first sweeps)
