@@ -39,6 +39,11 @@ from hifiasm_amd.workloads import WORKLOADS, LEN_JIT, n_reads_of  # noqa: E402
 
 STRONG = {"human3G_hifi40x", "ont_human_30x"}      # fixed-size problems: the read set is split over the ranks
 VARIANT_OF = {"chr1_250M_hifi30x": "chr1_250M_hifi30x_repeat", "bacterial5M_hifi30x": "bacterial5M_hifi30x_repeat"}      # the repeat-rich twin of a workload
+# a one-GPU PROXY of one rank of configs[3] on 8 GPUs (no multi-GPU box has been available in any round): a rank's read count at configs[3]'s coverage - i.e. its
+# seed-hit density - over an index padded (HAO_DBG_IX_PAD) to the replicated index's 3.45 G position records.  What it does NOT contain: the exchanges of
+# ha_ft_gen / ha_pt_gen (all-to-all-v, one 27.6 GB all-gather per round) and target ids spread over 8 M reads.  8 x its rate minus that all-gather is a PREDICTION of the
+# 8-GPU metric, not a measurement: no scaling curve has been measured.
+RANK_PROXY_OF = {"chr1_250M_hifi30x": ("human375M_hifi40x", 3_450_000_000)}
 JITTER_OF = {"chr1_250M_hifi30x": "chr1_250M_hifi30x_jitter"}      # the same bases in reads of 8 - 25 kb (uniform): the timed numbers of the headline workload see reads that are all exactly 15 000 bases
 # algorithmic bytes per unit (stated again in DESIGN.md 4)
 ALG = {
@@ -427,6 +432,7 @@ def main():
     ap.add_argument("--no-boundary", action="store_true", help="skip the boundary-inclusive (results delivered to host memory) measurement")
     ap.add_argument("--contexts", type=int, default=1, help="batch contexts (hao_attach) = host threads that run the batches of a pass concurrently; 1 keeps every kernel alone on the device (the roofline line)")
     ap.add_argument("--boundary-contexts", type=int, default=1, help="batch contexts of the boundary-inclusive measurement")
+    ap.add_argument("--no-rank-proxy", action="store_true", help="skip variants.rank_proxy_configs3 (1 M reads at 40x over an index padded to configs[3]'s size: a minute of generation and ha_ft_gen)")
     ap.add_argument("--no-variants", action="store_true", help="skip the repeat-rich twin of the workload (the `variants` block of the line)")
     ap.add_argument("--variant-steps", type=int, default=5, help="timed steps of the variant (at most --steps)")
     ap.add_argument("--no-tail-split", action="store_true", help="delivered pass: do not cut the last batch into 1/2 + 1/4 + 1/4 (A/B)")
@@ -489,6 +495,27 @@ def main():
         if jit and world == 1 and not a.no_variants:
             v = run_workload(a, jit, max(1, min(a.steps, a.variant_steps)), min(a.warmup, 1), rank, local_rank, world, dist, torch, force_sharded)
             out["variants"] = dict(out["variants"] or {}, length_jitter={k: v[k] for k in ("value", "ms_per_step", "value_resident", "ms_per_step_resident", "steps", "warmup", "roofline", "stage_ms", "config", "boundary")})
+        prox = RANK_PROXY_OF.get(a.workload)
+        if prox and world == 1 and not a.no_variants and not a.no_rank_proxy:
+            from hifiasm_amd import memplan
+            pw, ix_records = prox
+            g_, cov_, L_, err_ = WORKLOADS[pw][:4]
+            n_mz_ = int(0.02873 * g_ * cov_)      # (minimizers of the proxy's own reads: the pad brings the index to the replicated index's size)
+            os.environ["HAO_DBG_IX_PAD"] = str(max(0, ix_records - n_mz_))
+            try:
+                v = run_workload(a, pw, 1, 1, rank, local_rank, world, dist, torch, force_sharded)
+            finally:
+                del os.environ["HAO_DBG_IX_PAD"]
+            g3_, cov3_, L3_, err3_ = WORKLOADS[METRIC_WORKLOAD][:4]
+            plan = memplan.rank_plan(float(g3_) * cov3_, n_reads_of(METRIC_WORKLOAD), 8, 0.02873, 0.92 * 0.02873 * L3_ * cov3_, float(g3_), err=err3_)
+            pv = {k: v[k] for k in ("value", "ms_per_step", "value_resident", "ms_per_step_resident", "steps", "warmup", "roofline", "stage_ms", "config", "boundary", "device_memory")}
+            pv["index_records_with_pad"] = ix_records
+            pv["memory_plan_gb_of_a_configs3_rank"] = {k: (round(x / 1e9, 1) if isinstance(x, float) else x) for k, x in plan.items()}
+            allgather_s = 8.0 * ix_records / 8 * 7 / 8 / (7 * 153e9 * 0.7)      # a rank receives 7/8 of the index over 7 xGMI links at ~70 % of 153 GB/s each
+            pv["prediction_8_gpus"] = {"overlaps_per_s": round(8 * v["config"]["overlaps_per_gpu_step"] / (v["ms_per_step"] * 1e-3 + allgather_s), 1),
+                                       "assumed_allgather_s": round(allgather_s, 4),
+                                       "what": "8 x this rank-sized pass + one all-gather of the 27.6 GB index per round; a PREDICTION - no scaling curve was measured, RCCL with >= 2 ranks has not run"}
+            out["variants"] = dict(out["variants"] or {}, rank_proxy_configs3=pv)
         if metric_var is not None:
             out["variants"] = dict(out["variants"] or {}, metric_config=metric_var)
         if world > 1:      # what one rank holds, phase by phase (launcher-side arithmetic from the allocation sites' sizes: hifiasm_amd/memplan.py)

@@ -353,12 +353,14 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			HAO_CHECK_LAUNCH();
 			return HAO_OK;
 		};
-		if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql && c->sw.seed_lds && A <= (uint64_t)c->sw.seed_merge_avg * n && c->n_total < HAO_L5_MASK && c->ix_n_pos + c->sw.ix_pad < (1ULL << 40)) {
+		if (max_q <= HAO_QTAB_CAP && !c->sw.seed_noql && c->sw.seed_lds && (double)A * 100.0 <= (double)c->sw.seed_lds_ratio * (double)sum_q * (double)std::max(1, c->hom_cov) && c->n_total < HAO_L5_MASK && c->ix_n_pos + c->sw.ix_pad < (1ULL << 40)) {
 			B.seed_path = 2;
 			// the list-major kernel (hao_query5.cuh): one persistent workgroup per CU, a read's position lists read once with adjacent lanes on adjacent records into LDS,
 			// merged by target there.  The reads it leaves (more than 1536 minimizers, more records than the LDS holds, more than seed_merge_maxn hits) go through the
-			// table kernels below it (512-slot launch over the overflow list, then the launches without staged tiles).  Batches whose reads average more than
-			// seed_merge_avg hits - reads across repeat families: hundreds of targets, a merge step each - keep the table kernels.
+			// table kernels below it (512-slot launch over the overflow list, then the launches without staged tiles).  Batches of reads across repeat families - hundreds of
+			// targets per read, a merge step each - keep the table kernels (341 against 226 ms per pass of the repeat-rich 250 Mb set, profiles/r06/seed_ab.txt).  What tells
+			// them apart whatever the coverage: seed hits per (query minimizer x coverage peak) - 1.0 on repeat-free reads at 30 x and at 40 x (every minimizer meets the reads
+			// that cover it), 0.5 on ONT reads (1 % error), 1.4 on the repeat-rich set; the list-major kernel takes batches up to seed_lds_ratio = 1.2.
 			lds2 = hao_seed3_lds<10>::FIXED + lds_q; lds3 = hao_seed3_lds<11>::FIXED + lds_q;
 			auto k1 = seed_bin_kernel<9, 1, 512, true>; auto k2 = seed_bin3_kernel<10, 1, 4>; auto k3 = seed_bin3_kernel<11, 2, 4>;
 			HIP_TRY(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));

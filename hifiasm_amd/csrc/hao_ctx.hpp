@@ -63,7 +63,7 @@ struct hao_switches {
 	bool seedphase = false, qcphase = false, dp_stats = false, seq_chain = false, dp_seqtail = false, dp_nospec = false, dp_serial = false,
 		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, sk_v2 = false, dltime = false, sk_nofuse = false, pack_search = false, sk_select2 = false, seed_noql = false, sort64 = false, tiny_lane = false, pt_direct = false;
 	static constexpr bool SK_SELECT2_DEFAULT = true;       // the thinning kernel the sketch runs when the environment says nothing: the wave kernel (round 4: green on the device against every repeat-rich scenario and the 5 Mb / 250 Mb repeat-rich fixtures)
-	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; unsigned long long ix_pad = 0, sort40_min = 1ULL << 23; int fc_raw_every = 0, exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, arena_numa = 3, seed_merge_maxn = 24000, seed_merge_avg = 14000, ft_passes = 0, seed_lds = 1; long long ft_chunk_slots = 0;
+	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; unsigned long long ix_pad = 0, sort40_min = 1ULL << 23; int fc_raw_every = 0, exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, arena_numa = 3, seed_merge_maxn = 24000, seed_lds_ratio = 120, ft_passes = 0, seed_lds = 1; long long ft_chunk_slots = 0;
 	void load() {
 		auto on = [](const char *n) { return getenv(n) != nullptr; };
 		seedphase = on("HAO_DBG_SEEDPHASE"); qcphase = on("HAO_DBG_QCPHASE"); dp_stats = on("HAO_DBG_DP_STATS"); seq_chain = on("HAO_DBG_SEQ_CHAIN");
@@ -71,7 +71,7 @@ struct hao_switches {
 		selphase = on("HAO_DBG_SELPHASE"); sel1 = on("HAO_DBG_SEL1"); sk_generic = on("HAO_DBG_SK_GENERIC"); sk_v2 = on("HAO_DBG_SK_V2"); sk_nofuse = on("HAO_DBG_SK_NOFUSE"); pack_search = on("HAO_DBG_PACK_SEARCH");      // the wire packer searches every hit's minimizer (round-2 path) instead of gathering the quick check's code bytes
 		dltime = on("HAO_DBG_DLTIME");
 		if (const char *e = getenv("HAO_SEED_LDS")) seed_lds = atoi(e) ? 1 : 0;      // 0 = the table kernels (hao_query.cuh, hao_query3.cuh) for every read instead of the list-major kernel (hao_query5.cuh): the tests run them on every scenario - they carry repeat-rich batches and the reads the list-major kernel leaves
-		if (const char *e = getenv("HAO_SEED_MERGE_AVG")) seed_merge_avg = std::max(0, atoi(e));      // batches whose reads average more seed hits than this take the table kernels (the repeat-rich 250 Mb set averages 16 k, the repeat-free one 12 k; list-major kernel on it: 341 against 226 ms, profiles/r06/seed_ab.txt)
+		if (const char *e = getenv("HAO_SEED_LDS_RATIO")) seed_lds_ratio = std::max(0, atoi(e));      // (per cent) batches with more seed hits per (query minimizer x coverage peak) than this take the table kernels: reads across repeat families (hao_batch.hpp); tests force either side
 		if (const char *e = getenv("HAO_SEED_MERGE_MAXN")) seed_merge_maxn = std::max(0, atoi(e));      // reads with more seed hits than this are left to the table kernels by the list-major kernel (repeat families: hundreds of targets per read)
 		if (const char *e = getenv("HAO_FT_PASSES")) ft_passes = std::max(0, atoi(e));      // ha_ft_gen in this many hash-range passes (0: as many as the free device memory asks for)
 		if (const char *e = getenv("HAO_FT_CHUNK_SLOTS")) ft_chunk_slots = std::max(0LL, atoll(e));      // (tests) k-mer slots hashed per chunk of reads in pass mode

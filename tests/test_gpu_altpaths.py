@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 SWITCHES = ["HAO_DBG_SEQ_CHAIN", "HAO_DBG_DP_NOSPEC", "HAO_DBG_DP_SEQTAIL", "HAO_DBG_DP_SERIAL", "HAO_DBG_SEL1", "HAO_DBG_SEQ_PRUNE",
             "HAO_DBG_SK_GENERIC", "HAO_DBG_SK_GCAP", "HAO_SPEC_MINCLS", "HAO_CHAIN_WPB", "HAO_DBG_TINY_LANE",
             "HAO_SEED_NOQL", "HAO_PT_SORT64", "HAO_PT_DIRECT",
-            "HAO_SEED_LDS=0", "HAO_SEED_MERGE_AVG=1000000", "HAO_SEED_MERGE_AVG=1000", "HAO_SEED_MERGE_MAXN=3000", "HAO_SEED_MERGE_MAXN=1000000"]
+            "HAO_SEED_LDS=0", "HAO_SEED_LDS_RATIO=1000000", "HAO_SEED_LDS_RATIO=1", "HAO_SEED_MERGE_MAXN=3000", "HAO_SEED_MERGE_MAXN=1000000"]
 # (the seed stage: the table kernels for every read; the list-major kernel for every batch however many hits its reads average - these sets are repeat-rich - and the
 # seed-hit limit above which it leaves a read to the table kernels)
 VALUES = {"HAO_DBG_SK_GCAP": "1000", "HAO_SPEC_MINCLS": "0", "HAO_CHAIN_WPB": "4"}
