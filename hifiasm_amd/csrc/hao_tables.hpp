@@ -327,12 +327,16 @@ static uint64_t hao_ft_pass_count(hao_ctx *c, uint64_t n_slots, bool sharded, bo
 	if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return 1; }
 	const double per_slot = (sharded ? HAO_FT_BYTES_PER_SLOT_SHARDED : HAO_FT_BYTES_PER_SLOT) + (bloom ? HAO_FT_BYTES_PER_SLOT_BLOOM : 0.0);
 	const double need = per_slot * (double)n_slots + (double)(1ULL << 30), have = 0.9 * (double)fr;
-	if (need <= have) return 1;
+	// a pass's two occurrence buffers hold at most 2^32 slots (32 GB) each even when everything would fit at once: allocating (and first touching) a pair of 60 GB
+	// buffers costs more than hashing the reads a second time - configs[2] (7.5 G slots): 1.07 s in one pass (3 - 6 s on a box where the allocation stalls), 0.65 s in
+	// two, 0.80 in three (profiles/r06/ft_passes.txt)
+	const uint64_t p_size = (n_slots + (1ULL << 32) - 1) >> 32;
+	if (need <= have) return std::max<uint64_t>(1, std::min<uint64_t>(64, p_size));
 	// what the chunk scratch and the run lists of ALL passes leave (12 bytes per distinct k-mer, once more while a pass's runs are appended; one distinct k-mer per ~7
 	// occurrences is allowed for: 1 / coverage + error rate x k = 0.076 at 40x and 0.1 % - an exact count of noisy reads at this scale wants the Bloom filter, as in the reference)
 	const double rest = have - 2.0 * 8.0 * (double)HAO_FT_CHUNK_SLOTS - (double)(2ULL << 30) - HAO_FT_RUN_BYTES_PER_SLOT * (double)n_slots;
 	if (rest <= 0) return 64;
-	return (uint64_t)std::min<double>(64.0, std::ceil(per_slot * (double)n_slots / rest));
+	return (uint64_t)std::min<double>(64.0, std::max<double>((double)p_size, std::ceil(per_slot * (double)n_slots / rest)));
 }
 
 static int hao_ft_run(hao_ctx *c)

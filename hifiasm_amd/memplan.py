@@ -26,10 +26,11 @@ def ft_passes(slots: float, free_bytes: float, sharded: bool, bloom: bool = Fals
     import math
     per = (FT_PER_SLOT_SHARDED if sharded else FT_PER_SLOT) + (FT_PER_SLOT_BLOOM if bloom else 0.0)
     have = 0.9 * free_bytes
+    p_size = max(1, math.ceil(slots / 2 ** 32))      # a pass's occurrence buffers hold at most 2^32 slots each (allocating bigger ones costs more than a second hashing of the reads)
     if per * slots + (1 << 30) <= have:
-        return 1
+        return min(64, p_size)
     rest = have - 2 * 8 * FT_CHUNK_SLOTS - (2 << 30) - FT_RUN_PER_SLOT * slots      # (the run lists of all passes: 12 + 12 bytes per distinct k-mer, one per ~7 occurrences allowed for)
-    return 64 if rest <= 0 else min(64, math.ceil(per * slots / rest))
+    return 64 if rest <= 0 else min(64, max(p_size, math.ceil(per * slots / rest)))
 
 
 def rank_plan(total_bases: float, n_reads: float, world: int, mz_per_base: float, hits_per_read: float, genome: float, err: float = 0.001, k: int = 51,

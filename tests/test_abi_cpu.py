@@ -128,8 +128,9 @@ def test_rank_memory_plan_of_the_multi_gpu_configs():
     p3 = plans["human3G_hifi40x"]
     assert p3["passes_ft"] >= 2                                 # one pass would need 46 B x 15 Gbases = 690 GB
     assert memplan.FT_PER_SLOT_SHARDED * 3e9 * 40 / 8 > memplan.HBM_BYTES
-    one = memplan.rank_plan(250e6 * 30, 500_000, 1, 0.02873, 11_900, 250e6)      # configs[2] on one GPU: one pass (20 B x 7.5 Gbases = 150 GB)
-    assert one["passes_ft"] == 1 and one["peak"] < 0.9 * memplan.HBM_BYTES
+    one = memplan.rank_plan(250e6 * 30, 500_000, 1, 0.02873, 11_900, 250e6)      # configs[2] on one GPU: everything would fit at once (20 B x 7.5 Gbases = 150 GB); two passes because a pass's
+    assert one["passes_ft"] == 2 and one["peak"] < 0.9 * memplan.HBM_BYTES       # buffers stop at 2^32 slots (allocating bigger ones costs more than hashing the reads again)
+    assert memplan.ft_passes(4.0e9, 280e9, False) == 1 and memplan.ft_passes(4.4e9, 280e9, False) == 2
     print("[rank memory plan, 8 GPUs]", {k: {q: (round(v[q] / 1e9, 1) if isinstance(v[q], float) else v[q]) for q in ("passes_ft", "ft_gen", "pt_gen", "all_reads_pass", "index", "batches_per_pass")} for k, v in plans.items()})
 
 

@@ -86,10 +86,12 @@ def _phase_times(stderr):
 
 
 @pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(HAO)), reason="reference binaries not built")
-def test_bins_identical_configs1_with_wall_clocks():
+@pytest.mark.parametrize("farg", ["-f0", "-f37"])
+def test_bins_identical_configs1_with_wall_clocks(farg):
     """BASELINE.json configs[1] (5 Mb genome, 30x, 15 kb HiFi reads, 10 000 reads) through the unmodified reference executable and through the same objects with the seam
     served by libhao.so: three correction rounds + the final overlap round (Assembly.cpp:996-1010, 2055-2090 -> anchor.cpp:2302), every host core as a worker thread,
-    the shim's default batch size - thousands of h_ec_lchain calls per round stolen across the workers.  Bins byte-identical; the two wall-clocks go to the test log and
+    the shim's default batch size - thousands of h_ec_lchain calls per round stolen across the workers; at -f0 (exact counting) and at the reference's own default -f37
+    (its 16 GB blocked Bloom filter against the engine's per-block replay).  Bins byte-identical; the two wall-clocks go to the test log and
     to gpurun_out/dropin_configs1.json (the number a hifiasm user would ask for; most of either run is the reference's own CPU alignment / correction code)."""
     import json
     from hifiasm_amd import synth, workloads
@@ -101,7 +103,7 @@ def test_bins_identical_configs1_with_wall_clocks():
     env = {k: v for k, v in os.environ.items() if k not in ("HAO_SHIM_BATCH", "HAO_SHIM_FINAL_OL_ONLY")}
     res = {}
     for exe, tag in ((REF, "ref"), (HAO, "hao")):
-        r, wall = _run_timed(exe, ["-o", os.path.join(d, tag), "-t", nt, "-f0", "--bin-only", fa], d, env)
+        r, wall = _run_timed(exe, ["-o", os.path.join(d, tag), "-t", nt, farg, "--bin-only", fa], d, env)
         assert r.returncode == 0, f"{tag} failed: {r.stderr[-1500:]}"
         res[tag] = {"wall_s": round(wall, 2), "stamps": {k: v[-1] for k, v in _phase_times(r.stderr).items()}}
     for ext in ("ovlp.source.bin", "ovlp.reverse.bin"):
@@ -115,12 +117,12 @@ def test_bins_identical_configs1_with_wall_clocks():
     for i in _ec_mask(bytes(a)):
         a[i] = b[i] = 0
     assert a == b, "ec.bin differs outside the reference's uninitialised pad bytes"
-    res.update(workload="bacterial5M_hifi30x", reads=int(rs.n), threads=int(nt), args="-f0 --bin-only")
+    res.update(workload="bacterial5M_hifi30x", reads=int(rs.n), threads=int(nt), args=farg + " --bin-only")
     line = json.dumps(res)
     print("[dropin configs1] " + line)
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        open(os.path.join(ROOT, "gpurun_out", "dropin_configs1.json"), "w").write(line + "\n")
+        open(os.path.join(ROOT, "gpurun_out", "dropin_configs1" + ("" if farg == "-f0" else "_f37") + ".json"), "w").write(line + "\n")
     except OSError:
         pass
     import shutil
