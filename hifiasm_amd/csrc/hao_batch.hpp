@@ -1,5 +1,6 @@
 // Host orchestration of one query batch: h_ec_lchain for reads [lo, hi) (part of libhao.so).
 #pragma once
+#include <sys/mman.h>
 #include "hao_tables.hpp"
 #include "hao_query.cuh"
 #include "hao_query3.cuh"
@@ -32,7 +33,8 @@ struct hao_ctx::Batch {
 	int cur = 0;
 	OutSet &O() { return out[cur]; }
 	// delivery state: pinned host arenas, copy stream, per-slot completion events
-	unsigned char *arena[2] = { nullptr, nullptr }, *arena_dev[2] = { nullptr, nullptr }; size_t arena_cap[2] = { 0, 0 }; hipStream_t copy_stream = nullptr, copy_aux[8]; hipEvent_t ev_ready[2], ev_done[2], ev_aux[2][8]; int n_aux = 0; bool dl_ready = false, dl_pending[2] = { false, false };
+	unsigned char *arena[2] = { nullptr, nullptr }, *arena_dev[2] = { nullptr, nullptr }; size_t arena_cap[2] = { 0, 0 }; bool arena_reg[2] = { false, false };      // arena_reg: mmap + mbind + hipHostRegister (hao_arena_alloc)
+	void arena_free(int x) { if (!arena[x]) return; if (arena_reg[x]) { (void)hipHostUnregister(arena[x]); (void)munmap(arena[x], arena_cap[x]); } else (void)hipHostFree(arena[x]); arena[x] = nullptr; arena_cap[x] = 0; arena_reg[x] = false; } hipStream_t copy_stream = nullptr, copy_aux[8]; hipEvent_t ev_ready[2], ev_done[2], ev_aux[2][8]; int n_aux = 0; bool dl_ready = false, dl_pending[2] = { false, false };
 	uint32_t wgt_hi = 0xffffffffu, wgt_lo = 0xffffffffu;
 	double t_evsync = 0, t_enq = 0, t_alloc = 0, t_s1 = 0, t_s2 = 0, t_s3 = 0, t_run = 0, t_pre = 0; uint64_t t_n = 0, t_nrun = 0;      // host-side time spent in the delivery plumbing (HAO_DBG_DLTIME)
 	hao_delivery_t dl[2]; uint64_t dl_seq = 0, n_exc = 0; uint32_t dl_parts = 0; bool exact_valid = false; std::vector<uint8_t> h_exact;
@@ -45,7 +47,7 @@ struct hao_ctx::Batch {
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fcf_off.release();
 		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); g_cls.release(); slow.release(); ovf_list.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
 		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); cd.release(); pk_cnt.release(); pk_ecnt.release(); pk_erank.release(); hq.release(); ohq.release(); hcode.release(); out[0].release(); out[1].release();
-		if (dl_ready) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); for (int k = 0; k < n_aux; ++k) { (void)hipStreamSynchronize(copy_aux[k]); (void)hipStreamDestroy(copy_aux[k]); (void)hipEventDestroy(ev_aux[0][k]); (void)hipEventDestroy(ev_aux[1][k]); } for (int x = 0; x < 2; ++x) { (void)hipEventDestroy(ev_ready[x]); (void)hipEventDestroy(ev_done[x]); if (arena[x]) (void)hipHostFree(arena[x]); arena[x] = nullptr; arena_cap[x] = 0; } dl_ready = false; }
+		if (dl_ready) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); for (int k = 0; k < n_aux; ++k) { (void)hipStreamSynchronize(copy_aux[k]); (void)hipStreamDestroy(copy_aux[k]); (void)hipEventDestroy(ev_aux[0][k]); (void)hipEventDestroy(ev_aux[1][k]); } for (int x = 0; x < 2; ++x) { (void)hipEventDestroy(ev_ready[x]); (void)hipEventDestroy(ev_done[x]); arena_free(x); } dl_ready = false; }
 	}
 };
 
@@ -101,6 +103,30 @@ struct hao_mempolicy_guard {
 		(void)syscall(SYS_set_mempolicy, old_mode, any ? old_mask : (unsigned long*)nullptr, any ? 1024UL : 0UL);
 	}
 };
+// how many of 32 sampled pages of [p, p + bytes) lie on `node` (move_pages with no target nodes only reports); -1: cannot tell
+static int hao_pages_on_node(const void *p, size_t bytes, int node)
+{
+	const long ps = sysconf(_SC_PAGESIZE); if (ps <= 0 || bytes < (size_t)ps) return -1;
+	void *pg[32]; int st[32]; const size_t np = bytes / (size_t)ps;
+	for (int i = 0; i < 32; ++i) { pg[i] = (void*)(((uintptr_t)p + (np - 1) * (size_t)i / 31 * (size_t)ps) & ~(uintptr_t)(ps - 1)); st[i] = -1; }
+	if (syscall(SYS_move_pages, 0, 32UL, pg, (const int*)nullptr, st, 0) != 0) return -1;
+	int on = 0; for (int i = 0; i < 32; ++i) on += st[i] == node;
+	return on;
+}
+// A pinned host buffer whose pages are ON `node`, whatever the allocator of hipHostMalloc does: anonymous mapping, mbind(MPOL_BIND) before the first touch (the kernel
+// then reclaims that node's page cache instead of falling over to the far socket), touched, registered with the runtime.  nullptr when any step fails.
+static unsigned char *hao_arena_alloc_bound(size_t bytes, int node)
+{
+	if (node < 0 || node >= 1024) return nullptr;
+	void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+	if (m == MAP_FAILED) return nullptr;
+	unsigned long mask[16]; memset(mask, 0, sizeof(mask)); mask[node / 64] |= 1UL << (node % 64);
+	if (syscall(SYS_mbind, m, bytes, 2 /* MPOL_BIND */, mask, 1024UL, 0U) != 0) { (void)munmap(m, bytes); return nullptr; }
+	const long ps = sysconf(_SC_PAGESIZE);
+	for (size_t o = 0; o < bytes; o += (size_t)(ps > 0 ? ps : 4096)) ((volatile unsigned char*)m)[o] = 0;
+	if (hipHostRegister(m, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); (void)munmap(m, bytes); return nullptr; }
+	return (unsigned char*)m;
+}
 static inline double hao_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct ExcLess { __host__ __device__ bool operator()(const hao_exc_t &a, const hao_exc_t &b) const { return a.index < b.index; } };
 
@@ -172,8 +198,7 @@ static int hao_deliver_enqueue(hao_ctx *c)
 	size_t o_rank = o_bits + (cl ? al(nw_ * 8) : 0), o_codes = o_rank + (cl ? al(nr4_ * 4) : 0), o_exc = o_codes + (cl ? al(B.n_codes) : 0);
 	size_t o_ex = o_exc + (cl ? al(B.n_exc * sizeof(hao_exc_t)) : 0), total = o_ex + (ex ? al(B.n_ol) : 0);
 	if (total > B.arena_cap[s]) {
-		if (B.arena[s]) (void)hipHostFree(B.arena[s]);
-		B.arena[s] = nullptr; B.arena_cap[s] = 0;
+		B.arena_free(s);
 		const size_t want = total + total / 4 + (1 << 20);
 		const double t0_ = hao_now();
 		const int node_ = c->sw.arena_numa ? hao_gpu_numa_node(c->device) : -1;
@@ -193,7 +218,16 @@ static int hao_deliver_enqueue(hao_ctx *c)
 			he_ = hipHostMalloc((void**)&B.arena[s], want, (c->sw.arena_numa == 2 && g_.applied) ? hipHostMallocNumaUser : hipHostMallocDefault);
 			if (he_ == hipSuccess && g_.applied) how_ = "preferred";
 		}
-		if (c->sw.dltime) fprintf(stderr, "[deliver] arena %d: %zu MB, GPU NUMA node %d (requested mode %d, allocated %s)\n", s, want >> 20, node_, c->sw.arena_numa, he_ == hipSuccess ? how_ : "FAILED");
+		// where did the pages land?  hipHostMalloc does not always honour the calling thread's policy (one run of round 6 delivered configs[2] at 28.6 GB/s and, with
+		// arenas allocated later in the same process, at 53.5): if fewer than 28 of 32 sampled pages are on the GPU's node, the arena is allocated again by hand
+		int on_ = -1;
+		if (he_ == hipSuccess && node_ >= 0) {
+			on_ = hao_pages_on_node(B.arena[s], want, node_);
+			if ((on_ >= 0 && on_ < 28) || c->sw.arena_numa == 4) {      // (HAO_ARENA_NUMA=4: always by hand - tests)
+				if (unsigned char *m_ = hao_arena_alloc_bound(want, node_)) { (void)hipHostFree(B.arena[s]); B.arena[s] = m_; B.arena_reg[s] = true; how_ = "mmap + mbind + hipHostRegister"; on_ = hao_pages_on_node(m_, want, node_); }
+			}
+		}
+		if (c->sw.dltime) fprintf(stderr, "[deliver] arena %d: %zu MB, GPU NUMA node %d (requested mode %d, allocated %s, %d of 32 sampled pages on the node)\n", s, want >> 20, node_, c->sw.arena_numa, he_ == hipSuccess ? how_ : "FAILED", on_);
 		HIP_TRY(he_);
 		B.arena_cap[s] = want; B.t_alloc += hao_now() - t0_;
 		HIP_TRY(hipHostGetDevicePointer((void**)&B.arena_dev[s], B.arena[s], 0));

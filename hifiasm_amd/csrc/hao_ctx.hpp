@@ -88,7 +88,7 @@ struct hao_switches {
 		if (const char *e = getenv("HAO_DBG_EXC_CAP")) exc_cap = atoll(e);
 		if (const char *e = getenv("HAO_DBG_FC_RAW_EVERY")) fc_raw_every = std::max(0, atoi(e));      // tests: every n-th overlap's fake cigar travels raw (the fallback of the packed wire form)
 		if (const char *e = getenv("HAO_DBG_EXC_EVERY")) exc_every = atoi(e);      // ship every n-th hit of a chain verbatim (tests: exercise the exception list)
-		if (const char *e = getenv("HAO_ARENA_NUMA")) arena_numa = atoi(e);      // 0: plain hipHostMalloc, 1: thread policy "prefer the GPU's node", 3 (default): "bind to it", then 1 if that fails, 2: 3 + hipHostMallocNumaUser
+		if (const char *e = getenv("HAO_ARENA_NUMA")) arena_numa = atoi(e);      // 0: plain hipHostMalloc, 1: thread policy "prefer the GPU's node", 3 (default): "bind to it", then 1 if that fails - and, when the pages still are elsewhere, mmap + mbind + hipHostRegister; 2: 3 + hipHostMallocNumaUser; 4: always mmap + mbind + hipHostRegister (tests)
 		if (const char *e = getenv("HAO_STREAM_PRIO")) stream_prio = atoi(e);      // 1: the engine's streams at the highest priority (A/B: measured worse - the low-priority copy then starves)
 		if (const char *e = getenv("HAO_COPY_KERNEL")) copy_kernel = atoi(e);      // n > 0: the delivery copy is done by a kernel of n workgroups writing into the mapped arena (no DMA engine)
 		if (const char *e = getenv("HAO_COPY_STREAMS")) copy_streams = std::max(1, std::min(8, atoi(e)));      // DMA queues the delivery copy is spread over      // initial capacity of the wire format's verbatim-hit list (tests: force the grow-and-repack path)

@@ -95,6 +95,9 @@ inline hipError_t hipFree(void *p)
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template<class T> inline hipError_t hipHostMalloc(T **p, size_t n, unsigned f = 0) { return hipHostMalloc((void**)p, n, f); }
 inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+enum { hipHostRegisterMapped = 2, hipHostRegisterPortable = 1 };
+inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
+inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
 inline hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return hipSuccess; }
 template<class T> inline hipError_t hipHostGetDevicePointer(T **d, void *h, unsigned f) { return hipHostGetDevicePointer((void**)d, h, f); }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
