@@ -511,7 +511,7 @@ def main():
             pv = {k: v[k] for k in ("value", "ms_per_step", "value_resident", "ms_per_step_resident", "steps", "warmup", "roofline", "stage_ms", "config", "boundary", "device_memory")}
             pv["index_records_with_pad"] = ix_records
             pv["memory_plan_gb_of_a_configs3_rank"] = {k: (round(x / 1e9, 1) if isinstance(x, float) else x) for k, x in plan.items()}
-            allgather_s = 8.0 * ix_records / 8 * 7 / 8 / (7 * 153e9 * 0.7)      # a rank receives 7/8 of the index over 7 xGMI links at ~70 % of 153 GB/s each
+            allgather_s = 8.0 * ix_records * 7 / 8 / (7 * 153e9 * 0.7)      # a rank receives 7/8 of the 27.6 GB index over its 7 xGMI links at ~70 % of 153 GB/s each
             pv["prediction_8_gpus"] = {"overlaps_per_s": round(8 * v["config"]["overlaps_per_gpu_step"] / (v["ms_per_step"] * 1e-3 + allgather_s), 1),
                                        "assumed_allgather_s": round(allgather_s, 4),
                                        "what": "8 x this rank-sized pass + one all-gather of the 27.6 GB index per round; a PREDICTION - no scaling curve was measured, RCCL with >= 2 ranks has not run"}

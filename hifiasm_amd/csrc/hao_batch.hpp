@@ -14,7 +14,7 @@ struct hao_ctx::Batch {
 	bool valid = false, host_valid = false;
 	DevBuf<uint64_t> s_start, s_pk, a_off, seg, g_cnt, g_off, g_start, ch_base, cl_base, fc_base, fcs, fc_raw, ol_fc_off, cc_off, cc, fc_final, fcf_off;
 	DevBuf<uint64_t> nch64;
-	DevBuf<uint64_t> g_tmp, cls_cc, cls_co; DevBuf<hao_gent> glist; DevBuf<uint8_t> g_cls; DevBuf<uint32_t> slow, ovf_list; hipStream_t side[HAO_NCLS]; hipEvent_t ev_qc[HAO_NCLS], ev_dp[HAO_NCLS]; bool side_ready = false;
+	DevBuf<uint64_t> g_tmp, cls_cc, cls_co; DevBuf<hao_gent> glist; DevBuf<uint8_t> g_cls; DevBuf<uint32_t> slow, ovf_list; hipStream_t side[HAO_NCLS]; hipEvent_t ev_qc[HAO_NCLS], ev_dp[HAO_NCLS]; bool side_ready = false; hipEvent_t ev_pk0 = nullptr, ev_pk1 = nullptr; DevBuf<unsigned char> pk_tmp;
 	DevBuf<uint32_t> q_pos, q_cnt, s_n, g_read, wgt, nch, nout, perm, n_final, fclen;
 	DevBuf<hao_hit_t> hits, ohits, cl;
 	DevBuf<int32_t> f, ii, p, key_sc, tm; DevBuf<int64_t> t; DevBuf<uint64_t> key_xs; DevBuf<uint32_t> key_al, key_tmp;
@@ -42,6 +42,7 @@ struct hao_ctx::Batch {
 	std::vector<uint64_t> h_seg, h_fin_off, h_cl_off, h_fc_out_off; std::vector<hao_hit_t> h_hits, h_cl; std::vector<hao_ovlp_t> h_ol; std::vector<uint64_t> h_fc;
 	std::vector<uint64_t> fetch_fc_off, h_cco;
 	void release() {
+		pk_tmp.release(); if (ev_pk0) { (void)hipEventDestroy(ev_pk0); (void)hipEventDestroy(ev_pk1); ev_pk0 = ev_pk1 = nullptr; }
 		if (side_ready) { for (int x = 0; x < HAO_NCLS; ++x) { (void)hipStreamDestroy(side[x]); (void)hipEventDestroy(ev_qc[x]); (void)hipEventDestroy(ev_dp[x]); } side_ready = false; }
 		s_start.release(); s_pk.release(); a_off.release(); seg.release(); g_cnt.release(); g_off.release(); g_start.release(); ch_base.release(); cl_base.release();
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fcf_off.release();
@@ -538,36 +539,48 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	// cl->list -> wire format (hao_deliver.cuh): chain headers; codes of the chains the DP compacted; then ONE pass over the code array the quick check
 	// filled - bits, rank directory, code bytes of the flagged positions, verbatim list.  (The number of chains is only known on the device here: launches
 	// cover the bound, the kernels stop at ch_base[G].)
-	auto pack = [&]() -> int {
+	// The pack kernels need the chain descriptors (chain_assemble_kernel) and nothing the selection and chain_final_kernel write: they run on a side stream UNDER those
+	// (one-wave-per-read kernels that leave most of the device idle) and join the engine's stream in front of the batch's totals.  On the engine's stream they were
+	// 9.4 ms of a configs[2] pass that nothing else ran under.  (Their scans have a scratch buffer of their own: c->d_tmp belongs to the scans of the selection.)
+	auto pack = [&](hipStream_t ps) -> int {
 		if (!G) return HAO_OK;
 		hao_ctx::Batch::OutSet &O = B.O();
-		hipLaunchKernelGGL(hao_pack_hdr_kernel, dim3((unsigned)((NCmax + 255) / 256)), dim3(256), 0, c->stream, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH();
-		if (!pa.have_codes) { hipLaunchKernelGGL(hao_pack_ohits_kernel, dim3((unsigned)std::min<uint64_t>((NCmax + 3) / 4, 1u << 16)), dim3(256), 0, c->stream, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH(); }      // (HAO_DBG_PACK_SEARCH: every chain coded by the packer)
+		hipLaunchKernelGGL(hao_pack_hdr_kernel, dim3((unsigned)((NCmax + 255) / 256)), dim3(256), 0, ps, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH();
+		if (!pa.have_codes) { hipLaunchKernelGGL(hao_pack_ohits_kernel, dim3((unsigned)std::min<uint64_t>((NCmax + 3) / 4, 1u << 16)), dim3(256), 0, ps, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH(); }      // (HAO_DBG_PACK_SEARCH: every chain coded by the packer)
 		const bool scan_exc = pa.have_codes != 0;      // verbatim list by count + scan, in position order (the HAO_DBG_PACK_SEARCH packer appends its own entries through the counter: that list is sorted afterwards)
-		hipLaunchKernelGGL(hao_pack_bits_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, c->stream, pa, A, NW, O.bits.p, B.pk_cnt.p, scan_exc ? B.pk_ecnt.p : (uint32_t*)nullptr); HAO_CHECK_LAUNCH();
+		hipLaunchKernelGGL(hao_pack_bits_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, ps, pa, A, NW, O.bits.p, B.pk_cnt.p, scan_exc ? B.pk_ecnt.p : (uint32_t*)nullptr); HAO_CHECK_LAUNCH();
 		size_t tb = 0;
-		HIP_TRY(rocprim::exclusive_scan(nullptr, tb, B.pk_cnt.p, O.rank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), c->stream)); HIP_TRY(hao_tmp(c, tb));
-		HIP_TRY(rocprim::exclusive_scan(c->d_tmp.p, tb, B.pk_cnt.p, O.rank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), c->stream));
-		if (scan_exc) HIP_TRY(rocprim::exclusive_scan(c->d_tmp.p, tb, B.pk_ecnt.p, B.pk_erank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), c->stream));
-		hipLaunchKernelGGL(hao_pack_codes_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, c->stream, pa, B.hcode.p, A, O.bits.p, O.rank.p, NW, O.codes.p, d_n_codes, scan_exc ? B.pk_erank.p : (const uint32_t*)nullptr); HAO_CHECK_LAUNCH();
-		{ const uint64_t n4 = NW / 4 + 1; hipLaunchKernelGGL(hao_rank4_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, c->stream, O.rank.p, n4, O.rank4.p); HAO_CHECK_LAUNCH(); }
+		HIP_TRY(rocprim::exclusive_scan(nullptr, tb, B.pk_cnt.p, O.rank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), ps)); HIP_TRY(B.pk_tmp.reserve(tb + 256));
+		HIP_TRY(rocprim::exclusive_scan(B.pk_tmp.p, tb, B.pk_cnt.p, O.rank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), ps));
+		if (scan_exc) HIP_TRY(rocprim::exclusive_scan(B.pk_tmp.p, tb, B.pk_ecnt.p, B.pk_erank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), ps));
+		hipLaunchKernelGGL(hao_pack_codes_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, ps, pa, B.hcode.p, A, O.bits.p, O.rank.p, NW, O.codes.p, d_n_codes, scan_exc ? B.pk_erank.p : (const uint32_t*)nullptr); HAO_CHECK_LAUNCH();
+		{ const uint64_t n4 = NW / 4 + 1; hipLaunchKernelGGL(hao_rank4_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, ps, O.rank.p, n4, O.rank4.p); HAO_CHECK_LAUNCH(); }
 		return HAO_OK;
 	};
+	bool pack_on_side = false;
 	if (parts & HAO_DELIVER_CL) {
 		hao_ctx::Batch::OutSet &O = B.O();
 		HIP_TRY(O.hdr.reserve(NCmax + 1)); HIP_TRY(O.exc.reserve(c->sw.exc_cap >= 0 ? (uint64_t)c->sw.exc_cap + 1 : std::max<uint64_t>(1 << 14, A / 256)));
 		HIP_TRY(O.bits.reserve(NW + 2)); HIP_TRY(O.rank.reserve(NW + 6)); HIP_TRY(O.rank4.reserve(NW / 4 + 2)); HIP_TRY(B.pk_cnt.reserve(NW + 2)); HIP_TRY(O.codes.reserve(A + 16));
-		HIP_TRY(hipMemsetAsync(B.pk_cnt.p + NW, 0, 4, c->stream));      // (the scan runs over NW + 1 counts: its last output is the total)
-		HIP_TRY(B.pk_ecnt.reserve(NW + 2)); HIP_TRY(B.pk_erank.reserve(NW + 2)); HIP_TRY(hipMemsetAsync(B.pk_ecnt.p + NW, 0, 4, c->stream));
+		HIP_TRY(B.pk_ecnt.reserve(NW + 2)); HIP_TRY(B.pk_erank.reserve(NW + 2));
 		HIP_TRY(O.ch_off.reserve(n + 2)); HIP_TRY(O.cl_off.reserve(n + 2)); HIP_TRY(O.qm_off.reserve(n + 2)); HIP_TRY(O.qmz.reserve(nm + 1));
 		pa.cd = B.cd.p; pa.hits = B.hits.p; pa.ohits = B.ohits.p; pa.mz_off = c->d_ix_mz_off.p; pa.seg = B.seg.p; pa.n_sel = n; pa.rid_lo = lo; pa.mz0 = B.mz0; pa.q_pos = B.q_pos.p;
 		pa.hq = c->sw.pack_search ? nullptr : B.hq.p; pa.ohq = c->sw.pack_search ? nullptr : B.ohq.p; pa.have_codes = c->sw.pack_search ? 0 : 1;
 		pa.hdr = O.hdr.p; pa.bytes = B.hcode.p; pa.exc = O.exc.p; pa.exc_cnt = d_exc_cnt; pa.exc_every = (uint32_t)c->sw.exc_every;
 		pa.exc_cap = c->sw.exc_cap >= 0 ? std::min<uint64_t>(O.exc.cap, (uint64_t)c->sw.exc_cap) : O.exc.cap;
-		if (int rc = pack()) return rc;
-		hipLaunchKernelGGL(hao_read_ranges_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, B.g_off.p, B.ch_base.p, B.cl_base.p, c->d_ix_mz_off.p, lo, B.mz0, n, O.ch_off.p, O.cl_off.p, O.qm_off.p);
+		hipStream_t ps = c->stream;
+		if (B.side_ready && !c->sw.dp_serial) {      // (the side streams exist once a batch had groups; HAO_DBG_DP_SERIAL keeps everything on the engine's stream)
+			if (!B.ev_pk0) { HIP_TRY(hipEventCreateWithFlags(&B.ev_pk0, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&B.ev_pk1, hipEventDisableTiming)); }
+			ps = B.side[0]; pack_on_side = true;
+			HIP_TRY(hipEventRecord(B.ev_pk0, c->stream)); HIP_TRY(hipStreamWaitEvent(ps, B.ev_pk0, 0));
+		}
+		HIP_TRY(hipMemsetAsync(B.pk_cnt.p + NW, 0, 4, ps));      // (the scans run over NW + 1 counts: their last output is the total)
+		HIP_TRY(hipMemsetAsync(B.pk_ecnt.p + NW, 0, 4, ps));
+		if (int rc = pack(ps)) return rc;
+		hipLaunchKernelGGL(hao_read_ranges_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, ps, B.g_off.p, B.ch_base.p, B.cl_base.p, c->d_ix_mz_off.p, lo, B.mz0, n, O.ch_off.p, O.cl_off.p, O.qm_off.p);
 		HAO_CHECK_LAUNCH();
-		if (nm) { hipLaunchKernelGGL(hao_qtab_kernel, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, c->stream, B.q_pos.p, B.q_cnt.p, nm, O.qmz.p); HAO_CHECK_LAUNCH(); }
+		if (nm) { hipLaunchKernelGGL(hao_qtab_kernel, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, ps, B.q_pos.p, B.q_cnt.p, nm, O.qmz.p); HAO_CHECK_LAUNCH(); }
+		if (pack_on_side) HIP_TRY(hipEventRecord(B.ev_pk1, ps));
 	}
 	c->timer.mark("q_assemble");
 	// Q8 selection
@@ -622,6 +635,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	hipLaunchKernelGGL(chain_final_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, B.ol.p, B.ol_fc_off.p, B.fc_raw.p, B.perm.p, B.g_off.p, B.ch_base.p,
 					   B.O().fin_off.p, B.fcf_off.p, n, B.O().ol_out.p, B.O().fc_out.p, B.O().fc_out_off.p, fcw_ ? B.O().fcw.p : (uint32_t*)nullptr, fcw_ ? B.O().fcw_off.p : (uint64_t*)nullptr, d_n_fcw, (uint32_t)c->sw.fc_raw_every);
 	HAO_CHECK_LAUNCH();
+	if (pack_on_side) HIP_TRY(hipStreamWaitEvent(c->stream, B.ev_pk1, 0));      // the pack kernels have run under the selection
 	c->timer.mark("q_final");
 	unsigned long long slow_st[HAO_NCLS + 4], n_exc = 0;
 	{	// the totals of the batch: one wave gathers them into mapped host memory
@@ -643,7 +657,8 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	if ((parts & HAO_DELIVER_CL) && n_exc > pa.exc_cap) {      // more verbatim hits than the list holds: grow it and pack again (the sources are untouched)
 		HIP_TRY(B.O().exc.reserve(n_exc + 1024)); pa.exc = B.O().exc.p; pa.exc_cap = B.O().exc.cap;
 		HIP_TRY(hipMemsetAsync(d_exc_cnt, 0, 8, c->stream));
-		if (int rc = pack()) return rc;
+		HIP_TRY(hipMemsetAsync(B.pk_cnt.p + NW, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(B.pk_ecnt.p + NW, 0, 4, c->stream));
+		if (int rc = pack(c->stream)) return rc;
 		hipLaunchKernelGGL(hao_peek_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)d_exc_cnt, 1, c->peek_d + 5); HAO_CHECK_LAUNCH();
 		hipLaunchKernelGGL(hao_peek_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)d_n_codes, 1, c->peek_d + 6); HAO_CHECK_LAUNCH();
 		HIP_TRY(hipStreamSynchronize(c->stream));
