@@ -411,9 +411,9 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 					return HAO_OK;
 				};
 				int rc_;
-				if (c->sw.seedphase && b16_ && !wide_) rc_ = go_(seed_lds_kernel<true, 2, 14, true>, hao_l5_lds<true>::TOTAL);
-				else if (b16_) rc_ = wide_ ? go_(seed_lds_kernel<true, 3, 8, false>, hao_l5_lds<true>::TOTAL) : go_(seed_lds_kernel<true, 2, 16, false>, hao_l5_lds<true>::TOTAL);
-				else rc_ = wide_ ? go_(seed_lds_kernel<false, 3, 8, false>, hao_l5_lds<false>::TOTAL) : go_(seed_lds_kernel<false, 2, 16, false>, hao_l5_lds<false>::TOTAL);
+				if (c->sw.seedphase && b16_ && !wide_) rc_ = go_(seed_lds_kernel<true, 2, 14, true>, hao_l5_lds<true, 2>::TOTAL);
+				else if (b16_) rc_ = wide_ ? go_(seed_lds_kernel<true, 3, 8, false>, hao_l5_lds<true, 2>::TOTAL) : go_(seed_lds_kernel<true, 2, 16, false>, hao_l5_lds<true, 2>::TOTAL);
+				else rc_ = wide_ ? go_(seed_lds_kernel<false, 3, 8, false>, hao_l5_lds<false, 2>::TOTAL) : go_(seed_lds_kernel<false, 2, 16, false>, hao_l5_lds<false, 2>::TOTAL);
 				if (rc_) return rc_;
 			}
 			HAO_CHECK_LAUNCH();

@@ -37,8 +37,7 @@
 
 #define HAO_L5_THREADS 512
 #define HAO_L5_W 8                    // waves per workgroup = target ranges per read
-#define HAO_L5_QPT_MAX 3              // minimizers per thread (template parameter QPT = 2 or 3): a read has at most 1024 / 1536; the LDS is laid out for 1536
-#define HAO_L5_R (HAO_L5_QPT_MAX * HAO_L5_THREADS)
+// template parameter QPT: minimizers per thread (2 or 3): a read has at most 1024 / 1536; the LDS tables are laid out for that many rows (hao_l5_lds)
 #define HAO_L5_CH 16                  // records per load slot
 #define HAO_L5_LPS (HAO_L5_CH / 2)     // lanes per slot: a lane reads two consecutive records with one 16-byte load (half the load instructions of 8-byte loads: the
                                       // vector memory pipeline's address processing, not the bytes, was what the record loads of a read cost - 4 us per read)
@@ -49,8 +48,7 @@ struct hao_rec2 { uint64_t a, b; };
 // 48 / 80 / 121 for 8 / 16 / 24 rows per lane) and the minimizer words (8 QPT) are all alive while a read is merged, and a single spilled register is fatal here -
 // its reload is a scratch LOAD, and the s_waitcnt vmcnt(0) in front of its use waits for every record load in flight (the first device run spent the merge waiting
 // for the prefetch it was meant to hide).  So: <QPT 2, NPF 16> for batches whose reads have at most 1024 minimizers (HiFi reads up to ~35 kb), <QPT 3, NPF 8> beyond.
-#define HAO_L5_SL 2048                // slot table
-#define HAO_L5_GW 96                  // group entries per wave
+#define HAO_L5_GW 64                  // group entries per wave
 #define HAO_L5_HB 256                 // bins of the target histogram that splits a read's target range between the waves
 // the unrolled load / staging loops: stop the scheduler from hoisting all 32 address computations (64 more live registers) in front of the first access
 #ifndef HAO_L5_SCHED_FENCE
@@ -59,11 +57,14 @@ struct hao_rec2 { uint64_t a, b; };
 #define HAO_L5_MASK 0xfffffffu      // the read id 2^28 - 1 is the merge's end mark: a read set that uses it (exactly 2^28 reads) takes the table kernels
 #define HAO_L5_SENT 0xffffffffu
 
-template<bool B16> struct hao_l5_lds {
+template<bool B16, int QPT> struct hao_l5_lds {
 	typedef typename std::conditional<B16, uint16_t, uint32_t>::type off_t;
-	static constexpr uint32_t FIXED = HAO_L5_SL * 8 + HAO_L5_W * HAO_L5_GW * 8 + HAO_L5_R * 8 /* qw */ + (HAO_L5_QPT_MAX * HAO_L5_W + 4) * 8 /* scan */ + (HAO_L5_R + 4) * 4 /* ao */ + 64 /* small words */ + 5 * HAO_L5_HB * 4 /* hist x 2, bin_tid, bin_len (one word per THREAD: see the preparation) */ + HAO_L5_R * 2 /* qi */ + 64;
+	static constexpr uint32_t R = QPT * HAO_L5_THREADS;      // rows (minimizers with a list)
+	static constexpr uint32_t SL = 2048;                     // slot table (16 records per slot; a list of c records takes ceil(c / 16))
+	static constexpr uint32_t FIXED = SL * 8 + HAO_L5_W * HAO_L5_GW * 8 + R * 8 /* qw */ + (QPT * HAO_L5_W + 4) * 8 /* scan */ + (R + 4) * 4 /* ao */ + 64 /* small words */
+		+ 5 * HAO_L5_HB * 4 /* hist x 2, bin_tid, bin_len (one word per THREAD: see the preparation) */ + R * 2 /* qi */ + 64;
 	static constexpr uint32_t TOTAL = 160 * 1024;
-	static constexpr uint32_t CAP = ((TOTAL - FIXED) / (B16 ? 6 : 8) - 8) & ~7u;      // record slots (records + one sentinel per row + the guard slot 0)
+	static constexpr uint32_t CAP = ((TOTAL - FIXED) / (B16 ? 6 : 8) - 8) & ~7u;      // record slots (records + one sentinel per row + the guard slot 0): 20 592 at 6 bytes and 1024 rows, 19 568 at 1536
 };
 
 __device__ __forceinline__ uint32_t hao_mbcnt(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
@@ -80,12 +81,14 @@ __device__ __forceinline__ uint64_t hao_readlane_u64(uint64_t v, int l) { return
 struct hao_l5_read { uint64_t m0, s; uint32_t nq, n; uint32_t nk, nslots, nlds; bool valid, skip; };
 
 // the pointers of the workgroup's LDS block
-template<bool B16> struct hao_l5_ptr {
-	uint64_t *slots, *grp, *scan; uint2 *qw; uint32_t *recA, *ao, *sm, *hist, *bin_tid, *bin_len; uint16_t *qi; typename hao_l5_lds<B16>::off_t *recB;
+template<bool B16, int QPT> struct hao_l5_ptr {
+	typedef hao_l5_lds<B16, QPT> LD;
+	uint64_t *slots, *grp, *scan; uint2 *qw; uint32_t *recA, *ao, *sm, *hist, *bin_tid, *bin_len; uint16_t *qi; typename LD::off_t *recB;
 	__device__ __forceinline__ hao_l5_ptr(void *base) {
-		slots = (uint64_t*)base; grp = slots + HAO_L5_SL; qw = (uint2*)(grp + HAO_L5_W * HAO_L5_GW); scan = (uint64_t*)(qw + HAO_L5_R);
-		ao = (uint32_t*)(scan + HAO_L5_QPT_MAX * HAO_L5_W + 4); sm = ao + HAO_L5_R + 4; hist = sm + 16;      /* (hist is read 16 bytes at a time: every array before it is a multiple of 16 bytes) */ bin_tid = hist + 2 * HAO_L5_HB; bin_len = bin_tid + HAO_L5_HB; recA = bin_len + 2 * HAO_L5_HB;
-		recB = (typename hao_l5_lds<B16>::off_t*)(recA + hao_l5_lds<B16>::CAP); qi = (uint16_t*)(recB + hao_l5_lds<B16>::CAP);
+		slots = (uint64_t*)base; grp = slots + LD::SL; qw = (uint2*)(grp + HAO_L5_W * HAO_L5_GW); scan = (uint64_t*)(qw + LD::R);
+		ao = (uint32_t*)(scan + QPT * HAO_L5_W + 4); sm = ao + LD::R + 4; hist = sm + 16;      /* (hist is read 16 bytes at a time: every array before it is a multiple of 16 bytes) */
+		bin_tid = hist + 2 * HAO_L5_HB; bin_len = bin_tid + HAO_L5_HB; recA = bin_len + 2 * HAO_L5_HB;
+		recB = (typename LD::off_t*)(recA + LD::CAP); qi = (uint16_t*)(recB + LD::CAP);
 	}
 };
 
@@ -109,8 +112,8 @@ __device__ __forceinline__ void hao_l5_fold(uint64_t y, uint32_t z, uint32_t &a,
 }
 
 // ---- the merge of one read out of LDS, one wave = one target range [t_lo, t_hi) ----
-template<int RPL, bool B16>
-__device__ __forceinline__ uint32_t hao_l5_merge(const hao_l5_ptr<B16> &L, const uint32_t nk, const uint32_t t_lo, const uint32_t t_hi, const int wv, const int lane,
+template<int RPL, bool B16, int QPT>
+__device__ __forceinline__ uint32_t hao_l5_merge(const hao_l5_ptr<B16, QPT> &L, const uint32_t nk, const uint32_t t_lo, const uint32_t t_hi, const int wv, const int lane,
 		hao_hit_t *__restrict__ hits, uint16_t *__restrict__ hq, const uint32_t *__restrict__ len, const uint32_t hshift, uint32_t &ngr_out)
 {
 	uint32_t hd[RPL], cur[RPL];
@@ -146,7 +149,7 @@ __device__ __forceinline__ uint32_t hao_l5_merge(const hao_l5_ptr<B16> &L, const
 #pragma unroll
 	for (int i = 0; i < RPL; ++i) {
 		before += cur[i]; hd[i] = L.recA[cur[i]]; if constexpr (HBREG) hb[i] = (uint32_t)L.recB[cur[i]];
-		if constexpr (QREG) { const uint2 q_ = L.qw[min((uint32_t)(i * 64 + lane), (uint32_t)(HAO_L5_R - 1))]; qx[i] = q_.x; qy[i] = q_.y; }
+		if constexpr (QREG) { const uint2 q_ = L.qw[min((uint32_t)(i * 64 + lane), (uint32_t)(hao_l5_lds<B16, QPT>::R - 1))]; qx[i] = q_.x; qy[i] = q_.y; }
 	}
 	uint32_t run = hao_wave_incl_scan_u32(before); run = (uint32_t)__builtin_amdgcn_readlane((int)run, 63);
 	uint32_t ngr = 0;
@@ -238,9 +241,9 @@ template<bool B16, int QPT, int NPF, bool DBG>
 __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, const uint32_t *__restrict__ len, const uint64_t *__restrict__ s_pk,
 		uint32_t max_n, uint32_t w0_share, uint32_t *ovf_list, unsigned long long *ovf_cnt)
 {
-	constexpr uint32_t CAP = hao_l5_lds<B16>::CAP;
+	constexpr uint32_t CAP = hao_l5_lds<B16, QPT>::CAP;
 	extern __shared__ uint64_t l5_smem[];
-	const hao_l5_ptr<B16> L((void*)l5_smem);
+	const hao_l5_ptr<B16, QPT> L((void*)l5_smem);
 	const uint32_t tid = threadIdx.x; const int wv = tid >> 6, lane = hao_lane();
 	const uint32_t sg = tid / HAO_L5_LPS, sj = 2 * (tid % HAO_L5_LPS);      // this thread's slot group and its first record inside a slot (it takes records sj and sj + 1)
 	const uint32_t hshift = S.tb > 8 ? (uint32_t)S.tb - 8u : 0u;      // read ids have tb bits: 256 histogram bins over the id range
@@ -290,8 +293,8 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 				const uint32_t sl = i * HAO_L5_SUB + sg;
 				if (sl < re.nslots) {
 					const uint64_t e = L.slots[sl]; const uint32_t c = HAO_L5_SLOT_C(e), z = HAO_L5_SLOT_Z(e), o = HAO_L5_SLOT_O(e) + sj;
-					if (sj < c) { uint32_t a, b; hao_l5_fold(rec[i].a, z, a, b); const uint32_t t = a >> 1; L.recA[o] = a; L.recB[o] = (typename hao_l5_lds<B16>::off_t)b; atomicAdd(&hist_e[t >> hshift], 1u); L.bin_tid[t >> hshift] = t; }
-					if (sj + 1 < c) { uint32_t a, b; hao_l5_fold(rec[i].b, z, a, b); L.recA[o + 1] = a; L.recB[o + 1] = (typename hao_l5_lds<B16>::off_t)b; }      // (the histogram is a sample: every other record)
+					if (sj < c) { uint32_t a, b; hao_l5_fold(rec[i].a, z, a, b); const uint32_t t = a >> 1; L.recA[o] = a; L.recB[o] = (typename hao_l5_lds<B16, QPT>::off_t)b; atomicAdd(&hist_e[t >> hshift], 1u); L.bin_tid[t >> hshift] = t; }
+					if (sj + 1 < c) { uint32_t a, b; hao_l5_fold(rec[i].b, z, a, b); L.recA[o + 1] = a; L.recB[o + 1] = (typename hao_l5_lds<B16, QPT>::off_t)b; }      // (the histogram is a sample: every other record)
 				}
 				if ((i & 1) == 1) HAO_L5_SCHED_FENCE();
 			}
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 				const uint32_t c = HAO_L5_SLOT_C(e), z = HAO_L5_SLOT_Z(e), o = HAO_L5_SLOT_O(e) + sj;
 #pragma unroll
 				for (uint32_t x = 0; x < 2; ++x)
-					if (sj + x < c) { uint32_t a, b; hao_l5_fold(sinfo[HAO_L5_SLOT_G(e) + sj + x], z, a, b); const uint32_t t = a >> 1; L.recA[o + x] = a; L.recB[o + x] = (typename hao_l5_lds<B16>::off_t)b; atomicAdd(&hist_e[t >> hshift], 1u); L.bin_tid[t >> hshift] = t; }
+					if (sj + x < c) { uint32_t a, b; hao_l5_fold(sinfo[HAO_L5_SLOT_G(e) + sj + x], z, a, b); const uint32_t t = a >> 1; L.recA[o + x] = a; L.recB[o + x] = (typename hao_l5_lds<B16, QPT>::off_t)b; atomicAdd(&hist_e[t >> hshift], 1u); L.bin_tid[t >> hshift] = t; }
 			}
 		}
 		HAO_L5_TICK(0)
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 #pragma unroll
 				for (int w = 0; w < HAO_L5_W; ++w) { if (w == wv) basev[m] = run; run += L.scan[m * HAO_L5_W + w]; }
 			rd.nk = (uint32_t)run & 0xffffu; rd.nslots = (uint32_t)(run >> 16) & 0xffffffu; rd.nlds = (uint32_t)(run >> 40);
-			if (go && (rd.nslots > HAO_L5_SL || rd.nlds + 2 > CAP)) rd.skip = true;
+			if (go && (rd.nslots > hao_l5_lds<B16, QPT>::SL || rd.nlds + 2 > CAP)) rd.skip = true;
 			const bool go2 = rd.valid && !rd.skip;
 #pragma unroll
 			for (int m = 0; m < QPT; ++m) {
@@ -404,9 +407,9 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 				hao_hit_t *hits = S.hits + re.s; uint16_t *hq = S.hq ? S.hq + re.s : nullptr;
 				HAO_L5_TICK(5)
 				if (t_lo < t_hi) {
-					if (re.nk <= 8 * 64) (void)hao_l5_merge<8, B16>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, hshift, ngr);
-					else if (QPT == 2 || re.nk <= 16 * 64) (void)hao_l5_merge<16, B16>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, hshift, ngr);
-					else if constexpr (QPT > 2) (void)hao_l5_merge<24, B16>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, hshift, ngr);
+					if (re.nk <= 8 * 64) (void)hao_l5_merge<8, B16, QPT>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, hshift, ngr);
+					else if (QPT == 2 || re.nk <= 16 * 64) (void)hao_l5_merge<16, B16, QPT>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, hshift, ngr);
+					else if constexpr (QPT > 2) (void)hao_l5_merge<24, B16, QPT>(L, re.nk, t_lo, t_hi, wv, lane, hits, hq, len, hshift, ngr);
 				}
 				if (lane == 0) L.sm[wv] = ngr;
 				HAO_L5_TICK(6)

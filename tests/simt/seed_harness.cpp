@@ -60,7 +60,7 @@ extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t 
 		else if (b16) call = [&] { seed_lds_kernel<true, 2, 16, false>(sa, sinfo, len, S.s_pk.data(), max_n, 176u, ovf0.data(), &ovf0_cnt); };
 		else if (wide) call = [&] { seed_lds_kernel<false, 3, 8, false>(sa, sinfo, len, S.s_pk.data(), max_n, 176u, ovf0.data(), &ovf0_cnt); };
 		else call = [&] { seed_lds_kernel<false, 2, 16, false>(sa, sinfo, len, S.s_pk.data(), max_n, 176u, ovf0.data(), &ovf0_cnt); };
-		if (launch(grid, HAO_L5_THREADS, b16 ? hao_l5_lds<true>::TOTAL : hao_l5_lds<false>::TOTAL, call)) return fail(err, errcap, hao_simt::g.error);
+		if (launch(grid, HAO_L5_THREADS, b16 ? hao_l5_lds<true, 2>::TOTAL : hao_l5_lds<false, 2>::TOTAL, call)) return fail(err, errcap, hao_simt::g.error);
 		stats[6] = ovf0_cnt;
 		if (ovf0_cnt) {
 			std::function<void()> call = [&] { seed_bin_kernel<9, 1, 512, true>(sa, ovf0.data(), &ovf0_cnt, ovf1, &ovf_cnt[0]); };

@@ -21,10 +21,18 @@ NAME = "human375M_hifi40x"
 IX_RECORDS = 3_450_000_000      # minimizers of configs[3]'s 8 M reads = position records of the replicated index
 
 
+def device_mem_info():
+    """(free, total) bytes from the HIP runtime libhao.so is linked with (not torch's own copy of it: a second runtime in the process may not get the device)"""
+    import ctypes
+    so = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln}, key=lambda p: ("/torch/" in p, p))
+    hip = ctypes.CDLL(so[0]); fr, to = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert hip.hipMemGetInfo(ctypes.byref(fr), ctypes.byref(to)) == 0
+    return fr.value, to.value
+
+
 def test_a_configs3_rank_sized_round_against_the_reference():
     if not os.path.exists(os.path.join(GOLDEN, NAME + ".npz")):
         pytest.skip(f"no fixture tests/golden/{NAME}.npz (tests/golden/make_golden_big.py)")
-    import torch
     from hifiasm_amd import memplan
     from hifiasm_amd.api import Engine
     from hifiasm_amd.workloads import WORKLOADS, workload_reads, n_reads_of
@@ -46,7 +54,7 @@ def test_a_configs3_rank_sized_round_against_the_reference():
         assert (e.hist(1) == g["pt_hist"]).all()
         batch = 64_000
         dig = np.zeros(rs.n, dtype=np.uint64); dkh = np.zeros(rs.n, dtype=np.uint64); tot_ol = tot_cl = tot_kh = 0; left = 0
-        torch.cuda.synchronize(); t0 = time.time()
+        t0 = time.time()      # (every call below returns with its results on the host)
         for lo in range(0, rs.n, batch):
             hi = min(rs.n, lo + batch)
             e.overlap_batch(lo, hi)
@@ -54,8 +62,8 @@ def test_a_configs3_rank_sized_round_against_the_reference():
             sp = e.batch_seed_path(); assert sp["first_launch"] == "seed_lds_kernel", sp      # 40x repeat-free reads: 16 k hits per read, one per (minimizer x coverage)
             left += sp["left_to_tables"]
             d, k = e.batch_digest(hi - lo); dig[lo:hi] = d; dkh[lo:hi] = k
-        torch.cuda.synchronize(); t_pass = time.time() - t0
-        fr, to = torch.cuda.mem_get_info(0)
+        t_pass = time.time() - t0
+        fr, to = device_mem_info()
         assert tot_ol == m["pass_overlaps"] and tot_cl == m["pass_chained_hits"]
         f, fk = fold_digests(dig), fold_digests(dkh)
         assert (fk == g["dig_kh_fold"]).all(), f"seed hits differ in read blocks {np.flatnonzero(fk != g['dig_kh_fold'])[:10]}"
