@@ -40,7 +40,7 @@ from hifiasm_amd.workloads import WORKLOADS, LEN_JIT, n_reads_of  # noqa: E402
 STRONG = {"human3G_hifi40x", "ont_human_30x"}      # fixed-size problems: the read set is split over the ranks
 VARIANT_OF = {"chr1_250M_hifi30x": "chr1_250M_hifi30x_repeat", "bacterial5M_hifi30x": "bacterial5M_hifi30x_repeat"}      # the repeat-rich twin of a workload
 # a one-GPU PROXY of one rank of configs[3] on 8 GPUs (no multi-GPU box has been available in any round): a rank's read count at configs[3]'s coverage - i.e. its
-# seed-hit density - over an index padded (HAO_DBG_IX_PAD) to the replicated index's 3.45 G position records.  What it does NOT contain: the exchanges of
+# seed-hit density - over an index padded (HAO_DBG_TEST=ix_pad=N) to the replicated index's 3.45 G position records.  What it does NOT contain: the exchanges of
 # ha_ft_gen / ha_pt_gen (all-to-all-v, one 27.6 GB all-gather per round) and target ids spread over 8 M reads.  8 x its rate minus that all-gather is a PREDICTION of the
 # 8-GPU metric, not a measurement: no scaling curve has been measured.
 RANK_PROXY_OF = {"chr1_250M_hifi30x": ("human375M_hifi40x", 3_450_000_000)}
@@ -50,8 +50,7 @@ ALG = {
     "sketch_unit_kernel": ("base", 0.25 + 16.0 / 35.0),             # 2-bit bases in + one 16-B minimizer per ~35 bases out
     "chain_group_kernel": ("anchor", 16 + 4),                        # k_mer_hit in + fake-cigar / record out (hits stay in place)
     "seed_lds_kernel": ("anchor", 8 + 16),                           # index record in (once, coalesced), k_mer_hit out (the read's position lists staged in LDS and merged by target there, hao_query5.cuh)
-    "seed_merge_kernel": ("anchor", 8 + 16),                         # (HAO_SEED_LDS=0: round 5) the one-wave merge with lane-private list reads, hao_query4.cuh
-    "seed_bin_kernel": ("anchor", 8 + 16),                           # (repeat-rich batches; HAO_SEED_LDS=0 HAO_SEED_MERGE=0: the table kernels of rounds 1 - 4) index record in, k_mer_hit out
+    "seed_bin_kernel": ("anchor", 8 + 16),                           # (repeat-rich batches; HAO_SEED_LDS=0: the table kernels of rounds 1 - 4) index record in, k_mer_hit out
 }
 METRIC_WORKLOAD = "human3G_hifi40x"      # BASELINE.json configs[3]: the configuration the metric is quoted on (8 GPUs)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
@@ -321,7 +320,7 @@ def run_workload(a, workload, steps, warmup, rank, local_rank, world, dist, torc
         try:
             seed_path = eng.batch_seed_path()
         except Exception:      # (the owner context ran no batch of its own: --contexts > 1)
-            seed_path = {"first_launch": "seed_bin_kernel" if os.environ.get("HAO_SEED_LDS") == "0" and os.environ.get("HAO_SEED_MERGE") == "0" else "seed_lds_kernel", "left_to_tables": None}
+            seed_path = {"first_launch": "seed_bin_kernel" if os.environ.get("HAO_SEED_LDS") == "0" else "seed_lds_kernel", "left_to_tables": None}
         seed_kernel = seed_path["first_launch"]
         KERN_STAGE = {"sketch_unit_kernel": "sk_chunks", "chain_group_kernel": "q_chain", seed_kernel: "q_sort_bins"}
         dom = max(KERN_STAGE, key=lambda k: stage_ms.get(KERN_STAGE[k], 0.0))
@@ -501,11 +500,11 @@ def main():
             pw, ix_records = prox
             g_, cov_, L_, err_ = WORKLOADS[pw][:4]
             n_mz_ = int(0.02873 * g_ * cov_)      # (minimizers of the proxy's own reads: the pad brings the index to the replicated index's size)
-            os.environ["HAO_DBG_IX_PAD"] = str(max(0, ix_records - n_mz_))
+            os.environ["HAO_DBG_TEST"] = "ix_pad=" + str(max(0, ix_records - n_mz_))
             try:
                 v = run_workload(a, pw, 1, 1, rank, local_rank, world, dist, torch, force_sharded)
             finally:
-                del os.environ["HAO_DBG_IX_PAD"]
+                del os.environ["HAO_DBG_TEST"]
             g3_, cov3_, L3_, err3_ = WORKLOADS[METRIC_WORKLOAD][:4]
             plan = memplan.rank_plan(float(g3_) * cov3_, n_reads_of(METRIC_WORKLOAD), 8, 0.02873, 0.92 * 0.02873 * L3_ * cov3_, float(g3_), err=err3_)
             pv = {k: v[k] for k in ("value", "ms_per_step", "value_resident", "ms_per_step_resident", "steps", "warmup", "roofline", "stage_ms", "config", "boundary", "device_memory")}

@@ -47,7 +47,7 @@ class Delivery(C.Structure):
                 ("n_cl", C.c_uint64), ("n_exc", C.c_uint64), ("n_codes", C.c_uint64), ("n_pos", C.c_uint64), ("bytes", C.c_uint64),
                 ("ol_off", C.c_void_p), ("ol", C.c_void_p), ("fc_off", C.c_void_p), ("fc", C.c_void_p), ("ch_off", C.c_void_p),
                 ("cl_off", C.c_void_p), ("qm_off", C.c_void_p), ("chains", C.c_void_p), ("cl_bits", C.c_void_p), ("cl_rank", C.c_void_p), ("cl_codes", C.c_void_p), ("qmz", C.c_void_p),
-                ("cl_exc", C.c_void_p), ("exact", C.c_void_p), ("copy_ms", C.c_double)]
+                ("cl_exc", C.c_void_p), ("exact", C.c_void_p), ("copy_ms", C.c_double), ("qmz_pos", C.c_void_p), ("qmz_cnt", C.c_void_p)]
 
 
 DELIVER_OL, DELIVER_CL, DELIVER_EXACT = 1, 2, 4

@@ -26,16 +26,16 @@ struct hao_ctx::Batch {
 	struct OutSet {
 		DevBuf<hao_ovlp_t> ol_out; DevBuf<uint64_t> fin_off, fc_out, fc_out_off, ch_off, cl_off, qm_off, fcw_off; DevBuf<uint32_t> fcw;      // (fcw*: the fake cigars as they travel, hao_deliver.cuh)
 		//      // ol->list in final order, per-read offsets, fake cigars
-		DevBuf<hao_chain_hdr_t> hdr; DevBuf<uint64_t> bits; DevBuf<uint32_t> rank, rank4; DevBuf<uint8_t> codes; DevBuf<hao_exc_t> exc, exc2; DevBuf<hao_qmz_t> qmz;   // cl->list in the wire format (hao_deliver.cuh)
+		DevBuf<hao_chain_hdr_t> hdr; DevBuf<uint64_t> bits; DevBuf<uint32_t> rank, rank4; DevBuf<uint8_t> codes; DevBuf<hao_exc_t> exc; DevBuf<hao_qmz_t> qmz; DevBuf<uint16_t> qmz_pos, qmz_cnt; bool qmz16 = false;   // cl->list in the wire format (hao_deliver.cuh)
 		DevBuf<uint8_t> exact;                                                                        // exact-overlap flags of ol_out
-		void release() { fcw_off.release(); fcw.release(); ol_out.release(); fin_off.release(); fc_out.release(); fc_out_off.release(); ch_off.release(); cl_off.release(); qm_off.release(); hdr.release(); bits.release(); rank.release(); rank4.release(); codes.release(); exc.release(); exc2.release(); qmz.release(); exact.release(); }
+		void release() { fcw_off.release(); fcw.release(); ol_out.release(); fin_off.release(); fc_out.release(); fc_out_off.release(); ch_off.release(); cl_off.release(); qm_off.release(); hdr.release(); bits.release(); rank.release(); rank4.release(); codes.release(); exc.release(); qmz.release(); qmz_pos.release(); qmz_cnt.release(); exact.release(); }
 	} out[2];
 	int cur = 0;
 	OutSet &O() { return out[cur]; }
 	// delivery state: pinned host arenas, copy stream, per-slot completion events
-	unsigned char *arena[2] = { nullptr, nullptr }, *arena_dev[2] = { nullptr, nullptr }; size_t arena_cap[2] = { 0, 0 }; bool arena_reg[2] = { false, false };      // arena_reg: mmap + mbind + hipHostRegister (hao_arena_alloc)
-	void arena_free(int x) { if (!arena[x]) return; if (arena_reg[x]) { (void)hipHostUnregister(arena[x]); (void)munmap(arena[x], arena_cap[x]); } else (void)hipHostFree(arena[x]); arena[x] = nullptr; arena_cap[x] = 0; arena_reg[x] = false; } hipStream_t copy_stream = nullptr, copy_aux[8]; hipEvent_t ev_ready[2], ev_done[2], ev_aux[2][8]; int n_aux = 0; bool dl_ready = false, dl_pending[2] = { false, false };
-	uint32_t wgt_hi = 0xffffffffu, wgt_lo = 0xffffffffu;
+	unsigned char *arena[2] = { nullptr, nullptr }; size_t arena_cap[2] = { 0, 0 }; bool arena_reg[2] = { false, false };      // arena_reg: mmap + mbind + hipHostRegister (hao_arena_alloc)
+	void arena_free(int x) { if (!arena[x]) return; if (arena_reg[x]) { (void)hipHostUnregister(arena[x]); (void)munmap(arena[x], arena_cap[x]); } else (void)hipHostFree(arena[x]); arena[x] = nullptr; arena_cap[x] = 0; arena_reg[x] = false; } hipStream_t copy_stream = nullptr; hipEvent_t ev_ready[2], ev_done[2]; bool dl_ready = false, dl_pending[2] = { false, false };
+	uint32_t wgt_hi = 0xffffffffu, wgt_lo = 0xffffffffu, wgt_max = 0xffffffffu;      // (wgt_max: the largest k_mer_hit::cnt the pass's weight table can give)
 	double t_evsync = 0, t_enq = 0, t_alloc = 0, t_s1 = 0, t_s2 = 0, t_s3 = 0, t_run = 0, t_pre = 0; uint64_t t_n = 0, t_nrun = 0;      // host-side time spent in the delivery plumbing (HAO_DBG_DLTIME)
 	hao_delivery_t dl[2]; uint64_t dl_seq = 0, n_exc = 0; uint32_t dl_parts = 0; bool exact_valid = false; std::vector<uint8_t> h_exact;
 	// host copies for fetch
@@ -48,7 +48,7 @@ struct hao_ctx::Batch {
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fcf_off.release();
 		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); g_cls.release(); slow.release(); ovf_list.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
 		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); cd.release(); pk_cnt.release(); pk_ecnt.release(); pk_erank.release(); hq.release(); ohq.release(); hcode.release(); out[0].release(); out[1].release();
-		if (dl_ready) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); for (int k = 0; k < n_aux; ++k) { (void)hipStreamSynchronize(copy_aux[k]); (void)hipStreamDestroy(copy_aux[k]); (void)hipEventDestroy(ev_aux[0][k]); (void)hipEventDestroy(ev_aux[1][k]); } for (int x = 0; x < 2; ++x) { (void)hipEventDestroy(ev_ready[x]); (void)hipEventDestroy(ev_done[x]); arena_free(x); } dl_ready = false; }
+		if (dl_ready) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); for (int x = 0; x < 2; ++x) { (void)hipEventDestroy(ev_ready[x]); (void)hipEventDestroy(ev_done[x]); arena_free(x); } dl_ready = false; }
 	}
 };
 
@@ -129,7 +129,6 @@ static unsigned char *hao_arena_alloc_bound(size_t bytes, int node)
 	return (unsigned char*)m;
 }
 static inline double hao_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-struct ExcLess { __host__ __device__ bool operator()(const hao_exc_t &a, const hao_exc_t &b) const { return a.index < b.index; } };
 
 static int hao_scan_u32(hao_ctx *c, const uint32_t *in, uint64_t *out, uint64_t n_plus1)
 {
@@ -193,7 +192,8 @@ static int hao_deliver_enqueue(hao_ctx *c)
 	const bool ol = parts & HAO_DELIVER_OL, cl = parts & HAO_DELIVER_CL, ex = parts & HAO_DELIVER_EXACT;
 	size_t o_oloff = 0, o_ol = o_oloff + (ol ? al((n + 1) * 8) : 0), o_fcoff = o_ol + (ol ? al(B.n_ol * sizeof(hao_ovlp_t)) : 0), o_fc = o_fcoff + (ol ? al((B.n_ol + 1) * 8) : 0);
 	size_t o_choff = o_fc + (ol ? al(B.n_fcw * 4) : 0), o_cloff = o_choff + (cl ? al((n + 1) * 8) : 0), o_qmoff = o_cloff + (cl ? al((n + 1) * 8) : 0), o_hdr = o_qmoff + (cl ? al((n + 1) * 8) : 0);
-	size_t o_qmz = o_hdr + (cl ? al(B.n_chains * sizeof(hao_chain_hdr_t)) : 0), o_bits = o_qmz + (cl ? al(B.n_mz * sizeof(hao_qmz_t)) : 0);
+	const bool q16 = O.qmz16;      // the minimizer tables in 2 + 2 bytes per minimizer (hao_qtab16_kernel) instead of 8
+	size_t o_qmz = o_hdr + (cl ? al(B.n_chains * sizeof(hao_chain_hdr_t)) : 0), o_qmc = o_qmz + (cl ? al(B.n_mz * (q16 ? 2 : sizeof(hao_qmz_t))) : 0), o_bits = o_qmc + (cl && q16 ? al(B.n_mz * 2) : 0);
 	const uint64_t nw_ = cl ? (B.n_anchor + 63) / 64 : 0;      // 64-position words of the batch's bit stream (positions = seed hits)
 	const uint64_t nr4_ = cl ? nw_ / 4 + 1 : 0;      // rank directory entries on the wire: one per 256 positions
 	size_t o_rank = o_bits + (cl ? al(nw_ * 8) : 0), o_codes = o_rank + (cl ? al(nr4_ * 4) : 0), o_exc = o_codes + (cl ? al(B.n_codes) : 0);
@@ -231,19 +231,11 @@ static int hao_deliver_enqueue(hao_ctx *c)
 		if (c->sw.dltime) fprintf(stderr, "[deliver] arena %d: %zu MB, GPU NUMA node %d (requested mode %d, allocated %s, %d of 32 sampled pages on the node)\n", s, want >> 20, node_, c->sw.arena_numa, he_ == hipSuccess ? how_ : "FAILED", on_);
 		HIP_TRY(he_);
 		B.arena_cap[s] = want; B.t_alloc += hao_now() - t0_;
-		HIP_TRY(hipHostGetDevicePointer((void**)&B.arena_dev[s], B.arena[s], 0));
 	}
 	unsigned char *a = B.arena[s];
 	HIP_TRY(hipEventRecord(B.ev_ready[s], c->stream));
 	HIP_TRY(hipStreamWaitEvent(B.copy_stream, B.ev_ready[s], 0));
-	const int ck = c->sw.copy_kernel;      // copy by kernel (16-byte granules: sections are 64-byte aligned in the arena, device buffers have slack past their last element)
-	auto cp = [&](size_t off, const void *src, size_t bytes) -> hipError_t {
-		if (!bytes) return hipSuccess;
-		if (!ck) return hipMemcpyAsync(a + off, src, bytes, hipMemcpyDeviceToHost, B.copy_stream);
-		const uint64_t n16 = (bytes + 15) / 16;
-		hipLaunchKernelGGL(hao_d2h_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)ck, (n16 + 255) / 256)), dim3(256), 0, B.copy_stream, (const hao_v4u*)src, (hao_v4u*)(B.arena_dev[s] + off), n16);
-		return hipGetLastError();
-	};
+	auto cp = [&](size_t off, const void *src, size_t bytes) -> hipError_t { return bytes ? hipMemcpyAsync(a + off, src, bytes, hipMemcpyDeviceToHost, B.copy_stream) : hipSuccess; };
 	hao_delivery_t &d = B.dl[s];
 	d.rid_lo = B.lo; d.n_reads = n; d.n_ol = d.n_fc = d.n_chains = d.n_cl = d.n_exc = d.n_codes = d.n_pos = 0; d.bytes = 0;
 	if (ol && n) {
@@ -255,24 +247,12 @@ static int hao_deliver_enqueue(hao_ctx *c)
 	}
 	if (cl && n) {
 		HIP_TRY(cp(o_choff, O.ch_off.p, (n + 1) * 8)); HIP_TRY(cp(o_cloff, O.cl_off.p, (n + 1) * 8)); HIP_TRY(cp(o_qmoff, O.qm_off.p, (n + 1) * 8));
-		HIP_TRY(cp(o_hdr, O.hdr.p, B.n_chains * sizeof(hao_chain_hdr_t))); HIP_TRY(cp(o_qmz, O.qmz.p, B.n_mz * sizeof(hao_qmz_t))); HIP_TRY(cp(o_exc, O.exc.p, B.n_exc * sizeof(hao_exc_t)));
+		HIP_TRY(cp(o_hdr, O.hdr.p, B.n_chains * sizeof(hao_chain_hdr_t))); if (q16) { HIP_TRY(cp(o_qmz, O.qmz_pos.p, B.n_mz * 2)); HIP_TRY(cp(o_qmc, O.qmz_cnt.p, B.n_mz * 2)); } else HIP_TRY(cp(o_qmz, O.qmz.p, B.n_mz * sizeof(hao_qmz_t))); HIP_TRY(cp(o_exc, O.exc.p, B.n_exc * sizeof(hao_exc_t)));
 		HIP_TRY(cp(o_bits, O.bits.p, nw_ * 8)); HIP_TRY(cp(o_rank, O.rank4.p, nr4_ * 4));
-		{	// the code bytes: 1 + n_aux pieces on as many streams (separate DMA queues)
-			const int np = ck ? 1 : B.n_aux + 1; const uint64_t per = ((B.n_codes + np - 1) / np + 63) & ~63ULL;
-			for (int k = 0; k < np; ++k) {
-				const uint64_t lo_ = std::min<uint64_t>(B.n_codes, per * k), hi_ = std::min<uint64_t>(B.n_codes, per * (k + 1));
-				if (hi_ <= lo_) continue;
-				if (k == 0) { HIP_TRY(cp(o_codes, O.codes.p, hi_ - lo_)); continue; }
-				hipStream_t st = B.copy_aux[k - 1];
-				HIP_TRY(hipStreamWaitEvent(st, B.ev_ready[s], 0));
-				HIP_TRY(hipMemcpyAsync(a + o_codes + lo_, O.codes.p + lo_, hi_ - lo_, hipMemcpyDeviceToHost, st));
-				HIP_TRY(hipEventRecord(B.ev_aux[s][k - 1], st));
-				HIP_TRY(hipStreamWaitEvent(B.copy_stream, B.ev_aux[s][k - 1], 0));
-			}
-		}
+		HIP_TRY(cp(o_codes, O.codes.p, B.n_codes));
 		d.n_chains = B.n_chains; d.n_cl = B.n_cl; d.n_exc = B.n_exc; d.n_codes = B.n_codes; d.n_pos = B.n_anchor; d.ch_off = (const uint64_t*)(a + o_choff); d.cl_off = (const uint64_t*)(a + o_cloff); d.qm_off = (const uint64_t*)(a + o_qmoff);
-		d.chains = (const hao_chain_hdr_t*)(a + o_hdr); d.qmz = (const hao_qmz_t*)(a + o_qmz); d.cl_bits = (const uint64_t*)(a + o_bits); d.cl_rank = (const uint32_t*)(a + o_rank); d.cl_codes = a + o_codes; d.cl_exc = (const hao_exc_t*)(a + o_exc);
-		d.bytes += 3 * (n + 1) * 8 + B.n_chains * sizeof(hao_chain_hdr_t) + B.n_mz * sizeof(hao_qmz_t) + nw_ * 8 + nr4_ * 4 + B.n_codes + B.n_exc * sizeof(hao_exc_t);
+		d.chains = (const hao_chain_hdr_t*)(a + o_hdr); d.qmz = q16 ? nullptr : (const hao_qmz_t*)(a + o_qmz); d.qmz_pos = q16 ? (const uint16_t*)(a + o_qmz) : nullptr; d.qmz_cnt = q16 ? (const uint16_t*)(a + o_qmc) : nullptr; d.cl_bits = (const uint64_t*)(a + o_bits); d.cl_rank = (const uint32_t*)(a + o_rank); d.cl_codes = a + o_codes; d.cl_exc = (const hao_exc_t*)(a + o_exc);
+		d.bytes += 3 * (n + 1) * 8 + B.n_chains * sizeof(hao_chain_hdr_t) + B.n_mz * (q16 ? 4 : sizeof(hao_qmz_t)) + nw_ * 8 + nr4_ * 4 + B.n_codes + B.n_exc * sizeof(hao_exc_t);
 	}
 	if (ex && n) { HIP_TRY(cp(o_ex, O.exact.p, B.n_ol)); d.exact = a + o_ex; d.n_ol = B.n_ol; d.bytes += B.n_ol; }
 	HIP_TRY(hipEventRecord(B.ev_done[s], B.copy_stream));
@@ -285,8 +265,6 @@ static int hao_deliver_init(hao_ctx *c, hao_ctx::Batch &B)
 	if (B.dl_ready) return HAO_OK;
 	HIP_TRY(hipStreamCreateWithFlags(&B.copy_stream, hipStreamNonBlocking));
 	for (int x = 0; x < 2; ++x) { HIP_TRY(hipEventCreate(&B.ev_ready[x])); HIP_TRY(hipEventCreate(&B.ev_done[x])); }
-	B.n_aux = c->sw.copy_streams - 1;      // the bulk of a batch (the packed cl->list) is cut into pieces that travel on separate streams = separate DMA queues
-	for (int k = 0; k < B.n_aux; ++k) { HIP_TRY(hipStreamCreateWithFlags(&B.copy_aux[k], hipStreamNonBlocking)); for (int x = 0; x < 2; ++x) HIP_TRY(hipEventCreateWithFlags(&B.ev_aux[x][k], hipEventDisableTiming)); }
 	B.dl_ready = true;
 	return HAO_OK;
 }
@@ -324,7 +302,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	if (B.wgt_hi != ps.high_occ || B.wgt_lo != ps.low_occ || !B.wgt.p) {      // seed weights depend on the pass's occurrence thresholds only: uploaded when those change
 		std::vector<uint32_t> wt; hao_seed_weight_table(ps.high_occ, ps.low_occ, wt);
 		HIP_TRY(B.wgt.reserve(4096)); HIP_TRY(hipMemcpy(B.wgt.p, wt.data(), 4096 * 4, hipMemcpyHostToDevice));
-		B.wgt_hi = ps.high_occ; B.wgt_lo = ps.low_occ;
+		B.wgt_hi = ps.high_occ; B.wgt_lo = ps.low_occ; B.wgt_max = *std::max_element(wt.begin(), wt.end());
 	}
 	HIP_TRY(B.q_pos.reserve(nm + 1)); HIP_TRY(B.q_cnt.reserve(nm + 1));
 	HIP_TRY(B.s_start.reserve(nm + 1)); HIP_TRY(B.s_pk.reserve(nm + 1)); HIP_TRY(B.s_n.reserve(nm + 1)); HIP_TRY(B.a_off.reserve(nm + 2)); HIP_TRY(B.seg.reserve(n + 2));
@@ -363,8 +341,8 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		if (parts & HAO_DELIVER_CL) {      // the wire format's code array (one byte per seed hit, 0x08 = nothing to say) and, for the quick check's codes, every hit's minimizer index
 			HIP_TRY(B.hcode.reserve(A + 64));
 			// (the quick-check kernels write every position of every group they see; only the debug paths that bypass them need the array pre-filled)
-			if (c->sw.seq_chain || c->sw.tiny_lane || c->sw.pack_search || c->sw.dp_seqtail || c->sw.dp_nospec) { const uint64_t n16 = (A + 31) / 16; hipLaunchKernelGGL(hao_fill16_kernel, dim3((unsigned)std::min<uint64_t>((n16 + 255) / 256, 1u << 14)), dim3(256), 0, c->stream, (hao_fill_v4*)B.hcode.p, n16, 0x08080808u); HAO_CHECK_LAUNCH(); }
-			if (!c->sw.pack_search) { HIP_TRY(B.hq.reserve(A + 64)); sa_.hq = B.hq.p; }
+			if (c->sw.seq_chain || c->sw.dp_seqtail || c->sw.dp_nospec) { const uint64_t n16 = (A + 31) / 16; hipLaunchKernelGGL(hao_fill16_kernel, dim3((unsigned)std::min<uint64_t>((n16 + 255) / 256, 1u << 14)), dim3(256), 0, c->stream, (hao_fill_v4*)B.hcode.p, n16, 0x08080808u); HAO_CHECK_LAUNCH(); }
+			HIP_TRY(B.hq.reserve(A + 64)); sa_.hq = B.hq.p;
 		}
 		if (c->sw.seedphase) { HIP_TRY(B.dbgbuf.reserve(64)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 512, c->stream)); sa_.dbg = B.dbgbuf.p; }
 		HIP_TRY(B.ovf_list.reserve(3 * (n + 1)));
@@ -466,7 +444,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		hao_chain_args ca;
 		ca.hits = B.hits.p; ca.g_start = B.g_start.p; ca.g_read = B.g_read.p; ca.g_off = B.g_off.p; ca.seg = B.seg.p; ca.n_groups = G; ca.rid_lo = glo; ca.len = c->d_len_all.p; ca.par = par;
 		ca.dbg_qc = nullptr; ca.hq = nullptr; ca.hcode = nullptr; ca.ohq = nullptr; ca.exc_every = (uint32_t)c->sw.exc_every;
-		if ((parts & HAO_DELIVER_CL) && !c->sw.pack_search) { HIP_TRY(B.ohq.reserve(A + 64)); ca.hq = B.hq.p; ca.hcode = B.hcode.p; ca.ohq = B.ohq.p; }
+		if (parts & HAO_DELIVER_CL) { HIP_TRY(B.ohq.reserve(A + 64)); ca.hq = B.hq.p; ca.hcode = B.hcode.p; ca.ohq = B.ohq.p; }
 		if (c->sw.qcphase) { HIP_TRY(B.dbgbuf.reserve(8)); HIP_TRY(hipMemsetAsync(B.dbgbuf.p, 0, 64, c->stream)); ca.dbg_qc = B.dbgbuf.p; }
 		ca.stats = d_slow_cnt; ca.dbg_stats = c->sw.dp_stats ? 1 : 0;
 		ca.dbg_seq = c->sw.seq_chain ? 1 : (c->sw.dp_seqtail ? 3 : (c->sw.dp_nospec ? 4 : 0));
@@ -476,18 +454,17 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		ca.tm = B.tm.p; ca.f = B.f.p; ca.ii = B.ii.p; ca.p = B.p.p; ca.t = B.t.p; ca.ohits = B.ohits.p; ca.fcs = B.fcs.p; ca.rec = B.rec.p; ca.nch = B.nch.p; ca.nout = B.nout.p;
 		if (!B.side_ready) {
 			int plo_ = 0, phi_ = 0; (void)hipDeviceGetStreamPriorityRange(&plo_, &phi_);      // same priority class as the engine's stream (see hao_create)
-			for (int x = 0; x < HAO_NCLS; ++x) { HIP_TRY(hipStreamCreateWithPriority(&B.side[x], hipStreamNonBlocking, c->sw.stream_prio ? phi_ : plo_)); HIP_TRY(hipEventCreateWithFlags(&B.ev_qc[x], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&B.ev_dp[x], hipEventDisableTiming)); }
+			for (int x = 0; x < HAO_NCLS; ++x) { HIP_TRY(hipStreamCreateWithPriority(&B.side[x], hipStreamNonBlocking, plo_)); HIP_TRY(hipEventCreateWithFlags(&B.ev_qc[x], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&B.ev_dp[x], hipEventDisableTiming)); }
 			B.side_ready = true;
 		}
-		const int wpb = c->sw.chain_wpb;
 		const bool serial = c->sw.dp_serial;      // DP kernels on the main stream (no overlap), for A/B timing
-		const int spec_min = c->sw.spec_mincls;      // tiles of <= 64 hits gain nothing from speculation
+		const int spec_min = 2;      // tiles of <= 64 hits gain nothing from speculation
 		const int dbg_seq0 = ca.dbg_seq;
 		for (int x = HAO_NCLS - 1; x >= 1; --x) {
 			const uint64_t nl = cls_cnt[x]; if (!nl) continue;
 			ca.dbg_seq = (dbg_seq0 == 0 && x < spec_min) ? 4 : dbg_seq0;
 			const hao_gent *lst = B.glist.p + L.base[x]; uint32_t *slow = B.slow.p + L.base[x];
-			hipLaunchKernelGGL(chain_group_kernel, dim3((unsigned)((nl + wpb - 1) / wpb)), dim3(64 * wpb), 0, c->stream, ca, lst, nl, slow, x);
+			hipLaunchKernelGGL(chain_group_kernel, dim3((unsigned)nl), dim3(64), 0, c->stream, ca, lst, nl, slow, x);
 			HAO_CHECK_LAUNCH();
 			hipStream_t ds = serial ? c->stream : B.side[x];
 			if (!serial) { HIP_TRY(hipEventRecord(B.ev_qc[x], c->stream)); HIP_TRY(hipStreamWaitEvent(ds, B.ev_qc[x], 0)); }
@@ -498,10 +475,10 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 			if (!serial) HIP_TRY(hipEventRecord(B.ev_dp[x], ds));
 		}
 		ca.dbg_seq = dbg_seq0;
-		if (cls_cnt[0]) {      // groups of <= HAO_TINY_MAX hits: eight per wave through the data-parallel quick check (A/B and HAO_DBG_SEQ_CHAIN: one lane per group, the complete sequential algorithm)
+		if (cls_cnt[0]) {      // groups of <= HAO_TINY_MAX hits: eight per wave through the data-parallel quick check, the rejected ones by one lane each (HAO_DBG_FORCE=seq_chain: all of them)
 			const hao_gent *lst0 = B.glist.p + L.base[0]; uint32_t *slow0 = B.slow.p + L.base[0];
 			const unsigned nb_lane = (unsigned)std::min<uint64_t>((cls_cnt[0] + 63) / 64, 256 * 64);
-			if (c->sw.tiny_lane || ca.dbg_seq == 1) hipLaunchKernelGGL(chain_tiny_kernel, dim3(nb_lane), dim3(64), 0, c->stream, ca, lst0, (uint64_t)cls_cnt[0], (const uint32_t*)nullptr, (const unsigned long long*)nullptr);
+			if (ca.dbg_seq == 1) hipLaunchKernelGGL(chain_tiny_kernel, dim3(nb_lane), dim3(64), 0, c->stream, ca, lst0, (uint64_t)cls_cnt[0], (const uint32_t*)nullptr, (const unsigned long long*)nullptr);
 			else {
 				hipLaunchKernelGGL(chain_pack8_kernel, dim3((unsigned)((cls_cnt[0] + 31) / 32)), dim3(256), 0, c->stream, ca, lst0, (uint64_t)cls_cnt[0], slow0);
 				HAO_CHECK_LAUNCH();
@@ -546,14 +523,12 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		if (!G) return HAO_OK;
 		hao_ctx::Batch::OutSet &O = B.O();
 		hipLaunchKernelGGL(hao_pack_hdr_kernel, dim3((unsigned)((NCmax + 255) / 256)), dim3(256), 0, ps, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH();
-		if (!pa.have_codes) { hipLaunchKernelGGL(hao_pack_ohits_kernel, dim3((unsigned)std::min<uint64_t>((NCmax + 3) / 4, 1u << 16)), dim3(256), 0, ps, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH(); }      // (HAO_DBG_PACK_SEARCH: every chain coded by the packer)
-		const bool scan_exc = pa.have_codes != 0;      // verbatim list by count + scan, in position order (the HAO_DBG_PACK_SEARCH packer appends its own entries through the counter: that list is sorted afterwards)
-		hipLaunchKernelGGL(hao_pack_bits_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, ps, pa, A, NW, O.bits.p, B.pk_cnt.p, scan_exc ? B.pk_ecnt.p : (uint32_t*)nullptr); HAO_CHECK_LAUNCH();
+		hipLaunchKernelGGL(hao_pack_bits_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, ps, pa, A, NW, O.bits.p, B.pk_cnt.p, B.pk_ecnt.p); HAO_CHECK_LAUNCH();      // (the verbatim list: by count + scan, in position order)
 		size_t tb = 0;
 		HIP_TRY(rocprim::exclusive_scan(nullptr, tb, B.pk_cnt.p, O.rank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), ps)); HIP_TRY(B.pk_tmp.reserve(tb + 256));
 		HIP_TRY(rocprim::exclusive_scan(B.pk_tmp.p, tb, B.pk_cnt.p, O.rank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), ps));
-		if (scan_exc) HIP_TRY(rocprim::exclusive_scan(B.pk_tmp.p, tb, B.pk_ecnt.p, B.pk_erank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), ps));
-		hipLaunchKernelGGL(hao_pack_codes_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, ps, pa, B.hcode.p, A, O.bits.p, O.rank.p, NW, O.codes.p, d_n_codes, scan_exc ? B.pk_erank.p : (const uint32_t*)nullptr); HAO_CHECK_LAUNCH();
+		HIP_TRY(rocprim::exclusive_scan(B.pk_tmp.p, tb, B.pk_ecnt.p, B.pk_erank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), ps));
+		hipLaunchKernelGGL(hao_pack_codes_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, ps, pa, B.hcode.p, A, O.bits.p, O.rank.p, NW, O.codes.p, d_n_codes, B.pk_erank.p); HAO_CHECK_LAUNCH();
 		{ const uint64_t n4 = NW / 4 + 1; hipLaunchKernelGGL(hao_rank4_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, ps, O.rank.p, n4, O.rank4.p); HAO_CHECK_LAUNCH(); }
 		return HAO_OK;
 	};
@@ -563,13 +538,15 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		HIP_TRY(O.hdr.reserve(NCmax + 1)); HIP_TRY(O.exc.reserve(c->sw.exc_cap >= 0 ? (uint64_t)c->sw.exc_cap + 1 : std::max<uint64_t>(1 << 14, A / 256)));
 		HIP_TRY(O.bits.reserve(NW + 2)); HIP_TRY(O.rank.reserve(NW + 6)); HIP_TRY(O.rank4.reserve(NW / 4 + 2)); HIP_TRY(B.pk_cnt.reserve(NW + 2)); HIP_TRY(O.codes.reserve(A + 16));
 		HIP_TRY(B.pk_ecnt.reserve(NW + 2)); HIP_TRY(B.pk_erank.reserve(NW + 2));
-		HIP_TRY(O.ch_off.reserve(n + 2)); HIP_TRY(O.cl_off.reserve(n + 2)); HIP_TRY(O.qm_off.reserve(n + 2)); HIP_TRY(O.qmz.reserve(nm + 1));
+		HIP_TRY(O.ch_off.reserve(n + 2)); HIP_TRY(O.cl_off.reserve(n + 2)); HIP_TRY(O.qm_off.reserve(n + 2));
+		O.qmz16 = c->max_len_all < 65536 && B.wgt_max < 256 && !c->sw.qmz_raw;
+		if (O.qmz16) { HIP_TRY(O.qmz_pos.reserve(nm + 1)); HIP_TRY(O.qmz_cnt.reserve(nm + 1)); } else HIP_TRY(O.qmz.reserve(nm + 1));
 		pa.cd = B.cd.p; pa.hits = B.hits.p; pa.ohits = B.ohits.p; pa.mz_off = c->d_ix_mz_off.p; pa.seg = B.seg.p; pa.n_sel = n; pa.rid_lo = lo; pa.mz0 = B.mz0; pa.q_pos = B.q_pos.p;
-		pa.hq = c->sw.pack_search ? nullptr : B.hq.p; pa.ohq = c->sw.pack_search ? nullptr : B.ohq.p; pa.have_codes = c->sw.pack_search ? 0 : 1;
+		pa.hq = B.hq.p; pa.ohq = B.ohq.p;
 		pa.hdr = O.hdr.p; pa.bytes = B.hcode.p; pa.exc = O.exc.p; pa.exc_cnt = d_exc_cnt; pa.exc_every = (uint32_t)c->sw.exc_every;
 		pa.exc_cap = c->sw.exc_cap >= 0 ? std::min<uint64_t>(O.exc.cap, (uint64_t)c->sw.exc_cap) : O.exc.cap;
 		hipStream_t ps = c->stream;
-		if (B.side_ready && !c->sw.dp_serial) {      // (the side streams exist once a batch had groups; HAO_DBG_DP_SERIAL keeps everything on the engine's stream)
+		if (B.side_ready && !c->sw.dp_serial) {      // (the side streams exist once a batch had groups; HAO_DBG_FORCE=dp_serial keeps everything on the engine's stream)
 			if (!B.ev_pk0) { HIP_TRY(hipEventCreateWithFlags(&B.ev_pk0, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&B.ev_pk1, hipEventDisableTiming)); }
 			ps = B.side[0]; pack_on_side = true;
 			HIP_TRY(hipEventRecord(B.ev_pk0, c->stream)); HIP_TRY(hipStreamWaitEvent(ps, B.ev_pk0, 0));
@@ -579,7 +556,8 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		if (int rc = pack(ps)) return rc;
 		hipLaunchKernelGGL(hao_read_ranges_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, ps, B.g_off.p, B.ch_base.p, B.cl_base.p, c->d_ix_mz_off.p, lo, B.mz0, n, O.ch_off.p, O.cl_off.p, O.qm_off.p);
 		HAO_CHECK_LAUNCH();
-		if (nm) { hipLaunchKernelGGL(hao_qtab_kernel, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, ps, B.q_pos.p, B.q_cnt.p, nm, O.qmz.p); HAO_CHECK_LAUNCH(); }
+		if (nm && O.qmz16) { hipLaunchKernelGGL(hao_qtab16_kernel, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, ps, B.q_pos.p, B.q_cnt.p, nm, O.qmz_pos.p, O.qmz_cnt.p, c->d_err.p); HAO_CHECK_LAUNCH(); }
+		else if (nm) { hipLaunchKernelGGL(hao_qtab_kernel, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, ps, B.q_pos.p, B.q_cnt.p, nm, O.qmz.p); HAO_CHECK_LAUNCH(); }
 		if (pack_on_side) HIP_TRY(hipEventRecord(B.ev_pk1, ps));
 	}
 	c->timer.mark("q_assemble");
@@ -606,11 +584,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	// repeat-rich reads (beyond 1024 chains the keys stay in global scratch)
 	hipLaunchKernelGGL((chain_select_kernel<1, 128>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)0, (int64_t)129);
 	HAO_CHECK_LAUNCH();
-	if (c->sw.sel1) {      // one wave per read for every size (A/B)
-		hipLaunchKernelGGL((chain_select_kernel<1, 512>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)129, (int64_t)513);
-		HAO_CHECK_LAUNCH();
-		hipLaunchKernelGGL((chain_select_kernel<1, 1024>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)513, (int64_t)INT64_MAX);
-	} else {                           // 129 .. 1024 chains: four waves per read share the sorts; beyond 1024 chains: keys in global scratch, one wave
+	{	// 129 .. 4096 chains: four waves per read share the sorts; beyond: keys in global scratch, one wave
 		hipLaunchKernelGGL((chain_select4_kernel<512>), dim3((unsigned)n), dim3(256), 0, c->stream, sa, (int64_t)129, (int64_t)513);
 		HAO_CHECK_LAUNCH();
 		hipLaunchKernelGGL((chain_select4_kernel<1024>), dim3((unsigned)n), dim3(256), 0, c->stream, sa, (int64_t)513, (int64_t)1025);
@@ -641,7 +615,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	{	// the totals of the batch: one wave gathers them into mapped host memory
 		auto peek = [&](const void *src, int nw, int at) { hipLaunchKernelGGL(hao_peek_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)src, nw, c->peek_d + at); };
 		peek(B.ch_base.p + G, 1, 0); peek(B.cl_base.p + G, 1, 1); peek(B.fc_base.p + G * HAO_MCOPY_MAX, 1, 2); peek(B.O().fin_off.p + n, 1, 3); peek(B.fcf_off.p + n, 1, 4);
-		peek(d_slow_cnt, HAO_NCLS + 4, 8); peek(d_exc_cnt, 1, 5); peek(d_n_codes, 1, 6); peek(d_n_fcw, 1, 7); peek(B.stats.p + 3 * HAO_NCLS + 3, 3, 24);
+		peek(d_slow_cnt, HAO_NCLS + 4, 8); peek(d_exc_cnt, 1, 5); peek(d_n_codes, 1, 6); peek(d_n_fcw, 1, 7); peek(B.stats.p + 3 * HAO_NCLS + 3, 3, 24); peek(c->d_err.p, 1, 27);
 		HAO_CHECK_LAUNCH();
 		const double ts2_ = hao_now();
 		HIP_TRY(hipStreamSynchronize(c->stream));
@@ -651,6 +625,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		for (int x = 0; x < HAO_NCLS + 4; ++x) slow_st[x] = c->peek_h[8 + x];
 		B.seed_left[0] = c->peek_h[26]; B.seed_left[1] = c->peek_h[24]; B.seed_left[2] = c->peek_h[25];      // reads left by the first seed launch / by the 512-slot / by the 1024-slot table
 		if (parts & HAO_DELIVER_CL) { n_exc = c->peek_h[5]; B.n_codes = G ? c->peek_h[6] : 0; }
+		if ((parts & HAO_DELIVER_CL) && (uint32_t)c->peek_h[27]) { hao_set_err(c, "a minimizer position or seed weight that does not fit the packed minimizer table"); return HAO_EUNSUPP; }      // (hao_qtab16_kernel; the host's bounds rule it out)
 		if ((parts & HAO_DELIVER_OL) && (c->peek_h[7] >> 63)) { hao_set_err(c, "an overlap without fake-cigar entries: the packed cigar layout holds at least one per overlap"); return HAO_EUNSUPP; }
 		B.n_fcw = (parts & HAO_DELIVER_OL) ? (B.n_fc - B.n_ol) + c->peek_h[7] : 0;      // main region + the raw overlaps' words
 	}
@@ -664,13 +639,6 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		B.n_codes = c->peek_h[6];
 		n_exc = c->peek_h[5];
-	}
-	if ((parts & HAO_DELIVER_CL) && n_exc > 1 && !pa.have_codes) {      // (HAO_DBG_PACK_SEARCH) the list was appended in arrival order: sort it by hit index (the decoder looks hits up; also makes the bytes deterministic)
-		hao_ctx::Batch::OutSet &O = B.O(); size_t tb = 0;
-		HIP_TRY(O.exc2.reserve(n_exc + 1));
-		HIP_TRY(rocprim::merge_sort(nullptr, tb, O.exc.p, O.exc2.p, (size_t)n_exc, ExcLess(), c->stream)); HIP_TRY(hao_tmp(c, tb));
-		HIP_TRY(rocprim::merge_sort(c->d_tmp.p, tb, O.exc.p, O.exc2.p, (size_t)n_exc, ExcLess(), c->stream));
-		std::swap(O.exc, O.exc2);
 	}
 	B.n_exc = n_exc;
 	B.n_generic = 0; for (int x = 0; x < HAO_NCLS; ++x) B.n_generic += slow_st[x];

@@ -38,9 +38,9 @@ int hao_create(int device, const hao_opt_t *opt, hao_ctx **out)
 	{ int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu; }      // (persistent kernels: one workgroup per CU)
 	{	// HIP multiplexes streams onto a few hardware queues: with several copy streams in flight the engine's stream can end up behind a bulk copy in its
 		// queue (measured: every batch started ~5 ms late with four copy streams), which is why the delivery path uses ONE copy stream by default.
-		// HAO_STREAM_PRIO=1 puts the engine's streams in the highest priority class instead (own queues) - measured worse: the copy then starves.
+		// (The engine's streams in the highest priority class instead - own queues - measured worse: the copy then starves.)
 		int lo_ = 0, hi_ = 0; (void)hipDeviceGetStreamPriorityRange(&lo_, &hi_);
-		if (hipStreamCreateWithPriority(&c->stream, hipStreamDefault, c->sw.stream_prio ? hi_ : lo_) != hipSuccess) { delete c; return HAO_ENODEV; }
+		if (hipStreamCreateWithPriority(&c->stream, hipStreamDefault, lo_) != hipSuccess) { delete c; return HAO_ENODEV; }
 	}
 	if (hipHostMalloc((void**)&c->peek_h, 512 * 8, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&c->peek_d, c->peek_h, 0) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return HAO_ENOMEM; }
 	memset(c->ft_hist, 0, sizeof(c->ft_hist)); memset(c->pt_hist, 0, sizeof(c->pt_hist));

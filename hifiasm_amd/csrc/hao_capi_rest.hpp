@@ -158,7 +158,10 @@ uint64_t hao_unpack_hits(const hao_delivery_t *d, uint64_t rid, hao_hit_t *out, 
 	if (!d || rid < d->rid_lo || rid >= d->rid_lo + d->n_reads || !d->cl_off) return 0;
 	const uint64_t r = rid - d->rid_lo, h0 = d->cl_off[r], nh = d->cl_off[r + 1] - h0;
 	if (nh > cap || !out) return nh;
-	const hao_qmz_t *qt = d->qmz + d->qm_off[r];
+	const hao_qmz_t *qt = d->qmz ? d->qmz + d->qm_off[r] : nullptr;
+	const uint16_t *qp16 = d->qmz ? nullptr : d->qmz_pos + d->qm_off[r]; const uint16_t *qc8 = d->qmz ? nullptr : d->qmz_cnt + d->qm_off[r];      // (the packed tables)
+	auto q_self = [&](uint32_t q_) -> uint32_t { return qt ? qt[q_].self_offset : (uint32_t)qp16[q_]; };
+	auto q_cnt = [&](uint32_t q_) -> uint32_t { return qt ? qt[q_].cnt : (uint32_t)qc8[q_]; };
 	uint64_t k = 0;
 	for (uint64_t ci = d->ch_off[r]; ci < d->ch_off[r + 1]; ++ci) {
 		const hao_chain_hdr_t &H = d->chains[ci];
@@ -182,9 +185,9 @@ uint64_t hao_unpack_hits(const hao_delivery_t *d, uint64_t rid, hao_hit_t *out, 
 					o = d->cl_exc[lo].hit; o.w0 = H.w0; q = d->cl_exc[lo].q; off = o.offset;
 					continue;
 				}
-				const uint32_t qn = q + (w >> 4) + 1; off = (uint32_t)((int64_t)off + (int64_t)(qt[qn].self_offset - qt[q].self_offset) + (int64_t)(w & 15) - 8); q = qn;
+				const uint32_t qn = q + (w >> 4) + 1; off = (uint32_t)((int64_t)off + (int64_t)(q_self(qn) - q_self(q)) + (int64_t)(w & 15) - 8); q = qn;
 			}
-			o.w0 = H.w0; o.offset = off; o.self_offset = qt[q].self_offset; o.cnt = qt[q].cnt;
+			o.w0 = H.w0; o.offset = off; o.self_offset = q_self(q); o.cnt = q_cnt(q);
 		}
 		k += H.n_hits;
 	}

@@ -386,15 +386,15 @@ __device__ __forceinline__ hao_hit_t hao_shfl_up_hit(const hao_hit_t &h)      //
 // scores with per-pair validity flags - and no second chain qualifies for multi-copy output; then the best
 // block IS the chain: hits are copied through, the fake cigar is a flagged compaction.  >99.9 % of groups on
 // repeat-free genomes.  Everything else runs hao_chain_generic on lane 0 (exact sequential algorithm).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void chain_group_kernel(hao_chain_args A, const hao_gent *list, uint64_t n_list, uint32_t *slow, int cls)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void chain_group_kernel(hao_chain_args A, const hao_gent *list, uint64_t n_list, uint32_t *slow, int cls)
 {
-	const uint64_t li = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const uint64_t li = blockIdx.x;      // (one 64-thread workgroup per group)
 	if (li >= n_list) return;
 	const int lane = hao_lane();
 	// fake-cigar entries are collected during the scan (an entry wherever offset - self_offset changes: the region's constant only shifts the
 	// values), up to 64 per strand block in LDS, so the hits are read ONCE; longer cigars fall back to a second sweep
-	__shared__ uint64_t l_eb[4][2][64];
-	uint64_t (*eb)[64] = l_eb[threadIdx.x >> 6]; uint32_t ce0 = 0, ce1 = 0;
+	__shared__ uint64_t l_eb[2][64];
+	uint64_t (*eb)[64] = l_eb; uint32_t ce0 = 0, ce1 = 0;
 	const unsigned long long tq0 = A.dbg_qc ? wall_clock64() : 0;
 	const hao_gent e = list[li];                                  // wave-uniform: scalar loads
 	const uint64_t g = e.g, gs = e.start; const int32_t a_n = (int32_t)e.n;      // (a group has < 2^31 hits: a batch has < 2^32 seed hits)

@@ -5,6 +5,7 @@
 #include <map>
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include "hao_common.cuh"
 
 struct hao_ctx;
@@ -37,6 +38,7 @@ template<typename T> struct DevBuf {
 	void borrow(const DevBuf<T> &o) { release(); p = o.p; cap = o.cap; borrowed = o.p != nullptr; }
 };
 
+static bool hao_dbg_sync = false;      // HAO_DBG_PRINT=sync (hao_switches::load): wait after every stage and say its name - localises a device fault
 struct StageTimer {
 	std::vector<std::string> names; std::vector<hipEvent_t> ev; std::vector<double> host_t; hipStream_t st = nullptr;
 	static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
@@ -45,8 +47,7 @@ struct StageTimer {
 		size_t i = names.size();
 		if (i >= ev.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev.push_back(e); }
 		names.push_back(name); host_t.push_back(now()); (void)hipEventRecord(ev[i], st);
-		static const bool dbg_sync = getenv("HAO_DBG_SYNC") != nullptr;      // localise a device fault: wait for the stage and say its name
-		if (dbg_sync) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[stage] %s: %s\n", name, hipGetErrorString(e)); fflush(stderr); }
+		if (hao_dbg_sync) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[stage] %s: %s\n", name, hipGetErrorString(e)); fflush(stderr); }
 	}
 	// after stream sync: ms between consecutive marks, labelled by the later mark
 	void collect(std::vector<std::pair<std::string, float> > &out) {
@@ -58,40 +59,56 @@ struct StageTimer {
 	~StageTimer() { for (auto e : ev) (void)hipEventDestroy(e); }
 };
 
-// run-time switches (measurement aids): read from the environment ONCE, in hao_create
+// run-time switches: read from the environment ONCE, in hao_create.  Eight variables:
+//   HAO_SEED_LDS, HAO_SEED_LDS_RATIO, HAO_SEED_MERGE_MAXN   which reads / batches the list-major seed kernel takes (below)
+//   HAO_FT_PASSES                                           ha_ft_gen's hash-range passes (0: what the free device memory asks for)
+//   HAO_ARENA_NUMA                                          placement of the pinned delivery arenas
+//   HAO_DBG_PRINT=seed,qc,dp,sel,dl,bloom,sync              timers / counters on stderr (sync: wait after every stage and say its name - localises a device fault)
+//   HAO_DBG_FORCE=seq_chain,dp_seqtail,dp_nospec,dp_serial,seq_prune,noql      send every read / group down one of the engine's FALLBACK paths (tests: each has to give the default path's bytes)
+//   HAO_DBG_TEST=ix_pad=N,sort40_min=N,sk_gcap=N,exc_cap=N,fc_raw_every=N,exc_every=N,qmz_raw=1,ft_chunk_slots=N      capacities and thresholds shrunk so that small inputs reach the overflow / big-index code
 struct hao_switches {
-	bool seedphase = false, qcphase = false, dp_stats = false, seq_chain = false, dp_seqtail = false, dp_nospec = false, dp_serial = false,
-		 seq_prune = false, selphase = false, sel1 = false, sk_generic = false, sk_v2 = false, dltime = false, sk_nofuse = false, pack_search = false, sk_select2 = false, seed_noql = false, sort64 = false, tiny_lane = false, pt_direct = false;
-	static constexpr bool SK_SELECT2_DEFAULT = true;       // the thinning kernel the sketch runs when the environment says nothing: the wave kernel (round 4: green on the device against every repeat-rich scenario and the 5 Mb / 250 Mb repeat-rich fixtures)
-	int chain_wpb = 1, spec_mincls = 2; long long sk_gcap = -1, exc_cap = -1; unsigned long long ix_pad = 0, sort40_min = 1ULL << 23; int fc_raw_every = 0, exc_every = 0, copy_streams = 1, copy_kernel = 0, stream_prio = 0, arena_numa = 3, seed_merge_maxn = 24000, seed_lds_ratio = 120, ft_passes = 0, seed_lds = 1; long long ft_chunk_slots = 0;
+	bool seedphase = false, qcphase = false, dp_stats = false, selphase = false, dltime = false, bloom = false;                 // HAO_DBG_PRINT
+	bool seq_chain = false, dp_seqtail = false, dp_nospec = false, dp_serial = false, seq_prune = false, seed_noql = false;     // HAO_DBG_FORCE
+	long long sk_gcap = -1, exc_cap = -1, ft_chunk_slots = 0; unsigned long long ix_pad = 0, sort40_min = 1ULL << 23; int fc_raw_every = 0, exc_every = 0; bool qmz_raw = false;      // HAO_DBG_TEST
+	int arena_numa = 3, seed_merge_maxn = 24000, seed_lds_ratio = 120, ft_passes = 0, seed_lds = 1;
+	static bool in_list(const char *v, const char *name) {      // name is an element of the comma-separated list v
+		const size_t n = strlen(name);
+		for (const char *p = v; p && *p; ) { const char *e = strchr(p, ','); const size_t l = e ? (size_t)(e - p) : strlen(p); if (l == n && strncmp(p, name, n) == 0) return true; p = e ? e + 1 : nullptr; }
+		return false;
+	}
+	static bool in_kv(const char *v, const char *name, unsigned long long &out) {      // "name=123" is an element of v
+		const size_t n = strlen(name);
+		for (const char *p = v; p && *p; ) { const char *e = strchr(p, ','); if (strncmp(p, name, n) == 0 && p[n] == '=') { out = strtoull(p + n + 1, nullptr, 10); return true; } p = e ? e + 1 : nullptr; }
+		return false;
+	}
 	void load() {
-		auto on = [](const char *n) { return getenv(n) != nullptr; };
-		seedphase = on("HAO_DBG_SEEDPHASE"); qcphase = on("HAO_DBG_QCPHASE"); dp_stats = on("HAO_DBG_DP_STATS"); seq_chain = on("HAO_DBG_SEQ_CHAIN");
-		dp_seqtail = on("HAO_DBG_DP_SEQTAIL"); dp_nospec = on("HAO_DBG_DP_NOSPEC"); dp_serial = on("HAO_DBG_DP_SERIAL"); seq_prune = on("HAO_DBG_SEQ_PRUNE");
-		selphase = on("HAO_DBG_SELPHASE"); sel1 = on("HAO_DBG_SEL1"); sk_generic = on("HAO_DBG_SK_GENERIC"); sk_v2 = on("HAO_DBG_SK_V2"); sk_nofuse = on("HAO_DBG_SK_NOFUSE"); pack_search = on("HAO_DBG_PACK_SEARCH");      // the wire packer searches every hit's minimizer (round-2 path) instead of gathering the quick check's code bytes
-		dltime = on("HAO_DBG_DLTIME");
+		if (const char *v = getenv("HAO_DBG_PRINT")) {
+			seedphase = in_list(v, "seed"); qcphase = in_list(v, "qc"); dp_stats = in_list(v, "dp"); selphase = in_list(v, "sel"); dltime = in_list(v, "dl"); bloom = in_list(v, "bloom"); hao_dbg_sync = in_list(v, "sync");
+		}
+		if (const char *v = getenv("HAO_DBG_FORCE")) {
+			seq_chain = in_list(v, "seq_chain");      // every group through the complete sequential chaining routine (one lane per group)
+			dp_seqtail = in_list(v, "dp_seqtail");    // groups the quick check rejects: the DP's tail walked sequentially
+			dp_nospec = in_list(v, "dp_nospec");      // the DP without speculation
+			dp_serial = in_list(v, "dp_serial");      // DP and pack kernels on the engine's stream (no side streams)
+			seq_prune = in_list(v, "seq_prune");      // the selection's pruning by one lane
+			seed_noql = in_list(v, "noql");           // the seed kernels' generic per-minimizer tables (the path of batches with a read of more than HAO_QTAB_CAP minimizers)
+		}
+		if (const char *v = getenv("HAO_DBG_TEST")) {
+			unsigned long long x;
+			if (in_kv(v, "ix_pad", x)) ix_pad = x;                        // unused position records in front of the index (list starts beyond 2^32 on a small read set)
+			if (in_kv(v, "sort40_min", x)) sort40_min = x;                // the big-index path (40-bit sort + fix-up, gather, windowed scatter) from this many minimizers on (default 2^23: rocprim's bit-range sort, tests/test_gpu_rocprim.py)
+			if (in_kv(v, "sk_gcap", x)) sk_gcap = (long long)x;           // capacity of the sketch's minimizer pool (the grow-and-rerun path)
+			if (in_kv(v, "exc_cap", x)) exc_cap = (long long)x;           // capacity of the wire format's verbatim-hit list (the grow-and-repack path)
+			if (in_kv(v, "fc_raw_every", x)) fc_raw_every = (int)x;       // every n-th overlap's fake cigar travels raw (the fallback of the packed wire form)
+			if (in_kv(v, "exc_every", x)) exc_every = (int)x;             // every n-th hit of a chain travels verbatim (the exception list)
+			if (in_kv(v, "qmz_raw", x)) qmz_raw = x != 0;                   // the delivered minimizer tables in their 8-byte form whatever the read lengths (the form of batches with a read of 65 536 bases or more)
+			if (in_kv(v, "ft_chunk_slots", x)) ft_chunk_slots = (long long)x;      // k-mer slots hashed per chunk of reads in ha_ft_gen's pass mode
+		}
 		if (const char *e = getenv("HAO_SEED_LDS")) seed_lds = atoi(e) ? 1 : 0;      // 0 = the table kernels (hao_query.cuh, hao_query3.cuh) for every read instead of the list-major kernel (hao_query5.cuh): the tests run them on every scenario - they carry repeat-rich batches and the reads the list-major kernel leaves
 		if (const char *e = getenv("HAO_SEED_LDS_RATIO")) seed_lds_ratio = std::max(0, atoi(e));      // (per cent) batches with more seed hits per (query minimizer x coverage peak) than this take the table kernels: reads across repeat families (hao_batch.hpp); tests force either side
 		if (const char *e = getenv("HAO_SEED_MERGE_MAXN")) seed_merge_maxn = std::max(0, atoi(e));      // reads with more seed hits than this are left to the table kernels by the list-major kernel (repeat families: hundreds of targets per read)
-		if (const char *e = getenv("HAO_FT_PASSES")) ft_passes = std::max(0, atoi(e));      // ha_ft_gen in this many hash-range passes (0: as many as the free device memory asks for)
-		if (const char *e = getenv("HAO_FT_CHUNK_SLOTS")) ft_chunk_slots = std::max(0LL, atoll(e));      // (tests) k-mer slots hashed per chunk of reads in pass mode
-		if (const char *e = getenv("HAO_DBG_IX_PAD")) ix_pad = strtoull(e, nullptr, 10);      // tests: unused position records in front of the index (list starts beyond 2^32 on a small read set)
-		if (const char *e = getenv("HAO_DBG_SORT40_MIN")) sort40_min = strtoull(e, nullptr, 10);      // tests on the CPU emulation only: the big-index path (40-bit sort + fix-up, gather, windowed scatter) from this many minimizers on (on the device rocprim's bit-range sort is trusted from 2^23 elements on, tests/test_gpu_rocprim.py)
-		pt_direct = on("HAO_PT_DIRECT");      // A/B: the index's gather + scatter in one kernel (random 8-byte writes) instead of gather, one radix pass, windowed scatter
-		sort64 = on("HAO_PT_SORT64");      // A/B: the index sort over all 64 hash bits (8 passes) instead of 40 bits + fix-up (hao_index.cuh)
-		tiny_lane = on("HAO_DBG_TINY_LANE");      // A/B: groups of <= 8 hits by chain_tiny_kernel (one lane per group, sequential) instead of chain_pack8_kernel
-		seed_noql = on("HAO_SEED_NOQL");  // A/B: the seed kernel's generic per-minimizer tables (LDS or global, all minimizers) even when every read of the batch fits the LDS
-		sk_select2 = on("HAO_SK_SELECT2") || (SK_SELECT2_DEFAULT && !on("HAO_SK_SELECT1"));      // thinning of high-count minimizers: the wave kernel (hao_select2.cuh) / the one-lane replay (sketch_select_kernel)
-		if (const char *e = getenv("HAO_CHAIN_WPB")) chain_wpb = std::max(1, std::min(4, atoi(e)));
-		if (const char *e = getenv("HAO_SPEC_MINCLS")) spec_mincls = atoi(e);
-		if (const char *e = getenv("HAO_DBG_SK_GCAP")) sk_gcap = atoll(e);
-		if (const char *e = getenv("HAO_DBG_EXC_CAP")) exc_cap = atoll(e);
-		if (const char *e = getenv("HAO_DBG_FC_RAW_EVERY")) fc_raw_every = std::max(0, atoi(e));      // tests: every n-th overlap's fake cigar travels raw (the fallback of the packed wire form)
-		if (const char *e = getenv("HAO_DBG_EXC_EVERY")) exc_every = atoi(e);      // ship every n-th hit of a chain verbatim (tests: exercise the exception list)
+		if (const char *e = getenv("HAO_FT_PASSES")) ft_passes = std::max(0, atoi(e));
 		if (const char *e = getenv("HAO_ARENA_NUMA")) arena_numa = atoi(e);      // 0: plain hipHostMalloc, 1: thread policy "prefer the GPU's node", 3 (default): "bind to it", then 1 if that fails - and, when the pages still are elsewhere, mmap + mbind + hipHostRegister; 2: 3 + hipHostMallocNumaUser; 4: always mmap + mbind + hipHostRegister (tests)
-		if (const char *e = getenv("HAO_STREAM_PRIO")) stream_prio = atoi(e);      // 1: the engine's streams at the highest priority (A/B: measured worse - the low-priority copy then starves)
-		if (const char *e = getenv("HAO_COPY_KERNEL")) copy_kernel = atoi(e);      // n > 0: the delivery copy is done by a kernel of n workgroups writing into the mapped arena (no DMA engine)
-		if (const char *e = getenv("HAO_COPY_STREAMS")) copy_streams = std::max(1, std::min(8, atoi(e)));      // DMA queues the delivery copy is spread over      // initial capacity of the wire format's verbatim-hit list (tests: force the grow-and-repack path)
 	}
 };
 

@@ -72,12 +72,11 @@ __global__ __launch_bounds__(256) void hao_digest_kernel(hao_digest_args A)
 // hit) and skipped by the decoder.  Exception entries carry the hit as the seed stage wrote it: the decoder sets its readID word from the header.
 // ---------------------------------------------------------------------------------------
 #define HAO_PACK_QCAP 1024
-#define HAO_CODE_EXC_DONE 0xfe      // device only: "verbatim, and its list entry exists already" (hao_pack_ohits_kernel); leaves the device as 0xff
 struct hao_pack_args {
 	const hao_cdesc *cd; const hao_hit_t *hits, *ohits;
 	const uint64_t *mz_off, *seg; uint64_t rid_lo, mz0, n_sel; const uint32_t *q_pos;      // per-read minimizer ranges (global offsets), seed-hit ranges, the batch's self_offset table
 	hao_chain_hdr_t *hdr; uint8_t *bytes; hao_exc_t *exc; unsigned long long *exc_cnt; uint64_t exc_cap; uint32_t exc_every;
-	const uint16_t *hq; int have_codes;      // per seed hit: query minimizer index (seed kernel); have_codes: bytes[] holds the codes the chain kernels wrote (else every chain is coded here)
+	const uint16_t *hq;      // per seed hit: query minimizer index (seed kernel)
 	const uint16_t *ohq;                     // per ohits entry: query minimizer index (the DP tails, hao_chain.cuh)
 };
 
@@ -100,60 +99,10 @@ __global__ __launch_bounds__(256) void hao_pack_hdr_kernel(hao_pack_args A, cons
 	A.hdr[ci] = H;
 }
 
-// HAO_DBG_PACK_SEARCH only (A/B: the round-2 packer, which codes every chain here; by default the chain kernels have written every code and this kernel does not run):
-// one wave per chain, the minimizer index of a hit by a binary search of its self_offset in the read's table (staged in LDS once per read), codes
-// written at the chain's positions; a hit without a code goes to the verbatim list right here (its code is marked HAO_CODE_EXC_DONE).
-__global__ __launch_bounds__(256) void hao_pack_ohits_kernel(hao_pack_args A, const uint64_t *n_chains_dev)
-{
-	const uint64_t n_chains = *n_chains_dev, n_waves = (uint64_t)gridDim.x * 4;
-	const int lane = hao_lane();
-	__shared__ uint32_t s_tab[4][HAO_PACK_QCAP];
-	uint32_t *tab = s_tab[threadIdx.x >> 6];
-	uint64_t tab_read = ~0ULL;
-	for (uint64_t ci = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); ci < n_chains; ci += n_waves) {
-		const hao_cdesc d = A.cd[ci];
-		if (A.have_codes && !(d.src & HAO_CD_OHITS)) continue;
-		const hao_hit_t *src = hao_cd_src(d, A.hits, A.ohits); const uint64_t pos = d.src & ~HAO_CD_OHITS;
-		const uint64_t m0 = A.mz_off[A.rid_lo + d.r]; const uint32_t nq = (uint32_t)(A.mz_off[A.rid_lo + d.r + 1] - m0);
-		const uint32_t *qp = A.q_pos + (m0 - A.mz0);
-		const bool in_lds = nq <= HAO_PACK_QCAP;
-		if (in_lds && tab_read != d.r) {
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // (the previous chain's searches are done)
-			for (uint32_t k = lane; k < nq; k += 64) tab[k] = qp[k];
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-			tab_read = d.r;
-		}
-		uint32_t q_prev = 0, off_prev = 0, self_prev = 0;      // the last hit of the previous tile (uniform)
-		for (uint32_t b = 0; b < d.n; b += 64) {
-			const uint32_t i = b + lane; const bool act = i < d.n;
-			hao_hit_t h; h.w0 = 0; h.offset = 0; h.self_offset = 0; h.cnt = 0; uint32_t q = 0;
-			if (act) { h = src[i]; q = hao_pack_find_q(in_lds ? tab : qp, nq, h.self_offset); }
-			const uint32_t pq = hao_wave_shr1(q, q_prev), po = hao_wave_shr1(h.offset, off_prev), ps = hao_wave_shr1(h.self_offset, self_prev);
-			bool esc = false;
-			if (act && i > 0) {
-				const int64_t dq = (int64_t)q - (int64_t)pq, dd = ((int64_t)h.offset - (int64_t)po) - ((int64_t)h.self_offset - (int64_t)ps);
-				esc = dq < 1 || dq > 15 || dd < -8 || dd > 7 || (A.exc_every && i % A.exc_every == A.exc_every - 1);
-				A.bytes[pos + i] = esc ? (uint8_t)HAO_CODE_EXC_DONE : (uint8_t)((dq - 1) << 4 | (dd + 8));
-			}
-			const unsigned long long em = __ballot(esc);
-			if (em) {      // one atomic per wave and tile (a repeat-rich pass has millions of verbatim hits: one atomic each serialises on the counter)
-				unsigned long long base = 0;
-				if (lane == 0) base = atomicAdd(A.exc_cnt, (unsigned long long)__popcll(em));
-				base = (unsigned long long)hao_readlane_i64((int64_t)base, 0);
-				if (esc) {
-					const uint64_t k = base + __popcll(em & ((1ULL << lane) - 1));
-					if (k < A.exc_cap) { hao_exc_t e; e.index = pos + i; e.q = q; e.pad = 0; e.hit = h; A.exc[k] = e; }      // past the capacity only the count matters: the host grows the list and packs again
-				}
-			}
-			q_prev = hao_bcast(q, 63); off_prev = hao_bcast(h.offset, 63); self_prev = hao_bcast(h.self_offset, 63);
-		}
-	}
-}
-
 // One byte per position -> bit stream + per-word counts of the rank directory; a 0xff met on the way (the quick check could not express the hit) becomes
 // an entry of the verbatim list: the seed hit at the position and its minimizer index.  Thread t takes positions [8t, 8t + 8) (one 8-byte load); the
 // eight threads of a 64-position word combine their flags.
-// (ecnt != nullptr: the verbatim entries are NOT appended here - their number per word goes to ecnt[], a scan turns the counts into list positions and
+// (The verbatim entries are NOT appended here - their number per word goes to ecnt[], a scan turns the counts into list positions and
 // hao_pack_codes_kernel writes the entries in position order, in the pass that places the code bytes.  A repeat-rich 250 Mb batch has 14 M verbatim hits in 1.3 M waves: one atomic per wave on the list's
 // counter - all on one address - made this kernel 11 ms instead of 0.3, and the list then needed a 24-byte-record merge sort by position, ~10 ms more.)
 __global__ __launch_bounds__(256) void hao_pack_bits_kernel(hao_pack_args A, uint64_t n, uint64_t n_words, uint64_t *bits, uint32_t *cnt, uint32_t *ecnt)
@@ -169,41 +118,23 @@ __global__ __launch_bounds__(256) void hao_pack_bits_kernel(hao_pack_args A, uin
 			if (8 * t + k < n && (b == 0xff || b == HAO_CODE_EXC_OHITS)) e8 |= 1u << k;
 		}
 	}
-	if (ecnt) {
+	{
 		uint32_t ne = (uint32_t)__popc(e8);
 		ne += __shfl_xor(ne, 1); ne += __shfl_xor(ne, 2); ne += __shfl_xor(ne, 4);
 		if ((t & 7) == 0 && w < n_words) ecnt[w] = ne;
-	} else if (__ballot(e8 != 0)) {      // verbatim entries: one atomic per wave reserves the wave's slots (the repeat-rich sets have millions per pass)
-		const uint32_t ne = (uint32_t)__popc(e8), inc = hao_wave_incl_scan_u32(ne), tot = hao_bcast(inc, 63);
-		unsigned long long base = 0;
-		if (hao_lane() == 63) base = atomicAdd(A.exc_cnt, (unsigned long long)tot);
-		base = (unsigned long long)hao_readlane_i64((int64_t)base, 63);
-		unsigned long long kx = base + inc - ne;
-		for (uint32_t m = e8; m; m &= m - 1, ++kx) {
-			if (kx >= A.exc_cap) continue;      // past the capacity only the count matters: the host grows the list and packs again
-			const uint64_t p = 8 * t + (uint32_t)(__ffs((int)m) - 1);
-			const bool oh = (uint8_t)(v >> (8 * (__ffs((int)m) - 1))) == HAO_CODE_EXC_OHITS;      // a hit of a chain the DP compacted: it (and its minimizer index) sit in ohits / ohq at the position
-			hao_exc_t e; e.index = p; e.pad = 0; e.hit = oh ? A.ohits[p] : A.hits[p]; e.q = oh ? A.ohq[p] : (A.hq ? A.hq[p] : 65535u);
-			if (e.q == 65535u) {      // the 16-bit index saturated (a read of > 65 534 minimizers): the read of the position, then its table
-				uint64_t lo = 0, hi = A.n_sel; while (hi - lo > 1) { const uint64_t md = (lo + hi) >> 1; if (A.seg[md] <= p) lo = md; else hi = md; }
-				const uint64_t m0 = A.mz_off[A.rid_lo + lo];
-				e.q = hao_pack_find_q(A.q_pos + (m0 - A.mz0), (uint32_t)(A.mz_off[A.rid_lo + lo + 1] - m0), e.hit.self_offset);
-			}
-			A.exc[kx] = e;
-		}
 	}
 	uint64_t word = (uint64_t)m8 << ((t & 7) * 8);
 	word |= __shfl_xor(word, 1); word |= __shfl_xor(word, 2); word |= __shfl_xor(word, 4);
-	if ((t & 7) == 0 && w < n_words) { bits[w] = word; cnt[w] = (uint32_t)__popcll(word); }      // (no lane leaves early: the slot reservation above is wave-wide)
+	if ((t & 7) == 0 && w < n_words) { bits[w] = word; cnt[w] = (uint32_t)__popcll(word); }      // (no lane leaves early: the shuffles above are wave-wide)
 }
 
-// code bytes of the flagged positions, at their rank: thread t takes positions [8t, 8t + 8).  With erank != nullptr the same pass also writes the verbatim list
-// (hao_pack_exc_kernel's work: one read of the code array less per batch).
+// code bytes of the flagged positions, at their rank: thread t takes positions [8t, 8t + 8).  The same pass writes the verbatim list at the
+// positions erank[] (the scan of hao_pack_bits_kernel's counts) gives.
 __global__ __launch_bounds__(256) void hao_pack_codes_kernel(hao_pack_args A, const uint8_t *bytes, uint64_t n, const uint64_t *bits, const uint32_t *rank, uint64_t n_words, uint8_t *codes,
 		unsigned long long *n_codes, const uint32_t *erank)
 {
 	const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, w = t >> 3;
-	if (t == 0) { *n_codes = rank[n_words]; if (erank) *A.exc_cnt = erank[n_words]; }      // (exclusive prefixes over n_words + 1 counts: the last entries are the totals)
+	if (t == 0) { *n_codes = rank[n_words]; *A.exc_cnt = erank[n_words]; }      // (exclusive prefixes over n_words + 1 counts: the last entries are the totals)
 	const bool in = 8 * t < n;
 	const uint64_t word = in ? bits[w] : 0; const int sh = (int)(t & 7) * 8;
 	uint32_t m8 = (uint32_t)(word >> sh) & 0xffu, e8 = 0;
@@ -211,9 +142,8 @@ __global__ __launch_bounds__(256) void hao_pack_codes_kernel(hao_pack_args A, co
 	if (m8) v = *(const uint64_t*)(bytes + 8 * t);      // (a word's bits beyond n are zero)
 	if (m8) {
 		uint64_t at = rank[w] + (uint64_t)__popcll(word & ((1ULL << sh) - 1));
-		for (uint32_t m = m8; m; m &= m - 1) { const uint8_t b = (uint8_t)(v >> (8 * (__ffs((int)m) - 1))); codes[at++] = b >= HAO_CODE_EXC_OHITS ? (uint8_t)0xff : b; }      // (0xfd / 0xfe: device-only flavours of "verbatim")
+		for (uint32_t m = m8; m; m &= m - 1) { const uint8_t b = (uint8_t)(v >> (8 * (__ffs((int)m) - 1))); codes[at++] = b >= HAO_CODE_EXC_OHITS ? (uint8_t)0xff : b; }      // (0xfd: the device-only flavour of "verbatim")
 	}
-	if (!erank) return;      // (uniform)
 	// every verbatim position is a flagged position: only the set bits of m8 can be 0xff / 0xfd
 	for (uint32_t m = m8; m; m &= m - 1) { const int k = __ffs((int)m) - 1; const uint8_t b = (uint8_t)(v >> (8 * k)); if (b == 0xff || b == HAO_CODE_EXC_OHITS) e8 |= 1u << k; }
 	uint64_t eword = (uint64_t)e8 << sh;
@@ -265,6 +195,13 @@ __global__ void hao_qtab_kernel(const uint32_t *q_pos, const uint32_t *q_cnt, ui
 {
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n_mz) { hao_qmz_t v; v.self_offset = q_pos[i]; v.cnt = q_cnt[i]; out[i] = v; }
+}
+
+// the same in 4 bytes per minimizer (reads shorter than 65 536 bases, weights below 256: the host checked both; a value that does not fit raises *err all the same)
+__global__ void hao_qtab16_kernel(const uint32_t *q_pos, const uint32_t *q_cnt, uint64_t n_mz, uint16_t *pos, uint16_t *cnt, int *err)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n_mz) { const uint32_t p = q_pos[i], k = q_cnt[i]; pos[i] = (uint16_t)p; cnt[i] = (uint16_t)k; if (p > 0xffffu || k > 0xffffu) *err = 1; }
 }
 
 // per read: first chain / first hit of the read in the batch (ranges of the headers and of the packed words)
@@ -347,9 +284,3 @@ __global__ __launch_bounds__(256) void hao_exact_check_kernel(hao_exact_args A)
 }
 
 
-// device -> mapped pinned host memory by a few workgroups of plain 16-byte loads / stores (alternative to the DMA engines for the delivery copy)
-typedef uint32_t hao_v4u __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void hao_d2h_kernel(const hao_v4u *src, hao_v4u *dst, uint64_t n16)
-{
-	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
-}

@@ -38,8 +38,8 @@ static hao_ft_dev hao_ft_view(hao_ctx *c)
 static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int sample_dist, int stamp_rid)
 {
 	const uint64_t n_sel = hi - lo; const int k = c->opt.k, w = c->opt.w;
-	const bool unit_variant = w == 51 && k == 51 && !c->sw.sk_generic && !c->sw.sk_v2;     // default parameters: one wave per unit of 1024 window ordinals
-	const bool wave_variant = w == 51 && k + 7 <= 64 && !c->sw.sk_generic;     // other k at the default w (or HAO_DBG_SK_V2): the round-2 kernel, one workgroup per chunk
+	const bool unit_variant = w == 51 && k == 51;     // default parameters: one wave per unit of 1024 window ordinals
+	const bool wave_variant = w == 51 && k + 7 <= 64;     // other k at the default w: the round-2 kernel, one workgroup per chunk
 	const int chunk = unit_variant ? hao_sk3<51, 51>::MW : (wave_variant ? hao_sk2<51>::CHUNK : HAO_SK_CHUNK);
 	c->sk_lo = lo; c->sk_n = n_sel; c->sk_total = 0;
 	HIP_TRY(c->d_mz_off.reserve(n_sel + 2));
@@ -129,7 +129,7 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 		}
 		if (!slist.empty()) { sa.pass = 1; hipLaunchKernelGGL(sketch_scalar_kernel, dim3((unsigned)((slist.size() + 63) / 64)), dim3(64), 0, c->stream, sa); HAO_CHECK_LAUNCH(); }
 		// everything downstream is sized by gcap, so the exact total is read back only once, at the end
-		const bool thin = use_ft && (a.ft.n > 0 || c->sw.sk_nofuse) && sample_dist > w;      // (an empty filter table: no minimizer has a count, mz1_select_mz_h keeps everything)
+		const bool thin = use_ft && a.ft.n > 0 && sample_dist > w;      // (an empty filter table: no minimizer has a count, mz1_select_mz_h keeps everything)
 		HIP_TRY(c->d_g_off.reserve(n_sel + 2)); HIP_TRY(c->d_mz_x.reserve(gcap + 1)); HIP_TRY(c->d_mz_info.reserve(gcap + 1));
 		hipLaunchKernelGGL(sketch_read_off_kernel, dim3((unsigned)((n_sel + 256) / 256)), dim3(256), 0, c->stream, c->d_chunk_off.p, c->d_chunk_dst.p, n_sel, c->d_g_off.p);
 		HAO_CHECK_LAUNCH();
@@ -146,14 +146,11 @@ static int hao_sketch_run(hao_ctx *c, uint64_t lo, uint64_t hi, int use_ft, int 
 			HAO_CHECK_LAUNCH();
 			c->timer.mark("sk_gather");
 			HIP_TRY(c->d_new_n.reserve(n_sel + 2)); HIP_TRY(hipMemsetAsync(c->d_new_n.p + n_sel, 0, 4, c->stream));
-			if (c->sw.sk_select2) {      // the wave-parallel thinning (hao_select2.cuh), one wave per read: reads of up to 512 candidates (30 KB of LDS per wave), then the longer ones
+			{	// the wave-parallel thinning (hao_select2.cuh), one wave per read: reads of up to 512 candidates (30 KB of LDS per wave), then the longer ones
 				hipLaunchKernelGGL((sketch_select2_kernel<HAO_S2_CAP_SMALL, 64>), dim3((unsigned)n_sel), dim3(64), 0, c->stream, c->d_g_x.p, c->d_g_info.p, c->d_g_ord.p, c->d_g_off.p,
 								   c->d_len.p, c->d_tot_l.p, lo, n_sel, sample_dist, c->opt.rewin, k, c->d_new_n.p, c->d_err.p);
 				HAO_CHECK_LAUNCH();
 				hipLaunchKernelGGL((sketch_select2_kernel<HAO_S2_CAP, 256>), dim3((unsigned)n_sel), dim3(256), 0, c->stream, c->d_g_x.p, c->d_g_info.p, c->d_g_ord.p, c->d_g_off.p,
-								   c->d_len.p, c->d_tot_l.p, lo, n_sel, sample_dist, c->opt.rewin, k, c->d_new_n.p, c->d_err.p);
-			} else {
-				hipLaunchKernelGGL(sketch_select_kernel, dim3((unsigned)((n_sel + 3) / 4)), dim3(256), 0, c->stream, c->d_g_x.p, c->d_g_info.p, c->d_g_ord.p, c->d_g_off.p,
 								   c->d_len.p, c->d_tot_l.p, lo, n_sel, sample_dist, c->opt.rewin, k, c->d_new_n.p, c->d_err.p);
 			}
 			HAO_CHECK_LAUNCH();

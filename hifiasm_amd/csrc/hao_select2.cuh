@@ -1,6 +1,6 @@
 // High-count thinning of a read's minimizer candidates (mz1_select_mz_h, sketch.cpp:247-330; mz1_qfw :226-246; mz1_hf_select :194-216), data-parallel.
 //
-// The reference (and sketch_select_kernel, one LANE per read) replays a newest-wins state machine over the candidate list.  What that machine computes
+// The reference (and hao_select_high, hao_sketch.cuh: one LANE per read) replays a newest-wins state machine over the candidate list.  What that machine computes
 // (tests/sel_model.py derives it, tests/test_select_model_cpu.py checks it against the oracle): a high-count candidate is MARKED iff its (count, hash) key
 // equals the maximum, over the second-level windows that contain it, of the window's minimum key - windows W_i = { m <= i : ord[m] + w > ord[i] } for every
 // entry i from the first full window on (that first window is [0, i0]), plus the tail windows [s, n - 1] while ord[s] + w <= tot_l + 1.  Marked candidates
@@ -11,7 +11,7 @@
 // that owns their first entry, survivors are compacted by ballots.  Reads the closed form does not cover - more than 1024 candidates, k-mer ordinals that
 // restart (N bases), a window of more than 128 candidates - take the sequential routine.
 // tests/sel2_model.cpp compiles the element functions below with g++ and walks the kernel's phases with loops, tests/test_select_model_cpu.py compares with the
-// oracle on the CPU; tests/test_gpu_zz_new.py compares both thinning kernels (HAO_SK_SELECT1 / HAO_SK_SELECT2) with the oracle and the reference's digests on the device.
+// oracle on the CPU; tests/test_gpu_zz_new.py compares the kernel with the oracle and the reference's digests on the device.
 #pragma once
 #include <stdint.h>
 #ifdef HAO_SEL2_HOST_MODEL
@@ -158,7 +158,7 @@ HAO_S2_FN void hao_s2_finish_run(const hao_s2_view &V, int i, int e, int span, i
 
 #ifndef HAO_SEL2_HOST_MODEL
 // ---------------------------------------------------------------------------------------
-// One wave per read (blocks of 64 threads; ~61 KB of LDS).  Same interface as sketch_select_kernel; reads outside the closed form's reach run
+// One wave per read (blocks of 64 threads; ~61 KB of LDS).  Reads outside the closed form's reach run
 // hao_select_high (hao_sketch.cuh) on lane 0, as that kernel does.
 // ---------------------------------------------------------------------------------------
 // the sequential routine for the reads the closed form does not cover: kept out of line so that its registers are not the kernel's
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(NT) void sketch_select2_kernel(uint64_t *x, uint64_
 		}
 		hao_s2_sync<NT>();
 	}
-	// the sequential routine of sketch_select_kernel, by thread 0 (in place on the staged list, or on the global arrays of a very long read); survivors copied back by all
+	// the sequential routine (hao_select_high), by thread 0 (in place on the staged list, or on the global arrays of a very long read); survivors copied back by all
 	auto sequential = [&](bool staged) {
 		if (tid == 0) s_m = staged ? hao_s2_sequential(l_x, l_info, l_ord, n, V.len, sample_dist, rewin, k, V.tot_l) : hao_s2_sequential(x + o, info + o, ord + o, n, V.len, sample_dist, rewin, k, V.tot_l);
 		hao_s2_sync<NT>();

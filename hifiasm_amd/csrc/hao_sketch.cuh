@@ -759,37 +759,6 @@ __device__ int hao_select_high(hao_sel_view v, int len, int sample_dist, int w /
 	return m;
 }
 
-// One wave per read; tot_l = number of valid k-mer iterations = runs (N-free reads) or the value the scalar kernel recorded.
-// Only reads that contain a high-count minimizer do any work: their list is staged in LDS, lane 0 runs the (sequential,
-// order-dependent) thinning of mz1_select_mz_h on it, all lanes write the survivors back.
-#define HAO_SKSEL_CAP 1024
-__global__ __launch_bounds__(256) void sketch_select_kernel(uint64_t *x, uint64_t *info, uint32_t *ord, const uint64_t *mz_off, const uint32_t *len, const uint32_t *tot_l,
-		uint64_t rid_lo, uint64_t n_sel, int sample_dist, int rewin, int k, uint32_t *new_n, const int *err)
-{
-	if (*err) return;          // an upstream buffer overflowed: the host redoes the pass with bigger buffers, the lists here are incomplete
-	__shared__ uint64_t l_x[4][HAO_SKSEL_CAP], l_info[4][HAO_SKSEL_CAP]; __shared__ uint32_t l_ord[4][HAO_SKSEL_CAP];
-	const int wv = threadIdx.x >> 6, lane = hao_lane();
-	const uint64_t r = (uint64_t)blockIdx.x * 4 + wv;
-	if (r >= n_sel) return;
-	const uint64_t o = mz_off[r]; const int n = (int)(mz_off[r + 1] - o);
-	int any = 0;
-	for (int i = lane; i < n; i += 64) if (hao_info_rid(info[o + i]) > 0) any = 1;
-	if (!__any(any)) { if (lane == 0) new_n[r] = (uint32_t)n; return; }
-	const bool in_lds = n <= HAO_SKSEL_CAP;
-	hao_sel_view v; v.n = n;
-	if (in_lds) {
-		for (int i = lane; i < n; i += 64) { l_x[wv][i] = x[o + i]; l_info[wv][i] = info[o + i]; l_ord[wv][i] = ord[o + i]; }
-		v.x = l_x[wv]; v.info = l_info[wv]; v.ord = l_ord[wv];
-	} else { v.x = x + o; v.info = info + o; v.ord = ord + o; }
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-	int m = 0;
-	if (lane == 0) m = hao_select_high(v, (int)len[rid_lo + r], sample_dist, rewin, k, (int)tot_l[r]);
-	m = __shfl(m, 0);
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-	if (in_lds) for (int i = lane; i < m; i += 64) { x[o + i] = l_x[wv][i]; info[o + i] = l_info[wv][i]; }
-	if (lane == 0) new_n[r] = (uint32_t)m;
-}
-
 // final: compact the per-read lists (after thinning) and stamp the read id into info.rid (sketch.cpp:577-578)
 __global__ __launch_bounds__(256) void sketch_finish_kernel(const uint64_t *x, const uint64_t *info, const uint64_t *src_off, const uint64_t *dst_off,
 		uint64_t rid_lo, uint64_t n_sel, int stamp_rid, uint64_t *ox, uint64_t *oinfo, const int *err)

@@ -240,7 +240,7 @@ static int hao_bloom_filter(hao_ctx *c, uint64_t *in, uint64_t *alt, uint64_t n,
 	*out = in; *out_alt = alt; *n_out = 0;
 	if (n == 0) return HAO_OK;
 	DevBuf<uint32_t> blk, blk2; DevBuf<uint8_t> flag;
-	const bool dbg = getenv("HAO_DBG_BLOOM") != nullptr;
+	const bool dbg = c->sw.bloom;      // (HAO_DBG_PRINT=bloom)
 	auto now_ = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	double t_ = now_();
 	auto lap = [&](const char *what) { if (dbg) { (void)hipStreamSynchronize(c->stream); const double t1 = now_(); fprintf(stderr, "[bloom] %-14s %8.3f s  (%s)\n", what, t1 - t_, hipGetErrorString(hipGetLastError())); fflush(stderr); t_ = now_(); } };
@@ -705,7 +705,7 @@ static int hao_pt_run(hao_ctx *c)
 		HIP_TRY(c->w_runid.reserve(m + 1)); HIP_TRY(c->d_ix_lk.reserve(m + 1));
 		// big inputs: 5 passes over hash bits 24 .. 63 + the fix-up of the 40-bit runs that hold two keys (hao_index_sort).  Small ones sort all 64 bits (rocprim's
 		// bit-range sort mis-sorts inputs of 5 k - 200 k elements on this ROCm, tests/test_gpu_rocprim.py); so does a retry when the fix-up's scratch ran out.
-		bool sort40 = m >= c->sw.sort40_min && !c->sw.sort64;
+		bool sort40 = m >= c->sw.sort40_min;
 		for (;;) {
 			if (m) { if (int rc = hao_index_sort(c, c->d_ix_mz_x.p, c->d_ix_sx.p, c->w_oi.p, c->w_oi2.p, m, sort40)) return rc; }
 			c->ix_n_sorted = m;
@@ -725,7 +725,7 @@ static int hao_pt_run(hao_ctx *c)
 			size_t tb = 0;
 			HIP_TRY(rocprim::inclusive_scan(nullptr, tb, heads, c->w_runid.p, m, rocprim::plus<uint32_t>(), c->stream)); HIP_TRY(hao_tmp(c, tb));
 			HIP_TRY(rocprim::inclusive_scan(c->d_tmp.p, tb, heads, c->w_runid.p, m, rocprim::plus<uint32_t>(), c->stream));
-			if (m >= c->sw.sort40_min && !c->sw.pt_direct) {      // big index: gather, one radix pass on the top 8 bits of the read-order index, windowed scatter (hao_index.cuh)
+			if (m >= c->sw.sort40_min) {      // big index: gather, one radix pass on the top 8 bits of the read-order index, windowed scatter (hao_index.cuh)
 				int nb = 1; while ((1ULL << nb) < m) ++nb;
 				const int b0 = nb > 8 ? nb - 8 : 0;
 				HIP_TRY(c->w_lkv2.reserve(m + 1));

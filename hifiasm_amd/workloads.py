@@ -17,7 +17,7 @@ WORKLOADS = {
     "chr1_250M_hifi30x_jitter": (250_000_000, 30, 16500, 0.001, 0, 0),     # configs[2] with read lengths uniform in 8 - 25 kb (LEN_JIT below): the same bases in reads that are not all alike
     "human3G_hifi40x": (3_000_000_000, 40, 15000, 0.001, 0, 0),            # configs[3]: 8 M reads of 15 kb, sharded over 8 GPUs
     "human375M_hifi40x": (375_000_000, 40, 15000, 0.001, 0, 0),            # a one-GPU proxy of ONE RANK of configs[3] on 8 GPUs: a rank's read count (1 M reads of 15 kb, 15 Gbases) at configs[3]'s coverage,
-                                                                           # i.e. its seed-hit density (16 k per read); run with HAO_DBG_IX_PAD the index has the replicated index's 3.45 G records
+                                                                           # i.e. its seed-hit density (16 k per read); run with HAO_DBG_TEST=ix_pad=N the index has the replicated index's 3.45 G records
     "ont5M_30x": (5_000_000, 30, 30000, 0.01, 0, 1),
     "ont50M_30x": (50_000_000, 30, 30000, 0.01, 0, 1),                     # 50 000 ONT reads: the full-size parity case of --ont mode
     "ont_human_30x": (3_000_000_000, 30, 30000, 0.01, 0, 1),               # configs[4]: 3 M reads of 30 kb, --ont

@@ -195,10 +195,12 @@ typedef struct {
 	const uint64_t *cl_bits;         /* bit p (word p / 64, bit p % 64) = position p has a code byte */
 	const uint32_t *cl_rank;         /* [n_pos / 256 + 1]: code bytes before position 256 i */
 	const uint8_t *cl_codes;         /* [n_codes] code bytes, in position order */
-	const hao_qmz_t *qmz;            /* minimizer tables of the batch's reads */
+	const hao_qmz_t *qmz;            /* minimizer tables of the batch's reads; NULL when they travel packed (qmz_pos / qmz_cnt below) */
 	const hao_exc_t *cl_exc;         /* [n_exc] sorted by position */
 	const uint8_t *exact;            /* [n_ol] with HAO_DELIVER_EXACT, else NULL */
 	double copy_ms;                  /* from "batch computed" to "copy landed" (includes waiting behind the previous batch's copy); filled by hao_deliver_wait */
+	const uint16_t *qmz_pos;         /* packed minimizer tables (4 instead of 8 bytes per minimizer): self_offset and cnt of minimizer qm_off[r] + q in two 16-bit arrays.  The engine packs when */
+	const uint16_t *qmz_cnt;         /* every read is shorter than 65 536 bases and the pass's seed weights (anchor.cpp:160-173; cnt = weight << 8 | span) are below 256; else both are NULL and qmz is set */
 } hao_delivery_t;
 #define HAO_FC_RAW (1ULL << 63)
 /* The fake cigar (Fake_Cigar, Hash_Table.h:54-59; gen_fake_cigar, Hash_Table.cpp:88-109) of overlap j of a delivered batch as its ol[j].fc_len 8-byte entries

@@ -288,3 +288,12 @@ def ed_tasks_grid_all(lengths, ols, lo=0, wl=375, thre=15):
                     continue
                 out.append((yid, p0, p1 - p0, yrev, int(z[0]), ws, tn, 0, thre, ad))
     return np.array(out, dtype=np.uint32).reshape(-1, 10)
+
+
+def device_mem_info():
+    """(free, total) bytes from the HIP runtime libhao.so is linked with (not torch's own copy of it: a second runtime in the process may not get the device)"""
+    import ctypes
+    so = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln}, key=lambda p: ("/torch/" in p, p))
+    hip = ctypes.CDLL(so[0]); fr, to = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert hip.hipMemGetInfo(ctypes.byref(fr), ctypes.byref(to)) == 0
+    return fr.value, to.value

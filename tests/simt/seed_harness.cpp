@@ -16,7 +16,7 @@ int fail(char *err, int cap, const std::string &m) { snprintf(err, cap, "%s", m.
 }
 
 // mode 0: the table kernels as the library launches them (QL instances; overflowing reads through seed_bin3_kernel);
-// 2: HAO_SEED_NOQL (per-minimizer tables possibly in global memory: qcap_force > 0 caps the LDS table to force that path)
+// 2: HAO_DBG_FORCE=noql (per-minimizer tables possibly in global memory: qcap_force > 0 caps the LDS table to force that path)
 // 12 / 13: the list-major kernel (hao_query5.cuh) takes every read first; the reads it leaves go through the table kernels as in mode 0 (stats[6] = reads it left)
 // blocks: the reads to run in the first launch (others keep empty output); returns 0 or 1 with a message
 extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t *mz_info, const uint64_t *lk, const uint32_t *wgt, const uint64_t *sinfo, const uint32_t *len, uint64_t n_total,

@@ -31,7 +31,7 @@ def test_profile_lookup_prefers_the_newest_round():
     newest = max(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "pmc_traffic.json")))
     assert rel == f"profiles/{newest}/pmc_traffic.json" and os.path.exists(p)
     assert b.profile_file("no_such_file.json") == (None, None)
-    assert set(b.KERN_STAGE) <= set(b.ALG) and b.SEED_KERNEL in b.KERN_STAGE and len(b.KERN_STAGE) == 3
+    assert {"sketch_unit_kernel", "chain_group_kernel", "seed_lds_kernel", "seed_bin_kernel"} <= set(b.ALG)      # (the seed stage's kernel is named by the engine per run: hao_batch_seed_path)
 
 
 def test_default_workload_per_gpu_count():

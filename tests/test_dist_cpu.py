@@ -59,7 +59,7 @@ def _free_port():
 import pytest  # noqa: E402
 
 
-_RCCL_CASES = [("hifi", 2, {}), ("nn", 3, {}), ("bf24", 2, {}), ("hifi", 4, {}), ("hifi", 2, {"HAO_FT_PASSES": "3", "HAO_FT_CHUNK_SLOTS": "25000"})]
+_RCCL_CASES = [("hifi", 2, {}), ("nn", 3, {}), ("bf24", 2, {}), ("hifi", 4, {}), ("hifi", 2, {"HAO_FT_PASSES": "3", "HAO_DBG_TEST": "ft_chunk_slots=25000"})]
 
 
 @pytest.mark.parametrize("name,world,env", _RCCL_CASES if os.environ.get("HAO_SIMT_FULL") else [_RCCL_CASES[1], _RCCL_CASES[3], _RCCL_CASES[4]])      # (default suite: 3 ranks with N reads, 4 ranks, 2 ranks in passes; HAO_SIMT_FULL=1: all five)

@@ -1,7 +1,8 @@
-"""Every implementation variant that libhao.so can be switched to at run time (A/B switches kept for measurements, and the fallbacks behind
-them) must give the oracle's result: one-lane sequential chaining instead of the wave kernels, DP without speculative tiles, the one-lane DP
-tail, DP kernels on the main stream, one-wave selection for every size, the one-lane pruning scan, the generic (any w, k) sketch kernel,
-the sketch retry after an under-sized minimizer list, and the seed stage's table kernels / list-major kernel on every batch."""
+"""Every FALLBACK path of libhao.so that a run-time switch can force on every read / group (HAO_DBG_FORCE, HAO_DBG_TEST, the seed stage's
+HAO_SEED_* thresholds: hao_ctx.hpp) must give the oracle's result: one-lane sequential chaining instead of the wave kernels, DP without
+speculative tiles, the one-lane DP tail, DP and pack kernels on the engine's stream, the one-lane pruning scan, the sketch retry after an
+under-sized minimizer pool, the seed stage's generic tables, and the seed
+stage's table kernels / list-major kernel on every batch."""
 import os
 
 import pytest
@@ -10,20 +11,17 @@ from helpers import scenario_reads, scenario_oracle
 
 pytestmark = pytest.mark.gpu
 
-SWITCHES = ["HAO_DBG_SEQ_CHAIN", "HAO_DBG_DP_NOSPEC", "HAO_DBG_DP_SEQTAIL", "HAO_DBG_DP_SERIAL", "HAO_DBG_SEL1", "HAO_DBG_SEQ_PRUNE",
-            "HAO_DBG_SK_GENERIC", "HAO_DBG_SK_GCAP", "HAO_SPEC_MINCLS", "HAO_CHAIN_WPB", "HAO_DBG_TINY_LANE",
-            "HAO_SEED_NOQL", "HAO_PT_SORT64", "HAO_PT_DIRECT",
+SWITCHES = ["HAO_DBG_FORCE=seq_chain", "HAO_DBG_FORCE=dp_nospec", "HAO_DBG_FORCE=dp_seqtail", "HAO_DBG_FORCE=dp_serial", "HAO_DBG_FORCE=seq_prune", "HAO_DBG_FORCE=noql",
+            "HAO_DBG_TEST=sk_gcap=1000",
             "HAO_SEED_LDS=0", "HAO_SEED_LDS_RATIO=1000000", "HAO_SEED_LDS_RATIO=1", "HAO_SEED_MERGE_MAXN=3000", "HAO_SEED_MERGE_MAXN=1000000"]
-# (the seed stage: the table kernels for every read; the list-major kernel for every batch however many hits its reads average - these sets are repeat-rich - and the
-# seed-hit limit above which it leaves a read to the table kernels)
-VALUES = {"HAO_DBG_SK_GCAP": "1000", "HAO_SPEC_MINCLS": "0", "HAO_CHAIN_WPB": "4"}
+# (the big-index build on small sets - HAO_DBG_TEST=sort40_min=1 - runs on the CPU emulation only, tests/test_simt_schedules_cpu.py: rocprim's bit-range sort
+# mis-sorts inputs of 5 k - 200 k elements on this ROCm, tests/test_gpu_rocprim.py.  The seed stage: the table kernels for every read; the list-major kernel for every batch however many hits its reads average - these sets are repeat-rich - and the seed-hit limit
+# above which it leaves a read to the table kernels)
 
 
 def _env_of(switch):
-    """'A' -> {A: VALUES.get(A, '1')}; 'A=x,B=y' -> {A: x, B: y}"""
-    if "=" not in switch:
-        return {switch: VALUES.get(switch, "1")}
-    return dict(kv.split("=") for kv in switch.split(","))
+    """'A=x' -> {A: x} (x may hold '=' and ',': the lists of HAO_DBG_FORCE / HAO_DBG_TEST); several variables: 'A=x;B=y'"""
+    return dict(kv.split("=", 1) for kv in switch.split(";"))
 
 
 @pytest.mark.parametrize("switch", SWITCHES)
@@ -55,13 +53,13 @@ def test_switch_keeps_results(name, switch):
 
 @pytest.mark.parametrize("name", ["hifi", "rr"])
 def test_index_positions_beyond_2_32(name):
-    """List starts are 48-bit everywhere (lk[], the key table, the seed kernels' staged words, the host view): HAO_DBG_IX_PAD puts 2^32 + 12345 unused position
+    """List starts are 48-bit everywhere (lk[], the key table, the seed kernels' staged words, the host view): HAO_DBG_TEST=ix_pad=N puts 2^32 + 12345 unused position
     records in front of the index (34 GB), so every list of a small read set starts beyond 2^32 - the situation of a replicated index of more than 2^32
     minimizers (human genome, 50x).  Same tables, same overlaps."""
     from hifiasm_amd.api import Engine
     rs, okw = scenario_reads(name)
     o = scenario_oracle(name)
-    os.environ["HAO_DBG_IX_PAD"] = str((1 << 32) + 12345)
+    os.environ["HAO_DBG_TEST"] = "ix_pad=" + str((1 << 32) + 12345)
     try:
         e = Engine(0, **okw)
         e.set_readset(rs)
@@ -81,5 +79,5 @@ def test_index_positions_beyond_2_32(name):
                 bad += 1
         e.close()
     finally:
-        del os.environ["HAO_DBG_IX_PAD"]
+        del os.environ["HAO_DBG_TEST"]
     assert bad == 0, f"{bad}/{rs.n} reads differ"

@@ -41,15 +41,15 @@ def test_loopback_world_ft_in_passes(name, world, passes, monkeypatch):
     """sharded ha_ft_gen in hash-range passes: every pass is one partition + all-to-all-v + count of a P-th of every rank's range (exact) / of every rank's sub-tables
     (Bloom); all ranks run the same number of passes; tables, histograms and every read's overlaps as with one pass"""
     monkeypatch.setenv("HAO_FT_PASSES", str(passes))
-    monkeypatch.setenv("HAO_FT_CHUNK_SLOTS", "25000")
+    monkeypatch.setenv("HAO_DBG_TEST", "ft_chunk_slots=25000")
     _loopback_world(name, world)
 
 
 def test_replicated_index_beyond_2_32(monkeypatch):
     """The replicated index has no 2^32-record limit (only a rank's hash partition has, through its sort's arrival index): with 2^32 + 999 unused position
-    records in front of every rank's copy of the index (HAO_DBG_IX_PAD, 34 GB per rank) all list starts - the ones a partition's owner sends back to the
+    records in front of every rank's copy of the index (HAO_DBG_TEST=ix_pad=N, 34 GB per rank) all list starts - the ones a partition's owner sends back to the
     minimizers' home ranks included - lie beyond 2^32; tables and every read's overlaps must not change."""
-    monkeypatch.setenv("HAO_DBG_IX_PAD", str((1 << 32) + 999))
+    monkeypatch.setenv("HAO_DBG_TEST", "ix_pad=" + str((1 << 32) + 999))
     _loopback_world("rr", 2)
 
 

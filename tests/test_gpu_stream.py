@@ -15,23 +15,28 @@ def _same(a, b):
     return all(x.shape == y.shape and (x == y).all() for x, y in zip(a, b))
 
 
-@pytest.mark.parametrize("name", ["hifi", "rr", "ont", "edge", "rr_heavy", "long200k", "hifi+arena4"])
+@pytest.mark.parametrize("name", ["hifi", "rr", "ont", "edge", "rr_heavy", "long200k", "hifi+arena4", "hifi+qmz_raw", "rr+qmz_raw"])
 def test_delivered_results_equal_the_oracle(name, monkeypatch):
     from hifiasm_amd.api import Engine
     if name.endswith("+arena4"):      # the arenas allocated by hand (mmap + mbind to the GPU's NUMA node + hipHostRegister): what the engine falls back to when hipHostMalloc's pages are elsewhere
         monkeypatch.setenv("HAO_ARENA_NUMA", "4"); name = name.split("+")[0]
+    raw_tables = name.endswith("+qmz_raw")
+    if raw_tables:      # the minimizer tables of the wire format as 8-byte pairs (what batches with a read of 65 536 bases or more get: "ont", "long200k") for reads that would get 4 bytes
+        monkeypatch.setenv("HAO_DBG_TEST", "qmz_raw=1"); name = name.split("+")[0]
     rs, okw = scenario_reads(name)
     o = scenario_oracle(name)
     e = Engine(0, **okw)
     e.set_readset(rs)
     e.ha_ft_gen(); e.ha_pt_gen()
     cuts = [0, rs.n // 3, rs.n // 3, rs.n // 2 + 1, rs.n]          # includes an empty batch
-    pending, bad, n_exc, n_cl = None, [], 0, 0
+    pending, bad, n_exc, n_cl, packed_ = None, [], 0, 0, set()
 
     def check(slot, lo, hi):
         nonlocal n_exc, n_cl
         d = e.deliver_wait(slot)
         assert (d.rid_lo, d.n_reads) == (lo, hi - lo)
+        if d.n_cl:
+            packed_.add(bool(d.qmz_pos))
         n_exc += d.n_exc; n_cl += d.n_cl
         for r in range(lo, hi):
             if not _same(e.delivered_read(d, r), o.lchain(r)):
@@ -45,6 +50,7 @@ def test_delivered_results_equal_the_oracle(name, monkeypatch):
     check(*pending)
     assert not bad, bad[:10]
     assert n_cl > 0
+    assert packed_ == {int(rs.lengths.max()) < 65536 and not raw_tables}, (packed_, int(rs.lengths.max()))      # (these scenarios' seed weights are far below 256)
     # the blocking API afterwards (same engine) still serves the same bytes
     e.overlap_batch(0, rs.n)
     for r in range(0, rs.n, 7):
@@ -55,8 +61,7 @@ def test_delivered_results_equal_the_oracle(name, monkeypatch):
 
 def test_exception_list_overflow_repacks():
     from hifiasm_amd.api import Engine
-    os.environ["HAO_DBG_EXC_CAP"] = "3"
-    os.environ["HAO_DBG_EXC_EVERY"] = "5"            # every fifth hit of a chain travels verbatim
+    os.environ["HAO_DBG_TEST"] = "exc_cap=3,exc_every=5"           # every fifth hit of a chain travels verbatim
     try:
         rs, okw = scenario_reads("ont")
         o = scenario_oracle("ont")
@@ -69,18 +74,17 @@ def test_exception_list_overflow_repacks():
             assert _same(e.delivered_read(d, r), o.lchain(r)), r
         e.close()
     finally:
-        del os.environ["HAO_DBG_EXC_CAP"]
-        del os.environ["HAO_DBG_EXC_EVERY"]
+        del os.environ["HAO_DBG_TEST"]
 
 
 @pytest.mark.parametrize("name", ["ont", "rr"])
 def test_cigars_that_travel_raw(name, monkeypatch):
-    """a fake cigar with a step the packed word cannot hold travels raw behind the packed ones (bit 63 of its offset): HAO_DBG_FC_RAW_EVERY sends every third
+    """a fake cigar with a step the packed word cannot hold travels raw behind the packed ones (bit 63 of its offset): HAO_DBG_TEST=fc_raw_every=3 sends every third
     overlap that way - long ONT cigars (wave-cooperative copy) and short ones alike -, the decoder must give back the same entries"""
     from hifiasm_amd.api import Engine
     import ctypes as C
     import numpy as np
-    monkeypatch.setenv("HAO_DBG_FC_RAW_EVERY", "3")
+    monkeypatch.setenv("HAO_DBG_TEST", "fc_raw_every=3")
     rs, okw = scenario_reads(name)
     o = scenario_oracle(name)
     e = Engine(0, **okw)

@@ -70,7 +70,7 @@ def test_ft_gen_in_passes(name, passes, chunk, monkeypatch):
     from hifiasm_amd.api import Engine
     monkeypatch.setenv("HAO_FT_PASSES", str(passes))
     if chunk:
-        monkeypatch.setenv("HAO_FT_CHUNK_SLOTS", str(chunk))
+        monkeypatch.setenv("HAO_DBG_TEST", f"ft_chunk_slots={chunk}")
     rs, okw = scenario_reads(name)
     o = scenario_oracle(name)
     e = Engine(0, **okw)

@@ -1,8 +1,8 @@
 """Device code whose FIRST execution on a GPU is the driver's `pytest -m gpu` run (the file sorts last so that `pytest -x` cannot hide the rest of
 the suite behind it):
 
-  * the thinning kernel the sketch does NOT run by default (the other of sketch_select2_kernel / sketch_select_kernel, switched by environment):
-    minimizers of every read and every read's h_ec_lchain result on the repeat-rich scenarios, plus the repeat-rich 5 Mb full-size fixture;
+  * the sketch's thinning kernel (sketch_select2_kernel): minimizers of every read and every read's h_ec_lchain result on the repeat-rich
+    scenarios, plus the repeat-rich 5 Mb full-size fixture;
   * window alignment in bands of three and four 64-bit words (thre 64 .. 127; hao_al_kernel<hao_wide<3|4>, ...>) against the REFERENCE's own
     ed_band_cal_*_infi_* functions (tests/golden/ed_wide.npz, tests/golden/make_golden_ed_wide.py).
 
@@ -17,8 +17,7 @@ from helpers import (scenario_reads, scenario_oracle, load_golden, fold_digests,
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NOALN = 2**31 - 1
-# the thinning kernel is chosen by the environment: neither set = the default, HAO_SK_SELECT2 = the wave kernel (hao_select2.cuh), HAO_SK_SELECT1 = the one-lane replay
-SELECT_SWITCHES = [None, "HAO_SK_SELECT1", "HAO_SK_SELECT2"]
+SELECT_SWITCHES = [None]      # (the one-lane replay kernel of round 3 was removed in round 6: the wave kernel, hao_select2.cuh, is the only one)
 
 
 def _same(a, b):
@@ -28,7 +27,7 @@ def _same(a, b):
 @pytest.mark.parametrize("switch", SELECT_SWITCHES)
 @pytest.mark.parametrize("name", ["rr", "rr_big", "rr_heavy", "bf24", "fz3", "long_rr"])
 def test_thinning_kernels(name, switch):
-    """mz1_select_mz_h (sketch.cpp:247-330) by the wave kernel (closed form, hao_select2.cuh) and by the one-lane replay: same minimizers, same overlaps"""
+    """mz1_select_mz_h (sketch.cpp:247-330) by the wave kernel (closed form, hao_select2.cuh): the oracle's minimizers, the oracle's overlaps"""
     from hifiasm_amd.api import Engine
     rs, okw = scenario_reads(name)
     o = scenario_oracle(name)

@@ -1,5 +1,5 @@
 """A one-GPU PROXY of one rank of BASELINE.json configs[3] (3 Gb, 40x, 8 M reads on 8 GPUs), against the REAL reference: `human375M_hifi40x` = 1 M reads of 15 kb
-over a 375 Mb genome - a rank's read count at configs[3]'s coverage, i.e. its seed-hit density (16 k per read) - with HAO_DBG_IX_PAD bringing the position index to the
+over a 375 Mb genome - a rank's read count at configs[3]'s coverage, i.e. its seed-hit density (16 k per read) - with HAO_DBG_TEST=ix_pad=N bringing the position index to the
 replicated index's 3.45 G records (27.6 GB): ha_pt_gen and the all-reads pass at a rank's size, which the rank-share test of ha_ft_gen (test_gpu_zz_rankshare.py)
 left open.  The fixture (tests/golden/human375M_hifi40x.npz) is the unmodified reference's run on the same reads (tests/golden/make_golden_big.py): coverage peaks,
 thresholds, minimizer histogram, totals, and a digest of EVERY read's seed hits and (ol, fake cigars, cl).
@@ -14,20 +14,11 @@ import zlib
 import numpy as np
 import pytest
 
-from helpers import load_golden, fold_digests, GOLDEN
+from helpers import load_golden, fold_digests, GOLDEN, device_mem_info
 
 pytestmark = pytest.mark.gpu
 NAME = "human375M_hifi40x"
 IX_RECORDS = 3_450_000_000      # minimizers of configs[3]'s 8 M reads = position records of the replicated index
-
-
-def device_mem_info():
-    """(free, total) bytes from the HIP runtime libhao.so is linked with (not torch's own copy of it: a second runtime in the process may not get the device)"""
-    import ctypes
-    so = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln}, key=lambda p: ("/torch/" in p, p))
-    hip = ctypes.CDLL(so[0]); fr, to = ctypes.c_size_t(0), ctypes.c_size_t(0)
-    assert hip.hipMemGetInfo(ctypes.byref(fr), ctypes.byref(to)) == 0
-    return fr.value, to.value
 
 
 def test_a_configs3_rank_sized_round_against_the_reference():
@@ -39,11 +30,11 @@ def test_a_configs3_rank_sized_round_against_the_reference():
     g = load_golden(NAME); m = g["meta"]
     rs = workload_reads(NAME)
     assert zlib.crc32(rs.lengths.tobytes()) == int(g["len_crc"][0]) and zlib.crc32(rs.packed[: 1 << 20].tobytes()) == int(g["len_crc"][1]), "the synthetic read generator drifted"
-    os.environ["HAO_DBG_IX_PAD"] = str(IX_RECORDS - 431_000_000)
+    os.environ["HAO_DBG_TEST"] = "ix_pad=" + str(IX_RECORDS - 431_000_000)
     try:
         e = Engine(0)
     finally:
-        del os.environ["HAO_DBG_IX_PAD"]
+        del os.environ["HAO_DBG_TEST"]
     try:
         e.set_readset(rs)
         t0 = time.time(); hom_ft = e.ha_ft_gen(); t_ft = time.time() - t0

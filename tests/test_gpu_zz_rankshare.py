@@ -1,8 +1,9 @@
 """BASELINE.json configs[3]'s share of ONE of eight ranks through ha_ft_gen on one device: reads [0, 1 000 000) of the 8 M reads of the 3 Gb / 40x HiFi set - 15 Gbases,
 11 G HPC k-mer occurrences.  ha_ft_gen chooses its hash-range passes by itself (hao_ft_pass_count, hao_tables.hpp; htab.cpp:707-882 never holds all occurrences
-either: 4096 sub-tables filled batch by batch, :147-151, 594-606): on its own a device of 309 GB takes the two 8-byte buffers of 11 G occurrences in ONE pass (the choice
-must be what hifiasm_amd/memplan.py predicts from the free memory), as a rank of eight - with the receive buffer and its twin beside them - it needs three; both must stay
-inside the device and give the same histogram and filter table.  The measured peaks are printed next to the plan's figures."""
+either: 4096 sub-tables filled batch by batch, :147-151, 594-606): on its own a device of 309 GB has the memory for the two 8-byte buffers of 11 G occurrences at once,
+but a pass holds fewer than 2^32 occurrences (32-bit slot numbers): three passes (the choice must be what hifiasm_amd/memplan.py predicts from the free memory and that
+limit); as a rank of eight - with the receive buffer and its twin beside them - it needs more (forced here: six); both must stay inside the device and give the same
+histogram and filter table, the six-pass run in less memory.  The measured peaks are printed next to the plan's figures."""
 import json
 import os
 import threading
@@ -11,22 +12,25 @@ import time
 import numpy as np
 import pytest
 
+from helpers import device_mem_info
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class _PeakPoll(threading.Thread):
-    """smallest free device memory seen while it runs (torch.cuda.mem_get_info: a driver query, 5 ms apart)"""
+    """smallest free device memory seen while it runs (hipMemGetInfo of the runtime libhao.so runs on - helpers.device_mem_info: a driver query, 5 ms apart)"""
 
     def __init__(self):
         super().__init__(daemon=True)
-        import torch
-        self.t = torch; self.stop = False
-        self.free0, self.total = torch.cuda.mem_get_info(0); self.min_free = self.free0
+        from hifiasm_amd import api
+        api.lib()      # (the runtime must be in the process before it is asked)
+        self.stop = False
+        self.free0, self.total = device_mem_info(); self.min_free = self.free0
 
     def run(self):
         while not self.stop:
-            self.min_free = min(self.min_free, self.t.cuda.mem_get_info(0)[0]); time.sleep(0.005)
+            self.min_free = min(self.min_free, device_mem_info()[0]); time.sleep(0.005)
 
 
 def test_configs3_rank_share_through_ft_gen(monkeypatch):
@@ -42,7 +46,7 @@ def test_configs3_rank_share_through_ft_gen(monkeypatch):
     t_gen = time.time() - t0
     assert rs.total_bases > 14.5e9
     res = {}
-    for tag, passes in (("auto", None), ("as_a_rank", 3)):
+    for tag, passes in (("auto", None), ("as_a_rank", 6)):
         if passes is not None:
             monkeypatch.setenv("HAO_FT_PASSES", str(passes))
         poll = _PeakPoll(); poll.start()
@@ -59,9 +63,9 @@ def test_configs3_rank_share_through_ft_gen(monkeypatch):
             e.close()
     a, d = res["auto"], res["as_a_rank"]
     occ_ = int((a["hist"].astype(np.int64) * np.arange(a["hist"].size)).sum())
-    assert a["passes"] == memplan.ft_passes(occ_, (a["total_gb"] - a["before_gb"]) * 1e9, False) and d["passes"] == 3
+    assert a["passes"] == memplan.ft_passes(occ_, (a["total_gb"] - a["before_gb"]) * 1e9, False) and d["passes"] == 6 and a["passes"] == max(1, -(-occ_ // (1 << 32)))
     assert memplan.ft_passes(occ_, (a["total_gb"] - a["before_gb"]) * 1e9, True) >= 2      # the same share as one of eight ranks does not fit in one pass
-    assert a["peak_gb"] < 0.95 * a["total_gb"] and d["peak_gb"] < a["peak_gb"] - 50.0
+    assert a["peak_gb"] < 0.95 * a["total_gb"] and d["peak_gb"] < a["peak_gb"] - 20.0, (a["peak_gb"], d["peak_gb"])
     assert a["hom"] == d["hom"] and (a["hist"] == d["hist"]).all() and a["keys"].shape == d["keys"].shape and (a["keys"] == d["keys"]).all() and (a["vals"] == d["vals"]).all()
     # exact counting: every occurrence is in exactly one run; counts saturate at 4095 only in the histogram's last bin (a random genome has no such k-mer)
     h = a["hist"].astype(np.int64)

@@ -24,8 +24,8 @@ def test_other_schedules(name, env):
 @pytest.mark.parametrize("name", ["hifi", "bf22"])
 def test_big_index_path_on_a_small_read_set(name):
     """ha_pt_gen's path for >= 2^23 minimizers (the index sort on 40 hash bits + the fix-up of the runs that hold several keys, hao_index_gather_kernel, one radix
-    pass, the windowed scatter of the lookup results) - on the device only the full-size fixtures reach it; HAO_DBG_SORT40_MIN lowers the threshold for the emulation"""
-    r = subprocess.run([sys.executable, os.path.join(HERE, "simt_pipeline.py"), name], capture_output=True, text=True, env=dict(os.environ, HAO_DBG_SORT40_MIN="1", HAO_SIMT_PROF="1"))
+    pass, the windowed scatter of the lookup results) - on the device only the full-size fixtures reach it; HAO_DBG_TEST=sort40_min=N lowers the threshold for the emulation"""
+    r = subprocess.run([sys.executable, os.path.join(HERE, "simt_pipeline.py"), name], capture_output=True, text=True, env=dict(os.environ, HAO_DBG_TEST="sort40_min=1", HAO_SIMT_PROF="1"))
     assert r.returncode == 0 and r.stdout.startswith("OK"), (r.stdout[-400:], r.stderr[-1200:])
     if os.environ.get("HAO_SIMT_PROF"):      # (tools/simt_coverage.py collects these lines)
         sys.__stderr__.write("\n".join(l for l in r.stderr.splitlines() if l.startswith("[simt prof]")) + "\n")

@@ -5,15 +5,17 @@ the k_mer_hits it was made from.  No GPU involved: the device-side encoder is ch
 import ctypes as C
 
 import numpy as np
+import pytest
 
 from hifiasm_amd import api
 
 
-def _encode(reads, rid_lo=7, seed=3, fill=True):
+def _encode(reads, rid_lo=7, seed=3, fill=True, packed=False):
     """reads: list of (qmz [(self_offset, cnt)], chains [(w0, [(q, offset), ...])]) -> (Delivery, keep-alive list, expected hits per read).
     Positions are indices among the batch's seed hits: every chain is a run of consecutive positions somewhere in the read's range, with positions that
     belong to no chain (random code bytes, some of them flagged, one of them 0xff with a bogus list entry) between the chains; the byte at a chain's
-    first position is arbitrary as well."""
+    first position is arbitrary as well.  packed: the minimizer tables as two arrays (16-bit self_offset, 16-bit cnt: hao_delivery_t::qmz_pos / qmz_cnt) instead of
+    8-byte pairs."""
     rng = np.random.default_rng(seed)
     ch_off, cl_off, qm_off = [0], [0], [0]
     hdr, qmz, exc, want = [], [], [], []
@@ -78,10 +80,15 @@ def _encode(reads, rid_lo=7, seed=3, fill=True):
     d.rid_lo, d.n_reads, d.n_chains, d.n_cl, d.n_exc, d.n_codes, d.n_pos = rid_lo, len(reads), len(hdr), h, len(exc), int(codes.size), n_pos
     d.ch_off, d.cl_off, d.qm_off = (a.ctypes.data for a in arrs[:3])
     d.chains, d.qmz, d.cl_bits, d.cl_rank, d.cl_codes, d.cl_exc = (a.ctypes.data for a in arrs[3:])
+    if packed:
+        assert a_qmz[:, 0].max() < 65536 and a_qmz[:, 1].max() < 65536
+        arrs += [a_qmz[:, 0].astype(np.uint16), a_qmz[:, 1].astype(np.uint16)]
+        d.qmz, d.qmz_pos, d.qmz_cnt = None, arrs[-2].ctypes.data, arrs[-1].ctypes.data
     return d, arrs, want
 
 
-def test_decoder_inverts_the_format():
+@pytest.mark.parametrize("packed", [False, True])
+def test_decoder_inverts_the_format(packed):
     rng = np.random.default_rng(5)
     reads = []
     for r in range(9):
@@ -104,8 +111,8 @@ def test_decoder_inverts_the_format():
             if hits:
                 chains.append((int(rng.integers(0, 1 << 31)) | (int(rng.integers(0, 2)) << 31), hits))
         reads.append((qt, chains))
-    reads.append(([(10, 300)], []))                                                   # a read without chains
-    d, keep, want = _encode(reads)
+    reads.append(([(10, 300)], []))                                                 # a read without chains
+    d, keep, want = _encode(reads, packed=packed)
     L = api.lib()
     assert d.n_exc > 0 and d.n_codes > d.n_exc
     for r, exp in enumerate(want):

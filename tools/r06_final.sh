@@ -17,13 +17,13 @@ d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print(sys.argv[2], 'ms', d['ms_per_step'], 'M ov/s', round(d['value']/1e6,2), 'resident', d.get('ms_per_step_resident'), round(d['value_resident']/1e6,2), 'ok', ((d.get('boundary') or {}).get('delivered_bytes_check') or {}).get('equal_to_reference'))
 PY
 done; fi
-if has rrab; then for spec in rr_default: rr_maxn16k:HAO_SEED_MERGE_MAXN=16000 rr_all_merge:HAO_SEED_MERGE_MAXN=100000000 rr_tables:HAO_SEED_MERGE=0; do IFS=: read name envs <<< "$spec"; env ${envs:-X_=1} timeout 600 python bench.py --workload chr1_250M_hifi30x_repeat --cpu-baseline none --no-variants --no-boundary --steps 3 --warmup 1 > $O/$name.json 2> $O/$name.err; python - $O/$name.json $name <<'PY'
+if has rrab; then for spec in rr_default: rr_lds:HAO_SEED_LDS_RATIO=1000000 rr_tables:HAO_SEED_LDS=0; do IFS=: read name envs <<< "$spec"; env ${envs:-X_=1} timeout 600 python bench.py --workload chr1_250M_hifi30x_repeat --cpu-baseline none --no-variants --no-boundary --steps 3 --warmup 1 > $O/$name.json 2> $O/$name.err; python - $O/$name.json $name <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); s=d['stage_ms']
 print(sys.argv[2], 'resident', d['ms_per_step_resident'], 'seed', round(s['q_sort_bins'],1), 'chain', round(s['q_chain'],1), 'sel', round(s['q_select'],1), 'sketch', round(s['sk_chunks'],1))
 PY
 done; fi
-if has c2ab; then for spec in c2_merge: c2_tables:HAO_SEED_MERGE=0 c2_merge_locus:HAO_SEED_LOCUS=1; do IFS=: read name envs <<< "$spec"; env ${envs:-X_=1} timeout 600 python bench.py --workload chr1_250M_hifi30x --cpu-baseline none --no-variants --no-boundary --steps 20 --warmup 5 > $O/$name.json 2> $O/$name.err; python - $O/$name.json $name <<'PY'
+if has c2ab; then for spec in c2_lds: c2_tables:HAO_SEED_LDS=0; do IFS=: read name envs <<< "$spec"; env ${envs:-X_=1} timeout 600 python bench.py --workload chr1_250M_hifi30x --cpu-baseline none --no-variants --no-boundary --steps 20 --warmup 5 > $O/$name.json 2> $O/$name.err; python - $O/$name.json $name <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); s=d['stage_ms']
 print(sys.argv[2], 'resident', d['ms_per_step_resident'], 'seed', round(s['q_sort_bins'],2), 'chain', round(s['q_chain'],2), 'sketch', round(s['sk_chunks'],2), 'frac', d['roofline']['frac'])
