@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "hao_ft_cnt", "hao_pt_get", "hao_ft_table", "hao_pt_table", "hao_hist", "hao_stats", "hao_sketch_batch",
     "hao_fetch_sketch", "hao_overlap_batch", "hao_fetch_seed_hits", "hao_fetch_overlaps", "hao_batch_totals", "hao_batch_seed_path",
     "hao_stage_times", "hao_pass_default", "hao_overlap_batch_ex", "hao_set_shard", "hao_dist_unique_id", "hao_dist_init",
-    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_selftest_big", "hao_selftest_sortbits", "hao_unpack_cigar", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits", "hao_exact_check", "hao_fetch_exact", "hao_window_ed_batch", "hao_index_save", "hao_index_load", "hao_next_slot", "hao_attach", "hao_window_trace_batch", "hao_delivery_digest", "hao_ft_passes", "hao_ovlp_bin_read", "hao_ovlp_bin_write", "hao_window_ed_grid", "hao_fetch_ed_grid",
+    "hao_loop_create", "hao_loop_destroy", "hao_dist_init_loopback", "hao_batch_digest", "hao_selftest_rocprim", "hao_selftest_big", "hao_selftest_sortbits", "hao_unpack_cigar", "hao_unpack_overlaps", "hao_overlap_batch_async", "hao_deliver_wait", "hao_unpack_hits", "hao_exact_check", "hao_fetch_exact", "hao_window_ed_batch", "hao_index_save", "hao_index_load", "hao_next_slot", "hao_attach", "hao_window_trace_batch", "hao_delivery_digest", "hao_ft_passes", "hao_ovlp_bin_read", "hao_ovlp_bin_write", "hao_window_ed_grid", "hao_fetch_ed_grid",
 ]
 
 
@@ -109,6 +109,7 @@ def lib():
         L.hao_fetch_exact.argtypes = [vp, C.c_uint64, C.POINTER(vp), u64p]
         L.hao_unpack_hits.argtypes = [C.POINTER(Delivery), C.c_uint64, vp, C.c_uint64]; L.hao_unpack_hits.restype = C.c_uint64
         L.hao_unpack_cigar.argtypes = [C.POINTER(Delivery), C.c_uint64, vp, C.c_uint32]; L.hao_unpack_cigar.restype = C.c_uint32
+        L.hao_unpack_overlaps.argtypes = [C.POINTER(Delivery), C.c_uint64, vp, C.c_uint64]; L.hao_unpack_overlaps.restype = C.c_uint64
         L.hao_delivery_digest.argtypes = [C.POINTER(Delivery), u64p, C.c_int]
         L.hao_set_shard.argtypes = [vp, C.c_uint64, C.c_uint64, u32p]
         L.hao_dist_unique_id.argtypes = [u8p]
@@ -312,7 +313,9 @@ class Engine:
         r = rid - d.rid_lo
         oo = _arr(d.ol_off + 8 * r, 2, np.uint64)
         s_, e_ = int(oo[0]), int(oo[1])
-        ol = _arr(d.ol + 48 * s_, 12 * (e_ - s_), np.uint32).reshape(-1, 12)
+        ol = np.zeros((e_ - s_, 12), dtype=np.uint32)                      # (the wire carries 32 of an overlap's 48 bytes)
+        got = self.L.hao_unpack_overlaps(C.byref(d), rid, ol.ctypes.data_as(C.c_void_p), e_ - s_)
+        assert got == e_ - s_
         lens = ol[:, 11].astype(np.int64)                                  # fc_len of every overlap; the cigars come through the decoder (the wire packs them)
         fo = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
         fc = np.zeros(int(fo[-1]), dtype=np.uint64)

@@ -24,11 +24,11 @@ struct hao_ctx::Batch {
 	// Results of a batch that leave the device.  Two sets (+ two pinned host arenas): while the copy stream drains the set of batch i, batch i + 1
 	// computes into the other one (hao_overlap_batch_async).  The blocking API keeps using the current set.
 	struct OutSet {
-		DevBuf<hao_ovlp_t> ol_out; DevBuf<uint64_t> fin_off, fc_out, fc_out_off, ch_off, cl_off, qm_off, fcw_off; DevBuf<uint32_t> fcw;      // (fcw*: the fake cigars as they travel, hao_deliver.cuh)
+		DevBuf<hao_ovlp_t> ol_out; DevBuf<hao_ovlp_wire_t> ol_wire; DevBuf<uint64_t> fin_off, fc_out, fc_out_off, ch_off, cl_off, qm_off, fcw_off; DevBuf<uint32_t> fcw;      // (fcw*: the fake cigars as they travel, hao_deliver.cuh)
 		//      // ol->list in final order, per-read offsets, fake cigars
 		DevBuf<hao_chain_hdr_t> hdr; DevBuf<uint64_t> bits; DevBuf<uint32_t> rank, rank4; DevBuf<uint8_t> codes; DevBuf<hao_exc_t> exc; DevBuf<hao_qmz_t> qmz; DevBuf<uint16_t> qmz_pos, qmz_cnt; bool qmz16 = false;   // cl->list in the wire format (hao_deliver.cuh)
 		DevBuf<uint8_t> exact;                                                                        // exact-overlap flags of ol_out
-		void release() { fcw_off.release(); fcw.release(); ol_out.release(); fin_off.release(); fc_out.release(); fc_out_off.release(); ch_off.release(); cl_off.release(); qm_off.release(); hdr.release(); bits.release(); rank.release(); rank4.release(); codes.release(); exc.release(); qmz.release(); qmz_pos.release(); qmz_cnt.release(); exact.release(); }
+		void release() { fcw_off.release(); fcw.release(); ol_out.release(); ol_wire.release(); fin_off.release(); fc_out.release(); fc_out_off.release(); ch_off.release(); cl_off.release(); qm_off.release(); hdr.release(); bits.release(); rank.release(); rank4.release(); codes.release(); exc.release(); qmz.release(); qmz_pos.release(); qmz_cnt.release(); exact.release(); }
 	} out[2];
 	int cur = 0;
 	OutSet &O() { return out[cur]; }
@@ -190,7 +190,7 @@ static int hao_deliver_enqueue(hao_ctx *c)
 	hao_ctx::Batch &B = *c->batch; const int s = B.cur; hao_ctx::Batch::OutSet &O = B.O(); const uint64_t n = B.n; const uint32_t parts = B.dl_parts;
 	auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
 	const bool ol = parts & HAO_DELIVER_OL, cl = parts & HAO_DELIVER_CL, ex = parts & HAO_DELIVER_EXACT;
-	size_t o_oloff = 0, o_ol = o_oloff + (ol ? al((n + 1) * 8) : 0), o_fcoff = o_ol + (ol ? al(B.n_ol * sizeof(hao_ovlp_t)) : 0), o_fc = o_fcoff + (ol ? al((B.n_ol + 1) * 8) : 0);
+	size_t o_oloff = 0, o_ol = o_oloff + (ol ? al((n + 1) * 8) : 0), o_fcoff = o_ol + (ol ? al(B.n_ol * sizeof(hao_ovlp_wire_t)) : 0), o_fc = o_fcoff + (ol ? al((B.n_ol + 1) * 8) : 0);
 	size_t o_choff = o_fc + (ol ? al(B.n_fcw * 4) : 0), o_cloff = o_choff + (cl ? al((n + 1) * 8) : 0), o_qmoff = o_cloff + (cl ? al((n + 1) * 8) : 0), o_hdr = o_qmoff + (cl ? al((n + 1) * 8) : 0);
 	const bool q16 = O.qmz16;      // the minimizer tables in 2 + 2 bytes per minimizer (hao_qtab16_kernel) instead of 8
 	size_t o_qmz = o_hdr + (cl ? al(B.n_chains * sizeof(hao_chain_hdr_t)) : 0), o_qmc = o_qmz + (cl ? al(B.n_mz * (q16 ? 2 : sizeof(hao_qmz_t))) : 0), o_bits = o_qmc + (cl && q16 ? al(B.n_mz * 2) : 0);
@@ -239,11 +239,11 @@ static int hao_deliver_enqueue(hao_ctx *c)
 	hao_delivery_t &d = B.dl[s];
 	d.rid_lo = B.lo; d.n_reads = n; d.n_ol = d.n_fc = d.n_chains = d.n_cl = d.n_exc = d.n_codes = d.n_pos = 0; d.bytes = 0;
 	if (ol && n) {
-		HIP_TRY(cp(o_oloff, O.fin_off.p, (n + 1) * 8)); HIP_TRY(cp(o_ol, O.ol_out.p, B.n_ol * sizeof(hao_ovlp_t)));
+		HIP_TRY(cp(o_oloff, O.fin_off.p, (n + 1) * 8)); HIP_TRY(cp(o_ol, O.ol_wire.p, B.n_ol * sizeof(hao_ovlp_wire_t)));
 		HIP_TRY(cp(o_fcoff, O.fcw_off.p, B.n_ol * 8)); HIP_TRY(cp(o_fc, O.fcw.p, B.n_fcw * 4));
 		((uint64_t*)(a + o_fcoff))[B.n_ol] = B.n_fcw;      // end of the last cigar (a host-side word next to, not inside, the region the copy writes)
-		d.n_ol = B.n_ol; d.n_fc = B.n_fcw; d.ol_off = (const uint64_t*)(a + o_oloff); d.ol = (const hao_ovlp_t*)(a + o_ol); d.fc_off = (const uint64_t*)(a + o_fcoff); d.fc = (const uint32_t*)(a + o_fc);
-		d.bytes += (n + 1) * 8 + B.n_ol * (sizeof(hao_ovlp_t) + 8) + B.n_fcw * 4;
+		d.n_ol = B.n_ol; d.n_fc = B.n_fcw; d.ol_off = (const uint64_t*)(a + o_oloff); d.ol = (const hao_ovlp_wire_t*)(a + o_ol); d.fc_off = (const uint64_t*)(a + o_fcoff); d.fc = (const uint32_t*)(a + o_fc);
+		d.bytes += (n + 1) * 8 + B.n_ol * (sizeof(hao_ovlp_wire_t) + 8) + B.n_fcw * 4;
 	}
 	if (cl && n) {
 		HIP_TRY(cp(o_choff, O.ch_off.p, (n + 1) * 8)); HIP_TRY(cp(o_cloff, O.cl_off.p, (n + 1) * 8)); HIP_TRY(cp(o_qmoff, O.qm_off.p, (n + 1) * 8));
@@ -605,10 +605,11 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	HIP_TRY(B.O().ol_out.reserve(NCmax + 1)); HIP_TRY(B.O().fc_out.reserve(FCmax + 1)); HIP_TRY(B.O().fc_out_off.reserve(NCmax + 2));
 	unsigned long long *d_n_fcw = B.stats.p + 3 * HAO_NCLS;      // (slot [3 NCLS] of the stats block is free) words of the fake cigars that travel raw
 	const bool fcw_ = (parts & HAO_DELIVER_OL) != 0;
-	if (fcw_) { HIP_TRY(B.O().fcw_off.reserve(NCmax + 2)); HIP_TRY(B.O().fcw.reserve(3 * (FCmax + 1))); }      // main region: entries - overlaps words; raw overlaps behind it: two words per entry
+	if (fcw_) { HIP_TRY(B.O().fcw_off.reserve(NCmax + 2)); HIP_TRY(B.O().fcw.reserve(3 * (FCmax + 1))); HIP_TRY(B.O().ol_wire.reserve(NCmax + 1)); }      // main region: entries - overlaps words; raw overlaps behind it: two words per entry
 	hipLaunchKernelGGL(chain_final_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, B.ol.p, B.ol_fc_off.p, B.fc_raw.p, B.perm.p, B.g_off.p, B.ch_base.p,
 					   B.O().fin_off.p, B.fcf_off.p, n, B.O().ol_out.p, B.O().fc_out.p, B.O().fc_out_off.p, fcw_ ? B.O().fcw.p : (uint32_t*)nullptr, fcw_ ? B.O().fcw_off.p : (uint64_t*)nullptr, d_n_fcw, (uint32_t)c->sw.fc_raw_every);
 	HAO_CHECK_LAUNCH();
+	if (fcw_) { hipLaunchKernelGGL(hao_ol_wire_kernel, dim3((unsigned)std::min<uint64_t>((NCmax + 255) / 256, 4096)), dim3(256), 0, c->stream, B.O().ol_out.p, B.O().fin_off.p + n, B.O().ol_wire.p); HAO_CHECK_LAUNCH(); }
 	if (pack_on_side) HIP_TRY(hipStreamWaitEvent(c->stream, B.ev_pk1, 0));      // the pack kernels have run under the selection
 	c->timer.mark("q_final");
 	unsigned long long slow_st[HAO_NCLS + 4], n_exc = 0;

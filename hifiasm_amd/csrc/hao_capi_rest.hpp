@@ -194,6 +194,21 @@ uint64_t hao_unpack_hits(const hao_delivery_t *d, uint64_t rid, hao_hit_t *out, 
 	return k;
 }
 
+// ol->list of a delivered read back into hao_ovlp_t records (the wire drops x_id, x_pos_strand and align_length: the read, 0 and 0 - hao_ol_wire_kernel)
+uint64_t hao_unpack_overlaps(const hao_delivery_t *d, uint64_t rid, hao_ovlp_t *out, uint64_t cap)
+{
+	if (!d || rid < d->rid_lo || rid >= d->rid_lo + d->n_reads || !d->ol_off || !d->ol) return 0;
+	const uint64_t r = rid - d->rid_lo, o0 = d->ol_off[r], n = d->ol_off[r + 1] - o0;
+	if (n > cap || !out) return n;
+	for (uint64_t i = 0; i < n; ++i) {
+		const hao_ovlp_wire_t &w = d->ol[o0 + i]; hao_ovlp_t &o = out[i];
+		o.x_id = (uint32_t)rid; o.x_pos_s = w.x_pos_s; o.x_pos_e = w.x_pos_e; o.x_pos_strand = 0;
+		o.y_id = w.y & 0x7fffffffu; o.y_pos_s = w.y_pos_s; o.y_pos_e = w.y_pos_e; o.y_pos_strand = w.y >> 31;
+		o.shared_seed = w.shared_seed; o.align_length = 0; o.non_homopolymer_errors = w.non_homopolymer_errors; o.fc_len = w.fc_len;
+	}
+	return n;
+}
+
 // the fake cigar of delivered overlap j back into 8-byte entries (hao_deliver.cuh: "fake cigars on the wire")
 uint32_t hao_unpack_cigar(const hao_delivery_t *d, uint64_t j, uint64_t *out, uint32_t cap)
 {
@@ -223,14 +238,16 @@ int hao_delivery_digest(const hao_delivery_t *d, uint64_t *out, int n_threads)
 	if ((uint64_t)n_threads > n) n_threads = (int)std::max<uint64_t>(1, n);
 	std::atomic<uint64_t> next(0); std::atomic<int> bad(0);
 	auto work = [&]() {
-		std::vector<hao_hit_t> buf; std::vector<uint64_t> fcb;
+		std::vector<hao_hit_t> buf; std::vector<uint64_t> fcb; std::vector<hao_ovlp_t> olb;
 		for (;;) {
 			const uint64_t b0 = next.fetch_add(64); if (b0 >= n) break;
 			for (uint64_t r = b0; r < std::min(n, b0 + 64); ++r) {
 				const uint64_t o0 = d->ol_off[r], o1 = d->ol_off[r + 1], nh = d->cl_off[r + 1] - d->cl_off[r];
 				if (buf.size() < nh) buf.resize(nh + nh / 4 + 64);
 				if (hao_unpack_hits(d, d->rid_lo + r, buf.data(), nh) != nh) { bad = 1; out[r] = 0; continue; }
-				uint64_t s = 0; const uint64_t *w = (const uint64_t*)(d->ol + o0);
+				if (olb.size() < o1 - o0) olb.resize(o1 - o0 + 64);
+				if (hao_unpack_overlaps(d, d->rid_lo + r, olb.data(), o1 - o0) != o1 - o0) { bad = 1; out[r] = 0; continue; }
+				uint64_t s = 0; const uint64_t *w = (const uint64_t*)olb.data();
 				for (uint64_t i = 0; i < (o1 - o0) * 6; ++i) s += hao_dg_term(1, i, w[i]);
 				{	uint64_t fi = 0;      // the fake cigars of the read's overlaps, entry by entry, through the decoder
 					for (uint64_t j = o0; j < o1; ++j) {

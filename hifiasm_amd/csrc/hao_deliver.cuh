@@ -190,6 +190,18 @@ __global__ __launch_bounds__(256) void hao_fill16_kernel(hao_fill_v4 *p, uint64_
 	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) p[i] = v;
 }
 
+// ol->list for the wire: 32 of the 48 bytes of every final overlap (hao_ovlp_wire_t; the receiver knows the read, x_pos_strand = 0 and align_length = 0)
+__global__ __launch_bounds__(256) void hao_ol_wire_kernel(const hao_ovlp_t *ol, const uint64_t *n_dev, hao_ovlp_wire_t *out)
+{
+	const uint64_t n = *n_dev;
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+		const hao_ovlp_t o = ol[i]; hao_ovlp_wire_t w;
+		w.y = o.y_id | o.y_pos_strand << 31; w.x_pos_s = o.x_pos_s; w.x_pos_e = o.x_pos_e; w.y_pos_s = o.y_pos_s; w.y_pos_e = o.y_pos_e;
+		w.shared_seed = o.shared_seed; w.non_homopolymer_errors = o.non_homopolymer_errors; w.fc_len = o.fc_len;
+		out[i] = w;
+	}
+}
+
 // the batch's minimizer table for the consumer: (self_offset, cnt) per query minimizer, interleaved
 __global__ void hao_qtab_kernel(const uint32_t *q_pos, const uint32_t *q_cnt, uint64_t n_mz, hao_qmz_t *out)
 {

@@ -181,13 +181,15 @@ int hao_attach(hao_ctx *owner, hao_ctx **view);
 #define HAO_DELIVER_OL 1u      /* ol->list + fake cigars */
 #define HAO_DELIVER_CL 2u      /* cl->list (wire format) */
 #define HAO_DELIVER_EXACT 4u   /* one byte per overlap: the exact-overlap check of the final round (hao_exact_check) */
+/* one overlap of ol->list on the wire, 32 bytes: hao_ovlp_t without what the receiver knows (x_id = the read, x_pos_strand = 0, align_length = 0; y = y_id | y_pos_strand << 31) - hao_unpack_overlaps */
+typedef struct { uint32_t y, x_pos_s, x_pos_e, y_pos_s, y_pos_e; int32_t shared_seed; uint32_t non_homopolymer_errors, fc_len; } hao_ovlp_wire_t;
 typedef struct { uint32_t n_hits, w0, q0, offset; uint64_t pos; } hao_chain_hdr_t;   /* one chain of cl->list: hit count, the readID word its hits share, first hit: minimizer index in the read, target offset, position; hit i of the chain has position pos + i */
 typedef struct { uint32_t self_offset, cnt; } hao_qmz_t;                  /* one query minimizer: k_mer_hit::self_offset and ::cnt of every hit it seeds */
 typedef struct { uint64_t index; uint32_t q, pad; hao_hit_t hit; } hao_exc_t;   /* verbatim hit: its position, its minimizer index, the hit (its readID word is the seed stage's: the decoder writes the chain's) */
 typedef struct {
 	uint64_t rid_lo, n_reads, n_ol, n_fc, n_chains, n_cl, n_exc, n_codes, n_pos, bytes;   /* n_pos = positions of the batch (its seed hits); bytes = what crossed PCIe for this batch */
 	const uint64_t *ol_off;          /* [n_reads + 1]: ol->list of read r = ol[ol_off[r] .. ol_off[r + 1]) */
-	const hao_ovlp_t *ol;
+	const hao_ovlp_wire_t *ol;       /* [n_ol]: read them with hao_unpack_overlaps */
 	const uint64_t *fc_off;          /* [n_ol + 1]: the fake cigar of overlap j starts at 32-bit word fc_off[j] & ~HAO_FC_RAW of fc[]; read it with hao_unpack_cigar */
 	const uint32_t *fc;              /* [n_fc] words: 4 bytes per cigar entry after an overlap's first (site step | zigzag(shift step) << 20); raw overlaps (bit 63 of their offset): 2 words per entry */
 	const uint64_t *ch_off, *cl_off, *qm_off; /* [n_reads + 1]: chains / hits / minimizers of read r = chains[ch_off[r] ..), hits cl_off[r] .. of the batch, qmz[qm_off[r] ..) */
@@ -206,6 +208,9 @@ typedef struct {
 /* The fake cigar (Fake_Cigar, Hash_Table.h:54-59; gen_fake_cigar, Hash_Table.cpp:88-109) of overlap j of a delivered batch as its ol[j].fc_len 8-byte entries
  * (site << 32 | shift code), rebuilt from the packed words: a pure function of the view.  Returns the entry count (nothing is written when it exceeds cap). */
 uint32_t hao_unpack_cigar(const hao_delivery_t *d, uint64_t j, uint64_t *out, uint32_t cap);
+/* ol->list of read rid (a read of the delivered batch) as hao_ovlp_t records in out[cap]: overlaps ol_off[r] .. ol_off[r + 1) of the batch; returns their number (nothing is
+ * written if cap is too small).  A pure function of the view. */
+uint64_t hao_unpack_overlaps(const hao_delivery_t *d, uint64_t rid, hao_ovlp_t *out, uint64_t cap);
 int hao_overlap_batch_async(hao_ctx *c, uint64_t rid_lo, uint64_t rid_hi, const hao_pass_t *pass /* NULL: hao_pass_default */, uint32_t parts, int *slot);
 /* The delivery slot (0 / 1) the NEXT hao_overlap_batch_async of this context will write: the caller must have stopped reading that arena before it
  * starts the batch (the engine alternates the two slots; asking it keeps that policy out of the caller). */

@@ -275,8 +275,12 @@ void h_ec_lchain(ha_abuf_t *ab, uint32_t rid, char* rs, uint64_t rl, uint64_t mz
 	// push_ovlp_chain_qgen sets them (Hash_Table.cpp:1752-1780); f_cigar through the slot's own buffer
 	const uint64_t r = rid - d.rid_lo;
 	clear_overlap_region_alloc(overlap_list);
+	static thread_local std::vector<hao_ovlp_t> olb;      // the wire's 32-byte records back into hao_ovlp_t
+	const uint64_t n_ol = d.ol_off[r + 1] - d.ol_off[r];
+	if (olb.size() < n_ol) olb.resize(n_ol + 64);
+	if (hao_unpack_overlaps(&d, rid, olb.data(), n_ol) != n_ol) die("hao_unpack_overlaps");
 	for (uint64_t i = d.ol_off[r]; i < d.ol_off[r + 1]; ++i) {
-		const hao_ovlp_t &o = d.ol[i]; overlap_region *z;
+		const hao_ovlp_t &o = olb[i - d.ol_off[r]]; overlap_region *z;
 		kv_pushp_ol(overlap_region, (*overlap_list), &z);
 		z->x_id = o.x_id; z->x_pos_s = o.x_pos_s; z->x_pos_e = o.x_pos_e; z->x_pos_strand = o.x_pos_strand;
 		z->y_id = o.y_id; z->y_pos_s = o.y_pos_s; z->y_pos_e = o.y_pos_e; z->y_pos_strand = o.y_pos_strand;

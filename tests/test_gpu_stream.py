@@ -109,9 +109,11 @@ def test_ol_only_delivery():
     e.ha_ft_gen(); e.ha_pt_gen()
     d = e.deliver_wait(e.overlap_batch_async(0, rs.n, parts=DELIVER_OL))
     assert d.n_cl == 0 and d.n_ol > 0 and d.bytes < 200 * d.n_ol
+    import ctypes as C
     from hifiasm_amd.api import _arr
     off = _arr(d.ol_off, rs.n + 1, np.uint64)
     for r in range(rs.n):
-        ol = _arr(d.ol + 48 * int(off[r]), 12 * int(off[r + 1] - off[r]), np.uint32).reshape(-1, 12)
+        m = int(off[r + 1] - off[r]); ol = np.zeros((m, 12), dtype=np.uint32)
+        assert e.L.hao_unpack_overlaps(C.byref(d), r, ol.ctypes.data_as(C.c_void_p), m) == m      # (32 bytes per overlap on the wire: hao_ovlp_wire_t)
         assert (ol == o.lchain(r)[0]).all(), r
     e.close()

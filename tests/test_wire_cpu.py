@@ -159,7 +159,7 @@ def test_cigar_decoder_inverts_the_format():
             es.append(entry(site, sh))
         if j % 11 == 5:
             es[0] = entry(xs + 1, 0)                                             # a first entry that is not (x_pos_s, 0): raw as well
-        row = np.zeros(12, dtype=np.uint32); row[1] = xs; row[11] = len(es)
+        row = np.zeros(8, dtype=np.uint32); row[1] = xs; row[7] = len(es)      # hao_ovlp_wire_t: x_pos_s, fc_len
         ol.append(row); cig.append(es)
         packable = es[0] == entry(xs, 0)
         ws = []
@@ -190,3 +190,33 @@ def test_cigar_decoder_inverts_the_format():
         assert [int(x) for x in out[:len(es)]] == es and out[len(es)] == 0
         assert L.hao_unpack_cigar(C.byref(d), j, out.ctypes.data_as(C.c_void_p), len(es) - 1) == len(es)      # too small a buffer: the count, nothing written
     assert L.hao_unpack_cigar(C.byref(d), len(cig), None, 0) == 0
+
+
+def test_overlaps_come_back_from_their_wire_records():
+    """hao_unpack_overlaps: the 32-byte wire record (y_id | strand << 31, four positions, shared_seed, first-hit index, fc_len) back into hao_ovlp_t with x_id = the read,
+    x_pos_strand = 0, align_length = 0; reads of the batch only; a buffer that is too small gets the count and nothing else"""
+    rng = np.random.default_rng(11)
+    n_reads, rid_lo = 6, 1000
+    cnt = [0, 3, 1, 0, 5, 2]
+    off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
+    w = np.zeros((int(off[-1]), 8), dtype=np.uint32)
+    w[:, 0] = rng.integers(0, 1 << 28, w.shape[0]) | (rng.integers(0, 2, w.shape[0]).astype(np.uint32) << 31)
+    w[:, 1:5] = rng.integers(0, 1 << 27, (w.shape[0], 4))
+    w[:, 5] = rng.integers(-5, 1 << 20, w.shape[0]).astype(np.int32).view(np.uint32)
+    w[:, 6:8] = rng.integers(0, 1 << 30, (w.shape[0], 2))
+    d = api.Delivery()
+    d.rid_lo, d.n_reads, d.n_ol = rid_lo, n_reads, int(off[-1])
+    d.ol_off, d.ol = off.ctypes.data, w.ctypes.data
+    L = api.lib()
+    for r in range(n_reads):
+        m = cnt[r]; out = np.full((m + 1, 12), 0xdeadbeef, dtype=np.uint32)
+        assert L.hao_unpack_overlaps(C.byref(d), rid_lo + r, out.ctypes.data_as(C.c_void_p), m) == m
+        ww = w[int(off[r]):int(off[r + 1])]
+        exp = np.zeros((m, 12), dtype=np.uint32)
+        exp[:, 0] = rid_lo + r; exp[:, 1] = ww[:, 1]; exp[:, 2] = ww[:, 2]; exp[:, 4] = ww[:, 0] & 0x7fffffff; exp[:, 5] = ww[:, 3]; exp[:, 6] = ww[:, 4]; exp[:, 7] = ww[:, 0] >> 31
+        exp[:, 8] = ww[:, 5]; exp[:, 10] = ww[:, 6]; exp[:, 11] = ww[:, 7]
+        assert (out[:m] == exp).all() and (out[m] == 0xdeadbeef).all(), r
+        if m:
+            out[:] = 7
+            assert L.hao_unpack_overlaps(C.byref(d), rid_lo + r, out.ctypes.data_as(C.c_void_p), m - 1) == m and (out == 7).all()
+    assert L.hao_unpack_overlaps(C.byref(d), rid_lo + n_reads, None, 0) == 0 and L.hao_unpack_overlaps(C.byref(d), rid_lo - 1, None, 0) == 0
