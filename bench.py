@@ -205,9 +205,10 @@ def run_workload(a, workload, steps, warmup, rank, local_rank, world, dist, torc
     # with delivery a pass needs at least two batches for the copy of one to run under the compute of the next: a pass that fits one batch is cut in two
     # (more pieces hide more of the copy but pay the tails of the per-batch kernels once per piece: four pieces measured slower on every small workload)
     dranges = ranges if len(ranges) >= 2 else [(n_reads * i // 2, n_reads * (i + 1) // 2) for i in range(2) if n_reads * (i + 1) // 2 > n_reads * i // 2]
-    # the copy of a pass's LAST batch has no kernels to run under (~1 GB = 19 ms at 55 GB/s on configs[2]): the last range is cut into 1/2 + 1/4 + 1/4, so only a
-    # quarter batch's copy is exposed at the end of the pass (two more batches cost ~1 ms each of per-batch tails)
-    if len(dranges) >= 4 and not a.no_tail_split:
+    # (the copy of a pass's LAST batch has no kernels to run under: ~0.87 GB = 15 ms on configs[2].  Rounds 4 - 5 cut the last range into 1/2 + 1/4 + 1/4; since round 6
+    # the wire format is small enough - 5.2 GB per pass - for every batch's copy to end before the next batch does, and the two extra batches cost more than the shorter
+    # tail gains: 183.7 ms with the cut, 180.7 without.  --tail-split keeps the A/B.)
+    if len(dranges) >= 4 and a.tail_split:
         lo_, hi_ = dranges[-1]; m1, m2 = lo_ + (hi_ - lo_) // 2, lo_ + 3 * (hi_ - lo_) // 4
         if lo_ < m1 < m2 < hi_:
             dranges = dranges[:-1] + [(lo_, m1), (m1, m2), (m2, hi_)]
@@ -434,7 +435,7 @@ def main():
     ap.add_argument("--no-rank-proxy", action="store_true", help="skip variants.rank_proxy_configs3 (1 M reads at 40x over an index padded to configs[3]'s size: a minute of generation and ha_ft_gen)")
     ap.add_argument("--no-variants", action="store_true", help="skip the repeat-rich twin of the workload (the `variants` block of the line)")
     ap.add_argument("--variant-steps", type=int, default=5, help="timed steps of the variant (at most --steps)")
-    ap.add_argument("--no-tail-split", action="store_true", help="delivered pass: do not cut the last batch into 1/2 + 1/4 + 1/4 (A/B)")
+    ap.add_argument("--tail-split", action="store_true", help="delivered pass: cut the last batch into 1/2 + 1/4 + 1/4 (A/B: the default of rounds 4 - 5)")
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed pass that digests the delivered bytes and compares them with the reference's digests")
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
