@@ -329,7 +329,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	const uint64_t sum_q = c->h_ix_mz_off[hi] - c->h_ix_mz_off[lo];      // minimizers of the batch's reads
 	int tb = 1; while ((1ULL << tb) < c->n_total) ++tb;
 	HIP_TRY(B.g_cnt.reserve(n + 2)); HIP_TRY(B.g_off.reserve(n + 2)); HIP_TRY(B.g_tmp.reserve(A + 1));
-	HIP_TRY(B.stats.reserve(3 * HAO_NCLS + 6)); HIP_TRY(hipMemsetAsync(B.stats.p, 0, (3 * HAO_NCLS + 6) * 8, c->stream));
+	HIP_TRY(B.stats.reserve(3 * HAO_NCLS + 7)); HIP_TRY(hipMemsetAsync(B.stats.p, 0, (3 * HAO_NCLS + 7) * 8, c->stream));
 	unsigned long long *d_slow_cnt = B.stats.p, *d_cls_cnt = B.stats.p + HAO_NCLS + 4;   // [0..NCLS] slow groups per class + their hits
 	{
 		// Q2-Q5 in one kernel: index records -> bins -> sorted k_mer_hits + group lists (no anchor keys in memory)
@@ -385,7 +385,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 				const bool b16_ = c->max_len_all < 65536, wide_ = max_q > 2 * HAO_L5_THREADS;      // offsets of the staged records in 16 bits; reads with more than 1024 minimizers: three per thread
 				auto go_ = [&](auto k0, size_t lds_) -> int {
 					HIP_TRY(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
-					hipLaunchKernelGGL(k0, dim3(g_), dim3(HAO_L5_THREADS), lds_, c->stream, sa_, sinfo_, len_, spk_, (uint32_t)c->sw.seed_merge_maxn, 176u /* wave 0's share in 1/1024: profiles/r06/seed_ab.txt */, ovf0, d_ovf0);
+					hipLaunchKernelGGL(k0, dim3(g_), dim3(HAO_L5_THREADS), lds_, c->stream, sa_, sinfo_, len_, spk_, (uint32_t)c->sw.seed_merge_maxn, 176u /* wave 0's share in 1/1024: profiles/r06/seed_ab.txt */, ovf0, d_ovf0, B.stats.p + 3 * HAO_NCLS + 6 /* the kernel's read cursor: zero */);
 					return HAO_OK;
 				};
 				int rc_;

@@ -239,7 +239,7 @@ __device__ __forceinline__ uint32_t hao_l5_merge(const hao_l5_ptr<B16, QPT> &L, 
 
 template<bool B16, int QPT, int NPF, bool DBG>
 __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_args S, const uint64_t *__restrict__ sinfo, const uint32_t *__restrict__ len, const uint64_t *__restrict__ s_pk,
-		uint32_t max_n, uint32_t w0_share, uint32_t *ovf_list, unsigned long long *ovf_cnt)
+		uint32_t max_n, uint32_t w0_share, uint32_t *ovf_list, unsigned long long *ovf_cnt, unsigned long long *next_read)
 {
 	constexpr uint32_t CAP = hao_l5_lds<B16, QPT>::CAP;
 	extern __shared__ uint64_t l5_smem[];
@@ -251,7 +251,11 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 	if (b0 == 0 && tid == 0) S.g_cnt[S.n_sel] = 0;
 	if (b0 >= S.n_sel) return;
 	if (tid < 2 * HAO_L5_HB) L.hist[tid] = 0;
-	const uint64_t nrd = (S.n_sel - b0 + G - 1) / G;      // this workgroup's reads: b0, b0 + G, ...
+	// this workgroup's reads: b0, then whatever the batch's cursor hands out (*next_read, zero at launch: read G + its value).  A fixed share - b0, b0 + G, ... - cost 1 - 2 % of the
+	// stage (same box, three runs each: 43.3 against 44.0 ms per pass; 325 reads per workgroup whose hit counts vary by a quarter).  The cursor is asked one step ahead by thread 0 and its
+	// answer travels through LDS with the step's last barrier.
+	const uint32_t NONE = 0xffffffffu, n_sel32 = (uint32_t)S.n_sel;
+	uint32_t r_a = NONE, r_b = NONE, r_d = NONE, r_e = NONE; uint64_t nrd = 0;
 	// pipeline registers
 	uint64_t av = 0;                                                        // alpha: lanes 0 - 3 of every wave hold mz_off[r], mz_off[r + 1], seg[r], seg[r + 1]
 	uint64_t raw_s[QPT]; uint32_t raw_p[QPT], raw_c[QPT];      // beta: start | n << 48 | strand << 63, query position, cnt word of the thread's minimizers
@@ -268,10 +272,17 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 	// DBG instances: wall-clock ticks (100 MHz) of wave 0 per phase, summed over the workgroups into S.dbg[0 .. 9] (HAO_DBG_SEEDPHASE)
 	unsigned long long tk_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk_last = DBG ? wall_clock64() : 0;
 #define HAO_L5_TICK(k) if constexpr (DBG) { const unsigned long long now_ = wall_clock64(); tk_acc[k] += now_ - tk_last; tk_last = now_; }
-	for (uint64_t step = 0; step < nrd + 3; ++step) {
-		// reads of this step: e = step - 3 is staged and merged, d = step - 2 prepared and its records requested, b = step - 1: its minimizer words requested, a = step: its offsets
+	for (uint64_t step = 0; ; ++step) {
+		// reads of this step: e (taken three steps ago) is staged and merged, d prepared and its records requested, b: its minimizer words requested, a (new): its offsets
+		r_e = r_d; r_d = r_b; r_b = r_a;
+		r_a = step == 0 ? (uint32_t)b0 : (r_b < n_sel32 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)L.sm[12]) : NONE);      // (once the cursor has run past the batch it is not asked again)
+		if (r_a >= n_sel32) r_a = NONE;
+		if ((r_a & r_b & r_d & r_e) == NONE) break;
+		unsigned long long nx_ = 0;
+		if (tid == 0 && r_a != NONE) nx_ = atomicAdd(next_read, 1ULL);      // the read after r_a; lands in LDS at the end of the step
+		if (r_a != NONE) ++nrd;
 		re = rd; rd = rb;
-		rb.valid = step >= 1 && step - 1 < nrd; rb.skip = true;
+		rb.valid = r_b != NONE; rb.skip = true;
 		if (rb.valid) {
 			const uint64_t m0 = hao_readlane_u64(av, 0), m1 = hao_readlane_u64(av, 1), s0 = hao_readlane_u64(av, 2), s1 = hao_readlane_u64(av, 3);
 			rb.m0 = m0; rb.nq = (uint32_t)(m1 - m0); rb.s = s0; rb.n = (uint32_t)(s1 - s0);
@@ -377,14 +388,14 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 				if (q < nqb) { raw_s[m] = s_pk[li0 + q]; raw_p[m] = S.q_pos[li0 + q]; raw_c[m] = S.q_cnt[li0 + q]; }
 			}
 		}
-		if (step < nrd) {
-			const uint64_t r = b0 + step * G;
+		if (r_a != NONE) {
+			const uint64_t r = r_a;
 			if (lane < 4) av = lane < 2 ? S.mz_off[S.rid_lo + r + lane] : S.seg[r + lane - 2];
 		}
 		HAO_L5_TICK(4)
 		// ---- merge read e ----
 		if (re.valid) {
-			const uint64_t r = b0 + (step - 3) * G;
+			const uint64_t r = r_e;
 			uint32_t ngr = 0; bool gover = false;
 			if (!re.skip) {
 				// seven splitters from the target histogram: wave w starts at the first bin whose exclusive prefix sum reaches w / 8 of the read's hits
@@ -431,6 +442,7 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 			}
 		}
 		HAO_L5_TICK(7)
+		if (tid == 0 && r_a != NONE) L.sm[12] = G + nx_ < (unsigned long long)NONE ? (uint32_t)(G + nx_) : NONE;
 		__syncthreads();
 		HAO_L5_TICK(8)
 	}

@@ -48,7 +48,7 @@ extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t 
 	size_t lds1 = (size_t)22 * 512 + lds_tile + lds_q, lds2 = (size_t)22 * 1024 + std::max<size_t>(lds_tile, 12 * 1024) + lds_q, lds3 = (size_t)22 * 2048 + std::max<size_t>(lds_tile, 12 * 2048) + lds_q;
 	if (mode == 0 || mode >= 12) { lds2 = hao_seed3_lds<10>::FIXED + lds_q; lds3 = hao_seed3_lds<11>::FIXED + lds_q; }
 	const uint32_t *nil32 = nullptr; const unsigned long long *nil64 = nullptr;
-	std::vector<uint32_t> ovf0(n + 4, 0); unsigned long long ovf0_cnt = 0;
+	std::vector<uint32_t> ovf0(n + 4, 0); unsigned long long ovf0_cnt = 0, next_read = 0;      // (next_read: the kernel's read cursor, zero at launch)
 	const uint32_t max_n = getenv("SIMT_SEED_MAXN") ? (uint32_t)atoi(getenv("SIMT_SEED_MAXN")) : 0xffffffffu;      // reads with more seed hits go to the table kernels
 	if (mode == 12 || mode == 13) {      // the list-major kernel (hao_query5.cuh): persistent workgroups of 512 work-items, every read of the set; SIMT_SEED_GRID workgroups (default 3: every workgroup
 		// runs several reads through its pipeline); mode 12: 16-bit offsets when every read is shorter than 64 kb (what the library does), mode 13: 32-bit offsets
@@ -56,10 +56,10 @@ extern "C" int simt_seed_run(uint64_t n, const uint64_t *mz_off, const uint64_t 
 		const unsigned grid = (unsigned)std::min<uint64_t>(n, getenv("SIMT_SEED_GRID") ? (uint64_t)atoi(getenv("SIMT_SEED_GRID")) : 3);
 		const bool wide = max_q > 2 * HAO_L5_THREADS || getenv("SIMT_SEED_WIDE");      // (three minimizers per thread and fewer record registers: what the library launches for batches with long reads)
 		std::function<void()> call;
-		if (b16 && wide) call = [&] { seed_lds_kernel<true, 3, 8, false>(sa, sinfo, len, S.s_pk.data(), max_n, 176u, ovf0.data(), &ovf0_cnt); };
-		else if (b16) call = [&] { seed_lds_kernel<true, 2, 16, false>(sa, sinfo, len, S.s_pk.data(), max_n, 176u, ovf0.data(), &ovf0_cnt); };
-		else if (wide) call = [&] { seed_lds_kernel<false, 3, 8, false>(sa, sinfo, len, S.s_pk.data(), max_n, 176u, ovf0.data(), &ovf0_cnt); };
-		else call = [&] { seed_lds_kernel<false, 2, 16, false>(sa, sinfo, len, S.s_pk.data(), max_n, 176u, ovf0.data(), &ovf0_cnt); };
+		if (b16 && wide) call = [&] { seed_lds_kernel<true, 3, 8, false>(sa, sinfo, len, S.s_pk.data(), max_n, 176u, ovf0.data(), &ovf0_cnt, &next_read); };
+		else if (b16) call = [&] { seed_lds_kernel<true, 2, 16, false>(sa, sinfo, len, S.s_pk.data(), max_n, 176u, ovf0.data(), &ovf0_cnt, &next_read); };
+		else if (wide) call = [&] { seed_lds_kernel<false, 3, 8, false>(sa, sinfo, len, S.s_pk.data(), max_n, 176u, ovf0.data(), &ovf0_cnt, &next_read); };
+		else call = [&] { seed_lds_kernel<false, 2, 16, false>(sa, sinfo, len, S.s_pk.data(), max_n, 176u, ovf0.data(), &ovf0_cnt, &next_read); };
 		if (launch(grid, HAO_L5_THREADS, b16 ? hao_l5_lds<true, 2>::TOTAL : hao_l5_lds<false, 2>::TOTAL, call)) return fail(err, errcap, hao_simt::g.error);
 		stats[6] = ovf0_cnt;
 		if (ovf0_cnt) {
