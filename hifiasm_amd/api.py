@@ -406,7 +406,7 @@ class Engine:
         """which kernels carried the last batch's seed stage: (first launch: 2 list-major / 1 one-wave merge / 0 table kernels, reads left to the tables, 512- / 1024-slot overflows)"""
         out = (C.c_uint64 * 4)()
         self._ck(self.L.hao_batch_seed_path(self.h, out), "hao_batch_seed_path")
-        return dict(first_launch={0: "seed_bin_kernel", 1: "seed_merge_kernel", 2: "seed_lds_kernel"}[int(out[0])], left_to_tables=int(out[1]), overflow_512=int(out[2]), overflow_1024=int(out[3]))
+        return dict(first_launch={0: "seed_bin_kernel", 1: "(unused)", 2: "seed_lds_kernel"}[int(out[0])], left_to_tables=int(out[1]), overflow_512=int(out[2]), overflow_1024=int(out[3]))
 
     def batch_digest(self, n, with_seed_hits=True):
         """per-read digests of the last batch (n reads): (digest of ol / fake cigars / cl, digest of the seed hits or None)"""

@@ -147,7 +147,7 @@ int hao_deliver_wait(hao_ctx *c, int slot, hao_delivery_t *out)
 	HIP_TRY(hipSetDevice(c->device));
 	hao_ctx::Batch &B = *c->batch;
 	if (B.dl_pending[slot]) { HIP_TRY(hipEventSynchronize(B.ev_done[slot])); B.dl_pending[slot] = false; float ms = 0; if (hipEventElapsedTime(&ms, B.ev_ready[slot], B.ev_done[slot]) == hipSuccess) B.dl[slot].copy_ms = ms; }
-	if (B.dl[slot].n_ol && B.dl[slot].fc_off) ((uint64_t*)B.dl[slot].fc_off)[B.dl[slot].n_ol] = B.dl[slot].n_fc;      // end of the last cigar: set once the copy has landed (HAO_COPY_KERNEL rounds its sections up to 16 bytes and would overwrite an earlier store)
+	if (B.dl[slot].n_ol && B.dl[slot].fc_off) ((uint64_t*)B.dl[slot].fc_off)[B.dl[slot].n_ol] = B.dl[slot].n_fc;      // end of the last cigar: a host-side word next to the region the copy wrote, set once the copy has landed
 	*out = B.dl[slot];
 	return HAO_OK;
 }

@@ -154,7 +154,7 @@ struct hao_chain_args {
 	unsigned long long *stats;                   // [0 .. HAO_NCLS) groups of each size class needing the DP kernel, [HAO_NCLS] their hits
 	int32_t *tm;                                 // per-hit mark scratch for oversize groups
 	int dbg_seq, dbg_stats;          // dbg_seq: 1 one-lane sequential chaining, 3 one-lane DP tail, 4 no speculative tiles (all give identical results)
-	unsigned long long *dbg_qc;   // optional phase timers of chain_group_kernel (HAO_DBG_QCPHASE)
+	unsigned long long *dbg_qc;   // optional phase timers of chain_group_kernel (HAO_DBG_PRINT=qc)
 	uint32_t exc_every;      // (tests) every n-th hit of a group gets the code 0xff: exercises the verbatim list
 	const uint16_t *hq; uint8_t *hcode;      // delivery path: query minimizer index of every seed hit (seed kernel) -> wire code byte of every seed hit relative to its
 	                                         // predecessor in the sorted order (hao_deliver.cuh): the quick check has both hits in registers anyway
@@ -341,7 +341,7 @@ __device__ void hao_chain_generic_core(const hao_chain_args &A, const uint64_t g
 	hao_chain_tail(A, g, a, a_n, P, f, p, t, ii, msc, msc_i, plus);
 }
 
-// the same through the group arrays and the global per-hit scratch (debug path HAO_DBG_SEQ_CHAIN)
+// the same through the group arrays and the global per-hit scratch (HAO_DBG_FORCE=seq_chain)
 __device__ void hao_chain_generic(const hao_chain_args &A, const uint64_t g)
 {
 	const uint32_t r = A.g_read[g]; const uint64_t gs = A.g_start[g], ge = (g + 1 < A.g_off[r + 1]) ? A.g_start[g + 1] : A.seg[r + 1];
@@ -359,7 +359,7 @@ template<class T> struct hao_lane_arr { T *p; __device__ __forceinline__ T &oper
 // every such access was a dependent global load of the same 16 - 128 bytes - ~10 memory round trips per group, the whole cost of the kernel on the repeat-rich
 // sets (28 M groups of one or two hits per batch: 8.1 ms).
 struct hao_lane_hits { const hao_hit_t *p; __device__ __forceinline__ hao_hit_t operator[](int64_t i) const { return p[i * 64]; } };
-// slow == nullptr: every group of the list (A/B, HAO_DBG_SEQ_CHAIN); else the groups slow[0 .. *slow_cnt) that chain_pack8_kernel's quick check did not settle
+// slow == nullptr: every group of the list (HAO_DBG_FORCE=seq_chain); else the groups slow[0 .. *slow_cnt) that chain_pack8_kernel's quick check did not settle
 __global__ __launch_bounds__(64) void chain_tiny_kernel(hao_chain_args A, const hao_gent *list, uint64_t n_list, const uint32_t *slow, const unsigned long long *slow_cnt)
 {
 	__shared__ int32_t l_f[HAO_TINY_MAX * 64], l_ii[HAO_TINY_MAX * 64], l_p[HAO_TINY_MAX * 64]; __shared__ int64_t l_t[HAO_TINY_MAX * 64]; __shared__ hao_hit_t l_a[HAO_TINY_MAX * 64];
@@ -1348,8 +1348,8 @@ struct hao_sel_args {
 	uint64_t *key_xs; int32_t *key_sc; uint32_t *key_al, *key_tmp;   // global key scratch (reads with more chains than the LDS slice holds); key_tmp: 5 words per chain
 	uint32_t *perm; uint32_t *n_final; uint64_t *fc_final;        // outputs: permutation (per read slice), kept count, kept fake-cigar entries
 	uint64_t max_n_chain, ocv_w; uint32_t chain_cutoff;
-	int dbg_seq_prune;            // HAO_DBG_SEQ_PRUNE: one-lane pruning scan (A/B)
-	unsigned long long *dbg;      // optional phase timers (HAO_DBG_SELPHASE): wall-clock ticks summed over reads: score sort, prune, position sort, weak filter, reads
+	int dbg_seq_prune;            // HAO_DBG_FORCE=seq_prune: the one-lane pruning scan
+	unsigned long long *dbg;      // optional phase timers (HAO_DBG_PRINT=sel): wall-clock ticks summed over reads: score sort, prune, position sort, weak filter, reads
 };
 
 // the sequential part (lane 0). returns the kept count

@@ -83,7 +83,7 @@ __device__ __forceinline__ uint32_t hao_seed_locate(const uint32_t *ao, uint32_t
 #define HAO_OVF() __hip_atomic_load(&s_ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define HAO_OVF_SET() __hip_atomic_store(&s_ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 
-// ---- pieces the seed kernels share (seed_bin_kernel here, seed_bin2_kernel / seed_bin3_kernel in hao_query2.cuh / hao_query3.cuh); all 256 threads call them ----
+// ---- pieces the seed kernels share (seed_bin_kernel here, seed_bin3_kernel in hao_query3.cuh); all 256 threads call them ----
 // QL staging: the read's minimizers that have anchors, in order (stable compaction): l_ao[k] = first anchor of the k-th of them (relative to the read), l_ss[k] = its list
 // start | its index in the read's full minimizer list << 48 | its strand << 63; l_ao[nk] = n.  Returns nk.  (The caller synchronises before it reads the tables.)
 __device__ __forceinline__ uint32_t hao_seed_stage_nonempty(uint32_t *l_ao, uint64_t *l_ss, uint32_t *s_wt /* [4] */, const uint64_t *g_ao, const uint64_t *g_ss, const uint64_t *g_info,
@@ -134,7 +134,7 @@ struct hao_seed_args {
 	const uint64_t *mz_off, *mz_info; uint64_t rid_lo, mz0;
 	const uint64_t *s_start; const uint32_t *s_n; const uint64_t *a_off, *seg, *sinfo; const uint32_t *len, *q_pos, *q_cnt;
 	hao_hit_t *hits; uint64_t *g_tmp, *g_cnt; uint64_t n_sel; uint32_t qcap; int tb;
-	unsigned long long *dbg;      // optional: per-phase wall-clock ticks summed over workgroups (HAO_DBG_SEEDPHASE)
+	unsigned long long *dbg;      // optional: per-phase wall-clock ticks summed over workgroups (HAO_DBG_PRINT=seed)
 	uint16_t *hq;      // optional (delivery path): index of the query minimizer of every hit (saturating at 65535), next to hits[]: the wire packer's codes need it (hao_deliver.cuh)
 };
 

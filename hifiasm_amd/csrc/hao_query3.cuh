@@ -7,7 +7,7 @@
 //   * so: pass A counts the hits of every bin PER WAVE (a wave owns a contiguous quarter of the read's anchors), the sort + scan give the bin starts, wave w
 //     starts a bin at the bin's start + the counts of the waves before it, and pass B is wave-private and barrier-free: NU x 64 index records in flight per wave,
 //     hits ranked inside their 64-anchor window by ballot match groups, the bin's running position in an LDS word per (wave, slot), every hit stored where it
-//     belongs.  (The same re-cut WITH per-wave staging lost on the 512-slot launch - hao_query2.cuh - where tiles do hold several hits per bin.)
+//     belongs.  (The same re-cut WITH per-wave staging lost on the 512-slot launch - round 4's hao_query2.cuh, removed in round 6 - where tiles do hold several hits per bin.)
 // QL only: every read's minimizer table fits the LDS (the host launches seed_bin_kernel<.., false> otherwise).
 #pragma once
 #include "hao_query.cuh"

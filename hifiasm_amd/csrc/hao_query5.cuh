@@ -269,7 +269,7 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 #pragma unroll
 	for (int i = 0; i < NPF; ++i) rec[i].a = rec[i].b = 0;
 
-	// DBG instances: wall-clock ticks (100 MHz) of wave 0 per phase, summed over the workgroups into S.dbg[0 .. 9] (HAO_DBG_SEEDPHASE)
+	// DBG instances: wall-clock ticks (100 MHz) of wave 0 per phase, summed over the workgroups into S.dbg[0 .. 9] (HAO_DBG_PRINT=seed)
 	unsigned long long tk_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk_last = DBG ? wall_clock64() : 0;
 #define HAO_L5_TICK(k) if constexpr (DBG) { const unsigned long long now_ = wall_clock64(); tk_acc[k] += now_ - tk_last; tk_last = now_; }
 	for (uint64_t step = 0; ; ++step) {

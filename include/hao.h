@@ -152,7 +152,7 @@ int hao_fetch_overlaps(hao_ctx *c, uint64_t rid, const hao_ovlp_t **ol, uint64_t
  * out[3] = chain groups, out[4] = minimizers of the query reads */
 int hao_batch_totals(hao_ctx *c, uint64_t out[8]);
 /* which kernels carried the seed stage (minimizers_qgen0, anchor.cpp:987-1081) of the last batch - a measurement aid, the results do not depend on it:
- * out[0] = first launch: 2 the list-major kernel (hao_query5.cuh), 1 the one-wave merge kernel (hao_query4.cuh), 0 the table kernels for every read;
+ * out[0] = first launch: 2 the list-major kernel (hao_query5.cuh), 1 unused (round 5's one-wave merge kernel), 0 the table kernels for every read;
  * out[1] = reads that launch left to the table kernels, out[2] / out[3] = reads whose bins overflowed the 512- / the 1024-slot table */
 int hao_batch_seed_path(hao_ctx *c, uint64_t out[4]);
 

@@ -1,7 +1,7 @@
 // What does the memory system give the SEED STAGE's access pattern when no computation is attached to it?  (measurement aid, not part of the product)
 // The stage reads ~36 M position lists of ~28 eight-byte records each, scattered over a 2.3 GB index, and writes one 16-byte k_mer_hit per record to a sequential
 // 16 GB array (configs[2]: 993 M records per launch).  This program does exactly that and nothing else, in the two read shapes the engine's kernels use:
-//   rows  : a lane walks ITS OWN list with 32-byte reads (four records), 8 lists per lane, lists of a wave interleaved step by step (seed_merge_kernel<8, 4>: every read
+//   rows  : a lane walks ITS OWN list with 32-byte reads (four records), 8 lists per lane, lists of a wave interleaved step by step (round 5's seed_merge_kernel<8, 4>: every read
 //           moves a line nobody else in the wave wants);
 //   lists : adjacent lanes read adjacent records of one list after the other, each record read once (one pass of the table kernels' walk; they walk twice);
 // and, as the yardstick, `copy`: the same bytes (8 in, 16 out per record) streamed from and to sequential addresses.  Output positions are sequential per wave in all
