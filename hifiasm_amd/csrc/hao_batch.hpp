@@ -128,6 +128,19 @@ static unsigned char *hao_arena_alloc_bound(size_t bytes, int node)
 	if (hipHostRegister(m, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); (void)munmap(m, bytes); return nullptr; }
 	return (unsigned char*)m;
 }
+// GB/s of one device-to-host copy of nb bytes into `host` on the batch's copy stream (HIP events around it); -1 when it cannot be measured
+static double hao_arena_rate(hipStream_t st, unsigned char *host, const void *dsrc, size_t nb)
+{
+	hipEvent_t e0 = nullptr, e1 = nullptr; double r = -1;
+	if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess &&
+		hipEventRecord(e0, st) == hipSuccess && hipMemcpyAsync(host, dsrc, nb, hipMemcpyDeviceToHost, st) == hipSuccess && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess) {
+		float ms = 0; if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0) r = (double)nb / ((double)ms * 1e6);
+	}
+	if (e0) (void)hipEventDestroy(e0);
+	if (e1) (void)hipEventDestroy(e1);
+	(void)hipGetLastError();
+	return r;
+}
 static inline double hao_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static int hao_scan_u32(hao_ctx *c, const uint32_t *in, uint64_t *out, uint64_t n_plus1)
@@ -226,6 +239,30 @@ static int hao_deliver_enqueue(hao_ctx *c)
 			on_ = hao_pages_on_node(B.arena[s], want, node_);
 			if ((on_ >= 0 && on_ < 28) || c->sw.arena_numa == 4) {      // (HAO_ARENA_NUMA=4: always by hand - tests)
 				if (unsigned char *m_ = hao_arena_alloc_bound(want, node_)) { (void)hipHostFree(B.arena[s]); B.arena[s] = m_; B.arena_reg[s] = true; how_ = "mmap + mbind + hipHostRegister"; on_ = hao_pages_on_node(m_, want, node_); }
+			}
+		}
+		// What the placement is worth is MEASURED: one run in eight of round 6 still delivered at 28.7 instead of 50 GB/s (same box, next process: 49.8) with every page
+		// reported on the GPU's node.  A 128 MB copy into the new arena is timed; below 40 GB/s a 128 MB buffer bound to each NUMA node in turn gets the same copy and the
+		// arena moves to the best node when that is 10 % faster.  (Arenas of 64 MB and more; HAO_DBG_TEST=arena_probe=1: always and whatever the size - tests.)
+		if (he_ == hipSuccess && c->sw.arena_numa && (want >= ((size_t)64 << 20) || c->sw.arena_probe) && B.hits.p) {
+			const size_t nb = std::min<size_t>(std::min<size_t>(want, (size_t)128 << 20), B.hits.cap * sizeof(hao_hit_t)) & ~(size_t)4095;
+			if (nb >= 4096) {
+				(void)hao_arena_rate(B.copy_stream, B.arena[s], B.hits.p, nb);      // (first touch of the mapping)
+				const double r0 = hao_arena_rate(B.copy_stream, B.arena[s], B.hits.p, nb);
+				if ((r0 >= 0 && r0 < 40.0) || c->sw.arena_probe) {
+					int best_k = -1; double best = r0;
+					for (int k = 0; k < 16; ++k) {
+						unsigned char *m_ = hao_arena_alloc_bound(nb, k); if (!m_) continue;
+						(void)hao_arena_rate(B.copy_stream, m_, B.hits.p, nb);
+						const double rk = hao_arena_rate(B.copy_stream, m_, B.hits.p, nb);
+						(void)hipHostUnregister(m_); (void)munmap(m_, nb);
+						if (c->sw.dltime || c->sw.arena_probe) fprintf(stderr, "[deliver] arena %d probe: NUMA node %d %.1f GB/s\n", s, k, rk);
+						if (rk > best * 1.1) { best = rk; best_k = k; }
+					}
+					if (best_k >= 0) if (unsigned char *m_ = hao_arena_alloc_bound(want, best_k)) { B.arena_cap[s] = want; B.arena_free(s); B.arena[s] = m_; B.arena_reg[s] = true; how_ = "moved after the probe"; }      // (arena_free unmaps arena_cap bytes of a registered arena)
+					fprintf(stderr, "[hao] delivery arena %d: %.1f GB/s from the device as allocated (GPU NUMA node %d, %s)%s\n", s, r0, node_, how_, best_k >= 0 ? "" : "; no NUMA node does better");
+					if (best_k >= 0) fprintf(stderr, "[hao] delivery arena %d: moved to NUMA node %d (%.1f GB/s)\n", s, best_k, best);
+				}
 			}
 		}
 		if (c->sw.dltime) fprintf(stderr, "[deliver] arena %d: %zu MB, GPU NUMA node %d (requested mode %d, allocated %s, %d of 32 sampled pages on the node)\n", s, want >> 20, node_, c->sw.arena_numa, he_ == hipSuccess ? how_ : "FAILED", on_);

@@ -65,11 +65,11 @@ struct StageTimer {
 //   HAO_ARENA_NUMA                                          placement of the pinned delivery arenas
 //   HAO_DBG_PRINT=seed,qc,dp,sel,dl,bloom,sync              timers / counters on stderr (sync: wait after every stage and say its name - localises a device fault)
 //   HAO_DBG_FORCE=seq_chain,dp_seqtail,dp_nospec,dp_serial,seq_prune,noql      send every read / group down one of the engine's FALLBACK paths (tests: each has to give the default path's bytes)
-//   HAO_DBG_TEST=ix_pad=N,sort40_min=N,sk_gcap=N,exc_cap=N,fc_raw_every=N,exc_every=N,qmz_raw=1,ft_chunk_slots=N      capacities and thresholds shrunk so that small inputs reach the overflow / big-index code
+//   HAO_DBG_TEST=ix_pad=N,sort40_min=N,sk_gcap=N,exc_cap=N,fc_raw_every=N,exc_every=N,qmz_raw=1,arena_probe=1,ft_chunk_slots=N      capacities and thresholds shrunk so that small inputs reach the overflow / big-index code
 struct hao_switches {
 	bool seedphase = false, qcphase = false, dp_stats = false, selphase = false, dltime = false, bloom = false;                 // HAO_DBG_PRINT
 	bool seq_chain = false, dp_seqtail = false, dp_nospec = false, dp_serial = false, seq_prune = false, seed_noql = false;     // HAO_DBG_FORCE
-	long long sk_gcap = -1, exc_cap = -1, ft_chunk_slots = 0; unsigned long long ix_pad = 0, sort40_min = 1ULL << 23; int fc_raw_every = 0, exc_every = 0; bool qmz_raw = false;      // HAO_DBG_TEST
+	long long sk_gcap = -1, exc_cap = -1, ft_chunk_slots = 0; unsigned long long ix_pad = 0, sort40_min = 1ULL << 23; int fc_raw_every = 0, exc_every = 0; bool qmz_raw = false, arena_probe = false;      // HAO_DBG_TEST
 	int arena_numa = 3, seed_merge_maxn = 24000, seed_lds_ratio = 120, ft_passes = 0, seed_lds = 1;
 	static bool in_list(const char *v, const char *name) {      // name is an element of the comma-separated list v
 		const size_t n = strlen(name);
@@ -102,6 +102,7 @@ struct hao_switches {
 			if (in_kv(v, "fc_raw_every", x)) fc_raw_every = (int)x;       // every n-th overlap's fake cigar travels raw (the fallback of the packed wire form)
 			if (in_kv(v, "exc_every", x)) exc_every = (int)x;             // every n-th hit of a chain travels verbatim (the exception list)
 			if (in_kv(v, "qmz_raw", x)) qmz_raw = x != 0;                   // the delivered minimizer tables in their 8-byte form whatever the read lengths (the form of batches with a read of 65 536 bases or more)
+			if (in_kv(v, "arena_probe", x)) arena_probe = x != 0;           // the delivery arenas' placement probe (hao_deliver_enqueue) whatever their size and rate
 			if (in_kv(v, "ft_chunk_slots", x)) ft_chunk_slots = (long long)x;      // k-mer slots hashed per chunk of reads in ha_ft_gen's pass mode
 		}
 		if (const char *e = getenv("HAO_SEED_LDS")) seed_lds = atoi(e) ? 1 : 0;      // 0 = the table kernels (hao_query.cuh, hao_query3.cuh) for every read instead of the list-major kernel (hao_query5.cuh): the tests run them on every scenario - they carry repeat-rich batches and the reads the list-major kernel leaves

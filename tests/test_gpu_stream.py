@@ -15,11 +15,13 @@ def _same(a, b):
     return all(x.shape == y.shape and (x == y).all() for x, y in zip(a, b))
 
 
-@pytest.mark.parametrize("name", ["hifi", "rr", "ont", "edge", "rr_heavy", "long200k", "hifi+arena4", "hifi+qmz_raw", "rr+qmz_raw"])
+@pytest.mark.parametrize("name", ["hifi", "rr", "ont", "edge", "rr_heavy", "long200k", "hifi+arena4", "hifi+qmz_raw", "rr+qmz_raw", "hifi+arena_probe"])
 def test_delivered_results_equal_the_oracle(name, monkeypatch):
     from hifiasm_amd.api import Engine
     if name.endswith("+arena4"):      # the arenas allocated by hand (mmap + mbind to the GPU's NUMA node + hipHostRegister): what the engine falls back to when hipHostMalloc's pages are elsewhere
         monkeypatch.setenv("HAO_ARENA_NUMA", "4"); name = name.split("+")[0]
+    if name.endswith("+arena_probe"):      # the measured placement of the arenas (a timed copy per NUMA node, the arena moved to the best): forced on these small arenas
+        monkeypatch.setenv("HAO_DBG_TEST", "arena_probe=1"); name = name.split("+")[0]
     raw_tables = name.endswith("+qmz_raw")
     if raw_tables:      # the minimizer tables of the wire format as 8-byte pairs (what batches with a read of 65 536 bases or more get: "ont", "long200k") for reads that would get 4 bytes
         monkeypatch.setenv("HAO_DBG_TEST", "qmz_raw=1"); name = name.split("+")[0]
