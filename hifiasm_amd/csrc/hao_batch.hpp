@@ -621,23 +621,18 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 	// repeat-rich reads (beyond 1024 chains the keys stay in global scratch)
 	hipLaunchKernelGGL((chain_select_kernel<1, 128>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)0, (int64_t)129);
 	HAO_CHECK_LAUNCH();
-	{	// 129 .. 4096 chains: four waves per read share the sorts; beyond: keys in global scratch, one wave.  The size classes are different reads: each launch on a side
-		// stream of its own (the replayed introsorts are latency-bound - a few hundred workgroups of 64 / 128 KB of LDS each - and overlap well); joined in front of the scans
-		const bool fork_ = B.side_ready && !c->sw.dp_serial && B.seed_path != 2;      // (batches of reads across repeat families only - the ones the host kept off the list-major seed kernel: 172 against 182 ms per pass of the repeat-rich 250 Mb set; on configs[2] the classes are all but empty and the eight event operations cost 0.2 ms per batch)
-		if (fork_) { HIP_TRY(hipEventRecord(B.ev_qc[1], c->stream)); for (int x = 1; x <= 4; ++x) HIP_TRY(hipStreamWaitEvent(B.side[x], B.ev_qc[1], 0)); }
-		auto st_ = [&](int x) { return fork_ ? B.side[x] : c->stream; };
-		hipLaunchKernelGGL((chain_select4_kernel<512>), dim3((unsigned)n), dim3(256), 0, st_(1), sa, (int64_t)129, (int64_t)513);
+	{	// 129 .. 4096 chains: four waves per read share the sorts; beyond: keys in global scratch, one wave
+		hipLaunchKernelGGL((chain_select4_kernel<512>), dim3((unsigned)n), dim3(256), 0, c->stream, sa, (int64_t)129, (int64_t)513);
 		HAO_CHECK_LAUNCH();
-		hipLaunchKernelGGL((chain_select4_kernel<1024>), dim3((unsigned)n), dim3(256), 0, st_(2), sa, (int64_t)513, (int64_t)1025);
+		hipLaunchKernelGGL((chain_select4_kernel<1024>), dim3((unsigned)n), dim3(256), 0, c->stream, sa, (int64_t)513, (int64_t)1025);
 		HAO_CHECK_LAUNCH();
 		// reads that cross repeat families: thousands of chains (250 Mb repeat-rich set: a quarter of the reads have more than 1024).  With the keys in global scratch
 		// and one wave per read those took 17 ms per batch; 64 / 128 KB of LDS per read keeps them on the four-wave path
-		hipLaunchKernelGGL((chain_select4_kernel<2048>), dim3((unsigned)n), dim3(256), 0, st_(3), sa, (int64_t)1025, (int64_t)2049);
+		hipLaunchKernelGGL((chain_select4_kernel<2048>), dim3((unsigned)n), dim3(256), 0, c->stream, sa, (int64_t)1025, (int64_t)2049);
 		HAO_CHECK_LAUNCH();
-		hipLaunchKernelGGL((chain_select4_kernel<4096>), dim3((unsigned)n), dim3(256), 0, st_(4), sa, (int64_t)2049, (int64_t)4097);
+		hipLaunchKernelGGL((chain_select4_kernel<4096>), dim3((unsigned)n), dim3(256), 0, c->stream, sa, (int64_t)2049, (int64_t)4097);
 		HAO_CHECK_LAUNCH();
 		hipLaunchKernelGGL((chain_select_kernel<1, 1024>), dim3((unsigned)(n + 1)), dim3(64), 0, c->stream, sa, (int64_t)4097, (int64_t)INT64_MAX);
-		if (fork_) for (int x = 1; x <= 4; ++x) { HIP_TRY(hipEventRecord(B.ev_dp[x], B.side[x])); HIP_TRY(hipStreamWaitEvent(c->stream, B.ev_dp[x], 0)); }
 	}
 	HAO_CHECK_LAUNCH();
 	if (int rc = hao_scan_u32(c, B.n_final.p, B.O().fin_off.p, n + 1)) return rc;
