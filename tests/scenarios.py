@@ -77,11 +77,23 @@ def edge_reads():
     return synth.from_codes(out)
 
 
+def len65535_reads():
+    """long reads cut so that the longest has EXACTLY 65 535 bases: the last set whose positions fit 16 bits (the seed kernel's 6-byte LDS records, the 4-byte minimizer
+    tables of the wire format); one base more and the engine switches to the 32-bit forms ("long200k")"""
+    from hifiasm_amd import synth
+    rs = synth.dataset(genome_size=400_000, coverage=10, read_len=64_000, err=0.006, seed=43, len_jit=3000)
+    reads = [rs.codes[int(rs.code_off[i]):int(rs.code_off[i + 1])][:65535].copy() for i in range(rs.n)]
+    assert max(len(r) for r in reads) == 65535 and sum(len(r) == 65535 for r in reads) >= 2
+    return synth.from_codes(reads)
+
+
 def build_reads(dkw):
     """the read set of a scenario: synth.dataset(**dkw), or a hand-made set"""
     from hifiasm_amd import synth
     if dkw.get("builder") == "edge":
         return edge_reads()
+    if dkw.get("builder") == "len65535":
+        return len65535_reads()
     return synth.dataset(**dkw)
 
 
@@ -96,6 +108,8 @@ BIG_SCENARIOS = {
     # more than 1024 chains (selection keys in global scratch, bitonic finish)
     "long200k": (dict(genome_size=1_000_000, coverage=16, read_len=200_000, err=0.008, seed=31, len_jit=20_000), dict(is_ont=1)),
     "rr_heavy": (dict(genome_size=300_000, coverage=20, read_len=6000, err=0.001, seed=9, repeat_rich=1, len_jit=1500), {}),
+    "len65535": (dict(builder="len65535"), dict(is_ont=1)),                  # 1800 - 1930 minimizers per read: the table kernels
+    "len65535w": (dict(builder="len65535"), dict(is_ont=1, w=101)),         # the same reads at w = 101: ~950 minimizers per read, i.e. the list-major seed kernel with 16-bit positions up to 65 534
     # long reads over a repeat-rich genome: groups of several thousand hits that fail the quick check (chain DP with f/p/marks in global scratch)
     "long_rr":  (dict(genome_size=600_000, coverage=10, read_len=100_000, err=0.004, seed=33, repeat_rich=1, len_jit=20_000), dict(is_ont=1)),
 }

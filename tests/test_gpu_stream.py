@@ -15,7 +15,7 @@ def _same(a, b):
     return all(x.shape == y.shape and (x == y).all() for x, y in zip(a, b))
 
 
-@pytest.mark.parametrize("name", ["hifi", "rr", "ont", "edge", "rr_heavy", "long200k", "hifi+arena4", "hifi+qmz_raw", "rr+qmz_raw", "hifi+arena_probe"])
+@pytest.mark.parametrize("name", ["hifi", "rr", "ont", "edge", "rr_heavy", "long200k", "len65535", "len65535w", "hifi+arena4", "hifi+qmz_raw", "rr+qmz_raw", "hifi+arena_probe"])
 def test_delivered_results_equal_the_oracle(name, monkeypatch):
     from hifiasm_amd.api import Engine
     if name.endswith("+arena4"):      # the arenas allocated by hand (mmap + mbind to the GPU's NUMA node + hipHostRegister): what the engine falls back to when hipHostMalloc's pages are elsewhere
