@@ -205,13 +205,26 @@ def run_workload(a, workload, steps, warmup, rank, local_rank, world, dist, torc
     # with delivery a pass needs at least two batches for the copy of one to run under the compute of the next: a pass that fits one batch is cut in two
     # (more pieces hide more of the copy but pay the tails of the per-batch kernels once per piece: four pieces measured slower on every small workload)
     dranges = ranges if len(ranges) >= 2 else [(n_reads * i // 2, n_reads * (i + 1) // 2) for i in range(2) if n_reads * (i + 1) // 2 > n_reads * i // 2]
-    # (the copy of a pass's LAST batch has no kernels to run under: ~0.87 GB = 15 ms on configs[2].  Rounds 4 - 5 cut the last range into 1/2 + 1/4 + 1/4; since round 6
-    # the wire format is small enough - 5.2 GB per pass - for every batch's copy to end before the next batch does, and the two extra batches cost more than the shorter
-    # tail gains: 183.7 ms with the cut, 180.7 without.  --tail-split keeps the A/B.)
+    # The copy of a pass's LAST batch has no kernels to run under: ~0.87 GB = 15 ms on configs[2].  Rounds 4 - 5 cut the last range into 1/2 + 1/4 + 1/4 (--tail-split keeps
+    # the A/B): once a batch's copy ends before the next batch's kernels do, that cut makes the small pieces wait for the big one's copy - 183.7 ms with it, 180.7 without.
+    # What works is a TAPER (--taper, default 0.8,0.55,0.4,0.25; "none": equal batches): the last two batches re-cut into pieces that shrink step by step, so that every
+    # piece's copy still ends under the next, smaller piece's kernels and only a quarter batch's copy is left exposed - same box: 181.7 / 181.1 ms with equal batches,
+    # 178.0 / 177.0 with three pieces (0.85,0.7,0.45), 175.8 with four.
     if len(dranges) >= 4 and a.tail_split:
         lo_, hi_ = dranges[-1]; m1, m2 = lo_ + (hi_ - lo_) // 2, lo_ + 3 * (hi_ - lo_) // 4
         if lo_ < m1 < m2 < hi_:
             dranges = dranges[:-1] + [(lo_, m1), (m1, m2), (m2, hi_)]
+    # (the consumer takes batch k between the kernels of k + 1 and k + 2: a piece's copy has to end before the NEXT piece's kernels do, or the device waits for the host)
+    if len(dranges) >= 4 and a.taper and a.taper != "none" and not a.tail_split:
+        fr = [float(x) for x in a.taper.split(",")]
+        lo_, hi_ = dranges[-2][0], dranges[-1][1]
+        if abs(sum(fr) - 2.0) < 1e-6 and all(f > 0 for f in fr):
+            cuts = [lo_]; acc = 0.0
+            for f in fr[:-1]:
+                acc += f; cuts.append(lo_ + int(round((hi_ - lo_) * acc / 2.0)))
+            cuts.append(hi_)
+            if all(x < y for x, y in zip(cuts[:-1], cuts[1:])):
+                dranges = dranges[:-2] + list(zip(cuts[:-1], cuts[1:]))
 
     views = {}
 
@@ -397,7 +410,7 @@ def run_workload(a, workload, steps, warmup, rank, local_rank, world, dist, torc
                           "assemble_and_pack_ms_per_step": round(boundary["q_assemble_ms_per_step"], 2),
                           "host_ms_in_async": round(boundary["host_ms_in_async"], 1), "host_ms_in_wait": round(boundary["host_ms_in_wait"], 1),
                           "stage_ms": boundary["stage_ms"], "delivered_bytes_check": boundary.get("delivered_bytes_check"),
-                          "contexts": max(1, a.boundary_contexts),
+                          "contexts": max(1, a.boundary_contexts), "batches_per_pass": len(dranges), "batch_reads": [hi_ - lo_ for lo_, hi_ in dranges] if len(dranges) <= 16 else None,
                           "what": "same step with every batch's ol->list, fake cigars and packed cl->list delivered into pinned host memory (per batch context: double-buffered, copy stream under the next batch's compute); contexts = batch contexts (hao_attach), one host thread each, that share the pass"}
                          if boundary else None),
             "config": {"workload": workload, "batch_contexts": max(1, a.contexts), "reads_per_gpu": n_reads, "bases_per_gpu": rs.total_bases, "batches_per_pass": len(ranges),
@@ -435,6 +448,7 @@ def main():
     ap.add_argument("--no-rank-proxy", action="store_true", help="skip variants.rank_proxy_configs3 (1 M reads at 40x over an index padded to configs[3]'s size: a minute of generation and ha_ft_gen)")
     ap.add_argument("--no-variants", action="store_true", help="skip the repeat-rich twin of the workload (the `variants` block of the line)")
     ap.add_argument("--variant-steps", type=int, default=5, help="timed steps of the variant (at most --steps)")
+    ap.add_argument("--taper", default="0.8,0.55,0.4,0.25", help="delivered pass: sizes (in batches, sum 2) the last two batches are re-cut into; none: equal batches")
     ap.add_argument("--tail-split", action="store_true", help="delivered pass: cut the last batch into 1/2 + 1/4 + 1/4 (A/B: the default of rounds 4 - 5)")
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed pass that digests the delivered bytes and compares them with the reference's digests")
     ap.add_argument("--verbose", action="store_true")
