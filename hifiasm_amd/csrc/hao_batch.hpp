@@ -34,7 +34,7 @@ struct hao_ctx::Batch {
 	OutSet &O() { return out[cur]; }
 	// delivery state: pinned host arenas, copy stream, per-slot completion events
 	unsigned char *arena[2] = { nullptr, nullptr }; size_t arena_cap[2] = { 0, 0 }; bool arena_reg[2] = { false, false };      // arena_reg: mmap + mbind + hipHostRegister (hao_arena_alloc)
-	void arena_free(int x) { if (!arena[x]) return; if (arena_reg[x]) { (void)hipHostUnregister(arena[x]); (void)munmap(arena[x], arena_cap[x]); } else (void)hipHostFree(arena[x]); arena[x] = nullptr; arena_cap[x] = 0; arena_reg[x] = false; } hipStream_t copy_stream = nullptr; hipEvent_t ev_ready[2], ev_done[2]; bool dl_ready = false, dl_pending[2] = { false, false };
+	void arena_free(int x) { if (!arena[x]) return; if (arena_reg[x]) { (void)hipHostUnregister(arena[x]); (void)munmap(arena[x], arena_cap[x]); } else (void)hipHostFree(arena[x]); arena[x] = nullptr; arena_cap[x] = 0; arena_reg[x] = false; } hipStream_t copy_stream = nullptr; hipEvent_t ev_ready[2], ev_done[2], ev_cstart[2]; bool arena_bad[2] = { false, false }; int arena_retry[2] = { 0, 0 }; bool dl_ready = false, dl_pending[2] = { false, false };
 	uint32_t wgt_hi = 0xffffffffu, wgt_lo = 0xffffffffu, wgt_max = 0xffffffffu;      // (wgt_max: the largest k_mer_hit::cnt the pass's weight table can give)
 	double t_evsync = 0, t_enq = 0, t_alloc = 0, t_s1 = 0, t_s2 = 0, t_s3 = 0, t_run = 0, t_pre = 0; uint64_t t_n = 0, t_nrun = 0;      // host-side time spent in the delivery plumbing (HAO_DBG_PRINT=dl)
 	hao_delivery_t dl[2]; uint64_t dl_seq = 0, n_exc = 0; uint32_t dl_parts = 0; bool exact_valid = false; std::vector<uint8_t> h_exact;
@@ -48,7 +48,7 @@ struct hao_ctx::Batch {
 		fc_base.release(); fcs.release(); fc_raw.release(); ol_fc_off.release(); cc_off.release(); cc.release(); fc_final.release(); fcf_off.release();
 		nch64.release(); g_tmp.release(); cls_cc.release(); cls_co.release(); glist.release(); g_cls.release(); slow.release(); ovf_list.release(); q_pos.release(); q_cnt.release(); s_n.release(); g_read.release(); wgt.release(); nch.release(); nout.release(); perm.release(); n_final.release(); fclen.release();
 		tm.release(); key_sc.release(); key_xs.release(); key_al.release(); key_tmp.release(); hits.release(); ohits.release(); cl.release(); f.release(); ii.release(); p.release(); t.release(); rec.release(); ol.release(); cd.release(); pk_cnt.release(); pk_ecnt.release(); pk_erank.release(); hq.release(); ohq.release(); hcode.release(); out[0].release(); out[1].release();
-		if (dl_ready) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); for (int x = 0; x < 2; ++x) { (void)hipEventDestroy(ev_ready[x]); (void)hipEventDestroy(ev_done[x]); arena_free(x); } dl_ready = false; }
+		if (dl_ready) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); for (int x = 0; x < 2; ++x) { (void)hipEventDestroy(ev_ready[x]); (void)hipEventDestroy(ev_done[x]); (void)hipEventDestroy(ev_cstart[x]); arena_free(x); } dl_ready = false; }
 	}
 };
 
@@ -119,8 +119,15 @@ static int hao_pages_on_node(const void *p, size_t bytes, int node)
 static unsigned char *hao_arena_alloc_bound(size_t bytes, int node)
 {
 	if (node < 0 || node >= 1024) return nullptr;
-	void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-	if (m == MAP_FAILED) return nullptr;
+	// (2 MB-aligned and advised as huge pages: what round 6's slow arenas had in common was not their node - a fresh mapping on the SAME node copied at 56 GB/s where the
+	// hipHostMalloc'ed one gave 30 - which leaves the page size the DMA translates through.  The caller passes a multiple of 2 MB.)
+	const size_t HP = (size_t)2 << 20;
+	void *m0 = mmap(nullptr, bytes + HP, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+	if (m0 == MAP_FAILED) return nullptr;
+	void *m = (void*)(((uintptr_t)m0 + HP - 1) & ~(uintptr_t)(HP - 1));
+	if (m != m0) (void)munmap(m0, (size_t)((uintptr_t)m - (uintptr_t)m0));
+	{ const uintptr_t end0 = (uintptr_t)m0 + bytes + HP, end = (uintptr_t)m + ((bytes + 4095) & ~(size_t)4095); if (end0 > end) (void)munmap((void*)end, (size_t)(end0 - end)); }
+	(void)madvise(m, bytes, MADV_HUGEPAGE);
 	unsigned long mask[16]; memset(mask, 0, sizeof(mask)); mask[node / 64] |= 1UL << (node % 64);
 	if (syscall(SYS_mbind, m, bytes, 2 /* MPOL_BIND */, mask, 1024UL, 0U) != 0) { (void)munmap(m, bytes); return nullptr; }
 	const long ps = sysconf(_SC_PAGESIZE);
@@ -211,16 +218,18 @@ static int hao_deliver_enqueue(hao_ctx *c)
 	const uint64_t nr4_ = cl ? nw_ / 4 + 1 : 0;      // rank directory entries on the wire: one per 256 positions
 	size_t o_rank = o_bits + (cl ? al(nw_ * 8) : 0), o_codes = o_rank + (cl ? al(nr4_ * 4) : 0), o_exc = o_codes + (cl ? al(B.n_codes) : 0);
 	size_t o_ex = o_exc + (cl ? al(B.n_exc * sizeof(hao_exc_t)) : 0), total = o_ex + (ex ? al(B.n_ol) : 0);
-	if (total > B.arena_cap[s]) {
+	if (total > B.arena_cap[s] || B.arena_bad[s]) {
+		const bool redo_ = B.arena_bad[s]; B.arena_bad[s] = false;      // (hao_deliver_wait saw this slot's last batch copied at less than 40 GB/s: other pages, by hand)
 		B.arena_free(s);
-		const size_t want = total + total / 4 + (1 << 20);
+		const size_t want = (total + total / 4 + (1 << 20) + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1);      // (a multiple of 2 MB: hao_arena_alloc_bound)
 		const double t0_ = hao_now();
 		const int node_ = c->sw.arena_numa ? hao_gpu_numa_node(c->device) : -1;
 		// MPOL_BIND first: "preferred" silently falls over to the far socket when the GPU's node is short of FREE pages (a process that has just generated or
 		// parsed gigabytes of reads leaves it full of page cache) - the same box then delivers at 36 instead of 52 GB/s; bound, the kernel reclaims instead.
 		// If the bound allocation fails, once more with the preference only.
 		hipError_t he_ = hipErrorOutOfMemory; const char *how_ = "default policy";
-		if (node_ >= 0 && c->sw.arena_numa != 1) {
+		if (redo_) if (unsigned char *m_ = hao_arena_alloc_bound(want, node_ >= 0 ? node_ : 0)) { B.arena[s] = m_; B.arena_reg[s] = true; he_ = hipSuccess; how_ = "again, by hand"; }
+		if (he_ != hipSuccess && node_ >= 0 && c->sw.arena_numa != 1) {
 			hao_mempolicy_guard g_(node_, 2 /* MPOL_BIND */);
 			if (g_.applied) {
 				he_ = hipHostMalloc((void**)&B.arena[s], want, (c->sw.arena_numa == 2) ? hipHostMallocNumaUser : hipHostMallocDefault);
@@ -237,19 +246,19 @@ static int hao_deliver_enqueue(hao_ctx *c)
 		int on_ = -1;
 		if (he_ == hipSuccess && node_ >= 0) {
 			on_ = hao_pages_on_node(B.arena[s], want, node_);
-			if ((on_ >= 0 && on_ < 28) || c->sw.arena_numa == 4) {      // (HAO_ARENA_NUMA=4: always by hand - tests)
+			if (!B.arena_reg[s] && ((on_ >= 0 && on_ < 28) || c->sw.arena_numa == 4)) {      // (HAO_ARENA_NUMA=4: always by hand - tests)
 				if (unsigned char *m_ = hao_arena_alloc_bound(want, node_)) { (void)hipHostFree(B.arena[s]); B.arena[s] = m_; B.arena_reg[s] = true; how_ = "mmap + mbind + hipHostRegister"; on_ = hao_pages_on_node(m_, want, node_); }
 			}
 		}
 		// What the placement is worth is MEASURED: one run in eight of round 6 still delivered at 28.7 instead of 50 GB/s (same box, next process: 49.8) with every page
-		// reported on the GPU's node.  A 128 MB copy into the new arena is timed; below 40 GB/s a 128 MB buffer bound to each NUMA node in turn gets the same copy and the
+		// reported on the GPU's node.  A 128 MB copy into the new arena is timed; below 50 GB/s a 128 MB buffer bound to each NUMA node in turn gets the same copy and the
 		// arena moves to the best node when that is 10 % faster.  (Arenas of 64 MB and more; HAO_DBG_TEST=arena_probe=1: always and whatever the size - tests.)
 		if (he_ == hipSuccess && c->sw.arena_numa && (want >= ((size_t)64 << 20) || c->sw.arena_probe) && B.hits.p) {
 			const size_t nb = std::min<size_t>(std::min<size_t>(want, (size_t)128 << 20), B.hits.cap * sizeof(hao_hit_t)) & ~(size_t)4095;
 			if (nb >= 4096) {
 				(void)hao_arena_rate(B.copy_stream, B.arena[s], B.hits.p, nb);      // (first touch of the mapping)
 				const double r0 = hao_arena_rate(B.copy_stream, B.arena[s], B.hits.p, nb);
-				if ((r0 >= 0 && r0 < 40.0) || c->sw.arena_probe) {
+				if ((r0 >= 0 && r0 < 50.0) || c->sw.arena_probe) {      // (a good arena: 55 - 57 GB/s with the device otherwise idle, as it is here)
 					int best_k = -1; double best = r0;
 					for (int k = 0; k < 16; ++k) {
 						unsigned char *m_ = hao_arena_alloc_bound(nb, k); if (!m_) continue;
@@ -272,6 +281,7 @@ static int hao_deliver_enqueue(hao_ctx *c)
 	unsigned char *a = B.arena[s];
 	HIP_TRY(hipEventRecord(B.ev_ready[s], c->stream));
 	HIP_TRY(hipStreamWaitEvent(B.copy_stream, B.ev_ready[s], 0));
+	HIP_TRY(hipEventRecord(B.ev_cstart[s], B.copy_stream));      // (the copy itself, without the wait behind the previous batch's: hao_deliver_wait checks its rate)
 	auto cp = [&](size_t off, const void *src, size_t bytes) -> hipError_t { return bytes ? hipMemcpyAsync(a + off, src, bytes, hipMemcpyDeviceToHost, B.copy_stream) : hipSuccess; };
 	hao_delivery_t &d = B.dl[s];
 	d.rid_lo = B.lo; d.n_reads = n; d.n_ol = d.n_fc = d.n_chains = d.n_cl = d.n_exc = d.n_codes = d.n_pos = 0; d.bytes = 0;
@@ -301,7 +311,7 @@ static int hao_deliver_init(hao_ctx *c, hao_ctx::Batch &B)
 {
 	if (B.dl_ready) return HAO_OK;
 	HIP_TRY(hipStreamCreateWithFlags(&B.copy_stream, hipStreamNonBlocking));
-	for (int x = 0; x < 2; ++x) { HIP_TRY(hipEventCreate(&B.ev_ready[x])); HIP_TRY(hipEventCreate(&B.ev_done[x])); }
+	for (int x = 0; x < 2; ++x) { HIP_TRY(hipEventCreate(&B.ev_ready[x])); HIP_TRY(hipEventCreate(&B.ev_done[x])); HIP_TRY(hipEventCreate(&B.ev_cstart[x])); }
 	B.dl_ready = true;
 	return HAO_OK;
 }
