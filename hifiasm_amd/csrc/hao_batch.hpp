@@ -34,7 +34,7 @@ struct hao_ctx::Batch {
 	OutSet &O() { return out[cur]; }
 	// delivery state: pinned host arenas, copy stream, per-slot completion events
 	unsigned char *arena[2] = { nullptr, nullptr }; size_t arena_cap[2] = { 0, 0 }; bool arena_reg[2] = { false, false };      // arena_reg: mmap + mbind + hipHostRegister (hao_arena_alloc)
-	void arena_free(int x) { if (!arena[x]) return; if (arena_reg[x]) { (void)hipHostUnregister(arena[x]); (void)munmap(arena[x], arena_cap[x]); } else (void)hipHostFree(arena[x]); arena[x] = nullptr; arena_cap[x] = 0; arena_reg[x] = false; } hipStream_t copy_stream = nullptr; hipEvent_t ev_ready[2], ev_done[2], ev_cstart[2]; bool arena_bad[2] = { false, false }; int arena_retry[2] = { 0, 0 }; bool dl_ready = false, dl_pending[2] = { false, false };
+	void arena_free(int x) { if (!arena[x]) return; if (arena_reg[x]) { (void)hipHostUnregister(arena[x]); (void)munmap(arena[x], arena_cap[x]); } else (void)hipHostFree(arena[x]); arena[x] = nullptr; arena_cap[x] = 0; arena_reg[x] = false; } hipStream_t copy_stream = nullptr; hipEvent_t ev_ready[2], ev_done[2], ev_cstart[2]; bool arena_bad[2] = { false, false }; int arena_retry[2] = { 0, 0 }, arena_node = -1;      /* arena_node: the NUMA node a probe found best (a box of round 6 reported the GPU on node 0 and copied at 30 GB/s into node 0, 56 into node 1) */ bool dl_ready = false, dl_pending[2] = { false, false };
 	uint32_t wgt_hi = 0xffffffffu, wgt_lo = 0xffffffffu, wgt_max = 0xffffffffu;      // (wgt_max: the largest k_mer_hit::cnt the pass's weight table can give)
 	double t_evsync = 0, t_enq = 0, t_alloc = 0, t_s1 = 0, t_s2 = 0, t_s3 = 0, t_run = 0, t_pre = 0; uint64_t t_n = 0, t_nrun = 0;      // host-side time spent in the delivery plumbing (HAO_DBG_PRINT=dl)
 	hao_delivery_t dl[2]; uint64_t dl_seq = 0, n_exc = 0; uint32_t dl_parts = 0; bool exact_valid = false; std::vector<uint8_t> h_exact;
@@ -135,6 +135,9 @@ static unsigned char *hao_arena_alloc_bound(size_t bytes, int node)
 	if (hipHostRegister(m, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); (void)munmap(m, bytes); return nullptr; }
 	return (unsigned char*)m;
 }
+// the NUMA node a probe found best for a device's delivery arenas, kept for the process (every engine and batch context of the device starts from it)
+static int hao_arena_node_of[64] = { -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+	-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1 };
 // GB/s of one device-to-host copy of nb bytes into `host` on the batch's copy stream (HIP events around it); -1 when it cannot be measured
 static double hao_arena_rate(hipStream_t st, unsigned char *host, const void *dsrc, size_t nb)
 {
@@ -219,7 +222,7 @@ static int hao_deliver_enqueue(hao_ctx *c)
 	size_t o_rank = o_bits + (cl ? al(nw_ * 8) : 0), o_codes = o_rank + (cl ? al(nr4_ * 4) : 0), o_exc = o_codes + (cl ? al(B.n_codes) : 0);
 	size_t o_ex = o_exc + (cl ? al(B.n_exc * sizeof(hao_exc_t)) : 0), total = o_ex + (ex ? al(B.n_ol) : 0);
 	if (total > B.arena_cap[s] || B.arena_bad[s]) {
-		const bool redo_ = B.arena_bad[s]; B.arena_bad[s] = false;      // (hao_deliver_wait saw this slot's last batch copied at less than 40 GB/s: other pages, by hand)
+		const bool redo_ = B.arena_bad[s]; B.arena_bad[s] = false;      // (hao_deliver_wait saw this slot's last batch copied at less than 40 GB/s: the probe below tries every NUMA node)
 		B.arena_free(s);
 		const size_t want = (total + total / 4 + (1 << 20) + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1);      // (a multiple of 2 MB: hao_arena_alloc_bound)
 		const double t0_ = hao_now();
@@ -228,7 +231,7 @@ static int hao_deliver_enqueue(hao_ctx *c)
 		// parsed gigabytes of reads leaves it full of page cache) - the same box then delivers at 36 instead of 52 GB/s; bound, the kernel reclaims instead.
 		// If the bound allocation fails, once more with the preference only.
 		hipError_t he_ = hipErrorOutOfMemory; const char *how_ = "default policy";
-		if (redo_) if (unsigned char *m_ = hao_arena_alloc_bound(want, node_ >= 0 ? node_ : 0)) { B.arena[s] = m_; B.arena_reg[s] = true; he_ = hipSuccess; how_ = "again, by hand"; }
+		if (B.arena_node >= 0) if (unsigned char *m_ = hao_arena_alloc_bound(want, B.arena_node)) { B.arena[s] = m_; B.arena_reg[s] = true; he_ = hipSuccess; how_ = "by hand on the node an earlier probe chose"; }
 		if (he_ != hipSuccess && node_ >= 0 && c->sw.arena_numa != 1) {
 			hao_mempolicy_guard g_(node_, 2 /* MPOL_BIND */);
 			if (g_.applied) {
@@ -258,7 +261,7 @@ static int hao_deliver_enqueue(hao_ctx *c)
 			if (nb >= 4096) {
 				(void)hao_arena_rate(B.copy_stream, B.arena[s], B.hits.p, nb);      // (first touch of the mapping)
 				const double r0 = hao_arena_rate(B.copy_stream, B.arena[s], B.hits.p, nb);
-				if ((r0 >= 0 && r0 < 50.0) || c->sw.arena_probe) {      // (a good arena: 55 - 57 GB/s with the device otherwise idle, as it is here)
+				if ((r0 >= 0 && r0 < 50.0) || c->sw.arena_probe || redo_) {      // (a good arena: 55 - 57 GB/s with the device otherwise idle, as it is here)
 					int best_k = -1; double best = r0;
 					for (int k = 0; k < 16; ++k) {
 						unsigned char *m_ = hao_arena_alloc_bound(nb, k); if (!m_) continue;
@@ -268,7 +271,7 @@ static int hao_deliver_enqueue(hao_ctx *c)
 						if (c->sw.dltime || c->sw.arena_probe) fprintf(stderr, "[deliver] arena %d probe: NUMA node %d %.1f GB/s\n", s, k, rk);
 						if (rk > best * 1.1) { best = rk; best_k = k; }
 					}
-					if (best_k >= 0) if (unsigned char *m_ = hao_arena_alloc_bound(want, best_k)) { B.arena_cap[s] = want; B.arena_free(s); B.arena[s] = m_; B.arena_reg[s] = true; how_ = "moved after the probe"; }      // (arena_free unmaps arena_cap bytes of a registered arena)
+					if (best_k >= 0) if (unsigned char *m_ = hao_arena_alloc_bound(want, best_k)) { B.arena_cap[s] = want; B.arena_free(s); B.arena[s] = m_; B.arena_reg[s] = true; B.arena_node = best_k; if (c->device >= 0 && c->device < 64) hao_arena_node_of[c->device] = best_k; how_ = "moved after the probe"; }      // (arena_free unmaps arena_cap bytes of a registered arena)
 					fprintf(stderr, "[hao] delivery arena %d: %.1f GB/s from the device as allocated (GPU NUMA node %d, %s)%s\n", s, r0, node_, how_, best_k >= 0 ? "" : "; no NUMA node does better");
 					if (best_k >= 0) fprintf(stderr, "[hao] delivery arena %d: moved to NUMA node %d (%.1f GB/s)\n", s, best_k, best);
 				}
@@ -312,6 +315,7 @@ static int hao_deliver_init(hao_ctx *c, hao_ctx::Batch &B)
 	if (B.dl_ready) return HAO_OK;
 	HIP_TRY(hipStreamCreateWithFlags(&B.copy_stream, hipStreamNonBlocking));
 	for (int x = 0; x < 2; ++x) { HIP_TRY(hipEventCreate(&B.ev_ready[x])); HIP_TRY(hipEventCreate(&B.ev_done[x])); HIP_TRY(hipEventCreate(&B.ev_cstart[x])); }
+	if (c->device >= 0 && c->device < 64) B.arena_node = hao_arena_node_of[c->device];
 	B.dl_ready = true;
 	return HAO_OK;
 }

@@ -147,12 +147,12 @@ int hao_deliver_wait(hao_ctx *c, int slot, hao_delivery_t *out)
 	HIP_TRY(hipSetDevice(c->device));
 	hao_ctx::Batch &B = *c->batch;
 	if (B.dl_pending[slot]) { HIP_TRY(hipEventSynchronize(B.ev_done[slot])); B.dl_pending[slot] = false; float ms = 0; if (hipEventElapsedTime(&ms, B.ev_ready[slot], B.ev_done[slot]) == hipSuccess) B.dl[slot].copy_ms = ms;
-		// the rate of the copy itself: a big batch that crossed at less than 40 GB/s (a good arena gives 50 - 56 beside the next batch's kernels) gets its arena allocated again, by
-		// hand, before the slot's next batch (once per slot; round 6 saw arenas that passed the probe at allocation and then copied at 30 GB/s for the whole run)
+		// the rate of the copy itself: a big batch that crossed at less than 40 GB/s (a good arena gives 50 - 56 beside the next batch's kernels) gets its arena allocated again
+		// before the slot's next batch, with a timed copy into every NUMA node (batches of 256 MB and more: smaller ones pay per-copy overheads that say nothing about the arena) (once per slot; round 6 saw arenas that passed the probe at allocation and then copied at 30 GB/s for the whole run)
 		float cms = 0; const double mb_ = (double)B.dl[slot].bytes / 1e6;
-		if (hipEventElapsedTime(&cms, B.ev_cstart[slot], B.ev_done[slot]) == hipSuccess && cms > 0 && B.arena_retry[slot] < 1 && ((mb_ >= 64.0 && mb_ / cms < 40.0) || (c->sw.arena_probe && mb_ > 0))) {
+		if (hipEventElapsedTime(&cms, B.ev_cstart[slot], B.ev_done[slot]) == hipSuccess && cms > 0 && B.arena_retry[slot] < 1 && ((mb_ >= 256.0 && mb_ / cms < 40.0) || (c->sw.arena_probe && mb_ > 0))) {
 			B.arena_bad[slot] = true; ++B.arena_retry[slot];
-			fprintf(stderr, "[hao] delivery arena %d: a batch of %.0f MB was copied at %.1f GB/s; the arena is allocated again (by hand) for the slot's next batch\n", slot, mb_, mb_ / cms);
+			fprintf(stderr, "[hao] delivery arena %d: a batch of %.0f MB was copied at %.1f GB/s; the arena is allocated again for the slot's next batch, every NUMA node tried\n", slot, mb_, mb_ / cms);
 		}
 	}
 	if (B.dl[slot].n_ol && B.dl[slot].fc_off) ((uint64_t*)B.dl[slot].fc_off)[B.dl[slot].n_ol] = B.dl[slot].n_fc;      // end of the last cigar: a host-side word next to the region the copy wrote, set once the copy has landed
