@@ -4,13 +4,13 @@
 // Why: round 5's one-wave merge kernel (one wave per read, the same merge with lane-private list reads; profiles/r05) read its lists lane-privately (32 bytes at a time), which moves whole 128-byte lines through the fabric several times - it
 // fetched 2.5 - 5 x its records and sat at 0.33 of the HBM peak, where a coalesced walk of the same lists with the same stores runs at 0.53
 // (tools/ubench_gather.hip, profiles/r05).  The transposition between "list-major in" and "target-major out" needs the read's records on chip at once:
-// ~12 000 records of a 15 kb read at 30 x.  Here they are, 6 bytes each (key word: target | strand of the HIT << 28; offset word: 16 bits while every read is
-// shorter than 64 kb, else 32), in up to 118 KB of the CU's 160 KB.
+// ~12 000 records of a 15 kb read at 30 x.  Here they are, 6 bytes each (key word: target << 1 | strand of the HIT; offset word: 16 bits while every read is
+// shorter than 64 kb, else 32), in up to 124 KB of the CU's 160 KB (20 592 record slots for reads of up to 1024 rows).
 //
 // One workgroup of 8 waves owns the CU's LDS, so nothing else hides its memory latency: the kernel is a software pipeline over the workgroup's reads
-// (read i = blockIdx.x + i * gridDim.x).  While read e is merged,
-//   the records of read e + 1 are in flight into REGISTERS (one 8-byte record per lane and load slot; a slot = up to 16 consecutive records of one list,
-//   read by 16 adjacent lanes), issued from a slot table that the preparation of read e + 1 left in LDS;
+// (the first is read blockIdx.x, the next ones come from a cursor shared by the workgroups, asked one step ahead).  While read e is merged,
+//   the records of read e + 1 are in flight into REGISTERS (two adjacent 8-byte records = one 16-byte load per lane and load slot; a slot = up to 16 consecutive
+//   records of one list, read by 8 adjacent lanes), issued from a slot table that the preparation of read e + 1 left in LDS;
 //   the minimizer words of read e + 2 (list start | length | strand, query position, weight) are in flight into registers;
 //   the four offsets of read e + 3 are in flight.
 // A step: write read e's records from the registers into LDS (strand folded, offset precomputed), barrier, prepare read e + 1 from its minimizer words
@@ -19,8 +19,8 @@
 // The merge.  The hits of a read in the reference's order (target, strand, query minimizer, list order) are the merge of its lists by target (every list is
 // sorted by (rid, pos), htab.cpp:380-460).  The eight waves split the TARGET range: while the records are staged, a 256-bin histogram of their targets (bins =
 // equal slices of the read-id range) is counted in LDS; its prefix sums give seven bin boundaries with about an eighth of the read's hits between them, wave w takes
-// the targets in [s_w, s_w+1): a binary search per row in LDS finds where its range starts in every list, the sum of those positions is where its output starts.
-// (First version: splitters from 64 sampled records - eight samples per range: the slowest wave took twice the mean, profiles/r06/seed_phases.txt.)
+// the targets in [s_w, s_w+1): a 4-ary search per row in LDS finds where its range starts in every list, the sum of those positions is where its output starts.
+// (First version: splitters from 64 sampled records - eight samples per range: the slowest wave took twice the mean, profiles/r06/seed_ab.txt.)
 // Inside its range a wave steps bin by bin - the smallest (target, strand) key under any cursor by one wave-min, one ballot per 64 rows, the rows that stand on it
 // ranked by mbcnt, one 16-byte store per hit at a running position - with heads and cursors in registers (2 per row, up to 24 rows per lane: reads with up to 1536 minimizers
 // that have a list) and everything else read from LDS: no buffers to refill, an advance is a cursor increment and a 4-byte LDS read, the end of a list is a
@@ -29,7 +29,7 @@
 // (target, first hit) go to a per-wave LDS list and are written out behind each other after the merge.
 //
 // Reads this kernel leaves to the table kernels (overflow list): more than 1536 minimizers, more records than the LDS holds, more load
-// slots than the slot table, more than max_n hits (reads across repeat families: hundreds of targets, a step each), more than 96 groups in one wave's range.
+// slots than the slot table, more than max_n hits (reads across repeat families: hundreds of targets, a step each), more than 64 groups in one wave's range.
 // HBM traffic per seed hit: 8 bytes in (once, coalesced), 16 bytes out.
 #pragma once
 #include <type_traits>
@@ -161,7 +161,7 @@ __device__ __forceinline__ uint32_t hao_l5_merge(const hao_l5_ptr<B16, QPT> &L, 
 	// A step = one BIN: the smallest key K = (target, strand) under any cursor; the rows whose head is K emit it in row order and advance.  (The first version stepped
 	// by target and ranked forward and opposite-strand hits in one pass: a count pass over all blocks in front of every step and two ballots, two mbcnt pairs and four
 	// selects per block - 45 instructions per emitting block where this takes 16, and at two waves per SIMD the step loop runs at the latency of its dependent
-	// instructions, ~7 cycles each: profiles/r06/seed_phases.txt.)  A row's records of one target are in POSITION order, so behind a head (T, opposite) there can be a
+	// instructions, ~7 cycles each: profiles/r06/seed_ab.txt.)  A row's records of one target are in POSITION order, so behind a head (T, opposite) there can be a
 	// (T, forward) record that the forward bin's step did not see, and a row can hold a key twice: both show after the step as "the next key is not above this one,
 	// same target", and the target is redone in full by the general routine (per-row runs, forward records in list order, opposite-strand records in reverse list
 	// order: anchor.cpp:1023) from where its first bin started.
@@ -404,9 +404,9 @@ __global__ __launch_bounds__(HAO_L5_THREADS, 2) void seed_lds_kernel(hao_seed_ar
 					const uint4 hv = *(const uint4*)(hist_e + 4 * lane);
 					const uint32_t s4 = hv.x + hv.y + hv.z + hv.w, ex0 = hao_wave_incl_scan_u32(s4) - s4, ex1 = ex0 + hv.x, ex2 = ex1 + hv.y, ex3 = ex2 + hv.z;
 					// shares in 1/1024 of the read's hits: wave 0 needs no search for its start (about 4 % of a read's time), and the second wave of every SIMD (waves 4 - 7)
-					// loses the issue arbitration to the first (measured: 11.4 against 10.5 us per read for equal shares, profiles/r06/seed_phases.txt)
+					// loses the issue arbitration to the first (measured: 11.4 against 10.5 us per read for equal shares, profiles/r06/seed_ab.txt)
 					// shares in 1/1024 of the (sampled) hits: wave 0 needs no search for its start and gets w0_share (default 176), the others share the rest - the second
-					// wave of every SIMD (waves 4 - 7) 4 % less than the first: it loses the issue arbitration (profiles/r06/seed_phases.txt)
+					// wave of every SIMD (waves 4 - 7) 4 % less than the first: it loses the issue arbitration (profiles/r06/seed_ab.txt)
 					const uint32_t tot_ = (uint32_t)__builtin_amdgcn_readlane((int)(ex0 + s4), 63), rest_ = 1024u - w0_share;
 					auto cumw = [&](uint32_t w) -> uint32_t { return w == 0 ? 0u : w >= HAO_L5_W ? 1024u : w0_share + (w <= 4 ? (w - 1) * (rest_ * 37u >> 8) : 3u * (rest_ * 37u >> 8) + (w - 4) * (rest_ * 35u >> 8)); };
 					const uint32_t th_lo = (uint32_t)(((uint64_t)tot_ * cumw((uint32_t)wv)) >> 10), th_hi = (uint32_t)(((uint64_t)tot_ * cumw((uint32_t)wv + 1)) >> 10);
