@@ -574,7 +574,7 @@ static int hao_overlap_run(hao_ctx *c, uint64_t lo, uint64_t hi, const hao_pass_
 		if (!G) return HAO_OK;
 		hao_ctx::Batch::OutSet &O = B.O();
 		hipLaunchKernelGGL(hao_pack_hdr_kernel, dim3((unsigned)((NCmax + 255) / 256)), dim3(256), 0, ps, pa, B.ch_base.p + G); HAO_CHECK_LAUNCH();
-		hipLaunchKernelGGL(hao_pack_bits_kernel, dim3((unsigned)((NW * 8 + 255) / 256)), dim3(256), 0, ps, pa, A, NW, O.bits.p, B.pk_cnt.p, B.pk_ecnt.p); HAO_CHECK_LAUNCH();      // (the verbatim list: by count + scan, in position order)
+		hipLaunchKernelGGL(hao_pack_bits_kernel, dim3((unsigned)((NW * 8 + 256 * HAO_PACK_U - 1) / (256 * HAO_PACK_U))), dim3(256), 0, ps, pa, A, NW, O.bits.p, B.pk_cnt.p, B.pk_ecnt.p); HAO_CHECK_LAUNCH();      // (the verbatim list: by count + scan, in position order)
 		size_t tb = 0;
 		HIP_TRY(rocprim::exclusive_scan(nullptr, tb, B.pk_cnt.p, O.rank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), ps)); HIP_TRY(B.pk_tmp.reserve(tb + 256));
 		HIP_TRY(rocprim::exclusive_scan(B.pk_tmp.p, tb, B.pk_cnt.p, O.rank.p, 0u, NW + 1, rocprim::plus<uint32_t>(), ps));

@@ -105,27 +105,32 @@ __global__ __launch_bounds__(256) void hao_pack_hdr_kernel(hao_pack_args A, cons
 // (The verbatim entries are NOT appended here - their number per word goes to ecnt[], a scan turns the counts into list positions and
 // hao_pack_codes_kernel writes the entries in position order, in the pass that places the code bytes.  A repeat-rich 250 Mb batch has 14 M verbatim hits in 1.3 M waves: one atomic per wave on the list's
 // counter - all on one address - made this kernel 11 ms instead of 0.3, and the list then needed a 24-byte-record merge sort by position, ~10 ms more.)
+// (Round 6: four 8-byte chunks per thread, a grid's width apart, all four loads issued before the first is used - with one load per thread the kernel ran at 1.3 TB/s, the memory
+// parallelism of 32 waves x 512 bytes per CU - and the two byte tests as SWAR masks compressed by a multiplication instead of a loop over the bytes.)
+#define HAO_PACK_U 4
+static_assert(HAO_CODE_EXC_OHITS == 0xfd, "hao_pack_bits_kernel tests the byte 0xfd");
+__device__ __forceinline__ uint32_t hao_byte_flags(uint64_t hi_bits) { return (uint32_t)(((hi_bits >> 7) * 0x0102040810204080ULL) >> 56); }      // bit 7 of byte k -> bit k
 __global__ __launch_bounds__(256) void hao_pack_bits_kernel(hao_pack_args A, uint64_t n, uint64_t n_words, uint64_t *bits, uint32_t *cnt, uint32_t *ecnt)
 {
-	const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, w = t >> 3;
-	uint32_t m8 = 0, e8 = 0; uint64_t v = 0;
-	if (8 * t < n) {
-		v = *(const uint64_t*)(A.bytes + 8 * t);
+	const uint64_t T = (uint64_t)gridDim.x * 256, t0 = (uint64_t)blockIdx.x * 256 + threadIdx.x;      // (T is a multiple of 8: a word's eight threads stay adjacent lanes in every round)
+	const uint64_t L7 = 0x7f7f7f7f7f7f7f7fULL, H8 = 0x8080808080808080ULL;
+	uint64_t v[HAO_PACK_U];
 #pragma unroll
-		for (int k = 0; k < 8; ++k) {
-			const uint8_t b = (uint8_t)(v >> (8 * k));
-			if (8 * t + k < n && b != 0x08) m8 |= 1u << k;
-			if (8 * t + k < n && (b == 0xff || b == HAO_CODE_EXC_OHITS)) e8 |= 1u << k;
-		}
-	}
-	{
+	for (int u = 0; u < HAO_PACK_U; ++u) { const uint64_t t = t0 + (uint64_t)u * T; v[u] = 8 * t < n ? *(const uint64_t*)(A.bytes + 8 * t) : 0x0808080808080808ULL; }
+#pragma unroll
+	for (int u = 0; u < HAO_PACK_U; ++u) {
+		const uint64_t t = t0 + (uint64_t)u * T, w = t >> 3;
+		const uint64_t x = v[u] ^ 0x0808080808080808ULL, xf = ~v[u], xd = v[u] ^ 0xfdfdfdfdfdfdfdfdULL;      // a byte of x is zero iff the code is 0x08; of xf / xd iff it is 0xff / HAO_CODE_EXC_OHITS
+		uint32_t m8 = hao_byte_flags((x | ((x & L7) + L7)) & H8);                                                  // bytes != 0x08
+		uint32_t e8 = hao_byte_flags((~(((xf & L7) + L7) | xf | L7) | ~(((xd & L7) + L7) | xd | L7)) & H8);        // bytes == 0xff or == 0xfd
+		const uint64_t left = 8 * t < n ? n - 8 * t : 0;      // positions of this chunk that exist
+		if (left < 8) { const uint32_t keep = (1u << (uint32_t)left) - 1u; m8 &= keep; e8 &= keep; }
 		uint32_t ne = (uint32_t)__popc(e8);
 		ne += __shfl_xor(ne, 1); ne += __shfl_xor(ne, 2); ne += __shfl_xor(ne, 4);
-		if ((t & 7) == 0 && w < n_words) ecnt[w] = ne;
+		uint64_t word = (uint64_t)m8 << ((t & 7) * 8);
+		word |= __shfl_xor(word, 1); word |= __shfl_xor(word, 2); word |= __shfl_xor(word, 4);
+		if ((t & 7) == 0 && w < n_words) { bits[w] = word; cnt[w] = (uint32_t)__popcll(word); ecnt[w] = ne; }      // (no lane leaves early: the shuffles above are wave-wide)
 	}
-	uint64_t word = (uint64_t)m8 << ((t & 7) * 8);
-	word |= __shfl_xor(word, 1); word |= __shfl_xor(word, 2); word |= __shfl_xor(word, 4);
-	if ((t & 7) == 0 && w < n_words) { bits[w] = word; cnt[w] = (uint32_t)__popcll(word); }      // (no lane leaves early: the shuffles above are wave-wide)
 }
 
 // code bytes of the flagged positions, at their rank: thread t takes positions [8t, 8t + 8).  The same pass writes the verbatim list at the
