@@ -412,18 +412,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void chain
 	hao_cpar P; P.pen_gap = A.par.pen_gap; P.pen_skip = A.par.pen_skip; P.bw = A.par.bw; P.max_skip = A.par.max_skip; P.max_iter = A.par.max_iter; P.max_dis = A.par.max_dis;
 	P.xl = e.xl; P.yl = e.yl;
 	const unsigned long long tq1 = A.dbg_qc ? wall_clock64() + (first0.w0 & 0) : 0;      // (+ 0 through the loaded hit: the stamp waits for tile 0)
-	const uint32_t strand0 = HH_STRAND(first0);
 	// ---- parallel quick check ----
+	// A group's hits are sorted by (strand, query minimizer, list order): at most TWO strand blocks, block 0 in front.  So the per-block running score is a plain
+	// prefix sum (six v_add_dpp) minus its value in front of the boundary - no segmented scan -, every vote per block is ONE wave-wide vote split by the mask of
+	// block 1's lanes in scalar registers, and a block's last hit is the lane in front of the boundary (or the group's last lane): nothing of the NEXT tile is looked
+	// at, its load has a whole iteration to arrive.  (A third block - it cannot happen - sends the group to the exact path.)
 	int32_t carry_f = 0; hao_hit_t carry_h = first0;
-	bool fail0 = false, fail1 = false; int32_t maxf0 = INT32_MIN, maxf1 = INT32_MIN, flast0 = 0, flast1 = 0, k1 = 0; int64_t ddt0 = 0, ddt1 = 0;
+	bool fail0 = false, fail1 = false; int32_t maxf0 = INT32_MIN, maxf1 = INT32_MIN, flast0 = 0, flast1 = 0, k1 = 0, n_bnd = 0; int64_t ddt0 = 0, ddt1 = 0;
 	uint32_t last0_so = first0.self_offset, last0_of = first0.offset, last1_so = last0_so, last1_of = last0_of;      // (self_offset, offset) of each block's last hit: all that is used of it
 	for (int32_t t0 = 0; t0 < a_n; t0 += 64) {
-		const int32_t idx = t0 + lane; const bool act = idx < a_n;
+		const int32_t idx = t0 + lane, left = a_n - t0; const bool act = idx < a_n;
+		const unsigned long long actm = left >= 64 ? ~0ULL : (1ULL << left) - 1ULL;
 		hao_hit_t h = act ? hn : carry_h;
 		const uint32_t q = qn;
 		if (idx + 64 < a_n) { hn = a[idx + 64]; if (hcg) qn = hqg[idx + 64]; }
 		hao_hit_t ph = hao_shfl_up_hit(h); if (lane == 0) ph = carry_h;
-		const bool st = act && (idx == 0 || HH_STRAND(h) != HH_STRAND(ph));
+		const unsigned long long Mb = __ballot((int32_t)(h.w0 ^ first0.w0) < 0) & actm;       // lanes of block 1
+		const unsigned long long Mbnd = __ballot((int32_t)(h.w0 ^ ph.w0) < 0) & actm;        // block 1 starts at this lane (hit 0 has ph = itself)
+		const bool st = act && (idx == 0 || (int32_t)(h.w0 ^ ph.w0) < 0);
 		if (hcg) {      // wire code of this hit relative to the previous one of its strand block: minimizers skipped << 4 | diagonal shift + 8; 0xff = not expressible
 			const uint32_t pq = hao_wave_shr1(q, carry_q);
 			const int32_t dq = (int32_t)(q - pq), sh = (int32_t)((h.offset - ph.offset) - (h.self_offset - ph.self_offset));
@@ -431,31 +437,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void chain
 			if (act) hcg[idx] = code;
 			carry_q = hao_bcast(q, 63);
 		}
-		const int b = act && HH_STRAND(h) != strand0;
+		const int b = act && (int32_t)(h.w0 ^ first0.w0) < 0;
 		int32_t s = HH_SPAN(h); bool ok = true; int64_t dd = 0;
 		if (act && !st) { s = hao_pair_score(h, ph, P, &dd); ok = s != INT32_MIN; if (!ok) { s = 0; dd = 0; } }
 		{	const uint32_t diag = h.offset - h.self_offset, pdiag = ph.offset - ph.self_offset;
 			const bool cf = act && (st || diag != pdiag);
-			const unsigned long long c0 = __ballot(cf && b == 0), c1 = __ballot(cf && b == 1);
-			if (cf) { const uint32_t at = (b ? ce1 : ce0) + __popcll((b ? c1 : c0) & ((1ULL << lane) - 1)); if (at < 64) eb[b][at] = (uint64_t)h.self_offset << 32 | diag; }
-			ce0 += __popcll(c0); ce1 += __popcll(c1); }
-		int32_t x = act ? s : 0; int fl = st;
-		hao_seg_scan_add(x, fl);
-		if (!fl) x += carry_f;
-		const int32_t f = x; const int32_t fp = hao_wave_shr1(f, carry_f);
+			const unsigned long long Mcf = (__ballot(diag != pdiag) | Mbnd | (t0 == 0 ? 1ULL : 0ULL)) & actm;      // = the vote on cf
+			const uint32_t n0 = (uint32_t)__popcll(Mcf & ~Mb), n1 = (uint32_t)__popcll(Mcf & Mb);
+			if (cf) { const uint32_t at = hao_mbcnt(Mcf) + (b ? ce1 - n0 : ce0); if (at < 64) eb[b][at] = (uint64_t)h.self_offset << 32 | diag; }      // (block 0's entries are all below block 1's lanes)
+			ce0 += n0; ce1 += n1; }
+		const int32_t F = (int32_t)hao_wave_incl_scan_u32((uint32_t)(act ? s : 0));
+		int32_t f;
+		if (Mbnd) {
+			const int B = __ffsll((long long)Mbnd) - 1; n_bnd += __popcll(Mbnd);
+			const int32_t sub = B ? hao_bcast(F, B - 1) : 0;
+			f = lane >= B ? F - sub : F + carry_f;
+			// the hit in front of the boundary is block 0's last one
+			if (B) { flast0 = hao_bcast(f, B - 1); last0_so = hao_bcast(h.self_offset, B - 1); last0_of = hao_bcast(h.offset, B - 1); }
+			else { flast0 = carry_f; last0_so = carry_h.self_offset; last0_of = carry_h.offset; }
+		} else f = F + carry_f;
+		const int32_t fp = hao_wave_shr1(f, carry_f);
 		const bool brk = act && !st && (!ok || (int64_t)s + fp < (int64_t)HH_SPAN(h));
-		if (__ballot(brk && b == 0)) fail0 = true;
-		if (__ballot(brk && b == 1)) fail1 = true;
+		const unsigned long long Mbrk = __ballot(brk);
+		if (Mbrk & ~Mb) fail0 = true;
+		if (Mbrk & Mb) fail1 = true;
 		if (act) { if (b == 0) { maxf0 = max(maxf0, f); ddt0 += dd; } else { maxf1 = max(maxf1, f); ddt1 += dd; } }
-		k1 += __popcll(__ballot(act && b == 0));
-		// strand of the next hit: next lane, or lane 0 of the tile already on its way
-		const uint32_t nw0 = hao_wave_shl1(h.w0, (uint32_t)__builtin_amdgcn_readfirstlane((int)hn.w0));
-		const bool isend = act && (idx == a_n - 1 || (nw0 >> 31) != HH_STRAND(h));
-		unsigned long long m0 = __ballot(isend && b == 0), m1 = __ballot(isend && b == 1);
-		if (m0) { int src = __ffsll((long long)m0) - 1; flast0 = hao_bcast(f, src); last0_so = hao_bcast(h.self_offset, src); last0_of = hao_bcast(h.offset, src); }
-		if (m1) { int src = __ffsll((long long)m1) - 1; flast1 = hao_bcast(f, src); last1_so = hao_bcast(h.self_offset, src); last1_of = hao_bcast(h.offset, src); }
+		k1 += __popcll(actm & ~Mb);
+		if (left <= 64) {      // the group's last hit ends its block
+			const int Ls = left - 1; const int32_t vf = hao_bcast(f, Ls); const uint32_t vso = hao_bcast(h.self_offset, Ls), vof = hao_bcast(h.offset, Ls);
+			if ((Mb >> Ls) & 1ULL) { flast1 = vf; last1_so = vso; last1_of = vof; } else { flast0 = vf; last0_so = vso; last0_of = vof; }
+		}
 		carry_f = hao_bcast(f, 63); carry_h = hao_shfl_hit(h, 63);
 	}
+	if (n_bnd > 1) fail0 = fail1 = true;
 	maxf0 = hao_wave_max_i32(maxf0); maxf1 = hao_wave_max_i32(maxf1); ddt0 = hao_wave_sum_i64(ddt0); ddt1 = hao_wave_sum_i64(ddt1);
 	const unsigned long long tq2 = A.dbg_qc ? wall_clock64() + (unsigned long long)(maxf0 & 0) : 0;
 	const bool two = k1 < a_n;

@@ -108,6 +108,8 @@ __device__ __forceinline__ uint32_t hao_wave_incl_scan_u32(uint32_t x)
 #undef HAO_RED_STEP
 	return x;
 }
+// bits of the wave-uniform mask m below this lane (v_mbcnt_lo / v_mbcnt_hi)
+__device__ __forceinline__ uint32_t hao_mbcnt(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 // value of the next lane; lane 63 gets `fill` (DPP wave_shl:1)
 __device__ __forceinline__ uint32_t hao_wave_shl1(uint32_t v, uint32_t fill) { return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xf, 0xf, false); }
 

@@ -67,7 +67,6 @@ template<bool B16, int QPT> struct hao_l5_lds {
 	static constexpr uint32_t CAP = ((TOTAL - FIXED) / (B16 ? 6 : 8) - 8) & ~7u;      // record slots (records + one sentinel per row + the guard slot 0): 20 592 at 6 bytes and 1024 rows, 19 568 at 1536
 };
 
-__device__ __forceinline__ uint32_t hao_mbcnt(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 __device__ __forceinline__ uint64_t hao_wave_incl_scan_u64(uint64_t v)
 {
 #define HAO_RED_STEP(CTRL, RM) { const uint32_t lo2 = (uint32_t)hao_dpp<CTRL, RM>(0, (int)(uint32_t)v), hi2 = (uint32_t)hao_dpp<CTRL, RM>(0, (int)(uint32_t)(v >> 32)); v += (uint64_t)hi2 << 32 | lo2; }
