@@ -423,12 +423,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void chain
 	for (int32_t t0 = 0; t0 < a_n; t0 += 64) {
 		const int32_t idx = t0 + lane, left = a_n - t0; const bool act = idx < a_n;
 		const unsigned long long actm = left >= 64 ? ~0ULL : (1ULL << left) - 1ULL;
-		hao_hit_t h = act ? hn : carry_h;
+		const hao_hit_t h = hn;      // (lanes behind the group's end hold a stale hit: every use below is under `act` or a vote masked by actm)
 		const uint32_t q = qn;
 		if (idx + 64 < a_n) { hn = a[idx + 64]; if (hcg) qn = hqg[idx + 64]; }
-		hao_hit_t ph = hao_shfl_up_hit(h); if (lane == 0) ph = carry_h;
+		hao_hit_t ph; ph.w0 = hao_wave_shr1(h.w0, carry_h.w0); ph.offset = hao_wave_shr1(h.offset, carry_h.offset); ph.self_offset = hao_wave_shr1(h.self_offset, carry_h.self_offset); ph.cnt = 0;      // lane 0: the previous tile's last hit
 		const unsigned long long Mb = __ballot((int32_t)(h.w0 ^ first0.w0) < 0) & actm;       // lanes of block 1
 		const unsigned long long Mbnd = __ballot((int32_t)(h.w0 ^ ph.w0) < 0) & actm;        // block 1 starts at this lane (hit 0 has ph = itself)
+		const unsigned long long Mst = Mbnd | (unsigned long long)(t0 == 0);                 // a block starts at this lane
 		const bool st = act && (idx == 0 || (int32_t)(h.w0 ^ ph.w0) < 0);
 		if (hcg) {      // wire code of this hit relative to the previous one of its strand block: minimizers skipped << 4 | diagonal shift + 8; 0xff = not expressible
 			const uint32_t pq = hao_wave_shr1(q, carry_q);
@@ -438,15 +439,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void chain
 			carry_q = hao_bcast(q, 63);
 		}
 		const int b = act && (int32_t)(h.w0 ^ first0.w0) < 0;
-		int32_t s = HH_SPAN(h); bool ok = true; int64_t dd = 0;
-		if (act && !st) { s = hao_pair_score(h, ph, P, &dd); ok = s != INT32_MIN; if (!ok) { s = 0; dd = 0; } }
+		int32_t s = HH_SPAN(h); int64_t dd = 0;      // s: INT32_MIN = the pair cannot be chained (dd stays 0 then)
+		if (act && !st) s = hao_pair_score(h, ph, P, &dd);
 		{	const uint32_t diag = h.offset - h.self_offset, pdiag = ph.offset - ph.self_offset;
 			const bool cf = act && (st || diag != pdiag);
-			const unsigned long long Mcf = (__ballot(diag != pdiag) | Mbnd | (t0 == 0 ? 1ULL : 0ULL)) & actm;      // = the vote on cf
+			const unsigned long long Mcf = (__ballot(diag != pdiag) | Mst) & actm;      // = the vote on cf
 			const uint32_t n0 = (uint32_t)__popcll(Mcf & ~Mb), n1 = (uint32_t)__popcll(Mcf & Mb);
 			if (cf) { const uint32_t at = hao_mbcnt(Mcf) + (b ? ce1 - n0 : ce0); if (at < 64) eb[b][at] = (uint64_t)h.self_offset << 32 | diag; }      // (block 0's entries are all below block 1's lanes)
 			ce0 += n0; ce1 += n1; }
-		const int32_t F = (int32_t)hao_wave_incl_scan_u32((uint32_t)(act ? s : 0));
+		const int32_t F = (int32_t)hao_wave_incl_scan_u32((uint32_t)(act && s != INT32_MIN ? s : 0));
 		int32_t f;
 		if (Mbnd) {
 			const int B = __ffsll((long long)Mbnd) - 1; n_bnd += __popcll(Mbnd);
@@ -457,8 +458,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void chain
 			else { flast0 = carry_f; last0_so = carry_h.self_offset; last0_of = carry_h.offset; }
 		} else f = F + carry_f;
 		const int32_t fp = hao_wave_shr1(f, carry_f);
-		const bool brk = act && !st && (!ok || (int64_t)s + fp < (int64_t)HH_SPAN(h));
-		const unsigned long long Mbrk = __ballot(brk);
+		// the chain breaks at a hit that cannot follow its predecessor, or whose score with it falls below its own span: s + fp < span in 64 bits = the same with a
+		// SATURATING 32-bit sum (span >= 0; a sum beyond INT32_MAX is not below it, one below INT32_MIN - or s = INT32_MIN with any fp - is): v_add_i32 clamp + one compare
+		const unsigned long long Mbrk = __ballot(hao_add_sat_i32(s, fp) < HH_SPAN(h)) & actm & ~Mst;
 		if (Mbrk & ~Mb) fail0 = true;
 		if (Mbrk & Mb) fail1 = true;
 		if (act) { if (b == 0) { maxf0 = max(maxf0, f); ddt0 += dd; } else { maxf1 = max(maxf1, f); ddt1 += dd; } }

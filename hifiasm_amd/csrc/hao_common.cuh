@@ -108,6 +108,8 @@ __device__ __forceinline__ uint32_t hao_wave_incl_scan_u32(uint32_t x)
 #undef HAO_RED_STEP
 	return x;
 }
+// a + b clamped to [INT32_MIN, INT32_MAX] (the compiler turns this form into v_add_i32 ... clamp)
+__host__ __device__ __forceinline__ int32_t hao_add_sat_i32(int32_t a, int32_t b) { int32_t t; return __builtin_add_overflow(a, b, &t) ? (a < 0 ? INT32_MIN : INT32_MAX) : t; }
 // bits of the wave-uniform mask m below this lane (v_mbcnt_lo / v_mbcnt_hi)
 __device__ __forceinline__ uint32_t hao_mbcnt(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 // value of the next lane; lane 63 gets `fill` (DPP wave_shl:1)
