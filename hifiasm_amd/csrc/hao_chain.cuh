@@ -386,7 +386,7 @@ __device__ __forceinline__ hao_hit_t hao_shfl_up_hit(const hao_hit_t &h)      //
 // scores with per-pair validity flags - and no second chain qualifies for multi-copy output; then the best
 // block IS the chain: hits are copied through, the fake cigar is a flagged compaction.  >99.9 % of groups on
 // repeat-free genomes.  Everything else runs hao_chain_generic on lane 0 (exact sequential algorithm).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void chain_group_kernel(hao_chain_args A, const hao_gent *list, uint64_t n_list, uint32_t *slow, int cls)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void chain_group_kernel(hao_chain_args A, const hao_gent *list, uint64_t n_list, uint32_t *slow, int cls)
 {
 	const uint64_t li = blockIdx.x;      // (one 64-thread workgroup per group)
 	if (li >= n_list) return;
@@ -418,7 +418,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void chain
 	// block 1's lanes in scalar registers, and a block's last hit is the lane in front of the boundary (or the group's last lane): nothing of the NEXT tile is looked
 	// at, its load has a whole iteration to arrive.  (A third block - it cannot happen - sends the group to the exact path.)
 	int32_t carry_f = 0; hao_hit_t carry_h = first0;
-	bool fail0 = false, fail1 = false; int32_t maxf0 = INT32_MIN, maxf1 = INT32_MIN, flast0 = 0, flast1 = 0, k1 = 0, n_bnd = 0; int64_t ddt0 = 0, ddt1 = 0;
+	bool fail0 = false, fail1 = false; int32_t maxf0 = INT32_MIN, maxf1 = INT32_MIN, flast0 = 0, flast1 = 0, k1 = 0, n_bnd = 0;
+	uint32_t ddt0 = 0, ddt1 = 0;      // a block's sum of dd, SATURATING at 2^32 - 1: all that is asked of it is whether it exceeds 16 and a band of less than 2^31 (a 64-bit sum over the wave: ~35 instructions per block)
 	uint32_t last0_so = first0.self_offset, last0_of = first0.offset, last1_so = last0_so, last1_of = last0_of;      // (self_offset, offset) of each block's last hit: all that is used of it
 	for (int32_t t0 = 0; t0 < a_n; t0 += 64) {
 		const int32_t idx = t0 + lane, left = a_n - t0; const bool act = idx < a_n;
@@ -434,7 +435,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void chain
 		if (hcg) {      // wire code of this hit relative to the previous one of its strand block: minimizers skipped << 4 | diagonal shift + 8; 0xff = not expressible
 			const uint32_t pq = hao_wave_shr1(q, carry_q);
 			const int32_t dq = (int32_t)(q - pq), sh = (int32_t)((h.offset - ph.offset) - (h.self_offset - ph.self_offset));
-			const uint8_t code = st ? (uint8_t)0x08 : ((dq < 1 || dq > 15 || sh < -8 || sh > 7 || q == 65535u || (A.exc_every && (uint32_t)idx % A.exc_every == A.exc_every - 1)) ? (uint8_t)0xff : (uint8_t)((dq - 1) << 4 | (sh + 8)));
+			bool exc = false;
+			if (A.exc_every) { uint32_t ii = (uint32_t)idx, ee = A.exc_every; HAO_OPAQUE_U32(ii); HAO_OPAQUE_U32(ee); exc = ii % ee == ee - 1; }      // (tests only; opaque: the division's set-up - 12 instructions - otherwise moves in front of the loop of every group)
+			const uint8_t code = st ? (uint8_t)0x08 : ((dq < 1 || dq > 15 || sh < -8 || sh > 7 || q == 65535u || exc) ? (uint8_t)0xff : (uint8_t)((dq - 1) << 4 | (sh + 8)));
 			if (act) hcg[idx] = code;
 			carry_q = hao_bcast(q, 63);
 		}
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void chain
 		const unsigned long long Mbrk = __ballot(hao_add_sat_i32(s, fp) < HH_SPAN(h)) & actm & ~Mst;
 		if (Mbrk & ~Mb) fail0 = true;
 		if (Mbrk & Mb) fail1 = true;
-		if (act) { if (b == 0) { maxf0 = max(maxf0, f); ddt0 += dd; } else { maxf1 = max(maxf1, f); ddt1 += dd; } }
+		if (act) { if (b == 0) { maxf0 = max(maxf0, f); ddt0 = hao_add_sat_u32(ddt0, (uint32_t)dd); } else { maxf1 = max(maxf1, f); ddt1 = hao_add_sat_u32(ddt1, (uint32_t)dd); } }      // (dd < 2^28 per pair)
 		k1 += __popcll(actm & ~Mb);
 		if (left <= 64) {      // the group's last hit ends its block
 			const int Ls = left - 1; const int32_t vf = hao_bcast(f, Ls); const uint32_t vso = hao_bcast(h.self_offset, Ls), vof = hao_bcast(h.offset, Ls);
@@ -472,13 +475,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void chain
 		carry_f = hao_bcast(f, 63); carry_h = hao_shfl_hit(h, 63);
 	}
 	if (n_bnd > 1) fail0 = fail1 = true;
-	maxf0 = hao_wave_max_i32(maxf0); maxf1 = hao_wave_max_i32(maxf1); ddt0 = hao_wave_sum_i64(ddt0); ddt1 = hao_wave_sum_i64(ddt1);
-	const unsigned long long tq2 = A.dbg_qc ? wall_clock64() + (unsigned long long)(maxf0 & 0) : 0;
 	const bool two = k1 < a_n;
+	maxf0 = hao_wave_max_i32(maxf0); ddt0 = hao_wave_sum_sat_u32(ddt0);
+	if (two) { maxf1 = hao_wave_max_i32(maxf1); ddt1 = hao_wave_sum_sat_u32(ddt1); }      // (most groups have one strand block)
+	const unsigned long long tq2 = A.dbg_qc ? wall_clock64() + (unsigned long long)(maxf0 & 0) : 0;
 	const hao_hit_t first1 = two ? a[k1] : first0;
 	hao_hit_t last0, last1; last0.w0 = first0.w0; last0.cnt = 0; last0.self_offset = last0_so; last0.offset = last0_of; last1.w0 = first1.w0; last1.cnt = 0; last1.self_offset = last1_so; last1.offset = last1_of;
-	bool acc0 = !fail0 && flast0 == maxf0 && !(k1 >= 2 && ddt0 > 16 && ddt0 > hao_band(last0, first0, P));
-	bool acc1 = two && !fail1 && flast1 == maxf1 && !(a_n - k1 >= 2 && ddt1 > 16 && ddt1 > hao_band(last1, first1, P));
+	bool acc0 = !fail0 && flast0 == maxf0 && !(k1 >= 2 && ddt0 > 16u && (int64_t)ddt0 > (int64_t)hao_band(last0, first0, P));
+	bool acc1 = two && !fail1 && flast1 == maxf1 && !(a_n - k1 >= 2 && ddt1 > 16u && (int64_t)ddt1 > (int64_t)hao_band(last1, first1, P));
 	bool fast = acc0 && (!two || acc1);
 	int best = 0; int64_t msc = flast0;
 	if (fast && two) {

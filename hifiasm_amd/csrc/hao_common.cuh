@@ -63,6 +63,11 @@ __device__ __forceinline__ int hao_lane() { return threadIdx.x & 63; }
 #define HAO_SLOAD_U32(dst, ptr) asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dst) : "s"(ptr) : "memory")
 #endif
 
+// A value the compiler must not reason about (tests' switches inside hot loops: keeps a division's set-up inside the branch that uses it).  Nothing in the CPU emulation.
+#ifndef HAO_OPAQUE_U32
+#define HAO_OPAQUE_U32(x) asm volatile("" : "+v"(x))
+#endif
+
 // Cross-lane moves on the DPP path (one VALU op, no LDS crossbar trip like ds_bpermute).  gfx9 controls: 0x110+n row_shr:n (inside rows of
 // 16 lanes), 0x142 row_bcast:15 (lane 15 of a row -> the next row, use row_mask 0xa), 0x143 row_bcast:31 (lane 31 -> rows 2,3, row_mask 0xc),
 // 0x138 wave_shr:1.  Lanes without a valid source keep `old`.  Call only in wave-uniform control flow.
@@ -110,6 +115,15 @@ __device__ __forceinline__ uint32_t hao_wave_incl_scan_u32(uint32_t x)
 }
 // a + b clamped to [INT32_MIN, INT32_MAX] (the compiler turns this form into v_add_i32 ... clamp)
 __host__ __device__ __forceinline__ int32_t hao_add_sat_i32(int32_t a, int32_t b) { int32_t t; return __builtin_add_overflow(a, b, &t) ? (a < 0 ? INT32_MIN : INT32_MAX) : t; }
+// a + b clamped to 2^32 - 1 (v_add_u32 ... clamp), and the wave's sum of that kind (uniform result)
+__host__ __device__ __forceinline__ uint32_t hao_add_sat_u32(uint32_t a, uint32_t b) { uint32_t t; return __builtin_add_overflow(a, b, &t) ? 0xffffffffu : t; }
+__device__ __forceinline__ uint32_t hao_wave_sum_sat_u32(uint32_t v)
+{
+#define HAO_RED_STEP(CTRL, RM) v = hao_add_sat_u32(v, (uint32_t)hao_dpp<CTRL, RM>(0, (int)v));
+	HAO_RED_STEP(0x111, 0xf) HAO_RED_STEP(0x112, 0xf) HAO_RED_STEP(0x114, 0xf) HAO_RED_STEP(0x118, 0xf) HAO_RED_STEP(0x142, 0xa) HAO_RED_STEP(0x143, 0xc)
+#undef HAO_RED_STEP
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 // bits of the wave-uniform mask m below this lane (v_mbcnt_lo / v_mbcnt_hi)
 __device__ __forceinline__ uint32_t hao_mbcnt(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 // value of the next lane; lane 63 gets `fill` (DPP wave_shl:1)

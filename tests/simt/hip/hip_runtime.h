@@ -346,6 +346,7 @@ __forceinline__ unsigned long long __ballot(int pred, HAO_SIMT_SITE_ARGS)
 	return m;
 }
 #define HAO_SLOAD_U32(dst, ptr) ((dst) = *(ptr))      /* hao_common.cuh: a scalar load (inline assembly on the device) */
+#define HAO_OPAQUE_U32(x) ((void)0)      /* hao_common.cuh: a compiler barrier on the device */
 #define HAO_LOCKSTEP() do { uint64_t pr_; (void)hao_simt::exchange(0, &pr_, hao_simt::site_of(__FILE__, __LINE__)); } while (0)      /* hao_common.cuh: lanes of a wave run in lockstep */
 // the sources use release + acquire fence pairs where a wave's lanes hand data to each other through memory: the release is the rendezvous of the wave's lanes
 __forceinline__ void __builtin_amdgcn_fence(int order, const char *, HAO_SIMT_SITE_ARGS) { if (order != __ATOMIC_ACQUIRE) { uint64_t pr; (void)hao_simt::exchange(0, &pr, HAO_SIMT_SITE); } }
