@@ -417,22 +417,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void chain
 	// prefix sum (six v_add_dpp) minus its value in front of the boundary - no segmented scan -, every vote per block is ONE wave-wide vote split by the mask of
 	// block 1's lanes in scalar registers, and a block's last hit is the lane in front of the boundary (or the group's last lane): nothing of the NEXT tile is looked
 	// at, its load has a whole iteration to arrive.  (A third block - it cannot happen - sends the group to the exact path.)
-	int32_t carry_f = 0; hao_hit_t carry_h = first0;
-	bool fail0 = false, fail1 = false; int32_t maxf0 = INT32_MIN, maxf1 = INT32_MIN, flast0 = 0, flast1 = 0, k1 = 0, n_bnd = 0;
+	int32_t carry_f = 0; hao_hit_t carry_h = first0; carry_h.w0 ^= 0x80000000u;      // (hit 0 sees a predecessor of the other strand: it starts a block like block 1's first hit does)
+	bool fail0 = false, fail1 = false, seen = false; int32_t maxf0 = INT32_MIN, maxf1 = INT32_MIN, flast0 = 0, flast1 = 0, k1 = 0, n_bnd = 0;
 	uint32_t ddt0 = 0, ddt1 = 0;      // a block's sum of dd, SATURATING at 2^32 - 1: all that is asked of it is whether it exceeds 16 and a band of less than 2^31 (a 64-bit sum over the wave: ~35 instructions per block)
 	uint32_t last0_so = first0.self_offset, last0_of = first0.offset, last1_so = last0_so, last1_of = last0_of;      // (self_offset, offset) of each block's last hit: all that is used of it
+	unsigned long long first = 1ULL;      // bit 0 in the group's first tile
+	const uint32_t ulane = (uint32_t)lane;
 	for (int32_t t0 = 0; t0 < a_n; t0 += 64) {
-		const int32_t idx = t0 + lane, left = a_n - t0; const bool act = idx < a_n;
+		const int32_t left = a_n - t0; const bool act = lane < left;
 		const unsigned long long actm = left >= 64 ? ~0ULL : (1ULL << left) - 1ULL;
 		const hao_hit_t h = hn;      // (lanes behind the group's end hold a stale hit: every use below is under `act` or a vote masked by actm)
 		const uint32_t q = qn;
-		if (idx + 64 < a_n) { hn = a[idx + 64]; if (hcg) qn = hqg[idx + 64]; }
+		if (left > 64) {      // the next tile, from a uniform base; lanes behind its end repeat its last hit
+			const uint32_t j = min(ulane, (uint32_t)(left - 65)); const hao_hit_t *an = a + (t0 + 64);
+			hn = an[j]; if (hcg) qn = (hqg + (t0 + 64))[j];
+		}
 		hao_hit_t ph; ph.w0 = hao_wave_shr1(h.w0, carry_h.w0); ph.offset = hao_wave_shr1(h.offset, carry_h.offset); ph.self_offset = hao_wave_shr1(h.self_offset, carry_h.self_offset); ph.cnt = 0;      // lane 0: the previous tile's last hit
-		const unsigned long long Mb = __ballot((int32_t)(h.w0 ^ first0.w0) < 0) & actm;       // lanes of block 1
-		const unsigned long long Mbnd = __ballot((int32_t)(h.w0 ^ ph.w0) < 0) & actm;        // block 1 starts at this lane (hit 0 has ph = itself)
-		const unsigned long long Mst = Mbnd | (unsigned long long)(t0 == 0);                 // a block starts at this lane
-		const bool st = act && (idx == 0 || (int32_t)(h.w0 ^ ph.w0) < 0);
+		const bool bnd = (int32_t)(h.w0 ^ ph.w0) < 0, st = act && bnd;
+		const unsigned long long Mst = __ballot(bnd) & actm, Mbnd = Mst & ~first;      // a block starts at this lane; block 1 does
+		// lanes of block 1: behind the boundary (inactive lanes fall on either side: they add nothing)
+		unsigned long long Mb = 0; uint32_t bthr = 64; int B = 0;
+		if (seen) { Mb = actm; bthr = 0; }
+		else if (Mbnd) { B = __ffsll((long long)Mbnd) - 1; Mb = (~0ULL << B) & actm; bthr = (uint32_t)B; }
+		const int b = ulane >= bthr;
 		if (hcg) {      // wire code of this hit relative to the previous one of its strand block: minimizers skipped << 4 | diagonal shift + 8; 0xff = not expressible
+			const int32_t idx = t0 + lane;
 			const uint32_t pq = hao_wave_shr1(q, carry_q);
 			const int32_t dq = (int32_t)(q - pq), sh = (int32_t)((h.offset - ph.offset) - (h.self_offset - ph.self_offset));
 			bool exc = false;
@@ -441,19 +450,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void chain
 			if (act) hcg[idx] = code;
 			carry_q = hao_bcast(q, 63);
 		}
-		const int b = act && (int32_t)(h.w0 ^ first0.w0) < 0;
-		int32_t s = HH_SPAN(h); int64_t dd = 0;      // s: INT32_MIN = the pair cannot be chained (dd stays 0 then)
-		if (act && !st) s = hao_pair_score(h, ph, P, &dd);
-		{	const uint32_t diag = h.offset - h.self_offset, pdiag = ph.offset - ph.self_offset;
-			const bool cf = act && (st || diag != pdiag);
-			const unsigned long long Mcf = (__ballot(diag != pdiag) | Mst) & actm;      // = the vote on cf
+		// comput_sc_ch_ec (hao_pair_score) of every lane with its predecessor, WITHOUT its early returns: `bad` collects them, the arithmetic of a bad pair runs on
+		// and is thrown away (three nested exec regions with their defaults cost more than the few lanes they spare)
+		const int32_t span = HH_SPAN(h);
+		const int32_t dq = (int32_t)(h.self_offset - ph.self_offset), dr = (int32_t)(h.offset - ph.offset);
+		bool bad = dq <= 0 || dr <= 0;
+		const int32_t dd = dr > dq ? dr - dq : dq - dr, dg = dr < dq ? dr : dq;
+		if (!bad && dd > 16) { if (dd > hao_band(h, ph, P)) bad = true; }
+		int32_t sc = span < dg ? span : dg;
+		{	const int32_t wgt = HH_WGT(h);
+			if (wgt != 1) sc = sc >= wgt ? (wgt == 2 ? sc >> 1 : sc / wgt) : 1; }      // weight 1 (and 2) are the rule: the integer division (~40 instructions) only runs for rarer seeds
+		if (dd) {
+			double lin = P.pen_gap * (double)dd; const double skip = P.pen_skip * (double)dg;
+			if (!(dd < 4 && lin + skip < 1.0)) {      // (see hao_pair_score)
+				const double ap = (double)sc * (((double)dd / (double)dg) / P.bw);
+				if (dd < 4) lin = lin > ap ? ap : lin; else lin = lin < ap ? ap : lin;
+				lin += skip;
+				sc -= (int32_t)lin;
+			}
+		} else if (dg > span) sc -= (int32_t)(0.0 + P.pen_skip * (double)dg);
+		const bool scored = act && !bnd && !bad;                       // the pair counts
+		const int32_t s = bad ? INT32_MIN : sc;                        // (for the break test; block starts are masked there)
+		const int32_t x = st ? span : (scored ? sc : 0);
+		const uint32_t dde = scored ? (uint32_t)dd : 0u;              // (dd < 2^28 per pair)
+		{	const bool cf = act && (bnd || dr != dq);                  // the diagonal offset - self_offset changes here: a fake-cigar entry
+			const unsigned long long Mcf = (__ballot(dr != dq) | Mst) & actm;      // = the vote on cf
 			const uint32_t n0 = (uint32_t)__popcll(Mcf & ~Mb), n1 = (uint32_t)__popcll(Mcf & Mb);
-			if (cf) { const uint32_t at = hao_mbcnt(Mcf) + (b ? ce1 - n0 : ce0); if (at < 64) eb[b][at] = (uint64_t)h.self_offset << 32 | diag; }      // (block 0's entries are all below block 1's lanes)
+			if (cf) { const uint32_t at = hao_mbcnt(Mcf) + (b ? ce1 - n0 : ce0); if (at < 64) eb[b][at] = (uint64_t)h.self_offset << 32 | (h.offset - h.self_offset); }      // (block 0's entries are all below block 1's lanes)
 			ce0 += n0; ce1 += n1; }
-		const int32_t F = (int32_t)hao_wave_incl_scan_u32((uint32_t)(act && s != INT32_MIN ? s : 0));
+		const int32_t F = (int32_t)hao_wave_incl_scan_u32((uint32_t)x);
 		int32_t f;
 		if (Mbnd) {
-			const int B = __ffsll((long long)Mbnd) - 1; n_bnd += __popcll(Mbnd);
+			n_bnd += __popcll(Mbnd);
 			const int32_t sub = B ? hao_bcast(F, B - 1) : 0;
 			f = lane >= B ? F - sub : F + carry_f;
 			// the hit in front of the boundary is block 0's last one
@@ -463,16 +491,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void chain
 		const int32_t fp = hao_wave_shr1(f, carry_f);
 		// the chain breaks at a hit that cannot follow its predecessor, or whose score with it falls below its own span: s + fp < span in 64 bits = the same with a
 		// SATURATING 32-bit sum (span >= 0; a sum beyond INT32_MAX is not below it, one below INT32_MIN - or s = INT32_MIN with any fp - is): v_add_i32 clamp + one compare
-		const unsigned long long Mbrk = __ballot(hao_add_sat_i32(s, fp) < HH_SPAN(h)) & actm & ~Mst;
+		const unsigned long long Mbrk = __ballot(hao_add_sat_i32(s, fp) < span) & actm & ~Mst;
 		if (Mbrk & ~Mb) fail0 = true;
 		if (Mbrk & Mb) fail1 = true;
-		if (act) { if (b == 0) { maxf0 = max(maxf0, f); ddt0 = hao_add_sat_u32(ddt0, (uint32_t)dd); } else { maxf1 = max(maxf1, f); ddt1 = hao_add_sat_u32(ddt1, (uint32_t)dd); } }      // (dd < 2^28 per pair)
+		// a lane behind the group's end repeats the last hit's f and adds dd = 0: no guard
+		if (bthr == 64) { maxf0 = max(maxf0, f); ddt0 = hao_add_sat_u32(ddt0, dde); }
+		else if (bthr == 0) { maxf1 = max(maxf1, f); ddt1 = hao_add_sat_u32(ddt1, dde); }
+		else if (b == 0) { maxf0 = max(maxf0, f); ddt0 = hao_add_sat_u32(ddt0, dde); } else { maxf1 = max(maxf1, f); ddt1 = hao_add_sat_u32(ddt1, dde); }
 		k1 += __popcll(actm & ~Mb);
 		if (left <= 64) {      // the group's last hit ends its block
 			const int Ls = left - 1; const int32_t vf = hao_bcast(f, Ls); const uint32_t vso = hao_bcast(h.self_offset, Ls), vof = hao_bcast(h.offset, Ls);
 			if ((Mb >> Ls) & 1ULL) { flast1 = vf; last1_so = vso; last1_of = vof; } else { flast0 = vf; last0_so = vso; last0_of = vof; }
 		}
 		carry_f = hao_bcast(f, 63); carry_h = hao_shfl_hit(h, 63);
+		if (Mbnd) seen = true;
+		first = 0;
 	}
 	if (n_bnd > 1) fail0 = fail1 = true;
 	const bool two = k1 < a_n;
