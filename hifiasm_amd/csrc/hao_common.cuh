@@ -29,6 +29,32 @@ __host__ __device__ __forceinline__ uint64_t hao_hash64(uint64_t key)
 	return key;
 }
 
+// The same hash as the sketch kernel spends it - two per k-mer, 16 k-mers per lane - in the instruction forms gfx950 issues cheapest (tools/ubench_valu.hip: the form
+// above costs 86 SIMD cycles per hash as the compiler legalises its 64-bit multiplications - v_mad_u64_u32 for each half with moves between the register pairs -,
+// this one ~65): a multiplication by a small constant c as lo * c on v_mad_u64_u32 with (hi * c) << 32 as its addend; the first step ~key + (key << 21) as
+// key * (2^21 - 1) - 1 with a 24-bit multiplication for the high half (keys below 2^56: a bit plane of a k-mer of at most 56 bases); and the last step,
+// key += key << 31 = a multiplication by 2^31 + 1, taken out: hash(a) + hash(b) = fin(part(a) + part(b)).  Bit-identical to hao_hash64 (checked for 10^8 random keys on
+// the host, and by every sketch test).
+#define HAO_MUL64_C(key, c) { const uint32_t lo_ = (uint32_t)(key), hi_ = (uint32_t)((key) >> 32); const uint64_t p_ = (uint64_t)lo_ * (c); const uint32_t h2_ = (uint32_t)(p_ >> 32) + hi_ * (c); (key) = (uint64_t)h2_ << 32 | (uint32_t)p_; }
+__host__ __device__ __forceinline__ uint64_t hao_hash64_part56(uint64_t key)      // key < 2^56
+{
+	{	const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+		const uint64_t p = (uint64_t)lo * 0x1fffffu + 0xffffffffu; const uint32_t h2 = (uint32_t)(p >> 32) + ((hi & 0xffffffu) * 0x1fffffu + 0xffffffffu); key = (uint64_t)h2 << 32 | (uint32_t)p; }      // (the mask is free: v_mul_u32_u24 reads 24 bits, and it keeps the compiler from putting the 64-bit product back together)
+	key ^= key >> 24;
+	HAO_MUL64_C(key, 265u)
+	key ^= key >> 14;
+	HAO_MUL64_C(key, 21u)
+	key ^= key >> 28;
+	return key;
+}
+__host__ __device__ __forceinline__ uint64_t hao_hash64_fin(uint64_t s) { HAO_MUL64_C(s, 0x80000001u) return s; }
+// hash of a k-mer from its two bit planes (yak_hash_long, htab.h:161-166): K <= 56 takes the cheap form
+template<int K> __host__ __device__ __forceinline__ uint64_t hao_hash_planes(uint64_t p0, uint64_t p1)
+{
+	if (K <= 56) return hao_hash64_fin(hao_hash64_part56(p0) + hao_hash64_part56(p1));
+	return hao_hash64(p0) + hao_hash64(p1);
+}
+
 // minimizer / index-position record bit layout (htab.h:13-22): rid:28 | pos:27 | rev:1 | span:8
 __host__ __device__ __forceinline__ uint64_t hao_info_pack(uint32_t rid, uint32_t pos, uint32_t rev, uint32_t span)
 { return (uint64_t)(rid & 0xfffffffu) | (uint64_t)(pos & 0x7ffffffu) << 28 | (uint64_t)(rev & 1) << 55 | (uint64_t)(span & 0xff) << 56; }

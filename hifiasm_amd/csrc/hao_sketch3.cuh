@@ -90,7 +90,7 @@ template<int K> __device__ __forceinline__ uint64_t sk3_key_dyn(const unsigned l
 	const uint64_t W1 = ((uint64_t)__builtin_amdgcn_alignbit((uint32_t)(c2 >> 32), (uint32_t)(c1 >> 32), sh) << 32 | __builtin_amdgcn_alignbit((uint32_t)(c1 >> 32), (uint32_t)(c0 >> 32), sh)) & mask;
 	const uint64_t f1 = __brevll(W1) >> (64 - K), r1 = ~W1 & mask;
 	rev = f1 < r1 ? 0u : 1u;
-	return f1 < r1 ? hao_hash64(__brevll(W0) >> (64 - K)) + hao_hash64(f1) : hao_hash64(~W0 & mask) + hao_hash64(r1);
+	return f1 < r1 ? hao_hash_planes<K>(__brevll(W0) >> (64 - K), f1) : hao_hash_planes<K>(~W0 & mask, r1);
 }
 
 template<bool HAS_FT> __device__ __forceinline__ uint32_t sk3_proxy(uint64_t x, uint32_t c)
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void sketch_unit_kernel(hao_sk_args a)
 				: "=&v"(x0l), "=&v"(x0h), "=&v"(x1l), "=&v"(x1h), "=&v"(tmp)
 				: "v"(f1l), "v"(f1h), "v"(f0l), "v"(f0h), "v"(r1l), "v"(r1h), "v"(r0l), "v"(r0h) : "vcc");
 			const uint64_t x0 = (uint64_t)x0h << 32 | x0l, x1 = (uint64_t)x1h << 32 | x1l;
-			const uint64_t y = hao_hash64(x0) + hao_hash64(x1);
+			const uint64_t y = hao_hash_planes<K>(x0, x1);
 			if (HAS_FT) { const int32_t cnt = hao_ft_lookup(a.ft, y); p[i] = cnt < (1 << 28) ? sk3_proxy<true>(y, (uint32_t)cnt) : 0xffffffffu; }
 			else p[i] = sk3_proxy<false>(y, 0);
 		}
