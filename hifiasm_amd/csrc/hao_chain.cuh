@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(256) void chain_assemble_kernel(hao_asm_args A)
 			A.ol[oi] = o; A.ol_fc_off[oi] = fd;
 			hao_cdesc d; d.src = (gs + rc.src_rel) | (rc.in_place ? 0 : HAO_CD_OHITS); d.dst = hd; d.n = rc.n_hits; d.w0 = (rc.strand << 31) | (ord & 0x7fffffffu); d.r = r; d.pad = (rc.in_place && A.g_cls[g] >= 1) ? 1u : 0u;      // pad bit 0: the hits' wire codes exist (chain_group_kernel saw the group)
 			A.cd[oi] = d;
-			if (fl <= 8) for (uint32_t i = 0; i < fl; ++i) A.fc[fd + i] = fs[i];
+			if (fl <= 8) for (uint32_t i = 0; i < fl; ++i) A.fc[fd + i] = fs[i];      // (all entries requested before the first store, as chain_final_kernel does: 124 registers, 4 waves per SIMD, 0.3 ms per pass slower - the kernel is bound by its 48-byte records)
 		}
 		for (unsigned long long big = __ballot(has && fl > 8); big; big &= big - 1) {
 			const int l = __ffsll((long long)big) - 1;
@@ -1782,12 +1782,14 @@ __global__ __launch_bounds__(256) void chain_final_kernel(const hao_ovlp_t *ol, 
 			// the packed layout (wo = fo - J, n_main = entries - overlaps) needs at least one entry per overlap; gen_fake_cigar runs with apend_be = 1, so there always
 			// is one - should that ever change, the batch fails (bit 63 of the raw-word counter, read by the host) instead of shipping overlapping word ranges
 			if (fcw && fl == 0) atomicOr(fcw_raw_words, 1ULL << 63);
-			if (fl <= 16) {
-				uint64_t prev = 0;
-				for (uint32_t j = 0; j < fl; ++j) {
-					const uint64_t e = fc_raw[fs + j]; fc_out[fo + j] = e;
-					if (fcw) { uint32_t w = 0; if (j == 0) ok = ok && e == (uint64_t)o.x_pos_s << 32; else if (ok && hao_fc_step(prev, e, &w)) fcw[wo + j - 1] = w; else ok = false; }
-					prev = e;
+			if (fl <= 16) {      // every entry requested before the first is stored (one memory round trip for the cigar instead of one per entry)
+				uint64_t ev[16];
+#pragma unroll
+				for (uint32_t j = 0; j < 16; ++j) if (j < fl) ev[j] = fc_raw[fs + j];
+#pragma unroll
+				for (uint32_t j = 0; j < 16; ++j) if (j < fl) {
+					const uint64_t e = ev[j]; fc_out[fo + j] = e;
+					if (fcw) { uint32_t w = 0; if (j == 0) ok = ok && e == (uint64_t)o.x_pos_s << 32; else if (ok && hao_fc_step(ev[j ? j - 1 : 0], e, &w)) fcw[wo + j - 1] = w; else ok = false; }
 				}
 			}
 		}

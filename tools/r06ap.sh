@@ -7,6 +7,6 @@ python - $O/run$i.json <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); b=d['boundary']; s=d['stage_ms']
 print('delivered', b['ms_per_step'], 'resident', d['ms_per_step_resident'], 'seed', s['q_sort_bins'], 'chain', s['q_chain'], 'sk', s['sk_chunks'], 'ptl', s['pt_lookup'], 'frac', d['roofline']['frac'], 'ok', b['delivered_bytes_check']['equal_to_reference'])
-print([(k['kernel'],k['kernel_ms'],k['frac']) for k in d['roofline'].get('kernels',[])])
+print([(k["kernel"],k["kernel_ms"],k["frac"]) for k in d["roofline"].get("kernels",[])], "asm", s["q_assemble"], "sel", s["q_select"], "final", s["q_final"], "b_asm", b["stage_ms"]["q_assemble"], "b_final", b["stage_ms"]["q_final"])
 PY
 done
