@@ -119,6 +119,26 @@ __device__ __forceinline__ uint32_t hao_wave_excl_scan(uint32_t v, uint32_t *tot
 // ---------------------------------------------------------------------------------------
 #define SK3_MIN_TILE_RUNS 544      // hao_sketch3.cuh: a unit of 1024 window ordinals must fit 3 decode steps
 #define SK3_LONGSPAN_ENDS 67       // 17 consecutive 16-base words with <= 67 run ends: some 256 bases hold <= 51 runs, a k-mer span can reach 256
+// run-end bits of 16 bases (bit 30-2j <-> base j) from the big-endian word W, the base after it (nxt) and the bases left in the read from base 0 of the word
+__device__ __forceinline__ uint32_t sk3_run_ends(uint32_t Wd, uint32_t nxt, uint32_t rem, int hpc)
+{
+	if (rem == 0) return 0;
+	const uint32_t full = 0x55555555u;
+	if (!hpc) return rem >= 16 ? full : ((0xFFFFFFFFu << (32 - 2 * rem)) & full);
+	const uint32_t Y = Wd ^ ((Wd << 2) | nxt);
+	uint32_t ne = (Y | (Y >> 1)) & full;
+	const uint32_t q = rem > 16 ? 16 : rem - 1;                          // comparisons j vs j+1 are valid for j < q
+	const uint32_t m = q == 0 ? 0 : (q >= 16 ? full : ((0xFFFFFFFFu << (32 - 2 * q)) & full));
+	ne &= m;
+	if (rem <= 16) ne |= 1u << (30 - 2 * (rem - 1));                      // the last base of the read always ends a run
+	return ne;
+}
+// the 16 bases starting at base g0 (a multiple of 16) of a read: one unaligned 8-byte load (the read store has 16 bytes of slack at its end)
+__device__ __forceinline__ void sk3_load16(const uint8_t *rd, uint32_t g0, uint32_t &Wd, uint32_t &nxt)
+{
+	uint2 v; __builtin_memcpy(&v, rd + (g0 >> 2), 8);
+	Wd = __builtin_bswap32(v.x); nxt = (v.y & 0xffu) >> 6;
+}
 __global__ __launch_bounds__(256) void hpc_index_kernel(const uint8_t *packed, const uint64_t *pk_off, const uint32_t *len,
 		const uint64_t *tile_off, uint32_t *tile_ord, uint32_t *n_runs, uint64_t rid_lo, uint64_t n_sel, int hpc, uint8_t *slow_flag)
 {
@@ -127,22 +147,36 @@ __global__ __launch_bounds__(256) void hpc_index_kernel(const uint8_t *packed, c
 	uint64_t rid = rid_lo + r; const uint8_t *rd = packed + pk_off[rid]; uint32_t L = len[rid];
 	uint32_t *to = tile_ord + tile_off[r]; uint32_t run = 0, nt = (L + HAO_SK_TILE - 1) / HAO_SK_TILE;
 	uint32_t prev_cum = 0; bool slow = false;
-	for (uint32_t ti = 0; ti < nt; ++ti) {
-		uint32_t W, g0 = ti * HAO_SK_TILE + hao_lane() * 16, c;
-		if (hpc) c = __popc(hao_run_ends16(rd, L, g0, &W));
-		else c = g0 >= L ? 0 : (L - g0 > 16 ? 16 : L - g0);
-		uint32_t tot; const uint32_t excl = hao_wave_excl_scan(c, &tot);
-		if (hao_lane() == 0) to[ti] = run;
-		if (slow_flag && hpc) {       // reads the unit kernel leaves to the scalar one: long runs (see hao_sketch3.cuh)
-			const uint32_t cum = run + excl + c;                               // run ends up to and including this word
-			if (ti * HAO_SK_TILE + HAO_SK_TILE <= L && tot < SK3_MIN_TILE_RUNS) slow = true;
-			const int ln = hao_lane();
-			const uint32_t a = (uint32_t)__shfl((int)cum, (ln + 47) & 63), b = (uint32_t)__shfl((int)prev_cum, (ln + 47) & 63);   // lane - 17 (mod 64)
-			const uint32_t before = ln >= 17 ? a : (ti > 0 ? b : 0u);
-			if (ti * 64 + (uint32_t)ln >= 16 && g0 + 16 <= L && cum - before <= SK3_LONGSPAN_ENDS) slow = true;
-			prev_cum = cum;
+	// four tiles per round: their words are requested before the first is counted (tile by tile the loop ran at one memory round trip per tile, 15 per read)
+	for (uint32_t t4 = 0; t4 < nt; t4 += 4) {
+		uint32_t cc[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const uint32_t g0 = (t4 + u) * HAO_SK_TILE + hao_lane() * 16; uint32_t c = 0;
+			if (g0 < L) {
+				if (hpc) { uint32_t Wd, nxt; sk3_load16(rd, g0, Wd, nxt); c = __popc(sk3_run_ends(Wd, nxt, L - g0, 1)); }
+				else c = L - g0 > 16 ? 16 : L - g0;
+			}
+			cc[u] = c;
 		}
-		run += tot;
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const uint32_t ti = t4 + u;
+			if (ti >= nt) break;
+			const uint32_t g0 = ti * HAO_SK_TILE + hao_lane() * 16, c = cc[u];
+			uint32_t tot; const uint32_t excl = hao_wave_excl_scan(c, &tot);
+			if (hao_lane() == 0) to[ti] = run;
+			if (slow_flag && hpc) {       // reads the unit kernel leaves to the scalar one: long runs (see hao_sketch3.cuh)
+				const uint32_t cum = run + excl + c;                               // run ends up to and including this word
+				if (ti * HAO_SK_TILE + HAO_SK_TILE <= L && tot < SK3_MIN_TILE_RUNS) slow = true;
+				const int ln = hao_lane();
+				const uint32_t a = (uint32_t)__shfl((int)cum, (ln + 47) & 63), b = (uint32_t)__shfl((int)prev_cum, (ln + 47) & 63);   // lane - 17 (mod 64)
+				const uint32_t before = ln >= 17 ? a : (ti > 0 ? b : 0u);
+				if (ti * 64 + (uint32_t)ln >= 16 && g0 + 16 <= L && cum - before <= SK3_LONGSPAN_ENDS) slow = true;
+				prev_cum = cum;
+			}
+			run += tot;
+		}
 	}
 	if (hao_lane() == 0) { to[nt] = run; n_runs[r] = run; }
 	if (slow_flag && __any(slow) && hao_lane() == 0) slow_flag[r] = 1;

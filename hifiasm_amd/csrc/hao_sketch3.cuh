@@ -42,26 +42,7 @@ struct hao_sk3_lds {                                                     // per 
 	unsigned long long kx[SK3_RING]; uint32_t kc[SK3_RING]; uint16_t kq[SK3_RING];   // candidate ring: key, count | rev << 31, entry
 };
 
-// run-end bits of 16 bases (bit 30-2j <-> base j) from the big-endian word W, the base after it (nxt) and the bases left in the read from base 0 of the word
-__device__ __forceinline__ uint32_t sk3_run_ends(uint32_t Wd, uint32_t nxt, uint32_t rem, int hpc)
-{
-	if (rem == 0) return 0;
-	const uint32_t full = 0x55555555u;
-	if (!hpc) return rem >= 16 ? full : ((0xFFFFFFFFu << (32 - 2 * rem)) & full);
-	const uint32_t Y = Wd ^ ((Wd << 2) | nxt);
-	uint32_t ne = (Y | (Y >> 1)) & full;
-	const uint32_t q = rem > 16 ? 16 : rem - 1;                          // comparisons j vs j+1 are valid for j < q
-	const uint32_t m = q == 0 ? 0 : (q >= 16 ? full : ((0xFFFFFFFFu << (32 - 2 * q)) & full));
-	ne &= m;
-	if (rem <= 16) ne |= 1u << (30 - 2 * (rem - 1));                      // the last base of the read always ends a run
-	return ne;
-}
-// the 16 bases starting at base g0 (a multiple of 16) of a read: one unaligned 8-byte load (the read store has 16 bytes of slack at its end)
-__device__ __forceinline__ void sk3_load16(const uint8_t *rd, uint32_t g0, uint32_t &Wd, uint32_t &nxt)
-{
-	uint2 v; __builtin_memcpy(&v, rd + (g0 >> 2), 8);
-	Wd = __builtin_bswap32(v.x); nxt = (v.y & 0xffu) >> 6;
-}
+// (sk3_run_ends, sk3_load16: hao_sketch.cuh, next to hpc_index_kernel)
 __device__ __forceinline__ uint32_t sk3_even_bits(uint32_t x)            // bits 0,2,4,..,30 -> bits 0..15
 {
 	x = (x | x >> 1) & 0x33333333u; x = (x | x >> 2) & 0x0f0f0f0fu; x = (x | x >> 4) & 0x00ff00ffu; x = (x | x >> 8) & 0xffffu;
