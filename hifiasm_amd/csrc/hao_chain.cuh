@@ -107,10 +107,6 @@ __device__ uint32_t hao_fake_cigar(uint64_t *fc, const hao_chain_rec &o, HitAt h
 }
 
 // broadcast of lane src (wave-uniform src): v_readlane, no LDS crossbar
-__device__ __forceinline__ uint32_t hao_bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
-__device__ __forceinline__ int32_t hao_bcast(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
-__device__ __forceinline__ int64_t hao_readlane_i64(int64_t v, int l)
-{ return (int64_t)((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), l) << 32); }
 
 // gen_fake_cigar (apend_be = 1) by one wave: the k-th hit of the chain is hit(k); entries are a flagged compaction
 // (an entry wherever the diagonal changes).  Returns the entry count (uniform).

@@ -152,6 +152,11 @@ __device__ __forceinline__ uint32_t hao_wave_sum_sat_u32(uint32_t v)
 }
 // bits of the wave-uniform mask m below this lane (v_mbcnt_lo / v_mbcnt_hi)
 __device__ __forceinline__ uint32_t hao_mbcnt(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+// the value lane `src` holds (src wave-uniform: v_readlane_b32)
+__device__ __forceinline__ uint32_t hao_bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+__device__ __forceinline__ int32_t hao_bcast(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ int64_t hao_readlane_i64(int64_t v, int l)
+{ return (int64_t)((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), l) << 32); }
 // value of the next lane; lane 63 gets `fill` (DPP wave_shl:1)
 __device__ __forceinline__ uint32_t hao_wave_shl1(uint32_t v, uint32_t fill) { return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xf, 0xf, false); }
 

@@ -674,10 +674,28 @@ __global__ __launch_bounds__(256) void sketch_gather_finish_kernel(const uint64_
 	const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (r >= n_sel) return;
 	const uint64_t rid = stamp_rid ? ((rid_lo + r) & 0xfffffffULL) : 0ULL;
-	for (uint64_t ch = chunk_off[r]; ch < chunk_off[r + 1]; ++ch) {
-		const uint64_t b = chunk_base[ch], d = chunk_dst[ch]; const uint32_t n = chunk_cnt[ch];
-		if (d + n > out_cap) { if (hao_lane() == 0 && n) *err = 1; return; }
-		for (uint32_t i = hao_lane(); i < n; i += 64) { ox[d + i] = pool_x[b + i]; oinfo[d + i] = (pool_info[b + i] & ~0xfffffffULL) | rid; }
+	// The read's units (~14 of ~40 minimizers each).  Unit by unit - three scalars, then the unit's entries, then the stores - the loop ran at two memory round trips per
+	// unit; here the units' scalars are fetched by one lane each, and four units' entries are requested before the first is stored.
+	const uint64_t c0 = chunk_off[r], c1 = chunk_off[r + 1]; const uint32_t lane = (uint32_t)hao_lane();
+	for (uint64_t cb = c0; cb < c1; cb += 64) {
+		const uint64_t ch = cb + lane; uint64_t b = 0, d = 0; uint32_t n = 0;
+		if (ch < c1) { b = chunk_base[ch]; d = chunk_dst[ch]; n = chunk_cnt[ch]; }
+		if (__any(n && d + n > out_cap)) { if (lane == 0) *err = 1; return; }
+		const int m = (int)(c1 - cb < 64 ? c1 - cb : 64);
+		for (int j0 = 0; j0 < m; j0 += 4) {
+			uint64_t x[4], inf[4], bb[4], dd[4]; uint32_t nn[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const int j = j0 + u < m ? j0 + u : m - 1;      // (a round's spare slots repeat the last unit with no entries)
+				bb[u] = (uint64_t)hao_readlane_i64((int64_t)b, j); dd[u] = (uint64_t)hao_readlane_i64((int64_t)d, j); nn[u] = j0 + u < m ? hao_bcast(n, j) : 0u;
+				if (lane < nn[u]) { x[u] = pool_x[bb[u] + lane]; inf[u] = pool_info[bb[u] + lane]; }
+			}
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				if (lane < nn[u]) { ox[dd[u] + lane] = x[u]; oinfo[dd[u] + lane] = (inf[u] & ~0xfffffffULL) | rid; }
+				for (uint32_t i = 64 + lane; i < nn[u]; i += 64) { ox[dd[u] + i] = pool_x[bb[u] + i]; oinfo[dd[u] + i] = (pool_info[bb[u] + i] & ~0xfffffffULL) | rid; }      // (a unit with more than 64 minimizers: degenerate reads)
+			}
+		}
 	}
 }
 
