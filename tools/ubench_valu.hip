@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void NAME(uint32_t *out, uint32_t seed) { \
 	uint32_t a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19, b = seed | 1; \
 	for (int i = 0; i < ITERS; ++i) { \
 		asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7) ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7) \
-			: "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc"); \
+			: "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc", "s20"); \
 	} \
 	out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7; }
 
@@ -42,11 +42,27 @@ __global__ __launch_bounds__(256) void NAME(uint32_t *out, uint32_t seed) { \
 #define A_XOR3(x) "v_xor3_b32 %" #x ", %" #x ", %8, %8\n"
 #define A_LSHLADD(x) "v_lshl_add_u32 %" #x ", %" #x ", 3, %8\n"
 #define A_MAD24(x) "v_mad_u32_u24 %" #x ", %" #x ", %8, %8\n"
+#define A_AND(x) "v_and_b32 %" #x ", %" #x ", %8\n"
+#define A_OR(x) "v_or_b32 %" #x ", %" #x ", %8\n"
+#define A_SUB(x) "v_sub_u32 %" #x ", %" #x ", %8\n"
+#define A_NOT(x) "v_not_b32 %" #x ", %" #x "\n"
+#define A_MOV(x) "v_mov_b32 %" #x ", %8\n"
+#define A_LSHL(x) "v_lshlrev_b32 %" #x ", 3, %" #x "\n"
+#define A_LSHR(x) "v_lshrrev_b32 %" #x ", 3, %" #x "\n"
+#define A_CNDMASK(x) "v_cndmask_b32 %" #x ", %" #x ", %8, vcc\n"
+#define A_CMP(x) "v_cmp_lt_u32 vcc, %" #x ", %8\n"
+#define A_ADDSAT(x) "v_add_i32 %" #x ", %" #x ", %8 clamp\n"
+#define A_MUL24(x) "v_mul_u32_u24 %" #x ", %" #x ", %8\n"
+#define A_MBCNT(x) "v_mbcnt_lo_u32_b32 %" #x ", %8, %" #x "\n"
+#define A_READLANE(x) "v_readlane_b32 s20, %" #x ", 5\n"
+#define A_ADDCO(x) "v_add_co_u32 %" #x ", vcc, %" #x ", %8\n"
 
 KERNEL32(k_add, A_ADD) KERNEL32(k_xor, A_XOR) KERNEL32(k_min, A_MIN) KERNEL32(k_align, A_ALIGN) KERNEL32(k_bfrev, A_BFREV) KERNEL32(k_mullo, A_MULLO)
 KERNEL32(k_bfe, A_BFE) KERNEL32(k_bfi, A_BFI) KERNEL32(k_lshlor, A_LSHLOR) KERNEL32(k_perm, A_PERM) KERNEL32(k_dpp_wshr, A_DPP_WSHR) KERNEL32(k_dpp_rshr, A_DPP_RSHR)
 KERNEL32(k_min_dpp, A_MIN_DPP) KERNEL32(k_cmpsel, A_CMPSEL) KERNEL32(k_bperm, A_BPERM) KERNEL32(k_swap32, A_SWAP32) KERNEL32(k_swap16, A_SWAP16) KERNEL32(k_bcnt, A_BCNT)
 KERNEL32(k_add3, A_ADD3) KERNEL32(k_lshladd, A_LSHLADD) KERNEL32(k_mad24, A_MAD24)
+KERNEL32(k_and, A_AND) KERNEL32(k_or, A_OR) KERNEL32(k_sub, A_SUB) KERNEL32(k_not, A_NOT) KERNEL32(k_mov, A_MOV) KERNEL32(k_lshl, A_LSHL) KERNEL32(k_lshr, A_LSHR) KERNEL32(k_cndmask, A_CNDMASK)
+KERNEL32(k_cmp, A_CMP) KERNEL32(k_addsat, A_ADDSAT) KERNEL32(k_mul24, A_MUL24) KERNEL32(k_mbcnt, A_MBCNT) KERNEL32(k_readlane, A_READLANE) KERNEL32(k_addco, A_ADDCO)
 
 #define KERNEL64(NAME, ASM) \
 __global__ __launch_bounds__(256) void NAME(uint32_t *out, uint32_t seed) { \
@@ -120,6 +136,9 @@ int main() {
 	std::vector<T> ts = { {"v_add_u32", k_add, 16}, {"v_xor_b32", k_xor, 16}, {"v_min_u32", k_min, 16}, {"v_alignbit_b32", k_align, 16}, {"v_bfrev_b32", k_bfrev, 16}, {"v_mul_lo_u32", k_mullo, 16},
 		{"v_bfe_u32", k_bfe, 16}, {"v_bfi_b32", k_bfi, 16}, {"v_lshl_or_b32", k_lshlor, 16}, {"v_perm_b32", k_perm, 16}, {"v_add3_u32", k_add3, 16}, {"v_lshl_add_u32", k_lshladd, 16},
 		{"v_mad_u32_u24", k_mad24, 16}, {"v_bcnt_u32_b32", k_bcnt, 16},
+		{"v_and_b32", k_and, 16}, {"v_or_b32", k_or, 16}, {"v_sub_u32", k_sub, 16}, {"v_not_b32", k_not, 16}, {"v_mov_b32", k_mov, 16}, {"v_lshlrev_b32", k_lshl, 16}, {"v_lshrrev_b32", k_lshr, 16},
+		{"v_cndmask_b32 (vcc)", k_cndmask, 16}, {"v_cmp_lt_u32 (vcc)", k_cmp, 16}, {"v_add_i32 clamp", k_addsat, 16}, {"v_mul_u32_u24", k_mul24, 16}, {"v_mbcnt_lo_u32_b32", k_mbcnt, 16},
+		{"v_readlane_b32", k_readlane, 16}, {"v_add_co_u32", k_addco, 16},
 		{"v_mov_dpp wave_shr:1", k_dpp_wshr, 16}, {"v_mov_dpp row_shr:3", k_dpp_rshr, 16}, {"v_min_u32_dpp wave_shr:1", k_min_dpp, 16}, {"v_cmp_lt_u32+v_cndmask", k_cmpsel, 16},
 		{"ds_bpermute_b32", k_bperm, 16}, {"v_permlane32_swap", k_swap32, 16}, {"v_permlane16_swap", k_swap16, 16},
 		{"v_lshl_add_u64", k_lshladd64, 16}, {"v_lshlrev_b64", k_lshl64, 16}, {"v_lshrrev_b64", k_lshr64, 16}, {"v_mad_u64_u32", k_mad64, 16},
