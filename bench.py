@@ -393,7 +393,9 @@ def run_workload(a, workload, steps, warmup, rank, local_rank, world, dist, torc
                 ach = per_base * rs.total_bases / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else 0.0
                 sk["roofline_alu"] = {"achieved_valu_issue": round(ach, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
                                       "frac": round(ach / VALU_PEAK_GINST, 4), "valu_wave_insts_per_base": per_base,
-                                      "source": alu_rel + " (rocprofv3 --pmc SQ_INSTS_VALU ...) x this run's kernel time"}
+                                      "source": alu_rel + " (rocprofv3 --pmc SQ_INSTS_VALU ...) x this run's kernel time",
+                                      "peak_is": "the guide's 2 cycles per wave64 instruction; measured on the device (profiles/r06/ubench_valu.txt) only the simple two-operand "
+                                                 "integer instructions issue in 2.2 - 2.6 cycles, everything else in 4.0 - 4.5: this kernel's mix runs at its issue limit (DESIGN 8)"}
             except Exception:
                 pass
         out = {

@@ -1159,6 +1159,15 @@ template<int MODE> __device__ void hao_wave_intro_sort(const hao_sel_ctx &S, int
 	const int lane = hao_lane(); int32_t *stack = S.stack; int64_t top = 0, s, t, i, j, k; int d;
 	if (n < 1) return;
 	if (n == 2) { if (lane == 0 && hao_lt<MODE>(S, 1, 0)) hao_sw(S, 0, 1); HAO_WFENCE(); return; }
+	if (n <= 64) {
+		// One key per lane.  Whatever klib's partitions do, its closing insertion sort leaves the array sorted by key, and the order of EQUAL keys is all that depends on the
+		// path it took: when no two keys are equal the answer is the sorted order, and a lane's slot is the number of smaller keys - n rounds of two v_readlane and a compare
+		// instead of the replay's dozens of fenced LDS round trips (a HiFi read's ~60 chains: the common case of the position sort).  A tie sends the read through the replay.
+		const bool act = lane < (int)n; const uint32_t me = act ? S.pm[lane] : 0u; const uint64_t key = act ? hao_skey<MODE>(S, me) : 0ULL;
+		uint32_t rank = 0; bool tie = false;
+		for (int jj = 0; jj < (int)n; ++jj) { const uint64_t kj = (uint64_t)hao_readlane_i64((int64_t)key, jj); rank += kj < key ? 1u : 0u; tie = tie || (kj == key && jj != lane); }
+		if (!__any(act && tie)) { HAO_WFENCE(); if (act) S.pm[rank] = me; HAO_WFENCE(); return; }
+	}
 	for (d = 2; (1ull << d) < (uint64_t)n; ++d) {}
 	s = 0; t = n - 1; d <<= 1;
 	for (;;) {

@@ -10,3 +10,4 @@ print('delivered', b['ms_per_step'], 'resident', d['ms_per_step_resident'], 'see
 print([(k["kernel"],k["kernel_ms"],k["frac"]) for k in d["roofline"].get("kernels",[])], "asm", s["q_assemble"], "sel", s["q_select"], "final", s["q_final"], "b_asm", b["stage_ms"]["q_assemble"], "b_final", b["stage_ms"]["q_final"])
 PY
 done
+if [ -n "$SELDBG" ]; then HAO_DBG_PRINT=sel timeout 300 python bench.py --cpu-baseline none --no-variants --no-boundary --no-verify --steps 1 --warmup 0 > $O/seldbg.json 2> $O/seldbg.err; grep "\[select\]" $O/seldbg.err | head -8; fi
