@@ -1412,6 +1412,7 @@ struct hao_sel_args {
 
 // the sequential part (lane 0). returns the kept count
 // max_n_chain pruning (anchor.cpp:1957-2056) on the score-sorted permutation: sequential, lane 0
+#define HAO_WEAK_SWEEP_MAX 6   // weak-chain filter: up to this many candidate chains of a 64-chain batch are swept by the whole wave, more are searched one per lane
 #define HAO_SEL_CCAP 128       // coverage windows (read length / ocv_w) kept in LDS during the pruning scan; longer reads use the global array
 template<bool CCLDS>
 __device__ int64_t hao_select_prune(const hao_sel_args &A, const hao_sel_ctx &S, int64_t n, int lch, uint64_t r, int *lch_out, uint64_t *l_cc)
@@ -1606,21 +1607,43 @@ __device__ int64_t hao_select_weak(const hao_sel_args &A, const hao_sel_ctx &S, 
 						cand = oe > os && oe - os >= ob;
 					}
 				}
-				const unsigned long long inm = __ballot(inr); unsigned long long cm = __ballot(cand);
+				const unsigned long long inm = __ballot(inr);
 				const int nin = __popcll(inm);                      // the strong list is sorted by x_pos_s: the in-range lanes are a prefix
-				while (cm) {
-					const int l = __ffsll((long long)cm) - 1; cm &= cm - 1;
-					if (l >= nin) break;
-					const uint32_t cc_ = (uint32_t)__shfl((int)ci, l); const uint64_t cos = __shfl(os, l), coe = __shfl(oe, l);
-					const hao_hit_t *ch = hao_cd_src(cd[cc_], A.hits, A.ohits); const uint64_t nh = S.al[cc_];    // the chain's hits (the run of cl->list with its ordinal tag)
-					uint64_t kn = 0;
-					for (uint64_t b = 0; b < nh && kn < ocn; b += 64) {
-						bool in = false;
-						if (b + lane < nh) { uint64_t me = ch[b + lane].self_offset, ms = me - (ch[b + lane].cnt & 0xffu); in = ms >= cos && me <= coe; }
-						kn += __popcll(__ballot(in));
+				// Every candidate counts its own hits inside [os, oe], all candidates at once.  (One candidate after the other, the wave sweeping all of its hits,
+				// cost two dependent memory round trips per candidate - and a single-hit weak chain is covered by nobody, so every overlapping strong chain
+				// of the read was swept: 150 us per read, nearly all of chain_select_kernel.)  A chain's hits ascend in self_offset: a hit in front of the
+				// window start counts only when me - span wraps (a k-mer at the read's first bases: me < span <= 255), the rest is a binary search for the
+				// window's first hit and a walk to its last - the same count as the sweep's.
+				// Few candidates (a repeat-rich read: most chains weak, the first strong one usually covers): the wave sweeps them one after the other as before -
+				// two round trips each and an early exit beat the ~10 - 25 dependent loads of a lane's search and walk.
+				const unsigned long long cm0 = __ballot(cand && lane < nin);
+				if (__popcll(cm0) <= HAO_WEAK_SWEEP_MAX) {
+					for (unsigned long long cm = cm0; cm; cm &= cm - 1) {
+						const int l = __ffsll((long long)cm) - 1;
+						const uint32_t cc_ = (uint32_t)__shfl((int)ci, l); const uint64_t cos = __shfl(os, l), coe = __shfl(oe, l);
+						const hao_hit_t *ch = hao_cd_src(cd[cc_], A.hits, A.ohits); const uint64_t nh = S.al[cc_];
+						uint64_t kn = 0;
+						for (uint64_t b = 0; b < nh && kn < ocn; b += 64) {
+							bool in = false;
+							if (b + lane < nh) { uint64_t me = ch[b + lane].self_offset, ms = me - (ch[b + lane].cnt & 0xffu); in = ms >= cos && me <= coe; }
+							kn += __popcll(__ballot(in));
+						}
+						if (kn >= ocn) { covered = true; break; }
 					}
-					if (kn >= ocn) { covered = true; break; }
+					if (covered || nin < 64) break;
+					continue;
 				}
+				bool hit = false;
+				if (cand && lane < nin) {
+					const hao_hit_t *ch = hao_cd_src(cd[ci], A.hits, A.ohits); const uint64_t nh = S.al[ci];    // the chain's hits (the run of cl->list with its ordinal tag)
+					uint64_t kn = 0, b = 0;
+					for (; b < nh && kn < ocn; ++b) { const uint64_t me = ch[b].self_offset; if (me >= os || me >= 256) break; if (me - (ch[b].cnt & 0xffu) >= os) ++kn; }
+					uint64_t lo = b, hi = nh;
+					while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if ((uint64_t)ch[mid].self_offset < os) lo = mid + 1; else hi = mid; }
+					for (b = lo; b < nh && kn < ocn; ++b) { const uint64_t me = ch[b].self_offset; if (me > oe) break; if (me - (ch[b].cnt & 0xffu) >= os) ++kn; }
+					hit = kn >= ocn;
+				}
+				if (__any(hit)) { covered = true; break; }
 				if (nin < 64) break;
 			}
 			drop = covered;
