@@ -1412,6 +1412,7 @@ struct hao_sel_args {
 
 // the sequential part (lane 0). returns the kept count
 // max_n_chain pruning (anchor.cpp:1957-2056) on the score-sorted permutation: sequential, lane 0
+#define HAO_WEAK_LANEWISE_N 128   // weak-chain filter: reads with more chains than this keep the wave's sweep for every batch
 #define HAO_WEAK_SWEEP_MAX 6   // weak-chain filter: up to this many candidate chains of a 64-chain batch are swept by the whole wave, more are searched one per lane
 #define HAO_SEL_CCAP 128       // coverage windows (read length / ocv_w) kept in LDS during the pruning scan; longer reads use the global array
 template<bool CCLDS>
@@ -1614,10 +1615,11 @@ __device__ int64_t hao_select_weak(const hao_sel_args &A, const hao_sel_ctx &S, 
 				// of the read was swept: 150 us per read, nearly all of chain_select_kernel.)  A chain's hits ascend in self_offset: a hit in front of the
 				// window start counts only when me - span wraps (a k-mer at the read's first bases: me < span <= 255), the rest is a binary search for the
 				// window's first hit and a walk to its last - the same count as the sweep's.
-				// Few candidates (a repeat-rich read: most chains weak, the first strong one usually covers): the wave sweeps them one after the other as before -
-				// two round trips each and an early exit beat the ~10 - 25 dependent loads of a lane's search and walk.
+				// Few candidates, or a read with more than 128 chains (repeat-rich: most chains weak, the first strong one usually covers): the wave sweeps them one after
+				// the other as before - two round trips each and an early exit beat the ~10 - 25 dependent loads of a lane's search and walk (repeat-rich 250 Mb twin:
+				// 776 ms per pass with the sweep, 859 with the lane-wise form for every batch, 818 with it for batches of more than six candidates).
 				const unsigned long long cm0 = __ballot(cand && lane < nin);
-				if (__popcll(cm0) <= HAO_WEAK_SWEEP_MAX) {
+				if (n > HAO_WEAK_LANEWISE_N || __popcll(cm0) <= HAO_WEAK_SWEEP_MAX) {
 					for (unsigned long long cm = cm0; cm; cm &= cm - 1) {
 						const int l = __ffsll((long long)cm) - 1;
 						const uint32_t cc_ = (uint32_t)__shfl((int)ci, l); const uint64_t cos = __shfl(os, l), coe = __shfl(oe, l);
